@@ -1,0 +1,1133 @@
+"""Minimal MJCF-subset compiler producing an MjModel-like numpy struct.
+
+Why this exists: the reference's `put_model(mjm: mujoco.MjModel)` consumes a model compiled by
+MuJoCo C (/root/reference/mujoco_warp/_src/io.py:259, cli.py:87-95). The `mujoco` package is not
+available in this environment, so the hot-path benchmark models (humanoid.xml, and G1/Panda-class
+models with primitive colliders and explicit inertials) are compiled here.  Attribute names and
+array shapes follow MuJoCo's MjModel so `put_model` can `getattr` them exactly like the reference
+does (io.py:426).  If a real `mujoco.MjModel` is handed to `put_model`, it is used as is.
+
+Derived constants (`mj_setConst`): body_subtreemass, dof_invweight0, body_invweight0,
+stat.meaninertia follow the restatement in /root/reference/mujoco_warp/_src/set_const.py:35-59,
+170-375.  Compiler semantics (inertia-from-geom, fromto, defaults) follow MuJoCo's documented
+behaviour; they are NOT restated anywhere in the reference.
+
+Supported: nested <default class>, childclass, <include>, bodies, <inertial>, free/ball/slide/hinge
+joints, plane/sphere/capsule/cylinder/ellipsoid/box geoms (mesh geoms are kept as non-colliding
+placeholders when they carry no mass), motor/position/velocity/general actuators on joints,
+keyframes, <contact><exclude>, <option> + <flag>.  Unsupported features raise NotImplementedError.
+"""
+
+import os
+import xml.etree.ElementTree as ET
+
+import numpy as np
+
+from . import _npmath as nm
+
+# ---- enum values (MuJoCo's mjt* enums) ------------------------------------------------------
+JNT_FREE, JNT_BALL, JNT_SLIDE, JNT_HINGE = 0, 1, 2, 3
+GEOM_PLANE, GEOM_HFIELD, GEOM_SPHERE, GEOM_CAPSULE, GEOM_ELLIPSOID, GEOM_CYLINDER, GEOM_BOX, GEOM_MESH, GEOM_SDF = range(9)
+_GEOM_NAMES = {
+  "plane": GEOM_PLANE, "hfield": GEOM_HFIELD, "sphere": GEOM_SPHERE, "capsule": GEOM_CAPSULE,
+  "ellipsoid": GEOM_ELLIPSOID, "cylinder": GEOM_CYLINDER, "box": GEOM_BOX, "mesh": GEOM_MESH, "sdf": GEOM_SDF,
+}
+_JNT_NAMES = {"free": JNT_FREE, "ball": JNT_BALL, "slide": JNT_SLIDE, "hinge": JNT_HINGE}
+INT_EULER, INT_RK4, INT_IMPLICIT, INT_IMPLICITFAST = 0, 1, 2, 3
+_INT_NAMES = {"euler": INT_EULER, "rk4": INT_RK4, "implicit": INT_IMPLICIT, "implicitfast": INT_IMPLICITFAST}
+SOL_PGS, SOL_CG, SOL_NEWTON = 0, 1, 2
+_SOL_NAMES = {"pgs": SOL_PGS, "cg": SOL_CG, "newton": SOL_NEWTON}
+CONE_PYRAMIDAL, CONE_ELLIPTIC = 0, 1
+JAC_DENSE, JAC_SPARSE, JAC_AUTO = 0, 1, 2
+DYN_NONE, DYN_INTEGRATOR, DYN_FILTER, DYN_FILTEREXACT, DYN_MUSCLE, DYN_USER = range(6)
+GAIN_FIXED, GAIN_AFFINE, GAIN_MUSCLE, GAIN_USER = range(4)
+BIAS_NONE, BIAS_AFFINE, BIAS_MUSCLE, BIAS_USER = range(4)
+TRN_JOINT, TRN_JOINTINPARENT, TRN_SLIDERCRANK, TRN_TENDON, TRN_SITE, TRN_BODY = range(6)
+
+DSBL = {
+  "constraint": 1 << 0, "equality": 1 << 1, "frictionloss": 1 << 2, "limit": 1 << 3, "contact": 1 << 4,
+  "spring": 1 << 5, "damper": 1 << 6, "gravity": 1 << 7, "clampctrl": 1 << 8, "warmstart": 1 << 9,
+  "filterparent": 1 << 10, "actuation": 1 << 11, "refsafe": 1 << 12, "sensor": 1 << 13, "midphase": 1 << 14,
+  "eulerdamp": 1 << 15, "autoreset": 1 << 16, "nativeccd": 1 << 17, "island": 1 << 18, "multiccd": 1 << 19,
+}
+ENBL = {"override": 1 << 0, "energy": 1 << 1, "fwdinv": 1 << 2, "invdiscrete": 1 << 3, "sleep": 1 << 5}
+
+MJ_MINVAL = 1e-15
+
+
+class MjOption:
+  def __init__(self):
+    self.timestep = 0.002
+    self.tolerance = 1e-8
+    self.ls_tolerance = 0.01
+    self.ccd_tolerance = 1e-6
+    self.sleep_tolerance = 1e-4
+    self.noslip_tolerance = 1e-6
+    self.gravity = np.array([0.0, 0.0, -9.81])
+    self.wind = np.zeros(3)
+    self.magnetic = np.array([0.0, -0.5, 0.0])
+    self.density = 0.0
+    self.viscosity = 0.0
+    self.impratio = 1.0
+    self.integrator = INT_EULER
+    self.cone = CONE_PYRAMIDAL
+    self.jacobian = JAC_AUTO
+    self.solver = SOL_NEWTON
+    self.iterations = 100
+    self.ls_iterations = 50
+    self.noslip_iterations = 0
+    self.ccd_iterations = 35
+    self.disableflags = 0
+    self.enableflags = 0
+    self.sdf_initpoints = 40
+    self.sdf_iterations = 10
+
+
+class MjStatistic:
+  def __init__(self):
+    self.meaninertia = 1.0
+    self.meanmass = 1.0
+    self.meansize = 1.0
+    self.extent = 1.0
+    self.center = np.zeros(3)
+
+
+class MjModel:
+  """numpy stand-in for mujoco.MjModel (only fields on the mj_step hot path)."""
+
+  @staticmethod
+  def from_xml_path(path):
+    return load_xml(path)
+
+  @staticmethod
+  def from_xml_string(xml, assets_dir=None):
+    return from_xml_string(xml, assets_dir)
+
+  def body(self, name):
+    return self.body_names.index(name)
+
+
+class MjData:
+  """numpy stand-in for mujoco.MjData: state + the derived arrays get_data_into fills."""
+
+  def __init__(self, m):
+    self.time = 0.0
+    self.qpos = np.array(m.qpos0, dtype=np.float64).copy()
+    self.qvel = np.zeros(m.nv)
+    self.act = np.zeros(m.na)
+    self.ctrl = np.zeros(m.nu)
+    self.qacc_warmstart = np.zeros(m.nv)
+    self.qfrc_applied = np.zeros(m.nv)
+    self.xfrc_applied = np.zeros((m.nbody, 6))
+    self.mocap_pos = np.zeros((m.nmocap, 3))
+    self.mocap_quat = np.zeros((m.nmocap, 4))
+    self.qacc = np.zeros(m.nv)
+    self.ncon = 0
+    self.nefc = 0
+    self.ne = 0
+    self.nf = 0
+    self.nl = 0
+    self.solver_niter = np.zeros(1, dtype=np.int32)
+
+
+def mj_resetDataKeyframe(m, d, key):
+  """Reset state to keyframe `key` (reference call site: cli.py:159-160)."""
+  d.time = float(m.key_time[key]) if m.nkey > key else 0.0
+  d.qpos[:] = m.key_qpos[key] if m.nkey > key else m.qpos0
+  d.qvel[:] = m.key_qvel[key] if m.nkey > key else 0.0
+  d.act[:] = m.key_act[key] if m.nkey > key else 0.0
+  d.ctrl[:] = m.key_ctrl[key] if m.nkey > key else 0.0
+  d.qacc_warmstart[:] = 0.0
+  d.qfrc_applied[:] = 0.0
+  d.xfrc_applied[:] = 0.0
+
+
+# ---- parsing helpers ---------------------------------------------------------------------------
+def _floats(s):
+  return [float(x) for x in s.replace(",", " ").split()]
+
+
+def _bool(s):
+  s = s.strip().lower()
+  if s in ("true", "1"):
+    return True
+  if s in ("false", "0"):
+    return False
+  if s == "auto":
+    return None
+  raise ValueError(f"bad boolean {s}")
+
+
+def _vec(attrs, key, default):
+  """Attribute vector; a shorter attribute overrides only the leading entries (MuJoCo semantics)."""
+  out = np.array(default, dtype=np.float64).copy()
+  if key in attrs:
+    v = _floats(attrs[key])
+    if len(v) > len(out):
+      raise ValueError(f"attribute {key} has too many values")
+    out[: len(v)] = v
+  return out
+
+
+_ACT_TAGS = ("general", "motor", "position", "velocity", "intvelocity", "damper", "cylinder", "muscle", "adhesion")
+_DEFAULT_TAGS = ("geom", "joint", "site", "mesh", "material", "camera", "light", "pair", "equality", "tendon") + _ACT_TAGS
+
+
+class _Defaults:
+  def __init__(self, name, parent=None):
+    self.name = name
+    self.parent = parent
+    self.attrs = {}  # tag -> dict
+    if parent is not None:
+      for k, v in parent.attrs.items():
+        self.attrs[k] = dict(v)
+
+  def update(self, tag, attrs):
+    key = "actuator" if tag in _ACT_TAGS else tag
+    d = self.attrs.setdefault(key, {})
+    if key == "actuator":
+      # shortcut tags inside <default> carry their implied settings with them
+      d.update(_actuator_shortcut(tag, dict(attrs), in_default=True))
+    else:
+      d.update(attrs)
+
+
+def _parse_defaults(elem, parent, table):
+  name = elem.get("class", "main" if parent is None else None)
+  if name is None:
+    raise ValueError("nested <default> needs a class name")
+  d = _Defaults(name, parent)
+  if parent is None and "main" in table:
+    d = table["main"]
+  table[name] = d
+  for child in elem:
+    if child.tag == "default":
+      continue
+    if child.tag in _DEFAULT_TAGS:
+      d.update(child.tag, child.attrib)
+  for child in elem:
+    if child.tag == "default":
+      _parse_defaults(child, d, table)
+
+
+def _resolve(tag, elem, table, childclass):
+  cls = elem.get("class", childclass)
+  key = "actuator" if tag in _ACT_TAGS else tag
+  base = dict(table[cls if cls is not None else "main"].attrs.get(key, {})) if table else {}
+  explicit = {k: v for k, v in elem.attrib.items() if k != "class"}
+  return base, explicit
+
+
+def _actuator_shortcut(tag, attrs, in_default=False, base=None):
+  """Expand motor/position/velocity shortcuts to `general` attributes (MuJoCo XML reference)."""
+  out = dict(attrs)
+  base = base or {}
+  if tag == "motor":
+    out.setdefault("gaintype", "fixed")
+    out.setdefault("biastype", "none")
+    out.setdefault("dyntype", "none")
+    if not in_default or "gainprm" not in out:
+      out.setdefault("gainprm", "1")
+  elif tag == "position":
+    kp = float(out.pop("kp", 1.0)) if ("kp" in out or not (in_default or "_kp" in base)) else None
+    kv = float(out.pop("kv", 0.0)) if ("kv" in out or not (in_default or "_kv" in base)) else None
+    out.setdefault("gaintype", "fixed")
+    out.setdefault("biastype", "affine")
+    out.setdefault("dyntype", "none")
+    if kp is not None:
+      out["_kp"] = str(kp)
+    if kv is not None:
+      out["_kv"] = str(kv)
+    if "dampratio" in out or "timeconst" in out or "inheritrange" in out:
+      raise NotImplementedError("position actuator dampratio/timeconst/inheritrange")
+  elif tag == "velocity":
+    kv = float(out.pop("kv", 1.0)) if ("kv" in out or not (in_default or "_vkv" in base)) else None
+    out.setdefault("gaintype", "fixed")
+    out.setdefault("biastype", "affine")
+    out.setdefault("dyntype", "none")
+    if kv is not None:
+      out["_vkv"] = str(kv)
+  elif tag == "general":
+    pass
+  else:
+    raise NotImplementedError(f"actuator shortcut <{tag}>")
+  return out
+
+
+def _orientation(attrs, compiler):
+  """quat from quat/axisangle/euler/xyaxes/zaxis attributes."""
+  deg = compiler["angle"] == "degree"
+  if "quat" in attrs:
+    return nm.quat_normalize(_floats(attrs["quat"]))
+  if "axisangle" in attrs:
+    v = _floats(attrs["axisangle"])
+    ang = np.deg2rad(v[3]) if deg else v[3]
+    ax = np.array(v[:3]) / max(np.linalg.norm(v[:3]), MJ_MINVAL)
+    return nm.axis_angle_to_quat(ax, ang)
+  if "euler" in attrs:
+    v = np.array(_floats(attrs["euler"]))
+    if deg:
+      v = np.deg2rad(v)
+    q = np.array([1.0, 0, 0, 0])
+    for i, ch in enumerate(compiler["eulerseq"]):
+      ax = np.zeros(3)
+      ax["xyz".index(ch.lower())] = 1.0
+      r = nm.axis_angle_to_quat(ax, v[i])
+      q = nm.quat_mul(q, r) if ch.islower() else nm.quat_mul(r, q)
+    return nm.quat_normalize(q)
+  if "xyaxes" in attrs:
+    v = np.array(_floats(attrs["xyaxes"]))
+    x = v[:3] / np.linalg.norm(v[:3])
+    y = v[3:] - x * np.dot(x, v[3:])
+    y = y / np.linalg.norm(y)
+    z = np.cross(x, y)
+    return nm.mat_to_quat(np.stack([x, y, z], axis=1))
+  if "zaxis" in attrs:
+    return nm.quat_z2vec(_floats(attrs["zaxis"]))
+  return np.array([1.0, 0, 0, 0])
+
+
+def _expand_includes(elem, base_dir):
+  i = 0
+  children = list(elem)
+  for child in children:
+    if child.tag == "include":
+      path = os.path.join(base_dir, child.get("file"))
+      sub = ET.parse(path).getroot()
+      _expand_includes(sub, os.path.dirname(path))
+      idx = list(elem).index(child)
+      elem.remove(child)
+      for k, sc in enumerate(list(sub)):
+        elem.insert(idx + k, sc)
+    else:
+      _expand_includes(child, base_dir)
+    i += 1
+
+
+def load_xml(path):
+  root = ET.parse(path).getroot()
+  base = os.path.dirname(os.path.abspath(path))
+  _expand_includes(root, base)
+  return _compile(root, base)
+
+
+def from_xml_string(xml, assets_dir=None):
+  root = ET.fromstring(xml)
+  base = assets_dir or os.getcwd()
+  _expand_includes(root, base)
+  return _compile(root, base)
+
+
+# ---- geometry helpers ---------------------------------------------------------------------------
+def _geom_volume_inertia(gtype, size):
+  """Volume and unit-density-normalised diagonal inertia (per unit mass) in the geom frame."""
+  if gtype == GEOM_SPHERE:
+    r = size[0]
+    vol = 4.0 / 3.0 * np.pi * r**3
+    unit = np.full(3, 0.4 * r * r)
+  elif gtype == GEOM_CAPSULE:
+    r, h = size[0], 2.0 * size[1]
+    vol = np.pi * r * r * h + 4.0 / 3.0 * np.pi * r**3
+    ms = 4.0 * r / (4.0 * r + 3.0 * h) if (4.0 * r + 3.0 * h) > 0 else 1.0  # sphere mass fraction
+    mc = 1.0 - ms
+    ixy = mc * (3 * r * r + h * h) / 12.0 + 0.4 * ms * r * r + ms * h * (3 * r + 2 * h) / 8.0
+    iz = mc * r * r / 2.0 + 0.4 * ms * r * r
+    unit = np.array([ixy, ixy, iz])
+  elif gtype == GEOM_CYLINDER:
+    r, h = size[0], 2.0 * size[1]
+    vol = np.pi * r * r * h
+    unit = np.array([(3 * r * r + h * h) / 12.0, (3 * r * r + h * h) / 12.0, r * r / 2.0])
+  elif gtype == GEOM_BOX:
+    a, b, c = size
+    vol = 8.0 * a * b * c
+    unit = np.array([b * b + c * c, a * a + c * c, a * a + b * b]) / 3.0
+  elif gtype == GEOM_ELLIPSOID:
+    a, b, c = size
+    vol = 4.0 / 3.0 * np.pi * a * b * c
+    unit = np.array([b * b + c * c, a * a + c * c, a * a + b * b]) / 5.0
+  else:
+    vol, unit = 0.0, np.zeros(3)
+  return vol, unit
+
+
+def _geom_rbound_aabb(gtype, size):
+  if gtype == GEOM_SPHERE:
+    return size[0], np.array([size[0]] * 3)
+  if gtype == GEOM_CAPSULE:
+    return size[0] + size[1], np.array([size[0], size[0], size[0] + size[1]])
+  if gtype == GEOM_CYLINDER:
+    return float(np.hypot(size[0], size[1])), np.array([size[0], size[0], size[1]])
+  if gtype == GEOM_BOX:
+    return float(np.linalg.norm(size)), np.array(size)
+  if gtype == GEOM_ELLIPSOID:
+    return float(np.max(size)), np.array(size)
+  if gtype == GEOM_PLANE:
+    return 0.0, np.array([1e10, 1e10, 1e10])
+  return 0.0, np.zeros(3)
+
+
+class _Body:
+  pass
+
+
+def _compile(root, base_dir):
+  if root.tag != "mujoco":
+    raise ValueError("root element must be <mujoco>")
+  compiler = {"angle": "degree", "eulerseq": "xyz", "autolimits": True, "inertiafromgeom": "auto",
+              "boundmass": 0.0, "boundinertia": 0.0, "balanceinertia": False, "settotalmass": -1.0}
+  opt = MjOption()
+  stat = MjStatistic()
+  table = {}
+  for elem in root:
+    if elem.tag == "compiler":
+      for k, v in elem.attrib.items():
+        if k in ("angle", "eulerseq", "inertiafromgeom"):
+          compiler[k] = v
+        elif k in ("autolimits", "balanceinertia"):
+          compiler[k] = _bool(v)
+        elif k in ("boundmass", "boundinertia", "settotalmass"):
+          compiler[k] = float(v)
+        elif k == "coordinate" and v != "local":
+          raise NotImplementedError("global coordinates")
+    elif elem.tag == "option":
+      _parse_option(elem, opt)
+    elif elem.tag == "default":
+      _parse_defaults(elem, None, table)
+  if "main" not in table:
+    table["main"] = _Defaults("main")
+
+  deg = compiler["angle"] == "degree"
+
+  bodies, joints, geoms, sites = [], [], [], []
+  world = _Body()
+  world.name, world.parent, world.pos, world.quat = "world", 0, np.zeros(3), np.array([1.0, 0, 0, 0])
+  world.inertial, world.joints, world.geoms, world.gravcomp, world.mocap = None, [], [], 0.0, False
+  bodies.append(world)
+
+  def parse_geom(elem, childclass, bodyid):
+    base, explicit = _resolve("geom", elem, table, childclass)
+    a = dict(base)
+    a.update(explicit)
+    g = {}
+    g["name"] = a.get("name", "")
+    g["type"] = _GEOM_NAMES[a.get("type", "sphere")]
+    size = _vec(a, "size", [0, 0, 0])
+    g["contype"] = int(a.get("contype", 1))
+    g["conaffinity"] = int(a.get("conaffinity", 1))
+    g["condim"] = int(a.get("condim", 3))
+    g["group"] = int(a.get("group", 0))
+    g["priority"] = int(a.get("priority", 0))
+    g["friction"] = _vec(a, "friction", [1.0, 0.005, 0.0001])
+    g["solmix"] = float(a.get("solmix", 1.0))
+    g["solref"] = _vec(a, "solref", [0.02, 1.0])
+    g["solimp"] = _vec(a, "solimp", [0.9, 0.95, 0.001, 0.5, 2.0])
+    g["margin"] = float(a.get("margin", 0.0))
+    g["gap"] = float(a.get("gap", 0.0))
+    g["density"] = float(a.get("density", 1000.0))
+    g["mass"] = float(a["mass"]) if "mass" in a else None
+    g["mesh"] = a.get("mesh")
+    pos = _vec(a, "pos", [0, 0, 0])
+    quat = _orientation(a, compiler)
+    if "fromto" in a:
+      ft = np.array(_floats(a["fromto"]))
+      vec = ft[0:3] - ft[3:6]
+      length = np.linalg.norm(vec)
+      pos = 0.5 * (ft[0:3] + ft[3:6])
+      quat = nm.quat_z2vec(vec)
+      if g["type"] in (GEOM_CAPSULE, GEOM_CYLINDER):
+        size = np.array([size[0], length / 2.0, 0.0])
+      elif g["type"] in (GEOM_BOX, GEOM_ELLIPSOID):
+        size = np.array([size[0], size[1] if size[1] > 0 else size[0], length / 2.0])
+      else:
+        raise ValueError("fromto only for capsule/cylinder/box/ellipsoid")
+    if g["type"] == GEOM_SPHERE:
+      size = np.array([size[0], 0.0, 0.0])
+    elif g["type"] in (GEOM_CAPSULE, GEOM_CYLINDER):
+      size = np.array([size[0], size[1], 0.0])
+    g["size"], g["pos"], g["quat"], g["body"] = size, pos, quat, bodyid
+    if g["type"] in (GEOM_HFIELD, GEOM_SDF):
+      raise NotImplementedError("hfield/sdf geoms")
+    if g["type"] == GEOM_MESH and (g["contype"] or g["conaffinity"]):
+      raise NotImplementedError("colliding mesh geoms need the convex asset pipeline (SURVEY §8f row 4)")
+    return g
+
+  def parse_joint(elem, childclass, bodyid, free=False):
+    if free:
+      a = {"type": "free", "name": elem.get("name", "")}
+      for k in ("group", "align"):
+        pass
+    else:
+      base, explicit = _resolve("joint", elem, table, childclass)
+      a = dict(base)
+      a.update(explicit)
+    j = {}
+    j["name"] = a.get("name", "")
+    j["type"] = _JNT_NAMES[a.get("type", "hinge")]
+    j["pos"] = _vec(a, "pos", [0, 0, 0])
+    ax = _vec(a, "axis", [0, 0, 1])
+    j["axis"] = ax / max(np.linalg.norm(ax), MJ_MINVAL)
+    rng = _vec(a, "range", [0, 0])
+    has_range = "range" in a
+    lim = _bool(a["limited"]) if "limited" in a else None
+    if lim is None:
+      lim = has_range and compiler["autolimits"]
+    j["limited"] = bool(lim)
+    if deg and j["type"] in (JNT_HINGE, JNT_BALL):
+      rng = np.deg2rad(rng)
+    j["range"] = rng
+    j["stiffness"] = float(a.get("stiffness", 0.0))
+    j["damping"] = float(a.get("damping", 0.0))
+    j["armature"] = float(a.get("armature", 0.0))
+    j["frictionloss"] = float(a.get("frictionloss", 0.0))
+    j["margin"] = float(a.get("margin", 0.0))
+    ref = float(a.get("ref", 0.0))
+    sref = float(a.get("springref", 0.0))
+    if deg and j["type"] == JNT_HINGE:
+      ref, sref = np.deg2rad(ref), np.deg2rad(sref)
+    j["ref"], j["springref"] = ref, sref
+    j["solreflimit"] = _vec(a, "solreflimit", [0.02, 1.0])
+    j["solimplimit"] = _vec(a, "solimplimit", [0.9, 0.95, 0.001, 0.5, 2.0])
+    j["solreffriction"] = _vec(a, "solreffriction", [0.02, 1.0])
+    j["solimpfriction"] = _vec(a, "solimpfriction", [0.9, 0.95, 0.001, 0.5, 2.0])
+    afr = _vec(a, "actuatorfrcrange", [0, 0])
+    afl = _bool(a["actuatorfrclimited"]) if "actuatorfrclimited" in a else None
+    if afl is None:
+      afl = ("actuatorfrcrange" in a) and compiler["autolimits"]
+    j["actfrclimited"], j["actfrcrange"] = bool(afl), afr
+    j["actgravcomp"] = int(_bool(a.get("actuatorgravcomp", "false")) or 0)
+    j["body"] = bodyid
+    if j["type"] == JNT_FREE:
+      j["pos"], j["axis"] = np.zeros(3), np.array([0.0, 0, 1])
+      j["limited"] = False
+    return j
+
+  def parse_body(elem, parentid, childclass):
+    b = _Body()
+    cc = elem.get("childclass", childclass)
+    b.name = elem.get("name", "")
+    b.parent = parentid
+    b.pos = _vec(elem.attrib, "pos", [0, 0, 0])
+    b.quat = _orientation(elem.attrib, compiler)
+    b.gravcomp = float(elem.get("gravcomp", 0.0))
+    b.mocap = _bool(elem.get("mocap", "false")) or False
+    if b.mocap:
+      raise NotImplementedError("mocap bodies")
+    b.inertial, b.joints, b.geoms = None, [], []
+    bodies.append(b)
+    bid = len(bodies) - 1
+    for child in elem:
+      if child.tag == "inertial":
+        ia = child.attrib
+        ine = {"pos": _vec(ia, "pos", [0, 0, 0]), "quat": _orientation(ia, compiler), "mass": float(ia["mass"])}
+        if "diaginertia" in ia:
+          ine["diag"] = np.array(_floats(ia["diaginertia"]))
+        elif "fullinertia" in ia:
+          f = _floats(ia["fullinertia"])
+          full = np.array([[f[0], f[3], f[4]], [f[3], f[1], f[5]], [f[4], f[5], f[2]]])
+          w, v = np.linalg.eigh(full)
+          order = np.argsort(-w)
+          w, v = w[order], v[:, order]
+          if np.linalg.det(v) < 0:
+            v[:, 2] = -v[:, 2]
+          ine["diag"] = w
+          ine["quat"] = nm.quat_mul(ine["quat"], nm.mat_to_quat(v))
+        else:
+          raise ValueError("inertial needs diaginertia or fullinertia")
+        b.inertial = ine
+      elif child.tag == "freejoint":
+        b.joints.append(parse_joint(child, cc, bid, free=True))
+      elif child.tag == "joint":
+        b.joints.append(parse_joint(child, cc, bid))
+      elif child.tag == "geom":
+        b.geoms.append(parse_geom(child, cc, bid))
+      elif child.tag == "site":
+        base, explicit = _resolve("site", child, table, cc)
+        a = dict(base)
+        a.update(explicit)
+        sites.append({"name": a.get("name", ""), "body": bid, "pos": _vec(a, "pos", [0, 0, 0]),
+                      "quat": _orientation(a, compiler), "size": _vec(a, "size", [0.005, 0.005, 0.005])})
+      elif child.tag in ("camera", "light", "body", "plugin", "composite", "flexcomp", "frame"):
+        if child.tag in ("composite", "flexcomp", "frame", "plugin"):
+          raise NotImplementedError(f"<{child.tag}>")
+    for child in elem:
+      if child.tag == "body":
+        parse_body(child, bid, cc)
+
+  wb = root.find("worldbody")
+  if wb is None:
+    raise ValueError("no <worldbody>")
+  for child in wb:
+    if child.tag == "geom":
+      world.geoms.append(parse_geom(child, None, 0))
+    elif child.tag == "site":
+      base, explicit = _resolve("site", child, table, None)
+      a = dict(base)
+      a.update(explicit)
+      sites.append({"name": a.get("name", ""), "body": 0, "pos": _vec(a, "pos", [0, 0, 0]),
+                    "quat": _orientation(a, compiler), "size": _vec(a, "size", [0.005, 0.005, 0.005])})
+  for child in wb:
+    if child.tag == "body":
+      parse_body(child, 0, None)
+
+  for tag in ("equality", "tendon"):
+    e = root.find(tag)
+    if e is not None and len(list(e)) > 0:
+      raise NotImplementedError(f"<{tag}> is outside the hot-path scope (SURVEY §2 OUT rows)")
+
+  m = MjModel()
+  m.opt, m.stat = opt, stat
+  nbody = len(bodies)
+  m.nbody = nbody
+  m.body_names = [b.name for b in bodies]
+  m.body_parentid = np.array([b.parent for b in bodies], dtype=np.int32)
+  m.body_pos = np.array([b.pos for b in bodies])
+  m.body_quat = np.array([b.quat for b in bodies])
+  m.body_gravcomp = np.array([b.gravcomp for b in bodies])
+  m.body_mocapid = np.full(nbody, -1, dtype=np.int32)
+  m.nmocap = 0
+
+  # joints / dofs
+  jl = []
+  m.body_jntnum = np.zeros(nbody, dtype=np.int32)
+  m.body_jntadr = np.full(nbody, -1, dtype=np.int32)
+  m.body_dofnum = np.zeros(nbody, dtype=np.int32)
+  m.body_dofadr = np.full(nbody, -1, dtype=np.int32)
+  nq = nv = 0
+  qpos0, qpos_spring = [], []
+  jq, jd = [], []
+  dof_body, dof_jnt, dof_parent = [], [], []
+  last_dof_of_body = np.full(nbody, -1, dtype=np.int64)
+  for bid, b in enumerate(bodies):
+    if b.joints:
+      m.body_jntadr[bid] = len(jl)
+      m.body_jntnum[bid] = len(b.joints)
+      m.body_dofadr[bid] = nv
+    # last dof among ancestors
+    p = b.parent if bid > 0 else -1
+    prev = last_dof_of_body[p] if p >= 0 else -1
+    for j in b.joints:
+      if j["type"] == JNT_FREE and (b.parent != 0 or len(b.joints) != 1):
+        raise ValueError("free joint must be alone in a top-level body")
+      jid = len(jl)
+      jl.append(j)
+      jq.append(nq)
+      jd.append(nv)
+      t = j["type"]
+      if t == JNT_FREE:
+        q0 = np.concatenate([b.pos, b.quat])
+        qs = q0.copy()
+        ndof, nqj = 6, 7
+      elif t == JNT_BALL:
+        q0 = np.array([1.0, 0, 0, 0])
+        qs = q0.copy()
+        ndof, nqj = 3, 4
+      else:
+        q0 = np.array([j["ref"]])
+        qs = np.array([j["springref"]])
+        ndof, nqj = 1, 1
+      qpos0.append(q0)
+      qpos_spring.append(qs)
+      for k in range(ndof):
+        dof_body.append(bid)
+        dof_jnt.append(jid)
+        dof_parent.append(prev)
+        prev = nv
+        nv += 1
+      nq += nqj
+    m.body_dofnum[bid] = nv - (m.body_dofadr[bid] if b.joints else nv)
+    last_dof_of_body[bid] = prev
+  m.nq, m.nv, m.njnt = nq, nv, len(jl)
+  m.qpos0 = np.concatenate(qpos0) if qpos0 else np.zeros(0)
+  m.qpos_spring = np.concatenate(qpos_spring) if qpos_spring else np.zeros(0)
+  m.jnt_names = [j["name"] for j in jl]
+  m.jnt_type = np.array([j["type"] for j in jl], dtype=np.int32)
+  m.jnt_qposadr = np.array(jq, dtype=np.int32)
+  m.jnt_dofadr = np.array(jd, dtype=np.int32)
+  m.jnt_bodyid = np.array([j["body"] for j in jl], dtype=np.int32)
+  m.jnt_limited = np.array([j["limited"] for j in jl], dtype=np.int32)
+  m.jnt_actfrclimited = np.array([j["actfrclimited"] for j in jl], dtype=bool)
+  m.jnt_actgravcomp = np.array([j["actgravcomp"] for j in jl], dtype=np.int32)
+  m.jnt_solref = np.array([j["solreflimit"] for j in jl]).reshape(-1, 2)
+  m.jnt_solimp = np.array([j["solimplimit"] for j in jl]).reshape(-1, 5)
+  m.jnt_pos = np.array([j["pos"] for j in jl]).reshape(-1, 3)
+  m.jnt_axis = np.array([j["axis"] for j in jl]).reshape(-1, 3)
+  m.jnt_stiffness = np.array([j["stiffness"] for j in jl], dtype=np.float64)
+  m.jnt_stiffnesspoly = np.zeros((m.njnt, 2))
+  m.jnt_range = np.array([j["range"] for j in jl]).reshape(-1, 2)
+  m.jnt_actfrcrange = np.array([j["actfrcrange"] for j in jl]).reshape(-1, 2)
+  m.jnt_margin = np.array([j["margin"] for j in jl], dtype=np.float64)
+  m.dof_bodyid = np.array(dof_body, dtype=np.int32)
+  m.dof_jntid = np.array(dof_jnt, dtype=np.int32)
+  m.dof_parentid = np.array(dof_parent, dtype=np.int32)
+  m.dof_solref = np.array([jl[j]["solreffriction"] for j in dof_jnt]).reshape(-1, 2)
+  m.dof_solimp = np.array([jl[j]["solimpfriction"] for j in dof_jnt]).reshape(-1, 5)
+  m.dof_frictionloss = np.array([jl[j]["frictionloss"] for j in dof_jnt], dtype=np.float64)
+  m.dof_armature = np.array([jl[j]["armature"] for j in dof_jnt], dtype=np.float64)
+  m.dof_damping = np.array([jl[j]["damping"] for j in dof_jnt], dtype=np.float64)
+  m.dof_dampingpoly = np.zeros((nv, 2))
+
+  # weld / root / tree ids
+  m.body_weldid = np.zeros(nbody, dtype=np.int32)
+  m.body_rootid = np.zeros(nbody, dtype=np.int32)
+  m.body_treeid = np.full(nbody, -1, dtype=np.int32)
+  ntree = 0
+  for bid in range(1, nbody):
+    p = m.body_parentid[bid]
+    m.body_weldid[bid] = bid if m.body_jntnum[bid] > 0 else m.body_weldid[p]
+    m.body_rootid[bid] = bid if p == 0 else m.body_rootid[p]
+    if m.body_jntnum[bid] > 0 and m.body_treeid[p] < 0:
+      m.body_treeid[bid] = ntree
+      ntree += 1
+    else:
+      m.body_treeid[bid] = m.body_treeid[p]
+  m.ntree = ntree
+  m.dof_treeid = m.body_treeid[m.dof_bodyid] if nv else np.zeros(0, dtype=np.int32)
+  m.tree_dofadr = np.array([int(np.argmax(m.dof_treeid == t)) for t in range(ntree)], dtype=np.int32)
+  m.tree_dofnum = np.array([int(np.sum(m.dof_treeid == t)) for t in range(ntree)], dtype=np.int32)
+  m.tree_bodynum = np.array([int(np.sum(m.body_treeid == t)) for t in range(ntree)], dtype=np.int32)
+
+  # geoms (ordered by body)
+  gl = []
+  m.body_geomnum = np.zeros(nbody, dtype=np.int32)
+  m.body_geomadr = np.full(nbody, -1, dtype=np.int32)
+  for bid, b in enumerate(bodies):
+    if b.geoms:
+      m.body_geomadr[bid] = len(gl)
+      m.body_geomnum[bid] = len(b.geoms)
+    gl.extend(b.geoms)
+  ng = len(gl)
+  m.ngeom = ng
+  m.geom_names = [g["name"] for g in gl]
+  m.geom_type = np.array([g["type"] for g in gl], dtype=np.int32)
+  m.geom_contype = np.array([g["contype"] for g in gl], dtype=np.int32)
+  m.geom_conaffinity = np.array([g["conaffinity"] for g in gl], dtype=np.int32)
+  m.geom_condim = np.array([g["condim"] for g in gl], dtype=np.int32)
+  m.geom_bodyid = np.array([g["body"] for g in gl], dtype=np.int32)
+  m.geom_dataid = np.full(ng, -1, dtype=np.int32)
+  m.geom_group = np.array([g["group"] for g in gl], dtype=np.int32)
+  m.geom_priority = np.array([g["priority"] for g in gl], dtype=np.int32)
+  m.geom_solmix = np.array([g["solmix"] for g in gl], dtype=np.float64)
+  m.geom_solref = np.array([g["solref"] for g in gl]).reshape(-1, 2)
+  m.geom_solimp = np.array([g["solimp"] for g in gl]).reshape(-1, 5)
+  m.geom_size = np.array([g["size"] for g in gl]).reshape(-1, 3)
+  m.geom_pos = np.array([g["pos"] for g in gl]).reshape(-1, 3)
+  m.geom_quat = np.array([g["quat"] for g in gl]).reshape(-1, 4)
+  m.geom_friction = np.array([g["friction"] for g in gl]).reshape(-1, 3)
+  m.geom_margin = np.array([g["margin"] for g in gl], dtype=np.float64)
+  m.geom_gap = np.array([g["gap"] for g in gl], dtype=np.float64)
+  rb = [_geom_rbound_aabb(g["type"], g["size"]) for g in gl]
+  m.geom_rbound = np.array([r[0] for r in rb], dtype=np.float64)
+  m.geom_aabb = np.zeros((ng, 6))
+  for i, r in enumerate(rb):
+    m.geom_aabb[i, 3:] = r[1]
+
+  # sites
+  m.nsite = len(sites)
+  m.site_bodyid = np.array([s["body"] for s in sites], dtype=np.int32)
+  m.site_pos = np.array([s["pos"] for s in sites]).reshape(-1, 3)
+  m.site_quat = np.array([s["quat"] for s in sites]).reshape(-1, 4)
+
+  # body inertial properties
+  m.body_mass = np.zeros(nbody)
+  m.body_ipos = np.zeros((nbody, 3))
+  m.body_iquat = np.tile(np.array([1.0, 0, 0, 0]), (nbody, 1))
+  m.body_inertia = np.zeros((nbody, 3))
+  for bid, b in enumerate(bodies):
+    use_geoms = compiler["inertiafromgeom"] == "true" or (compiler["inertiafromgeom"] == "auto" and b.inertial is None)
+    if b.inertial is not None and not use_geoms:
+      m.body_mass[bid] = b.inertial["mass"]
+      m.body_ipos[bid] = b.inertial["pos"]
+      m.body_iquat[bid] = b.inertial["quat"]
+      m.body_inertia[bid] = b.inertial["diag"]
+      continue
+    if bid == 0:
+      continue
+    tot, com = 0.0, np.zeros(3)
+    parts = []
+    for g in b.geoms:
+      vol, unit = _geom_volume_inertia(g["type"], g["size"])
+      mass = g["mass"] if g["mass"] is not None else g["density"] * vol
+      if g["type"] in (GEOM_PLANE, GEOM_MESH):
+        mass = 0.0
+      if mass <= 0:
+        continue
+      parts.append((mass, g["pos"], nm.quat_to_mat(g["quat"]), unit * mass))
+      tot += mass
+      com += mass * g["pos"]
+    if tot <= 0:
+      continue
+    com /= tot
+    inertia = np.zeros((3, 3))
+    for mass, p, R, diag in parts:
+      d = p - com
+      inertia += R @ np.diag(diag) @ R.T + mass * (np.dot(d, d) * np.eye(3) - np.outer(d, d))
+    w, v = np.linalg.eigh(inertia)
+    order = np.argsort(-w)
+    w, v = w[order], v[:, order]
+    if np.linalg.det(v) < 0:
+      v[:, 2] = -v[:, 2]
+    m.body_mass[bid] = tot
+    m.body_ipos[bid] = com
+    m.body_iquat[bid] = nm.mat_to_quat(v)
+    m.body_inertia[bid] = w
+  if compiler["boundmass"] > 0:
+    m.body_mass[1:] = np.maximum(m.body_mass[1:], compiler["boundmass"])
+  if compiler["boundinertia"] > 0:
+    m.body_inertia[1:] = np.maximum(m.body_inertia[1:], compiler["boundinertia"])
+  for bid in range(1, nbody):
+    if m.body_weldid[bid] != 0 and m.body_dofnum[bid] > 0:
+      # a moving body (or one of its welded children) must carry mass
+      pass
+
+  # actuators
+  acts = []
+  ae = root.find("actuator")
+  if ae is not None:
+    for child in ae:
+      if child.tag not in _ACT_TAGS:
+        continue
+      base, explicit = _resolve(child.tag, child, table, None)
+      a = dict(base)
+      a.update(_actuator_shortcut(child.tag, explicit, base=base))
+      acts.append(a)
+  nu = len(acts)
+  m.nu = nu
+  m.actuator_names = [a.get("name", "") for a in acts]
+  m.actuator_trntype = np.zeros(nu, dtype=np.int32)
+  m.actuator_dyntype = np.zeros(nu, dtype=np.int32)
+  m.actuator_gaintype = np.zeros(nu, dtype=np.int32)
+  m.actuator_biastype = np.zeros(nu, dtype=np.int32)
+  m.actuator_trnid = np.full((nu, 2), -1, dtype=np.int32)
+  m.actuator_actadr = np.full(nu, -1, dtype=np.int32)
+  m.actuator_actnum = np.zeros(nu, dtype=np.int32)
+  m.actuator_dynprm = np.zeros((nu, 10))
+  m.actuator_gainprm = np.zeros((nu, 10))
+  m.actuator_biasprm = np.zeros((nu, 10))
+  m.actuator_ctrllimited = np.zeros(nu, dtype=bool)
+  m.actuator_forcelimited = np.zeros(nu, dtype=bool)
+  m.actuator_actlimited = np.zeros(nu, dtype=bool)
+  m.actuator_actearly = np.zeros(nu, dtype=bool)
+  m.actuator_ctrlrange = np.zeros((nu, 2))
+  m.actuator_forcerange = np.zeros((nu, 2))
+  m.actuator_actrange = np.zeros((nu, 2))
+  m.actuator_gear = np.zeros((nu, 6))
+  m.actuator_cranklength = np.zeros(nu)
+  m.actuator_acc0 = np.zeros(nu)
+  m.actuator_lengthrange = np.zeros((nu, 2))
+  na = 0
+  dynmap = {"none": DYN_NONE, "integrator": DYN_INTEGRATOR, "filter": DYN_FILTER, "filterexact": DYN_FILTEREXACT}
+  gainmap = {"fixed": GAIN_FIXED, "affine": GAIN_AFFINE}
+  biasmap = {"none": BIAS_NONE, "affine": BIAS_AFFINE}
+  for i, a in enumerate(acts):
+    if "joint" not in a:
+      raise NotImplementedError("only joint transmissions are supported")
+    jid = m.jnt_names.index(a["joint"])
+    if m.jnt_type[jid] not in (JNT_HINGE, JNT_SLIDE):
+      raise NotImplementedError("actuators on ball/free joints")
+    m.actuator_trntype[i] = TRN_JOINT
+    m.actuator_trnid[i, 0] = jid
+    m.actuator_dyntype[i] = dynmap[a.get("dyntype", "none")]
+    m.actuator_gaintype[i] = gainmap[a.get("gaintype", "fixed")]
+    m.actuator_biastype[i] = biasmap[a.get("biastype", "none")]
+    m.actuator_dynprm[i] = _vec(a, "dynprm", [1.0] + [0.0] * 9)
+    m.actuator_gainprm[i] = _vec(a, "gainprm", [1.0] + [0.0] * 9)
+    m.actuator_biasprm[i] = _vec(a, "biasprm", [0.0] * 10)
+    if "_kp" in a:
+      kp = float(a["_kp"])
+      kv = float(a.get("_kv", 0.0))
+      m.actuator_gainprm[i, 0] = kp
+      m.actuator_biasprm[i, 0:3] = [0.0, -kp, -kv]
+    if "_vkv" in a:
+      kv = float(a["_vkv"])
+      m.actuator_gainprm[i, 0] = kv
+      m.actuator_biasprm[i, 0:3] = [0.0, 0.0, -kv]
+    g = _vec(a, "gear", [1.0, 0, 0, 0, 0, 0])
+    m.actuator_gear[i] = g
+    for key, lim, rngname in (("ctrl", m.actuator_ctrllimited, m.actuator_ctrlrange),
+                              ("force", m.actuator_forcelimited, m.actuator_forcerange),
+                              ("act", m.actuator_actlimited, m.actuator_actrange)):
+      has = (key + "range") in a
+      l = _bool(a[key + "limited"]) if (key + "limited") in a else None
+      if l is None:
+        l = has and compiler["autolimits"]
+      lim[i] = bool(l)
+      rngname[i] = _vec(a, key + "range", [0, 0])
+    m.actuator_actearly[i] = bool(_bool(a.get("actearly", "false")))
+    if m.actuator_dyntype[i] != DYN_NONE:
+      m.actuator_actadr[i] = na
+      m.actuator_actnum[i] = 1
+      na += 1
+  m.na = na
+
+  # contact excludes / pairs
+  m.exclude_signature = np.zeros(0, dtype=np.int32)
+  m.npair = 0
+  m.pair_geom1 = np.zeros(0, dtype=np.int32)
+  m.pair_geom2 = np.zeros(0, dtype=np.int32)
+  ce = root.find("contact")
+  if ce is not None:
+    sig = []
+    for child in ce:
+      if child.tag == "exclude":
+        b1 = m.body_names.index(child.get("body1"))
+        b2 = m.body_names.index(child.get("body2"))
+        lo, hi = min(b1, b2), max(b1, b2)
+        sig.append((lo << 16) + hi)
+      elif child.tag == "pair":
+        raise NotImplementedError("explicit contact <pair>")
+    m.exclude_signature = np.array(sig, dtype=np.int32)
+  m.nexclude = len(m.exclude_signature)
+
+  # keyframes
+  keys = []
+  ke = root.find("keyframe")
+  if ke is not None:
+    keys = [k for k in ke if k.tag == "key"]
+  m.nkey = len(keys)
+  m.key_names = [k.get("name", "") for k in keys]
+  m.key_time = np.zeros(m.nkey)
+  m.key_qpos = np.tile(m.qpos0, (m.nkey, 1)) if m.nkey else np.zeros((0, nq))
+  m.key_qvel = np.zeros((m.nkey, nv))
+  m.key_act = np.zeros((m.nkey, na))
+  m.key_ctrl = np.zeros((m.nkey, nu))
+  for i, k in enumerate(keys):
+    if "time" in k.attrib:
+      m.key_time[i] = float(k.get("time"))
+    for name, arr in (("qpos", m.key_qpos), ("qvel", m.key_qvel), ("act", m.key_act), ("ctrl", m.key_ctrl)):
+      if name in k.attrib:
+        v = _floats(k.get(name))
+        if len(v) != arr.shape[1]:
+          raise ValueError(f"keyframe {name} size {len(v)} != {arr.shape[1]}")
+        arr[i] = v
+
+  # sizes not on the hot path
+  m.neq = m.ntendon = m.nsensor = m.nmesh = m.nhfield = m.nflex = m.nplugin = 0
+  m.ncam = m.nlight = 0
+  m.nuserdata = m.nsensordata = 0
+
+  _sparse_structure(m)
+  set_const(m)
+  return m
+
+
+def _parse_option(elem, opt):
+  for k, v in elem.attrib.items():
+    if k in ("timestep", "tolerance", "ls_tolerance", "impratio", "density", "viscosity", "noslip_tolerance", "ccd_tolerance"):
+      setattr(opt, k, float(v))
+    elif k in ("iterations", "ls_iterations", "noslip_iterations", "ccd_iterations", "sdf_iterations", "sdf_initpoints"):
+      setattr(opt, k, int(v))
+    elif k in ("gravity", "wind", "magnetic"):
+      setattr(opt, k, np.array(_floats(v)))
+    elif k == "integrator":
+      opt.integrator = _INT_NAMES[v.lower()]
+    elif k == "solver":
+      opt.solver = _SOL_NAMES[v.lower()]
+    elif k == "cone":
+      opt.cone = CONE_ELLIPTIC if v.lower() == "elliptic" else CONE_PYRAMIDAL
+    elif k == "jacobian":
+      opt.jacobian = {"dense": JAC_DENSE, "sparse": JAC_SPARSE, "auto": JAC_AUTO}[v.lower()]
+  for f in elem.findall("flag"):
+    for k, v in f.attrib.items():
+      on = v.lower() == "enable"
+      if k in DSBL:
+        if on:
+          opt.disableflags &= ~DSBL[k]
+        else:
+          opt.disableflags |= DSBL[k]
+      elif k in ENBL:
+        if on:
+          opt.enableflags |= ENBL[k]
+        else:
+          opt.enableflags &= ~ENBL[k]
+      elif k == "passive":
+        bits = DSBL["spring"] | DSBL["damper"]
+        opt.disableflags = (opt.disableflags & ~bits) if on else (opt.disableflags | bits)
+
+
+def _sparse_structure(m):
+  """CSR "M-structure": row i = dof-ancestor chain in ascending order, diagonal last
+  (reference smooth.py:1064-1076, set_const.py:186-188)."""
+  nv = m.nv
+  rownnz = np.zeros(nv, dtype=np.int32)
+  rows = []
+  for i in range(nv):
+    chain = []
+    j = i
+    while j >= 0:
+      chain.append(j)
+      j = m.dof_parentid[j]
+    chain.reverse()
+    rows.append(chain)
+    rownnz[i] = len(chain)
+  rowadr = np.zeros(nv, dtype=np.int32)
+  if nv:
+    rowadr[1:] = np.cumsum(rownnz)[:-1]
+  m.M_rownnz = rownnz
+  m.M_rowadr = rowadr
+  m.M_colind = np.array([c for r in rows for c in r], dtype=np.int32)
+  m.nC = m.nM = int(rownnz.sum())
+  m.dof_Madr = (rowadr + rownnz - 1).astype(np.int32)  # address of the diagonal in CSR order
+  # body-level helpers used by host code
+  m.body_subtreemass = np.zeros(m.nbody)
+
+
+# ---- host-side float64 smooth dynamics at one configuration (used by set_const only) ------------
+def _host_kinematics(m, qpos):
+  nb = m.nbody
+  xpos, xquat = np.zeros((nb, 3)), np.zeros((nb, 4))
+  xquat[0] = [1, 0, 0, 0]
+  xanchor, xaxis = np.zeros((m.njnt, 3)), np.zeros((m.njnt, 3))
+  for b in range(1, nb):
+    p = m.body_parentid[b]
+    ja, jn = m.body_jntadr[b], m.body_jntnum[b]
+    if jn == 1 and m.jnt_type[ja] == JNT_FREE:
+      qa = m.jnt_qposadr[ja]
+      xpos[b] = qpos[qa : qa + 3]
+      xquat[b] = nm.quat_normalize(qpos[qa + 3 : qa + 7])
+      xanchor[ja] = xpos[b]
+      xaxis[ja] = m.jnt_axis[ja]
+      continue
+    pos = nm.rot_vec_quat(m.body_pos[b], xquat[p]) + xpos[p]
+    quat = nm.quat_mul(xquat[p], m.body_quat[b])
+    for j in range(ja, ja + jn):
+      qa = m.jnt_qposadr[j]
+      anchor = nm.rot_vec_quat(m.jnt_pos[j], quat) + pos
+      axis = nm.rot_vec_quat(m.jnt_axis[j], quat)
+      t = m.jnt_type[j]
+      if t == JNT_BALL:
+        quat = nm.quat_mul(quat, nm.quat_normalize(qpos[qa : qa + 4]))
+        pos = anchor - nm.rot_vec_quat(m.jnt_pos[j], quat)
+      elif t == JNT_SLIDE:
+        pos = pos + axis * (qpos[qa] - m.qpos0[qa])
+      elif t == JNT_HINGE:
+        quat = nm.quat_mul(quat, nm.axis_angle_to_quat(m.jnt_axis[j], qpos[qa] - m.qpos0[qa]))
+        pos = anchor - nm.rot_vec_quat(m.jnt_pos[j], quat)
+      xanchor[j], xaxis[j] = anchor, axis
+    xpos[b], xquat[b] = pos, nm.quat_normalize(quat)
+  return xpos, xquat, xanchor, xaxis
+
+
+def host_mass_matrix(m, qpos):
+  """Dense M(q) (float64) plus intermediate fields; mirrors smooth.py com_pos/crb."""
+  nb, nv = m.nbody, m.nv
+  xpos, xquat, xanchor, xaxis = _host_kinematics(m, qpos)
+  xmat = np.array([nm.quat_to_mat(q) for q in xquat])
+  xipos = np.array([xpos[b] + xmat[b] @ m.body_ipos[b] for b in range(nb)])
+  ximat = np.array([nm.quat_to_mat(nm.quat_mul(xquat[b], m.body_iquat[b])) for b in range(nb)])
+  # subtree com
+  sub = xipos * m.body_mass[:, None]
+  for b in range(nb - 1, 0, -1):
+    sub[m.body_parentid[b]] += sub[b]
+  stm = m.body_mass.copy()
+  for b in range(nb - 1, 0, -1):
+    stm[m.body_parentid[b]] += stm[b]
+  for b in range(nb):
+    if stm[b] != 0:
+      sub[b] /= stm[b]
+    else:
+      sub[b] = xipos[b]
+  cinert = np.zeros((nb, 10))
+  for b in range(nb):
+    mat, inert, mass = ximat[b], m.body_inertia[b], m.body_mass[b]
+    dif = xipos[b] - sub[m.body_rootid[b]]
+    tmp = mat @ np.diag(inert) @ mat.T
+    r = np.zeros(10)
+    r[0:3] = [tmp[0, 0], tmp[1, 1], tmp[2, 2]]
+    r[3:6] = [tmp[0, 1], tmp[0, 2], tmp[1, 2]]
+    r[0] += mass * (dif[1] ** 2 + dif[2] ** 2)
+    r[1] += mass * (dif[0] ** 2 + dif[2] ** 2)
+    r[2] += mass * (dif[0] ** 2 + dif[1] ** 2)
+    r[3] -= mass * dif[0] * dif[1]
+    r[4] -= mass * dif[0] * dif[2]
+    r[5] -= mass * dif[1] * dif[2]
+    r[6:9] = mass * dif
+    r[9] = mass
+    cinert[b] = r
+  cdof = np.zeros((nv, 6))
+  for j in range(m.njnt):
+    b, d, t = m.jnt_bodyid[j], m.jnt_dofadr[j], m.jnt_type[j]
+    off = sub[m.body_rootid[b]] - xanchor[j]
+    if t == JNT_FREE:
+      cdof[d + 0, 3] = cdof[d + 1, 4] = cdof[d + 2, 5] = 1.0
+      for k in range(3):
+        ax = xmat[b][:, k]
+        cdof[d + 3 + k] = np.concatenate([ax, np.cross(ax, off)])
+    elif t == JNT_BALL:
+      for k in range(3):
+        ax = xmat[b][:, k]
+        cdof[d + k] = np.concatenate([ax, np.cross(ax, off)])
+    elif t == JNT_SLIDE:
+      cdof[d] = np.concatenate([np.zeros(3), xaxis[j]])
+    else:
+      cdof[d] = np.concatenate([xaxis[j], np.cross(xaxis[j], off)])
+  crb = cinert.copy()
+  for b in range(nb - 1, 0, -1):
+    p = m.body_parentid[b]
+    if p != 0:
+      crb[p] += crb[b]
+  M = np.zeros((nv, nv))
+  for i in range(nv):
+    buf = nm.inert_vec(crb[m.dof_bodyid[i]], cdof[i])
+    j = i
+    while j >= 0:
+      M[i, j] = M[j, i] = np.dot(cdof[j], buf)
+      j = m.dof_parentid[j]
+    M[i, i] += m.dof_armature[i]
+  return dict(M=M, xpos=xpos, xquat=xquat, xmat=xmat, xipos=xipos, ximat=ximat, subtree_com=sub,
+              cinert=cinert, cdof=cdof, crb=crb, xanchor=xanchor, xaxis=xaxis)
+
+
+def set_const(m):
+  """mj_setConst restatement (reference set_const.py:35-59, 170-190, 208-375)."""
+  nb, nv = m.nbody, m.nv
+  stm = m.body_mass.copy()
+  for b in range(nb - 1, 0, -1):
+    stm[m.body_parentid[b]] += stm[b]
+  m.body_subtreemass = stm
+  m.dof_invweight0 = np.zeros(nv)
+  m.body_invweight0 = np.zeros((nb, 2))
+  if nv == 0:
+    m.stat.meaninertia = 1.0
+    return
+  h = host_mass_matrix(m, m.qpos0)
+  M = h["M"]
+  m.stat.meaninertia = float(np.mean(np.diag(M)))
+  Minv = np.linalg.inv(M)
+  A = np.diag(Minv)
+  for j in range(m.njnt):
+    d, t = m.jnt_dofadr[j], m.jnt_type[j]
+    if t == JNT_FREE:
+      m.dof_invweight0[d : d + 3] = np.mean(A[d : d + 3])
+      m.dof_invweight0[d + 3 : d + 6] = np.mean(A[d + 3 : d + 6])
+    elif t == JNT_BALL:
+      m.dof_invweight0[d : d + 3] = np.mean(A[d : d + 3])
+    else:
+      m.dof_invweight0[d] = A[d]
+  for b in range(1, nb):
+    if m.body_weldid[b] == 0:
+      continue
+    bb = b
+    while bb > 0 and m.body_dofnum[bb] == 0:
+      bb = m.body_parentid[bb]
+    if bb == 0:
+      continue
+    J = np.zeros((6, nv))
+    off = h["xipos"][b] - h["subtree_com"][m.body_rootid[b]]
+    d = m.body_dofadr[bb] + m.body_dofnum[bb] - 1
+    while d >= 0:
+      ang, lin = h["cdof"][d, :3], h["cdof"][d, 3:]
+      J[0:3, d] = lin + np.cross(ang, off)
+      J[3:6, d] = ang
+      d = m.dof_parentid[d]
+    Ad = np.einsum("ri,ij,rj->r", J, Minv, J)
+    tr, ro = float(np.mean(Ad[:3])), float(np.mean(Ad[3:]))
+    if tr < MJ_MINVAL and ro > MJ_MINVAL:
+      tr = ro
+    elif ro < MJ_MINVAL and tr > MJ_MINVAL:
+      ro = tr
+    m.body_invweight0[b] = [tr, ro]
+  # actuator_acc0 = |M^-1 moment| for joint transmissions (set_const.py:494-506)
+  for i in range(m.nu):
+    mom = np.zeros(nv)
+    mom[m.jnt_dofadr[m.actuator_trnid[i, 0]]] = m.actuator_gear[i, 0]
+    m.actuator_acc0[i] = float(np.linalg.norm(Minv @ mom))

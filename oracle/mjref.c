@@ -1,0 +1,1430 @@
+/* oracle/mjref.c -- TEST INFRASTRUCTURE ONLY (see mjref.h header: "PARITY UNPINNED").
+ *
+ * float64 single-world restatement of the reference's mj_step hot path.  Every function cites the
+ * reference kernel(s) it follows (paths relative to /root/reference/mujoco_warp/_src/).
+ * Deterministic ordering replaces the reference's atomic allocation: contacts are emitted in
+ * geom-pair order, constraint rows in MuJoCo order (friction dofs, joint limits, contacts).
+ */
+#include "mjref.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define MINVAL 1e-15
+#define MAXVAL 1e10
+#define MINIMP 0.0001
+#define MAXIMP 0.9999
+#define MINMU 1e-5
+
+enum { JNT_FREE = 0, JNT_BALL = 1, JNT_SLIDE = 2, JNT_HINGE = 3 };
+enum { G_PLANE = 0, G_HFIELD, G_SPHERE, G_CAPSULE, G_ELLIPSOID, G_CYLINDER, G_BOX, G_MESH };
+enum { ST_SATISFIED = 0, ST_QUADRATIC = 1, ST_LINEARNEG = 2, ST_LINEARPOS = 3, ST_CONE = 4 };
+enum { CT_EQUALITY = 0, CT_FRICTION_DOF = 1, CT_FRICTION_TENDON = 2, CT_LIMIT_JOINT = 3, CT_LIMIT_TENDON = 4,
+       CT_CONTACT_FRICTIONLESS = 5, CT_CONTACT_PYRAMIDAL = 6, CT_CONTACT_ELLIPTIC = 7 };
+enum { DSBL_CONSTRAINT = 1 << 0, DSBL_FRICTIONLOSS = 1 << 2, DSBL_LIMIT = 1 << 3, DSBL_CONTACT = 1 << 4,
+       DSBL_SPRING = 1 << 5, DSBL_DAMPER = 1 << 6, DSBL_GRAVITY = 1 << 7, DSBL_CLAMPCTRL = 1 << 8,
+       DSBL_WARMSTART = 1 << 9, DSBL_ACTUATION = 1 << 11, DSBL_REFSAFE = 1 << 12, DSBL_EULERDAMP = 1 << 15 };
+enum { SOL_PGS = 0, SOL_CG = 1, SOL_NEWTON = 2 };
+enum { INT_EULER = 0, INT_RK4 = 1, INT_IMPLICIT = 2, INT_IMPLICITFAST = 3 };
+enum { OVF_NEFC = 1 << 0, OVF_NARROW = 1 << 3, OVF_ITER = 1 << 9, OVF_LS = 1 << 10 };
+
+/* ---------------------------------------------------------------- math.py:24-333 */
+static void v3set(double* r, double x, double y, double z) { r[0] = x; r[1] = y; r[2] = z; }
+static void v3cpy(double* r, const double* a) { r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; }
+static void v3sub(double* r, const double* a, const double* b) { r[0] = a[0] - b[0]; r[1] = a[1] - b[1]; r[2] = a[2] - b[2]; }
+static void v3add(double* r, const double* a, const double* b) { r[0] = a[0] + b[0]; r[1] = a[1] + b[1]; r[2] = a[2] + b[2]; }
+static void v3addscl(double* r, const double* a, const double* b, double s) { r[0] = a[0] + s * b[0]; r[1] = a[1] + s * b[1]; r[2] = a[2] + s * b[2]; }
+static double v3dot(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static double v3len(const double* a) { return sqrt(v3dot(a, a)); }
+static void v3cross(double* r, const double* a, const double* b) {
+  double x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+static double v3normalize(double* a) { /* wp.normalize: zero stays zero */
+  double n = v3len(a);
+  if (n > 0) { a[0] /= n; a[1] /= n; a[2] /= n; }
+  return n;
+}
+static double safe_div(double x, double y) { return x / (y != 0.0 ? y : MINVAL); }
+static double clampd(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+static void mul_quat(double* r, const double* u, const double* v) { /* math.py:24 */
+  double w = u[0] * v[0] - u[1] * v[1] - u[2] * v[2] - u[3] * v[3];
+  double x = u[0] * v[1] + u[1] * v[0] + u[2] * v[3] - u[3] * v[2];
+  double y = u[0] * v[2] - u[1] * v[3] + u[2] * v[0] + u[3] * v[1];
+  double z = u[0] * v[3] + u[1] * v[2] - u[2] * v[1] + u[3] * v[0];
+  r[0] = w; r[1] = x; r[2] = y; r[3] = z;
+}
+static void rot_vec_quat(double* r, const double* v, const double* q) { /* math.py:46 */
+  double s = q[0];
+  const double* u = q + 1;
+  double uv = v3dot(u, v), uu = v3dot(u, u), c[3];
+  v3cross(c, u, v);
+  for (int i = 0; i < 3; i++) r[i] = 2.0 * uv * u[i] + (s * s - uu) * v[i] + 2.0 * s * c[i];
+}
+static void axis_angle_to_quat(double* q, const double* axis, double angle) { /* math.py:54 */
+  double s = sin(angle * 0.5), c = cos(angle * 0.5);
+  q[0] = c; q[1] = axis[0] * s; q[2] = axis[1] * s; q[3] = axis[2] * s;
+}
+static void quat_normalize(double* q) {
+  double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  if (n > 0) { q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n; }
+}
+static void quat_to_mat(double* m, const double* q) { /* math.py:61 */
+  double q00 = q[0] * q[0], q01 = q[0] * q[1], q02 = q[0] * q[2], q03 = q[0] * q[3];
+  double q11 = q[1] * q[1], q12 = q[1] * q[2], q13 = q[1] * q[3];
+  double q22 = q[2] * q[2], q23 = q[2] * q[3], q33 = q[3] * q[3];
+  m[0] = q00 + q11 - q22 - q33; m[1] = 2.0 * (q12 - q03); m[2] = 2.0 * (q13 + q02);
+  m[3] = 2.0 * (q12 + q03); m[4] = q00 - q11 + q22 - q33; m[5] = 2.0 * (q23 - q01);
+  m[6] = 2.0 * (q13 - q02); m[7] = 2.0 * (q23 + q01); m[8] = q00 - q11 - q22 + q33;
+}
+static void quat_integrate(double* q, const double* v, double dt) { /* math.py:189 */
+  double vv[3] = {v[0], v[1], v[2]};
+  double norm = v3normalize(vv);
+  double qr[4], qn[4] = {q[0], q[1], q[2], q[3]}, out[4];
+  axis_angle_to_quat(qr, vv, dt * norm);
+  quat_normalize(qn);
+  mul_quat(out, qn, qr);
+  quat_normalize(out);
+  memcpy(q, out, sizeof(out));
+}
+static void quat_sub(double* res, const double* qa, const double* qb) { /* math.py:176 + quat_to_vel:161 */
+  double qneg[4] = {qb[0], -qb[1], -qb[2], -qb[3]}, qdif[4];
+  mul_quat(qdif, qneg, qa);
+  double axis[3] = {qdif[1], qdif[2], qdif[3]};
+  double s = v3len(axis);
+  if (s == 0.0) { v3set(res, 0, 0, 0); return; }
+  double speed = 2.0 * atan2(s, qdif[0]);
+  if (speed > M_PI) speed -= 2.0 * M_PI;
+  for (int i = 0; i < 3; i++) res[i] = axis[i] * speed / s;
+}
+static void mat_mul_vec(double* r, const double* m, const double* v) {
+  double x = m[0] * v[0] + m[1] * v[1] + m[2] * v[2];
+  double y = m[3] * v[0] + m[4] * v[1] + m[5] * v[2];
+  double z = m[6] * v[0] + m[7] * v[1] + m[8] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+static void matT_mul_vec(double* r, const double* m, const double* v) {
+  double x = m[0] * v[0] + m[3] * v[1] + m[6] * v[2];
+  double y = m[1] * v[0] + m[4] * v[1] + m[7] * v[2];
+  double z = m[2] * v[0] + m[5] * v[1] + m[8] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+static void inert_vec(double* r, const double* i, const double* v) { /* math.py:121 */
+  r[0] = i[0] * v[0] + i[3] * v[1] + i[4] * v[2] - i[8] * v[4] + i[7] * v[5];
+  r[1] = i[3] * v[0] + i[1] * v[1] + i[5] * v[2] + i[8] * v[3] - i[6] * v[5];
+  r[2] = i[4] * v[0] + i[5] * v[1] + i[2] * v[2] - i[7] * v[3] + i[6] * v[4];
+  r[3] = i[8] * v[1] - i[7] * v[2] + i[9] * v[3];
+  r[4] = i[6] * v[2] - i[8] * v[0] + i[9] * v[4];
+  r[5] = i[7] * v[0] - i[6] * v[1] + i[9] * v[5];
+}
+static void motion_cross(double* r, const double* u, const double* v) { /* math.py:134 */
+  double a[3], b[3], c[3];
+  v3cross(a, u, v);
+  v3cross(b, u + 3, v);
+  v3cross(c, u, v + 3);
+  r[0] = a[0]; r[1] = a[1]; r[2] = a[2];
+  r[3] = b[0] + c[0]; r[4] = b[1] + c[1]; r[5] = b[2] + c[2];
+}
+static void motion_cross_force(double* r, const double* v, const double* f) { /* math.py:148 */
+  double a[3], b[3], c[3];
+  v3cross(a, v, f);
+  v3cross(b, v + 3, f + 3);
+  v3cross(c, v, f + 3);
+  r[0] = a[0] + b[0]; r[1] = a[1] + b[1]; r[2] = a[2] + b[2];
+  r[3] = c[0]; r[4] = c[1]; r[5] = c[2];
+}
+static void orthogonals(const double* a, double* b, double* c) { /* math.py:203 */
+  double y[3] = {0, 1, 0}, z[3] = {0, 0, 1};
+  const double* s = (-0.5 < a[1] && a[1] < 0.5) ? y : z;
+  double d = v3dot(a, s);
+  for (int i = 0; i < 3; i++) b[i] = s[i] - a[i] * d;
+  v3normalize(b);
+  if (v3len(a) == 0.0) v3set(b, 0, 0, 0);
+  v3cross(c, a, b);
+}
+static void make_frame(double* frame, const double* a_in) { /* math.py:247 */
+  double a[3] = {a_in[0], a_in[1], a_in[2]}, b[3], c[3];
+  v3normalize(a);
+  orthogonals(a, b, c);
+  v3cpy(frame, a); v3cpy(frame + 3, b); v3cpy(frame + 6, c);
+}
+
+/* ---------------------------------------------------------------- smooth.py:46-145, 148-200 */
+void ref_kinematics(const RefModel* m, RefData* d) {
+  v3set(d->xpos, 0, 0, 0);
+  d->xquat[0] = 1; d->xquat[1] = d->xquat[2] = d->xquat[3] = 0;
+  for (int b = 1; b < m->nbody; b++) {
+    int pid = m->body_parentid[b], jntadr = m->body_jntadr[b], jntnum = m->body_jntnum[b];
+    double* xpos = d->xpos + 3 * b;
+    double* xquat = d->xquat + 4 * b;
+    if (jntnum == 1 && m->jnt_type[jntadr] == JNT_FREE) {
+      int qa = m->jnt_qposadr[jntadr];
+      v3cpy(xpos, d->qpos + qa);
+      memcpy(xquat, d->qpos + qa + 3, 4 * sizeof(double));
+      quat_normalize(xquat);
+      v3cpy(d->xanchor + 3 * jntadr, xpos);
+      v3cpy(d->xaxis + 3 * jntadr, m->jnt_axis + 3 * jntadr);
+      continue;
+    }
+    double pos[3], quat[4];
+    rot_vec_quat(pos, m->body_pos + 3 * b, d->xquat + 4 * pid);
+    v3add(pos, pos, d->xpos + 3 * pid);
+    mul_quat(quat, d->xquat + 4 * pid, m->body_quat + 4 * b);
+    for (int j = jntadr; j < jntadr + jntnum; j++) {
+      int qa = m->jnt_qposadr[j], t = m->jnt_type[j];
+      double anchor[3], axis[3], tmp[3];
+      rot_vec_quat(anchor, m->jnt_pos + 3 * j, quat);
+      v3add(anchor, anchor, pos);
+      rot_vec_quat(axis, m->jnt_axis + 3 * j, quat);
+      if (t == JNT_BALL) {
+        double qloc[4] = {d->qpos[qa], d->qpos[qa + 1], d->qpos[qa + 2], d->qpos[qa + 3]}, q2[4];
+        quat_normalize(qloc);
+        mul_quat(q2, quat, qloc);
+        memcpy(quat, q2, sizeof(q2));
+        rot_vec_quat(tmp, m->jnt_pos + 3 * j, quat);
+        v3sub(pos, anchor, tmp);
+      } else if (t == JNT_SLIDE) {
+        v3addscl(pos, pos, axis, d->qpos[qa] - m->qpos0[qa]);
+      } else if (t == JNT_HINGE) {
+        double qloc[4], q2[4];
+        axis_angle_to_quat(qloc, m->jnt_axis + 3 * j, d->qpos[qa] - m->qpos0[qa]);
+        mul_quat(q2, quat, qloc);
+        memcpy(quat, q2, sizeof(q2));
+        rot_vec_quat(tmp, m->jnt_pos + 3 * j, quat);
+        v3sub(pos, anchor, tmp);
+      }
+      v3cpy(d->xanchor + 3 * j, anchor);
+      v3cpy(d->xaxis + 3 * j, axis);
+    }
+    quat_normalize(quat);
+    v3cpy(xpos, pos);
+    memcpy(xquat, quat, sizeof(quat));
+  }
+  for (int b = 0; b < m->nbody; b++) {
+    double tmp[3], q[4];
+    quat_to_mat(d->xmat + 9 * b, d->xquat + 4 * b);
+    rot_vec_quat(tmp, m->body_ipos + 3 * b, d->xquat + 4 * b);
+    v3add(d->xipos + 3 * b, d->xpos + 3 * b, tmp);
+    mul_quat(q, d->xquat + 4 * b, m->body_iquat + 4 * b);
+    quat_to_mat(d->ximat + 9 * b, q);
+  }
+  for (int g = 0; g < m->ngeom; g++) {
+    int b = m->geom_bodyid[g];
+    double tmp[3], q[4];
+    rot_vec_quat(tmp, m->geom_pos + 3 * g, d->xquat + 4 * b);
+    v3add(d->geom_xpos + 3 * g, d->xpos + 3 * b, tmp);
+    mul_quat(q, d->xquat + 4 * b, m->geom_quat + 4 * g);
+    quat_to_mat(d->geom_xmat + 9 * g, q);
+  }
+}
+
+/* ---------------------------------------------------------------- smooth.py:686-822 */
+void ref_com_pos(const RefModel* m, RefData* d) {
+  int nb = m->nbody;
+  for (int b = 0; b < nb; b++)
+    for (int k = 0; k < 3; k++) d->subtree_com[3 * b + k] = d->xipos[3 * b + k] * m->body_mass[b];
+  for (int b = nb - 1; b > 0; b--) {
+    int p = m->body_parentid[b];
+    for (int k = 0; k < 3; k++) d->subtree_com[3 * p + k] += d->subtree_com[3 * b + k];
+  }
+  for (int b = 0; b < nb; b++) {
+    double mass = m->body_subtreemass[b];
+    if (mass != 0.0)
+      for (int k = 0; k < 3; k++) d->subtree_com[3 * b + k] /= mass;
+  }
+  for (int b = 0; b < nb; b++) { /* _cinert smooth.py:733 */
+    const double* mat = d->ximat + 9 * b;
+    const double* inert = m->body_inertia + 3 * b;
+    double mass = m->body_mass[b], dif[3], tmp[9];
+    v3sub(dif, d->xipos + 3 * b, d->subtree_com + 3 * m->body_rootid[b]);
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++)
+        tmp[3 * i + j] = mat[3 * i] * inert[0] * mat[3 * j] + mat[3 * i + 1] * inert[1] * mat[3 * j + 1] + mat[3 * i + 2] * inert[2] * mat[3 * j + 2];
+    double* r = d->cinert + 10 * b;
+    r[0] = tmp[0] + mass * (dif[1] * dif[1] + dif[2] * dif[2]);
+    r[1] = tmp[4] + mass * (dif[0] * dif[0] + dif[2] * dif[2]);
+    r[2] = tmp[8] + mass * (dif[0] * dif[0] + dif[1] * dif[1]);
+    r[3] = tmp[1] - mass * dif[0] * dif[1];
+    r[4] = tmp[2] - mass * dif[0] * dif[2];
+    r[5] = tmp[5] - mass * dif[1] * dif[2];
+    r[6] = mass * dif[0]; r[7] = mass * dif[1]; r[8] = mass * dif[2];
+    r[9] = mass;
+  }
+  for (int j = 0; j < m->njnt; j++) { /* _cdof smooth.py:779 */
+    int b = m->jnt_bodyid[j], dof = m->jnt_dofadr[j], t = m->jnt_type[j];
+    const double* xmat = d->xmat + 9 * b;
+    double off[3], c[3];
+    v3sub(off, d->subtree_com + 3 * m->body_rootid[b], d->xanchor + 3 * j);
+    if (t == JNT_FREE || t == JNT_BALL) {
+      if (t == JNT_FREE) {
+        for (int k = 0; k < 3; k++) {
+          memset(d->cdof + 6 * (dof + k), 0, 6 * sizeof(double));
+          d->cdof[6 * (dof + k) + 3 + k] = 1.0;
+        }
+        dof += 3;
+      }
+      for (int k = 0; k < 3; k++) {
+        double ax[3] = {xmat[k], xmat[3 + k], xmat[6 + k]};
+        v3cross(c, ax, off);
+        v3cpy(d->cdof + 6 * (dof + k), ax);
+        v3cpy(d->cdof + 6 * (dof + k) + 3, c);
+      }
+    } else if (t == JNT_SLIDE) {
+      v3set(d->cdof + 6 * dof, 0, 0, 0);
+      v3cpy(d->cdof + 6 * dof + 3, d->xaxis + 3 * j);
+    } else {
+      v3cross(c, d->xaxis + 3 * j, off);
+      v3cpy(d->cdof + 6 * dof, d->xaxis + 3 * j);
+      v3cpy(d->cdof + 6 * dof + 3, c);
+    }
+  }
+}
+
+/* ---------------------------------------------------------------- smooth.py:1029-1098 */
+void ref_crb(const RefModel* m, RefData* d) {
+  memcpy(d->crb, d->cinert, sizeof(double) * 10 * m->nbody);
+  for (int b = m->nbody - 1; b > 0; b--) {
+    int p = m->body_parentid[b];
+    if (p == 0) continue;
+    for (int k = 0; k < 10; k++) d->crb[10 * p + k] += d->crb[10 * b + k];
+  }
+  memset(d->M, 0, sizeof(double) * m->nC);
+  for (int i = 0; i < m->nv; i++) {
+    int adr = m->M_rowadr[i] + m->M_rownnz[i] - 1;
+    double buf[6];
+    d->M[adr] = m->dof_armature[i];
+    inert_vec(buf, d->crb + 10 * m->dof_bodyid[i], d->cdof + 6 * i);
+    int j = i;
+    while (j >= 0) {
+      double s = 0;
+      for (int k = 0; k < 6; k++) s += d->cdof[6 * j + k] * buf[k];
+      d->M[adr] += s;
+      adr--;
+      j = m->dof_parentid[j];
+    }
+  }
+}
+
+/* sparse L'DL: smooth.py:1183-1232 (_qLD_acc, _qLDiag_div), same recursion as MuJoCo's mj_factorI */
+static void factor_sparse(const RefModel* m, const double* M, double* L, double* Dinv) {
+  memcpy(L, M, sizeof(double) * m->nC);
+  for (int k = m->nv - 1; k >= 0; k--) {
+    int start = m->M_rowadr[k], diag = start + m->M_rownnz[k] - 1;
+    for (int adr = diag - 1; adr >= start; adr--) {
+      int i = m->M_colind[adr];
+      double tmp = L[adr] / L[diag];
+      int ai = m->M_rowadr[i];
+      for (int j = 0; j < m->M_rownnz[i]; j++) L[ai + j] -= L[start + j] * tmp;
+      L[adr] = tmp;
+    }
+    Dinv[k] = 1.0 / L[diag];
+  }
+}
+static void solve_sparse(const RefModel* m, const double* L, const double* Dinv, double* x, const double* y) {
+  int nv = m->nv;
+  if (x != y) memcpy(x, y, sizeof(double) * nv);
+  for (int k = nv - 1; k >= 0; k--) { /* x <- L^-T x */
+    int start = m->M_rowadr[k], diag = start + m->M_rownnz[k] - 1;
+    for (int adr = start; adr < diag; adr++) x[m->M_colind[adr]] -= L[adr] * x[k];
+  }
+  for (int k = 0; k < nv; k++) x[k] *= Dinv[k];
+  for (int k = 0; k < nv; k++) { /* x <- L^-1 x */
+    int start = m->M_rowadr[k], diag = start + m->M_rownnz[k] - 1;
+    for (int adr = start; adr < diag; adr++) x[k] -= L[adr] * x[m->M_colind[adr]];
+  }
+}
+void ref_factor_m(const RefModel* m, RefData* d) { factor_sparse(m, d->M, d->qLD, d->qLDiagInv); }
+void ref_solve_m(const RefModel* m, const RefData* d, double* x, const double* y) { solve_sparse(m, d->qLD, d->qLDiagInv, x, y); }
+void ref_mul_m(const RefModel* m, const RefData* d, double* res, const double* vec) { /* support.py:154 */
+  for (int i = 0; i < m->nv; i++) res[i] = 0;
+  for (int i = 0; i < m->nv; i++) {
+    int start = m->M_rowadr[i], diag = start + m->M_rownnz[i] - 1;
+    res[i] += d->M[diag] * vec[i];
+    for (int adr = start; adr < diag; adr++) {
+      int j = m->M_colind[adr];
+      res[i] += d->M[adr] * vec[j];
+      res[j] += d->M[adr] * vec[i];
+    }
+  }
+}
+
+/* ---------------------------------------------------------------- smooth.py:2179-2258 */
+void ref_com_vel(const RefModel* m, RefData* d) {
+  memset(d->cvel, 0, 6 * sizeof(double));
+  for (int b = 1; b < m->nbody; b++) {
+    double cvel[6];
+    memcpy(cvel, d->cvel + 6 * m->body_parentid[b], sizeof(cvel));
+    int dof = m->body_dofadr[b];
+    for (int j = m->body_jntadr[b]; j < m->body_jntadr[b] + m->body_jntnum[b]; j++) {
+      int t = m->jnt_type[j];
+      if (t == JNT_FREE) {
+        for (int k = 0; k < 3; k++) {
+          for (int c = 0; c < 6; c++) cvel[c] += d->cdof[6 * (dof + k) + c] * d->qvel[dof + k];
+          memset(d->cdof_dot + 6 * (dof + k), 0, 6 * sizeof(double));
+        }
+        for (int k = 3; k < 6; k++) motion_cross(d->cdof_dot + 6 * (dof + k), cvel, d->cdof + 6 * (dof + k));
+        for (int k = 3; k < 6; k++)
+          for (int c = 0; c < 6; c++) cvel[c] += d->cdof[6 * (dof + k) + c] * d->qvel[dof + k];
+        dof += 6;
+      } else if (t == JNT_BALL) {
+        for (int k = 0; k < 3; k++) motion_cross(d->cdof_dot + 6 * (dof + k), cvel, d->cdof + 6 * (dof + k));
+        for (int k = 0; k < 3; k++)
+          for (int c = 0; c < 6; c++) cvel[c] += d->cdof[6 * (dof + k) + c] * d->qvel[dof + k];
+        dof += 3;
+      } else {
+        motion_cross(d->cdof_dot + 6 * dof, cvel, d->cdof + 6 * dof);
+        for (int c = 0; c < 6; c++) cvel[c] += d->cdof[6 * dof + c] * d->qvel[dof];
+        dof += 1;
+      }
+    }
+    memcpy(d->cvel + 6 * b, cvel, sizeof(cvel));
+  }
+}
+
+/* ---------------------------------------------------------------- passive.py:74-210, 275-306, 631-668 */
+void ref_passive(const RefModel* m, RefData* d) {
+  int nv = m->nv;
+  for (int i = 0; i < nv; i++) d->qfrc_spring[i] = d->qfrc_damper[i] = d->qfrc_gravcomp[i] = 0.0;
+  int spring = !(m->disableflags & DSBL_SPRING), damper = !(m->disableflags & DSBL_DAMPER);
+  for (int j = 0; j < m->njnt; j++) {
+    int dof = m->jnt_dofadr[j], qa = m->jnt_qposadr[j], t = m->jnt_type[j];
+    double k = m->jnt_stiffness[j];
+    if (spring && k != 0.0) {
+      if (t == JNT_FREE) {
+        for (int c = 0; c < 3; c++) d->qfrc_spring[dof + c] = -k * (d->qpos[qa + c] - m->qpos_spring[qa + c]);
+        double rot[4] = {d->qpos[qa + 3], d->qpos[qa + 4], d->qpos[qa + 5], d->qpos[qa + 6]}, dif[3];
+        quat_normalize(rot);
+        quat_sub(dif, rot, m->qpos_spring + qa + 3);
+        for (int c = 0; c < 3; c++) d->qfrc_spring[dof + 3 + c] = -k * dif[c];
+      } else if (t == JNT_BALL) {
+        double rot[4] = {d->qpos[qa], d->qpos[qa + 1], d->qpos[qa + 2], d->qpos[qa + 3]}, dif[3];
+        quat_normalize(rot);
+        quat_sub(dif, rot, m->qpos_spring + qa);
+        for (int c = 0; c < 3; c++) d->qfrc_spring[dof + c] = -k * dif[c];
+      } else {
+        d->qfrc_spring[dof] = -k * (d->qpos[qa] - m->qpos_spring[qa]);
+      }
+    }
+  }
+  if (damper)
+    for (int i = 0; i < nv; i++) d->qfrc_damper[i] = -m->dof_damping[i] * d->qvel[i];
+  /* gravity compensation passive.py:275-306 */
+  if (!(m->disableflags & DSBL_GRAVITY)) {
+    for (int b = 1; b < m->nbody; b++) {
+      double gc = m->body_gravcomp[b];
+      if (gc == 0.0) continue;
+      double force[3];
+      for (int c = 0; c < 3; c++) force[c] = -m->gravity[c] * m->body_mass[b] * gc;
+      /* apply at xipos: J^T force */
+      int bb = b;
+      while (bb > 0 && m->body_dofnum[bb] == 0) bb = m->body_parentid[bb];
+      if (bb == 0) continue;
+      double off[3];
+      v3sub(off, d->xipos + 3 * b, d->subtree_com + 3 * m->body_rootid[b]);
+      int dof = m->body_dofadr[bb] + m->body_dofnum[bb] - 1;
+      while (dof >= 0) {
+        double jp[3];
+        v3cross(jp, d->cdof + 6 * dof, off);
+        v3add(jp, jp, d->cdof + 6 * dof + 3);
+        d->qfrc_gravcomp[dof] += v3dot(jp, force);
+        dof = m->dof_parentid[dof];
+      }
+    }
+  }
+  for (int i = 0; i < nv; i++) d->qfrc_passive[i] = d->qfrc_spring[i] + d->qfrc_damper[i] + d->qfrc_gravcomp[i];
+}
+
+/* ---------------------------------------------------------------- smooth.py:1353-1515 */
+void ref_rne(const RefModel* m, RefData* d) {
+  int nb = m->nbody;
+  memset(d->cacc, 0, 6 * sizeof(double));
+  if (!(m->disableflags & DSBL_GRAVITY))
+    for (int c = 0; c < 3; c++) d->cacc[3 + c] = -m->gravity[c];
+  for (int b = 1; b < nb; b++) {
+    double cacc[6];
+    memcpy(cacc, d->cacc + 6 * m->body_parentid[b], sizeof(cacc));
+    for (int k = 0; k < m->body_dofnum[b]; k++) {
+      int dof = m->body_dofadr[b] + k;
+      for (int c = 0; c < 6; c++) cacc[c] += d->cdof_dot[6 * dof + c] * d->qvel[dof];
+    }
+    memcpy(d->cacc + 6 * b, cacc, sizeof(cacc));
+  }
+  memset(d->cfrc_int, 0, 6 * sizeof(double));
+  for (int b = 1; b < nb; b++) {
+    double f1[6], iv[6], f2[6];
+    inert_vec(f1, d->cinert + 10 * b, d->cacc + 6 * b);
+    inert_vec(iv, d->cinert + 10 * b, d->cvel + 6 * b);
+    motion_cross_force(f2, d->cvel + 6 * b, iv);
+    for (int c = 0; c < 6; c++) d->cfrc_int[6 * b + c] = f1[c] + f2[c];
+  }
+  for (int b = nb - 1; b > 0; b--) {
+    int p = m->body_parentid[b];
+    for (int c = 0; c < 6; c++) d->cfrc_int[6 * p + c] += d->cfrc_int[6 * b + c];
+  }
+  for (int i = 0; i < m->nv; i++) {
+    double s = 0;
+    for (int c = 0; c < 6; c++) s += d->cdof[6 * i + c] * d->cfrc_int[6 * m->dof_bodyid[i] + c];
+    d->qfrc_bias[i] = s;
+  }
+}
+
+/* ---------------------------------------------------------------- smooth.py:2288-2400 (joint branch), forward.py:680-702 */
+void ref_transmission(const RefModel* m, RefData* d) {
+  for (int i = 0; i < m->nu; i++) {
+    int j = m->actuator_trnid[2 * i];
+    double gear = m->actuator_gear[6 * i];
+    d->actuator_length[i] = d->qpos[m->jnt_qposadr[j]] * gear; /* slide/hinge only */
+  }
+}
+
+/* forward.py:756-1050 (NONE/INTEGRATOR/FILTER/FILTEREXACT dyn; FIXED/AFFINE gain; NONE/AFFINE bias), 1097-1149 */
+void ref_fwd_actuation(const RefModel* m, RefData* d) {
+  int nv = m->nv;
+  for (int i = 0; i < nv; i++) d->qfrc_actuator[i] = 0.0;
+  if (m->disableflags & DSBL_ACTUATION) {
+    for (int i = 0; i < m->nu; i++) d->actuator_force[i] = 0.0;
+    return;
+  }
+  for (int i = 0; i < m->nu; i++) {
+    double ctrl = d->ctrl[i];
+    if (m->actuator_ctrllimited[i] && !(m->disableflags & DSBL_CLAMPCTRL))
+      ctrl = clampd(ctrl, m->actuator_ctrlrange[2 * i], m->actuator_ctrlrange[2 * i + 1]);
+    double ctrl_act = ctrl;
+    int dyn = m->actuator_dyntype[i];
+    if (dyn != 0) {
+      int adr = m->actuator_actadr[i];
+      double act = d->act[adr], act_dot = 0.0;
+      const double* prm = m->actuator_dynprm + 10 * i;
+      if (dyn == 1) act_dot = ctrl;                                   /* INTEGRATOR */
+      else if (dyn == 2 || dyn == 3) act_dot = (ctrl - act) / fmax(MINVAL, prm[0]); /* FILTER(EXACT) */
+      d->act_dot[adr] = act_dot;
+      ctrl_act = act;
+    }
+    double length = d->actuator_length[i], velocity = d->actuator_velocity[i];
+    const double* gp = m->actuator_gainprm + 10 * i;
+    const double* bp = m->actuator_biasprm + 10 * i;
+    double gain = (m->actuator_gaintype[i] == 0) ? gp[0] : gp[0] + gp[1] * length + gp[2] * velocity;
+    double bias = (m->actuator_biastype[i] == 0) ? 0.0 : bp[0] + bp[1] * length + bp[2] * velocity;
+    double force = gain * ctrl_act + bias;
+    if (m->actuator_forcelimited[i]) force = clampd(force, m->actuator_forcerange[2 * i], m->actuator_forcerange[2 * i + 1]);
+    d->actuator_force[i] = force;
+    int dof = m->jnt_dofadr[m->actuator_trnid[2 * i]];
+    d->qfrc_actuator[dof] += m->actuator_gear[6 * i] * force;
+  }
+}
+
+void ref_fwd_velocity(const RefModel* m, RefData* d) { /* forward.py:732-753 */
+  for (int i = 0; i < m->nu; i++) {
+    int dof = m->jnt_dofadr[m->actuator_trnid[2 * i]];
+    d->actuator_velocity[i] = m->actuator_gear[6 * i] * d->qvel[dof];
+  }
+  ref_com_vel(m, d);
+  ref_passive(m, d);
+  ref_rne(m, d);
+}
+
+/* forward.py:1255-1324: qfrc_smooth, xfrc (support.py:259-322), qacc_smooth = M^-1 qfrc_smooth */
+void ref_fwd_acceleration(const RefModel* m, RefData* d) {
+  for (int i = 0; i < m->nv; i++)
+    d->qfrc_smooth[i] = d->qfrc_passive[i] - d->qfrc_bias[i] + d->qfrc_actuator[i] + d->qfrc_applied[i];
+  for (int b = 1; b < m->nbody; b++) { /* xfrc_applied: (force[3], torque[3]) at xipos */
+    const double* f = d->xfrc_applied + 6 * b;
+    if (f[0] == 0 && f[1] == 0 && f[2] == 0 && f[3] == 0 && f[4] == 0 && f[5] == 0) continue;
+    int bb = b;
+    while (bb > 0 && m->body_dofnum[bb] == 0) bb = m->body_parentid[bb];
+    if (bb == 0) continue;
+    double off[3];
+    v3sub(off, d->xipos + 3 * b, d->subtree_com + 3 * m->body_rootid[b]);
+    int dof = m->body_dofadr[bb] + m->body_dofnum[bb] - 1;
+    while (dof >= 0) {
+      double jp[3];
+      v3cross(jp, d->cdof + 6 * dof, off);
+      v3add(jp, jp, d->cdof + 6 * dof + 3);
+      d->qfrc_smooth[dof] += v3dot(jp, f) + v3dot(d->cdof + 6 * dof, f + 3);
+      dof = m->dof_parentid[dof];
+    }
+  }
+  ref_factor_m(m, d);
+  ref_solve_m(m, d, d->qacc_smooth, d->qfrc_smooth);
+}
+
+/* ================================================================ collision */
+typedef struct { double dist; double pos[3]; double frame[9]; } Con;
+
+/* collision_primitive_core.py:48 */
+static void plane_sphere(const double* n, const double* ppos, const double* spos, double r, double* dist, double* pos) {
+  double dif[3];
+  v3sub(dif, spos, ppos);
+  *dist = v3dot(dif, n) - r;
+  v3addscl(pos, spos, n, -(r + 0.5 * (*dist)));
+}
+/* collision_primitive_core.py:56 */
+static void sphere_sphere(const double* p1, double r1, const double* p2, double r2, double* dist, double* pos, double* n) {
+  double dir[3];
+  v3sub(dir, p2, p1);
+  double dd = v3len(dir);
+  if (dd == 0.0) v3set(n, 1, 0, 0);
+  else { n[0] = dir[0] / dd; n[1] = dir[1] / dd; n[2] = dir[2] / dd; }
+  *dist = dd - (r1 + r2);
+  v3addscl(pos, p1, n, r1 + 0.5 * (*dist));
+}
+static void closest_segment_point(double* r, const double* a, const double* b, const double* pt) { /* math.py:270 */
+  double ab[3], pa[3];
+  v3sub(ab, b, a);
+  v3sub(pa, pt, a);
+  double t = v3dot(pa, ab) / (v3dot(ab, ab) + 1e-6);
+  v3addscl(r, a, ab, clampd(t, 0.0, 1.0));
+}
+
+static int collide_pair(const RefModel* m, const RefData* d, int g1, int g2, double margin, Con* out) {
+  int t1 = m->geom_type[g1], t2 = m->geom_type[g2];
+  const double *p1 = d->geom_xpos + 3 * g1, *p2 = d->geom_xpos + 3 * g2;
+  const double *R1 = d->geom_xmat + 9 * g1, *R2 = d->geom_xmat + 9 * g2;
+  const double *s1 = m->geom_size + 3 * g1, *s2 = m->geom_size + 3 * g2;
+  double ax1[3] = {R1[2], R1[5], R1[8]}, ax2[3] = {R2[2], R2[5], R2[8]};
+  int n = 0;
+  if (t1 == G_PLANE && t2 == G_SPHERE) { /* collision_primitive.py:281 */
+    plane_sphere(ax1, p1, p2, s2[0], &out[0].dist, out[0].pos);
+    make_frame(out[0].frame, ax1);
+    n = 1;
+  } else if (t1 == G_PLANE && t2 == G_CAPSULE) { /* core:253 */
+    double b[3], c[3], seg[3], e[3];
+    double dn = v3dot(ax1, ax2);
+    for (int i = 0; i < 3; i++) b[i] = ax2[i] - ax1[i] * dn;
+    double bn = v3len(b);
+    if (bn > 0) { b[0] /= bn; b[1] /= bn; b[2] /= bn; }
+    if (bn < 0.5) {
+      if (-0.5 < ax1[1] && ax1[1] < 0.5) v3set(b, 0, 1, 0);
+      else v3set(b, 0, 0, 1);
+    }
+    v3cross(c, ax1, b);
+    for (int i = 0; i < 3; i++) seg[i] = ax2[i] * s2[1];
+    for (int k = 0; k < 2; k++) {
+      v3addscl(e, p2, seg, k == 0 ? 1.0 : -1.0);
+      plane_sphere(ax1, p1, e, s2[0], &out[k].dist, out[k].pos);
+      v3cpy(out[k].frame, ax1); v3cpy(out[k].frame + 3, b); v3cpy(out[k].frame + 6, c);
+    }
+    n = 2;
+  } else if (t1 == G_PLANE && t2 == G_BOX) { /* core:337 */
+    double dif[3];
+    v3sub(dif, p2, p1);
+    double cd = v3dot(dif, ax1);
+    for (int i = 0; i < 8; i++) {
+      double corner[3] = {(i & 1) ? s2[0] : -s2[0], (i & 2) ? s2[1] : -s2[1], (i & 4) ? s2[2] : -s2[2]}, cw[3];
+      mat_mul_vec(cw, R2, corner);
+      double cdist = cd + v3dot(ax1, cw);
+      out[i].dist = cdist;
+      for (int k = 0; k < 3; k++) out[i].pos[k] = cw[k] + p2[k] - 0.5 * ax1[k] * cdist;
+      make_frame(out[i].frame, ax1);
+    }
+    n = 8;
+  } else if (t1 == G_PLANE && t2 == G_ELLIPSOID) { /* core:306 */
+    double loc[3], sup[3], pw[3], dif[3];
+    matT_mul_vec(loc, R2, ax1);
+    for (int k = 0; k < 3; k++) sup[k] = loc[k] * s2[k];
+    v3normalize(sup);
+    for (int k = 0; k < 3; k++) sup[k] = -sup[k] * s2[k];
+    mat_mul_vec(pw, R2, sup);
+    v3add(pw, pw, p2);
+    v3sub(dif, pw, p1);
+    double dist = v3dot(ax1, dif);
+    out[0].dist = dist;
+    v3addscl(out[0].pos, pw, ax1, -0.5 * dist);
+    make_frame(out[0].frame, ax1);
+    n = 1;
+  } else if (t1 == G_PLANE && t2 == G_CYLINDER) { /* core:460 */
+    double axis[3] = {ax2[0], ax2[1], ax2[2]}, vec[3], dif[3], vec1[3];
+    double r = s2[0], hh = s2[1];
+    double prjaxis = v3dot(ax1, axis);
+    if (prjaxis > 0) { axis[0] = -axis[0]; axis[1] = -axis[1]; axis[2] = -axis[2]; prjaxis = -prjaxis; }
+    v3sub(dif, p2, p1);
+    double dist0 = v3dot(dif, ax1);
+    for (int k = 0; k < 3; k++) vec[k] = axis[k] * prjaxis - ax1[k];
+    double len_sqr = v3dot(vec, vec);
+    if (len_sqr >= 1e-12) { double s = safe_div(r, sqrt(len_sqr)); vec[0] *= s; vec[1] *= s; vec[2] *= s; }
+    else v3set(vec, r, 0, 0);
+    double prjvec = v3dot(vec, ax1);
+    for (int k = 0; k < 3; k++) axis[k] *= hh;
+    prjaxis *= hh;
+    double d1 = dist0 + prjaxis + prjvec, d2 = dist0 - prjaxis + prjvec;
+    for (int k = 0; k < 3; k++) out[0].pos[k] = p2[k] + vec[k] + axis[k] - ax1[k] * d1 * 0.5;
+    for (int k = 0; k < 3; k++) out[1].pos[k] = p2[k] + vec[k] - axis[k] - ax1[k] * d2 * 0.5;
+    out[0].dist = d1; out[1].dist = d2;
+    double d3 = dist0 + prjaxis - 0.5 * prjvec;
+    v3cross(vec1, vec, axis);
+    v3normalize(vec1);
+    for (int k = 0; k < 3; k++) vec1[k] *= r * sqrt(3.0) * 0.5;
+    for (int k = 0; k < 3; k++) out[2].pos[k] = p2[k] + vec1[k] + axis[k] - vec[k] * 0.5 - ax1[k] * d3 * 0.5;
+    for (int k = 0; k < 3; k++) out[3].pos[k] = p2[k] - vec1[k] + axis[k] - vec[k] * 0.5 - ax1[k] * d3 * 0.5;
+    out[2].dist = out[3].dist = d3;
+    for (int i = 0; i < 4; i++) make_frame(out[i].frame, ax1);
+    n = 4;
+  } else if (t1 == G_SPHERE && t2 == G_SPHERE) {
+    double nn[3];
+    sphere_sphere(p1, s1[0], p2, s2[0], &out[0].dist, out[0].pos, nn);
+    make_frame(out[0].frame, nn);
+    n = 1;
+  } else if (t1 == G_SPHERE && t2 == G_CAPSULE) { /* core:88 */
+    double seg[3], a[3], b[3], pt[3], nn[3];
+    for (int k = 0; k < 3; k++) seg[k] = ax2[k] * s2[1];
+    v3sub(a, p2, seg);
+    v3add(b, p2, seg);
+    closest_segment_point(pt, a, b, p1);
+    sphere_sphere(p1, s1[0], pt, s2[0], &out[0].dist, out[0].pos, nn);
+    make_frame(out[0].frame, nn);
+    n = 1;
+  } else if (t1 == G_CAPSULE && t2 == G_CAPSULE) { /* core:123 */
+    double axis1[3], axis2[3], dif[3], v1[3], v2[3], nn[3];
+    for (int k = 0; k < 3; k++) { axis1[k] = ax1[k] * s1[1]; axis2[k] = ax2[k] * s2[1]; }
+    v3sub(dif, p1, p2);
+    double ma = v3dot(axis1, axis1), mb = -v3dot(axis1, axis2), mc = v3dot(axis2, axis2);
+    double u = -v3dot(axis1, dif), v = v3dot(axis2, dif);
+    double det = ma * mc - mb * mb;
+    if (fabs(det) >= MINVAL) {
+      double x1 = (mc * u - mb * v) / det, x2 = (ma * v - mb * u) / det;
+      if (x1 > 1.0) { x1 = 1.0; x2 = (v - mb) / mc; }
+      else if (x1 < -1.0) { x1 = -1.0; x2 = (v + mb) / mc; }
+      if (x2 > 1.0) { x2 = 1.0; x1 = clampd((u - mb) / ma, -1.0, 1.0); }
+      else if (x2 < -1.0) { x2 = -1.0; x1 = clampd((u + mb) / ma, -1.0, 1.0); }
+      v3addscl(v1, p1, axis1, x1);
+      v3addscl(v2, p2, axis2, x2);
+      double dist, pos[3];
+      sphere_sphere(v1, s1[0], v2, s2[0], &dist, pos, nn);
+      if (dist <= margin) { out[0].dist = dist; v3cpy(out[0].pos, pos); make_frame(out[0].frame, nn); n = 1; }
+    } else {
+      double dist, pos[3], x1, x2;
+      v3add(v1, p1, axis1);
+      x2 = clampd((v - mb) / mc, -1.0, 1.0);
+      v3addscl(v2, p2, axis2, x2);
+      sphere_sphere(v1, s1[0], v2, s2[0], &dist, pos, nn);
+      if (dist <= margin) { out[n].dist = dist; v3cpy(out[n].pos, pos); make_frame(out[n].frame, nn); n++; }
+      v3sub(v1, p1, axis1);
+      x2 = clampd((v + mb) / mc, -1.0, 1.0);
+      v3addscl(v2, p2, axis2, x2);
+      sphere_sphere(v1, s1[0], v2, s2[0], &dist, pos, nn);
+      if (dist <= margin) { out[n].dist = dist; v3cpy(out[n].pos, pos); make_frame(out[n].frame, nn); n++; }
+      if (n < 2) {
+        v3add(v2, p2, axis2);
+        x1 = clampd((u - mb) / ma, -1.0, 1.0);
+        v3addscl(v1, p1, axis1, x1);
+        sphere_sphere(v1, s1[0], v2, s2[0], &dist, pos, nn);
+        if (dist <= margin) { out[n].dist = dist; v3cpy(out[n].pos, pos); make_frame(out[n].frame, nn); n++; }
+      }
+      if (n < 2) {
+        v3sub(v2, p2, axis2);
+        x1 = clampd((u + mb) / ma, -1.0, 1.0);
+        v3addscl(v1, p1, axis1, x1);
+        sphere_sphere(v1, s1[0], v2, s2[0], &dist, pos, nn);
+        if (dist <= margin) { out[n].dist = dist; v3cpy(out[n].pos, pos); make_frame(out[n].frame, nn); n++; }
+      }
+    }
+  } else if (t1 == G_SPHERE && t2 == G_BOX) { /* core:1044 */
+    double dif[3], center[3], clamped[3], cdir[3], pos[3], nn[3];
+    v3sub(dif, p1, p2);
+    matT_mul_vec(center, R2, dif);
+    for (int k = 0; k < 3; k++) clamped[k] = fmax(-s2[k], fmin(s2[k], center[k]));
+    v3sub(cdir, clamped, center);
+    double dist = v3normalize(cdir);
+    if (dist <= MINVAL) {
+      double closest = 2.0 * (s2[0] + s2[1] + s2[2]);
+      int kk = 0;
+      for (int i = 0; i < 6; i++) {
+        double fd = fabs(((i % 2) ? 1.0 : -1.0) * s2[i / 2] - center[i / 2]);
+        if (closest > fd) { closest = fd; kk = i; }
+      }
+      double nearest[3] = {0, 0, 0};
+      nearest[kk / 2] = (kk % 2) ? -1.0 : 1.0;
+      for (int k = 0; k < 3; k++) pos[k] = center[k] + nearest[k] * (s1[0] - closest) / 2.0;
+      mat_mul_vec(nn, R2, nearest);
+      out[0].dist = -closest - s1[0];
+    } else {
+      for (int k = 0; k < 3; k++) pos[k] = 0.5 * (clamped[k] + center[k] + cdir[k] * s1[0]);
+      mat_mul_vec(nn, R2, cdir);
+      out[0].dist = dist - s1[0];
+    }
+    mat_mul_vec(out[0].pos, R2, pos);
+    v3add(out[0].pos, out[0].pos, p2);
+    make_frame(out[0].frame, nn);
+    n = 1;
+  }
+  return n;
+}
+
+/* collision_core.py:321-414 (priority/solmix mixing) + 297-318 (margin/gap) */
+static void contact_params(const RefModel* m, int g1, int g2, int* condim, double* friction, double* solref,
+                           double* solreffriction, double* solimp, double* margin, double* gap) {
+  *margin = m->geom_margin[g1] + m->geom_margin[g2];
+  *gap = m->geom_gap[g1] + m->geom_gap[g2];
+  double s1 = m->geom_solmix[g1], s2 = m->geom_solmix[g2], mix;
+  int p1 = m->geom_priority[g1], p2 = m->geom_priority[g2];
+  double f[3];
+  if (p1 > p2) { mix = 1.0; *condim = m->geom_condim[g1]; v3cpy(f, m->geom_friction + 3 * g1); }
+  else if (p2 > p1) { mix = 0.0; *condim = m->geom_condim[g2]; v3cpy(f, m->geom_friction + 3 * g2); }
+  else {
+    mix = safe_div(s1, s1 + s2);
+    if (s1 < MINVAL && s2 < MINVAL) mix = 0.5;
+    if (s1 < MINVAL && s2 >= MINVAL) mix = 0.0;
+    if (s1 >= MINVAL && s2 < MINVAL) mix = 1.0;
+    *condim = m->geom_condim[g1] > m->geom_condim[g2] ? m->geom_condim[g1] : m->geom_condim[g2];
+    for (int k = 0; k < 3; k++) f[k] = fmax(m->geom_friction[3 * g1 + k], m->geom_friction[3 * g2 + k]);
+  }
+  friction[0] = friction[1] = f[0]; friction[2] = f[1]; friction[3] = friction[4] = f[2];
+  const double *r1 = m->geom_solref + 2 * g1, *r2 = m->geom_solref + 2 * g2;
+  if (r1[0] > 0.0 && r2[0] > 0.0) { solref[0] = mix * r1[0] + (1 - mix) * r2[0]; solref[1] = mix * r1[1] + (1 - mix) * r2[1]; }
+  else { solref[0] = fmin(r1[0], r2[0]); solref[1] = fmin(r1[1], r2[1]); }
+  solreffriction[0] = solreffriction[1] = 0.0;
+  for (int k = 0; k < 5; k++) solimp[k] = mix * m->geom_solimp[5 * g1 + k] + (1 - mix) * m->geom_solimp[5 * g2 + k];
+  for (int k = 0; k < 5; k++) friction[k] = fmax(MINMU, friction[k]);
+}
+
+/* collision_driver.py:98-120 (plane, sphere filters), 684-770 (nxn), collision_core.py:214-294 (write_contact) */
+void ref_collision(const RefModel* m, RefData* d) {
+  d->ncon = 0;
+  d->ncollision = 0;
+  if (m->disableflags & (DSBL_CONSTRAINT | DSBL_CONTACT)) return;
+  for (int p = 0; p < m->npair; p++) {
+    int g1 = m->pair_geom[2 * p], g2 = m->pair_geom[2 * p + 1];
+    double rb1 = m->geom_rbound[g1], rb2 = m->geom_rbound[g2];
+    double mg = m->geom_margin[g1] + m->geom_gap[g1] + m->geom_margin[g2] + m->geom_gap[g2];
+    const double *x1 = d->geom_xpos + 3 * g1, *x2 = d->geom_xpos + 3 * g2;
+    double dif[3];
+    int pass = 1;
+    if (rb1 == 0.0 || rb2 == 0.0) {
+      if (rb1 == 0.0) {
+        const double* R = d->geom_xmat + 9 * g1;
+        double nrm[3] = {R[2], R[5], R[8]};
+        v3sub(dif, x2, x1);
+        pass = v3dot(dif, nrm) <= rb2 + mg;
+      } else {
+        const double* R = d->geom_xmat + 9 * g2;
+        double nrm[3] = {R[2], R[5], R[8]};
+        v3sub(dif, x1, x2);
+        pass = v3dot(dif, nrm) <= rb1 + mg;
+      }
+    } else {
+      double bound = rb1 + rb2 + mg;
+      v3sub(dif, x2, x1);
+      pass = v3dot(dif, dif) <= bound * bound;
+    }
+    if (!pass) continue;
+    d->ncollision++;
+    if (m->geom_type[g1] > m->geom_type[g2]) { int t = g1; g1 = g2; g2 = t; }
+    int condim;
+    double friction[5], solref[2], solreffriction[2], solimp[5], margin, gap;
+    contact_params(m, g1, g2, &condim, friction, solref, solreffriction, solimp, &margin, &gap);
+    Con out[8];
+    int n = collide_pair(m, d, g1, g2, margin, out);
+    for (int k = 0; k < n; k++) {
+      if (!(out[k].dist < margin + gap)) continue;
+      int c = d->ncon;
+      if (c >= m->nconmax) { d->overflow |= OVF_NARROW; d->ncon++; continue; }
+      d->con_dist[c] = out[k].dist;
+      v3cpy(d->con_pos + 3 * c, out[k].pos);
+      memcpy(d->con_frame + 9 * c, out[k].frame, 9 * sizeof(double));
+      d->con_includemargin[c] = margin;
+      memcpy(d->con_friction + 5 * c, friction, sizeof(friction));
+      memcpy(d->con_solref + 2 * c, solref, sizeof(solref));
+      memcpy(d->con_solreffriction + 2 * c, solreffriction, sizeof(solreffriction));
+      memcpy(d->con_solimp + 5 * c, solimp, sizeof(solimp));
+      d->con_dim[c] = condim;
+      d->con_geom[2 * c] = g1;
+      d->con_geom[2 * c + 1] = g2;
+      for (int j = 0; j < 10; j++) d->con_efc_address[10 * c + j] = -1;
+      d->ncon++;
+    }
+  }
+  if (d->ncon > m->nconmax) d->ncon = m->nconmax;
+}
+
+/* ================================================================ constraint.py */
+/* _efc_row constraint.py:84-153 */
+static void efc_row(const RefModel* m, RefData* d, int r, double pos_aref, double pos_imp, double invweight,
+                    const double* solref, const double* solimp, double margin, double vel, double frictionloss,
+                    int type, int id) {
+  double timeconst = solref[0], dampratio = solref[1];
+  double dmin = solimp[0], dmax = solimp[1], width = solimp[2], mid = solimp[3], power = solimp[4];
+  if (!(m->disableflags & DSBL_REFSAFE)) timeconst = fmax(timeconst, 2.0 * m->timestep);
+  dmin = clampd(dmin, MINIMP, MAXIMP);
+  dmax = clampd(dmax, MINIMP, MAXIMP);
+  width = fmax(MINVAL, width);
+  mid = clampd(mid, MINIMP, MAXIMP);
+  power = fmax(1.0, power);
+  double dmax_sq = dmax * dmax;
+  double k = 1.0 / (dmax_sq * timeconst * timeconst * dampratio * dampratio);
+  double b = 2.0 / (dmax * timeconst);
+  if (solref[0] <= 0) k = -solref[0] / dmax_sq;
+  if (solref[1] <= 0) b = -solref[1] / dmax;
+  double imp_x = fabs(pos_imp) / width;
+  double imp_a = (1.0 / pow(mid, power - 1.0)) * pow(imp_x, power);
+  double imp_b = 1.0 - (1.0 / pow(1.0 - mid, power - 1.0)) * pow(1.0 - imp_x, power);
+  double imp_y = imp_x < mid ? imp_a : imp_b;
+  double imp = dmin + imp_y * (dmax - dmin);
+  imp = clampd(imp, dmin, dmax);
+  if (imp_x > 1.0) imp = dmax;
+  d->efc_D[r] = 1.0 / fmax(invweight * (1.0 - imp) / imp, MINVAL);
+  d->efc_vel[r] = vel;
+  d->efc_aref[r] = -k * imp * pos_aref - b * vel;
+  d->efc_pos[r] = pos_aref + margin;
+  d->efc_margin[r] = margin;
+  d->efc_frictionloss[r] = frictionloss;
+  d->efc_type[r] = type;
+  d->efc_id[r] = id;
+}
+
+void ref_make_constraint(const RefModel* m, RefData* d) {
+  int nv = m->nv, njmax = m->njmax;
+  d->ne = d->nf = d->nl = d->nefc = 0;
+  if (m->disableflags & DSBL_CONSTRAINT) return;
+  int nefc = 0;
+  /* dof friction: constraint.py:1766-1865 */
+  if (!(m->disableflags & DSBL_FRICTIONLOSS)) {
+    for (int i = 0; i < nv; i++) {
+      if (m->dof_frictionloss[i] <= 0.0) continue;
+      d->nf++;
+      int r = nefc++;
+      if (r >= njmax) continue;
+      memset(d->efc_J + (size_t)r * nv, 0, sizeof(double) * nv);
+      d->efc_J[(size_t)r * nv + i] = 1.0;
+      efc_row(m, d, r, 0.0, 0.0, m->dof_invweight0[i], m->dof_solref + 2 * i, m->dof_solimp + 5 * i, 0.0, d->qvel[i],
+              m->dof_frictionloss[i], CT_FRICTION_DOF, i);
+    }
+  }
+  /* joint limits: constraint.py:1991-2105 (slide/hinge), 2107-2240 (ball) */
+  if (!(m->disableflags & DSBL_LIMIT)) {
+    for (int j = 0; j < m->njnt; j++) {
+      if (!m->jnt_limited[j]) continue;
+      int t = m->jnt_type[j], dof = m->jnt_dofadr[j], qa = m->jnt_qposadr[j];
+      double margin = m->jnt_margin[j];
+      if (t == JNT_SLIDE || t == JNT_HINGE) {
+        double q = d->qpos[qa];
+        double dmin = q - m->jnt_range[2 * j], dmax = m->jnt_range[2 * j + 1] - q;
+        double pos = fmin(dmin, dmax) - margin;
+        if (!(pos < 0)) continue;
+        d->nl++;
+        int r = nefc++;
+        if (r >= njmax) continue;
+        double J = (dmin < dmax) ? 1.0 : -1.0;
+        memset(d->efc_J + (size_t)r * nv, 0, sizeof(double) * nv);
+        d->efc_J[(size_t)r * nv + dof] = J;
+        efc_row(m, d, r, pos, pos, m->dof_invweight0[dof], m->jnt_solref + 2 * j, m->jnt_solimp + 5 * j, margin,
+                J * d->qvel[dof], 0.0, CT_LIMIT_JOINT, j);
+      } else if (t == JNT_BALL) {
+        double q[4] = {d->qpos[qa], d->qpos[qa + 1], d->qpos[qa + 2], d->qpos[qa + 3]}, aa[3];
+        quat_normalize(q);
+        double unit[4] = {1, 0, 0, 0};
+        quat_sub(aa, q, unit); /* quat_to_vel(q) */
+        double angle = v3normalize(aa);
+        double pos = fmax(m->jnt_range[2 * j], m->jnt_range[2 * j + 1]) - angle - margin;
+        if (!(pos < 0)) continue;
+        d->nl++;
+        int r = nefc++;
+        if (r >= njmax) continue;
+        memset(d->efc_J + (size_t)r * nv, 0, sizeof(double) * nv);
+        double vel = 0;
+        for (int k = 0; k < 3; k++) { d->efc_J[(size_t)r * nv + dof + k] = -aa[k]; vel -= aa[k] * d->qvel[dof + k]; }
+        efc_row(m, d, r, pos, pos, m->dof_invweight0[dof], m->jnt_solref + 2 * j, m->jnt_solimp + 5 * j, margin, vel, 0.0,
+                CT_LIMIT_JOINT, j);
+      }
+    }
+  }
+  /* contacts (pyramidal / frictionless): constraint.py:2641-2757, 3751-3879, 4197-4343 */
+  if (!(m->disableflags & DSBL_CONTACT)) {
+    double* jacp = (double*)malloc(sizeof(double) * 6 * nv);
+    double* jacr = jacp + 3 * nv;
+    for (int c = 0; c < d->ncon; c++) {
+      double includemargin = d->con_includemargin[c];
+      double pos = d->con_dist[c] - includemargin;
+      if (!(pos < 0.0)) continue;
+      int condim = d->con_dim[c];
+      int ndim = condim == 1 ? 1 : 2 * (condim - 1);
+      int base = nefc;
+      nefc += ndim;
+      int g1 = d->con_geom[2 * c], g2 = d->con_geom[2 * c + 1];
+      int b1 = m->geom_bodyid[g1], b2 = m->geom_bodyid[g2];
+      /* jac difference: support.py:488-533 */
+      memset(jacp, 0, sizeof(double) * 6 * nv);
+      for (int side = 0; side < 2; side++) {
+        int b = side ? b2 : b1;
+        double sgn = side ? 1.0 : -1.0;
+        int bb = b;
+        while (bb > 0 && m->body_dofnum[bb] == 0) bb = m->body_parentid[bb];
+        if (bb == 0) continue;
+        double off[3];
+        v3sub(off, d->con_pos + 3 * c, d->subtree_com + 3 * m->body_rootid[b]);
+        int dof = m->body_dofadr[bb] + m->body_dofnum[bb] - 1;
+        while (dof >= 0) {
+          double jp[3];
+          v3cross(jp, d->cdof + 6 * dof, off);
+          v3add(jp, jp, d->cdof + 6 * dof + 3);
+          for (int k = 0; k < 3; k++) {
+            jacp[k * nv + dof] += sgn * jp[k];
+            jacr[k * nv + dof] += sgn * d->cdof[6 * dof + k];
+          }
+          dof = m->dof_parentid[dof];
+        }
+      }
+      const double* frame = d->con_frame + 9 * c;
+      const double* fri = d->con_friction + 5 * c;
+      double invweight = m->body_invweight0[2 * b1] + m->body_invweight0[2 * b2];
+      if (condim > 1) {
+        double fri0 = fri[0];
+        invweight = invweight + fri0 * fri0 * invweight;
+        invweight = invweight * 2.0 * fri0 * fri0 / m->impratio;
+      }
+      for (int dimid = 0; dimid < ndim; dimid++) {
+        int r = base + dimid;
+        if (r >= njmax) { d->con_efc_address[10 * c + dimid] = -1; continue; }
+        d->con_efc_address[10 * c + dimid] = r;
+        double* J = d->efc_J + (size_t)r * nv;
+        double vel = 0;
+        for (int i = 0; i < nv; i++) {
+          double j0 = frame[0] * jacp[i] + frame[1] * jacp[nv + i] + frame[2] * jacp[2 * nv + i];
+          double val = j0;
+          if (condim > 1) {
+            int dimid2 = dimid / 2 + 1;
+            double frii = fri[dimid2 - 1] * (1.0 - 2.0 * (double)(dimid & 1));
+            double ji;
+            if (dimid2 < 3) {
+              const double* fr = frame + 3 * dimid2;
+              ji = fr[0] * jacp[i] + fr[1] * jacp[nv + i] + fr[2] * jacp[2 * nv + i];
+            } else {
+              const double* fr = frame + 3 * (dimid2 - 3);
+              ji = fr[0] * jacr[i] + fr[1] * jacr[nv + i] + fr[2] * jacr[2 * nv + i];
+            }
+            val += ji * frii;
+          }
+          J[i] = val;
+          vel += val * d->qvel[i];
+        }
+        efc_row(m, d, r, pos, pos, invweight, d->con_solref + 2 * c, d->con_solimp + 5 * c, includemargin, vel, 0.0,
+                condim == 1 ? CT_CONTACT_FRICTIONLESS : CT_CONTACT_PYRAMIDAL, c);
+      }
+    }
+    free(jacp);
+  }
+  d->nefc = nefc;
+  if (nefc > njmax) d->overflow |= OVF_NEFC;
+}
+
+/* ================================================================ solver.py */
+typedef struct {
+  int nv, nefc;
+  double *Jaref, *jv, *search, *mv, *grad, *Mgrad, *prev_grad, *prev_Mgrad, *H;
+} Ctx;
+
+/* _update_constraint_efc solver.py:1698-1822 + _eval_constraint 424-517 (pyramidal), qfrc_constraint 1912-1947 */
+static void update_constraint(const RefModel* m, RefData* d, Ctx* c) {
+  int nv = c->nv, nefc = c->nefc, ne = d->ne, nf = d->nf;
+  for (int r = 0; r < nefc; r++) {
+    double jaref = c->Jaref[r], D = d->efc_D[r];
+    if (r < ne) { d->efc_force[r] = -D * jaref; d->efc_state[r] = ST_QUADRATIC; }
+    else if (r < ne + nf) {
+      double f = d->efc_frictionloss[r], rf = safe_div(f, D);
+      if (jaref <= -rf) { d->efc_force[r] = f; d->efc_state[r] = ST_LINEARNEG; }
+      else if (jaref >= rf) { d->efc_force[r] = -f; d->efc_state[r] = ST_LINEARPOS; }
+      else { d->efc_force[r] = -D * jaref; d->efc_state[r] = ST_QUADRATIC; }
+    } else {
+      if (jaref >= 0.0) { d->efc_force[r] = 0.0; d->efc_state[r] = ST_SATISFIED; }
+      else { d->efc_force[r] = -D * jaref; d->efc_state[r] = ST_QUADRATIC; }
+    }
+  }
+  for (int i = 0; i < nv; i++) {
+    double s = 0;
+    for (int r = 0; r < nefc; r++) s += d->efc_J[(size_t)r * nv + i] * d->efc_force[r];
+    d->qfrc_constraint[i] = s;
+  }
+}
+
+static int chol_factor(double* A, int n) { /* lower Cholesky in place; returns rank deficiency flag */
+  for (int j = 0; j < n; j++) {
+    double s = A[j * n + j];
+    for (int k = 0; k < j; k++) s -= A[j * n + k] * A[j * n + k];
+    if (s < MINVAL) s = MINVAL;
+    double l = sqrt(s);
+    A[j * n + j] = l;
+    for (int i = j + 1; i < n; i++) {
+      double t = A[i * n + j];
+      for (int k = 0; k < j; k++) t -= A[i * n + k] * A[j * n + k];
+      A[i * n + j] = t / l;
+    }
+  }
+  return 0;
+}
+static void chol_solve(const double* L, int n, double* x, const double* b) {
+  for (int i = 0; i < n; i++) {
+    double t = b[i];
+    for (int k = 0; k < i; k++) t -= L[i * n + k] * x[k];
+    x[i] = t / L[i * n + i];
+  }
+  for (int i = n - 1; i >= 0; i--) {
+    double t = x[i];
+    for (int k = i + 1; k < n; k++) t -= L[k * n + i] * x[k];
+    x[i] = t / L[i * n + i];
+  }
+}
+
+/* _update_gradient solver.py:3061-3220; Newton H = M + J^T diag(D*active) J (2365-2440), Cholesky (2567-2603) */
+static void update_gradient(const RefModel* m, RefData* d, Ctx* c, double* grad_dot, double* search_dot, double* decrement) {
+  int nv = c->nv, nefc = c->nefc;
+  double gd = 0;
+  for (int i = 0; i < nv; i++) {
+    c->grad[i] = d->Ma[i] - d->qfrc_smooth[i] - d->qfrc_constraint[i];
+    gd += c->grad[i] * c->grad[i];
+  }
+  *grad_dot = gd;
+  if (m->solver == SOL_CG) {
+    ref_solve_m(m, d, c->Mgrad, c->grad);
+  } else {
+    double* H = c->H;
+    memset(H, 0, sizeof(double) * nv * nv);
+    for (int i = 0; i < nv; i++) {
+      int start = m->M_rowadr[i], diag = start + m->M_rownnz[i] - 1;
+      H[i * nv + i] = d->M[diag];
+      for (int adr = start; adr < diag; adr++) {
+        int j = m->M_colind[adr];
+        H[i * nv + j] = H[j * nv + i] = d->M[adr];
+      }
+    }
+    for (int r = 0; r < nefc; r++) {
+      if (d->efc_state[r] != ST_QUADRATIC) continue;
+      const double* J = d->efc_J + (size_t)r * nv;
+      double D = d->efc_D[r];
+      for (int i = 0; i < nv; i++) {
+        if (J[i] == 0.0) continue;
+        double ji = J[i] * D;
+        for (int j = 0; j <= i; j++) H[i * nv + j] += ji * J[j];
+      }
+    }
+    for (int i = 0; i < nv; i++)
+      for (int j = i + 1; j < nv; j++) H[i * nv + j] = H[j * nv + i];
+    chol_factor(H, nv);
+    chol_solve(H, nv, c->Mgrad, c->grad);
+    double sd = 0, dec = 0;
+    for (int i = 0; i < nv; i++) { sd += c->Mgrad[i] * c->Mgrad[i]; dec += c->grad[i] * c->Mgrad[i]; }
+    for (int i = 0; i < nv; i++) c->search[i] = -c->Mgrad[i];
+    *search_dot = sd;
+    *decrement = dec;
+  }
+}
+
+/* per-row (cost - cost0, grad, hess) at alpha: _compute_efc_eval_pt_pyramidal solver.py:518-556 */
+static void eval_pt(const RefData* d, const Ctx* c, double alpha, double* out) {
+  int ne = d->ne, nf = d->nf;
+  double s0 = 0, s1 = 0, s2 = 0;
+  for (int r = 0; r < c->nefc; r++) {
+    double ja = c->Jaref[r], jv = c->jv[r], D = d->efc_D[r];
+    double x = ja + alpha * jv, jvD = jv * D, hess = jv * jvD;
+    if (r >= ne + nf) {
+      double quad0 = 0.5 * D * ja * ja, cost0 = ja < 0.0 ? quad0 : 0.0;
+      if (x < 0.0) { s0 += alpha * (jvD * ja + 0.5 * alpha * hess) + (quad0 - cost0); s1 += jvD * ja + alpha * hess; s2 += hess; }
+      else s0 += -cost0;
+    } else if (r >= ne) {
+      double f = d->efc_frictionloss[r], rf = safe_div(f, D);
+      double cost0 = (-rf < ja && ja < rf) ? 0.5 * D * ja * ja : (ja <= -rf ? f * (-0.5 * rf - ja) : f * (-0.5 * rf + ja));
+      if (-rf < x && x < rf) { s0 += 0.5 * D * x * x - cost0; s1 += jvD * x; s2 += hess; }
+      else if (x <= -rf) { s0 += f * (-0.5 * rf - x) - cost0; s1 += -f * jv; }
+      else { s0 += f * (-0.5 * rf + x) - cost0; s1 += f * jv; }
+    } else {
+      s0 += alpha * (jvD * ja + 0.5 * alpha * hess); s1 += jvD * ja + alpha * hess; s2 += hess;
+    }
+  }
+  out[0] = s0; out[1] = s1; out[2] = s2;
+}
+static int in_bracket(const double* x, const double* y) { return (x[1] < y[1] && y[1] < 0.0) || (x[1] > y[1] && y[1] > 0.0); }
+
+/* _linesearch_iterative_kernel solver.py:835-1347 (pyramidal, non-incremental) */
+static double linesearch(const RefModel* m, RefData* d, Ctx* c, double search_dot, double* improvement_out) {
+  int nv = c->nv;
+  double gauss1 = 0, gauss2 = 0;
+  for (int i = 0; i < nv; i++) {
+    gauss1 += c->search[i] * (d->Ma[i] - d->qfrc_smooth[i]);
+    gauss2 += 0.5 * c->search[i] * c->mv[i];
+  }
+  double snorm = sqrt(search_dot), scale = m->meaninertia * (double)nv;
+  double gtol = fmax(m->tolerance * m->ls_tolerance * snorm * scale, 1e-6);
+  double p0s[3], p0[3], lo_in[3], tmp[3];
+  /* alpha = 0 (_compute_efc_eval_pt_alpha_zero_pyramidal 620-647): same as eval_pt(0) but with unshifted cost */
+  eval_pt(d, c, 0.0, p0s);
+  p0[0] = 0.0; p0[1] = gauss1 + p0s[1]; p0[2] = 2.0 * gauss2 + p0s[2];
+  double p0_delta[3] = {0.0, p0[1], p0[2]};
+  double lo_alpha_in = -safe_div(p0[1], p0[2]);
+  eval_pt(d, c, lo_alpha_in, tmp);
+  lo_in[0] = lo_alpha_in * lo_alpha_in * gauss2 + lo_alpha_in * gauss1 + tmp[0];
+  lo_in[1] = 2.0 * lo_alpha_in * gauss2 + gauss1 + tmp[1];
+  lo_in[2] = 2.0 * gauss2 + tmp[2];
+  double alpha = 0.0, improvement = 0.0;
+  int converged = fabs(lo_in[1]) < gtol && lo_in[0] < 0.0;
+  if (converged) { alpha = lo_alpha_in; improvement = -lo_in[0]; }
+  else {
+    int lo_less = lo_in[1] < p0[1];
+    double lo[3], hi[3], lo_alpha, hi_alpha;
+    memcpy(lo, lo_less ? lo_in : p0_delta, sizeof(lo));
+    memcpy(hi, lo_less ? p0_delta : lo_in, sizeof(hi));
+    lo_alpha = lo_less ? lo_alpha_in : 0.0;
+    hi_alpha = lo_less ? 0.0 : lo_alpha_in;
+    for (int it = 0; it < m->ls_iterations; it++) {
+      double a3[3] = {lo_alpha - safe_div(lo[1], lo[2]), hi_alpha - safe_div(hi[1], hi[2]), 0.5 * (lo_alpha + hi_alpha)};
+      double pt[3][3];
+      for (int k = 0; k < 3; k++) {
+        eval_pt(d, c, a3[k], tmp);
+        pt[k][0] = a3[k] * a3[k] * gauss2 + a3[k] * gauss1 + tmp[0];
+        pt[k][1] = 2.0 * a3[k] * gauss2 + gauss1 + tmp[1];
+        pt[k][2] = 2.0 * gauss2 + tmp[2];
+      }
+      double *lo_next = pt[0], *hi_next = pt[1], *mid = pt[2];
+      int s1 = in_bracket(lo, lo_next);
+      if (s1) { memcpy(lo, lo_next, sizeof(lo)); lo_alpha = a3[0]; }
+      int s2 = in_bracket(lo, mid);
+      if (s2) { memcpy(lo, mid, sizeof(lo)); lo_alpha = a3[2]; }
+      int s3 = in_bracket(lo, hi_next);
+      if (s3) { memcpy(lo, hi_next, sizeof(lo)); lo_alpha = a3[1]; }
+      int swap_lo = s1 || s2 || s3;
+      int h1 = in_bracket(hi, hi_next);
+      if (h1) { memcpy(hi, hi_next, sizeof(hi)); hi_alpha = a3[1]; }
+      int h2 = in_bracket(hi, mid);
+      if (h2) { memcpy(hi, mid, sizeof(hi)); hi_alpha = a3[2]; }
+      int h3 = in_bracket(hi, lo_next);
+      if (h3) { memcpy(hi, lo_next, sizeof(hi)); hi_alpha = a3[0]; }
+      int swap_hi = h1 || h2 || h3;
+      int ls_done = (!swap_lo && !swap_hi) || (lo[0] < 0.0 && lo[1] < 0.0 && lo[1] > -gtol) || (hi[0] < 0.0 && hi[1] > 0.0 && hi[1] < gtol);
+      int improved = lo[0] < 0.0 || hi[0] < 0.0;
+      int lo_better = lo[0] < hi[0];
+      if (improved) { alpha = lo_better ? lo_alpha : hi_alpha; improvement = -(lo_better ? lo[0] : hi[0]); }
+      if (ls_done) { converged = 1; break; }
+    }
+  }
+  if (!converged) d->overflow |= OVF_LS;
+  *improvement_out = improvement;
+  return alpha;
+}
+
+/* solve solver.py:3671-3743, _solver_iteration 3525-3620, init_context 3622-3668 */
+void ref_solve(const RefModel* m, RefData* d) {
+  int nv = m->nv, nefc = d->nefc < m->njmax ? d->nefc : m->njmax;
+  d->solver_niter = 0;
+  if (nefc == 0 || nv == 0 || m->njmax == 0) {
+    memcpy(d->qacc, d->qacc_smooth, sizeof(double) * nv);
+    for (int i = 0; i < nv; i++) d->qfrc_constraint[i] = 0.0;
+    ref_mul_m(m, d, d->Ma, d->qacc);
+    return;
+  }
+  Ctx c;
+  c.nv = nv; c.nefc = nefc;
+  double* buf = (double*)calloc((size_t)2 * m->njmax + 7 * nv + (size_t)nv * nv, sizeof(double));
+  c.Jaref = buf; c.jv = c.Jaref + m->njmax; c.search = c.jv + m->njmax; c.mv = c.search + nv; c.grad = c.mv + nv;
+  c.Mgrad = c.grad + nv; c.prev_grad = c.Mgrad + nv; c.prev_Mgrad = c.prev_grad + nv; c.H = c.prev_Mgrad + nv;
+  int warm = !(m->disableflags & DSBL_WARMSTART);
+  memcpy(d->qacc, warm ? d->qacc_warmstart : d->qacc_smooth, sizeof(double) * nv);
+  for (int r = 0; r < nefc; r++) {
+    double s = 0;
+    for (int i = 0; i < nv; i++) s += d->efc_J[(size_t)r * nv + i] * d->qacc[i];
+    c.Jaref[r] = s - d->efc_aref[r];
+  }
+  ref_mul_m(m, d, d->Ma, d->qacc);
+  double grad_dot = 0, search_dot = 0, decrement = 0;
+  update_constraint(m, d, &c);
+  update_gradient(m, d, &c, &grad_dot, &search_dot, &decrement);
+  if (m->solver == SOL_CG) {
+    search_dot = 0;
+    for (int i = 0; i < nv; i++) {
+      c.search[i] = -c.Mgrad[i];
+      search_dot += c.search[i] * c.search[i];
+      c.prev_grad[i] = c.grad[i];
+      c.prev_Mgrad[i] = c.Mgrad[i];
+    }
+  }
+  double scl = 1.0 / (m->meaninertia * (double)nv);
+  for (int iter = 0; iter < m->iterations; iter++) {
+    ref_mul_m(m, d, c.mv, c.search);
+    for (int r = 0; r < nefc; r++) {
+      double s = 0;
+      for (int i = 0; i < nv; i++) s += d->efc_J[(size_t)r * nv + i] * c.search[i];
+      c.jv[r] = s;
+    }
+    double improvement;
+    double alpha = linesearch(m, d, &c, search_dot, &improvement);
+    for (int i = 0; i < nv; i++) { d->qacc[i] += alpha * c.search[i]; d->Ma[i] += alpha * c.mv[i]; }
+    for (int r = 0; r < nefc; r++) c.Jaref[r] += alpha * c.jv[r];
+    update_constraint(m, d, &c);
+    update_gradient(m, d, &c, &grad_dot, &search_dot, &decrement);
+    d->solver_niter++;
+    double imp = scl * improvement, gradient = scl * sqrt(grad_dot);
+    int done;
+    if (m->solver == SOL_CG) {
+      double num = 0, den = 0;
+      for (int i = 0; i < nv; i++) { num += c.grad[i] * (c.Mgrad[i] - c.prev_Mgrad[i]); den += c.prev_grad[i] * c.prev_Mgrad[i]; }
+      double beta = fmax(0.0, num / fmax(MINVAL, den));
+      done = (imp < m->tolerance) || (gradient < m->tolerance);
+      if (!done) {
+        search_dot = 0;
+        for (int i = 0; i < nv; i++) {
+          c.search[i] = -c.Mgrad[i] + beta * c.search[i];
+          search_dot += c.search[i] * c.search[i];
+          c.prev_grad[i] = c.grad[i];
+          c.prev_Mgrad[i] = c.Mgrad[i];
+        }
+      }
+    } else {
+      double model_imp = scl * 0.5 * decrement;
+      done = (imp < m->tolerance) || (gradient < m->tolerance) || (model_imp < m->tolerance);
+    }
+    if (done) break;
+    if (d->solver_niter == m->iterations) d->overflow |= OVF_ITER;
+  }
+  free(buf);
+}
+
+/* ================================================================ forward.py */
+void ref_fwd_position(const RefModel* m, RefData* d) { /* forward.py:635-679 */
+  ref_kinematics(m, d);
+  ref_com_pos(m, d);
+  ref_crb(m, d);
+  ref_factor_m(m, d);
+  ref_collision(m, d);
+  ref_make_constraint(m, d);
+  ref_transmission(m, d);
+}
+void ref_forward(const RefModel* m, RefData* d) { /* forward.py:1341-1366 */
+  ref_fwd_position(m, d);
+  ref_fwd_velocity(m, d);
+  ref_fwd_actuation(m, d);
+  ref_fwd_acceleration(m, d);
+  ref_solve(m, d);
+}
+
+/* _advance forward.py:276-349; next_act support.py:38 */
+static void advance(const RefModel* m, RefData* d, const double* qacc) {
+  double h = m->timestep;
+  for (int i = 0; i < m->nu; i++) {
+    int dyn = m->actuator_dyntype[i];
+    if (dyn == 0) continue;
+    int adr = m->actuator_actadr[i];
+    double act = d->act[adr], act_dot = d->act_dot[adr];
+    if (dyn == 3) { /* FILTEREXACT */
+      double tau = fmax(MINVAL, m->actuator_dynprm[10 * i]);
+      act = act + act_dot * tau * (1.0 - exp(-h / tau));
+    } else act = act + act_dot * h;
+    if (m->actuator_actlimited[i]) act = clampd(act, m->actuator_actrange[2 * i], m->actuator_actrange[2 * i + 1]);
+    d->act[adr] = act;
+  }
+  for (int i = 0; i < m->nv; i++) d->qvel[i] += qacc[i] * h;
+  for (int j = 0; j < m->njnt; j++) { /* _next_position forward.py:53 */
+    int qa = m->jnt_qposadr[j], dof = m->jnt_dofadr[j], t = m->jnt_type[j];
+    if (t == JNT_FREE) {
+      for (int k = 0; k < 3; k++) d->qpos[qa + k] += h * d->qvel[dof + k];
+      quat_integrate(d->qpos + qa + 3, d->qvel + dof + 3, h);
+    } else if (t == JNT_BALL) quat_integrate(d->qpos + qa, d->qvel + dof, h);
+    else d->qpos[qa] += h * d->qvel[dof];
+  }
+  d->time += h;
+  memcpy(d->qacc_warmstart, d->qacc, sizeof(double) * m->nv);
+}
+
+void ref_euler(const RefModel* m, RefData* d) { /* forward.py:387-417 */
+  int nv = m->nv;
+  if (!(m->disableflags & (DSBL_EULERDAMP | DSBL_DAMPER))) {
+    int any = 0;
+    for (int i = 0; i < nv; i++) any |= (m->dof_damping[i] != 0.0);
+    if (any) {
+      double* Mh = (double*)malloc(sizeof(double) * (2 * m->nC + 2 * nv));
+      double *L = Mh + m->nC, *Dinv = L + m->nC, *qacc = Dinv + nv;
+      memcpy(Mh, d->M, sizeof(double) * m->nC);
+      for (int i = 0; i < nv; i++) Mh[m->M_rowadr[i] + m->M_rownnz[i] - 1] += m->timestep * m->dof_damping[i];
+      factor_sparse(m, Mh, L, Dinv);
+      solve_sparse(m, L, Dinv, qacc, d->Ma);
+      advance(m, d, qacc);
+      free(Mh);
+      return;
+    }
+  }
+  advance(m, d, d->qacc);
+}
+
+/* implicitfast forward.py:578-612 with derivative.py:1117 deriv_smooth_vel restricted to joint damping and
+   affine actuator velocity terms: (M - h*dF/dv) qacc' = M qacc */
+void ref_implicitfast(const RefModel* m, RefData* d) {
+  int nv = m->nv;
+  double* Mh = (double*)malloc(sizeof(double) * (2 * m->nC + 2 * nv));
+  double *L = Mh + m->nC, *Dinv = L + m->nC, *qacc = Dinv + nv;
+  memcpy(Mh, d->M, sizeof(double) * m->nC);
+  if (!(m->disableflags & DSBL_DAMPER))
+    for (int i = 0; i < nv; i++) Mh[m->M_rowadr[i] + m->M_rownnz[i] - 1] += m->timestep * m->dof_damping[i];
+  if (!(m->disableflags & DSBL_ACTUATION))
+    for (int i = 0; i < m->nu; i++) {
+      double bias_vel = (m->actuator_biastype[i] == 1) ? m->actuator_biasprm[10 * i + 2] : 0.0;
+      double gain_vel = (m->actuator_gaintype[i] == 1) ? m->actuator_gainprm[10 * i + 2] : 0.0;
+      double ctrl = d->ctrl[i];
+      if (m->actuator_dyntype[i] != 0) ctrl = d->act[m->actuator_actadr[i]];
+      else if (m->actuator_ctrllimited[i] && !(m->disableflags & DSBL_CLAMPCTRL))
+        ctrl = clampd(ctrl, m->actuator_ctrlrange[2 * i], m->actuator_ctrlrange[2 * i + 1]);
+      double dv = bias_vel + gain_vel * ctrl;
+      if (dv == 0.0) continue;
+      if (m->actuator_forcelimited[i]) {
+        double f = d->actuator_force[i];
+        if (f <= m->actuator_forcerange[2 * i] || f >= m->actuator_forcerange[2 * i + 1]) continue;
+      }
+      int dof = m->jnt_dofadr[m->actuator_trnid[2 * i]];
+      double g = m->actuator_gear[6 * i];
+      Mh[m->M_rowadr[dof] + m->M_rownnz[dof] - 1] -= m->timestep * g * g * dv;
+    }
+  factor_sparse(m, Mh, L, Dinv);
+  solve_sparse(m, L, Dinv, qacc, d->Ma);
+  advance(m, d, qacc);
+  free(Mh);
+}
+
+void ref_step(const RefModel* m, RefData* d) { /* forward.py:1368-1380 */
+  ref_forward(m, d);
+  if (m->integrator == INT_IMPLICITFAST) ref_implicitfast(m, d);
+  else ref_euler(m, d);
+}
+
+/* util_misc.py:61 halton (float32 arithmetic in the reference; restated in float32 here on purpose) */
+double ref_halton(int index, int base) {
+  int n0 = index;
+  float b = (float)base, f = 1.0f / b, hn = 0.0f;
+  while (n0 > 0) {
+    int n1 = n0 / base;
+    int r = n0 - n1 * base;
+    hn += f * (float)r;
+    f /= b;
+    n0 = n1;
+  }
+  return (double)hn;
+}
+
+/* cli.py:103-145 _ctrl_noise */
+void ref_ctrl_noise(const RefModel* m, RefData* d, const double* center, int step, int worldid, double noise_std, double noise_rate) {
+  double rate = exp(-m->timestep / noise_rate);
+  double scale = noise_std * sqrt(1.0 - rate * rate);
+  for (int a = 0; a < m->nu; a++) {
+    double midpoint = 0.0, halfrange = 1.0;
+    int lim = m->actuator_ctrllimited[a];
+    double lo = m->actuator_ctrlrange[2 * a], hi = m->actuator_ctrlrange[2 * a + 1];
+    if (lim) { midpoint = 0.5 * (hi + lo); halfrange = 0.5 * (hi - lo); }
+    if (center) midpoint = center[a];
+    double ctrl = rate * d->ctrl[a] + (1.0 - rate) * midpoint;
+    ctrl += scale * halfrange * (2.0 * ref_halton((step + 1) * (worldid + 1), a + 2) - 1.0);
+    if (lim) ctrl = clampd(ctrl, lo, hi);
+    d->ctrl[a] = ctrl;
+  }
+}
+
+/* nstep steps with per-step ctrl noise around centre 0 (cli.py:270-292 loop body); returns #steps with finite qpos */
+int ref_rollout(const RefModel* m, RefData* d, int nstep, int worldid, double noise_std, double noise_rate, double* qpos_out, double* qvel_out) {
+  double* center = (double*)calloc(m->nu > 0 ? m->nu : 1, sizeof(double));
+  int ok = 0;
+  for (int s = 0; s < nstep; s++) {
+    if (noise_std >= 0) ref_ctrl_noise(m, d, center, s, worldid, noise_std, noise_rate);
+    ref_step(m, d);
+    if (qpos_out) memcpy(qpos_out + (size_t)s * m->nq, d->qpos, sizeof(double) * m->nq);
+    if (qvel_out) memcpy(qvel_out + (size_t)s * m->nv, d->qvel, sizeof(double) * m->nv);
+    int fin = 1;
+    for (int i = 0; i < m->nq; i++) fin &= isfinite(d->qpos[i]);
+    ok += fin;
+  }
+  free(center);
+  return ok;
+}

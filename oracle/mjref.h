@@ -1,0 +1,218 @@
+/* oracle/mjref.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * float64, single-world, plain-C restatement of the reference's mj_step hot path
+ * (/root/reference/mujoco_warp/_src/{smooth,passive,forward,collision_*,constraint,solver}.py).
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library;
+ * the product path (mujoco_warp_amd) never does.
+ *
+ * PARITY UNPINNED: the arithmetic of record is MuJoCo C (mujoco 3.11.1.dev954833728, uv.lock:1053),
+ * which is absent from /root/reference and from this environment, and the reference holds no golden
+ * vectors for FK/CRBA/RNE/collision/solver/step.  This restatement follows the
+ * reference's own kernels line by line (citations at each function) and is pinned only by
+ * self-consistency checks in tests/ (energy, M symmetry/PD, M*(M^-1 y)=y, KKT residuals).
+ *
+ * The struct layouts below are parsed by oracle/ref.py (one declaration per line, no macros).
+ */
+#ifndef MJREF_H
+#define MJREF_H
+
+typedef struct RefModel {
+  int nq;
+  int nv;
+  int nu;
+  int na;
+  int nbody;
+  int njnt;
+  int ngeom;
+  int nC;
+  int npair;
+  int njmax;
+  int nconmax;
+  int integrator;
+  int cone;
+  int solver;
+  int iterations;
+  int ls_iterations;
+  int disableflags;
+  double timestep;
+  double tolerance;
+  double ls_tolerance;
+  double impratio;
+  double meaninertia;
+  double* gravity;
+  double* qpos0;
+  double* qpos_spring;
+  int* body_parentid;
+  int* body_rootid;
+  int* body_weldid;
+  int* body_jntnum;
+  int* body_jntadr;
+  int* body_dofnum;
+  int* body_dofadr;
+  double* body_pos;
+  double* body_quat;
+  double* body_ipos;
+  double* body_iquat;
+  double* body_mass;
+  double* body_subtreemass;
+  double* body_inertia;
+  double* body_invweight0;
+  double* body_gravcomp;
+  int* jnt_type;
+  int* jnt_qposadr;
+  int* jnt_dofadr;
+  int* jnt_bodyid;
+  int* jnt_limited;
+  double* jnt_solref;
+  double* jnt_solimp;
+  double* jnt_pos;
+  double* jnt_axis;
+  double* jnt_stiffness;
+  double* jnt_range;
+  double* jnt_margin;
+  int* dof_bodyid;
+  int* dof_jntid;
+  int* dof_parentid;
+  double* dof_solref;
+  double* dof_solimp;
+  double* dof_frictionloss;
+  double* dof_armature;
+  double* dof_damping;
+  double* dof_invweight0;
+  int* M_rownnz;
+  int* M_rowadr;
+  int* M_colind;
+  int* geom_type;
+  int* geom_condim;
+  int* geom_bodyid;
+  int* geom_priority;
+  double* geom_solmix;
+  double* geom_solref;
+  double* geom_solimp;
+  double* geom_size;
+  double* geom_rbound;
+  double* geom_pos;
+  double* geom_quat;
+  double* geom_friction;
+  double* geom_margin;
+  double* geom_gap;
+  int* pair_geom;
+  int* actuator_dyntype;
+  int* actuator_gaintype;
+  int* actuator_biastype;
+  int* actuator_trnid;
+  int* actuator_actadr;
+  int* actuator_ctrllimited;
+  int* actuator_forcelimited;
+  int* actuator_actlimited;
+  double* actuator_dynprm;
+  double* actuator_gainprm;
+  double* actuator_biasprm;
+  double* actuator_ctrlrange;
+  double* actuator_forcerange;
+  double* actuator_actrange;
+  double* actuator_gear;
+} RefModel;
+
+typedef struct RefData {
+  double time;
+  int ncon;
+  int ne;
+  int nf;
+  int nl;
+  int nefc;
+  int solver_niter;
+  int ncollision;
+  int overflow;
+  double* qpos;
+  double* qvel;
+  double* act;
+  double* ctrl;
+  double* qacc_warmstart;
+  double* qfrc_applied;
+  double* xfrc_applied;
+  double* xpos;
+  double* xquat;
+  double* xmat;
+  double* xipos;
+  double* ximat;
+  double* xanchor;
+  double* xaxis;
+  double* geom_xpos;
+  double* geom_xmat;
+  double* subtree_com;
+  double* cinert;
+  double* cdof;
+  double* crb;
+  double* M;
+  double* qLD;
+  double* qLDiagInv;
+  double* cvel;
+  double* cdof_dot;
+  double* qfrc_spring;
+  double* qfrc_damper;
+  double* qfrc_gravcomp;
+  double* qfrc_passive;
+  double* qfrc_bias;
+  double* cacc;
+  double* cfrc_int;
+  double* actuator_length;
+  double* actuator_velocity;
+  double* actuator_force;
+  double* act_dot;
+  double* qfrc_actuator;
+  double* qfrc_smooth;
+  double* qacc_smooth;
+  double* qacc;
+  double* qfrc_constraint;
+  double* Ma;
+  double* con_dist;
+  double* con_pos;
+  double* con_frame;
+  double* con_includemargin;
+  double* con_friction;
+  double* con_solref;
+  double* con_solreffriction;
+  double* con_solimp;
+  int* con_dim;
+  int* con_geom;
+  int* con_efc_address;
+  int* efc_type;
+  int* efc_id;
+  int* efc_state;
+  double* efc_J;
+  double* efc_pos;
+  double* efc_margin;
+  double* efc_D;
+  double* efc_vel;
+  double* efc_aref;
+  double* efc_frictionloss;
+  double* efc_force;
+} RefData;
+
+void ref_kinematics(const RefModel* m, RefData* d);
+void ref_com_pos(const RefModel* m, RefData* d);
+void ref_crb(const RefModel* m, RefData* d);
+void ref_factor_m(const RefModel* m, RefData* d);
+void ref_solve_m(const RefModel* m, const RefData* d, double* x, const double* y);
+void ref_mul_m(const RefModel* m, const RefData* d, double* res, const double* vec);
+void ref_collision(const RefModel* m, RefData* d);
+void ref_make_constraint(const RefModel* m, RefData* d);
+void ref_transmission(const RefModel* m, RefData* d);
+void ref_com_vel(const RefModel* m, RefData* d);
+void ref_passive(const RefModel* m, RefData* d);
+void ref_rne(const RefModel* m, RefData* d);
+void ref_fwd_position(const RefModel* m, RefData* d);
+void ref_fwd_velocity(const RefModel* m, RefData* d);
+void ref_fwd_actuation(const RefModel* m, RefData* d);
+void ref_fwd_acceleration(const RefModel* m, RefData* d);
+void ref_solve(const RefModel* m, RefData* d);
+void ref_forward(const RefModel* m, RefData* d);
+void ref_euler(const RefModel* m, RefData* d);
+void ref_implicitfast(const RefModel* m, RefData* d);
+void ref_step(const RefModel* m, RefData* d);
+void ref_ctrl_noise(const RefModel* m, RefData* d, const double* center, int step, int worldid, double noise_std, double noise_rate);
+double ref_halton(int index, int base);
+int ref_rollout(const RefModel* m, RefData* d, int nstep, int worldid, double noise_std, double noise_rate, double* qpos_out, double* qvel_out);
+
+#endif

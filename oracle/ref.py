@@ -1,0 +1,246 @@
+"""ctypes front-end of the float64 CPU oracle (oracle/mjref.c).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the
+product package `mujoco_warp_amd` never does.  PARITY UNPINNED: see oracle/mjref.h.
+"""
+
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_DIR, "libmjref.so")
+
+
+def build(force=False):
+  src = [os.path.join(_DIR, f) for f in ("mjref.c", "mjref.h")]
+  if force or not os.path.exists(_LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in src):
+    subprocess.check_call(["make", "-C", _DIR, "-B", "libmjref.so"], stdout=subprocess.DEVNULL)
+  return _LIB_PATH
+
+
+def _parse_struct(header, name):
+  body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), header, re.S).group(1)
+  fields = []
+  for line in body.splitlines():
+    line = line.strip()
+    mm = re.match(r"(int|double)(\*?)\s+(\w+);", line)
+    if mm:
+      fields.append((mm.group(3), mm.group(1), bool(mm.group(2))))
+  return fields
+
+
+_HEADER = open(os.path.join(_DIR, "mjref.h")).read()
+_MODEL_FIELDS = _parse_struct(_HEADER, "RefModel")
+_DATA_FIELDS = _parse_struct(_HEADER, "RefData")
+
+
+def _ctype(kind, ptr):
+  base = ctypes.c_int if kind == "int" else ctypes.c_double
+  return ctypes.POINTER(base) if ptr else base
+
+
+class CRefModel(ctypes.Structure):
+  _fields_ = [(n, _ctype(k, p)) for n, k, p in _MODEL_FIELDS]
+
+
+class CRefData(ctypes.Structure):
+  _fields_ = [(n, _ctype(k, p)) for n, k, p in _DATA_FIELDS]
+
+
+_lib = None
+
+
+def lib():
+  global _lib
+  if _lib is None:
+    _lib = ctypes.CDLL(build())
+    mp, dp = ctypes.POINTER(CRefModel), ctypes.POINTER(CRefData)
+    for fn in ("kinematics", "com_pos", "crb", "factor_m", "collision", "make_constraint", "transmission", "com_vel",
+               "passive", "rne", "fwd_position", "fwd_velocity", "fwd_actuation", "fwd_acceleration", "solve",
+               "forward", "euler", "implicitfast", "step"):
+      f = getattr(_lib, "ref_" + fn)
+      f.argtypes = [mp, dp]
+      f.restype = None
+    dptr = ctypes.POINTER(ctypes.c_double)
+    _lib.ref_solve_m.argtypes = [mp, dp, dptr, dptr]
+    _lib.ref_mul_m.argtypes = [mp, dp, dptr, dptr]
+    _lib.ref_ctrl_noise.argtypes = [mp, dp, dptr, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double]
+    _lib.ref_halton.argtypes = [ctypes.c_int, ctypes.c_int]
+    _lib.ref_halton.restype = ctypes.c_double
+    _lib.ref_rollout.argtypes = [mp, dp, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double, dptr, dptr]
+    _lib.ref_rollout.restype = ctypes.c_int
+  return _lib
+
+
+def filtered_geom_pairs(mjm):
+  """Pre-filtered geom pairs in upper-triangular order (reference io.py:551-577)."""
+  DSBL_FILTERPARENT = 1 << 10
+  filterparent = not (mjm.opt.disableflags & DSBL_FILTERPARENT)
+  out = []
+  excl = set(int(x) for x in np.atleast_1d(mjm.exclude_signature))
+  for g1 in range(mjm.ngeom):
+    for g2 in range(g1 + 1, mjm.ngeom):
+      b1, b2 = int(mjm.geom_bodyid[g1]), int(mjm.geom_bodyid[g2])
+      w1, w2 = int(mjm.body_weldid[b1]), int(mjm.body_weldid[b2])
+      wp1, wp2 = int(mjm.body_weldid[mjm.body_parentid[w1]]), int(mjm.body_weldid[mjm.body_parentid[w2]])
+      if w1 == w2:
+        continue
+      if filterparent and w1 != 0 and w2 != 0 and (w1 == wp2 or w2 == wp1):
+        continue
+      mask = (mjm.geom_contype[g1] & mjm.geom_conaffinity[g2]) | (mjm.geom_contype[g2] & mjm.geom_conaffinity[g1])
+      if not mask:
+        continue
+      if ((b1 << 16) + b2) in excl:
+        continue
+      out.append((g1, g2))
+  return np.array(out, dtype=np.int32).reshape(-1, 2)
+
+
+_SIZES = {
+  "qpos": "nq", "qvel": "nv", "act": "na", "ctrl": "nu", "qacc_warmstart": "nv", "qfrc_applied": "nv",
+  "xfrc_applied": ("nbody", 6), "xpos": ("nbody", 3), "xquat": ("nbody", 4), "xmat": ("nbody", 9), "xipos": ("nbody", 3),
+  "ximat": ("nbody", 9), "xanchor": ("njnt", 3), "xaxis": ("njnt", 3), "geom_xpos": ("ngeom", 3), "geom_xmat": ("ngeom", 9),
+  "subtree_com": ("nbody", 3), "cinert": ("nbody", 10), "cdof": ("nv", 6), "crb": ("nbody", 10), "M": "nC", "qLD": "nC",
+  "qLDiagInv": "nv", "cvel": ("nbody", 6), "cdof_dot": ("nv", 6), "qfrc_spring": "nv", "qfrc_damper": "nv",
+  "qfrc_gravcomp": "nv", "qfrc_passive": "nv", "qfrc_bias": "nv", "cacc": ("nbody", 6), "cfrc_int": ("nbody", 6),
+  "actuator_length": "nu", "actuator_velocity": "nu", "actuator_force": "nu", "act_dot": "na", "qfrc_actuator": "nv",
+  "qfrc_smooth": "nv", "qacc_smooth": "nv", "qacc": "nv", "qfrc_constraint": "nv", "Ma": "nv",
+  "con_dist": "nconmax", "con_pos": ("nconmax", 3), "con_frame": ("nconmax", 9), "con_includemargin": "nconmax",
+  "con_friction": ("nconmax", 5), "con_solref": ("nconmax", 2), "con_solreffriction": ("nconmax", 2),
+  "con_solimp": ("nconmax", 5), "con_dim": "nconmax", "con_geom": ("nconmax", 2), "con_efc_address": ("nconmax", 10),
+  "efc_type": "njmax", "efc_id": "njmax", "efc_state": "njmax", "efc_J": ("njmax", "nv"), "efc_pos": "njmax",
+  "efc_margin": "njmax", "efc_D": "njmax", "efc_vel": "njmax", "efc_aref": "njmax", "efc_frictionloss": "njmax",
+  "efc_force": "njmax",
+}
+
+
+class RefSim:
+  """One float64 world: model struct + data arrays (numpy-owned) for the C oracle."""
+
+  def __init__(self, mjm, nconmax=64, njmax=256, tolerance=None, solver=None, iterations=None, ls_iterations=None,
+               integrator=None):
+    self.mjm = mjm
+    self._keep = []
+    cm = CRefModel()
+    opt = mjm.opt
+    sizes = dict(nq=mjm.nq, nv=mjm.nv, nu=mjm.nu, na=mjm.na, nbody=mjm.nbody, njnt=mjm.njnt, ngeom=mjm.ngeom,
+                 nC=int(mjm.M_rownnz.sum()) if mjm.nv else 0, njmax=njmax, nconmax=nconmax)
+    pairs = filtered_geom_pairs(mjm)
+    sizes["npair"] = len(pairs)
+    scalars = dict(
+      integrator=int(opt.integrator if integrator is None else integrator), cone=int(opt.cone),
+      solver=int(opt.solver if solver is None else solver),
+      iterations=int(opt.iterations if iterations is None else iterations),
+      ls_iterations=int(opt.ls_iterations if ls_iterations is None else ls_iterations),
+      disableflags=int(opt.disableflags), timestep=float(opt.timestep),
+      tolerance=float(opt.tolerance if tolerance is None else tolerance), ls_tolerance=float(opt.ls_tolerance),
+      impratio=float(opt.impratio), meaninertia=float(mjm.stat.meaninertia))
+    if scalars["cone"] != 0:
+      raise NotImplementedError("oracle: elliptic cones")
+    special = {"gravity": np.asarray(opt.gravity, dtype=np.float64), "pair_geom": pairs,
+               "actuator_trnid": mjm.actuator_trnid, "M_colind": mjm.M_colind}
+    for name, kind, ptr in _MODEL_FIELDS:
+      if not ptr:
+        setattr(cm, name, sizes[name] if name in sizes else scalars[name])
+        continue
+      src = special[name] if name in special else getattr(mjm, name)
+      arr = np.ascontiguousarray(np.asarray(src), dtype=np.int32 if kind == "int" else np.float64)
+      if arr.size == 0:
+        arr = np.zeros(1, dtype=arr.dtype)
+      self._keep.append(arr)
+      setattr(cm, name, arr.ctypes.data_as(_ctype(kind, True)))
+    self.cm = cm
+    self.sizes = sizes
+    cd = CRefData()
+    self.arr = {}
+    for name, kind, ptr in _DATA_FIELDS:
+      if not ptr:
+        continue
+      spec = _SIZES[name]
+      if isinstance(spec, str):
+        shape = (sizes[spec],)
+      else:
+        shape = tuple(sizes[s] if isinstance(s, str) else s for s in spec)
+      a = np.zeros(max(int(np.prod(shape)), 1), dtype=np.int32 if kind == "int" else np.float64)
+      self.arr[name] = a
+      setattr(cd, name, a.ctypes.data_as(_ctype(kind, True)))
+      setattr(self, "_shape_" + name, shape)
+    self.cd = cd
+    self.lib = lib()
+    self.reset()
+
+  def reset(self, key=None):
+    m = self.mjm
+    for a in self.arr.values():
+      a[:] = 0
+    self.qpos[:] = m.qpos0 if key is None else m.key_qpos[key]
+    if key is not None:
+      self.qvel[:] = m.key_qvel[key]
+      self.ctrl[:] = m.key_ctrl[key]
+      if m.na:
+        self.act[:] = m.key_act[key]
+    self.cd.time = 0.0
+    self.cd.overflow = 0
+
+  def __getattr__(self, name):
+    arr = self.__dict__.get("arr", {})
+    if name in arr:
+      shape = self.__dict__["_shape_" + name]
+      n = int(np.prod(shape))
+      return arr[name][:n].reshape(shape)
+    if name in ("ncon", "ne", "nf", "nl", "nefc", "solver_niter", "overflow", "time", "ncollision"):
+      return getattr(self.__dict__["cd"], name)
+    raise AttributeError(name)
+
+  def _call(self, fn):
+    getattr(self.lib, "ref_" + fn)(ctypes.byref(self.cm), ctypes.byref(self.cd))
+
+  def step(self):
+    self._call("step")
+
+  def forward(self):
+    self._call("forward")
+
+  def stage(self, name):
+    self._call(name)
+
+  def solve_m(self, y):
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    x = np.zeros_like(y)
+    dp = ctypes.POINTER(ctypes.c_double)
+    self.lib.ref_solve_m(ctypes.byref(self.cm), ctypes.byref(self.cd), x.ctypes.data_as(dp), y.ctypes.data_as(dp))
+    return x
+
+  def mul_m(self, v):
+    v = np.ascontiguousarray(v, dtype=np.float64)
+    r = np.zeros_like(v)
+    dp = ctypes.POINTER(ctypes.c_double)
+    self.lib.ref_mul_m(ctypes.byref(self.cm), ctypes.byref(self.cd), r.ctypes.data_as(dp), v.ctypes.data_as(dp))
+    return r
+
+  def ctrl_noise(self, step, worldid, noise_std=0.01, noise_rate=0.1, center=None):
+    dp = ctypes.POINTER(ctypes.c_double)
+    c = np.zeros(max(self.mjm.nu, 1)) if center is None else np.ascontiguousarray(center, dtype=np.float64)
+    self.lib.ref_ctrl_noise(ctypes.byref(self.cm), ctypes.byref(self.cd), c.ctypes.data_as(dp), step, worldid, noise_std, noise_rate)
+
+  def rollout(self, nstep, worldid=0, noise_std=0.01, noise_rate=0.1, record=True):
+    dp = ctypes.POINTER(ctypes.c_double)
+    qp = np.zeros((nstep, self.mjm.nq)) if record else None
+    qv = np.zeros((nstep, self.mjm.nv)) if record else None
+    ok = self.lib.ref_rollout(ctypes.byref(self.cm), ctypes.byref(self.cd), nstep, worldid, noise_std, noise_rate,
+                              qp.ctypes.data_as(dp) if record else None, qv.ctypes.data_as(dp) if record else None)
+    return ok, qp, qv
+
+  def dense_M(self):
+    m = self.mjm
+    nv = m.nv
+    M = np.zeros((nv, nv))
+    for i in range(nv):
+      for k in range(m.M_rownnz[i]):
+        j = m.M_colind[m.M_rowadr[i] + k]
+        M[i, j] = M[j, i] = self.M[m.M_rowadr[i] + k]
+    return M
