@@ -1,0 +1,204 @@
+/* mjhip.h -- C ABI of libmjhip.so: the MI355X-native batched mj_step engine.
+ *
+ * This is the drop-in boundary for the reference's L3/L1 seam: the reference's Python
+ * functions `step/forward/kinematics/com_pos/crb/factor_m/collision/make_constraint/fwd_velocity/
+ * fwd_actuation/fwd_acceleration/solve/euler/implicit` (/root/reference/mujoco_warp/__init__.py:26-101,
+ * _src/forward.py:1341-1380) each become one extern "C" entry point taking flat pointer tables.
+ *
+ *   MjhModel  <->  reference `Model` dataclass  (_src/types.py:982-1960; only hot-path fields)
+ *   MjhData   <->  reference `Data` / `Contact` / `Constraint` (_src/types.py:1975-2374)
+ *
+ * Conventions: every array is float32/int32, row-major, world-major ([nworld, n, ...]); a Model
+ * array with a companion `<name>_nb` field may carry a leading batch dimension of size nb and is
+ * indexed `worldid % nb` (reference "*" fields, types.py:1535-1808).  All pointers are DEVICE
+ * pointers owned by the caller; entry points never allocate and never synchronise.  Return value:
+ * 0 on success, negative MJH_E_* otherwise; mjh_last_error() returns a static message.
+ * Entry points are re-entrant per (MjhModel, MjhData, stream).
+ *
+ * One declaration per statement, no macros inside the structs: mujoco_warp_amd/_abi.py parses this
+ * file to build the ctypes mirror, so the header is the single source of truth.
+ */
+#ifndef MJHIP_H
+#define MJHIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MJH_OK 0
+#define MJH_E_ARG -1
+#define MJH_E_UNSUPPORTED -2
+#define MJH_E_LAUNCH -3
+
+/* stage ids for mjh_stage() -- names follow the reference's public stage functions */
+#define MJH_STAGE_KINEMATICS 0       /* smooth.kinematics            smooth.py:447  */
+#define MJH_STAGE_COM_POS 1          /* smooth.com_pos               smooth.py:824  */
+#define MJH_STAGE_CRB 2              /* smooth.crb                   smooth.py:1079 */
+#define MJH_STAGE_FACTOR_M 3         /* smooth.factor_m              smooth.py:1340 */
+#define MJH_STAGE_COLLISION 4        /* collision_driver.collision   collision_driver.py:885 */
+#define MJH_STAGE_MAKE_CONSTRAINT 5  /* constraint.make_constraint   constraint.py:4898 */
+#define MJH_STAGE_TRANSMISSION 6     /* smooth.transmission          smooth.py:2890 */
+#define MJH_STAGE_COM_VEL 7          /* smooth.com_vel               smooth.py:2261 */
+#define MJH_STAGE_PASSIVE 8          /* passive.passive              passive.py:1257 */
+#define MJH_STAGE_RNE 9              /* smooth.rne                   smooth.py:1499 */
+#define MJH_STAGE_FWD_VELOCITY 10    /* forward.fwd_velocity         forward.py:732 */
+#define MJH_STAGE_FWD_ACTUATION 11   /* forward.fwd_actuation        forward.py:1152 */
+#define MJH_STAGE_FWD_ACCELERATION 12 /* forward.fwd_acceleration    forward.py:1290 */
+#define MJH_STAGE_SOLVE 13           /* solver.solve                 solver.py:3671 */
+#define MJH_STAGE_EULER 14           /* forward.euler                forward.py:387 */
+#define MJH_STAGE_IMPLICIT 15        /* forward.implicit (implicitfast) forward.py:578 */
+#define MJH_STAGE_FWD_POSITION 16    /* forward.fwd_position         forward.py:635 */
+#define MJH_STAGE_FORWARD 17         /* forward.forward              forward.py:1341 */
+#define MJH_STAGE_STEP 18            /* forward.step                 forward.py:1368 */
+
+typedef struct MjhModel {
+  /* sizes */
+  int nq; int nv; int nu; int na; int nbody; int njnt; int ngeom; int nsite; int nC; int npair;
+  int nbodylevel; int ndoflevel; int nv_pad;
+  /* options (types.py:836-905) */
+  int integrator; int cone; int solver; int iterations; int ls_iterations; int disableflags; int enableflags;
+  const float* opt_timestep; int opt_timestep_nb;
+  const float* opt_tolerance; int opt_tolerance_nb;
+  const float* opt_ls_tolerance; int opt_ls_tolerance_nb;
+  const float* opt_gravity; int opt_gravity_nb;
+  const float* opt_impratio_invsqrt; int opt_impratio_invsqrt_nb;
+  const float* stat_meaninertia; int stat_meaninertia_nb;
+  const float* qpos0; int qpos0_nb;
+  const float* qpos_spring; int qpos_spring_nb;
+  /* bodies */
+  const int* body_parentid; const int* body_rootid; const int* body_weldid;
+  const int* body_jntnum; const int* body_jntadr; const int* body_dofnum; const int* body_dofadr;
+  const int* body_lastdof;      /* last dof affecting the body, -1 if static                    */
+  const int* body_subtreenum;   /* bodies in the (contiguous, depth-first) subtree, incl. self  */
+  const int* body_tree;         /* body ids sorted by tree depth (io.py:495-500)                */
+  const int* body_leveladr;     /* [nbodylevel+1] offsets into body_tree                        */
+  const unsigned int* body_dofmask; /* [nbody, ceil(nv/32)] bit i set <=> dof i moves the body (io.py:536-549) */
+  const float* body_pos; int body_pos_nb;
+  const float* body_quat; int body_quat_nb;
+  const float* body_ipos; int body_ipos_nb;
+  const float* body_iquat; int body_iquat_nb;
+  const float* body_mass; int body_mass_nb;
+  const float* body_subtreemass; int body_subtreemass_nb;
+  const float* body_inertia; int body_inertia_nb;
+  const float* body_invweight0; int body_invweight0_nb;
+  const float* body_gravcomp; int body_gravcomp_nb;
+  /* joints */
+  const int* jnt_type; const int* jnt_qposadr; const int* jnt_dofadr; const int* jnt_bodyid; const int* jnt_limited;
+  const float* jnt_solref; int jnt_solref_nb;
+  const float* jnt_solimp; int jnt_solimp_nb;
+  const float* jnt_pos; int jnt_pos_nb;
+  const float* jnt_axis; int jnt_axis_nb;
+  const float* jnt_stiffness; int jnt_stiffness_nb;
+  const float* jnt_range; int jnt_range_nb;
+  const float* jnt_margin; int jnt_margin_nb;
+  /* dofs */
+  const int* dof_bodyid; const int* dof_jntid; const int* dof_parentid;
+  const int* dof_grpadr;        /* first dof of the ball/free rotational triple containing the dof, else the dof itself */
+  const int* dof_tree;          /* dof ids sorted by depth in the dof tree   */
+  const int* dof_leveladr;      /* [ndoflevel+1] offsets into dof_tree       */
+  const float* dof_solref; int dof_solref_nb;
+  const float* dof_solimp; int dof_solimp_nb;
+  const float* dof_frictionloss; int dof_frictionloss_nb;
+  const float* dof_armature; int dof_armature_nb;
+  const float* dof_damping; int dof_damping_nb;
+  const float* dof_invweight0; int dof_invweight0_nb;
+  const int* M_rownnz; const int* M_rowadr; const int* M_colind;
+  /* geoms */
+  const int* geom_type; const int* geom_condim; const int* geom_bodyid; const int* geom_priority;
+  const float* geom_solmix; int geom_solmix_nb;
+  const float* geom_solref; int geom_solref_nb;
+  const float* geom_solimp; int geom_solimp_nb;
+  const float* geom_size; int geom_size_nb;
+  const float* geom_rbound; int geom_rbound_nb;
+  const float* geom_pos; int geom_pos_nb;
+  const float* geom_quat; int geom_quat_nb;
+  const float* geom_friction; int geom_friction_nb;
+  const float* geom_margin; int geom_margin_nb;
+  const float* geom_gap; int geom_gap_nb;
+  const int* nxn_geom_pair;     /* [npair, 2] pre-filtered geom pairs, upper-triangular order (io.py:551-640) */
+  /* sites */
+  const int* site_bodyid;
+  const float* site_pos; int site_pos_nb;
+  const float* site_quat; int site_quat_nb;
+  /* actuators (joint transmission) */
+  const int* actuator_dyntype; const int* actuator_gaintype; const int* actuator_biastype; const int* actuator_trnid;
+  const int* actuator_actadr; const int* actuator_ctrllimited; const int* actuator_forcelimited; const int* actuator_actlimited;
+  const float* actuator_dynprm; int actuator_dynprm_nb;
+  const float* actuator_gainprm; int actuator_gainprm_nb;
+  const float* actuator_biasprm; int actuator_biasprm_nb;
+  const float* actuator_ctrlrange; int actuator_ctrlrange_nb;
+  const float* actuator_forcerange; int actuator_forcerange_nb;
+  const float* actuator_actrange; int actuator_actrange_nb;
+  const float* actuator_gear; int actuator_gear_nb;
+} MjhModel;
+
+typedef struct MjhData {
+  int nworld; int nconmax; int naconmax; int njmax; int njmax_pad; int nv_pad; int nmaxpyramid; int world_offset;
+  /* state (types.py:2240-2262) */
+  float* time; float* qpos; float* qvel; float* act; float* ctrl; float* qacc_warmstart;
+  float* qfrc_applied; float* xfrc_applied;
+  /* position-dependent */
+  float* xpos; float* xquat; float* xmat; float* xipos; float* ximat; float* xanchor; float* xaxis;
+  float* geom_xpos; float* geom_xmat; float* site_xpos; float* site_xmat;
+  float* subtree_com; float* cinert; float* cdof; float* crb; float* M; float* qLD; float* qLDiagInv;
+  float* actuator_length; float* actuator_moment;
+  /* velocity-dependent */
+  float* actuator_velocity; float* cvel; float* cdof_dot;
+  float* qfrc_spring; float* qfrc_damper; float* qfrc_gravcomp; float* qfrc_passive; float* qfrc_bias;
+  float* cacc; float* cfrc_int;
+  /* actuation / acceleration */
+  float* act_dot; float* actuator_force; float* qfrc_actuator; float* qfrc_smooth; float* qacc_smooth;
+  /* constraint solver outputs */
+  float* qacc; float* qfrc_constraint; float* efc_Ma;
+  int* solver_niter; int* ne; int* nf; int* nl; int* nefc; int* overflow;
+  /* contacts: public flat arrays [naconmax] (types.py:1975-2018) + counters */
+  int* nacon; int* ncollision;
+  float* contact_dist; float* contact_pos; float* contact_frame; float* contact_includemargin;
+  float* contact_friction; float* contact_solref; float* contact_solreffriction; float* contact_solimp;
+  int* contact_dim; int* contact_geom; int* contact_efc_address; int* contact_worldid; int* contact_type;
+  int* contact_geomcollisionid;
+  /* constraints (types.py:2021-2072): J is [nworld, njmax_pad, nv_pad] */
+  int* efc_type; int* efc_id; int* efc_state;
+  float* efc_J; float* efc_pos; float* efc_margin; float* efc_D; float* efc_vel; float* efc_aref;
+  float* efc_frictionloss; float* efc_force;
+  /* engine workspace (pre-allocated by make_data; replaces the reference's per-step temporaries) */
+  int* ws_ncon;        /* [nworld]   contacts found per world                         */
+  int* ws_conadr;      /* [nworld]   exclusive scan of ws_ncon = first public slot    */
+  int* ws_ncollision;  /* [nworld]   broadphase candidates per world                  */
+} MjhData;
+
+/* One launch sequence for a reference stage function (MJH_STAGE_*); `stream` is a hipStream_t. */
+int mjh_stage(const MjhModel* m, const MjhData* d, int stage, void* stream);
+
+/* step == mjh_stage(MJH_STAGE_STEP): forward.step forward.py:1368 */
+int mjh_step(const MjhModel* m, const MjhData* d, void* stream);
+int mjh_forward(const MjhModel* m, const MjhData* d, void* stream);
+
+/* x = M^-1 y with the stored factor (smooth.solve_m smooth.py:3214); x,y: [nworld, nv] device */
+int mjh_solve_m(const MjhModel* m, const MjhData* d, float* x, const float* y, void* stream);
+/* res = M vec (support.mul_m support.py:218) */
+int mjh_mul_m(const MjhModel* m, const MjhData* d, float* res, const float* vec, void* stream);
+
+/* cli._ctrl_noise cli.py:103-145; ctrl_center may be NULL (-> actuator midpoint); worldid is global */
+int mjh_ctrl_noise(const MjhModel* m, const MjhData* d, const float* ctrl_center, int step, float noise_std,
+                   float noise_rate, void* stream);
+
+/* hipGraph capture/replay of one step (the reference captures step in a CUDA graph, cli.py:262-265) */
+int mjh_graph_create(const MjhModel* m, const MjhData* d, void* stream, void** graph_exec_out);
+int mjh_graph_launch(void* graph_exec, void* stream);
+int mjh_graph_destroy(void* graph_exec);
+
+/* timed loop helper: runs `nstep` x (ctrl_noise + step) on `stream`, bracketed by hipEvents recorded on
+ * that stream; returns elapsed milliseconds through *ms_out (events, not host clocks).  If per_kernel_ms
+ * is non-NULL it must hold MJH_NKERNEL floats and receives the summed duration of each kernel class. */
+#define MJH_NKERNEL 8
+int mjh_timed_steps(const MjhModel* m, const MjhData* d, int nstep, int step0, float noise_std, float noise_rate,
+                    void* stream, float* ms_out, float* per_kernel_ms);
+
+const char* mjh_last_error(void);
+int mjh_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,131 @@
+"""ctypes mirror of include/mjhip.h and loader/builder of libmjhip.so.
+
+The header is the single source of truth: the struct layouts are parsed from it, so the Python side can
+never drift from the C ABI.  There is NO CPU fallback: if the library is missing or no GPU is present the
+engine raises (the product path must fail loudly, never route through oracle/).
+"""
+
+import ctypes
+import os
+import re
+import subprocess
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_PKG)
+HEADER = os.path.join(_ROOT, "include", "mjhip.h")
+LIB_PATH = os.path.join(_PKG, "libmjhip.so")
+SOURCES = [os.path.join(_PKG, "csrc", f) for f in
+           ("mjhip.hip", "dev_common.hpp", "smooth.hpp", "collide.hpp", "constraint.hpp", "solver.hpp", "integrate.hpp")]
+
+_CTYPES = {"int": ctypes.c_int, "float": ctypes.c_float, "unsigned int": ctypes.c_uint}
+
+
+def _parse_struct(text, name):
+  body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), text, re.S).group(1)
+  body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+  fields = []
+  for stmt in body.split(";"):
+    stmt = " ".join(stmt.split())
+    if not stmt:
+      continue
+    mm = re.match(r"^(const )?(unsigned int|int|float)\s*(\*?)\s*(\w+)$", stmt)
+    if not mm:
+      raise ValueError(f"cannot parse declaration '{stmt}' in struct {name}")
+    fields.append((mm.group(4), mm.group(2), bool(mm.group(3))))
+  return fields
+
+
+def _parse_defines(text):
+  out = {}
+  for mm in re.finditer(r"#define (MJH_\w+) (-?\d+)", text):
+    out[mm.group(1)] = int(mm.group(2))
+  return out
+
+
+def _parse_functions(text):
+  return re.findall(r"^\s*(?:const char\*|int)\s+(mjh_\w+)\(", text, flags=re.M)
+
+
+_HEADER_TEXT = open(HEADER).read()
+MODEL_FIELDS = _parse_struct(_HEADER_TEXT, "MjhModel")
+DATA_FIELDS = _parse_struct(_HEADER_TEXT, "MjhData")
+DEFINES = _parse_defines(_HEADER_TEXT)
+FUNCTIONS = _parse_functions(_HEADER_TEXT)
+
+
+def _mk(fields):
+  return [(n, ctypes.c_void_p if ptr else _CTYPES[k]) for n, k, ptr in fields]
+
+
+class CModel(ctypes.Structure):
+  _fields_ = _mk(MODEL_FIELDS)
+
+
+class CData(ctypes.Structure):
+  _fields_ = _mk(DATA_FIELDS)
+
+
+def needs_build():
+  if not os.path.exists(LIB_PATH):
+    return True
+  t = os.path.getmtime(LIB_PATH)
+  return any(os.path.getmtime(s) > t for s in SOURCES + [HEADER])
+
+
+def build(force=False, verbose=False):
+  """Compile libmjhip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+  if not force and not needs_build():
+    return LIB_PATH
+  cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
+         "-o", LIB_PATH, SOURCES[0]]
+  if verbose:
+    print(" ".join(cmd))
+  subprocess.check_call(cmd)
+  return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+  """Load libmjhip.so (building it if a compiler is available and the sources are newer)."""
+  global _lib
+  if _lib is not None:
+    return _lib
+  if needs_build():
+    try:
+      build()
+    except (OSError, subprocess.CalledProcessError) as e:
+      if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"libmjhip.so is missing and could not be built: {e}") from e
+  L = ctypes.CDLL(LIB_PATH)
+  mp, dp, vp = ctypes.POINTER(CModel), ctypes.POINTER(CData), ctypes.c_void_p
+  L.mjh_stage.argtypes = [mp, dp, ctypes.c_int, vp]
+  L.mjh_step.argtypes = [mp, dp, vp]
+  L.mjh_forward.argtypes = [mp, dp, vp]
+  L.mjh_solve_m.argtypes = [mp, dp, vp, vp, vp]
+  L.mjh_mul_m.argtypes = [mp, dp, vp, vp, vp]
+  L.mjh_ctrl_noise.argtypes = [mp, dp, vp, ctypes.c_int, ctypes.c_float, ctypes.c_float, vp]
+  L.mjh_graph_create.argtypes = [mp, dp, vp, ctypes.POINTER(vp)]
+  L.mjh_graph_launch.argtypes = [vp, vp]
+  L.mjh_graph_destroy.argtypes = [vp]
+  L.mjh_timed_steps.argtypes = [mp, dp, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, vp,
+                                ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
+  L.mjh_last_error.restype = ctypes.c_char_p
+  for f in FUNCTIONS:
+    if f != "mjh_last_error":
+      getattr(L, f).restype = ctypes.c_int
+  _lib = L
+  return L
+
+
+class EngineError(RuntimeError):
+  pass
+
+
+def check(rc):
+  if rc != 0:
+    msg = lib().mjh_last_error().decode()
+    if rc == DEFINES["MJH_E_UNSUPPORTED"]:
+      raise NotImplementedError(msg)
+    raise EngineError(f"libmjhip error {rc}: {msg}")

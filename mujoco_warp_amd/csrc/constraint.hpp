@@ -1,0 +1,342 @@
+// constraint.hpp -- constraint assembly fused per world (one lane group per world).
+//
+// Reference: constraint.py:84-153 (_efc_row), 1766-1865 (_friction_dof), 1991-2105 (_limit_slide_hinge),
+// 2107-2240 (_limit_ball), 2641-2757 (_efc_contact_init), 3751-3879 (_efc_contact_jac_dense),
+// 4197-4343 (_efc_contact_update); support.py:488-533 (jac helpers).
+//
+// MI355X mapping: the reference allocates rows with per-world atomics from five separate launches (row order
+// nondeterministic).  Here rows are allocated with ballot/prefix compaction in MuJoCo's canonical order
+// (dof friction, joint limits, contacts in contact order), J rows are written with lanes mapped to dofs
+// (coalesced 128 B row segments), and J*qvel comes from DPP/permute group reductions -- no atomics at all.
+#pragma once
+#include "dev_common.hpp"
+
+struct EfcRowOut {
+  float D, aref, pos;
+};
+
+// _efc_row constraint.py:84-153
+DEV EfcRowOut efc_row(int dsbl, float timestep, float pos_aref, float pos_imp, float invweight, const float* solref,
+                      const float* solimp, float margin, float vel) {
+  float timeconst = solref[0];
+  const float dampratio = solref[1];
+  float dmin = solimp[0], dmax = solimp[1], width = solimp[2], mid = solimp[3], power = solimp[4];
+  if (!(dsbl & DSBL_REFSAFE)) timeconst = fmaxf(timeconst, 2.0f * timestep);
+  dmin = clampf(dmin, MJ_MINIMP, MJ_MAXIMP);
+  dmax = clampf(dmax, MJ_MINIMP, MJ_MAXIMP);
+  width = fmaxf(MJ_MINVAL, width);
+  mid = clampf(mid, MJ_MINIMP, MJ_MAXIMP);
+  power = fmaxf(1.0f, power);
+  const float dmax_sq = dmax * dmax;
+  float k = 1.0f / (dmax_sq * timeconst * timeconst * dampratio * dampratio);
+  float b = 2.0f / (dmax * timeconst);
+  if (solref[0] <= 0.0f) k = -solref[0] / dmax_sq;
+  if (solref[1] <= 0.0f) b = -solref[1] / dmax;
+  const float imp_x = fabsf(pos_imp) / width;
+  const float imp_a = (1.0f / powf(mid, power - 1.0f)) * powf(imp_x, power);
+  const float imp_b = 1.0f - (1.0f / powf(1.0f - mid, power - 1.0f)) * powf(1.0f - imp_x, power);
+  const float imp_y = imp_x < mid ? imp_a : imp_b;
+  float imp = dmin + imp_y * (dmax - dmin);
+  imp = clampf(imp, dmin, dmax);
+  if (imp_x > 1.0f) imp = dmax;
+  EfcRowOut o;
+  o.D = 1.0f / fmaxf(invweight * (1.0f - imp) / imp, MJ_MINVAL);
+  o.aref = -k * imp * pos_aref - b * vel;
+  o.pos = pos_aref + margin;
+  return o;
+}
+
+struct ConLayout {
+  int cdof, qvel, rowvel, rowdof, rowval, row2con, clist, total;
+};
+__host__ __device__ inline ConLayout con_layout(int nv, int njmax, int ncap) {
+  ConLayout p;
+  int o = 0;
+  p.cdof = o; o += 6 * nv;
+  p.qvel = o; o += nv;
+  p.rowvel = o; o += njmax;
+  p.rowdof = o; o += njmax;
+  p.rowval = o; o += njmax;
+  p.row2con = o; o += njmax;
+  p.clist = o; o += 3 * ncap;
+  p.total = ((o + 3) / 4) * 4 + 1;
+  return p;
+}
+
+template <int G>
+__global__ void __launch_bounds__(256) k_make_constraint(MjhModel m, MjhData d, int ncap) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lig = threadIdx.x & (G - 1), gib = threadIdx.x / G;
+  const int w = blockIdx.x * (blockDim.x / G) + gib;
+  if (w >= d.nworld) return;
+  const int nv = m.nv, njnt = m.njnt, nbody = m.nbody, njmax = d.njmax, nvp = d.nv_pad;
+  const ConLayout lay = con_layout(nv, njmax, ncap);
+  float* S = smem + (size_t)gib * lay.total;
+  float *cdof = S + lay.cdof, *qvel = S + lay.qvel, *rowvel = S + lay.rowvel, *rowval = S + lay.rowval;
+  int *rowdof = reinterpret_cast<int*>(S + lay.rowdof), *row2con = reinterpret_cast<int*>(S + lay.row2con),
+      *clist = reinterpret_cast<int*>(S + lay.clist);
+  const int dsbl = m.disableflags;
+  float* J = d.efc_J + (size_t)w * d.njmax_pad * nvp;
+  const size_t eo = (size_t)w * njmax;
+
+  if (dsbl & DSBL_CONSTRAINT) {
+    if (lig == 0) d.ne[w] = d.nf[w] = d.nl[w] = d.nefc[w] = 0;
+    return;
+  }
+  gcopy<G>(cdof, d.cdof + (size_t)w * 6 * nv, 6 * nv, lig);
+  gcopy<G>(qvel, d.qvel + (size_t)w * nv, nv, lig);
+  const float timestep = bf(m.opt_timestep, m.opt_timestep_nb, w, 1)[0];
+  const float* qpos = d.qpos + (size_t)w * m.nq;
+  const float* invw = bf(m.dof_invweight0, m.dof_invweight0_nb, w, nv);
+  gsync();
+
+  int nefc = 0, nf = 0, nl = 0;
+  // ---- dof friction loss (constraint.py:1766-1865) ---------------------------------------------------------
+  if (!(dsbl & DSBL_FRICTIONLOSS)) {
+    const float* fl = bf(m.dof_frictionloss, m.dof_frictionloss_nb, w, nv);
+    for (int base = 0; base < nv; base += G) {
+      const int i = base + lig;
+      const bool act = i < nv && fl[i] > 0.0f;
+      int tot;
+      const int r = nefc + grank<G>(act, lig, tot);
+      if (act && r < njmax) {
+        rowdof[r] = i;
+        rowval[r] = 1.0f;
+        const float vel = qvel[i];
+        EfcRowOut o = efc_row(dsbl, timestep, 0.0f, 0.0f, invw[i], bf(m.dof_solref, m.dof_solref_nb, w, 2 * nv) + 2 * i,
+                              bf(m.dof_solimp, m.dof_solimp_nb, w, 5 * nv) + 5 * i, 0.0f, vel);
+        d.efc_D[eo + r] = o.D;
+        d.efc_aref[eo + r] = o.aref;
+        d.efc_pos[eo + r] = o.pos;
+        d.efc_margin[eo + r] = 0.0f;
+        d.efc_vel[eo + r] = vel;
+        d.efc_frictionloss[eo + r] = fl[i];
+        d.efc_type[eo + r] = CT_FRICTION_DOF;
+        d.efc_id[eo + r] = i;
+      }
+      nefc += tot;
+      nf += tot;
+    }
+  }
+  // ---- joint limits (constraint.py:1991-2240) ---------------------------------------------------------------
+  int nball = 0;
+  if (!(dsbl & DSBL_LIMIT)) {
+    const float* jrange = bf(m.jnt_range, m.jnt_range_nb, w, 2 * njnt);
+    const float* jmargin = bf(m.jnt_margin, m.jnt_margin_nb, w, njnt);
+    for (int base = 0; base < njnt; base += G) {
+      const int j = base + lig;
+      bool act = false;
+      float pos = 0.0f, jval = 0.0f, margin = 0.0f;
+      V3 axis = V3{0, 0, 0};
+      int t = -1, dof = 0;
+      if (j < njnt && m.jnt_limited[j]) {
+        t = m.jnt_type[j];
+        dof = m.jnt_dofadr[j];
+        margin = jmargin[j];
+        const int qa = m.jnt_qposadr[j];
+        if (t == JNT_SLIDE || t == JNT_HINGE) {
+          const float q = qpos[qa];
+          const float dmin = q - jrange[2 * j], dmax = jrange[2 * j + 1] - q;
+          pos = fminf(dmin, dmax) - margin;
+          jval = dmin < dmax ? 1.0f : -1.0f;
+          act = pos < 0.0f;
+        } else if (t == JNT_BALL) {
+          float angle;
+          axis = normalize_with_norm(quat_to_vel(quat_normalize(ld4(qpos + qa))), angle);
+          pos = fmaxf(jrange[2 * j], jrange[2 * j + 1]) - angle - margin;
+          act = pos < 0.0f;
+        }
+      }
+      int tot;
+      const int r = nefc + grank<G>(act, lig, tot);
+      if (act && r < njmax) {
+        float vel;
+        if (t == JNT_BALL) {
+          rowdof[r] = -(dof + 1);  // ball row: three entries written below
+          rowval[r] = 0.0f;
+          vel = -(axis.x * qvel[dof] + axis.y * qvel[dof + 1] + axis.z * qvel[dof + 2]);
+        } else {
+          rowdof[r] = dof;
+          rowval[r] = jval;
+          vel = jval * qvel[dof];
+        }
+        EfcRowOut o = efc_row(dsbl, timestep, pos, pos, invw[dof], bf(m.jnt_solref, m.jnt_solref_nb, w, 2 * njnt) + 2 * j,
+                              bf(m.jnt_solimp, m.jnt_solimp_nb, w, 5 * njnt) + 5 * j, margin, vel);
+        d.efc_D[eo + r] = o.D;
+        d.efc_aref[eo + r] = o.aref;
+        d.efc_pos[eo + r] = o.pos;
+        d.efc_margin[eo + r] = margin;
+        d.efc_vel[eo + r] = vel;
+        d.efc_frictionloss[eo + r] = 0.0f;
+        d.efc_type[eo + r] = CT_LIMIT_JOINT;
+        d.efc_id[eo + r] = j;
+      }
+      nball += gsumi<G>((act && t == JNT_BALL) ? 1 : 0);
+      nefc += tot;
+      nl += tot;
+    }
+  }
+  gsync();
+  // cooperative, coalesced write of the (one-hot) friction/limit rows of J
+  {
+    const int nrow = min(nefc, njmax);
+    for (int idx = lig; idx < nrow * nvp; idx += G) {
+      const int r = idx / nvp, c = idx - r * nvp;
+      J[idx] = (c == rowdof[r]) ? rowval[r] : 0.0f;
+    }
+    if (nball > 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      for (int r = lig; r < nrow; r += G)
+        if (rowdof[r] < 0) {
+          const int dof = -rowdof[r] - 1;
+          const int j = m.dof_jntid[dof];
+          float angle;
+          V3 axis = normalize_with_norm(quat_to_vel(quat_normalize(ld4(qpos + m.jnt_qposadr[j]))), angle);
+          J[r * nvp + dof] = -axis.x;
+          J[r * nvp + dof + 1] = -axis.y;
+          J[r * nvp + dof + 2] = -axis.z;
+        }
+    }
+  }
+  const int nrow_noncontact = nefc;
+
+  // ---- contacts (constraint.py:2641-2757 init, 3751-3879 jac, 4197-4343 update) ---------------------------
+  int nactive = 0;
+  const int ncon = (dsbl & DSBL_CONTACT) ? 0 : d.ws_ncon[w];
+  const int cadr = d.ws_conadr[w];
+  for (int base = 0; base < ncon; base += G) {
+    const int c = base + lig;
+    bool act = false;
+    int ndim = 0;
+    if (c < ncon) {
+      const size_t o = (size_t)(cadr + c);
+      const float pos = d.contact_dist[o] - d.contact_includemargin[o];
+      act = pos < 0.0f;
+      const int condim = d.contact_dim[o];
+      ndim = act ? (condim == 1 ? 1 : 2 * (condim - 1)) : 0;
+    }
+    int incl = ndim;
+    for (int off = 1; off < G; off <<= 1) {
+      int v = __shfl_up(incl, off, G);
+      if (lig >= off) incl += v;
+    }
+    const int rbase = nefc + incl - ndim;
+    int tot;
+    const int arank = nactive + grank<G>(act, lig, tot);
+    if (act) {
+      const size_t o = (size_t)(cadr + c);
+      for (int k = 0; k < ndim; ++k) {
+        const int r = rbase + k;
+        d.contact_efc_address[o * d.nmaxpyramid + k] = r < njmax ? r : -1;
+        if (r < njmax) row2con[r] = c * 16 + k;
+      }
+      if (arank < ncap) {
+        clist[3 * arank] = c;
+        clist[3 * arank + 1] = rbase;
+        clist[3 * arank + 2] = ndim;
+      }
+    }
+    nefc += __shfl(incl, G - 1, G);
+    nactive += tot;
+  }
+  gsync();
+  if (nactive > ncap) nactive = ncap;
+  const int nw = (nv + 31) / 32;
+  for (int a = 0; a < nactive; ++a) {
+    const int c = clist[3 * a], rbase = clist[3 * a + 1], ndim = clist[3 * a + 2];
+    if (rbase >= njmax) break;
+    const size_t o = (size_t)(cadr + c);
+    const int g1 = d.contact_geom[2 * o], g2 = d.contact_geom[2 * o + 1];
+    const int b1 = m.geom_bodyid[g1], b2 = m.geom_bodyid[g2];
+    const V3 cpos = ld3(d.contact_pos + 3 * o);
+    const V3 off1 = cpos - ld3(d.subtree_com + ((size_t)w * nbody + m.body_rootid[b1]) * 3);
+    const V3 off2 = cpos - ld3(d.subtree_com + ((size_t)w * nbody + m.body_rootid[b2]) * 3);
+    const float* frame = d.contact_frame + 9 * o;
+    const V3 f0 = ld3(frame), f1 = ld3(frame + 3), f2 = ld3(frame + 6);
+    const float* fri = d.contact_friction + 5 * o;
+    const int condim = d.contact_dim[o];
+    float part[10];
+    for (int k = 0; k < 10; ++k) part[k] = 0.0f;
+    for (int i0 = 0; i0 < nvp; i0 += G) {
+      const int i = i0 + lig;
+      V3 jp = V3{0, 0, 0}, jr = V3{0, 0, 0};
+      if (i < nv) {
+        const bool a1 = m.body_dofmask[b1 * nw + (i >> 5)] & (1u << (i & 31));
+        const bool a2 = m.body_dofmask[b2 * nw + (i >> 5)] & (1u << (i & 31));
+        const V3 ang = ld3(cdof + 6 * i), lin = ld3(cdof + 6 * i + 3);
+        if (a2) {
+          jp = jp + lin + cross(ang, off2);
+          jr = jr + ang;
+        }
+        if (a1) {
+          jp = jp - (lin + cross(ang, off1));
+          jr = jr - ang;
+        }
+      }
+      if (i < nvp) {
+        const float j0p = dot(f0, jp);
+        const float qv = i < nv ? qvel[i] : 0.0f;
+        for (int k = 0; k < ndim; ++k) {
+          const int r = rbase + k;
+          if (r >= njmax) break;
+          float val = j0p;
+          if (condim > 1) {
+            const int dimid2 = k / 2 + 1;
+            const float frii = fri[dimid2 - 1] * (1.0f - 2.0f * (float)(k & 1));
+            float ji;
+            if (dimid2 == 1) ji = dot(f1, jp);
+            else if (dimid2 == 2) ji = dot(f2, jp);
+            else if (dimid2 == 3) ji = dot(f0, jr);
+            else if (dimid2 == 4) ji = dot(f1, jr);
+            else ji = dot(f2, jr);
+            val += ji * frii;
+          }
+          J[(size_t)r * nvp + i] = val;
+          part[k] += val * qv;
+        }
+      }
+    }
+    for (int k = 0; k < ndim; ++k) {
+      const float v = gsum<G>(part[k]);
+      if (lig == 0 && rbase + k < njmax) rowvel[rbase + k] = v;
+    }
+  }
+  gsync();
+  // per-row contact parameters (lane per row)
+  {
+    const int nrow = min(nefc, njmax);
+    const float impr2 = bf(m.opt_impratio_invsqrt, m.opt_impratio_invsqrt_nb, w, 1)[0];
+    const float* biw = bf(m.body_invweight0, m.body_invweight0_nb, w, 2 * nbody);
+    for (int r = nrow_noncontact + lig; r < nrow; r += G) {
+      const int c = row2con[r] >> 4;
+      const size_t o = (size_t)(cadr + c);
+      const float includemargin = d.contact_includemargin[o];
+      const float pos = d.contact_dist[o] - includemargin;
+      const int condim = d.contact_dim[o];
+      const int b1 = m.geom_bodyid[d.contact_geom[2 * o]], b2 = m.geom_bodyid[d.contact_geom[2 * o + 1]];
+      float invweight = biw[2 * b1] + biw[2 * b2];
+      if (condim > 1) {
+        const float fri0 = d.contact_friction[5 * o];
+        invweight = invweight + fri0 * fri0 * invweight;
+        invweight = invweight * 2.0f * fri0 * fri0 * impr2 * impr2;
+      }
+      const float vel = rowvel[r];
+      EfcRowOut eo_ = efc_row(dsbl, timestep, pos, pos, invweight, d.contact_solref + 2 * o, d.contact_solimp + 5 * o, includemargin, vel);
+      d.efc_D[eo + r] = eo_.D;
+      d.efc_aref[eo + r] = eo_.aref;
+      d.efc_pos[eo + r] = eo_.pos;
+      d.efc_margin[eo + r] = includemargin;
+      d.efc_vel[eo + r] = vel;
+      d.efc_frictionloss[eo + r] = 0.0f;
+      d.efc_type[eo + r] = condim == 1 ? CT_CONTACT_FRICTIONLESS : CT_CONTACT_PYRAMIDAL;
+      d.efc_id[eo + r] = cadr + c;
+    }
+  }
+  if (lig == 0) {
+    d.ne[w] = 0;
+    d.nf[w] = nf;
+    d.nl[w] = nl;
+    d.nefc[w] = nefc;
+    if (nefc > njmax) atomicOr(d.overflow + w, OVF_NEFC);
+  }
+}

@@ -1,0 +1,208 @@
+// integrate.hpp -- integrators and small utility kernels.
+//
+// Reference: forward.py:53-131 (_next_position/_next_velocity), 134-219 (_next_activation), 221-273 (_next_time
+// overflow flags), 276-349 (_advance), 353-417 (euler with implicit joint damping), 578-612 (implicitfast) with
+// derivative.py:1117 (deriv_smooth_vel; joint damping + affine actuator velocity terms, joint transmissions);
+// cli.py:103-145 (_ctrl_noise) and util_misc.py:61 (halton).
+#pragma once
+#include "dev_common.hpp"
+#include "smooth.hpp"
+
+struct IntLayout {
+  int L, dinv, x, qvel, total;
+};
+__host__ __device__ inline IntLayout int_layout(int nv, int nC) {
+  IntLayout p;
+  int o = 0;
+  p.L = o; o += nC;
+  p.dinv = o; o += nv;
+  p.x = o; o += nv;
+  p.qvel = o; o += nv;
+  p.total = ((o + 3) / 4) * 4 + 1;
+  return p;
+}
+
+// mode: 0 = Euler (forward.py:387), 1 = implicitfast (forward.py:578)
+template <int G>
+__global__ void __launch_bounds__(256) k_integrate(MjhModel m, MjhData d, int mode) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int nq = m.nq, nv = m.nv, nC = m.nC, nu = m.nu, njnt = m.njnt;
+  const IntLayout lay = int_layout(nv, nC);
+  int* shi = reinterpret_cast<int*>(smem);
+  const MStruct ms = load_mstruct<G>(m, shi);
+  const int lig = threadIdx.x & (G - 1), gib = threadIdx.x / G;
+  const int w = blockIdx.x * (blockDim.x / G) + gib;
+  if (w >= d.nworld) return;
+  float* S = smem + mstruct_ints(nv, nC) + (size_t)gib * lay.total;
+  float *L = S + lay.L, *dinv = S + lay.dinv, *x = S + lay.x, *qvel = S + lay.qvel;
+  const int dsbl = m.disableflags;
+  const float h = bf(m.opt_timestep, m.opt_timestep_nb, w, 1)[0];
+  const size_t vo = (size_t)w * nv;
+  const float* damp = bf(m.dof_damping, m.dof_damping_nb, w, nv);
+
+  // does the velocity update need an implicit solve?
+  bool implicit = false;
+  if (mode == 1) implicit = true;
+  else if (!(dsbl & (DSBL_EULERDAMP | DSBL_DAMPER))) {
+    float mx = 0.0f;
+    for (int i = lig; i < nv; i += G) mx = fmaxf(mx, fabsf(damp[i]));
+    implicit = gmax<G>(mx) > 0.0f;
+  }
+  if (implicit) {
+    gcopy<G>(L, d.M + (size_t)w * nC, nC, lig);
+    gcopy<G>(x, d.efc_Ma + vo, nv, lig);
+    gsync();
+    if (!(dsbl & DSBL_DAMPER))
+      for (int i = lig; i < nv; i += G) L[ms.rowadr[i] + ms.rownnz[i] - 1] += h * damp[i];
+    if (mode == 1 && !(dsbl & DSBL_ACTUATION)) {
+      // d(qfrc_actuator)/d(qvel) for joint transmissions is diagonal: gear^2 * (bias_vel + gain_vel * ctrl)
+      gsync();
+      const float* gear = bf(m.actuator_gear, m.actuator_gear_nb, w, 6 * nu);
+      for (int i = lig; i < nv; i += G) {
+        float acc = 0.0f;
+        for (int u = 0; u < nu; ++u) {
+          if (m.jnt_dofadr[m.actuator_trnid[2 * u]] != i) continue;
+          const float bias_vel = m.actuator_biastype[u] == 1 ? bf(m.actuator_biasprm, m.actuator_biasprm_nb, w, 10 * nu)[10 * u + 2] : 0.0f;
+          const float gain_vel = m.actuator_gaintype[u] == 1 ? bf(m.actuator_gainprm, m.actuator_gainprm_nb, w, 10 * nu)[10 * u + 2] : 0.0f;
+          float ctrl = d.ctrl[(size_t)w * nu + u];
+          if (m.actuator_dyntype[u] != 0) ctrl = d.act[(size_t)w * m.na + m.actuator_actadr[u]];
+          else if (m.actuator_ctrllimited[u] && !(dsbl & DSBL_CLAMPCTRL)) {
+            const float* cr = bf(m.actuator_ctrlrange, m.actuator_ctrlrange_nb, w, 2 * nu) + 2 * u;
+            ctrl = clampf(ctrl, cr[0], cr[1]);
+          }
+          const float dv = bias_vel + gain_vel * ctrl;
+          if (dv == 0.0f) continue;
+          if (m.actuator_forcelimited[u]) {
+            const float* fr = bf(m.actuator_forcerange, m.actuator_forcerange_nb, w, 2 * nu) + 2 * u;
+            const float f = d.actuator_force[(size_t)w * nu + u];
+            if (f <= fr[0] || f >= fr[1]) continue;
+          }
+          acc += gear[6 * u] * gear[6 * u] * dv;
+        }
+        L[ms.rowadr[i] + ms.rownnz[i] - 1] -= h * acc;
+      }
+    }
+    gsync();
+    factor_ld<G>(ms, L, dinv, nv, lig);
+    solve_ld<G>(m, ms, L, dinv, x, nv, lig);
+  } else {
+    gcopy<G>(x, d.qacc + vo, nv, lig);
+    gsync();
+  }
+
+  // ---- _advance (forward.py:276-349) -------------------------------------------------------------------
+  for (int u = lig; u < nu; u += G) {  // activations (support.py:38 next_act)
+    const int dyn = m.actuator_dyntype[u];
+    if (dyn == 0) continue;
+    const size_t a = (size_t)w * m.na + m.actuator_actadr[u];
+    float act = d.act[a];
+    const float act_dot = d.act_dot[a];
+    if (dyn == 3) {
+      const float tau = fmaxf(MJ_MINVAL, bf(m.actuator_dynprm, m.actuator_dynprm_nb, w, 10 * nu)[10 * u]);
+      act = act + act_dot * tau * (1.0f - expf(-h / tau));
+    } else {
+      act = act + act_dot * h;
+    }
+    if (m.actuator_actlimited[u]) {
+      const float* ar = bf(m.actuator_actrange, m.actuator_actrange_nb, w, 2 * nu) + 2 * u;
+      act = clampf(act, ar[0], ar[1]);
+    }
+    d.act[a] = act;
+  }
+  for (int i = lig; i < nv; i += G) {
+    const float v = d.qvel[vo + i] + x[i] * h;
+    qvel[i] = v;
+    d.qvel[vo + i] = v;
+    d.qacc_warmstart[vo + i] = d.qacc[vo + i];
+  }
+  gsync();
+  float* qpos = d.qpos + (size_t)w * nq;
+  for (int j = lig; j < njnt; j += G) {  // _next_position forward.py:53
+    const int qa = m.jnt_qposadr[j], dof = m.jnt_dofadr[j], t = m.jnt_type[j];
+    if (t == JNT_FREE) {
+      for (int k = 0; k < 3; ++k) qpos[qa + k] += h * qvel[dof + k];
+      st4(qpos + qa + 3, quat_integrate(ld4(qpos + qa + 3), ld3(qvel + dof + 3), h));
+    } else if (t == JNT_BALL) {
+      st4(qpos + qa, quat_integrate(ld4(qpos + qa), ld3(qvel + dof), h));
+    } else {
+      qpos[qa] += h * qvel[dof];
+    }
+  }
+  if (lig == 0) d.time[w] += h;
+}
+
+// cli.py:103-145; halton in float32 exactly like util_misc.py:61
+DEV float halton(int index, int base) {
+  int n0 = index;
+  const float b = (float)base;
+  float f = 1.0f / b, hn = 0.0f;
+  while (n0 > 0) {
+    const int n1 = n0 / base;
+    const int r = n0 - n1 * base;
+    hn += f * (float)r;
+    f /= b;
+    n0 = n1;
+  }
+  return hn;
+}
+__global__ void k_ctrl_noise(MjhModel m, MjhData d, const float* center, int step, float noise_std, float noise_rate) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nu = m.nu;
+  if (idx >= d.nworld * nu) return;
+  const int w = idx / nu, a = idx - w * nu;
+  const float h = bf(m.opt_timestep, m.opt_timestep_nb, w, 1)[0];
+  const float rate = expf(-h / noise_rate);
+  const float scale = noise_std * sqrtf(1.0f - rate * rate);
+  float midpoint = 0.0f, halfrange = 1.0f;
+  const float* cr = bf(m.actuator_ctrlrange, m.actuator_ctrlrange_nb, w, 2 * nu) + 2 * a;
+  const bool lim = m.actuator_ctrllimited[a];
+  if (lim) {
+    midpoint = 0.5f * (cr[1] + cr[0]);
+    halfrange = 0.5f * (cr[1] - cr[0]);
+  }
+  if (center) midpoint = center[a];
+  float ctrl = rate * d.ctrl[idx] + (1.0f - rate) * midpoint;
+  const int gw = w + d.world_offset;  // global world id keeps trajectories shard-invariant across GPUs
+  ctrl += scale * halfrange * (2.0f * halton((step + 1) * (gw + 1), a + 2) - 1.0f);
+  if (lim) ctrl = clampf(ctrl, cr[0], cr[1]);
+  d.ctrl[idx] = ctrl;
+}
+
+// x = M^-1 y (smooth.solve_m) and res = M vec (support.mul_m) on user arrays
+template <int G>
+__global__ void __launch_bounds__(256) k_solve_m(MjhModel m, MjhData d, float* xout, const float* yin, int mul) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int nv = m.nv, nC = m.nC;
+  const IntLayout lay = int_layout(nv, nC);
+  int* shi = reinterpret_cast<int*>(smem);
+  const MStruct ms = load_mstruct<G>(m, shi);
+  const int lig = threadIdx.x & (G - 1), gib = threadIdx.x / G;
+  const int w = blockIdx.x * (blockDim.x / G) + gib;
+  if (w >= d.nworld) return;
+  float* S = smem + mstruct_ints(nv, nC) + (size_t)gib * lay.total;
+  float *L = S + lay.L, *dinv = S + lay.dinv, *x = S + lay.x, *y = S + lay.qvel;
+  if (mul) {
+    gcopy<G>(L, d.M + (size_t)w * nC, nC, lig);
+    gcopy<G>(y, yin + (size_t)w * nv, nv, lig);
+    gsync();
+    mul_m_ld<G>(ms, L, y, x, nv, lig);
+  } else {
+    gcopy<G>(L, d.qLD + (size_t)w * nC, nC, lig);
+    gcopy<G>(dinv, d.qLDiagInv + (size_t)w * nv, nv, lig);
+    gcopy<G>(x, yin + (size_t)w * nv, nv, lig);
+    gsync();
+    solve_ld<G>(m, ms, L, dinv, x, nv, lig);
+  }
+  gsync();
+  gcopy<G>(xout + (size_t)w * nv, x, nv, lig);
+}
+
+// end-of-step overflow flags that depend on global counters (forward.py:221-273)
+__global__ void k_overflow(MjhData d) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= d.nworld) return;
+  int o = 0;
+  if (d.nefc[w] > d.njmax) o |= OVF_NEFC;
+  if (d.nacon[0] > d.naconmax) o |= OVF_NARROWPHASE;
+  if (o) d.overflow[w] |= o;
+}

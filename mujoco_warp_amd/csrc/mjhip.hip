@@ -1,0 +1,350 @@
+// mjhip.hip -- extern "C" entry points of libmjhip.so (see include/mjhip.h) and launch sequencing.
+//
+// One `step` = 6 kernel launches on the caller's stream (reference: ~90 fixed launches + ~12 per solver
+// iteration, forward.py:1341-1380):
+//   k_fwd_pos (kinematics+com_pos+crb) -> k_collision -> k_make_constraint -> k_fwd_vel (com_vel, passive, rne,
+//   actuation, factor+solve) -> k_solve (whole Newton/CG solve) -> k_integrate.
+// Nothing here allocates or synchronises (hipGraph-capturable); workspace lives in MjhData.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "../../include/mjhip.h"
+#include "collide.hpp"
+#include "constraint.hpp"
+#include "dev_common.hpp"
+#include "integrate.hpp"
+#include "smooth.hpp"
+#include "solver.hpp"
+
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, const char* a = "") {
+  snprintf(g_err, sizeof(g_err), fmt, a);
+  return code;
+}
+#define HIPCHK(expr)                                                      \
+  do {                                                                    \
+    hipError_t e_ = (expr);                                               \
+    if (e_ != hipSuccess) return fail(MJH_E_LAUNCH, #expr ": %s", hipGetErrorString(e_)); \
+  } while (0)
+
+static const int kLdsPerCU = 160 * 1024;
+
+// pick threads per block in {256,128,64} maximising resident worlds per CU for the given LDS needs
+static int pick_block(size_t shared_bytes, size_t per_world_bytes, int G, size_t* lds_out) {
+  int best = 0, best_worlds = -1;
+  for (int threads : {256, 128, 64}) {
+    const int wpb = threads / G;
+    if (wpb < 1) continue;
+    const size_t lds = shared_bytes + per_world_bytes * wpb;
+    if (lds > (size_t)kLdsPerCU) continue;
+    int blocks = (int)(kLdsPerCU / lds);
+    const int wave_cap = 32 / (threads / 64);
+    if (blocks > wave_cap) blocks = wave_cap;
+    const int worlds = blocks * wpb;
+    if (worlds > best_worlds) {
+      best_worlds = worlds;
+      best = threads;
+    }
+  }
+  if (best) *lds_out = shared_bytes + per_world_bytes * (best / G);
+  return best;
+}
+
+// raise the dynamic-LDS cap of a kernel once (never during stream capture: mjh_graph_create warms up first)
+template <typename K>
+static hipError_t set_lds(K kernel, size_t bytes) {
+  if (bytes <= 64 * 1024) return hipSuccess;
+  static std::mutex mu;
+  static std::vector<std::pair<const void*, size_t>> done;
+  const void* f = reinterpret_cast<const void*>(kernel);
+  std::lock_guard<std::mutex> lock(mu);
+  for (auto& p : done)
+    if (p.first == f && p.second >= bytes) return hipSuccess;
+  hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e == hipSuccess) done.emplace_back(f, bytes);
+  return e;
+}
+
+static int contact_cap(const MjhData* d) {
+  int cap = d->nconmax * 2;
+  if (cap < 16) cap = 16;
+  if (cap > 256) cap = 256;
+  return cap;
+}
+
+constexpr int G = 32;
+
+static int launch_pos(const MjhModel* m, const MjhData* d, int first, int last, hipStream_t s) {
+  const PosLayout lay = pos_layout(m->nq, m->nv, m->nbody, m->njnt, m->nC);
+  size_t lds;
+  const int threads = pick_block(sizeof(int) * mstruct_ints(m->nv, m->nC), sizeof(float) * lay.total, G, &lds);
+  if (!threads) return fail(MJH_E_UNSUPPORTED, "k_fwd_pos: model does not fit in LDS");
+  HIPCHK(set_lds(k_fwd_pos<G>, lds));
+  const int wpb = threads / G;
+  hipLaunchKernelGGL(k_fwd_pos<G>, dim3((d->nworld + wpb - 1) / wpb), dim3(threads), lds, s, *m, *d, first, last);
+  return MJH_OK;
+}
+static int launch_vel(const MjhModel* m, const MjhData* d, int first, int last, hipStream_t s) {
+  const VelLayout lay = vel_layout(m->nq, m->nv, m->nbody, m->nC, m->nu);
+  size_t lds;
+  const int threads = pick_block(sizeof(int) * mstruct_ints(m->nv, m->nC), sizeof(float) * lay.total, G, &lds);
+  if (!threads) return fail(MJH_E_UNSUPPORTED, "k_fwd_vel: model does not fit in LDS");
+  HIPCHK(set_lds(k_fwd_vel<G>, lds));
+  const int wpb = threads / G;
+  hipLaunchKernelGGL(k_fwd_vel<G>, dim3((d->nworld + wpb - 1) / wpb), dim3(threads), lds, s, *m, *d, first, last);
+  return MJH_OK;
+}
+static int launch_collision(const MjhModel* m, const MjhData* d, hipStream_t s) {
+  HIPCHK(hipMemsetAsync(d->nacon, 0, sizeof(int), s));
+  HIPCHK(hipMemsetAsync(d->ncollision, 0, sizeof(int), s));
+  const int cap = contact_cap(d);
+  size_t lds;
+  const int threads = pick_block(0, sizeof(float) * collide_lds_words(m->npair, cap), G, &lds);
+  if (!threads) return fail(MJH_E_UNSUPPORTED, "k_collision: pair list does not fit in LDS");
+  HIPCHK(set_lds(k_collision<G>, lds));
+  const int wpb = threads / G;
+  hipLaunchKernelGGL(k_collision<G>, dim3((d->nworld + wpb - 1) / wpb), dim3(threads), lds, s, *m, *d, cap);
+  return MJH_OK;
+}
+static int launch_constraint(const MjhModel* m, const MjhData* d, hipStream_t s) {
+  const int cap = contact_cap(d);
+  const ConLayout lay = con_layout(m->nv, d->njmax, cap);
+  size_t lds;
+  const int threads = pick_block(0, sizeof(float) * lay.total, G, &lds);
+  if (!threads) return fail(MJH_E_UNSUPPORTED, "k_make_constraint: does not fit in LDS");
+  HIPCHK(set_lds(k_make_constraint<G>, lds));
+  const int wpb = threads / G;
+  hipLaunchKernelGGL(k_make_constraint<G>, dim3((d->nworld + wpb - 1) / wpb), dim3(threads), lds, s, *m, *d, cap);
+  return MJH_OK;
+}
+template <int NVP, bool NEWTON>
+static int launch_solve_t(const MjhModel* m, const MjhData* d, hipStream_t s) {
+  const SolveLayout lay = solve_layout<NVP>(d->njmax, m->nC, !NEWTON);
+  size_t lds;
+  const int threads = pick_block(sizeof(int) * mstruct_ints(m->nv, m->nC), sizeof(float) * lay.total, 32, &lds);
+  if (!threads) return fail(MJH_E_UNSUPPORTED, "k_solve: njmax x nv does not fit in LDS");
+  HIPCHK(set_lds(k_solve<NVP, NEWTON>, lds));
+  const int wpb = threads / 32;
+  hipLaunchKernelGGL((k_solve<NVP, NEWTON>), dim3((d->nworld + wpb - 1) / wpb), dim3(threads), lds, s, *m, *d);
+  return MJH_OK;
+}
+static int launch_solve(const MjhModel* m, const MjhData* d, hipStream_t s) {
+  if (m->cone != 0) return fail(MJH_E_UNSUPPORTED, "elliptic cones are not implemented yet");
+  if (m->nv > 32) return fail(MJH_E_UNSUPPORTED, "nv > 32 needs the sparse/blocked solver path (not implemented yet)");
+  const bool newton = m->solver == SOL_NEWTON;
+  if (m->solver != SOL_NEWTON && m->solver != SOL_CG) return fail(MJH_E_UNSUPPORTED, "solver must be CG or Newton");
+  if (m->nv <= 8) return newton ? launch_solve_t<8, true>(m, d, s) : launch_solve_t<8, false>(m, d, s);
+  if (m->nv <= 16) return newton ? launch_solve_t<16, true>(m, d, s) : launch_solve_t<16, false>(m, d, s);
+  return newton ? launch_solve_t<32, true>(m, d, s) : launch_solve_t<32, false>(m, d, s);
+}
+static int launch_integrate(const MjhModel* m, const MjhData* d, int mode, hipStream_t s) {
+  const IntLayout lay = int_layout(m->nv, m->nC);
+  size_t lds;
+  const int threads = pick_block(sizeof(int) * mstruct_ints(m->nv, m->nC), sizeof(float) * lay.total, G, &lds);
+  if (!threads) return fail(MJH_E_UNSUPPORTED, "k_integrate: does not fit in LDS");
+  HIPCHK(set_lds(k_integrate<G>, lds));
+  const int wpb = threads / G;
+  hipLaunchKernelGGL(k_integrate<G>, dim3((d->nworld + wpb - 1) / wpb), dim3(threads), lds, s, *m, *d, mode);
+  hipLaunchKernelGGL(k_overflow, dim3((d->nworld + 255) / 256), dim3(256), 0, s, *d);
+  return MJH_OK;
+}
+
+#define TRY(x)               \
+  do {                       \
+    int rc_ = (x);           \
+    if (rc_ != MJH_OK) return rc_; \
+  } while (0)
+
+static int check(const MjhModel* m, const MjhData* d) {
+  if (!m || !d) return fail(MJH_E_ARG, "null model/data");
+  if (d->nworld <= 0) return fail(MJH_E_ARG, "nworld must be positive");
+  if (m->integrator != INT_EULER && m->integrator != INT_IMPLICITFAST) return fail(MJH_E_UNSUPPORTED, "integrator must be Euler or implicitfast");
+  return MJH_OK;
+}
+
+// optional per-kernel event instrumentation used by mjh_timed_steps
+struct Instr {
+  std::vector<hipEvent_t> ev;  // pairs
+  std::vector<int> cls;
+  hipStream_t s;
+  bool on = false;
+};
+static thread_local Instr* g_instr = nullptr;
+struct Scope {
+  int cls;
+  hipEvent_t a, b;
+  bool on;
+  explicit Scope(int c) : cls(c), on(g_instr && g_instr->on) {
+    if (on) {
+      hipEventCreate(&a);
+      hipEventCreate(&b);
+      hipEventRecord(a, g_instr->s);
+    }
+  }
+  ~Scope() {
+    if (on) {
+      hipEventRecord(b, g_instr->s);
+      g_instr->ev.push_back(a);
+      g_instr->ev.push_back(b);
+      g_instr->cls.push_back(cls);
+    }
+  }
+};
+enum { K_NOISE = 0, K_POS = 1, K_COLLISION = 2, K_CONSTRAINT = 3, K_VEL = 4, K_SOLVE = 5, K_INTEGRATE = 6, K_OTHER = 7 };
+
+static int run_stage(const MjhModel* m, const MjhData* d, int stage, hipStream_t s) {
+  switch (stage) {
+    case MJH_STAGE_KINEMATICS: { Scope sc(K_POS); return launch_pos(m, d, POS_KINEMATICS, POS_KINEMATICS, s); }
+    case MJH_STAGE_COM_POS: { Scope sc(K_POS); return launch_pos(m, d, POS_COM, POS_COM, s); }
+    case MJH_STAGE_CRB: { Scope sc(K_POS); return launch_pos(m, d, POS_CRB, POS_CRB, s); }
+    case MJH_STAGE_FACTOR_M: { Scope sc(K_POS); return launch_pos(m, d, POS_FACTOR, POS_FACTOR, s); }
+    case MJH_STAGE_COLLISION: { Scope sc(K_COLLISION); return launch_collision(m, d, s); }
+    case MJH_STAGE_MAKE_CONSTRAINT: { Scope sc(K_CONSTRAINT); return launch_constraint(m, d, s); }
+    case MJH_STAGE_TRANSMISSION: return MJH_OK;  // joint transmissions: length/moment are produced by fwd_actuation
+    case MJH_STAGE_COM_VEL: { Scope sc(K_VEL); return launch_vel(m, d, VEL_COMVEL, VEL_COMVEL, s); }
+    case MJH_STAGE_PASSIVE: { Scope sc(K_VEL); return launch_vel(m, d, VEL_PASSIVE, VEL_PASSIVE, s); }
+    case MJH_STAGE_RNE: { Scope sc(K_VEL); return launch_vel(m, d, VEL_RNE, VEL_RNE, s); }
+    case MJH_STAGE_FWD_VELOCITY: { Scope sc(K_VEL); return launch_vel(m, d, VEL_COMVEL, VEL_RNE, s); }
+    case MJH_STAGE_FWD_ACTUATION: { Scope sc(K_VEL); return launch_vel(m, d, VEL_ACTUATION, VEL_ACTUATION, s); }
+    case MJH_STAGE_FWD_ACCELERATION: { Scope sc(K_VEL); return launch_vel(m, d, VEL_ACCEL, VEL_ACCEL, s); }
+    case MJH_STAGE_SOLVE: { Scope sc(K_SOLVE); return launch_solve(m, d, s); }
+    case MJH_STAGE_EULER: { Scope sc(K_INTEGRATE); return launch_integrate(m, d, 0, s); }
+    case MJH_STAGE_IMPLICIT: { Scope sc(K_INTEGRATE); return launch_integrate(m, d, 1, s); }
+    case MJH_STAGE_FWD_POSITION:
+      { Scope sc(K_POS); TRY(launch_pos(m, d, POS_KINEMATICS, POS_FACTOR, s)); }
+      { Scope sc(K_COLLISION); TRY(launch_collision(m, d, s)); }
+      { Scope sc(K_CONSTRAINT); TRY(launch_constraint(m, d, s)); }
+      return MJH_OK;
+    case MJH_STAGE_FORWARD:
+      { Scope sc(K_POS); TRY(launch_pos(m, d, POS_KINEMATICS, POS_CRB, s)); }
+      { Scope sc(K_COLLISION); TRY(launch_collision(m, d, s)); }
+      { Scope sc(K_CONSTRAINT); TRY(launch_constraint(m, d, s)); }
+      { Scope sc(K_VEL); TRY(launch_vel(m, d, VEL_COMVEL, VEL_ACCEL, s)); }
+      { Scope sc(K_SOLVE); TRY(launch_solve(m, d, s)); }
+      return MJH_OK;
+    case MJH_STAGE_STEP:
+      TRY(run_stage(m, d, MJH_STAGE_FORWARD, s));
+      { Scope sc(K_INTEGRATE); TRY(launch_integrate(m, d, m->integrator == INT_IMPLICITFAST ? 1 : 0, s)); }
+      return MJH_OK;
+    default:
+      return fail(MJH_E_ARG, "unknown stage");
+  }
+}
+
+extern "C" {
+
+int mjh_abi_version(void) { return 1; }
+const char* mjh_last_error(void) { return g_err; }
+
+int mjh_stage(const MjhModel* m, const MjhData* d, int stage, void* stream) {
+  TRY(check(m, d));
+  TRY(run_stage(m, d, stage, (hipStream_t)stream));
+  HIPCHK(hipGetLastError());
+  return MJH_OK;
+}
+int mjh_step(const MjhModel* m, const MjhData* d, void* stream) { return mjh_stage(m, d, MJH_STAGE_STEP, stream); }
+int mjh_forward(const MjhModel* m, const MjhData* d, void* stream) { return mjh_stage(m, d, MJH_STAGE_FORWARD, stream); }
+
+static int launch_solve_m(const MjhModel* m, const MjhData* d, float* x, const float* y, int mul, hipStream_t s) {
+  const IntLayout lay = int_layout(m->nv, m->nC);
+  size_t lds;
+  const int threads = pick_block(sizeof(int) * mstruct_ints(m->nv, m->nC), sizeof(float) * lay.total, G, &lds);
+  if (!threads) return fail(MJH_E_UNSUPPORTED, "k_solve_m: does not fit in LDS");
+  HIPCHK(set_lds(k_solve_m<G>, lds));
+  const int wpb = threads / G;
+  hipLaunchKernelGGL(k_solve_m<G>, dim3((d->nworld + wpb - 1) / wpb), dim3(threads), lds, s, *m, *d, x, y, mul);
+  HIPCHK(hipGetLastError());
+  return MJH_OK;
+}
+int mjh_solve_m(const MjhModel* m, const MjhData* d, float* x, const float* y, void* stream) {
+  TRY(check(m, d));
+  return launch_solve_m(m, d, x, y, 0, (hipStream_t)stream);
+}
+int mjh_mul_m(const MjhModel* m, const MjhData* d, float* res, const float* vec, void* stream) {
+  TRY(check(m, d));
+  return launch_solve_m(m, d, res, vec, 1, (hipStream_t)stream);
+}
+
+int mjh_ctrl_noise(const MjhModel* m, const MjhData* d, const float* ctrl_center, int step, float noise_std, float noise_rate, void* stream) {
+  TRY(check(m, d));
+  const int n = d->nworld * m->nu;
+  if (n == 0) return MJH_OK;
+  Scope sc(K_NOISE);
+  hipLaunchKernelGGL(k_ctrl_noise, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, *m, *d, ctrl_center, step, noise_std, noise_rate);
+  HIPCHK(hipGetLastError());
+  return MJH_OK;
+}
+
+int mjh_graph_create(const MjhModel* m, const MjhData* d, void* stream, void** graph_exec_out) {
+  TRY(check(m, d));
+  hipStream_t s = (hipStream_t)stream;
+  // warm the kernels (function attributes must be set outside capture)
+  TRY(run_stage(m, d, MJH_STAGE_STEP, s));
+  HIPCHK(hipStreamSynchronize(s));
+  hipGraph_t graph;
+  HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+  int rc = run_stage(m, d, MJH_STAGE_STEP, s);
+  hipError_t e = hipStreamEndCapture(s, &graph);
+  if (rc != MJH_OK) return rc;
+  HIPCHK(e);
+  hipGraphExec_t exec;
+  HIPCHK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+  hipGraphDestroy(graph);
+  *graph_exec_out = (void*)exec;
+  return MJH_OK;
+}
+int mjh_graph_launch(void* graph_exec, void* stream) {
+  HIPCHK(hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)stream));
+  return MJH_OK;
+}
+int mjh_graph_destroy(void* graph_exec) {
+  HIPCHK(hipGraphExecDestroy((hipGraphExec_t)graph_exec));
+  return MJH_OK;
+}
+
+int mjh_timed_steps(const MjhModel* m, const MjhData* d, int nstep, int step0, float noise_std, float noise_rate,
+                    void* stream, float* ms_out, float* per_kernel_ms) {
+  TRY(check(m, d));
+  hipStream_t s = (hipStream_t)stream;
+  Instr instr;
+  instr.s = s;
+  instr.on = per_kernel_ms != nullptr;
+  g_instr = &instr;
+  hipEvent_t t0, t1;
+  hipEventCreate(&t0);
+  hipEventCreate(&t1);
+  hipEventRecord(t0, s);
+  int rc = MJH_OK;
+  for (int i = 0; i < nstep && rc == MJH_OK; ++i) {
+    if (noise_std >= 0.0f) rc = mjh_ctrl_noise(m, d, nullptr, step0 + i, noise_std, noise_rate, stream);
+    if (rc == MJH_OK) rc = run_stage(m, d, MJH_STAGE_STEP, s);
+  }
+  hipEventRecord(t1, s);
+  hipError_t e = hipEventSynchronize(t1);
+  g_instr = nullptr;
+  float ms = 0.0f;
+  hipEventElapsedTime(&ms, t0, t1);
+  if (ms_out) *ms_out = ms;
+  if (per_kernel_ms) {
+    for (int k = 0; k < MJH_NKERNEL; ++k) per_kernel_ms[k] = 0.0f;
+    for (size_t i = 0; i < instr.cls.size(); ++i) {
+      float t = 0.0f;
+      hipEventElapsedTime(&t, instr.ev[2 * i], instr.ev[2 * i + 1]);
+      per_kernel_ms[instr.cls[i]] += t;
+      hipEventDestroy(instr.ev[2 * i]);
+      hipEventDestroy(instr.ev[2 * i + 1]);
+    }
+  }
+  hipEventDestroy(t0);
+  hipEventDestroy(t1);
+  if (rc != MJH_OK) return rc;
+  HIPCHK(e);
+  HIPCHK(hipGetLastError());
+  return MJH_OK;
+}
+
+}  // extern "C"

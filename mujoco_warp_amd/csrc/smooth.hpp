@@ -1,0 +1,677 @@
+// smooth.hpp -- position- and velocity-dependent smooth dynamics, one lane group per world.
+//
+//   k_fwd_pos : kinematics -> com_pos -> crb -> (factor_m)      reference smooth.py:46-226, 686-855, 1029-1098, 1183-1232
+//   k_fwd_vel : com_vel -> passive -> rne -> actuation -> fwd_acceleration (factor + solve)
+//               reference smooth.py:2179-2285, 1353-1515, passive.py:74-306, forward.py:680-702, 756-1149, 1255-1324
+//
+// MI355X mapping: the whole per-world pipeline runs out of one LDS slice (qpos row staged with a
+// coalesced load, all intermediates LDS-resident, every API-visible array written back with
+// group-contiguous 128 B stores).  Tree recursions are restated so that no level-by-level launches and
+// no atomics are needed: subtree sums use the depth-first contiguity of MuJoCo body ids
+// (body_subtreenum), chain sums (cvel, cacc) walk the dof-ancestor row of the CSR M-structure.
+#pragma once
+#include "dev_common.hpp"
+
+// block-shared copy of the M-structure (read by every world of the block in factor/solve loops)
+struct MStruct {
+  const int* rowadr;
+  const int* rownnz;
+  const int* colind;
+};
+
+template <int G>
+DEV MStruct load_mstruct(const MjhModel& m, int* sh) {
+  // cooperative (whole block) copy of M_rowadr | M_rownnz | M_colind into LDS; ends with __syncthreads
+  int nv = m.nv, nC = m.nC;
+  for (int i = threadIdx.x; i < nv; i += blockDim.x) {
+    sh[i] = m.M_rowadr[i];
+    sh[nv + i] = m.M_rownnz[i];
+  }
+  for (int i = threadIdx.x; i < nC; i += blockDim.x) sh[2 * nv + i] = m.M_colind[i];
+  __syncthreads();
+  return MStruct{sh, sh + nv, sh + 2 * nv};
+}
+__host__ __device__ inline int mstruct_ints(int nv, int nC) { return ((2 * nv + nC + 3) / 4) * 4; }
+
+// sparse L'DL factorisation in LDS (reference smooth.py:1183-1232 _qLD_acc/_qLDiag_div == MuJoCo mj_factorI).
+// L holds a copy of M on entry.  Row k is eliminated sequentially (leaf to root); the updates of its
+// ancestor rows are spread over the lanes (one ancestor row per lane, no write conflicts).
+template <int G>
+DEV void factor_ld(const MStruct& ms, float* L, float* dinv, int nv, int lig) {
+  for (int k = nv - 1; k >= 0; --k) {
+    const int start = ms.rowadr[k], n = ms.rownnz[k], diag = start + n - 1;
+    const float dk = L[diag];
+    for (int a = lig; a < n - 1; a += G) {
+      const float t = L[start + a] / dk;
+      const int ai = ms.rowadr[ms.colind[start + a]];
+      for (int j = 0; j <= a; ++j) L[ai + j] -= L[start + j] * t;
+    }
+    gsync();
+    for (int a = lig; a < n - 1; a += G) L[start + a] = L[start + a] / dk;
+    if (lig == 0) dinv[k] = 1.0f / dk;
+  }
+  gsync();
+}
+
+// x <- (L' D L)^-1 x in LDS (reference solve_LD smooth.py:3187 == MuJoCo mj_solveLD)
+template <int G>
+DEV void solve_ld(const MjhModel& m, const MStruct& ms, const float* L, const float* dinv, float* x, int nv, int lig) {
+  for (int k = nv - 1; k >= 0; --k) {  // x <- L^-T x
+    const int start = ms.rowadr[k], n = ms.rownnz[k];
+    const float xk = x[k];
+    for (int a = lig; a < n - 1; a += G) x[ms.colind[start + a]] -= L[start + a] * xk;
+    gsync();
+  }
+  for (int i = lig; i < nv; i += G) x[i] *= dinv[i];
+  gsync();
+  for (int l = 1; l < m.ndoflevel; ++l) {  // x <- L^-1 x, level by level down the dof tree
+    const int beg = m.dof_leveladr[l], end = m.dof_leveladr[l + 1];
+    for (int idx = beg + lig; idx < end; idx += G) {
+      const int k = m.dof_tree[idx];
+      const int start = ms.rowadr[k], n = ms.rownnz[k];
+      float s = x[k];
+      for (int a = 0; a < n - 1; ++a) s -= L[start + a] * x[ms.colind[start + a]];
+      x[k] = s;
+    }
+    gsync();
+  }
+}
+
+// res = M * vec (support.py:154 mul_m); M CSR in LDS or global, vec/res in LDS
+template <int G>
+DEV void mul_m_ld(const MStruct& ms, const float* M, const float* vec, float* res, int nv, int lig) {
+  // row part (ancestors + diagonal) ...
+  for (int i = lig; i < nv; i += G) {
+    const int start = ms.rowadr[i], n = ms.rownnz[i];
+    float s = 0.0f;
+    for (int a = 0; a < n; ++a) s += M[start + a] * vec[ms.colind[start + a]];
+    res[i] = s;
+  }
+  gsync();
+  // ... plus the symmetric column part, scattered sequentially per descendant row (deterministic)
+  for (int k = 0; k < nv; ++k) {
+    const int start = ms.rowadr[k], n = ms.rownnz[k];
+    const float vk = vec[k];
+    for (int a = lig; a < n - 1; a += G) res[ms.colind[start + a]] += M[start + a] * vk;
+    gsync();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+struct PosLayout {
+  int qpos, xpos, xquat, xmat, xipos, ximat, xanchor, xaxis, scom, cinert, cdof, crb, M, L, dinv, total;
+};
+__host__ __device__ inline PosLayout pos_layout(int nq, int nv, int nbody, int njnt, int nC) {
+  PosLayout p;
+  int o = 0;
+  p.qpos = o; o += nq;
+  p.xpos = o; o += 3 * nbody;
+  p.xquat = o; o += 4 * nbody;
+  p.xmat = o; o += 9 * nbody;
+  p.xipos = o; o += 3 * nbody;
+  p.ximat = o; o += 9 * nbody;
+  p.xanchor = o; o += 3 * njnt;
+  p.xaxis = o; o += 3 * njnt;
+  p.scom = o; o += 3 * nbody;
+  p.cinert = o; o += 10 * nbody;
+  p.cdof = o; o += 6 * nv;
+  p.crb = o; o += 10 * nbody;
+  p.M = o; o += nC;
+  p.L = o; o += nC;
+  p.dinv = o; o += nv;
+  p.total = ((o + 3) / 4) * 4 + 1;  // odd-ish stride keeps worlds of one wave on different banks
+  return p;
+}
+
+enum { POS_KINEMATICS = 0, POS_COM = 1, POS_CRB = 2, POS_FACTOR = 3 };
+
+template <int G>
+__global__ void __launch_bounds__(256) k_fwd_pos(MjhModel m, MjhData d, int first, int last) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int nq = m.nq, nv = m.nv, nbody = m.nbody, njnt = m.njnt, nC = m.nC;
+  const PosLayout lay = pos_layout(nq, nv, nbody, njnt, nC);
+  int* shi = reinterpret_cast<int*>(smem);
+  const MStruct ms = load_mstruct<G>(m, shi);
+  const int lig = threadIdx.x & (G - 1), gib = threadIdx.x / G;
+  const int w = blockIdx.x * (blockDim.x / G) + gib;
+  if (w >= d.nworld) return;
+  float* S = smem + mstruct_ints(nv, nC) + (size_t)gib * lay.total;
+  float *qpos = S + lay.qpos, *xpos = S + lay.xpos, *xquat = S + lay.xquat, *xmat = S + lay.xmat, *xipos = S + lay.xipos,
+        *ximat = S + lay.ximat, *xanchor = S + lay.xanchor, *xaxis = S + lay.xaxis, *scom = S + lay.scom,
+        *cinert = S + lay.cinert, *cdof = S + lay.cdof, *crb = S + lay.crb, *M = S + lay.M, *L = S + lay.L,
+        *dinv = S + lay.dinv;
+
+  // ---- kinematics (smooth.py:46-226) ---------------------------------------------------------------
+  if (first <= POS_KINEMATICS) {
+    gcopy<G>(qpos, d.qpos + (size_t)w * nq, nq, lig);
+    gsync();
+    const float* qpos0 = bf(m.qpos0, m.qpos0_nb, w, nq);
+    const float* body_pos = bf(m.body_pos, m.body_pos_nb, w, 3 * nbody);
+    const float* body_quat = bf(m.body_quat, m.body_quat_nb, w, 4 * nbody);
+    const float* jnt_pos = bf(m.jnt_pos, m.jnt_pos_nb, w, 3 * njnt);
+    const float* jnt_axis = bf(m.jnt_axis, m.jnt_axis_nb, w, 3 * njnt);
+    for (int l = 0; l < m.nbodylevel; ++l) {
+      const int beg = m.body_leveladr[l], end = m.body_leveladr[l + 1];
+      for (int idx = beg + lig; idx < end; idx += G) {
+        const int b = m.body_tree[idx];
+        if (b == 0) {
+          st3(xpos, V3{0, 0, 0});
+          st4(xquat, Q4{1, 0, 0, 0});
+          continue;
+        }
+        const int pid = m.body_parentid[b], jntadr = m.body_jntadr[b], jntnum = m.body_jntnum[b];
+        if (jntnum == 1 && m.jnt_type[jntadr] == JNT_FREE) {
+          const int qa = m.jnt_qposadr[jntadr];
+          V3 p = ld3(qpos + qa);
+          Q4 q = quat_normalize(ld4(qpos + qa + 3));
+          st3(xpos + 3 * b, p);
+          st4(xquat + 4 * b, q);
+          st3(xanchor + 3 * jntadr, p);
+          st3(xaxis + 3 * jntadr, ld3(jnt_axis + 3 * jntadr));
+          continue;
+        }
+        Q4 pq = ld4(xquat + 4 * pid);
+        V3 pos = rot_vec_quat(ld3(body_pos + 3 * b), pq) + ld3(xpos + 3 * pid);
+        Q4 quat = mul_quat(pq, ld4(body_quat + 4 * b));
+        for (int j = jntadr; j < jntadr + jntnum; ++j) {
+          const int qa = m.jnt_qposadr[j], t = m.jnt_type[j];
+          V3 jp = ld3(jnt_pos + 3 * j), ja = ld3(jnt_axis + 3 * j);
+          V3 anchor = rot_vec_quat(jp, quat) + pos;
+          V3 axis = rot_vec_quat(ja, quat);
+          if (t == JNT_BALL) {
+            quat = mul_quat(quat, quat_normalize(ld4(qpos + qa)));
+            pos = anchor - rot_vec_quat(jp, quat);
+          } else if (t == JNT_SLIDE) {
+            pos = pos + axis * (qpos[qa] - qpos0[qa]);
+          } else if (t == JNT_HINGE) {
+            quat = mul_quat(quat, axis_angle_to_quat(ja, qpos[qa] - qpos0[qa]));
+            pos = anchor - rot_vec_quat(jp, quat);
+          }
+          st3(xanchor + 3 * j, anchor);
+          st3(xaxis + 3 * j, axis);
+        }
+        st3(xpos + 3 * b, pos);
+        st4(xquat + 4 * b, quat_normalize(quat));
+      }
+      gsync();
+    }
+    const float* body_ipos = bf(m.body_ipos, m.body_ipos_nb, w, 3 * nbody);
+    const float* body_iquat = bf(m.body_iquat, m.body_iquat_nb, w, 4 * nbody);
+    for (int b = lig; b < nbody; b += G) {
+      Q4 q = ld4(xquat + 4 * b);
+      quat_to_mat(q, xmat + 9 * b);
+      st3(xipos + 3 * b, ld3(xpos + 3 * b) + rot_vec_quat(ld3(body_ipos + 3 * b), q));
+      quat_to_mat(mul_quat(q, ld4(body_iquat + 4 * b)), ximat + 9 * b);
+    }
+    {  // geoms and sites go straight to HBM (consumed by the collision kernel)
+      const float* geom_pos = bf(m.geom_pos, m.geom_pos_nb, w, 3 * m.ngeom);
+      const float* geom_quat = bf(m.geom_quat, m.geom_quat_nb, w, 4 * m.ngeom);
+      for (int g = lig; g < m.ngeom; g += G) {
+        const int b = m.geom_bodyid[g];
+        Q4 q = ld4(xquat + 4 * b);
+        float mat[9];
+        st3(d.geom_xpos + ((size_t)w * m.ngeom + g) * 3, ld3(xpos + 3 * b) + rot_vec_quat(ld3(geom_pos + 3 * g), q));
+        quat_to_mat(mul_quat(q, ld4(geom_quat + 4 * g)), mat);
+        float* out = d.geom_xmat + ((size_t)w * m.ngeom + g) * 9;
+        for (int k = 0; k < 9; ++k) out[k] = mat[k];
+      }
+      const float* site_pos = bf(m.site_pos, m.site_pos_nb, w, 3 * m.nsite);
+      const float* site_quat = bf(m.site_quat, m.site_quat_nb, w, 4 * m.nsite);
+      for (int s = lig; s < m.nsite; s += G) {
+        const int b = m.site_bodyid[s];
+        Q4 q = ld4(xquat + 4 * b);
+        float mat[9];
+        st3(d.site_xpos + ((size_t)w * m.nsite + s) * 3, ld3(xpos + 3 * b) + rot_vec_quat(ld3(site_pos + 3 * s), q));
+        quat_to_mat(mul_quat(q, ld4(site_quat + 4 * s)), mat);
+        float* out = d.site_xmat + ((size_t)w * m.nsite + s) * 9;
+        for (int k = 0; k < 9; ++k) out[k] = mat[k];
+      }
+    }
+    gsync();
+    gcopy<G>(d.xpos + (size_t)w * 3 * nbody, xpos, 3 * nbody, lig);
+    gcopy<G>(d.xquat + (size_t)w * 4 * nbody, xquat, 4 * nbody, lig);
+    gcopy<G>(d.xmat + (size_t)w * 9 * nbody, xmat, 9 * nbody, lig);
+    gcopy<G>(d.xipos + (size_t)w * 3 * nbody, xipos, 3 * nbody, lig);
+    gcopy<G>(d.ximat + (size_t)w * 9 * nbody, ximat, 9 * nbody, lig);
+    gcopy<G>(d.xanchor + (size_t)w * 3 * njnt, xanchor, 3 * njnt, lig);
+    gcopy<G>(d.xaxis + (size_t)w * 3 * njnt, xaxis, 3 * njnt, lig);
+  }
+  if (last < POS_COM) return;
+
+  // ---- com_pos (smooth.py:686-822) -------------------------------------------------------------------
+  if (first <= POS_COM) {
+    if (first == POS_COM) {
+      gcopy<G>(xmat, d.xmat + (size_t)w * 9 * nbody, 9 * nbody, lig);
+      gcopy<G>(xipos, d.xipos + (size_t)w * 3 * nbody, 3 * nbody, lig);
+      gcopy<G>(ximat, d.ximat + (size_t)w * 9 * nbody, 9 * nbody, lig);
+      gcopy<G>(xanchor, d.xanchor + (size_t)w * 3 * njnt, 3 * njnt, lig);
+      gcopy<G>(xaxis, d.xaxis + (size_t)w * 3 * njnt, 3 * njnt, lig);
+      gsync();
+    }
+    const float* body_mass = bf(m.body_mass, m.body_mass_nb, w, nbody);
+    const float* body_subtreemass = bf(m.body_subtreemass, m.body_subtreemass_nb, w, nbody);
+    const float* body_inertia = bf(m.body_inertia, m.body_inertia_nb, w, 3 * nbody);
+    for (int b = lig; b < nbody; b += G) {  // subtree = contiguous id range (depth-first numbering)
+      V3 s = V3{0, 0, 0};
+      const int end = b + m.body_subtreenum[b];
+      for (int c = b; c < end; ++c) s = s + ld3(xipos + 3 * c) * body_mass[c];
+      const float mass = body_subtreemass[b];
+      if (mass != 0.0f) s = s * (1.0f / mass);
+      st3(scom + 3 * b, s);
+    }
+    gsync();
+    for (int b = lig; b < nbody; b += G) {  // _cinert smooth.py:733
+      const float* mat = ximat + 9 * b;
+      V3 in = ld3(body_inertia + 3 * b);
+      const float mass = body_mass[b];
+      V3 dif = ld3(xipos + 3 * b) - ld3(scom + 3 * m.body_rootid[b]);
+      float t00 = mat[0] * in.x * mat[0] + mat[1] * in.y * mat[1] + mat[2] * in.z * mat[2];
+      float t11 = mat[3] * in.x * mat[3] + mat[4] * in.y * mat[4] + mat[5] * in.z * mat[5];
+      float t22 = mat[6] * in.x * mat[6] + mat[7] * in.y * mat[7] + mat[8] * in.z * mat[8];
+      float t01 = mat[0] * in.x * mat[3] + mat[1] * in.y * mat[4] + mat[2] * in.z * mat[5];
+      float t02 = mat[0] * in.x * mat[6] + mat[1] * in.y * mat[7] + mat[2] * in.z * mat[8];
+      float t12 = mat[3] * in.x * mat[6] + mat[4] * in.y * mat[7] + mat[5] * in.z * mat[8];
+      float* r = cinert + 10 * b;
+      r[0] = t00 + mass * (dif.y * dif.y + dif.z * dif.z);
+      r[1] = t11 + mass * (dif.x * dif.x + dif.z * dif.z);
+      r[2] = t22 + mass * (dif.x * dif.x + dif.y * dif.y);
+      r[3] = t01 - mass * dif.x * dif.y;
+      r[4] = t02 - mass * dif.x * dif.z;
+      r[5] = t12 - mass * dif.y * dif.z;
+      r[6] = mass * dif.x;
+      r[7] = mass * dif.y;
+      r[8] = mass * dif.z;
+      r[9] = mass;
+    }
+    for (int j = lig; j < njnt; j += G) {  // _cdof smooth.py:779
+      const int b = m.jnt_bodyid[j], t = m.jnt_type[j];
+      int dof = m.jnt_dofadr[j];
+      const float* xm = xmat + 9 * b;
+      V3 off = ld3(scom + 3 * m.body_rootid[b]) - ld3(xanchor + 3 * j);
+      if (t == JNT_FREE || t == JNT_BALL) {
+        if (t == JNT_FREE) {
+          for (int k = 0; k < 3; ++k) {
+            float* c = cdof + 6 * (dof + k);
+            c[0] = c[1] = c[2] = 0.0f;
+            c[3] = k == 0 ? 1.0f : 0.0f;
+            c[4] = k == 1 ? 1.0f : 0.0f;
+            c[5] = k == 2 ? 1.0f : 0.0f;
+          }
+          dof += 3;
+        }
+        for (int k = 0; k < 3; ++k) {
+          V3 ax = V3{xm[k], xm[3 + k], xm[6 + k]};
+          st3(cdof + 6 * (dof + k), ax);
+          st3(cdof + 6 * (dof + k) + 3, cross(ax, off));
+        }
+      } else if (t == JNT_SLIDE) {
+        st3(cdof + 6 * dof, V3{0, 0, 0});
+        st3(cdof + 6 * dof + 3, ld3(xaxis + 3 * j));
+      } else {
+        V3 ax = ld3(xaxis + 3 * j);
+        st3(cdof + 6 * dof, ax);
+        st3(cdof + 6 * dof + 3, cross(ax, off));
+      }
+    }
+    gsync();
+    gcopy<G>(d.subtree_com + (size_t)w * 3 * nbody, scom, 3 * nbody, lig);
+    gcopy<G>(d.cinert + (size_t)w * 10 * nbody, cinert, 10 * nbody, lig);
+    gcopy<G>(d.cdof + (size_t)w * 6 * nv, cdof, 6 * nv, lig);
+  }
+  if (last < POS_CRB) return;
+
+  // ---- crb (smooth.py:1029-1098) -----------------------------------------------------------------------
+  if (first <= POS_CRB) {
+    if (first == POS_CRB) {
+      gcopy<G>(cinert, d.cinert + (size_t)w * 10 * nbody, 10 * nbody, lig);
+      gcopy<G>(cdof, d.cdof + (size_t)w * 6 * nv, 6 * nv, lig);
+      gsync();
+    }
+    for (int b = lig; b < nbody; b += G) {
+      float acc[10];
+      for (int k = 0; k < 10; ++k) acc[k] = cinert[10 * b + k];
+      if (b > 0) {
+        const int end = b + m.body_subtreenum[b];
+        for (int c = b + 1; c < end; ++c)
+          for (int k = 0; k < 10; ++k) acc[k] += cinert[10 * c + k];
+      }
+      for (int k = 0; k < 10; ++k) crb[10 * b + k] = acc[k];
+    }
+    gsync();
+    const float* armature = bf(m.dof_armature, m.dof_armature_nb, w, nv);
+    for (int i = lig; i < nv; i += G) {  // _M smooth.py:1048
+      int adr = ms.rowadr[i] + ms.rownnz[i] - 1;
+      float buf[6], ci[6];
+      for (int k = 0; k < 6; ++k) ci[k] = cdof[6 * i + k];
+      inert_vec(crb + 10 * m.dof_bodyid[i], ci, buf);
+      int j = i;
+      float arm = armature[i];
+      while (j >= 0) {
+        float s = 0.0f;
+        for (int k = 0; k < 6; ++k) s += cdof[6 * j + k] * buf[k];
+        M[adr] = s + arm;
+        arm = 0.0f;
+        --adr;
+        j = m.dof_parentid[j];
+      }
+    }
+    gsync();
+    gcopy<G>(d.crb + (size_t)w * 10 * nbody, crb, 10 * nbody, lig);
+    gcopy<G>(d.M + (size_t)w * nC, M, nC, lig);
+  }
+  if (last < POS_FACTOR) return;
+
+  // ---- factor_m (smooth.py:1183-1232) -----------------------------------------------------------------
+  if (first == POS_FACTOR) gcopy<G>(L, d.M + (size_t)w * nC, nC, lig);
+  else gcopy<G>(L, M, nC, lig);
+  gsync();
+  factor_ld<G>(ms, L, dinv, nv, lig);
+  gcopy<G>(d.qLD + (size_t)w * nC, L, nC, lig);
+  gcopy<G>(d.qLDiagInv + (size_t)w * nv, dinv, nv, lig);
+}
+
+// ---------------------------------------------------------------------------------------------------
+struct VelLayout {
+  int qpos, qvel, cdof, cinert, cvel, cdof_dot, cacc, cfrc, cfi, uforce, fspring, fdamper, fgrav, fpassive, fbias, factuator, x, L, dinv, total;
+};
+__host__ __device__ inline VelLayout vel_layout(int nq, int nv, int nbody, int nC, int nu) {
+  VelLayout p;
+  int o = 0;
+  p.qpos = o; o += nq;
+  p.qvel = o; o += nv;
+  p.cdof = o; o += 6 * nv;
+  p.cinert = o; o += 10 * nbody;
+  p.cvel = o; o += 6 * nbody;
+  p.cdof_dot = o; o += 6 * nv;
+  p.cacc = o; o += 6 * nbody;
+  p.cfrc = o; o += 6 * nbody;
+  p.cfi = o; o += 6 * nbody;
+  p.uforce = o; o += nu;
+  p.fspring = o; o += nv;
+  p.fdamper = o; o += nv;
+  p.fgrav = o; o += nv;
+  p.fpassive = o; o += nv;
+  p.fbias = o; o += nv;
+  p.factuator = o; o += nv;
+  p.x = o; o += nv;
+  p.L = o; o += nC;
+  p.dinv = o; o += nv;
+  p.total = ((o + 3) / 4) * 4 + 1;
+  return p;
+}
+
+enum { VEL_COMVEL = 0, VEL_PASSIVE = 1, VEL_RNE = 2, VEL_ACTUATION = 3, VEL_ACCEL = 4 };
+
+// J^T f contribution of a Cartesian wrench applied at `point` on body b to dof i (support.py:259-322, 488-533)
+DEV float jac_dot(const MjhModel& m, const float* cdof_i, V3 offset, V3 force, V3 torque) {
+  V3 ang = ld3(cdof_i), lin = ld3(cdof_i + 3);
+  return dot(lin + cross(ang, offset), force) + dot(ang, torque);
+}
+
+template <int G>
+__global__ void __launch_bounds__(256) k_fwd_vel(MjhModel m, MjhData d, int first, int last) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int nq = m.nq, nv = m.nv, nbody = m.nbody, njnt = m.njnt, nC = m.nC, nu = m.nu;
+  const VelLayout lay = vel_layout(nq, nv, nbody, nC, nu);
+  int* shi = reinterpret_cast<int*>(smem);
+  const MStruct ms = load_mstruct<G>(m, shi);
+  const int lig = threadIdx.x & (G - 1), gib = threadIdx.x / G;
+  const int w = blockIdx.x * (blockDim.x / G) + gib;
+  if (w >= d.nworld) return;
+  float* S = smem + mstruct_ints(nv, nC) + (size_t)gib * lay.total;
+  float *qpos = S + lay.qpos, *qvel = S + lay.qvel, *cdof = S + lay.cdof, *cinert = S + lay.cinert, *cvel = S + lay.cvel,
+        *cdof_dot = S + lay.cdof_dot, *cacc = S + lay.cacc, *cfrc = S + lay.cfrc, *cfi = S + lay.cfi, *uforce = S + lay.uforce,
+        *fspring = S + lay.fspring,
+        *fdamper = S + lay.fdamper, *fgrav = S + lay.fgrav, *fpassive = S + lay.fpassive, *fbias = S + lay.fbias,
+        *factuator = S + lay.factuator, *x = S + lay.x, *L = S + lay.L, *dinv = S + lay.dinv;
+  const int dsbl = m.disableflags;
+
+  gcopy<G>(qpos, d.qpos + (size_t)w * nq, nq, lig);
+  gcopy<G>(qvel, d.qvel + (size_t)w * nv, nv, lig);
+  gcopy<G>(cdof, d.cdof + (size_t)w * 6 * nv, 6 * nv, lig);
+  if (first <= VEL_RNE && last >= VEL_RNE) gcopy<G>(cinert, d.cinert + (size_t)w * 10 * nbody, 10 * nbody, lig);
+  gsync();
+
+  // ---- com_vel (smooth.py:2179-2258) + actuator_velocity (forward.py:680-702) ---------------------------
+  if (first <= VEL_COMVEL) {
+    // cdof_dot[i] = cvel_before(i) x cdof[i]; cvel_before = sum over dof-ancestors outside i's own
+    // rotational triple, accumulated root -> leaf exactly like the sequential recursion
+    for (int i = lig; i < nv; i += G) {
+      const int start = ms.rowadr[i], n = ms.rownnz[i];
+      const int grp = m.dof_grpadr[i];
+      const int jt = m.jnt_type[m.dof_jntid[i]];
+      float cv[6] = {0, 0, 0, 0, 0, 0};
+      for (int a = 0; a < n - 1; ++a) {
+        const int j = ms.colind[start + a];
+        if (j >= grp) break;
+        const float qv = qvel[j];
+        for (int k = 0; k < 6; ++k) cv[k] += cdof[6 * j + k] * qv;
+      }
+      float r[6];
+      const bool free_trans = (jt == JNT_FREE) && (i - m.jnt_dofadr[m.dof_jntid[i]] < 3);
+      if (free_trans) {
+        for (int k = 0; k < 6; ++k) r[k] = 0.0f;
+      } else {
+        float ci[6];
+        for (int k = 0; k < 6; ++k) ci[k] = cdof[6 * i + k];
+        motion_cross(cv, ci, r);
+      }
+      for (int k = 0; k < 6; ++k) cdof_dot[6 * i + k] = r[k];
+    }
+    for (int b = lig; b < nbody; b += G) {
+      float cv[6] = {0, 0, 0, 0, 0, 0};
+      const int ld = m.body_lastdof[b];
+      if (ld >= 0) {
+        const int start = ms.rowadr[ld], n = ms.rownnz[ld];
+        for (int a = 0; a < n; ++a) {
+          const int j = ms.colind[start + a];
+          const float qv = qvel[j];
+          for (int k = 0; k < 6; ++k) cv[k] += cdof[6 * j + k] * qv;
+        }
+      }
+      for (int k = 0; k < 6; ++k) cvel[6 * b + k] = cv[k];
+    }
+    const float* gear = bf(m.actuator_gear, m.actuator_gear_nb, w, 6 * nu);
+    for (int u = lig; u < nu; u += G)
+      d.actuator_velocity[(size_t)w * nu + u] = gear[6 * u] * qvel[m.jnt_dofadr[m.actuator_trnid[2 * u]]];
+    gsync();
+    gcopy<G>(d.cvel + (size_t)w * 6 * nbody, cvel, 6 * nbody, lig);
+    gcopy<G>(d.cdof_dot + (size_t)w * 6 * nv, cdof_dot, 6 * nv, lig);
+  }
+  if (last < VEL_PASSIVE) return;
+
+  // ---- passive (passive.py:74-210 spring/damper, 275-306 gravcomp, 631-668 sum) --------------------------
+  if (first <= VEL_PASSIVE) {
+    const float* stiff = bf(m.jnt_stiffness, m.jnt_stiffness_nb, w, njnt);
+    const float* damp = bf(m.dof_damping, m.dof_damping_nb, w, nv);
+    const float* qspring = bf(m.qpos_spring, m.qpos_spring_nb, w, nq);
+    for (int i = lig; i < nv; i += G) {
+      fspring[i] = 0.0f;
+      fgrav[i] = 0.0f;
+      fdamper[i] = (dsbl & DSBL_DAMPER) ? 0.0f : -damp[i] * qvel[i];
+    }
+    gsync();
+    if (!(dsbl & DSBL_SPRING)) {
+      for (int j = lig; j < njnt; j += G) {
+        const float k = stiff[j];
+        if (k == 0.0f) continue;
+        const int dof = m.jnt_dofadr[j], qa = m.jnt_qposadr[j], t = m.jnt_type[j];
+        if (t == JNT_FREE) {
+          for (int c = 0; c < 3; ++c) fspring[dof + c] = -k * (qpos[qa + c] - qspring[qa + c]);
+          V3 dif = quat_sub(quat_normalize(ld4(qpos + qa + 3)), ld4(qspring + qa + 3));
+          st3(fspring + dof + 3, dif * (-k));
+        } else if (t == JNT_BALL) {
+          V3 dif = quat_sub(quat_normalize(ld4(qpos + qa)), ld4(qspring + qa));
+          st3(fspring + dof, dif * (-k));
+        } else {
+          fspring[dof] = -k * (qpos[qa] - qspring[qa]);
+        }
+      }
+    }
+    if (!(dsbl & DSBL_GRAVITY)) {
+      const float* gcomp = bf(m.body_gravcomp, m.body_gravcomp_nb, w, nbody);
+      const float* mass = bf(m.body_mass, m.body_mass_nb, w, nbody);
+      const float* grav = bf(m.opt_gravity, m.opt_gravity_nb, w, 3);
+      const int nw = (nv + 31) / 32;
+      for (int b = 1; b < nbody; ++b) {
+        const float gc = gcomp[b];
+        if (gc == 0.0f) continue;
+        V3 force = ld3(grav) * (-mass[b] * gc);
+        V3 off = ld3(d.xipos + ((size_t)w * nbody + b) * 3) - ld3(d.subtree_com + ((size_t)w * nbody + m.body_rootid[b]) * 3);
+        for (int i = lig; i < nv; i += G)
+          if (m.body_dofmask[b * nw + (i >> 5)] & (1u << (i & 31))) fgrav[i] += jac_dot(m, cdof + 6 * i, off, force, V3{0, 0, 0});
+      }
+    }
+    gsync();
+    for (int i = lig; i < nv; i += G) fpassive[i] = fspring[i] + fdamper[i] + fgrav[i];
+    gsync();
+    gcopy<G>(d.qfrc_spring + (size_t)w * nv, fspring, nv, lig);
+    gcopy<G>(d.qfrc_damper + (size_t)w * nv, fdamper, nv, lig);
+    gcopy<G>(d.qfrc_gravcomp + (size_t)w * nv, fgrav, nv, lig);
+    gcopy<G>(d.qfrc_passive + (size_t)w * nv, fpassive, nv, lig);
+  }
+  if (last < VEL_RNE) return;
+
+  // ---- rne (smooth.py:1353-1515) -------------------------------------------------------------------------
+  if (first <= VEL_RNE) {
+    if (first == VEL_RNE) {
+      gcopy<G>(cvel, d.cvel + (size_t)w * 6 * nbody, 6 * nbody, lig);
+      gcopy<G>(cdof_dot, d.cdof_dot + (size_t)w * 6 * nv, 6 * nv, lig);
+      gsync();
+    }
+    const float* grav = bf(m.opt_gravity, m.opt_gravity_nb, w, 3);
+    for (int b = lig; b < nbody; b += G) {
+      float ca[6] = {0, 0, 0, 0, 0, 0};
+      if (!(dsbl & DSBL_GRAVITY)) {
+        ca[3] = -grav[0];
+        ca[4] = -grav[1];
+        ca[5] = -grav[2];
+      }
+      const int ld = m.body_lastdof[b];
+      if (ld >= 0) {
+        const int start = ms.rowadr[ld], n = ms.rownnz[ld];
+        for (int a = 0; a < n; ++a) {
+          const int j = ms.colind[start + a];
+          const float qv = qvel[j];
+          for (int k = 0; k < 6; ++k) ca[k] += cdof_dot[6 * j + k] * qv;
+        }
+      }
+      for (int k = 0; k < 6; ++k) cacc[6 * b + k] = ca[k];
+      float f[6] = {0, 0, 0, 0, 0, 0};
+      if (b > 0) {
+        float cv[6], iv[6], f1[6], f2[6];
+        for (int k = 0; k < 6; ++k) cv[k] = cvel[6 * b + k];
+        inert_vec(cinert + 10 * b, ca, f1);
+        inert_vec(cinert + 10 * b, cv, iv);
+        motion_cross_force(cv, iv, f2);
+        for (int k = 0; k < 6; ++k) f[k] = f1[k] + f2[k];
+      }
+      for (int k = 0; k < 6; ++k) cfrc[6 * b + k] = f[k];
+    }
+    gsync();
+    // backward accumulation (smooth.py:1459) restated as a subtree-range sum over depth-first body ids
+    for (int b = lig; b < nbody; b += G) {
+      float acc[6] = {0, 0, 0, 0, 0, 0};
+      const int end = b + m.body_subtreenum[b];
+      for (int c = (b == 0 ? 1 : b); c < end; ++c)
+        for (int k = 0; k < 6; ++k) acc[k] += cfrc[6 * c + k];
+      for (int k = 0; k < 6; ++k) cfi[6 * b + k] = acc[k];
+    }
+    gsync();
+    for (int i = lig; i < nv; i += G) {
+      const int b = m.dof_bodyid[i];
+      float s = 0.0f;
+      for (int k = 0; k < 6; ++k) s += cdof[6 * i + k] * cfi[6 * b + k];
+      fbias[i] = s;
+    }
+    gsync();
+    gcopy<G>(d.cfrc_int + (size_t)w * 6 * nbody, cfi, 6 * nbody, lig);
+    gcopy<G>(d.cacc + (size_t)w * 6 * nbody, cacc, 6 * nbody, lig);
+    gcopy<G>(d.qfrc_bias + (size_t)w * nv, fbias, nv, lig);
+  }
+  if (last < VEL_ACTUATION) return;
+
+  // ---- fwd_actuation (forward.py:756-1149; NONE/INTEGRATOR/FILTER dyn, FIXED/AFFINE gain, NONE/AFFINE bias) --
+  if (first <= VEL_ACTUATION) {
+    const float* gear = bf(m.actuator_gear, m.actuator_gear_nb, w, 6 * nu);
+    for (int u = lig; u < nu; u += G) {
+      float force = 0.0f;
+      if (!(dsbl & DSBL_ACTUATION)) {
+        float ctrl = d.ctrl[(size_t)w * nu + u];
+        if (m.actuator_ctrllimited[u] && !(dsbl & DSBL_CLAMPCTRL)) {
+          const float* cr = bf(m.actuator_ctrlrange, m.actuator_ctrlrange_nb, w, 2 * nu) + 2 * u;
+          ctrl = clampf(ctrl, cr[0], cr[1]);
+        }
+        float ctrl_act = ctrl;
+        const int dyn = m.actuator_dyntype[u];
+        if (dyn != 0) {
+          const int adr = m.actuator_actadr[u];
+          const float act = d.act[(size_t)w * m.na + adr];
+          float act_dot = 0.0f;
+          if (dyn == 1) act_dot = ctrl;
+          else if (dyn == 2 || dyn == 3) act_dot = (ctrl - act) / fmaxf(MJ_MINVAL, bf(m.actuator_dynprm, m.actuator_dynprm_nb, w, 10 * nu)[10 * u]);
+          d.act_dot[(size_t)w * m.na + adr] = act_dot;
+          ctrl_act = act;
+        }
+        const int jid = m.actuator_trnid[2 * u];
+        const float length = qpos[m.jnt_qposadr[jid]] * gear[6 * u];
+        const float velocity = gear[6 * u] * qvel[m.jnt_dofadr[jid]];
+        const float* gp = bf(m.actuator_gainprm, m.actuator_gainprm_nb, w, 10 * nu) + 10 * u;
+        const float* bp = bf(m.actuator_biasprm, m.actuator_biasprm_nb, w, 10 * nu) + 10 * u;
+        const float gain = m.actuator_gaintype[u] == 0 ? gp[0] : gp[0] + gp[1] * length + gp[2] * velocity;
+        const float bias = m.actuator_biastype[u] == 0 ? 0.0f : bp[0] + bp[1] * length + bp[2] * velocity;
+        force = gain * ctrl_act + bias;
+        if (m.actuator_forcelimited[u]) {
+          const float* fr = bf(m.actuator_forcerange, m.actuator_forcerange_nb, w, 2 * nu) + 2 * u;
+          force = clampf(force, fr[0], fr[1]);
+        }
+        d.actuator_length[(size_t)w * nu + u] = length;
+      }
+      d.actuator_force[(size_t)w * nu + u] = force;
+      uforce[u] = force;
+    }
+    // qfrc_actuator = moment^T force: gather per dof over actuators (deterministic, no atomics)
+    gsync();
+    for (int i = lig; i < nv; i += G) {
+      float s = 0.0f;
+      if (!(dsbl & DSBL_ACTUATION))
+        for (int u = 0; u < nu; ++u)
+          if (m.jnt_dofadr[m.actuator_trnid[2 * u]] == i) s += gear[6 * u] * uforce[u];
+      factuator[i] = s;
+    }
+    gsync();
+    gcopy<G>(d.qfrc_actuator + (size_t)w * nv, factuator, nv, lig);
+  }
+  if (last < VEL_ACCEL) return;
+
+  // ---- fwd_acceleration (forward.py:1255-1324): qfrc_smooth, factor(M), qacc_smooth = M^-1 qfrc_smooth -------
+  {
+    if (first == VEL_ACCEL) {
+      gcopy<G>(fpassive, d.qfrc_passive + (size_t)w * nv, nv, lig);
+      gcopy<G>(fbias, d.qfrc_bias + (size_t)w * nv, nv, lig);
+      gcopy<G>(factuator, d.qfrc_actuator + (size_t)w * nv, nv, lig);
+    }
+    gcopy<G>(L, d.M + (size_t)w * nC, nC, lig);
+    gsync();
+    for (int i = lig; i < nv; i += G) x[i] = fpassive[i] - fbias[i] + factuator[i] + d.qfrc_applied[(size_t)w * nv + i];
+    // xfrc_applied (support.py:259-322): wrench (force, torque) at xipos of each body
+    {
+      const int nw = (nv + 31) / 32;
+      for (int b = 1; b < nbody; ++b) {
+        const float* f = d.xfrc_applied + ((size_t)w * nbody + b) * 6;
+        V3 force = ld3(f), torque = ld3(f + 3);
+        if (force.x == 0.0f && force.y == 0.0f && force.z == 0.0f && torque.x == 0.0f && torque.y == 0.0f && torque.z == 0.0f) continue;
+        V3 off = ld3(d.xipos + ((size_t)w * nbody + b) * 3) - ld3(d.subtree_com + ((size_t)w * nbody + m.body_rootid[b]) * 3);
+        for (int i = lig; i < nv; i += G)
+          if (m.body_dofmask[b * nw + (i >> 5)] & (1u << (i & 31))) x[i] += jac_dot(m, cdof + 6 * i, off, force, torque);
+      }
+    }
+    gsync();
+    gcopy<G>(d.qfrc_smooth + (size_t)w * nv, x, nv, lig);
+    factor_ld<G>(ms, L, dinv, nv, lig);
+    solve_ld<G>(m, ms, L, dinv, x, nv, lig);
+    gcopy<G>(d.qacc_smooth + (size_t)w * nv, x, nv, lig);
+    gcopy<G>(d.qLD + (size_t)w * nC, L, nC, lig);
+    gcopy<G>(d.qLDiagInv + (size_t)w * nv, dinv, nv, lig);
+  }
+}

@@ -1,0 +1,162 @@
+"""Physics pipeline entry points: thin Python shims over the C ABI (include/mjhip.h).
+
+Same names and `(m, d) -> None` signatures as the reference's stage functions
+(/root/reference/mujoco_warp/__init__.py:26-101, _src/forward.py:1341-1380); every call is one launch
+sequence on torch's current HIP stream and returns without synchronising, like `wp.launch`.
+"""
+
+import ctypes
+
+import torch
+
+from . import _abi
+from . import io
+from . import types
+from .device import DeviceArray
+
+_S = _abi.DEFINES
+
+
+def _stream():
+  if not torch.cuda.is_available():
+    raise RuntimeError("mujoco_warp_amd needs an AMD GPU: no HIP device is visible (there is no CPU fallback).")
+  return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _run(stage, m, d):
+  L = _abi.lib()
+  _abi.check(L.mjh_stage(ctypes.byref(io.c_model(m)), ctypes.byref(io.c_data(d)), stage, _stream()))
+
+
+def step(m: types.Model, d: types.Data):
+  """Advance simulation by one step (reference forward.py:1368)."""
+  _run(_S["MJH_STAGE_STEP"], m, d)
+
+
+def forward(m: types.Model, d: types.Data):
+  """Forward dynamics (reference forward.py:1341)."""
+  _run(_S["MJH_STAGE_FORWARD"], m, d)
+
+
+def kinematics(m, d):
+  _run(_S["MJH_STAGE_KINEMATICS"], m, d)
+
+
+def com_pos(m, d):
+  _run(_S["MJH_STAGE_COM_POS"], m, d)
+
+
+def crb(m, d):
+  _run(_S["MJH_STAGE_CRB"], m, d)
+
+
+def factor_m(m, d):
+  _run(_S["MJH_STAGE_FACTOR_M"], m, d)
+
+
+def collision(m, d):
+  _run(_S["MJH_STAGE_COLLISION"], m, d)
+
+
+def make_constraint(m, d):
+  _run(_S["MJH_STAGE_MAKE_CONSTRAINT"], m, d)
+
+
+def transmission(m, d):
+  _run(_S["MJH_STAGE_TRANSMISSION"], m, d)
+
+
+def com_vel(m, d):
+  _run(_S["MJH_STAGE_COM_VEL"], m, d)
+
+
+def passive(m, d):
+  _run(_S["MJH_STAGE_PASSIVE"], m, d)
+
+
+def rne(m, d):
+  _run(_S["MJH_STAGE_RNE"], m, d)
+
+
+def fwd_position(m, d):
+  _run(_S["MJH_STAGE_FWD_POSITION"], m, d)
+
+
+def fwd_velocity(m, d):
+  _run(_S["MJH_STAGE_FWD_VELOCITY"], m, d)
+
+
+def fwd_actuation(m, d):
+  _run(_S["MJH_STAGE_FWD_ACTUATION"], m, d)
+
+
+def fwd_acceleration(m, d):
+  _run(_S["MJH_STAGE_FWD_ACCELERATION"], m, d)
+
+
+def solve(m, d):
+  _run(_S["MJH_STAGE_SOLVE"], m, d)
+
+
+def euler(m, d):
+  _run(_S["MJH_STAGE_EULER"], m, d)
+
+
+def implicit(m, d):
+  _run(_S["MJH_STAGE_IMPLICIT"], m, d)
+
+
+def solve_m(m, d, x: DeviceArray, y: DeviceArray):
+  """x = M^-1 y using the stored factor (reference smooth.py:3214)."""
+  L = _abi.lib()
+  _abi.check(L.mjh_solve_m(ctypes.byref(io.c_model(m)), ctypes.byref(io.c_data(d)), x.ptr, y.ptr, _stream()))
+
+
+def mul_m(m, d, res: DeviceArray, vec: DeviceArray):
+  """res = M vec (reference support.py:218)."""
+  L = _abi.lib()
+  _abi.check(L.mjh_mul_m(ctypes.byref(io.c_model(m)), ctypes.byref(io.c_data(d)), res.ptr, vec.ptr, _stream()))
+
+
+def ctrl_noise(m, d, step_index: int, noise_std: float = 0.01, noise_rate: float = 0.1, center: DeviceArray = None):
+  """Ornstein-Uhlenbeck/Halton control noise of the benchmark harness (reference cli.py:103-145)."""
+  L = _abi.lib()
+  _abi.check(L.mjh_ctrl_noise(ctypes.byref(io.c_model(m)), ctypes.byref(io.c_data(d)), center.ptr if center is not None else None,
+                              int(step_index), float(noise_std), float(noise_rate), _stream()))
+
+
+class StepGraph:
+  """hipGraph of one `step` (the reference captures step in a CUDA graph: cli.py:262-265)."""
+
+  def __init__(self, m, d):
+    self._m, self._d = m, d  # keep the buffers alive
+    self._exec = ctypes.c_void_p()
+    L = _abi.lib()
+    _abi.check(L.mjh_graph_create(ctypes.byref(io.c_model(m)), ctypes.byref(io.c_data(d)), _stream(), ctypes.byref(self._exec)))
+
+  def launch(self):
+    _abi.check(_abi.lib().mjh_graph_launch(self._exec, _stream()))
+
+  def __del__(self):
+    try:
+      if self._exec:
+        _abi.lib().mjh_graph_destroy(self._exec)
+    except Exception:
+      pass
+
+
+def timed_steps(m, d, nstep: int, step0: int = 0, noise_std: float = 0.01, noise_rate: float = 0.1, per_kernel: bool = False):
+  """Run nstep x (ctrl_noise + step) bracketed by HIP events on the launch stream.
+
+  Returns (elapsed_ms, per_kernel_ms or None); per-kernel times come from event pairs around each launch
+  and are only meaningful for profiling (the extra events perturb the total slightly).
+  """
+  L = _abi.lib()
+  ms = ctypes.c_float(0.0)
+  pk = (ctypes.c_float * _S["MJH_NKERNEL"])() if per_kernel else None
+  _abi.check(L.mjh_timed_steps(ctypes.byref(io.c_model(m)), ctypes.byref(io.c_data(d)), int(nstep), int(step0), float(noise_std),
+                               float(noise_rate), _stream(), ctypes.byref(ms), pk))
+  return ms.value, (list(pk) if per_kernel else None)
+
+
+KERNEL_NAMES = ["ctrl_noise", "fwd_pos", "collision", "make_constraint", "fwd_vel", "solve", "integrate", "other"]

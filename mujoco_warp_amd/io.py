@@ -1,0 +1,550 @@
+"""Host <-> device IO: the drop-in boundary of the engine.
+
+Mirrors /root/reference/mujoco_warp/_src/io.py: put_model 259 (validation 284-360, derived tables 495-652),
+make_data 1680, put_data 1890, get_data_into 2184, reset_data 2435, reset_data_keyframe 2797,
+override_model 2933; default sizing _default_nconmax 1284 / _default_njmax 1299 / _get_padded_sizes 1268.
+Same signatures, shapes, dtypes and error behaviour (ValueError / NotImplementedError at put/make time;
+capacity problems at run time are bits in `d.overflow`).
+"""
+
+import ctypes
+from typing import Optional
+
+import numpy as np
+
+from . import _abi
+from . import types
+from .device import DeviceArray
+
+_BATCHED_MODEL_FIELDS = [n[:-3] for n, k, p in _abi.MODEL_FIELDS if n.endswith("_nb")]
+_MODEL_PTR_FIELDS = [(n, k) for n, k, p in _abi.MODEL_FIELDS if p]
+_DATA_PTR_FIELDS = [(n, k) for n, k, p in _abi.DATA_FIELDS if p]
+
+
+def _valid_sizes():
+  return (2 + (np.arange(19) % 2)) * (2 ** (np.arange(19) // 2 + 3))
+
+
+def _default_nconmax(mjm, mjd=None):
+  vs = _valid_sizes()
+  nconmax = max(45, getattr(mjd, "ncon", 0) if mjd is not None else 0)
+  return int(nconmax) if nconmax > vs[-1] else int(vs[np.searchsorted(vs, nconmax)])
+
+
+def _default_njmax(mjm, mjd=None):
+  vs = _valid_sizes()
+  njmax = max(53, getattr(mjd, "nefc", 0) if mjd is not None else 0)
+  return int(njmax) if njmax > vs[-1] else int(vs[np.searchsorted(vs, njmax)])
+
+
+def _get_padded_sizes(nv, njmax):
+  def round_up(x, mult):
+    return ((x + mult - 1) // mult) * mult
+
+  return round_up(max(njmax, 1), 16), max(round_up(nv, 4), 4)
+
+
+def is_sparse(mjm):
+  jac = int(mjm.opt.jacobian)
+  if jac == 2:  # auto
+    return mjm.nv > 32
+  return jac == 1
+
+
+def geom_pairs(mjm):
+  """Pre-filtered geom pairs in upper-triangular order (reference io.py:551-577, 631-640)."""
+  filterparent = not (int(mjm.opt.disableflags) & types.DisableBit.FILTERPARENT)
+  ng = mjm.ngeom
+  if ng < 2:
+    return np.zeros((0, 2), dtype=np.int32)
+  g1, g2 = np.triu_indices(ng, k=1)
+  b1, b2 = mjm.geom_bodyid[g1], mjm.geom_bodyid[g2]
+  w1, w2 = mjm.body_weldid[b1], mjm.body_weldid[b2]
+  wp1 = mjm.body_weldid[mjm.body_parentid[w1]]
+  wp2 = mjm.body_weldid[mjm.body_parentid[w2]]
+  self_col = w1 == w2
+  parent_child = filterparent & (w1 != 0) & (w2 != 0) & ((w1 == wp2) | (w2 == wp1))
+  mask = ((mjm.geom_contype[g1] & mjm.geom_conaffinity[g2]) | (mjm.geom_contype[g2] & mjm.geom_conaffinity[g1])) != 0
+  exclude = np.isin((b1.astype(np.int64) << 16) + b2, np.asarray(mjm.exclude_signature, dtype=np.int64))
+  keep = mask & ~self_col & ~parent_child & ~exclude
+  return np.stack([g1[keep], g2[keep]], axis=1).astype(np.int32)
+
+
+_SUPPORTED_PAIRS = {(0, 2), (0, 3), (0, 4), (0, 5), (0, 6), (2, 2), (2, 3), (2, 6), (3, 3)}
+
+
+def _arr(x, dtype):
+  return np.ascontiguousarray(np.asarray(x), dtype=dtype)
+
+
+def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
+  """Creates a model on device (reference io.py:259).
+
+  Args:
+    mjm: compiled model (mujoco.MjModel, or the numpy stand-in built by mujoco_warp_amd.mjcf).
+    batch_sizes: optional {field name: nworld} making "*" fields per-world (domain randomisation).
+  """
+  opt = mjm.opt
+  # ---- validation (io.py:284-360) ----
+  for name in ("ntendon", "neq", "nflex", "nhfield", "nmocap", "nplugin"):
+    if int(getattr(mjm, name, 0)) > 0:
+      raise NotImplementedError(f"{name} > 0 is outside the hot-path scope of this engine")
+  if int(opt.integrator) not in (types.IntegratorType.EULER, types.IntegratorType.IMPLICITFAST):
+    raise NotImplementedError(f"Integrator {int(opt.integrator)} is unsupported (Euler and implicitfast only).")
+  if int(opt.solver) not in (types.SolverType.CG, types.SolverType.NEWTON):
+    raise NotImplementedError("Solver must be CG or Newton (PGS is unsupported, as in the reference types.py:502).")
+  if int(opt.cone) != types.ConeType.PYRAMIDAL:
+    raise NotImplementedError("Elliptic friction cones are not implemented yet.")
+  if mjm.nv > 32:
+    raise NotImplementedError("nv > 32 requires the sparse-J / blocked-Cholesky path (SURVEY §8f row 2), not implemented yet.")
+  if mjm.nu and (np.asarray(mjm.actuator_trntype) != types.TrnType.JOINT).any():
+    raise NotImplementedError("Only joint transmissions are supported.")
+  if int(getattr(opt, "noslip_iterations", 0)) > 0:
+    raise NotImplementedError("noslip solver is unsupported.")
+  pairs = geom_pairs(mjm)
+  gt = np.asarray(mjm.geom_type)
+  for a, b in pairs:
+    t = (int(min(gt[a], gt[b])), int(max(gt[a], gt[b])))
+    if t not in _SUPPORTED_PAIRS:
+      raise NotImplementedError(f"collision between geom types {t} is not implemented yet")
+  condims = set(int(c) for c in np.unique(np.asarray(mjm.geom_condim)[np.unique(pairs)])) if len(pairs) else set()
+  if not condims <= {1, 3, 4, 6}:
+    raise NotImplementedError(f"unsupported condim values {condims}")
+
+  m = types.Model()
+  nv, nbody, njnt, ngeom, nu = int(mjm.nv), int(mjm.nbody), int(mjm.njnt), int(mjm.ngeom), int(mjm.nu)
+  for name in ("nq", "nv", "nu", "na", "nbody", "njnt", "ngeom", "nsite", "nkey", "nmocap"):
+    setattr(m, name, int(getattr(mjm, name, 0)))
+  for name in ("neq", "ntendon", "nsensor", "nmesh", "nflex", "nhfield", "ncam", "nlight"):
+    setattr(m, name, int(getattr(mjm, name, 0)))
+  m.nC = int(np.sum(mjm.M_rownnz)) if nv else 0
+  m.nM = m.nC
+  m.is_sparse = False
+  m.nv_pad = _get_padded_sizes(nv, 1)[1]
+
+  # ---- options (io.py:392-470) ----
+  o = types.Option()
+  o._root = m
+  f32 = np.float32
+  o.timestep = np.array([opt.timestep], dtype=f32)
+  # float32 device arithmetic cannot resolve MuJoCo's default 1e-8 (io.py:398-401)
+  o.tolerance = np.array([max(float(opt.tolerance), 1e-6)], dtype=f32)
+  o.ls_tolerance = np.array([opt.ls_tolerance], dtype=f32)
+  o.gravity = _arr(opt.gravity, f32).reshape(1, 3)
+  o.impratio_invsqrt = np.array([1.0 / np.sqrt(max(float(opt.impratio), types.MJ_MINVAL))], dtype=f32)
+  for name in ("integrator", "cone", "solver", "iterations", "ls_iterations", "disableflags", "enableflags"):
+    setattr(o, name, int(getattr(opt, name)))
+  o.broadphase = types.BroadphaseType.NXN
+  o.broadphase_filter = types.BroadphaseFilter.PLANE | types.BroadphaseFilter.SPHERE
+  o.graph_conditional = False
+  o.run_collision_detection = True
+  o.warn_overflow = False
+  s = types.Statistic()
+  s._root = m
+  s.meaninertia = np.array([mjm.stat.meaninertia], dtype=f32)
+
+  # ---- derived tables ----
+  parent = _arr(mjm.body_parentid, np.int32)
+  depth = np.zeros(nbody, dtype=np.int32)
+  for b in range(1, nbody):
+    depth[b] = depth[parent[b]] + 1
+  order = np.argsort(depth, kind="stable").astype(np.int32)
+  nlevel = int(depth.max()) + 1 if nbody else 0
+  leveladr = np.zeros(nlevel + 1, dtype=np.int32)
+  for l in range(nlevel):
+    leveladr[l + 1] = leveladr[l] + int(np.sum(depth == l))
+  subtreenum = np.ones(nbody, dtype=np.int32)
+  for b in range(nbody - 1, 0, -1):
+    subtreenum[parent[b]] += subtreenum[b]
+  for b in range(1, nbody):  # depth-first numbering => each subtree is a contiguous id range
+    if parent[b] >= b or not (parent[b] < b < parent[b] + subtreenum[parent[b]]):
+      raise ValueError("bodies must be numbered depth-first (MuJoCo order)")
+  dofnum, dofadr = _arr(mjm.body_dofnum, np.int32), _arr(mjm.body_dofadr, np.int32)
+  lastdof = np.full(nbody, -1, dtype=np.int32)
+  for b in range(1, nbody):
+    lastdof[b] = dofadr[b] + dofnum[b] - 1 if dofnum[b] > 0 else lastdof[parent[b]]
+  dof_parent = _arr(mjm.dof_parentid, np.int32)
+  nw = max((nv + 31) // 32, 1)
+  dofmask = np.zeros((nbody, nw), dtype=np.uint32)
+  for b in range(nbody):  # io.py:536-549 body_isdofancestor as bit masks
+    dsel = lastdof[b]
+    while dsel >= 0:
+      dofmask[b, dsel >> 5] |= np.uint32(1 << (dsel & 31))
+      dsel = dof_parent[dsel]
+  ddepth = np.zeros(nv, dtype=np.int32)
+  for i in range(nv):
+    ddepth[i] = 0 if dof_parent[i] < 0 else ddepth[dof_parent[i]] + 1
+  dorder = np.argsort(ddepth, kind="stable").astype(np.int32)
+  ndlevel = int(ddepth.max()) + 1 if nv else 0
+  dleveladr = np.zeros(ndlevel + 1, dtype=np.int32)
+  for l in range(ndlevel):
+    dleveladr[l + 1] = dleveladr[l] + int(np.sum(ddepth == l))
+  jnt_type, jnt_dofadr = _arr(mjm.jnt_type, np.int32), _arr(mjm.jnt_dofadr, np.int32)
+  dof_jnt = _arr(mjm.dof_jntid, np.int32)
+  grpadr = np.arange(nv, dtype=np.int32)
+  for i in range(nv):
+    j = dof_jnt[i]
+    if jnt_type[j] == types.JointType.BALL:
+      grpadr[i] = jnt_dofadr[j]
+    elif jnt_type[j] == types.JointType.FREE and i - jnt_dofadr[j] >= 3:
+      grpadr[i] = jnt_dofadr[j] + 3
+
+  host = {}  # name -> numpy array in ABI dtype
+  i32 = np.int32
+  host.update(
+    opt_timestep=o.timestep, opt_tolerance=o.tolerance, opt_ls_tolerance=o.ls_tolerance, opt_gravity=o.gravity,
+    opt_impratio_invsqrt=o.impratio_invsqrt, stat_meaninertia=s.meaninertia,
+    qpos0=_arr(mjm.qpos0, f32).reshape(1, -1), qpos_spring=_arr(mjm.qpos_spring, f32).reshape(1, -1),
+    body_parentid=parent, body_rootid=_arr(mjm.body_rootid, i32), body_weldid=_arr(mjm.body_weldid, i32),
+    body_jntnum=_arr(mjm.body_jntnum, i32), body_jntadr=_arr(mjm.body_jntadr, i32), body_dofnum=dofnum, body_dofadr=dofadr,
+    body_lastdof=lastdof, body_subtreenum=subtreenum, body_tree=order, body_leveladr=leveladr, body_dofmask=dofmask,
+    jnt_type=jnt_type, jnt_qposadr=_arr(mjm.jnt_qposadr, i32), jnt_dofadr=jnt_dofadr, jnt_bodyid=_arr(mjm.jnt_bodyid, i32),
+    jnt_limited=_arr(mjm.jnt_limited, i32),
+    dof_bodyid=_arr(mjm.dof_bodyid, i32), dof_jntid=dof_jnt, dof_parentid=dof_parent, dof_grpadr=grpadr, dof_tree=dorder,
+    dof_leveladr=dleveladr,
+    M_rownnz=_arr(mjm.M_rownnz, i32), M_rowadr=_arr(mjm.M_rowadr, i32), M_colind=_arr(mjm.M_colind, i32),
+    geom_type=_arr(mjm.geom_type, i32), geom_condim=_arr(mjm.geom_condim, i32), geom_bodyid=_arr(mjm.geom_bodyid, i32),
+    geom_priority=_arr(mjm.geom_priority, i32), nxn_geom_pair=pairs,
+    site_bodyid=_arr(getattr(mjm, "site_bodyid", np.zeros(0)), i32),
+    actuator_dyntype=_arr(mjm.actuator_dyntype, i32), actuator_gaintype=_arr(mjm.actuator_gaintype, i32),
+    actuator_biastype=_arr(mjm.actuator_biastype, i32), actuator_trnid=_arr(mjm.actuator_trnid, i32).reshape(-1, 2),
+    actuator_actadr=_arr(mjm.actuator_actadr, i32), actuator_ctrllimited=_arr(mjm.actuator_ctrllimited, i32),
+    actuator_forcelimited=_arr(mjm.actuator_forcelimited, i32), actuator_actlimited=_arr(mjm.actuator_actlimited, i32),
+  )
+  vec = {"body_pos": 3, "body_quat": 4, "body_ipos": 3, "body_iquat": 4, "body_inertia": 3, "body_invweight0": 2,
+         "jnt_solref": 2, "jnt_solimp": 5, "jnt_pos": 3, "jnt_axis": 3, "jnt_range": 2, "dof_solref": 2, "dof_solimp": 5,
+         "geom_solref": 2, "geom_solimp": 5, "geom_size": 3, "geom_pos": 3, "geom_quat": 4, "geom_friction": 3,
+         "site_pos": 3, "site_quat": 4, "actuator_dynprm": 10, "actuator_gainprm": 10, "actuator_biasprm": 10,
+         "actuator_ctrlrange": 2, "actuator_forcerange": 2, "actuator_actrange": 2, "actuator_gear": 6}
+  for name in _BATCHED_MODEL_FIELDS:
+    if name in host:
+      continue
+    src = getattr(mjm, name, None)
+    if src is None:
+      if name in ("site_pos", "site_quat"):
+        src = np.zeros((0, vec[name]))
+      else:
+        raise AttributeError(f"model is missing field {name}")
+    a = _arr(src, f32)
+    host[name] = a.reshape(1, -1, vec[name]) if name in vec else a.reshape(1, -1)
+
+  batch_sizes = batch_sizes or {}
+  for name, n in batch_sizes.items():
+    key = {"timestep": "opt_timestep", "tolerance": "opt_tolerance", "gravity": "opt_gravity",
+           "meaninertia": "stat_meaninertia"}.get(name, name)
+    if key not in _BATCHED_MODEL_FIELDS:
+      raise ValueError(f"{name} is not a batched ('*') Model field")
+    host[key] = np.repeat(host[key][:1], int(n), axis=0)
+
+  # ---- upload; public attribute names follow the reference Model ----
+  for name, kind in _MODEL_PTR_FIELDS:
+    da = DeviceArray.from_numpy(host[name])
+    if name.startswith("opt_"):
+      setattr(o, name[4:], da)
+    elif name.startswith("stat_"):
+      setattr(s, name[5:], da)
+    else:
+      setattr(m, name, da)
+  m.opt, m.stat = o, s
+  m.npair = int(len(pairs))
+  m.nxn_geom_pair_filtered = m.nxn_geom_pair
+  m.nbodylevel, m.ndoflevel = nlevel, ndlevel
+  m.nmaxcondim = int(max(condims)) if condims else 1
+  m.nmaxpyramid = max(1, 2 * (m.nmaxcondim - 1))
+  m.key_qpos = _arr(getattr(mjm, "key_qpos", np.zeros((0, m.nq))), f32)
+  m.key_qvel = _arr(getattr(mjm, "key_qvel", np.zeros((0, nv))), f32)
+  m.key_ctrl = _arr(getattr(mjm, "key_ctrl", np.zeros((0, nu))), f32)
+  m.key_act = _arr(getattr(mjm, "key_act", np.zeros((0, m.na))), f32)
+  m.key_time = _arr(getattr(mjm, "key_time", np.zeros(0)), f32)
+  m._dirty = True
+  m._c = None
+  return m
+
+
+def c_model(m: types.Model):
+  """ctypes MjhModel for `m`, rebuilt only when a field was re-bound."""
+  if m._c is not None and not m._dirty:
+    return m._c
+  c = _abi.CModel()
+  for name, kind, ptr in _abi.MODEL_FIELDS:
+    if ptr:
+      src = getattr(m.opt, name[4:]) if name.startswith("opt_") else getattr(m.stat, name[5:]) if name.startswith("stat_") else getattr(m, name)
+      setattr(c, name, src.ptr)
+      if name in _BATCHED_MODEL_FIELDS:
+        setattr(c, name + "_nb", src.shape[0])
+    elif name.endswith("_nb"):
+      continue
+    elif name in ("integrator", "cone", "solver", "iterations", "ls_iterations", "disableflags", "enableflags"):
+      setattr(c, name, int(getattr(m.opt, name)))
+    else:
+      setattr(c, name, int(getattr(m, name)))
+  object.__setattr__(m, "_c", c)
+  object.__setattr__(m, "_dirty", False)
+  return c
+
+
+def _data_shapes(m, nworld, nconmax, njmax, naconmax):
+  njmax_pad, nv_pad = _get_padded_sizes(m.nv, njmax)
+  nb, nv, nq, nu, na, ng, nj, ns, nC = m.nbody, m.nv, m.nq, m.nu, m.na, m.ngeom, m.njnt, m.nsite, m.nC
+  W = nworld
+  sh = dict(
+    time=(W,), qpos=(W, nq), qvel=(W, nv), act=(W, na), ctrl=(W, nu), qacc_warmstart=(W, nv), qfrc_applied=(W, nv),
+    xfrc_applied=(W, nb, 6), xpos=(W, nb, 3), xquat=(W, nb, 4), xmat=(W, nb, 3, 3), xipos=(W, nb, 3), ximat=(W, nb, 3, 3),
+    xanchor=(W, nj, 3), xaxis=(W, nj, 3), geom_xpos=(W, ng, 3), geom_xmat=(W, ng, 3, 3), site_xpos=(W, ns, 3),
+    site_xmat=(W, ns, 3, 3), subtree_com=(W, nb, 3), cinert=(W, nb, 10), cdof=(W, nv, 6), crb=(W, nb, 10), M=(W, nC),
+    qLD=(W, nC), qLDiagInv=(W, nv), actuator_length=(W, nu), actuator_moment=(W, nu), actuator_velocity=(W, nu),
+    cvel=(W, nb, 6), cdof_dot=(W, nv, 6), qfrc_spring=(W, nv), qfrc_damper=(W, nv), qfrc_gravcomp=(W, nv),
+    qfrc_passive=(W, nv), qfrc_bias=(W, nv), cacc=(W, nb, 6), cfrc_int=(W, nb, 6), act_dot=(W, na),
+    actuator_force=(W, nu), qfrc_actuator=(W, nv), qfrc_smooth=(W, nv), qacc_smooth=(W, nv), qacc=(W, nv),
+    qfrc_constraint=(W, nv), efc_Ma=(W, nv), solver_niter=(W,), ne=(W,), nf=(W,), nl=(W,), nefc=(W,), overflow=(W,),
+    nacon=(1,), ncollision=(1,),
+    contact_dist=(naconmax,), contact_pos=(naconmax, 3), contact_frame=(naconmax, 3, 3), contact_includemargin=(naconmax,),
+    contact_friction=(naconmax, 5), contact_solref=(naconmax, 2), contact_solreffriction=(naconmax, 2),
+    contact_solimp=(naconmax, 5), contact_dim=(naconmax,), contact_geom=(naconmax, 2),
+    contact_efc_address=(naconmax, m.nmaxpyramid), contact_worldid=(naconmax,), contact_type=(naconmax,),
+    contact_geomcollisionid=(naconmax,),
+    efc_type=(W, njmax), efc_id=(W, njmax), efc_state=(W, njmax), efc_J=(W, njmax_pad, nv_pad), efc_pos=(W, njmax),
+    efc_margin=(W, njmax), efc_D=(W, njmax), efc_vel=(W, njmax), efc_aref=(W, njmax), efc_frictionloss=(W, njmax),
+    efc_force=(W, njmax), ws_ncon=(W,), ws_conadr=(W,), ws_ncollision=(W,),
+  )
+  return sh, njmax_pad, nv_pad
+
+
+def _alloc_data(m: types.Model, nworld, nconmax, njmax, naconmax):
+  if nconmax is None:
+    nconmax = _default_nconmax(None)
+  if njmax is None:
+    njmax = _default_njmax(None)
+  if nconmax < 0:
+    raise ValueError("nconmax must be >= 0")
+  if njmax < 0:
+    raise ValueError("njmax must be >= 0")
+  if nworld < 1:
+    raise ValueError("nworld must be >= 1")
+  if naconmax is None:
+    naconmax = nworld * nconmax
+  if naconmax < 0:
+    raise ValueError("naconmax must be >= 0")
+  shapes, njmax_pad, nv_pad = _data_shapes(m, nworld, nconmax, njmax, naconmax)
+  d = types.Data()
+  d.contact = types.Contact()
+  d.efc = types.Constraint()
+  d.contact._root = d
+  d.efc._root = d
+  for name, kind in _DATA_PTR_FIELDS:
+    arr = DeviceArray.zeros(shapes[name], dtype=np.int32 if kind == "int" else np.float32)
+    _set_data_field(d, name, arr)
+  d.nworld, d.nconmax, d.naconmax, d.njmax, d.njmax_pad, d.nv_pad = nworld, nconmax, naconmax, njmax, njmax_pad, nv_pad
+  d.nmaxpyramid = m.nmaxpyramid
+  d.world_offset = 0
+  d.njmax_nnz = njmax * m.nv
+  d._c = None
+  d._dirty = True
+  return d
+
+
+def _set_data_field(d, name, arr):
+  if name.startswith("contact_"):
+    setattr(d.contact, name[8:], arr)
+  elif name.startswith("efc_"):
+    setattr(d.efc, name[4:], arr)
+  else:
+    setattr(d, name, arr)
+
+
+def _get_data_field(d, name):
+  if name.startswith("contact_"):
+    return getattr(d.contact, name[8:])
+  if name.startswith("efc_"):
+    return getattr(d.efc, name[4:])
+  return getattr(d, name)
+
+
+def c_data(d: types.Data):
+  if d._c is not None and not d._dirty:
+    return d._c
+  c = _abi.CData()
+  for name, kind, ptr in _abi.DATA_FIELDS:
+    if ptr:
+      setattr(c, name, _get_data_field(d, name).ptr)
+    else:
+      setattr(c, name, int(getattr(d, name)))
+  object.__setattr__(d, "_c", c)
+  object.__setattr__(d, "_dirty", False)
+  return c
+
+
+def _model_of(mjm):
+  """put_data/make_data take the host model like the reference; cache its device Model."""
+  m = getattr(mjm, "_mjh_model", None)
+  if m is None:
+    m = put_model(mjm)
+    try:
+      mjm._mjh_model = m
+    except AttributeError:
+      pass
+  return m
+
+
+def make_data(mjm, nworld: int = 1, nconmax: Optional[int] = None, nccdmax: Optional[int] = None,
+              njmax: Optional[int] = None, njmax_nnz: Optional[int] = None, naconmax: Optional[int] = None,
+              naccdmax: Optional[int] = None, nvmax: Optional[int] = None) -> types.Data:
+  """Creates a data object on device (reference io.py:1680); state = qpos0."""
+  m = mjm if isinstance(mjm, types.Model) else _model_of(mjm)
+  d = _alloc_data(m, nworld, nconmax, njmax, naconmax)
+  d.qpos.assign(np.tile(m.qpos0.numpy()[0], (nworld, 1)))
+  return d
+
+
+def put_data(mjm, mjd, nworld: int = 1, nconmax: Optional[int] = None, nccdmax: Optional[int] = None,
+             njmax: Optional[int] = None, njmax_nnz: Optional[int] = None, naconmax: Optional[int] = None,
+             naccdmax: Optional[int] = None, nvmax: Optional[int] = None) -> types.Data:
+  """Moves data from host to a device (reference io.py:1890): the single host state is tiled nworld times."""
+  m = mjm if isinstance(mjm, types.Model) else _model_of(mjm)
+  d = _alloc_data(m, nworld, nconmax, njmax, naconmax)
+  for name in ("qpos", "qvel", "act", "ctrl", "qacc_warmstart", "qfrc_applied", "xfrc_applied"):
+    src = np.asarray(getattr(mjd, name), dtype=np.float32)
+    dst = getattr(d, name)
+    if dst.size:
+      dst.assign(np.broadcast_to(src.reshape((1,) + dst.shape[1:]), dst.shape))
+  d.time.fill_(float(mjd.time))
+  return d
+
+
+def get_data_into(result, mjm, d: types.Data, world_id: int = 0):
+  """Gets data from a device into an existing host MjData-like object (reference io.py:2184)."""
+  w = world_id
+  for name in ("qpos", "qvel", "act", "ctrl", "qacc_warmstart", "qfrc_applied", "xfrc_applied", "qacc", "xpos", "xquat",
+               "xmat", "xipos", "ximat", "xanchor", "xaxis", "geom_xpos", "geom_xmat", "subtree_com", "cinert", "cdof", "crb",
+               "qLD", "qLDiagInv", "cvel", "cdof_dot", "qfrc_bias", "qfrc_passive", "qfrc_spring", "qfrc_damper",
+               "qfrc_actuator", "qfrc_smooth", "qacc_smooth", "qfrc_constraint", "actuator_force", "actuator_length",
+               "actuator_velocity", "cacc", "cfrc_int"):
+    arr = getattr(d, name).numpy()[w]
+    cur = getattr(result, name, None)
+    if isinstance(cur, np.ndarray) and cur.size == arr.size:
+      cur[...] = arr.reshape(cur.shape)
+    else:
+      setattr(result, name, arr.astype(np.float64))
+  result.qM = d.M.numpy()[w].astype(np.float64)
+  result.time = float(d.time.numpy()[w])
+  # contacts of this world, in the engine's deterministic per-world order
+  ncon, adr = int(d.ws_ncon.numpy()[w]), int(d.ws_conadr.numpy()[w])
+  result.ncon = ncon
+  sl = slice(adr, adr + ncon)
+  result.contact_dist = d.contact.dist.numpy()[sl].astype(np.float64)
+  result.contact_pos = d.contact.pos.numpy()[sl].astype(np.float64)
+  result.contact_frame = d.contact.frame.numpy()[sl].reshape(ncon, 9).astype(np.float64)
+  result.contact_geom = d.contact.geom.numpy()[sl]
+  result.contact_dim = d.contact.dim.numpy()[sl]
+  result.contact_efc_address = d.contact.efc_address.numpy()[sl]
+  nefc = min(int(d.nefc.numpy()[w]), d.njmax)
+  result.nefc, result.ne, result.nf, result.nl = nefc, int(d.ne.numpy()[w]), int(d.nf.numpy()[w]), int(d.nl.numpy()[w])
+  nv = d.qvel.shape[1]
+  result.efc_J = d.efc.J.numpy()[w, :nefc, :nv].astype(np.float64)
+  for name in ("pos", "margin", "D", "vel", "aref", "frictionloss", "force"):
+    setattr(result, "efc_" + name, getattr(d.efc, name).numpy()[w, :nefc].astype(np.float64))
+  for name in ("type", "id", "state"):
+    setattr(result, "efc_" + name, getattr(d.efc, name).numpy()[w, :nefc])
+  result.solver_niter = np.array([int(d.solver_niter.numpy()[w])])
+
+
+def reset_data(m: types.Model, d: types.Data, reset=None):
+  """Resets data to qpos0 (reference io.py:2435); `reset` is an optional per-world bool mask."""
+  mask = None if reset is None else np.asarray(reset.numpy() if hasattr(reset, "numpy") else reset, dtype=bool)
+  _reset_state(m, d, np.tile(m.qpos0.numpy()[:1], (d.nworld, 1)) if m.qpos0.shape[0] == 1 else m.qpos0.numpy()[np.arange(d.nworld) % m.qpos0.shape[0]],
+               None, None, None, 0.0, mask)
+
+
+def reset_data_keyframe(m: types.Model, d: types.Data, key: int, reset=None):
+  """Resets data to keyframe `key` (reference io.py:2797)."""
+  if key < 0 or key >= m.nkey:
+    raise ValueError(f"keyframe {key} out of range [0, {m.nkey})")
+  mask = None if reset is None else np.asarray(reset.numpy() if hasattr(reset, "numpy") else reset, dtype=bool)
+  W = d.nworld
+  _reset_state(m, d, np.tile(m.key_qpos[key], (W, 1)), np.tile(m.key_qvel[key], (W, 1)),
+               np.tile(m.key_act[key], (W, 1)) if m.na else None, np.tile(m.key_ctrl[key], (W, 1)) if m.nu else None,
+               float(m.key_time[key]), mask)
+
+
+def _reset_state(m, d, qpos, qvel, act, ctrl, time, mask):
+  def put(dst, val):
+    if dst.size == 0:
+      return
+    if val is None:
+      val = np.zeros(dst.shape, dtype=np.float32)
+    if mask is None:
+      dst.assign(val)
+    else:
+      cur = dst.numpy().copy()
+      cur[mask] = np.asarray(val, dtype=cur.dtype)[mask]
+      dst.assign(cur)
+
+  put(d.qpos, qpos)
+  put(d.qvel, qvel)
+  put(d.act, act)
+  put(d.ctrl, ctrl)
+  put(d.qacc_warmstart, None)
+  put(d.qacc, None)
+  put(d.qfrc_applied, None)
+  put(d.xfrc_applied, None)
+  put(d.time, np.full(d.time.shape, time, dtype=np.float32))
+  if mask is None:
+    for name in ("nefc", "ne", "nf", "nl", "solver_niter", "overflow", "nacon", "ncollision", "ws_ncon", "ws_conadr"):
+      getattr(d, name).zero_()
+
+
+_ENUMS = {"solver": types.SolverType, "integrator": types.IntegratorType, "cone": types.ConeType}
+
+
+def override_model(model, overrides):
+  """Overrides model parameters, e.g. {"opt.solver": "cg"} or ["opt.iterations=10"] (reference io.py:2933).
+
+  Works on the host model (MjModel-like, before put_model) and on a device Model.
+  """
+  if isinstance(overrides, (list, tuple)):
+    ov = {}
+    for item in overrides:
+      k, v = item.split("=", 1)
+      ov[k.strip()] = v.strip()
+    overrides = ov
+  for key, val in overrides.items():
+    obj = model
+    parts = key.split(".")
+    for p in parts[:-1]:
+      obj = getattr(obj, p)
+    attr = parts[-1]
+    if not hasattr(obj, attr):
+      raise ValueError(f"Unrecognized model field: {key}")
+    if attr in _ENUMS and isinstance(val, str) and not val.lstrip("-").isdigit():
+      val = int(_ENUMS[attr][val.upper()])
+    elif attr in ("disableflags", "enableflags") and isinstance(val, str) and not val.lstrip("-").isdigit():
+      enum_cls = types.DisableBit if attr == "disableflags" else types.EnableBit
+      bits = 0
+      for tok in val.split("|"):
+        bits |= int(enum_cls[tok.strip().upper()])
+      val = bits
+    cur = getattr(obj, attr)
+    if isinstance(cur, DeviceArray):
+      a = np.asarray(val if not isinstance(val, str) else [float(x) for x in val.replace(",", " ").split()], dtype=np.float32)
+      if attr == "tolerance":
+        a = np.maximum(a, 1e-6)
+      cur.assign(np.broadcast_to(a.reshape(-1) if a.ndim else a, cur.shape) if a.size == 1 else a.reshape(cur.shape))
+    elif isinstance(cur, (int, np.integer)):
+      setattr(obj, attr, int(val))
+    elif isinstance(cur, float):
+      setattr(obj, attr, float(val))
+    elif isinstance(cur, np.ndarray):
+      a = np.asarray(val if not isinstance(val, str) else [float(x) for x in val.replace(",", " ").split()], dtype=cur.dtype)
+      cur[...] = a.reshape(cur.shape) if a.size == cur.size else a
+    else:
+      setattr(obj, attr, val)
+    if isinstance(model, types.Model) and attr in ("solver", "integrator", "cone"):
+      put = {"solver": (types.SolverType.CG, types.SolverType.NEWTON), "integrator": (types.IntegratorType.EULER, types.IntegratorType.IMPLICITFAST),
+             "cone": (types.ConeType.PYRAMIDAL,)}[attr]
+      if int(getattr(obj, attr)) not in put:
+        raise NotImplementedError(f"unsupported {attr} {val}")
+    if hasattr(model, "_mjh_model"):
+      try:
+        del model._mjh_model
+      except AttributeError:
+        pass
