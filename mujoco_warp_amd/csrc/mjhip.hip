@@ -288,7 +288,7 @@ int mjh_graph_create(const MjhModel* m, const MjhData* d, void* stream, void** g
   hipGraph_t graph;
   HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
   int rc = run_stage(m, d, MJH_STAGE_STEP, s);
-  hipError_t e = hipStreamEndCapture(s, &graph);
+  hipError_t e = hipStreamEndCapture(s, &graph);  // always end the capture so the stream stays usable
   if (rc != MJH_OK) return rc;
   HIPCHK(e);
   hipGraphExec_t exec;

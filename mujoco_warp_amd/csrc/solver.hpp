@@ -37,6 +37,67 @@ DEV float gsum32(float v) {
   return bcast32(v, 31);
 }
 
+// ---- dense Cholesky with lane i owning row i (NVP <= 32), all indices compile-time ----------------------
+// h: row i of the SPD matrix on entry, row i of L on exit (entries above the diagonal are junk);
+// lt: column i of L below the diagonal (for the transposed solve); rdiag = 1 / L[i][i].
+// `col` is an LDS scratch of 8*(NVP+4) floats private to the group.  Lanes >= NVP must hold identity rows.
+template <int NVP>
+DEV void chol_factor_rows(float (&h)[NVP], float (&lt)[NVP], float& rdiag, float* col, int lig) {
+  constexpr int JS = NVP + 4;
+  const bool own = lig < NVP;
+  const int ligc = own ? lig : NVP - 1;
+  rdiag = 1.0f;
+#pragma unroll
+  for (int j = 0; j < NVP; ++j) {  // right-looking; pivot column broadcast through LDS (double buffered)
+    float* cb = col + (j & 1) * NVP;
+    if (own) cb[lig] = h[j];
+    gsync();
+    const float piv = sqrtf(fmaxf(cb[j], MJ_MINVAL));
+    const float inv = 1.0f / piv;
+    const float lij = (lig == j) ? piv : h[j] * inv;
+    h[j] = lij;
+    if (lig == j) rdiag = inv;
+#pragma unroll
+    for (int k = j + 1; k < NVP; ++k) h[k] -= lij * (cb[k] * inv);
+  }
+  gsync();
+#pragma unroll
+  for (int c0 = 0; c0 < NVP; c0 += 8) {  // column i of L: rows pass through an 8-row LDS tile
+    if (lig >= c0 && lig < c0 + 8 && own) {
+#pragma unroll
+      for (int c4 = 0; c4 < NVP / 4; ++c4)
+        *reinterpret_cast<float4*>(col + (lig - c0) * JS + 4 * c4) = make_float4(h[4 * c4], h[4 * c4 + 1], h[4 * c4 + 2], h[4 * c4 + 3]);
+    }
+    gsync();
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      const float v = col[kk * JS + ligc];
+      lt[c0 + kk] = (own && c0 + kk > lig) ? v : 0.0f;
+    }
+    gsync();
+  }
+}
+// x = (L L^T)^-1 g for the lane's component; broadcasts via v_readlane (no LDS traffic)
+template <int NVP>
+DEV float chol_solve_rows(const float (&h)[NVP], const float (&lt)[NVP], float rdiag, float g) {
+  const int lig = threadIdx.x & 31;
+  float acc = g, y = 0.0f, x = 0.0f;
+#pragma unroll
+  for (int k = 0; k < NVP; ++k) {
+    const float yk = bcast32(acc * rdiag, k);
+    if (lig == k) y = yk;
+    acc -= h[k] * yk;
+  }
+  acc = y;
+#pragma unroll
+  for (int k = NVP - 1; k >= 0; --k) {
+    const float xk = bcast32(acc * rdiag, k);
+    if (lig == k) x = xk;
+    acc -= lt[k] * xk;
+  }
+  return x;
+}
+
 struct SolveLayout {
   int J, D, Jaref, jv, floss, force, state, qacc, Ma, grad, search, mv, fs, Mg, pg, pMg, qc, col, L, dinv, total;
 };
@@ -51,19 +112,19 @@ __host__ __device__ inline SolveLayout solve_layout(int njmax, int nC, bool cg) 
   p.floss = o; o += njmax;
   p.force = o; o += njmax;
   p.state = o; o += njmax;
-  p.qacc = o; o += NVP;
-  p.Ma = o; o += NVP;
-  p.grad = o; o += NVP;
-  p.search = o; o += NVP;
-  p.mv = o; o += NVP;
-  p.fs = o; o += NVP;
-  p.Mg = o; o += NVP;
-  p.pg = o; o += NVP;
-  p.pMg = o; o += NVP;
-  p.qc = o; o += NVP;
+  p.qacc = o; o += 32;  // nv-vectors are indexed by lane id (0..31)
+  p.Ma = o; o += 32;
+  p.grad = o; o += 32;
+  p.search = o; o += 32;
+  p.mv = o; o += 32;
+  p.fs = o; o += 32;
+  p.Mg = o; o += 32;
+  p.pg = o; o += 32;
+  p.pMg = o; o += 32;
+  p.qc = o; o += 32;
   p.col = o; o += 8 * (NVP + 4);  // pivot-column double buffer (2*NVP) / 8-row transpose tile
-  p.L = o; o += cg ? ((nC + 3) / 4) * 4 : 0;
-  p.dinv = o; o += cg ? NVP : 0;
+  p.L = o;
+  p.dinv = o;
   p.total = ((o + 3) / 4) * 4;
   return p;
 }
@@ -130,7 +191,6 @@ __global__ void __launch_bounds__(256) k_solve(MjhModel m, MjhData d) {
   int* estate = reinterpret_cast<int*>(S + lay.state);
   float *vq = S + lay.qacc, *vMa = S + lay.Ma, *vgrad = S + lay.grad, *vsearch = S + lay.search, *vmv = S + lay.mv,
         *vfs = S + lay.fs, *vMg = S + lay.Mg, *vpg = S + lay.pg, *vpMg = S + lay.pMg, *vqc = S + lay.qc, *col = S + lay.col;
-  float *Lf = S + lay.L, *dinv = S + lay.dinv;
 
   const int nefc = min(d.nefc[w], njmax);
   const int ne = d.ne[w], nf = d.nf[w];
@@ -201,10 +261,6 @@ __global__ void __launch_bounds__(256) k_solve(MjhModel m, MjhData d) {
       eD[r] = d.efc_D[eo + r];
       efl[r] = d.efc_frictionloss[eo + r];
     }
-    if (!NEWTON) {
-      gcopy<G>(Lf, d.qLD + (size_t)w * nC, nC, lig);
-      dinv[lig] = active ? d.qLDiagInv[vo + lig] : 1.0f;
-    }
   }
   gsync();
   auto j_dot = [&](const float* vec, int r) __attribute__((always_inline)) {  // J[r,:] . vec  (row-per-lane, conflict-free b128 reads)
@@ -228,6 +284,7 @@ __global__ void __launch_bounds__(256) k_solve(MjhModel m, MjhData d) {
 
   float grad_dot = 0.0f, search_dot = 0.0f, decrement = 0.0f;
   float h[NVP], lt[NVP];
+  float mrdiag = 1.0f;
 
   // force/state per row + qfrc_constraint = J^T force (solver.py:1698-1822, 1912-1947)
   auto update_constraint = [&]() __attribute__((always_inline)) {
@@ -281,56 +338,9 @@ __global__ void __launch_bounds__(256) k_solve(MjhModel m, MjhData d) {
           h[4 * c4 + 3] += jd * j4.w;
         }
       }
-      // right-looking Cholesky: lane i owns row i; pivot column broadcast through LDS (double buffered)
-      float rdiag = 1.0f;
-#pragma unroll
-      for (int j = 0; j < NVP; ++j) {
-        float* cb = col + (j & 1) * NVP;
-        cb[lig] = h[j];
-        gsync();
-        const float piv = sqrtf(fmaxf(cb[j], MJ_MINVAL));
-        const float inv = 1.0f / piv;
-        const float lij = (lig == j) ? piv : h[j] * inv;
-        h[j] = lij;
-        if (lig == j) rdiag = inv;
-#pragma unroll
-        for (int k = j + 1; k < NVP; ++k) {
-          const float lkj = cb[k] * inv;
-          h[k] -= lij * lkj;
-        }
-      }
-      // column i of L for the transposed solve: rows go through a small LDS tile, 8 rows at a time
-      gsync();
-#pragma unroll
-      for (int c0 = 0; c0 < NVP; c0 += 8) {
-        if (lig >= c0 && lig < c0 + 8) {
-#pragma unroll
-          for (int c4 = 0; c4 < NVP / 4; ++c4)
-            *reinterpret_cast<float4*>(col + (lig - c0) * JS + 4 * c4) = make_float4(h[4 * c4], h[4 * c4 + 1], h[4 * c4 + 2], h[4 * c4 + 3]);
-        }
-        gsync();
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-          const float v = col[kk * JS + lig];
-          lt[c0 + kk] = (c0 + kk > lig) ? v : 0.0f;
-        }
-        gsync();
-      }
-      // forward  L y = grad, backward  L^T x = y ; broadcasts via v_readlane
-      float acc = g, y = 0.0f, x = 0.0f;
-#pragma unroll
-      for (int k = 0; k < NVP; ++k) {
-        const float yk = bcast32(acc * rdiag, k);
-        if (lig == k) y = yk;
-        acc -= h[k] * yk;
-      }
-      acc = y;
-#pragma unroll
-      for (int k = NVP - 1; k >= 0; --k) {
-        const float xk = bcast32(acc * rdiag, k);
-        if (lig == k) x = xk;
-        acc -= lt[k] * xk;
-      }
+      float rdiag;
+      chol_factor_rows<NVP>(h, lt, rdiag, col, lig);
+      float x = chol_solve_rows<NVP>(h, lt, rdiag, g);
       if (!active) x = 0.0f;
       vMg[lig] = x;
       vsearch[lig] = -x;
@@ -338,11 +348,18 @@ __global__ void __launch_bounds__(256) k_solve(MjhModel m, MjhData d) {
       decrement = gsum32(g * x);
       gsync();
     } else {
-      vMg[lig] = g;
+      // CG: Mgrad = M^-1 grad with the dense Cholesky factor of M held in registers (factored once per solve)
+      float x = chol_solve_rows<NVP>(h, lt, mrdiag, g);
+      if (!active) x = 0.0f;
+      vMg[lig] = x;
       gsync();
-      solve_ld<G>(m, ms, Lf, dinv, vMg, nv, lig);
     }
   };
+  if (!NEWTON) {
+#pragma unroll
+    for (int c = 0; c < NVP; ++c) h[c] = mrow[c];
+    chol_factor_rows<NVP>(h, lt, mrdiag, col, lig);
+  }
 
   int niter = 0;
   const int maxiter = m.iterations, ls_iterations = m.ls_iterations;

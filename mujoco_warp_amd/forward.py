@@ -132,7 +132,13 @@ class StepGraph:
     self._m, self._d = m, d  # keep the buffers alive
     self._exec = ctypes.c_void_p()
     L = _abi.lib()
-    _abi.check(L.mjh_graph_create(ctypes.byref(io.c_model(m)), ctypes.byref(io.c_data(d)), _stream(), ctypes.byref(self._exec)))
+    _stream()  # raises without a GPU
+    # stream capture is illegal on the legacy default stream: capture on a side stream ordered after the current one
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    rc = L.mjh_graph_create(ctypes.byref(io.c_model(m)), ctypes.byref(io.c_data(d)), ctypes.c_void_p(side.cuda_stream), ctypes.byref(self._exec))
+    torch.cuda.current_stream().wait_stream(side)
+    _abi.check(rc)
 
   def launch(self):
     _abi.check(_abi.lib().mjh_graph_launch(self._exec, _stream()))

@@ -1,0 +1,135 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+  sys.path.insert(0, ROOT)
+
+HUMANOID_XML = os.path.join(ROOT, "benchmarks", "humanoid", "humanoid.xml")
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+  config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _has_gpu():
+  try:
+    import torch
+
+    return torch.cuda.is_available()
+  except Exception:
+    return False
+
+
+def pytest_collection_modifyitems(config, items):
+  if _has_gpu():
+    return
+  skip = pytest.mark.skip(reason="no HIP device visible")
+  for item in items:
+    if "gpu" in item.keywords:
+      item.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def humanoid():
+  import mujoco_warp_amd as mjw
+
+  return mjw.mjcf.load_xml(HUMANOID_XML)
+
+
+def relerr(a, b):
+  a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+  if a.size == 0:
+    return 0.0
+  return float(np.max(np.abs(a - b)) / (np.max(np.abs(b)) + 1e-12))
+
+
+# small inline models shared by CPU and GPU tests (same role as the reference's test_data/*.xml)
+PENDULA_XML = """
+<mujoco>
+  <option timestep="0.002" gravity="0 0 -9.81"/>
+  <worldbody>
+    <geom name="floor" type="plane" size="0 0 .05" pos="0 0 -1.2"/>
+    <body name="p1" pos="0 0 0">
+      <joint name="h1" type="hinge" axis="0 1 0" damping="0.05" armature="0.01" range="-60 60" limited="true"/>
+      <geom type="capsule" fromto="0 0 0 0 0 -.3" size=".03"/>
+      <body name="p2" pos="0 0 -.3">
+        <joint name="h2" type="hinge" axis="1 0 0" stiffness="2" springref="10" frictionloss="0.05"/>
+        <geom type="capsule" fromto="0 0 0 0 0 -.3" size=".025"/>
+        <body name="p3" pos="0 0 -.3">
+          <joint name="s3" type="slide" axis="0 0 1" range="-.1 .1" limited="true" damping=".5"/>
+          <geom type="sphere" size=".05" pos="0 0 -.1"/>
+        </body>
+      </body>
+    </body>
+    <body name="ballbody" pos=".5 0 0">
+      <joint name="b1" type="ball" damping="0.02" range="0 40" limited="true"/>
+      <geom type="capsule" fromto="0 0 0 .2 0 -.2" size=".03"/>
+    </body>
+  </worldbody>
+  <actuator>
+    <motor joint="h1" gear="2" ctrlrange="-1 1" ctrllimited="true"/>
+    <position joint="s3" kp="20" kv="1"/>
+  </actuator>
+  <keyframe>
+    <key name="k0" qpos="0.9 0.2 0.05 0.9 0.3 0.3 0.1" qvel="0.5 -0.3 0.1 0.2 -0.4 0.3" ctrl="0.3 0.02"/>
+  </keyframe>
+</mujoco>
+"""
+
+FREE_BODIES_XML = """
+<mujoco>
+  <option timestep="0.004"/>
+  <default>
+    <geom contype="0" conaffinity="1"/>
+  </default>
+  <worldbody>
+    <geom name="floor" type="plane" size="0 0 .05" condim="3" contype="1" conaffinity="0"/>
+    <body name="box" pos="0 0 .099">
+      <freejoint/>
+      <geom type="box" size=".1 .15 .1" friction=".8"/>
+    </body>
+    <body name="ball" pos=".5 0 .079">
+      <freejoint/>
+      <geom type="sphere" size=".08" condim="1"/>
+    </body>
+    <body name="cyl" pos="-.5 0 .099">
+      <freejoint/>
+      <geom type="cylinder" size=".07 .1" condim="3"/>
+    </body>
+    <body name="ell" pos="0 .6 .049">
+      <freejoint/>
+      <geom type="ellipsoid" size=".1 .08 .05"/>
+    </body>
+    <body name="cap" pos="0 -.6 .049" euler="0 80 20">
+      <freejoint/>
+      <geom type="capsule" size=".05 .1"/>
+    </body>
+  </worldbody>
+  <keyframe>
+    <key name="drop" qvel="0.3 0 0 0 1 0   0 0.2 -0.1 1 0 0   0 0 0 0 0 2   0.1 0 0 0 0 0   0 0 0 0.5 0 0"/>
+  </keyframe>
+</mujoco>
+"""
+
+# spheres / capsules / a box hitting each other and the floor (sphere-sphere, sphere-capsule, capsule-capsule, sphere-box)
+PILE_XML = """
+<mujoco>
+  <option timestep="0.003" solver="CG"/>
+  <worldbody>
+    <geom name="floor" type="plane" size="0 0 .05"/>
+    <body name="s1" pos="0 0 .1"><freejoint/><geom type="sphere" size=".1"/></body>
+    <body name="s2" pos=".02 .01 .29"><freejoint/><geom type="sphere" size=".09" condim="1"/></body>
+    <body name="c1" pos=".5 0 .06" euler="90 0 0"><freejoint/><geom type="capsule" size=".06 .15"/></body>
+    <body name="c2" pos=".5 0.02 .17" euler="0 90 0"><freejoint/><geom type="capsule" size=".05 .12"/></body>
+    <body name="s3" pos=".5 -.13 .2"><freejoint/><geom type="sphere" size=".06"/></body>
+  </worldbody>
+  <keyframe>
+    <key name="k" qvel="0 0 0 0 0 0  0.1 0 -0.5 0 0 0  0 0 0 0 0 0  0 0 -0.3 0 0 0  0 0.2 -0.2 0 0 0"/>
+  </keyframe>
+</mujoco>
+"""

@@ -1,0 +1,47 @@
+"""Generates tests/golden/*.npz from the float64 oracle (PARITY UNPINNED: see oracle/mjref.h).
+
+The reference holds no golden vectors for the hot path and MuJoCo C is unavailable here, so these files are
+regression anchors produced by the oracle itself, not by the reference.  Run from the repo root:
+    python tests/golden/make_golden.py
+"""
+
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import mujoco_warp_amd as mjw  # noqa: E402
+from oracle import ref  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def main():
+  mjm = mjw.mjcf.load_xml(os.path.join(ROOT, "benchmarks", "humanoid", "humanoid.xml"))
+  nstep, stride, tol = 400, 20, 1e-6
+  s = ref.RefSim(mjm, nconmax=24, njmax=64, tolerance=tol)
+  s.reset(key=0)
+  ok, qp, qv = s.rollout(nstep, worldid=0)
+  assert ok == nstep
+  np.savez(os.path.join(OUT, "humanoid_oracle_rollout.npz"), qpos=qp[::stride], qvel=qv[::stride], nstep=nstep, stride=stride,
+           tolerance=tol, worldid=0)
+  # one-step fixtures from a generic state: inputs + oracle outputs of forward()
+  s.reset(key=0)
+  s.rollout(25, worldid=3, record=False)
+  s.ctrl_noise(25, 3)
+  state = {k: getattr(s, k).copy() for k in ("qpos", "qvel", "ctrl", "qacc_warmstart")}
+  s.forward()
+  out = {k: getattr(s, k).copy() for k in ("xpos", "xquat", "subtree_com", "cinert", "cdof", "M", "qfrc_bias", "qfrc_passive",
+                                            "qfrc_actuator", "qacc_smooth", "qacc", "qfrc_constraint")}
+  out["nefc"], out["ncon"] = s.nefc, s.ncon
+  out["efc_J"], out["efc_D"], out["efc_aref"] = s.efc_J[: s.nefc].copy(), s.efc_D[: s.nefc].copy(), s.efc_aref[: s.nefc].copy()
+  s.step()
+  out["qpos_next"], out["qvel_next"] = s.qpos.copy(), s.qvel.copy()
+  np.savez(os.path.join(OUT, "humanoid_oracle_forward.npz"), tolerance=tol, **{"in_" + k: v for k, v in state.items()}, **out)
+  print("wrote golden files to", OUT)
+
+
+if __name__ == "__main__":
+  main()

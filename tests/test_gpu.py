@@ -1,0 +1,347 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the float64 oracle and the golden fixtures.
+
+Tolerances (float32 device arithmetic vs float64 oracle; the reference's own tests use 5e-4 for smooth
+stages and 0.1 for the solver, smooth_test.py:32-38 / solver_test.py:34-40):
+  SMOOTH   2e-5 : FK / CoM / CRBA / RNE / passive / actuation fields, relative to the field's max magnitude
+  FACTOR   1e-4 : L'DL factor and M^-1 products
+  EFC      5e-4 : constraint rows (D, aref depend on contact distances ~1e-4 m resolved at float32 eps)
+  SOLVE    2e-3 : qacc / forces after the iterative solve
+  STEP     qpos 1e-5, qvel 1e-3 relative per re-synchronised step
+"""
+
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import conftest
+import mujoco_warp_amd as mjw
+from conftest import relerr
+from oracle import ref
+
+pytestmark = pytest.mark.gpu
+
+SMOOTH, FACTOR, EFC, SOLVE = 2e-5, 1e-4, 5e-4, 2e-3
+
+_SMOOTH_FIELDS = ("xpos", "xquat", "xmat", "xipos", "ximat", "xanchor", "xaxis", "geom_xpos", "geom_xmat", "subtree_com", "cinert",
+                  "cdof", "crb", "M", "cvel", "cdof_dot", "qfrc_spring", "qfrc_damper", "qfrc_passive", "qfrc_bias", "cacc",
+                  "cfrc_int", "actuator_force", "qfrc_actuator", "qfrc_smooth")
+
+
+def _pair(mjm, nworld=3, nconmax=32, njmax=96, solver=None, integrator=None, key=0, warm_steps=15, noise=True):
+  """(oracle sim, device model, device data) in the same generic state."""
+  if solver is not None:
+    mjm.opt.solver = solver
+  if integrator is not None:
+    mjm.opt.integrator = integrator
+  s = ref.RefSim(mjm, nconmax=nconmax, njmax=njmax, tolerance=max(mjm.opt.tolerance, 1e-6))
+  s.reset(key=key if mjm.nkey else None)
+  for i in range(warm_steps):
+    if noise and mjm.nu:
+      s.ctrl_noise(i, 0)
+    s.step()
+  m = mjw.put_model(mjm)
+  d = mjw.put_data(mjm, mjw.MjData(mjm), nworld=nworld, nconmax=nconmax, njmax=njmax)
+  _sync(s, d)
+  return s, m, d
+
+
+def _sync(s, d):
+  for name in ("qpos", "qvel", "act", "ctrl", "qacc_warmstart"):
+    dst = getattr(d, name)
+    if dst.size:
+      dst.assign(np.tile(getattr(s, name).astype(np.float32), (d.nworld, 1)))
+
+
+def _check_fields(s, d, names, tol, w=-1):
+  for name in names:
+    g = getattr(d, name).numpy()[w].reshape(-1)
+    o = getattr(s, name).reshape(-1)
+    assert relerr(g, o) <= tol, f"{name}: rel err {relerr(g, o):.3e} > {tol}"
+
+
+def _check_contacts_and_rows(s, d, mjm, w=-1):
+  ww = w % d.nworld
+  ncon, adr = int(d.ws_ncon.numpy()[ww]), int(d.ws_conadr.numpy()[ww])
+  assert ncon == s.ncon
+  sl = slice(adr, adr + ncon)
+  if ncon:
+    np.testing.assert_array_equal(d.contact.geom.numpy()[sl], s.con_geom[:ncon])
+    np.testing.assert_array_equal(d.contact.dim.numpy()[sl], s.con_dim[:ncon])
+    np.testing.assert_array_equal(d.contact.worldid.numpy()[sl], ww)
+    np.testing.assert_allclose(d.contact.dist.numpy()[sl], s.con_dist[:ncon], atol=2e-7)  # float32 eps at ~1 m
+    assert relerr(d.contact.pos.numpy()[sl], s.con_pos[:ncon]) <= SMOOTH
+    assert relerr(d.contact.frame.numpy()[sl].reshape(ncon, 9), s.con_frame[:ncon]) <= SMOOTH
+    for a, b in (("friction", "con_friction"), ("solref", "con_solref"), ("solimp", "con_solimp"), ("includemargin", "con_includemargin")):
+      assert relerr(getattr(d.contact, a).numpy()[sl].reshape(ncon, -1), getattr(s, b)[:ncon].reshape(ncon, -1)) <= 1e-6
+    np.testing.assert_array_equal(d.contact.efc_address.numpy()[sl], s.con_efc_address[:ncon, : d.nmaxpyramid])
+  nefc = int(d.nefc.numpy()[ww])
+  assert (nefc, int(d.nf.numpy()[ww]), int(d.nl.numpy()[ww])) == (s.nefc, s.nf, s.nl)
+  n = min(nefc, d.njmax)
+  if n:
+    assert relerr(d.efc.J.numpy()[ww, :n, : mjm.nv], s.efc_J[:n]) <= SMOOTH
+    assert (d.efc.J.numpy()[ww, :n, mjm.nv :] == 0).all()
+    np.testing.assert_array_equal(d.efc.type.numpy()[ww, :n], s.efc_type[:n])
+    for name in ("D", "aref", "pos", "vel", "margin", "frictionloss"):
+      assert relerr(getattr(d.efc, name).numpy()[ww, :n], getattr(s, "efc_" + name)[:n]) <= EFC, name
+
+
+def _check_solution(s, d, w=-1):
+  ww = w % d.nworld
+  n = min(int(d.nefc.numpy()[ww]), d.njmax)
+  _check_fields(s, d, ("qacc_smooth",), FACTOR, w)
+  _check_fields(s, d, ("qacc", "qfrc_constraint"), SOLVE, w)
+  assert relerr(d.efc.Ma.numpy()[ww], s.Ma) <= SOLVE
+  if n:
+    assert relerr(d.efc.force.numpy()[ww, :n], s.efc_force[:n]) <= SOLVE
+  assert int(d.overflow.numpy()[ww]) == 0
+
+
+@pytest.mark.parametrize("solver", [mjw.SolverType.NEWTON, mjw.SolverType.CG])
+def test_humanoid_forward_matches_oracle(solver):
+  mjm = mjw.mjcf.load_xml(conftest.HUMANOID_XML)
+  s, m, d = _pair(mjm, nconmax=24, njmax=64, solver=int(solver))
+  mjw.forward(m, d)
+  s.forward()
+  _check_fields(s, d, _SMOOTH_FIELDS, SMOOTH)
+  _check_fields(s, d, ("qLD", "qLDiagInv"), FACTOR)
+  _check_contacts_and_rows(s, d, mjm)
+  _check_solution(s, d)
+  # every world got the same inputs -> bitwise identical outputs
+  q = d.qacc.numpy()
+  assert (q == q[0]).all()
+  assert abs(int(d.solver_niter.numpy()[0]) - s.solver_niter) <= 2
+  assert int(d.nacon.numpy()[0]) == d.nworld * s.ncon
+
+
+def test_stage_functions_individually():
+  """Each reference stage function is callable on its own and reads its inputs from Data (smooth_test.py style)."""
+  mjm = mjw.mjcf.load_xml(conftest.HUMANOID_XML)
+  s, m, d = _pair(mjm, nconmax=24, njmax=64)
+  s.forward()
+  for fn, fields, tol in (
+    (mjw.kinematics, ("xpos", "xquat", "xmat", "xipos", "ximat", "xanchor", "xaxis", "geom_xpos", "geom_xmat"), SMOOTH),
+    (mjw.com_pos, ("subtree_com", "cinert", "cdof"), SMOOTH),
+    (mjw.crb, ("crb", "M"), SMOOTH),
+    (mjw.factor_m, ("qLD", "qLDiagInv"), FACTOR),
+    (mjw.com_vel, ("cvel", "cdof_dot"), SMOOTH),
+    (mjw.passive, ("qfrc_spring", "qfrc_damper", "qfrc_passive"), SMOOTH),
+    (mjw.rne, ("qfrc_bias", "cacc", "cfrc_int"), SMOOTH),
+    (mjw.fwd_actuation, ("actuator_force", "qfrc_actuator"), SMOOTH),
+    (mjw.fwd_acceleration, ("qfrc_smooth", "qacc_smooth"), FACTOR),
+  ):
+    for name in fields:  # poison the outputs like the reference's tests do
+      getattr(d, name).fill_(float("inf"))
+    fn(m, d)
+    _check_fields(s, d, fields, tol)
+  mjw.collision(m, d)
+  mjw.make_constraint(m, d)
+  _check_contacts_and_rows(s, d, mjm)
+  d.qacc.fill_(float("inf"))
+  mjw.solve(m, d)
+  _check_solution(s, d)
+  # fwd_position / fwd_velocity composites
+  mjw.fwd_position(m, d)
+  mjw.fwd_velocity(m, d)
+  _check_fields(s, d, ("M", "qLD", "qfrc_bias", "cvel"), FACTOR)
+  # solve_m / mul_m
+  y = np.random.RandomState(0).randn(d.nworld, mjm.nv).astype(np.float32)
+  ya, xa, ra = mjw.DeviceArray.from_numpy(y), mjw.DeviceArray.zeros(y.shape), mjw.DeviceArray.zeros(y.shape)
+  mjw.solve_m(m, d, xa, ya)
+  mjw.mul_m(m, d, ra, xa)
+  assert relerr(xa.numpy()[1], s.solve_m(y[1].astype(np.float64))) <= FACTOR
+  assert relerr(ra.numpy(), y) <= FACTOR
+
+
+@pytest.mark.parametrize("solver", [mjw.SolverType.NEWTON, mjw.SolverType.CG])
+def test_per_step_parity_resynced(solver):
+  """North-star parity: same state in, one step each, qpos/qvel compared; 150 steps along the oracle trajectory."""
+  mjm = mjw.mjcf.load_xml(conftest.HUMANOID_XML)
+  s, m, d = _pair(mjm, nworld=2, nconmax=24, njmax=64, solver=int(solver), warm_steps=0)
+  worst_q = worst_v = 0.0
+  for i in range(150):
+    s.ctrl_noise(i, 0)
+    _sync(s, d)
+    mjw.step(m, d)
+    s.step()
+    worst_q = max(worst_q, relerr(d.qpos.numpy()[1], s.qpos))
+    worst_v = max(worst_v, relerr(d.qvel.numpy()[1], s.qvel))
+  assert worst_q <= 1e-5, worst_q
+  assert worst_v <= 1e-3, worst_v
+  assert (d.overflow.numpy() == 0).all()
+
+
+@pytest.mark.parametrize("xml,njmax", [(conftest.PENDULA_XML, 32), (conftest.FREE_BODIES_XML, 96), (conftest.PILE_XML, 96)])
+def test_small_models_forward_and_step(xml, njmax):
+  """ball/slide/hinge limits, frictionloss, springs, position actuators; box/cylinder/ellipsoid/sphere/capsule contacts."""
+  mjm = mjw.mjcf.from_xml_string(xml)
+  s, m, d = _pair(mjm, nworld=2, nconmax=32, njmax=njmax, warm_steps=40, noise=False)
+  mjw.forward(m, d)
+  s.forward()
+  _check_fields(s, d, _SMOOTH_FIELDS, SMOOTH)
+  _check_contacts_and_rows(s, d, mjm)
+  _check_solution(s, d)
+  for _ in range(20):
+    _sync(s, d)
+    mjw.step(m, d)
+    s.step()
+    assert relerr(d.qpos.numpy()[0], s.qpos) <= 1e-5
+    assert relerr(d.qvel.numpy()[0], s.qvel) <= 2e-3
+
+
+def test_implicitfast_integrator():
+  mjm = mjw.mjcf.from_xml_string(conftest.PENDULA_XML)
+  s, m, d = _pair(mjm, nworld=2, njmax=32, integrator=int(mjw.IntegratorType.IMPLICITFAST), warm_steps=10, noise=False)
+  for _ in range(30):
+    _sync(s, d)
+    mjw.step(m, d)
+    s.step()
+    assert relerr(d.qpos.numpy()[0], s.qpos) <= 1e-5
+    assert relerr(d.qvel.numpy()[0], s.qvel) <= 1e-3
+    assert relerr(d.act.numpy()[0], s.act) <= 1e-5 if mjm.na else True
+
+
+def test_golden_forward_fixture():
+  g = np.load(os.path.join(conftest.GOLDEN_DIR, "humanoid_oracle_forward.npz"))
+  mjm = mjw.mjcf.load_xml(conftest.HUMANOID_XML)
+  m = mjw.put_model(mjm)
+  d = mjw.make_data(mjm, nworld=2, nconmax=24, njmax=64)
+  for name in ("qpos", "qvel", "ctrl", "qacc_warmstart"):
+    getattr(d, name).assign(np.tile(g["in_" + name].astype(np.float32), (2, 1)))
+  mjw.step(m, d)
+  for name, tol in (("xpos", SMOOTH), ("xquat", SMOOTH), ("subtree_com", SMOOTH), ("cinert", SMOOTH), ("cdof", SMOOTH), ("M", SMOOTH),
+                    ("qfrc_bias", SMOOTH), ("qfrc_passive", SMOOTH), ("qfrc_actuator", SMOOTH), ("qacc_smooth", FACTOR), ("qacc", SOLVE),
+                    ("qfrc_constraint", SOLVE)):
+    assert relerr(getattr(d, name).numpy()[1].reshape(-1), g[name].reshape(-1)) <= tol, name
+  assert int(d.nefc.numpy()[1]) == int(g["nefc"]) and int(d.ws_ncon.numpy()[1]) == int(g["ncon"])
+  assert relerr(d.efc.J.numpy()[1, : int(g["nefc"]), :27], g["efc_J"]) <= SMOOTH
+  assert relerr(d.qpos.numpy()[1], g["qpos_next"]) <= 1e-5
+  assert relerr(d.qvel.numpy()[1], g["qvel_next"]) <= 1e-3
+
+
+def test_golden_rollout_free_running():
+  """400 free-running steps from key 0 with the harness' control noise: world 0 tracks the oracle's golden rollout."""
+  g = np.load(os.path.join(conftest.GOLDEN_DIR, "humanoid_oracle_rollout.npz"))
+  mjm = mjw.mjcf.load_xml(conftest.HUMANOID_XML)
+  m = mjw.put_model(mjm)
+  d = mjw.make_data(mjm, nworld=4, nconmax=24, njmax=64)
+  mjw.reset_data_keyframe(m, d, 0)
+  stride = int(g["stride"])
+  errs = []
+  for i in range(int(g["nstep"])):
+    mjw.ctrl_noise(m, d, i)
+    mjw.step(m, d)
+    if i % stride == 0:
+      errs.append(relerr(d.qpos.numpy()[0], g["qpos"][i // stride]))
+  assert errs[0] <= 1e-5
+  assert errs[5] <= 1e-3  # 100 steps of contact-rich falling: drift stays small before chaos amplifies rounding
+  assert np.isfinite(d.qpos.numpy()).all()
+
+
+def test_ctrl_noise_matches_oracle():
+  mjm = mjw.mjcf.load_xml(conftest.HUMANOID_XML)
+  s, m, d = _pair(mjm, nworld=64, nconmax=24, njmax=64, warm_steps=0)
+  d.world_offset = 1000  # global world ids 1000..1063
+  for step in range(3):
+    mjw.ctrl_noise(m, d, step)
+  for w in (0, 17, 63):
+    s.ctrl[:] = 0
+    for step in range(3):
+      s.ctrl_noise(step, 1000 + w)
+    np.testing.assert_allclose(d.ctrl.numpy()[w], s.ctrl, atol=2e-7)
+
+
+def test_large_batch_properties():
+  """BASELINE size (8192 worlds): size-independent invariants instead of an oracle comparison."""
+  mjm = mjw.mjcf.load_xml(conftest.HUMANOID_XML)
+  m = mjw.put_model(mjm)
+  nworld = 8192
+  d = mjw.make_data(mjm, nworld=nworld, nconmax=24, njmax=64)
+  mjw.reset_data_keyframe(m, d, 0)
+  mjw.forward(m, d)
+  q = d.qacc.numpy()
+  assert (q == q[0]).all()  # identical worlds -> bitwise identical results regardless of block / XCD placement
+  ncon = d.ws_ncon.numpy()
+  assert int(d.nacon.numpy()[0]) == int(ncon.sum()) and (ncon == ncon[0]).all()
+  wid = d.contact.worldid.numpy()[: int(d.nacon.numpy()[0])]
+  assert (np.bincount(wid, minlength=nworld) == ncon).all()
+  adr = d.ws_conadr.numpy()
+  assert len(set(adr.tolist())) == nworld and (wid[adr] == np.arange(nworld)).all()  # disjoint contiguous blocks
+  for i in range(40):
+    mjw.ctrl_noise(m, d, i)
+    mjw.step(m, d)
+  qpos = d.qpos.numpy()
+  assert np.isfinite(qpos).all()
+  assert len(np.unique(qpos[:, 2])) > nworld // 2  # noise decorrelates the worlds
+  quat = qpos[:, 3:7]
+  np.testing.assert_allclose(np.linalg.norm(quat, axis=1), 1.0, atol=1e-5)
+  nefc = d.nefc.numpy()
+  ovf = d.overflow.numpy()
+  assert ((nefc <= 64) | ((ovf & int(mjw.OverflowType.NEFC)) != 0)).all()
+  assert (d.solver_niter.numpy() <= mjm.opt.iterations).all()
+  np.testing.assert_allclose(d.time.numpy(), 40 * 0.005, rtol=1e-5)
+  # run-to-run determinism of the whole pipeline
+  d2 = mjw.make_data(mjm, nworld=nworld, nconmax=24, njmax=64)
+  mjw.reset_data_keyframe(m, d2, 0)
+  for i in range(40):
+    mjw.ctrl_noise(m, d2, i)
+    mjw.step(m, d2)
+  assert (d2.qpos.numpy() == qpos).all()
+
+
+def test_batched_gravity_and_mass():
+  mjm = mjw.mjcf.load_xml(conftest.HUMANOID_XML)
+  m = mjw.put_model(mjm, batch_sizes={"gravity": 2})
+  m.opt.gravity.assign(np.array([[0, 0, -9.81], [0, 0, 0]], dtype=np.float32))
+  d = mjw.make_data(mjm, nworld=4, nconmax=24, njmax=64)
+  mjw.reset_data_keyframe(m, d, 2)  # in the air, no contacts
+  for _ in range(20):
+    mjw.step(m, d)
+  z = d.qpos.numpy()[:, 2]
+  assert z[0] < 2.0 - 0.04 and z[2] == z[0]  # worlds 0,2 fall
+  np.testing.assert_allclose(z[1], 2.0, atol=1e-4)  # worlds 1,3 float (zero gravity, springs only move joints)
+  assert z[3] == z[1]
+
+
+def test_graph_replay_matches_eager():
+  mjm = mjw.mjcf.load_xml(conftest.HUMANOID_XML)
+  m = mjw.put_model(mjm)
+  da = mjw.make_data(mjm, nworld=256, nconmax=24, njmax=64)
+  db = mjw.make_data(mjm, nworld=256, nconmax=24, njmax=64)
+  for d in (da, db):
+    mjw.reset_data_keyframe(m, d, 0)
+  graph = mjw.StepGraph(m, db)  # capture warms up with one real step
+  mjw.step(m, da)
+  for i in range(10):
+    mjw.ctrl_noise(m, da, i)
+    mjw.ctrl_noise(m, db, i)
+    mjw.step(m, da)
+    graph.launch()
+  torch.cuda.synchronize()
+  assert (da.qpos.numpy() == db.qpos.numpy()).all()
+
+
+def test_overflow_flags():
+  mjm = mjw.mjcf.load_xml(conftest.HUMANOID_XML)
+  m = mjw.put_model(mjm)
+  d = mjw.make_data(mjm, nworld=2, nconmax=24, njmax=16)  # squat pose needs 32 rows
+  mjw.reset_data_keyframe(m, d, 0)
+  mjw.step(m, d)
+  assert (d.overflow.numpy() & int(mjw.OverflowType.NEFC)).all()
+  assert np.isfinite(d.qpos.numpy()).all()
+  d = mjw.make_data(mjm, nworld=2, nconmax=2, njmax=64)  # only 4 public contact slots for 16 contacts
+  mjw.reset_data_keyframe(m, d, 0)
+  mjw.step(m, d)
+  assert (d.overflow.numpy() & int(mjw.OverflowType.NARROWPHASE)).any()
+
+
+def test_timed_steps_reports_kernel_classes():
+  mjm = mjw.mjcf.load_xml(conftest.HUMANOID_XML)
+  m = mjw.put_model(mjm)
+  d = mjw.make_data(mjm, nworld=512, nconmax=24, njmax=64)
+  mjw.reset_data_keyframe(m, d, 0)
+  ms, pk = mjw.timed_steps(m, d, 5, per_kernel=True)
+  assert ms > 0 and len(pk) == len(mjw.KERNEL_NAMES)
+  assert all(pk[mjw.KERNEL_NAMES.index(k)] > 0 for k in ("fwd_pos", "collision", "make_constraint", "fwd_vel", "solve", "integrate"))
+  np.testing.assert_allclose(d.time.numpy(), 5 * 0.005, rtol=1e-5)

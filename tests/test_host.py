@@ -1,0 +1,208 @@
+"""CPU tests of the host side: MJCF compiler, the C-ABI library (symbols only, no GPU compute), IO boundary."""
+
+import ctypes
+import re
+
+import numpy as np
+import pytest
+
+import conftest
+import mujoco_warp_amd as mjw
+from mujoco_warp_amd import _abi
+from mujoco_warp_amd import io
+
+
+# ---------------------------------------------------------------------------------- MJCF compiler
+def test_humanoid_sizes_match_survey(humanoid):
+  # nq=28, nv=27, nbody=17, njnt=22, ngeom=20, nu=21, nkey=3, nC=243
+  m = humanoid
+  assert (m.nq, m.nv, m.nbody, m.njnt, m.ngeom, m.nu, m.nkey) == (28, 27, 17, 22, 20, 21, 3)
+  assert int(m.M_rownnz.sum()) == 243
+  assert m.opt.timestep == 0.005 and m.opt.integrator == 0 and m.opt.solver == 2
+  assert m.opt.disableflags & mjw.DisableBit.EULERDAMP
+  # joint ranges are in degrees in the XML (default compiler angle)
+  np.testing.assert_allclose(m.jnt_range[1], np.deg2rad([-45, 45]))
+  assert m.jnt_limited[1:].all() and not m.jnt_limited[0]
+  np.testing.assert_allclose(m.actuator_gear[5, 0], 120.0)
+  np.testing.assert_allclose(m.key_qpos[0][:7], [0, 0, 0.596, 0.988015, 0, 0.154359, 0])
+
+
+def test_capsule_and_sphere_inertia_closed_form():
+  m = mjw.mjcf.from_xml_string("""
+<mujoco><worldbody>
+ <body name="s"><freejoint/><geom type="sphere" size=".1"/></body>
+ <body name="c" pos="1 0 0"><freejoint/><geom type="capsule" size=".05 .2"/></body>
+ <body name="b" pos="2 0 0"><freejoint/><geom type="box" size=".1 .2 .3" density="500"/></body>
+</worldbody></mujoco>""")
+  rho = 1000.0
+  ms = rho * 4 / 3 * np.pi * 0.1**3
+  np.testing.assert_allclose(m.body_mass[1], ms)
+  np.testing.assert_allclose(m.body_inertia[1], [0.4 * ms * 0.01] * 3)
+  r, h = 0.05, 0.4
+  mc, msph = rho * np.pi * r * r * h, rho * 4 / 3 * np.pi * r**3
+  np.testing.assert_allclose(m.body_mass[2], mc + msph)
+  izz = mc * r * r / 2 + 0.4 * msph * r * r
+  ixx = mc * (3 * r * r + h * h) / 12 + 0.4 * msph * r * r + msph * h * (3 * r + 2 * h) / 8
+  np.testing.assert_allclose(sorted(m.body_inertia[2]), sorted([ixx, ixx, izz]), rtol=1e-12)
+  mb = 500 * 8 * 0.1 * 0.2 * 0.3
+  np.testing.assert_allclose(m.body_mass[3], mb)
+  np.testing.assert_allclose(sorted(m.body_inertia[3]), sorted(mb / 3 * np.array([0.2**2 + 0.3**2, 0.1**2 + 0.3**2, 0.1**2 + 0.2**2])))
+
+
+def test_defaults_childclass_and_fromto(humanoid):
+  m = humanoid
+  g = m.geom_names.index("shin_right")
+  np.testing.assert_allclose(m.geom_size[g][:2], [0.049, 0.15])  # class "shin": fromto 0 0 0 0 0 -.3, size .049
+  np.testing.assert_allclose(m.geom_pos[g], [0, 0, -0.15])
+  np.testing.assert_allclose(m.geom_friction[g], [0.7, 0.005, 0.0001])
+  np.testing.assert_allclose(m.geom_solimp[g], [0.9, 0.99, 0.003, 0.5, 2])
+  assert m.geom_condim[g] == 1 and m.geom_condim[0] == 3
+  j = m.jnt_names.index("knee_right")
+  np.testing.assert_allclose(m.jnt_axis[j], [0, -1, 0])
+  np.testing.assert_allclose(m.jnt_range[j], np.deg2rad([-160, 2]))
+  np.testing.assert_allclose([m.jnt_stiffness[j], m.dof_damping[m.jnt_dofadr[j]], m.dof_armature[m.jnt_dofadr[j]]], [1, 0.2, 0.01])
+  j = m.jnt_names.index("abdomen_z")  # class joint_big_stiff inherits damping 5 from joint_big
+  np.testing.assert_allclose([m.jnt_stiffness[j], m.dof_damping[m.jnt_dofadr[j]]], [20, 5])
+  np.testing.assert_allclose(m.jnt_solimp[j], [0, 0.99, 0.01, 0.5, 2])
+
+
+def test_set_const(humanoid):
+  m = humanoid
+  np.testing.assert_allclose(m.body_subtreemass[0], m.body_mass.sum())
+  M = mjw.mjcf.host_mass_matrix(m, m.qpos0)["M"]
+  np.testing.assert_allclose(m.stat.meaninertia, np.mean(np.diag(M)))
+  A = np.diag(np.linalg.inv(M))
+  np.testing.assert_allclose(m.dof_invweight0[0:3], np.mean(A[0:3]))
+  np.testing.assert_allclose(m.dof_invweight0[3:6], np.mean(A[3:6]))
+  np.testing.assert_allclose(m.dof_invweight0[6], A[6])
+  assert (m.body_invweight0[1:] > 0).all() and (m.body_invweight0[0] == 0).all()
+
+
+def test_unsupported_features_raise():
+  with pytest.raises(NotImplementedError):
+    mjw.mjcf.from_xml_string('<mujoco><worldbody><body><joint/><geom size=".1"/></body></worldbody>'
+                             '<tendon><fixed><joint joint="x" coef="1"/></fixed></tendon></mujoco>')
+  m = mjw.mjcf.from_xml_string('<mujoco><option cone="elliptic"/><worldbody><body><joint/><geom size=".1"/></body></worldbody></mujoco>')
+  with pytest.raises(NotImplementedError):
+    mjw.put_model(m)
+  m = mjw.mjcf.from_xml_string('<mujoco><option integrator="RK4"/><worldbody><body><joint/><geom size=".1"/></body></worldbody></mujoco>')
+  with pytest.raises(NotImplementedError):
+    mjw.put_model(m)
+
+
+# ---------------------------------------------------------------------------------- C ABI
+def test_library_exports_every_declared_symbol():
+  L = _abi.lib()
+  header = open(_abi.HEADER).read()
+  declared = re.findall(r"^\s*(?:const char\*|int)\s+(mjh_\w+)\(", header, flags=re.M)
+  assert len(declared) >= 12
+  for name in declared:
+    assert hasattr(L, name), f"libmjhip.so does not export {name}"
+  assert L.mjh_abi_version() == 1
+
+
+def test_struct_layout_matches_header():
+  assert ctypes.sizeof(_abi.CModel) % 8 == 0 and ctypes.sizeof(_abi.CData) % 8 == 0
+  names = [n for n, _, _ in _abi.MODEL_FIELDS]
+  assert names[:3] == ["nq", "nv", "nu"] and "nxn_geom_pair" in names and "body_dofmask" in names
+  dnames = [n for n, _, _ in _abi.DATA_FIELDS]
+  assert dnames[0] == "nworld" and "efc_J" in dnames and dnames[-1] == "ws_ncollision"
+  # every batched pointer has its _nb companion right after it
+  for i, (n, k, p) in enumerate(_abi.MODEL_FIELDS):
+    if n.endswith("_nb"):
+      assert _abi.MODEL_FIELDS[i - 1][0] == n[:-3] and _abi.MODEL_FIELDS[i - 1][2]
+
+
+def test_no_cpu_fallback(humanoid):
+  import torch
+
+  if torch.cuda.is_available():
+    pytest.skip("GPU present")
+  m = mjw.put_model(humanoid)
+  d = mjw.make_data(humanoid, nworld=2)
+  with pytest.raises(RuntimeError, match="no CPU fallback"):
+    mjw.step(m, d)
+
+
+# ---------------------------------------------------------------------------------- IO boundary
+def test_put_model_and_make_data_shapes(humanoid):
+  m = mjw.put_model(humanoid)
+  assert (m.nq, m.nv, m.nC, m.nv_pad, m.npair) == (28, 27, 243, 28, 161)
+  assert m.opt.timestep.shape == (1,) and m.opt.timestep.dtype == np.float32
+  np.testing.assert_allclose(m.opt.tolerance.numpy(), [1e-6])  # clamped like io.py:398-401
+  assert m.body_pos.shape == (1, 17, 3) and m.geom_size.shape == (1, 20, 3) and m.actuator_gear.shape == (1, 21, 6)
+  assert m.body_parentid.dtype == np.int32
+  d = mjw.make_data(humanoid, nworld=5, nconmax=24, njmax=64)
+  assert (d.nworld, d.naconmax, d.njmax, d.njmax_pad, d.nv_pad) == (5, 120, 64, 64, 28)
+  assert d.qpos.shape == (5, 28) and d.xmat.shape == (5, 17, 3, 3) and d.cdof.shape == (5, 27, 6)
+  assert d.efc.J.shape == (5, 64, 28) and d.efc.D.shape == (5, 64) and d.contact.frame.shape == (120, 3, 3)
+  assert d.contact.efc_address.shape == (120, 4) and d.nacon.shape == (1,) and d.M.shape == (5, 243)
+  np.testing.assert_allclose(d.qpos.numpy()[3], humanoid.qpos0.astype(np.float32))
+  with pytest.raises(ValueError):
+    mjw.make_data(humanoid, nworld=0)
+  with pytest.raises(ValueError):
+    mjw.make_data(humanoid, nworld=1, njmax=-1)
+
+
+def test_put_data_get_data_roundtrip(humanoid):
+  mjd = mjw.MjData(humanoid)
+  mjw.mj_resetDataKeyframe(humanoid, mjd, 1)
+  mjd.qvel[:] = np.arange(27) * 0.01
+  mjd.ctrl[:] = 0.1
+  mjd.time = 1.5
+  d = mjw.put_data(humanoid, mjd, nworld=3, nconmax=8, njmax=32)
+  out = mjw.MjData(humanoid)
+  mjw.get_data_into(out, humanoid, d, world_id=2)
+  np.testing.assert_allclose(out.qpos, mjd.qpos.astype(np.float32))
+  np.testing.assert_allclose(out.qvel, mjd.qvel.astype(np.float32))
+  assert out.time == 1.5 and out.ncon == 0 and out.nefc == 0
+
+
+def test_reset_and_override(humanoid):
+  m = mjw.put_model(humanoid)
+  d = mjw.make_data(humanoid, nworld=4)
+  mjw.reset_data_keyframe(m, d, 0)
+  np.testing.assert_allclose(d.qpos.numpy()[1][:7], [0, 0, 0.596, 0.988015, 0, 0.154359, 0], rtol=1e-6)
+  d.qvel.fill_(1.0)
+  mjw.reset_data(m, d, reset=np.array([True, False, True, False]))
+  q = d.qvel.numpy()
+  assert (q[0] == 0).all() and (q[1] == 1).all()
+  mjw.override_model(m, {"opt.solver": "cg", "opt.iterations": 7})
+  assert m.opt.solver == mjw.SolverType.CG and m.opt.iterations == 7
+  assert io.c_model(m).solver == 1 and io.c_model(m).iterations == 7
+  host = mjw.mjcf.load_xml(conftest.HUMANOID_XML)
+  mjw.override_model(host, ["opt.solver=newton", "opt.ls_iterations=12"])
+  assert host.opt.solver == 2 and host.opt.ls_iterations == 12
+  with pytest.raises(ValueError):
+    mjw.override_model(m, {"opt.nonexistent": 1})
+
+
+def test_batched_model_field(humanoid):
+  m = mjw.put_model(humanoid, batch_sizes={"gravity": 4, "body_mass": 4})
+  assert m.opt.gravity.shape == (4, 3) and m.body_mass.shape == (4, 17)
+  assert io.c_model(m).opt_gravity_nb == 4 and io.c_model(m).body_mass_nb == 4 and io.c_model(m).body_pos_nb == 1
+  with pytest.raises(ValueError):
+    mjw.put_model(humanoid, batch_sizes={"body_parentid": 4})
+
+
+def test_geom_pair_filter(humanoid):
+  pairs = io.geom_pairs(humanoid)
+  from oracle.ref import filtered_geom_pairs
+
+  np.testing.assert_array_equal(pairs, filtered_geom_pairs(humanoid))
+  # floor collides with every body geom; parent/child and same-body pairs are filtered
+  assert (pairs[:, 0] == 0).sum() == 19
+  b = humanoid.geom_bodyid
+  assert all(b[i] != b[j] for i, j in pairs)
+
+
+def test_device_array_surface():
+  a = mjw.DeviceArray.zeros((3, 4))
+  assert a.shape == (3, 4) and a.dtype == np.float32 and a.size == 12 and a.capacity == 48
+  a.fill_(2.0)
+  assert (a.numpy() == 2).all()
+  a.zero_()
+  a[1].assign(np.arange(4))
+  np.testing.assert_array_equal(a.numpy()[1], [0, 1, 2, 3])
+  b = mjw.DeviceArray.from_numpy(np.array([1, 2], dtype=np.uint32))
+  assert b.numpy().dtype == np.uint32

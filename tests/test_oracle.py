@@ -1,0 +1,269 @@
+"""CPU tests of the float64 oracle (oracle/mjref.c).
+
+The oracle is PARITY-UNPINNED against MuJoCo C (no `mujoco` in this environment, no golden vectors in the
+reference: SURVEY.md §8c).  These tests pin it with everything that is available instead:
+  * MuJoCo-independent physics identities (energy, M = d2T/dv2, gravity torques = -dV/dq, KKT residual),
+  * closed-form collision cases with hand-derived answers,
+  * the reference's own MuJoCo-independent known-answer helpers (math_test.py-style Halton / quaternion facts),
+  * the committed golden rollout (tests/golden/), as a regression anchor for both oracle and HIP path.
+"""
+
+import os
+
+import numpy as np
+import pytest
+
+import conftest
+import mujoco_warp_amd as mjw
+from oracle import ref
+
+
+def _sim(mjm, **kw):
+  kw.setdefault("nconmax", 32)
+  kw.setdefault("njmax", 96)
+  kw.setdefault("tolerance", 1e-6)
+  return ref.RefSim(mjm, **kw)
+
+
+def _generic_state(s, mjm, seed=1, nstep=10):
+  rng = np.random.RandomState(seed)
+  s.reset(key=0 if mjm.nkey else None)
+  s.qvel[:] = 0.3 * rng.randn(mjm.nv)
+  s.ctrl[:] = 0.2 * rng.randn(mjm.nu)
+  for _ in range(nstep):
+    s.step()
+
+
+def test_halton_known_answers():
+  L = ref.lib()
+  # van der Corput / Halton sequence (reference util_misc.py:61)
+  assert L.ref_halton(1, 2) == 0.5
+  assert L.ref_halton(2, 2) == 0.25
+  assert L.ref_halton(3, 2) == 0.75
+  np.testing.assert_allclose(L.ref_halton(1, 3), 1.0 / 3.0, rtol=1e-6)
+  np.testing.assert_allclose(L.ref_halton(5, 3), 2.0 / 3.0 + 1.0 / 9.0, rtol=1e-6)
+  assert L.ref_halton(0, 2) == 0.0
+
+
+def test_mass_matrix_symmetric_pd_and_matches_host(humanoid):
+  s = _sim(humanoid)
+  _generic_state(s, humanoid)
+  s.forward()
+  M = s.dense_M()
+  assert np.allclose(M, M.T)
+  assert np.linalg.eigvalsh(M).min() > 0
+  Mh = mjw.mjcf.host_mass_matrix(humanoid, s.qpos.copy())["M"]
+  np.testing.assert_allclose(M, Mh, atol=1e-12)
+
+
+def test_kinetic_energy_identity(humanoid):
+  """0.5 v'Mv (CRBA) == sum_b 0.5 cvel_b' I_b cvel_b (per-body spatial inertia)."""
+  s = _sim(humanoid)
+  _generic_state(s, humanoid)
+  s.forward()
+  v = s.qvel.copy()
+  ke_m = 0.5 * v @ (s.dense_M() - np.diag(humanoid.dof_armature)) @ v
+  ke_b = 0.0
+  for b in range(1, humanoid.nbody):
+    ke_b += 0.5 * s.cvel[b] @ mjw._npmath.inert_vec(s.cinert[b], s.cvel[b])
+  np.testing.assert_allclose(ke_m, ke_b, rtol=1e-10)
+
+
+def test_factor_solve_roundtrip(humanoid):
+  s = _sim(humanoid)
+  _generic_state(s, humanoid)
+  s.forward()
+  y = np.random.RandomState(0).randn(humanoid.nv)
+  np.testing.assert_allclose(s.mul_m(s.solve_m(y)), y, atol=1e-10)
+  np.testing.assert_allclose(s.solve_m(y), np.linalg.solve(s.dense_M(), y), rtol=1e-9)
+
+
+def test_gravity_bias_equals_potential_gradient(humanoid):
+  """At qvel=0, qfrc_bias = dV/dq with V = -sum m g.xipos (finite differences on hinge dofs)."""
+  s = _sim(humanoid)
+  s.reset(key=1)
+  s.qvel[:] = 0
+  s.forward()
+  bias = s.qfrc_bias.copy()
+  g = np.asarray(humanoid.opt.gravity)
+
+  def V():
+    s.stage("kinematics")
+    return -sum(humanoid.body_mass[b] * g @ s.xipos[b] for b in range(humanoid.nbody))
+
+  eps = 1e-6
+  for j in range(1, humanoid.njnt):  # hinge joints
+    qa, da = humanoid.jnt_qposadr[j], humanoid.jnt_dofadr[j]
+    q0 = s.qpos[qa]
+    s.qpos[qa] = q0 + eps
+    vp = V()
+    s.qpos[qa] = q0 - eps
+    vm = V()
+    s.qpos[qa] = q0
+    np.testing.assert_allclose(bias[da], (vp - vm) / (2 * eps), rtol=2e-5, atol=1e-6)
+
+
+def test_energy_conservation_free_flight(humanoid):
+  """No contacts, no damping/springs/limits/actuation: Euler keeps total energy to O(h)."""
+  m = mjw.mjcf.load_xml(conftest.HUMANOID_XML)
+  m.opt.disableflags |= (1 << 5) | (1 << 6) | (1 << 3) | (1 << 11) | (1 << 4)
+  m.opt.timestep = 1e-4
+  s = _sim(m)
+  s.reset(key=2)
+  rng = np.random.RandomState(3)
+  s.qvel[:] = 0.5 * rng.randn(m.nv)
+  g = np.asarray(m.opt.gravity)
+
+  def energy():
+    s.forward()
+    v = s.qvel.copy()
+    return 0.5 * v @ s.dense_M() @ v - sum(m.body_mass[b] * g @ s.xipos[b] for b in range(m.nbody))
+
+  e0 = energy()
+  for _ in range(300):
+    s.step()
+  e1 = energy()
+  assert abs(e1 - e0) < 2e-3 * max(1.0, abs(e0))
+
+
+@pytest.mark.parametrize("solver", [1, 2])
+def test_solver_kkt_and_state_consistency(humanoid, solver):
+  s = _sim(humanoid, nconmax=24, njmax=64, solver=solver, tolerance=1e-10, iterations=300)
+  s.reset(key=0)
+  for i in range(30):
+    s.ctrl_noise(i, 0)
+    s.step()
+  s.forward()
+  nefc = s.nefc
+  assert nefc > 0 and s.overflow == 0
+  J = s.efc_J[:nefc]
+  # stationarity of the primal problem: M qacc - qfrc_smooth - J' f = 0
+  res = s.dense_M() @ s.qacc - s.qfrc_smooth - J.T @ s.efc_force[:nefc]
+  scale = humanoid.stat.meaninertia * humanoid.nv
+  assert np.linalg.norm(res) / scale < (1e-6 if solver == 2 else 1e-4)
+  # force/state consistency for limit + contact rows
+  jaref = J @ s.qacc - s.efc_aref[:nefc]
+  for r in range(nefc):
+    if jaref[r] >= 0:
+      assert s.efc_state[r] == 0 and s.efc_force[r] == 0.0
+    else:
+      assert s.efc_state[r] == 1
+      np.testing.assert_allclose(s.efc_force[r], -s.efc_D[r] * jaref[r], rtol=1e-9)
+
+
+def test_newton_and_cg_agree(humanoid):
+  a, b = _sim(humanoid, nconmax=24, njmax=64, solver=2, tolerance=1e-10), _sim(humanoid, nconmax=24, njmax=64, solver=1, tolerance=1e-10)
+  for s in (a, b):
+    s.reset(key=0)
+    s.forward()
+  np.testing.assert_allclose(a.qacc, b.qacc, rtol=1e-4, atol=1e-4)
+
+
+def _one_geom_model(geom_xml, extra=""):
+  return mjw.mjcf.from_xml_string(f"""
+<mujoco><worldbody>
+  <geom name="floor" type="plane" size="0 0 .05"/>
+  <body name="a" pos="0 0 0"><freejoint/>{geom_xml}</body>{extra}
+</worldbody></mujoco>""")
+
+
+def test_collision_plane_sphere_closed_form():
+  m = _one_geom_model('<geom type="sphere" size=".1"/>')
+  s = _sim(m)
+  s.qpos[:] = [0.3, -0.2, 0.08, 1, 0, 0, 0]
+  s.stage("kinematics")
+  s.stage("collision")
+  assert s.ncon == 1
+  np.testing.assert_allclose(s.con_dist[0], -0.02, atol=1e-12)
+  np.testing.assert_allclose(s.con_pos[0], [0.3, -0.2, -0.01], atol=1e-12)  # midpoint between surfaces
+  np.testing.assert_allclose(s.con_frame[0][:3], [0, 0, 1], atol=1e-12)
+  s.qpos[2] = 0.11
+  s.stage("kinematics")
+  s.stage("collision")
+  assert s.ncon == 0
+
+
+def test_collision_plane_capsule_two_contacts():
+  m = _one_geom_model('<geom type="capsule" size=".05 .2"/>')
+  s = _sim(m)
+  q = mjw._npmath.axis_angle_to_quat([0, 1, 0], np.pi / 2)  # lying along x
+  s.qpos[:] = [0, 0, 0.04, *q]
+  s.stage("kinematics")
+  s.stage("collision")
+  assert s.ncon == 2
+  np.testing.assert_allclose(s.con_dist[:2], [-0.01, -0.01], atol=1e-12)
+  np.testing.assert_allclose(sorted(s.con_pos[:2, 0]), [-0.2, 0.2], atol=1e-12)
+
+
+def test_collision_sphere_sphere_and_capsule_capsule():
+  m = mjw.mjcf.from_xml_string("""
+<mujoco><worldbody>
+  <body name="a"><freejoint/><geom type="sphere" size=".1"/></body>
+  <body name="b" pos=".15 0 0"><freejoint/><geom type="sphere" size=".1"/></body>
+  <body name="c" pos="0 2 0"><freejoint/><geom type="capsule" size=".05 .3"/></body>
+  <body name="d" pos=".08 2 0" euler="90 0 0"><freejoint/><geom type="capsule" size=".05 .3"/></body>
+</worldbody></mujoco>""")
+  s = _sim(m)
+  s.stage("kinematics")
+  s.stage("collision")
+  assert s.ncon == 2
+  np.testing.assert_allclose(s.con_dist[0], 0.15 - 0.2, atol=1e-12)
+  np.testing.assert_allclose(s.con_frame[0][:3], [1, 0, 0], atol=1e-12)
+  np.testing.assert_allclose(s.con_dist[1], 0.08 - 0.1, atol=1e-9)  # crossed capsules: axis distance - radii
+  np.testing.assert_allclose(np.abs(s.con_frame[1][:3]), [1, 0, 0], atol=1e-9)
+
+
+def test_collision_plane_box_and_sphere_box():
+  m = _one_geom_model('<geom type="box" size=".1 .2 .3"/>',
+                      '<body name="s" pos="0 0 .69"><freejoint/><geom type="sphere" size=".1"/></body>')
+  s = _sim(m)
+  s.qpos[2] = 0.295
+  s.stage("kinematics")
+  s.stage("collision")
+  # 4 bottom corners penetrate by 5 mm, the sphere rests 5 mm into the box top (z = .595)
+  assert s.ncon == 5
+  np.testing.assert_allclose(s.con_dist[:4], -0.005, atol=1e-12)
+  np.testing.assert_allclose(s.con_dist[4], 0.69 - 0.1 - 0.595, atol=1e-12)
+
+
+def test_constraint_row_limit_closed_form():
+  """One hinge beyond its upper limit: J=-1, pos = range1 - q, D and aref from the solref/solimp formulas."""
+  m = mjw.mjcf.from_xml_string("""
+<mujoco><option timestep="0.01"/><worldbody><body><joint name="h" type="hinge" axis="0 1 0" range="-30 30" limited="true"/>
+<geom type="capsule" fromto="0 0 0 0 0 -.5" size=".05"/></body></worldbody></mujoco>""")
+  s = _sim(m)
+  q = np.deg2rad(35.0)
+  s.qpos[0] = q
+  s.qvel[0] = 0.7
+  s.forward()
+  assert (s.nefc, s.nl, s.ncon) == (1, 1, 0)
+  pos = np.deg2rad(30.0) - q
+  np.testing.assert_allclose(s.efc_pos[0], pos, rtol=1e-12)
+  np.testing.assert_allclose(s.efc_J[0, 0], -1.0)
+  np.testing.assert_allclose(s.efc_vel[0], -0.7)
+  # default solref (.02,1), solimp (.9,.95,.001,.5,2): |pos|/width > 1 -> imp = dmax
+  imp, tc = 0.95, max(0.02, 2 * 0.01)
+  k, b = 1 / (0.95**2 * tc**2), 2 / (0.95 * tc)
+  np.testing.assert_allclose(s.efc_aref[0], -k * imp * pos - b * (-0.7), rtol=1e-12)
+  np.testing.assert_allclose(s.efc_D[0], 1 / (m.dof_invweight0[0] * (1 - imp) / imp), rtol=1e-12)
+
+
+def test_golden_rollout_regression(humanoid):
+  path = os.path.join(conftest.GOLDEN_DIR, "humanoid_oracle_rollout.npz")
+  g = np.load(path)
+  s = _sim(humanoid, nconmax=24, njmax=64, tolerance=float(g["tolerance"]))
+  s.reset(key=0)
+  ok, qp, qv = s.rollout(int(g["nstep"]), worldid=int(g["worldid"]))
+  assert ok == int(g["nstep"])
+  np.testing.assert_allclose(qp[:: int(g["stride"])], g["qpos"], rtol=0, atol=1e-9)
+  np.testing.assert_allclose(qv[:: int(g["stride"])], g["qvel"], rtol=0, atol=1e-8)
+
+
+def test_pendula_and_pile_models_run():
+  for xml, njmax in ((conftest.PENDULA_XML, 32), (conftest.FREE_BODIES_XML, 96), (conftest.PILE_XML, 96)):
+    m = mjw.mjcf.from_xml_string(xml)
+    s = _sim(m, njmax=njmax)
+    s.reset(key=0)
+    ok, qp, qv = s.rollout(200, noise_std=-1)
+    assert ok == 200 and s.overflow == 0
+    assert np.isfinite(qp).all()

@@ -1,0 +1,94 @@
+"""Condense rocprofv3 (rocpd sqlite) output dirs into one small JSON summary.
+
+usage: python tools/summarize_profile.py gpurun_out/prof_<tag> [out.json]
+Per kernel: calls, mean/min/max duration from the kernel trace; per-dispatch mean of every PMC counter
+(summed over hardware instances, i.e. SEs/XCCs).  FETCH_SIZE/WRITE_SIZE are in KiB (rocprofv3 convention);
+on gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md, HBM section) -- the
+corrected byte figures are emitted next to the raw ones.
+"""
+
+import glob
+import json
+import os
+import sqlite3
+import sys
+from collections import defaultdict
+
+
+def _tables(cur):
+  t = {}
+  for (name,) in cur.execute("select name from sqlite_master where type='table'"):
+    t[name.rsplit("_0000", 1)[0]] = name
+  return t
+
+
+def _short(n):
+  n = n.replace(".kd", "")
+  for key in ("k_fwd_pos", "k_fwd_vel", "k_collision", "k_make_constraint", "k_solve_m", "k_solve", "k_integrate", "k_ctrl_noise", "k_overflow"):
+    if key in n:
+      if key == "k_solve" and "ILi" in n:
+        i = n.index("ILi")
+        return "k_solve<" + n[i + 3 : i + 5].rstrip("E") + ("," + ("newton" if "Lb1" in n else "cg")) + ">"
+      return key
+  return n[:60]
+
+
+def kernel_trace(dbpath):
+  db = sqlite3.connect(dbpath)
+  cur = db.cursor()
+  t = _tables(cur)
+  names = {r[0]: r[1] for r in cur.execute(f"select id, kernel_name from '{t['rocpd_info_kernel_symbol']}'")}
+  agg = defaultdict(list)
+  for kid, s, e in cur.execute(f"select kernel_id, start, end from '{t['rocpd_kernel_dispatch']}'"):
+    agg[_short(names.get(kid, str(kid)))].append(e - s)
+  total = sum(sum(v) for v in agg.values())
+  out = []
+  for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+    out.append({"kernel": k, "calls": len(v), "mean_us": sum(v) / len(v) / 1e3, "min_us": min(v) / 1e3, "max_us": max(v) / 1e3,
+                "total_ms": sum(v) / 1e6, "pct": 100.0 * sum(v) / max(total, 1)})
+  return out
+
+
+def pmc(dbpath):
+  db = sqlite3.connect(dbpath)
+  cur = db.cursor()
+  t = _tables(cur)
+  names = {r[0]: r[1] for r in cur.execute(f"select id, kernel_name from '{t['rocpd_info_kernel_symbol']}'")}
+  pmcn = {r[0]: r[1] for r in cur.execute(f"select id, name from '{t['rocpd_info_pmc']}'")}
+  ev2k = {r[0]: _short(names.get(r[1], str(r[1]))) for r in cur.execute(f"select event_id, kernel_id from '{t['rocpd_kernel_dispatch']}'")}
+  per = defaultdict(lambda: defaultdict(float))
+  ndisp = defaultdict(set)
+  for ev, pid, val in cur.execute(f"select event_id, pmc_id, value from '{t['rocpd_pmc_event']}'"):
+    k = ev2k.get(ev)
+    if k is None:
+      continue
+    per[k][pmcn.get(pid, str(pid))] += val
+    ndisp[k].add(ev)
+  return {k: {c: v / max(len(ndisp[k]), 1) for c, v in cs.items()} for k, cs in per.items()}
+
+
+def main():
+  out = sys.argv[1]
+  summary = {"source": out}
+  for f in glob.glob(os.path.join(out, "trace", "*.db")):
+    summary["kernel_trace"] = kernel_trace(f)
+  counters = defaultdict(dict)
+  for tag in ("pmc_sq", "pmc_sq2", "pmc_fetch", "pmc_write"):
+    for f in glob.glob(os.path.join(out, tag, "*.db")):
+      for k, cs in pmc(f).items():
+        counters[k].update(cs)
+  for k, cs in counters.items():
+    if "FETCH_SIZE" in cs:
+      cs["fetch_bytes_raw"] = cs["FETCH_SIZE"] * 1024
+      cs["fetch_bytes_gfx950_corrected"] = cs["FETCH_SIZE"] * 1024 * 2
+    if "WRITE_SIZE" in cs:
+      cs["write_bytes"] = cs["WRITE_SIZE"] * 1024
+  summary["pmc_per_dispatch"] = counters
+  text = json.dumps(summary, indent=1)
+  if len(sys.argv) > 2:
+    open(sys.argv[2], "w").write(text)
+  print(text)
+
+
+if __name__ == "__main__":
+  main()
