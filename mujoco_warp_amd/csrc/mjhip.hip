@@ -121,25 +121,40 @@ static int launch_constraint(const MjhModel* m, const MjhData* d, hipStream_t s)
   hipLaunchKernelGGL(k_make_constraint<G>, dim3((d->nworld + wpb - 1) / wpb), dim3(threads), lds, s, *m, *d, cap);
   return MJH_OK;
 }
-template <int NVP, bool NEWTON>
+template <int NV4, int NR, bool NEWTON>
 static int launch_solve_t(const MjhModel* m, const MjhData* d, hipStream_t s) {
-  const SolveLayout lay = solve_layout<NVP>(d->njmax, m->nC, !NEWTON);
+  const SolveLayout lay = solve_layout<NV4, NR>(d->njmax);
   size_t lds;
   const int threads = pick_block(sizeof(int) * mstruct_ints(m->nv, m->nC), sizeof(float) * lay.total, 32, &lds);
   if (!threads) return fail(MJH_E_UNSUPPORTED, "k_solve: njmax x nv does not fit in LDS");
-  HIPCHK(set_lds(k_solve<NVP, NEWTON>, lds));
+  HIPCHK(set_lds(k_solve<NV4, NR, NEWTON>, lds));
   const int wpb = threads / 32;
-  hipLaunchKernelGGL((k_solve<NVP, NEWTON>), dim3((d->nworld + wpb - 1) / wpb), dim3(threads), lds, s, *m, *d);
+  hipLaunchKernelGGL((k_solve<NV4, NR, NEWTON>), dim3((d->nworld + wpb - 1) / wpb), dim3(threads), lds, s, *m, *d);
   return MJH_OK;
+}
+template <int NR, bool NEWTON>
+static int launch_solve_n(const MjhModel* m, const MjhData* d, hipStream_t s) {
+  switch ((m->nv + 3) / 4) {  // kernels are specialised on ceil(nv/4): no padded matrix columns
+    case 0:
+    case 1: return launch_solve_t<1, NR, NEWTON>(m, d, s);
+    case 2: return launch_solve_t<2, NR, NEWTON>(m, d, s);
+    case 3: return launch_solve_t<3, NR, NEWTON>(m, d, s);
+    case 4: return launch_solve_t<4, NR, NEWTON>(m, d, s);
+    case 5: return launch_solve_t<5, NR, NEWTON>(m, d, s);
+    case 6: return launch_solve_t<6, NR, NEWTON>(m, d, s);
+    case 7: return launch_solve_t<7, NR, NEWTON>(m, d, s);
+    default: return launch_solve_t<8, NR, NEWTON>(m, d, s);
+  }
 }
 static int launch_solve(const MjhModel* m, const MjhData* d, hipStream_t s) {
   if (m->cone != 0) return fail(MJH_E_UNSUPPORTED, "elliptic cones are not implemented yet");
   if (m->nv > 32) return fail(MJH_E_UNSUPPORTED, "nv > 32 needs the sparse/blocked solver path (not implemented yet)");
-  const bool newton = m->solver == SOL_NEWTON;
   if (m->solver != SOL_NEWTON && m->solver != SOL_CG) return fail(MJH_E_UNSUPPORTED, "solver must be CG or Newton");
-  if (m->nv <= 8) return newton ? launch_solve_t<8, true>(m, d, s) : launch_solve_t<8, false>(m, d, s);
-  if (m->nv <= 16) return newton ? launch_solve_t<16, true>(m, d, s) : launch_solve_t<16, false>(m, d, s);
-  return newton ? launch_solve_t<32, true>(m, d, s) : launch_solve_t<32, false>(m, d, s);
+  if (d->njmax > 192) return fail(MJH_E_UNSUPPORTED, "njmax > 192 is not supported by the register-resident solver yet");
+  const bool newton = m->solver == SOL_NEWTON;
+  // rows per lane (32 lanes per world): 2 covers njmax <= 64 (humanoid, panda), 6 covers njmax <= 192 (G1-class)
+  if (d->njmax <= 64) return newton ? launch_solve_n<2, true>(m, d, s) : launch_solve_n<2, false>(m, d, s);
+  return newton ? launch_solve_n<6, true>(m, d, s) : launch_solve_n<6, false>(m, d, s);
 }
 static int launch_integrate(const MjhModel* m, const MjhData* d, int mode, hipStream_t s) {
   const IntLayout lay = int_layout(m->nv, m->nC);

@@ -6,13 +6,15 @@
 // (_solve_done).  The reference runs ~12 launches per iteration inside a CUDA conditional-graph while loop and
 // keeps J/H/vectors in global memory; every world iterates until ALL worlds converge.
 //
-// MI355X mapping: one 32-lane group (half a wavefront) owns a world for the WHOLE solve.  J (njmax x nv) and
-// all solver vectors are LDS resident; for Newton, lane i keeps row i of M, of H = M + J^T D J and column i
-// of its Cholesky factor in VGPRs (the kernel is LDS-capacity bound, so VGPRs are free), the factorisation
-// is a right-looking Cholesky whose pivot column is broadcast through a 128 B LDS line, the triangular
-// solves broadcast with v_readlane, and every row reduction of the line search is a DPP row_shr/row_bcast
-// tree.  Each world leaves the loop as soon as ITS convergence test passes.  HBM traffic is the algorithmic
-// minimum: J, D, aref, M, three nv-vectors in; qacc, qfrc_constraint, Ma, force, state out.
+// MI355X mapping: one 32-lane group (half a wavefront) owns a world for the WHOLE solve.  J (njmax x JS) and all
+// solver vectors are LDS resident; lane i keeps row i of M, of the matrix being factored (H = M + J^T D J for
+// Newton, M itself for CG) and column i of its Cholesky factor in VGPRs (the kernel is LDS-capacity bound, so
+// VGPRs are free).  The factorisation is a right-looking Cholesky whose pivot column is broadcast through one
+// LDS line, the triangular solves broadcast with v_readlane, and every row reduction of the line search is a DPP
+// row_shr/row_bcast tree.  The kernel is specialised on NV4 = ceil(nv/4): all matrix loops are fully unrolled
+// over exactly NVR = 4*NV4 columns.  Each world leaves the loop as soon as ITS convergence test passes.
+// HBM traffic is the algorithmic minimum: J, D, aref, M, three nv-vectors in; qacc, qfrc_constraint, Ma, force,
+// state out.
 #pragma once
 #include "dev_common.hpp"
 #include "smooth.hpp"
@@ -37,19 +39,18 @@ DEV float gsum32(float v) {
   return bcast32(v, 31);
 }
 
-// ---- dense Cholesky with lane i owning row i (NVP <= 32), all indices compile-time ----------------------
+// ---- dense Cholesky with lane i owning row i (NVR <= 32), all indices compile-time ----------------------
 // h: row i of the SPD matrix on entry, row i of L on exit (entries above the diagonal are junk);
 // lt: column i of L below the diagonal (for the transposed solve); rdiag = 1 / L[i][i].
-// `col` is an LDS scratch of 8*(NVP+4) floats private to the group.  Lanes >= NVP must hold identity rows.
-template <int NVP>
-DEV void chol_factor_rows(float (&h)[NVP], float (&lt)[NVP], float& rdiag, float* col, int lig) {
-  constexpr int JS = NVP + 4;
-  const bool own = lig < NVP;
-  const int ligc = own ? lig : NVP - 1;
+// `col` is an LDS scratch of max(64, 8*JS) floats private to the group.  Lanes >= nv must hold identity rows.
+template <int NVR, int JS>
+DEV void chol_factor_rows(float (&h)[NVR], float (&lt)[NVR], float& rdiag, float* col, int lig) {
+  const bool own = lig < NVR;
+  const int ligc = own ? lig : NVR - 1;
   rdiag = 1.0f;
 #pragma unroll
-  for (int j = 0; j < NVP; ++j) {  // right-looking; pivot column broadcast through LDS (double buffered)
-    float* cb = col + (j & 1) * NVP;
+  for (int j = 0; j < NVR; ++j) {  // right-looking; pivot column broadcast through LDS (double buffered)
+    float* cb = col + (j & 1) * 32;
     if (own) cb[lig] = h[j];
     gsync();
     const float piv = sqrtf(fmaxf(cb[j], MJ_MINVAL));
@@ -57,40 +58,43 @@ DEV void chol_factor_rows(float (&h)[NVP], float (&lt)[NVP], float& rdiag, float
     const float lij = (lig == j) ? piv : h[j] * inv;
     h[j] = lij;
     if (lig == j) rdiag = inv;
+    const float t = lij * inv;
 #pragma unroll
-    for (int k = j + 1; k < NVP; ++k) h[k] -= lij * (cb[k] * inv);
+    for (int k = j + 1; k < NVR; ++k) h[k] -= t * cb[k];
   }
   gsync();
 #pragma unroll
-  for (int c0 = 0; c0 < NVP; c0 += 8) {  // column i of L: rows pass through an 8-row LDS tile
+  for (int c0 = 0; c0 < NVR; c0 += 8) {  // column i of L: rows pass through an 8-row LDS tile
     if (lig >= c0 && lig < c0 + 8 && own) {
 #pragma unroll
-      for (int c4 = 0; c4 < NVP / 4; ++c4)
+      for (int c4 = 0; c4 < NVR / 4; ++c4)
         *reinterpret_cast<float4*>(col + (lig - c0) * JS + 4 * c4) = make_float4(h[4 * c4], h[4 * c4 + 1], h[4 * c4 + 2], h[4 * c4 + 3]);
     }
     gsync();
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) {
-      const float v = col[kk * JS + ligc];
-      lt[c0 + kk] = (own && c0 + kk > lig) ? v : 0.0f;
+      if (c0 + kk < NVR) {
+        const float v = col[kk * JS + ligc];
+        lt[c0 + kk] = (own && c0 + kk > lig) ? v : 0.0f;
+      }
     }
     gsync();
   }
 }
 // x = (L L^T)^-1 g for the lane's component; broadcasts via v_readlane (no LDS traffic)
-template <int NVP>
-DEV float chol_solve_rows(const float (&h)[NVP], const float (&lt)[NVP], float rdiag, float g) {
+template <int NVR>
+DEV float chol_solve_rows(const float (&h)[NVR], const float (&lt)[NVR], float rdiag, float g) {
   const int lig = threadIdx.x & 31;
   float acc = g, y = 0.0f, x = 0.0f;
 #pragma unroll
-  for (int k = 0; k < NVP; ++k) {
+  for (int k = 0; k < NVR; ++k) {
     const float yk = bcast32(acc * rdiag, k);
     if (lig == k) y = yk;
     acc -= h[k] * yk;
   }
   acc = y;
 #pragma unroll
-  for (int k = NVP - 1; k >= 0; --k) {
+  for (int k = NVR - 1; k >= 0; --k) {
     const float xk = bcast32(acc * rdiag, k);
     if (lig == k) x = xk;
     acc -= lt[k] * xk;
@@ -99,108 +103,134 @@ DEV float chol_solve_rows(const float (&h)[NVP], const float (&lt)[NVP], float r
 }
 
 struct SolveLayout {
-  int J, D, Jaref, jv, floss, force, state, qacc, Ma, grad, search, mv, fs, Mg, pg, pMg, qc, col, L, dinv, total;
+  int J, force, da, bsearch, bgrad, col, total;
 };
-template <int NVP>
-__host__ __device__ inline SolveLayout solve_layout(int njmax, int nC, bool cg) {
+template <int NV4, int NR>
+__host__ __device__ inline SolveLayout solve_layout(int njmax) {
+  constexpr int NVR = 4 * NV4;
+  constexpr int JS = (NV4 & 1) ? NVR : NVR + 4;  // JS/4 odd: row-per-lane 16-byte reads hit distinct banks
+  const int njp = ((njmax + 3) / 4) * 4;
   SolveLayout p;
   int o = 0;
-  p.J = o; o += (njmax > NVP ? njmax : NVP) * (NVP + 4);  // also stages the dense NVP x NVP copy of M
-  p.D = o; o += njmax;
-  p.Jaref = o; o += njmax;
-  p.jv = o; o += njmax;
-  p.floss = o; o += njmax;
-  p.force = o; o += njmax;
-  p.state = o; o += njmax;
-  p.qacc = o; o += 32;  // nv-vectors are indexed by lane id (0..31)
-  p.Ma = o; o += 32;
-  p.grad = o; o += 32;
-  p.search = o; o += 32;
-  p.mv = o; o += 32;
-  p.fs = o; o += 32;
-  p.Mg = o; o += 32;
-  p.pg = o; o += 32;
-  p.pMg = o; o += 32;
-  p.qc = o; o += 32;
-  p.col = o; o += 8 * (NVP + 4);  // pivot-column double buffer (2*NVP) / 8-row transpose tile
-  p.L = o;
-  p.dinv = o;
+  p.J = o; o += (njp > NVR ? njp : NVR) * JS;  // also stages the dense NVR x NVR copy of M
+  p.force = o; o += 32 * NR;                    // efc_force of the current iterate (for J^T f)
+  p.da = o; o += 32 * NR;                       // D * [state == QUADRATIC] (Newton: J^T D J)
+  p.bsearch = o; o += 32;                       // broadcast copies of the two nv-vectors other lanes read
+  p.bgrad = o; o += 32;
+  p.col = o; o += 8 * JS > 64 ? 8 * JS : 64;    // Cholesky pivot column / transpose tile, Gauss-Jordan pivot row
   p.total = ((o + 3) / 4) * 4;
   return p;
 }
 
-// (cost - cost(0), grad, hess) of the constraint part along the ray at three step sizes
-// (solver.py:702-755 _compute_efc_eval_pt_3alphas_pyramidal; single-alpha variants 518-556, 620-647)
-struct Pt3 {
-  float c[3], g[3], h[3];
-};
-DEV void eval_rows(const float* eJaref, const float* ejv, const float* eD, const float* efl, int nefc, int ne, int nf,
-                   int lig, float a0, float a1, float a2, Pt3& out) {
-  float c0 = 0, c1 = 0, c2 = 0, g0 = 0, g1 = 0, g2 = 0, h0 = 0, h1 = 0, h2 = 0;
-  for (int r = lig; r < nefc; r += 32) {
-    const float ja = eJaref[r], jv = ejv[r], D = eD[r];
-    const float jvD = jv * D, hess = jv * jvD, grad0 = jvD * ja;
-    const float x0 = ja + a0 * jv, x1 = ja + a1 * jv, x2 = ja + a2 * jv;
-    if (r >= ne + nf) {
-      const float quad0 = 0.5f * D * ja * ja;
-      const float cost0 = ja < 0.0f ? quad0 : 0.0f;
-      const float offset = quad0 - cost0;
-      if (x0 < 0.0f) { c0 += a0 * (grad0 + 0.5f * a0 * hess) + offset; g0 += grad0 + a0 * hess; h0 += hess; } else c0 -= cost0;
-      if (x1 < 0.0f) { c1 += a1 * (grad0 + 0.5f * a1 * hess) + offset; g1 += grad0 + a1 * hess; h1 += hess; } else c1 -= cost0;
-      if (x2 < 0.0f) { c2 += a2 * (grad0 + 0.5f * a2 * hess) + offset; g2 += grad0 + a2 * hess; h2 += hess; } else c2 -= cost0;
-    } else if (r >= ne) {
-      const float f = efl[r], rf = safe_div(f, D);
-      const float cost0 = (-rf < ja && ja < rf) ? 0.5f * D * ja * ja : (ja <= -rf ? f * (-0.5f * rf - ja) : f * (-0.5f * rf + ja));
-      const float fjv = f * jv;
-      if (-rf < x0 && x0 < rf) { c0 += 0.5f * D * x0 * x0 - cost0; g0 += jvD * x0; h0 += hess; }
-      else if (x0 <= -rf) { c0 += f * (-0.5f * rf - x0) - cost0; g0 -= fjv; } else { c0 += f * (-0.5f * rf + x0) - cost0; g0 += fjv; }
-      if (-rf < x1 && x1 < rf) { c1 += 0.5f * D * x1 * x1 - cost0; g1 += jvD * x1; h1 += hess; }
-      else if (x1 <= -rf) { c1 += f * (-0.5f * rf - x1) - cost0; g1 -= fjv; } else { c1 += f * (-0.5f * rf + x1) - cost0; g1 += fjv; }
-      if (-rf < x2 && x2 < rf) { c2 += 0.5f * D * x2 * x2 - cost0; g2 += jvD * x2; h2 += hess; }
-      else if (x2 <= -rf) { c2 += f * (-0.5f * rf - x2) - cost0; g2 -= fjv; } else { c2 += f * (-0.5f * rf + x2) - cost0; g2 += fjv; }
-    } else {
-      c0 += a0 * (grad0 + 0.5f * a0 * hess); g0 += grad0 + a0 * hess; h0 += hess;
-      c1 += a1 * (grad0 + 0.5f * a1 * hess); g1 += grad0 + a1 * hess; h1 += hess;
-      c2 += a2 * (grad0 + 0.5f * a2 * hess); g2 += grad0 + a2 * hess; h2 += hess;
-    }
-  }
-  out.c[0] = gsum32(c0); out.c[1] = gsum32(c1); out.c[2] = gsum32(c2);
-  out.g[0] = gsum32(g0); out.g[1] = gsum32(g1); out.g[2] = gsum32(g2);
-  out.h[0] = gsum32(h0); out.h[1] = gsum32(h1); out.h[2] = gsum32(h2);
-}
+// (cost - cost(0), grad, hess) of ONE constraint row on the ray at step alpha
+// (solver.py:518-556 _compute_efc_eval_pt_pyramidal; alpha = 0 variant 620-647)
 struct P3 {
   float c, g, h;
 };
+DEV P3 eval_row(float ja, float jv, float D, float f, int kind, float a) {
+  const float jvD = jv * D, hess = jv * jvD, grad0 = jvD * ja;
+  const float x = ja + a * jv;
+  P3 r = P3{0.0f, 0.0f, 0.0f};
+  if (kind == 2) {  // limit / contact: active only when x < 0
+    const float quad0 = 0.5f * D * ja * ja;
+    const float cost0 = ja < 0.0f ? quad0 : 0.0f;
+    if (x < 0.0f) {
+      r.c = a * (grad0 + 0.5f * a * hess) + (quad0 - cost0);
+      r.g = grad0 + a * hess;
+      r.h = hess;
+    } else {
+      r.c = -cost0;
+    }
+  } else if (kind == 1) {  // friction loss
+    const float rf = safe_div(f, D);
+    const float cost0 = (-rf < ja && ja < rf) ? 0.5f * D * ja * ja : (ja <= -rf ? f * (-0.5f * rf - ja) : f * (-0.5f * rf + ja));
+    if (-rf < x && x < rf) {
+      r.c = 0.5f * D * x * x - cost0;
+      r.g = jvD * x;
+      r.h = hess;
+    } else if (x <= -rf) {
+      r.c = f * (-0.5f * rf - x) - cost0;
+      r.g = -f * jv;
+    } else {
+      r.c = f * (-0.5f * rf + x) - cost0;
+      r.g = f * jv;
+    }
+  } else if (kind == 0) {  // equality
+    r.c = a * (grad0 + 0.5f * a * hess);
+    r.g = grad0 + a * hess;
+    r.h = hess;
+  }
+  return r;
+}
 DEV bool in_bracket(P3 x, P3 y) { return (x.g < y.g && y.g < 0.0f) || (x.g > y.g && y.g > 0.0f); }
 
-template <int NVP, bool NEWTON>
+// Rows of M^-1 by Gauss-Jordan with lane i owning row i of [A | B] (A = M, B = I); no pivoting (M is SPD).
+// At step k lane k publishes the entries the other rows need -- B[k][0..k] and A[k][k+1..] -- as ONE LDS line
+// (double buffered), the pivot A[k][k] travels by v_readlane; every lane then applies one rank-1 update.
+// The scale step of row k is folded into the same update with the multiplier 1 - 1/pivot.
+template <int NVR>
+DEV void invert_rows(const float (&mrow)[NVR], float (&b)[NVR], float* buf, int lig) {
+  float a[NVR];
+#pragma unroll
+  for (int c = 0; c < NVR; ++c) {
+    a[c] = mrow[c];
+    b[c] = (c == lig) ? 1.0f : 0.0f;
+  }
+#pragma unroll
+  for (int k = 0; k < NVR; ++k) {
+    float* pb = buf + (k & 1) * 32;
+    if (lig == k) {
+#pragma unroll
+      for (int c4 = 0; c4 < NVR / 4; ++c4) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (4 * c4 + e <= k) ? b[4 * c4 + e] : a[4 * c4 + e];
+        *reinterpret_cast<float4*>(pb + 4 * c4) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+    gsync();
+    const float ipk = 1.0f / bcast32(a[k], k);
+    const float f = (lig == k) ? (1.0f - ipk) : a[k] * ipk;
+#pragma unroll
+    for (int c4 = 0; c4 < NVR / 4; ++c4) {
+      const float4 v4 = *reinterpret_cast<const float4*>(pb + 4 * c4);
+      const float pr[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = 4 * c4 + e;
+        if (c <= k) b[c] -= f * pr[e];
+        else a[c] -= f * pr[e];
+      }
+    }
+  }
+}
+
+template <int NV4, int NR, bool NEWTON>
 __global__ void __launch_bounds__(256) k_solve(MjhModel m, MjhData d) {
   constexpr int G = 32;
-  constexpr int JS = NVP + 4;
+  constexpr int NVR = 4 * NV4;
+  constexpr int JS = (NV4 & 1) ? NVR : NVR + 4;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int nv = m.nv, nC = m.nC, njmax = d.njmax, nvp = d.nv_pad;
-  const SolveLayout lay = solve_layout<NVP>(njmax, nC, !NEWTON);
+  const SolveLayout lay = solve_layout<NV4, NR>(njmax);
   int* shi = reinterpret_cast<int*>(smem);
   const MStruct ms = load_mstruct<G>(m, shi);
   const int lig = threadIdx.x & (G - 1), gib = threadIdx.x / G;
   const int w = blockIdx.x * (blockDim.x / G) + gib;
   if (w >= d.nworld) return;
   float* S = smem + mstruct_ints(nv, nC) + (size_t)gib * lay.total;
-  float* Jl = S + lay.J;
-  float *eD = S + lay.D, *eJaref = S + lay.Jaref, *ejv = S + lay.jv, *efl = S + lay.floss, *eforce = S + lay.force;
-  int* estate = reinterpret_cast<int*>(S + lay.state);
-  float *vq = S + lay.qacc, *vMa = S + lay.Ma, *vgrad = S + lay.grad, *vsearch = S + lay.search, *vmv = S + lay.mv,
-        *vfs = S + lay.fs, *vMg = S + lay.Mg, *vpg = S + lay.pg, *vpMg = S + lay.pMg, *vqc = S + lay.qc, *col = S + lay.col;
+  float *Jl = S + lay.J, *eforce = S + lay.force, *eda = S + lay.da, *bsearch = S + lay.bsearch, *bgrad = S + lay.bgrad, *col = S + lay.col;
 
-  const int nefc = min(d.nefc[w], njmax);
+  const int nefc = min(min(d.nefc[w], njmax), 32 * NR);
   const int ne = d.ne[w], nf = d.nf[w];
   const size_t vo = (size_t)w * nv, eo = (size_t)w * njmax;
   const bool active = lig < nv;
+  const int ligr = lig < NVR ? lig : NVR - 1;  // clamped row index for lanes beyond the matrix
 
   // ---- M row of this lane into registers (dense staging in the J region) ----------------------------------
-  float mrow[NVP];
+  float mrow[NVR];
   {
-    for (int idx = lig; idx < NVP * JS; idx += G) Jl[idx] = 0.0f;
+    for (int idx = lig; idx < NVR * JS; idx += G) Jl[idx] = 0.0f;
     gsync();
     const float* Mg = d.M + (size_t)w * nC;
     for (int i = lig; i < nv; i += G) {
@@ -214,66 +244,92 @@ __global__ void __launch_bounds__(256) k_solve(MjhModel m, MjhData d) {
     }
     gsync();
 #pragma unroll
-    for (int c = 0; c < NVP; ++c) mrow[c] = active ? Jl[lig * JS + c] : (c == lig ? 1.0f : 0.0f);
+    for (int c4 = 0; c4 < NV4; ++c4) {
+      const float4 v4 = *reinterpret_cast<const float4*>(Jl + ligr * JS + 4 * c4);
+      mrow[4 * c4] = active ? v4.x : (4 * c4 == lig ? 1.0f : 0.0f);
+      mrow[4 * c4 + 1] = active ? v4.y : (4 * c4 + 1 == lig ? 1.0f : 0.0f);
+      mrow[4 * c4 + 2] = active ? v4.z : (4 * c4 + 2 == lig ? 1.0f : 0.0f);
+      mrow[4 * c4 + 3] = active ? v4.w : (4 * c4 + 3 == lig ? 1.0f : 0.0f);
+    }
     gsync();
   }
 
-  // ---- dof vectors --------------------------------------------------------------------------------------
+  // ---- lane-owned dof scalars (element `lig` of each nv-vector lives in a register) ------------------------
   const bool warm = !(m.disableflags & DSBL_WARMSTART);
-  {
-    float q = 0.0f, fs = 0.0f;
-    if (active) {
-      q = nefc > 0 && warm ? d.qacc_warmstart[vo + lig] : d.qacc_smooth[vo + lig];
-      fs = d.qfrc_smooth[vo + lig];
-    }
-    vq[lig] = q;
-    vfs[lig] = fs;
-    vsearch[lig] = 0.0f;
+  float q = 0.0f, fs = 0.0f;
+  if (active) {
+    q = nefc > 0 && warm ? d.qacc_warmstart[vo + lig] : d.qacc_smooth[vo + lig];
+    fs = d.qfrc_smooth[vo + lig];
   }
-  gsync();
-  auto mul_m_row = [&](const float* vec) __attribute__((always_inline)) {  // lane i: sum_c M[i][c] vec[c], vec broadcast from LDS
-    float s = 0.0f;
+  // lane i: sum_c M[i][c] vec[c], vec broadcast from an LDS line
+  auto mul_row = [&](const float (&row)[NVR], const float* vec) __attribute__((always_inline)) {
+    float s0 = 0.0f, s1 = 0.0f;
 #pragma unroll
-    for (int c4 = 0; c4 < NVP / 4; ++c4) {
+    for (int c4 = 0; c4 < NV4; ++c4) {
       const float4 v4 = *reinterpret_cast<const float4*>(vec + 4 * c4);
-      s += mrow[4 * c4] * v4.x + mrow[4 * c4 + 1] * v4.y + mrow[4 * c4 + 2] * v4.z + mrow[4 * c4 + 3] * v4.w;
+      s0 += row[4 * c4] * v4.x + row[4 * c4 + 2] * v4.z;
+      s1 += row[4 * c4 + 1] * v4.y + row[4 * c4 + 3] * v4.w;
     }
-    return active ? s : 0.0f;
+    return active ? s0 + s1 : 0.0f;
   };
-  vMa[lig] = mul_m_row(vq);
+  bsearch[lig] = q;
+  gsync();
+  float Ma = mul_row(mrow, bsearch);
 
   if (nefc == 0) {  // unconstrained: qacc = qacc_smooth (solver.py:3684-3686)
     if (active) {
-      d.qacc[vo + lig] = vq[lig];
+      d.qacc[vo + lig] = q;
       d.qfrc_constraint[vo + lig] = 0.0f;
-      d.efc_Ma[vo + lig] = vMa[lig];
+      d.efc_Ma[vo + lig] = Ma;
     }
     if (lig == 0) d.solver_niter[w] = 0;
     return;
   }
 
-  // ---- J, D, aref, frictionloss into LDS ------------------------------------------------------------------
+  // ---- CG: rows of M^-1 in registers, once per solve; Newton: per-iteration Cholesky of H ------------------
+  float h[NVR], lt[NVR];  // Newton: H row / L row and L column; CG: h = row of M^-1
+  if (!NEWTON) invert_rows<NVR>(mrow, h, col, lig);
+
+  // ---- J into LDS; this lane's rows (D, aref, frictionloss, Jaref) into registers ---------------------------
+  const int nefc4 = (nefc + 3) & ~3;
   {
     const float* Jg = d.efc_J + (size_t)w * d.njmax_pad * nvp;
     for (int r = 0; r < nefc; ++r)
       for (int c = lig; c < JS; c += G) Jl[r * JS + c] = c < nvp ? Jg[(size_t)r * nvp + c] : 0.0f;
-    for (int r = lig; r < nefc; r += G) {
-      eD[r] = d.efc_D[eo + r];
-      efl[r] = d.efc_frictionloss[eo + r];
-    }
+    for (int r = nefc; r < nefc4; ++r)
+      for (int c = lig; c < JS; c += G) Jl[r * JS + c] = 0.0f;
+  }
+  float rD[NR], rfl[NR], rja[NR], rjv[NR], rfrc[NR];
+  int rst[NR], rkind[NR];
+  bool rhas[NR];
+#pragma unroll
+  for (int k = 0; k < NR; ++k) {
+    const int r = lig + 32 * k;
+    rhas[k] = r < nefc;
+    rD[k] = rhas[k] ? d.efc_D[eo + r] : 0.0f;
+    rfl[k] = rhas[k] ? d.efc_frictionloss[eo + r] : 0.0f;
+    rkind[k] = !rhas[k] ? 3 : (r >= ne + nf ? 2 : (r >= ne ? 1 : 0));  // 3: padding row (contributes nothing)
+    rjv[k] = 0.0f;
+    rfrc[k] = 0.0f;
+    rst[k] = 0;
+    eforce[r] = 0.0f;
+    eda[r] = 0.0f;
   }
   gsync();
-  auto j_dot = [&](const float* vec, int r) __attribute__((always_inline)) {  // J[r,:] . vec  (row-per-lane, conflict-free b128 reads)
-    float s = 0.0f;
+  // J[r,:] . vec  (row-per-lane, conflict-free 16-byte reads)
+  auto j_dot = [&](const float* vec, int r) __attribute__((always_inline)) {
+    float s0 = 0.0f, s1 = 0.0f;
 #pragma unroll
-    for (int c4 = 0; c4 < NVP / 4; ++c4) {
+    for (int c4 = 0; c4 < NV4; ++c4) {
       const float4 j4 = *reinterpret_cast<const float4*>(Jl + r * JS + 4 * c4);
       const float4 v4 = *reinterpret_cast<const float4*>(vec + 4 * c4);
-      s += j4.x * v4.x + j4.y * v4.y + j4.z * v4.z + j4.w * v4.w;
+      s0 += j4.x * v4.x + j4.z * v4.z;
+      s1 += j4.y * v4.y + j4.w * v4.w;
     }
-    return s;
+    return s0 + s1;
   };
-  for (int r = lig; r < nefc; r += G) eJaref[r] = j_dot(vq, r) - d.efc_aref[eo + r];
+#pragma unroll
+  for (int k = 0; k < NR; ++k) rja[k] = rhas[k] ? j_dot(bsearch, lig + 32 * k) - d.efc_aref[eo + lig + 32 * k] : 0.0f;
   gsync();
 
   const float tolerance = bf(m.opt_tolerance, m.opt_tolerance_nb, w, 1)[0];
@@ -283,83 +339,7 @@ __global__ void __launch_bounds__(256) k_solve(MjhModel m, MjhData d) {
   const float rscale = 1.0f / scale;
 
   float grad_dot = 0.0f, search_dot = 0.0f, decrement = 0.0f;
-  float h[NVP], lt[NVP];
-  float mrdiag = 1.0f;
-
-  // force/state per row + qfrc_constraint = J^T force (solver.py:1698-1822, 1912-1947)
-  auto update_constraint = [&]() __attribute__((always_inline)) {
-    for (int r = lig; r < nefc; r += G) {
-      const float ja = eJaref[r], D = eD[r];
-      float force;
-      int state;
-      if (r < ne) {
-        force = -D * ja;
-        state = ST_QUADRATIC;
-      } else if (r < ne + nf) {
-        const float f = efl[r], rf = safe_div(f, D);
-        if (ja <= -rf) { force = f; state = ST_LINEARNEG; }
-        else if (ja >= rf) { force = -f; state = ST_LINEARPOS; }
-        else { force = -D * ja; state = ST_QUADRATIC; }
-      } else if (ja >= 0.0f) {
-        force = 0.0f;
-        state = ST_SATISFIED;
-      } else {
-        force = -D * ja;
-        state = ST_QUADRATIC;
-      }
-      eforce[r] = force;
-      estate[r] = state;
-    }
-    gsync();
-    float s = 0.0f;
-    if (lig < JS)
-      for (int r = 0; r < nefc; ++r) s += Jl[r * JS + lig] * eforce[r];
-    vqc[lig] = active ? s : 0.0f;
-  };
-
-  // grad, then search direction (solver.py:3061-3220)
-  auto update_gradient = [&]() __attribute__((always_inline)) {
-    const float g = active ? (vMa[lig] - vfs[lig] - vqc[lig]) : 0.0f;
-    vgrad[lig] = g;
-    grad_dot = gsum32(g * g);
-    if (NEWTON) {
-      // H row = M row + sum over QUADRATIC rows of D * J[r][i] * J[r][:]   (JTDAJ, solver.py:2365-2440)
-#pragma unroll
-      for (int c = 0; c < NVP; ++c) h[c] = mrow[c];
-      for (int r = 0; r < nefc; ++r) {
-        if (estate[r] != ST_QUADRATIC) continue;
-        const float jd = Jl[r * JS + lig] * eD[r];
-#pragma unroll
-        for (int c4 = 0; c4 < NVP / 4; ++c4) {
-          const float4 j4 = *reinterpret_cast<const float4*>(Jl + r * JS + 4 * c4);
-          h[4 * c4] += jd * j4.x;
-          h[4 * c4 + 1] += jd * j4.y;
-          h[4 * c4 + 2] += jd * j4.z;
-          h[4 * c4 + 3] += jd * j4.w;
-        }
-      }
-      float rdiag;
-      chol_factor_rows<NVP>(h, lt, rdiag, col, lig);
-      float x = chol_solve_rows<NVP>(h, lt, rdiag, g);
-      if (!active) x = 0.0f;
-      vMg[lig] = x;
-      vsearch[lig] = -x;
-      search_dot = gsum32(x * x);
-      decrement = gsum32(g * x);
-      gsync();
-    } else {
-      // CG: Mgrad = M^-1 grad with the dense Cholesky factor of M held in registers (factored once per solve)
-      float x = chol_solve_rows<NVP>(h, lt, mrdiag, g);
-      if (!active) x = 0.0f;
-      vMg[lig] = x;
-      gsync();
-    }
-  };
-  if (!NEWTON) {
-#pragma unroll
-    for (int c = 0; c < NVP; ++c) h[c] = mrow[c];
-    chol_factor_rows<NVP>(h, lt, mrdiag, col, lig);
-  }
+  float g = 0.0f, Mg = 0.0f, pg = 0.0f, pMg = 0.0f, srch = 0.0f, qc = 0.0f;
 
   int niter = 0;
   const int maxiter = m.iterations, ls_iterations = m.ls_iterations;
@@ -368,17 +348,77 @@ __global__ void __launch_bounds__(256) k_solve(MjhModel m, MjhData d) {
   // One loop body = [constraint update, gradient/search update, convergence test, line search + move], so that the
   // (large, fully unrolled) gradient code has a single call site.  Iteration 0 is init_context (solver.py:3622).
   for (;;) {
-    update_constraint();
+    // ---- force/state of this lane's rows (solver.py:1698-1822) ------------------------------------------------
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      const float ja = rja[k], D = rD[k];
+      float force = 0.0f;
+      int state = ST_SATISFIED;
+      if (rkind[k] == 0) {
+        force = -D * ja;
+        state = ST_QUADRATIC;
+      } else if (rkind[k] == 1) {
+        const float f = rfl[k], rf = safe_div(f, D);
+        if (ja <= -rf) { force = f; state = ST_LINEARNEG; }
+        else if (ja >= rf) { force = -f; state = ST_LINEARPOS; }
+        else { force = -D * ja; state = ST_QUADRATIC; }
+      } else if (rkind[k] == 2 && ja < 0.0f) {
+        force = -D * ja;
+        state = ST_QUADRATIC;
+      }
+      rfrc[k] = force;
+      rst[k] = state;
+      eforce[lig + 32 * k] = force;
+      if (NEWTON) eda[lig + 32 * k] = state == ST_QUADRATIC ? D : 0.0f;
+    }
     gsync();
-    update_gradient();
+    // ---- qfrc_constraint = J^T force (solver.py:1912-1947): lane = dof, 4 rows per step ------------------------
+    {
+      float s0 = 0.0f, s1 = 0.0f;
+      const float* Jc = Jl + ligr;
+      for (int r = 0; r < nefc4; r += 4) {  // rows nefc..nefc4 carry zero force and zero J
+        const float4 f4 = *reinterpret_cast<const float4*>(eforce + r);
+        s0 += Jc[r * JS] * f4.x + Jc[(r + 2) * JS] * f4.z;
+        s1 += Jc[(r + 1) * JS] * f4.y + Jc[(r + 3) * JS] * f4.w;
+      }
+      qc = active ? s0 + s1 : 0.0f;
+    }
+    // ---- gradient and search direction (solver.py:3061-3220) ---------------------------------------------------
+    g = active ? (Ma - fs - qc) : 0.0f;
+    grad_dot = gsum32(g * g);
+    if (NEWTON) {
+      // H row = M row + sum_r (D_r [state_r == QUADRATIC]) J[r][i] J[r][:]   (JTDAJ, solver.py:2365-2440)
+#pragma unroll
+      for (int c = 0; c < NVR; ++c) h[c] = mrow[c];
+      for (int r = 0; r < nefc; ++r) {
+        const float jd = Jl[r * JS + ligr] * eda[r];
+#pragma unroll
+        for (int c4 = 0; c4 < NV4; ++c4) {
+          const float4 j4 = *reinterpret_cast<const float4*>(Jl + r * JS + 4 * c4);
+          h[4 * c4] += jd * j4.x;
+          h[4 * c4 + 1] += jd * j4.y;
+          h[4 * c4 + 2] += jd * j4.z;
+          h[4 * c4 + 3] += jd * j4.w;
+        }
+      }
+      float rdiag;
+      chol_factor_rows<NVR, JS>(h, lt, rdiag, col, lig);
+      Mg = chol_solve_rows<NVR>(h, lt, rdiag, g);
+      if (!active) Mg = 0.0f;
+      srch = -Mg;
+      search_dot = gsum32(Mg * Mg);
+      decrement = gsum32(g * Mg);
+    } else {
+      bgrad[lig] = g;
+      gsync();
+      Mg = mul_row(h, bgrad);  // Mgrad = M^-1 grad
+    }
     if (niter == 0) {
       if (!NEWTON) {  // CG: search = -Mgrad (solver.py:1663-1695)
-        const float mg = vMg[lig];
-        vsearch[lig] = -mg;
-        search_dot = gsum32(active ? mg * mg : 0.0f);
-        vpg[lig] = vgrad[lig];
-        vpMg[lig] = mg;
-        gsync();
+        srch = -Mg;
+        search_dot = gsum32(Mg * Mg);
+        pg = g;
+        pMg = Mg;
       }
     } else {
       const float imp = improvement * rscale, gradient = sqrtf(grad_dot) * rscale;
@@ -387,18 +427,15 @@ __global__ void __launch_bounds__(256) k_solve(MjhModel m, MjhData d) {
         done = (imp < tolerance) || (gradient < tolerance) || (0.5f * decrement * rscale < tolerance);
       } else {
         // Polak-Ribiere (solver.py:3283-3450)
-        const float mg = vMg[lig], pm = vpMg[lig];
-        const float num = gsum32(active ? vgrad[lig] * (mg - pm) : 0.0f);
-        const float den = gsum32(active ? vpg[lig] * pm : 0.0f);
+        const float num = gsum32(g * (Mg - pMg));
+        const float den = gsum32(pg * pMg);
         const float beta = fmaxf(0.0f, num / fmaxf(MJ_MINVAL, den));
         done = (imp < tolerance) || (gradient < tolerance);
         if (!done) {
-          const float s = -mg + beta * vsearch[lig];
-          vsearch[lig] = s;
-          search_dot = gsum32(active ? s * s : 0.0f);
-          vpg[lig] = vgrad[lig];
-          vpMg[lig] = mg;
-          gsync();
+          srch = -Mg + beta * srch;
+          search_dot = gsum32(srch * srch);
+          pg = g;
+          pMg = Mg;
         }
       }
       if (done) break;
@@ -409,21 +446,34 @@ __global__ void __launch_bounds__(256) k_solve(MjhModel m, MjhData d) {
     }
     if (maxiter == 0) break;
     // ---- mv = M search, jv = J search --------------------------------------------------------------------
-    vmv[lig] = mul_m_row(vsearch);
-    for (int r = lig; r < nefc; r += G) ejv[r] = j_dot(vsearch, r);
+    bsearch[lig] = srch;
     gsync();
-    // ---- line search (solver.py:835-1347) -------------------------------------------------------------------
-    const float sr = vsearch[lig];
-    const float gauss1 = gsum32(active ? sr * (vMa[lig] - vfs[lig]) : 0.0f);
-    const float gauss2 = gsum32(active ? 0.5f * sr * vmv[lig] : 0.0f);
+    const float mvi = mul_row(mrow, bsearch);
+#pragma unroll
+    for (int k = 0; k < NR; ++k) rjv[k] = rhas[k] ? j_dot(bsearch, lig + 32 * k) : 0.0f;
+    // ---- line search (solver.py:835-1347); rows and all sums stay in registers ----------------------------------
+    const float gauss1 = gsum32(srch * (Ma - fs));
+    const float gauss2 = gsum32(0.5f * srch * mvi);
     const float gtol = fmaxf(tolerance * ls_tolerance * sqrtf(search_dot) * scale, 1e-6f);
-    Pt3 e;
-    eval_rows(eJaref, ejv, eD, efl, nefc, ne, nf, lig, 0.0f, 0.0f, 0.0f, e);
-    const P3 p0 = P3{0.0f, gauss1 + e.g[0], 2.0f * gauss2 + e.h[0]};
+    auto eval = [&](float a) __attribute__((always_inline)) {
+      P3 s = P3{0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int k = 0; k < NR; ++k) {
+        const P3 t = eval_row(rja[k], rjv[k], rD[k], rfl[k], rkind[k], a);
+        s.c += t.c;
+        s.g += t.g;
+        s.h += t.h;
+      }
+      return s;
+    };
+    // group sums + the Gauss (smooth) quadratic
+    auto total = [&](P3 s, float a) __attribute__((always_inline)) {
+      return P3{a * a * gauss2 + a * gauss1 + gsum32(s.c), 2.0f * a * gauss2 + gauss1 + gsum32(s.g), 2.0f * gauss2 + gsum32(s.h)};
+    };
+    const P3 e = eval(0.0f);
+    const P3 p0 = P3{0.0f, gauss1 + gsum32(e.g), 2.0f * gauss2 + gsum32(e.h)};
     const float lo_alpha_in = -safe_div(p0.g, p0.h);
-    eval_rows(eJaref, ejv, eD, efl, nefc, ne, nf, lig, lo_alpha_in, lo_alpha_in, lo_alpha_in, e);
-    const P3 lo_in = P3{lo_alpha_in * lo_alpha_in * gauss2 + lo_alpha_in * gauss1 + e.c[0],
-                        2.0f * lo_alpha_in * gauss2 + gauss1 + e.g[0], 2.0f * gauss2 + e.h[0]};
+    const P3 lo_in = total(eval(lo_alpha_in), lo_alpha_in);
     float alpha = 0.0f;
     improvement = 0.0f;
     bool ls_converged = fabsf(lo_in.g) < gtol && lo_in.c < 0.0f;
@@ -437,10 +487,7 @@ __global__ void __launch_bounds__(256) k_solve(MjhModel m, MjhData d) {
       for (int it = 0; it < ls_iterations; ++it) {
         const float a_lo = lo_alpha - safe_div(lo.g, lo.h), a_hi = hi_alpha - safe_div(hi.g, hi.h);
         const float a_mid = 0.5f * (lo_alpha + hi_alpha);
-        eval_rows(eJaref, ejv, eD, efl, nefc, ne, nf, lig, a_lo, a_hi, a_mid, e);
-        const P3 lo_next = P3{a_lo * a_lo * gauss2 + a_lo * gauss1 + e.c[0], 2.0f * a_lo * gauss2 + gauss1 + e.g[0], 2.0f * gauss2 + e.h[0]};
-        const P3 hi_next = P3{a_hi * a_hi * gauss2 + a_hi * gauss1 + e.c[1], 2.0f * a_hi * gauss2 + gauss1 + e.g[1], 2.0f * gauss2 + e.h[1]};
-        const P3 mid = P3{a_mid * a_mid * gauss2 + a_mid * gauss1 + e.c[2], 2.0f * a_mid * gauss2 + gauss1 + e.g[2], 2.0f * gauss2 + e.h[2]};
+        const P3 lo_next = total(eval(a_lo), a_lo), hi_next = total(eval(a_hi), a_hi), mid = total(eval(a_mid), a_mid);
         const bool s1 = in_bracket(lo, lo_next);
         if (s1) { lo = lo_next; lo_alpha = a_lo; }
         const bool s2 = in_bracket(lo, mid);
@@ -468,24 +515,26 @@ __global__ void __launch_bounds__(256) k_solve(MjhModel m, MjhData d) {
       }
     }
     if (!ls_converged) ovf |= OVF_LS_ITERATIONS;
-    // ---- move along the ray ------------------------------------------------------------------------------
-    vq[lig] += alpha * sr;
-    vMa[lig] += alpha * vmv[lig];
-    for (int r = lig; r < nefc; r += G) eJaref[r] += alpha * ejv[r];
-    gsync();
+    // ---- move along the ray (registers only) ---------------------------------------------------------------
+    q += alpha * srch;
+    Ma += alpha * mvi;
+#pragma unroll
+    for (int k = 0; k < NR; ++k) rja[k] += alpha * rjv[k];
     ++niter;
   }
 
   // ---- outputs ---------------------------------------------------------------------------------------------
   if (active) {
-    d.qacc[vo + lig] = vq[lig];
-    d.qfrc_constraint[vo + lig] = vqc[lig];
-    d.efc_Ma[vo + lig] = vMa[lig];
+    d.qacc[vo + lig] = q;
+    d.qfrc_constraint[vo + lig] = qc;
+    d.efc_Ma[vo + lig] = Ma;
   }
-  for (int r = lig; r < nefc; r += G) {
-    d.efc_force[eo + r] = eforce[r];
-    d.efc_state[eo + r] = estate[r];
-  }
+#pragma unroll
+  for (int k = 0; k < NR; ++k)
+    if (rhas[k]) {
+      d.efc_force[eo + lig + 32 * k] = rfrc[k];
+      d.efc_state[eo + lig + 32 * k] = rst[k];
+    }
   if (lig == 0) {
     d.solver_niter[w] = niter;
     if (ovf) atomicOr(d.overflow + w, ovf);
