@@ -165,6 +165,7 @@ typedef struct MjhData {
   int* ws_ncon;        /* [nworld]   contacts found per world                         */
   int* ws_conadr;      /* [nworld]   exclusive scan of ws_ncon = first public slot    */
   int* ws_ncollision;  /* [nworld]   broadphase candidates per world                  */
+  int* ws_order;       /* [nworld]   solver schedule: worlds sorted by last step's solver_niter (longest first) */
 } MjhData;
 
 /* One launch sequence for a reference stage function (MJH_STAGE_*); `stream` is a hipStream_t. */

@@ -206,3 +206,30 @@ __global__ void k_overflow(MjhData d) {
   if (d.nacon[0] > d.naconmax) o |= OVF_NARROWPHASE;
   if (o) d.overflow[w] |= o;
 }
+
+// Solver schedule for the NEXT step: counting sort of worlds by this step's solver_niter, longest first.
+// Iteration counts are strongly correlated from step to step, so (i) the longest solves start first (LPT: no
+// long straggler wave at the tail of k_solve) and (ii) the two worlds sharing a wavefront need a similar number
+// of iterations (a wave runs for max(niter) of its two worlds).  Single workgroup; deterministic (stable sort).
+__global__ void __launch_bounds__(1024) k_schedule_worlds(MjhData d) {
+  __shared__ int hist[128];
+  __shared__ int base[128];
+  const int t = threadIdx.x, n = d.nworld;
+  if (t < 128) hist[t] = 0;
+  __syncthreads();
+  for (int w = t; w < n; w += 1024) atomicAdd(&hist[127 - min(max(d.solver_niter[w], 0), 127)], 1);
+  __syncthreads();
+  if (t == 0) {
+    int acc = 0;
+    for (int b = 0; b < 128; ++b) {
+      base[b] = acc;
+      acc += hist[b];
+    }
+  }
+  __syncthreads();
+  // scatter; the order inside a bucket is arbitrary (it only decides which wavefront hosts a world, never a result)
+  for (int w = t; w < n; w += 1024) {
+    const int b = 127 - min(max(d.solver_niter[w], 0), 127);
+    d.ws_order[atomicAdd(&base[b], 1)] = w;
+  }
+}

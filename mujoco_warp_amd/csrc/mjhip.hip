@@ -211,6 +211,28 @@ struct Scope {
 };
 enum { K_NOISE = 0, K_POS = 1, K_COLLISION = 2, K_CONSTRAINT = 3, K_VEL = 4, K_SOLVE = 5, K_INTEGRATE = 6, K_OTHER = 7 };
 
+// one non-blocking side stream + fork/join events per host thread and device (created on first use, never freed)
+struct Side {
+  hipStream_t stream;
+  hipEvent_t fork, join;
+};
+static Side* side_stream() {
+  static thread_local Side* per_dev[16] = {nullptr};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  if (!per_dev[dev]) {
+    Side* sd = new Side();
+    if (hipStreamCreateWithFlags(&sd->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&sd->fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&sd->join, hipEventDisableTiming) != hipSuccess) {
+      delete sd;
+      return nullptr;
+    }
+    per_dev[dev] = sd;
+  }
+  return per_dev[dev];
+}
+
 static int run_stage(const MjhModel* m, const MjhData* d, int stage, hipStream_t s) {
   switch (stage) {
     case MJH_STAGE_KINEMATICS: { Scope sc(K_POS); return launch_pos(m, d, POS_KINEMATICS, POS_KINEMATICS, s); }
@@ -234,13 +256,26 @@ static int run_stage(const MjhModel* m, const MjhData* d, int stage, hipStream_t
       { Scope sc(K_COLLISION); TRY(launch_collision(m, d, s)); }
       { Scope sc(K_CONSTRAINT); TRY(launch_constraint(m, d, s)); }
       return MJH_OK;
-    case MJH_STAGE_FORWARD:
+    case MJH_STAGE_FORWARD: {
       { Scope sc(K_POS); TRY(launch_pos(m, d, POS_KINEMATICS, POS_CRB, s)); }
+      // {collision -> make_constraint} and fwd_vel only depend on fwd_pos: both are latency-bound at ~2 waves/SIMD, so
+      // they run concurrently (fork/join through events on a side stream; capturable into a hipGraph).  The per-kernel
+      // instrumentation pass keeps them serial so that the event pairs time one kernel at a time.
+      Side* side = (g_instr && g_instr->on) ? nullptr : side_stream();
+      if (side) {
+        HIPCHK(hipEventRecord(side->fork, s));
+        HIPCHK(hipStreamWaitEvent(side->stream, side->fork, 0));
+        TRY(launch_vel(m, d, VEL_COMVEL, VEL_ACCEL, side->stream));
+        HIPCHK(hipEventRecord(side->join, side->stream));
+      }
       { Scope sc(K_COLLISION); TRY(launch_collision(m, d, s)); }
       { Scope sc(K_CONSTRAINT); TRY(launch_constraint(m, d, s)); }
-      { Scope sc(K_VEL); TRY(launch_vel(m, d, VEL_COMVEL, VEL_ACCEL, s)); }
+      if (side) HIPCHK(hipStreamWaitEvent(s, side->join, 0));
+      else { Scope sc(K_VEL); TRY(launch_vel(m, d, VEL_COMVEL, VEL_ACCEL, s)); }
       { Scope sc(K_SOLVE); TRY(launch_solve(m, d, s)); }
+      hipLaunchKernelGGL(k_schedule_worlds, dim3(1), dim3(1024), 0, s, *d);  // solver schedule for the next step
       return MJH_OK;
+    }
     case MJH_STAGE_STEP:
       TRY(run_stage(m, d, MJH_STAGE_FORWARD, s));
       { Scope sc(K_INTEGRATE); TRY(launch_integrate(m, d, m->integrator == INT_IMPLICITFAST ? 1 : 0, s)); }

@@ -53,8 +53,11 @@ DEV void chol_factor_rows(float (&h)[NVR], float (&lt)[NVR], float& rdiag, float
     float* cb = col + (j & 1) * 32;
     if (own) cb[lig] = h[j];
     gsync();
-    const float piv = sqrtf(fmaxf(cb[j], MJ_MINVAL));
-    const float inv = 1.0f / piv;
+    // pivot by v_readlane (off the LDS round trip); 1/sqrt = v_rsq_f32 + one Newton step (~0.5 ulp)
+    const float pv = fmaxf(bcast32(h[j], j), MJ_MINVAL);
+    float inv = __builtin_amdgcn_rsqf(pv);
+    inv = inv * (1.5f - 0.5f * pv * inv * inv);
+    const float piv = pv * inv;
     const float lij = (lig == j) ? piv : h[j] * inv;
     h[j] = lij;
     if (lig == j) rdiag = inv;
@@ -216,8 +219,10 @@ __global__ void __launch_bounds__(256) k_solve(MjhModel m, MjhData d) {
   int* shi = reinterpret_cast<int*>(smem);
   const MStruct ms = load_mstruct<G>(m, shi);
   const int lig = threadIdx.x & (G - 1), gib = threadIdx.x / G;
-  const int w = blockIdx.x * (blockDim.x / G) + gib;
-  if (w >= d.nworld) return;
+  const int slot = blockIdx.x * (blockDim.x / G) + gib;
+  if (slot >= d.nworld) return;
+  // worlds are scheduled longest-expected-solve first and paired with a similar neighbour (k_schedule_worlds)
+  const int w = d.ws_order[slot];
   float* S = smem + mstruct_ints(nv, nC) + (size_t)gib * lay.total;
   float *Jl = S + lay.J, *eforce = S + lay.force, *eda = S + lay.da, *bsearch = S + lay.bsearch, *bgrad = S + lay.bgrad, *col = S + lay.col;
 
@@ -390,15 +395,16 @@ __global__ void __launch_bounds__(256) k_solve(MjhModel m, MjhData d) {
       // H row = M row + sum_r (D_r [state_r == QUADRATIC]) J[r][i] J[r][:]   (JTDAJ, solver.py:2365-2440)
 #pragma unroll
       for (int c = 0; c < NVR; ++c) h[c] = mrow[c];
-      for (int r = 0; r < nefc; ++r) {
-        const float jd = Jl[r * JS + ligr] * eda[r];
+      for (int r = 0; r < nefc4; r += 2) {  // two rows per LDS round trip (padding rows have J = 0, D = 0)
+        const float jd0 = Jl[r * JS + ligr] * eda[r], jd1 = Jl[(r + 1) * JS + ligr] * eda[r + 1];
 #pragma unroll
         for (int c4 = 0; c4 < NV4; ++c4) {
-          const float4 j4 = *reinterpret_cast<const float4*>(Jl + r * JS + 4 * c4);
-          h[4 * c4] += jd * j4.x;
-          h[4 * c4 + 1] += jd * j4.y;
-          h[4 * c4 + 2] += jd * j4.z;
-          h[4 * c4 + 3] += jd * j4.w;
+          const float4 a4 = *reinterpret_cast<const float4*>(Jl + r * JS + 4 * c4);
+          const float4 b4 = *reinterpret_cast<const float4*>(Jl + (r + 1) * JS + 4 * c4);
+          h[4 * c4] += jd0 * a4.x + jd1 * b4.x;
+          h[4 * c4 + 1] += jd0 * a4.y + jd1 * b4.y;
+          h[4 * c4 + 2] += jd0 * a4.z + jd1 * b4.z;
+          h[4 * c4 + 3] += jd0 * a4.w + jd1 * b4.w;
         }
       }
       float rdiag;

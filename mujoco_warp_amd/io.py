@@ -305,7 +305,7 @@ def _data_shapes(m, nworld, nconmax, njmax, naconmax):
     contact_geomcollisionid=(naconmax,),
     efc_type=(W, njmax), efc_id=(W, njmax), efc_state=(W, njmax), efc_J=(W, njmax_pad, nv_pad), efc_pos=(W, njmax),
     efc_margin=(W, njmax), efc_D=(W, njmax), efc_vel=(W, njmax), efc_aref=(W, njmax), efc_frictionloss=(W, njmax),
-    efc_force=(W, njmax), ws_ncon=(W,), ws_conadr=(W,), ws_ncollision=(W,),
+    efc_force=(W, njmax), ws_ncon=(W,), ws_conadr=(W,), ws_ncollision=(W,), ws_order=(W,),
   )
   return sh, njmax_pad, nv_pad
 
@@ -335,6 +335,7 @@ def _alloc_data(m: types.Model, nworld, nconmax, njmax, naconmax):
     arr = DeviceArray.zeros(shapes[name], dtype=np.int32 if kind == "int" else np.float32)
     _set_data_field(d, name, arr)
   d.nworld, d.nconmax, d.naconmax, d.njmax, d.njmax_pad, d.nv_pad = nworld, nconmax, naconmax, njmax, njmax_pad, nv_pad
+  d.ws_order.assign(np.arange(nworld, dtype=np.int32))
   d.nmaxpyramid = m.nmaxpyramid
   d.world_offset = 0
   d.njmax_nnz = njmax * m.nv
