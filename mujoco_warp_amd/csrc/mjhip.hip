@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -34,9 +35,13 @@ static int fail(int code, const char* fmt, const char* a = "") {
 static const int kLdsPerCU = 160 * 1024;
 
 // pick threads per block in {256,128,64} maximising resident worlds per CU for the given LDS needs
-static int pick_block(size_t shared_bytes, size_t per_world_bytes, int G, size_t* lds_out) {
+static int pick_block(size_t shared_bytes, size_t per_world_bytes, int G, size_t* lds_out, bool prefer_small = false) {
   int best = 0, best_worlds = -1;
-  for (int threads : {256, 128, 64}) {
+  // ties go to the first candidate: large blocks amortise the block-shared tables, small blocks retire as soon as
+  // their own worlds converge (k_solve: per-world work varies by an order of magnitude)
+  const int order_big[3] = {256, 128, 64}, order_small[3] = {64, 128, 256};
+  for (int oi = 0; oi < 3; ++oi) {
+    const int threads = prefer_small ? order_small[oi] : order_big[oi];
     const int wpb = threads / G;
     if (wpb < 1) continue;
     const size_t lds = shared_bytes + per_world_bytes * wpb;
@@ -125,8 +130,12 @@ template <int NV4, int NR, bool NEWTON>
 static int launch_solve_t(const MjhModel* m, const MjhData* d, hipStream_t s) {
   const SolveLayout lay = solve_layout<NV4, NR>(d->njmax);
   size_t lds;
-  const int threads = pick_block(sizeof(int) * mstruct_ints(m->nv, m->nC), sizeof(float) * lay.total, 32, &lds);
+  int threads = pick_block(sizeof(int) * mstruct_ints(m->nv, m->nC), sizeof(float) * lay.total, 32, &lds, true);
   if (!threads) return fail(MJH_E_UNSUPPORTED, "k_solve: njmax x nv does not fit in LDS");
+  if (const char* e = getenv("MJH_SOLVE_THREADS")) {  // tuning knob (developer only)
+    threads = atoi(e);
+    lds = sizeof(int) * mstruct_ints(m->nv, m->nC) + sizeof(float) * lay.total * (threads / 32);
+  }
   HIPCHK(set_lds(k_solve<NV4, NR, NEWTON>, lds));
   const int wpb = threads / 32;
   hipLaunchKernelGGL((k_solve<NV4, NR, NEWTON>), dim3((d->nworld + wpb - 1) / wpb), dim3(threads), lds, s, *m, *d);

@@ -391,6 +391,9 @@ __global__ void __launch_bounds__(256) k_solve(MjhModel m, MjhData d) {
     // ---- gradient and search direction (solver.py:3061-3220) ---------------------------------------------------
     g = active ? (Ma - fs - qc) : 0.0f;
     grad_dot = gsum32(g * g);
+    // improvement / gradient tests need no search direction: a world that passes them skips the H rebuild + Cholesky
+    const bool done_early = niter > 0 && ((improvement * rscale < tolerance) || (sqrtf(grad_dot) * rscale < tolerance));
+    if (NEWTON && done_early) break;
     if (NEWTON) {
       // H row = M row + sum_r (D_r [state_r == QUADRATIC]) J[r][i] J[r][:]   (JTDAJ, solver.py:2365-2440)
 #pragma unroll

@@ -1,0 +1,183 @@
+"""mjwarp-testspeed work-alike: benchmark a mujoco_warp_amd function on batched worlds.
+
+Mirrors /root/reference/mujoco_warp/testspeed.py (flags 51-61, metrics 359-378) and the unroll loop of
+/root/reference/mujoco_warp/_src/cli.py:240-297 with argparse in place of absl (absent here):
+
+    python -m mujoco_warp_amd.testspeed benchmarks/humanoid/humanoid.xml --nworld=8192 --nconmax=24 --njmax=64 \
+        -o opt.solver=cg --format=short --event_trace=true --measure_solver=true --measure_alloc=true
+
+Timer placement is the reference's: per step, the control-noise kernel runs and is synchronised OUTSIDE the timed
+region; the timed region is one hipGraph launch of `step` + device synchronise (cli.py:289-292).  Output keys of
+--format=short|json are the reference's (jit_duration, run_time, steps_per_second, converged_worlds, *_memory,
+ncon_mean/p95, nefc_mean/p95, solver_niter_mean/p95) plus the flattened per-stage trace in ns per world-step.
+"""
+
+import argparse
+import json
+import sys
+import time
+
+import numpy as np
+
+
+def _bool(s):
+  return str(s).lower() in ("1", "true", "yes", "on")
+
+
+def _memory(obj, prefix=""):
+  from .device import DeviceArray
+
+  out = {}
+  for k, v in vars(obj).items():
+    if k.startswith("_"):
+      continue
+    if isinstance(v, DeviceArray):
+      out[prefix + k] = v.capacity
+    elif hasattr(v, "__dict__") and not isinstance(v, (int, float, str)) and type(v).__module__.endswith("types"):
+      out.update(_memory(v, prefix + k + "."))
+  return out
+
+
+def main(argv=None):
+  ap = argparse.ArgumentParser(prog="mujoco_warp_amd.testspeed", description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+  ap.add_argument("mjcf")
+  ap.add_argument("--function", default="step")
+  ap.add_argument("--nworld", type=int, default=8192)
+  ap.add_argument("--nstep", type=int, default=1000)
+  ap.add_argument("--nconmax", type=int, default=None)
+  ap.add_argument("--njmax", type=int, default=None)
+  ap.add_argument("--keyframe", type=int, default=0)
+  ap.add_argument("--noise_std", type=float, default=0.01)
+  ap.add_argument("--noise_rate", type=float, default=0.1)
+  ap.add_argument("-o", "--override", action="append", default=[])
+  ap.add_argument("--format", default="human", choices=["human", "short", "json"])
+  ap.add_argument("--event_trace", type=_bool, default=False)
+  ap.add_argument("--measure_alloc", type=_bool, default=False)
+  ap.add_argument("--measure_solver", type=_bool, default=False)
+  ap.add_argument("--memory", type=_bool, default=False)
+  ap.add_argument("--overflow_behavior", default="error", choices=["error", "continue"])
+  ap.add_argument("--clear_warp_cache", type=_bool, default=False, help="accepted for run.py compatibility (no JIT cache here)")
+  ap.add_argument("--device", default=None)
+  args = ap.parse_args(argv)
+
+  import torch
+
+  import mujoco_warp_amd as mjw
+  from mujoco_warp_amd import device as mdev
+
+  if not torch.cuda.is_available():
+    raise ValueError("testspeed available for gpu only")
+  if args.device:
+    mdev.set_device(args.device)
+  fn = getattr(mjw, args.function)
+
+  if args.format == "human":
+    print(f"Loading model from: {args.mjcf}...\n")
+  mjm = mjw.mjcf.load_xml(args.mjcf)
+  if args.override:
+    mjw.override_model(mjm, args.override)
+  free0 = torch.cuda.mem_get_info()[0]
+  m = mjw.put_model(mjm)
+  mjd = mjw.MjData(mjm)
+  if mjm.nkey > args.keyframe:
+    mjw.mj_resetDataKeyframe(mjm, mjd, args.keyframe)
+  d = mjw.put_data(mjm, mjd, nworld=args.nworld, nconmax=args.nconmax, njmax=args.njmax)
+  center = mjw.DeviceArray.from_numpy(np.asarray(mjd.ctrl, dtype=np.float32)) if mjm.nu else None
+
+  if args.format == "human":
+    print(f"Model\n  nq: {m.nq} nv: {m.nv} nu: {m.nu} nbody: {m.nbody} ngeom: {m.ngeom}")
+    print(f"  solver: {mjw.SolverType(m.opt.solver).name} cone: {mjw.ConeType(m.opt.cone).name} integrator: {mjw.IntegratorType(m.opt.integrator).name}"
+          f" iterations: {m.opt.iterations} ls_iterations: {m.opt.ls_iterations} is_sparse: {m.is_sparse}")
+    print(f"Data\n  nworld: {d.nworld} naconmax: {d.naconmax} njmax: {d.njmax}\n")
+    print(f"Rolling out {args.nstep} steps at dt = {m.opt.timestep.numpy()[0]:.3f}...")
+
+  # "JIT": graph capture of the benchmarked function (kernels are precompiled; nothing is compiled at run time)
+  t0 = time.perf_counter()
+  graph = mjw.StepGraph(m, d) if args.function == "step" else None
+  if graph is not None:  # capture warmed up with one real step: restore the initial state
+    d2 = mjw.put_data(mjm, mjd, nworld=args.nworld, nconmax=args.nconmax, njmax=args.njmax)
+    for name in ("qpos", "qvel", "act", "ctrl", "qacc_warmstart", "time"):
+      getattr(d, name).assign(getattr(d2, name))
+    del d2
+  torch.cuda.synchronize()
+  jit_duration = time.perf_counter() - t0
+
+  nacon, nefc, niter = [], [], []
+  runtime = 0.0
+  trace_ms = np.zeros(len(mjw.KERNEL_NAMES))
+  for i in range(args.nstep):
+    if mjm.nu:
+      mjw.ctrl_noise(m, d, i, args.noise_std, args.noise_rate, center)
+      torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    if graph is not None:
+      graph.launch()
+    else:
+      fn(m, d)
+    torch.cuda.synchronize()
+    runtime += time.perf_counter() - t1
+    if args.measure_alloc:
+      nacon.append(int(d.nacon.numpy()[0]))
+      nefc.append(float(np.max(d.nefc.numpy())))
+    if args.measure_solver:
+      niter.append(float(np.max(d.solver_niter.numpy())))
+    if args.overflow_behavior == "error":
+      ovf = d.overflow.numpy()
+      if ovf.any():
+        raise RuntimeError(f"overflow (OverflowType bits {int(np.bitwise_or.reduce(ovf))}) at step {i}: raise nconmax/njmax or pass --overflow_behavior=continue")
+
+  trace = {}
+  if args.event_trace and args.function == "step":
+    # per-kernel HIP-event timing of a few extra steps (the reference's EventTracer keys, ns per world-step)
+    ms, pk = mjw.timed_steps(m, d, 20, step0=args.nstep, noise_std=args.noise_std, noise_rate=args.noise_rate, per_kernel=True)
+    ns = {k: 1e6 * v / 20 / args.nworld for k, v in zip(mjw.KERNEL_NAMES, pk)}
+    fwd_position = ns["fwd_pos"] + ns["collision"] + ns["make_constraint"]
+    forward = fwd_position + ns["fwd_vel"] + ns["solve"]
+    trace = {
+      "step": forward + ns["integrate"], "step.forward": forward, "step.forward.fwd_position": fwd_position,
+      "step.forward.fwd_position.kinematics_com_pos_crb": ns["fwd_pos"], "step.forward.fwd_position.collision": ns["collision"],
+      "step.forward.fwd_position.make_constraint": ns["make_constraint"],
+      "step.forward.fwd_velocity_actuation_acceleration": ns["fwd_vel"], "step.forward.solve": ns["solve"], "step.euler": ns["integrate"],
+    }
+
+  nconverged = int(np.sum(~np.any(np.isnan(d.qpos.numpy()), axis=1)))
+  steps = args.nworld * args.nstep
+  model_mem, data_mem = _memory(m), _memory(d)
+  total_mem = free0 - torch.cuda.mem_get_info()[0]
+  if args.format == "human":
+    dt = float(m.opt.timestep.numpy()[0])
+    print(f"""
+Summary for {d.nworld} parallel rollouts
+
+Total JIT time: {jit_duration:.2f} s
+Total simulation time: {runtime:.2f} s
+Total steps per second: {steps / runtime:,.0f}
+Total realtime factor: {steps * dt / runtime:,.2f} x
+Total time per step: {1e9 * runtime / steps:.2f} ns
+Total converged worlds: {nconverged} / {d.nworld}""")
+    if trace:
+      print("\nEvent trace (ns per world-step):\n")
+      for k, v in trace.items():
+        print(f"{'  ' * k.count('.')}{k.split('.')[-1]}: {v:.2f}")
+    if args.memory:
+      print(f"\nModel memory {sum(model_mem.values()) / 2**20:.2f} MiB, Data memory {sum(data_mem.values()) / 2**20:.2f} MiB, total {total_mem / 2**20:.2f} MiB")
+  else:
+    metrics = {
+      "jit_duration": jit_duration, "run_time": runtime, "steps_per_second": steps / runtime, "converged_worlds": nconverged,
+      "model_memory": sum(model_mem.values()), "data_memory": sum(data_mem.values()), "total_memory": total_mem,
+      "ncon_mean": float(np.mean(nacon)) / args.nworld if nacon else 0.0,
+      "ncon_p95": float(np.percentile(nacon, 95)) / args.nworld if nacon else 0.0,
+      "nefc_mean": float(np.mean(nefc)) if nefc else 0.0, "nefc_p95": float(np.percentile(nefc, 95)) if nefc else 0.0,
+      "solver_niter_mean": float(np.mean(niter)) if niter else 0.0, "solver_niter_p95": float(np.percentile(niter, 95)) if niter else 0.0,
+    }
+    metrics.update(trace)
+    if args.format == "short":
+      for k, v in metrics.items():
+        print(f"{k}: {v}")
+    else:
+      print(json.dumps(metrics))
+  return 0
+
+
+if __name__ == "__main__":
+  sys.exit(main())

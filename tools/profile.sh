@@ -14,5 +14,6 @@ rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_SM
 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pmc -- $BENCH > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o pmc -- $BENCH > $OUT/pmc_write.log 2>&1
 cd - >/dev/null
-python tools/summarize_profile.py $OUT > $OUT/summary.txt 2>&1
-cat $OUT/summary.txt
+python tools/summarize_profile.py $OUT $OUT/summary.json > /dev/null 2>&1
+rm -rf $OUT/trace $OUT/pmc_sq $OUT/pmc_sq2 $OUT/pmc_fetch $OUT/pmc_write  # keep only the small summary (gpurun_out is capped at 64 MiB)
+ls -la $OUT
