@@ -134,6 +134,8 @@ typedef struct MjhModel {
 
 typedef struct MjhData {
   int nworld; int nconmax; int naconmax; int njmax; int njmax_pad; int nv_pad; int nmaxpyramid; int world_offset;
+  int concap;          /* per-world contact capacity of ws_contact: clamp(2 nconmax, 16, 256)          */
+  int reserved0;
   /* state (types.py:2240-2262) */
   float* time; float* qpos; float* qvel; float* act; float* ctrl; float* qacc_warmstart;
   float* qfrc_applied; float* xfrc_applied;
@@ -163,9 +165,11 @@ typedef struct MjhData {
   float* efc_frictionloss; float* efc_force;
   /* engine workspace (pre-allocated by make_data; replaces the reference's per-step temporaries) */
   int* ws_ncon;        /* [nworld]   contacts found per world                         */
-  int* ws_conadr;      /* [nworld]   exclusive scan of ws_ncon = first public slot    */
+  int* ws_conadr;      /* [nworld]   exclusive scan of ws_ncon = first public slot (k_contact_scan) */
   int* ws_ncollision;  /* [nworld]   broadphase candidates per world                  */
   int* ws_order;       /* [nworld]   solver schedule: worlds sorted by last step's solver_niter (longest first) */
+  float* ws_contact;   /* [nworld, concap, 32] per-world contact records (collision -> make_constraint hand-off;
+                          the public contact_* arrays are compacted from these off the critical path) */
 } MjhData;
 
 /* One launch sequence for a reference stage function (MJH_STAGE_*); `stream` is a hipStream_t. */

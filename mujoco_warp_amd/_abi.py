@@ -98,7 +98,8 @@ def lib():
     except (OSError, subprocess.CalledProcessError) as e:
       if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"libmjhip.so is missing and could not be built: {e}") from e
-  L = ctypes.CDLL(LIB_PATH)
+  # MJH_LIB: developer knob to A/B two builds of the same ABI in one GPU session (tools/ab.sh)
+  L = ctypes.CDLL(os.environ.get("MJH_LIB", LIB_PATH))
   mp, dp, vp = ctypes.POINTER(CModel), ctypes.POINTER(CData), ctypes.c_void_p
   L.mjh_stage.argtypes = [mp, dp, ctypes.c_int, vp]
   L.mjh_step.argtypes = [mp, dp, vp]

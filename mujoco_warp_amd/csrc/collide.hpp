@@ -13,13 +13,17 @@
 #pragma once
 #include "dev_common.hpp"
 
-#define MJH_MAXCON_PER_PAIR 8
-
-struct ConGeom {
-  float dist;
-  V3 pos;
-  float frame[9];
+// A collider reports each candidate contact through `emit(index, dist, pos, frame_row0, frame_row1, frame_row2)`.
+// The kernel runs every collider twice with different emitters (count, then write): nothing is buffered per
+// lane, so the kernel needs no scratch memory and no dynamically indexed register arrays.
+struct Frame {
+  V3 a, b, c;
 };
+DEV Frame make_frame3(V3 n) {  // math.py:203-257
+  float f[9];
+  make_frame(n, f);
+  return Frame{ld3(f), ld3(f + 3), ld3(f + 6)};
+}
 
 DEV void plane_sphere(V3 n, V3 ppos, V3 spos, float r, float& dist, V3& pos) {  // core:48
   dist = dot(spos - ppos, n) - r;
@@ -38,50 +42,43 @@ DEV V3 closest_segment_point(V3 a, V3 b, V3 pt) {  // math.py:270
   return a + ab * clampf(t, 0.0f, 1.0f);
 }
 
-// runs the collider for geoms (g1,g2) with type1 <= type2; returns number of candidate contacts
-DEV int collide_pair(int t1, int t2, V3 p1, const float* R1, V3 s1, V3 p2, const float* R2, V3 s2, float margin, ConGeom* out) {
+// runs the collider for geoms (g1,g2) with type1 <= type2
+template <class Emit>
+DEV void collide_pair(int t1, int t2, V3 p1, const float* R1, V3 s1, V3 p2, const float* R2, V3 s2, float margin, Emit&& emit) {
   V3 ax1 = V3{R1[2], R1[5], R1[8]}, ax2 = V3{R2[2], R2[5], R2[8]};
-  int n = 0;
+  float dist;
+  V3 pos, nn;
   if (t1 == G_PLANE && t2 == G_SPHERE) {
-    plane_sphere(ax1, p1, p2, s2.x, out[0].dist, out[0].pos);
-    make_frame(ax1, out[0].frame);
-    n = 1;
+    plane_sphere(ax1, p1, p2, s2.x, dist, pos);
+    const Frame f = make_frame3(ax1);
+    emit(0, dist, pos, f.a, f.b, f.c);
   } else if (t1 == G_PLANE && t2 == G_CAPSULE) {  // core:253
     float bn;
     V3 b = normalize_with_norm(ax2 - ax1 * dot(ax1, ax2), bn);
     if (bn < 0.5f) b = (-0.5f < ax1.y && ax1.y < 0.5f) ? V3{0, 1, 0} : V3{0, 0, 1};
     V3 c = cross(ax1, b);
     V3 seg = ax2 * s2.y;
-    for (int k = 0; k < 2; ++k) {
-      plane_sphere(ax1, p1, k == 0 ? p2 + seg : p2 - seg, s2.x, out[k].dist, out[k].pos);
-      st3(out[k].frame, ax1);
-      st3(out[k].frame + 3, b);
-      st3(out[k].frame + 6, c);
-    }
-    n = 2;
+    plane_sphere(ax1, p1, p2 + seg, s2.x, dist, pos);
+    emit(0, dist, pos, ax1, b, c);
+    plane_sphere(ax1, p1, p2 - seg, s2.x, dist, pos);
+    emit(1, dist, pos, ax1, b, c);
   } else if (t1 == G_PLANE && t2 == G_BOX) {  // core:337
-    float cd = dot(p2 - p1, ax1);
-    float fr[9];
-    make_frame(ax1, fr);
+    const float cd = dot(p2 - p1, ax1);
+    const Frame f = make_frame3(ax1);
     for (int i = 0; i < 8; ++i) {
       V3 corner = V3{(i & 1) ? s2.x : -s2.x, (i & 2) ? s2.y : -s2.y, (i & 4) ? s2.z : -s2.z};
       V3 cw = mat_mul(R2, corner);
-      float cdist = cd + dot(ax1, cw);
-      out[i].dist = cdist;
-      out[i].pos = cw + p2 - ax1 * (0.5f * cdist);
-      for (int k = 0; k < 9; ++k) out[i].frame[k] = fr[k];
+      const float cdist = cd + dot(ax1, cw);
+      emit(i, cdist, cw + p2 - ax1 * (0.5f * cdist), f.a, f.b, f.c);
     }
-    n = 8;
   } else if (t1 == G_PLANE && t2 == G_ELLIPSOID) {  // core:306
     V3 loc = matT_mul(R2, ax1);
     V3 sup = normalize(V3{loc.x * s2.x, loc.y * s2.y, loc.z * s2.z});
     sup = V3{-sup.x * s2.x, -sup.y * s2.y, -sup.z * s2.z};
     V3 pw = mat_mul(R2, sup) + p2;
-    float dist = dot(ax1, pw - p1);
-    out[0].dist = dist;
-    out[0].pos = pw - ax1 * (0.5f * dist);
-    make_frame(ax1, out[0].frame);
-    n = 1;
+    dist = dot(ax1, pw - p1);
+    const Frame f = make_frame3(ax1);
+    emit(0, dist, pw - ax1 * (0.5f * dist), f.a, f.b, f.c);
   } else if (t1 == G_PLANE && t2 == G_CYLINDER) {  // core:460
     V3 axis = ax2;
     const float r = s2.x, hh = s2.y;
@@ -98,38 +95,28 @@ DEV int collide_pair(int t1, int t2, V3 p1, const float* R1, V3 s1, V3 p2, const
     axis = axis * hh;
     prjaxis *= hh;
     const float d1 = dist0 + prjaxis + prjvec, d2 = dist0 - prjaxis + prjvec;
-    out[0].dist = d1;
-    out[0].pos = p2 + vec + axis - ax1 * (d1 * 0.5f);
-    out[1].dist = d2;
-    out[1].pos = p2 + vec - axis - ax1 * (d2 * 0.5f);
+    const Frame f = make_frame3(ax1);
+    emit(0, d1, p2 + vec + axis - ax1 * (d1 * 0.5f), f.a, f.b, f.c);
+    emit(1, d2, p2 + vec - axis - ax1 * (d2 * 0.5f), f.a, f.b, f.c);
     const float d3 = dist0 + prjaxis - 0.5f * prjvec;
     V3 vec1 = normalize(cross(vec, axis)) * (r * sqrtf(3.0f) * 0.5f);
-    out[2].dist = d3;
-    out[2].pos = p2 + vec1 + axis - vec * 0.5f - ax1 * (d3 * 0.5f);
-    out[3].dist = d3;
-    out[3].pos = p2 - vec1 + axis - vec * 0.5f - ax1 * (d3 * 0.5f);
-    float fr[9];
-    make_frame(ax1, fr);
-    for (int i = 0; i < 4; ++i)
-      for (int k = 0; k < 9; ++k) out[i].frame[k] = fr[k];
-    n = 4;
+    emit(2, d3, p2 + vec1 + axis - vec * 0.5f - ax1 * (d3 * 0.5f), f.a, f.b, f.c);
+    emit(3, d3, p2 - vec1 + axis - vec * 0.5f - ax1 * (d3 * 0.5f), f.a, f.b, f.c);
   } else if (t1 == G_SPHERE && t2 == G_SPHERE) {
-    V3 nn;
-    sphere_sphere(p1, s1.x, p2, s2.x, out[0].dist, out[0].pos, nn);
-    make_frame(nn, out[0].frame);
-    n = 1;
+    sphere_sphere(p1, s1.x, p2, s2.x, dist, pos, nn);
+    const Frame f = make_frame3(nn);
+    emit(0, dist, pos, f.a, f.b, f.c);
   } else if (t1 == G_SPHERE && t2 == G_CAPSULE) {  // core:88
-    V3 seg = ax2 * s2.y, nn;
+    V3 seg = ax2 * s2.y;
     V3 pt = closest_segment_point(p2 - seg, p2 + seg, p1);
-    sphere_sphere(p1, s1.x, pt, s2.x, out[0].dist, out[0].pos, nn);
-    make_frame(nn, out[0].frame);
-    n = 1;
+    sphere_sphere(p1, s1.x, pt, s2.x, dist, pos, nn);
+    const Frame f = make_frame3(nn);
+    emit(0, dist, pos, f.a, f.b, f.c);
   } else if (t1 == G_CAPSULE && t2 == G_CAPSULE) {  // core:123
-    V3 axis1 = ax1 * s1.y, axis2 = ax2 * s2.y, dif = p1 - p2, nn, pos;
+    V3 axis1 = ax1 * s1.y, axis2 = ax2 * s2.y, dif = p1 - p2;
     const float ma = dot(axis1, axis1), mb = -dot(axis1, axis2), mc = dot(axis2, axis2);
     const float u = -dot(axis1, dif), v = dot(axis2, dif);
     const float det = ma * mc - mb * mb;
-    float dist;
     if (fabsf(det) >= MJ_MINVAL) {
       float x1 = (mc * u - mb * v) / det, x2 = (ma * v - mb * u) / det;
       if (x1 > 1.0f) {
@@ -148,12 +135,11 @@ DEV int collide_pair(int t1, int t2, V3 p1, const float* R1, V3 s1, V3 p2, const
       }
       sphere_sphere(p1 + axis1 * x1, s1.x, p2 + axis2 * x2, s2.x, dist, pos, nn);
       if (dist <= margin) {
-        out[0].dist = dist;
-        out[0].pos = pos;
-        make_frame(nn, out[0].frame);
-        n = 1;
+        const Frame f = make_frame3(nn);
+        emit(0, dist, pos, f.a, f.b, f.c);
       }
     } else {  // parallel axes: up to 2 contacts from the 4 endpoint tests
+      int n = 0;
       for (int e = 0; e < 4 && n < 2; ++e) {
         V3 v1, v2;
         if (e == 0) {
@@ -171,9 +157,8 @@ DEV int collide_pair(int t1, int t2, V3 p1, const float* R1, V3 s1, V3 p2, const
         }
         sphere_sphere(v1, s1.x, v2, s2.x, dist, pos, nn);
         if (dist <= margin) {
-          out[n].dist = dist;
-          out[n].pos = pos;
-          make_frame(nn, out[n].frame);
+          const Frame f = make_frame3(nn);
+          emit(n, dist, pos, f.a, f.b, f.c);
           ++n;
         }
       }
@@ -181,9 +166,7 @@ DEV int collide_pair(int t1, int t2, V3 p1, const float* R1, V3 s1, V3 p2, const
   } else if (t1 == G_SPHERE && t2 == G_BOX) {  // core:1044
     V3 center = matT_mul(R2, p1 - p2);
     V3 clamped = V3{fmaxf(-s2.x, fminf(s2.x, center.x)), fmaxf(-s2.y, fminf(s2.y, center.y)), fmaxf(-s2.z, fminf(s2.z, center.z))};
-    float dist;
     V3 cdir = normalize_with_norm(clamped - center, dist);
-    V3 pos, nn;
     if (dist <= MJ_MINVAL) {
       const float sz[3] = {s2.x, s2.y, s2.z}, ce[3] = {center.x, center.y, center.z};
       float closest = 2.0f * (s2.x + s2.y + s2.z);
@@ -195,22 +178,19 @@ DEV int collide_pair(int t1, int t2, V3 p1, const float* R1, V3 s1, V3 p2, const
           kk = i;
         }
       }
-      float ne[3] = {0, 0, 0};
-      ne[kk / 2] = (kk % 2) ? -1.0f : 1.0f;
-      V3 nearest = V3{ne[0], ne[1], ne[2]};
+      const float sg = (kk % 2) ? -1.0f : 1.0f;
+      V3 nearest = V3{kk / 2 == 0 ? sg : 0.0f, kk / 2 == 1 ? sg : 0.0f, kk / 2 == 2 ? sg : 0.0f};
       pos = center + nearest * ((s1.x - closest) * 0.5f);
       nn = mat_mul(R2, nearest);
-      out[0].dist = -closest - s1.x;
+      dist = -closest - s1.x;
     } else {
       pos = (clamped + center + cdir * s1.x) * 0.5f;
       nn = mat_mul(R2, cdir);
-      out[0].dist = dist - s1.x;
+      dist = dist - s1.x;
     }
-    out[0].pos = mat_mul(R2, pos) + p2;
-    make_frame(nn, out[0].frame);
-    n = 1;
+    const Frame f = make_frame3(nn);
+    emit(0, dist, mat_mul(R2, pos) + p2, f.a, f.b, f.c);
   }
-  return n;
 }
 
 struct PairParams {
@@ -267,35 +247,55 @@ DEV PairParams contact_params(const MjhModel& m, int w, int g1, int g2) {
   return p;
 }
 
-// per-world LDS: candidate list (ints) | staged contacts: per contact 16 words (dist,pos3,frame9,pairidx,cid,pad)
-#define CON_STAGE_WORDS 16
-__host__ __device__ inline int collide_lds_words(int npair, int ncap) { return ((npair + 3) / 4) * 4 + ncap * CON_STAGE_WORDS + 1; }
+// Contact record (CON_REC words; CON_STRIDE in the per-world hand-off buffer d.ws_contact, so that a record is one
+// aligned 128-byte line):
+//   0 dist | 1-3 pos | 4-12 frame | 13 includemargin | 14-16 friction (slide, spin, roll) | 17-18 solref |
+//   19-23 solimp | 24 condim | 25-26 geoms | 27 collider contact id | 28 first efc row or -1 | 29 number of rows
+// (28-29 are filled by k_make_constraint).  k_collision hands the contacts of a world to k_make_constraint through
+// d.ws_contact[w]; the public, compact contact_* arrays are produced from the same records by k_contact_scan +
+// k_publish_contacts, which run beside the solver.  The reference reserves public slots with one global atomic per
+// contact (collision_core.py write_contact); on MI355X one same-address device atomic per WORLD already cost 25-50 us
+// per launch (they resolve at the memory side, ~6 ns each, and every later load of the wave waits behind them).
+#define CON_WINDOW 16
+#define CON_REC 30
+#define CON_LDS 31  /* odd LDS stride: lane-per-contact reads are bank-conflict free */
+#define CON_STRIDE 32
+// per-world LDS: geom poses (12 words per geom) | candidate pair list | first contact slot << 8 | contact mask per
+// candidate | staging window of CON_WINDOW records
+__host__ __device__ inline int collide_lds_words(int ngeom, int npair) {
+  return 12 * ngeom + ((npair + 3) / 4) * 4 + ((npair + 3) / 4) * 4 + CON_WINDOW * CON_LDS;
+}
 
 template <int G>
-__global__ void __launch_bounds__(256) k_collision(MjhModel m, MjhData d, int ncap) {
+__global__ void __launch_bounds__(256) k_collision(MjhModel m, MjhData d) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lig = threadIdx.x & (G - 1), gib = threadIdx.x / G;
   const int w = blockIdx.x * (blockDim.x / G) + gib;
   if (w >= d.nworld) return;
-  const int npair = m.npair, ng = m.ngeom;
-  float* S = smem + (size_t)gib * collide_lds_words(npair, ncap);
-  int* cand = reinterpret_cast<int*>(S);
-  float* stage = S + ((npair + 3) / 4) * 4;
+  const int npair = m.npair, ng = m.ngeom, ncap = d.concap;
+  float* S = smem + (size_t)gib * collide_lds_words(ng, npair);
+  float* gxpos = S;
+  float* gxmat = S + 3 * ng;
+  int* cand = reinterpret_cast<int*>(S + 12 * ng);
+  int* cslot = cand + ((npair + 3) / 4) * 4;
+  float* rec = reinterpret_cast<float*>(cslot + ((npair + 3) / 4) * 4);
 
   if (m.disableflags & (DSBL_CONSTRAINT | DSBL_CONTACT)) {
     if (lig == 0) {
       d.ws_ncon[w] = 0;
-      d.ws_conadr[w] = 0;
       d.ws_ncollision[w] = 0;
     }
     return;
   }
-  const float* gxpos = d.geom_xpos + (size_t)w * 3 * ng;
-  const float* gxmat = d.geom_xmat + (size_t)w * 9 * ng;
+  PhaseClock pc(2, lig);
+  gcopy<G>(gxpos, d.geom_xpos + (size_t)w * 3 * ng, 3 * ng, lig);
+  gcopy<G>(gxmat, d.geom_xmat + (size_t)w * 9 * ng, 9 * ng, lig);
   const float* rbound = bf(m.geom_rbound, m.geom_rbound_nb, w, ng);
   const float* gmargin = bf(m.geom_margin, m.geom_margin_nb, w, ng);
   const float* ggap = bf(m.geom_gap, m.geom_gap_nb, w, ng);
   const float* gsize = bf(m.geom_size, m.geom_size_nb, w, 3 * ng);
+  gsync();
+  pc.mark(0);
 
   // ---- broadphase: plane / bounding-sphere filter, ordered compaction -----------------------------------
   int ncand = 0;
@@ -327,96 +327,189 @@ __global__ void __launch_bounds__(256) k_collision(MjhModel m, MjhData d, int nc
     ncand += tot;
   }
   gsync();
+  pc.mark(1);
 
-  // ---- narrowphase over candidates, ordered compaction of detected contacts ------------------------------
+  // ---- narrowphase, pass 1: contacts per candidate and their exclusive prefix (contacts stay in pair order) ----
+  auto load_pair = [&](int p, int& g1, int& g2, int& t1, int& t2) {
+    g1 = m.nxn_geom_pair[2 * p];
+    g2 = m.nxn_geom_pair[2 * p + 1];
+    t1 = m.geom_type[g1];
+    t2 = m.geom_type[g2];
+    if (t1 > t2) {
+      int t = g1; g1 = g2; g2 = t;
+      t = t1; t1 = t2; t2 = t;
+    }
+  };
   int ncon = 0;
   for (int base = 0; base < ncand; base += G) {
     const int ci = base + lig;
-    ConGeom out[MJH_MAXCON_PER_PAIR];
-    unsigned keep = 0;
-    int p = -1, nk = 0;
+    // which of the collider's (at most 8) contacts pass the margin test: pass 2 replays this mask instead of
+    // re-testing, so the two passes agree even if the compiler contracts the distance arithmetic differently
+    unsigned mask = 0u;
     if (ci < ncand) {
-      p = cand[ci];
-      int g1 = m.nxn_geom_pair[2 * p], g2 = m.nxn_geom_pair[2 * p + 1];
-      int t1 = m.geom_type[g1], t2 = m.geom_type[g2];
-      if (t1 > t2) {
-        int t = g1; g1 = g2; g2 = t;
-        t = t1; t1 = t2; t2 = t;
-      }
-      const float margin = gmargin[g1] + gmargin[g2], gap = ggap[g1] + ggap[g2];
-      const int n = collide_pair(t1, t2, ld3(gxpos + 3 * g1), gxmat + 9 * g1, ld3(gsize + 3 * g1), ld3(gxpos + 3 * g2),
-                                 gxmat + 9 * g2, ld3(gsize + 3 * g2), margin, out);
-      for (int k = 0; k < n; ++k)
-        if (out[k].dist < margin + gap) {
-          keep |= 1u << k;
-          ++nk;
-        }
+      int g1, g2, t1, t2;
+      load_pair(cand[ci], g1, g2, t1, t2);
+      const float margin = gmargin[g1] + gmargin[g2];
+      const float lim = margin + ggap[g1] + ggap[g2];
+      collide_pair(t1, t2, ld3(gxpos + 3 * g1), gxmat + 9 * g1, ld3(gsize + 3 * g1), ld3(gxpos + 3 * g2), gxmat + 9 * g2,
+                   ld3(gsize + 3 * g2), margin, [&](int k, float dist, V3, V3, V3, V3) { mask |= dist < lim ? (1u << (k & 7)) : 0u; });
     }
-    // exclusive prefix of nk over the group (ordered by candidate index)
+    const int nk = __popc(mask);
     int incl = nk;
     for (int off = 1; off < G; off <<= 1) {
       int v = __shfl_up(incl, off, G);
       if (lig >= off) incl += v;
     }
-    const int excl = incl - nk;
-    const int tot = __shfl(incl, G - 1, G);
-    int slot = ncon + excl;
-    for (int k = 0; k < MJH_MAXCON_PER_PAIR; ++k) {
-      if (!(keep & (1u << k))) continue;
-      if (slot < ncap) {
-        float* s = stage + slot * CON_STAGE_WORDS;
-        s[0] = out[k].dist;
-        st3(s + 1, out[k].pos);
-        for (int q = 0; q < 9; ++q) s[4 + q] = out[k].frame[q];
-        reinterpret_cast<int*>(s)[13] = p;
-        reinterpret_cast<int*>(s)[14] = k;
-      }
-      ++slot;
-    }
-    ncon += tot;
+    if (ci < ncand) cslot[ci] = ((ncon + incl - nk) << 8) | (int)mask;
+    ncon += __shfl(incl, G - 1, G);
   }
   gsync();
+  pc.mark(2);
 
-  // ---- reserve a block of the public contact arrays (one atomic per world) and publish ------------------
+  // ---- pass 2, CON_WINDOW contacts at a time: contacting candidates recompute their contacts into the LDS window,
+  // then the group copies the window to the world's slice of d.ws_contact with consecutive addresses -------------
   const int nfound = ncon;
   if (ncon > ncap) ncon = ncap;
-  int adr = 0;
-  if (lig == 0) {
-    adr = atomicAdd(d.nacon, ncon);
-    atomicAdd(d.ncollision, ncand);
-  }
-  adr = __shfl(adr, 0, G);
-  int nwrite = ncon;
-  if (adr + nwrite > d.naconmax) nwrite = max(0, d.naconmax - adr);
-  if (lig == 0) {
-    d.ws_ncon[w] = nwrite;
-    d.ws_conadr[w] = adr;
-    d.ws_ncollision[w] = ncand;
-    if (nwrite < nfound) atomicOr(d.overflow + w, OVF_NARROWPHASE);
-  }
-  for (int c = lig; c < nwrite; c += G) {
-    const float* s = stage + c * CON_STAGE_WORDS;
-    const int p = reinterpret_cast<const int*>(s)[13], cid = reinterpret_cast<const int*>(s)[14];
-    int g1 = m.nxn_geom_pair[2 * p], g2 = m.nxn_geom_pair[2 * p + 1];
-    if (m.geom_type[g1] > m.geom_type[g2]) {
-      int t = g1; g1 = g2; g2 = t;
+  float* out = d.ws_contact + (size_t)w * ncap * CON_STRIDE;
+  for (int wbase = 0; wbase < ncon; wbase += CON_WINDOW) {
+    const int wend = min(wbase + CON_WINDOW, ncon);
+    // a slot that pass 2 fails to reproduce (see the mask above) becomes a harmless inactive contact
+    for (int idx = lig; idx < CON_WINDOW * CON_LDS; idx += G) {
+      const int f = idx % CON_LDS;
+      rec[idx] = f == 0 ? 1e10f : (f == 24 ? __int_as_float(1) : (f == 28 ? __int_as_float(-1) : 0.0f));
     }
-    const PairParams pp = contact_params(m, w, g1, g2);
-    const size_t o = (size_t)(adr + c);
-    d.contact_dist[o] = s[0];
-    for (int q = 0; q < 3; ++q) d.contact_pos[3 * o + q] = s[1 + q];
-    for (int q = 0; q < 9; ++q) d.contact_frame[9 * o + q] = s[4 + q];
-    d.contact_includemargin[o] = pp.margin;
-    for (int q = 0; q < 5; ++q) d.contact_friction[5 * o + q] = pp.friction[q];
-    for (int q = 0; q < 2; ++q) d.contact_solref[2 * o + q] = pp.solref[q];
-    for (int q = 0; q < 2; ++q) d.contact_solreffriction[2 * o + q] = pp.solreffriction[q];
-    for (int q = 0; q < 5; ++q) d.contact_solimp[5 * o + q] = pp.solimp[q];
-    d.contact_dim[o] = pp.condim;
-    d.contact_geom[2 * o] = g1;
-    d.contact_geom[2 * o + 1] = g2;
+    gsync();
+    pc.mark(3);
+    for (int base = 0; base < ncand; base += G) {
+      const int ci = base + lig;
+      if (ci >= ncand) continue;
+      const unsigned mask = (unsigned)cslot[ci] & 0xffu;
+      int slot = cslot[ci] >> 8;
+      const int send = slot + __popc(mask);
+      if (mask == 0u || slot >= wend || send <= wbase) continue;
+      int g1, g2, t1, t2;
+      load_pair(cand[ci], g1, g2, t1, t2);
+      const float margin = gmargin[g1] + gmargin[g2];
+      const PairParams pp = contact_params(m, w, g1, g2);
+      collide_pair(t1, t2, ld3(gxpos + 3 * g1), gxmat + 9 * g1, ld3(gsize + 3 * g1), ld3(gxpos + 3 * g2), gxmat + 9 * g2,
+                   ld3(gsize + 3 * g2), margin, [&](int cid, float dist, V3 pos, V3 fa, V3 fb, V3 fc) {
+                     if (!((mask >> (cid & 7)) & 1u)) return;
+                     if (slot >= wbase && slot < wend) {
+                       float* r = rec + (slot - wbase) * CON_LDS;
+                       r[0] = dist;
+                       st3(r + 1, pos);
+                       st3(r + 4, fa);
+                       st3(r + 7, fb);
+                       st3(r + 10, fc);
+                       r[13] = pp.margin;
+                       r[14] = pp.friction[0];
+                       r[15] = pp.friction[2];
+                       r[16] = pp.friction[3];
+                       r[17] = pp.solref[0];
+                       r[18] = pp.solref[1];
+                       for (int q = 0; q < 5; ++q) r[19 + q] = pp.solimp[q];
+                       int* ri = reinterpret_cast<int*>(r);
+                       ri[24] = pp.condim;
+                       ri[25] = g1;
+                       ri[26] = g2;
+                       ri[27] = cid;
+                     }
+                     ++slot;
+                   });
+    }
+    gsync();
+    pc.mark(4);
+    const int nw = (wend - wbase) * CON_STRIDE;
+    for (int idx = lig; idx < nw; idx += G) {
+      const int f = idx & (CON_STRIDE - 1);
+      out[(size_t)wbase * CON_STRIDE + idx] = f < CON_LDS ? rec[(idx / CON_STRIDE) * CON_LDS + f] : 0.0f;
+    }
+    gsync();
+    pc.mark(5);
+  }
+  if (lig == 0) {
+    d.ws_ncon[w] = ncon;
+    d.ws_ncollision[w] = ncand;
+    if (ncon < nfound) atomicOr(d.overflow + w, OVF_NARROWPHASE);
+  }
+}
+
+// ---- publication of the compact public contact arrays (off the critical path) ---------------------------------
+// k_contact_scan: one workgroup; exclusive prefix of ws_ncon -> ws_conadr, totals -> nacon / ncollision.
+__global__ void __launch_bounds__(1024) k_contact_scan(MjhData d) {
+  __shared__ int part[1024];
+  __shared__ int part2[1024];
+  const int t = threadIdx.x, n = d.nworld;
+  const int per = (n + 1023) / 1024;
+  const int lo = min(t * per, n), hi = min(lo + per, n);
+  int s = 0, s2 = 0;
+  for (int w = lo; w < hi; ++w) {
+    s += d.ws_ncon[w];
+    s2 += d.ws_ncollision[w];
+  }
+  part[t] = s;
+  part2[t] = s2;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
+    const int v = t >= off ? part[t - off] : 0, v2 = t >= off ? part2[t - off] : 0;
+    __syncthreads();
+    part[t] += v;
+    part2[t] += v2;
+    __syncthreads();
+  }
+  int run = part[t] - s;
+  for (int w = lo; w < hi; ++w) {
+    d.ws_conadr[w] = run;
+    run += d.ws_ncon[w];
+  }
+  if (t == 1023) {
+    d.nacon[0] = part[t];
+    d.ncollision[0] = part2[t];
+  }
+}
+
+// k_publish_contacts: one group per world copies its records to the public SoA arrays (consecutive addresses per
+// array), fills contact.efc_address and the contact rows of efc.id.  Worlds are published in world order, so the
+// public arrays are deterministic (the reference's order depends on atomic arrival).
+template <int G>
+__global__ void __launch_bounds__(256) k_publish_contacts(MjhData d) {
+  const int lig = threadIdx.x & (G - 1), gib = threadIdx.x / G;
+  const int w = blockIdx.x * (blockDim.x / G) + gib;
+  if (w >= d.nworld) return;
+  const int ncon = d.ws_ncon[w], adr = d.ws_conadr[w], njmax = d.njmax, npyr = d.nmaxpyramid;
+  int n = ncon;
+  if (adr + n > d.naconmax) n = max(0, d.naconmax - adr);
+  if (n < ncon && lig == 0) atomicOr(d.overflow + w, OVF_NARROWPHASE);
+  const float* rec = d.ws_contact + (size_t)w * d.concap * CON_STRIDE;
+  const int* reci = reinterpret_cast<const int*>(rec);
+  const size_t o0 = (size_t)adr;
+  for (int c = lig; c < n; c += G) {  // one contact per lane: the scalar-per-contact arrays
+    const float* r = rec + c * CON_STRIDE;
+    const int* ri = reci + c * CON_STRIDE;
+    const size_t o = o0 + c;
+    d.contact_dist[o] = r[0];
+    d.contact_includemargin[o] = r[13];
+    *reinterpret_cast<float2*>(d.contact_solref + 2 * o) = float2{r[17], r[18]};
+    *reinterpret_cast<float2*>(d.contact_solreffriction + 2 * o) = float2{0.0f, 0.0f};
+    d.contact_dim[o] = ri[24];
+    *reinterpret_cast<int2*>(d.contact_geom + 2 * o) = int2{ri[25], ri[26]};
     d.contact_worldid[o] = w;
     d.contact_type[o] = CONTACT_TYPE_CONSTRAINT;
-    d.contact_geomcollisionid[o] = cid;
-    for (int q = 0; q < d.nmaxpyramid; ++q) d.contact_efc_address[o * d.nmaxpyramid + q] = -1;
+    d.contact_geomcollisionid[o] = ri[27];
+    const int rbase = ri[28], ndim = ri[29];
+    for (int k = 0; k < ndim; ++k)
+      if (rbase >= 0 && rbase + k < njmax) d.efc_id[(size_t)w * njmax + rbase + k] = adr + c;
+  }
+  for (int idx = lig; idx < 3 * n; idx += G) d.contact_pos[3 * o0 + idx] = rec[(idx / 3) * CON_STRIDE + 1 + idx % 3];
+  for (int idx = lig; idx < 9 * n; idx += G) d.contact_frame[9 * o0 + idx] = rec[(idx / 9) * CON_STRIDE + 4 + idx % 9];
+  for (int idx = lig; idx < 5 * n; idx += G) {
+    const int q = idx % 5;
+    d.contact_friction[5 * o0 + idx] = rec[(idx / 5) * CON_STRIDE + 14 + (q < 2 ? 0 : q - 1 - (q == 4 ? 1 : 0))];
+    d.contact_solimp[5 * o0 + idx] = rec[(idx / 5) * CON_STRIDE + 19 + q];
+  }
+  for (int idx = lig; idx < npyr * n; idx += G) {
+    const int c = idx / npyr, k = idx % npyr;
+    const int rbase = reci[c * CON_STRIDE + 28], ndim = reci[c * CON_STRIDE + 29];
+    d.contact_efc_address[npyr * o0 + idx] = (rbase >= 0 && k < ndim && rbase + k < njmax) ? rbase + k : -1;
   }
 }

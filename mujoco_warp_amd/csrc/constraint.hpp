@@ -47,9 +47,9 @@ DEV EfcRowOut efc_row(int dsbl, float timestep, float pos_aref, float pos_imp, f
 }
 
 struct ConLayout {
-  int cdof, qvel, rowvel, rowdof, rowval, row2con, clist, total;
+  int cdof, qvel, rowvel, rowdof, rowval, row2con, clist, cwin, scom, gbody, broot, bmask, total;
 };
-__host__ __device__ inline ConLayout con_layout(int nv, int njmax, int ncap) {
+__host__ __device__ inline ConLayout con_layout(int nv, int njmax, int ncap, int nbody, int ngeom) {
   ConLayout p;
   int o = 0;
   p.cdof = o; o += 6 * nv;
@@ -59,22 +59,33 @@ __host__ __device__ inline ConLayout con_layout(int nv, int njmax, int ncap) {
   p.rowval = o; o += njmax;
   p.row2con = o; o += njmax;
   p.clist = o; o += 3 * ncap;
+  p.cwin = o; o += CON_WINDOW * CON_STRIDE;  // staged contact records (see collide.hpp)
+  // model/kinematic tables of the contact Jacobian: the contact loop must not issue global loads, because a wave's
+  // loads wait behind its earlier J stores (one vmcnt counter for both on gfx9)
+  p.scom = o; o += 3 * nbody;
+  p.gbody = o; o += ngeom;
+  p.broot = o; o += nbody;
+  p.bmask = o; o += nbody * ((nv + 31) / 32);
   p.total = ((o + 3) / 4) * 4 + 1;
   return p;
 }
 
 template <int G>
-__global__ void __launch_bounds__(256) k_make_constraint(MjhModel m, MjhData d, int ncap) {
+__global__ void __launch_bounds__(256) k_make_constraint(MjhModel m, MjhData d) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int lig = threadIdx.x & (G - 1), gib = threadIdx.x / G;
   const int w = blockIdx.x * (blockDim.x / G) + gib;
   if (w >= d.nworld) return;
-  const int nv = m.nv, njnt = m.njnt, nbody = m.nbody, njmax = d.njmax, nvp = d.nv_pad;
-  const ConLayout lay = con_layout(nv, njmax, ncap);
+  const int nv = m.nv, njnt = m.njnt, nbody = m.nbody, njmax = d.njmax, nvp = d.nv_pad, ncap = d.concap;
+  const ConLayout lay = con_layout(nv, njmax, ncap, nbody, m.ngeom);
   float* S = smem + (size_t)gib * lay.total;
   float *cdof = S + lay.cdof, *qvel = S + lay.qvel, *rowvel = S + lay.rowvel, *rowval = S + lay.rowval;
   int *rowdof = reinterpret_cast<int*>(S + lay.rowdof), *row2con = reinterpret_cast<int*>(S + lay.row2con),
       *clist = reinterpret_cast<int*>(S + lay.clist);
+  float* cwin = S + lay.cwin;
+  float* scom = S + lay.scom;
+  int *gbody = reinterpret_cast<int*>(S + lay.gbody), *broot = reinterpret_cast<int*>(S + lay.broot);
+  unsigned* bmask = reinterpret_cast<unsigned*>(S + lay.bmask);
   const int dsbl = m.disableflags;
   float* J = d.efc_J + (size_t)w * d.njmax_pad * nvp;
   const size_t eo = (size_t)w * njmax;
@@ -83,12 +94,18 @@ __global__ void __launch_bounds__(256) k_make_constraint(MjhModel m, MjhData d, 
     if (lig == 0) d.ne[w] = d.nf[w] = d.nl[w] = d.nefc[w] = 0;
     return;
   }
+  PhaseClock pc(3, lig);
   gcopy<G>(cdof, d.cdof + (size_t)w * 6 * nv, 6 * nv, lig);
   gcopy<G>(qvel, d.qvel + (size_t)w * nv, nv, lig);
+  gcopy<G>(scom, d.subtree_com + (size_t)w * 3 * nbody, 3 * nbody, lig);
+  gcopyi<G>(gbody, m.geom_bodyid, m.ngeom, lig);
+  gcopyi<G>(broot, m.body_rootid, nbody, lig);
+  for (int i = lig; i < nbody * ((nv + 31) / 32); i += G) bmask[i] = m.body_dofmask[i];
   const float timestep = bf(m.opt_timestep, m.opt_timestep_nb, w, 1)[0];
   const float* qpos = d.qpos + (size_t)w * m.nq;
   const float* invw = bf(m.dof_invweight0, m.dof_invweight0_nb, w, nv);
   gsync();
+  pc.mark(0);
 
   int nefc = 0, nf = 0, nl = 0;
   // ---- dof friction loss (constraint.py:1766-1865) ---------------------------------------------------------
@@ -177,6 +194,7 @@ __global__ void __launch_bounds__(256) k_make_constraint(MjhModel m, MjhData d, 
     }
   }
   gsync();
+  pc.mark(1);
   // cooperative, coalesced write of the (one-hot) friction/limit rows of J
   {
     const int nrow = min(nefc, njmax);
@@ -199,21 +217,23 @@ __global__ void __launch_bounds__(256) k_make_constraint(MjhModel m, MjhData d, 
     }
   }
   const int nrow_noncontact = nefc;
+  pc.mark(2);
 
   // ---- contacts (constraint.py:2641-2757 init, 3751-3879 jac, 4197-4343 update) ---------------------------
+  // The world's contact records come from d.ws_contact (k_collision); the public contact_* arrays are not read.
   int nactive = 0;
-  const int ncon = (dsbl & DSBL_CONTACT) ? 0 : d.ws_ncon[w];
-  const int cadr = d.ws_conadr[w];
+  const int ncon = (dsbl & DSBL_CONTACT) ? 0 : min(d.ws_ncon[w], ncap);
+  float* crec = d.ws_contact + (size_t)w * ncap * CON_STRIDE;
+  int* creci = reinterpret_cast<int*>(crec);
   for (int base = 0; base < ncon; base += G) {
     const int c = base + lig;
     bool act = false;
     int ndim = 0;
     if (c < ncon) {
-      const size_t o = (size_t)(cadr + c);
-      const float pos = d.contact_dist[o] - d.contact_includemargin[o];
+      const float pos = crec[c * CON_STRIDE] - crec[c * CON_STRIDE + 13];
       act = pos < 0.0f;
-      const int condim = d.contact_dim[o];
-      ndim = act ? (condim == 1 ? 1 : 2 * (condim - 1)) : 0;
+      const int condim = creci[c * CON_STRIDE + 24];
+      ndim = act ? min(condim == 1 ? 1 : 2 * (condim - 1), d.nmaxpyramid) : 0;
     }
     int incl = ndim;
     for (int off = 1; off < G; off <<= 1) {
@@ -223,85 +243,97 @@ __global__ void __launch_bounds__(256) k_make_constraint(MjhModel m, MjhData d, 
     const int rbase = nefc + incl - ndim;
     int tot;
     const int arank = nactive + grank<G>(act, lig, tot);
+    if (c < ncon) {
+      creci[c * CON_STRIDE + 28] = act ? rbase : -1;  // contact.efc_address / efc.id are published from these
+      creci[c * CON_STRIDE + 29] = ndim;
+    }
     if (act) {
-      const size_t o = (size_t)(cadr + c);
-      for (int k = 0; k < ndim; ++k) {
-        const int r = rbase + k;
-        d.contact_efc_address[o * d.nmaxpyramid + k] = r < njmax ? r : -1;
-        if (r < njmax) row2con[r] = c * 16 + k;
-      }
-      if (arank < ncap) {
-        clist[3 * arank] = c;
-        clist[3 * arank + 1] = rbase;
-        clist[3 * arank + 2] = ndim;
-      }
+      for (int k = 0; k < ndim; ++k)
+        if (rbase + k < njmax) row2con[rbase + k] = c * 16 + k;
+      clist[3 * arank] = c;
+      clist[3 * arank + 1] = rbase;
+      clist[3 * arank + 2] = ndim;
     }
     nefc += __shfl(incl, G - 1, G);
     nactive += tot;
   }
   gsync();
-  if (nactive > ncap) nactive = ncap;
+  pc.mark(3);
   const int nw = (nv + 31) / 32;
-  for (int a = 0; a < nactive; ++a) {
-    const int c = clist[3 * a], rbase = clist[3 * a + 1], ndim = clist[3 * a + 2];
-    if (rbase >= njmax) break;
-    const size_t o = (size_t)(cadr + c);
-    const int g1 = d.contact_geom[2 * o], g2 = d.contact_geom[2 * o + 1];
-    const int b1 = m.geom_bodyid[g1], b2 = m.geom_bodyid[g2];
-    const V3 cpos = ld3(d.contact_pos + 3 * o);
-    const V3 off1 = cpos - ld3(d.subtree_com + ((size_t)w * nbody + m.body_rootid[b1]) * 3);
-    const V3 off2 = cpos - ld3(d.subtree_com + ((size_t)w * nbody + m.body_rootid[b2]) * 3);
-    const float* frame = d.contact_frame + 9 * o;
-    const V3 f0 = ld3(frame), f1 = ld3(frame + 3), f2 = ld3(frame + 6);
-    const float* fri = d.contact_friction + 5 * o;
-    const int condim = d.contact_dim[o];
-    float part[10];
-    for (int k = 0; k < 10; ++k) part[k] = 0.0f;
-    for (int i0 = 0; i0 < nvp; i0 += G) {
-      const int i = i0 + lig;
-      V3 jp = V3{0, 0, 0}, jr = V3{0, 0, 0};
-      if (i < nv) {
-        const bool a1 = m.body_dofmask[b1 * nw + (i >> 5)] & (1u << (i & 31));
-        const bool a2 = m.body_dofmask[b2 * nw + (i >> 5)] & (1u << (i & 31));
-        const V3 ang = ld3(cdof + 6 * i), lin = ld3(cdof + 6 * i + 3);
-        if (a2) {
-          jp = jp + lin + cross(ang, off2);
-          jr = jr + ang;
-        }
-        if (a1) {
-          jp = jp - (lin + cross(ang, off1));
-          jr = jr - ang;
-        }
+  int a = 0;
+  for (int wbase = 0; wbase < ncon && a < nactive; wbase += CON_WINDOW) {
+    const int wend = min(wbase + CON_WINDOW, ncon);
+    if (clist[3 * a] >= wend) continue;  // no active contact in this window
+    // stage the window's records with consecutive addresses: one memory round trip for up to 16 contacts
+    for (int idx = lig; idx < (wend - wbase) * CON_STRIDE; idx += G) cwin[idx] = crec[(size_t)wbase * CON_STRIDE + idx];
+    gsync();
+    for (; a < nactive; ++a) {
+      const int c = clist[3 * a], rbase = clist[3 * a + 1], ndim = clist[3 * a + 2];
+      if (c >= wend) break;
+      if (rbase >= njmax) {
+        a = nactive;
+        break;
       }
-      if (i < nvp) {
-        const float j0p = dot(f0, jp);
-        const float qv = i < nv ? qvel[i] : 0.0f;
-        for (int k = 0; k < ndim; ++k) {
-          const int r = rbase + k;
-          if (r >= njmax) break;
-          float val = j0p;
-          if (condim > 1) {
-            const int dimid2 = k / 2 + 1;
-            const float frii = fri[dimid2 - 1] * (1.0f - 2.0f * (float)(k & 1));
-            float ji;
-            if (dimid2 == 1) ji = dot(f1, jp);
-            else if (dimid2 == 2) ji = dot(f2, jp);
-            else if (dimid2 == 3) ji = dot(f0, jr);
-            else if (dimid2 == 4) ji = dot(f1, jr);
-            else ji = dot(f2, jr);
-            val += ji * frii;
+      const float* cr = cwin + (c - wbase) * CON_STRIDE;
+      const int* cri = reinterpret_cast<const int*>(cr);
+      const int g1 = cri[25], g2 = cri[26];
+      const int b1 = gbody[g1], b2 = gbody[g2];
+      const V3 cpos = ld3(cr + 1);
+      const V3 off1 = cpos - ld3(scom + 3 * broot[b1]);
+      const V3 off2 = cpos - ld3(scom + 3 * broot[b2]);
+      const V3 f0 = ld3(cr + 4), f1 = ld3(cr + 7), f2 = ld3(cr + 10);
+      const float fri[5] = {cr[14], cr[14], cr[15], cr[16], cr[16]};
+      const int condim = cri[24];
+      float part[10];
+      for (int k = 0; k < 10; ++k) part[k] = 0.0f;
+      for (int i0 = 0; i0 < nvp; i0 += G) {
+        const int i = i0 + lig;
+        V3 jp = V3{0, 0, 0}, jr = V3{0, 0, 0};
+        if (i < nv) {
+          const bool a1 = bmask[b1 * nw + (i >> 5)] & (1u << (i & 31));
+          const bool a2 = bmask[b2 * nw + (i >> 5)] & (1u << (i & 31));
+          const V3 ang = ld3(cdof + 6 * i), lin = ld3(cdof + 6 * i + 3);
+          if (a2) {
+            jp = jp + lin + cross(ang, off2);
+            jr = jr + ang;
           }
-          J[(size_t)r * nvp + i] = val;
-          part[k] += val * qv;
+          if (a1) {
+            jp = jp - (lin + cross(ang, off1));
+            jr = jr - ang;
+          }
+        }
+        if (i < nvp) {
+          const float j0p = dot(f0, jp);
+          const float qv = i < nv ? qvel[i] : 0.0f;
+          for (int k = 0; k < ndim; ++k) {
+            const int r = rbase + k;
+            if (r >= njmax) break;
+            float val = j0p;
+            if (condim > 1) {
+              const int dimid2 = k / 2 + 1;
+              const float frii = fri[dimid2 - 1] * (1.0f - 2.0f * (float)(k & 1));
+              float ji;
+              if (dimid2 == 1) ji = dot(f1, jp);
+              else if (dimid2 == 2) ji = dot(f2, jp);
+              else if (dimid2 == 3) ji = dot(f0, jr);
+              else if (dimid2 == 4) ji = dot(f1, jr);
+              else ji = dot(f2, jr);
+              val += ji * frii;
+            }
+            J[(size_t)r * nvp + i] = val;
+            part[k] += val * qv;
+          }
         }
       }
+      for (int k = 0; k < ndim; ++k) {
+        const float v = gsum<G>(part[k]);
+        if (lig == 0 && rbase + k < njmax) rowvel[rbase + k] = v;
+      }
     }
-    for (int k = 0; k < ndim; ++k) {
-      const float v = gsum<G>(part[k]);
-      if (lig == 0 && rbase + k < njmax) rowvel[rbase + k] = v;
-    }
+    gsync();
   }
   gsync();
+  pc.mark(4);
   // per-row contact parameters (lane per row)
   {
     const int nrow = min(nefc, njmax);
@@ -309,19 +341,20 @@ __global__ void __launch_bounds__(256) k_make_constraint(MjhModel m, MjhData d, 
     const float* biw = bf(m.body_invweight0, m.body_invweight0_nb, w, 2 * nbody);
     for (int r = nrow_noncontact + lig; r < nrow; r += G) {
       const int c = row2con[r] >> 4;
-      const size_t o = (size_t)(cadr + c);
-      const float includemargin = d.contact_includemargin[o];
-      const float pos = d.contact_dist[o] - includemargin;
-      const int condim = d.contact_dim[o];
-      const int b1 = m.geom_bodyid[d.contact_geom[2 * o]], b2 = m.geom_bodyid[d.contact_geom[2 * o + 1]];
+      const float* cr = crec + c * CON_STRIDE;
+      const int* cri = creci + c * CON_STRIDE;
+      const float includemargin = cr[13];
+      const float pos = cr[0] - includemargin;
+      const int condim = cri[24];
+      const int b1 = gbody[cri[25]], b2 = gbody[cri[26]];
       float invweight = biw[2 * b1] + biw[2 * b2];
       if (condim > 1) {
-        const float fri0 = d.contact_friction[5 * o];
+        const float fri0 = cr[14];
         invweight = invweight + fri0 * fri0 * invweight;
         invweight = invweight * 2.0f * fri0 * fri0 * impr2 * impr2;
       }
       const float vel = rowvel[r];
-      EfcRowOut eo_ = efc_row(dsbl, timestep, pos, pos, invweight, d.contact_solref + 2 * o, d.contact_solimp + 5 * o, includemargin, vel);
+      EfcRowOut eo_ = efc_row(dsbl, timestep, pos, pos, invweight, cr + 17, cr + 19, includemargin, vel);
       d.efc_D[eo + r] = eo_.D;
       d.efc_aref[eo + r] = eo_.aref;
       d.efc_pos[eo + r] = eo_.pos;
@@ -329,7 +362,7 @@ __global__ void __launch_bounds__(256) k_make_constraint(MjhModel m, MjhData d, 
       d.efc_vel[eo + r] = vel;
       d.efc_frictionloss[eo + r] = 0.0f;
       d.efc_type[eo + r] = condim == 1 ? CT_CONTACT_FRICTIONLESS : CT_CONTACT_PYRAMIDAL;
-      d.efc_id[eo + r] = cadr + c;
+      d.efc_id[eo + r] = c;  // world-local; k_publish_contacts rewrites it with the public contact id
     }
   }
   if (lig == 0) {
@@ -339,4 +372,5 @@ __global__ void __launch_bounds__(256) k_make_constraint(MjhModel m, MjhData d, 
     d.nefc[w] = nefc;
     if (nefc > njmax) atomicOr(d.overflow + w, OVF_NEFC);
   }
+  pc.mark(5);
 }

@@ -207,3 +207,35 @@ template <int G>
 DEV void gcopyi(int* dst, const int* src, int n, int lig) {
   for (int i = lig; i < n; i += G) dst[i] = src[i];
 }
+
+// Phase clock (profiling builds only: hipcc -DMJH_PHASE_CLOCK, tools/phase_clock.py).  Lane 0 of every group adds the
+// shader-clock ticks between consecutive marks to g_phase_ticks[kernel][phase]; the product build compiles it away.
+#ifdef MJH_PHASE_CLOCK
+__device__ unsigned long long g_phase_ticks[64][8][16];  // [copy = block & 63] spreads the flush atomics
+struct PhaseClock {
+  long long t;
+  unsigned acc[16];
+  int k;
+  bool on;
+  DEV PhaseClock(int kernel, int lig) : t(clock64()), k(kernel), on(lig == 0) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0u;
+  }
+  DEV void mark(int phase) {  // phase must be a compile-time constant (register-resident accumulators)
+    const long long n = clock64();
+    acc[phase] += (unsigned)(n - t);
+    t = clock64();
+  }
+  DEV ~PhaseClock() {
+    if (!on) return;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      if (acc[i]) atomicAdd(&g_phase_ticks[blockIdx.x & 63][k][i], (unsigned long long)acc[i]);
+  }
+};
+#else
+struct PhaseClock {
+  DEV PhaseClock(int, int) {}
+  DEV void mark(int) {}
+};
+#endif

@@ -128,7 +128,13 @@ __global__ void __launch_bounds__(256) k_integrate(MjhModel m, MjhData d, int mo
       qpos[qa] += h * qvel[dof];
     }
   }
-  if (lig == 0) d.time[w] += h;
+  if (lig == 0) {
+    d.time[w] += h;
+    // end-of-step overflow flags that depend on counters (forward.py:221-273)
+    int o = 0;
+    if (d.nefc[w] > d.njmax) o |= OVF_NEFC;
+    if (o) atomicOr(d.overflow + w, o);  // k_publish_contacts may be flagging the same world concurrently
+  }
 }
 
 // cli.py:103-145; halton in float32 exactly like util_misc.py:61
@@ -195,16 +201,6 @@ __global__ void __launch_bounds__(256) k_solve_m(MjhModel m, MjhData d, float* x
   }
   gsync();
   gcopy<G>(xout + (size_t)w * nv, x, nv, lig);
-}
-
-// end-of-step overflow flags that depend on global counters (forward.py:221-273)
-__global__ void k_overflow(MjhData d) {
-  const int w = blockIdx.x * blockDim.x + threadIdx.x;
-  if (w >= d.nworld) return;
-  int o = 0;
-  if (d.nefc[w] > d.njmax) o |= OVF_NEFC;
-  if (d.nacon[0] > d.naconmax) o |= OVF_NARROWPHASE;
-  if (o) d.overflow[w] |= o;
 }
 
 // Solver schedule for the NEXT step: counting sort of worlds by this step's solver_niter, longest first.

@@ -35,7 +35,9 @@ static int fail(int code, const char* fmt, const char* a = "") {
 static const int kLdsPerCU = 160 * 1024;
 
 // pick threads per block in {256,128,64} maximising resident worlds per CU for the given LDS needs
-static int pick_block(size_t shared_bytes, size_t per_world_bytes, int G, size_t* lds_out, bool prefer_small = false) {
+static int pick_block(size_t shared_bytes, size_t per_world_bytes, int G, size_t* lds_out, bool prefer_small_arg = false) {
+  static const int small_env = getenv("MJH_SMALL_BLOCKS") ? atoi(getenv("MJH_SMALL_BLOCKS")) : -1;  // developer knob
+  const bool prefer_small = small_env >= 0 ? (small_env != 0) : prefer_small_arg;
   int best = 0, best_worlds = -1;
   // ties go to the first candidate: large blocks amortise the block-shared tables, small blocks retire as soon as
   // their own worlds converge (k_solve: per-world work varies by an order of magnitude)
@@ -74,13 +76,6 @@ static hipError_t set_lds(K kernel, size_t bytes) {
   return e;
 }
 
-static int contact_cap(const MjhData* d) {
-  int cap = d->nconmax * 2;
-  if (cap < 16) cap = 16;
-  if (cap > 256) cap = 256;
-  return cap;
-}
-
 constexpr int G = 32;
 
 static int launch_pos(const MjhModel* m, const MjhData* d, int first, int last, hipStream_t s) {
@@ -103,27 +98,40 @@ static int launch_vel(const MjhModel* m, const MjhData* d, int first, int last, 
   hipLaunchKernelGGL(k_fwd_vel<G>, dim3((d->nworld + wpb - 1) / wpb), dim3(threads), lds, s, *m, *d, first, last);
   return MJH_OK;
 }
-static int launch_collision(const MjhModel* m, const MjhData* d, hipStream_t s) {
-  HIPCHK(hipMemsetAsync(d->nacon, 0, sizeof(int), s));
-  HIPCHK(hipMemsetAsync(d->ncollision, 0, sizeof(int), s));
-  const int cap = contact_cap(d);
+// public L'DL factor (qLD, qLDiagInv) and, on request, qacc_smooth: outputs nobody inside the step waits for
+static int launch_factor_smooth(const MjhModel* m, const MjhData* d, int write_qacc, hipStream_t s) {
+  const FacLayout lay = fac_layout(m->nv, m->nC);
   size_t lds;
-  const int threads = pick_block(0, sizeof(float) * collide_lds_words(m->npair, cap), G, &lds);
+  const int threads = pick_block(sizeof(int) * mstruct_ints(m->nv, m->nC), sizeof(float) * lay.total, G, &lds);
+  if (!threads) return fail(MJH_E_UNSUPPORTED, "k_factor_smooth: model does not fit in LDS");
+  HIPCHK(set_lds(k_factor_smooth<G>, lds));
+  const int wpb = threads / G;
+  hipLaunchKernelGGL(k_factor_smooth<G>, dim3((d->nworld + wpb - 1) / wpb), dim3(threads), lds, s, *m, *d, write_qacc);
+  return MJH_OK;
+}
+static int launch_collision(const MjhModel* m, const MjhData* d, hipStream_t s) {
+  size_t lds;
+  const int threads = pick_block(0, sizeof(float) * collide_lds_words(m->ngeom, m->npair), G, &lds);
   if (!threads) return fail(MJH_E_UNSUPPORTED, "k_collision: pair list does not fit in LDS");
   HIPCHK(set_lds(k_collision<G>, lds));
   const int wpb = threads / G;
-  hipLaunchKernelGGL(k_collision<G>, dim3((d->nworld + wpb - 1) / wpb), dim3(threads), lds, s, *m, *d, cap);
+  hipLaunchKernelGGL(k_collision<G>, dim3((d->nworld + wpb - 1) / wpb), dim3(threads), lds, s, *m, *d);
+  return MJH_OK;
+}
+// compact public contact arrays, contact.efc_address and efc.id of contact rows from the per-world records
+static int launch_publish(const MjhData* d, hipStream_t s) {
+  hipLaunchKernelGGL(k_contact_scan, dim3(1), dim3(1024), 0, s, *d);
+  hipLaunchKernelGGL(k_publish_contacts<G>, dim3((d->nworld + 7) / 8), dim3(256), 0, s, *d);
   return MJH_OK;
 }
 static int launch_constraint(const MjhModel* m, const MjhData* d, hipStream_t s) {
-  const int cap = contact_cap(d);
-  const ConLayout lay = con_layout(m->nv, d->njmax, cap);
+  const ConLayout lay = con_layout(m->nv, d->njmax, d->concap, m->nbody, m->ngeom);
   size_t lds;
   const int threads = pick_block(0, sizeof(float) * lay.total, G, &lds);
   if (!threads) return fail(MJH_E_UNSUPPORTED, "k_make_constraint: does not fit in LDS");
   HIPCHK(set_lds(k_make_constraint<G>, lds));
   const int wpb = threads / G;
-  hipLaunchKernelGGL(k_make_constraint<G>, dim3((d->nworld + wpb - 1) / wpb), dim3(threads), lds, s, *m, *d, cap);
+  hipLaunchKernelGGL(k_make_constraint<G>, dim3((d->nworld + wpb - 1) / wpb), dim3(threads), lds, s, *m, *d);
   return MJH_OK;
 }
 template <int NV4, int NR, bool NEWTON>
@@ -173,7 +181,6 @@ static int launch_integrate(const MjhModel* m, const MjhData* d, int mode, hipSt
   HIPCHK(set_lds(k_integrate<G>, lds));
   const int wpb = threads / G;
   hipLaunchKernelGGL(k_integrate<G>, dim3((d->nworld + wpb - 1) / wpb), dim3(threads), lds, s, *m, *d, mode);
-  hipLaunchKernelGGL(k_overflow, dim3((d->nworld + 255) / 256), dim3(256), 0, s, *d);
   return MJH_OK;
 }
 
@@ -186,6 +193,7 @@ static int launch_integrate(const MjhModel* m, const MjhData* d, int mode, hipSt
 static int check(const MjhModel* m, const MjhData* d) {
   if (!m || !d) return fail(MJH_E_ARG, "null model/data");
   if (d->nworld <= 0) return fail(MJH_E_ARG, "nworld must be positive");
+  if (d->concap <= 0 || !d->ws_contact) return fail(MJH_E_ARG, "Data.ws_contact / concap missing (allocate Data with make_data/put_data)");
   if (m->integrator != INT_EULER && m->integrator != INT_IMPLICITFAST) return fail(MJH_E_UNSUPPORTED, "integrator must be Euler or implicitfast");
   return MJH_OK;
 }
@@ -223,17 +231,21 @@ enum { K_NOISE = 0, K_POS = 1, K_COLLISION = 2, K_CONSTRAINT = 3, K_VEL = 4, K_S
 // one non-blocking side stream + fork/join events per host thread and device (created on first use, never freed)
 struct Side {
   hipStream_t stream;
-  hipEvent_t fork, join;
+  hipEvent_t fork, join, join2, vel_done;
 };
 static Side* side_stream() {
   static thread_local Side* per_dev[16] = {nullptr};
+  static const bool disabled = getenv("MJH_NO_OVERLAP") != nullptr;  // developer knob: serialise everything
+  if (disabled) return nullptr;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
   if (!per_dev[dev]) {
     Side* sd = new Side();
     if (hipStreamCreateWithFlags(&sd->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&sd->fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&sd->join, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&sd->join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&sd->join2, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&sd->vel_done, hipEventDisableTiming) != hipSuccess) {
       delete sd;
       return nullptr;
     }
@@ -248,15 +260,21 @@ static int run_stage(const MjhModel* m, const MjhData* d, int stage, hipStream_t
     case MJH_STAGE_COM_POS: { Scope sc(K_POS); return launch_pos(m, d, POS_COM, POS_COM, s); }
     case MJH_STAGE_CRB: { Scope sc(K_POS); return launch_pos(m, d, POS_CRB, POS_CRB, s); }
     case MJH_STAGE_FACTOR_M: { Scope sc(K_POS); return launch_pos(m, d, POS_FACTOR, POS_FACTOR, s); }
-    case MJH_STAGE_COLLISION: { Scope sc(K_COLLISION); return launch_collision(m, d, s); }
-    case MJH_STAGE_MAKE_CONSTRAINT: { Scope sc(K_CONSTRAINT); return launch_constraint(m, d, s); }
+    case MJH_STAGE_COLLISION:
+      { Scope sc(K_COLLISION); TRY(launch_collision(m, d, s)); }
+      { Scope sc(K_OTHER); return launch_publish(d, s); }
+    case MJH_STAGE_MAKE_CONSTRAINT:
+      { Scope sc(K_CONSTRAINT); TRY(launch_constraint(m, d, s)); }
+      { Scope sc(K_OTHER); return launch_publish(d, s); }
     case MJH_STAGE_TRANSMISSION: return MJH_OK;  // joint transmissions: length/moment are produced by fwd_actuation
     case MJH_STAGE_COM_VEL: { Scope sc(K_VEL); return launch_vel(m, d, VEL_COMVEL, VEL_COMVEL, s); }
     case MJH_STAGE_PASSIVE: { Scope sc(K_VEL); return launch_vel(m, d, VEL_PASSIVE, VEL_PASSIVE, s); }
     case MJH_STAGE_RNE: { Scope sc(K_VEL); return launch_vel(m, d, VEL_RNE, VEL_RNE, s); }
     case MJH_STAGE_FWD_VELOCITY: { Scope sc(K_VEL); return launch_vel(m, d, VEL_COMVEL, VEL_RNE, s); }
     case MJH_STAGE_FWD_ACTUATION: { Scope sc(K_VEL); return launch_vel(m, d, VEL_ACTUATION, VEL_ACTUATION, s); }
-    case MJH_STAGE_FWD_ACCELERATION: { Scope sc(K_VEL); return launch_vel(m, d, VEL_ACCEL, VEL_ACCEL, s); }
+    case MJH_STAGE_FWD_ACCELERATION:
+      { Scope sc(K_VEL); TRY(launch_vel(m, d, VEL_ACCEL, VEL_ACCEL, s)); }
+      { Scope sc(K_OTHER); return launch_factor_smooth(m, d, 1, s); }
     case MJH_STAGE_SOLVE: { Scope sc(K_SOLVE); return launch_solve(m, d, s); }
     case MJH_STAGE_EULER: { Scope sc(K_INTEGRATE); return launch_integrate(m, d, 0, s); }
     case MJH_STAGE_IMPLICIT: { Scope sc(K_INTEGRATE); return launch_integrate(m, d, 1, s); }
@@ -264,31 +282,51 @@ static int run_stage(const MjhModel* m, const MjhData* d, int stage, hipStream_t
       { Scope sc(K_POS); TRY(launch_pos(m, d, POS_KINEMATICS, POS_FACTOR, s)); }
       { Scope sc(K_COLLISION); TRY(launch_collision(m, d, s)); }
       { Scope sc(K_CONSTRAINT); TRY(launch_constraint(m, d, s)); }
+      { Scope sc(K_OTHER); TRY(launch_publish(d, s)); }
       return MJH_OK;
-    case MJH_STAGE_FORWARD: {
+    case MJH_STAGE_FORWARD:
+    case MJH_STAGE_STEP: {
       { Scope sc(K_POS); TRY(launch_pos(m, d, POS_KINEMATICS, POS_CRB, s)); }
-      // {collision -> make_constraint} and fwd_vel only depend on fwd_pos: both are latency-bound at ~2 waves/SIMD, so
-      // they run concurrently (fork/join through events on a side stream; capturable into a hipGraph).  The per-kernel
-      // instrumentation pass keeps them serial so that the event pairs time one kernel at a time.
+      // {collision -> make_constraint} and fwd_vel only depend on fwd_pos and are latency-bound at ~2 waves/SIMD: they run
+      // concurrently (fork/join through events on a side stream; capturable into a hipGraph).  The compaction of the
+      // public contact arrays is needed by nobody inside the step: it stays on the side stream, beside the solver.
+      // The per-kernel instrumentation pass keeps everything serial so that event pairs time one kernel at a time.
       Side* side = (g_instr && g_instr->on) ? nullptr : side_stream();
+      const int write_qacc = m->solver == SOL_NEWTON ? 1 : 0;  // k_solve<CG> writes qacc_smooth itself
       if (side) {
+        // fwd_vel (the long pole: one 94 KB block per CU) stays on the caller's stream so that it is dispatched first;
+        // the collision blocks arrive a few microseconds later through the event wait and fill the remaining LDS.
+        // The other way round the collision kernel wins the race, fills every CU and the two kernels serialise
+        // (measured 0.683 vs 0.640 ms/step).
         HIPCHK(hipEventRecord(side->fork, s));
         HIPCHK(hipStreamWaitEvent(side->stream, side->fork, 0));
-        TRY(launch_vel(m, d, VEL_COMVEL, VEL_ACCEL, side->stream));
+        TRY(launch_vel(m, d, VEL_COMVEL, VEL_ACCEL, s));
+        HIPCHK(hipEventRecord(side->vel_done, s));
+        TRY(launch_collision(m, d, side->stream));
+        TRY(launch_constraint(m, d, side->stream));
         HIPCHK(hipEventRecord(side->join, side->stream));
+        // beside the solver: public contact arrays, L'DL factor (+ qacc_smooth when the solver does not write it)
+        TRY(launch_publish(d, side->stream));
+        HIPCHK(hipStreamWaitEvent(side->stream, side->vel_done, 0));
+        TRY(launch_factor_smooth(m, d, write_qacc, side->stream));
+        HIPCHK(hipEventRecord(side->join2, side->stream));
+        HIPCHK(hipStreamWaitEvent(s, side->join, 0));
+      } else {
+        { Scope sc(K_COLLISION); TRY(launch_collision(m, d, s)); }
+        { Scope sc(K_CONSTRAINT); TRY(launch_constraint(m, d, s)); }
+        { Scope sc(K_OTHER); TRY(launch_publish(d, s)); }
+        { Scope sc(K_VEL); TRY(launch_vel(m, d, VEL_COMVEL, VEL_ACCEL, s)); }
+        { Scope sc(K_OTHER); TRY(launch_factor_smooth(m, d, write_qacc, s)); }
       }
-      { Scope sc(K_COLLISION); TRY(launch_collision(m, d, s)); }
-      { Scope sc(K_CONSTRAINT); TRY(launch_constraint(m, d, s)); }
-      if (side) HIPCHK(hipStreamWaitEvent(s, side->join, 0));
-      else { Scope sc(K_VEL); TRY(launch_vel(m, d, VEL_COMVEL, VEL_ACCEL, s)); }
       { Scope sc(K_SOLVE); TRY(launch_solve(m, d, s)); }
-      hipLaunchKernelGGL(k_schedule_worlds, dim3(1), dim3(1024), 0, s, *d);  // solver schedule for the next step
+      { Scope sc(K_OTHER); hipLaunchKernelGGL(k_schedule_worlds, dim3(1), dim3(1024), 0, s, *d); }  // solver schedule for the next step
+      if (stage == MJH_STAGE_STEP) {
+        Scope sc(K_INTEGRATE);
+        TRY(launch_integrate(m, d, m->integrator == INT_IMPLICITFAST ? 1 : 0, s));
+      }
+      if (side) HIPCHK(hipStreamWaitEvent(s, side->join2, 0));  // every fork rejoins the caller's stream
       return MJH_OK;
     }
-    case MJH_STAGE_STEP:
-      TRY(run_stage(m, d, MJH_STAGE_FORWARD, s));
-      { Scope sc(K_INTEGRATE); TRY(launch_integrate(m, d, m->integrator == INT_IMPLICITFAST ? 1 : 0, s)); }
-      return MJH_OK;
     default:
       return fail(MJH_E_ARG, "unknown stage");
   }
@@ -405,5 +443,17 @@ int mjh_timed_steps(const MjhModel* m, const MjhData* d, int nstep, int step0, f
   HIPCHK(hipGetLastError());
   return MJH_OK;
 }
+
+#ifdef MJH_PHASE_CLOCK
+// profiling builds only (tools/phase_clock.py): read (and optionally reset) the per-kernel, per-phase tick sums
+int mjh_debug_phase_ticks(unsigned long long* out, int reset) {
+  if (out) HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_ticks), sizeof(unsigned long long) * 64 * 8 * 16));
+  if (reset) {
+    static unsigned long long zeros[64 * 8 * 16] = {0};
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_phase_ticks), zeros, sizeof(zeros)));
+  }
+  return MJH_OK;
+}
+#endif
 
 }  // extern "C"

@@ -17,6 +17,8 @@ struct MStruct {
   const int* rowadr;
   const int* rownnz;
   const int* colind;
+  const int* dof_tree;      // dof ids sorted by depth
+  const int* dof_leveladr;  // [ndoflevel + 1]
 };
 
 template <int G>
@@ -28,10 +30,14 @@ DEV MStruct load_mstruct(const MjhModel& m, int* sh) {
     sh[nv + i] = m.M_rownnz[i];
   }
   for (int i = threadIdx.x; i < nC; i += blockDim.x) sh[2 * nv + i] = m.M_colind[i];
+  int* lv = sh + 2 * nv + nC;
+  for (int i = threadIdx.x; i < nv; i += blockDim.x) lv[i] = m.dof_tree[i];
+  for (int i = threadIdx.x; i <= m.ndoflevel; i += blockDim.x) lv[nv + i] = m.dof_leveladr[i];
   __syncthreads();
-  return MStruct{sh, sh + nv, sh + 2 * nv};
+  return MStruct{sh, sh + nv, sh + 2 * nv, lv, lv + nv};
 }
-__host__ __device__ inline int mstruct_ints(int nv, int nC) { return ((2 * nv + nC + 3) / 4) * 4; }
+// M_rowadr | M_rownnz | M_colind | dof_tree | dof_leveladr (ndoflevel <= nv)
+__host__ __device__ inline int mstruct_ints(int nv, int nC) { return ((4 * nv + 1 + nC + 3) / 4) * 4; }
 
 // sparse L'DL factorisation in LDS (reference smooth.py:1183-1232 _qLD_acc/_qLDiag_div == MuJoCo mj_factorI).
 // L holds a copy of M on entry.  Row k is eliminated sequentially (leaf to root); the updates of its
@@ -65,9 +71,9 @@ DEV void solve_ld(const MjhModel& m, const MStruct& ms, const float* L, const fl
   for (int i = lig; i < nv; i += G) x[i] *= dinv[i];
   gsync();
   for (int l = 1; l < m.ndoflevel; ++l) {  // x <- L^-1 x, level by level down the dof tree
-    const int beg = m.dof_leveladr[l], end = m.dof_leveladr[l + 1];
+    const int beg = ms.dof_leveladr[l], end = ms.dof_leveladr[l + 1];
     for (int idx = beg + lig; idx < end; idx += G) {
-      const int k = m.dof_tree[idx];
+      const int k = ms.dof_tree[idx];
       const int start = ms.rowadr[k], n = ms.rownnz[k];
       float s = x[k];
       for (int a = 0; a < n - 1; ++a) s -= L[start + a] * x[ms.colind[start + a]];
@@ -135,6 +141,7 @@ __global__ void __launch_bounds__(256) k_fwd_pos(MjhModel m, MjhData d, int firs
   const int lig = threadIdx.x & (G - 1), gib = threadIdx.x / G;
   const int w = blockIdx.x * (blockDim.x / G) + gib;
   if (w >= d.nworld) return;
+  PhaseClock pc(1, lig);
   float* S = smem + mstruct_ints(nv, nC) + (size_t)gib * lay.total;
   float *qpos = S + lay.qpos, *xpos = S + lay.xpos, *xquat = S + lay.xquat, *xmat = S + lay.xmat, *xipos = S + lay.xipos,
         *ximat = S + lay.ximat, *xanchor = S + lay.xanchor, *xaxis = S + lay.xaxis, *scom = S + lay.scom,
@@ -236,6 +243,7 @@ __global__ void __launch_bounds__(256) k_fwd_pos(MjhModel m, MjhData d, int firs
     gcopy<G>(d.xanchor + (size_t)w * 3 * njnt, xanchor, 3 * njnt, lig);
     gcopy<G>(d.xaxis + (size_t)w * 3 * njnt, xaxis, 3 * njnt, lig);
   }
+  pc.mark(0);
   if (last < POS_COM) return;
 
   // ---- com_pos (smooth.py:686-822) -------------------------------------------------------------------
@@ -318,6 +326,7 @@ __global__ void __launch_bounds__(256) k_fwd_pos(MjhModel m, MjhData d, int firs
     gcopy<G>(d.cinert + (size_t)w * 10 * nbody, cinert, 10 * nbody, lig);
     gcopy<G>(d.cdof + (size_t)w * 6 * nv, cdof, 6 * nv, lig);
   }
+  pc.mark(1);
   if (last < POS_CRB) return;
 
   // ---- crb (smooth.py:1029-1098) -----------------------------------------------------------------------
@@ -359,6 +368,7 @@ __global__ void __launch_bounds__(256) k_fwd_pos(MjhModel m, MjhData d, int firs
     gcopy<G>(d.crb + (size_t)w * 10 * nbody, crb, 10 * nbody, lig);
     gcopy<G>(d.M + (size_t)w * nC, M, nC, lig);
   }
+  pc.mark(2);
   if (last < POS_FACTOR) return;
 
   // ---- factor_m (smooth.py:1183-1232) -----------------------------------------------------------------
@@ -368,11 +378,12 @@ __global__ void __launch_bounds__(256) k_fwd_pos(MjhModel m, MjhData d, int firs
   factor_ld<G>(ms, L, dinv, nv, lig);
   gcopy<G>(d.qLD + (size_t)w * nC, L, nC, lig);
   gcopy<G>(d.qLDiagInv + (size_t)w * nv, dinv, nv, lig);
+  pc.mark(3);
 }
 
 // ---------------------------------------------------------------------------------------------------
 struct VelLayout {
-  int qpos, qvel, cdof, cinert, cvel, cdof_dot, cacc, cfrc, cfi, uforce, fspring, fdamper, fgrav, fpassive, fbias, factuator, x, L, dinv, total;
+  int qpos, qvel, cdof, cinert, cvel, cdof_dot, cacc, cfrc, cfi, uforce, fspring, fdamper, fgrav, fpassive, fbias, factuator, x, total;
 };
 __host__ __device__ inline VelLayout vel_layout(int nq, int nv, int nbody, int nC, int nu) {
   VelLayout p;
@@ -394,8 +405,6 @@ __host__ __device__ inline VelLayout vel_layout(int nq, int nv, int nbody, int n
   p.fbias = o; o += nv;
   p.factuator = o; o += nv;
   p.x = o; o += nv;
-  p.L = o; o += nC;
-  p.dinv = o; o += nv;
   p.total = ((o + 3) / 4) * 4 + 1;
   return p;
 }
@@ -423,14 +432,16 @@ __global__ void __launch_bounds__(256) k_fwd_vel(MjhModel m, MjhData d, int firs
         *cdof_dot = S + lay.cdof_dot, *cacc = S + lay.cacc, *cfrc = S + lay.cfrc, *cfi = S + lay.cfi, *uforce = S + lay.uforce,
         *fspring = S + lay.fspring,
         *fdamper = S + lay.fdamper, *fgrav = S + lay.fgrav, *fpassive = S + lay.fpassive, *fbias = S + lay.fbias,
-        *factuator = S + lay.factuator, *x = S + lay.x, *L = S + lay.L, *dinv = S + lay.dinv;
+        *factuator = S + lay.factuator, *x = S + lay.x;
   const int dsbl = m.disableflags;
+  PhaseClock pc(4, lig);
 
   gcopy<G>(qpos, d.qpos + (size_t)w * nq, nq, lig);
   gcopy<G>(qvel, d.qvel + (size_t)w * nv, nv, lig);
   gcopy<G>(cdof, d.cdof + (size_t)w * 6 * nv, 6 * nv, lig);
   if (first <= VEL_RNE && last >= VEL_RNE) gcopy<G>(cinert, d.cinert + (size_t)w * 10 * nbody, 10 * nbody, lig);
   gsync();
+  pc.mark(0);
 
   // ---- com_vel (smooth.py:2179-2258) + actuator_velocity (forward.py:680-702) ---------------------------
   if (first <= VEL_COMVEL) {
@@ -478,6 +489,7 @@ __global__ void __launch_bounds__(256) k_fwd_vel(MjhModel m, MjhData d, int firs
     gcopy<G>(d.cvel + (size_t)w * 6 * nbody, cvel, 6 * nbody, lig);
     gcopy<G>(d.cdof_dot + (size_t)w * 6 * nv, cdof_dot, 6 * nv, lig);
   }
+  pc.mark(1);
   if (last < VEL_PASSIVE) return;
 
   // ---- passive (passive.py:74-210 spring/damper, 275-306 gravcomp, 631-668 sum) --------------------------
@@ -530,6 +542,7 @@ __global__ void __launch_bounds__(256) k_fwd_vel(MjhModel m, MjhData d, int firs
     gcopy<G>(d.qfrc_gravcomp + (size_t)w * nv, fgrav, nv, lig);
     gcopy<G>(d.qfrc_passive + (size_t)w * nv, fpassive, nv, lig);
   }
+  pc.mark(2);
   if (last < VEL_RNE) return;
 
   // ---- rne (smooth.py:1353-1515) -------------------------------------------------------------------------
@@ -589,6 +602,7 @@ __global__ void __launch_bounds__(256) k_fwd_vel(MjhModel m, MjhData d, int firs
     gcopy<G>(d.cacc + (size_t)w * 6 * nbody, cacc, 6 * nbody, lig);
     gcopy<G>(d.qfrc_bias + (size_t)w * nv, fbias, nv, lig);
   }
+  pc.mark(3);
   if (last < VEL_ACTUATION) return;
 
   // ---- fwd_actuation (forward.py:756-1149; NONE/INTEGRATOR/FILTER dyn, FIXED/AFFINE gain, NONE/AFFINE bias) --
@@ -642,6 +656,7 @@ __global__ void __launch_bounds__(256) k_fwd_vel(MjhModel m, MjhData d, int firs
     gsync();
     gcopy<G>(d.qfrc_actuator + (size_t)w * nv, factuator, nv, lig);
   }
+  pc.mark(4);
   if (last < VEL_ACCEL) return;
 
   // ---- fwd_acceleration (forward.py:1255-1324): qfrc_smooth, factor(M), qacc_smooth = M^-1 qfrc_smooth -------
@@ -651,7 +666,6 @@ __global__ void __launch_bounds__(256) k_fwd_vel(MjhModel m, MjhData d, int firs
       gcopy<G>(fbias, d.qfrc_bias + (size_t)w * nv, nv, lig);
       gcopy<G>(factuator, d.qfrc_actuator + (size_t)w * nv, nv, lig);
     }
-    gcopy<G>(L, d.M + (size_t)w * nC, nC, lig);
     gsync();
     for (int i = lig; i < nv; i += G) x[i] = fpassive[i] - fbias[i] + factuator[i] + d.qfrc_applied[(size_t)w * nv + i];
     // xfrc_applied (support.py:259-322): wrench (force, torque) at xipos of each body
@@ -667,11 +681,45 @@ __global__ void __launch_bounds__(256) k_fwd_vel(MjhModel m, MjhData d, int firs
       }
     }
     gsync();
+    // qLD / qLDiagInv / qacc_smooth are produced by k_factor_smooth beside the solver (k_solve takes M^-1 qfrc_smooth
+    // from its own register-resident factor), so the L'DL latency chain is off the critical path of the step
     gcopy<G>(d.qfrc_smooth + (size_t)w * nv, x, nv, lig);
-    factor_ld<G>(ms, L, dinv, nv, lig);
-    solve_ld<G>(m, ms, L, dinv, x, nv, lig);
-    gcopy<G>(d.qacc_smooth + (size_t)w * nv, x, nv, lig);
-    gcopy<G>(d.qLD + (size_t)w * nC, L, nC, lig);
-    gcopy<G>(d.qLDiagInv + (size_t)w * nv, dinv, nv, lig);
+    pc.mark(5);
   }
+}
+
+// L'DL factor of M and (optionally) qacc_smooth = M^-1 qfrc_smooth: the public outputs of fwd_acceleration
+// (forward.py:1255-1324, smooth.py:1183-1232 factor_m, 3187 solve_LD).
+struct FacLayout {
+  int L, dinv, x, total;
+};
+__host__ __device__ inline FacLayout fac_layout(int nv, int nC) {
+  FacLayout p;
+  int o = 0;
+  p.L = o; o += nC;
+  p.dinv = o; o += nv;
+  p.x = o; o += nv;
+  p.total = ((o + 3) / 4) * 4 + 1;
+  return p;
+}
+template <int G>
+__global__ void __launch_bounds__(256) k_factor_smooth(MjhModel m, MjhData d, int write_qacc) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int nv = m.nv, nC = m.nC;
+  const FacLayout lay = fac_layout(nv, nC);
+  int* shi = reinterpret_cast<int*>(smem);
+  const MStruct ms = load_mstruct<G>(m, shi);
+  const int lig = threadIdx.x & (G - 1), gib = threadIdx.x / G;
+  const int w = blockIdx.x * (blockDim.x / G) + gib;
+  if (w >= d.nworld) return;
+  float* S = smem + mstruct_ints(nv, nC) + (size_t)gib * lay.total;
+  float *L = S + lay.L, *dinv = S + lay.dinv, *x = S + lay.x;
+  gcopy<G>(L, d.M + (size_t)w * nC, nC, lig);
+  if (write_qacc) gcopy<G>(x, d.qfrc_smooth + (size_t)w * nv, nv, lig);
+  gsync();
+  factor_ld<G>(ms, L, dinv, nv, lig);
+  if (write_qacc) solve_ld<G>(m, ms, L, dinv, x, nv, lig);
+  gcopy<G>(d.qLD + (size_t)w * nC, L, nC, lig);
+  gcopy<G>(d.qLDiagInv + (size_t)w * nv, dinv, nv, lig);
+  if (write_qacc) gcopy<G>(d.qacc_smooth + (size_t)w * nv, x, nv, lig);
 }

@@ -232,6 +232,7 @@ __global__ void __launch_bounds__(256) k_solve(MjhModel m, MjhData d) {
   const bool active = lig < nv;
   const int ligr = lig < NVR ? lig : NVR - 1;  // clamped row index for lanes beyond the matrix
 
+  PhaseClock pc(5, lig);
   // ---- M row of this lane into registers (dense staging in the J region) ----------------------------------
   float mrow[NVR];
   {
@@ -259,13 +260,10 @@ __global__ void __launch_bounds__(256) k_solve(MjhModel m, MjhData d) {
     gsync();
   }
 
+  pc.mark(0);
   // ---- lane-owned dof scalars (element `lig` of each nv-vector lives in a register) ------------------------
   const bool warm = !(m.disableflags & DSBL_WARMSTART);
-  float q = 0.0f, fs = 0.0f;
-  if (active) {
-    q = nefc > 0 && warm ? d.qacc_warmstart[vo + lig] : d.qacc_smooth[vo + lig];
-    fs = d.qfrc_smooth[vo + lig];
-  }
+  const float fs = active ? d.qfrc_smooth[vo + lig] : 0.0f;
   // lane i: sum_c M[i][c] vec[c], vec broadcast from an LDS line
   auto mul_row = [&](const float (&row)[NVR], const float* vec) __attribute__((always_inline)) {
     float s0 = 0.0f, s1 = 0.0f;
@@ -277,6 +275,29 @@ __global__ void __launch_bounds__(256) k_solve(MjhModel m, MjhData d) {
     }
     return active ? s0 + s1 : 0.0f;
   };
+  // ---- qacc_smooth = M^-1 qfrc_smooth from the register-resident factor (the L'DL factor qLD is produced beside
+  // the solver by k_factor_smooth).  CG: rows of M^-1, computed once per solve and reused as the preconditioner; it
+  // also writes the public qacc_smooth.  Newton: only a cold start / an unconstrained world needs it (Cholesky of M).
+  float h[NVR], lt[NVR];  // Newton: H row / L row and L column; CG: h = row of M^-1
+  float qs = 0.0f;
+  if (!NEWTON) {
+    invert_rows<NVR>(mrow, h, col, lig);
+    bgrad[lig] = fs;
+    gsync();
+    qs = mul_row(h, bgrad);
+    if (active) d.qacc_smooth[vo + lig] = qs;
+    gsync();
+  } else if (nefc == 0 || !warm) {
+#pragma unroll
+    for (int c = 0; c < NVR; ++c) h[c] = mrow[c];
+    float rdiag0;
+    chol_factor_rows<NVR, JS>(h, lt, rdiag0, col, lig);
+    qs = chol_solve_rows<NVR>(h, lt, rdiag0, fs);
+    if (!active) qs = 0.0f;
+  }
+  float q = 0.0f;
+  if (active) q = nefc > 0 && warm ? d.qacc_warmstart[vo + lig] : qs;
+  pc.mark(1);
   bsearch[lig] = q;
   gsync();
   float Ma = mul_row(mrow, bsearch);
@@ -291,9 +312,6 @@ __global__ void __launch_bounds__(256) k_solve(MjhModel m, MjhData d) {
     return;
   }
 
-  // ---- CG: rows of M^-1 in registers, once per solve; Newton: per-iteration Cholesky of H ------------------
-  float h[NVR], lt[NVR];  // Newton: H row / L row and L column; CG: h = row of M^-1
-  if (!NEWTON) invert_rows<NVR>(mrow, h, col, lig);
 
   // ---- J into LDS; this lane's rows (D, aref, frictionloss, Jaref) into registers ---------------------------
   const int nefc4 = (nefc + 3) & ~3;
@@ -337,6 +355,7 @@ __global__ void __launch_bounds__(256) k_solve(MjhModel m, MjhData d) {
   for (int k = 0; k < NR; ++k) rja[k] = rhas[k] ? j_dot(bsearch, lig + 32 * k) - d.efc_aref[eo + lig + 32 * k] : 0.0f;
   gsync();
 
+  pc.mark(2);
   const float tolerance = bf(m.opt_tolerance, m.opt_tolerance_nb, w, 1)[0];
   const float ls_tolerance = bf(m.opt_ls_tolerance, m.opt_ls_tolerance_nb, w, 1)[0];
   const float meaninertia = bf(m.stat_meaninertia, m.stat_meaninertia_nb, w, 1)[0];
@@ -393,6 +412,7 @@ __global__ void __launch_bounds__(256) k_solve(MjhModel m, MjhData d) {
     grad_dot = gsum32(g * g);
     // improvement / gradient tests need no search direction: a world that passes them skips the H rebuild + Cholesky
     const bool done_early = niter > 0 && ((improvement * rscale < tolerance) || (sqrtf(grad_dot) * rscale < tolerance));
+    pc.mark(3);
     if (NEWTON && done_early) break;
     if (NEWTON) {
       // H row = M row + sum_r (D_r [state_r == QUADRATIC]) J[r][i] J[r][:]   (JTDAJ, solver.py:2365-2440)
@@ -422,6 +442,7 @@ __global__ void __launch_bounds__(256) k_solve(MjhModel m, MjhData d) {
       gsync();
       Mg = mul_row(h, bgrad);  // Mgrad = M^-1 grad
     }
+    pc.mark(4);
     if (niter == 0) {
       if (!NEWTON) {  // CG: search = -Mgrad (solver.py:1663-1695)
         srch = -Mg;
@@ -460,6 +481,7 @@ __global__ void __launch_bounds__(256) k_solve(MjhModel m, MjhData d) {
     const float mvi = mul_row(mrow, bsearch);
 #pragma unroll
     for (int k = 0; k < NR; ++k) rjv[k] = rhas[k] ? j_dot(bsearch, lig + 32 * k) : 0.0f;
+    pc.mark(5);
     // ---- line search (solver.py:835-1347); rows and all sums stay in registers ----------------------------------
     const float gauss1 = gsum32(srch * (Ma - fs));
     const float gauss2 = gsum32(0.5f * srch * mvi);
@@ -524,13 +546,16 @@ __global__ void __launch_bounds__(256) k_solve(MjhModel m, MjhData d) {
       }
     }
     if (!ls_converged) ovf |= OVF_LS_ITERATIONS;
+    pc.mark(6);
     // ---- move along the ray (registers only) ---------------------------------------------------------------
     q += alpha * srch;
     Ma += alpha * mvi;
 #pragma unroll
     for (int k = 0; k < NR; ++k) rja[k] += alpha * rjv[k];
     ++niter;
+    pc.mark(7);
   }
+  pc.mark(8);
 
   // ---- outputs ---------------------------------------------------------------------------------------------
   if (active) {
@@ -548,4 +573,5 @@ __global__ void __launch_bounds__(256) k_solve(MjhModel m, MjhData d) {
     d.solver_niter[w] = niter;
     if (ovf) atomicOr(d.overflow + w, ovf);
   }
+  pc.mark(9);
 }

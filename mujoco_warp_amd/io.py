@@ -283,6 +283,11 @@ def c_model(m: types.Model):
   return c
 
 
+def contact_cap(nconmax: int) -> int:
+  """Per-world contact capacity of the collision -> constraint hand-off buffer (twice the average budget)."""
+  return int(min(max(2 * nconmax, 16), 256))
+
+
 def _data_shapes(m, nworld, nconmax, njmax, naconmax):
   njmax_pad, nv_pad = _get_padded_sizes(m.nv, njmax)
   nb, nv, nq, nu, na, ng, nj, ns, nC = m.nbody, m.nv, m.nq, m.nu, m.na, m.ngeom, m.njnt, m.nsite, m.nC
@@ -306,6 +311,7 @@ def _data_shapes(m, nworld, nconmax, njmax, naconmax):
     efc_type=(W, njmax), efc_id=(W, njmax), efc_state=(W, njmax), efc_J=(W, njmax_pad, nv_pad), efc_pos=(W, njmax),
     efc_margin=(W, njmax), efc_D=(W, njmax), efc_vel=(W, njmax), efc_aref=(W, njmax), efc_frictionloss=(W, njmax),
     efc_force=(W, njmax), ws_ncon=(W,), ws_conadr=(W,), ws_ncollision=(W,), ws_order=(W,),
+    ws_contact=(W, contact_cap(nconmax), 32),
   )
   return sh, njmax_pad, nv_pad
 
@@ -338,6 +344,8 @@ def _alloc_data(m: types.Model, nworld, nconmax, njmax, naconmax):
   d.ws_order.assign(np.arange(nworld, dtype=np.int32))
   d.nmaxpyramid = m.nmaxpyramid
   d.world_offset = 0
+  d.concap = contact_cap(nconmax)
+  d.reserved0 = 0
   d.njmax_nnz = njmax * m.nv
   d._c = None
   d._dirty = True

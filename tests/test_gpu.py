@@ -345,3 +345,37 @@ def test_timed_steps_reports_kernel_classes():
   assert ms > 0 and len(pk) == len(mjw.KERNEL_NAMES)
   assert all(pk[mjw.KERNEL_NAMES.index(k)] > 0 for k in ("fwd_pos", "collision", "make_constraint", "fwd_vel", "solve", "integrate"))
   np.testing.assert_allclose(d.time.numpy(), 5 * 0.005, rtol=1e-5)
+
+
+def test_long_rollout_contact_records_stay_valid():
+  """300 noisy steps at BASELINE size: every published contact record stays well-formed and agrees with the
+  per-world bookkeeping (catches count/publish disagreement between the two narrowphase passes), staged and fused."""
+  mjm = mjw.mjcf.load_xml(conftest.HUMANOID_XML)
+  mjm.opt.solver = mjw.SolverType.CG
+  m = mjw.put_model(mjm)
+  nworld = 8192
+  d = mjw.make_data(mjm, nworld=nworld, nconmax=24, njmax=64)
+  mjw.reset_data_keyframe(m, d, 0)
+  for chunk in range(6):
+    mjw.timed_steps(m, d, 50, step0=50 * chunk)
+    # one staged step (separate launches, serial) on top of the fused ones
+    mjw.kinematics(m, d); mjw.com_pos(m, d); mjw.crb(m, d); mjw.factor_m(m, d)
+    mjw.collision(m, d)
+    mjw.make_constraint(m, d)
+    torch.cuda.synchronize()
+    n = int(d.nacon.numpy()[0])
+    ncon, adr = d.ws_ncon.numpy(), d.ws_conadr.numpy()
+    assert n == int(ncon.sum()) <= d.naconmax
+    wid = d.contact.worldid.numpy()[:n]
+    assert (np.bincount(wid, minlength=nworld) == ncon).all()
+    dim = d.contact.dim.numpy()[:n]
+    assert np.isin(dim, (1, 3, 4, 6)).all()
+    geom = d.contact.geom.numpy()[:n]
+    assert ((geom >= 0) & (geom < mjm.ngeom)).all() and (geom[:, 0] != geom[:, 1]).all()
+    dist = d.contact.dist.numpy()[:n]
+    assert np.isfinite(dist).all() and (np.abs(dist) < 1.0).all()  # no placeholder (inactive filler) records
+    frame = d.contact.frame.numpy()[:n].reshape(n, 3, 3)
+    np.testing.assert_allclose(np.einsum("nij,nkj->nik", frame, frame), np.broadcast_to(np.eye(3), (n, 3, 3)), atol=1e-4)
+    nefc = d.nefc.numpy()
+    assert (nefc >= 0).all() and (nefc <= 10 * 24 + 64).all()
+    assert np.isfinite(d.qpos.numpy()).all()

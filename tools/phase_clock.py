@@ -1,0 +1,68 @@
+"""In-kernel phase timing: where does a world's time go inside each kernel at full occupancy?
+
+Builds libmjhip_clk.so with -DMJH_PHASE_CLOCK (lane 0 of every world adds shader-clock ticks between phase marks to a
+device table), runs N humanoid steps and prints each phase's share of its kernel and the absolute ticks per world-step.
+Run on the GPU box:  python tools/phase_clock.py [--solver cg|newton] [--build-only]
+"""
+import argparse, ctypes, os, subprocess, sys
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+LIB = os.path.join(ROOT, "mujoco_warp_amd", "libmjhip_clk.so")
+
+PHASES = {
+  1: ("fwd_pos", ["kinematics", "com_pos", "crb", "factor"]),
+  2: ("collision", ["stage geoms", "broadphase", "narrow pass1", "window init", "pass2 stage", "write records"]),
+  3: ("make_constraint", ["load", "friction+limits", "J rows fl", "contact list", "contact J", "contact rows"]),
+  4: ("fwd_vel", ["load", "com_vel", "passive", "rne", "actuation", "qfrc_smooth"]),
+  5: ("solve", ["M rows", "Ma+Minv", "J+rows", "it: update+JTf+grad", "it: Mgrad/chol", "it: conv+mv+jv", "it: linesearch",
+                "it: move", "exit", "store"]),
+}
+
+
+def build():
+  src = os.path.join(ROOT, "mujoco_warp_amd", "csrc", "mjhip.hip")
+  subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
+                         "-DMJH_PHASE_CLOCK", "-o", LIB, src])
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument("--solver", default="cg")
+  ap.add_argument("--nworld", type=int, default=8192)
+  ap.add_argument("--steps", type=int, default=50)
+  ap.add_argument("--build-only", action="store_true")
+  args = ap.parse_args()
+  if args.build_only or not os.path.exists(LIB):
+    build()
+    if args.build_only:
+      return
+  os.environ["MJH_LIB"] = LIB
+  import mujoco_warp_amd as mjw
+  from mujoco_warp_amd import _abi
+
+  mjm = mjw.mjcf.load_xml(os.path.join(ROOT, "benchmarks", "humanoid", "humanoid.xml"))
+  mjw.override_model(mjm, [f"opt.solver={args.solver}"])
+  m = mjw.put_model(mjm)
+  mjd = mjw.MjData(mjm)
+  mjw.mj_resetDataKeyframe(mjm, mjd, 0)
+  d = mjw.put_data(mjm, mjd, nworld=args.nworld, nconmax=24, njmax=64)
+  mjw.timed_steps(m, d, 100, step0=0)  # warm-up into the steady contact regime
+  L = _abi.lib()
+  L.mjh_debug_phase_ticks.argtypes = [ctypes.c_void_p, ctypes.c_int]
+  L.mjh_debug_phase_ticks(None, 1)
+  ms, _ = mjw.timed_steps(m, d, args.steps, step0=100)
+  buf = np.zeros((64, 8, 16), dtype=np.uint64)
+  L.mjh_debug_phase_ticks(buf.ctypes.data, 0)
+  print(f"{args.solver}: {ms / args.steps * 1e3:.1f} us/step (instrumented build)")
+  per = buf.astype(np.float64).sum(axis=0) / (args.steps * args.nworld)
+  for k, (name, phases) in PHASES.items():
+    tot = per[k].sum()
+    print(f"{name}: {tot:.0f} ticks per world-step")
+    for i, ph in enumerate(phases):
+      print(f"    {ph:24s} {per[k, i]:9.0f}  {100 * per[k, i] / max(tot, 1):5.1f}%")
+
+
+if __name__ == "__main__":
+  main()
