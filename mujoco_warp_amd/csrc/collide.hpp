@@ -252,8 +252,8 @@ DEV PairParams contact_params(const MjhModel& m, int w, int g1, int g2) {
 //   0 dist | 1-3 pos | 4-12 frame | 13 includemargin | 14-16 friction (slide, spin, roll) | 17-18 solref |
 //   19-23 solimp | 24 condim | 25-26 geoms | 27 collider contact id | 28 first efc row or -1 | 29 number of rows
 // (28-29 are filled by k_make_constraint).  k_collision hands the contacts of a world to k_make_constraint through
-// d.ws_contact[w]; the public, compact contact_* arrays are produced from the same records by k_contact_scan +
-// k_publish_contacts, which run beside the solver.  The reference reserves public slots with one global atomic per
+// d.ws_contact[w]; the public, compact contact_* arrays are produced from the same records by publish_body
+// (appended to the integrator launch or run as k_publish_contacts).  The reference reserves public slots with one global atomic per
 // contact (collision_core.py write_contact); on MI355X one same-address device atomic per WORLD already cost 25-50 us
 // per launch (they resolve at the memory side, ~6 ns each, and every later load of the wave waits behind them).
 #define CON_WINDOW 16
@@ -267,13 +267,12 @@ __host__ __device__ inline int collide_lds_words(int ngeom, int npair) {
 }
 
 template <int G>
-__global__ void __launch_bounds__(256) k_collision(MjhModel m, MjhData d) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const Blk& b, int stride_words = 0) {
   const int lig = threadIdx.x & (G - 1), gib = threadIdx.x / G;
-  const int w = blockIdx.x * (blockDim.x / G) + gib;
-  if (w >= d.nworld) return;
+  const int w = b.w0 + gib;
+  if ((int)threadIdx.x >= b.nthreads || w >= d.nworld) return;
   const int npair = m.npair, ng = m.ngeom, ncap = d.concap;
-  float* S = smem + (size_t)gib * collide_lds_words(ng, npair);
+  float* S = smem + (size_t)gib * (stride_words ? stride_words : collide_lds_words(ng, npair));
   float* gxpos = S;
   float* gxmat = S + 3 * ng;
   int* cand = reinterpret_cast<int*>(S + 12 * ng);
@@ -434,49 +433,60 @@ __global__ void __launch_bounds__(256) k_collision(MjhModel m, MjhData d) {
   }
 }
 
-// ---- publication of the compact public contact arrays (off the critical path) ---------------------------------
-// k_contact_scan: one workgroup; exclusive prefix of ws_ncon -> ws_conadr, totals -> nacon / ncollision.
-__global__ void __launch_bounds__(1024) k_contact_scan(MjhData d) {
-  __shared__ int part[1024];
-  __shared__ int part2[1024];
-  const int t = threadIdx.x, n = d.nworld;
-  const int per = (n + 1023) / 1024;
-  const int lo = min(t * per, n), hi = min(lo + per, n);
-  int s = 0, s2 = 0;
-  for (int w = lo; w < hi; ++w) {
-    s += d.ws_ncon[w];
-    s2 += d.ws_ncollision[w];
-  }
-  part[t] = s;
-  part2[t] = s2;
-  __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
-    const int v = t >= off ? part[t - off] : 0, v2 = t >= off ? part2[t - off] : 0;
-    __syncthreads();
-    part[t] += v;
-    part2[t] += v2;
-    __syncthreads();
-  }
-  int run = part[t] - s;
-  for (int w = lo; w < hi; ++w) {
-    d.ws_conadr[w] = run;
-    run += d.ws_ncon[w];
-  }
-  if (t == 1023) {
-    d.nacon[0] = part[t];
-    d.ncollision[0] = part2[t];
-  }
+template <int G>
+__global__ void __launch_bounds__(256) k_collision(MjhModel m, MjhData d) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  collision_body<G>(m, d, smem, blk_of_launch<G>());
 }
 
-// k_publish_contacts: one group per world copies its records to the public SoA arrays (consecutive addresses per
-// array), fills contact.efc_address and the contact rows of efc.id.  Worlds are published in world order, so the
-// public arrays are deterministic (the reference's order depends on atomic arrival).
+// ---- publication of the compact public contact arrays (off the critical path) ---------------------------------
+// publish_body: one group per world copies its records to the public SoA arrays (consecutive addresses per array),
+// fills contact.efc_address and the contact rows of efc.id.  Worlds are published in world order, so the public
+// arrays are deterministic (the reference's order depends on atomic arrival).
+// self_prefix: the workgroup first sums ws_ncon over all earlier worlds itself (the counts are L2-resident: 32 KB at
+// 8192 worlds), so that no scan kernel has to run before it; the workgroup of the last world also writes the totals.
+// `sh` needs 64 ints of LDS.
 template <int G>
-__global__ void __launch_bounds__(256) k_publish_contacts(MjhData d) {
+DEV void publish_body(const MjhData& d, int self_prefix, int* sh, const Blk& b) {
+  if ((int)threadIdx.x >= b.nthreads) return;
   const int lig = threadIdx.x & (G - 1), gib = threadIdx.x / G;
-  const int w = blockIdx.x * (blockDim.x / G) + gib;
+  const int w = b.w0 + gib;
+  int adr_self = 0;
+  if (self_prefix) {
+    const int t = threadIdx.x, nwave = (b.nthreads + 63) / 64;
+    const bool last = b.w0 + b.nw >= d.nworld;
+    int s = 0, s2 = 0;
+    for (int i = t; i < b.w0; i += b.nthreads) s += d.ws_ncon[i];
+    if (last)
+      for (int i = t; i < d.nworld; i += b.nthreads) s2 += d.ws_ncollision[i];
+    for (int off = 32; off > 0; off >>= 1) {
+      s += __shfl_xor(s, off, 64);
+      s2 += __shfl_xor(s2, off, 64);
+    }
+    if ((t & 63) == 0) {
+      sh[t >> 6] = s;
+      sh[16 + (t >> 6)] = s2;
+    }
+    __syncthreads();
+    int base = 0, tot2 = 0;
+    for (int k = 0; k < nwave; ++k) {
+      base += sh[k];
+      tot2 += sh[16 + k];
+    }
+    if (w < d.nworld) {
+      // exclusive prefix inside the workgroup: worlds of a workgroup are consecutive
+      int adr = base;
+      for (int i = b.w0; i < w; ++i) adr += d.ws_ncon[i];
+      adr_self = adr;
+      if (lig == 0) d.ws_conadr[w] = adr;
+      if (last && w == d.nworld - 1 && lig == 0) {
+        d.nacon[0] = adr + d.ws_ncon[w];
+        d.ncollision[0] = tot2;
+      }
+    }
+  }
   if (w >= d.nworld) return;
-  const int ncon = d.ws_ncon[w], adr = d.ws_conadr[w], njmax = d.njmax, npyr = d.nmaxpyramid;
+  const int ncon = d.ws_ncon[w], adr = self_prefix ? adr_self : d.ws_conadr[w], njmax = d.njmax, npyr = d.nmaxpyramid;
   int n = ncon;
   if (adr + n > d.naconmax) n = max(0, d.naconmax - adr);
   if (n < ncon && lig == 0) atomicOr(d.overflow + w, OVF_NARROWPHASE);
@@ -512,4 +522,10 @@ __global__ void __launch_bounds__(256) k_publish_contacts(MjhData d) {
     const int rbase = reci[c * CON_STRIDE + 28], ndim = reci[c * CON_STRIDE + 29];
     d.contact_efc_address[npyr * o0 + idx] = (rbase >= 0 && k < ndim && rbase + k < njmax) ? rbase + k : -1;
   }
+}
+
+template <int G>
+__global__ void __launch_bounds__(256) k_publish_contacts(MjhData d, int self_prefix) {
+  __shared__ int sh[64];
+  publish_body<G>(d, self_prefix, sh, blk_of_launch<G>());
 }

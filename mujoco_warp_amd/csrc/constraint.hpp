@@ -71,14 +71,13 @@ __host__ __device__ inline ConLayout con_layout(int nv, int njmax, int ncap, int
 }
 
 template <int G>
-__global__ void __launch_bounds__(256) k_make_constraint(MjhModel m, MjhData d) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+DEV void make_constraint_body(const MjhModel& m, const MjhData& d, float* smem, const Blk& b, int stride_words = 0) {
   const int lig = threadIdx.x & (G - 1), gib = threadIdx.x / G;
-  const int w = blockIdx.x * (blockDim.x / G) + gib;
-  if (w >= d.nworld) return;
+  const int w = b.w0 + gib;
+  if ((int)threadIdx.x >= b.nthreads || w >= d.nworld) return;
   const int nv = m.nv, njnt = m.njnt, nbody = m.nbody, njmax = d.njmax, nvp = d.nv_pad, ncap = d.concap;
   const ConLayout lay = con_layout(nv, njmax, ncap, nbody, m.ngeom);
-  float* S = smem + (size_t)gib * lay.total;
+  float* S = smem + (size_t)gib * (stride_words ? stride_words : lay.total);
   float *cdof = S + lay.cdof, *qvel = S + lay.qvel, *rowvel = S + lay.rowvel, *rowval = S + lay.rowval;
   int *rowdof = reinterpret_cast<int*>(S + lay.rowdof), *row2con = reinterpret_cast<int*>(S + lay.row2con),
       *clist = reinterpret_cast<int*>(S + lay.clist);
@@ -282,10 +281,11 @@ __global__ void __launch_bounds__(256) k_make_constraint(MjhModel m, MjhData d) 
       const V3 off1 = cpos - ld3(scom + 3 * broot[b1]);
       const V3 off2 = cpos - ld3(scom + 3 * broot[b2]);
       const V3 f0 = ld3(cr + 4), f1 = ld3(cr + 7), f2 = ld3(cr + 10);
-      const float fri[5] = {cr[14], cr[14], cr[15], cr[16], cr[16]};
       const int condim = cri[24];
-      float part[10];
-      for (int k = 0; k < 10; ++k) part[k] = 0.0f;
+      // pyramid rows 2(q-1), 2(q-1)+1 = normal component +- mu_q * component q (q = 1..condim-1): tangent 1, tangent 2,
+      // spin, roll 1, roll 2.  All indexing below is static (fully unrolled), so nothing lives in scratch or movrel.
+      const float mu[6] = {0.0f, cr[14], cr[14], cr[15], cr[16], cr[16]};
+      float acc[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
       for (int i0 = 0; i0 < nvp; i0 += G) {
         const int i = i0 + lig;
         V3 jp = V3{0, 0, 0}, jr = V3{0, 0, 0};
@@ -303,31 +303,40 @@ __global__ void __launch_bounds__(256) k_make_constraint(MjhModel m, MjhData d) 
           }
         }
         if (i < nvp) {
-          const float j0p = dot(f0, jp);
+          const float comp[6] = {dot(f0, jp), dot(f1, jp), dot(f2, jp), dot(f0, jr), dot(f1, jr), dot(f2, jr)};
           const float qv = i < nv ? qvel[i] : 0.0f;
-          for (int k = 0; k < ndim; ++k) {
-            const int r = rbase + k;
-            if (r >= njmax) break;
-            float val = j0p;
-            if (condim > 1) {
-              const int dimid2 = k / 2 + 1;
-              const float frii = fri[dimid2 - 1] * (1.0f - 2.0f * (float)(k & 1));
-              float ji;
-              if (dimid2 == 1) ji = dot(f1, jp);
-              else if (dimid2 == 2) ji = dot(f2, jp);
-              else if (dimid2 == 3) ji = dot(f0, jr);
-              else if (dimid2 == 4) ji = dot(f1, jr);
-              else ji = dot(f2, jr);
-              val += ji * frii;
+          acc[0] += comp[0] * qv;
+          if (condim == 1) {
+            if (rbase < njmax) J[(size_t)rbase * nvp + i] = comp[0];
+          } else {
+#pragma unroll
+            for (int q = 1; q < 6; ++q) {
+              if (q < condim && 2 * (q - 1) + 1 < ndim) {
+                const int r = rbase + 2 * (q - 1);
+                if (r < njmax) J[(size_t)r * nvp + i] = comp[0] + mu[q] * comp[q];
+                if (r + 1 < njmax) J[(size_t)(r + 1) * nvp + i] = comp[0] - mu[q] * comp[q];
+                acc[q] += comp[q] * qv;
+              }
             }
-            J[(size_t)r * nvp + i] = val;
-            part[k] += val * qv;
           }
         }
       }
-      for (int k = 0; k < ndim; ++k) {
-        const float v = gsum<G>(part[k]);
-        if (lig == 0 && rbase + k < njmax) rowvel[rbase + k] = v;
+      float v[6];
+#pragma unroll
+      for (int q = 0; q < 6; ++q) v[q] = (q == 0 || q < condim) ? gsum<G>(acc[q]) : 0.0f;
+      if (lig == 0) {
+        if (condim == 1) {
+          if (rbase < njmax) rowvel[rbase] = v[0];
+        } else {
+#pragma unroll
+          for (int q = 1; q < 6; ++q) {
+            if (q < condim && 2 * (q - 1) + 1 < ndim) {
+              const int r = rbase + 2 * (q - 1);
+              if (r < njmax) rowvel[r] = v[0] + mu[q] * v[q];
+              if (r + 1 < njmax) rowvel[r + 1] = v[0] - mu[q] * v[q];
+            }
+          }
+        }
       }
     }
     gsync();
@@ -373,4 +382,10 @@ __global__ void __launch_bounds__(256) k_make_constraint(MjhModel m, MjhData d) 
     if (nefc > njmax) atomicOr(d.overflow + w, OVF_NEFC);
   }
   pc.mark(5);
+}
+
+template <int G>
+__global__ void __launch_bounds__(256) k_make_constraint(MjhModel m, MjhData d) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  make_constraint_body<G>(m, d, smem, blk_of_launch<G>());
 }

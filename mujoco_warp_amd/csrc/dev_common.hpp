@@ -208,6 +208,18 @@ DEV void gcopyi(int* dst, const int* src, int n, int lig) {
   for (int i = lig; i < n; i += G) dst[i] = src[i];
 }
 
+// The worlds handled by one workgroup.  Plain kernels derive it from blockIdx (blk_of_launch); composite launches
+// (mjhip.hip: k_mid, k_solve_plus, k_integrate_plus) give every workgroup a role and a world range of its own.
+struct Blk {
+  int w0;        // first world (or first schedule slot) of this workgroup
+  int nw;        // worlds in this workgroup
+  int nthreads;  // = nw * G: threads that take part (block-wide loops and barriers); the rest return at once
+};
+template <int G>
+DEV Blk blk_of_launch() {
+  return Blk{(int)(blockIdx.x * (blockDim.x / G)), (int)(blockDim.x / G), (int)blockDim.x};
+}
+
 // Phase clock (profiling builds only: hipcc -DMJH_PHASE_CLOCK, tools/phase_clock.py).  Lane 0 of every group adds the
 // shader-clock ticks between consecutive marks to g_phase_ticks[kernel][phase]; the product build compiles it away.
 #ifdef MJH_PHASE_CLOCK

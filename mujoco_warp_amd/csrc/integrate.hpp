@@ -24,14 +24,14 @@ __host__ __device__ inline IntLayout int_layout(int nv, int nC) {
 
 // mode: 0 = Euler (forward.py:387), 1 = implicitfast (forward.py:578)
 template <int G>
-__global__ void __launch_bounds__(256) k_integrate(MjhModel m, MjhData d, int mode) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+DEV void integrate_body(const MjhModel& m, const MjhData& d, int mode, float* smem, const Blk& b) {
+  if ((int)threadIdx.x >= b.nthreads) return;
   const int nq = m.nq, nv = m.nv, nC = m.nC, nu = m.nu, njnt = m.njnt;
   const IntLayout lay = int_layout(nv, nC);
   int* shi = reinterpret_cast<int*>(smem);
-  const MStruct ms = load_mstruct<G>(m, shi);
+  const MStruct ms = load_mstruct<G>(m, shi, b.nthreads);
   const int lig = threadIdx.x & (G - 1), gib = threadIdx.x / G;
-  const int w = blockIdx.x * (blockDim.x / G) + gib;
+  const int w = b.w0 + gib;
   if (w >= d.nworld) return;
   float* S = smem + mstruct_ints(nv, nC) + (size_t)gib * lay.total;
   float *L = S + lay.L, *dinv = S + lay.dinv, *x = S + lay.x, *qvel = S + lay.qvel;
@@ -181,7 +181,7 @@ __global__ void __launch_bounds__(256) k_solve_m(MjhModel m, MjhData d, float* x
   const int nv = m.nv, nC = m.nC;
   const IntLayout lay = int_layout(nv, nC);
   int* shi = reinterpret_cast<int*>(smem);
-  const MStruct ms = load_mstruct<G>(m, shi);
+  const MStruct ms = load_mstruct<G>(m, shi, blockDim.x);
   const int lig = threadIdx.x & (G - 1), gib = threadIdx.x / G;
   const int w = blockIdx.x * (blockDim.x / G) + gib;
   if (w >= d.nworld) return;
@@ -207,13 +207,14 @@ __global__ void __launch_bounds__(256) k_solve_m(MjhModel m, MjhData d, float* x
 // Iteration counts are strongly correlated from step to step, so (i) the longest solves start first (LPT: no
 // long straggler wave at the tail of k_solve) and (ii) the two worlds sharing a wavefront need a similar number
 // of iterations (a wave runs for max(niter) of its two worlds).  Single workgroup; deterministic (stable sort).
-__global__ void __launch_bounds__(1024) k_schedule_worlds(MjhData d) {
-  __shared__ int hist[128];
-  __shared__ int base[128];
+// `sh` needs 256 ints of LDS; any workgroup size.
+DEV void schedule_body(const MjhData& d, int* sh, int nthreads) {
+  int* hist = sh;
+  int* base = sh + 128;
   const int t = threadIdx.x, n = d.nworld;
-  if (t < 128) hist[t] = 0;
+  for (int i = t; i < 128; i += nthreads) hist[i] = 0;
   __syncthreads();
-  for (int w = t; w < n; w += 1024) atomicAdd(&hist[127 - min(max(d.solver_niter[w], 0), 127)], 1);
+  for (int w = t; w < n; w += nthreads) atomicAdd(&hist[127 - min(max(d.solver_niter[w], 0), 127)], 1);
   __syncthreads();
   if (t == 0) {
     int acc = 0;
@@ -224,8 +225,18 @@ __global__ void __launch_bounds__(1024) k_schedule_worlds(MjhData d) {
   }
   __syncthreads();
   // scatter; the order inside a bucket is arbitrary (it only decides which wavefront hosts a world, never a result)
-  for (int w = t; w < n; w += 1024) {
+  for (int w = t; w < n; w += nthreads) {
     const int b = 127 - min(max(d.solver_niter[w], 0), 127);
     d.ws_order[atomicAdd(&base[b], 1)] = w;
   }
+}
+__global__ void __launch_bounds__(1024) k_schedule_worlds(MjhData d) {
+  __shared__ int sh[256];
+  schedule_body(d, sh, blockDim.x);
+}
+
+template <int G>
+__global__ void __launch_bounds__(256) k_integrate(MjhModel m, MjhData d, int mode) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  integrate_body<G>(m, d, mode, smem, blk_of_launch<G>());
 }

@@ -7,6 +7,7 @@
 // Nothing here allocates or synchronises (hipGraph-capturable); workspace lives in MjhData.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -120,8 +121,7 @@ static int launch_collision(const MjhModel* m, const MjhData* d, hipStream_t s) 
 }
 // compact public contact arrays, contact.efc_address and efc.id of contact rows from the per-world records
 static int launch_publish(const MjhData* d, hipStream_t s) {
-  hipLaunchKernelGGL(k_contact_scan, dim3(1), dim3(1024), 0, s, *d);
-  hipLaunchKernelGGL(k_publish_contacts<G>, dim3((d->nworld + 7) / 8), dim3(256), 0, s, *d);
+  hipLaunchKernelGGL(k_publish_contacts<G>, dim3((d->nworld + 7) / 8), dim3(256), 0, s, *d, 1);
   return MJH_OK;
 }
 static int launch_constraint(const MjhModel* m, const MjhData* d, hipStream_t s) {
@@ -163,11 +163,9 @@ static int launch_solve_n(const MjhModel* m, const MjhData* d, hipStream_t s) {
     default: return launch_solve_t<8, NR, NEWTON>(m, d, s);
   }
 }
+static int solve_supported(const MjhModel* m, const MjhData* d);
 static int launch_solve(const MjhModel* m, const MjhData* d, hipStream_t s) {
-  if (m->cone != 0) return fail(MJH_E_UNSUPPORTED, "elliptic cones are not implemented yet");
-  if (m->nv > 32) return fail(MJH_E_UNSUPPORTED, "nv > 32 needs the sparse/blocked solver path (not implemented yet)");
-  if (m->solver != SOL_NEWTON && m->solver != SOL_CG) return fail(MJH_E_UNSUPPORTED, "solver must be CG or Newton");
-  if (d->njmax > 192) return fail(MJH_E_UNSUPPORTED, "njmax > 192 is not supported by the register-resident solver yet");
+  if (int rc = solve_supported(m, d)) return rc;
   const bool newton = m->solver == SOL_NEWTON;
   // rows per lane (32 lanes per world): 2 covers njmax <= 64 (humanoid, panda), 6 covers njmax <= 192 (G1-class)
   if (d->njmax <= 64) return newton ? launch_solve_n<2, true>(m, d, s) : launch_solve_n<2, false>(m, d, s);
@@ -181,6 +179,142 @@ static int launch_integrate(const MjhModel* m, const MjhData* d, int mode, hipSt
   HIPCHK(set_lds(k_integrate<G>, lds));
   const int wpb = threads / G;
   hipLaunchKernelGGL(k_integrate<G>, dim3((d->nworld + wpb - 1) / wpb), dim3(threads), lds, s, *m, *d, mode);
+  return MJH_OK;
+}
+
+// ---- composite launches of the fused step --------------------------------------------------------------------
+// Cross-stream fork/join costs 5-15 us per hop on the critical path (event record -> barrier packet -> dispatch),
+// while consecutive kernels of one stream start back to back.  The fused step therefore uses ONE stream and gives
+// the workgroups of a launch different roles:
+//   k_mid           : {collision -> make_constraint} workgroups interleaved with fwd_vel workgroups (both only depend
+//                     on k_fwd_pos; both are latency-bound, so they share the CUs)
+//   k_solve_plus    : solver workgroups (longest expected solve first), then factor_smooth workgroups: dispatched last,
+//                     they fill the CUs that the solver's stragglers leave idle
+//   k_fwd_pos_plus  : k_fwd_pos + one workgroup computing the solver schedule from the previous step's solver_niter
+//   k_integrate_plus: integrator workgroups, then publish_contacts workgroups
+template <int G>
+__global__ void __launch_bounds__(256) k_mid(MjhModel m, MjhData d, int ncc, int nvb, int nw_cc, int nw_v, int stride_cc) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const long long n = (long long)ncc + nvb, bi = blockIdx.x;
+  const int cc_before = (int)(bi * ncc / n);                    // evenly interleaved roles
+  const bool is_cc = (int)((bi + 1) * ncc / n) > cc_before;
+  if (is_cc) {
+    const Blk b{cc_before * nw_cc, nw_cc, nw_cc * G};
+    collision_body<G>(m, d, smem, b, stride_cc);
+    __threadfence_block();  // the world's contact records (global) are read back by the same lanes
+    make_constraint_body<G>(m, d, smem, b, stride_cc);
+  } else {
+    const Blk b{((int)bi - cc_before) * nw_v, nw_v, nw_v * G};
+    fwd_vel_body<G>(m, d, VEL_COMVEL, VEL_ACCEL, smem, b);
+  }
+}
+template <int NV4, int NR, bool NEWTON>
+__global__ void __launch_bounds__(256) k_solve_plus(MjhModel m, MjhData d, int nsolve, int write_qacc) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int wpb = blockDim.x / 32;
+  if ((int)blockIdx.x < nsolve) solve_body<NV4, NR, NEWTON>(m, d, smem, Blk{(int)blockIdx.x * wpb, wpb, (int)blockDim.x});
+  else factor_smooth_body<32>(m, d, write_qacc, smem, Blk{((int)blockIdx.x - nsolve) * wpb, wpb, (int)blockDim.x});
+}
+template <int G>
+__global__ void __launch_bounds__(256) k_integrate_plus(MjhModel m, MjhData d, int mode, int nint) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int wpb = blockDim.x / G, bi = blockIdx.x;
+  if (bi < nint) integrate_body<G>(m, d, mode, smem, Blk{bi * wpb, wpb, (int)blockDim.x});
+  else publish_body<G>(d, 1, reinterpret_cast<int*>(smem), Blk{(bi - nint) * wpb, wpb, (int)blockDim.x});
+}
+// k_fwd_pos + one workgroup that sorts the worlds by the PREVIOUS step's solver_niter (the solver schedule of this step)
+template <int G>
+__global__ void __launch_bounds__(256) k_fwd_pos_plus(MjhModel m, MjhData d, int first, int last, int npos) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  if ((int)blockIdx.x < npos) fwd_pos_body<G>(m, d, first, last, smem, blk_of_launch<G>());
+  else schedule_body(d, reinterpret_cast<int*>(smem), blockDim.x);
+}
+
+static int launch_mid(const MjhModel* m, const MjhData* d, hipStream_t s) {
+  const ConLayout cl = con_layout(m->nv, d->njmax, d->concap, m->nbody, m->ngeom);
+  const int stride_cc = std::max(cl.total, collide_lds_words(m->ngeom, m->npair) | 1);
+  const VelLayout vl = vel_layout(m->nq, m->nv, m->nbody, m->nC, m->nu);
+  const size_t ms_bytes = sizeof(int) * mstruct_ints(m->nv, m->nC);
+  // 8 collision+constraint worlds per workgroup; as many fwd_vel worlds as fit in the same LDS footprint
+  int nw_cc = 8;
+  while (nw_cc > 1 && sizeof(float) * stride_cc * nw_cc > (size_t)kLdsPerCU / 2) nw_cc >>= 1;
+  size_t lds = sizeof(float) * stride_cc * nw_cc;
+  int nw_v = (int)((lds > ms_bytes ? lds - ms_bytes : 0) / (sizeof(float) * vl.total));
+  if (nw_v < 1) nw_v = 1;
+  if (nw_v > 8) nw_v = 8;
+  lds = std::max(lds, ms_bytes + sizeof(float) * vl.total * nw_v);
+  if (lds > (size_t)kLdsPerCU) return fail(MJH_E_UNSUPPORTED, "k_mid: model does not fit in LDS");
+  HIPCHK(set_lds(k_mid<G>, lds));
+  const int ncc = (d->nworld + nw_cc - 1) / nw_cc, nvb = (d->nworld + nw_v - 1) / nw_v;
+  hipLaunchKernelGGL(k_mid<G>, dim3(ncc + nvb), dim3(256), lds, s, *m, *d, ncc, nvb, nw_cc, nw_v, stride_cc);
+  return MJH_OK;
+}
+template <int NV4, int NR, bool NEWTON>
+static int launch_solve_plus_t(const MjhModel* m, const MjhData* d, hipStream_t s) {
+  const SolveLayout lay = solve_layout<NV4, NR>(d->njmax);
+  const FacLayout fl = fac_layout(m->nv, m->nC);
+  const size_t ms_bytes = sizeof(int) * mstruct_ints(m->nv, m->nC);
+  size_t lds;
+  int threads = pick_block(ms_bytes, sizeof(float) * lay.total, 32, &lds, true);
+  if (!threads) return fail(MJH_E_UNSUPPORTED, "k_solve: njmax x nv does not fit in LDS");
+  if (const char* e = getenv("MJH_SOLVE_THREADS")) {  // tuning knob (developer only)
+    threads = atoi(e);
+    lds = ms_bytes + sizeof(float) * lay.total * (threads / 32);
+  }
+  const int wpb = threads / 32;
+  lds = std::max(lds, ms_bytes + sizeof(float) * fl.total * wpb);
+  HIPCHK(set_lds(k_solve_plus<NV4, NR, NEWTON>, lds));
+  const int nsolve = (d->nworld + wpb - 1) / wpb;
+  hipLaunchKernelGGL((k_solve_plus<NV4, NR, NEWTON>), dim3(2 * nsolve), dim3(threads), lds, s, *m, *d, nsolve, NEWTON ? 1 : 0);
+  return MJH_OK;
+}
+template <int NR, bool NEWTON>
+static int launch_solve_plus_n(const MjhModel* m, const MjhData* d, hipStream_t s) {
+  switch ((m->nv + 3) / 4) {
+    case 0:
+    case 1: return launch_solve_plus_t<1, NR, NEWTON>(m, d, s);
+    case 2: return launch_solve_plus_t<2, NR, NEWTON>(m, d, s);
+    case 3: return launch_solve_plus_t<3, NR, NEWTON>(m, d, s);
+    case 4: return launch_solve_plus_t<4, NR, NEWTON>(m, d, s);
+    case 5: return launch_solve_plus_t<5, NR, NEWTON>(m, d, s);
+    case 6: return launch_solve_plus_t<6, NR, NEWTON>(m, d, s);
+    case 7: return launch_solve_plus_t<7, NR, NEWTON>(m, d, s);
+    default: return launch_solve_plus_t<8, NR, NEWTON>(m, d, s);
+  }
+}
+static int solve_supported(const MjhModel* m, const MjhData* d) {
+  if (m->cone != 0) return fail(MJH_E_UNSUPPORTED, "elliptic cones are not implemented yet");
+  if (m->nv > 32) return fail(MJH_E_UNSUPPORTED, "nv > 32 needs the sparse/blocked solver path (not implemented yet)");
+  if (m->solver != SOL_NEWTON && m->solver != SOL_CG) return fail(MJH_E_UNSUPPORTED, "solver must be CG or Newton");
+  if (d->njmax > 192) return fail(MJH_E_UNSUPPORTED, "njmax > 192 is not supported by the register-resident solver yet");
+  return MJH_OK;
+}
+static int launch_solve_plus(const MjhModel* m, const MjhData* d, hipStream_t s) {
+  if (int rc = solve_supported(m, d)) return rc;
+  const bool newton = m->solver == SOL_NEWTON;
+  if (d->njmax <= 64) return newton ? launch_solve_plus_n<2, true>(m, d, s) : launch_solve_plus_n<2, false>(m, d, s);
+  return newton ? launch_solve_plus_n<6, true>(m, d, s) : launch_solve_plus_n<6, false>(m, d, s);
+}
+// integrator (optional) + publication of the contact arrays + solver schedule
+static int launch_integrate_plus(const MjhModel* m, const MjhData* d, int mode, bool integrate, hipStream_t s) {
+  const IntLayout lay = int_layout(m->nv, m->nC);
+  const size_t ms_bytes = sizeof(int) * mstruct_ints(m->nv, m->nC);
+  size_t lds = std::max(ms_bytes + sizeof(float) * lay.total * 8, (size_t)2048);
+  if (lds > (size_t)kLdsPerCU) return fail(MJH_E_UNSUPPORTED, "k_integrate: does not fit in LDS");
+  HIPCHK(set_lds(k_integrate_plus<G>, lds));
+  const int nb = (d->nworld + 7) / 8;
+  hipLaunchKernelGGL(k_integrate_plus<G>, dim3((integrate ? nb : 0) + nb), dim3(256), lds, s, *m, *d, mode, integrate ? nb : 0);
+  return MJH_OK;
+}
+static int launch_pos_plus(const MjhModel* m, const MjhData* d, int first, int last, hipStream_t s) {
+  const PosLayout lay = pos_layout(m->nq, m->nv, m->nbody, m->njnt, m->nC);
+  size_t lds;
+  const int threads = pick_block(sizeof(int) * mstruct_ints(m->nv, m->nC), sizeof(float) * lay.total, G, &lds);
+  if (!threads) return fail(MJH_E_UNSUPPORTED, "k_fwd_pos: model does not fit in LDS");
+  lds = std::max(lds, (size_t)1024);
+  HIPCHK(set_lds(k_fwd_pos_plus<G>, lds));
+  const int wpb = threads / G, npos = (d->nworld + wpb - 1) / wpb;
+  hipLaunchKernelGGL(k_fwd_pos_plus<G>, dim3(npos + 1), dim3(threads), lds, s, *m, *d, first, last, npos);
   return MJH_OK;
 }
 
@@ -228,32 +362,6 @@ struct Scope {
 };
 enum { K_NOISE = 0, K_POS = 1, K_COLLISION = 2, K_CONSTRAINT = 3, K_VEL = 4, K_SOLVE = 5, K_INTEGRATE = 6, K_OTHER = 7 };
 
-// one non-blocking side stream + fork/join events per host thread and device (created on first use, never freed)
-struct Side {
-  hipStream_t stream;
-  hipEvent_t fork, join, join2, vel_done;
-};
-static Side* side_stream() {
-  static thread_local Side* per_dev[16] = {nullptr};
-  static const bool disabled = getenv("MJH_NO_OVERLAP") != nullptr;  // developer knob: serialise everything
-  if (disabled) return nullptr;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-  if (!per_dev[dev]) {
-    Side* sd = new Side();
-    if (hipStreamCreateWithFlags(&sd->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&sd->fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&sd->join, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&sd->join2, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&sd->vel_done, hipEventDisableTiming) != hipSuccess) {
-      delete sd;
-      return nullptr;
-    }
-    per_dev[dev] = sd;
-  }
-  return per_dev[dev];
-}
-
 static int run_stage(const MjhModel* m, const MjhData* d, int stage, hipStream_t s) {
   switch (stage) {
     case MJH_STAGE_KINEMATICS: { Scope sc(K_POS); return launch_pos(m, d, POS_KINEMATICS, POS_KINEMATICS, s); }
@@ -286,45 +394,27 @@ static int run_stage(const MjhModel* m, const MjhData* d, int stage, hipStream_t
       return MJH_OK;
     case MJH_STAGE_FORWARD:
     case MJH_STAGE_STEP: {
-      { Scope sc(K_POS); TRY(launch_pos(m, d, POS_KINEMATICS, POS_CRB, s)); }
-      // {collision -> make_constraint} and fwd_vel only depend on fwd_pos and are latency-bound at ~2 waves/SIMD: they run
-      // concurrently (fork/join through events on a side stream; capturable into a hipGraph).  The compaction of the
-      // public contact arrays is needed by nobody inside the step: it stays on the side stream, beside the solver.
-      // The per-kernel instrumentation pass keeps everything serial so that event pairs time one kernel at a time.
-      Side* side = (g_instr && g_instr->on) ? nullptr : side_stream();
-      const int write_qacc = m->solver == SOL_NEWTON ? 1 : 0;  // k_solve<CG> writes qacc_smooth itself
-      if (side) {
-        // fwd_vel (the long pole: one 94 KB block per CU) stays on the caller's stream so that it is dispatched first;
-        // the collision blocks arrive a few microseconds later through the event wait and fill the remaining LDS.
-        // The other way round the collision kernel wins the race, fills every CU and the two kernels serialise
-        // (measured 0.683 vs 0.640 ms/step).
-        HIPCHK(hipEventRecord(side->fork, s));
-        HIPCHK(hipStreamWaitEvent(side->stream, side->fork, 0));
-        TRY(launch_vel(m, d, VEL_COMVEL, VEL_ACCEL, s));
-        HIPCHK(hipEventRecord(side->vel_done, s));
-        TRY(launch_collision(m, d, side->stream));
-        TRY(launch_constraint(m, d, side->stream));
-        HIPCHK(hipEventRecord(side->join, side->stream));
-        // beside the solver: public contact arrays, L'DL factor (+ qacc_smooth when the solver does not write it)
-        TRY(launch_publish(d, side->stream));
-        HIPCHK(hipStreamWaitEvent(side->stream, side->vel_done, 0));
-        TRY(launch_factor_smooth(m, d, write_qacc, side->stream));
-        HIPCHK(hipEventRecord(side->join2, side->stream));
-        HIPCHK(hipStreamWaitEvent(s, side->join, 0));
-      } else {
+      const int mode = m->integrator == INT_IMPLICITFAST ? 1 : 0;
+      static const bool plain = getenv("MJH_PLAIN") != nullptr;  // developer knob: one plain kernel per stage, serial
+      if ((g_instr && g_instr->on) || plain) {
+        // profiling pass: one plain kernel per stage, so that the event pairs time one kernel at a time
+        { Scope sc(K_OTHER); hipLaunchKernelGGL(k_schedule_worlds, dim3(1), dim3(1024), 0, s, *d); }
+        { Scope sc(K_POS); TRY(launch_pos(m, d, POS_KINEMATICS, POS_CRB, s)); }
         { Scope sc(K_COLLISION); TRY(launch_collision(m, d, s)); }
         { Scope sc(K_CONSTRAINT); TRY(launch_constraint(m, d, s)); }
-        { Scope sc(K_OTHER); TRY(launch_publish(d, s)); }
         { Scope sc(K_VEL); TRY(launch_vel(m, d, VEL_COMVEL, VEL_ACCEL, s)); }
-        { Scope sc(K_OTHER); TRY(launch_factor_smooth(m, d, write_qacc, s)); }
+        { Scope sc(K_SOLVE); TRY(launch_solve(m, d, s)); }
+        if (stage == MJH_STAGE_STEP) { Scope sc(K_INTEGRATE); TRY(launch_integrate(m, d, mode, s)); }
+        Scope sc(K_OTHER);
+        TRY(launch_publish(d, s));
+        TRY(launch_factor_smooth(m, d, m->solver == SOL_NEWTON ? 1 : 0, s));
+        return MJH_OK;
       }
-      { Scope sc(K_SOLVE); TRY(launch_solve(m, d, s)); }
-      { Scope sc(K_OTHER); hipLaunchKernelGGL(k_schedule_worlds, dim3(1), dim3(1024), 0, s, *d); }  // solver schedule for the next step
-      if (stage == MJH_STAGE_STEP) {
-        Scope sc(K_INTEGRATE);
-        TRY(launch_integrate(m, d, m->integrator == INT_IMPLICITFAST ? 1 : 0, s));
-      }
-      if (side) HIPCHK(hipStreamWaitEvent(s, side->join2, 0));  // every fork rejoins the caller's stream
+      // fused step: four launches on the caller's stream (see "composite launches" above)
+      TRY(launch_pos_plus(m, d, POS_KINEMATICS, POS_CRB, s));
+      TRY(launch_mid(m, d, s));
+      TRY(launch_solve_plus(m, d, s));
+      TRY(launch_integrate_plus(m, d, mode, stage == MJH_STAGE_STEP, s));
       return MJH_OK;
     }
     default:

@@ -22,17 +22,17 @@ struct MStruct {
 };
 
 template <int G>
-DEV MStruct load_mstruct(const MjhModel& m, int* sh) {
+DEV MStruct load_mstruct(const MjhModel& m, int* sh, int nthreads) {
   // cooperative (whole block) copy of M_rowadr | M_rownnz | M_colind into LDS; ends with __syncthreads
   int nv = m.nv, nC = m.nC;
-  for (int i = threadIdx.x; i < nv; i += blockDim.x) {
+  for (int i = threadIdx.x; i < nv; i += nthreads) {
     sh[i] = m.M_rowadr[i];
     sh[nv + i] = m.M_rownnz[i];
   }
-  for (int i = threadIdx.x; i < nC; i += blockDim.x) sh[2 * nv + i] = m.M_colind[i];
+  for (int i = threadIdx.x; i < nC; i += nthreads) sh[2 * nv + i] = m.M_colind[i];
   int* lv = sh + 2 * nv + nC;
-  for (int i = threadIdx.x; i < nv; i += blockDim.x) lv[i] = m.dof_tree[i];
-  for (int i = threadIdx.x; i <= m.ndoflevel; i += blockDim.x) lv[nv + i] = m.dof_leveladr[i];
+  for (int i = threadIdx.x; i < nv; i += nthreads) lv[i] = m.dof_tree[i];
+  for (int i = threadIdx.x; i <= m.ndoflevel; i += nthreads) lv[nv + i] = m.dof_leveladr[i];
   __syncthreads();
   return MStruct{sh, sh + nv, sh + 2 * nv, lv, lv + nv};
 }
@@ -132,14 +132,14 @@ __host__ __device__ inline PosLayout pos_layout(int nq, int nv, int nbody, int n
 enum { POS_KINEMATICS = 0, POS_COM = 1, POS_CRB = 2, POS_FACTOR = 3 };
 
 template <int G>
-__global__ void __launch_bounds__(256) k_fwd_pos(MjhModel m, MjhData d, int first, int last) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+DEV void fwd_pos_body(const MjhModel& m, const MjhData& d, int first, int last, float* smem, const Blk& b) {
+  if ((int)threadIdx.x >= b.nthreads) return;
   const int nq = m.nq, nv = m.nv, nbody = m.nbody, njnt = m.njnt, nC = m.nC;
   const PosLayout lay = pos_layout(nq, nv, nbody, njnt, nC);
   int* shi = reinterpret_cast<int*>(smem);
-  const MStruct ms = load_mstruct<G>(m, shi);
+  const MStruct ms = load_mstruct<G>(m, shi, b.nthreads);
   const int lig = threadIdx.x & (G - 1), gib = threadIdx.x / G;
-  const int w = blockIdx.x * (blockDim.x / G) + gib;
+  const int w = b.w0 + gib;
   if (w >= d.nworld) return;
   PhaseClock pc(1, lig);
   float* S = smem + mstruct_ints(nv, nC) + (size_t)gib * lay.total;
@@ -418,14 +418,14 @@ DEV float jac_dot(const MjhModel& m, const float* cdof_i, V3 offset, V3 force, V
 }
 
 template <int G>
-__global__ void __launch_bounds__(256) k_fwd_vel(MjhModel m, MjhData d, int first, int last) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+DEV void fwd_vel_body(const MjhModel& m, const MjhData& d, int first, int last, float* smem, const Blk& b) {
+  if ((int)threadIdx.x >= b.nthreads) return;
   const int nq = m.nq, nv = m.nv, nbody = m.nbody, njnt = m.njnt, nC = m.nC, nu = m.nu;
   const VelLayout lay = vel_layout(nq, nv, nbody, nC, nu);
   int* shi = reinterpret_cast<int*>(smem);
-  const MStruct ms = load_mstruct<G>(m, shi);
+  const MStruct ms = load_mstruct<G>(m, shi, b.nthreads);
   const int lig = threadIdx.x & (G - 1), gib = threadIdx.x / G;
-  const int w = blockIdx.x * (blockDim.x / G) + gib;
+  const int w = b.w0 + gib;
   if (w >= d.nworld) return;
   float* S = smem + mstruct_ints(nv, nC) + (size_t)gib * lay.total;
   float *qpos = S + lay.qpos, *qvel = S + lay.qvel, *cdof = S + lay.cdof, *cinert = S + lay.cinert, *cvel = S + lay.cvel,
@@ -703,14 +703,14 @@ __host__ __device__ inline FacLayout fac_layout(int nv, int nC) {
   return p;
 }
 template <int G>
-__global__ void __launch_bounds__(256) k_factor_smooth(MjhModel m, MjhData d, int write_qacc) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+DEV void factor_smooth_body(const MjhModel& m, const MjhData& d, int write_qacc, float* smem, const Blk& b) {
+  if ((int)threadIdx.x >= b.nthreads) return;
   const int nv = m.nv, nC = m.nC;
   const FacLayout lay = fac_layout(nv, nC);
   int* shi = reinterpret_cast<int*>(smem);
-  const MStruct ms = load_mstruct<G>(m, shi);
+  const MStruct ms = load_mstruct<G>(m, shi, b.nthreads);
   const int lig = threadIdx.x & (G - 1), gib = threadIdx.x / G;
-  const int w = blockIdx.x * (blockDim.x / G) + gib;
+  const int w = b.w0 + gib;
   if (w >= d.nworld) return;
   float* S = smem + mstruct_ints(nv, nC) + (size_t)gib * lay.total;
   float *L = S + lay.L, *dinv = S + lay.dinv, *x = S + lay.x;
@@ -722,4 +722,20 @@ __global__ void __launch_bounds__(256) k_factor_smooth(MjhModel m, MjhData d, in
   gcopy<G>(d.qLD + (size_t)w * nC, L, nC, lig);
   gcopy<G>(d.qLDiagInv + (size_t)w * nv, dinv, nv, lig);
   if (write_qacc) gcopy<G>(d.qacc_smooth + (size_t)w * nv, x, nv, lig);
+}
+
+template <int G>
+__global__ void __launch_bounds__(256) k_fwd_pos(MjhModel m, MjhData d, int first, int last) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  fwd_pos_body<G>(m, d, first, last, smem, blk_of_launch<G>());
+}
+template <int G>
+__global__ void __launch_bounds__(256) k_fwd_vel(MjhModel m, MjhData d, int first, int last) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  fwd_vel_body<G>(m, d, first, last, smem, blk_of_launch<G>());
+}
+template <int G>
+__global__ void __launch_bounds__(256) k_factor_smooth(MjhModel m, MjhData d, int write_qacc) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  factor_smooth_body<G>(m, d, write_qacc, smem, blk_of_launch<G>());
 }

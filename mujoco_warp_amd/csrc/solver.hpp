@@ -209,17 +209,17 @@ DEV void invert_rows(const float (&mrow)[NVR], float (&b)[NVR], float* buf, int 
 }
 
 template <int NV4, int NR, bool NEWTON>
-__global__ void __launch_bounds__(256) k_solve(MjhModel m, MjhData d) {
+DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk& b) {
   constexpr int G = 32;
+  if ((int)threadIdx.x >= b.nthreads) return;
   constexpr int NVR = 4 * NV4;
   constexpr int JS = (NV4 & 1) ? NVR : NVR + 4;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
   const int nv = m.nv, nC = m.nC, njmax = d.njmax, nvp = d.nv_pad;
   const SolveLayout lay = solve_layout<NV4, NR>(njmax);
   int* shi = reinterpret_cast<int*>(smem);
-  const MStruct ms = load_mstruct<G>(m, shi);
+  const MStruct ms = load_mstruct<G>(m, shi, b.nthreads);
   const int lig = threadIdx.x & (G - 1), gib = threadIdx.x / G;
-  const int slot = blockIdx.x * (blockDim.x / G) + gib;
+  const int slot = b.w0 + gib;
   if (slot >= d.nworld) return;
   // worlds are scheduled longest-expected-solve first and paired with a similar neighbour (k_schedule_worlds)
   const int w = d.ws_order[slot];
@@ -574,4 +574,10 @@ __global__ void __launch_bounds__(256) k_solve(MjhModel m, MjhData d) {
     if (ovf) atomicOr(d.overflow + w, ovf);
   }
   pc.mark(9);
+}
+
+template <int NV4, int NR, bool NEWTON>
+__global__ void __launch_bounds__(256) k_solve(MjhModel m, MjhData d) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  solve_body<NV4, NR, NEWTON>(m, d, smem, blk_of_launch<32>());
 }

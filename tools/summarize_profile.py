@@ -24,7 +24,7 @@ def _tables(cur):
 
 def _short(n):
   n = n.replace(".kd", "")
-  for key in ("k_fwd_pos", "k_fwd_vel", "k_collision", "k_make_constraint", "k_solve_m", "k_solve", "k_integrate", "k_ctrl_noise", "k_overflow"):
+  for key in ("k_fwd_pos", "k_fwd_vel", "k_collision", "k_make_constraint", "k_solve_m", "k_solve", "k_integrate", "k_ctrl_noise", "k_contact_scan", "k_publish_contacts", "k_factor_smooth", "k_schedule_worlds"):
     if key in n:
       if key == "k_solve" and "ILi" in n:
         i = n.index("ILi")
@@ -47,6 +47,21 @@ def kernel_trace(dbpath):
     out.append({"kernel": k, "calls": len(v), "mean_us": sum(v) / len(v) / 1e3, "min_us": min(v) / 1e3, "max_us": max(v) / 1e3,
                 "total_ms": sum(v) / 1e6, "pct": 100.0 * sum(v) / max(total, 1)})
   return out
+
+
+def timeline(dbpath, ndispatch=40):
+  """Start offset / duration / queue of the last dispatches: shows overlap and the gaps between dependent kernels."""
+  db = sqlite3.connect(dbpath)
+  cur = db.cursor()
+  t = _tables(cur)
+  names = {r[0]: r[1] for r in cur.execute(f"select id, kernel_name from '{t['rocpd_info_kernel_symbol']}'")}
+  cols = [r[1] for r in cur.execute(f"pragma table_info('{t['rocpd_kernel_dispatch']}')")]
+  qcol = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols else None)
+  rows = list(cur.execute(f"select kernel_id, start, end{', ' + qcol if qcol else ''} from '{t['rocpd_kernel_dispatch']}' order by start"))
+  rows = rows[-ndispatch:]
+  t0 = rows[0][1]
+  return [{"kernel": _short(names.get(r[0], str(r[0]))), "start_us": (r[1] - t0) / 1e3, "dur_us": (r[2] - r[1]) / 1e3,
+           "end_us": (r[2] - t0) / 1e3, "queue": (r[3] if qcol else None)} for r in rows]
 
 
 def pmc(dbpath):
@@ -72,6 +87,7 @@ def main():
   summary = {"source": out}
   for f in glob.glob(os.path.join(out, "trace", "*.db")):
     summary["kernel_trace"] = kernel_trace(f)
+    summary["timeline"] = timeline(f)
   counters = defaultdict(dict)
   for tag in ("pmc_sq", "pmc_sq2", "pmc_fetch", "pmc_write"):
     for f in glob.glob(os.path.join(out, tag, "*.db")):
