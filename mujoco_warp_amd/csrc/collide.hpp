@@ -456,9 +456,26 @@ DEV void publish_body(const MjhData& d, int self_prefix, int* sh, const Blk& b) 
     const int t = threadIdx.x, nwave = (b.nthreads + 63) / 64;
     const bool last = b.w0 + b.nw >= d.nworld;
     int s = 0, s2 = 0;
-    for (int i = t; i < b.w0; i += b.nthreads) s += d.ws_ncon[i];
-    if (last)
-      for (int i = t; i < d.nworld; i += b.nthreads) s2 += d.ws_ncollision[i];
+    {  // 16-byte loads, all in flight before the first add (a dependent scalar loop costs ~0.5 us per trip)
+      const int4* p4 = reinterpret_cast<const int4*>(d.ws_ncon);
+      const int n4 = b.w0 >> 2;
+#pragma unroll 8
+      for (int i = t; i < n4; i += b.nthreads) {
+        const int4 v = p4[i];
+        s += v.x + v.y + v.z + v.w;
+      }
+      for (int i = (n4 << 2) + t; i < b.w0; i += b.nthreads) s += d.ws_ncon[i];
+    }
+    if (last) {
+      const int4* p4 = reinterpret_cast<const int4*>(d.ws_ncollision);
+      const int n4 = d.nworld >> 2;
+#pragma unroll 8
+      for (int i = t; i < n4; i += b.nthreads) {
+        const int4 v = p4[i];
+        s2 += v.x + v.y + v.z + v.w;
+      }
+      for (int i = (n4 << 2) + t; i < d.nworld; i += b.nthreads) s2 += d.ws_ncollision[i];
+    }
     for (int off = 32; off > 0; off >>= 1) {
       s += __shfl_xor(s, off, 64);
       s2 += __shfl_xor(s2, off, 64);

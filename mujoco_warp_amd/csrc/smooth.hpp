@@ -671,13 +671,23 @@ DEV void fwd_vel_body(const MjhModel& m, const MjhData& d, int first, int last, 
     // xfrc_applied (support.py:259-322): wrench (force, torque) at xipos of each body
     {
       const int nw = (nv + 31) / 32;
-      for (int b = 1; b < nbody; ++b) {
+      // which bodies carry a wrench: one parallel probe (lane = body) instead of nbody dependent per-world loads
+      for (int b0 = 0; b0 < nbody; b0 += G) {
+        bool any = false;
+        if (b0 + lig < nbody && b0 + lig > 0) {
+          const float* f = d.xfrc_applied + ((size_t)w * nbody + b0 + lig) * 6;
+          any = f[0] != 0.0f || f[1] != 0.0f || f[2] != 0.0f || f[3] != 0.0f || f[4] != 0.0f || f[5] != 0.0f;
+        }
+        unsigned mask = (unsigned)(gballot<G>(any));
+        while (mask) {
+        const int b = b0 + __ffs(mask) - 1;
+        mask &= mask - 1;
         const float* f = d.xfrc_applied + ((size_t)w * nbody + b) * 6;
         V3 force = ld3(f), torque = ld3(f + 3);
-        if (force.x == 0.0f && force.y == 0.0f && force.z == 0.0f && torque.x == 0.0f && torque.y == 0.0f && torque.z == 0.0f) continue;
         V3 off = ld3(d.xipos + ((size_t)w * nbody + b) * 3) - ld3(d.subtree_com + ((size_t)w * nbody + m.body_rootid[b]) * 3);
         for (int i = lig; i < nv; i += G)
           if (m.body_dofmask[b * nw + (i >> 5)] & (1u << (i & 31))) x[i] += jac_dot(m, cdof + 6 * i, off, force, torque);
+        }
       }
     }
     gsync();
