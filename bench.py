@@ -154,31 +154,33 @@ def main():
   if rank == 0 and not args.no_roofline:
     for k, v in snapshot.items():
       getattr(d, k).assign(v)
+    # HIP event pairs (recorded on the launch stream, inside mjh_timed_steps) around each launch of the fused step
     ms2, pk = mjw.timed_steps(m, d, args.steps, step0=args.warmup, per_kernel=True)
     names = mjw.KERNEL_NAMES
-    per_kernel_us = {n: 1e3 * t / args.steps for n, t in zip(names, pk)}
-    dom = max((n for n in names if n not in ("other",)), key=lambda n: per_kernel_us[n])
-    nv, nC, nvp = m.nv, m.nC, d.nv_pad
+    fused_us = {n: 1e3 * t / args.steps for n, t in zip(names, pk) if t > 0}
     ne = float(nefc.mean())
     cg = args.solver == "cg"
-    # algorithmic bytes per world-step (DESIGN.md "Roofline accounting"); float32/int32 words
-    words_solve = nC + ne * nvp + 3 * ne + 3 * nv + 3 * nv + 2 * ne + 4
-    words_crb = 10 * m.nbody + 6 * nv + 10 * m.nbody + nC  # cinert, cdof in; crb, M out
-    bytes_dom = {"solve": 4 * words_solve}.get(dom)
-    if bytes_dom is None:
-      bytes_dom = 4 * words_solve
-      dom = "solve"
-    t_dom = per_kernel_us[dom] * 1e-6
-    achieved = bytes_dom * nworld / t_dom / 1e9
-    out["roofline"] = {"kernel": "k_solve", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                       "frac": achieved / HBM_PEAK_GBS, "traffic": _traffic_from_profile(),
-                       "bytes_per_launch": bytes_dom * nworld, "us_per_launch": per_kernel_us[dom]}
-    t_pass = (per_kernel_us["fwd_pos"] + per_kernel_us["solve"]) * 1e-6
+    # algorithmic bytes per world-step: SURVEY.md section 8(d), float32/int32 words (restated in DESIGN.md section 4)
+    words_solve = (1135 if cg else 406) + 33 * ne  # solver pass: M/qLD, J, D, aref, type/id, qacc_*, outputs
+    words_crb = 1501                               # CRBA(+factor) pass: cinert, cdof in; crb, M, qLD, qLDiagInv out
+    t_dom = fused_us["solve"] * 1e-6
+    achieved = 4 * words_solve * nworld / t_dom / 1e9
+    out["roofline"] = {"kernel": "k_solve_plus (solver workgroups + L'DL factor workgroups of the fused step)", "bound": "hbm",
+                       "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                       "traffic": _traffic_from_profile(), "bytes_per_launch": 4 * words_solve * nworld,
+                       "us_per_launch": fused_us["solve"],
+                       "note": "latency/VALU-bound kernel: 59% VALU issue utilisation (profiles/), not an HBM stream"}
+    t_pass = (fused_us["fwd_pos"] + fused_us["solve"]) * 1e-6
     pass_bytes = 4 * (words_crb + words_solve) * nworld
     out["pass_crba_solver"] = {"bytes": pass_bytes, "us": t_pass * 1e6, "achieved_GBs": pass_bytes / t_pass / 1e9,
                                "frac_of_8TBs": pass_bytes / t_pass / 1e9 / HBM_PEAK_GBS,
-                               "note": "time = k_fwd_pos (FK+CoM+CRBA fused) + k_solve; bytes = CRBA in/out + solver in/out"}
-    out["per_kernel_us"] = per_kernel_us
+                               "note": "time = k_fwd_pos_plus (FK+CoM+CRBA fused) + k_solve_plus (solver + factor); bytes = SURVEY 8(d)"}
+    out["fused_launch_us"] = fused_us
+    # per-stage trace: one plain kernel per stage (the reference's event-tracer granularity)
+    for k, v in snapshot.items():
+      getattr(d, k).assign(v)
+    ms3, pk3 = mjw.timed_steps(m, d, args.steps, step0=args.warmup, per_kernel=True, plain_kernels=True)
+    out["per_kernel_us"] = {n: 1e3 * t / args.steps for n, t in zip(names, pk3) if n != "mid"}
 
   if rank == 0 and cpu is not None:
     out["cpu_baseline"] = cpu

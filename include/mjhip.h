@@ -195,10 +195,13 @@ int mjh_graph_destroy(void* graph_exec);
 
 /* timed loop helper: runs `nstep` x (ctrl_noise + step) on `stream`, bracketed by hipEvents recorded on
  * that stream; returns elapsed milliseconds through *ms_out (events, not host clocks).  If per_kernel_ms
- * is non-NULL it must hold MJH_NKERNEL floats and receives the summed duration of each kernel class. */
-#define MJH_NKERNEL 8
+ * is non-NULL it must hold MJH_NKERNEL floats and receives the summed duration of each kernel class:
+ *   0 ctrl_noise | 1 fwd_pos | 2 collision | 3 make_constraint | 4 fwd_vel | 5 solve | 6 integrate | 7 other | 8 mid
+ * plain_kernels = 0 times the launches of the fused step (classes 0, 1, 8 = collision+make_constraint+fwd_vel in one
+ * launch, 5, 6); plain_kernels = 1 runs one plain kernel per stage instead (classes 0-7), for the per-stage trace. */
+#define MJH_NKERNEL 9
 int mjh_timed_steps(const MjhModel* m, const MjhData* d, int nstep, int step0, float noise_std, float noise_rate,
-                    void* stream, float* ms_out, float* per_kernel_ms);
+                    void* stream, float* ms_out, float* per_kernel_ms, int plain_kernels);
 
 const char* mjh_last_error(void);
 int mjh_abi_version(void);

@@ -111,7 +111,7 @@ def lib():
   L.mjh_graph_launch.argtypes = [vp, vp]
   L.mjh_graph_destroy.argtypes = [vp]
   L.mjh_timed_steps.argtypes = [mp, dp, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, vp,
-                                ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
+                                ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), ctypes.c_int]
   L.mjh_last_error.restype = ctypes.c_char_p
   for f in FUNCTIONS:
     if f != "mjh_last_error":

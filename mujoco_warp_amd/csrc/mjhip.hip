@@ -338,6 +338,7 @@ struct Instr {
   std::vector<int> cls;
   hipStream_t s;
   bool on = false;
+  bool plain = false;  // one plain kernel per stage instead of the fused launches
 };
 static thread_local Instr* g_instr = nullptr;
 struct Scope {
@@ -360,7 +361,7 @@ struct Scope {
     }
   }
 };
-enum { K_NOISE = 0, K_POS = 1, K_COLLISION = 2, K_CONSTRAINT = 3, K_VEL = 4, K_SOLVE = 5, K_INTEGRATE = 6, K_OTHER = 7 };
+enum { K_NOISE = 0, K_POS = 1, K_COLLISION = 2, K_CONSTRAINT = 3, K_VEL = 4, K_SOLVE = 5, K_INTEGRATE = 6, K_OTHER = 7, K_MID = 8 };
 
 static int run_stage(const MjhModel* m, const MjhData* d, int stage, hipStream_t s) {
   switch (stage) {
@@ -396,7 +397,7 @@ static int run_stage(const MjhModel* m, const MjhData* d, int stage, hipStream_t
     case MJH_STAGE_STEP: {
       const int mode = m->integrator == INT_IMPLICITFAST ? 1 : 0;
       static const bool plain = getenv("MJH_PLAIN") != nullptr;  // developer knob: one plain kernel per stage, serial
-      if ((g_instr && g_instr->on) || plain) {
+      if ((g_instr && g_instr->on && g_instr->plain) || plain) {
         // profiling pass: one plain kernel per stage, so that the event pairs time one kernel at a time
         { Scope sc(K_OTHER); hipLaunchKernelGGL(k_schedule_worlds, dim3(1), dim3(1024), 0, s, *d); }
         { Scope sc(K_POS); TRY(launch_pos(m, d, POS_KINEMATICS, POS_CRB, s)); }
@@ -411,10 +412,10 @@ static int run_stage(const MjhModel* m, const MjhData* d, int stage, hipStream_t
         return MJH_OK;
       }
       // fused step: four launches on the caller's stream (see "composite launches" above)
-      TRY(launch_pos_plus(m, d, POS_KINEMATICS, POS_CRB, s));
-      TRY(launch_mid(m, d, s));
-      TRY(launch_solve_plus(m, d, s));
-      TRY(launch_integrate_plus(m, d, mode, stage == MJH_STAGE_STEP, s));
+      { Scope sc(K_POS); TRY(launch_pos_plus(m, d, POS_KINEMATICS, POS_CRB, s)); }
+      { Scope sc(K_MID); TRY(launch_mid(m, d, s)); }
+      { Scope sc(K_SOLVE); TRY(launch_solve_plus(m, d, s)); }
+      { Scope sc(K_INTEGRATE); TRY(launch_integrate_plus(m, d, mode, stage == MJH_STAGE_STEP, s)); }
       return MJH_OK;
     }
     default:
@@ -424,7 +425,7 @@ static int run_stage(const MjhModel* m, const MjhData* d, int stage, hipStream_t
 
 extern "C" {
 
-int mjh_abi_version(void) { return 1; }
+int mjh_abi_version(void) { return 2; }
 const char* mjh_last_error(void) { return g_err; }
 
 int mjh_stage(const MjhModel* m, const MjhData* d, int stage, void* stream) {
@@ -494,12 +495,13 @@ int mjh_graph_destroy(void* graph_exec) {
 }
 
 int mjh_timed_steps(const MjhModel* m, const MjhData* d, int nstep, int step0, float noise_std, float noise_rate,
-                    void* stream, float* ms_out, float* per_kernel_ms) {
+                    void* stream, float* ms_out, float* per_kernel_ms, int plain_kernels) {
   TRY(check(m, d));
   hipStream_t s = (hipStream_t)stream;
   Instr instr;
   instr.s = s;
   instr.on = per_kernel_ms != nullptr;
+  instr.plain = plain_kernels != 0;
   g_instr = &instr;
   hipEvent_t t0, t1;
   hipEventCreate(&t0);

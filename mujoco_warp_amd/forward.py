@@ -151,18 +151,21 @@ class StepGraph:
       pass
 
 
-def timed_steps(m, d, nstep: int, step0: int = 0, noise_std: float = 0.01, noise_rate: float = 0.1, per_kernel: bool = False):
+def timed_steps(m, d, nstep: int, step0: int = 0, noise_std: float = 0.01, noise_rate: float = 0.1, per_kernel: bool = False,
+                plain_kernels: bool = False):
   """Run nstep x (ctrl_noise + step) bracketed by HIP events on the launch stream.
 
   Returns (elapsed_ms, per_kernel_ms or None); per-kernel times come from event pairs around each launch
-  and are only meaningful for profiling (the extra events perturb the total slightly).
+  and are only meaningful for profiling (the extra events perturb the total slightly).  per_kernel times the four
+  launches of the fused step (KERNEL_NAMES: ctrl_noise, fwd_pos, mid, solve, integrate); with plain_kernels the step
+  runs one plain kernel per stage instead, which gives the per-stage trace of the reference's event tracer.
   """
   L = _abi.lib()
   ms = ctypes.c_float(0.0)
   pk = (ctypes.c_float * _S["MJH_NKERNEL"])() if per_kernel else None
   _abi.check(L.mjh_timed_steps(ctypes.byref(io.c_model(m)), ctypes.byref(io.c_data(d)), int(nstep), int(step0), float(noise_std),
-                               float(noise_rate), _stream(), ctypes.byref(ms), pk))
+                               float(noise_rate), _stream(), ctypes.byref(ms), pk, int(bool(plain_kernels))))
   return ms.value, (list(pk) if per_kernel else None)
 
 
-KERNEL_NAMES = ["ctrl_noise", "fwd_pos", "collision", "make_constraint", "fwd_vel", "solve", "integrate", "other"]
+KERNEL_NAMES = ["ctrl_noise", "fwd_pos", "collision", "make_constraint", "fwd_vel", "solve", "integrate", "other", "mid"]

@@ -129,7 +129,8 @@ def main(argv=None):
   trace = {}
   if args.event_trace and args.function == "step":
     # per-kernel HIP-event timing of a few extra steps (the reference's EventTracer keys, ns per world-step)
-    ms, pk = mjw.timed_steps(m, d, 20, step0=args.nstep, noise_std=args.noise_std, noise_rate=args.noise_rate, per_kernel=True)
+    ms, pk = mjw.timed_steps(m, d, 20, step0=args.nstep, noise_std=args.noise_std, noise_rate=args.noise_rate, per_kernel=True,
+                             plain_kernels=True)
     ns = {k: 1e6 * v / 20 / args.nworld for k, v in zip(mjw.KERNEL_NAMES, pk)}
     fwd_position = ns["fwd_pos"] + ns["collision"] + ns["make_constraint"]
     forward = fwd_position + ns["fwd_vel"] + ns["solve"]

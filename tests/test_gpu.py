@@ -341,10 +341,13 @@ def test_timed_steps_reports_kernel_classes():
   m = mjw.put_model(mjm)
   d = mjw.make_data(mjm, nworld=512, nconmax=24, njmax=64)
   mjw.reset_data_keyframe(m, d, 0)
-  ms, pk = mjw.timed_steps(m, d, 5, per_kernel=True)
+  ms, pk = mjw.timed_steps(m, d, 5, per_kernel=True)  # the four launches of the fused step
   assert ms > 0 and len(pk) == len(mjw.KERNEL_NAMES)
-  assert all(pk[mjw.KERNEL_NAMES.index(k)] > 0 for k in ("fwd_pos", "collision", "make_constraint", "fwd_vel", "solve", "integrate"))
-  np.testing.assert_allclose(d.time.numpy(), 5 * 0.005, rtol=1e-5)
+  assert all(pk[mjw.KERNEL_NAMES.index(k)] > 0 for k in ("ctrl_noise", "fwd_pos", "mid", "solve", "integrate"))
+  assert all(pk[mjw.KERNEL_NAMES.index(k)] == 0 for k in ("collision", "make_constraint", "fwd_vel"))
+  ms, pk = mjw.timed_steps(m, d, 5, step0=5, per_kernel=True, plain_kernels=True)  # one plain kernel per stage
+  assert all(pk[mjw.KERNEL_NAMES.index(k)] > 0 for k in ("fwd_pos", "collision", "make_constraint", "fwd_vel", "solve", "integrate", "other"))
+  np.testing.assert_allclose(d.time.numpy(), 10 * 0.005, rtol=1e-5)
 
 
 def test_long_rollout_contact_records_stay_valid():
