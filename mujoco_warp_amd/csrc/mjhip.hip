@@ -213,14 +213,17 @@ __global__ void __launch_bounds__(256) k_solve_plus(MjhModel m, MjhData d, int n
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int wpb = blockDim.x / 32;
   if ((int)blockIdx.x < nsolve) solve_body<NV4, NR, NEWTON>(m, d, smem, Blk{(int)blockIdx.x * wpb, wpb, (int)blockDim.x});
-  else factor_smooth_body<32>(m, d, write_qacc, smem, Blk{((int)blockIdx.x - nsolve) * wpb, wpb, (int)blockDim.x});
+  // CG only: the Newton kernel holds 256 VGPRs (one wave per SIMD), which would throttle the factor workgroups too
+  // (measured +120 us); for Newton they ride along with the integrator launch instead
+  else if (!NEWTON) factor_smooth_body<32>(m, d, write_qacc, smem, Blk{((int)blockIdx.x - nsolve) * wpb, wpb, (int)blockDim.x});
 }
 template <int G>
-__global__ void __launch_bounds__(256) k_integrate_plus(MjhModel m, MjhData d, int mode, int nint) {
+__global__ void __launch_bounds__(256) k_integrate_plus(MjhModel m, MjhData d, int mode, int nint, int npub) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int wpb = blockDim.x / G, bi = blockIdx.x;
   if (bi < nint) integrate_body<G>(m, d, mode, smem, Blk{bi * wpb, wpb, (int)blockDim.x});
-  else publish_body<G>(d, 1, reinterpret_cast<int*>(smem), Blk{(bi - nint) * wpb, wpb, (int)blockDim.x});
+  else if (bi < nint + npub) publish_body<G>(d, 1, reinterpret_cast<int*>(smem), Blk{(bi - nint) * wpb, wpb, (int)blockDim.x});
+  else factor_smooth_body<G>(m, d, 1, smem, Blk{(bi - nint - npub) * wpb, wpb, (int)blockDim.x});  // Newton only, see k_solve_plus
 }
 // k_fwd_pos + one workgroup that sorts the worlds by the PREVIOUS step's solver_niter (the solver schedule of this step)
 template <int G>
@@ -265,7 +268,7 @@ static int launch_solve_plus_t(const MjhModel* m, const MjhData* d, hipStream_t 
   lds = std::max(lds, ms_bytes + sizeof(float) * fl.total * wpb);
   HIPCHK(set_lds(k_solve_plus<NV4, NR, NEWTON>, lds));
   const int nsolve = (d->nworld + wpb - 1) / wpb;
-  hipLaunchKernelGGL((k_solve_plus<NV4, NR, NEWTON>), dim3(2 * nsolve), dim3(threads), lds, s, *m, *d, nsolve, NEWTON ? 1 : 0);
+  hipLaunchKernelGGL((k_solve_plus<NV4, NR, NEWTON>), dim3(NEWTON ? nsolve : 2 * nsolve), dim3(threads), lds, s, *m, *d, nsolve, 0);
   return MJH_OK;
 }
 template <int NR, bool NEWTON>
@@ -298,12 +301,15 @@ static int launch_solve_plus(const MjhModel* m, const MjhData* d, hipStream_t s)
 // integrator (optional) + publication of the contact arrays + solver schedule
 static int launch_integrate_plus(const MjhModel* m, const MjhData* d, int mode, bool integrate, hipStream_t s) {
   const IntLayout lay = int_layout(m->nv, m->nC);
+  const FacLayout fl = fac_layout(m->nv, m->nC);
   const size_t ms_bytes = sizeof(int) * mstruct_ints(m->nv, m->nC);
-  size_t lds = std::max(ms_bytes + sizeof(float) * lay.total * 8, (size_t)2048);
+  const bool with_factor = m->solver == SOL_NEWTON;
+  size_t lds = std::max(ms_bytes + sizeof(float) * std::max(lay.total, fl.total) * 8, (size_t)2048);
   if (lds > (size_t)kLdsPerCU) return fail(MJH_E_UNSUPPORTED, "k_integrate: does not fit in LDS");
   HIPCHK(set_lds(k_integrate_plus<G>, lds));
   const int nb = (d->nworld + 7) / 8;
-  hipLaunchKernelGGL(k_integrate_plus<G>, dim3((integrate ? nb : 0) + nb), dim3(256), lds, s, *m, *d, mode, integrate ? nb : 0);
+  hipLaunchKernelGGL(k_integrate_plus<G>, dim3((integrate ? nb : 0) + nb + (with_factor ? nb : 0)), dim3(256), lds, s, *m, *d, mode,
+                     integrate ? nb : 0, nb);
   return MJH_OK;
 }
 static int launch_pos_plus(const MjhModel* m, const MjhData* d, int first, int last, hipStream_t s) {
