@@ -38,6 +38,10 @@ DEV float gsum32(float v) {
   v = dpp_add_f<0x142, 0xa, 0xf>(v);  // row_bcast:15 into rows 1 and 3 -> lanes 31 / 63 hold the group sums
   return bcast32(v, 31);
 }
+// (A butterfly all-reduce -- quad_perm, row_half_mirror, row_mirror, v_permlane16_swap or ds_swizzle -- is two VALU ops
+// shorter and passes in isolation, but inside k_solve it broke parity with both cross-row variants; not pursued.)
+// division for step-size candidates and ratios that only steer the search (v_rcp_f32, 1 ulp; an IEEE divide is ~10 ops)
+DEV float fast_div(float x, float y) { return x * __builtin_amdgcn_rcpf(y != 0.0f ? y : MJ_MINVAL); }
 
 // ---- dense Cholesky with lane i owning row i (NVR <= 32), all indices compile-time ----------------------
 // h: row i of the SPD matrix on entry, row i of L on exit (entries above the diagonal are junk);
@@ -112,7 +116,7 @@ template <int NV4, int NR>
 __host__ __device__ inline SolveLayout solve_layout(int njmax) {
   constexpr int NVR = 4 * NV4;
   constexpr int JS = (NV4 & 1) ? NVR : NVR + 4;  // JS/4 odd: row-per-lane 16-byte reads hit distinct banks
-  const int njp = ((njmax + 3) / 4) * 4;
+  const int njp = ((njmax + 15) / 16) * 16;  // J^T f runs over 16-row chunks (rows past nefc are zero)
   SolveLayout p;
   int o = 0;
   p.J = o; o += (njp > NVR ? njp : NVR) * JS;  // also stages the dense NVR x NVR copy of M
@@ -319,7 +323,7 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
     const float* Jg = d.efc_J + (size_t)w * d.njmax_pad * nvp;
     for (int r = 0; r < nefc; ++r)
       for (int c = lig; c < JS; c += G) Jl[r * JS + c] = c < nvp ? Jg[(size_t)r * nvp + c] : 0.0f;
-    for (int r = nefc; r < nefc4; ++r)
+    for (int r = nefc; r < ((nefc + 15) & ~15); ++r)  // zero rows up to the next 16-row chunk boundary
       for (int c = lig; c < JS; c += G) Jl[r * JS + c] = 0.0f;
   }
   float rD[NR], rfl[NR], rja[NR], rjv[NR], rfrc[NR];
@@ -400,10 +404,18 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
     {
       float s0 = 0.0f, s1 = 0.0f;
       const float* Jc = Jl + ligr;
-      for (int r = 0; r < nefc4; r += 4) {  // rows nefc..nefc4 carry zero force and zero J
-        const float4 f4 = *reinterpret_cast<const float4*>(eforce + r);
-        s0 += Jc[r * JS] * f4.x + Jc[(r + 2) * JS] * f4.z;
-        s1 += Jc[(r + 1) * JS] * f4.y + Jc[(r + 3) * JS] * f4.w;
+      // fully unrolled 16-row chunks: every LDS read has an immediate offset (no address arithmetic); rows between
+      // nefc and the chunk boundary carry zero force and zero J
+#pragma unroll
+      for (int r0 = 0; r0 < 32 * NR; r0 += 16) {
+        if (r0 < nefc) {
+#pragma unroll
+          for (int r = r0; r < r0 + 16; r += 4) {
+            const float4 f4 = *reinterpret_cast<const float4*>(eforce + r);
+            s0 += Jc[r * JS] * f4.x + Jc[(r + 2) * JS] * f4.z;
+            s1 += Jc[(r + 1) * JS] * f4.y + Jc[(r + 3) * JS] * f4.w;
+          }
+        }
       }
       qc = active ? s0 + s1 : 0.0f;
     }
@@ -459,7 +471,7 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
         // Polak-Ribiere (solver.py:3283-3450)
         const float num = gsum32(g * (Mg - pMg));
         const float den = gsum32(pg * pMg);
-        const float beta = fmaxf(0.0f, num / fmaxf(MJ_MINVAL, den));
+        const float beta = fmaxf(0.0f, num * __builtin_amdgcn_rcpf(fmaxf(MJ_MINVAL, den)));
         done = (imp < tolerance) || (gradient < tolerance);
         if (!done) {
           srch = -Mg + beta * srch;
@@ -503,7 +515,7 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
     };
     const P3 e = eval(0.0f);
     const P3 p0 = P3{0.0f, gauss1 + gsum32(e.g), 2.0f * gauss2 + gsum32(e.h)};
-    const float lo_alpha_in = -safe_div(p0.g, p0.h);
+    const float lo_alpha_in = -fast_div(p0.g, p0.h);
     const P3 lo_in = total(eval(lo_alpha_in), lo_alpha_in);
     float alpha = 0.0f;
     improvement = 0.0f;
@@ -516,7 +528,7 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
       P3 lo = lo_less ? lo_in : p0, hi = lo_less ? p0 : lo_in;
       float lo_alpha = lo_less ? lo_alpha_in : 0.0f, hi_alpha = lo_less ? 0.0f : lo_alpha_in;
       for (int it = 0; it < ls_iterations; ++it) {
-        const float a_lo = lo_alpha - safe_div(lo.g, lo.h), a_hi = hi_alpha - safe_div(hi.g, hi.h);
+        const float a_lo = lo_alpha - fast_div(lo.g, lo.h), a_hi = hi_alpha - fast_div(hi.g, hi.h);
         const float a_mid = 0.5f * (lo_alpha + hi_alpha);
         const P3 lo_next = total(eval(a_lo), a_lo), hi_next = total(eval(a_hi), a_hi), mid = total(eval(a_mid), a_mid);
         const bool s1 = in_bracket(lo, lo_next);
