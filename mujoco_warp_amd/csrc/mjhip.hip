@@ -134,43 +134,7 @@ static int launch_constraint(const MjhModel* m, const MjhData* d, hipStream_t s)
   hipLaunchKernelGGL(k_make_constraint<G>, dim3((d->nworld + wpb - 1) / wpb), dim3(threads), lds, s, *m, *d);
   return MJH_OK;
 }
-template <int NV4, int NR, bool NEWTON>
-static int launch_solve_t(const MjhModel* m, const MjhData* d, hipStream_t s) {
-  const SolveLayout lay = solve_layout<NV4, NR>(d->njmax);
-  size_t lds;
-  int threads = pick_block(sizeof(int) * mstruct_ints(m->nv, m->nC), sizeof(float) * lay.total, 32, &lds, true);
-  if (!threads) return fail(MJH_E_UNSUPPORTED, "k_solve: njmax x nv does not fit in LDS");
-  if (const char* e = getenv("MJH_SOLVE_THREADS")) {  // tuning knob (developer only)
-    threads = atoi(e);
-    lds = sizeof(int) * mstruct_ints(m->nv, m->nC) + sizeof(float) * lay.total * (threads / 32);
-  }
-  HIPCHK(set_lds(k_solve<NV4, NR, NEWTON>, lds));
-  const int wpb = threads / 32;
-  hipLaunchKernelGGL((k_solve<NV4, NR, NEWTON>), dim3((d->nworld + wpb - 1) / wpb), dim3(threads), lds, s, *m, *d);
-  return MJH_OK;
-}
-template <int NR, bool NEWTON>
-static int launch_solve_n(const MjhModel* m, const MjhData* d, hipStream_t s) {
-  switch ((m->nv + 3) / 4) {  // kernels are specialised on ceil(nv/4): no padded matrix columns
-    case 0:
-    case 1: return launch_solve_t<1, NR, NEWTON>(m, d, s);
-    case 2: return launch_solve_t<2, NR, NEWTON>(m, d, s);
-    case 3: return launch_solve_t<3, NR, NEWTON>(m, d, s);
-    case 4: return launch_solve_t<4, NR, NEWTON>(m, d, s);
-    case 5: return launch_solve_t<5, NR, NEWTON>(m, d, s);
-    case 6: return launch_solve_t<6, NR, NEWTON>(m, d, s);
-    case 7: return launch_solve_t<7, NR, NEWTON>(m, d, s);
-    default: return launch_solve_t<8, NR, NEWTON>(m, d, s);
-  }
-}
-static int solve_supported(const MjhModel* m, const MjhData* d);
-static int launch_solve(const MjhModel* m, const MjhData* d, hipStream_t s) {
-  if (int rc = solve_supported(m, d)) return rc;
-  const bool newton = m->solver == SOL_NEWTON;
-  // rows per lane (32 lanes per world): 2 covers njmax <= 64 (humanoid, panda), 6 covers njmax <= 192 (G1-class)
-  if (d->njmax <= 64) return newton ? launch_solve_n<2, true>(m, d, s) : launch_solve_n<2, false>(m, d, s);
-  return newton ? launch_solve_n<6, true>(m, d, s) : launch_solve_n<6, false>(m, d, s);
-}
+static int launch_solve(const MjhModel* m, const MjhData* d, hipStream_t s);  // = the solver workgroups of k_solve_plus
 static int launch_integrate(const MjhModel* m, const MjhData* d, int mode, hipStream_t s) {
   const IntLayout lay = int_layout(m->nv, m->nC);
   size_t lds;
@@ -208,14 +172,17 @@ __global__ void __launch_bounds__(256) k_mid(MjhModel m, MjhData d, int ncc, int
     fwd_vel_body<G>(m, d, VEL_COMVEL, VEL_ACCEL, smem, b);
   }
 }
-template <int NV4, int NR, bool NEWTON>
-__global__ void __launch_bounds__(256) k_solve_plus(MjhModel m, MjhData d, int nsolve, int write_qacc) {
+template <int NV4, int NR, bool NEWTON, int SG>
+__global__ void __launch_bounds__(256) k_solve_plus(MjhModel m, MjhData d, int nsolve) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int wpb = blockDim.x / 32;
-  if ((int)blockIdx.x < nsolve) solve_body<NV4, NR, NEWTON>(m, d, smem, Blk{(int)blockIdx.x * wpb, wpb, (int)blockDim.x});
+  const int wpb = blockDim.x / SG;
+  if ((int)blockIdx.x < nsolve) solve_body<NV4, NR, NEWTON, SG>(m, d, smem, Blk{(int)blockIdx.x * wpb, wpb, (int)blockDim.x});
   // CG only: the Newton kernel holds 256 VGPRs (one wave per SIMD), which would throttle the factor workgroups too
   // (measured +120 us); for Newton they ride along with the integrator launch instead
-  else if (!NEWTON) factor_smooth_body<32>(m, d, write_qacc, smem, Blk{((int)blockIdx.x - nsolve) * wpb, wpb, (int)blockDim.x});
+  else if (!NEWTON) {
+    const int wf = blockDim.x / 32;
+    factor_smooth_body<32>(m, d, 0, smem, Blk{((int)blockIdx.x - nsolve) * wf, wf, (int)blockDim.x});
+  }
 }
 template <int G>
 __global__ void __launch_bounds__(256) k_integrate_plus(MjhModel m, MjhData d, int mode, int nint, int npub) {
@@ -252,52 +219,72 @@ static int launch_mid(const MjhModel* m, const MjhData* d, hipStream_t s) {
   hipLaunchKernelGGL(k_mid<G>, dim3(ncc + nvb), dim3(256), lds, s, *m, *d, ncc, nvb, nw_cc, nw_v, stride_cc);
   return MJH_OK;
 }
-template <int NV4, int NR, bool NEWTON>
-static int launch_solve_plus_t(const MjhModel* m, const MjhData* d, hipStream_t s) {
-  const SolveLayout lay = solve_layout<NV4, NR>(d->njmax);
-  const FacLayout fl = fac_layout(m->nv, m->nC);
-  const size_t ms_bytes = sizeof(int) * mstruct_ints(m->nv, m->nC);
-  size_t lds;
-  int threads = pick_block(ms_bytes, sizeof(float) * lay.total, 32, &lds, true);
-  if (!threads) return fail(MJH_E_UNSUPPORTED, "k_solve: njmax x nv does not fit in LDS");
-  if (const char* e = getenv("MJH_SOLVE_THREADS")) {  // tuning knob (developer only)
-    threads = atoi(e);
-    lds = ms_bytes + sizeof(float) * lay.total * (threads / 32);
-  }
-  const int wpb = threads / 32;
-  lds = std::max(lds, ms_bytes + sizeof(float) * fl.total * wpb);
-  HIPCHK(set_lds(k_solve_plus<NV4, NR, NEWTON>, lds));
-  const int nsolve = (d->nworld + wpb - 1) / wpb;
-  hipLaunchKernelGGL((k_solve_plus<NV4, NR, NEWTON>), dim3(NEWTON ? nsolve : 2 * nsolve), dim3(threads), lds, s, *m, *d, nsolve, 0);
-  return MJH_OK;
-}
-template <int NR, bool NEWTON>
-static int launch_solve_plus_n(const MjhModel* m, const MjhData* d, hipStream_t s) {
-  switch ((m->nv + 3) / 4) {
-    case 0:
-    case 1: return launch_solve_plus_t<1, NR, NEWTON>(m, d, s);
-    case 2: return launch_solve_plus_t<2, NR, NEWTON>(m, d, s);
-    case 3: return launch_solve_plus_t<3, NR, NEWTON>(m, d, s);
-    case 4: return launch_solve_plus_t<4, NR, NEWTON>(m, d, s);
-    case 5: return launch_solve_plus_t<5, NR, NEWTON>(m, d, s);
-    case 6: return launch_solve_plus_t<6, NR, NEWTON>(m, d, s);
-    case 7: return launch_solve_plus_t<7, NR, NEWTON>(m, d, s);
-    default: return launch_solve_plus_t<8, NR, NEWTON>(m, d, s);
-  }
-}
 static int solve_supported(const MjhModel* m, const MjhData* d) {
   if (m->cone != 0) return fail(MJH_E_UNSUPPORTED, "elliptic cones are not implemented yet");
-  if (m->nv > 32) return fail(MJH_E_UNSUPPORTED, "nv > 32 needs the sparse/blocked solver path (not implemented yet)");
+  if (m->nv > 64) return fail(MJH_E_UNSUPPORTED, "nv > 64 needs the sparse/blocked solver path (not implemented yet)");
   if (m->solver != SOL_NEWTON && m->solver != SOL_CG) return fail(MJH_E_UNSUPPORTED, "solver must be CG or Newton");
   if (d->njmax > 192) return fail(MJH_E_UNSUPPORTED, "njmax > 192 is not supported by the register-resident solver yet");
   return MJH_OK;
 }
-static int launch_solve_plus(const MjhModel* m, const MjhData* d, hipStream_t s) {
+// SG = lanes per world: 32 (two worlds per wavefront) for nv <= 32, 64 for 32 < nv <= 64.  with_factor appends the
+// L'DL-factor workgroups (fused step, CG); without it the launch is the plain `solve` stage.
+template <int NV4, int NR, bool NEWTON, int SG>
+static int launch_solve_t(const MjhModel* m, const MjhData* d, bool with_factor, hipStream_t s) {
+  const SolveLayout lay = solve_layout<NV4, NR, SG>(d->njmax);
+  const FacLayout fl = fac_layout(m->nv, m->nC);
+  const size_t ms_bytes = sizeof(int) * mstruct_ints(m->nv, m->nC);
+  size_t lds;
+  int threads = pick_block(ms_bytes, sizeof(float) * lay.total, SG, &lds, true);
+  if (!threads) return fail(MJH_E_UNSUPPORTED, "k_solve: njmax x nv does not fit in LDS");
+  if (const char* e = getenv("MJH_SOLVE_THREADS")) {  // tuning knob (developer only)
+    threads = std::max(atoi(e), SG);
+    lds = ms_bytes + sizeof(float) * lay.total * (threads / SG);
+  }
+  const int wpb = threads / SG, wf = threads / 32;
+  with_factor = with_factor && !NEWTON;
+  if (with_factor) lds = std::max(lds, ms_bytes + sizeof(float) * fl.total * wf);
+  HIPCHK(set_lds((k_solve_plus<NV4, NR, NEWTON, SG>), lds));
+  const int nsolve = (d->nworld + wpb - 1) / wpb, nfac = with_factor ? (d->nworld + wf - 1) / wf : 0;
+  hipLaunchKernelGGL((k_solve_plus<NV4, NR, NEWTON, SG>), dim3(nsolve + nfac), dim3(threads), lds, s, *m, *d, nsolve);
+  return MJH_OK;
+}
+template <int NR, bool NEWTON>
+static int launch_solve_32(const MjhModel* m, const MjhData* d, bool wf, hipStream_t s) {
+  switch ((m->nv + 3) / 4) {  // kernels are specialised on ceil(nv/4): no padded matrix columns
+    case 0:
+    case 1: return launch_solve_t<1, NR, NEWTON, 32>(m, d, wf, s);
+    case 2: return launch_solve_t<2, NR, NEWTON, 32>(m, d, wf, s);
+    case 3: return launch_solve_t<3, NR, NEWTON, 32>(m, d, wf, s);
+    case 4: return launch_solve_t<4, NR, NEWTON, 32>(m, d, wf, s);
+    case 5: return launch_solve_t<5, NR, NEWTON, 32>(m, d, wf, s);
+    case 6: return launch_solve_t<6, NR, NEWTON, 32>(m, d, wf, s);
+    case 7: return launch_solve_t<7, NR, NEWTON, 32>(m, d, wf, s);
+    default: return launch_solve_t<8, NR, NEWTON, 32>(m, d, wf, s);
+  }
+}
+template <int NR, bool NEWTON>
+static int launch_solve_64(const MjhModel* m, const MjhData* d, bool wf, hipStream_t s) {
+  const int nv4 = (m->nv + 3) / 4;  // rounded up to an instantiated size (lanes past nv hold identity rows)
+  if (nv4 <= 9) return launch_solve_t<9, NR, NEWTON, 64>(m, d, wf, s);
+  if (nv4 <= 10) return launch_solve_t<10, NR, NEWTON, 64>(m, d, wf, s);
+  if (nv4 <= 12) return launch_solve_t<12, NR, NEWTON, 64>(m, d, wf, s);
+  if (nv4 <= 14) return launch_solve_t<14, NR, NEWTON, 64>(m, d, wf, s);
+  return launch_solve_t<16, NR, NEWTON, 64>(m, d, wf, s);
+}
+static int launch_solve_any(const MjhModel* m, const MjhData* d, bool with_factor, hipStream_t s) {
   if (int rc = solve_supported(m, d)) return rc;
   const bool newton = m->solver == SOL_NEWTON;
-  if (d->njmax <= 64) return newton ? launch_solve_plus_n<2, true>(m, d, s) : launch_solve_plus_n<2, false>(m, d, s);
-  return newton ? launch_solve_plus_n<6, true>(m, d, s) : launch_solve_plus_n<6, false>(m, d, s);
+  if (m->nv <= 32) {
+    // rows per lane (32 lanes per world): 2 covers njmax <= 64 (humanoid, panda), 6 covers njmax <= 192
+    if (d->njmax <= 64) return newton ? launch_solve_32<2, true>(m, d, with_factor, s) : launch_solve_32<2, false>(m, d, with_factor, s);
+    return newton ? launch_solve_32<6, true>(m, d, with_factor, s) : launch_solve_32<6, false>(m, d, with_factor, s);
+  }
+  // 64 lanes per world: 1 row per lane covers njmax <= 64, 3 cover njmax <= 192 (G1-class)
+  if (d->njmax <= 64) return newton ? launch_solve_64<1, true>(m, d, with_factor, s) : launch_solve_64<1, false>(m, d, with_factor, s);
+  return newton ? launch_solve_64<3, true>(m, d, with_factor, s) : launch_solve_64<3, false>(m, d, with_factor, s);
 }
+static int launch_solve(const MjhModel* m, const MjhData* d, hipStream_t s) { return launch_solve_any(m, d, false, s); }
+static int launch_solve_plus(const MjhModel* m, const MjhData* d, hipStream_t s) { return launch_solve_any(m, d, true, s); }
 // integrator (optional) + publication of the contact arrays + solver schedule
 static int launch_integrate_plus(const MjhModel* m, const MjhData* d, int mode, bool integrate, hipStream_t s) {
   const IntLayout lay = int_layout(m->nv, m->nC);

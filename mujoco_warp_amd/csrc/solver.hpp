@@ -25,18 +25,26 @@ DEV float dpp_add_f(float v) {
   const int r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, BANK_MASK, true);
   return v + __int_as_float(r);
 }
-DEV float bcast32(float v, int k) {  // value of lane k of this lane's 32-group (k compile-time)
+// G = 32: two worlds per wavefront (nv <= 32); G = 64: one world per wavefront (32 < nv <= 64)
+template <int G>
+DEV float bcastg(float v, int k) {  // value of lane k of this lane's group (k compile-time)
   const int a = __builtin_amdgcn_readlane(__float_as_int(v), k);
+  if (G == 64) return __int_as_float(a);
   const int b = __builtin_amdgcn_readlane(__float_as_int(v), k + 32);
   return __int_as_float((threadIdx.x & 32) ? b : a);
 }
-DEV float gsum32(float v) {
+template <int G>
+DEV float gsumg(float v) {
   v = dpp_add_f<0x111, 0xf, 0xf>(v);  // row_shr:1
   v = dpp_add_f<0x112, 0xf, 0xf>(v);  // row_shr:2
   v = dpp_add_f<0x114, 0xf, 0xf>(v);  // row_shr:4
   v = dpp_add_f<0x118, 0xf, 0xf>(v);  // row_shr:8  -> lane 15 of each row holds the row sum
-  v = dpp_add_f<0x142, 0xa, 0xf>(v);  // row_bcast:15 into rows 1 and 3 -> lanes 31 / 63 hold the group sums
-  return bcast32(v, 31);
+  v = dpp_add_f<0x142, 0xa, 0xf>(v);  // row_bcast:15 into rows 1 and 3 -> lanes 31 / 63 hold the 32-lane sums
+  if (G == 64) {
+    v = dpp_add_f<0x143, 0xc, 0xf>(v);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave sum
+    return bcastg<64>(v, 63);
+  }
+  return bcastg<32>(v, 31);
 }
 // (A butterfly all-reduce -- quad_perm, row_half_mirror, row_mirror, v_permlane16_swap or ds_swizzle -- is two VALU ops
 // shorter and passes in isolation, but inside k_solve it broke parity with both cross-row variants; not pursued.)
@@ -47,18 +55,18 @@ DEV float fast_div(float x, float y) { return x * __builtin_amdgcn_rcpf(y != 0.0
 // h: row i of the SPD matrix on entry, row i of L on exit (entries above the diagonal are junk);
 // lt: column i of L below the diagonal (for the transposed solve); rdiag = 1 / L[i][i].
 // `col` is an LDS scratch of max(64, 8*JS) floats private to the group.  Lanes >= nv must hold identity rows.
-template <int NVR, int JS>
+template <int NVR, int JS, int G>
 DEV void chol_factor_rows(float (&h)[NVR], float (&lt)[NVR], float& rdiag, float* col, int lig) {
   const bool own = lig < NVR;
   const int ligc = own ? lig : NVR - 1;
   rdiag = 1.0f;
 #pragma unroll
   for (int j = 0; j < NVR; ++j) {  // right-looking; pivot column broadcast through LDS (double buffered)
-    float* cb = col + (j & 1) * 32;
+    float* cb = col + (j & 1) * G;
     if (own) cb[lig] = h[j];
     gsync();
     // pivot by v_readlane (off the LDS round trip); 1/sqrt = v_rsq_f32 + one Newton step (~0.5 ulp)
-    const float pv = fmaxf(bcast32(h[j], j), MJ_MINVAL);
+    const float pv = fmaxf(bcastg<G>(h[j], j), MJ_MINVAL);
     float inv = __builtin_amdgcn_rsqf(pv);
     inv = inv * (1.5f - 0.5f * pv * inv * inv);
     const float piv = pv * inv;
@@ -89,20 +97,20 @@ DEV void chol_factor_rows(float (&h)[NVR], float (&lt)[NVR], float& rdiag, float
   }
 }
 // x = (L L^T)^-1 g for the lane's component; broadcasts via v_readlane (no LDS traffic)
-template <int NVR>
+template <int NVR, int G>
 DEV float chol_solve_rows(const float (&h)[NVR], const float (&lt)[NVR], float rdiag, float g) {
-  const int lig = threadIdx.x & 31;
+  const int lig = threadIdx.x & (G - 1);
   float acc = g, y = 0.0f, x = 0.0f;
 #pragma unroll
   for (int k = 0; k < NVR; ++k) {
-    const float yk = bcast32(acc * rdiag, k);
+    const float yk = bcastg<G>(acc * rdiag, k);
     if (lig == k) y = yk;
     acc -= h[k] * yk;
   }
   acc = y;
 #pragma unroll
   for (int k = NVR - 1; k >= 0; --k) {
-    const float xk = bcast32(acc * rdiag, k);
+    const float xk = bcastg<G>(acc * rdiag, k);
     if (lig == k) x = xk;
     acc -= lt[k] * xk;
   }
@@ -112,7 +120,7 @@ DEV float chol_solve_rows(const float (&h)[NVR], const float (&lt)[NVR], float r
 struct SolveLayout {
   int J, force, da, bsearch, bgrad, col, total;
 };
-template <int NV4, int NR>
+template <int NV4, int NR, int G>
 __host__ __device__ inline SolveLayout solve_layout(int njmax) {
   constexpr int NVR = 4 * NV4;
   constexpr int JS = (NV4 & 1) ? NVR : NVR + 4;  // JS/4 odd: row-per-lane 16-byte reads hit distinct banks
@@ -120,11 +128,11 @@ __host__ __device__ inline SolveLayout solve_layout(int njmax) {
   SolveLayout p;
   int o = 0;
   p.J = o; o += (njp > NVR ? njp : NVR) * JS;  // also stages the dense NVR x NVR copy of M
-  p.force = o; o += 32 * NR;                    // efc_force of the current iterate (for J^T f)
-  p.da = o; o += 32 * NR;                       // D * [state == QUADRATIC] (Newton: J^T D J)
-  p.bsearch = o; o += 32;                       // broadcast copies of the two nv-vectors other lanes read
-  p.bgrad = o; o += 32;
-  p.col = o; o += 8 * JS > 64 ? 8 * JS : 64;    // Cholesky pivot column / transpose tile, Gauss-Jordan pivot row
+  p.force = o; o += G * NR;                     // efc_force of the current iterate (for J^T f)
+  p.da = o; o += G * NR;                        // D * [state == QUADRATIC] (Newton: J^T D J)
+  p.bsearch = o; o += G;                        // broadcast copies of the two nv-vectors other lanes read
+  p.bgrad = o; o += G;
+  p.col = o; o += 8 * JS > 2 * G ? 8 * JS : 2 * G;    // Cholesky pivot column / transpose tile, Gauss-Jordan pivot row
   p.total = ((o + 3) / 4) * 4;
   return p;
 }
@@ -175,7 +183,7 @@ DEV bool in_bracket(P3 x, P3 y) { return (x.g < y.g && y.g < 0.0f) || (x.g > y.g
 // At step k lane k publishes the entries the other rows need -- B[k][0..k] and A[k][k+1..] -- as ONE LDS line
 // (double buffered), the pivot A[k][k] travels by v_readlane; every lane then applies one rank-1 update.
 // The scale step of row k is folded into the same update with the multiplier 1 - 1/pivot.
-template <int NVR>
+template <int NVR, int G>
 DEV void invert_rows(const float (&mrow)[NVR], float (&b)[NVR], float* buf, int lig) {
   float a[NVR];
 #pragma unroll
@@ -185,7 +193,7 @@ DEV void invert_rows(const float (&mrow)[NVR], float (&b)[NVR], float* buf, int 
   }
 #pragma unroll
   for (int k = 0; k < NVR; ++k) {
-    float* pb = buf + (k & 1) * 32;
+    float* pb = buf + (k & 1) * G;
     if (lig == k) {
 #pragma unroll
       for (int c4 = 0; c4 < NVR / 4; ++c4) {
@@ -196,7 +204,7 @@ DEV void invert_rows(const float (&mrow)[NVR], float (&b)[NVR], float* buf, int 
       }
     }
     gsync();
-    const float ipk = 1.0f / bcast32(a[k], k);
+    const float ipk = 1.0f / bcastg<G>(a[k], k);
     const float f = (lig == k) ? (1.0f - ipk) : a[k] * ipk;
 #pragma unroll
     for (int c4 = 0; c4 < NVR / 4; ++c4) {
@@ -212,14 +220,13 @@ DEV void invert_rows(const float (&mrow)[NVR], float (&b)[NVR], float* buf, int 
   }
 }
 
-template <int NV4, int NR, bool NEWTON>
+template <int NV4, int NR, bool NEWTON, int G>
 DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk& b) {
-  constexpr int G = 32;
   if ((int)threadIdx.x >= b.nthreads) return;
   constexpr int NVR = 4 * NV4;
   constexpr int JS = (NV4 & 1) ? NVR : NVR + 4;
   const int nv = m.nv, nC = m.nC, njmax = d.njmax, nvp = d.nv_pad;
-  const SolveLayout lay = solve_layout<NV4, NR>(njmax);
+  const SolveLayout lay = solve_layout<NV4, NR, G>(njmax);
   int* shi = reinterpret_cast<int*>(smem);
   const MStruct ms = load_mstruct<G>(m, shi, b.nthreads);
   const int lig = threadIdx.x & (G - 1), gib = threadIdx.x / G;
@@ -230,7 +237,7 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
   float* S = smem + mstruct_ints(nv, nC) + (size_t)gib * lay.total;
   float *Jl = S + lay.J, *eforce = S + lay.force, *eda = S + lay.da, *bsearch = S + lay.bsearch, *bgrad = S + lay.bgrad, *col = S + lay.col;
 
-  const int nefc = min(min(d.nefc[w], njmax), 32 * NR);
+  const int nefc = min(min(d.nefc[w], njmax), G * NR);
   const int ne = d.ne[w], nf = d.nf[w];
   const size_t vo = (size_t)w * nv, eo = (size_t)w * njmax;
   const bool active = lig < nv;
@@ -285,7 +292,7 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
   float h[NVR], lt[NVR];  // Newton: H row / L row and L column; CG: h = row of M^-1
   float qs = 0.0f;
   if (!NEWTON) {
-    invert_rows<NVR>(mrow, h, col, lig);
+    invert_rows<NVR, G>(mrow, h, col, lig);
     bgrad[lig] = fs;
     gsync();
     qs = mul_row(h, bgrad);
@@ -295,8 +302,8 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
 #pragma unroll
     for (int c = 0; c < NVR; ++c) h[c] = mrow[c];
     float rdiag0;
-    chol_factor_rows<NVR, JS>(h, lt, rdiag0, col, lig);
-    qs = chol_solve_rows<NVR>(h, lt, rdiag0, fs);
+    chol_factor_rows<NVR, JS, G>(h, lt, rdiag0, col, lig);
+    qs = chol_solve_rows<NVR, G>(h, lt, rdiag0, fs);
     if (!active) qs = 0.0f;
   }
   float q = 0.0f;
@@ -331,7 +338,7 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
   bool rhas[NR];
 #pragma unroll
   for (int k = 0; k < NR; ++k) {
-    const int r = lig + 32 * k;
+    const int r = lig + G * k;
     rhas[k] = r < nefc;
     rD[k] = rhas[k] ? d.efc_D[eo + r] : 0.0f;
     rfl[k] = rhas[k] ? d.efc_frictionloss[eo + r] : 0.0f;
@@ -356,7 +363,7 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
     return s0 + s1;
   };
 #pragma unroll
-  for (int k = 0; k < NR; ++k) rja[k] = rhas[k] ? j_dot(bsearch, lig + 32 * k) - d.efc_aref[eo + lig + 32 * k] : 0.0f;
+  for (int k = 0; k < NR; ++k) rja[k] = rhas[k] ? j_dot(bsearch, lig + G * k) - d.efc_aref[eo + lig + G * k] : 0.0f;
   gsync();
 
   pc.mark(2);
@@ -396,8 +403,8 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
       }
       rfrc[k] = force;
       rst[k] = state;
-      eforce[lig + 32 * k] = force;
-      if (NEWTON) eda[lig + 32 * k] = state == ST_QUADRATIC ? D : 0.0f;
+      eforce[lig + G * k] = force;
+      if (NEWTON) eda[lig + G * k] = state == ST_QUADRATIC ? D : 0.0f;
     }
     gsync();
     // ---- qfrc_constraint = J^T force (solver.py:1912-1947): lane = dof, 4 rows per step ------------------------
@@ -407,7 +414,7 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
       // fully unrolled 16-row chunks: every LDS read has an immediate offset (no address arithmetic); rows between
       // nefc and the chunk boundary carry zero force and zero J
 #pragma unroll
-      for (int r0 = 0; r0 < 32 * NR; r0 += 16) {
+      for (int r0 = 0; r0 < G * NR; r0 += 16) {
         if (r0 < nefc) {
 #pragma unroll
           for (int r = r0; r < r0 + 16; r += 4) {
@@ -421,7 +428,7 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
     }
     // ---- gradient and search direction (solver.py:3061-3220) ---------------------------------------------------
     g = active ? (Ma - fs - qc) : 0.0f;
-    grad_dot = gsum32(g * g);
+    grad_dot = gsumg<G>(g * g);
     // improvement / gradient tests need no search direction: a world that passes them skips the H rebuild + Cholesky
     const bool done_early = niter > 0 && ((improvement * rscale < tolerance) || (sqrtf(grad_dot) * rscale < tolerance));
     pc.mark(3);
@@ -443,12 +450,12 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
         }
       }
       float rdiag;
-      chol_factor_rows<NVR, JS>(h, lt, rdiag, col, lig);
-      Mg = chol_solve_rows<NVR>(h, lt, rdiag, g);
+      chol_factor_rows<NVR, JS, G>(h, lt, rdiag, col, lig);
+      Mg = chol_solve_rows<NVR, G>(h, lt, rdiag, g);
       if (!active) Mg = 0.0f;
       srch = -Mg;
-      search_dot = gsum32(Mg * Mg);
-      decrement = gsum32(g * Mg);
+      search_dot = gsumg<G>(Mg * Mg);
+      decrement = gsumg<G>(g * Mg);
     } else {
       bgrad[lig] = g;
       gsync();
@@ -458,7 +465,7 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
     if (niter == 0) {
       if (!NEWTON) {  // CG: search = -Mgrad (solver.py:1663-1695)
         srch = -Mg;
-        search_dot = gsum32(Mg * Mg);
+        search_dot = gsumg<G>(Mg * Mg);
         pg = g;
         pMg = Mg;
       }
@@ -469,13 +476,13 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
         done = (imp < tolerance) || (gradient < tolerance) || (0.5f * decrement * rscale < tolerance);
       } else {
         // Polak-Ribiere (solver.py:3283-3450)
-        const float num = gsum32(g * (Mg - pMg));
-        const float den = gsum32(pg * pMg);
+        const float num = gsumg<G>(g * (Mg - pMg));
+        const float den = gsumg<G>(pg * pMg);
         const float beta = fmaxf(0.0f, num * __builtin_amdgcn_rcpf(fmaxf(MJ_MINVAL, den)));
         done = (imp < tolerance) || (gradient < tolerance);
         if (!done) {
           srch = -Mg + beta * srch;
-          search_dot = gsum32(srch * srch);
+          search_dot = gsumg<G>(srch * srch);
           pg = g;
           pMg = Mg;
         }
@@ -492,11 +499,11 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
     gsync();
     const float mvi = mul_row(mrow, bsearch);
 #pragma unroll
-    for (int k = 0; k < NR; ++k) rjv[k] = rhas[k] ? j_dot(bsearch, lig + 32 * k) : 0.0f;
+    for (int k = 0; k < NR; ++k) rjv[k] = rhas[k] ? j_dot(bsearch, lig + G * k) : 0.0f;
     pc.mark(5);
     // ---- line search (solver.py:835-1347); rows and all sums stay in registers ----------------------------------
-    const float gauss1 = gsum32(srch * (Ma - fs));
-    const float gauss2 = gsum32(0.5f * srch * mvi);
+    const float gauss1 = gsumg<G>(srch * (Ma - fs));
+    const float gauss2 = gsumg<G>(0.5f * srch * mvi);
     const float gtol = fmaxf(tolerance * ls_tolerance * sqrtf(search_dot) * scale, 1e-6f);
     auto eval = [&](float a) __attribute__((always_inline)) {
       P3 s = P3{0.0f, 0.0f, 0.0f};
@@ -511,10 +518,10 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
     };
     // group sums + the Gauss (smooth) quadratic
     auto total = [&](P3 s, float a) __attribute__((always_inline)) {
-      return P3{a * a * gauss2 + a * gauss1 + gsum32(s.c), 2.0f * a * gauss2 + gauss1 + gsum32(s.g), 2.0f * gauss2 + gsum32(s.h)};
+      return P3{a * a * gauss2 + a * gauss1 + gsumg<G>(s.c), 2.0f * a * gauss2 + gauss1 + gsumg<G>(s.g), 2.0f * gauss2 + gsumg<G>(s.h)};
     };
     const P3 e = eval(0.0f);
-    const P3 p0 = P3{0.0f, gauss1 + gsum32(e.g), 2.0f * gauss2 + gsum32(e.h)};
+    const P3 p0 = P3{0.0f, gauss1 + gsumg<G>(e.g), 2.0f * gauss2 + gsumg<G>(e.h)};
     const float lo_alpha_in = -fast_div(p0.g, p0.h);
     const P3 lo_in = total(eval(lo_alpha_in), lo_alpha_in);
     float alpha = 0.0f;
@@ -578,18 +585,12 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
 #pragma unroll
   for (int k = 0; k < NR; ++k)
     if (rhas[k]) {
-      d.efc_force[eo + lig + 32 * k] = rfrc[k];
-      d.efc_state[eo + lig + 32 * k] = rst[k];
+      d.efc_force[eo + lig + G * k] = rfrc[k];
+      d.efc_state[eo + lig + G * k] = rst[k];
     }
   if (lig == 0) {
     d.solver_niter[w] = niter;
     if (ovf) atomicOr(d.overflow + w, ovf);
   }
   pc.mark(9);
-}
-
-template <int NV4, int NR, bool NEWTON>
-__global__ void __launch_bounds__(256) k_solve(MjhModel m, MjhData d) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  solve_body<NV4, NR, NEWTON>(m, d, smem, blk_of_launch<32>());
 }

@@ -553,9 +553,12 @@ def _compile(root, base_dir):
       if child.tag == "body":
         parse_body(child, bid, cc)
 
-  wb = root.find("worldbody")
-  if wb is None:
+  # a model may hold several <worldbody> (and <actuator>, <contact>, <keyframe>) sections, typically one per included
+  # file; MuJoCo merges them in document order: all world geoms/sites first, then the bodies
+  wbs = root.findall("worldbody")
+  if not wbs:
     raise ValueError("no <worldbody>")
+  wb = [child for sec in wbs for child in sec]
   for child in wb:
     if child.tag == "geom":
       world.geoms.append(parse_geom(child, None, 0))
@@ -570,8 +573,7 @@ def _compile(root, base_dir):
       parse_body(child, 0, None)
 
   for tag in ("equality", "tendon"):
-    e = root.find(tag)
-    if e is not None and len(list(e)) > 0:
+    if any(len(list(e)) > 0 for e in root.findall(tag)):
       raise NotImplementedError(f"<{tag}> is outside the hot-path scope (SURVEY §2 OUT rows)")
 
   m = MjModel()
@@ -781,8 +783,8 @@ def _compile(root, base_dir):
 
   # actuators
   acts = []
-  ae = root.find("actuator")
-  if ae is not None:
+  ae = [child for sec in root.findall("actuator") for child in sec]
+  if ae:
     for child in ae:
       if child.tag not in _ACT_TAGS:
         continue
@@ -864,8 +866,8 @@ def _compile(root, base_dir):
   m.npair = 0
   m.pair_geom1 = np.zeros(0, dtype=np.int32)
   m.pair_geom2 = np.zeros(0, dtype=np.int32)
-  ce = root.find("contact")
-  if ce is not None:
+  ce = [child for sec in root.findall("contact") for child in sec]
+  if ce:
     sig = []
     for child in ce:
       if child.tag == "exclude":
@@ -880,9 +882,7 @@ def _compile(root, base_dir):
 
   # keyframes
   keys = []
-  ke = root.find("keyframe")
-  if ke is not None:
-    keys = [k for k in ke if k.tag == "key"]
+  keys = [k for sec in root.findall("keyframe") for k in sec if k.tag == "key"]
   m.nkey = len(keys)
   m.key_names = [k.get("name", "") for k in keys]
   m.key_time = np.zeros(m.nkey)

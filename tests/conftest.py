@@ -9,6 +9,8 @@ if ROOT not in sys.path:
   sys.path.insert(0, ROOT)
 
 HUMANOID_XML = os.path.join(ROOT, "benchmarks", "humanoid", "humanoid.xml")
+G1_XML = os.path.join(ROOT, "benchmarks", "unitree_g1", "scene_flat.xml")
+PANDA_XML = os.path.join(ROOT, "benchmarks", "franka_emika_panda", "scene.xml")
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 
 

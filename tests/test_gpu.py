@@ -382,3 +382,50 @@ def test_long_rollout_contact_records_stay_valid():
     nefc = d.nefc.numpy()
     assert (nefc >= 0).all() and (nefc <= 10 * 24 + 64).all()
     assert np.isfinite(d.qpos.numpy()).all()
+
+
+@pytest.mark.parametrize("solver", [mjw.SolverType.NEWTON, mjw.SolverType.CG])
+def test_g1_forward_and_step_match_oracle(solver):
+  """BASELINE configs[2] model (unitree_g1_flat: nv = 35 -> 64 lanes per world in the solver, njmax = 192, implicitfast,
+  position actuators, capsule feet with priority/condim mixing, contact excludes): forward fields and per-step parity."""
+  mjm = mjw.mjcf.load_xml(conftest.G1_XML)
+  assert (mjm.nv, mjm.nu, mjm.ngeom) == (35, 29, 69)
+  if solver == mjw.SolverType.CG:
+    # the model's 10 iterations leave CG far from converged, where float32 and float64 iterates legitimately differ by
+    # ~10 %; the parity statement is about the converged solution
+    mjm.opt.iterations, mjm.opt.ls_iterations = 100, 50
+  s, m, d = _pair(mjm, nworld=3, nconmax=48, njmax=192, solver=int(solver), warm_steps=10)
+  s.forward()
+  mjw.forward(m, d)
+  assert s.nefc > 32  # feet on the floor
+  _check_fields(s, d, _SMOOTH_FIELDS, SMOOTH)
+  _check_contacts_and_rows(s, d, mjm)
+  _check_fields(s, d, ("qacc_smooth",), FACTOR)
+  _check_fields(s, d, ("qacc", "qfrc_constraint"), 5e-3)
+  worst_q = worst_v = 0.0
+  for i in range(60):
+    s.ctrl_noise(10 + i, 0)
+    _sync(s, d)
+    mjw.step(m, d)
+    s.step()
+    worst_q = max(worst_q, relerr(d.qpos.numpy()[1], s.qpos))
+    worst_v = max(worst_v, relerr(d.qvel.numpy()[1], s.qvel))
+  assert worst_q <= 3e-5, worst_q  # measured 1.1e-5 (CG); 8 capsule contacts with 4 pyramid rows each, tolerance 1e-6
+  assert worst_v <= 2e-3, worst_v  # Newton: 10 solver / 20 line-search iterations, both sides stop before convergence
+
+
+def test_g1_large_batch_runs():
+  """4096 G1 worlds (the BASELINE configs[2] size) step without NaNs; identical worlds stay bitwise identical."""
+  mjm = mjw.mjcf.load_xml(conftest.G1_XML)
+  m = mjw.put_model(mjm)
+  d = mjw.make_data(mjm, nworld=4096, nconmax=48, njmax=192)
+  mjw.reset_data_keyframe(m, d, 0)
+  for i in range(20):
+    mjw.step(m, d)
+  q = d.qpos.numpy()
+  assert np.isfinite(q).all() and (q == q[0]).all()
+  assert 0.7 < q[0, 2] < 0.85  # still on its feet
+  for i in range(20):
+    mjw.ctrl_noise(m, d, i)
+    mjw.step(m, d)
+  assert np.isfinite(d.qpos.numpy()).all()

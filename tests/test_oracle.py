@@ -267,3 +267,19 @@ def test_pendula_and_pile_models_run():
     ok, qp, qv = s.rollout(200, noise_std=-1)
     assert ok == 200 and s.overflow == 0
     assert np.isfinite(qp).all()
+
+
+def test_g1_model_compiles_and_stands():
+  """BASELINE configs[2] model: two <worldbody> sections merge (floor = geom 0), mesh geoms are skipped for collision,
+  nv = 35; the oracle keeps the robot on its capsule feet over the first 60 steps from the home keyframe."""
+  from mujoco_warp_amd import mjcf
+  mjm = mjcf.load_xml(conftest.G1_XML)
+  assert (mjm.nq, mjm.nv, mjm.nbody, mjm.ngeom, mjm.nu, mjm.nkey) == (36, 35, 31, 69, 29, 1)
+  assert mjm.geom_type[0] == 0 and mjm.opt.integrator == 3 and mjm.opt.iterations == 10
+  s = ref.RefSim(mjm, nconmax=48, njmax=192)
+  s.reset(key=0)
+  s.forward()
+  assert s.ncon >= 8 and 32 <= s.nefc <= 192  # both feet (4 capsules each) on the floor
+  for i in range(40):
+    s.step()
+  assert np.isfinite(s.qpos).all() and 0.7 < s.qpos[2] < 0.85 and s.ncon >= 4
