@@ -54,7 +54,7 @@ extern "C" {
 typedef struct MjhModel {
   /* sizes */
   int nq; int nv; int nu; int na; int nbody; int njnt; int ngeom; int nsite; int nC; int npair;
-  int nbodylevel; int ndoflevel; int nv_pad;
+  int nbodylevel; int ndoflevel; int nv_pad; int neq;
   /* options (types.py:836-905) */
   int integrator; int cone; int solver; int iterations; int ls_iterations; int disableflags; int enableflags;
   const float* opt_timestep; int opt_timestep_nb;
@@ -130,6 +130,11 @@ typedef struct MjhModel {
   const float* actuator_forcerange; int actuator_forcerange_nb;
   const float* actuator_actrange; int actuator_actrange_nb;
   const float* actuator_gear; int actuator_gear_nb;
+  /* equality constraints: joint couplings only (constraint.py:500-640); eq_data = polycoef[0..4] */
+  const int* eq_obj1id; const int* eq_obj2id;
+  const float* eq_solref; int eq_solref_nb;
+  const float* eq_solimp; int eq_solimp_nb;
+  const float* eq_data; int eq_data_nb;
 } MjhModel;
 
 typedef struct MjhData {
@@ -168,6 +173,7 @@ typedef struct MjhData {
   int* ws_conadr;      /* [nworld]   exclusive scan of ws_ncon = first public slot (k_contact_scan) */
   int* ws_ncollision;  /* [nworld]   broadphase candidates per world                  */
   int* ws_order;       /* [nworld]   solver schedule: worlds sorted by last step's solver_niter (longest first) */
+  int* eq_active;      /* [nworld, neq] Data.eq_active (types.py:2262), initialised from eq_active0 */
   float* ws_contact;   /* [nworld, concap, 32] per-world contact records (collision -> make_constraint hand-off;
                           the public contact_* arrays are compacted from these off the critical path) */
 } MjhData;

@@ -106,7 +106,53 @@ DEV void make_constraint_body(const MjhModel& m, const MjhData& d, float* smem, 
   gsync();
   pc.mark(0);
 
-  int nefc = 0, nf = 0, nl = 0;
+  int nefc = 0, ne = 0, nf = 0, nl = 0;
+  // ---- equality constraints: joint couplings (constraint.py:500-640); rows in equality-id order -------------
+  if (!(dsbl & DSBL_EQUALITY)) {
+    const int neq = m.neq;
+    const float* qpos0 = bf(m.qpos0, m.qpos0_nb, w, m.nq);
+    for (int base = 0; base < neq; base += G) {
+      const int e = base + lig;
+      const bool act = e < neq && d.eq_active[(size_t)w * neq + e] != 0;
+      int tot;
+      const int r = nefc + grank<G>(act, lig, tot);
+      if (act && r < njmax) {
+        const int j1 = m.eq_obj1id[e], j2 = m.eq_obj2id[e];
+        const float* data = bf(m.eq_data, m.eq_data_nb, w, 11 * neq) + 11 * e;
+        const int dof1 = m.jnt_dofadr[j1], qa1 = m.jnt_qposadr[j1];
+        for (int c = 0; c < nvp; ++c) J[(size_t)r * nvp + c] = 0.0f;
+        J[(size_t)r * nvp + dof1] = 1.0f;
+        float pos, vel, invweight;
+        if (j2 >= 0) {
+          const int dof2 = m.jnt_dofadr[j2], qa2 = m.jnt_qposadr[j2];
+          const float dif = qpos[qa2] - qpos0[qa2];
+          const float rhs = data[0] + dif * (data[1] + dif * (data[2] + dif * (data[3] + dif * data[4])));
+          const float deriv = data[1] + dif * (2.0f * data[2] + dif * (3.0f * data[3] + dif * 4.0f * data[4]));
+          pos = qpos[qa1] - qpos0[qa1] - rhs;
+          vel = qvel[dof1] - qvel[dof2] * deriv;
+          invweight = invw[dof1] + invw[dof2];
+          J[(size_t)r * nvp + dof2] = -deriv;
+        } else {
+          pos = qpos[qa1] - qpos0[qa1] - data[0];
+          vel = qvel[dof1];
+          invweight = invw[dof1];
+        }
+        EfcRowOut o = efc_row(dsbl, timestep, pos, pos, invweight, bf(m.eq_solref, m.eq_solref_nb, w, 2 * neq) + 2 * e,
+                              bf(m.eq_solimp, m.eq_solimp_nb, w, 5 * neq) + 5 * e, 0.0f, vel);
+        d.efc_D[eo + r] = o.D;
+        d.efc_aref[eo + r] = o.aref;
+        d.efc_pos[eo + r] = o.pos;
+        d.efc_margin[eo + r] = 0.0f;
+        d.efc_vel[eo + r] = vel;
+        d.efc_frictionloss[eo + r] = 0.0f;
+        d.efc_type[eo + r] = CT_EQUALITY;
+        d.efc_id[eo + r] = e;
+      }
+      nefc += tot;
+      ne += tot;
+    }
+  }
+  const int nrow_equality = nefc;
   // ---- dof friction loss (constraint.py:1766-1865) ---------------------------------------------------------
   if (!(dsbl & DSBL_FRICTIONLOSS)) {
     const float* fl = bf(m.dof_frictionloss, m.dof_frictionloss_nb, w, nv);
@@ -197,13 +243,13 @@ DEV void make_constraint_body(const MjhModel& m, const MjhData& d, float* smem, 
   // cooperative, coalesced write of the (one-hot) friction/limit rows of J
   {
     const int nrow = min(nefc, njmax);
-    for (int idx = lig; idx < nrow * nvp; idx += G) {
+    for (int idx = nrow_equality * nvp + lig; idx < nrow * nvp; idx += G) {  // equality rows were written above
       const int r = idx / nvp, c = idx - r * nvp;
       J[idx] = (c == rowdof[r]) ? rowval[r] : 0.0f;
     }
     if (nball > 0) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      for (int r = lig; r < nrow; r += G)
+      for (int r = nrow_equality + lig; r < nrow; r += G)
         if (rowdof[r] < 0) {
           const int dof = -rowdof[r] - 1;
           const int j = m.dof_jntid[dof];
@@ -375,7 +421,7 @@ DEV void make_constraint_body(const MjhModel& m, const MjhData& d, float* smem, 
     }
   }
   if (lig == 0) {
-    d.ne[w] = 0;
+    d.ne[w] = ne;
     d.nf[w] = nf;
     d.nl[w] = nl;
     d.nefc[w] = nefc;

@@ -86,7 +86,9 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
   """
   opt = mjm.opt
   # ---- validation (io.py:284-360) ----
-  for name in ("ntendon", "neq", "nflex", "nhfield", "nmocap", "nplugin"):
+  if int(getattr(mjm, "neq", 0)) > 0 and (np.asarray(mjm.eq_type) != types.EqType.JOINT).any():
+    raise NotImplementedError("only joint equality constraints are implemented")
+  for name in ("ntendon", "nflex", "nhfield", "nmocap", "nplugin"):
     if int(getattr(mjm, name, 0)) > 0:
       raise NotImplementedError(f"{name} > 0 is outside the hot-path scope of this engine")
   if int(opt.integrator) not in (types.IntegratorType.EULER, types.IntegratorType.IMPLICITFAST):
@@ -211,7 +213,13 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
     actuator_biastype=_arr(mjm.actuator_biastype, i32), actuator_trnid=_arr(mjm.actuator_trnid, i32).reshape(-1, 2),
     actuator_actadr=_arr(mjm.actuator_actadr, i32), actuator_ctrllimited=_arr(mjm.actuator_ctrllimited, i32),
     actuator_forcelimited=_arr(mjm.actuator_forcelimited, i32), actuator_actlimited=_arr(mjm.actuator_actlimited, i32),
+    eq_obj1id=_arr(getattr(mjm, "eq_obj1id", np.zeros(0)), i32), eq_obj2id=_arr(getattr(mjm, "eq_obj2id", np.zeros(0)), i32),
   )
+  neq = int(getattr(mjm, "neq", 0))
+  host["eq_solref"] = _arr(getattr(mjm, "eq_solref", np.zeros((0, 2))), f32).reshape(1, neq, 2)
+  host["eq_solimp"] = _arr(getattr(mjm, "eq_solimp", np.zeros((0, 5))), f32).reshape(1, neq, 5)
+  host["eq_data"] = _arr(getattr(mjm, "eq_data", np.zeros((0, 11))), f32).reshape(1, neq, 11)
+  m.eq_active0 = _arr(getattr(mjm, "eq_active0", np.zeros(0)), i32)
   vec = {"body_pos": 3, "body_quat": 4, "body_ipos": 3, "body_iquat": 4, "body_inertia": 3, "body_invweight0": 2,
          "jnt_solref": 2, "jnt_solimp": 5, "jnt_pos": 3, "jnt_axis": 3, "jnt_range": 2, "dof_solref": 2, "dof_solimp": 5,
          "geom_solref": 2, "geom_solimp": 5, "geom_size": 3, "geom_pos": 3, "geom_quat": 4, "geom_friction": 3,
@@ -312,7 +320,7 @@ def _data_shapes(m, nworld, nconmax, njmax, naconmax):
     efc_type=(W, njmax), efc_id=(W, njmax), efc_state=(W, njmax), efc_J=(W, njmax_pad, nv_pad), efc_pos=(W, njmax),
     efc_margin=(W, njmax), efc_D=(W, njmax), efc_vel=(W, njmax), efc_aref=(W, njmax), efc_frictionloss=(W, njmax),
     efc_force=(W, njmax), ws_ncon=(W,), ws_conadr=(W,), ws_ncollision=(W,), ws_order=(W,),
-    ws_contact=(W, contact_cap(nconmax), 32),
+    eq_active=(W, m.neq), ws_contact=(W, contact_cap(nconmax), 32),
   )
   return sh, njmax_pad, nv_pad
 
@@ -343,6 +351,8 @@ def _alloc_data(m: types.Model, nworld, nconmax, njmax, naconmax):
     _set_data_field(d, name, arr)
   d.nworld, d.nconmax, d.naconmax, d.njmax, d.njmax_pad, d.nv_pad = nworld, nconmax, naconmax, njmax, njmax_pad, nv_pad
   d.ws_order.assign(np.arange(nworld, dtype=np.int32))
+  if m.neq:
+    d.eq_active.assign(np.tile(m.eq_active0, (nworld, 1)))
   d.nmaxpyramid = m.nmaxpyramid
   d.world_offset = 0
   d.concap = contact_cap(nconmax)
@@ -498,6 +508,8 @@ def _reset_state(m, d, qpos, qvel, act, ctrl, time, mask):
   put(d.qfrc_applied, None)
   put(d.xfrc_applied, None)
   put(d.time, np.full(d.time.shape, time, dtype=np.float32))
+  if m.neq:
+    put(d.eq_active, np.tile(m.eq_active0, (d.nworld, 1)))
   if mask is None:
     for name in ("nefc", "ne", "nf", "nl", "solver_niter", "overflow", "nacon", "ncollision", "ws_ncon", "ws_conadr"):
       getattr(d, name).zero_()

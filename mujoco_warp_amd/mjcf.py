@@ -572,9 +572,8 @@ def _compile(root, base_dir):
     if child.tag == "body":
       parse_body(child, 0, None)
 
-  for tag in ("equality", "tendon"):
-    if any(len(list(e)) > 0 for e in root.findall(tag)):
-      raise NotImplementedError(f"<{tag}> is outside the hot-path scope (SURVEY §2 OUT rows)")
+  if any(len(list(e)) > 0 for e in root.findall("tendon")):
+    raise NotImplementedError("<tendon> is outside the hot-path scope (SURVEY §2 OUT rows)")
 
   m = MjModel()
   m.opt, m.stat = opt, stat
@@ -861,6 +860,33 @@ def _compile(root, base_dir):
       na += 1
   m.na = na
 
+  # equality constraints: joint couplings only (constraint.py:500-640; Panda's finger coupling)
+  eqs = []
+  for child in (c for sec in root.findall("equality") for c in sec):
+    if child.tag != "joint":
+      raise NotImplementedError(f"<equality><{child.tag}> is outside the hot-path scope (only joint equalities are built)")
+    base, explicit = _resolve("equality", child, table, None)
+    a = dict(base)
+    a.update(explicit)
+    j2 = a.get("joint2")
+    data = np.zeros(11)
+    data[:5] = _vec(a, "polycoef", [0.0, 1.0, 0.0, 0.0, 0.0])
+    eqs.append({"obj1": m.jnt_names.index(a["joint1"]), "obj2": m.jnt_names.index(j2) if j2 else -1,
+                "active": _bool(a.get("active", "true")), "solref": _vec(a, "solref", [0.02, 1.0]),
+                "solimp": _vec(a, "solimp", [0.9, 0.95, 0.001, 0.5, 2.0]), "data": data})
+  for e in eqs:
+    for jid in (e["obj1"], e["obj2"]):
+      if jid >= 0 and m.jnt_type[jid] not in (2, 3):
+        raise ValueError("joint equality needs slide or hinge joints")
+  m.neq = len(eqs)
+  m.eq_type = np.full(m.neq, 2, dtype=np.int32)  # mjEQ_JOINT
+  m.eq_obj1id = np.array([e["obj1"] for e in eqs], dtype=np.int32)
+  m.eq_obj2id = np.array([e["obj2"] for e in eqs], dtype=np.int32)
+  m.eq_active0 = np.array([int(e["active"]) for e in eqs], dtype=np.int32)
+  m.eq_solref = np.array([e["solref"] for e in eqs]).reshape(-1, 2)
+  m.eq_solimp = np.array([e["solimp"] for e in eqs]).reshape(-1, 5)
+  m.eq_data = np.array([e["data"] for e in eqs]).reshape(-1, 11)
+
   # contact excludes / pairs
   m.exclude_signature = np.zeros(0, dtype=np.int32)
   m.npair = 0
@@ -901,7 +927,7 @@ def _compile(root, base_dir):
         arr[i] = v
 
   # sizes not on the hot path
-  m.neq = m.ntendon = m.nsensor = m.nmesh = m.nhfield = m.nflex = m.nplugin = 0
+  m.ntendon = m.nsensor = m.nmesh = m.nhfield = m.nflex = m.nplugin = 0
   m.ncam = m.nlight = 0
   m.nuserdata = m.nsensordata = 0
 

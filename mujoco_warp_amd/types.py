@@ -147,6 +147,14 @@ class ConstraintState(enum.IntEnum):
   CONE = 4
 
 
+class EqType(enum.IntEnum):
+  CONNECT = 0
+  WELD = 1
+  JOINT = 2
+  TENDON = 3
+  FLEX = 4
+
+
 class ConstraintType(enum.IntEnum):
   EQUALITY = 0
   FRICTION_DOF = 1

@@ -22,7 +22,7 @@ enum { G_PLANE = 0, G_HFIELD, G_SPHERE, G_CAPSULE, G_ELLIPSOID, G_CYLINDER, G_BO
 enum { ST_SATISFIED = 0, ST_QUADRATIC = 1, ST_LINEARNEG = 2, ST_LINEARPOS = 3, ST_CONE = 4 };
 enum { CT_EQUALITY = 0, CT_FRICTION_DOF = 1, CT_FRICTION_TENDON = 2, CT_LIMIT_JOINT = 3, CT_LIMIT_TENDON = 4,
        CT_CONTACT_FRICTIONLESS = 5, CT_CONTACT_PYRAMIDAL = 6, CT_CONTACT_ELLIPTIC = 7 };
-enum { DSBL_CONSTRAINT = 1 << 0, DSBL_FRICTIONLOSS = 1 << 2, DSBL_LIMIT = 1 << 3, DSBL_CONTACT = 1 << 4,
+enum { DSBL_CONSTRAINT = 1 << 0, DSBL_EQUALITY = 1 << 1, DSBL_FRICTIONLOSS = 1 << 2, DSBL_LIMIT = 1 << 3, DSBL_CONTACT = 1 << 4,
        DSBL_SPRING = 1 << 5, DSBL_DAMPER = 1 << 6, DSBL_GRAVITY = 1 << 7, DSBL_CLAMPCTRL = 1 << 8,
        DSBL_WARMSTART = 1 << 9, DSBL_ACTUATION = 1 << 11, DSBL_REFSAFE = 1 << 12, DSBL_EULERDAMP = 1 << 15 };
 enum { SOL_PGS = 0, SOL_CG = 1, SOL_NEWTON = 2 };
@@ -878,6 +878,36 @@ void ref_make_constraint(const RefModel* m, RefData* d) {
   d->ne = d->nf = d->nl = d->nefc = 0;
   if (m->disableflags & DSBL_CONSTRAINT) return;
   int nefc = 0;
+  /* equality constraints, joint couplings only: constraint.py:500-640 (_equality_joint) */
+  if (!(m->disableflags & DSBL_EQUALITY)) {
+    for (int e = 0; e < m->neq; e++) {
+      if (!m->eq_active0[e]) continue;
+      d->ne++;
+      int r = nefc++;
+      if (r >= njmax) continue;
+      int j1 = m->eq_obj1id[e], j2 = m->eq_obj2id[e];
+      const double* data = m->eq_data + 11 * e;
+      int dof1 = m->jnt_dofadr[j1], qa1 = m->jnt_qposadr[j1];
+      memset(d->efc_J + (size_t)r * nv, 0, sizeof(double) * nv);
+      d->efc_J[(size_t)r * nv + dof1] = 1.0;
+      double pos, vel, invweight;
+      if (j2 >= 0) {
+        int dof2 = m->jnt_dofadr[j2], qa2 = m->jnt_qposadr[j2];
+        double dif = d->qpos[qa2] - m->qpos0[qa2];
+        double rhs = data[0] + dif * (data[1] + dif * (data[2] + dif * (data[3] + dif * data[4])));
+        double deriv = data[1] + dif * (2.0 * data[2] + dif * (3.0 * data[3] + dif * 4.0 * data[4]));
+        pos = d->qpos[qa1] - m->qpos0[qa1] - rhs;
+        vel = d->qvel[dof1] - d->qvel[dof2] * deriv;
+        invweight = m->dof_invweight0[dof1] + m->dof_invweight0[dof2];
+        d->efc_J[(size_t)r * nv + dof2] = -deriv;
+      } else {
+        pos = d->qpos[qa1] - m->qpos0[qa1] - data[0];
+        vel = d->qvel[dof1];
+        invweight = m->dof_invweight0[dof1];
+      }
+      efc_row(m, d, r, pos, pos, invweight, m->eq_solref + 2 * e, m->eq_solimp + 5 * e, 0.0, vel, 0.0, CT_EQUALITY, e);
+    }
+  }
   /* dof friction: constraint.py:1766-1865 */
   if (!(m->disableflags & DSBL_FRICTIONLOSS)) {
     for (int i = 0; i < nv; i++) {

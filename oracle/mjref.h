@@ -26,6 +26,7 @@ typedef struct RefModel {
   int ngeom;
   int nC;
   int npair;
+  int neq;
   int njmax;
   int nconmax;
   int integrator;
@@ -112,6 +113,12 @@ typedef struct RefModel {
   double* actuator_forcerange;
   double* actuator_actrange;
   double* actuator_gear;
+  int* eq_obj1id;
+  int* eq_obj2id;
+  int* eq_active0;
+  double* eq_solref;
+  double* eq_solimp;
+  double* eq_data;
 } RefModel;
 
 typedef struct RefData {

@@ -131,6 +131,7 @@ class RefSim:
                  nC=int(mjm.M_rownnz.sum()) if mjm.nv else 0, njmax=njmax, nconmax=nconmax)
     pairs = filtered_geom_pairs(mjm)
     sizes["npair"] = len(pairs)
+    sizes["neq"] = int(getattr(mjm, "neq", 0))
     scalars = dict(
       integrator=int(opt.integrator if integrator is None else integrator), cone=int(opt.cone),
       solver=int(opt.solver if solver is None else solver),

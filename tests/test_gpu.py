@@ -429,3 +429,37 @@ def test_g1_large_batch_runs():
     mjw.ctrl_noise(m, d, i)
     mjw.step(m, d)
   assert np.isfinite(d.qpos.numpy()).all()
+
+
+@pytest.mark.parametrize("solver", [mjw.SolverType.NEWTON, mjw.SolverType.CG])
+def test_panda_equality_implicitfast_match_oracle(solver):
+  """BASELINE configs[3] model (franka_emika_panda: nv = 9, implicitfast, position/general actuators with affine bias and
+  velocity gain, a joint equality coupling the fingers, joint limits, plane-box finger pads): forward + per-step parity."""
+  mjm = mjw.mjcf.load_xml(conftest.PANDA_XML)
+  assert (mjm.nv, mjm.nu, mjm.neq) == (9, 8, 1)
+  mjm.opt.iterations, mjm.opt.ls_iterations = 100, 50
+  s, m, d = _pair(mjm, nworld=3, nconmax=8, njmax=16, solver=int(solver), warm_steps=0)
+  rng = np.random.default_rng(3)
+  s.qpos[:7] = 0.3 * rng.standard_normal(7)
+  s.qpos[3] = -1.5
+  s.qpos[7:9] = (0.03, 0.01)  # fingers apart: the equality row is active and violated
+  s.qvel[:] = 0.2 * rng.standard_normal(9)
+  s.ctrl[:] = 0.2 * rng.standard_normal(8)
+  _sync(s, d)
+  s.forward()
+  mjw.forward(m, d)
+  assert s.ne == 1 and int(d.ne.numpy()[0]) == 1
+  _check_fields(s, d, _SMOOTH_FIELDS, SMOOTH)
+  _check_contacts_and_rows(s, d, mjm)
+  _check_solution(s, d)
+  worst_q = worst_v = 0.0
+  for i in range(100):
+    s.ctrl_noise(i, 0)
+    _sync(s, d)
+    mjw.step(m, d)
+    s.step()
+    worst_q = max(worst_q, relerr(d.qpos.numpy()[1], s.qpos))
+    worst_v = max(worst_v, relerr(d.qvel.numpy()[1], s.qvel))
+  assert worst_q <= 1e-5, worst_q
+  assert worst_v <= 1e-3, worst_v
+  assert abs(s.qpos[7] - s.qpos[8]) < 5e-3  # the coupling pulled the fingers together

@@ -106,7 +106,7 @@ def test_struct_layout_matches_header():
   names = [n for n, _, _ in _abi.MODEL_FIELDS]
   assert names[:3] == ["nq", "nv", "nu"] and "nxn_geom_pair" in names and "body_dofmask" in names
   dnames = [n for n, _, _ in _abi.DATA_FIELDS]
-  assert dnames[0] == "nworld" and "efc_J" in dnames and dnames[-1] == "ws_contact"
+  assert dnames[0] == "nworld" and "efc_J" in dnames and dnames[-1] == "ws_contact" and "eq_active" in dnames
   # every batched pointer has its _nb companion right after it
   for i, (n, k, p) in enumerate(_abi.MODEL_FIELDS):
     if n.endswith("_nb"):

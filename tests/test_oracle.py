@@ -283,3 +283,21 @@ def test_g1_model_compiles_and_stands():
   for i in range(40):
     s.step()
   assert np.isfinite(s.qpos).all() and 0.7 < s.qpos[2] < 0.85 and s.ncon >= 4
+
+
+def test_panda_joint_equality_couples_the_fingers():
+  """BASELINE configs[3] model: <equality><joint> (polycoef 0 1 0 0 0) is an always-active row (ne = 1) that drives
+  finger_joint1 - finger_joint2 to zero; its Jacobian row is (+1, -1) on the two finger dofs."""
+  from mujoco_warp_amd import mjcf
+  mjm = mjcf.load_xml(conftest.PANDA_XML)
+  assert (mjm.nq, mjm.nv, mjm.nu, mjm.neq, mjm.opt.integrator) == (9, 9, 8, 1, 3)
+  s = ref.RefSim(mjm, nconmax=8, njmax=16)
+  s.reset()
+  s.qpos[7] = 0.03
+  s.forward()
+  assert s.ne == 1 and s.efc_type[0] == 0
+  np.testing.assert_allclose(s.efc_J[0], [0, 0, 0, 0, 0, 0, 0, 1, -1])
+  np.testing.assert_allclose(s.efc_pos[0], 0.03)
+  for i in range(150):
+    s.step()
+  assert np.isfinite(s.qpos).all() and abs(s.qpos[7] - s.qpos[8]) < 1e-4
