@@ -239,6 +239,7 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
 
   const int nefc = min(min(d.nefc[w], njmax), G * NR);
   const int ne = d.ne[w], nf = d.nf[w];
+  const bool has_fl = nf > 0;  // friction-loss rows present: the line search needs the three-zone cost (rare)
   const size_t vo = (size_t)w * nv, eo = (size_t)w * njmax;
   const bool active = lig < nv;
   const int ligr = lig < NVR ? lig : NVR - 1;  // clamped row index for lanes beyond the matrix
@@ -387,19 +388,15 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
       const float ja = rja[k], D = rD[k];
-      float force = 0.0f;
-      int state = ST_SATISFIED;
-      if (rkind[k] == 0) {
-        force = -D * ja;
-        state = ST_QUADRATIC;
-      } else if (rkind[k] == 1) {
+      // equality rows are always active, limit/contact rows when violated, padding rows (D = 0) never: branch-free
+      const bool quad = rkind[k] == 0 || (rkind[k] == 2 && ja < 0.0f);
+      float force = quad ? -D * ja : 0.0f;
+      int state = quad ? ST_QUADRATIC : ST_SATISFIED;
+      if (has_fl && rkind[k] == 1) {  // friction loss: three zones
         const float f = rfl[k], rf = safe_div(f, D);
         if (ja <= -rf) { force = f; state = ST_LINEARNEG; }
         else if (ja >= rf) { force = -f; state = ST_LINEARPOS; }
         else { force = -D * ja; state = ST_QUADRATIC; }
-      } else if (rkind[k] == 2 && ja < 0.0f) {
-        force = -D * ja;
-        state = ST_QUADRATIC;
       }
       rfrc[k] = force;
       rst[k] = state;
@@ -505,14 +502,37 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
     const float gauss1 = gsumg<G>(srch * (Ma - fs));
     const float gauss2 = gsumg<G>(0.5f * srch * mvi);
     const float gtol = fmaxf(tolerance * ls_tolerance * sqrtf(search_dot) * scale, 1e-6f);
+    // per-row constants of the ray (solver.py:518-556): cost(a) - cost(0) = a (grad0 + a hess / 2) + cact when the
+    // row is active at a, cin otherwise; equality rows are always active, padding rows have D = jv = 0
+    float ehess[NR], egrad0[NR], ecact[NR], ecin[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      const float jvD = rjv[k] * rD[k], quad0 = 0.5f * rD[k] * rja[k] * rja[k];
+      const float cost0 = (rkind[k] == 0 || rja[k] < 0.0f) ? quad0 : 0.0f;
+      ehess[k] = rjv[k] * jvD;
+      egrad0[k] = jvD * rja[k];
+      ecact[k] = quad0 - cost0;
+      ecin[k] = -cost0;
+    }
     auto eval = [&](float a) __attribute__((always_inline)) {
       P3 s = P3{0.0f, 0.0f, 0.0f};
+      if (!has_fl) {  // equality / limit / contact rows only: branch-free
+        const float ha = 0.5f * a;
 #pragma unroll
-      for (int k = 0; k < NR; ++k) {
-        const P3 t = eval_row(rja[k], rjv[k], rD[k], rfl[k], rkind[k], a);
-        s.c += t.c;
-        s.g += t.g;
-        s.h += t.h;
+        for (int k = 0; k < NR; ++k) {
+          const bool act = rkind[k] == 0 || (rja[k] + a * rjv[k] < 0.0f);
+          s.c += act ? a * (egrad0[k] + ha * ehess[k]) + ecact[k] : ecin[k];
+          s.g += act ? egrad0[k] + a * ehess[k] : 0.0f;
+          s.h += act ? ehess[k] : 0.0f;
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+          const P3 t = eval_row(rja[k], rjv[k], rD[k], rfl[k], rkind[k], a);
+          s.c += t.c;
+          s.g += t.g;
+          s.h += t.h;
+        }
       }
       return s;
     };
@@ -538,26 +558,31 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
         const float a_lo = lo_alpha - fast_div(lo.g, lo.h), a_hi = hi_alpha - fast_div(hi.g, hi.h);
         const float a_mid = 0.5f * (lo_alpha + hi_alpha);
         const P3 lo_next = total(eval(a_lo), a_lo), hi_next = total(eval(a_hi), a_hi), mid = total(eval(a_mid), a_mid);
+        // conditional moves, not branches: the six updates are wave-divergent between the two worlds of a wavefront
+        auto take = [](bool c, P3& dst, float& da, const P3& src, float sa) __attribute__((always_inline)) {
+          dst.c = c ? src.c : dst.c;
+          dst.g = c ? src.g : dst.g;
+          dst.h = c ? src.h : dst.h;
+          da = c ? sa : da;
+        };
         const bool s1 = in_bracket(lo, lo_next);
-        if (s1) { lo = lo_next; lo_alpha = a_lo; }
+        take(s1, lo, lo_alpha, lo_next, a_lo);
         const bool s2 = in_bracket(lo, mid);
-        if (s2) { lo = mid; lo_alpha = a_mid; }
+        take(s2, lo, lo_alpha, mid, a_mid);
         const bool s3 = in_bracket(lo, hi_next);
-        if (s3) { lo = hi_next; lo_alpha = a_hi; }
+        take(s3, lo, lo_alpha, hi_next, a_hi);
         const bool h1 = in_bracket(hi, hi_next);
-        if (h1) { hi = hi_next; hi_alpha = a_hi; }
+        take(h1, hi, hi_alpha, hi_next, a_hi);
         const bool h2 = in_bracket(hi, mid);
-        if (h2) { hi = mid; hi_alpha = a_mid; }
+        take(h2, hi, hi_alpha, mid, a_mid);
         const bool h3 = in_bracket(hi, lo_next);
-        if (h3) { hi = lo_next; hi_alpha = a_lo; }
+        take(h3, hi, hi_alpha, lo_next, a_lo);
         const bool swap_lo = s1 || s2 || s3, swap_hi = h1 || h2 || h3;
         const bool ls_done = (!swap_lo && !swap_hi) || (lo.c < 0.0f && lo.g < 0.0f && lo.g > -gtol) || (hi.c < 0.0f && hi.g > 0.0f && hi.g < gtol);
         const bool improved = lo.c < 0.0f || hi.c < 0.0f;
         const bool lo_better = lo.c < hi.c;
-        if (improved) {
-          alpha = lo_better ? lo_alpha : hi_alpha;
-          improvement = -(lo_better ? lo.c : hi.c);
-        }
+        alpha = improved ? (lo_better ? lo_alpha : hi_alpha) : alpha;
+        improvement = improved ? -(lo_better ? lo.c : hi.c) : improvement;
         if (ls_done) {
           ls_converged = true;
           break;
