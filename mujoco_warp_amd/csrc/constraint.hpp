@@ -33,8 +33,14 @@ DEV EfcRowOut efc_row(int dsbl, float timestep, float pos_aref, float pos_imp, f
   if (solref[0] <= 0.0f) k = -solref[0] / dmax_sq;
   if (solref[1] <= 0.0f) b = -solref[1] / dmax;
   const float imp_x = fabsf(pos_imp) / width;
-  const float imp_a = (1.0f / powf(mid, power - 1.0f)) * powf(imp_x, power);
-  const float imp_b = 1.0f - (1.0f / powf(1.0f - mid, power - 1.0f)) * powf(1.0f - imp_x, power);
+  float imp_a, imp_b;
+  if (power == 2.0f) {  // MuJoCo's default: x^2 / mid and 1 - (1-x)^2 / (1-mid) without four powf expansions (~300 VALU ops)
+    imp_a = imp_x * imp_x / mid;
+    imp_b = 1.0f - (1.0f - imp_x) * (1.0f - imp_x) / (1.0f - mid);
+  } else {
+    imp_a = (1.0f / powf(mid, power - 1.0f)) * powf(imp_x, power);
+    imp_b = 1.0f - (1.0f / powf(1.0f - mid, power - 1.0f)) * powf(1.0f - imp_x, power);
+  }
   const float imp_y = imp_x < mid ? imp_a : imp_b;
   float imp = dmin + imp_y * (dmax - dmin);
   imp = clampf(imp, dmin, dmax);
