@@ -152,7 +152,7 @@ static int launch_integrate(const MjhModel* m, const MjhData* d, int mode, hipSt
 // the workgroups of a launch different roles:
 //   k_mid           : {collision -> make_constraint} workgroups interleaved with fwd_vel workgroups (both only depend
 //                     on k_fwd_pos; both are latency-bound, so they share the CUs)
-//   k_solve_plus    : solver workgroups (longest expected solve first), then factor_smooth workgroups: dispatched last,
+//   k_solve_plus    : solver workgroups (longest expected solve first), then factor_smooth and publish workgroups: dispatched last,
 //                     they fill the CUs that the solver's stragglers leave idle
 //   k_fwd_pos_plus  : k_fwd_pos + one workgroup computing the solver schedule from the previous step's solver_niter
 //   k_integrate_plus: integrator workgroups, then publish_contacts workgroups
@@ -173,15 +173,16 @@ __global__ void __launch_bounds__(256) k_mid(MjhModel m, MjhData d, int ncc, int
   }
 }
 template <int NV4, int NR, bool NEWTON, int SG>
-__global__ void __launch_bounds__(256) k_solve_plus(MjhModel m, MjhData d, int nsolve) {
+__global__ void __launch_bounds__(256) k_solve_plus(MjhModel m, MjhData d, int nsolve, int nfac) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int wpb = blockDim.x / SG;
   if ((int)blockIdx.x < nsolve) solve_body<NV4, NR, NEWTON, SG>(m, d, smem, Blk{(int)blockIdx.x * wpb, wpb, (int)blockDim.x});
-  // CG only: the Newton kernel holds 256 VGPRs (one wave per SIMD), which would throttle the factor workgroups too
-  // (measured +120 us); for Newton they ride along with the integrator launch instead
+  // CG only: the Newton kernel holds 256 VGPRs (one wave per SIMD), which would throttle the riders too (measured
+  // +120 us); for Newton they ride along with the integrator launch instead
   else if (!NEWTON) {
-    const int wf = blockDim.x / 32;
-    factor_smooth_body<32>(m, d, 0, smem, Blk{((int)blockIdx.x - nsolve) * wf, wf, (int)blockDim.x});
+    const int wf = blockDim.x / 32, bi = (int)blockIdx.x - nsolve;
+    if (bi < nfac) factor_smooth_body<32>(m, d, 0, smem, Blk{bi * wf, wf, (int)blockDim.x});
+    else publish_body<32>(d, 1, reinterpret_cast<int*>(smem), Blk{(bi - nfac) * wf, wf, (int)blockDim.x});
   }
 }
 template <int G>
@@ -245,7 +246,8 @@ static int launch_solve_t(const MjhModel* m, const MjhData* d, bool with_factor,
   if (with_factor) lds = std::max(lds, ms_bytes + sizeof(float) * fl.total * wf);
   HIPCHK(set_lds((k_solve_plus<NV4, NR, NEWTON, SG>), lds));
   const int nsolve = (d->nworld + wpb - 1) / wpb, nfac = with_factor ? (d->nworld + wf - 1) / wf : 0;
-  hipLaunchKernelGGL((k_solve_plus<NV4, NR, NEWTON, SG>), dim3(nsolve + nfac), dim3(threads), lds, s, *m, *d, nsolve);
+  // riders (fused step, CG): factor workgroups, then as many contact-publication workgroups
+  hipLaunchKernelGGL((k_solve_plus<NV4, NR, NEWTON, SG>), dim3(nsolve + 2 * nfac), dim3(threads), lds, s, *m, *d, nsolve, nfac);
   return MJH_OK;
 }
 template <int NR, bool NEWTON>
@@ -295,8 +297,10 @@ static int launch_integrate_plus(const MjhModel* m, const MjhData* d, int mode, 
   if (lds > (size_t)kLdsPerCU) return fail(MJH_E_UNSUPPORTED, "k_integrate: does not fit in LDS");
   HIPCHK(set_lds(k_integrate_plus<G>, lds));
   const int nb = (d->nworld + 7) / 8;
-  hipLaunchKernelGGL(k_integrate_plus<G>, dim3((integrate ? nb : 0) + nb + (with_factor ? nb : 0)), dim3(256), lds, s, *m, *d, mode,
-                     integrate ? nb : 0, nb);
+  // Newton: publication and factor workgroups ride here; CG: they already rode with the solver launch
+  const int nint = integrate ? nb : 0, npub = with_factor ? nb : 0, nfac = with_factor ? nb : 0;
+  if (nint + npub + nfac == 0) return MJH_OK;
+  hipLaunchKernelGGL(k_integrate_plus<G>, dim3(nint + npub + nfac), dim3(256), lds, s, *m, *d, mode, nint, npub);
   return MJH_OK;
 }
 static int launch_pos_plus(const MjhModel* m, const MjhData* d, int first, int last, hipStream_t s) {

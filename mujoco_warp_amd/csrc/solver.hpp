@@ -329,8 +329,18 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
   const int nefc4 = (nefc + 3) & ~3;
   {
     const float* Jg = d.efc_J + (size_t)w * d.njmax_pad * nvp;
-    for (int r = 0; r < nefc; ++r)
-      for (int c = lig; c < JS; c += G) Jl[r * JS + c] = c < nvp ? Jg[(size_t)r * nvp + c] : 0.0f;
+    if (nvp == JS) {
+      // same row stride in HBM and LDS: one flat copy with 16-byte loads, all in flight (a world's J block is 16-byte
+      // aligned: njmax_pad * nv_pad is a multiple of 4)
+      const float4* src = reinterpret_cast<const float4*>(Jg);
+      float4* dst = reinterpret_cast<float4*>(Jl);
+      const int n4 = nefc * (JS / 4);
+#pragma unroll 4
+      for (int i = lig; i < n4; i += G) dst[i] = src[i];
+    } else {
+      for (int r = 0; r < nefc; ++r)
+        for (int c = lig; c < JS; c += G) Jl[r * JS + c] = c < nvp ? Jg[(size_t)r * nvp + c] : 0.0f;
+    }
     for (int r = nefc; r < ((nefc + 15) & ~15); ++r)  // zero rows up to the next 16-row chunk boundary
       for (int c = lig; c < JS; c += G) Jl[r * JS + c] = 0.0f;
   }
