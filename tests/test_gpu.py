@@ -463,3 +463,53 @@ def test_panda_equality_implicitfast_match_oracle(solver):
   assert worst_q <= 1e-5, worst_q
   assert worst_v <= 1e-3, worst_v
   assert abs(s.qpos[7] - s.qpos[8]) < 5e-3  # the coupling pulled the fingers together
+
+
+_D = mjw.DisableBit
+
+
+@pytest.mark.parametrize("flag", [_D.CONSTRAINT, _D.LIMIT, _D.CONTACT, _D.GRAVITY, _D.CLAMPCTRL, _D.WARMSTART, _D.ACTUATION,
+                                  _D.REFSAFE, _D.DAMPER | _D.SPRING, _D.FILTERPARENT, _D.EULERDAMP])
+def test_disable_flags_match_oracle(flag):
+  """Every option.disableflags bit the path honours (types.py DisableBit), toggled on the humanoid: forward and 25 steps.
+  EULERDAMP is set in humanoid.xml; toggling it ENABLES the implicit-damping Euler branch (forward.py:387-417)."""
+  mjm = mjw.mjcf.load_xml(conftest.HUMANOID_XML)
+  mjm.opt.disableflags = int(mjm.opt.disableflags) ^ int(flag)
+  njmax = 96 if flag == _D.FILTERPARENT else 64  # more self-collision pairs without the parent filter
+  s, m, d = _pair(mjm, nworld=2, nconmax=32, njmax=njmax, solver=int(mjw.SolverType.NEWTON), warm_steps=10)
+  s.forward()
+  mjw.forward(m, d)
+  _check_fields(s, d, _SMOOTH_FIELDS, SMOOTH)
+  _check_contacts_and_rows(s, d, mjm)
+  _check_fields(s, d, ("qacc_smooth",), FACTOR)
+  _check_fields(s, d, ("qacc", "qfrc_constraint"), SOLVE)
+  worst_q = worst_v = 0.0
+  for i in range(25):
+    s.ctrl_noise(10 + i, 0)
+    _sync(s, d)
+    mjw.step(m, d)
+    s.step()
+    worst_q = max(worst_q, relerr(d.qpos.numpy()[1], s.qpos))
+    worst_v = max(worst_v, relerr(d.qvel.numpy()[1], s.qvel))
+  assert worst_q <= 1e-5, worst_q
+  assert worst_v <= 1e-3, worst_v
+
+
+def test_disable_equality_and_frictionloss():
+  """EQUALITY on the Panda (the finger coupling row disappears) and FRICTIONLOSS on the pendula model."""
+  for xml, flag, attr in ((conftest.PANDA_XML, _D.EQUALITY, "ne"), (conftest.PENDULA_XML, _D.FRICTIONLOSS, "nf")):
+    mjm = mjw.mjcf.load_xml(xml) if os.path.exists(str(xml)) else mjw.mjcf.from_xml_string(xml)
+    base = ref.RefSim(mjm, nconmax=8, njmax=32)
+    base.qpos[:] = mjm.qpos0
+    base.qvel[:] = 0.3
+    base.forward()
+    assert getattr(base, attr) >= 1
+    mjm.opt.disableflags = int(mjm.opt.disableflags) | int(flag)
+    s, m, d = _pair(mjm, nworld=2, nconmax=8, njmax=32, solver=int(mjw.SolverType.NEWTON), warm_steps=0)
+    s.qvel[:] = 0.3
+    _sync(s, d)
+    s.forward()
+    mjw.forward(m, d)
+    assert getattr(s, attr) == 0 and int(getattr(d, attr).numpy()[0]) == 0
+    _check_contacts_and_rows(s, d, mjm)
+    _check_fields(s, d, ("qacc",), SOLVE)
