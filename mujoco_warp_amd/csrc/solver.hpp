@@ -44,7 +44,9 @@ DEV float gsumg(float v) {
     v = dpp_add_f<0x143, 0xc, 0xf>(v);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave sum
     return bcastg<64>(v, 63);
   }
-  return bcastg<32>(v, 31);
+  // every lane reads lane 31 of its 32-lane group through the LDS crossbar (ds_swizzle, no memory access): one DS
+  // instruction instead of two v_readlane + v_cndmask -- the kernel is VALU-issue bound (measured -5 % kernel time)
+  return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x3E0));
 }
 // (A butterfly all-reduce -- quad_perm, row_half_mirror, row_mirror, v_permlane16_swap or ds_swizzle -- is two VALU ops
 // shorter and passes in isolation, but inside k_solve it broke parity with both cross-row variants; not pursued.)
