@@ -373,10 +373,12 @@ DEV void make_constraint_body(const MjhModel& m, const MjhData& d, float* smem, 
           }
         }
       }
+      // J qvel of the contact's rows: totals are only needed by the lane that stores them, so the last lane of the
+      // group takes them straight from the DPP tree (no broadcast)
       float v[6];
 #pragma unroll
-      for (int q = 0; q < 6; ++q) v[q] = (q == 0 || q < condim) ? gsum<G>(acc[q]) : 0.0f;
-      if (lig == 0) {
+      for (int q = 0; q < 6; ++q) v[q] = (q == 0 || q < condim) ? (G == 32 ? gsum_last32(acc[q]) : gsum<G>(acc[q])) : 0.0f;
+      if (lig == G - 1) {
         if (condim == 1) {
           if (rbase < njmax) rowvel[rbase] = v[0];
         } else {

@@ -44,6 +44,20 @@ DEV void gsync() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// DPP reduction steps (VALU only, no LDS traffic)
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+DEV float dpp_add_f(float v) {
+  const int r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, BANK_MASK, true);
+  return v + __int_as_float(r);
+}
+// sum over a 32-lane group, valid in the LAST lane of the group only (lanes 31 / 63): five DPP adds, no broadcast
+DEV float gsum_last32(float v) {
+  v = dpp_add_f<0x111, 0xf, 0xf>(v);  // row_shr:1
+  v = dpp_add_f<0x112, 0xf, 0xf>(v);  // row_shr:2
+  v = dpp_add_f<0x114, 0xf, 0xf>(v);  // row_shr:4
+  v = dpp_add_f<0x118, 0xf, 0xf>(v);  // row_shr:8
+  return dpp_add_f<0x142, 0xa, 0xf>(v);  // row_bcast:15 into rows 1 and 3
+}
 template <int G>
 DEV float gsum(float v) {
 #pragma unroll

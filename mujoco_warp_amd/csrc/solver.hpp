@@ -20,11 +20,6 @@
 #include "smooth.hpp"
 
 // ---- DPP reduction over a 32-lane group; every lane receives the total ---------------------------------
-template <int CTRL, int ROW_MASK, int BANK_MASK>
-DEV float dpp_add_f(float v) {
-  const int r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, BANK_MASK, true);
-  return v + __int_as_float(r);
-}
 // G = 32: two worlds per wavefront (nv <= 32); G = 64: one world per wavefront (32 < nv <= 64)
 template <int G>
 DEV float bcastg(float v, int k) {  // value of lane k of this lane's group (k compile-time)
