@@ -80,7 +80,7 @@ static hipError_t set_lds(K kernel, size_t bytes) {
 constexpr int G = 32;
 
 static int launch_pos(const MjhModel* m, const MjhData* d, int first, int last, hipStream_t s) {
-  const PosLayout lay = pos_layout(m->nq, m->nv, m->nbody, m->njnt, m->nC);
+  const PosLayout lay = pos_layout(m->nq, m->nv, m->nbody, m->njnt, m->nC, last >= POS_FACTOR);
   size_t lds;
   const int threads = pick_block(sizeof(int) * mstruct_ints(m->nv, m->nC), sizeof(float) * lay.total, G, &lds);
   if (!threads) return fail(MJH_E_UNSUPPORTED, "k_fwd_pos: model does not fit in LDS");
@@ -304,7 +304,7 @@ static int launch_integrate_plus(const MjhModel* m, const MjhData* d, int mode, 
   return MJH_OK;
 }
 static int launch_pos_plus(const MjhModel* m, const MjhData* d, int first, int last, hipStream_t s) {
-  const PosLayout lay = pos_layout(m->nq, m->nv, m->nbody, m->njnt, m->nC);
+  const PosLayout lay = pos_layout(m->nq, m->nv, m->nbody, m->njnt, m->nC, last >= POS_FACTOR);
   size_t lds;
   const int threads = pick_block(sizeof(int) * mstruct_ints(m->nv, m->nC), sizeof(float) * lay.total, G, &lds);
   if (!threads) return fail(MJH_E_UNSUPPORTED, "k_fwd_pos: model does not fit in LDS");

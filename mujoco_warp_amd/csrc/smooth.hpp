@@ -107,7 +107,10 @@ DEV void mul_m_ld(const MStruct& ms, const float* M, const float* vec, float* re
 struct PosLayout {
   int qpos, xpos, xquat, xmat, xipos, ximat, xanchor, xaxis, scom, cinert, cdof, crb, M, L, dinv, total;
 };
-__host__ __device__ inline PosLayout pos_layout(int nq, int nv, int nbody, int njnt, int nC) {
+// with_factor: the POS_FACTOR phase (factor_m stage only) needs L and dinv.  M lives on top of xmat/ximat when it fits:
+// both are dead (already written back) by the time crb runs.  LDS per world decides how many worlds a CU holds, i.e.
+// how many dependent tree levels overlap: 1,703 -> 1,190 words for the humanoid (20 -> 28 worlds per CU).
+__host__ __device__ inline PosLayout pos_layout(int nq, int nv, int nbody, int njnt, int nC, bool with_factor) {
   PosLayout p;
   int o = 0;
   p.qpos = o; o += nq;
@@ -122,9 +125,13 @@ __host__ __device__ inline PosLayout pos_layout(int nq, int nv, int nbody, int n
   p.cinert = o; o += 10 * nbody;
   p.cdof = o; o += 6 * nv;
   p.crb = o; o += 10 * nbody;
-  p.M = o; o += nC;
-  p.L = o; o += nC;
-  p.dinv = o; o += nv;
+  if (nC <= 21 * nbody) {
+    p.M = p.xmat;  // xmat, xipos, ximat are adjacent (21 nbody words) and no longer read once com_pos is done
+  } else {
+    p.M = o; o += nC;
+  }
+  p.L = o; o += with_factor ? nC : 0;
+  p.dinv = o; o += with_factor ? nv : 0;
   p.total = ((o + 3) / 4) * 4 + 1;  // odd-ish stride keeps worlds of one wave on different banks
   return p;
 }
@@ -135,7 +142,7 @@ template <int G>
 DEV void fwd_pos_body(const MjhModel& m, const MjhData& d, int first, int last, float* smem, const Blk& b) {
   if ((int)threadIdx.x >= b.nthreads) return;
   const int nq = m.nq, nv = m.nv, nbody = m.nbody, njnt = m.njnt, nC = m.nC;
-  const PosLayout lay = pos_layout(nq, nv, nbody, njnt, nC);
+  const PosLayout lay = pos_layout(nq, nv, nbody, njnt, nC, last >= POS_FACTOR);
   int* shi = reinterpret_cast<int*>(smem);
   const MStruct ms = load_mstruct<G>(m, shi, b.nthreads);
   const int lig = threadIdx.x & (G - 1), gib = threadIdx.x / G;
