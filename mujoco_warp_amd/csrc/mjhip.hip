@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(256) k_mid(MjhModel m, MjhData d, int ncc, int
   }
 }
 template <int NV4, int NR, bool NEWTON, int SG>
-__global__ void __launch_bounds__(256) k_solve_plus(MjhModel m, MjhData d, int nsolve, int nfac) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((!NEWTON && SG == 32 && NR == 2) ? 3 : 1, 8))) k_solve_plus(MjhModel m, MjhData d, int nsolve, int nfac) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int wpb = blockDim.x / SG;
   if ((int)blockIdx.x < nsolve) solve_body<NV4, NR, NEWTON, SG>(m, d, smem, Blk{(int)blockIdx.x * wpb, wpb, (int)blockDim.x});
@@ -231,15 +231,15 @@ static int solve_supported(const MjhModel* m, const MjhData* d) {
 // L'DL-factor workgroups (fused step, CG); without it the launch is the plain `solve` stage.
 template <int NV4, int NR, bool NEWTON, int SG>
 static int launch_solve_t(const MjhModel* m, const MjhData* d, bool with_factor, hipStream_t s) {
-  const SolveLayout lay = solve_layout<NV4, NR, SG>(d->njmax);
+  const SolveLayout lay = solve_layout<NV4, NR, SG, NEWTON>(d->njmax);
   const FacLayout fl = fac_layout(m->nv, m->nC);
-  const size_t ms_bytes = sizeof(int) * mstruct_ints(m->nv, m->nC);
+  const size_t ms_bytes = sizeof(int) * mstruct_ints(m->nv, m->nC);  // riders only: the solver keeps no shared tables
   size_t lds;
-  int threads = pick_block(ms_bytes, sizeof(float) * lay.total, SG, &lds, true);
+  int threads = pick_block(0, sizeof(float) * lay.total, SG, &lds, true);
   if (!threads) return fail(MJH_E_UNSUPPORTED, "k_solve: njmax x nv does not fit in LDS");
   if (const char* e = getenv("MJH_SOLVE_THREADS")) {  // tuning knob (developer only)
     threads = std::max(atoi(e), SG);
-    lds = ms_bytes + sizeof(float) * lay.total * (threads / SG);
+    lds = sizeof(float) * lay.total * (threads / SG);
   }
   const int wpb = threads / SG, wf = threads / 32;
   with_factor = with_factor && !NEWTON;

@@ -117,7 +117,7 @@ DEV float chol_solve_rows(const float (&h)[NVR], const float (&lt)[NVR], float r
 struct SolveLayout {
   int J, force, da, bsearch, bgrad, col, total;
 };
-template <int NV4, int NR, int G>
+template <int NV4, int NR, int G, bool NEWTON>
 __host__ __device__ inline SolveLayout solve_layout(int njmax) {
   constexpr int NVR = 4 * NV4;
   constexpr int JS = (NV4 & 1) ? NVR : NVR + 4;  // JS/4 odd: row-per-lane 16-byte reads hit distinct banks
@@ -126,12 +126,27 @@ __host__ __device__ inline SolveLayout solve_layout(int njmax) {
   int o = 0;
   p.J = o; o += (njp > NVR ? njp : NVR) * JS;  // also stages the dense NVR x NVR copy of M
   p.force = o; o += G * NR;                     // efc_force of the current iterate (for J^T f)
-  p.da = o; o += G * NR;                        // D * [state == QUADRATIC] (Newton: J^T D J)
+  p.da = o; o += NEWTON ? G * NR : 0;           // D * [state == QUADRATIC] (Newton: J^T D J)
   p.bsearch = o; o += G;                        // broadcast copies of the two nv-vectors other lanes read
   p.bgrad = o; o += G;
-  p.col = o; o += 8 * JS > 2 * G ? 8 * JS : 2 * G;    // Cholesky pivot column / transpose tile, Gauss-Jordan pivot row
+  // Newton: Cholesky pivot column + 8-row transpose tile; CG: the double-buffered Gauss-Jordan pivot row only
+  p.col = o; o += NEWTON ? (8 * JS > 2 * G ? 8 * JS : 2 * G) : 2 * (NVR > G ? NVR : G);
   p.total = ((o + 3) / 4) * 4;
   return p;
+}
+
+// force and state of one row at Jaref = ja (solver.py:1698-1822): equality rows are always active, limit/contact rows
+// when violated, padding rows (D = 0) never -- branch-free; friction-loss rows (rare) have three zones
+DEV void row_force(int kind, float ja, float D, bool has_fl, const float* floss, float& force, int& state) {
+  const bool quad = kind == 0 || (kind == 2 && ja < 0.0f);
+  force = quad ? -D * ja : 0.0f;
+  state = quad ? ST_QUADRATIC : ST_SATISFIED;
+  if (has_fl && kind == 1) {
+    const float f = *floss, rf = safe_div(f, D);
+    if (ja <= -rf) { force = f; state = ST_LINEARNEG; }
+    else if (ja >= rf) { force = -f; state = ST_LINEARPOS; }
+    else { force = -D * ja; state = ST_QUADRATIC; }
+  }
 }
 
 // (cost - cost(0), grad, hess) of ONE constraint row on the ray at step alpha
@@ -223,15 +238,15 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
   constexpr int NVR = 4 * NV4;
   constexpr int JS = (NV4 & 1) ? NVR : NVR + 4;
   const int nv = m.nv, nC = m.nC, njmax = d.njmax, nvp = d.nv_pad;
-  const SolveLayout lay = solve_layout<NV4, NR, G>(njmax);
-  int* shi = reinterpret_cast<int*>(smem);
-  const MStruct ms = load_mstruct<G>(m, shi, b.nthreads);
+  const SolveLayout lay = solve_layout<NV4, NR, G, NEWTON>(njmax);
   const int lig = threadIdx.x & (G - 1), gib = threadIdx.x / G;
   const int slot = b.w0 + gib;
   if (slot >= d.nworld) return;
   // worlds are scheduled longest-expected-solve first and paired with a similar neighbour (k_schedule_worlds)
   const int w = d.ws_order[slot];
-  float* S = smem + mstruct_ints(nv, nC) + (size_t)gib * lay.total;
+  // LDS decides how many worlds a CU holds (the kernel runs 2-3 rounds): no block-shared tables here, the M-structure
+  // is read once from global (L1 hits)
+  float* S = smem + (size_t)gib * lay.total;
   float *Jl = S + lay.J, *eforce = S + lay.force, *eda = S + lay.da, *bsearch = S + lay.bsearch, *bgrad = S + lay.bgrad, *col = S + lay.col;
 
   const int nefc = min(min(d.nefc[w], njmax), G * NR);
@@ -249,9 +264,9 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
     gsync();
     const float* Mg = d.M + (size_t)w * nC;
     for (int i = lig; i < nv; i += G) {
-      const int start = ms.rowadr[i], n = ms.rownnz[i];
+      const int start = m.M_rowadr[i], n = m.M_rownnz[i];
       for (int a = 0; a < n; ++a) {
-        const int j = ms.colind[start + a];
+        const int j = m.M_colind[start + a];
         const float v = Mg[start + a];
         Jl[i * JS + j] = v;
         Jl[j * JS + i] = v;
@@ -341,21 +356,19 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
     for (int r = nefc; r < ((nefc + 15) & ~15); ++r)  // zero rows up to the next 16-row chunk boundary
       for (int c = lig; c < JS; c += G) Jl[r * JS + c] = 0.0f;
   }
-  float rD[NR], rfl[NR], rja[NR], rjv[NR], rfrc[NR];
-  int rst[NR], rkind[NR];
-  bool rhas[NR];
+  // persistent per-row registers are kept to the minimum (the kernel sits at the 3-waves-per-SIMD VGPR boundary):
+  // frictionloss is re-read in the rare friction-loss path, force/state are recomputed once at the end
+  float rD[NR], rja[NR], rjv[NR];
+  int rkind[NR];
 #pragma unroll
   for (int k = 0; k < NR; ++k) {
     const int r = lig + G * k;
-    rhas[k] = r < nefc;
-    rD[k] = rhas[k] ? d.efc_D[eo + r] : 0.0f;
-    rfl[k] = rhas[k] ? d.efc_frictionloss[eo + r] : 0.0f;
-    rkind[k] = !rhas[k] ? 3 : (r >= ne + nf ? 2 : (r >= ne ? 1 : 0));  // 3: padding row (contributes nothing)
+    const bool has = r < nefc;
+    rD[k] = has ? d.efc_D[eo + r] : 0.0f;
+    rkind[k] = !has ? 3 : (r >= ne + nf ? 2 : (r >= ne ? 1 : 0));  // 3: padding row (contributes nothing)
     rjv[k] = 0.0f;
-    rfrc[k] = 0.0f;
-    rst[k] = 0;
     eforce[r] = 0.0f;
-    eda[r] = 0.0f;
+    if (NEWTON) eda[r] = 0.0f;  // CG has no eda region
   }
   gsync();
   // J[r,:] . vec  (row-per-lane, conflict-free 16-byte reads)
@@ -371,7 +384,7 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
     return s0 + s1;
   };
 #pragma unroll
-  for (int k = 0; k < NR; ++k) rja[k] = rhas[k] ? j_dot(bsearch, lig + G * k) - d.efc_aref[eo + lig + G * k] : 0.0f;
+  for (int k = 0; k < NR; ++k) rja[k] = rkind[k] != 3 ? j_dot(bsearch, lig + G * k) - d.efc_aref[eo + lig + G * k] : 0.0f;
   gsync();
 
   pc.mark(2);
@@ -396,17 +409,9 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
     for (int k = 0; k < NR; ++k) {
       const float ja = rja[k], D = rD[k];
       // equality rows are always active, limit/contact rows when violated, padding rows (D = 0) never: branch-free
-      const bool quad = rkind[k] == 0 || (rkind[k] == 2 && ja < 0.0f);
-      float force = quad ? -D * ja : 0.0f;
-      int state = quad ? ST_QUADRATIC : ST_SATISFIED;
-      if (has_fl && rkind[k] == 1) {  // friction loss: three zones
-        const float f = rfl[k], rf = safe_div(f, D);
-        if (ja <= -rf) { force = f; state = ST_LINEARNEG; }
-        else if (ja >= rf) { force = -f; state = ST_LINEARPOS; }
-        else { force = -D * ja; state = ST_QUADRATIC; }
-      }
-      rfrc[k] = force;
-      rst[k] = state;
+      float force;
+      int state;
+      row_force(rkind[k], ja, D, has_fl, d.efc_frictionloss + eo + lig + G * k, force, state);
       eforce[lig + G * k] = force;
       if (NEWTON) eda[lig + G * k] = state == ST_QUADRATIC ? D : 0.0f;
     }
@@ -503,7 +508,7 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
     gsync();
     const float mvi = mul_row(mrow, bsearch);
 #pragma unroll
-    for (int k = 0; k < NR; ++k) rjv[k] = rhas[k] ? j_dot(bsearch, lig + G * k) : 0.0f;
+    for (int k = 0; k < NR; ++k) rjv[k] = rkind[k] != 3 ? j_dot(bsearch, lig + G * k) : 0.0f;
     pc.mark(5);
     // ---- line search (solver.py:835-1347); rows and all sums stay in registers ----------------------------------
     const float gauss1 = gsumg<G>(srch * (Ma - fs));
@@ -535,7 +540,7 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
       } else {
 #pragma unroll
         for (int k = 0; k < NR; ++k) {
-          const P3 t = eval_row(rja[k], rjv[k], rD[k], rfl[k], rkind[k], a);
+          const P3 t = eval_row(rja[k], rjv[k], rD[k], rkind[k] == 1 ? d.efc_frictionloss[eo + lig + G * k] : 0.0f, rkind[k], a);
           s.c += t.c;
           s.g += t.g;
           s.h += t.h;
@@ -616,9 +621,12 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
   }
 #pragma unroll
   for (int k = 0; k < NR; ++k)
-    if (rhas[k]) {
-      d.efc_force[eo + lig + G * k] = rfrc[k];
-      d.efc_state[eo + lig + G * k] = rst[k];
+    if (rkind[k] != 3) {  // force/state at the final iterate: the same expression the last constraint update evaluated
+      float force;
+      int state;
+      row_force(rkind[k], rja[k], rD[k], has_fl, d.efc_frictionloss + eo + lig + G * k, force, state);
+      d.efc_force[eo + lig + G * k] = force;
+      d.efc_state[eo + lig + G * k] = state;
     }
   if (lig == 0) {
     d.solver_niter[w] = niter;
