@@ -210,7 +210,8 @@ int mjh_timed_steps(const MjhModel* m, const MjhData* d, int nstep, int step0, f
                     void* stream, float* ms_out, float* per_kernel_ms, int plain_kernels);
 
 const char* mjh_last_error(void);
-int mjh_abi_version(void);
+#define MJH_ABI_VERSION 2
+int mjh_abi_version(void); /* returns MJH_ABI_VERSION of the library that was loaded */
 
 #ifdef __cplusplus
 }

@@ -422,7 +422,7 @@ static int run_stage(const MjhModel* m, const MjhData* d, int stage, hipStream_t
 
 extern "C" {
 
-int mjh_abi_version(void) { return 2; }
+int mjh_abi_version(void) { return MJH_ABI_VERSION; }
 const char* mjh_last_error(void) { return g_err; }
 
 int mjh_stage(const MjhModel* m, const MjhData* d, int stage, void* stream) {
