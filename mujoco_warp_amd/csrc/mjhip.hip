@@ -197,8 +197,14 @@ __global__ void __launch_bounds__(256) k_integrate_plus(MjhModel m, MjhData d, i
 template <int G>
 __global__ void __launch_bounds__(256) k_fwd_pos_plus(MjhModel m, MjhData d, int first, int last, int npos) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  if ((int)blockIdx.x < npos) fwd_pos_body<G>(m, d, first, last, smem, blk_of_launch<G>());
-  else schedule_body(d, reinterpret_cast<int*>(smem), blockDim.x);
+  // the schedule workgroup goes FIRST: workgroups are dispatched in index order, so as the last one it would start
+  // when the launch is nearly over and add its whole duration (~8 us) to it
+  if (blockIdx.x == 0) {
+    schedule_body(d, reinterpret_cast<int*>(smem), blockDim.x);
+  } else {
+    const int wpb = blockDim.x / G;
+    fwd_pos_body<G>(m, d, first, last, smem, Blk{((int)blockIdx.x - 1) * wpb, wpb, (int)blockDim.x});
+  }
 }
 
 static int launch_mid(const MjhModel* m, const MjhData* d, hipStream_t s) {
