@@ -150,7 +150,7 @@ static int launch_integrate(const MjhModel* m, const MjhData* d, int mode, hipSt
 // Cross-stream fork/join costs 5-15 us per hop on the critical path (event record -> barrier packet -> dispatch),
 // while consecutive kernels of one stream start back to back.  The fused step therefore uses ONE stream and gives
 // the workgroups of a launch different roles:
-//   k_mid           : {collision -> make_constraint} workgroups interleaved with fwd_vel workgroups (both only depend
+//   k_mid           : {collision -> make_constraint} workgroups, then the (shorter) fwd_vel workgroups (both only depend
 //                     on k_fwd_pos; both are latency-bound, so they share the CUs)
 //   k_solve_plus    : solver workgroups (longest expected solve first), then factor_smooth and publish workgroups: dispatched last,
 //                     they fill the CUs that the solver's stragglers leave idle
@@ -159,9 +159,10 @@ static int launch_integrate(const MjhModel* m, const MjhData* d, int mode, hipSt
 template <int G>
 __global__ void __launch_bounds__(256) k_mid(MjhModel m, MjhData d, int ncc, int nvb, int nw_cc, int nw_v, int stride_cc) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const long long n = (long long)ncc + nvb, bi = blockIdx.x;
-  const int cc_before = (int)(bi * ncc / n);                    // evenly interleaved roles
-  const bool is_cc = (int)((bi + 1) * ncc / n) > cc_before;
+  const int bi = blockIdx.x;
+  (void)nvb;
+  const int cc_before = bi < ncc ? (int)bi : ncc;               // longest jobs first: all CC workgroups, then fwd_vel
+  const bool is_cc = bi < ncc;
   if (is_cc) {
     const Blk b{cc_before * nw_cc, nw_cc, nw_cc * G};
     collision_body<G>(m, d, smem, b, stride_cc);
