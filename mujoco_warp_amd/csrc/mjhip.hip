@@ -220,6 +220,13 @@ static int launch_mid(const MjhModel* m, const MjhData* d, hipStream_t s) {
   int nw_v = (int)((lds > ms_bytes ? lds - ms_bytes : 0) / (sizeof(float) * vl.total));
   if (nw_v < 1) nw_v = 1;
   if (nw_v > 8) nw_v = 8;
+  // an odd world count leaves half a wavefront slot empty: round up when the same number of workgroups still fits a CU
+  if ((nw_v & 1) && nw_v < 8) {
+    const size_t up = ms_bytes + sizeof(float) * vl.total * (nw_v + 1);
+    if ((size_t)kLdsPerCU / std::max(up, lds) == (size_t)kLdsPerCU / lds) ++nw_v;
+    else --nw_v;
+  }
+  if (nw_v < 1) nw_v = 1;
   lds = std::max(lds, ms_bytes + sizeof(float) * vl.total * nw_v);
   if (lds > (size_t)kLdsPerCU) return fail(MJH_E_UNSUPPORTED, "k_mid: model does not fit in LDS");
   HIPCHK(set_lds(k_mid<G>, lds));
