@@ -227,11 +227,15 @@ static int launch_mid(const MjhModel* m, const MjhData* d, hipStream_t s) {
     else --nw_v;
   }
   if (nw_v < 1) nw_v = 1;
+  if (const char* e = getenv("MJH_MID_W")) {  // tuning knob (developer only): worlds per workgroup of both roles
+    nw_cc = nw_v = atoi(e);
+    lds = sizeof(float) * stride_cc * nw_cc;
+  }
   lds = std::max(lds, ms_bytes + sizeof(float) * vl.total * nw_v);
   if (lds > (size_t)kLdsPerCU) return fail(MJH_E_UNSUPPORTED, "k_mid: model does not fit in LDS");
   HIPCHK(set_lds(k_mid<G>, lds));
   const int ncc = (d->nworld + nw_cc - 1) / nw_cc, nvb = (d->nworld + nw_v - 1) / nw_v;
-  hipLaunchKernelGGL(k_mid<G>, dim3(ncc + nvb), dim3(256), lds, s, *m, *d, ncc, nvb, nw_cc, nw_v, stride_cc);
+  hipLaunchKernelGGL(k_mid<G>, dim3(ncc + nvb), dim3(G * std::max(nw_cc, nw_v)), lds, s, *m, *d, ncc, nvb, nw_cc, nw_v, stride_cc);
   return MJH_OK;
 }
 static int solve_supported(const MjhModel* m, const MjhData* d) {
