@@ -40,6 +40,31 @@ def main():
   s.step()
   out["qpos_next"], out["qvel_next"] = s.qpos.copy(), s.qvel.copy()
   np.savez(os.path.join(OUT, "humanoid_oracle_forward.npz"), tolerance=tol, **{"in_" + k: v for k, v in state.items()}, **out)
+  # BASELINE configs[2] and [3] models: one-step fixtures (G1: nv 35, implicitfast; Panda: joint equality, affine actuators)
+  for name, rel, ncm, njm, warm in (("g1", ("unitree_g1", "scene_flat.xml"), 48, 192, 12), ("panda", ("franka_emika_panda", "scene.xml"), 8, 16, 0)):
+    mjm = mjw.mjcf.load_xml(os.path.join(ROOT, "benchmarks", *rel))
+    s = ref.RefSim(mjm, nconmax=ncm, njmax=njm, tolerance=tol, iterations=100, ls_iterations=50)
+    s.reset(key=0 if mjm.nkey else None)
+    if name == "panda":
+      rng = np.random.default_rng(7)
+      s.qpos[:7] = 0.3 * rng.standard_normal(7)
+      s.qpos[3] = -1.5
+      s.qpos[7:9] = (0.03, 0.01)
+      s.qvel[:] = 0.2 * rng.standard_normal(mjm.nv)
+      s.ctrl[:] = 0.2 * rng.standard_normal(mjm.nu)
+    for i in range(warm):
+      s.ctrl_noise(i, 1)
+      s.step()
+    state = {k: getattr(s, k).copy() for k in ("qpos", "qvel", "ctrl", "qacc_warmstart")}
+    s.forward()
+    out = {k: getattr(s, k).copy() for k in ("xpos", "xquat", "subtree_com", "cdof", "M", "qfrc_bias", "qfrc_actuator", "qacc_smooth",
+                                              "qacc", "qfrc_constraint")}
+    out["nefc"], out["ncon"], out["ne"] = s.nefc, s.ncon, s.ne
+    out["efc_J"], out["efc_D"], out["efc_aref"] = s.efc_J[: s.nefc].copy(), s.efc_D[: s.nefc].copy(), s.efc_aref[: s.nefc].copy()
+    s.step()
+    out["qpos_next"], out["qvel_next"] = s.qpos.copy(), s.qvel.copy()
+    np.savez(os.path.join(OUT, f"{name}_oracle_forward.npz"), tolerance=tol, nconmax=ncm, njmax=njm,
+             **{"in_" + k: v for k, v in state.items()}, **out)
   print("wrote golden files to", OUT)
 
 

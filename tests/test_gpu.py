@@ -535,3 +535,23 @@ def test_ragged_world_counts_are_bitwise_consistent():
       ref_q = (q[0].copy(), v[0].copy())
     else:
       assert (q[0] == ref_q[0]).all() and (v[0] == ref_q[1]).all()
+
+
+@pytest.mark.parametrize("name,xml", [("g1", conftest.G1_XML), ("panda", conftest.PANDA_XML)])
+def test_golden_forward_fixture_g1_panda(name, xml):
+  """Committed oracle fixtures for the BASELINE configs[2] / [3] models (tests/golden/make_golden.py), Newton, converged."""
+  g = np.load(os.path.join(conftest.GOLDEN_DIR, f"{name}_oracle_forward.npz"))
+  mjm = mjw.mjcf.load_xml(xml)
+  mjm.opt.iterations, mjm.opt.ls_iterations = 100, 50
+  m = mjw.put_model(mjm)
+  d = mjw.make_data(mjm, nworld=2, nconmax=int(g["nconmax"]), njmax=int(g["njmax"]))
+  for k in ("qpos", "qvel", "ctrl", "qacc_warmstart"):
+    getattr(d, k).assign(np.tile(g["in_" + k].astype(np.float32), (2, 1)))
+  mjw.step(m, d)
+  for k, tol in (("xpos", SMOOTH), ("xquat", SMOOTH), ("subtree_com", SMOOTH), ("cdof", SMOOTH), ("M", SMOOTH), ("qfrc_bias", SMOOTH),
+                 ("qfrc_actuator", SMOOTH), ("qacc_smooth", FACTOR), ("qacc", 5e-3), ("qfrc_constraint", 5e-3)):
+    assert relerr(getattr(d, k).numpy()[1].reshape(-1), g[k].reshape(-1)) <= tol, k
+  assert (int(d.nefc.numpy()[1]), int(d.ws_ncon.numpy()[1]), int(d.ne.numpy()[1])) == (int(g["nefc"]), int(g["ncon"]), int(g["ne"]))
+  assert relerr(d.efc.J.numpy()[1, : int(g["nefc"]), : mjm.nv], g["efc_J"]) <= SMOOTH
+  assert relerr(d.qpos.numpy()[1], g["qpos_next"]) <= 1e-5
+  assert relerr(d.qvel.numpy()[1], g["qvel_next"]) <= 2e-3

@@ -301,3 +301,19 @@ def test_panda_joint_equality_couples_the_fingers():
   for i in range(150):
     s.step()
   assert np.isfinite(s.qpos).all() and abs(s.qpos[7] - s.qpos[8]) < 1e-4
+
+
+@pytest.mark.parametrize("name,xml", [("g1", conftest.G1_XML), ("panda", conftest.PANDA_XML)])
+def test_golden_forward_regression_g1_panda(name, xml):
+  """The committed G1 / Panda fixtures are what the oracle produces today (regression anchor for oracle changes)."""
+  from mujoco_warp_amd import mjcf
+  g = np.load(os.path.join(conftest.GOLDEN_DIR, f"{name}_oracle_forward.npz"))
+  mjm = mjcf.load_xml(xml)
+  s = ref.RefSim(mjm, nconmax=int(g["nconmax"]), njmax=int(g["njmax"]), tolerance=float(g["tolerance"]), iterations=100, ls_iterations=50)
+  for k in ("qpos", "qvel", "ctrl", "qacc_warmstart"):
+    getattr(s, k)[:] = g["in_" + k]
+  s.forward()
+  assert (s.nefc, s.ncon, s.ne) == (int(g["nefc"]), int(g["ncon"]), int(g["ne"]))
+  np.testing.assert_allclose(s.qacc, g["qacc"], rtol=1e-9, atol=1e-9)
+  s.step()
+  np.testing.assert_allclose(s.qpos, g["qpos_next"], rtol=1e-12, atol=1e-12)
