@@ -207,27 +207,46 @@ __global__ void __launch_bounds__(256) k_solve_m(MjhModel m, MjhData d, float* x
 // Iteration counts are strongly correlated from step to step, so (i) the longest solves start first (LPT: no
 // long straggler wave at the tail of k_solve) and (ii) the two worlds sharing a wavefront need a similar number
 // of iterations (a wave runs for max(niter) of its two worlds).  Single workgroup; deterministic (stable sort).
-// `sh` needs 256 ints of LDS; any workgroup size.
+// `sh` needs 256 ints of LDS; any workgroup size that is a multiple of 64.  Global loads are batched eight deep ahead
+// of the LDS atomics (a load -> atomic -> store chain per world costs a full memory latency per iteration: 50-70 us
+// for 8192 worlds on one small workgroup), the 128-bin prefix is one wavefront scan.
 DEV void schedule_body(const MjhData& d, int* sh, int nthreads) {
   int* hist = sh;
   int* base = sh + 128;
   const int t = threadIdx.x, n = d.nworld;
   for (int i = t; i < 128; i += nthreads) hist[i] = 0;
   __syncthreads();
-  for (int w = t; w < n; w += nthreads) atomicAdd(&hist[127 - min(max(d.solver_niter[w], 0), 127)], 1);
+  for (int w0 = t; w0 < n; w0 += 8 * nthreads) {
+    int v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = w0 + k * nthreads < n ? d.solver_niter[w0 + k * nthreads] : -1;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (w0 + k * nthreads < n) atomicAdd(&hist[127 - min(max(v[k], 0), 127)], 1);
+  }
   __syncthreads();
-  if (t == 0) {
-    int acc = 0;
-    for (int b = 0; b < 128; ++b) {
-      base[b] = acc;
-      acc += hist[b];
+  if (t < 64) {  // exclusive prefix over the 128 bins: two bins per lane of the first wavefront
+    const int a = hist[2 * t], b = hist[2 * t + 1];
+    int incl = a + b;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int u = __shfl_up(incl, off, 64);
+      if (t >= off) incl += u;
     }
+    base[2 * t] = incl - a - b;
+    base[2 * t + 1] = incl - b;
   }
   __syncthreads();
   // scatter; the order inside a bucket is arbitrary (it only decides which wavefront hosts a world, never a result)
-  for (int w = t; w < n; w += nthreads) {
-    const int b = 127 - min(max(d.solver_niter[w], 0), 127);
-    d.ws_order[atomicAdd(&base[b], 1)] = w;
+  for (int w0 = t; w0 < n; w0 += 8 * nthreads) {
+    int v[8], pos[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = w0 + k * nthreads < n ? d.solver_niter[w0 + k * nthreads] : -1;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) pos[k] = w0 + k * nthreads < n ? atomicAdd(&base[127 - min(max(v[k], 0), 127)], 1) : 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (w0 + k * nthreads < n) d.ws_order[pos[k]] = w0 + k * nthreads;
   }
 }
 __global__ void __launch_bounds__(1024) k_schedule_worlds(MjhData d) {
