@@ -157,10 +157,16 @@ static int launch_integrate(const MjhModel* m, const MjhData* d, int mode, hipSt
 //   k_fwd_pos_plus  : k_fwd_pos + one workgroup computing the solver schedule from the previous step's solver_niter
 //   k_integrate_plus: integrator workgroups, then publish_contacts workgroups
 template <int G>
-__global__ void __launch_bounds__(256) k_mid(MjhModel m, MjhData d, int ncc, int nvb, int nw_cc, int nw_v, int stride_cc) {
+__global__ void __launch_bounds__(256) k_mid(MjhModel m, MjhData d, int ncc, int nvb, int nw_cc, int nw_v, int stride_cc, int sched) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int bi = blockIdx.x;
   (void)nvb;
+  // sched: workgroup 0 sorts the solver schedule here instead of in the k_fwd_pos launch (models whose fwd_pos
+  // workgroups are too small to do it quickly)
+  if (sched && blockIdx.x == 0) {
+    schedule_body(d, reinterpret_cast<int*>(smem), blockDim.x);
+    return;
+  }
+  const int bi = (int)blockIdx.x - sched;
   const int cc_before = bi < ncc ? (int)bi : ncc;               // longest jobs first: all CC workgroups, then fwd_vel
   const bool is_cc = bi < ncc;
   if (is_cc) {
@@ -208,7 +214,7 @@ __global__ void __launch_bounds__(256) k_fwd_pos_plus(MjhModel m, MjhData d, int
   }
 }
 
-static int launch_mid(const MjhModel* m, const MjhData* d, hipStream_t s) {
+static int launch_mid(const MjhModel* m, const MjhData* d, bool sched, hipStream_t s) {
   const ConLayout cl = con_layout(m->nv, d->njmax, d->concap, m->nbody, m->ngeom);
   const int stride_cc = std::max(cl.total, collide_lds_words(m->ngeom, m->npair) | 1);
   const VelLayout vl = vel_layout(m->nq, m->nv, m->nbody, m->nC, m->nu);
@@ -235,7 +241,8 @@ static int launch_mid(const MjhModel* m, const MjhData* d, hipStream_t s) {
   if (lds > (size_t)kLdsPerCU) return fail(MJH_E_UNSUPPORTED, "k_mid: model does not fit in LDS");
   HIPCHK(set_lds(k_mid<G>, lds));
   const int ncc = (d->nworld + nw_cc - 1) / nw_cc, nvb = (d->nworld + nw_v - 1) / nw_v;
-  hipLaunchKernelGGL(k_mid<G>, dim3(ncc + nvb), dim3(G * std::max(nw_cc, nw_v)), lds, s, *m, *d, ncc, nvb, nw_cc, nw_v, stride_cc);
+  hipLaunchKernelGGL(k_mid<G>, dim3(ncc + nvb + (sched ? 1 : 0)), dim3(G * std::max(nw_cc, nw_v)), lds, s, *m, *d, ncc, nvb, nw_cc, nw_v,
+                     stride_cc, sched ? 1 : 0);
   return MJH_OK;
 }
 static int solve_supported(const MjhModel* m, const MjhData* d) {
@@ -321,11 +328,15 @@ static int launch_integrate_plus(const MjhModel* m, const MjhData* d, int mode, 
   hipLaunchKernelGGL(k_integrate_plus<G>, dim3(nint + npub + nfac), dim3(256), lds, s, *m, *d, mode, nint, npub);
   return MJH_OK;
 }
-static int launch_pos_plus(const MjhModel* m, const MjhData* d, int first, int last, hipStream_t s) {
+// *sched_done: whether the launch carried the schedule workgroup (it needs >= 128 threads to be quick; otherwise it
+// rides with k_mid, whose workgroups always have 256)
+static int launch_pos_plus(const MjhModel* m, const MjhData* d, int first, int last, bool* sched_done, hipStream_t s) {
   const PosLayout lay = pos_layout(m->nq, m->nv, m->nbody, m->njnt, m->nC, last >= POS_FACTOR);
   size_t lds;
   const int threads = pick_block(sizeof(int) * mstruct_ints(m->nv, m->nC), sizeof(float) * lay.total, G, &lds);
   if (!threads) return fail(MJH_E_UNSUPPORTED, "k_fwd_pos: model does not fit in LDS");
+  *sched_done = threads >= 128;
+  if (!*sched_done) return launch_pos(m, d, first, last, s);
   lds = std::max(lds, (size_t)1024);
   HIPCHK(set_lds(k_fwd_pos_plus<G>, lds));
   const int wpb = threads / G, npos = (d->nworld + wpb - 1) / wpb;
@@ -427,8 +438,9 @@ static int run_stage(const MjhModel* m, const MjhData* d, int stage, hipStream_t
         return MJH_OK;
       }
       // fused step: four launches on the caller's stream (see "composite launches" above)
-      { Scope sc(K_POS); TRY(launch_pos_plus(m, d, POS_KINEMATICS, POS_CRB, s)); }
-      { Scope sc(K_MID); TRY(launch_mid(m, d, s)); }
+      bool sched_done = false;
+      { Scope sc(K_POS); TRY(launch_pos_plus(m, d, POS_KINEMATICS, POS_CRB, &sched_done, s)); }
+      { Scope sc(K_MID); TRY(launch_mid(m, d, !sched_done, s)); }
       { Scope sc(K_SOLVE); TRY(launch_solve_plus(m, d, s)); }
       { Scope sc(K_INTEGRATE); TRY(launch_integrate_plus(m, d, mode, stage == MJH_STAGE_STEP, s)); }
       return MJH_OK;
