@@ -180,10 +180,10 @@ __global__ void __launch_bounds__(256) k_mid(MjhModel m, MjhData d, int ncc, int
   }
 }
 template <int NV4, int NR, bool NEWTON, int SG>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((!NEWTON && SG == 32 && NR == 2) ? 3 : 1, 8))) k_solve_plus(MjhModel m, MjhData d, int nsolve, int nfac) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((!NEWTON && SG == 32 && NR == 2) ? 3 : 1, 8))) k_solve_plus(MjhModel m, MjhData d, int nsolve, int nfac, int nefc_lo, int nefc_hi) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int wpb = blockDim.x / SG;
-  if ((int)blockIdx.x < nsolve) solve_body<NV4, NR, NEWTON, SG>(m, d, smem, Blk{(int)blockIdx.x * wpb, wpb, (int)blockDim.x});
+  if ((int)blockIdx.x < nsolve) solve_body<NV4, NR, NEWTON, SG>(m, d, smem, Blk{(int)blockIdx.x * wpb, wpb, (int)blockDim.x}, nefc_lo, nefc_hi);
   // CG only: the Newton kernel holds 256 VGPRs (one wave per SIMD), which would throttle the riders too (measured
   // +120 us); for Newton they ride along with the integrator launch instead
   else if (!NEWTON) {
@@ -255,7 +255,7 @@ static int solve_supported(const MjhModel* m, const MjhData* d) {
 // SG = lanes per world: 32 (two worlds per wavefront) for nv <= 32, 64 for 32 < nv <= 64.  with_factor appends the
 // L'DL-factor workgroups (fused step, CG); without it the launch is the plain `solve` stage.
 template <int NV4, int NR, bool NEWTON, int SG>
-static int launch_solve_t(const MjhModel* m, const MjhData* d, bool with_factor, hipStream_t s) {
+static int launch_solve_t(const MjhModel* m, const MjhData* d, bool with_factor, hipStream_t s, int nefc_lo = -1, int nefc_hi = 0x7fffffff) {
   const SolveLayout lay = solve_layout<NV4, NR, SG, NEWTON>(d->njmax);
   const FacLayout fl = fac_layout(m->nv, m->nC);
   const size_t ms_bytes = sizeof(int) * mstruct_ints(m->nv, m->nC);  // riders only: the solver keeps no shared tables
@@ -272,43 +272,50 @@ static int launch_solve_t(const MjhModel* m, const MjhData* d, bool with_factor,
   HIPCHK(set_lds((k_solve_plus<NV4, NR, NEWTON, SG>), lds));
   const int nsolve = (d->nworld + wpb - 1) / wpb, nfac = with_factor ? (d->nworld + wf - 1) / wf : 0;
   // riders (fused step, CG): factor workgroups, then as many contact-publication workgroups
-  hipLaunchKernelGGL((k_solve_plus<NV4, NR, NEWTON, SG>), dim3(nsolve + 2 * nfac), dim3(threads), lds, s, *m, *d, nsolve, nfac);
+  hipLaunchKernelGGL((k_solve_plus<NV4, NR, NEWTON, SG>), dim3(nsolve + 2 * nfac), dim3(threads), lds, s, *m, *d, nsolve, nfac, nefc_lo, nefc_hi);
   return MJH_OK;
 }
 template <int NR, bool NEWTON>
-static int launch_solve_32(const MjhModel* m, const MjhData* d, bool wf, hipStream_t s) {
+static int launch_solve_32(const MjhModel* m, const MjhData* d, bool wf, hipStream_t s, int lo = -1, int hi = 0x7fffffff) {
   switch ((m->nv + 3) / 4) {  // kernels are specialised on ceil(nv/4): no padded matrix columns
     case 0:
-    case 1: return launch_solve_t<1, NR, NEWTON, 32>(m, d, wf, s);
-    case 2: return launch_solve_t<2, NR, NEWTON, 32>(m, d, wf, s);
-    case 3: return launch_solve_t<3, NR, NEWTON, 32>(m, d, wf, s);
-    case 4: return launch_solve_t<4, NR, NEWTON, 32>(m, d, wf, s);
-    case 5: return launch_solve_t<5, NR, NEWTON, 32>(m, d, wf, s);
-    case 6: return launch_solve_t<6, NR, NEWTON, 32>(m, d, wf, s);
-    case 7: return launch_solve_t<7, NR, NEWTON, 32>(m, d, wf, s);
-    default: return launch_solve_t<8, NR, NEWTON, 32>(m, d, wf, s);
+    case 1: return launch_solve_t<1, NR, NEWTON, 32>(m, d, wf, s, lo, hi);
+    case 2: return launch_solve_t<2, NR, NEWTON, 32>(m, d, wf, s, lo, hi);
+    case 3: return launch_solve_t<3, NR, NEWTON, 32>(m, d, wf, s, lo, hi);
+    case 4: return launch_solve_t<4, NR, NEWTON, 32>(m, d, wf, s, lo, hi);
+    case 5: return launch_solve_t<5, NR, NEWTON, 32>(m, d, wf, s, lo, hi);
+    case 6: return launch_solve_t<6, NR, NEWTON, 32>(m, d, wf, s, lo, hi);
+    case 7: return launch_solve_t<7, NR, NEWTON, 32>(m, d, wf, s, lo, hi);
+    default: return launch_solve_t<8, NR, NEWTON, 32>(m, d, wf, s, lo, hi);
   }
 }
 template <int NR, bool NEWTON>
-static int launch_solve_64(const MjhModel* m, const MjhData* d, bool wf, hipStream_t s) {
+static int launch_solve_64(const MjhModel* m, const MjhData* d, bool wf, hipStream_t s, int lo = -1, int hi = 0x7fffffff) {
   const int nv4 = (m->nv + 3) / 4;  // rounded up to an instantiated size (lanes past nv hold identity rows)
-  if (nv4 <= 9) return launch_solve_t<9, NR, NEWTON, 64>(m, d, wf, s);
-  if (nv4 <= 10) return launch_solve_t<10, NR, NEWTON, 64>(m, d, wf, s);
-  if (nv4 <= 12) return launch_solve_t<12, NR, NEWTON, 64>(m, d, wf, s);
-  if (nv4 <= 14) return launch_solve_t<14, NR, NEWTON, 64>(m, d, wf, s);
-  return launch_solve_t<16, NR, NEWTON, 64>(m, d, wf, s);
+  if (nv4 <= 9) return launch_solve_t<9, NR, NEWTON, 64>(m, d, wf, s, lo, hi);
+  if (nv4 <= 10) return launch_solve_t<10, NR, NEWTON, 64>(m, d, wf, s, lo, hi);
+  if (nv4 <= 12) return launch_solve_t<12, NR, NEWTON, 64>(m, d, wf, s, lo, hi);
+  if (nv4 <= 14) return launch_solve_t<14, NR, NEWTON, 64>(m, d, wf, s, lo, hi);
+  return launch_solve_t<16, NR, NEWTON, 64>(m, d, wf, s, lo, hi);
 }
 static int launch_solve_any(const MjhModel* m, const MjhData* d, bool with_factor, hipStream_t s) {
   if (int rc = solve_supported(m, d)) return rc;
   const bool newton = m->solver == SOL_NEWTON;
+  // njmax > 64: two launches over the same world list (see solve_body): a small-row instantiation for the worlds with
+  // at most 64 rows, the big one (riders attached) for the rest
   if (m->nv <= 32) {
-    // rows per lane (32 lanes per world): 2 covers njmax <= 64 (humanoid, panda), 6 covers njmax <= 192
+    // rows per lane (32 lanes per world): 2 covers 64 rows (humanoid, panda), 6 covers 192
     if (d->njmax <= 64) return newton ? launch_solve_32<2, true>(m, d, with_factor, s) : launch_solve_32<2, false>(m, d, with_factor, s);
-    return newton ? launch_solve_32<6, true>(m, d, with_factor, s) : launch_solve_32<6, false>(m, d, with_factor, s);
+    if (int rc = newton ? launch_solve_32<2, true>(m, d, false, s, -1, 64) : launch_solve_32<2, false>(m, d, false, s, -1, 64)) return rc;
+    return newton ? launch_solve_32<6, true>(m, d, with_factor, s, 64) : launch_solve_32<6, false>(m, d, with_factor, s, 64);
   }
-  // 64 lanes per world: 1 row per lane covers njmax <= 64, 3 cover njmax <= 192 (G1-class)
+  // 64 lanes per world: 1 / 2 / 3 rows per lane cover 64 / 128 / 192 rows.  The second launch of a pair runs after the
+  // first on the same stream, so the split point is chosen to leave it (almost) empty: its real worlds would otherwise
+  // be a serial tail on an idle GPU (G1: 6 % of the worlds exceed 64 rows, practically none exceed 128)
   if (d->njmax <= 64) return newton ? launch_solve_64<1, true>(m, d, with_factor, s) : launch_solve_64<1, false>(m, d, with_factor, s);
-  return newton ? launch_solve_64<3, true>(m, d, with_factor, s) : launch_solve_64<3, false>(m, d, with_factor, s);
+  if (d->njmax <= 128) return newton ? launch_solve_64<2, true>(m, d, with_factor, s) : launch_solve_64<2, false>(m, d, with_factor, s);
+  if (int rc = newton ? launch_solve_64<2, true>(m, d, with_factor, s, -1, 128) : launch_solve_64<2, false>(m, d, with_factor, s, -1, 128)) return rc;
+  return newton ? launch_solve_64<3, true>(m, d, false, s, 128) : launch_solve_64<3, false>(m, d, false, s, 128);
 }
 static int launch_solve(const MjhModel* m, const MjhData* d, hipStream_t s) { return launch_solve_any(m, d, false, s); }
 static int launch_solve_plus(const MjhModel* m, const MjhData* d, hipStream_t s) { return launch_solve_any(m, d, true, s); }

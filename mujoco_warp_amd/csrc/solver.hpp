@@ -121,7 +121,8 @@ template <int NV4, int NR, int G, bool NEWTON>
 __host__ __device__ inline SolveLayout solve_layout(int njmax) {
   constexpr int NVR = 4 * NV4;
   constexpr int JS = (NV4 & 1) ? NVR : NVR + 4;  // JS/4 odd: row-per-lane 16-byte reads hit distinct banks
-  const int njp = ((njmax + 15) / 16) * 16;  // J^T f runs over 16-row chunks (rows past nefc are zero)
+  // J^T f runs over 16-row chunks (rows past nefc are zero); a kernel never holds more rows than its lanes cover
+  const int njp = min(((njmax + 15) / 16) * 16, G * NR);
   SolveLayout p;
   int o = 0;
   p.J = o; o += (njp > NVR ? njp : NVR) * JS;  // also stages the dense NVR x NVR copy of M
@@ -233,7 +234,7 @@ DEV void invert_rows(const float (&mrow)[NVR], float (&b)[NVR], float* buf, int 
 }
 
 template <int NV4, int NR, bool NEWTON, int G>
-DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk& b) {
+DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk& b, int nefc_lo = -1, int nefc_hi = 0x7fffffff) {
   if ((int)threadIdx.x >= b.nthreads) return;
   constexpr int NVR = 4 * NV4;
   constexpr int JS = (NV4 & 1) ? NVR : NVR + 4;
@@ -249,7 +250,12 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
   float* S = smem + (size_t)gib * lay.total;
   float *Jl = S + lay.J, *eforce = S + lay.force, *eda = S + lay.da, *bsearch = S + lay.bsearch, *bgrad = S + lay.bgrad, *col = S + lay.col;
 
-  const int nefc = min(min(d.nefc[w], njmax), G * NR);
+  // Two-size dispatch (njmax > 64): the same world list is offered to a small-row and a big-row instantiation; a world
+  // is solved by the one whose range (nefc_lo, nefc_hi] holds its row count and skipped by the other.  LDS per world
+  // follows the instantiation's row capacity, so the common few-row worlds run at several times the occupancy.
+  const int nefc_all = min(d.nefc[w], njmax);
+  if (nefc_all <= nefc_lo || nefc_all > nefc_hi) return;
+  const int nefc = min(nefc_all, G * NR);
   const int ne = d.ne[w], nf = d.nf[w];
   const bool has_fl = nf > 0;  // friction-loss rows present: the line search needs the three-zone cost (rare)
   const size_t vo = (size_t)w * nv, eo = (size_t)w * njmax;
