@@ -180,10 +180,10 @@ __global__ void __launch_bounds__(256) k_mid(MjhModel m, MjhData d, int ncc, int
   }
 }
 template <int NV4, int NR, bool NEWTON, int SG>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((!NEWTON && SG == 32 && NR == 2) ? 3 : 1, 8))) k_solve_plus(MjhModel m, MjhData d, int nsolve, int nfac, int nefc_lo, int nefc_hi) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((!NEWTON && SG == 32 && NR == 2) ? 3 : 1, 8))) k_solve_plus(MjhModel m, MjhData d, int nsolve, int nfac, int nefc_lo, int nefc_hi, int fuse_euler) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int wpb = blockDim.x / SG;
-  if ((int)blockIdx.x < nsolve) solve_body<NV4, NR, NEWTON, SG>(m, d, smem, Blk{(int)blockIdx.x * wpb, wpb, (int)blockDim.x}, nefc_lo, nefc_hi);
+  if ((int)blockIdx.x < nsolve) solve_body<NV4, NR, NEWTON, SG>(m, d, smem, Blk{(int)blockIdx.x * wpb, wpb, (int)blockDim.x}, nefc_lo, nefc_hi, fuse_euler);
   // CG only: the Newton kernel holds 256 VGPRs (one wave per SIMD), which would throttle the riders too (measured
   // +120 us); for Newton they ride along with the integrator launch instead
   else if (!NEWTON) {
@@ -245,6 +245,8 @@ static int launch_mid(const MjhModel* m, const MjhData* d, bool sched, hipStream
                      stride_cc, sched ? 1 : 0);
   return MJH_OK;
 }
+// set by the fused STEP path when the solver launch also integrates (see euler_fusable)
+static thread_local bool g_fuse_euler = false;
 static int solve_supported(const MjhModel* m, const MjhData* d) {
   if (m->cone != 0) return fail(MJH_E_UNSUPPORTED, "elliptic cones are not implemented yet");
   if (m->nv > 64) return fail(MJH_E_UNSUPPORTED, "nv > 64 needs the sparse/blocked solver path (not implemented yet)");
@@ -272,7 +274,7 @@ static int launch_solve_t(const MjhModel* m, const MjhData* d, bool with_factor,
   HIPCHK(set_lds((k_solve_plus<NV4, NR, NEWTON, SG>), lds));
   const int nsolve = (d->nworld + wpb - 1) / wpb, nfac = with_factor ? (d->nworld + wf - 1) / wf : 0;
   // riders (fused step, CG): factor workgroups, then as many contact-publication workgroups
-  hipLaunchKernelGGL((k_solve_plus<NV4, NR, NEWTON, SG>), dim3(nsolve + 2 * nfac), dim3(threads), lds, s, *m, *d, nsolve, nfac, nefc_lo, nefc_hi);
+  hipLaunchKernelGGL((k_solve_plus<NV4, NR, NEWTON, SG>), dim3(nsolve + 2 * nfac), dim3(threads), lds, s, *m, *d, nsolve, nfac, nefc_lo, nefc_hi, g_fuse_euler ? 1 : 0);
   return MJH_OK;
 }
 template <int NR, bool NEWTON>
@@ -448,8 +450,17 @@ static int run_stage(const MjhModel* m, const MjhData* d, int stage, hipStream_t
       bool sched_done = false;
       { Scope sc(K_POS); TRY(launch_pos_plus(m, d, POS_KINEMATICS, POS_CRB, &sched_done, s)); }
       { Scope sc(K_MID); TRY(launch_mid(m, d, !sched_done, s)); }
-      { Scope sc(K_SOLVE); TRY(launch_solve_plus(m, d, s)); }
-      { Scope sc(K_INTEGRATE); TRY(launch_integrate_plus(m, d, mode, stage == MJH_STAGE_STEP, s)); }
+      // explicit Euler without activations: the velocity/position update is a few loads and stores per dof, done by the
+      // solver's own epilogue (saves a launch); every other case keeps the integrator workgroups
+      // (CG only: the Newton launch keeps its integrator launch anyway, for the riders, and measured 2 % slower fused)
+      const bool fuse_euler = stage == MJH_STAGE_STEP && m->integrator == INT_EULER && m->na == 0 && m->solver == SOL_CG &&
+                              (m->disableflags & (DSBL_EULERDAMP | DSBL_DAMPER)) != 0;
+      g_fuse_euler = fuse_euler;
+      int rc;
+      { Scope sc(K_SOLVE); rc = launch_solve_plus(m, d, s); }
+      g_fuse_euler = false;
+      TRY(rc);
+      { Scope sc(K_INTEGRATE); TRY(launch_integrate_plus(m, d, mode, stage == MJH_STAGE_STEP && !fuse_euler, s)); }
       return MJH_OK;
     }
     default:
