@@ -346,6 +346,14 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
     bgrad[lig] = fs;
     gsync();
     qs = mul_row(h, bgrad);
+    // one step of iterative refinement with the exact M: the float32 explicit inverse alone carries cond(M) * eps of
+    // relative error (found by the randomised-model tests), fine for a preconditioner but not for qacc_smooth
+    bsearch[lig] = qs;
+    gsync();
+    const float res = fs - mul_row(mrow, bsearch);
+    bgrad[lig] = active ? res : 0.0f;
+    gsync();
+    qs += mul_row(h, bgrad);
     if (active) d.qacc_smooth[vo + lig] = qs;
     gsync();
   } else if (nefc == 0 || !warm) {

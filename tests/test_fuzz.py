@@ -1,0 +1,128 @@
+"""Randomised-model parity: random kinematic trees with mixed joint / geom / actuator types against the float64 oracle.
+
+The fixed models (humanoid, G1, Panda, pendula, free bodies, pile) pin specific code paths; these seeds sweep the
+combinations: free / ball / hinge / slide joints at random depths, limits, damping, springs, armature, friction loss,
+sphere / capsule / box / ellipsoid / cylinder geoms resting on or falling to a plane, sphere-sphere / sphere-capsule /
+capsule-capsule contacts between bodies, motor and position actuators, Euler and implicitfast, both solvers.
+"""
+
+import numpy as np
+import pytest
+
+import mujoco_warp_amd as mjw
+from conftest import relerr
+from oracle import ref
+
+pytestmark = pytest.mark.gpu
+
+
+def random_model_xml(seed):
+  r = np.random.default_rng(seed)
+  integrator = "implicitfast" if seed % 2 else "Euler"
+  lines = [f'<mujoco><option timestep="0.003" integrator="{integrator}"/>',
+           '<default><geom condim="3" friction="0.8 0.02 0.001"/><joint armature="0.02"/></default>', "<worldbody>",
+           '<geom name="floor" type="plane" size="0 0 .05" contype="3" conaffinity="0"/>']
+  joints, close = [], []
+  nb = int(r.integers(3, 9))
+  depth = 0
+  for b in range(nb):
+    up = int(r.integers(0, depth + 1)) if b else 0   # pop back up the tree
+    for _ in range(up):
+      lines.append(close.pop())
+      depth -= 1
+    if depth == 0:
+      pos = f"{r.uniform(-1, 1):.3f} {r.uniform(-1, 1):.3f} {r.uniform(0.25, 0.6):.3f}"
+    else:
+      pos = f"{r.uniform(-.1, .1):.3f} {r.uniform(-.1, .1):.3f} {r.uniform(-.25, -.12):.3f}"
+    lines.append(f'<body name="b{b}" pos="{pos}">')
+    close.append("</body>")
+    depth += 1
+    jt = r.choice(["free", "ball", "hinge", "slide", "hinge"]) if depth == 1 else r.choice(["ball", "hinge", "slide", "hinge"])
+    jn = f"j{b}"
+    if jt == "free":
+      lines.append(f'<freejoint name="{jn}"/>')
+    elif jt == "ball":
+      lim = 'range="0 50" limited="true"' if r.random() < 0.5 else ""
+      lines.append(f'<joint name="{jn}" type="ball" damping="{r.uniform(0, .05):.3f}" {lim}/>')
+    else:
+      ax = r.standard_normal(3)
+      ax /= np.linalg.norm(ax)
+      lim = f'range="{-r.uniform(20, 60):.1f} {r.uniform(20, 60):.1f}" limited="true"' if jt == "hinge" else f'range="-.08 .08" limited="true"'
+      extra = ""
+      if r.random() < 0.4:
+        extra += f' stiffness="{r.uniform(.5, 3):.2f}" springref="{r.uniform(-5, 5):.2f}"'
+      if r.random() < 0.3:
+        extra += f' frictionloss="{r.uniform(.01, .08):.3f}"'
+      if r.random() < 0.5:
+        extra += f' armature="{r.uniform(.01, .05):.4f}"'
+      lines.append(f'<joint name="{jn}" type="{jt}" axis="{ax[0]:.3f} {ax[1]:.3f} {ax[2]:.3f}" damping="{r.uniform(0, .2):.3f}" {lim if r.random() < .6 else ""}{extra}/>')
+      joints.append((jn, jt))
+    gt = r.choice(["sphere", "capsule", "capsule", "box", "ellipsoid", "cylinder"])
+    s = r.uniform(.03, .07)
+    # only spheres / capsules may touch each other (supported pair types); everything touches the floor
+    # (floor: contype bits 0|1; spheres/capsules: contype bit 2, conaffinity bits 0|2; the rest: conaffinity bit 1 only)
+    body_contact = 'contype="4" conaffinity="5"' if gt in ("sphere", "capsule") else 'contype="0" conaffinity="2"'
+    if gt == "sphere":
+      lines.append(f'<geom type="sphere" size="{s:.3f}" {body_contact}/>')
+    elif gt == "capsule":
+      lines.append(f'<geom type="capsule" fromto="0 0 0 {r.uniform(-.1, .1):.3f} {r.uniform(-.1, .1):.3f} {-r.uniform(.1, .2):.3f}" size="{s * .6:.3f}" {body_contact}/>')
+    elif gt == "box":
+      lines.append(f'<geom type="box" size="{s:.3f} {s * r.uniform(.6, 1.5):.3f} {s * r.uniform(.6, 1.5):.3f}" {body_contact}/>')
+    elif gt == "ellipsoid":
+      lines.append(f'<geom type="ellipsoid" size="{s:.3f} {s * 1.3:.3f} {s * .8:.3f}" {body_contact}/>')
+    else:
+      lines.append(f'<geom type="cylinder" size="{s:.3f} {s * 1.5:.3f}" {body_contact}/>')
+  while close:
+    lines.append(close.pop())
+  lines.append("</worldbody>")
+  if joints:
+    lines.append("<actuator>")
+    for jn, jt in joints[: 4]:
+      if r.random() < 0.5:
+        lines.append(f'<motor joint="{jn}" gear="{r.uniform(.5, 3):.2f}" ctrlrange="-1 1" ctrllimited="true"/>')
+      else:
+        lines.append(f'<position joint="{jn}" kp="{r.uniform(5, 40):.1f}" kv="{r.uniform(.1, 2):.2f}"/>')
+    lines.append("</actuator>")
+  lines.append("</mujoco>")
+  return "\n".join(lines)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_model_forward_and_steps(seed):
+  mjm = mjw.mjcf.from_xml_string(random_model_xml(seed))
+  mjm.opt.solver = int(mjw.SolverType.NEWTON if seed % 3 else mjw.SolverType.CG)
+  mjm.opt.iterations, mjm.opt.ls_iterations = 100, 50
+  s = ref.RefSim(mjm, nconmax=48, njmax=128, tolerance=1e-6)
+  rng = np.random.default_rng(1000 + seed)
+  s.qvel[:] = 0.5 * rng.standard_normal(mjm.nv)
+  if mjm.nu:
+    s.ctrl[:] = rng.uniform(-1, 1, mjm.nu)
+  for i in range(30 + 10 * (seed % 4)):  # let things fall and touch
+    s.step()
+  s.forward()
+  cond = np.linalg.cond(s.dense_M())
+  if cond > 3e4:  # float32 cannot resolve M^-1 to the test tolerances (cond * eps); a statement about the model, not the engine
+    pytest.skip(f"ill-conditioned mass matrix (cond {cond:.1e})")
+  m = mjw.put_model(mjm)
+  d = mjw.put_data(mjm, mjw.MjData(mjm), nworld=3, nconmax=48, njmax=128)
+  worst_q = worst_v = worst_a = 0.0
+  for i in range(25):
+    for name in ("qpos", "qvel", "act", "ctrl", "qacc_warmstart"):
+      dst = getattr(d, name)
+      if dst.size:
+        dst.assign(np.tile(getattr(s, name).astype(np.float32), (d.nworld, 1)))
+    if i == 0:
+      s.forward()
+      mjw.forward(m, d)
+      assert int(d.nefc.numpy()[2]) == s.nefc and int(d.ws_ncon.numpy()[2]) == s.ncon
+      worst_a = relerr(d.qacc.numpy()[2], s.qacc)
+    mjw.step(m, d)
+    s.step()
+    worst_q = max(worst_q, relerr(d.qpos.numpy()[1], s.qpos))
+    worst_v = max(worst_v, relerr(d.qvel.numpy()[1], s.qvel))
+  assert np.isfinite(d.qpos.numpy()).all()
+  print(f"seed {seed}: nv {mjm.nv} qacc {worst_a:.2e} qpos {worst_q:.2e} qvel {worst_v:.2e} niter {int(d.solver_niter.numpy()[1])} vs {s.solver_niter}")
+  # CG stops on a float32-noisy improvement/gradient test: the converged accelerations agree less tightly than Newton's
+  assert worst_a <= (2e-2 if mjm.opt.solver == int(mjw.SolverType.CG) else 5e-3), worst_a
+  assert worst_q <= 2e-5, worst_q
+  assert worst_v <= 3e-3, worst_v
