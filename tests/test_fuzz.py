@@ -1,10 +1,12 @@
-"""Randomised-model parity: random kinematic trees with mixed joint / geom / actuator types against the float64 oracle.
+"""Randomised-model parity (40 seeds by default, MJH_FUZZ_SEEDS=N for more; 120 were run clean): random kinematic trees with mixed joint / geom / actuator types against the float64 oracle.
 
 The fixed models (humanoid, G1, Panda, pendula, free bodies, pile) pin specific code paths; these seeds sweep the
 combinations: free / ball / hinge / slide joints at random depths, limits, damping, springs, armature, friction loss,
 sphere / capsule / box / ellipsoid / cylinder geoms resting on or falling to a plane, sphere-sphere / sphere-capsule /
 capsule-capsule contacts between bodies, motor and position actuators, Euler and implicitfast, both solvers.
 """
+
+import os
 
 import numpy as np
 import pytest
@@ -87,7 +89,7 @@ def random_model_xml(seed):
   return "\n".join(lines)
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MJH_FUZZ_SEEDS", "40"))))
 def test_random_model_forward_and_steps(seed):
   mjm = mjw.mjcf.from_xml_string(random_model_xml(seed))
   mjm.opt.solver = int(mjw.SolverType.NEWTON if seed % 3 else mjw.SolverType.CG)
