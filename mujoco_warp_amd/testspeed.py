@@ -43,10 +43,12 @@ def main(argv=None):
   ap.add_argument("mjcf")
   ap.add_argument("--function", default="step")
   ap.add_argument("--nworld", type=int, default=8192)
-  ap.add_argument("--nstep", type=int, default=1000)
+  ap.add_argument("--nstep", type=int, default=None, help="default 1000, or the length of the --replay sequence")
   ap.add_argument("--nconmax", type=int, default=None)
   ap.add_argument("--njmax", type=int, default=None)
   ap.add_argument("--keyframe", type=int, default=0)
+  ap.add_argument("--replay", default=None, help="NPZ file with a `ctrl` [nstep, nu] sequence used as the centre of the control noise "
+                  "(reference cli.py:53, 153-161); nstep defaults to its length; an initial qpos/qvel in the file is applied")
   ap.add_argument("--noise_std", type=float, default=0.01)
   ap.add_argument("--noise_rate", type=float, default=0.1)
   ap.add_argument("-o", "--override", action="append", default=[])
@@ -81,8 +83,22 @@ def main(argv=None):
   mjd = mjw.MjData(mjm)
   if mjm.nkey > args.keyframe:
     mjw.mj_resetDataKeyframe(mjm, mjd, args.keyframe)
+  ctrls = None
+  if args.replay:
+    z = np.load(args.replay)
+    ctrls = np.asarray(z["ctrl"], dtype=np.float32)
+    if ctrls.ndim != 2 or ctrls.shape[1] != mjm.nu:
+      raise ValueError(f"replay ctrl has shape {ctrls.shape}, expected [nstep, {mjm.nu}]")
+    if "qpos" in z.files and z["qpos"].shape[-1] == mjm.nq:
+      mjd.qpos[:] = z["qpos"][0]
+    if "qvel" in z.files and z["qvel"].shape[-1] == mjm.nv:
+      mjd.qvel[:] = z["qvel"][0]
+    args.nstep = len(ctrls) if args.nstep is None else min(args.nstep, len(ctrls))
+  if args.nstep is None:
+    args.nstep = 1000
   d = mjw.put_data(mjm, mjd, nworld=args.nworld, nconmax=args.nconmax, njmax=args.njmax)
   center = mjw.DeviceArray.from_numpy(np.asarray(mjd.ctrl, dtype=np.float32)) if mjm.nu else None
+  centers = [mjw.DeviceArray.from_numpy(c) for c in ctrls[: args.nstep]] if ctrls is not None else None
 
   if args.format == "human":
     print(f"Model\n  nq: {m.nq} nv: {m.nv} nu: {m.nu} nbody: {m.nbody} ngeom: {m.ngeom}")
@@ -107,7 +123,7 @@ def main(argv=None):
   trace_ms = np.zeros(len(mjw.KERNEL_NAMES))
   for i in range(args.nstep):
     if mjm.nu:
-      mjw.ctrl_noise(m, d, i, args.noise_std, args.noise_rate, center)
+      mjw.ctrl_noise(m, d, i, args.noise_std, args.noise_rate, centers[i] if centers is not None else center)
       torch.cuda.synchronize()
     t1 = time.perf_counter()
     if graph is not None:
