@@ -76,11 +76,20 @@ def build(force=False, verbose=False):
   """Compile libmjhip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
   if not force and not needs_build():
     return LIB_PATH
-  cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
-         "-o", LIB_PATH, SOURCES[0]]
-  if verbose:
-    print(" ".join(cmd))
-  subprocess.check_call(cmd)
+  # one builder at a time (N ranks of a multi-GPU launch may all find the library missing); write-then-rename so that a
+  # concurrent loader never maps a half-written file
+  import fcntl
+
+  with open(LIB_PATH + ".lock", "w") as lock:
+    fcntl.flock(lock, fcntl.LOCK_EX)
+    if not force and not needs_build():
+      return LIB_PATH
+    tmp = LIB_PATH + f".tmp{os.getpid()}"
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value", "-o", tmp, SOURCES[0]]
+    if verbose:
+      print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    os.replace(tmp, LIB_PATH)
   return LIB_PATH
 
 
