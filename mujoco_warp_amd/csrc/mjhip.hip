@@ -247,6 +247,8 @@ static int launch_mid(const MjhModel* m, const MjhData* d, bool sched, hipStream
 }
 // set by the fused STEP path when the solver launch also integrates (see euler_fusable)
 static thread_local bool g_fuse_euler = false;
+// set by the fused path when the Newton riders run on the side stream (see side_stream)
+static thread_local bool g_riders_on_side = false;
 static int solve_supported(const MjhModel* m, const MjhData* d) {
   if (m->cone != 0) return fail(MJH_E_UNSUPPORTED, "elliptic cones are not implemented yet");
   if (m->nv > 64) return fail(MJH_E_UNSUPPORTED, "nv > 64 needs the sparse/blocked solver path (not implemented yet)");
@@ -326,7 +328,7 @@ static int launch_integrate_plus(const MjhModel* m, const MjhData* d, int mode, 
   const IntLayout lay = int_layout(m->nv, m->nC);
   const FacLayout fl = fac_layout(m->nv, m->nC);
   const size_t ms_bytes = sizeof(int) * mstruct_ints(m->nv, m->nC);
-  const bool with_factor = m->solver == SOL_NEWTON;
+  const bool with_factor = m->solver == SOL_NEWTON && !g_riders_on_side;
   size_t lds = std::max(ms_bytes + sizeof(float) * std::max(lay.total, fl.total) * 8, (size_t)2048);
   if (lds > (size_t)kLdsPerCU) return fail(MJH_E_UNSUPPORTED, "k_integrate: does not fit in LDS");
   HIPCHK(set_lds(k_integrate_plus<G>, lds));
@@ -398,6 +400,34 @@ struct Scope {
 };
 enum { K_NOISE = 0, K_POS = 1, K_COLLISION = 2, K_CONSTRAINT = 3, K_VEL = 4, K_SOLVE = 5, K_INTEGRATE = 6, K_OTHER = 7, K_MID = 8 };
 
+// Newton only: the public-output riders (contact publication, L'DL factor + qacc_smooth) cannot ride with the solver
+// launch (its 256 VGPRs throttle them) and cost 55 us at the end of the integrator launch; they run on a low-priority
+// side stream beside the solver instead.  Two event hops (fork after k_mid, join after the integrator), neither on the
+// solver's critical path; created on first use per host thread and device, never freed.
+struct Side {
+  hipStream_t stream;
+  hipEvent_t fork, join;
+};
+static Side* side_stream() {
+  static thread_local Side* per_dev[16] = {nullptr};
+  static const bool disabled = getenv("MJH_NO_SIDE") != nullptr;  // developer knob
+  if (disabled) return nullptr;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  if (!per_dev[dev]) {
+    Side* sd = new Side();
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
+    if (hipStreamCreateWithPriority(&sd->stream, hipStreamNonBlocking, least) != hipSuccess ||
+        hipEventCreateWithFlags(&sd->fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&sd->join, hipEventDisableTiming) != hipSuccess) {
+      delete sd;
+      return nullptr;
+    }
+    per_dev[dev] = sd;
+  }
+  return per_dev[dev];
+}
 static int run_stage(const MjhModel* m, const MjhData* d, int stage, hipStream_t s) {
   switch (stage) {
     case MJH_STAGE_KINEMATICS: { Scope sc(K_POS); return launch_pos(m, d, POS_KINEMATICS, POS_KINEMATICS, s); }
@@ -450,6 +480,14 @@ static int run_stage(const MjhModel* m, const MjhData* d, int stage, hipStream_t
       bool sched_done = false;
       { Scope sc(K_POS); TRY(launch_pos_plus(m, d, POS_KINEMATICS, POS_CRB, &sched_done, s)); }
       { Scope sc(K_MID); TRY(launch_mid(m, d, !sched_done, s)); }
+      Side* side = (m->solver == SOL_NEWTON && !(g_instr && g_instr->on)) ? side_stream() : nullptr;
+      if (side) {
+        HIPCHK(hipEventRecord(side->fork, s));
+        HIPCHK(hipStreamWaitEvent(side->stream, side->fork, 0));
+        TRY(launch_publish(d, side->stream));
+        TRY(launch_factor_smooth(m, d, 1, side->stream));
+        HIPCHK(hipEventRecord(side->join, side->stream));
+      }
       // explicit Euler without activations: the velocity/position update is a few loads and stores per dof, done by the
       // solver's own epilogue (saves a launch); every other case keeps the integrator workgroups
       // (CG only: the Newton launch keeps its integrator launch anyway, for the riders, and measured 2 % slower fused)
@@ -460,7 +498,11 @@ static int run_stage(const MjhModel* m, const MjhData* d, int stage, hipStream_t
       { Scope sc(K_SOLVE); rc = launch_solve_plus(m, d, s); }
       g_fuse_euler = false;
       TRY(rc);
-      { Scope sc(K_INTEGRATE); TRY(launch_integrate_plus(m, d, mode, stage == MJH_STAGE_STEP && !fuse_euler, s)); }
+      g_riders_on_side = side != nullptr;
+      { Scope sc(K_INTEGRATE); rc = launch_integrate_plus(m, d, mode, stage == MJH_STAGE_STEP && !fuse_euler, s); }
+      g_riders_on_side = false;
+      TRY(rc);
+      if (side) HIPCHK(hipStreamWaitEvent(s, side->join, 0));  // every fork rejoins the caller's stream
       return MJH_OK;
     }
     default:
