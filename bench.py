@@ -83,7 +83,7 @@ def main():
   ap.add_argument("--steps", type=int, default=200)
   ap.add_argument("--warmup", type=int, default=20)
   ap.add_argument("--nworld", type=int, default=8192, help="worlds per GPU")
-  ap.add_argument("--solver", default="cg", choices=["cg", "newton"])
+  ap.add_argument("--solver", default="cg", choices=["cg", "newton", "pgs"])
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--no-roofline", action="store_true")
   args = ap.parse_args()
@@ -91,7 +91,7 @@ def main():
   xml = os.path.join(ROOT, "benchmarks", "humanoid", "humanoid.xml")
   cpu = None
   if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_cpu_baseline:
-    cpu = cpu_baseline(xml, {"cg": 1, "newton": 2}[args.solver])  # before any HIP context exists (fork-safe)
+    cpu = cpu_baseline(xml, {"pgs": 0, "cg": 1, "newton": 2}[args.solver])  # before any HIP context exists (fork-safe)
 
   import torch
 
@@ -165,7 +165,7 @@ def main():
     words_crb = 1501                               # CRBA(+factor) pass: cinert, cdof in; crb, M, qLD, qLDiagInv out
     t_dom = fused_us["solve"] * 1e-6
     achieved = 4 * words_solve * nworld / t_dom / 1e9
-    out["roofline"] = {"kernel": "k_solve_plus (solver workgroups + L'DL factor workgroups of the fused step)", "bound": "hbm",
+    out["roofline"] = {"kernel": "k_solve_pgs" if args.solver == "pgs" else "k_solve_plus (solver workgroups + L'DL factor workgroups of the fused step)", "bound": "hbm",
                        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                        "traffic": _traffic_from_profile(), "bytes_per_launch": 4 * words_solve * nworld,
                        "us_per_launch": fused_us["solve"],

@@ -15,7 +15,7 @@ _ROOT = os.path.dirname(_PKG)
 HEADER = os.path.join(_ROOT, "include", "mjhip.h")
 LIB_PATH = os.path.join(_PKG, "libmjhip.so")
 SOURCES = [os.path.join(_PKG, "csrc", f) for f in
-           ("mjhip.hip", "dev_common.hpp", "smooth.hpp", "collide.hpp", "constraint.hpp", "solver.hpp", "integrate.hpp")]
+           ("mjhip.hip", "dev_common.hpp", "smooth.hpp", "collide.hpp", "constraint.hpp", "solver.hpp", "pgs.hpp", "integrate.hpp")]
 
 _CTYPES = {"int": ctypes.c_int, "float": ctypes.c_float, "unsigned int": ctypes.c_uint}
 

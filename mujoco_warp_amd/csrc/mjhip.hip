@@ -21,6 +21,7 @@
 #include "integrate.hpp"
 #include "smooth.hpp"
 #include "solver.hpp"
+#include "pgs.hpp"
 
 static thread_local char g_err[512] = "";
 static int fail(int code, const char* fmt, const char* a = "") {
@@ -252,7 +253,7 @@ static thread_local bool g_riders_on_side = false;
 static int solve_supported(const MjhModel* m, const MjhData* d) {
   if (m->cone != 0) return fail(MJH_E_UNSUPPORTED, "elliptic cones are not implemented yet");
   if (m->nv > 64) return fail(MJH_E_UNSUPPORTED, "nv > 64 needs the sparse/blocked solver path (not implemented yet)");
-  if (m->solver != SOL_NEWTON && m->solver != SOL_CG) return fail(MJH_E_UNSUPPORTED, "solver must be CG or Newton");
+  if (m->solver != SOL_NEWTON && m->solver != SOL_CG && m->solver != SOL_PGS) return fail(MJH_E_UNSUPPORTED, "unknown solver");
   if (d->njmax > 192) return fail(MJH_E_UNSUPPORTED, "njmax > 192 is not supported by the register-resident solver yet");
   return MJH_OK;
 }
@@ -302,8 +303,56 @@ static int launch_solve_64(const MjhModel* m, const MjhData* d, bool wf, hipStre
   if (nv4 <= 14) return launch_solve_t<14, NR, NEWTON, 64>(m, d, wf, s, lo, hi);
   return launch_solve_t<16, NR, NEWTON, 64>(m, d, wf, s, lo, hi);
 }
+// PGS (pgs.hpp): one launch, no riders (publish + factor ride with the integrator launch, as for Newton)
+// REG: the register-resident sweep for njmax <= 64 (see pgs.hpp)
+template <int NV4, int SG, bool REG>
+__global__ void __launch_bounds__(256) k_solve_pgs(MjhModel m, MjhData d, int refresh) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int wpb = blockDim.x / SG;
+  pgs_body<NV4, SG, REG>(m, d, smem, Blk{(int)blockIdx.x * wpb, wpb, (int)blockDim.x}, refresh);
+}
+template <int NV4, int SG, bool REG>
+static int launch_pgs_r(const MjhModel* m, const MjhData* d, hipStream_t s) {
+  const PgsLayout lay = pgs_layout<NV4, SG>(d->njmax);
+  size_t lds;
+  const int threads = pick_block(0, sizeof(float) * lay.total, SG, &lds, true);
+  if (!threads) return fail(MJH_E_UNSUPPORTED, "k_solve_pgs: njmax x nv does not fit in LDS");
+  HIPCHK(set_lds((k_solve_pgs<NV4, SG, REG>), lds));
+  const int wpb = threads / SG;
+  static const int refresh = getenv("MJH_PGS_REFRESH") ? atoi(getenv("MJH_PGS_REFRESH")) : 8;  // developer knob (REG sweep): residual rebuild period
+  hipLaunchKernelGGL((k_solve_pgs<NV4, SG, REG>), dim3((d->nworld + wpb - 1) / wpb), dim3(threads), lds, s, *m, *d, refresh);
+  return MJH_OK;
+}
+template <int NV4, int SG>
+static int launch_pgs_t(const MjhModel* m, const MjhData* d, hipStream_t s) {
+  static const bool no_reg = getenv("MJH_PGS_NOREG") != nullptr;  // developer knob: force the general (LDS) sweep
+  if (d->njmax <= 64 && !no_reg) return launch_pgs_r<NV4, 64, true>(m, d, s);  // one world per wavefront
+  return launch_pgs_r<NV4, SG, false>(m, d, s);
+}
+static int launch_pgs(const MjhModel* m, const MjhData* d, hipStream_t s) {
+  const int nv4 = (m->nv + 3) / 4;
+  if (m->nv <= 32) {
+    switch (nv4) {
+      case 0:
+      case 1: return launch_pgs_t<1, 32>(m, d, s);
+      case 2: return launch_pgs_t<2, 32>(m, d, s);
+      case 3: return launch_pgs_t<3, 32>(m, d, s);
+      case 4: return launch_pgs_t<4, 32>(m, d, s);
+      case 5: return launch_pgs_t<5, 32>(m, d, s);
+      case 6: return launch_pgs_t<6, 32>(m, d, s);
+      case 7: return launch_pgs_t<7, 32>(m, d, s);
+      default: return launch_pgs_t<8, 32>(m, d, s);
+    }
+  }
+  if (nv4 <= 9) return launch_pgs_t<9, 64>(m, d, s);
+  if (nv4 <= 10) return launch_pgs_t<10, 64>(m, d, s);
+  if (nv4 <= 12) return launch_pgs_t<12, 64>(m, d, s);
+  if (nv4 <= 14) return launch_pgs_t<14, 64>(m, d, s);
+  return launch_pgs_t<16, 64>(m, d, s);
+}
 static int launch_solve_any(const MjhModel* m, const MjhData* d, bool with_factor, hipStream_t s) {
   if (int rc = solve_supported(m, d)) return rc;
+  if (m->solver == SOL_PGS) return launch_pgs(m, d, s);
   const bool newton = m->solver == SOL_NEWTON;
   // njmax > 64: two launches over the same world list (see solve_body): a small-row instantiation for the worlds with
   // at most 64 rows, the big one (riders attached) for the rest
@@ -328,7 +377,7 @@ static int launch_integrate_plus(const MjhModel* m, const MjhData* d, int mode, 
   const IntLayout lay = int_layout(m->nv, m->nC);
   const FacLayout fl = fac_layout(m->nv, m->nC);
   const size_t ms_bytes = sizeof(int) * mstruct_ints(m->nv, m->nC);
-  const bool with_factor = m->solver == SOL_NEWTON && !g_riders_on_side;
+  const bool with_factor = m->solver != SOL_CG && !g_riders_on_side;
   size_t lds = std::max(ms_bytes + sizeof(float) * std::max(lay.total, fl.total) * 8, (size_t)2048);
   if (lds > (size_t)kLdsPerCU) return fail(MJH_E_UNSUPPORTED, "k_integrate: does not fit in LDS");
   HIPCHK(set_lds(k_integrate_plus<G>, lds));
@@ -473,7 +522,7 @@ static int run_stage(const MjhModel* m, const MjhData* d, int stage, hipStream_t
         if (stage == MJH_STAGE_STEP) { Scope sc(K_INTEGRATE); TRY(launch_integrate(m, d, mode, s)); }
         Scope sc(K_OTHER);
         TRY(launch_publish(d, s));
-        TRY(launch_factor_smooth(m, d, m->solver == SOL_NEWTON ? 1 : 0, s));
+        TRY(launch_factor_smooth(m, d, m->solver == SOL_NEWTON ? 1 : 0, s));  // CG and PGS write qacc_smooth themselves
         return MJH_OK;
       }
       // fused step: four launches on the caller's stream (see "composite launches" above)

@@ -93,8 +93,9 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
       raise NotImplementedError(f"{name} > 0 is outside the hot-path scope of this engine")
   if int(opt.integrator) not in (types.IntegratorType.EULER, types.IntegratorType.IMPLICITFAST):
     raise NotImplementedError(f"Integrator {int(opt.integrator)} is unsupported (Euler and implicitfast only).")
-  if int(opt.solver) not in (types.SolverType.CG, types.SolverType.NEWTON):
-    raise NotImplementedError("Solver must be CG or Newton (PGS is unsupported, as in the reference types.py:502).")
+  # (the reference rejects PGS, io.py solver check / types.py:502; this engine implements MuJoCo C's dual PGS, csrc/pgs.hpp)
+  if int(opt.solver) not in (types.SolverType.PGS, types.SolverType.CG, types.SolverType.NEWTON):
+    raise NotImplementedError(f"Unknown solver {int(opt.solver)}.")
   if int(opt.cone) != types.ConeType.PYRAMIDAL:
     raise NotImplementedError("Elliptic friction cones are not implemented yet.")
   if mjm.nv > 64:
@@ -561,7 +562,7 @@ def override_model(model, overrides):
     else:
       setattr(obj, attr, val)
     if isinstance(model, types.Model) and attr in ("solver", "integrator", "cone"):
-      put = {"solver": (types.SolverType.CG, types.SolverType.NEWTON), "integrator": (types.IntegratorType.EULER, types.IntegratorType.IMPLICITFAST),
+      put = {"solver": (types.SolverType.PGS, types.SolverType.CG, types.SolverType.NEWTON), "integrator": (types.IntegratorType.EULER, types.IntegratorType.IMPLICITFAST),
              "cone": (types.ConeType.PYRAMIDAL,)}[attr]
       if int(getattr(obj, attr)) not in put:
         raise NotImplementedError(f"unsupported {attr} {val}")

@@ -134,7 +134,7 @@ class GeomType(enum.IntEnum):
 
 
 class SolverType(enum.IntEnum):
-  PGS = 0  # not available in the reference either (types.py:502)
+  PGS = 0  # the reference has none (types.py:502); here: MuJoCo C's dual projected Gauss-Seidel (csrc/pgs.hpp)
   CG = 1
   NEWTON = 2
 

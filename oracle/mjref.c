@@ -1230,6 +1230,94 @@ static double linesearch(const RefModel* m, RefData* d, Ctx* c, double search_do
   return alpha;
 }
 
+/* Projected Gauss-Seidel on the dual problem  min_f 0.5 f'(A+R)f + f'b,  A = J M^-1 J', R = 1/D, b = J qacc_smooth - aref,
+ * with f unbounded on equality rows, |f| <= frictionloss on friction-loss rows and f >= 0 on limit / (pyramidal or
+ * frictionless) contact rows.
+ *
+ * The reference has NO PGS (types.py:502 "unsupported", io.py solver check), so there is no file:line to follow and no
+ * reference test: this restates the algorithm MuJoCo C documents and implements (mujoco 3.x, engine_solver.c mj_solPGS with
+ * its helpers residual / costChange / dualState / dualFinish, and the PGS branch of engine_forward.c warmstart):
+ *   warm start : force = primal constraint update at qacc_warmstart; kept only if its dual cost is <= 0 (the cost of f = 0)
+ *   sweep      : for every row i in order: res = b_i + (A+R)_i. f;  f_i <- project(f_i - res / (A+R)_ii);
+ *                change = 0.5 delta^2 (A+R)_ii + delta res;  a row whose change is > 1e-10 is restored
+ *   stop       : -(sum of changes) / (meaninertia * max(1, nv)) < tolerance, or `iterations` sweeps
+ *   finish     : qfrc_constraint = J' f,  qacc = qacc_smooth + M^-1 qfrc_constraint, states from the forces
+ * Parity unpinned (like the rest of this oracle); tests/test_oracle.py additionally checks that the PGS fixed point agrees
+ * with the Newton solution of the primal problem, which pins the restatement against an independent algorithm. */
+static void solve_pgs(const RefModel* m, RefData* d, int nefc) {
+  int nv = m->nv, ne = d->ne, nf = d->nf;
+  double* buf = (double*)calloc((size_t)nefc * nv + (size_t)nefc * nefc + 3 * (size_t)nefc + 2 * (size_t)nv, sizeof(double));
+  double *B = buf, *AR = B + (size_t)nefc * nv, *b = AR + (size_t)nefc * nefc, *jar = b + nefc, *ARf = jar + nefc, *y = ARf + nefc, *z = y + nv;
+  for (int r = 0; r < nefc; r++) solve_sparse(m, d->qLD, d->qLDiagInv, B + (size_t)r * nv, d->efc_J + (size_t)r * nv);
+  for (int r = 0; r < nefc; r++) {
+    for (int c = 0; c < nefc; c++) {
+      double s = 0;
+      for (int i = 0; i < nv; i++) s += d->efc_J[(size_t)r * nv + i] * B[(size_t)c * nv + i];
+      AR[(size_t)r * nefc + c] = s;
+    }
+    AR[(size_t)r * nefc + r] += 1.0 / d->efc_D[r];
+    double s = 0, sw = 0;
+    for (int i = 0; i < nv; i++) {
+      s += d->efc_J[(size_t)r * nv + i] * d->qacc_smooth[i];
+      sw += d->efc_J[(size_t)r * nv + i] * d->qacc_warmstart[i];
+    }
+    b[r] = s - d->efc_aref[r];
+    jar[r] = sw - d->efc_aref[r];
+  }
+  double* f = d->efc_force;
+  int warm = !(m->disableflags & DSBL_WARMSTART);
+  if (warm) {
+    Ctx c;
+    c.nv = nv; c.nefc = nefc; c.Jaref = jar;
+    update_constraint(m, d, &c);
+    double cost = 0;
+    for (int r = 0; r < nefc; r++) {
+      double s = 0;
+      for (int k = 0; k < nefc; k++) s += AR[(size_t)r * nefc + k] * f[k];
+      cost += f[r] * (b[r] + 0.5 * s);
+    }
+    if (cost > 0.0) warm = 0;
+  }
+  if (!warm) for (int r = 0; r < nefc; r++) f[r] = 0.0;
+  double scl = 1.0 / (m->meaninertia * (double)(nv > 1 ? nv : 1));
+  for (int iter = 0; iter < m->iterations; iter++) {
+    double improvement = 0;
+    for (int i = 0; i < nefc; i++) {
+      double res = b[i], Aii = AR[(size_t)i * nefc + i], old = f[i];
+      for (int k = 0; k < nefc; k++) res += AR[(size_t)i * nefc + k] * f[k];
+      double fn = old - res / Aii;
+      if (i >= ne && i < ne + nf) {
+        double fl = d->efc_frictionloss[i];
+        fn = fn < -fl ? -fl : (fn > fl ? fl : fn);
+      } else if (i >= ne + nf) {
+        if (fn < 0.0) fn = 0.0;
+      }
+      double delta = fn - old, change = 0.5 * delta * delta * Aii + delta * res;
+      if (change > 1e-10) { fn = old; change = 0.0; }
+      f[i] = fn;
+      improvement -= change;
+    }
+    d->solver_niter++;
+    if (improvement * scl < m->tolerance) break;
+  }
+  for (int r = 0; r < nefc; r++) {  /* dualState */
+    if (r < ne) d->efc_state[r] = ST_QUADRATIC;
+    else if (r < ne + nf) {
+      double fl = d->efc_frictionloss[r];
+      d->efc_state[r] = f[r] <= -fl ? ST_LINEARPOS : (f[r] >= fl ? ST_LINEARNEG : ST_QUADRATIC);
+    } else d->efc_state[r] = f[r] <= 0.0 ? ST_SATISFIED : ST_QUADRATIC;
+  }
+  for (int i = 0; i < nv; i++) {  /* dualFinish */
+    double s = 0;
+    for (int r = 0; r < nefc; r++) s += d->efc_J[(size_t)r * nv + i] * f[r];
+    d->qfrc_constraint[i] = y[i] = s;
+  }
+  solve_sparse(m, d->qLD, d->qLDiagInv, z, y);
+  for (int i = 0; i < nv; i++) d->qacc[i] = d->qacc_smooth[i] + z[i];
+  ref_mul_m(m, d, d->Ma, d->qacc);
+  free(buf);
+}
+
 /* solve solver.py:3671-3743, _solver_iteration 3525-3620, init_context 3622-3668 */
 void ref_solve(const RefModel* m, RefData* d) {
   int nv = m->nv, nefc = d->nefc < m->njmax ? d->nefc : m->njmax;
@@ -1238,6 +1326,10 @@ void ref_solve(const RefModel* m, RefData* d) {
     memcpy(d->qacc, d->qacc_smooth, sizeof(double) * nv);
     for (int i = 0; i < nv; i++) d->qfrc_constraint[i] = 0.0;
     ref_mul_m(m, d, d->Ma, d->qacc);
+    return;
+  }
+  if (m->solver == SOL_PGS) {
+    solve_pgs(m, d, nefc);
     return;
   }
   Ctx c;

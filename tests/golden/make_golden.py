@@ -65,7 +65,26 @@ def main():
     out["qpos_next"], out["qvel_next"] = s.qpos.copy(), s.qvel.copy()
     np.savez(os.path.join(OUT, f"{name}_oracle_forward.npz"), tolerance=tol, nconmax=ncm, njmax=njm,
              **{"in_" + k: v for k, v in state.items()}, **out)
+  pgs_fixture()
   print("wrote golden files to", OUT)
+
+
+def pgs_fixture():
+  """PGS solve of the humanoid forward fixture's state (same inputs; solver = PGS, 100 sweeps)."""
+  mjm = mjw.mjcf.load_xml(os.path.join(ROOT, "benchmarks", "humanoid", "humanoid.xml"))
+  f = np.load(os.path.join(OUT, "humanoid_oracle_forward.npz"))
+  tol = 1e-6
+  s = ref.RefSim(mjm, nconmax=24, njmax=64, tolerance=tol, solver=0)
+  s.reset(key=0)
+  for k in ("qpos", "qvel", "ctrl", "qacc_warmstart"):
+    getattr(s, k)[:] = f["in_" + k]
+  s.forward()
+  out = {k: getattr(s, k).copy() for k in ("qacc", "qfrc_constraint")}
+  out["efc_force"], out["efc_state"] = s.efc_force[: s.nefc].copy(), s.efc_state[: s.nefc].copy()
+  out["nefc"], out["solver_niter"] = s.nefc, s.solver_niter
+  s.step()
+  out["qpos_next"], out["qvel_next"] = s.qpos.copy(), s.qvel.copy()
+  np.savez(os.path.join(OUT, "humanoid_pgs_forward.npz"), tolerance=tol, **out)
 
 
 if __name__ == "__main__":
