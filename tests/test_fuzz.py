@@ -89,10 +89,9 @@ def random_model_xml(seed):
   return "\n".join(lines)
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("MJH_FUZZ_SEEDS", "40"))))
-def test_random_model_forward_and_steps(seed):
+def _run_seed(seed, solver, njmax_dev=128):
   mjm = mjw.mjcf.from_xml_string(random_model_xml(seed))
-  mjm.opt.solver = int(mjw.SolverType.NEWTON if seed % 3 else mjw.SolverType.CG)
+  mjm.opt.solver = int(solver)
   mjm.opt.iterations, mjm.opt.ls_iterations = 100, 50
   s = ref.RefSim(mjm, nconmax=48, njmax=128, tolerance=1e-6)
   rng = np.random.default_rng(1000 + seed)
@@ -106,25 +105,42 @@ def test_random_model_forward_and_steps(seed):
   if cond > 3e4:  # float32 cannot resolve M^-1 to the test tolerances (cond * eps); a statement about the model, not the engine
     pytest.skip(f"ill-conditioned mass matrix (cond {cond:.1e})")
   m = mjw.put_model(mjm)
-  d = mjw.put_data(mjm, mjw.MjData(mjm), nworld=3, nconmax=48, njmax=128)
+  d = mjw.put_data(mjm, mjw.MjData(mjm), nworld=3, nconmax=48, njmax=njmax_dev)
   worst_q = worst_v = worst_a = 0.0
   for i in range(25):
     for name in ("qpos", "qvel", "act", "ctrl", "qacc_warmstart"):
       dst = getattr(d, name)
       if dst.size:
         dst.assign(np.tile(getattr(s, name).astype(np.float32), (d.nworld, 1)))
+    s.forward()
+    if s.nefc > njmax_dev:
+      pytest.skip(f"model needs more than {njmax_dev} rows")
     if i == 0:
-      s.forward()
       mjw.forward(m, d)
       assert int(d.nefc.numpy()[2]) == s.nefc and int(d.ws_ncon.numpy()[2]) == s.ncon
       worst_a = relerr(d.qacc.numpy()[2], s.qacc)
     mjw.step(m, d)
+    same_rows = int(d.nefc.numpy()[1]) == s.nefc
     s.step()
+    if not same_rows and solver == mjw.SolverType.PGS:
+      continue  # a contact at the detection boundary within float32 resolution (see tests/test_pgs.py); re-synchronised next step
     worst_q = max(worst_q, relerr(d.qpos.numpy()[1], s.qpos))
     worst_v = max(worst_v, relerr(d.qvel.numpy()[1], s.qvel))
   assert np.isfinite(d.qpos.numpy()).all()
   print(f"seed {seed}: nv {mjm.nv} qacc {worst_a:.2e} qpos {worst_q:.2e} qvel {worst_v:.2e} niter {int(d.solver_niter.numpy()[1])} vs {s.solver_niter}")
-  # CG stops on a float32-noisy improvement/gradient test: the converged accelerations agree less tightly than Newton's
-  assert worst_a <= (2e-2 if mjm.opt.solver == int(mjw.SolverType.CG) else 5e-3), worst_a
+  # CG stops on a float32-noisy improvement/gradient test: the converged accelerations agree less tightly than Newton's;
+  # PGS stops far from its fixed point (linear convergence), one sweep more or less moves qacc by ~1e-3
+  assert worst_a <= (5e-3 if solver == mjw.SolverType.NEWTON else 2e-2), worst_a
   assert worst_q <= 2e-5, worst_q
   assert worst_v <= 3e-3, worst_v
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MJH_FUZZ_SEEDS", "40"))))
+def test_random_model_forward_and_steps(seed):
+  _run_seed(seed, mjw.SolverType.NEWTON if seed % 3 else mjw.SolverType.CG)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MJH_FUZZ_PGS_SEEDS", "12"))))
+def test_random_model_pgs(seed):
+  """PGS on the same random models: even seeds with njmax 64 (register-resident sweep), odd seeds with 128 (LDS sweep)."""
+  _run_seed(seed, mjw.SolverType.PGS, 64 if seed % 2 == 0 else 128)
