@@ -14,8 +14,13 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 HEADER = os.path.join(_ROOT, "include", "mjhip.h")
 LIB_PATH = os.path.join(_PKG, "libmjhip.so")
-SOURCES = [os.path.join(_PKG, "csrc", f) for f in
-           ("mjhip.hip", "dev_common.hpp", "smooth.hpp", "collide.hpp", "constraint.hpp", "solver.hpp", "pgs.hpp", "integrate.hpp")]
+# translation units of the library (compiled in parallel; the solver kernels are ~70 template instantiations) and the
+# headers they include
+UNITS = ["mjhip.hip", "solve_cg32.hip", "solve_newton32.hip", "solve_cg64.hip", "solve_newton64.hip", "pgs_tu.hip"]
+HEADERS = ["host.hpp", "solve_tu.hpp", "dev_common.hpp", "smooth.hpp", "collide.hpp", "constraint.hpp", "solver.hpp", "pgs.hpp",
+           "integrate.hpp"]
+SOURCES = [os.path.join(_PKG, "csrc", f) for f in UNITS + HEADERS]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wno-unused-value", "-Wno-pass-failed"]
 
 _CTYPES = {"int": ctypes.c_int, "float": ctypes.c_float, "unsigned int": ctypes.c_uint}
 
@@ -85,10 +90,24 @@ def build(force=False, verbose=False):
     if not force and not needs_build():
       return LIB_PATH
     tmp = LIB_PATH + f".tmp{os.getpid()}"
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value", "-o", tmp, SOURCES[0]]
+    objdir = os.path.join(_ROOT, "build", f"obj{os.getpid()}")
+    os.makedirs(objdir, exist_ok=True)
+    procs = []
+    for u in UNITS:
+      cmd = ["hipcc", *HIPCC_FLAGS, "-c", "-o", os.path.join(objdir, u + ".o"), os.path.join(_PKG, "csrc", u)]
+      if verbose:
+        print(" ".join(cmd))
+      procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, pr in procs:
+      if pr.wait() != 0:
+        raise subprocess.CalledProcessError(pr.returncode, cmd)
+    cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + [os.path.join(objdir, u + ".o") for u in UNITS]
     if verbose:
       print(" ".join(cmd))
     subprocess.check_call(cmd)
+    import shutil
+
+    shutil.rmtree(objdir, ignore_errors=True)
     os.replace(tmp, LIB_PATH)
   return LIB_PATH
 

@@ -1,0 +1,53 @@
+// host.hpp -- host-side helpers shared by the translation units of libmjhip.so.
+//
+// The library is built from several translation units compiled in parallel (the solver kernels are ~70 template
+// instantiations and dominate the build time): mjhip.hip (entry points, launch sequencing, every non-solver kernel),
+// solve_cg32 / solve_newton32 / solve_cg64 / solve_newton64 .hip (k_solve_plus instantiations) and pgs_tu.hip (k_solve_pgs).
+// Device code is header-only and fully inlined per kernel, so no relocatable device code is needed.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "../../include/mjhip.h"
+
+int mjh_fail(int code, const char* fmt, const char* a = "");  // records the message for mjh_last_error (mjhip.hip)
+#define fail mjh_fail
+#define HIPCHK(expr)                                                      \
+  do {                                                                    \
+    hipError_t e_ = (expr);                                               \
+    if (e_ != hipSuccess) return fail(MJH_E_LAUNCH, #expr ": %s", hipGetErrorString(e_)); \
+  } while (0)
+
+static const int kLdsPerCU = 160 * 1024;
+
+// pick threads per block in {256,128,64} maximising resident worlds per CU for the given LDS needs (mjhip.hip)
+int pick_block(size_t shared_bytes, size_t per_world_bytes, int G, size_t* lds_out, bool prefer_small_arg = false);
+
+// raise the dynamic-LDS cap of a kernel once (never during stream capture: mjh_graph_create warms up first)
+template <typename K>
+static hipError_t set_lds(K kernel, size_t bytes) {
+  if (bytes <= 64 * 1024) return hipSuccess;
+  static std::mutex mu;
+  static std::vector<std::pair<const void*, size_t>> done;
+  const void* f = reinterpret_cast<const void*>(kernel);
+  std::lock_guard<std::mutex> lock(mu);
+  for (auto& p : done)
+    if (p.first == f && p.second >= bytes) return hipSuccess;
+  hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e == hipSuccess) done.emplace_back(f, bytes);
+  return e;
+}
+
+// solver launches, one translation unit each (nr = rows per lane: 2 / 6 with 32 lanes per world, 1 / 2 / 3 with 64;
+// (lo, hi] = row-count range of the worlds this launch solves; fuse_euler: explicit Euler step in the solver epilogue)
+int launch_solve_32_cg(const MjhModel* m, const MjhData* d, int nr, bool with_factor, int fuse_euler, hipStream_t s, int lo, int hi);
+int launch_solve_32_newton(const MjhModel* m, const MjhData* d, int nr, bool with_factor, int fuse_euler, hipStream_t s, int lo, int hi);
+int launch_solve_64_cg(const MjhModel* m, const MjhData* d, int nr, bool with_factor, int fuse_euler, hipStream_t s, int lo, int hi);
+int launch_solve_64_newton(const MjhModel* m, const MjhData* d, int nr, bool with_factor, int fuse_euler, hipStream_t s, int lo, int hi);
+int launch_pgs(const MjhModel* m, const MjhData* d, hipStream_t s);

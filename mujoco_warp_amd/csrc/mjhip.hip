@@ -5,39 +5,22 @@
 //   k_fwd_pos (kinematics+com_pos+crb) -> k_collision -> k_make_constraint -> k_fwd_vel (com_vel, passive, rne,
 //   actuation, factor+solve) -> k_solve (whole Newton/CG solve) -> k_integrate.
 // Nothing here allocates or synchronises (hipGraph-capturable); workspace lives in MjhData.
-#include <hip/hip_runtime.h>
+#include "host.hpp"
 
-#include <algorithm>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <mutex>
-#include <vector>
-
-#include "../../include/mjhip.h"
 #include "collide.hpp"
 #include "constraint.hpp"
 #include "dev_common.hpp"
 #include "integrate.hpp"
 #include "smooth.hpp"
-#include "solver.hpp"
-#include "pgs.hpp"
 
 static thread_local char g_err[512] = "";
-static int fail(int code, const char* fmt, const char* a = "") {
+int mjh_fail(int code, const char* fmt, const char* a) {
   snprintf(g_err, sizeof(g_err), fmt, a);
   return code;
 }
-#define HIPCHK(expr)                                                      \
-  do {                                                                    \
-    hipError_t e_ = (expr);                                               \
-    if (e_ != hipSuccess) return fail(MJH_E_LAUNCH, #expr ": %s", hipGetErrorString(e_)); \
-  } while (0)
-
-static const int kLdsPerCU = 160 * 1024;
 
 // pick threads per block in {256,128,64} maximising resident worlds per CU for the given LDS needs
-static int pick_block(size_t shared_bytes, size_t per_world_bytes, int G, size_t* lds_out, bool prefer_small_arg = false) {
+int pick_block(size_t shared_bytes, size_t per_world_bytes, int G, size_t* lds_out, bool prefer_small_arg) {
   static const int small_env = getenv("MJH_SMALL_BLOCKS") ? atoi(getenv("MJH_SMALL_BLOCKS")) : -1;  // developer knob
   const bool prefer_small = small_env >= 0 ? (small_env != 0) : prefer_small_arg;
   int best = 0, best_worlds = -1;
@@ -61,21 +44,6 @@ static int pick_block(size_t shared_bytes, size_t per_world_bytes, int G, size_t
   }
   if (best) *lds_out = shared_bytes + per_world_bytes * (best / G);
   return best;
-}
-
-// raise the dynamic-LDS cap of a kernel once (never during stream capture: mjh_graph_create warms up first)
-template <typename K>
-static hipError_t set_lds(K kernel, size_t bytes) {
-  if (bytes <= 64 * 1024) return hipSuccess;
-  static std::mutex mu;
-  static std::vector<std::pair<const void*, size_t>> done;
-  const void* f = reinterpret_cast<const void*>(kernel);
-  std::lock_guard<std::mutex> lock(mu);
-  for (auto& p : done)
-    if (p.first == f && p.second >= bytes) return hipSuccess;
-  hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-  if (e == hipSuccess) done.emplace_back(f, bytes);
-  return e;
 }
 
 constexpr int G = 32;
@@ -180,19 +148,6 @@ __global__ void __launch_bounds__(256) k_mid(MjhModel m, MjhData d, int ncc, int
     fwd_vel_body<G>(m, d, VEL_COMVEL, VEL_ACCEL, smem, b);
   }
 }
-template <int NV4, int NR, bool NEWTON, int SG>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((!NEWTON && SG == 32 && NR == 2) ? 3 : 1, 8))) k_solve_plus(MjhModel m, MjhData d, int nsolve, int nfac, int nefc_lo, int nefc_hi, int fuse_euler) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int wpb = blockDim.x / SG;
-  if ((int)blockIdx.x < nsolve) solve_body<NV4, NR, NEWTON, SG>(m, d, smem, Blk{(int)blockIdx.x * wpb, wpb, (int)blockDim.x}, nefc_lo, nefc_hi, fuse_euler);
-  // CG only: the Newton kernel holds 256 VGPRs (one wave per SIMD), which would throttle the riders too (measured
-  // +120 us); for Newton they ride along with the integrator launch instead
-  else if (!NEWTON) {
-    const int wf = blockDim.x / 32, bi = (int)blockIdx.x - nsolve;
-    if (bi < nfac) factor_smooth_body<32>(m, d, 0, smem, Blk{bi * wf, wf, (int)blockDim.x});
-    else publish_body<32>(d, 1, reinterpret_cast<int*>(smem), Blk{(bi - nfac) * wf, wf, (int)blockDim.x});
-  }
-}
 template <int G>
 __global__ void __launch_bounds__(256) k_integrate_plus(MjhModel m, MjhData d, int mode, int nint, int npub) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -257,118 +212,30 @@ static int solve_supported(const MjhModel* m, const MjhData* d) {
   if (d->njmax > 192) return fail(MJH_E_UNSUPPORTED, "njmax > 192 is not supported by the register-resident solver yet");
   return MJH_OK;
 }
-// SG = lanes per world: 32 (two worlds per wavefront) for nv <= 32, 64 for 32 < nv <= 64.  with_factor appends the
-// L'DL-factor workgroups (fused step, CG); without it the launch is the plain `solve` stage.
-template <int NV4, int NR, bool NEWTON, int SG>
-static int launch_solve_t(const MjhModel* m, const MjhData* d, bool with_factor, hipStream_t s, int nefc_lo = -1, int nefc_hi = 0x7fffffff) {
-  const SolveLayout lay = solve_layout<NV4, NR, SG, NEWTON>(d->njmax);
-  const FacLayout fl = fac_layout(m->nv, m->nC);
-  const size_t ms_bytes = sizeof(int) * mstruct_ints(m->nv, m->nC);  // riders only: the solver keeps no shared tables
-  size_t lds;
-  int threads = pick_block(0, sizeof(float) * lay.total, SG, &lds, true);
-  if (!threads) return fail(MJH_E_UNSUPPORTED, "k_solve: njmax x nv does not fit in LDS");
-  if (const char* e = getenv("MJH_SOLVE_THREADS")) {  // tuning knob (developer only)
-    threads = std::max(atoi(e), SG);
-    lds = sizeof(float) * lay.total * (threads / SG);
-  }
-  const int wpb = threads / SG, wf = threads / 32;
-  with_factor = with_factor && !NEWTON;
-  if (with_factor) lds = std::max(lds, ms_bytes + sizeof(float) * fl.total * wf);
-  HIPCHK(set_lds((k_solve_plus<NV4, NR, NEWTON, SG>), lds));
-  const int nsolve = (d->nworld + wpb - 1) / wpb, nfac = with_factor ? (d->nworld + wf - 1) / wf : 0;
-  // riders (fused step, CG): factor workgroups, then as many contact-publication workgroups
-  hipLaunchKernelGGL((k_solve_plus<NV4, NR, NEWTON, SG>), dim3(nsolve + 2 * nfac), dim3(threads), lds, s, *m, *d, nsolve, nfac, nefc_lo, nefc_hi, g_fuse_euler ? 1 : 0);
-  return MJH_OK;
-}
-template <int NR, bool NEWTON>
-static int launch_solve_32(const MjhModel* m, const MjhData* d, bool wf, hipStream_t s, int lo = -1, int hi = 0x7fffffff) {
-  switch ((m->nv + 3) / 4) {  // kernels are specialised on ceil(nv/4): no padded matrix columns
-    case 0:
-    case 1: return launch_solve_t<1, NR, NEWTON, 32>(m, d, wf, s, lo, hi);
-    case 2: return launch_solve_t<2, NR, NEWTON, 32>(m, d, wf, s, lo, hi);
-    case 3: return launch_solve_t<3, NR, NEWTON, 32>(m, d, wf, s, lo, hi);
-    case 4: return launch_solve_t<4, NR, NEWTON, 32>(m, d, wf, s, lo, hi);
-    case 5: return launch_solve_t<5, NR, NEWTON, 32>(m, d, wf, s, lo, hi);
-    case 6: return launch_solve_t<6, NR, NEWTON, 32>(m, d, wf, s, lo, hi);
-    case 7: return launch_solve_t<7, NR, NEWTON, 32>(m, d, wf, s, lo, hi);
-    default: return launch_solve_t<8, NR, NEWTON, 32>(m, d, wf, s, lo, hi);
-  }
-}
-template <int NR, bool NEWTON>
-static int launch_solve_64(const MjhModel* m, const MjhData* d, bool wf, hipStream_t s, int lo = -1, int hi = 0x7fffffff) {
-  const int nv4 = (m->nv + 3) / 4;  // rounded up to an instantiated size (lanes past nv hold identity rows)
-  if (nv4 <= 9) return launch_solve_t<9, NR, NEWTON, 64>(m, d, wf, s, lo, hi);
-  if (nv4 <= 10) return launch_solve_t<10, NR, NEWTON, 64>(m, d, wf, s, lo, hi);
-  if (nv4 <= 12) return launch_solve_t<12, NR, NEWTON, 64>(m, d, wf, s, lo, hi);
-  if (nv4 <= 14) return launch_solve_t<14, NR, NEWTON, 64>(m, d, wf, s, lo, hi);
-  return launch_solve_t<16, NR, NEWTON, 64>(m, d, wf, s, lo, hi);
-}
-// PGS (pgs.hpp): one launch, no riders (publish + factor ride with the integrator launch, as for Newton)
-// REG: the register-resident sweep for njmax <= 64 (see pgs.hpp)
-template <int NV4, int SG, bool REG>
-__global__ void __launch_bounds__(256) k_solve_pgs(MjhModel m, MjhData d, int refresh) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int wpb = blockDim.x / SG;
-  pgs_body<NV4, SG, REG>(m, d, smem, Blk{(int)blockIdx.x * wpb, wpb, (int)blockDim.x}, refresh);
-}
-template <int NV4, int SG, bool REG>
-static int launch_pgs_r(const MjhModel* m, const MjhData* d, hipStream_t s) {
-  const PgsLayout lay = pgs_layout<NV4, SG>(d->njmax);
-  size_t lds;
-  const int threads = pick_block(0, sizeof(float) * lay.total, SG, &lds, true);
-  if (!threads) return fail(MJH_E_UNSUPPORTED, "k_solve_pgs: njmax x nv does not fit in LDS");
-  HIPCHK(set_lds((k_solve_pgs<NV4, SG, REG>), lds));
-  const int wpb = threads / SG;
-  static const int refresh = getenv("MJH_PGS_REFRESH") ? atoi(getenv("MJH_PGS_REFRESH")) : 8;  // developer knob (REG sweep): residual rebuild period
-  hipLaunchKernelGGL((k_solve_pgs<NV4, SG, REG>), dim3((d->nworld + wpb - 1) / wpb), dim3(threads), lds, s, *m, *d, refresh);
-  return MJH_OK;
-}
-template <int NV4, int SG>
-static int launch_pgs_t(const MjhModel* m, const MjhData* d, hipStream_t s) {
-  static const bool no_reg = getenv("MJH_PGS_NOREG") != nullptr;  // developer knob: force the general (LDS) sweep
-  if (d->njmax <= 64 && !no_reg) return launch_pgs_r<NV4, 64, true>(m, d, s);  // one world per wavefront
-  return launch_pgs_r<NV4, SG, false>(m, d, s);
-}
-static int launch_pgs(const MjhModel* m, const MjhData* d, hipStream_t s) {
-  const int nv4 = (m->nv + 3) / 4;
-  if (m->nv <= 32) {
-    switch (nv4) {
-      case 0:
-      case 1: return launch_pgs_t<1, 32>(m, d, s);
-      case 2: return launch_pgs_t<2, 32>(m, d, s);
-      case 3: return launch_pgs_t<3, 32>(m, d, s);
-      case 4: return launch_pgs_t<4, 32>(m, d, s);
-      case 5: return launch_pgs_t<5, 32>(m, d, s);
-      case 6: return launch_pgs_t<6, 32>(m, d, s);
-      case 7: return launch_pgs_t<7, 32>(m, d, s);
-      default: return launch_pgs_t<8, 32>(m, d, s);
-    }
-  }
-  if (nv4 <= 9) return launch_pgs_t<9, 64>(m, d, s);
-  if (nv4 <= 10) return launch_pgs_t<10, 64>(m, d, s);
-  if (nv4 <= 12) return launch_pgs_t<12, 64>(m, d, s);
-  if (nv4 <= 14) return launch_pgs_t<14, 64>(m, d, s);
-  return launch_pgs_t<16, 64>(m, d, s);
-}
 static int launch_solve_any(const MjhModel* m, const MjhData* d, bool with_factor, hipStream_t s) {
   if (int rc = solve_supported(m, d)) return rc;
   if (m->solver == SOL_PGS) return launch_pgs(m, d, s);
   const bool newton = m->solver == SOL_NEWTON;
+  const int fe = g_fuse_euler ? 1 : 0;
+  const int all = 0x7fffffff;
+  // the k_solve_plus instantiations live in their own translation units (host.hpp): pick by lanes per world and solver
+  auto s32 = newton ? launch_solve_32_newton : launch_solve_32_cg;
+  auto s64 = newton ? launch_solve_64_newton : launch_solve_64_cg;
   // njmax > 64: two launches over the same world list (see solve_body): a small-row instantiation for the worlds with
   // at most 64 rows, the big one (riders attached) for the rest
   if (m->nv <= 32) {
     // rows per lane (32 lanes per world): 2 covers 64 rows (humanoid, panda), 6 covers 192
-    if (d->njmax <= 64) return newton ? launch_solve_32<2, true>(m, d, with_factor, s) : launch_solve_32<2, false>(m, d, with_factor, s);
-    if (int rc = newton ? launch_solve_32<2, true>(m, d, false, s, -1, 64) : launch_solve_32<2, false>(m, d, false, s, -1, 64)) return rc;
-    return newton ? launch_solve_32<6, true>(m, d, with_factor, s, 64) : launch_solve_32<6, false>(m, d, with_factor, s, 64);
+    if (d->njmax <= 64) return s32(m, d, 2, with_factor, fe, s, -1, all);
+    if (int rc = s32(m, d, 2, false, fe, s, -1, 64)) return rc;
+    return s32(m, d, 6, with_factor, fe, s, 64, all);
   }
   // 64 lanes per world: 1 / 2 / 3 rows per lane cover 64 / 128 / 192 rows.  The second launch of a pair runs after the
   // first on the same stream, so the split point is chosen to leave it (almost) empty: its real worlds would otherwise
   // be a serial tail on an idle GPU (G1: 6 % of the worlds exceed 64 rows, practically none exceed 128)
-  if (d->njmax <= 64) return newton ? launch_solve_64<1, true>(m, d, with_factor, s) : launch_solve_64<1, false>(m, d, with_factor, s);
-  if (d->njmax <= 128) return newton ? launch_solve_64<2, true>(m, d, with_factor, s) : launch_solve_64<2, false>(m, d, with_factor, s);
-  if (int rc = newton ? launch_solve_64<2, true>(m, d, with_factor, s, -1, 128) : launch_solve_64<2, false>(m, d, with_factor, s, -1, 128)) return rc;
-  return newton ? launch_solve_64<3, true>(m, d, false, s, 128) : launch_solve_64<3, false>(m, d, false, s, 128);
+  if (d->njmax <= 64) return s64(m, d, 1, with_factor, fe, s, -1, all);
+  if (d->njmax <= 128) return s64(m, d, 2, with_factor, fe, s, -1, all);
+  if (int rc = s64(m, d, 2, with_factor, fe, s, -1, 128)) return rc;
+  return s64(m, d, 3, false, fe, s, 128, all);
 }
 static int launch_solve(const MjhModel* m, const MjhData* d, hipStream_t s) { return launch_solve_any(m, d, false, s); }
 static int launch_solve_plus(const MjhModel* m, const MjhData* d, hipStream_t s) { return launch_solve_any(m, d, true, s); }
@@ -560,6 +427,8 @@ static int run_stage(const MjhModel* m, const MjhData* d, int stage, hipStream_t
   }
 }
 
+// the C ABI is the only exported surface (the library is built with -fvisibility=hidden)
+#pragma GCC visibility push(default)
 extern "C" {
 
 int mjh_abi_version(void) { return MJH_ABI_VERSION; }
@@ -686,3 +555,4 @@ int mjh_debug_phase_ticks(unsigned long long* out, int reset) {
 #endif
 
 }  // extern "C"
+#pragma GCC visibility pop

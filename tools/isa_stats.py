@@ -1,4 +1,4 @@
-"""Static instruction mix of selected kernels from `hipcc -S --cuda-device-only` output (build/mjhip.s)."""
+"""Static instruction mix of selected kernels from `hipcc -S --cuda-device-only ... csrc/unity.hip` output (build/mjhip.s)."""
 import collections, re, sys
 path = sys.argv[1] if len(sys.argv) > 1 else "build/mjhip.s"
 pats = sys.argv[2:] or ["k_solve_plusILi7ELi2ELb0", "k_solve_plusILi7ELi2ELb1", "k_midILi32", "k_fwd_pos_plusILi32", "k_integrate_plusILi32"]

@@ -22,7 +22,7 @@ PHASES = {
 
 
 def build():
-  src = os.path.join(ROOT, "mujoco_warp_amd", "csrc", "mjhip.hip")
+  src = os.path.join(ROOT, "mujoco_warp_amd", "csrc", "unity.hip")  # one TU: a single copy of the device counters
   subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
                          "-DMJH_PHASE_CLOCK", "-o", LIB, src])
 
