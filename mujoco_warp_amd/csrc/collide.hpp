@@ -190,6 +190,29 @@ DEV void collide_pair(int t1, int t2, V3 p1, const float* R1, V3 s1, V3 p2, cons
     }
     const Frame f = make_frame3(nn);
     emit(0, dist, mat_mul(R2, pos) + p2, f.a, f.b, f.c);
+  } else if (t1 == G_SPHERE && t2 == G_CYLINDER) {  // core:388
+    const float r = s2.x, hh = s2.y;
+    const V3 vec = p1 - p2;
+    const float x = dot(vec, ax2);
+    const V3 aproj = ax2 * x, pproj = vec - aproj;
+    const float psq = dot(pproj, pproj);
+    bool side = fabsf(x) < hh, cap = psq < r * r;
+    if (side && cap) {  // centre inside the cylinder: the nearer surface wins
+      if (hh - fabsf(x) < r - sqrtf(psq)) side = false;
+      else cap = false;
+    }
+    if (side) {
+      sphere_sphere(p1, s1.x, p2 + aproj, r, dist, pos, nn);
+    } else if (cap) {
+      const V3 pn = ax2 * (x > 0.0f ? 1.0f : -1.0f);
+      plane_sphere(pn, p2 + pn * hh, p1, s1.x, dist, pos);
+      nn = pn * -1.0f;
+    } else {  // rim
+      const float sg = x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f);
+      sphere_sphere(p1, s1.x, p2 + ax2 * (sg * hh) + pproj * (r * safe_div(1.0f, sqrtf(psq))), 0.0f, dist, pos, nn);
+    }
+    const Frame f = make_frame3(nn);
+    emit(0, dist, pos, f.a, f.b, f.c);
   }
 }
 

@@ -70,7 +70,7 @@ def geom_pairs(mjm):
   return np.stack([g1[keep], g2[keep]], axis=1).astype(np.int32)
 
 
-_SUPPORTED_PAIRS = {(0, 2), (0, 3), (0, 4), (0, 5), (0, 6), (2, 2), (2, 3), (2, 6), (3, 3)}
+_SUPPORTED_PAIRS = {(0, 2), (0, 3), (0, 4), (0, 5), (0, 6), (2, 2), (2, 3), (2, 5), (2, 6), (3, 3)}
 
 
 def _arr(x, dtype):

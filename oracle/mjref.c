@@ -748,6 +748,34 @@ static int collide_pair(const RefModel* m, const RefData* d, int g1, int g2, dou
     v3add(out[0].pos, out[0].pos, p2);
     make_frame(out[0].frame, nn);
     n = 1;
+  } else if (t1 == G_SPHERE && t2 == G_CYLINDER) { /* core:388 */
+    double vec[3], aproj[3], pproj[3], nn[3], pos[3], target[3], dist;
+    double r = s2[0], hh = s2[1];
+    v3sub(vec, p1, p2);
+    double x = v3dot(vec, ax2);
+    for (int k = 0; k < 3; k++) { aproj[k] = ax2[k] * x; pproj[k] = vec[k] - aproj[k]; }
+    double psq = v3dot(pproj, pproj);
+    int side = fabs(x) < hh, cap = psq < r * r;
+    if (side && cap) { /* centre inside the cylinder: the nearer surface wins */
+      if (hh - fabs(x) < r - sqrt(psq)) side = 0; else cap = 0;
+    }
+    if (side) {
+      v3add(target, p2, aproj);
+      sphere_sphere(p1, s1[0], target, r, &dist, pos, nn);
+    } else if (cap) {
+      double sg = x > 0.0 ? 1.0 : -1.0, pn[3], pc[3];
+      for (int k = 0; k < 3; k++) { pn[k] = sg * ax2[k]; pc[k] = p2[k] + pn[k] * hh; }
+      plane_sphere(pn, pc, p1, s1[0], &dist, pos);
+      for (int k = 0; k < 3; k++) nn[k] = -pn[k];
+    } else { /* rim */
+      double inv = safe_div(1.0, sqrt(psq)), sg = x > 0.0 ? 1.0 : (x < 0.0 ? -1.0 : 0.0);
+      for (int k = 0; k < 3; k++) target[k] = p2[k] + ax2[k] * (sg * hh) + pproj[k] * (r * inv);
+      sphere_sphere(p1, s1[0], target, 0.0, &dist, pos, nn);
+    }
+    out[0].dist = dist;
+    v3cpy(out[0].pos, pos);
+    make_frame(out[0].frame, nn);
+    n = 1;
   }
   return n;
 }

@@ -135,3 +135,23 @@ PILE_XML = """
   </keyframe>
 </mujoco>
 """
+
+# spheres resting on / pushed against cylinders: side, cap and rim regimes of sphere_cylinder (the upright cylinder is static: a
+# free upright cylinder loaded off-centre tilts by ~1e-4 rad, where plane_cylinder senses the tilt through 1 - cos(tilt) and
+# float32 cannot; contype 2: the cylinders do not collide with each other -- cylinder-cylinder needs the convex path)
+SPHERE_CYLINDER_XML = """
+<mujoco>
+  <option timestep="0.003"/>
+  <worldbody>
+    <geom name="floor" type="plane" size="0 0 .05"/>
+    <body name="cyl_up" pos="0 0 .15"><geom type="cylinder" size=".12 .15" contype="2"/></body>
+    <body name="on_cap" pos=".03 .02 .379"><freejoint/><geom type="sphere" size=".08"/></body>
+    <body name="on_rim" pos=".16 0 .33"><freejoint/><geom type="sphere" size=".06" condim="1"/></body>
+    <body name="cyl_side" pos=".6 0 .1" euler="90 0 0"><freejoint/><geom type="cylinder" size=".1 .2" contype="2"/></body>
+    <body name="on_side" pos=".62 .05 .279"><freejoint/><geom type="sphere" size=".08"/></body>
+  </worldbody>
+  <keyframe>
+    <key name="k" qvel="0 0 -0.2 0 0 0  -0.3 0 -0.2 0 0 0  0 0 0 0 0 0  0 0 -0.3 0 0 0"/>
+  </keyframe>
+</mujoco>
+"""

@@ -172,7 +172,8 @@ def test_per_step_parity_resynced(solver):
   assert (d.overflow.numpy() == 0).all()
 
 
-@pytest.mark.parametrize("xml,njmax", [(conftest.PENDULA_XML, 32), (conftest.FREE_BODIES_XML, 96), (conftest.PILE_XML, 96)])
+@pytest.mark.parametrize("xml,njmax", [(conftest.PENDULA_XML, 32), (conftest.FREE_BODIES_XML, 96), (conftest.PILE_XML, 96),
+                                       (conftest.SPHERE_CYLINDER_XML, 96)])
 def test_small_models_forward_and_step(xml, njmax):
   """ball/slide/hinge limits, frictionloss, springs, position actuators; box/cylinder/ellipsoid/sphere/capsule contacts."""
   mjm = mjw.mjcf.from_xml_string(xml)
@@ -188,6 +189,18 @@ def test_small_models_forward_and_step(xml, njmax):
     s.step()
     assert relerr(d.qpos.numpy()[0], s.qpos) <= 1e-5
     assert relerr(d.qvel.numpy()[0], s.qvel) <= 2e-3
+
+
+def test_sphere_cylinder_rim_regime():
+  """10 steps in, the small sphere still rolls over the cylinder's rim (the 40-step state above only has cap and side)."""
+  mjm = mjw.mjcf.from_xml_string(conftest.SPHERE_CYLINDER_XML)
+  s, m, d = _pair(mjm, nworld=2, nconmax=32, njmax=96, warm_steps=10, noise=False)
+  mjw.forward(m, d)
+  s.forward()
+  pairs = [tuple(int(x) for x in g) for g in s.con_geom[: s.ncon]]
+  assert (3, 1) in pairs and (2, 1) in pairs and (5, 4) in pairs, pairs  # rim, cap, side
+  _check_contacts_and_rows(s, d, mjm)
+  _check_solution(s, d)
 
 
 def test_implicitfast_integrator():

@@ -226,6 +226,33 @@ def test_collision_plane_box_and_sphere_box():
   np.testing.assert_allclose(s.con_dist[4], 0.69 - 0.1 - 0.595, atol=1e-12)
 
 
+def test_collision_sphere_cylinder_side_cap_rim():
+  """sphere_cylinder (collision_primitive_core.py:388): closed-form distances for the three contact regimes."""
+  m = mjw.mjcf.from_xml_string("""
+<mujoco><worldbody>
+  <body name="c"><freejoint/><geom type="cylinder" size=".2 .3"/></body>
+  <body name="s"><freejoint/><geom type="sphere" size=".1"/></body>
+</worldbody></mujoco>""")
+  s = _sim(m)
+  for spos, dist, normal in (
+    ((0.28, 0.0, 0.1), 0.28 - 0.3, (-1, 0, 0)),             # side: radial distance - both radii
+    ((0.05, 0.0, 0.38), 0.38 - 0.3 - 0.1, (0, 0, -1)),      # cap: height above the top face - sphere radius
+    ((0.23, 0.0, 0.34), np.hypot(0.03, 0.04) - 0.1, (-0.6, 0, -0.8)),  # rim: distance to the edge circle - radius
+    ((0.05, 0.0, 0.25), -(0.3 - 0.25) - 0.1, (0, 0, -1)),   # centre inside, nearer to the cap
+  ):
+    s.qpos[:] = [0, 0, 0, 1, 0, 0, 0, *spos, 1, 0, 0, 0]
+    s.stage("kinematics")
+    s.stage("collision")
+    assert s.ncon == 1, spos
+    np.testing.assert_allclose(s.con_dist[0], dist, atol=1e-12)
+    # frame normal points from geom1 (sphere: the lower type id) to geom2 (cylinder)
+    np.testing.assert_allclose(s.con_frame[0][:3], normal, atol=1e-12)
+  s.qpos[7:10] = [0.5, 0, 0]
+  s.stage("kinematics")
+  s.stage("collision")
+  assert s.ncon == 0
+
+
 def test_constraint_row_limit_closed_form():
   """One hinge beyond its upper limit: J=-1, pos = range1 - q, D and aref from the solref/solimp formulas."""
   m = mjw.mjcf.from_xml_string("""
