@@ -53,14 +53,13 @@ DEV EfcRowOut efc_row(int dsbl, float timestep, float pos_aref, float pos_imp, f
 }
 
 struct ConLayout {
-  int cdof, qvel, rowvel, rowdof, rowval, row2con, clist, cwin, scom, gbody, broot, bmask, total;
+  int cdof, qvel, rowdof, rowval, row2con, clist, cwin, scom, gbody, broot, bmask, total;
 };
 __host__ __device__ inline ConLayout con_layout(int nv, int njmax, int ncap, int nbody, int ngeom) {
   ConLayout p;
   int o = 0;
   p.cdof = o; o += 6 * nv;
   p.qvel = o; o += nv;
-  p.rowvel = o; o += njmax;
   p.rowdof = o; o += njmax;
   p.rowval = o; o += njmax;
   p.row2con = o; o += njmax;
@@ -84,7 +83,7 @@ DEV void make_constraint_body(const MjhModel& m, const MjhData& d, float* smem, 
   const int nv = m.nv, njnt = m.njnt, nbody = m.nbody, njmax = d.njmax, nvp = d.nv_pad, ncap = d.concap;
   const ConLayout lay = con_layout(nv, njmax, ncap, nbody, m.ngeom);
   float* S = smem + (size_t)gib * (stride_words ? stride_words : lay.total);
-  float *cdof = S + lay.cdof, *qvel = S + lay.qvel, *rowvel = S + lay.rowvel, *rowval = S + lay.rowval;
+  float *cdof = S + lay.cdof, *qvel = S + lay.qvel, *rowval = S + lay.rowval;
   int *rowdof = reinterpret_cast<int*>(S + lay.rowdof), *row2con = reinterpret_cast<int*>(S + lay.row2con),
       *clist = reinterpret_cast<int*>(S + lay.clist);
   float* cwin = S + lay.cwin;
@@ -337,7 +336,6 @@ DEV void make_constraint_body(const MjhModel& m, const MjhData& d, float* smem, 
       // pyramid rows 2(q-1), 2(q-1)+1 = normal component +- mu_q * component q (q = 1..condim-1): tangent 1, tangent 2,
       // spin, roll 1, roll 2.  All indexing below is static (fully unrolled), so nothing lives in scratch or movrel.
       const float mu[6] = {0.0f, cr[14], cr[14], cr[15], cr[16], cr[16]};
-      float acc[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
       for (int i0 = 0; i0 < nvp; i0 += G) {
         const int i = i0 + lig;
         V3 jp = V3{0, 0, 0}, jr = V3{0, 0, 0};
@@ -356,8 +354,6 @@ DEV void make_constraint_body(const MjhModel& m, const MjhData& d, float* smem, 
         }
         if (i < nvp) {
           const float comp[6] = {dot(f0, jp), dot(f1, jp), dot(f2, jp), dot(f0, jr), dot(f1, jr), dot(f2, jr)};
-          const float qv = i < nv ? qvel[i] : 0.0f;
-          acc[0] += comp[0] * qv;
           if (condim == 1) {
             if (rbase < njmax) J[(size_t)rbase * nvp + i] = comp[0];
           } else {
@@ -367,27 +363,7 @@ DEV void make_constraint_body(const MjhModel& m, const MjhData& d, float* smem, 
                 const int r = rbase + 2 * (q - 1);
                 if (r < njmax) J[(size_t)r * nvp + i] = comp[0] + mu[q] * comp[q];
                 if (r + 1 < njmax) J[(size_t)(r + 1) * nvp + i] = comp[0] - mu[q] * comp[q];
-                acc[q] += comp[q] * qv;
               }
-            }
-          }
-        }
-      }
-      // J qvel of the contact's rows: totals are only needed by the lane that stores them, so the last lane of the
-      // group takes them straight from the DPP tree (no broadcast)
-      float v[6];
-#pragma unroll
-      for (int q = 0; q < 6; ++q) v[q] = (q == 0 || q < condim) ? (G == 32 ? gsum_last32(acc[q]) : gsum<G>(acc[q])) : 0.0f;
-      if (lig == G - 1) {
-        if (condim == 1) {
-          if (rbase < njmax) rowvel[rbase] = v[0];
-        } else {
-#pragma unroll
-          for (int q = 1; q < 6; ++q) {
-            if (q < condim && 2 * (q - 1) + 1 < ndim) {
-              const int r = rbase + 2 * (q - 1);
-              if (r < njmax) rowvel[r] = v[0] + mu[q] * v[q];
-              if (r + 1 < njmax) rowvel[r + 1] = v[0] - mu[q] * v[q];
             }
           }
         }
@@ -395,6 +371,10 @@ DEV void make_constraint_body(const MjhModel& m, const MjhData& d, float* smem, 
     }
     gsync();
   }
+  // the rows' velocities J qvel are taken row-per-lane from the finished J below (one dot product per row instead of up to
+  // six cross-lane reductions per contact inside the serial contact loop); the rows were written by other lanes of this
+  // wavefront: make them visible first
+  __threadfence_block();
   gsync();
   pc.mark(4);
   // per-row contact parameters (lane per row)
@@ -416,7 +396,17 @@ DEV void make_constraint_body(const MjhModel& m, const MjhData& d, float* smem, 
         invweight = invweight + fri0 * fri0 * invweight;
         invweight = invweight * 2.0f * fri0 * fri0 * impr2 * impr2;
       }
-      const float vel = rowvel[r];
+      float v0 = 0.0f, v1 = 0.0f;
+      {
+        const float4* Jr = reinterpret_cast<const float4*>(J + (size_t)r * nvp);  // nvp % 4 == 0, rows are 16-byte aligned
+        for (int c4 = 0; c4 < nvp / 4; ++c4) {
+          const float4 j4 = Jr[c4];
+          const int c = 4 * c4;  // (padding columns of J are zero; qvel has nv entries)
+          v0 += j4.x * qvel[c] + (c + 2 < nv ? j4.z * qvel[c + 2] : 0.0f);
+          v1 += (c + 1 < nv ? j4.y * qvel[c + 1] : 0.0f) + (c + 3 < nv ? j4.w * qvel[c + 3] : 0.0f);
+        }
+      }
+      const float vel = v0 + v1;
       EfcRowOut eo_ = efc_row(dsbl, timestep, pos, pos, invweight, cr + 17, cr + 19, includemargin, vel);
       d.efc_D[eo + r] = eo_.D;
       d.efc_aref[eo + r] = eo_.aref;
