@@ -34,6 +34,7 @@ from .forward import step
 from .forward import timed_steps
 from .forward import transmission
 from .io import get_data_into
+from .io import load_trajectory
 from .io import make_data
 from .io import override_model
 from .io import put_data

@@ -571,3 +571,36 @@ def override_model(model, overrides):
         del model._mjh_model
       except AttributeError:
         pass
+
+
+def load_trajectory(npz_path, mjm, mjd) -> np.ndarray:
+  """Control sequence of an NPZ recording resampled onto the model timestep, zero-order hold (reference io.py:3067).
+
+  The file holds `ctrl` [n, nu] and `times` [n] (one timestamp per control; the last control is held for the previous
+  interval, or one model timestep if there is only one) or [n + 1] (interval boundaries).  Optional `qpos` [1, nq] /
+  `qvel` [1, nv] set the initial state of `mjd`.  Returns ctrl [nstep, nu] with nstep = round(duration / timestep);
+  control intervals shorter than a timestep may be skipped.
+  """
+  z = np.load(npz_path)
+  ctrl, times = np.asarray(z["ctrl"]), np.asarray(z["times"])
+  if ctrl.ndim != 2 or ctrl.shape[0] == 0:
+    raise ValueError(f"ctrl must have shape (nstep, nu) with nstep > 0, got {ctrl.shape}")
+  if ctrl.shape[1] != mjm.nu:
+    raise ValueError(f"ctrl shape {ctrl.shape} does not match model nu={mjm.nu}")
+  n = ctrl.shape[0]
+  if times.ndim != 1 or times.shape[0] not in (n, n + 1):
+    raise ValueError(f"times shape {times.shape} must contain {n} or {n + 1} timestamps")
+  if not np.isfinite(times).all():
+    raise ValueError("times must be finite")
+  if (np.diff(times) <= 0).any():
+    raise ValueError("times must be strictly increasing")
+  for name, size in (("qpos", mjm.nq), ("qvel", mjm.nv)):
+    if name in z.files and z[name].ndim == 2 and z[name].shape[1] == size:
+      getattr(mjd, name)[:] = z[name][0]
+  dt = float(mjm.opt.timestep)
+  if times.shape[0] == n:  # close the last interval
+    hold = times[-1] - times[-2] if n > 1 else dt
+    times = np.concatenate([times, [times[-1] + hold]])
+  nstep = int(np.round((times[-1] - times[0]) / dt))
+  sample = times[0] + (np.arange(nstep) + 1e-7) * dt  # nudged off the boundaries so that equal timestamps hold the new control
+  return ctrl[np.searchsorted(times, sample, side="right") - 1]

@@ -86,13 +86,16 @@ def main(argv=None):
   ctrls = None
   if args.replay:
     z = np.load(args.replay)
-    ctrls = np.asarray(z["ctrl"], dtype=np.float32)
-    if ctrls.ndim != 2 or ctrls.shape[1] != mjm.nu:
-      raise ValueError(f"replay ctrl has shape {ctrls.shape}, expected [nstep, {mjm.nu}]")
-    if "qpos" in z.files and z["qpos"].shape[-1] == mjm.nq:
-      mjd.qpos[:] = z["qpos"][0]
-    if "qvel" in z.files and z["qvel"].shape[-1] == mjm.nv:
-      mjd.qvel[:] = z["qvel"][0]
+    if "times" in z.files:  # the reference's recording format: resampled onto the model timestep (io.load_trajectory)
+      ctrls = np.asarray(mjw.load_trajectory(args.replay, mjm, mjd), dtype=np.float32)
+    else:  # bare [nstep, nu] sequence, one control per step
+      ctrls = np.asarray(z["ctrl"], dtype=np.float32)
+      if ctrls.ndim != 2 or ctrls.shape[1] != mjm.nu:
+        raise ValueError(f"replay ctrl has shape {ctrls.shape}, expected [nstep, {mjm.nu}]")
+      if "qpos" in z.files and z["qpos"].shape[-1] == mjm.nq:
+        mjd.qpos[:] = z["qpos"][0]
+      if "qvel" in z.files and z["qvel"].shape[-1] == mjm.nv:
+        mjd.qvel[:] = z["qvel"][0]
     args.nstep = len(ctrls) if args.nstep is None else min(args.nstep, len(ctrls))
   if args.nstep is None:
     args.nstep = 1000

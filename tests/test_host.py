@@ -206,3 +206,30 @@ def test_device_array_surface():
   np.testing.assert_array_equal(a.numpy()[1], [0, 1, 2, 3])
   b = mjw.DeviceArray.from_numpy(np.array([1, 2], dtype=np.uint32))
   assert b.numpy().dtype == np.uint32
+
+
+def test_load_trajectory_zero_order_hold(humanoid, tmp_path):
+  """io.load_trajectory (reference io.py:3067): controls held on the model timestep; both `times` conventions; errors."""
+  nu, dt = humanoid.nu, float(humanoid.opt.timestep)  # dt = 0.005
+  ctrl = np.arange(3 * nu, dtype=np.float64).reshape(3, nu)
+  mjd = mjw.MjData(humanoid)
+  p = str(tmp_path / "t.npz")
+  # one timestamp per control, 4 model steps per control; the last control is held for the same interval
+  np.savez(p, ctrl=ctrl, times=np.array([0.0, 0.02, 0.04]), qpos=np.full((1, humanoid.nq), 0.25))
+  out = mjw.load_trajectory(p, humanoid, mjd)
+  assert out.shape == (12, nu)
+  np.testing.assert_array_equal(out[:, 0], np.repeat(ctrl[:, 0], 4))
+  np.testing.assert_array_equal(mjd.qpos, 0.25)
+  # interval boundaries (n + 1 timestamps), uneven intervals: 2, 1 and 3 steps
+  np.savez(p, ctrl=ctrl, times=np.array([1.0, 1.0 + 2 * dt, 1.0 + 3 * dt, 1.0 + 6 * dt]))
+  out = mjw.load_trajectory(p, humanoid, mjd)
+  np.testing.assert_array_equal(out[:, 0], np.repeat(ctrl[:, 0], [2, 1, 3]))
+  # a single control is held for one model timestep
+  np.savez(p, ctrl=ctrl[:1], times=np.array([0.0]))
+  assert mjw.load_trajectory(p, humanoid, mjd).shape == (1, nu)
+  for bad in (dict(ctrl=ctrl[:, :-1], times=np.arange(3.0)), dict(ctrl=ctrl, times=np.array([0.0, 0.02])),
+              dict(ctrl=ctrl, times=np.array([0.0, 0.02, 0.02])), dict(ctrl=ctrl, times=np.array([0.0, np.inf, 1.0])),
+              dict(ctrl=np.zeros((0, nu)), times=np.zeros(0))):
+    np.savez(p, **bad)
+    with pytest.raises(ValueError):
+      mjw.load_trajectory(p, humanoid, mjd)
