@@ -174,6 +174,8 @@ typedef struct MjhData {
   int* ws_ncollision;  /* [nworld]   broadphase candidates per world                  */
   int* ws_order;       /* [nworld]   solver schedule: worlds sorted by last step's solver_niter (longest first) */
   int* eq_active;      /* [nworld, neq] Data.eq_active (types.py:2262), initialised from eq_active0 */
+  float* ws_rk;        /* [nworld, nq + 3 nv + 2 na] RK4 scratch: qpos, qvel, act at t0 and the weighted sums of qvel, qacc,
+                          act_dot (the temporaries forward.rungekutta4 allocates per step, forward.py:530-540) */
   float* ws_contact;   /* [nworld, concap, 32] per-world contact records (collision -> make_constraint hand-off;
                           the public contact_* arrays are compacted from these off the critical path) */
 } MjhData;
@@ -210,7 +212,7 @@ int mjh_timed_steps(const MjhModel* m, const MjhData* d, int nstep, int step0, f
                     void* stream, float* ms_out, float* per_kernel_ms, int plain_kernels);
 
 const char* mjh_last_error(void);
-#define MJH_ABI_VERSION 2
+#define MJH_ABI_VERSION 3
 int mjh_abi_version(void); /* returns MJH_ABI_VERSION of the library that was loaded */
 
 #ifdef __cplusplus

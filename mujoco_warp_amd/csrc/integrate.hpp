@@ -137,6 +137,89 @@ DEV void integrate_body(const MjhModel& m, const MjhData& d, int mode, float* sm
   }
 }
 
+// Runge-Kutta 4 (forward.py:420-557 rungekutta4, _rk_perturb_state, _rk_accumulate): step = forward, then three more
+// forwards at perturbed states.  One launch of this kernel sits after each forward:
+//   stage 0    : save (qpos, qvel, act) at t0; sums = B0 * (qvel, qacc, act_dot); perturb the state with A0
+//   stage 1, 2 : sums += B_s * (qvel, qacc, act_dot) of the stage just evaluated; perturb with A_s
+//   stage 3    : sums += B3 * (...); restore t0 and advance with the sums (_advance with qacc_rk, qvel_rk)
+// perturb(a): qpos = qpos_t0 (+) a h qvel_stage, qvel = qvel_t0 + a h qacc_stage, act = next_act(act_t0, act_dot_stage, a h).
+// RK4 tableau: A = (1/2, 1/2, 1), B = (1/6, 1/3, 1/3, 1/6).  smem: nv floats per world.
+template <int G>
+__global__ void __launch_bounds__(256) k_rk4(MjhModel m, MjhData d, int stage, float a, float bw) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int nq = m.nq, nv = m.nv, na = m.na, nu = m.nu, njnt = m.njnt;
+  const int lig = threadIdx.x & (G - 1), gib = threadIdx.x / G;
+  const int w = blockIdx.x * (blockDim.x / G) + gib;
+  if (w >= d.nworld) return;
+  float* vel = smem + (size_t)gib * (nv + 1);  // the velocity the position update integrates
+  float* rk = d.ws_rk + (size_t)w * (nq + 3 * nv + 2 * na);
+  float *qpos0 = rk, *qvel0 = rk + nq, *qvel_rk = qvel0 + nv, *qacc_rk = qvel_rk + nv, *act0 = qacc_rk + nv, *actdot_rk = act0 + na;
+  const float h = bf(m.opt_timestep, m.opt_timestep_nb, w, 1)[0];
+  const bool last = stage == 3;
+  const float dt = last ? h : a * h;
+  const size_t vo = (size_t)w * nv;
+  for (int i = lig; i < nv; i += G) {
+    const float cv = d.qvel[vo + i], ca = d.qacc[vo + i];
+    const float v0 = stage == 0 ? cv : qvel0[i];
+    const float sv = (stage == 0 ? 0.0f : qvel_rk[i]) + bw * cv, sa = (stage == 0 ? 0.0f : qacc_rk[i]) + bw * ca;
+    if (stage == 0) qvel0[i] = cv;
+    qvel_rk[i] = sv;
+    qacc_rk[i] = sa;
+    vel[i] = last ? sv : cv;
+    d.qvel[vo + i] = v0 + dt * (last ? sa : ca);
+    if (last) d.qacc_warmstart[vo + i] = ca;  // qacc of the last evaluation (forward.py:343)
+  }
+  for (int u = lig; u < nu; u += G) {  // activations (support.py:38 next_act with the stage's act_dot)
+    const int dyn = m.actuator_dyntype[u];
+    if (dyn == 0) continue;
+    const int ai = m.actuator_actadr[u];
+    const size_t ga = (size_t)w * na + ai;
+    const float cd = d.act_dot[ga];
+    const float a0 = stage == 0 ? d.act[ga] : act0[ai];
+    const float sd = (stage == 0 ? 0.0f : actdot_rk[ai]) + bw * cd;
+    if (stage == 0) act0[ai] = a0;
+    actdot_rk[ai] = sd;
+    const float rate = last ? sd : cd;
+    float act;
+    if (dyn == 3) {
+      const float tau = fmaxf(MJ_MINVAL, bf(m.actuator_dynprm, m.actuator_dynprm_nb, w, 10 * nu)[10 * u]);
+      act = a0 + rate * tau * (1.0f - expf(-dt / tau));
+    } else {
+      act = a0 + rate * dt;
+    }
+    if (m.actuator_actlimited[u]) {
+      const float* ar = bf(m.actuator_actrange, m.actuator_actrange_nb, w, 2 * nu) + 2 * u;
+      act = clampf(act, ar[0], ar[1]);
+    }
+    d.act[ga] = act;
+    if (last) d.act_dot[ga] = sd;
+  }
+  gsync();
+  float* qpos = d.qpos + (size_t)w * nq;
+  for (int j = lig; j < njnt; j += G) {  // _next_position forward.py:53 from the t0 position
+    const int qa = m.jnt_qposadr[j], dof = m.jnt_dofadr[j], t = m.jnt_type[j];
+    const int nqj = t == JNT_FREE ? 7 : (t == JNT_BALL ? 4 : 1);
+    float q0[7];
+    for (int k = 0; k < 7; ++k)
+      if (k < nqj) {
+        q0[k] = stage == 0 ? qpos[qa + k] : qpos0[qa + k];
+        if (stage == 0) qpos0[qa + k] = q0[k];
+      }
+    if (t == JNT_FREE) {
+      for (int k = 0; k < 3; ++k) qpos[qa + k] = q0[k] + dt * vel[dof + k];
+      st4(qpos + qa + 3, quat_integrate(Q4{q0[3], q0[4], q0[5], q0[6]}, ld3(vel + dof + 3), dt));
+    } else if (t == JNT_BALL) {
+      st4(qpos + qa, quat_integrate(Q4{q0[0], q0[1], q0[2], q0[3]}, ld3(vel + dof), dt));
+    } else {
+      qpos[qa] = q0[0] + dt * vel[dof];
+    }
+  }
+  if (last && lig == 0) {
+    d.time[w] += h;
+    if (d.nefc[w] > d.njmax) atomicOr(d.overflow + w, OVF_NEFC);
+  }
+}
+
 // cli.py:103-145; halton in float32 exactly like util_misc.py:61
 DEV float halton(int index, int base) {
   int n0 = index;

@@ -281,7 +281,9 @@ static int check(const MjhModel* m, const MjhData* d) {
   if (!m || !d) return fail(MJH_E_ARG, "null model/data");
   if (d->nworld <= 0) return fail(MJH_E_ARG, "nworld must be positive");
   if (d->concap <= 0 || !d->ws_contact) return fail(MJH_E_ARG, "Data.ws_contact / concap missing (allocate Data with make_data/put_data)");
-  if (m->integrator != INT_EULER && m->integrator != INT_IMPLICITFAST) return fail(MJH_E_UNSUPPORTED, "integrator must be Euler or implicitfast");
+  if (m->integrator != INT_EULER && m->integrator != INT_IMPLICITFAST && m->integrator != INT_RK4)
+    return fail(MJH_E_UNSUPPORTED, "integrator must be Euler, RK4 or implicitfast");
+  if (m->integrator == INT_RK4 && !d->ws_rk) return fail(MJH_E_ARG, "Data.ws_rk missing (allocate Data with make_data/put_data)");
   return MJH_OK;
 }
 
@@ -376,6 +378,17 @@ static int run_stage(const MjhModel* m, const MjhData* d, int stage, hipStream_t
       return MJH_OK;
     case MJH_STAGE_FORWARD:
     case MJH_STAGE_STEP: {
+      if (stage == MJH_STAGE_STEP && m->integrator == INT_RK4) {
+        // forward.rungekutta4 (forward.py:524-557): four forwards, one k_rk4 launch after each (accumulate + perturb,
+        // the last one restores t0 and advances); tableau A = (1/2, 1/2, 1), B = (1/6, 1/3, 1/3, 1/6)
+        static const float A[4] = {0.5f, 0.5f, 1.0f, 0.0f}, B[4] = {1.0f / 6.0f, 1.0f / 3.0f, 1.0f / 3.0f, 1.0f / 6.0f};
+        for (int k = 0; k < 4; ++k) {
+          TRY(run_stage(m, d, MJH_STAGE_FORWARD, s));
+          Scope sc(K_INTEGRATE);
+          hipLaunchKernelGGL(k_rk4<G>, dim3((d->nworld + 7) / 8), dim3(8 * G), sizeof(float) * 8 * (m->nv + 1), s, *m, *d, k, A[k], B[k]);
+        }
+        return MJH_OK;
+      }
       const int mode = m->integrator == INT_IMPLICITFAST ? 1 : 0;
       static const bool plain = getenv("MJH_PLAIN") != nullptr;  // developer knob: one plain kernel per stage, serial
       if ((g_instr && g_instr->on && g_instr->plain) || plain) {

@@ -91,8 +91,8 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
   for name in ("ntendon", "nflex", "nhfield", "nmocap", "nplugin"):
     if int(getattr(mjm, name, 0)) > 0:
       raise NotImplementedError(f"{name} > 0 is outside the hot-path scope of this engine")
-  if int(opt.integrator) not in (types.IntegratorType.EULER, types.IntegratorType.IMPLICITFAST):
-    raise NotImplementedError(f"Integrator {int(opt.integrator)} is unsupported (Euler and implicitfast only).")
+  if int(opt.integrator) not in (types.IntegratorType.EULER, types.IntegratorType.RK4, types.IntegratorType.IMPLICITFAST):
+    raise NotImplementedError(f"Integrator {int(opt.integrator)} is unsupported (Euler, RK4 and implicitfast only).")
   # (the reference rejects PGS, io.py solver check / types.py:502; this engine implements MuJoCo C's dual PGS, csrc/pgs.hpp)
   if int(opt.solver) not in (types.SolverType.PGS, types.SolverType.CG, types.SolverType.NEWTON):
     raise NotImplementedError(f"Unknown solver {int(opt.solver)}.")
@@ -321,7 +321,7 @@ def _data_shapes(m, nworld, nconmax, njmax, naconmax):
     efc_type=(W, njmax), efc_id=(W, njmax), efc_state=(W, njmax), efc_J=(W, njmax_pad, nv_pad), efc_pos=(W, njmax),
     efc_margin=(W, njmax), efc_D=(W, njmax), efc_vel=(W, njmax), efc_aref=(W, njmax), efc_frictionloss=(W, njmax),
     efc_force=(W, njmax), ws_ncon=(W,), ws_conadr=(W,), ws_ncollision=(W,), ws_order=(W,),
-    eq_active=(W, m.neq), ws_contact=(W, contact_cap(nconmax), 32),
+    eq_active=(W, m.neq), ws_rk=(W, nq + 3 * nv + 2 * na), ws_contact=(W, contact_cap(nconmax), 32),
   )
   return sh, njmax_pad, nv_pad
 
@@ -562,7 +562,7 @@ def override_model(model, overrides):
     else:
       setattr(obj, attr, val)
     if isinstance(model, types.Model) and attr in ("solver", "integrator", "cone"):
-      put = {"solver": (types.SolverType.PGS, types.SolverType.CG, types.SolverType.NEWTON), "integrator": (types.IntegratorType.EULER, types.IntegratorType.IMPLICITFAST),
+      put = {"solver": (types.SolverType.PGS, types.SolverType.CG, types.SolverType.NEWTON), "integrator": (types.IntegratorType.EULER, types.IntegratorType.RK4, types.IntegratorType.IMPLICITFAST),
              "cone": (types.ConeType.PYRAMIDAL,)}[attr]
       if int(getattr(obj, attr)) not in put:
         raise NotImplementedError(f"unsupported {attr} {val}")

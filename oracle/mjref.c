@@ -1525,9 +1525,65 @@ void ref_implicitfast(const RefModel* m, RefData* d) {
   free(Mh);
 }
 
+/* state update from t0 with explicit rates and step dt: act (_next_activation forward.py:134 with `scale`), qvel
+ * (_next_velocity 117), qpos (_next_position 53 integrates `vel_pos`) */
+static void rk_set_state(const RefModel* m, RefData* d, const double* qpos0, const double* qvel0, const double* act0,
+                         const double* vel_pos, const double* qacc, const double* act_dot, double dt) {
+  for (int i = 0; i < m->nu; i++) {
+    int dyn = m->actuator_dyntype[i];
+    if (dyn == 0) continue;
+    int adr = m->actuator_actadr[i];
+    double act;
+    if (dyn == 3) {
+      double tau = fmax(MINVAL, m->actuator_dynprm[10 * i]);
+      act = act0[adr] + act_dot[adr] * tau * (1.0 - exp(-dt / tau));
+    } else act = act0[adr] + act_dot[adr] * dt;
+    if (m->actuator_actlimited[i]) act = clampd(act, m->actuator_actrange[2 * i], m->actuator_actrange[2 * i + 1]);
+    d->act[adr] = act;
+  }
+  for (int i = 0; i < m->nv; i++) d->qvel[i] = qvel0[i] + dt * qacc[i];
+  memcpy(d->qpos, qpos0, sizeof(double) * m->nq);
+  for (int j = 0; j < m->njnt; j++) {
+    int qa = m->jnt_qposadr[j], dof = m->jnt_dofadr[j], t = m->jnt_type[j];
+    if (t == JNT_FREE) {
+      for (int k = 0; k < 3; k++) d->qpos[qa + k] += dt * vel_pos[dof + k];
+      quat_integrate(d->qpos + qa + 3, vel_pos + dof + 3, dt);
+    } else if (t == JNT_BALL) quat_integrate(d->qpos + qa, vel_pos + dof, dt);
+    else d->qpos[qa] += dt * vel_pos[dof];
+  }
+}
+
+/* rungekutta4 forward.py:524-557 (_rk_perturb_state 420, _rk_accumulate 498): called after forward() at t0 */
+void ref_rungekutta4(const RefModel* m, RefData* d) {
+  static const double A[3] = {0.5, 0.5, 1.0}, B[4] = {1.0 / 6.0, 1.0 / 3.0, 1.0 / 3.0, 1.0 / 6.0};
+  int nq = m->nq, nv = m->nv, na = m->na;
+  double* buf = (double*)calloc((size_t)nq + 4 * nv + 3 * na + 3, sizeof(double));
+  double *qpos0 = buf, *qvel0 = qpos0 + nq, *qvel_rk = qvel0 + nv, *qacc_rk = qvel_rk + nv, *vel = qacc_rk + nv,
+         *act0 = vel + nv, *actdot_rk = act0 + na + 1, *actdot = actdot_rk + na + 1;
+  memcpy(qpos0, d->qpos, sizeof(double) * nq);
+  memcpy(qvel0, d->qvel, sizeof(double) * nv);
+  memcpy(act0, d->act, sizeof(double) * na);
+  double h = m->timestep;
+  for (int k = 0; k < 4; k++) {
+    for (int i = 0; i < nv; i++) { qvel_rk[i] += B[k] * d->qvel[i]; qacc_rk[i] += B[k] * d->qacc[i]; }
+    for (int i = 0; i < na; i++) actdot_rk[i] += B[k] * d->act_dot[i];
+    if (k == 3) break;
+    memcpy(vel, d->qvel, sizeof(double) * nv); /* the stage's velocity moves the position */
+    memcpy(actdot, d->act_dot, sizeof(double) * na);
+    rk_set_state(m, d, qpos0, qvel0, act0, vel, d->qacc, actdot, A[k] * h);
+    ref_forward(m, d);
+  }
+  memcpy(d->act_dot, actdot_rk, sizeof(double) * na);
+  rk_set_state(m, d, qpos0, qvel0, act0, qvel_rk, qacc_rk, actdot_rk, h); /* _advance(m, d, qacc_rk, qvel_rk) */
+  d->time += h;
+  memcpy(d->qacc_warmstart, d->qacc, sizeof(double) * nv);
+  free(buf);
+}
+
 void ref_step(const RefModel* m, RefData* d) { /* forward.py:1368-1380 */
   ref_forward(m, d);
   if (m->integrator == INT_IMPLICITFAST) ref_implicitfast(m, d);
+  else if (m->integrator == INT_RK4) ref_rungekutta4(m, d);
   else ref_euler(m, d);
 }
 

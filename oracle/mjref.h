@@ -217,6 +217,7 @@ void ref_solve(const RefModel* m, RefData* d);
 void ref_forward(const RefModel* m, RefData* d);
 void ref_euler(const RefModel* m, RefData* d);
 void ref_implicitfast(const RefModel* m, RefData* d);
+void ref_rungekutta4(const RefModel* m, RefData* d); /* forward.py:524; call after ref_forward */
 void ref_step(const RefModel* m, RefData* d);
 void ref_ctrl_noise(const RefModel* m, RefData* d, const double* center, int step, int worldid, double noise_std, double noise_rate);
 double ref_halton(int index, int base);

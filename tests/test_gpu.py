@@ -215,6 +215,37 @@ def test_implicitfast_integrator():
     assert relerr(d.act.numpy()[0], s.act) <= 1e-5 if mjm.na else True
 
 
+@pytest.mark.parametrize("solver", [mjw.SolverType.NEWTON, mjw.SolverType.CG])
+def test_rk4_integrator(solver):
+  """forward.rungekutta4 (forward.py:524): four forwards per step; humanoid per-step parity, then a model with ball / slide /
+  hinge joints, activations and contacts (every branch of the state perturbation)."""
+  mjm = mjw.mjcf.load_xml(conftest.HUMANOID_XML)
+  s, m, d = _pair(mjm, nworld=2, nconmax=24, njmax=64, solver=int(solver), integrator=int(mjw.IntegratorType.RK4), warm_steps=5)
+  worst_q = worst_v = 0.0
+  for i in range(40):
+    s.ctrl_noise(5 + i, 0)
+    _sync(s, d)
+    mjw.step(m, d)
+    s.step()
+    worst_q = max(worst_q, relerr(d.qpos.numpy()[1], s.qpos))
+    worst_v = max(worst_v, relerr(d.qvel.numpy()[1], s.qvel))
+  assert worst_q <= 1e-5, worst_q
+  assert worst_v <= 1e-3, worst_v
+  assert relerr(d.qacc_warmstart.numpy()[1], s.qacc_warmstart) <= SOLVE
+  np.testing.assert_allclose(d.time.numpy(), 40 * mjm.opt.timestep, rtol=1e-5)  # one timestep per step, not per evaluation
+  mjm = mjw.mjcf.from_xml_string(conftest.PENDULA_XML)
+  s, m, d = _pair(mjm, nworld=2, nconmax=32, njmax=32, solver=int(solver), integrator=int(mjw.IntegratorType.RK4), warm_steps=20,
+                  noise=False)
+  for _ in range(20):
+    _sync(s, d)
+    mjw.step(m, d)
+    s.step()
+    assert relerr(d.qpos.numpy()[0], s.qpos) <= 1e-5
+    assert relerr(d.qvel.numpy()[0], s.qvel) <= 2e-3
+    if mjm.na:
+      assert relerr(d.act.numpy()[0], s.act) <= 1e-5
+
+
 def test_golden_forward_fixture():
   g = np.load(os.path.join(conftest.GOLDEN_DIR, "humanoid_oracle_forward.npz"))
   mjm = mjw.mjcf.load_xml(conftest.HUMANOID_XML)

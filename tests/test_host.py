@@ -85,7 +85,7 @@ def test_unsupported_features_raise():
   m = mjw.mjcf.from_xml_string('<mujoco><option cone="elliptic"/><worldbody><body><joint/><geom size=".1"/></body></worldbody></mujoco>')
   with pytest.raises(NotImplementedError):
     mjw.put_model(m)
-  m = mjw.mjcf.from_xml_string('<mujoco><option integrator="RK4"/><worldbody><body><joint/><geom size=".1"/></body></worldbody></mujoco>')
+  m = mjw.mjcf.from_xml_string('<mujoco><option integrator="implicit"/><worldbody><body><joint/><geom size=".1"/></body></worldbody></mujoco>')
   with pytest.raises(NotImplementedError):
     mjw.put_model(m)
 
@@ -98,7 +98,7 @@ def test_library_exports_every_declared_symbol():
   assert len(declared) >= 12
   for name in declared:
     assert hasattr(L, name), f"libmjhip.so does not export {name}"
-  assert L.mjh_abi_version() == _abi.DEFINES["MJH_ABI_VERSION"] == 2
+  assert L.mjh_abi_version() == _abi.DEFINES["MJH_ABI_VERSION"] == 3
 
 
 def test_struct_layout_matches_header():
@@ -106,7 +106,7 @@ def test_struct_layout_matches_header():
   names = [n for n, _, _ in _abi.MODEL_FIELDS]
   assert names[:3] == ["nq", "nv", "nu"] and "nxn_geom_pair" in names and "body_dofmask" in names
   dnames = [n for n, _, _ in _abi.DATA_FIELDS]
-  assert dnames[0] == "nworld" and "efc_J" in dnames and dnames[-1] == "ws_contact" and "eq_active" in dnames
+  assert dnames[0] == "nworld" and "efc_J" in dnames and dnames[-1] == "ws_contact" and "eq_active" in dnames and "ws_rk" in dnames
   # every batched pointer has its _nb companion right after it
   for i, (n, k, p) in enumerate(_abi.MODEL_FIELDS):
     if n.endswith("_nb"):
