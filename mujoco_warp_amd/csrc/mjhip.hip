@@ -1,9 +1,10 @@
 // mjhip.hip -- extern "C" entry points of libmjhip.so (see include/mjhip.h) and launch sequencing.
 //
-// One `step` = 6 kernel launches on the caller's stream (reference: ~90 fixed launches + ~12 per solver
+// One `step` = 3-4 composite launches on the caller's stream (reference: ~90 fixed launches + ~12 per solver
 // iteration, forward.py:1341-1380):
-//   k_fwd_pos (kinematics+com_pos+crb) -> k_collision -> k_make_constraint -> k_fwd_vel (com_vel, passive, rne,
-//   actuation, factor+solve) -> k_solve (whole Newton/CG solve) -> k_integrate.
+//   k_fwd_pos_plus (kinematics+com_pos+crb, solver schedule) -> k_mid ({collision -> make_constraint} and fwd_vel
+//   workgroups) -> k_solve_plus / k_solve_pgs (the whole solve, riders) -> k_integrate_plus (integrator, riders);
+// the stage API launches the same bodies as plain kernels.  See "composite launches" below and DESIGN.md section 3.
 // Nothing here allocates or synchronises (hipGraph-capturable); workspace lives in MjhData.
 #include "host.hpp"
 
