@@ -393,6 +393,13 @@ def _compile(root, base_dir):
       _parse_option(elem, opt)
     elif elem.tag == "default":
       _parse_defaults(elem, None, table)
+    elif elem.tag in ("deformable", "extension"):
+      if len(list(elem)):
+        raise NotImplementedError(f"<{elem.tag}> is outside the hot-path scope")
+    elif elem.tag not in ("worldbody", "actuator", "contact", "keyframe", "equality", "tendon", "asset", "visual", "statistic",
+                          "size", "custom", "sensor"):
+      # (<sensor> and <custom> do not enter the dynamics; <include> etc. would change the model: never skipped silently)
+      raise NotImplementedError(f"<{elem.tag}>")
   if "main" not in table:
     table["main"] = _Defaults("main")
 
@@ -546,9 +553,9 @@ def _compile(root, base_dir):
         a.update(explicit)
         sites.append({"name": a.get("name", ""), "body": bid, "pos": _vec(a, "pos", [0, 0, 0]),
                       "quat": _orientation(a, compiler), "size": _vec(a, "size", [0.005, 0.005, 0.005])})
-      elif child.tag in ("camera", "light", "body", "plugin", "composite", "flexcomp", "frame"):
-        if child.tag in ("composite", "flexcomp", "frame", "plugin"):
-          raise NotImplementedError(f"<{child.tag}>")
+      elif child.tag not in ("camera", "light", "body"):
+        # <frame>, <replicate>, <attach>, <composite>, <flexcomp>, <plugin>, ...: never skipped silently
+        raise NotImplementedError(f"<{child.tag}> inside <body>")
     for child in elem:
       if child.tag == "body":
         parse_body(child, bid, cc)
@@ -571,6 +578,8 @@ def _compile(root, base_dir):
   for child in wb:
     if child.tag == "body":
       parse_body(child, 0, None)
+    elif child.tag not in ("geom", "site", "camera", "light"):
+      raise NotImplementedError(f"<{child.tag}> inside <worldbody>")  # <frame>, <replicate>, <attach>, <composite>, ...
 
   if any(len(list(e)) > 0 for e in root.findall("tendon")):
     raise NotImplementedError("<tendon> is outside the hot-path scope (SURVEY §2 OUT rows)")
@@ -933,6 +942,9 @@ def _compile(root, base_dir):
 
   _sparse_structure(m)
   set_const(m)
+  for st in root.findall("statistic"):  # explicit overrides of the compiled statistics (the solver scales its tolerances by it)
+    if "meaninertia" in st.attrib:
+      m.stat.meaninertia = float(st.get("meaninertia"))
   return m
 
 

@@ -85,6 +85,15 @@ def test_unsupported_features_raise():
   m = mjw.mjcf.from_xml_string('<mujoco><option cone="elliptic"/><worldbody><body><joint/><geom size=".1"/></body></worldbody></mujoco>')
   with pytest.raises(NotImplementedError):
     mjw.put_model(m)
+  # structural elements the subset compiler does not expand are never skipped silently (they would change the model)
+  for body in ('<replicate count="2"><body><joint/><geom size=".1"/></body></replicate>', '<frame><geom size=".1"/></frame>',
+               '<body><joint/><geom size=".1"/><attach model="x" body="y" prefix="z"/></body>'):
+    with pytest.raises(NotImplementedError):
+      mjw.mjcf.from_xml_string(f"<mujoco><worldbody>{body}</worldbody></mujoco>")
+  with pytest.raises(NotImplementedError):
+    mjw.mjcf.from_xml_string('<mujoco><worldbody><body><joint/><geom size=".1"/></body></worldbody><bogus/></mujoco>')
+  m = mjw.mjcf.from_xml_string('<mujoco><statistic meaninertia="2.5"/><worldbody><body><joint/><geom size=".1"/></body></worldbody></mujoco>')
+  assert m.stat.meaninertia == 2.5
   m = mjw.mjcf.from_xml_string('<mujoco><option integrator="implicit"/><worldbody><body><joint/><geom size=".1"/></body></worldbody></mujoco>')
   with pytest.raises(NotImplementedError):
     mjw.put_model(m)
