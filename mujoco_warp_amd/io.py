@@ -105,6 +105,18 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
     raise NotImplementedError("Only joint transmissions are supported.")
   if int(getattr(opt, "noslip_iterations", 0)) > 0:
     raise NotImplementedError("noslip solver is unsupported.")
+  if mjm.nu:
+    for name, allowed, what in (("actuator_dyntype", (0, 1, 2, 3), "none / integrator / filter / filterexact"),
+                                ("actuator_gaintype", (0, 1), "fixed / affine"), ("actuator_biastype", (0, 1), "none / affine")):
+      if not np.isin(np.asarray(getattr(mjm, name)), allowed).all():
+        raise NotImplementedError(f"{name}: only {what} are implemented (no muscle / user types).")
+  # physics this engine does not compute must not be dropped silently
+  if float(getattr(opt, "density", 0.0)) != 0.0 or float(getattr(opt, "viscosity", 0.0)) != 0.0:
+    raise NotImplementedError("fluid forces (option density / viscosity, passive.py _fluid_force) are not implemented.")
+  unsupported_enable = int(opt.enableflags) & int(types.EnableBit.OVERRIDE | types.EnableBit.SLEEP | types.EnableBit.FWDINV
+                                                  | types.EnableBit.INVDISCRETE)
+  if unsupported_enable:
+    raise NotImplementedError(f"enable flags {types.EnableBit(unsupported_enable)!r} are not implemented.")
   pairs = geom_pairs(mjm)
   gt = np.asarray(mjm.geom_type)
   for a, b in pairs:

@@ -836,6 +836,9 @@ def _compile(root, base_dir):
       raise NotImplementedError("actuators on ball/free joints")
     m.actuator_trntype[i] = TRN_JOINT
     m.actuator_trnid[i, 0] = jid
+    for key, table_, dflt in (("dyntype", dynmap, "none"), ("gaintype", gainmap, "fixed"), ("biastype", biasmap, "none")):
+      if a.get(key, dflt) not in table_:
+        raise NotImplementedError(f"actuator {key} '{a[key]}'")
     m.actuator_dyntype[i] = dynmap[a.get("dyntype", "none")]
     m.actuator_gaintype[i] = gainmap[a.get("gaintype", "fixed")]
     m.actuator_biastype[i] = biasmap[a.get("biastype", "none")]

@@ -94,6 +94,13 @@ def test_unsupported_features_raise():
     mjw.mjcf.from_xml_string('<mujoco><worldbody><body><joint/><geom size=".1"/></body></worldbody><bogus/></mujoco>')
   m = mjw.mjcf.from_xml_string('<mujoco><statistic meaninertia="2.5"/><worldbody><body><joint/><geom size=".1"/></body></worldbody></mujoco>')
   assert m.stat.meaninertia == 2.5
+  for opt in ('density="1.2"', 'viscosity="0.1"'):
+    m = mjw.mjcf.from_xml_string(f'<mujoco><option {opt}/><worldbody><body><joint/><geom size=".1"/></body></worldbody></mujoco>')
+    with pytest.raises(NotImplementedError):
+      mjw.put_model(m)
+  m = mjw.mjcf.from_xml_string('<mujoco><option><flag override="enable"/></option><worldbody><body><joint/><geom size=".1"/></body></worldbody></mujoco>')
+  with pytest.raises(NotImplementedError):
+    mjw.put_model(m)
   m = mjw.mjcf.from_xml_string('<mujoco><option integrator="implicit"/><worldbody><body><joint/><geom size=".1"/></body></worldbody></mujoco>')
   with pytest.raises(NotImplementedError):
     mjw.put_model(m)
