@@ -208,13 +208,14 @@ static thread_local bool g_fuse_euler = false;
 static thread_local bool g_riders_on_side = false;
 static int solve_supported(const MjhModel* m, const MjhData* d) {
   if (m->cone != 0) return fail(MJH_E_UNSUPPORTED, "elliptic cones are not implemented yet");
-  if (m->nv > 64) return fail(MJH_E_UNSUPPORTED, "nv > 64 needs the sparse/blocked solver path (not implemented yet)");
+  if (m->nv > 64 && m->solver == SOL_PGS) return fail(MJH_E_UNSUPPORTED, "PGS supports at most 64 dofs");
   if (m->solver != SOL_NEWTON && m->solver != SOL_CG && m->solver != SOL_PGS) return fail(MJH_E_UNSUPPORTED, "unknown solver");
   if (d->njmax > 192) return fail(MJH_E_UNSUPPORTED, "njmax > 192 is not supported by the register-resident solver yet");
   return MJH_OK;
 }
 static int launch_solve_any(const MjhModel* m, const MjhData* d, bool with_factor, hipStream_t s) {
   if (int rc = solve_supported(m, d)) return rc;
+  if (m->nv > 64) return launch_solve_big(m, d, s);  // no riders: they go with the integrator launch
   if (m->solver == SOL_PGS) return launch_pgs(m, d, s);
   const bool newton = m->solver == SOL_NEWTON;
   const int fe = g_fuse_euler ? 1 : 0;
@@ -245,7 +246,7 @@ static int launch_integrate_plus(const MjhModel* m, const MjhData* d, int mode, 
   const IntLayout lay = int_layout(m->nv, m->nC);
   const FacLayout fl = fac_layout(m->nv, m->nC);
   const size_t ms_bytes = sizeof(int) * mstruct_ints(m->nv, m->nC);
-  const bool with_factor = m->solver != SOL_CG && !g_riders_on_side;
+  const bool with_factor = (m->solver != SOL_CG || m->nv > 64) && !g_riders_on_side;
   size_t lds = std::max(ms_bytes + sizeof(float) * std::max(lay.total, fl.total) * 8, (size_t)2048);
   if (lds > (size_t)kLdsPerCU) return fail(MJH_E_UNSUPPORTED, "k_integrate: does not fit in LDS");
   HIPCHK(set_lds(k_integrate_plus<G>, lds));
@@ -422,7 +423,7 @@ static int run_stage(const MjhModel* m, const MjhData* d, int stage, hipStream_t
       // explicit Euler without activations: the velocity/position update is a few loads and stores per dof, done by the
       // solver's own epilogue (saves a launch); every other case keeps the integrator workgroups
       // (CG only: the Newton launch keeps its integrator launch anyway, for the riders, and measured 2 % slower fused)
-      const bool fuse_euler = stage == MJH_STAGE_STEP && m->integrator == INT_EULER && m->na == 0 && m->solver == SOL_CG &&
+      const bool fuse_euler = stage == MJH_STAGE_STEP && m->integrator == INT_EULER && m->na == 0 && m->solver == SOL_CG && m->nv <= 64 &&
                               (m->disableflags & (DSBL_EULERDAMP | DSBL_DAMPER)) != 0;
       g_fuse_euler = fuse_euler;
       int rc;

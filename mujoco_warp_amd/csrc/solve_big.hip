@@ -1,0 +1,18 @@
+// solve_big.hip -- k_solve_big: CG / Newton for models with more than 64 dofs (one translation unit of libmjhip.so, see host.hpp)
+#include "host.hpp"
+
+#include "solver_big.hpp"
+
+__global__ void __launch_bounds__(64) k_solve_big(MjhModel m, MjhData d) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  solve_big_body<64>(m, d, smem, Blk{(int)blockIdx.x, 1, 64});
+}
+
+int launch_solve_big(const MjhModel* m, const MjhData* d, hipStream_t s) {
+  const BigLayout lay = big_layout(m->nv, m->nC, d->njmax, m->solver == SOL_NEWTON);
+  const size_t lds = sizeof(int) * mstruct_ints(m->nv, m->nC) + sizeof(float) * lay.total;
+  if (lds > (size_t)kLdsPerCU) return fail(MJH_E_UNSUPPORTED, "k_solve_big: nv / njmax do not fit in LDS");
+  HIPCHK(set_lds(k_solve_big, lds));
+  hipLaunchKernelGGL(k_solve_big, dim3(d->nworld), dim3(64), lds, s, *m, *d);
+  return MJH_OK;
+}

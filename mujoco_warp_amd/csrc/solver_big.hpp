@@ -1,0 +1,356 @@
+// solver_big.hpp -- CG / Newton constraint solver for models with more than 64 dofs (three_humanoids: nv = 81).
+//
+// Same algorithm as solver.hpp (reference solver.py:3671-3743 solve, 3525-3620 iteration, 835-1347 line search,
+// 1698-1822 constraint update, 3061-3220 gradient, 3283-3450 CG) but without the "lane i owns row i" register layout,
+// which ends at 64 dofs: one wavefront per world, every vector in LDS, every loop strided over the 64 lanes.
+//   * J stays in HBM/L2 (njmax x nv is 64 KB at nv 81, njmax 192: LDS-resident it would leave one wave per CU); it is
+//     read twice per iteration: row-per-lane for J v, column-per-lane (coalesced) for J' f.
+//   * CG applies M^-1 through the sparse L'DL factor (factor_ld / solve_ld, smooth.hpp: no fill-in for tree-structured M),
+//     so independent trees (three humanoids) cost the sum of their sizes, not the square of the total.
+//   * Newton builds the dense H = M + J' diag(D active) J in LDS (nv^2 floats) one J row at a time and factors it with a
+//     column-synchronous Cholesky.  (The reference switches to a blocked 16x16 Cholesky + sparse J here,
+//     solver.py:2801-3052; at nv ~ 100 the dense factor is 26-64 KB of LDS and a few hundred microseconds.)
+// This is the correctness path for big models, not a tuned one: the register-resident kernels cover nv <= 64.
+#pragma once
+#include "solver.hpp"
+
+struct BigLayout {
+  int q, Ma, grad, Mgrad, search, mv, pgrad, pMgrad, qc, fs, x;  // nv-vectors
+  int ja, jv, D, fl, force, da, kind;                            // row vectors (njmax)
+  int M, L, dinv, H, total;
+};
+__host__ __device__ inline BigLayout big_layout(int nv, int nC, int njmax, bool newton) {
+  BigLayout p;
+  int o = 0;
+  int* nvv[] = {&p.q, &p.Ma, &p.grad, &p.Mgrad, &p.search, &p.mv, &p.pgrad, &p.pMgrad, &p.qc, &p.fs, &p.x};
+  for (int* f : nvv) { *f = o; o += nv; }
+  int* rv[] = {&p.ja, &p.jv, &p.D, &p.fl, &p.force, &p.da, &p.kind};
+  for (int* f : rv) { *f = o; o += njmax; }
+  p.M = o; o += nC;
+  p.L = o; o += nC;
+  p.dinv = o; o += nv;
+  p.H = o; o += newton ? nv * (nv + 1) : 0;  // row stride nv + 1
+  p.total = ((o + 3) / 4) * 4;
+  return p;
+}
+
+template <int G>
+DEV void solve_big_body(const MjhModel& m, const MjhData& d, float* smem, const Blk& b) {
+  if ((int)threadIdx.x >= b.nthreads) return;
+  const int nv = m.nv, nC = m.nC, njmax = d.njmax, nvp = d.nv_pad;
+  const bool newton = m.solver == SOL_NEWTON;
+  const BigLayout lay = big_layout(nv, nC, njmax, newton);
+  int* shi = reinterpret_cast<int*>(smem);
+  const MStruct ms = load_mstruct<G>(m, shi, b.nthreads);
+  const int lig = threadIdx.x & (G - 1), gib = threadIdx.x / G;
+  const int slot = b.w0 + gib;
+  if (slot >= d.nworld) return;
+  const int w = d.ws_order[slot];
+  float* S = smem + mstruct_ints(nv, nC) + (size_t)gib * lay.total;
+  float *q = S + lay.q, *Ma = S + lay.Ma, *grad = S + lay.grad, *Mgrad = S + lay.Mgrad, *search = S + lay.search, *mv = S + lay.mv,
+        *pgrad = S + lay.pgrad, *pMgrad = S + lay.pMgrad, *qc = S + lay.qc, *fs = S + lay.fs, *x = S + lay.x;
+  float *ja = S + lay.ja, *jv = S + lay.jv, *rD = S + lay.D, *rfl = S + lay.fl, *force = S + lay.force, *da = S + lay.da;
+  int* kind = reinterpret_cast<int*>(S + lay.kind);
+  float *Ml = S + lay.M, *Ll = S + lay.L, *dinv = S + lay.dinv, *H = S + lay.H;
+  const int HS = nv + 1;
+
+  const int nefc = min(d.nefc[w], njmax);
+  const int ne = d.ne[w], nf = d.nf[w];
+  const size_t vo = (size_t)w * nv, eo = (size_t)w * njmax;
+  const float* Jg = d.efc_J + (size_t)w * d.njmax_pad * nvp;
+  const bool warm = !(m.disableflags & DSBL_WARMSTART);
+
+  // ---- M, its sparse factor, qacc_smooth = M^-1 qfrc_smooth ------------------------------------------------------
+  gcopy<G>(Ml, d.M + (size_t)w * nC, nC, lig);
+  gcopy<G>(Ll, d.M + (size_t)w * nC, nC, lig);
+  gcopy<G>(fs, d.qfrc_smooth + vo, nv, lig);
+  gcopy<G>(x, d.qfrc_smooth + vo, nv, lig);
+  gsync();
+  factor_ld<G>(ms, Ll, dinv, nv, lig);
+  solve_ld<G>(m, ms, Ll, dinv, x, nv, lig);
+  gsync();
+  for (int i = lig; i < nv; i += G) {
+    d.qacc_smooth[vo + i] = x[i];
+    q[i] = nefc > 0 && warm ? d.qacc_warmstart[vo + i] : x[i];
+  }
+  gsync();
+  mul_m_ld<G>(ms, Ml, q, Ma, nv, lig);
+  gsync();
+  if (nefc == 0) {  // unconstrained: qacc = qacc_smooth (solver.py:3684-3686)
+    for (int i = lig; i < nv; i += G) {
+      d.qacc[vo + i] = q[i];
+      d.qfrc_constraint[vo + i] = 0.0f;
+      d.efc_Ma[vo + i] = Ma[i];
+    }
+    if (lig == 0) d.solver_niter[w] = 0;
+    return;
+  }
+
+  // J[r,:] . vec for this lane's rows (row-per-lane; a row is nvp contiguous floats, 16-byte aligned)
+  auto j_dot = [&](int r, const float* vec) __attribute__((always_inline)) {
+    const float4* Jr = reinterpret_cast<const float4*>(Jg + (size_t)r * nvp);
+    float s0 = 0.0f, s1 = 0.0f;
+    for (int c4 = 0; c4 < nvp / 4; ++c4) {
+      const float4 j4 = Jr[c4];
+      const int c = 4 * c4;  // (padding columns of J are zero; the vectors have nv entries)
+      s0 += j4.x * vec[c] + (c + 2 < nv ? j4.z * vec[c + 2] : 0.0f);
+      s1 += (c + 1 < nv ? j4.y * vec[c + 1] : 0.0f) + (c + 3 < nv ? j4.w * vec[c + 3] : 0.0f);
+    }
+    return s0 + s1;
+  };
+  for (int r = lig; r < nefc; r += G) {
+    rD[r] = d.efc_D[eo + r];
+    rfl[r] = d.efc_frictionloss[eo + r];
+    kind[r] = r >= ne + nf ? 2 : (r >= ne ? 1 : 0);
+    ja[r] = j_dot(r, q) - d.efc_aref[eo + r];
+    jv[r] = 0.0f;
+  }
+  gsync();
+
+  const float tolerance = bf(m.opt_tolerance, m.opt_tolerance_nb, w, 1)[0];
+  const float ls_tolerance = bf(m.opt_ls_tolerance, m.opt_ls_tolerance_nb, w, 1)[0];
+  const float meaninertia = bf(m.stat_meaninertia, m.stat_meaninertia_nb, w, 1)[0];
+  const float scale = meaninertia * (float)nv, rscale = 1.0f / scale;
+  const int maxiter = m.iterations, ls_iterations = m.ls_iterations;
+  const bool has_fl = nf > 0;
+  int niter = 0, ovf = 0;
+  float improvement = 0.0f, search_dot = 0.0f;
+
+  for (;;) {
+    // ---- force / state of every row (solver.py:1698-1822), qfrc_constraint = J' force (1912-1947) -------------------
+    for (int r = lig; r < nefc; r += G) {
+      float f;
+      int st;
+      row_force(kind[r], ja[r], rD[r], has_fl, rfl + r, f, st);
+      force[r] = f;
+      da[r] = st == ST_QUADRATIC ? rD[r] : 0.0f;
+    }
+    gsync();
+    for (int c = lig; c < nv; c += G) {  // column-per-lane: consecutive lanes read consecutive addresses of every row
+      float s = 0.0f;
+      for (int r = 0; r < nefc; ++r) s += Jg[(size_t)r * nvp + c] * force[r];
+      qc[c] = s;
+    }
+    gsync();
+    // ---- gradient (solver.py:3061-3220) -------------------------------------------------------------------------
+    float gd = 0.0f;
+    for (int i = lig; i < nv; i += G) {
+      const float g = Ma[i] - fs[i] - qc[i];
+      grad[i] = g;
+      gd += g * g;
+    }
+    const float grad_dot = gsum<G>(gd);
+    gsync();
+    float decrement = 0.0f;
+    if (newton) {
+      // H = M + J' diag(da) J, dense lower triangle (row stride nv + 1), one J row at a time through the LDS line `x`
+      for (int i = lig; i < nv; i += G)
+        for (int j = 0; j <= i; ++j) H[i * HS + j] = 0.0f;
+      gsync();
+      for (int i = lig; i < nv; i += G) {
+        const int start = ms.rowadr[i], n = ms.rownnz[i];
+        for (int a = 0; a < n; ++a) H[i * HS + ms.colind[start + a]] = Ml[start + a];  // colind <= i
+      }
+      gsync();
+      for (int r = 0; r < nefc; ++r) {
+        const float dr = da[r];
+        if (dr == 0.0f) continue;  // (uniform over the wave: da lives in LDS)
+        for (int c = lig; c < nv; c += G) x[c] = Jg[(size_t)r * nvp + c];
+        gsync();
+        for (int i = lig; i < nv; i += G) {
+          const float t = dr * x[i];
+          if (t != 0.0f)
+            for (int j = 0; j <= i; ++j) H[i * HS + j] += t * x[j];
+        }
+        gsync();
+      }
+      // Cholesky in place (lower), column by column; then (L L')^-1 grad
+      for (int j = 0; j < nv; ++j) {
+        const float pv = fmaxf(H[j * HS + j], MJ_MINVAL);
+        const float inv = 1.0f / sqrtf(pv);
+        gsync();
+        for (int i = j + lig; i < nv; i += G) H[i * HS + j] = i == j ? pv * inv : H[i * HS + j] * inv;
+        gsync();
+        for (int i = j + 1 + lig; i < nv; i += G) {
+          const float lij = H[i * HS + j];
+          for (int k = j + 1; k <= i; ++k) H[i * HS + k] -= lij * H[k * HS + j];
+        }
+        gsync();
+      }
+      for (int i = lig; i < nv; i += G) Mgrad[i] = grad[i];
+      gsync();
+      for (int j = 0; j < nv; ++j) {  // forward substitution, column oriented
+        if (lig == 0) Mgrad[j] = Mgrad[j] / H[j * HS + j];
+        gsync();
+        const float yj = Mgrad[j];
+        for (int i = j + 1 + lig; i < nv; i += G) Mgrad[i] -= H[i * HS + j] * yj;
+        gsync();
+      }
+      for (int j = nv - 1; j >= 0; --j) {  // backward substitution with L'
+        if (lig == 0) Mgrad[j] = Mgrad[j] / H[j * HS + j];
+        gsync();
+        const float xj = Mgrad[j];
+        for (int i = lig; i < j; i += G) Mgrad[i] -= H[j * HS + i] * xj;
+        gsync();
+      }
+      float sd = 0.0f, dc = 0.0f;
+      for (int i = lig; i < nv; i += G) {
+        search[i] = -Mgrad[i];
+        sd += Mgrad[i] * Mgrad[i];
+        dc += grad[i] * Mgrad[i];
+      }
+      search_dot = gsum<G>(sd);
+      decrement = gsum<G>(dc);
+    } else {
+      for (int i = lig; i < nv; i += G) Mgrad[i] = grad[i];
+      gsync();
+      solve_ld<G>(m, ms, Ll, dinv, Mgrad, nv, lig);  // Mgrad = M^-1 grad
+      gsync();
+    }
+    // ---- convergence, search direction ----------------------------------------------------------------------------
+    if (niter == 0) {
+      if (!newton) {
+        float sd = 0.0f;
+        for (int i = lig; i < nv; i += G) {
+          search[i] = -Mgrad[i];
+          sd += Mgrad[i] * Mgrad[i];
+          pgrad[i] = grad[i];
+          pMgrad[i] = Mgrad[i];
+        }
+        search_dot = gsum<G>(sd);
+      }
+    } else {
+      const float imp = improvement * rscale, gradient = sqrtf(grad_dot) * rscale;
+      bool done;
+      if (newton) {
+        done = (imp < tolerance) || (gradient < tolerance) || (0.5f * decrement * rscale < tolerance);
+      } else {
+        float num = 0.0f, den = 0.0f;
+        for (int i = lig; i < nv; i += G) {
+          num += grad[i] * (Mgrad[i] - pMgrad[i]);
+          den += pgrad[i] * pMgrad[i];
+        }
+        num = gsum<G>(num);
+        den = gsum<G>(den);
+        const float beta = fmaxf(0.0f, num / fmaxf(MJ_MINVAL, den));
+        done = (imp < tolerance) || (gradient < tolerance);
+        if (!done) {
+          float sd = 0.0f;
+          for (int i = lig; i < nv; i += G) {
+            const float s = -Mgrad[i] + beta * search[i];
+            search[i] = s;
+            sd += s * s;
+            pgrad[i] = grad[i];
+            pMgrad[i] = Mgrad[i];
+          }
+          search_dot = gsum<G>(sd);
+        }
+      }
+      if (done) break;
+      if (niter >= maxiter) {
+        ovf |= OVF_ITERATIONS;
+        break;
+      }
+    }
+    if (maxiter == 0) break;
+    gsync();
+    // ---- mv = M search, jv = J search ---------------------------------------------------------------------------
+    mul_m_ld<G>(ms, Ml, search, mv, nv, lig);
+    gsync();
+    for (int r = lig; r < nefc; r += G) jv[r] = j_dot(r, search);
+    float g1 = 0.0f, g2 = 0.0f;
+    for (int i = lig; i < nv; i += G) {
+      g1 += search[i] * (Ma[i] - fs[i]);
+      g2 += 0.5f * search[i] * mv[i];
+    }
+    const float gauss1 = gsum<G>(g1), gauss2 = gsum<G>(g2);
+    gsync();
+    // ---- line search (solver.py:835-1347) ------------------------------------------------------------------------
+    const float gtol = fmaxf(tolerance * ls_tolerance * sqrtf(search_dot) * scale, 1e-6f);
+    auto total = [&](float a) __attribute__((always_inline)) {
+      P3 s = P3{0.0f, 0.0f, 0.0f};
+      for (int r = lig; r < nefc; r += G) {
+        const P3 t = eval_row(ja[r], jv[r], rD[r], rfl[r], kind[r], a);
+        s.c += t.c;
+        s.g += t.g;
+        s.h += t.h;
+      }
+      return P3{a * a * gauss2 + a * gauss1 + gsum<G>(s.c), 2.0f * a * gauss2 + gauss1 + gsum<G>(s.g), 2.0f * gauss2 + gsum<G>(s.h)};
+    };
+    P3 p0 = total(0.0f);
+    p0.c = 0.0f;
+    const float lo_alpha_in = -fast_div(p0.g, p0.h);
+    const P3 lo_in = total(lo_alpha_in);
+    float alpha = 0.0f;
+    improvement = 0.0f;
+    bool ls_converged = fabsf(lo_in.g) < gtol && lo_in.c < 0.0f;
+    if (ls_converged) {
+      alpha = lo_alpha_in;
+      improvement = -lo_in.c;
+    } else {
+      const bool lo_less = lo_in.g < p0.g;
+      P3 lo = lo_less ? lo_in : p0, hi = lo_less ? p0 : lo_in;
+      float lo_alpha = lo_less ? lo_alpha_in : 0.0f, hi_alpha = lo_less ? 0.0f : lo_alpha_in;
+      for (int it = 0; it < ls_iterations; ++it) {
+        const float a_lo = lo_alpha - fast_div(lo.g, lo.h), a_hi = hi_alpha - fast_div(hi.g, hi.h);
+        const float a_mid = 0.5f * (lo_alpha + hi_alpha);
+        const P3 lo_next = total(a_lo), hi_next = total(a_hi), mid = total(a_mid);
+        auto take = [](bool c, P3& dst, float& da_, const P3& src, float sa) __attribute__((always_inline)) {
+          dst.c = c ? src.c : dst.c;
+          dst.g = c ? src.g : dst.g;
+          dst.h = c ? src.h : dst.h;
+          da_ = c ? sa : da_;
+        };
+        const bool s1 = in_bracket(lo, lo_next);
+        take(s1, lo, lo_alpha, lo_next, a_lo);
+        const bool s2 = in_bracket(lo, mid);
+        take(s2, lo, lo_alpha, mid, a_mid);
+        const bool s3 = in_bracket(lo, hi_next);
+        take(s3, lo, lo_alpha, hi_next, a_hi);
+        const bool h1 = in_bracket(hi, hi_next);
+        take(h1, hi, hi_alpha, hi_next, a_hi);
+        const bool h2 = in_bracket(hi, mid);
+        take(h2, hi, hi_alpha, mid, a_mid);
+        const bool h3 = in_bracket(hi, lo_next);
+        take(h3, hi, hi_alpha, lo_next, a_lo);
+        const bool swap_lo = s1 || s2 || s3, swap_hi = h1 || h2 || h3;
+        const bool ls_done = (!swap_lo && !swap_hi) || (lo.c < 0.0f && lo.g < 0.0f && lo.g > -gtol) || (hi.c < 0.0f && hi.g > 0.0f && hi.g < gtol);
+        const bool improved = lo.c < 0.0f || hi.c < 0.0f;
+        const bool lo_better = lo.c < hi.c;
+        alpha = improved ? (lo_better ? lo_alpha : hi_alpha) : alpha;
+        improvement = improved ? -(lo_better ? lo.c : hi.c) : improvement;
+        if (ls_done) {
+          ls_converged = true;
+          break;
+        }
+      }
+    }
+    if (!ls_converged) ovf |= OVF_LS_ITERATIONS;
+    // ---- move along the ray ---------------------------------------------------------------------------------------
+    for (int i = lig; i < nv; i += G) {
+      q[i] += alpha * search[i];
+      Ma[i] += alpha * mv[i];
+    }
+    for (int r = lig; r < nefc; r += G) ja[r] += alpha * jv[r];
+    gsync();
+    ++niter;
+  }
+
+  // ---- outputs ------------------------------------------------------------------------------------------------------
+  for (int i = lig; i < nv; i += G) {
+    d.qacc[vo + i] = q[i];
+    d.qfrc_constraint[vo + i] = qc[i];
+    d.efc_Ma[vo + i] = Ma[i];
+  }
+  for (int r = lig; r < nefc; r += G) {
+    float f;
+    int st;
+    row_force(kind[r], ja[r], rD[r], has_fl, rfl + r, f, st);
+    d.efc_force[eo + r] = f;
+    d.efc_state[eo + r] = st;
+  }
+  if (lig == 0) {
+    d.solver_niter[w] = niter;
+    if (ovf) atomicOr(d.overflow + w, ovf);
+  }
+}

@@ -6,3 +6,4 @@
 #include "solve_cg64.hip"
 #include "solve_newton64.hip"
 #include "pgs_tu.hip"
+#include "solve_big.hip"

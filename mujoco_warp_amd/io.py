@@ -98,9 +98,8 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
     raise NotImplementedError(f"Unknown solver {int(opt.solver)}.")
   if int(opt.cone) != types.ConeType.PYRAMIDAL:
     raise NotImplementedError("Elliptic friction cones are not implemented yet.")
-  if mjm.nv > 64:
-    raise NotImplementedError("nv > 64 requires the sparse-J / blocked-Cholesky path (SURVEY §8f row 2), not implemented yet "
-                              "(nv <= 32: 32 lanes per world; 32 < nv <= 64: dense J with 64 lanes per world).")
+  if mjm.nv > 64 and int(opt.solver) == types.SolverType.PGS:
+    raise NotImplementedError("PGS supports at most 64 dofs (CG and Newton have a generic path for larger models).")
   if mjm.nu and (np.asarray(mjm.actuator_trntype) != types.TrnType.JOINT).any():
     raise NotImplementedError("Only joint transmissions are supported.")
   if int(getattr(opt, "noslip_iterations", 0)) > 0:

@@ -155,3 +155,33 @@ SPHERE_CYLINDER_XML = """
   </keyframe>
 </mujoco>
 """
+
+
+def multi_humanoid_xml(n=3, spacing=1.5):
+  """n copies of the benchmark humanoid side by side in one model (nv = 27 n), built by cloning the torso subtree and the
+  actuators with suffixed names -- the structure of the reference's three_humanoids.xml (which uses <replicate>/<attach>,
+  elements the subset compiler does not expand)."""
+  import copy
+  import xml.etree.ElementTree as ET
+
+  root = ET.parse(HUMANOID_XML).getroot()
+  wb = root.find("worldbody")
+  torso = next(b for b in wb.findall("body") if b.get("name") == "torso")
+  acts = root.find("actuator")
+  act0 = list(acts)
+  for k in range(1, n):
+    t = copy.deepcopy(torso)
+    for e in t.iter():
+      if e.get("name"):
+        e.set("name", f"{e.get('name')}_{k}")
+    p = [float(x) for x in torso.get("pos").split()]
+    t.set("pos", f"{p[0]} {p[1] + k * spacing} {p[2]}")
+    wb.append(t)
+    for a in act0:
+      c = copy.deepcopy(a)
+      c.set("name", f"{a.get('name')}_{k}")
+      c.set("joint", f"{a.get('joint')}_{k}")
+      acts.append(c)
+  for sec in root.findall("keyframe") + root.findall("contact") + root.findall("sensor"):
+    root.remove(sec)
+  return ET.tostring(root, encoding="unicode")
