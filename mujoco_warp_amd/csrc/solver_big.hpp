@@ -7,8 +7,8 @@
 //     read twice per iteration: row-per-lane for J v, column-per-lane (coalesced) for J' f.
 //   * CG applies M^-1 through the sparse L'DL factor (factor_ld / solve_ld, smooth.hpp: no fill-in for tree-structured M),
 //     so independent trees (three humanoids) cost the sum of their sizes, not the square of the total.
-//   * Newton builds the dense H = M + J' diag(D active) J in LDS (nv^2 floats) one J row at a time and factors it with a
-//     column-synchronous Cholesky.  (The reference switches to a blocked 16x16 Cholesky + sparse J here,
+//   * Newton builds the dense H = M + J' diag(D active) J in LDS (nv^2 floats) from 16-row blocks of J and factors it with a
+//     left-looking Cholesky (sums in registers).  (The reference switches to a blocked 16x16 Cholesky + sparse J here,
 //     solver.py:2801-3052; at nv ~ 100 the dense factor is 26-64 KB of LDS and a few hundred microseconds.)
 // This is the correctness path for big models, not a tuned one: the register-resident kernels cover nv <= 64.
 #pragma once
@@ -17,8 +17,9 @@
 struct BigLayout {
   int q, Ma, grad, Mgrad, search, mv, pgrad, pMgrad, qc, fs, x;  // nv-vectors
   int ja, jv, D, fl, force, da, kind;                            // row vectors (njmax)
-  int M, L, dinv, H, total;
+  int M, L, dinv, H, stage, HS, total;
 };
+constexpr int BIG_RB = 16;  // J rows staged per block of the H build
 __host__ __device__ inline BigLayout big_layout(int nv, int nC, int njmax, bool newton) {
   BigLayout p;
   int o = 0;
@@ -29,7 +30,11 @@ __host__ __device__ inline BigLayout big_layout(int nv, int nC, int njmax, bool 
   p.M = o; o += nC;
   p.L = o; o += nC;
   p.dinv = o; o += nv;
-  p.H = o; o += newton ? nv * (nv + 1) : 0;  // row stride nv + 1
+  o = ((o + 3) / 4) * 4;
+  const int nvp = ((nv + 3) / 4) * 4;
+  p.HS = ((nvp / 4) & 1) ? nvp : nvp + 4;  // H row stride: a multiple of 4 with HS/4 odd (row-per-lane 16-byte reads, no conflicts)
+  p.H = o; o += newton ? nv * p.HS : 0;
+  p.stage = o; o += newton ? BIG_RB * nvp : 0;
   p.total = ((o + 3) / 4) * 4;
   return p;
 }
@@ -51,8 +56,8 @@ DEV void solve_big_body(const MjhModel& m, const MjhData& d, float* smem, const 
         *pgrad = S + lay.pgrad, *pMgrad = S + lay.pMgrad, *qc = S + lay.qc, *fs = S + lay.fs, *x = S + lay.x;
   float *ja = S + lay.ja, *jv = S + lay.jv, *rD = S + lay.D, *rfl = S + lay.fl, *force = S + lay.force, *da = S + lay.da;
   int* kind = reinterpret_cast<int*>(S + lay.kind);
-  float *Ml = S + lay.M, *Ll = S + lay.L, *dinv = S + lay.dinv, *H = S + lay.H;
-  const int HS = nv + 1;
+  float *Ml = S + lay.M, *Ll = S + lay.L, *dinv = S + lay.dinv, *H = S + lay.H, *stage = S + lay.stage;
+  const int HS = lay.HS;
 
   const int nefc = min(d.nefc[w], njmax);
   const int ne = d.ne[w], nf = d.nf[w];
@@ -139,42 +144,73 @@ DEV void solve_big_body(const MjhModel& m, const MjhData& d, float* smem, const 
       grad[i] = g;
       gd += g * g;
     }
-    const float grad_dot = gsum<G>(gd);
+    const float grad_dot = gsumg<G>(gd);
     gsync();
     float decrement = 0.0f;
     if (newton) {
-      // H = M + J' diag(da) J, dense lower triangle (row stride nv + 1), one J row at a time through the LDS line `x`
+      // H = M + J' diag(da) J, dense lower triangle.  J is staged BIG_RB rows at a time (one coalesced copy: the rows of a
+      // world are contiguous); lane i then adds the block to row i four columns at a time with the sums in registers, so H
+      // sees one read-modify-write per block instead of one per J row.
       for (int i = lig; i < nv; i += G)
-        for (int j = 0; j <= i; ++j) H[i * HS + j] = 0.0f;
+        for (int j = 0; j < HS; ++j) H[i * HS + j] = 0.0f;
       gsync();
       for (int i = lig; i < nv; i += G) {
         const int start = ms.rowadr[i], n = ms.rownnz[i];
         for (int a = 0; a < n; ++a) H[i * HS + ms.colind[start + a]] = Ml[start + a];  // colind <= i
       }
       gsync();
-      for (int r = 0; r < nefc; ++r) {
-        const float dr = da[r];
-        if (dr == 0.0f) continue;  // (uniform over the wave: da lives in LDS)
-        for (int c = lig; c < nv; c += G) x[c] = Jg[(size_t)r * nvp + c];
+      for (int r0 = 0; r0 < nefc; r0 += BIG_RB) {
+        const int nr = min(BIG_RB, nefc - r0);
+        {
+          const float4* src = reinterpret_cast<const float4*>(Jg + (size_t)r0 * nvp);
+          float4* dst = reinterpret_cast<float4*>(stage);
+          for (int idx = lig; idx < nr * (nvp / 4); idx += G) dst[idx] = src[idx];
+        }
         gsync();
         for (int i = lig; i < nv; i += G) {
-          const float t = dr * x[i];
-          if (t != 0.0f)
-            for (int j = 0; j <= i; ++j) H[i * HS + j] += t * x[j];
+          float t[BIG_RB];
+          bool any = false;
+#pragma unroll
+          for (int k = 0; k < BIG_RB; ++k) {
+            t[k] = k < nr ? da[r0 + k] * stage[k * nvp + i] : 0.0f;
+            any = any || t[k] != 0.0f;
+          }
+          if (!any) continue;
+          for (int j0 = 0; j0 <= i; j0 += 4) {
+            float4 acc = *reinterpret_cast<const float4*>(H + i * HS + j0);
+#pragma unroll
+            for (int k = 0; k < BIG_RB; ++k) {
+              const float4 j4 = *reinterpret_cast<const float4*>(stage + k * nvp + j0);  // (rows >= nr hold stale data: t = 0)
+              acc.x += t[k] * j4.x;
+              acc.y += t[k] * j4.y;
+              acc.z += t[k] * j4.z;
+              acc.w += t[k] * j4.w;
+            }
+            *reinterpret_cast<float4*>(H + i * HS + j0) = acc;
+          }
         }
         gsync();
       }
-      // Cholesky in place (lower), column by column; then (L L')^-1 grad
+      // Cholesky in place (lower), left-looking: column j of L from the finished columns k < j,
+      //   s_i = H[i][j] - sum_k L[i][k] L[j][k]   (lane i: own row i against the broadcast row j, sums in registers)
       for (int j = 0; j < nv; ++j) {
+        for (int i = j + lig; i < nv; i += G) {
+          float s0 = 0.0f, s1 = 0.0f;
+          int k = 0;
+          for (; k + 4 <= j; k += 4) {
+            const float4 a4 = *reinterpret_cast<const float4*>(H + i * HS + k);
+            const float4 b4 = *reinterpret_cast<const float4*>(H + j * HS + k);
+            s0 += a4.x * b4.x + a4.z * b4.z;
+            s1 += a4.y * b4.y + a4.w * b4.w;
+          }
+          for (; k < j; ++k) s0 += H[i * HS + k] * H[j * HS + k];
+          H[i * HS + j] -= s0 + s1;
+        }
+        gsync();
         const float pv = fmaxf(H[j * HS + j], MJ_MINVAL);
         const float inv = 1.0f / sqrtf(pv);
         gsync();
         for (int i = j + lig; i < nv; i += G) H[i * HS + j] = i == j ? pv * inv : H[i * HS + j] * inv;
-        gsync();
-        for (int i = j + 1 + lig; i < nv; i += G) {
-          const float lij = H[i * HS + j];
-          for (int k = j + 1; k <= i; ++k) H[i * HS + k] -= lij * H[k * HS + j];
-        }
         gsync();
       }
       for (int i = lig; i < nv; i += G) Mgrad[i] = grad[i];
@@ -199,8 +235,8 @@ DEV void solve_big_body(const MjhModel& m, const MjhData& d, float* smem, const 
         sd += Mgrad[i] * Mgrad[i];
         dc += grad[i] * Mgrad[i];
       }
-      search_dot = gsum<G>(sd);
-      decrement = gsum<G>(dc);
+      search_dot = gsumg<G>(sd);
+      decrement = gsumg<G>(dc);
     } else {
       for (int i = lig; i < nv; i += G) Mgrad[i] = grad[i];
       gsync();
@@ -217,7 +253,7 @@ DEV void solve_big_body(const MjhModel& m, const MjhData& d, float* smem, const 
           pgrad[i] = grad[i];
           pMgrad[i] = Mgrad[i];
         }
-        search_dot = gsum<G>(sd);
+        search_dot = gsumg<G>(sd);
       }
     } else {
       const float imp = improvement * rscale, gradient = sqrtf(grad_dot) * rscale;
@@ -230,8 +266,8 @@ DEV void solve_big_body(const MjhModel& m, const MjhData& d, float* smem, const 
           num += grad[i] * (Mgrad[i] - pMgrad[i]);
           den += pgrad[i] * pMgrad[i];
         }
-        num = gsum<G>(num);
-        den = gsum<G>(den);
+        num = gsumg<G>(num);
+        den = gsumg<G>(den);
         const float beta = fmaxf(0.0f, num / fmaxf(MJ_MINVAL, den));
         done = (imp < tolerance) || (gradient < tolerance);
         if (!done) {
@@ -243,7 +279,7 @@ DEV void solve_big_body(const MjhModel& m, const MjhData& d, float* smem, const 
             pgrad[i] = grad[i];
             pMgrad[i] = Mgrad[i];
           }
-          search_dot = gsum<G>(sd);
+          search_dot = gsumg<G>(sd);
         }
       }
       if (done) break;
@@ -263,7 +299,7 @@ DEV void solve_big_body(const MjhModel& m, const MjhData& d, float* smem, const 
       g1 += search[i] * (Ma[i] - fs[i]);
       g2 += 0.5f * search[i] * mv[i];
     }
-    const float gauss1 = gsum<G>(g1), gauss2 = gsum<G>(g2);
+    const float gauss1 = gsumg<G>(g1), gauss2 = gsumg<G>(g2);
     gsync();
     // ---- line search (solver.py:835-1347) ------------------------------------------------------------------------
     const float gtol = fmaxf(tolerance * ls_tolerance * sqrtf(search_dot) * scale, 1e-6f);
@@ -275,7 +311,7 @@ DEV void solve_big_body(const MjhModel& m, const MjhData& d, float* smem, const 
         s.g += t.g;
         s.h += t.h;
       }
-      return P3{a * a * gauss2 + a * gauss1 + gsum<G>(s.c), 2.0f * a * gauss2 + gauss1 + gsum<G>(s.g), 2.0f * gauss2 + gsum<G>(s.h)};
+      return P3{a * a * gauss2 + a * gauss1 + gsumg<G>(s.c), 2.0f * a * gauss2 + gauss1 + gsumg<G>(s.g), 2.0f * gauss2 + gsumg<G>(s.h)};
     };
     P3 p0 = total(0.0f);
     p0.c = 0.0f;
