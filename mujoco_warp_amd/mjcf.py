@@ -18,6 +18,7 @@ placeholders when they carry no mass), motor/position/velocity/general actuators
 keyframes, <contact><exclude>, <option> + <flag>.  Unsupported features raise NotImplementedError.
 """
 
+import copy
 import os
 import xml.etree.ElementTree as ET
 
@@ -304,10 +305,190 @@ def _expand_includes(elem, base_dir):
     i += 1
 
 
+# ---- structural elements: <frame>, <replicate>, <attach> are expanded into plain bodies before compilation ------------------
+_ORIENT_KEYS = ("quat", "axisangle", "euler", "xyaxes", "zaxis")
+_POSED_TAGS = ("body", "geom", "site", "camera", "light")
+
+
+def _fmt(v):
+  return " ".join(repr(float(x)) for x in v)
+
+
+def _compiler_of(root):
+  comp = {"angle": "degree", "eulerseq": "xyz"}
+  for c in root.findall("compiler"):
+    for k in comp:
+      if k in c.attrib:
+        comp[k] = c.get(k)
+  return comp
+
+
+def _place(elem, fpos, fquat, comp):
+  """Re-express a posed child of a frame in the frame's parent: p' = fpos + R(fquat) p, q' = fquat * q."""
+  if elem.tag not in ("body", "geom", "site"):
+    return  # cameras and lights do not enter the dynamics
+  a = elem.attrib
+  if "fromto" in a:
+    ft = _floats(a["fromto"])
+    p0 = fpos + nm.rot_vec_quat(np.array(ft[:3]), fquat)
+    p1 = fpos + nm.rot_vec_quat(np.array(ft[3:]), fquat)
+    a["fromto"] = _fmt(np.concatenate([p0, p1]))
+    return
+  pos = _vec(a, "pos", [0, 0, 0])
+  quat = _orientation(a, comp)
+  for k in _ORIENT_KEYS:
+    a.pop(k, None)
+  a["pos"] = _fmt(fpos + nm.rot_vec_quat(pos, fquat))
+  a["quat"] = _fmt(nm.quat_normalize(nm.quat_mul(fquat, quat)))
+
+
+class _Structure:
+  """State of one expansion pass: the document root (attach appends actuators / excludes / defaults to it), the sub-models
+  named by <asset><model>, and the name suffix of the enclosing <replicate> copies."""
+
+  def __init__(self, root, base_dir):
+    self.root, self.base_dir, self.comp = root, base_dir, _compiler_of(root)
+    self.models, self.defaults_done = {}, set()
+    for asset in root.findall("asset"):
+      for mdl in asset.findall("model"):
+        path = os.path.join(base_dir, mdl.get("file"))
+        sub = ET.parse(path).getroot()
+        _expand_includes(sub, os.path.dirname(path))
+        _expand_structure(sub, os.path.dirname(path))
+        if _compiler_of(sub) != self.comp:
+          raise NotImplementedError("<attach> of a model with different <compiler> angle/eulerseq settings")
+        self.models[mdl.get("name", os.path.splitext(os.path.basename(path))[0])] = sub
+
+  def section(self, tag):
+    sec = self.root.find(tag)
+    if sec is None:
+      sec = ET.SubElement(self.root, tag)
+    return sec
+
+  def children(self, parent, suffix):
+    """Expanded child list of `parent` (a body, worldbody, frame or replicate)."""
+    out = []
+    for child in list(parent):
+      if child.tag == "frame":
+        fpos, fquat = _vec(child.attrib, "pos", [0, 0, 0]), _orientation(child.attrib, self.comp)
+        cc = child.get("childclass")
+        for c in self.children(child, suffix):
+          _place(c, fpos, fquat, self.comp)
+          if cc is not None:
+            key = "childclass" if c.tag == "body" else "class"
+            if c.tag in ("body", "geom", "site", "joint") and key not in c.attrib:
+              c.set(key, cc)
+          out.append(c)
+      elif child.tag == "replicate":
+        count = int(child.get("count"))
+        step_pos = _vec(child.attrib, "offset", [0, 0, 0])
+        step_quat = _orientation({"euler": child.get("euler")} if "euler" in child.attrib else {}, self.comp)
+        sep = child.get("sep", "")
+        pos, quat = np.zeros(3), np.array([1.0, 0, 0, 0])
+        for i in range(count):  # copy i carries the replicate transform applied i times
+          sfx = f"{sep}{i:0{len(str(count - 1))}d}"
+          holder = ET.Element("frame")
+          for c in child:
+            cp = copy.deepcopy(c)
+            for e in cp.iter():
+              if e.tag not in ("attach",) and e.get("name"):
+                e.set("name", e.get("name") + sfx)
+            holder.append(cp)
+          for c in self.children(holder, suffix + sfx):
+            _place(c, pos, quat, self.comp)
+            out.append(c)
+          pos = pos + nm.rot_vec_quat(step_pos, quat)
+          quat = nm.quat_normalize(nm.quat_mul(quat, step_quat))
+      elif child.tag == "attach":
+        out.append(self.attach(child, suffix))
+      else:
+        if child.tag == "body":
+          new = self.children(child, suffix)
+          for c in list(child):
+            child.remove(c)
+          child.extend(new)
+        out.append(child)
+    return out
+
+  def attach(self, elem, suffix):
+    """<attach model= body= prefix=>: the named subtree of a sub-model with prefixed names, plus the sub-model's defaults
+    (as classes of the parent document) and the actuators / contact excludes / joint equalities that refer to the subtree."""
+    name, prefix = elem.get("model"), elem.get("prefix", "")
+    if name not in self.models:
+      raise ValueError(f"<attach>: unknown model '{name}'")
+    sub = self.models[name]
+    src = next((b for b in sub.iter("body") if b.get("name") == elem.get("body")), None)
+    if src is None:
+      raise ValueError(f"<attach>: model '{name}' has no body '{elem.get('body')}'")
+    main = prefix + "main"
+    if (name, prefix) not in self.defaults_done:  # the sub-model's default tree becomes the class `prefix + main`
+      self.defaults_done.add((name, prefix))
+      holder = ET.SubElement(self.section("default"), "default", {"class": main})
+      for dsec in sub.findall("default"):
+        for c in dsec:
+          holder.append(self._prefixed(c, prefix, ""))
+    body = self._prefixed(src, prefix, suffix)
+    if "childclass" not in body.attrib:
+      body.set("childclass", main)
+    names = {tag: {e.get("name") for e in src.iter(tag) if e.get("name")} for tag in ("body", "joint")}
+    names["body"].add(src.get("name"))
+    for sec in sub.findall("actuator"):
+      for a in sec:
+        if a.get("joint") in names["joint"]:
+          c = self._prefixed(a, prefix, suffix)
+          c.set("joint", prefix + a.get("joint") + suffix)
+          if "class" not in c.attrib:
+            c.set("class", main)
+          self.section("actuator").append(c)
+        elif any(k in a.attrib for k in ("tendon", "site", "body", "slidersite")):
+          raise NotImplementedError("<attach>: actuators with non-joint transmissions")
+    for sec in sub.findall("contact"):
+      for ex in sec.findall("exclude"):
+        if ex.get("body1") in names["body"] and ex.get("body2") in names["body"]:
+          c = self._prefixed(ex, prefix, suffix)
+          c.set("body1", prefix + ex.get("body1") + suffix)
+          c.set("body2", prefix + ex.get("body2") + suffix)
+          self.section("contact").append(c)
+    for sec in sub.findall("equality"):
+      for eq in sec:
+        if eq.tag == "joint" and eq.get("joint1") in names["joint"]:
+          c = self._prefixed(eq, prefix, suffix)
+          for k in ("joint1", "joint2"):
+            if k in c.attrib:
+              c.set(k, prefix + eq.get(k) + suffix)
+          if "class" not in c.attrib:
+            c.set("class", main)
+          self.section("equality").append(c)
+    return body
+
+  @staticmethod
+  def _prefixed(elem, prefix, suffix):
+    cp = copy.deepcopy(elem)
+    for e in cp.iter():
+      if e.get("name"):
+        e.set("name", prefix + e.get("name") + suffix)
+      for k in ("class", "childclass"):
+        if k in e.attrib:
+          e.set(k, prefix + e.get(k))
+    return cp
+
+
+def _expand_structure(root, base_dir):
+  if not any(True for tag in ("frame", "replicate", "attach") for _ in root.iter(tag)):
+    return
+  st = _Structure(root, base_dir)
+  for wb in root.findall("worldbody"):
+    new = st.children(wb, "")
+    for c in list(wb):
+      wb.remove(c)
+    wb.extend(new)
+
+
 def load_xml(path):
   root = ET.parse(path).getroot()
   base = os.path.dirname(os.path.abspath(path))
   _expand_includes(root, base)
+  _expand_structure(root, base)
   return _compile(root, base)
 
 
@@ -315,6 +496,7 @@ def from_xml_string(xml, assets_dir=None):
   root = ET.fromstring(xml)
   base = assets_dir or os.getcwd()
   _expand_includes(root, base)
+  _expand_structure(root, base)
   return _compile(root, base)
 
 

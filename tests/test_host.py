@@ -86,8 +86,7 @@ def test_unsupported_features_raise():
   with pytest.raises(NotImplementedError):
     mjw.put_model(m)
   # structural elements the subset compiler does not expand are never skipped silently (they would change the model)
-  for body in ('<replicate count="2"><body><joint/><geom size=".1"/></body></replicate>', '<frame><geom size=".1"/></frame>',
-               '<body><joint/><geom size=".1"/><attach model="x" body="y" prefix="z"/></body>'):
+  for body in ('<composite type="grid"/>', '<body><joint/><geom size=".1"/><flexcomp name="f"/></body>'):
     with pytest.raises(NotImplementedError):
       mjw.mjcf.from_xml_string(f"<mujoco><worldbody>{body}</worldbody></mujoco>")
   with pytest.raises(NotImplementedError):
@@ -249,3 +248,52 @@ def test_load_trajectory_zero_order_hold(humanoid, tmp_path):
     np.savez(p, **bad)
     with pytest.raises(ValueError):
       mjw.load_trajectory(p, humanoid, mjd)
+
+
+
+def test_frame_and_replicate_expansion():
+  """<frame> re-expresses its children in the parent; <replicate> applies its transform i times and suffixes the names."""
+  m = mjw.mjcf.from_xml_string("""
+<mujoco><worldbody>
+  <frame pos="1 0 0" euler="0 0 90">
+    <geom name="g" type="capsule" fromto="0 0 0 1 0 0" size=".05"/>
+    <body name="a" pos="1 0 0"><joint name="ja" type="hinge" axis="1 0 0"/><geom size=".1"/></body>
+  </frame>
+  <replicate count="3" offset="0 0 .5" euler="0 0 90" sep="-">
+    <body name="r" pos="1 0 0"><freejoint/><geom size=".1"/></body>
+  </replicate>
+</worldbody></mujoco>""")
+  names = list(m.body_names)
+  assert names == ["world", "a", "r-0", "r-1", "r-2"]
+  np.testing.assert_allclose(m.body_pos[1], [1, 1, 0], atol=1e-12)  # (1,0,0) rotated 90 deg about z, then shifted
+  np.testing.assert_allclose(nm_rot(m.body_quat[1], [1, 0, 0]), [0, 1, 0], atol=1e-12)
+  # copy i: transform applied i times -> rotation i * 90 deg about z and height i * 0.5
+  np.testing.assert_allclose(m.body_pos[2:5], [[1, 0, 0], [0, 1, 0.5], [-1, 0, 1.0]], atol=1e-12)
+  g = list(m.geom_names).index("g")
+  np.testing.assert_allclose(m.geom_pos[g], [1, 0.5, 0], atol=1e-12)  # midpoint of the rotated, shifted segment
+  assert m.nv == 1 + 3 * 6
+
+
+def nm_rot(q, v):
+  from mujoco_warp_amd import _npmath as nm
+
+  return nm.rot_vec_quat(np.asarray(v, dtype=np.float64), np.asarray(q))
+
+
+def test_attach_three_humanoids_matches_manual_clone():
+  """benchmarks/humanoid/three_humanoids.xml (<asset><model>, <replicate>, <frame>, <attach>) against the same model built by
+  cloning the torso subtree by hand (conftest.multi_humanoid_xml): identical trees, masses, defaults and actuators."""
+  import os
+
+  a = mjw.mjcf.load_xml(os.path.join(os.path.dirname(conftest.HUMANOID_XML), "three_humanoids.xml"))
+  b = mjw.mjcf.from_xml_string(conftest.multi_humanoid_xml(3), assets_dir=os.path.dirname(conftest.HUMANOID_XML))
+  assert (a.nv, a.nbody, a.nu, a.ngeom, a.njnt) == (b.nv, b.nbody, b.nu, b.ngeom, b.njnt) == (81, 49, 63, 58, 66)
+  torsos = [i for i, n in enumerate(a.body_names) if n.startswith("_torso")]
+  assert [a.body_names[i] for i in torsos] == ["_torso-0", "_torso-1", "_torso-2"]
+  ang = np.deg2rad(16.36) * np.arange(3)
+  np.testing.assert_allclose(a.body_pos[torsos], np.stack([4 * np.sin(ang), -4 * np.cos(ang), np.full(3, 1.282)], axis=1), atol=1e-9)
+  for f in ("body_mass", "body_inertia", "dof_armature", "dof_damping", "jnt_range", "jnt_stiffness", "actuator_gear", "actuator_ctrlrange",
+            "geom_friction", "geom_condim", "body_parentid", "M_rownnz", "jnt_type", "actuator_trnid"):
+    np.testing.assert_allclose(getattr(a, f), getattr(b, f), atol=1e-12, err_msg=f)
+  np.testing.assert_allclose(a.geom_size[1:], b.geom_size[1:], atol=1e-12)  # (the floors differ)
+  assert a.stat.meaninertia == pytest.approx(b.stat.meaninertia, rel=1e-12)
