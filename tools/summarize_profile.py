@@ -24,6 +24,14 @@ def _tables(cur):
 
 def _short(n):
   n = n.replace(".kd", "")
+  if "k_solve_pgs" in n:
+    return "k_solve_pgs" + ("<reg>" if "Lb1" in n else "<lds>")
+  if "k_solve_big" in n:
+    return "k_solve_big"
+  if "k_rk4" in n:
+    return "k_rk4"
+  if "k_mid" in n:
+    return "k_mid"
   for key in ("k_fwd_pos", "k_fwd_vel", "k_collision", "k_make_constraint", "k_solve_m", "k_solve", "k_integrate", "k_ctrl_noise", "k_contact_scan", "k_publish_contacts", "k_factor_smooth", "k_schedule_worlds"):
     if key in n:
       if key == "k_solve" and "ILi" in n:
