@@ -55,6 +55,7 @@ typedef struct MjhModel {
   /* sizes */
   int nq; int nv; int nu; int na; int nbody; int njnt; int ngeom; int nsite; int nC; int npair;
   int nbodylevel; int ndoflevel; int nv_pad; int neq;
+  int heavy_colliders; /* 1: the pair list holds capsule-box pairs (selects the kernel instantiation that carries them) */
   /* options (types.py:836-905); solver: 0 = PGS (extension, the reference has none: types.py:502), 1 = CG, 2 = Newton */
   int integrator; int cone; int solver; int iterations; int ls_iterations; int disableflags; int enableflags;
   const float* opt_timestep; int opt_timestep_nb;
@@ -212,7 +213,7 @@ int mjh_timed_steps(const MjhModel* m, const MjhData* d, int nstep, int step0, f
                     void* stream, float* ms_out, float* per_kernel_ms, int plain_kernels);
 
 const char* mjh_last_error(void);
-#define MJH_ABI_VERSION 3
+#define MJH_ABI_VERSION 4
 int mjh_abi_version(void); /* returns MJH_ABI_VERSION of the library that was loaded */
 
 #ifdef __cplusplus

@@ -42,8 +42,163 @@ DEV V3 closest_segment_point(V3 a, V3 b, V3 pt) {  // math.py:270
   return a + ab * clampf(t, 0.0f, 1.0f);
 }
 
+// sphere_box core:1044 -- contact of a sphere (centre sp, radius r) with a box; results in world coordinates
+DEV void sphere_box(V3 sp, float r, V3 bp, const float* R, V3 bs, float& dist, V3& wpos, V3& nn) {
+  V3 center = matT_mul(R, sp - bp);
+  V3 clamped = V3{fmaxf(-bs.x, fminf(bs.x, center.x)), fmaxf(-bs.y, fminf(bs.y, center.y)), fmaxf(-bs.z, fminf(bs.z, center.z))};
+  V3 pos;
+  V3 cdir = normalize_with_norm(clamped - center, dist);
+  if (dist <= MJ_MINVAL) {  // centre inside the box: push out through the nearest face
+    const float sz[3] = {bs.x, bs.y, bs.z}, ce[3] = {center.x, center.y, center.z};
+    float closest = 2.0f * (bs.x + bs.y + bs.z);
+    int kk = 0;
+    for (int i = 0; i < 6; ++i) {
+      float fd = fabsf(((i % 2) ? 1.0f : -1.0f) * sz[i / 2] - ce[i / 2]);
+      if (closest > fd) {
+        closest = fd;
+        kk = i;
+      }
+    }
+    const float sg = (kk % 2) ? -1.0f : 1.0f;
+    V3 nearest = V3{kk / 2 == 0 ? sg : 0.0f, kk / 2 == 1 ? sg : 0.0f, kk / 2 == 2 ? sg : 0.0f};
+    pos = center + nearest * ((r - closest) * 0.5f);
+    nn = mat_mul(R, nearest);
+    dist = -closest - r;
+  } else {
+    pos = (clamped + center + cdir * r) * 0.5f;
+    nn = mat_mul(R, cdir);
+    dist = dist - r;
+  }
+  wpos = mat_mul(R, pos) + bp;
+}
+
+DEV float pick3(V3 v, int k) { return k == 0 ? v.x : (k == 1 ? v.y : v.z); }
+
+// capsule_box core:1099 (MuJoCo's mjc_CapsuleBox).  Returns the segment parameters (point = pos + t * halfaxis, in [-1, 1])
+// of the contact spheres: t1 always (unless the configuration is degenerate: returns 0), t2 when the capsule lies along a
+// face or an edge of the box.  Same decision tree as oracle/mjref.c:capsule_box.
+DEV int capsule_box_params(V3 pos, V3 axis, float hl, V3 bs, float& t1, float& t2) {
+  const V3 ha = axis * hl;
+  const float p[3] = {pos.x, pos.y, pos.z}, h[3] = {ha.x, ha.y, ha.z}, s[3] = {bs.x, bs.y, bs.z};
+  const int axisdir = (ha.x > 0.0f ? 1 : 0) + (ha.y > 0.0f ? 2 : 0) + (ha.z > 0.0f ? 4 : 0);
+  float bestdist = 1e32f, bestseg = -12.0f, bestbox = 0.0f, second = -4.0f;
+  int cltype = -4, clface = -12, clcorner = -123, cledge = -123;
+  // (1) a capsule end over a face (or inside): clamped in at most one coordinate
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const float sgn = e == 0 ? -1.0f : 1.0f;
+    float d2 = 0.0f;
+    int nout = 0, axout = -1;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float tip = p[k] + sgn * h[k];
+      float c = tip;
+      if (c < -s[k]) { ++nout; axout = k; c = -s[k]; }
+      else if (c > s[k]) { ++nout; axout = k; c = s[k]; }
+      d2 += (c - tip) * (c - tip);
+    }
+    if (nout <= 1 && d2 < bestdist) {
+      bestdist = d2;
+      bestseg = sgn;
+      cltype = e == 0 ? -3 : -1;
+      clface = axout;
+    }
+  }
+  // (2) the segment against each of the 12 box edges (corner i, edge direction j with bit j of i clear)
+  for (int i = 0; i < 8; ++i) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      if (i & (1 << j)) continue;
+      float dif[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) dif[k] = (k == j ? 0.0f : (((i >> k) & 1) ? s[k] : -s[k])) - p[k];
+      const float u = -s[j] * dif[j], v = h[0] * dif[0] + h[1] * dif[1] + h[2] * dif[2];
+      const float ma = s[j] * s[j], mb = -s[j] * h[j], mc = hl * hl;
+      const float det = ma * mc - mb * mb;
+      if (fabsf(det) < MJ_MINVAL) continue;
+      float x1 = (mc * u - mb * v) / det, x2 = (ma * v - mb * u) / det;  // x1 along the edge, x2 along the capsule
+      int s1 = 1, s2 = 1;                                                // 1: interior, 0 / 2: lower / upper end
+      if (x1 > 1.0f) { x1 = 1.0f; s1 = 2; x2 = safe_div(v - mb, mc); }
+      else if (x1 < -1.0f) { x1 = -1.0f; s1 = 0; x2 = safe_div(v + mb, mc); }
+      if (x2 > 1.0f || x2 < -1.0f) {
+        if (x2 > 1.0f) { x2 = 1.0f; s2 = 2; x1 = safe_div(u - mb, ma); }
+        else { x2 = -1.0f; s2 = 0; x1 = safe_div(u + mb, ma); }
+        if (x1 > 1.0f) { x1 = 1.0f; s1 = 2; }
+        else if (x1 < -1.0f) { x1 = -1.0f; s1 = 0; }
+      }
+      float d2 = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float dk = dif[k] - h[k] * x2 + (k == j ? s[j] * x1 : 0.0f);
+        d2 += dk * dk;
+      }
+      if (d2 < bestdist - MJ_MINVAL) {
+        const int ct = s1 * 3 + s2;
+        bestdist = d2;
+        bestseg = x2;
+        bestbox = x1;
+        clcorner = i + (1 << j) * (ct / 6);  // the box corner nearest to the closest point
+        cledge = j;
+        cltype = ct;
+      }
+    }
+  }
+  if (cltype == -4) return 0;
+  // (3) a second contact further along the capsule
+  if (cltype >= 0 && cltype / 3 != 1) {  // closest box point is a corner
+    int c1 = axisdir ^ clcorner;
+    if (c1 != 0 && c1 != 7) {  // the capsule does not point straight at / away from the corner
+      float mul = 1.0f;
+      if (!(c1 == 1 || c1 == 2 || c1 == 4)) {
+        mul = -1.0f;
+        c1 = 7 - c1;
+      }
+      const int ax = c1 == 1 ? 0 : (c1 == 2 ? 1 : 2), ax1 = (ax + 1) % 3, ax2 = (ax + 2) % 3;
+      const float aa = pick3(axis, ax);
+      if (aa * aa > 0.5f) {  // along the edge
+        second = fminf(1.0f - mul * bestseg, 2.0f * safe_div(pick3(bs, ax), fabsf(pick3(ha, ax))));
+      } else {  // across a face
+        const float mlim = 2.0f * fminf(safe_div(pick3(bs, ax1), fabsf(pick3(ha, ax1))), safe_div(pick3(bs, ax2), fabsf(pick3(ha, ax2))));
+        second = -fminf(1.0f + mul * bestseg, mlim);
+      }
+      second *= mul;
+    }
+  } else if (cltype >= 0) {  // closest box point is inside an edge
+    const int c1 = (axisdir ^ clcorner) & (7 - (1 << cledge));
+    if (c1 == 1 || c1 == 2 || c1 == 4) {  // X configuration (a T configuration has no second contact)
+      const int ax = cledge;
+      int ax1 = (ax + 1) % 3, ax2 = (ax + 2) % 3;
+      if (fabsf(pick3(axis, ax1)) > fabsf(pick3(axis, ax2))) ax1 = ax2;  // the face the capsule makes the smaller angle with
+      ax2 = 3 - ax - ax1;
+      float mul;
+      if (c1 & (1 << ax2)) { mul = 1.0f; second = 1.0f - bestseg; }
+      else { mul = -1.0f; second = 1.0f + bestseg; }
+      second = fminf(2.0f * safe_div(pick3(bs, ax2), fabsf(pick3(ha, ax2))), second);
+      const float e2 = (((axisdir & (1 << ax)) != 0) == ((c1 & (1 << ax2)) != 0)) ? 1.0f - bestbox : 1.0f + bestbox;
+      second = fminf(pick3(bs, ax) * safe_div(e2, fabsf(pick3(ha, ax))), second);
+      second *= mul;
+    }
+  } else if (clface != -1) {  // an end is closest to a face: follow the capsule until it leaves the box footprint
+    const float mul = cltype == -3 ? 1.0f : -1.0f;
+    second = 2.0f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      if (k == clface) continue;
+      const float tmp = p[k] - h[k] * mul, har = safe_div(mul, h[k]);
+      float e1 = (s[k] - tmp) * har;
+      if (0.0f < e1 && e1 < second) second = e1;
+      e1 = (-s[k] - tmp) * har;
+      if (0.0f < e1 && e1 < second) second = e1;
+    }
+    second *= mul;
+  }
+  t1 = bestseg;
+  t2 = second + bestseg;
+  return second > -3.0f ? 2 : 1;
+}
+
 // runs the collider for geoms (g1,g2) with type1 <= type2
-template <class Emit>
+template <bool HEAVY, class Emit>
 DEV void collide_pair(int t1, int t2, V3 p1, const float* R1, V3 s1, V3 p2, const float* R2, V3 s2, float margin, Emit&& emit) {
   V3 ax1 = V3{R1[2], R1[5], R1[8]}, ax2 = V3{R2[2], R2[5], R2[8]};
   float dist;
@@ -164,32 +319,18 @@ DEV void collide_pair(int t1, int t2, V3 p1, const float* R1, V3 s1, V3 p2, cons
       }
     }
   } else if (t1 == G_SPHERE && t2 == G_BOX) {  // core:1044
-    V3 center = matT_mul(R2, p1 - p2);
-    V3 clamped = V3{fmaxf(-s2.x, fminf(s2.x, center.x)), fmaxf(-s2.y, fminf(s2.y, center.y)), fmaxf(-s2.z, fminf(s2.z, center.z))};
-    V3 cdir = normalize_with_norm(clamped - center, dist);
-    if (dist <= MJ_MINVAL) {
-      const float sz[3] = {s2.x, s2.y, s2.z}, ce[3] = {center.x, center.y, center.z};
-      float closest = 2.0f * (s2.x + s2.y + s2.z);
-      int kk = 0;
-      for (int i = 0; i < 6; ++i) {
-        float fd = fabsf(((i % 2) ? 1.0f : -1.0f) * sz[i / 2] - ce[i / 2]);
-        if (closest > fd) {
-          closest = fd;
-          kk = i;
-        }
-      }
-      const float sg = (kk % 2) ? -1.0f : 1.0f;
-      V3 nearest = V3{kk / 2 == 0 ? sg : 0.0f, kk / 2 == 1 ? sg : 0.0f, kk / 2 == 2 ? sg : 0.0f};
-      pos = center + nearest * ((s1.x - closest) * 0.5f);
-      nn = mat_mul(R2, nearest);
-      dist = -closest - s1.x;
-    } else {
-      pos = (clamped + center + cdir * s1.x) * 0.5f;
-      nn = mat_mul(R2, cdir);
-      dist = dist - s1.x;
-    }
+    sphere_box(p1, s1.x, p2, R2, s2, dist, pos, nn);
     const Frame f = make_frame3(nn);
-    emit(0, dist, mat_mul(R2, pos) + p2, f.a, f.b, f.c);
+    emit(0, dist, pos, f.a, f.b, f.c);
+  } else if (HEAVY && t1 == G_CAPSULE && t2 == G_BOX) {  // core:1099
+    const V3 lp = matT_mul(R2, p1 - p2), la = matT_mul(R2, ax1);
+    float tt[2];
+    const int n = capsule_box_params(lp, la, s1.y, s2, tt[0], tt[1]);
+    for (int c = 0; c < n; ++c) {
+      sphere_box(mat_mul(R2, lp + la * (s1.y * tt[c])) + p2, s1.x, p2, R2, s2, dist, pos, nn);
+      const Frame f = make_frame3(nn);
+      emit(c, dist, pos, f.a, f.b, f.c);
+    }
   } else if (t1 == G_SPHERE && t2 == G_CYLINDER) {  // core:388
     const float r = s2.x, hh = s2.y;
     const V3 vec = p1 - p2;
@@ -289,7 +430,9 @@ __host__ __device__ inline int collide_lds_words(int ngeom, int npair) {
   return 12 * ngeom + ((npair + 3) / 4) * 4 + ((npair + 3) / 4) * 4 + CON_WINDOW * CON_LDS;
 }
 
-template <int G>
+// HEAVY: the instantiation that also carries the large colliders (capsule-box); models without such pairs run the light one,
+// whose register footprint (and with it the occupancy of k_mid) is unchanged
+template <int G, bool HEAVY = false>
 DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const Blk& b, int stride_words = 0) {
   const int lig = threadIdx.x & (G - 1), gib = threadIdx.x / G;
   const int w = b.w0 + gib;
@@ -373,7 +516,7 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
       load_pair(cand[ci], g1, g2, t1, t2);
       const float margin = gmargin[g1] + gmargin[g2];
       const float lim = margin + ggap[g1] + ggap[g2];
-      collide_pair(t1, t2, ld3(gxpos + 3 * g1), gxmat + 9 * g1, ld3(gsize + 3 * g1), ld3(gxpos + 3 * g2), gxmat + 9 * g2,
+      collide_pair<HEAVY>(t1, t2, ld3(gxpos + 3 * g1), gxmat + 9 * g1, ld3(gsize + 3 * g1), ld3(gxpos + 3 * g2), gxmat + 9 * g2,
                    ld3(gsize + 3 * g2), margin, [&](int k, float dist, V3, V3, V3, V3) { mask |= dist < lim ? (1u << (k & 7)) : 0u; });
     }
     const int nk = __popc(mask);
@@ -413,7 +556,7 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
       load_pair(cand[ci], g1, g2, t1, t2);
       const float margin = gmargin[g1] + gmargin[g2];
       const PairParams pp = contact_params(m, w, g1, g2);
-      collide_pair(t1, t2, ld3(gxpos + 3 * g1), gxmat + 9 * g1, ld3(gsize + 3 * g1), ld3(gxpos + 3 * g2), gxmat + 9 * g2,
+      collide_pair<HEAVY>(t1, t2, ld3(gxpos + 3 * g1), gxmat + 9 * g1, ld3(gsize + 3 * g1), ld3(gxpos + 3 * g2), gxmat + 9 * g2,
                    ld3(gsize + 3 * g2), margin, [&](int cid, float dist, V3 pos, V3 fa, V3 fb, V3 fc) {
                      if (!((mask >> (cid & 7)) & 1u)) return;
                      if (slot >= wbase && slot < wend) {
@@ -456,10 +599,10 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
   }
 }
 
-template <int G>
+template <int G, bool HEAVY>
 __global__ void __launch_bounds__(256) k_collision(MjhModel m, MjhData d) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  collision_body<G>(m, d, smem, blk_of_launch<G>());
+  collision_body<G, HEAVY>(m, d, smem, blk_of_launch<G>());
 }
 
 // ---- publication of the compact public contact arrays (off the critical path) ---------------------------------

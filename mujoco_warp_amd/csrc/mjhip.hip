@@ -84,9 +84,15 @@ static int launch_collision(const MjhModel* m, const MjhData* d, hipStream_t s) 
   size_t lds;
   const int threads = pick_block(0, sizeof(float) * collide_lds_words(m->ngeom, m->npair), G, &lds);
   if (!threads) return fail(MJH_E_UNSUPPORTED, "k_collision: pair list does not fit in LDS");
-  HIPCHK(set_lds(k_collision<G>, lds));
+  if (m->heavy_colliders) {
+    HIPCHK(set_lds((k_collision<G, true>), lds));
+    const int wpb_h = threads / G;
+    hipLaunchKernelGGL((k_collision<G, true>), dim3((d->nworld + wpb_h - 1) / wpb_h), dim3(threads), lds, s, *m, *d);
+    return MJH_OK;
+  }
+  HIPCHK(set_lds((k_collision<G, false>), lds));
   const int wpb = threads / G;
-  hipLaunchKernelGGL(k_collision<G>, dim3((d->nworld + wpb - 1) / wpb), dim3(threads), lds, s, *m, *d);
+  hipLaunchKernelGGL((k_collision<G, false>), dim3((d->nworld + wpb - 1) / wpb), dim3(threads), lds, s, *m, *d);
   return MJH_OK;
 }
 // compact public contact arrays, contact.efc_address and efc.id of contact rows from the per-world records
@@ -126,7 +132,7 @@ static int launch_integrate(const MjhModel* m, const MjhData* d, int mode, hipSt
 //                     they fill the CUs that the solver's stragglers leave idle
 //   k_fwd_pos_plus  : k_fwd_pos + one workgroup computing the solver schedule from the previous step's solver_niter
 //   k_integrate_plus: integrator workgroups, then publish_contacts workgroups
-template <int G>
+template <int G, bool HEAVY>
 __global__ void __launch_bounds__(256) k_mid(MjhModel m, MjhData d, int ncc, int nvb, int nw_cc, int nw_v, int stride_cc, int sched) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   (void)nvb;
@@ -141,7 +147,7 @@ __global__ void __launch_bounds__(256) k_mid(MjhModel m, MjhData d, int ncc, int
   const bool is_cc = bi < ncc;
   if (is_cc) {
     const Blk b{cc_before * nw_cc, nw_cc, nw_cc * G};
-    collision_body<G>(m, d, smem, b, stride_cc);
+    collision_body<G, HEAVY>(m, d, smem, b, stride_cc);
     __threadfence_block();  // the world's contact records (global) are read back by the same lanes
     make_constraint_body<G>(m, d, smem, b, stride_cc);
   } else {
@@ -196,10 +202,12 @@ static int launch_mid(const MjhModel* m, const MjhData* d, bool sched, hipStream
   }
   lds = std::max(lds, ms_bytes + sizeof(float) * vl.total * nw_v);
   if (lds > (size_t)kLdsPerCU) return fail(MJH_E_UNSUPPORTED, "k_mid: model does not fit in LDS");
-  HIPCHK(set_lds(k_mid<G>, lds));
+  if (m->heavy_colliders) HIPCHK(set_lds((k_mid<G, true>), lds));
+  else HIPCHK(set_lds((k_mid<G, false>), lds));
   const int ncc = (d->nworld + nw_cc - 1) / nw_cc, nvb = (d->nworld + nw_v - 1) / nw_v;
-  hipLaunchKernelGGL(k_mid<G>, dim3(ncc + nvb + (sched ? 1 : 0)), dim3(G * std::max(nw_cc, nw_v)), lds, s, *m, *d, ncc, nvb, nw_cc, nw_v,
-                     stride_cc, sched ? 1 : 0);
+  const dim3 grid(ncc + nvb + (sched ? 1 : 0)), block(G * std::max(nw_cc, nw_v));
+  if (m->heavy_colliders) hipLaunchKernelGGL((k_mid<G, true>), grid, block, lds, s, *m, *d, ncc, nvb, nw_cc, nw_v, stride_cc, sched ? 1 : 0);
+  else hipLaunchKernelGGL((k_mid<G, false>), grid, block, lds, s, *m, *d, ncc, nvb, nw_cc, nw_v, stride_cc, sched ? 1 : 0);
   return MJH_OK;
 }
 // set by the fused STEP path when the solver launch also integrates (see euler_fusable)

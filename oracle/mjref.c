@@ -578,6 +578,155 @@ static void closest_segment_point(double* r, const double* a, const double* b, c
   v3addscl(r, a, ab, clampd(t, 0.0, 1.0));
 }
 
+/* sphere_box collision_primitive_core.py:1044: contact of a sphere (centre sp, radius r) with a box (pos, R, half sizes) */
+static void sphere_box(const double* sp, double r, const double* bp, const double* R, const double* bs, Con* out) {
+  double dif[3], center[3], clamped[3], cdir[3], pos[3], nn[3];
+  v3sub(dif, sp, bp);
+  matT_mul_vec(center, R, dif);
+  for (int k = 0; k < 3; k++) clamped[k] = fmax(-bs[k], fmin(bs[k], center[k]));
+  v3sub(cdir, clamped, center);
+  double dist = v3normalize(cdir);
+  if (dist <= MINVAL) { /* centre inside the box: push out through the nearest face */
+    double closest = 2.0 * (bs[0] + bs[1] + bs[2]);
+    int kk = 0;
+    for (int i = 0; i < 6; i++) {
+      double fd = fabs(((i % 2) ? 1.0 : -1.0) * bs[i / 2] - center[i / 2]);
+      if (closest > fd) { closest = fd; kk = i; }
+    }
+    double nearest[3] = {0, 0, 0};
+    nearest[kk / 2] = (kk % 2) ? -1.0 : 1.0;
+    for (int k = 0; k < 3; k++) pos[k] = center[k] + nearest[k] * (r - closest) / 2.0;
+    mat_mul_vec(nn, R, nearest);
+    out->dist = -closest - r;
+  } else {
+    for (int k = 0; k < 3; k++) pos[k] = 0.5 * (clamped[k] + center[k] + cdir[k] * r);
+    mat_mul_vec(nn, R, cdir);
+    out->dist = dist - r;
+  }
+  mat_mul_vec(out->pos, R, pos);
+  v3add(out->pos, out->pos, bp);
+  make_frame(out->frame, nn);
+}
+
+/* capsule_box collision_primitive_core.py:1099 (MuJoCo's mjc_CapsuleBox): the point of the capsule segment closest to the box
+ * gives the first contact sphere; when the capsule lies along a face or an edge a second sphere is placed further along the
+ * segment (as far as the capsule still is above the box).  Segment parameter t in [-1, 1]: point = pos + t * halfaxis. */
+static int capsule_box(const double* cpos, const double* caxis, double r, double hl, const double* bpos, const double* R,
+                       const double* bs, Con* out) {
+  double dif0[3], pos[3], axis[3], ha[3];
+  v3sub(dif0, cpos, bpos);
+  matT_mul_vec(pos, R, dif0);
+  matT_mul_vec(axis, R, caxis);
+  for (int k = 0; k < 3; k++) ha[k] = axis[k] * hl;
+  int axisdir = (ha[0] > 0.0) + 2 * (ha[1] > 0.0) + 4 * (ha[2] > 0.0);
+  double bestdist = 1e32, bestseg = -12.0, bestbox = 0.0, second = -4.0;
+  int cltype = -4, clface = -12, clcorner = -123, cledge = -123;
+  /* (1) a capsule end over a face (or inside): clamped in at most one coordinate */
+  for (int sgn = -1; sgn <= 1; sgn += 2) {
+    double tip[3], d2 = 0.0;
+    int nout = 0, axout = -1;
+    for (int k = 0; k < 3; k++) {
+      tip[k] = pos[k] + sgn * ha[k];
+      double c = tip[k];
+      if (c < -bs[k]) { nout++; axout = k; c = -bs[k]; }
+      else if (c > bs[k]) { nout++; axout = k; c = bs[k]; }
+      d2 += (c - tip[k]) * (c - tip[k]);
+    }
+    if (nout > 1) continue;
+    if (d2 < bestdist) { bestdist = d2; bestseg = sgn; cltype = -2 + sgn; clface = axout; }
+  }
+  /* (2) the segment against each of the 12 box edges (corner i, edge direction j with bit j of i clear) */
+  for (int i = 0; i < 8; i++) {
+    for (int j = 0; j < 3; j++) {
+      if (i & (1 << j)) continue;
+      double bp[3], dif[3];
+      for (int k = 0; k < 3; k++) bp[k] = ((i >> k) & 1 ? 1.0 : -1.0) * bs[k];
+      bp[j] = 0.0;
+      v3sub(dif, bp, pos);
+      double u = -bs[j] * dif[j], v = v3dot(ha, dif);
+      double ma = bs[j] * bs[j], mb = -bs[j] * ha[j], mc = hl * hl;
+      double det = ma * mc - mb * mb;
+      if (fabs(det) < MINVAL) continue;
+      double x1 = (mc * u - mb * v) / det, x2 = (ma * v - mb * u) / det; /* x1 along the edge, x2 along the capsule */
+      int s1 = 1, s2 = 1;                                                /* 1: interior, 0 / 2: lower / upper end */
+      if (x1 > 1.0) { x1 = 1.0; s1 = 2; x2 = safe_div(v - mb, mc); }
+      else if (x1 < -1.0) { x1 = -1.0; s1 = 0; x2 = safe_div(v + mb, mc); }
+      if (x2 > 1.0 || x2 < -1.0) {
+        if (x2 > 1.0) { x2 = 1.0; s2 = 2; x1 = safe_div(u - mb, ma); }
+        else { x2 = -1.0; s2 = 0; x1 = safe_div(u + mb, ma); }
+        if (x1 > 1.0) { x1 = 1.0; s1 = 2; }
+        else if (x1 < -1.0) { x1 = -1.0; s1 = 0; }
+      }
+      for (int k = 0; k < 3; k++) dif[k] -= ha[k] * x2;
+      dif[j] += bs[j] * x1;
+      double d2 = v3dot(dif, dif);
+      if (d2 < bestdist - MINVAL) {
+        int ct = s1 * 3 + s2;
+        bestdist = d2; bestseg = x2; bestbox = x1;
+        clcorner = i + (1 << j) * (ct / 6); /* the box corner nearest to the closest point */
+        cledge = j;
+        cltype = ct;
+      }
+    }
+  }
+  if (cltype == -4) return 0;
+  /* (3) a second contact further along the capsule */
+  if (cltype >= 0 && cltype / 3 != 1) { /* closest box point is a corner */
+    int c1 = axisdir ^ clcorner;
+    if (c1 != 0 && c1 != 7) { /* the capsule does not point straight at / away from the corner */
+      int mul = 1;
+      if (!(c1 == 1 || c1 == 2 || c1 == 4)) { mul = -1; c1 = 7 - c1; }
+      int ax = c1 == 1 ? 0 : (c1 == 2 ? 1 : 2), ax1 = (ax + 1) % 3, ax2 = (ax + 2) % 3;
+      if (axis[ax] * axis[ax] > 0.5) { /* along the edge */
+        double mlim = 2.0 * safe_div(bs[ax], fabs(ha[ax]));
+        second = fmin(1.0 - mul * bestseg, mlim);
+      } else { /* across a face */
+        double mlim = 2.0 * fmin(safe_div(bs[ax1], fabs(ha[ax1])), safe_div(bs[ax2], fabs(ha[ax2])));
+        second = -fmin(1.0 + mul * bestseg, mlim);
+      }
+      second *= mul;
+    }
+  } else if (cltype >= 0) { /* closest box point is inside an edge */
+    int c1 = (axisdir ^ clcorner) & (7 - (1 << cledge));
+    if (c1 == 1 || c1 == 2 || c1 == 4) { /* X configuration (a T configuration has no second contact) */
+      int ax = cledge, ax1 = (ax + 1) % 3, ax2 = (ax + 2) % 3;
+      if (fabs(axis[ax1]) > fabs(axis[ax2])) ax1 = ax2; /* the face the capsule makes the smaller angle with */
+      ax2 = 3 - ax - ax1;
+      int mul;
+      if (c1 & (1 << ax2)) { mul = 1; second = 1.0 - bestseg; }
+      else { mul = -1; second = 1.0 + bestseg; }
+      second = fmin(2.0 * safe_div(bs[ax2], fabs(ha[ax2])), second);
+      double e2 = (((axisdir & (1 << ax)) != 0) == ((c1 & (1 << ax2)) != 0)) ? 1.0 - bestbox : 1.0 + bestbox;
+      second = fmin(bs[ax] * safe_div(e2, fabs(ha[ax])), second);
+      second *= mul;
+    }
+  } else if (clface != -1) { /* an end is closest to a face: follow the capsule until it leaves the box footprint */
+    int mul = cltype == -3 ? 1 : -1;
+    second = 2.0;
+    for (int k = 0; k < 3; k++) {
+      if (k == clface) continue;
+      double tmp = pos[k] - ha[k] * mul, har = safe_div((double)mul, ha[k]);
+      double e1 = (bs[k] - tmp) * har;
+      if (0.0 < e1 && e1 < second) second = e1;
+      e1 = (-bs[k] - tmp) * har;
+      if (0.0 < e1 && e1 < second) second = e1;
+    }
+    second *= mul;
+  }
+  /* contact spheres at the chosen segment points, in world coordinates */
+  int n = 0;
+  for (int c = 0; c < 2; c++) {
+    if (c == 1 && !(second > -3.0)) break;
+    double t = c == 0 ? bestseg : second + bestseg, loc[3], sp[3];
+    for (int k = 0; k < 3; k++) loc[k] = pos[k] + ha[k] * t;
+    mat_mul_vec(sp, R, loc);
+    v3add(sp, sp, bpos);
+    sphere_box(sp, r, bpos, R, bs, &out[n]);
+    n++;
+  }
+  return n;
+}
+
 static int collide_pair(const RefModel* m, const RefData* d, int g1, int g2, double margin, Con* out) {
   int t1 = m->geom_type[g1], t2 = m->geom_type[g2];
   const double *p1 = d->geom_xpos + 3 * g1, *p2 = d->geom_xpos + 3 * g2;
@@ -721,33 +870,10 @@ static int collide_pair(const RefModel* m, const RefData* d, int g1, int g2, dou
       }
     }
   } else if (t1 == G_SPHERE && t2 == G_BOX) { /* core:1044 */
-    double dif[3], center[3], clamped[3], cdir[3], pos[3], nn[3];
-    v3sub(dif, p1, p2);
-    matT_mul_vec(center, R2, dif);
-    for (int k = 0; k < 3; k++) clamped[k] = fmax(-s2[k], fmin(s2[k], center[k]));
-    v3sub(cdir, clamped, center);
-    double dist = v3normalize(cdir);
-    if (dist <= MINVAL) {
-      double closest = 2.0 * (s2[0] + s2[1] + s2[2]);
-      int kk = 0;
-      for (int i = 0; i < 6; i++) {
-        double fd = fabs(((i % 2) ? 1.0 : -1.0) * s2[i / 2] - center[i / 2]);
-        if (closest > fd) { closest = fd; kk = i; }
-      }
-      double nearest[3] = {0, 0, 0};
-      nearest[kk / 2] = (kk % 2) ? -1.0 : 1.0;
-      for (int k = 0; k < 3; k++) pos[k] = center[k] + nearest[k] * (s1[0] - closest) / 2.0;
-      mat_mul_vec(nn, R2, nearest);
-      out[0].dist = -closest - s1[0];
-    } else {
-      for (int k = 0; k < 3; k++) pos[k] = 0.5 * (clamped[k] + center[k] + cdir[k] * s1[0]);
-      mat_mul_vec(nn, R2, cdir);
-      out[0].dist = dist - s1[0];
-    }
-    mat_mul_vec(out[0].pos, R2, pos);
-    v3add(out[0].pos, out[0].pos, p2);
-    make_frame(out[0].frame, nn);
+    sphere_box(p1, s1[0], p2, R2, s2, &out[0]);
     n = 1;
+  } else if (t1 == G_CAPSULE && t2 == G_BOX) { /* core:1099 */
+    n = capsule_box(p1, ax1, s1[0], s1[1], p2, R2, s2, out);
   } else if (t1 == G_SPHERE && t2 == G_CYLINDER) { /* core:388 */
     double vec[3], aproj[3], pproj[3], nn[3], pos[3], target[3], dist;
     double r = s2[0], hh = s2[1];

@@ -185,3 +185,25 @@ def multi_humanoid_xml(n=3, spacing=1.5):
   for sec in root.findall("keyframe") + root.findall("contact") + root.findall("sensor"):
     root.remove(sec)
   return ET.tostring(root, encoding="unicode")
+
+
+# capsules against boxes in every capsule_box regime: lying on a face, standing on it, overhanging an edge, leaning on an edge,
+# next to a corner (the static box keeps the scene simple; the capsules also rest on the floor or on each other)
+CAPSULE_BOX_XML = """
+<mujoco>
+  <option timestep="0.003"/>
+  <worldbody>
+    <geom name="floor" type="plane" size="0 0 .05"/>
+    <body name="table" pos="0 0 .2"><geom type="box" size=".4 .3 .2" contype="2"/></body>
+    <body name="lying" pos="0 0 .449" euler="0 90 0"><freejoint/><geom type="capsule" size=".05 .15"/></body>
+    <body name="standing" pos=".2 .15 .599"><freejoint/><geom type="capsule" size=".04 .16" condim="1"/></body>
+    <body name="overhang" pos=".4 -.15 .449" euler="0 90 20"><freejoint/><geom type="capsule" size=".05 .2"/></body>
+    <body name="leaning" pos="-.52 0 .23" euler="0 35 0"><freejoint/><geom type="capsule" size=".04 .3"/></body>
+    <body name="box2" pos="1 0 .0699"><freejoint/><geom type="box" size=".06 .05 .07" contype="2"/></body>
+    <body name="onbox" pos="1 0 .1789" euler="90 0 0"><freejoint/><geom type="capsule" size=".04 .1"/></body>
+  </worldbody>
+  <keyframe>
+    <key name="k" qvel="0 0 -.1 0 0 0  0 0 -.1 0 0 0  0 0 -.1 0 0.5 0  0 0 0 0 0 0  0 0 -.1 0 0 0  0 0 -.2 0 0 0"/>
+  </keyframe>
+</mujoco>
+"""

@@ -191,6 +191,28 @@ def test_small_models_forward_and_step(xml, njmax):
     assert relerr(d.qvel.numpy()[0], s.qvel) <= 2e-3
 
 
+@pytest.mark.parametrize("warm", [5, 15, 60])
+def test_capsule_box_collider(warm):
+  """capsule_box (core:1099) on the kernel instantiation that carries the large colliders: capsules lying / standing on a box,
+  overhanging and leaning on its edges, and resting on a small free box; contacts, rows, solution and 20 steps."""
+  mjm = mjw.mjcf.from_xml_string(conftest.CAPSULE_BOX_XML)
+  s, m, d = _pair(mjm, nworld=2, nconmax=48, njmax=160, warm_steps=warm, noise=False)
+  assert m.heavy_colliders == 1
+  mjw.forward(m, d)
+  s.forward()
+  pairs = {tuple(int(x) for x in g) for g in s.con_geom[: s.ncon]}
+  assert (2, 1) in pairs and (3, 1) in pairs  # capsule geoms 2.. against the table box (geom 1)
+  _check_fields(s, d, _SMOOTH_FIELDS, SMOOTH)
+  _check_contacts_and_rows(s, d, mjm, dist_atol=5e-7)
+  _check_solution(s, d)
+  for _ in range(20):
+    _sync(s, d)
+    mjw.step(m, d)
+    s.step()
+    assert relerr(d.qpos.numpy()[0], s.qpos) <= 1e-5
+    assert relerr(d.qvel.numpy()[0], s.qvel) <= 2e-3
+
+
 def test_sphere_cylinder_rim_regime():
   """10 steps in, the small sphere still rolls over the cylinder's rim (the 40-step state above only has cap and side)."""
   mjm = mjw.mjcf.from_xml_string(conftest.SPHERE_CYLINDER_XML)

@@ -405,3 +405,52 @@ def test_rk4_humanoid_step_runs_and_warmstart_is_last_stage(humanoid):
   assert np.isfinite(s.qpos).all() and s.overflow == 0
   np.testing.assert_array_equal(s.qacc_warmstart, s.qacc)  # qacc of the fourth evaluation (forward.py:343)
   assert abs(s.time - 20 * mjm.opt.timestep) < 1e-12
+
+
+def test_collision_capsule_box_closed_form():
+  """capsule_box (collision_primitive_core.py:1099): one sphere at the closest segment point, a second one further along the
+  capsule when it lies along a face or an edge.  Box half sizes (.3, .2, .1), capsule radius .05, half length .15."""
+  m = mjw.mjcf.from_xml_string("""
+<mujoco><worldbody>
+  <body name="box"><freejoint/><geom type="box" size=".3 .2 .1"/></body>
+  <body name="cap"><freejoint/><geom type="capsule" size=".05 .15"/></body>
+</worldbody></mujoco>""")
+  s = _sim(m)
+  nm = mjw._npmath
+  along_x = nm.axis_angle_to_quat(np.array([0, 1.0, 0]), np.pi / 2)
+  along_y = nm.axis_angle_to_quat(np.array([1.0, 0, 0]), np.pi / 2)
+
+  def contacts(cpos, cquat):
+    s.qpos[:] = [0, 0, 0, 1, 0, 0, 0, *cpos, *cquat]
+    s.stage("kinematics")
+    s.stage("collision")
+    n = s.ncon
+    assert (s.con_geom[:n] == [1, 0]).all()  # capsule (type 3) before box (type 6)
+    order = np.lexsort(s.con_pos[:n].T[::-1])
+    return s.con_dist[:n][order], s.con_pos[:n][order], s.con_frame[:n, :3][order]
+
+  # lying flat on the top face, 1 cm deep: a contact under each end, normal from the capsule into the box
+  dist, pos, nrm = contacts([0, 0, 0.14], along_x)
+  np.testing.assert_allclose(dist, [-0.01, -0.01], atol=1e-12)
+  np.testing.assert_allclose(pos, [[-0.15, 0, 0.095], [0.15, 0, 0.095]], atol=1e-12)
+  np.testing.assert_allclose(nrm, [[0, 0, -1]] * 2, atol=1e-12)
+  # standing on the top face: one contact under the lower end
+  dist, pos, nrm = contacts([0.1, 0.05, 0.29], [1, 0, 0, 0])
+  np.testing.assert_allclose(dist, [-0.01], atol=1e-12)
+  np.testing.assert_allclose(pos, [[0.1, 0.05, 0.095]], atol=1e-12)
+  # overhanging the +x edge: the second contact stops at the edge of the box
+  dist, pos, nrm = contacts([0.3, 0, 0.14], along_x)
+  np.testing.assert_allclose(pos, [[0.15, 0, 0.095], [0.3, 0, 0.095]], atol=1e-12)
+  np.testing.assert_allclose(dist, [-0.01, -0.01], atol=1e-12)
+  # lying against the +x face
+  dist, pos, nrm = contacts([0.34, 0, 0.05], along_y)
+  np.testing.assert_allclose(dist, [-0.01, -0.01], atol=1e-12)
+  np.testing.assert_allclose(pos, [[0.295, -0.15, 0.05], [0.295, 0.15, 0.05]], atol=1e-12)
+  np.testing.assert_allclose(nrm, [[-1, 0, 0]] * 2, atol=1e-12)
+  # parallel to a vertical edge of the box, outside the corner: contacts at the box top and at the capsule's lower end
+  dist, pos, nrm = contacts([0.33, 0.23, 0.13], [1, 0, 0, 0])
+  np.testing.assert_allclose(dist, [np.hypot(0.03, 0.03) - 0.05] * 2, atol=1e-12)
+  np.testing.assert_allclose(pos[:, 2], [-0.02, 0.1], atol=1e-12)
+  np.testing.assert_allclose(nrm, [[-np.sqrt(0.5), -np.sqrt(0.5), 0]] * 2, atol=1e-12)
+  # separated
+  assert len(contacts([1, 1, 1], [1, 0, 0, 0])[0]) == 0
