@@ -1,4 +1,4 @@
-"""Randomised-model parity (40 seeds by default, MJH_FUZZ_SEEDS=N for more; 120 were run clean): random kinematic trees with mixed joint / geom / actuator types against the float64 oracle.
+"""Randomised-model parity (40 + 12 PGS + 16 extra-collider seeds by default; MJH_FUZZ_SEEDS / MJH_FUZZ_PGS_SEEDS / MJH_FUZZ_COLLIDER_SEEDS for more: 240 + 80 + 96 were run clean): random kinematic trees with mixed joint / geom / actuator types against the float64 oracle.
 
 The fixed models (humanoid, G1, Panda, pendula, free bodies, pile) pin specific code paths; these seeds sweep the
 combinations: free / ball / hinge / slide joints at random depths, limits, damping, springs, armature, friction loss,
@@ -18,12 +18,16 @@ from oracle import ref
 pytestmark = pytest.mark.gpu
 
 
-def random_model_xml(seed):
+def random_model_xml(seed, more_colliders=False):
   r = np.random.default_rng(seed)
   integrator = "implicitfast" if seed % 2 else "Euler"
   lines = [f'<mujoco><option timestep="0.003" integrator="{integrator}"/>',
            '<default><geom condim="3" friction="0.8 0.02 0.001"/><joint armature="0.02"/></default>', "<worldbody>",
            '<geom name="floor" type="plane" size="0 0 .05" contype="3" conaffinity="0"/>']
+  # more_colliders: same trees and geoms, but boxes also collide with spheres and capsules (sphere_box, capsule_box) and
+  # cylinders with spheres (sphere_cylinder); contype/conaffinity bits: 0 floor->round, 1 floor->rest, 2 round<->round,
+  # 3 round->box, 4 sphere->cylinder (box-box, cylinder-* and ellipsoid-* pairs stay off: no collider for them)
+  bits = {"sphere": (4 + 8 + 16, 1 + 4), "capsule": (4 + 8, 1 + 4), "box": (0, 2 + 8), "cylinder": (0, 2 + 16), "ellipsoid": (0, 2)}
   joints, close = [], []
   nb = int(r.integers(3, 9))
   depth = 0
@@ -64,6 +68,8 @@ def random_model_xml(seed):
     # only spheres / capsules may touch each other (supported pair types); everything touches the floor
     # (floor: contype bits 0|1; spheres/capsules: contype bit 2, conaffinity bits 0|2; the rest: conaffinity bit 1 only)
     body_contact = 'contype="4" conaffinity="5"' if gt in ("sphere", "capsule") else 'contype="0" conaffinity="2"'
+    if more_colliders:
+      body_contact = f'contype="{bits[gt][0]}" conaffinity="{bits[gt][1]}"'
     if gt == "sphere":
       lines.append(f'<geom type="sphere" size="{s:.3f}" {body_contact}/>')
     elif gt == "capsule":
@@ -89,8 +95,8 @@ def random_model_xml(seed):
   return "\n".join(lines)
 
 
-def _run_seed(seed, solver, njmax_dev=128):
-  mjm = mjw.mjcf.from_xml_string(random_model_xml(seed))
+def _run_seed(seed, solver, njmax_dev=128, more_colliders=False):
+  mjm = mjw.mjcf.from_xml_string(random_model_xml(seed, more_colliders))
   mjm.opt.solver = int(solver)
   mjm.opt.iterations, mjm.opt.ls_iterations = 100, 50
   s = ref.RefSim(mjm, nconmax=48, njmax=128, tolerance=1e-6)
@@ -144,3 +150,10 @@ def test_random_model_forward_and_steps(seed):
 def test_random_model_pgs(seed):
   """PGS on the same random models: even seeds with njmax 64 (register-resident sweep), odd seeds with 128 (LDS sweep)."""
   _run_seed(seed, mjw.SolverType.PGS, 64 if seed % 2 == 0 else 128)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MJH_FUZZ_COLLIDER_SEEDS", "16"))))
+def test_random_model_more_colliders(seed):
+  """The same random trees with boxes colliding against spheres and capsules and cylinders against spheres: random poses for
+  sphere_box, capsule_box (the instantiation that carries the large colliders) and sphere_cylinder."""
+  _run_seed(seed, mjw.SolverType.NEWTON if seed % 2 else mjw.SolverType.CG, more_colliders=True)
