@@ -109,6 +109,17 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
                                 ("actuator_gaintype", (0, 1), "fixed / affine"), ("actuator_biastype", (0, 1), "none / affine")):
       if not np.isin(np.asarray(getattr(mjm, name)), allowed).all():
         raise NotImplementedError(f"{name}: only {what} are implemented (no muscle / user types).")
+    if np.asarray(getattr(mjm, "actuator_actearly", [0])).any():
+      raise NotImplementedError("actuator actearly is not implemented.")
+    if (np.asarray(getattr(mjm, "actuator_actnum", [0])) > 1).any():
+      raise NotImplementedError("actuators with more than one activation variable are not implemented.")
+  for name, what in (("jnt_actfrclimited", "joint actuatorfrcrange (clamp of the summed actuator force, forward.py _qfrc_actuator)"),
+                     ("jnt_actgravcomp", "actuatorgravcomp (gravity compensation routed through the actuators)")):
+    if np.asarray(getattr(mjm, name, [0])).any():
+      raise NotImplementedError(f"{what} is not implemented.")
+  for name in ("jnt_stiffnesspoly", "dof_dampingpoly"):
+    if np.asarray(getattr(mjm, name, [0.0])).any():
+      raise NotImplementedError(f"{name} (polynomial stiffness / damping) is not implemented.")
   # physics this engine does not compute must not be dropped silently
   if float(getattr(opt, "density", 0.0)) != 0.0 or float(getattr(opt, "viscosity", 0.0)) != 0.0:
     raise NotImplementedError("fluid forces (option density / viscosity, passive.py _fluid_force) are not implemented.")

@@ -100,6 +100,9 @@ def test_unsupported_features_raise():
   m = mjw.mjcf.from_xml_string('<mujoco><option><flag override="enable"/></option><worldbody><body><joint/><geom size=".1"/></body></worldbody></mujoco>')
   with pytest.raises(NotImplementedError):
     mjw.put_model(m)
+  m = mjw.mjcf.from_xml_string('<mujoco><worldbody><body><joint actuatorfrcrange="-1 1"/><geom size=".1"/></body></worldbody></mujoco>')
+  with pytest.raises(NotImplementedError):
+    mjw.put_model(m)
   m = mjw.mjcf.from_xml_string('<mujoco><option integrator="implicit"/><worldbody><body><joint/><geom size=".1"/></body></worldbody></mujoco>')
   with pytest.raises(NotImplementedError):
     mjw.put_model(m)
