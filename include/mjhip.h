@@ -55,7 +55,7 @@ typedef struct MjhModel {
   /* sizes */
   int nq; int nv; int nu; int na; int nbody; int njnt; int ngeom; int nsite; int nC; int npair;
   int nbodylevel; int ndoflevel; int nv_pad; int neq;
-  int heavy_colliders; /* 1: the pair list holds capsule-box pairs (selects the kernel instantiation that carries them) */
+  int heavy_colliders; /* 1: the pair list holds capsule-box or box-box pairs (selects the kernel instantiation that carries them) */
   /* options (types.py:836-905); solver: 0 = PGS (extension, the reference has none: types.py:502), 1 = CG, 2 = Newton */
   int integrator; int cone; int solver; int iterations; int ls_iterations; int disableflags; int enableflags;
   const float* opt_timestep; int opt_timestep_nb;

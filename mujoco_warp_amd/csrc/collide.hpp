@@ -197,6 +197,304 @@ DEV int capsule_box_params(V3 pos, V3 axis, float hl, V3 bs, float& t1, float& t
   return second > -3.0f ? 2 : 1;
 }
 
+// ---- box_box core:589 (MuJoCo's mjc_BoxBox); same structure as oracle/mjref.c:box_box ------------------------------------
+DEV void bb_face_rot(int f, float* r) {  // rotation taking face f of a box to +z (core:557)
+  const float T[6][9] = {{0, 0, -1, 0, 1, 0, 1, 0, 0}, {1, 0, 0, 0, 0, -1, 0, 1, 0}, {1, 0, 0, 0, 1, 0, 0, 0, 1},
+                         {0, 0, 1, 0, 1, 0, -1, 0, 0}, {1, 0, 0, 0, 0, 1, 0, -1, 0}, {-1, 0, 0, 0, 1, 0, 0, 0, -1}};
+  for (int k = 0; k < 9; ++k) r[k] = T[f][k];
+}
+DEV void bb_mul(float* r, const float* a, const float* b) {
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) r[3 * i + j] = a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j] + a[3 * i + 2] * b[6 + j];
+}
+DEV void bb_T(float* r, const float* a) {
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) r[3 * i + j] = a[3 * j + i];
+}
+DEV void bb_mv(float* r, const float* m, const float* v) {
+  for (int i = 0; i < 3; ++i) r[i] = m[3 * i] * v[0] + m[3 * i + 1] * v[1] + m[3 * i + 2] * v[2];
+}
+// returns the number of contacts; pts (world) / depth / normal (world) are filled
+DEV int box_box(V3 P1, const float* R1, V3 S1, V3 P2, const float* R2, V3 S2, float margin, float (*wp)[3], float* depth, float* normal) {
+  const float p1[3] = {P1.x, P1.y, P1.z}, p2[3] = {P2.x, P2.y, P2.z}, s1[3] = {S1.x, S1.y, S1.z}, s2[3] = {S2.x, S2.y, S2.z};
+  float pos21[3], pos12[3], R1T[9], R2T[9], rot21[9], rot12[9], a21[9], a12[9], plen1[3], plen2[3], dv[3];
+  bb_T(R1T, R1);
+  bb_T(R2T, R2);
+  for (int k = 0; k < 3; ++k) dv[k] = p2[k] - p1[k];
+  bb_mv(pos21, R1T, dv);
+  for (int k = 0; k < 3; ++k) dv[k] = -dv[k];
+  bb_mv(pos12, R2T, dv);
+  bb_mul(rot21, R1T, R2);
+  bb_T(rot12, rot21);
+  for (int k = 0; k < 9; ++k) {
+    a21[k] = fabsf(rot21[k]);
+    a12[k] = fabsf(rot12[k]);
+  }
+  bb_mv(plen2, a21, s2);
+  bb_mv(plen1, a12, s1);
+  float separation = margin + 3.0f * (s1[0] + s2[0]) + 3.0f * (s1[1] + s2[1]) + 3.0f * (s1[2] + s2[2]);
+  int code = -1;
+  const float tie = 5e-7f * (s1[0] + s1[1] + s1[2] + s2[0] + s2[1] + s2[2]);  // ~3x the float32 round-off of the overlap sums
+  for (int i = 0; i < 3; ++i) {  // face normals
+    const float c1 = -fabsf(pos21[i]) + s1[i] + plen2[i], c2 = -fabsf(pos12[i]) + s2[i] + plen1[i];
+    if (c1 < -margin || c2 < -margin) return 0;
+    // ties go to the earlier candidate, not to round-off (see the edge axes below)
+    if (c1 < separation - tie) { separation = c1; code = i + 3 * (pos21[i] < 0.0f ? 1 : 0); }
+    if (c2 < separation - tie) { separation = c2; code = i + 3 * (pos12[i] < 0.0f ? 1 : 0) + 6; }
+  }
+  float clnorm[3] = {0, 0, 0};
+  int inv = 0, cle1 = 0, cle2 = 0;
+  for (int i = 0; i < 3; ++i) {  // edge i of box 1 x edge j of box 2
+    for (int j = 0; j < 3; ++j) {
+      const float* a = rot12 + 3 * j;  // axis j of box 2 in the frame of box 1
+      float cr[3];
+      if (i == 0) { cr[0] = 0.0f; cr[1] = -a[2]; cr[2] = a[1]; }
+      else if (i == 1) { cr[0] = a[2]; cr[1] = 0.0f; cr[2] = -a[0]; }
+      else { cr[0] = -a[1]; cr[1] = a[0]; cr[2] = 0.0f; }
+      const float len = sqrtf(cr[0] * cr[0] + cr[1] * cr[1] + cr[2] * cr[2]);
+      if (len < MJ_MINVAL) continue;
+      for (int k = 0; k < 3; ++k) cr[k] /= len;
+      const float bd = pos21[0] * cr[0] + pos21[1] * cr[1] + pos21[2] * cr[2];
+      float c3 = 0.0f;
+      for (int k = 0; k < 3; ++k) {
+        if (k != i) c3 += s1[k] * fabsf(cr[k]);
+        if (k != j) c3 += s2[k] * a21[3 * i + (3 - k - j)] / len;
+      }
+      c3 -= fabsf(bd);
+      if (c3 < -margin) return 0;
+      // An edge axis only replaces a face axis when it is clearly less penetrated.  MuJoCo C guards the tie of flat face-face
+      // contact (every edge cross product is then parallel to the face normal and has the same overlap) with a relative
+      // 1e-12, which float32 cannot represent (the reference's float32 kernel keeps the constant, so its guard is a no-op);
+      // here the guard is scaled to the float32 round-off of the overlap sums (`tie`, sub-micrometre for decimetre boxes).
+      if (c3 < separation - tie) {
+        separation = c3;
+        cle1 = cle2 = 0;
+        for (int k = 0; k < 3; ++k) {
+          if (k != i && ((cr[k] > 0.0f) != (bd < 0.0f))) cle1 += 1 << k;
+          if (k != j && (((rot21[3 * i + (3 - k - j)] > 0.0f) != (bd < 0.0f)) != (((k - j + 3) % 3) == 1))) cle2 += 1 << k;
+        }
+        code = 12 + 3 * i + j;
+        for (int k = 0; k < 3; ++k) clnorm[k] = cr[k];
+        inv = bd < 0.0f;
+      }
+    }
+  }
+  if (code == -1) return 0;
+  float pts[8][3], rw[9], pw[3], hz;
+  int n = 0;
+  if (code < 12) {  // a face of one box against vertices / edges of the other
+    const int f = code % 6, bi = code / 6;
+    float rm[9], rmT[9], r[9], rt[9], pp[3], ss[3], tmp[3];
+    bb_face_rot(f, rm);
+    bb_T(rmT, rm);
+    bb_mul(r, rm, bi ? rot12 : rot21);
+    bb_mv(pp, rm, bi ? pos12 : pos21);
+    bb_mv(tmp, rm, bi ? s2 : s1);
+    for (int k = 0; k < 3; ++k) ss[k] = fabsf(tmp[k]);
+    const float* so = bi ? s1 : s2;  // half sizes of the other box
+    bb_T(rt, r);
+    const float lx = ss[0], ly = ss[1];
+    hz = ss[2];
+    pp[2] -= hz;
+    int corner = 0;
+    for (int i = 0; i < 3; ++i)
+      if (r[6 + i] < 0.0f) corner += 1 << i;
+    float lp[3], cn1[3] = {0, 0, 0}, cn2[3] = {0, 0, 0};
+    for (int k = 0; k < 3; ++k) lp[k] = pp[k];
+    for (int i = 0; i < 3; ++i)
+      for (int k = 0; k < 3; ++k) lp[k] += rt[3 * i + k] * so[i] * (((corner >> i) & 1) ? 1.0f : -1.0f);
+    int dirs = 0;
+    for (int i = 0; i < 3; ++i) {
+      if (fabsf(r[6 + i]) < 0.5f) {
+        const float sc = so[i] * (((corner >> i) & 1) ? -2.0f : 2.0f);
+        for (int k = 0; k < 3; ++k) (dirs ? cn2 : cn1)[k] = rt[3 * i + k] * sc;
+        ++dirs;
+      }
+    }
+    // candidates are filtered (z <= margin) as they are produced; the reference compacts afterwards, same order
+    auto push = [&](float x, float y, float z) {
+      if (z > margin || n >= 8) return;
+      pts[n][0] = x;
+      pts[n][1] = y;
+      pts[n][2] = 0.5f * z;
+      depth[n] = z;
+      ++n;
+    };
+    for (int i = 0; i < dirs * dirs; ++i) {  // edges of the other box's lowest face against the face rectangle
+      for (int q = 0; q < 2; ++q) {
+        float lav[3], lbv[3];
+        for (int k = 0; k < 3; ++k) {
+          lav[k] = lp[k] + (i < 2 ? 0.0f : (i == 2 ? cn1[k] : cn2[k]));
+          lbv[k] = (i == 0 || i == 3) ? cn1[k] : cn2[k];
+        }
+        if (fabsf(lbv[q]) > MJ_MINVAL) {
+          const float br = 1.0f / lbv[q];
+          for (int j = -1; j <= 1; j += 2) {
+            const float l = ss[q] * (float)j, c1 = (l - lav[q]) * br;
+            if (c1 < 0.0f || c1 > 1.0f) continue;
+            const float c2 = lav[1 - q] + lbv[1 - q] * c1;
+            if (fabsf(c2) > ss[1 - q]) continue;
+            push(lav[0] + c1 * lbv[0], lav[1] + c1 * lbv[1], lav[2] + c1 * lbv[2]);
+          }
+        }
+      }
+    }
+    if (dirs == 2) {  // rectangle corners inside the other face's parallelogram
+      const float ax = cn1[0], bx = cn2[0], ay = cn1[1], by = cn2[1], C = safe_div(1.0f, ax * by - bx * ay);
+      for (int i = 0; i < 4; ++i) {
+        const float llx = (i / 2) ? lx : -lx, lly = (i % 2) ? ly : -ly, x = llx - lp[0], y = lly - lp[1];
+        const float u = (x * by - y * bx) * C, v = (y * ax - x * ay) * C;
+        if (u > 0.0f && v > 0.0f && u < 1.0f && v < 1.0f) push(llx, lly, lp[2] + u * cn1[2] + v * cn2[2]);
+      }
+    }
+    for (int i = 0; i < (1 << dirs); ++i) {  // the other box's corners above the rectangle
+      float t[3];
+      for (int k = 0; k < 3; ++k) t[k] = lp[k] + (float)(i & 1) * cn1[k] + ((i & 2) ? cn2[k] : 0.0f);
+      if (t[0] > -lx && t[0] < lx && t[1] > -ly && t[1] < ly) push(t[0], t[1], t[2]);
+    }
+    bb_mul(rw, bi ? R2 : R1, rmT);
+    for (int k = 0; k < 3; ++k) {
+      pw[k] = bi ? p2[k] : p1[k];
+      normal[k] = (bi ? -1.0f : 1.0f) * rw[3 * k + 2];
+    }
+  } else {  // edge against edge
+    const int e1 = (code - 12) / 3, e2 = (code - 12) % 3;
+    int ax1 = 1 - (e2 & 1), ax2 = 2 - (e2 & 2), pax1 = 1 - (e1 & 1), pax2 = 2 - (e1 & 2);
+    if (a21[3 * e1 + ax1] < a21[3 * e1 + ax2]) { const int t = ax1; ax1 = ax2; ax2 = t; }
+    if (a12[3 * e2 + pax1] < a12[3 * e2 + pax2]) { const int t = pax1; pax1 = pax2; pax2 = t; }
+    float rm[9], rmT[9], pp[3], rnorm[3], r[9], rt[9], tmp[3], sz[3];
+    bb_face_rot((cle1 & (1 << pax2)) ? pax2 : pax2 + 3, rm);
+    bb_T(rmT, rm);
+    bb_mv(pp, rm, pos21);
+    bb_mv(rnorm, rm, clnorm);
+    bb_mul(r, rm, rot21);
+    bb_T(rt, r);
+    bb_mv(tmp, rmT, s1);
+    for (int k = 0; k < 3; ++k) sz[k] = fabsf(tmp[k]);
+    const float lx = sz[0], ly = sz[1];
+    hz = sz[2];
+    pp[2] -= hz;
+    float q4[4][3];  // the face of box 2 nearest to box 1, as 4 points
+    for (int k = 0; k < 3; ++k) {
+      const float b1 = rt[3 * ax1 + k] * s2[ax1], b2 = rt[3 * ax2 + k] * s2[ax2], be = rt[3 * e2 + k] * s2[e2];
+      const float sg1 = (cle2 & (1 << ax1)) ? 1.0f : -1.0f, sg2 = (cle2 & (1 << ax2)) ? 1.0f : -1.0f;
+      const float base0 = pp[k] + b1 * sg1 + b2 * sg2, base2 = pp[k] - b1 * sg1 + b2 * sg2;
+      q4[0][k] = base0 + be;
+      q4[1][k] = base0 - be;
+      q4[2][k] = base2 + be;
+      q4[3][k] = base2 - be;
+    }
+    float axi_lp[3], axi_cn1[3], axi_cn2[3];
+    for (int k = 0; k < 3; ++k) {
+      axi_lp[k] = q4[0][k];
+      axi_cn1[k] = q4[1][k] - q4[0][k];
+      axi_cn2[k] = q4[2][k] - q4[0][k];
+    }
+    if (fabsf(rnorm[2]) < MJ_MINVAL) return 0;
+    const float sgn = inv ? -1.0f : 1.0f, innorm = sgn / rnorm[2];
+    float pu[4][3];
+    for (int i = 0; i < 4; ++i) {  // project along the contact normal onto the plane z = 0
+      const float c = q4[i][2] * sgn * innorm;
+      for (int k = 0; k < 3; ++k) {
+        pu[i][k] = q4[i][k];
+        q4[i][k] -= rnorm[k] * c;
+      }
+    }
+    float lp[3], cn1[3], cn2[3];
+    for (int k = 0; k < 3; ++k) {
+      lp[k] = q4[0][k];
+      cn1[k] = q4[1][k] - q4[0][k];
+      cn2[k] = q4[2][k] - q4[0][k];
+    }
+    for (int i = 0; i < 4; ++i) {
+      for (int q = 0; q < 2; ++q) {
+        const float la = lp[q] + (i < 2 ? 0.0f : (i == 2 ? cn1[q] : cn2[q])), lb = (i == 0 || i == 3) ? cn1[q] : cn2[q];
+        const float lc = lp[1 - q] + (i < 2 ? 0.0f : (i == 2 ? cn1[1 - q] : cn2[1 - q])), ld = (i == 0 || i == 3) ? cn1[1 - q] : cn2[1 - q];
+        float lua[3], lub[3];
+        for (int k = 0; k < 3; ++k) {
+          lua[k] = axi_lp[k] + (i < 2 ? 0.0f : (i == 2 ? axi_cn1[k] : axi_cn2[k]));
+          lub[k] = (i == 0 || i == 3) ? axi_cn1[k] : axi_cn2[k];
+        }
+        if (fabsf(lb) > MJ_MINVAL) {
+          const float br = 1.0f / lb;
+          for (int j = -1; j <= 1; j += 2) {
+            if (n == 8) break;
+            const float l = sz[q] * (float)j, c1 = (l - la) * br;
+            if (c1 < 0.0f || c1 > 1.0f) continue;
+            const float c2 = lc + ld * c1;
+            if (fabsf(c2) > sz[1 - q]) continue;
+            if ((lua[2] + lub[2] * c1) * innorm > margin) continue;
+            for (int k = 0; k < 3; ++k) pts[n][k] = lua[k] * 0.5f + c1 * lub[k] * 0.5f;
+            pts[n][q] += 0.5f * l;
+            pts[n][1 - q] += 0.5f * c2;
+            depth[n] = pts[n][2] * innorm * 2.0f;
+            ++n;
+          }
+        }
+      }
+    }
+    const int nl = n;
+    const float ax = cn1[0], bx = cn2[0], ay = cn1[1], by = cn2[1], C = safe_div(1.0f, ax * by - bx * ay);
+    for (int i = 0; i < 4; ++i) {
+      if (n == 8) break;
+      const float llx = (i / 2) ? lx : -lx, lly = (i % 2) ? ly : -ly, x = llx - lp[0], y = lly - lp[1];
+      float u = (x * by - y * bx) * C, v = (y * ax - x * ay) * C;
+      if (nl == 0) {
+        if ((u < 0.0f || u > 1.0f) && (v < 0.0f || v > 1.0f)) continue;
+      } else if (u < 0.0f || v < 0.0f || u > 1.0f || v > 1.0f) continue;
+      u = clampf(u, 0.0f, 1.0f);
+      v = clampf(v, 0.0f, 1.0f);
+      const float w = 1.0f - u - v;
+      float vt[3], tc1 = 0.0f;
+      const float corner3[3] = {llx, lly, 0.0f};
+      for (int k = 0; k < 3; ++k) {
+        vt[k] = pu[0][k] * w + pu[1][k] * u + pu[2][k] * v;
+        tc1 += (corner3[k] - vt[k]) * (corner3[k] - vt[k]);
+      }
+      if (vt[2] > 0.0f && tc1 > margin * margin) continue;
+      for (int k = 0; k < 3; ++k) pts[n][k] = 0.5f * (corner3[k] + vt[k]);
+      depth[n] = sqrtf(tc1) * (vt[2] < 0.0f ? -1.0f : 1.0f);
+      ++n;
+    }
+    const int nf = n;
+    for (int i = 0; i < 4; ++i) {
+      if (n >= 8) break;
+      const float x = pu[i][0], y = pu[i][1];
+      if (nl == 0 && nf != 0) {
+        if ((x < -lx || x > lx) && (y < -ly || y > ly)) continue;
+      } else if (x < -lx || x > lx || y < -ly || y > ly) continue;
+      float c1 = 0.0f;
+      for (int j = 0; j < 2; ++j) {
+        if (pu[i][j] < -sz[j]) c1 += (pu[i][j] + sz[j]) * (pu[i][j] + sz[j]);
+        else if (pu[i][j] > sz[j]) c1 += (pu[i][j] - sz[j]) * (pu[i][j] - sz[j]);
+      }
+      c1 += pu[i][2] * innorm * pu[i][2] * innorm;
+      if (pu[i][2] > 0.0f && c1 > margin * margin) continue;
+      float tp[3] = {pu[i][0], pu[i][1], 0.0f};
+      for (int j = 0; j < 2; ++j) {
+        if (pu[i][j] < -sz[j]) tp[j] = -sz[j] * 0.5f;
+        else if (pu[i][j] > sz[j]) tp[j] = sz[j] * 0.5f;
+      }
+      for (int k = 0; k < 3; ++k) pts[n][k] = 0.5f * (tp[k] + pu[i][k]);
+      depth[n] = sqrtf(c1) * (pu[i][2] < 0.0f ? -1.0f : 1.0f);
+      ++n;
+    }
+    bb_mul(rw, R1, rmT);
+    float nn[3];
+    bb_mv(nn, rw, rnorm);
+    for (int k = 0; k < 3; ++k) {
+      pw[k] = p1[k];
+      normal[k] = sgn * nn[k];
+    }
+  }
+  for (int i = 0; i < n; ++i) {
+    pts[i][2] += hz;
+    bb_mv(wp[i], rw, pts[i]);
+    for (int k = 0; k < 3; ++k) wp[i][k] += pw[k];
+  }
+  return n;
+}
+
 // runs the collider for geoms (g1,g2) with type1 <= type2
 template <bool HEAVY, class Emit>
 DEV void collide_pair(int t1, int t2, V3 p1, const float* R1, V3 s1, V3 p2, const float* R2, V3 s2, float margin, Emit&& emit) {
@@ -331,6 +629,11 @@ DEV void collide_pair(int t1, int t2, V3 p1, const float* R1, V3 s1, V3 p2, cons
       const Frame f = make_frame3(nn);
       emit(c, dist, pos, f.a, f.b, f.c);
     }
+  } else if (HEAVY && t1 == G_BOX && t2 == G_BOX) {  // core:589
+    float wpts[8][3], dep[8], nrm[3];
+    const int n = box_box(p1, R1, s1, p2, R2, s2, margin, wpts, dep, nrm);
+    const Frame f = make_frame3(V3{nrm[0], nrm[1], nrm[2]});
+    for (int c = 0; c < n; ++c) emit(c, dep[c], V3{wpts[c][0], wpts[c][1], wpts[c][2]}, f.a, f.b, f.c);
   } else if (t1 == G_SPHERE && t2 == G_CYLINDER) {  // core:388
     const float r = s2.x, hh = s2.y;
     const V3 vec = p1 - p2;

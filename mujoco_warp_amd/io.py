@@ -70,7 +70,7 @@ def geom_pairs(mjm):
   return np.stack([g1[keep], g2[keep]], axis=1).astype(np.int32)
 
 
-_SUPPORTED_PAIRS = {(0, 2), (0, 3), (0, 4), (0, 5), (0, 6), (2, 2), (2, 3), (2, 5), (2, 6), (3, 3), (3, 6)}
+_SUPPORTED_PAIRS = {(0, 2), (0, 3), (0, 4), (0, 5), (0, 6), (2, 2), (2, 3), (2, 5), (2, 6), (3, 3), (3, 6), (6, 6)}
 
 
 def _arr(x, dtype):
@@ -146,7 +146,7 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
   m.nC = int(np.sum(mjm.M_rownnz)) if nv else 0
   m.nM = m.nC
   # capsule-box pairs select the kernel instantiation that carries the large colliders (include/mjhip.h)
-  m.heavy_colliders = int(any((int(min(gt[a], gt[b])), int(max(gt[a], gt[b]))) == (3, 6) for a, b in pairs))
+  m.heavy_colliders = int(any((int(min(gt[a], gt[b])), int(max(gt[a], gt[b]))) in ((3, 6), (6, 6)) for a, b in pairs))
   m.is_sparse = False
   m.nv_pad = _get_padded_sizes(nv, 1)[1]
 

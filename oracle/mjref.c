@@ -727,6 +727,289 @@ static int capsule_box(const double* cpos, const double* caxis, double r, double
   return n;
 }
 
+/* rotation that takes face `f` (0..2: +x,+y,+z side; 3..5: -x,-y,-z) of a box to the +z direction (core:557) */
+static void face_rot(int f, double* r) {
+  static const double T[6][9] = {{0, 0, -1, 0, 1, 0, 1, 0, 0}, {1, 0, 0, 0, 0, -1, 0, 1, 0}, {1, 0, 0, 0, 1, 0, 0, 0, 1},
+                                 {0, 0, 1, 0, 1, 0, -1, 0, 0}, {1, 0, 0, 0, 0, 1, 0, -1, 0}, {-1, 0, 0, 0, 1, 0, 0, 0, -1}};
+  memcpy(r, T[f], sizeof(T[f]));
+}
+static void m3mul(double* r, const double* a, const double* b) {
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) r[3 * i + j] = a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j] + a[3 * i + 2] * b[6 + j];
+}
+static void m3T(double* r, const double* a) {
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) r[3 * i + j] = a[3 * j + i];
+}
+
+/* box_box collision_primitive_core.py:589 (MuJoCo's mjc_BoxBox): separating-axis test over the 6 face normals and the 9
+ * edge cross products; the axis of least penetration selects a face-vertex clipping (up to 8 contacts on the face plane) or
+ * an edge-edge configuration.  Returns the number of contacts written to out (dist, pos, frame). */
+static int box_box(const double* p1, const double* R1, const double* s1, const double* p2, const double* R2, const double* s2,
+                   double margin, Con* out) {
+  double d21[3], d12[3], pos21[3], pos12[3], R1T[9], R2T[9], rot21[9], rot12[9], a21[9], a12[9], plen1[3], plen2[3];
+  v3sub(d21, p2, p1);
+  v3sub(d12, p1, p2);
+  matT_mul_vec(pos21, R1, d21);
+  matT_mul_vec(pos12, R2, d12);
+  m3T(R1T, R1);
+  m3T(R2T, R2);
+  m3mul(rot21, R1T, R2);
+  m3T(rot12, rot21);
+  for (int k = 0; k < 9; k++) { a21[k] = fabs(rot21[k]); a12[k] = fabs(rot12[k]); }
+  mat_mul_vec(plen2, a21, s2);
+  mat_mul_vec(plen1, a12, s1);
+  double separation = margin + 3.0 * (s1[0] + s2[0]) + 3.0 * (s1[1] + s2[1]) + 3.0 * (s1[2] + s2[2]);
+  int code = -1;
+  const double tie = 1e-12 * (s1[0] + s1[1] + s1[2] + s2[0] + s2[1] + s2[2]);
+  for (int i = 0; i < 3; i++) { /* face normals */
+    double c1 = -fabs(pos21[i]) + s1[i] + plen2[i], c2 = -fabs(pos12[i]) + s2[i] + plen1[i];
+    if (c1 < -margin || c2 < -margin) return 0;
+    /* ties (flat face-face contact: the two boxes' faces overlap by the same amount) go to the earlier candidate instead
+     * of to round-off; same rule, with a float32-sized guard, in csrc/collide.hpp */
+    if (c1 < separation - tie) { separation = c1; code = i + 3 * (pos21[i] < 0.0); }
+    if (c2 < separation - tie) { separation = c2; code = i + 3 * (pos12[i] < 0.0) + 6; }
+  }
+  double clnorm[3] = {0, 0, 0};
+  int inv = 0, cle1 = 0, cle2 = 0;
+  for (int i = 0; i < 3; i++) { /* edge i of box 1 x edge j of box 2 */
+    for (int j = 0; j < 3; j++) {
+      const double* a = rot12 + 3 * j; /* axis j of box 2 in the frame of box 1 */
+      double cr[3];
+      if (i == 0) v3set(cr, 0.0, -a[2], a[1]);
+      else if (i == 1) v3set(cr, a[2], 0.0, -a[0]);
+      else v3set(cr, -a[1], a[0], 0.0);
+      double len = v3len(cr);
+      if (len < MINVAL) continue;
+      for (int k = 0; k < 3; k++) cr[k] /= len;
+      double bd = v3dot(pos21, cr), c3 = 0.0;
+      for (int k = 0; k < 3; k++) {
+        if (k != i) c3 += s1[k] * fabs(cr[k]);
+        if (k != j) c3 += s2[k] * a21[3 * i + (3 - k - j)] / len;
+      }
+      c3 -= fabs(bd);
+      if (c3 < -margin) return 0;
+      if (c3 < separation * (1.0 - 1e-12)) {
+        separation = c3;
+        cle1 = cle2 = 0;
+        for (int k = 0; k < 3; k++) {
+          if (k != i && ((cr[k] > 0.0) ^ (bd < 0.0))) cle1 += 1 << k;
+          if (k != j && ((rot21[3 * i + (3 - k - j)] > 0.0) ^ (bd < 0.0) ^ (((k - j + 3) % 3) == 1))) cle2 += 1 << k;
+        }
+        code = 12 + 3 * i + j;
+        v3cpy(clnorm, cr);
+        inv = bd < 0.0;
+      }
+    }
+  }
+  if (code == -1) return 0;
+  double pts[8][3], depth[8], rw[9], pw[3], normal[3], hz;
+  int n = 0;
+  if (code < 12) { /* a face of one box against vertices / edges of the other */
+    int f = code % 6, bi = code / 6;
+    double rm[9], rmT[9], r[9], rt[9], pp[3], ss[3], tmp[3];
+    face_rot(f, rm);
+    m3T(rmT, rm);
+    m3mul(r, rm, bi ? rot12 : rot21);
+    mat_mul_vec(pp, rm, bi ? pos12 : pos21);
+    mat_mul_vec(tmp, rm, bi ? s2 : s1);
+    for (int k = 0; k < 3; k++) ss[k] = fabs(tmp[k]);
+    const double* so = bi ? s1 : s2; /* half sizes of the other box */
+    m3T(rt, r);
+    double lx = ss[0], ly = ss[1];
+    hz = ss[2];
+    pp[2] -= hz;
+    int corner = 0;
+    for (int i = 0; i < 3; i++)
+      if (r[6 + i] < 0.0) corner += 1 << i;
+    double lp[3], cn1[3] = {0, 0, 0}, cn2[3] = {0, 0, 0};
+    v3cpy(lp, pp);
+    for (int i = 0; i < 3; i++) v3addscl(lp, lp, rt + 3 * i, so[i] * ((corner >> i) & 1 ? 1.0 : -1.0));
+    int dirs = 0;
+    for (int i = 0; i < 3; i++) {
+      if (fabs(r[6 + i]) < 0.5) {
+        double sc = so[i] * ((corner >> i) & 1 ? -2.0 : 2.0);
+        double* cn = dirs ? cn2 : cn1;
+        for (int k = 0; k < 3; k++) cn[k] = rt[3 * i + k] * sc;
+        dirs++;
+      }
+    }
+    double cand[24][3];
+    int nc = 0;
+    for (int i = 0; i < dirs * dirs; i++) { /* edges of the other box's lowest face against the face rectangle */
+      for (int q = 0; q < 2; q++) {
+        double lav[3], lbv[3];
+        for (int k = 0; k < 3; k++) {
+          lav[k] = lp[k] + (i < 2 ? 0.0 : (i == 2 ? cn1[k] : cn2[k]));
+          lbv[k] = (i == 0 || i == 3) ? cn1[k] : cn2[k];
+        }
+        if (fabs(lbv[q]) > MINVAL) {
+          double br = 1.0 / lbv[q];
+          for (int j = -1; j <= 1; j += 2) {
+            double l = ss[q] * j, c1 = (l - lav[q]) * br;
+            if (c1 < 0.0 || c1 > 1.0) continue;
+            double c2 = lav[1 - q] + lbv[1 - q] * c1;
+            if (fabs(c2) > ss[1 - q]) continue;
+            for (int k = 0; k < 3; k++) cand[nc][k] = lav[k] + c1 * lbv[k];
+            nc++;
+          }
+        }
+      }
+    }
+    if (dirs == 2) { /* rectangle corners inside the other face's parallelogram */
+      double ax = cn1[0], bx = cn2[0], ay = cn1[1], by = cn2[1], C = safe_div(1.0, ax * by - bx * ay);
+      for (int i = 0; i < 4; i++) {
+        double llx = (i / 2) ? lx : -lx, lly = (i % 2) ? ly : -ly, x = llx - lp[0], y = lly - lp[1];
+        double u = (x * by - y * bx) * C, v = (y * ax - x * ay) * C;
+        if (u > 0.0 && v > 0.0 && u < 1.0 && v < 1.0) {
+          v3set(cand[nc], llx, lly, lp[2] + u * cn1[2] + v * cn2[2]);
+          nc++;
+        }
+      }
+    }
+    for (int i = 0; i < (1 << dirs); i++) { /* the other box's corners above the rectangle */
+      double t[3];
+      for (int k = 0; k < 3; k++) t[k] = lp[k] + (double)(i & 1) * cn1[k] + (double)((i & 2) != 0) * cn2[k];
+      if (t[0] > -lx && t[0] < lx && t[1] > -ly && t[1] < ly) { v3cpy(cand[nc], t); nc++; }
+    }
+    for (int i = 0; i < nc && n < 8; i++) {
+      if (cand[i][2] > margin) continue;
+      v3cpy(pts[n], cand[i]);
+      depth[n] = pts[n][2];
+      pts[n][2] *= 0.5;
+      n++;
+    }
+    m3mul(rw, bi ? R2 : R1, rmT);
+    v3cpy(pw, bi ? p2 : p1);
+    for (int k = 0; k < 3; k++) normal[k] = (bi ? -1.0 : 1.0) * rw[3 * k + 2];
+  } else { /* edge against edge */
+    int e1 = (code - 12) / 3, e2 = (code - 12) % 3;
+    int ax1 = 1 - (e2 & 1), ax2 = 2 - (e2 & 2), pax1 = 1 - (e1 & 1), pax2 = 2 - (e1 & 2);
+    if (a21[3 * e1 + ax1] < a21[3 * e1 + ax2]) { int t = ax1; ax1 = ax2; ax2 = t; }
+    if (a12[3 * e2 + pax1] < a12[3 * e2 + pax2]) { int t = pax1; pax1 = pax2; pax2 = t; }
+    double rm[9], rmT[9], pp[3], rnorm[3], r[9], rt[9], tmp[3], s[3];
+    face_rot((cle1 & (1 << pax2)) ? pax2 : pax2 + 3, rm);
+    m3T(rmT, rm);
+    mat_mul_vec(pp, rm, pos21);
+    mat_mul_vec(rnorm, rm, clnorm);
+    m3mul(r, rm, rot21);
+    m3T(rt, r);
+    mat_mul_vec(tmp, rmT, s1);
+    for (int k = 0; k < 3; k++) s[k] = fabs(tmp[k]);
+    double lx = s[0], ly = s[1];
+    hz = s[2];
+    pp[2] -= hz;
+    double q4[4][3]; /* the face of box 2 nearest to box 1, as 4 points */
+    for (int k = 0; k < 3; k++) {
+      double b1 = rt[3 * ax1 + k] * s2[ax1], b2 = rt[3 * ax2 + k] * s2[ax2], be = rt[3 * e2 + k] * s2[e2];
+      double sg1 = (cle2 & (1 << ax1)) ? 1.0 : -1.0, sg2 = (cle2 & (1 << ax2)) ? 1.0 : -1.0;
+      double base0 = pp[k] + b1 * sg1 + b2 * sg2, base2 = pp[k] - b1 * sg1 + b2 * sg2;
+      q4[0][k] = base0 + be; q4[1][k] = base0 - be;
+      q4[2][k] = base2 + be; q4[3][k] = base2 - be;
+    }
+    double axi_lp[3], axi_cn1[3], axi_cn2[3];
+    v3cpy(axi_lp, q4[0]);
+    v3sub(axi_cn1, q4[1], q4[0]);
+    v3sub(axi_cn2, q4[2], q4[0]);
+    if (fabs(rnorm[2]) < MINVAL) return 0;
+    double sgn = inv ? -1.0 : 1.0, innorm = sgn / rnorm[2];
+    double pu[4][3];
+    for (int i = 0; i < 4; i++) { /* project along the contact normal onto the plane z = 0 */
+      v3cpy(pu[i], q4[i]);
+      double c = q4[i][2] * sgn * innorm;
+      for (int k = 0; k < 3; k++) q4[i][k] -= rnorm[k] * c;
+    }
+    double lp[3], cn1[3], cn2[3];
+    v3cpy(lp, q4[0]);
+    v3sub(cn1, q4[1], q4[0]);
+    v3sub(cn2, q4[2], q4[0]);
+    for (int i = 0; i < 4; i++) {
+      for (int q = 0; q < 2; q++) {
+        double la = lp[q] + (i < 2 ? 0.0 : (i == 2 ? cn1[q] : cn2[q])), lb = (i == 0 || i == 3) ? cn1[q] : cn2[q];
+        double lc = lp[1 - q] + (i < 2 ? 0.0 : (i == 2 ? cn1[1 - q] : cn2[1 - q])), ld = (i == 0 || i == 3) ? cn1[1 - q] : cn2[1 - q];
+        double lua[3], lub[3];
+        for (int k = 0; k < 3; k++) {
+          lua[k] = axi_lp[k] + (i < 2 ? 0.0 : (i == 2 ? axi_cn1[k] : axi_cn2[k]));
+          lub[k] = (i == 0 || i == 3) ? axi_cn1[k] : axi_cn2[k];
+        }
+        if (fabs(lb) > MINVAL) {
+          double br = 1.0 / lb;
+          for (int j = -1; j <= 1; j += 2) {
+            if (n == 8) break;
+            double l = s[q] * j, c1 = (l - la) * br;
+            if (c1 < 0.0 || c1 > 1.0) continue;
+            double c2 = lc + ld * c1;
+            if (fabs(c2) > s[1 - q]) continue;
+            if ((lua[2] + lub[2] * c1) * innorm > margin) continue;
+            for (int k = 0; k < 3; k++) pts[n][k] = lua[k] * 0.5 + c1 * lub[k] * 0.5;
+            pts[n][q] += 0.5 * l;
+            pts[n][1 - q] += 0.5 * c2;
+            depth[n] = pts[n][2] * innorm * 2.0;
+            n++;
+          }
+        }
+      }
+    }
+    int nl = n;
+    double ax = cn1[0], bx = cn2[0], ay = cn1[1], by = cn2[1], C = safe_div(1.0, ax * by - bx * ay);
+    for (int i = 0; i < 4; i++) {
+      if (n == 8) break;
+      double llx = (i / 2) ? lx : -lx, lly = (i % 2) ? ly : -ly, x = llx - lp[0], y = lly - lp[1];
+      double u = (x * by - y * bx) * C, v = (y * ax - x * ay) * C;
+      if (nl == 0) {
+        if ((u < 0.0 || u > 1.0) && (v < 0.0 || v > 1.0)) continue;
+      } else if (u < 0.0 || v < 0.0 || u > 1.0 || v > 1.0) continue;
+      u = clampd(u, 0.0, 1.0);
+      v = clampd(v, 0.0, 1.0);
+      double w = 1.0 - u - v, vt[3], dd[3];
+      for (int k = 0; k < 3; k++) vt[k] = pu[0][k] * w + pu[1][k] * u + pu[2][k] * v;
+      v3set(pts[n], llx, lly, 0.0);
+      v3sub(dd, pts[n], vt);
+      double tc1 = v3dot(dd, dd);
+      if (vt[2] > 0.0 && tc1 > margin * margin) continue;
+      for (int k = 0; k < 3; k++) pts[n][k] = 0.5 * (pts[n][k] + vt[k]);
+      depth[n] = sqrt(tc1) * (vt[2] < 0.0 ? -1.0 : 1.0);
+      n++;
+    }
+    int nf = n;
+    for (int i = 0; i < 4; i++) {
+      if (n >= 8) break;
+      double x = pu[i][0], y = pu[i][1];
+      if (nl == 0 && nf != 0) {
+        if ((x < -lx || x > lx) && (y < -ly || y > ly)) continue;
+      } else if (x < -lx || x > lx || y < -ly || y > ly) continue;
+      double c1 = 0.0;
+      for (int j = 0; j < 2; j++) {
+        if (pu[i][j] < -s[j]) c1 += (pu[i][j] + s[j]) * (pu[i][j] + s[j]);
+        else if (pu[i][j] > s[j]) c1 += (pu[i][j] - s[j]) * (pu[i][j] - s[j]);
+      }
+      c1 += pu[i][2] * innorm * pu[i][2] * innorm;
+      if (pu[i][2] > 0.0 && c1 > margin * margin) continue;
+      double tp[3] = {pu[i][0], pu[i][1], 0.0};
+      for (int j = 0; j < 2; j++) {
+        if (pu[i][j] < -s[j]) tp[j] = -s[j] * 0.5;
+        else if (pu[i][j] > s[j]) tp[j] = s[j] * 0.5;
+      }
+      for (int k = 0; k < 3; k++) pts[n][k] = 0.5 * (tp[k] + pu[i][k]);
+      depth[n] = sqrt(c1) * (pu[i][2] < 0.0 ? -1.0 : 1.0);
+      n++;
+    }
+    m3mul(rw, R1, rmT);
+    v3cpy(pw, p1);
+    double nn[3];
+    mat_mul_vec(nn, rw, rnorm);
+    for (int k = 0; k < 3; k++) normal[k] = sgn * nn[k];
+  }
+  for (int i = 0; i < n; i++) {
+    pts[i][2] += hz;
+    mat_mul_vec(out[i].pos, rw, pts[i]);
+    v3add(out[i].pos, out[i].pos, pw);
+    out[i].dist = depth[i];
+    make_frame(out[i].frame, normal);
+  }
+  return n;
+}
+
 static int collide_pair(const RefModel* m, const RefData* d, int g1, int g2, double margin, Con* out) {
   int t1 = m->geom_type[g1], t2 = m->geom_type[g2];
   const double *p1 = d->geom_xpos + 3 * g1, *p2 = d->geom_xpos + 3 * g2;
@@ -874,6 +1157,8 @@ static int collide_pair(const RefModel* m, const RefData* d, int g1, int g2, dou
     n = 1;
   } else if (t1 == G_CAPSULE && t2 == G_BOX) { /* core:1099 */
     n = capsule_box(p1, ax1, s1[0], s1[1], p2, R2, s2, out);
+  } else if (t1 == G_BOX && t2 == G_BOX) { /* core:589 */
+    n = box_box(p1, R1, s1, p2, R2, s2, margin, out);
   } else if (t1 == G_SPHERE && t2 == G_CYLINDER) { /* core:388 */
     double vec[3], aproj[3], pproj[3], nn[3], pos[3], target[3], dist;
     double r = s2[0], hh = s2[1];

