@@ -55,6 +55,7 @@ typedef struct MjhModel {
   /* sizes */
   int nq; int nv; int nu; int na; int nbody; int njnt; int ngeom; int nsite; int nC; int npair;
   int nbodylevel; int ndoflevel; int nv_pad; int neq;
+  int nmocap;          /* mocap bodies (static bodies posed by Data.mocap_pos / mocap_quat, smooth.py:104-108) */
   int heavy_colliders; /* 1: the pair list holds capsule-box or box-box pairs (selects the kernel instantiation that carries them) */
   /* options (types.py:836-905); solver: 0 = PGS (extension, the reference has none: types.py:502), 1 = CG, 2 = Newton */
   int integrator; int cone; int solver; int iterations; int ls_iterations; int disableflags; int enableflags;
@@ -70,6 +71,7 @@ typedef struct MjhModel {
   const int* body_parentid; const int* body_rootid; const int* body_weldid;
   const int* body_jntnum; const int* body_jntadr; const int* body_dofnum; const int* body_dofadr;
   const int* body_lastdof;      /* last dof affecting the body, -1 if static                    */
+  const int* body_mocapid;      /* [nbody] index into Data.mocap_*, -1 for ordinary bodies       */
   const int* body_subtreenum;   /* bodies in the (contiguous, depth-first) subtree, incl. self  */
   const int* body_tree;         /* body ids sorted by tree depth (io.py:495-500)                */
   const int* body_leveladr;     /* [nbodylevel+1] offsets into body_tree                        */
@@ -145,6 +147,7 @@ typedef struct MjhData {
   /* state (types.py:2240-2262) */
   float* time; float* qpos; float* qvel; float* act; float* ctrl; float* qacc_warmstart;
   float* qfrc_applied; float* xfrc_applied;
+  float* mocap_pos; float* mocap_quat;  /* [nworld, nmocap, 3 / 4] (types.py Data.mocap_pos / mocap_quat) */
   /* position-dependent */
   float* xpos; float* xquat; float* xmat; float* xipos; float* ximat; float* xanchor; float* xaxis;
   float* geom_xpos; float* geom_xmat; float* site_xpos; float* site_xmat;
@@ -213,7 +216,7 @@ int mjh_timed_steps(const MjhModel* m, const MjhData* d, int nstep, int step0, f
                     void* stream, float* ms_out, float* per_kernel_ms, int plain_kernels);
 
 const char* mjh_last_error(void);
-#define MJH_ABI_VERSION 4
+#define MJH_ABI_VERSION 5
 int mjh_abi_version(void); /* returns MJH_ABI_VERSION of the library that was loaded */
 
 #ifdef __cplusplus

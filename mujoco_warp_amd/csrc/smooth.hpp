@@ -185,8 +185,12 @@ DEV void fwd_pos_body(const MjhModel& m, const MjhData& d, int first, int last, 
           continue;
         }
         Q4 pq = ld4(xquat + 4 * pid);
-        V3 pos = rot_vec_quat(ld3(body_pos + 3 * b), pq) + ld3(xpos + 3 * pid);
-        Q4 quat = mul_quat(pq, ld4(body_quat + 4 * b));
+        // mocap bodies (children of the world without joints) take their pose from Data.mocap_* (smooth.py:104-108)
+        const int mid = m.nmocap ? m.body_mocapid[b] : -1;
+        const V3 bp = mid >= 0 ? ld3(d.mocap_pos + ((size_t)w * m.nmocap + mid) * 3) : ld3(body_pos + 3 * b);
+        const Q4 bq = mid >= 0 ? ld4(d.mocap_quat + ((size_t)w * m.nmocap + mid) * 4) : ld4(body_quat + 4 * b);
+        V3 pos = rot_vec_quat(bp, pq) + ld3(xpos + 3 * pid);
+        Q4 quat = mul_quat(pq, bq);
         for (int j = jntadr; j < jntadr + jntnum; ++j) {
           const int qa = m.jnt_qposadr[j], t = m.jnt_type[j];
           V3 jp = ld3(jnt_pos + 3 * j), ja = ld3(jnt_axis + 3 * j);

@@ -88,7 +88,7 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
   # ---- validation (io.py:284-360) ----
   if int(getattr(mjm, "neq", 0)) > 0 and (np.asarray(mjm.eq_type) != types.EqType.JOINT).any():
     raise NotImplementedError("only joint equality constraints are implemented")
-  for name in ("ntendon", "nflex", "nhfield", "nmocap", "nplugin"):
+  for name in ("ntendon", "nflex", "nhfield", "nplugin"):
     if int(getattr(mjm, name, 0)) > 0:
       raise NotImplementedError(f"{name} > 0 is outside the hot-path scope of this engine")
   if int(opt.integrator) not in (types.IntegratorType.EULER, types.IntegratorType.RK4, types.IntegratorType.IMPLICITFAST):
@@ -225,7 +225,7 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
     qpos0=_arr(mjm.qpos0, f32).reshape(1, -1), qpos_spring=_arr(mjm.qpos_spring, f32).reshape(1, -1),
     body_parentid=parent, body_rootid=_arr(mjm.body_rootid, i32), body_weldid=_arr(mjm.body_weldid, i32),
     body_jntnum=_arr(mjm.body_jntnum, i32), body_jntadr=_arr(mjm.body_jntadr, i32), body_dofnum=dofnum, body_dofadr=dofadr,
-    body_lastdof=lastdof, body_subtreenum=subtreenum, body_tree=order, body_leveladr=leveladr, body_dofmask=dofmask,
+    body_lastdof=lastdof, body_mocapid=_arr(getattr(mjm, "body_mocapid", np.full(nbody, -1)), i32), body_subtreenum=subtreenum, body_tree=order, body_leveladr=leveladr, body_dofmask=dofmask,
     jnt_type=jnt_type, jnt_qposadr=_arr(mjm.jnt_qposadr, i32), jnt_dofadr=jnt_dofadr, jnt_bodyid=_arr(mjm.jnt_bodyid, i32),
     jnt_limited=_arr(mjm.jnt_limited, i32),
     dof_bodyid=_arr(mjm.dof_bodyid, i32), dof_jntid=dof_jnt, dof_parentid=dof_parent, dof_grpadr=grpadr, dof_tree=dorder,
@@ -328,7 +328,7 @@ def _data_shapes(m, nworld, nconmax, njmax, naconmax):
   W = nworld
   sh = dict(
     time=(W,), qpos=(W, nq), qvel=(W, nv), act=(W, na), ctrl=(W, nu), qacc_warmstart=(W, nv), qfrc_applied=(W, nv),
-    xfrc_applied=(W, nb, 6), xpos=(W, nb, 3), xquat=(W, nb, 4), xmat=(W, nb, 3, 3), xipos=(W, nb, 3), ximat=(W, nb, 3, 3),
+    xfrc_applied=(W, nb, 6), mocap_pos=(W, m.nmocap, 3), mocap_quat=(W, m.nmocap, 4), xpos=(W, nb, 3), xquat=(W, nb, 4), xmat=(W, nb, 3, 3), xipos=(W, nb, 3), ximat=(W, nb, 3, 3),
     xanchor=(W, nj, 3), xaxis=(W, nj, 3), geom_xpos=(W, ng, 3), geom_xmat=(W, ng, 3, 3), site_xpos=(W, ns, 3),
     site_xmat=(W, ns, 3, 3), subtree_com=(W, nb, 3), cinert=(W, nb, 10), cdof=(W, nv, 6), crb=(W, nb, 10), M=(W, nC),
     qLD=(W, nC), qLDiagInv=(W, nv), actuator_length=(W, nu), actuator_moment=(W, nu), actuator_velocity=(W, nu),
@@ -378,6 +378,7 @@ def _alloc_data(m: types.Model, nworld, nconmax, njmax, naconmax):
   d.ws_order.assign(np.arange(nworld, dtype=np.int32))
   if m.neq:
     d.eq_active.assign(np.tile(m.eq_active0, (nworld, 1)))
+  _reset_mocap(m, d, None)
   d.nmaxpyramid = m.nmaxpyramid
   d.world_offset = 0
   d.concap = contact_cap(nconmax)
@@ -447,7 +448,9 @@ def put_data(mjm, mjd, nworld: int = 1, nconmax: Optional[int] = None, nccdmax: 
   """Moves data from host to a device (reference io.py:1890): the single host state is tiled nworld times."""
   m = mjm if isinstance(mjm, types.Model) else _model_of(mjm)
   d = _alloc_data(m, nworld, nconmax, njmax, naconmax)
-  for name in ("qpos", "qvel", "act", "ctrl", "qacc_warmstart", "qfrc_applied", "xfrc_applied"):
+  for name in ("qpos", "qvel", "act", "ctrl", "qacc_warmstart", "qfrc_applied", "xfrc_applied", "mocap_pos", "mocap_quat"):
+    if not hasattr(mjd, name):
+      continue
     src = np.asarray(getattr(mjd, name), dtype=np.float32)
     dst = getattr(d, name)
     if dst.size:
@@ -459,7 +462,7 @@ def put_data(mjm, mjd, nworld: int = 1, nconmax: Optional[int] = None, nccdmax: 
 def get_data_into(result, mjm, d: types.Data, world_id: int = 0):
   """Gets data from a device into an existing host MjData-like object (reference io.py:2184)."""
   w = world_id
-  for name in ("qpos", "qvel", "act", "ctrl", "qacc_warmstart", "qfrc_applied", "xfrc_applied", "qacc", "xpos", "xquat",
+  for name in ("qpos", "qvel", "act", "ctrl", "qacc_warmstart", "qfrc_applied", "xfrc_applied", "mocap_pos", "mocap_quat", "qacc", "xpos", "xquat",
                "xmat", "xipos", "ximat", "xanchor", "xaxis", "geom_xpos", "geom_xmat", "subtree_com", "cinert", "cdof", "crb",
                "qLD", "qLDiagInv", "cvel", "cdof_dot", "qfrc_bias", "qfrc_passive", "qfrc_spring", "qfrc_damper",
                "qfrc_actuator", "qfrc_smooth", "qacc_smooth", "qfrc_constraint", "actuator_force", "actuator_length",
@@ -511,6 +514,24 @@ def reset_data_keyframe(m: types.Model, d: types.Data, key: int, reset=None):
                float(m.key_time[key]), mask)
 
 
+def _reset_mocap(m, d, mask):
+  """mocap_pos / mocap_quat = the model pose of the mocap bodies (reference io.py:2552 reset_mocap)."""
+  if not m.nmocap:
+    return
+  mid = m.body_mocapid.numpy()
+  order = np.argsort(mid[mid >= 0])
+  bodies = np.flatnonzero(mid >= 0)[order]
+  for name, src in (("mocap_pos", m.body_pos), ("mocap_quat", m.body_quat)):
+    val = src.numpy()[np.arange(d.nworld) % src.shape[0]][:, bodies]
+    dst = getattr(d, name)
+    if mask is None:
+      dst.assign(val)
+    else:
+      cur = dst.numpy().copy()
+      cur[mask] = val[mask]
+      dst.assign(cur)
+
+
 def _reset_state(m, d, qpos, qvel, act, ctrl, time, mask):
   def put(dst, val):
     if dst.size == 0:
@@ -533,6 +554,7 @@ def _reset_state(m, d, qpos, qvel, act, ctrl, time, mask):
   put(d.qfrc_applied, None)
   put(d.xfrc_applied, None)
   put(d.time, np.full(d.time.shape, time, dtype=np.float32))
+  _reset_mocap(m, d, mask)
   if m.neq:
     put(d.eq_active, np.tile(m.eq_active0, (d.nworld, 1)))
   if mask is None:

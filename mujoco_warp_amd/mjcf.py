@@ -120,8 +120,9 @@ class MjData:
     self.qacc_warmstart = np.zeros(m.nv)
     self.qfrc_applied = np.zeros(m.nv)
     self.xfrc_applied = np.zeros((m.nbody, 6))
-    self.mocap_pos = np.zeros((m.nmocap, 3))
-    self.mocap_quat = np.zeros((m.nmocap, 4))
+    mb = [int(np.flatnonzero(m.body_mocapid == k)[0]) for k in range(m.nmocap)]
+    self.mocap_pos = np.array(m.body_pos[mb], dtype=np.float64).reshape(m.nmocap, 3)
+    self.mocap_quat = np.array(m.body_quat[mb], dtype=np.float64).reshape(m.nmocap, 4)
     self.qacc = np.zeros(m.nv)
     self.ncon = 0
     self.nefc = 0
@@ -699,8 +700,8 @@ def _compile(root, base_dir):
     b.quat = _orientation(elem.attrib, compiler)
     b.gravcomp = float(elem.get("gravcomp", 0.0))
     b.mocap = _bool(elem.get("mocap", "false")) or False
-    if b.mocap:
-      raise NotImplementedError("mocap bodies")
+    if b.mocap and parentid != 0:
+      raise ValueError("mocap bodies must be children of the world")
     b.inertial, b.joints, b.geoms = None, [], []
     bodies.append(b)
     bid = len(bodies) - 1
@@ -777,6 +778,12 @@ def _compile(root, base_dir):
   m.body_gravcomp = np.array([b.gravcomp for b in bodies])
   m.body_mocapid = np.full(nbody, -1, dtype=np.int32)
   m.nmocap = 0
+  for i, b in enumerate(bodies):
+    if b.mocap:
+      if b.joints:
+        raise ValueError("mocap bodies cannot have joints")
+      m.body_mocapid[i] = m.nmocap
+      m.nmocap += 1
 
   # joints / dofs
   jl = []

@@ -169,9 +169,12 @@ void ref_kinematics(const RefModel* m, RefData* d) {
       continue;
     }
     double pos[3], quat[4];
-    rot_vec_quat(pos, m->body_pos + 3 * b, d->xquat + 4 * pid);
+    int mid = m->nmocap ? m->body_mocapid[b] : -1; /* mocap bodies are posed by Data (smooth.py:104-108) */
+    const double* bp = mid >= 0 ? d->mocap_pos + 3 * mid : m->body_pos + 3 * b;
+    const double* bq = mid >= 0 ? d->mocap_quat + 4 * mid : m->body_quat + 4 * b;
+    rot_vec_quat(pos, bp, d->xquat + 4 * pid);
     v3add(pos, pos, d->xpos + 3 * pid);
-    mul_quat(quat, d->xquat + 4 * pid, m->body_quat + 4 * b);
+    mul_quat(quat, d->xquat + 4 * pid, bq);
     for (int j = jntadr; j < jntadr + jntnum; j++) {
       int qa = m->jnt_qposadr[j], t = m->jnt_type[j];
       double anchor[3], axis[3], tmp[3];

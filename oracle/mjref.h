@@ -29,6 +29,7 @@ typedef struct RefModel {
   int neq;
   int njmax;
   int nconmax;
+  int nmocap;
   int integrator;
   int cone;
   int solver;
@@ -44,6 +45,7 @@ typedef struct RefModel {
   double* qpos0;
   double* qpos_spring;
   int* body_parentid;
+  int* body_mocapid;
   int* body_rootid;
   int* body_weldid;
   int* body_jntnum;
@@ -138,6 +140,8 @@ typedef struct RefData {
   double* qacc_warmstart;
   double* qfrc_applied;
   double* xfrc_applied;
+  double* mocap_pos;
+  double* mocap_quat;
   double* xpos;
   double* xquat;
   double* xmat;

@@ -102,7 +102,7 @@ def filtered_geom_pairs(mjm):
 
 _SIZES = {
   "qpos": "nq", "qvel": "nv", "act": "na", "ctrl": "nu", "qacc_warmstart": "nv", "qfrc_applied": "nv",
-  "xfrc_applied": ("nbody", 6), "xpos": ("nbody", 3), "xquat": ("nbody", 4), "xmat": ("nbody", 9), "xipos": ("nbody", 3),
+  "xfrc_applied": ("nbody", 6), "mocap_pos": ("nmocap", 3), "mocap_quat": ("nmocap", 4), "xpos": ("nbody", 3), "xquat": ("nbody", 4), "xmat": ("nbody", 9), "xipos": ("nbody", 3),
   "ximat": ("nbody", 9), "xanchor": ("njnt", 3), "xaxis": ("njnt", 3), "geom_xpos": ("ngeom", 3), "geom_xmat": ("ngeom", 9),
   "subtree_com": ("nbody", 3), "cinert": ("nbody", 10), "cdof": ("nv", 6), "crb": ("nbody", 10), "M": "nC", "qLD": "nC",
   "qLDiagInv": "nv", "cvel": ("nbody", 6), "cdof_dot": ("nv", 6), "qfrc_spring": "nv", "qfrc_damper": "nv",
@@ -132,6 +132,7 @@ class RefSim:
     pairs = filtered_geom_pairs(mjm)
     sizes["npair"] = len(pairs)
     sizes["neq"] = int(getattr(mjm, "neq", 0))
+    sizes["nmocap"] = int(getattr(mjm, "nmocap", 0))
     scalars = dict(
       integrator=int(opt.integrator if integrator is None else integrator), cone=int(opt.cone),
       solver=int(opt.solver if solver is None else solver),
@@ -186,6 +187,10 @@ class RefSim:
         self.act[:] = m.key_act[key]
     self.cd.time = 0.0
     self.cd.overflow = 0
+    for b in range(m.nbody):  # mocap bodies start at their model pose
+      if int(m.body_mocapid[b]) >= 0:
+        self.mocap_pos[int(m.body_mocapid[b])] = m.body_pos[b]
+        self.mocap_quat[int(m.body_mocapid[b])] = m.body_quat[b]
 
   def __getattr__(self, name):
     arr = self.__dict__.get("arr", {})

@@ -230,3 +230,19 @@ BOX_BOX_XML = """
   </keyframe>
 </mujoco>
 """
+
+
+# a mocap platform (posed through Data.mocap_pos / mocap_quat) carrying a ball and tilting under a box
+MOCAP_XML = """
+<mujoco>
+  <option timestep="0.003"/>
+  <worldbody>
+    <geom name="floor" type="plane" size="0 0 .05"/>
+    <body name="tray" mocap="true" pos="0 0 .3"><geom type="box" size=".25 .2 .02"/></body>
+    <body name="ball" pos=".05 0 .3699"><freejoint/><geom type="sphere" size=".05"/></body>
+    <body name="crate" pos="-.1 .05 .3599"><freejoint/><geom type="box" size=".05 .04 .04"/></body>
+    <body name="pole" mocap="true" pos=".6 0 .2" euler="0 20 0"><geom type="capsule" size=".03 .2"/></body>
+    <body name="arm" pos=".6 0 .6"><joint type="hinge" axis="0 1 0" damping=".05"/><geom type="capsule" fromto="0 0 0 0 0 -.25" size=".03"/></body>
+  </worldbody>
+</mujoco>
+"""

@@ -250,6 +250,37 @@ def test_box_box_collider(warm):
     assert relerr(d.qvel.numpy()[0], s.qvel) <= 3e-3
 
 
+def test_mocap_bodies():
+  """Mocap bodies (smooth.py:104-108): static bodies posed per world through Data.mocap_pos / mocap_quat; a tray that rises and
+  tilts under a ball and a crate, a pole swept against a hinged arm."""
+  mjm = mjw.mjcf.from_xml_string(conftest.MOCAP_XML)
+  assert mjm.nmocap == 2
+  s, m, d = _pair(mjm, nworld=3, nconmax=32, njmax=96, warm_steps=10, noise=False)
+  assert d.mocap_pos.shape == (3, 2, 3) and d.mocap_quat.shape == (3, 2, 4)
+  np.testing.assert_allclose(d.mocap_pos.numpy()[1], [[0, 0, 0.3], [0.6, 0, 0.2]], atol=1e-7)
+  nm = mjw._npmath
+  for i in range(60):
+    tilt = 0.002 * i
+    s.mocap_pos[0] = [0.0, 0.0, 0.3 + 0.0004 * i]
+    s.mocap_quat[0] = nm.axis_angle_to_quat(np.array([0.0, 1.0, 0.0]), tilt)
+    s.mocap_pos[1] = [0.6 - 0.002 * i, 0.0, 0.2]
+    d.mocap_pos.assign(np.tile(s.mocap_pos.astype(np.float32), (3, 1, 1)))
+    d.mocap_quat.assign(np.tile(s.mocap_quat.astype(np.float32), (3, 1, 1)))
+    _sync(s, d)
+    if i % 20 == 0:
+      s.forward()
+      mjw.forward(m, d)
+      _check_fields(s, d, ("xpos", "xquat", "geom_xpos", "geom_xmat"), SMOOTH)
+      _check_contacts_and_rows(s, d, mjm, dist_atol=5e-7)
+    mjw.step(m, d)
+    s.step()
+    assert relerr(d.qpos.numpy()[1], s.qpos) <= 1e-5
+    assert relerr(d.qvel.numpy()[1], s.qvel) <= 3e-3
+  assert s.ncon >= 5  # ball and crate on the tray (the pole has pushed the arm aside)
+  mjw.reset_data(m, d)
+  np.testing.assert_allclose(d.mocap_pos.numpy()[2], [[0, 0, 0.3], [0.6, 0, 0.2]], atol=1e-7)
+
+
 def test_sphere_cylinder_rim_regime():
   """10 steps in, the small sphere still rolls over the cylinder's rim (the 40-step state above only has cap and side)."""
   mjm = mjw.mjcf.from_xml_string(conftest.SPHERE_CYLINDER_XML)
