@@ -55,8 +55,9 @@ typedef struct MjhModel {
   /* sizes */
   int nq; int nv; int nu; int na; int nbody; int njnt; int ngeom; int nsite; int nC; int npair;
   int nbodylevel; int ndoflevel; int nv_pad; int neq;
+  int nexplicit;       /* explicit <contact><pair> entries (pair_* tables below); 0: every pair mixes its geoms' parameters */
   int nmocap;          /* mocap bodies (static bodies posed by Data.mocap_pos / mocap_quat, smooth.py:104-108) */
-  int heavy_colliders; /* 1: the pair list holds capsule-box or box-box pairs (selects the kernel instantiation that carries them) */
+  int heavy_colliders; /* 1: capsule-box / box-box pairs or explicit contact pairs present (selects the kernel instantiation that carries them) */
   /* options (types.py:836-905); solver: 0 = PGS (extension, the reference has none: types.py:502), 1 = CG, 2 = Newton */
   int integrator; int cone; int solver; int iterations; int ls_iterations; int disableflags; int enableflags;
   const float* opt_timestep; int opt_timestep_nb;
@@ -119,6 +120,10 @@ typedef struct MjhModel {
   const float* geom_margin; int geom_margin_nb;
   const float* geom_gap; int geom_gap_nb;
   const int* nxn_geom_pair;     /* [npair, 2] pre-filtered geom pairs, upper-triangular order (io.py:551-640) */
+  const int* nxn_pairid;        /* [npair] explicit pair index or -1 (io.py:575-590)             */
+  /* explicit contact pairs (types.py Model.pair_*): parameters that replace the geom mixing */
+  const int* pair_dim; const float* pair_friction; const float* pair_solref; const float* pair_solreffriction;
+  const float* pair_solimp; const float* pair_margin; const float* pair_gap;
   /* sites */
   const int* site_bodyid;
   const float* site_pos; int site_pos_nb;
@@ -216,7 +221,7 @@ int mjh_timed_steps(const MjhModel* m, const MjhData* d, int nstep, int step0, f
                     void* stream, float* ms_out, float* per_kernel_ms, int plain_kernels);
 
 const char* mjh_last_error(void);
-#define MJH_ABI_VERSION 5
+#define MJH_ABI_VERSION 6
 int mjh_abi_version(void); /* returns MJH_ABI_VERSION of the library that was loaded */
 
 #ifdef __cplusplus

@@ -666,8 +666,22 @@ struct PairParams {
 };
 
 // collision_core.py:297-414
-DEV PairParams contact_params(const MjhModel& m, int w, int g1, int g2) {
+DEV PairParams contact_params(const MjhModel& m, int w, int g1, int g2, int pid = -1) {
   PairParams p;
+  if (pid >= 0) {  // explicit <contact><pair>: its own parameters (collision_core.py contact_params, pairid >= 0)
+    p.condim = m.pair_dim[pid];
+    for (int k = 0; k < 5; ++k) {
+      p.friction[k] = fmaxf(MJ_MINMU, m.pair_friction[5 * pid + k]);
+      p.solimp[k] = m.pair_solimp[5 * pid + k];
+    }
+    for (int k = 0; k < 2; ++k) {
+      p.solref[k] = m.pair_solref[2 * pid + k];
+      p.solreffriction[k] = m.pair_solreffriction[2 * pid + k];
+    }
+    p.margin = m.pair_margin[pid];
+    p.gap = m.pair_gap[pid];
+    return p;
+  }
   const int ng = m.ngeom;
   const float* gm = bf(m.geom_margin, m.geom_margin_nb, w, ng);
   const float* gg = bf(m.geom_gap, m.geom_gap_nb, w, ng);
@@ -733,8 +747,9 @@ __host__ __device__ inline int collide_lds_words(int ngeom, int npair) {
   return 12 * ngeom + ((npair + 3) / 4) * 4 + ((npair + 3) / 4) * 4 + CON_WINDOW * CON_LDS;
 }
 
-// HEAVY: the instantiation that also carries the large colliders (capsule-box); models without such pairs run the light one,
-// whose register footprint (and with it the occupancy of k_mid) is unchanged
+// HEAVY: the instantiation that also carries the large colliders (capsule-box, box-box) and the explicit <contact><pair>
+// parameter tables; models without them run the light one, whose register footprint (and with it the occupancy of k_mid: 125
+// VGPRs, exactly four waves per SIMD) is unchanged.  (Measured: the pair-id lookups alone cost the light k_mid 20 us.)
 template <int G, bool HEAVY = false>
 DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const Blk& b, int stride_words = 0) {
   const int lig = threadIdx.x & (G - 1), gib = threadIdx.x / G;
@@ -773,7 +788,8 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
     if (p < npair) {
       const int g1 = m.nxn_geom_pair[2 * p], g2 = m.nxn_geom_pair[2 * p + 1];
       const float rb1 = rbound[g1], rb2 = rbound[g2];
-      const float mg = gmargin[g1] + ggap[g1] + gmargin[g2] + ggap[g2];
+      const int pid = (HEAVY && m.nexplicit) ? m.nxn_pairid[p] : -1;
+      const float mg = pid >= 0 ? m.pair_margin[pid] + m.pair_gap[pid] : gmargin[g1] + ggap[g1] + gmargin[g2] + ggap[g2];
       V3 x1 = ld3(gxpos + 3 * g1), x2 = ld3(gxpos + 3 * g2);
       if (rb1 == 0.0f || rb2 == 0.0f) {
         if (rb1 == 0.0f) {
@@ -817,8 +833,9 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
     if (ci < ncand) {
       int g1, g2, t1, t2;
       load_pair(cand[ci], g1, g2, t1, t2);
-      const float margin = gmargin[g1] + gmargin[g2];
-      const float lim = margin + ggap[g1] + ggap[g2];
+      const int pid = (HEAVY && m.nexplicit) ? m.nxn_pairid[cand[ci]] : -1;
+      const float margin = pid >= 0 ? m.pair_margin[pid] : gmargin[g1] + gmargin[g2];
+      const float lim = margin + (pid >= 0 ? m.pair_gap[pid] : ggap[g1] + ggap[g2]);
       collide_pair<HEAVY>(t1, t2, ld3(gxpos + 3 * g1), gxmat + 9 * g1, ld3(gsize + 3 * g1), ld3(gxpos + 3 * g2), gxmat + 9 * g2,
                    ld3(gsize + 3 * g2), margin, [&](int k, float dist, V3, V3, V3, V3) { mask |= dist < lim ? (1u << (k & 7)) : 0u; });
     }
@@ -857,8 +874,9 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
       if (mask == 0u || slot >= wend || send <= wbase) continue;
       int g1, g2, t1, t2;
       load_pair(cand[ci], g1, g2, t1, t2);
-      const float margin = gmargin[g1] + gmargin[g2];
-      const PairParams pp = contact_params(m, w, g1, g2);
+      const int pid = (HEAVY && m.nexplicit) ? m.nxn_pairid[cand[ci]] : -1;
+      const PairParams pp = contact_params(m, w, g1, g2, pid);
+      const float margin = pp.margin;
       collide_pair<HEAVY>(t1, t2, ld3(gxpos + 3 * g1), gxmat + 9 * g1, ld3(gsize + 3 * g1), ld3(gxpos + 3 * g2), gxmat + 9 * g2,
                    ld3(gsize + 3 * g2), margin, [&](int cid, float dist, V3 pos, V3 fa, V3 fb, V3 fc) {
                      if (!((mask >> (cid & 7)) & 1u)) return;

@@ -70,6 +70,22 @@ def geom_pairs(mjm):
   return np.stack([g1[keep], g2[keep]], axis=1).astype(np.int32)
 
 
+def geom_pairs_with_ids(mjm):
+  """(pairs, pairid): the filtered pairs plus the explicit <contact><pair> entries, still in upper-triangular order; pairid is
+  the explicit pair's index (its parameters override the geom mixing and it is included whatever the filters say) or -1
+  (reference io.py:575-590 nxn_pairid)."""
+  pairs = geom_pairs(mjm)
+  npair = int(getattr(mjm, "npair", 0))
+  if not npair:
+    return pairs, np.full(len(pairs), -1, dtype=np.int32)
+  table = {(int(a), int(b)): -1 for a, b in pairs}
+  for i in range(npair):
+    a, b = int(mjm.pair_geom1[i]), int(mjm.pair_geom2[i])
+    table[(min(a, b), max(a, b))] = i
+  keys = sorted(table)
+  return np.array(keys, dtype=np.int32).reshape(-1, 2), np.array([table[k] for k in keys], dtype=np.int32)
+
+
 _SUPPORTED_PAIRS = {(0, 2), (0, 3), (0, 4), (0, 5), (0, 6), (2, 2), (2, 3), (2, 5), (2, 6), (3, 3), (3, 6), (6, 6)}
 
 
@@ -127,13 +143,21 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
                                                   | types.EnableBit.INVDISCRETE)
   if unsupported_enable:
     raise NotImplementedError(f"enable flags {types.EnableBit(unsupported_enable)!r} are not implemented.")
-  pairs = geom_pairs(mjm)
+  pairs, pairid = geom_pairs_with_ids(mjm)
   gt = np.asarray(mjm.geom_type)
   for a, b in pairs:
     t = (int(min(gt[a], gt[b])), int(max(gt[a], gt[b])))
     if t not in _SUPPORTED_PAIRS:
       raise NotImplementedError(f"collision between geom types {t} is not implemented yet")
   condims = set(int(c) for c in np.unique(np.asarray(mjm.geom_condim)[np.unique(pairs)])) if len(pairs) else set()
+  nexplicit = int(getattr(mjm, "npair", 0))
+  if nexplicit:
+    condims |= set(int(c) for c in np.asarray(mjm.pair_dim))
+    fr = np.asarray(mjm.pair_friction, dtype=np.float64).reshape(-1, 5)
+    if (fr[:, 0] != fr[:, 1]).any() or (fr[:, 3] != fr[:, 4]).any():
+      raise NotImplementedError("explicit contact pairs with anisotropic friction (tangent1 != tangent2 or roll1 != roll2)")
+    if np.asarray(mjm.pair_solreffriction).any():
+      raise NotImplementedError("explicit contact pairs with solreffriction (only elliptic friction rows would use it)")
   if not condims <= {1, 3, 4, 6}:
     raise NotImplementedError(f"unsupported condim values {condims}")
 
@@ -145,8 +169,8 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
     setattr(m, name, int(getattr(mjm, name, 0)))
   m.nC = int(np.sum(mjm.M_rownnz)) if nv else 0
   m.nM = m.nC
-  # capsule-box pairs select the kernel instantiation that carries the large colliders (include/mjhip.h)
-  m.heavy_colliders = int(any((int(min(gt[a], gt[b])), int(max(gt[a], gt[b]))) in ((3, 6), (6, 6)) for a, b in pairs))
+  # capsule-box / box-box pairs and explicit contact pairs select the kernel instantiation that carries them (include/mjhip.h)
+  m.heavy_colliders = int(any((int(min(gt[a], gt[b])), int(max(gt[a], gt[b]))) in ((3, 6), (6, 6)) for a, b in pairs) or int(getattr(mjm, "npair", 0)) > 0)
   m.is_sparse = False
   m.nv_pad = _get_padded_sizes(nv, 1)[1]
 
@@ -232,7 +256,12 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
     dof_leveladr=dleveladr,
     M_rownnz=_arr(mjm.M_rownnz, i32), M_rowadr=_arr(mjm.M_rowadr, i32), M_colind=_arr(mjm.M_colind, i32),
     geom_type=_arr(mjm.geom_type, i32), geom_condim=_arr(mjm.geom_condim, i32), geom_bodyid=_arr(mjm.geom_bodyid, i32),
-    geom_priority=_arr(mjm.geom_priority, i32), nxn_geom_pair=pairs,
+    geom_priority=_arr(mjm.geom_priority, i32), nxn_geom_pair=pairs, nxn_pairid=pairid,
+    pair_dim=_arr(getattr(mjm, "pair_dim", np.zeros(0)), i32), pair_friction=_arr(getattr(mjm, "pair_friction", np.zeros((0, 5))), f32).reshape(-1, 5),
+    pair_solref=_arr(getattr(mjm, "pair_solref", np.zeros((0, 2))), f32).reshape(-1, 2),
+    pair_solreffriction=_arr(getattr(mjm, "pair_solreffriction", np.zeros((0, 2))), f32).reshape(-1, 2),
+    pair_solimp=_arr(getattr(mjm, "pair_solimp", np.zeros((0, 5))), f32).reshape(-1, 5),
+    pair_margin=_arr(getattr(mjm, "pair_margin", np.zeros(0)), f32), pair_gap=_arr(getattr(mjm, "pair_gap", np.zeros(0)), f32),
     site_bodyid=_arr(getattr(mjm, "site_bodyid", np.zeros(0)), i32),
     actuator_dyntype=_arr(mjm.actuator_dyntype, i32), actuator_gaintype=_arr(mjm.actuator_gaintype, i32),
     actuator_biastype=_arr(mjm.actuator_biastype, i32), actuator_trnid=_arr(mjm.actuator_trnid, i32).reshape(-1, 2),
@@ -281,6 +310,7 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
       setattr(m, name, da)
   m.opt, m.stat = o, s
   m.npair = int(len(pairs))
+  m.nexplicit = nexplicit
   m.nxn_geom_pair_filtered = m.nxn_geom_pair
   m.nbodylevel, m.ndoflevel = nlevel, ndlevel
   m.nmaxcondim = int(max(condims)) if condims else 1

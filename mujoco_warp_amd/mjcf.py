@@ -1102,9 +1102,34 @@ def _compile(root, base_dir):
         b2 = m.body_names.index(child.get("body2"))
         lo, hi = min(b1, b2), max(b1, b2)
         sig.append((lo << 16) + hi)
-      elif child.tag == "pair":
-        raise NotImplementedError("explicit contact <pair>")
     m.exclude_signature = np.array(sig, dtype=np.int32)
+    # explicit pairs: unspecified attributes take the values the two geoms would mix to (MuJoCo compiler semantics)
+    prs = [child for child in ce if child.tag == "pair"]
+    m.npair = len(prs)
+    m.pair_geom1 = np.zeros(m.npair, dtype=np.int32)
+    m.pair_geom2 = np.zeros(m.npair, dtype=np.int32)
+    m.pair_dim = np.zeros(m.npair, dtype=np.int32)
+    m.pair_friction = np.zeros((m.npair, 5))
+    m.pair_solref = np.zeros((m.npair, 2))
+    m.pair_solreffriction = np.zeros((m.npair, 2))
+    m.pair_solimp = np.zeros((m.npair, 5))
+    m.pair_margin = np.zeros(m.npair)
+    m.pair_gap = np.zeros(m.npair)
+    for i, child in enumerate(prs):
+      base, explicit = _resolve("pair", child, table, None)
+      a = dict(base)
+      a.update(explicit)
+      g1, g2 = m.geom_names.index(a["geom1"]), m.geom_names.index(a["geom2"])
+      mix = mixed_contact_params(m, g1, g2)
+      m.pair_geom1[i], m.pair_geom2[i] = g1, g2
+      m.pair_dim[i] = int(a.get("condim", mix["condim"]))
+      fr = _floats(a["friction"]) if "friction" in a else []
+      m.pair_friction[i] = np.maximum(1e-5, np.concatenate([fr, mix["friction"][len(fr):]]))
+      m.pair_solref[i] = _vec(a, "solref", mix["solref"])
+      m.pair_solreffriction[i] = _vec(a, "solreffriction", [0.0, 0.0])
+      m.pair_solimp[i] = _vec(a, "solimp", mix["solimp"])
+      m.pair_margin[i] = float(a.get("margin", mix["margin"]))
+      m.pair_gap[i] = float(a.get("gap", mix["gap"]))
   m.nexclude = len(m.exclude_signature)
 
   # keyframes
@@ -1138,6 +1163,26 @@ def _compile(root, base_dir):
     if "meaninertia" in st.attrib:
       m.stat.meaninertia = float(st.get("meaninertia"))
   return m
+
+
+def mixed_contact_params(m, g1, g2):
+  """Contact parameters two geoms mix to (reference collision_core.py:297-414): priority, then solmix-weighted."""
+  s1, s2 = float(m.geom_solmix[g1]), float(m.geom_solmix[g2])
+  p1, p2 = int(m.geom_priority[g1]), int(m.geom_priority[g2])
+  f1, f2 = np.asarray(m.geom_friction[g1], dtype=np.float64), np.asarray(m.geom_friction[g2], dtype=np.float64)
+  if p1 > p2:
+    mix, condim, f = 1.0, int(m.geom_condim[g1]), f1
+  elif p2 > p1:
+    mix, condim, f = 0.0, int(m.geom_condim[g2]), f2
+  else:
+    small1, small2 = s1 < MJ_MINVAL, s2 < MJ_MINVAL
+    mix = 0.5 if (small1 and small2) else 0.0 if small1 else 1.0 if small2 else s1 / (s1 + s2)
+    condim, f = max(int(m.geom_condim[g1]), int(m.geom_condim[g2])), np.maximum(f1, f2)
+  r1, r2 = np.asarray(m.geom_solref[g1]), np.asarray(m.geom_solref[g2])
+  solref = mix * r1 + (1 - mix) * r2 if (r1[0] > 0 and r2[0] > 0) else np.minimum(r1, r2)
+  return {"condim": condim, "friction": np.array([f[0], f[0], f[1], f[2], f[2]]), "solref": solref,
+          "solimp": mix * np.asarray(m.geom_solimp[g1]) + (1 - mix) * np.asarray(m.geom_solimp[g2]),
+          "margin": float(m.geom_margin[g1] + m.geom_margin[g2]), "gap": float(m.geom_gap[g1] + m.geom_gap[g2])}
 
 
 def _parse_option(elem, opt):

@@ -1195,8 +1195,16 @@ static int collide_pair(const RefModel* m, const RefData* d, int g1, int g2, dou
 }
 
 /* collision_core.py:321-414 (priority/solmix mixing) + 297-318 (margin/gap) */
-static void contact_params(const RefModel* m, int g1, int g2, int* condim, double* friction, double* solref,
+static void contact_params(const RefModel* m, int g1, int g2, int pid, int* condim, double* friction, double* solref,
                            double* solreffriction, double* solimp, double* margin, double* gap) {
+  if (pid >= 0) { /* explicit pair: its own parameters */
+    *condim = m->xpair_dim[pid];
+    for (int k = 0; k < 5; k++) { friction[k] = fmax(MINMU, m->xpair_friction[5 * pid + k]); solimp[k] = m->xpair_solimp[5 * pid + k]; }
+    for (int k = 0; k < 2; k++) { solref[k] = m->xpair_solref[2 * pid + k]; solreffriction[k] = m->xpair_solreffriction[2 * pid + k]; }
+    *margin = m->xpair_margin[pid];
+    *gap = m->xpair_gap[pid];
+    return;
+  }
   *margin = m->geom_margin[g1] + m->geom_margin[g2];
   *gap = m->geom_gap[g1] + m->geom_gap[g2];
   double s1 = m->geom_solmix[g1], s2 = m->geom_solmix[g2], mix;
@@ -1229,7 +1237,9 @@ void ref_collision(const RefModel* m, RefData* d) {
   for (int p = 0; p < m->npair; p++) {
     int g1 = m->pair_geom[2 * p], g2 = m->pair_geom[2 * p + 1];
     double rb1 = m->geom_rbound[g1], rb2 = m->geom_rbound[g2];
-    double mg = m->geom_margin[g1] + m->geom_gap[g1] + m->geom_margin[g2] + m->geom_gap[g2];
+    int pid = m->nexplicit ? m->nxn_pairid[p] : -1;
+    double mg = pid >= 0 ? m->xpair_margin[pid] + m->xpair_gap[pid]
+                         : m->geom_margin[g1] + m->geom_gap[g1] + m->geom_margin[g2] + m->geom_gap[g2];
     const double *x1 = d->geom_xpos + 3 * g1, *x2 = d->geom_xpos + 3 * g2;
     double dif[3];
     int pass = 1;
@@ -1255,7 +1265,7 @@ void ref_collision(const RefModel* m, RefData* d) {
     if (m->geom_type[g1] > m->geom_type[g2]) { int t = g1; g1 = g2; g2 = t; }
     int condim;
     double friction[5], solref[2], solreffriction[2], solimp[5], margin, gap;
-    contact_params(m, g1, g2, &condim, friction, solref, solreffriction, solimp, &margin, &gap);
+    contact_params(m, g1, g2, pid, &condim, friction, solref, solreffriction, solimp, &margin, &gap);
     Con out[8];
     int n = collide_pair(m, d, g1, g2, margin, out);
     for (int k = 0; k < n; k++) {

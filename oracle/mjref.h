@@ -30,6 +30,7 @@ typedef struct RefModel {
   int njmax;
   int nconmax;
   int nmocap;
+  int nexplicit;
   int integrator;
   int cone;
   int solver;
@@ -100,6 +101,14 @@ typedef struct RefModel {
   double* geom_margin;
   double* geom_gap;
   int* pair_geom;
+  int* nxn_pairid;      /* explicit <contact><pair> index or -1, per filtered pair */
+  int* xpair_dim;
+  double* xpair_friction;
+  double* xpair_solref;
+  double* xpair_solreffriction;
+  double* xpair_solimp;
+  double* xpair_margin;
+  double* xpair_gap;
   int* actuator_dyntype;
   int* actuator_gaintype;
   int* actuator_biastype;

@@ -130,7 +130,18 @@ class RefSim:
     sizes = dict(nq=mjm.nq, nv=mjm.nv, nu=mjm.nu, na=mjm.na, nbody=mjm.nbody, njnt=mjm.njnt, ngeom=mjm.ngeom,
                  nC=int(mjm.M_rownnz.sum()) if mjm.nv else 0, njmax=njmax, nconmax=nconmax)
     pairs = filtered_geom_pairs(mjm)
+    nexplicit = int(getattr(mjm, "npair", 0))
+    pairid = np.full(len(pairs), -1, dtype=np.int32)
+    if nexplicit:  # explicit <contact><pair> entries override / extend the filtered list (reference io.py:575-590)
+      table = {(int(a), int(b)): -1 for a, b in pairs}
+      for i in range(nexplicit):
+        a, b = int(mjm.pair_geom1[i]), int(mjm.pair_geom2[i])
+        table[(min(a, b), max(a, b))] = i
+      keys = sorted(table)
+      pairs = np.array(keys, dtype=np.int32).reshape(-1, 2)
+      pairid = np.array([table[k] for k in keys], dtype=np.int32)
     sizes["npair"] = len(pairs)
+    sizes["nexplicit"] = nexplicit
     sizes["neq"] = int(getattr(mjm, "neq", 0))
     sizes["nmocap"] = int(getattr(mjm, "nmocap", 0))
     scalars = dict(
@@ -143,7 +154,11 @@ class RefSim:
       impratio=float(opt.impratio), meaninertia=float(mjm.stat.meaninertia))
     if scalars["cone"] != 0:
       raise NotImplementedError("oracle: elliptic cones")
-    special = {"gravity": np.asarray(opt.gravity, dtype=np.float64), "pair_geom": pairs,
+    special = {"gravity": np.asarray(opt.gravity, dtype=np.float64), "pair_geom": pairs, "nxn_pairid": pairid,
+               "xpair_dim": getattr(mjm, "pair_dim", np.zeros(0)), "xpair_friction": getattr(mjm, "pair_friction", np.zeros(0)),
+               "xpair_solref": getattr(mjm, "pair_solref", np.zeros(0)), "xpair_solreffriction": getattr(mjm, "pair_solreffriction", np.zeros(0)),
+               "xpair_solimp": getattr(mjm, "pair_solimp", np.zeros(0)), "xpair_margin": getattr(mjm, "pair_margin", np.zeros(0)),
+               "xpair_gap": getattr(mjm, "pair_gap", np.zeros(0)),
                "actuator_trnid": mjm.actuator_trnid, "M_colind": mjm.M_colind}
     for name, kind, ptr in _MODEL_FIELDS:
       if not ptr:

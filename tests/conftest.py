@@ -246,3 +246,25 @@ MOCAP_XML = """
   </worldbody>
 </mujoco>
 """
+
+
+# explicit <contact><pair>: a pair the type/affinity filter would drop (ghost sphere on the floor), a pair whose parameters
+# override the geoms' (soft, frictionless capsule on the floor, with margin and gap) next to ordinary filtered pairs
+EXPLICIT_PAIR_XML = """
+<mujoco>
+  <option timestep="0.003"/>
+  <default><pair solref="0.01 1"/></default>
+  <worldbody>
+    <geom name="floor" type="plane" size="0 0 .05"/>
+    <body name="ghost" pos="0 0 .099"><freejoint/><geom name="ghost" type="sphere" size=".1" contype="0" conaffinity="0"/></body>
+    <body name="soft" pos=".5 0 .06" euler="0 90 0"><freejoint/><geom name="soft" type="capsule" size=".05 .15"/></body>
+    <body name="plain" pos="-.5 0 .079"><freejoint/><geom name="plain" type="sphere" size=".08"/></body>
+    <body name="rider" pos="-.5 .02 .235"><freejoint/><geom name="rider" type="sphere" size=".08"/></body>
+  </worldbody>
+  <contact>
+    <pair geom1="floor" geom2="ghost" condim="1"/>
+    <pair geom1="soft" geom2="floor" condim="4" margin="0.02" gap="0.005" friction="0.3 0.3 0.02 0.001 0.001" solref="0.03 0.8" solimp="0.8 0.9 0.01 0.5 2"/>
+    <pair geom1="plain" geom2="rider" friction="2 2 0.01 0.0005 0.0005"/>
+  </contact>
+</mujoco>
+"""

@@ -281,6 +281,35 @@ def test_mocap_bodies():
   np.testing.assert_allclose(d.mocap_pos.numpy()[2], [[0, 0, 0.3], [0.6, 0, 0.2]], atol=1e-7)
 
 
+def test_explicit_contact_pairs():
+  """<contact><pair> (io.py:575-590, collision_core.py contact_params with pairid >= 0): a pair the filters would drop, a pair
+  overriding condim / margin / gap / friction / solref / solimp, and unspecified attributes falling back to the geom mix."""
+  mjm = mjw.mjcf.from_xml_string(conftest.EXPLICIT_PAIR_XML)
+  assert mjm.npair == 3
+  pairs, pairid = mjw.io.geom_pairs_with_ids(mjm)
+  assert sorted(pairid[pairid >= 0].tolist()) == [0, 1, 2] and (pairid == -1).sum() == len(pairs) - 3
+  s, m, d = _pair(mjm, nworld=2, nconmax=16, njmax=48, warm_steps=30, noise=False)
+  assert m.nexplicit == 3
+  mjw.forward(m, d)
+  s.forward()
+  assert s.ncon >= 4
+  _check_fields(s, d, _SMOOTH_FIELDS, SMOOTH)
+  _check_contacts_and_rows(s, d, mjm, dist_atol=5e-7)
+  _check_solution(s, d)
+  dims = {tuple(int(x) for x in g): int(c) for g, c in zip(s.con_geom[: s.ncon], s.con_dim[: s.ncon])}
+  assert dims[(0, 1)] == 1 and dims[(0, 2)] == 4  # the explicit pairs' condim, not the geoms' default 3
+  adr = int(d.ws_conadr.numpy()[1])
+  k = [tuple(int(x) for x in g) for g in s.con_geom[: s.ncon]].index((0, 2))
+  np.testing.assert_allclose(d.contact.includemargin.numpy()[adr + k], 0.02, atol=1e-7)  # (collision_core.py:278: the margin; detection at margin + gap)
+  np.testing.assert_allclose(d.contact.solref.numpy()[adr + k], [0.03, 0.8], atol=1e-7)
+  for _ in range(20):
+    _sync(s, d)
+    mjw.step(m, d)
+    s.step()
+    assert relerr(d.qpos.numpy()[0], s.qpos) <= 1e-5
+    assert relerr(d.qvel.numpy()[0], s.qvel) <= 2e-3
+
+
 def test_sphere_cylinder_rim_regime():
   """10 steps in, the small sphere still rolls over the cylinder's rim (the 40-step state above only has cap and side)."""
   mjm = mjw.mjcf.from_xml_string(conftest.SPHERE_CYLINDER_XML)
