@@ -318,6 +318,8 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
   m.key_qpos = _arr(getattr(mjm, "key_qpos", np.zeros((0, m.nq))), f32)
   m.key_qvel = _arr(getattr(mjm, "key_qvel", np.zeros((0, nv))), f32)
   m.key_ctrl = _arr(getattr(mjm, "key_ctrl", np.zeros((0, nu))), f32)
+  m.key_mpos = _arr(getattr(mjm, "key_mpos", np.zeros((0, 3 * m.nmocap))), f32)
+  m.key_mquat = _arr(getattr(mjm, "key_mquat", np.zeros((0, 4 * m.nmocap))), f32)
   m.key_act = _arr(getattr(mjm, "key_act", np.zeros((0, m.na))), f32)
   m.key_time = _arr(getattr(mjm, "key_time", np.zeros(0)), f32)
   m._dirty = True
@@ -542,6 +544,16 @@ def reset_data_keyframe(m: types.Model, d: types.Data, key: int, reset=None):
   _reset_state(m, d, np.tile(m.key_qpos[key], (W, 1)), np.tile(m.key_qvel[key], (W, 1)),
                np.tile(m.key_act[key], (W, 1)) if m.na else None, np.tile(m.key_ctrl[key], (W, 1)) if m.nu else None,
                float(m.key_time[key]), mask)
+  if m.nmocap and getattr(m, "key_mpos", None) is not None and len(m.key_mpos) > key:  # keyframe mocap poses (io.py:2855)
+    for name, src, width in (("mocap_pos", m.key_mpos, 3), ("mocap_quat", m.key_mquat, 4)):
+      val = np.tile(np.asarray(src[key], dtype=np.float32).reshape(1, m.nmocap, width), (W, 1, 1))
+      dst = getattr(d, name)
+      if mask is None:
+        dst.assign(val)
+      else:
+        cur = dst.numpy().copy()
+        cur[mask] = val[mask]
+        dst.assign(cur)
 
 
 def _reset_mocap(m, d, mask):

@@ -139,6 +139,9 @@ def mj_resetDataKeyframe(m, d, key):
   d.qvel[:] = m.key_qvel[key] if m.nkey > key else 0.0
   d.act[:] = m.key_act[key] if m.nkey > key else 0.0
   d.ctrl[:] = m.key_ctrl[key] if m.nkey > key else 0.0
+  if m.nmocap and m.nkey > key:
+    d.mocap_pos[:] = m.key_mpos[key].reshape(-1, 3)
+    d.mocap_quat[:] = m.key_mquat[key].reshape(-1, 4)
   d.qacc_warmstart[:] = 0.0
   d.qfrc_applied[:] = 0.0
   d.xfrc_applied[:] = 0.0
@@ -1142,10 +1145,14 @@ def _compile(root, base_dir):
   m.key_qvel = np.zeros((m.nkey, nv))
   m.key_act = np.zeros((m.nkey, na))
   m.key_ctrl = np.zeros((m.nkey, nu))
+  mb = [int(np.flatnonzero(m.body_mocapid == j)[0]) for j in range(m.nmocap)]
+  m.key_mpos = np.tile(m.body_pos[mb].reshape(1, -1), (m.nkey, 1)) if m.nkey else np.zeros((0, 3 * m.nmocap))
+  m.key_mquat = np.tile(m.body_quat[mb].reshape(1, -1), (m.nkey, 1)) if m.nkey else np.zeros((0, 4 * m.nmocap))
   for i, k in enumerate(keys):
     if "time" in k.attrib:
       m.key_time[i] = float(k.get("time"))
-    for name, arr in (("qpos", m.key_qpos), ("qvel", m.key_qvel), ("act", m.key_act), ("ctrl", m.key_ctrl)):
+    for name, arr in (("qpos", m.key_qpos), ("qvel", m.key_qvel), ("act", m.key_act), ("ctrl", m.key_ctrl), ("mpos", m.key_mpos),
+                      ("mquat", m.key_mquat)):
       if name in k.attrib:
         v = _floats(k.get(name))
         if len(v) != arr.shape[1]:

@@ -279,6 +279,14 @@ def test_mocap_bodies():
   assert s.ncon >= 5  # ball and crate on the tray (the pole has pushed the arm aside)
   mjw.reset_data(m, d)
   np.testing.assert_allclose(d.mocap_pos.numpy()[2], [[0, 0, 0.3], [0.6, 0, 0.2]], atol=1e-7)
+  # keyframe mocap poses (mpos / mquat) reach the device through reset_data_keyframe
+  mk = mjw.mjcf.from_xml_string(conftest.MOCAP_XML.replace("</mujoco>", '<keyframe><key mpos="0 0 .5  .7 0 .2"/></keyframe></mujoco>'))
+  mm = mjw.put_model(mk)
+  dd = mjw.make_data(mk, nworld=2, nconmax=32, njmax=96)
+  mjw.reset_data_keyframe(mm, dd, 0)
+  np.testing.assert_allclose(dd.mocap_pos.numpy()[1], [[0, 0, 0.5], [0.7, 0, 0.2]], atol=1e-7)
+  mjw.kinematics(mm, dd)
+  np.testing.assert_allclose(dd.xpos.numpy()[1, 1], [0, 0, 0.5], atol=1e-7)
 
 
 def test_explicit_contact_pairs():

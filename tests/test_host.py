@@ -300,3 +300,20 @@ def test_attach_three_humanoids_matches_manual_clone():
     np.testing.assert_allclose(getattr(a, f), getattr(b, f), atol=1e-12, err_msg=f)
   np.testing.assert_allclose(a.geom_size[1:], b.geom_size[1:], atol=1e-12)  # (the floors differ)
   assert a.stat.meaninertia == pytest.approx(b.stat.meaninertia, rel=1e-12)
+
+
+def test_mocap_model_and_keyframe():
+  m = mjw.mjcf.from_xml_string("""
+<mujoco><worldbody>
+  <body name="hand" mocap="true" pos="0 0 .3"><geom type="box" size=".1 .1 .02"/></body>
+  <body name="ball" pos="0 0 .4"><freejoint/><geom type="sphere" size=".05"/></body>
+</worldbody>
+<keyframe><key name="k" mpos="1 2 3" mquat="0 1 0 0"/></keyframe></mujoco>""")
+  assert m.nmocap == 1 and list(m.body_mocapid) == [-1, 0, -1]
+  d = mjw.MjData(m)
+  np.testing.assert_array_equal(d.mocap_pos, [[0, 0, 0.3]])
+  mjw.mj_resetDataKeyframe(m, d, 0)
+  np.testing.assert_array_equal(d.mocap_pos, [[1, 2, 3]])
+  np.testing.assert_array_equal(d.mocap_quat, [[0, 1, 0, 0]])
+  with pytest.raises(ValueError):
+    mjw.mjcf.from_xml_string('<mujoco><worldbody><body><joint/><geom size=".1"/><body mocap="true"><geom size=".1"/></body></body></worldbody></mujoco>')
