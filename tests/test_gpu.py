@@ -517,8 +517,11 @@ def test_batched_gravity_and_mass():
   assert z[3] == z[1]
 
 
-def test_graph_replay_matches_eager():
+@pytest.mark.parametrize("override", [[], ["opt.solver=cg"], ["opt.solver=pgs"], ["opt.integrator=RK4"], ["opt.integrator=implicitfast"]])
+def test_graph_replay_matches_eager(override):
+  """hipGraph capture of one step (side-stream fork/join for Newton, fused Euler for CG, four forwards for RK4) replays bit for bit."""
   mjm = mjw.mjcf.load_xml(conftest.HUMANOID_XML)
+  mjw.override_model(mjm, override)
   m = mjw.put_model(mjm)
   da = mjw.make_data(mjm, nworld=256, nconmax=24, njmax=64)
   db = mjw.make_data(mjm, nworld=256, nconmax=24, njmax=64)
