@@ -234,8 +234,12 @@ DEV float halton(int index, int base) {
   }
   return hn;
 }
-__global__ void k_ctrl_noise(MjhModel m, MjhData d, const float* center, int step, float noise_std, float noise_rate) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+struct NoiseArgs {  // one application of the benchmark's control noise (cli.py:103-145); n = 0: none
+  int n, step;
+  float noise_std, noise_rate;
+  const float* center;
+};
+DEV void ctrl_noise_elem(const MjhModel& m, const MjhData& d, const float* center, int step, float noise_std, float noise_rate, int idx) {
   const int nu = m.nu;
   if (idx >= d.nworld * nu) return;
   const int w = idx / nu, a = idx - w * nu;
@@ -255,6 +259,9 @@ __global__ void k_ctrl_noise(MjhModel m, MjhData d, const float* center, int ste
   ctrl += scale * halfrange * (2.0f * halton((step + 1) * (gw + 1), a + 2) - 1.0f);
   if (lim) ctrl = clampf(ctrl, cr[0], cr[1]);
   d.ctrl[idx] = ctrl;
+}
+__global__ void k_ctrl_noise(MjhModel m, MjhData d, const float* center, int step, float noise_std, float noise_rate) {
+  ctrl_noise_elem(m, d, center, step, noise_std, noise_rate, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 // x = M^-1 y (smooth.solve_m) and res = M vec (support.mul_m) on user arrays

@@ -165,15 +165,20 @@ __global__ void __launch_bounds__(256) k_integrate_plus(MjhModel m, MjhData d, i
 }
 // k_fwd_pos + one workgroup that sorts the worlds by the PREVIOUS step's solver_niter (the solver schedule of this step)
 template <int G>
-__global__ void __launch_bounds__(256) k_fwd_pos_plus(MjhModel m, MjhData d, int first, int last, int npos) {
+__global__ void __launch_bounds__(256) k_fwd_pos_plus(MjhModel m, MjhData d, int first, int last, int npos, NoiseArgs noise) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   // the schedule workgroup goes FIRST: workgroups are dispatched in index order, so as the last one it would start
   // when the launch is nearly over and add its whole duration (~8 us) to it
   if (blockIdx.x == 0) {
     schedule_body(d, reinterpret_cast<int*>(smem), blockDim.x);
-  } else {
+  } else if ((int)blockIdx.x <= npos) {
     const int wpb = blockDim.x / G;
     fwd_pos_body<G>(m, d, first, last, smem, Blk{((int)blockIdx.x - 1) * wpb, wpb, (int)blockDim.x});
+  } else {
+    // the benchmark loop's control noise rides here (mjh_timed_steps): nothing in this launch reads ctrl, the next launch
+    // (fwd_vel's actuation) does; dispatched last, these few trivial workgroups run in the launch's tail
+    const int idx = ((int)blockIdx.x - npos - 1) * blockDim.x + threadIdx.x;
+    if (idx < noise.n) ctrl_noise_elem(m, d, noise.center, noise.step, noise.noise_std, noise.noise_rate, idx);
   }
 }
 
@@ -268,17 +273,24 @@ static int launch_integrate_plus(const MjhModel* m, const MjhData* d, int mode, 
 }
 // *sched_done: whether the launch carried the schedule workgroup (it needs >= 128 threads to be quick; otherwise it
 // rides with k_mid, whose workgroups always have 256)
+// control noise queued by mjh_timed_steps for the next fused step: it rides with that step's first launch
+static thread_local NoiseArgs g_noise = {0, 0, 0.0f, 0.0f, nullptr};
 static int launch_pos_plus(const MjhModel* m, const MjhData* d, int first, int last, bool* sched_done, hipStream_t s) {
+  const NoiseArgs noise = g_noise;
+  g_noise.n = 0;
   const PosLayout lay = pos_layout(m->nq, m->nv, m->nbody, m->njnt, m->nC, last >= POS_FACTOR);
   size_t lds;
   const int threads = pick_block(sizeof(int) * mstruct_ints(m->nv, m->nC), sizeof(float) * lay.total, G, &lds);
   if (!threads) return fail(MJH_E_UNSUPPORTED, "k_fwd_pos: model does not fit in LDS");
   *sched_done = threads >= 128;
-  if (!*sched_done) return launch_pos(m, d, first, last, s);
+  if (!*sched_done) {
+    if (noise.n) hipLaunchKernelGGL(k_ctrl_noise, dim3((noise.n + 255) / 256), dim3(256), 0, s, *m, *d, noise.center, noise.step, noise.noise_std, noise.noise_rate);
+    return launch_pos(m, d, first, last, s);
+  }
   lds = std::max(lds, (size_t)1024);
   HIPCHK(set_lds(k_fwd_pos_plus<G>, lds));
-  const int wpb = threads / G, npos = (d->nworld + wpb - 1) / wpb;
-  hipLaunchKernelGGL(k_fwd_pos_plus<G>, dim3(npos + 1), dim3(threads), lds, s, *m, *d, first, last, npos);
+  const int wpb = threads / G, npos = (d->nworld + wpb - 1) / wpb, nnoise = (noise.n + threads - 1) / threads;
+  hipLaunchKernelGGL(k_fwd_pos_plus<G>, dim3(npos + 1 + nnoise), dim3(threads), lds, s, *m, *d, first, last, npos, noise);
   return MJH_OK;
 }
 
@@ -539,8 +551,15 @@ int mjh_timed_steps(const MjhModel* m, const MjhData* d, int nstep, int step0, f
   hipEventRecord(t0, s);
   int rc = MJH_OK;
   for (int i = 0; i < nstep && rc == MJH_OK; ++i) {
-    if (noise_std >= 0.0f) rc = mjh_ctrl_noise(m, d, nullptr, step0 + i, noise_std, noise_rate, stream);
+    // the noise of step i rides with that step's first launch (the fused path); the per-kernel profiling passes and the plain
+    // path keep it as its own kernel
+    static const bool plain_env = getenv("MJH_PLAIN") != nullptr || getenv("MJH_NO_NOISE_FUSION") != nullptr;
+    if (noise_std >= 0.0f && m->nu > 0) {
+      if (instr.on || plain_env) rc = mjh_ctrl_noise(m, d, nullptr, step0 + i, noise_std, noise_rate, stream);
+      else g_noise = NoiseArgs{d->nworld * m->nu, step0 + i, noise_std, noise_rate, nullptr};
+    }
     if (rc == MJH_OK) rc = run_stage(m, d, MJH_STAGE_STEP, s);
+    g_noise.n = 0;
   }
   hipEventRecord(t1, s);
   hipError_t e = hipEventSynchronize(t1);

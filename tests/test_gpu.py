@@ -567,6 +567,26 @@ def test_timed_steps_reports_kernel_classes():
   np.testing.assert_allclose(d.time.numpy(), 10 * 0.005, rtol=1e-5)
 
 
+@pytest.mark.parametrize("override", [[], ["opt.solver=cg"], ["opt.integrator=RK4"]])
+def test_timed_steps_equals_noise_plus_step(override):
+  """The benchmark loop (mjh_timed_steps: the control noise rides with the first launch of each fused step) produces bit for
+  bit the trajectory of the API calls ctrl_noise + step, and so does its per-kernel profiling pass (noise as its own kernel)."""
+  mjm = mjw.mjcf.load_xml(conftest.HUMANOID_XML)
+  mjw.override_model(mjm, override)
+  m = mjw.put_model(mjm)
+  da, db, dc = (mjw.make_data(mjm, nworld=300, nconmax=24, njmax=64) for _ in range(3))
+  for d in (da, db, dc):
+    mjw.reset_data_keyframe(m, d, 0)
+  mjw.timed_steps(m, da, 12, step0=3)
+  mjw.timed_steps(m, dc, 12, step0=3, per_kernel=True)
+  for i in range(12):
+    mjw.ctrl_noise(m, db, 3 + i)
+    mjw.step(m, db)
+  for name in ("qpos", "qvel", "ctrl", "qacc_warmstart"):
+    assert (getattr(da, name).numpy() == getattr(db, name).numpy()).all(), name
+    assert (getattr(dc, name).numpy() == getattr(db, name).numpy()).all(), name
+
+
 def test_long_rollout_contact_records_stay_valid():
   """300 noisy steps at BASELINE size: every published contact record stays well-formed and agrees with the
   per-world bookkeeping (catches count/publish disagreement between the two narrowphase passes), staged and fused."""
