@@ -443,8 +443,8 @@ static int run_stage(const MjhModel* m, const MjhData* d, int stage, hipStream_t
       }
       // explicit Euler without activations: the velocity/position update is a few loads and stores per dof, done by the
       // solver's own epilogue (saves a launch); every other case keeps the integrator workgroups
-      // (CG only: the Newton launch keeps its integrator launch anyway, for the riders, and measured 2 % slower fused)
-      const bool fuse_euler = stage == MJH_STAGE_STEP && m->integrator == INT_EULER && m->na == 0 && m->solver == SOL_CG && m->nv <= 64 &&
+      // (Newton: only when its riders run on the side stream -- otherwise the integrator launch exists anyway, for them)
+      const bool fuse_euler = stage == MJH_STAGE_STEP && m->integrator == INT_EULER && m->na == 0 && (m->solver == SOL_CG || side != nullptr) && m->nv <= 64 &&
                               (m->disableflags & (DSBL_EULERDAMP | DSBL_DAMPER)) != 0;
       g_fuse_euler = fuse_euler;
       int rc;
