@@ -66,7 +66,36 @@ def main():
     np.savez(os.path.join(OUT, f"{name}_oracle_forward.npz"), tolerance=tol, nconmax=ncm, njmax=njm,
              **{"in_" + k: v for k, v in state.items()}, **out)
   pgs_fixture()
+  scene_fixtures()
   print("wrote golden files to", OUT)
+
+
+def scene_fixtures():
+  """Forward + one step of the collider scenes and of the three-humanoid model (generic nv > 64 solver)."""
+  sys.path.insert(0, os.path.join(ROOT, "tests"))
+  import conftest
+
+  tol = 1e-6
+  for name, mjm, ncm, njm, warm in (
+    ("boxes", mjw.mjcf.from_xml_string(conftest.BOX_BOX_XML), 64, 192, 30),
+    ("capsule_box", mjw.mjcf.from_xml_string(conftest.CAPSULE_BOX_XML), 48, 160, 15),
+    ("three_humanoids", mjw.mjcf.load_xml(os.path.join(ROOT, "benchmarks", "humanoid", "three_humanoids.xml")), 100, 192, 40),
+  ):
+    s = ref.RefSim(mjm, nconmax=ncm, njmax=njm, tolerance=tol)
+    s.reset(key=0 if mjm.nkey else None)
+    for i in range(warm):
+      if mjm.nu:
+        s.ctrl_noise(i, 2)
+      s.step()
+    state = {k: getattr(s, k).copy() for k in ("qpos", "qvel", "ctrl", "qacc_warmstart")}
+    s.forward()
+    out = {k: getattr(s, k).copy() for k in ("xpos", "xquat", "M", "qfrc_bias", "qacc_smooth", "qacc", "qfrc_constraint")}
+    out["nefc"], out["ncon"] = s.nefc, s.ncon
+    out["con_dist"], out["con_pos"], out["con_geom"] = s.con_dist[: s.ncon].copy(), s.con_pos[: s.ncon].copy(), s.con_geom[: s.ncon].copy()
+    s.step()
+    out["qpos_next"], out["qvel_next"] = s.qpos.copy(), s.qvel.copy()
+    np.savez(os.path.join(OUT, f"{name}_oracle_forward.npz"), tolerance=tol, nconmax=ncm, njmax=njm,
+             **{"in_" + k: v for k, v in state.items()}, **out)
 
 
 def pgs_fixture():

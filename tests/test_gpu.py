@@ -792,3 +792,34 @@ def test_golden_forward_fixture_g1_panda(name, xml):
   assert relerr(d.efc.J.numpy()[1, : int(g["nefc"]), : mjm.nv], g["efc_J"]) <= SMOOTH
   assert relerr(d.qpos.numpy()[1], g["qpos_next"]) <= 1e-5
   assert relerr(d.qvel.numpy()[1], g["qvel_next"]) <= 2e-3
+
+
+@pytest.mark.parametrize("name", ["boxes", "capsule_box", "three_humanoids"])
+def test_golden_scene_fixtures(name):
+  """HIP path against the committed fixtures of the collider scenes (heavy instantiation) and of three_humanoids.xml (loader
+  expansion of <replicate>/<frame>/<attach> + the generic nv > 64 solver); contacts compared per geom pair as sets."""
+  from test_oracle import _scene_model
+
+  g = np.load(os.path.join(conftest.GOLDEN_DIR, f"{name}_oracle_forward.npz"))
+  mjm = _scene_model(name)
+  m = mjw.put_model(mjm)
+  d = mjw.make_data(mjm, nworld=2, nconmax=int(g["nconmax"]), njmax=int(g["njmax"]))
+  for k in ("qpos", "qvel", "ctrl", "qacc_warmstart"):
+    if getattr(d, k).size:
+      getattr(d, k).assign(np.tile(g["in_" + k].astype(np.float32), (2, 1)))
+  mjw.step(m, d)
+  for k, tol in (("xpos", SMOOTH), ("xquat", SMOOTH), ("M", SMOOTH), ("qfrc_bias", SMOOTH), ("qacc_smooth", FACTOR), ("qacc", 5e-3),
+                 ("qfrc_constraint", 5e-3)):
+    assert relerr(getattr(d, k).numpy()[1].reshape(-1), g[k].reshape(-1)) <= tol, k
+  ncon, adr = int(d.ws_ncon.numpy()[1]), int(d.ws_conadr.numpy()[1])
+  assert (int(d.nefc.numpy()[1]), ncon) == (int(g["nefc"]), int(g["ncon"]))
+  gg, gd, gp = (getattr(d.contact, k).numpy()[adr : adr + ncon] for k in ("geom", "dist", "pos"))
+  np.testing.assert_array_equal(gg, g["con_geom"])
+  for pair in {tuple(x) for x in gg.tolist()}:
+    idx = np.flatnonzero((gg == pair).all(axis=1))
+    og = idx[np.lexsort(np.round(gp[idx], 4).T[::-1])]
+    oo = idx[np.lexsort(np.round(g["con_pos"][idx], 4).T[::-1])]
+    np.testing.assert_allclose(gd[og], g["con_dist"][oo], atol=2e-6)
+    np.testing.assert_allclose(gp[og], g["con_pos"][oo], atol=5e-6)
+  assert relerr(d.qpos.numpy()[1], g["qpos_next"]) <= 1e-5
+  assert relerr(d.qvel.numpy()[1], g["qvel_next"]) <= 2e-3

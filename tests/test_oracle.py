@@ -346,6 +346,31 @@ def test_golden_forward_regression_g1_panda(name, xml):
   np.testing.assert_allclose(s.qpos, g["qpos_next"], rtol=1e-12, atol=1e-12)
 
 
+def _scene_model(name):
+  if name == "boxes":
+    return mjw.mjcf.from_xml_string(conftest.BOX_BOX_XML)
+  if name == "capsule_box":
+    return mjw.mjcf.from_xml_string(conftest.CAPSULE_BOX_XML)
+  return mjw.mjcf.load_xml(os.path.join(os.path.dirname(conftest.HUMANOID_XML), "three_humanoids.xml"))
+
+
+@pytest.mark.parametrize("name", ["boxes", "capsule_box", "three_humanoids"])
+def test_golden_scene_regression(name):
+  """Committed fixtures of the box-box / capsule-box scenes and of three_humanoids.xml (regression anchors, make_golden.py)."""
+  g = np.load(os.path.join(conftest.GOLDEN_DIR, f"{name}_oracle_forward.npz"))
+  s = ref.RefSim(_scene_model(name), nconmax=int(g["nconmax"]), njmax=int(g["njmax"]), tolerance=float(g["tolerance"]))
+  for k in ("qpos", "qvel", "ctrl", "qacc_warmstart"):
+    getattr(s, k)[:] = g["in_" + k]
+  s.forward()
+  assert (s.nefc, s.ncon) == (int(g["nefc"]), int(g["ncon"]))
+  np.testing.assert_array_equal(s.con_geom[: s.ncon], g["con_geom"])
+  np.testing.assert_allclose(s.con_dist[: s.ncon], g["con_dist"], rtol=0, atol=1e-12)
+  np.testing.assert_allclose(s.con_pos[: s.ncon], g["con_pos"], rtol=0, atol=1e-12)
+  np.testing.assert_allclose(s.qacc, g["qacc"], rtol=1e-9, atol=1e-9)
+  s.step()
+  np.testing.assert_allclose(s.qpos, g["qpos_next"], rtol=1e-12, atol=1e-12)
+
+
 _DOUBLE_PENDULUM_XML = """
 <mujoco>
   <option timestep="{h}" integrator="{integ}"><flag contact="disable"/></option>
