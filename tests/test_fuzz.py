@@ -1,4 +1,4 @@
-"""Randomised-model parity (40 + 12 PGS + 16 extra-collider seeds by default; MJH_FUZZ_SEEDS / MJH_FUZZ_PGS_SEEDS / MJH_FUZZ_COLLIDER_SEEDS for more: 240 + 80 + 160 were run clean): random kinematic trees with mixed joint / geom / actuator types against the float64 oracle.
+"""Randomised-model parity (40 + 12 PGS + 16 extra-collider seeds by default; MJH_FUZZ_SEEDS / MJH_FUZZ_PGS_SEEDS / MJH_FUZZ_COLLIDER_SEEDS for more: 480 + 160 + 320 were run clean): random kinematic trees with mixed joint / geom / actuator types against the float64 oracle.
 
 The fixed models (humanoid, G1, Panda, pendula, free bodies, pile) pin specific code paths; these seeds sweep the
 combinations: free / ball / hinge / slide joints at random depths, limits, damping, springs, armature, friction loss,
