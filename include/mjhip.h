@@ -50,6 +50,7 @@ extern "C" {
 #define MJH_STAGE_FWD_POSITION 16    /* forward.fwd_position         forward.py:635 */
 #define MJH_STAGE_FORWARD 17         /* forward.forward              forward.py:1341 */
 #define MJH_STAGE_STEP 18            /* forward.step                 forward.py:1368 */
+#define MJH_STAGE_RUNGEKUTTA4 19     /* forward.rungekutta4 (after a forward)  forward.py:524 */
 
 typedef struct MjhModel {
   /* sizes */

@@ -27,7 +27,11 @@ from .forward import kinematics
 from .forward import make_constraint
 from .forward import mul_m
 from .forward import passive
+from .forward import fwd_kinematics
 from .forward import rne
+from .forward import rungekutta4
+from .forward import step1
+from .forward import step2
 from .forward import solve
 from .forward import solve_m
 from .forward import step
@@ -62,6 +66,7 @@ from .types import GeomType
 from .types import IntegratorType
 from .types import JointType
 from .types import Model
+from .types import ObjType
 from .types import Option
 from .types import OverflowType
 from .types import SolverType

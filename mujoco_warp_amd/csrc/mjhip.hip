@@ -399,18 +399,23 @@ static int run_stage(const MjhModel* m, const MjhData* d, int stage, hipStream_t
       { Scope sc(K_CONSTRAINT); TRY(launch_constraint(m, d, s)); }
       { Scope sc(K_OTHER); TRY(launch_publish(d, s)); }
       return MJH_OK;
+    case MJH_STAGE_RUNGEKUTTA4: {
+      // forward.rungekutta4 (forward.py:524-557), called after a forward at t0: one k_rk4 launch after each evaluation
+      // (accumulate + perturb; the last one restores t0 and advances); tableau A = (1/2, 1/2, 1), B = (1/6, 1/3, 1/3, 1/6)
+      if (!d->ws_rk) return fail(MJH_E_ARG, "Data.ws_rk missing (allocate Data with make_data/put_data)");
+      static const float A[4] = {0.5f, 0.5f, 1.0f, 0.0f}, B[4] = {1.0f / 6.0f, 1.0f / 3.0f, 1.0f / 3.0f, 1.0f / 6.0f};
+      for (int k = 0; k < 4; ++k) {
+        if (k) TRY(run_stage(m, d, MJH_STAGE_FORWARD, s));
+        Scope sc(K_INTEGRATE);
+        hipLaunchKernelGGL(k_rk4<G>, dim3((d->nworld + 7) / 8), dim3(8 * G), sizeof(float) * 8 * (m->nv + 1), s, *m, *d, k, A[k], B[k]);
+      }
+      return MJH_OK;
+    }
     case MJH_STAGE_FORWARD:
     case MJH_STAGE_STEP: {
       if (stage == MJH_STAGE_STEP && m->integrator == INT_RK4) {
-        // forward.rungekutta4 (forward.py:524-557): four forwards, one k_rk4 launch after each (accumulate + perturb,
-        // the last one restores t0 and advances); tableau A = (1/2, 1/2, 1), B = (1/6, 1/3, 1/3, 1/6)
-        static const float A[4] = {0.5f, 0.5f, 1.0f, 0.0f}, B[4] = {1.0f / 6.0f, 1.0f / 3.0f, 1.0f / 3.0f, 1.0f / 6.0f};
-        for (int k = 0; k < 4; ++k) {
-          TRY(run_stage(m, d, MJH_STAGE_FORWARD, s));
-          Scope sc(K_INTEGRATE);
-          hipLaunchKernelGGL(k_rk4<G>, dim3((d->nworld + 7) / 8), dim3(8 * G), sizeof(float) * 8 * (m->nv + 1), s, *m, *d, k, A[k], B[k]);
-        }
-        return MJH_OK;
+        TRY(run_stage(m, d, MJH_STAGE_FORWARD, s));
+        return run_stage(m, d, MJH_STAGE_RUNGEKUTTA4, s);
       }
       const int mode = m->integrator == INT_IMPLICITFAST ? 1 : 0;
       static const bool plain = getenv("MJH_PLAIN") != nullptr;  // developer knob: one plain kernel per stage, serial

@@ -106,6 +106,34 @@ def implicit(m, d):
   _run(_S["MJH_STAGE_IMPLICIT"], m, d)
 
 
+def rungekutta4(m, d):
+  """Runge-Kutta 4 integration; call after `forward` (reference forward.py:524)."""
+  _run(_S["MJH_STAGE_RUNGEKUTTA4"], m, d)
+
+
+def fwd_kinematics(m, d):
+  """Kinematics-dependent computations (reference forward.py:616; no cameras / flex / tendons here)."""
+  kinematics(m, d)
+  com_pos(m, d)
+
+
+def step1(m, d):
+  """First half of `step`, before the user sets controls (reference forward.py:1384; no sensors / energy here)."""
+  fwd_position(m, d)
+  fwd_velocity(m, d)
+
+
+def step2(m, d):
+  """Second half of `step` (reference forward.py:1403): RK4 falls back to Euler, as in the reference."""
+  fwd_actuation(m, d)
+  fwd_acceleration(m, d)
+  solve(m, d)
+  if int(m.opt.integrator) in (int(types.IntegratorType.IMPLICITFAST), int(types.IntegratorType.IMPLICIT)):
+    implicit(m, d)
+  else:
+    euler(m, d)
+
+
 def solve_m(m, d, x: DeviceArray, y: DeviceArray):
   """x = M^-1 y using the stored factor (reference smooth.py:3214)."""
   L = _abi.lib()

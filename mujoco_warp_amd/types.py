@@ -70,6 +70,18 @@ class EnableBit(enum.IntFlag):
   SLEEP = 1 << 5
 
 
+class ObjType(enum.IntEnum):
+  """Object types (reference types.py:651; mjtObj values)."""
+
+  UNKNOWN = 0
+  BODY = 1
+  XBODY = 2
+  GEOM = 5
+  SITE = 6
+  CAMERA = 7
+  FLEX = 9
+
+
 class TrnType(enum.IntEnum):
   JOINT = 0
   JOINTINPARENT = 1

@@ -823,3 +823,28 @@ def test_golden_scene_fixtures(name):
     np.testing.assert_allclose(gp[og], g["con_pos"][oo], atol=5e-6)
   assert relerr(d.qpos.numpy()[1], g["qpos_next"]) <= 1e-5
   assert relerr(d.qvel.numpy()[1], g["qvel_next"]) <= 2e-3
+
+
+@pytest.mark.parametrize("integrator", ["Euler", "implicitfast", "RK4"])
+def test_step1_step2_and_rungekutta4_stage(integrator):
+  """step1 + step2 (forward.py:1384-1415) reproduce step (RK4 falls back to Euler there, as in the reference); for RK4,
+  forward + rungekutta4 reproduces step."""
+  mjm = mjw.mjcf.load_xml(conftest.HUMANOID_XML)
+  mjw.override_model(mjm, [f"opt.integrator={integrator}", "opt.solver=newton"])
+  m = mjw.put_model(mjm)
+  da, db = (mjw.make_data(mjm, nworld=8, nconmax=24, njmax=64) for _ in range(2))
+  for d in (da, db):
+    mjw.reset_data_keyframe(m, d, 0)
+  for i in range(12):
+    for d in (da, db):
+      mjw.ctrl_noise(m, d, i)
+    mjw.step(m, da)
+    if integrator == "RK4":
+      mjw.forward(m, db)
+      mjw.rungekutta4(m, db)
+    else:
+      mjw.step1(m, db)
+      mjw.step2(m, db)
+  np.testing.assert_allclose(db.qpos.numpy(), da.qpos.numpy(), rtol=0, atol=2e-6)
+  np.testing.assert_allclose(db.qvel.numpy(), da.qvel.numpy(), rtol=0, atol=2e-4)
+  assert hasattr(mjw, "fwd_kinematics") and mjw.ObjType.SITE == 6
