@@ -23,7 +23,8 @@ def init_process_group(backend=None):
   if world_size > 1 and not dist.is_initialized():
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
-    backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+    # MJH_DIST_BACKEND=gloo: developer knob to run several ranks on ONE GPU (RCCL refuses duplicate devices)
+    backend = backend or os.environ.get("MJH_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     if backend == "nccl":
       torch.cuda.set_device(local_rank % torch.cuda.device_count())
     dist.init_process_group(backend=backend, rank=rank, world_size=world_size)
