@@ -17,7 +17,7 @@ PHASES = {
   3: ("make_constraint", ["load", "friction+limits", "J rows fl", "contact list", "contact J", "contact rows"]),
   4: ("fwd_vel", ["load", "com_vel", "passive", "rne", "actuation", "qfrc_smooth"]),
   5: ("solve", ["M rows", "Ma+Minv", "J+rows", "it: update+JTf+grad", "it: Mgrad/chol", "it: conv+mv+jv", "it: linesearch",
-                "it: move", "exit", "store"]),
+                "it: move", "exit", "store", "it: H build (mfma)", "it: H swap + M", "it: chol factor"]),
 }
 
 
