@@ -611,6 +611,38 @@ static void sphere_box(const double* sp, double r, const double* bp, const doubl
   make_frame(out->frame, nn);
 }
 
+/* ---- small math.py functions that carry reference-held test vectors (math_test.py:27-130) ------------------------------ */
+/* closest_segment_to_segment_points math.py:283-316 (not on the mj_step path of the primitive colliders restated here -- the
+ * reference uses it for triangle / flex queries, collision_primitive_core.py:1939 -- restated so that the vectors the
+ * reference's own test holds pin this file's vector conventions) */
+void ref_closest_segment_to_segment_points(const double* a0, const double* a1, const double* b0, const double* b1, double* best_a_out,
+                                           double* best_b_out) {
+  double da[3], db[3], la = 0, lb = 0;
+  for (int k = 0; k < 3; k++) { da[k] = a1[k] - a0[k]; db[k] = b1[k] - b0[k]; la += da[k] * da[k]; lb += db[k] * db[k]; }
+  la = sqrt(la); lb = sqrt(lb);
+  if (la != 0.0) for (int k = 0; k < 3; k++) da[k] /= la;  /* normalize_with_norm math.py:258: zero stays zero */
+  if (lb != 0.0) for (int k = 0; k < 3; k++) db[k] /= lb;
+  double ha = 0.5 * la, hb = 0.5 * lb, am[3], bm[3], tr[3];
+  for (int k = 0; k < 3; k++) { am[k] = a0[k] + da[k] * ha; bm[k] = b0[k] + db[k] * hb; tr[k] = am[k] - bm[k]; }
+  double dab = v3dot(da, db), dat = v3dot(da, tr), dbt = v3dot(db, tr), denom = 1.0 - dab * dab;
+  double ota = (-dat + dab * dbt) / (denom + 1e-6), otb = dbt + ota * dab;
+  double ta = clampd(ota, -ha, ha), tb = clampd(otb, -hb, hb);
+  double ba[3], bb[3], na[3], nb[3];
+  for (int k = 0; k < 3; k++) { ba[k] = am[k] + da[k] * ta; bb[k] = bm[k] + db[k] * tb; }
+  closest_segment_point(na, a0, a1, bb);
+  closest_segment_point(nb, b0, b1, ba);
+  double d1 = 0, d2 = 0;
+  for (int k = 0; k < 3; k++) { d1 += (bb[k] - na[k]) * (bb[k] - na[k]); d2 += (ba[k] - nb[k]) * (ba[k] - nb[k]); }
+  if (d1 < d2) { v3cpy(best_a_out, na); v3cpy(best_b_out, bb); }
+  else { v3cpy(best_a_out, ba); v3cpy(best_b_out, nb); }
+}
+/* math.py:323-333: index of a_ij = a_ji in a packed upper triangle without / with the diagonal */
+int ref_upper_tri_index(int n, int i, int j) { return (i * (2 * n - i - 3)) / 2 + j - 1; }
+int ref_upper_trid_index(int n, int i, int j) {
+  if (j < i) { int t = i; i = j; j = t; }
+  return (i * (2 * n - i - 1)) / 2 + j;
+}
+
 /* capsule_box collision_primitive_core.py:1099 (MuJoCo's mjc_CapsuleBox): the point of the capsule segment closest to the box
  * gives the first contact sphere; when the capsule lies along a face or an edge a second sphere is placed further along the
  * segment (as far as the capsule still is above the box).  Segment parameter t in [-1, 1]: point = pos + t * halfaxis. */
@@ -1229,37 +1261,152 @@ static void contact_params(const RefModel* m, int g1, int g2, int pid, int* cond
   for (int k = 0; k < 5; k++) friction[k] = fmax(MINMU, friction[k]);
 }
 
-/* collision_driver.py:98-120 (plane, sphere filters), 684-770 (nxn), collision_core.py:214-294 (write_contact) */
+/* _aabb_filter collision_driver.py:124-223: world-aligned boxes around the two rotated local boxes */
+static int aabb_filter(const double* c1, const double* c2, const double* s1, const double* s2, double margin, const double* x1,
+                       const double* x2, const double* R1, const double* R2) {
+  double ctr[2][3], mx[2][3], mn[2][3];
+  const double* cs[2] = {c1, c2};
+  const double* ss[2] = {s1, s2};
+  const double* xs[2] = {x1, x2};
+  const double* Rs[2] = {R1, R2};
+  for (int g = 0; g < 2; g++) {
+    for (int k = 0; k < 3; k++) {
+      ctr[g][k] = Rs[g][3 * k] * cs[g][0] + Rs[g][3 * k + 1] * cs[g][1] + Rs[g][3 * k + 2] * cs[g][2] + xs[g][k];
+      mx[g][k] = -MAXVAL;
+      mn[g][k] = MAXVAL;
+    }
+    for (int i = 0; i < 8; i++) {
+      double corner[3] = {(i & 4 ? 1 : -1) * ss[g][0], (i & 2 ? 1 : -1) * ss[g][1], (i & 1 ? 1 : -1) * ss[g][2]};
+      for (int k = 0; k < 3; k++) {
+        double pk = Rs[g][3 * k] * corner[0] + Rs[g][3 * k + 1] * corner[1] + Rs[g][3 * k + 2] * corner[2];
+        if (pk > mx[g][k]) mx[g][k] = pk;
+        if (pk < mn[g][k]) mn[g][k] = pk;
+      }
+    }
+  }
+  for (int k = 0; k < 3; k++) {
+    if (ctr[0][k] + mx[0][k] + margin < ctr[1][k] + mn[1][k]) return 0;
+    if (ctr[1][k] + mx[1][k] + margin < ctr[0][k] + mn[0][k]) return 0;
+  }
+  return 1;
+}
+/* _obb_filter collision_driver.py:226-275 (mj_collideOBB): separating axis test on the six face normals */
+static int obb_filter(const double* c1, const double* c2, const double* s1, const double* s2, double margin, const double* x1,
+                      const double* x2, const double* R1, const double* R2) {
+  double xc[2][3], nrm[6][3];
+  const double* ss[2] = {s1, s2};
+  for (int k = 0; k < 3; k++) {
+    xc[0][k] = R1[3 * k] * c1[0] + R1[3 * k + 1] * c1[1] + R1[3 * k + 2] * c1[2] + x1[k];
+    xc[1][k] = R2[3 * k] * c2[0] + R2[3 * k + 1] * c2[1] + R2[3 * k + 2] * c2[2] + x2[k];
+  }
+  for (int a = 0; a < 3; a++)
+    for (int k = 0; k < 3; k++) { nrm[a][k] = R1[3 * k + a]; nrm[3 + a][k] = R2[3 * k + a]; }
+  for (int j = 0; j < 2; j++)
+    for (int k = 0; k < 3; k++) {
+      double proj[2], radius[2];
+      for (int i = 0; i < 2; i++) {
+        proj[i] = v3dot(xc[i], nrm[3 * j + k]);
+        radius[i] = fabs(ss[i][0] * v3dot(nrm[3 * i], nrm[3 * j + k])) + fabs(ss[i][1] * v3dot(nrm[3 * i + 1], nrm[3 * j + k])) +
+                    fabs(ss[i][2] * v3dot(nrm[3 * i + 2], nrm[3 * j + k]));
+      }
+      if (radius[0] + radius[1] + margin < fabs(proj[1] - proj[0])) return 0;
+    }
+  return 1;
+}
+/* _broadphase_filter collision_driver.py:278-334.  (Explicit <contact><pair> entries use the pair's margin + gap here, as
+ * MuJoCo C does; the reference uses the geoms' own.) */
+static int broadphase_filter(const RefModel* m, const RefData* d, int p, int g1, int g2) {
+  double rb1 = m->geom_rbound[g1], rb2 = m->geom_rbound[g2];
+  int pid = m->nexplicit ? m->nxn_pairid[p] : -1;
+  double mg = pid >= 0 ? m->xpair_margin[pid] + m->xpair_gap[pid]
+                       : m->geom_margin[g1] + m->geom_gap[g1] + m->geom_margin[g2] + m->geom_gap[g2];
+  const double *x1 = d->geom_xpos + 3 * g1, *x2 = d->geom_xpos + 3 * g2;
+  const double *R1 = d->geom_xmat + 9 * g1, *R2 = d->geom_xmat + 9 * g2;
+  double dif[3];
+  int filt = m->broadphase_filter;
+  if (rb1 == 0.0 || rb2 == 0.0) {
+    if (!(filt & 1)) return 1;
+    if (rb1 == 0.0) {
+      double nrm[3] = {R1[2], R1[5], R1[8]};
+      v3sub(dif, x2, x1);
+      return v3dot(dif, nrm) <= rb2 + mg;
+    }
+    double nrm[3] = {R2[2], R2[5], R2[8]};
+    v3sub(dif, x1, x2);
+    return v3dot(dif, nrm) <= rb1 + mg;
+  }
+  if (filt & 2) {
+    double bound = rb1 + rb2 + mg;
+    v3sub(dif, x2, x1);
+    if (!(v3dot(dif, dif) <= bound * bound)) return 0;
+  }
+  const double *a1 = m->geom_aabb + 6 * g1, *a2 = m->geom_aabb + 6 * g2;
+  if ((filt & 4) && !aabb_filter(a1, a2, a1 + 3, a2 + 3, mg, x1, x2, R1, R2)) return 0;
+  if ((filt & 8) && !obb_filter(a1, a2, a1 + 3, a2 + 3, mg, x1, x2, R1, R2)) return 0;
+  return 1;
+}
+
+/* sap_broadphase collision_driver.py:567-682: candidates = pairs whose bounding-sphere projections on a fixed direction overlap
+ * (_sap_project 375, sort, sap_range collision_core.py:501 incl. its "limit" element, sweep 424).  The reference appends pairs
+ * in atomic order; here the surviving pairs are reported in the canonical pair order so that contacts do not depend on the
+ * broadphase.  mark[p] = 1 for every filtered pair index p the sweep visits. */
+static void sap_candidates(const RefModel* m, const RefData* d, unsigned char* mark) {
+  int ng = m->ngeom;
+  double dir[3] = {0.5935, 0.7790, 0.1235};
+  double dn = sqrt(v3dot(dir, dir));
+  for (int k = 0; k < 3; k++) dir[k] /= dn;
+  double* lo = (double*)malloc(sizeof(double) * 2 * (size_t)(ng > 0 ? ng : 1));
+  double* hi = lo + ng;
+  int* idx = (int*)malloc(sizeof(int) * (size_t)(ng > 0 ? ng : 1));
+  for (int g = 0; g < ng; g++) {
+    double rb = m->geom_rbound[g];
+    if (rb == 0.0) rb = MAXVAL;
+    double radius = rb + m->geom_margin[g] + m->geom_gap[g], center = v3dot(dir, d->geom_xpos + 3 * g);
+    idx[g] = g;
+    if (center == center) { lo[g] = center - radius; hi[g] = center + radius; }
+    else { lo[g] = MAXVAL; hi[g] = MAXVAL; }
+  }
+  for (int i = 1; i < ng; i++) {  /* stable insertion sort by the lower bound */
+    int gi = idx[i];
+    int j = i - 1;
+    while (j >= 0 && lo[idx[j]] > lo[gi]) { idx[j + 1] = idx[j]; j--; }
+    idx[j + 1] = gi;
+  }
+  /* pair index of an unordered geom pair in the filtered list (-1: filtered out) */
+  for (int i = 0; i < ng; i++) {
+    double upper = hi[idx[i]];
+    int lower_i = i + 1, upper_i = ng;  /* sap_binary_search: first sorted element with lower bound > upper */
+    while (lower_i < upper_i) {
+      int mid = (lower_i + upper_i) >> 1;
+      if (lo[idx[mid]] > upper) upper_i = mid; else lower_i = mid + 1;
+    }
+    int limit = upper_i < ng - 1 ? upper_i : ng - 1;
+    for (int j = i + 1; j <= limit; j++) {
+      int g1 = idx[i], g2 = idx[j];
+      if (g2 < g1) { int t = g1; g1 = g2; g2 = t; }
+      for (int p = 0; p < m->npair; p++)  /* (the oracle scans; the engine looks the pair up in a table) */
+        if (m->pair_geom[2 * p] == g1 && m->pair_geom[2 * p + 1] == g2) { mark[p] = 1; break; }
+    }
+  }
+  free(lo);
+  free(idx);
+}
+
+/* collision_driver.py:98-334 (filters), 567-682 (SAP), 684-770 (nxn), collision_core.py:214-294 (write_contact) */
 void ref_collision(const RefModel* m, RefData* d) {
   d->ncon = 0;
   d->ncollision = 0;
   if (m->disableflags & (DSBL_CONSTRAINT | DSBL_CONTACT)) return;
+  unsigned char* mark = NULL;
+  if (m->broadphase != 0) {
+    mark = (unsigned char*)calloc((size_t)(m->npair > 0 ? m->npair : 1), 1);
+    sap_candidates(m, d, mark);
+  }
   for (int p = 0; p < m->npair; p++) {
     int g1 = m->pair_geom[2 * p], g2 = m->pair_geom[2 * p + 1];
-    double rb1 = m->geom_rbound[g1], rb2 = m->geom_rbound[g2];
     int pid = m->nexplicit ? m->nxn_pairid[p] : -1;
-    double mg = pid >= 0 ? m->xpair_margin[pid] + m->xpair_gap[pid]
-                         : m->geom_margin[g1] + m->geom_gap[g1] + m->geom_margin[g2] + m->geom_gap[g2];
-    const double *x1 = d->geom_xpos + 3 * g1, *x2 = d->geom_xpos + 3 * g2;
-    double dif[3];
-    int pass = 1;
-    if (rb1 == 0.0 || rb2 == 0.0) {
-      if (rb1 == 0.0) {
-        const double* R = d->geom_xmat + 9 * g1;
-        double nrm[3] = {R[2], R[5], R[8]};
-        v3sub(dif, x2, x1);
-        pass = v3dot(dif, nrm) <= rb2 + mg;
-      } else {
-        const double* R = d->geom_xmat + 9 * g2;
-        double nrm[3] = {R[2], R[5], R[8]};
-        v3sub(dif, x1, x2);
-        pass = v3dot(dif, nrm) <= rb1 + mg;
-      }
-    } else {
-      double bound = rb1 + rb2 + mg;
-      v3sub(dif, x2, x1);
-      pass = v3dot(dif, dif) <= bound * bound;
-    }
+    if (mark && !mark[p]) continue;
+    int pass = broadphase_filter(m, d, p, g1, g2);
     if (!pass) continue;
     d->ncollision++;
     if (m->geom_type[g1] > m->geom_type[g2]) { int t = g1; g1 = g2; g2 = t; }
@@ -1288,6 +1435,7 @@ void ref_collision(const RefModel* m, RefData* d) {
     }
   }
   if (d->ncon > m->nconmax) d->ncon = m->nconmax;
+  free(mark);
 }
 
 /* ================================================================ constraint.py */

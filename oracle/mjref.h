@@ -37,6 +37,8 @@ typedef struct RefModel {
   int iterations;
   int ls_iterations;
   int disableflags;
+  int broadphase;        /* BroadphaseType: 0 NXN, 1 SAP_TILE, 2 SAP_SEGMENTED (io.py:631-636) */
+  int broadphase_filter; /* BroadphaseFilter bits: 1 plane, 2 sphere, 4 AABB, 8 OBB (io.py:405) */
   double timestep;
   double tolerance;
   double ls_tolerance;
@@ -95,6 +97,7 @@ typedef struct RefModel {
   double* geom_solimp;
   double* geom_size;
   double* geom_rbound;
+  double* geom_aabb; /* [ngeom, 6]: centre, half sizes in the geom frame */
   double* geom_pos;
   double* geom_quat;
   double* geom_friction;
@@ -234,6 +237,10 @@ void ref_rungekutta4(const RefModel* m, RefData* d); /* forward.py:524; call aft
 void ref_step(const RefModel* m, RefData* d);
 void ref_ctrl_noise(const RefModel* m, RefData* d, const double* center, int step, int worldid, double noise_std, double noise_rate);
 double ref_halton(int index, int base);
+void ref_closest_segment_to_segment_points(const double* a0, const double* a1, const double* b0, const double* b1, double* best_a_out,
+                                           double* best_b_out); /* math.py:283 */
+int ref_upper_tri_index(int n, int i, int j);  /* math.py:323 */
+int ref_upper_trid_index(int n, int i, int j); /* math.py:329 */
 int ref_rollout(const RefModel* m, RefData* d, int nstep, int worldid, double noise_std, double noise_rate, double* qpos_out, double* qvel_out);
 
 #endif

@@ -73,6 +73,11 @@ def lib():
     _lib.ref_halton.restype = ctypes.c_double
     _lib.ref_rollout.argtypes = [mp, dp, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double, dptr, dptr]
     _lib.ref_rollout.restype = ctypes.c_int
+    _lib.ref_closest_segment_to_segment_points.argtypes = [dptr] * 6
+    _lib.ref_closest_segment_to_segment_points.restype = None
+    for fn in (_lib.ref_upper_tri_index, _lib.ref_upper_trid_index):
+      fn.argtypes = [ctypes.c_int] * 3
+      fn.restype = ctypes.c_int
   return _lib
 
 
@@ -122,7 +127,7 @@ class RefSim:
   """One float64 world: model struct + data arrays (numpy-owned) for the C oracle."""
 
   def __init__(self, mjm, nconmax=64, njmax=256, tolerance=None, solver=None, iterations=None, ls_iterations=None,
-               integrator=None):
+               integrator=None, broadphase=0, broadphase_filter=3):
     self.mjm = mjm
     self._keep = []
     cm = CRefModel()
@@ -149,7 +154,7 @@ class RefSim:
       solver=int(opt.solver if solver is None else solver),
       iterations=int(opt.iterations if iterations is None else iterations),
       ls_iterations=int(opt.ls_iterations if ls_iterations is None else ls_iterations),
-      disableflags=int(opt.disableflags), timestep=float(opt.timestep),
+      disableflags=int(opt.disableflags), broadphase=int(broadphase), broadphase_filter=int(broadphase_filter), timestep=float(opt.timestep),
       tolerance=float(opt.tolerance if tolerance is None else tolerance), ls_tolerance=float(opt.ls_tolerance),
       impratio=float(opt.impratio), meaninertia=float(mjm.stat.meaninertia))
     if scalars["cone"] != 0:
