@@ -58,7 +58,10 @@ typedef struct MjhModel {
   int nbodylevel; int ndoflevel; int nv_pad; int neq;
   int nexplicit;       /* explicit <contact><pair> entries (pair_* tables below); 0: every pair mixes its geoms' parameters */
   int nmocap;          /* mocap bodies (static bodies posed by Data.mocap_pos / mocap_quat, smooth.py:104-108) */
-  int heavy_colliders; /* 1: capsule-box / box-box pairs or explicit contact pairs present (selects the kernel instantiation that carries them) */
+  int heavy_colliders; /* 1: capsule-box / box-box pairs, explicit contact pairs, AABB / OBB broadphase filters or the SAP broadphase
+                          (selects the kernel instantiation that carries them) */
+  int broadphase;        /* BroadphaseType (types.py:60-71): 0 NXN, 1 SAP_TILE, 2 SAP_SEGMENTED (both: in-LDS bitonic sort per world) */
+  int broadphase_filter; /* BroadphaseFilter bits (types.py:73-87): 1 plane, 2 sphere, 4 AABB, 8 OBB */
   /* options (types.py:836-905); solver: 0 = PGS (extension, the reference has none: types.py:502), 1 = CG, 2 = Newton */
   int integrator; int cone; int solver; int iterations; int ls_iterations; int disableflags; int enableflags;
   const float* opt_timestep; int opt_timestep_nb;
@@ -115,6 +118,7 @@ typedef struct MjhModel {
   const float* geom_solimp; int geom_solimp_nb;
   const float* geom_size; int geom_size_nb;
   const float* geom_rbound; int geom_rbound_nb;
+  const float* geom_aabb; int geom_aabb_nb;   /* [ngeom, 6]: centre, half sizes in the geom frame (types.py Model.geom_aabb) */
   const float* geom_pos; int geom_pos_nb;
   const float* geom_quat; int geom_quat_nb;
   const float* geom_friction; int geom_friction_nb;
@@ -122,6 +126,8 @@ typedef struct MjhModel {
   const float* geom_gap; int geom_gap_nb;
   const int* nxn_geom_pair;     /* [npair, 2] pre-filtered geom pairs, upper-triangular order (io.py:551-640) */
   const int* nxn_pairid;        /* [npair] explicit pair index or -1 (io.py:575-590)             */
+  const int* nxn_pairindex;     /* [ngeom (ngeom - 1) / 2] index into nxn_geom_pair of the unordered geom pair (math.upper_tri_index
+                                   order) or -1 when the pair is filtered out: the SAP sweep's lookup (collision_driver.py:485) */
   /* explicit contact pairs (types.py Model.pair_*): parameters that replace the geom mixing */
   const int* pair_dim; const float* pair_friction; const float* pair_solref; const float* pair_solreffriction;
   const float* pair_solimp; const float* pair_margin; const float* pair_gap;
@@ -222,7 +228,7 @@ int mjh_timed_steps(const MjhModel* m, const MjhData* d, int nstep, int step0, f
                     void* stream, float* ms_out, float* per_kernel_ms, int plain_kernels);
 
 const char* mjh_last_error(void);
-#define MJH_ABI_VERSION 6
+#define MJH_ABI_VERSION 7
 int mjh_abi_version(void); /* returns MJH_ABI_VERSION of the library that was loaded */
 
 #ifdef __cplusplus

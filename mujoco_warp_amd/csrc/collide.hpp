@@ -743,8 +743,69 @@ DEV PairParams contact_params(const MjhModel& m, int w, int g1, int g2, int pid 
 #define CON_STRIDE 32
 // per-world LDS: geom poses (12 words per geom) | candidate pair list | first contact slot << 8 | contact mask per
 // candidate | staging window of CON_WINDOW records
-__host__ __device__ inline int collide_lds_words(int ngeom, int npair) {
-  return 12 * ngeom + ((npair + 3) / 4) * 4 + ((npair + 3) / 4) * 4 + CON_WINDOW * CON_LDS;
+// SAP broadphase (sap != 0) adds: projection bounds (2 words per geom, padded to a power of two for the bitonic sort) | sorted
+// geom ids | one mark bit per filtered pair
+__host__ __device__ inline int sap_pow2(int n) {
+  int p = 1;
+  while (p < n) p <<= 1;
+  return p;
+}
+// candidate capacity per world: every filtered pair for ordinary models; capped for big scenes (thousands of pairs of which few
+// survive the broadphase), where running out sets OverflowType.BROADPHASE like the reference's full pair queue
+__host__ __device__ inline int collide_ccap(int npair, int concap) {
+  const int cap = 8 * concap > 512 ? 8 * concap : 512;
+  return ((npair < cap ? npair : cap) + 3) / 4 * 4;
+}
+__host__ __device__ inline int collide_lds_words(int ngeom, int npair, int concap, int sap = 0) {
+  const int base = 12 * ngeom + 2 * collide_ccap(npair, concap) + CON_WINDOW * CON_LDS;
+  return base + (sap ? 3 * sap_pow2(ngeom) + ((npair + 31) / 32 + 3) / 4 * 4 : 0);
+}
+
+// ---- broadphase filters beyond plane / bounding sphere (collision_driver.py:124-275), HEAVY instantiation only ----------
+// world-aligned boxes around the two rotated local boxes (_aabb_filter)
+DEV bool aabb_filter(const float* a1, const float* a2, float margin, V3 x1, V3 x2, const float* R1, const float* R2) {
+  float ctr[2][3], mx[2][3], mn[2][3];
+  const float* as[2] = {a1, a2};
+  const float* Rs[2] = {R1, R2};
+  const V3 xs[2] = {x1, x2};
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const V3 c = mat_mul(Rs[g], ld3(as[g])) + xs[g];
+    ctr[g][0] = c.x; ctr[g][1] = c.y; ctr[g][2] = c.z;
+    const float sx = as[g][3], sy = as[g][4], sz = as[g][5];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {  // extreme of R (+-sx, +-sy, +-sz) along world axis k = sum of absolute terms
+      const float e = fabsf(Rs[g][3 * k] * sx) + fabsf(Rs[g][3 * k + 1] * sy) + fabsf(Rs[g][3 * k + 2] * sz);
+      mx[g][k] = e;
+      mn[g][k] = -e;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    if (ctr[0][k] + mx[0][k] + margin < ctr[1][k] + mn[1][k]) return false;
+    if (ctr[1][k] + mx[1][k] + margin < ctr[0][k] + mn[0][k]) return false;
+  }
+  return true;
+}
+// separating-axis test on the six face normals of the two oriented boxes (_obb_filter, mj_collideOBB)
+DEV bool obb_filter(const float* a1, const float* a2, float margin, V3 x1, V3 x2, const float* R1, const float* R2) {
+  const V3 c1 = mat_mul(R1, ld3(a1)) + x1, c2 = mat_mul(R2, ld3(a2)) + x2;
+  V3 nrm[6];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    nrm[a] = V3{R1[a], R1[3 + a], R1[6 + a]};
+    nrm[3 + a] = V3{R2[a], R2[3 + a], R2[6 + a]};
+  }
+  const float* ss[2] = {a1 + 3, a2 + 3};
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    float radius = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      radius += fabsf(ss[i][0] * dot(nrm[3 * i], nrm[j])) + fabsf(ss[i][1] * dot(nrm[3 * i + 1], nrm[j])) + fabsf(ss[i][2] * dot(nrm[3 * i + 2], nrm[j]));
+    if (radius + margin < fabsf(dot(c2, nrm[j]) - dot(c1, nrm[j]))) return false;
+  }
+  return true;
 }
 
 // HEAVY: the instantiation that also carries the large colliders (capsule-box, box-box) and the explicit <contact><pair>
@@ -756,12 +817,13 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
   const int w = b.w0 + gib;
   if ((int)threadIdx.x >= b.nthreads || w >= d.nworld) return;
   const int npair = m.npair, ng = m.ngeom, ncap = d.concap;
-  float* S = smem + (size_t)gib * (stride_words ? stride_words : collide_lds_words(ng, npair));
+  float* S = smem + (size_t)gib * (stride_words ? stride_words : collide_lds_words(ng, npair, ncap, HEAVY ? m.broadphase : 0));
   float* gxpos = S;
   float* gxmat = S + 3 * ng;
   int* cand = reinterpret_cast<int*>(S + 12 * ng);
-  int* cslot = cand + ((npair + 3) / 4) * 4;
-  float* rec = reinterpret_cast<float*>(cslot + ((npair + 3) / 4) * 4);
+  const int ccap = collide_ccap(npair, ncap);
+  int* cslot = cand + ccap;
+  float* rec = reinterpret_cast<float*>(cslot + ccap);
 
   if (m.disableflags & (DSBL_CONSTRAINT | DSBL_CONTACT)) {
     if (lig == 0) {
@@ -780,19 +842,95 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
   gsync();
   pc.mark(0);
 
-  // ---- broadphase: plane / bounding-sphere filter, ordered compaction -----------------------------------
+  // ---- broadphase (collision_driver.py:278-334 filters, 567-682 SAP, 684-770 NXN), ordered compaction --------------------
+  // The candidates always leave in the canonical pair order, whatever produced them, so contacts do not depend on the
+  // broadphase.  Plane / bounding-sphere filters live in both instantiations; AABB / OBB filters and the sweep-and-prune
+  // candidate generator only in the HEAVY one (the light k_mid sits exactly at its 4-waves-per-SIMD register budget).
+  const int filt = HEAVY ? m.broadphase_filter : 3;
+  const float* gaabb = HEAVY ? bf(m.geom_aabb, m.geom_aabb_nb, w, 6 * ng) : nullptr;
+  unsigned* sapmark = nullptr;
+  if (HEAVY && m.broadphase != 0) {
+    // sweep and prune: project the bounding spheres on a fixed direction, sort by the lower bound (bitonic, in LDS), sweep
+    const int np2 = sap_pow2(ng);
+    float* plo = rec + CON_WINDOW * CON_LDS;
+    float* phi = plo + np2;
+    int* sidx = reinterpret_cast<int*>(phi + np2);
+    sapmark = reinterpret_cast<unsigned*>(sidx + np2);
+    const float dn = 1.0f / sqrtf(0.5935f * 0.5935f + 0.7790f * 0.7790f + 0.1235f * 0.1235f);
+    const V3 dir = V3{0.5935f * dn, 0.7790f * dn, 0.1235f * dn};
+    for (int g = lig; g < np2; g += G) {
+      float lo = 3.0e38f, hi = 3.0e38f;  // padding sorts last
+      if (g < ng) {
+        float rb = rbound[g];
+        if (rb == 0.0f) rb = MJ_MAXVAL;
+        const float radius = rb + gmargin[g] + ggap[g], center = dot(dir, ld3(gxpos + 3 * g));
+        const bool ok = center == center;
+        lo = ok ? center - radius : MJ_MAXVAL;
+        hi = ok ? center + radius : MJ_MAXVAL;
+      }
+      plo[g] = lo;
+      phi[g] = hi;
+      sidx[g] = g;
+    }
+    for (int i = lig; i < (npair + 31) / 32; i += G) sapmark[i] = 0u;
+    gsync();
+    for (int k = 2; k <= np2; k <<= 1)  // bitonic sort of (lower bound, geom id); ties broken by geom id: deterministic
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int t = lig; t < np2; t += G) {
+          const int u = t ^ j;
+          if (u > t) {
+            const int a = sidx[t], b2 = sidx[u];
+            const float la = plo[a < ng ? a : 0], lb = plo[b2 < ng ? b2 : 0];
+            const float ka = a < ng ? la : 3.0e38f, kb = b2 < ng ? lb : 3.0e38f;
+            const bool up = (t & k) == 0;
+            const bool gt = ka > kb || (ka == kb && a > b2);
+            if (gt == up) {
+              sidx[t] = b2;
+              sidx[u] = a;
+            }
+          }
+        }
+        gsync();
+      }
+    // sap_range (collision_core.py:501) + sweep: sorted element i against i+1 .. limit (the first element whose lower bound
+    // exceeds i's upper bound, included as in the reference)
+    for (int i = lig; i < ng; i += G) {
+      const int gi = sidx[i];
+      const float upper = phi[gi];
+      int lo_i = i + 1, hi_i = ng;
+      while (lo_i < hi_i) {
+        const int mid = (lo_i + hi_i) >> 1;
+        if (plo[sidx[mid]] > upper) hi_i = mid;
+        else lo_i = mid + 1;
+      }
+      const int limit = hi_i < ng - 1 ? hi_i : ng - 1;
+      for (int j = i + 1; j <= limit; ++j) {
+        int g1 = gi, g2 = sidx[j];
+        if (g2 < g1) {
+          const int t = g1;
+          g1 = g2;
+          g2 = t;
+        }
+        const int p = m.nxn_pairindex[(g1 * (2 * ng - g1 - 3)) / 2 + g2 - 1];  // upper_tri_index math.py:323
+        if (p >= 0) atomicOr(sapmark + (p >> 5), 1u << (p & 31));
+      }
+    }
+    gsync();
+  }
   int ncand = 0;
   for (int base = 0; base < npair; base += G) {
     const int p = base + lig;
     bool pass = false;
-    if (p < npair) {
+    if (p < npair && (!sapmark || ((sapmark[p >> 5] >> (p & 31)) & 1u))) {
       const int g1 = m.nxn_geom_pair[2 * p], g2 = m.nxn_geom_pair[2 * p + 1];
       const float rb1 = rbound[g1], rb2 = rbound[g2];
       const int pid = (HEAVY && m.nexplicit) ? m.nxn_pairid[p] : -1;
       const float mg = pid >= 0 ? m.pair_margin[pid] + m.pair_gap[pid] : gmargin[g1] + ggap[g1] + gmargin[g2] + ggap[g2];
       V3 x1 = ld3(gxpos + 3 * g1), x2 = ld3(gxpos + 3 * g2);
       if (rb1 == 0.0f || rb2 == 0.0f) {
-        if (rb1 == 0.0f) {
+        if (!(filt & 1)) {
+          pass = true;
+        } else if (rb1 == 0.0f) {
           const float* R = gxmat + 9 * g1;
           pass = dot(x2 - x1, V3{R[2], R[5], R[8]}) <= rb2 + mg;
         } else {
@@ -800,16 +938,25 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
           pass = dot(x1 - x2, V3{R[2], R[5], R[8]}) <= rb1 + mg;
         }
       } else {
-        const float bound = rb1 + rb2 + mg;
-        V3 dif = x2 - x1;
-        pass = dot(dif, dif) <= bound * bound;
+        pass = true;
+        if (filt & 2) {
+          const float bound = rb1 + rb2 + mg;
+          V3 dif = x2 - x1;
+          pass = dot(dif, dif) <= bound * bound;
+        }
+        if (HEAVY) {
+          if (pass && (filt & 4)) pass = aabb_filter(gaabb + 6 * g1, gaabb + 6 * g2, mg, x1, x2, gxmat + 9 * g1, gxmat + 9 * g2);
+          if (pass && (filt & 8)) pass = obb_filter(gaabb + 6 * g1, gaabb + 6 * g2, mg, x1, x2, gxmat + 9 * g1, gxmat + 9 * g2);
+        }
       }
     }
     int tot;
     const int rank = grank<G>(pass, lig, tot);
-    if (pass) cand[ncand + rank] = p;
+    if (pass && ncand + rank < ccap) cand[ncand + rank] = p;
     ncand += tot;
   }
+  const int nbroad = ncand;  // candidates found (Data.ncollision); the capacity bounds what the narrowphase sees
+  if (ncand > ccap) ncand = ccap;
   gsync();
   pc.mark(1);
 
@@ -915,8 +1062,9 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
   }
   if (lig == 0) {
     d.ws_ncon[w] = ncon;
-    d.ws_ncollision[w] = ncand;
+    d.ws_ncollision[w] = nbroad;
     if (ncon < nfound) atomicOr(d.overflow + w, OVF_NARROWPHASE);
+    if (ncand < nbroad) atomicOr(d.overflow + w, OVF_BROADPHASE);
   }
 }
 

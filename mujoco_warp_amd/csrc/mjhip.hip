@@ -82,7 +82,7 @@ static int launch_factor_smooth(const MjhModel* m, const MjhData* d, int write_q
 }
 static int launch_collision(const MjhModel* m, const MjhData* d, hipStream_t s) {
   size_t lds;
-  const int threads = pick_block(0, sizeof(float) * collide_lds_words(m->ngeom, m->npair), G, &lds);
+  const int threads = pick_block(0, sizeof(float) * collide_lds_words(m->ngeom, m->npair, d->concap, m->heavy_colliders ? m->broadphase : 0), G, &lds);
   if (!threads) return fail(MJH_E_UNSUPPORTED, "k_collision: pair list does not fit in LDS");
   if (m->heavy_colliders) {
     HIPCHK(set_lds((k_collision<G, true>), lds));
@@ -184,7 +184,7 @@ __global__ void __launch_bounds__(256) k_fwd_pos_plus(MjhModel m, MjhData d, int
 
 static int launch_mid(const MjhModel* m, const MjhData* d, bool sched, hipStream_t s) {
   const ConLayout cl = con_layout(m->nv, d->njmax, d->concap, m->nbody, m->ngeom);
-  const int stride_cc = std::max(cl.total, collide_lds_words(m->ngeom, m->npair) | 1);
+  const int stride_cc = std::max(cl.total, collide_lds_words(m->ngeom, m->npair, d->concap, m->heavy_colliders ? m->broadphase : 0) | 1);
   const VelLayout vl = vel_layout(m->nq, m->nv, m->nbody, m->nC, m->nu);
   const size_t ms_bytes = sizeof(int) * mstruct_ints(m->nv, m->nC);
   // 8 collision+constraint worlds per workgroup; as many fwd_vel worlds as fit in the same LDS footprint

@@ -89,6 +89,16 @@ def geom_pairs_with_ids(mjm):
 _SUPPORTED_PAIRS = {(0, 2), (0, 3), (0, 4), (0, 5), (0, 6), (2, 2), (2, 3), (2, 5), (2, 6), (3, 3), (3, 6), (6, 6)}
 
 
+def _pair_index(ngeom, pairs):
+  """[ngeom (ngeom - 1) / 2] index into the filtered pair list of every unordered geom pair, -1 if filtered out (the SAP sweep's
+  lookup; enumeration = math.upper_tri_index, reference math.py:323, collision_driver.py:485)."""
+  out = np.full(max(ngeom * (ngeom - 1) // 2, 1), -1, dtype=np.int32)
+  for p, (a, b) in enumerate(pairs):
+    a, b = int(min(a, b)), int(max(a, b))
+    out[(a * (2 * ngeom - a - 3)) // 2 + b - 1] = p
+  return out
+
+
 def _arr(x, dtype):
   return np.ascontiguousarray(np.asarray(x), dtype=dtype)
 
@@ -161,6 +171,7 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
   if not condims <= {1, 3, 4, 6}:
     raise NotImplementedError(f"unsupported condim values {condims}")
 
+  ngeom_ = int(mjm.ngeom)
   m = types.Model()
   nv, nbody, njnt, ngeom, nu = int(mjm.nv), int(mjm.nbody), int(mjm.njnt), int(mjm.ngeom), int(mjm.nu)
   for name in ("nq", "nv", "nu", "na", "nbody", "njnt", "ngeom", "nsite", "nkey", "nmocap"):
@@ -170,7 +181,8 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
   m.nC = int(np.sum(mjm.M_rownnz)) if nv else 0
   m.nM = m.nC
   # capsule-box / box-box pairs and explicit contact pairs select the kernel instantiation that carries them (include/mjhip.h)
-  m.heavy_colliders = int(any((int(min(gt[a], gt[b])), int(max(gt[a], gt[b]))) in ((3, 6), (6, 6)) for a, b in pairs) or int(getattr(mjm, "npair", 0)) > 0)
+  m._heavy_pairs = int(any((int(min(gt[a], gt[b])), int(max(gt[a], gt[b]))) in ((3, 6), (6, 6)) for a, b in pairs) or int(getattr(mjm, "npair", 0)) > 0)
+  m.heavy_colliders = m._heavy_pairs  # c_model() adds the broadphase options (they may be changed after put_model)
   m.is_sparse = False
   m.nv_pad = _get_padded_sizes(nv, 1)[1]
 
@@ -186,7 +198,11 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
   o.impratio_invsqrt = np.array([1.0 / np.sqrt(max(float(opt.impratio), types.MJ_MINVAL))], dtype=f32)
   for name in ("integrator", "cone", "solver", "iterations", "ls_iterations", "disableflags", "enableflags"):
     setattr(o, name, int(getattr(opt, name)))
-  o.broadphase = types.BroadphaseType.NXN
+  # reference io.py:631-636: NXN below 250k filtered pairs, SAP above (tile sort below 1000 geoms)
+  o.broadphase = (types.BroadphaseType.NXN if len(pairs) < 250_000 else
+                  types.BroadphaseType.SAP_TILE if ngeom_ < 1000 else types.BroadphaseType.SAP_SEGMENTED)
+  # the reference's default adds the OBB filter (io.py:405); contacts do not depend on the filter set (every filter is
+  # conservative), only Data.ncollision does, and plane + sphere keeps the light collision kernel
   o.broadphase_filter = types.BroadphaseFilter.PLANE | types.BroadphaseFilter.SPHERE
   o.graph_conditional = False
   o.run_collision_detection = True
@@ -256,7 +272,7 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
     dof_leveladr=dleveladr,
     M_rownnz=_arr(mjm.M_rownnz, i32), M_rowadr=_arr(mjm.M_rowadr, i32), M_colind=_arr(mjm.M_colind, i32),
     geom_type=_arr(mjm.geom_type, i32), geom_condim=_arr(mjm.geom_condim, i32), geom_bodyid=_arr(mjm.geom_bodyid, i32),
-    geom_priority=_arr(mjm.geom_priority, i32), nxn_geom_pair=pairs, nxn_pairid=pairid,
+    geom_priority=_arr(mjm.geom_priority, i32), nxn_geom_pair=pairs, nxn_pairid=pairid, nxn_pairindex=_pair_index(ngeom, pairs),
     pair_dim=_arr(getattr(mjm, "pair_dim", np.zeros(0)), i32), pair_friction=_arr(getattr(mjm, "pair_friction", np.zeros((0, 5))), f32).reshape(-1, 5),
     pair_solref=_arr(getattr(mjm, "pair_solref", np.zeros((0, 2))), f32).reshape(-1, 2),
     pair_solreffriction=_arr(getattr(mjm, "pair_solreffriction", np.zeros((0, 2))), f32).reshape(-1, 2),
@@ -274,7 +290,7 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
   host["eq_solimp"] = _arr(getattr(mjm, "eq_solimp", np.zeros((0, 5))), f32).reshape(1, neq, 5)
   host["eq_data"] = _arr(getattr(mjm, "eq_data", np.zeros((0, 11))), f32).reshape(1, neq, 11)
   m.eq_active0 = _arr(getattr(mjm, "eq_active0", np.zeros(0)), i32)
-  vec = {"body_pos": 3, "body_quat": 4, "body_ipos": 3, "body_iquat": 4, "body_inertia": 3, "body_invweight0": 2,
+  vec = {"geom_aabb": 6, "body_pos": 3, "body_quat": 4, "body_ipos": 3, "body_iquat": 4, "body_inertia": 3, "body_invweight0": 2,
          "jnt_solref": 2, "jnt_solimp": 5, "jnt_pos": 3, "jnt_axis": 3, "jnt_range": 2, "dof_solref": 2, "dof_solimp": 5,
          "geom_solref": 2, "geom_solimp": 5, "geom_size": 3, "geom_pos": 3, "geom_quat": 4, "geom_friction": 3,
          "site_pos": 3, "site_quat": 4, "actuator_dynprm": 10, "actuator_gainprm": 10, "actuator_biasprm": 10,
@@ -340,8 +356,15 @@ def c_model(m: types.Model):
         setattr(c, name + "_nb", src.shape[0])
     elif name.endswith("_nb"):
       continue
-    elif name in ("integrator", "cone", "solver", "iterations", "ls_iterations", "disableflags", "enableflags"):
+    elif name in ("integrator", "cone", "solver", "iterations", "ls_iterations", "disableflags", "enableflags", "broadphase", "broadphase_filter"):
       setattr(c, name, int(getattr(m.opt, name)))
+    elif name == "heavy_colliders":
+      bf_ = int(m.opt.broadphase_filter)
+      if bf_ & ~0xF:
+        raise ValueError(f"unknown broadphase filter bits {bf_:#x}")
+      if int(m.opt.broadphase) not in (0, 1, 2):
+        raise ValueError(f"unknown broadphase {int(m.opt.broadphase)}")
+      setattr(c, name, int(bool(m._heavy_pairs or bf_ != 3 or int(m.opt.broadphase) != 0)))  # (the light instantiation hard-wires plane + sphere)
     else:
       setattr(c, name, int(getattr(m, name)))
   object.__setattr__(m, "_c", c)

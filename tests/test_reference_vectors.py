@@ -300,3 +300,59 @@ def test_box_box_gap_distance_gpu(z2, expect):
   np.testing.assert_allclose(d.contact.dist.numpy()[:n], expect, atol=5e-5)
   normal = d.contact.frame.numpy()[:n, 0]
   np.testing.assert_allclose(np.abs(normal @ np.array([0.0, 0.0, 1.0])), 1.0, atol=1e-4)
+
+
+# ---- SAP against NXN on a crowded scene (no reference numbers: the two broadphases must agree with each other and the oracle) --
+def _crowd_xml(n=120, seed=3):
+  rng = np.random.default_rng(seed)
+  bodies = []
+  for i in range(n):
+    p = rng.uniform(-1.0, 1.0, 3) * np.array([1.2, 1.2, 0.4]) + np.array([0, 0, 0.6])
+    if i % 3 == 0:
+      g = f'<geom type="capsule" size="{rng.uniform(.04, .08):.3f} {rng.uniform(.05, .15):.3f}"/>'
+    elif i % 3 == 1:
+      g = f'<geom type="sphere" size="{rng.uniform(.05, .1):.3f}"/>'
+    else:
+      g = f'<geom type="box" size="{rng.uniform(.04, .09):.3f} {rng.uniform(.04, .09):.3f} {rng.uniform(.04, .09):.3f}"/>'
+    q = rng.standard_normal(4)
+    q /= np.linalg.norm(q)
+    bodies.append(f'<body pos="{p[0]:.3f} {p[1]:.3f} {p[2]:.3f}" quat="{q[0]:.4f} {q[1]:.4f} {q[2]:.4f} {q[3]:.4f}"><freejoint/>{g}</body>')
+  return '<mujoco><worldbody><geom name="floor" type="plane" size="0 0 .05"/>' + "".join(bodies) + "</worldbody></mujoco>"
+
+
+@pytest.mark.parametrize("bfilter", [3, 15])
+def test_sap_equals_nxn_oracle_crowd(bfilter):
+  mjm = mjw.mjcf.from_xml_string(_crowd_xml(60))
+  out = []
+  for bp in (0, 1):
+    s = ref.RefSim(mjm, nconmax=400, njmax=1600, broadphase=bp, broadphase_filter=bfilter)
+    s.reset()
+    s.stage("kinematics")
+    s.stage("collision")
+    out.append((s.ncollision, s.ncon, s.con_geom[: s.ncon].copy(), s.con_dist[: s.ncon].copy()))
+  assert out[0][0] == out[1][0] > 3 and out[0][1] == out[1][1] > 1
+  assert (out[0][2] == out[1][2]).all() and (out[0][3] == out[1][3]).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bfilter", [3, 15])
+def test_sap_equals_nxn_gpu_crowd(bfilter):
+  mjm = mjw.mjcf.from_xml_string(_crowd_xml(120))  # 121 geoms, 7260 pairs: the candidate list is capped, the pair bits are not
+  s = ref.RefSim(mjm, nconmax=800, njmax=3200, broadphase=0, broadphase_filter=bfilter)
+  s.reset()
+  s.stage("kinematics")
+  s.stage("collision")
+  res = []
+  for bp in (mjw.BroadphaseType.NXN, mjw.BroadphaseType.SAP_TILE):
+    m = mjw.put_model(mjm)
+    m.opt.broadphase, m.opt.broadphase_filter = int(bp), bfilter
+    d = mjw.make_data(mjm, nworld=2, nconmax=400, njmax=1600)
+    mjw.kinematics(m, d)
+    mjw.collision(m, d)
+    n = int(d.ws_ncon.numpy()[0])
+    res.append((int(d.ws_ncollision.numpy()[0]), n, d.contact.geom.numpy()[:n].copy(), d.contact.dist.numpy()[:n].copy()))
+    assert (d.overflow.numpy() == 0).all()
+  assert res[0][0] == res[1][0] == s.ncollision and res[0][1] == res[1][1] == s.ncon
+  assert (res[0][2] == res[1][2]).all() and (res[0][3] == res[1][3]).all()  # bitwise: same pairs in the same order
+  assert (res[0][2] == s.con_geom[: s.ncon]).all()
+  np.testing.assert_allclose(res[0][3], s.con_dist[: s.ncon], atol=2e-6)
