@@ -227,6 +227,10 @@ int mjh_graph_destroy(void* graph_exec);
 int mjh_timed_steps(const MjhModel* m, const MjhData* d, int nstep, int step0, float noise_std, float noise_rate,
                     void* stream, float* ms_out, float* per_kernel_ms, int plain_kernels);
 
+/* Frees what the calling host thread holds inside the library (the low-priority side stream and its two events that a Newton
+ * step forks onto, one set per device).  Optional: call when a stepping thread ends; safe to call more than once. */
+int mjh_release_thread_resources(void);
+
 const char* mjh_last_error(void);
 #define MJH_ABI_VERSION 7
 int mjh_abi_version(void); /* returns MJH_ABI_VERSION of the library that was loaded */

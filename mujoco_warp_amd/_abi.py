@@ -144,6 +144,9 @@ def lib():
   for f in FUNCTIONS:
     if f != "mjh_last_error":
       getattr(L, f).restype = ctypes.c_int
+  import atexit
+
+  atexit.register(lambda: L.mjh_release_thread_resources())  # the main thread's side streams (stepping threads call it themselves)
   _lib = L
   return L
 

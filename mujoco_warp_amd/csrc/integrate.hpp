@@ -64,12 +64,9 @@ DEV void integrate_body(const MjhModel& m, const MjhData& d, int mode, float* sm
           if (m.jnt_dofadr[m.actuator_trnid[2 * u]] != i) continue;
           const float bias_vel = m.actuator_biastype[u] == 1 ? bf(m.actuator_biasprm, m.actuator_biasprm_nb, w, 10 * nu)[10 * u + 2] : 0.0f;
           const float gain_vel = m.actuator_gaintype[u] == 1 ? bf(m.actuator_gainprm, m.actuator_gainprm_nb, w, 10 * nu)[10 * u + 2] : 0.0f;
+          // the RAW control, not the clamped one, multiplies the velocity gain (derivative.py:159-161, mjd_actuator_vel)
           float ctrl = d.ctrl[(size_t)w * nu + u];
           if (m.actuator_dyntype[u] != 0) ctrl = d.act[(size_t)w * m.na + m.actuator_actadr[u]];
-          else if (m.actuator_ctrllimited[u] && !(dsbl & DSBL_CLAMPCTRL)) {
-            const float* cr = bf(m.actuator_ctrlrange, m.actuator_ctrlrange_nb, w, 2 * nu) + 2 * u;
-            ctrl = clampf(ctrl, cr[0], cr[1]);
-          }
           const float dv = bias_vel + gain_vel * ctrl;
           if (dv == 0.0f) continue;
           if (m.actuator_forcelimited[u]) {

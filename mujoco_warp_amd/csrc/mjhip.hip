@@ -317,25 +317,33 @@ struct Instr {
   hipStream_t s;
   bool on = false;
   bool plain = false;  // one plain kernel per stage instead of the fused launches
+  hipError_t err = hipSuccess;  // first failing hipEvent* call of a Scope (reported by mjh_timed_steps)
 };
 static thread_local Instr* g_instr = nullptr;
 struct Scope {
   int cls;
   hipEvent_t a, b;
   bool on;
-  explicit Scope(int c) : cls(c), on(g_instr && g_instr->on) {
+  static void note(hipError_t e) {
+    if (e != hipSuccess && g_instr && g_instr->err == hipSuccess) g_instr->err = e;
+  }
+  explicit Scope(int c) : cls(c), a(nullptr), b(nullptr), on(g_instr && g_instr->on) {
     if (on) {
-      hipEventCreate(&a);
-      hipEventCreate(&b);
-      hipEventRecord(a, g_instr->s);
+      note(hipEventCreate(&a));
+      note(hipEventCreate(&b));
+      if (a && b) note(hipEventRecord(a, g_instr->s));
+      else on = false;
     }
   }
   ~Scope() {
     if (on) {
-      hipEventRecord(b, g_instr->s);
+      note(hipEventRecord(b, g_instr->s));
       g_instr->ev.push_back(a);
       g_instr->ev.push_back(b);
       g_instr->cls.push_back(cls);
+    } else {
+      if (a) hipEventDestroy(a);
+      if (b) hipEventDestroy(b);
     }
   }
 };
@@ -344,13 +352,14 @@ enum { K_NOISE = 0, K_POS = 1, K_COLLISION = 2, K_CONSTRAINT = 3, K_VEL = 4, K_S
 // Newton only: the public-output riders (contact publication, L'DL factor + qacc_smooth) cannot ride with the solver
 // launch (its 256 VGPRs throttle them) and cost 55 us at the end of the integrator launch; they run on a low-priority
 // side stream beside the solver instead.  Two event hops (fork after k_mid, join after the integrator), neither on the
-// solver's critical path; created on first use per host thread and device, never freed.
+// solver's critical path; created on first use per host thread and device, released by mjh_release_thread_resources().
 struct Side {
   hipStream_t stream;
   hipEvent_t fork, join;
 };
+static thread_local Side* g_side_per_dev[16] = {nullptr};
 static Side* side_stream() {
-  static thread_local Side* per_dev[16] = {nullptr};
+  Side** per_dev = g_side_per_dev;
   static const bool disabled = getenv("MJH_NO_SIDE") != nullptr;  // developer knob
   if (disabled) return nullptr;
   int dev = 0;
@@ -514,6 +523,22 @@ int mjh_ctrl_noise(const MjhModel* m, const MjhData* d, const float* ctrl_center
   return MJH_OK;
 }
 
+int mjh_release_thread_resources(void) {
+  // the calling thread's side streams and events (one set per device it stepped a Newton model on)
+  int rc = MJH_OK;
+  for (int dev = 0; dev < 16; ++dev) {
+    Side* sd = g_side_per_dev[dev];
+    if (!sd) continue;
+    g_side_per_dev[dev] = nullptr;
+    if (hipStreamSynchronize(sd->stream) != hipSuccess) rc = MJH_E_LAUNCH;
+    if (hipEventDestroy(sd->fork) != hipSuccess) rc = MJH_E_LAUNCH;
+    if (hipEventDestroy(sd->join) != hipSuccess) rc = MJH_E_LAUNCH;
+    if (hipStreamDestroy(sd->stream) != hipSuccess) rc = MJH_E_LAUNCH;
+    delete sd;
+  }
+  return rc == MJH_OK ? MJH_OK : fail(rc, "mjh_release_thread_resources: %s", "a HIP call failed");
+}
+
 int mjh_graph_create(const MjhModel* m, const MjhData* d, void* stream, void** graph_exec_out) {
   TRY(check(m, d));
   hipStream_t s = (hipStream_t)stream;
@@ -551,9 +576,9 @@ int mjh_timed_steps(const MjhModel* m, const MjhData* d, int nstep, int step0, f
   instr.plain = plain_kernels != 0;
   g_instr = &instr;
   hipEvent_t t0, t1;
-  hipEventCreate(&t0);
-  hipEventCreate(&t1);
-  hipEventRecord(t0, s);
+  HIPCHK(hipEventCreate(&t0));
+  HIPCHK(hipEventCreate(&t1));
+  HIPCHK(hipEventRecord(t0, s));
   int rc = MJH_OK;
   for (int i = 0; i < nstep && rc == MJH_OK; ++i) {
     // the noise of step i rides with that step's first launch (the fused path); the per-kernel profiling passes and the plain
@@ -566,8 +591,9 @@ int mjh_timed_steps(const MjhModel* m, const MjhData* d, int nstep, int step0, f
     if (rc == MJH_OK) rc = run_stage(m, d, MJH_STAGE_STEP, s);
     g_noise.n = 0;
   }
-  hipEventRecord(t1, s);
-  hipError_t e = hipEventSynchronize(t1);
+  hipError_t e = hipEventRecord(t1, s);
+  if (e == hipSuccess) e = hipEventSynchronize(t1);
+  if (e == hipSuccess) e = instr.err;
   g_instr = nullptr;
   float ms = 0.0f;
   hipEventElapsedTime(&ms, t0, t1);

@@ -71,6 +71,8 @@ class DeviceArray:
 
   @property
   def dtype(self):
+    if self._unsigned:
+      return np.uint32
     return self.numpy().dtype if self.t.numel() == 0 else {torch.float32: np.float32, torch.int32: np.int32, torch.bool: np.bool_}[self.t.dtype]
 
   @property

@@ -164,8 +164,13 @@ class StepGraph:
     # stream capture is illegal on the legacy default stream: capture on a side stream ordered after the current one
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
+    # mjh_graph_create runs one real step before capturing (kernel attributes cannot be set during capture): keep the state,
+    # constructing a graph must not advance the simulation (the reference's capture does not either)
+    keep = {k: getattr(d, k).t.clone() for k in ("qpos", "qvel", "act", "ctrl", "time", "qacc_warmstart", "qacc", "solver_niter", "overflow") if getattr(d, k).size}
     rc = L.mjh_graph_create(ctypes.byref(io.c_model(m)), ctypes.byref(io.c_data(d)), ctypes.c_void_p(side.cuda_stream), ctypes.byref(self._exec))
     torch.cuda.current_stream().wait_stream(side)
+    for k, v in keep.items():
+      getattr(d, k).t.copy_(v)
     _abi.check(rc)
 
   def launch(self):

@@ -128,6 +128,12 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
     raise NotImplementedError("PGS supports at most 64 dofs (CG and Newton have a generic path for larger models).")
   if mjm.nu and (np.asarray(mjm.actuator_trntype) != types.TrnType.JOINT).any():
     raise NotImplementedError("Only joint transmissions are supported.")
+  if mjm.nu:
+    # the kernels use gear[0], qpos[jnt_qposadr] and the joint's first dof only (smooth.hpp fwd_actuation, integrate.hpp): a
+    # motor on a ball / free joint (gear[0:3] / gear[0:6] in the reference, smooth.py:2288-2400) would silently be wrong
+    tj = np.asarray(mjm.jnt_type)[np.asarray(mjm.actuator_trnid).reshape(-1, 2)[:, 0]]
+    if np.isin(tj, (int(types.JointType.BALL), int(types.JointType.FREE))).any():
+      raise NotImplementedError("actuators on ball / free joints are not implemented (hinge and slide targets only).")
   if int(getattr(opt, "noslip_iterations", 0)) > 0:
     raise NotImplementedError("noslip solver is unsupported.")
   if mjm.nu:
@@ -405,11 +411,11 @@ def _data_shapes(m, nworld, nconmax, njmax, naconmax):
   return sh, njmax_pad, nv_pad
 
 
-def _alloc_data(m: types.Model, nworld, nconmax, njmax, naconmax):
+def _alloc_data(m: types.Model, nworld, nconmax, njmax, naconmax, mjd=None):
   if nconmax is None:
-    nconmax = _default_nconmax(None)
+    nconmax = _default_nconmax(None, mjd)  # at least what the host data already holds (reference io.py:1284-1311)
   if njmax is None:
-    njmax = _default_njmax(None)
+    njmax = _default_njmax(None, mjd)
   if nconmax < 0:
     raise ValueError("nconmax must be >= 0")
   if njmax < 0:
@@ -502,7 +508,9 @@ def put_data(mjm, mjd, nworld: int = 1, nconmax: Optional[int] = None, nccdmax: 
              naccdmax: Optional[int] = None, nvmax: Optional[int] = None) -> types.Data:
   """Moves data from host to a device (reference io.py:1890): the single host state is tiled nworld times."""
   m = mjm if isinstance(mjm, types.Model) else _model_of(mjm)
-  d = _alloc_data(m, nworld, nconmax, njmax, naconmax)
+  d = _alloc_data(m, nworld, nconmax, njmax, naconmax, mjd)
+  if m.neq and getattr(mjd, "eq_active", None) is not None:
+    d.eq_active.assign(np.tile(np.asarray(mjd.eq_active, dtype=np.int32).reshape(1, -1), (nworld, 1)))
   for name in ("qpos", "qvel", "act", "ctrl", "qacc_warmstart", "qfrc_applied", "xfrc_applied", "mocap_pos", "mocap_quat"):
     if not hasattr(mjd, name):
       continue
@@ -623,8 +631,14 @@ def _reset_state(m, d, qpos, qvel, act, ctrl, time, mask):
   if m.neq:
     put(d.eq_active, np.tile(m.eq_active0, (d.nworld, 1)))
   if mask is None:
-    for name in ("nefc", "ne", "nf", "nl", "solver_niter", "overflow", "nacon", "ncollision", "ws_ncon", "ws_conadr"):
+    for name in ("nefc", "ne", "nf", "nl", "solver_niter", "overflow", "nacon", "ncollision", "ws_ncon", "ws_conadr", "ws_ncollision"):
       getattr(d, name).zero_()
+  else:  # per-world counters of the reset worlds (the global nacon / ncollision are recomputed by the next collision)
+    for name in ("nefc", "ne", "nf", "nl", "solver_niter", "overflow", "ws_ncon", "ws_ncollision"):
+      dst = getattr(d, name)
+      cur = dst.numpy().copy()
+      cur[mask] = 0
+      dst.assign(cur)
 
 
 _ENUMS = {"solver": types.SolverType, "integrator": types.IntegratorType, "cone": types.ConeType}

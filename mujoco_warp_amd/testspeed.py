@@ -112,12 +112,7 @@ def main(argv=None):
 
   # "JIT": graph capture of the benchmarked function (kernels are precompiled; nothing is compiled at run time)
   t0 = time.perf_counter()
-  graph = mjw.StepGraph(m, d) if args.function == "step" else None
-  if graph is not None:  # capture warmed up with one real step: restore the initial state
-    d2 = mjw.put_data(mjm, mjd, nworld=args.nworld, nconmax=args.nconmax, njmax=args.njmax)
-    for name in ("qpos", "qvel", "act", "ctrl", "qacc_warmstart", "time"):
-      getattr(d, name).assign(getattr(d2, name))
-    del d2
+  graph = mjw.StepGraph(m, d) if args.function == "step" else None  # (leaves the state untouched)
   torch.cuda.synchronize()
   jit_duration = time.perf_counter() - t0
 

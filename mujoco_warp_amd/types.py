@@ -9,7 +9,12 @@ Deviation (documented in DESIGN.md): `Data.qLD` holds MuJoCo's sparse L'DL facto
 ([nworld, nC], plus `qLDiagInv`), not the reference's packed dense per-tree Cholesky blocks.
 """
 
+import dataclasses
 import enum
+
+import numpy as np
+
+from .device import DeviceArray
 
 
 class BroadphaseType(enum.IntEnum):
@@ -190,6 +195,12 @@ MJ_MAXIMP = 0.9999
 MJ_MINMU = 1e-5
 
 
+def _arr(shape, dtype, host=False):
+  """Declares an array field: `shape` is a tuple of sizes or size NAMES evaluated against the owning Model / Data ('*' = 1 or
+  nworld, the reference's batched fields, types.py:822-833), `dtype` its numpy dtype; host arrays stay numpy (keyframes)."""
+  return dataclasses.field(default=None, repr=False, metadata={"shape": tuple(shape), "dtype": dtype, "host": host})
+
+
 class _Dirty:
   """Attribute container that remembers when a field was re-bound (so the C struct is rebuilt lazily)."""
 
@@ -202,25 +213,291 @@ class _Dirty:
         object.__setattr__(root, "_dirty", True)
 
 
+@dataclasses.dataclass(eq=False)
 class Option(_Dirty):
-  """Physics options (reference types.py:836-905)."""
+  """Physics options (reference types.py:836-905); batched ('*') fields carry a leading dimension of 1 or nworld."""
 
+  timestep: DeviceArray = _arr(('*',), "float32")
+  tolerance: DeviceArray = _arr(('*',), "float32")
+  ls_tolerance: DeviceArray = _arr(('*',), "float32")
+  gravity: DeviceArray = _arr(('*', 3), "float32")
+  impratio_invsqrt: DeviceArray = _arr(('*',), "float32")
+  integrator: int = 0
+  cone: int = 0
+  solver: int = 0
+  iterations: int = 0
+  ls_iterations: int = 0
+  disableflags: int = 0
+  enableflags: int = 0
+  broadphase: int = 0
+  broadphase_filter: int = 0
+  graph_conditional: bool = False
+  run_collision_detection: bool = False
+  warn_overflow: bool = False
 
+@dataclasses.dataclass(eq=False)
 class Statistic(_Dirty):
   """Model statistics (reference types.py:922-931)."""
 
+  meaninertia: DeviceArray = _arr(('*',), "float32")
 
+@dataclasses.dataclass(eq=False)
 class Model(_Dirty):
-  """Device-resident model (reference types.py:982-1960, hot-path subset)."""
+  """Device-resident model (reference types.py:982-1960, hot-path subset).  '*' = 1 or nworld (domain randomisation)."""
 
+  nq: int = 0
+  nv: int = 0
+  nu: int = 0
+  na: int = 0
+  nbody: int = 0
+  njnt: int = 0
+  ngeom: int = 0
+  nsite: int = 0
+  nkey: int = 0
+  nmocap: int = 0
+  neq: int = 0
+  ntendon: int = 0
+  nsensor: int = 0
+  nmesh: int = 0
+  nflex: int = 0
+  nhfield: int = 0
+  ncam: int = 0
+  nlight: int = 0
+  nC: int = 0
+  nM: int = 0
+  heavy_colliders: int = 0
+  is_sparse: bool = False
+  nv_pad: int = 0
+  eq_active0: np.ndarray = _arr(('neq',), "int32", host=True)
+  qpos0: DeviceArray = _arr(('*', 'nq'), "float32")
+  qpos_spring: DeviceArray = _arr(('*', 'nq'), "float32")
+  body_parentid: DeviceArray = _arr(('nbody',), "int32")
+  body_rootid: DeviceArray = _arr(('nbody',), "int32")
+  body_weldid: DeviceArray = _arr(('nbody',), "int32")
+  body_jntnum: DeviceArray = _arr(('nbody',), "int32")
+  body_jntadr: DeviceArray = _arr(('nbody',), "int32")
+  body_dofnum: DeviceArray = _arr(('nbody',), "int32")
+  body_dofadr: DeviceArray = _arr(('nbody',), "int32")
+  body_lastdof: DeviceArray = _arr(('nbody',), "int32")
+  body_mocapid: DeviceArray = _arr(('nbody',), "int32")
+  body_subtreenum: DeviceArray = _arr(('nbody',), "int32")
+  body_tree: DeviceArray = _arr(('nbody',), "int32")
+  body_leveladr: DeviceArray = _arr(('nbodylevel+1',), "int32")
+  body_dofmask: DeviceArray = _arr(('nbody', '(nv+31)//32'), "uint32")
+  body_pos: DeviceArray = _arr(('*', 'nbody', 3), "float32")
+  body_quat: DeviceArray = _arr(('*', 'nbody', 4), "float32")
+  body_ipos: DeviceArray = _arr(('*', 'nbody', 3), "float32")
+  body_iquat: DeviceArray = _arr(('*', 'nbody', 4), "float32")
+  body_mass: DeviceArray = _arr(('*', 'nbody'), "float32")
+  body_subtreemass: DeviceArray = _arr(('*', 'nbody'), "float32")
+  body_inertia: DeviceArray = _arr(('*', 'nbody', 3), "float32")
+  body_invweight0: DeviceArray = _arr(('*', 'nbody', 2), "float32")
+  body_gravcomp: DeviceArray = _arr(('*', 'nbody'), "float32")
+  jnt_type: DeviceArray = _arr(('njnt',), "int32")
+  jnt_qposadr: DeviceArray = _arr(('njnt',), "int32")
+  jnt_dofadr: DeviceArray = _arr(('njnt',), "int32")
+  jnt_bodyid: DeviceArray = _arr(('njnt',), "int32")
+  jnt_limited: DeviceArray = _arr(('njnt',), "int32")
+  jnt_solref: DeviceArray = _arr(('*', 'njnt', 2), "float32")
+  jnt_solimp: DeviceArray = _arr(('*', 'njnt', 5), "float32")
+  jnt_pos: DeviceArray = _arr(('*', 'njnt', 3), "float32")
+  jnt_axis: DeviceArray = _arr(('*', 'njnt', 3), "float32")
+  jnt_stiffness: DeviceArray = _arr(('*', 'njnt'), "float32")
+  jnt_range: DeviceArray = _arr(('*', 'njnt', 2), "float32")
+  jnt_margin: DeviceArray = _arr(('*', 'njnt'), "float32")
+  dof_bodyid: DeviceArray = _arr(('nv',), "int32")
+  dof_jntid: DeviceArray = _arr(('nv',), "int32")
+  dof_parentid: DeviceArray = _arr(('nv',), "int32")
+  dof_grpadr: DeviceArray = _arr(('nv',), "int32")
+  dof_tree: DeviceArray = _arr(('nv',), "int32")
+  dof_leveladr: DeviceArray = _arr(('ndoflevel+1',), "int32")
+  dof_solref: DeviceArray = _arr(('*', 'nv', 2), "float32")
+  dof_solimp: DeviceArray = _arr(('*', 'nv', 5), "float32")
+  dof_frictionloss: DeviceArray = _arr(('*', 'nv'), "float32")
+  dof_armature: DeviceArray = _arr(('*', 'nv'), "float32")
+  dof_damping: DeviceArray = _arr(('*', 'nv'), "float32")
+  dof_invweight0: DeviceArray = _arr(('*', 'nv'), "float32")
+  M_rownnz: DeviceArray = _arr(('nv',), "int32")
+  M_rowadr: DeviceArray = _arr(('nv',), "int32")
+  M_colind: DeviceArray = _arr(('nC',), "int32")
+  geom_type: DeviceArray = _arr(('ngeom',), "int32")
+  geom_condim: DeviceArray = _arr(('ngeom',), "int32")
+  geom_bodyid: DeviceArray = _arr(('ngeom',), "int32")
+  geom_priority: DeviceArray = _arr(('ngeom',), "int32")
+  geom_solmix: DeviceArray = _arr(('*', 'ngeom'), "float32")
+  geom_solref: DeviceArray = _arr(('*', 'ngeom', 2), "float32")
+  geom_solimp: DeviceArray = _arr(('*', 'ngeom', 5), "float32")
+  geom_size: DeviceArray = _arr(('*', 'ngeom', 3), "float32")
+  geom_rbound: DeviceArray = _arr(('*', 'ngeom'), "float32")
+  geom_aabb: DeviceArray = _arr(('*', 'ngeom', 6), "float32")
+  geom_pos: DeviceArray = _arr(('*', 'ngeom', 3), "float32")
+  geom_quat: DeviceArray = _arr(('*', 'ngeom', 4), "float32")
+  geom_friction: DeviceArray = _arr(('*', 'ngeom', 3), "float32")
+  geom_margin: DeviceArray = _arr(('*', 'ngeom'), "float32")
+  geom_gap: DeviceArray = _arr(('*', 'ngeom'), "float32")
+  nxn_geom_pair: DeviceArray = _arr(('npair', 2), "int32")
+  nxn_pairid: DeviceArray = _arr(('npair',), "int32")
+  nxn_pairindex: DeviceArray = _arr(('ngeom*(ngeom-1)//2',), "int32")
+  pair_dim: DeviceArray = _arr(('nexplicit',), "int32")
+  pair_friction: DeviceArray = _arr(('nexplicit', 5), "float32")
+  pair_solref: DeviceArray = _arr(('nexplicit', 2), "float32")
+  pair_solreffriction: DeviceArray = _arr(('nexplicit', 2), "float32")
+  pair_solimp: DeviceArray = _arr(('nexplicit', 5), "float32")
+  pair_margin: DeviceArray = _arr(('nexplicit',), "float32")
+  pair_gap: DeviceArray = _arr(('nexplicit',), "float32")
+  site_bodyid: DeviceArray = _arr(('nsite',), "int32")
+  site_pos: DeviceArray = _arr(('*', 'nsite', 3), "float32")
+  site_quat: DeviceArray = _arr(('*', 'nsite', 4), "float32")
+  actuator_dyntype: DeviceArray = _arr(('nu',), "int32")
+  actuator_gaintype: DeviceArray = _arr(('nu',), "int32")
+  actuator_biastype: DeviceArray = _arr(('nu',), "int32")
+  actuator_trnid: DeviceArray = _arr(('nu', 2), "int32")
+  actuator_actadr: DeviceArray = _arr(('nu',), "int32")
+  actuator_ctrllimited: DeviceArray = _arr(('nu',), "int32")
+  actuator_forcelimited: DeviceArray = _arr(('nu',), "int32")
+  actuator_actlimited: DeviceArray = _arr(('nu',), "int32")
+  actuator_dynprm: DeviceArray = _arr(('*', 'nu', 10), "float32")
+  actuator_gainprm: DeviceArray = _arr(('*', 'nu', 10), "float32")
+  actuator_biasprm: DeviceArray = _arr(('*', 'nu', 10), "float32")
+  actuator_ctrlrange: DeviceArray = _arr(('*', 'nu', 2), "float32")
+  actuator_forcerange: DeviceArray = _arr(('*', 'nu', 2), "float32")
+  actuator_actrange: DeviceArray = _arr(('*', 'nu', 2), "float32")
+  actuator_gear: DeviceArray = _arr(('*', 'nu', 6), "float32")
+  eq_obj1id: DeviceArray = _arr(('neq',), "int32")
+  eq_obj2id: DeviceArray = _arr(('neq',), "int32")
+  eq_solref: DeviceArray = _arr(('*', 'neq', 2), "float32")
+  eq_solimp: DeviceArray = _arr(('*', 'neq', 5), "float32")
+  eq_data: DeviceArray = _arr(('*', 'neq', 11), "float32")
+  opt: "Option" = None
+  stat: "Statistic" = None
+  npair: int = 0
+  nexplicit: int = 0
+  nxn_geom_pair_filtered: DeviceArray = _arr(('npair', 2), "int32")
+  nbodylevel: int = 0
+  ndoflevel: int = 0
+  nmaxcondim: int = 0
+  nmaxpyramid: int = 0
+  key_qpos: np.ndarray = _arr(('nkey', 'nq'), "float32", host=True)
+  key_qvel: np.ndarray = _arr(('nkey', 'nv'), "float32", host=True)
+  key_ctrl: np.ndarray = _arr(('nkey', 'nu'), "float32", host=True)
+  key_mpos: np.ndarray = _arr(('nkey', '3*nmocap'), "float32", host=True)
+  key_mquat: np.ndarray = _arr(('nkey', '4*nmocap'), "float32", host=True)
+  key_act: np.ndarray = _arr(('nkey', 'na'), "float32", host=True)
+  key_time: np.ndarray = _arr(('nkey',), "float32", host=True)
 
+@dataclasses.dataclass(eq=False)
 class Contact(_Dirty):
   """Contact arrays, flat over all worlds (reference types.py:1975-2018)."""
 
+  dist: DeviceArray = _arr(('naconmax',), "float32")
+  pos: DeviceArray = _arr(('naconmax', 3), "float32")
+  frame: DeviceArray = _arr(('naconmax', 3, 3), "float32")
+  includemargin: DeviceArray = _arr(('naconmax',), "float32")
+  friction: DeviceArray = _arr(('naconmax', 5), "float32")
+  solref: DeviceArray = _arr(('naconmax', 2), "float32")
+  solreffriction: DeviceArray = _arr(('naconmax', 2), "float32")
+  solimp: DeviceArray = _arr(('naconmax', 5), "float32")
+  dim: DeviceArray = _arr(('naconmax',), "int32")
+  geom: DeviceArray = _arr(('naconmax', 2), "int32")
+  efc_address: DeviceArray = _arr(('naconmax', 'nmaxpyramid'), "int32")
+  worldid: DeviceArray = _arr(('naconmax',), "int32")
+  type: DeviceArray = _arr(('naconmax',), "int32")
+  geomcollisionid: DeviceArray = _arr(('naconmax',), "int32")
 
+@dataclasses.dataclass(eq=False)
 class Constraint(_Dirty):
   """Constraint arrays (reference types.py:2021-2072); J is dense [nworld, njmax_pad, nv_pad]."""
 
+  Ma: DeviceArray = _arr(('nworld', 'nv'), "float32")
+  type: DeviceArray = _arr(('nworld', 'njmax'), "int32")
+  id: DeviceArray = _arr(('nworld', 'njmax'), "int32")
+  state: DeviceArray = _arr(('nworld', 'njmax'), "int32")
+  J: DeviceArray = _arr(('nworld', 'njmax_pad', 'nv_pad'), "float32")
+  pos: DeviceArray = _arr(('nworld', 'njmax'), "float32")
+  margin: DeviceArray = _arr(('nworld', 'njmax'), "float32")
+  D: DeviceArray = _arr(('nworld', 'njmax'), "float32")
+  vel: DeviceArray = _arr(('nworld', 'njmax'), "float32")
+  aref: DeviceArray = _arr(('nworld', 'njmax'), "float32")
+  frictionloss: DeviceArray = _arr(('nworld', 'njmax'), "float32")
+  force: DeviceArray = _arr(('nworld', 'njmax'), "float32")
 
+@dataclasses.dataclass(eq=False)
 class Data(_Dirty):
-  """Device-resident, batched simulation state (reference types.py:2075-2374, hot-path subset)."""
+  """Device-resident, batched simulation state (reference types.py:2075-2374, hot-path subset; ws_* = engine workspace)."""
+
+  contact: "Contact" = None
+  efc: "Constraint" = None
+  time: DeviceArray = _arr(('nworld',), "float32")
+  qpos: DeviceArray = _arr(('nworld', 'nq'), "float32")
+  qvel: DeviceArray = _arr(('nworld', 'nv'), "float32")
+  act: DeviceArray = _arr(('nworld', 'na'), "float32")
+  ctrl: DeviceArray = _arr(('nworld', 'nu'), "float32")
+  qacc_warmstart: DeviceArray = _arr(('nworld', 'nv'), "float32")
+  qfrc_applied: DeviceArray = _arr(('nworld', 'nv'), "float32")
+  xfrc_applied: DeviceArray = _arr(('nworld', 'nbody', 6), "float32")
+  mocap_pos: DeviceArray = _arr(('nworld', 'nmocap', 3), "float32")
+  mocap_quat: DeviceArray = _arr(('nworld', 'nmocap', 4), "float32")
+  xpos: DeviceArray = _arr(('nworld', 'nbody', 3), "float32")
+  xquat: DeviceArray = _arr(('nworld', 'nbody', 4), "float32")
+  xmat: DeviceArray = _arr(('nworld', 'nbody', 3, 3), "float32")
+  xipos: DeviceArray = _arr(('nworld', 'nbody', 3), "float32")
+  ximat: DeviceArray = _arr(('nworld', 'nbody', 3, 3), "float32")
+  xanchor: DeviceArray = _arr(('nworld', 'njnt', 3), "float32")
+  xaxis: DeviceArray = _arr(('nworld', 'njnt', 3), "float32")
+  geom_xpos: DeviceArray = _arr(('nworld', 'ngeom', 3), "float32")
+  geom_xmat: DeviceArray = _arr(('nworld', 'ngeom', 3, 3), "float32")
+  site_xpos: DeviceArray = _arr(('nworld', 'nsite', 3), "float32")
+  site_xmat: DeviceArray = _arr(('nworld', 'nsite', 3, 3), "float32")
+  subtree_com: DeviceArray = _arr(('nworld', 'nbody', 3), "float32")
+  cinert: DeviceArray = _arr(('nworld', 'nbody', 10), "float32")
+  cdof: DeviceArray = _arr(('nworld', 'nv', 6), "float32")
+  crb: DeviceArray = _arr(('nworld', 'nbody', 10), "float32")
+  M: DeviceArray = _arr(('nworld', 'nC'), "float32")
+  qLD: DeviceArray = _arr(('nworld', 'nC'), "float32")
+  qLDiagInv: DeviceArray = _arr(('nworld', 'nv'), "float32")
+  actuator_length: DeviceArray = _arr(('nworld', 'nu'), "float32")
+  actuator_moment: DeviceArray = _arr(('nworld', 'nu'), "float32")
+  actuator_velocity: DeviceArray = _arr(('nworld', 'nu'), "float32")
+  cvel: DeviceArray = _arr(('nworld', 'nbody', 6), "float32")
+  cdof_dot: DeviceArray = _arr(('nworld', 'nv', 6), "float32")
+  qfrc_spring: DeviceArray = _arr(('nworld', 'nv'), "float32")
+  qfrc_damper: DeviceArray = _arr(('nworld', 'nv'), "float32")
+  qfrc_gravcomp: DeviceArray = _arr(('nworld', 'nv'), "float32")
+  qfrc_passive: DeviceArray = _arr(('nworld', 'nv'), "float32")
+  qfrc_bias: DeviceArray = _arr(('nworld', 'nv'), "float32")
+  cacc: DeviceArray = _arr(('nworld', 'nbody', 6), "float32")
+  cfrc_int: DeviceArray = _arr(('nworld', 'nbody', 6), "float32")
+  act_dot: DeviceArray = _arr(('nworld', 'na'), "float32")
+  actuator_force: DeviceArray = _arr(('nworld', 'nu'), "float32")
+  qfrc_actuator: DeviceArray = _arr(('nworld', 'nv'), "float32")
+  qfrc_smooth: DeviceArray = _arr(('nworld', 'nv'), "float32")
+  qacc_smooth: DeviceArray = _arr(('nworld', 'nv'), "float32")
+  qacc: DeviceArray = _arr(('nworld', 'nv'), "float32")
+  qfrc_constraint: DeviceArray = _arr(('nworld', 'nv'), "float32")
+  solver_niter: DeviceArray = _arr(('nworld',), "int32")
+  ne: DeviceArray = _arr(('nworld',), "int32")
+  nf: DeviceArray = _arr(('nworld',), "int32")
+  nl: DeviceArray = _arr(('nworld',), "int32")
+  nefc: DeviceArray = _arr(('nworld',), "int32")
+  overflow: DeviceArray = _arr(('nworld',), "int32")
+  nacon: DeviceArray = _arr((1,), "int32")
+  ncollision: DeviceArray = _arr((1,), "int32")
+  ws_ncon: DeviceArray = _arr(('nworld',), "int32")
+  ws_conadr: DeviceArray = _arr(('nworld',), "int32")
+  ws_ncollision: DeviceArray = _arr(('nworld',), "int32")
+  ws_order: DeviceArray = _arr(('nworld',), "int32")
+  eq_active: DeviceArray = _arr(('nworld', 'neq'), "int32")
+  ws_rk: DeviceArray = _arr(('nworld', 'nq+3*nv+2*na'), "float32")
+  ws_contact: DeviceArray = _arr(('nworld', 'concap', 32), "float32")
+  nworld: int = 0
+  nconmax: int = 0
+  naconmax: int = 0
+  njmax: int = 0
+  njmax_pad: int = 0
+  nv_pad: int = 0
+  nmaxpyramid: int = 0
+  world_offset: int = 0
+  concap: int = 0
+  reserved0: int = 0
+  njmax_nnz: int = 0
+

@@ -2078,9 +2078,7 @@ void ref_implicitfast(const RefModel* m, RefData* d) {
       double bias_vel = (m->actuator_biastype[i] == 1) ? m->actuator_biasprm[10 * i + 2] : 0.0;
       double gain_vel = (m->actuator_gaintype[i] == 1) ? m->actuator_gainprm[10 * i + 2] : 0.0;
       double ctrl = d->ctrl[i];
-      if (m->actuator_dyntype[i] != 0) ctrl = d->act[m->actuator_actadr[i]];
-      else if (m->actuator_ctrllimited[i] && !(m->disableflags & DSBL_CLAMPCTRL))
-        ctrl = clampd(ctrl, m->actuator_ctrlrange[2 * i], m->actuator_ctrlrange[2 * i + 1]);
+      if (m->actuator_dyntype[i] != 0) ctrl = d->act[m->actuator_actadr[i]]; /* raw ctrl otherwise: derivative.py:159-161 */
       double dv = bias_vel + gain_vel * ctrl;
       if (dv == 0.0) continue;
       if (m->actuator_forcelimited[i]) {

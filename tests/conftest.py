@@ -44,10 +44,21 @@ def humanoid():
 
 
 def relerr(a, b):
+  """MAX-NORM relative error max|a - b| / max|b|: the right measure for a field whose entries share one scale (a Jacobian, a
+  force vector); for state vectors use relerr_elem."""
   a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
   if a.size == 0:
     return 0.0
   return float(np.max(np.abs(a - b)) / (np.max(np.abs(b)) + 1e-12))
+
+
+def relerr_elem(a, b, floor):
+  """PER-ELEMENT relative error max_i |a_i - b_i| / max(|b_i|, floor); `floor` is an absolute value in the field's unit below
+  which an entry is compared absolutely (a joint angle of 1e-3 rad must not hide behind a root position of 1 m)."""
+  a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+  if a.size == 0:
+    return 0.0
+  return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), floor)))
 
 
 # small inline models shared by CPU and GPU tests (same role as the reference's test_data/*.xml)

@@ -317,3 +317,48 @@ def test_mocap_model_and_keyframe():
   np.testing.assert_array_equal(d.mocap_quat, [[0, 1, 0, 0]])
   with pytest.raises(ValueError):
     mjw.mjcf.from_xml_string('<mujoco><worldbody><body><joint/><geom size=".1"/><body mocap="true"><geom size=".1"/></body></body></worldbody></mujoco>')
+
+
+# ---------------------------------------------------------------------------------- declared schema of Model / Data
+def _schema_check(obj, env, nworld):
+  import dataclasses
+
+  from mujoco_warp_amd.device import DeviceArray
+
+  declared = {f.name: f for f in dataclasses.fields(obj)}
+  public = {k for k in vars(obj) if not k.startswith("_")}
+  assert public <= set(declared), f"undeclared attributes on {type(obj).__name__}: {sorted(public - set(declared))}"
+  for name, f in declared.items():
+    v = getattr(obj, name)
+    meta = f.metadata
+    if "shape" not in meta:
+      continue
+    assert v is not None, f"{type(obj).__name__}.{name} is declared but was never set"
+    assert isinstance(v, np.ndarray if meta["host"] else DeviceArray), name
+    assert np.dtype(v.dtype) == np.dtype(meta["dtype"]), (name, v.dtype, meta["dtype"])
+    want = []
+    for i, s in enumerate(meta["shape"]):
+      if s == "*":
+        assert v.shape[i] in (1, nworld), name
+        want.append(v.shape[i])
+      else:
+        want.append(int(eval(s, {}, env)) if isinstance(s, str) else s)
+    assert tuple(v.shape) == tuple(want), (type(obj).__name__, name, v.shape, want)
+
+
+@pytest.mark.parametrize("xml", ["humanoid", "panda", "pendula"])
+def test_declared_schema_matches_arrays(xml):
+  """types.Model / Data / Option / Contact / Constraint are real dataclasses: every attribute put_model / make_data sets is a
+  declared field and every declared array has the declared (symbolic) shape and dtype."""
+  import dataclasses
+
+  mjm = {"humanoid": lambda: mjw.mjcf.load_xml(conftest.HUMANOID_XML), "panda": lambda: mjw.mjcf.load_xml(conftest.PANDA_XML),
+         "pendula": lambda: mjw.mjcf.from_xml_string(conftest.PENDULA_XML)}[xml]()
+  m = mjw.put_model(mjm)
+  d = mjw.make_data(mjm, nworld=3, nconmax=7, njmax=21)
+  assert dataclasses.is_dataclass(mjw.Model) and dataclasses.is_dataclass(mjw.Data)
+  env = {k: getattr(m, k) for k in ("nq", "nv", "nu", "na", "nbody", "njnt", "ngeom", "nsite", "nkey", "nmocap", "neq", "nC", "npair",
+                                    "nexplicit", "nbodylevel", "ndoflevel", "nmaxpyramid")}
+  env.update(nworld=d.nworld, njmax=d.njmax, njmax_pad=d.njmax_pad, nv_pad=d.nv_pad, naconmax=d.naconmax, concap=d.concap)
+  for obj in (m.opt, m.stat, m, d.contact, d.efc, d):
+    _schema_check(obj, env, d.nworld)
