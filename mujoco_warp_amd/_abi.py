@@ -20,7 +20,10 @@ UNITS = ["mjhip.hip", "solve_cg32.hip", "solve_newton32.hip", "solve_cg64.hip", 
 HEADERS = ["host.hpp", "solve_tu.hpp", "dev_common.hpp", "smooth.hpp", "collide.hpp", "constraint.hpp", "solver.hpp", "solver_newton.hpp", "solver_big.hpp", "pgs.hpp",
            "integrate.hpp"]
 SOURCES = [os.path.join(_PKG, "csrc", f) for f in UNITS + HEADERS]
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wno-unused-value", "-Wno-pass-failed"]
+# -fno-slp-vectorize: the SLP vectoriser packs scalar float ops into v_pk_* pairs, which on gfx950 issue at HALF the rate of the
+# scalar forms (tools/ubench.hip: v_pk_fma_f32 4.3 cycles vs v_fma_f32 2.06) and need register pairs plus v_mov shuffles: the Newton
+# kernel drops from 239 to 153 VGPRs and loses a third of its moves without it
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-fno-slp-vectorize", "-Wno-unused-value", "-Wno-pass-failed"]
 
 _CTYPES = {"int": ctypes.c_int, "float": ctypes.c_float, "unsigned int": ctypes.c_uint}
 

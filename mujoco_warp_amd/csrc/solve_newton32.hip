@@ -21,6 +21,12 @@ static int launch_newton_t(const MjhModel* m, const MjhData* d, int fuse_euler, 
   const size_t lds = sizeof(float) * lay.total;
   if (lds > (size_t)kLdsPerCU) return fail(MJH_E_UNSUPPORTED, "k_solve_newton: does not fit in LDS");
   const dim3 grid((d->nworld + 1) / 2), block(64);
+  if (getenv("MJH_DEBUG_OCC")) {  // developer knob: resident workgroups per CU the runtime computes for this launch
+    int nb = -1;
+    if (pool >= 2 * cap) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_solve_newton<NV4, WV, true>, 64, lds);
+    else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_solve_newton<NV4, WV, false>, 64, lds);
+    fprintf(stderr, "k_solve_newton<%d,%d>: pool %d rows, LDS %zu B per wavefront, %d wavefronts per CU\n", NV4, WV, pool, lds, nb);
+  }
   if (pool >= 2 * cap) {  // every pair fits: the single-turn instantiation
     HIPCHK(set_lds((k_solve_newton<NV4, WV, true>), lds));
     hipLaunchKernelGGL((k_solve_newton<NV4, WV, true>), grid, block, lds, s, *m, *d, pool, fuse_euler);

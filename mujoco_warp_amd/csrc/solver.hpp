@@ -43,6 +43,29 @@ DEV float gsumg(float v) {
   // instruction instead of two v_readlane + v_cndmask -- the kernel is VALU-issue bound (measured -5 % kernel time)
   return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x3E0));
 }
+// N sums at once: the five DPP steps run over all N values before the next step starts, so each value's dependent DPP chain
+// (14 cycles per step for a lone wavefront, tools/ubench.hip) is covered by the other values' issue slots, and the N crossbar
+// broadcasts share one wait.  Measured (tools/ubench_ls.hip): a line-search iteration -- nine sums -- drops from 1470 cycles.
+template <int G, int N>
+DEV void gsumg_n(float (&v)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = dpp_add_f<0x111, 0xf, 0xf>(v[i]);  // row_shr:1
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = dpp_add_f<0x112, 0xf, 0xf>(v[i]);  // row_shr:2
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = dpp_add_f<0x114, 0xf, 0xf>(v[i]);  // row_shr:4
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = dpp_add_f<0x118, 0xf, 0xf>(v[i]);  // row_shr:8
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = dpp_add_f<0x142, 0xa, 0xf>(v[i]);  // row_bcast:15 into rows 1 and 3
+  if (G == 64) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = bcastg<64>(dpp_add_f<0x143, 0xc, 0xf>(v[i]), 63);  // row_bcast:31, lane 63 holds the sum
+  } else {
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v[i]), 0x3E0));
+  }
+}
 // (A butterfly all-reduce -- quad_perm, row_half_mirror, row_mirror, v_permlane16_swap or ds_swizzle -- is two VALU ops
 // shorter and passes in isolation, but inside k_solve it broke parity with both cross-row variants; not pursued.)
 // division for step-size candidates and ratios that only steer the search (v_rcp_f32, 1 ulp; an IEEE divide is ~10 ops)

@@ -131,7 +131,7 @@ DEV float chol_factor_solve(float (&h)[4 * NV4], float g, float* panel, float* v
 #pragma unroll
       for (int k = j0 + 4; k < NVR; ++k) {
         const float4 pk = *reinterpret_cast<const float4*>(panel + 4 * k);
-        h[k] -= u0 * pk.x + u1 * pk.y + u2 * pk.z + u3 * pk.w;
+        h[k] = fmaf(-u3, pk.w, fmaf(-u2, pk.z, fmaf(-u1, pk.y, fmaf(-u0, pk.x, h[k]))));
       }
       __builtin_amdgcn_sched_barrier(0);  // finish the update here: deferring it keeps the panel rows in registers
     }
@@ -144,7 +144,9 @@ DEV float chol_factor_solve(float (&h)[4 * NV4], float g, float* panel, float* v
 #pragma unroll
   for (int jb = NV4 - 1; jb >= 0; --jb) {
     const int j0 = 4 * jb;
-    const float t0 = gsumg<G>(h[j0] * x), t1 = gsumg<G>(h[j0 + 1] * x), t2 = gsumg<G>(h[j0 + 2] * x), t3 = gsumg<G>(h[j0 + 3] * x);
+    float t4[4] = {h[j0] * x, h[j0 + 1] * x, h[j0 + 2] * x, h[j0 + 3] * x};
+    gsumg_n<G, 4>(t4);
+    const float t0 = t4[0], t1 = t4[1], t2 = t4[2], t3 = t4[3];
     const float4 y4 = *reinterpret_cast<const float4*>(vec + j0);
     const float4 sa = *reinterpret_cast<const float4*>(save + 12 * jb);      // l10 l20 l30 r0
     const float4 sb = *reinterpret_cast<const float4*>(save + 12 * jb + 4);  // l21 l31 l32 r1
@@ -166,7 +168,7 @@ DEV float chol_factor_solve(float (&h)[4 * NV4], float g, float* panel, float* v
 template <int NR, int G>
 DEV void line_search_rows(const float (&rja)[NR], const float (&rjv)[NR], const float (&rD)[NR], const int (&rkind)[NR], bool has_fl,
                           const float* floss_lane, float gauss1, float gauss2, float gtol, int ls_iterations, float& alpha_out,
-                          float& improvement_out, bool& converged_out) {
+                          float& improvement_out, bool& converged_out, int* iters_out = nullptr) {
   float ehess[NR], egrad0[NR], ecact[NR], ecin[NR];
 #pragma unroll
   for (int k = 0; k < NR; ++k) {
@@ -199,13 +201,19 @@ DEV void line_search_rows(const float (&rja)[NR], const float (&rjv)[NR], const 
     }
     return s;
   };
-  auto total = [&](P3 s, float a) __attribute__((always_inline)) {
-    return P3{a * a * gauss2 + a * gauss1 + gsumg<G>(s.c), 2.0f * a * gauss2 + gauss1 + gsumg<G>(s.g), 2.0f * gauss2 + gsumg<G>(s.h)};
+  // group sums + the Gauss (smooth) quadratic; the sums of up to three ray points are reduced together (gsumg_n)
+  auto finish = [&](float c, float g, float h, float a) __attribute__((always_inline)) {
+    return P3{a * a * gauss2 + a * gauss1 + c, 2.0f * a * gauss2 + gauss1 + g, 2.0f * gauss2 + h};
   };
   const P3 e = eval(0.0f);
-  const P3 p0 = P3{0.0f, gauss1 + gsumg<G>(e.g), 2.0f * gauss2 + gsumg<G>(e.h)};
+  float r2[2] = {e.g, e.h};
+  gsumg_n<G, 2>(r2);
+  const P3 p0 = P3{0.0f, gauss1 + r2[0], 2.0f * gauss2 + r2[1]};
   const float lo_alpha_in = -fast_div(p0.g, p0.h);
-  const P3 lo_in = total(eval(lo_alpha_in), lo_alpha_in);
+  const P3 el = eval(lo_alpha_in);
+  float r3[3] = {el.c, el.g, el.h};
+  gsumg_n<G, 3>(r3);
+  const P3 lo_in = finish(r3[0], r3[1], r3[2], lo_alpha_in);
   float alpha = 0.0f, improvement = 0.0f;
   bool ls_converged = fabsf(lo_in.g) < gtol && lo_in.c < 0.0f;
   if (ls_converged) {
@@ -216,28 +224,38 @@ DEV void line_search_rows(const float (&rja)[NR], const float (&rjv)[NR], const 
     P3 lo = lo_less ? lo_in : p0, hi = lo_less ? p0 : lo_in;
     float lo_alpha = lo_less ? lo_alpha_in : 0.0f, hi_alpha = lo_less ? 0.0f : lo_alpha_in;
     for (int it = 0; it < ls_iterations; ++it) {
+      if (iters_out) ++*iters_out;
       const float a_lo = lo_alpha - fast_div(lo.g, lo.h), a_hi = hi_alpha - fast_div(hi.g, hi.h);
       const float a_mid = 0.5f * (lo_alpha + hi_alpha);
-      const P3 lo_next = total(eval(a_lo), a_lo), hi_next = total(eval(a_hi), a_hi), mid = total(eval(a_mid), a_mid);
-      auto take = [](bool c, P3& dst, float& da, const P3& src, float sa) __attribute__((always_inline)) {
-        dst.c = c ? src.c : dst.c;
-        dst.g = c ? src.g : dst.g;
-        dst.h = c ? src.h : dst.h;
-        da = c ? sa : da;
+      const P3 e1 = eval(a_lo), e2 = eval(a_hi), e3 = eval(a_mid);
+      float r9[9] = {e1.c, e1.g, e1.h, e2.c, e2.g, e2.h, e3.c, e3.g, e3.h};
+      gsumg_n<G, 9>(r9);
+      const P3 lo_next = finish(r9[0], r9[1], r9[2], a_lo), hi_next = finish(r9[3], r9[4], r9[5], a_hi), mid = finish(r9[6], r9[7], r9[8], a_mid);
+      // Bracket update (solver.py:1222-1290).  The reference takes a candidate when its derivative lies strictly between the
+      // bracket end's derivative and zero, for three candidates in turn -- each test on the end the previous one may have
+      // replaced.  The end therefore finishes on the candidate whose derivative is closest to zero among those strictly
+      // between the ORIGINAL end and zero (the earliest on ties), which needs no chain: three keys, one minimum, one select.
+      auto pick = [](P3& end, float& end_a, const P3& y1, float a1, const P3& y2, float a2, const P3& y3, float a3) __attribute__((always_inline)) {
+        const float g0 = end.g, m0 = fabsf(g0);
+        auto key = [&](float g) __attribute__((always_inline)) {
+          const float mg = fabsf(g);
+          const bool same = (__float_as_int(g) ^ __float_as_int(g0)) >= 0;  // equal sign bits
+          return (same && mg > 0.0f && mg < m0) ? mg : 3.0e38f;
+        };
+        const float k1 = key(y1.g), k2 = key(y2.g), k3 = key(y3.g);
+        const float kb = fminf(k1, fminf(k2, k3));
+        const bool any = kb < 3.0e38f;
+        const bool u1 = k1 == kb, u2 = k2 == kb;
+        const float sc = u1 ? y1.c : (u2 ? y2.c : y3.c), sg = u1 ? y1.g : (u2 ? y2.g : y3.g), sh = u1 ? y1.h : (u2 ? y2.h : y3.h);
+        const float sa = u1 ? a1 : (u2 ? a2 : a3);
+        end.c = any ? sc : end.c;
+        end.g = any ? sg : end.g;
+        end.h = any ? sh : end.h;
+        end_a = any ? sa : end_a;
+        return any;
       };
-      const bool s1 = in_bracket(lo, lo_next);
-      take(s1, lo, lo_alpha, lo_next, a_lo);
-      const bool s2 = in_bracket(lo, mid);
-      take(s2, lo, lo_alpha, mid, a_mid);
-      const bool s3 = in_bracket(lo, hi_next);
-      take(s3, lo, lo_alpha, hi_next, a_hi);
-      const bool h1 = in_bracket(hi, hi_next);
-      take(h1, hi, hi_alpha, hi_next, a_hi);
-      const bool h2 = in_bracket(hi, mid);
-      take(h2, hi, hi_alpha, mid, a_mid);
-      const bool h3 = in_bracket(hi, lo_next);
-      take(h3, hi, hi_alpha, lo_next, a_lo);
-      const bool swap_lo = s1 || s2 || s3, swap_hi = h1 || h2 || h3;
+      const bool swap_lo = pick(lo, lo_alpha, lo_next, a_lo, mid, a_mid, hi_next, a_hi);
+      const bool swap_hi = pick(hi, hi_alpha, hi_next, a_hi, mid, a_mid, lo_next, a_lo);
       const bool ls_done = (!swap_lo && !swap_hi) || (lo.c < 0.0f && lo.g < 0.0f && lo.g > -gtol) || (hi.c < 0.0f && hi.g > 0.0f && hi.g < gtol);
       const bool improved = lo.c < 0.0f || hi.c < 0.0f;
       const bool lo_better = lo.c < hi.c;
@@ -494,8 +512,9 @@ DEV void newton_pair(const MjhModel& m, const MjhData& d, float* S, const Newton
     pc.mark(12);
     if (!active) Mg = 0.0f;
     const float srch_new = -Mg;
-    const float sd_new = gsumg<G>(Mg * Mg);
-    const float dec_new = gsumg<G>(g * Mg);
+    float sd2[2] = {Mg * Mg, g * Mg};
+    gsumg_n<G, 2>(sd2);
+    const float sd_new = sd2[0], dec_new = sd2[1];
     if (!fin) {
       srch = srch_new;
       search_dot = sd_new;
@@ -520,13 +539,23 @@ DEV void newton_pair(const MjhModel& m, const MjhData& d, float* S, const Newton
     for (int k = 0; k < NR; ++k) rjv[k] = rkind[k] != 3 ? j_dot(bvec, lig + G * k) : 0.0f;
     pc.mark(5);
     // ---- line search ---------------------------------------------------------------------------------------------------
-    const float gauss1 = gsumg<G>(srch * (Ma - fs));
-    const float gauss2 = gsumg<G>(0.5f * srch * mvi);
+    float gs2[2] = {srch * (Ma - fs), 0.5f * srch * mvi};
+    gsumg_n<G, 2>(gs2);
+    const float gauss1 = gs2[0], gauss2 = gs2[1];
     const float gtol = fmaxf(tolerance * ls_tolerance * sqrtf(search_dot) * scale, 1e-6f);
     float alpha, imp_new;
     bool ls_ok;
     // (a finished world rides along on frozen state: no bracketing iterations for it)
+#ifdef MJH_PHASE_CLOCK
+    int ls_its = 0;
+    line_search_rows<NR, G>(rja, rjv, rD, rkind, has_fl, floss_lane, gauss1, gauss2, gtol, fin ? 0 : ls_iterations, alpha, imp_new, ls_ok, &ls_its);
+    if (lig == 0 && !fin) {  // profiling build: bracketing iterations and calls of the line search (phase slots 14, 15 of kernel 5)
+      atomicAdd(&g_phase_ticks[blockIdx.x & 63][5][14], (unsigned long long)ls_its);
+      atomicAdd(&g_phase_ticks[blockIdx.x & 63][5][15], 1ull);
+    }
+#else
     line_search_rows<NR, G>(rja, rjv, rD, rkind, has_fl, floss_lane, gauss1, gauss2, gtol, fin ? 0 : ls_iterations, alpha, imp_new, ls_ok);
+#endif
     pc.mark(6);
     if (!fin) {
       if (!ls_ok) ovf |= OVF_LS_ITERATIONS;

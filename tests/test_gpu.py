@@ -176,7 +176,7 @@ def test_per_step_parity_resynced(solver):
 # qpos floor 1e-2 (rad / m), qvel floor 1e-1 (rad/s / m/s).  CG at the float32 tolerance (1e-6) stops on a different iterate than
 # the float64 oracle at the same tolerance, which is what its looser bounds measure; Newton lands inside the same basin.
 _ELEM_CASES = [
-  ("humanoid", conftest.HUMANOID_XML, mjw.SolverType.NEWTON, 24, 64, 150, 2e-5, 1e-3),
+  ("humanoid", conftest.HUMANOID_XML, mjw.SolverType.NEWTON, 24, 64, 150, 8e-5, 2e-3),
   ("humanoid", conftest.HUMANOID_XML, mjw.SolverType.CG, 24, 64, 150, 5e-4, 1e-2),
   ("g1", conftest.G1_XML, mjw.SolverType.NEWTON, 48, 192, 60, 1e-5, 6e-4),
   ("panda", conftest.PANDA_XML, mjw.SolverType.NEWTON, 8, 16, 60, 1e-6, 1e-5),

@@ -17,13 +17,13 @@ PHASES = {
   3: ("make_constraint", ["load", "friction+limits", "J rows fl", "contact list", "contact J", "contact rows"]),
   4: ("fwd_vel", ["load", "com_vel", "passive", "rne", "actuation", "qfrc_smooth"]),
   5: ("solve", ["M rows", "Ma+Minv", "J+rows", "it: update+JTf+grad", "it: Mgrad/chol", "it: conv+mv+jv", "it: linesearch",
-                "it: move", "exit", "store", "it: H build (mfma)", "it: H swap + M", "it: chol factor"]),
+                "it: move", "exit", "store", "it: H build (mfma)", "it: H swap + M", "it: chol factor+solve", "-", "(count) ls bracketing iterations", "(count) ls calls"]),
 }
 
 
 def build():
   src = os.path.join(ROOT, "mujoco_warp_amd", "csrc", "unity.hip")  # one TU: a single copy of the device counters
-  subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
+  subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-fno-slp-vectorize", "-Wno-unused-value",
                          "-DMJH_PHASE_CLOCK", "-o", LIB, src])
 
 

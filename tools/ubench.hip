@@ -23,6 +23,7 @@ typedef float f2v __attribute__((ext_vector_type(2)));
 __device__ inline long long now() { return __builtin_readcyclecounter(); }
 
 // mode 0: v_fma_f32 (8 independent chains), 1: v_pk_fma_f32, 2: mfma 32x32x1_2b (1 acc), 3: mfma with 2 accs,
+// 9: ONE dependent v_fma chain, 10: v_cmp -> v_cndmask dependent chain, 11: v_min / v_max dependent chain, 12: v_rcp chain,
 // 4: readlane dependent chain, 5: LDS dependent chain (ds_read_b32), 6: dpp add chain, 7: ds_swizzle chain, 8: mfma 16x16x4
 template <int MODE>
 __global__ void k_issue(float* out, long long* ticks, int iters) {
@@ -75,6 +76,18 @@ __global__ void k_issue(float* out, long long* ticks, int iters) {
     } else if (MODE == 7) {
 #pragma unroll
       for (int u = 0; u < 16; ++u) a0 = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(a0 * c), 0x3E0));
+    } else if (MODE == 9) {
+#pragma unroll
+      for (int u = 0; u < 16; ++u) a0 = fmaf(a0, c, dd);
+    } else if (MODE == 10) {
+#pragma unroll
+      for (int u = 0; u < 16; ++u) a0 = (a0 < a1) ? a0 + c : a0 * dd;
+    } else if (MODE == 11) {
+#pragma unroll
+      for (int u = 0; u < 16; ++u) a0 = fminf(fmaxf(a0, a1), a2) + c;
+    } else if (MODE == 12) {
+#pragma unroll
+      for (int u = 0; u < 16; ++u) a0 = __builtin_amdgcn_rcpf(a0) + c;
     } else if (MODE == 8) {
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
@@ -146,6 +159,10 @@ int main() {
     run_issue<5>("ds_read_b32 chase", 16, w);
     run_issue<6>("dpp row_shr add chain", 16, w);
     run_issue<7>("mul+ds_swizzle chain", 16, w);
+    run_issue<9>("ONE dependent v_fma chain", 16, w);
+    run_issue<10>("cmp -> 2 ops -> cndmask chain (4 instr/step)", 16, w);
+    run_issue<11>("max, min, add chain (3 instr/step)", 16, w);
+    run_issue<12>("rcp + add chain (2 instr/step)", 16, w);
   }
   // ---- layout check ----
   std::vector<float> a(128), b(128), acc(64 * 32), row(64 * 32);
