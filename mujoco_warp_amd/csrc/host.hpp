@@ -45,6 +45,17 @@ static hipError_t set_lds(K kernel, size_t bytes) {
   return e;
 }
 
+// developer knob MJH_DEBUG_OCC: print the resident workgroups per CU the runtime computes for a launch and the rounds its grid needs
+template <typename K>
+static void debug_occupancy(const char* name, K kernel, int grid, int threads, size_t lds) {
+  static const bool on = getenv("MJH_DEBUG_OCC") != nullptr;
+  if (!on) return;
+  int nb = -1;
+  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, threads, lds);
+  fprintf(stderr, "%-22s grid %5d x %3d threads, LDS %6zu B: %2d workgroups per CU = %4.1f wavefronts per SIMD, %.2f rounds on 256 CUs\n", name, grid,
+          threads, lds, nb, nb * (threads / 64) / 4.0, nb > 0 ? grid / (256.0 * nb) : 0.0);
+}
+
 // solver launches, one translation unit each (nr = rows per lane: 2 / 6 with 32 lanes per world, 1 / 2 / 3 with 64;
 // (lo, hi] = row-count range of the worlds this launch solves; fuse_euler: explicit Euler step in the solver epilogue)
 int launch_solve_32_cg(const MjhModel* m, const MjhData* d, int nr, bool with_factor, int fuse_euler, hipStream_t s, int lo, int hi);

@@ -52,7 +52,7 @@ constexpr int G = 32;
 static int launch_pos(const MjhModel* m, const MjhData* d, int first, int last, hipStream_t s) {
   const PosLayout lay = pos_layout(m->nq, m->nv, m->nbody, m->njnt, m->nC, last >= POS_FACTOR);
   size_t lds;
-  const int threads = pick_block(sizeof(int) * mstruct_ints(m->nv, m->nC), sizeof(float) * lay.total, G, &lds);
+  const int threads = pick_block(sizeof(int) * pos_shared_words(m->nv, m->nC, m->nbody, m->njnt, m->nbodylevel), sizeof(float) * lay.total, G, &lds);
   if (!threads) return fail(MJH_E_UNSUPPORTED, "k_fwd_pos: model does not fit in LDS");
   HIPCHK(set_lds(k_fwd_pos<G>, lds));
   const int wpb = threads / G;
@@ -211,6 +211,8 @@ static int launch_mid(const MjhModel* m, const MjhData* d, bool sched, hipStream
   else HIPCHK(set_lds((k_mid<G, false>), lds));
   const int ncc = (d->nworld + nw_cc - 1) / nw_cc, nvb = (d->nworld + nw_v - 1) / nw_v;
   const dim3 grid(ncc + nvb + (sched ? 1 : 0)), block(G * std::max(nw_cc, nw_v));
+  if (m->heavy_colliders) debug_occupancy("k_mid<heavy>", k_mid<G, true>, (int)grid.x, (int)block.x, lds);
+  else debug_occupancy("k_mid", k_mid<G, false>, (int)grid.x, (int)block.x, lds);
   if (m->heavy_colliders) hipLaunchKernelGGL((k_mid<G, true>), grid, block, lds, s, *m, *d, ncc, nvb, nw_cc, nw_v, stride_cc, sched ? 1 : 0);
   else hipLaunchKernelGGL((k_mid<G, false>), grid, block, lds, s, *m, *d, ncc, nvb, nw_cc, nw_v, stride_cc, sched ? 1 : 0);
   return MJH_OK;
@@ -268,6 +270,7 @@ static int launch_integrate_plus(const MjhModel* m, const MjhData* d, int mode, 
   // Newton: publication and factor workgroups ride here; CG: they already rode with the solver launch
   const int nint = integrate ? nb : 0, npub = with_factor ? nb : 0, nfac = with_factor ? nb : 0;
   if (nint + npub + nfac == 0) return MJH_OK;
+  debug_occupancy("k_integrate_plus", k_integrate_plus<G>, nint + npub + nfac, 256, lds);
   hipLaunchKernelGGL(k_integrate_plus<G>, dim3(nint + npub + nfac), dim3(256), lds, s, *m, *d, mode, nint, npub);
   return MJH_OK;
 }
@@ -280,7 +283,7 @@ static int launch_pos_plus(const MjhModel* m, const MjhData* d, int first, int l
   g_noise.n = 0;
   const PosLayout lay = pos_layout(m->nq, m->nv, m->nbody, m->njnt, m->nC, last >= POS_FACTOR);
   size_t lds;
-  const int threads = pick_block(sizeof(int) * mstruct_ints(m->nv, m->nC), sizeof(float) * lay.total, G, &lds);
+  const int threads = pick_block(sizeof(int) * pos_shared_words(m->nv, m->nC, m->nbody, m->njnt, m->nbodylevel), sizeof(float) * lay.total, G, &lds);
   if (!threads) return fail(MJH_E_UNSUPPORTED, "k_fwd_pos: model does not fit in LDS");
   *sched_done = threads >= 128;
   if (!*sched_done) {
@@ -290,6 +293,7 @@ static int launch_pos_plus(const MjhModel* m, const MjhData* d, int first, int l
   lds = std::max(lds, (size_t)1024);
   HIPCHK(set_lds(k_fwd_pos_plus<G>, lds));
   const int wpb = threads / G, npos = (d->nworld + wpb - 1) / wpb, nnoise = (noise.n + threads - 1) / threads;
+  debug_occupancy("k_fwd_pos_plus", k_fwd_pos_plus<G>, npos + 1 + nnoise, threads, lds);
   hipLaunchKernelGGL(k_fwd_pos_plus<G>, dim3(npos + 1 + nnoise), dim3(threads), lds, s, *m, *d, first, last, npos, noise);
   return MJH_OK;
 }

@@ -39,6 +39,49 @@ DEV MStruct load_mstruct(const MjhModel& m, int* sh, int nthreads) {
 // M_rowadr | M_rownnz | M_colind | dof_tree | dof_leveladr (ndoflevel <= nv)
 __host__ __device__ inline int mstruct_ints(int nv, int nC) { return ((4 * nv + 1 + nC + 3) / 4) * 4; }
 
+// Block-shared kinematics table (fwd_pos fast path): everything the level loop of the forward kinematics looks up per body and
+// per joint, staged once per workgroup so that the loop chases LDS (64 cycles a hop) instead of model tables in global memory
+// (five dependent L1/L2 hops per tree level).  Valid when the staged fields are not batched per world.
+//   per body  (FKB words): parent | jntadr | jntnum | mocapid | pos[3] | quat[4]
+//   per joint (FKJ words): type | qposadr | pos[3] | axis[3] | qpos0[qposadr]
+//   then body_tree[nbody] and body_leveladr[nbodylevel + 1]
+#define FKB 11
+#define FKJ 9
+__host__ __device__ inline int fk_table_words(int nbody, int njnt, int nlevel) { return ((FKB * nbody + FKJ * njnt + nbody + nlevel + 1 + 3) / 4) * 4; }
+DEV bool fk_table_ok(const MjhModel& m) {
+  return m.body_pos_nb <= 1 && m.body_quat_nb <= 1 && m.jnt_pos_nb <= 1 && m.jnt_axis_nb <= 1 && m.qpos0_nb <= 1;
+}
+// cooperative (whole workgroup) fill; ends with __syncthreads
+DEV void load_fk_table(const MjhModel& m, float* T, int nthreads) {
+  const int nbody = m.nbody, njnt = m.njnt;
+  int* Ti = reinterpret_cast<int*>(T);
+  for (int b = threadIdx.x; b < nbody; b += nthreads) {
+    float* r = T + FKB * b;
+    int* ri = Ti + FKB * b;
+    ri[0] = m.body_parentid[b];
+    ri[1] = m.body_jntadr[b];
+    ri[2] = m.body_jntnum[b];
+    ri[3] = m.nmocap ? m.body_mocapid[b] : -1;
+    for (int k = 0; k < 3; ++k) r[4 + k] = m.body_pos[3 * b + k];
+    for (int k = 0; k < 4; ++k) r[7 + k] = m.body_quat[4 * b + k];
+  }
+  float* J = T + FKB * nbody;
+  for (int j = threadIdx.x; j < njnt; j += nthreads) {
+    float* r = J + FKJ * j;
+    int* ri = reinterpret_cast<int*>(r);
+    const int qa = m.jnt_qposadr[j];
+    ri[0] = m.jnt_type[j];
+    ri[1] = qa;
+    for (int k = 0; k < 3; ++k) r[2 + k] = m.jnt_pos[3 * j + k];
+    for (int k = 0; k < 3; ++k) r[5 + k] = m.jnt_axis[3 * j + k];
+    r[8] = m.qpos0[qa];
+  }
+  int* L = reinterpret_cast<int*>(J + FKJ * njnt);
+  for (int i = threadIdx.x; i < nbody; i += nthreads) L[i] = m.body_tree[i];
+  for (int i = threadIdx.x; i <= m.nbodylevel; i += nthreads) L[nbody + i] = m.body_leveladr[i];
+  __syncthreads();
+}
+
 // sparse L'DL factorisation in LDS (reference smooth.py:1183-1232 _qLD_acc/_qLDiag_div == MuJoCo mj_factorI).
 // L holds a copy of M on entry.  Row k is eliminated sequentially (leaf to root); the updates of its
 // ancestor rows are spread over the lanes (one ancestor row per lane, no write conflicts).
@@ -136,6 +179,12 @@ __host__ __device__ inline PosLayout pos_layout(int nq, int nv, int nbody, int n
   return p;
 }
 
+// block-shared words in front of the per-world slices: the larger of the M-structure and the kinematics table
+__host__ __device__ inline int pos_shared_words(int nv, int nC, int nbody, int njnt, int nlevel) {
+  const int a = mstruct_ints(nv, nC), b = fk_table_words(nbody, njnt, nlevel);
+  return a > b ? a : b;
+}
+
 enum { POS_KINEMATICS = 0, POS_COM = 1, POS_CRB = 2, POS_FACTOR = 3 };
 
 template <int G>
@@ -144,19 +193,115 @@ DEV void fwd_pos_body(const MjhModel& m, const MjhData& d, int first, int last, 
   const int nq = m.nq, nv = m.nv, nbody = m.nbody, njnt = m.njnt, nC = m.nC;
   const PosLayout lay = pos_layout(nq, nv, nbody, njnt, nC, last >= POS_FACTOR);
   int* shi = reinterpret_cast<int*>(smem);
-  const MStruct ms = load_mstruct<G>(m, shi, b.nthreads);
+  const int shared_words = pos_shared_words(nv, nC, nbody, njnt, m.nbodylevel);
+  const bool fk_fast = first <= POS_KINEMATICS && fk_table_ok(m);
+  // the block-shared region holds the kinematics table first and the M-structure afterwards (both: one fill + barrier)
+  if (fk_fast) load_fk_table(m, smem, b.nthreads);
+  MStruct ms = MStruct{nullptr, nullptr, nullptr, nullptr, nullptr};
+  if (!fk_fast) ms = load_mstruct<G>(m, shi, b.nthreads);
   const int lig = threadIdx.x & (G - 1), gib = threadIdx.x / G;
   const int w = b.w0 + gib;
-  if (w >= d.nworld) return;
+  const bool valid = w < d.nworld;  // (no early return: the workgroup meets again at the barriers below)
   PhaseClock pc(1, lig);
-  float* S = smem + mstruct_ints(nv, nC) + (size_t)gib * lay.total;
+  float* S = smem + shared_words + (size_t)gib * lay.total;
   float *qpos = S + lay.qpos, *xpos = S + lay.xpos, *xquat = S + lay.xquat, *xmat = S + lay.xmat, *xipos = S + lay.xipos,
         *ximat = S + lay.ximat, *xanchor = S + lay.xanchor, *xaxis = S + lay.xaxis, *scom = S + lay.scom,
         *cinert = S + lay.cinert, *cdof = S + lay.cdof, *crb = S + lay.crb, *M = S + lay.M, *L = S + lay.L,
         *dinv = S + lay.dinv;
 
   // ---- kinematics (smooth.py:46-226) ---------------------------------------------------------------
-  if (first <= POS_KINEMATICS) {
+  if (first <= POS_KINEMATICS && valid && fk_fast) {
+    gcopy<G>(qpos, d.qpos + (size_t)w * nq, nq, lig);
+    gsync();
+    const float* TB = smem;
+    const float* TJ = smem + FKB * nbody;
+    const int* TL = reinterpret_cast<const int*>(TJ + FKJ * njnt);
+    // joint-local transforms, one lane per joint (all trigonometry up front, off the level chain): lq = rotation of the joint
+    // about its own axis (hinge) / the ball quaternion / identity, disp = slide displacement.  Parked in the cinert slice.
+    float* lq = cinert;
+    for (int j = lig; j < njnt; j += G) {
+      const float* r = TJ + FKJ * j;
+      const int t = __float_as_int(r[0]), qa = __float_as_int(r[1]);
+      Q4 q = Q4{1, 0, 0, 0};
+      float disp = 0.0f;
+      if (t == JNT_HINGE) q = axis_angle_to_quat(ld3(r + 5), qpos[qa] - r[8]);
+      else if (t == JNT_BALL) q = quat_normalize(ld4(qpos + qa));
+      else if (t == JNT_SLIDE) disp = qpos[qa] - r[8];
+      st4(lq + 5 * j, q);
+      lq[5 * j + 4] = disp;
+    }
+    gsync();
+    pc.mark(4);
+  }
+  if (fk_fast && first <= POS_KINEMATICS) {
+    // ---- level loop, REPACKED: a tree level holds a handful of bodies (at most 4 for the humanoid), so with one 32-lane group
+    // per world 7/8 of every instruction's lanes idle -- and the loop is issue-bound (four wavefronts per SIMD).  Instead LW
+    // lanes per world (the widest level, rounded up to a power of two) walk the levels, for 64 / LW worlds per wavefront: the
+    // same arithmetic in an eighth of the wavefront-instructions; the other wavefronts of the workgroup wait at the barrier.
+    __syncthreads();  // every world's joint-local transforms are in LDS
+    const float* TB = smem;
+    const float* TJ = smem + FKB * nbody;
+    const int* TL = reinterpret_cast<const int*>(TJ + FKJ * njnt);
+    int maxw = 1;
+    for (int l = 0; l < m.nbodylevel; ++l) maxw = max(maxw, TL[nbody + l + 1] - TL[nbody + l]);
+    int LW = 1;
+    while (LW < maxw) LW <<= 1;
+    if (LW > G) LW = G;  // (wider levels: the lanes stride, as before)
+    const int t = (int)threadIdx.x, g2 = t / LW, slot = t - g2 * LW;
+    const int w2 = b.w0 + g2;
+    if (g2 < b.nw && w2 < d.nworld) {
+      float* S2 = smem + shared_words + (size_t)g2 * lay.total;
+      float *qpos = S2 + lay.qpos, *xpos = S2 + lay.xpos, *xquat = S2 + lay.xquat, *xanchor = S2 + lay.xanchor, *xaxis = S2 + lay.xaxis;
+      const float* lq = S2 + lay.cinert;
+      for (int l = 0; l < m.nbodylevel; ++l) {
+        const int beg = TL[nbody + l], end = TL[nbody + l + 1];
+        for (int idx = beg + slot; idx < end; idx += LW) {
+          const int b = TL[idx];
+          if (b == 0) {
+            st3(xpos, V3{0, 0, 0});
+            st4(xquat, Q4{1, 0, 0, 0});
+            continue;
+          }
+          const float* rb = TB + FKB * b;
+          const int pid = __float_as_int(rb[0]), jntadr = __float_as_int(rb[1]), jntnum = __float_as_int(rb[2]), mid = __float_as_int(rb[3]);
+          if (jntnum == 1 && __float_as_int(TJ[FKJ * jntadr]) == JNT_FREE) {
+            const int qa = __float_as_int(TJ[FKJ * jntadr + 1]);
+            V3 p = ld3(qpos + qa);
+            Q4 q = quat_normalize(ld4(qpos + qa + 3));
+            st3(xpos + 3 * b, p);
+            st4(xquat + 4 * b, q);
+            st3(xanchor + 3 * jntadr, p);
+            st3(xaxis + 3 * jntadr, ld3(TJ + FKJ * jntadr + 5));
+            continue;
+          }
+          Q4 pq = ld4(xquat + 4 * pid);
+          // mocap bodies (children of the world without joints) take their pose from Data.mocap_* (smooth.py:104-108)
+          const V3 bp = mid >= 0 ? ld3(d.mocap_pos + ((size_t)w2 * m.nmocap + mid) * 3) : ld3(rb + 4);
+          const Q4 bq = mid >= 0 ? ld4(d.mocap_quat + ((size_t)w2 * m.nmocap + mid) * 4) : ld4(rb + 7);
+          V3 pos = rot_vec_quat(bp, pq) + ld3(xpos + 3 * pid);
+          Q4 quat = mul_quat(pq, bq);
+          for (int j = jntadr; j < jntadr + jntnum; ++j) {
+            const float* r = TJ + FKJ * j;
+            const int tj = __float_as_int(r[0]);
+            const V3 jp = ld3(r + 2), ja = ld3(r + 5);
+            V3 anchor = rot_vec_quat(jp, quat) + pos;
+            V3 axis = rot_vec_quat(ja, quat);
+            if (tj == JNT_SLIDE) {
+              pos = pos + axis * lq[5 * j + 4];
+            } else if (tj == JNT_BALL || tj == JNT_HINGE) {
+              quat = mul_quat(quat, ld4(lq + 5 * j));
+              pos = anchor - rot_vec_quat(jp, quat);
+            }
+            st3(xanchor + 3 * j, anchor);
+            st3(xaxis + 3 * j, axis);
+          }
+          st3(xpos + 3 * b, pos);
+          st4(xquat + 4 * b, quat_normalize(quat));
+        }
+        gsync();  // (the LW lanes of a world sit in one wavefront: 64 % LW == 0)
+      }
+    }
+  } else if (first <= POS_KINEMATICS && valid) {
     gcopy<G>(qpos, d.qpos + (size_t)w * nq, nq, lig);
     gsync();
     const float* qpos0 = bf(m.qpos0, m.qpos0_nb, w, nq);
@@ -213,6 +358,14 @@ DEV void fwd_pos_body(const MjhModel& m, const MjhData& d, int first, int last, 
       }
       gsync();
     }
+  }
+  if (fk_fast) {  // every wavefront is done with the kinematics table: the M-structure takes its place
+    __syncthreads();
+    ms = load_mstruct<G>(m, shi, b.nthreads);
+  }
+  if (!valid) return;
+  pc.mark(5);
+  if (first <= POS_KINEMATICS) {
     const float* body_ipos = bf(m.body_ipos, m.body_ipos_nb, w, 3 * nbody);
     const float* body_iquat = bf(m.body_iquat, m.body_iquat_nb, w, 4 * nbody);
     for (int b = lig; b < nbody; b += G) {
@@ -221,6 +374,7 @@ DEV void fwd_pos_body(const MjhModel& m, const MjhData& d, int first, int last, 
       st3(xipos + 3 * b, ld3(xpos + 3 * b) + rot_vec_quat(ld3(body_ipos + 3 * b), q));
       quat_to_mat(mul_quat(q, ld4(body_iquat + 4 * b)), ximat + 9 * b);
     }
+    pc.mark(6);
     {  // geoms and sites go straight to HBM (consumed by the collision kernel)
       const float* geom_pos = bf(m.geom_pos, m.geom_pos_nb, w, 3 * m.ngeom);
       const float* geom_quat = bf(m.geom_quat, m.geom_quat_nb, w, 4 * m.ngeom);
@@ -246,6 +400,7 @@ DEV void fwd_pos_body(const MjhModel& m, const MjhData& d, int first, int last, 
       }
     }
     gsync();
+    pc.mark(7);
     gcopy<G>(d.xpos + (size_t)w * 3 * nbody, xpos, 3 * nbody, lig);
     gcopy<G>(d.xquat + (size_t)w * 4 * nbody, xquat, 4 * nbody, lig);
     gcopy<G>(d.xmat + (size_t)w * 9 * nbody, xmat, 9 * nbody, lig);

@@ -39,6 +39,7 @@ static int launch_solve_t(const MjhModel* m, const MjhData* d, bool with_factor,
   HIPCHK(set_lds((k_solve_plus<NV4, NR, NEWTON, SG>), lds));
   const int nsolve = (d->nworld + wpb - 1) / wpb, nfac = with_factor ? (d->nworld + wf - 1) / wf : 0;
   // riders (fused step, CG): factor workgroups, then as many contact-publication workgroups
+  debug_occupancy(NEWTON ? "k_solve_plus<newton>" : "k_solve_plus<cg>", k_solve_plus<NV4, NR, NEWTON, SG>, nsolve + 2 * nfac, threads, lds);
   hipLaunchKernelGGL((k_solve_plus<NV4, NR, NEWTON, SG>), dim3(nsolve + 2 * nfac), dim3(threads), lds, s, *m, *d, nsolve, nfac, nefc_lo, nefc_hi, fuse_euler);
   return MJH_OK;
 }

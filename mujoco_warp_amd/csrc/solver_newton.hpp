@@ -165,8 +165,9 @@ DEV float chol_factor_solve(float (&h)[4 * NV4], float g, float* panel, float* v
 
 // exact line search on the convex cost of ONE world (solver.py:835-1347), rows and sums in registers; the same arithmetic as
 // the line search inside solve_body (solver.hpp), as a function
-template <int NR, int G>
-DEV void line_search_rows(const float (&rja)[NR], const float (&rjv)[NR], const float (&rD)[NR], const int (&rkind)[NR], bool has_fl,
+// HAS_FL: friction-loss rows present (three-zone cost, rare): a compile-time switch, the common instantiation is branch-free
+template <int NR, int G, bool HAS_FL>
+DEV void line_search_rows(const float (&rja)[NR], const float (&rjv)[NR], const float (&rD)[NR], const int (&rkind)[NR],
                           const float* floss_lane, float gauss1, float gauss2, float gtol, int ls_iterations, float& alpha_out,
                           float& improvement_out, bool& converged_out, int* iters_out = nullptr) {
   float ehess[NR], egrad0[NR], ecact[NR], ecin[NR];
@@ -181,7 +182,7 @@ DEV void line_search_rows(const float (&rja)[NR], const float (&rjv)[NR], const 
   }
   auto eval = [&](float a) __attribute__((always_inline)) {
     P3 s = P3{0.0f, 0.0f, 0.0f};
-    if (!has_fl) {
+    if (!HAS_FL) {
       const float ha = 0.5f * a;
 #pragma unroll
       for (int k = 0; k < NR; ++k) {
@@ -548,13 +549,15 @@ DEV void newton_pair(const MjhModel& m, const MjhData& d, float* S, const Newton
     // (a finished world rides along on frozen state: no bracketing iterations for it)
 #ifdef MJH_PHASE_CLOCK
     int ls_its = 0;
-    line_search_rows<NR, G>(rja, rjv, rD, rkind, has_fl, floss_lane, gauss1, gauss2, gtol, fin ? 0 : ls_iterations, alpha, imp_new, ls_ok, &ls_its);
+    if (wave_any(has_fl)) line_search_rows<NR, G, true>(rja, rjv, rD, rkind, floss_lane, gauss1, gauss2, gtol, fin ? 0 : ls_iterations, alpha, imp_new, ls_ok, &ls_its);
+    else line_search_rows<NR, G, false>(rja, rjv, rD, rkind, floss_lane, gauss1, gauss2, gtol, fin ? 0 : ls_iterations, alpha, imp_new, ls_ok, &ls_its);
     if (lig == 0 && !fin) {  // profiling build: bracketing iterations and calls of the line search (phase slots 14, 15 of kernel 5)
       atomicAdd(&g_phase_ticks[blockIdx.x & 63][5][14], (unsigned long long)ls_its);
       atomicAdd(&g_phase_ticks[blockIdx.x & 63][5][15], 1ull);
     }
 #else
-    line_search_rows<NR, G>(rja, rjv, rD, rkind, has_fl, floss_lane, gauss1, gauss2, gtol, fin ? 0 : ls_iterations, alpha, imp_new, ls_ok);
+    if (wave_any(has_fl)) line_search_rows<NR, G, true>(rja, rjv, rD, rkind, floss_lane, gauss1, gauss2, gtol, fin ? 0 : ls_iterations, alpha, imp_new, ls_ok);
+    else line_search_rows<NR, G, false>(rja, rjv, rD, rkind, floss_lane, gauss1, gauss2, gtol, fin ? 0 : ls_iterations, alpha, imp_new, ls_ok);
 #endif
     pc.mark(6);
     if (!fin) {

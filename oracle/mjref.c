@@ -1568,7 +1568,8 @@ void ref_make_constraint(const RefModel* m, RefData* d) {
       double pos = d->con_dist[c] - includemargin;
       if (!(pos < 0.0)) continue;
       int condim = d->con_dim[c];
-      int ndim = condim == 1 ? 1 : 2 * (condim - 1);
+      int elliptic = m->cone == 1 && condim > 1;
+      int ndim = condim == 1 ? 1 : (elliptic ? condim : 2 * (condim - 1)); /* constraint.py:2698-2704 */
       int base = nefc;
       nefc += ndim;
       int g1 = d->con_geom[2 * c], g2 = d->con_geom[2 * c + 1];
@@ -1598,7 +1599,7 @@ void ref_make_constraint(const RefModel* m, RefData* d) {
       const double* frame = d->con_frame + 9 * c;
       const double* fri = d->con_friction + 5 * c;
       double invweight = m->body_invweight0[2 * b1] + m->body_invweight0[2 * b2];
-      if (condim > 1) {
+      if (condim > 1 && !elliptic) {
         double fri0 = fri[0];
         invweight = invweight + fri0 * fri0 * invweight;
         invweight = invweight * 2.0 * fri0 * fri0 / m->impratio;
@@ -1609,6 +1610,29 @@ void ref_make_constraint(const RefModel* m, RefData* d) {
         d->con_efc_address[10 * c + dimid] = r;
         double* J = d->efc_J + (size_t)r * nv;
         double vel = 0;
+        if (elliptic) {
+          /* elliptic cone: one row per contact dimension (constraint.py:3836-3847): normal, two tangents (translational Jacobian
+           * along the frame axes), then torsion and the two rolling directions (rotational Jacobian); parameters of the
+           * friction rows: constraint.py:4277-4294 */
+          const double* fr = frame + 3 * (dimid < 3 ? dimid : dimid - 3);
+          const double* jac = dimid < 3 ? jacp : jacr;
+          for (int i = 0; i < nv; i++) {
+            J[i] = fr[0] * jac[i] + fr[1] * jac[nv + i] + fr[2] * jac[2 * nv + i];
+            vel += J[i] * d->qvel[i];
+          }
+          double iw = invweight;
+          const double* ref = d->con_solref + 2 * c;
+          double pos_aref = pos;
+          if (dimid > 0) {
+            const double* srf = d->con_solreffriction + 2 * c;
+            if (srf[0] != 0.0 || srf[1] != 0.0) ref = srf;
+            iw = iw / m->impratio;
+            if (dimid > 1) iw *= fri[0] * fri[0] / (fri[dimid - 1] * fri[dimid - 1]);
+            pos_aref = 0.0;
+          }
+          efc_row(m, d, r, pos_aref, pos, iw, ref, d->con_solimp + 5 * c, includemargin, vel, 0.0, CT_CONTACT_ELLIPTIC, c);
+          continue;
+        }
         for (int i = 0; i < nv; i++) {
           double j0 = frame[0] * jacp[i] + frame[1] * jacp[nv + i] + frame[2] * jacp[2 * nv + i];
           double val = j0;
@@ -1655,6 +1679,24 @@ static void update_constraint(const RefModel* m, RefData* d, Ctx* c) {
       if (jaref <= -rf) { d->efc_force[r] = f; d->efc_state[r] = ST_LINEARNEG; }
       else if (jaref >= rf) { d->efc_force[r] = -f; d->efc_state[r] = ST_LINEARPOS; }
       else { d->efc_force[r] = -D * jaref; d->efc_state[r] = ST_QUADRATIC; }
+    } else if (d->efc_type[r] == CT_CONTACT_ELLIPTIC) {
+      /* _eval_constraint solver.py:455-472 + _eval_elliptic_middle 406-421: the rows of one contact decide together */
+      int con = d->efc_id[r], r0 = d->con_efc_address[10 * con], dim = d->con_dim[con];
+      const double* fri = d->con_friction + 5 * con;
+      double mu = fri[0] / sqrt(m->impratio), N = c->Jaref[r0] * mu, TT = 0.0, ufrictionj = 0.0;
+      for (int j = 1; j < dim; j++) {
+        double uj = c->Jaref[r0 + j] * fri[j - 1];
+        TT += uj * uj;
+        if (r == r0 + j) ufrictionj = uj * fri[j - 1];
+      }
+      double T = TT <= 0.0 ? 0.0 : sqrt(TT);
+      if (N >= mu * T || (T <= 0.0 && N >= 0.0)) { d->efc_force[r] = 0.0; d->efc_state[r] = ST_SATISFIED; }
+      else if (mu * N + T <= 0.0 || (T <= 0.0 && N < 0.0)) { d->efc_force[r] = -D * jaref; d->efc_state[r] = ST_QUADRATIC; }
+      else {
+        double dm = safe_div(d->efc_D[r0], mu * mu * (1.0 + mu * mu)), fn = -dm * (N - mu * T) * mu;
+        d->efc_force[r] = r == r0 ? fn : -safe_div(fn, T) * ufrictionj;
+        d->efc_state[r] = ST_CONE;
+      }
     } else {
       if (jaref >= 0.0) { d->efc_force[r] = 0.0; d->efc_state[r] = ST_SATISFIED; }
       else { d->efc_force[r] = -D * jaref; d->efc_state[r] = ST_QUADRATIC; }
@@ -1727,6 +1769,29 @@ static void update_gradient(const RefModel* m, RefData* d, Ctx* c, double* grad_
         for (int j = 0; j <= i; j++) H[i * nv + j] += ji * J[j];
       }
     }
+    /* cone Hessian of the contacts in the middle zone (_update_gradient_JTCJ_dense solver.py:2466-2564) */
+    for (int r = 0; r < nefc; r++) {
+      if (d->efc_type[r] != CT_CONTACT_ELLIPTIC || d->efc_state[r] != ST_CONE) continue;
+      int con = d->efc_id[r], r0 = d->con_efc_address[10 * con], dim = d->con_dim[con];
+      if (r != r0) continue;
+      const double* fri = d->con_friction + 5 * con;
+      double mu = fri[0] / sqrt(m->impratio), mu2 = mu * mu, dm = safe_div(d->efc_D[r0], mu2 * (1.0 + mu2));
+      if (dm == 0.0) continue;
+      double n = c->Jaref[r0] * mu, tt = 0.0;
+      for (int j = 1; j < dim; j++) { double u = c->Jaref[r0 + j] * fri[j - 1]; tt += u * u; }
+      double t = fmax(sqrt(tt), MINVAL), ttt = fmax(t * t * t, MINVAL), mu_tinv = safe_div(mu, t);
+      double mu_n_ttt = mu * safe_div(n, ttt), tdiag = mu2 - n * mu_tinv;
+      for (int i = 0; i < nv; i++)
+        for (int k = 0; k <= i; k++) {
+          double z01 = mu * d->efc_J[(size_t)r0 * nv + i], z02 = mu * d->efc_J[(size_t)r0 * nv + k], p1 = 0, p2 = 0, td = 0;
+          for (int j = 1; j < dim; j++) {
+            double sc = fri[j - 1], u = c->Jaref[r0 + j] * sc;
+            double z1 = sc * d->efc_J[(size_t)(r0 + j) * nv + i], z2 = sc * d->efc_J[(size_t)(r0 + j) * nv + k];
+            p1 += u * z1; p2 += u * z2; td += z1 * z2;
+          }
+          H[i * nv + k] += dm * (z01 * z02 - mu_tinv * (z01 * p2 + z02 * p1) + mu_n_ttt * p1 * p2 + tdiag * td);
+        }
+    }
     for (int i = 0; i < nv; i++)
       for (int j = i + 1; j < nv; j++) H[i * nv + j] = H[j * nv + i];
     chol_factor(H, nv);
@@ -1740,12 +1805,42 @@ static void update_gradient(const RefModel* m, RefData* d, Ctx* c, double* grad_
 }
 
 /* per-row (cost - cost0, grad, hess) at alpha: _compute_efc_eval_pt_pyramidal solver.py:518-556 */
+static double m_impratio = 1.0; /* set by ref_solve (eval_pt has no model argument) */
 static void eval_pt(const RefData* d, const Ctx* c, double alpha, double* out) {
   int ne = d->ne, nf = d->nf;
   double s0 = 0, s1 = 0, s2 = 0;
   for (int r = 0; r < c->nefc; r++) {
     double ja = c->Jaref[r], jv = c->jv[r], D = d->efc_D[r];
     double x = ja + alpha * jv, jvD = jv * D, hess = jv * jvD;
+    if (d->efc_type[r] == CT_CONTACT_ELLIPTIC) {
+      /* cost(alpha) - cost(0), derivative and curvature of one elliptic contact on the ray (solver.py:272-403; float64 can
+       * afford the plain difference of costs where the reference uses shifted forms): evaluated at the contact's first row */
+      int con = d->efc_id[r], r0 = d->con_efc_address[10 * con], dim = d->con_dim[con];
+      if (r != r0) continue;
+      const double* fri = d->con_friction + 5 * con;
+      double mu = fri[0] / sqrt(m_impratio), dm = safe_div(d->efc_D[r0], mu * mu * (1.0 + mu * mu));
+      double cost[2], grad = 0.0, hs = 0.0;
+      for (int pass = 0; pass < 2; pass++) { /* pass 0: alpha = 0 (the reference point), pass 1: alpha */
+        double a = pass ? alpha : 0.0;
+        double N = (c->Jaref[r0] + a * c->jv[r0]) * mu, v0 = c->jv[r0] * mu, uu = 0, uv = 0, vv = 0, quad = 0, quadg = 0, quadh = 0;
+        for (int j = 0; j < dim; j++) {
+          double xj = c->Jaref[r0 + j] + a * c->jv[r0 + j], Dj = d->efc_D[r0 + j];
+          quad += 0.5 * Dj * xj * xj; quadg += Dj * xj * c->jv[r0 + j]; quadh += Dj * c->jv[r0 + j] * c->jv[r0 + j];
+          if (j > 0) { double uj = xj * fri[j - 1], vj = c->jv[r0 + j] * fri[j - 1]; uu += uj * uj; uv += uj * vj; vv += vj * vj; }
+        }
+        double T = uu <= 0.0 ? 0.0 : sqrt(uu), cst, g = 0.0, h = 0.0;
+        if (N >= mu * T || (T <= 0.0 && N >= 0.0)) cst = 0.0;
+        else if (mu * N + T <= 0.0 || (T <= 0.0 && N < 0.0)) { cst = quad; g = quadg; h = quadh; }
+        else {
+          double rr = N - mu * T, T1 = uv / T, T2 = (vv - T1 * T1) / T, r1 = v0 - mu * T1;
+          cst = 0.5 * dm * rr * rr; g = dm * rr * r1; h = dm * (r1 * r1 + rr * (-mu * T2));
+        }
+        cost[pass] = cst;
+        if (pass) { grad = g; hs = h; }
+      }
+      s0 += cost[1] - cost[0]; s1 += grad; s2 += hs;
+      continue;
+    }
     if (r >= ne + nf) {
       double quad0 = 0.5 * D * ja * ja, cost0 = ja < 0.0 ? quad0 : 0.0;
       if (x < 0.0) { s0 += alpha * (jvD * ja + 0.5 * alpha * hess) + (quad0 - cost0); s1 += jvD * ja + alpha * hess; s2 += hess; }
@@ -1932,6 +2027,7 @@ void ref_solve(const RefModel* m, RefData* d) {
     solve_pgs(m, d, nefc);
     return;
   }
+  m_impratio = m->impratio;
   Ctx c;
   c.nv = nv; c.nefc = nefc;
   double* buf = (double*)calloc((size_t)2 * m->njmax + 7 * nv + (size_t)nv * nv, sizeof(double));

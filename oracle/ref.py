@@ -157,8 +157,8 @@ class RefSim:
       disableflags=int(opt.disableflags), broadphase=int(broadphase), broadphase_filter=int(broadphase_filter), timestep=float(opt.timestep),
       tolerance=float(opt.tolerance if tolerance is None else tolerance), ls_tolerance=float(opt.ls_tolerance),
       impratio=float(opt.impratio), meaninertia=float(mjm.stat.meaninertia))
-    if scalars["cone"] != 0:
-      raise NotImplementedError("oracle: elliptic cones")
+    if scalars["cone"] != 0 and scalars["solver"] == 0:
+      raise NotImplementedError("oracle: PGS with elliptic cones")
     special = {"gravity": np.asarray(opt.gravity, dtype=np.float64), "pair_geom": pairs, "nxn_pairid": pairid,
                "xpair_dim": getattr(mjm, "pair_dim", np.zeros(0)), "xpair_friction": getattr(mjm, "pair_friction", np.zeros(0)),
                "xpair_solref": getattr(mjm, "pair_solref", np.zeros(0)), "xpair_solreffriction": getattr(mjm, "pair_solreffriction", np.zeros(0)),

@@ -12,7 +12,7 @@ sys.path.insert(0, ROOT)
 LIB = os.path.join(ROOT, "mujoco_warp_amd", "libmjhip_clk.so")
 
 PHASES = {
-  1: ("fwd_pos", ["kinematics", "com_pos", "crb", "factor"]),
+  1: ("fwd_pos", ["kin: copy out", "com_pos", "crb", "factor", "kin: qpos + joint-local", "kin: level loop (+ table swap)", "kin: body mats", "kin: geoms/sites"]),
   2: ("collision", ["stage geoms", "broadphase", "narrow pass1", "window init", "pass2 stage", "write records"]),
   3: ("make_constraint", ["load", "friction+limits", "J rows fl", "contact list", "contact J", "contact rows"]),
   4: ("fwd_vel", ["load", "com_vel", "passive", "rne", "actuation", "qfrc_smooth"]),
