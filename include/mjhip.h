@@ -188,6 +188,8 @@ typedef struct MjhData {
   int* ws_ncon;        /* [nworld]   contacts found per world                         */
   int* ws_conadr;      /* [nworld]   exclusive scan of ws_ncon = first public slot (k_contact_scan) */
   int* ws_ncollision;  /* [nworld]   broadphase candidates per world                  */
+  int* ws_efc_con;     /* [nworld, njmax] contact rows: 16 * (world-local contact) + row within the contact (make_constraint -> solver,
+                          elliptic cones only) */
   int* ws_order;       /* [nworld]   solver schedule: worlds sorted by last step's solver_niter (longest first) */
   int* eq_active;      /* [nworld, neq] Data.eq_active (types.py:2262), initialised from eq_active0 */
   float* ws_rk;        /* [nworld, nq + 3 nv + 2 na] RK4 scratch: qpos, qvel, act at t0 and the weighted sums of qvel, qacc,
@@ -232,7 +234,7 @@ int mjh_timed_steps(const MjhModel* m, const MjhData* d, int nstep, int step0, f
 int mjh_release_thread_resources(void);
 
 const char* mjh_last_error(void);
-#define MJH_ABI_VERSION 7
+#define MJH_ABI_VERSION 8
 int mjh_abi_version(void); /* returns MJH_ABI_VERSION of the library that was loaded */
 
 #ifdef __cplusplus

@@ -740,7 +740,6 @@ DEV PairParams contact_params(const MjhModel& m, int w, int g1, int g2, int pid 
 #define CON_WINDOW 16
 #define CON_REC 30
 #define CON_LDS 31  /* odd LDS stride: lane-per-contact reads are bank-conflict free */
-#define CON_STRIDE 32
 // per-world LDS: geom poses (12 words per geom) | candidate pair list | first contact slot << 8 | contact mask per
 // candidate | staging window of CON_WINDOW records
 // SAP broadphase (sap != 0) adds: projection bounds (2 words per geom, padded to a power of two for the bitonic sort) | sorted

@@ -283,7 +283,8 @@ DEV void make_constraint_body(const MjhModel& m, const MjhData& d, float* smem, 
       const float pos = crec[c * CON_STRIDE] - crec[c * CON_STRIDE + 13];
       act = pos < 0.0f;
       const int condim = creci[c * CON_STRIDE + 24];
-      ndim = act ? min(condim == 1 ? 1 : 2 * (condim - 1), d.nmaxpyramid) : 0;
+      // pyramidal: two rows per friction dimension; elliptic: one row per contact dimension (constraint.py:2698-2704)
+      ndim = act ? min(condim == 1 ? 1 : (m.cone == CONE_ELLIPTIC ? condim : 2 * (condim - 1)), d.nmaxpyramid) : 0;
     }
     int incl = ndim;
     for (int off = 1; off < G; off <<= 1) {
@@ -356,6 +357,10 @@ DEV void make_constraint_body(const MjhModel& m, const MjhData& d, float* smem, 
           const float comp[6] = {dot(f0, jp), dot(f1, jp), dot(f2, jp), dot(f0, jr), dot(f1, jr), dot(f2, jr)};
           if (condim == 1) {
             if (rbase < njmax) J[(size_t)rbase * nvp + i] = comp[0];
+          } else if (m.cone == CONE_ELLIPTIC) {  // rows = normal, tangent 1, tangent 2, spin, roll 1, roll 2 (constraint.py:3836-3847)
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+              if (q < ndim && rbase + q < njmax) J[(size_t)(rbase + q) * nvp + i] = comp[q];
           } else {
 #pragma unroll
             for (int q = 1; q < 6; ++q) {
@@ -383,7 +388,7 @@ DEV void make_constraint_body(const MjhModel& m, const MjhData& d, float* smem, 
     const float impr2 = bf(m.opt_impratio_invsqrt, m.opt_impratio_invsqrt_nb, w, 1)[0];
     const float* biw = bf(m.body_invweight0, m.body_invweight0_nb, w, 2 * nbody);
     for (int r = nrow_noncontact + lig; r < nrow; r += G) {
-      const int c = row2con[r] >> 4;
+      const int c = row2con[r] >> 4, dimid = row2con[r] & 15;
       const float* cr = crec + c * CON_STRIDE;
       const int* cri = creci + c * CON_STRIDE;
       const float includemargin = cr[13];
@@ -391,7 +396,16 @@ DEV void make_constraint_body(const MjhModel& m, const MjhData& d, float* smem, 
       const int condim = cri[24];
       const int b1 = gbody[cri[25]], b2 = gbody[cri[26]];
       float invweight = biw[2 * b1] + biw[2 * b2];
-      if (condim > 1) {
+      const bool elliptic = m.cone == CONE_ELLIPTIC && condim > 1;
+      if (elliptic) {
+        // friction rows of an elliptic contact (constraint.py:4277-4294): regularisation scaled by 1 / impratio and by
+        // (mu_1 / mu_dim)^2, no position term in aref (solreffriction is rejected by put_model: the rows use solref)
+        if (dimid > 0) invweight *= impr2 * impr2;
+        if (dimid > 1) {
+          const float frii = cr[dimid == 2 ? 14 : (dimid == 3 ? 15 : 16)];
+          invweight *= cr[14] * cr[14] / (frii * frii);
+        }
+      } else if (condim > 1) {
         const float fri0 = cr[14];
         invweight = invweight + fri0 * fri0 * invweight;
         invweight = invweight * 2.0f * fri0 * fri0 * impr2 * impr2;
@@ -407,15 +421,16 @@ DEV void make_constraint_body(const MjhModel& m, const MjhData& d, float* smem, 
         }
       }
       const float vel = v0 + v1;
-      EfcRowOut eo_ = efc_row(dsbl, timestep, pos, pos, invweight, cr + 17, cr + 19, includemargin, vel);
+      EfcRowOut eo_ = efc_row(dsbl, timestep, elliptic && dimid > 0 ? 0.0f : pos, pos, invweight, cr + 17, cr + 19, includemargin, vel);
       d.efc_D[eo + r] = eo_.D;
       d.efc_aref[eo + r] = eo_.aref;
       d.efc_pos[eo + r] = eo_.pos;
       d.efc_margin[eo + r] = includemargin;
       d.efc_vel[eo + r] = vel;
       d.efc_frictionloss[eo + r] = 0.0f;
-      d.efc_type[eo + r] = condim == 1 ? CT_CONTACT_FRICTIONLESS : CT_CONTACT_PYRAMIDAL;
+      d.efc_type[eo + r] = condim == 1 ? CT_CONTACT_FRICTIONLESS : (elliptic ? CT_CONTACT_ELLIPTIC : CT_CONTACT_PYRAMIDAL);
       d.efc_id[eo + r] = c;  // world-local; k_publish_contacts rewrites it with the public contact id
+      if (m.cone == CONE_ELLIPTIC) d.ws_efc_con[eo + r] = row2con[r];  // the solver groups the rows of a contact
     }
   }
   if (lig == 0) {

@@ -2,7 +2,8 @@
 //
 // The library is built from several translation units compiled in parallel (the solver kernels are ~70 template
 // instantiations and dominate the build time): mjhip.hip (entry points, launch sequencing, every non-solver kernel),
-// solve_cg32 / solve_newton32 / solve_cg64 / solve_newton64 .hip (k_solve_plus instantiations), pgs_tu.hip (k_solve_pgs) and
+// solve_cg32 / solve_newton32 / solve_cg64 / solve_newton64 .hip and their elliptic-cone twins solve_ell_*.hip (k_solve_plus
+// instantiations), pgs_tu.hip (k_solve_pgs) and
 // solve_big.hip (k_solve_big).
 // Device code is header-only and fully inlined per kernel, so no relocatable device code is needed.
 #pragma once
@@ -62,5 +63,10 @@ int launch_solve_32_cg(const MjhModel* m, const MjhData* d, int nr, bool with_fa
 int launch_solve_32_newton(const MjhModel* m, const MjhData* d, int nr, bool with_factor, int fuse_euler, hipStream_t s, int lo, int hi);
 int launch_solve_64_cg(const MjhModel* m, const MjhData* d, int nr, bool with_factor, int fuse_euler, hipStream_t s, int lo, int hi);
 int launch_solve_64_newton(const MjhModel* m, const MjhData* d, int nr, bool with_factor, int fuse_euler, hipStream_t s, int lo, int hi);
+// the same with elliptic friction cones (solve_ell_*.hip)
+int launch_solve_32_cg_ell(const MjhModel* m, const MjhData* d, int nr, bool with_factor, int fuse_euler, hipStream_t s, int lo, int hi);
+int launch_solve_32_newton_ell(const MjhModel* m, const MjhData* d, int nr, bool with_factor, int fuse_euler, hipStream_t s, int lo, int hi);
+int launch_solve_64_cg_ell(const MjhModel* m, const MjhData* d, int nr, bool with_factor, int fuse_euler, hipStream_t s, int lo, int hi);
+int launch_solve_64_newton_ell(const MjhModel* m, const MjhData* d, int nr, bool with_factor, int fuse_euler, hipStream_t s, int lo, int hi);
 int launch_pgs(const MjhModel* m, const MjhData* d, hipStream_t s);
 int launch_solve_big(const MjhModel* m, const MjhData* d, hipStream_t s);  // nv > 64 (solver_big.hpp)

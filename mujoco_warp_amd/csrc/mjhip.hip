@@ -222,7 +222,9 @@ static thread_local bool g_fuse_euler = false;
 // set by the fused path when the Newton riders run on the side stream (see side_stream)
 static thread_local bool g_riders_on_side = false;
 static int solve_supported(const MjhModel* m, const MjhData* d) {
-  if (m->cone != 0) return fail(MJH_E_UNSUPPORTED, "elliptic cones are not implemented yet");
+  if (m->cone != CONE_PYRAMIDAL && m->cone != CONE_ELLIPTIC) return fail(MJH_E_UNSUPPORTED, "unknown cone type");
+  if (m->cone == CONE_ELLIPTIC && (m->nv > 64 || m->solver == SOL_PGS))
+    return fail(MJH_E_UNSUPPORTED, "elliptic cones need the CG or Newton solver and at most 64 dofs");
   if (m->nv > 64 && m->solver == SOL_PGS) return fail(MJH_E_UNSUPPORTED, "PGS supports at most 64 dofs");
   if (m->solver != SOL_NEWTON && m->solver != SOL_CG && m->solver != SOL_PGS) return fail(MJH_E_UNSUPPORTED, "unknown solver");
   if (m->nv <= 64 && m->solver != SOL_PGS && d->njmax > 192)
@@ -237,8 +239,9 @@ static int launch_solve_any(const MjhModel* m, const MjhData* d, bool with_facto
   const int fe = g_fuse_euler ? 1 : 0;
   const int all = 0x7fffffff;
   // the k_solve_plus instantiations live in their own translation units (host.hpp): pick by lanes per world and solver
-  auto s32 = newton ? launch_solve_32_newton : launch_solve_32_cg;
-  auto s64 = newton ? launch_solve_64_newton : launch_solve_64_cg;
+  const bool ell = m->cone == CONE_ELLIPTIC && d->nmaxpyramid > 1;  // (condim 1 everywhere: the cone type is moot)
+  auto s32 = ell ? (newton ? launch_solve_32_newton_ell : launch_solve_32_cg_ell) : (newton ? launch_solve_32_newton : launch_solve_32_cg);
+  auto s64 = ell ? (newton ? launch_solve_64_newton_ell : launch_solve_64_cg_ell) : (newton ? launch_solve_64_newton : launch_solve_64_cg);
   // njmax > 64: two launches over the same world list (see solve_body): a small-row instantiation for the worlds with
   // at most 64 rows, the big one (riders attached) for the rest
   if (m->nv <= 32) {

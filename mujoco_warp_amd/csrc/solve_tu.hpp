@@ -6,11 +6,11 @@
 #include "smooth.hpp"
 #include "solver.hpp"
 
-template <int NV4, int NR, bool NEWTON, int SG>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((!NEWTON && SG == 32 && NR == 2) ? 3 : 1, 8))) k_solve_plus(MjhModel m, MjhData d, int nsolve, int nfac, int nefc_lo, int nefc_hi, int fuse_euler) {
+template <int NV4, int NR, bool NEWTON, int SG, bool ELL = false>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((!NEWTON && !ELL && SG == 32 && NR == 2) ? 3 : 1, 8))) k_solve_plus(MjhModel m, MjhData d, int nsolve, int nfac, int nefc_lo, int nefc_hi, int fuse_euler) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int wpb = blockDim.x / SG;
-  if ((int)blockIdx.x < nsolve) solve_body<NV4, NR, NEWTON, SG>(m, d, smem, Blk{(int)blockIdx.x * wpb, wpb, (int)blockDim.x}, nefc_lo, nefc_hi, fuse_euler);
+  if ((int)blockIdx.x < nsolve) solve_body<NV4, NR, NEWTON, SG, ELL>(m, d, smem, Blk{(int)blockIdx.x * wpb, wpb, (int)blockDim.x}, nefc_lo, nefc_hi, fuse_euler);
   // CG only: the Newton kernel holds 256 VGPRs (one wave per SIMD), which would throttle the riders too (measured
   // +120 us); for Newton they ride along with the integrator launch instead
   else if (!NEWTON) {
@@ -21,9 +21,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((!NEWT
 }
 // SG = lanes per world: 32 (two worlds per wavefront) for nv <= 32, 64 for 32 < nv <= 64.  with_factor appends the
 // L'DL-factor workgroups (fused step, CG); without it the launch is the plain `solve` stage.
-template <int NV4, int NR, bool NEWTON, int SG>
+template <int NV4, int NR, bool NEWTON, int SG, bool ELL = false>
 static int launch_solve_t(const MjhModel* m, const MjhData* d, bool with_factor, int fuse_euler, hipStream_t s, int nefc_lo, int nefc_hi) {
-  const SolveLayout lay = solve_layout<NV4, NR, SG, NEWTON>(d->njmax);
+  const SolveLayout lay = solve_layout<NV4, NR, SG, NEWTON, ELL>(d->njmax);
   const FacLayout fl = fac_layout(m->nv, m->nC);
   const size_t ms_bytes = sizeof(int) * mstruct_ints(m->nv, m->nC);  // riders only: the solver keeps no shared tables
   size_t lds;
@@ -36,33 +36,33 @@ static int launch_solve_t(const MjhModel* m, const MjhData* d, bool with_factor,
   const int wpb = threads / SG, wf = threads / 32;
   with_factor = with_factor && !NEWTON;
   if (with_factor) lds = std::max(lds, ms_bytes + sizeof(float) * fl.total * wf);
-  HIPCHK(set_lds((k_solve_plus<NV4, NR, NEWTON, SG>), lds));
+  HIPCHK(set_lds((k_solve_plus<NV4, NR, NEWTON, SG, ELL>), lds));
   const int nsolve = (d->nworld + wpb - 1) / wpb, nfac = with_factor ? (d->nworld + wf - 1) / wf : 0;
   // riders (fused step, CG): factor workgroups, then as many contact-publication workgroups
-  debug_occupancy(NEWTON ? "k_solve_plus<newton>" : "k_solve_plus<cg>", k_solve_plus<NV4, NR, NEWTON, SG>, nsolve + 2 * nfac, threads, lds);
-  hipLaunchKernelGGL((k_solve_plus<NV4, NR, NEWTON, SG>), dim3(nsolve + 2 * nfac), dim3(threads), lds, s, *m, *d, nsolve, nfac, nefc_lo, nefc_hi, fuse_euler);
+  debug_occupancy(NEWTON ? "k_solve_plus<newton>" : "k_solve_plus<cg>", k_solve_plus<NV4, NR, NEWTON, SG, ELL>, nsolve + 2 * nfac, threads, lds);
+  hipLaunchKernelGGL((k_solve_plus<NV4, NR, NEWTON, SG, ELL>), dim3(nsolve + 2 * nfac), dim3(threads), lds, s, *m, *d, nsolve, nfac, nefc_lo, nefc_hi, fuse_euler);
   return MJH_OK;
 }
-template <int NR, bool NEWTON>
+template <int NR, bool NEWTON, bool ELL = false>
 static int launch_solve_32(const MjhModel* m, const MjhData* d, bool wf, int fe, hipStream_t s, int lo, int hi) {
   switch ((m->nv + 3) / 4) {  // kernels are specialised on ceil(nv/4): no padded matrix columns
     case 0:
-    case 1: return launch_solve_t<1, NR, NEWTON, 32>(m, d, wf, fe, s, lo, hi);
-    case 2: return launch_solve_t<2, NR, NEWTON, 32>(m, d, wf, fe, s, lo, hi);
-    case 3: return launch_solve_t<3, NR, NEWTON, 32>(m, d, wf, fe, s, lo, hi);
-    case 4: return launch_solve_t<4, NR, NEWTON, 32>(m, d, wf, fe, s, lo, hi);
-    case 5: return launch_solve_t<5, NR, NEWTON, 32>(m, d, wf, fe, s, lo, hi);
-    case 6: return launch_solve_t<6, NR, NEWTON, 32>(m, d, wf, fe, s, lo, hi);
-    case 7: return launch_solve_t<7, NR, NEWTON, 32>(m, d, wf, fe, s, lo, hi);
-    default: return launch_solve_t<8, NR, NEWTON, 32>(m, d, wf, fe, s, lo, hi);
+    case 1: return launch_solve_t<1, NR, NEWTON, 32, ELL>(m, d, wf, fe, s, lo, hi);
+    case 2: return launch_solve_t<2, NR, NEWTON, 32, ELL>(m, d, wf, fe, s, lo, hi);
+    case 3: return launch_solve_t<3, NR, NEWTON, 32, ELL>(m, d, wf, fe, s, lo, hi);
+    case 4: return launch_solve_t<4, NR, NEWTON, 32, ELL>(m, d, wf, fe, s, lo, hi);
+    case 5: return launch_solve_t<5, NR, NEWTON, 32, ELL>(m, d, wf, fe, s, lo, hi);
+    case 6: return launch_solve_t<6, NR, NEWTON, 32, ELL>(m, d, wf, fe, s, lo, hi);
+    case 7: return launch_solve_t<7, NR, NEWTON, 32, ELL>(m, d, wf, fe, s, lo, hi);
+    default: return launch_solve_t<8, NR, NEWTON, 32, ELL>(m, d, wf, fe, s, lo, hi);
   }
 }
-template <int NR, bool NEWTON>
+template <int NR, bool NEWTON, bool ELL = false>
 static int launch_solve_64(const MjhModel* m, const MjhData* d, bool wf, int fe, hipStream_t s, int lo, int hi) {
   const int nv4 = (m->nv + 3) / 4;  // rounded up to an instantiated size (lanes past nv hold identity rows)
-  if (nv4 <= 9) return launch_solve_t<9, NR, NEWTON, 64>(m, d, wf, fe, s, lo, hi);
-  if (nv4 <= 10) return launch_solve_t<10, NR, NEWTON, 64>(m, d, wf, fe, s, lo, hi);
-  if (nv4 <= 12) return launch_solve_t<12, NR, NEWTON, 64>(m, d, wf, fe, s, lo, hi);
-  if (nv4 <= 14) return launch_solve_t<14, NR, NEWTON, 64>(m, d, wf, fe, s, lo, hi);
-  return launch_solve_t<16, NR, NEWTON, 64>(m, d, wf, fe, s, lo, hi);
+  if (nv4 <= 9) return launch_solve_t<9, NR, NEWTON, 64, ELL>(m, d, wf, fe, s, lo, hi);
+  if (nv4 <= 10) return launch_solve_t<10, NR, NEWTON, 64, ELL>(m, d, wf, fe, s, lo, hi);
+  if (nv4 <= 12) return launch_solve_t<12, NR, NEWTON, 64, ELL>(m, d, wf, fe, s, lo, hi);
+  if (nv4 <= 14) return launch_solve_t<14, NR, NEWTON, 64, ELL>(m, d, wf, fe, s, lo, hi);
+  return launch_solve_t<16, NR, NEWTON, 64, ELL>(m, d, wf, fe, s, lo, hi);
 }

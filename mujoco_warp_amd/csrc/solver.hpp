@@ -138,9 +138,9 @@ DEV float chol_solve_rows(const float (&h)[NVR], const float (&lt)[NVR], float r
 }
 
 struct SolveLayout {
-  int J, force, da, bsearch, bgrad, col, total;
+  int J, force, da, bsearch, bgrad, col, ex, cone, total;
 };
-template <int NV4, int NR, int G, bool NEWTON>
+template <int NV4, int NR, int G, bool NEWTON, bool ELL = false>
 __host__ __device__ inline SolveLayout solve_layout(int njmax) {
   constexpr int NVR = 4 * NV4;
   constexpr int JS = (NV4 & 1) ? NVR : NVR + 4;  // JS/4 odd: row-per-lane 16-byte reads hit distinct banks
@@ -155,6 +155,10 @@ __host__ __device__ inline SolveLayout solve_layout(int njmax) {
   p.bgrad = o; o += G;
   // Newton: Cholesky pivot column + 8-row transpose tile; CG: the double-buffered Gauss-Jordan pivot row only
   p.col = o; o += NEWTON ? (8 * JS > 2 * G ? 8 * JS : 2 * G) : 2 * (NVR > G ? NVR : G);
+  // elliptic cones: per-row exchange lines (scaled Jaref / jv, the three quadratic-cost terms, the row's friction scale) through
+  // which the rows of one contact see each other; Newton adds the cone Hessian block rows (6 words) + first row / size
+  p.ex = o; o += ELL ? 6 * G * NR : 0;
+  p.cone = o; o += (ELL && NEWTON) ? 7 * G * NR : 0;
   p.total = ((o + 3) / 4) * 4;
   return p;
 }
@@ -245,6 +249,89 @@ DEV P3 eval_row(float ja, float jv, float D, float f, int kind, float a) {
 }
 DEV bool in_bracket(P3 x, P3 y) { return (x.g < y.g && y.g < 0.0f) || (x.g > y.g && y.g > 0.0f); }
 
+// ---- elliptic friction cones (solver.py:272-421) -------------------------------------------------------------
+// One contact = `dim` consecutive rows (normal, then friction directions).  In the reference's scaled coordinates
+// N = mu * Jaref_0 and T = |(fri_j * Jaref_j)_j>=1| the contact is SATISFIED for N >= mu T (top zone), QUADRATIC for
+// mu N + T <= 0 (bottom zone, every row an independent quadratic) and in the CONE (middle) zone otherwise, where its cost is
+// dm/2 (N - mu T)^2, dm = D_0 / (mu^2 (1 + mu^2)), mu = friction_0 / sqrt(impratio).
+DEV int ell_zone(float mu, float N, float T) {
+  if (N >= mu * T || (T <= 0.0f && N >= 0.0f)) return ST_SATISFIED;
+  if (mu * N + T <= 0.0f || (T <= 0.0f && N < 0.0f)) return ST_QUADRATIC;
+  return ST_CONE;
+}
+// constants of one contact on the search ray, held by the lane that owns the contact's first row
+struct EllRay {
+  float mu, dm, q0, q1, q2, u0, v0, uu, uv, vv;  // q = sum_j (D ja^2 / 2, D jv ja, D jv^2 / 2); u = scaled Jaref, v = scaled jv
+  float cost0, T0, r0;                            // the reference point alpha = 0 (_eval_elliptic_reference solver.py:275-298)
+  int state0;
+};
+DEV void ell_ray_reference(EllRay& e) {
+  e.T0 = 0.0f;
+  e.r0 = 0.0f;
+  if (e.uu <= 0.0f) {
+    e.state0 = e.u0 < 0.0f ? ST_QUADRATIC : ST_SATISFIED;
+    e.cost0 = e.u0 < 0.0f ? e.q0 : 0.0f;
+    return;
+  }
+  e.T0 = sqrtf(e.uu);
+  if (e.u0 >= e.mu * e.T0) {
+    e.state0 = ST_SATISFIED;
+    e.cost0 = 0.0f;
+  } else if (e.mu * e.u0 + e.T0 <= 0.0f) {
+    e.state0 = ST_QUADRATIC;
+    e.cost0 = e.q0;
+  } else {
+    e.r0 = e.u0 - e.mu * e.T0;
+    e.state0 = ST_CONE;
+    e.cost0 = 0.5f * e.dm * e.r0 * e.r0;
+  }
+}
+// (cost(alpha) - cost(0), d/dalpha, d2/dalpha2) of one elliptic contact: the shifted forms of the reference
+// (_eval_elliptic_shifted solver.py:343-403), which difference against the reference point analytically -- in float32
+// the plain difference of two costs loses the line search's whole signal near convergence
+DEV P3 ell_eval(const EllRay& e, float a) {
+  const float N = e.u0 + a * e.v0;
+  const float Td = a * (2.0f * e.uv + a * e.vv), Tsqr = e.uu + Td;
+  const float aq2 = a * e.q2;
+  bool quadz = false, conez = false;
+  float T = 0.0f;
+  if (Tsqr <= 0.0f) {
+    quadz = N < 0.0f;
+  } else {
+    T = sqrtf(Tsqr);
+    if (N >= e.mu * T) {
+    } else if (e.mu * N + T <= 0.0f) quadz = true;
+    else conez = true;
+  }
+  if (quadz) {  // _eval_elliptic_quadratic_shifted solver.py:318-340
+    float cost = a * (aq2 + e.q1);
+    if (e.state0 == ST_CONE) {
+      const float b0 = e.mu * e.u0 + e.T0;
+      cost += 0.5f * e.dm * b0 * b0;
+    } else if (e.state0 == ST_SATISFIED) {
+      cost = 0.5f * e.dm * (1.0f + e.mu * e.mu) * (N * N + fmaxf(Tsqr, 0.0f));
+    }
+    return P3{cost, 2.0f * aq2 + e.q1, 2.0f * e.q2};
+  }
+  if (conez) {
+    const float Tinv = 1.0f / T;
+    const float T1 = (e.uv + a * e.vv) * Tinv, T2 = (e.vv - T1 * T1) * Tinv;
+    const float r = N - e.mu * T, r1 = e.v0 - e.mu * T1;
+    float cost;
+    if (e.state0 == ST_CONE) {  // rationalised T - T0
+      const float Tdelta = Td / (T + e.T0), rdelta = a * e.v0 - e.mu * Tdelta;
+      cost = 0.5f * e.dm * rdelta * (2.0f * e.r0 + rdelta);
+    } else if (e.state0 == ST_QUADRATIC) {
+      const float b = e.mu * N + T;
+      cost = a * (aq2 + e.q1) - 0.5f * e.dm * b * b;
+    } else {
+      cost = 0.5f * e.dm * r * r;
+    }
+    return P3{cost, e.dm * r * r1, e.dm * (r1 * r1 - e.mu * r * T2)};
+  }
+  return P3{-e.cost0, 0.0f, 0.0f};
+}
+
 // Rows of M^-1 by Gauss-Jordan with lane i owning row i of [A | B] (A = M, B = I); no pivoting (M is SPD).
 // At step k lane k publishes the entries the other rows need -- B[k][0..k] and A[k][k+1..] -- as ONE LDS line
 // (double buffered), the pivot A[k][k] travels by v_readlane; every lane then applies one rank-1 update.
@@ -286,14 +373,14 @@ DEV void invert_rows(const float (&mrow)[NVR], float (&b)[NVR], float* buf, int 
   }
 }
 
-template <int NV4, int NR, bool NEWTON, int G>
+template <int NV4, int NR, bool NEWTON, int G, bool ELL = false>
 DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk& b, int nefc_lo = -1, int nefc_hi = 0x7fffffff,
                     int fuse_euler = 0) {
   if ((int)threadIdx.x >= b.nthreads) return;
   constexpr int NVR = 4 * NV4;
   constexpr int JS = (NV4 & 1) ? NVR : NVR + 4;
   const int nv = m.nv, nC = m.nC, njmax = d.njmax, nvp = d.nv_pad;
-  const SolveLayout lay = solve_layout<NV4, NR, G, NEWTON>(njmax);
+  const SolveLayout lay = solve_layout<NV4, NR, G, NEWTON, ELL>(njmax);
   const int lig = threadIdx.x & (G - 1), gib = threadIdx.x / G;
   const int slot = b.w0 + gib;
   if (slot >= d.nworld) return;
@@ -303,6 +390,11 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
   // is read once from global (L1 hits)
   float* S = smem + (size_t)gib * lay.total;
   float *Jl = S + lay.J, *eforce = S + lay.force, *eda = S + lay.da, *bsearch = S + lay.bsearch, *bgrad = S + lay.bgrad, *col = S + lay.col;
+  constexpr int GR = G * NR;
+  // elliptic: exchange lines (see solve_layout); exs = friction scale of each row, persistent over the solve
+  float *exu = S + lay.ex, *exv = exu + GR, *exq0 = exv + GR, *exq1 = exq0 + GR, *exq2 = exq1 + GR, *exs = exq2 + GR;
+  float* econe = S + lay.cone;                              // Newton: row r of the contact's cone Hessian block, 6 words
+  int* einfo = reinterpret_cast<int*>(S + lay.cone) + 6 * GR;  // first row | rows << 8 of a contact in the cone zone, else -1
 
   // Two-size dispatch (njmax > 64): the same world list is offered to a small-row and a big-row instantiation; a world
   // is solved by the one whose range (nefc_lo, nefc_hi] holds its row count and skipped by the other.  LDS per world
@@ -429,6 +521,10 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
   // frictionloss is re-read in the rare friction-loss path, force/state are recomputed once at the end
   float rD[NR], rja[NR], rjv[NR];
   int rkind[NR];
+  // elliptic rows (kind 4: first row of a contact, 5: its other rows): friction scale of the row (mu for the first), the
+  // contact's mu and dm, first row | rows << 8
+  float rs[NR], rmu[NR], rdm[NR];
+  int rcon[NR];
 #pragma unroll
   for (int k = 0; k < NR; ++k) {
     const int r = lig + G * k;
@@ -438,6 +534,27 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
     rjv[k] = 0.0f;
     eforce[r] = 0.0f;
     if (NEWTON) eda[r] = 0.0f;  // CG has no eda region
+    if (ELL) {
+      rs[k] = rmu[k] = rdm[k] = 0.0f;
+      rcon[k] = 0;
+      if (has && r >= ne + nf + d.nl[w]) {
+        const int cid = d.ws_efc_con[eo + r], c = cid >> 4, dimid = cid & 15;
+        const float* cr = d.ws_contact + ((size_t)w * d.concap + c) * CON_STRIDE;
+        const int* cri = reinterpret_cast<const int*>(cr);
+        if (cri[24] > 1) {
+          const int r0 = r - dimid, dim = min(cri[29], nefc - r0);
+          const float impr2 = bf(m.opt_impratio_invsqrt, m.opt_impratio_invsqrt_nb, w, 1)[0];
+          const float mu = cr[14] * impr2;
+          rkind[k] = dimid == 0 ? 4 : 5;
+          rmu[k] = mu;
+          rs[k] = dimid == 0 ? mu : cr[dimid <= 2 ? 14 : (dimid == 3 ? 15 : 16)];
+          rdm[k] = safe_div(d.efc_D[eo + r0], mu * mu * (1.0f + mu * mu));
+          rcon[k] = r0 | (dim << 8);
+        }
+      }
+      exs[r] = rs[k];
+      exu[r] = 0.0f;
+    }
   }
   gsync();
   // J[r,:] . vec  (row-per-lane, conflict-free 16-byte reads)
@@ -466,6 +583,47 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
   float grad_dot = 0.0f, search_dot = 0.0f, decrement = 0.0f;
   float g = 0.0f, Mg = 0.0f, pg = 0.0f, pMg = 0.0f, srch = 0.0f, qc = 0.0f;
 
+  // force and state of one row of an elliptic contact (_eval_constraint solver.py:455-472, _eval_elliptic_middle 406-421): the
+  // rows of a contact decide together from the scaled Jaref the lanes just published in exu.  Newton also gets the row of the
+  // contact's cone Hessian block C (H += J_c^T C J_c, _update_gradient_JTCJ_dense solver.py:2466-2564):
+  //   C_ab = dm s_a s_b [ d_a0 d_b0 - (mu/T)(d_a0 u_b + u_a d_b0) + (mu N / T^3) u_a u_b + (mu^2 - N mu / T) d_ab [a >= 1] ],
+  // u_0 := 0, s = friction scales (s_0 = mu)
+  auto ell_row_force = [&](int k, float& force, int& state, bool& cone) __attribute__((always_inline)) {
+    const int r = lig + G * k, r0 = rcon[k] & 255, dim = rcon[k] >> 8, a = r - r0;
+    const float mu = rmu[k], dm = rdm[k];
+    float u[6];
+    float tt = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      u[j] = j < dim ? exu[r0 + j] : 0.0f;
+      if (j > 0) tt += u[j] * u[j];
+    }
+    const float N = u[0], T = tt <= 0.0f ? 0.0f : sqrtf(tt);
+    state = ell_zone(mu, N, T);
+    cone = state == ST_CONE;
+    if (state == ST_SATISFIED) force = 0.0f;
+    else if (state == ST_QUADRATIC) force = -rD[k] * rja[k];
+    else {
+      const float fn = -dm * (N - mu * T) * mu;
+      force = a == 0 ? fn : -safe_div(fn, T) * (exu[r] * rs[k]);
+      if (NEWTON) {
+        const float t = fmaxf(T, MJ_MINVAL), ttt = fmaxf(t * t * t, MJ_MINVAL);
+        const float mu_tinv = safe_div(mu, t), mu_n_ttt = mu * safe_div(N, ttt), tdiag = mu * mu - N * mu_tinv;
+        const float ua = a == 0 ? 0.0f : exu[r];
+#pragma unroll
+        for (int bq = 0; bq < 6; ++bq) {
+          const float ub = bq == 0 ? 0.0f : u[bq];
+          float cab = mu_n_ttt * ua * ub;
+          if (a == 0 && bq == 0) cab += 1.0f;
+          if (a == 0) cab -= mu_tinv * ub;
+          if (bq == 0) cab -= mu_tinv * ua;
+          if (a == bq && a > 0) cab += tdiag;
+          econe[6 * r + bq] = bq < dim ? dm * rs[k] * exs[r0 + (bq < dim ? bq : 0)] * cab : 0.0f;
+        }
+      }
+    }
+  };
+
   int niter = 0;
   const int maxiter = m.iterations, ls_iterations = m.ls_iterations;
   int ovf = 0;
@@ -474,6 +632,11 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
   // (large, fully unrolled) gradient code has a single call site.  Iteration 0 is init_context (solver.py:3622).
   for (;;) {
     // ---- force/state of this lane's rows (solver.py:1698-1822) ------------------------------------------------
+    if (ELL) {
+#pragma unroll
+      for (int k = 0; k < NR; ++k) exu[lig + G * k] = rja[k] * rs[k];
+      gsync();
+    }
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
       const float ja = rja[k], D = rD[k];
@@ -481,8 +644,11 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
       float force;
       int state;
       row_force(rkind[k], ja, D, has_fl, d.efc_frictionloss + eo + lig + G * k, force, state);
+      bool cone = false;
+      if (ELL && rkind[k] >= 4) ell_row_force(k, force, state, cone);
       eforce[lig + G * k] = force;
       if (NEWTON) eda[lig + G * k] = state == ST_QUADRATIC ? D : 0.0f;
+      if (ELL && NEWTON) einfo[lig + G * k] = cone ? rcon[k] : -1;
     }
     gsync();
     // ---- qfrc_constraint = J^T force (solver.py:1912-1947): lane = dof, 4 rows per step ------------------------
@@ -516,7 +682,18 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
 #pragma unroll
       for (int c = 0; c < NVR; ++c) h[c] = mrow[c];
       for (int r = 0; r < nefc4; r += 2) {  // two rows per LDS round trip (padding rows have J = 0, D = 0)
-        const float jd0 = Jl[r * JS + ligr] * eda[r], jd1 = Jl[(r + 1) * JS + ligr] * eda[r + 1];
+        float jd0 = Jl[r * JS + ligr] * eda[r], jd1 = Jl[(r + 1) * JS + ligr] * eda[r + 1];
+        if (ELL) {  // rows of a contact in the cone zone: (C J_c)[a][lane's dof] replaces D J[r][lane's dof]
+          const int i0 = einfo[r], i1 = r + 1 < nefc ? einfo[r + 1] : -1;
+          if (i0 >= 0) {
+            jd0 = 0.0f;
+            for (int bq = 0; bq < (i0 >> 8); ++bq) jd0 += econe[6 * r + bq] * Jl[((i0 & 255) + bq) * JS + ligr];
+          }
+          if (i1 >= 0) {
+            jd1 = 0.0f;
+            for (int bq = 0; bq < (i1 >> 8); ++bq) jd1 += econe[6 * (r + 1) + bq] * Jl[((i1 & 255) + bq) * JS + ligr];
+          }
+        }
 #pragma unroll
         for (int c4 = 0; c4 < NV4; ++c4) {
           const float4 a4 = *reinterpret_cast<const float4*>(Jl + r * JS + 4 * c4);
@@ -594,14 +771,61 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
       egrad0[k] = jvD * rja[k];
       ecact[k] = quad0 - cost0;
       ecin[k] = -cost0;
+      if (ELL) {  // every row of an elliptic contact publishes its terms; the contact is evaluated by its first row's lane
+        const int r = lig + G * k;
+        exu[r] = rja[k] * rs[k];
+        exv[r] = rjv[k] * rs[k];
+        exq0[r] = quad0;
+        exq1[r] = egrad0[k];
+        exq2[r] = 0.5f * ehess[k];
+        if (rkind[k] >= 4) ehess[k] = egrad0[k] = ecact[k] = ecin[k] = 0.0f;
+      }
+    }
+    EllRay ray[NR];
+    if (ELL) {
+      gsync();
+#pragma unroll
+      for (int k = 0; k < NR; ++k) {
+        EllRay& e = ray[k];
+        e.mu = rmu[k];
+        e.dm = rdm[k];
+        e.q0 = e.q1 = e.q2 = e.uu = e.uv = e.vv = 0.0f;
+        const int r0 = lig + G * k, dim = rkind[k] == 4 ? rcon[k] >> 8 : 0;
+        e.u0 = rkind[k] == 4 ? exu[r0] : 0.0f;
+        e.v0 = rkind[k] == 4 ? exv[r0] : 0.0f;
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+          if (j < dim) {
+            e.q0 += exq0[r0 + j];
+            e.q1 += exq1[r0 + j];
+            e.q2 += exq2[r0 + j];
+            if (j > 0) {
+              const float uj = exu[r0 + j], vj = exv[r0 + j];
+              e.uu += uj * uj;
+              e.uv += uj * vj;
+              e.vv += vj * vj;
+            }
+          }
+        ell_ray_reference(e);
+      }
     }
     auto eval = [&](float a) __attribute__((always_inline)) {
       P3 s = P3{0.0f, 0.0f, 0.0f};
+      if (ELL) {
+#pragma unroll
+        for (int k = 0; k < NR; ++k)
+          if (rkind[k] == 4) {
+            const P3 t = ell_eval(ray[k], a);
+            s.c += t.c;
+            s.g += t.g;
+            s.h += t.h;
+          }
+      }
       if (!has_fl) {  // equality / limit / contact rows only: branch-free
         const float ha = 0.5f * a;
 #pragma unroll
         for (int k = 0; k < NR; ++k) {
-          const bool act = rkind[k] == 0 || (rja[k] + a * rjv[k] < 0.0f);
+          const bool act = rkind[k] == 0 || (rja[k] + a * rjv[k] < 0.0f);  // (elliptic rows: all four terms are zero)
           s.c += act ? a * (egrad0[k] + ha * ehess[k]) + ecact[k] : ecin[k];
           s.g += act ? egrad0[k] + a * ehess[k] : 0.0f;
           s.h += act ? ehess[k] : 0.0f;
@@ -688,12 +912,21 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
     d.qfrc_constraint[vo + lig] = qc;
     d.efc_Ma[vo + lig] = Ma;
   }
+  if (ELL) {
+#pragma unroll
+    for (int k = 0; k < NR; ++k) exu[lig + G * k] = rja[k] * rs[k];
+    gsync();
+  }
 #pragma unroll
   for (int k = 0; k < NR; ++k)
     if (rkind[k] != 3) {  // force/state at the final iterate: the same expression the last constraint update evaluated
       float force;
       int state;
       row_force(rkind[k], rja[k], rD[k], has_fl, d.efc_frictionloss + eo + lig + G * k, force, state);
+      if (ELL && rkind[k] >= 4) {
+        bool cone;
+        ell_row_force(k, force, state, cone);
+      }
       d.efc_force[eo + lig + G * k] = force;
       d.efc_state[eo + lig + G * k] = state;
     }

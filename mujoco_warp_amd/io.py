@@ -122,8 +122,10 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
   # (the reference rejects PGS, io.py solver check / types.py:502; this engine implements MuJoCo C's dual PGS, csrc/pgs.hpp)
   if int(opt.solver) not in (types.SolverType.PGS, types.SolverType.CG, types.SolverType.NEWTON):
     raise NotImplementedError(f"Unknown solver {int(opt.solver)}.")
-  if int(opt.cone) != types.ConeType.PYRAMIDAL:
-    raise NotImplementedError("Elliptic friction cones are not implemented yet.")
+  if int(opt.cone) not in (types.ConeType.PYRAMIDAL, types.ConeType.ELLIPTIC):
+    raise NotImplementedError(f"Unknown cone {int(opt.cone)}.")
+  if int(opt.cone) == types.ConeType.ELLIPTIC and (mjm.nv > 64 or int(opt.solver) == types.SolverType.PGS):
+    raise NotImplementedError("Elliptic friction cones need the CG or Newton solver and at most 64 dofs.")
   if mjm.nv > 64 and int(opt.solver) == types.SolverType.PGS:
     raise NotImplementedError("PGS supports at most 64 dofs (CG and Newton have a generic path for larger models).")
   if mjm.nu and (np.asarray(mjm.actuator_trntype) != types.TrnType.JOINT).any():
@@ -405,7 +407,7 @@ def _data_shapes(m, nworld, nconmax, njmax, naconmax):
     contact_geomcollisionid=(naconmax,),
     efc_type=(W, njmax), efc_id=(W, njmax), efc_state=(W, njmax), efc_J=(W, njmax_pad, nv_pad), efc_pos=(W, njmax),
     efc_margin=(W, njmax), efc_D=(W, njmax), efc_vel=(W, njmax), efc_aref=(W, njmax), efc_frictionloss=(W, njmax),
-    efc_force=(W, njmax), ws_ncon=(W,), ws_conadr=(W,), ws_ncollision=(W,), ws_order=(W,),
+    efc_force=(W, njmax), ws_ncon=(W,), ws_conadr=(W,), ws_ncollision=(W,), ws_efc_con=(W, njmax), ws_order=(W,),
     eq_active=(W, m.neq), ws_rk=(W, nq + 3 * nv + 2 * na), ws_contact=(W, contact_cap(nconmax), 32),
   )
   return sh, njmax_pad, nv_pad
@@ -688,7 +690,7 @@ def override_model(model, overrides):
       setattr(obj, attr, val)
     if isinstance(model, types.Model) and attr in ("solver", "integrator", "cone"):
       put = {"solver": (types.SolverType.PGS, types.SolverType.CG, types.SolverType.NEWTON), "integrator": (types.IntegratorType.EULER, types.IntegratorType.RK4, types.IntegratorType.IMPLICITFAST),
-             "cone": (types.ConeType.PYRAMIDAL,)}[attr]
+             "cone": (types.ConeType.PYRAMIDAL, types.ConeType.ELLIPTIC)}[attr]
       if int(getattr(obj, attr)) not in put:
         raise NotImplementedError(f"unsupported {attr} {val}")
     if hasattr(model, "_mjh_model"):

@@ -485,6 +485,7 @@ class Data(_Dirty):
   ws_ncon: DeviceArray = _arr(('nworld',), "int32")
   ws_conadr: DeviceArray = _arr(('nworld',), "int32")
   ws_ncollision: DeviceArray = _arr(('nworld',), "int32")
+  ws_efc_con: DeviceArray = _arr(('nworld', 'njmax'), "int32")
   ws_order: DeviceArray = _arr(('nworld',), "int32")
   eq_active: DeviceArray = _arr(('nworld', 'neq'), "int32")
   ws_rk: DeviceArray = _arr(('nworld', 'nq+3*nv+2*na'), "float32")

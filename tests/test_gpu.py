@@ -87,14 +87,14 @@ def _check_contacts_and_rows(s, d, mjm, w=-1, dist_atol=2e-7):
       assert relerr(getattr(d.efc, name).numpy()[ww, :n], getattr(s, "efc_" + name)[:n]) <= EFC, name
 
 
-def _check_solution(s, d, w=-1):
+def _check_solution(s, d, w=-1, tol=SOLVE):
   ww = w % d.nworld
   n = min(int(d.nefc.numpy()[ww]), d.njmax)
   _check_fields(s, d, ("qacc_smooth",), FACTOR, w)
-  _check_fields(s, d, ("qacc", "qfrc_constraint"), SOLVE, w)
-  assert relerr(d.efc.Ma.numpy()[ww], s.Ma) <= SOLVE
+  _check_fields(s, d, ("qacc", "qfrc_constraint"), tol, w)
+  assert relerr(d.efc.Ma.numpy()[ww], s.Ma) <= tol
   if n:
-    assert relerr(d.efc.force.numpy()[ww, :n], s.efc_force[:n]) <= SOLVE
+    assert relerr(d.efc.force.numpy()[ww, :n], s.efc_force[:n]) <= tol
   assert int(d.overflow.numpy()[ww]) == 0
 
 
@@ -218,6 +218,67 @@ def test_small_models_forward_and_step(xml, njmax):
     s.step()
     assert relerr(d.qpos.numpy()[0], s.qpos) <= 1e-5
     assert relerr(d.qvel.numpy()[0], s.qvel) <= 2e-3
+
+
+@pytest.mark.parametrize("solver", ["Newton", "CG"])
+@pytest.mark.parametrize("xml,njmax", [(conftest.FREE_BODIES_XML, 96), (conftest.PILE_XML, 96), (conftest.SPHERE_CYLINDER_XML, 96),
+                                       (conftest.FREE_BODIES_XML, 48)])
+def test_small_models_elliptic_cones(xml, njmax, solver):
+  """cone="elliptic" impratio="10" on the contact scenes: rows (condim per contact, friction-row parameters), zones, line search
+  and cone Hessian of the register-resident solver against the oracle (reference constraint.py:2698-2704, 4277-4294;
+  solver.py:272-517, 2466-2564).  njmax 96 runs the six-rows-per-lane instantiation, 48 the two-rows one."""
+  import re
+  xml = re.sub(r"<option ([^>]*?)(solver=\"\w+\")?/>", lambda mo: f'<option {mo.group(1)} cone="elliptic" impratio="10" solver="{solver}"/>', xml, count=1)
+  mjm = mjw.mjcf.from_xml_string(xml)
+  assert mjm.opt.cone == 1 and mjm.opt.impratio == 10.0
+  s, m, d = _pair(mjm, nworld=2, nconmax=32, njmax=njmax, warm_steps=40, noise=False)
+  mjw.forward(m, d)
+  s.forward()
+  assert (s.efc_type[: s.nefc] == 7).sum() >= 6
+  _check_fields(s, d, _SMOOTH_FIELDS, SMOOTH)
+  _check_contacts_and_rows(s, d, mjm)
+  # (CG stops at the float32 tolerance 1e-6 on a different iterate than the float64 oracle: measured 2.4e-3 on the pile scene)
+  _check_solution(s, d, tol=SOLVE if solver == "Newton" else 3 * SOLVE)
+  assert (d.efc.state.numpy()[0, : s.nefc] == s.efc_state[: s.nefc]).mean() > 0.9
+  for _ in range(20):
+    _sync(s, d)
+    mjw.step(m, d)
+    s.step()
+    assert relerr(d.qpos.numpy()[0], s.qpos) <= 1e-5
+    assert relerr(d.qvel.numpy()[0], s.qvel) <= 2e-3
+  assert (d.overflow.numpy() == 0).all()
+
+
+@pytest.mark.parametrize("name,xml,solver,nconmax,njmax,nstep", [
+  ("humanoid", conftest.HUMANOID_XML, mjw.SolverType.NEWTON, 24, 64, 100), ("humanoid", conftest.HUMANOID_XML, mjw.SolverType.CG, 24, 64, 100),
+  ("g1", conftest.G1_XML, mjw.SolverType.NEWTON, 48, 128, 40)])
+def test_per_step_parity_elliptic(name, xml, solver, nconmax, njmax, nstep):
+  """The benchmark robots with cone="elliptic": one step from the same state along the oracle trajectory (humanoid: 32 lanes per
+  world, G1 with 35 dofs: 64 lanes per world)."""
+  mjm = mjw.mjcf.load_xml(xml)
+  mjm.opt.cone = int(mjw.ConeType.ELLIPTIC)
+  mjm.opt.impratio = 4.0
+  if name == "g1":
+    # its file caps the solver at 10 iterations and the line search at 20: float32 bracketing needs more line-search iterations
+    # than float64 (measured 2-4 % of world-steps flag LS_ITERATIONS at 20, pyramidal and elliptic alike, none at 50); CG does not
+    # converge on this model with elliptic cones within 50 iterations in the float64 oracle either, so only Newton is compared
+    mjm.opt.iterations, mjm.opt.ls_iterations = 50, 50
+  s, m, d = _pair(mjm, nworld=2, nconmax=nconmax, njmax=njmax, solver=int(solver), warm_steps=0)
+  worst_q = worst_v = 0.0
+  nell = 0
+  for i in range(nstep):
+    if mjm.nu:
+      s.ctrl_noise(i, 0)
+    _sync(s, d)
+    mjw.step(m, d)
+    s.step()
+    nell += int((s.efc_type[: s.nefc] == 7).sum())
+    worst_q = max(worst_q, relerr(d.qpos.numpy()[1], s.qpos))
+    worst_v = max(worst_v, relerr(d.qvel.numpy()[1], s.qvel))
+  assert nell > 3 * nstep
+  assert worst_q <= 1e-5, worst_q
+  assert worst_v <= 2e-3, worst_v
+  assert (d.overflow.numpy() == 0).all()
 
 
 @pytest.mark.parametrize("warm", [5, 15, 60])

@@ -82,7 +82,8 @@ def test_unsupported_features_raise():
   with pytest.raises(NotImplementedError):
     mjw.mjcf.from_xml_string('<mujoco><worldbody><body><joint/><geom size=".1"/></body></worldbody>'
                              '<tendon><fixed><joint joint="x" coef="1"/></fixed></tendon></mujoco>')
-  m = mjw.mjcf.from_xml_string('<mujoco><option cone="elliptic"/><worldbody><body><joint/><geom size=".1"/></body></worldbody></mujoco>')
+  # elliptic cones: CG / Newton only (the oracle's PGS restates MuJoCo C's pyramidal / frictionless projection)
+  m = mjw.mjcf.from_xml_string('<mujoco><option cone="elliptic" solver="PGS"/><worldbody><body><joint/><geom size=".1"/></body></worldbody></mujoco>')
   with pytest.raises(NotImplementedError):
     mjw.put_model(m)
   # structural elements the subset compiler does not expand are never skipped silently (they would change the model)
