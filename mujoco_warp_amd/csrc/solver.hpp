@@ -249,6 +249,132 @@ DEV P3 eval_row(float ja, float jv, float D, float f, int kind, float a) {
 }
 DEV bool in_bracket(P3 x, P3 y) { return (x.g < y.g && y.g < 0.0f) || (x.g > y.g && y.g > 0.0f); }
 
+#ifndef MJH_LS_NOISE_ULPS
+#define MJH_LS_NOISE_ULPS 4
+#endif
+// ---- the line search (solver.py:835-1347) over rows held in registers; every sum of an evaluation round is reduced together
+// HAS_FL: friction-loss rows present (three-zone cost, rare): a compile-time switch, the common instantiation is branch-free
+template <int NR, int G, bool HAS_FL>
+DEV void line_search_rows(const float (&rja)[NR], const float (&rjv)[NR], const float (&rD)[NR], const int (&rkind)[NR],
+                          const float* floss_lane, float gauss1, float gauss2, float gtol_in, int ls_iterations, float& alpha_out,
+                          float& improvement_out, bool& converged_out, int* iters_out = nullptr, float gauss1_abs = 0.0f) {
+  float ehess[NR], egrad0[NR], ecact[NR], ecin[NR];
+#pragma unroll
+  for (int k = 0; k < NR; ++k) {
+    const float jvD = rjv[k] * rD[k], quad0 = 0.5f * rD[k] * rja[k] * rja[k];
+    const float cost0 = (rkind[k] == 0 || rja[k] < 0.0f) ? quad0 : 0.0f;
+    ehess[k] = rjv[k] * jvD;
+    egrad0[k] = jvD * rja[k];
+    ecact[k] = quad0 - cost0;
+    ecin[k] = -cost0;
+  }
+  auto eval = [&](float a) __attribute__((always_inline)) {
+    P3 s = P3{0.0f, 0.0f, 0.0f};
+    if (!HAS_FL) {
+      const float ha = 0.5f * a;
+#pragma unroll
+      for (int k = 0; k < NR; ++k) {
+        const bool act = rkind[k] == 0 || (rja[k] + a * rjv[k] < 0.0f);
+        s.c += act ? a * (egrad0[k] + ha * ehess[k]) + ecact[k] : ecin[k];
+        s.g += act ? egrad0[k] + a * ehess[k] : 0.0f;
+        s.h += act ? ehess[k] : 0.0f;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < NR; ++k) {
+        const P3 t = eval_row(rja[k], rjv[k], rD[k], rkind[k] == 1 ? floss_lane[G * k] : 0.0f, rkind[k], a);
+        s.c += t.c;
+        s.g += t.g;
+        s.h += t.h;
+      }
+    }
+    return s;
+  };
+  // group sums + the Gauss (smooth) quadratic; the sums of up to three ray points are reduced together (gsumg_n)
+  auto finish = [&](float c, float g, float h, float a) __attribute__((always_inline)) {
+    return P3{a * a * gauss2 + a * gauss1 + c, 2.0f * a * gauss2 + gauss1 + g, 2.0f * gauss2 + h};
+  };
+  const P3 e = eval(0.0f);
+#if MJH_LS_NOISE_ULPS > 0
+  // float32: the ray derivative is a sum of ~nefc + nv terms that mostly cancel at the minimum, so it carries rounding noise of
+  // about eps * sum |term|.  A derivative inside that noise is zero as far as float32 can tell: bracketing on (the reference's
+  // tolerance floor of 1e-6 is an absolute number chosen for float64) only chases noise -- measured 2.5 bracketing iterations
+  // per call against 0.75 for the float64 oracle, with no effect on the iterates.
+  float eabs = 0.0f;
+#pragma unroll
+  for (int k = 0; k < NR; ++k) eabs += fabsf(egrad0[k]);
+  float r2[3] = {e.g, e.h, eabs};
+  gsumg_n<G, 3>(r2);
+  const float gtol = fmaxf(gtol_in, (MJH_LS_NOISE_ULPS * 5.96e-8f) * (gauss1_abs + r2[2]));
+#else
+  float r2[2] = {e.g, e.h};
+  gsumg_n<G, 2>(r2);
+  const float gtol = gtol_in;
+#endif
+  const P3 p0 = P3{0.0f, gauss1 + r2[0], 2.0f * gauss2 + r2[1]};
+  const float lo_alpha_in = -fast_div(p0.g, p0.h);
+  const P3 el = eval(lo_alpha_in);
+  float r3[3] = {el.c, el.g, el.h};
+  gsumg_n<G, 3>(r3);
+  const P3 lo_in = finish(r3[0], r3[1], r3[2], lo_alpha_in);
+  float alpha = 0.0f, improvement = 0.0f;
+  bool ls_converged = fabsf(lo_in.g) < gtol && lo_in.c < 0.0f;
+  if (ls_converged) {
+    alpha = lo_alpha_in;
+    improvement = -lo_in.c;
+  } else {
+    const bool lo_less = lo_in.g < p0.g;
+    P3 lo = lo_less ? lo_in : p0, hi = lo_less ? p0 : lo_in;
+    float lo_alpha = lo_less ? lo_alpha_in : 0.0f, hi_alpha = lo_less ? 0.0f : lo_alpha_in;
+    for (int it = 0; it < ls_iterations; ++it) {
+      if (iters_out) ++*iters_out;
+      const float a_lo = lo_alpha - fast_div(lo.g, lo.h), a_hi = hi_alpha - fast_div(hi.g, hi.h);
+      const float a_mid = 0.5f * (lo_alpha + hi_alpha);
+      const P3 e1 = eval(a_lo), e2 = eval(a_hi), e3 = eval(a_mid);
+      float r9[9] = {e1.c, e1.g, e1.h, e2.c, e2.g, e2.h, e3.c, e3.g, e3.h};
+      gsumg_n<G, 9>(r9);
+      const P3 lo_next = finish(r9[0], r9[1], r9[2], a_lo), hi_next = finish(r9[3], r9[4], r9[5], a_hi), mid = finish(r9[6], r9[7], r9[8], a_mid);
+      // Bracket update (solver.py:1222-1290).  The reference takes a candidate when its derivative lies strictly between the
+      // bracket end's derivative and zero, for three candidates in turn -- each test on the end the previous one may have
+      // replaced.  The end therefore finishes on the candidate whose derivative is closest to zero among those strictly
+      // between the ORIGINAL end and zero (the earliest on ties), which needs no chain: three keys, one minimum, one select.
+      auto pick = [](P3& end, float& end_a, const P3& y1, float a1, const P3& y2, float a2, const P3& y3, float a3) __attribute__((always_inline)) {
+        const float g0 = end.g, m0 = fabsf(g0);
+        auto key = [&](float g) __attribute__((always_inline)) {
+          const float mg = fabsf(g);
+          const bool same = (__float_as_int(g) ^ __float_as_int(g0)) >= 0;  // equal sign bits
+          return (same && mg > 0.0f && mg < m0) ? mg : 3.0e38f;
+        };
+        const float k1 = key(y1.g), k2 = key(y2.g), k3 = key(y3.g);
+        const float kb = fminf(k1, fminf(k2, k3));
+        const bool any = kb < 3.0e38f;
+        const bool u1 = k1 == kb, u2 = k2 == kb;
+        const float sc = u1 ? y1.c : (u2 ? y2.c : y3.c), sg = u1 ? y1.g : (u2 ? y2.g : y3.g), sh = u1 ? y1.h : (u2 ? y2.h : y3.h);
+        const float sa = u1 ? a1 : (u2 ? a2 : a3);
+        end.c = any ? sc : end.c;
+        end.g = any ? sg : end.g;
+        end.h = any ? sh : end.h;
+        end_a = any ? sa : end_a;
+        return any;
+      };
+      const bool swap_lo = pick(lo, lo_alpha, lo_next, a_lo, mid, a_mid, hi_next, a_hi);
+      const bool swap_hi = pick(hi, hi_alpha, hi_next, a_hi, mid, a_mid, lo_next, a_lo);
+      const bool ls_done = (!swap_lo && !swap_hi) || (lo.c < 0.0f && lo.g < 0.0f && lo.g > -gtol) || (hi.c < 0.0f && hi.g > 0.0f && hi.g < gtol);
+      const bool improved = lo.c < 0.0f || hi.c < 0.0f;
+      const bool lo_better = lo.c < hi.c;
+      alpha = improved ? (lo_better ? lo_alpha : hi_alpha) : alpha;
+      improvement = improved ? -(lo_better ? lo.c : hi.c) : improvement;
+      if (ls_done) {
+        ls_converged = true;
+        break;
+      }
+    }
+  }
+  alpha_out = alpha;
+  improvement_out = improvement;
+  converged_out = ls_converged;
+}
+
 // ---- elliptic friction cones (solver.py:272-421) -------------------------------------------------------------
 // One contact = `dim` consecutive rows (normal, then friction directions).  In the reference's scaled coordinates
 // N = mu * Jaref_0 and T = |(fri_j * Jaref_j)_j>=1| the contact is SATISFIED for N >= mu T (top zone), QUADRATIC for
@@ -731,8 +857,9 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
         done = (imp < tolerance) || (gradient < tolerance) || (0.5f * decrement * rscale < tolerance);
       } else {
         // Polak-Ribiere (solver.py:3283-3450)
-        const float num = gsumg<G>(g * (Mg - pMg));
-        const float den = gsumg<G>(pg * pMg);
+        float pr[2] = {g * (Mg - pMg), pg * pMg};
+        gsumg_n<G, 2>(pr);
+        const float num = pr[0], den = pr[1];
         const float beta = fmaxf(0.0f, num * __builtin_amdgcn_rcpf(fmaxf(MJ_MINVAL, den)));
         done = (imp < tolerance) || (gradient < tolerance);
         if (!done) {
@@ -757,140 +884,148 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
     for (int k = 0; k < NR; ++k) rjv[k] = rkind[k] != 3 ? j_dot(bsearch, lig + G * k) : 0.0f;
     pc.mark(5);
     // ---- line search (solver.py:835-1347); rows and all sums stay in registers ----------------------------------
-    const float gauss1 = gsumg<G>(srch * (Ma - fs));
-    const float gauss2 = gsumg<G>(0.5f * srch * mvi);
+    float gs[3] = {srch * (Ma - fs), 0.5f * srch * mvi, fabsf(srch * (Ma - fs))};
+    gsumg_n<G, 3>(gs);
+    const float gauss1 = gs[0], gauss2 = gs[1];
     const float gtol = fmaxf(tolerance * ls_tolerance * sqrtf(search_dot) * scale, 1e-6f);
-    // per-row constants of the ray (solver.py:518-556): cost(a) - cost(0) = a (grad0 + a hess / 2) + cact when the
-    // row is active at a, cin otherwise; equality rows are always active, padding rows have D = jv = 0
-    float ehess[NR], egrad0[NR], ecact[NR], ecin[NR];
-#pragma unroll
-    for (int k = 0; k < NR; ++k) {
-      const float jvD = rjv[k] * rD[k], quad0 = 0.5f * rD[k] * rja[k] * rja[k];
-      const float cost0 = (rkind[k] == 0 || rja[k] < 0.0f) ? quad0 : 0.0f;
-      ehess[k] = rjv[k] * jvD;
-      egrad0[k] = jvD * rja[k];
-      ecact[k] = quad0 - cost0;
-      ecin[k] = -cost0;
-      if (ELL) {  // every row of an elliptic contact publishes its terms; the contact is evaluated by its first row's lane
-        const int r = lig + G * k;
-        exu[r] = rja[k] * rs[k];
-        exv[r] = rjv[k] * rs[k];
-        exq0[r] = quad0;
-        exq1[r] = egrad0[k];
-        exq2[r] = 0.5f * ehess[k];
-        if (rkind[k] >= 4) ehess[k] = egrad0[k] = ecact[k] = ecin[k] = 0.0f;
-      }
-    }
-    EllRay ray[NR];
-    if (ELL) {
-      gsync();
+    float alpha = 0.0f;
+    improvement = 0.0f;
+    bool ls_converged = false;
+    if (!ELL) {
+      const float* floss_lane = d.efc_frictionloss + eo + lig;
+      if (has_fl) line_search_rows<NR, G, true>(rja, rjv, rD, rkind, floss_lane, gauss1, gauss2, gtol, ls_iterations, alpha, improvement, ls_converged, nullptr, gs[2]);
+      else line_search_rows<NR, G, false>(rja, rjv, rD, rkind, floss_lane, gauss1, gauss2, gtol, ls_iterations, alpha, improvement, ls_converged, nullptr, gs[2]);
+    } else {
+      // per-row constants of the ray (solver.py:518-556): cost(a) - cost(0) = a (grad0 + a hess / 2) + cact when the
+      // row is active at a, cin otherwise; equality rows are always active, padding rows have D = jv = 0
+      float ehess[NR], egrad0[NR], ecact[NR], ecin[NR];
 #pragma unroll
       for (int k = 0; k < NR; ++k) {
-        EllRay& e = ray[k];
-        e.mu = rmu[k];
-        e.dm = rdm[k];
-        e.q0 = e.q1 = e.q2 = e.uu = e.uv = e.vv = 0.0f;
-        const int r0 = lig + G * k, dim = rkind[k] == 4 ? rcon[k] >> 8 : 0;
-        e.u0 = rkind[k] == 4 ? exu[r0] : 0.0f;
-        e.v0 = rkind[k] == 4 ? exv[r0] : 0.0f;
-#pragma unroll
-        for (int j = 0; j < 6; ++j)
-          if (j < dim) {
-            e.q0 += exq0[r0 + j];
-            e.q1 += exq1[r0 + j];
-            e.q2 += exq2[r0 + j];
-            if (j > 0) {
-              const float uj = exu[r0 + j], vj = exv[r0 + j];
-              e.uu += uj * uj;
-              e.uv += uj * vj;
-              e.vv += vj * vj;
-            }
-          }
-        ell_ray_reference(e);
+        const float jvD = rjv[k] * rD[k], quad0 = 0.5f * rD[k] * rja[k] * rja[k];
+        const float cost0 = (rkind[k] == 0 || rja[k] < 0.0f) ? quad0 : 0.0f;
+        ehess[k] = rjv[k] * jvD;
+        egrad0[k] = jvD * rja[k];
+        ecact[k] = quad0 - cost0;
+        ecin[k] = -cost0;
+        if (ELL) {  // every row of an elliptic contact publishes its terms; the contact is evaluated by its first row's lane
+          const int r = lig + G * k;
+          exu[r] = rja[k] * rs[k];
+          exv[r] = rjv[k] * rs[k];
+          exq0[r] = quad0;
+          exq1[r] = egrad0[k];
+          exq2[r] = 0.5f * ehess[k];
+          if (rkind[k] >= 4) ehess[k] = egrad0[k] = ecact[k] = ecin[k] = 0.0f;
+        }
       }
-    }
-    auto eval = [&](float a) __attribute__((always_inline)) {
-      P3 s = P3{0.0f, 0.0f, 0.0f};
+      EllRay ray[NR];
       if (ELL) {
+        gsync();
 #pragma unroll
-        for (int k = 0; k < NR; ++k)
-          if (rkind[k] == 4) {
-            const P3 t = ell_eval(ray[k], a);
+        for (int k = 0; k < NR; ++k) {
+          EllRay& e = ray[k];
+          e.mu = rmu[k];
+          e.dm = rdm[k];
+          e.q0 = e.q1 = e.q2 = e.uu = e.uv = e.vv = 0.0f;
+          const int r0 = lig + G * k, dim = rkind[k] == 4 ? rcon[k] >> 8 : 0;
+          e.u0 = rkind[k] == 4 ? exu[r0] : 0.0f;
+          e.v0 = rkind[k] == 4 ? exv[r0] : 0.0f;
+#pragma unroll
+          for (int j = 0; j < 6; ++j)
+            if (j < dim) {
+              e.q0 += exq0[r0 + j];
+              e.q1 += exq1[r0 + j];
+              e.q2 += exq2[r0 + j];
+              if (j > 0) {
+                const float uj = exu[r0 + j], vj = exv[r0 + j];
+                e.uu += uj * uj;
+                e.uv += uj * vj;
+                e.vv += vj * vj;
+              }
+            }
+          ell_ray_reference(e);
+        }
+      }
+      auto eval = [&](float a) __attribute__((always_inline)) {
+        P3 s = P3{0.0f, 0.0f, 0.0f};
+        if (ELL) {
+#pragma unroll
+          for (int k = 0; k < NR; ++k)
+            if (rkind[k] == 4) {
+              const P3 t = ell_eval(ray[k], a);
+              s.c += t.c;
+              s.g += t.g;
+              s.h += t.h;
+            }
+        }
+        if (!has_fl) {  // equality / limit / contact rows only: branch-free
+          const float ha = 0.5f * a;
+#pragma unroll
+          for (int k = 0; k < NR; ++k) {
+            const bool act = rkind[k] == 0 || (rja[k] + a * rjv[k] < 0.0f);  // (elliptic rows: all four terms are zero)
+            s.c += act ? a * (egrad0[k] + ha * ehess[k]) + ecact[k] : ecin[k];
+            s.g += act ? egrad0[k] + a * ehess[k] : 0.0f;
+            s.h += act ? ehess[k] : 0.0f;
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < NR; ++k) {
+            const P3 t = eval_row(rja[k], rjv[k], rD[k], rkind[k] == 1 ? d.efc_frictionloss[eo + lig + G * k] : 0.0f, rkind[k], a);
             s.c += t.c;
             s.g += t.g;
             s.h += t.h;
           }
-      }
-      if (!has_fl) {  // equality / limit / contact rows only: branch-free
-        const float ha = 0.5f * a;
-#pragma unroll
-        for (int k = 0; k < NR; ++k) {
-          const bool act = rkind[k] == 0 || (rja[k] + a * rjv[k] < 0.0f);  // (elliptic rows: all four terms are zero)
-          s.c += act ? a * (egrad0[k] + ha * ehess[k]) + ecact[k] : ecin[k];
-          s.g += act ? egrad0[k] + a * ehess[k] : 0.0f;
-          s.h += act ? ehess[k] : 0.0f;
         }
+        return s;
+      };
+      // group sums + the Gauss (smooth) quadratic
+      auto total = [&](P3 s, float a) __attribute__((always_inline)) {
+        return P3{a * a * gauss2 + a * gauss1 + gsumg<G>(s.c), 2.0f * a * gauss2 + gauss1 + gsumg<G>(s.g), 2.0f * gauss2 + gsumg<G>(s.h)};
+      };
+      const P3 e = eval(0.0f);
+      const P3 p0 = P3{0.0f, gauss1 + gsumg<G>(e.g), 2.0f * gauss2 + gsumg<G>(e.h)};
+      const float lo_alpha_in = -fast_div(p0.g, p0.h);
+      const P3 lo_in = total(eval(lo_alpha_in), lo_alpha_in);
+      ls_converged = fabsf(lo_in.g) < gtol && lo_in.c < 0.0f;
+      if (ls_converged) {
+        alpha = lo_alpha_in;
+        improvement = -lo_in.c;
       } else {
-#pragma unroll
-        for (int k = 0; k < NR; ++k) {
-          const P3 t = eval_row(rja[k], rjv[k], rD[k], rkind[k] == 1 ? d.efc_frictionloss[eo + lig + G * k] : 0.0f, rkind[k], a);
-          s.c += t.c;
-          s.g += t.g;
-          s.h += t.h;
-        }
-      }
-      return s;
-    };
-    // group sums + the Gauss (smooth) quadratic
-    auto total = [&](P3 s, float a) __attribute__((always_inline)) {
-      return P3{a * a * gauss2 + a * gauss1 + gsumg<G>(s.c), 2.0f * a * gauss2 + gauss1 + gsumg<G>(s.g), 2.0f * gauss2 + gsumg<G>(s.h)};
-    };
-    const P3 e = eval(0.0f);
-    const P3 p0 = P3{0.0f, gauss1 + gsumg<G>(e.g), 2.0f * gauss2 + gsumg<G>(e.h)};
-    const float lo_alpha_in = -fast_div(p0.g, p0.h);
-    const P3 lo_in = total(eval(lo_alpha_in), lo_alpha_in);
-    float alpha = 0.0f;
-    improvement = 0.0f;
-    bool ls_converged = fabsf(lo_in.g) < gtol && lo_in.c < 0.0f;
-    if (ls_converged) {
-      alpha = lo_alpha_in;
-      improvement = -lo_in.c;
-    } else {
-      const bool lo_less = lo_in.g < p0.g;
-      P3 lo = lo_less ? lo_in : p0, hi = lo_less ? p0 : lo_in;
-      float lo_alpha = lo_less ? lo_alpha_in : 0.0f, hi_alpha = lo_less ? 0.0f : lo_alpha_in;
-      for (int it = 0; it < ls_iterations; ++it) {
-        const float a_lo = lo_alpha - fast_div(lo.g, lo.h), a_hi = hi_alpha - fast_div(hi.g, hi.h);
-        const float a_mid = 0.5f * (lo_alpha + hi_alpha);
-        const P3 lo_next = total(eval(a_lo), a_lo), hi_next = total(eval(a_hi), a_hi), mid = total(eval(a_mid), a_mid);
-        // conditional moves, not branches: the six updates are wave-divergent between the two worlds of a wavefront
-        auto take = [](bool c, P3& dst, float& da, const P3& src, float sa) __attribute__((always_inline)) {
-          dst.c = c ? src.c : dst.c;
-          dst.g = c ? src.g : dst.g;
-          dst.h = c ? src.h : dst.h;
-          da = c ? sa : da;
-        };
-        const bool s1 = in_bracket(lo, lo_next);
-        take(s1, lo, lo_alpha, lo_next, a_lo);
-        const bool s2 = in_bracket(lo, mid);
-        take(s2, lo, lo_alpha, mid, a_mid);
-        const bool s3 = in_bracket(lo, hi_next);
-        take(s3, lo, lo_alpha, hi_next, a_hi);
-        const bool h1 = in_bracket(hi, hi_next);
-        take(h1, hi, hi_alpha, hi_next, a_hi);
-        const bool h2 = in_bracket(hi, mid);
-        take(h2, hi, hi_alpha, mid, a_mid);
-        const bool h3 = in_bracket(hi, lo_next);
-        take(h3, hi, hi_alpha, lo_next, a_lo);
-        const bool swap_lo = s1 || s2 || s3, swap_hi = h1 || h2 || h3;
-        const bool ls_done = (!swap_lo && !swap_hi) || (lo.c < 0.0f && lo.g < 0.0f && lo.g > -gtol) || (hi.c < 0.0f && hi.g > 0.0f && hi.g < gtol);
-        const bool improved = lo.c < 0.0f || hi.c < 0.0f;
-        const bool lo_better = lo.c < hi.c;
-        alpha = improved ? (lo_better ? lo_alpha : hi_alpha) : alpha;
-        improvement = improved ? -(lo_better ? lo.c : hi.c) : improvement;
-        if (ls_done) {
-          ls_converged = true;
-          break;
+        const bool lo_less = lo_in.g < p0.g;
+        P3 lo = lo_less ? lo_in : p0, hi = lo_less ? p0 : lo_in;
+        float lo_alpha = lo_less ? lo_alpha_in : 0.0f, hi_alpha = lo_less ? 0.0f : lo_alpha_in;
+        for (int it = 0; it < ls_iterations; ++it) {
+          const float a_lo = lo_alpha - fast_div(lo.g, lo.h), a_hi = hi_alpha - fast_div(hi.g, hi.h);
+          const float a_mid = 0.5f * (lo_alpha + hi_alpha);
+          const P3 lo_next = total(eval(a_lo), a_lo), hi_next = total(eval(a_hi), a_hi), mid = total(eval(a_mid), a_mid);
+          // conditional moves, not branches: the six updates are wave-divergent between the two worlds of a wavefront
+          auto take = [](bool c, P3& dst, float& da, const P3& src, float sa) __attribute__((always_inline)) {
+            dst.c = c ? src.c : dst.c;
+            dst.g = c ? src.g : dst.g;
+            dst.h = c ? src.h : dst.h;
+            da = c ? sa : da;
+          };
+          const bool s1 = in_bracket(lo, lo_next);
+          take(s1, lo, lo_alpha, lo_next, a_lo);
+          const bool s2 = in_bracket(lo, mid);
+          take(s2, lo, lo_alpha, mid, a_mid);
+          const bool s3 = in_bracket(lo, hi_next);
+          take(s3, lo, lo_alpha, hi_next, a_hi);
+          const bool h1 = in_bracket(hi, hi_next);
+          take(h1, hi, hi_alpha, hi_next, a_hi);
+          const bool h2 = in_bracket(hi, mid);
+          take(h2, hi, hi_alpha, mid, a_mid);
+          const bool h3 = in_bracket(hi, lo_next);
+          take(h3, hi, hi_alpha, lo_next, a_lo);
+          const bool swap_lo = s1 || s2 || s3, swap_hi = h1 || h2 || h3;
+          const bool ls_done = (!swap_lo && !swap_hi) || (lo.c < 0.0f && lo.g < 0.0f && lo.g > -gtol) || (hi.c < 0.0f && hi.g > 0.0f && hi.g < gtol);
+          const bool improved = lo.c < 0.0f || hi.c < 0.0f;
+          const bool lo_better = lo.c < hi.c;
+          alpha = improved ? (lo_better ? lo_alpha : hi_alpha) : alpha;
+          improvement = improved ? -(lo_better ? lo.c : hi.c) : improvement;
+          if (ls_done) {
+            ls_converged = true;
+            break;
+          }
         }
       }
     }

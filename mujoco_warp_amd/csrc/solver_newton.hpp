@@ -164,115 +164,6 @@ DEV float chol_factor_solve(float (&h)[4 * NV4], float g, float* panel, float* v
 }
 
 // exact line search on the convex cost of ONE world (solver.py:835-1347), rows and sums in registers; the same arithmetic as
-// the line search inside solve_body (solver.hpp), as a function
-// HAS_FL: friction-loss rows present (three-zone cost, rare): a compile-time switch, the common instantiation is branch-free
-template <int NR, int G, bool HAS_FL>
-DEV void line_search_rows(const float (&rja)[NR], const float (&rjv)[NR], const float (&rD)[NR], const int (&rkind)[NR],
-                          const float* floss_lane, float gauss1, float gauss2, float gtol, int ls_iterations, float& alpha_out,
-                          float& improvement_out, bool& converged_out, int* iters_out = nullptr) {
-  float ehess[NR], egrad0[NR], ecact[NR], ecin[NR];
-#pragma unroll
-  for (int k = 0; k < NR; ++k) {
-    const float jvD = rjv[k] * rD[k], quad0 = 0.5f * rD[k] * rja[k] * rja[k];
-    const float cost0 = (rkind[k] == 0 || rja[k] < 0.0f) ? quad0 : 0.0f;
-    ehess[k] = rjv[k] * jvD;
-    egrad0[k] = jvD * rja[k];
-    ecact[k] = quad0 - cost0;
-    ecin[k] = -cost0;
-  }
-  auto eval = [&](float a) __attribute__((always_inline)) {
-    P3 s = P3{0.0f, 0.0f, 0.0f};
-    if (!HAS_FL) {
-      const float ha = 0.5f * a;
-#pragma unroll
-      for (int k = 0; k < NR; ++k) {
-        const bool act = rkind[k] == 0 || (rja[k] + a * rjv[k] < 0.0f);
-        s.c += act ? a * (egrad0[k] + ha * ehess[k]) + ecact[k] : ecin[k];
-        s.g += act ? egrad0[k] + a * ehess[k] : 0.0f;
-        s.h += act ? ehess[k] : 0.0f;
-      }
-    } else {
-#pragma unroll
-      for (int k = 0; k < NR; ++k) {
-        const P3 t = eval_row(rja[k], rjv[k], rD[k], rkind[k] == 1 ? floss_lane[G * k] : 0.0f, rkind[k], a);
-        s.c += t.c;
-        s.g += t.g;
-        s.h += t.h;
-      }
-    }
-    return s;
-  };
-  // group sums + the Gauss (smooth) quadratic; the sums of up to three ray points are reduced together (gsumg_n)
-  auto finish = [&](float c, float g, float h, float a) __attribute__((always_inline)) {
-    return P3{a * a * gauss2 + a * gauss1 + c, 2.0f * a * gauss2 + gauss1 + g, 2.0f * gauss2 + h};
-  };
-  const P3 e = eval(0.0f);
-  float r2[2] = {e.g, e.h};
-  gsumg_n<G, 2>(r2);
-  const P3 p0 = P3{0.0f, gauss1 + r2[0], 2.0f * gauss2 + r2[1]};
-  const float lo_alpha_in = -fast_div(p0.g, p0.h);
-  const P3 el = eval(lo_alpha_in);
-  float r3[3] = {el.c, el.g, el.h};
-  gsumg_n<G, 3>(r3);
-  const P3 lo_in = finish(r3[0], r3[1], r3[2], lo_alpha_in);
-  float alpha = 0.0f, improvement = 0.0f;
-  bool ls_converged = fabsf(lo_in.g) < gtol && lo_in.c < 0.0f;
-  if (ls_converged) {
-    alpha = lo_alpha_in;
-    improvement = -lo_in.c;
-  } else {
-    const bool lo_less = lo_in.g < p0.g;
-    P3 lo = lo_less ? lo_in : p0, hi = lo_less ? p0 : lo_in;
-    float lo_alpha = lo_less ? lo_alpha_in : 0.0f, hi_alpha = lo_less ? 0.0f : lo_alpha_in;
-    for (int it = 0; it < ls_iterations; ++it) {
-      if (iters_out) ++*iters_out;
-      const float a_lo = lo_alpha - fast_div(lo.g, lo.h), a_hi = hi_alpha - fast_div(hi.g, hi.h);
-      const float a_mid = 0.5f * (lo_alpha + hi_alpha);
-      const P3 e1 = eval(a_lo), e2 = eval(a_hi), e3 = eval(a_mid);
-      float r9[9] = {e1.c, e1.g, e1.h, e2.c, e2.g, e2.h, e3.c, e3.g, e3.h};
-      gsumg_n<G, 9>(r9);
-      const P3 lo_next = finish(r9[0], r9[1], r9[2], a_lo), hi_next = finish(r9[3], r9[4], r9[5], a_hi), mid = finish(r9[6], r9[7], r9[8], a_mid);
-      // Bracket update (solver.py:1222-1290).  The reference takes a candidate when its derivative lies strictly between the
-      // bracket end's derivative and zero, for three candidates in turn -- each test on the end the previous one may have
-      // replaced.  The end therefore finishes on the candidate whose derivative is closest to zero among those strictly
-      // between the ORIGINAL end and zero (the earliest on ties), which needs no chain: three keys, one minimum, one select.
-      auto pick = [](P3& end, float& end_a, const P3& y1, float a1, const P3& y2, float a2, const P3& y3, float a3) __attribute__((always_inline)) {
-        const float g0 = end.g, m0 = fabsf(g0);
-        auto key = [&](float g) __attribute__((always_inline)) {
-          const float mg = fabsf(g);
-          const bool same = (__float_as_int(g) ^ __float_as_int(g0)) >= 0;  // equal sign bits
-          return (same && mg > 0.0f && mg < m0) ? mg : 3.0e38f;
-        };
-        const float k1 = key(y1.g), k2 = key(y2.g), k3 = key(y3.g);
-        const float kb = fminf(k1, fminf(k2, k3));
-        const bool any = kb < 3.0e38f;
-        const bool u1 = k1 == kb, u2 = k2 == kb;
-        const float sc = u1 ? y1.c : (u2 ? y2.c : y3.c), sg = u1 ? y1.g : (u2 ? y2.g : y3.g), sh = u1 ? y1.h : (u2 ? y2.h : y3.h);
-        const float sa = u1 ? a1 : (u2 ? a2 : a3);
-        end.c = any ? sc : end.c;
-        end.g = any ? sg : end.g;
-        end.h = any ? sh : end.h;
-        end_a = any ? sa : end_a;
-        return any;
-      };
-      const bool swap_lo = pick(lo, lo_alpha, lo_next, a_lo, mid, a_mid, hi_next, a_hi);
-      const bool swap_hi = pick(hi, hi_alpha, hi_next, a_hi, mid, a_mid, lo_next, a_lo);
-      const bool ls_done = (!swap_lo && !swap_hi) || (lo.c < 0.0f && lo.g < 0.0f && lo.g > -gtol) || (hi.c < 0.0f && hi.g > 0.0f && hi.g < gtol);
-      const bool improved = lo.c < 0.0f || hi.c < 0.0f;
-      const bool lo_better = lo.c < hi.c;
-      alpha = improved ? (lo_better ? lo_alpha : hi_alpha) : alpha;
-      improvement = improved ? -(lo_better ? lo.c : hi.c) : improvement;
-      if (ls_done) {
-        ls_converged = true;
-        break;
-      }
-    }
-  }
-  alpha_out = alpha;
-  improvement_out = improvement;
-  converged_out = ls_converged;
-}
-
 DEV bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 
 // Global accesses with a uniform base and a 32-bit per-lane BYTE offset: one VGPR per address (saddr + voffset form) instead
@@ -540,8 +431,8 @@ DEV void newton_pair(const MjhModel& m, const MjhData& d, float* S, const Newton
     for (int k = 0; k < NR; ++k) rjv[k] = rkind[k] != 3 ? j_dot(bvec, lig + G * k) : 0.0f;
     pc.mark(5);
     // ---- line search ---------------------------------------------------------------------------------------------------
-    float gs2[2] = {srch * (Ma - fs), 0.5f * srch * mvi};
-    gsumg_n<G, 2>(gs2);
+    float gs2[3] = {srch * (Ma - fs), 0.5f * srch * mvi, fabsf(srch * (Ma - fs))};
+    gsumg_n<G, 3>(gs2);
     const float gauss1 = gs2[0], gauss2 = gs2[1];
     const float gtol = fmaxf(tolerance * ls_tolerance * sqrtf(search_dot) * scale, 1e-6f);
     float alpha, imp_new;
@@ -549,15 +440,15 @@ DEV void newton_pair(const MjhModel& m, const MjhData& d, float* S, const Newton
     // (a finished world rides along on frozen state: no bracketing iterations for it)
 #ifdef MJH_PHASE_CLOCK
     int ls_its = 0;
-    if (wave_any(has_fl)) line_search_rows<NR, G, true>(rja, rjv, rD, rkind, floss_lane, gauss1, gauss2, gtol, fin ? 0 : ls_iterations, alpha, imp_new, ls_ok, &ls_its);
-    else line_search_rows<NR, G, false>(rja, rjv, rD, rkind, floss_lane, gauss1, gauss2, gtol, fin ? 0 : ls_iterations, alpha, imp_new, ls_ok, &ls_its);
+    if (wave_any(has_fl)) line_search_rows<NR, G, true>(rja, rjv, rD, rkind, floss_lane, gauss1, gauss2, gtol, fin ? 0 : ls_iterations, alpha, imp_new, ls_ok, &ls_its, gs2[2]);
+    else line_search_rows<NR, G, false>(rja, rjv, rD, rkind, floss_lane, gauss1, gauss2, gtol, fin ? 0 : ls_iterations, alpha, imp_new, ls_ok, &ls_its, gs2[2]);
     if (lig == 0 && !fin) {  // profiling build: bracketing iterations and calls of the line search (phase slots 14, 15 of kernel 5)
       atomicAdd(&g_phase_ticks[blockIdx.x & 63][5][14], (unsigned long long)ls_its);
       atomicAdd(&g_phase_ticks[blockIdx.x & 63][5][15], 1ull);
     }
 #else
-    if (wave_any(has_fl)) line_search_rows<NR, G, true>(rja, rjv, rD, rkind, floss_lane, gauss1, gauss2, gtol, fin ? 0 : ls_iterations, alpha, imp_new, ls_ok);
-    else line_search_rows<NR, G, false>(rja, rjv, rD, rkind, floss_lane, gauss1, gauss2, gtol, fin ? 0 : ls_iterations, alpha, imp_new, ls_ok);
+    if (wave_any(has_fl)) line_search_rows<NR, G, true>(rja, rjv, rD, rkind, floss_lane, gauss1, gauss2, gtol, fin ? 0 : ls_iterations, alpha, imp_new, ls_ok, nullptr, gs2[2]);
+    else line_search_rows<NR, G, false>(rja, rjv, rD, rkind, floss_lane, gauss1, gauss2, gtol, fin ? 0 : ls_iterations, alpha, imp_new, ls_ok, nullptr, gs2[2]);
 #endif
     pc.mark(6);
     if (!fin) {

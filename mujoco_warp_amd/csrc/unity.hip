@@ -5,5 +5,9 @@
 #include "solve_newton32.hip"
 #include "solve_cg64.hip"
 #include "solve_newton64.hip"
+#include "solve_ell_cg32.hip"
+#include "solve_ell_newton32.hip"
+#include "solve_ell_cg64.hip"
+#include "solve_ell_newton64.hip"
 #include "pgs_tu.hip"
 #include "solve_big.hip"

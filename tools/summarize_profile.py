@@ -28,6 +28,8 @@ def _short(n):
     return "k_solve_pgs" + ("<reg>" if "Lb1" in n else "<lds>")
   if "k_solve_big" in n:
     return "k_solve_big"
+  if "k_solve_newton" in n:
+    return "k_solve_newton"
   if "k_rk4" in n:
     return "k_rk4"
   if "k_mid" in n:
