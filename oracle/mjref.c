@@ -1045,13 +1045,44 @@ static int box_box(const double* p1, const double* R1, const double* s1, const d
   return n;
 }
 
-static int collide_pair(const RefModel* m, const RefData* d, int g1, int g2, double margin, Con* out) {
+#include "ccd.c"
+
+/* contact of a convex pair through GJK / EPA (collision_convex.py:747-977 eval_ccd_write_contact): both geoms carry the pair's
+ * margin (support points are inflated by half of it), the GJK cutoff is the gap, and the distance is reported un-inflated */
+static int ccd_contact(const RefModel* m, int t1, const double* p1, const double* R1, const double* s1, int t2, const double* p2,
+                       const double* R2, const double* s2, double margin, double gap, Con* out, int* overflow) {
+  CcdGeom a, b;
+  a.type = t1; b.type = t2;
+  v3cpy(a.pos, p1); v3cpy(b.pos, p2);
+  memcpy(a.rot, R1, sizeof(a.rot)); memcpy(b.rot, R2, sizeof(b.rot));
+  v3cpy(a.size, s1); v3cpy(b.size, s2);
+  a.margin = b.margin = margin;
+  static Polytope pt; /* (the oracle is single threaded) */
+  double dist, w1[3], w2[3], nrm[3];
+  int face;
+  int n = ccd_run(m->ccd_tolerance, gap, m->ccd_iterations, m->ccd_iterations, a, b, &dist, w1, w2, overflow, &face, &pt);
+  if (n == 0 || dist >= gap) return 0;
+  dist += margin;
+  if (dist <= margin) v3sub(nrm, w1, w2); /* overlapping: witness 1 has crossed witness 2 */
+  else v3sub(nrm, w2, w1);
+  out[0].dist = dist;
+  for (int k = 0; k < 3; k++) out[0].pos[k] = 0.5 * (w1[k] + w2[k]);
+  make_frame(out[0].frame, nrm);
+  return 1;
+}
+static int is_convex_pair(int t1, int t2) { /* MJ_COLLISION_TABLE collision_driver.py:47-80, primitive shapes only */
+  return (t1 == G_SPHERE && t2 == G_ELLIPSOID) || (t1 == G_CAPSULE && (t2 == G_ELLIPSOID || t2 == G_CYLINDER)) ||
+         (t1 == G_ELLIPSOID && (t2 == G_ELLIPSOID || t2 == G_CYLINDER || t2 == G_BOX)) || (t1 == G_CYLINDER && (t2 == G_CYLINDER || t2 == G_BOX));
+}
+
+static int collide_pair(const RefModel* m, RefData* d, int g1, int g2, double margin, double gap, Con* out) {
   int t1 = m->geom_type[g1], t2 = m->geom_type[g2];
   const double *p1 = d->geom_xpos + 3 * g1, *p2 = d->geom_xpos + 3 * g2;
   const double *R1 = d->geom_xmat + 9 * g1, *R2 = d->geom_xmat + 9 * g2;
   const double *s1 = m->geom_size + 3 * g1, *s2 = m->geom_size + 3 * g2;
   double ax1[3] = {R1[2], R1[5], R1[8]}, ax2[3] = {R2[2], R2[5], R2[8]};
   int n = 0;
+  if (is_convex_pair(t1, t2)) return ccd_contact(m, t1, p1, R1, s1, t2, p2, R2, s2, margin, gap, out, &d->overflow);
   if (t1 == G_PLANE && t2 == G_SPHERE) { /* collision_primitive.py:281 */
     plane_sphere(ax1, p1, p2, s2[0], &out[0].dist, out[0].pos);
     make_frame(out[0].frame, ax1);
@@ -1414,7 +1445,7 @@ void ref_collision(const RefModel* m, RefData* d) {
     double friction[5], solref[2], solreffriction[2], solimp[5], margin, gap;
     contact_params(m, g1, g2, pid, &condim, friction, solref, solreffriction, solimp, &margin, &gap);
     Con out[8];
-    int n = collide_pair(m, d, g1, g2, margin, out);
+    int n = collide_pair(m, d, g1, g2, margin, gap, out);
     for (int k = 0; k < n; k++) {
       if (!(out[k].dist < margin + gap)) continue;
       int c = d->ncon;
@@ -1436,6 +1467,23 @@ void ref_collision(const RefModel* m, RefData* d) {
   }
   if (d->ncon > m->nconmax) d->ncon = m->nconmax;
   free(mark);
+}
+
+int ref_ccd(int type1, const double* pos1, const double* mat1, const double* size1, int type2, const double* pos2, const double* mat2,
+            const double* size2, double margin, double tolerance, double cutoff, int iterations, int multiccd, double* out, double* wit) {
+  CcdGeom a, b;
+  a.type = type1; b.type = type2;
+  v3cpy(a.pos, pos1); v3cpy(b.pos, pos2);
+  memcpy(a.rot, mat1, sizeof(a.rot)); memcpy(b.rot, mat2, sizeof(b.rot));
+  v3cpy(a.size, size1); v3cpy(b.size, size2);
+  a.margin = b.margin = margin;
+  static Polytope pt;
+  int face, overflow = 0;
+  int n = ccd_run(tolerance, cutoff, iterations, iterations, a, b, out, out + 1, out + 4, &overflow, &face, &pt);
+  out[7] = (double)overflow;
+  out[8] = (double)face;
+  (void)multiccd; (void)wit;
+  return n;
 }
 
 /* ================================================================ constraint.py */

@@ -39,10 +39,12 @@ typedef struct RefModel {
   int disableflags;
   int broadphase;        /* BroadphaseType: 0 NXN, 1 SAP_TILE, 2 SAP_SEGMENTED (io.py:631-636) */
   int broadphase_filter; /* BroadphaseFilter bits: 1 plane, 2 sphere, 4 AABB, 8 OBB (io.py:405) */
+  int ccd_iterations;    /* GJK and EPA iteration cap (opt.ccd_iterations) */
   double timestep;
   double tolerance;
   double ls_tolerance;
   double impratio;
+  double ccd_tolerance;
   double meaninertia;
   double* gravity;
   double* qpos0;
@@ -241,6 +243,10 @@ void ref_closest_segment_to_segment_points(const double* a0, const double* a1, c
                                            double* best_b_out); /* math.py:283 */
 int ref_upper_tri_index(int n, int i, int j);  /* math.py:323 */
 int ref_upper_trid_index(int n, int i, int j); /* math.py:329 */
+/* collision_gjk.py:2529 ccd on two posed primitive convex geoms (types: GeomType values; mat row-major 3x3); out = dist, x1[3], x2[3];
+ * returns the number of contacts (box pairs: after multi-contact recovery when multiccd != 0, witness pairs in wit[8][3]) */
+int ref_ccd(int type1, const double* pos1, const double* mat1, const double* size1, int type2, const double* pos2, const double* mat2,
+            const double* size2, double margin, double tolerance, double cutoff, int iterations, int multiccd, double* out, double* wit);
 int ref_rollout(const RefModel* m, RefData* d, int nstep, int worldid, double noise_std, double noise_rate, double* qpos_out, double* qvel_out);
 
 #endif

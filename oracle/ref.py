@@ -16,7 +16,7 @@ _LIB_PATH = os.path.join(_DIR, "libmjref.so")
 
 
 def build(force=False):
-  src = [os.path.join(_DIR, f) for f in ("mjref.c", "mjref.h")]
+  src = [os.path.join(_DIR, f) for f in ("mjref.c", "mjref.h", "ccd.c")]
   if force or not os.path.exists(_LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in src):
     subprocess.check_call(["make", "-C", _DIR, "-B", "libmjref.so"], stdout=subprocess.DEVNULL)
   return _LIB_PATH
@@ -78,7 +78,25 @@ def lib():
     for fn in (_lib.ref_upper_tri_index, _lib.ref_upper_trid_index):
       fn.argtypes = [ctypes.c_int] * 3
       fn.restype = ctypes.c_int
+    _lib.ref_ccd.argtypes = [ctypes.c_int, dptr, dptr, dptr, ctypes.c_int, dptr, dptr, dptr, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                             ctypes.c_int, ctypes.c_int, dptr, dptr]
+    _lib.ref_ccd.restype = ctypes.c_int
   return _lib
+
+
+def ccd(type1, pos1, mat1, size1, type2, pos2, mat2, size2, margin=0.0, tolerance=1e-6, cutoff=1e30, iterations=35, multiccd=False):
+  """GJK / EPA on two posed primitive convex geoms (reference collision_gjk.py:2529 `ccd`, called like its test harness
+  collision_gjk_test.py:36-300).  Returns (dist, ncon, x1, x2, witness pairs [ncon, 2, 3])."""
+  def arr(x, n):
+    a = np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(-1))
+    assert a.size == n
+    return a
+  p1, m1, s1, p2, m2, s2 = arr(pos1, 3), arr(mat1, 9), arr(size1, 3), arr(pos2, 3), arr(mat2, 9), arr(size2, 3)
+  out, wit = np.zeros(9), np.zeros(48)
+  dp = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+  n = lib().ref_ccd(int(type1), dp(p1), dp(m1), dp(s1), int(type2), dp(p2), dp(m2), dp(s2), float(margin), float(tolerance), float(cutoff),
+                    int(iterations), int(bool(multiccd)), dp(out), dp(wit))
+  return float(out[0]), n, out[1:4].copy(), out[4:7].copy(), wit.reshape(8, 2, 3)[: max(n, 0)].copy()
 
 
 def filtered_geom_pairs(mjm):
@@ -154,7 +172,8 @@ class RefSim:
       solver=int(opt.solver if solver is None else solver),
       iterations=int(opt.iterations if iterations is None else iterations),
       ls_iterations=int(opt.ls_iterations if ls_iterations is None else ls_iterations),
-      disableflags=int(opt.disableflags), broadphase=int(broadphase), broadphase_filter=int(broadphase_filter), timestep=float(opt.timestep),
+      disableflags=int(opt.disableflags), broadphase=int(broadphase), broadphase_filter=int(broadphase_filter), ccd_iterations=int(getattr(opt, 'ccd_iterations', 35)),
+      ccd_tolerance=float(getattr(opt, 'ccd_tolerance', 1e-6)), timestep=float(opt.timestep),
       tolerance=float(opt.tolerance if tolerance is None else tolerance), ls_tolerance=float(opt.ls_tolerance),
       impratio=float(opt.impratio), meaninertia=float(mjm.stat.meaninertia))
     if scalars["cone"] != 0 and scalars["solver"] == 0:
