@@ -64,11 +64,13 @@ typedef struct MjhModel {
   int broadphase_filter; /* BroadphaseFilter bits (types.py:73-87): 1 plane, 2 sphere, 4 AABB, 8 OBB */
   /* options (types.py:836-905); solver: 0 = PGS (extension, the reference has none: types.py:502), 1 = CG, 2 = Newton */
   int integrator; int cone; int solver; int iterations; int ls_iterations; int disableflags; int enableflags;
+  int ccd_iterations;  /* GJK / EPA iteration cap of the convex narrowphase (capped at 64 by this engine) */
   const float* opt_timestep; int opt_timestep_nb;
   const float* opt_tolerance; int opt_tolerance_nb;
   const float* opt_ls_tolerance; int opt_ls_tolerance_nb;
   const float* opt_gravity; int opt_gravity_nb;
   const float* opt_impratio_invsqrt; int opt_impratio_invsqrt_nb;
+  const float* opt_ccd_tolerance; int opt_ccd_tolerance_nb;
   const float* stat_meaninertia; int stat_meaninertia_nb;
   const float* qpos0; int qpos0_nb;
   const float* qpos_spring; int qpos_spring_nb;
@@ -188,6 +190,8 @@ typedef struct MjhData {
   int* ws_ncon;        /* [nworld]   contacts found per world                         */
   int* ws_conadr;      /* [nworld]   exclusive scan of ws_ncon = first public slot (k_contact_scan) */
   int* ws_ncollision;  /* [nworld]   broadphase candidates per world                  */
+  float* ws_ccd;       /* [nworld, ccd_words(ccd_iterations), 32] EPA polytopes of the convex narrowphase, one per lane of a world, interleaved by
+                          lane (csrc/convex.hpp); empty unless the model has convex (GJK) pairs */
   int* ws_efc_con;     /* [nworld, njmax] contact rows: 16 * (world-local contact) + row within the contact (make_constraint -> solver,
                           elliptic cones only) */
   int* ws_order;       /* [nworld]   solver schedule: worlds sorted by last step's solver_niter (longest first) */
@@ -234,7 +238,7 @@ int mjh_timed_steps(const MjhModel* m, const MjhData* d, int nstep, int step0, f
 int mjh_release_thread_resources(void);
 
 const char* mjh_last_error(void);
-#define MJH_ABI_VERSION 8
+#define MJH_ABI_VERSION 9
 int mjh_abi_version(void); /* returns MJH_ABI_VERSION of the library that was loaded */
 
 #ifdef __cplusplus

@@ -12,6 +12,7 @@
 // collider's own contact index); only the order of the per-world blocks depends on scheduling.
 #pragma once
 #include "dev_common.hpp"
+#include "convex.hpp"
 
 // A collider reports each candidate contact through `emit(index, dist, pos, frame_row0, frame_row1, frame_row2)`.
 // The kernel runs every collider twice with different emitters (count, then write): nothing is buffered per
@@ -496,6 +497,21 @@ DEV int box_box(V3 P1, const float* R1, V3 S1, V3 P2, const float* R2, V3 S2, fl
 }
 
 // runs the collider for geoms (g1,g2) with type1 <= type2
+// convex pair through GJK / EPA (collision_convex.py:747-977): both geoms carry the pair's margin (support points are inflated by
+// half of it), the GJK cutoff is the gap, the reported distance is un-inflated, the contact sits midway between the witness points
+template <class Emit>
+DEV void collide_convex(float tolerance, int iterations, int t1, int t2, V3 p1, const float* R1, V3 s1, V3 p2, const float* R2, V3 s2, float margin,
+                        float gap, float* scratch, int& overflow, Emit&& emit) {
+  const CcdGeom a = CcdGeom{t1, p1, R1, s1, margin}, b = CcdGeom{t2, p2, R2, s2, margin};
+  float dist;
+  V3 w1, w2;
+  const int n = ccd_run(tolerance, gap, iterations, iterations, a, b, scratch, dist, w1, w2, overflow);
+  if (n == 0 || dist >= gap) return;
+  dist += margin;
+  const Frame f = make_frame3(dist <= margin ? w1 - w2 : w2 - w1);
+  emit(0, dist, 0.5f * (w1 + w2), f.a, f.b, f.c);
+}
+
 template <bool HEAVY, class Emit>
 DEV void collide_pair(int t1, int t2, V3 p1, const float* R1, V3 s1, V3 p2, const float* R2, V3 s2, float margin, Emit&& emit) {
   V3 ax1 = V3{R1[2], R1[5], R1[8]}, ax2 = V3{R2[2], R2[5], R2[8]};
@@ -970,6 +986,11 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
       t = t1; t1 = t2; t2 = t;
     }
   };
+  // EPA polytope of this lane (convex.hpp): word k of lane l at k * 32 + l inside the world's slice of d.ws_ccd
+  float* ccd_scratch = (HEAVY && d.ws_ccd) ? d.ws_ccd + (size_t)w * ccd_words(m.ccd_iterations) * CCD_LANES + (lig & (CCD_LANES - 1)) : nullptr;
+  const float ccd_tol = HEAVY ? bf(m.opt_ccd_tolerance, m.opt_ccd_tolerance_nb, w, 1)[0] : 0.0f;
+  const int ccd_it = min(m.ccd_iterations, CCD_MAX_ITER);
+  int ccd_overflow = 0;
   int ncon = 0;
   for (int base = 0; base < ncand; base += G) {
     const int ci = base + lig;
@@ -981,9 +1002,15 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
       load_pair(cand[ci], g1, g2, t1, t2);
       const int pid = (HEAVY && m.nexplicit) ? m.nxn_pairid[cand[ci]] : -1;
       const float margin = pid >= 0 ? m.pair_margin[pid] : gmargin[g1] + gmargin[g2];
-      const float lim = margin + (pid >= 0 ? m.pair_gap[pid] : ggap[g1] + ggap[g2]);
-      collide_pair<HEAVY>(t1, t2, ld3(gxpos + 3 * g1), gxmat + 9 * g1, ld3(gsize + 3 * g1), ld3(gxpos + 3 * g2), gxmat + 9 * g2,
-                   ld3(gsize + 3 * g2), margin, [&](int k, float dist, V3, V3, V3, V3) { mask |= dist < lim ? (1u << (k & 7)) : 0u; });
+      const float gap = pid >= 0 ? m.pair_gap[pid] : ggap[g1] + ggap[g2];
+      const float lim = margin + gap;
+      auto count = [&](int k, float dist, V3, V3, V3, V3) { mask |= dist < lim ? (1u << (k & 7)) : 0u; };
+      if (HEAVY && is_convex_pair(t1, t2))
+        collide_convex(ccd_tol, ccd_it, t1, t2, ld3(gxpos + 3 * g1), gxmat + 9 * g1, ld3(gsize + 3 * g1), ld3(gxpos + 3 * g2), gxmat + 9 * g2, ld3(gsize + 3 * g2),
+                       margin, gap, ccd_scratch, ccd_overflow, count);
+      else
+        collide_pair<HEAVY>(t1, t2, ld3(gxpos + 3 * g1), gxmat + 9 * g1, ld3(gsize + 3 * g1), ld3(gxpos + 3 * g2), gxmat + 9 * g2,
+                            ld3(gsize + 3 * g2), margin, count);
     }
     const int nk = __popc(mask);
     int incl = nk;
@@ -1023,8 +1050,7 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
       const int pid = (HEAVY && m.nexplicit) ? m.nxn_pairid[cand[ci]] : -1;
       const PairParams pp = contact_params(m, w, g1, g2, pid);
       const float margin = pp.margin;
-      collide_pair<HEAVY>(t1, t2, ld3(gxpos + 3 * g1), gxmat + 9 * g1, ld3(gsize + 3 * g1), ld3(gxpos + 3 * g2), gxmat + 9 * g2,
-                   ld3(gsize + 3 * g2), margin, [&](int cid, float dist, V3 pos, V3 fa, V3 fb, V3 fc) {
+      auto write = [&](int cid, float dist, V3 pos, V3 fa, V3 fb, V3 fc) {
                      if (!((mask >> (cid & 7)) & 1u)) return;
                      if (slot >= wbase && slot < wend) {
                        float* r = rec + (slot - wbase) * CON_LDS;
@@ -1047,7 +1073,13 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
                        ri[27] = cid;
                      }
                      ++slot;
-                   });
+                   };
+      if (HEAVY && is_convex_pair(t1, t2))
+        collide_convex(ccd_tol, ccd_it, t1, t2, ld3(gxpos + 3 * g1), gxmat + 9 * g1, ld3(gsize + 3 * g1), ld3(gxpos + 3 * g2), gxmat + 9 * g2, ld3(gsize + 3 * g2),
+                       margin, pp.gap, ccd_scratch, ccd_overflow, write);
+      else
+        collide_pair<HEAVY>(t1, t2, ld3(gxpos + 3 * g1), gxmat + 9 * g1, ld3(gsize + 3 * g1), ld3(gxpos + 3 * g2), gxmat + 9 * g2,
+                            ld3(gsize + 3 * g2), margin, write);
     }
     gsync();
     pc.mark(4);
@@ -1065,6 +1097,7 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
     if (ncon < nfound) atomicOr(d.overflow + w, OVF_NARROWPHASE);
     if (ncand < nbroad) atomicOr(d.overflow + w, OVF_BROADPHASE);
   }
+  if (HEAVY && ccd_overflow) atomicOr(d.overflow + w, ccd_overflow);
 }
 
 template <int G, bool HEAVY>

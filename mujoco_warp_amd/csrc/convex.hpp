@@ -1,0 +1,670 @@
+// convex.hpp -- general convex narrowphase (GJK distance + EPA penetration) for the primitive convex shapes.
+//
+// Reference: collision_gjk.py support 116-223, signed-volume sub-distance 281-593, gjk 635-770, polytope seeds 1021-1286,
+// EPA 1319-1454, witness points 947-1018, gjk_phase / epa_phase / ccd 2303-2575; collision_convex.py 747-977
+// (eval_ccd_write_contact: margins, cutoff, un-inflated distance, frame, midpoint).  Pair types routed here
+// (MJ_COLLISION_TABLE collision_driver.py:47-80 minus meshes / height fields): sphere-ellipsoid, capsule-ellipsoid,
+// capsule-cylinder, ellipsoid-ellipsoid / -cylinder / -box, cylinder-cylinder / -box.
+//
+// MI355X mapping: the reference runs one thread per candidate pair with the EPA polytope in a global scratch row per pair.
+// Here a candidate pair is still one lane (the collision kernel's lane-per-candidate narrowphase); the GJK simplex lives in
+// registers, the EPA polytope of a lane in a per-world global workspace interleaved by lane (word k of lane l at k * 32 + l), so the
+// 32 lanes of a world that walk their polytopes in step touch consecutive addresses.  Only the HEAVY collision instantiation
+// carries this code.
+#pragma once
+#include "dev_common.hpp"
+
+#define CCD_FLOAT_MAX 1e30f
+#define CCD_MINVAL 1e-15f
+#define CCD_MINVAL2 1e-30f
+#define CCD_MIN_DIST2 1e-10f
+#define CCD_MIN_DIST3 1e-10f
+#define CCD_MIN_DIST4 1e-17f
+#define CCD_MIN_EPATOL 1e-7f
+#define CCD_MAX_HORIZON 24  // types.py:31
+#define CCD_EPAFACES 5      // types.py:33
+#define CCD_MAX_ITER 64     // cap of opt.ccd_iterations on this engine (workspace words per lane: ccd_words)
+#define CCD_LANES 32        // polytope slots per world = lanes of a world's group
+
+// workspace words of one lane's polytope: vertex pairs (6 floats + 2 ids) | faces (packed verts, projection, norm^2) | horizon
+__host__ __device__ inline int ccd_words(int iterations) {
+  const int it = iterations < CCD_MAX_ITER ? iterations : CCD_MAX_ITER;
+  return 8 * (5 + it) + 5 * (6 + CCD_EPAFACES * it) + CCD_MAX_HORIZON;
+}
+
+struct CcdGeom {
+  int type;
+  V3 pos;
+  const float* rot;  // 3x3 row-major
+  V3 size;
+  float margin;
+};
+struct GjkOut {
+  bool separated;
+  int dim;
+  float dist;
+  V3 x1, x2;
+  V3 s[4], s1[4], s2[4];
+  int i1[4], i2[4];
+};
+
+DEV float ccd_sign(float x) { return x < 0.0f ? -1.0f : 1.0f; }
+
+DEV V3 ccd_support(const CcdGeom& g, V3 dir, int& vid) {
+  vid = -1;
+  if (g.type == G_SPHERE) return g.pos + (g.size.x + 0.5f * g.margin) * dir;
+  const V3 l = matT_mul(g.rot, dir);
+  V3 r = V3{0.0f, 0.0f, 0.0f};
+  if (g.type == G_BOX) {
+    const float sx = ccd_sign(l.x), sy = ccd_sign(l.y), sz = ccd_sign(l.z);
+    r = V3{sx * g.size.x, sy * g.size.y, sz * g.size.z};
+    vid = (sx > 0.0f ? 1 : 0) + (sy > 0.0f ? 2 : 0) + (sz > 0.0f ? 4 : 0);
+  } else if (g.type == G_CAPSULE) {
+    r = l * g.size.x;
+    r.z += ccd_sign(l.z) * g.size.y;
+  } else if (g.type == G_ELLIPSOID) {
+    r = normalize(V3{l.x * g.size.x, l.y * g.size.y, l.z * g.size.z});
+    r = V3{r.x * g.size.x, r.y * g.size.y, r.z * g.size.z};
+  } else if (g.type == G_CYLINDER) {
+    const float dd = sqrtf(l.x * l.x + l.y * l.y);
+    if (dd > CCD_MINVAL) {
+      const float scl = g.size.x / dd;
+      r.x = l.x * scl;
+      r.y = l.y * scl;
+    }
+    r.z = ccd_sign(l.z) * g.size.y;
+  }
+  V3 out = mat_mul(g.rot, r) + g.pos;
+  if (g.margin > 0.0f) out = out + dir * (0.5f * g.margin);
+  return out;
+}
+
+DEV float ccd_det3(V3 a, V3 b, V3 c) { return dot(a, cross(b, c)); }
+DEV int ccd_same_sign(float a, float b) { return (a > 0.0f && b > 0.0f) ? 1 : ((a < 0.0f && b < 0.0f) ? -1 : 0); }
+DEV float v3c(V3 a, int k) { return k == 0 ? a.x : (k == 1 ? a.y : a.z); }
+
+DEV V3 ccd_origin_on_line(V3 v1, V3 v2) {
+  const V3 df = v2 - v1;
+  const float scl = -(dot(v2, df) / dot(df, df));
+  return v2 + scl * df;
+}
+DEV bool ccd_origin_on_plane(V3 v1, V3 v2, V3 v3_, V3& out) {  // true: degenerate triangle
+  const V3 d21 = v2 - v1, d31 = v3_ - v1, d32 = v3_ - v2;
+  V3 n = cross(d32, d21);
+  float nv = dot(n, v2), nn = dot(n, n);
+  out = V3{0.0f, 0.0f, 0.0f};
+  if (nn == 0.0f) return true;
+  if (nv != 0.0f && nn > CCD_MINVAL) { out = (nv / nn) * n; return false; }
+  n = cross(d21, d31);
+  nv = dot(n, v1);
+  nn = dot(n, n);
+  if (nn == 0.0f) return true;
+  if (nv != 0.0f && nn > CCD_MINVAL) { out = (nv / nn) * n; return false; }
+  n = cross(d31, d32);
+  nv = dot(n, v3_);
+  nn = dot(n, n);
+  out = (nv / nn) * n;
+  return false;
+}
+
+// barycentric coordinates of the simplex point closest to the origin (signed volumes): 1-, 2-, 3-simplex
+DEV void ccd_s1d(V3 s1, V3 s2, float& l0, float& l1) {
+  const V3 po = ccd_origin_on_line(s1, s2);
+  float mu_max = s1.x - s2.x;
+  int idx = 0;
+  float mu = s1.y - s2.y;
+  if (fabsf(mu) >= fabsf(mu_max)) { mu_max = mu; idx = 1; }
+  mu = s1.z - s2.z;
+  if (fabsf(mu) >= fabsf(mu_max)) { mu_max = mu; idx = 2; }
+  const float c1 = v3c(po, idx) - v3c(s2, idx), c2 = v3c(s1, idx) - v3c(po, idx);
+  if (ccd_same_sign(mu_max, c1) && ccd_same_sign(mu_max, c2)) { l0 = c1 / mu_max; l1 = c2 / mu_max; }
+  else { l0 = 0.0f; l1 = 1.0f; }
+}
+DEV void ccd_minors(V3 s1, V3 s2, V3 s3, float& mmax, int& x, int& y) {
+  const float m14 = s2.y * s3.z - s2.z * s3.y - s1.y * s3.z + s1.z * s3.y + s1.y * s2.z - s1.z * s2.y;
+  const float m24 = s2.x * s3.z - s2.z * s3.x - s1.x * s3.z + s1.z * s3.x + s1.x * s2.z - s1.z * s2.x;
+  const float m34 = s2.x * s3.y - s2.y * s3.x - s1.x * s3.y + s1.y * s3.x + s1.x * s2.y - s1.y * s2.x;
+  const float mu1 = fabsf(m14), mu2 = fabsf(m24), mu3 = fabsf(m34);
+  if (mu1 >= mu2 && mu1 >= mu3) { mmax = m14; x = 1; y = 2; }
+  else if (mu2 >= mu3) { mmax = m24; x = 0; y = 2; }
+  else { mmax = m34; x = 0; y = 1; }
+}
+DEV void ccd_areas(V3 v1, V3 v2, V3 v3_, V3 p, int x, int y, float& c31, float& c32, float& c33) {
+  const float ax = v3c(v1, x), ay = v3c(v1, y), bx = v3c(v2, x), by = v3c(v2, y), cx = v3c(v3_, x), cy = v3c(v3_, y), px = v3c(p, x), py = v3c(p, y);
+  c31 = px * by + py * cx + bx * cy - px * cy - py * bx - cx * by;
+  c32 = px * cy + py * ax + cx * ay - px * ay - py * cx - ax * cy;
+  c33 = px * ay + py * bx + ax * by - px * by - py * ax - bx * ay;
+}
+DEV void ccd_s2d(V3 s1, V3 s2, V3 s3, float& l0, float& l1, float& l2) {
+  V3 po;
+  if (ccd_origin_on_plane(s1, s2, s3, po)) {
+    ccd_s1d(s1, s2, l0, l1);
+    l2 = 0.0f;
+    return;
+  }
+  float mmax, c31, c32, c33;
+  int x, y;
+  ccd_minors(s1, s2, s3, mmax, x, y);
+  ccd_areas(s1, s2, s3, po, x, y, c31, c32, c33);
+  const int k1 = ccd_same_sign(mmax, c31), k2 = ccd_same_sign(mmax, c32), k3 = ccd_same_sign(mmax, c33);
+  if (k1 && k2 && k3) { l0 = c31 / mmax; l1 = c32 / mmax; l2 = c33 / mmax; return; }
+  float dmin = CCD_FLOAT_MAX, a, b;
+  l0 = l1 = l2 = 0.0f;
+  if (!k1) {
+    ccd_s1d(s2, s3, a, b);
+    const V3 xx = a * s2 + b * s3;
+    l0 = 0.0f; l1 = a; l2 = b;
+    dmin = dot(xx, xx);
+  }
+  if (!k2) {
+    ccd_s1d(s1, s3, a, b);
+    const V3 xx = a * s1 + b * s3;
+    const float dd = dot(xx, xx);
+    if (dd < dmin) { l0 = a; l1 = 0.0f; l2 = b; dmin = dd; }
+  }
+  if (!k3) {
+    ccd_s1d(s1, s2, a, b);
+    const V3 xx = a * s1 + b * s2;
+    const float dd = dot(xx, xx);
+    if (dd < dmin) { l0 = a; l1 = b; l2 = 0.0f; }
+  }
+}
+DEV void ccd_s3d(V3 s1, V3 s2, V3 s3, V3 s4, float (&lam)[4]) {
+  const float c41 = -ccd_det3(s2, s3, s4), c42 = ccd_det3(s1, s3, s4), c43 = -ccd_det3(s1, s2, s4), c44 = ccd_det3(s1, s2, s3);
+  const float mdet = c41 + c42 + c43 + c44;
+  const int k1 = ccd_same_sign(mdet, c41), k2 = ccd_same_sign(mdet, c42), k3 = ccd_same_sign(mdet, c43), k4 = ccd_same_sign(mdet, c44);
+  if (k1 && k2 && k3 && k4) {
+    lam[0] = c41 / mdet; lam[1] = c42 / mdet; lam[2] = c43 / mdet; lam[3] = c44 / mdet;
+    return;
+  }
+  float dmin = CCD_FLOAT_MAX, a, b, c;
+  lam[0] = lam[1] = lam[2] = lam[3] = 0.0f;
+  if (!k1) {
+    ccd_s2d(s2, s3, s4, a, b, c);
+    const V3 xx = a * s2 + b * s3 + c * s4;
+    const float dd = dot(xx, xx);
+    if (dd < dmin) { lam[0] = 0.0f; lam[1] = a; lam[2] = b; lam[3] = c; dmin = dd; }
+  }
+  if (!k2) {
+    ccd_s2d(s1, s3, s4, a, b, c);
+    const V3 xx = a * s1 + b * s3 + c * s4;
+    const float dd = dot(xx, xx);
+    if (dd < dmin) { lam[0] = a; lam[1] = 0.0f; lam[2] = b; lam[3] = c; dmin = dd; }
+  }
+  if (!k3) {
+    ccd_s2d(s1, s2, s4, a, b, c);
+    const V3 xx = a * s1 + b * s2 + c * s4;
+    const float dd = dot(xx, xx);
+    if (dd < dmin) { lam[0] = a; lam[1] = b; lam[2] = 0.0f; lam[3] = c; dmin = dd; }
+  }
+  if (!k4) {
+    ccd_s2d(s1, s2, s3, a, b, c);
+    const V3 xx = a * s1 + b * s2 + c * s3;
+    const float dd = dot(xx, xx);
+    if (dd < dmin) { lam[0] = a; lam[1] = b; lam[2] = c; lam[3] = 0.0f; }
+  }
+}
+DEV V3 ccd_combine(int n, const float (&lam)[4], const V3 (&m)[4]) {
+  V3 o = V3{0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (i < n) o = o + lam[i] * m[i];
+  return o;
+}
+
+DEV void ccd_gjk(float tolerance, int iterations, const CcdGeom& g1, const CcdGeom& g2, V3 x1_0, V3 x2_0, float cutoff, bool is_discrete,
+                 GjkOut& res) {
+  int n = 0;
+  float lam[4] = {1.0f, 0.0f, 0.0f, 0.0f};
+  const float epsilon = is_discrete ? 0.0f : 0.5f * tolerance * tolerance, min_norm = is_discrete ? CCD_MINVAL : tolerance;
+  V3 xk = x1_0 - x2_0;
+  float xnorm = sqrtf(dot(xk, xk)), xnorm_prev = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    res.s[i] = res.s1[i] = res.s2[i] = V3{0.0f, 0.0f, 0.0f};
+    res.i1[i] = res.i2[i] = -1;
+  }
+  res.separated = false;
+  res.dim = 0;
+  res.dist = 0.0f;
+  res.x1 = res.x2 = V3{0.0f, 0.0f, 0.0f};
+  for (int it = 0; it < iterations; ++it) {
+    if (xnorm < min_norm || fabsf(xnorm_prev - xnorm) < CCD_MINVAL) break;
+    V3 dneg = xk * (1.0f / xnorm);
+    if (is_discrete && xnorm < 1e-4f) {
+      if (n == 2) {
+        const V3 e = res.s[1] - res.s[0];
+        const float e2 = dot(e, e);
+        if (e2 > CCD_MINVAL2) {
+          dneg = dneg - (dot(dneg, e) / e2) * e;
+          const float dn = length(dneg);
+          if (dn > CCD_MINVAL) dneg = dneg * (1.0f / dn);
+        }
+      } else if (n == 3) {
+        const V3 nr = cross(res.s[1] - res.s[0], res.s[2] - res.s[0]);
+        const float nn = length(nr);
+        if (nn > CCD_MINVAL) dneg = (ccd_sign(dot(dneg, nr)) / nn) * nr;
+      }
+    }
+    int v1, v2;
+    const V3 p1 = ccd_support(g1, -dneg, v1), p2 = ccd_support(g2, dneg, v2);
+    const V3 sn = p1 - p2;
+    // slot n of the simplex (static indexing: the arrays stay in registers)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (i == n) {
+        res.s1[i] = p1;
+        res.s2[i] = p2;
+        res.s[i] = sn;
+        res.i1[i] = v1;
+        res.i2[i] = v2;
+      }
+    if (dot(xk, xk - sn) < epsilon) break;
+    const float lower = dot(xk, sn);
+    if ((cutoff == 0.0f && lower > 0.0f) || (cutoff != 0.0f && cutoff < CCD_FLOAT_MAX && lower > 0.0f && lower >= cutoff * xnorm)) {
+      res.separated = true;
+      res.dim = 0;
+      res.dist = CCD_FLOAT_MAX;
+      return;
+    }
+    lam[0] = 1.0f;
+    lam[1] = lam[2] = lam[3] = 0.0f;
+    if (n + 1 == 4) ccd_s3d(res.s[0], res.s[1], res.s[2], res.s[3], lam);
+    else if (n + 1 == 3) ccd_s2d(res.s[0], res.s[1], res.s[2], lam[0], lam[1], lam[2]);
+    else if (n + 1 == 2) ccd_s1d(res.s[0], res.s[1], lam[0], lam[1]);
+    // compact the vertices that still carry weight (a stable, fully unrolled compaction)
+    int mcount = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (lam[i] == 0.0f) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (j == mcount && j <= i) {
+          res.s[j] = res.s[i];
+          res.s1[j] = res.s1[i];
+          res.s2[j] = res.s2[i];
+          res.i1[j] = res.i1[i];
+          res.i2[j] = res.i2[i];
+          lam[j] = lam[i];
+        }
+      ++mcount;
+    }
+    n = mcount;
+    if (n < 1) break;
+    xk = ccd_combine(n, lam, res.s);
+    xnorm_prev = xnorm;
+    xnorm = sqrtf(dot(xk, xk));
+    if (n == 4) break;
+  }
+  res.separated = false;
+  res.x1 = n == 0 ? x1_0 : ccd_combine(n, lam, res.s1);
+  res.x2 = n == 0 ? x2_0 : ccd_combine(n, lam, res.s2);
+  if (xnorm > 0.0f) {
+    const V3 dir = xk * (1.0f / xnorm);
+    int v;
+    const V3 p1 = ccd_support(g1, -dir, v), p2 = ccd_support(g2, dir, v);
+    res.separated = dot(xk, p1 - p2) > 0.0f;
+  }
+  res.dist = (n == 4 && !res.separated) ? 0.0f : xnorm;
+  res.dim = n;
+}
+
+// ---- EPA polytope in the lane-interleaved workspace ------------------------------------------------------------------------------
+struct Poly {
+  float* base;  // word 0 of this lane
+  int vcap, fcap, o_vidx, o_face, o_fpr, o_fn2, o_hor;
+  int status, nvert, nface, nhorizon;
+  V3 center;
+  DEV float& F(int k) const { return base[(size_t)k * CCD_LANES]; }
+  DEV int& I(int k) const { return reinterpret_cast<int*>(base)[(size_t)k * CCD_LANES]; }
+  DEV V3 vert(int i) const { return V3{F(3 * i), F(3 * i + 1), F(3 * i + 2)}; }  // vertex pair v: 2v on geom 1, 2v + 1 on geom 2
+  DEV void set_vert(int i, V3 p) const { F(3 * i) = p.x; F(3 * i + 1) = p.y; F(3 * i + 2) = p.z; }
+  DEV V3 diff(int v) const { return vert(2 * v) - vert(2 * v + 1); }
+  DEV int& vidx(int i) const { return I(o_vidx + i); }
+  DEV int& face(int f) const { return I(o_face + f); }  // 10 bits per vertex | bit 31 deleted | bit 30 invalid
+  DEV V3 fpr(int f) const { return V3{F(o_fpr + 3 * f), F(o_fpr + 3 * f + 1), F(o_fpr + 3 * f + 2)}; }
+  DEV float& fn2(int f) const { return F(o_fn2 + f); }
+  DEV int& hor(int i) const { return I(o_hor + i); }
+};
+DEV void poly_init(Poly& pt, float* base, int iterations) {
+  pt.base = base;
+  pt.vcap = 5 + iterations;
+  pt.fcap = 6 + CCD_EPAFACES * iterations;
+  pt.o_vidx = 6 * pt.vcap;
+  pt.o_face = pt.o_vidx + 2 * pt.vcap;
+  pt.o_fpr = pt.o_face + pt.fcap;
+  pt.o_fn2 = pt.o_fpr + 3 * pt.fcap;
+  pt.o_hor = pt.o_fn2 + pt.fcap;
+  pt.status = pt.nvert = pt.nface = pt.nhorizon = 0;
+  pt.center = V3{0.0f, 0.0f, 0.0f};
+}
+DEV float poly_attach_face(Poly& pt, int idx, int v1, int v2, int v3_) {
+  if (pt.nface == pt.fcap) return 0.0f;
+  const V3 p1 = pt.diff(v1), p2 = pt.diff(v2), p3 = pt.diff(v3_);
+  V3 r;
+  if (ccd_origin_on_plane(p3, p2, p1, r)) return 0.0f;
+  if (dot(r, p1 - pt.center) < 0.0f) r = -r;
+  pt.face(idx) = v1 | (v2 << 10) | (v3_ << 20);
+  pt.F(pt.o_fpr + 3 * idx) = r.x;
+  pt.F(pt.o_fpr + 3 * idx + 1) = r.y;
+  pt.F(pt.o_fpr + 3 * idx + 2) = r.z;
+  const float n2 = dot(r, r);
+  pt.fn2(idx) = n2;
+  return n2;
+}
+DEV void poly_support(Poly& pt, int idx, const CcdGeom& g1, const CcdGeom& g2, V3 dir) {
+  int v1, v2;
+  pt.set_vert(2 * idx, ccd_support(g1, dir, v1));
+  pt.set_vert(2 * idx + 1, ccd_support(g2, -dir, v2));
+  pt.vidx(2 * idx) = v1;
+  pt.vidx(2 * idx + 1) = v2;
+}
+DEV void poly_put(Poly& pt, int v, const GjkOut& res, int i) {  // simplex vertex i -> polytope vertex pair v (i static)
+  pt.set_vert(2 * v, res.s1[i]);
+  pt.set_vert(2 * v + 1, res.s2[i]);
+  pt.vidx(2 * v) = res.i1[i];
+  pt.vidx(2 * v + 1) = res.i2[i];
+}
+DEV void poly_replace_simplex3(const Poly& pt, int v1, int v2, int v3_, GjkOut& res) {
+  const int v[3] = {v1, v2, v3_};
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    res.s1[i] = pt.vert(2 * v[i]);
+    res.s2[i] = pt.vert(2 * v[i] + 1);
+    res.s[i] = res.s1[i] - res.s2[i];
+    res.i1[i] = pt.vidx(2 * v[i]);
+    res.i2[i] = pt.vidx(2 * v[i] + 1);
+  }
+  res.dim = 3;
+}
+DEV bool ccd_same_side(V3 p0, V3 p1, V3 p2, V3 p3) {
+  const V3 n = cross(p1 - p0, p2 - p0);
+  const float d1 = dot(n, p3 - p0), d2 = dot(n, -p0);
+  return (d1 > 0.0f && d2 > 0.0f) || (d1 < 0.0f && d2 < 0.0f);
+}
+DEV bool ccd_test_tetra(V3 p0, V3 p1, V3 p2, V3 p3) {
+  return ccd_same_side(p0, p1, p2, p3) && ccd_same_side(p1, p2, p3, p0) && ccd_same_side(p2, p3, p0, p1) && ccd_same_side(p3, p0, p1, p2);
+}
+DEV V3 ccd_tri_affine(V3 v1, V3 v2, V3 v3_, V3 p) {
+  float mmax, c31, c32, c33;
+  int x, y;
+  ccd_minors(v1, v2, v3_, mmax, x, y);
+  ccd_areas(v1, v2, v3_, p, x, y, c31, c32, c33);
+  return V3{c31 / mmax, c32 / mmax, c33 / mmax};
+}
+DEV bool ccd_tri_point_intersect(V3 v1, V3 v2, V3 v3_, V3 p) {
+  const V3 l = ccd_tri_affine(v1, v2, v3_, p);
+  if (l.x < 0.0f || l.y < 0.0f || l.z < 0.0f) return false;
+  const V3 pr = l.x * v1 + l.y * v2 + l.z * v3_;
+  return length(pr - p) < CCD_MINVAL;
+}
+DEV int ccd_ray_triangle(V3 v1, V3 v2, V3 v3_, V3 v4, V3 v5) {
+  const V3 e = v2 - v1;
+  const float vol1 = ccd_det3(v3_ - v1, v4 - v1, e), vol2 = ccd_det3(v4 - v1, v5 - v1, e), vol3 = ccd_det3(v5 - v1, v3_ - v1, e);
+  if (vol1 >= 0.0f && vol2 >= 0.0f && vol3 >= 0.0f) return 1;
+  if (vol1 <= 0.0f && vol2 <= 0.0f && vol3 <= 0.0f) return -1;
+  return 0;
+}
+
+// seed polytopes from GJK's 1-, 2-, 3-simplex; status 0: ready, -1: continue from the 2-simplex written into res, > 0: no depth
+DEV void poly_seed2(Poly& pt, GjkOut& res, const CcdGeom& g1, const CcdGeom& g2) {
+  const V3 df = res.s[1] - res.s[0];
+  pt.center = 0.5f * (res.s[0] + res.s[1]);
+  int index = 0;
+  float val = fabsf(df.x);
+  if (fabsf(df.y) < val) { val = fabsf(df.y); index = 1; }
+  if (fabsf(df.z) < val) index = 2;
+  const V3 e = V3{index == 0 ? 1.0f : 0.0f, index == 1 ? 1.0f : 0.0f, index == 2 ? 1.0f : 0.0f};
+  const V3 d1 = cross(e, df);
+  const float n = length(df), u1 = df.x / n, u2 = df.y / n, u3 = df.z / n, sn = 0.86602540378f, cs = -0.5f;
+  const float R[9] = {cs + u1 * u1 * (1 - cs),      u1 * u2 * (1 - cs) - u3 * sn, u1 * u3 * (1 - cs) + u2 * sn,
+                      u2 * u1 * (1 - cs) + u3 * sn, cs + u2 * u2 * (1 - cs),      u2 * u3 * (1 - cs) - u1 * sn,
+                      u1 * u3 * (1 - cs) - u2 * sn, u2 * u3 * (1 - cs) + u1 * sn, cs + u3 * u3 * (1 - cs)};
+  const V3 d2 = mat_mul(R, d1), d3 = mat_mul(R, d2);
+  poly_put(pt, 0, res, 0);
+  poly_put(pt, 1, res, 1);
+  poly_support(pt, 2, g1, g2, d1 * (1.0f / length(d1)));
+  poly_support(pt, 3, g1, g2, d2 * (1.0f / length(d2)));
+  poly_support(pt, 4, g1, g2, d3 * (1.0f / length(d3)));
+  const int Fc[6][3] = {{0, 2, 3}, {0, 4, 2}, {0, 3, 4}, {1, 3, 2}, {1, 2, 4}, {1, 4, 3}};
+  for (int f = 0; f < 6; ++f)
+    if (poly_attach_face(pt, f, Fc[f][0], Fc[f][1], Fc[f][2]) < CCD_MIN_DIST2) {
+      pt.status = -1;
+      poly_replace_simplex3(pt, Fc[f][0], Fc[f][1], Fc[f][2], res);
+      return;
+    }
+  if (!ccd_ray_triangle(res.s[0], res.s[1], pt.diff(2), pt.diff(3), pt.diff(4))) {
+    pt.status = 1;
+    return;
+  }
+  pt.nvert = 5;
+  pt.nface = 6;
+  pt.status = 0;
+}
+DEV void poly_seed3(Poly& pt, const GjkOut& res, const CcdGeom& g1, const CcdGeom& g2) {
+  pt.center = (res.s[0] + res.s[1] + res.s[2]) * (1.0f / 3.0f);
+  V3 n = cross(res.s[1] - res.s[0], res.s[2] - res.s[0]);
+  const float norm = length(n);
+  if (norm < CCD_MINVAL) { pt.status = 2; return; }
+  n = n * (1.0f / norm);
+  poly_put(pt, 0, res, 0);
+  poly_put(pt, 1, res, 1);
+  poly_put(pt, 2, res, 2);
+  poly_support(pt, 3, g1, g2, -n);
+  poly_support(pt, 4, g1, g2, n);
+  const V3 v4 = pt.diff(3), v5 = pt.diff(4);
+  if (ccd_tri_point_intersect(res.s[0], res.s[1], res.s[2], v4)) { pt.status = 3; return; }
+  if (ccd_tri_point_intersect(res.s[0], res.s[1], res.s[2], v5)) { pt.status = 4; return; }
+  if (res.dist > 1e-5f && !ccd_test_tetra(res.s[0], res.s[1], res.s[2], v4) && !ccd_test_tetra(res.s[0], res.s[1], res.s[2], v5)) {
+    pt.status = 5;
+    return;
+  }
+  const int Fc[6][3] = {{4, 0, 1}, {4, 2, 0}, {4, 1, 2}, {3, 1, 0}, {3, 0, 2}, {3, 2, 1}};
+  for (int f = 0; f < 6; ++f)
+    if (poly_attach_face(pt, f, Fc[f][0], Fc[f][1], Fc[f][2]) < CCD_MIN_DIST3) { pt.status = 6 + f; return; }
+  pt.nvert = 5;
+  pt.nface = 6;
+  pt.status = 0;
+}
+DEV void poly_seed4(Poly& pt, GjkOut& res) {
+  pt.center = 0.25f * (res.s[0] + res.s[1] + res.s[2] + res.s[3]);
+  poly_put(pt, 0, res, 0);
+  poly_put(pt, 1, res, 1);
+  poly_put(pt, 2, res, 2);
+  poly_put(pt, 3, res, 3);
+  const int Fc[4][3] = {{0, 1, 2}, {0, 3, 1}, {0, 2, 3}, {3, 2, 1}};
+  float dist[4];
+  int idx = 0;
+  for (int f = 0; f < 4; ++f) {
+    dist[f] = poly_attach_face(pt, f, Fc[f][0], Fc[f][1], Fc[f][2]);
+    if (dist[f] < CCD_MIN_DIST4) {
+      pt.status = -1;
+      poly_replace_simplex3(pt, Fc[f][0], Fc[f][1], Fc[f][2], res);
+      return;
+    }
+    if (f > 0 && dist[f] < dist[idx]) idx = f;
+  }
+  if (!ccd_test_tetra(res.s[0], res.s[1], res.s[2], res.s[3])) {
+    if (dist[idx] > CCD_MINVAL) { pt.status = 12; return; }
+    pt.status = -1;
+    poly_replace_simplex3(pt, Fc[idx][0], Fc[idx][1], Fc[idx][2], res);
+    return;
+  }
+  pt.nvert = 4;
+  pt.nface = 4;
+  pt.status = 0;
+}
+DEV int poly_add_edge(Poly& pt, int e1, int e2) {
+  const int n = pt.nhorizon;
+  if (n < 0) return -1;
+  const int edge = (min(e1, e2) << 10) | max(e1, e2);
+  for (int i = 0; i < n; ++i)
+    if (pt.hor(i) == edge) {
+      pt.hor(i) = pt.hor(n - 1);
+      return n - 1;
+    }
+  if (n == CCD_MAX_HORIZON) return -1;
+  pt.hor(n) = edge;
+  return n + 1;
+}
+#define CCD_FACE_DELETED 0x80000000u
+#define CCD_FACE_INVALID 0x40000000u
+DEV void poly_delete_face(Poly& pt, int f) {
+  const unsigned fc = (unsigned)pt.face(f);
+  pt.face(f) = (int)(fc | CCD_FACE_DELETED);
+  pt.nhorizon = poly_add_edge(pt, fc & 0x3FF, (fc >> 10) & 0x3FF);
+  pt.nhorizon = poly_add_edge(pt, (fc >> 10) & 0x3FF, (fc >> 20) & 0x3FF);
+  pt.nhorizon = poly_add_edge(pt, (fc >> 20) & 0x3FF, fc & 0x3FF);
+}
+// returns the closest face (-1: no contact); dist <= 0 and the witness points of the penetration
+DEV int ccd_epa(float tolerance, int iterations, Poly& pt, const CcdGeom& g1, const CcdGeom& g2, bool is_discrete, int& overflow, float& dist,
+                V3& x1, V3& x2) {
+  float upper = CCD_FLOAT_MAX, upper2 = CCD_FLOAT_MAX;
+  const float epsilon = is_discrete ? CCD_MIN_EPATOL : tolerance;
+  int idx = -1, nvalid = pt.nface;
+  for (int it = 0; it < iterations; ++it) {
+    const int pidx = idx;
+    idx = -1;
+    float lower2 = CCD_FLOAT_MAX;
+    for (int i = 0; i < pt.nface; ++i) {
+      const float n2 = pt.fn2(i);
+      if (!((unsigned)pt.face(i) & (CCD_FACE_DELETED | CCD_FACE_INVALID)) && n2 < lower2) {
+        idx = i;
+        lower2 = n2;
+      }
+    }
+    if (lower2 > upper2 || idx < 0) {
+      idx = pidx;
+      break;
+    }
+    if (lower2 <= 0.0f) break;
+    const float lower = sqrtf(lower2);
+    const int wi = pt.nvert;
+    const V3 fpr = pt.fpr(idx);
+    poly_support(pt, wi, g1, g2, fpr * (1.0f / lower));
+    const V3 w = pt.diff(wi);
+    pt.nvert++;
+    const float upper_k = dot(fpr, w) / lower;
+    if (upper_k < upper) {
+      upper = upper_k;
+      upper2 = upper * upper;
+    }
+    if (upper - lower < epsilon) break;
+    if (is_discrete) {
+      bool rep = false;
+      const int a = pt.vidx(2 * wi), b = pt.vidx(2 * wi + 1);
+      for (int i = 0; i < pt.nvert - 1 && !rep; ++i) rep = pt.vidx(2 * i) == a && pt.vidx(2 * i + 1) == b;
+      if (rep) break;
+    }
+    nvalid--;
+    poly_delete_face(pt, idx);
+    if (pt.nhorizon == -1) {
+      overflow |= OVF_EPA_HORIZON;
+      idx = -1;
+      break;
+    }
+    for (int i = 0; i < pt.nface; ++i) {
+      const unsigned fc = (unsigned)pt.face(i);
+      if (fc & CCD_FACE_DELETED) continue;
+      if (dot(pt.fpr(i), w) - pt.fn2(i) > 1e-10f) {
+        if (!(fc & CCD_FACE_INVALID)) nvalid--;
+        poly_delete_face(pt, i);
+        if (pt.nhorizon == -1) {
+          overflow |= OVF_EPA_HORIZON;
+          idx = -1;
+          break;
+        }
+      }
+    }
+    for (int i = 0; i < pt.nhorizon; ++i) {
+      const int e = pt.hor(i);
+      const float d2 = poly_attach_face(pt, pt.nface, wi, e & 0x3FF, (e >> 10) & 0x3FF);
+      if (d2 == 0.0f) {
+        idx = -1;
+        break;
+      }
+      pt.nface++;
+      if (d2 >= lower2 && d2 <= upper2) nvalid++;
+      else pt.face(pt.nface - 1) = (int)((unsigned)pt.face(pt.nface - 1) | CCD_FACE_INVALID);
+    }
+    if (nvalid == 0 || idx == -1) break;
+    pt.nhorizon = 0;
+  }
+  if (idx < 0) {
+    dist = 0.0f;
+    return -1;
+  }
+  const unsigned fc = (unsigned)pt.face(idx);
+  const int f0 = fc & 0x3FF, f1 = (fc >> 10) & 0x3FF, f2 = (fc >> 20) & 0x3FF;
+  const V3 l = ccd_tri_affine(pt.diff(f0), pt.diff(f1), pt.diff(f2), pt.fpr(idx));
+  x1 = l.x * pt.vert(2 * f0) + l.y * pt.vert(2 * f1) + l.z * pt.vert(2 * f2);
+  x2 = l.x * pt.vert(2 * f0 + 1) + l.y * pt.vert(2 * f1 + 1) + l.z * pt.vert(2 * f2 + 1);
+  dist = -sqrtf(pt.fn2(idx));
+  return idx;
+}
+
+// gjk_phase + epa_phase: number of contacts (0 / 1), distance between the margin-inflated shapes and the witness points
+DEV int ccd_run(float tolerance, float cutoff, int gjk_iterations, int epa_iterations, CcdGeom g1, CcdGeom g2, float* scratch, float& dist_out,
+                V3& x1, V3& x2, int& overflow) {
+  const CcdGeom o1 = g1, o2 = g2;
+  float full1 = 0.0f, full2 = 0.0f, size1 = 0.0f, size2 = 0.0f;
+  const bool is_discrete = g1.type == G_BOX && g2.type == G_BOX && g1.margin == 0.0f && g2.margin == 0.0f;
+  GjkOut res;
+  if (g1.type == G_SPHERE || g1.type == G_CAPSULE) {
+    size1 = g1.size.x;
+    full1 = size1 + 0.5f * g1.margin;
+    g1.margin = 0.0f;
+    g1.size.x = 0.0f;
+  }
+  if (g2.type == G_SPHERE || g2.type == G_CAPSULE) {
+    size2 = g2.size.x;
+    full2 = size2 + 0.5f * g2.margin;
+    g2.margin = 0.0f;
+    g2.size.x = 0.0f;
+  }
+  if (size1 + size2 > 0.0f) {
+    cutoff += full1 + full2;
+    ccd_gjk(tolerance, gjk_iterations, g1, g2, g1.pos, g2.pos, cutoff, is_discrete, res);
+    if (res.dist > tolerance) {
+      dist_out = res.dist;
+      x1 = res.x1;
+      x2 = res.x2;
+      if (res.dist == CCD_FLOAT_MAX) return 1;
+      const V3 n = normalize(res.x2 - res.x1);
+      if (full1 > 0.0f) x1 = x1 + full1 * n;
+      if (full2 > 0.0f) x2 = x2 - full2 * n;
+      dist_out = res.dist - (full1 + full2);
+      return 1;
+    }
+    g1 = o1;
+    g2 = o2;
+    cutoff -= full1 + full2;
+  }
+  ccd_gjk(tolerance, gjk_iterations, g1, g2, g1.pos, g2.pos, cutoff, is_discrete, res);
+  dist_out = res.dist;
+  x1 = res.x1;
+  x2 = res.x2;
+  if (res.dist > tolerance || res.dim < 2 || res.separated) return 1;
+  Poly pt;
+  poly_init(pt, scratch, epa_iterations);
+  if (res.dim == 2) poly_seed2(pt, res, g1, g2);
+  else if (res.dim == 4) poly_seed4(pt, res);
+  if (res.dim == 3) {
+    pt.status = 0;
+    poly_seed3(pt, res, g1, g2);
+  }
+  if (pt.status) return 1;
+  float dist;
+  const int idx = ccd_epa(tolerance, epa_iterations, pt, g1, g2, is_discrete, overflow, dist, x1, x2);
+  if (idx == -1) {
+    dist_out = CCD_FLOAT_MAX;
+    return 0;
+  }
+  dist_out = dist;
+  return 1;
+}
+
+DEV bool is_convex_pair(int t1, int t2) {
+  return (t1 == G_SPHERE && t2 == G_ELLIPSOID) || (t1 == G_CAPSULE && (t2 == G_ELLIPSOID || t2 == G_CYLINDER)) ||
+         (t1 == G_ELLIPSOID && (t2 == G_ELLIPSOID || t2 == G_CYLINDER || t2 == G_BOX)) || (t1 == G_CYLINDER && (t2 == G_CYLINDER || t2 == G_BOX));
+}

@@ -87,6 +87,9 @@ def geom_pairs_with_ids(mjm):
 
 
 _SUPPORTED_PAIRS = {(0, 2), (0, 3), (0, 4), (0, 5), (0, 6), (2, 2), (2, 3), (2, 5), (2, 6), (3, 3), (3, 6), (6, 6)}
+# pairs of the reference's CONVEX class (collision_driver.py:47-80) that go through GJK / EPA (csrc/convex.hpp); box-box stays on the
+# primitive collider (the reference's choice when DisableBit.NATIVECCD is set, collision_driver.py:867-870)
+_CONVEX_PAIRS = {(2, 4), (3, 4), (3, 5), (4, 4), (4, 5), (4, 6), (5, 5), (5, 6)}
 
 
 def _pair_index(ngeom, pairs):
@@ -165,7 +168,7 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
   gt = np.asarray(mjm.geom_type)
   for a, b in pairs:
     t = (int(min(gt[a], gt[b])), int(max(gt[a], gt[b])))
-    if t not in _SUPPORTED_PAIRS:
+    if t not in _SUPPORTED_PAIRS and t not in _CONVEX_PAIRS:
       raise NotImplementedError(f"collision between geom types {t} is not implemented yet")
   condims = set(int(c) for c in np.unique(np.asarray(mjm.geom_condim)[np.unique(pairs)])) if len(pairs) else set()
   nexplicit = int(getattr(mjm, "npair", 0))
@@ -189,7 +192,9 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
   m.nC = int(np.sum(mjm.M_rownnz)) if nv else 0
   m.nM = m.nC
   # capsule-box / box-box pairs and explicit contact pairs select the kernel instantiation that carries them (include/mjhip.h)
-  m._heavy_pairs = int(any((int(min(gt[a], gt[b])), int(max(gt[a], gt[b]))) in ((3, 6), (6, 6)) for a, b in pairs) or int(getattr(mjm, "npair", 0)) > 0)
+  m._convex_pairs = int(any((int(min(gt[a], gt[b])), int(max(gt[a], gt[b]))) in _CONVEX_PAIRS for a, b in pairs))
+  m._heavy_pairs = int(any((int(min(gt[a], gt[b])), int(max(gt[a], gt[b]))) in ((3, 6), (6, 6)) for a, b in pairs) or int(getattr(mjm, "npair", 0)) > 0
+                       or m._convex_pairs)
   m.heavy_colliders = m._heavy_pairs  # c_model() adds the broadphase options (they may be changed after put_model)
   m.is_sparse = False
   m.nv_pad = _get_padded_sizes(nv, 1)[1]
@@ -204,8 +209,10 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
   o.ls_tolerance = np.array([opt.ls_tolerance], dtype=f32)
   o.gravity = _arr(opt.gravity, f32).reshape(1, 3)
   o.impratio_invsqrt = np.array([1.0 / np.sqrt(max(float(opt.impratio), types.MJ_MINVAL))], dtype=f32)
+  o.ccd_tolerance = np.array([float(getattr(opt, "ccd_tolerance", 1e-6))], dtype=f32)
   for name in ("integrator", "cone", "solver", "iterations", "ls_iterations", "disableflags", "enableflags"):
     setattr(o, name, int(getattr(opt, name)))
+  o.ccd_iterations = int(getattr(opt, "ccd_iterations", 35))
   # reference io.py:631-636: NXN below 250k filtered pairs, SAP above (tile sort below 1000 geoms)
   o.broadphase = (types.BroadphaseType.NXN if len(pairs) < 250_000 else
                   types.BroadphaseType.SAP_TILE if ngeom_ < 1000 else types.BroadphaseType.SAP_SEGMENTED)
@@ -269,7 +276,7 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
   i32 = np.int32
   host.update(
     opt_timestep=o.timestep, opt_tolerance=o.tolerance, opt_ls_tolerance=o.ls_tolerance, opt_gravity=o.gravity,
-    opt_impratio_invsqrt=o.impratio_invsqrt, stat_meaninertia=s.meaninertia,
+    opt_impratio_invsqrt=o.impratio_invsqrt, opt_ccd_tolerance=o.ccd_tolerance, stat_meaninertia=s.meaninertia,
     qpos0=_arr(mjm.qpos0, f32).reshape(1, -1), qpos_spring=_arr(mjm.qpos_spring, f32).reshape(1, -1),
     body_parentid=parent, body_rootid=_arr(mjm.body_rootid, i32), body_weldid=_arr(mjm.body_weldid, i32),
     body_jntnum=_arr(mjm.body_jntnum, i32), body_jntadr=_arr(mjm.body_jntadr, i32), body_dofnum=dofnum, body_dofadr=dofadr,
@@ -364,7 +371,7 @@ def c_model(m: types.Model):
         setattr(c, name + "_nb", src.shape[0])
     elif name.endswith("_nb"):
       continue
-    elif name in ("integrator", "cone", "solver", "iterations", "ls_iterations", "disableflags", "enableflags", "broadphase", "broadphase_filter"):
+    elif name in ("integrator", "cone", "solver", "iterations", "ls_iterations", "disableflags", "enableflags", "broadphase", "broadphase_filter", "ccd_iterations"):
       setattr(c, name, int(getattr(m.opt, name)))
     elif name == "heavy_colliders":
       bf_ = int(m.opt.broadphase_filter)
@@ -378,6 +385,12 @@ def c_model(m: types.Model):
   object.__setattr__(m, "_c", c)
   object.__setattr__(m, "_dirty", False)
   return c
+
+
+def _ccd_words(iterations: int) -> int:
+  """Workspace words of one lane's EPA polytope (csrc/convex.hpp ccd_words)."""
+  it = min(int(iterations), 64)
+  return 8 * (5 + it) + 5 * (6 + 5 * it) + 24
 
 
 def contact_cap(nconmax: int) -> int:
@@ -407,7 +420,7 @@ def _data_shapes(m, nworld, nconmax, njmax, naconmax):
     contact_geomcollisionid=(naconmax,),
     efc_type=(W, njmax), efc_id=(W, njmax), efc_state=(W, njmax), efc_J=(W, njmax_pad, nv_pad), efc_pos=(W, njmax),
     efc_margin=(W, njmax), efc_D=(W, njmax), efc_vel=(W, njmax), efc_aref=(W, njmax), efc_frictionloss=(W, njmax),
-    efc_force=(W, njmax), ws_ncon=(W,), ws_conadr=(W,), ws_ncollision=(W,), ws_efc_con=(W, njmax), ws_order=(W,),
+    efc_force=(W, njmax), ws_ncon=(W,), ws_conadr=(W,), ws_ncollision=(W,), ws_efc_con=(W, njmax), ws_order=(W,), ws_ccd=(W if m._convex_pairs else 0, _ccd_words(m.opt.ccd_iterations), 32),
     eq_active=(W, m.neq), ws_rk=(W, nq + 3 * nv + 2 * na), ws_contact=(W, contact_cap(nconmax), 32),
   )
   return sh, njmax_pad, nv_pad
@@ -443,6 +456,7 @@ def _alloc_data(m: types.Model, nworld, nconmax, njmax, naconmax, mjd=None):
     d.eq_active.assign(np.tile(m.eq_active0, (nworld, 1)))
   _reset_mocap(m, d, None)
   d.nmaxpyramid = m.nmaxpyramid
+  d.nccdworld, d.nccdword = shapes["ws_ccd"][0], shapes["ws_ccd"][1]
   d.world_offset = 0
   d.concap = contact_cap(nconmax)
   d.reserved0 = 0

@@ -222,11 +222,13 @@ class Option(_Dirty):
   ls_tolerance: DeviceArray = _arr(('*',), "float32")
   gravity: DeviceArray = _arr(('*', 3), "float32")
   impratio_invsqrt: DeviceArray = _arr(('*',), "float32")
+  ccd_tolerance: DeviceArray = _arr(('*',), "float32")
   integrator: int = 0
   cone: int = 0
   solver: int = 0
   iterations: int = 0
   ls_iterations: int = 0
+  ccd_iterations: int = 0
   disableflags: int = 0
   enableflags: int = 0
   broadphase: int = 0
@@ -486,6 +488,7 @@ class Data(_Dirty):
   ws_conadr: DeviceArray = _arr(('nworld',), "int32")
   ws_ncollision: DeviceArray = _arr(('nworld',), "int32")
   ws_efc_con: DeviceArray = _arr(('nworld', 'njmax'), "int32")
+  ws_ccd: DeviceArray = _arr(('nccdworld', 'nccdword', 32), "float32")
   ws_order: DeviceArray = _arr(('nworld',), "int32")
   eq_active: DeviceArray = _arr(('nworld', 'neq'), "int32")
   ws_rk: DeviceArray = _arr(('nworld', 'nq+3*nv+2*na'), "float32")
@@ -497,6 +500,8 @@ class Data(_Dirty):
   njmax_pad: int = 0
   nv_pad: int = 0
   nmaxpyramid: int = 0
+  nccdworld: int = 0  # worlds with an EPA workspace: nworld if the model has convex (GJK) pairs, else 0
+  nccdword: int = 0  # workspace words per lane of a world (csrc/convex.hpp ccd_words)
   world_offset: int = 0
   concap: int = 0
   reserved0: int = 0

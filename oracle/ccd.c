@@ -19,7 +19,7 @@
 #define CCD_MAX_ITER 128
 #define CCD_MAX_HORIZON 24 /* types.py:31 MJ_MAX_EPAHORIZON */
 #define CCD_EPAFACES 5     /* types.py:33 MJ_MAX_EPAFACES */
-#define OVF_EPA_HORIZON (1 << 4)
+#define OVF_EPA_HORIZON (1 << 8) /* types.py OverflowType.EPA_HORIZON */
 
 typedef struct CcdGeom {
   int type;

@@ -136,3 +136,136 @@ def test_ccd_against_closed_forms(seed):
     u = c2 / np.linalg.norm(c2)
     np.testing.assert_allclose(x1, u * r1, atol=2e-6 if exact else 3e-2)
     np.testing.assert_allclose(x2, c2 - u * r2, atol=2e-6 if exact else 3e-2)
+
+
+# ---- GPU vs oracle -------------------------------------------------------------------------------------------------------------
+CONVEX_XML = """
+<mujoco>
+  <option timestep="0.003"/>
+  <worldbody>
+    <geom name="floor" type="plane" size="0 0 .05"/>
+    <body name="ell" pos="0 0 .2"><freejoint/><geom type="ellipsoid" size=".12 .08 .05"/></body>
+    <body name="cyl" pos=".4 0 .2"><freejoint/><geom type="cylinder" size=".06 .1"/></body>
+    <body name="cap" pos=".8 0 .2"><freejoint/><geom type="capsule" size=".04 .1"/></body>
+    <body name="box" pos="1.2 0 .2"><freejoint/><geom type="box" size=".08 .06 .05"/></body>
+    <body name="sph" pos="1.6 0 .2"><freejoint/><geom type="sphere" size=".07"/></body>
+    <body name="ell2" pos="2.0 0 .2"><freejoint/><geom type="ellipsoid" size=".05 .09 .07"/></body>
+    <body name="cyl2" pos="2.4 0 .2"><freejoint/><geom type="cylinder" size=".08 .04"/></body>
+  </worldbody>
+</mujoco>
+"""
+# body index (qpos block) of each shape and the convex pairs exercised: (a, b)
+_SHAPES = {"ell": 0, "cyl": 1, "cap": 2, "box": 3, "sph": 4, "ell2": 5, "cyl2": 6}
+_PAIRS = [("sph", "ell"), ("cap", "ell"), ("cap", "cyl"), ("ell", "ell2"), ("ell", "cyl"), ("ell", "box"), ("cyl", "cyl2"), ("cyl", "box")]
+
+
+def _pose_pairs(rng, gapscale):
+  """qpos with every pair of _PAIRS placed near contact somewhere far from the other pairs (the two shapes of a pair are moved,
+  every pair gets its own copy of the state: returned as a list of qpos vectors)."""
+  out = []
+  for a, b in _PAIRS:
+    q = np.zeros(7 * len(_SHAPES))
+    for name, i in _SHAPES.items():
+      q[7 * i : 7 * i + 3] = [3.0 * i, 5.0, 1.0 + 0.5 * i]  # parked apart, off the floor
+      q[7 * i + 3] = 1.0
+    for k, name in enumerate((a, b)):
+      i = _SHAPES[name]
+      quat = rng.normal(size=4)
+      q[7 * i + 3 : 7 * i + 7] = quat / np.linalg.norm(quat)
+    ia, ib = _SHAPES[a], _SHAPES[b]
+    direction = rng.normal(size=3)
+    direction /= np.linalg.norm(direction)
+    q[7 * ia : 7 * ia + 3] = [0, 0, 2.0]
+    q[7 * ib : 7 * ib + 3] = np.array([0, 0, 2.0]) + direction * gapscale * rng.uniform(0.1, 0.2)
+    out.append(q)
+  return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("margin", [0.0, 0.03])
+@pytest.mark.parametrize("seed", range(6))
+def test_gpu_convex_contacts_match_oracle(seed, margin):
+  import mujoco_warp_amd as mjw
+
+  # margin > 0: support points are inflated by half of it and contacts appear before the surfaces touch (dist in (0, margin))
+  mjm = mjw.mjcf.from_xml_string(CONVEX_XML.replace("<worldbody>", f'<default><geom margin="{margin}"/></default><worldbody>'))
+  rng = np.random.default_rng(seed)
+  qs = _pose_pairs(rng, 1.0)
+  m = mjw.put_model(mjm)
+  d = mjw.put_data(mjm, mjw.MjData(mjm), nworld=len(qs), nconmax=16, njmax=64)
+  d.qpos.assign(np.asarray(qs, dtype=np.float32))
+  mjw.kinematics(m, d)
+  mjw.collision(m, d)
+  ncon = d.ws_ncon.numpy()
+  adr = d.ws_conadr.numpy()
+  nhit = 0
+  for w, q in enumerate(qs):
+    s = ref.RefSim(mjm, nconmax=16, njmax=64)
+    s.qpos[:] = q
+    s.stage("kinematics")
+    s.stage("collision")
+    assert int(ncon[w]) == s.ncon, (_PAIRS[w], int(ncon[w]), s.ncon)
+    nhit += s.ncon
+    for c in range(s.ncon):
+      o = int(adr[w]) + c
+      assert tuple(d.contact.geom.numpy()[o]) == tuple(s.con_geom[c])
+      depth = abs(s.con_dist[c])
+      # GJK answers (separated / shallow) agree to float32 rounding; EPA depths of curved shapes are only as converged as 35
+      # support points allow (see test_ccd_against_closed_forms), and float32 / float64 may stop on neighbouring faces
+      tol = 2e-6 + 5e-3 * depth
+      assert abs(d.contact.dist.numpy()[o] - s.con_dist[c]) < tol, (_PAIRS[w], d.contact.dist.numpy()[o], s.con_dist[c])
+      np.testing.assert_allclose(d.contact.pos.numpy()[o], s.con_pos[c], atol=5e-5 + 0.25 * depth)  # (flat faces: the witness point is not unique)
+      np.testing.assert_allclose(d.contact.frame.numpy()[o].reshape(9)[:3], s.con_frame[c][:3], atol=2e-4 if s.con_dist[c] > s.con_includemargin[c] else 6e-2)  # (EPA normal = a facet of a <= 40-vertex polytope)
+  assert nhit >= 3
+  assert (d.overflow.numpy() == 0).all()
+
+
+CONVEX_SCENE_XML = """
+<mujoco>
+  <option timestep="0.002"/>
+  <worldbody>
+    <geom name="floor" type="plane" size="0 0 .05"/>
+    <geom name="table" type="box" size=".6 .3 .05" pos="0 0 .05"/>
+    <geom name="log" type="cylinder" size=".08 .25" pos="0 1 .08" euler="90 0 0"/>
+    <geom name="dome" type="ellipsoid" size=".3 .3 .12" pos="1.2 0 .12"/>
+    <body name="egg" pos="-.4 0 .149"><freejoint/><geom type="ellipsoid" size=".09 .06 .05"/></body>
+    <body name="can" pos="0 0 .179"><freejoint/><geom type="cylinder" size=".05 .08"/></body>
+    <body name="roll" pos=".4 0 .149" euler="90 0 0"><freejoint/><geom type="cylinder" size=".05 .1"/></body>
+    <body name="cross" pos="0 .9 .209" euler="0 90 0"><freejoint/><geom type="cylinder" size=".05 .15"/></body>
+    <body name="pill" pos="0 1.15 .199" euler="0 90 0"><freejoint/><geom type="capsule" size=".04 .12"/></body>
+    <body name="ball" pos="1.2 0 .299"><freejoint/><geom type="sphere" size=".06"/></body>
+    <body name="pebble" pos="1.0 .1 .27"><freejoint/><geom type="ellipsoid" size=".05 .04 .03"/></body>
+  </worldbody>
+</mujoco>
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("solver", ["Newton", "CG"])
+def test_gpu_convex_scene_steps_match_oracle(solver):
+  """Bodies resting / rolling on convex supports (ellipsoid-box, cylinder-box flat and rolling, crossed cylinders, capsule-cylinder,
+  sphere-ellipsoid, ellipsoid-ellipsoid): one step from the same state along the oracle's trajectory."""
+  import mujoco_warp_amd as mjw
+  from tests.conftest import relerr
+
+  mjm = mjw.mjcf.from_xml_string(CONVEX_SCENE_XML)
+  mjm.opt.solver = int(mjw.SolverType.NEWTON if solver == "Newton" else mjw.SolverType.CG)
+  s = ref.RefSim(mjm, nconmax=32, njmax=128, tolerance=1e-6)
+  s.reset()
+  m = mjw.put_model(mjm)
+  d = mjw.put_data(mjm, mjw.MjData(mjm), nworld=2, nconmax=32, njmax=128)
+  worst_q = worst_v = 0.0
+  ncon_total = 0
+  for i in range(60):
+    for name in ("qpos", "qvel", "qacc_warmstart"):
+      getattr(d, name).assign(np.tile(getattr(s, name).astype(np.float32), (2, 1)))
+    mjw.step(m, d)
+    s.step()
+    ncon_total += s.ncon
+    assert int(d.ws_ncon.numpy()[1]) == s.ncon
+    worst_q = max(worst_q, relerr(d.qpos.numpy()[1], s.qpos))
+    worst_v = max(worst_v, relerr(d.qvel.numpy()[1], s.qvel))
+  assert ncon_total >= 6 * 60
+  assert worst_q <= 1e-5, worst_q
+  assert worst_v <= 5e-3, worst_v
+  assert (d.overflow.numpy() == 0).all()

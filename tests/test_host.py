@@ -360,6 +360,6 @@ def test_declared_schema_matches_arrays(xml):
   assert dataclasses.is_dataclass(mjw.Model) and dataclasses.is_dataclass(mjw.Data)
   env = {k: getattr(m, k) for k in ("nq", "nv", "nu", "na", "nbody", "njnt", "ngeom", "nsite", "nkey", "nmocap", "neq", "nC", "npair",
                                     "nexplicit", "nbodylevel", "ndoflevel", "nmaxpyramid")}
-  env.update(nworld=d.nworld, njmax=d.njmax, njmax_pad=d.njmax_pad, nv_pad=d.nv_pad, naconmax=d.naconmax, concap=d.concap)
+  env.update(nworld=d.nworld, njmax=d.njmax, njmax_pad=d.njmax_pad, nv_pad=d.nv_pad, naconmax=d.naconmax, concap=d.concap, nccdworld=d.nccdworld, nccdword=d.nccdword)
   for obj in (m.opt, m.stat, m, d.contact, d.efc, d):
     _schema_check(obj, env, d.nworld)
