@@ -542,6 +542,59 @@ def test_golden_rollout_free_running():
   assert np.isfinite(d.qpos.numpy()).all()
 
 
+def _ks(a, b):
+  """two-sample Kolmogorov-Smirnov statistic"""
+  both = np.sort(np.concatenate([a, b]))
+  return float(np.max(np.abs(np.searchsorted(np.sort(a), both, side="right") / a.size - np.searchsorted(np.sort(b), both, side="right") / b.size)))
+
+
+def test_free_running_1000_steps_statistics():
+  """1000 free-running steps (the benchmark's length) of 192 worlds against 192 float64 oracle worlds with the same per-world control
+  noise.  Trajectories are chaotic -- a float32 / float64 pair decorrelates after ~100 contact-rich steps -- so the comparison is
+  between DISTRIBUTIONS over worlds at steps 250 / 500 / 1000: root height, torso tilt, speed, contact and row counts
+  (two-sample KS at alpha = 0.001, means within four standard errors)."""
+  nw, marks = 192, (250, 500, 1000)
+  mjm = mjw.mjcf.load_xml(conftest.HUMANOID_XML)
+  m = mjw.put_model(mjm)
+  d = mjw.make_data(mjm, nworld=nw, nconmax=24, njmax=64)
+  mjw.reset_data_keyframe(m, d, 0)
+
+  def feats(qpos, qvel, ncon, nefc):
+    w, x, y, z = qpos[:, 3], qpos[:, 4], qpos[:, 5], qpos[:, 6]
+    up = 1.0 - 2.0 * (x * x + y * y)  # z component of the torso's z axis
+    return {"height": qpos[:, 2], "tilt": up, "speed": np.sqrt((qvel ** 2).mean(axis=1)), "ncon": ncon.astype(float), "nefc": nefc.astype(float)}
+
+  gpu = {}
+  for i in range(marks[-1]):
+    mjw.ctrl_noise(m, d, i)
+    mjw.step(m, d)
+    if i + 1 in marks:
+      gpu[i + 1] = feats(d.qpos.numpy(), d.qvel.numpy(), d.ws_ncon.numpy(), np.minimum(d.nefc.numpy(), d.njmax))
+  assert np.isfinite(d.qpos.numpy()).all()
+  cpu = {k: {f: np.zeros(nw) for f in ("height", "tilt", "speed", "ncon", "nefc")} for k in marks}
+  s = ref.RefSim(mjm, nconmax=24, njmax=64, tolerance=1e-6)
+  for w in range(nw):
+    s.reset(key=0)
+    t = 0
+    for k in marks:
+      # (ref_rollout restarts its noise step index at 0: advance with explicit steps so the noise sequence continues)
+      for i in range(t, k):
+        s.ctrl_noise(i, w)
+        s.step()
+      t = k
+      f = feats(s.qpos[None], s.qvel[None], np.array([s.ncon]), np.array([s.nefc]))
+      for name in f:
+        cpu[k][name][w] = f[name][0]
+  crit = 1.95 * np.sqrt(2.0 / nw)  # KS critical value at alpha = 0.001
+  for k in marks:
+    for name in ("height", "tilt", "speed", "ncon", "nefc"):
+      a, b = gpu[k][name], cpu[k][name]
+      se = np.sqrt(a.var() / nw + b.var() / nw)
+      assert abs(a.mean() - b.mean()) <= 4.0 * se + 1e-3 * (1.0 + abs(b.mean())), (k, name, a.mean(), b.mean(), se)
+      if name in ("height", "tilt", "speed"):
+        assert _ks(a, b) <= crit, (k, name, _ks(a, b), crit)
+
+
 def test_ctrl_noise_matches_oracle():
   mjm = mjw.mjcf.load_xml(conftest.HUMANOID_XML)
   s, m, d = _pair(mjm, nworld=64, nconmax=24, njmax=64, warm_steps=0)
