@@ -213,6 +213,11 @@ int mjh_forward(const MjhModel* m, const MjhData* d, void* stream);
 int mjh_solve_m(const MjhModel* m, const MjhData* d, float* x, const float* y, void* stream);
 /* res = M vec (support.mul_m support.py:218) */
 int mjh_mul_m(const MjhModel* m, const MjhData* d, float* res, const float* vec, void* stream);
+/* CSR copy of the dense efc.J in the reference's sparse layout (types.py:2021-2070: J_rownnz / J_rowadr [nworld, njmax], J_colind / J
+ * [nworld, njmax_nnz]; the reference stores efc.J this way for nv > 32, io.py:1804-1808).  Entries = the numerically non-zero values of
+ * each row (a subset of the reference's structural pattern); rows whose entries do not fit njmax_nnz are truncated and
+ * OverflowType.NJMAX_NNZ is set.  Opt-in: nothing inside step reads it. */
+int mjh_efc_j_sparse(const MjhModel* m, const MjhData* d, int njmax_nnz, int* rownnz, int* rowadr, int* colind, float* values, void* stream);
 
 /* cli._ctrl_noise cli.py:103-145; ctrl_center may be NULL (-> actuator midpoint); worldid is global */
 int mjh_ctrl_noise(const MjhModel* m, const MjhData* d, const float* ctrl_center, int step, float noise_std,
@@ -238,7 +243,7 @@ int mjh_timed_steps(const MjhModel* m, const MjhData* d, int nstep, int step0, f
 int mjh_release_thread_resources(void);
 
 const char* mjh_last_error(void);
-#define MJH_ABI_VERSION 9
+#define MJH_ABI_VERSION 10
 int mjh_abi_version(void); /* returns MJH_ABI_VERSION of the library that was loaded */
 
 #ifdef __cplusplus

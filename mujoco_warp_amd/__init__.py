@@ -15,6 +15,7 @@ from .forward import com_vel
 from .forward import collision
 from .forward import crb
 from .forward import ctrl_noise
+from .forward import efc_J_sparse
 from .forward import euler
 from .forward import factor_m
 from .forward import forward

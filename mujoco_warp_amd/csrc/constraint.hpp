@@ -448,3 +448,41 @@ __global__ void __launch_bounds__(256) k_make_constraint(MjhModel m, MjhData d) 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   make_constraint_body<G>(m, d, smem, blk_of_launch<G>());
 }
+
+
+// ---- CSR view of efc.J (opt-in, mjh_efc_j_sparse) --------------------------------------------------------------------------------
+// one 64-lane wavefront per world: rows in order, each row's non-zeros compacted with a ballot prefix over 64-column chunks
+__global__ void __launch_bounds__(64) k_efc_j_sparse(MjhData d, int nv, int njmax_nnz, int* rownnz, int* rowadr, int* colind, float* values) {
+  const int w = blockIdx.x, lane = threadIdx.x;
+  if (w >= d.nworld) return;
+  const int nefc = min(d.nefc[w], d.njmax), nvp = d.nv_pad;
+  const float* J = d.efc_J + (size_t)w * d.njmax_pad * nvp;
+  int adr = 0;
+  bool ovf = false;
+  for (int r = 0; r < d.njmax; ++r) {
+    int nnz = 0;
+    if (r < nefc) {
+      for (int c0 = 0; c0 < nv; c0 += 64) {
+        const int c = c0 + lane;
+        const float v = c < nv ? J[(size_t)r * nvp + c] : 0.0f;
+        const unsigned long long bits = __ballot(v != 0.0f);
+        const int rank = __popcll(bits & ((1ull << lane) - 1ull)), o = adr + nnz + rank;
+        if (v != 0.0f) {
+          if (o < njmax_nnz) {
+            colind[(size_t)w * njmax_nnz + o] = c;
+            values[(size_t)w * njmax_nnz + o] = v;
+          } else {
+            ovf = true;
+          }
+        }
+        nnz += __popcll(bits);
+      }
+    }
+    if (lane == 0) {
+      rownnz[(size_t)w * d.njmax + r] = min(nnz, max(njmax_nnz - adr, 0));
+      rowadr[(size_t)w * d.njmax + r] = min(adr, njmax_nnz);
+    }
+    adr += nnz;
+  }
+  if (__ballot(ovf) && lane == 0) atomicOr(d.overflow + w, OVF_NJMAX_NNZ);
+}

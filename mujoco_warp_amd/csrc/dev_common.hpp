@@ -33,7 +33,7 @@ enum { SOL_PGS = 0, SOL_CG = 1, SOL_NEWTON = 2 };
 enum { CONE_PYRAMIDAL = 0, CONE_ELLIPTIC = 1 };
 #define CON_STRIDE 32  /* words per contact record in d.ws_contact (layout: collide.hpp) */
 enum { INT_EULER = 0, INT_RK4 = 1, INT_IMPLICIT = 2, INT_IMPLICITFAST = 3 };
-enum { OVF_NEFC = 1 << 0, OVF_BROADPHASE = 1 << 2, OVF_NARROWPHASE = 1 << 3, OVF_EPA_HORIZON = 1 << 8, OVF_ITERATIONS = 1 << 9, OVF_LS_ITERATIONS = 1 << 10 };
+enum { OVF_NEFC = 1 << 0, OVF_NJMAX_NNZ = 1 << 1, OVF_BROADPHASE = 1 << 2, OVF_NARROWPHASE = 1 << 3, OVF_EPA_HORIZON = 1 << 8, OVF_ITERATIONS = 1 << 9, OVF_LS_ITERATIONS = 1 << 10 };
 enum { CONTACT_TYPE_CONSTRAINT = 1 };
 
 #define DEV __device__ __forceinline__

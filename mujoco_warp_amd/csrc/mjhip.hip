@@ -520,6 +520,14 @@ int mjh_mul_m(const MjhModel* m, const MjhData* d, float* res, const float* vec,
   return launch_solve_m(m, d, res, vec, 1, (hipStream_t)stream);
 }
 
+int mjh_efc_j_sparse(const MjhModel* m, const MjhData* d, int njmax_nnz, int* rownnz, int* rowadr, int* colind, float* values, void* stream) {
+  TRY(check(m, d));
+  if (njmax_nnz < 0 || !rownnz || !rowadr || (njmax_nnz > 0 && (!colind || !values))) return fail(MJH_E_ARG, "mjh_efc_j_sparse: null output or negative njmax_nnz");
+  hipLaunchKernelGGL(k_efc_j_sparse, dim3(d->nworld), dim3(64), 0, (hipStream_t)stream, *d, m->nv, njmax_nnz, rownnz, rowadr, colind, values);
+  HIPCHK(hipGetLastError());
+  return MJH_OK;
+}
+
 int mjh_ctrl_noise(const MjhModel* m, const MjhData* d, const float* ctrl_center, int step, float noise_std, float noise_rate, void* stream) {
   TRY(check(m, d));
   const int n = d->nworld * m->nu;

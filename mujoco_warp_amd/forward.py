@@ -7,6 +7,7 @@ sequence on torch's current HIP stream and returns without synchronising, like `
 
 import ctypes
 
+import numpy as np
 import torch
 
 from . import _abi
@@ -144,6 +145,20 @@ def mul_m(m, d, res: DeviceArray, vec: DeviceArray):
   """res = M vec (reference support.py:218)."""
   L = _abi.lib()
   _abi.check(L.mjh_mul_m(ctypes.byref(io.c_model(m)), ctypes.byref(io.c_data(d)), res.ptr, vec.ptr, _stream()))
+
+
+def efc_J_sparse(m, d, njmax_nnz: int = None):
+  """CSR copy of `d.efc.J` in the reference's sparse layout (reference types.py:2021-2070; the reference stores efc.J like this for
+  nv > 32, io.py:1804-1808; this engine keeps the dense tile and offers the CSR form on request).  Returns
+  (J_rownnz [nworld, njmax], J_rowadr [nworld, njmax], J_colind [nworld, 1, njmax_nnz], J [nworld, 1, njmax_nnz])."""
+  nnz = int(d.njmax_nnz if njmax_nnz is None else njmax_nnz)
+  rownnz = DeviceArray.zeros((d.nworld, d.njmax), dtype=np.int32)
+  rowadr = DeviceArray.zeros((d.nworld, d.njmax), dtype=np.int32)
+  colind = DeviceArray.zeros((d.nworld, 1, nnz), dtype=np.int32)
+  vals = DeviceArray.zeros((d.nworld, 1, nnz), dtype=np.float32)
+  L = _abi.lib()
+  _abi.check(L.mjh_efc_j_sparse(ctypes.byref(io.c_model(m)), ctypes.byref(io.c_data(d)), nnz, rownnz.ptr, rowadr.ptr, colind.ptr, vals.ptr, _stream()))
+  return rownnz, rowadr, colind, vals
 
 
 def ctrl_noise(m, d, step_index: int, noise_std: float = 0.01, noise_rate: float = 0.1, center: DeviceArray = None):

@@ -595,6 +595,32 @@ def test_free_running_1000_steps_statistics():
         assert _ks(a, b) <= crit, (k, name, _ks(a, b), crit)
 
 
+def test_efc_J_sparse_view():
+  """The reference keeps efc.J in CSR form for nv > 32 (types.py:2021-2070); this engine keeps the dense tile and hands out the CSR
+  copy on request: rows, addresses and values must reproduce the dense Jacobian (G1, nv 35)."""
+  mjm = mjw.mjcf.load_xml(conftest.G1_XML)
+  s, m, d = _pair(mjm, nworld=3, nconmax=48, njmax=128, warm_steps=10)
+  mjw.forward(m, d)
+  rownnz, rowadr, colind, vals = mjw.efc_J_sparse(m, d)
+  assert colind.shape == (3, 1, d.njmax_nnz) and rownnz.shape == (3, d.njmax)
+  J = d.efc.J.numpy()
+  for w in range(3):
+    nefc = int(d.nefc.numpy()[w])
+    assert nefc > 10
+    dense = np.zeros((nefc, mjm.nv), dtype=np.float32)
+    for r in range(nefc):
+      a, n = int(rowadr.numpy()[w, r]), int(rownnz.numpy()[w, r])
+      cols = colind.numpy()[w, 0, a : a + n]
+      assert (np.diff(cols) > 0).all()
+      dense[r, cols] = vals.numpy()[w, 0, a : a + n]
+      assert (vals.numpy()[w, 0, a : a + n] != 0).all()
+    np.testing.assert_array_equal(dense, J[w, :nefc, : mjm.nv])
+    assert (rownnz.numpy()[w, nefc:] == 0).all()
+  # too small a buffer truncates and flags NJMAX_NNZ instead of writing out of bounds
+  mjw.efc_J_sparse(m, d, njmax_nnz=16)
+  assert (d.overflow.numpy() & int(mjw.OverflowType.NJMAX_NNZ)).all()
+
+
 def test_ctrl_noise_matches_oracle():
   mjm = mjw.mjcf.load_xml(conftest.HUMANOID_XML)
   s, m, d = _pair(mjm, nworld=64, nconmax=24, njmax=64, warm_steps=0)

@@ -363,3 +363,61 @@ def test_declared_schema_matches_arrays(xml):
   env.update(nworld=d.nworld, njmax=d.njmax, njmax_pad=d.njmax_pad, nv_pad=d.nv_pad, naconmax=d.naconmax, concap=d.concap, nccdworld=d.nccdworld, nccdword=d.nccdword)
   for obj in (m.opt, m.stat, m, d.contact, d.efc, d):
     _schema_check(obj, env, d.nworld)
+
+
+# The attributes of mujoco.MjModel / MjOption / MjStatistic that put_model / make_data may read: every name below is used by the
+# reference itself as `mjm.<name>` or declared as a Model field (checked against /root/reference/mujoco_warp/_src when this list
+# was written), so an object carrying exactly these -- the real mujoco.MjModel on the day the package is importable -- drops in.
+_MJMODEL_NAMES = set("""
+M_colind M_rowadr M_rownnz actuator_actadr actuator_actearly actuator_actlimited actuator_actnum actuator_actrange actuator_biasprm
+actuator_biastype actuator_ctrllimited actuator_ctrlrange actuator_dynprm actuator_dyntype actuator_forcelimited actuator_forcerange
+actuator_gainprm actuator_gaintype actuator_gear actuator_trnid actuator_trntype body_dofadr body_dofnum body_gravcomp body_inertia
+body_invweight0 body_ipos body_iquat body_jntadr body_jntnum body_mass body_mocapid body_parentid body_pos body_quat body_rootid
+body_subtreemass body_weldid dof_armature dof_bodyid dof_damping dof_dampingpoly dof_frictionloss dof_invweight0 dof_jntid dof_parentid
+dof_solimp dof_solref eq_active0 eq_data eq_obj1id eq_obj2id eq_solimp eq_solref eq_type exclude_signature geom_aabb geom_bodyid
+geom_conaffinity geom_condim geom_contype geom_friction geom_gap geom_margin geom_pos geom_priority geom_quat geom_rbound geom_size
+geom_solimp geom_solmix geom_solref geom_type jnt_actfrclimited jnt_actgravcomp jnt_axis jnt_bodyid jnt_dofadr jnt_limited jnt_margin
+jnt_pos jnt_qposadr jnt_range jnt_solimp jnt_solref jnt_stiffness jnt_stiffnesspoly jnt_type key_act key_ctrl key_mpos key_mquat key_qpos
+key_qvel key_time na nbody ncam neq nflex ngeom nhfield njnt nkey nlight nmesh nmocap npair nplugin nq nsensor nsite ntendon nu nv opt stat
+qpos0 qpos_spring site_bodyid site_pos site_quat pair_dim pair_friction pair_gap pair_geom1 pair_geom2 pair_margin pair_solimp pair_solref
+pair_solreffriction nexclude
+""".split())
+_MJOPTION_NAMES = set("ccd_iterations ccd_tolerance cone density disableflags enableflags gravity impratio integrator iterations ls_iterations "
+                      "ls_tolerance noslip_iterations solver timestep tolerance viscosity wind magnetic".split())
+
+
+class _StrictModel:
+  """Exposes only genuine mujoco.MjModel attribute names of the wrapped object; anything else raises AttributeError, exactly as a
+  real MjModel would."""
+
+  def __init__(self, obj, names, log):
+    object.__setattr__(self, "_obj", obj)
+    object.__setattr__(self, "_names", names)
+    object.__setattr__(self, "_log", log)
+
+  def __getattr__(self, k):
+    if k not in self._names:
+      raise AttributeError(f"'mujoco.MjModel' object has no attribute '{k}'")
+    self._log.add(k)
+    v = getattr(self._obj, k)
+    if k == "opt":
+      return _StrictModel(v, _MJOPTION_NAMES, self._log)
+    if k == "stat":
+      return _StrictModel(v, {"meaninertia", "meanmass", "meansize", "extent", "center"}, self._log)
+    return v
+
+
+@pytest.mark.parametrize("xml", ["humanoid", "g1", "panda"])
+def test_put_model_accepts_a_duck_typed_mjmodel(xml):
+  path = {"humanoid": conftest.HUMANOID_XML, "g1": conftest.G1_XML, "panda": conftest.PANDA_XML}[xml]
+  mjm = mjw.mjcf.load_xml(path)
+  log = set()
+  strict = _StrictModel(mjm, _MJMODEL_NAMES, log)
+  m = mjw.put_model(strict)
+  ref_m = mjw.put_model(mjm)
+  assert (m.nq, m.nv, m.nC, m.npair) == (ref_m.nq, ref_m.nv, ref_m.nC, ref_m.npair)
+  np.testing.assert_array_equal(m.body_inertia.numpy(), ref_m.body_inertia.numpy())
+  np.testing.assert_array_equal(m.geom_size.numpy(), ref_m.geom_size.numpy())
+  d = mjw.make_data(strict, nworld=2)
+  assert d.qpos.shape == (2, mjm.nq)
+  assert len(log) > 100  # the whole model was read through the strict view
