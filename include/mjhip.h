@@ -64,7 +64,8 @@ typedef struct MjhModel {
   int broadphase_filter; /* BroadphaseFilter bits (types.py:73-87): 1 plane, 2 sphere, 4 AABB, 8 OBB */
   /* options (types.py:836-905); solver: 0 = PGS (extension, the reference has none: types.py:502), 1 = CG, 2 = Newton */
   int integrator; int cone; int solver; int iterations; int ls_iterations; int disableflags; int enableflags;
-  int ccd_iterations;  /* GJK / EPA iteration cap of the convex narrowphase (capped at 64 by this engine) */
+  int ccd_iterations;  /* GJK iteration cap of the convex narrowphase (capped at 64 by this engine) */
+  int epa_iterations;  /* EPA iteration cap: 16 when every convex pair of the model is box-box, else ccd_iterations (collision_convex.py:1223) */
   const float* opt_timestep; int opt_timestep_nb;
   const float* opt_tolerance; int opt_tolerance_nb;
   const float* opt_ls_tolerance; int opt_ls_tolerance_nb;
@@ -243,7 +244,7 @@ int mjh_timed_steps(const MjhModel* m, const MjhData* d, int nstep, int step0, f
 int mjh_release_thread_resources(void);
 
 const char* mjh_last_error(void);
-#define MJH_ABI_VERSION 10
+#define MJH_ABI_VERSION 11
 int mjh_abi_version(void); /* returns MJH_ABI_VERSION of the library that was loaded */
 
 #ifdef __cplusplus

@@ -500,14 +500,24 @@ DEV int box_box(V3 P1, const float* R1, V3 S1, V3 P2, const float* R2, V3 S2, fl
 // convex pair through GJK / EPA (collision_convex.py:747-977): both geoms carry the pair's margin (support points are inflated by
 // half of it), the GJK cutoff is the gap, the reported distance is un-inflated, the contact sits midway between the witness points
 template <class Emit>
-DEV void collide_convex(float tolerance, int iterations, int t1, int t2, V3 p1, const float* R1, V3 s1, V3 p2, const float* R2, V3 s2, float margin,
+DEV void collide_convex(float tolerance, int iterations, int epa_iterations, int t1, int t2, V3 p1, const float* R1, V3 s1, V3 p2, const float* R2, V3 s2, float margin,
                         float gap, float* scratch, int& overflow, Emit&& emit) {
   const CcdGeom a = CcdGeom{t1, p1, R1, s1, margin}, b = CcdGeom{t2, p2, R2, s2, margin};
   float dist;
   V3 w1, w2;
-  const int n = ccd_run(tolerance, gap, iterations, iterations, a, b, scratch, dist, w1, w2, overflow);
+  int face;
+  Poly pt;
+  int n = ccd_run(tolerance, gap, iterations, epa_iterations, a, b, scratch, dist, w1, w2, overflow, face, pt);
   if (n == 0 || dist >= gap) return;
   dist += margin;
+  if (face >= 0) {  // two boxes, zero margin: up to four contacts from the EPA face, same distance and frame (collision_convex.py:888-960)
+    V3 m1[4], m2[4];
+    n = ccd_multicontact_box(pt, face, w1, w2, a, b, m1, m2);
+    if (n == 0) return;
+    const Frame f = make_frame3(dist <= margin ? m1[0] - m2[0] : m2[0] - m1[0]);
+    for (int i = 0; i < n; ++i) emit(i, dist, 0.5f * (m1[i] + m2[i]), f.a, f.b, f.c);
+    return;
+  }
   const Frame f = make_frame3(dist <= margin ? w1 - w2 : w2 - w1);
   emit(0, dist, 0.5f * (w1 + w2), f.a, f.b, f.c);
 }
@@ -987,9 +997,10 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
     }
   };
   // EPA polytope of this lane (convex.hpp): word k of lane l at k * 32 + l inside the world's slice of d.ws_ccd
-  float* ccd_scratch = (HEAVY && d.ws_ccd) ? d.ws_ccd + (size_t)w * ccd_words(m.ccd_iterations) * CCD_LANES + (lig & (CCD_LANES - 1)) : nullptr;
+  float* ccd_scratch = (HEAVY && d.ws_ccd) ? d.ws_ccd + (size_t)w * ccd_words(max(m.ccd_iterations, m.epa_iterations)) * CCD_LANES + (lig & (CCD_LANES - 1)) : nullptr;
   const float ccd_tol = HEAVY ? bf(m.opt_ccd_tolerance, m.opt_ccd_tolerance_nb, w, 1)[0] : 0.0f;
-  const int ccd_it = min(m.ccd_iterations, CCD_MAX_ITER);
+  const int ccd_it = min(m.ccd_iterations, CCD_MAX_ITER), epa_it = min(m.epa_iterations, CCD_MAX_ITER);
+  const bool box_ccd = !(m.disableflags & DSBL_NATIVECCD);  // box-box: CCD + multi-contact unless the flag asks for mjc_BoxBox
   int ccd_overflow = 0;
   int ncon = 0;
   for (int base = 0; base < ncand; base += G) {
@@ -1005,8 +1016,8 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
       const float gap = pid >= 0 ? m.pair_gap[pid] : ggap[g1] + ggap[g2];
       const float lim = margin + gap;
       auto count = [&](int k, float dist, V3, V3, V3, V3) { mask |= dist < lim ? (1u << (k & 7)) : 0u; };
-      if (HEAVY && is_convex_pair(t1, t2))
-        collide_convex(ccd_tol, ccd_it, t1, t2, ld3(gxpos + 3 * g1), gxmat + 9 * g1, ld3(gsize + 3 * g1), ld3(gxpos + 3 * g2), gxmat + 9 * g2, ld3(gsize + 3 * g2),
+      if (HEAVY && (is_convex_pair(t1, t2) || (box_ccd && t1 == G_BOX && t2 == G_BOX)))
+        collide_convex(ccd_tol, ccd_it, epa_it, t1, t2, ld3(gxpos + 3 * g1), gxmat + 9 * g1, ld3(gsize + 3 * g1), ld3(gxpos + 3 * g2), gxmat + 9 * g2, ld3(gsize + 3 * g2),
                        margin, gap, ccd_scratch, ccd_overflow, count);
       else
         collide_pair<HEAVY>(t1, t2, ld3(gxpos + 3 * g1), gxmat + 9 * g1, ld3(gsize + 3 * g1), ld3(gxpos + 3 * g2), gxmat + 9 * g2,
@@ -1074,8 +1085,8 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
                      }
                      ++slot;
                    };
-      if (HEAVY && is_convex_pair(t1, t2))
-        collide_convex(ccd_tol, ccd_it, t1, t2, ld3(gxpos + 3 * g1), gxmat + 9 * g1, ld3(gsize + 3 * g1), ld3(gxpos + 3 * g2), gxmat + 9 * g2, ld3(gsize + 3 * g2),
+      if (HEAVY && (is_convex_pair(t1, t2) || (box_ccd && t1 == G_BOX && t2 == G_BOX)))
+        collide_convex(ccd_tol, ccd_it, epa_it, t1, t2, ld3(gxpos + 3 * g1), gxmat + 9 * g1, ld3(gsize + 3 * g1), ld3(gxpos + 3 * g2), gxmat + 9 * g2, ld3(gsize + 3 * g2),
                        margin, pp.gap, ccd_scratch, ccd_overflow, write);
       else
         collide_pair<HEAVY>(t1, t2, ld3(gxpos + 3 * g1), gxmat + 9 * g1, ld3(gsize + 3 * g1), ld3(gxpos + 3 * g2), gxmat + 9 * g2,

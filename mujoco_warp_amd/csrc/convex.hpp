@@ -604,9 +604,11 @@ DEV int ccd_epa(float tolerance, int iterations, Poly& pt, const CcdGeom& g1, co
 }
 
 // gjk_phase + epa_phase: number of contacts (0 / 1), distance between the margin-inflated shapes and the witness points
+// face_out: the closest EPA face when the pair qualifies for multi-contact recovery (two boxes, zero margin), else -1
 DEV int ccd_run(float tolerance, float cutoff, int gjk_iterations, int epa_iterations, CcdGeom g1, CcdGeom g2, float* scratch, float& dist_out,
-                V3& x1, V3& x2, int& overflow) {
+                V3& x1, V3& x2, int& overflow, int& face_out, Poly& pt) {
   const CcdGeom o1 = g1, o2 = g2;
+  face_out = -1;
   float full1 = 0.0f, full2 = 0.0f, size1 = 0.0f, size2 = 0.0f;
   const bool is_discrete = g1.type == G_BOX && g2.type == G_BOX && g1.margin == 0.0f && g2.margin == 0.0f;
   GjkOut res;
@@ -645,7 +647,6 @@ DEV int ccd_run(float tolerance, float cutoff, int gjk_iterations, int epa_itera
   x1 = res.x1;
   x2 = res.x2;
   if (res.dist > tolerance || res.dim < 2 || res.separated) return 1;
-  Poly pt;
   poly_init(pt, scratch, epa_iterations);
   if (res.dim == 2) poly_seed2(pt, res, g1, g2);
   else if (res.dim == 4) poly_seed4(pt, res);
@@ -661,7 +662,301 @@ DEV int ccd_run(float tolerance, float cutoff, int gjk_iterations, int epa_itera
     return 0;
   }
   dist_out = dist;
+  if (g1.margin == 0.0f && g2.margin == 0.0f && g1.type == G_BOX && g2.type == G_BOX) face_out = idx;
   return 1;
+}
+
+// ---- multi-contact recovery for box pairs (collision_gjk.py:2076-2300, box branches) -------------------------------------------------
+// From the EPA face closest to the origin: the features (vertex / edge / face) of the two boxes it was built from, the box faces whose
+// normals oppose each other within FACE_TOL (or an edge perpendicular to a face within EDGE_TOL), then the clipping of one face (or
+// edge) against the side planes of the other, pruned to the quadrilateral of largest area.
+#define CCD_FACE_TOL 0.99999872f
+#define CCD_EDGE_TOL 0.0015999993f
+#define CCD_INTERSECT_TOL 0.0000003f
+DEV V3 mc_axis(int k, float v) { return V3{k == 0 ? v : 0.0f, k == 1 ? v : 0.0f, k == 2 ? v : 0.0f}; }
+DEV V3 mc_face_normal(int i) { return mc_axis(i >> 1, (i & 1) ? -1.0f : 1.0f); }
+DEV int mc_feature_dim(const Poly& pt, const int (&face)[3], int offset, int (&fi)[3], V3 (&fv)[3]) {
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    fi[k] = pt.vidx(2 * face[k] + offset);
+    fv[k] = pt.vert(2 * face[k] + offset);
+  }
+  if (fi[0] != fi[1]) return (fi[2] == fi[0] || fi[2] == fi[1]) ? 2 : 3;
+  fi[1] = fi[2];
+  fv[1] = fv[2];
+  return fi[0] != fi[2] ? 2 : 1;
+}
+DEV int mc_box_normals2(const float* mat, V3 n, V3 (&nout)[3], int (&iout)[3]) {
+  const V3 ln = normalize(matT_mul(mat, n));
+  for (int i = 0; i < 6; ++i)
+    if (dot(ln, mc_face_normal(i)) > CCD_FACE_TOL) {
+      nout[0] = mat_mul(mat, mc_face_normal(i));
+      iout[0] = i;
+      return 1;
+    }
+  return 0;
+}
+DEV int mc_box_normals(int dim, const int (&fi)[3], const float* mat, V3 dir, V3 (&nout)[3], int (&iout)[3]) {
+  const int v1 = fi[0], v2 = fi[1], v3_ = fi[2];
+  if (dim == 3) {
+    int c = 0;
+    float ax[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int b = 1 << k;
+      ax[k] = (float)((v1 & b) && (v2 & b) && (v3_ & b)) - (float)(!(v1 & b) && !(v2 & b) && !(v3_ & b));
+    }
+    nout[0] = mat_mul(mat, V3{ax[0], ax[1], ax[2]});
+    const float sgn = ax[0] + ax[1] + ax[2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      if (ax[k] != 0.0f) {
+        if (c == 0) iout[0] = 2 * k;
+        else if (c == 1) iout[1] = 2 * k;
+        else iout[2] = 2 * k;
+        ++c;
+      }
+    if (sgn == -1.0f) iout[0] = iout[0] + 1;
+    if (c == 1) return 1;
+    return mc_box_normals2(mat, dir, nout, iout);
+  }
+  if (dim == 2) {
+    int c = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int b = 1 << k;
+      const float a = (float)((v1 & b) && (v2 & b)) - (float)(!(v1 & b) && !(v2 & b));
+      if (a != 0.0f) {
+        const V3 nn = mat_mul(mat, mc_axis(k, a));
+        const int id = a > 0.0f ? 2 * k : 2 * k + 1;
+        if (c == 0) { nout[0] = nn; iout[0] = id; }
+        else if (c == 1) { nout[1] = nn; iout[1] = id; }
+        else { nout[2] = nn; iout[2] = id; }
+        ++c;
+      }
+    }
+    if (c == 1 || c == 2) return c;
+    return mc_box_normals2(mat, dir, nout, iout);
+  }
+  if (dim == 1) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float e = (v1 & (1 << k)) ? 1.0f : -1.0f;
+      nout[k] = mat_mul(mat, mc_axis(k, e));
+      iout[k] = e > 0.0f ? 2 * k : 2 * k + 1;
+    }
+    return 3;
+  }
+  return 0;
+}
+DEV int mc_box_edge_normals(int dim, const CcdGeom& g, V3 v1, V3 v2, int v1i, V3 (&nout)[3], V3 (&endv)[3]) {
+  if (dim == 2) {
+    endv[0] = v2;
+    nout[0] = normalize(v2 - v1);
+    return 1;
+  }
+  if (dim == 1) {
+    const float c[3] = {(v1i & 1) ? g.size.x : -g.size.x, (v1i & 2) ? g.size.y : -g.size.y, (v1i & 4) ? g.size.z : -g.size.z};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const V3 a = V3{k == 0 ? -c[0] : c[0], k == 1 ? -c[1] : c[1], k == 2 ? -c[2] : c[2]};
+      endv[k] = mat_mul(g.rot, a) + g.pos;
+      nout[k] = normalize(endv[k] - v1);
+    }
+    return 3;
+  }
+  return 0;
+}
+DEV int mc_box_face(const CcdGeom& g, int idx, V3 (&face)[4]) {
+  if (idx < 0 || idx > 5) return 0;
+  // corner signs of the six faces in the reference's vertex order (collision_gjk.py:1848-1888)
+  const float S[6][4][3] = {{{1, 1, 1}, {1, 1, -1}, {1, -1, -1}, {1, -1, 1}},     {{-1, 1, -1}, {-1, 1, 1}, {-1, -1, 1}, {-1, -1, -1}},
+                            {{-1, 1, -1}, {1, 1, -1}, {1, 1, 1}, {-1, 1, 1}},     {{-1, -1, 1}, {1, -1, 1}, {1, -1, -1}, {-1, -1, -1}},
+                            {{-1, 1, 1}, {1, 1, 1}, {1, -1, 1}, {-1, -1, 1}},     {{1, 1, -1}, {-1, 1, -1}, {-1, -1, -1}, {1, -1, -1}}};
+  for (int i = 0; i < 4; ++i) face[i] = mat_mul(g.rot, V3{S[idx][i][0] * g.size.x, S[idx][i][1] * g.size.y, S[idx][i][2] * g.size.z}) + g.pos;
+  return 4;
+}
+DEV float mc_area4(V3 a, V3 b, V3 c, V3 d) { return 0.5f * length(cross(a - d, d - b) + cross(b - c, c - a)); }
+DEV void mc_polygon_quad(const V3* poly, int n, int (&res)[4]) {
+  int b = 1, c = 2, d = 3;
+  res[0] = 0; res[1] = b; res[2] = c; res[3] = d;
+  float m = mc_area4(poly[0], poly[b], poly[c], poly[d]);
+  for (int a = 0; a < n; ++a) {
+    for (;;) {
+      float mn = mc_area4(poly[a], poly[b], poly[c], poly[(d + 1) % n]);
+      if (mn <= m) break;
+      m = mn;
+      d = (d + 1) % n;
+      res[0] = a; res[1] = b; res[2] = c; res[3] = d;
+      for (;;) {
+        mn = mc_area4(poly[a], poly[b], poly[(c + 1) % n], poly[d]);
+        if (mn <= m) break;
+        m = mn;
+        c = (c + 1) % n;
+        res[0] = a; res[1] = b; res[2] = c; res[3] = d;
+      }
+      for (;;) {
+        mn = mc_area4(poly[a], poly[(b + 1) % n], poly[c], poly[d]);
+        if (mn <= m) break;
+        m = mn;
+        b = (b + 1) % n;
+        res[0] = a; res[1] = b; res[2] = c; res[3] = d;
+      }
+    }
+    if (b == a) {
+      b = (b + 1) % n;
+      if (c == b) {
+        c = (c + 1) % n;
+        if (d == c) d = (d + 1) % n;
+      }
+    }
+  }
+}
+// clip polygon face2 against the side planes of face1 (normal n): w2 = clipped points, w1 = w2 - dir; returns the number of contacts
+DEV int mc_polygon_clip(const V3 (&face1)[4], int nface1, const V3 (&face2)[4], int nface2, V3 n, V3 dir, V3 (&w1)[4], V3 (&w2)[4]) {
+  if (nface1 < 3) return 0;
+  V3 pn[4], bufa[8], bufb[8];
+  float pd[4];
+  V3* poly = bufa;
+  V3* clip = bufb;
+  for (int i = 0; i < nface1; ++i) {
+    const V3 a = face1[i], b = face1[(i + 1) % nface1];
+    pn[i] = cross(b - a, (a + n) - a);
+    pd[i] = dot(pn[i], a);
+  }
+  int np = nface2, nc = 0;
+  for (int i = 0; i < nface2; ++i) poly[i] = face2[i];
+  for (int e = 0; e < nface1; ++e) {
+    for (int i = 0; i < np; ++i) {
+      const V3 P = poly[i], Q = poly[(i + 1) % np];
+      const bool in1 = dot(P - face1[e], pn[e]) > -1e-10f, in2 = dot(Q - face1[e], pn[e]) > -1e-10f;
+      if (!in1 && !in2) continue;
+      if (in1 && in2) {
+        if (nc < 8) clip[nc] = Q;
+        ++nc;
+        continue;
+      }
+      const V3 pq = Q - P;
+      const float dt = dot(pn[e], pq);
+      float t = fabsf(dt) < 1e-10f ? CCD_FLOAT_MAX : (pd[e] - dot(pn[e], P)) / dt;
+      if (t > -CCD_INTERSECT_TOL && t < 1.0f + CCD_INTERSECT_TOL) {
+        t = clampf(t, 0.0f, 1.0f);
+        if (nc < 8) clip[nc] = P + t * pq;
+        ++nc;
+      }
+      if (in2) {
+        if (nc < 8) clip[nc] = Q;
+        ++nc;
+      }
+    }
+    if (nc > 8) nc = 8;
+    V3* tmp = poly;
+    poly = clip;
+    clip = tmp;
+    np = nc;
+    nc = 0;
+  }
+  if (np < 1) return 0;
+  if (nface2 == 2 && np > 2) {
+    int b1 = 0, b2 = 1;
+    float maxd = 0.0f;
+    for (int i = 0; i < np; ++i)
+      for (int j = i + 1; j < np; ++j) {
+        const V3 df = poly[j] - poly[i];
+        const float d2 = dot(df, df);
+        if (d2 > maxd) {
+          maxd = d2;
+          b1 = i;
+          b2 = j;
+        }
+      }
+    w2[0] = poly[b1];
+    w1[0] = w2[0] - dir;
+    w2[1] = poly[b2];
+    w1[1] = w2[1] - dir;
+    return 2;
+  }
+  if (np > 4) {
+    int q[4];
+    mc_polygon_quad(poly, np, q);
+    for (int i = 0; i < 4; ++i) {
+      w2[i] = poly[q[i]];
+      w1[i] = w2[i] - dir;
+    }
+    return 4;
+  }
+  for (int i = 0; i < np; ++i) {
+    w2[i] = poly[i];
+    w1[i] = w2[i] - dir;
+  }
+  return np;
+}
+DEV int ccd_multicontact_box(const Poly& pt, int epa_face, V3 x1, V3 x2, const CcdGeom& g1, const CcdGeom& g2, V3 (&w1)[4], V3 (&w2)[4]) {
+  w1[0] = x1;
+  w2[0] = x2;
+  const unsigned fc = (unsigned)pt.face(epa_face);
+  const int face[3] = {(int)(fc & 0x3FF), (int)((fc >> 10) & 0x3FF), (int)((fc >> 20) & 0x3FF)};
+  int fi1[3], fi2[3], idx1[3] = {0, 0, 0}, idx2[3] = {0, 0, 0};
+  V3 fv1[3], fv2[3], n1[3], n2[3], endv[3];
+  const int nf1 = mc_feature_dim(pt, face, 0, fi1, fv1), nf2 = mc_feature_dim(pt, face, 1, fi2, fv2);
+  const V3 dir = x2 - x1;
+  int nn1 = mc_box_normals(nf1, fi1, g1.rot, -dir, n1, idx1), nn2 = mc_box_normals(nf2, fi2, g2.rot, dir, n2, idx2);
+  bool edge1 = false, edge2 = false, found = false;
+  int ri = 0, rj = 0;
+  for (int i = 0; i < nn1 && !found; ++i)
+    for (int j = 0; j < nn2 && !found; ++j)
+      if (dot(n1[i], n2[j]) < -CCD_FACE_TOL) {
+        ri = i;
+        rj = j;
+        found = true;
+      }
+  if (!found) {
+    if (nf1 < 3 && nf1 <= nf2) {
+      nn1 = mc_box_edge_normals(nf1, g1, fv1[0], fv1[1], fi1[0], n1, endv);
+      for (int i = 0; i < nn2 && !found; ++i)
+        for (int j = 0; j < nn1 && !found; ++j)
+          if (fabsf(dot(n1[j], n2[i])) < CCD_EDGE_TOL) {
+            ri = j;
+            rj = i;
+            found = true;
+          }
+      if (!found) return 1;
+      edge1 = true;
+    } else if (nf2 < 3) {
+      nn2 = mc_box_edge_normals(nf2, g2, fv2[0], fv2[1], fi2[0], n2, endv);
+      for (int i = 0; i < nn1 && !found; ++i)
+        for (int j = 0; j < nn2 && !found; ++j)
+          if (fabsf(dot(n2[j], n1[i])) < CCD_EDGE_TOL) {
+            ri = j;
+            rj = i;
+            found = true;
+          }
+      if (!found) return 1;
+      edge2 = true;
+    } else {
+      return 1;
+    }
+  }
+  V3 face1[4], face2[4];
+  int nface1, nface2;
+  if (edge1) {
+    face1[0] = pt.vert(2 * face[0]);
+    face1[1] = endv[ri];
+    nface1 = 2;
+  } else {
+    nface1 = mc_box_face(g1, edge2 ? idx1[rj] : idx1[ri], face1);
+  }
+  if (edge2) {
+    face2[0] = pt.vert(2 * face[0] + 1);
+    face2[1] = endv[ri];
+    nface2 = 2;
+  } else {
+    nface2 = mc_box_face(g2, idx2[rj], face2);
+  }
+  const float dn = length(dir);
+  if (edge1) return mc_polygon_clip(face2, nface2, face1, nface1, n2[rj], (-dn) * n2[rj], w2, w1);
+  if (edge2) return mc_polygon_clip(face1, nface1, face2, nface2, n1[rj], (-dn) * n1[rj], w1, w2);
+  return mc_polygon_clip(face1, nface1, face2, nface2, n1[ri], dn * n2[rj], w1, w2);
 }
 
 DEV bool is_convex_pair(int t1, int t2) {

@@ -87,8 +87,8 @@ def geom_pairs_with_ids(mjm):
 
 
 _SUPPORTED_PAIRS = {(0, 2), (0, 3), (0, 4), (0, 5), (0, 6), (2, 2), (2, 3), (2, 5), (2, 6), (3, 3), (3, 6), (6, 6)}
-# pairs of the reference's CONVEX class (collision_driver.py:47-80) that go through GJK / EPA (csrc/convex.hpp); box-box stays on the
-# primitive collider (the reference's choice when DisableBit.NATIVECCD is set, collision_driver.py:867-870)
+# pairs of the reference's CONVEX class (collision_driver.py:47-80) that go through GJK / EPA (csrc/convex.hpp); box-box joins them
+# unless DisableBit.NATIVECCD is set (collision_driver.py:867-870), see put_model
 _CONVEX_PAIRS = {(2, 4), (3, 4), (3, 5), (4, 4), (4, 5), (4, 6), (5, 5), (5, 6)}
 
 
@@ -192,7 +192,15 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
   m.nC = int(np.sum(mjm.M_rownnz)) if nv else 0
   m.nM = m.nC
   # capsule-box / box-box pairs and explicit contact pairs select the kernel instantiation that carries them (include/mjhip.h)
-  m._convex_pairs = int(any((int(min(gt[a], gt[b])), int(max(gt[a], gt[b]))) in _CONVEX_PAIRS for a, b in pairs))
+  ptypes = [(int(min(gt[a], gt[b])), int(max(gt[a], gt[b]))) for a, b in pairs]
+  # box-box is a CONVEX pair (GJK / EPA + multi-contact) unless DisableBit.NATIVECCD selects the primitive collider
+  # (reference collision_driver.py:78, 867-870)
+  box_ccd = not (int(opt.disableflags) & int(types.DisableBit.NATIVECCD))
+  nboxbox = sum(t == (6, 6) for t in ptypes) if box_ccd else 0
+  nconvex = sum(t in _CONVEX_PAIRS for t in ptypes)
+  m._convex_pairs = int(nconvex + nboxbox > 0)
+  # EPA iteration cap (reference collision_convex.py:1223): 16 when every convex pair of the model is box-box
+  m._epa_iterations = 16 if (nboxbox > 0 and nconvex == 0) else int(getattr(opt, "ccd_iterations", 35))
   m._heavy_pairs = int(any((int(min(gt[a], gt[b])), int(max(gt[a], gt[b]))) in ((3, 6), (6, 6)) for a, b in pairs) or int(getattr(mjm, "npair", 0)) > 0
                        or m._convex_pairs)
   m.heavy_colliders = m._heavy_pairs  # c_model() adds the broadphase options (they may be changed after put_model)
@@ -213,6 +221,7 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
   for name in ("integrator", "cone", "solver", "iterations", "ls_iterations", "disableflags", "enableflags"):
     setattr(o, name, int(getattr(opt, name)))
   o.ccd_iterations = int(getattr(opt, "ccd_iterations", 35))
+  m.epa_iterations = m._epa_iterations
   # reference io.py:631-636: NXN below 250k filtered pairs, SAP above (tile sort below 1000 geoms)
   o.broadphase = (types.BroadphaseType.NXN if len(pairs) < 250_000 else
                   types.BroadphaseType.SAP_TILE if ngeom_ < 1000 else types.BroadphaseType.SAP_SEGMENTED)
@@ -420,7 +429,7 @@ def _data_shapes(m, nworld, nconmax, njmax, naconmax):
     contact_geomcollisionid=(naconmax,),
     efc_type=(W, njmax), efc_id=(W, njmax), efc_state=(W, njmax), efc_J=(W, njmax_pad, nv_pad), efc_pos=(W, njmax),
     efc_margin=(W, njmax), efc_D=(W, njmax), efc_vel=(W, njmax), efc_aref=(W, njmax), efc_frictionloss=(W, njmax),
-    efc_force=(W, njmax), ws_ncon=(W,), ws_conadr=(W,), ws_ncollision=(W,), ws_efc_con=(W, njmax), ws_order=(W,), ws_ccd=(W if m._convex_pairs else 0, _ccd_words(m.opt.ccd_iterations), 32),
+    efc_force=(W, njmax), ws_ncon=(W,), ws_conadr=(W,), ws_ncollision=(W,), ws_efc_con=(W, njmax), ws_order=(W,), ws_ccd=(W if m._convex_pairs else 0, _ccd_words(max(int(m.opt.ccd_iterations), int(m.epa_iterations))), 32),
     eq_active=(W, m.neq), ws_rk=(W, nq + 3 * nv + 2 * na), ws_contact=(W, contact_cap(nconmax), 32),
   )
   return sh, njmax_pad, nv_pad

@@ -378,6 +378,7 @@ class Model(_Dirty):
   nbodylevel: int = 0
   ndoflevel: int = 0
   nmaxcondim: int = 0
+  epa_iterations: int = 0  # EPA iteration cap of the convex narrowphase (reference collision_convex.py:1223)
   nmaxpyramid: int = 0
   key_qpos: np.ndarray = _arr(('nkey', 'nq'), "float32", host=True)
   key_qvel: np.ndarray = _arr(('nkey', 'nv'), "float32", host=True)

@@ -626,3 +626,275 @@ static int ccd_run(double tolerance, double cutoff, int gjk_iterations, int epa_
   if (g1.margin == 0.0 && g2.margin == 0.0 && g1.type == G_BOX && g2.type == G_BOX) *face_out = idx;
   return 1;
 }
+
+/* ---- multi-contact recovery for box pairs (collision_gjk.py:2076-2300 multicontact, box branches only) -------------------------------
+ * From the EPA face closest to the origin: the features (vertex / edge / face) of the two boxes it was built from, the box
+ * faces whose normals oppose each other within FACE_TOL (or an edge perpendicular to a face within EDGE_TOL), then the clipping of
+ * one face (or edge) against the side planes of the other (Sutherland-Hodgman), pruned to the quadrilateral of largest area. */
+#define CCD_FACE_TOL 0.99999872000027307    /* cos(0.0016) */
+#define CCD_EDGE_TOL 0.0015999993173334207  /* sin(0.0016) */
+#define CCD_INTERSECT_TOL 0.0000003
+
+static int mc_feature_dim(const Polytope* pt, const int* face, int offset, int* fidx, double fvert[3][3]) { /* 1503-1526 */
+  for (int k = 0; k < 3; k++) {
+    fidx[k] = pt->vidx[2 * face[k] + offset];
+    v3cpy(fvert[k], pt->vert[2 * face[k] + offset]);
+  }
+  if (fidx[0] != fidx[1]) return (fidx[2] == fidx[0] || fidx[2] == fidx[1]) ? 2 : 3;
+  fidx[1] = fidx[2];
+  v3cpy(fvert[1], fvert[2]);
+  return fidx[0] != fidx[2] ? 2 : 1;
+}
+static const double MC_FACE_NORMALS[6][3] = {{1, 0, 0}, {-1, 0, 0}, {0, 1, 0}, {0, -1, 0}, {0, 0, 1}, {0, 0, -1}};
+static int mc_box_normals2(const double* mat, const double* n, double nout[3][3], int* iout) { /* 1703-1733 */
+  double ln[3];
+  matT_mul_vec(ln, mat, n);
+  v3normalize(ln);
+  for (int i = 0; i < 6; i++)
+    if (v3dot(ln, MC_FACE_NORMALS[i]) > CCD_FACE_TOL) {
+      mat_mul_vec(nout[0], mat, MC_FACE_NORMALS[i]);
+      iout[0] = i;
+      return 1;
+    }
+  return 0;
+}
+static int mc_box_normals(int dim, const int* fi, const double* mat, const double* dir, double nout[3][3], int* iout) { /* 1736-1807 */
+  int v1 = fi[0], v2 = fi[1], v3 = fi[2];
+  if (dim == 3) {
+    int c = 0;
+    double ax[3];
+    for (int k = 0; k < 3; k++) {
+      int b = 1 << k;
+      ax[k] = (double)((v1 & b) && (v2 & b) && (v3 & b)) - (double)(!(v1 & b) && !(v2 & b) && !(v3 & b));
+    }
+    mat_mul_vec(nout[0], mat, ax);
+    double sgn = ax[0] + ax[1] + ax[2];
+    for (int k = 0; k < 3; k++)
+      if (ax[k] != 0.0) iout[c++] = 2 * k;
+    if (sgn == -1.0) iout[0] = iout[0] + 1;
+    if (c == 1) return 1;
+    return mc_box_normals2(mat, dir, nout, iout);
+  }
+  if (dim == 2) {
+    int c = 0;
+    for (int k = 0; k < 3; k++) {
+      int b = 1 << k;
+      double a = (double)((v1 & b) && (v2 & b)) - (double)(!(v1 & b) && !(v2 & b));
+      if (a != 0.0) {
+        double e[3] = {0, 0, 0};
+        e[k] = a;
+        mat_mul_vec(nout[c], mat, e);
+        iout[c] = a > 0.0 ? 2 * k : 2 * k + 1;
+        c++;
+      }
+    }
+    if (c == 1 || c == 2) return c; /* 1: diagonal of a face, 2: a box edge */
+    return mc_box_normals2(mat, dir, nout, iout);
+  }
+  if (dim == 1) {
+    for (int k = 0; k < 3; k++) {
+      double e[3] = {0, 0, 0};
+      e[k] = (v1 & (1 << k)) ? 1.0 : -1.0;
+      mat_mul_vec(nout[k], mat, e);
+      iout[k] = e[k] > 0.0 ? 2 * k : 2 * k + 1;
+    }
+    return 3;
+  }
+  return 0;
+}
+static int mc_box_edge_normals(int dim, const CcdGeom* g, const double* v1, const double* v2, int v1i, double nout[3][3], double endv[3][3]) {
+  if (dim == 2) { /* 1810-1845 */
+    v3cpy(endv[0], v2);
+    v3sub(nout[0], v2, v1);
+    v3normalize(nout[0]);
+    return 1;
+  }
+  if (dim == 1) {
+    double c[3] = {(v1i & 1) ? g->size[0] : -g->size[0], (v1i & 2) ? g->size[1] : -g->size[1], (v1i & 4) ? g->size[2] : -g->size[2]};
+    for (int k = 0; k < 3; k++) {
+      double a[3] = {c[0], c[1], c[2]};
+      a[k] = -a[k];
+      mat_mul_vec(endv[k], g->rot, a);
+      v3add(endv[k], endv[k], g->pos);
+      v3sub(nout[k], endv[k], v1);
+      v3normalize(nout[k]);
+    }
+    return 3;
+  }
+  return 0;
+}
+static int mc_box_face(const CcdGeom* g, int idx, double face[4][3]) { /* 1848-1888 */
+  static const double C[6][4][3] = {
+    {{1, 1, 1}, {1, 1, -1}, {1, -1, -1}, {1, -1, 1}},     {{-1, 1, -1}, {-1, 1, 1}, {-1, -1, 1}, {-1, -1, -1}},
+    {{-1, 1, -1}, {1, 1, -1}, {1, 1, 1}, {-1, 1, 1}},     {{-1, -1, 1}, {1, -1, 1}, {1, -1, -1}, {-1, -1, -1}},
+    {{-1, 1, 1}, {1, 1, 1}, {1, -1, 1}, {-1, -1, 1}},     {{1, 1, -1}, {-1, 1, -1}, {-1, -1, -1}, {1, -1, -1}}};
+  if (idx < 0 || idx > 5) return 0;
+  for (int i = 0; i < 4; i++) {
+    double c[3] = {C[idx][i][0] * g->size[0], C[idx][i][1] * g->size[1], C[idx][i][2] * g->size[2]};
+    mat_mul_vec(face[i], g->rot, c);
+    v3add(face[i], face[i], g->pos);
+  }
+  return 4;
+}
+static double mc_area4(const double* a, const double* b, const double* c, const double* d) { /* 1457 */
+  double ad[3], db[3], bc[3], ca[3], x1[3], x2[3];
+  v3sub(ad, a, d); v3sub(db, d, b); v3sub(bc, b, c); v3sub(ca, c, a);
+  v3cross(x1, ad, db);
+  v3cross(x2, bc, ca);
+  v3add(x1, x1, x2);
+  return 0.5 * v3len(x1);
+}
+static void mc_polygon_quad(double poly[][3], int n, int* res) { /* 1463-1499: rotating search for the largest quadrilateral */
+  int b = 1, c = 2, d = 3;
+  res[0] = 0; res[1] = b; res[2] = c; res[3] = d;
+  double m = mc_area4(poly[0], poly[b], poly[c], poly[d]);
+  for (int a = 0; a < n; a++) {
+    for (;;) {
+      double mn = mc_area4(poly[a], poly[b], poly[c], poly[(d + 1) % n]);
+      if (mn <= m) break;
+      m = mn;
+      d = (d + 1) % n;
+      res[0] = a; res[1] = b; res[2] = c; res[3] = d;
+      for (;;) {
+        mn = mc_area4(poly[a], poly[b], poly[(c + 1) % n], poly[d]);
+        if (mn <= m) break;
+        m = mn;
+        c = (c + 1) % n;
+        res[0] = a; res[1] = b; res[2] = c; res[3] = d;
+      }
+      for (;;) {
+        mn = mc_area4(poly[a], poly[(b + 1) % n], poly[c], poly[d]);
+        if (mn <= m) break;
+        m = mn;
+        b = (b + 1) % n;
+        res[0] = a; res[1] = b; res[2] = c; res[3] = d;
+      }
+    }
+    if (b == a) {
+      b = (b + 1) % n;
+      if (c == b) {
+        c = (c + 1) % n;
+        if (d == c) d = (d + 1) % n;
+      }
+    }
+  }
+}
+/* clip polygon face2 against the side planes of face1 (normal n); returns the number of contacts, w2 = clipped points, w1 = w2 - dir */
+static int mc_polygon_clip(double face1[4][3], int nface1, double face2[4][3], int nface2, const double* n, const double* dir, double w1[4][3],
+                           double w2[4][3]) { /* 1941-2056 */
+  if (nface1 < 3) return 0;
+  double pn[4][3], pd[4], bufa[8][3], bufb[8][3];
+  double(*poly)[3] = bufa;
+  double(*clip)[3] = bufb;
+  for (int i = 0; i < nface1; i++) {
+    const double *a = face1[i], *b = face1[(i + 1) % nface1];
+    double v3[3], e1[3], e2[3];
+    v3add(v3, a, n);
+    v3sub(e1, b, a);
+    v3sub(e2, v3, a);
+    v3cross(pn[i], e1, e2);
+    pd[i] = v3dot(pn[i], a);
+  }
+  int np = nface2, nc = 0;
+  for (int i = 0; i < nface2; i++) v3cpy(poly[i], face2[i]);
+  for (int e = 0; e < nface1; e++) {
+    for (int i = 0; i < np; i++) {
+      const double *P = poly[i], *Q = poly[(i + 1) % np];
+      double dp[3], dq[3];
+      v3sub(dp, P, face1[e]);
+      v3sub(dq, Q, face1[e]);
+      int in1 = v3dot(dp, pn[e]) > -1e-10, in2 = v3dot(dq, pn[e]) > -1e-10;
+      if (!in1 && !in2) continue;
+      if (in1 && in2) { if (nc < 8) v3cpy(clip[nc], Q); nc++; continue; }
+      double pq[3];
+      v3sub(pq, Q, P);
+      double dt = v3dot(pn[e], pq), t = fabs(dt) < 1e-10 ? CCD_FLOAT_MAX : (pd[e] - v3dot(pn[e], P)) / dt;
+      if (t > -CCD_INTERSECT_TOL && t < 1.0 + CCD_INTERSECT_TOL) {
+        t = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
+        if (nc < 8) v3addscl(clip[nc], P, pq, t);
+        nc++;
+      }
+      if (in2) { if (nc < 8) v3cpy(clip[nc], Q); nc++; }
+    }
+    if (nc > 8) nc = 8; /* (2 * npolygonmax = 8 slots in the reference's buffers) */
+    double(*tmp)[3] = poly; poly = clip; clip = tmp;
+    np = nc;
+    nc = 0;
+  }
+  if (np < 1) return 0;
+  if (nface2 == 2 && np > 2) { /* an edge: keep the two points farthest apart */
+    int b1 = 0, b2 = 1;
+    double maxd = 0.0;
+    for (int i = 0; i < np; i++)
+      for (int j = i + 1; j < np; j++) {
+        double df[3];
+        v3sub(df, poly[j], poly[i]);
+        double d2 = v3dot(df, df);
+        if (d2 > maxd) { maxd = d2; b1 = i; b2 = j; }
+      }
+    v3cpy(w2[0], poly[b1]); v3sub(w1[0], w2[0], dir);
+    v3cpy(w2[1], poly[b2]); v3sub(w1[1], w2[1], dir);
+    return 2;
+  }
+  if (np > 4) {
+    int q[4];
+    mc_polygon_quad(poly, np, q);
+    for (int i = 0; i < 4; i++) { v3cpy(w2[i], poly[q[i]]); v3sub(w1[i], w2[i], dir); }
+    return 4;
+  }
+  for (int i = 0; i < np; i++) { v3cpy(w2[i], poly[i]); v3sub(w1[i], w2[i], dir); }
+  return np;
+}
+/* returns the number of contacts (>= 1) and their witness points; x1 / x2 = EPA's witness points (contact 0 when nothing is recovered) */
+static int ccd_multicontact_box(const Polytope* pt, int epa_face, const double* x1, const double* x2, const CcdGeom* g1, const CcdGeom* g2,
+                                double w1[4][3], double w2[4][3]) {
+  v3cpy(w1[0], x1);
+  v3cpy(w2[0], x2);
+  const int* face = pt->fv[epa_face];
+  int fi1[3], fi2[3], idx1[3], idx2[3];
+  double fv1[3][3], fv2[3][3], n1[3][3], n2[3][3], endv[3][3], dir[3], dneg[3];
+  int nf1 = mc_feature_dim(pt, face, 0, fi1, fv1), nf2 = mc_feature_dim(pt, face, 1, fi2, fv2);
+  v3sub(dir, x2, x1);
+  for (int k = 0; k < 3; k++) dneg[k] = -dir[k];
+  int nn1 = mc_box_normals(nf1, fi1, g1->rot, dneg, n1, idx1), nn2 = mc_box_normals(nf2, fi2, g2->rot, dir, n2, idx2);
+  int edge1 = 0, edge2 = 0, found = 0, ri = 0, rj = 0;
+  for (int i = 0; i < nn1 && !found; i++) /* _aligned_faces 1529 */
+    for (int j = 0; j < nn2 && !found; j++)
+      if (v3dot(n1[i], n2[j]) < -CCD_FACE_TOL) { ri = i; rj = j; found = 1; }
+  if (!found) {
+    if (nf1 < 3 && nf1 <= nf2) { /* an edge (or vertex) of box 1 against a face of box 2 */
+      nn1 = mc_box_edge_normals(nf1, g1, fv1[0], fv1[1], fi1[0], n1, endv);
+      for (int i = 0; i < nn2 && !found; i++) /* _aligned_face_edge(edge = n1, face = n2) 1543 */
+        for (int j = 0; j < nn1 && !found; j++)
+          if (fabs(v3dot(n1[j], n2[i])) < CCD_EDGE_TOL) { ri = j; rj = i; found = 1; }
+      if (!found) return 1;
+      edge1 = 1;
+    } else if (nf2 < 3) {
+      nn2 = mc_box_edge_normals(nf2, g2, fv2[0], fv2[1], fi2[0], n2, endv);
+      for (int i = 0; i < nn1 && !found; i++)
+        for (int j = 0; j < nn2 && !found; j++)
+          if (fabs(v3dot(n2[j], n1[i])) < CCD_EDGE_TOL) { ri = j; rj = i; found = 1; }
+      if (!found) return 1;
+      edge2 = 1;
+    } else {
+      return 1;
+    }
+  }
+  double face1[4][3], face2[4][3], approx[3];
+  int nface1, nface2;
+  if (edge1) { v3cpy(face1[0], pt->vert[2 * face[0]]); v3cpy(face1[1], endv[ri]); nface1 = 2; }
+  else nface1 = mc_box_face(g1, edge2 ? idx1[rj] : idx1[ri], face1);
+  if (edge2) { v3cpy(face2[0], pt->vert[2 * face[0] + 1]); v3cpy(face2[1], endv[ri]); nface2 = 2; }
+  else nface2 = mc_box_face(g2, idx2[rj], face2);
+  double dn = v3len(dir);
+  if (edge1) { /* clip the edge of box 1 against the face of box 2; the roles of the witness arrays swap back afterwards */
+    for (int k = 0; k < 3; k++) approx[k] = -dn * n2[rj][k];
+    return mc_polygon_clip(face2, nface2, face1, nface1, n2[rj], approx, w2, w1);
+  }
+  if (edge2) {
+    for (int k = 0; k < 3; k++) approx[k] = -dn * n1[rj][k];
+    return mc_polygon_clip(face1, nface1, face2, nface2, n1[rj], approx, w1, w2);
+  }
+  for (int k = 0; k < 3; k++) approx[k] = dn * n2[rj][k];
+  return mc_polygon_clip(face1, nface1, face2, nface2, n1[ri], approx, w1, w2);
+}

@@ -24,7 +24,7 @@ enum { CT_EQUALITY = 0, CT_FRICTION_DOF = 1, CT_FRICTION_TENDON = 2, CT_LIMIT_JO
        CT_CONTACT_FRICTIONLESS = 5, CT_CONTACT_PYRAMIDAL = 6, CT_CONTACT_ELLIPTIC = 7 };
 enum { DSBL_CONSTRAINT = 1 << 0, DSBL_EQUALITY = 1 << 1, DSBL_FRICTIONLOSS = 1 << 2, DSBL_LIMIT = 1 << 3, DSBL_CONTACT = 1 << 4,
        DSBL_SPRING = 1 << 5, DSBL_DAMPER = 1 << 6, DSBL_GRAVITY = 1 << 7, DSBL_CLAMPCTRL = 1 << 8,
-       DSBL_WARMSTART = 1 << 9, DSBL_ACTUATION = 1 << 11, DSBL_REFSAFE = 1 << 12, DSBL_EULERDAMP = 1 << 15 };
+       DSBL_WARMSTART = 1 << 9, DSBL_ACTUATION = 1 << 11, DSBL_REFSAFE = 1 << 12, DSBL_EULERDAMP = 1 << 15, DSBL_NATIVECCD = 1 << 17 };
 enum { SOL_PGS = 0, SOL_CG = 1, SOL_NEWTON = 2 };
 enum { INT_EULER = 0, INT_RK4 = 1, INT_IMPLICIT = 2, INT_IMPLICITFAST = 3 };
 enum { OVF_NEFC = 1 << 0, OVF_NARROW = 1 << 3, OVF_ITER = 1 << 9, OVF_LS = 1 << 10 };
@@ -1058,19 +1058,28 @@ static int ccd_contact(const RefModel* m, int t1, const double* p1, const double
   v3cpy(a.size, s1); v3cpy(b.size, s2);
   a.margin = b.margin = margin;
   static Polytope pt; /* (the oracle is single threaded) */
-  double dist, w1[3], w2[3], nrm[3];
+  double dist, w1[4][3], w2[4][3], nrm[3];
   int face;
-  int n = ccd_run(m->ccd_tolerance, gap, m->ccd_iterations, m->ccd_iterations, a, b, &dist, w1, w2, overflow, &face, &pt);
+  int n = ccd_run(m->ccd_tolerance, gap, m->ccd_iterations, m->epa_iterations, a, b, &dist, w1[0], w2[0], overflow, &face, &pt);
   if (n == 0 || dist >= gap) return 0;
   dist += margin;
-  if (dist <= margin) v3sub(nrm, w1, w2); /* overlapping: witness 1 has crossed witness 2 */
-  else v3sub(nrm, w2, w1);
-  out[0].dist = dist;
-  for (int k = 0; k < 3; k++) out[0].pos[k] = 0.5 * (w1[k] + w2[k]);
-  make_frame(out[0].frame, nrm);
-  return 1;
+  if (face >= 0) { /* box pair, zero margin: recover up to four contacts from the EPA face (collision_convex.py:888-917) */
+    double x1[3], x2[3];
+    v3cpy(x1, w1[0]);
+    v3cpy(x2, w2[0]);
+    n = ccd_multicontact_box(&pt, face, x1, x2, &a, &b, w1, w2);
+    if (n == 0) return 0;
+  }
+  if (dist <= margin) v3sub(nrm, w1[0], w2[0]); /* overlapping: witness 1 has crossed witness 2 */
+  else v3sub(nrm, w2[0], w1[0]);
+  for (int i = 0; i < n; i++) {
+    out[i].dist = dist;
+    for (int k = 0; k < 3; k++) out[i].pos[k] = 0.5 * (w1[i][k] + w2[i][k]);
+    make_frame(out[i].frame, nrm);
+  }
+  return n;
 }
-static int is_convex_pair(int t1, int t2) { /* MJ_COLLISION_TABLE collision_driver.py:47-80, primitive shapes only */
+static int is_convex_pair(int t1, int t2) { /* MJ_COLLISION_TABLE collision_driver.py:47-80, primitive shapes only (box-box: below) */
   return (t1 == G_SPHERE && t2 == G_ELLIPSOID) || (t1 == G_CAPSULE && (t2 == G_ELLIPSOID || t2 == G_CYLINDER)) ||
          (t1 == G_ELLIPSOID && (t2 == G_ELLIPSOID || t2 == G_CYLINDER || t2 == G_BOX)) || (t1 == G_CYLINDER && (t2 == G_CYLINDER || t2 == G_BOX));
 }
@@ -1082,7 +1091,9 @@ static int collide_pair(const RefModel* m, RefData* d, int g1, int g2, double ma
   const double *s1 = m->geom_size + 3 * g1, *s2 = m->geom_size + 3 * g2;
   double ax1[3] = {R1[2], R1[5], R1[8]}, ax2[3] = {R2[2], R2[5], R2[8]};
   int n = 0;
-  if (is_convex_pair(t1, t2)) return ccd_contact(m, t1, p1, R1, s1, t2, p2, R2, s2, margin, gap, out, &d->overflow);
+  /* box-box is a convex pair unless DisableBit.NATIVECCD asks for the primitive collider (collision_driver.py:867-870) */
+  if (is_convex_pair(t1, t2) || (t1 == G_BOX && t2 == G_BOX && !(m->disableflags & DSBL_NATIVECCD)))
+    return ccd_contact(m, t1, p1, R1, s1, t2, p2, R2, s2, margin, gap, out, &d->overflow);
   if (t1 == G_PLANE && t2 == G_SPHERE) { /* collision_primitive.py:281 */
     plane_sphere(ax1, p1, p2, s2[0], &out[0].dist, out[0].pos);
     make_frame(out[0].frame, ax1);
@@ -1482,7 +1493,13 @@ int ref_ccd(int type1, const double* pos1, const double* mat1, const double* siz
   int n = ccd_run(tolerance, cutoff, iterations, iterations, a, b, out, out + 1, out + 4, &overflow, &face, &pt);
   out[7] = (double)overflow;
   out[8] = (double)face;
-  (void)multiccd; (void)wit;
+  for (int k = 0; k < 3; k++) { wit[k] = out[1 + k]; wit[3 + k] = out[4 + k]; }
+  if (multiccd && n > 0 && face >= 0) {
+    double w1[4][3], w2[4][3];
+    n = ccd_multicontact_box(&pt, face, out + 1, out + 4, &a, &b, w1, w2);
+    for (int i = 0; i < n; i++)
+      for (int k = 0; k < 3; k++) { wit[6 * i + k] = w1[i][k]; wit[6 * i + 3 + k] = w2[i][k]; }
+  }
   return n;
 }
 

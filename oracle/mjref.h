@@ -39,7 +39,8 @@ typedef struct RefModel {
   int disableflags;
   int broadphase;        /* BroadphaseType: 0 NXN, 1 SAP_TILE, 2 SAP_SEGMENTED (io.py:631-636) */
   int broadphase_filter; /* BroadphaseFilter bits: 1 plane, 2 sphere, 4 AABB, 8 OBB (io.py:405) */
-  int ccd_iterations;    /* GJK and EPA iteration cap (opt.ccd_iterations) */
+  int ccd_iterations;    /* GJK iteration cap (opt.ccd_iterations) */
+  int epa_iterations;    /* EPA iteration cap: 16 when every convex pair of the model is box-box, else ccd_iterations (collision_convex.py:1223) */
   double timestep;
   double tolerance;
   double ls_tolerance;

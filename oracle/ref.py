@@ -99,6 +99,21 @@ def ccd(type1, pos1, mat1, size1, type2, pos2, mat2, size2, margin=0.0, toleranc
   return float(out[0]), n, out[1:4].copy(), out[4:7].copy(), wit.reshape(8, 2, 3)[: max(n, 0)].copy()
 
 
+def _epa_iterations(mjm, pairs):
+  """EPA iteration cap (reference collision_convex.py:1209-1223): 16 when every convex-class pair of the model is box-box."""
+  convex = {(2, 4), (3, 4), (3, 5), (4, 4), (4, 5), (4, 6), (5, 5), (5, 6)}
+  nativeccd_off = bool(int(mjm.opt.disableflags) & (1 << 17))
+  gt = np.asarray(mjm.geom_type)
+  nbb = nother = 0
+  for a, b in np.asarray(pairs).reshape(-1, 2):
+    t = (int(min(gt[a], gt[b])), int(max(gt[a], gt[b])))
+    if t == (6, 6) and not nativeccd_off:
+      nbb += 1
+    elif t in convex:
+      nother += 1
+  return 16 if (nbb > 0 and nother == 0) else int(getattr(mjm.opt, "ccd_iterations", 35))
+
+
 def filtered_geom_pairs(mjm):
   """Pre-filtered geom pairs in upper-triangular order (reference io.py:551-577)."""
   DSBL_FILTERPARENT = 1 << 10
@@ -172,7 +187,7 @@ class RefSim:
       solver=int(opt.solver if solver is None else solver),
       iterations=int(opt.iterations if iterations is None else iterations),
       ls_iterations=int(opt.ls_iterations if ls_iterations is None else ls_iterations),
-      disableflags=int(opt.disableflags), broadphase=int(broadphase), broadphase_filter=int(broadphase_filter), ccd_iterations=int(getattr(opt, 'ccd_iterations', 35)),
+      disableflags=int(opt.disableflags), broadphase=int(broadphase), broadphase_filter=int(broadphase_filter), ccd_iterations=int(getattr(opt, 'ccd_iterations', 35)), epa_iterations=_epa_iterations(mjm, pairs),
       ccd_tolerance=float(getattr(opt, 'ccd_tolerance', 1e-6)), timestep=float(opt.timestep),
       tolerance=float(opt.tolerance if tolerance is None else tolerance), ls_tolerance=float(opt.ls_tolerance),
       impratio=float(opt.impratio), meaninertia=float(mjm.stat.meaninertia))

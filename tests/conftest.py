@@ -224,7 +224,7 @@ CAPSULE_BOX_XML = """
 # onto the table's rim (edge-edge and vertex-face configurations appear along the rollout)
 BOX_BOX_XML = """
 <mujoco>
-  <option timestep="0.003"/>
+  <option timestep="0.003"><flag nativeccd="disable"/></option>  <!-- the primitive box-box collider (the default is CCD + multi-contact: BOX_CCD_XML) -->
   <worldbody>
     <geom name="floor" type="plane" size="0 0 .05"/>
     <body name="table" pos="0 0 .2"><geom type="box" size=".5 .4 .2"/></body>
@@ -246,7 +246,7 @@ BOX_BOX_XML = """
 # a mocap platform (posed through Data.mocap_pos / mocap_quat) carrying a ball and tilting under a box
 MOCAP_XML = """
 <mujoco>
-  <option timestep="0.003"/>
+  <option timestep="0.003"><flag nativeccd="disable"/></option>  <!-- (the crate on the tilting tray sits at the 1.6 mrad face-alignment threshold of the CCD multi-contact path; this scene is about mocap) -->
   <worldbody>
     <geom name="floor" type="plane" size="0 0 .05"/>
     <body name="tray" mocap="true" pos="0 0 .3"><geom type="box" size=".25 .2 .02"/></body>

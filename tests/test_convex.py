@@ -113,6 +113,41 @@ def test_box_box_shallow_depth():  # :483
   assert abs(dist + 0.00025054812) < 5e-8
 
 
+def _quat_mat(q):
+  w, x, y, z = np.asarray(q, dtype=float) / np.linalg.norm(q)
+  return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)], [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                   [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+
+
+def test_box_box_multicontact_counts():
+  """multicontact (collision_gjk.py:2076): contact counts the reference's tests assert for box pairs."""
+  # test_box_box_shallow_penetration :483 -- 4 contacts, depth as above
+  dist, n, _, _, _ = ref.ccd(BOX, [0, 0, 0.19972974], I3, [0.2] * 3, BOX, [0, 0, 0.49947918], I3, [0.1] * 3, multiccd=True)
+  assert n == 4 and abs(dist + 0.00025054812) < 5e-8
+  # test_box_edge :499 -- an edge resting on a face: 2 contacts
+  _, n, _, _, _ = ref.ccd(BOX, [0, 0, 2], I3, [1, 1, 1], BOX, [0, 0, 4.4], _euler_xyz([0, 90, 40]), [1, 1, 1], multiccd=True)
+  assert n == 2
+  # test_box_box_ccd :513 -- a box on a slab: 4 contacts
+  _, n, _, _, _ = ref.ccd(BOX, [0, 0, 1.9], I3, [1, 1, 1], BOX, [0, 0, 0], I3, [10, 10, 1], multiccd=True)
+  assert n == 4
+  # test_box_box_ccd2 :548 -- rotated, shifted box on a box: 4 contacts
+  _, n, _, _, _ = ref.ccd(BOX, [0, 0, 2], I3, [1, 1, 1], BOX, [0, 1, 3.99], _euler_xyz([0, 0, 40]), [1, 1, 1], multiccd=True)
+  assert n == 4
+  # test_box_box_diagonal :866 -- 4 contacts
+  pos2 = [0.135535001754761, -0.195535004138947, 0.124984227120876]
+  rot2 = [1.0, 0.000000000048563, -0.000000135524601, -0.000000000048577, 1.0, -0.000000103374248, 0.000000135524601, 0.000000103374248, 1.0]
+  dist, n, _, _, _ = ref.ccd(BOX, [0, 0, 0], I3, [0.5, 0.5, 0.1], BOX, pos2, rot2, [0.025] * 3, multiccd=True)
+  assert n == 4 and abs(dist + 1.5778851595232846e-05) < 5e-8
+
+
+def test_box_edge_flipped_witness_points():  # :986
+  dist, n, _, _, wit = ref.ccd(BOX, [1.10164554, -0.11389316, 0.74], _quat_mat([-0.348312918, 0, 0, 0.937378318]), [0.65, 0.48, 0.04], BOX,
+                               [1.4, 0, 1.425], I3, [0.1, 1.2, 1.4], multiccd=True)
+  assert n == 2
+  np.testing.assert_allclose(wit[0, 0], [1.907368, -0.052973, 0.700000], atol=1e-4)
+  np.testing.assert_allclose(wit[0, 1], [1.30000, -0.052973, 0.700000], atol=1e-4)
+
+
 @pytest.mark.parametrize("seed", range(40))
 def test_ccd_against_closed_forms(seed):
   """Ellipsoids with equal radii are spheres and capsules against them have a closed form: distance, witness points and the
@@ -266,6 +301,86 @@ def test_gpu_convex_scene_steps_match_oracle(solver):
     worst_q = max(worst_q, relerr(d.qpos.numpy()[1], s.qpos))
     worst_v = max(worst_v, relerr(d.qvel.numpy()[1], s.qvel))
   assert ncon_total >= 6 * 60
+  assert worst_q <= 1e-5, worst_q
+  assert worst_v <= 5e-3, worst_v
+  assert (d.overflow.numpy() == 0).all()
+
+
+# ---- box-box through CCD + multi-contact (the reference's default; the primitive mjc_BoxBox collider needs DisableBit.NATIVECCD) ----
+BOX_CCD_XML = """
+<mujoco>
+  <option timestep="0.003"/>
+  <worldbody>
+    <geom name="floor" type="plane" size="0 0 .05"/>
+    <geom name="table" type="box" size=".5 .4 .05" pos="0 0 .05"/>
+    <body name="flat" pos="-.25 0 .1495"><freejoint/><geom type="box" size=".08 .06 .05"/></body>
+    <body name="turned" pos=".05 .1 .1495" euler="0 0 33"><freejoint/><geom type="box" size=".07 .05 .05"/></body>
+    <body name="over" pos=".46 -.2 .1495"><freejoint/><geom type="box" size=".09 .05 .05"/></body>
+    <body name="base" pos=".25 .15 .1395"><freejoint/><geom type="box" size=".07 .07 .04"/></body>
+    <body name="top" pos=".26 .16 .2085" euler="0 0 20"><freejoint/><geom type="box" size=".03 .035 .03"/></body>
+    <body name="edge" pos="-.05 -.22 .17" euler="45 0 10"><freejoint/><geom type="box" size=".06 .05 .05"/></body>
+  </worldbody>
+</mujoco>
+"""
+
+
+def _sorted_points(p):
+  p = np.asarray(p, dtype=np.float64).reshape(-1, 3)
+  return p[np.lexsort((np.round(p[:, 2], 4), np.round(p[:, 1], 4), np.round(p[:, 0], 4)))]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("solver", ["Newton", "CG"])
+def test_gpu_box_ccd_scene_matches_oracle(solver):
+  """Boxes resting flat, turned, overhanging the table edge, stacked and balanced on an edge: contact sets per box pair (count,
+  distance, positions as a set) and 40 steps.  Every clipped polygon here has at most four vertices: with more, the reference prunes
+  with a greedy largest-quadrilateral search (`_polygon_quad`, collision_gjk.py:1463) whose result depends on the start vertex (on
+  a 5-gon the selected area varies 300-fold with the rotation of the vertex list), so float32 and float64 legitimately keep different
+  corners there."""
+  import mujoco_warp_amd as mjw
+  from tests.conftest import relerr
+
+  mjm = mjw.mjcf.from_xml_string(BOX_CCD_XML)
+  mjm.opt.solver = int(mjw.SolverType.NEWTON if solver == "Newton" else mjw.SolverType.CG)
+  s = ref.RefSim(mjm, nconmax=48, njmax=192, tolerance=1e-6)
+  s.reset()
+  for _ in range(10):
+    s.step()
+  m = mjw.put_model(mjm)
+  assert m.heavy_colliders == 1 and m.epa_iterations == 16
+  d = mjw.put_data(mjm, mjw.MjData(mjm), nworld=2, nconmax=48, njmax=192)
+  worst_q = worst_v = 0.0
+  nbox = mismatched = boundary_steps = 0
+  for i in range(40):
+    for name in ("qpos", "qvel", "qacc_warmstart"):
+      getattr(d, name).assign(np.tile(getattr(s, name).astype(np.float32), (2, 1)))
+    if i % 10 == 0:
+      mjw.forward(m, d)
+      s.forward()
+      ncon, adr = int(d.ws_ncon.numpy()[1]), int(d.ws_conadr.numpy()[1])
+      gg = d.contact.geom.numpy()[adr : adr + ncon]
+      for pair in {tuple(g) for g in s.con_geom[: s.ncon]}:
+        io = [c for c in range(s.ncon) if tuple(s.con_geom[c]) == pair]
+        ig = [c for c in range(ncon) if tuple(gg[c]) == pair]
+        if len(io) != len(ig):
+          # two faces count as aligned when their normals agree within 1.6 mrad (FACE_TOL): a box rocking on its support crosses
+          # that threshold, and float32 / float64 cross it a step apart (the oracle itself flickers between 2 and 4 contacts here)
+          mismatched += 1
+          continue
+        if mjm.geom_type[pair[0]] == 6 and mjm.geom_type[pair[1]] == 6:
+          nbox += len(io)
+          np.testing.assert_allclose(d.contact.dist.numpy()[adr + np.array(ig)], s.con_dist[io], atol=2e-6)
+          np.testing.assert_allclose(_sorted_points(d.contact.pos.numpy()[adr + np.array(ig)]), _sorted_points(s.con_pos[io]), atol=2e-5)
+          np.testing.assert_allclose(d.contact.frame.numpy()[adr + ig[0]].reshape(9)[:3], s.con_frame[io[0]][:3], atol=5e-4)  # (normal = difference of two float32 witness points ~1e-3 apart)
+    mjw.step(m, d)
+    s.step()
+    if int(d.ws_ncon.numpy()[1]) != s.ncon:
+      boundary_steps += 1
+      continue
+    worst_q = max(worst_q, relerr(d.qpos.numpy()[1], s.qpos))
+    worst_v = max(worst_v, relerr(d.qvel.numpy()[1], s.qvel))
+  assert mismatched <= 2 and boundary_steps <= 8, (mismatched, boundary_steps)
+  assert nbox >= 4 * 10
   assert worst_q <= 1e-5, worst_q
   assert worst_v <= 5e-3, worst_v
   assert (d.overflow.numpy() == 0).all()

@@ -502,7 +502,7 @@ def test_collision_box_box_closed_form_and_sat_depth():
   form, then 600 random poses: a contact exists iff the boxes overlap on all 15 separating axes, and the deepest contact
   distance equals minus the minimum overlap (the penetration depth along the axis the algorithm picks)."""
   m = mjw.mjcf.from_xml_string("""
-<mujoco><worldbody>
+<mujoco><option><flag nativeccd="disable"/></option><worldbody>
   <body name="a"><freejoint/><geom type="box" size=".3 .2 .1"/></body>
   <body name="b"><freejoint/><geom type="box" size=".1 .1 .1"/></body>
 </worldbody></mujoco>""")
