@@ -6,8 +6,12 @@
 #include "smooth.hpp"
 #include "solver.hpp"
 
+#ifndef MJH_N64_WAVES
+#define MJH_N64_WAVES 1
+#endif
+
 template <int NV4, int NR, bool NEWTON, int SG, bool ELL = false>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((!NEWTON && !ELL && SG == 32 && NR == 2) ? 3 : 1, 8))) k_solve_plus(MjhModel m, MjhData d, int nsolve, int nfac, int nefc_lo, int nefc_hi, int fuse_euler) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((!NEWTON && !ELL && SG == 32 && NR == 2) ? 3 : ((NEWTON && SG == 64 && MJH_N64_WAVES > 1) ? MJH_N64_WAVES : 1), 8))) k_solve_plus(MjhModel m, MjhData d, int nsolve, int nfac, int nefc_lo, int nefc_hi, int fuse_euler) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int wpb = blockDim.x / SG;
   if ((int)blockIdx.x < nsolve) solve_body<NV4, NR, NEWTON, SG, ELL>(m, d, smem, Blk{(int)blockIdx.x * wpb, wpb, (int)blockDim.x}, nefc_lo, nefc_hi, fuse_euler);

@@ -83,7 +83,8 @@ DEV void chol_factor_rows(float (&h)[NVR], float (&lt)[NVR], float& rdiag, float
 #pragma unroll
   for (int j = 0; j < NVR; ++j) {  // right-looking; pivot column broadcast through LDS (double buffered)
     float* cb = col + (j & 1) * G;
-    if (own) cb[lig] = h[j];
+    // (unconditional: lanes past the matrix write slots nobody reads; a branch here lets LLVM sink the updates below across it)
+    cb[lig] = h[j];
     gsync();
     // pivot by v_readlane (off the LDS round trip); 1/sqrt = v_rsq_f32 + one Newton step (~0.5 ulp)
     const float pv = fmaxf(bcastg<G>(h[j], j), MJ_MINVAL);
@@ -92,7 +93,7 @@ DEV void chol_factor_rows(float (&h)[NVR], float (&lt)[NVR], float& rdiag, float
     const float piv = pv * inv;
     const float lij = (lig == j) ? piv : h[j] * inv;
     h[j] = lij;
-    if (lig == j) rdiag = inv;
+    rdiag = (lig == j) ? inv : rdiag;
     const float t = lij * inv;
 #pragma unroll
     for (int k = j + 1; k < NVR; ++k) h[k] -= t * cb[k];
