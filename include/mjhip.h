@@ -107,6 +107,15 @@ typedef struct MjhModel {
   const int* dof_grpadr;        /* first dof of the ball/free rotational triple containing the dof, else the dof itself */
   const int* dof_tree;          /* dof ids sorted by depth in the dof tree   */
   const int* dof_leveladr;      /* [ndoflevel+1] offsets into dof_tree       */
+  /* kinematic trees (contiguous dof ranges; M is block diagonal over them): the per-tree solver dispatch for nv > 64 */
+  int ntree;                    /* trees with at least one dof */
+  int tree_nvmax;               /* dofs of the largest tree */
+  int tree_solve;               /* 1: nv > 64, every tree has <= 32 dofs, CG / Newton with pyramidal cones: worlds whose constraint rows
+                                   each touch one tree are solved per (world, tree) by the register-resident kernel */
+  const int* tree_dofadr;       /* [ntree] first dof */
+  const int* tree_dofnum;       /* [ntree] dofs */
+  const int* dof_treeid;        /* [nv] */
+  const int* body_treeid;       /* [nbody] tree of the body's dofs (its own or its nearest ancestor's), -1: static */
   const float* dof_solref; int dof_solref_nb;
   const float* dof_solimp; int dof_solimp_nb;
   const float* dof_frictionloss; int dof_frictionloss_nb;
@@ -193,6 +202,9 @@ typedef struct MjhData {
   int* ws_ncollision;  /* [nworld]   broadphase candidates per world                  */
   float* ws_ccd;       /* [nworld, ccd_words(ccd_iterations), 32] EPA polytopes of the convex narrowphase, one per lane of a world, interleaved by
                           lane (csrc/convex.hpp); empty unless the model has convex (GJK) pairs */
+  int* ws_tree_rowadr; /* [nworld, ntree + 1] first entry of each tree in ws_tree_rowmap (per-tree solve, MjhModel.tree_solve)  */
+  int* ws_tree_rowmap; /* [nworld, njmax] constraint rows grouped by tree                                                  */
+  int* ws_separable;   /* [nworld] 1: no row couples two trees (the world is solved per tree), 0: generic solver           */
   int* ws_efc_con;     /* [nworld, njmax] contact rows: 16 * (world-local contact) + row within the contact (make_constraint -> solver,
                           elliptic cones only) */
   int* ws_order;       /* [nworld]   solver schedule: worlds sorted by last step's solver_niter (longest first) */
@@ -244,7 +256,7 @@ int mjh_timed_steps(const MjhModel* m, const MjhData* d, int nstep, int step0, f
 int mjh_release_thread_resources(void);
 
 const char* mjh_last_error(void);
-#define MJH_ABI_VERSION 11
+#define MJH_ABI_VERSION 12
 int mjh_abi_version(void); /* returns MJH_ABI_VERSION of the library that was loaded */
 
 #ifdef __cplusplus

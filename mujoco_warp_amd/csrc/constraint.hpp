@@ -430,7 +430,7 @@ DEV void make_constraint_body(const MjhModel& m, const MjhData& d, float* smem, 
       d.efc_frictionloss[eo + r] = 0.0f;
       d.efc_type[eo + r] = condim == 1 ? CT_CONTACT_FRICTIONLESS : (elliptic ? CT_CONTACT_ELLIPTIC : CT_CONTACT_PYRAMIDAL);
       d.efc_id[eo + r] = c;  // world-local; k_publish_contacts rewrites it with the public contact id
-      if (m.cone == CONE_ELLIPTIC) d.ws_efc_con[eo + r] = row2con[r];  // the solver groups the rows of a contact
+      if (m.cone == CONE_ELLIPTIC || m.tree_solve) d.ws_efc_con[eo + r] = row2con[r];  // the solver groups the rows of a contact / of a tree
     }
   }
   if (lig == 0) {
@@ -485,4 +485,59 @@ __global__ void __launch_bounds__(64) k_efc_j_sparse(MjhData d, int nv, int njma
     adr += nnz;
   }
   if (__ballot(ovf) && lane == 0) atomicOr(d.overflow + w, OVF_NJMAX_NNZ);
+}
+
+
+// ---- per-tree solve (nv > 64, MjhModel.tree_solve): constraint rows grouped by kinematic tree -------------------------------------
+// One 64-lane wavefront per world.  A row belongs to the tree of the dofs it touches: joint equalities and limits through their
+// joint, dof friction through its dof, contacts through the bodies of their two geoms (a static body has no tree).  A row that
+// touches two trees couples them: the world is then left to the generic solver (ws_separable = 0).  Rows are grouped stably (row
+// order inside a tree is the global order) with ballot prefixes; ws_tree_rowadr[t] .. [t + 1] delimit tree t in ws_tree_rowmap.
+__global__ void __launch_bounds__(64) k_tree_rows(MjhModel m, MjhData d) {
+  extern __shared__ int sh_tree[];  // [njmax] tree of each row
+  const int w = blockIdx.x, lane = threadIdx.x;
+  if (w >= d.nworld) return;
+  const int njmax = d.njmax, nefc = min(d.nefc[w], njmax), ntree = m.ntree;
+  const size_t eo = (size_t)w * njmax;
+  int* rowadr = d.ws_tree_rowadr + (size_t)w * (ntree + 1);
+  int* rowmap = d.ws_tree_rowmap + eo;
+  bool coupled = false;
+  for (int r = lane; r < nefc; r += 64) {
+    const int type = d.efc_type[eo + r];
+    int t = 0;
+    if (type == CT_EQUALITY) {
+      const int e = d.efc_id[eo + r], j1 = m.eq_obj1id[e], j2 = m.eq_obj2id[e];
+      t = m.dof_treeid[m.jnt_dofadr[j1]];
+      if (j2 >= 0 && m.dof_treeid[m.jnt_dofadr[j2]] != t) coupled = true;
+    } else if (type == CT_FRICTION_DOF) {
+      t = m.dof_treeid[d.efc_id[eo + r]];
+    } else if (type == CT_LIMIT_JOINT) {
+      t = m.dof_treeid[m.jnt_dofadr[d.efc_id[eo + r]]];
+    } else {  // contact rows (efc.id is being rewritten by the contact publication: the row -> contact map is ws_efc_con)
+      const int c = d.ws_efc_con[eo + r] >> 4;
+      const int* rec = reinterpret_cast<const int*>(d.ws_contact + ((size_t)w * d.concap + c) * CON_STRIDE);
+      const int t1 = m.body_treeid[m.geom_bodyid[rec[25]]], t2 = m.body_treeid[m.geom_bodyid[rec[26]]];
+      if (t1 >= 0 && t2 >= 0 && t1 != t2) coupled = true;
+      t = t1 >= 0 ? t1 : (t2 >= 0 ? t2 : 0);  // (two static bodies: an all-zero row, any tree will do)
+    }
+    sh_tree[r] = t;
+  }
+  __syncthreads();
+  const bool any_coupled = __ballot(coupled) != 0ull;
+  int adr = 0;
+  for (int t = 0; t < ntree; ++t) {
+    if (lane == 0) rowadr[t] = adr;
+    for (int r0 = 0; r0 < nefc; r0 += 64) {
+      const int r = r0 + lane;
+      const bool mine = r < nefc && sh_tree[r] == t;
+      const unsigned long long bits = __ballot(mine);
+      if (mine) rowmap[adr + __popcll(bits & ((1ull << lane) - 1ull))] = r;
+      adr += __popcll(bits);
+    }
+  }
+  if (lane == 0) {
+    rowadr[ntree] = adr;
+    d.ws_separable[w] = any_coupled ? 0 : 1;
+    d.solver_niter[w] = 0;
+  }
 }

@@ -233,7 +233,19 @@ static int solve_supported(const MjhModel* m, const MjhData* d) {
 }
 static int launch_solve_any(const MjhModel* m, const MjhData* d, bool with_factor, hipStream_t s) {
   if (int rc = solve_supported(m, d)) return rc;
-  if (m->nv > 64) return launch_solve_big(m, d, s);  // no riders: they go with the integrator launch
+  if (m->nv > 64) {  // no riders: they go with the integrator launch
+    if (m->tree_solve) {
+      // rows grouped by kinematic tree; worlds none of whose rows couples two trees are solved per (world, tree) by the
+      // register-resident kernel (two sizes by the rows of a tree), the others by the generic solver below
+      hipLaunchKernelGGL(k_tree_rows, dim3(d->nworld), dim3(64), sizeof(int) * (size_t)std::max(d->njmax, 1), s, *m, *d);
+      auto tree = m->solver == SOL_NEWTON ? launch_solve_tree_newton : launch_solve_tree_cg;
+      const int nv4 = (m->tree_nvmax + 3) / 4;
+      if (int rc = tree(m, d, nv4, 2, s, -1, 64)) return rc;
+      if (d->njmax > 64)
+        if (int rc = tree(m, d, nv4, 6, s, 64, 0x7fffffff)) return rc;
+    }
+    return launch_solve_big(m, d, s);
+  }
   if (m->solver == SOL_PGS) return launch_pgs(m, d, s);
   const bool newton = m->solver == SOL_NEWTON;
   const int fe = g_fuse_euler ? 1 : 0;

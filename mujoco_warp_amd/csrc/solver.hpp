@@ -139,9 +139,9 @@ DEV float chol_solve_rows(const float (&h)[NVR], const float (&lt)[NVR], float r
 }
 
 struct SolveLayout {
-  int J, force, da, bsearch, bgrad, col, ex, cone, total;
+  int J, force, da, bsearch, bgrad, col, ex, cone, fl, total;
 };
-template <int NV4, int NR, int G, bool NEWTON, bool ELL = false>
+template <int NV4, int NR, int G, bool NEWTON, bool ELL = false, bool TREE = false>
 __host__ __device__ inline SolveLayout solve_layout(int njmax) {
   constexpr int NVR = 4 * NV4;
   constexpr int JS = (NV4 & 1) ? NVR : NVR + 4;  // JS/4 odd: row-per-lane 16-byte reads hit distinct banks
@@ -160,6 +160,7 @@ __host__ __device__ inline SolveLayout solve_layout(int njmax) {
   // which the rows of one contact see each other; Newton adds the cone Hessian block rows (6 words) + first row / size
   p.ex = o; o += ELL ? 6 * G * NR : 0;
   p.cone = o; o += (ELL && NEWTON) ? 7 * G * NR : 0;
+  p.fl = o; o += TREE ? G * NR : 0;  // per-tree solve: frictionloss of this tree's rows, gathered through the row map
   p.total = ((o + 3) / 4) * 4;
   return p;
 }
@@ -500,19 +501,29 @@ DEV void invert_rows(const float (&mrow)[NVR], float (&b)[NVR], float* buf, int 
   }
 }
 
-template <int NV4, int NR, bool NEWTON, int G, bool ELL = false>
+// TREE (nv > 64, MjhModel.tree_solve): the unit of work is one kinematic tree of one world -- dofs [dof0, dof0 + nv) and the rows
+// k_tree_rows grouped under that tree (M is block diagonal over trees, so a world none of whose rows couples two trees separates
+// exactly into per-tree problems); every global index goes through dof0 / the row map, everything else is the same kernel.
+template <int NV4, int NR, bool NEWTON, int G, bool ELL = false, bool TREE = false>
 DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk& b, int nefc_lo = -1, int nefc_hi = 0x7fffffff,
                     int fuse_euler = 0) {
   if ((int)threadIdx.x >= b.nthreads) return;
   constexpr int NVR = 4 * NV4;
   constexpr int JS = (NV4 & 1) ? NVR : NVR + 4;
-  const int nv = m.nv, nC = m.nC, njmax = d.njmax, nvp = d.nv_pad;
-  const SolveLayout lay = solve_layout<NV4, NR, G, NEWTON, ELL>(njmax);
+  static_assert(!TREE || !ELL, "per-tree solve: pyramidal cones only");
+  const int nv_all = m.nv, nC = m.nC, njmax = d.njmax, nvp = d.nv_pad;
+  const SolveLayout lay = solve_layout<NV4, NR, G, NEWTON, ELL, TREE>(njmax);
   const int lig = threadIdx.x & (G - 1), gib = threadIdx.x / G;
   const int slot = b.w0 + gib;
-  if (slot >= d.nworld) return;
+  if (slot >= (TREE ? d.nworld * m.ntree : d.nworld)) return;
   // worlds are scheduled longest-expected-solve first and paired with a similar neighbour (k_schedule_worlds)
-  const int w = d.ws_order[slot];
+  const int w = TREE ? slot / m.ntree : d.ws_order[slot];
+  const int tree = TREE ? slot - w * m.ntree : 0;
+  if (TREE && !d.ws_separable[w]) return;  // a row couples two trees: the generic solver takes this world
+  const int dof0 = TREE ? m.tree_dofadr[tree] : 0;
+  const int nv = TREE ? m.tree_dofnum[tree] : nv_all;
+  const int* rmap = TREE ? d.ws_tree_rowmap + (size_t)w * njmax + d.ws_tree_rowadr[(size_t)w * (m.ntree + 1) + tree] : nullptr;
+  auto R = [&](int r) __attribute__((always_inline)) { return TREE ? rmap[r] : r; };  // global row of this problem's row r
   // LDS decides how many worlds a CU holds (the kernel runs 2-3 rounds): no block-shared tables here, the M-structure
   // is read once from global (L1 hits)
   float* S = smem + (size_t)gib * lay.total;
@@ -526,12 +537,27 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
   // Two-size dispatch (njmax > 64): the same world list is offered to a small-row and a big-row instantiation; a world
   // is solved by the one whose range (nefc_lo, nefc_hi] holds its row count and skipped by the other.  LDS per world
   // follows the instantiation's row capacity, so the common few-row worlds run at several times the occupancy.
-  const int nefc_all = min(d.nefc[w], njmax);
+  const int nefc_all = TREE ? d.ws_tree_rowadr[(size_t)w * (m.ntree + 1) + tree + 1] - d.ws_tree_rowadr[(size_t)w * (m.ntree + 1) + tree]
+                            : min(d.nefc[w], njmax);
   if (nefc_all <= nefc_lo || nefc_all > nefc_hi) return;
   const int nefc = min(nefc_all, G * NR);
-  const int ne = d.ne[w], nf = d.nf[w];
-  const bool has_fl = nf > 0;  // friction-loss rows present: the line search needs the three-zone cost (rare)
-  const size_t vo = (size_t)w * nv, eo = (size_t)w * njmax;
+  const int ne = TREE ? 0 : d.ne[w], nf = TREE ? 0 : d.nf[w];
+  const size_t vo = (size_t)w * nv_all + dof0, eo = (size_t)w * njmax;
+  // friction-loss rows present: the line search needs the three-zone cost (rare).  TREE: row kinds come from efc.type and the
+  // frictionloss values are gathered into an LDS line (the row map breaks the lane-strided addressing of the plain path)
+  float* flds = S + lay.fl;
+  bool has_fl = nf > 0;
+  if (TREE) {
+    bool any = false;
+    for (int r = lig; r < G * NR; r += G) {
+      const bool fr = r < nefc && (d.efc_type[eo + rmap[r]] == CT_FRICTION_DOF || d.efc_type[eo + rmap[r]] == CT_FRICTION_TENDON);
+      flds[r] = fr ? d.efc_frictionloss[eo + rmap[r]] : 0.0f;
+      any |= fr;
+    }
+    has_fl = gballot<G>(any) != 0ull;
+    gsync();
+  }
+  const float* floss = TREE ? flds : d.efc_frictionloss + eo;  // floss[r]: frictionloss of this problem's row r
   const bool active = lig < nv;
   const int ligr = lig < NVR ? lig : NVR - 1;  // clamped row index for lanes beyond the matrix
 
@@ -543,9 +569,9 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
     gsync();
     const float* Mg = d.M + (size_t)w * nC;
     for (int i = lig; i < nv; i += G) {
-      const int start = m.M_rowadr[i], n = m.M_rownnz[i];
+      const int start = m.M_rowadr[dof0 + i], n = m.M_rownnz[dof0 + i];
       for (int a = 0; a < n; ++a) {
-        const int j = m.M_colind[start + a];
+        const int j = m.M_colind[start + a] - dof0;  // (ancestors of a dof lie in its own tree)
         const float v = Mg[start + a];
         Jl[i * JS + j] = v;
         Jl[j * JS + i] = v;
@@ -619,8 +645,8 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
       d.qfrc_constraint[vo + lig] = 0.0f;
       d.efc_Ma[vo + lig] = Ma;
     }
-    if (lig == 0) d.solver_niter[w] = 0;
-    if (fuse_euler) euler_advance<G>(m, d, w, lig, active, q, bsearch);
+    if (lig == 0 && !TREE) d.solver_niter[w] = 0;  // (TREE: k_tree_rows zeroed it; trees report with atomicMax)
+    if (fuse_euler && !TREE) euler_advance<G>(m, d, w, lig, active, q, bsearch);
     return;
   }
 
@@ -629,7 +655,10 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
   const int nefc4 = (nefc + 3) & ~3;
   {
     const float* Jg = d.efc_J + (size_t)w * d.njmax_pad * nvp;
-    if (nvp == JS) {
+    if (TREE) {  // this tree's rows and columns
+      for (int r = 0; r < nefc; ++r)
+        for (int c = lig; c < JS; c += G) Jl[r * JS + c] = c < nv ? Jg[(size_t)rmap[r] * nvp + dof0 + c] : 0.0f;
+    } else if (nvp == JS) {
       // same row stride in HBM and LDS: one flat copy with 16-byte loads, all in flight (a world's J block is 16-byte
       // aligned: njmax_pad * nv_pad is a multiple of 4)
       const float4* src = reinterpret_cast<const float4*>(Jg);
@@ -656,8 +685,12 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
   for (int k = 0; k < NR; ++k) {
     const int r = lig + G * k;
     const bool has = r < nefc;
-    rD[k] = has ? d.efc_D[eo + r] : 0.0f;
+    rD[k] = has ? d.efc_D[eo + R(r)] : 0.0f;
     rkind[k] = !has ? 3 : (r >= ne + nf ? 2 : (r >= ne ? 1 : 0));  // 3: padding row (contributes nothing)
+    if (TREE && has) {
+      const int ty = d.efc_type[eo + rmap[r]];
+      rkind[k] = ty == CT_EQUALITY ? 0 : ((ty == CT_FRICTION_DOF || ty == CT_FRICTION_TENDON) ? 1 : 2);
+    }
     rjv[k] = 0.0f;
     eforce[r] = 0.0f;
     if (NEWTON) eda[r] = 0.0f;  // CG has no eda region
@@ -697,14 +730,14 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
     return s0 + s1;
   };
 #pragma unroll
-  for (int k = 0; k < NR; ++k) rja[k] = rkind[k] != 3 ? j_dot(bsearch, lig + G * k) - d.efc_aref[eo + lig + G * k] : 0.0f;
+  for (int k = 0; k < NR; ++k) rja[k] = rkind[k] != 3 ? j_dot(bsearch, lig + G * k) - d.efc_aref[eo + R(lig + G * k)] : 0.0f;
   gsync();
 
   pc.mark(2);
   const float tolerance = bf(m.opt_tolerance, m.opt_tolerance_nb, w, 1)[0];
   const float ls_tolerance = bf(m.opt_ls_tolerance, m.opt_ls_tolerance_nb, w, 1)[0];
   const float meaninertia = bf(m.stat_meaninertia, m.stat_meaninertia_nb, w, 1)[0];
-  const float scale = meaninertia * (float)nv;
+  const float scale = meaninertia * (float)nv_all;
   const float rscale = 1.0f / scale;
 
   float grad_dot = 0.0f, search_dot = 0.0f, decrement = 0.0f;
@@ -770,7 +803,7 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
       // equality rows are always active, limit/contact rows when violated, padding rows (D = 0) never: branch-free
       float force;
       int state;
-      row_force(rkind[k], ja, D, has_fl, d.efc_frictionloss + eo + lig + G * k, force, state);
+      row_force(rkind[k], ja, D, has_fl, floss + lig + G * k, force, state);
       bool cone = false;
       if (ELL && rkind[k] >= 4) ell_row_force(k, force, state, cone);
       eforce[lig + G * k] = force;
@@ -893,7 +926,7 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
     improvement = 0.0f;
     bool ls_converged = false;
     if (!ELL) {
-      const float* floss_lane = d.efc_frictionloss + eo + lig;
+      const float* floss_lane = floss + lig;
       if (has_fl) line_search_rows<NR, G, true>(rja, rjv, rD, rkind, floss_lane, gauss1, gauss2, gtol, ls_iterations, alpha, improvement, ls_converged, nullptr, gs[2]);
       else line_search_rows<NR, G, false>(rja, rjv, rD, rkind, floss_lane, gauss1, gauss2, gtol, ls_iterations, alpha, improvement, ls_converged, nullptr, gs[2]);
     } else {
@@ -970,7 +1003,7 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
         } else {
 #pragma unroll
           for (int k = 0; k < NR; ++k) {
-            const P3 t = eval_row(rja[k], rjv[k], rD[k], rkind[k] == 1 ? d.efc_frictionloss[eo + lig + G * k] : 0.0f, rkind[k], a);
+            const P3 t = eval_row(rja[k], rjv[k], rD[k], rkind[k] == 1 ? floss[lig + G * k] : 0.0f, rkind[k], a);
             s.c += t.c;
             s.g += t.g;
             s.h += t.h;
@@ -1058,19 +1091,20 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
     if (rkind[k] != 3) {  // force/state at the final iterate: the same expression the last constraint update evaluated
       float force;
       int state;
-      row_force(rkind[k], rja[k], rD[k], has_fl, d.efc_frictionloss + eo + lig + G * k, force, state);
+      row_force(rkind[k], rja[k], rD[k], has_fl, floss + lig + G * k, force, state);
       if (ELL && rkind[k] >= 4) {
         bool cone;
         ell_row_force(k, force, state, cone);
       }
-      d.efc_force[eo + lig + G * k] = force;
-      d.efc_state[eo + lig + G * k] = state;
+      d.efc_force[eo + R(lig + G * k)] = force;
+      d.efc_state[eo + R(lig + G * k)] = state;
     }
   if (lig == 0) {
-    d.solver_niter[w] = niter;
+    if (TREE) atomicMax(d.solver_niter + w, niter);
+    else d.solver_niter[w] = niter;
     if (ovf) atomicOr(d.overflow + w, ovf);
   }
-  if (fuse_euler) {
+  if (fuse_euler && !TREE) {
     gsync();
     euler_advance<G>(m, d, w, lig, active, q, bsearch);
   }

@@ -51,6 +51,7 @@ DEV void solve_big_body(const MjhModel& m, const MjhData& d, float* smem, const 
   const int slot = b.w0 + gib;
   if (slot >= d.nworld) return;
   const int w = d.ws_order[slot];
+  if (m.tree_solve && d.ws_separable[w]) return;  // solved per tree by k_solve_tree (no row couples two trees)
   float* S = smem + mstruct_ints(nv, nC) + (size_t)gib * lay.total;
   float *q = S + lay.q, *Ma = S + lay.Ma, *grad = S + lay.grad, *Mgrad = S + lay.Mgrad, *search = S + lay.search, *mv = S + lay.mv,
         *pgrad = S + lay.pgrad, *pMgrad = S + lay.pMgrad, *qc = S + lay.qc, *fs = S + lay.fs, *x = S + lay.x;

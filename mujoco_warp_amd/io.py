@@ -205,6 +205,7 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
                        or m._convex_pairs)
   m.heavy_colliders = m._heavy_pairs  # c_model() adds the broadphase options (they may be changed after put_model)
   m.is_sparse = False
+
   m.nv_pad = _get_padded_sizes(nv, 1)[1]
 
   # ---- options (io.py:392-470) ----
@@ -256,6 +257,23 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
   for b in range(1, nbody):
     lastdof[b] = dofadr[b] + dofnum[b] - 1 if dofnum[b] > 0 else lastdof[parent[b]]
   dof_parent = _arr(mjm.dof_parentid, np.int32)
+  # kinematic trees: dofs of the bodies below one child of the world, contiguous in MuJoCo's depth-first order
+  dof_root = np.zeros(nv, dtype=np.int32)
+  for i in range(nv):
+    dof_root[i] = i if dof_parent[i] < 0 else dof_root[dof_parent[i]]
+  roots = sorted(set(int(r) for r in dof_root))
+  tree_dofadr = np.array(roots, dtype=np.int32)
+  tree_dofnum = np.array([int(np.sum(dof_root == r)) for r in roots], dtype=np.int32)
+  dof_treeid = np.array([roots.index(int(r)) for r in dof_root], dtype=np.int32)
+  for t, r in enumerate(roots):
+    if not (dof_treeid[r : r + tree_dofnum[t]] == t).all():
+      raise ValueError("dofs of a kinematic tree must be contiguous (MuJoCo order)")
+  body_treeid = np.array([dof_treeid[lastdof[b]] if lastdof[b] >= 0 else -1 for b in range(nbody)], dtype=np.int32)
+  m.ntree = len(roots)
+  m.tree_nvmax = int(tree_dofnum.max()) if len(roots) else 0
+  # nv > 64: worlds whose rows each touch one kinematic tree are solved per (world, tree) by the register-resident kernels
+  m.tree_solve = int(nv > 64 and m.ntree > 1 and m.tree_nvmax <= 32 and int(opt.solver) != types.SolverType.PGS
+                     and int(opt.cone) == types.ConeType.PYRAMIDAL)
   nw = max((nv + 31) // 32, 1)
   dofmask = np.zeros((nbody, nw), dtype=np.uint32)
   for b in range(nbody):  # io.py:536-549 body_isdofancestor as bit masks
@@ -293,7 +311,7 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
     jnt_type=jnt_type, jnt_qposadr=_arr(mjm.jnt_qposadr, i32), jnt_dofadr=jnt_dofadr, jnt_bodyid=_arr(mjm.jnt_bodyid, i32),
     jnt_limited=_arr(mjm.jnt_limited, i32),
     dof_bodyid=_arr(mjm.dof_bodyid, i32), dof_jntid=dof_jnt, dof_parentid=dof_parent, dof_grpadr=grpadr, dof_tree=dorder,
-    dof_leveladr=dleveladr,
+    dof_leveladr=dleveladr, tree_dofadr=tree_dofadr, tree_dofnum=tree_dofnum, dof_treeid=dof_treeid, body_treeid=body_treeid,
     M_rownnz=_arr(mjm.M_rownnz, i32), M_rowadr=_arr(mjm.M_rowadr, i32), M_colind=_arr(mjm.M_colind, i32),
     geom_type=_arr(mjm.geom_type, i32), geom_condim=_arr(mjm.geom_condim, i32), geom_bodyid=_arr(mjm.geom_bodyid, i32),
     geom_priority=_arr(mjm.geom_priority, i32), nxn_geom_pair=pairs, nxn_pairid=pairid, nxn_pairindex=_pair_index(ngeom, pairs),
@@ -429,7 +447,8 @@ def _data_shapes(m, nworld, nconmax, njmax, naconmax):
     contact_geomcollisionid=(naconmax,),
     efc_type=(W, njmax), efc_id=(W, njmax), efc_state=(W, njmax), efc_J=(W, njmax_pad, nv_pad), efc_pos=(W, njmax),
     efc_margin=(W, njmax), efc_D=(W, njmax), efc_vel=(W, njmax), efc_aref=(W, njmax), efc_frictionloss=(W, njmax),
-    efc_force=(W, njmax), ws_ncon=(W,), ws_conadr=(W,), ws_ncollision=(W,), ws_efc_con=(W, njmax), ws_order=(W,), ws_ccd=(W if m._convex_pairs else 0, _ccd_words(max(int(m.opt.ccd_iterations), int(m.epa_iterations))), 32),
+    efc_force=(W, njmax), ws_ncon=(W,), ws_conadr=(W,), ws_ncollision=(W,), ws_efc_con=(W, njmax), ws_tree_rowadr=(W, (m.ntree + 1) if m.tree_solve else 0), ws_tree_rowmap=(W, njmax if m.tree_solve else 0),
+    ws_separable=(W,), ws_order=(W,), ws_ccd=(W if m._convex_pairs else 0, _ccd_words(max(int(m.opt.ccd_iterations), int(m.epa_iterations))), 32),
     eq_active=(W, m.neq), ws_rk=(W, nq + 3 * nv + 2 * na), ws_contact=(W, contact_cap(nconmax), 32),
   )
   return sh, njmax_pad, nv_pad

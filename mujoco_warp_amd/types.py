@@ -313,6 +313,10 @@ class Model(_Dirty):
   dof_grpadr: DeviceArray = _arr(('nv',), "int32")
   dof_tree: DeviceArray = _arr(('nv',), "int32")
   dof_leveladr: DeviceArray = _arr(('ndoflevel+1',), "int32")
+  tree_dofadr: DeviceArray = _arr(('ntree',), "int32")
+  tree_dofnum: DeviceArray = _arr(('ntree',), "int32")
+  dof_treeid: DeviceArray = _arr(('nv',), "int32")
+  body_treeid: DeviceArray = _arr(('nbody',), "int32")
   dof_solref: DeviceArray = _arr(('*', 'nv', 2), "float32")
   dof_solimp: DeviceArray = _arr(('*', 'nv', 5), "float32")
   dof_frictionloss: DeviceArray = _arr(('*', 'nv'), "float32")
@@ -379,6 +383,9 @@ class Model(_Dirty):
   ndoflevel: int = 0
   nmaxcondim: int = 0
   epa_iterations: int = 0  # EPA iteration cap of the convex narrowphase (reference collision_convex.py:1223)
+  ntree: int = 0  # kinematic trees with at least one dof
+  tree_nvmax: int = 0  # dofs of the largest tree
+  tree_solve: int = 0  # 1: nv > 64 with trees of <= 32 dofs: tree-separable worlds are solved per (world, tree)
   nmaxpyramid: int = 0
   key_qpos: np.ndarray = _arr(('nkey', 'nq'), "float32", host=True)
   key_qvel: np.ndarray = _arr(('nkey', 'nv'), "float32", host=True)
@@ -489,6 +496,9 @@ class Data(_Dirty):
   ws_conadr: DeviceArray = _arr(('nworld',), "int32")
   ws_ncollision: DeviceArray = _arr(('nworld',), "int32")
   ws_efc_con: DeviceArray = _arr(('nworld', 'njmax'), "int32")
+  ws_tree_rowadr: DeviceArray = _arr(('nworld', 'ntreeadr'), "int32")
+  ws_tree_rowmap: DeviceArray = _arr(('nworld', 'ntreerow'), "int32")
+  ws_separable: DeviceArray = _arr(('nworld',), "int32")
   ws_ccd: DeviceArray = _arr(('nccdworld', 'nccdword', 32), "float32")
   ws_order: DeviceArray = _arr(('nworld',), "int32")
   eq_active: DeviceArray = _arr(('nworld', 'neq'), "int32")

@@ -464,6 +464,46 @@ def test_rk4_integrator(solver):
 
 
 @pytest.mark.parametrize("solver", [mjw.SolverType.NEWTON, mjw.SolverType.CG])
+def test_tree_solve_mixes_separable_and_coupled_worlds(solver):
+  """nv = 81: a world whose rows each touch one humanoid is solved per (world, tree) by the register-resident kernel; a world in
+  which two humanoids touch each other has rows coupling two trees and goes to the generic solver -- in the same batch."""
+  mjm = mjw.mjcf.from_xml_string(conftest.multi_humanoid_xml(3), assets_dir=os.path.dirname(conftest.HUMANOID_XML))
+  mjm.opt.solver = int(solver)
+  sims = []
+  for w in range(2):
+    s = ref.RefSim(mjm, nconmax=100, njmax=192, tolerance=1e-6)
+    s.reset(key=0 if mjm.nkey else None)
+    if w == 1:  # second humanoid moved onto the first one: arms and torsos interpenetrate
+      s.qpos[28 : 28 + 3] = s.qpos[0:3] + np.array([0.12, 0.05, 0.0])
+    for _ in range(30):
+      s.step()
+    sims.append(s)
+  m = mjw.put_model(mjm)
+  assert m.tree_solve == 1 and m.ntree == 3
+  d = mjw.put_data(mjm, mjw.MjData(mjm), nworld=2, nconmax=100, njmax=192)
+  worst = [0.0, 0.0]
+  seen = set()
+  for i in range(15):
+    for name in ("qpos", "qvel", "qacc_warmstart"):
+      getattr(d, name).assign(np.stack([getattr(s, name) for s in sims]).astype(np.float32))
+    mjw.step(m, d)
+    sep = d.ws_separable.numpy()
+    for w, s in enumerate(sims):
+      s.step()
+      trees = {tuple(sorted({int(m.body_treeid.numpy()[mjm.geom_bodyid[g]]) for g in s.con_geom[c]} - {-1})) for c in range(s.ncon)}
+      coupled = any(len(t) == 2 for t in trees)
+      assert int(sep[w]) == (0 if coupled else 1), (w, trees)
+      seen.add((w, coupled))
+      if int(d.ws_ncon.numpy()[w]) != s.ncon:
+        continue
+      worst[0] = max(worst[0], relerr(d.qpos.numpy()[w], s.qpos))
+      worst[1] = max(worst[1], relerr(d.qvel.numpy()[w], s.qvel))
+      assert int(d.solver_niter.numpy()[w]) > 0
+  assert (0, False) in seen and (1, True) in seen
+  assert worst[0] <= 1e-5 and worst[1] <= 5e-3, worst
+
+
+@pytest.mark.parametrize("solver", [mjw.SolverType.NEWTON, mjw.SolverType.CG])
 def test_three_humanoids_nv81(solver):
   """nv = 81 > 64: the generic LDS solver (csrc/solver_big.hpp) -- the structure of the reference's three_humanoids benchmark
   (benchmarks/humanoid/__init__.py: nconmax 100, njmax 192).  Forward fields, then per-step parity."""
@@ -476,7 +516,11 @@ def test_three_humanoids_nv81(solver):
   _check_fields(s, d, _SMOOTH_FIELDS, SMOOTH)
   _check_fields(s, d, ("qLD", "qLDiagInv"), FACTOR)
   _check_contacts_and_rows(s, d, mjm, dist_atol=1e-6)  # bodies up to 3 m from the origin: float32 eps there is 2.4e-7
-  _check_solution(s, d)
+  # worlds whose rows each touch one humanoid are solved per (world, tree) (solve_body TREE): every tree runs its own line searches
+  # and stops on its own test, so CG -- which stops far from the fixed point at tolerance 1e-6 -- lands on a slightly different iterate
+  # than the oracle's joint solve (measured 2.4e-3 on the forces); Newton converges to the same point
+  assert m.tree_solve == 1 and int(d.ws_separable.numpy().min()) in (0, 1)
+  _check_solution(s, d, tol=SOLVE if solver == mjw.SolverType.NEWTON else 2 * SOLVE)
   worst_q = worst_v = 0.0
   boundary_steps = 0
   for i in range(40):

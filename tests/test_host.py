@@ -117,7 +117,7 @@ def test_library_exports_every_declared_symbol():
   assert len(declared) >= 12
   for name in declared:
     assert hasattr(L, name), f"libmjhip.so does not export {name}"
-  assert L.mjh_abi_version() == _abi.DEFINES["MJH_ABI_VERSION"] >= 7
+  assert L.mjh_abi_version() == _abi.DEFINES["MJH_ABI_VERSION"] >= 12
 
 
 def test_struct_layout_matches_header():
@@ -359,8 +359,8 @@ def test_declared_schema_matches_arrays(xml):
   d = mjw.make_data(mjm, nworld=3, nconmax=7, njmax=21)
   assert dataclasses.is_dataclass(mjw.Model) and dataclasses.is_dataclass(mjw.Data)
   env = {k: getattr(m, k) for k in ("nq", "nv", "nu", "na", "nbody", "njnt", "ngeom", "nsite", "nkey", "nmocap", "neq", "nC", "npair",
-                                    "nexplicit", "nbodylevel", "ndoflevel", "nmaxpyramid")}
-  env.update(nworld=d.nworld, njmax=d.njmax, njmax_pad=d.njmax_pad, nv_pad=d.nv_pad, naconmax=d.naconmax, concap=d.concap, nccdworld=d.nccdworld, nccdword=d.nccdword)
+                                    "nexplicit", "nbodylevel", "ndoflevel", "nmaxpyramid", "ntree")}
+  env.update(nworld=d.nworld, njmax=d.njmax, njmax_pad=d.njmax_pad, nv_pad=d.nv_pad, naconmax=d.naconmax, concap=d.concap, nccdworld=d.nccdworld, nccdword=d.nccdword, ntreeadr=(m.ntree + 1) if m.tree_solve else 0, ntreerow=d.njmax if m.tree_solve else 0)
   for obj in (m.opt, m.stat, m, d.contact, d.efc, d):
     _schema_check(obj, env, d.nworld)
 
