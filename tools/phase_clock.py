@@ -33,6 +33,9 @@ def main():
   ap.add_argument("--nworld", type=int, default=8192)
   ap.add_argument("--steps", type=int, default=50)
   ap.add_argument("--build-only", action="store_true")
+  ap.add_argument("--xml", default=os.path.join(ROOT, "benchmarks", "humanoid", "humanoid.xml"))
+  ap.add_argument("--nconmax", type=int, default=24)
+  ap.add_argument("--njmax", type=int, default=64)
   args = ap.parse_args()
   if args.build_only or not os.path.exists(LIB):
     build()
@@ -42,12 +45,12 @@ def main():
   import mujoco_warp_amd as mjw
   from mujoco_warp_amd import _abi
 
-  mjm = mjw.mjcf.load_xml(os.path.join(ROOT, "benchmarks", "humanoid", "humanoid.xml"))
+  mjm = mjw.mjcf.load_xml(args.xml)
   mjw.override_model(mjm, [f"opt.solver={args.solver}"])
   m = mjw.put_model(mjm)
   mjd = mjw.MjData(mjm)
   mjw.mj_resetDataKeyframe(mjm, mjd, 0)
-  d = mjw.put_data(mjm, mjd, nworld=args.nworld, nconmax=24, njmax=64)
+  d = mjw.put_data(mjm, mjd, nworld=args.nworld, nconmax=args.nconmax, njmax=args.njmax)
   mjw.timed_steps(m, d, 100, step0=0)  # warm-up into the steady contact regime
   L = _abi.lib()
   L.mjh_debug_phase_ticks.argtypes = [ctypes.c_void_p, ctypes.c_int]
