@@ -110,8 +110,10 @@ typedef struct MjhModel {
   /* kinematic trees (contiguous dof ranges; M is block diagonal over them): the per-tree solver dispatch for nv > 64 */
   int ntree;                    /* trees with at least one dof */
   int tree_nvmax;               /* dofs of the largest tree */
-  int tree_solve;               /* 1: nv > 64, every tree has <= 32 dofs, CG / Newton with pyramidal cones: worlds whose constraint rows
-                                   each touch one tree are solved per (world, tree) by the register-resident kernel */
+  int isl_nv4;                  /* ceil(dofs / 4) of the widest island of at most 32 dofs the model can form (kernel size class) */
+  int isl_wide;                 /* 1: islands of 33..64 dofs can form */
+  int tree_solve;               /* 1: nv > 64, several trees of <= 64 dofs, CG / Newton with pyramidal cones: worlds whose constraint islands
+                                   (trees joined by coupling rows) have <= 64 dofs are solved per island by the register-resident kernels */
   const int* tree_dofadr;       /* [ntree] first dof */
   const int* tree_dofnum;       /* [ntree] dofs */
   const int* dof_treeid;        /* [nv] */
@@ -202,9 +204,17 @@ typedef struct MjhData {
   int* ws_ncollision;  /* [nworld]   broadphase candidates per world                  */
   float* ws_ccd;       /* [nworld, ccd_words(ccd_iterations), 32] EPA polytopes of the convex narrowphase, one per lane of a world, interleaved by
                           lane (csrc/convex.hpp); empty unless the model has convex (GJK) pairs */
-  int* ws_tree_rowadr; /* [nworld, ntree + 1] first entry of each tree in ws_tree_rowmap (per-tree solve, MjhModel.tree_solve)  */
-  int* ws_tree_rowmap; /* [nworld, njmax] constraint rows grouped by tree                                                  */
-  int* ws_separable;   /* [nworld] 1: no row couples two trees (the world is solved per tree), 0: generic solver           */
+  /* constraint islands at tree granularity (MjhModel.tree_solve, csrc/constraint.hpp k_tree_rows); island k of a world: */
+  int* ws_tree_rowadr; /* [nworld, ntree + 1] its rows are ws_tree_rowmap[rowadr[k] .. rowadr[k + 1])                       */
+  int* ws_tree_rowmap; /* [nworld, njmax] constraint rows grouped by island                                                */
+  int* ws_isl_dofadr;  /* [nworld, ntree + 1] its dofs are ws_isl_dofmap[dofadr[k] .. dofadr[k + 1])                       */
+  int* ws_isl_dofmap;  /* [nworld, nv] island-local dof -> dof, grouped by island                                         */
+  int* ws_isl_dofinv;  /* [nworld, nv] dof -> index within its island                                                     */
+  int* ws_nisland;     /* [nworld] islands                                                                                */
+  int* ws_isl_flags;   /* [nworld] bit 0: an island of 33..64 dofs, bit 1: an island of <= 32 dofs with more than 64 rows          */
+  int* ws_isl_list;    /* [3, nworld] worlds holding an island with > 64 rows | of 33..64 dofs | of > 64 dofs (generic solver)      */
+  int* ws_isl_count;   /* [4] entries of the three lists                                                                        */
+  int* ws_separable;   /* [nworld] 1: every island has at most 64 dofs (solved per island), 0: generic solver             */
   int* ws_efc_con;     /* [nworld, njmax] contact rows: 16 * (world-local contact) + row within the contact (make_constraint -> solver,
                           elliptic cones only) */
   int* ws_order;       /* [nworld]   solver schedule: worlds sorted by last step's solver_niter (longest first) */
@@ -256,7 +266,7 @@ int mjh_timed_steps(const MjhModel* m, const MjhData* d, int nstep, int step0, f
 int mjh_release_thread_resources(void);
 
 const char* mjh_last_error(void);
-#define MJH_ABI_VERSION 12
+#define MJH_ABI_VERSION 13
 int mjh_abi_version(void); /* returns MJH_ABI_VERSION of the library that was loaded */
 
 #ifdef __cplusplus

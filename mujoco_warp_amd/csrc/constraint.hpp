@@ -488,56 +488,125 @@ __global__ void __launch_bounds__(64) k_efc_j_sparse(MjhData d, int nv, int njma
 }
 
 
-// ---- per-tree solve (nv > 64, MjhModel.tree_solve): constraint rows grouped by kinematic tree -------------------------------------
-// One 64-lane wavefront per world.  A row belongs to the tree of the dofs it touches: joint equalities and limits through their
-// joint, dof friction through its dof, contacts through the bodies of their two geoms (a static body has no tree).  A row that
-// touches two trees couples them: the world is then left to the generic solver (ws_separable = 0).  Rows are grouped stably (row
-// order inside a tree is the global order) with ballot prefixes; ws_tree_rowadr[t] .. [t + 1] delimit tree t in ws_tree_rowmap.
+// ---- constraint islands for nv > 64 (MjhModel.tree_solve) ---------------------------------------------------------------------------
+// M is block diagonal over kinematic trees, so the constraint problem of a world separates over the connected components of the graph
+// whose nodes are trees and whose edges are the rows touching two trees (a contact between bodies of two trees, a joint equality across
+// them) -- MuJoCo's constraint islands at tree granularity (reference island.py).  One 64-lane wavefront per world:
+//   1. tree(s) of every row from its type: equalities and limits through their joint, dof friction through its dof, contacts through
+//      the bodies of their geoms (a static body has no tree);
+//   2. connected components by min-label propagation over the coupling rows (LDS atomics, at most ntree sweeps);
+//   3. islands numbered by their smallest tree; their dofs (tree ranges concatenated in tree order) listed in ws_isl_dofmap with the
+//      inverse in ws_isl_dofinv, their rows grouped stably in ws_tree_rowmap; ws_isl_dofadr / ws_tree_rowadr delimit island k.
+// ws_separable = 1 when every island has at most 64 dofs: the world is then solved per island by the register-resident kernels
+// (solve_body TREE), otherwise by the generic solver.
+// clears the list counters of k_tree_rows (a kernel, not hipMemsetAsync: a memset node inside the captured step graph faulted on ROCm 7.2)
+__global__ void __launch_bounds__(64) k_isl_clear(MjhData d) {
+  if (threadIdx.x < 4) d.ws_isl_count[threadIdx.x] = 0;
+}
 __global__ void __launch_bounds__(64) k_tree_rows(MjhModel m, MjhData d) {
-  extern __shared__ int sh_tree[];  // [njmax] tree of each row
+  extern __shared__ int sh_isl[];  // [njmax] first tree of each row | [njmax] second tree or -1 | [ntree] label | [ntree] island of tree
   const int w = blockIdx.x, lane = threadIdx.x;
   if (w >= d.nworld) return;
-  const int njmax = d.njmax, nefc = min(d.nefc[w], njmax), ntree = m.ntree;
+  const int njmax = d.njmax, nefc = min(d.nefc[w], njmax), ntree = m.ntree, nv = m.nv;
+  int *rt1 = sh_isl, *rt2 = sh_isl + njmax, *label = sh_isl + 2 * njmax, *isl_of = label + ntree;
   const size_t eo = (size_t)w * njmax;
   int* rowadr = d.ws_tree_rowadr + (size_t)w * (ntree + 1);
+  int* dofadr = d.ws_isl_dofadr + (size_t)w * (ntree + 1);
   int* rowmap = d.ws_tree_rowmap + eo;
-  bool coupled = false;
+  int* dmap = d.ws_isl_dofmap + (size_t)w * nv;
+  int* dinv = d.ws_isl_dofinv + (size_t)w * nv;
+  for (int t = lane; t < ntree; t += 64) label[t] = t;
   for (int r = lane; r < nefc; r += 64) {
     const int type = d.efc_type[eo + r];
-    int t = 0;
+    int t1 = 0, t2 = -1;
     if (type == CT_EQUALITY) {
       const int e = d.efc_id[eo + r], j1 = m.eq_obj1id[e], j2 = m.eq_obj2id[e];
-      t = m.dof_treeid[m.jnt_dofadr[j1]];
-      if (j2 >= 0 && m.dof_treeid[m.jnt_dofadr[j2]] != t) coupled = true;
+      t1 = m.dof_treeid[m.jnt_dofadr[j1]];
+      if (j2 >= 0) t2 = m.dof_treeid[m.jnt_dofadr[j2]];
     } else if (type == CT_FRICTION_DOF) {
-      t = m.dof_treeid[d.efc_id[eo + r]];
+      t1 = m.dof_treeid[d.efc_id[eo + r]];
     } else if (type == CT_LIMIT_JOINT) {
-      t = m.dof_treeid[m.jnt_dofadr[d.efc_id[eo + r]]];
+      t1 = m.dof_treeid[m.jnt_dofadr[d.efc_id[eo + r]]];
     } else {  // contact rows (efc.id is being rewritten by the contact publication: the row -> contact map is ws_efc_con)
       const int c = d.ws_efc_con[eo + r] >> 4;
       const int* rec = reinterpret_cast<const int*>(d.ws_contact + ((size_t)w * d.concap + c) * CON_STRIDE);
-      const int t1 = m.body_treeid[m.geom_bodyid[rec[25]]], t2 = m.body_treeid[m.geom_bodyid[rec[26]]];
-      if (t1 >= 0 && t2 >= 0 && t1 != t2) coupled = true;
-      t = t1 >= 0 ? t1 : (t2 >= 0 ? t2 : 0);  // (two static bodies: an all-zero row, any tree will do)
+      const int a = m.body_treeid[m.geom_bodyid[rec[25]]], b = m.body_treeid[m.geom_bodyid[rec[26]]];
+      t1 = a >= 0 ? a : (b >= 0 ? b : 0);  // (two static bodies: an all-zero row, any tree will do)
+      t2 = (a >= 0 && b >= 0) ? b : -1;
     }
-    sh_tree[r] = t;
+    if (t2 == t1) t2 = -1;
+    rt1[r] = t1;
+    rt2[r] = t2;
   }
   __syncthreads();
-  const bool any_coupled = __ballot(coupled) != 0ull;
+  for (int sweep = 0; sweep < ntree; ++sweep) {  // labels only decrease; a path of k trees needs at most k sweeps
+    for (int r = lane; r < nefc; r += 64)
+      if (rt2[r] >= 0) {
+        const int lo = min(label[rt1[r]], label[rt2[r]]);
+        atomicMin(&label[rt1[r]], lo);
+        atomicMin(&label[rt2[r]], lo);
+      }
+    __syncthreads();
+    for (int t = lane; t < ntree; t += 64) label[t] = label[label[t]];
+    __syncthreads();
+  }
+  // islands in the order of their smallest tree (its label is itself): lane 0 walks the (few) trees and records for every tree its
+  // island and the first island-local dof, then all lanes fill the dof maps
+  int nisland = 0;
+  bool fits = true;
+  if (lane == 0) {
+    int adr = 0;
+    for (int t = 0; t < ntree; ++t) {
+      if (label[t] != t) continue;
+      dofadr[nisland] = adr;
+      for (int u = t; u < ntree; ++u)
+        if (label[u] == t) {
+          isl_of[u] = nisland;
+          label[u] = -1 - adr;  // (the label has served: keep the tree's first slot in the dof map, tagged negative)
+          adr += m.tree_dofnum[u];
+        }
+      if (adr - dofadr[nisland] > 64) fits = false;
+      ++nisland;
+    }
+    for (int k = nisland; k <= ntree; ++k) dofadr[k] = adr;
+  }
+  __syncthreads();
+  for (int i = lane; i < nv; i += 64) {
+    const int t = m.dof_treeid[i], slot0 = -1 - label[t], pos = slot0 + i - m.tree_dofadr[t];
+    dmap[pos] = i;
+    dinv[i] = pos - dofadr[isl_of[t]];
+  }
+  nisland = __builtin_amdgcn_readfirstlane(nisland);
+  __syncthreads();
   int adr = 0;
-  for (int t = 0; t < ntree; ++t) {
-    if (lane == 0) rowadr[t] = adr;
+  for (int k = 0; k < nisland; ++k) {
+    if (lane == 0) rowadr[k] = adr;
     for (int r0 = 0; r0 < nefc; r0 += 64) {
       const int r = r0 + lane;
-      const bool mine = r < nefc && sh_tree[r] == t;
+      const bool mine = r < nefc && isl_of[rt1[r]] == k;
       const unsigned long long bits = __ballot(mine);
       if (mine) rowmap[adr + __popcll(bits & ((1ull << lane) - 1ull))] = r;
       adr += __popcll(bits);
     }
   }
   if (lane == 0) {
-    rowadr[ntree] = adr;
-    d.ws_separable[w] = any_coupled ? 0 : 1;
+    for (int k = nisland; k <= ntree; ++k) rowadr[k] = adr;
+    rowadr[nisland] = adr;
+    int flags = 0;  // which rare island classes this world holds (the LOOPED launches of solve_tree.hpp test them)
+    for (int k = 0; k < nisland; ++k) {
+      const int nd = dofadr[k + 1] - dofadr[k], nr = rowadr[k + 1] - rowadr[k];
+      if (nd > 32) flags |= ISL_WIDE;
+      else if (nr > 64) flags |= ISL_MANYROWS;
+    }
+    d.ws_isl_flags[w] = fits ? flags : 0;
+    // worlds of the rare classes are listed for the looped launches (one atomic each; the counters are cleared before this kernel)
+    if (!fits) d.ws_isl_list[(size_t)ISL_LIST_GENERIC * d.nworld + atomicAdd(d.ws_isl_count + ISL_LIST_GENERIC, 1)] = w;
+    else {
+      if (flags & ISL_WIDE) d.ws_isl_list[(size_t)ISL_LIST_WIDE * d.nworld + atomicAdd(d.ws_isl_count + ISL_LIST_WIDE, 1)] = w;
+      if (flags & ISL_MANYROWS) d.ws_isl_list[(size_t)ISL_LIST_MANYROWS * d.nworld + atomicAdd(d.ws_isl_count + ISL_LIST_MANYROWS, 1)] = w;
+    }
+    d.ws_nisland[w] = nisland;
+    d.ws_separable[w] = fits ? 1 : 0;
     d.solver_niter[w] = 0;
   }
 }

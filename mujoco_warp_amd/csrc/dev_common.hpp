@@ -31,6 +31,8 @@ enum { DSBL_CONSTRAINT = 1 << 0, DSBL_EQUALITY = 1 << 1, DSBL_FRICTIONLOSS = 1 <
        DSBL_REFSAFE = 1 << 12, DSBL_EULERDAMP = 1 << 15, DSBL_NATIVECCD = 1 << 17 };
 enum { SOL_PGS = 0, SOL_CG = 1, SOL_NEWTON = 2 };
 enum { CONE_PYRAMIDAL = 0, CONE_ELLIPTIC = 1 };
+enum { ISL_WIDE = 1, ISL_MANYROWS = 2 };
+enum { ISL_LIST_MANYROWS = 0, ISL_LIST_WIDE = 1, ISL_LIST_GENERIC = 2 };  // Data.ws_isl_list / ws_isl_count classes  // Data.ws_isl_flags: a world holds an island of 33..64 dofs / of <= 32 dofs and > 64 rows
 #define CON_STRIDE 32  /* words per contact record in d.ws_contact (layout: collide.hpp) */
 enum { INT_EULER = 0, INT_RK4 = 1, INT_IMPLICIT = 2, INT_IMPLICITFAST = 3 };
 enum { OVF_NEFC = 1 << 0, OVF_NJMAX_NNZ = 1 << 1, OVF_BROADPHASE = 1 << 2, OVF_NARROWPHASE = 1 << 3, OVF_EPA_HORIZON = 1 << 8, OVF_ITERATIONS = 1 << 9, OVF_LS_ITERATIONS = 1 << 10 };

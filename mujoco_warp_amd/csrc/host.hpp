@@ -68,8 +68,8 @@ int launch_solve_32_cg_ell(const MjhModel* m, const MjhData* d, int nr, bool wit
 int launch_solve_32_newton_ell(const MjhModel* m, const MjhData* d, int nr, bool with_factor, int fuse_euler, hipStream_t s, int lo, int hi);
 int launch_solve_64_cg_ell(const MjhModel* m, const MjhData* d, int nr, bool with_factor, int fuse_euler, hipStream_t s, int lo, int hi);
 int launch_solve_64_newton_ell(const MjhModel* m, const MjhData* d, int nr, bool with_factor, int fuse_euler, hipStream_t s, int lo, int hi);
-// per-(world, tree) solves for nv > 64 (solve_tree_*.hip)
-int launch_solve_tree_cg(const MjhModel* m, const MjhData* d, int nv4, int nr, hipStream_t s, int lo, int hi);
-int launch_solve_tree_newton(const MjhModel* m, const MjhData* d, int nv4, int nr, hipStream_t s, int lo, int hi);
+// per-(world, island) solves for nv > 64 (solve_tree_*.hip)
+int launch_solve_tree_cg(const MjhModel* m, const MjhData* d, hipStream_t s);
+int launch_solve_tree_newton(const MjhModel* m, const MjhData* d, hipStream_t s);
 int launch_pgs(const MjhModel* m, const MjhData* d, hipStream_t s);
 int launch_solve_big(const MjhModel* m, const MjhData* d, hipStream_t s);  // nv > 64 (solver_big.hpp)

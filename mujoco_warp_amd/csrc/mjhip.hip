@@ -235,14 +235,11 @@ static int launch_solve_any(const MjhModel* m, const MjhData* d, bool with_facto
   if (int rc = solve_supported(m, d)) return rc;
   if (m->nv > 64) {  // no riders: they go with the integrator launch
     if (m->tree_solve) {
-      // rows grouped by kinematic tree; worlds none of whose rows couples two trees are solved per (world, tree) by the
-      // register-resident kernel (two sizes by the rows of a tree), the others by the generic solver below
-      hipLaunchKernelGGL(k_tree_rows, dim3(d->nworld), dim3(64), sizeof(int) * (size_t)std::max(d->njmax, 1), s, *m, *d);
-      auto tree = m->solver == SOL_NEWTON ? launch_solve_tree_newton : launch_solve_tree_cg;
-      const int nv4 = (m->tree_nvmax + 3) / 4;
-      if (int rc = tree(m, d, nv4, 2, s, -1, 64)) return rc;
-      if (d->njmax > 64)
-        if (int rc = tree(m, d, nv4, 6, s, 64, 0x7fffffff)) return rc;
+      // constraint islands (trees joined by coupling rows): worlds whose islands all have at most 64 dofs are solved per island by the
+      // register-resident kernels, the others by the generic solver below
+      hipLaunchKernelGGL(k_isl_clear, dim3(1), dim3(64), 0, s, *d);
+      hipLaunchKernelGGL(k_tree_rows, dim3(d->nworld), dim3(64), sizeof(int) * (size_t)(2 * std::max(d->njmax, 1) + 2 * m->ntree), s, *m, *d);
+      if (int rc = (m->solver == SOL_NEWTON ? launch_solve_tree_newton : launch_solve_tree_cg)(m, d, s)) return rc;
     }
     return launch_solve_big(m, d, s);
   }

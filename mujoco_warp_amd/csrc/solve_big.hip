@@ -5,7 +5,19 @@
 
 __global__ void __launch_bounds__(64) k_solve_big(MjhModel m, MjhData d) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  solve_big_body<64>(m, d, smem, Blk{(int)blockIdx.x, 1, 64});
+  // with constraint islands (MjhModel.tree_solve) only the worlds holding an island of more than 64 dofs come here: a small grid
+  // walks their list (an LDS-heavy block per world would cost ~100 us of empty rounds)
+  if (m.tree_solve) {
+    const int nlist = d.ws_isl_count[ISL_LIST_GENERIC];
+#pragma nounroll
+    for (int i = blockIdx.x; i < nlist; i += gridDim.x) {
+      int w = __builtin_amdgcn_readfirstlane(d.ws_isl_list[(size_t)ISL_LIST_GENERIC * d.nworld + i]);  // (block-uniform)
+      asm volatile("" : "+s"(w));
+      solve_big_body<64>(m, d, smem, Blk{w, 1, 64}, true);
+    }
+    return;
+  }
+  solve_big_body<64>(m, d, smem, Blk{(int)blockIdx.x, 1, 64}, false);
 }
 
 int launch_solve_big(const MjhModel* m, const MjhData* d, hipStream_t s) {
@@ -13,6 +25,6 @@ int launch_solve_big(const MjhModel* m, const MjhData* d, hipStream_t s) {
   const size_t lds = sizeof(int) * mstruct_ints(m->nv, m->nC) + sizeof(float) * lay.total;
   if (lds > (size_t)kLdsPerCU) return fail(MJH_E_UNSUPPORTED, "k_solve_big: nv / njmax do not fit in LDS");
   HIPCHK(set_lds(k_solve_big, lds));
-  hipLaunchKernelGGL(k_solve_big, dim3(d->nworld), dim3(64), lds, s, *m, *d);
+  hipLaunchKernelGGL(k_solve_big, dim3(m->tree_solve ? std::min(d->nworld, 1024) : d->nworld), dim3(64), lds, s, *m, *d);
   return MJH_OK;
 }

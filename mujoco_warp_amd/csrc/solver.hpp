@@ -501,27 +501,32 @@ DEV void invert_rows(const float (&mrow)[NVR], float (&b)[NVR], float* buf, int 
   }
 }
 
-// TREE (nv > 64, MjhModel.tree_solve): the unit of work is one kinematic tree of one world -- dofs [dof0, dof0 + nv) and the rows
-// k_tree_rows grouped under that tree (M is block diagonal over trees, so a world none of whose rows couples two trees separates
-// exactly into per-tree problems); every global index goes through dof0 / the row map, everything else is the same kernel.
+// TREE (nv > 64, MjhModel.tree_solve): the unit of work is one constraint island of one world -- the dofs of the kinematic trees
+// that k_tree_rows found connected by coupling rows (M is block diagonal over trees, so the problem separates exactly over islands)
+// and the rows grouped under that island; every global index goes through the island's dof map / row map, everything else is the
+// same kernel.  An instantiation serves the islands whose dof count lies in (nv_lo, nv_hi] (32 lanes: <= 32 dofs, 64 lanes: 33..64).
 template <int NV4, int NR, bool NEWTON, int G, bool ELL = false, bool TREE = false>
 DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk& b, int nefc_lo = -1, int nefc_hi = 0x7fffffff,
-                    int fuse_euler = 0) {
+                    int fuse_euler = 0, int nv_lo = 0, int nv_hi = 0x7fffffff) {
   if ((int)threadIdx.x >= b.nthreads) return;
   constexpr int NVR = 4 * NV4;
   constexpr int JS = (NV4 & 1) ? NVR : NVR + 4;
-  static_assert(!TREE || !ELL, "per-tree solve: pyramidal cones only");
+  static_assert(!TREE || !ELL, "per-island solve: pyramidal cones only");
   const int nv_all = m.nv, nC = m.nC, njmax = d.njmax, nvp = d.nv_pad;
   const SolveLayout lay = solve_layout<NV4, NR, G, NEWTON, ELL, TREE>(njmax);
   const int lig = threadIdx.x & (G - 1), gib = threadIdx.x / G;
   const int slot = b.w0 + gib;
+  if (TREE && gib >= b.nw) return;  // (a looped launch hands a block fewer islands than it has lane groups)
   if (slot >= (TREE ? d.nworld * m.ntree : d.nworld)) return;
   // worlds are scheduled longest-expected-solve first and paired with a similar neighbour (k_schedule_worlds)
   const int w = TREE ? slot / m.ntree : d.ws_order[slot];
-  const int tree = TREE ? slot - w * m.ntree : 0;
-  if (TREE && !d.ws_separable[w]) return;  // a row couples two trees: the generic solver takes this world
-  const int dof0 = TREE ? m.tree_dofadr[tree] : 0;
-  const int nv = TREE ? m.tree_dofnum[tree] : nv_all;
+  const int tree = TREE ? slot - w * m.ntree : 0;  // island index
+  if (TREE && (!d.ws_separable[w] || tree >= d.ws_nisland[w])) return;  // (an island of more than 64 dofs: the generic solver)
+  const int* dadr = TREE ? d.ws_isl_dofadr + (size_t)w * (m.ntree + 1) + tree : nullptr;
+  const int nv = TREE ? dadr[1] - dadr[0] : nv_all;
+  if (TREE && (nv <= nv_lo || nv > nv_hi)) return;
+  const int* dmap = TREE ? d.ws_isl_dofmap + (size_t)w * nv_all + dadr[0] : nullptr;  // island dof -> dof
+  const int* dinv = TREE ? d.ws_isl_dofinv + (size_t)w * nv_all : nullptr;            // dof -> island dof
   const int* rmap = TREE ? d.ws_tree_rowmap + (size_t)w * njmax + d.ws_tree_rowadr[(size_t)w * (m.ntree + 1) + tree] : nullptr;
   auto R = [&](int r) __attribute__((always_inline)) { return TREE ? rmap[r] : r; };  // global row of this problem's row r
   // LDS decides how many worlds a CU holds (the kernel runs 2-3 rounds): no block-shared tables here, the M-structure
@@ -542,7 +547,8 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
   if (nefc_all <= nefc_lo || nefc_all > nefc_hi) return;
   const int nefc = min(nefc_all, G * NR);
   const int ne = TREE ? 0 : d.ne[w], nf = TREE ? 0 : d.nf[w];
-  const size_t vo = (size_t)w * nv_all + dof0, eo = (size_t)w * njmax;
+  // vo + lig = this lane's entry of a world's nv-vector (TREE: through the island's dof map, hence a per-lane base)
+  const size_t vo = TREE ? (size_t)w * nv_all + (lig < nv ? dmap[lig] : 0) - lig : (size_t)w * nv_all, eo = (size_t)w * njmax;
   // friction-loss rows present: the line search needs the three-zone cost (rare).  TREE: row kinds come from efc.type and the
   // frictionloss values are gathered into an LDS line (the row map breaks the lane-strided addressing of the plain path)
   float* flds = S + lay.fl;
@@ -569,9 +575,10 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
     gsync();
     const float* Mg = d.M + (size_t)w * nC;
     for (int i = lig; i < nv; i += G) {
-      const int start = m.M_rowadr[dof0 + i], n = m.M_rownnz[dof0 + i];
+      const int gi = TREE ? dmap[i] : i;
+      const int start = m.M_rowadr[gi], n = m.M_rownnz[gi];
       for (int a = 0; a < n; ++a) {
-        const int j = m.M_colind[start + a] - dof0;  // (ancestors of a dof lie in its own tree)
+        const int j = TREE ? dinv[m.M_colind[start + a]] : m.M_colind[start + a];  // (ancestors of a dof lie in its own tree)
         const float v = Mg[start + a];
         Jl[i * JS + j] = v;
         Jl[j * JS + i] = v;
@@ -657,7 +664,7 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
     const float* Jg = d.efc_J + (size_t)w * d.njmax_pad * nvp;
     if (TREE) {  // this tree's rows and columns
       for (int r = 0; r < nefc; ++r)
-        for (int c = lig; c < JS; c += G) Jl[r * JS + c] = c < nv ? Jg[(size_t)rmap[r] * nvp + dof0 + c] : 0.0f;
+        for (int c = lig; c < JS; c += G) Jl[r * JS + c] = c < nv ? Jg[(size_t)rmap[r] * nvp + dmap[c]] : 0.0f;
     } else if (nvp == JS) {
       // same row stride in HBM and LDS: one flat copy with 16-byte loads, all in flight (a world's J block is 16-byte
       // aligned: njmax_pad * nv_pad is a multiple of 4)

@@ -40,7 +40,7 @@ __host__ __device__ inline BigLayout big_layout(int nv, int nC, int njmax, bool 
 }
 
 template <int G>
-DEV void solve_big_body(const MjhModel& m, const MjhData& d, float* smem, const Blk& b) {
+DEV void solve_big_body(const MjhModel& m, const MjhData& d, float* smem, const Blk& b, bool direct = false) {
   if ((int)threadIdx.x >= b.nthreads) return;
   const int nv = m.nv, nC = m.nC, njmax = d.njmax, nvp = d.nv_pad;
   const bool newton = m.solver == SOL_NEWTON;
@@ -50,8 +50,7 @@ DEV void solve_big_body(const MjhModel& m, const MjhData& d, float* smem, const 
   const int lig = threadIdx.x & (G - 1), gib = threadIdx.x / G;
   const int slot = b.w0 + gib;
   if (slot >= d.nworld) return;
-  const int w = d.ws_order[slot];
-  if (m.tree_solve && d.ws_separable[w]) return;  // solved per tree by k_solve_tree (no row couples two trees)
+  const int w = direct ? slot : d.ws_order[slot];  // (direct: the caller hands world ids, not schedule slots)
   float* S = smem + mstruct_ints(nv, nC) + (size_t)gib * lay.total;
   float *q = S + lay.q, *Ma = S + lay.Ma, *grad = S + lay.grad, *Mgrad = S + lay.Mgrad, *search = S + lay.search, *mv = S + lay.mv,
         *pgrad = S + lay.pgrad, *pMgrad = S + lay.pMgrad, *qc = S + lay.qc, *fs = S + lay.fs, *x = S + lay.x;

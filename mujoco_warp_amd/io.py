@@ -272,8 +272,16 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
   m.ntree = len(roots)
   m.tree_nvmax = int(tree_dofnum.max()) if len(roots) else 0
   # nv > 64: worlds whose rows each touch one kinematic tree are solved per (world, tree) by the register-resident kernels
-  m.tree_solve = int(nv > 64 and m.ntree > 1 and m.tree_nvmax <= 32 and int(opt.solver) != types.SolverType.PGS
+  m.tree_solve = int(nv > 64 and m.ntree > 1 and m.tree_nvmax <= 64 and int(opt.solver) != types.SolverType.PGS
                      and int(opt.cone) == types.ConeType.PYRAMIDAL)
+  # size classes of the island kernels: islands of <= 32 dofs run with 32 lanes and ceil(dofs / 4) quarter-rows -- the widest one is a
+  # single tree unless two trees together fit --, islands of 33..64 dofs with 64 lanes
+  small = sorted(int(n) for n in tree_dofnum if n <= 32)
+  widest = max(small) if small else 0
+  if len(small) >= 2 and small[0] + small[1] <= 32:
+    widest = 32
+  m.isl_nv4 = (widest + 3) // 4
+  m.isl_wide = int(nv > 32)
   nw = max((nv + 31) // 32, 1)
   dofmask = np.zeros((nbody, nw), dtype=np.uint32)
   for b in range(nbody):  # io.py:536-549 body_isdofancestor as bit masks
@@ -448,6 +456,7 @@ def _data_shapes(m, nworld, nconmax, njmax, naconmax):
     efc_type=(W, njmax), efc_id=(W, njmax), efc_state=(W, njmax), efc_J=(W, njmax_pad, nv_pad), efc_pos=(W, njmax),
     efc_margin=(W, njmax), efc_D=(W, njmax), efc_vel=(W, njmax), efc_aref=(W, njmax), efc_frictionloss=(W, njmax),
     efc_force=(W, njmax), ws_ncon=(W,), ws_conadr=(W,), ws_ncollision=(W,), ws_efc_con=(W, njmax), ws_tree_rowadr=(W, (m.ntree + 1) if m.tree_solve else 0), ws_tree_rowmap=(W, njmax if m.tree_solve else 0),
+    ws_isl_dofadr=(W, (m.ntree + 1) if m.tree_solve else 0), ws_isl_dofmap=(W, nv if m.tree_solve else 0), ws_isl_dofinv=(W, nv if m.tree_solve else 0), ws_nisland=(W,), ws_isl_flags=(W,), ws_isl_list=(3, W if m.tree_solve else 0), ws_isl_count=(4,),
     ws_separable=(W,), ws_order=(W,), ws_ccd=(W if m._convex_pairs else 0, _ccd_words(max(int(m.opt.ccd_iterations), int(m.epa_iterations))), 32),
     eq_active=(W, m.neq), ws_rk=(W, nq + 3 * nv + 2 * na), ws_contact=(W, contact_cap(nconmax), 32),
   )

@@ -385,7 +385,9 @@ class Model(_Dirty):
   epa_iterations: int = 0  # EPA iteration cap of the convex narrowphase (reference collision_convex.py:1223)
   ntree: int = 0  # kinematic trees with at least one dof
   tree_nvmax: int = 0  # dofs of the largest tree
-  tree_solve: int = 0  # 1: nv > 64 with trees of <= 32 dofs: tree-separable worlds are solved per (world, tree)
+  isl_nv4: int = 0  # quarter-rows of the widest island of <= 32 dofs (kernel size class)
+  isl_wide: int = 0  # islands of 33..64 dofs can form
+  tree_solve: int = 0  # 1: nv > 64, several trees: worlds whose constraint islands have <= 64 dofs are solved per island
   nmaxpyramid: int = 0
   key_qpos: np.ndarray = _arr(('nkey', 'nq'), "float32", host=True)
   key_qvel: np.ndarray = _arr(('nkey', 'nv'), "float32", host=True)
@@ -498,6 +500,13 @@ class Data(_Dirty):
   ws_efc_con: DeviceArray = _arr(('nworld', 'njmax'), "int32")
   ws_tree_rowadr: DeviceArray = _arr(('nworld', 'ntreeadr'), "int32")
   ws_tree_rowmap: DeviceArray = _arr(('nworld', 'ntreerow'), "int32")
+  ws_isl_dofadr: DeviceArray = _arr(('nworld', 'ntreeadr'), "int32")
+  ws_isl_dofmap: DeviceArray = _arr(('nworld', 'ntreedof'), "int32")
+  ws_isl_dofinv: DeviceArray = _arr(('nworld', 'ntreedof'), "int32")
+  ws_nisland: DeviceArray = _arr(('nworld',), "int32")
+  ws_isl_flags: DeviceArray = _arr(('nworld',), "int32")
+  ws_isl_list: DeviceArray = _arr((3, 'ntreeworld'), "int32")
+  ws_isl_count: DeviceArray = _arr((4,), "int32")
   ws_separable: DeviceArray = _arr(('nworld',), "int32")
   ws_ccd: DeviceArray = _arr(('nccdworld', 'nccdword', 32), "float32")
   ws_order: DeviceArray = _arr(('nworld',), "int32")

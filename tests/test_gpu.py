@@ -464,42 +464,52 @@ def test_rk4_integrator(solver):
 
 
 @pytest.mark.parametrize("solver", [mjw.SolverType.NEWTON, mjw.SolverType.CG])
-def test_tree_solve_mixes_separable_and_coupled_worlds(solver):
-  """nv = 81: a world whose rows each touch one humanoid is solved per (world, tree) by the register-resident kernel; a world in
-  which two humanoids touch each other has rows coupling two trees and goes to the generic solver -- in the same batch."""
+def test_constraint_islands_nv81(solver):
+  """nv = 81, three humanoids (27 dofs each): constraint islands = kinematic trees joined by coupling rows (reference island.py at
+  tree granularity).  World 0: apart -- three islands of 27 dofs (32-lane kernel); world 1: two humanoids interpenetrate -- an island
+  of 54 dofs (64-lane kernel) and one of 27; world 2: all three touch -- one island of 81 dofs, too wide for the register kernels:
+  the generic solver.  All in one batch, each against its own float64 oracle world."""
   mjm = mjw.mjcf.from_xml_string(conftest.multi_humanoid_xml(3), assets_dir=os.path.dirname(conftest.HUMANOID_XML))
   mjm.opt.solver = int(solver)
   sims = []
-  for w in range(2):
+  for w in range(3):
     s = ref.RefSim(mjm, nconmax=100, njmax=192, tolerance=1e-6)
     s.reset(key=0 if mjm.nkey else None)
-    if w == 1:  # second humanoid moved onto the first one: arms and torsos interpenetrate
+    if w >= 1:  # second humanoid moved onto the first one: arms and torsos interpenetrate
       s.qpos[28 : 28 + 3] = s.qpos[0:3] + np.array([0.12, 0.05, 0.0])
+    if w == 2:  # and the third onto both
+      s.qpos[56 : 56 + 3] = s.qpos[0:3] + np.array([-0.1, -0.05, 0.0])
     for _ in range(30):
       s.step()
     sims.append(s)
   m = mjw.put_model(mjm)
-  assert m.tree_solve == 1 and m.ntree == 3
-  d = mjw.put_data(mjm, mjw.MjData(mjm), nworld=2, nconmax=100, njmax=192)
+  assert m.tree_solve == 1 and m.ntree == 3 and m.isl_nv4 == 7
+  d = mjw.put_data(mjm, mjw.MjData(mjm), nworld=3, nconmax=100, njmax=192)
+  bt = m.body_treeid.numpy()
   worst = [0.0, 0.0]
   seen = set()
   for i in range(15):
     for name in ("qpos", "qvel", "qacc_warmstart"):
       getattr(d, name).assign(np.stack([getattr(s, name) for s in sims]).astype(np.float32))
     mjw.step(m, d)
-    sep = d.ws_separable.numpy()
+    sep, nisl = d.ws_separable.numpy(), d.ws_nisland.numpy()
     for w, s in enumerate(sims):
       s.step()
-      trees = {tuple(sorted({int(m.body_treeid.numpy()[mjm.geom_bodyid[g]]) for g in s.con_geom[c]} - {-1})) for c in range(s.ncon)}
-      coupled = any(len(t) == 2 for t in trees)
-      assert int(sep[w]) == (0 if coupled else 1), (w, trees)
-      seen.add((w, coupled))
+      comp = list(range(3))  # islands from the oracle's contacts
+      for c in range(s.ncon):
+        t = sorted({int(bt[mjm.geom_bodyid[g]]) for g in s.con_geom[c]} - {-1})
+        if len(t) == 2:
+          a, b2 = comp[t[0]], comp[t[1]]
+          comp = [min(a, b2) if x in (a, b2) else x for x in comp]
+      widest = max(comp.count(x) for x in set(comp)) * 27
       if int(d.ws_ncon.numpy()[w]) != s.ncon:
         continue
+      assert int(nisl[w]) == len(set(comp)) and int(sep[w]) == (1 if widest <= 64 else 0), (w, comp, nisl[w], sep[w])
+      seen.add((w, widest))
       worst[0] = max(worst[0], relerr(d.qpos.numpy()[w], s.qpos))
       worst[1] = max(worst[1], relerr(d.qvel.numpy()[w], s.qvel))
       assert int(d.solver_niter.numpy()[w]) > 0
-  assert (0, False) in seen and (1, True) in seen
+  assert (0, 27) in seen and (1, 54) in seen and (2, 81) in seen, seen
   assert worst[0] <= 1e-5 and worst[1] <= 5e-3, worst
 
 
@@ -519,7 +529,7 @@ def test_three_humanoids_nv81(solver):
   # worlds whose rows each touch one humanoid are solved per (world, tree) (solve_body TREE): every tree runs its own line searches
   # and stops on its own test, so CG -- which stops far from the fixed point at tolerance 1e-6 -- lands on a slightly different iterate
   # than the oracle's joint solve (measured 2.4e-3 on the forces); Newton converges to the same point
-  assert m.tree_solve == 1 and int(d.ws_separable.numpy().min()) in (0, 1)
+  assert m.tree_solve == 1 and int(d.ws_nisland.numpy().min()) >= 1
   _check_solution(s, d, tol=SOLVE if solver == mjw.SolverType.NEWTON else 2 * SOLVE)
   worst_q = worst_v = 0.0
   boundary_steps = 0
