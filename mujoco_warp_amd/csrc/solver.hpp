@@ -48,6 +48,17 @@ DEV float gsumg(float v) {
 // broadcasts share one wait.  Measured (tools/ubench_ls.hip): a line-search iteration -- nine sums -- drops from 1470 cycles.
 template <int G, int N>
 DEV void gsumg_n(float (&v)[N]) {
+#ifdef MJH_F64_LS
+  // experiment: the cross-lane sums of the line search / CG scalars accumulated in float64
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    double x = (double)v[i];
+#pragma unroll
+    for (int off = G / 2; off >= 1; off >>= 1) x += __shfl_xor(x, off, G);
+    v[i] = (float)x;
+  }
+  return;
+#endif
 #pragma unroll
   for (int i = 0; i < N; ++i) v[i] = dpp_add_f<0x111, 0xf, 0xf>(v[i]);  // row_shr:1
 #pragma unroll
