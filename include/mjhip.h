@@ -240,6 +240,11 @@ int mjh_mul_m(const MjhModel* m, const MjhData* d, float* res, const float* vec,
  * [nworld, njmax_nnz]; the reference stores efc.J this way for nv > 32, io.py:1804-1808).  Entries = the numerically non-zero values of
  * each row (a subset of the reference's structural pattern); rows whose entries do not fit njmax_nnz are truncated and
  * OverflowType.NJMAX_NNZ is set.  Opt-in: nothing inside step reads it. */
+/* Dense Cholesky factors of M's diagonal (kinematic-tree) blocks in the reference's packed layout (io.py:173-211 m_block_layout,
+ * smooth.py:3256: upper factor U with M = U^T U, n x n row-major per tree at qld_dense + nworld stride * w + block offset, blocks in tree
+ * order; entries below the diagonal are zero).  Opt-in: Data.qLD of this engine stays MuJoCo's sparse L^T D L factor (DESIGN.md, section
+ * 2).  Trees of more than 64 dofs are skipped (the reference keeps the sparse factor for them too). */
+int mjh_qld_dense(const MjhModel* m, const MjhData* d, float* qld_dense, int stride, void* stream);
 int mjh_efc_j_sparse(const MjhModel* m, const MjhData* d, int njmax_nnz, int* rownnz, int* rowadr, int* colind, float* values, void* stream);
 
 /* cli._ctrl_noise cli.py:103-145; ctrl_center may be NULL (-> actuator midpoint); worldid is global */
@@ -266,7 +271,7 @@ int mjh_timed_steps(const MjhModel* m, const MjhData* d, int nstep, int step0, f
 int mjh_release_thread_resources(void);
 
 const char* mjh_last_error(void);
-#define MJH_ABI_VERSION 13
+#define MJH_ABI_VERSION 14
 int mjh_abi_version(void); /* returns MJH_ABI_VERSION of the library that was loaded */
 
 #ifdef __cplusplus

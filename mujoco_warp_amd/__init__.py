@@ -16,6 +16,7 @@ from .forward import collision
 from .forward import crb
 from .forward import ctrl_noise
 from .forward import efc_J_sparse
+from .forward import qLD_dense
 from .forward import euler
 from .forward import factor_m
 from .forward import forward

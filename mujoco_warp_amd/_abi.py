@@ -138,6 +138,7 @@ def lib():
   L.mjh_forward.argtypes = [mp, dp, vp]
   L.mjh_solve_m.argtypes = [mp, dp, vp, vp, vp]
   L.mjh_mul_m.argtypes = [mp, dp, vp, vp, vp]
+  L.mjh_qld_dense.argtypes = [mp, dp, vp, ctypes.c_int, vp]
   L.mjh_efc_j_sparse.argtypes = [mp, dp, ctypes.c_int, vp, vp, vp, vp, vp]
   L.mjh_ctrl_noise.argtypes = [mp, dp, vp, ctypes.c_int, ctypes.c_float, ctypes.c_float, vp]
   L.mjh_graph_create.argtypes = [mp, dp, vp, ctypes.POINTER(vp)]

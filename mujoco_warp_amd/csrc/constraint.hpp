@@ -610,3 +610,45 @@ __global__ void __launch_bounds__(64) k_tree_rows(MjhModel m, MjhData d) {
     d.solver_niter[w] = 0;
   }
 }
+
+
+// ---- opt-in: dense upper Cholesky factors of M's tree blocks in the reference's packed qLD layout (mjh_qld_dense) --------------------
+// one 64-lane wavefront per (world, tree), n <= 64: the block is densified in LDS, factored column by column (lane = column of the
+// trailing update), and stored as U (M = U^T U) row-major with zeros below the diagonal
+__global__ void __launch_bounds__(64) k_qld_dense(MjhModel m, MjhData d, float* out, int stride) {
+  __shared__ float A[64 * 65];
+  const int w = blockIdx.x / m.ntree, t = blockIdx.x % m.ntree, lane = threadIdx.x;
+  if (w >= d.nworld) return;
+  const int d0 = m.tree_dofadr[t], n = m.tree_dofnum[t];
+  if (n > 64) return;
+  int off = 0;
+  for (int u = 0; u < t; ++u) off += m.tree_dofnum[u] <= 64 ? m.tree_dofnum[u] * m.tree_dofnum[u] : 0;
+  const float* Mg = d.M + (size_t)w * m.nC;
+  for (int idx = lane; idx < n * 65; idx += 64) A[idx] = 0.0f;
+  __syncthreads();
+  for (int i = lane; i < n; i += 64) {
+    const int start = m.M_rowadr[d0 + i], nn = m.M_rownnz[d0 + i];
+    for (int a = 0; a < nn; ++a) {
+      const int j = m.M_colind[start + a] - d0;
+      A[i * 65 + j] = Mg[start + a];
+      A[j * 65 + i] = Mg[start + a];
+    }
+  }
+  __syncthreads();
+  for (int k = 0; k < n; ++k) {  // U[k][k..] = A[k][k..] / sqrt(A[k][k]); A[i][j] -= U[k][i] U[k][j]
+    const float piv = sqrtf(fmaxf(A[k * 65 + k], MJ_MINVAL));
+    __syncthreads();
+    if (lane >= k && lane < n) A[k * 65 + lane] = A[k * 65 + lane] / piv;
+    __syncthreads();
+    if (lane > k && lane < n) {
+      const float ukj = A[k * 65 + lane];
+      for (int i = k + 1; i <= lane; ++i) A[i * 65 + lane] -= A[k * 65 + i] * ukj;
+    }
+    __syncthreads();
+  }
+  float* o = out + (size_t)w * stride + off;
+  for (int idx = lane; idx < n * n; idx += 64) {
+    const int i = idx / n, j = idx % n;
+    o[idx] = j >= i ? A[i * 65 + j] : 0.0f;
+  }
+}

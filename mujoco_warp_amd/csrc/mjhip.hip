@@ -529,6 +529,15 @@ int mjh_mul_m(const MjhModel* m, const MjhData* d, float* res, const float* vec,
   return launch_solve_m(m, d, res, vec, 1, (hipStream_t)stream);
 }
 
+int mjh_qld_dense(const MjhModel* m, const MjhData* d, float* qld_dense, int stride, void* stream) {
+  TRY(check(m, d));
+  if (!qld_dense || stride < 0) return fail(MJH_E_ARG, "mjh_qld_dense: null output");
+  if (m->ntree == 0 || d->nworld == 0) return MJH_OK;
+  hipLaunchKernelGGL(k_qld_dense, dim3(d->nworld * m->ntree), dim3(64), 0, (hipStream_t)stream, *m, *d, qld_dense, stride);
+  HIPCHK(hipGetLastError());
+  return MJH_OK;
+}
+
 int mjh_efc_j_sparse(const MjhModel* m, const MjhData* d, int njmax_nnz, int* rownnz, int* rowadr, int* colind, float* values, void* stream) {
   TRY(check(m, d));
   if (njmax_nnz < 0 || !rownnz || !rowadr || (njmax_nnz > 0 && (!colind || !values))) return fail(MJH_E_ARG, "mjh_efc_j_sparse: null output or negative njmax_nnz");

@@ -915,3 +915,4 @@ __global__ void __launch_bounds__(256) k_factor_smooth(MjhModel m, MjhData d, in
   extern __shared__ __attribute__((aligned(16))) float smem[];
   factor_smooth_body<G>(m, d, write_qacc, smem, blk_of_launch<G>());
 }
+

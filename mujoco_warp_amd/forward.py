@@ -147,6 +147,25 @@ def mul_m(m, d, res: DeviceArray, vec: DeviceArray):
   _abi.check(L.mjh_mul_m(ctypes.byref(io.c_model(m)), ctypes.byref(io.c_data(d)), res.ptr, vec.ptr, _stream()))
 
 
+def qLD_dense(m, d):
+  """Dense Cholesky factors of M's kinematic-tree blocks in the reference's packed `qLD` layout (reference io.py:173-211
+  m_block_layout, smooth.py:3256: upper factor U, M = U^T U, n x n row-major per tree).  `Data.qLD` of this engine is MuJoCo's sparse
+  L^T D L factor; this is the reference-layout copy on request (call after `factor_m` / `forward`).  Returns (qLD [nworld, total],
+  block_adr [nv]: offset of each dof's block, -1 for trees of more than 64 dofs)."""
+  nums = m.tree_dofnum.numpy()
+  adrs = m.tree_dofadr.numpy()
+  block_adr = np.full(m.nv, -1, dtype=np.int32)
+  total = 0
+  for a, n in zip(adrs, nums):
+    if n <= 64:
+      block_adr[a : a + n] = total
+      total += int(n) * int(n)
+  out = DeviceArray.zeros((d.nworld, total), dtype=np.float32)
+  L = _abi.lib()
+  _abi.check(L.mjh_qld_dense(ctypes.byref(io.c_model(m)), ctypes.byref(io.c_data(d)), out.ptr, total, _stream()))
+  return out, block_adr
+
+
 def efc_J_sparse(m, d, njmax_nnz: int = None):
   """CSR copy of `d.efc.J` in the reference's sparse layout (reference types.py:2021-2070; the reference stores efc.J like this for
   nv > 32, io.py:1804-1808; this engine keeps the dense tile and offers the CSR form on request).  Returns

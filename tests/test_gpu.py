@@ -649,6 +649,27 @@ def test_free_running_1000_steps_statistics():
         assert _ks(a, b) <= crit, (k, name, _ks(a, b), crit)
 
 
+@pytest.mark.parametrize("which", ["humanoid", "three"])
+def test_qLD_dense_view(which):
+  """The reference packs one dense Cholesky factor per kinematic tree into qLD (io.py:173-211); this engine keeps MuJoCo's sparse
+  factor there and hands out the reference-layout copy on request: U^T U must reproduce each tree block of the oracle's M."""
+  if which == "humanoid":
+    mjm = mjw.mjcf.load_xml(conftest.HUMANOID_XML)
+  else:
+    mjm = mjw.mjcf.from_xml_string(conftest.multi_humanoid_xml(3), assets_dir=os.path.dirname(conftest.HUMANOID_XML))
+  s, m, d = _pair(mjm, nworld=2, nconmax=100, njmax=192, warm_steps=5)
+  mjw.forward(m, d)
+  s.forward()
+  q, adr = mjw.qLD_dense(m, d)
+  M = s.dense_M()
+  for a, n in zip(m.tree_dofadr.numpy(), m.tree_dofnum.numpy()):
+    U = q.numpy()[1, adr[a] : adr[a] + n * n].reshape(n, n)
+    assert (np.tril(U, -1) == 0).all() and (np.diag(U) > 0).all()
+    blk = M[a : a + n, a : a + n]
+    assert relerr(U.T @ U, blk) <= 2e-5
+    assert relerr(U, np.linalg.cholesky(blk).T) <= 2e-4
+
+
 def test_efc_J_sparse_view():
   """The reference keeps efc.J in CSR form for nv > 32 (types.py:2021-2070); this engine keeps the dense tile and hands out the CSR
   copy on request: rows, addresses and values must reproduce the dense Jacobian (G1, nv 35)."""
