@@ -72,4 +72,5 @@ int launch_solve_64_newton_ell(const MjhModel* m, const MjhData* d, int nr, bool
 int launch_solve_tree_cg(const MjhModel* m, const MjhData* d, hipStream_t s);
 int launch_solve_tree_newton(const MjhModel* m, const MjhData* d, hipStream_t s);
 int launch_pgs(const MjhModel* m, const MjhData* d, hipStream_t s);
-int launch_solve_big(const MjhModel* m, const MjhData* d, hipStream_t s);  // nv > 64 (solver_big.hpp)
+// generic LDS solver (solver_big.hpp): nv > 64, and the worlds of a small model with more than nefc_lo = 192 rows
+int launch_solve_big(const MjhModel* m, const MjhData* d, hipStream_t s, int nefc_lo = -1);

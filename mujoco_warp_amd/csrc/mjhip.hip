@@ -227,8 +227,8 @@ static int solve_supported(const MjhModel* m, const MjhData* d) {
     return fail(MJH_E_UNSUPPORTED, "elliptic cones need the CG or Newton solver and at most 64 dofs");
   if (m->nv > 64 && m->solver == SOL_PGS) return fail(MJH_E_UNSUPPORTED, "PGS supports at most 64 dofs");
   if (m->solver != SOL_NEWTON && m->solver != SOL_CG && m->solver != SOL_PGS) return fail(MJH_E_UNSUPPORTED, "unknown solver");
-  if (m->nv <= 64 && m->solver != SOL_PGS && d->njmax > 192)
-    return fail(MJH_E_UNSUPPORTED, "njmax > 192 is not supported by the register-resident solver yet (nv <= 64; larger models use the generic solver)");
+  if (m->nv <= 64 && d->njmax > 192 && (m->solver == SOL_PGS || m->cone == CONE_ELLIPTIC))
+    return fail(MJH_E_UNSUPPORTED, "njmax > 192 with PGS or elliptic cones is not supported (the generic solver that takes the worlds with more than 192 rows is CG / Newton, pyramidal)");
   return MJH_OK;
 }
 static int launch_solve_any(const MjhModel* m, const MjhData* d, bool with_factor, hipStream_t s) {
@@ -253,11 +253,15 @@ static int launch_solve_any(const MjhModel* m, const MjhData* d, bool with_facto
   auto s64 = ell ? (newton ? launch_solve_64_newton_ell : launch_solve_64_cg_ell) : (newton ? launch_solve_64_newton : launch_solve_64_cg);
   // njmax > 64: two launches over the same world list (see solve_body): a small-row instantiation for the worlds with
   // at most 64 rows, the big one (riders attached) for the rest
+  // njmax > 192: the register-resident kernels end at 192 rows (6 x 32 / 3 x 64 lanes); the (rare) worlds beyond go to the generic
+  // solver, which keeps J in HBM and is generic in njmax
+  const int top = d->njmax > 192 ? 192 : all;
   if (m->nv <= 32) {
     // rows per lane (32 lanes per world): 2 covers 64 rows (humanoid, panda), 6 covers 192
     if (d->njmax <= 64) return s32(m, d, 2, with_factor, fe, s, -1, all);
     if (int rc = s32(m, d, 2, false, fe, s, -1, 64)) return rc;
-    return s32(m, d, 6, with_factor, fe, s, 64, all);
+    if (int rc = s32(m, d, 6, with_factor, fe, s, 64, top)) return rc;
+    return d->njmax > 192 ? launch_solve_big(m, d, s, 192) : MJH_OK;
   }
   // 64 lanes per world: 1 / 2 / 3 rows per lane cover 64 / 128 / 192 rows.  The second launch of a pair runs after the
   // first on the same stream, so the split point is chosen to leave it (almost) empty: its real worlds would otherwise
@@ -265,7 +269,8 @@ static int launch_solve_any(const MjhModel* m, const MjhData* d, bool with_facto
   if (d->njmax <= 64) return s64(m, d, 1, with_factor, fe, s, -1, all);
   if (d->njmax <= 128) return s64(m, d, 2, with_factor, fe, s, -1, all);
   if (int rc = s64(m, d, 2, with_factor, fe, s, -1, 128)) return rc;
-  return s64(m, d, 3, false, fe, s, 128, all);
+  if (int rc = s64(m, d, 3, false, fe, s, 128, top)) return rc;
+  return d->njmax > 192 ? launch_solve_big(m, d, s, 192) : MJH_OK;
 }
 static int launch_solve(const MjhModel* m, const MjhData* d, hipStream_t s) { return launch_solve_any(m, d, false, s); }
 static int launch_solve_plus(const MjhModel* m, const MjhData* d, hipStream_t s) { return launch_solve_any(m, d, true, s); }
@@ -475,6 +480,7 @@ static int run_stage(const MjhModel* m, const MjhData* d, int stage, hipStream_t
       // solver's own epilogue (saves a launch); every other case keeps the integrator workgroups
       // (Newton: only when its riders run on the side stream -- otherwise the integrator launch exists anyway, for them)
       const bool fuse_euler = stage == MJH_STAGE_STEP && m->integrator == INT_EULER && m->na == 0 && (m->solver == SOL_CG || side != nullptr) && m->nv <= 64 &&
+                              d->njmax <= 192 &&  // (beyond: some worlds go to the generic solver, which does not integrate)
                               (m->disableflags & (DSBL_EULERDAMP | DSBL_DAMPER)) != 0;
       g_fuse_euler = fuse_euler;
       int rc;

@@ -3,7 +3,7 @@
 
 #include "solver_big.hpp"
 
-__global__ void __launch_bounds__(64) k_solve_big(MjhModel m, MjhData d) {
+__global__ void __launch_bounds__(64) k_solve_big(MjhModel m, MjhData d, int nefc_lo) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   // with constraint islands (MjhModel.tree_solve) only the worlds holding an island of more than 64 dofs come here: a small grid
   // walks their list (an LDS-heavy block per world would cost ~100 us of empty rounds)
@@ -17,14 +17,14 @@ __global__ void __launch_bounds__(64) k_solve_big(MjhModel m, MjhData d) {
     }
     return;
   }
-  solve_big_body<64>(m, d, smem, Blk{(int)blockIdx.x, 1, 64}, false);
+  solve_big_body<64>(m, d, smem, Blk{(int)blockIdx.x, 1, 64}, false, nefc_lo);
 }
 
-int launch_solve_big(const MjhModel* m, const MjhData* d, hipStream_t s) {
+int launch_solve_big(const MjhModel* m, const MjhData* d, hipStream_t s, int nefc_lo) {
   const BigLayout lay = big_layout(m->nv, m->nC, d->njmax, m->solver == SOL_NEWTON);
   const size_t lds = sizeof(int) * mstruct_ints(m->nv, m->nC) + sizeof(float) * lay.total;
   if (lds > (size_t)kLdsPerCU) return fail(MJH_E_UNSUPPORTED, "k_solve_big: nv / njmax do not fit in LDS");
   HIPCHK(set_lds(k_solve_big, lds));
-  hipLaunchKernelGGL(k_solve_big, dim3(m->tree_solve ? std::min(d->nworld, 1024) : d->nworld), dim3(64), lds, s, *m, *d);
+  hipLaunchKernelGGL(k_solve_big, dim3(m->tree_solve ? std::min(d->nworld, 1024) : d->nworld), dim3(64), lds, s, *m, *d, nefc_lo);
   return MJH_OK;
 }

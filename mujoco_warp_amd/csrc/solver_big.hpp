@@ -40,7 +40,7 @@ __host__ __device__ inline BigLayout big_layout(int nv, int nC, int njmax, bool 
 }
 
 template <int G>
-DEV void solve_big_body(const MjhModel& m, const MjhData& d, float* smem, const Blk& b, bool direct = false) {
+DEV void solve_big_body(const MjhModel& m, const MjhData& d, float* smem, const Blk& b, bool direct = false, int nefc_lo = -1) {
   if ((int)threadIdx.x >= b.nthreads) return;
   const int nv = m.nv, nC = m.nC, njmax = d.njmax, nvp = d.nv_pad;
   const bool newton = m.solver == SOL_NEWTON;
@@ -60,6 +60,7 @@ DEV void solve_big_body(const MjhModel& m, const MjhData& d, float* smem, const 
   const int HS = lay.HS;
 
   const int nefc = min(d.nefc[w], njmax);
+  if (nefc <= nefc_lo) return;  // (njmax > 192 on a small model: the register-resident kernels took the worlds with fewer rows)
   const int ne = d.ne[w], nf = d.nf[w];
   const size_t vo = (size_t)w * nv, eo = (size_t)w * njmax;
   const float* Jg = d.efc_J + (size_t)w * d.njmax_pad * nvp;

@@ -180,6 +180,7 @@ _ELEM_CASES = [
   ("humanoid", conftest.HUMANOID_XML, mjw.SolverType.CG, 24, 64, 150, 5e-4, 1e-2),
   ("g1", conftest.G1_XML, mjw.SolverType.NEWTON, 48, 192, 60, 1e-5, 6e-4),
   ("panda", conftest.PANDA_XML, mjw.SolverType.NEWTON, 8, 16, 60, 1e-6, 1e-5),
+  ("panda", conftest.PANDA_XML, mjw.SolverType.NEWTON, 1, 5, 60, 1e-6, 1e-5),  # BASELINE configs[3]: nconmax 1, njmax 5
 ]
 
 
@@ -647,6 +648,95 @@ def test_free_running_1000_steps_statistics():
       assert abs(a.mean() - b.mean()) <= 4.0 * se + 1e-3 * (1.0 + abs(b.mean())), (k, name, a.mean(), b.mean(), se)
       if name in ("height", "tilt", "speed"):
         assert _ks(a, b) <= crit, (k, name, _ks(a, b), crit)
+
+
+def _primal_cost(s, qacc):
+  """The solver's objective (Gauss term + constraint costs, reference solver.py:115-272) at qacc, from the oracle's rows."""
+  n = s.nefc
+  J, D, aref = s.efc_J[:n], s.efc_D[:n], s.efc_aref[:n]
+  dq = qacc - s.qacc_smooth
+  cost = 0.5 * dq @ (s.dense_M() @ dq)
+  x = J @ qacc - aref
+  for r in range(n):
+    if r < s.ne:
+      cost += 0.5 * D[r] * x[r] ** 2
+    elif r < s.ne + s.nf:
+      f = s.efc_frictionloss[r]
+      rf = f / D[r]
+      cost += 0.5 * D[r] * x[r] ** 2 if abs(x[r]) < rf else f * (abs(x[r]) - 0.5 * rf)
+    elif x[r] < 0:
+      cost += 0.5 * D[r] * x[r] ** 2
+  return cost
+
+
+def test_g1_cg_at_the_models_own_iteration_cap():
+  """unitree_g1_flat caps the solver at 10 iterations (unitree_g1_mjlab.xml:14-15), where CG has not converged: float32 and float64
+  iterates then differ visibly (measured 22 % on qacc), so the statement that can be tested is about the OBJECTIVE -- after the same
+  10 iterations the engine's qacc is as good a minimiser as the oracle's (cost within 2.5 %, the reference's own style of solver
+  check), and both are far below the cost of the warm start."""
+  mjm = mjw.mjcf.load_xml(conftest.G1_XML)
+  assert mjm.opt.iterations == 10
+  s, m, d = _pair(mjm, nworld=2, nconmax=48, njmax=192, solver=int(mjw.SolverType.CG), warm_steps=0)
+  worse = 0
+  for i in range(40):
+    s.ctrl_noise(i, 0)
+    _sync(s, d)
+    mjw.forward(m, d)
+    s.forward()
+    if s.nefc == 0 or int(d.nefc.numpy()[1]) != s.nefc:
+      s.step()
+      continue
+    c_gpu, c_ref, c_warm = _primal_cost(s, d.qacc.numpy()[1].astype(np.float64)), _primal_cost(s, s.qacc), _primal_cost(s, s.qacc_warmstart)
+    assert c_gpu <= c_ref + 0.025 * abs(c_ref) + 1e-6, (i, c_gpu, c_ref)
+    worse += c_gpu > c_warm
+    s.step()
+  assert worse == 0
+
+
+MANY_ROWS_XML = """
+<mujoco>
+  <option timestep="0.003" solver="{solver}"><flag eulerdamp="disable"/></option>
+  <worldbody>
+    <geom name="floor" type="plane" size="0 0 .05"/>
+    {bodies}
+  </worldbody>
+</mujoco>
+"""
+
+
+@pytest.mark.parametrize("solver", ["Newton", "CG"])
+def test_njmax_beyond_192_small_model(solver):
+  """nv = 60 <= 64 with njmax = 384 (BASELINE configs[4] asks for it): worlds with at most 192 rows run the register-resident
+  kernels, worlds beyond go to the generic solver -- a batch with both, each against the oracle."""
+  bodies = "".join(f'<body pos="{0.21 * (i % 4):.2f} {0.21 * (i // 4):.2f} .0995"><freejoint/><geom type="box" size=".1 .1 .1" condim="4"/></body>'
+                   for i in range(10))  # 10 boxes x 4 contacts x 6 pyramid rows = 240 rows
+  mjm = mjw.mjcf.from_xml_string(MANY_ROWS_XML.format(solver=solver, bodies=bodies))
+  assert mjm.nv == 60
+  sims = []
+  for w in range(2):
+    s = ref.RefSim(mjm, nconmax=128, njmax=384, tolerance=1e-6)
+    s.reset()
+    if w == 1:  # only three boxes touch the floor, the others hover: few rows
+      s.qpos[7 * 3 + 2 :: 7] += 0.5
+    sims.append(s)
+  m = mjw.put_model(mjm)
+  d = mjw.put_data(mjm, mjw.MjData(mjm), nworld=2, nconmax=128, njmax=384)
+  worst = [0.0, 0.0]
+  rows = set()
+  for i in range(12):
+    for name in ("qpos", "qvel", "qacc_warmstart"):
+      getattr(d, name).assign(np.stack([getattr(s, name) for s in sims]).astype(np.float32))
+    mjw.step(m, d)
+    for w, s in enumerate(sims):
+      s.step()
+      assert int(d.nefc.numpy()[w]) == s.nefc
+      rows.add((w, s.nefc > 192))
+      worst[0] = max(worst[0], relerr(d.qpos.numpy()[w], s.qpos))
+      worst[1] = max(worst[1], relerr(d.qvel.numpy()[w], s.qvel))
+      assert int(d.solver_niter.numpy()[w]) > 0
+  assert (0, True) in rows and (1, False) in rows, rows
+  assert worst[0] <= 1e-5 and worst[1] <= 5e-3, worst
+  assert (d.overflow.numpy() == 0).all()
 
 
 @pytest.mark.parametrize("which", ["humanoid", "three"])
