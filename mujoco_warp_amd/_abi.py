@@ -102,16 +102,22 @@ def build(force=False, verbose=False):
       if verbose:
         print(" ".join(cmd))
       procs.append((cmd, subprocess.Popen(cmd)))
+    import shutil
+
+    failed = None
     for cmd, pr in procs:
-      if pr.wait() != 0:
-        raise subprocess.CalledProcessError(pr.returncode, cmd)
+      if pr.wait() != 0 and failed is None:
+        failed = (pr.returncode, cmd)
+    if failed:
+      shutil.rmtree(objdir, ignore_errors=True)  # (objects of a failed build are of no use and pile up otherwise)
+      raise subprocess.CalledProcessError(*failed)
     cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + [os.path.join(objdir, u + ".o") for u in UNITS]
     if verbose:
       print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    import shutil
-
-    shutil.rmtree(objdir, ignore_errors=True)
+    try:
+      subprocess.check_call(cmd)
+    finally:
+      shutil.rmtree(objdir, ignore_errors=True)
     os.replace(tmp, LIB_PATH)
   return LIB_PATH
 
