@@ -1,6 +1,7 @@
 """Randomised-model parity (40 + 12 PGS + 16 extra-collider + 16 convex-pair seeds by default; MJH_FUZZ_SEEDS / MJH_FUZZ_PGS_SEEDS /
-MJH_FUZZ_COLLIDER_SEEDS / MJH_FUZZ_CONVEX_SEEDS for more: 480 + 160 + 320 were run clean; of 320 convex-pair seeds 315 pass, 3 skip on the
-mass-matrix condition and 2 (242, 275) exceed the per-step bounds by EPA facet noise: qpos 3e-5 / 4.6e-4): random kinematic trees with mixed joint / geom / actuator types against the float64 oracle.
+MJH_FUZZ_COLLIDER_SEEDS / MJH_FUZZ_CONVEX_SEEDS for more: 480 + 160 + 320 were run clean; of 320 convex-pair seeds -- box pairs included,
+through CCD + multi-contact -- 313 pass, 3 skip on the mass-matrix condition and 4 (46, 242, 275, 315) exceed the per-step bounds by EPA
+facet noise or a face-alignment decision at its 1.6 mrad threshold: qpos 3e-5 .. 2.3e-3): random kinematic trees with mixed joint / geom / actuator types against the float64 oracle.
 
 The fixed models (humanoid, G1, Panda, pendula, free bodies, pile) pin specific code paths; these seeds sweep the
 combinations: free / ball / hinge / slide joints at random depths, limits, damping, springs, armature, friction loss,
