@@ -1000,6 +1000,7 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
   float* ccd_scratch = (HEAVY && d.ws_ccd) ? d.ws_ccd + (size_t)w * ccd_words(max(m.ccd_iterations, m.epa_iterations)) * CCD_LANES + (lig & (CCD_LANES - 1)) : nullptr;
   const float ccd_tol = HEAVY ? bf(m.opt_ccd_tolerance, m.opt_ccd_tolerance_nb, w, 1)[0] : 0.0f;
   const int ccd_it = min(m.ccd_iterations, CCD_MAX_ITER), epa_it = min(m.epa_iterations, CCD_MAX_ITER);
+  const int ccd_cache0 = ccd_poly_words(max(m.ccd_iterations, m.epa_iterations));  // first word of the lane's contact cache
   const bool box_ccd = !(m.disableflags & DSBL_NATIVECCD);  // box-box: CCD + multi-contact unless the flag asks for mjc_BoxBox
   int ccd_overflow = 0;
   int ncon = 0;
@@ -1016,9 +1017,27 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
       const float gap = pid >= 0 ? m.pair_gap[pid] : ggap[g1] + ggap[g2];
       const float lim = margin + gap;
       auto count = [&](int k, float dist, V3, V3, V3, V3) { mask |= dist < lim ? (1u << (k & 7)) : 0u; };
-      if (HEAVY && (is_convex_pair(t1, t2) || (box_ccd && t1 == G_BOX && t2 == G_BOX)))
+      if (HEAVY && (is_convex_pair(t1, t2) || (box_ccd && t1 == G_BOX && t2 == G_BOX))) {
+        const int cslot_c = base / G;  // this lane's k-th candidate
+        float* cache = (ccd_scratch && cslot_c < CCD_CACHE_SLOTS) ? ccd_scratch + (size_t)(ccd_cache0 + cslot_c * CCD_CACHE_WORDS) * CCD_LANES : nullptr;
+        int nem = 0;
         collide_convex(ccd_tol, ccd_it, epa_it, t1, t2, ld3(gxpos + 3 * g1), gxmat + 9 * g1, ld3(gsize + 3 * g1), ld3(gxpos + 3 * g2), gxmat + 9 * g2, ld3(gsize + 3 * g2),
-                       margin, gap, ccd_scratch, ccd_overflow, count);
+                       margin, gap, ccd_scratch, ccd_overflow, [&](int k, float dist, V3 pos, V3 fa, V3 fb, V3 fc) {
+                         count(k, dist, pos, fa, fb, fc);
+                         if (cache && k < 4) {
+                           if (k == 0) {
+                             cache[1 * CCD_LANES] = dist;
+                             const float fr[9] = {fa.x, fa.y, fa.z, fb.x, fb.y, fb.z, fc.x, fc.y, fc.z};
+                             for (int q = 0; q < 9; ++q) cache[(2 + q) * CCD_LANES] = fr[q];
+                           }
+                           cache[(11 + 3 * k) * CCD_LANES] = pos.x;
+                           cache[(12 + 3 * k) * CCD_LANES] = pos.y;
+                           cache[(13 + 3 * k) * CCD_LANES] = pos.z;
+                           nem = k + 1;
+                         }
+                       });
+        if (cache) reinterpret_cast<int*>(cache)[0] = nem;
+      }
       else
         collide_pair<HEAVY>(t1, t2, ld3(gxpos + 3 * g1), gxmat + 9 * g1, ld3(gsize + 3 * g1), ld3(gxpos + 3 * g2), gxmat + 9 * g2,
                             ld3(gsize + 3 * g2), margin, count);
@@ -1085,9 +1104,22 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
                      }
                      ++slot;
                    };
-      if (HEAVY && (is_convex_pair(t1, t2) || (box_ccd && t1 == G_BOX && t2 == G_BOX)))
-        collide_convex(ccd_tol, ccd_it, epa_it, t1, t2, ld3(gxpos + 3 * g1), gxmat + 9 * g1, ld3(gsize + 3 * g1), ld3(gxpos + 3 * g2), gxmat + 9 * g2, ld3(gsize + 3 * g2),
-                       margin, pp.gap, ccd_scratch, ccd_overflow, write);
+      if (HEAVY && (is_convex_pair(t1, t2) || (box_ccd && t1 == G_BOX && t2 == G_BOX))) {
+        const int cslot_c = base / G;
+        if (ccd_scratch && cslot_c < CCD_CACHE_SLOTS) {  // replay the contacts pass 1 found
+          const float* cache = ccd_scratch + (size_t)(ccd_cache0 + cslot_c * CCD_CACHE_WORDS) * CCD_LANES;
+          const int nem = reinterpret_cast<const int*>(cache)[0];
+          const float dist = cache[1 * CCD_LANES];
+          float fr[9];
+          for (int q = 0; q < 9; ++q) fr[q] = cache[(2 + q) * CCD_LANES];
+          for (int k = 0; k < nem; ++k)
+            write(k, dist, V3{cache[(11 + 3 * k) * CCD_LANES], cache[(12 + 3 * k) * CCD_LANES], cache[(13 + 3 * k) * CCD_LANES]}, V3{fr[0], fr[1], fr[2]},
+                  V3{fr[3], fr[4], fr[5]}, V3{fr[6], fr[7], fr[8]});
+        } else {
+          collide_convex(ccd_tol, ccd_it, epa_it, t1, t2, ld3(gxpos + 3 * g1), gxmat + 9 * g1, ld3(gsize + 3 * g1), ld3(gxpos + 3 * g2), gxmat + 9 * g2,
+                         ld3(gsize + 3 * g2), margin, pp.gap, ccd_scratch, ccd_overflow, write);
+        }
+      }
       else
         collide_pair<HEAVY>(t1, t2, ld3(gxpos + 3 * g1), gxmat + 9 * g1, ld3(gsize + 3 * g1), ld3(gxpos + 3 * g2), gxmat + 9 * g2,
                             ld3(gsize + 3 * g2), margin, write);

@@ -425,7 +425,7 @@ def c_model(m: types.Model):
 def _ccd_words(iterations: int) -> int:
   """Workspace words of one lane's EPA polytope (csrc/convex.hpp ccd_words)."""
   it = min(int(iterations), 64)
-  return 8 * (5 + it) + 5 * (6 + 5 * it) + 24
+  return 8 * (5 + it) + 5 * (6 + 5 * it) + 24 + 4 * 24  # polytope + contact cache (CCD_CACHE_SLOTS x CCD_CACHE_WORDS)
 
 
 def contact_cap(nconmax: int) -> int:
