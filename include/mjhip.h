@@ -108,6 +108,7 @@ typedef struct MjhModel {
   const int* dof_tree;          /* dof ids sorted by depth in the dof tree   */
   const int* dof_leveladr;      /* [ndoflevel+1] offsets into dof_tree       */
   /* kinematic trees (contiguous dof ranges; M is block diagonal over them): the per-tree solver dispatch for nv > 64 */
+  int act_dof_max;              /* largest number of actuators acting on one dof (implicit integrators: see csrc/integrate.hpp) */
   int ntree;                    /* trees with at least one dof */
   int tree_nvmax;               /* dofs of the largest tree */
   int isl_nv4;                  /* ceil(dofs / 4) of the widest island of at most 32 dofs the model can form (kernel size class) */
@@ -271,7 +272,7 @@ int mjh_timed_steps(const MjhModel* m, const MjhData* d, int nstep, int step0, f
 int mjh_release_thread_resources(void);
 
 const char* mjh_last_error(void);
-#define MJH_ABI_VERSION 14
+#define MJH_ABI_VERSION 15
 int mjh_abi_version(void); /* returns MJH_ABI_VERSION of the library that was loaded */
 
 #ifdef __cplusplus

@@ -39,6 +39,7 @@ DEV void integrate_body(const MjhModel& m, const MjhData& d, int mode, float* sm
   const float h = bf(m.opt_timestep, m.opt_timestep_nb, w, 1)[0];
   const size_t vo = (size_t)w * nv;
   const float* damp = bf(m.dof_damping, m.dof_damping_nb, w, nv);
+  PhaseClock pc(6, lig);
 
   // does the velocity update need an implicit solve?
   bool implicit = false;
@@ -48,6 +49,7 @@ DEV void integrate_body(const MjhModel& m, const MjhData& d, int mode, float* sm
     for (int i = lig; i < nv; i += G) mx = fmaxf(mx, fabsf(damp[i]));
     implicit = gmax<G>(mx) > 0.0f;
   }
+  pc.mark(0);
   if (implicit) {
     gcopy<G>(L, d.M + (size_t)w * nC, nC, lig);
     gcopy<G>(x, d.efc_Ma + vo, nv, lig);
@@ -58,30 +60,50 @@ DEV void integrate_body(const MjhModel& m, const MjhData& d, int mode, float* sm
       // d(qfrc_actuator)/d(qvel) for joint transmissions is diagonal: gear^2 * (bias_vel + gain_vel * ctrl)
       gsync();
       const float* gear = bf(m.actuator_gear, m.actuator_gear_nb, w, 6 * nu);
-      for (int i = lig; i < nv; i += G) {
-        float acc = 0.0f;
-        for (int u = 0; u < nu; ++u) {
-          if (m.jnt_dofadr[m.actuator_trnid[2 * u]] != i) continue;
-          const float bias_vel = m.actuator_biastype[u] == 1 ? bf(m.actuator_biasprm, m.actuator_biasprm_nb, w, 10 * nu)[10 * u + 2] : 0.0f;
-          const float gain_vel = m.actuator_gaintype[u] == 1 ? bf(m.actuator_gainprm, m.actuator_gainprm_nb, w, 10 * nu)[10 * u + 2] : 0.0f;
-          // the RAW control, not the clamped one, multiplies the velocity gain (derivative.py:159-161, mjd_actuator_vel)
-          float ctrl = d.ctrl[(size_t)w * nu + u];
-          if (m.actuator_dyntype[u] != 0) ctrl = d.act[(size_t)w * m.na + m.actuator_actadr[u]];
-          const float dv = bias_vel + gain_vel * ctrl;
-          if (dv == 0.0f) continue;
-          if (m.actuator_forcelimited[u]) {
-            const float* fr = bf(m.actuator_forcerange, m.actuator_forcerange_nb, w, 2 * nu) + 2 * u;
-            const float f = d.actuator_force[(size_t)w * nu + u];
-            if (f <= fr[0] || f >= fr[1]) continue;
-          }
-          acc += gear[6 * u] * gear[6 * u] * dv;
+      // one lane per ACTUATOR (the dof-major double loop below costs nv x nu dependent table loads: measured 40 % of this kernel on
+      // the G1); contributions meet in LDS with atomic adds, which is order-independent -- hence deterministic -- as long as no dof
+      // has more than two actuators (float addition commutes); models beyond that keep the dof-major loop
+      auto act_dv = [&](int u, float& val) __attribute__((always_inline)) {
+        const float bias_vel = m.actuator_biastype[u] == 1 ? bf(m.actuator_biasprm, m.actuator_biasprm_nb, w, 10 * nu)[10 * u + 2] : 0.0f;
+        const float gain_vel = m.actuator_gaintype[u] == 1 ? bf(m.actuator_gainprm, m.actuator_gainprm_nb, w, 10 * nu)[10 * u + 2] : 0.0f;
+        // the RAW control, not the clamped one, multiplies the velocity gain (derivative.py:159-161, mjd_actuator_vel)
+        float ctrl = d.ctrl[(size_t)w * nu + u];
+        if (m.actuator_dyntype[u] != 0) ctrl = d.act[(size_t)w * m.na + m.actuator_actadr[u]];
+        const float dv = bias_vel + gain_vel * ctrl;
+        if (dv == 0.0f) return false;
+        if (m.actuator_forcelimited[u]) {
+          const float* fr = bf(m.actuator_forcerange, m.actuator_forcerange_nb, w, 2 * nu) + 2 * u;
+          const float f = d.actuator_force[(size_t)w * nu + u];
+          if (f <= fr[0] || f >= fr[1]) return false;
         }
-        L[ms.rowadr[i] + ms.rownnz[i] - 1] -= h * acc;
+        val = gear[6 * u] * gear[6 * u] * dv;
+        return true;
+      };
+      if (m.act_dof_max <= 2) {
+        for (int u = lig; u < nu; u += G) {
+          float val;
+          if (!act_dv(u, val)) continue;
+          const int i = m.jnt_dofadr[m.actuator_trnid[2 * u]];
+          atomicAdd(&L[ms.rowadr[i] + ms.rownnz[i] - 1], -h * val);
+        }
+      } else {
+        for (int i = lig; i < nv; i += G) {
+          float acc = 0.0f;
+          for (int u = 0; u < nu; ++u) {
+            float val;
+            if (m.jnt_dofadr[m.actuator_trnid[2 * u]] != i || !act_dv(u, val)) continue;
+            acc += val;
+          }
+          L[ms.rowadr[i] + ms.rownnz[i] - 1] -= h * acc;
+        }
       }
     }
     gsync();
+    pc.mark(1);
     factor_ld<G>(ms, L, dinv, nv, lig);
+    pc.mark(2);
     solve_ld<G>(m, ms, L, dinv, x, nv, lig);
+    pc.mark(3);
   } else {
     gcopy<G>(x, d.qacc + vo, nv, lig);
     gsync();
@@ -125,6 +147,7 @@ DEV void integrate_body(const MjhModel& m, const MjhData& d, int mode, float* sm
       qpos[qa] += h * qvel[dof];
     }
   }
+  pc.mark(4);
   if (lig == 0) {
     d.time[w] += h;
     // end-of-step overflow flags that depend on counters (forward.py:221-273)

@@ -468,7 +468,8 @@ static int run_stage(const MjhModel* m, const MjhData* d, int stage, hipStream_t
       { Scope sc(K_POS); TRY(launch_pos_plus(m, d, POS_KINEMATICS, POS_CRB, &sched_done, s)); }
       { Scope sc(K_MID); TRY(launch_mid(m, d, !sched_done, s)); }
       // (nv <= 32 only: beside the 64-lane solver of larger models the riders cost more than they save, G1 -3 %)
-      Side* side = (m->solver == SOL_NEWTON && m->nv <= 32 && !(g_instr && g_instr->on)) ? side_stream() : nullptr;
+      static const int side_nv = getenv("MJH_SIDE_NV") ? atoi(getenv("MJH_SIDE_NV")) : 32;  // developer knob
+      Side* side = (m->solver == SOL_NEWTON && m->nv <= side_nv && !(g_instr && g_instr->on)) ? side_stream() : nullptr;
       if (side) {
         HIPCHK(hipEventRecord(side->fork, s));
         HIPCHK(hipStreamWaitEvent(side->stream, side->fork, 0));

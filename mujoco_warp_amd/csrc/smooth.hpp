@@ -85,6 +85,8 @@ DEV void load_fk_table(const MjhModel& m, float* T, int nthreads) {
 // sparse L'DL factorisation in LDS (reference smooth.py:1183-1232 _qLD_acc/_qLDiag_div == MuJoCo mj_factorI).
 // L holds a copy of M on entry.  Row k is eliminated sequentially (leaf to root); the updates of its
 // ancestor rows are spread over the lanes (one ancestor row per lane, no write conflicts).
+// (Tried in round 2: one lane per (ancestor, column) pair, and a level-wise gather for the transposed solve -- the per-row chain of
+// dependent LDS round trips is what costs, ~1,800 cycles per row on the G1 either way; the gather was twice as slow.)
 template <int G>
 DEV void factor_ld(const MStruct& ms, float* L, float* dinv, int nv, int lig) {
   for (int k = nv - 1; k >= 0; --k) {

@@ -270,6 +270,11 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
       raise ValueError("dofs of a kinematic tree must be contiguous (MuJoCo order)")
   body_treeid = np.array([dof_treeid[lastdof[b]] if lastdof[b] >= 0 else -1 for b in range(nbody)], dtype=np.int32)
   m.ntree = len(roots)
+  if mjm.nu:
+    adof = np.asarray(mjm.jnt_dofadr)[np.asarray(mjm.actuator_trnid).reshape(-1, 2)[:, 0]]
+    m.act_dof_max = int(np.bincount(adof, minlength=max(nv, 1)).max())
+  else:
+    m.act_dof_max = 0
   m.tree_nvmax = int(tree_dofnum.max()) if len(roots) else 0
   # nv > 64: worlds whose rows each touch one kinematic tree are solved per (world, tree) by the register-resident kernels
   m.tree_solve = int(nv > 64 and m.ntree > 1 and m.tree_nvmax <= 64 and int(opt.solver) != types.SolverType.PGS

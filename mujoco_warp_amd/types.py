@@ -383,6 +383,7 @@ class Model(_Dirty):
   ndoflevel: int = 0
   nmaxcondim: int = 0
   epa_iterations: int = 0  # EPA iteration cap of the convex narrowphase (reference collision_convex.py:1223)
+  act_dof_max: int = 0  # largest number of actuators acting on one dof
   ntree: int = 0  # kinematic trees with at least one dof
   tree_nvmax: int = 0  # dofs of the largest tree
   isl_nv4: int = 0  # quarter-rows of the widest island of <= 32 dofs (kernel size class)

@@ -16,6 +16,7 @@ PHASES = {
   2: ("collision", ["stage geoms", "broadphase", "narrow pass1", "window init", "pass2 stage", "write records"]),
   3: ("make_constraint", ["load", "friction+limits", "J rows fl", "contact list", "contact J", "contact rows"]),
   4: ("fwd_vel", ["load", "com_vel", "passive", "rne", "actuation", "qfrc_smooth"]),
+  6: ("integrate", ["load + implicit?", "M copy + qDeriv (damping, actuators)", "factor_ld", "solve_ld", "advance"]),
   5: ("solve", ["M rows", "Ma+Minv", "J+rows", "it: update+JTf+grad", "it: Mgrad/chol", "it: conv+mv+jv", "it: linesearch",
                 "it: move", "exit", "store", "it: H build (mfma)", "it: H swap + M", "it: chol factor+solve", "-", "(count) ls bracketing iterations", "(count) ls calls"]),
 }
