@@ -50,6 +50,12 @@ extern "C" {
 #define MJH_STAGE_FWD_POSITION 16    /* forward.fwd_position         forward.py:635 */
 #define MJH_STAGE_FORWARD 17         /* forward.forward              forward.py:1341 */
 #define MJH_STAGE_STEP 18            /* forward.step                 forward.py:1368 */
+#define MJH_STAGE_UPDATE_SLEEP 20    /* sleep.update_sleep           sleep.py:171 */
+#define MJH_STAGE_WAKE 21            /* sleep.wake (+ update_sleep)  sleep.py:721 */
+#define MJH_STAGE_WAKE_COLLISION 22  /* sleep.wake_collision (+ update_sleep) sleep.py:744 */
+#define MJH_STAGE_WAKE_EQUALITY 23   /* sleep.wake_equality (+ update_sleep)  sleep.py:793 */
+#define MJH_STAGE_ISLAND 24          /* island.island                island.py:294 */
+#define MJH_STAGE_SLEEP 25           /* sleep.sleep (+ update_sleep) sleep.py:947 */
 #define MJH_STAGE_RUNGEKUTTA4 19     /* forward.rungekutta4 (after a forward)  forward.py:524 */
 
 typedef struct MjhModel {
@@ -64,6 +70,9 @@ typedef struct MjhModel {
   int broadphase_filter; /* BroadphaseFilter bits (types.py:73-87): 1 plane, 2 sphere, 4 AABB, 8 OBB */
   /* options (types.py:836-905); solver: 0 = PGS (extension, the reference has none: types.py:502), 1 = CG, 2 = Newton */
   int integrator; int cone; int solver; int iterations; int ls_iterations; int disableflags; int enableflags;
+  int sleep_enabled;   /* EnableBit.SLEEP set and DisableBit.ISLAND clear (forward.py:345): sleeping / waking of kinematic trees
+                          (csrc/sleep.hpp; staged launch sequence, Newton only like the reference io.py:359) */
+  float opt_sleep_tolerance; /* Option.sleep_tolerance (types.py:845) */
   int ccd_iterations;  /* GJK iteration cap of the convex narrowphase (capped at 64 by this engine) */
   int epa_iterations;  /* EPA iteration cap: 16 when every convex pair of the model is box-box, else ccd_iterations (collision_convex.py:1223) */
   const float* opt_timestep; int opt_timestep_nb;
@@ -108,6 +117,8 @@ typedef struct MjhModel {
   const int* dof_tree;          /* dof ids sorted by depth in the dof tree   */
   const int* dof_leveladr;      /* [ndoflevel+1] offsets into dof_tree       */
   /* kinematic trees (contiguous dof ranges; M is block diagonal over them): the per-tree solver dispatch for nv > 64 */
+  const int* tree_sleep_policy; /* [ntree] SleepPolicy (types.py:296): 1 AUTO_NEVER, 2 AUTO_ALLOWED */
+  const float* dof_length;      /* [nv] velocity weights of the sleep test (types.py:1098) */
   int act_dof_max;              /* largest number of actuators acting on one dof (implicit integrators: see csrc/integrate.hpp) */
   int ntree;                    /* trees with at least one dof */
   int tree_nvmax;               /* dofs of the largest tree */
@@ -216,6 +227,19 @@ typedef struct MjhData {
   int* ws_isl_list;    /* [3, nworld] worlds holding an island with > 64 rows | of 33..64 dofs | of > 64 dofs (generic solver)      */
   int* ws_isl_count;   /* [4] entries of the three lists                                                                        */
   int* ws_separable;   /* [nworld] 1: every island has at most 64 dofs (solved per island), 0: generic solver             */
+  /* sleeping (types.py:2330-2345; all empty unless MjhModel.sleep_enabled) */
+  int* tree_asleep;    /* [nworld, ntree] < 0: awake (counts up to -1 while the tree could sleep), >= 0: next tree of its sleep cycle */
+  int* tree_awake;     /* [nworld, ntree] */
+  int* body_awake;     /* [nworld, nbody] SleepState: -1 static, 0 asleep, 1 awake */
+  int* body_awake_ind; /* [nworld, nbody] bodies that are not asleep (ascending; the reference's order depends on atomics) */
+  int* dof_awake_ind;  /* [nworld, nv] dofs of awake trees (ascending) */
+  int* ntree_awake; int* nbody_awake; int* nv_awake; /* [nworld] */
+  int* tree_island;    /* [nworld, ntree] constraint island of each tree (numbered by smallest tree), -1: no constraint row (island.py:206) */
+  int* nisland;        /* [nworld] */
+  float* ws_sleep_J;   /* [nworld, njmax_pad, nv_pad] efc.J with the columns of sleeping dofs zeroed: what the solver reads (see csrc/sleep.hpp) */
+  float* ws_sleep_warm; /* [nworld, nv] qacc_warmstart with sleeping dofs zeroed */
+  int* ws_sleep_flag;  /* [nworld] a tree of the world was woken by a contact of collision pass 1 (forward.py:652-666) */
+  int sleep_pass;      /* launch-local: 0 plain collision, 2 second pass (only worlds with ws_sleep_flag set recompute) */
   int* ws_efc_con;     /* [nworld, njmax] contact rows: 16 * (world-local contact) + row within the contact (make_constraint -> solver,
                           elliptic cones only) */
   int* ws_order;       /* [nworld]   solver schedule: worlds sorted by last step's solver_niter (longest first) */
@@ -272,7 +296,7 @@ int mjh_timed_steps(const MjhModel* m, const MjhData* d, int nstep, int step0, f
 int mjh_release_thread_resources(void);
 
 const char* mjh_last_error(void);
-#define MJH_ABI_VERSION 15
+#define MJH_ABI_VERSION 16
 int mjh_abi_version(void); /* returns MJH_ABI_VERSION of the library that was loaded */
 
 #ifdef __cplusplus

@@ -11,6 +11,12 @@ from .device import copy
 from .forward import KERNEL_NAMES
 from .forward import StepGraph
 from .forward import com_pos
+from .forward import island
+from .forward import sleep
+from .forward import update_sleep
+from .forward import wake
+from .forward import wake_collision
+from .forward import wake_equality
 from .forward import com_vel
 from .forward import collision
 from .forward import crb
@@ -71,6 +77,8 @@ from .types import Model
 from .types import ObjType
 from .types import Option
 from .types import OverflowType
+from .types import SleepPolicy
+from .types import SleepState
 from .types import SolverType
 from .types import Statistic
 from .types import TrnType

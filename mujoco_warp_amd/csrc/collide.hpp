@@ -841,6 +841,8 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
   const int lig = threadIdx.x & (G - 1), gib = threadIdx.x / G;
   const int w = b.w0 + gib;
   if ((int)threadIdx.x >= b.nthreads || w >= d.nworld) return;
+  // sleeping, second collision pass (forward.py:652-666): only worlds where a contact of pass 1 woke a tree can gain pairs
+  if (HEAVY && d.sleep_pass == 2 && !d.ws_sleep_flag[w]) return;
   const int npair = m.npair, ng = m.ngeom, ncap = d.concap;
   float* S = smem + (size_t)gib * (stride_words ? stride_words : collide_lds_words(ng, npair, ncap, HEAVY ? m.broadphase : 0));
   float* gxpos = S;
@@ -973,6 +975,11 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
           if (pass && (filt & 4)) pass = aabb_filter(gaabb + 6 * g1, gaabb + 6 * g2, mg, x1, x2, gxmat + 9 * g1, gxmat + 9 * g2);
           if (pass && (filt & 8)) pass = obb_filter(gaabb + 6 * g1, gaabb + 6 * g2, mg, x1, x2, gxmat + 9 * g1, gxmat + 9 * g2);
         }
+      }
+      if (HEAVY && m.sleep_enabled && pass) {  // collision_driver.py:494-503: no pair of two sleeping bodies, or of a sleeping and a static one
+        const int* bawake = d.body_awake + (size_t)w * m.nbody;
+        const int s1 = bawake[m.geom_bodyid[g1]], s2 = bawake[m.geom_bodyid[g2]];
+        if ((s1 == 0 && s2 == 0) || (s1 == 0 && s2 == -1) || (s2 == 0 && s1 == -1)) pass = false;
       }
     }
     int tot;

@@ -12,6 +12,7 @@
 #include "constraint.hpp"
 #include "dev_common.hpp"
 #include "integrate.hpp"
+#include "sleep.hpp"
 #include "smooth.hpp"
 
 static thread_local char g_err[512] = "";
@@ -399,6 +400,54 @@ static Side* side_stream() {
   }
   return per_dev[dev];
 }
+// forward / step of a model with sleeping enabled (forward.py:345-349, 652-675, 1290-1324, 1341-1347): the staged launch sequence
+// with the sleep bookkeeping between the stages (csrc/sleep.hpp)
+static int run_sleep_step(const MjhModel* m, const MjhData* d, bool step, hipStream_t s) {
+  if (!d->tree_asleep || !d->ws_sleep_J) return fail(MJH_E_ARG, "Data sleep tables missing (allocate Data with make_data/put_data)");
+  if (m->solver != SOL_NEWTON) return fail(MJH_E_UNSUPPORTED, "sleeping requires the Newton solver (reference io.py:359)");
+  if (step && m->integrator == INT_RK4) return fail(MJH_E_UNSUPPORTED, "sleeping with the RK4 integrator");
+  const dim3 gw((d->nworld + 63) / 64), bw(64);
+  const int mode = m->integrator == INT_IMPLICITFAST ? 1 : 0;
+  { Scope sc(K_OTHER); hipLaunchKernelGGL(k_sleep, gw, bw, 0, s, *m, *d, (int)SLP_WAKE); }
+  { Scope sc(K_POS); TRY(launch_pos(m, d, POS_KINEMATICS, POS_CRB, s)); }
+  { Scope sc(K_COLLISION); TRY(launch_collision(m, d, s)); }
+  { Scope sc(K_OTHER); hipLaunchKernelGGL(k_sleep, gw, bw, 0, s, *m, *d, (int)SLP_WAKE_COLLISION); }
+  {
+    // pass 2: waking only ever lets more pairs through the sleep filter, so the pairs of pass 1 plus "the pairs pass 1 skipped that
+    // involve a newly awakened body" are the pairs that pass the filter now: the woken worlds recompute their list
+    Scope sc(K_COLLISION);
+    MjhData d2 = *d;
+    d2.sleep_pass = 2;
+    TRY(launch_collision(m, &d2, s));
+  }
+  { Scope sc(K_CONSTRAINT); TRY(launch_constraint(m, d, s)); }
+  { Scope sc(K_OTHER); hipLaunchKernelGGL(k_sleep, gw, bw, 0, s, *m, *d, (int)SLP_POST_CONSTRAINT); }
+  { Scope sc(K_VEL); TRY(launch_vel(m, d, VEL_COMVEL, VEL_ACCEL, s)); }
+  {
+    Scope sc(K_OTHER);
+    if (m->nv > 0) hipLaunchKernelGGL(k_sleep_qfrc, dim3((d->nworld * m->nv + 255) / 256), dim3(256), 0, s, *m, *d);
+    hipLaunchKernelGGL(k_sleep_mask, dim3(d->nworld), dim3(256), 0, s, *m, *d);
+  }
+  {
+    Scope sc(K_SOLVE);
+    MjhData d3 = *d;  // the solver reads the masked copies (sleeping dofs frozen), and writes the public outputs
+    d3.efc_J = d->ws_sleep_J;
+    d3.qacc_warmstart = d->ws_sleep_warm;
+    TRY(launch_solve(m, &d3, s));
+  }
+  if (step) { Scope sc(K_INTEGRATE); TRY(launch_integrate(m, d, mode, s)); }
+  {
+    Scope sc(K_OTHER);
+    TRY(launch_publish(d, s));
+    TRY(launch_factor_smooth(m, d, 1, s));
+  }
+  if (step) {
+    { Scope sc(K_OTHER); hipLaunchKernelGGL(k_sleep, gw, bw, 0, s, *m, *d, (int)SLP_SLEEP); }
+    { Scope sc(K_VEL); TRY(launch_vel(m, d, VEL_COMVEL, VEL_RNE, s)); }
+  }
+  return MJH_OK;
+}
+
 static int run_stage(const MjhModel* m, const MjhData* d, int stage, hipStream_t s) {
   switch (stage) {
     case MJH_STAGE_KINEMATICS: { Scope sc(K_POS); return launch_pos(m, d, POS_KINEMATICS, POS_KINEMATICS, s); }
@@ -429,6 +478,19 @@ static int run_stage(const MjhModel* m, const MjhData* d, int stage, hipStream_t
       { Scope sc(K_CONSTRAINT); TRY(launch_constraint(m, d, s)); }
       { Scope sc(K_OTHER); TRY(launch_publish(d, s)); }
       return MJH_OK;
+    case MJH_STAGE_UPDATE_SLEEP:
+    case MJH_STAGE_WAKE:
+    case MJH_STAGE_WAKE_COLLISION:
+    case MJH_STAGE_WAKE_EQUALITY:
+    case MJH_STAGE_ISLAND:
+    case MJH_STAGE_SLEEP: {
+      if (!d->tree_asleep) return fail(MJH_E_ARG, "Data sleep tables missing (allocate Data with make_data/put_data)");
+      const int phase = stage == MJH_STAGE_UPDATE_SLEEP ? SLP_UPDATE : stage == MJH_STAGE_WAKE ? SLP_WAKE : stage == MJH_STAGE_WAKE_COLLISION ? SLP_WAKE_COLLISION
+                        : stage == MJH_STAGE_WAKE_EQUALITY ? SLP_WAKE_EQUALITY : stage == MJH_STAGE_ISLAND ? SLP_ISLAND : SLP_SLEEP;
+      Scope sc(K_OTHER);
+      hipLaunchKernelGGL(k_sleep, dim3((d->nworld + 63) / 64), dim3(64), 0, s, *m, *d, phase);
+      return MJH_OK;
+    }
     case MJH_STAGE_RUNGEKUTTA4: {
       // forward.rungekutta4 (forward.py:524-557), called after a forward at t0: one k_rk4 launch after each evaluation
       // (accumulate + perturb; the last one restores t0 and advances); tableau A = (1/2, 1/2, 1), B = (1/6, 1/3, 1/3, 1/6)
@@ -443,6 +505,7 @@ static int run_stage(const MjhModel* m, const MjhData* d, int stage, hipStream_t
     }
     case MJH_STAGE_FORWARD:
     case MJH_STAGE_STEP: {
+      if (m->sleep_enabled) return run_sleep_step(m, d, stage == MJH_STAGE_STEP, s);
       if (stage == MJH_STAGE_STEP && m->integrator == INT_RK4) {
         TRY(run_stage(m, d, MJH_STAGE_FORWARD, s));
         return run_stage(m, d, MJH_STAGE_RUNGEKUTTA4, s);

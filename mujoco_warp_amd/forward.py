@@ -112,6 +112,36 @@ def rungekutta4(m, d):
   _run(_S["MJH_STAGE_RUNGEKUTTA4"], m, d)
 
 
+def update_sleep(m, d):
+  """Sleep tables (tree_awake, body_awake, awake index lists and counts) from Data.tree_asleep (reference sleep.py:171)."""
+  _run(_S["MJH_STAGE_UPDATE_SLEEP"], m, d)
+
+
+def wake(m, d):
+  """Wakes sleeping trees the user touched: velocity, applied forces (reference sleep.py:721), then update_sleep."""
+  _run(_S["MJH_STAGE_WAKE"], m, d)
+
+
+def wake_collision(m, d):
+  """Wakes sleeping trees in contact with awake ones (reference sleep.py:744), then update_sleep."""
+  _run(_S["MJH_STAGE_WAKE_COLLISION"], m, d)
+
+
+def wake_equality(m, d):
+  """Wakes sleeping trees tied to awake ones by an active equality (reference sleep.py:793), then update_sleep."""
+  _run(_S["MJH_STAGE_WAKE_EQUALITY"], m, d)
+
+
+def island(m, d):
+  """Constraint islands at tree granularity: Data.tree_island, Data.nisland (reference island.py:294)."""
+  _run(_S["MJH_STAGE_ISLAND"], m, d)
+
+
+def sleep(m, d):
+  """Puts trees below the velocity tolerance to sleep, island by island (reference sleep.py:947), then update_sleep."""
+  _run(_S["MJH_STAGE_SLEEP"], m, d)
+
+
 def fwd_kinematics(m, d):
   """Kinematics-dependent computations (reference forward.py:616; no cameras / flex / tendons here)."""
   kinematics(m, d)

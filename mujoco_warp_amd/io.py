@@ -160,10 +160,14 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
   # physics this engine does not compute must not be dropped silently
   if float(getattr(opt, "density", 0.0)) != 0.0 or float(getattr(opt, "viscosity", 0.0)) != 0.0:
     raise NotImplementedError("fluid forces (option density / viscosity, passive.py _fluid_force) are not implemented.")
-  unsupported_enable = int(opt.enableflags) & int(types.EnableBit.OVERRIDE | types.EnableBit.SLEEP | types.EnableBit.FWDINV
-                                                  | types.EnableBit.INVDISCRETE)
+  unsupported_enable = int(opt.enableflags) & int(types.EnableBit.OVERRIDE | types.EnableBit.FWDINV | types.EnableBit.INVDISCRETE)
   if unsupported_enable:
     raise NotImplementedError(f"enable flags {types.EnableBit(unsupported_enable)!r} are not implemented.")
+  # sleeping (reference io.py:356-360): Newton only; active when islands are not disabled (forward.py:345)
+  if (int(opt.enableflags) & int(types.EnableBit.SLEEP)) and int(opt.solver) != int(types.SolverType.NEWTON):
+    raise ValueError(f"sleeping requires the Newton solver (got solver={types.SolverType(int(opt.solver)).name})")
+  if (int(opt.enableflags) & int(types.EnableBit.SLEEP)) and int(opt.integrator) == int(types.IntegratorType.RK4):
+    raise NotImplementedError("sleeping with the RK4 integrator is not implemented.")
   pairs, pairid = geom_pairs_with_ids(mjm)
   gt = np.asarray(mjm.geom_type)
   for a, b in pairs:
@@ -340,6 +344,12 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
     actuator_forcelimited=_arr(mjm.actuator_forcelimited, i32), actuator_actlimited=_arr(mjm.actuator_actlimited, i32),
     eq_obj1id=_arr(getattr(mjm, "eq_obj1id", np.zeros(0)), i32), eq_obj2id=_arr(getattr(mjm, "eq_obj2id", np.zeros(0)), i32),
   )
+  m.sleep_enabled = int(bool(int(opt.enableflags) & int(types.EnableBit.SLEEP)) and not (int(opt.disableflags) & int(types.DisableBit.ISLAND)))
+  m.opt_sleep_tolerance = float(getattr(opt, "sleep_tolerance", 1e-4))
+  host["tree_sleep_policy"] = _arr(getattr(mjm, "tree_sleep_policy", np.full(m.ntree, int(types.SleepPolicy.AUTO_ALLOWED))), i32)
+  host["dof_length"] = _arr(getattr(mjm, "dof_length", np.ones(nv)), f32)
+  if m.sleep_enabled and (host["tree_sleep_policy"] > int(types.SleepPolicy.AUTO_ALLOWED)).any():
+    raise NotImplementedError("sleep policies NEVER / ALLOWED / INIT are not implemented (reference types.py:308).")
   neq = int(getattr(mjm, "neq", 0))
   host["eq_solref"] = _arr(getattr(mjm, "eq_solref", np.zeros((0, 2))), f32).reshape(1, neq, 2)
   host["eq_solimp"] = _arr(getattr(mjm, "eq_solimp", np.zeros((0, 5))), f32).reshape(1, neq, 5)
@@ -413,13 +423,15 @@ def c_model(m: types.Model):
       continue
     elif name in ("integrator", "cone", "solver", "iterations", "ls_iterations", "disableflags", "enableflags", "broadphase", "broadphase_filter", "ccd_iterations"):
       setattr(c, name, int(getattr(m.opt, name)))
+    elif name == "opt_sleep_tolerance":
+      setattr(c, name, float(m.opt_sleep_tolerance))
     elif name == "heavy_colliders":
       bf_ = int(m.opt.broadphase_filter)
       if bf_ & ~0xF:
         raise ValueError(f"unknown broadphase filter bits {bf_:#x}")
       if int(m.opt.broadphase) not in (0, 1, 2):
         raise ValueError(f"unknown broadphase {int(m.opt.broadphase)}")
-      setattr(c, name, int(bool(m._heavy_pairs or bf_ != 3 or int(m.opt.broadphase) != 0)))  # (the light instantiation hard-wires plane + sphere)
+      setattr(c, name, int(bool(m._heavy_pairs or bf_ != 3 or int(m.opt.broadphase) != 0 or m.sleep_enabled)))  # (sleep filter: heavy instantiation only)  # (the light instantiation hard-wires plane + sphere)
     else:
       setattr(c, name, int(getattr(m, name)))
   object.__setattr__(m, "_c", c)
@@ -463,6 +475,9 @@ def _data_shapes(m, nworld, nconmax, njmax, naconmax):
     efc_force=(W, njmax), ws_ncon=(W,), ws_conadr=(W,), ws_ncollision=(W,), ws_efc_con=(W, njmax), ws_tree_rowadr=(W, (m.ntree + 1) if m.tree_solve else 0), ws_tree_rowmap=(W, njmax if m.tree_solve else 0),
     ws_isl_dofadr=(W, (m.ntree + 1) if m.tree_solve else 0), ws_isl_dofmap=(W, nv if m.tree_solve else 0), ws_isl_dofinv=(W, nv if m.tree_solve else 0), ws_nisland=(W,), ws_isl_flags=(W,), ws_isl_list=(3, W if m.tree_solve else 0), ws_isl_count=(4,),
     ws_separable=(W,), ws_order=(W,), ws_ccd=(W if m._convex_pairs else 0, _ccd_words(max(int(m.opt.ccd_iterations), int(m.epa_iterations))), 32),
+    tree_asleep=(W, m.ntree), tree_awake=(W, m.ntree), body_awake=(W, nb), body_awake_ind=(W, nb), dof_awake_ind=(W, nv), ntree_awake=(W,), nbody_awake=(W,),
+    nv_awake=(W,), tree_island=(W, m.ntree), nisland=(W,), ws_sleep_J=(W if m.sleep_enabled else 0, njmax_pad, nv_pad), ws_sleep_warm=(W if m.sleep_enabled else 0, nv),
+    ws_sleep_flag=(W,),
     eq_active=(W, m.neq), ws_rk=(W, nq + 3 * nv + 2 * na), ws_contact=(W, contact_cap(nconmax), 32),
   )
   return sh, njmax_pad, nv_pad
@@ -494,6 +509,9 @@ def _alloc_data(m: types.Model, nworld, nconmax, njmax, naconmax, mjd=None):
     _set_data_field(d, name, arr)
   d.nworld, d.nconmax, d.naconmax, d.njmax, d.njmax_pad, d.nv_pad = nworld, nconmax, naconmax, njmax, njmax_pad, nv_pad
   d.ws_order.assign(np.arange(nworld, dtype=np.int32))
+  d.sleep_pass = 0
+  d.nsleepworld = shapes["ws_sleep_J"][0]
+  _reset_sleep(m, d, None)
   if m.neq:
     d.eq_active.assign(np.tile(m.eq_active0, (nworld, 1)))
   _reset_mocap(m, d, None)
@@ -663,6 +681,28 @@ def _reset_mocap(m, d, mask):
       dst.assign(cur)
 
 
+def _reset_sleep(m, d, mask):
+  """Every tree fully awake (reference io.py:2637-2670 reset_sleep; make_data io.py:1869-1871)."""
+  nt, nb, nv = m.ntree, m.nbody, m.nv
+  treeid = m.body_treeid.numpy()
+  mocap = m.body_mocapid.numpy()
+  body_awake = np.where(treeid >= 0, int(types.SleepState.AWAKE), np.where(mocap >= 0, int(types.SleepState.AWAKE), int(types.SleepState.STATIC))).astype(np.int32)
+  vals = dict(tree_asleep=np.full((d.nworld, nt), -(1 + types.MJ_MINAWAKE), np.int32), tree_awake=np.ones((d.nworld, nt), np.int32),
+              body_awake=np.tile(body_awake, (d.nworld, 1)), body_awake_ind=np.tile(np.arange(nb, dtype=np.int32), (d.nworld, 1)),
+              dof_awake_ind=np.tile(np.arange(nv, dtype=np.int32), (d.nworld, 1)), ntree_awake=np.full(d.nworld, nt, np.int32),
+              nbody_awake=np.full(d.nworld, nb, np.int32), nv_awake=np.full(d.nworld, nv, np.int32), tree_island=np.full((d.nworld, nt), -1, np.int32),
+              nisland=np.zeros(d.nworld, np.int32))
+  for name, val in vals.items():
+    dst = getattr(d, name)
+    if dst.size == 0:
+      continue
+    if mask is not None:
+      cur = dst.numpy().copy()
+      cur[mask] = val[mask]
+      val = cur
+    dst.assign(val)
+
+
 def _reset_state(m, d, qpos, qvel, act, ctrl, time, mask):
   def put(dst, val):
     if dst.size == 0:
@@ -686,6 +726,7 @@ def _reset_state(m, d, qpos, qvel, act, ctrl, time, mask):
   put(d.xfrc_applied, None)
   put(d.time, np.full(d.time.shape, time, dtype=np.float32))
   _reset_mocap(m, d, mask)
+  _reset_sleep(m, d, mask)
   if m.neq:
     put(d.eq_active, np.tile(m.eq_active0, (d.nworld, 1)))
   if mask is None:

@@ -702,6 +702,8 @@ def _compile(root, base_dir):
     b.pos = _vec(elem.attrib, "pos", [0, 0, 0])
     b.quat = _orientation(elem.attrib, compiler)
     b.gravcomp = float(elem.get("gravcomp", 0.0))
+    if elem.get("sleep", "auto") != "auto":
+      raise NotImplementedError("body sleep policies other than auto (reference types.py:308: NEVER, ALLOWED, INIT unsupported)")
     b.mocap = _bool(elem.get("mocap", "false")) or False
     if b.mocap and parentid != 0:
       raise ValueError("mocap bodies must be children of the world")
@@ -1194,7 +1196,7 @@ def mixed_contact_params(m, g1, g2):
 
 def _parse_option(elem, opt):
   for k, v in elem.attrib.items():
-    if k in ("timestep", "tolerance", "ls_tolerance", "impratio", "density", "viscosity", "noslip_tolerance", "ccd_tolerance"):
+    if k in ("timestep", "tolerance", "ls_tolerance", "impratio", "density", "viscosity", "noslip_tolerance", "ccd_tolerance", "sleep_tolerance"):
       setattr(opt, k, float(v))
     elif k in ("iterations", "ls_iterations", "noslip_iterations", "ccd_iterations", "sdf_iterations", "sdf_initpoints"):
       setattr(opt, k, int(v))
@@ -1370,6 +1372,7 @@ def set_const(m):
   m.body_invweight0 = np.zeros((nb, 2))
   if nv == 0:
     m.stat.meaninertia = 1.0
+    m.tree_sleep_policy, m.dof_length = np.zeros(0, dtype=np.int32), np.zeros(0)
     return
   h = host_mass_matrix(m, m.qpos0)
   M = h["M"]
@@ -1413,3 +1416,48 @@ def set_const(m):
     mom = np.zeros(nv)
     mom[m.jnt_dofadr[m.actuator_trnid[i, 0]]] = m.actuator_gear[i, 0]
     m.actuator_acc0[i] = float(np.linalg.norm(Minv @ mom))
+  _sleep_tables(m, h)
+
+
+def _sleep_tables(m, h):
+  """Per-tree sleep policy and per-dof velocity weights (MjModel.tree_sleep_policy / dof_length; consumed by reference sleep.py:273-322).
+
+  MuJoCo's compiler derives both; its source is not in the reference tree, so this is an UNPINNED stand-in for models loaded
+  through this module (a real mujoco.MjModel carries its own values): a tree some actuator drives never sleeps (AUTO_NEVER, the one
+  case the reference's own test holds: sleep_test.py:761-792), every other tree may (AUTO_ALLOWED); translational dofs weigh 1,
+  rotational dofs weigh the reach of their body's subtree about the joint anchor at qpos0 (farthest geom bounding sphere, at least
+  the body's equivalent-inertia-box half extent), which makes |dof_length * qvel| a linear speed as sleep_tolerance expects."""
+  nv = m.nv
+  m.tree_sleep_policy = np.full(m.ntree, 2, dtype=np.int32)  # SleepPolicy.AUTO_ALLOWED
+  for i in range(m.nu):
+    m.tree_sleep_policy[m.dof_treeid[m.jnt_dofadr[m.actuator_trnid[i, 0]]]] = 1  # SleepPolicy.AUTO_NEVER
+  m.dof_length = np.ones(nv)
+  if nv == 0:
+    return
+  xpos, xquat, xanchor, _ = _host_kinematics(m, m.qpos0)
+  inbox = np.zeros(m.nbody)
+  for b in range(1, m.nbody):
+    if m.body_mass[b] > 0:
+      I = np.asarray(m.body_inertia[b])
+      ext = np.sqrt(np.maximum(6.0 * (I.sum() / 2.0 - I) / m.body_mass[b], 0.0)) * 0.5  # half sizes of the equivalent box
+      inbox[b] = float(np.linalg.norm(ext))
+  for i in range(nv):
+    j = m.dof_jntid[i]
+    t, b = m.jnt_type[j], m.dof_bodyid[i]
+    rotational = (t == JNT_HINGE) or (t == JNT_BALL) or (t == JNT_FREE and i - m.jnt_dofadr[j] >= 3)
+    if not rotational:
+      continue
+    reach = 0.0
+    for bb in range(b, m.nbody):
+      p = bb  # bodies of the subtree of b
+      while p > b:
+        p = m.body_parentid[p]
+      if p != b:
+        continue
+      ipos = nm.rot_vec_quat(m.body_ipos[bb], xquat[bb]) + xpos[bb]
+      reach = max(reach, float(np.linalg.norm(ipos - xanchor[j])) + inbox[bb])
+      for g in range(m.ngeom):
+        if m.geom_bodyid[g] == bb and m.geom_type[g] != 0:
+          gp = nm.rot_vec_quat(m.geom_pos[g], xquat[bb]) + xpos[bb]
+          reach = max(reach, float(np.linalg.norm(gp - xanchor[j])) + float(m.geom_rbound[g]))
+    m.dof_length[i] = reach if reach > 0 else 1.0

@@ -150,6 +150,25 @@ class GeomType(enum.IntEnum):
   SDF = 8
 
 
+MJ_MINAWAKE = 10  # mjMINAWAKE: steps a tree must stay below the sleep tolerance before it may sleep (reference types.py:29)
+
+
+class SleepPolicy(enum.IntEnum):
+  """Per-tree sleep policy (reference types.py:296; NEVER / ALLOWED / INIT unsupported there and here)."""
+
+  AUTO = 0
+  AUTO_NEVER = 1
+  AUTO_ALLOWED = 2
+
+
+class SleepState(enum.IntEnum):
+  """Body sleep state (reference types.py:311; mjtSleepState)."""
+
+  STATIC = -1
+  ASLEEP = 0
+  AWAKE = 1
+
+
 class SolverType(enum.IntEnum):
   PGS = 0  # the reference has none (types.py:502); here: MuJoCo C's dual projected Gauss-Seidel (csrc/pgs.hpp)
   CG = 1
@@ -384,6 +403,10 @@ class Model(_Dirty):
   nmaxcondim: int = 0
   epa_iterations: int = 0  # EPA iteration cap of the convex narrowphase (reference collision_convex.py:1223)
   act_dof_max: int = 0  # largest number of actuators acting on one dof
+  sleep_enabled: int = 0  # EnableBit.SLEEP set and DisableBit.ISLAND clear (reference forward.py:345)
+  opt_sleep_tolerance: float = 0.0  # Option.sleep_tolerance (one value per model)
+  tree_sleep_policy: DeviceArray = _arr(('ntree',), "int32")
+  dof_length: DeviceArray = _arr(('nv',), "float32")
   ntree: int = 0  # kinematic trees with at least one dof
   tree_nvmax: int = 0  # dofs of the largest tree
   isl_nv4: int = 0  # quarter-rows of the widest island of <= 32 dofs (kernel size class)
@@ -511,6 +534,21 @@ class Data(_Dirty):
   ws_separable: DeviceArray = _arr(('nworld',), "int32")
   ws_ccd: DeviceArray = _arr(('nccdworld', 'nccdword', 32), "float32")
   ws_order: DeviceArray = _arr(('nworld',), "int32")
+  tree_asleep: DeviceArray = _arr(('nworld', 'ntree'), "int32")  # reference types.py:2330-2345
+  tree_awake: DeviceArray = _arr(('nworld', 'ntree'), "int32")
+  body_awake: DeviceArray = _arr(('nworld', 'nbody'), "int32")
+  body_awake_ind: DeviceArray = _arr(('nworld', 'nbody'), "int32")
+  dof_awake_ind: DeviceArray = _arr(('nworld', 'nv'), "int32")
+  ntree_awake: DeviceArray = _arr(('nworld',), "int32")
+  nbody_awake: DeviceArray = _arr(('nworld',), "int32")
+  nv_awake: DeviceArray = _arr(('nworld',), "int32")
+  tree_island: DeviceArray = _arr(('nworld', 'ntree'), "int32")
+  nisland: DeviceArray = _arr(('nworld',), "int32")
+  ws_sleep_J: DeviceArray = _arr(('nsleepworld', 'njmax_pad', 'nv_pad'), "float32")
+  ws_sleep_warm: DeviceArray = _arr(('nsleepworld', 'nv'), "float32")
+  ws_sleep_flag: DeviceArray = _arr(('nworld',), "int32")
+  sleep_pass: int = 0
+  nsleepworld: int = 0
   eq_active: DeviceArray = _arr(('nworld', 'neq'), "int32")
   ws_rk: DeviceArray = _arr(('nworld', 'nq+3*nv+2*na'), "float32")
   ws_contact: DeviceArray = _arr(('nworld', 'concap', 32), "float32")

@@ -27,6 +27,14 @@ enum { DSBL_CONSTRAINT = 1 << 0, DSBL_EQUALITY = 1 << 1, DSBL_FRICTIONLOSS = 1 <
        DSBL_WARMSTART = 1 << 9, DSBL_ACTUATION = 1 << 11, DSBL_REFSAFE = 1 << 12, DSBL_EULERDAMP = 1 << 15, DSBL_NATIVECCD = 1 << 17 };
 enum { SOL_PGS = 0, SOL_CG = 1, SOL_NEWTON = 2 };
 enum { INT_EULER = 0, INT_RK4 = 1, INT_IMPLICIT = 2, INT_IMPLICITFAST = 3 };
+enum { ENBL_SLEEP = 1 << 5, DSBL_ISLAND = 1 << 18 };
+enum { SLEEP_STATIC = -1, SLEEP_ASLEEP = 0, SLEEP_AWAKE = 1 };     /* SleepState (types.py:311; mjtSleepState) */
+enum { POLICY_AUTO = 0, POLICY_AUTO_NEVER = 1, POLICY_AUTO_ALLOWED = 2 }; /* SleepPolicy (types.py:296) */
+enum { MINAWAKE = 10 };                                              /* mjMINAWAKE (types.py:29) */
+#define K_AWAKE_VAL (-(1 + MINAWAKE))                                /* sleep.py:28 */
+static int sleep_enabled(const RefModel* m) { /* forward.py:345 */
+  return (m->enableflags & ENBL_SLEEP) && !(m->disableflags & DSBL_ISLAND);
+}
 enum { OVF_NEFC = 1 << 0, OVF_NARROW = 1 << 3, OVF_ITER = 1 << 9, OVF_LS = 1 << 10 };
 
 /* ---------------------------------------------------------------- math.py:24-333 */
@@ -532,6 +540,9 @@ void ref_fwd_velocity(const RefModel* m, RefData* d) { /* forward.py:732-753 */
 void ref_fwd_acceleration(const RefModel* m, RefData* d) {
   for (int i = 0; i < m->nv; i++)
     d->qfrc_smooth[i] = d->qfrc_passive[i] - d->qfrc_bias[i] + d->qfrc_actuator[i] + d->qfrc_applied[i];
+  if (sleep_enabled(m)) /* forward.py:1273-1278: no smooth force on the dofs of a sleeping tree */
+    for (int i = 0; i < m->nv; i++)
+      if (!d->tree_awake[m->dof_treeid[i]]) d->qfrc_smooth[i] = 0.0;
   for (int b = 1; b < m->nbody; b++) { /* xfrc_applied: (force[3], torque[3]) at xipos */
     const double* f = d->xfrc_applied + 6 * b;
     if (f[0] == 0 && f[1] == 0 && f[2] == 0 && f[3] == 0 && f[4] == 0 && f[5] == 0) continue;
@@ -551,6 +562,10 @@ void ref_fwd_acceleration(const RefModel* m, RefData* d) {
   }
   ref_factor_m(m, d);
   ref_solve_m(m, d, d->qacc_smooth, d->qfrc_smooth);
+  if (sleep_enabled(m)) /* solver.py:3899 smooth_solve_compact: M is block diagonal over trees, so the compacted solve is the full one
+                           on the awake trees; sleeping dofs are frozen at 0 (_scatter_solution solver.py:3882) */
+    for (int i = 0; i < m->nv; i++)
+      if (!d->tree_awake[m->dof_treeid[i]]) d->qacc_smooth[i] = 0.0;
 }
 
 /* ================================================================ collision */
@@ -1448,6 +1463,11 @@ void ref_collision(const RefModel* m, RefData* d) {
     int g1 = m->pair_geom[2 * p], g2 = m->pair_geom[2 * p + 1];
     int pid = m->nexplicit ? m->nxn_pairid[p] : -1;
     if (mark && !mark[p]) continue;
+    if (sleep_enabled(m)) { /* collision_driver.py:494-503: no pair of two sleeping bodies, or of a sleeping and a static one */
+      int s1 = d->body_awake[m->geom_bodyid[g1]], s2 = d->body_awake[m->geom_bodyid[g2]];
+      if (s1 == SLEEP_ASLEEP && s2 == SLEEP_ASLEEP) continue;
+      if ((s1 == SLEEP_ASLEEP && s2 == SLEEP_STATIC) || (s2 == SLEEP_ASLEEP && s1 == SLEEP_STATIC)) continue;
+    }
     int pass = broadphase_filter(m, d, p, g1, g2);
     if (!pass) continue;
     d->ncollision++;
@@ -2079,7 +2099,7 @@ static void solve_pgs(const RefModel* m, RefData* d, int nefc) {
 }
 
 /* solve solver.py:3671-3743, _solver_iteration 3525-3620, init_context 3622-3668 */
-void ref_solve(const RefModel* m, RefData* d) {
+static void solve_full(const RefModel* m, RefData* d) {
   int nv = m->nv, nefc = d->nefc < m->njmax ? d->nefc : m->njmax;
   d->solver_niter = 0;
   if (nefc == 0 || nv == 0 || m->njmax == 0) {
@@ -2160,16 +2180,259 @@ void ref_solve(const RefModel* m, RefData* d) {
 }
 
 /* ================================================================ forward.py */
+/* solver.py:3671 solve; with sleeping: solver.py:4022 solve_compact.  The reference gathers the awake dofs into dense nvmax-wide
+   arrays (M block, J columns, warm start, smooth terms), runs the stock solver there -- with the tolerances rescaled by nv / nvmax
+   so that the nv-normalised termination test is the full model's (io.py:1630) -- and scatters back with the sleeping dofs frozen
+   at 0.  Because M is block diagonal over kinematic trees, that is the full-size solve with the sleeping dofs' columns of J and
+   their warm start, qacc_smooth and qfrc_smooth zeroed (the gradient then vanishes identically on those dofs, so they never
+   move); the restatement does it that way on a masked copy and restores the public J afterwards. */
+void ref_solve(const RefModel* m, RefData* d) {
+  if (!sleep_enabled(m)) {
+    solve_full(m, d);
+    return;
+  }
+  int nv = m->nv, nefc = d->nefc < m->njmax ? d->nefc : m->njmax;
+  double* save = (double*)malloc(sizeof(double) * ((size_t)(nefc > 0 ? nefc : 1) * nv + nv));
+  double* wsave = save + (size_t)(nefc > 0 ? nefc : 1) * nv;
+  memcpy(save, d->efc_J, sizeof(double) * (size_t)nefc * nv);
+  memcpy(wsave, d->qacc_warmstart, sizeof(double) * nv);
+  for (int i = 0; i < nv; i++)
+    if (!d->tree_awake[m->dof_treeid[i]]) {
+      for (int r = 0; r < nefc; r++) d->efc_J[(size_t)r * nv + i] = 0.0;
+      d->qacc_warmstart[i] = 0.0;
+    }
+  solve_full(m, d);
+  memcpy(d->efc_J, save, sizeof(double) * (size_t)nefc * nv);
+  memcpy(d->qacc_warmstart, wsave, sizeof(double) * nv);
+  for (int i = 0; i < nv; i++)
+    if (!d->tree_awake[m->dof_treeid[i]]) { d->qacc[i] = 0.0; d->qfrc_constraint[i] = 0.0; }
+  ref_mul_m(m, d, d->Ma, d->qacc); /* _compact_scatter solver.py:4108 */
+  free(save);
+}
+
+/* ================================================================ constraint islands + sleeping */
+/* sleep.py:171-215 update_sleep (flg_staticawake = 0): tree / body / dof awake tables from tree_asleep.  (The reference fills the
+   index lists through atomics, in no particular order; here ascending.) */
+void ref_update_sleep(const RefModel* m, RefData* d) {
+  d->ntree_awake = d->nbody_awake = d->nv_awake = 0;
+  for (int t = 0; t < m->ntree; t++) {
+    d->tree_awake[t] = d->tree_asleep[t] < 0;
+    d->ntree_awake += d->tree_awake[t];
+  }
+  for (int b = 0; b < m->nbody; b++) {
+    int tree = m->body_treeid[b], state;
+    if (tree < 0) state = m->body_mocapid[m->body_rootid[b]] >= 0 ? SLEEP_AWAKE : SLEEP_STATIC;
+    else state = d->tree_awake[tree] ? SLEEP_AWAKE : SLEEP_ASLEEP;
+    d->body_awake[b] = state;
+    if (state != SLEEP_ASLEEP) d->body_awake_ind[d->nbody_awake++] = b;
+  }
+  for (int i = 0; i < m->nv; i++) {
+    int b = m->dof_bodyid[i];
+    if (m->body_treeid[b] >= 0 && d->body_awake[b] == SLEEP_AWAKE) d->dof_awake_ind[d->nv_awake++] = i;
+  }
+}
+static int sleep_cycle(const RefModel* m, const RefData* d, int treeid) { /* sleep.py:33: smallest tree of the cycle, -1 if awake */
+  if (treeid < 0 || treeid >= m->ntree) return -1;
+  int smallest = treeid, current = treeid;
+  for (int step = 0; step < m->ntree + 1; step++) {
+    int next = d->tree_asleep[current];
+    if (next < 0 || next >= m->ntree) return -1;
+    if (next < smallest) smallest = next;
+    current = next;
+    if (current == treeid) break;
+  }
+  return smallest;
+}
+static int wake_tree(const RefModel* m, RefData* d, int treeid, int wakeval) { /* sleep.py:236: wakes the tree and its cycle */
+  if (treeid < 0 || treeid >= m->ntree) return 0;
+  int val = d->tree_asleep[treeid];
+  if (val < 0) {
+    if (wakeval < val) d->tree_asleep[treeid] = wakeval;
+    return 0;
+  }
+  int nwoke = 0, current = treeid;
+  for (int step = 0; step < m->ntree + 1; step++) {
+    int next = d->tree_asleep[current];
+    if (next < 0 || next >= m->ntree) break;
+    d->tree_asleep[current] = wakeval;
+    nwoke++;
+    current = next;
+    if (current == treeid) break;
+  }
+  return nwoke;
+}
+static int tree_can_sleep(const RefModel* m, const RefData* d, int t, double tol) { /* sleep.py:273 */
+  if (m->tree_sleep_policy[t] == POLICY_AUTO_NEVER) return 0;
+  for (int b = 0; b < m->nbody; b++)
+    if (m->body_treeid[b] == t)
+      for (int i = 0; i < 6; i++)
+        if (d->xfrc_applied[6 * b + i] != 0.0) return 0;
+  int adr = m->tree_dofadr[t], num = m->tree_dofnum[t];
+  for (int k = 0; k < num; k++)
+    if (d->qfrc_applied[adr + k] != 0.0) return 0;
+  for (int k = 0; k < num; k++) {
+    double v = d->qvel[adr + k];
+    if (tol > 0.0) {
+      if (fabs(m->dof_length[adr + k] * v) >= tol) return 0;
+    } else if (v != 0.0) return 0;
+  }
+  return 1;
+}
+void ref_wake(const RefModel* m, RefData* d) { /* sleep.py:325, 721: user changes (velocity, applied forces) wake a sleeping tree */
+  for (int t = 0; t < m->ntree; t++) {
+    if (d->tree_asleep[t] < 0) continue;
+    if (d->tree_awake[t] == 1 || !tree_can_sleep(m, d, t, 0.0)) wake_tree(m, d, t, K_AWAKE_VAL);
+  }
+}
+void ref_wake_collision(const RefModel* m, RefData* d) { /* sleep.py:367, 744: a contact between an awake and a sleeping tree */
+  for (int c = 0; c < d->ncon; c++) {
+    int g1 = d->con_geom[2 * c], g2 = d->con_geom[2 * c + 1];
+    if (g1 < 0 || g2 < 0) continue;
+    int t1 = m->body_treeid[m->geom_bodyid[g1]], t2 = m->body_treeid[m->geom_bodyid[g2]];
+    if (t1 < 0 || t2 < 0) continue;
+    int a1 = d->tree_awake[t1], a2 = d->tree_awake[t2];
+    if (a1 == a2) continue;
+    wake_tree(m, d, a1 == 1 ? t2 : t1, a1 == 1 ? d->tree_asleep[t1] : d->tree_asleep[t2]);
+  }
+}
+void ref_wake_equality(const RefModel* m, RefData* d) { /* sleep.py:579, 793 (joint equalities: the only type on this path) */
+  for (int e = 0; e < m->neq; e++) {
+    if (!m->eq_active0[e]) continue;
+    int id1 = m->eq_obj1id[e], id2 = m->eq_obj2id[e];
+    int t1 = id1 >= 0 ? m->body_treeid[m->jnt_bodyid[id1]] : -1, t2 = id2 >= 0 ? m->body_treeid[m->jnt_bodyid[id2]] : -1;
+    int s1 = t1 >= 0 ? d->tree_awake[t1] : SLEEP_STATIC, s2 = t2 >= 0 ? d->tree_awake[t2] : SLEEP_STATIC;
+    if (s1 != SLEEP_ASLEEP && s2 != SLEEP_ASLEEP) continue;
+    if (s1 == SLEEP_STATIC || s2 == SLEEP_STATIC) continue;
+    if (t1 == t2) continue;
+    if (s1 == SLEEP_ASLEEP && s2 == SLEEP_ASLEEP) {
+      if (sleep_cycle(m, d, t1) != sleep_cycle(m, d, t2)) {
+        wake_tree(m, d, t1, K_AWAKE_VAL);
+        wake_tree(m, d, t2, K_AWAKE_VAL);
+      }
+    } else wake_tree(m, d, s1 == SLEEP_ASLEEP ? t1 : t2, K_AWAKE_VAL);
+  }
+}
+/* island.py:28-310: tree-tree edges from the constraint rows, flood fill in the order of the smallest tree; trees without rows
+   keep island -1 */
+void ref_island(const RefModel* m, RefData* d) {
+  int nt = m->ntree, nv = m->nv;
+  d->nisland = 0;
+  if (nt == 0) return;
+  unsigned char* tt = (unsigned char*)calloc((size_t)nt * nt, 1);
+  int nefc = d->nefc < m->njmax ? d->nefc : m->njmax;
+  for (int r = 0; r < nefc; r++) {
+    int type = d->efc_type[r], id = d->efc_id[r], t0 = -1, t1 = -1, generic = 0;
+    if (type == CT_EQUALITY) generic = 1; /* (connect / weld would use their bodies; joint equalities scan the row) */
+    else if (type == CT_FRICTION_DOF) t0 = m->dof_treeid[id];
+    else if (type == CT_LIMIT_JOINT) t0 = m->dof_treeid[m->jnt_dofadr[id]];
+    else if (type == CT_CONTACT_FRICTIONLESS || type == CT_CONTACT_PYRAMIDAL || type == CT_CONTACT_ELLIPTIC) {
+      t0 = m->body_treeid[m->geom_bodyid[d->con_geom[2 * id]]];
+      t1 = m->body_treeid[m->geom_bodyid[d->con_geom[2 * id + 1]]];
+    } else generic = 1;
+    if (!generic) {
+      if (t0 < 0 && t1 >= 0) { t0 = t1; t1 = -1; }
+      if (t0 >= 0) {
+        if (t1 < 0 || t0 == t1) tt[t0 * nt + t0] = 1;
+        else tt[t0 * nt + t1] = tt[t1 * nt + t0] = 1;
+      }
+      continue;
+    }
+    int first = -1, cross = 0;
+    for (int i = 0; i < nv; i++) {
+      if (d->efc_J[(size_t)r * nv + i] == 0.0) continue;
+      int t = m->dof_treeid[i];
+      if (t < 0) continue;
+      if (first == -1) first = t;
+      else if (t != first) { tt[first * nt + t] = tt[t * nt + first] = 1; cross = 1; }
+    }
+    if (first >= 0 && !cross) tt[first * nt + first] = 1;
+  }
+  int* stack = (int*)malloc(sizeof(int) * ((size_t)nt * nt + 1));
+  for (int t = 0; t < nt; t++) d->tree_island[t] = -1;
+  for (int i = 0; i < nt; i++) {
+    if (d->tree_island[i] != -1) continue;
+    int has = 0;
+    for (int j = 0; j < nt; j++) has |= tt[i * nt + j];
+    if (!has) continue;
+    int ns = 0;
+    stack[ns++] = i;
+    while (ns > 0) {
+      int v = stack[--ns];
+      if (d->tree_island[v] != -1) continue;
+      d->tree_island[v] = d->nisland;
+      for (int n = 0; n < nt; n++)
+        if (tt[v * nt + n] && d->tree_island[n] == -1) stack[ns++] = n;
+    }
+    d->nisland++;
+  }
+  free(stack);
+  free(tt);
+}
+void ref_sleep(const RefModel* m, RefData* d) { /* sleep.py:824-999 */
+  int nt = m->ntree;
+  for (int t = 0; t < nt; t++) { /* 1. awake trees count towards sleep while they could sleep */
+    int val = d->tree_asleep[t];
+    if (val >= 0) continue;
+    if (tree_can_sleep(m, d, t, m->sleep_tolerance)) {
+      if (val < -1) d->tree_asleep[t] = val + 1;
+    } else d->tree_asleep[t] = K_AWAKE_VAL;
+  }
+  int* can = (int*)malloc(sizeof(int) * (nt + 1)); /* 2. an island sleeps only when every tree in it is ready */
+  for (int k = 0; k < nt; k++) can[k] = 1;
+  for (int t = 0; t < nt; t++) {
+    int isl = d->tree_island[t];
+    if (isl >= 0 && isl < d->nisland && d->tree_asleep[t] < -1) can[isl] = 0;
+  }
+  for (int isl = 0; isl < d->nisland; isl++) { /* 3. sleep cycles of sleeping islands */
+    if (!can[isl]) continue;
+    int first = -1, prev = -1;
+    for (int t = 0; t < nt; t++) {
+      if (d->tree_island[t] != isl) continue;
+      if (first == -1) first = t;
+      if (prev != -1) d->tree_asleep[prev] = t;
+      prev = t;
+      for (int k = 0; k < m->tree_dofnum[t]; k++) d->qvel[m->tree_dofadr[t] + k] = d->qacc[m->tree_dofadr[t] + k] = 0.0;
+    }
+    if (first != -1) d->tree_asleep[prev] = first;
+  }
+  for (int t = 0; t < nt; t++) { /* unconstrained trees sleep on their own */
+    int isl = d->tree_island[t];
+    if (isl < 0 || isl >= d->nisland) {
+      if (d->tree_asleep[t] == -1) d->tree_asleep[t] = t;
+      if (d->tree_asleep[t] >= 0)
+        for (int k = 0; k < m->tree_dofnum[t]; k++) d->qvel[m->tree_dofadr[t] + k] = d->qacc[m->tree_dofadr[t] + k] = 0.0;
+    }
+  }
+  free(can);
+}
+
 void ref_fwd_position(const RefModel* m, RefData* d) { /* forward.py:635-679 */
   ref_kinematics(m, d);
   ref_com_pos(m, d);
   ref_crb(m, d);
   ref_factor_m(m, d);
   ref_collision(m, d);
+  if (sleep_enabled(m)) {
+    /* forward.py:652-666: contacts of pass 1 wake sleeping trees touched by awake ones; pass 2 adds the pairs pass 1 skipped that
+       involve a newly awakened body.  Waking only ever lets more pairs through the filter, so pass 1 + pass 2 is the set of pairs
+       that pass the filter under the new state: the restatement recomputes the whole list (in canonical pair order). */
+    ref_wake_collision(m, d);
+    ref_update_sleep(m, d);
+    ref_collision(m, d);
+  }
   ref_make_constraint(m, d);
+  if (sleep_enabled(m)) {
+    if (m->neq > 0) ref_wake_equality(m, d);
+    ref_update_sleep(m, d);
+    ref_island(m, d);
+  }
   ref_transmission(m, d);
 }
 void ref_forward(const RefModel* m, RefData* d) { /* forward.py:1341-1366 */
+  if (sleep_enabled(m)) {
+    ref_wake(m, d);
+    ref_update_sleep(m, d);
+  }
   ref_fwd_position(m, d);
   ref_fwd_velocity(m, d);
   ref_fwd_actuation(m, d);
@@ -2316,6 +2579,11 @@ void ref_step(const RefModel* m, RefData* d) { /* forward.py:1368-1380 */
   if (m->integrator == INT_IMPLICITFAST) ref_implicitfast(m, d);
   else if (m->integrator == INT_RK4) ref_rungekutta4(m, d);
   else ref_euler(m, d);
+  if (sleep_enabled(m)) { /* forward.py:345-349 (end of _advance) */
+    ref_sleep(m, d);
+    ref_fwd_velocity(m, d);
+    ref_update_sleep(m, d);
+  }
 }
 
 /* util_misc.py:61 halton (float32 arithmetic in the reference; restated in float32 here on purpose) */

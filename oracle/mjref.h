@@ -31,6 +31,8 @@ typedef struct RefModel {
   int nconmax;
   int nmocap;
   int nexplicit;
+  int ntree;
+  int enableflags;       /* EnableBit: SLEEP = 1 << 5 (with DisableBit.ISLAND clear: forward.py:345) */
   int integrator;
   int cone;
   int solver;
@@ -47,6 +49,7 @@ typedef struct RefModel {
   double impratio;
   double ccd_tolerance;
   double meaninertia;
+  double sleep_tolerance;
   double* gravity;
   double* qpos0;
   double* qpos_spring;
@@ -136,6 +139,12 @@ typedef struct RefModel {
   double* eq_solref;
   double* eq_solimp;
   double* eq_data;
+  int* body_treeid;
+  int* dof_treeid;
+  int* tree_dofadr;
+  int* tree_dofnum;
+  int* tree_sleep_policy; /* SleepPolicy: 0 AUTO, 1 AUTO_NEVER, 2 AUTO_ALLOWED */
+  double* dof_length;
 } RefModel;
 
 typedef struct RefData {
@@ -148,6 +157,10 @@ typedef struct RefData {
   int solver_niter;
   int ncollision;
   int overflow;
+  int nisland;
+  int ntree_awake;
+  int nbody_awake;
+  int nv_awake;
   double* qpos;
   double* qvel;
   double* act;
@@ -214,6 +227,12 @@ typedef struct RefData {
   double* efc_aref;
   double* efc_frictionloss;
   double* efc_force;
+  int* tree_asleep;   /* sleep.py: < 0 awake (countdown to -1), >= 0 next tree of the sleep cycle */
+  int* tree_awake;
+  int* body_awake;    /* SleepState: -1 static, 0 asleep, 1 awake */
+  int* tree_island;
+  int* body_awake_ind;
+  int* dof_awake_ind;
 } RefData;
 
 void ref_kinematics(const RefModel* m, RefData* d);
@@ -238,6 +257,13 @@ void ref_euler(const RefModel* m, RefData* d);
 void ref_implicitfast(const RefModel* m, RefData* d);
 void ref_rungekutta4(const RefModel* m, RefData* d); /* forward.py:524; call after ref_forward */
 void ref_step(const RefModel* m, RefData* d);
+/* sleep.py / island.py:28-310 (tree-level constraint islands, sleeping, waking) */
+void ref_update_sleep(const RefModel* m, RefData* d);
+void ref_wake(const RefModel* m, RefData* d);
+void ref_wake_collision(const RefModel* m, RefData* d);
+void ref_wake_equality(const RefModel* m, RefData* d);
+void ref_island(const RefModel* m, RefData* d);
+void ref_sleep(const RefModel* m, RefData* d);
 void ref_ctrl_noise(const RefModel* m, RefData* d, const double* center, int step, int worldid, double noise_std, double noise_rate);
 double ref_halton(int index, int base);
 void ref_closest_segment_to_segment_points(const double* a0, const double* a1, const double* b0, const double* b1, double* best_a_out,

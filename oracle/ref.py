@@ -152,8 +152,10 @@ _SIZES = {
   "con_solimp": ("nconmax", 5), "con_dim": "nconmax", "con_geom": ("nconmax", 2), "con_efc_address": ("nconmax", 10),
   "efc_type": "njmax", "efc_id": "njmax", "efc_state": "njmax", "efc_J": ("njmax", "nv"), "efc_pos": "njmax",
   "efc_margin": "njmax", "efc_D": "njmax", "efc_vel": "njmax", "efc_aref": "njmax", "efc_frictionloss": "njmax",
-  "efc_force": "njmax",
+  "efc_force": "njmax", "tree_asleep": "ntree", "tree_awake": "ntree", "body_awake": "nbody", "tree_island": "ntree",
+  "body_awake_ind": "nbody", "dof_awake_ind": "nv",
 }
+MJ_MINAWAKE = 10  # mjMINAWAKE (reference types.py:29)
 
 
 class RefSim:
@@ -182,12 +184,13 @@ class RefSim:
     sizes["nexplicit"] = nexplicit
     sizes["neq"] = int(getattr(mjm, "neq", 0))
     sizes["nmocap"] = int(getattr(mjm, "nmocap", 0))
+    sizes["ntree"] = int(getattr(mjm, "ntree", 0))
     scalars = dict(
       integrator=int(opt.integrator if integrator is None else integrator), cone=int(opt.cone),
       solver=int(opt.solver if solver is None else solver),
       iterations=int(opt.iterations if iterations is None else iterations),
       ls_iterations=int(opt.ls_iterations if ls_iterations is None else ls_iterations),
-      disableflags=int(opt.disableflags), broadphase=int(broadphase), broadphase_filter=int(broadphase_filter), ccd_iterations=int(getattr(opt, 'ccd_iterations', 35)), epa_iterations=_epa_iterations(mjm, pairs),
+      disableflags=int(opt.disableflags), enableflags=int(getattr(opt, 'enableflags', 0)), sleep_tolerance=float(getattr(opt, 'sleep_tolerance', 1e-4)), broadphase=int(broadphase), broadphase_filter=int(broadphase_filter), ccd_iterations=int(getattr(opt, 'ccd_iterations', 35)), epa_iterations=_epa_iterations(mjm, pairs),
       ccd_tolerance=float(getattr(opt, 'ccd_tolerance', 1e-6)), timestep=float(opt.timestep),
       tolerance=float(opt.tolerance if tolerance is None else tolerance), ls_tolerance=float(opt.ls_tolerance),
       impratio=float(opt.impratio), meaninertia=float(mjm.stat.meaninertia))
@@ -199,6 +202,8 @@ class RefSim:
                "xpair_solimp": getattr(mjm, "pair_solimp", np.zeros(0)), "xpair_margin": getattr(mjm, "pair_margin", np.zeros(0)),
                "xpair_gap": getattr(mjm, "pair_gap", np.zeros(0)),
                "actuator_trnid": mjm.actuator_trnid, "M_colind": mjm.M_colind}
+    for name, dt in (("tree_sleep_policy", np.int32), ("dof_length", np.float64)):  # (absent on models that predate sleeping)
+      special[name] = np.asarray(getattr(mjm, name, np.full(sizes["ntree"], 2) if name == "tree_sleep_policy" else np.ones(mjm.nv)), dtype=dt)
     for name, kind, ptr in _MODEL_FIELDS:
       if not ptr:
         setattr(cm, name, sizes[name] if name in sizes else scalars[name])
@@ -241,6 +246,9 @@ class RefSim:
         self.act[:] = m.key_act[key]
     self.cd.time = 0.0
     self.cd.overflow = 0
+    self.tree_asleep[:] = -(1 + MJ_MINAWAKE)  # fully awake (reference io.py:1869)
+    self.tree_island[:] = -1
+    self._call("update_sleep")
     for b in range(m.nbody):  # mocap bodies start at their model pose
       if int(m.body_mocapid[b]) >= 0:
         self.mocap_pos[int(m.body_mocapid[b])] = m.body_pos[b]
@@ -252,7 +260,7 @@ class RefSim:
       shape = self.__dict__["_shape_" + name]
       n = int(np.prod(shape))
       return arr[name][:n].reshape(shape)
-    if name in ("ncon", "ne", "nf", "nl", "nefc", "solver_niter", "overflow", "time", "ncollision"):
+    if name in ("ncon", "ne", "nf", "nl", "nefc", "solver_niter", "overflow", "time", "ncollision", "nisland", "ntree_awake", "nbody_awake", "nv_awake"):
       return getattr(self.__dict__["cd"], name)
     raise AttributeError(name)
 
