@@ -595,6 +595,12 @@ def put_data(mjm, mjd, nworld: int = 1, nconmax: Optional[int] = None, nccdmax: 
     if dst.size:
       dst.assign(np.broadcast_to(src.reshape((1,) + dst.shape[1:]), dst.shape))
   d.time.fill_(float(mjd.time))
+  if m.ntree and getattr(mjd, "tree_asleep", None) is not None:  # reference io.py:2010-2012, 2138-2140: the host sleep state, tiled
+    asleep = np.asarray(mjd.tree_asleep, dtype=np.int32).reshape(1, -1)
+    d.tree_asleep.assign(np.tile(asleep, (nworld, 1)))
+    d.tree_awake.assign(np.tile((asleep < 0).astype(np.int32), (nworld, 1)))
+    if getattr(mjd, "body_awake", None) is not None:
+      d.body_awake.assign(np.tile(np.asarray(mjd.body_awake, dtype=np.int32).reshape(1, -1), (nworld, 1)))
   return d
 
 
@@ -633,6 +639,8 @@ def get_data_into(result, mjm, d: types.Data, world_id: int = 0):
   for name in ("type", "id", "state"):
     setattr(result, "efc_" + name, getattr(d.efc, name).numpy()[w, :nefc])
   result.solver_niter = np.array([int(d.solver_niter.numpy()[w])])
+  for name in ("tree_asleep", "tree_awake", "body_awake"):  # reference io.py:2409-2412
+    setattr(result, name, getattr(d, name).numpy()[w].copy())
 
 
 def reset_data(m: types.Model, d: types.Data, reset=None):

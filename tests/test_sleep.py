@@ -454,3 +454,53 @@ def test_gpu_pile_free_running_tables():
   assert slept.all(), slept
   assert woke[[0, 1, 3]].all() and not woke[2], woke  # the projectile at rest (world 2) wakes nobody
   assert (d.ntree_awake.numpy() == 0).all() and int(d.nacon.numpy()[0]) == 0 and (d.overflow.numpy() == 0).all()
+
+
+def _many_boxes_xml(n=12):
+  bodies = []
+  for i in range(n):
+    x, y = 0.5 * (i % 4), 0.5 * (i // 4)
+    bodies.append(f'<body pos="{x} {y} 0.101"><freejoint/><geom type="box" size=".1 .1 .1"/></body>')
+  bodies.append('<body pos="0 0 0.305"><freejoint/><geom type="box" size=".08 .08 .1"/></body>')  # stacked on box 0
+  return ('<mujoco><option timestep="0.004" sleep_tolerance="0.02"><flag sleep="enable" island="enable" nativeccd="disable"/></option>'
+          '<worldbody><geom type="plane" size="10 10 .1"/>' + "".join(bodies) + "</worldbody></mujoco>")
+
+
+@pytest.mark.gpu
+def test_gpu_sleep_nv78_tree_solver_and_host_roundtrip():
+  """13 free boxes (nv 78 > 64: the per-island solver path, MjhModel.tree_solve) with sleeping: tables vs the oracle while everything
+  settles and sleeps; then put_data / get_data_into carry the sleep state."""
+  xml = _many_boxes_xml()
+  mjm, m, d = _gpu(xml, 2, nconmax=80, njmax=320)
+  assert m.tree_solve == 1 and m.sleep_enabled == 1
+  s = ref.RefSim(mjm, nconmax=80, njmax=320)
+  v = d.qvel.numpy()
+  v[1, 6 * 5 + 2] = 1.0  # world 1: box 5 hops
+  d.qvel.assign(v)
+  sims = [s, ref.RefSim(mjm, nconmax=80, njmax=320)]
+  sims[1].qvel[6 * 5 + 2] = 1.0
+  for step in range(120):
+    mjw.step(m, d)
+    for w, sim in enumerate(sims):
+      sim.step()
+      _check_tables(d, w, sim, f"step {step} world {w}")
+      assert relerr(d.qpos.numpy()[w], sim.qpos) < 1e-4
+  assert (d.overflow.numpy() == 0).all()
+  assert (d.ntree_awake.numpy() == 0).all(), d.tree_asleep.numpy()
+  ta = d.tree_asleep.numpy()[0]
+  assert {int(ta[0]), int(ta[12])} == {0, 12}  # the stack is one sleep cycle
+  # host round trip
+  class Host:
+    pass
+
+  res = Host()
+  mjw.get_data_into(res, mjm, d, world_id=1)
+  assert (res.tree_asleep == ta).all() and (res.tree_awake == 0).all() and res.body_awake[0] == mjw.SleepState.STATIC and (res.body_awake[1:] == mjw.SleepState.ASLEEP).all()
+  mjd = mjw.mjcf.MjData(mjm)
+  mjd.qpos[:] = res.qpos
+  mjd.tree_asleep = res.tree_asleep
+  mjd.body_awake = res.body_awake
+  d2 = mjw.put_data(mjm, mjd, nworld=2, nconmax=80, njmax=320)
+  assert (d2.tree_asleep.numpy() == ta).all() and (d2.tree_awake.numpy() == 0).all()
+  mjw.step(m, d2)
+  assert (d2.tree_awake.numpy() == 0).all() and int(d2.nacon.numpy()[0]) == 0 and (d2.qvel.numpy() == 0).all()
