@@ -139,6 +139,9 @@ typedef struct MjhModel {
   const int* M_rownnz; const int* M_rowadr; const int* M_colind;
   /* geoms */
   const int* geom_type; const int* geom_condim; const int* geom_bodyid; const int* geom_priority;
+  const int* geom_dataid;       /* [ngeom] mesh id of mesh geoms, -1 otherwise (types.py:1266)                  */
+  const int* mesh_vertadr; const int* mesh_vertnum; /* [nmesh] first vertex / number of vertices (types.py:1707-1709) */
+  const float* mesh_vert;       /* [nmeshvert, 3] vertices in the mesh (= geom) frame; searched exhaustively by the convex narrowphase */
   const float* geom_solmix; int geom_solmix_nb;
   const float* geom_solref; int geom_solref_nb;
   const float* geom_solimp; int geom_solimp_nb;
@@ -296,7 +299,7 @@ int mjh_timed_steps(const MjhModel* m, const MjhData* d, int nstep, int step0, f
 int mjh_release_thread_resources(void);
 
 const char* mjh_last_error(void);
-#define MJH_ABI_VERSION 16
+#define MJH_ABI_VERSION 17
 int mjh_abi_version(void); /* returns MJH_ABI_VERSION of the library that was loaded */
 
 #ifdef __cplusplus

@@ -501,8 +501,8 @@ DEV int box_box(V3 P1, const float* R1, V3 S1, V3 P2, const float* R2, V3 S2, fl
 // half of it), the GJK cutoff is the gap, the reported distance is un-inflated, the contact sits midway between the witness points
 template <class Emit>
 DEV void collide_convex(float tolerance, int iterations, int epa_iterations, int t1, int t2, V3 p1, const float* R1, V3 s1, V3 p2, const float* R2, V3 s2, float margin,
-                        float gap, float* scratch, int& overflow, Emit&& emit) {
-  const CcdGeom a = CcdGeom{t1, p1, R1, s1, margin}, b = CcdGeom{t2, p2, R2, s2, margin};
+                        float gap, float* scratch, int& overflow, Emit&& emit, const float* vert1 = nullptr, int nvert1 = 0, const float* vert2 = nullptr, int nvert2 = 0) {
+  const CcdGeom a = CcdGeom{t1, p1, R1, s1, margin, vert1, nvert1, -1}, b = CcdGeom{t2, p2, R2, s2, margin, vert2, nvert2, -1};
   float dist;
   V3 w1, w2;
   int face;
@@ -522,12 +522,82 @@ DEV void collide_convex(float tolerance, int iterations, int epa_iterations, int
   emit(0, dist, 0.5f * (w1 + w2), f.a, f.b, f.c);
 }
 
+// plane - convex mesh (collision_primitive.py:52-274 plane_convex, the exhaustive branch: meshes without a hill-climbing graph or with
+// fewer than 10 vertices): the deepest vertex a, then among the vertices within 1 mm of it the one furthest from a, the one furthest
+// from the line a-b and the one furthest from the other two edges; vertices that were picked once become contacts (at most 4)
+template <class Emit>
+DEV void plane_mesh(V3 pn, V3 pp, V3 mp, const float* R, const float* vert, int nvert, Emit&& emit) {
+  const float HUGE_V = 1e6f;
+  const V3 pl = matT_mul(R, pp - mp), nl = matT_mul(R, pn);
+  int idx[4] = {-1, -1, -1, -1};
+  float max_support = -HUGE_V;
+  V3 a = V3{0, 0, 0}, b = a, c = a;
+  for (int i = 0; i < nvert; ++i) {
+    const V3 v = ld3(vert + 3 * i);
+    const float sup = dot(pl - v, nl);
+    if (sup > max_support) {
+      max_support = sup;
+      idx[0] = i;
+      a = v;
+    }
+  }
+  if (max_support < 0.0f) return;
+  const float threshold = max_support - 1e-3f;
+  float best = -HUGE_V;
+  for (int i = 0; i < nvert; ++i) {
+    const V3 v = ld3(vert + 3 * i);
+    const float mask = dot(pl - v, nl) > threshold ? 0.0f : -HUGE_V;
+    const float dd = dot(a - v, a - v) + mask;
+    if (dd > best) {
+      idx[1] = i;
+      best = dd;
+      b = v;
+    }
+  }
+  const V3 ab = cross(nl, a - b);
+  best = -HUGE_V;
+  for (int i = 0; i < nvert; ++i) {
+    const V3 v = ld3(vert + 3 * i);
+    const float mask = dot(pl - v, nl) > threshold ? 0.0f : -HUGE_V;
+    const float dd = fabsf(dot(a - v, ab)) + mask;
+    if (dd > best) {
+      idx[2] = i;
+      best = dd;
+      c = v;
+    }
+  }
+  const V3 ac = cross(nl, a - c), bc = cross(nl, b - c);
+  best = -HUGE_V;
+  for (int i = 0; i < nvert; ++i) {
+    const V3 v = ld3(vert + 3 * i);
+    const float mask = dot(pl - v, nl) > threshold ? 0.0f : -HUGE_V;
+    const float dd = (fabsf(dot(a - v, ac)) + mask) + (fabsf(dot(b - v, bc)) + mask);
+    if (dd > best) {
+      idx[3] = i;
+      best = dd;
+    }
+  }
+  const Frame f = make_frame3(pn);
+  int n = 0;
+  for (int i = 3; i >= 0; --i) {
+    int count = 0;
+    for (int j = 0; j <= i; ++j) count += idx[j] == idx[i];
+    if (count != 1) continue;
+    const V3 v = ld3(vert + 3 * idx[i]);
+    const float dist = -dot(pl - v, nl);
+    emit(n++, dist, mp + mat_mul(R, v) - (0.5f * dist) * pn, f.a, f.b, f.c);
+  }
+}
+
 template <bool HEAVY, class Emit>
-DEV void collide_pair(int t1, int t2, V3 p1, const float* R1, V3 s1, V3 p2, const float* R2, V3 s2, float margin, Emit&& emit) {
+DEV void collide_pair(int t1, int t2, V3 p1, const float* R1, V3 s1, V3 p2, const float* R2, V3 s2, float margin, Emit&& emit, const float* vert2 = nullptr,
+                      int nvert2 = 0) {
   V3 ax1 = V3{R1[2], R1[5], R1[8]}, ax2 = V3{R2[2], R2[5], R2[8]};
   float dist;
   V3 pos, nn;
-  if (t1 == G_PLANE && t2 == G_SPHERE) {
+  if (HEAVY && t1 == G_PLANE && t2 == G_MESH) {
+    plane_mesh(ax1, p1, p2, R2, vert2, nvert2, emit);
+  } else if (t1 == G_PLANE && t2 == G_SPHERE) {
     plane_sphere(ax1, p1, p2, s2.x, dist, pos);
     const Frame f = make_frame3(ax1);
     emit(0, dist, pos, f.a, f.b, f.c);
@@ -1003,6 +1073,15 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
       t = t1; t1 = t2; t2 = t;
     }
   };
+  auto mesh_of = [&](int g, int t, const float*& vert, int& nvert) {  // mesh geoms: their vertices in the geom frame
+    vert = nullptr;
+    nvert = 0;
+    if (HEAVY && t == G_MESH) {
+      const int id = m.geom_dataid[g];
+      vert = m.mesh_vert + 3 * m.mesh_vertadr[id];
+      nvert = m.mesh_vertnum[id];
+    }
+  };
   // EPA polytope of this lane (convex.hpp): word k of lane l at k * 32 + l inside the world's slice of d.ws_ccd
   float* ccd_scratch = (HEAVY && d.ws_ccd) ? d.ws_ccd + (size_t)w * ccd_words(max(m.ccd_iterations, m.epa_iterations)) * CCD_LANES + (lig & (CCD_LANES - 1)) : nullptr;
   const float ccd_tol = HEAVY ? bf(m.opt_ccd_tolerance, m.opt_ccd_tolerance_nb, w, 1)[0] : 0.0f;
@@ -1024,6 +1103,10 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
       const float gap = pid >= 0 ? m.pair_gap[pid] : ggap[g1] + ggap[g2];
       const float lim = margin + gap;
       auto count = [&](int k, float dist, V3, V3, V3, V3) { mask |= dist < lim ? (1u << (k & 7)) : 0u; };
+      const float *mv1, *mv2;
+      int mn1, mn2;
+      mesh_of(g1, t1, mv1, mn1);
+      mesh_of(g2, t2, mv2, mn2);
       if (HEAVY && (is_convex_pair(t1, t2) || (box_ccd && t1 == G_BOX && t2 == G_BOX))) {
         const int cslot_c = base / G;  // this lane's k-th candidate
         float* cache = (ccd_scratch && cslot_c < CCD_CACHE_SLOTS) ? ccd_scratch + (size_t)(ccd_cache0 + cslot_c * CCD_CACHE_WORDS) * CCD_LANES : nullptr;
@@ -1042,12 +1125,12 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
                            cache[(13 + 3 * k) * CCD_LANES] = pos.z;
                            nem = k + 1;
                          }
-                       });
+                       }, mv1, mn1, mv2, mn2);
         if (cache) reinterpret_cast<int*>(cache)[0] = nem;
       }
       else
         collide_pair<HEAVY>(t1, t2, ld3(gxpos + 3 * g1), gxmat + 9 * g1, ld3(gsize + 3 * g1), ld3(gxpos + 3 * g2), gxmat + 9 * g2,
-                            ld3(gsize + 3 * g2), margin, count);
+                            ld3(gsize + 3 * g2), margin, count, mv2, mn2);
     }
     const int nk = __popc(mask);
     int incl = nk;
@@ -1123,13 +1206,21 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
             write(k, dist, V3{cache[(11 + 3 * k) * CCD_LANES], cache[(12 + 3 * k) * CCD_LANES], cache[(13 + 3 * k) * CCD_LANES]}, V3{fr[0], fr[1], fr[2]},
                   V3{fr[3], fr[4], fr[5]}, V3{fr[6], fr[7], fr[8]});
         } else {
+          const float *mv1, *mv2;
+          int mn1, mn2;
+          mesh_of(g1, t1, mv1, mn1);
+          mesh_of(g2, t2, mv2, mn2);
           collide_convex(ccd_tol, ccd_it, epa_it, t1, t2, ld3(gxpos + 3 * g1), gxmat + 9 * g1, ld3(gsize + 3 * g1), ld3(gxpos + 3 * g2), gxmat + 9 * g2,
-                         ld3(gsize + 3 * g2), margin, pp.gap, ccd_scratch, ccd_overflow, write);
+                         ld3(gsize + 3 * g2), margin, pp.gap, ccd_scratch, ccd_overflow, write, mv1, mn1, mv2, mn2);
         }
       }
-      else
+      else {
+        const float* mv2;
+        int mn2;
+        mesh_of(g2, t2, mv2, mn2);
         collide_pair<HEAVY>(t1, t2, ld3(gxpos + 3 * g1), gxmat + 9 * g1, ld3(gsize + 3 * g1), ld3(gxpos + 3 * g2), gxmat + 9 * g2,
-                            ld3(gsize + 3 * g2), margin, write);
+                            ld3(gsize + 3 * g2), margin, write, mv2, mn2);
+      }
     }
     gsync();
     pc.mark(4);

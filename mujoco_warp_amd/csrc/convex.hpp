@@ -44,6 +44,9 @@ struct CcdGeom {
   const float* rot;  // 3x3 row-major
   V3 size;
   float margin;
+  const float* vert;  // mesh: vertices in the geom frame (Model.mesh_vert)
+  int nvert;
+  int index;  // mesh: vertex of the last support call (warm start: wins ties), -1 at the start (reference Geom.index)
 };
 struct GjkOut {
   bool separated;
@@ -71,6 +74,20 @@ DEV V3 ccd_support(const CcdGeom& g, V3 dir, int& vid) {
   } else if (g.type == G_ELLIPSOID) {
     r = normalize(V3{l.x * g.size.x, l.y * g.size.y, l.z * g.size.z});
     r = V3{r.x * g.size.x, r.y * g.size.y, r.z * g.size.z};
+  } else if (g.type == G_MESH) {  // collision_gjk.py:154-169: exhaustive vertex search, the cached vertex first
+    float best = -CCD_FLOAT_MAX;
+    if (g.index > -1) {
+      vid = g.index;
+      best = dot(ld3(g.vert + 3 * vid), l);
+    }
+    for (int i = 0; i < g.nvert; ++i) {
+      const float dd = dot(ld3(g.vert + 3 * i), l);
+      if (dd > best) {
+        best = dd;
+        vid = i;
+      }
+    }
+    r = ld3(g.vert + 3 * vid);
   } else if (g.type == G_CYLINDER) {
     const float dd = sqrtf(l.x * l.x + l.y * l.y);
     if (dd > CCD_MINVAL) {
@@ -254,6 +271,8 @@ DEV void ccd_gjk(float tolerance, int iterations, const CcdGeom& g1, const CcdGe
     }
     int v1, v2;
     const V3 p1 = ccd_support(g1, -dneg, v1), p2 = ccd_support(g2, dneg, v2);
+    const_cast<CcdGeom&>(g1).index = v1;  // collision_gjk.py:675-680 (only meshes read it)
+    const_cast<CcdGeom&>(g2).index = v2;
     const V3 sn = p1 - p2;
     // slot n of the simplex (static indexing: the arrays stay in registers)
 #pragma unroll
@@ -548,6 +567,8 @@ DEV int ccd_epa(float tolerance, int iterations, Poly& pt, const CcdGeom& g1, co
     const int wi = pt.nvert;
     const V3 fpr = pt.fpr(idx);
     poly_support(pt, wi, g1, g2, fpr * (1.0f / lower));
+    const_cast<CcdGeom&>(g1).index = pt.vidx(2 * wi);  // collision_gjk.py:1370-1373
+    const_cast<CcdGeom&>(g2).index = pt.vidx(2 * wi + 1);
     const V3 w = pt.diff(wi);
     pt.nvert++;
     const float upper_k = dot(fpr, w) / lower;
@@ -616,7 +637,7 @@ DEV int ccd_run(float tolerance, float cutoff, int gjk_iterations, int epa_itera
   const CcdGeom o1 = g1, o2 = g2;
   face_out = -1;
   float full1 = 0.0f, full2 = 0.0f, size1 = 0.0f, size2 = 0.0f;
-  const bool is_discrete = g1.type == G_BOX && g2.type == G_BOX && g1.margin == 0.0f && g2.margin == 0.0f;
+  const bool is_discrete = (g1.type == G_BOX || g1.type == G_MESH) && (g2.type == G_BOX || g2.type == G_MESH) && g1.margin == 0.0f && g2.margin == 0.0f;  // collision_gjk.py:109
   GjkOut res;
   if (g1.type == G_SPHERE || g1.type == G_CAPSULE) {
     size1 = g1.size.x;
@@ -644,8 +665,10 @@ DEV int ccd_run(float tolerance, float cutoff, int gjk_iterations, int epa_itera
       dist_out = res.dist - (full1 + full2);
       return 1;
     }
-    g1 = o1;
-    g2 = o2;
+    g1.margin = o1.margin;  /* (the cached mesh vertex of the first run stays: collision_gjk.py:2403-2406 restores margin and size only) */
+    g1.size = o1.size;
+    g2.margin = o2.margin;
+    g2.size = o2.size;
     cutoff -= full1 + full2;
   }
   ccd_gjk(tolerance, gjk_iterations, g1, g2, g1.pos, g2.pos, cutoff, is_discrete, res);
@@ -966,6 +989,7 @@ DEV int ccd_multicontact_box(const Poly& pt, int epa_face, V3 x1, V3 x2, const C
 }
 
 DEV bool is_convex_pair(int t1, int t2) {
+  if (t2 == G_MESH && t1 >= G_SPHERE) return true;  // every mesh pair except plane-mesh (primitive) goes through GJK / EPA
   return (t1 == G_SPHERE && t2 == G_ELLIPSOID) || (t1 == G_CAPSULE && (t2 == G_ELLIPSOID || t2 == G_CYLINDER)) ||
          (t1 == G_ELLIPSOID && (t2 == G_ELLIPSOID || t2 == G_CYLINDER || t2 == G_BOX)) || (t1 == G_CYLINDER && (t2 == G_CYLINDER || t2 == G_BOX));
 }

@@ -89,7 +89,8 @@ def geom_pairs_with_ids(mjm):
 _SUPPORTED_PAIRS = {(0, 2), (0, 3), (0, 4), (0, 5), (0, 6), (2, 2), (2, 3), (2, 5), (2, 6), (3, 3), (3, 6), (6, 6)}
 # pairs of the reference's CONVEX class (collision_driver.py:47-80) that go through GJK / EPA (csrc/convex.hpp); box-box joins them
 # unless DisableBit.NATIVECCD is set (collision_driver.py:867-870), see put_model
-_CONVEX_PAIRS = {(2, 4), (3, 4), (3, 5), (4, 4), (4, 5), (4, 6), (5, 5), (5, 6)}
+_CONVEX_PAIRS = {(2, 4), (3, 4), (3, 5), (4, 4), (4, 5), (4, 6), (5, 5), (5, 6), (2, 7), (3, 7), (4, 7), (5, 7), (6, 7), (7, 7)}
+_PLANE_MESH = (0, 7)  # primitive collider plane_convex (collision_primitive.py:52), heavy instantiation
 
 
 def _pair_index(ngeom, pairs):
@@ -172,8 +173,22 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
   gt = np.asarray(mjm.geom_type)
   for a, b in pairs:
     t = (int(min(gt[a], gt[b])), int(max(gt[a], gt[b])))
-    if t not in _SUPPORTED_PAIRS and t not in _CONVEX_PAIRS:
+    if t not in _SUPPORTED_PAIRS and t not in _CONVEX_PAIRS and t != _PLANE_MESH:
       raise NotImplementedError(f"collision between geom types {t} is not implemented yet")
+    if 7 in t:  # convex meshes: exhaustive vertex search, single contact
+      for g in (a, b):
+        if int(gt[g]) != 7:
+          continue
+        mid = int(np.asarray(getattr(mjm, "geom_dataid", np.full(len(gt), -1)))[g])
+        if mid < 0 or not hasattr(mjm, "mesh_vert"):
+          raise NotImplementedError("colliding mesh geom without mesh vertices (Model.mesh_vert / geom_dataid)")
+        gadr = np.asarray(getattr(mjm, "mesh_graphadr", np.full(mid + 1, -1)))
+        if int(gadr[mid]) >= 0 and int(np.asarray(mjm.mesh_vertnum)[mid]) >= 10:
+          raise NotImplementedError("meshes with a hill-climbing graph and 10 or more vertices (collision_gjk.py:170-196, collision_primitive.py:131-243) "
+                                    "are not implemented: only the exhaustive vertex search is")
+      if t in ((6, 7), (7, 7)) and not (int(opt.disableflags) & int(types.DisableBit.MULTICCD)):
+        raise NotImplementedError("multi-contact recovery for box-mesh / mesh-mesh pairs (collision_gjk.py:2076 multicontact, mesh branches) is not "
+                                  "implemented: set <flag multiccd=\"disable\"/> (one contact per pair, as the reference then computes)")
   condims = set(int(c) for c in np.unique(np.asarray(mjm.geom_condim)[np.unique(pairs)])) if len(pairs) else set()
   nexplicit = int(getattr(mjm, "npair", 0))
   if nexplicit:
@@ -205,7 +220,7 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
   m._convex_pairs = int(nconvex + nboxbox > 0)
   # EPA iteration cap (reference collision_convex.py:1223): 16 when every convex pair of the model is box-box
   m._epa_iterations = 16 if (nboxbox > 0 and nconvex == 0) else int(getattr(opt, "ccd_iterations", 35))
-  m._heavy_pairs = int(any((int(min(gt[a], gt[b])), int(max(gt[a], gt[b]))) in ((3, 6), (6, 6)) for a, b in pairs) or int(getattr(mjm, "npair", 0)) > 0
+  m._heavy_pairs = int(any((int(min(gt[a], gt[b])), int(max(gt[a], gt[b]))) in ((3, 6), (6, 6), (0, 7)) for a, b in pairs) or int(getattr(mjm, "npair", 0)) > 0
                        or m._convex_pairs)
   m.heavy_colliders = m._heavy_pairs  # c_model() adds the broadphase options (they may be changed after put_model)
   m.is_sparse = False
@@ -331,7 +346,9 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
     dof_leveladr=dleveladr, tree_dofadr=tree_dofadr, tree_dofnum=tree_dofnum, dof_treeid=dof_treeid, body_treeid=body_treeid,
     M_rownnz=_arr(mjm.M_rownnz, i32), M_rowadr=_arr(mjm.M_rowadr, i32), M_colind=_arr(mjm.M_colind, i32),
     geom_type=_arr(mjm.geom_type, i32), geom_condim=_arr(mjm.geom_condim, i32), geom_bodyid=_arr(mjm.geom_bodyid, i32),
-    geom_priority=_arr(mjm.geom_priority, i32), nxn_geom_pair=pairs, nxn_pairid=pairid, nxn_pairindex=_pair_index(ngeom, pairs),
+    geom_priority=_arr(mjm.geom_priority, i32), geom_dataid=_arr(getattr(mjm, "geom_dataid", np.full(ngeom, -1)), i32),
+    mesh_vertadr=_arr(getattr(mjm, "mesh_vertadr", np.zeros(0)), i32), mesh_vertnum=_arr(getattr(mjm, "mesh_vertnum", np.zeros(0)), i32),
+    mesh_vert=_arr(getattr(mjm, "mesh_vert", np.zeros((0, 3))), f32).reshape(-1, 3), nxn_geom_pair=pairs, nxn_pairid=pairid, nxn_pairindex=_pair_index(ngeom, pairs),
     pair_dim=_arr(getattr(mjm, "pair_dim", np.zeros(0)), i32), pair_friction=_arr(getattr(mjm, "pair_friction", np.zeros((0, 5))), f32).reshape(-1, 5),
     pair_solref=_arr(getattr(mjm, "pair_solref", np.zeros((0, 2))), f32).reshape(-1, 2),
     pair_solreffriction=_arr(getattr(mjm, "pair_solreffriction", np.zeros((0, 2))), f32).reshape(-1, 2),
@@ -344,6 +361,8 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
     actuator_forcelimited=_arr(mjm.actuator_forcelimited, i32), actuator_actlimited=_arr(mjm.actuator_actlimited, i32),
     eq_obj1id=_arr(getattr(mjm, "eq_obj1id", np.zeros(0)), i32), eq_obj2id=_arr(getattr(mjm, "eq_obj2id", np.zeros(0)), i32),
   )
+  m.nmeshvert = int(host["mesh_vert"].shape[0])
+  m.nmesh = int(host["mesh_vertadr"].shape[0])
   m.sleep_enabled = int(bool(int(opt.enableflags) & int(types.EnableBit.SLEEP)) and not (int(opt.disableflags) & int(types.DisableBit.ISLAND)))
   m.opt_sleep_tolerance = float(getattr(opt, "sleep_tolerance", 1e-4))
   host["tree_sleep_policy"] = _arr(getattr(mjm, "tree_sleep_policy", np.full(m.ntree, int(types.SleepPolicy.AUTO_ALLOWED))), i32)

@@ -552,6 +552,45 @@ def _geom_rbound_aabb(gtype, size):
   return 0.0, np.zeros(3)
 
 
+def _compile_mesh(verts):
+  """Convex collision asset from inline vertices (MJCF <mesh vertex="...">), following what MuJoCo's compiler does with a mesh:
+  convex hull, volume / centre of mass / inertia of the hull (uniform density), vertices re-expressed in the frame centred at the
+  centre of mass and aligned with the principal axes (the geom frame is composed with that offset).  UNPINNED like the rest of this
+  loader (MuJoCo's compiler is not in the reference tree); the axis order / signs of the principal frame are this module's own
+  (descending moments, right handed): the physics does not depend on them.  No hill-climbing graph is built (mesh_graphadr = -1:
+  the engine then searches vertices exhaustively, the reference's path for such meshes, collision_gjk.py:156)."""
+  from scipy.spatial import ConvexHull
+
+  verts = np.asarray(verts, dtype=np.float64).reshape(-1, 3)
+  if len(verts) < 4:
+    raise ValueError("a mesh needs at least 4 vertices")
+  hull = ConvexHull(verts)
+  vol, com, second = 0.0, np.zeros(3), np.zeros((3, 3))
+  centre = verts[hull.vertices].mean(axis=0)
+  canon = np.array([[2, 1, 1], [1, 2, 1], [1, 1, 2]]) / 120.0  # integral of x x^T over the unit tetrahedron
+  for tri, eq in zip(hull.simplices, hull.equations):
+    a, b, c = verts[tri] - centre
+    if np.dot(np.cross(b - a, c - a), eq[:3]) < 0:
+      b, c = c, b
+    A = np.stack([a, b, c], axis=1)
+    det = np.linalg.det(A)  # 6 x signed volume of the tetrahedron (centre, a, b, c)
+    vol += det / 6.0
+    com += det / 24.0 * (a + b + c)
+    second += det * (A @ canon @ A.T)
+  com /= vol
+  second -= vol * np.outer(com, com)  # second moment about the centre of mass
+  inertia = np.trace(second) * np.eye(3) - second
+  w, v = np.linalg.eigh(inertia)
+  order = np.argsort(-w)
+  w, v = w[order], v[:, order]
+  if np.linalg.det(v) < 0:
+    v[:, 2] = -v[:, 2]
+  local = (verts - centre - com) @ v
+  lo, hi = local.min(axis=0), local.max(axis=0)
+  return dict(vert=local, pos=centre + com, quat=nm.mat_to_quat(v), vol=vol, unit=w / vol, aabb=np.concatenate([(lo + hi) / 2, (hi - lo) / 2]),
+              rbound=float(np.max(np.linalg.norm(local, axis=1))))
+
+
 class _Body:
   pass
 
@@ -590,6 +629,15 @@ def _compile(root, base_dir):
     table["main"] = _Defaults("main")
 
   deg = compiler["angle"] == "degree"
+  mesh_assets = {}  # name -> <mesh> element (compiled on first use by a colliding geom)
+  for asset in root.findall("asset"):
+    for me in asset.findall("mesh"):
+      base, explicit = _resolve("mesh", me, table, None)
+      a = dict(base)
+      a.update(explicit)
+      name = a.get("name") or os.path.splitext(os.path.basename(a.get("file", "")))[0]
+      mesh_assets[name] = a
+  mesh_compiled = {}
 
   bodies, joints, geoms, sites = [], [], [], []
   world = _Body()
@@ -640,8 +688,21 @@ def _compile(root, base_dir):
     g["size"], g["pos"], g["quat"], g["body"] = size, pos, quat, bodyid
     if g["type"] in (GEOM_HFIELD, GEOM_SDF):
       raise NotImplementedError("hfield/sdf geoms")
+    g["meshdata"] = None
     if g["type"] == GEOM_MESH and (g["contype"] or g["conaffinity"]):
-      raise NotImplementedError("colliding mesh geoms need the convex asset pipeline (SURVEY §8f row 4)")
+      asset = mesh_assets.get(g["mesh"])
+      if asset is None:
+        raise ValueError(f"geom refers to unknown mesh {g['mesh']!r}")
+      if "vertex" not in asset:
+        raise NotImplementedError("colliding mesh geoms need inline vertices (<mesh vertex=...>): mesh files are not in this tree")
+      if g["mesh"] not in mesh_compiled:
+        v = np.array(_floats(asset["vertex"])).reshape(-1, 3) * _vec(asset, "scale", [1, 1, 1])
+        mesh_compiled[g["mesh"]] = _compile_mesh(v)
+      md = mesh_compiled[g["mesh"]]
+      g["meshdata"] = md
+      g["pos"] = pos + nm.rot_vec_quat(md["pos"], quat)  # the geom frame is the mesh's inertial frame (MuJoCo's convention)
+      g["quat"] = nm.quat_mul(quat, md["quat"])
+      g["size"] = md["aabb"][3:].copy()
     return g
 
   def parse_joint(elem, childclass, bodyid, free=False):
@@ -908,6 +969,17 @@ def _compile(root, base_dir):
   m.geom_condim = np.array([g["condim"] for g in gl], dtype=np.int32)
   m.geom_bodyid = np.array([g["body"] for g in gl], dtype=np.int32)
   m.geom_dataid = np.full(ng, -1, dtype=np.int32)
+  mesh_names = [n for n in mesh_compiled]
+  m.nmesh = len(mesh_names)
+  m.mesh_vertnum = np.array([len(mesh_compiled[n]["vert"]) for n in mesh_names], dtype=np.int32)
+  m.mesh_vertadr = np.concatenate([[0], np.cumsum(m.mesh_vertnum)[:-1]]).astype(np.int32) if mesh_names else np.zeros(0, dtype=np.int32)
+  m.mesh_vert = np.concatenate([mesh_compiled[n]["vert"] for n in mesh_names]).reshape(-1, 3) if mesh_names else np.zeros((0, 3))
+  m.nmeshvert = len(m.mesh_vert)
+  m.mesh_graphadr = np.full(m.nmesh, -1, dtype=np.int32)
+  m.mesh_graph = np.zeros(0, dtype=np.int32)
+  for i, g in enumerate(gl):
+    if g["meshdata"] is not None:
+      m.geom_dataid[i] = mesh_names.index(g["mesh"])
   m.geom_group = np.array([g["group"] for g in gl], dtype=np.int32)
   m.geom_priority = np.array([g["priority"] for g in gl], dtype=np.int32)
   m.geom_solmix = np.array([g["solmix"] for g in gl], dtype=np.float64)
@@ -924,6 +996,9 @@ def _compile(root, base_dir):
   m.geom_aabb = np.zeros((ng, 6))
   for i, r in enumerate(rb):
     m.geom_aabb[i, 3:] = r[1]
+    if gl[i]["meshdata"] is not None:
+      m.geom_rbound[i] = gl[i]["meshdata"]["rbound"]
+      m.geom_aabb[i] = gl[i]["meshdata"]["aabb"]
 
   # sites
   m.nsite = len(sites)
@@ -950,8 +1025,10 @@ def _compile(root, base_dir):
     parts = []
     for g in b.geoms:
       vol, unit = _geom_volume_inertia(g["type"], g["size"])
+      if g["meshdata"] is not None:
+        vol, unit = g["meshdata"]["vol"], g["meshdata"]["unit"]
       mass = g["mass"] if g["mass"] is not None else g["density"] * vol
-      if g["type"] in (GEOM_PLANE, GEOM_MESH):
+      if g["type"] == GEOM_PLANE or (g["type"] == GEOM_MESH and g["meshdata"] is None):
         mass = 0.0
       if mass <= 0:
         continue

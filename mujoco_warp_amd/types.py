@@ -406,6 +406,11 @@ class Model(_Dirty):
   sleep_enabled: int = 0  # EnableBit.SLEEP set and DisableBit.ISLAND clear (reference forward.py:345)
   opt_sleep_tolerance: float = 0.0  # Option.sleep_tolerance (one value per model)
   tree_sleep_policy: DeviceArray = _arr(('ntree',), "int32")
+  geom_dataid: DeviceArray = _arr(('ngeom',), "int32")
+  mesh_vertadr: DeviceArray = _arr(('nmesh',), "int32")
+  mesh_vertnum: DeviceArray = _arr(('nmesh',), "int32")
+  mesh_vert: DeviceArray = _arr(('nmeshvert', 3), "float32")
+  nmeshvert: int = 0
   dof_length: DeviceArray = _arr(('nv',), "float32")
   ntree: int = 0  # kinematic trees with at least one dof
   tree_nvmax: int = 0  # dofs of the largest tree

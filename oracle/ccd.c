@@ -1,7 +1,8 @@
 /* oracle/ccd.c -- TEST INFRASTRUCTURE ONLY (textually included by mjref.c; never linked into the product).
  *
  * float64 restatement of the reference's general convex collision detection for the primitive convex shapes
- * (sphere, capsule, ellipsoid, cylinder, box; meshes and height fields are out of scope):
+ * (sphere, capsule, ellipsoid, cylinder, box) and convex meshes (exhaustive vertex search: the reference's path for meshes without a
+ * hill-climbing graph or with fewer than 10 vertices, collision_gjk.py:154-169; height fields are out of scope):
  *   collision_gjk.py  support 116-223 | sub-distance (signed volumes) 281-593 | gjk 635-770 | polytope seeds 1021-1286 |
  *                     EPA 1319-1454 | witness points 947-1018 | gjk_phase / epa_phase / ccd 2303-2575
  *   collision_convex.py eval_ccd_write_contact 747-977 (margins, cutoff, frame, midpoint)
@@ -24,6 +25,9 @@
 typedef struct CcdGeom {
   int type;
   double pos[3], rot[9], size[3], margin;
+  const double* vert; /* mesh: vertices in the geom frame */
+  int nvert;
+  int index;          /* mesh: vertex of the last support call (warm start: wins ties), -1 at the start (Geom.index) */
 } CcdGeom;
 
 typedef struct GjkOut {
@@ -58,6 +62,17 @@ static int ccd_support(const CcdGeom* g, const double* dir, double* out) {
     for (int k = 0; k < 3; k++) r[k] = l[k] * g->size[k];
     v3normalize(r);
     for (int k = 0; k < 3; k++) r[k] *= g->size[k];
+  } else if (g->type == G_MESH) { /* 154-169: exhaustive search, the cached vertex first */
+    double best = -CCD_FLOAT_MAX;
+    if (g->index > -1) {
+      vid = g->index;
+      best = v3dot(g->vert + 3 * vid, l);
+    }
+    for (int i = 0; i < g->nvert; i++) {
+      double dd = v3dot(g->vert + 3 * i, l);
+      if (dd > best) { best = dd; vid = i; }
+    }
+    v3cpy(r, g->vert + 3 * vid);
   } else if (g->type == G_CYLINDER) {
     double d = sqrt(l[0] * l[0] + l[1] * l[1]);
     if (d > CCD_MINVAL) {
@@ -244,6 +259,8 @@ static void ccd_gjk(double tolerance, int iterations, const CcdGeom* g1, const C
     for (int k = 0; k < 3; k++) dpos[k] = -dneg[k];
     res->i1[n] = ccd_support(g1, dpos, res->s1[n]);
     res->i2[n] = ccd_support(g2, dneg, res->s2[n]);
+    ((CcdGeom*)g1)->index = res->i1[n]; /* 675-680 (only meshes read it) */
+    ((CcdGeom*)g2)->index = res->i2[n];
     v3sub(res->s[n], res->s1[n], res->s2[n]);
     double gap[3];
     v3sub(gap, xk, res->s[n]);
@@ -512,6 +529,8 @@ static int ccd_epa(double tolerance, int iterations, Polytope* pt, const CcdGeom
     int wi = pt->nvert;
     for (int k = 0; k < 3; k++) dir[k] = pt->fpr[idx][k] / lower;
     pt_support(pt, wi, g1, g2, dir);
+    ((CcdGeom*)g1)->index = pt->vidx[2 * wi]; /* 1370-1373 */
+    ((CcdGeom*)g2)->index = pt->vidx[2 * wi + 1];
     pt_diff(pt, wi, w);
     pt->nvert++;
     double upper_k = v3dot(pt->fpr[idx], w) / lower;
@@ -568,7 +587,7 @@ static int ccd_epa(double tolerance, int iterations, Polytope* pt, const CcdGeom
   return idx;
 }
 
-static int ccd_discrete(int t1, int t2) { return t1 == G_BOX && t2 == G_BOX; } /* (meshes / hfields: out of scope) */
+static int ccd_discrete(int t1, int t2) { return (t1 == G_BOX || t1 == G_MESH) && (t2 == G_BOX || t2 == G_MESH); } /* 109 (hfields: out of scope) */
 
 /* ccd = gjk_phase + epa_phase (collision_gjk.py:2350-2575).  Returns the number of contacts (0 / 1); *face_out = closest EPA
  * face when the pair qualifies for multi-contact recovery (boxes, zero margin), else -1; pt_out receives the final polytope */
@@ -598,8 +617,9 @@ static int ccd_run(double tolerance, double cutoff, int gjk_iterations, int epa_
       *dist_out = res.dist - (full1 + full2);
       return 1;
     }
-    g1 = o1;
-    g2 = o2;
+    g1.margin = o1.margin; /* (the cached mesh vertex of the first run stays: collision_gjk.py:2403-2406 restores margin and size only) */
+    g2.margin = o2.margin;
+    for (int k = 0; k < 3; k++) { g1.size[k] = o1.size[k]; g2.size[k] = o2.size[k]; }
     cutoff -= full1 + full2;
   }
   ccd_gjk(tolerance, gjk_iterations, &g1, &g2, g1.pos, g2.pos, cutoff, is_discrete, &res);

@@ -1064,10 +1064,22 @@ static int box_box(const double* p1, const double* R1, const double* s1, const d
 
 /* contact of a convex pair through GJK / EPA (collision_convex.py:747-977 eval_ccd_write_contact): both geoms carry the pair's
  * margin (support points are inflated by half of it), the GJK cutoff is the gap, and the distance is reported un-inflated */
-static int ccd_contact(const RefModel* m, int t1, const double* p1, const double* R1, const double* s1, int t2, const double* p2,
+static void mesh_of(const RefModel* m, int g, const double** vert, int* nvert) {
+  *vert = NULL;
+  *nvert = 0;
+  if (g >= 0 && m->geom_type[g] == G_MESH) {
+    int id = m->geom_dataid[g];
+    *vert = m->mesh_vert + 3 * m->mesh_vertadr[id];
+    *nvert = m->mesh_vertnum[id];
+  }
+}
+static int ccd_contact(const RefModel* m, int g1, int g2, int t1, const double* p1, const double* R1, const double* s1, int t2, const double* p2,
                        const double* R2, const double* s2, double margin, double gap, Con* out, int* overflow) {
   CcdGeom a, b;
   a.type = t1; b.type = t2;
+  mesh_of(m, g1, &a.vert, &a.nvert);
+  mesh_of(m, g2, &b.vert, &b.nvert);
+  a.index = b.index = -1;
   v3cpy(a.pos, p1); v3cpy(b.pos, p2);
   memcpy(a.rot, R1, sizeof(a.rot)); memcpy(b.rot, R2, sizeof(b.rot));
   v3cpy(a.size, s1); v3cpy(b.size, s2);
@@ -1094,7 +1106,8 @@ static int ccd_contact(const RefModel* m, int t1, const double* p1, const double
   }
   return n;
 }
-static int is_convex_pair(int t1, int t2) { /* MJ_COLLISION_TABLE collision_driver.py:47-80, primitive shapes only (box-box: below) */
+static int is_convex_pair(int t1, int t2) { /* MJ_COLLISION_TABLE collision_driver.py:47-80 (box-box: below; plane-mesh is primitive) */
+  if (t2 == G_MESH && t1 >= G_SPHERE) return 1;
   return (t1 == G_SPHERE && t2 == G_ELLIPSOID) || (t1 == G_CAPSULE && (t2 == G_ELLIPSOID || t2 == G_CYLINDER)) ||
          (t1 == G_ELLIPSOID && (t2 == G_ELLIPSOID || t2 == G_CYLINDER || t2 == G_BOX)) || (t1 == G_CYLINDER && (t2 == G_CYLINDER || t2 == G_BOX));
 }
@@ -1108,7 +1121,70 @@ static int collide_pair(const RefModel* m, RefData* d, int g1, int g2, double ma
   int n = 0;
   /* box-box is a convex pair unless DisableBit.NATIVECCD asks for the primitive collider (collision_driver.py:867-870) */
   if (is_convex_pair(t1, t2) || (t1 == G_BOX && t2 == G_BOX && !(m->disableflags & DSBL_NATIVECCD)))
-    return ccd_contact(m, t1, p1, R1, s1, t2, p2, R2, s2, margin, gap, out, &d->overflow);
+    return ccd_contact(m, g1, g2, t1, p1, R1, s1, t2, p2, R2, s2, margin, gap, out, &d->overflow);
+  if (t1 == G_PLANE && t2 == G_MESH) { /* collision_primitive.py:52-274 plane_convex, exhaustive branch (no graph or < 10 vertices) */
+    const double* vert;
+    int nvert, idx[4] = {-1, -1, -1, -1};
+    mesh_of(m, g2, &vert, &nvert);
+    const double HUGE_V = 1e6;
+    double pl[3], nl[3], dif[3];
+    v3sub(dif, p1, p2);
+    matT_mul_vec(pl, R2, dif);
+    matT_mul_vec(nl, R2, ax1);
+    double max_support = -HUGE_V, a[3] = {0, 0, 0}, b[3] = {0, 0, 0}, c[3] = {0, 0, 0}, t[3];
+    for (int i = 0; i < nvert; i++) {
+      v3sub(t, pl, vert + 3 * i);
+      double sup = v3dot(t, nl);
+      if (sup > max_support) { max_support = sup; idx[0] = i; v3cpy(a, vert + 3 * i); }
+    }
+    if (max_support < 0) return 0;
+    double threshold = max_support - 1e-3, best = -HUGE_V;
+    for (int i = 0; i < nvert; i++) { /* b: furthest from a among the vertices within 1 mm of the deepest */
+      v3sub(t, pl, vert + 3 * i);
+      double mask = v3dot(t, nl) > threshold ? 0.0 : -HUGE_V;
+      v3sub(t, a, vert + 3 * i);
+      double dd = v3dot(t, t) + mask;
+      if (dd > best) { idx[1] = i; best = dd; v3cpy(b, vert + 3 * i); }
+    }
+    double ab[3], ac[3], bc[3];
+    v3sub(t, a, b);
+    v3cross(ab, nl, t);
+    best = -HUGE_V;
+    for (int i = 0; i < nvert; i++) { /* c: furthest from the line a-b */
+      v3sub(t, pl, vert + 3 * i);
+      double mask = v3dot(t, nl) > threshold ? 0.0 : -HUGE_V;
+      v3sub(t, a, vert + 3 * i);
+      double dd = fabs(v3dot(t, ab)) + mask;
+      if (dd > best) { idx[2] = i; best = dd; v3cpy(c, vert + 3 * i); }
+    }
+    v3sub(t, a, c);
+    v3cross(ac, nl, t);
+    v3sub(t, b, c);
+    v3cross(bc, nl, t);
+    best = -HUGE_V;
+    for (int i = 0; i < nvert; i++) { /* d: furthest from the other two edges */
+      v3sub(t, pl, vert + 3 * i);
+      double mask = v3dot(t, nl) > threshold ? 0.0 : -HUGE_V, ap[3], bp[3];
+      v3sub(ap, a, vert + 3 * i);
+      v3sub(bp, b, vert + 3 * i);
+      double dd = fabs(v3dot(ap, ac)) + mask + fabs(v3dot(bp, bc)) + mask;
+      if (dd > best) { idx[3] = i; best = dd; }
+    }
+    for (int i = 3; i >= 0; i--) { /* vertices that appear once among indices[0..i] */
+      int count = 0;
+      for (int j = 0; j <= i; j++) count += idx[j] == idx[i];
+      if (count != 1) continue;
+      double pw[3];
+      mat_mul_vec(pw, R2, vert + 3 * idx[i]);
+      v3sub(t, pl, vert + 3 * idx[i]);
+      double dist = -v3dot(t, nl);
+      for (int k = 0; k < 3; k++) out[n].pos[k] = p2[k] + pw[k] - 0.5 * dist * ax1[k];
+      out[n].dist = dist;
+      make_frame(out[n].frame, ax1);
+      n++;
+    }
+    return n;
+  }
   if (t1 == G_PLANE && t2 == G_SPHERE) { /* collision_primitive.py:281 */
     plane_sphere(ax1, p1, p2, s2[0], &out[0].dist, out[0].pos);
     make_frame(out[0].frame, ax1);
@@ -1500,14 +1576,24 @@ void ref_collision(const RefModel* m, RefData* d) {
   free(mark);
 }
 
+int ref_ccd_mesh(int type1, const double* pos1, const double* mat1, const double* size1, const double* vert1, int nvert1, int type2,
+                 const double* pos2, const double* mat2, const double* size2, const double* vert2, int nvert2, double margin, double tolerance,
+                 double cutoff, int iterations, int multiccd, double* out, double* wit);
 int ref_ccd(int type1, const double* pos1, const double* mat1, const double* size1, int type2, const double* pos2, const double* mat2,
             const double* size2, double margin, double tolerance, double cutoff, int iterations, int multiccd, double* out, double* wit) {
+  return ref_ccd_mesh(type1, pos1, mat1, size1, NULL, 0, type2, pos2, mat2, size2, NULL, 0, margin, tolerance, cutoff, iterations, multiccd, out, wit);
+}
+int ref_ccd_mesh(int type1, const double* pos1, const double* mat1, const double* size1, const double* vert1, int nvert1, int type2,
+                 const double* pos2, const double* mat2, const double* size2, const double* vert2, int nvert2, double margin, double tolerance,
+                 double cutoff, int iterations, int multiccd, double* out, double* wit) {
   CcdGeom a, b;
   a.type = type1; b.type = type2;
   v3cpy(a.pos, pos1); v3cpy(b.pos, pos2);
   memcpy(a.rot, mat1, sizeof(a.rot)); memcpy(b.rot, mat2, sizeof(b.rot));
   v3cpy(a.size, size1); v3cpy(b.size, size2);
   a.margin = b.margin = margin;
+  a.vert = vert1; a.nvert = nvert1; b.vert = vert2; b.nvert = nvert2;
+  a.index = b.index = -1;
   static Polytope pt;
   int face, overflow = 0;
   int n = ccd_run(tolerance, cutoff, iterations, iterations, a, b, out, out + 1, out + 4, &overflow, &face, &pt);

@@ -139,6 +139,10 @@ typedef struct RefModel {
   double* eq_solref;
   double* eq_solimp;
   double* eq_data;
+  int* geom_dataid;   /* [ngeom] mesh id of mesh geoms, -1 otherwise */
+  int* mesh_vertadr;
+  int* mesh_vertnum;
+  double* mesh_vert;  /* [nmeshvert, 3] vertices in the mesh (= geom) frame */
   int* body_treeid;
   int* dof_treeid;
   int* tree_dofadr;
@@ -274,6 +278,9 @@ int ref_upper_trid_index(int n, int i, int j); /* math.py:329 */
  * returns the number of contacts (box pairs: after multi-contact recovery when multiccd != 0, witness pairs in wit[8][3]) */
 int ref_ccd(int type1, const double* pos1, const double* mat1, const double* size1, int type2, const double* pos2, const double* mat2,
             const double* size2, double margin, double tolerance, double cutoff, int iterations, int multiccd, double* out, double* wit);
+int ref_ccd_mesh(int type1, const double* pos1, const double* mat1, const double* size1, const double* vert1, int nvert1, int type2,
+                 const double* pos2, const double* mat2, const double* size2, const double* vert2, int nvert2, double margin, double tolerance,
+                 double cutoff, int iterations, int multiccd, double* out, double* wit); /* ref_ccd with mesh vertices (geom frame) */
 int ref_rollout(const RefModel* m, RefData* d, int nstep, int worldid, double noise_std, double noise_rate, double* qpos_out, double* qvel_out);
 
 #endif

@@ -84,7 +84,7 @@ def lib():
   return _lib
 
 
-def ccd(type1, pos1, mat1, size1, type2, pos2, mat2, size2, margin=0.0, tolerance=1e-6, cutoff=1e30, iterations=35, multiccd=False):
+def ccd(type1, pos1, mat1, size1, type2, pos2, mat2, size2, margin=0.0, tolerance=1e-6, cutoff=1e30, iterations=35, multiccd=False, vert1=None, vert2=None):
   """GJK / EPA on two posed primitive convex geoms (reference collision_gjk.py:2529 `ccd`, called like its test harness
   collision_gjk_test.py:36-300).  Returns (dist, ncon, x1, x2, witness pairs [ncon, 2, 3])."""
   def arr(x, n):
@@ -94,14 +94,18 @@ def ccd(type1, pos1, mat1, size1, type2, pos2, mat2, size2, margin=0.0, toleranc
   p1, m1, s1, p2, m2, s2 = arr(pos1, 3), arr(mat1, 9), arr(size1, 3), arr(pos2, 3), arr(mat2, 9), arr(size2, 3)
   out, wit = np.zeros(9), np.zeros(48)
   dp = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
-  n = lib().ref_ccd(int(type1), dp(p1), dp(m1), dp(s1), int(type2), dp(p2), dp(m2), dp(s2), float(margin), float(tolerance), float(cutoff),
-                    int(iterations), int(bool(multiccd)), dp(out), dp(wit))
+  v1 = np.ascontiguousarray(np.asarray(vert1 if vert1 is not None else np.zeros((0, 3)), dtype=np.float64).reshape(-1, 3))  # mesh vertices, geom frame
+  v2 = np.ascontiguousarray(np.asarray(vert2 if vert2 is not None else np.zeros((0, 3)), dtype=np.float64).reshape(-1, 3))
+  fn = lib().ref_ccd_mesh
+  fn.restype = ctypes.c_int
+  n = fn(int(type1), dp(p1), dp(m1), dp(s1), dp(v1) if len(v1) else None, len(v1), int(type2), dp(p2), dp(m2), dp(s2), dp(v2) if len(v2) else None, len(v2),
+         ctypes.c_double(margin), ctypes.c_double(tolerance), ctypes.c_double(cutoff), int(iterations), int(bool(multiccd)), dp(out), dp(wit))
   return float(out[0]), n, out[1:4].copy(), out[4:7].copy(), wit.reshape(8, 2, 3)[: max(n, 0)].copy()
 
 
 def _epa_iterations(mjm, pairs):
   """EPA iteration cap (reference collision_convex.py:1209-1223): 16 when every convex-class pair of the model is box-box."""
-  convex = {(2, 4), (3, 4), (3, 5), (4, 4), (4, 5), (4, 6), (5, 5), (5, 6)}
+  convex = {(2, 4), (3, 4), (3, 5), (4, 4), (4, 5), (4, 6), (5, 5), (5, 6), (2, 7), (3, 7), (4, 7), (5, 7), (6, 7), (7, 7)}
   nativeccd_off = bool(int(mjm.opt.disableflags) & (1 << 17))
   gt = np.asarray(mjm.geom_type)
   nbb = nother = 0
@@ -202,6 +206,8 @@ class RefSim:
                "xpair_solimp": getattr(mjm, "pair_solimp", np.zeros(0)), "xpair_margin": getattr(mjm, "pair_margin", np.zeros(0)),
                "xpair_gap": getattr(mjm, "pair_gap", np.zeros(0)),
                "actuator_trnid": mjm.actuator_trnid, "M_colind": mjm.M_colind}
+    for name, dflt in (("geom_dataid", np.full(mjm.ngeom, -1)), ("mesh_vertadr", np.zeros(0)), ("mesh_vertnum", np.zeros(0)), ("mesh_vert", np.zeros((0, 3)))):
+      special[name] = np.asarray(getattr(mjm, name, dflt))
     for name, dt in (("tree_sleep_policy", np.int32), ("dof_length", np.float64)):  # (absent on models that predate sleeping)
       special[name] = np.asarray(getattr(mjm, name, np.full(sizes["ntree"], 2) if name == "tree_sleep_policy" else np.ones(mjm.nv)), dtype=dt)
     for name, kind, ptr in _MODEL_FIELDS:
