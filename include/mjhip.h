@@ -142,6 +142,15 @@ typedef struct MjhModel {
   const int* geom_dataid;       /* [ngeom] mesh id of mesh geoms, -1 otherwise (types.py:1266)                  */
   const int* mesh_vertadr; const int* mesh_vertnum; /* [nmesh] first vertex / number of vertices (types.py:1707-1709) */
   const float* mesh_vert;       /* [nmeshvert, 3] vertices in the mesh (= geom) frame; searched exhaustively by the convex narrowphase */
+  /* mesh polygon tables for the multi-contact recovery on mesh faces (types.py:1710-1733; csrc/convex.hpp ccd_multicontact_mesh) */
+  int nmeshpoly;                /* polygons of all meshes; 0: no tables (mesh pairs then keep EPA's single contact)           */
+  int npolygonmax;              /* the clip buffers hold 2 * npolygonmax points (collision_convex.py:1226-1234)               */
+  const int* mesh_polyadr;      /* [nmesh] first polygon                                                                     */
+  const float* mesh_polynormal; /* [nmeshpoly, 3] outward normals, mesh frame                                                */
+  const int* mesh_polyvertadr; const int* mesh_polyvertnum; /* [nmeshpoly] into mesh_polyvert                                */
+  const int* mesh_polyvert;     /* mesh-local vertex ids, counter-clockwise seen from outside                                */
+  const int* mesh_polymapadr; const int* mesh_polymapnum;   /* [nmeshvert] into mesh_polymap                                 */
+  const int* mesh_polymap;      /* mesh-local ids of the polygons around each vertex                                         */
   const float* geom_solmix; int geom_solmix_nb;
   const float* geom_solref; int geom_solref_nb;
   const float* geom_solimp; int geom_solimp_nb;
@@ -299,7 +308,7 @@ int mjh_timed_steps(const MjhModel* m, const MjhData* d, int nstep, int step0, f
 int mjh_release_thread_resources(void);
 
 const char* mjh_last_error(void);
-#define MJH_ABI_VERSION 17
+#define MJH_ABI_VERSION 18
 int mjh_abi_version(void); /* returns MJH_ABI_VERSION of the library that was loaded */
 
 #ifdef __cplusplus

@@ -501,8 +501,9 @@ DEV int box_box(V3 P1, const float* R1, V3 S1, V3 P2, const float* R2, V3 S2, fl
 // half of it), the GJK cutoff is the gap, the reported distance is un-inflated, the contact sits midway between the witness points
 template <class Emit>
 DEV void collide_convex(float tolerance, int iterations, int epa_iterations, int t1, int t2, V3 p1, const float* R1, V3 s1, V3 p2, const float* R2, V3 s2, float margin,
-                        float gap, float* scratch, int& overflow, Emit&& emit, const float* vert1 = nullptr, int nvert1 = 0, const float* vert2 = nullptr, int nvert2 = 0) {
-  const CcdGeom a = CcdGeom{t1, p1, R1, s1, margin, vert1, nvert1, -1}, b = CcdGeom{t2, p2, R2, s2, margin, vert2, nvert2, -1};
+                        float gap, float* scratch, int& overflow, Emit&& emit, const float* vert1 = nullptr, int nvert1 = 0, const float* vert2 = nullptr, int nvert2 = 0,
+                        const MjhModel* mm = nullptr, int mesh1 = -1, int mesh2 = -1) {
+  const CcdGeom a = CcdGeom{t1, p1, R1, s1, margin, vert1, nvert1, -1, mesh1}, b = CcdGeom{t2, p2, R2, s2, margin, vert2, nvert2, -1, mesh2};
   float dist;
   V3 w1, w2;
   int face;
@@ -510,9 +511,12 @@ DEV void collide_convex(float tolerance, int iterations, int epa_iterations, int
   int n = ccd_run(tolerance, gap, iterations, epa_iterations, a, b, scratch, dist, w1, w2, overflow, face, pt);
   if (n == 0 || dist >= gap) return;
   dist += margin;
-  if (face >= 0) {  // two boxes, zero margin: up to four contacts from the EPA face, same distance and frame (collision_convex.py:888-960)
+  // multi-contact recovery (collision_convex.py:875-889): box-box always; box-mesh / mesh-mesh unless DisableBit.MULTICCD (meshes need their polygon tables)
+  const bool anymesh = t1 == G_MESH || t2 == G_MESH;
+  if (face >= 0 && anymesh && (!mm || (mm->disableflags & DSBL_MULTICCD) || mm->nmeshpoly == 0)) face = -1;
+  if (face >= 0) {  // zero margin: up to four contacts from the EPA face, same distance and frame (collision_convex.py:888-960)
     V3 m1[4], m2[4];
-    n = ccd_multicontact_box(pt, face, w1, w2, a, b, m1, m2);
+    n = anymesh ? ccd_multicontact_mesh(*mm, pt, face, w1, w2, a, b, m1, m2) : ccd_multicontact_box(pt, face, w1, w2, a, b, m1, m2);
     if (n == 0) return;
     const Frame f = make_frame3(dist <= margin ? m1[0] - m2[0] : m2[0] - m1[0]);
     for (int i = 0; i < n; ++i) emit(i, dist, 0.5f * (m1[i] + m2[i]), f.a, f.b, f.c);
@@ -1125,7 +1129,7 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
                            cache[(13 + 3 * k) * CCD_LANES] = pos.z;
                            nem = k + 1;
                          }
-                       }, mv1, mn1, mv2, mn2);
+                       }, mv1, mn1, mv2, mn2, &m, t1 == G_MESH ? m.geom_dataid[g1] : -1, t2 == G_MESH ? m.geom_dataid[g2] : -1);
         if (cache) reinterpret_cast<int*>(cache)[0] = nem;
       }
       else
@@ -1211,7 +1215,7 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
           mesh_of(g1, t1, mv1, mn1);
           mesh_of(g2, t2, mv2, mn2);
           collide_convex(ccd_tol, ccd_it, epa_it, t1, t2, ld3(gxpos + 3 * g1), gxmat + 9 * g1, ld3(gsize + 3 * g1), ld3(gxpos + 3 * g2), gxmat + 9 * g2,
-                         ld3(gsize + 3 * g2), margin, pp.gap, ccd_scratch, ccd_overflow, write, mv1, mn1, mv2, mn2);
+                         ld3(gsize + 3 * g2), margin, pp.gap, ccd_scratch, ccd_overflow, write, mv1, mn1, mv2, mn2, &m, t1 == G_MESH ? m.geom_dataid[g1] : -1, t2 == G_MESH ? m.geom_dataid[g2] : -1);
         }
       }
       else {

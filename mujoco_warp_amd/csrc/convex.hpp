@@ -47,6 +47,7 @@ struct CcdGeom {
   const float* vert;  // mesh: vertices in the geom frame (Model.mesh_vert)
   int nvert;
   int index;  // mesh: vertex of the last support call (warm start: wins ties), -1 at the start (reference Geom.index)
+  int meshid;  // mesh: Model.geom_dataid (polygon tables for the multi-contact recovery), -1 otherwise
 };
 struct GjkOut {
   bool separated;
@@ -691,7 +692,7 @@ DEV int ccd_run(float tolerance, float cutoff, int gjk_iterations, int epa_itera
     return 0;
   }
   dist_out = dist;
-  if (g1.margin == 0.0f && g2.margin == 0.0f && g1.type == G_BOX && g2.type == G_BOX) face_out = idx;
+  if (g1.margin == 0.0f && g2.margin == 0.0f && (g1.type == G_BOX || g1.type == G_MESH) && (g2.type == G_BOX || g2.type == G_MESH)) face_out = idx;  // collision_gjk.py:2517-2523
   return 1;
 }
 
@@ -986,6 +987,270 @@ DEV int ccd_multicontact_box(const Poly& pt, int epa_face, V3 x1, V3 x2, const C
   if (edge1) return mc_polygon_clip(face2, nface2, face1, nface1, n2[rj], (-dn) * n2[rj], w2, w1);
   if (edge2) return mc_polygon_clip(face1, nface1, face2, nface2, n1[rj], (-dn) * n1[rj], w1, w2);
   return mc_polygon_clip(face1, nface1, face2, nface2, n1[ri], dn * n2[rj], w1, w2);
+}
+
+// ---- multi-contact recovery with mesh faces (collision_gjk.py:1556-1700, 1891-1913, 2076-2300) ------------------------------------------
+// Pairs box-mesh / mesh-mesh, unless DisableBit.MULTICCD.  Same flow as ccd_multicontact_box with the mesh polygon tables of the Model
+// (types.py:1707-1733) in place of the box's closed forms.  Features hold up to MC_GN normals / polygon vertices (put_model checks the
+// meshes against it); the arrays are indexed dynamically, so this lives in scratch memory: a separate non-inlined function keeps it out of
+// the register budget of the narrowphase that calls it (it runs for the few pairs whose EPA face is a face-face / edge-face contact).
+#define MC_GN 8
+DEV int mc_intersect(const int* a1, int n1, const int* a2, int n2, int (&res)[2]) {
+  int count = 0;
+  for (int i = 0; i < n1; ++i)
+    for (int j = 0; j < n2; ++j)
+      if (a1[i] == a2[j]) {
+        res[count++] = a1[i];
+        if (count == 2) return 2;
+      }
+  return count;
+}
+struct MeshTab {  // the polygon tables of one mesh, offset to it
+  const float* vert;
+  const float* polynormal;
+  const int *polyvertadr, *polyvertnum, *polyvert, *polymapadr, *polymapnum, *polymap;
+};
+DEV MeshTab mesh_tab(const MjhModel& m, const CcdGeom& g) {
+  const int pa = m.mesh_polyadr[g.meshid], va = m.mesh_vertadr[g.meshid];
+  return MeshTab{g.vert, m.mesh_polynormal + 3 * pa, m.mesh_polyvertadr + pa, m.mesh_polyvertnum + pa, m.mesh_polyvert, m.mesh_polymapadr + va, m.mesh_polymapnum + va, m.mesh_polymap};
+}
+DEV int mc_mesh_normals(int dim, const int (&fi)[3], const MeshTab& t, const float* rot, V3* nout, int* iout) {
+  const int* m1 = t.polymap + t.polymapadr[fi[0]];
+  const int n1 = t.polymapnum[fi[0]];
+  if (dim == 3) {
+    int edgeset[2], faceset[2];
+    int n = mc_intersect(m1, n1, t.polymap + t.polymapadr[fi[1]], t.polymapnum[fi[1]], edgeset);
+    if (n == 0) return 0;
+    n = mc_intersect(edgeset, n, t.polymap + t.polymapadr[fi[2]], t.polymapnum[fi[2]], faceset);
+    if (n == 0) return 0;
+    nout[0] = mat_mul(rot, ld3(t.polynormal + 3 * faceset[0]));
+    iout[0] = faceset[0];
+    return 1;
+  }
+  if (dim == 2) {
+    int edgeset[2];
+    const int n = mc_intersect(m1, n1, t.polymap + t.polymapadr[fi[1]], t.polymapnum[fi[1]], edgeset);
+    for (int i = 0; i < n; ++i) {
+      nout[i] = mat_mul(rot, ld3(t.polynormal + 3 * edgeset[i]));
+      iout[i] = edgeset[i];
+    }
+    return n;
+  }
+  if (dim == 1) {
+    const int n = min(n1, MC_GN);
+    for (int i = 0; i < n; ++i) {
+      nout[i] = mat_mul(rot, ld3(t.polynormal + 3 * m1[i]));
+      iout[i] = m1[i];
+    }
+    return n;
+  }
+  return 0;
+}
+DEV int mc_mesh_edge_normals(int dim, const MeshTab& t, const CcdGeom& g, V3 v1, V3 v2, int v1i, V3* nout, V3* endv) {
+  if (dim == 2) {
+    endv[0] = v2;
+    nout[0] = normalize(v2 - v1);
+    return 1;
+  }
+  if (dim == 1) {
+    const int* pm = t.polymap + t.polymapadr[v1i];
+    const int n = min(t.polymapnum[v1i], MC_GN);
+    for (int i = 0; i < n; ++i) {
+      const int adr = t.polyvertadr[pm[i]], nv = t.polyvertnum[pm[i]];
+      for (int j = 0; j < nv; ++j)
+        if (t.polyvert[adr + j] == v1i) {
+          const int k = j == 0 ? nv - 1 : j - 1;
+          endv[i] = mat_mul(g.rot, ld3(t.vert + 3 * t.polyvert[adr + k])) + g.pos;
+          nout[i] = normalize(endv[i] - v1);
+        }
+    }
+    return n;
+  }
+  return 0;
+}
+DEV int mc_mesh_face(const MeshTab& t, const CcdGeom& g, int idx, V3* face) {
+  const int adr = t.polyvertadr[idx], nv = min(t.polyvertnum[idx], MC_GN);
+  int j = 0;
+  for (int i = nv - 1; i >= 0; --i) face[j++] = mat_mul(g.rot, ld3(t.vert + 3 * t.polyvert[adr + i])) + g.pos;
+  return nv;
+}
+// mc_polygon_clip for polygons of up to MC_GN vertices; cap = 2 * npolygonmax slots (collision_convex.py:1226-1234)
+DEV int mc_polygon_clip_n(const V3* face1, int nface1, const V3* face2, int nface2, V3 n, V3 dir, int cap, V3 (&w1)[4], V3 (&w2)[4]) {
+  if (nface1 < 3) return 0;
+  V3 pn[MC_GN], bufa[2 * MC_GN], bufb[2 * MC_GN];
+  float pd[MC_GN];
+  V3* poly = bufa;
+  V3* clip = bufb;
+  cap = min(cap, 2 * MC_GN);
+  for (int i = 0; i < nface1; ++i) {
+    const V3 a = face1[i], b = face1[(i + 1) % nface1];
+    pn[i] = cross(b - a, (a + n) - a);
+    pd[i] = dot(pn[i], a);
+  }
+  int np = nface2, nc = 0;
+  for (int i = 0; i < nface2; ++i) poly[i] = face2[i];
+  for (int e = 0; e < nface1; ++e) {
+    for (int i = 0; i < np; ++i) {
+      const V3 P = poly[i], Q = poly[(i + 1) % np];
+      const bool in1 = dot(P - face1[e], pn[e]) > -1e-10f, in2 = dot(Q - face1[e], pn[e]) > -1e-10f;
+      if (!in1 && !in2) continue;
+      if (in1 && in2) {
+        if (nc < cap) clip[nc] = Q;
+        ++nc;
+        continue;
+      }
+      const V3 pq = Q - P;
+      const float dt = dot(pn[e], pq);
+      float t = fabsf(dt) < 1e-10f ? CCD_FLOAT_MAX : (pd[e] - dot(pn[e], P)) / dt;
+      if (t > -CCD_INTERSECT_TOL && t < 1.0f + CCD_INTERSECT_TOL) {
+        t = clampf(t, 0.0f, 1.0f);
+        if (nc < cap) clip[nc] = P + t * pq;
+        ++nc;
+      }
+      if (in2) {
+        if (nc < cap) clip[nc] = Q;
+        ++nc;
+      }
+    }
+    if (nc > cap) nc = cap;
+    V3* tmp = poly;
+    poly = clip;
+    clip = tmp;
+    np = nc;
+    nc = 0;
+  }
+  if (np < 1) return 0;
+  if (nface2 == 2 && np > 2) {
+    int b1 = 0, b2 = 1;
+    float maxd = 0.0f;
+    for (int i = 0; i < np; ++i)
+      for (int j = i + 1; j < np; ++j) {
+        const V3 df = poly[j] - poly[i];
+        const float d2 = dot(df, df);
+        if (d2 > maxd) {
+          maxd = d2;
+          b1 = i;
+          b2 = j;
+        }
+      }
+    w2[0] = poly[b1];
+    w1[0] = w2[0] - dir;
+    w2[1] = poly[b2];
+    w1[1] = w2[1] - dir;
+    return 2;
+  }
+  if (np > 4) {
+    int q[4];
+    mc_polygon_quad(poly, np, q);
+    for (int i = 0; i < 4; ++i) {
+      w2[i] = poly[q[i]];
+      w1[i] = w2[i] - dir;
+    }
+    return 4;
+  }
+  for (int i = 0; i < np; ++i) {
+    w2[i] = poly[i];
+    w1[i] = w2[i] - dir;
+  }
+  return np;
+}
+__device__ __noinline__ int ccd_multicontact_mesh(const MjhModel& m, const Poly& pt, int epa_face, V3 x1, V3 x2, const CcdGeom& g1, const CcdGeom& g2,
+                                                  V3 (&w1)[4], V3 (&w2)[4]) {
+  w1[0] = x1;
+  w2[0] = x2;
+  const unsigned fc = (unsigned)pt.face(epa_face);
+  const int face[3] = {(int)(fc & 0x3FF), (int)((fc >> 10) & 0x3FF), (int)((fc >> 20) & 0x3FF)};
+  const bool mesh1 = g1.type == G_MESH, mesh2 = g2.type == G_MESH;
+  const MeshTab t1 = mesh1 ? mesh_tab(m, g1) : MeshTab{}, t2 = mesh2 ? mesh_tab(m, g2) : MeshTab{};
+  int fi1[3], fi2[3], idx1[MC_GN], idx2[MC_GN];
+  V3 fv1[3], fv2[3], n1[MC_GN], n2[MC_GN], endv[MC_GN];
+  const int nf1 = mc_feature_dim(pt, face, 0, fi1, fv1), nf2 = mc_feature_dim(pt, face, 1, fi2, fv2);
+  const V3 dir = x2 - x1;
+  auto box_normals = [&](int dim, const int (&fi)[3], const float* rot, V3 d, V3* nout, int* iout) {
+    V3 nb[3];
+    int ib[3] = {0, 0, 0};
+    const int n = mc_box_normals(dim, fi, rot, d, nb, ib);
+    for (int k = 0; k < n; ++k) {
+      nout[k] = nb[k];
+      iout[k] = ib[k];
+    }
+    return n;
+  };
+  auto box_edge_normals = [&](int dim, const CcdGeom& g, V3 v1, V3 v2, int v1i, V3* nout, V3* ev) {
+    V3 nb[3], eb[3];
+    const int n = mc_box_edge_normals(dim, g, v1, v2, v1i, nb, eb);
+    for (int k = 0; k < n; ++k) {
+      nout[k] = nb[k];
+      ev[k] = eb[k];
+    }
+    return n;
+  };
+  auto box_face = [&](const CcdGeom& g, int idx, V3* f) {
+    V3 fb[4];
+    const int n = mc_box_face(g, idx, fb);
+    for (int k = 0; k < n; ++k) f[k] = fb[k];
+    return n;
+  };
+  int nn1 = mesh1 ? mc_mesh_normals(nf1, fi1, t1, g1.rot, n1, idx1) : box_normals(nf1, fi1, g1.rot, -dir, n1, idx1);
+  int nn2 = mesh2 ? mc_mesh_normals(nf2, fi2, t2, g2.rot, n2, idx2) : box_normals(nf2, fi2, g2.rot, dir, n2, idx2);
+  bool edge1 = false, edge2 = false, found = false;
+  int ri = 0, rj = 0;
+  for (int i = 0; i < nn1 && !found; ++i)
+    for (int j = 0; j < nn2 && !found; ++j)
+      if (dot(n1[i], n2[j]) < -CCD_FACE_TOL) {
+        ri = i;
+        rj = j;
+        found = true;
+      }
+  if (!found) {
+    if (nf1 < 3 && nf1 <= nf2) {
+      nn1 = mesh1 ? mc_mesh_edge_normals(nf1, t1, g1, fv1[0], fv1[1], fi1[0], n1, endv) : box_edge_normals(nf1, g1, fv1[0], fv1[1], fi1[0], n1, endv);
+      for (int i = 0; i < nn2 && !found; ++i)
+        for (int j = 0; j < nn1 && !found; ++j)
+          if (fabsf(dot(n1[j], n2[i])) < CCD_EDGE_TOL) {
+            ri = j;
+            rj = i;
+            found = true;
+          }
+      if (!found) return 1;
+      edge1 = true;
+    } else if (nf2 < 3) {
+      nn2 = mesh2 ? mc_mesh_edge_normals(nf2, t2, g2, fv2[0], fv2[1], fi2[0], n2, endv) : box_edge_normals(nf2, g2, fv2[0], fv2[1], fi2[0], n2, endv);
+      for (int i = 0; i < nn1 && !found; ++i)
+        for (int j = 0; j < nn2 && !found; ++j)
+          if (fabsf(dot(n2[j], n1[i])) < CCD_EDGE_TOL) {
+            ri = j;
+            rj = i;
+            found = true;
+          }
+      if (!found) return 1;
+      edge2 = true;
+    } else {
+      return 1;
+    }
+  }
+  V3 face1[MC_GN], face2[MC_GN];
+  int nface1, nface2;
+  if (edge1) {
+    face1[0] = pt.vert(2 * face[0]);
+    face1[1] = endv[ri];
+    nface1 = 2;
+  } else {
+    const int ind = edge2 ? idx1[rj] : idx1[ri];
+    nface1 = mesh1 ? mc_mesh_face(t1, g1, ind, face1) : box_face(g1, ind, face1);
+  }
+  if (edge2) {
+    face2[0] = pt.vert(2 * face[0] + 1);
+    face2[1] = endv[ri];
+    nface2 = 2;
+  } else {
+    nface2 = mesh2 ? mc_mesh_face(t2, g2, idx2[rj], face2) : box_face(g2, idx2[rj], face2);
+  }
+  const float dn = length(dir);
+  const int cap = 2 * m.npolygonmax;
+  if (edge1) return mc_polygon_clip_n(face2, nface2, face1, nface1, n2[rj], (-dn) * n2[rj], cap, w2, w1);
+  if (edge2) return mc_polygon_clip_n(face1, nface1, face2, nface2, n1[rj], (-dn) * n1[rj], cap, w1, w2);
+  return mc_polygon_clip_n(face1, nface1, face2, nface2, n1[ri], dn * n2[rj], cap, w1, w2);
 }
 
 DEV bool is_convex_pair(int t1, int t2) {

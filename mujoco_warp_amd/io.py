@@ -187,8 +187,11 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
           raise NotImplementedError("meshes with a hill-climbing graph and 10 or more vertices (collision_gjk.py:170-196, collision_primitive.py:131-243) "
                                     "are not implemented: only the exhaustive vertex search is")
       if t in ((6, 7), (7, 7)) and not (int(opt.disableflags) & int(types.DisableBit.MULTICCD)):
-        raise NotImplementedError("multi-contact recovery for box-mesh / mesh-mesh pairs (collision_gjk.py:2076 multicontact, mesh branches) is not "
-                                  "implemented: set <flag multiccd=\"disable\"/> (one contact per pair, as the reference then computes)")
+        # multi-contact recovery on mesh faces (collision_gjk.py:2076): features of up to 8 normals / polygon vertices (csrc/convex.hpp MC_GN)
+        pv, pm = np.asarray(getattr(mjm, "mesh_polyvertnum", np.zeros(0))), np.asarray(getattr(mjm, "mesh_polymapnum", np.zeros(0)))
+        if len(pv) and (int(pv.max()) > 8 or int(pm.max()) > 8):
+          raise NotImplementedError("multi-contact recovery on meshes with polygons of more than 8 vertices or vertices shared by more than 8 polygons "
+                                    "is not implemented: set <flag multiccd=\"disable\"/> (one contact per pair, as the reference then computes)")
   condims = set(int(c) for c in np.unique(np.asarray(mjm.geom_condim)[np.unique(pairs)])) if len(pairs) else set()
   nexplicit = int(getattr(mjm, "npair", 0))
   if nexplicit:
@@ -348,7 +351,11 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
     geom_type=_arr(mjm.geom_type, i32), geom_condim=_arr(mjm.geom_condim, i32), geom_bodyid=_arr(mjm.geom_bodyid, i32),
     geom_priority=_arr(mjm.geom_priority, i32), geom_dataid=_arr(getattr(mjm, "geom_dataid", np.full(ngeom, -1)), i32),
     mesh_vertadr=_arr(getattr(mjm, "mesh_vertadr", np.zeros(0)), i32), mesh_vertnum=_arr(getattr(mjm, "mesh_vertnum", np.zeros(0)), i32),
-    mesh_vert=_arr(getattr(mjm, "mesh_vert", np.zeros((0, 3))), f32).reshape(-1, 3), nxn_geom_pair=pairs, nxn_pairid=pairid, nxn_pairindex=_pair_index(ngeom, pairs),
+    mesh_vert=_arr(getattr(mjm, "mesh_vert", np.zeros((0, 3))), f32).reshape(-1, 3),
+    mesh_polyadr=_arr(getattr(mjm, "mesh_polyadr", np.zeros(0)), i32), mesh_polynormal=_arr(getattr(mjm, "mesh_polynormal", np.zeros((0, 3))), f32).reshape(-1, 3),
+    mesh_polyvertadr=_arr(getattr(mjm, "mesh_polyvertadr", np.zeros(0)), i32), mesh_polyvertnum=_arr(getattr(mjm, "mesh_polyvertnum", np.zeros(0)), i32),
+    mesh_polyvert=_arr(getattr(mjm, "mesh_polyvert", np.zeros(0)), i32), mesh_polymapadr=_arr(getattr(mjm, "mesh_polymapadr", np.zeros(0)), i32),
+    mesh_polymapnum=_arr(getattr(mjm, "mesh_polymapnum", np.zeros(0)), i32), mesh_polymap=_arr(getattr(mjm, "mesh_polymap", np.zeros(0)), i32), nxn_geom_pair=pairs, nxn_pairid=pairid, nxn_pairindex=_pair_index(ngeom, pairs),
     pair_dim=_arr(getattr(mjm, "pair_dim", np.zeros(0)), i32), pair_friction=_arr(getattr(mjm, "pair_friction", np.zeros((0, 5))), f32).reshape(-1, 5),
     pair_solref=_arr(getattr(mjm, "pair_solref", np.zeros((0, 2))), f32).reshape(-1, 2),
     pair_solreffriction=_arr(getattr(mjm, "pair_solreffriction", np.zeros((0, 2))), f32).reshape(-1, 2),
@@ -362,6 +369,13 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
     eq_obj1id=_arr(getattr(mjm, "eq_obj1id", np.zeros(0)), i32), eq_obj2id=_arr(getattr(mjm, "eq_obj2id", np.zeros(0)), i32),
   )
   m.nmeshvert = int(host["mesh_vert"].shape[0])
+  m.nmeshpoly = int(host["mesh_polyvertnum"].shape[0])
+  m.nmeshpolyvert, m.nmeshpolymap = int(host["mesh_polyvert"].shape[0]), int(host["mesh_polymap"].shape[0])
+  # clip buffers of the multi-contact recovery: 2 * npolygonmax points (reference collision_convex.py:1226-1234)
+  nboxmesh, nmeshmesh = sum(t == (6, 7) for t in ptypes), sum(t == (7, 7) for t in ptypes)
+  m.npolygonmax = 4 if nboxbox > 0 else 0
+  if not (int(opt.disableflags) & int(types.DisableBit.MULTICCD)) and nboxmesh + nmeshmesh > 0:
+    m.npolygonmax = max(int(host["mesh_polyvertnum"].max()) if m.nmeshpoly else 0, 4 if nboxmesh else m.npolygonmax)
   m.nmesh = int(host["mesh_vertadr"].shape[0])
   m.sleep_enabled = int(bool(int(opt.enableflags) & int(types.EnableBit.SLEEP)) and not (int(opt.disableflags) & int(types.DisableBit.ISLAND)))
   m.opt_sleep_tolerance = float(getattr(opt, "sleep_tolerance", 1e-4))

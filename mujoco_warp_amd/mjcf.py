@@ -587,8 +587,30 @@ def _compile_mesh(verts):
     v[:, 2] = -v[:, 2]
   local = (verts - centre - com) @ v
   lo, hi = local.min(axis=0), local.max(axis=0)
+  # polygon tables for multi-contact recovery (Model.mesh_poly*, types.py:1707-1733): coplanar hull triangles merged into convex
+  # polygons, vertices counter-clockwise seen from outside; per vertex the polygons it belongs to
+  groups = []
+  for tri, eq in zip(hull.simplices, hull.equations):
+    for gr in groups:
+      if np.dot(gr["n"], eq[:3]) > 1.0 - 1e-9 and abs(gr["d"] - eq[3]) < 1e-9 * max(1.0, abs(eq[3])):
+        gr["verts"].update(int(i) for i in tri)
+        break
+    else:
+      groups.append(dict(n=eq[:3].copy(), d=float(eq[3]), verts=set(int(i) for i in tri)))
+  polys, normals = [], []
+  for gr in groups:
+    ids = sorted(gr["verts"])
+    pts = verts[ids]
+    c = pts.mean(axis=0)
+    e1 = pts[0] - c
+    e1 /= np.linalg.norm(e1)
+    e2 = np.cross(gr["n"], e1)
+    ang = np.arctan2((pts - c) @ e2, (pts - c) @ e1)
+    polys.append([ids[i] for i in np.argsort(ang)])
+    normals.append(gr["n"] @ v)  # in the mesh frame
+  polymap = [[p for p, poly in enumerate(polys) if i in poly] for i in range(len(verts))]
   return dict(vert=local, pos=centre + com, quat=nm.mat_to_quat(v), vol=vol, unit=w / vol, aabb=np.concatenate([(lo + hi) / 2, (hi - lo) / 2]),
-              rbound=float(np.max(np.linalg.norm(local, axis=1))))
+              rbound=float(np.max(np.linalg.norm(local, axis=1))), polys=polys, polynormal=np.array(normals), polymap=polymap)
 
 
 class _Body:
@@ -977,6 +999,16 @@ def _compile(root, base_dir):
   m.nmeshvert = len(m.mesh_vert)
   m.mesh_graphadr = np.full(m.nmesh, -1, dtype=np.int32)
   m.mesh_graph = np.zeros(0, dtype=np.int32)
+  mds = [mesh_compiled[n] for n in mesh_names]
+  m.mesh_polynum = np.array([len(md["polys"]) for md in mds], dtype=np.int32)
+  m.mesh_polyadr = np.concatenate([[0], np.cumsum(m.mesh_polynum)[:-1]]).astype(np.int32) if mds else np.zeros(0, dtype=np.int32)
+  m.mesh_polynormal = np.concatenate([md["polynormal"] for md in mds]).reshape(-1, 3) if mds else np.zeros((0, 3))
+  m.mesh_polyvertnum = np.array([len(p) for md in mds for p in md["polys"]], dtype=np.int32)
+  m.mesh_polyvertadr = np.concatenate([[0], np.cumsum(m.mesh_polyvertnum)[:-1]]).astype(np.int32) if mds else np.zeros(0, dtype=np.int32)
+  m.mesh_polyvert = np.array([i for md in mds for p in md["polys"] for i in p], dtype=np.int32)
+  m.mesh_polymapnum = np.array([len(pm) for md in mds for pm in md["polymap"]], dtype=np.int32)  # per vertex (global vertex index)
+  m.mesh_polymapadr = np.concatenate([[0], np.cumsum(m.mesh_polymapnum)[:-1]]).astype(np.int32) if mds else np.zeros(0, dtype=np.int32)
+  m.mesh_polymap = np.array([p for md in mds for pm in md["polymap"] for p in pm], dtype=np.int32)
   for i, g in enumerate(gl):
     if g["meshdata"] is not None:
       m.geom_dataid[i] = mesh_names.index(g["mesh"])

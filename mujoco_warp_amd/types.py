@@ -411,6 +411,18 @@ class Model(_Dirty):
   mesh_vertnum: DeviceArray = _arr(('nmesh',), "int32")
   mesh_vert: DeviceArray = _arr(('nmeshvert', 3), "float32")
   nmeshvert: int = 0
+  nmeshpoly: int = 0
+  nmeshpolyvert: int = 0
+  nmeshpolymap: int = 0
+  npolygonmax: int = 0
+  mesh_polyadr: DeviceArray = _arr(('nmesh',), "int32")
+  mesh_polynormal: DeviceArray = _arr(('nmeshpoly', 3), "float32")
+  mesh_polyvertadr: DeviceArray = _arr(('nmeshpoly',), "int32")
+  mesh_polyvertnum: DeviceArray = _arr(('nmeshpoly',), "int32")
+  mesh_polyvert: DeviceArray = _arr(('nmeshpolyvert',), "int32")
+  mesh_polymapadr: DeviceArray = _arr(('nmeshvert',), "int32")
+  mesh_polymapnum: DeviceArray = _arr(('nmeshvert',), "int32")
+  mesh_polymap: DeviceArray = _arr(('nmeshpolymap',), "int32")
   dof_length: DeviceArray = _arr(('nv',), "float32")
   ntree: int = 0  # kinematic trees with at least one dof
   tree_nvmax: int = 0  # dofs of the largest tree

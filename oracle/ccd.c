@@ -28,7 +28,16 @@ typedef struct CcdGeom {
   const double* vert; /* mesh: vertices in the geom frame */
   int nvert;
   int index;          /* mesh: vertex of the last support call (warm start: wins ties), -1 at the start (Geom.index) */
+  /* mesh polygon tables for multi-contact recovery (types.py:1707-1733), already offset to this mesh; NULL when absent */
+  const double* polynormal; /* [npoly, 3] */
+  const int* polyvertadr;   /* [npoly] into polyvert (global array) */
+  const int* polyvertnum;
+  const int* polyvert;      /* global array of mesh-local vertex ids */
+  const int* polymapadr;    /* [nvert] into polymap (global array) */
+  const int* polymapnum;
+  const int* polymap;       /* global array of mesh-local polygon ids */
 } CcdGeom;
+#define MC_MAXN 32 /* normals / polygon vertices the restatement holds per feature (the reference sizes its buffers from the model) */
 
 typedef struct GjkOut {
   int separated, dim;
@@ -643,7 +652,7 @@ static int ccd_run(double tolerance, double cutoff, int gjk_iterations, int epa_
   int idx = ccd_epa(tolerance, epa_iterations, pt, &g1, &g2, is_discrete, overflow, &dist, x1, x2);
   if (idx == -1) { *dist_out = CCD_FLOAT_MAX; return 0; }
   *dist_out = dist;
-  if (g1.margin == 0.0 && g2.margin == 0.0 && g1.type == G_BOX && g2.type == G_BOX) *face_out = idx;
+  if (g1.margin == 0.0 && g2.margin == 0.0 && (g1.type == G_BOX || g1.type == G_MESH) && (g2.type == G_BOX || g2.type == G_MESH)) *face_out = idx; /* 2517-2523 */
   return 1;
 }
 
@@ -800,10 +809,12 @@ static void mc_polygon_quad(double poly[][3], int n, int* res) { /* 1463-1499: r
   }
 }
 /* clip polygon face2 against the side planes of face1 (normal n); returns the number of contacts, w2 = clipped points, w1 = w2 - dir */
-static int mc_polygon_clip(double face1[4][3], int nface1, double face2[4][3], int nface2, const double* n, const double* dir, double w1[4][3],
+static int g_mc_cap = 8; /* slots of the clip buffers = 2 * npolygonmax (collision_convex.py:1226-1234): 8 for box-only models */
+static int mc_polygon_clip(double face1[][3], int nface1, double face2[][3], int nface2, const double* n, const double* dir, double w1[4][3],
                            double w2[4][3]) { /* 1941-2056 */
   if (nface1 < 3) return 0;
-  double pn[4][3], pd[4], bufa[8][3], bufb[8][3];
+  double pn[MC_MAXN][3], pd[MC_MAXN], bufa[2 * MC_MAXN][3], bufb[2 * MC_MAXN][3];
+  const int cap = g_mc_cap < 2 * MC_MAXN ? g_mc_cap : 2 * MC_MAXN;
   double(*poly)[3] = bufa;
   double(*clip)[3] = bufb;
   for (int i = 0; i < nface1; i++) {
@@ -825,18 +836,18 @@ static int mc_polygon_clip(double face1[4][3], int nface1, double face2[4][3], i
       v3sub(dq, Q, face1[e]);
       int in1 = v3dot(dp, pn[e]) > -1e-10, in2 = v3dot(dq, pn[e]) > -1e-10;
       if (!in1 && !in2) continue;
-      if (in1 && in2) { if (nc < 8) v3cpy(clip[nc], Q); nc++; continue; }
+      if (in1 && in2) { if (nc < cap) v3cpy(clip[nc], Q); nc++; continue; }
       double pq[3];
       v3sub(pq, Q, P);
       double dt = v3dot(pn[e], pq), t = fabs(dt) < 1e-10 ? CCD_FLOAT_MAX : (pd[e] - v3dot(pn[e], P)) / dt;
       if (t > -CCD_INTERSECT_TOL && t < 1.0 + CCD_INTERSECT_TOL) {
         t = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
-        if (nc < 8) v3addscl(clip[nc], P, pq, t);
+        if (nc < cap) v3addscl(clip[nc], P, pq, t);
         nc++;
       }
-      if (in2) { if (nc < 8) v3cpy(clip[nc], Q); nc++; }
+      if (in2) { if (nc < cap) v3cpy(clip[nc], Q); nc++; }
     }
-    if (nc > 8) nc = 8; /* (2 * npolygonmax = 8 slots in the reference's buffers) */
+    if (nc > cap) nc = cap; /* (the reference's buffers hold 2 * npolygonmax points) */
     double(*tmp)[3] = poly; poly = clip; clip = tmp;
     np = nc;
     nc = 0;
@@ -865,32 +876,112 @@ static int mc_polygon_clip(double face1[4][3], int nface1, double face2[4][3], i
   for (int i = 0; i < np; i++) { v3cpy(w2[i], poly[i]); v3sub(w1[i], w2[i], dir); }
   return np;
 }
-/* returns the number of contacts (>= 1) and their witness points; x1 / x2 = EPA's witness points (contact 0 when nothing is recovered) */
+/* ---- mesh features (collision_gjk.py:1556-1700, 1891-1913) ---- */
+static int mc_intersect(const int* a1, int n1, const int* a2, int n2, int* res) { /* up to two common entries: _intersect1 / _intersect2 */
+  int count = 0;
+  for (int i = 0; i < n1; i++)
+    for (int j = 0; j < n2; j++)
+      if (a1[i] == a2[j]) {
+        res[count++] = a1[i];
+        if (count == 2) return 2;
+      }
+  return count;
+}
+static int mc_mesh_normals(int dim, const int* fi, const CcdGeom* g, double nout[][3], int* iout) { /* 1585-1652 */
+  const int *m1 = g->polymap + g->polymapadr[fi[0]], n1 = g->polymapnum[fi[0]];
+  if (dim == 3) {
+    int edgeset[2], faceset[2];
+    int n = mc_intersect(m1, n1, g->polymap + g->polymapadr[fi[1]], g->polymapnum[fi[1]], edgeset);
+    if (n == 0) return 0;
+    n = mc_intersect(edgeset, n, g->polymap + g->polymapadr[fi[2]], g->polymapnum[fi[2]], faceset);
+    if (n == 0) return 0;
+    mat_mul_vec(nout[0], g->rot, g->polynormal + 3 * faceset[0]); /* three vertices of a mesh define one face */
+    iout[0] = faceset[0];
+    return 1;
+  }
+  if (dim == 2) {
+    int edgeset[2];
+    int n = mc_intersect(m1, n1, g->polymap + g->polymapadr[fi[1]], g->polymapnum[fi[1]], edgeset);
+    for (int i = 0; i < n; i++) {
+      mat_mul_vec(nout[i], g->rot, g->polynormal + 3 * edgeset[i]);
+      iout[i] = edgeset[i];
+    }
+    return n;
+  }
+  if (dim == 1) {
+    int n = n1 < MC_MAXN ? n1 : MC_MAXN;
+    for (int i = 0; i < n; i++) {
+      mat_mul_vec(nout[i], g->rot, g->polynormal + 3 * m1[i]);
+      iout[i] = m1[i];
+    }
+    return n;
+  }
+  return 0;
+}
+static int mc_mesh_edge_normals(int dim, const CcdGeom* g, const double* v1, const double* v2, int v1i, double nout[][3], double endv[][3]) { /* 1655-1700 */
+  if (dim == 2) {
+    v3cpy(endv[0], v2);
+    v3sub(nout[0], v2, v1);
+    v3normalize(nout[0]);
+    return 1;
+  }
+  if (dim == 1) {
+    const int* pm = g->polymap + g->polymapadr[v1i];
+    int n = g->polymapnum[v1i] < MC_MAXN ? g->polymapnum[v1i] : MC_MAXN;
+    for (int i = 0; i < n; i++) { /* in every polygon around the vertex: the edge to the previous vertex of the polygon */
+      int adr = g->polyvertadr[pm[i]], nv = g->polyvertnum[pm[i]];
+      for (int j = 0; j < nv; j++)
+        if (g->polyvert[adr + j] == v1i) {
+          int k = j == 0 ? nv - 1 : j - 1;
+          mat_mul_vec(endv[i], g->rot, g->vert + 3 * g->polyvert[adr + k]);
+          v3add(endv[i], endv[i], g->pos);
+          v3sub(nout[i], endv[i], v1);
+          v3normalize(nout[i]);
+        }
+    }
+    return n;
+  }
+  return 0;
+}
+static int mc_mesh_face(const CcdGeom* g, int idx, double face[][3]) { /* 1891-1913: the polygon in reverse order */
+  int adr = g->polyvertadr[idx], nv = g->polyvertnum[idx], j = 0;
+  if (nv > MC_MAXN) nv = MC_MAXN;
+  for (int i = nv - 1; i >= 0; i--) {
+    mat_mul_vec(face[j], g->rot, g->vert + 3 * g->polyvert[adr + i]);
+    v3add(face[j], face[j], g->pos);
+    j++;
+  }
+  return nv;
+}
+/* multicontact (collision_gjk.py:2076-2300), boxes and meshes.  Returns the number of contacts (>= 1) and their witness points; x1 / x2 =
+   EPA's witness points (contact 0 when nothing is recovered) */
 static int ccd_multicontact_box(const Polytope* pt, int epa_face, const double* x1, const double* x2, const CcdGeom* g1, const CcdGeom* g2,
                                 double w1[4][3], double w2[4][3]) {
   v3cpy(w1[0], x1);
   v3cpy(w2[0], x2);
   const int* face = pt->fv[epa_face];
-  int fi1[3], fi2[3], idx1[3], idx2[3];
-  double fv1[3][3], fv2[3][3], n1[3][3], n2[3][3], endv[3][3], dir[3], dneg[3];
+  const int mesh1 = g1->type == G_MESH, mesh2 = g2->type == G_MESH;
+  int fi1[3], fi2[3], idx1[MC_MAXN], idx2[MC_MAXN];
+  double fv1[3][3], fv2[3][3], n1[MC_MAXN][3], n2[MC_MAXN][3], endv[MC_MAXN][3], dir[3], dneg[3];
   int nf1 = mc_feature_dim(pt, face, 0, fi1, fv1), nf2 = mc_feature_dim(pt, face, 1, fi2, fv2);
   v3sub(dir, x2, x1);
   for (int k = 0; k < 3; k++) dneg[k] = -dir[k];
-  int nn1 = mc_box_normals(nf1, fi1, g1->rot, dneg, n1, idx1), nn2 = mc_box_normals(nf2, fi2, g2->rot, dir, n2, idx2);
+  int nn1 = mesh1 ? mc_mesh_normals(nf1, fi1, g1, n1, idx1) : mc_box_normals(nf1, fi1, g1->rot, dneg, n1, idx1);
+  int nn2 = mesh2 ? mc_mesh_normals(nf2, fi2, g2, n2, idx2) : mc_box_normals(nf2, fi2, g2->rot, dir, n2, idx2);
   int edge1 = 0, edge2 = 0, found = 0, ri = 0, rj = 0;
   for (int i = 0; i < nn1 && !found; i++) /* _aligned_faces 1529 */
     for (int j = 0; j < nn2 && !found; j++)
       if (v3dot(n1[i], n2[j]) < -CCD_FACE_TOL) { ri = i; rj = j; found = 1; }
   if (!found) {
-    if (nf1 < 3 && nf1 <= nf2) { /* an edge (or vertex) of box 1 against a face of box 2 */
-      nn1 = mc_box_edge_normals(nf1, g1, fv1[0], fv1[1], fi1[0], n1, endv);
+    if (nf1 < 3 && nf1 <= nf2) { /* an edge (or vertex) of geom 1 against a face of geom 2 */
+      nn1 = mesh1 ? mc_mesh_edge_normals(nf1, g1, fv1[0], fv1[1], fi1[0], n1, endv) : mc_box_edge_normals(nf1, g1, fv1[0], fv1[1], fi1[0], n1, endv);
       for (int i = 0; i < nn2 && !found; i++) /* _aligned_face_edge(edge = n1, face = n2) 1543 */
         for (int j = 0; j < nn1 && !found; j++)
           if (fabs(v3dot(n1[j], n2[i])) < CCD_EDGE_TOL) { ri = j; rj = i; found = 1; }
       if (!found) return 1;
       edge1 = 1;
     } else if (nf2 < 3) {
-      nn2 = mc_box_edge_normals(nf2, g2, fv2[0], fv2[1], fi2[0], n2, endv);
+      nn2 = mesh2 ? mc_mesh_edge_normals(nf2, g2, fv2[0], fv2[1], fi2[0], n2, endv) : mc_box_edge_normals(nf2, g2, fv2[0], fv2[1], fi2[0], n2, endv);
       for (int i = 0; i < nn1 && !found; i++)
         for (int j = 0; j < nn2 && !found; j++)
           if (fabs(v3dot(n2[j], n1[i])) < CCD_EDGE_TOL) { ri = j; rj = i; found = 1; }
@@ -900,14 +991,17 @@ static int ccd_multicontact_box(const Polytope* pt, int epa_face, const double* 
       return 1;
     }
   }
-  double face1[4][3], face2[4][3], approx[3];
+  double face1[MC_MAXN][3], face2[MC_MAXN][3], approx[3];
   int nface1, nface2;
   if (edge1) { v3cpy(face1[0], pt->vert[2 * face[0]]); v3cpy(face1[1], endv[ri]); nface1 = 2; }
-  else nface1 = mc_box_face(g1, edge2 ? idx1[rj] : idx1[ri], face1);
+  else {
+    int ind = edge2 ? idx1[rj] : idx1[ri];
+    nface1 = mesh1 ? mc_mesh_face(g1, ind, face1) : mc_box_face(g1, ind, face1);
+  }
   if (edge2) { v3cpy(face2[0], pt->vert[2 * face[0] + 1]); v3cpy(face2[1], endv[ri]); nface2 = 2; }
-  else nface2 = mc_box_face(g2, idx2[rj], face2);
+  else nface2 = mesh2 ? mc_mesh_face(g2, idx2[rj], face2) : mc_box_face(g2, idx2[rj], face2);
   double dn = v3len(dir);
-  if (edge1) { /* clip the edge of box 1 against the face of box 2; the roles of the witness arrays swap back afterwards */
+  if (edge1) { /* clip the edge of geom 1 against the face of geom 2; the roles of the witness arrays swap back afterwards */
     for (int k = 0; k < 3; k++) approx[k] = -dn * n2[rj][k];
     return mc_polygon_clip(face2, nface2, face1, nface1, n2[rj], approx, w2, w1);
   }

@@ -24,7 +24,7 @@ enum { CT_EQUALITY = 0, CT_FRICTION_DOF = 1, CT_FRICTION_TENDON = 2, CT_LIMIT_JO
        CT_CONTACT_FRICTIONLESS = 5, CT_CONTACT_PYRAMIDAL = 6, CT_CONTACT_ELLIPTIC = 7 };
 enum { DSBL_CONSTRAINT = 1 << 0, DSBL_EQUALITY = 1 << 1, DSBL_FRICTIONLOSS = 1 << 2, DSBL_LIMIT = 1 << 3, DSBL_CONTACT = 1 << 4,
        DSBL_SPRING = 1 << 5, DSBL_DAMPER = 1 << 6, DSBL_GRAVITY = 1 << 7, DSBL_CLAMPCTRL = 1 << 8,
-       DSBL_WARMSTART = 1 << 9, DSBL_ACTUATION = 1 << 11, DSBL_REFSAFE = 1 << 12, DSBL_EULERDAMP = 1 << 15, DSBL_NATIVECCD = 1 << 17 };
+       DSBL_WARMSTART = 1 << 9, DSBL_ACTUATION = 1 << 11, DSBL_REFSAFE = 1 << 12, DSBL_EULERDAMP = 1 << 15, DSBL_NATIVECCD = 1 << 17, DSBL_MULTICCD = 1 << 19 };
 enum { SOL_PGS = 0, SOL_CG = 1, SOL_NEWTON = 2 };
 enum { INT_EULER = 0, INT_RK4 = 1, INT_IMPLICIT = 2, INT_IMPLICITFAST = 3 };
 enum { ENBL_SLEEP = 1 << 5, DSBL_ISLAND = 1 << 18 };
@@ -1073,12 +1073,38 @@ static void mesh_of(const RefModel* m, int g, const double** vert, int* nvert) {
     *nvert = m->mesh_vertnum[id];
   }
 }
+static void mesh_poly_of(const RefModel* m, int g, CcdGeom* c) { /* polygon tables, offset to the geom's mesh */
+  c->polynormal = NULL;
+  c->polyvertadr = c->polyvertnum = c->polyvert = c->polymapadr = c->polymapnum = c->polymap = NULL;
+  if (g >= 0 && m->geom_type[g] == G_MESH && m->nmeshpoly > 0) {
+    int id = m->geom_dataid[g], pa = m->mesh_polyadr[id], va = m->mesh_vertadr[id];
+    c->polynormal = m->mesh_polynormal + 3 * pa;
+    c->polyvertadr = m->mesh_polyvertadr + pa;
+    c->polyvertnum = m->mesh_polyvertnum + pa;
+    c->polyvert = m->mesh_polyvert;
+    c->polymapadr = m->mesh_polymapadr + va;
+    c->polymapnum = m->mesh_polymapnum + va;
+    c->polymap = m->mesh_polymap;
+  }
+}
+/* multi-contact recovery applies to (collision_convex.py:875-889): box-box always; box-mesh / mesh-mesh unless DisableBit.MULTICCD;
+   meshes need their polygon tables */
+static int multiccd_pair(const RefModel* m, const CcdGeom* a, const CcdGeom* b) {
+  int bb = a->type == G_BOX && b->type == G_BOX;
+  if (!bb && (m->disableflags & DSBL_MULTICCD)) return 0;
+  if ((a->type != G_BOX && a->type != G_MESH) || (b->type != G_BOX && b->type != G_MESH)) return 0;
+  if ((a->type == G_MESH && !a->polynormal) || (b->type == G_MESH && !b->polynormal)) return 0;
+  return 1;
+}
 static int ccd_contact(const RefModel* m, int g1, int g2, int t1, const double* p1, const double* R1, const double* s1, int t2, const double* p2,
                        const double* R2, const double* s2, double margin, double gap, Con* out, int* overflow) {
   CcdGeom a, b;
   a.type = t1; b.type = t2;
   mesh_of(m, g1, &a.vert, &a.nvert);
   mesh_of(m, g2, &b.vert, &b.nvert);
+  mesh_poly_of(m, g1, &a);
+  mesh_poly_of(m, g2, &b);
+  g_mc_cap = 2 * m->npolygonmax;
   a.index = b.index = -1;
   v3cpy(a.pos, p1); v3cpy(b.pos, p2);
   memcpy(a.rot, R1, sizeof(a.rot)); memcpy(b.rot, R2, sizeof(b.rot));
@@ -1090,7 +1116,7 @@ static int ccd_contact(const RefModel* m, int g1, int g2, int t1, const double* 
   int n = ccd_run(m->ccd_tolerance, gap, m->ccd_iterations, m->epa_iterations, a, b, &dist, w1[0], w2[0], overflow, &face, &pt);
   if (n == 0 || dist >= gap) return 0;
   dist += margin;
-  if (face >= 0) { /* box pair, zero margin: recover up to four contacts from the EPA face (collision_convex.py:888-917) */
+  if (face >= 0 && multiccd_pair(m, &a, &b)) { /* zero margin: recover up to four contacts from the EPA face (collision_convex.py:875-917) */
     double x1[3], x2[3];
     v3cpy(x1, w1[0]);
     v3cpy(x2, w2[0]);
@@ -1593,6 +1619,42 @@ int ref_ccd_mesh(int type1, const double* pos1, const double* mat1, const double
   v3cpy(a.size, size1); v3cpy(b.size, size2);
   a.margin = b.margin = margin;
   a.vert = vert1; a.nvert = nvert1; b.vert = vert2; b.nvert = nvert2;
+  a.index = b.index = -1;
+  mesh_poly_of(NULL, -1, &a);
+  mesh_poly_of(NULL, -1, &b);
+  g_mc_cap = 8;
+  static Polytope pt;
+  int face, overflow = 0;
+  int n = ccd_run(tolerance, cutoff, iterations, iterations, a, b, out, out + 1, out + 4, &overflow, &face, &pt);
+  if (type1 == G_MESH || type2 == G_MESH) face = -1; /* (no polygon tables on this entry: see ref_ccd_geoms) */
+  out[7] = (double)overflow;
+  out[8] = (double)face;
+  for (int k = 0; k < 3; k++) { wit[k] = out[1 + k]; wit[3 + k] = out[4 + k]; }
+  if (multiccd && n > 0 && face >= 0) {
+    double w1[4][3], w2[4][3];
+    n = ccd_multicontact_box(&pt, face, out + 1, out + 4, &a, &b, w1, w2);
+    for (int i = 0; i < n; i++)
+      for (int k = 0; k < 3; k++) { wit[6 * i + k] = w1[i][k]; wit[6 * i + 3 + k] = w2[i][k]; }
+  }
+  return n;
+}
+
+/* ccd on two geoms of a model at given poses, with multi-contact recovery when `multiccd` (collision_gjk_test.py:_geom_dist) */
+int ref_ccd_geoms(const RefModel* m, int g1, int g2, const double* pos1, const double* mat1, const double* pos2, const double* mat2, double margin,
+                  double tolerance, double cutoff, int iterations, int multiccd, double* out, double* wit) {
+  CcdGeom a, b;
+  a.type = m->geom_type[g1]; b.type = m->geom_type[g2];
+  v3cpy(a.pos, pos1); v3cpy(b.pos, pos2);
+  memcpy(a.rot, mat1, sizeof(a.rot)); memcpy(b.rot, mat2, sizeof(b.rot));
+  v3cpy(a.size, m->geom_size + 3 * g1); v3cpy(b.size, m->geom_size + 3 * g2);
+  a.margin = b.margin = margin;
+  mesh_of(m, g1, &a.vert, &a.nvert);
+  mesh_of(m, g2, &b.vert, &b.nvert);
+  mesh_poly_of(m, g1, &a);
+  mesh_poly_of(m, g2, &b);
+  g_mc_cap = 8; /* (posed pairs need not be colliding pairs of the model: size the clip buffers from the two geoms, like the reference's harness) */
+  for (int p = 0; p < m->nmeshpoly; p++)
+    if (2 * m->mesh_polyvertnum[p] > g_mc_cap) g_mc_cap = 2 * m->mesh_polyvertnum[p];
   a.index = b.index = -1;
   static Polytope pt;
   int face, overflow = 0;

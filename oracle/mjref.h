@@ -32,6 +32,8 @@ typedef struct RefModel {
   int nmocap;
   int nexplicit;
   int ntree;
+  int nmeshpoly;   /* polygons of all meshes (0: no polygon tables, no multi-contact recovery on meshes) */
+  int npolygonmax; /* clip buffers hold 2 * npolygonmax points (collision_convex.py:1226-1234) */
   int enableflags;       /* EnableBit: SLEEP = 1 << 5 (with DisableBit.ISLAND clear: forward.py:345) */
   int integrator;
   int cone;
@@ -143,6 +145,14 @@ typedef struct RefModel {
   int* mesh_vertadr;
   int* mesh_vertnum;
   double* mesh_vert;  /* [nmeshvert, 3] vertices in the mesh (= geom) frame */
+  int* mesh_polyadr;
+  double* mesh_polynormal;
+  int* mesh_polyvertadr;
+  int* mesh_polyvertnum;
+  int* mesh_polyvert;
+  int* mesh_polymapadr;
+  int* mesh_polymapnum;
+  int* mesh_polymap;
   int* body_treeid;
   int* dof_treeid;
   int* tree_dofadr;
@@ -281,6 +291,8 @@ int ref_ccd(int type1, const double* pos1, const double* mat1, const double* siz
 int ref_ccd_mesh(int type1, const double* pos1, const double* mat1, const double* size1, const double* vert1, int nvert1, int type2,
                  const double* pos2, const double* mat2, const double* size2, const double* vert2, int nvert2, double margin, double tolerance,
                  double cutoff, int iterations, int multiccd, double* out, double* wit); /* ref_ccd with mesh vertices (geom frame) */
+int ref_ccd_geoms(const RefModel* m, int g1, int g2, const double* pos1, const double* mat1, const double* pos2, const double* mat2, double margin,
+                  double tolerance, double cutoff, int iterations, int multiccd, double* out, double* wit);
 int ref_rollout(const RefModel* m, RefData* d, int nstep, int worldid, double noise_std, double noise_rate, double* qpos_out, double* qvel_out);
 
 #endif

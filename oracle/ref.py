@@ -118,6 +118,20 @@ def _epa_iterations(mjm, pairs):
   return 16 if (nbb > 0 and nother == 0) else int(getattr(mjm.opt, "ccd_iterations", 35))
 
 
+def npolygonmax(mjm, pairs):
+  """Vertices per clip polygon the multi-contact buffers are sized for (reference collision_convex.py:1226-1234)."""
+  gt = np.asarray(mjm.geom_type)
+  types = [(int(min(gt[a], gt[b])), int(max(gt[a], gt[b]))) for a, b in np.asarray(pairs).reshape(-1, 2)]
+  nativeccd_off = bool(int(mjm.opt.disableflags) & (1 << 17))
+  nboxbox = 0 if nativeccd_off else sum(t == (6, 6) for t in types)
+  nboxmesh, nmeshmesh = sum(t == (6, 7) for t in types), sum(t == (7, 7) for t in types)
+  n = 4 if nboxbox > 0 else 0
+  if not (int(mjm.opt.disableflags) & (1 << 19)) and nboxmesh + nmeshmesh > 0:
+    pv = np.asarray(getattr(mjm, "mesh_polyvertnum", np.zeros(0)))
+    n = max(int(pv.max()) if len(pv) else 0, 4 if nboxmesh else n)
+  return n
+
+
 def filtered_geom_pairs(mjm):
   """Pre-filtered geom pairs in upper-triangular order (reference io.py:551-577)."""
   DSBL_FILTERPARENT = 1 << 10
@@ -206,8 +220,12 @@ class RefSim:
                "xpair_solimp": getattr(mjm, "pair_solimp", np.zeros(0)), "xpair_margin": getattr(mjm, "pair_margin", np.zeros(0)),
                "xpair_gap": getattr(mjm, "pair_gap", np.zeros(0)),
                "actuator_trnid": mjm.actuator_trnid, "M_colind": mjm.M_colind}
-    for name, dflt in (("geom_dataid", np.full(mjm.ngeom, -1)), ("mesh_vertadr", np.zeros(0)), ("mesh_vertnum", np.zeros(0)), ("mesh_vert", np.zeros((0, 3)))):
+    for name, dflt in (("geom_dataid", np.full(mjm.ngeom, -1)), ("mesh_vertadr", np.zeros(0)), ("mesh_vertnum", np.zeros(0)), ("mesh_vert", np.zeros((0, 3))),
+                       ("mesh_polyadr", np.zeros(0)), ("mesh_polynormal", np.zeros((0, 3))), ("mesh_polyvertadr", np.zeros(0)), ("mesh_polyvertnum", np.zeros(0)),
+                       ("mesh_polyvert", np.zeros(0)), ("mesh_polymapadr", np.zeros(0)), ("mesh_polymapnum", np.zeros(0)), ("mesh_polymap", np.zeros(0))):
       special[name] = np.asarray(getattr(mjm, name, dflt))
+    sizes["nmeshpoly"] = int(len(special["mesh_polyvertnum"]))
+    sizes["npolygonmax"] = npolygonmax(mjm, pairs)
     for name, dt in (("tree_sleep_policy", np.int32), ("dof_length", np.float64)):  # (absent on models that predate sleeping)
       special[name] = np.asarray(getattr(mjm, name, np.full(sizes["ntree"], 2) if name == "tree_sleep_policy" else np.ones(mjm.nv)), dtype=dt)
     for name, kind, ptr in _MODEL_FIELDS:
@@ -308,6 +326,21 @@ class RefSim:
     ok = self.lib.ref_rollout(ctypes.byref(self.cm), ctypes.byref(self.cd), nstep, worldid, noise_std, noise_rate,
                               qp.ctypes.data_as(dp) if record else None, qv.ctypes.data_as(dp) if record else None)
     return ok, qp, qv
+
+  def ccd_geoms(self, g1, g2, pos1=None, mat1=None, pos2=None, mat2=None, margin=0.0, tolerance=1e-6, cutoff=1e30, iterations=35, multiccd=True):
+    """GJK / EPA / multi-contact on two geoms of the model at given poses (default: their current geom_xpos / geom_xmat); like the
+    reference's test harness collision_gjk_test.py:_geom_dist.  Returns (dist, ncon, witness pairs [ncon, 2, 3])."""
+    def arr(x, dflt):
+      return np.ascontiguousarray(np.asarray(dflt if x is None else x, dtype=np.float64).reshape(-1))
+    p1, m1 = arr(pos1, self.geom_xpos[g1]), arr(mat1, self.geom_xmat[g1])
+    p2, m2 = arr(pos2, self.geom_xpos[g2]), arr(mat2, self.geom_xmat[g2])
+    out, wit = np.zeros(9), np.zeros(48)
+    dp = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    fn = self.lib.ref_ccd_geoms
+    fn.restype = ctypes.c_int
+    n = fn(ctypes.byref(self.cm), int(g1), int(g2), dp(p1), dp(m1), dp(p2), dp(m2), ctypes.c_double(margin), ctypes.c_double(tolerance),
+           ctypes.c_double(cutoff), int(iterations), int(bool(multiccd)), dp(out), dp(wit))
+    return float(out[0]), n, wit.reshape(8, 2, 3)[: max(n, 0)].copy()
 
   def dense_M(self):
     m = self.mjm

@@ -55,6 +55,32 @@ def test_reference_held_mesh_vectors():
   assert abs(d + 0.001) < 1e-7
 
 
+def test_oracle_mesh_multicontact():
+  """collision_gjk_test.py:528-546 test_mesh_mesh_ccd holds 4 contacts for two cube meshes face to face; a cube mesh against a box must
+  give the very contacts of the box-box pair (same geometry, the box side drives the clip order); mesh-mesh picks its four points from
+  the same clipped polygon (the greedy quadrilateral search starts from a different vertex: DESIGN section 6)."""
+  def run(g1, g2):
+    xml = f'<mujoco><asset><mesh name="smallbox" vertex="{CUBE}"/></asset><worldbody><geom pos="0 0 2" {g1}/><geom pos="0 1 3.99" euler="0 0 40" {g2}/></worldbody></mujoco>'
+    s = ref.RefSim(mjw.mjcf.from_xml_string(xml))
+    s.forward()
+    return s.ccd_geoms(0, 1)
+
+  mesh, box = 'type="mesh" mesh="smallbox"', 'type="box" size="1 1 1"'
+  (dm, nm_, wm), (db, nb, wb), (dc, nc, wc), (de, ne, we) = run(mesh, mesh), run(box, box), run(box, mesh), run(mesh, box)
+  assert nm_ == 4 and nb == 4 and nc == 4 and ne == 4  # (reference-held: 4)
+  assert abs(dm + 0.01) < 1e-9 and abs(db + 0.01) < 1e-9
+  key = lambda w: sorted(map(tuple, w.reshape(len(w), 6).round(6)))
+  assert key(wc) == key(wb)
+  # every mesh-mesh witness lies on the boundary of the overlap of the two faces (z = 3 / 2.99, inside both squares)
+  c, s_ = np.cos(np.deg2rad(40)), np.sin(np.deg2rad(40))
+  for w in np.concatenate([wm, we]):
+    assert abs(w[0, 2] - 3.0) < 1e-9 and abs(w[1, 2] - 2.99) < 1e-9
+    x, y = w[0, 0], w[0, 1]
+    assert abs(x) <= 1 + 1e-9 and abs(y) <= 1 + 1e-9
+    u, v = c * x + s_ * (y - 1), -s_ * x + c * (y - 1)
+    assert abs(u) <= 1 + 1e-9 and abs(v) <= 1 + 1e-9
+
+
 MESH_SCENE = """
 <mujoco>
   <option timestep="0.004"><flag multiccd="disable"/></option>
@@ -90,8 +116,13 @@ def test_loader_mesh_equals_box():
   for i in range(a.nmesh):
     v = a.mesh_vert[a.mesh_vertadr[i] : a.mesh_vertadr[i] + a.mesh_vertnum[i]]
     assert np.abs(mjw.mjcf._compile_mesh(v)["pos"]).max() < 1e-12
-  with pytest.raises(NotImplementedError, match="multi-contact"):
-    mjw.put_model(mjw.mjcf.from_xml_string(MESH_SCENE.replace('<flag multiccd="disable"/>', "")))
+  # polygon tables: the cube has 6 quads, every vertex belongs to 3 of them, vertices counter-clockwise seen from outside
+  assert a.mesh_polynum[0] == 6 and (a.mesh_polyvertnum[:6] == 4).all() and (a.mesh_polymapnum[:8] == 3).all()
+  v = a.mesh_vert[:8]
+  for p in range(6):
+    ids = a.mesh_polyvert[a.mesh_polyvertadr[p] : a.mesh_polyvertadr[p] + 4]
+    nrm = np.cross(v[ids[1]] - v[ids[0]], v[ids[2]] - v[ids[1]])
+    assert np.dot(nrm, a.mesh_polynormal[p]) > 0 and np.allclose(np.cross(nrm, a.mesh_polynormal[p]), 0, atol=1e-12)
 
 
 def test_oracle_mesh_cube_equals_box_primitive():
@@ -155,3 +186,80 @@ def test_gpu_mesh_scene_vs_oracle():
       ncon_seen.add(s.ncon)
     assert int(d.nacon.numpy()[0]) == nacon
   assert (d.overflow.numpy() == 0).all() and max(ncon_seen) >= 12
+
+
+MESH_STACK = """
+<mujoco>
+  <option timestep="0.004"/>
+  <asset>
+    <mesh name="slab" vertex="-.4 -.35 -.05  .4 -.35 -.05  -.4 .35 -.05  .4 .35 -.05  -.4 -.35 .05  .4 -.35 .05  -.4 .35 .05  .4 .35 .05"/>
+    <mesh name="wedge" vertex="0 0 0  .3 0 0  0 .2 0  .3 .2 0  0 0 .15  0 .2 .15"/>
+    <mesh name="prism" vertex=".1 0 -.08  -.05 .0866 -.08  -.05 -.0866 -.08  .1 0 .08  -.05 .0866 .08  -.05 -.0866 .08"/>
+  </asset>
+  <worldbody>
+    <geom type="plane" size="5 5 .1"/>
+    <body pos="0 0 .051"><freejoint/><geom type="mesh" mesh="slab"/></body>
+    <body pos=".05 .18 .183" euler="0 0 15"><freejoint/><geom type="box" size=".12 .1 .08"/></body>
+    <body pos=".2 -.2 .183" euler="0 0 5"><freejoint/><geom type="mesh" mesh="prism"/></body>
+    <body pos="-.35 -.3 .103" euler="0 0 10"><freejoint/><geom type="mesh" mesh="wedge"/></body>
+    <body pos=".06 .17 .3435" euler="0 0 -20"><freejoint/><geom type="mesh" mesh="prism"/></body>
+  </worldbody>
+</mujoco>
+"""
+# (every body rests with a whole face inside the face below it, so that the clipped polygons are the faces themselves: a polygon of five
+# vertices pruned to four by the reference's greedy search is ill-conditioned -- which four survive flips with rounding, DESIGN section 6)
+
+
+@pytest.mark.gpu
+def test_gpu_mesh_multicontact_vs_oracle():
+  """Multi-contact recovery on mesh faces (box on a mesh slab, prism and wedge meshes on it): contact counts per step identical to the
+  oracle's, positions / frames / distances of every contact within float32 noise, per-step state parity."""
+  mjm = mjw.mjcf.from_xml_string(MESH_STACK)
+  m = mjw.put_model(mjm)
+  assert m.npolygonmax == 4 and m.nmeshpoly == 6 + 5 + 5 and m.nmesh == 3
+  d = mjw.make_data(mjm, nworld=2, nconmax=64, njmax=256)
+  sims = [ref.RefSim(mjm, nconmax=64, njmax=256) for _ in range(2)]
+  q = d.qpos.numpy()
+  q[1, 7] += 0.01
+  d.qpos.assign(q)
+  sims[1].qpos[:] = q[1]
+  multi = mismatch = groups = 0
+  for step in range(120):
+    for w, s in enumerate(sims):
+      s.qpos[:] = d.qpos.numpy()[w]
+      s.qvel[:] = d.qvel.numpy()[w]
+      s.qacc_warmstart[:] = d.qacc_warmstart.numpy()[w]
+    mjw.step(m, d)
+    adr = 0
+    for w, s in enumerate(sims):
+      s.step()
+      n = int(d.ws_ncon.numpy()[w])
+      before = mismatch
+      groups += 1
+      if n != s.ncon:  # a face pair aligned within FACE_TOL (1.6 mrad) on one side only: 2 contacts instead of 4 (or the reverse) for a step
+        mismatch += 1
+        adr += n
+        assert relerr(d.qpos.numpy()[w], s.qpos) < 3e-3, (step, w)
+        continue
+      geoms = d.contact.geom.numpy()[adr : adr + n]
+      assert (geoms == s.con_geom[:n]).all()
+      gpos, gdist, gfr = d.contact.pos.numpy()[adr : adr + n], d.contact.dist.numpy()[adr : adr + n], d.contact.frame.numpy()[adr : adr + n].reshape(n, 9)
+      for g1, g2 in sorted(set(map(tuple, s.con_geom[:n]))):
+        sel = (s.con_geom[:n] == (g1, g2)).all(axis=1)
+        if g1 > 0 and int(sel.sum()) > 1:
+          multi += 1
+        groups += 1
+        # the contacts of a pair as a set: which four vertices of a clipped 5-gon survive the greedy quadrilateral search, and the order
+        # they come in, can flip with float32 rounding (DESIGN section 6, as for boxes); distance and normal are those of the EPA face
+        order_g = np.lexsort(np.round(gpos[sel], 4).T)
+        order_s = np.lexsort(np.round(s.con_pos[:n][sel], 4).T)
+        if np.abs(gpos[sel][order_g] - s.con_pos[:n][sel][order_s]).max() > 6e-4:
+          mismatch += 1
+          continue
+        assert np.abs(gdist[sel][order_g] - s.con_dist[:n][sel][order_s]).max() < 1e-4, (step, w)  # (float32 EPA on penetrations of ~1e-4: tests/test_convex.py)
+        assert np.abs(gfr[sel][order_g][:, :3] - s.con_frame[:n][sel][order_s][:, :3]).max() < 1e-2, (step, w)
+      adr += n
+      # (a step on which the two sides kept different vertices of a clipped polygon is solved with slightly different contact points)
+      assert relerr(d.qpos.numpy()[w], s.qpos) < (3e-4 if mismatch == before else 3e-3), (step, w)
+  assert multi > 200 and (d.overflow.numpy() == 0).all()
+  assert mismatch <= 0.03 * groups, (mismatch, groups)
