@@ -142,6 +142,8 @@ typedef struct MjhModel {
   const int* geom_dataid;       /* [ngeom] mesh id of mesh geoms, -1 otherwise (types.py:1266)                  */
   const int* mesh_vertadr; const int* mesh_vertnum; /* [nmesh] first vertex / number of vertices (types.py:1707-1709) */
   const float* mesh_vert;       /* [nmeshvert, 3] vertices in the mesh (= geom) frame; searched exhaustively by the convex narrowphase */
+  const int* mesh_graphadr;     /* [nmesh] first word of the mesh's hill-climbing graph in mesh_graph, -1: none (types.py: mesh_graphadr) */
+  const int* mesh_graph;        /* MuJoCo's layout: numvert, numface, vert_edgeadr[numvert], vert_globalid[numvert], edge_localid[...], face_globalid[...] */
   /* mesh polygon tables for the multi-contact recovery on mesh faces (types.py:1710-1733; csrc/convex.hpp ccd_multicontact_mesh) */
   int nmeshpoly;                /* polygons of all meshes; 0: no tables (mesh pairs then keep EPA's single contact)           */
   int npolygonmax;              /* the clip buffers hold 2 * npolygonmax points (collision_convex.py:1226-1234)               */
@@ -308,7 +310,7 @@ int mjh_timed_steps(const MjhModel* m, const MjhData* d, int nstep, int step0, f
 int mjh_release_thread_resources(void);
 
 const char* mjh_last_error(void);
-#define MJH_ABI_VERSION 18
+#define MJH_ABI_VERSION 19
 int mjh_abi_version(void); /* returns MJH_ABI_VERSION of the library that was loaded */
 
 #ifdef __cplusplus

@@ -503,7 +503,8 @@ template <class Emit>
 DEV void collide_convex(float tolerance, int iterations, int epa_iterations, int t1, int t2, V3 p1, const float* R1, V3 s1, V3 p2, const float* R2, V3 s2, float margin,
                         float gap, float* scratch, int& overflow, Emit&& emit, const float* vert1 = nullptr, int nvert1 = 0, const float* vert2 = nullptr, int nvert2 = 0,
                         const MjhModel* mm = nullptr, int mesh1 = -1, int mesh2 = -1) {
-  const CcdGeom a = CcdGeom{t1, p1, R1, s1, margin, vert1, nvert1, -1, mesh1}, b = CcdGeom{t2, p2, R2, s2, margin, vert2, nvert2, -1, mesh2};
+  auto graph_of = [&](int meshid) -> const int* { return (mm && meshid >= 0 && mm->mesh_graphadr[meshid] >= 0) ? mm->mesh_graph + mm->mesh_graphadr[meshid] : nullptr; };
+  const CcdGeom a = CcdGeom{t1, p1, R1, s1, margin, vert1, nvert1, -1, mesh1, graph_of(mesh1), -1}, b = CcdGeom{t2, p2, R2, s2, margin, vert2, nvert2, -1, mesh2, graph_of(mesh2), -1};
   float dist;
   V3 w1, w2;
   int face;
@@ -530,12 +531,55 @@ DEV void collide_convex(float tolerance, int iterations, int epa_iterations, int
 // fewer than 10 vertices): the deepest vertex a, then among the vertices within 1 mm of it the one furthest from a, the one furthest
 // from the line a-b and the one furthest from the other two edges; vertices that were picked once become contacts (at most 4)
 template <class Emit>
-DEV void plane_mesh(V3 pn, V3 pp, V3 mp, const float* R, const float* vert, int nvert, Emit&& emit) {
+DEV void plane_mesh(V3 pn, V3 pp, V3 mp, const float* R, const float* vert, int nvert, Emit&& emit, const int* graph = nullptr) {
   const float HUGE_V = 1e6f;
   const V3 pl = matT_mul(R, pp - mp), nl = matT_mul(R, pn);
   int idx[4] = {-1, -1, -1, -1};
   float max_support = -HUGE_V;
   V3 a = V3{0, 0, 0}, b = a, c = a;
+  if (graph && nvert >= 10) {
+    // collision_primitive.py:131-243: the same four picks by hill climbing on the hull's vertex graph, each climb starting where the
+    // previous one ended (local maxima along the graph; no early exit for a separated mesh, unlike the exhaustive branch)
+    const int numvert = graph[0];
+    const int *edgeadr = graph + 2, *globalid = graph + 2 + numvert, *edge = graph + 2 + 2 * numvert;
+    int imax = 0, prev;
+    float threshold = 0.0f;
+    V3 ab = a, ac = a, bc = a;
+    auto climb = [&](auto&& score) {  // score(vertex) -> value to maximise; the running best persists across the sweeps of one climb
+      float best = -HUGE_V;
+      do {
+        prev = imax;
+        for (int i = edgeadr[imax]; edge[i] >= 0; ++i) {
+          const float dd = score(ld3(vert + 3 * globalid[edge[i]]));
+          if (dd > best) {
+            best = dd;
+            imax = edge[i];
+          }
+        }
+      } while (imax != prev);
+      return best;
+    };
+    max_support = climb([&](V3 v) { return dot(pl - v, nl); });
+    threshold = fmaxf(0.0f, max_support - 1e-3f);
+    auto mask = [&](V3 v) { return dot(pl - v, nl) > threshold ? 0.0f : -HUGE_V; };
+    climb([&](V3 v) {
+      const float sup = dot(pl - v, nl);
+      return sup > threshold ? sup : -HUGE_V;
+    });
+    idx[0] = globalid[imax];
+    a = ld3(vert + 3 * idx[0]);
+    climb([&](V3 v) { return dot(a - v, a - v) + mask(v); });
+    idx[1] = globalid[imax];
+    b = ld3(vert + 3 * idx[1]);
+    ab = cross(nl, a - b);
+    climb([&](V3 v) { return fabsf(dot(a - v, ab)) + mask(v); });
+    idx[2] = globalid[imax];
+    c = ld3(vert + 3 * idx[2]);
+    ac = cross(nl, a - c);
+    bc = cross(nl, b - c);
+    climb([&](V3 v) { return (fabsf(dot(a - v, ac)) + mask(v)) + (fabsf(dot(b - v, bc)) + mask(v)); });
+    idx[3] = globalid[imax];
+  } else {
   for (int i = 0; i < nvert; ++i) {
     const V3 v = ld3(vert + 3 * i);
     const float sup = dot(pl - v, nl);
@@ -581,6 +625,7 @@ DEV void plane_mesh(V3 pn, V3 pp, V3 mp, const float* R, const float* vert, int 
       best = dd;
     }
   }
+  }
   const Frame f = make_frame3(pn);
   int n = 0;
   for (int i = 3; i >= 0; --i) {
@@ -595,12 +640,12 @@ DEV void plane_mesh(V3 pn, V3 pp, V3 mp, const float* R, const float* vert, int 
 
 template <bool HEAVY, class Emit>
 DEV void collide_pair(int t1, int t2, V3 p1, const float* R1, V3 s1, V3 p2, const float* R2, V3 s2, float margin, Emit&& emit, const float* vert2 = nullptr,
-                      int nvert2 = 0) {
+                      int nvert2 = 0, const int* graph2 = nullptr) {
   V3 ax1 = V3{R1[2], R1[5], R1[8]}, ax2 = V3{R2[2], R2[5], R2[8]};
   float dist;
   V3 pos, nn;
   if (HEAVY && t1 == G_PLANE && t2 == G_MESH) {
-    plane_mesh(ax1, p1, p2, R2, vert2, nvert2, emit);
+    plane_mesh(ax1, p1, p2, R2, vert2, nvert2, emit, graph2);
   } else if (t1 == G_PLANE && t2 == G_SPHERE) {
     plane_sphere(ax1, p1, p2, s2.x, dist, pos);
     const Frame f = make_frame3(ax1);
@@ -1086,6 +1131,11 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
       nvert = m.mesh_vertnum[id];
     }
   };
+  auto graph_of_geom = [&](int g, int t) -> const int* {
+    if (!HEAVY || t != G_MESH) return nullptr;
+    const int adr = m.mesh_graphadr[m.geom_dataid[g]];
+    return adr >= 0 ? m.mesh_graph + adr : nullptr;
+  };
   // EPA polytope of this lane (convex.hpp): word k of lane l at k * 32 + l inside the world's slice of d.ws_ccd
   float* ccd_scratch = (HEAVY && d.ws_ccd) ? d.ws_ccd + (size_t)w * ccd_words(max(m.ccd_iterations, m.epa_iterations)) * CCD_LANES + (lig & (CCD_LANES - 1)) : nullptr;
   const float ccd_tol = HEAVY ? bf(m.opt_ccd_tolerance, m.opt_ccd_tolerance_nb, w, 1)[0] : 0.0f;
@@ -1134,7 +1184,7 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
       }
       else
         collide_pair<HEAVY>(t1, t2, ld3(gxpos + 3 * g1), gxmat + 9 * g1, ld3(gsize + 3 * g1), ld3(gxpos + 3 * g2), gxmat + 9 * g2,
-                            ld3(gsize + 3 * g2), margin, count, mv2, mn2);
+                            ld3(gsize + 3 * g2), margin, count, mv2, mn2, graph_of_geom(g2, t2));
     }
     const int nk = __popc(mask);
     int incl = nk;
@@ -1223,7 +1273,7 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
         int mn2;
         mesh_of(g2, t2, mv2, mn2);
         collide_pair<HEAVY>(t1, t2, ld3(gxpos + 3 * g1), gxmat + 9 * g1, ld3(gsize + 3 * g1), ld3(gxpos + 3 * g2), gxmat + 9 * g2,
-                            ld3(gsize + 3 * g2), margin, write, mv2, mn2);
+                            ld3(gsize + 3 * g2), margin, write, mv2, mn2, graph_of_geom(g2, t2));
       }
     }
     gsync();

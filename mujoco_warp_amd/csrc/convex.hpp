@@ -48,6 +48,8 @@ struct CcdGeom {
   int nvert;
   int index;  // mesh: vertex of the last support call (warm start: wins ties), -1 at the start (reference Geom.index)
   int meshid;  // mesh: Model.geom_dataid (polygon tables for the multi-contact recovery), -1 otherwise
+  const int* graph;  // mesh: its block of Model.mesh_graph (hill climbing for meshes of 10 or more vertices) or nullptr
+  int cache;  // out of ccd_support: SupportPoint.cached_index (a vertex id on the exhaustive path, a graph-local id when hill climbing)
 };
 struct GjkOut {
   bool separated;
@@ -75,7 +77,7 @@ DEV V3 ccd_support(const CcdGeom& g, V3 dir, int& vid) {
   } else if (g.type == G_ELLIPSOID) {
     r = normalize(V3{l.x * g.size.x, l.y * g.size.y, l.z * g.size.z});
     r = V3{r.x * g.size.x, r.y * g.size.y, r.z * g.size.z};
-  } else if (g.type == G_MESH) {  // collision_gjk.py:154-169: exhaustive vertex search, the cached vertex first
+  } else if (g.type == G_MESH && (!g.graph || g.nvert < 10)) {  // collision_gjk.py:154-169: exhaustive vertex search, the cached vertex first
     float best = -CCD_FLOAT_MAX;
     if (g.index > -1) {
       vid = g.index;
@@ -88,6 +90,25 @@ DEV V3 ccd_support(const CcdGeom& g, V3 dir, int& vid) {
         vid = i;
       }
     }
+    const_cast<CcdGeom&>(g).cache = vid;
+    r = ld3(g.vert + 3 * vid);
+  } else if (g.type == G_MESH) {  // collision_gjk.py:170-196: hill climbing on the hull's vertex graph from the cached vertex
+    const int numvert = g.graph[0];
+    const int *edgeadr = g.graph + 2, *globalid = g.graph + 2 + numvert, *edge = g.graph + 2 + 2 * numvert;
+    int prev = -1, imax = g.index > -1 ? g.index : 0;
+    float best = dot(l, ld3(g.vert + 3 * globalid[imax]));
+    while (imax != prev) {
+      prev = imax;
+      for (int i = edgeadr[imax]; edge[i] >= 0; ++i) {
+        const float dd = dot(l, ld3(g.vert + 3 * globalid[edge[i]]));
+        if (dd > best) {
+          best = dd;
+          imax = edge[i];
+        }
+      }
+    }
+    const_cast<CcdGeom&>(g).cache = imax;
+    vid = globalid[imax];
     r = ld3(g.vert + 3 * vid);
   } else if (g.type == G_CYLINDER) {
     const float dd = sqrtf(l.x * l.x + l.y * l.y);
@@ -272,8 +293,8 @@ DEV void ccd_gjk(float tolerance, int iterations, const CcdGeom& g1, const CcdGe
     }
     int v1, v2;
     const V3 p1 = ccd_support(g1, -dneg, v1), p2 = ccd_support(g2, dneg, v2);
-    const_cast<CcdGeom&>(g1).index = v1;  // collision_gjk.py:675-680 (only meshes read it)
-    const_cast<CcdGeom&>(g2).index = v2;
+    const_cast<CcdGeom&>(g1).index = g1.cache;  // collision_gjk.py:675-680 (only meshes read it)
+    const_cast<CcdGeom&>(g2).index = g2.cache;
     const V3 sn = p1 - p2;
     // slot n of the simplex (static indexing: the arrays stay in registers)
 #pragma unroll
@@ -568,8 +589,8 @@ DEV int ccd_epa(float tolerance, int iterations, Poly& pt, const CcdGeom& g1, co
     const int wi = pt.nvert;
     const V3 fpr = pt.fpr(idx);
     poly_support(pt, wi, g1, g2, fpr * (1.0f / lower));
-    const_cast<CcdGeom&>(g1).index = pt.vidx(2 * wi);  // collision_gjk.py:1370-1373
-    const_cast<CcdGeom&>(g2).index = pt.vidx(2 * wi + 1);
+    const_cast<CcdGeom&>(g1).index = g1.cache;  // collision_gjk.py:1370-1373
+    const_cast<CcdGeom&>(g2).index = g2.cache;
     const V3 w = pt.diff(wi);
     pt.nvert++;
     const float upper_k = dot(fpr, w) / lower;

@@ -182,10 +182,6 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
         mid = int(np.asarray(getattr(mjm, "geom_dataid", np.full(len(gt), -1)))[g])
         if mid < 0 or not hasattr(mjm, "mesh_vert"):
           raise NotImplementedError("colliding mesh geom without mesh vertices (Model.mesh_vert / geom_dataid)")
-        gadr = np.asarray(getattr(mjm, "mesh_graphadr", np.full(mid + 1, -1)))
-        if int(gadr[mid]) >= 0 and int(np.asarray(mjm.mesh_vertnum)[mid]) >= 10:
-          raise NotImplementedError("meshes with a hill-climbing graph and 10 or more vertices (collision_gjk.py:170-196, collision_primitive.py:131-243) "
-                                    "are not implemented: only the exhaustive vertex search is")
       if t in ((6, 7), (7, 7)) and not (int(opt.disableflags) & int(types.DisableBit.MULTICCD)):
         # multi-contact recovery on mesh faces (collision_gjk.py:2076): features of up to 8 normals / polygon vertices (csrc/convex.hpp MC_GN)
         pv, pm = np.asarray(getattr(mjm, "mesh_polyvertnum", np.zeros(0))), np.asarray(getattr(mjm, "mesh_polymapnum", np.zeros(0)))
@@ -352,6 +348,7 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
     geom_priority=_arr(mjm.geom_priority, i32), geom_dataid=_arr(getattr(mjm, "geom_dataid", np.full(ngeom, -1)), i32),
     mesh_vertadr=_arr(getattr(mjm, "mesh_vertadr", np.zeros(0)), i32), mesh_vertnum=_arr(getattr(mjm, "mesh_vertnum", np.zeros(0)), i32),
     mesh_vert=_arr(getattr(mjm, "mesh_vert", np.zeros((0, 3))), f32).reshape(-1, 3),
+    mesh_graphadr=_arr(getattr(mjm, "mesh_graphadr", np.full(int(getattr(mjm, "nmesh", 0)), -1)), i32), mesh_graph=_arr(getattr(mjm, "mesh_graph", np.zeros(0)), i32),
     mesh_polyadr=_arr(getattr(mjm, "mesh_polyadr", np.zeros(0)), i32), mesh_polynormal=_arr(getattr(mjm, "mesh_polynormal", np.zeros((0, 3))), f32).reshape(-1, 3),
     mesh_polyvertadr=_arr(getattr(mjm, "mesh_polyvertadr", np.zeros(0)), i32), mesh_polyvertnum=_arr(getattr(mjm, "mesh_polyvertnum", np.zeros(0)), i32),
     mesh_polyvert=_arr(getattr(mjm, "mesh_polyvert", np.zeros(0)), i32), mesh_polymapadr=_arr(getattr(mjm, "mesh_polymapadr", np.zeros(0)), i32),
@@ -370,6 +367,7 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
   )
   m.nmeshvert = int(host["mesh_vert"].shape[0])
   m.nmeshpoly = int(host["mesh_polyvertnum"].shape[0])
+  m.nmeshgraph = int(host["mesh_graph"].shape[0])
   m.nmeshpolyvert, m.nmeshpolymap = int(host["mesh_polyvert"].shape[0]), int(host["mesh_polymap"].shape[0])
   # clip buffers of the multi-contact recovery: 2 * npolygonmax points (reference collision_convex.py:1226-1234)
   nboxmesh, nmeshmesh = sum(t == (6, 7) for t in ptypes), sum(t == (7, 7) for t in ptypes)

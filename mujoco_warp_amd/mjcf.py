@@ -557,8 +557,9 @@ def _compile_mesh(verts):
   convex hull, volume / centre of mass / inertia of the hull (uniform density), vertices re-expressed in the frame centred at the
   centre of mass and aligned with the principal axes (the geom frame is composed with that offset).  UNPINNED like the rest of this
   loader (MuJoCo's compiler is not in the reference tree); the axis order / signs of the principal frame are this module's own
-  (descending moments, right handed): the physics does not depend on them.  No hill-climbing graph is built (mesh_graphadr = -1:
-  the engine then searches vertices exhaustively, the reference's path for such meshes, collision_gjk.py:156)."""
+  (descending moments, right handed): the physics does not depend on them.  The hull's vertex adjacency is stored as a hill-climbing
+  graph in MuJoCo's layout (meshes of 10 or more vertices are then searched by hill climbing, smaller ones exhaustively:
+  collision_gjk.py:156)."""
   from scipy.spatial import ConvexHull
 
   verts = np.asarray(verts, dtype=np.float64).reshape(-1, 3)
@@ -585,8 +586,8 @@ def _compile_mesh(verts):
   w, v = w[order], v[:, order]
   if np.linalg.det(v) < 0:
     v[:, 2] = -v[:, 2]
-  local = (verts - centre - com) @ v
-  lo, hi = local.min(axis=0), local.max(axis=0)
+  vlocal = (verts - centre - com) @ v
+  lo, hi = vlocal.min(axis=0), vlocal.max(axis=0)
   # polygon tables for multi-contact recovery (Model.mesh_poly*, types.py:1707-1733): coplanar hull triangles merged into convex
   # polygons, vertices counter-clockwise seen from outside; per vertex the polygons it belongs to
   groups = []
@@ -609,8 +610,24 @@ def _compile_mesh(verts):
     polys.append([ids[i] for i in np.argsort(ang)])
     normals.append(gr["n"] @ v)  # in the mesh frame
   polymap = [[p for p, poly in enumerate(polys) if i in poly] for i in range(len(verts))]
-  return dict(vert=local, pos=centre + com, quat=nm.mat_to_quat(v), vol=vol, unit=w / vol, aabb=np.concatenate([(lo + hi) / 2, (hi - lo) / 2]),
-              rbound=float(np.max(np.linalg.norm(local, axis=1))), polys=polys, polynormal=np.array(normals), polymap=polymap)
+  # hill-climbing graph in MuJoCo's mesh_graph layout (numvert, numface, vert_edgeadr[numvert], vert_globalid[numvert],
+  # edge_localid[numvert + 3 numface] = neighbours of each hull vertex as local ids, -1 terminated, face_globalid[3 numface]); consumed by
+  # reference collision_gjk.py:170-196 and collision_primitive.py:131-243 for meshes of 10 or more vertices
+  hv = [int(i) for i in hull.vertices]
+  local = {g: l for l, g in enumerate(hv)}
+  nbr = [set() for _ in hv]
+  for tri in hull.simplices:
+    for a_, b_ in ((0, 1), (1, 2), (2, 0)):
+      nbr[local[int(tri[a_])]].add(local[int(tri[b_])])
+      nbr[local[int(tri[b_])]].add(local[int(tri[a_])])
+  edgeadr, edges = [], []
+  for l in range(len(hv)):
+    edgeadr.append(len(edges))
+    edges.extend(sorted(nbr[l]))
+    edges.append(-1)
+  graph = [len(hv), len(hull.simplices)] + edgeadr + hv + edges + [int(i) for tri in hull.simplices for i in tri]
+  return dict(vert=vlocal, pos=centre + com, quat=nm.mat_to_quat(v), vol=vol, unit=w / vol, aabb=np.concatenate([(lo + hi) / 2, (hi - lo) / 2]),
+              rbound=float(np.max(np.linalg.norm(vlocal, axis=1))), polys=polys, polynormal=np.array(normals), polymap=polymap, graph=graph)
 
 
 class _Body:
@@ -997,9 +1014,10 @@ def _compile(root, base_dir):
   m.mesh_vertadr = np.concatenate([[0], np.cumsum(m.mesh_vertnum)[:-1]]).astype(np.int32) if mesh_names else np.zeros(0, dtype=np.int32)
   m.mesh_vert = np.concatenate([mesh_compiled[n]["vert"] for n in mesh_names]).reshape(-1, 3) if mesh_names else np.zeros((0, 3))
   m.nmeshvert = len(m.mesh_vert)
-  m.mesh_graphadr = np.full(m.nmesh, -1, dtype=np.int32)
-  m.mesh_graph = np.zeros(0, dtype=np.int32)
   mds = [mesh_compiled[n] for n in mesh_names]
+  glen = [len(md["graph"]) for md in mds]
+  m.mesh_graphadr = np.concatenate([[0], np.cumsum(glen)[:-1]]).astype(np.int32) if mds else np.zeros(0, dtype=np.int32)
+  m.mesh_graph = np.array([x for md in mds for x in md["graph"]], dtype=np.int32)
   m.mesh_polynum = np.array([len(md["polys"]) for md in mds], dtype=np.int32)
   m.mesh_polyadr = np.concatenate([[0], np.cumsum(m.mesh_polynum)[:-1]]).astype(np.int32) if mds else np.zeros(0, dtype=np.int32)
   m.mesh_polynormal = np.concatenate([md["polynormal"] for md in mds]).reshape(-1, 3) if mds else np.zeros((0, 3))

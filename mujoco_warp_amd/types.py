@@ -415,6 +415,9 @@ class Model(_Dirty):
   nmeshpolyvert: int = 0
   nmeshpolymap: int = 0
   npolygonmax: int = 0
+  nmeshgraph: int = 0
+  mesh_graphadr: DeviceArray = _arr(('nmesh',), "int32")
+  mesh_graph: DeviceArray = _arr(('nmeshgraph',), "int32")
   mesh_polyadr: DeviceArray = _arr(('nmesh',), "int32")
   mesh_polynormal: DeviceArray = _arr(('nmeshpoly', 3), "float32")
   mesh_polyvertadr: DeviceArray = _arr(('nmeshpoly',), "int32")

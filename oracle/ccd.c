@@ -27,7 +27,11 @@ typedef struct CcdGeom {
   double pos[3], rot[9], size[3], margin;
   const double* vert; /* mesh: vertices in the geom frame */
   int nvert;
-  int index;          /* mesh: vertex of the last support call (warm start: wins ties), -1 at the start (Geom.index) */
+  int index;          /* mesh: cache of the last support call (warm start), -1 at the start (Geom.index): a vertex id on the exhaustive
+                         path, a graph-local vertex id on the hill-climbing path */
+  int cache;          /* out of ccd_support: SupportPoint.cached_index */
+  const int* graph;   /* mesh: hill-climbing graph (MuJoCo's mesh_graph block of this mesh: numvert, numface, vert_edgeadr[numvert],
+                         vert_globalid[numvert], edge_localid[numvert + 3 numface], ...) or NULL */
   /* mesh polygon tables for multi-contact recovery (types.py:1707-1733), already offset to this mesh; NULL when absent */
   const double* polynormal; /* [npoly, 3] */
   const int* polyvertadr;   /* [npoly] into polyvert (global array) */
@@ -71,7 +75,7 @@ static int ccd_support(const CcdGeom* g, const double* dir, double* out) {
     for (int k = 0; k < 3; k++) r[k] = l[k] * g->size[k];
     v3normalize(r);
     for (int k = 0; k < 3; k++) r[k] *= g->size[k];
-  } else if (g->type == G_MESH) { /* 154-169: exhaustive search, the cached vertex first */
+  } else if (g->type == G_MESH && (!g->graph || g->nvert < 10)) { /* 154-169: exhaustive search, the cached vertex first */
     double best = -CCD_FLOAT_MAX;
     if (g->index > -1) {
       vid = g->index;
@@ -81,6 +85,22 @@ static int ccd_support(const CcdGeom* g, const double* dir, double* out) {
       double dd = v3dot(g->vert + 3 * i, l);
       if (dd > best) { best = dd; vid = i; }
     }
+    ((CcdGeom*)g)->cache = vid;
+    v3cpy(r, g->vert + 3 * vid);
+  } else if (g->type == G_MESH) { /* 170-196: hill climbing on the hull's vertex graph from the cached vertex */
+    int numvert = g->graph[0];
+    const int *edgeadr = g->graph + 2, *globalid = g->graph + 2 + numvert, *edge = g->graph + 2 + 2 * numvert;
+    int prev = -1, imax = g->index > -1 ? g->index : 0;
+    double best = v3dot(l, g->vert + 3 * globalid[imax]);
+    while (imax != prev) {
+      prev = imax;
+      for (int i = edgeadr[imax]; edge[i] >= 0; i++) {
+        double dd = v3dot(l, g->vert + 3 * globalid[edge[i]]);
+        if (dd > best) { best = dd; imax = edge[i]; }
+      }
+    }
+    ((CcdGeom*)g)->cache = imax;
+    vid = globalid[imax];
     v3cpy(r, g->vert + 3 * vid);
   } else if (g->type == G_CYLINDER) {
     double d = sqrt(l[0] * l[0] + l[1] * l[1]);
@@ -268,8 +288,8 @@ static void ccd_gjk(double tolerance, int iterations, const CcdGeom* g1, const C
     for (int k = 0; k < 3; k++) dpos[k] = -dneg[k];
     res->i1[n] = ccd_support(g1, dpos, res->s1[n]);
     res->i2[n] = ccd_support(g2, dneg, res->s2[n]);
-    ((CcdGeom*)g1)->index = res->i1[n]; /* 675-680 (only meshes read it) */
-    ((CcdGeom*)g2)->index = res->i2[n];
+    ((CcdGeom*)g1)->index = g1->cache; /* 675-680 (only meshes read it) */
+    ((CcdGeom*)g2)->index = g2->cache;
     v3sub(res->s[n], res->s1[n], res->s2[n]);
     double gap[3];
     v3sub(gap, xk, res->s[n]);
@@ -538,8 +558,8 @@ static int ccd_epa(double tolerance, int iterations, Polytope* pt, const CcdGeom
     int wi = pt->nvert;
     for (int k = 0; k < 3; k++) dir[k] = pt->fpr[idx][k] / lower;
     pt_support(pt, wi, g1, g2, dir);
-    ((CcdGeom*)g1)->index = pt->vidx[2 * wi]; /* 1370-1373 */
-    ((CcdGeom*)g2)->index = pt->vidx[2 * wi + 1];
+    ((CcdGeom*)g1)->index = g1->cache; /* 1370-1373 */
+    ((CcdGeom*)g2)->index = g2->cache;
     pt_diff(pt, wi, w);
     pt->nvert++;
     double upper_k = v3dot(pt->fpr[idx], w) / lower;

@@ -1073,6 +1073,10 @@ static void mesh_of(const RefModel* m, int g, const double** vert, int* nvert) {
     *nvert = m->mesh_vertnum[id];
   }
 }
+static const int* mesh_graph_of(const RefModel* m, int g) { /* the mesh's block of mesh_graph, NULL without one */
+  if (m && g >= 0 && m->geom_type[g] == G_MESH && m->mesh_graphadr[m->geom_dataid[g]] >= 0) return m->mesh_graph + m->mesh_graphadr[m->geom_dataid[g]];
+  return NULL;
+}
 static void mesh_poly_of(const RefModel* m, int g, CcdGeom* c) { /* polygon tables, offset to the geom's mesh */
   c->polynormal = NULL;
   c->polyvertadr = c->polyvertnum = c->polyvert = c->polymapadr = c->polymapnum = c->polymap = NULL;
@@ -1105,7 +1109,9 @@ static int ccd_contact(const RefModel* m, int g1, int g2, int t1, const double* 
   mesh_poly_of(m, g1, &a);
   mesh_poly_of(m, g2, &b);
   g_mc_cap = 2 * m->npolygonmax;
-  a.index = b.index = -1;
+  a.index = b.index = a.cache = b.cache = -1;
+  a.graph = mesh_graph_of(m, g1);
+  b.graph = mesh_graph_of(m, g2);
   v3cpy(a.pos, p1); v3cpy(b.pos, p2);
   memcpy(a.rot, R1, sizeof(a.rot)); memcpy(b.rot, R2, sizeof(b.rot));
   v3cpy(a.size, s1); v3cpy(b.size, s2);
@@ -1158,6 +1164,82 @@ static int collide_pair(const RefModel* m, RefData* d, int g1, int g2, double ma
     matT_mul_vec(pl, R2, dif);
     matT_mul_vec(nl, R2, ax1);
     double max_support = -HUGE_V, a[3] = {0, 0, 0}, b[3] = {0, 0, 0}, c[3] = {0, 0, 0}, t[3];
+    const int* graph = mesh_graph_of(m, g2);
+    if (graph && nvert >= 10) {
+      /* collision_primitive.py:131-243: the same four picks by hill climbing on the hull's vertex graph, each climb starting where the
+         previous one ended (the results are local maxima along the graph, not the exhaustive branch's global ones) */
+      int numvert = graph[0];
+      const int *edgeadr = graph + 2, *globalid = graph + 2 + numvert, *edge = graph + 2 + 2 * numvert;
+      int imax = 0, prev;
+      do { /* deepest vertex */
+        prev = imax;
+        for (int i = edgeadr[imax]; edge[i] >= 0; i++) {
+          v3sub(t, pl, vert + 3 * globalid[edge[i]]);
+          double sup = v3dot(t, nl);
+          if (sup > max_support) { max_support = sup; imax = edge[i]; }
+        }
+      } while (imax != prev);
+      double threshold = fmax(0.0, max_support - 1e-3), best = -HUGE_V;
+      do { /* a: deepest among the vertices above the threshold (the climb may start on a vertex that was never scored) */
+        prev = imax;
+        for (int i = edgeadr[imax]; edge[i] >= 0; i++) {
+          v3sub(t, pl, vert + 3 * globalid[edge[i]]);
+          double sup = v3dot(t, nl), dd = sup > threshold ? sup : -HUGE_V;
+          if (dd > best) { best = dd; imax = edge[i]; }
+        }
+      } while (imax != prev);
+      idx[0] = globalid[imax];
+      v3cpy(a, vert + 3 * idx[0]);
+      best = -HUGE_V;
+      do { /* b: furthest from a */
+        prev = imax;
+        for (int i = edgeadr[imax]; edge[i] >= 0; i++) {
+          const double* v = vert + 3 * globalid[edge[i]];
+          v3sub(t, pl, v);
+          double mask = v3dot(t, nl) > threshold ? 0.0 : -HUGE_V;
+          v3sub(t, a, v);
+          double dd = v3dot(t, t) + mask;
+          if (dd > best) { best = dd; imax = edge[i]; }
+        }
+      } while (imax != prev);
+      idx[1] = globalid[imax];
+      v3cpy(b, vert + 3 * idx[1]);
+      double ab[3], ac[3], bc[3];
+      v3sub(t, a, b);
+      v3cross(ab, nl, t);
+      best = -HUGE_V;
+      do { /* c: furthest from the line a-b */
+        prev = imax;
+        for (int i = edgeadr[imax]; edge[i] >= 0; i++) {
+          const double* v = vert + 3 * globalid[edge[i]];
+          v3sub(t, pl, v);
+          double mask = v3dot(t, nl) > threshold ? 0.0 : -HUGE_V;
+          v3sub(t, a, v);
+          double dd = fabs(v3dot(t, ab)) + mask;
+          if (dd > best) { best = dd; imax = edge[i]; }
+        }
+      } while (imax != prev);
+      idx[2] = globalid[imax];
+      v3cpy(c, vert + 3 * idx[2]);
+      v3sub(t, a, c);
+      v3cross(ac, nl, t);
+      v3sub(t, b, c);
+      v3cross(bc, nl, t);
+      best = -HUGE_V;
+      do { /* d: furthest from the other two edges */
+        prev = imax;
+        for (int i = edgeadr[imax]; edge[i] >= 0; i++) {
+          const double* v = vert + 3 * globalid[edge[i]];
+          v3sub(t, pl, v);
+          double mask = v3dot(t, nl) > threshold ? 0.0 : -HUGE_V, ap[3], bp[3];
+          v3sub(ap, a, v);
+          v3sub(bp, b, v);
+          double dd = fabs(v3dot(ap, ac)) + mask + fabs(v3dot(bp, bc)) + mask;
+          if (dd > best) { best = dd; imax = edge[i]; }
+        }
+      } while (imax != prev);
+      idx[3] = globalid[imax];
+    } else {
     for (int i = 0; i < nvert; i++) {
       v3sub(t, pl, vert + 3 * i);
       double sup = v3dot(t, nl);
@@ -1195,6 +1277,7 @@ static int collide_pair(const RefModel* m, RefData* d, int g1, int g2, double ma
       v3sub(bp, b, vert + 3 * i);
       double dd = fabs(v3dot(ap, ac)) + mask + fabs(v3dot(bp, bc)) + mask;
       if (dd > best) { idx[3] = i; best = dd; }
+    }
     }
     for (int i = 3; i >= 0; i--) { /* vertices that appear once among indices[0..i] */
       int count = 0;
@@ -1619,7 +1702,8 @@ int ref_ccd_mesh(int type1, const double* pos1, const double* mat1, const double
   v3cpy(a.size, size1); v3cpy(b.size, size2);
   a.margin = b.margin = margin;
   a.vert = vert1; a.nvert = nvert1; b.vert = vert2; b.nvert = nvert2;
-  a.index = b.index = -1;
+  a.index = b.index = a.cache = b.cache = -1;
+  a.graph = b.graph = NULL;
   mesh_poly_of(NULL, -1, &a);
   mesh_poly_of(NULL, -1, &b);
   g_mc_cap = 8;
@@ -1655,7 +1739,9 @@ int ref_ccd_geoms(const RefModel* m, int g1, int g2, const double* pos1, const d
   g_mc_cap = 8; /* (posed pairs need not be colliding pairs of the model: size the clip buffers from the two geoms, like the reference's harness) */
   for (int p = 0; p < m->nmeshpoly; p++)
     if (2 * m->mesh_polyvertnum[p] > g_mc_cap) g_mc_cap = 2 * m->mesh_polyvertnum[p];
-  a.index = b.index = -1;
+  a.index = b.index = a.cache = b.cache = -1;
+  a.graph = mesh_graph_of(m, g1);
+  b.graph = mesh_graph_of(m, g2);
   static Polytope pt;
   int face, overflow = 0;
   int n = ccd_run(tolerance, cutoff, iterations, iterations, a, b, out, out + 1, out + 4, &overflow, &face, &pt);

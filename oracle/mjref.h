@@ -145,6 +145,8 @@ typedef struct RefModel {
   int* mesh_vertadr;
   int* mesh_vertnum;
   double* mesh_vert;  /* [nmeshvert, 3] vertices in the mesh (= geom) frame */
+  int* mesh_graphadr; /* [nmesh] first word of the mesh's hill-climbing graph in mesh_graph, -1: none */
+  int* mesh_graph;
   int* mesh_polyadr;
   double* mesh_polynormal;
   int* mesh_polyvertadr;

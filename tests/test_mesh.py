@@ -6,8 +6,8 @@ Reference-held numbers reproduced by the float64 oracle (collision_gjk_test.py):
 penetration -0.01 (:405-439), the degenerate mesh pair -0.0031312597856874586 with one contact (:441-467), sphere-mesh with margin
 -0.001 (:648-665); collision_driver_test.py:691-711 (plane and a separated tetrahedron: no contact closer than 0.05).  The loader's
 mesh compilation (hull, centre of mass, principal frame) is pinned by a cube given as a mesh, which must equal the box primitive.
-Not built: multi-contact recovery on mesh faces (models must set multiccd="disable" for box-mesh / mesh-mesh pairs), hill-climbing
-support on meshes that carry a graph, mesh files.
+Multi-contact recovery on mesh faces (collision_gjk.py:2076) and the hill-climbing branches for meshes of 10 or more vertices follow
+further down.  Not built: mesh files, height fields.
 """
 
 import numpy as np
@@ -263,3 +263,108 @@ def test_gpu_mesh_multicontact_vs_oracle():
       assert relerr(d.qpos.numpy()[w], s.qpos) < (3e-4 if mismatch == before else 3e-3), (step, w)
   assert multi > 200 and (d.overflow.numpy() == 0).all()
   assert mismatch <= 0.03 * groups, (mismatch, groups)
+
+
+# ---- meshes of 10 or more vertices: hill climbing on the hull's vertex graph (collision_gjk.py:170-196, collision_primitive.py:131-243) ----
+_PHI = (1 + 5**0.5) / 2
+ICOSA = " ".join(f"{x * 0.08:.6f}" for v in ([0, 1, _PHI], [0, -1, _PHI], [0, 1, -_PHI], [0, -1, -_PHI], [1, _PHI, 0], [-1, _PHI, 0], [1, -_PHI, 0], [-1, -_PHI, 0],
+                                              [_PHI, 0, 1], [-_PHI, 0, 1], [_PHI, 0, -1], [-_PHI, 0, -1]) for x in v)
+CUBOCTA = " ".join(f"{x * 0.1:.6f}" for v in ([1, 1, 0], [1, -1, 0], [-1, 1, 0], [-1, -1, 0], [1, 0, 1], [1, 0, -1], [-1, 0, 1], [-1, 0, -1], [0, 1, 1], [0, 1, -1],
+                                              [0, -1, 1], [0, -1, -1]) for x in v)
+GRAPH_SCENE = f"""
+<mujoco>
+  <option timestep="0.004"/>
+  <asset><mesh name="ico" vertex="{ICOSA}"/><mesh name="cubo" vertex="{CUBOCTA}"/></asset>
+  <worldbody>
+    <geom type="plane" size="5 5 .1"/>
+    <body pos="0 0 .2" euler="20 10 0"><freejoint/><geom type="mesh" mesh="ico"/></body>
+    <body pos=".4 0 .2" euler="0 30 10"><freejoint/><geom type="mesh" mesh="cubo"/></body>
+    <body pos=".02 .01 .5" euler="50 0 20"><freejoint/><geom type="mesh" mesh="cubo"/></body>
+    <body pos=".41 .02 .5"><freejoint/><geom type="sphere" size=".07"/></body>
+    <body pos="-.4 0 .15"><freejoint/><geom type="box" size=".1 .1 .1"/></body>
+    <body pos="-.38 .03 .45" euler="0 40 0"><freejoint/><geom type="mesh" mesh="ico"/></body>
+    <body pos="0 .45 .2" euler="90 0 0"><freejoint/><geom type="capsule" size=".05 .12"/></body>
+    <body pos="0 .47 .45" euler="10 10 10"><freejoint/><geom type="mesh" mesh="ico"/></body>
+  </worldbody>
+</mujoco>
+"""
+
+
+def test_oracle_hill_climb_equals_exhaustive_support():
+  """On a convex mesh the graph walk ends at the global support vertex: GJK / EPA distances with the graph equal those of the exhaustive
+  search (mesh_graphadr = -1) on random poses; the loader's graph has MuJoCo's layout."""
+  mjm = mjw.mjcf.from_xml_string(GRAPH_SCENE)
+  assert mjm.mesh_vertnum.tolist() == [12, 12] and (mjm.mesh_graphadr >= 0).all()
+  g = mjm.mesh_graph[mjm.mesh_graphadr[0] :]
+  nv, nf = int(g[0]), int(g[1])
+  assert nv == 12 and nf == 20 and sorted(g[2 + nv : 2 + 2 * nv]) == list(range(12))
+  edges = g[2 + 2 * nv : 2 + 2 * nv + nv + 3 * nf]
+  assert (edges == -1).sum() == nv and all(int((edges[g[2 + l] :] == -1).argmax()) == 5 for l in range(nv))  # icosahedron: 5 neighbours each
+  a = ref.RefSim(mjm, nconmax=64, njmax=256)
+  nog = mjw.mjcf.from_xml_string(GRAPH_SCENE)
+  nog.mesh_graphadr[:] = -1
+  b = ref.RefSim(nog, nconmax=64, njmax=256)
+  rng = np.random.default_rng(5)
+  pairs = [(1, 2), (1, 3), (2, 6), (1, 4), (5, 6), (7, 8), (3, 8)]
+  n = 0
+  for trial in range(60):
+    for s in (a, b):
+      s.forward()
+    g1, g2 = pairs[trial % len(pairs)]
+    q = rng.normal(size=4)
+    R = nm.quat_to_mat(q / np.linalg.norm(q))
+    p2 = a.geom_xpos[g1] + rng.normal(size=3) * 0.09
+    da, na, _ = a.ccd_geoms(g1, g2, pos2=p2, mat2=R, multiccd=False)
+    db, nb, _ = b.ccd_geoms(g1, g2, pos2=p2, mat2=R, multiccd=False)
+    assert na == nb and abs(da - db) < 1e-9, (trial, da, db)
+    n += da < 0
+  assert n > 10
+
+
+def test_oracle_plane_mesh_hill_climb_contacts_are_low_vertices():
+  mjm = mjw.mjcf.from_xml_string(GRAPH_SCENE)
+  s = ref.RefSim(mjm, nconmax=64, njmax=256)
+  s.qpos[2] = 0.12  # icosahedron resting into the floor
+  s.forward()
+  cons = [c for c in range(s.ncon) if tuple(s.con_geom[c]) == (0, 1)]
+  assert 1 <= len(cons) <= 4
+  v = mjm.mesh_vert[:12] @ s.geom_xmat[1].reshape(3, 3).T + s.geom_xpos[1]
+  zmin = v[:, 2].min()
+  for c in cons:  # each contact is a vertex within 1 mm of the lowest one, reported midway between vertex and plane
+    k = int(np.argmin(np.linalg.norm(v[:, :2] - s.con_pos[c][:2], axis=1)))
+    assert np.linalg.norm(v[k, :2] - s.con_pos[c][:2]) < 1e-9 and abs(s.con_dist[c] - v[k, 2]) < 1e-9 and v[k, 2] < zmin + 1e-3
+    assert abs(s.con_pos[c][2] - 0.5 * v[k, 2]) < 1e-9
+  assert min(s.con_dist[c] for c in cons) == pytest.approx(zmin, abs=1e-9)
+
+
+@pytest.mark.gpu
+def test_gpu_graph_meshes_vs_oracle():
+  """12-vertex meshes (hill-climbing support and plane collider) against plane / sphere / box / capsule / mesh: per-step parity."""
+  mjm = mjw.mjcf.from_xml_string(GRAPH_SCENE)
+  m = mjw.put_model(mjm)
+  assert m.nmeshgraph == len(mjm.mesh_graph) > 0
+  d = mjw.make_data(mjm, nworld=2, nconmax=64, njmax=256)
+  sims = [ref.RefSim(mjm, nconmax=64, njmax=256) for _ in range(2)]
+  q = d.qpos.numpy()
+  q[1, 0::7] += 0.013
+  d.qpos.assign(q)
+  seen = set()
+  flicker = total = 0
+  for step in range(150):
+    for w, s in enumerate(sims):
+      s.qpos[:] = d.qpos.numpy()[w]
+      s.qvel[:] = d.qvel.numpy()[w]
+      s.qacc_warmstart[:] = d.qacc_warmstart.numpy()[w]
+    mjw.step(m, d)
+    for w, s in enumerate(sims):
+      s.step()
+      total += 1
+      if int(d.ws_ncon.numpy()[w]) != s.ncon:  # (plane_convex keeps the vertices within 1 mm of the deepest: a rocking mesh crosses that line)
+        flicker += 1
+        assert relerr(d.qpos.numpy()[w], s.qpos) < 3e-3, (step, w)
+        continue
+      assert relerr(d.qpos.numpy()[w], s.qpos) < 3e-4, (step, w)
+      seen |= set(map(tuple, s.con_geom[: s.ncon]))
+  assert flicker <= 0.03 * total, (flicker, total)
+  assert {(0, 1), (0, 2)} <= seen and len(seen) >= 6, seen
+  assert (d.overflow.numpy() == 0).all()
