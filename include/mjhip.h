@@ -142,6 +142,11 @@ typedef struct MjhModel {
   const int* geom_dataid;       /* [ngeom] mesh id of mesh geoms, -1 otherwise (types.py:1266)                  */
   const int* mesh_vertadr; const int* mesh_vertnum; /* [nmesh] first vertex / number of vertices (types.py:1707-1709) */
   const float* mesh_vert;       /* [nmeshvert, 3] vertices in the mesh (= geom) frame; searched exhaustively by the convex narrowphase */
+  /* height fields (types.py: hfield_*; geom_dataid of an hfield geom is its height field) */
+  int nhfield;
+  const float* hfield_size;     /* [nhfield, 4] x, y half sizes, top scale of the elevation data, base thickness */
+  const int* hfield_nrow; const int* hfield_ncol; const int* hfield_adr;
+  const float* hfield_data;     /* elevations normalised to [0, 1], row 0 at -y */
   const int* mesh_graphadr;     /* [nmesh] first word of the mesh's hill-climbing graph in mesh_graph, -1: none (types.py: mesh_graphadr) */
   const int* mesh_graph;        /* MuJoCo's layout: numvert, numface, vert_edgeadr[numvert], vert_globalid[numvert], edge_localid[...], face_globalid[...] */
   /* mesh polygon tables for the multi-contact recovery on mesh faces (types.py:1710-1733; csrc/convex.hpp ccd_multicontact_mesh) */
@@ -310,7 +315,7 @@ int mjh_timed_steps(const MjhModel* m, const MjhData* d, int nstep, int step0, f
 int mjh_release_thread_resources(void);
 
 const char* mjh_last_error(void);
-#define MJH_ABI_VERSION 19
+#define MJH_ABI_VERSION 20
 int mjh_abi_version(void); /* returns MJH_ABI_VERSION of the library that was loaded */
 
 #ifdef __cplusplus

@@ -504,7 +504,7 @@ DEV void collide_convex(float tolerance, int iterations, int epa_iterations, int
                         float gap, float* scratch, int& overflow, Emit&& emit, const float* vert1 = nullptr, int nvert1 = 0, const float* vert2 = nullptr, int nvert2 = 0,
                         const MjhModel* mm = nullptr, int mesh1 = -1, int mesh2 = -1) {
   auto graph_of = [&](int meshid) -> const int* { return (mm && meshid >= 0 && mm->mesh_graphadr[meshid] >= 0) ? mm->mesh_graph + mm->mesh_graphadr[meshid] : nullptr; };
-  const CcdGeom a = CcdGeom{t1, p1, R1, s1, margin, vert1, nvert1, -1, mesh1, graph_of(mesh1), -1}, b = CcdGeom{t2, p2, R2, s2, margin, vert2, nvert2, -1, mesh2, graph_of(mesh2), -1};
+  const CcdGeom a = CcdGeom{t1, p1, R1, s1, margin, vert1, nvert1, -1, mesh1, graph_of(mesh1), -1, nullptr}, b = CcdGeom{t2, p2, R2, s2, margin, vert2, nvert2, -1, mesh2, graph_of(mesh2), -1, nullptr};
   float dist;
   V3 w1, w2;
   int face;
@@ -636,6 +636,143 @@ DEV void plane_mesh(V3 pn, V3 pp, V3 mp, const float* R, const float* vert, int 
     const float dist = -dot(pl - v, nl);
     emit(n++, dist, mp + mat_mul(R, v) - (0.5f * dist) * pn, f.a, f.b, f.c);
   }
+}
+
+// height field against a convex geom (collision_convex.py:60-161 _hfield_filter, 164-730; MuJoCo mjc_ConvexHField): in the height field's
+// frame, every triangular prism of the cells under the geom's bounding box runs GJK / EPA against the geom (one lane walks them in turn);
+// of the (at most 50) results up to four are kept: the deepest, the one furthest from it, the one furthest from that line, the one furthest
+// from the other two edges.  hf = this lane's slice of the workspace (7 words per kept prism, lane-interleaved).
+template <class Emit>
+__device__ __noinline__ void collide_hfield(const MjhModel& m, float tolerance, int iterations, int epa_iterations, int g1, int t2, V3 pos1, const float* mat1, V3 pos2,
+                                            const float* mat2, V3 size2, float rbound2, float fmargin, float margin, float* scratch, float* hf, int& overflow,
+                                            Emit&& emit, const float* vert2, int nvert2, int mesh2) {
+  const int hid = m.geom_dataid[g1];
+  const float* size1 = m.hfield_size + 4 * hid;
+  const V3 pos = matT_mul(mat1, pos2 - pos1);
+  if (size1[0] < pos.x - rbound2 - fmargin || -size1[0] > pos.x + rbound2 + fmargin) return;
+  if (size1[1] < pos.y - rbound2 - fmargin || -size1[1] > pos.y + rbound2 + fmargin) return;
+  if (size1[2] < pos.z - rbound2 - fmargin) return;
+  if (-size1[3] > pos.z + rbound2 + fmargin) return;
+  float R[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) R[3 * i + j] = mat1[i] * mat2[j] + mat1[3 + i] * mat2[3 + j] + mat1[6 + i] * mat2[6 + j];
+  const int* graph2 = (mesh2 >= 0 && m.mesh_graphadr[mesh2] >= 0) ? m.mesh_graph + m.mesh_graphadr[mesh2] : nullptr;
+  CcdGeom b = CcdGeom{t2, pos, R, size2, 0.0f, vert2, nvert2, -1, mesh2, graph2, -1, nullptr};
+  int vid;
+  const float xmax = ccd_support(b, V3{1, 0, 0}, vid).x, xmin = ccd_support(b, V3{-1, 0, 0}, vid).x;
+  const float ymax = ccd_support(b, V3{0, 1, 0}, vid).y, ymin = ccd_support(b, V3{0, -1, 0}, vid).y;
+  const float zmax = ccd_support(b, V3{0, 0, 1}, vid).z, zmin = ccd_support(b, V3{0, 0, -1}, vid).z;
+  if (xmin - fmargin > size1[0] || xmax + fmargin < -size1[0] || ymin - fmargin > size1[1] || ymax + fmargin < -size1[1] || zmin - fmargin > size1[2] ||
+      zmax + fmargin < -size1[3])
+    return;
+  const int nrow = m.hfield_nrow[hid], ncol = m.hfield_ncol[hid], adr = m.hfield_adr[hid];
+  const float x_scale = 0.5f * (float)(ncol - 1) / size1[0], y_scale = 0.5f * (float)(nrow - 1) / size1[1];
+  const int cmin = max(0, (int)floorf((xmin + size1[0]) * x_scale)), cmax = min(ncol - 1, (int)ceilf((xmax + size1[0]) * x_scale));
+  const int rmin = max(0, (int)floorf((ymin + size1[1]) * y_scale)), rmax = min(nrow - 1, (int)ceilf((ymax + size1[1]) * y_scale));
+  const float dx = 2.0f * size1[0] / (float)(ncol - 1), dy = 2.0f * size1[1] / (float)(nrow - 1);
+  b.margin = margin;  // the geom is inflated by half the margin, the prism tops are raised by the whole of it
+  V3 prism[6];
+  for (int i = 0; i < 6; ++i) prism[i] = V3{0.0f, 0.0f, 0.0f};
+  prism[0].z = prism[1].z = prism[2].z = -size1[3];
+  const float ident[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  float min_dist = MJ_MAXVAL;
+  V3 min_pos = V3{MJ_MAXVAL, MJ_MAXVAL, MJ_MAXVAL}, min_nrm = min_pos;
+  int min_id = -1, count = 0;
+  auto hfget = [&](int i, int q) -> float& { return hf[(size_t)(7 * i + q) * CCD_LANES]; };
+  auto hfpos = [&](int i) { return V3{hfget(i, 1), hfget(i, 2), hfget(i, 3)}; };
+  auto hfnrm = [&](int i) { return V3{hfget(i, 4), hfget(i, 5), hfget(i, 6)}; };
+  auto shift = [&](float x, float y, float z) {
+    prism[0] = prism[1];
+    prism[1] = prism[2];
+    prism[3] = prism[4];
+    prism[4] = prism[5];
+    prism[2].x = prism[5].x = x;
+    prism[2].y = prism[5].y = y;
+    prism[5].z = z;
+  };
+  for (int r = rmin; r < rmax; ++r) {
+    for (int k = 0; k < 2; ++k) {
+      const int rr = r + (k == 0 ? 1 : 0);
+      shift(dx * (float)cmin - size1[0], dy * (float)rr - size1[1], m.hfield_data[adr + rr * ncol + cmin] * size1[2] + margin);
+    }
+    for (int c = cmin + 1; c <= cmax; ++c)
+      for (int k = 0; k < 2; ++k) {
+        if (count >= CCD_HF_MAXCONPAIR) {
+          overflow |= OVF_HFIELD;
+          continue;
+        }
+        const int rr = r + (k == 0 ? 1 : 0);
+        shift(dx * (float)c - size1[0], dy * (float)rr - size1[1], m.hfield_data[adr + rr * ncol + c] * size1[2] + margin);
+        if (prism[3].z < zmin && prism[4].z < zmin && prism[5].z < zmin) continue;
+        const V3 centre = (prism[0] + prism[1] + prism[2] + prism[3] + prism[4] + prism[5]) * (1.0f / 6.0f);
+        const CcdGeom a = CcdGeom{G_HFIELD, centre, ident, V3{0, 0, 0}, 0.0f, nullptr, 0, -1, -1, nullptr, -1, prism};
+        b.index = -1;  // (the reference passes its geom structs by value: every prism starts from the uncached geom)
+        float dist;
+        V3 w1, w2;
+        int face;
+        Poly pt;
+        const int n = ccd_run(tolerance, 0.0f, iterations, epa_iterations, a, b, scratch, dist, w1, w2, overflow, face, pt);
+        if (n == 0) continue;
+        const V3 p = mat_mul(mat1, 0.5f * (w1 + w2)) + pos1;
+        const V3 nrm = mat_mul(mat1, make_frame3(w1 - w2).a);
+        hfget(count, 0) = dist;
+        hfget(count, 1) = p.x; hfget(count, 2) = p.y; hfget(count, 3) = p.z;
+        hfget(count, 4) = nrm.x; hfget(count, 5) = nrm.y; hfget(count, 6) = nrm.z;
+        if (dist < min_dist) {
+          min_dist = dist;
+          min_nrm = nrm;
+          min_pos = p;
+          min_id = count;
+        }
+        ++count;
+      }
+  }
+  int nout = 0;
+  auto put = [&](float dist, V3 p, V3 nrm) {
+    const Frame f = make_frame3(nrm);
+    emit(nout++, dist, p, f.a, f.b, f.c);
+  };
+  put(min_dist, min_pos, min_nrm);  // (written unconditionally; the caller's margin test drops an empty one)
+  const float MIN_NEXT = 1.0e-3f;
+  int id1 = -1, id2 = -1, id3 = -1;
+  float best = -MJ_MAXVAL;
+  for (int i = 0; i < count; ++i) {
+    if (i == min_id) continue;
+    const float dd = length(hfpos(i) - min_pos);
+    if (dd > best) {
+      id1 = i;
+      best = dd;
+    }
+  }
+  if (id1 == -1 || (0.0f < best && best < MIN_NEXT)) return;
+  const V3 pos_1 = hfpos(id1);
+  put(hfget(id1, 0), pos_1, hfnrm(id1));
+  const V3 dmin1 = cross(min_nrm, min_pos - pos_1);
+  best = -MJ_MAXVAL;
+  for (int i = 0; i < count; ++i) {
+    if (i == min_id || i == id1) continue;
+    const float dd = fabsf(dot(hfpos(i) - min_pos, dmin1));
+    if (dd > best) {
+      id2 = i;
+      best = dd;
+    }
+  }
+  if (id2 == -1 || (0.0f < best && best < MIN_NEXT)) return;
+  const V3 pos_2 = hfpos(id2);
+  put(hfget(id2, 0), pos_2, hfnrm(id2));
+  const V3 vmin2 = cross(min_nrm, min_pos - pos_2), v12 = cross(min_nrm, pos_1 - pos_2);
+  best = -MJ_MAXVAL;
+  for (int i = 0; i < count; ++i) {
+    if (i == min_id || i == id1 || i == id2) continue;
+    const V3 p = hfpos(i);
+    const float dd = fabsf(dot(p - min_pos, vmin2)) + fabsf(dot(pos_1 - p, v12));
+    if (dd > best) {
+      id3 = i;
+      best = dd;
+    }
+  }
+  if (id3 == -1 || (0.0f < best && best < MIN_NEXT)) return;
+  put(hfget(id3, 0), hfpos(id3), hfnrm(id3));
 }
 
 template <bool HEAVY, class Emit>
@@ -1137,7 +1274,8 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
     return adr >= 0 ? m.mesh_graph + adr : nullptr;
   };
   // EPA polytope of this lane (convex.hpp): word k of lane l at k * 32 + l inside the world's slice of d.ws_ccd
-  float* ccd_scratch = (HEAVY && d.ws_ccd) ? d.ws_ccd + (size_t)w * ccd_words(max(m.ccd_iterations, m.epa_iterations)) * CCD_LANES + (lig & (CCD_LANES - 1)) : nullptr;
+  float* ccd_scratch = (HEAVY && d.ws_ccd) ? d.ws_ccd + (size_t)w * ccd_words(max(m.ccd_iterations, m.epa_iterations), m.nhfield) * CCD_LANES + (lig & (CCD_LANES - 1)) : nullptr;
+  const int hf0 = ccd_words(max(m.ccd_iterations, m.epa_iterations), 0);  // first word of the lane's height-field result table
   const float ccd_tol = HEAVY ? bf(m.opt_ccd_tolerance, m.opt_ccd_tolerance_nb, w, 1)[0] : 0.0f;
   const int ccd_it = min(m.ccd_iterations, CCD_MAX_ITER), epa_it = min(m.epa_iterations, CCD_MAX_ITER);
   const int ccd_cache0 = ccd_poly_words(max(m.ccd_iterations, m.epa_iterations));  // first word of the lane's contact cache
@@ -1161,7 +1299,12 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
       int mn1, mn2;
       mesh_of(g1, t1, mv1, mn1);
       mesh_of(g2, t2, mv2, mn2);
-      if (HEAVY && (is_convex_pair(t1, t2) || (box_ccd && t1 == G_BOX && t2 == G_BOX))) {
+      if (HEAVY && t1 == G_HFIELD) {  // (not cached: each of its contacts has its own distance and frame; pass 2 recomputes)
+        if (t2 >= G_SPHERE && ccd_scratch)
+          collide_hfield(m, ccd_tol, ccd_it, epa_it, g1, t2, ld3(gxpos + 3 * g1), gxmat + 9 * g1, ld3(gxpos + 3 * g2), gxmat + 9 * g2, ld3(gsize + 3 * g2), rbound[g2],
+                         gmargin[g1] + gmargin[g2], margin, ccd_scratch, ccd_scratch + (size_t)hf0 * CCD_LANES, ccd_overflow, count, mv2, mn2,
+                         t2 == G_MESH ? m.geom_dataid[g2] : -1);
+      } else if (HEAVY && (is_convex_pair(t1, t2) || (box_ccd && t1 == G_BOX && t2 == G_BOX))) {
         const int cslot_c = base / G;  // this lane's k-th candidate
         float* cache = (ccd_scratch && cslot_c < CCD_CACHE_SLOTS) ? ccd_scratch + (size_t)(ccd_cache0 + cslot_c * CCD_CACHE_WORDS) * CCD_LANES : nullptr;
         int nem = 0;
@@ -1248,7 +1391,15 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
                      }
                      ++slot;
                    };
-      if (HEAVY && (is_convex_pair(t1, t2) || (box_ccd && t1 == G_BOX && t2 == G_BOX))) {
+      if (HEAVY && t1 == G_HFIELD) {
+        const float* mv2;
+        int mn2;
+        mesh_of(g2, t2, mv2, mn2);
+        if (t2 >= G_SPHERE && ccd_scratch)
+          collide_hfield(m, ccd_tol, ccd_it, epa_it, g1, t2, ld3(gxpos + 3 * g1), gxmat + 9 * g1, ld3(gxpos + 3 * g2), gxmat + 9 * g2, ld3(gsize + 3 * g2), rbound[g2],
+                         gmargin[g1] + gmargin[g2], margin, ccd_scratch, ccd_scratch + (size_t)hf0 * CCD_LANES, ccd_overflow, write, mv2, mn2,
+                         t2 == G_MESH ? m.geom_dataid[g2] : -1);
+      } else if (HEAVY && (is_convex_pair(t1, t2) || (box_ccd && t1 == G_BOX && t2 == G_BOX))) {
         const int cslot_c = base / G;
         if (ccd_scratch && cslot_c < CCD_CACHE_SLOTS) {  // replay the contacts pass 1 found
           const float* cache = ccd_scratch + (size_t)(ccd_cache0 + cslot_c * CCD_CACHE_WORDS) * CCD_LANES;

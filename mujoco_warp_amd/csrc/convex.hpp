@@ -36,7 +36,11 @@ __host__ __device__ inline int ccd_poly_words(int iterations) {
   const int it = iterations < CCD_MAX_ITER ? iterations : CCD_MAX_ITER;
   return 8 * (5 + it) + 5 * (6 + CCD_EPAFACES * it) + CCD_MAX_HORIZON;
 }
-__host__ __device__ inline int ccd_words(int iterations) { return ccd_poly_words(iterations) + CCD_CACHE_SLOTS * CCD_CACHE_WORDS; }
+#define CCD_HF_MAXCONPAIR 50  // mjMAXCONPAIR (types.py:27): prisms of one height-field pair whose result is kept
+#define CCD_HF_WORDS (7 * CCD_HF_MAXCONPAIR)  // distance, position, normal of each (models with height fields only)
+__host__ __device__ inline int ccd_words(int iterations, int hfield = 0) {
+  return ccd_poly_words(iterations) + CCD_CACHE_SLOTS * CCD_CACHE_WORDS + (hfield ? CCD_HF_WORDS : 0);
+}
 
 struct CcdGeom {
   int type;
@@ -50,6 +54,7 @@ struct CcdGeom {
   int meshid;  // mesh: Model.geom_dataid (polygon tables for the multi-contact recovery), -1 otherwise
   const int* graph;  // mesh: its block of Model.mesh_graph (hill climbing for meshes of 10 or more vertices) or nullptr
   int cache;  // out of ccd_support: SupportPoint.cached_index (a vertex id on the exhaustive path, a graph-local id when hill climbing)
+  const V3* prism;  // height-field prism (type G_HFIELD): six vertices in the frame the pair is solved in (collision_gjk.py:197-206)
 };
 struct GjkOut {
   bool separated;
@@ -65,6 +70,20 @@ DEV float ccd_sign(float x) { return x < 0.0f ? -1.0f : 1.0f; }
 DEV V3 ccd_support(const CcdGeom& g, V3 dir, int& vid) {
   vid = -1;
   if (g.type == G_SPHERE) return g.pos + (g.size.x + 0.5f * g.margin) * dir;
+  if (g.type == G_HFIELD) {  // the furthest of the prism's six vertices
+    float best = -CCD_FLOAT_MAX;
+    V3 p = V3{0.0f, 0.0f, 0.0f};
+    vid = dir.z < 0.0f ? -2 : -3;
+    for (int i = 0; i < 6; ++i) {
+      const float dd = dot(g.prism[i], dir);
+      if (dd > best) {
+        best = dd;
+        p = g.prism[i];
+      }
+    }
+    if (g.margin > 0.0f) p = p + dir * (0.5f * g.margin);
+    return p;
+  }
   const V3 l = matT_mul(g.rot, dir);
   V3 r = V3{0.0f, 0.0f, 0.0f};
   if (g.type == G_BOX) {
@@ -312,6 +331,7 @@ DEV void ccd_gjk(float tolerance, int iterations, const CcdGeom& g1, const CcdGe
       res.separated = true;
       res.dim = 0;
       res.dist = CCD_FLOAT_MAX;
+      res.x1 = res.x2 = V3{0.0f, 0.0f, 0.0f};  // (an empty GJKResult: the height-field contact selection reads the witness points of separated prisms too)
       return;
     }
     lam[0] = 1.0f;
@@ -354,6 +374,16 @@ DEV void ccd_gjk(float tolerance, int iterations, const CcdGeom& g1, const CcdGe
   }
   res.dist = (n == 4 && !res.separated) ? 0.0f : xnorm;
   res.dim = n;
+  // The separation test above fires once the lower bound x_k . s reaches cutoff |x_k|; at convergence that bound is |x_k|^2, so a pair
+  // at least `cutoff` apart is always reported as separated -- unless the duality-gap test, which comes first in the loop, stops that very
+  // iteration, and in float32 the gap is rounding noise at that point: a coin flip.  Only the height-field collider can tell the two
+  // outcomes apart (it keeps the witness points of separated prisms in its contact selection); normalise to the separation test's verdict
+  // (oracle/ccd.c does the same).
+  if (res.separated && xnorm > 0.0f && (cutoff == 0.0f || (cutoff < CCD_FLOAT_MAX && xnorm >= cutoff))) {
+    res.dim = 0;
+    res.dist = CCD_FLOAT_MAX;
+    res.x1 = res.x2 = V3{0.0f, 0.0f, 0.0f};
+  }
 }
 
 // ---- EPA polytope in the lane-interleaved workspace ------------------------------------------------------------------------------
@@ -659,7 +689,7 @@ DEV int ccd_run(float tolerance, float cutoff, int gjk_iterations, int epa_itera
   const CcdGeom o1 = g1, o2 = g2;
   face_out = -1;
   float full1 = 0.0f, full2 = 0.0f, size1 = 0.0f, size2 = 0.0f;
-  const bool is_discrete = (g1.type == G_BOX || g1.type == G_MESH) && (g2.type == G_BOX || g2.type == G_MESH) && g1.margin == 0.0f && g2.margin == 0.0f;  // collision_gjk.py:109
+  const bool is_discrete = (g1.type == G_BOX || g1.type == G_MESH || g1.type == G_HFIELD) && (g2.type == G_BOX || g2.type == G_MESH || g2.type == G_HFIELD) && g1.margin == 0.0f && g2.margin == 0.0f;  // collision_gjk.py:109
   GjkOut res;
   if (g1.type == G_SPHERE || g1.type == G_CAPSULE) {
     size1 = g1.size.x;

@@ -90,6 +90,7 @@ _SUPPORTED_PAIRS = {(0, 2), (0, 3), (0, 4), (0, 5), (0, 6), (2, 2), (2, 3), (2, 
 # pairs of the reference's CONVEX class (collision_driver.py:47-80) that go through GJK / EPA (csrc/convex.hpp); box-box joins them
 # unless DisableBit.NATIVECCD is set (collision_driver.py:867-870), see put_model
 _CONVEX_PAIRS = {(2, 4), (3, 4), (3, 5), (4, 4), (4, 5), (4, 6), (5, 5), (5, 6), (2, 7), (3, 7), (4, 7), (5, 7), (6, 7), (7, 7)}
+_HFIELD_PAIRS = {(1, 2), (1, 3), (1, 4), (1, 5), (1, 6), (1, 7)}  # height field vs convex geom: prism-wise GJK / EPA (collision_convex.py:164), heavy instantiation
 _PLANE_MESH = (0, 7)  # primitive collider plane_convex (collision_primitive.py:52), heavy instantiation
 
 
@@ -118,7 +119,7 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
   # ---- validation (io.py:284-360) ----
   if int(getattr(mjm, "neq", 0)) > 0 and (np.asarray(mjm.eq_type) != types.EqType.JOINT).any():
     raise NotImplementedError("only joint equality constraints are implemented")
-  for name in ("ntendon", "nflex", "nhfield", "nplugin"):
+  for name in ("ntendon", "nflex", "nplugin"):
     if int(getattr(mjm, name, 0)) > 0:
       raise NotImplementedError(f"{name} > 0 is outside the hot-path scope of this engine")
   if int(opt.integrator) not in (types.IntegratorType.EULER, types.IntegratorType.RK4, types.IntegratorType.IMPLICITFAST):
@@ -173,7 +174,9 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
   gt = np.asarray(mjm.geom_type)
   for a, b in pairs:
     t = (int(min(gt[a], gt[b])), int(max(gt[a], gt[b])))
-    if t not in _SUPPORTED_PAIRS and t not in _CONVEX_PAIRS and t != _PLANE_MESH:
+    if t in ((0, 1), (1, 1)):
+      continue  # (plane / height-field against a height field: no collider in the reference either, collision_driver.py:47-59)
+    if t not in _SUPPORTED_PAIRS and t not in _CONVEX_PAIRS and t != _PLANE_MESH and t not in _HFIELD_PAIRS:
       raise NotImplementedError(f"collision between geom types {t} is not implemented yet")
     if 7 in t:  # convex meshes: exhaustive vertex search, single contact
       for g in (a, b):
@@ -215,7 +218,7 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
   # (reference collision_driver.py:78, 867-870)
   box_ccd = not (int(opt.disableflags) & int(types.DisableBit.NATIVECCD))
   nboxbox = sum(t == (6, 6) for t in ptypes) if box_ccd else 0
-  nconvex = sum(t in _CONVEX_PAIRS for t in ptypes)
+  nconvex = sum(t in _CONVEX_PAIRS or t in _HFIELD_PAIRS for t in ptypes)
   m._convex_pairs = int(nconvex + nboxbox > 0)
   # EPA iteration cap (reference collision_convex.py:1223): 16 when every convex pair of the model is box-box
   m._epa_iterations = 16 if (nboxbox > 0 and nconvex == 0) else int(getattr(opt, "ccd_iterations", 35))
@@ -348,6 +351,9 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
     geom_priority=_arr(mjm.geom_priority, i32), geom_dataid=_arr(getattr(mjm, "geom_dataid", np.full(ngeom, -1)), i32),
     mesh_vertadr=_arr(getattr(mjm, "mesh_vertadr", np.zeros(0)), i32), mesh_vertnum=_arr(getattr(mjm, "mesh_vertnum", np.zeros(0)), i32),
     mesh_vert=_arr(getattr(mjm, "mesh_vert", np.zeros((0, 3))), f32).reshape(-1, 3),
+    hfield_size=_arr(getattr(mjm, "hfield_size", np.zeros((0, 4))), f32).reshape(-1, 4), hfield_nrow=_arr(getattr(mjm, "hfield_nrow", np.zeros(0)), i32),
+    hfield_ncol=_arr(getattr(mjm, "hfield_ncol", np.zeros(0)), i32), hfield_adr=_arr(getattr(mjm, "hfield_adr", np.zeros(0)), i32),
+    hfield_data=_arr(getattr(mjm, "hfield_data", np.zeros(0)), f32),
     mesh_graphadr=_arr(getattr(mjm, "mesh_graphadr", np.full(int(getattr(mjm, "nmesh", 0)), -1)), i32), mesh_graph=_arr(getattr(mjm, "mesh_graph", np.zeros(0)), i32),
     mesh_polyadr=_arr(getattr(mjm, "mesh_polyadr", np.zeros(0)), i32), mesh_polynormal=_arr(getattr(mjm, "mesh_polynormal", np.zeros((0, 3))), f32).reshape(-1, 3),
     mesh_polyvertadr=_arr(getattr(mjm, "mesh_polyvertadr", np.zeros(0)), i32), mesh_polyvertnum=_arr(getattr(mjm, "mesh_polyvertnum", np.zeros(0)), i32),
@@ -368,6 +374,7 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
   m.nmeshvert = int(host["mesh_vert"].shape[0])
   m.nmeshpoly = int(host["mesh_polyvertnum"].shape[0])
   m.nmeshgraph = int(host["mesh_graph"].shape[0])
+  m.nhfield, m.nhfielddata = int(host["hfield_nrow"].shape[0]), int(host["hfield_data"].shape[0])
   m.nmeshpolyvert, m.nmeshpolymap = int(host["mesh_polyvert"].shape[0]), int(host["mesh_polymap"].shape[0])
   # clip buffers of the multi-contact recovery: 2 * npolygonmax points (reference collision_convex.py:1226-1234)
   nboxmesh, nmeshmesh = sum(t == (6, 7) for t in ptypes), sum(t == (7, 7) for t in ptypes)
@@ -470,10 +477,11 @@ def c_model(m: types.Model):
   return c
 
 
-def _ccd_words(iterations: int) -> int:
+def _ccd_words(iterations: int, hfield: int = 0) -> int:
   """Workspace words of one lane's EPA polytope (csrc/convex.hpp ccd_words)."""
   it = min(int(iterations), 64)
-  return 8 * (5 + it) + 5 * (6 + 5 * it) + 24 + 4 * 24  # polytope + contact cache (CCD_CACHE_SLOTS x CCD_CACHE_WORDS)
+  # polytope + contact cache (CCD_CACHE_SLOTS x CCD_CACHE_WORDS) + the height-field result table (CCD_HF_WORDS)
+  return 8 * (5 + it) + 5 * (6 + 5 * it) + 24 + 4 * 24 + (7 * 50 if hfield else 0)
 
 
 def contact_cap(nconmax: int) -> int:
@@ -505,7 +513,7 @@ def _data_shapes(m, nworld, nconmax, njmax, naconmax):
     efc_margin=(W, njmax), efc_D=(W, njmax), efc_vel=(W, njmax), efc_aref=(W, njmax), efc_frictionloss=(W, njmax),
     efc_force=(W, njmax), ws_ncon=(W,), ws_conadr=(W,), ws_ncollision=(W,), ws_efc_con=(W, njmax), ws_tree_rowadr=(W, (m.ntree + 1) if m.tree_solve else 0), ws_tree_rowmap=(W, njmax if m.tree_solve else 0),
     ws_isl_dofadr=(W, (m.ntree + 1) if m.tree_solve else 0), ws_isl_dofmap=(W, nv if m.tree_solve else 0), ws_isl_dofinv=(W, nv if m.tree_solve else 0), ws_nisland=(W,), ws_isl_flags=(W,), ws_isl_list=(3, W if m.tree_solve else 0), ws_isl_count=(4,),
-    ws_separable=(W,), ws_order=(W,), ws_ccd=(W if m._convex_pairs else 0, _ccd_words(max(int(m.opt.ccd_iterations), int(m.epa_iterations))), 32),
+    ws_separable=(W,), ws_order=(W,), ws_ccd=(W if m._convex_pairs else 0, _ccd_words(max(int(m.opt.ccd_iterations), int(m.epa_iterations)), m.nhfield), 32),
     tree_asleep=(W, m.ntree), tree_awake=(W, m.ntree), body_awake=(W, nb), body_awake_ind=(W, nb), dof_awake_ind=(W, nv), ntree_awake=(W,), nbody_awake=(W,),
     nv_awake=(W,), tree_island=(W, m.ntree), nisland=(W,), ws_sleep_J=(W if m.sleep_enabled else 0, njmax_pad, nv_pad), ws_sleep_warm=(W if m.sleep_enabled else 0, nv),
     ws_sleep_flag=(W,),

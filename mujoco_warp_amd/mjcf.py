@@ -677,6 +677,10 @@ def _compile(root, base_dir):
       name = a.get("name") or os.path.splitext(os.path.basename(a.get("file", "")))[0]
       mesh_assets[name] = a
   mesh_compiled = {}
+  hfield_assets, hfield_names = {}, []  # inline height fields (<hfield nrow= ncol= size= elevation=>); files are not in this tree
+  for asset in root.findall("asset"):
+    for he in asset.findall("hfield"):
+      hfield_assets[he.get("name")] = he.attrib
 
   bodies, joints, geoms, sites = [], [], [], []
   world = _Body()
@@ -725,8 +729,20 @@ def _compile(root, base_dir):
     elif g["type"] in (GEOM_CAPSULE, GEOM_CYLINDER):
       size = np.array([size[0], size[1], 0.0])
     g["size"], g["pos"], g["quat"], g["body"] = size, pos, quat, bodyid
-    if g["type"] in (GEOM_HFIELD, GEOM_SDF):
-      raise NotImplementedError("hfield/sdf geoms")
+    if g["type"] == GEOM_SDF:
+      raise NotImplementedError("sdf geoms")
+    g["hfield"] = None
+    if g["type"] == GEOM_HFIELD:
+      name = a.get("hfield")
+      if name not in hfield_assets:
+        raise ValueError(f"geom refers to unknown hfield {name!r}")
+      if "elevation" not in hfield_assets[name]:
+        raise NotImplementedError("height fields need inline elevation data (<hfield elevation=...>): files are not in this tree")
+      if name not in hfield_names:
+        hfield_names.append(name)
+      g["hfield"] = name
+      hs = np.array(_floats(hfield_assets[name]["size"]))
+      g["size"] = np.array([hs[0], hs[1], 0.25 * hs[2] + 0.5 * hs[3]])  # (unpinned: only rbound / aabb below enter the engine)
     g["meshdata"] = None
     if g["type"] == GEOM_MESH and (g["contype"] or g["conaffinity"]):
       asset = mesh_assets.get(g["mesh"])
@@ -1008,6 +1024,27 @@ def _compile(root, base_dir):
   m.geom_condim = np.array([g["condim"] for g in gl], dtype=np.int32)
   m.geom_bodyid = np.array([g["body"] for g in gl], dtype=np.int32)
   m.geom_dataid = np.full(ng, -1, dtype=np.int32)
+  # height fields (MjModel.hfield_*): elevation normalised to [0, 1] like MuJoCo's compiler (raw = z_top * data)
+  m.nhfield = len(hfield_names)
+  m.hfield_size = np.zeros((m.nhfield, 4))
+  m.hfield_nrow, m.hfield_ncol, m.hfield_adr = (np.zeros(m.nhfield, dtype=np.int32) for _ in range(3))
+  hdata = []
+  for i, name in enumerate(hfield_names):
+    ha = hfield_assets[name]
+    nrow, ncol = int(ha["nrow"]), int(ha["ncol"])
+    e = np.array(_floats(ha["elevation"]), dtype=np.float64)
+    if e.size != nrow * ncol:
+      raise ValueError(f"hfield {name}: elevation has {e.size} values, expected {nrow * ncol}")
+    e = e.reshape(nrow, ncol)[::-1]  # (MJCF lists the rows from the far edge (+y) first; MuJoCo stores row 0 at -y)
+    lo, hi = float(e.min()), float(e.max())
+    e = (e - lo) / (hi - lo) if hi > lo else np.zeros_like(e)
+    m.hfield_size[i] = _floats(ha["size"])
+    m.hfield_nrow[i], m.hfield_ncol[i], m.hfield_adr[i] = nrow, ncol, sum(len(x) for x in hdata)
+    hdata.append(e.reshape(-1))
+  m.hfield_data = np.concatenate(hdata) if hdata else np.zeros(0)
+  for i, g in enumerate(gl):
+    if g["hfield"] is not None:
+      m.geom_dataid[i] = hfield_names.index(g["hfield"])
   mesh_names = [n for n in mesh_compiled]
   m.nmesh = len(mesh_names)
   m.mesh_vertnum = np.array([len(mesh_compiled[n]["vert"]) for n in mesh_names], dtype=np.int32)
@@ -1049,6 +1086,10 @@ def _compile(root, base_dir):
     if gl[i]["meshdata"] is not None:
       m.geom_rbound[i] = gl[i]["meshdata"]["rbound"]
       m.geom_aabb[i] = gl[i]["meshdata"]["aabb"]
+    if gl[i]["hfield"] is not None:  # box from -base to +top around the grid
+      hs = m.hfield_size[hfield_names.index(gl[i]["hfield"])]
+      m.geom_aabb[i] = [0.0, 0.0, 0.5 * (hs[2] - hs[3]), hs[0], hs[1], 0.5 * (hs[2] + hs[3])]
+      m.geom_rbound[i] = float(np.sqrt(hs[0] ** 2 + hs[1] ** 2 + max(hs[2], hs[3]) ** 2))
 
   # sites
   m.nsite = len(sites)
@@ -1289,7 +1330,7 @@ def _compile(root, base_dir):
         arr[i] = v
 
   # sizes not on the hot path
-  m.ntendon = m.nsensor = m.nmesh = m.nhfield = m.nflex = m.nplugin = 0
+  m.ntendon = m.nsensor = m.nflex = m.nplugin = 0
   m.ncam = m.nlight = 0
   m.nuserdata = m.nsensordata = 0
 

@@ -416,6 +416,12 @@ class Model(_Dirty):
   nmeshpolymap: int = 0
   npolygonmax: int = 0
   nmeshgraph: int = 0
+  nhfielddata: int = 0
+  hfield_size: DeviceArray = _arr(('nhfield', 4), "float32")
+  hfield_nrow: DeviceArray = _arr(('nhfield',), "int32")
+  hfield_ncol: DeviceArray = _arr(('nhfield',), "int32")
+  hfield_adr: DeviceArray = _arr(('nhfield',), "int32")
+  hfield_data: DeviceArray = _arr(('nhfielddata',), "float32")
   mesh_graphadr: DeviceArray = _arr(('nmesh',), "int32")
   mesh_graph: DeviceArray = _arr(('nmeshgraph',), "int32")
   mesh_polyadr: DeviceArray = _arr(('nmesh',), "int32")

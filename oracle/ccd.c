@@ -27,6 +27,7 @@ typedef struct CcdGeom {
   double pos[3], rot[9], size[3], margin;
   const double* vert; /* mesh: vertices in the geom frame */
   int nvert;
+  double prism[6][3]; /* height-field prism (type G_HFIELD): vertices in the height field's frame (collision_gjk.py:197-206) */
   int index;          /* mesh: cache of the last support call (warm start), -1 at the start (Geom.index): a vertex id on the exhaustive
                          path, a graph-local vertex id on the hill-climbing path */
   int cache;          /* out of ccd_support: SupportPoint.cached_index */
@@ -57,6 +58,17 @@ static int ccd_support(const CcdGeom* g, const double* dir, double* out) {
   int vid = -1;
   if (g->type == G_SPHERE) {
     for (int k = 0; k < 3; k++) out[k] = g->pos[k] + (g->size[0] + 0.5 * g->margin) * dir[k];
+    return vid;
+  }
+  if (g->type == G_HFIELD) { /* 197-206: the furthest of the prism's six vertices (the prism lives in the frame the pair is solved in) */
+    double best = -CCD_FLOAT_MAX;
+    vid = dir[2] < 0.0 ? -2 : -3;
+    for (int i = 0; i < 6; i++) {
+      double dd = v3dot(g->prism[i], dir);
+      if (dd > best) { best = dd; v3cpy(out, g->prism[i]); }
+    }
+    if (g->margin > 0.0)
+      for (int k = 0; k < 3; k++) out[k] += dir[k] * (0.5 * g->margin);
     return vid;
   }
   double l[3], r[3] = {0, 0, 0};
@@ -332,6 +344,17 @@ static void ccd_gjk(double tolerance, int iterations, const CcdGeom* g1, const C
   }
   res->dist = (n == 4 && !res->separated) ? 0.0 : xnorm;
   res->dim = n;
+  /* The reference's separation test (690-710) fires once the lower bound x_k . s reaches cutoff |x_k| (any positive value for cutoff 0).
+     At convergence that bound equals |x_k|^2, so a pair whose distance is at least the cutoff is always reported as separated -- except
+     that the duality-gap test above comes first in the loop and can stop the very iteration in which the bound would have been reached
+     (always in float64; in float32, the reference's arithmetic, the gap x_k . (x_k - s) is rounding noise at that point and the outcome is
+     a coin flip).  Only the height-field collider can tell the two outcomes apart (it keeps the witness points of separated prisms in its
+     contact selection); this engine and its oracle both normalise to the separation test's verdict: */
+  if (res->separated && xnorm > 0.0 && ((cutoff == 0.0) || (cutoff < CCD_FLOAT_MAX && xnorm >= cutoff))) {
+    memset(res, 0, sizeof(*res));
+    res->separated = 1;
+    res->dist = CCD_FLOAT_MAX;
+  }
 }
 
 /* ---- EPA ---------------------------------------------------------------------------------------------------------------- */
@@ -616,7 +639,7 @@ static int ccd_epa(double tolerance, int iterations, Polytope* pt, const CcdGeom
   return idx;
 }
 
-static int ccd_discrete(int t1, int t2) { return (t1 == G_BOX || t1 == G_MESH) && (t2 == G_BOX || t2 == G_MESH); } /* 109 (hfields: out of scope) */
+static int ccd_discrete(int t1, int t2) { return (t1 == G_BOX || t1 == G_MESH || t1 == G_HFIELD) && (t2 == G_BOX || t2 == G_MESH || t2 == G_HFIELD); } /* 109 */
 
 /* ccd = gjk_phase + epa_phase (collision_gjk.py:2350-2575).  Returns the number of contacts (0 / 1); *face_out = closest EPA
  * face when the pair qualifies for multi-contact recovery (boxes, zero margin), else -1; pt_out receives the final polytope */

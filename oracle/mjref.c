@@ -8,6 +8,7 @@
 #include "mjref.h"
 
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -1138,6 +1139,151 @@ static int ccd_contact(const RefModel* m, int g1, int g2, int t1, const double* 
   }
   return n;
 }
+/* height field against a convex geom (collision_convex.py:60-161 _hfield_filter, 164-730 ccd_hfield kernel; MuJoCo mjc_ConvexHField):
+   in the height field's frame, every triangular prism of the cells under the geom's bounding box runs GJK / EPA against the geom; of the
+   (at most MJ_MAXCONPAIR = 50) results up to four are kept: the deepest, the one furthest from it, the one furthest from that line, the
+   one furthest from the other two edges */
+#define MAXCONPAIR 50
+enum { OVF_HFIELD = 1 << 5 }; /* types.py:171 */
+static int collide_hfield(const RefModel* m, RefData* d, int g1, int g2, double margin, double gap, Con* out) {
+  const double *pos1 = d->geom_xpos + 3 * g1, *mat1 = d->geom_xmat + 9 * g1, *pos2 = d->geom_xpos + 3 * g2, *mat2 = d->geom_xmat + 9 * g2;
+  int hid = m->geom_dataid[g1], t2 = m->geom_type[g2];
+  const double* size1 = m->hfield_size + 4 * hid;
+  double dif[3], pos[3], R[9];
+  v3sub(dif, pos2, pos1);
+  matT_mul_vec(pos, mat1, dif);
+  double r2 = m->geom_rbound[g2], fmargin = m->geom_margin[g1] + m->geom_margin[g2];
+  for (int i = 0; i < 2; i++)
+    if (size1[i] < pos[i] - r2 - fmargin || -size1[i] > pos[i] + r2 + fmargin) return 0;
+  if (size1[2] < pos[2] - r2 - fmargin) return 0;
+  if (-size1[3] > pos[2] + r2 + fmargin) return 0;
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) R[3 * i + j] = mat1[i] * mat2[j] + mat1[3 + i] * mat2[3 + j] + mat1[6 + i] * mat2[6 + j]; /* mat1^T mat2 */
+  CcdGeom b, a;
+  memset(&a, 0, sizeof(a));
+  memset(&b, 0, sizeof(b));
+  b.type = t2;
+  v3cpy(b.pos, pos);
+  memcpy(b.rot, R, sizeof(R));
+  v3cpy(b.size, m->geom_size + 3 * g2);
+  b.margin = 0.0;
+  b.index = b.cache = -1;
+  mesh_of(m, g2, &b.vert, &b.nvert);
+  b.graph = mesh_graph_of(m, g2);
+  mesh_poly_of(m, g2, &b);
+  double ext[6], p[3];
+  static const double AX[6][3] = {{1, 0, 0}, {-1, 0, 0}, {0, 1, 0}, {0, -1, 0}, {0, 0, 1}, {0, 0, -1}};
+  for (int k = 0; k < 6; k++) { /* tight bounds through the support function: xmax, xmin, ymax, ymin, zmax, zmin */
+    ccd_support(&b, AX[k], p);
+    ext[k] = p[k / 2];
+  }
+  double xmax = ext[0], xmin = ext[1], ymax = ext[2], ymin = ext[3], zmax = ext[4], zmin = ext[5];
+  if (xmin - fmargin > size1[0] || xmax + fmargin < -size1[0] || ymin - fmargin > size1[1] || ymax + fmargin < -size1[1] || zmin - fmargin > size1[2] ||
+      zmax + fmargin < -size1[3])
+    return 0;
+  int nrow = m->hfield_nrow[hid], ncol = m->hfield_ncol[hid], adr = m->hfield_adr[hid];
+  double x_scale = 0.5 * (double)(ncol - 1) / size1[0], y_scale = 0.5 * (double)(nrow - 1) / size1[1];
+  int cmin = (int)floor((xmin + size1[0]) * x_scale), cmax = (int)ceil((xmax + size1[0]) * x_scale);
+  int rmin = (int)floor((ymin + size1[1]) * y_scale), rmax = (int)ceil((ymax + size1[1]) * y_scale);
+  if (cmin < 0) cmin = 0;
+  if (cmax > ncol - 1) cmax = ncol - 1;
+  if (rmin < 0) rmin = 0;
+  if (rmax > nrow - 1) rmax = nrow - 1;
+  double dx = 2.0 * size1[0] / (double)(ncol - 1), dy = 2.0 * size1[1] / (double)(nrow - 1);
+  a.type = G_HFIELD;
+  a.rot[0] = a.rot[4] = a.rot[8] = 1.0;
+  a.margin = 0.0;
+  a.index = a.cache = -1;
+  b.margin = margin; /* the geom is inflated by half the margin, the prism tops are raised by the whole of it */
+  double prism[6][3];
+  memset(prism, 0, sizeof(prism));
+  prism[0][2] = prism[1][2] = prism[2][2] = -size1[3];
+  double cdist[MAXCONPAIR], cpos[MAXCONPAIR][3], cnrm[MAXCONPAIR][3];
+  double min_dist = 1e10, min_pos[3] = {1e10, 1e10, 1e10}, min_nrm[3] = {1e10, 1e10, 1e10};
+  int min_id = -1, count = 0;
+  static Polytope pt;
+  for (int r = rmin; r < rmax; r++) {
+    for (int k = 0; k < 2; k++) { /* the first two vertices of the row strip */
+      double x = dx * (double)cmin - size1[0], y = dy * (double)(r + (k == 0 ? 1 : 0)) - size1[1];
+      double z = m->hfield_data[adr + (r + (k == 0 ? 1 : 0)) * ncol + cmin] * size1[2] + margin;
+      v3cpy(prism[0], prism[1]); v3cpy(prism[1], prism[2]); v3cpy(prism[3], prism[4]); v3cpy(prism[4], prism[5]);
+      prism[2][0] = prism[5][0] = x;
+      prism[2][1] = prism[5][1] = y;
+      prism[5][2] = z;
+    }
+    for (int c = cmin + 1; c <= cmax; c++)
+      for (int k = 0; k < 2; k++) { /* both triangles of the cell */
+        if (count >= MAXCONPAIR) { d->overflow |= OVF_HFIELD; continue; }
+        int rr = r + (k == 0 ? 1 : 0);
+        double x = dx * (double)c - size1[0], y = dy * (double)rr - size1[1], z = m->hfield_data[adr + rr * ncol + c] * size1[2] + margin;
+        v3cpy(prism[0], prism[1]); v3cpy(prism[1], prism[2]); v3cpy(prism[3], prism[4]); v3cpy(prism[4], prism[5]);
+        prism[2][0] = prism[5][0] = x;
+        prism[2][1] = prism[5][1] = y;
+        prism[5][2] = z;
+        if (prism[3][2] < zmin && prism[4][2] < zmin && prism[5][2] < zmin) continue;
+        memcpy(a.prism, prism, sizeof(prism));
+        for (int q = 0; q < 3; q++) a.pos[q] = (prism[0][q] + prism[1][q] + prism[2][q] + prism[3][q] + prism[4][q] + prism[5][q]) * (1.0 / 6.0);
+        double dist, w1[3], w2[3];
+        int face;
+        b.index = -1; /* (the reference passes its geom structs by value: every prism starts from the uncached geom) */
+        a.index = -1;
+        int n = ccd_run(m->ccd_tolerance, 0.0, m->ccd_iterations, m->epa_iterations, a, b, &dist, w1, w2, &d->overflow, &face, &pt);
+        if (n == 0) continue;
+        cdist[count] = dist;
+        double pl[3], fr[9], wd[3];
+        for (int q = 0; q < 3; q++) pl[q] = 0.5 * (w1[q] + w2[q]);
+        mat_mul_vec(cpos[count], mat1, pl);
+        v3add(cpos[count], cpos[count], pos1);
+        v3sub(wd, w1, w2);
+        make_frame(fr, wd);
+        mat_mul_vec(cnrm[count], mat1, fr);
+        if (dist < min_dist) { min_dist = dist; v3cpy(min_nrm, cnrm[count]); v3cpy(min_pos, cpos[count]); min_id = count; }
+        count++;
+      }
+  }
+  int nout = 0;
+#define HF_EMIT(dist_, pos_, nrm_) do { out[nout].dist = (dist_); v3cpy(out[nout].pos, (pos_)); make_frame(out[nout].frame, (nrm_)); nout++; } while (0)
+  HF_EMIT(min_dist, min_pos, min_nrm); /* (contact 0 is written unconditionally; the caller's margin test drops an empty one) */
+  const double MIN_NEXT = 1.0e-3;
+  int id1 = -1, id2 = -1, id3 = -1;
+  double best = -1e10, t[3], u[3];
+  for (int i = 0; i < count; i++) { /* furthest from the deepest */
+    if (i == min_id) continue;
+    v3sub(t, cpos[i], min_pos);
+    double dd = v3len(t);
+    if (dd > best) { id1 = i; best = dd; }
+  }
+  if (id1 == -1 || (0.0 < best && best < MIN_NEXT)) return nout;
+  HF_EMIT(cdist[id1], cpos[id1], cnrm[id1]);
+  double dmin1[3];
+  v3sub(t, min_pos, cpos[id1]);
+  v3cross(dmin1, min_nrm, t);
+  best = -1e10;
+  for (int i = 0; i < count; i++) { /* furthest from the line deepest - contact 1 */
+    if (i == min_id || i == id1) continue;
+    v3sub(t, cpos[i], min_pos);
+    double dd = fabs(v3dot(t, dmin1));
+    if (dd > best) { id2 = i; best = dd; }
+  }
+  if (id2 == -1 || (0.0 < best && best < MIN_NEXT)) return nout;
+  HF_EMIT(cdist[id2], cpos[id2], cnrm[id2]);
+  double vmin2[3], v12[3];
+  v3sub(t, min_pos, cpos[id2]);
+  v3cross(vmin2, min_nrm, t);
+  v3sub(t, cpos[id1], cpos[id2]);
+  v3cross(v12, min_nrm, t);
+  best = -1e10;
+  for (int i = 0; i < count; i++) { /* furthest from the other two edges */
+    if (i == min_id || i == id1 || i == id2) continue;
+    v3sub(t, cpos[i], min_pos);
+    v3sub(u, cpos[id1], cpos[i]);
+    double dd = fabs(v3dot(t, vmin2)) + fabs(v3dot(u, v12));
+    if (dd > best) { id3 = i; best = dd; }
+  }
+  if (id3 == -1 || (0.0 < best && best < MIN_NEXT)) return nout;
+  HF_EMIT(cdist[id3], cpos[id3], cnrm[id3]);
+  return nout;
+}
 static int is_convex_pair(int t1, int t2) { /* MJ_COLLISION_TABLE collision_driver.py:47-80 (box-box: below; plane-mesh is primitive) */
   if (t2 == G_MESH && t1 >= G_SPHERE) return 1;
   return (t1 == G_SPHERE && t2 == G_ELLIPSOID) || (t1 == G_CAPSULE && (t2 == G_ELLIPSOID || t2 == G_CYLINDER)) ||
@@ -1151,6 +1297,7 @@ static int collide_pair(const RefModel* m, RefData* d, int g1, int g2, double ma
   const double *s1 = m->geom_size + 3 * g1, *s2 = m->geom_size + 3 * g2;
   double ax1[3] = {R1[2], R1[5], R1[8]}, ax2[3] = {R2[2], R2[5], R2[8]};
   int n = 0;
+  if (t1 == G_HFIELD) return t2 >= G_SPHERE ? collide_hfield(m, d, g1, g2, margin, gap, out) : 0; /* collision_driver.py:54-59 */
   /* box-box is a convex pair unless DisableBit.NATIVECCD asks for the primitive collider (collision_driver.py:867-870) */
   if (is_convex_pair(t1, t2) || (t1 == G_BOX && t2 == G_BOX && !(m->disableflags & DSBL_NATIVECCD)))
     return ccd_contact(m, g1, g2, t1, p1, R1, s1, t2, p2, R2, s2, margin, gap, out, &d->overflow);

@@ -145,6 +145,11 @@ typedef struct RefModel {
   int* mesh_vertadr;
   int* mesh_vertnum;
   double* mesh_vert;  /* [nmeshvert, 3] vertices in the mesh (= geom) frame */
+  double* hfield_size; /* [nhfield, 4]: x, y half sizes, top scale of the elevation data, base thickness */
+  int* hfield_nrow;
+  int* hfield_ncol;
+  int* hfield_adr;
+  double* hfield_data; /* elevations normalised to [0, 1] */
   int* mesh_graphadr; /* [nmesh] first word of the mesh's hill-climbing graph in mesh_graph, -1: none */
   int* mesh_graph;
   int* mesh_polyadr;

@@ -221,6 +221,7 @@ class RefSim:
                "xpair_gap": getattr(mjm, "pair_gap", np.zeros(0)),
                "actuator_trnid": mjm.actuator_trnid, "M_colind": mjm.M_colind}
     for name, dflt in (("geom_dataid", np.full(mjm.ngeom, -1)), ("mesh_vertadr", np.zeros(0)), ("mesh_vertnum", np.zeros(0)), ("mesh_vert", np.zeros((0, 3))),
+                       ("hfield_size", np.zeros((0, 4))), ("hfield_nrow", np.zeros(0)), ("hfield_ncol", np.zeros(0)), ("hfield_adr", np.zeros(0)), ("hfield_data", np.zeros(0)),
                        ("mesh_graphadr", np.full(max(int(getattr(mjm, "nmesh", 0)), 1), -1)), ("mesh_graph", np.zeros(0)), ("mesh_polyadr", np.zeros(0)), ("mesh_polynormal", np.zeros((0, 3))), ("mesh_polyvertadr", np.zeros(0)), ("mesh_polyvertnum", np.zeros(0)),
                        ("mesh_polyvert", np.zeros(0)), ("mesh_polymapadr", np.zeros(0)), ("mesh_polymapnum", np.zeros(0)), ("mesh_polymap", np.zeros(0))):
       special[name] = np.asarray(getattr(mjm, name, dflt))

@@ -1,0 +1,153 @@
+"""Height fields against convex geoms (reference collision_convex.py:60-161 _hfield_filter, 164-730 ccd_hfield kernel; MuJoCo
+mjc_ConvexHField): every triangular prism of the cells under the geom runs GJK / EPA against it, up to four
+of the results are kept.
+
+The reference's own fixtures for this path (collision_driver_test.py:626-690 _HFIELD_FIXTURES) are compared with MuJoCo C at run time --
+absent here -- so the float64 oracle is pinned by closed forms instead: on a flat height field the contact of a sphere / box / capsule
+is the plane contact (distance, position midway, normal +z); on a tilted plane sampled as a height field a sphere's distance is the
+distance to that plane.  The GPU path is then compared with the oracle on a bumpy terrain with every convex shape.
+"""
+
+import numpy as np
+import pytest
+
+import mujoco_warp_amd as mjw
+from oracle import ref
+from tests.conftest import relerr
+
+FLAT = """
+<mujoco>
+  <asset><hfield name="terrain" nrow="3" ncol="4" size="1 .8 .2 .1" elevation="0 0 0 0  0 0 0 0  0 0 0 0"/></asset>
+  <worldbody>
+    <geom type="hfield" hfield="terrain" pos="0 0 {z}"/>
+    <body pos=".1 .05 .09"><freejoint/><geom type="sphere" size=".1"/></body>
+    <body pos="-.4 .2 .1"><freejoint/><geom type="box" size=".1 .1 .11"/></body>
+    <body pos=".5 -.3 .04" euler="0 90 0"><freejoint/><geom type="capsule" size=".05 .1"/></body>
+    <body pos="0 -.5 .5"><freejoint/><geom type="sphere" size=".1"/></body>
+  </worldbody>
+</mujoco>
+"""
+
+
+def _terrain(nrow, ncol, fn, sx=1.0, sy=0.8):
+  rows = []
+  for r in range(nrow):  # MJCF lists the far (+y) row first
+    y = sy - 2 * sy * r / (nrow - 1)
+    rows.append(" ".join(f"{fn(-sx + 2 * sx * c / (ncol - 1), y):.6f}" for c in range(ncol)))
+  return "  ".join(rows)
+
+
+def test_oracle_flat_hfield_is_a_plane():
+  s = ref.RefSim(mjw.mjcf.from_xml_string(FLAT.format(z=0)), nconmax=32, njmax=128)
+  s.forward()
+  by = {}
+  for c in range(s.ncon):
+    by.setdefault(int(s.con_geom[c][1]), []).append(c)
+  assert sorted(by) == [1, 2, 3]  # (the high sphere is filtered)
+  for g, cons in by.items():
+    for c in cons:
+      assert abs(s.con_dist[c] + 0.01) < 1e-9 and np.allclose(s.con_frame[c][:3], [0, 0, 1], atol=1e-9) and abs(s.con_pos[c][2] + 0.005) < 1e-9
+  assert np.allclose(s.con_pos[by[1][0]][:2], [0.1, 0.05], atol=1e-9)
+  assert len(by[2]) >= 2 and all(abs(s.con_pos[c][0] + 0.4) <= 0.1 + 1e-9 and abs(s.con_pos[c][1] - 0.2) <= 0.1 + 1e-9 for c in by[2])
+  # the height field's own pose enters: lifted by 5 cm the penetrations grow by 5 cm
+  s2 = ref.RefSim(mjw.mjcf.from_xml_string(FLAT.format(z=0.05)), nconmax=32, njmax=128)
+  s2.forward()
+  # (a deeper geom also meets the side walls of the neighbouring prisms -- each prism is a closed solid -- so further contacts appear
+  # with tilted normals; the deepest one of every geom is the plane contact)
+  for g in (1, 2, 3):
+    cons = [c for c in range(s2.ncon) if s2.con_geom[c][1] == g]
+    c = cons[int(np.argmin([s2.con_dist[k] for k in cons]))]
+    assert abs(s2.con_dist[c] + 0.06) < 1e-7 and np.allclose(s2.con_frame[c][:3], [0, 0, 1], atol=1e-6)
+
+
+def test_oracle_tilted_plane_as_hfield():
+  """z = 0.1 + 0.1 x + 0.05 y sampled on a grid is exactly piecewise planar: a sphere's contact distance is its distance to that plane."""
+  plane = lambda x, y: 0.1 + 0.1 * x + 0.05 * y
+  xml = f"""<mujoco><asset><hfield name="t" nrow="9" ncol="11" size="1 .8 1 .1" elevation="{_terrain(9, 11, plane)}"/></asset>
+  <worldbody><geom type="hfield" hfield="t"/><body pos=".23 -.17 .2"><freejoint/><geom type="sphere" size=".1"/></body></worldbody></mujoco>"""
+  mjm = mjw.mjcf.from_xml_string(xml)
+  # the loader normalises the data to [0, 1] and MuJoCo scales it by size[2]: rescale so that the terrain is the plane again
+  lo, hi = plane(-1, -0.8), plane(1, 0.8)
+  mjm.hfield_size[0, 2] = hi - lo
+  s = ref.RefSim(mjm, nconmax=32, njmax=128)
+  n = np.array([-0.1, -0.05, 1.0])
+  n /= np.linalg.norm(n)
+  for z in (0.16, 0.19, 0.215):
+    s.qpos[2] = z
+    s.forward()
+    centre = np.array([0.23, -0.17, z])
+    # the normalisation subtracts the lowest sample: the terrain is the plane through (0, 0, plane(0, 0) - lo) with normal n
+    expect = np.dot(centre - np.array([0.0, 0.0, plane(0, 0) - lo]), n) - 0.1
+    if expect < 0:
+      assert s.ncon >= 1
+      c = int(np.argmin(s.con_dist[: s.ncon]))
+      assert abs(s.con_dist[c] - expect) < 1e-6, (z, s.con_dist[c], expect)
+      assert np.allclose(s.con_frame[c][:3], n, atol=1e-6)
+    else:
+      assert s.ncon == 0
+
+
+BUMPY = f"""
+<mujoco>
+  <option timestep="0.004"><flag multiccd="disable"/></option>
+  <asset>
+    <hfield name="bumps" nrow="13" ncol="17" size="1 .8 .12 .1" elevation="{_terrain(13, 17, lambda x, y: 0.5 + 0.5 * np.sin(3.1 * x) * np.cos(2.7 * y))}"/>
+    <mesh name="gem" vertex=".12 0 0  -.12 0 0  0 .1 0  0 -.1 0  0 0 .16  0 0 -.09  .07 .06 .08  -.06 -.07 .05"/>
+  </asset>
+  <worldbody>
+    <geom type="hfield" hfield="bumps"/>
+    <body pos="-.6 -.4 .3"><freejoint/><geom type="sphere" size=".08"/></body>
+    <body pos="-.2 -.4 .3" euler="20 30 0"><freejoint/><geom type="box" size=".09 .07 .06"/></body>
+    <body pos=".2 -.4 .3" euler="0 70 10"><freejoint/><geom type="capsule" size=".05 .1"/></body>
+    <body pos=".6 -.4 .3" euler="10 0 0"><freejoint/><geom type="ellipsoid" size=".1 .07 .05"/></body>
+    <body pos="-.4 .3 .3" euler="80 0 0"><freejoint/><geom type="cylinder" size=".06 .08"/></body>
+    <body pos=".3 .3 .35" euler="0 20 40"><freejoint/><geom type="mesh" mesh="gem"/></body>
+  </worldbody>
+</mujoco>
+"""
+
+
+def test_oracle_bumpy_terrain_keeps_bodies_up():
+  s = ref.RefSim(mjw.mjcf.from_xml_string(BUMPY), nconmax=64, njmax=256)
+  seen = set()
+  for _ in range(250):  # (later the capsule rolls off the edge of the terrain)
+    s.step()
+    seen |= {int(s.con_geom[c][1]) for c in range(s.ncon)}
+  assert seen == {1, 2, 3, 4, 5, 6} and s.overflow == 0
+  assert (s.qpos[2::7] > 0.03).all(), s.qpos[2::7]  # nothing fell through the terrain
+
+
+@pytest.mark.gpu
+def test_gpu_hfield_vs_oracle():
+  mjm = mjw.mjcf.from_xml_string(BUMPY)
+  m = mjw.put_model(mjm)
+  assert m.nhfield == 1 and m.heavy_colliders == 1
+  d = mjw.make_data(mjm, nworld=2, nconmax=64, njmax=256)
+  sims = [ref.RefSim(mjm, nconmax=64, njmax=256) for _ in range(2)]
+  q = d.qpos.numpy()
+  q[1, 0::7] += 0.021
+  d.qpos.assign(q)
+  seen = set()
+  flicker = total = 0
+  for step in range(250):
+    for w, s in enumerate(sims):
+      s.qpos[:] = d.qpos.numpy()[w]
+      s.qvel[:] = d.qvel.numpy()[w]
+      s.qacc_warmstart[:] = d.qacc_warmstart.numpy()[w]
+    mjw.step(m, d)
+    for w, s in enumerate(sims):
+      s.step()
+      total += 1
+      err = relerr(d.qpos.numpy()[w], s.qpos)
+      # The selection of the (up to four) contacts of a pair is ill-conditioned by construction: which of two neighbouring prisms with the
+      # same depth is "the deepest", the 1 mm rule that ends the selection, and -- for boxes and meshes -- which face of a prism EPA leaves
+      # through (its top or the side wall next to it: depths of 4.5 vs 1.9 mm were seen for one box corner) flip between float32 and
+      # float64.  Such a step is solved with a different, equally admissible contact set; the state stays within 5e-3 of the oracle's.
+      if int(d.ws_ncon.numpy()[w]) != s.ncon or err >= 3e-4:
+        flicker += 1
+        assert err < 5e-3, (step, w)
+        continue
+      seen |= {int(s.con_geom[c][1]) for c in range(s.ncon)}
+  assert flicker <= 0.3 * total, (flicker, total)
+  assert seen == {1, 2, 3, 4, 5, 6}
+  assert (d.overflow.numpy() == 0).all()
