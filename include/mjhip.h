@@ -56,6 +56,7 @@ extern "C" {
 #define MJH_STAGE_WAKE_EQUALITY 23   /* sleep.wake_equality (+ update_sleep)  sleep.py:793 */
 #define MJH_STAGE_ISLAND 24          /* island.island                island.py:294 */
 #define MJH_STAGE_SLEEP 25           /* sleep.sleep (+ update_sleep) sleep.py:947 */
+#define MJH_STAGE_SENSOR 26          /* sensor.sensor_pos + sensor_vel + (actuator forces of) sensor_acc  sensor.py:810, 1432, 2512 */
 #define MJH_STAGE_RUNGEKUTTA4 19     /* forward.rungekutta4 (after a forward)  forward.py:524 */
 
 typedef struct MjhModel {
@@ -142,6 +143,11 @@ typedef struct MjhModel {
   const int* geom_dataid;       /* [ngeom] mesh id of mesh geoms, -1 otherwise (types.py:1266)                  */
   const int* mesh_vertadr; const int* mesh_vertnum; /* [nmesh] first vertex / number of vertices (types.py:1707-1709) */
   const float* mesh_vert;       /* [nmeshvert, 3] vertices in the mesh (= geom) frame; searched exhaustively by the convex narrowphase */
+  /* sensors (types.py: sensor_*; csrc/sensor.hpp computes joint / actuator / ball / frame / velocimeter / gyro / subtreecom / clock) */
+  int nsensor; int nsensordata;
+  const int* sensor_type; const int* sensor_datatype; const int* sensor_objtype; const int* sensor_objid; const int* sensor_reftype; const int* sensor_refid;
+  const int* sensor_dim; const int* sensor_adr;
+  const float* sensor_cutoff;
   /* height fields (types.py: hfield_*; geom_dataid of an hfield geom is its height field) */
   int nhfield;
   const float* hfield_size;     /* [nhfield, 4] x, y half sizes, top scale of the elevation data, base thickness */
@@ -247,6 +253,7 @@ typedef struct MjhData {
   int* ws_isl_count;   /* [4] entries of the three lists                                                                        */
   int* ws_separable;   /* [nworld] 1: every island has at most 64 dofs (solved per island), 0: generic solver             */
   /* sleeping (types.py:2330-2345; all empty unless MjhModel.sleep_enabled) */
+  float* sensordata;   /* [nworld, nsensordata] Data.sensordata (types.py) */
   int* tree_asleep;    /* [nworld, ntree] < 0: awake (counts up to -1 while the tree could sleep), >= 0: next tree of its sleep cycle */
   int* tree_awake;     /* [nworld, ntree] */
   int* body_awake;     /* [nworld, nbody] SleepState: -1 static, 0 asleep, 1 awake */
@@ -315,7 +322,7 @@ int mjh_timed_steps(const MjhModel* m, const MjhData* d, int nstep, int step0, f
 int mjh_release_thread_resources(void);
 
 const char* mjh_last_error(void);
-#define MJH_ABI_VERSION 20
+#define MJH_ABI_VERSION 21
 int mjh_abi_version(void); /* returns MJH_ABI_VERSION of the library that was loaded */
 
 #ifdef __cplusplus

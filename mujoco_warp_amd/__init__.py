@@ -12,6 +12,7 @@ from .forward import KERNEL_NAMES
 from .forward import StepGraph
 from .forward import com_pos
 from .forward import island
+from .forward import sensor
 from .forward import sleep
 from .forward import update_sleep
 from .forward import wake

@@ -28,7 +28,7 @@ enum { CT_EQUALITY = 0, CT_FRICTION_DOF = 1, CT_FRICTION_TENDON = 2, CT_LIMIT_JO
 enum { DSBL_CONSTRAINT = 1 << 0, DSBL_EQUALITY = 1 << 1, DSBL_FRICTIONLOSS = 1 << 2, DSBL_LIMIT = 1 << 3,
        DSBL_CONTACT = 1 << 4, DSBL_SPRING = 1 << 5, DSBL_DAMPER = 1 << 6, DSBL_GRAVITY = 1 << 7,
        DSBL_CLAMPCTRL = 1 << 8, DSBL_WARMSTART = 1 << 9, DSBL_FILTERPARENT = 1 << 10, DSBL_ACTUATION = 1 << 11,
-       DSBL_REFSAFE = 1 << 12, DSBL_EULERDAMP = 1 << 15, DSBL_NATIVECCD = 1 << 17, DSBL_MULTICCD = 1 << 19 };
+       DSBL_REFSAFE = 1 << 12, DSBL_SENSOR = 1 << 13, DSBL_EULERDAMP = 1 << 15, DSBL_NATIVECCD = 1 << 17, DSBL_MULTICCD = 1 << 19 };
 enum { SOL_PGS = 0, SOL_CG = 1, SOL_NEWTON = 2 };
 enum { CONE_PYRAMIDAL = 0, CONE_ELLIPTIC = 1 };
 enum { ISL_WIDE = 1, ISL_MANYROWS = 2 };

@@ -12,6 +12,7 @@
 #include "constraint.hpp"
 #include "dev_common.hpp"
 #include "integrate.hpp"
+#include "sensor.hpp"
 #include "sleep.hpp"
 #include "smooth.hpp"
 
@@ -109,6 +110,12 @@ static int launch_constraint(const MjhModel* m, const MjhData* d, hipStream_t s)
   HIPCHK(set_lds(k_make_constraint<G>, lds));
   const int wpb = threads / G;
   hipLaunchKernelGGL(k_make_constraint<G>, dim3((d->nworld + wpb - 1) / wpb), dim3(threads), lds, s, *m, *d);
+  return MJH_OK;
+}
+static int launch_sensor(const MjhModel* m, const MjhData* d, hipStream_t s) {
+  if (m->nsensor == 0 || (m->disableflags & DSBL_SENSOR)) return MJH_OK;
+  if (!d->sensordata) return fail(MJH_E_ARG, "Data.sensordata missing (allocate Data with make_data/put_data)");
+  hipLaunchKernelGGL(k_sensor, dim3((d->nworld * m->nsensor + 255) / 256), dim3(256), 0, s, *m, *d);
   return MJH_OK;
 }
 static int launch_solve(const MjhModel* m, const MjhData* d, hipStream_t s);  // = the solver workgroups of k_solve_plus
@@ -423,6 +430,7 @@ static int run_sleep_step(const MjhModel* m, const MjhData* d, bool step, hipStr
   { Scope sc(K_CONSTRAINT); TRY(launch_constraint(m, d, s)); }
   { Scope sc(K_OTHER); hipLaunchKernelGGL(k_sleep, gw, bw, 0, s, *m, *d, (int)SLP_POST_CONSTRAINT); }
   { Scope sc(K_VEL); TRY(launch_vel(m, d, VEL_COMVEL, VEL_ACCEL, s)); }
+  { Scope sc(K_OTHER); TRY(launch_sensor(m, d, s)); }
   {
     Scope sc(K_OTHER);
     if (m->nv > 0) hipLaunchKernelGGL(k_sleep_qfrc, dim3((d->nworld * m->nv + 255) / 256), dim3(256), 0, s, *m, *d);
@@ -478,6 +486,7 @@ static int run_stage(const MjhModel* m, const MjhData* d, int stage, hipStream_t
       { Scope sc(K_CONSTRAINT); TRY(launch_constraint(m, d, s)); }
       { Scope sc(K_OTHER); TRY(launch_publish(d, s)); }
       return MJH_OK;
+    case MJH_STAGE_SENSOR: { Scope sc(K_OTHER); return launch_sensor(m, d, s); }
     case MJH_STAGE_UPDATE_SLEEP:
     case MJH_STAGE_WAKE:
     case MJH_STAGE_WAKE_COLLISION:
@@ -519,6 +528,7 @@ static int run_stage(const MjhModel* m, const MjhData* d, int stage, hipStream_t
         { Scope sc(K_COLLISION); TRY(launch_collision(m, d, s)); }
         { Scope sc(K_CONSTRAINT); TRY(launch_constraint(m, d, s)); }
         { Scope sc(K_VEL); TRY(launch_vel(m, d, VEL_COMVEL, VEL_ACCEL, s)); }
+        { Scope sc(K_OTHER); TRY(launch_sensor(m, d, s)); }
         { Scope sc(K_SOLVE); TRY(launch_solve(m, d, s)); }
         if (stage == MJH_STAGE_STEP) { Scope sc(K_INTEGRATE); TRY(launch_integrate(m, d, mode, s)); }
         Scope sc(K_OTHER);
@@ -530,6 +540,7 @@ static int run_stage(const MjhModel* m, const MjhData* d, int stage, hipStream_t
       bool sched_done = false;
       { Scope sc(K_POS); TRY(launch_pos_plus(m, d, POS_KINEMATICS, POS_CRB, &sched_done, s)); }
       { Scope sc(K_MID); TRY(launch_mid(m, d, !sched_done, s)); }
+      { Scope sc(K_OTHER); TRY(launch_sensor(m, d, s)); }  // (no launch without sensors; before the solver, whose epilogue may integrate the state)
       // (nv <= 32 only: beside the 64-lane solver of larger models the riders cost more than they save, G1 -3 %)
       static const int side_nv = getenv("MJH_SIDE_NV") ? atoi(getenv("MJH_SIDE_NV")) : 32;  // developer knob
       Side* side = (m->solver == SOL_NEWTON && m->nv <= side_nv && !(g_instr && g_instr->on)) ? side_stream() : nullptr;

@@ -1,0 +1,132 @@
+// Sensors (reference sensor.py), the subset of RL-style consumers: joint / actuator / ball-joint readings, frame position / axes /
+// quaternion / linear and angular velocity (optionally relative to a reference frame), the IMU-style site sensors velocimeter and gyro,
+// subtree centre of mass, clock.  One thread per (world, sensor); everything is read from the public Data arrays, which are final for all
+// of these once fwd_position / fwd_velocity / fwd_actuation have run -- the launch sits before the solver (whose fused epilogue may
+// already integrate the state: Data.qpos / qvel / time must still be the step's inputs when JOINTPOS / JOINTVEL / CLOCK are read).
+// Not built: sensors that need rne_postconstraint (accelerometer, force, torque, touch, frame accelerations), tendons, cameras, rays,
+// collision sensors, energies (put_model / the loader raise).
+#pragma once
+#include "dev_common.hpp"
+
+enum { SENS_VELOCIMETER = 2, SENS_GYRO = 3, SENS_JOINTPOS = 9, SENS_JOINTVEL = 10, SENS_ACTUATORPOS = 13, SENS_ACTUATORVEL = 14, SENS_ACTUATORFRC = 15,
+       SENS_BALLQUAT = 18, SENS_BALLANGVEL = 19, SENS_FRAMEPOS = 26, SENS_FRAMEQUAT = 27, SENS_FRAMEXAXIS = 28, SENS_FRAMEYAXIS = 29, SENS_FRAMEZAXIS = 30,
+       SENS_FRAMELINVEL = 31, SENS_FRAMEANGVEL = 32, SENS_SUBTREECOM = 35, SENS_CLOCK = 45 };
+enum { OBJ_BODY = 1, OBJ_XBODY = 2, OBJ_GEOM = 5, OBJ_SITE = 6 };
+
+struct SensFrame {
+  V3 pos;
+  const float* mat;
+  int body;
+};
+// sensor.py:266-340 _get_pos / _get_mat / _get_body_id
+DEV SensFrame sens_frame(const MjhModel& m, const MjhData& d, int w, int objtype, int id) {
+  SensFrame f{V3{0, 0, 0}, nullptr, 0};
+  if (objtype == OBJ_BODY) {
+    f.body = id;
+    f.pos = ld3(d.xipos + ((size_t)w * m.nbody + id) * 3);
+    f.mat = d.ximat + ((size_t)w * m.nbody + id) * 9;
+  } else if (objtype == OBJ_XBODY) {
+    f.body = id;
+    f.pos = ld3(d.xpos + ((size_t)w * m.nbody + id) * 3);
+    f.mat = d.xmat + ((size_t)w * m.nbody + id) * 9;
+  } else if (objtype == OBJ_GEOM) {
+    f.body = m.geom_bodyid[id];
+    f.pos = ld3(d.geom_xpos + ((size_t)w * m.ngeom + id) * 3);
+    f.mat = d.geom_xmat + ((size_t)w * m.ngeom + id) * 9;
+  } else if (objtype == OBJ_SITE) {
+    f.body = m.site_bodyid[id];
+    f.pos = ld3(d.site_xpos + ((size_t)w * m.nsite + id) * 3);
+    f.mat = d.site_xmat + ((size_t)w * m.nsite + id) * 9;
+  }
+  return f;
+}
+// sensor.py:342-374 _get_quat
+DEV Q4 sens_quat(const MjhModel& m, const MjhData& d, int w, int objtype, int id) {
+  const float* xquat = d.xquat + (size_t)w * m.nbody * 4;
+  if (objtype == OBJ_BODY) return mul_quat(ld4(xquat + 4 * id), ld4(bf(m.body_iquat, m.body_iquat_nb, w, 4 * m.nbody) + 4 * id));
+  if (objtype == OBJ_XBODY) return ld4(xquat + 4 * id);
+  if (objtype == OBJ_GEOM) return mul_quat(ld4(xquat + 4 * m.geom_bodyid[id]), ld4(bf(m.geom_quat, m.geom_quat_nb, w, 4 * m.ngeom) + 4 * id));
+  if (objtype == OBJ_SITE) return mul_quat(ld4(xquat + 4 * m.site_bodyid[id]), ld4(bf(m.site_quat, m.site_quat_nb, w, 4 * m.nsite) + 4 * id));
+  return Q4{1, 0, 0, 0};
+}
+// sensor.py:1066-1105 _cvel_offset and the velocity of the frame's origin
+DEV void sens_vel(const MjhModel& m, const MjhData& d, int w, const SensFrame& f, V3& lin, V3& ang) {
+  const float* cv = d.cvel + ((size_t)w * m.nbody + f.body) * 6;
+  const V3 off = f.pos - ld3(d.subtree_com + ((size_t)w * m.nbody + m.body_rootid[f.body]) * 3);
+  ang = ld3(cv);
+  lin = ld3(cv + 3) - cross(off, ang);
+}
+
+__global__ void __launch_bounds__(256) k_sensor(MjhModel m, MjhData d) {
+  const int idx = blockIdx.x * 256 + threadIdx.x, ns = m.nsensor;
+  if (idx >= d.nworld * ns) return;
+  const int w = idx / ns, i = idx - w * ns;
+  const int t = m.sensor_type[i], id = m.sensor_objid[i], ot = m.sensor_objtype[i], rid = m.sensor_refid[i], rt = m.sensor_reftype[i];
+  float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  auto put3 = [&](V3 a) {
+    v[0] = a.x;
+    v[1] = a.y;
+    v[2] = a.z;
+  };
+  if (t == SENS_JOINTPOS) v[0] = d.qpos[(size_t)w * m.nq + m.jnt_qposadr[id]];
+  else if (t == SENS_JOINTVEL) v[0] = d.qvel[(size_t)w * m.nv + m.jnt_dofadr[id]];
+  else if (t == SENS_ACTUATORPOS) v[0] = d.actuator_length[(size_t)w * m.nu + id];
+  else if (t == SENS_ACTUATORVEL) v[0] = d.actuator_velocity[(size_t)w * m.nu + id];
+  else if (t == SENS_ACTUATORFRC) v[0] = d.actuator_force[(size_t)w * m.nu + id];
+  else if (t == SENS_BALLQUAT) {
+    const Q4 q = quat_normalize(ld4(d.qpos + (size_t)w * m.nq + m.jnt_qposadr[id]));
+    v[0] = q.w; v[1] = q.x; v[2] = q.y; v[3] = q.z;
+  } else if (t == SENS_BALLANGVEL) put3(ld3(d.qvel + (size_t)w * m.nv + m.jnt_dofadr[id]));
+  else if (t == SENS_CLOCK) v[0] = d.time[w];
+  else if (t == SENS_SUBTREECOM) put3(ld3(d.subtree_com + ((size_t)w * m.nbody + id) * 3));
+  else if (t == SENS_FRAMEPOS) {
+    const SensFrame f = sens_frame(m, d, w, ot, id);
+    if (rid == -1) put3(f.pos);
+    else {
+      const SensFrame r = sens_frame(m, d, w, rt, rid);
+      put3(matT_mul(r.mat, f.pos - r.pos));
+    }
+  } else if (t == SENS_FRAMEXAXIS || t == SENS_FRAMEYAXIS || t == SENS_FRAMEZAXIS) {
+    const int ax = t - SENS_FRAMEXAXIS;
+    const SensFrame f = sens_frame(m, d, w, ot, id);
+    const V3 a = V3{f.mat[ax], f.mat[3 + ax], f.mat[6 + ax]};
+    if (rid == -1) put3(a);
+    else put3(matT_mul(sens_frame(m, d, w, rt, rid).mat, a));
+  } else if (t == SENS_FRAMEQUAT) {
+    Q4 q = sens_quat(m, d, w, ot, id);
+    if (rid != -1) {
+      const Q4 r = sens_quat(m, d, w, rt, rid);
+      q = mul_quat(Q4{r.w, -r.x, -r.y, -r.z}, q);
+    }
+    v[0] = q.w; v[1] = q.x; v[2] = q.y; v[3] = q.z;
+  } else if (t == SENS_VELOCIMETER || t == SENS_GYRO) {
+    const SensFrame f = sens_frame(m, d, w, OBJ_SITE, id);
+    V3 lin, ang;
+    sens_vel(m, d, w, f, lin, ang);
+    put3(matT_mul(f.mat, t == SENS_GYRO ? ang : lin));
+  } else if (t == SENS_FRAMELINVEL || t == SENS_FRAMEANGVEL) {
+    const SensFrame f = sens_frame(m, d, w, ot, id);
+    V3 lin, ang;
+    sens_vel(m, d, w, f, lin, ang);
+    if (rid == -1) put3(t == SENS_FRAMELINVEL ? lin : ang);
+    else {
+      const SensFrame r = sens_frame(m, d, w, rt, rid);
+      V3 rlin, rang;
+      sens_vel(m, d, w, r, rlin, rang);
+      if (t == SENS_FRAMELINVEL) put3(matT_mul(r.mat, lin - rlin + cross(f.pos - r.pos, rang)));
+      else put3(matT_mul(r.mat, ang - rang));
+    }
+  }
+  // sensor.py:57-114: cutoff for real (clamp) and positive (min) data
+  const float cut = m.sensor_cutoff[i];
+  const int dt = m.sensor_datatype[i], adr = m.sensor_adr[i], dim = m.sensor_dim[i];
+  float* out = d.sensordata + (size_t)w * m.nsensordata + adr;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (k < dim) {
+      float x = v[k];
+      if (cut > 0.0f && dt == 0) x = fminf(fmaxf(x, -cut), cut);
+      else if (cut > 0.0f && dt == 1) x = fminf(x, cut);
+      out[k] = x;
+    }
+}

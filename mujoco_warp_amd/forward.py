@@ -112,6 +112,12 @@ def rungekutta4(m, d):
   _run(_S["MJH_STAGE_RUNGEKUTTA4"], m, d)
 
 
+def sensor(m, d):
+  """Data.sensordata from the current position / velocity / actuation results (reference sensor.sensor_pos / sensor_vel and the actuator
+  forces of sensor_acc, sensor.py:810, 1432, 2512); `forward` and `step` call it themselves."""
+  _run(_S["MJH_STAGE_SENSOR"], m, d)
+
+
 def update_sleep(m, d):
   """Sleep tables (tree_awake, body_awake, awake index lists and counts) from Data.tree_asleep (reference sleep.py:171)."""
   _run(_S["MJH_STAGE_UPDATE_SLEEP"], m, d)

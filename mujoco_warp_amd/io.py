@@ -16,6 +16,8 @@ from . import _abi
 from . import types
 from .device import DeviceArray
 
+from .mjcf import SENS as mjcf_SENS  # mjtSensor values of the supported sensors
+
 _BATCHED_MODEL_FIELDS = [n[:-3] for n, k, p in _abi.MODEL_FIELDS if n.endswith("_nb")]
 _MODEL_PTR_FIELDS = [(n, k) for n, k, p in _abi.MODEL_FIELDS if p]
 _DATA_PTR_FIELDS = [(n, k) for n, k, p in _abi.DATA_FIELDS if p]
@@ -351,6 +353,11 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
     geom_priority=_arr(mjm.geom_priority, i32), geom_dataid=_arr(getattr(mjm, "geom_dataid", np.full(ngeom, -1)), i32),
     mesh_vertadr=_arr(getattr(mjm, "mesh_vertadr", np.zeros(0)), i32), mesh_vertnum=_arr(getattr(mjm, "mesh_vertnum", np.zeros(0)), i32),
     mesh_vert=_arr(getattr(mjm, "mesh_vert", np.zeros((0, 3))), f32).reshape(-1, 3),
+    sensor_type=_arr(getattr(mjm, "sensor_type", np.zeros(0)), i32), sensor_datatype=_arr(getattr(mjm, "sensor_datatype", np.zeros(0)), i32),
+    sensor_objtype=_arr(getattr(mjm, "sensor_objtype", np.zeros(0)), i32), sensor_objid=_arr(getattr(mjm, "sensor_objid", np.zeros(0)), i32),
+    sensor_reftype=_arr(getattr(mjm, "sensor_reftype", np.zeros(0)), i32), sensor_refid=_arr(getattr(mjm, "sensor_refid", np.zeros(0)), i32),
+    sensor_dim=_arr(getattr(mjm, "sensor_dim", np.zeros(0)), i32), sensor_adr=_arr(getattr(mjm, "sensor_adr", np.zeros(0)), i32),
+    sensor_cutoff=_arr(getattr(mjm, "sensor_cutoff", np.zeros(0)), f32),
     hfield_size=_arr(getattr(mjm, "hfield_size", np.zeros((0, 4))), f32).reshape(-1, 4), hfield_nrow=_arr(getattr(mjm, "hfield_nrow", np.zeros(0)), i32),
     hfield_ncol=_arr(getattr(mjm, "hfield_ncol", np.zeros(0)), i32), hfield_adr=_arr(getattr(mjm, "hfield_adr", np.zeros(0)), i32),
     hfield_data=_arr(getattr(mjm, "hfield_data", np.zeros(0)), f32),
@@ -371,6 +378,13 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
     actuator_forcelimited=_arr(mjm.actuator_forcelimited, i32), actuator_actlimited=_arr(mjm.actuator_actlimited, i32),
     eq_obj1id=_arr(getattr(mjm, "eq_obj1id", np.zeros(0)), i32), eq_obj2id=_arr(getattr(mjm, "eq_obj2id", np.zeros(0)), i32),
   )
+  m.nsensor, m.nsensordata = int(host["sensor_type"].shape[0]), int(getattr(mjm, "nsensordata", 0))
+  supported_sensors = set(mjcf_SENS.values())
+  bad = [int(t) for t in host["sensor_type"] if int(t) not in supported_sensors]
+  if bad:  # (sensors do not enter the dynamics: the model still loads, their sensordata slots stay zero)
+    import warnings
+
+    warnings.warn(f"sensor types {sorted(set(bad))} are not computed by this engine (csrc/sensor.hpp computes {sorted(supported_sensors)}): their sensordata entries are 0")
   m.nmeshvert = int(host["mesh_vert"].shape[0])
   m.nmeshpoly = int(host["mesh_polyvertnum"].shape[0])
   m.nmeshgraph = int(host["mesh_graph"].shape[0])
@@ -517,7 +531,7 @@ def _data_shapes(m, nworld, nconmax, njmax, naconmax):
     tree_asleep=(W, m.ntree), tree_awake=(W, m.ntree), body_awake=(W, nb), body_awake_ind=(W, nb), dof_awake_ind=(W, nv), ntree_awake=(W,), nbody_awake=(W,),
     nv_awake=(W,), tree_island=(W, m.ntree), nisland=(W,), ws_sleep_J=(W if m.sleep_enabled else 0, njmax_pad, nv_pad), ws_sleep_warm=(W if m.sleep_enabled else 0, nv),
     ws_sleep_flag=(W,),
-    eq_active=(W, m.neq), ws_rk=(W, nq + 3 * nv + 2 * na), ws_contact=(W, contact_cap(nconmax), 32),
+    sensordata=(W, m.nsensordata), eq_active=(W, m.neq), ws_rk=(W, nq + 3 * nv + 2 * na), ws_contact=(W, contact_cap(nconmax), 32),
   )
   return sh, njmax_pad, nv_pad
 

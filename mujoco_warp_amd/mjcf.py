@@ -1330,9 +1330,10 @@ def _compile(root, base_dir):
         arr[i] = v
 
   # sizes not on the hot path
-  m.ntendon = m.nsensor = m.nflex = m.nplugin = 0
+  m.ntendon = m.nflex = m.nplugin = 0
   m.ncam = m.nlight = 0
-  m.nuserdata = m.nsensordata = 0
+  m.nuserdata = 0
+  _compile_sensors(m, root, [s_["name"] for s_ in sites])
 
   _sparse_structure(m)
   set_const(m)
@@ -1340,6 +1341,64 @@ def _compile(root, base_dir):
     if "meaninertia" in st.attrib:
       m.stat.meaninertia = float(st.get("meaninertia"))
   return m
+
+
+# mjtSensor / mjtObj / mjtDataType / mjtStage values used below (MuJoCo's enums; UNPINNED here -- the mujoco package is absent: a real
+# MjModel carries its own numbers in sensor_type, which put_model compares with these)
+SENS = {"velocimeter": 2, "gyro": 3, "jointpos": 9, "jointvel": 10, "actuatorpos": 13, "actuatorvel": 14, "actuatorfrc": 15, "ballquat": 18, "ballangvel": 19,
+        "framepos": 26, "framequat": 27, "framexaxis": 28, "frameyaxis": 29, "framezaxis": 30, "framelinvel": 31, "frameangvel": 32, "subtreecom": 35, "clock": 45}
+# sensors that keep their slot in sensordata (the reference's layout) but are not computed: the engine writes zeros and put_model warns
+SENS_UNSUPPORTED = {"touch": (0, 1), "accelerometer": (1, 3), "force": (4, 3), "torque": (5, 3), "magnetometer": (6, 3), "rangefinder": (7, 1), "jointactuatorfrc": (16, 1),
+                    "jointlimitpos": (20, 1), "jointlimitvel": (21, 1), "jointlimitfrc": (22, 1), "framelinacc": (33, 3), "frameangacc": (34, 3), "subtreelinvel": (36, 3),
+                    "subtreeangmom": (37, 3), "e_potential": (43, 1), "e_kinetic": (44, 1)}
+_SENS_DIM = {"ballquat": 4, "framequat": 4, "jointpos": 1, "jointvel": 1, "actuatorpos": 1, "actuatorvel": 1, "actuatorfrc": 1, "clock": 1}
+_SENS_STAGE = {"velocimeter": 2, "gyro": 2, "jointvel": 2, "actuatorvel": 2, "ballangvel": 2, "framelinvel": 2, "frameangvel": 2, "actuatorfrc": 3}  # default: POS (1)
+_OBJ = {"body": 1, "xbody": 2, "geom": 5, "site": 6, "camera": 7}
+
+
+def _compile_sensors(m, root, site_names):
+  """<sensor> section, the subset csrc/sensor.hpp computes (reference sensor.py: joint / actuator / ball / frame / IMU-style site sensors,
+  subtree centre of mass, clock); anything else raises."""
+  rows = []
+  lookup = {1: m.body_names, 2: m.body_names, 5: m.geom_names, 6: site_names}
+  for sec in root.findall("sensor"):
+    for e in sec:
+      a = e.attrib
+      if e.tag in SENS_UNSUPPORTED:
+        rows.append(dict(type=SENS_UNSUPPORTED[e.tag][0], datatype=0, needstage=3, objtype=0, objid=-1, reftype=0, refid=-1, dim=SENS_UNSUPPORTED[e.tag][1], cutoff=0.0,
+                         name=a.get("name", "")))
+        continue
+      if e.tag not in SENS:
+        raise NotImplementedError(f"sensor <{e.tag}> is not implemented")
+      objtype, objid, reftype, refid = 0, -1, 0, -1
+      if e.tag in ("jointpos", "jointvel", "ballquat", "ballangvel"):
+        objtype, objid = 3, m.jnt_names.index(a["joint"])  # mjOBJ_JOINT
+        ball = m.jnt_type[objid] == JNT_BALL
+        if ball != (e.tag in ("ballquat", "ballangvel")) or m.jnt_type[objid] == JNT_FREE:
+          raise ValueError(f"sensor <{e.tag}> on a joint of the wrong type")
+      elif e.tag in ("actuatorpos", "actuatorvel", "actuatorfrc"):
+        objtype, objid = 19, m.actuator_names.index(a["actuator"])  # mjOBJ_ACTUATOR
+      elif e.tag in ("velocimeter", "gyro"):
+        objtype, objid = 6, site_names.index(a["site"])
+      elif e.tag == "subtreecom":
+        objtype, objid = 1, m.body_names.index(a["body"])
+      elif e.tag != "clock":
+        objtype = _OBJ[a["objtype"]]
+        objid = lookup[objtype].index(a["objname"])
+        if "reftype" in a:
+          reftype = _OBJ[a["reftype"]]
+          refid = lookup[reftype].index(a["refname"])
+      dim = _SENS_DIM.get(e.tag, 3)
+      rows.append(dict(type=SENS[e.tag], datatype=3 if e.tag in ("ballquat", "framequat") else (2 if e.tag.startswith("frame") and e.tag.endswith("axis") else 0),
+                       needstage=_SENS_STAGE.get(e.tag, 1), objtype=objtype, objid=objid, reftype=reftype, refid=refid, dim=dim,
+                       cutoff=float(a.get("cutoff", 0.0)), name=a.get("name", "")))
+  m.nsensor = len(rows)
+  for k in ("type", "datatype", "needstage", "objtype", "objid", "reftype", "refid", "dim"):
+    setattr(m, "sensor_" + k, np.array([r[k] for r in rows], dtype=np.int32))
+  m.sensor_cutoff = np.array([r["cutoff"] for r in rows], dtype=np.float64)
+  m.sensor_adr = np.concatenate([[0], np.cumsum(m.sensor_dim)[:-1]]).astype(np.int32) if rows else np.zeros(0, dtype=np.int32)
+  m.nsensordata = int(m.sensor_dim.sum()) if rows else 0
+  m.sensor_names = [r["name"] for r in rows]
 
 
 def mixed_contact_params(m, g1, g2):

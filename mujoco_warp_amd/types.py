@@ -415,6 +415,16 @@ class Model(_Dirty):
   nmeshpolyvert: int = 0
   nmeshpolymap: int = 0
   npolygonmax: int = 0
+  nsensordata: int = 0
+  sensor_type: DeviceArray = _arr(('nsensor',), "int32")
+  sensor_datatype: DeviceArray = _arr(('nsensor',), "int32")
+  sensor_objtype: DeviceArray = _arr(('nsensor',), "int32")
+  sensor_objid: DeviceArray = _arr(('nsensor',), "int32")
+  sensor_reftype: DeviceArray = _arr(('nsensor',), "int32")
+  sensor_refid: DeviceArray = _arr(('nsensor',), "int32")
+  sensor_dim: DeviceArray = _arr(('nsensor',), "int32")
+  sensor_adr: DeviceArray = _arr(('nsensor',), "int32")
+  sensor_cutoff: DeviceArray = _arr(('nsensor',), "float32")
   nmeshgraph: int = 0
   nhfielddata: int = 0
   hfield_size: DeviceArray = _arr(('nhfield', 4), "float32")
@@ -560,6 +570,7 @@ class Data(_Dirty):
   ws_separable: DeviceArray = _arr(('nworld',), "int32")
   ws_ccd: DeviceArray = _arr(('nccdworld', 'nccdword', 32), "float32")
   ws_order: DeviceArray = _arr(('nworld',), "int32")
+  sensordata: DeviceArray = _arr(('nworld', 'nsensordata'), "float32")
   tree_asleep: DeviceArray = _arr(('nworld', 'ntree'), "int32")  # reference types.py:2330-2345
   tree_awake: DeviceArray = _arr(('nworld', 'ntree'), "int32")
   body_awake: DeviceArray = _arr(('nworld', 'nbody'), "int32")

@@ -2787,6 +2787,134 @@ void ref_sleep(const RefModel* m, RefData* d) { /* sleep.py:824-999 */
   free(can);
 }
 
+/* ================================================================ sensors (sensor.py, subset) */
+enum { SENS_VELOCIMETER = 2, SENS_GYRO = 3, SENS_JOINTPOS = 9, SENS_JOINTVEL = 10, SENS_ACTUATORPOS = 13, SENS_ACTUATORVEL = 14, SENS_ACTUATORFRC = 15,
+       SENS_BALLQUAT = 18, SENS_BALLANGVEL = 19, SENS_FRAMEPOS = 26, SENS_FRAMEQUAT = 27, SENS_FRAMEXAXIS = 28, SENS_FRAMEYAXIS = 29, SENS_FRAMEZAXIS = 30,
+       SENS_FRAMELINVEL = 31, SENS_FRAMEANGVEL = 32, SENS_SUBTREECOM = 35, SENS_CLOCK = 45 };
+enum { OBJ_BODY = 1, OBJ_XBODY = 2, OBJ_GEOM = 5, OBJ_SITE = 6 };
+/* pose, quaternion and body of a frame object (sensor.py:266-374 _get_pos / _get_mat / _get_quat / _get_body_id; sites are posed here: the
+   oracle keeps no site arrays) */
+static int frame_of(const RefModel* m, const RefData* d, int objtype, int id, double* pos, double* mat, double* quat) {
+  double q[4] = {1, 0, 0, 0}, p[3] = {0, 0, 0};
+  int body = 0;
+  if (objtype == OBJ_BODY) {
+    body = id;
+    v3cpy(p, d->xipos + 3 * id);
+    mul_quat(q, d->xquat + 4 * id, m->body_iquat + 4 * id);
+  } else if (objtype == OBJ_XBODY) {
+    body = id;
+    v3cpy(p, d->xpos + 3 * id);
+    memcpy(q, d->xquat + 4 * id, sizeof(q));
+  } else if (objtype == OBJ_GEOM) {
+    body = m->geom_bodyid[id];
+    v3cpy(p, d->geom_xpos + 3 * id);
+    mul_quat(q, d->xquat + 4 * body, m->geom_quat + 4 * id);
+  } else if (objtype == OBJ_SITE) {
+    body = m->site_bodyid[id];
+    rot_vec_quat(p, m->site_pos + 3 * id, d->xquat + 4 * body);
+    v3add(p, p, d->xpos + 3 * body);
+    mul_quat(q, d->xquat + 4 * body, m->site_quat + 4 * id);
+  }
+  if (pos) v3cpy(pos, p);
+  if (quat) memcpy(quat, q, sizeof(q));
+  if (mat) {
+    if (objtype == OBJ_BODY) memcpy(mat, d->ximat + 9 * id, 9 * sizeof(double));
+    else if (objtype == OBJ_XBODY) memcpy(mat, d->xmat + 9 * id, 9 * sizeof(double));
+    else if (objtype == OBJ_GEOM) memcpy(mat, d->geom_xmat + 9 * id, 9 * sizeof(double));
+    else { quat_normalize(q); quat_to_mat(mat, q); }
+  }
+  return body;
+}
+/* linear and angular velocity of a frame object in world coordinates (sensor.py:1066-1105 _cvel_offset + 1196-1200) */
+static void frame_vel(const RefModel* m, const RefData* d, int objtype, int id, double* lin, double* ang) {
+  double pos[3], off[3], c[3];
+  int body = frame_of(m, d, objtype, id, pos, NULL, NULL);
+  const double* cv = d->cvel + 6 * body;
+  v3sub(off, pos, d->subtree_com + 3 * m->body_rootid[body]);
+  v3cpy(ang, cv);
+  v3cross(c, off, cv);
+  v3sub(lin, cv + 3, c);
+}
+static void sensor_write(const RefModel* m, RefData* d, int i, const double* v) { /* sensor.py:57-114: cutoff for real / positive data */
+  int adr = m->sensor_adr[i], dt = m->sensor_datatype[i];
+  double cut = m->sensor_cutoff[i];
+  for (int k = 0; k < m->sensor_dim[i]; k++) {
+    double x = v[k];
+    if (cut > 0.0 && dt == 0) x = clampd(x, -cut, cut);
+    else if (cut > 0.0 && dt == 1) x = x < cut ? x : cut;
+    d->sensordata[adr + k] = x;
+  }
+}
+void ref_sensor(const RefModel* m, RefData* d) {
+  if (m->disableflags & (1 << 13)) return; /* DisableBit.SENSOR */
+  for (int i = 0; i < m->nsensor; i++) {
+    int t = m->sensor_type[i], id = m->sensor_objid[i], ot = m->sensor_objtype[i], rid = m->sensor_refid[i], rt = m->sensor_reftype[i];
+    double v[4] = {0, 0, 0, 0}, pos[3], mat[9], q[4], rpos[3], rmat[9], rq[4], dif[3];
+    if (t == SENS_JOINTPOS) v[0] = d->qpos[m->jnt_qposadr[id]];
+    else if (t == SENS_JOINTVEL) v[0] = d->qvel[m->jnt_dofadr[id]];
+    else if (t == SENS_ACTUATORPOS) v[0] = d->actuator_length[id];
+    else if (t == SENS_ACTUATORVEL) v[0] = d->actuator_velocity[id];
+    else if (t == SENS_ACTUATORFRC) v[0] = d->actuator_force[id];
+    else if (t == SENS_BALLQUAT) { /* 216-225 */
+      memcpy(v, d->qpos + m->jnt_qposadr[id], 4 * sizeof(double));
+      quat_normalize(v);
+    } else if (t == SENS_BALLANGVEL) memcpy(v, d->qvel + m->jnt_dofadr[id], 3 * sizeof(double));
+    else if (t == SENS_CLOCK) v[0] = d->time;
+    else if (t == SENS_SUBTREECOM) v3cpy(v, d->subtree_com + 3 * id);
+    else if (t == SENS_FRAMEPOS) { /* 377-403 */
+      frame_of(m, d, ot, id, pos, NULL, NULL);
+      if (rid == -1) v3cpy(v, pos);
+      else {
+        frame_of(m, d, rt, rid, rpos, rmat, NULL);
+        v3sub(dif, pos, rpos);
+        matT_mul_vec(v, rmat, dif);
+      }
+    } else if (t == SENS_FRAMEXAXIS || t == SENS_FRAMEYAXIS || t == SENS_FRAMEZAXIS) { /* 406-429 */
+      int ax = t - SENS_FRAMEXAXIS;
+      frame_of(m, d, ot, id, NULL, mat, NULL);
+      double a[3] = {mat[ax], mat[3 + ax], mat[6 + ax]};
+      if (rid == -1) v3cpy(v, a);
+      else {
+        frame_of(m, d, rt, rid, NULL, rmat, NULL);
+        matT_mul_vec(v, rmat, a);
+      }
+    } else if (t == SENS_FRAMEQUAT) { /* 432-482 */
+      frame_of(m, d, ot, id, NULL, NULL, q);
+      if (rid == -1) memcpy(v, q, sizeof(q));
+      else {
+        frame_of(m, d, rt, rid, NULL, NULL, rq);
+        rq[1] = -rq[1]; rq[2] = -rq[2]; rq[3] = -rq[3];
+        mul_quat(v, rq, q);
+      }
+    } else if (t == SENS_VELOCIMETER || t == SENS_GYRO) { /* 964-1004: site frame */
+      double lin[3], ang[3];
+      frame_vel(m, d, OBJ_SITE, id, lin, ang);
+      frame_of(m, d, OBJ_SITE, id, NULL, mat, NULL);
+      matT_mul_vec(v, mat, t == SENS_GYRO ? ang : lin);
+    } else if (t == SENS_FRAMELINVEL || t == SENS_FRAMEANGVEL) { /* 1108-1293 */
+      double lin[3], ang[3], rlin[3], rang[3];
+      frame_vel(m, d, ot, id, lin, ang);
+      if (rid == -1) v3cpy(v, t == SENS_FRAMELINVEL ? lin : ang);
+      else {
+        frame_vel(m, d, rt, rid, rlin, rang);
+        frame_of(m, d, rt, rid, rpos, rmat, NULL);
+        if (t == SENS_FRAMELINVEL) {
+          double rel[3], c[3];
+          frame_of(m, d, ot, id, pos, NULL, NULL);
+          v3sub(dif, pos, rpos);
+          v3cross(c, dif, rang);
+          for (int k = 0; k < 3; k++) rel[k] = lin[k] - rlin[k] + c[k];
+          matT_mul_vec(v, rmat, rel);
+        } else {
+          v3sub(dif, ang, rang);
+          matT_mul_vec(v, rmat, dif);
+        }
+      }
+    }
+    sensor_write(m, d, i, v);
+  }
+}
+
 void ref_fwd_position(const RefModel* m, RefData* d) { /* forward.py:635-679 */
   ref_kinematics(m, d);
   ref_com_pos(m, d);
@@ -2818,6 +2946,7 @@ void ref_forward(const RefModel* m, RefData* d) { /* forward.py:1341-1366 */
   ref_fwd_velocity(m, d);
   ref_fwd_actuation(m, d);
   ref_fwd_acceleration(m, d);
+  ref_sensor(m, d); /* (position / velocity stage sensors and actuator forces: all final before the solve) */
   ref_solve(m, d);
 }
 

@@ -32,6 +32,9 @@ typedef struct RefModel {
   int nmocap;
   int nexplicit;
   int ntree;
+  int nsite;
+  int nsensor;
+  int nsensordata;
   int nmeshpoly;   /* polygons of all meshes (0: no polygon tables, no multi-contact recovery on meshes) */
   int npolygonmax; /* clip buffers hold 2 * npolygonmax points (collision_convex.py:1226-1234) */
   int enableflags;       /* EnableBit: SLEEP = 1 << 5 (with DisableBit.ISLAND clear: forward.py:345) */
@@ -145,6 +148,18 @@ typedef struct RefModel {
   int* mesh_vertadr;
   int* mesh_vertnum;
   double* mesh_vert;  /* [nmeshvert, 3] vertices in the mesh (= geom) frame */
+  int* site_bodyid;
+  double* site_pos;
+  double* site_quat;
+  int* sensor_type;     /* mjtSensor */
+  int* sensor_datatype; /* mjtDataType: 0 real, 1 positive, 2 axis, 3 quaternion */
+  int* sensor_objtype;  /* mjtObj: 1 body (inertial frame), 2 xbody, 5 geom, 6 site */
+  int* sensor_objid;
+  int* sensor_reftype;
+  int* sensor_refid;
+  int* sensor_dim;
+  int* sensor_adr;
+  double* sensor_cutoff;
   double* hfield_size; /* [nhfield, 4]: x, y half sizes, top scale of the elevation data, base thickness */
   int* hfield_nrow;
   int* hfield_ncol;
@@ -248,6 +263,7 @@ typedef struct RefData {
   double* efc_aref;
   double* efc_frictionloss;
   double* efc_force;
+  double* sensordata;
   int* tree_asleep;   /* sleep.py: < 0 awake (countdown to -1), >= 0 next tree of the sleep cycle */
   int* tree_awake;
   int* body_awake;    /* SleepState: -1 static, 0 asleep, 1 awake */
@@ -278,6 +294,7 @@ void ref_euler(const RefModel* m, RefData* d);
 void ref_implicitfast(const RefModel* m, RefData* d);
 void ref_rungekutta4(const RefModel* m, RefData* d); /* forward.py:524; call after ref_forward */
 void ref_step(const RefModel* m, RefData* d);
+void ref_sensor(const RefModel* m, RefData* d); /* sensor.py sensor_pos / sensor_vel / sensor_acc, the subset in oracle/mjref.c; called by ref_forward */
 /* sleep.py / island.py:28-310 (tree-level constraint islands, sleeping, waking) */
 void ref_update_sleep(const RefModel* m, RefData* d);
 void ref_wake(const RefModel* m, RefData* d);

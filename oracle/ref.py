@@ -171,7 +171,7 @@ _SIZES = {
   "efc_type": "njmax", "efc_id": "njmax", "efc_state": "njmax", "efc_J": ("njmax", "nv"), "efc_pos": "njmax",
   "efc_margin": "njmax", "efc_D": "njmax", "efc_vel": "njmax", "efc_aref": "njmax", "efc_frictionloss": "njmax",
   "efc_force": "njmax", "tree_asleep": "ntree", "tree_awake": "ntree", "body_awake": "nbody", "tree_island": "ntree",
-  "body_awake_ind": "nbody", "dof_awake_ind": "nv",
+  "body_awake_ind": "nbody", "dof_awake_ind": "nv", "sensordata": "nsensordata",
 }
 MJ_MINAWAKE = 10  # mjMINAWAKE (reference types.py:29)
 
@@ -203,6 +203,7 @@ class RefSim:
     sizes["neq"] = int(getattr(mjm, "neq", 0))
     sizes["nmocap"] = int(getattr(mjm, "nmocap", 0))
     sizes["ntree"] = int(getattr(mjm, "ntree", 0))
+    sizes["nsite"], sizes["nsensor"], sizes["nsensordata"] = int(getattr(mjm, "nsite", 0)), int(getattr(mjm, "nsensor", 0)), int(getattr(mjm, "nsensordata", 0))
     scalars = dict(
       integrator=int(opt.integrator if integrator is None else integrator), cone=int(opt.cone),
       solver=int(opt.solver if solver is None else solver),
@@ -221,6 +222,9 @@ class RefSim:
                "xpair_gap": getattr(mjm, "pair_gap", np.zeros(0)),
                "actuator_trnid": mjm.actuator_trnid, "M_colind": mjm.M_colind}
     for name, dflt in (("geom_dataid", np.full(mjm.ngeom, -1)), ("mesh_vertadr", np.zeros(0)), ("mesh_vertnum", np.zeros(0)), ("mesh_vert", np.zeros((0, 3))),
+                       ("site_bodyid", np.zeros(0)), ("site_pos", np.zeros((0, 3))), ("site_quat", np.zeros((0, 4))), ("sensor_type", np.zeros(0)), ("sensor_datatype", np.zeros(0)),
+                       ("sensor_objtype", np.zeros(0)), ("sensor_objid", np.zeros(0)), ("sensor_reftype", np.zeros(0)), ("sensor_refid", np.zeros(0)), ("sensor_dim", np.zeros(0)),
+                       ("sensor_adr", np.zeros(0)), ("sensor_cutoff", np.zeros(0)),
                        ("hfield_size", np.zeros((0, 4))), ("hfield_nrow", np.zeros(0)), ("hfield_ncol", np.zeros(0)), ("hfield_adr", np.zeros(0)), ("hfield_data", np.zeros(0)),
                        ("mesh_graphadr", np.full(max(int(getattr(mjm, "nmesh", 0)), 1), -1)), ("mesh_graph", np.zeros(0)), ("mesh_polyadr", np.zeros(0)), ("mesh_polynormal", np.zeros((0, 3))), ("mesh_polyvertadr", np.zeros(0)), ("mesh_polyvertnum", np.zeros(0)),
                        ("mesh_polyvert", np.zeros(0)), ("mesh_polymapadr", np.zeros(0)), ("mesh_polymapnum", np.zeros(0)), ("mesh_polymap", np.zeros(0))):

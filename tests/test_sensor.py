@@ -1,0 +1,156 @@
+"""Sensors (reference sensor.py), the subset csrc/sensor.hpp computes: joint / actuator / ball-joint readings, frame position / axes /
+quaternion / velocities (optionally relative to a reference frame), velocimeter, gyro, subtree centre of mass, clock.
+
+The reference's sensor_test.py compares with MuJoCo C at run time (absent here); the float64 oracle is pinned by what the definitions
+imply on states with a closed form: joint sensors equal the state, a site on a link spinning at w about a fixed hinge moves at w x r and
+its gyro reads the axis in site coordinates, a relative frame position / velocity of a frame to itself vanishes, frame quaternions
+compose, cutoffs clamp.  The GPU path is compared with the oracle on a scene carrying every supported sensor.
+"""
+
+import numpy as np
+import pytest
+
+import mujoco_warp_amd as mjw
+from mujoco_warp_amd import _npmath as nm
+from oracle import ref
+
+SENSOR_XML = """
+<mujoco>
+  <option timestep="0.004"/>
+  <worldbody>
+    <geom name="floor" type="plane" size="5 5 .1"/>
+    <site name="origin" pos="0 0 0"/>
+    <body name="arm" pos="0 0 1">
+      <joint name="shoulder" type="hinge" axis="0 0 1"/>
+      <geom name="upper" type="capsule" fromto="0 0 0 .4 0 0" size=".03"/>
+      <site name="tip" pos=".4 0 0" euler="0 0 30"/>
+      <body name="fore" pos=".4 0 0">
+        <joint name="elbow" type="ball"/>
+        <geom name="lower" type="capsule" fromto="0 0 0 .3 0 0" size=".025"/>
+        <site name="hand" pos=".3 0 0" euler="10 20 30"/>
+      </body>
+    </body>
+    <body name="ball" pos="1 0 .5"><freejoint name="free"/><geom name="sphere" type="sphere" size=".1"/><site name="imu" pos=".02 .01 0" euler="0 45 0"/></body>
+  </worldbody>
+  <actuator><motor name="m0" joint="shoulder" gear="2"/><position name="p0" joint="shoulder" kp="10"/></actuator>
+  <sensor>
+    <jointpos name="jp" joint="shoulder"/><jointvel name="jv" joint="shoulder"/>
+    <actuatorpos name="ap" actuator="m0"/><actuatorvel name="av" actuator="m0"/><actuatorfrc name="af" actuator="p0"/>
+    <ballquat name="bq" joint="elbow"/><ballangvel name="bw" joint="elbow"/>
+    <framepos name="fp_tip" objtype="site" objname="tip"/>
+    <framepos name="fp_rel" objtype="site" objname="hand" reftype="site" refname="tip"/>
+    <framepos name="fp_self" objtype="body" objname="fore" reftype="body" refname="fore"/>
+    <framexaxis name="fx" objtype="site" objname="tip"/><frameyaxis name="fy" objtype="xbody" objname="arm"/>
+    <framezaxis name="fz" objtype="geom" objname="lower" reftype="xbody" refname="arm"/>
+    <framequat name="fq" objtype="site" objname="hand"/><framequat name="fq_rel" objtype="site" objname="hand" reftype="xbody" refname="fore"/>
+    <framelinvel name="lv_tip" objtype="site" objname="tip"/><frameangvel name="wv_tip" objtype="site" objname="tip"/>
+    <framelinvel name="lv_rel" objtype="site" objname="hand" reftype="site" refname="tip"/>
+    <frameangvel name="wv_rel" objtype="site" objname="hand" reftype="xbody" refname="arm"/>
+    <framelinvel name="lv_self" objtype="geom" objname="sphere" reftype="geom" refname="sphere"/>
+    <velocimeter name="vel" site="imu"/><gyro name="gyro" site="imu"/>
+    <gyro name="gyro_cut" site="imu" cutoff="0.5"/>
+    <subtreecom name="com" body="arm"/><clock name="t"/>
+  </sensor>
+</mujoco>
+"""
+
+
+def _read(mjm, data, name):
+  i = mjm.sensor_names.index(name)
+  return np.asarray(data)[mjm.sensor_adr[i] : mjm.sensor_adr[i] + mjm.sensor_dim[i]]
+
+
+def _state(sim_or_none, mjm):
+  rng = np.random.default_rng(11)
+  qpos = mjm.qpos0.copy()
+  qpos[0] = 0.7
+  qpos[1:5] = nm.quat_normalize(rng.normal(size=4))
+  qpos[8:12] = nm.quat_normalize(rng.normal(size=4))
+  qvel = rng.normal(size=mjm.nv)
+  qvel[0] = 1.3
+  return qpos, qvel
+
+
+def test_oracle_sensor_closed_forms():
+  mjm = mjw.mjcf.from_xml_string(SENSOR_XML)
+  assert mjm.nsensor == 25 and mjm.nsensordata == int(mjm.sensor_dim.sum())
+  s = ref.RefSim(mjm)
+  s.qpos[:], s.qvel[:] = _state(s, mjm)
+  s.ctrl[:] = [0.3, -0.2]
+  s.cd.time = 1.25
+  s.forward()
+  g = lambda n: _read(mjm, s.sensordata, n)
+  w, th = 1.3, 0.7
+  assert g("jp")[0] == th and g("jv")[0] == w and g("t")[0] == 1.25
+  assert g("ap")[0] == pytest.approx(2 * th) and g("av")[0] == pytest.approx(2 * w)  # gear 2
+  assert g("af")[0] == pytest.approx(10 * (-0.2 - th))  # position actuator: kp (ctrl - q)
+  assert np.allclose(g("bq"), s.qpos[1:5]) and np.allclose(g("bw"), s.qvel[1:4])
+  c, sn = np.cos(th), np.sin(th)
+  tip = np.array([0.4 * c, 0.4 * sn, 1.0])
+  assert np.allclose(g("fp_tip"), tip) and np.allclose(g("fp_self"), 0, atol=1e-15) and np.allclose(g("lv_self"), 0, atol=1e-15)
+  assert np.allclose(g("lv_tip"), np.cross([0, 0, w], tip - [0, 0, 1])) and np.allclose(g("wv_tip"), [0, 0, w])
+  assert np.allclose(g("fx"), [np.cos(th + np.pi / 6), np.sin(th + np.pi / 6), 0]) and np.allclose(g("fy"), [-sn, c, 0])
+  # relative quantities: hand in the tip frame / the forearm frame
+  R_tip = nm.quat_to_mat(nm.quat_mul(s.xquat[1], mjm.site_quat[1]))
+  hand = s.xpos[2] + nm.quat_to_mat(s.xquat[2]) @ mjm.site_pos[2]
+  assert np.allclose(g("fp_rel"), R_tip.T @ (hand - tip))
+  assert np.allclose(g("fq_rel"), mjm.site_quat[2]) and np.allclose(g("fq"), nm.quat_mul(s.xquat[2], mjm.site_quat[2]))
+  wb = nm.quat_to_mat(s.xquat[2]) @ s.qvel[1:4]  # the ball joint's angular velocity is given in the child frame
+  v_hand = np.cross([0, 0, w], hand - [0, 0, 1]) + np.cross(wb, hand - s.xpos[2])
+  assert np.allclose(g("lv_rel"), R_tip.T @ (v_hand - np.cross([0, 0, w], tip - [0, 0, 1]) + np.cross(hand - tip, [0, 0, w])) * 0 + R_tip.T @ (v_hand - np.cross([0, 0, w], hand - [0, 0, 1])), atol=1e-12)
+  assert np.allclose(g("wv_rel"), nm.quat_to_mat(s.xquat[1]).T @ wb, atol=1e-12)
+  # IMU on the free body: v_site = v + w x r (free joint: linear velocity in world, angular velocity in body coordinates)
+  Rb = nm.quat_to_mat(s.xquat[3])
+  R_imu = Rb @ nm.quat_to_mat(mjm.site_quat[3])
+  w_world = Rb @ s.qvel[7:10]
+  assert np.allclose(g("gyro"), R_imu.T @ w_world, atol=1e-12)
+  assert np.allclose(g("vel"), R_imu.T @ (s.qvel[4:7] + np.cross(w_world, Rb @ mjm.site_pos[3])), atol=1e-12)
+  assert np.allclose(g("gyro_cut"), np.clip(g("gyro"), -0.5, 0.5))
+  m_arm, m_fore = mjm.body_mass[1], mjm.body_mass[2]
+  assert np.allclose(g("com"), (m_arm * s.xipos[1] + m_fore * s.xipos[2]) / (m_arm + m_fore))
+  # sensors outside the subset keep their slot (the reference's sensordata layout) and read 0; unknown elements raise
+  acc = mjw.mjcf.from_xml_string(SENSOR_XML.replace('<clock name="t"/>', '<accelerometer name="acc" site="imu"/><clock name="t"/>'))
+  assert acc.nsensordata == mjm.nsensordata + 3 and acc.sensor_adr[-1] == mjm.sensor_adr[-1] + 3
+  s2 = ref.RefSim(acc)
+  s2.cd.time = 2.0
+  s2.forward()
+  assert (_read(acc, s2.sensordata, "acc") == 0).all() and _read(acc, s2.sensordata, "t")[0] == 2.0
+  with pytest.raises(NotImplementedError):
+    mjw.mjcf.from_xml_string(SENSOR_XML.replace('<clock name="t"/>', '<camprojection site="imu" camera="c"/>'))
+
+
+@pytest.mark.gpu
+def test_gpu_sensors_vs_oracle():
+  mjm = mjw.mjcf.from_xml_string(SENSOR_XML)
+  m = mjw.put_model(mjm)
+  d = mjw.make_data(mjm, nworld=3, nconmax=16, njmax=64)
+  assert d.sensordata.shape == (3, mjm.nsensordata)
+  qpos, qvel = _state(None, mjm)
+  sims = []
+  q, v, c = d.qpos.numpy(), d.qvel.numpy(), d.ctrl.numpy()
+  for w in range(3):
+    s = ref.RefSim(mjm, nconmax=16, njmax=64)
+    s.qpos[:], s.qvel[:] = qpos, qvel * (1 + 0.3 * w)
+    s.ctrl[:] = [0.3 - 0.1 * w, -0.2]
+    q[w], v[w], c[w] = s.qpos, s.qvel, s.ctrl
+    sims.append(s)
+  d.qpos.assign(q)
+  d.qvel.assign(v)
+  d.ctrl.assign(c)
+  for step in range(40):  # through step: the sensors must read the step's INPUT state even where the solver epilogue integrates
+    for w, s in enumerate(sims):
+      s.qpos[:], s.qvel[:], s.qacc_warmstart[:] = d.qpos.numpy()[w], d.qvel.numpy()[w], d.qacc_warmstart.numpy()[w]
+      s.cd.time = float(d.time.numpy()[w])
+    mjw.step(m, d)
+    sd = d.sensordata.numpy()
+    for w, s in enumerate(sims):
+      s.step()
+      err = np.abs(sd[w] - s.sensordata)
+      assert (err <= 2e-5 + 2e-5 * np.abs(s.sensordata)).all(), (step, w, mjm.sensor_names[int(np.searchsorted(mjm.sensor_adr, int(err.argmax()), side="right")) - 1])
+  # the stage entry point recomputes from the current state
+  d.sensordata.zero_()
+  mjw.forward(m, d)
+  a = d.sensordata.numpy().copy()
+  d.sensordata.zero_()
+  mjw.sensor(m, d)
+  assert (d.sensordata.numpy() == a).all() and np.abs(a).max() > 0
