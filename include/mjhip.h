@@ -145,6 +145,7 @@ typedef struct MjhModel {
   const float* mesh_vert;       /* [nmeshvert, 3] vertices in the mesh (= geom) frame; searched exhaustively by the convex narrowphase */
   /* sensors (types.py: sensor_*; csrc/sensor.hpp computes joint / actuator / ball / frame / velocimeter / gyro / subtreecom / clock) */
   int nsensor; int nsensordata;
+  int nsensor_acc;  /* sensors of the acceleration stage (accelerometer, framelinacc, frameangacc): one more launch between solver and integrator */
   const int* sensor_type; const int* sensor_datatype; const int* sensor_objtype; const int* sensor_objid; const int* sensor_reftype; const int* sensor_refid;
   const int* sensor_dim; const int* sensor_adr;
   const float* sensor_cutoff;
@@ -322,7 +323,7 @@ int mjh_timed_steps(const MjhModel* m, const MjhData* d, int nstep, int step0, f
 int mjh_release_thread_resources(void);
 
 const char* mjh_last_error(void);
-#define MJH_ABI_VERSION 21
+#define MJH_ABI_VERSION 22
 int mjh_abi_version(void); /* returns MJH_ABI_VERSION of the library that was loaded */
 
 #ifdef __cplusplus

@@ -112,10 +112,10 @@ static int launch_constraint(const MjhModel* m, const MjhData* d, hipStream_t s)
   hipLaunchKernelGGL(k_make_constraint<G>, dim3((d->nworld + wpb - 1) / wpb), dim3(threads), lds, s, *m, *d);
   return MJH_OK;
 }
-static int launch_sensor(const MjhModel* m, const MjhData* d, hipStream_t s) {
-  if (m->nsensor == 0 || (m->disableflags & DSBL_SENSOR)) return MJH_OK;
+static int launch_sensor(const MjhModel* m, const MjhData* d, int stage, hipStream_t s) {  // stage 1: acceleration-stage sensors (after the solver)
+  if (m->nsensor == 0 || (m->disableflags & DSBL_SENSOR) || (stage == 1 && m->nsensor_acc == 0)) return MJH_OK;
   if (!d->sensordata) return fail(MJH_E_ARG, "Data.sensordata missing (allocate Data with make_data/put_data)");
-  hipLaunchKernelGGL(k_sensor, dim3((d->nworld * m->nsensor + 255) / 256), dim3(256), 0, s, *m, *d);
+  hipLaunchKernelGGL(k_sensor, dim3((d->nworld * m->nsensor + 255) / 256), dim3(256), 0, s, *m, *d, stage);
   return MJH_OK;
 }
 static int launch_solve(const MjhModel* m, const MjhData* d, hipStream_t s);  // = the solver workgroups of k_solve_plus
@@ -430,7 +430,7 @@ static int run_sleep_step(const MjhModel* m, const MjhData* d, bool step, hipStr
   { Scope sc(K_CONSTRAINT); TRY(launch_constraint(m, d, s)); }
   { Scope sc(K_OTHER); hipLaunchKernelGGL(k_sleep, gw, bw, 0, s, *m, *d, (int)SLP_POST_CONSTRAINT); }
   { Scope sc(K_VEL); TRY(launch_vel(m, d, VEL_COMVEL, VEL_ACCEL, s)); }
-  { Scope sc(K_OTHER); TRY(launch_sensor(m, d, s)); }
+  { Scope sc(K_OTHER); TRY(launch_sensor(m, d, 0, s)); }
   {
     Scope sc(K_OTHER);
     if (m->nv > 0) hipLaunchKernelGGL(k_sleep_qfrc, dim3((d->nworld * m->nv + 255) / 256), dim3(256), 0, s, *m, *d);
@@ -443,6 +443,7 @@ static int run_sleep_step(const MjhModel* m, const MjhData* d, bool step, hipStr
     d3.qacc_warmstart = d->ws_sleep_warm;
     TRY(launch_solve(m, &d3, s));
   }
+  { Scope sc(K_OTHER); TRY(launch_sensor(m, d, 1, s)); }
   if (step) { Scope sc(K_INTEGRATE); TRY(launch_integrate(m, d, mode, s)); }
   {
     Scope sc(K_OTHER);
@@ -486,7 +487,7 @@ static int run_stage(const MjhModel* m, const MjhData* d, int stage, hipStream_t
       { Scope sc(K_CONSTRAINT); TRY(launch_constraint(m, d, s)); }
       { Scope sc(K_OTHER); TRY(launch_publish(d, s)); }
       return MJH_OK;
-    case MJH_STAGE_SENSOR: { Scope sc(K_OTHER); return launch_sensor(m, d, s); }
+    case MJH_STAGE_SENSOR: { Scope sc(K_OTHER); TRY(launch_sensor(m, d, 0, s)); return launch_sensor(m, d, 1, s); }
     case MJH_STAGE_UPDATE_SLEEP:
     case MJH_STAGE_WAKE:
     case MJH_STAGE_WAKE_COLLISION:
@@ -528,8 +529,9 @@ static int run_stage(const MjhModel* m, const MjhData* d, int stage, hipStream_t
         { Scope sc(K_COLLISION); TRY(launch_collision(m, d, s)); }
         { Scope sc(K_CONSTRAINT); TRY(launch_constraint(m, d, s)); }
         { Scope sc(K_VEL); TRY(launch_vel(m, d, VEL_COMVEL, VEL_ACCEL, s)); }
-        { Scope sc(K_OTHER); TRY(launch_sensor(m, d, s)); }
+        { Scope sc(K_OTHER); TRY(launch_sensor(m, d, 0, s)); }
         { Scope sc(K_SOLVE); TRY(launch_solve(m, d, s)); }
+        { Scope sc(K_OTHER); TRY(launch_sensor(m, d, 1, s)); }
         if (stage == MJH_STAGE_STEP) { Scope sc(K_INTEGRATE); TRY(launch_integrate(m, d, mode, s)); }
         Scope sc(K_OTHER);
         TRY(launch_publish(d, s));
@@ -540,7 +542,7 @@ static int run_stage(const MjhModel* m, const MjhData* d, int stage, hipStream_t
       bool sched_done = false;
       { Scope sc(K_POS); TRY(launch_pos_plus(m, d, POS_KINEMATICS, POS_CRB, &sched_done, s)); }
       { Scope sc(K_MID); TRY(launch_mid(m, d, !sched_done, s)); }
-      { Scope sc(K_OTHER); TRY(launch_sensor(m, d, s)); }  // (no launch without sensors; before the solver, whose epilogue may integrate the state)
+      { Scope sc(K_OTHER); TRY(launch_sensor(m, d, 0, s)); }  // (no launch without sensors; before the solver, whose epilogue may integrate the state)
       // (nv <= 32 only: beside the 64-lane solver of larger models the riders cost more than they save, G1 -3 %)
       static const int side_nv = getenv("MJH_SIDE_NV") ? atoi(getenv("MJH_SIDE_NV")) : 32;  // developer knob
       Side* side = (m->solver == SOL_NEWTON && m->nv <= side_nv && !(g_instr && g_instr->on)) ? side_stream() : nullptr;
@@ -555,6 +557,7 @@ static int run_stage(const MjhModel* m, const MjhData* d, int stage, hipStream_t
       // solver's own epilogue (saves a launch); every other case keeps the integrator workgroups
       // (Newton: only when its riders run on the side stream -- otherwise the integrator launch exists anyway, for them)
       const bool fuse_euler = stage == MJH_STAGE_STEP && m->integrator == INT_EULER && m->na == 0 && (m->solver == SOL_CG || side != nullptr) && m->nv <= 64 &&
+                              m->nsensor_acc == 0 &&  // (acceleration-stage sensors read qvel / qacc between the solver and the integrator)
                               d->njmax <= 192 &&  // (beyond: some worlds go to the generic solver, which does not integrate)
                               (m->disableflags & (DSBL_EULERDAMP | DSBL_DAMPER)) != 0;
       g_fuse_euler = fuse_euler;
@@ -562,6 +565,7 @@ static int run_stage(const MjhModel* m, const MjhData* d, int stage, hipStream_t
       { Scope sc(K_SOLVE); rc = launch_solve_plus(m, d, s); }
       g_fuse_euler = false;
       TRY(rc);
+      { Scope sc(K_OTHER); TRY(launch_sensor(m, d, 1, s)); }
       g_riders_on_side = side != nullptr;
       { Scope sc(K_INTEGRATE); rc = launch_integrate_plus(m, d, mode, stage == MJH_STAGE_STEP && !fuse_euler, s); }
       g_riders_on_side = false;

@@ -8,9 +8,9 @@
 #pragma once
 #include "dev_common.hpp"
 
-enum { SENS_VELOCIMETER = 2, SENS_GYRO = 3, SENS_JOINTPOS = 9, SENS_JOINTVEL = 10, SENS_ACTUATORPOS = 13, SENS_ACTUATORVEL = 14, SENS_ACTUATORFRC = 15,
+enum { SENS_ACCELEROMETER = 1, SENS_VELOCIMETER = 2, SENS_GYRO = 3, SENS_JOINTPOS = 9, SENS_JOINTVEL = 10, SENS_ACTUATORPOS = 13, SENS_ACTUATORVEL = 14, SENS_ACTUATORFRC = 15,
        SENS_BALLQUAT = 18, SENS_BALLANGVEL = 19, SENS_FRAMEPOS = 26, SENS_FRAMEQUAT = 27, SENS_FRAMEXAXIS = 28, SENS_FRAMEYAXIS = 29, SENS_FRAMEZAXIS = 30,
-       SENS_FRAMELINVEL = 31, SENS_FRAMEANGVEL = 32, SENS_SUBTREECOM = 35, SENS_CLOCK = 45 };
+       SENS_FRAMELINVEL = 31, SENS_FRAMEANGVEL = 32, SENS_FRAMELINACC = 33, SENS_FRAMEANGACC = 34, SENS_SUBTREECOM = 35, SENS_CLOCK = 45 };
 enum { OBJ_BODY = 1, OBJ_XBODY = 2, OBJ_GEOM = 5, OBJ_SITE = 6 };
 
 struct SensFrame {
@@ -57,11 +57,31 @@ DEV void sens_vel(const MjhModel& m, const MjhData& d, int w, const SensFrame& f
   lin = ld3(cv + 3) - cross(off, ang);
 }
 
-__global__ void __launch_bounds__(256) k_sensor(MjhModel m, MjhData d) {
+// acceleration of a body's frame at the tree's centre of mass (smooth.py:1354-1426 rne_postconstraint's cacc with flg_acc): the world
+// accelerates at -gravity, every dof on the way down adds cdof_dot qvel + cdof qacc; one thread walks the body's dof chain
+DEV void sens_cacc(const MjhModel& m, const MjhData& d, int w, int body, V3& ang, V3& lin) {
+  ang = V3{0, 0, 0};
+  lin = (m.disableflags & DSBL_GRAVITY) ? V3{0, 0, 0} : V3{0, 0, 0} - ld3(bf(m.opt_gravity, m.opt_gravity_nb, w, 3));
+  int dof = m.body_lastdof[body];  // last dof of the body or of its nearest moving ancestor, -1 for static bodies
+  const float* cdof = d.cdof + (size_t)w * m.nv * 6;
+  const float* cdd = d.cdof_dot + (size_t)w * m.nv * 6;
+  const float* qvel = d.qvel + (size_t)w * m.nv;
+  const float* qacc = d.qacc + (size_t)w * m.nv;
+  while (dof >= 0) {
+    ang = ang + qvel[dof] * ld3(cdd + 6 * dof) + qacc[dof] * ld3(cdof + 6 * dof);
+    lin = lin + qvel[dof] * ld3(cdd + 6 * dof + 3) + qacc[dof] * ld3(cdof + 6 * dof + 3);
+    dof = m.dof_parentid[dof];
+  }
+}
+
+// stage 0: position / velocity stage sensors and actuator forces (before the solver); stage 1: acceleration stage (after it, before the integrator)
+__global__ void __launch_bounds__(256) k_sensor(MjhModel m, MjhData d, int stage) {
   const int idx = blockIdx.x * 256 + threadIdx.x, ns = m.nsensor;
   if (idx >= d.nworld * ns) return;
   const int w = idx / ns, i = idx - w * ns;
   const int t = m.sensor_type[i], id = m.sensor_objid[i], ot = m.sensor_objtype[i], rid = m.sensor_refid[i], rt = m.sensor_reftype[i];
+  const bool acc_type = t == SENS_ACCELEROMETER || t == SENS_FRAMELINACC || t == SENS_FRAMEANGACC;
+  if (acc_type != (stage == 1)) return;
   float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   auto put3 = [&](V3 a) {
     v[0] = a.x;
@@ -115,6 +135,19 @@ __global__ void __launch_bounds__(256) k_sensor(MjhModel m, MjhData d) {
       sens_vel(m, d, w, r, rlin, rang);
       if (t == SENS_FRAMELINVEL) put3(matT_mul(r.mat, lin - rlin + cross(f.pos - r.pos, rang)));
       else put3(matT_mul(r.mat, ang - rang));
+    }
+  }
+  else if (acc_type) {  // sensor.py:1510-1539, 1678-1753
+    const SensFrame f = sens_frame(m, d, w, t == SENS_ACCELEROMETER ? OBJ_SITE : ot, id);
+    V3 aang, alin;
+    sens_cacc(m, d, w, f.body, aang, alin);
+    if (t == SENS_FRAMEANGACC) put3(aang);
+    else {
+      V3 lin, ang;
+      sens_vel(m, d, w, f, lin, ang);
+      const V3 off = f.pos - ld3(d.subtree_com + ((size_t)w * m.nbody + m.body_rootid[f.body]) * 3);
+      const V3 a = alin - cross(off, aang) + cross(ang, lin);
+      put3(t == SENS_ACCELEROMETER ? matT_mul(f.mat, a) : a);
     }
   }
   // sensor.py:57-114: cutoff for real (clamp) and positive (min) data

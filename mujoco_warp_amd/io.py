@@ -380,6 +380,7 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
   )
   m.nsensor, m.nsensordata = int(host["sensor_type"].shape[0]), int(getattr(mjm, "nsensordata", 0))
   supported_sensors = set(mjcf_SENS.values())
+  m.nsensor_acc = int(sum(int(t) in (1, 33, 34) for t in host["sensor_type"]))
   bad = [int(t) for t in host["sensor_type"] if int(t) not in supported_sensors]
   if bad:  # (sensors do not enter the dynamics: the model still loads, their sensordata slots stay zero)
     import warnings

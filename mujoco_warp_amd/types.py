@@ -416,6 +416,7 @@ class Model(_Dirty):
   nmeshpolymap: int = 0
   npolygonmax: int = 0
   nsensordata: int = 0
+  nsensor_acc: int = 0
   sensor_type: DeviceArray = _arr(('nsensor',), "int32")
   sensor_datatype: DeviceArray = _arr(('nsensor',), "int32")
   sensor_objtype: DeviceArray = _arr(('nsensor',), "int32")

@@ -2788,7 +2788,7 @@ void ref_sleep(const RefModel* m, RefData* d) { /* sleep.py:824-999 */
 }
 
 /* ================================================================ sensors (sensor.py, subset) */
-enum { SENS_VELOCIMETER = 2, SENS_GYRO = 3, SENS_JOINTPOS = 9, SENS_JOINTVEL = 10, SENS_ACTUATORPOS = 13, SENS_ACTUATORVEL = 14, SENS_ACTUATORFRC = 15,
+enum { SENS_ACCELEROMETER = 1, SENS_FRAMELINACC = 33, SENS_FRAMEANGACC = 34, SENS_VELOCIMETER = 2, SENS_GYRO = 3, SENS_JOINTPOS = 9, SENS_JOINTVEL = 10, SENS_ACTUATORPOS = 13, SENS_ACTUATORVEL = 14, SENS_ACTUATORFRC = 15,
        SENS_BALLQUAT = 18, SENS_BALLANGVEL = 19, SENS_FRAMEPOS = 26, SENS_FRAMEQUAT = 27, SENS_FRAMEXAXIS = 28, SENS_FRAMEYAXIS = 29, SENS_FRAMEZAXIS = 30,
        SENS_FRAMELINVEL = 31, SENS_FRAMEANGVEL = 32, SENS_SUBTREECOM = 35, SENS_CLOCK = 45 };
 enum { OBJ_BODY = 1, OBJ_XBODY = 2, OBJ_GEOM = 5, OBJ_SITE = 6 };
@@ -2845,9 +2845,23 @@ static void sensor_write(const RefModel* m, RefData* d, int i, const double* v) 
     d->sensordata[adr + k] = x;
   }
 }
-void ref_sensor(const RefModel* m, RefData* d) {
+/* acceleration of a body's frame at the tree's centre of mass: smooth.py:1354-1426 (rne_postconstraint's cacc, flg_acc) */
+static void body_cacc(const RefModel* m, const RefData* d, int body, double* cacc) {
+  for (int k = 0; k < 6; k++) cacc[k] = 0.0;
+  if (!(m->disableflags & DSBL_GRAVITY))
+    for (int k = 0; k < 3; k++) cacc[3 + k] = -m->gravity[k];
+  int bb = body;
+  while (bb > 0 && m->body_dofnum[bb] == 0) bb = m->body_parentid[bb];
+  if (bb == 0) return;
+  for (int dof = m->body_dofadr[bb] + m->body_dofnum[bb] - 1; dof >= 0; dof = m->dof_parentid[dof])
+    for (int k = 0; k < 6; k++) cacc[k] += d->cdof_dot[6 * dof + k] * d->qvel[dof] + d->cdof[6 * dof + k] * d->qacc[dof];
+}
+/* stage 0: position / velocity stage sensors and actuator forces; stage 1: acceleration stage (accelerometer, frame accelerations) */
+static void sensor_stage(const RefModel* m, RefData* d, int stage) {
   if (m->disableflags & (1 << 13)) return; /* DisableBit.SENSOR */
   for (int i = 0; i < m->nsensor; i++) {
+    int acc_type = m->sensor_type[i] == SENS_ACCELEROMETER || m->sensor_type[i] == SENS_FRAMELINACC || m->sensor_type[i] == SENS_FRAMEANGACC;
+    if (acc_type != (stage == 1)) continue;
     int t = m->sensor_type[i], id = m->sensor_objid[i], ot = m->sensor_objtype[i], rid = m->sensor_refid[i], rt = m->sensor_reftype[i];
     double v[4] = {0, 0, 0, 0}, pos[3], mat[9], q[4], rpos[3], rmat[9], rq[4], dif[3];
     if (t == SENS_JOINTPOS) v[0] = d->qpos[m->jnt_qposadr[id]];
@@ -2911,8 +2925,28 @@ void ref_sensor(const RefModel* m, RefData* d) {
         }
       }
     }
+    else if (acc_type) { /* sensor.py:1510-1539, 1678-1753 */
+      int fot = t == SENS_ACCELEROMETER ? OBJ_SITE : ot;
+      double cacc[6], lin[3], ang[3], off[3], c1[3], c2[3], a[3];
+      int body = frame_of(m, d, fot, id, pos, mat, NULL);
+      body_cacc(m, d, body, cacc);
+      if (t == SENS_FRAMEANGACC) v3cpy(v, cacc);
+      else {
+        frame_vel(m, d, fot, id, lin, ang);
+        v3sub(off, pos, d->subtree_com + 3 * m->body_rootid[body]);
+        v3cross(c1, off, cacc);
+        v3cross(c2, ang, lin);
+        for (int k = 0; k < 3; k++) a[k] = cacc[3 + k] - c1[k] + c2[k];
+        if (t == SENS_ACCELEROMETER) matT_mul_vec(v, mat, a);
+        else v3cpy(v, a);
+      }
+    }
     sensor_write(m, d, i, v);
   }
+}
+void ref_sensor(const RefModel* m, RefData* d) {
+  sensor_stage(m, d, 0);
+  sensor_stage(m, d, 1);
 }
 
 void ref_fwd_position(const RefModel* m, RefData* d) { /* forward.py:635-679 */
@@ -2946,8 +2980,9 @@ void ref_forward(const RefModel* m, RefData* d) { /* forward.py:1341-1366 */
   ref_fwd_velocity(m, d);
   ref_fwd_actuation(m, d);
   ref_fwd_acceleration(m, d);
-  ref_sensor(m, d); /* (position / velocity stage sensors and actuator forces: all final before the solve) */
+  sensor_stage(m, d, 0); /* (position / velocity stage sensors and actuator forces: all final before the solve) */
   ref_solve(m, d);
+  sensor_stage(m, d, 1);
 }
 
 /* _advance forward.py:276-349; next_act support.py:38 */

@@ -1,5 +1,5 @@
 """Sensors (reference sensor.py), the subset csrc/sensor.hpp computes: joint / actuator / ball-joint readings, frame position / axes /
-quaternion / velocities (optionally relative to a reference frame), velocimeter, gyro, subtree centre of mass, clock.
+quaternion / velocities (optionally relative to a reference frame), velocimeter, gyro, accelerometer, frame accelerations, subtree centre of mass, clock.
 
 The reference's sensor_test.py compares with MuJoCo C at run time (absent here); the float64 oracle is pinned by what the definitions
 imply on states with a closed form: joint sensors equal the state, a site on a link spinning at w about a fixed hinge moves at w x r and
@@ -49,6 +49,8 @@ SENSOR_XML = """
     <framelinvel name="lv_self" objtype="geom" objname="sphere" reftype="geom" refname="sphere"/>
     <velocimeter name="vel" site="imu"/><gyro name="gyro" site="imu"/>
     <gyro name="gyro_cut" site="imu" cutoff="0.5"/>
+    <accelerometer name="acc" site="imu"/><framelinacc name="la" objtype="site" objname="imu"/><frameangacc name="aa" objtype="body" objname="ball"/>
+    <framelinacc name="la_tip" objtype="site" objname="tip"/>
     <subtreecom name="com" body="arm"/><clock name="t"/>
   </sensor>
 </mujoco>
@@ -73,7 +75,7 @@ def _state(sim_or_none, mjm):
 
 def test_oracle_sensor_closed_forms():
   mjm = mjw.mjcf.from_xml_string(SENSOR_XML)
-  assert mjm.nsensor == 25 and mjm.nsensordata == int(mjm.sensor_dim.sum())
+  assert mjm.nsensor == 29 and mjm.nsensordata == int(mjm.sensor_dim.sum())
   s = ref.RefSim(mjm)
   s.qpos[:], s.qvel[:] = _state(s, mjm)
   s.ctrl[:] = [0.3, -0.2]
@@ -106,10 +108,15 @@ def test_oracle_sensor_closed_forms():
   assert np.allclose(g("gyro"), R_imu.T @ w_world, atol=1e-12)
   assert np.allclose(g("vel"), R_imu.T @ (s.qvel[4:7] + np.cross(w_world, Rb @ mjm.site_pos[3])), atol=1e-12)
   assert np.allclose(g("gyro_cut"), np.clip(g("gyro"), -0.5, 0.5))
+  # acceleration stage: the free sphere is in free fall (isotropic inertia: no angular acceleration), so a point at r from its centre
+  # accelerates at g + w x (w x r) and the accelerometer, which subtracts gravity, reads the centripetal term in site coordinates
+  r_imu = Rb @ mjm.site_pos[3]
+  cent = np.cross(w_world, np.cross(w_world, r_imu))
+  assert np.allclose(g("aa"), 0, atol=1e-9) and np.allclose(g("acc"), R_imu.T @ cent, atol=1e-9) and np.allclose(g("la"), cent, atol=1e-9)
   m_arm, m_fore = mjm.body_mass[1], mjm.body_mass[2]
   assert np.allclose(g("com"), (m_arm * s.xipos[1] + m_fore * s.xipos[2]) / (m_arm + m_fore))
   # sensors outside the subset keep their slot (the reference's sensordata layout) and read 0; unknown elements raise
-  acc = mjw.mjcf.from_xml_string(SENSOR_XML.replace('<clock name="t"/>', '<accelerometer name="acc" site="imu"/><clock name="t"/>'))
+  acc = mjw.mjcf.from_xml_string(SENSOR_XML.replace('<clock name="t"/>', '<force name="acc" site="imu"/><clock name="t"/>'))
   assert acc.nsensordata == mjm.nsensordata + 3 and acc.sensor_adr[-1] == mjm.sensor_adr[-1] + 3
   s2 = ref.RefSim(acc)
   s2.cd.time = 2.0
@@ -146,7 +153,11 @@ def test_gpu_sensors_vs_oracle():
     for w, s in enumerate(sims):
       s.step()
       err = np.abs(sd[w] - s.sensordata)
-      assert (err <= 2e-5 + 2e-5 * np.abs(s.sensordata)).all(), (step, w, mjm.sensor_names[int(np.searchsorted(mjm.sensor_adr, int(err.argmax()), side="right")) - 1])
+      tol = 2e-5 + 2e-5 * np.abs(s.sensordata)
+      for name in ("acc", "la", "aa", "la_tip"):  # accelerations are sums of cancelling terms of size w^2 |r|, g (tens of m/s^2)
+        k = mjm.sensor_names.index(name)
+        tol[mjm.sensor_adr[k] : mjm.sensor_adr[k] + 3] = 1e-3
+      assert (err <= tol).all(), (step, w, mjm.sensor_names[int(np.searchsorted(mjm.sensor_adr, int(err.argmax()), side="right")) - 1])
   # the stage entry point recomputes from the current state
   d.sensordata.zero_()
   mjw.forward(m, d)
