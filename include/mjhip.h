@@ -297,6 +297,11 @@ int mjh_mul_m(const MjhModel* m, const MjhData* d, float* res, const float* vec,
  * order; entries below the diagonal are zero).  Opt-in: Data.qLD of this engine stays MuJoCo's sparse L^T D L factor (DESIGN.md, section
  * 2).  Trees of more than 64 dofs are skipped (the reference keeps the sparse factor for them too). */
 int mjh_qld_dense(const MjhModel* m, const MjhData* d, float* qld_dense, int stride, void* stream);
+/* support.contact_force (support.py:445): 6D force (normal, tangent 1, tangent 2, spin, roll 1, roll 2) of the public contacts contact_ids[0..n),
+ * in the contact frame or (to_world_frame != 0) rotated to world axes; force is [n, 6] device memory; slots of ids >= nacon are left untouched */
+int mjh_contact_force(const MjhModel* m, const MjhData* d, const int* contact_ids, int n, int to_world_frame, float* force, void* stream);
+/* support.jac (support.py:581): Jacobians [nworld, 3, nv] of point[w] (world coordinates) moving with body[w]; jacp or jacr may be NULL */
+int mjh_jac(const MjhModel* m, const MjhData* d, float* jacp, float* jacr, const float* point, const int* body, void* stream);
 int mjh_efc_j_sparse(const MjhModel* m, const MjhData* d, int njmax_nnz, int* rownnz, int* rowadr, int* colind, float* values, void* stream);
 
 /* cli._ctrl_noise cli.py:103-145; ctrl_center may be NULL (-> actuator midpoint); worldid is global */
@@ -323,7 +328,7 @@ int mjh_timed_steps(const MjhModel* m, const MjhData* d, int nstep, int step0, f
 int mjh_release_thread_resources(void);
 
 const char* mjh_last_error(void);
-#define MJH_ABI_VERSION 22
+#define MJH_ABI_VERSION 23
 int mjh_abi_version(void); /* returns MJH_ABI_VERSION of the library that was loaded */
 
 #ifdef __cplusplus

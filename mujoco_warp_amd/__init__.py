@@ -11,6 +11,11 @@ from .device import copy
 from .forward import KERNEL_NAMES
 from .forward import StepGraph
 from .forward import com_pos
+from .forward import contact_force
+from .forward import jac
+from .forward import sensor_acc
+from .forward import sensor_pos
+from .forward import sensor_vel
 from .forward import island
 from .forward import sensor
 from .forward import sleep
@@ -47,6 +52,9 @@ from .forward import step
 from .forward import timed_steps
 from .forward import transmission
 from .io import get_data_into
+from .io import get_state
+from .io import set_state
+from .io import state_size
 from .io import load_trajectory
 from .io import make_data
 from .io import override_model
@@ -81,6 +89,7 @@ from .types import OverflowType
 from .types import SleepPolicy
 from .types import SleepState
 from .types import SolverType
+from .types import State
 from .types import Statistic
 from .types import TrnType
 

@@ -15,6 +15,7 @@
 #include "sensor.hpp"
 #include "sleep.hpp"
 #include "smooth.hpp"
+#include "support.hpp"
 
 static thread_local char g_err[512] = "";
 int mjh_fail(int code, const char* fmt, const char* a) {
@@ -619,6 +620,24 @@ int mjh_qld_dense(const MjhModel* m, const MjhData* d, float* qld_dense, int str
   if (!qld_dense || stride < 0) return fail(MJH_E_ARG, "mjh_qld_dense: null output");
   if (m->ntree == 0 || d->nworld == 0) return MJH_OK;
   hipLaunchKernelGGL(k_qld_dense, dim3(d->nworld * m->ntree), dim3(64), 0, (hipStream_t)stream, *m, *d, qld_dense, stride);
+  HIPCHK(hipGetLastError());
+  return MJH_OK;
+}
+
+int mjh_contact_force(const MjhModel* m, const MjhData* d, const int* contact_ids, int n, int to_world_frame, float* force, void* stream) {
+  TRY(check(m, d));
+  if (n < 0 || (n > 0 && (!contact_ids || !force))) return fail(MJH_E_ARG, "mjh_contact_force: null argument");
+  if (n == 0) return MJH_OK;
+  hipLaunchKernelGGL(k_contact_force, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, *m, *d, contact_ids, n, to_world_frame, force);
+  HIPCHK(hipGetLastError());
+  return MJH_OK;
+}
+
+int mjh_jac(const MjhModel* m, const MjhData* d, float* jacp, float* jacr, const float* point, const int* body, void* stream) {
+  TRY(check(m, d));
+  if (!point || !body) return fail(MJH_E_ARG, "mjh_jac: null point / body");
+  if (m->nv == 0 || (!jacp && !jacr)) return MJH_OK;
+  hipLaunchKernelGGL(k_jac, dim3((d->nworld * m->nv + 255) / 256), dim3(256), 0, (hipStream_t)stream, *m, *d, jacp, jacr, point, body);
   HIPCHK(hipGetLastError());
   return MJH_OK;
 }

@@ -1,0 +1,66 @@
+// Support functions of the reference's public API (support.py): contact_force (:445, 6D force of selected contacts from the constraint
+// forces) and jac (:581, translational / rotational Jacobian of a point on a body).  Small helper kernels, one thread per output.
+#pragma once
+#include "dev_common.hpp"
+
+// support.py:311-397: pyramidal rows decode to normal / friction components; elliptic rows are the components themselves
+__global__ void __launch_bounds__(256) k_contact_force(MjhModel m, MjhData d, const int* contact_ids, int n, int to_world_frame, float* out) {
+  const int tid = blockIdx.x * 256 + threadIdx.x;
+  if (tid >= n) return;
+  const int cid = contact_ids[tid];
+  if (cid >= d.nacon[0]) return;
+  float f[6] = {0, 0, 0, 0, 0, 0};
+  const int w = d.contact_worldid[cid], condim = d.contact_dim[cid], npyr = d.nmaxpyramid;
+  const int adr0 = d.contact_efc_address[(size_t)cid * npyr];
+  if (cid >= 0 && adr0 >= 0) {
+    const float* force = d.efc_force + (size_t)w * d.njmax;
+    if (m.cone == CONE_PYRAMIDAL) {
+      if (condim == 1) f[0] = force[adr0];
+      else
+        for (int i = 0; i < condim - 1; ++i) {
+          const int adr = adr0 + 2 * i;
+          const float d1 = adr < d.njmax ? force[adr] : 0.0f, d2 = adr + 1 < d.njmax ? force[adr + 1] : 0.0f;
+          f[0] += d1 + d2;
+          f[i + 1] = (d1 - d2) * d.contact_friction[(size_t)cid * 5 + i];
+        }
+    } else {
+      for (int i = 0; i < condim; ++i) {
+        const int adr = d.contact_efc_address[(size_t)cid * npyr + i];
+        if (adr >= 0 && adr < d.njmax) f[i] = force[adr];
+      }
+    }
+  }
+  if (to_world_frame) {  // row vector times the contact frame (rows = normal, tangent 1, tangent 2)
+    const float* R = d.contact_frame + (size_t)cid * 9;
+    const float t[3] = {f[0], f[1], f[2]}, b[3] = {f[3], f[4], f[5]};
+    for (int k = 0; k < 3; ++k) {
+      f[k] = t[0] * R[k] + t[1] * R[3 + k] + t[2] * R[6 + k];
+      f[3 + k] = b[0] * R[k] + b[1] * R[3 + k] + b[2] * R[6 + k];
+    }
+  }
+  for (int k = 0; k < 6; ++k) out[(size_t)tid * 6 + k] = f[k];
+}
+
+// support.py:505-578: column dof of the Jacobians of `point` (world coordinates) moving with body `body[w]`; either output may be null
+__global__ void __launch_bounds__(256) k_jac(MjhModel m, MjhData d, float* jacp, float* jacr, const float* point, const int* body) {
+  const int idx = blockIdx.x * 256 + threadIdx.x, nv = m.nv;
+  if (idx >= d.nworld * nv) return;
+  const int w = idx / nv, dof = idx - w * nv, b = body[w], nw32 = (nv + 31) / 32;
+  V3 jp = V3{0, 0, 0}, jr = V3{0, 0, 0};
+  if (m.body_dofmask[b * nw32 + (dof >> 5)] & (1u << (dof & 31))) {
+    const V3 off = ld3(point + 3 * w) - ld3(d.subtree_com + ((size_t)w * m.nbody + m.body_rootid[b]) * 3);
+    const float* cd = d.cdof + ((size_t)w * nv + dof) * 6;
+    jr = ld3(cd);
+    jp = ld3(cd + 3) + cross(jr, off);
+  }
+  if (jacp) {
+    jacp[((size_t)w * 3 + 0) * nv + dof] = jp.x;
+    jacp[((size_t)w * 3 + 1) * nv + dof] = jp.y;
+    jacp[((size_t)w * 3 + 2) * nv + dof] = jp.z;
+  }
+  if (jacr) {
+    jacr[((size_t)w * 3 + 0) * nv + dof] = jr.x;
+    jacr[((size_t)w * 3 + 1) * nv + dof] = jr.y;
+    jacr[((size_t)w * 3 + 2) * nv + dof] = jr.z;
+  }
+}

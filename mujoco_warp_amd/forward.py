@@ -6,6 +6,7 @@ sequence on torch's current HIP stream and returns without synchronising, like `
 """
 
 import ctypes
+from typing import Optional
 
 import numpy as np
 import torch
@@ -200,6 +201,44 @@ def qLD_dense(m, d):
   L = _abi.lib()
   _abi.check(L.mjh_qld_dense(ctypes.byref(io.c_model(m)), ctypes.byref(io.c_data(d)), out.ptr, total, _stream()))
   return out, block_adr
+
+
+def contact_force(m, d, contact_ids: DeviceArray, to_world_frame: bool, force: DeviceArray):
+  """6D forces of the contacts `contact_ids` (int32 [n]) into `force` ([n, 6] float32): normal, two tangents, spin, two rolls, in the
+  contact frame or rotated to world axes (reference support.contact_force, support.py:445)."""
+  n = int(np.prod(contact_ids.shape))
+  if tuple(force.shape) != (n, 6):
+    raise ValueError(f"force must have shape ({n}, 6)")
+  L = _abi.lib()
+  _abi.check(L.mjh_contact_force(ctypes.byref(io.c_model(m)), ctypes.byref(io.c_data(d)), contact_ids.ptr, n, int(bool(to_world_frame)), force.ptr, _stream()))
+
+
+def jac(m, d, jacp: Optional[DeviceArray], jacr: Optional[DeviceArray], point: DeviceArray, body: DeviceArray):
+  """Translational / rotational Jacobians ([nworld, 3, nv]; either may be None) of `point` ([nworld, 3], world coordinates) moving with
+  `body` ([nworld] int32) (reference support.jac, support.py:581)."""
+  for j in (jacp, jacr):
+    if j is not None and tuple(j.shape) != (d.nworld, 3, m.nv):
+      raise ValueError(f"Jacobian outputs must have shape ({d.nworld}, 3, {m.nv})")
+  L = _abi.lib()
+  _abi.check(L.mjh_jac(ctypes.byref(io.c_model(m)), ctypes.byref(io.c_data(d)), jacp.ptr if jacp is not None else None,
+                       jacr.ptr if jacr is not None else None, point.ptr, body.ptr, _stream()))
+
+
+def sensor_pos(m, d):
+  """Position-stage sensors (reference sensor.sensor_pos, sensor.py:810).  This engine computes the position and velocity stages (and
+  the actuator forces) in one launch: sensor_pos and sensor_vel both run it; call them after fwd_position / fwd_velocity / fwd_actuation."""
+  _run(_S["MJH_STAGE_SENSOR"], m, d)
+
+
+def sensor_vel(m, d):
+  """Velocity-stage sensors (reference sensor.sensor_vel, sensor.py:1432); see sensor_pos."""
+  _run(_S["MJH_STAGE_SENSOR"], m, d)
+
+
+def sensor_acc(m, d):
+  """Acceleration-stage sensors (reference sensor.sensor_acc, sensor.py:2512): accelerometer, frame accelerations, actuator forces; call
+  after the solver."""
+  _run(_S["MJH_STAGE_SENSOR"], m, d)
 
 
 def efc_J_sparse(m, d, njmax_nnz: int = None):

@@ -697,6 +697,62 @@ def get_data_into(result, mjm, d: types.Data, world_id: int = 0):
     setattr(result, name, getattr(d, name).numpy()[w].copy())
 
 
+def _state_fields(m, d, sig):
+  """(tensor viewed as [nworld, size]) of the components selected by sig, in bit order (reference support.py:674-960)."""
+  if sig < 0 or sig >= (1 << int(types.State.NSTATE)):
+    raise ValueError(f"invalid state signature {sig} >= 2^mjNSTATE")
+  S = types.State
+  fields = [(S.TIME, d.time, 1), (S.QPOS, d.qpos, m.nq), (S.QVEL, d.qvel, m.nv), (S.ACT, d.act, m.na), (S.WARMSTART, d.qacc_warmstart, m.nv),
+            (S.CTRL, d.ctrl, m.nu), (S.QFRC_APPLIED, d.qfrc_applied, m.nv), (S.XFRC_APPLIED, d.xfrc_applied, 6 * m.nbody), (S.EQ_ACTIVE, d.eq_active, m.neq),
+            (S.MOCAP_POS, d.mocap_pos, 3 * m.nmocap), (S.MOCAP_QUAT, d.mocap_quat, 4 * m.nmocap)]
+  return [(arr, n) for bit, arr, n in fields if (sig & int(bit)) and n > 0]
+
+
+def state_size(m: types.Model, sig: int) -> int:
+  """Number of floats of the state components selected by sig (reference mj_stateSize)."""
+  S = types.State
+  sizes = {S.TIME: 1, S.QPOS: m.nq, S.QVEL: m.nv, S.ACT: m.na, S.WARMSTART: m.nv, S.CTRL: m.nu, S.QFRC_APPLIED: m.nv, S.XFRC_APPLIED: 6 * m.nbody,
+           S.EQ_ACTIVE: m.neq, S.MOCAP_POS: 3 * m.nmocap, S.MOCAP_QUAT: 4 * m.nmocap}
+  return int(sum(n for bit, n in sizes.items() if sig & int(bit)))
+
+
+def get_state(m: types.Model, d: types.Data, state: DeviceArray, sig: int, active=None):
+  """Copies the concatenated state components selected by sig (types.State bits) from Data into state [nworld, state_size(m, sig)]
+  (reference support.get_state, support.py:674); `active` is an optional per-world mask.  Device-to-device copies."""
+  import torch
+
+  mask = None if active is None else torch.as_tensor(np.asarray(active.numpy() if hasattr(active, "numpy") else active, dtype=bool), device=state.t.device)
+  adr = 0
+  for arr, n in _state_fields(m, d, int(sig)):
+    src = arr.t.reshape(d.nworld, n).to(state.t.dtype)
+    dst = state.t[:, adr : adr + n]
+    if mask is None:
+      dst.copy_(src)
+    else:
+      dst[mask] = src[mask]
+    adr += n
+  if tuple(state.shape) != (d.nworld, adr):
+    raise ValueError(f"state must have shape ({d.nworld}, {adr})")
+
+
+def set_state(m: types.Model, d: types.Data, state: DeviceArray, sig: int, active=None):
+  """Copies the concatenated state components selected by sig from state into Data (reference support.set_state, support.py:829)."""
+  import torch
+
+  if tuple(state.shape) != (d.nworld, state_size(m, int(sig))):
+    raise ValueError(f"state must have shape ({d.nworld}, {state_size(m, int(sig))})")
+  mask = None if active is None else torch.as_tensor(np.asarray(active.numpy() if hasattr(active, "numpy") else active, dtype=bool), device=state.t.device)
+  adr = 0
+  for arr, n in _state_fields(m, d, int(sig)):
+    dst = arr.t.reshape(d.nworld, n)
+    src = state.t[:, adr : adr + n].to(dst.dtype)
+    if mask is None:
+      dst.copy_(src)
+    else:
+      dst[mask] = src[mask]
+    adr += n
+
+
 def reset_data(m: types.Model, d: types.Data, reset=None):
   """Resets data to qpos0 (reference io.py:2435); `reset` is an optional per-world bool mask."""
   mask = None if reset is None else np.asarray(reset.numpy() if hasattr(reset, "numpy") else reset, dtype=bool)

@@ -150,6 +150,31 @@ class GeomType(enum.IntEnum):
   SDF = 8
 
 
+class State(enum.IntFlag):
+  """State components as bit flags (reference types.py:712; mjtState -- UNPINNED here: the mujoco package is absent, the order follows the
+  reference's attribute list).  HISTORY, USERDATA and PLUGIN have no storage in this engine."""
+
+  TIME = 1 << 0
+  QPOS = 1 << 1
+  QVEL = 1 << 2
+  ACT = 1 << 3
+  HISTORY = 1 << 4
+  WARMSTART = 1 << 5
+  CTRL = 1 << 6
+  QFRC_APPLIED = 1 << 7
+  XFRC_APPLIED = 1 << 8
+  EQ_ACTIVE = 1 << 9
+  MOCAP_POS = 1 << 10
+  MOCAP_QUAT = 1 << 11
+  USERDATA = 1 << 12
+  PLUGIN = 1 << 13
+  NSTATE = 14
+  PHYSICS = TIME | QPOS | QVEL | ACT | HISTORY
+  FULLPHYSICS = PHYSICS | PLUGIN
+  USER = CTRL | QFRC_APPLIED | XFRC_APPLIED | EQ_ACTIVE | MOCAP_POS | MOCAP_QUAT | USERDATA
+  INTEGRATION = FULLPHYSICS | USER | WARMSTART
+
+
 MJ_MINAWAKE = 10  # mjMINAWAKE: steps a tree must stay below the sleep tolerance before it may sleep (reference types.py:29)
 
 
