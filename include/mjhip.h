@@ -57,6 +57,7 @@ extern "C" {
 #define MJH_STAGE_ISLAND 24          /* island.island                island.py:294 */
 #define MJH_STAGE_SLEEP 25           /* sleep.sleep (+ update_sleep) sleep.py:947 */
 #define MJH_STAGE_SENSOR 26          /* sensor.sensor_pos + sensor_vel + (actuator forces of) sensor_acc  sensor.py:810, 1432, 2512 */
+#define MJH_STAGE_ENERGY 27          /* sensor.energy_pos + energy_vel  sensor.py:2934, 3003 */
 #define MJH_STAGE_RUNGEKUTTA4 19     /* forward.rungekutta4 (after a forward)  forward.py:524 */
 
 typedef struct MjhModel {
@@ -255,6 +256,7 @@ typedef struct MjhData {
   int* ws_separable;   /* [nworld] 1: every island has at most 64 dofs (solved per island), 0: generic solver             */
   /* sleeping (types.py:2330-2345; all empty unless MjhModel.sleep_enabled) */
   float* sensordata;   /* [nworld, nsensordata] Data.sensordata (types.py) */
+  float* energy;       /* [nworld, 2] potential, kinetic energy (EnableBit.ENERGY; zero otherwise) */
   int* tree_asleep;    /* [nworld, ntree] < 0: awake (counts up to -1 while the tree could sleep), >= 0: next tree of its sleep cycle */
   int* tree_awake;     /* [nworld, ntree] */
   int* body_awake;     /* [nworld, nbody] SleepState: -1 static, 0 asleep, 1 awake */
@@ -328,7 +330,7 @@ int mjh_timed_steps(const MjhModel* m, const MjhData* d, int nstep, int step0, f
 int mjh_release_thread_resources(void);
 
 const char* mjh_last_error(void);
-#define MJH_ABI_VERSION 23
+#define MJH_ABI_VERSION 24
 int mjh_abi_version(void); /* returns MJH_ABI_VERSION of the library that was loaded */
 
 #ifdef __cplusplus

@@ -12,6 +12,8 @@ from .forward import KERNEL_NAMES
 from .forward import StepGraph
 from .forward import com_pos
 from .forward import contact_force
+from .forward import energy_pos
+from .forward import energy_vel
 from .forward import jac
 from .forward import sensor_acc
 from .forward import sensor_pos

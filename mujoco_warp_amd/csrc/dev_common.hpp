@@ -31,6 +31,7 @@ enum { DSBL_CONSTRAINT = 1 << 0, DSBL_EQUALITY = 1 << 1, DSBL_FRICTIONLOSS = 1 <
        DSBL_REFSAFE = 1 << 12, DSBL_SENSOR = 1 << 13, DSBL_EULERDAMP = 1 << 15, DSBL_NATIVECCD = 1 << 17, DSBL_MULTICCD = 1 << 19 };
 enum { SOL_PGS = 0, SOL_CG = 1, SOL_NEWTON = 2 };
 enum { CONE_PYRAMIDAL = 0, CONE_ELLIPTIC = 1 };
+enum { ENBL_ENERGY = 1 << 1, ENBL_SLEEP = 1 << 5 };
 enum { ISL_WIDE = 1, ISL_MANYROWS = 2 };
 enum { ISL_LIST_MANYROWS = 0, ISL_LIST_WIDE = 1, ISL_LIST_GENERIC = 2 };  // Data.ws_isl_list / ws_isl_count classes  // Data.ws_isl_flags: a world holds an island of 33..64 dofs / of <= 32 dofs and > 64 rows
 #define CON_STRIDE 32  /* words per contact record in d.ws_contact (layout: collide.hpp) */

@@ -114,6 +114,10 @@ static int launch_constraint(const MjhModel* m, const MjhData* d, hipStream_t s)
   return MJH_OK;
 }
 static int launch_sensor(const MjhModel* m, const MjhData* d, int stage, hipStream_t s) {  // stage 1: acceleration-stage sensors (after the solver)
+  if (stage == 0 && (m->enableflags & ENBL_ENERGY)) {  // Data.energy rides with the position / velocity stage sensors (forward.py:1326-1338)
+    if (!d->energy) return fail(MJH_E_ARG, "Data.energy missing (allocate Data with make_data/put_data)");
+    hipLaunchKernelGGL(k_energy, dim3((d->nworld + 63) / 64), dim3(64), 0, s, *m, *d);
+  }
   if (m->nsensor == 0 || (m->disableflags & DSBL_SENSOR) || (stage == 1 && m->nsensor_acc == 0)) return MJH_OK;
   if (!d->sensordata) return fail(MJH_E_ARG, "Data.sensordata missing (allocate Data with make_data/put_data)");
   hipLaunchKernelGGL(k_sensor, dim3((d->nworld * m->nsensor + 255) / 256), dim3(256), 0, s, *m, *d, stage);
@@ -488,6 +492,12 @@ static int run_stage(const MjhModel* m, const MjhData* d, int stage, hipStream_t
       { Scope sc(K_CONSTRAINT); TRY(launch_constraint(m, d, s)); }
       { Scope sc(K_OTHER); TRY(launch_publish(d, s)); }
       return MJH_OK;
+    case MJH_STAGE_ENERGY: {
+      if (!d->energy) return fail(MJH_E_ARG, "Data.energy missing (allocate Data with make_data/put_data)");
+      Scope sc(K_OTHER);
+      hipLaunchKernelGGL(k_energy, dim3((d->nworld + 63) / 64), dim3(64), 0, s, *m, *d);
+      return MJH_OK;
+    }
     case MJH_STAGE_SENSOR: { Scope sc(K_OTHER); TRY(launch_sensor(m, d, 0, s)); return launch_sensor(m, d, 1, s); }
     case MJH_STAGE_UPDATE_SLEEP:
     case MJH_STAGE_WAKE:

@@ -64,3 +64,48 @@ __global__ void __launch_bounds__(256) k_jac(MjhModel m, MjhData d, float* jacp,
     jacr[((size_t)w * 3 + 2) * nv + dof] = jr.z;
   }
 }
+
+// sensor.energy_pos / energy_vel (sensor.py:2773-3018; EnableBit.ENERGY): Data.energy = (potential, kinetic).  Potential = -sum m g . xipos
+// + joint springs 0.5 k r^2 (r = displacement from qpos_spring; quaternion joints: the rotation vector); kinetic = 0.5 qvel . M qvel from
+// the sparse M (row i = the dof's ancestor chain, diagonal last).  One thread per world: a few hundred FLOPs.
+__global__ void __launch_bounds__(64) k_energy(MjhModel m, MjhData d) {
+  const int w = blockIdx.x * 64 + threadIdx.x;
+  if (w >= d.nworld) return;
+  const V3 g = ld3(bf(m.opt_gravity, m.opt_gravity_nb, w, 3));
+  const float* mass = bf(m.body_mass, m.body_mass_nb, w, m.nbody);
+  float pot = 0.0f;
+  if (!(m.disableflags & DSBL_GRAVITY))
+    for (int b = 1; b < m.nbody; ++b) pot -= mass[b] * dot(g, ld3(d.xipos + ((size_t)w * m.nbody + b) * 3));
+  if (!(m.disableflags & DSBL_SPRING)) {
+    const float* stiff = bf(m.jnt_stiffness, m.jnt_stiffness_nb, w, m.njnt);
+    const float* qs = bf(m.qpos_spring, m.qpos_spring_nb, w, m.nq);
+    const float* qpos = d.qpos + (size_t)w * m.nq;
+    for (int j = 0; j < m.njnt; ++j) {
+      const float kk = stiff[j];
+      if (kk == 0.0f) continue;
+      const int qa = m.jnt_qposadr[j], t = m.jnt_type[j];
+      if (t == JNT_FREE) {
+        const V3 d0 = ld3(qpos + qa) - ld3(qs + qa);
+        const V3 d1 = quat_sub(quat_normalize(ld4(qpos + qa + 3)), ld4(qs + qa + 3));
+        pot += 0.5f * kk * (dot(d0, d0) + dot(d1, d1));
+      } else if (t == JNT_BALL) {
+        const V3 d1 = quat_sub(quat_normalize(ld4(qpos + qa)), ld4(qs + qa));
+        pot += 0.5f * kk * dot(d1, d1);
+      } else {
+        const float r = qpos[qa] - qs[qa];
+        pot += 0.5f * kk * r * r;
+      }
+    }
+  }
+  const float* M = d.M + (size_t)w * m.nC;
+  const float* v = d.qvel + (size_t)w * m.nv;
+  float kin = 0.0f;
+  for (int i = 0; i < m.nv; ++i) {
+    const int adr = m.M_rowadr[i], nnz = m.M_rownnz[i];
+    float acc = 0.5f * M[adr + nnz - 1] * v[i];  // diagonal is the last entry of the row
+    for (int q = 0; q < nnz - 1; ++q) acc += M[adr + q] * v[m.M_colind[adr + q]];
+    kin += v[i] * acc;
+  }
+  d.energy[2 * w] = pot;
+  d.energy[2 * w + 1] = kin;
+}

@@ -224,6 +224,17 @@ def jac(m, d, jacp: Optional[DeviceArray], jacr: Optional[DeviceArray], point: D
                        jacr.ptr if jacr is not None else None, point.ptr, body.ptr, _stream()))
 
 
+def energy_pos(m, d):
+  """Data.energy = (potential, kinetic) from the current kinematics, M and qvel (reference sensor.energy_pos / energy_vel, sensor.py:2934,
+  3003: one launch computes both here).  `forward` / `step` call it when EnableBit.ENERGY is set."""
+  _run(_S["MJH_STAGE_ENERGY"], m, d)
+
+
+def energy_vel(m, d):
+  """See energy_pos (both components are computed together)."""
+  _run(_S["MJH_STAGE_ENERGY"], m, d)
+
+
 def sensor_pos(m, d):
   """Position-stage sensors (reference sensor.sensor_pos, sensor.py:810).  This engine computes the position and velocity stages (and
   the actuator forces) in one launch: sensor_pos and sensor_vel both run it; call them after fwd_position / fwd_velocity / fwd_actuation."""

@@ -532,7 +532,7 @@ def _data_shapes(m, nworld, nconmax, njmax, naconmax):
     tree_asleep=(W, m.ntree), tree_awake=(W, m.ntree), body_awake=(W, nb), body_awake_ind=(W, nb), dof_awake_ind=(W, nv), ntree_awake=(W,), nbody_awake=(W,),
     nv_awake=(W,), tree_island=(W, m.ntree), nisland=(W,), ws_sleep_J=(W if m.sleep_enabled else 0, njmax_pad, nv_pad), ws_sleep_warm=(W if m.sleep_enabled else 0, nv),
     ws_sleep_flag=(W,),
-    sensordata=(W, m.nsensordata), eq_active=(W, m.neq), ws_rk=(W, nq + 3 * nv + 2 * na), ws_contact=(W, contact_cap(nconmax), 32),
+    sensordata=(W, m.nsensordata), energy=(W, 2), eq_active=(W, m.neq), ws_rk=(W, nq + 3 * nv + 2 * na), ws_contact=(W, contact_cap(nconmax), 32),
   )
   return sh, njmax_pad, nv_pad
 

@@ -597,6 +597,7 @@ class Data(_Dirty):
   ws_ccd: DeviceArray = _arr(('nccdworld', 'nccdword', 32), "float32")
   ws_order: DeviceArray = _arr(('nworld',), "int32")
   sensordata: DeviceArray = _arr(('nworld', 'nsensordata'), "float32")
+  energy: DeviceArray = _arr(('nworld', 2), "float32")
   tree_asleep: DeviceArray = _arr(('nworld', 'ntree'), "int32")  # reference types.py:2330-2345
   tree_awake: DeviceArray = _arr(('nworld', 'ntree'), "int32")
   body_awake: DeviceArray = _arr(('nworld', 'nbody'), "int32")
