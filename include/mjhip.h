@@ -58,6 +58,7 @@ extern "C" {
 #define MJH_STAGE_SLEEP 25           /* sleep.sleep (+ update_sleep) sleep.py:947 */
 #define MJH_STAGE_SENSOR 26          /* sensor.sensor_pos + sensor_vel + (actuator forces of) sensor_acc  sensor.py:810, 1432, 2512 */
 #define MJH_STAGE_ENERGY 27          /* sensor.energy_pos + energy_vel  sensor.py:2934, 3003 */
+#define MJH_STAGE_SUBTREE_VEL 28     /* smooth.subtree_vel  smooth.py:3614 */
 #define MJH_STAGE_RUNGEKUTTA4 19     /* forward.rungekutta4 (after a forward)  forward.py:524 */
 
 typedef struct MjhModel {
@@ -146,6 +147,7 @@ typedef struct MjhModel {
   const float* mesh_vert;       /* [nmeshvert, 3] vertices in the mesh (= geom) frame; searched exhaustively by the convex narrowphase */
   /* sensors (types.py: sensor_*; csrc/sensor.hpp computes joint / actuator / ball / frame / velocimeter / gyro / subtreecom / clock) */
   int nsensor; int nsensordata;
+  int nsensor_subtree; /* subtreelinvel / subtreeangmom sensors: smooth.subtree_vel runs before the sensor launch */
   int nsensor_acc;  /* sensors of the acceleration stage (accelerometer, framelinacc, frameangacc): one more launch between solver and integrator */
   const int* sensor_type; const int* sensor_datatype; const int* sensor_objtype; const int* sensor_objid; const int* sensor_reftype; const int* sensor_refid;
   const int* sensor_dim; const int* sensor_adr;
@@ -256,6 +258,7 @@ typedef struct MjhData {
   int* ws_separable;   /* [nworld] 1: every island has at most 64 dofs (solved per island), 0: generic solver             */
   /* sleeping (types.py:2330-2345; all empty unless MjhModel.sleep_enabled) */
   float* sensordata;   /* [nworld, nsensordata] Data.sensordata (types.py) */
+  float* subtree_linvel; float* subtree_angmom; /* [nworld, nbody, 3] smooth.subtree_vel (computed on request or for sensors that read them) */
   float* energy;       /* [nworld, 2] potential, kinetic energy (EnableBit.ENERGY; zero otherwise) */
   int* tree_asleep;    /* [nworld, ntree] < 0: awake (counts up to -1 while the tree could sleep), >= 0: next tree of its sleep cycle */
   int* tree_awake;     /* [nworld, ntree] */
@@ -330,7 +333,7 @@ int mjh_timed_steps(const MjhModel* m, const MjhData* d, int nstep, int step0, f
 int mjh_release_thread_resources(void);
 
 const char* mjh_last_error(void);
-#define MJH_ABI_VERSION 24
+#define MJH_ABI_VERSION 25
 int mjh_abi_version(void); /* returns MJH_ABI_VERSION of the library that was loaded */
 
 #ifdef __cplusplus

@@ -119,6 +119,10 @@ static int launch_sensor(const MjhModel* m, const MjhData* d, int stage, hipStre
     hipLaunchKernelGGL(k_energy, dim3((d->nworld + 63) / 64), dim3(64), 0, s, *m, *d);
   }
   if (m->nsensor == 0 || (m->disableflags & DSBL_SENSOR) || (stage == 1 && m->nsensor_acc == 0)) return MJH_OK;
+  if (stage == 0 && m->nsensor_subtree > 0) {
+    if (!d->subtree_linvel || !d->subtree_angmom) return fail(MJH_E_ARG, "Data.subtree_linvel / subtree_angmom missing");
+    hipLaunchKernelGGL(k_subtree_vel, dim3((d->nworld + 63) / 64), dim3(64), 0, s, *m, *d);
+  }
   if (!d->sensordata) return fail(MJH_E_ARG, "Data.sensordata missing (allocate Data with make_data/put_data)");
   hipLaunchKernelGGL(k_sensor, dim3((d->nworld * m->nsensor + 255) / 256), dim3(256), 0, s, *m, *d, stage);
   return MJH_OK;
@@ -492,6 +496,12 @@ static int run_stage(const MjhModel* m, const MjhData* d, int stage, hipStream_t
       { Scope sc(K_CONSTRAINT); TRY(launch_constraint(m, d, s)); }
       { Scope sc(K_OTHER); TRY(launch_publish(d, s)); }
       return MJH_OK;
+    case MJH_STAGE_SUBTREE_VEL: {
+      if (!d->subtree_linvel || !d->subtree_angmom) return fail(MJH_E_ARG, "Data.subtree_linvel / subtree_angmom missing");
+      Scope sc(K_OTHER);
+      hipLaunchKernelGGL(k_subtree_vel, dim3((d->nworld + 63) / 64), dim3(64), 0, s, *m, *d);
+      return MJH_OK;
+    }
     case MJH_STAGE_ENERGY: {
       if (!d->energy) return fail(MJH_E_ARG, "Data.energy missing (allocate Data with make_data/put_data)");
       Scope sc(K_OTHER);

@@ -10,7 +10,7 @@
 
 enum { SENS_ACCELEROMETER = 1, SENS_VELOCIMETER = 2, SENS_GYRO = 3, SENS_JOINTPOS = 9, SENS_JOINTVEL = 10, SENS_ACTUATORPOS = 13, SENS_ACTUATORVEL = 14, SENS_ACTUATORFRC = 15,
        SENS_BALLQUAT = 18, SENS_BALLANGVEL = 19, SENS_FRAMEPOS = 26, SENS_FRAMEQUAT = 27, SENS_FRAMEXAXIS = 28, SENS_FRAMEYAXIS = 29, SENS_FRAMEZAXIS = 30,
-       SENS_FRAMELINVEL = 31, SENS_FRAMEANGVEL = 32, SENS_FRAMELINACC = 33, SENS_FRAMEANGACC = 34, SENS_SUBTREECOM = 35, SENS_CLOCK = 45 };
+       SENS_FRAMELINVEL = 31, SENS_FRAMEANGVEL = 32, SENS_FRAMELINACC = 33, SENS_FRAMEANGACC = 34, SENS_SUBTREECOM = 35, SENS_SUBTREELINVEL = 36, SENS_SUBTREEANGMOM = 37, SENS_CLOCK = 45 };
 enum { OBJ_BODY = 1, OBJ_XBODY = 2, OBJ_GEOM = 5, OBJ_SITE = 6 };
 
 struct SensFrame {
@@ -99,6 +99,8 @@ __global__ void __launch_bounds__(256) k_sensor(MjhModel m, MjhData d, int stage
   } else if (t == SENS_BALLANGVEL) put3(ld3(d.qvel + (size_t)w * m.nv + m.jnt_dofadr[id]));
   else if (t == SENS_CLOCK) v[0] = d.time[w];
   else if (t == SENS_SUBTREECOM) put3(ld3(d.subtree_com + ((size_t)w * m.nbody + id) * 3));
+  else if (t == SENS_SUBTREELINVEL) put3(ld3(d.subtree_linvel + ((size_t)w * m.nbody + id) * 3));  // (k_subtree_vel ran just before)
+  else if (t == SENS_SUBTREEANGMOM) put3(ld3(d.subtree_angmom + ((size_t)w * m.nbody + id) * 3));
   else if (t == SENS_FRAMEPOS) {
     const SensFrame f = sens_frame(m, d, w, ot, id);
     if (rid == -1) put3(f.pos);

@@ -109,3 +109,41 @@ __global__ void __launch_bounds__(64) k_energy(MjhModel m, MjhData d) {
   d.energy[2 * w] = pot;
   d.energy[2 * w + 1] = kin;
 }
+
+// smooth.subtree_vel (smooth.py:3502-3662): linear velocity of every subtree's centre of mass and angular momentum of every subtree about
+// it.  One thread per world walks the bodies (children have larger ids than their parents): momenta are summed towards the root in
+// reverse body order, exactly the level-by-level accumulation of the reference.
+DEV V3 body_com_linvel(const MjhModel& m, const MjhData& d, int w, int b) {
+  const float* cv = d.cvel + ((size_t)w * m.nbody + b) * 6;
+  const V3 off = ld3(d.xipos + ((size_t)w * m.nbody + b) * 3) - ld3(d.subtree_com + ((size_t)w * m.nbody + m.body_rootid[b]) * 3);
+  return ld3(cv + 3) - cross(off, ld3(cv));
+}
+__global__ void __launch_bounds__(64) k_subtree_vel(MjhModel m, MjhData d) {
+  const int w = blockIdx.x * 64 + threadIdx.x, nb = m.nbody;
+  if (w >= d.nworld) return;
+  const float* mass = bf(m.body_mass, m.body_mass_nb, w, nb);
+  const float* inertia = bf(m.body_inertia, m.body_inertia_nb, w, 3 * nb);
+  const float* stm = bf(m.body_subtreemass, m.body_subtreemass_nb, w, nb);
+  float* linvel = d.subtree_linvel + (size_t)w * nb * 3;
+  float* angmom = d.subtree_angmom + (size_t)w * nb * 3;
+  const float* scom = d.subtree_com + (size_t)w * nb * 3;
+  for (int b = 0; b < nb; ++b) {
+    st3(linvel + 3 * b, mass[b] * body_com_linvel(m, d, w, b));
+    const float* R = d.ximat + ((size_t)w * nb + b) * 9;
+    V3 dv = matT_mul(R, ld3(d.cvel + ((size_t)w * nb + b) * 6));
+    dv = V3{dv.x * inertia[3 * b], dv.y * inertia[3 * b + 1], dv.z * inertia[3 * b + 2]};
+    st3(angmom + 3 * b, mat_mul(R, dv));
+  }
+  for (int b = nb - 1; b >= 0; --b) {
+    if (b > 0) st3(linvel + 3 * m.body_parentid[b], ld3(linvel + 3 * m.body_parentid[b]) + ld3(linvel + 3 * b));
+    st3(linvel + 3 * b, ld3(linvel + 3 * b) * (1.0f / fmaxf(MJ_MINVAL, stm[b])));
+  }
+  for (int b = nb - 1; b > 0; --b) {
+    const int p = m.body_parentid[b];
+    const V3 lv = ld3(linvel + 3 * b);
+    V3 L = ld3(angmom + 3 * b) + cross(ld3(d.xipos + ((size_t)w * nb + b) * 3) - ld3(scom + 3 * b), (body_com_linvel(m, d, w, b) - lv) * mass[b]);
+    st3(angmom + 3 * b, L);
+    L = L + cross(ld3(scom + 3 * b) - ld3(scom + 3 * p), (lv - ld3(linvel + 3 * p)) * stm[b]);
+    st3(angmom + 3 * p, ld3(angmom + 3 * p) + L);
+  }
+}

@@ -224,6 +224,12 @@ def jac(m, d, jacp: Optional[DeviceArray], jacr: Optional[DeviceArray], point: D
                        jacr.ptr if jacr is not None else None, point.ptr, body.ptr, _stream()))
 
 
+def subtree_vel(m, d):
+  """Data.subtree_linvel / subtree_angmom: velocity of every subtree's centre of mass and its angular momentum about it (reference
+  smooth.subtree_vel, smooth.py:3614); call after fwd_velocity.  `forward` runs it when a sensor reads the result."""
+  _run(_S["MJH_STAGE_SUBTREE_VEL"], m, d)
+
+
 def energy_pos(m, d):
   """Data.energy = (potential, kinetic) from the current kinematics, M and qvel (reference sensor.energy_pos / energy_vel, sensor.py:2934,
   3003: one launch computes both here).  `forward` / `step` call it when EnableBit.ENERGY is set."""

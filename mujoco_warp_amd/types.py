@@ -442,6 +442,7 @@ class Model(_Dirty):
   npolygonmax: int = 0
   nsensordata: int = 0
   nsensor_acc: int = 0
+  nsensor_subtree: int = 0
   sensor_type: DeviceArray = _arr(('nsensor',), "int32")
   sensor_datatype: DeviceArray = _arr(('nsensor',), "int32")
   sensor_objtype: DeviceArray = _arr(('nsensor',), "int32")
@@ -598,6 +599,8 @@ class Data(_Dirty):
   ws_order: DeviceArray = _arr(('nworld',), "int32")
   sensordata: DeviceArray = _arr(('nworld', 'nsensordata'), "float32")
   energy: DeviceArray = _arr(('nworld', 2), "float32")
+  subtree_linvel: DeviceArray = _arr(('nworld', 'nbody', 3), "float32")
+  subtree_angmom: DeviceArray = _arr(('nworld', 'nbody', 3), "float32")
   tree_asleep: DeviceArray = _arr(('nworld', 'ntree'), "int32")  # reference types.py:2330-2345
   tree_awake: DeviceArray = _arr(('nworld', 'ntree'), "int32")
   body_awake: DeviceArray = _arr(('nworld', 'nbody'), "int32")

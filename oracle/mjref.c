@@ -2790,7 +2790,7 @@ void ref_sleep(const RefModel* m, RefData* d) { /* sleep.py:824-999 */
 /* ================================================================ sensors (sensor.py, subset) */
 enum { SENS_ACCELEROMETER = 1, SENS_FRAMELINACC = 33, SENS_FRAMEANGACC = 34, SENS_VELOCIMETER = 2, SENS_GYRO = 3, SENS_JOINTPOS = 9, SENS_JOINTVEL = 10, SENS_ACTUATORPOS = 13, SENS_ACTUATORVEL = 14, SENS_ACTUATORFRC = 15,
        SENS_BALLQUAT = 18, SENS_BALLANGVEL = 19, SENS_FRAMEPOS = 26, SENS_FRAMEQUAT = 27, SENS_FRAMEXAXIS = 28, SENS_FRAMEYAXIS = 29, SENS_FRAMEZAXIS = 30,
-       SENS_FRAMELINVEL = 31, SENS_FRAMEANGVEL = 32, SENS_SUBTREECOM = 35, SENS_CLOCK = 45 };
+       SENS_FRAMELINVEL = 31, SENS_FRAMEANGVEL = 32, SENS_SUBTREECOM = 35, SENS_SUBTREELINVEL = 36, SENS_SUBTREEANGMOM = 37, SENS_CLOCK = 45 };
 enum { OBJ_BODY = 1, OBJ_XBODY = 2, OBJ_GEOM = 5, OBJ_SITE = 6 };
 /* pose, quaternion and body of a frame object (sensor.py:266-374 _get_pos / _get_mat / _get_quat / _get_body_id; sites are posed here: the
    oracle keeps no site arrays) */
@@ -2856,9 +2856,47 @@ static void body_cacc(const RefModel* m, const RefData* d, int body, double* cac
   for (int dof = m->body_dofadr[bb] + m->body_dofnum[bb] - 1; dof >= 0; dof = m->dof_parentid[dof])
     for (int k = 0; k < 6; k++) cacc[k] += d->cdof_dot[6 * dof + k] * d->qvel[dof] + d->cdof[6 * dof + k] * d->qacc[dof];
 }
+/* smooth.py:3502-3662 subtree_vel: velocity of every subtree's centre of mass, angular momentum of every subtree about it */
+void ref_subtree_vel(const RefModel* m, RefData* d) {
+  int nb = m->nbody;
+  double* lin = (double*)malloc(sizeof(double) * 3 * nb); /* velocity of each body's own centre of mass */
+  for (int b = 0; b < nb; b++) {
+    const double* cv = d->cvel + 6 * b;
+    double off[3], c[3], dv[3];
+    v3sub(off, d->xipos + 3 * b, d->subtree_com + 3 * m->body_rootid[b]);
+    v3cross(c, off, cv);
+    v3sub(lin + 3 * b, cv + 3, c);
+    for (int k = 0; k < 3; k++) d->subtree_linvel[3 * b + k] = m->body_mass[b] * lin[3 * b + k];
+    matT_mul_vec(dv, d->ximat + 9 * b, cv);
+    for (int k = 0; k < 3; k++) dv[k] *= m->body_inertia[3 * b + k];
+    mat_mul_vec(d->subtree_angmom + 3 * b, d->ximat + 9 * b, dv);
+  }
+  for (int b = nb - 1; b >= 0; b--) {
+    if (b > 0) v3add(d->subtree_linvel + 3 * m->body_parentid[b], d->subtree_linvel + 3 * m->body_parentid[b], d->subtree_linvel + 3 * b);
+    double s = 1.0 / fmax(MINVAL, m->body_subtreemass[b]);
+    for (int k = 0; k < 3; k++) d->subtree_linvel[3 * b + k] *= s;
+  }
+  for (int b = nb - 1; b > 0; b--) {
+    int p = m->body_parentid[b];
+    double dx[3], dv[3], dL[3];
+    v3sub(dx, d->xipos + 3 * b, d->subtree_com + 3 * b);
+    for (int k = 0; k < 3; k++) dv[k] = (lin[3 * b + k] - d->subtree_linvel[3 * b + k]) * m->body_mass[b];
+    v3cross(dL, dx, dv);
+    v3add(d->subtree_angmom + 3 * b, d->subtree_angmom + 3 * b, dL);
+    v3add(d->subtree_angmom + 3 * p, d->subtree_angmom + 3 * p, d->subtree_angmom + 3 * b);
+    v3sub(dx, d->subtree_com + 3 * b, d->subtree_com + 3 * p);
+    for (int k = 0; k < 3; k++) dv[k] = (d->subtree_linvel[3 * b + k] - d->subtree_linvel[3 * p + k]) * m->body_subtreemass[b];
+    v3cross(dL, dx, dv);
+    v3add(d->subtree_angmom + 3 * p, d->subtree_angmom + 3 * p, dL);
+  }
+  free(lin);
+}
 /* stage 0: position / velocity stage sensors and actuator forces; stage 1: acceleration stage (accelerometer, frame accelerations) */
 static void sensor_stage(const RefModel* m, RefData* d, int stage) {
   if (m->disableflags & (1 << 13)) return; /* DisableBit.SENSOR */
+  if (stage == 0)
+    for (int i = 0; i < m->nsensor; i++)
+      if (m->sensor_type[i] == SENS_SUBTREELINVEL || m->sensor_type[i] == SENS_SUBTREEANGMOM) { ref_subtree_vel(m, d); break; }
   for (int i = 0; i < m->nsensor; i++) {
     int acc_type = m->sensor_type[i] == SENS_ACCELEROMETER || m->sensor_type[i] == SENS_FRAMELINACC || m->sensor_type[i] == SENS_FRAMEANGACC;
     if (acc_type != (stage == 1)) continue;
@@ -2875,6 +2913,8 @@ static void sensor_stage(const RefModel* m, RefData* d, int stage) {
     } else if (t == SENS_BALLANGVEL) memcpy(v, d->qvel + m->jnt_dofadr[id], 3 * sizeof(double));
     else if (t == SENS_CLOCK) v[0] = d->time;
     else if (t == SENS_SUBTREECOM) v3cpy(v, d->subtree_com + 3 * id);
+    else if (t == SENS_SUBTREELINVEL) v3cpy(v, d->subtree_linvel + 3 * id);
+    else if (t == SENS_SUBTREEANGMOM) v3cpy(v, d->subtree_angmom + 3 * id);
     else if (t == SENS_FRAMEPOS) { /* 377-403 */
       frame_of(m, d, ot, id, pos, NULL, NULL);
       if (rid == -1) v3cpy(v, pos);

@@ -264,6 +264,8 @@ typedef struct RefData {
   double* efc_frictionloss;
   double* efc_force;
   double* sensordata;
+  double* subtree_linvel;
+  double* subtree_angmom;
   int* tree_asleep;   /* sleep.py: < 0 awake (countdown to -1), >= 0 next tree of the sleep cycle */
   int* tree_awake;
   int* body_awake;    /* SleepState: -1 static, 0 asleep, 1 awake */
@@ -294,6 +296,7 @@ void ref_euler(const RefModel* m, RefData* d);
 void ref_implicitfast(const RefModel* m, RefData* d);
 void ref_rungekutta4(const RefModel* m, RefData* d); /* forward.py:524; call after ref_forward */
 void ref_step(const RefModel* m, RefData* d);
+void ref_subtree_vel(const RefModel* m, RefData* d); /* smooth.py:3614 */
 void ref_sensor(const RefModel* m, RefData* d); /* sensor.py sensor_pos / sensor_vel / sensor_acc, the subset in oracle/mjref.c; called by ref_forward */
 /* sleep.py / island.py:28-310 (tree-level constraint islands, sleeping, waking) */
 void ref_update_sleep(const RefModel* m, RefData* d);

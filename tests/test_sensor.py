@@ -51,6 +51,7 @@ SENSOR_XML = """
     <gyro name="gyro_cut" site="imu" cutoff="0.5"/>
     <accelerometer name="acc" site="imu"/><framelinacc name="la" objtype="site" objname="imu"/><frameangacc name="aa" objtype="body" objname="ball"/>
     <framelinacc name="la_tip" objtype="site" objname="tip"/>
+    <subtreelinvel name="slv" body="arm"/><subtreeangmom name="sam" body="arm"/><subtreeangmom name="sam_ball" body="ball"/>
     <subtreecom name="com" body="arm"/><clock name="t"/>
   </sensor>
 </mujoco>
@@ -75,7 +76,7 @@ def _state(sim_or_none, mjm):
 
 def test_oracle_sensor_closed_forms():
   mjm = mjw.mjcf.from_xml_string(SENSOR_XML)
-  assert mjm.nsensor == 29 and mjm.nsensordata == int(mjm.sensor_dim.sum())
+  assert mjm.nsensor == 32 and mjm.nsensordata == int(mjm.sensor_dim.sum())
   s = ref.RefSim(mjm)
   s.qpos[:], s.qvel[:] = _state(s, mjm)
   s.ctrl[:] = [0.3, -0.2]
@@ -113,6 +114,25 @@ def test_oracle_sensor_closed_forms():
   r_imu = Rb @ mjm.site_pos[3]
   cent = np.cross(w_world, np.cross(w_world, r_imu))
   assert np.allclose(g("aa"), 0, atol=1e-9) and np.allclose(g("acc"), R_imu.T @ cent, atol=1e-9) and np.allclose(g("la"), cent, atol=1e-9)
+  # subtree momenta: velocity of the arm subtree's centre of mass = sum m v / sum m; angular momentum about it = sum (r x m v + R I R^T w)
+  def body_vel(b, wb_world):
+    c = s.xipos[b]
+    return wb_world, c
+
+  m1, m2 = mjm.body_mass[1], mjm.body_mass[2]
+  w1 = np.array([0, 0, w])
+  v1 = np.cross(w1, s.xipos[1] - [0, 0, 1])
+  w2 = w1 + wb
+  v2 = np.cross(w1, s.xpos[2] - [0, 0, 1]) + np.cross(w2, s.xipos[2] - s.xpos[2])
+  com = (m1 * s.xipos[1] + m2 * s.xipos[2]) / (m1 + m2)
+  assert np.allclose(g("slv"), (m1 * v1 + m2 * v2) / (m1 + m2), atol=1e-12)
+  L = np.zeros(3)
+  for b, mb, vb, wb_ in ((1, m1, v1, w1), (2, m2, v2, w2)):
+    R = s.ximat[b].reshape(3, 3)
+    L += np.cross(s.xipos[b] - com, mb * vb) + R @ (mjm.body_inertia[b] * (R.T @ wb_))
+  assert np.allclose(g("sam"), L, atol=1e-12)
+  Rs = s.ximat[3].reshape(3, 3)
+  assert np.allclose(g("sam_ball"), Rs @ (mjm.body_inertia[3] * (Rs.T @ w_world)), atol=1e-12)
   m_arm, m_fore = mjm.body_mass[1], mjm.body_mass[2]
   assert np.allclose(g("com"), (m_arm * s.xipos[1] + m_fore * s.xipos[2]) / (m_arm + m_fore))
   # sensors outside the subset keep their slot (the reference's sensordata layout) and read 0; unknown elements raise
