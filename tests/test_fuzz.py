@@ -1,7 +1,7 @@
 """Randomised-model parity (40 + 12 PGS + 16 extra-collider + 16 convex-pair seeds by default; MJH_FUZZ_SEEDS / MJH_FUZZ_PGS_SEEDS /
 MJH_FUZZ_COLLIDER_SEEDS / MJH_FUZZ_CONVEX_SEEDS for more: 480 + 160 + 320 were run clean; of 320 convex-pair seeds -- box pairs included,
 through CCD + multi-contact -- 313 pass, 3 skip on the mass-matrix condition and 4 (46, 242, 275, 315) exceed the per-step bounds by EPA
-facet noise or a face-alignment decision at its 1.6 mrad threshold: qpos 3e-5 .. 2.3e-3): random kinematic trees with mixed joint / geom / actuator types against the float64 oracle.
+facet noise or a face-alignment decision at its 1.6 mrad threshold: qpos 3e-5 .. 2.3e-3; + 16 random-convex-mesh seeds, MJH_FUZZ_MESH_SEEDS: 200 run, 182 pass, 18 skip on the row budget): random kinematic trees with mixed joint / geom / actuator types against the float64 oracle.
 
 The fixed models (humanoid, G1, Panda, pendula, free bodies, pile) pin specific code paths; these seeds sweep the
 combinations: free / ball / hinge / slide joints at random depths, limits, damping, springs, armature, friction loss,
@@ -21,8 +21,9 @@ from oracle import ref
 pytestmark = pytest.mark.gpu
 
 
-def random_model_xml(seed, more_colliders=False, convex_pairs=False):
+def random_model_xml(seed, more_colliders=False, convex_pairs=False, meshes=False):
   r = np.random.default_rng(seed)
+  assets = []
   integrator = "implicitfast" if seed % 2 else "Euler"
   lines = [f'<mujoco><option timestep="0.003" integrator="{integrator}"/>',
            '<default><geom condim="3" friction="0.8 0.02 0.001"/><joint armature="0.02"/></default>', "<worldbody>",
@@ -75,7 +76,14 @@ def random_model_xml(seed, more_colliders=False, convex_pairs=False):
       body_contact = f'contype="{bits[gt][0]}" conaffinity="{bits[gt][1]}"'
     if convex_pairs:  # everything collides with everything: cylinder-* and ellipsoid-* pairs go through GJK / EPA
       body_contact = 'contype="1" conaffinity="1"'
-    if gt == "sphere":
+    if meshes and gt in ("box", "ellipsoid", "cylinder"):
+      # a random convex polytope instead: 6..8 vertices with multi-contact recovery on (vertex degree <= 7), up to 14 with it off
+      nvert = int(r.integers(6, 9)) if seed % 2 == 0 else int(r.integers(6, 15))
+      pts = r.standard_normal((nvert, 3))
+      pts = pts / np.linalg.norm(pts, axis=1, keepdims=True) * r.uniform(0.8, 1.2, (nvert, 1)) * np.array([s, s * r.uniform(.7, 1.4), s * r.uniform(.7, 1.4)])
+      assets.append(f'<mesh name="m{b}" vertex="{" ".join(f"{x:.4f}" for x in pts.reshape(-1))}"/>')
+      lines.append(f'<geom type="mesh" mesh="m{b}" {body_contact}/>')
+    elif gt == "sphere":
       lines.append(f'<geom type="sphere" size="{s:.3f}" {body_contact}/>')
     elif gt == "capsule":
       lines.append(f'<geom type="capsule" fromto="0 0 0 {r.uniform(-.1, .1):.3f} {r.uniform(-.1, .1):.3f} {-r.uniform(.1, .2):.3f}" size="{s * .6:.3f}" {body_contact}/>')
@@ -97,11 +105,13 @@ def random_model_xml(seed, more_colliders=False, convex_pairs=False):
         lines.append(f'<position joint="{jn}" kp="{r.uniform(5, 40):.1f}" kv="{r.uniform(.1, 2):.2f}"/>')
     lines.append("</actuator>")
   lines.append("</mujoco>")
+  if meshes:
+    lines.insert(1, "<asset>" + "".join(assets) + "</asset>" + ('<option><flag multiccd="disable"/></option>' if seed % 2 else ""))
   return "\n".join(lines)
 
 
-def _run_seed(seed, solver, njmax_dev=128, more_colliders=False, convex_pairs=False):
-  mjm = mjw.mjcf.from_xml_string(random_model_xml(seed, more_colliders, convex_pairs))
+def _run_seed(seed, solver, njmax_dev=128, more_colliders=False, convex_pairs=False, meshes=False):
+  mjm = mjw.mjcf.from_xml_string(random_model_xml(seed, more_colliders, convex_pairs, meshes))
   mjm.opt.solver = int(solver)
   mjm.opt.iterations, mjm.opt.ls_iterations = 100, 50
   s = ref.RefSim(mjm, nconmax=48, njmax=128, tolerance=1e-6)
@@ -133,7 +143,7 @@ def _run_seed(seed, solver, njmax_dev=128, more_colliders=False, convex_pairs=Fa
     # convex pairs: deep interpenetrations (bodies spawned or pushed into each other) leave EPA's facet normal ill-determined --
     # its polytope has at most 40 vertices, float32 and float64 stop on neighbouring facets up to 6e-2 rad apart (tests/test_convex.py);
     # such states are stepped but not compared
-    deep = convex_pairs and any(s.con_dist[c] < -0.004 and (int(mjm.geom_type[s.con_geom[c][0]]) in (4, 5) or int(mjm.geom_type[s.con_geom[c][1]]) in (4, 5))
+    deep = convex_pairs and any(s.con_dist[c] < -0.004 and (int(mjm.geom_type[s.con_geom[c][0]]) in (4, 5, 7) or int(mjm.geom_type[s.con_geom[c][1]]) in (4, 5, 7))
                                 and int(mjm.geom_type[s.con_geom[c][0]]) != 0 for c in range(s.ncon))
     mjw.step(m, d)
     same_rows = int(d.nefc.numpy()[1]) == s.nefc
@@ -180,3 +190,10 @@ def test_random_model_convex_pairs(seed):
   """The same random trees with every geom colliding with every other: ellipsoid-* and cylinder-* pairs run GJK / EPA
   (csrc/convex.hpp) next to the primitive colliders."""
   _run_seed(seed, mjw.SolverType.NEWTON if seed % 2 else mjw.SolverType.CG, convex_pairs=True)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MJH_FUZZ_MESH_SEEDS", "16"))))
+def test_random_model_meshes(seed):
+  """The same random trees with boxes / ellipsoids / cylinders replaced by random convex polytopes (inline mesh assets), every geom
+  colliding with every other: mesh support in GJK / EPA, plane-mesh, and (even seeds) multi-contact recovery on mesh faces."""
+  _run_seed(seed, mjw.SolverType.NEWTON if seed % 2 else mjw.SolverType.CG, convex_pairs=True, meshes=True)
