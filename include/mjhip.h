@@ -59,6 +59,7 @@ extern "C" {
 #define MJH_STAGE_SENSOR 26          /* sensor.sensor_pos + sensor_vel + (actuator forces of) sensor_acc  sensor.py:810, 1432, 2512 */
 #define MJH_STAGE_ENERGY 27          /* sensor.energy_pos + energy_vel  sensor.py:2934, 3003 */
 #define MJH_STAGE_SUBTREE_VEL 28     /* smooth.subtree_vel  smooth.py:3614 */
+#define MJH_STAGE_RNE_POSTCONSTRAINT 29 /* smooth.rne_postconstraint  smooth.py:1744 */
 #define MJH_STAGE_RUNGEKUTTA4 19     /* forward.rungekutta4 (after a forward)  forward.py:524 */
 
 typedef struct MjhModel {
@@ -148,6 +149,7 @@ typedef struct MjhModel {
   /* sensors (types.py: sensor_*; csrc/sensor.hpp computes joint / actuator / ball / frame / velocimeter / gyro / subtreecom / clock) */
   int nsensor; int nsensordata;
   int nsensor_subtree; /* subtreelinvel / subtreeangmom sensors: smooth.subtree_vel runs before the sensor launch */
+  int nsensor_frc;  /* force / torque sensors: smooth.rne_postconstraint runs before the acceleration-stage sensor launch */
   int nsensor_acc;  /* sensors of the acceleration stage (accelerometer, framelinacc, frameangacc): one more launch between solver and integrator */
   const int* sensor_type; const int* sensor_datatype; const int* sensor_objtype; const int* sensor_objid; const int* sensor_reftype; const int* sensor_refid;
   const int* sensor_dim; const int* sensor_adr;
@@ -223,7 +225,7 @@ typedef struct MjhData {
   /* velocity-dependent */
   float* actuator_velocity; float* cvel; float* cdof_dot;
   float* qfrc_spring; float* qfrc_damper; float* qfrc_gravcomp; float* qfrc_passive; float* qfrc_bias;
-  float* cacc; float* cfrc_int;
+  float* cacc; float* cfrc_int; float* cfrc_ext; /* cfrc_ext [nworld, nbody, 6]: smooth.rne_postconstraint (which also rewrites cacc / cfrc_int) */
   /* actuation / acceleration */
   float* act_dot; float* actuator_force; float* qfrc_actuator; float* qfrc_smooth; float* qacc_smooth;
   /* constraint solver outputs */
@@ -333,7 +335,7 @@ int mjh_timed_steps(const MjhModel* m, const MjhData* d, int nstep, int step0, f
 int mjh_release_thread_resources(void);
 
 const char* mjh_last_error(void);
-#define MJH_ABI_VERSION 25
+#define MJH_ABI_VERSION 26
 int mjh_abi_version(void); /* returns MJH_ABI_VERSION of the library that was loaded */
 
 #ifdef __cplusplus

@@ -119,6 +119,10 @@ static int launch_sensor(const MjhModel* m, const MjhData* d, int stage, hipStre
     hipLaunchKernelGGL(k_energy, dim3((d->nworld + 63) / 64), dim3(64), 0, s, *m, *d);
   }
   if (m->nsensor == 0 || (m->disableflags & DSBL_SENSOR) || (stage == 1 && m->nsensor_acc == 0)) return MJH_OK;
+  if (stage == 1 && m->nsensor_frc > 0) {
+    if (!d->cfrc_ext) return fail(MJH_E_ARG, "Data.cfrc_ext missing");
+    hipLaunchKernelGGL(k_rne_postconstraint, dim3((d->nworld + 63) / 64), dim3(64), 0, s, *m, *d);
+  }
   if (stage == 0 && m->nsensor_subtree > 0) {
     if (!d->subtree_linvel || !d->subtree_angmom) return fail(MJH_E_ARG, "Data.subtree_linvel / subtree_angmom missing");
     hipLaunchKernelGGL(k_subtree_vel, dim3((d->nworld + 63) / 64), dim3(64), 0, s, *m, *d);
@@ -496,6 +500,12 @@ static int run_stage(const MjhModel* m, const MjhData* d, int stage, hipStream_t
       { Scope sc(K_CONSTRAINT); TRY(launch_constraint(m, d, s)); }
       { Scope sc(K_OTHER); TRY(launch_publish(d, s)); }
       return MJH_OK;
+    case MJH_STAGE_RNE_POSTCONSTRAINT: {
+      if (!d->cfrc_ext) return fail(MJH_E_ARG, "Data.cfrc_ext missing");
+      Scope sc(K_OTHER);
+      hipLaunchKernelGGL(k_rne_postconstraint, dim3((d->nworld + 63) / 64), dim3(64), 0, s, *m, *d);
+      return MJH_OK;
+    }
     case MJH_STAGE_SUBTREE_VEL: {
       if (!d->subtree_linvel || !d->subtree_angmom) return fail(MJH_E_ARG, "Data.subtree_linvel / subtree_angmom missing");
       Scope sc(K_OTHER);

@@ -8,7 +8,7 @@
 #pragma once
 #include "dev_common.hpp"
 
-enum { SENS_ACCELEROMETER = 1, SENS_VELOCIMETER = 2, SENS_GYRO = 3, SENS_JOINTPOS = 9, SENS_JOINTVEL = 10, SENS_ACTUATORPOS = 13, SENS_ACTUATORVEL = 14, SENS_ACTUATORFRC = 15,
+enum { SENS_ACCELEROMETER = 1, SENS_FORCE = 4, SENS_TORQUE = 5, SENS_VELOCIMETER = 2, SENS_GYRO = 3, SENS_JOINTPOS = 9, SENS_JOINTVEL = 10, SENS_ACTUATORPOS = 13, SENS_ACTUATORVEL = 14, SENS_ACTUATORFRC = 15,
        SENS_BALLQUAT = 18, SENS_BALLANGVEL = 19, SENS_FRAMEPOS = 26, SENS_FRAMEQUAT = 27, SENS_FRAMEXAXIS = 28, SENS_FRAMEYAXIS = 29, SENS_FRAMEZAXIS = 30,
        SENS_FRAMELINVEL = 31, SENS_FRAMEANGVEL = 32, SENS_FRAMELINACC = 33, SENS_FRAMEANGACC = 34, SENS_SUBTREECOM = 35, SENS_SUBTREELINVEL = 36, SENS_SUBTREEANGMOM = 37, SENS_CLOCK = 45 };
 enum { OBJ_BODY = 1, OBJ_XBODY = 2, OBJ_GEOM = 5, OBJ_SITE = 6 };
@@ -80,7 +80,7 @@ __global__ void __launch_bounds__(256) k_sensor(MjhModel m, MjhData d, int stage
   if (idx >= d.nworld * ns) return;
   const int w = idx / ns, i = idx - w * ns;
   const int t = m.sensor_type[i], id = m.sensor_objid[i], ot = m.sensor_objtype[i], rid = m.sensor_refid[i], rt = m.sensor_reftype[i];
-  const bool acc_type = t == SENS_ACCELEROMETER || t == SENS_FRAMELINACC || t == SENS_FRAMEANGACC;
+  const bool acc_type = t == SENS_ACCELEROMETER || t == SENS_FRAMELINACC || t == SENS_FRAMEANGACC || t == SENS_FORCE || t == SENS_TORQUE;
   if (acc_type != (stage == 1)) return;
   float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   auto put3 = [&](V3 a) {
@@ -139,7 +139,15 @@ __global__ void __launch_bounds__(256) k_sensor(MjhModel m, MjhData d, int stage
       else put3(matT_mul(r.mat, ang - rang));
     }
   }
-  else if (acc_type) {  // sensor.py:1510-1539, 1678-1753
+  else if (t == SENS_FORCE || t == SENS_TORQUE) {  // sensor.py:1542-1577: the interaction force / torque at the site's body (k_rne_postconstraint ran just before)
+    const SensFrame f = sens_frame(m, d, w, OBJ_SITE, id);
+    const float* ci = d.cfrc_int + ((size_t)w * m.nbody + f.body) * 6;
+    if (t == SENS_FORCE) put3(matT_mul(f.mat, ld3(ci + 3)));
+    else {
+      const V3 dif = f.pos - ld3(d.subtree_com + ((size_t)w * m.nbody + m.body_rootid[f.body]) * 3);
+      put3(matT_mul(f.mat, ld3(ci) - cross(dif, ld3(ci + 3))));
+    }
+  } else if (acc_type) {  // sensor.py:1510-1539, 1678-1753
     const SensFrame f = sens_frame(m, d, w, t == SENS_ACCELEROMETER ? OBJ_SITE : ot, id);
     V3 aang, alin;
     sens_cacc(m, d, w, f.body, aang, alin);

@@ -4,12 +4,18 @@
 #include "dev_common.hpp"
 
 // support.py:311-397: pyramidal rows decode to normal / friction components; elliptic rows are the components themselves
+DEV void contact_force_of(const MjhModel& m, const MjhData& d, int cid, int to_world_frame, float (&f)[6]);
 __global__ void __launch_bounds__(256) k_contact_force(MjhModel m, MjhData d, const int* contact_ids, int n, int to_world_frame, float* out) {
   const int tid = blockIdx.x * 256 + threadIdx.x;
   if (tid >= n) return;
   const int cid = contact_ids[tid];
   if (cid >= d.nacon[0]) return;
-  float f[6] = {0, 0, 0, 0, 0, 0};
+  float f[6];
+  contact_force_of(m, d, cid, to_world_frame, f);
+  for (int k = 0; k < 6; ++k) out[(size_t)tid * 6 + k] = f[k];
+}
+DEV void contact_force_of(const MjhModel& m, const MjhData& d, int cid, int to_world_frame, float (&f)[6]) {
+  for (int k = 0; k < 6; ++k) f[k] = 0.0f;
   const int w = d.contact_worldid[cid], condim = d.contact_dim[cid], npyr = d.nmaxpyramid;
   const int adr0 = d.contact_efc_address[(size_t)cid * npyr];
   if (cid >= 0 && adr0 >= 0) {
@@ -38,7 +44,6 @@ __global__ void __launch_bounds__(256) k_contact_force(MjhModel m, MjhData d, co
       f[3 + k] = b[0] * R[k] + b[1] * R[3 + k] + b[2] * R[6 + k];
     }
   }
-  for (int k = 0; k < 6; ++k) out[(size_t)tid * 6 + k] = f[k];
 }
 
 // support.py:505-578: column dof of the Jacobians of `point` (world coordinates) moving with body `body[w]`; either output may be null
@@ -146,4 +151,87 @@ __global__ void __launch_bounds__(64) k_subtree_vel(MjhModel m, MjhData d) {
     L = L + cross(ld3(scom + 3 * b) - ld3(scom + 3 * p), (lv - ld3(linvel + 3 * p)) * stm[b]);
     st3(angmom + 3 * p, ld3(angmom + 3 * p) + L);
   }
+}
+
+// smooth.rne_postconstraint (smooth.py:1519-1826): cacc, cfrc_ext, cfrc_int with the constraint forces in.  cfrc_ext = applied Cartesian
+// forces + contact forces moved to the tree's centre of mass (spatial vectors: torque first); cacc from qacc down the tree; cfrc_int =
+// I cacc + v x* (I v) - cfrc_ext, summed towards the root.  One thread per world (equality rows: joint equalities exert no cfrc_ext).
+__global__ void __launch_bounds__(64) k_rne_postconstraint(MjhModel m, MjhData d) {
+  const int w = blockIdx.x * 64 + threadIdx.x, nb = m.nbody;
+  if (w >= d.nworld) return;
+  float* cext = d.cfrc_ext + (size_t)w * nb * 6;
+  float* cint = d.cfrc_int + (size_t)w * nb * 6;
+  float* cacc = d.cacc + (size_t)w * nb * 6;
+  const float* scom = d.subtree_com + (size_t)w * nb * 3;
+  auto add_force = [&](int b, V3 force, V3 torque, V3 offset, float sgn) {  // support.transform_force: (torque - offset x force, force)
+    const V3 t = torque - cross(offset, force);
+    float* c = cext + 6 * b;
+    c[0] += sgn * t.x; c[1] += sgn * t.y; c[2] += sgn * t.z;
+    c[3] += sgn * force.x; c[4] += sgn * force.y; c[5] += sgn * force.z;
+  };
+  for (int b = 0; b < nb; ++b) {
+    for (int k = 0; k < 6; ++k) cext[6 * b + k] = 0.0f;
+    if (b == 0) continue;
+    const float* xf = d.xfrc_applied + ((size_t)w * nb + b) * 6;
+    add_force(b, ld3(xf), ld3(xf + 3), ld3(scom + 3 * m.body_rootid[b]) - ld3(d.xipos + ((size_t)w * nb + b) * 3), 1.0f);
+  }
+  // contacts: from the world's records (collide.hpp; the public contact arrays are published off the critical path and may not be
+  // there yet when the acceleration-stage sensors run); same decoding as k_contact_force
+  const int ncon = min(d.ws_ncon[w], d.concap);
+  const float* efc_force = d.efc_force + (size_t)w * d.njmax;
+  for (int c = 0; c < ncon; ++c) {
+    const float* rec = d.ws_contact + ((size_t)w * d.concap + c) * CON_STRIDE;
+    const int* reci = reinterpret_cast<const int*>(rec);
+    const int b1 = m.geom_bodyid[reci[25]], b2 = m.geom_bodyid[reci[26]], adr0 = reci[28], condim = reci[24];
+    if ((b1 == 0 && b2 == 0) || adr0 < 0) continue;
+    float f[6] = {0, 0, 0, 0, 0, 0};
+    if (m.cone == CONE_PYRAMIDAL) {
+      if (condim == 1) f[0] = adr0 < d.njmax ? efc_force[adr0] : 0.0f;
+      else
+        for (int i = 0; i < condim - 1; ++i) {
+          const int a = adr0 + 2 * i;
+          const float d1 = a < d.njmax ? efc_force[a] : 0.0f, d2 = a + 1 < d.njmax ? efc_force[a + 1] : 0.0f;
+          f[0] += d1 + d2;
+          f[i + 1] = (d1 - d2) * rec[i < 2 ? 14 : (i == 2 ? 15 : 16)];
+        }
+    } else {
+      for (int i = 0; i < condim; ++i)
+        if (adr0 + i < d.njmax) f[i] = efc_force[adr0 + i];
+    }
+    const float* R = rec + 4;  // contact frame rows: normal, tangent 1, tangent 2
+    const V3 force = V3{f[0] * R[0] + f[1] * R[3] + f[2] * R[6], f[0] * R[1] + f[1] * R[4] + f[2] * R[7], f[0] * R[2] + f[1] * R[5] + f[2] * R[8]};
+    const V3 torque = V3{f[3] * R[0] + f[4] * R[3] + f[5] * R[6], f[3] * R[1] + f[4] * R[4] + f[5] * R[7], f[3] * R[2] + f[4] * R[5] + f[5] * R[8]};
+    const V3 pos = ld3(rec + 1);
+    if (b1) add_force(b1, force, torque, ld3(scom + 3 * m.body_rootid[b1]) - pos, -1.0f);
+    if (b2) add_force(b2, force, torque, ld3(scom + 3 * m.body_rootid[b2]) - pos, 1.0f);
+  }
+  const V3 g = ld3(bf(m.opt_gravity, m.opt_gravity_nb, w, 3));
+  const float* qvel = d.qvel + (size_t)w * m.nv;
+  const float* qacc = d.qacc + (size_t)w * m.nv;
+  for (int b = 0; b < nb; ++b) {
+    float a[6] = {0, 0, 0, 0, 0, 0};
+    if (b == 0) {
+      if (!(m.disableflags & DSBL_GRAVITY)) { a[3] = -g.x; a[4] = -g.y; a[5] = -g.z; }
+    } else {
+      for (int k = 0; k < 6; ++k) a[k] = cacc[6 * m.body_parentid[b] + k];
+      for (int j = 0; j < m.body_dofnum[b]; ++j) {
+        const int dof = m.body_dofadr[b] + j;
+        const float* cd = d.cdof + ((size_t)w * m.nv + dof) * 6;
+        const float* cdd = d.cdof_dot + ((size_t)w * m.nv + dof) * 6;
+        for (int k = 0; k < 6; ++k) a[k] += cdd[k] * qvel[dof] + cd[k] * qacc[dof];
+      }
+    }
+    for (int k = 0; k < 6; ++k) cacc[6 * b + k] = a[k];
+    float f1[6] = {0, 0, 0, 0, 0, 0}, iv[6], f2[6] = {0, 0, 0, 0, 0, 0};
+    if (b > 0) {
+      const float* ci = d.cinert + ((size_t)w * nb + b) * 10;
+      const float* cv = d.cvel + ((size_t)w * nb + b) * 6;
+      inert_vec(ci, a, f1);
+      inert_vec(ci, cv, iv);
+      motion_cross_force(cv, iv, f2);
+    }
+    for (int k = 0; k < 6; ++k) cint[6 * b + k] = b ? f1[k] + f2[k] - cext[6 * b + k] : 0.0f;
+  }
+  for (int b = nb - 1; b > 0; --b)
+    for (int k = 0; k < 6; ++k) cint[6 * m.body_parentid[b] + k] += cint[6 * b + k];
 }

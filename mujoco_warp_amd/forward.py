@@ -224,6 +224,12 @@ def jac(m, d, jacp: Optional[DeviceArray], jacr: Optional[DeviceArray], point: D
                        jacr.ptr if jacr is not None else None, point.ptr, body.ptr, _stream()))
 
 
+def rne_postconstraint(m, d):
+  """Data.cacc / cfrc_int / cfrc_ext with the constraint forces in (reference smooth.rne_postconstraint, smooth.py:1744); call after the
+  solver.  `forward` runs it when a force / torque sensor reads the result."""
+  _run(_S["MJH_STAGE_RNE_POSTCONSTRAINT"], m, d)
+
+
 def subtree_vel(m, d):
   """Data.subtree_linvel / subtree_angmom: velocity of every subtree's centre of mass and its angular momentum about it (reference
   smooth.subtree_vel, smooth.py:3614); call after fwd_velocity.  `forward` runs it when a sensor reads the result."""

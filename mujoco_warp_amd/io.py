@@ -380,7 +380,8 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
   )
   m.nsensor, m.nsensordata = int(host["sensor_type"].shape[0]), int(getattr(mjm, "nsensordata", 0))
   supported_sensors = set(mjcf_SENS.values())
-  m.nsensor_acc = int(sum(int(t) in (1, 33, 34) for t in host["sensor_type"]))
+  m.nsensor_acc = int(sum(int(t) in (1, 4, 5, 33, 34) for t in host["sensor_type"]))
+  m.nsensor_frc = int(sum(int(t) in (4, 5) for t in host["sensor_type"]))
   m.nsensor_subtree = int(sum(int(t) in (36, 37) for t in host["sensor_type"]))
   bad = [int(t) for t in host["sensor_type"] if int(t) not in supported_sensors]
   if bad:  # (sensors do not enter the dynamics: the model still loads, their sensordata slots stay zero)
@@ -533,7 +534,7 @@ def _data_shapes(m, nworld, nconmax, njmax, naconmax):
     tree_asleep=(W, m.ntree), tree_awake=(W, m.ntree), body_awake=(W, nb), body_awake_ind=(W, nb), dof_awake_ind=(W, nv), ntree_awake=(W,), nbody_awake=(W,),
     nv_awake=(W,), tree_island=(W, m.ntree), nisland=(W,), ws_sleep_J=(W if m.sleep_enabled else 0, njmax_pad, nv_pad), ws_sleep_warm=(W if m.sleep_enabled else 0, nv),
     ws_sleep_flag=(W,),
-    sensordata=(W, m.nsensordata), energy=(W, 2), subtree_linvel=(W, nb, 3), subtree_angmom=(W, nb, 3), eq_active=(W, m.neq), ws_rk=(W, nq + 3 * nv + 2 * na), ws_contact=(W, contact_cap(nconmax), 32),
+    sensordata=(W, m.nsensordata), energy=(W, 2), subtree_linvel=(W, nb, 3), subtree_angmom=(W, nb, 3), cfrc_ext=(W, nb, 6), eq_active=(W, m.neq), ws_rk=(W, nq + 3 * nv + 2 * na), ws_contact=(W, contact_cap(nconmax), 32),
   )
   return sh, njmax_pad, nv_pad
 

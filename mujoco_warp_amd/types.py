@@ -443,6 +443,7 @@ class Model(_Dirty):
   nsensordata: int = 0
   nsensor_acc: int = 0
   nsensor_subtree: int = 0
+  nsensor_frc: int = 0
   sensor_type: DeviceArray = _arr(('nsensor',), "int32")
   sensor_datatype: DeviceArray = _arr(('nsensor',), "int32")
   sensor_objtype: DeviceArray = _arr(('nsensor',), "int32")
@@ -601,6 +602,7 @@ class Data(_Dirty):
   energy: DeviceArray = _arr(('nworld', 2), "float32")
   subtree_linvel: DeviceArray = _arr(('nworld', 'nbody', 3), "float32")
   subtree_angmom: DeviceArray = _arr(('nworld', 'nbody', 3), "float32")
+  cfrc_ext: DeviceArray = _arr(('nworld', 'nbody', 6), "float32")
   tree_asleep: DeviceArray = _arr(('nworld', 'ntree'), "int32")  # reference types.py:2330-2345
   tree_awake: DeviceArray = _arr(('nworld', 'ntree'), "int32")
   body_awake: DeviceArray = _arr(('nworld', 'nbody'), "int32")

@@ -2788,7 +2788,7 @@ void ref_sleep(const RefModel* m, RefData* d) { /* sleep.py:824-999 */
 }
 
 /* ================================================================ sensors (sensor.py, subset) */
-enum { SENS_ACCELEROMETER = 1, SENS_FRAMELINACC = 33, SENS_FRAMEANGACC = 34, SENS_VELOCIMETER = 2, SENS_GYRO = 3, SENS_JOINTPOS = 9, SENS_JOINTVEL = 10, SENS_ACTUATORPOS = 13, SENS_ACTUATORVEL = 14, SENS_ACTUATORFRC = 15,
+enum { SENS_ACCELEROMETER = 1, SENS_FORCE = 4, SENS_TORQUE = 5, SENS_FRAMELINACC = 33, SENS_FRAMEANGACC = 34, SENS_VELOCIMETER = 2, SENS_GYRO = 3, SENS_JOINTPOS = 9, SENS_JOINTVEL = 10, SENS_ACTUATORPOS = 13, SENS_ACTUATORVEL = 14, SENS_ACTUATORFRC = 15,
        SENS_BALLQUAT = 18, SENS_BALLANGVEL = 19, SENS_FRAMEPOS = 26, SENS_FRAMEQUAT = 27, SENS_FRAMEXAXIS = 28, SENS_FRAMEYAXIS = 29, SENS_FRAMEZAXIS = 30,
        SENS_FRAMELINVEL = 31, SENS_FRAMEANGVEL = 32, SENS_SUBTREECOM = 35, SENS_SUBTREELINVEL = 36, SENS_SUBTREEANGMOM = 37, SENS_CLOCK = 45 };
 enum { OBJ_BODY = 1, OBJ_XBODY = 2, OBJ_GEOM = 5, OBJ_SITE = 6 };
@@ -2845,6 +2845,73 @@ static void sensor_write(const RefModel* m, RefData* d, int i, const double* v) 
     d->sensordata[adr + k] = x;
   }
 }
+/* smooth.py:1519-1826 rne_postconstraint: cacc, cfrc_ext, cfrc_int with the constraint forces in (spatial vectors: torque first).
+   Joint equalities -- the only equality type on this path -- put nothing into cfrc_ext (only connect / weld do, smooth.py:1570). */
+void ref_rne_postconstraint(const RefModel* m, RefData* d) {
+  int nb = m->nbody, nefc = d->nefc < m->njmax ? d->nefc : m->njmax;
+  for (int k = 0; k < 6 * nb; k++) d->cfrc_ext[k] = 0.0;
+  for (int b = 1; b < nb; b++) { /* support.transform_force(xfrc_applied, subtree_com - xipos) */
+    const double* xf = d->xfrc_applied + 6 * b;
+    double off[3], c[3];
+    v3sub(off, d->subtree_com + 3 * m->body_rootid[b], d->xipos + 3 * b);
+    v3cross(c, off, xf);
+    for (int k = 0; k < 3; k++) { d->cfrc_ext[6 * b + k] = xf[3 + k] - c[k]; d->cfrc_ext[6 * b + 3 + k] = xf[k]; }
+  }
+  for (int ci = 0; ci < d->ncon; ci++) { /* _cfrc_ext_contact with support.contact_force_fn (support.py:311-397) */
+    int b1 = m->geom_bodyid[d->con_geom[2 * ci]], b2 = m->geom_bodyid[d->con_geom[2 * ci + 1]], adr0 = d->con_efc_address[10 * ci], condim = d->con_dim[ci];
+    if ((b1 == 0 && b2 == 0) || adr0 < 0) continue;
+    double f[6] = {0, 0, 0, 0, 0, 0};
+    if (m->cone == 0) {
+      if (condim == 1) f[0] = adr0 < nefc ? d->efc_force[adr0] : 0.0;
+      else
+        for (int i = 0; i < condim - 1; i++) {
+          int a = adr0 + 2 * i;
+          double d1 = a < m->njmax ? d->efc_force[a] : 0.0, d2 = a + 1 < m->njmax ? d->efc_force[a + 1] : 0.0;
+          f[0] += d1 + d2;
+          f[i + 1] = (d1 - d2) * d->con_friction[5 * ci + i];
+        }
+    } else {
+      for (int i = 0; i < condim; i++)
+        if (adr0 + i < m->njmax) f[i] = d->efc_force[adr0 + i];
+    }
+    const double* R = d->con_frame + 9 * ci;
+    double force[3], torque[3];
+    for (int k = 0; k < 3; k++) {
+      force[k] = f[0] * R[k] + f[1] * R[3 + k] + f[2] * R[6 + k];
+      torque[k] = f[3] * R[k] + f[4] * R[3 + k] + f[5] * R[6 + k];
+    }
+    for (int side = 0; side < 2; side++) {
+      int b = side ? b2 : b1;
+      if (!b) continue;
+      double off[3], c[3], sg = side ? 1.0 : -1.0;
+      v3sub(off, d->subtree_com + 3 * m->body_rootid[b], d->con_pos + 3 * ci);
+      v3cross(c, off, force);
+      for (int k = 0; k < 3; k++) { d->cfrc_ext[6 * b + k] += sg * (torque[k] - c[k]); d->cfrc_ext[6 * b + 3 + k] += sg * force[k]; }
+    }
+  }
+  for (int b = 0; b < nb; b++) {
+    double* a = d->cacc + 6 * b;
+    if (b == 0) {
+      for (int k = 0; k < 6; k++) a[k] = 0.0;
+      if (!(m->disableflags & DSBL_GRAVITY))
+        for (int k = 0; k < 3; k++) a[3 + k] = -m->gravity[k];
+      for (int k = 0; k < 6; k++) d->cfrc_int[k] = 0.0;
+      continue;
+    }
+    memcpy(a, d->cacc + 6 * m->body_parentid[b], 6 * sizeof(double));
+    for (int j = 0; j < m->body_dofnum[b]; j++) {
+      int dof = m->body_dofadr[b] + j;
+      for (int k = 0; k < 6; k++) a[k] += d->cdof_dot[6 * dof + k] * d->qvel[dof] + d->cdof[6 * dof + k] * d->qacc[dof];
+    }
+    double f1[6], iv[6], f2[6];
+    inert_vec(f1, d->cinert + 10 * b, a);
+    inert_vec(iv, d->cinert + 10 * b, d->cvel + 6 * b);
+    motion_cross_force(f2, d->cvel + 6 * b, iv);
+    for (int k = 0; k < 6; k++) d->cfrc_int[6 * b + k] = f1[k] + f2[k] - d->cfrc_ext[6 * b + k];
+  }
+  for (int b = nb - 1; b > 0; b--)
+    for (int k = 0; k < 6; k++) d->cfrc_int[6 * m->body_parentid[b] + k] += d->cfrc_int[6 * b + k];
+}
 /* acceleration of a body's frame at the tree's centre of mass: smooth.py:1354-1426 (rne_postconstraint's cacc, flg_acc) */
 static void body_cacc(const RefModel* m, const RefData* d, int body, double* cacc) {
   for (int k = 0; k < 6; k++) cacc[k] = 0.0;
@@ -2894,11 +2961,15 @@ void ref_subtree_vel(const RefModel* m, RefData* d) {
 /* stage 0: position / velocity stage sensors and actuator forces; stage 1: acceleration stage (accelerometer, frame accelerations) */
 static void sensor_stage(const RefModel* m, RefData* d, int stage) {
   if (m->disableflags & (1 << 13)) return; /* DisableBit.SENSOR */
+  if (stage == 1)
+    for (int i = 0; i < m->nsensor; i++)
+      if (m->sensor_type[i] == SENS_FORCE || m->sensor_type[i] == SENS_TORQUE) { ref_rne_postconstraint(m, d); break; }
   if (stage == 0)
     for (int i = 0; i < m->nsensor; i++)
       if (m->sensor_type[i] == SENS_SUBTREELINVEL || m->sensor_type[i] == SENS_SUBTREEANGMOM) { ref_subtree_vel(m, d); break; }
   for (int i = 0; i < m->nsensor; i++) {
-    int acc_type = m->sensor_type[i] == SENS_ACCELEROMETER || m->sensor_type[i] == SENS_FRAMELINACC || m->sensor_type[i] == SENS_FRAMEANGACC;
+    int acc_type = m->sensor_type[i] == SENS_ACCELEROMETER || m->sensor_type[i] == SENS_FRAMELINACC || m->sensor_type[i] == SENS_FRAMEANGACC ||
+                   m->sensor_type[i] == SENS_FORCE || m->sensor_type[i] == SENS_TORQUE;
     if (acc_type != (stage == 1)) continue;
     int t = m->sensor_type[i], id = m->sensor_objid[i], ot = m->sensor_objtype[i], rid = m->sensor_refid[i], rt = m->sensor_reftype[i];
     double v[4] = {0, 0, 0, 0}, pos[3], mat[9], q[4], rpos[3], rmat[9], rq[4], dif[3];
@@ -2965,7 +3036,18 @@ static void sensor_stage(const RefModel* m, RefData* d, int stage) {
         }
       }
     }
-    else if (acc_type) { /* sensor.py:1510-1539, 1678-1753 */
+    else if (t == SENS_FORCE || t == SENS_TORQUE) { /* sensor.py:1542-1577 */
+      int body = frame_of(m, d, OBJ_SITE, id, pos, mat, NULL);
+      const double* ci = d->cfrc_int + 6 * body;
+      if (t == SENS_FORCE) matT_mul_vec(v, mat, ci + 3);
+      else {
+        double c[3], tq[3];
+        v3sub(dif, pos, d->subtree_com + 3 * m->body_rootid[body]);
+        v3cross(c, dif, ci + 3);
+        v3sub(tq, ci, c);
+        matT_mul_vec(v, mat, tq);
+      }
+    } else if (acc_type) { /* sensor.py:1510-1539, 1678-1753 */
       int fot = t == SENS_ACCELEROMETER ? OBJ_SITE : ot;
       double cacc[6], lin[3], ang[3], off[3], c1[3], c2[3], a[3];
       int body = frame_of(m, d, fot, id, pos, mat, NULL);

@@ -231,6 +231,7 @@ typedef struct RefData {
   double* qfrc_bias;
   double* cacc;
   double* cfrc_int;
+  double* cfrc_ext;
   double* actuator_length;
   double* actuator_velocity;
   double* actuator_force;
@@ -297,6 +298,7 @@ void ref_implicitfast(const RefModel* m, RefData* d);
 void ref_rungekutta4(const RefModel* m, RefData* d); /* forward.py:524; call after ref_forward */
 void ref_step(const RefModel* m, RefData* d);
 void ref_subtree_vel(const RefModel* m, RefData* d); /* smooth.py:3614 */
+void ref_rne_postconstraint(const RefModel* m, RefData* d); /* smooth.py:1744; call after ref_solve */
 void ref_sensor(const RefModel* m, RefData* d); /* sensor.py sensor_pos / sensor_vel / sensor_acc, the subset in oracle/mjref.c; called by ref_forward */
 /* sleep.py / island.py:28-310 (tree-level constraint islands, sleeping, waking) */
 void ref_update_sleep(const RefModel* m, RefData* d);

@@ -171,7 +171,7 @@ _SIZES = {
   "efc_type": "njmax", "efc_id": "njmax", "efc_state": "njmax", "efc_J": ("njmax", "nv"), "efc_pos": "njmax",
   "efc_margin": "njmax", "efc_D": "njmax", "efc_vel": "njmax", "efc_aref": "njmax", "efc_frictionloss": "njmax",
   "efc_force": "njmax", "tree_asleep": "ntree", "tree_awake": "ntree", "body_awake": "nbody", "tree_island": "ntree",
-  "body_awake_ind": "nbody", "dof_awake_ind": "nv", "sensordata": "nsensordata", "subtree_linvel": ("nbody", 3), "subtree_angmom": ("nbody", 3),
+  "body_awake_ind": "nbody", "dof_awake_ind": "nv", "sensordata": "nsensordata", "subtree_linvel": ("nbody", 3), "subtree_angmom": ("nbody", 3), "cfrc_ext": ("nbody", 6),
 }
 MJ_MINAWAKE = 10  # mjMINAWAKE (reference types.py:29)
 

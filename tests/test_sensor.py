@@ -185,3 +185,77 @@ def test_gpu_sensors_vs_oracle():
   d.sensordata.zero_()
   mjw.sensor(m, d)
   assert (d.sensordata.numpy() == a).all() and np.abs(a).max() > 0
+
+
+FORCE_XML = """
+<mujoco>
+  <option timestep="0.002"/>
+  <worldbody>
+    <geom type="plane" size="5 5 .1"/>
+    <body name="pend" pos="0 0 2">
+      <joint name="hinge" type="hinge" axis="0 1 0"/><geom type="capsule" fromto="0 0 0 0 0 -.5" size=".03" mass="1.5"/>
+      <site name="root" pos="0 0 0" euler="0 0 40"/>
+      <body name="bob" pos="0 0 -.5"><geom type="sphere" size=".06" mass="0.7"/><site name="neck" pos="0 0 0"/></body>
+    </body>
+    <body name="slab" pos="1 0 .0495"><freejoint/><geom type="box" size=".2 .2 .05" mass="3"/><site name="slab_s" pos="0 0 0"/>
+      <body name="load" pos="0 .05 .1"><geom type="sphere" size=".05" mass="0.4" contype="0" conaffinity="0"/><site name="load_s" pos="0 0 0" euler="30 0 0"/></body>
+    </body>
+  </worldbody>
+  <sensor>
+    <force name="f_root" site="root"/><torque name="t_root" site="root"/><force name="f_neck" site="neck"/>
+    <force name="f_slab" site="slab_s"/><force name="f_load" site="load_s"/><torque name="t_load" site="load_s"/>
+  </sensor>
+</mujoco>
+"""
+
+
+def _force_expectations(mjm, g):
+  g9 = 9.81
+  R_root = nm.quat_to_mat(mjm.site_quat[mjm.sensor_objid[mjm.sensor_names.index("f_root")]])
+  return {"f_root": R_root.T @ np.array([0, 0, (1.5 + 0.7) * g9]), "t_root": np.zeros(3), "f_neck": np.array([0, 0, 0.7 * g9]), "f_slab": np.zeros(3)}
+
+
+def test_oracle_force_torque_statics():
+  """rne_postconstraint + force / torque sensors on static configurations: a hanging pendulum's joint carries the weight below it, a bob
+  fixed to it is held by its own weight, a slab resting on the floor needs nothing from its free joint (contact forces balance its
+  weight and its load's), the load fixed on the slab is held by its weight and no torque about its own centre."""
+  mjm = mjw.mjcf.from_xml_string(FORCE_XML)
+  s = ref.RefSim(mjm, nconmax=16, njmax=64)
+  for _ in range(400):
+    s.step()
+  s.forward()
+  g = lambda n: _read(mjm, s.sensordata, n)
+  for name, want in _force_expectations(mjm, g).items():
+    assert np.allclose(g(name), want, atol=2e-3), (name, g(name), want)
+  R_load = nm.quat_to_mat(nm.quat_mul(s.xquat[4], mjm.site_quat[mjm.sensor_objid[mjm.sensor_names.index("f_load")]]))
+  assert np.allclose(g("f_load"), R_load.T @ np.array([0, 0, 0.4 * 9.81]), atol=2e-3) and np.allclose(g("t_load"), 0, atol=2e-3)
+  # the bodies' external forces: the slab's contacts carry slab + load
+  assert abs(s.cfrc_ext[3][5] - (3 + 0.4) * 9.81) < 5e-3
+
+
+@pytest.mark.gpu
+def test_gpu_force_torque_vs_oracle():
+  mjm = mjw.mjcf.from_xml_string(FORCE_XML)
+  m = mjw.put_model(mjm)
+  assert m.nsensor_frc == 6 and m.nsensor_acc == 6
+  d = mjw.make_data(mjm, nworld=2, nconmax=16, njmax=64)
+  q = d.qpos.numpy()
+  q[1, 0] = 0.6  # world 1: the pendulum swings
+  d.qpos.assign(q)
+  sims = [ref.RefSim(mjm, nconmax=16, njmax=64) for _ in range(2)]
+  for step in range(150):
+    for w, s in enumerate(sims):
+      s.qpos[:], s.qvel[:], s.qacc_warmstart[:] = d.qpos.numpy()[w], d.qvel.numpy()[w], d.qacc_warmstart.numpy()[w]
+    mjw.step(m, d)
+    sd = d.sensordata.numpy()
+    for w, s in enumerate(sims):
+      s.step()
+      assert np.abs(sd[w] - s.sensordata).max() < 5e-3, (step, w, sd[w], s.sensordata)  # forces of ~20 N from float32 accelerations
+  mjw.forward(m, d)
+  mjw.rne_postconstraint(m, d)
+  for w, s in enumerate(sims):
+    s.qpos[:], s.qvel[:], s.qacc_warmstart[:] = d.qpos.numpy()[w], d.qvel.numpy()[w], d.qacc_warmstart.numpy()[w]
+    s.forward()
+    s._call("rne_postconstraint")
+    for f in ("cacc", "cfrc_int", "cfrc_ext"):
+      assert np.abs(getattr(d, f).numpy()[w] - getattr(s, f)).max() < 1e-2, f
