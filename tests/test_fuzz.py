@@ -1,5 +1,6 @@
 """Randomised-model parity (40 + 12 PGS + 16 extra-collider + 16 convex-pair seeds by default; MJH_FUZZ_SEEDS / MJH_FUZZ_PGS_SEEDS /
-MJH_FUZZ_COLLIDER_SEEDS / MJH_FUZZ_CONVEX_SEEDS for more: 480 + 160 + 320 were run clean; of 320 convex-pair seeds -- box pairs included,
+MJH_FUZZ_COLLIDER_SEEDS / MJH_FUZZ_CONVEX_SEEDS for more.  Last full sweep (final round-2 code): 480 + 160 clean; of 320 extra-collider seeds 318 pass and 2
+(262, 315: box-box pairs, which run CCD + multi-contact by default) exceed the bounds through the same face-alignment decision as below; of 320 convex-pair seeds -- box pairs included,
 through CCD + multi-contact -- 313 pass, 3 skip on the mass-matrix condition and 4 (46, 242, 275, 315) exceed the per-step bounds by EPA
 facet noise or a face-alignment decision at its 1.6 mrad threshold: qpos 3e-5 .. 2.3e-3; + 16 random-convex-mesh seeds, MJH_FUZZ_MESH_SEEDS: 200 run, 182 pass, 18 skip on the row budget): random kinematic trees with mixed joint / geom / actuator types against the float64 oracle.
 
