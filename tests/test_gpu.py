@@ -1183,3 +1183,30 @@ def test_step1_step2_and_rungekutta4_stage(integrator):
   np.testing.assert_allclose(db.qpos.numpy(), da.qpos.numpy(), rtol=0, atol=2e-6)
   np.testing.assert_allclose(db.qvel.numpy(), da.qvel.numpy(), rtol=0, atol=2e-4)
   assert hasattr(mjw, "fwd_kinematics") and mjw.ObjType.SITE == 6
+
+
+def test_graph_replay_with_sleep_sensors_and_energy():
+  """hipGraph capture of the staged paths: a sleep-enabled model (bookkeeping kernels, two collision passes, masked solve), a model with
+  position / velocity / acceleration / force sensors and subtree momenta, and EnableBit.ENERGY replay bit for bit."""
+  from tests import test_sensor, test_sleep
+
+  energy_xml = test_sensor.FORCE_XML.replace('<option timestep="0.002"/>', '<option timestep="0.002"><flag energy="enable"/></option>')
+  energy_xml = energy_xml.replace("</sensor>", '<accelerometer site="neck"/><subtreeangmom body="pend"/><gyro site="root"/></sensor>')
+  for xml, nconmax, njmax in ((test_sleep.PILE_XML, 48, 160), (energy_xml, 16, 64)):
+    mjm = mjw.mjcf.from_xml_string(xml)
+    m = mjw.put_model(mjm)
+    da = mjw.make_data(mjm, nworld=8, nconmax=nconmax, njmax=njmax)
+    db = mjw.make_data(mjm, nworld=8, nconmax=nconmax, njmax=njmax)
+    for d in (da, db):
+      v = d.qvel.numpy()
+      v[:, 0] = np.linspace(0.1, 2.0, 8)
+      d.qvel.assign(v)
+    graph = mjw.StepGraph(m, db)
+    for _ in range(60):
+      mjw.step(m, da)
+      graph.launch()
+    torch.cuda.synchronize()
+    for f in ("qpos", "qvel", "sensordata", "energy", "tree_asleep", "body_awake"):
+      a, b = getattr(da, f).numpy(), getattr(db, f).numpy()
+      assert (a == b).all(), f
+    assert mjm.nsensor == 0 or np.abs(da.sensordata.numpy()).max() > 0
