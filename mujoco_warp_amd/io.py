@@ -697,6 +697,8 @@ def get_data_into(result, mjm, d: types.Data, world_id: int = 0):
   result.solver_niter = np.array([int(d.solver_niter.numpy()[w])])
   for name in ("tree_asleep", "tree_awake", "body_awake"):  # reference io.py:2409-2412
     setattr(result, name, getattr(d, name).numpy()[w].copy())
+  result.sensordata = d.sensordata.numpy()[w].astype(np.float64)  # reference io.py: sensordata / energy
+  result.energy = d.energy.numpy()[w].astype(np.float64)
 
 
 def _state_fields(m, d, sig):

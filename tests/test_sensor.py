@@ -178,6 +178,12 @@ def test_gpu_sensors_vs_oracle():
         k = mjm.sensor_names.index(name)
         tol[mjm.sensor_adr[k] : mjm.sensor_adr[k] + 3] = 1e-3
       assert (err <= tol).all(), (step, w, mjm.sensor_names[int(np.searchsorted(mjm.sensor_adr, int(err.argmax()), side="right")) - 1])
+  class Host:
+    pass
+
+  res = Host()
+  mjw.get_data_into(res, mjm, d, world_id=1)
+  assert (res.sensordata == d.sensordata.numpy()[1]).all() and res.energy.shape == (2,)
   # the stage entry point recomputes from the current state
   d.sensordata.zero_()
   mjw.forward(m, d)
