@@ -149,6 +149,7 @@ typedef struct MjhModel {
   /* sensors (types.py: sensor_*; csrc/sensor.hpp computes joint / actuator / ball / frame / velocimeter / gyro / subtreecom / clock) */
   int nsensor; int nsensordata;
   int nsensor_subtree; /* subtreelinvel / subtreeangmom sensors: smooth.subtree_vel runs before the sensor launch */
+  int nsensor_energy; /* e_potential / e_kinetic sensors: the energy kernel runs even without EnableBit.ENERGY */
   int nsensor_frc;  /* force / torque sensors: smooth.rne_postconstraint runs before the acceleration-stage sensor launch */
   int nsensor_acc;  /* sensors of the acceleration stage (accelerometer, framelinacc, frameangacc): one more launch between solver and integrator */
   const int* sensor_type; const int* sensor_datatype; const int* sensor_objtype; const int* sensor_objid; const int* sensor_reftype; const int* sensor_refid;
@@ -335,7 +336,7 @@ int mjh_timed_steps(const MjhModel* m, const MjhData* d, int nstep, int step0, f
 int mjh_release_thread_resources(void);
 
 const char* mjh_last_error(void);
-#define MJH_ABI_VERSION 26
+#define MJH_ABI_VERSION 27
 int mjh_abi_version(void); /* returns MJH_ABI_VERSION of the library that was loaded */
 
 #ifdef __cplusplus

@@ -114,7 +114,7 @@ static int launch_constraint(const MjhModel* m, const MjhData* d, hipStream_t s)
   return MJH_OK;
 }
 static int launch_sensor(const MjhModel* m, const MjhData* d, int stage, hipStream_t s) {  // stage 1: acceleration-stage sensors (after the solver)
-  if (stage == 0 && (m->enableflags & ENBL_ENERGY)) {  // Data.energy rides with the position / velocity stage sensors (forward.py:1326-1338)
+  if (stage == 0 && ((m->enableflags & ENBL_ENERGY) || m->nsensor_energy > 0)) {  // Data.energy rides with the position / velocity stage sensors (forward.py:1326-1338)
     if (!d->energy) return fail(MJH_E_ARG, "Data.energy missing (allocate Data with make_data/put_data)");
     hipLaunchKernelGGL(k_energy, dim3((d->nworld + 63) / 64), dim3(64), 0, s, *m, *d);
   }

@@ -9,8 +9,8 @@
 #include "dev_common.hpp"
 
 enum { SENS_ACCELEROMETER = 1, SENS_FORCE = 4, SENS_TORQUE = 5, SENS_VELOCIMETER = 2, SENS_GYRO = 3, SENS_JOINTPOS = 9, SENS_JOINTVEL = 10, SENS_ACTUATORPOS = 13, SENS_ACTUATORVEL = 14, SENS_ACTUATORFRC = 15,
-       SENS_BALLQUAT = 18, SENS_BALLANGVEL = 19, SENS_FRAMEPOS = 26, SENS_FRAMEQUAT = 27, SENS_FRAMEXAXIS = 28, SENS_FRAMEYAXIS = 29, SENS_FRAMEZAXIS = 30,
-       SENS_FRAMELINVEL = 31, SENS_FRAMEANGVEL = 32, SENS_FRAMELINACC = 33, SENS_FRAMEANGACC = 34, SENS_SUBTREECOM = 35, SENS_SUBTREELINVEL = 36, SENS_SUBTREEANGMOM = 37, SENS_CLOCK = 45 };
+       SENS_JOINTACTFRC = 16, SENS_BALLQUAT = 18, SENS_BALLANGVEL = 19, SENS_JOINTLIMITPOS = 20, SENS_JOINTLIMITVEL = 21, SENS_JOINTLIMITFRC = 22, SENS_FRAMEPOS = 26, SENS_FRAMEQUAT = 27, SENS_FRAMEXAXIS = 28, SENS_FRAMEYAXIS = 29, SENS_FRAMEZAXIS = 30,
+       SENS_FRAMELINVEL = 31, SENS_FRAMEANGVEL = 32, SENS_FRAMELINACC = 33, SENS_FRAMEANGACC = 34, SENS_SUBTREECOM = 35, SENS_SUBTREELINVEL = 36, SENS_SUBTREEANGMOM = 37, SENS_E_POTENTIAL = 43, SENS_E_KINETIC = 44, SENS_CLOCK = 45 };
 enum { OBJ_BODY = 1, OBJ_XBODY = 2, OBJ_GEOM = 5, OBJ_SITE = 6 };
 
 struct SensFrame {
@@ -80,7 +80,7 @@ __global__ void __launch_bounds__(256) k_sensor(MjhModel m, MjhData d, int stage
   if (idx >= d.nworld * ns) return;
   const int w = idx / ns, i = idx - w * ns;
   const int t = m.sensor_type[i], id = m.sensor_objid[i], ot = m.sensor_objtype[i], rid = m.sensor_refid[i], rt = m.sensor_reftype[i];
-  const bool acc_type = t == SENS_ACCELEROMETER || t == SENS_FRAMELINACC || t == SENS_FRAMEANGACC || t == SENS_FORCE || t == SENS_TORQUE;
+  const bool acc_type = t == SENS_ACCELEROMETER || t == SENS_FRAMELINACC || t == SENS_FRAMEANGACC || t == SENS_FORCE || t == SENS_TORQUE || t == SENS_JOINTLIMITFRC;
   if (acc_type != (stage == 1)) return;
   float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   auto put3 = [&](V3 a) {
@@ -93,7 +93,17 @@ __global__ void __launch_bounds__(256) k_sensor(MjhModel m, MjhData d, int stage
   else if (t == SENS_ACTUATORPOS) v[0] = d.actuator_length[(size_t)w * m.nu + id];
   else if (t == SENS_ACTUATORVEL) v[0] = d.actuator_velocity[(size_t)w * m.nu + id];
   else if (t == SENS_ACTUATORFRC) v[0] = d.actuator_force[(size_t)w * m.nu + id];
-  else if (t == SENS_BALLQUAT) {
+  else if (t == SENS_JOINTACTFRC) v[0] = d.qfrc_actuator[(size_t)w * m.nv + m.jnt_dofadr[id]];
+  else if (t == SENS_E_POTENTIAL) v[0] = d.energy[2 * w];  // (k_energy ran just before)
+  else if (t == SENS_E_KINETIC) v[0] = d.energy[2 * w + 1];
+  else if (t == SENS_JOINTLIMITPOS || t == SENS_JOINTLIMITVEL || t == SENS_JOINTLIMITFRC) {
+    // sensor.py:228-263, 1028-1063, 1640-1675: the joint's limit row if it is active (0 otherwise)
+    const int r0 = d.ne[w] + d.nf[w], r1 = min(r0 + d.nl[w], d.njmax);
+    const size_t eo = (size_t)w * d.njmax;
+    for (int r = r0; r < r1; ++r)
+      if (d.efc_type[eo + r] == CT_LIMIT_JOINT && d.efc_id[eo + r] == id)
+        v[0] = t == SENS_JOINTLIMITPOS ? d.efc_pos[eo + r] - d.efc_margin[eo + r] : (t == SENS_JOINTLIMITVEL ? d.efc_vel[eo + r] : d.efc_force[eo + r]);
+  } else if (t == SENS_BALLQUAT) {
     const Q4 q = quat_normalize(ld4(d.qpos + (size_t)w * m.nq + m.jnt_qposadr[id]));
     v[0] = q.w; v[1] = q.x; v[2] = q.y; v[3] = q.z;
   } else if (t == SENS_BALLANGVEL) put3(ld3(d.qvel + (size_t)w * m.nv + m.jnt_dofadr[id]));

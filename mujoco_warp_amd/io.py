@@ -380,7 +380,8 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
   )
   m.nsensor, m.nsensordata = int(host["sensor_type"].shape[0]), int(getattr(mjm, "nsensordata", 0))
   supported_sensors = set(mjcf_SENS.values())
-  m.nsensor_acc = int(sum(int(t) in (1, 4, 5, 33, 34) for t in host["sensor_type"]))
+  m.nsensor_acc = int(sum(int(t) in (1, 4, 5, 22, 33, 34) for t in host["sensor_type"]))
+  m.nsensor_energy = int(sum(int(t) in (43, 44) for t in host["sensor_type"]))
   m.nsensor_frc = int(sum(int(t) in (4, 5) for t in host["sensor_type"]))
   m.nsensor_subtree = int(sum(int(t) in (36, 37) for t in host["sensor_type"]))
   bad = [int(t) for t in host["sensor_type"] if int(t) not in supported_sensors]

@@ -444,6 +444,7 @@ class Model(_Dirty):
   nsensor_acc: int = 0
   nsensor_subtree: int = 0
   nsensor_frc: int = 0
+  nsensor_energy: int = 0
   sensor_type: DeviceArray = _arr(('nsensor',), "int32")
   sensor_datatype: DeviceArray = _arr(('nsensor',), "int32")
   sensor_objtype: DeviceArray = _arr(('nsensor',), "int32")

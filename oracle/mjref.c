@@ -2790,7 +2790,8 @@ void ref_sleep(const RefModel* m, RefData* d) { /* sleep.py:824-999 */
 /* ================================================================ sensors (sensor.py, subset) */
 enum { SENS_ACCELEROMETER = 1, SENS_FORCE = 4, SENS_TORQUE = 5, SENS_FRAMELINACC = 33, SENS_FRAMEANGACC = 34, SENS_VELOCIMETER = 2, SENS_GYRO = 3, SENS_JOINTPOS = 9, SENS_JOINTVEL = 10, SENS_ACTUATORPOS = 13, SENS_ACTUATORVEL = 14, SENS_ACTUATORFRC = 15,
        SENS_BALLQUAT = 18, SENS_BALLANGVEL = 19, SENS_FRAMEPOS = 26, SENS_FRAMEQUAT = 27, SENS_FRAMEXAXIS = 28, SENS_FRAMEYAXIS = 29, SENS_FRAMEZAXIS = 30,
-       SENS_FRAMELINVEL = 31, SENS_FRAMEANGVEL = 32, SENS_SUBTREECOM = 35, SENS_SUBTREELINVEL = 36, SENS_SUBTREEANGMOM = 37, SENS_CLOCK = 45 };
+       SENS_FRAMELINVEL = 31, SENS_FRAMEANGVEL = 32, SENS_SUBTREECOM = 35, SENS_SUBTREELINVEL = 36, SENS_SUBTREEANGMOM = 37, SENS_CLOCK = 45,
+       SENS_JOINTACTFRC = 16, SENS_JOINTLIMITPOS = 20, SENS_JOINTLIMITVEL = 21, SENS_JOINTLIMITFRC = 22, SENS_E_POTENTIAL = 43, SENS_E_KINETIC = 44 };
 enum { OBJ_BODY = 1, OBJ_XBODY = 2, OBJ_GEOM = 5, OBJ_SITE = 6 };
 /* pose, quaternion and body of a frame object (sensor.py:266-374 _get_pos / _get_mat / _get_quat / _get_body_id; sites are posed here: the
    oracle keeps no site arrays) */
@@ -2969,7 +2970,7 @@ static void sensor_stage(const RefModel* m, RefData* d, int stage) {
       if (m->sensor_type[i] == SENS_SUBTREELINVEL || m->sensor_type[i] == SENS_SUBTREEANGMOM) { ref_subtree_vel(m, d); break; }
   for (int i = 0; i < m->nsensor; i++) {
     int acc_type = m->sensor_type[i] == SENS_ACCELEROMETER || m->sensor_type[i] == SENS_FRAMELINACC || m->sensor_type[i] == SENS_FRAMEANGACC ||
-                   m->sensor_type[i] == SENS_FORCE || m->sensor_type[i] == SENS_TORQUE;
+                   m->sensor_type[i] == SENS_FORCE || m->sensor_type[i] == SENS_TORQUE || m->sensor_type[i] == SENS_JOINTLIMITFRC;
     if (acc_type != (stage == 1)) continue;
     int t = m->sensor_type[i], id = m->sensor_objid[i], ot = m->sensor_objtype[i], rid = m->sensor_refid[i], rt = m->sensor_reftype[i];
     double v[4] = {0, 0, 0, 0}, pos[3], mat[9], q[4], rpos[3], rmat[9], rq[4], dif[3];
@@ -2978,7 +2979,39 @@ static void sensor_stage(const RefModel* m, RefData* d, int stage) {
     else if (t == SENS_ACTUATORPOS) v[0] = d->actuator_length[id];
     else if (t == SENS_ACTUATORVEL) v[0] = d->actuator_velocity[id];
     else if (t == SENS_ACTUATORFRC) v[0] = d->actuator_force[id];
-    else if (t == SENS_BALLQUAT) { /* 216-225 */
+    else if (t == SENS_JOINTACTFRC) v[0] = d->qfrc_actuator[m->jnt_dofadr[id]];
+    else if (t == SENS_E_POTENTIAL || t == SENS_E_KINETIC) { /* sensor.py:2773-3018 energy_pos / energy_vel */
+      if (t == SENS_E_KINETIC) {
+        double* mv = (double*)malloc(sizeof(double) * (m->nv > 0 ? m->nv : 1));
+        ref_mul_m(m, d, mv, d->qvel);
+        for (int k = 0; k < m->nv; k++) v[0] += 0.5 * d->qvel[k] * mv[k];
+        free(mv);
+      } else {
+        if (!(m->disableflags & DSBL_GRAVITY))
+          for (int b = 1; b < m->nbody; b++) v[0] -= m->body_mass[b] * v3dot(m->gravity, d->xipos + 3 * b);
+        if (!(m->disableflags & DSBL_SPRING))
+          for (int j = 0; j < m->njnt; j++) {
+            double kk = m->jnt_stiffness[j];
+            if (kk == 0.0) continue;
+            int qa = m->jnt_qposadr[j], jt = m->jnt_type[j];
+            if (jt == JNT_FREE || jt == JNT_BALL) {
+              int o = jt == JNT_FREE ? 3 : 0;
+              double qn[4], dq[3];
+              memcpy(qn, d->qpos + qa + o, sizeof(qn));
+              quat_normalize(qn);
+              quat_sub(dq, qn, m->qpos_spring + qa + o);
+              v[0] += 0.5 * kk * v3dot(dq, dq);
+              if (jt == JNT_FREE)
+                for (int k = 0; k < 3; k++) v[0] += 0.5 * kk * (d->qpos[qa + k] - m->qpos_spring[qa + k]) * (d->qpos[qa + k] - m->qpos_spring[qa + k]);
+            } else v[0] += 0.5 * kk * (d->qpos[qa] - m->qpos_spring[qa]) * (d->qpos[qa] - m->qpos_spring[qa]);
+          }
+      }
+    } else if (t == SENS_JOINTLIMITPOS || t == SENS_JOINTLIMITVEL || t == SENS_JOINTLIMITFRC) { /* 228-263, 1028-1063, 1640-1675 */
+      int r1 = d->ne + d->nf + d->nl < m->njmax ? d->ne + d->nf + d->nl : m->njmax;
+      for (int r = d->ne + d->nf; r < r1; r++)
+        if (d->efc_type[r] == CT_LIMIT_JOINT && d->efc_id[r] == id)
+          v[0] = t == SENS_JOINTLIMITPOS ? d->efc_pos[r] - d->efc_margin[r] : (t == SENS_JOINTLIMITVEL ? d->efc_vel[r] : d->efc_force[r]);
+    } else if (t == SENS_BALLQUAT) { /* 216-225 */
       memcpy(v, d->qpos + m->jnt_qposadr[id], 4 * sizeof(double));
       quat_normalize(v);
     } else if (t == SENS_BALLANGVEL) memcpy(v, d->qvel + m->jnt_dofadr[id], 3 * sizeof(double));

@@ -21,7 +21,7 @@ SENSOR_XML = """
     <geom name="floor" type="plane" size="5 5 .1"/>
     <site name="origin" pos="0 0 0"/>
     <body name="arm" pos="0 0 1">
-      <joint name="shoulder" type="hinge" axis="0 0 1"/>
+      <joint name="shoulder" type="hinge" axis="0 0 1" range="-30 30" limited="true" stiffness="2"/>
       <geom name="upper" type="capsule" fromto="0 0 0 .4 0 0" size=".03"/>
       <site name="tip" pos=".4 0 0" euler="0 0 30"/>
       <body name="fore" pos=".4 0 0">
@@ -51,6 +51,8 @@ SENSOR_XML = """
     <gyro name="gyro_cut" site="imu" cutoff="0.5"/>
     <accelerometer name="acc" site="imu"/><framelinacc name="la" objtype="site" objname="imu"/><frameangacc name="aa" objtype="body" objname="ball"/>
     <framelinacc name="la_tip" objtype="site" objname="tip"/>
+    <jointactuatorfrc name="jaf" joint="shoulder"/><jointlimitpos name="jlp" joint="shoulder"/><jointlimitvel name="jlv" joint="shoulder"/>
+    <jointlimitfrc name="jlf" joint="shoulder"/><e_potential name="ep"/><e_kinetic name="ek"/>
     <subtreelinvel name="slv" body="arm"/><subtreeangmom name="sam" body="arm"/><subtreeangmom name="sam_ball" body="ball"/>
     <subtreecom name="com" body="arm"/><clock name="t"/>
   </sensor>
@@ -76,7 +78,7 @@ def _state(sim_or_none, mjm):
 
 def test_oracle_sensor_closed_forms():
   mjm = mjw.mjcf.from_xml_string(SENSOR_XML)
-  assert mjm.nsensor == 32 and mjm.nsensordata == int(mjm.sensor_dim.sum())
+  assert mjm.nsensor == 38 and mjm.nsensordata == int(mjm.sensor_dim.sum())
   s = ref.RefSim(mjm)
   s.qpos[:], s.qvel[:] = _state(s, mjm)
   s.ctrl[:] = [0.3, -0.2]
@@ -109,6 +111,12 @@ def test_oracle_sensor_closed_forms():
   assert np.allclose(g("gyro"), R_imu.T @ w_world, atol=1e-12)
   assert np.allclose(g("vel"), R_imu.T @ (s.qvel[4:7] + np.cross(w_world, Rb @ mjm.site_pos[3])), atol=1e-12)
   assert np.allclose(g("gyro_cut"), np.clip(g("gyro"), -0.5, 0.5))
+  # joint-level readings: actuator force on the joint (motor gear 2 + position servo), the violated upper limit (0.7 rad > 30 deg), energies
+  assert g("jaf")[0] == pytest.approx(2 * 0.3 + 10 * (-0.2 - th))
+  assert g("jlp")[0] == pytest.approx(np.deg2rad(30) - th) and g("jlv")[0] == pytest.approx(-w) and g("jlf")[0] > 0
+  M = s.dense_M()
+  assert g("ek")[0] == pytest.approx(0.5 * s.qvel @ M @ s.qvel, rel=1e-12)
+  assert g("ep")[0] == pytest.approx(-sum(mjm.body_mass[b] * np.dot(mjm.opt.gravity, s.xipos[b]) for b in range(1, mjm.nbody)) + 0.5 * 2 * th**2, rel=1e-12)
   # acceleration stage: the free sphere is in free fall (isotropic inertia: no angular acceleration), so a point at r from its centre
   # accelerates at g + w x (w x r) and the accelerometer, which subtracts gravity, reads the centripetal term in site coordinates
   r_imu = Rb @ mjm.site_pos[3]
@@ -177,6 +185,7 @@ def test_gpu_sensors_vs_oracle():
       for name in ("acc", "la", "aa", "la_tip"):  # accelerations are sums of cancelling terms of size w^2 |r|, g (tens of m/s^2)
         k = mjm.sensor_names.index(name)
         tol[mjm.sensor_adr[k] : mjm.sensor_adr[k] + 3] = 1e-3
+      tol[mjm.sensor_adr[mjm.sensor_names.index("jlf")]] = 5e-3 * max(1.0, abs(_read(mjm, s.sensordata, "jlf")[0]))  # (a constraint force: solver tolerance)
       assert (err <= tol).all(), (step, w, mjm.sensor_names[int(np.searchsorted(mjm.sensor_adr, int(err.argmax()), side="right")) - 1])
   class Host:
     pass
