@@ -193,6 +193,8 @@ typedef struct MjhModel {
   const int* site_bodyid;
   const float* site_pos; int site_pos_nb;
   const float* site_quat; int site_quat_nb;
+  const int* site_type;         /* [nsite] GeomType of the site's shape (touch sensor zones) */
+  const float* site_size;       /* [nsite, 3] */
   /* actuators (joint transmission) */
   const int* actuator_dyntype; const int* actuator_gaintype; const int* actuator_biastype; const int* actuator_trnid;
   const int* actuator_actadr; const int* actuator_ctrllimited; const int* actuator_forcelimited; const int* actuator_actlimited;
@@ -336,7 +338,7 @@ int mjh_timed_steps(const MjhModel* m, const MjhData* d, int nstep, int step0, f
 int mjh_release_thread_resources(void);
 
 const char* mjh_last_error(void);
-#define MJH_ABI_VERSION 27
+#define MJH_ABI_VERSION 28
 int mjh_abi_version(void); /* returns MJH_ABI_VERSION of the library that was loaded */
 
 #ifdef __cplusplus

@@ -8,7 +8,7 @@
 #pragma once
 #include "dev_common.hpp"
 
-enum { SENS_ACCELEROMETER = 1, SENS_FORCE = 4, SENS_TORQUE = 5, SENS_VELOCIMETER = 2, SENS_GYRO = 3, SENS_JOINTPOS = 9, SENS_JOINTVEL = 10, SENS_ACTUATORPOS = 13, SENS_ACTUATORVEL = 14, SENS_ACTUATORFRC = 15,
+enum { SENS_TOUCH = 0, SENS_ACCELEROMETER = 1, SENS_FORCE = 4, SENS_TORQUE = 5, SENS_VELOCIMETER = 2, SENS_GYRO = 3, SENS_JOINTPOS = 9, SENS_JOINTVEL = 10, SENS_ACTUATORPOS = 13, SENS_ACTUATORVEL = 14, SENS_ACTUATORFRC = 15,
        SENS_JOINTACTFRC = 16, SENS_BALLQUAT = 18, SENS_BALLANGVEL = 19, SENS_JOINTLIMITPOS = 20, SENS_JOINTLIMITVEL = 21, SENS_JOINTLIMITFRC = 22, SENS_FRAMEPOS = 26, SENS_FRAMEQUAT = 27, SENS_FRAMEXAXIS = 28, SENS_FRAMEYAXIS = 29, SENS_FRAMEZAXIS = 30,
        SENS_FRAMELINVEL = 31, SENS_FRAMEANGVEL = 32, SENS_FRAMELINACC = 33, SENS_FRAMEANGACC = 34, SENS_SUBTREECOM = 35, SENS_SUBTREELINVEL = 36, SENS_SUBTREEANGMOM = 37, SENS_E_POTENTIAL = 43, SENS_E_KINETIC = 44, SENS_CLOCK = 45 };
 enum { OBJ_BODY = 1, OBJ_XBODY = 2, OBJ_GEOM = 5, OBJ_SITE = 6 };
@@ -74,13 +74,67 @@ DEV void sens_cacc(const MjhModel& m, const MjhData& d, int w, int body, V3& ang
   }
 }
 
+// does the ray pnt + t vec, t >= 0, meet the site's shape (sensor.py:2063-2139 asks ray.ray_geom for a non-negative distance; only the
+// yes / no matters, so the conventions of the reference's ray routines do not enter): sphere, ellipsoid, box, cylinder, capsule
+DEV bool ray_interval_cyl(V3 p, V3 v, float r, float hh, float& t0, float& t1) {  // finite cylinder about z: entry / exit parameters
+  const float a = v.x * v.x + v.y * v.y, b = p.x * v.x + p.y * v.y, c = p.x * p.x + p.y * p.y - r * r;
+  t0 = -3.0e38f;
+  t1 = 3.0e38f;
+  if (a < 1e-20f) {
+    if (c > 0.0f) return false;
+  } else {
+    const float disc = b * b - a * c;
+    if (disc < 0.0f) return false;
+    const float sq = sqrtf(disc);
+    t0 = (-b - sq) / a;
+    t1 = (-b + sq) / a;
+  }
+  if (fabsf(v.z) < 1e-20f) {
+    if (fabsf(p.z) > hh) return false;
+  } else {
+    const float ta = (-hh - p.z) / v.z, tb = (hh - p.z) / v.z;
+    t0 = fmaxf(t0, fminf(ta, tb));
+    t1 = fminf(t1, fmaxf(ta, tb));
+  }
+  return t1 >= fmaxf(t0, 0.0f);
+}
+DEV bool ray_hits_sphere(V3 p, V3 v, float r) {
+  const float a = dot(v, v), b = dot(p, v), c = dot(p, p) - r * r, disc = b * b - a * c;
+  return a > 0.0f && disc >= 0.0f && (-b + sqrtf(disc)) >= 0.0f;
+}
+DEV bool ray_hits_zone(int type, V3 size, V3 pos, const float* mat, V3 pnt, V3 vec) {
+  const V3 p = matT_mul(mat, pnt - pos), v = matT_mul(mat, vec);
+  float t0, t1;
+  if (type == G_SPHERE) return ray_hits_sphere(p, v, size.x);
+  if (type == G_ELLIPSOID) return ray_hits_sphere(V3{p.x / size.x, p.y / size.y, p.z / size.z}, V3{v.x / size.x, v.y / size.y, v.z / size.z}, 1.0f);
+  if (type == G_CYLINDER) return ray_interval_cyl(p, v, size.x, size.y, t0, t1);
+  if (type == G_CAPSULE)
+    return ray_interval_cyl(p, v, size.x, size.y, t0, t1) || ray_hits_sphere(p - V3{0, 0, size.y}, v, size.x) || ray_hits_sphere(p + V3{0, 0, size.y}, v, size.x);
+  if (type == G_BOX) {
+    t0 = -3.0e38f;
+    t1 = 3.0e38f;
+    const float pp[3] = {p.x, p.y, p.z}, vv[3] = {v.x, v.y, v.z}, ss[3] = {size.x, size.y, size.z};
+    for (int k = 0; k < 3; ++k) {
+      if (fabsf(vv[k]) < 1e-20f) {
+        if (fabsf(pp[k]) > ss[k]) return false;
+      } else {
+        const float ta = (-ss[k] - pp[k]) / vv[k], tb = (ss[k] - pp[k]) / vv[k];
+        t0 = fmaxf(t0, fminf(ta, tb));
+        t1 = fminf(t1, fmaxf(ta, tb));
+      }
+    }
+    return t1 >= fmaxf(t0, 0.0f);
+  }
+  return false;
+}
+
 // stage 0: position / velocity stage sensors and actuator forces (before the solver); stage 1: acceleration stage (after it, before the integrator)
 __global__ void __launch_bounds__(256) k_sensor(MjhModel m, MjhData d, int stage) {
   const int idx = blockIdx.x * 256 + threadIdx.x, ns = m.nsensor;
   if (idx >= d.nworld * ns) return;
   const int w = idx / ns, i = idx - w * ns;
   const int t = m.sensor_type[i], id = m.sensor_objid[i], ot = m.sensor_objtype[i], rid = m.sensor_refid[i], rt = m.sensor_reftype[i];
-  const bool acc_type = t == SENS_ACCELEROMETER || t == SENS_FRAMELINACC || t == SENS_FRAMEANGACC || t == SENS_FORCE || t == SENS_TORQUE || t == SENS_JOINTLIMITFRC;
+  const bool acc_type = t == SENS_ACCELEROMETER || t == SENS_FRAMELINACC || t == SENS_FRAMEANGACC || t == SENS_FORCE || t == SENS_TORQUE || t == SENS_JOINTLIMITFRC || t == SENS_TOUCH;
   if (acc_type != (stage == 1)) return;
   float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   auto put3 = [&](V3 a) {
@@ -149,7 +203,28 @@ __global__ void __launch_bounds__(256) k_sensor(MjhModel m, MjhData d, int stage
       else put3(matT_mul(r.mat, ang - rang));
     }
   }
-  else if (t == SENS_FORCE || t == SENS_TORQUE) {  // sensor.py:1542-1577: the interaction force / torque at the site's body (k_rne_postconstraint ran just before)
+  else if (t == SENS_TOUCH) {
+    // sensor.py:2063-2139: sum of the normal forces of the contacts of the site's body whose normal ray meets the site's zone (from the
+    // world's contact records: the public contact arrays are published off the critical path)
+    const SensFrame f = sens_frame(m, d, w, OBJ_SITE, id);
+    const V3 zsize = ld3(m.site_size + 3 * id);
+    const int ztype = m.site_type[id], ncon = min(d.ws_ncon[w], d.concap);
+    const float* force = d.efc_force + (size_t)w * d.njmax;
+    for (int c = 0; c < ncon; ++c) {
+      const float* rec = d.ws_contact + ((size_t)w * d.concap + c) * CON_STRIDE;
+      const int* reci = reinterpret_cast<const int*>(rec);
+      const int b1 = m.geom_bodyid[reci[25]], b2 = m.geom_bodyid[reci[26]], adr0 = reci[28], nrow = reci[29];
+      if (adr0 < 0 || (f.body != b1 && f.body != b2)) continue;
+      float nf = 0.0f;
+      const int rows = m.cone == CONE_PYRAMIDAL ? nrow : 1;  // pyramidal: the rows of a contact add up to its normal force
+      for (int k = 0; k < rows; ++k)
+        if (adr0 + k < d.njmax) nf += force[adr0 + k];
+      if (nf <= 0.0f) continue;
+      V3 ray = normalize(ld3(rec + 4) * nf);
+      if (f.body == b2) ray = V3{0, 0, 0} - ray;
+      if (ray_hits_zone(ztype, zsize, f.pos, f.mat, ld3(rec + 1), ray)) v[0] += nf;
+    }
+  } else if (t == SENS_FORCE || t == SENS_TORQUE) {  // sensor.py:1542-1577: the interaction force / torque at the site's body (k_rne_postconstraint ran just before)
     const SensFrame f = sens_frame(m, d, w, OBJ_SITE, id);
     const float* ci = d.cfrc_int + ((size_t)w * m.nbody + f.body) * 6;
     if (t == SENS_FORCE) put3(matT_mul(f.mat, ld3(ci + 3)));

@@ -372,6 +372,7 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
     pair_solimp=_arr(getattr(mjm, "pair_solimp", np.zeros((0, 5))), f32).reshape(-1, 5),
     pair_margin=_arr(getattr(mjm, "pair_margin", np.zeros(0)), f32), pair_gap=_arr(getattr(mjm, "pair_gap", np.zeros(0)), f32),
     site_bodyid=_arr(getattr(mjm, "site_bodyid", np.zeros(0)), i32),
+    site_type=_arr(getattr(mjm, "site_type", np.full(int(getattr(mjm, "nsite", 0)), 2)), i32), site_size=_arr(getattr(mjm, "site_size", np.full((int(getattr(mjm, "nsite", 0)), 3), 0.005)), f32).reshape(-1, 3),
     actuator_dyntype=_arr(mjm.actuator_dyntype, i32), actuator_gaintype=_arr(mjm.actuator_gaintype, i32),
     actuator_biastype=_arr(mjm.actuator_biastype, i32), actuator_trnid=_arr(mjm.actuator_trnid, i32).reshape(-1, 2),
     actuator_actadr=_arr(mjm.actuator_actadr, i32), actuator_ctrllimited=_arr(mjm.actuator_ctrllimited, i32),
@@ -380,7 +381,7 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
   )
   m.nsensor, m.nsensordata = int(host["sensor_type"].shape[0]), int(getattr(mjm, "nsensordata", 0))
   supported_sensors = set(mjcf_SENS.values())
-  m.nsensor_acc = int(sum(int(t) in (1, 4, 5, 22, 33, 34) for t in host["sensor_type"]))
+  m.nsensor_acc = int(sum(int(t) in (0, 1, 4, 5, 22, 33, 34) for t in host["sensor_type"]))
   m.nsensor_energy = int(sum(int(t) in (43, 44) for t in host["sensor_type"]))
   m.nsensor_frc = int(sum(int(t) in (4, 5) for t in host["sensor_type"]))
   m.nsensor_subtree = int(sum(int(t) in (36, 37) for t in host["sensor_type"]))

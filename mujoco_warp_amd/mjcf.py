@@ -630,6 +630,12 @@ def _compile_mesh(verts):
               rbound=float(np.max(np.linalg.norm(vlocal, axis=1))), polys=polys, polynormal=np.array(normals), polymap=polymap, graph=graph)
 
 
+def _site_size(a):
+  """Site size with MuJoCo's fill rule for short size attributes (missing entries repeat the first; default 0.005)."""
+  v = _floats(a["size"]) if "size" in a else [0.005]
+  return np.array((list(v) + [v[0]] * 3)[:3], dtype=np.float64)
+
+
 class _Body:
   pass
 
@@ -856,7 +862,7 @@ def _compile(root, base_dir):
         a = dict(base)
         a.update(explicit)
         sites.append({"name": a.get("name", ""), "body": bid, "pos": _vec(a, "pos", [0, 0, 0]),
-                      "quat": _orientation(a, compiler), "size": _vec(a, "size", [0.005, 0.005, 0.005])})
+                      "quat": _orientation(a, compiler), "size": _site_size(a), "type": _GEOM_NAMES[a.get("type", "sphere")]})
       elif child.tag not in ("camera", "light", "body"):
         # <frame>, <replicate>, <attach>, <composite>, <flexcomp>, <plugin>, ...: never skipped silently
         raise NotImplementedError(f"<{child.tag}> inside <body>")
@@ -878,7 +884,7 @@ def _compile(root, base_dir):
       a = dict(base)
       a.update(explicit)
       sites.append({"name": a.get("name", ""), "body": 0, "pos": _vec(a, "pos", [0, 0, 0]),
-                    "quat": _orientation(a, compiler), "size": _vec(a, "size", [0.005, 0.005, 0.005])})
+                    "quat": _orientation(a, compiler), "size": _site_size(a), "type": _GEOM_NAMES[a.get("type", "sphere")]})
   for child in wb:
     if child.tag == "body":
       parse_body(child, 0, None)
@@ -1096,6 +1102,8 @@ def _compile(root, base_dir):
   m.site_bodyid = np.array([s["body"] for s in sites], dtype=np.int32)
   m.site_pos = np.array([s["pos"] for s in sites]).reshape(-1, 3)
   m.site_quat = np.array([s["quat"] for s in sites]).reshape(-1, 4)
+  m.site_size = np.array([s["size"] for s in sites]).reshape(-1, 3)
+  m.site_type = np.array([s["type"] for s in sites], dtype=np.int32)
 
   # body inertial properties
   m.body_mass = np.zeros(nbody)
@@ -1345,12 +1353,12 @@ def _compile(root, base_dir):
 
 # mjtSensor / mjtObj / mjtDataType / mjtStage values used below (MuJoCo's enums; UNPINNED here -- the mujoco package is absent: a real
 # MjModel carries its own numbers in sensor_type, which put_model compares with these)
-SENS = {"accelerometer": 1, "force": 4, "torque": 5, "jointactuatorfrc": 16, "jointlimitpos": 20, "jointlimitvel": 21, "jointlimitfrc": 22, "e_potential": 43, "e_kinetic": 44, "framelinacc": 33, "frameangacc": 34, "velocimeter": 2, "gyro": 3, "jointpos": 9, "jointvel": 10, "actuatorpos": 13, "actuatorvel": 14, "actuatorfrc": 15, "ballquat": 18, "ballangvel": 19,
+SENS = {"touch": 0, "accelerometer": 1, "force": 4, "torque": 5, "jointactuatorfrc": 16, "jointlimitpos": 20, "jointlimitvel": 21, "jointlimitfrc": 22, "e_potential": 43, "e_kinetic": 44, "framelinacc": 33, "frameangacc": 34, "velocimeter": 2, "gyro": 3, "jointpos": 9, "jointvel": 10, "actuatorpos": 13, "actuatorvel": 14, "actuatorfrc": 15, "ballquat": 18, "ballangvel": 19,
         "framepos": 26, "framequat": 27, "framexaxis": 28, "frameyaxis": 29, "framezaxis": 30, "framelinvel": 31, "frameangvel": 32, "subtreecom": 35, "subtreelinvel": 36, "subtreeangmom": 37, "clock": 45}
 # sensors that keep their slot in sensordata (the reference's layout) but are not computed: the engine writes zeros and put_model warns
-SENS_UNSUPPORTED = {"touch": (0, 1), "magnetometer": (6, 3), "rangefinder": (7, 1),}
-_SENS_DIM = {"ballquat": 4, "framequat": 4, "jointactuatorfrc": 1, "jointlimitpos": 1, "jointlimitvel": 1, "jointlimitfrc": 1, "e_potential": 1, "e_kinetic": 1, "jointpos": 1, "jointvel": 1, "actuatorpos": 1, "actuatorvel": 1, "actuatorfrc": 1, "clock": 1}
-_SENS_STAGE = {"velocimeter": 2, "gyro": 2, "jointvel": 2, "actuatorvel": 2, "ballangvel": 2, "framelinvel": 2, "frameangvel": 2, "subtreelinvel": 2, "subtreeangmom": 2, "jointlimitvel": 2, "e_kinetic": 2, "jointlimitfrc": 3, "jointactuatorfrc": 3, "actuatorfrc": 3, "accelerometer": 3, "force": 3, "torque": 3, "framelinacc": 3, "frameangacc": 3}  # default: POS (1)
+SENS_UNSUPPORTED = {"magnetometer": (6, 3), "rangefinder": (7, 1),}
+_SENS_DIM = {"touch": 1, "ballquat": 4, "framequat": 4, "jointactuatorfrc": 1, "jointlimitpos": 1, "jointlimitvel": 1, "jointlimitfrc": 1, "e_potential": 1, "e_kinetic": 1, "jointpos": 1, "jointvel": 1, "actuatorpos": 1, "actuatorvel": 1, "actuatorfrc": 1, "clock": 1}
+_SENS_STAGE = {"velocimeter": 2, "gyro": 2, "jointvel": 2, "actuatorvel": 2, "ballangvel": 2, "framelinvel": 2, "frameangvel": 2, "subtreelinvel": 2, "subtreeangmom": 2, "jointlimitvel": 2, "e_kinetic": 2, "touch": 3, "jointlimitfrc": 3, "jointactuatorfrc": 3, "actuatorfrc": 3, "accelerometer": 3, "force": 3, "torque": 3, "framelinacc": 3, "frameangacc": 3}  # default: POS (1)
 _OBJ = {"body": 1, "xbody": 2, "geom": 5, "site": 6, "camera": 7}
 
 
@@ -1378,7 +1386,7 @@ def _compile_sensors(m, root, site_names):
           raise ValueError(f"sensor <{e.tag}> on a joint of the wrong type")
       elif e.tag in ("actuatorpos", "actuatorvel", "actuatorfrc"):
         objtype, objid = 19, m.actuator_names.index(a["actuator"])  # mjOBJ_ACTUATOR
-      elif e.tag in ("velocimeter", "gyro", "accelerometer", "force", "torque"):
+      elif e.tag in ("velocimeter", "gyro", "accelerometer", "force", "torque", "touch"):
         objtype, objid = 6, site_names.index(a["site"])
       elif e.tag in ("subtreecom", "subtreelinvel", "subtreeangmom"):
         objtype, objid = 1, m.body_names.index(a["body"])
@@ -1389,7 +1397,7 @@ def _compile_sensors(m, root, site_names):
           reftype = _OBJ[a["reftype"]]
           refid = lookup[reftype].index(a["refname"])
       dim = _SENS_DIM.get(e.tag, 3)
-      rows.append(dict(type=SENS[e.tag], datatype=3 if e.tag in ("ballquat", "framequat") else (2 if e.tag.startswith("frame") and e.tag.endswith("axis") else 0),
+      rows.append(dict(type=SENS[e.tag], datatype=1 if e.tag == "touch" else 3 if e.tag in ("ballquat", "framequat") else (2 if e.tag.startswith("frame") and e.tag.endswith("axis") else 0),
                        needstage=_SENS_STAGE.get(e.tag, 1), objtype=objtype, objid=objid, reftype=reftype, refid=refid, dim=dim,
                        cutoff=float(a.get("cutoff", 0.0)), name=a.get("name", "")))
   m.nsensor = len(rows)

@@ -445,6 +445,8 @@ class Model(_Dirty):
   nsensor_subtree: int = 0
   nsensor_frc: int = 0
   nsensor_energy: int = 0
+  site_type: DeviceArray = _arr(('nsite',), "int32")
+  site_size: DeviceArray = _arr(('nsite', 3), "float32")
   sensor_type: DeviceArray = _arr(('nsensor',), "int32")
   sensor_datatype: DeviceArray = _arr(('nsensor',), "int32")
   sensor_objtype: DeviceArray = _arr(('nsensor',), "int32")

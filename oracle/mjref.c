@@ -2788,7 +2788,7 @@ void ref_sleep(const RefModel* m, RefData* d) { /* sleep.py:824-999 */
 }
 
 /* ================================================================ sensors (sensor.py, subset) */
-enum { SENS_ACCELEROMETER = 1, SENS_FORCE = 4, SENS_TORQUE = 5, SENS_FRAMELINACC = 33, SENS_FRAMEANGACC = 34, SENS_VELOCIMETER = 2, SENS_GYRO = 3, SENS_JOINTPOS = 9, SENS_JOINTVEL = 10, SENS_ACTUATORPOS = 13, SENS_ACTUATORVEL = 14, SENS_ACTUATORFRC = 15,
+enum { SENS_TOUCH = 0, SENS_ACCELEROMETER = 1, SENS_FORCE = 4, SENS_TORQUE = 5, SENS_FRAMELINACC = 33, SENS_FRAMEANGACC = 34, SENS_VELOCIMETER = 2, SENS_GYRO = 3, SENS_JOINTPOS = 9, SENS_JOINTVEL = 10, SENS_ACTUATORPOS = 13, SENS_ACTUATORVEL = 14, SENS_ACTUATORFRC = 15,
        SENS_BALLQUAT = 18, SENS_BALLANGVEL = 19, SENS_FRAMEPOS = 26, SENS_FRAMEQUAT = 27, SENS_FRAMEXAXIS = 28, SENS_FRAMEYAXIS = 29, SENS_FRAMEZAXIS = 30,
        SENS_FRAMELINVEL = 31, SENS_FRAMEANGVEL = 32, SENS_SUBTREECOM = 35, SENS_SUBTREELINVEL = 36, SENS_SUBTREEANGMOM = 37, SENS_CLOCK = 45,
        SENS_JOINTACTFRC = 16, SENS_JOINTLIMITPOS = 20, SENS_JOINTLIMITVEL = 21, SENS_JOINTLIMITFRC = 22, SENS_E_POTENTIAL = 43, SENS_E_KINETIC = 44 };
@@ -2924,6 +2924,58 @@ static void body_cacc(const RefModel* m, const RefData* d, int body, double* cac
   for (int dof = m->body_dofadr[bb] + m->body_dofnum[bb] - 1; dof >= 0; dof = m->dof_parentid[dof])
     for (int k = 0; k < 6; k++) cacc[k] += d->cdof_dot[6 * dof + k] * d->qvel[dof] + d->cdof[6 * dof + k] * d->qacc[dof];
 }
+/* does the ray pnt + t vec, t >= 0, meet a site's shape (sensor.py:2063-2139 asks ray.ray_geom for a non-negative distance; only the
+   yes / no matters, so the conventions of the reference's ray routines do not enter) */
+static int ray_cyl(const double* p, const double* v, double r, double hh) {
+  double a = v[0] * v[0] + v[1] * v[1], b = p[0] * v[0] + p[1] * v[1], c = p[0] * p[0] + p[1] * p[1] - r * r, t0 = -1e300, t1 = 1e300;
+  if (a < 1e-300) { if (c > 0.0) return 0; }
+  else {
+    double disc = b * b - a * c;
+    if (disc < 0.0) return 0;
+    t0 = (-b - sqrt(disc)) / a;
+    t1 = (-b + sqrt(disc)) / a;
+  }
+  if (fabs(v[2]) < 1e-300) { if (fabs(p[2]) > hh) return 0; }
+  else {
+    double ta = (-hh - p[2]) / v[2], tb = (hh - p[2]) / v[2];
+    t0 = fmax(t0, fmin(ta, tb));
+    t1 = fmin(t1, fmax(ta, tb));
+  }
+  return t1 >= fmax(t0, 0.0);
+}
+static int ray_sph(const double* p, const double* v, double r) {
+  double a = v3dot(v, v), b = v3dot(p, v), c = v3dot(p, p) - r * r, disc = b * b - a * c;
+  return a > 0.0 && disc >= 0.0 && (-b + sqrt(disc)) >= 0.0;
+}
+static int ray_hits_zone(int type, const double* size, const double* pos, const double* mat, const double* pnt, const double* vec) {
+  double dif[3], p[3], v[3];
+  v3sub(dif, pnt, pos);
+  matT_mul_vec(p, mat, dif);
+  matT_mul_vec(v, mat, vec);
+  if (type == G_SPHERE) return ray_sph(p, v, size[0]);
+  if (type == G_ELLIPSOID) {
+    double ps[3] = {p[0] / size[0], p[1] / size[1], p[2] / size[2]}, vs[3] = {v[0] / size[0], v[1] / size[1], v[2] / size[2]};
+    return ray_sph(ps, vs, 1.0);
+  }
+  if (type == G_CYLINDER) return ray_cyl(p, v, size[0], size[1]);
+  if (type == G_CAPSULE) {
+    double pa[3] = {p[0], p[1], p[2] - size[1]}, pb[3] = {p[0], p[1], p[2] + size[1]};
+    return ray_cyl(p, v, size[0], size[1]) || ray_sph(pa, v, size[0]) || ray_sph(pb, v, size[0]);
+  }
+  if (type == G_BOX) {
+    double t0 = -1e300, t1 = 1e300;
+    for (int k = 0; k < 3; k++) {
+      if (fabs(v[k]) < 1e-300) { if (fabs(p[k]) > size[k]) return 0; }
+      else {
+        double ta = (-size[k] - p[k]) / v[k], tb = (size[k] - p[k]) / v[k];
+        t0 = fmax(t0, fmin(ta, tb));
+        t1 = fmin(t1, fmax(ta, tb));
+      }
+    }
+    return t1 >= fmax(t0, 0.0);
+  }
+  return 0;
+}
 /* smooth.py:3502-3662 subtree_vel: velocity of every subtree's centre of mass, angular momentum of every subtree about it */
 void ref_subtree_vel(const RefModel* m, RefData* d) {
   int nb = m->nbody;
@@ -2970,7 +3022,7 @@ static void sensor_stage(const RefModel* m, RefData* d, int stage) {
       if (m->sensor_type[i] == SENS_SUBTREELINVEL || m->sensor_type[i] == SENS_SUBTREEANGMOM) { ref_subtree_vel(m, d); break; }
   for (int i = 0; i < m->nsensor; i++) {
     int acc_type = m->sensor_type[i] == SENS_ACCELEROMETER || m->sensor_type[i] == SENS_FRAMELINACC || m->sensor_type[i] == SENS_FRAMEANGACC ||
-                   m->sensor_type[i] == SENS_FORCE || m->sensor_type[i] == SENS_TORQUE || m->sensor_type[i] == SENS_JOINTLIMITFRC;
+                   m->sensor_type[i] == SENS_FORCE || m->sensor_type[i] == SENS_TORQUE || m->sensor_type[i] == SENS_JOINTLIMITFRC || m->sensor_type[i] == SENS_TOUCH;
     if (acc_type != (stage == 1)) continue;
     int t = m->sensor_type[i], id = m->sensor_objid[i], ot = m->sensor_objtype[i], rid = m->sensor_refid[i], rt = m->sensor_reftype[i];
     double v[4] = {0, 0, 0, 0}, pos[3], mat[9], q[4], rpos[3], rmat[9], rq[4], dif[3];
@@ -3069,7 +3121,22 @@ static void sensor_stage(const RefModel* m, RefData* d, int stage) {
         }
       }
     }
-    else if (t == SENS_FORCE || t == SENS_TORQUE) { /* sensor.py:1542-1577 */
+    else if (t == SENS_TOUCH) { /* sensor.py:2063-2139 */
+      int body = frame_of(m, d, OBJ_SITE, id, pos, mat, NULL);
+      for (int c = 0; c < d->ncon; c++) {
+        int b1 = m->geom_bodyid[d->con_geom[2 * c]], b2 = m->geom_bodyid[d->con_geom[2 * c + 1]], adr0 = d->con_efc_address[10 * c];
+        if (adr0 < 0 || (body != b1 && body != b2)) continue;
+        double nf = d->efc_force[adr0];
+        if (m->cone == 0)
+          for (int k = 1; k < 2 * (d->con_dim[c] - 1); k++)
+            if (d->con_efc_address[10 * c + k] >= 0) nf += d->efc_force[d->con_efc_address[10 * c + k]];
+        if (nf <= 0.0) continue;
+        double ray[3] = {d->con_frame[9 * c] * nf, d->con_frame[9 * c + 1] * nf, d->con_frame[9 * c + 2] * nf};
+        v3normalize(ray);
+        if (body == b2) { ray[0] = -ray[0]; ray[1] = -ray[1]; ray[2] = -ray[2]; }
+        if (ray_hits_zone(m->site_type[id], m->site_size + 3 * id, pos, mat, d->con_pos + 3 * c, ray)) v[0] += nf;
+      }
+    } else if (t == SENS_FORCE || t == SENS_TORQUE) { /* sensor.py:1542-1577 */
       int body = frame_of(m, d, OBJ_SITE, id, pos, mat, NULL);
       const double* ci = d->cfrc_int + 6 * body;
       if (t == SENS_FORCE) matT_mul_vec(v, mat, ci + 3);

@@ -151,6 +151,8 @@ typedef struct RefModel {
   int* site_bodyid;
   double* site_pos;
   double* site_quat;
+  int* site_type;
+  double* site_size;
   int* sensor_type;     /* mjtSensor */
   int* sensor_datatype; /* mjtDataType: 0 real, 1 positive, 2 axis, 3 quaternion */
   int* sensor_objtype;  /* mjtObj: 1 body (inertial frame), 2 xbody, 5 geom, 6 site */

@@ -222,7 +222,7 @@ class RefSim:
                "xpair_gap": getattr(mjm, "pair_gap", np.zeros(0)),
                "actuator_trnid": mjm.actuator_trnid, "M_colind": mjm.M_colind}
     for name, dflt in (("geom_dataid", np.full(mjm.ngeom, -1)), ("mesh_vertadr", np.zeros(0)), ("mesh_vertnum", np.zeros(0)), ("mesh_vert", np.zeros((0, 3))),
-                       ("site_bodyid", np.zeros(0)), ("site_pos", np.zeros((0, 3))), ("site_quat", np.zeros((0, 4))), ("sensor_type", np.zeros(0)), ("sensor_datatype", np.zeros(0)),
+                       ("site_bodyid", np.zeros(0)), ("site_pos", np.zeros((0, 3))), ("site_quat", np.zeros((0, 4))), ("site_type", np.zeros(0)), ("site_size", np.zeros((0, 3))), ("sensor_type", np.zeros(0)), ("sensor_datatype", np.zeros(0)),
                        ("sensor_objtype", np.zeros(0)), ("sensor_objid", np.zeros(0)), ("sensor_reftype", np.zeros(0)), ("sensor_refid", np.zeros(0)), ("sensor_dim", np.zeros(0)),
                        ("sensor_adr", np.zeros(0)), ("sensor_cutoff", np.zeros(0)),
                        ("hfield_size", np.zeros((0, 4))), ("hfield_nrow", np.zeros(0)), ("hfield_ncol", np.zeros(0)), ("hfield_adr", np.zeros(0)), ("hfield_data", np.zeros(0)),

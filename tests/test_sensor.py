@@ -213,12 +213,15 @@ FORCE_XML = """
       <body name="bob" pos="0 0 -.5"><geom type="sphere" size=".06" mass="0.7"/><site name="neck" pos="0 0 0"/></body>
     </body>
     <body name="slab" pos="1 0 .0495"><freejoint/><geom type="box" size=".2 .2 .05" mass="3"/><site name="slab_s" pos="0 0 0"/>
+      <site name="pad_all" type="box" size=".25 .25 .08" pos="0 0 0"/><site name="pad_half" type="box" size=".12 .25 .08" pos=".13 0 0"/>
+      <site name="pad_off" type="sphere" size=".03" pos="0 0 .3"/><site name="pad_cyl" type="cylinder" size=".5 .1" pos="0 0 -.04"/>
       <body name="load" pos="0 .05 .1"><geom type="sphere" size=".05" mass="0.4" contype="0" conaffinity="0"/><site name="load_s" pos="0 0 0" euler="30 0 0"/></body>
     </body>
   </worldbody>
   <sensor>
     <force name="f_root" site="root"/><torque name="t_root" site="root"/><force name="f_neck" site="neck"/>
     <force name="f_slab" site="slab_s"/><force name="f_load" site="load_s"/><torque name="t_load" site="load_s"/>
+    <touch name="touch_all" site="pad_all"/><touch name="touch_half" site="pad_half"/><touch name="touch_off" site="pad_off"/><touch name="touch_cyl" site="pad_cyl"/>
   </sensor>
 </mujoco>
 """
@@ -244,6 +247,11 @@ def test_oracle_force_torque_statics():
     assert np.allclose(g(name), want, atol=2e-3), (name, g(name), want)
   R_load = nm.quat_to_mat(nm.quat_mul(s.xquat[4], mjm.site_quat[mjm.sensor_objid[mjm.sensor_names.index("f_load")]]))
   assert np.allclose(g("f_load"), R_load.T @ np.array([0, 0, 0.4 * 9.81]), atol=2e-3) and np.allclose(g("t_load"), 0, atol=2e-3)
+  # touch: a pad around the whole slab feels the full weight on it, a pad over its +x half feels the two contacts there (half of it),
+  # a small pad above the slab none (the contact normals point away from it), a wide cylinder around the slab's base everything
+  wgt = (3 + 0.4) * 9.81
+  assert abs(g("touch_all")[0] - wgt) < 5e-3 and abs(g("touch_cyl")[0] - wgt) < 5e-3 and g("touch_off")[0] == 0.0
+  assert abs(g("touch_half")[0] - 0.5 * wgt) < 0.35  # (the load sits at y = .05: the four corner forces differ in y, not in x)
   # the bodies' external forces: the slab's contacts carry slab + load
   assert abs(s.cfrc_ext[3][5] - (3 + 0.4) * 9.81) < 5e-3
 
@@ -252,7 +260,7 @@ def test_oracle_force_torque_statics():
 def test_gpu_force_torque_vs_oracle():
   mjm = mjw.mjcf.from_xml_string(FORCE_XML)
   m = mjw.put_model(mjm)
-  assert m.nsensor_frc == 6 and m.nsensor_acc == 6
+  assert m.nsensor_frc == 6 and m.nsensor_acc == 10
   d = mjw.make_data(mjm, nworld=2, nconmax=16, njmax=64)
   q = d.qpos.numpy()
   q[1, 0] = 0.6  # world 1: the pendulum swings
