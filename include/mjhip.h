@@ -85,6 +85,7 @@ typedef struct MjhModel {
   const float* opt_gravity; int opt_gravity_nb;
   const float* opt_impratio_invsqrt; int opt_impratio_invsqrt_nb;
   const float* opt_ccd_tolerance; int opt_ccd_tolerance_nb;
+  const float* opt_magnetic; int opt_magnetic_nb;  /* Option.magnetic (types.py: magnetometer sensor) */
   const float* stat_meaninertia; int stat_meaninertia_nb;
   const float* qpos0; int qpos0_nb;
   const float* qpos_spring; int qpos_spring_nb;
@@ -338,7 +339,7 @@ int mjh_timed_steps(const MjhModel* m, const MjhData* d, int nstep, int step0, f
 int mjh_release_thread_resources(void);
 
 const char* mjh_last_error(void);
-#define MJH_ABI_VERSION 28
+#define MJH_ABI_VERSION 29
 int mjh_abi_version(void); /* returns MJH_ABI_VERSION of the library that was loaded */
 
 #ifdef __cplusplus

@@ -8,7 +8,7 @@
 #pragma once
 #include "dev_common.hpp"
 
-enum { SENS_TOUCH = 0, SENS_ACCELEROMETER = 1, SENS_FORCE = 4, SENS_TORQUE = 5, SENS_VELOCIMETER = 2, SENS_GYRO = 3, SENS_JOINTPOS = 9, SENS_JOINTVEL = 10, SENS_ACTUATORPOS = 13, SENS_ACTUATORVEL = 14, SENS_ACTUATORFRC = 15,
+enum { SENS_TOUCH = 0, SENS_ACCELEROMETER = 1, SENS_FORCE = 4, SENS_TORQUE = 5, SENS_MAGNETOMETER = 6, SENS_VELOCIMETER = 2, SENS_GYRO = 3, SENS_JOINTPOS = 9, SENS_JOINTVEL = 10, SENS_ACTUATORPOS = 13, SENS_ACTUATORVEL = 14, SENS_ACTUATORFRC = 15,
        SENS_JOINTACTFRC = 16, SENS_BALLQUAT = 18, SENS_BALLANGVEL = 19, SENS_JOINTLIMITPOS = 20, SENS_JOINTLIMITVEL = 21, SENS_JOINTLIMITFRC = 22, SENS_FRAMEPOS = 26, SENS_FRAMEQUAT = 27, SENS_FRAMEXAXIS = 28, SENS_FRAMEYAXIS = 29, SENS_FRAMEZAXIS = 30,
        SENS_FRAMELINVEL = 31, SENS_FRAMEANGVEL = 32, SENS_FRAMELINACC = 33, SENS_FRAMEANGACC = 34, SENS_SUBTREECOM = 35, SENS_SUBTREELINVEL = 36, SENS_SUBTREEANGMOM = 37, SENS_E_POTENTIAL = 43, SENS_E_KINETIC = 44, SENS_CLOCK = 45 };
 enum { OBJ_BODY = 1, OBJ_XBODY = 2, OBJ_GEOM = 5, OBJ_SITE = 6 };
@@ -147,6 +147,7 @@ __global__ void __launch_bounds__(256) k_sensor(MjhModel m, MjhData d, int stage
   else if (t == SENS_ACTUATORPOS) v[0] = d.actuator_length[(size_t)w * m.nu + id];
   else if (t == SENS_ACTUATORVEL) v[0] = d.actuator_velocity[(size_t)w * m.nu + id];
   else if (t == SENS_ACTUATORFRC) v[0] = d.actuator_force[(size_t)w * m.nu + id];
+  else if (t == SENS_MAGNETOMETER) put3(matT_mul(sens_frame(m, d, w, OBJ_SITE, id).mat, ld3(bf(m.opt_magnetic, m.opt_magnetic_nb, w, 3))));  // sensor.py:117-128
   else if (t == SENS_JOINTACTFRC) v[0] = d.qfrc_actuator[(size_t)w * m.nv + m.jnt_dofadr[id]];
   else if (t == SENS_E_POTENTIAL) v[0] = d.energy[2 * w];  // (k_energy ran just before)
   else if (t == SENS_E_KINETIC) v[0] = d.energy[2 * w + 1];

@@ -242,6 +242,7 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
   o.gravity = _arr(opt.gravity, f32).reshape(1, 3)
   o.impratio_invsqrt = np.array([1.0 / np.sqrt(max(float(opt.impratio), types.MJ_MINVAL))], dtype=f32)
   o.ccd_tolerance = np.array([float(getattr(opt, "ccd_tolerance", 1e-6))], dtype=f32)
+  o.magnetic = _arr(getattr(opt, "magnetic", [0.0, -0.5, 0.0]), f32).reshape(1, 3)
   for name in ("integrator", "cone", "solver", "iterations", "ls_iterations", "disableflags", "enableflags"):
     setattr(o, name, int(getattr(opt, name)))
   o.ccd_iterations = int(getattr(opt, "ccd_iterations", 35))
@@ -339,7 +340,7 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
   i32 = np.int32
   host.update(
     opt_timestep=o.timestep, opt_tolerance=o.tolerance, opt_ls_tolerance=o.ls_tolerance, opt_gravity=o.gravity,
-    opt_impratio_invsqrt=o.impratio_invsqrt, opt_ccd_tolerance=o.ccd_tolerance, stat_meaninertia=s.meaninertia,
+    opt_impratio_invsqrt=o.impratio_invsqrt, opt_ccd_tolerance=o.ccd_tolerance, opt_magnetic=o.magnetic, stat_meaninertia=s.meaninertia,
     qpos0=_arr(mjm.qpos0, f32).reshape(1, -1), qpos_spring=_arr(mjm.qpos_spring, f32).reshape(1, -1),
     body_parentid=parent, body_rootid=_arr(mjm.body_rootid, i32), body_weldid=_arr(mjm.body_weldid, i32),
     body_jntnum=_arr(mjm.body_jntnum, i32), body_jntadr=_arr(mjm.body_jntadr, i32), body_dofnum=dofnum, body_dofadr=dofadr,

@@ -1353,10 +1353,10 @@ def _compile(root, base_dir):
 
 # mjtSensor / mjtObj / mjtDataType / mjtStage values used below (MuJoCo's enums; UNPINNED here -- the mujoco package is absent: a real
 # MjModel carries its own numbers in sensor_type, which put_model compares with these)
-SENS = {"touch": 0, "accelerometer": 1, "force": 4, "torque": 5, "jointactuatorfrc": 16, "jointlimitpos": 20, "jointlimitvel": 21, "jointlimitfrc": 22, "e_potential": 43, "e_kinetic": 44, "framelinacc": 33, "frameangacc": 34, "velocimeter": 2, "gyro": 3, "jointpos": 9, "jointvel": 10, "actuatorpos": 13, "actuatorvel": 14, "actuatorfrc": 15, "ballquat": 18, "ballangvel": 19,
+SENS = {"touch": 0, "accelerometer": 1, "force": 4, "torque": 5, "magnetometer": 6, "jointactuatorfrc": 16, "jointlimitpos": 20, "jointlimitvel": 21, "jointlimitfrc": 22, "e_potential": 43, "e_kinetic": 44, "framelinacc": 33, "frameangacc": 34, "velocimeter": 2, "gyro": 3, "jointpos": 9, "jointvel": 10, "actuatorpos": 13, "actuatorvel": 14, "actuatorfrc": 15, "ballquat": 18, "ballangvel": 19,
         "framepos": 26, "framequat": 27, "framexaxis": 28, "frameyaxis": 29, "framezaxis": 30, "framelinvel": 31, "frameangvel": 32, "subtreecom": 35, "subtreelinvel": 36, "subtreeangmom": 37, "clock": 45}
 # sensors that keep their slot in sensordata (the reference's layout) but are not computed: the engine writes zeros and put_model warns
-SENS_UNSUPPORTED = {"magnetometer": (6, 3), "rangefinder": (7, 1),}
+SENS_UNSUPPORTED = {"rangefinder": (7, 1),}
 _SENS_DIM = {"touch": 1, "ballquat": 4, "framequat": 4, "jointactuatorfrc": 1, "jointlimitpos": 1, "jointlimitvel": 1, "jointlimitfrc": 1, "e_potential": 1, "e_kinetic": 1, "jointpos": 1, "jointvel": 1, "actuatorpos": 1, "actuatorvel": 1, "actuatorfrc": 1, "clock": 1}
 _SENS_STAGE = {"velocimeter": 2, "gyro": 2, "jointvel": 2, "actuatorvel": 2, "ballangvel": 2, "framelinvel": 2, "frameangvel": 2, "subtreelinvel": 2, "subtreeangmom": 2, "jointlimitvel": 2, "e_kinetic": 2, "touch": 3, "jointlimitfrc": 3, "jointactuatorfrc": 3, "actuatorfrc": 3, "accelerometer": 3, "force": 3, "torque": 3, "framelinacc": 3, "frameangacc": 3}  # default: POS (1)
 _OBJ = {"body": 1, "xbody": 2, "geom": 5, "site": 6, "camera": 7}
@@ -1386,7 +1386,7 @@ def _compile_sensors(m, root, site_names):
           raise ValueError(f"sensor <{e.tag}> on a joint of the wrong type")
       elif e.tag in ("actuatorpos", "actuatorvel", "actuatorfrc"):
         objtype, objid = 19, m.actuator_names.index(a["actuator"])  # mjOBJ_ACTUATOR
-      elif e.tag in ("velocimeter", "gyro", "accelerometer", "force", "torque", "touch"):
+      elif e.tag in ("velocimeter", "gyro", "accelerometer", "force", "torque", "touch", "magnetometer"):
         objtype, objid = 6, site_names.index(a["site"])
       elif e.tag in ("subtreecom", "subtreelinvel", "subtreeangmom"):
         objtype, objid = 1, m.body_names.index(a["body"])

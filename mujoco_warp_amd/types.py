@@ -267,6 +267,7 @@ class Option(_Dirty):
   gravity: DeviceArray = _arr(('*', 3), "float32")
   impratio_invsqrt: DeviceArray = _arr(('*',), "float32")
   ccd_tolerance: DeviceArray = _arr(('*',), "float32")
+  magnetic: DeviceArray = _arr(('*', 3), "float32")
   integrator: int = 0
   cone: int = 0
   solver: int = 0

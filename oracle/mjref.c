@@ -2788,7 +2788,7 @@ void ref_sleep(const RefModel* m, RefData* d) { /* sleep.py:824-999 */
 }
 
 /* ================================================================ sensors (sensor.py, subset) */
-enum { SENS_TOUCH = 0, SENS_ACCELEROMETER = 1, SENS_FORCE = 4, SENS_TORQUE = 5, SENS_FRAMELINACC = 33, SENS_FRAMEANGACC = 34, SENS_VELOCIMETER = 2, SENS_GYRO = 3, SENS_JOINTPOS = 9, SENS_JOINTVEL = 10, SENS_ACTUATORPOS = 13, SENS_ACTUATORVEL = 14, SENS_ACTUATORFRC = 15,
+enum { SENS_TOUCH = 0, SENS_MAGNETOMETER = 6, SENS_ACCELEROMETER = 1, SENS_FORCE = 4, SENS_TORQUE = 5, SENS_FRAMELINACC = 33, SENS_FRAMEANGACC = 34, SENS_VELOCIMETER = 2, SENS_GYRO = 3, SENS_JOINTPOS = 9, SENS_JOINTVEL = 10, SENS_ACTUATORPOS = 13, SENS_ACTUATORVEL = 14, SENS_ACTUATORFRC = 15,
        SENS_BALLQUAT = 18, SENS_BALLANGVEL = 19, SENS_FRAMEPOS = 26, SENS_FRAMEQUAT = 27, SENS_FRAMEXAXIS = 28, SENS_FRAMEYAXIS = 29, SENS_FRAMEZAXIS = 30,
        SENS_FRAMELINVEL = 31, SENS_FRAMEANGVEL = 32, SENS_SUBTREECOM = 35, SENS_SUBTREELINVEL = 36, SENS_SUBTREEANGMOM = 37, SENS_CLOCK = 45,
        SENS_JOINTACTFRC = 16, SENS_JOINTLIMITPOS = 20, SENS_JOINTLIMITVEL = 21, SENS_JOINTLIMITFRC = 22, SENS_E_POTENTIAL = 43, SENS_E_KINETIC = 44 };
@@ -3031,6 +3031,10 @@ static void sensor_stage(const RefModel* m, RefData* d, int stage) {
     else if (t == SENS_ACTUATORPOS) v[0] = d->actuator_length[id];
     else if (t == SENS_ACTUATORVEL) v[0] = d->actuator_velocity[id];
     else if (t == SENS_ACTUATORFRC) v[0] = d->actuator_force[id];
+    else if (t == SENS_MAGNETOMETER) { /* 117-128 */
+      frame_of(m, d, OBJ_SITE, id, NULL, mat, NULL);
+      matT_mul_vec(v, mat, m->magnetic);
+    }
     else if (t == SENS_JOINTACTFRC) v[0] = d->qfrc_actuator[m->jnt_dofadr[id]];
     else if (t == SENS_E_POTENTIAL || t == SENS_E_KINETIC) { /* sensor.py:2773-3018 energy_pos / energy_vel */
       if (t == SENS_E_KINETIC) {

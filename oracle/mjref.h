@@ -56,6 +56,7 @@ typedef struct RefModel {
   double meaninertia;
   double sleep_tolerance;
   double* gravity;
+  double* magnetic;
   double* qpos0;
   double* qpos_spring;
   int* body_parentid;

@@ -215,7 +215,7 @@ class RefSim:
       impratio=float(opt.impratio), meaninertia=float(mjm.stat.meaninertia))
     if scalars["cone"] != 0 and scalars["solver"] == 0:
       raise NotImplementedError("oracle: PGS with elliptic cones")
-    special = {"gravity": np.asarray(opt.gravity, dtype=np.float64), "pair_geom": pairs, "nxn_pairid": pairid,
+    special = {"gravity": np.asarray(opt.gravity, dtype=np.float64), "magnetic": np.asarray(getattr(opt, "magnetic", [0.0, -0.5, 0.0]), dtype=np.float64), "pair_geom": pairs, "nxn_pairid": pairid,
                "xpair_dim": getattr(mjm, "pair_dim", np.zeros(0)), "xpair_friction": getattr(mjm, "pair_friction", np.zeros(0)),
                "xpair_solref": getattr(mjm, "pair_solref", np.zeros(0)), "xpair_solreffriction": getattr(mjm, "pair_solreffriction", np.zeros(0)),
                "xpair_solimp": getattr(mjm, "pair_solimp", np.zeros(0)), "xpair_margin": getattr(mjm, "pair_margin", np.zeros(0)),

@@ -47,7 +47,7 @@ SENSOR_XML = """
     <framelinvel name="lv_rel" objtype="site" objname="hand" reftype="site" refname="tip"/>
     <frameangvel name="wv_rel" objtype="site" objname="hand" reftype="xbody" refname="arm"/>
     <framelinvel name="lv_self" objtype="geom" objname="sphere" reftype="geom" refname="sphere"/>
-    <velocimeter name="vel" site="imu"/><gyro name="gyro" site="imu"/>
+    <magnetometer name="mag" site="imu"/><velocimeter name="vel" site="imu"/><gyro name="gyro" site="imu"/>
     <gyro name="gyro_cut" site="imu" cutoff="0.5"/>
     <accelerometer name="acc" site="imu"/><framelinacc name="la" objtype="site" objname="imu"/><frameangacc name="aa" objtype="body" objname="ball"/>
     <framelinacc name="la_tip" objtype="site" objname="tip"/>
@@ -78,7 +78,7 @@ def _state(sim_or_none, mjm):
 
 def test_oracle_sensor_closed_forms():
   mjm = mjw.mjcf.from_xml_string(SENSOR_XML)
-  assert mjm.nsensor == 38 and mjm.nsensordata == int(mjm.sensor_dim.sum())
+  assert mjm.nsensor == 39 and mjm.nsensordata == int(mjm.sensor_dim.sum())
   s = ref.RefSim(mjm)
   s.qpos[:], s.qvel[:] = _state(s, mjm)
   s.ctrl[:] = [0.3, -0.2]
@@ -111,6 +111,7 @@ def test_oracle_sensor_closed_forms():
   assert np.allclose(g("gyro"), R_imu.T @ w_world, atol=1e-12)
   assert np.allclose(g("vel"), R_imu.T @ (s.qvel[4:7] + np.cross(w_world, Rb @ mjm.site_pos[3])), atol=1e-12)
   assert np.allclose(g("gyro_cut"), np.clip(g("gyro"), -0.5, 0.5))
+  assert np.allclose(g("mag"), R_imu.T @ np.array([0.0, -0.5, 0.0]), atol=1e-12)
   # joint-level readings: actuator force on the joint (motor gear 2 + position servo), the violated upper limit (0.7 rad > 30 deg), energies
   assert g("jaf")[0] == pytest.approx(2 * 0.3 + 10 * (-0.2 - th))
   assert g("jlp")[0] == pytest.approx(np.deg2rad(30) - th) and g("jlv")[0] == pytest.approx(-w) and g("jlf")[0] > 0
