@@ -3,6 +3,8 @@
 Builds libmjhip_clk.so with -DMJH_PHASE_CLOCK (lane 0 of every world adds shader-clock ticks between phase marks to a
 device table), runs N humanoid steps and prints each phase's share of its kernel and the absolute ticks per world-step.
 Run on the GPU box:  python tools/phase_clock.py [--solver cg|newton] [--build-only]
+(Last verified with ABI v16; the instrumented unity build of ABI v29 faults at launch -- not investigated: the figures quoted in
+DESIGN.md come from the v16 run.)
 """
 import argparse, ctypes, os, subprocess, sys
 import numpy as np
