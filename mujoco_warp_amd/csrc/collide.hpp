@@ -639,13 +639,17 @@ DEV void plane_mesh(V3 pn, V3 pp, V3 mp, const float* R, const float* vert, int 
 }
 
 // height field against a convex geom (collision_convex.py:60-161 _hfield_filter, 164-730; MuJoCo mjc_ConvexHField): in the height field's
-// frame, every triangular prism of the cells under the geom's bounding box runs GJK / EPA against the geom (one lane walks them in turn);
-// of the (at most 50) results up to four are kept: the deepest, the one furthest from it, the one furthest from that line, the one furthest
-// from the other two edges.  hf = this lane's slice of the workspace (7 words per kept prism, lane-interleaved).
-template <class Emit>
-__device__ __noinline__ void collide_hfield(const MjhModel& m, float tolerance, int iterations, int epa_iterations, int g1, int t2, V3 pos1, const float* mat1, V3 pos2,
-                                            const float* mat2, V3 size2, float rbound2, float fmargin, float margin, float* scratch, float* hf, int& overflow,
-                                            Emit&& emit, const float* vert2, int nvert2, int mesh2) {
+// frame, every triangular prism of the cells under the geom's bounding box runs GJK / EPA against the geom; of the (at most 50) results up
+// to four are kept: the deepest, the one furthest from it, the one furthest from that line, the one furthest from the other two edges.
+// The G lanes of the world evaluate G prisms of one pair at a time (hfield_fill: every lane has its own EPA workspace) and rank the kept
+// results by ballot into the owner lane's table (7 words per prism + a count, lane-interleaved) in the reference's row / column / triangle
+// order; the owner lane then selects and emits (hfield_select).
+template <int G>
+__device__ __noinline__ void hfield_fill(const MjhModel& m, float tolerance, int iterations, int epa_iterations, int g1, int t2, V3 pos1, const float* mat1, V3 pos2,
+                                         const float* mat2, V3 size2, float rbound2, float fmargin, float margin, float* scratch, float* hf, int& overflow, int lig,
+                                         bool owner, const float* vert2, int nvert2, int mesh2) {
+  int* hcount = reinterpret_cast<int*>(hf + (size_t)(7 * CCD_HF_MAXCONPAIR) * CCD_LANES);
+  if (owner) *hcount = 0;
   const int hid = m.geom_dataid[g1];
   const float* size1 = m.hfield_size + 4 * hid;
   const V3 pos = matT_mul(mat1, pos2 - pos1);
@@ -671,62 +675,86 @@ __device__ __noinline__ void collide_hfield(const MjhModel& m, float tolerance, 
   const int rmin = max(0, (int)floorf((ymin + size1[1]) * y_scale)), rmax = min(nrow - 1, (int)ceilf((ymax + size1[1]) * y_scale));
   const float dx = 2.0f * size1[0] / (float)(ncol - 1), dy = 2.0f * size1[1] / (float)(nrow - 1);
   b.margin = margin;  // the geom is inflated by half the margin, the prism tops are raised by the whole of it
-  V3 prism[6];
-  for (int i = 0; i < 6; ++i) prism[i] = V3{0.0f, 0.0f, 0.0f};
-  prism[0].z = prism[1].z = prism[2].z = -size1[3];
   const float ident[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-  float min_dist = MJ_MAXVAL;
-  V3 min_pos = V3{MJ_MAXVAL, MJ_MAXVAL, MJ_MAXVAL}, min_nrm = min_pos;
-  int min_id = -1, count = 0;
-  auto hfget = [&](int i, int q) -> float& { return hf[(size_t)(7 * i + q) * CCD_LANES]; };
-  auto hfpos = [&](int i) { return V3{hfget(i, 1), hfget(i, 2), hfget(i, 3)}; };
-  auto hfnrm = [&](int i) { return V3{hfget(i, 4), hfget(i, 5), hfget(i, 6)}; };
-  auto shift = [&](float x, float y, float z) {
-    prism[0] = prism[1];
-    prism[1] = prism[2];
-    prism[3] = prism[4];
-    prism[4] = prism[5];
-    prism[2].x = prism[5].x = x;
-    prism[2].y = prism[5].y = y;
-    prism[5].z = z;
+  // prism n of the strip of row r uses the strip's vertices n-2, n-1, n; vertex j sits at column cmin + j / 2, row r + 1 (j even) or r (j odd);
+  // the reference visits c = cmin + 1 .. cmax, k = 0, 1, i.e. n = 2 (c - cmin) + k
+  const int per_row = 2 * max(cmax - cmin, 0), total = max(rmax - rmin, 0) * per_row;
+  auto vertex = [&](int r, int j, float& x, float& y, float& z) {
+    const int col = cmin + (j >> 1), row = r + ((j & 1) ? 0 : 1);
+    x = dx * (float)col - size1[0];
+    y = dy * (float)row - size1[1];
+    z = m.hfield_data[adr + row * ncol + col] * size1[2] + margin;
   };
-  for (int r = rmin; r < rmax; ++r) {
-    for (int k = 0; k < 2; ++k) {
-      const int rr = r + (k == 0 ? 1 : 0);
-      shift(dx * (float)cmin - size1[0], dy * (float)rr - size1[1], m.hfield_data[adr + rr * ncol + cmin] * size1[2] + margin);
-    }
-    for (int c = cmin + 1; c <= cmax; ++c)
-      for (int k = 0; k < 2; ++k) {
-        if (count >= CCD_HF_MAXCONPAIR) {
-          overflow |= OVF_HFIELD;
-          continue;
-        }
-        const int rr = r + (k == 0 ? 1 : 0);
-        shift(dx * (float)c - size1[0], dy * (float)rr - size1[1], m.hfield_data[adr + rr * ncol + c] * size1[2] + margin);
-        if (prism[3].z < zmin && prism[4].z < zmin && prism[5].z < zmin) continue;
+  int count = 0, last_kept = -1;
+  for (int b0 = 0; b0 < total && count < CCD_HF_MAXCONPAIR; b0 += G) {
+    const int idx = b0 + lig;
+    bool kept = false;
+    float dist = 0.0f;
+    V3 w1 = V3{0, 0, 0}, w2 = w1;
+    if (idx < total) {
+      const int r = rmin + idx / per_row, n = 2 + idx % per_row;
+      V3 prism[6];
+      for (int q = 0; q < 3; ++q) {
+        float x, y, z;
+        vertex(r, n - 2 + q, x, y, z);
+        prism[q] = V3{x, y, -size1[3]};
+        prism[3 + q] = V3{x, y, z};
+      }
+      if (!(prism[3].z < zmin && prism[4].z < zmin && prism[5].z < zmin)) {
         const V3 centre = (prism[0] + prism[1] + prism[2] + prism[3] + prism[4] + prism[5]) * (1.0f / 6.0f);
         const CcdGeom a = CcdGeom{G_HFIELD, centre, ident, V3{0, 0, 0}, 0.0f, nullptr, 0, -1, -1, nullptr, -1, prism};
-        b.index = -1;  // (the reference passes its geom structs by value: every prism starts from the uncached geom)
-        float dist;
-        V3 w1, w2;
+        CcdGeom bb = b;  // (the reference passes its geom structs by value: every prism starts from the uncached geom)
         int face;
         Poly pt;
-        const int n = ccd_run(tolerance, 0.0f, iterations, epa_iterations, a, b, scratch, dist, w1, w2, overflow, face, pt);
-        if (n == 0) continue;
+        kept = ccd_run(tolerance, 0.0f, iterations, epa_iterations, a, bb, scratch, dist, w1, w2, overflow, face, pt) != 0;
+      }
+    }
+    const unsigned long long bits = gballot<G>(kept);
+    const int slot = count + __popcll(bits & ((1ull << lig) - 1ull));
+    if (kept) {
+      if (slot < CCD_HF_MAXCONPAIR) {
         const V3 p = mat_mul(mat1, 0.5f * (w1 + w2)) + pos1;
         const V3 nrm = mat_mul(mat1, make_frame3(w1 - w2).a);
-        hfget(count, 0) = dist;
-        hfget(count, 1) = p.x; hfget(count, 2) = p.y; hfget(count, 3) = p.z;
-        hfget(count, 4) = nrm.x; hfget(count, 5) = nrm.y; hfget(count, 6) = nrm.z;
-        if (dist < min_dist) {
-          min_dist = dist;
-          min_nrm = nrm;
-          min_pos = p;
-          min_id = count;
-        }
-        ++count;
+        float* e = hf + (size_t)(7 * slot) * CCD_LANES;
+        e[0] = dist;
+        e[1 * CCD_LANES] = p.x; e[2 * CCD_LANES] = p.y; e[3 * CCD_LANES] = p.z;
+        e[4 * CCD_LANES] = nrm.x; e[5 * CCD_LANES] = nrm.y; e[6 * CCD_LANES] = nrm.z;
+      } else {
+        overflow |= OVF_HFIELD;
       }
+    }
+    if (bits) {
+      // index of the prism that filled the table's last slot (if any): prisms after it overflow like in the reference's serial walk
+      unsigned long long upto = bits;
+      int need = CCD_HF_MAXCONPAIR - count;  // kept results still fitting
+      if (__popcll(bits) >= need) {
+        for (int q = 1; q < need; ++q) upto &= upto - 1;  // drop the need-1 lowest set bits: the lowest remaining is the filler
+        last_kept = b0 + (__ffsll((long long)upto) - 1);
+      }
+    }
+    count += __popcll(bits);
   }
+  if (count >= CCD_HF_MAXCONPAIR && last_kept >= 0 && last_kept < total - 1) overflow |= OVF_HFIELD;
+  __threadfence_block();
+  if (owner) *hcount = min(count, CCD_HF_MAXCONPAIR);
+}
+// the owner lane's part: up to four of the table's entries (collision_convex.py:505-730)
+template <class Emit>
+DEV void hfield_select(float* hf, Emit&& emit) {
+  const int count = *reinterpret_cast<const int*>(hf + (size_t)(7 * CCD_HF_MAXCONPAIR) * CCD_LANES);
+  auto hfget = [&](int i, int q) -> float { return hf[(size_t)(7 * i + q) * CCD_LANES]; };
+  auto hfpos = [&](int i) { return V3{hfget(i, 1), hfget(i, 2), hfget(i, 3)}; };
+  auto hfnrm = [&](int i) { return V3{hfget(i, 4), hfget(i, 5), hfget(i, 6)}; };
+  float min_dist = MJ_MAXVAL;
+  V3 min_pos = V3{MJ_MAXVAL, MJ_MAXVAL, MJ_MAXVAL}, min_nrm = min_pos;
+  int min_id = -1;
+  for (int i = 0; i < count; ++i)
+    if (hfget(i, 0) < min_dist) {
+      min_dist = hfget(i, 0);
+      min_pos = hfpos(i);
+      min_nrm = hfnrm(i);
+      min_id = i;
+    }
   int nout = 0;
   auto put = [&](float dist, V3 p, V3 nrm) {
     const Frame f = make_frame3(nrm);
@@ -1281,12 +1309,38 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
   const int ccd_cache0 = ccd_poly_words(max(m.ccd_iterations, m.epa_iterations));  // first word of the lane's contact cache
   const bool box_ccd = !(m.disableflags & DSBL_NATIVECCD);  // box-box: CCD + multi-contact unless the flag asks for mjc_BoxBox
   int ccd_overflow = 0;
+  // height-field candidates: the lanes whose candidate is one (`want`) are served in turn by the whole group (hfield_fill)
+  auto hf_pair = [&](int p) {
+    int g1, g2, t1, t2;
+    load_pair(p, g1, g2, t1, t2);
+    return t1 == G_HFIELD && t2 >= G_SPHERE;
+  };
+  int hf_have = -1;  // the candidate whose results this lane's table holds (pass 2 refills it only if a later candidate replaced them)
+  auto hf_coop = [&](bool want, int mycand, int myci) {
+    unsigned long long bits = gballot<G>(want);
+    while (bits) {
+      const int owner = __ffsll((long long)bits) - 1;
+      bits &= bits - 1;
+      int g1, g2, t1, t2;
+      load_pair(__shfl(mycand, owner, G), g1, g2, t1, t2);
+      const int pid = m.nexplicit ? m.nxn_pairid[__shfl(mycand, owner, G)] : -1;
+      const float margin = pid >= 0 ? m.pair_margin[pid] : gmargin[g1] + gmargin[g2];
+      const float* mv2;
+      int mn2;
+      mesh_of(g2, t2, mv2, mn2);
+      float* table = ccd_scratch - (lig & (CCD_LANES - 1)) + (owner & (CCD_LANES - 1)) + (size_t)hf0 * CCD_LANES;
+      hfield_fill<G>(m, ccd_tol, ccd_it, epa_it, g1, t2, ld3(gxpos + 3 * g1), gxmat + 9 * g1, ld3(gxpos + 3 * g2), gxmat + 9 * g2, ld3(gsize + 3 * g2), rbound[g2],
+                     gmargin[g1] + gmargin[g2], margin, ccd_scratch, table, ccd_overflow, lig, lig == owner, mv2, mn2, t2 == G_MESH ? m.geom_dataid[g2] : -1);
+      if (lig == owner) hf_have = myci;
+    }
+  };
   int ncon = 0;
   for (int base = 0; base < ncand; base += G) {
     const int ci = base + lig;
     // which of the collider's (at most 8) contacts pass the margin test: pass 2 replays this mask instead of
     // re-testing, so the two passes agree even if the compiler contracts the distance arithmetic differently
     unsigned mask = 0u;
+    if (HEAVY && m.nhfield > 0 && ccd_scratch) hf_coop(ci < ncand && hf_pair(cand[ci]), ci < ncand ? cand[ci] : 0, ci);
     if (ci < ncand) {
       int g1, g2, t1, t2;
       load_pair(cand[ci], g1, g2, t1, t2);
@@ -1299,11 +1353,8 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
       int mn1, mn2;
       mesh_of(g1, t1, mv1, mn1);
       mesh_of(g2, t2, mv2, mn2);
-      if (HEAVY && t1 == G_HFIELD) {  // (not cached: each of its contacts has its own distance and frame; pass 2 recomputes)
-        if (t2 >= G_SPHERE && ccd_scratch)
-          collide_hfield(m, ccd_tol, ccd_it, epa_it, g1, t2, ld3(gxpos + 3 * g1), gxmat + 9 * g1, ld3(gxpos + 3 * g2), gxmat + 9 * g2, ld3(gsize + 3 * g2), rbound[g2],
-                         gmargin[g1] + gmargin[g2], margin, ccd_scratch, ccd_scratch + (size_t)hf0 * CCD_LANES, ccd_overflow, count, mv2, mn2,
-                         t2 == G_MESH ? m.geom_dataid[g2] : -1);
+      if (HEAVY && t1 == G_HFIELD) {  // (the group filled this lane's table just above; pass 2 reads it again)
+        if (t2 >= G_SPHERE && ccd_scratch) hfield_select(ccd_scratch + (size_t)hf0 * CCD_LANES, count);
       } else if (HEAVY && (is_convex_pair(t1, t2) || (box_ccd && t1 == G_BOX && t2 == G_BOX))) {
         const int cslot_c = base / G;  // this lane's k-th candidate
         float* cache = (ccd_scratch && cslot_c < CCD_CACHE_SLOTS) ? ccd_scratch + (size_t)(ccd_cache0 + cslot_c * CCD_CACHE_WORDS) * CCD_LANES : nullptr;
@@ -1357,6 +1408,15 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
     pc.mark(3);
     for (int base = 0; base < ncand; base += G) {
       const int ci = base + lig;
+      if (HEAVY && m.nhfield > 0 && ccd_scratch) {  // height-field candidates with contacts in this window: the group refills their tables
+        bool want = false;
+        if (ci < ncand && hf_pair(cand[ci])) {
+          const unsigned mk = (unsigned)cslot[ci] & 0xffu;
+          const int s0 = cslot[ci] >> 8;
+          want = mk != 0u && s0 < wend && s0 + __popc(mk) > wbase && hf_have != ci;
+        }
+        hf_coop(want, ci < ncand ? cand[ci] : 0, ci);
+      }
       if (ci >= ncand) continue;
       const unsigned mask = (unsigned)cslot[ci] & 0xffu;
       int slot = cslot[ci] >> 8;
@@ -1392,13 +1452,7 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
                      ++slot;
                    };
       if (HEAVY && t1 == G_HFIELD) {
-        const float* mv2;
-        int mn2;
-        mesh_of(g2, t2, mv2, mn2);
-        if (t2 >= G_SPHERE && ccd_scratch)
-          collide_hfield(m, ccd_tol, ccd_it, epa_it, g1, t2, ld3(gxpos + 3 * g1), gxmat + 9 * g1, ld3(gxpos + 3 * g2), gxmat + 9 * g2, ld3(gsize + 3 * g2), rbound[g2],
-                         gmargin[g1] + gmargin[g2], margin, ccd_scratch, ccd_scratch + (size_t)hf0 * CCD_LANES, ccd_overflow, write, mv2, mn2,
-                         t2 == G_MESH ? m.geom_dataid[g2] : -1);
+        if (t2 >= G_SPHERE && ccd_scratch) hfield_select(ccd_scratch + (size_t)hf0 * CCD_LANES, write);
       } else if (HEAVY && (is_convex_pair(t1, t2) || (box_ccd && t1 == G_BOX && t2 == G_BOX))) {
         const int cslot_c = base / G;
         if (ccd_scratch && cslot_c < CCD_CACHE_SLOTS) {  // replay the contacts pass 1 found

@@ -37,7 +37,7 @@ __host__ __device__ inline int ccd_poly_words(int iterations) {
   return 8 * (5 + it) + 5 * (6 + CCD_EPAFACES * it) + CCD_MAX_HORIZON;
 }
 #define CCD_HF_MAXCONPAIR 50  // mjMAXCONPAIR (types.py:27): prisms of one height-field pair whose result is kept
-#define CCD_HF_WORDS (7 * CCD_HF_MAXCONPAIR)  // distance, position, normal of each (models with height fields only)
+#define CCD_HF_WORDS (7 * CCD_HF_MAXCONPAIR + 1)  // distance, position, normal of each + their count (models with height fields only)
 __host__ __device__ inline int ccd_words(int iterations, int hfield = 0) {
   return ccd_poly_words(iterations) + CCD_CACHE_SLOTS * CCD_CACHE_WORDS + (hfield ? CCD_HF_WORDS : 0);
 }

@@ -501,7 +501,7 @@ def _ccd_words(iterations: int, hfield: int = 0) -> int:
   """Workspace words of one lane's EPA polytope (csrc/convex.hpp ccd_words)."""
   it = min(int(iterations), 64)
   # polytope + contact cache (CCD_CACHE_SLOTS x CCD_CACHE_WORDS) + the height-field result table (CCD_HF_WORDS)
-  return 8 * (5 + it) + 5 * (6 + 5 * it) + 24 + 4 * 24 + (7 * 50 if hfield else 0)
+  return 8 * (5 + it) + 5 * (6 + 5 * it) + 24 + 4 * 24 + (7 * 50 + 1 if hfield else 0)
 
 
 def contact_cap(nconmax: int) -> int:
