@@ -144,6 +144,8 @@ typedef struct MjhModel {
   const int* M_rownnz; const int* M_rowadr; const int* M_colind;
   /* geoms */
   const int* geom_type; const int* geom_condim; const int* geom_bodyid; const int* geom_priority;
+  /* ray casting (ray.py:52 _ray_eliminate): group and visibility of the geoms; nmat materials */
+  int nmat; const int* geom_group; const int* geom_matid; const float* geom_rgba; /* [ngeom, 4] */ const float* mat_rgba; /* [nmat, 4] */
   const int* geom_dataid;       /* [ngeom] mesh id of mesh geoms, -1 otherwise (types.py:1266)                  */
   const int* mesh_vertadr; const int* mesh_vertnum; /* [nmesh] first vertex / number of vertices (types.py:1707-1709) */
   const float* mesh_vert;       /* [nmeshvert, 3] vertices in the mesh (= geom) frame; searched exhaustively by the convex narrowphase */
@@ -313,6 +315,11 @@ int mjh_qld_dense(const MjhModel* m, const MjhData* d, float* qld_dense, int str
 int mjh_contact_force(const MjhModel* m, const MjhData* d, const int* contact_ids, int n, int to_world_frame, float* force, void* stream);
 /* support.jac (support.py:581): Jacobians [nworld, 3, nv] of point[w] (world coordinates) moving with body[w]; jacp or jacr may be NULL */
 int mjh_jac(const MjhModel* m, const MjhData* d, float* jacp, float* jacr, const float* point, const int* body, void* stream);
+/* ray.rays (ray.py:1219): nearest intersection of nray rays per world with the primitive geoms (mesh / height-field geoms are not
+   intersected).  pnt, vec [pnt_nworld (1 or nworld), nray, 3] device; geomgroup: 6 host floats (NULL or six -1: every group; otherwise
+   groups whose entry is 0 are skipped); bodyexclude [nray] device ints or NULL; dist [nworld, nray] (-1: no hit); geomid, normal may be NULL */
+int mjh_rays(const MjhModel* m, const MjhData* d, const float* pnt, const float* vec, int pnt_nworld, int nray, const float* geomgroup,
+             int flg_static, const int* bodyexclude, float* dist, int* geomid, float* normal, void* stream);
 int mjh_efc_j_sparse(const MjhModel* m, const MjhData* d, int njmax_nnz, int* rownnz, int* rowadr, int* colind, float* values, void* stream);
 
 /* cli._ctrl_noise cli.py:103-145; ctrl_center may be NULL (-> actuator midpoint); worldid is global */
@@ -339,7 +346,7 @@ int mjh_timed_steps(const MjhModel* m, const MjhData* d, int nstep, int step0, f
 int mjh_release_thread_resources(void);
 
 const char* mjh_last_error(void);
-#define MJH_ABI_VERSION 29
+#define MJH_ABI_VERSION 30
 int mjh_abi_version(void); /* returns MJH_ABI_VERSION of the library that was loaded */
 
 #ifdef __cplusplus

@@ -672,6 +672,20 @@ int mjh_jac(const MjhModel* m, const MjhData* d, float* jacp, float* jacr, const
   return MJH_OK;
 }
 
+int mjh_rays(const MjhModel* m, const MjhData* d, const float* pnt, const float* vec, int pnt_nworld, int nray, const float* geomgroup, int flg_static,
+             const int* bodyexclude, float* dist, int* geomid, float* normal, void* stream) {
+  TRY(check(m, d));
+  if (!pnt || !vec || !dist) return fail(MJH_E_ARG, "mjh_rays: null pnt / vec / dist");
+  if (nray < 0 || (pnt_nworld != 1 && pnt_nworld != d->nworld)) return fail(MJH_E_ARG, "mjh_rays: pnt_nworld must be 1 or nworld");
+  if (nray == 0) return MJH_OK;
+  RayGroup gg;
+  for (int i = 0; i < 6; ++i) gg.g[i] = geomgroup ? geomgroup[i] : -1.0f;
+  hipLaunchKernelGGL(k_rays, dim3((d->nworld * nray + 255) / 256), dim3(256), 0, (hipStream_t)stream, *m, *d, pnt, vec, pnt_nworld, nray, gg, flg_static, bodyexclude, dist,
+                     geomid, normal);
+  HIPCHK(hipGetLastError());
+  return MJH_OK;
+}
+
 int mjh_efc_j_sparse(const MjhModel* m, const MjhData* d, int njmax_nnz, int* rownnz, int* rowadr, int* colind, float* values, void* stream) {
   TRY(check(m, d));
   if (njmax_nnz < 0 || !rownnz || !rowadr || (njmax_nnz > 0 && (!colind || !values))) return fail(MJH_E_ARG, "mjh_efc_j_sparse: null output or negative njmax_nnz");

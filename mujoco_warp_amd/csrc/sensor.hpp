@@ -7,10 +7,11 @@
 // collision sensors, energies (put_model / the loader raise).
 #pragma once
 #include "dev_common.hpp"
+#include "ray.hpp"
 
 enum { SENS_TOUCH = 0, SENS_ACCELEROMETER = 1, SENS_FORCE = 4, SENS_TORQUE = 5, SENS_MAGNETOMETER = 6, SENS_VELOCIMETER = 2, SENS_GYRO = 3, SENS_JOINTPOS = 9, SENS_JOINTVEL = 10, SENS_ACTUATORPOS = 13, SENS_ACTUATORVEL = 14, SENS_ACTUATORFRC = 15,
        SENS_JOINTACTFRC = 16, SENS_BALLQUAT = 18, SENS_BALLANGVEL = 19, SENS_JOINTLIMITPOS = 20, SENS_JOINTLIMITVEL = 21, SENS_JOINTLIMITFRC = 22, SENS_FRAMEPOS = 26, SENS_FRAMEQUAT = 27, SENS_FRAMEXAXIS = 28, SENS_FRAMEYAXIS = 29, SENS_FRAMEZAXIS = 30,
-       SENS_FRAMELINVEL = 31, SENS_FRAMEANGVEL = 32, SENS_FRAMELINACC = 33, SENS_FRAMEANGACC = 34, SENS_SUBTREECOM = 35, SENS_SUBTREELINVEL = 36, SENS_SUBTREEANGMOM = 37, SENS_E_POTENTIAL = 43, SENS_E_KINETIC = 44, SENS_CLOCK = 45 };
+       SENS_FRAMELINVEL = 31, SENS_FRAMEANGVEL = 32, SENS_FRAMELINACC = 33, SENS_FRAMEANGACC = 34, SENS_SUBTREECOM = 35, SENS_SUBTREELINVEL = 36, SENS_SUBTREEANGMOM = 37, SENS_E_POTENTIAL = 43, SENS_E_KINETIC = 44, SENS_CLOCK = 45, SENS_RANGEFINDER = 7 };
 enum { OBJ_BODY = 1, OBJ_XBODY = 2, OBJ_GEOM = 5, OBJ_SITE = 6 };
 
 struct SensFrame {
@@ -163,6 +164,13 @@ __global__ void __launch_bounds__(256) k_sensor(MjhModel m, MjhData d, int stage
     v[0] = q.w; v[1] = q.x; v[2] = q.y; v[3] = q.z;
   } else if (t == SENS_BALLANGVEL) put3(ld3(d.qvel + (size_t)w * m.nv + m.jnt_dofadr[id]));
   else if (t == SENS_CLOCK) v[0] = d.time[w];
+  else if (t == SENS_RANGEFINDER) {  // sensor.py:179-196, 815-845: along the site's z axis, past the site's own body, every group, static geoms too
+    const float* xm = d.site_xmat + ((size_t)w * m.nsite + id) * 9;
+    const RayGroup all = {{MJ_MAXVAL, MJ_MAXVAL, MJ_MAXVAL, MJ_MAXVAL, MJ_MAXVAL, MJ_MAXVAL}};
+    int g;
+    V3 n;
+    v[0] = ray_world(m, d, w, ld3(d.site_xpos + ((size_t)w * m.nsite + id) * 3), V3{xm[2], xm[5], xm[8]}, all, 1, m.site_bodyid[id], g, n);
+  }
   else if (t == SENS_SUBTREECOM) put3(ld3(d.subtree_com + ((size_t)w * m.nbody + id) * 3));
   else if (t == SENS_SUBTREELINVEL) put3(ld3(d.subtree_linvel + ((size_t)w * m.nbody + id) * 3));  // (k_subtree_vel ran just before)
   else if (t == SENS_SUBTREEANGMOM) put3(ld3(d.subtree_angmom + ((size_t)w * m.nbody + id) * 3));

@@ -351,7 +351,9 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
     dof_leveladr=dleveladr, tree_dofadr=tree_dofadr, tree_dofnum=tree_dofnum, dof_treeid=dof_treeid, body_treeid=body_treeid,
     M_rownnz=_arr(mjm.M_rownnz, i32), M_rowadr=_arr(mjm.M_rowadr, i32), M_colind=_arr(mjm.M_colind, i32),
     geom_type=_arr(mjm.geom_type, i32), geom_condim=_arr(mjm.geom_condim, i32), geom_bodyid=_arr(mjm.geom_bodyid, i32),
-    geom_priority=_arr(mjm.geom_priority, i32), geom_dataid=_arr(getattr(mjm, "geom_dataid", np.full(ngeom, -1)), i32),
+    geom_priority=_arr(mjm.geom_priority, i32), geom_group=_arr(getattr(mjm, "geom_group", np.zeros(ngeom)), i32),
+    geom_matid=_arr(getattr(mjm, "geom_matid", np.full(ngeom, -1)), i32), geom_rgba=_arr(getattr(mjm, "geom_rgba", np.tile([0.5, 0.5, 0.5, 1.0], (ngeom, 1))), f32).reshape(-1, 4),
+    mat_rgba=_arr(getattr(mjm, "mat_rgba", np.zeros((0, 4))), f32).reshape(-1, 4), geom_dataid=_arr(getattr(mjm, "geom_dataid", np.full(ngeom, -1)), i32),
     mesh_vertadr=_arr(getattr(mjm, "mesh_vertadr", np.zeros(0)), i32), mesh_vertnum=_arr(getattr(mjm, "mesh_vertnum", np.zeros(0)), i32),
     mesh_vert=_arr(getattr(mjm, "mesh_vert", np.zeros((0, 3))), f32).reshape(-1, 3),
     sensor_type=_arr(getattr(mjm, "sensor_type", np.zeros(0)), i32), sensor_datatype=_arr(getattr(mjm, "sensor_datatype", np.zeros(0)), i32),
@@ -402,6 +404,7 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
   if not (int(opt.disableflags) & int(types.DisableBit.MULTICCD)) and nboxmesh + nmeshmesh > 0:
     m.npolygonmax = max(int(host["mesh_polyvertnum"].max()) if m.nmeshpoly else 0, 4 if nboxmesh else m.npolygonmax)
   m.nmesh = int(host["mesh_vertadr"].shape[0])
+  m.nmat = int(host["mat_rgba"].shape[0])
   m.sleep_enabled = int(bool(int(opt.enableflags) & int(types.EnableBit.SLEEP)) and not (int(opt.disableflags) & int(types.DisableBit.ISLAND)))
   m.opt_sleep_tolerance = float(getattr(opt, "sleep_tolerance", 1e-4))
   host["tree_sleep_policy"] = _arr(getattr(mjm, "tree_sleep_policy", np.full(m.ntree, int(types.SleepPolicy.AUTO_ALLOWED))), i32)

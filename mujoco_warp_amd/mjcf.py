@@ -688,6 +688,15 @@ def _compile(root, base_dir):
     for he in asset.findall("hfield"):
       hfield_assets[he.get("name")] = he.attrib
 
+  mat_names, mat_rgba = [], []  # materials: only their colour is kept (rays skip geoms whose material is fully transparent)
+  for asset in root.findall("asset"):
+    for ma in asset.findall("material"):
+      base, explicit = _resolve("material", ma, table, None)
+      a = dict(base)
+      a.update(explicit)
+      mat_names.append(a.get("name", ""))
+      mat_rgba.append(_vec(a, "rgba", [1.0, 1.0, 1.0, 1.0]))
+
   bodies, joints, geoms, sites = [], [], [], []
   world = _Body()
   world.name, world.parent, world.pos, world.quat = "world", 0, np.zeros(3), np.array([1.0, 0, 0, 0])
@@ -706,6 +715,8 @@ def _compile(root, base_dir):
     g["conaffinity"] = int(a.get("conaffinity", 1))
     g["condim"] = int(a.get("condim", 3))
     g["group"] = int(a.get("group", 0))
+    g["rgba"] = _vec(a, "rgba", [0.5, 0.5, 0.5, 1.0])
+    g["matid"] = mat_names.index(a["material"]) if a.get("material") in mat_names else -1
     g["priority"] = int(a.get("priority", 0))
     g["friction"] = _vec(a, "friction", [1.0, 0.005, 0.0001])
     g["solmix"] = float(a.get("solmix", 1.0))
@@ -1074,6 +1085,10 @@ def _compile(root, base_dir):
     if g["meshdata"] is not None:
       m.geom_dataid[i] = mesh_names.index(g["mesh"])
   m.geom_group = np.array([g["group"] for g in gl], dtype=np.int32)
+  m.geom_rgba = np.array([g["rgba"] for g in gl], dtype=np.float64).reshape(-1, 4)
+  m.geom_matid = np.array([g["matid"] for g in gl], dtype=np.int32)
+  m.nmat = len(mat_names)
+  m.mat_rgba = np.array(mat_rgba, dtype=np.float64).reshape(-1, 4)
   m.geom_priority = np.array([g["priority"] for g in gl], dtype=np.int32)
   m.geom_solmix = np.array([g["solmix"] for g in gl], dtype=np.float64)
   m.geom_solref = np.array([g["solref"] for g in gl]).reshape(-1, 2)
@@ -1354,10 +1369,10 @@ def _compile(root, base_dir):
 # mjtSensor / mjtObj / mjtDataType / mjtStage values used below (MuJoCo's enums; UNPINNED here -- the mujoco package is absent: a real
 # MjModel carries its own numbers in sensor_type, which put_model compares with these)
 SENS = {"touch": 0, "accelerometer": 1, "force": 4, "torque": 5, "magnetometer": 6, "jointactuatorfrc": 16, "jointlimitpos": 20, "jointlimitvel": 21, "jointlimitfrc": 22, "e_potential": 43, "e_kinetic": 44, "framelinacc": 33, "frameangacc": 34, "velocimeter": 2, "gyro": 3, "jointpos": 9, "jointvel": 10, "actuatorpos": 13, "actuatorvel": 14, "actuatorfrc": 15, "ballquat": 18, "ballangvel": 19,
-        "framepos": 26, "framequat": 27, "framexaxis": 28, "frameyaxis": 29, "framezaxis": 30, "framelinvel": 31, "frameangvel": 32, "subtreecom": 35, "subtreelinvel": 36, "subtreeangmom": 37, "clock": 45}
+        "framepos": 26, "framequat": 27, "framexaxis": 28, "frameyaxis": 29, "framezaxis": 30, "framelinvel": 31, "frameangvel": 32, "subtreecom": 35, "subtreelinvel": 36, "subtreeangmom": 37, "clock": 45, "rangefinder": 7}
 # sensors that keep their slot in sensordata (the reference's layout) but are not computed: the engine writes zeros and put_model warns
-SENS_UNSUPPORTED = {"rangefinder": (7, 1),}
-_SENS_DIM = {"touch": 1, "ballquat": 4, "framequat": 4, "jointactuatorfrc": 1, "jointlimitpos": 1, "jointlimitvel": 1, "jointlimitfrc": 1, "e_potential": 1, "e_kinetic": 1, "jointpos": 1, "jointvel": 1, "actuatorpos": 1, "actuatorvel": 1, "actuatorfrc": 1, "clock": 1}
+SENS_UNSUPPORTED = {}
+_SENS_DIM = {"touch": 1, "rangefinder": 1, "ballquat": 4, "framequat": 4, "jointactuatorfrc": 1, "jointlimitpos": 1, "jointlimitvel": 1, "jointlimitfrc": 1, "e_potential": 1, "e_kinetic": 1, "jointpos": 1, "jointvel": 1, "actuatorpos": 1, "actuatorvel": 1, "actuatorfrc": 1, "clock": 1}
 _SENS_STAGE = {"velocimeter": 2, "gyro": 2, "jointvel": 2, "actuatorvel": 2, "ballangvel": 2, "framelinvel": 2, "frameangvel": 2, "subtreelinvel": 2, "subtreeangmom": 2, "jointlimitvel": 2, "e_kinetic": 2, "touch": 3, "jointlimitfrc": 3, "jointactuatorfrc": 3, "actuatorfrc": 3, "accelerometer": 3, "force": 3, "torque": 3, "framelinacc": 3, "frameangacc": 3}  # default: POS (1)
 _OBJ = {"body": 1, "xbody": 2, "geom": 5, "site": 6, "camera": 7}
 
@@ -1386,7 +1401,7 @@ def _compile_sensors(m, root, site_names):
           raise ValueError(f"sensor <{e.tag}> on a joint of the wrong type")
       elif e.tag in ("actuatorpos", "actuatorvel", "actuatorfrc"):
         objtype, objid = 19, m.actuator_names.index(a["actuator"])  # mjOBJ_ACTUATOR
-      elif e.tag in ("velocimeter", "gyro", "accelerometer", "force", "torque", "touch", "magnetometer"):
+      elif e.tag in ("velocimeter", "gyro", "accelerometer", "force", "torque", "touch", "magnetometer", "rangefinder"):
         objtype, objid = 6, site_names.index(a["site"])
       elif e.tag in ("subtreecom", "subtreelinvel", "subtreeangmom"):
         objtype, objid = 1, m.body_names.index(a["body"])

@@ -375,6 +375,11 @@ class Model(_Dirty):
   geom_condim: DeviceArray = _arr(('ngeom',), "int32")
   geom_bodyid: DeviceArray = _arr(('ngeom',), "int32")
   geom_priority: DeviceArray = _arr(('ngeom',), "int32")
+  nmat: int = 0
+  geom_group: DeviceArray = _arr(('ngeom',), "int32")
+  geom_matid: DeviceArray = _arr(('ngeom',), "int32")
+  geom_rgba: DeviceArray = _arr(('ngeom', 4), "float32")
+  mat_rgba: DeviceArray = _arr(('nmat', 4), "float32")
   geom_solmix: DeviceArray = _arr(('*', 'ngeom'), "float32")
   geom_solref: DeviceArray = _arr(('*', 'ngeom', 2), "float32")
   geom_solimp: DeviceArray = _arr(('*', 'ngeom', 5), "float32")

@@ -2787,11 +2787,162 @@ void ref_sleep(const RefModel* m, RefData* d) { /* sleep.py:824-999 */
   free(can);
 }
 
+/* ================================================================ rays (ray.py) */
+/* a x^2 + 2 b x + c = 0 (ray.py:105-125): smallest non-negative root, both roots in xx */
+static double ray_quad(double a, double b, double c, double* xx) {
+  xx[0] = xx[1] = -1.0;
+  double det = b * b - a * c;
+  if (det < MINVAL) return -1.0;
+  det = sqrt(det);
+  double den = 1.0 / (a != 0.0 ? a : MINVAL);
+  xx[0] = (-b - det) * den;
+  xx[1] = (-b + det) * den;
+  if (xx[0] >= 0.0) return xx[0];
+  if (xx[1] >= 0.0) return xx[1];
+  return -1.0;
+}
+static void ray_map(const double* pos, const double* mat, const double* pnt, const double* vec, double* lpnt, double* lvec) { /* ray.py:32-49 */
+  double dif[3];
+  v3sub(dif, pnt, pos);
+  matT_mul_vec(lpnt, mat, dif);
+  matT_mul_vec(lvec, mat, vec);
+}
+static double ray_sphere(const double* pos, double dist_sqr, const double* pnt, const double* vec, double* normal) { /* ray.py:237-251 */
+  double dif[3], xx[2];
+  v3sub(dif, pnt, pos);
+  double sol = ray_quad(v3dot(vec, vec), v3dot(vec, dif), v3dot(dif, dif) - dist_sqr, xx);
+  normal[0] = normal[1] = normal[2] = 0.0;
+  if (sol >= 0.0) {
+    for (int k = 0; k < 3; k++) normal[k] = pnt[k] + vec[k] * sol - pos[k];
+    v3normalize(normal);
+  }
+  return sol;
+}
+static double ray_geom(int type, const double* pos, const double* mat, const double* size, const double* pnt, const double* vec, double* normal) {
+  double lp[3], lv[3], xx[2], n[3] = {0, 0, 0}, x = -1.0;
+  normal[0] = normal[1] = normal[2] = 0.0;
+  if (type == G_SPHERE) return ray_sphere(pos, size[0] * size[0], pnt, vec, normal);
+  if (type != G_PLANE && type != G_CAPSULE && type != G_ELLIPSOID && type != G_CYLINDER && type != G_BOX) return -1.0;
+  /* bounding spheres (ray.py:257-261, 362-366, 425-429) */
+  double bound = type == G_CAPSULE ? (size[0] + size[1]) * (size[0] + size[1]) : (type == G_CYLINDER ? size[0] * size[0] + size[1] * size[1] : (type == G_BOX ? v3dot(size, size) : -1.0));
+  if (bound >= 0.0 && ray_sphere(pos, bound, pnt, vec, n) < 0.0) return -1.0;
+  ray_map(pos, mat, pnt, vec, lp, lv);
+  if (type == G_PLANE) { /* ray.py:213-234 */
+    if (lv[2] > -MINVAL) return -1.0;
+    x = -lp[2] / lv[2];
+    if (x < 0.0) return -1.0;
+    double p0 = lp[0] + x * lv[0], p1 = lp[1] + x * lv[1];
+    if ((size[0] <= 0.0 || fabs(p0) <= size[0]) && (size[1] <= 0.0 || fabs(p1) <= size[1])) {
+      normal[0] = mat[2], normal[1] = mat[5], normal[2] = mat[8];
+      return x;
+    }
+    return -1.0;
+  }
+  if (type == G_ELLIPSOID) { /* ray.py:328-356 */
+    double s[3], slv[3], slp[3];
+    for (int k = 0; k < 3; k++) {
+      double q = size[k] * size[k];
+      s[k] = 1.0 / (q != 0.0 ? q : MINVAL);
+      slv[k] = s[k] * lv[k];
+      slp[k] = s[k] * lp[k];
+    }
+    x = ray_quad(v3dot(slv, lv), v3dot(slv, lp), v3dot(slp, lp) - 1.0, xx);
+    if (x >= 0.0) {
+      for (int k = 0; k < 3; k++) n[k] = s[k] * (lp[k] + lv[k] * x);
+      v3normalize(n);
+      mat_mul_vec(normal, mat, n);
+    }
+    return x;
+  }
+  if (type == G_CAPSULE) { /* ray.py:254-325 */
+    int part = 0;
+    double r2 = size[0] * size[0], a = lv[0] * lv[0] + lv[1] * lv[1];
+    double sol = ray_quad(a, lv[0] * lp[0] + lv[1] * lp[1], lp[0] * lp[0] + lp[1] * lp[1] - r2, xx);
+    if (sol >= 0.0 && fabs(lp[2] + sol * lv[2]) <= size[1]) x = sol;
+    a += lv[2] * lv[2];
+    for (int cap = 1; cap >= -1; cap -= 2) {
+      double ld[3] = {lp[0], lp[1], lp[2] - cap * size[1]};
+      ray_quad(a, v3dot(lv, ld), v3dot(ld, ld) - r2, xx);
+      for (int i = 0; i < 2; i++) {
+        int outer = cap > 0 ? lp[2] + xx[i] * lv[2] >= size[1] : lp[2] + xx[i] * lv[2] <= -size[1];
+        if (xx[i] >= 0.0 && outer && (x < 0.0 || xx[i] < x)) x = xx[i], part = cap;
+      }
+    }
+    if (x >= 0.0) {
+      n[0] = lp[0] + lv[0] * x, n[1] = lp[1] + lv[1] * x, n[2] = part == 0 ? 0.0 : lp[2] + lv[2] * x - size[1] * part;
+      v3normalize(n);
+      mat_mul_vec(normal, mat, n);
+    }
+    return x;
+  }
+  if (type == G_CYLINDER) { /* ray.py:359-417 */
+    int part = 0;
+    if (fabs(lv[2]) > MINVAL)
+      for (int side = -1; side <= 1; side += 2) {
+        double sol = (side * size[1] - lp[2]) / lv[2];
+        if (sol >= 0.0) {
+          double p0 = lp[0] + sol * lv[0], p1 = lp[1] + sol * lv[1];
+          if (p0 * p0 + p1 * p1 <= size[0] * size[0] && (x < 0.0 || sol < x)) x = sol, part = side;
+        }
+      }
+    double sol = ray_quad(lv[0] * lv[0] + lv[1] * lv[1], lv[0] * lp[0] + lv[1] * lp[1], lp[0] * lp[0] + lp[1] * lp[1] - size[0] * size[0], xx);
+    if (sol >= 0.0 && fabs(lp[2] + sol * lv[2]) <= size[1] && (x < 0.0 || sol < x)) x = sol, part = 0;
+    if (x >= 0.0) {
+      if (part == 0) {
+        n[0] = lp[0] + lv[0] * x, n[1] = lp[1] + lv[1] * x, n[2] = 0.0;
+        v3normalize(n);
+      } else n[0] = n[1] = 0.0, n[2] = part;
+      mat_mul_vec(normal, mat, n);
+    }
+    return x;
+  }
+  /* box (ray.py:420-471) */
+  int face_axis = -1, face_side = -1;
+  for (int i = 0; i < 3; i++) {
+    if (!(fabs(lv[i]) > MINVAL)) continue;
+    for (int side = -1; side <= 1; side += 2) {
+      double sol = (side * size[i] - lp[i]) / lv[i];
+      if (sol < 0.0) continue;
+      int id0 = i == 0 ? 1 : 0, id1 = i == 2 ? 1 : 2;
+      if (fabs(lp[id0] + sol * lv[id0]) <= size[id0] && fabs(lp[id1] + sol * lv[id1]) <= size[id1] && (x < 0.0 || sol < x)) x = sol, face_axis = i, face_side = side;
+    }
+  }
+  if (x >= 0.0) {
+    n[0] = n[1] = n[2] = 0.0;
+    n[face_axis] = face_side;
+    mat_mul_vec(normal, mat, n);
+  }
+  return x;
+}
+static int ray_eliminate(const RefModel* m, int g, const double* gg, int flg_static, int bodyexclude) { /* ray.py:52-102 */
+  int b = m->geom_bodyid[g], mat = m->geom_matid[g];
+  if (b == bodyexclude) return 1;
+  if (mat < 0 && m->geom_rgba[4 * g + 3] == 0.0) return 1;
+  if (mat >= 0 && m->mat_rgba[4 * mat + 3] == 0.0) return 1;
+  if (!flg_static && m->body_weldid[b] == 0) return 1;
+  if (!gg || (gg[0] == -1 && gg[1] == -1 && gg[2] == -1 && gg[3] == -1 && gg[4] == -1 && gg[5] == -1)) return 0;
+  int grp = m->geom_group[g] < 0 ? 0 : (m->geom_group[g] > 5 ? 5 : m->geom_group[g]);
+  return gg[grp] == 0.0;
+}
+double ref_ray(const RefModel* m, const RefData* d, const double* pnt, const double* vec, const double* geomgroup, int flg_static, int bodyexclude, int* geomid,
+               double* normal) {
+  double best = MAXVAL, n[3], nb[3] = {0, 0, 0};
+  int gid = -1;
+  for (int g = 0; g < m->ngeom; g++) {
+    if (ray_eliminate(m, g, geomgroup, flg_static, bodyexclude)) continue;
+    double dist = ray_geom(m->geom_type[g], d->geom_xpos + 3 * g, d->geom_xmat + 9 * g, m->geom_size + 3 * g, pnt, vec, n);
+    if (dist >= 0.0 && dist < best) best = dist, gid = g, v3cpy(nb, n);
+  }
+  if (geomid) *geomid = gid;
+  if (normal) v3cpy(normal, nb);
+  return best >= MAXVAL ? -1.0 : best;
+}
+
 /* ================================================================ sensors (sensor.py, subset) */
 enum { SENS_TOUCH = 0, SENS_MAGNETOMETER = 6, SENS_ACCELEROMETER = 1, SENS_FORCE = 4, SENS_TORQUE = 5, SENS_FRAMELINACC = 33, SENS_FRAMEANGACC = 34, SENS_VELOCIMETER = 2, SENS_GYRO = 3, SENS_JOINTPOS = 9, SENS_JOINTVEL = 10, SENS_ACTUATORPOS = 13, SENS_ACTUATORVEL = 14, SENS_ACTUATORFRC = 15,
        SENS_BALLQUAT = 18, SENS_BALLANGVEL = 19, SENS_FRAMEPOS = 26, SENS_FRAMEQUAT = 27, SENS_FRAMEXAXIS = 28, SENS_FRAMEYAXIS = 29, SENS_FRAMEZAXIS = 30,
        SENS_FRAMELINVEL = 31, SENS_FRAMEANGVEL = 32, SENS_SUBTREECOM = 35, SENS_SUBTREELINVEL = 36, SENS_SUBTREEANGMOM = 37, SENS_CLOCK = 45,
-       SENS_JOINTACTFRC = 16, SENS_JOINTLIMITPOS = 20, SENS_JOINTLIMITVEL = 21, SENS_JOINTLIMITFRC = 22, SENS_E_POTENTIAL = 43, SENS_E_KINETIC = 44 };
+       SENS_JOINTACTFRC = 16, SENS_JOINTLIMITPOS = 20, SENS_JOINTLIMITVEL = 21, SENS_JOINTLIMITFRC = 22, SENS_E_POTENTIAL = 43, SENS_E_KINETIC = 44, SENS_RANGEFINDER = 7 };
 enum { OBJ_BODY = 1, OBJ_XBODY = 2, OBJ_GEOM = 5, OBJ_SITE = 6 };
 /* pose, quaternion and body of a frame object (sensor.py:266-374 _get_pos / _get_mat / _get_quat / _get_body_id; sites are posed here: the
    oracle keeps no site arrays) */
@@ -3072,6 +3223,12 @@ static void sensor_stage(const RefModel* m, RefData* d, int stage) {
       quat_normalize(v);
     } else if (t == SENS_BALLANGVEL) memcpy(v, d->qvel + m->jnt_dofadr[id], 3 * sizeof(double));
     else if (t == SENS_CLOCK) v[0] = d->time;
+    else if (t == SENS_RANGEFINDER) { /* sensor.py:179-196, 815-845 */
+      double all[6] = {MAXVAL, MAXVAL, MAXVAL, MAXVAL, MAXVAL, MAXVAL}, z[3];
+      int body = frame_of(m, d, OBJ_SITE, id, pos, mat, q);
+      z[0] = mat[2], z[1] = mat[5], z[2] = mat[8];
+      v[0] = ref_ray(m, d, pos, z, all, 1, body, NULL, NULL);
+    }
     else if (t == SENS_SUBTREECOM) v3cpy(v, d->subtree_com + 3 * id);
     else if (t == SENS_SUBTREELINVEL) v3cpy(v, d->subtree_linvel + 3 * id);
     else if (t == SENS_SUBTREEANGMOM) v3cpy(v, d->subtree_angmom + 3 * id);

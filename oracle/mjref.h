@@ -104,6 +104,10 @@ typedef struct RefModel {
   int* geom_condim;
   int* geom_bodyid;
   int* geom_priority;
+  int* geom_group;  /* ray casting (ray.py:52): group, material and colour (alpha 0 = invisible to rays) */
+  int* geom_matid;
+  double* geom_rgba; /* [ngeom, 4] */
+  double* mat_rgba;  /* [nmat, 4] */
   double* geom_solmix;
   double* geom_solref;
   double* geom_solimp;
@@ -302,6 +306,9 @@ void ref_rungekutta4(const RefModel* m, RefData* d); /* forward.py:524; call aft
 void ref_step(const RefModel* m, RefData* d);
 void ref_subtree_vel(const RefModel* m, RefData* d); /* smooth.py:3614 */
 void ref_rne_postconstraint(const RefModel* m, RefData* d); /* smooth.py:1744; call after ref_solve */
+/* ray.py:907-1011 _ray for one ray: distance to the nearest primitive geom (-1: none), its id and the normal there; geomgroup: 6 doubles or NULL */
+double ref_ray(const RefModel* m, const RefData* d, const double* pnt, const double* vec, const double* geomgroup, int flg_static, int bodyexclude,
+               int* geomid, double* normal);
 void ref_sensor(const RefModel* m, RefData* d); /* sensor.py sensor_pos / sensor_vel / sensor_acc, the subset in oracle/mjref.c; called by ref_forward */
 /* sleep.py / island.py:28-310 (tree-level constraint islands, sleeping, waking) */
 void ref_update_sleep(const RefModel* m, RefData* d);

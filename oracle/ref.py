@@ -222,7 +222,7 @@ class RefSim:
                "xpair_gap": getattr(mjm, "pair_gap", np.zeros(0)),
                "actuator_trnid": mjm.actuator_trnid, "M_colind": mjm.M_colind}
     for name, dflt in (("geom_dataid", np.full(mjm.ngeom, -1)), ("mesh_vertadr", np.zeros(0)), ("mesh_vertnum", np.zeros(0)), ("mesh_vert", np.zeros((0, 3))),
-                       ("site_bodyid", np.zeros(0)), ("site_pos", np.zeros((0, 3))), ("site_quat", np.zeros((0, 4))), ("site_type", np.zeros(0)), ("site_size", np.zeros((0, 3))), ("sensor_type", np.zeros(0)), ("sensor_datatype", np.zeros(0)),
+                       ("site_bodyid", np.zeros(0)), ("site_pos", np.zeros((0, 3))), ("site_quat", np.zeros((0, 4))), ("site_type", np.zeros(0)), ("site_size", np.zeros((0, 3))), ("geom_group", np.zeros(mjm.ngeom)), ("geom_matid", np.full(mjm.ngeom, -1)), ("geom_rgba", np.tile([0.5, 0.5, 0.5, 1.0], (mjm.ngeom, 1))), ("mat_rgba", np.zeros((0, 4))), ("sensor_type", np.zeros(0)), ("sensor_datatype", np.zeros(0)),
                        ("sensor_objtype", np.zeros(0)), ("sensor_objid", np.zeros(0)), ("sensor_reftype", np.zeros(0)), ("sensor_refid", np.zeros(0)), ("sensor_dim", np.zeros(0)),
                        ("sensor_adr", np.zeros(0)), ("sensor_cutoff", np.zeros(0)),
                        ("hfield_size", np.zeros((0, 4))), ("hfield_nrow", np.zeros(0)), ("hfield_ncol", np.zeros(0)), ("hfield_adr", np.zeros(0)), ("hfield_data", np.zeros(0)),
@@ -346,6 +346,17 @@ class RefSim:
     n = fn(ctypes.byref(self.cm), int(g1), int(g2), dp(p1), dp(m1), dp(p2), dp(m2), ctypes.c_double(margin), ctypes.c_double(tolerance),
            ctypes.c_double(cutoff), int(iterations), int(bool(multiccd)), dp(out), dp(wit))
     return float(out[0]), n, wit.reshape(8, 2, 3)[: max(n, 0)].copy()
+
+  def ray(self, pnt, vec, geomgroup=None, flg_static=True, bodyexclude=-1):
+    """Nearest intersection of one ray with the model's primitive geoms at their current poses (ray.py:907 _ray): (dist, geomid, normal)."""
+    dp = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    p, v = np.ascontiguousarray(pnt, dtype=np.float64), np.ascontiguousarray(vec, dtype=np.float64)
+    gg = None if geomgroup is None else np.ascontiguousarray(geomgroup, dtype=np.float64)
+    gid, nrm = ctypes.c_int(-1), np.zeros(3)
+    fn = self.lib.ref_ray
+    fn.restype = ctypes.c_double
+    dist = fn(ctypes.byref(self.cm), ctypes.byref(self.cd), dp(p), dp(v), None if gg is None else dp(gg), int(bool(flg_static)), int(bodyexclude), ctypes.byref(gid), dp(nrm))
+    return float(dist), int(gid.value), nrm
 
   def dense_M(self):
     m = self.mjm

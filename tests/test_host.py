@@ -359,7 +359,7 @@ def test_declared_schema_matches_arrays(xml):
   d = mjw.make_data(mjm, nworld=3, nconmax=7, njmax=21)
   assert dataclasses.is_dataclass(mjw.Model) and dataclasses.is_dataclass(mjw.Data)
   env = {k: getattr(m, k) for k in ("nq", "nv", "nu", "na", "nbody", "njnt", "ngeom", "nsite", "nkey", "nmocap", "neq", "nC", "npair",
-                                    "nexplicit", "nbodylevel", "ndoflevel", "nmaxpyramid", "ntree", "nmesh", "nmeshvert", "nmeshpoly", "nmeshpolyvert", "nmeshpolymap", "nmeshgraph", "nhfield", "nhfielddata", "nsensor", "nsensordata")}
+                                    "nexplicit", "nbodylevel", "ndoflevel", "nmaxpyramid", "ntree", "nmesh", "nmeshvert", "nmeshpoly", "nmeshpolyvert", "nmeshpolymap", "nmeshgraph", "nhfield", "nhfielddata", "nsensor", "nsensordata", "nmat")}
   env.update(nworld=d.nworld, njmax=d.njmax, njmax_pad=d.njmax_pad, nv_pad=d.nv_pad, naconmax=d.naconmax, concap=d.concap, nccdworld=d.nccdworld, nccdword=d.nccdword, ntreeadr=(m.ntree + 1) if m.tree_solve else 0, ntreerow=d.njmax if m.tree_solve else 0, ntreedof=m.nv if m.tree_solve else 0, ntreeworld=d.nworld if m.tree_solve else 0, nsleepworld=d.nsleepworld)
   for obj in (m.opt, m.stat, m, d.contact, d.efc, d):
     _schema_check(obj, env, d.nworld)
