@@ -193,3 +193,25 @@ def test_gpu_rangefinder_vs_oracle():
       assert np.abs(d.sensordata.numpy()[w] - sims[w].sensordata).max() < 1e-4, (step, w, d.sensordata.numpy()[w], sims[w].sensordata)
     mjw.step(m, d)
   assert d.sensordata.numpy()[0, 0] < 0.75  # (the ball fell towards the floor)
+
+
+def test_rays_argument_checks():
+  # (host-side validation only: nothing is launched)
+  mjm = mjw.mjcf.from_xml_string(SCENE)
+  m = mjw.put_model(mjm)
+  d = mjw.make_data(mjm, nworld=2)
+  z = lambda *s, dt=np.float32: DeviceArray.zeros(s, dt)
+  with pytest.raises(ValueError):
+    mjw.rays(m, d, z(1, 4, 3), z(1, 5, 3), None, True, None, z(2, 4), None, None)  # pnt / vec shapes differ
+  with pytest.raises(ValueError):
+    mjw.rays(m, d, z(3, 4, 3), z(3, 4, 3), None, True, None, z(2, 4), None, None)  # neither 1 nor nworld origins
+  with pytest.raises(ValueError):
+    mjw.rays(m, d, z(1, 4, 3), z(1, 4, 3), None, True, None, z(2, 5), None, None)  # dist of the wrong shape
+  with pytest.raises(ValueError):
+    mjw.rays(m, d, z(1, 4, 3), z(1, 4, 3), [1, 1, 1], True, None, z(2, 4), None, None)  # five group entries missing
+  with pytest.raises(ValueError):
+    mjw.rays(m, d, z(1, 4, 3), z(1, 4, 3), None, True, z(3, dt=np.int32), z(2, 4), None, None)  # bodyexclude per ray
+  with pytest.raises(NotImplementedError):
+    mjw.rays(m, d, z(1, 4, 3), z(1, 4, 3), None, True, None, z(2, 4), None, None, rc=object())
+  with pytest.raises(ValueError):
+    mjw.ray(m, d, z(1, 4, 3), z(1, 4, 3))  # several rays: rays()
