@@ -142,6 +142,8 @@ typedef struct MjhModel {
   const float* dof_damping; int dof_damping_nb;
   const float* dof_invweight0; int dof_invweight0_nb;
   const int* M_rownnz; const int* M_rowadr; const int* M_colind;
+  const int* M_dense;           /* [nv, 4 ceil(nv / 4)] index into Data.M of the dense entry (i, c), -1 where M is structurally zero: the solvers gather
+                                   their dense row of M with independent loads (engine-private; io.py put_model)                */
   /* geoms */
   const int* geom_type; const int* geom_condim; const int* geom_bodyid; const int* geom_priority;
   /* ray casting (ray.py:52 _ray_eliminate): group and visibility of the geoms; nmat materials */
@@ -346,7 +348,7 @@ int mjh_timed_steps(const MjhModel* m, const MjhData* d, int nstep, int step0, f
 int mjh_release_thread_resources(void);
 
 const char* mjh_last_error(void);
-#define MJH_ABI_VERSION 30
+#define MJH_ABI_VERSION 31
 int mjh_abi_version(void); /* returns MJH_ABI_VERSION of the library that was loaded */
 
 #ifdef __cplusplus

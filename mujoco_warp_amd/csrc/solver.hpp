@@ -269,8 +269,8 @@ DEV bool in_bracket(P3 x, P3 y) { return (x.g < y.g && y.g < 0.0f) || (x.g > y.g
 // HAS_FL: friction-loss rows present (three-zone cost, rare): a compile-time switch, the common instantiation is branch-free
 template <int NR, int G, bool HAS_FL>
 DEV void line_search_rows(const float (&rja)[NR], const float (&rjv)[NR], const float (&rD)[NR], const int (&rkind)[NR],
-                          const float* floss_lane, float gauss1, float gauss2, float gtol_in, int ls_iterations, float& alpha_out,
-                          float& improvement_out, bool& converged_out, int* iters_out = nullptr, float gauss1_abs = 0.0f) {
+                          const float* floss_lane, float gauss1_lane, float gauss2_lane, float gauss1_abs_lane, float gtol_in, int ls_iterations,
+                          float& alpha_out, float& improvement_out, bool& converged_out, int* iters_out = nullptr) {
   float ehess[NR], egrad0[NR], ecact[NR], ecin[NR];
 #pragma unroll
   for (int k = 0; k < NR; ++k) {
@@ -303,27 +303,31 @@ DEV void line_search_rows(const float (&rja)[NR], const float (&rjv)[NR], const 
     }
     return s;
   };
-  // group sums + the Gauss (smooth) quadratic; the sums of up to three ray points are reduced together (gsumg_n)
-  auto finish = [&](float c, float g, float h, float a) __attribute__((always_inline)) {
-    return P3{a * a * gauss2 + a * gauss1 + c, 2.0f * a * gauss2 + gauss1 + g, 2.0f * gauss2 + h};
-  };
   const P3 e = eval(0.0f);
 #if MJH_LS_NOISE_ULPS > 0
   // float32: the ray derivative is a sum of ~nefc + nv terms that mostly cancel at the minimum, so it carries rounding noise of
   // about eps * sum |term|.  A derivative inside that noise is zero as far as float32 can tell: bracketing on (the reference's
   // tolerance floor of 1e-6 is an absolute number chosen for float64) only chases noise -- measured 2.5 bracketing iterations
   // per call against 0.75 for the float64 oracle, with no effect on the iterates.
+  // (round 3: the three sums of the Gauss quadratic -- search . (Ma - qfrc_smooth), search . M search / 2 and the absolute terms of the
+  // first -- ride in the same reduction: one dependent DPP chain per solver iteration less)
   float eabs = 0.0f;
 #pragma unroll
   for (int k = 0; k < NR; ++k) eabs += fabsf(egrad0[k]);
-  float r2[3] = {e.g, e.h, eabs};
-  gsumg_n<G, 3>(r2);
-  const float gtol = fmaxf(gtol_in, (MJH_LS_NOISE_ULPS * 5.96e-8f) * (gauss1_abs + r2[2]));
+  float r2[6] = {e.g, e.h, eabs, gauss1_lane, gauss2_lane, gauss1_abs_lane};
+  gsumg_n<G, 6>(r2);
+  const float gauss1 = r2[3], gauss2 = r2[4];
+  const float gtol = fmaxf(gtol_in, (MJH_LS_NOISE_ULPS * 5.96e-8f) * (r2[5] + r2[2]));
 #else
-  float r2[2] = {e.g, e.h};
-  gsumg_n<G, 2>(r2);
+  float r2[4] = {e.g, e.h, gauss1_lane, gauss2_lane};
+  gsumg_n<G, 4>(r2);
+  const float gauss1 = r2[2], gauss2 = r2[3];
   const float gtol = gtol_in;
 #endif
+  // group sums + the Gauss (smooth) quadratic; the sums of up to three ray points are reduced together (gsumg_n)
+  auto finish = [&](float c, float g, float h, float a) __attribute__((always_inline)) {
+    return P3{a * a * gauss2 + a * gauss1 + c, 2.0f * a * gauss2 + gauss1 + g, 2.0f * gauss2 + h};
+  };
   const P3 p0 = P3{0.0f, gauss1 + r2[0], 2.0f * gauss2 + r2[1]};
   const float lo_alpha_in = -fast_div(p0.g, p0.h);
   const P3 el = eval(lo_alpha_in);
@@ -512,6 +516,79 @@ DEV void invert_rows(const float (&mrow)[NVR], float (&b)[NVR], float* buf, int 
   }
 }
 
+// The same inverse, four pivots per step (round 3): the lanes of the pivot block publish their rows as one 4 x NVR LDS tile, every
+// lane inverts the 4 x 4 pivot block P redundantly in registers and applies one rank-4 update -- NVR / 4 LDS round trips and
+// divisions chains instead of NVR (the single-pivot version spent 30 k cycles per world, 1 k per step, on the dependent
+// write -> read -> divide -> update chain).  Compact storage as above: column c holds the inverse-in-progress B once its block
+// was eliminated, A before.  For rows outside the block F = A_iK P^-1 and row_i -= F row_K; a row of the block becomes
+// P^-1 row_K, written as the same update with F = e_i - (P^-1)_i; the block's own columns end as delta_ic - F_c.
+// `buf` holds 2 x 4 x NVR floats (double buffered).
+template <int NVR, int G>
+DEV void invert_rows_b4(const float (&mrow)[NVR], float (&s)[NVR], float* buf, int lig) {
+#pragma unroll
+  for (int c = 0; c < NVR; ++c) s[c] = mrow[c];
+#pragma unroll
+  for (int kb = 0; kb < NVR / 4; ++kb) {
+    constexpr int T = 4 * NVR;
+    const int k = 4 * kb;
+    float* pb = buf + (kb & 1) * T;
+    const int q = lig - k;  // 0..3 for the lanes of the pivot block
+    if (q >= 0 && q < 4) {
+#pragma unroll
+      for (int c4 = 0; c4 < NVR / 4; ++c4) *reinterpret_cast<float4*>(pb + q * NVR + 4 * c4) = make_float4(s[4 * c4], s[4 * c4 + 1], s[4 * c4 + 2], s[4 * c4 + 3]);
+    }
+    gsync();
+    // P = rows K, columns K (symmetric positive definite); P^-1 by unrolled Gauss-Jordan without pivoting
+    float P[4][4], Pi[4][4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const float4 v = *reinterpret_cast<const float4*>(pb + p * NVR + k);
+      P[p][0] = v.x; P[p][1] = v.y; P[p][2] = v.z; P[p][3] = v.w;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) Pi[p][e] = p == e ? 1.0f : 0.0f;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float ip = 1.0f / P[j][j];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        P[j][e] *= ip;
+        Pi[j][e] *= ip;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (r != j) {
+          const float f = P[r][j];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            P[r][e] -= f * P[j][e];
+            Pi[r][e] -= f * Pi[j][e];
+          }
+        }
+    }
+    const bool inb = q >= 0 && q < 4;
+    float F[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const float out = s[k] * Pi[0][p] + s[k + 1] * Pi[1][p] + s[k + 2] * Pi[2][p] + s[k + 3] * Pi[3][p];
+      const float own = (q == p ? 1.0f : 0.0f) - (q == 0 ? Pi[0][p] : (q == 1 ? Pi[1][p] : (q == 2 ? Pi[2][p] : Pi[3][p])));
+      F[p] = inb ? own : out;
+    }
+#pragma unroll
+    for (int c4 = 0; c4 < NVR / 4; ++c4) {
+      if (c4 == kb) continue;
+      const float4 r0 = *reinterpret_cast<const float4*>(pb + 4 * c4), r1 = *reinterpret_cast<const float4*>(pb + NVR + 4 * c4),
+                   r2 = *reinterpret_cast<const float4*>(pb + 2 * NVR + 4 * c4), r3 = *reinterpret_cast<const float4*>(pb + 3 * NVR + 4 * c4);
+      s[4 * c4] -= F[0] * r0.x + F[1] * r1.x + F[2] * r2.x + F[3] * r3.x;
+      s[4 * c4 + 1] -= F[0] * r0.y + F[1] * r1.y + F[2] * r2.y + F[3] * r3.y;
+      s[4 * c4 + 2] -= F[0] * r0.z + F[1] * r1.z + F[2] * r2.z + F[3] * r3.z;
+      s[4 * c4 + 3] -= F[0] * r0.w + F[1] * r1.w + F[2] * r2.w + F[3] * r3.w;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s[k + e] = (q == e ? 1.0f : 0.0f) - F[e];
+  }
+}
+
 // TREE (nv > 64, MjhModel.tree_solve): the unit of work is one constraint island of one world -- the dofs of the kinematic trees
 // that k_tree_rows found connected by coupling rows (M is block diagonal over trees, so the problem separates exactly over islands)
 // and the rows grouped under that island; every global index goes through the island's dof map / row map, everything else is the
@@ -581,7 +658,24 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
   PhaseClock pc(5, lig);
   // ---- M row of this lane into registers (dense staging in the J region) ----------------------------------
   float mrow[NVR];
-  {
+  if (!TREE) {
+    // every lane gathers its dense row through the model-wide address table M_dense: 2 x NV4 independent loads, all in flight
+    // (the sparse -> dense staging through LDS that this replaces was a chain of dependent global loads: 9 k cycles per world)
+    const float* Mg = d.M + (size_t)w * nC;
+    const int nv4r = (nv_all + 3) >> 2;  // table row stride in 16-byte units (<= NV4: the 64-lane kernels round NV4 up)
+    const int4* tab = reinterpret_cast<const int4*>(m.M_dense) + (size_t)(active ? lig : 0) * nv4r;
+    int idx[NVR];
+#pragma unroll
+    for (int c4 = 0; c4 < NV4; ++c4) {
+      const int4 t4 = c4 < nv4r ? tab[c4] : make_int4(-1, -1, -1, -1);
+      idx[4 * c4] = t4.x; idx[4 * c4 + 1] = t4.y; idx[4 * c4 + 2] = t4.z; idx[4 * c4 + 3] = t4.w;
+    }
+#pragma unroll
+    for (int c = 0; c < NVR; ++c) {
+      const float v = Mg[idx[c] < 0 ? 0 : idx[c]];
+      mrow[c] = active ? (idx[c] < 0 ? 0.0f : v) : (c == lig ? 1.0f : 0.0f);
+    }
+  } else {
     for (int idx = lig; idx < NVR * JS; idx += G) Jl[idx] = 0.0f;
     gsync();
     const float* Mg = d.M + (size_t)w * nC;
@@ -628,7 +722,9 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
   float h[NVR], lt[NVR];  // Newton: H row / L row and L column; CG: h = row of M^-1
   float qs = 0.0f;
   if (!NEWTON) {
-    invert_rows<NVR, G>(mrow, h, col, lig);
+    // (the J region is free until the rows are loaded below: it lends the 2 x 4 x NVR-word tile buffer)
+    if (NVR * JS >= 8 * NVR) invert_rows_b4<NVR, G>(mrow, h, Jl, lig);
+    else invert_rows<NVR, G>(mrow, h, col, lig);
     bgrad[lig] = fs;
     gsync();
     qs = mul_row(h, bgrad);
@@ -760,6 +856,7 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
 
   float grad_dot = 0.0f, search_dot = 0.0f, decrement = 0.0f;
   float g = 0.0f, Mg = 0.0f, pg = 0.0f, pMg = 0.0f, srch = 0.0f, qc = 0.0f;
+  float cg5[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
 
   // force and state of one row of an elliptic contact (_eval_constraint solver.py:455-472, _eval_elliptic_middle 406-421): the
   // rows of a contact decide together from the scaled Jaref the lanes just published in exu.  Newton also gets the row of the
@@ -850,7 +947,7 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
     }
     // ---- gradient and search direction (solver.py:3061-3220) ---------------------------------------------------
     g = active ? (Ma - fs - qc) : 0.0f;
-    grad_dot = gsumg<G>(g * g);
+    if (NEWTON) grad_dot = gsumg<G>(g * g);  // (CG: reduced with the Polak-Ribiere sums below)
     // improvement / gradient tests need no search direction: a world that passes them skips the H rebuild + Cholesky
     const bool done_early = niter > 0 && ((improvement * rscale < tolerance) || (sqrtf(grad_dot) * rscale < tolerance));
     pc.mark(3);
@@ -893,12 +990,18 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
       bgrad[lig] = g;
       gsync();
       Mg = mul_row(h, bgrad);  // Mgrad = M^-1 grad
+      // one reduction for everything this iteration's direction needs (round 3; was three dependent DPP chains): |grad|^2, the
+      // Polak-Ribiere numerator and denominator, and |search|^2 of the NEW direction -Mgrad + beta search expanded into
+      // |Mgrad|^2 - 2 beta Mgrad . search + beta^2 |search|^2 (it only scales the line search's gradient tolerance)
+      cg5[0] = g * g; cg5[1] = g * (Mg - pMg); cg5[2] = pg * pMg; cg5[3] = Mg * Mg; cg5[4] = Mg * srch;
+      gsumg_n<G, 5>(cg5);
+      grad_dot = cg5[0];
     }
     pc.mark(4);
     if (niter == 0) {
       if (!NEWTON) {  // CG: search = -Mgrad (solver.py:1663-1695)
         srch = -Mg;
-        search_dot = gsumg<G>(Mg * Mg);
+        search_dot = cg5[3];
         pg = g;
         pMg = Mg;
       }
@@ -909,14 +1012,12 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
         done = (imp < tolerance) || (gradient < tolerance) || (0.5f * decrement * rscale < tolerance);
       } else {
         // Polak-Ribiere (solver.py:3283-3450)
-        float pr[2] = {g * (Mg - pMg), pg * pMg};
-        gsumg_n<G, 2>(pr);
-        const float num = pr[0], den = pr[1];
+        const float num = cg5[1], den = cg5[2];
         const float beta = fmaxf(0.0f, num * __builtin_amdgcn_rcpf(fmaxf(MJ_MINVAL, den)));
         done = (imp < tolerance) || (gradient < tolerance);
         if (!done) {
           srch = -Mg + beta * srch;
-          search_dot = gsumg<G>(srch * srch);
+          search_dot = fmaxf(cg5[3] + beta * (beta * search_dot - 2.0f * cg5[4]), 0.0f);
           pg = g;
           pMg = Mg;
         }
@@ -937,17 +1038,17 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
     pc.mark(5);
     // ---- line search (solver.py:835-1347); rows and all sums stay in registers ----------------------------------
     float gs[3] = {srch * (Ma - fs), 0.5f * srch * mvi, fabsf(srch * (Ma - fs))};
-    gsumg_n<G, 3>(gs);
-    const float gauss1 = gs[0], gauss2 = gs[1];
     const float gtol = fmaxf(tolerance * ls_tolerance * sqrtf(search_dot) * scale, 1e-6f);
     float alpha = 0.0f;
     improvement = 0.0f;
     bool ls_converged = false;
     if (!ELL) {
       const float* floss_lane = floss + lig;
-      if (has_fl) line_search_rows<NR, G, true>(rja, rjv, rD, rkind, floss_lane, gauss1, gauss2, gtol, ls_iterations, alpha, improvement, ls_converged, nullptr, gs[2]);
-      else line_search_rows<NR, G, false>(rja, rjv, rD, rkind, floss_lane, gauss1, gauss2, gtol, ls_iterations, alpha, improvement, ls_converged, nullptr, gs[2]);
+      if (has_fl) line_search_rows<NR, G, true>(rja, rjv, rD, rkind, floss_lane, gs[0], gs[1], gs[2], gtol, ls_iterations, alpha, improvement, ls_converged);
+      else line_search_rows<NR, G, false>(rja, rjv, rD, rkind, floss_lane, gs[0], gs[1], gs[2], gtol, ls_iterations, alpha, improvement, ls_converged);
     } else {
+      gsumg_n<G, 3>(gs);
+      const float gauss1 = gs[0], gauss2 = gs[1];
       // per-row constants of the ray (solver.py:518-556): cost(a) - cost(0) = a (grad0 + a hess / 2) + cact when the
       // row is active at a, cin otherwise; equality rows are always active, padding rows have D = jv = 0
       float ehess[NR], egrad0[NR], ecact[NR], ecin[NR];

@@ -431,24 +431,22 @@ DEV void newton_pair(const MjhModel& m, const MjhData& d, float* S, const Newton
     for (int k = 0; k < NR; ++k) rjv[k] = rkind[k] != 3 ? j_dot(bvec, lig + G * k) : 0.0f;
     pc.mark(5);
     // ---- line search ---------------------------------------------------------------------------------------------------
-    float gs2[3] = {srch * (Ma - fs), 0.5f * srch * mvi, fabsf(srch * (Ma - fs))};
-    gsumg_n<G, 3>(gs2);
-    const float gauss1 = gs2[0], gauss2 = gs2[1];
+    const float gs2[3] = {srch * (Ma - fs), 0.5f * srch * mvi, fabsf(srch * (Ma - fs))};  // lane-local: reduced inside the line search with its alpha = 0 sums
     const float gtol = fmaxf(tolerance * ls_tolerance * sqrtf(search_dot) * scale, 1e-6f);
     float alpha, imp_new;
     bool ls_ok;
     // (a finished world rides along on frozen state: no bracketing iterations for it)
 #ifdef MJH_PHASE_CLOCK
     int ls_its = 0;
-    if (wave_any(has_fl)) line_search_rows<NR, G, true>(rja, rjv, rD, rkind, floss_lane, gauss1, gauss2, gtol, fin ? 0 : ls_iterations, alpha, imp_new, ls_ok, &ls_its, gs2[2]);
-    else line_search_rows<NR, G, false>(rja, rjv, rD, rkind, floss_lane, gauss1, gauss2, gtol, fin ? 0 : ls_iterations, alpha, imp_new, ls_ok, &ls_its, gs2[2]);
+    if (wave_any(has_fl)) line_search_rows<NR, G, true>(rja, rjv, rD, rkind, floss_lane, gs2[0], gs2[1], gs2[2], gtol, fin ? 0 : ls_iterations, alpha, imp_new, ls_ok, &ls_its);
+    else line_search_rows<NR, G, false>(rja, rjv, rD, rkind, floss_lane, gs2[0], gs2[1], gs2[2], gtol, fin ? 0 : ls_iterations, alpha, imp_new, ls_ok, &ls_its);
     if (lig == 0 && !fin) {  // profiling build: bracketing iterations and calls of the line search (phase slots 14, 15 of kernel 5)
       atomicAdd(&g_phase_ticks[blockIdx.x & 63][5][14], (unsigned long long)ls_its);
       atomicAdd(&g_phase_ticks[blockIdx.x & 63][5][15], 1ull);
     }
 #else
-    if (wave_any(has_fl)) line_search_rows<NR, G, true>(rja, rjv, rD, rkind, floss_lane, gauss1, gauss2, gtol, fin ? 0 : ls_iterations, alpha, imp_new, ls_ok, nullptr, gs2[2]);
-    else line_search_rows<NR, G, false>(rja, rjv, rD, rkind, floss_lane, gauss1, gauss2, gtol, fin ? 0 : ls_iterations, alpha, imp_new, ls_ok, nullptr, gs2[2]);
+    if (wave_any(has_fl)) line_search_rows<NR, G, true>(rja, rjv, rD, rkind, floss_lane, gs2[0], gs2[1], gs2[2], gtol, fin ? 0 : ls_iterations, alpha, imp_new, ls_ok);
+    else line_search_rows<NR, G, false>(rja, rjv, rD, rkind, floss_lane, gs2[0], gs2[1], gs2[2], gtol, fin ? 0 : ls_iterations, alpha, imp_new, ls_ok);
 #endif
     pc.mark(6);
     if (!fin) {

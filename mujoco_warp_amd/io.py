@@ -349,7 +349,7 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
     jnt_limited=_arr(mjm.jnt_limited, i32),
     dof_bodyid=_arr(mjm.dof_bodyid, i32), dof_jntid=dof_jnt, dof_parentid=dof_parent, dof_grpadr=grpadr, dof_tree=dorder,
     dof_leveladr=dleveladr, tree_dofadr=tree_dofadr, tree_dofnum=tree_dofnum, dof_treeid=dof_treeid, body_treeid=body_treeid,
-    M_rownnz=_arr(mjm.M_rownnz, i32), M_rowadr=_arr(mjm.M_rowadr, i32), M_colind=_arr(mjm.M_colind, i32),
+    M_rownnz=_arr(mjm.M_rownnz, i32), M_rowadr=_arr(mjm.M_rowadr, i32), M_colind=_arr(mjm.M_colind, i32), M_dense=_m_dense(mjm, nv),
     geom_type=_arr(mjm.geom_type, i32), geom_condim=_arr(mjm.geom_condim, i32), geom_bodyid=_arr(mjm.geom_bodyid, i32),
     geom_priority=_arr(mjm.geom_priority, i32), geom_group=_arr(getattr(mjm, "geom_group", np.zeros(ngeom)), i32),
     geom_matid=_arr(getattr(mjm, "geom_matid", np.full(ngeom, -1)), i32), geom_rgba=_arr(getattr(mjm, "geom_rgba", np.tile([0.5, 0.5, 0.5, 1.0], (ngeom, 1))), f32).reshape(-1, 4),
@@ -467,6 +467,18 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
   m._dirty = True
   m._c = None
   return m
+
+
+def _m_dense(mjm, nv):
+  """[nv, 4 ceil(nv / 4)] address in the CSR M-structure of the dense entry (i, c) (symmetric), -1 where M has no entry."""
+  nvr = 4 * ((nv + 3) // 4)
+  t = np.full((max(nv, 1), max(nvr, 4)), -1, dtype=np.int32)
+  rowadr, rownnz, colind = np.asarray(mjm.M_rowadr), np.asarray(mjm.M_rownnz), np.asarray(mjm.M_colind)
+  for i in range(nv):
+    for a in range(int(rownnz[i])):
+      j = int(colind[rowadr[i] + a])
+      t[i, j] = t[j, i] = rowadr[i] + a
+  return t[:nv] if nv else t[:0]
 
 
 def c_model(m: types.Model):

@@ -371,6 +371,7 @@ class Model(_Dirty):
   M_rownnz: DeviceArray = _arr(('nv',), "int32")
   M_rowadr: DeviceArray = _arr(('nv',), "int32")
   M_colind: DeviceArray = _arr(('nC',), "int32")
+  M_dense: DeviceArray = _arr(('nv', '4*((nv+3)//4)'), "int32")
   geom_type: DeviceArray = _arr(('ngeom',), "int32")
   geom_condim: DeviceArray = _arr(('ngeom',), "int32")
   geom_bodyid: DeviceArray = _arr(('ngeom',), "int32")

@@ -39,6 +39,7 @@ def main():
   ap.add_argument("--xml", default=os.path.join(ROOT, "benchmarks", "humanoid", "humanoid.xml"))
   ap.add_argument("--nconmax", type=int, default=24)
   ap.add_argument("--njmax", type=int, default=64)
+  ap.add_argument("--iterations", type=int, default=-1, help="cap opt.iterations for the measured steps (state from the uncapped warm-up)")
   args = ap.parse_args()
   if args.build_only or not os.path.exists(LIB):
     build()
@@ -57,6 +58,11 @@ def main():
   mjw.timed_steps(m, d, 100, step0=0)  # warm-up into the steady contact regime
   L = _abi.lib()
   L.mjh_debug_phase_ticks.argtypes = [ctypes.c_void_p, ctypes.c_int]
+  if args.iterations >= 0:
+    snap = {k: getattr(d, k).numpy().copy() for k in ("qpos", "qvel", "ctrl", "qacc_warmstart", "time")}
+    mjw.override_model(mjm, [f"opt.iterations={args.iterations}"])
+    m = mjw.put_model(mjm)
+    args.steps = 1
   L.mjh_debug_phase_ticks(None, 1)
   ms, _ = mjw.timed_steps(m, d, args.steps, step0=100)
   buf = np.zeros((64, 8, 16), dtype=np.uint64)

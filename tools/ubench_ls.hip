@@ -20,7 +20,7 @@ __global__ void __launch_bounds__(512) k(float* io, long long* ticks, int reps, 
   for (int it = 0; it < reps; ++it) {
     float alpha, imp;
     bool ok;
-    line_search_rows<2, 32, false>(rja, rjv, rD, rkind, io, -3.0f + acc * 1e-20f, 2.0f, gtol, ls_iterations, alpha, imp, ok, &its);
+    line_search_rows<2, 32, false>(rja, rjv, rD, rkind, io, (-3.0f + acc * 1e-20f) / 32.0f, 2.0f / 32.0f, 0.0f, gtol, ls_iterations, alpha, imp, ok, &its);
     acc += alpha + imp;
   }
   const long long t1 = __builtin_readcyclecounter();
