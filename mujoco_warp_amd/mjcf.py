@@ -552,7 +552,73 @@ def _geom_rbound_aabb(gtype, size):
   return 0.0, np.zeros(3)
 
 
-def _compile_mesh(verts):
+def read_stl(path):
+  """Vertices [n, 3] and triangles [m, 3] of an STL file, binary or ASCII; repeated vertices are merged (as MuJoCo's compiler does)."""
+  raw = open(path, "rb").read()
+  tri = None
+  if len(raw) >= 84:
+    n = int(np.frombuffer(raw, dtype="<u4", count=1, offset=80)[0])
+    if len(raw) == 84 + 50 * n:  # binary: 80-byte header, count, then 50-byte records (normal, 3 vertices, attribute word)
+      rec = np.frombuffer(raw, dtype=np.dtype([("n", "<f4", 3), ("v", "<f4", (3, 3)), ("a", "<u2")]), count=n, offset=84)
+      tri = rec["v"].astype(np.float64).reshape(-1, 3)
+  if tri is None:
+    txt = raw.decode("ascii", errors="replace")
+    if not txt.lstrip().lower().startswith("solid"):
+      raise ValueError(f"{path}: neither a binary STL (size does not match its triangle count) nor an ASCII one")
+    pts = [[float(x) for x in line.split()[1:4]] for line in txt.splitlines() if line.strip().lower().startswith("vertex")]
+    if not pts or len(pts) % 3:
+      raise ValueError(f"{path}: ASCII STL with {len(pts)} vertex lines")
+    tri = np.array(pts, dtype=np.float64)
+  verts, inv = np.unique(tri, axis=0, return_inverse=True)
+  return verts, np.asarray(inv).reshape(-1, 3).astype(np.int32)
+
+
+def read_obj(path):
+  """Vertices and (fan-triangulated) faces of a Wavefront OBJ file: `v x y z` and `f a b c ...` lines (texture / normal indices after
+  a slash are ignored, negative indices count from the end)."""
+  verts, faces = [], []
+  for line in open(path, "r", errors="replace"):
+    t = line.split()
+    if not t:
+      continue
+    if t[0] == "v":
+      verts.append([float(x) for x in t[1:4]])
+    elif t[0] == "f":
+      ids = [int(x.split("/")[0]) for x in t[1:]]
+      ids = [i - 1 if i > 0 else len(verts) + i for i in ids]
+      faces.extend([ids[0], ids[k], ids[k + 1]] for k in range(1, len(ids) - 1))
+  if not verts:
+    raise ValueError(f"{path}: no vertices")
+  return np.array(verts, dtype=np.float64), np.array(faces, dtype=np.int32).reshape(-1, 3)
+
+
+def read_mesh_file(path):
+  ext = os.path.splitext(path)[1].lower()
+  if ext == ".stl":
+    return read_stl(path)
+  if ext == ".obj":
+    return read_obj(path)
+  raise NotImplementedError(f"mesh file format {ext!r} (STL and OBJ are supported)")
+
+
+def read_hfield_file(path):
+  """(nrow, ncol, elevation [nrow, ncol] with row 0 at -y) of a height-field file: a PNG image (grey levels, the image's top row is the
+  +y edge) or MuJoCo's binary format (int32 nrow, int32 ncol, float32 data).  UNPINNED like the rest of this loader."""
+  if os.path.splitext(path)[1].lower() == ".png":
+    try:
+      from PIL import Image
+    except ImportError as e:  # pragma: no cover
+      raise NotImplementedError("PNG height fields need the PIL package") from e
+    img = np.asarray(Image.open(path).convert("F"), dtype=np.float64)
+    return img.shape[0], img.shape[1], img[::-1].copy()
+  raw = open(path, "rb").read()
+  nrow, ncol = (int(x) for x in np.frombuffer(raw, dtype="<i4", count=2))
+  if nrow <= 0 or ncol <= 0 or len(raw) != 8 + 4 * nrow * ncol:
+    raise ValueError(f"{path}: not a height-field file (int32 nrow, int32 ncol, float32 data[nrow * ncol])")
+  return nrow, ncol, np.frombuffer(raw, dtype="<f4", count=nrow * ncol, offset=8).astype(np.float64).reshape(nrow, ncol)
+
+
+def _compile_mesh(verts, maxhullvert=-1):
   """Convex collision asset from inline vertices (MJCF <mesh vertex="...">), following what MuJoCo's compiler does with a mesh:
   convex hull, volume / centre of mass / inertia of the hull (uniform density), vertices re-expressed in the frame centred at the
   centre of mass and aligned with the principal axes (the geom frame is composed with that offset).  UNPINNED like the rest of this
@@ -565,11 +631,16 @@ def _compile_mesh(verts):
   verts = np.asarray(verts, dtype=np.float64).reshape(-1, 3)
   if len(verts) < 4:
     raise ValueError("a mesh needs at least 4 vertices")
-  hull = ConvexHull(verts)
+  # maxhullvert: MuJoCo stops Qhull after maxhullvert - 4 added vertices (`TA` option): an inner approximation of the hull
+  if maxhullvert != -1 and maxhullvert < 4:
+    raise ValueError("maxhullvert must be -1 or at least 4")
+  hull = ConvexHull(verts, qhull_options=f"Qt TA{maxhullvert - 4}" if maxhullvert >= 4 else None)
   vol, com, second = 0.0, np.zeros(3), np.zeros((3, 3))
-  centre = verts[hull.vertices].mean(axis=0)
+  # mass properties come from the whole mesh (its exact hull), the truncated hull only feeds the collision tables
+  hull_in = ConvexHull(verts) if maxhullvert >= 4 else hull
+  centre = verts[hull_in.vertices].mean(axis=0)
   canon = np.array([[2, 1, 1], [1, 2, 1], [1, 1, 2]]) / 120.0  # integral of x x^T over the unit tetrahedron
-  for tri, eq in zip(hull.simplices, hull.equations):
+  for tri, eq in zip(hull_in.simplices, hull_in.equations):
     a, b, c = verts[tri] - centre
     if np.dot(np.cross(b - a, c - a), eq[:3]) < 0:
       b, c = c, b
@@ -644,14 +715,14 @@ def _compile(root, base_dir):
   if root.tag != "mujoco":
     raise ValueError("root element must be <mujoco>")
   compiler = {"angle": "degree", "eulerseq": "xyz", "autolimits": True, "inertiafromgeom": "auto",
-              "boundmass": 0.0, "boundinertia": 0.0, "balanceinertia": False, "settotalmass": -1.0}
+              "boundmass": 0.0, "boundinertia": 0.0, "balanceinertia": False, "settotalmass": -1.0, "meshdir": None, "assetdir": None}
   opt = MjOption()
   stat = MjStatistic()
   table = {}
   for elem in root:
     if elem.tag == "compiler":
       for k, v in elem.attrib.items():
-        if k in ("angle", "eulerseq", "inertiafromgeom"):
+        if k in ("angle", "eulerseq", "inertiafromgeom", "meshdir", "assetdir"):
           compiler[k] = v
         elif k in ("autolimits", "balanceinertia"):
           compiler[k] = _bool(v)
@@ -753,8 +824,8 @@ def _compile(root, base_dir):
       name = a.get("hfield")
       if name not in hfield_assets:
         raise ValueError(f"geom refers to unknown hfield {name!r}")
-      if "elevation" not in hfield_assets[name]:
-        raise NotImplementedError("height fields need inline elevation data (<hfield elevation=...>): files are not in this tree")
+      if "elevation" not in hfield_assets[name] and "file" not in hfield_assets[name]:
+        raise ValueError(f"hfield {name!r} has neither elevation data nor a file")
       if name not in hfield_names:
         hfield_names.append(name)
       g["hfield"] = name
@@ -765,11 +836,22 @@ def _compile(root, base_dir):
       asset = mesh_assets.get(g["mesh"])
       if asset is None:
         raise ValueError(f"geom refers to unknown mesh {g['mesh']!r}")
-      if "vertex" not in asset:
-        raise NotImplementedError("colliding mesh geoms need inline vertices (<mesh vertex=...>): mesh files are not in this tree")
       if g["mesh"] not in mesh_compiled:
-        v = np.array(_floats(asset["vertex"])).reshape(-1, 3) * _vec(asset, "scale", [1, 1, 1])
-        mesh_compiled[g["mesh"]] = _compile_mesh(v)
+        if "vertex" in asset:
+          v = np.array(_floats(asset["vertex"])).reshape(-1, 3)
+        elif "file" in asset:  # STL / OBJ, relative to <compiler meshdir> (or assetdir), itself relative to the model file
+          for k in ("refpos", "refquat"):
+            if k in asset:
+              raise NotImplementedError(f"<mesh {k}=...>")
+          mdir = compiler["meshdir"] if compiler["meshdir"] is not None else (compiler["assetdir"] or "")
+          path = asset["file"] if os.path.isabs(asset["file"]) else os.path.join(base_dir or "", mdir, asset["file"])
+          if not os.path.exists(path):
+            raise FileNotFoundError(f"mesh {g['mesh']!r}: file {path!r} not found (colliding mesh geoms need their asset; non-colliding ones do not)")
+          v, _ = read_mesh_file(path)
+        else:
+          raise ValueError(f"mesh {g['mesh']!r} has neither vertex data nor a file")
+        v = v * _vec(asset, "scale", [1, 1, 1])
+        mesh_compiled[g["mesh"]] = _compile_mesh(v, int(asset.get("maxhullvert", -1)))
       md = mesh_compiled[g["mesh"]]
       g["meshdata"] = md
       g["pos"] = pos + nm.rot_vec_quat(md["pos"], quat)  # the geom frame is the mesh's inertial frame (MuJoCo's convention)
@@ -1048,11 +1130,18 @@ def _compile(root, base_dir):
   hdata = []
   for i, name in enumerate(hfield_names):
     ha = hfield_assets[name]
-    nrow, ncol = int(ha["nrow"]), int(ha["ncol"])
-    e = np.array(_floats(ha["elevation"]), dtype=np.float64)
-    if e.size != nrow * ncol:
-      raise ValueError(f"hfield {name}: elevation has {e.size} values, expected {nrow * ncol}")
-    e = e.reshape(nrow, ncol)[::-1]  # (MJCF lists the rows from the far edge (+y) first; MuJoCo stores row 0 at -y)
+    if "elevation" in ha:
+      nrow, ncol = int(ha["nrow"]), int(ha["ncol"])
+      e = np.array(_floats(ha["elevation"]), dtype=np.float64)
+      if e.size != nrow * ncol:
+        raise ValueError(f"hfield {name}: elevation has {e.size} values, expected {nrow * ncol}")
+      e = e.reshape(nrow, ncol)[::-1]  # (MJCF lists the rows from the far edge (+y) first; MuJoCo stores row 0 at -y)
+    else:  # PNG or MuJoCo's binary height-field format, relative to <compiler assetdir> (or meshdir)
+      adir = compiler["assetdir"] if compiler["assetdir"] is not None else (compiler["meshdir"] or "")
+      path = ha["file"] if os.path.isabs(ha["file"]) else os.path.join(base_dir or "", adir, ha["file"])
+      if not os.path.exists(path):
+        raise FileNotFoundError(f"hfield {name!r}: file {path!r} not found")
+      nrow, ncol, e = read_hfield_file(path)
     lo, hi = float(e.min()), float(e.max())
     e = (e - lo) / (hi - lo) if hi > lo else np.zeros_like(e)
     m.hfield_size[i] = _floats(ha["size"])
