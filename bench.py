@@ -188,6 +188,52 @@ def steady_1000(mjw, m, mjm, nworld, world_offset, nstep=1000):
           "timing": "reference placement: per-step device sync, control noise outside the timed region (cli.py:289-292), eager launches"}
 
 
+def other_configs(mjw, nstep=200):
+  """BASELINE.json configs[2] and [3] on this GPU, off the timed headline: the model as authored (Newton, implicitfast), the
+  reference's measurement loop (per-step device sync, noise / replayed control untimed) over `nstep` steps after an untimed lead-in."""
+  import torch
+
+  out = {}
+  for name, rel, nworld, nconmax, njmax, replay in (
+      ("unitree_g1_flat", ("unitree_g1", "scene_flat.xml"), 4096, 48, 192, "shuffle_dance.npz"),
+      ("franka_emika_panda", ("franka_emika_panda", "scene.xml"), 8192, 1, 5, None)):
+    mjm = mjw.mjcf.load_xml(os.path.join(ROOT, "benchmarks", *rel))
+    m = mjw.put_model(mjm)
+    d = mjw.make_data(mjm, nworld=nworld, nconmax=nconmax, njmax=njmax)
+    if mjm.nkey:
+      mjw.reset_data_keyframe(m, d, 0)
+    center = None
+    if replay:  # the recorded controls are the noise centre (reference cli.py:119-145 with --replay)
+      ctrl = mjw.load_trajectory(os.path.join(ROOT, "benchmarks", rel[0], replay), mjm, mjw.MjData(mjm))
+      center = [mjw.DeviceArray.from_numpy(np.asarray(c, dtype=np.float32)) for c in ctrl[: 100 + nstep]]  # [nu]: the noise centre of every world
+      z = np.load(os.path.join(ROOT, "benchmarks", rel[0], replay))
+      if "qpos" in z.files and z["qpos"].shape[1] == mjm.nq:  # start where the recording starts: the controls were made for that state
+        d.qpos.assign(np.tile(z["qpos"][0].astype(np.float32), (nworld, 1)))
+        d.qvel.assign(np.tile(z["qvel"][0].astype(np.float32), (nworld, 1)))
+    total = nefc = niter = 0.0
+    for i in range(100 + nstep):
+      mjw.ctrl_noise(m, d, i, center=center[i] if center else None)
+      torch.cuda.synchronize()
+      t0 = time.perf_counter()
+      mjw.step(m, d)
+      torch.cuda.synchronize()
+      if i >= 100:
+        total += time.perf_counter() - t0
+        if i % 50 == 49:
+          nefc += float(np.minimum(d.nefc.numpy(), d.njmax).mean())
+          niter += float(d.solver_niter.numpy().mean())
+    ok = bool(np.isfinite(d.qpos.numpy()).all())
+    ms_b2b, _ = mjw.timed_steps(m, d, nstep, step0=100 + nstep)
+    out[name] = {"workload": f"{rel[1]}, nworld={nworld}, nconmax={nconmax}, njmax={njmax}, solver / integrator / iteration caps as authored"
+                             + (f", initial state and control centre from {replay} + noise" if replay else ", control noise"),
+                 "value": nworld * nstep / total, "unit": "env-steps/s", "nstep": nstep, "ms_per_step": 1e3 * total / nstep,
+                 "back_to_back_value": nworld * nstep / (ms_b2b * 1e-3), "nefc_mean": nefc / (nstep // 50), "solver_niter_mean": niter / (nstep // 50),
+                 "finite": ok, "overflow_bits": int(np.bitwise_or.reduce(d.overflow.numpy())),
+                 "timing": "reference placement (per-step sync, control untimed); back_to_back_value = the same steps enqueued without syncs"}
+    del d
+  return out
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument("--gpus", type=int, default=1)
@@ -199,7 +245,9 @@ def main():
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--no-roofline", action="store_true")
   ap.add_argument("--no-steady", action="store_true", help="skip the 1000-step reference-placement figure")
-  ap.add_argument("--pmc-profile", default=None, help="rocprofv3 PMC summary (tools/make_pmc_summary.py) of this solver's kernel")
+  ap.add_argument("--pmc-profile", default="auto", help="rocprofv3 PMC summary (tools/make_pmc_summary.py) of this solver's kernel; "
+                  "auto = the committed profiles/round3_pmc_<solver>.json (labelled as such in traffic_source), none = null")
+  ap.add_argument("--no-configs", action="store_true", help="skip the BASELINE configs[2] / [3] figures (G1 4096 worlds, Panda 8192 worlds)")
   args = ap.parse_args()
   if args.gpus < 1:
     raise SystemExit("--gpus must be >= 1")
@@ -308,6 +356,8 @@ def main():
     out["steady_1000"] = steady_1000(mjw, m, mjm, cnt, off)
   shard.barrier()
 
+  if rank == 0 and world_size == 1 and not args.no_configs:
+    out["configs"] = other_configs(mjw)
   if rank == 0 and cpu is not None:
     out["cpu_baseline"] = cpu
   if rank == 0:
@@ -321,14 +371,21 @@ def main():
 def _traffic_from_profile(path, solver):
   """HBM bytes per solver launch from a rocprofv3 PMC summary of the SAME solver's kernel (FETCH_SIZE x2 on gfx950 + WRITE_SIZE,
   separate passes: MI355X_MICROARCH.md).  Without such a profile the field is null: a number from another run is not a measurement."""
-  if not path:
+  committed = False
+  if path == "auto":
+    path = os.path.join(ROOT, "profiles", f"round3_pmc_{solver}.json")
+    committed = True
+    if not os.path.exists(path):
+      path = None
+  if not path or path == "none":
     return None, "not collected in this run (rocprofv3 --pmc needs its own passes; see profiles/)"
   try:
     with open(path) as f:
       j = json.load(f)
     if j.get("solver") != solver:
       return None, f"{path} holds solver={j.get('solver')}, this run is {solver}"
-    return j.get("k_solve_hbm_bytes_per_launch"), f"{path} (rocprofv3 PMC passes of the same workload, not this process)"
+    src = f"{os.path.relpath(path, ROOT)} (rocprofv3 PMC passes of the same workload and solver, NOT this process"
+    return j.get("k_solve_hbm_bytes_per_launch"), src + ("; committed with the repo: re-collect with tools/profile_round.sh after kernel changes)" if committed else ")")
   except Exception as e:
     return None, f"{path}: {e}"
 

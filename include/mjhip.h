@@ -56,7 +56,9 @@ extern "C" {
 #define MJH_STAGE_WAKE_EQUALITY 23   /* sleep.wake_equality (+ update_sleep)  sleep.py:793 */
 #define MJH_STAGE_ISLAND 24          /* island.island                island.py:294 */
 #define MJH_STAGE_SLEEP 25           /* sleep.sleep (+ update_sleep) sleep.py:947 */
-#define MJH_STAGE_SENSOR 26          /* sensor.sensor_pos + sensor_vel + (actuator forces of) sensor_acc  sensor.py:810, 1432, 2512 */
+#define MJH_STAGE_SENSOR 26          /* sensor.sensor_pos + sensor_vel, then sensor_acc  sensor.py:810, 1432, 2512 */
+#define MJH_STAGE_SENSOR_POSVEL 30   /* sensor.sensor_pos + sensor_vel only (before the solver: nothing reads qacc / efc_force)  sensor.py:810, 1432 */
+#define MJH_STAGE_SENSOR_ACC 31      /* sensor.sensor_acc only (after the solver; runs rne_postconstraint when a sensor needs it)  sensor.py:2512 */
 #define MJH_STAGE_ENERGY 27          /* sensor.energy_pos + energy_vel  sensor.py:2934, 3003 */
 #define MJH_STAGE_SUBTREE_VEL 28     /* smooth.subtree_vel  smooth.py:3614 */
 #define MJH_STAGE_RNE_POSTCONSTRAINT 29 /* smooth.rne_postconstraint  smooth.py:1744 */

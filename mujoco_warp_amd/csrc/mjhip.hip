@@ -519,6 +519,8 @@ static int run_stage(const MjhModel* m, const MjhData* d, int stage, hipStream_t
       return MJH_OK;
     }
     case MJH_STAGE_SENSOR: { Scope sc(K_OTHER); TRY(launch_sensor(m, d, 0, s)); return launch_sensor(m, d, 1, s); }
+    case MJH_STAGE_SENSOR_POSVEL: { Scope sc(K_OTHER); return launch_sensor(m, d, 0, s); }
+    case MJH_STAGE_SENSOR_ACC: { Scope sc(K_OTHER); return launch_sensor(m, d, 1, s); }
     case MJH_STAGE_UPDATE_SLEEP:
     case MJH_STAGE_WAKE:
     case MJH_STAGE_WAKE_COLLISION:
@@ -678,6 +680,7 @@ int mjh_rays(const MjhModel* m, const MjhData* d, const float* pnt, const float*
   if (!pnt || !vec || !dist) return fail(MJH_E_ARG, "mjh_rays: null pnt / vec / dist");
   if (nray < 0 || (pnt_nworld != 1 && pnt_nworld != d->nworld)) return fail(MJH_E_ARG, "mjh_rays: pnt_nworld must be 1 or nworld");
   if (nray == 0) return MJH_OK;
+  if ((long long)d->nworld * nray > 0x7fffffffLL) return fail(MJH_E_ARG, "mjh_rays: nworld * nray exceeds 2^31 - 1 (cast the rays in several calls)");
   RayGroup gg;
   for (int i = 0; i < 6; ++i) gg.g[i] = geomgroup ? geomgroup[i] : -1.0f;
   hipLaunchKernelGGL(k_rays, dim3((d->nworld * nray + 255) / 256), dim3(256), 0, (hipStream_t)stream, *m, *d, pnt, vec, pnt_nworld, nray, gg, flg_static, bodyexclude, dist,

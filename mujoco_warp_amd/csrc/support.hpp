@@ -9,9 +9,9 @@ __global__ void __launch_bounds__(256) k_contact_force(MjhModel m, MjhData d, co
   const int tid = blockIdx.x * 256 + threadIdx.x;
   if (tid >= n) return;
   const int cid = contact_ids[tid];
-  if (cid >= d.nacon[0]) return;
-  float f[6];
-  contact_force_of(m, d, cid, to_world_frame, f);
+  float f[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+  // (-1 is the usual "no contact" marker: a zero wrench, and nothing is read through the id)
+  if (cid >= 0 && cid < d.nacon[0]) contact_force_of(m, d, cid, to_world_frame, f);
   for (int k = 0; k < 6; ++k) out[(size_t)tid * 6 + k] = f[k];
 }
 DEV void contact_force_of(const MjhModel& m, const MjhData& d, int cid, int to_world_frame, float (&f)[6]) {

@@ -249,19 +249,20 @@ def energy_vel(m, d):
 
 def sensor_pos(m, d):
   """Position-stage sensors (reference sensor.sensor_pos, sensor.py:810).  This engine computes the position and velocity stages (and
-  the actuator forces) in one launch: sensor_pos and sensor_vel both run it; call them after fwd_position / fwd_velocity / fwd_actuation."""
-  _run(_S["MJH_STAGE_SENSOR"], m, d)
+  Data.energy) in one launch: sensor_pos and sensor_vel both run it; call them after fwd_position / fwd_velocity.  Nothing of the
+  acceleration stage runs (no rne_postconstraint on stale forces, cacc / cfrc_* untouched)."""
+  _run(_S["MJH_STAGE_SENSOR_POSVEL"], m, d)
 
 
 def sensor_vel(m, d):
   """Velocity-stage sensors (reference sensor.sensor_vel, sensor.py:1432); see sensor_pos."""
-  _run(_S["MJH_STAGE_SENSOR"], m, d)
+  _run(_S["MJH_STAGE_SENSOR_POSVEL"], m, d)
 
 
 def sensor_acc(m, d):
-  """Acceleration-stage sensors (reference sensor.sensor_acc, sensor.py:2512): accelerometer, frame accelerations, actuator forces; call
-  after the solver."""
-  _run(_S["MJH_STAGE_SENSOR"], m, d)
+  """Acceleration-stage sensors only (reference sensor.sensor_acc, sensor.py:2512): accelerometer, force / torque / touch (after an
+  rne_postconstraint launch when one of them is present), frame accelerations, actuator forces; call after the solver."""
+  _run(_S["MJH_STAGE_SENSOR_ACC"], m, d)
 
 
 def efc_J_sparse(m, d, njmax_nnz: int = None):
@@ -298,7 +299,10 @@ class StepGraph:
     side.wait_stream(torch.cuda.current_stream())
     # mjh_graph_create runs one real step before capturing (kernel attributes cannot be set during capture): keep the state,
     # constructing a graph must not advance the simulation (the reference's capture does not either)
-    keep = {k: getattr(d, k).t.clone() for k in ("qpos", "qvel", "act", "ctrl", "time", "qacc_warmstart", "qacc", "solver_niter", "overflow") if getattr(d, k).size}
+    names = ["qpos", "qvel", "act", "ctrl", "time", "qacc_warmstart", "qacc", "solver_niter", "overflow", "sensordata", "energy", "act_dot"]
+    # sleeping models: the warm-up step would advance the sleep counters / wake state / island tables by one step
+    names += ["tree_asleep", "tree_awake", "body_awake", "body_awake_ind", "dof_awake_ind", "ntree_awake", "nbody_awake", "nv_awake", "tree_island", "nisland"]
+    keep = {k: getattr(d, k).t.clone() for k in names if getattr(d, k, None) is not None and getattr(d, k).size}
     rc = L.mjh_graph_create(ctypes.byref(io.c_model(m)), ctypes.byref(io.c_data(d)), ctypes.c_void_p(side.cuda_stream), ctypes.byref(self._exec))
     torch.cuda.current_stream().wait_stream(side)
     for k, v in keep.items():

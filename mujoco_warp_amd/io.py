@@ -227,6 +227,16 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
   m._heavy_pairs = int(any((int(min(gt[a], gt[b])), int(max(gt[a], gt[b]))) in ((3, 6), (6, 6), (0, 7)) for a, b in pairs) or int(getattr(mjm, "npair", 0)) > 0
                        or m._convex_pairs)
   m.heavy_colliders = m._heavy_pairs  # c_model() adds the broadphase options (they may be changed after put_model)
+  # mesh / height-field geoms a ray could hit (visible colour: the reference's _ray_eliminate keeps them, ray.py:52): rays against
+  # them are not implemented, so rays() and the rangefinder sensor refuse such models instead of silently reporting "no hit"
+  g_rgba = np.asarray(getattr(mjm, "geom_rgba", np.tile([0.5, 0.5, 0.5, 1.0], (ngeom, 1))), dtype=np.float64).reshape(-1, 4)
+  g_mat = np.asarray(getattr(mjm, "geom_matid", np.full(ngeom, -1))).reshape(-1)
+  m_rgba = np.asarray(getattr(mjm, "mat_rgba", np.zeros((0, 4))), dtype=np.float64).reshape(-1, 4)
+  m._ray_unsupported_geoms = int(sum(1 for g in range(ngeom) if int(gt[g]) in (int(types.GeomType.MESH), int(types.GeomType.HFIELD))
+                                     and (m_rgba[g_mat[g], 3] if g_mat[g] >= 0 else g_rgba[g, 3]) != 0.0))
+  if m._ray_unsupported_geoms and any(int(t) == 7 for t in np.asarray(getattr(mjm, "sensor_type", np.zeros(0))).reshape(-1)):
+    raise NotImplementedError("rangefinder sensor in a model with visible mesh / height-field geoms: rays against those geoms are not implemented "
+                              "(they would be reported as no hit); make them invisible to rays (rgba alpha 0) or drop the sensor")
   m.is_sparse = False
 
   m.nv_pad = _get_padded_sizes(nv, 1)[1]
@@ -743,6 +753,8 @@ def get_state(m: types.Model, d: types.Data, state: DeviceArray, sig: int, activ
   (reference support.get_state, support.py:674); `active` is an optional per-world mask.  Device-to-device copies."""
   import torch
 
+  if tuple(state.shape) != (d.nworld, state_size(m, int(sig))):  # (checked before anything is written)
+    raise ValueError(f"state must have shape ({d.nworld}, {state_size(m, int(sig))})")
   mask = None if active is None else torch.as_tensor(np.asarray(active.numpy() if hasattr(active, "numpy") else active, dtype=bool), device=state.t.device)
   adr = 0
   for arr, n in _state_fields(m, d, int(sig)):
@@ -753,8 +765,6 @@ def get_state(m: types.Model, d: types.Data, state: DeviceArray, sig: int, activ
     else:
       dst[mask] = src[mask]
     adr += n
-  if tuple(state.shape) != (d.nworld, adr):
-    raise ValueError(f"state must have shape ({d.nworld}, {adr})")
 
 
 def set_state(m: types.Model, d: types.Data, state: DeviceArray, sig: int, active=None):

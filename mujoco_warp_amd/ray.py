@@ -1,6 +1,8 @@
 """Ray casting against the primitive geoms (reference ray.py:1172 ray, 1219 rays): host mirror over mjh_rays (csrc/ray.hpp).
 
-Mesh and height-field geoms are not intersected (they report no hit); there is no BVH / render context."""
+Mesh and height-field geoms are not intersected: `rays()` and `put_model` (for a rangefinder sensor) raise NotImplementedError on a model
+that has such geoms with a visible colour (the reference's ray elimination, ray.py:52) instead of silently reporting "no hit"; there is
+no BVH / render context."""
 
 import ctypes
 from typing import Optional, Sequence, Tuple
@@ -23,6 +25,9 @@ def rays(m, d, pnt: DeviceArray, vec: DeviceArray, geomgroup: Optional[Sequence[
   dist [nworld, nray] (-1: no hit), geomid [nworld, nray] (-1), normal [nworld, nray, 3] are written; geomid / normal may be None."""
   if rc is not None:
     raise NotImplementedError("render contexts (BVH-accelerated mesh / flex rays) are not part of this engine")
+  if getattr(m, "_ray_unsupported_geoms", 0):
+    raise NotImplementedError(f"{m._ray_unsupported_geoms} mesh / height-field geom(s) can be hit by rays in this model: rays against them are not "
+                              "implemented (they would silently report no hit); give those geoms rgba alpha 0 if rays are meant to pass through them")
   if len(pnt.shape) != 3 or pnt.shape[2] != 3 or tuple(pnt.shape) != tuple(vec.shape):
     raise ValueError(f"pnt {pnt.shape} and vec {vec.shape} must both be [1 or nworld, nray, 3]")
   if pnt.shape[0] not in (1, d.nworld):

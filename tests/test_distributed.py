@@ -63,3 +63,79 @@ def test_metrics_allreduce_gloo_world_size_2():
 
 def test_reduce_metrics_single_process():
   assert shard.reduce_metrics(0.5, 100.0, 0.0, 1.0) == (0.5, 100.0, 0.0, 1.0)
+
+
+def test_bench_respawn_builds_the_torchrun_command(monkeypatch):
+  """`python bench.py --gpus N` without a torch.distributed environment re-executes itself under torch.distributed.run: one rank per
+  GPU on this node, rendezvous on 127.0.0.1, the caller's flags passed through, dmabuf IPC mode kept in the environment."""
+  import sys
+
+  sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+  import bench
+
+  seen = {}
+
+  def fake_call(cmd, env=None):
+    seen["cmd"], seen["env"] = cmd, env
+    return 7
+
+  monkeypatch.setattr(bench.subprocess, "call", fake_call)
+  monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "20", "--warmup", "5", "--scaling", "strong"])
+  monkeypatch.delenv("HSA_ENABLE_IPC_MODE_LEGACY", raising=False)
+  monkeypatch.setenv("MJH_DIST_BACKEND", "gloo")
+  assert bench.respawn_under_torchrun(4) == 7
+  cmd = seen["cmd"]
+  assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+  assert "--nnodes=1" in cmd and "--nproc-per-node=4" in cmd
+  assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and 1024 < int(cmd[cmd.index("--master-port") + 1]) < 65536
+  i = cmd.index(os.path.abspath(bench.__file__))
+  assert cmd[i + 1 :] == ["--gpus", "4", "--steps", "20", "--warmup", "5", "--scaling", "strong"]
+  assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and seen["env"]["MJH_DIST_BACKEND"] == "gloo"
+
+
+def test_bench_main_respawns_only_without_a_distributed_environment(monkeypatch):
+  import sys
+
+  sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+  import bench
+
+  calls = []
+  monkeypatch.setattr(bench, "respawn_under_torchrun", lambda n: calls.append(n) or 0)
+  monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2"])
+  monkeypatch.delenv("WORLD_SIZE", raising=False)
+  with pytest.raises(SystemExit) as e:
+    bench.main()
+  assert e.value.code == 0 and calls == [2]
+  with pytest.raises(SystemExit):  # --gpus must be positive
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "0"])
+    bench.main()
+
+
+@pytest.mark.gpu
+def test_gpu_shard_invariance_with_control_noise():
+  """(e): 64 worlds stepped as ONE Data are bitwise the 64 worlds stepped as two Data of 32 with world_offset 0 / 32 -- control noise
+  on (it is keyed by the global world id), 50 steps, CG and Newton.  The solver's longest-first schedule and world pairing differ
+  between the two layouts; no world's arithmetic may depend on which worlds share its wavefront."""
+  import mujoco_warp_amd as mjw
+  from tests import conftest
+
+  mjm = mjw.mjcf.load_xml(conftest.HUMANOID_XML)
+  for solver in ("cg", "newton"):
+    mjw.override_model(mjm, {"opt.solver": solver})
+    m = mjw.put_model(mjm)
+    whole = mjw.make_data(mjm, nworld=64, nconmax=24, njmax=64)
+    halves = [mjw.make_data(mjm, nworld=32, nconmax=24, njmax=64) for _ in range(2)]
+    halves[1].world_offset = 32
+    for d in [whole] + halves:
+      mjw.reset_data_keyframe(m, d, 0)
+    for i in range(50):
+      for d in [whole] + halves:
+        mjw.ctrl_noise(m, d, i)
+        mjw.step(m, d)
+    q = np.concatenate([h.qpos.numpy() for h in halves])
+    v = np.concatenate([h.qvel.numpy() for h in halves])
+    c = np.concatenate([h.ctrl.numpy() for h in halves])
+    assert (whole.ctrl.numpy() == c).all(), solver
+    assert len(np.unique(whole.qpos.numpy(), axis=0)) == 64  # the noise really decorrelated the worlds
+    assert (whole.qpos.numpy() == q).all() and (whole.qvel.numpy() == v).all(), solver
+    assert (whole.solver_niter.numpy() == np.concatenate([h.solver_niter.numpy() for h in halves])).all()

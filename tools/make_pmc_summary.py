@@ -1,18 +1,30 @@
-"""profiles/round1_pmc_summary.json from a tools/profile.sh summary: HBM traffic per launch of the dominant kernel.
+"""profiles/roundN_pmc_<solver>.json from a tools/profile.sh summary: HBM traffic per launch of every kernel, MFMA counters.
 
 usage: python tools/make_pmc_summary.py gpurun_out/prof_<tag>/summary.json profiles/roundN_pmc_<solver>.json <solver>
-FETCH_SIZE / WRITE_SIZE are collected in their own rocprofv3 --pmc passes (tools/profile.sh); FETCH_SIZE is doubled on
-gfx950 as MI355X_MICROARCH.md prescribes (it under-reports wide coalesced reads by 2x), both are KiB units.
+FETCH_SIZE / WRITE_SIZE are collected in their own rocprofv3 --pmc passes (tools/profile.sh), both in KiB.  On gfx950 FETCH_SIZE
+under-reports WIDE coalesced reads (16 bytes per lane) by 2x (MI355X_MICROARCH.md); other access widths are uncalibrated there.  Round 3
+calibrates per kernel instead of doubling everything: a kernel whose reads are 4-byte lane loads is taken at face value -- checked on
+k_fwd_pos, whose only Data read is qpos (8192 x 28 x 4 = 0.92 MB: raw 0.86 MB, doubled 1.72 MB) --, a kernel that reads mostly with
+16-byte lane loads is doubled, and the solver (J rows by float4, everything else by dword) is reported as the [raw, 2 x raw] bracket
+with the J share doubled as the point estimate.
 """
 import json, sys
 src, dst = sys.argv[1], sys.argv[2]
 s = json.load(open(src))
 out = {"source": src, "solver": sys.argv[3] if len(sys.argv) > 3 else None, "kernels": {}}
+# read width of each kernel's Data loads (csrc): gcopy / scalar loads = 4 bytes per lane; the solvers stage J with float4 loads
+WIDE_SHARE = {"k_fwd_pos": 0.0, "k_mid": 0.0, "k_integrate": 0.0, "k_fwd_vel": 0.0, "k_collision": 0.0, "k_make_constraint": 0.15, "k_publish_contacts": 0.0,
+              "k_factor_smooth": 0.0, "k_ctrl_noise": 0.0}
 for k, c in s.get("pmc_per_dispatch", {}).items():
-  if "fetch_bytes_gfx950_corrected" in c:
-    out["kernels"][k] = {"fetch_bytes_per_launch": c["fetch_bytes_gfx950_corrected"], "write_bytes_per_launch": c.get("write_bytes"),
-                         "hbm_bytes_per_launch": c["fetch_bytes_gfx950_corrected"] + c.get("write_bytes", 0.0),
-                         "valu_insts_per_launch": c.get("SQ_INSTS_VALU"), "busy_cycles_sum": c.get("SQ_BUSY_CYCLES")}
+  if "fetch_bytes_raw" in c:
+    raw = c["fetch_bytes_raw"]
+    share = WIDE_SHARE.get(k, 0.75 if k.startswith("k_solve") else None)  # solver: J is ~3/4 of what it reads
+    est = raw * (1.0 + share) if share is not None else None
+    out["kernels"][k] = {"fetch_bytes_raw": raw, "fetch_bytes_x2": 2 * raw, "fetch_bytes_calibrated": est, "wide_load_share_assumed": share,
+                         "write_bytes_per_launch": c.get("write_bytes"),
+                         "hbm_bytes_per_launch": (est if est is not None else 2 * raw) + c.get("write_bytes", 0.0),
+                         "valu_insts_per_launch": c.get("SQ_INSTS_VALU"), "busy_cycles_sum": c.get("SQ_BUSY_CYCLES"),
+                         "mfma_mops_f32": c.get("SQ_INSTS_VALU_MFMA_MOPS_F32"), "mfma_busy_cycles": c.get("SQ_VALU_MFMA_BUSY_CYCLES"), "mfma_insts": c.get("SQ_INSTS_MFMA")}
 dom = [k for k in out["kernels"] if k.startswith("k_solve<") or k == "k_solve_newton"]
 dom.sort(key=lambda k: -(out["kernels"][k].get("busy_cycles_sum") or 0.0))
 if dom:
@@ -21,5 +33,9 @@ if dom:
 for t in s.get("kernel_trace", []):
   if t["kernel"] in out["kernels"]:
     out["kernels"][t["kernel"]]["mean_us"] = t["mean_us"]
+    k = out["kernels"][t["kernel"]]
+    if k.get("mfma_busy_cycles") and k.get("busy_cycles_sum"):
+      # MFMA pipe utilisation: busy cycles of the MFMA unit / busy cycles of the shader engines' SQs over the kernel (both summed over instances)
+      k["mfma_busy_frac_of_sq_busy"] = k["mfma_busy_cycles"] / k["busy_cycles_sum"]
 json.dump(out, open(dst, "w"), indent=1)
 print(json.dumps(out)[:600])

@@ -99,7 +99,7 @@ def main():
     summary["kernel_trace"] = kernel_trace(f)
     summary["timeline"] = timeline(f)
   counters = defaultdict(dict)
-  for tag in ("pmc_sq", "pmc_sq2", "pmc_fetch", "pmc_write"):
+  for tag in ("pmc_sq", "pmc_sq2", "pmc_mfma", "pmc_fetch", "pmc_write"):
     for f in glob.glob(os.path.join(out, tag, "*.db")):
       for k, cs in pmc(f).items():
         counters[k].update(cs)
