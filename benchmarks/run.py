@@ -54,6 +54,11 @@ def main():
     nstep = args.nstep if args.nstep is not None else b.get("nstep")
     if nstep is not None:
       cmd.append(f"--nstep={nstep}")
+    for key in ("nvmax", "nccdmax"):
+      if b.get(key) is not None:
+        cmd.append(f"--{key}={b[key]}")
+    if b.get("init_asleep"):
+      cmd.append("--init_asleep=true")
     if b.get("replay"):
       cmd.append("--replay=" + os.path.join(folder, b["replay"]))
     for o in b.get("override", []):

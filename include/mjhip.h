@@ -284,6 +284,8 @@ typedef struct MjhData {
   float* ws_sleep_warm; /* [nworld, nv] qacc_warmstart with sleeping dofs zeroed */
   int* ws_sleep_flag;  /* [nworld] a tree of the world was woken by a contact of collision pass 1 (forward.py:652-666) */
   int sleep_pass;      /* launch-local: 0 plain collision, 2 second pass (only worlds with ws_sleep_flag set recompute) */
+  int nvmax;           /* capacity for awake dofs per world (make_data / put_data nvmax, reference io.py:1704; default nv): a world with
+                          more awake dofs gets OverflowType.NVMAX (island.py:1010-1019) -- this engine still solves it in full */
   int* ws_efc_con;     /* [nworld, njmax] contact rows: 16 * (world-local contact) + row within the contact (make_constraint -> solver,
                           elliptic cones only) */
   int* ws_order;       /* [nworld]   solver schedule: worlds sorted by last step's solver_niter (longest first) */
@@ -350,7 +352,7 @@ int mjh_timed_steps(const MjhModel* m, const MjhData* d, int nstep, int step0, f
 int mjh_release_thread_resources(void);
 
 const char* mjh_last_error(void);
-#define MJH_ABI_VERSION 31
+#define MJH_ABI_VERSION 32
 int mjh_abi_version(void); /* returns MJH_ABI_VERSION of the library that was loaded */
 
 #ifdef __cplusplus

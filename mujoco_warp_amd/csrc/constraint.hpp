@@ -597,6 +597,7 @@ __global__ void __launch_bounds__(64) k_tree_rows(MjhModel m, MjhData d) {
       const int nd = dofadr[k + 1] - dofadr[k], nr = rowadr[k + 1] - rowadr[k];
       if (nd > 32) flags |= ISL_WIDE;
       else if (nr > 64) flags |= ISL_MANYROWS;
+      if (nr > 192) fits = false;  // (the register-resident kernels end at 192 rows per island: 6 x 32 / 3 x 64 lanes -- the generic solver takes the world)
     }
     d.ws_isl_flags[w] = fits ? flags : 0;
     // worlds of the rare classes are listed for the looped launches (one atomic each; the counters are cleared before this kernel)

@@ -138,6 +138,9 @@ DEV void integrate_body(const MjhModel& m, const MjhData& d, int mode, float* sm
   float* qpos = d.qpos + (size_t)w * nq;
   for (int j = lig; j < njnt; j += G) {  // _next_position forward.py:53
     const int qa = m.jnt_qposadr[j], dof = m.jnt_dofadr[j], t = m.jnt_type[j];
+    // joints of a sleeping tree are not integrated at all (the reference advances the awake dofs only, forward.py:276-349 over
+    // dof_awake_ind): their velocity is zero, but re-normalising a quaternion would still move it by an ulp per step
+    if (m.sleep_enabled && d.tree_awake && !d.tree_awake[(size_t)w * m.ntree + m.dof_treeid[dof]]) continue;
     if (t == JNT_FREE) {
       for (int k = 0; k < 3; ++k) qpos[qa + k] += h * qvel[dof + k];
       st4(qpos + qa + 3, quat_integrate(ld4(qpos + qa + 3), ld3(qvel + dof + 3), h));

@@ -244,12 +244,11 @@ static thread_local bool g_fuse_euler = false;
 static thread_local bool g_riders_on_side = false;
 static int solve_supported(const MjhModel* m, const MjhData* d) {
   if (m->cone != CONE_PYRAMIDAL && m->cone != CONE_ELLIPTIC) return fail(MJH_E_UNSUPPORTED, "unknown cone type");
-  if (m->cone == CONE_ELLIPTIC && (m->nv > 64 || m->solver == SOL_PGS))
-    return fail(MJH_E_UNSUPPORTED, "elliptic cones need the CG or Newton solver and at most 64 dofs");
+  if (m->cone == CONE_ELLIPTIC && m->solver == SOL_PGS) return fail(MJH_E_UNSUPPORTED, "PGS with elliptic cones is not implemented");
   if (m->nv > 64 && m->solver == SOL_PGS) return fail(MJH_E_UNSUPPORTED, "PGS supports at most 64 dofs");
   if (m->solver != SOL_NEWTON && m->solver != SOL_CG && m->solver != SOL_PGS) return fail(MJH_E_UNSUPPORTED, "unknown solver");
-  if (m->nv <= 64 && d->njmax > 192 && (m->solver == SOL_PGS || m->cone == CONE_ELLIPTIC))
-    return fail(MJH_E_UNSUPPORTED, "njmax > 192 with PGS or elliptic cones is not supported (the generic solver that takes the worlds with more than 192 rows is CG / Newton, pyramidal)");
+  if (m->nv <= 64 && d->njmax > 192 && m->solver == SOL_PGS)
+    return fail(MJH_E_UNSUPPORTED, "njmax > 192 with PGS is not supported (the generic solver that takes the worlds with more than 192 rows is CG / Newton)");
   return MJH_OK;
 }
 static int launch_solve_any(const MjhModel* m, const MjhData* d, bool with_factor, hipStream_t s) {
@@ -260,7 +259,8 @@ static int launch_solve_any(const MjhModel* m, const MjhData* d, bool with_facto
       // register-resident kernels, the others by the generic solver below
       hipLaunchKernelGGL(k_isl_clear, dim3(1), dim3(64), 0, s, *d);
       hipLaunchKernelGGL(k_tree_rows, dim3(d->nworld), dim3(64), sizeof(int) * (size_t)(2 * std::max(d->njmax, 1) + 2 * m->ntree), s, *m, *d);
-      if (int rc = (m->solver == SOL_NEWTON ? launch_solve_tree_newton : launch_solve_tree_cg)(m, d, s)) return rc;
+      const bool ell_t = m->cone == CONE_ELLIPTIC && d->nmaxpyramid > 1;
+      if (int rc = (m->solver == SOL_NEWTON ? (ell_t ? launch_solve_tree_newton_ell : launch_solve_tree_newton) : (ell_t ? launch_solve_tree_cg_ell : launch_solve_tree_cg))(m, d, s)) return rc;
     }
     return launch_solve_big(m, d, s);
   }

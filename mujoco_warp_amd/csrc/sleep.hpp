@@ -256,6 +256,9 @@ __global__ void __launch_bounds__(256) k_sleep_mask(MjhModel m, MjhData d) {
     d.ws_sleep_J[jo + idx] = awake ? d.efc_J[jo + idx] : 0.0f;
   }
   for (int i = threadIdx.x; i < nv; i += 256) d.ws_sleep_warm[(size_t)w * nv + i] = tawake[m.dof_treeid[i]] ? d.qacc_warmstart[(size_t)w * nv + i] : 0.0f;
+  // the reference compacts the awake dofs into nvmax-wide arrays and flags a world that does not fit (island.py:1010-1019, "behavior
+  // undefined"); here nothing is compacted, so the world is solved in full and only the flag is raised
+  if (threadIdx.x == 0 && d.nv_awake[w] > d.nvmax) atomicOr(d.overflow + w, OVF_NVMAX);
 }
 // forward.py:1273-1278: no smooth force on the dofs of a sleeping tree (the L'DL solve of a zero right-hand side then leaves their
 // qacc_smooth at exactly 0, the reference's "frozen inactive DOF", solver.py:3896)

@@ -21,7 +21,7 @@ __global__ void __launch_bounds__(64) k_solve_big(MjhModel m, MjhData d, int nef
 }
 
 int launch_solve_big(const MjhModel* m, const MjhData* d, hipStream_t s, int nefc_lo) {
-  const BigLayout lay = big_layout(m->nv, m->nC, d->njmax, m->solver == SOL_NEWTON);
+  const BigLayout lay = big_layout(m->nv, m->nC, d->njmax, m->solver == SOL_NEWTON, m->cone == CONE_ELLIPTIC && d->nmaxpyramid > 1);
   const size_t lds = sizeof(int) * mstruct_ints(m->nv, m->nC) + sizeof(float) * lay.total;
   if (lds > (size_t)kLdsPerCU) return fail(MJH_E_UNSUPPORTED, "k_solve_big: nv / njmax do not fit in LDS");
   HIPCHK(set_lds(k_solve_big, lds));

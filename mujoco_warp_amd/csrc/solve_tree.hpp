@@ -11,7 +11,7 @@
 // such an island (ws_isl_list / ws_isl_count, one atomic per listed world); a small grid walks that list, so a batch without such
 // islands costs one load per wavefront instead of one empty LDS-heavy block per island slot (measured: two mostly empty launches cost
 // 140 us on 8192 three-humanoid worlds) and a batch with many of them is spread evenly over the grid.
-template <int NV4, int NR, bool NEWTON, int SG, bool LOOPED>
+template <int NV4, int NR, bool NEWTON, int SG, bool LOOPED, bool ELL = false>
 __global__ void __launch_bounds__(256) k_solve_tree(MjhModel m, MjhData d, int nefc_lo, int nefc_hi, int nv_lo, int nv_hi, int need) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int wpb = blockDim.x / SG;
@@ -25,16 +25,16 @@ __global__ void __launch_bounds__(256) k_solve_tree(MjhModel m, MjhData d, int n
       for (int k0 = 0; k0 < nisl; k0 += wpb) {
         int slot = w * m.ntree + k0;
         asm volatile("" : "+s"(slot));  // (keeps LICM from hoisting the body's address arithmetic out of the loops)
-        solve_body<NV4, NR, NEWTON, SG, false, true>(m, d, smem, Blk{slot, min(wpb, nisl - k0), (int)blockDim.x}, nefc_lo, nefc_hi, 0, nv_lo, nv_hi);
+        solve_body<NV4, NR, NEWTON, SG, ELL, true>(m, d, smem, Blk{slot, min(wpb, nisl - k0), (int)blockDim.x}, nefc_lo, nefc_hi, 0, nv_lo, nv_hi);
       }
     }
     return;
   }
-  solve_body<NV4, NR, NEWTON, SG, false, true>(m, d, smem, Blk{(int)blockIdx.x * wpb, wpb, (int)blockDim.x}, nefc_lo, nefc_hi, 0, nv_lo, nv_hi);
+  solve_body<NV4, NR, NEWTON, SG, ELL, true>(m, d, smem, Blk{(int)blockIdx.x * wpb, wpb, (int)blockDim.x}, nefc_lo, nefc_hi, 0, nv_lo, nv_hi);
 }
-template <int NV4, int NR, bool NEWTON, int SG, bool LOOPED>
+template <int NV4, int NR, bool NEWTON, int SG, bool LOOPED, bool ELL = false>
 static int launch_tree_t(const MjhModel* m, const MjhData* d, hipStream_t s, int lo, int hi, int nv_lo, int nv_hi, int need = 0) {
-  const SolveLayout lay = solve_layout<NV4, NR, SG, NEWTON, false, true>(d->njmax);
+  const SolveLayout lay = solve_layout<NV4, NR, SG, NEWTON, ELL, true>(d->njmax);
   size_t lds;
   int threads = pick_block(0, sizeof(float) * lay.total, SG, &lds, true);
   if (!threads) return fail(MJH_E_UNSUPPORTED, "k_solve_tree: rows x dofs of an island do not fit in LDS");
@@ -42,38 +42,38 @@ static int launch_tree_t(const MjhModel* m, const MjhData* d, hipStream_t s, int
     threads = 64;
     lds = sizeof(float) * lay.total * (64 / SG);
   }
-  HIPCHK(set_lds((k_solve_tree<NV4, NR, NEWTON, SG, LOOPED>), lds));
+  HIPCHK(set_lds((k_solve_tree<NV4, NR, NEWTON, SG, LOOPED, ELL>), lds));
   const int wpb = threads / SG, n = d->nworld * m->ntree;
   const int grid = LOOPED ? std::min(d->nworld, 2048) : (n + wpb - 1) / wpb;
-  debug_occupancy(NEWTON ? "k_solve_tree<newton>" : "k_solve_tree<cg>", k_solve_tree<NV4, NR, NEWTON, SG, LOOPED>, grid, threads, lds);
-  hipLaunchKernelGGL((k_solve_tree<NV4, NR, NEWTON, SG, LOOPED>), dim3(grid), dim3(threads), lds, s, *m, *d, lo, hi, nv_lo, nv_hi, need);
+  debug_occupancy(NEWTON ? "k_solve_tree<newton>" : "k_solve_tree<cg>", k_solve_tree<NV4, NR, NEWTON, SG, LOOPED, ELL>, grid, threads, lds);
+  hipLaunchKernelGGL((k_solve_tree<NV4, NR, NEWTON, SG, LOOPED, ELL>), dim3(grid), dim3(threads), lds, s, *m, *d, lo, hi, nv_lo, nv_hi, need);
   return MJH_OK;
 }
-template <int NR, bool NEWTON, bool LOOPED>
+template <int NR, bool NEWTON, bool LOOPED, bool ELL = false>
 static int launch_tree_32(const MjhModel* m, const MjhData* d, int nv4, hipStream_t s, int lo, int hi, int need) {
   switch (nv4) {
     case 0:
-    case 1: return launch_tree_t<1, NR, NEWTON, 32, LOOPED>(m, d, s, lo, hi, 0, 32, need);
-    case 2: return launch_tree_t<2, NR, NEWTON, 32, LOOPED>(m, d, s, lo, hi, 0, 32, need);
-    case 3: return launch_tree_t<3, NR, NEWTON, 32, LOOPED>(m, d, s, lo, hi, 0, 32, need);
-    case 4: return launch_tree_t<4, NR, NEWTON, 32, LOOPED>(m, d, s, lo, hi, 0, 32, need);
-    case 5: return launch_tree_t<5, NR, NEWTON, 32, LOOPED>(m, d, s, lo, hi, 0, 32, need);
-    case 6: return launch_tree_t<6, NR, NEWTON, 32, LOOPED>(m, d, s, lo, hi, 0, 32, need);
-    case 7: return launch_tree_t<7, NR, NEWTON, 32, LOOPED>(m, d, s, lo, hi, 0, 32, need);
-    default: return launch_tree_t<8, NR, NEWTON, 32, LOOPED>(m, d, s, lo, hi, 0, 32, need);
+    case 1: return launch_tree_t<1, NR, NEWTON, 32, LOOPED, ELL>(m, d, s, lo, hi, 0, 32, need);
+    case 2: return launch_tree_t<2, NR, NEWTON, 32, LOOPED, ELL>(m, d, s, lo, hi, 0, 32, need);
+    case 3: return launch_tree_t<3, NR, NEWTON, 32, LOOPED, ELL>(m, d, s, lo, hi, 0, 32, need);
+    case 4: return launch_tree_t<4, NR, NEWTON, 32, LOOPED, ELL>(m, d, s, lo, hi, 0, 32, need);
+    case 5: return launch_tree_t<5, NR, NEWTON, 32, LOOPED, ELL>(m, d, s, lo, hi, 0, 32, need);
+    case 6: return launch_tree_t<6, NR, NEWTON, 32, LOOPED, ELL>(m, d, s, lo, hi, 0, 32, need);
+    case 7: return launch_tree_t<7, NR, NEWTON, 32, LOOPED, ELL>(m, d, s, lo, hi, 0, 32, need);
+    default: return launch_tree_t<8, NR, NEWTON, 32, LOOPED, ELL>(m, d, s, lo, hi, 0, 32, need);
   }
 }
 // the two-size row dispatch of the whole-world solver (mjhip.hip launch_solve_any), per island
-template <bool NEWTON>
+template <bool NEWTON, bool ELL = false>
 static int launch_tree_all(const MjhModel* m, const MjhData* d, hipStream_t s) {
   const int all = 0x7fffffff;
   // islands of at most 32 dofs: 2 rows per lane cover 64 rows (the common case: one block per two island slots), 6 cover 192
-  if (int rc = launch_tree_32<2, NEWTON, false>(m, d, m->isl_nv4, s, -1, 64, 0)) return rc;
+  if (int rc = launch_tree_32<2, NEWTON, false, ELL>(m, d, m->isl_nv4, s, -1, 64, 0)) return rc;
   if (d->njmax > 64)
-    if (int rc = launch_tree_32<6, NEWTON, true>(m, d, m->isl_nv4, s, 64, all, ISL_MANYROWS)) return rc;
+    if (int rc = launch_tree_32<6, NEWTON, true, ELL>(m, d, m->isl_nv4, s, 64, all, ISL_MANYROWS)) return rc;
   // islands of 33..64 dofs (several trees joined, or a wide tree): one island per wavefront, padded to 64 columns
-  if (d->njmax <= 64) return launch_tree_t<16, 1, NEWTON, 64, true>(m, d, s, -1, all, 32, 64, ISL_WIDE);
-  if (int rc = launch_tree_t<16, 2, NEWTON, 64, true>(m, d, s, -1, 128, 32, 64, ISL_WIDE)) return rc;
-  if (d->njmax > 128) return launch_tree_t<16, 3, NEWTON, 64, true>(m, d, s, 128, all, 32, 64, ISL_WIDE);
+  if (d->njmax <= 64) return launch_tree_t<16, 1, NEWTON, 64, true, ELL>(m, d, s, -1, all, 32, 64, ISL_WIDE);
+  if (int rc = launch_tree_t<16, 2, NEWTON, 64, true, ELL>(m, d, s, -1, 128, 32, 64, ISL_WIDE)) return rc;
+  if (d->njmax > 128) return launch_tree_t<16, 3, NEWTON, 64, true, ELL>(m, d, s, 128, all, 32, 64, ISL_WIDE);
   return MJH_OK;
 }

@@ -599,7 +599,6 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
   if ((int)threadIdx.x >= b.nthreads) return;
   constexpr int NVR = 4 * NV4;
   constexpr int JS = (NV4 & 1) ? NVR : NVR + 4;
-  static_assert(!TREE || !ELL, "per-island solve: pyramidal cones only");
   const int nv_all = m.nv, nC = m.nC, njmax = d.njmax, nvp = d.nv_pad;
   const SolveLayout lay = solve_layout<NV4, NR, G, NEWTON, ELL, TREE>(njmax);
   const int lig = threadIdx.x & (G - 1), gib = threadIdx.x / G;
@@ -811,8 +810,9 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
     if (ELL) {
       rs[k] = rmu[k] = rdm[k] = 0.0f;
       rcon[k] = 0;
-      if (has && r >= ne + nf + d.nl[w]) {
-        const int cid = d.ws_efc_con[eo + r], c = cid >> 4, dimid = cid & 15;
+      // (TREE: the rows are the island's, in island order -- a contact's rows stay consecutive --, and reach the world's tables through R())
+      if (has && (TREE ? d.efc_type[eo + R(r)] == CT_CONTACT_ELLIPTIC : r >= ne + nf + d.nl[w])) {
+        const int cid = d.ws_efc_con[eo + R(r)], c = cid >> 4, dimid = cid & 15;
         const float* cr = d.ws_contact + ((size_t)w * d.concap + c) * CON_STRIDE;
         const int* cri = reinterpret_cast<const int*>(cr);
         if (cri[24] > 1) {
@@ -822,7 +822,7 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
           rkind[k] = dimid == 0 ? 4 : 5;
           rmu[k] = mu;
           rs[k] = dimid == 0 ? mu : cr[dimid <= 2 ? 14 : (dimid == 3 ? 15 : 16)];
-          rdm[k] = safe_div(d.efc_D[eo + r0], mu * mu * (1.0f + mu * mu));
+          rdm[k] = safe_div(d.efc_D[eo + R(r0)], mu * mu * (1.0f + mu * mu));
           rcon[k] = r0 | (dim << 8);
         }
       }

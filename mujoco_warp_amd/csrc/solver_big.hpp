@@ -18,15 +18,19 @@ struct BigLayout {
   int q, Ma, grad, Mgrad, search, mv, pgrad, pMgrad, qc, fs, x;  // nv-vectors
   int ja, jv, D, fl, force, da, kind;                            // row vectors (njmax)
   int M, L, dinv, H, stage, HS, total;
+  int rs, rmu, rdm, rcon, econe;  // elliptic cones: friction scale / mu / dm of the row's contact, first row | dim << 16, cone Hessian rows (Newton)
 };
 constexpr int BIG_RB = 16;  // J rows staged per block of the H build
-__host__ __device__ inline BigLayout big_layout(int nv, int nC, int njmax, bool newton) {
+__host__ __device__ inline BigLayout big_layout(int nv, int nC, int njmax, bool newton, bool ell = false) {
   BigLayout p;
   int o = 0;
   int* nvv[] = {&p.q, &p.Ma, &p.grad, &p.Mgrad, &p.search, &p.mv, &p.pgrad, &p.pMgrad, &p.qc, &p.fs, &p.x};
   for (int* f : nvv) { *f = o; o += nv; }
   int* rv[] = {&p.ja, &p.jv, &p.D, &p.fl, &p.force, &p.da, &p.kind};
   for (int* f : rv) { *f = o; o += njmax; }
+  int* ev[] = {&p.rs, &p.rmu, &p.rdm, &p.rcon};
+  for (int* f : ev) { *f = o; o += ell ? njmax : 0; }
+  p.econe = o; o += (ell && newton) ? 6 * njmax : 0;
   p.M = o; o += nC;
   p.L = o; o += nC;
   p.dinv = o; o += nv;
@@ -44,7 +48,8 @@ DEV void solve_big_body(const MjhModel& m, const MjhData& d, float* smem, const 
   if ((int)threadIdx.x >= b.nthreads) return;
   const int nv = m.nv, nC = m.nC, njmax = d.njmax, nvp = d.nv_pad;
   const bool newton = m.solver == SOL_NEWTON;
-  const BigLayout lay = big_layout(nv, nC, njmax, newton);
+  const bool ell = m.cone == CONE_ELLIPTIC && d.nmaxpyramid > 1;
+  const BigLayout lay = big_layout(nv, nC, njmax, newton, ell);
   int* shi = reinterpret_cast<int*>(smem);
   const MStruct ms = load_mstruct<G>(m, shi, b.nthreads);
   const int lig = threadIdx.x & (G - 1), gib = threadIdx.x / G;
@@ -56,6 +61,8 @@ DEV void solve_big_body(const MjhModel& m, const MjhData& d, float* smem, const 
         *pgrad = S + lay.pgrad, *pMgrad = S + lay.pMgrad, *qc = S + lay.qc, *fs = S + lay.fs, *x = S + lay.x;
   float *ja = S + lay.ja, *jv = S + lay.jv, *rD = S + lay.D, *rfl = S + lay.fl, *force = S + lay.force, *da = S + lay.da;
   int* kind = reinterpret_cast<int*>(S + lay.kind);
+  float *rs = S + lay.rs, *rmu = S + lay.rmu, *rdm = S + lay.rdm, *econe = S + lay.econe;
+  int* rcon = reinterpret_cast<int*>(S + lay.rcon);
   float *Ml = S + lay.M, *Ll = S + lay.L, *dinv = S + lay.dinv, *H = S + lay.H, *stage = S + lay.stage;
   const int HS = lay.HS;
 
@@ -110,8 +117,70 @@ DEV void solve_big_body(const MjhModel& m, const MjhData& d, float* smem, const 
     kind[r] = r >= ne + nf ? 2 : (r >= ne ? 1 : 0);
     ja[r] = j_dot(r, q) - d.efc_aref[eo + r];
     jv[r] = 0.0f;
+    if (ell) {  // rows of an elliptic contact (solver.hpp: kind 4 = first row, 5 = the others); the first row's lane handles the contact
+      rs[r] = rmu[r] = rdm[r] = 0.0f;
+      rcon[r] = -1;
+      if (r >= ne + nf + d.nl[w]) {
+        const int cid = d.ws_efc_con[eo + r], c = cid >> 4, dimid = cid & 15;
+        const float* cr = d.ws_contact + ((size_t)w * d.concap + c) * CON_STRIDE;
+        const int* cri = reinterpret_cast<const int*>(cr);
+        if (cri[24] > 1) {
+          const int r0 = r - dimid, dim = min(cri[29], nefc - r0);
+          const float mu = cr[14] * bf(m.opt_impratio_invsqrt, m.opt_impratio_invsqrt_nb, w, 1)[0];
+          kind[r] = dimid == 0 ? 4 : 5;
+          rmu[r] = mu;
+          rs[r] = dimid == 0 ? mu : cr[dimid <= 2 ? 14 : (dimid == 3 ? 15 : 16)];
+          rdm[r] = safe_div(d.efc_D[eo + r0], mu * mu * (1.0f + mu * mu));
+          rcon[r] = r0 | (dim << 16);
+        }
+      }
+    }
   }
   gsync();
+  // force / state of the rows of one elliptic contact (first row r0): zones of _eval_constraint solver.py:455-472, middle-zone forces
+  // 406-421, and for Newton the rows of the cone Hessian block C (solver.py:2466-2564; same formulas as solver.hpp ell_row_force)
+  auto ell_contact = [&](int r0, bool final_state) __attribute__((always_inline)) {
+    const int dim = rcon[r0] >> 16;
+    const float mu = rmu[r0], dm = rdm[r0];
+    float u[6];
+    float tt = 0.0f;
+    for (int j = 0; j < 6; ++j) {
+      u[j] = j < dim ? ja[r0 + j] * rs[r0 + j] : 0.0f;
+      if (j > 0) tt += u[j] * u[j];
+    }
+    const float N = u[0], T = tt <= 0.0f ? 0.0f : sqrtf(tt);
+    const int zone = ell_zone(mu, N, T);
+    const float fn = -dm * (N - mu * T) * mu;
+    for (int a = 0; a < dim; ++a) {
+      const int r = r0 + a;
+      float f = 0.0f;
+      if (zone == ST_QUADRATIC) f = -rD[r] * ja[r];
+      else if (zone == ST_CONE) f = a == 0 ? fn : -safe_div(fn, T) * (u[a] * rs[r]);
+      force[r] = f;
+      da[r] = zone == ST_QUADRATIC ? rD[r] : 0.0f;
+      if (final_state) {
+        d.efc_force[eo + r] = f;
+        d.efc_state[eo + r] = zone;
+      }
+      if (newton && !final_state) {
+        kind[r] = (kind[r] & 7) | (zone == ST_CONE ? 8 : 0);  // bit 3: the row's contact is in the cone zone (H takes C J_c instead of D J)
+        if (zone == ST_CONE) {
+          const float t = fmaxf(T, MJ_MINVAL), ttt = fmaxf(t * t * t, MJ_MINVAL);
+          const float mu_tinv = safe_div(mu, t), mu_n_ttt = mu * safe_div(N, ttt), tdiag = mu * mu - N * mu_tinv;
+          const float ua = a == 0 ? 0.0f : u[a];
+          for (int bq = 0; bq < 6; ++bq) {
+            const float ub = bq == 0 ? 0.0f : u[bq];
+            float cab = mu_n_ttt * ua * ub;
+            if (a == 0 && bq == 0) cab += 1.0f;
+            if (a == 0) cab -= mu_tinv * ub;
+            if (bq == 0) cab -= mu_tinv * ua;
+            if (a == bq && a > 0) cab += tdiag;
+            econe[6 * r + bq] = bq < dim ? dm * rs[r] * rs[r0 + bq] * cab : 0.0f;
+          }
+        }
+      }
+    }
+  };
 
   const float tolerance = bf(m.opt_tolerance, m.opt_tolerance_nb, w, 1)[0];
   const float ls_tolerance = bf(m.opt_ls_tolerance, m.opt_ls_tolerance_nb, w, 1)[0];
@@ -125,9 +194,12 @@ DEV void solve_big_body(const MjhModel& m, const MjhData& d, float* smem, const 
   for (;;) {
     // ---- force / state of every row (solver.py:1698-1822), qfrc_constraint = J' force (1912-1947) -------------------
     for (int r = lig; r < nefc; r += G) {
+      const int kr = kind[r] & 7;
+      if (kr == 4) ell_contact(r, false);
+      if (kr >= 4) continue;
       float f;
       int st;
-      row_force(kind[r], ja[r], rD[r], has_fl, rfl + r, f, st);
+      row_force(kr, ja[r], rD[r], has_fl, rfl + r, f, st);
       force[r] = f;
       da[r] = st == ST_QUADRATIC ? rD[r] : 0.0f;
     }
@@ -174,6 +246,12 @@ DEV void solve_big_body(const MjhModel& m, const MjhData& d, float* smem, const 
 #pragma unroll
           for (int k = 0; k < BIG_RB; ++k) {
             t[k] = k < nr ? da[r0 + k] * stage[k * nvp + i] : 0.0f;
+            if (ell && k < nr && (kind[r0 + k] & 8)) {  // row of a contact in the cone zone: (C J_c)[row][i] (its rows may straddle the staged block: from L2)
+              const int rc0 = rcon[r0 + k] & 0xffff, dim = rcon[r0 + k] >> 16;
+              float acc = 0.0f;
+              for (int bq = 0; bq < dim; ++bq) acc += econe[6 * (r0 + k) + bq] * Jg[(size_t)(rc0 + bq) * nvp + i];
+              t[k] = acc;
+            }
             any = any || t[k] != 0.0f;
           }
           if (!any) continue;
@@ -307,7 +385,34 @@ DEV void solve_big_body(const MjhModel& m, const MjhData& d, float* smem, const 
     auto total = [&](float a) __attribute__((always_inline)) {
       P3 s = P3{0.0f, 0.0f, 0.0f};
       for (int r = lig; r < nefc; r += G) {
-        const P3 t = eval_row(ja[r], jv[r], rD[r], rfl[r], kind[r], a);
+        const int kr = kind[r] & 7;
+        if (kr == 5) continue;  // (evaluated with its contact by the first row's lane)
+        P3 t;
+        if (kr == 4) {  // the contact's ray constants (solver.hpp EllRay), then the reference's shifted forms
+          const int dim = rcon[r] >> 16;
+          EllRay e;
+          e.mu = rmu[r];
+          e.dm = rdm[r];
+          e.q0 = e.q1 = e.q2 = e.uu = e.uv = e.vv = 0.0f;
+          e.u0 = ja[r] * rs[r];
+          e.v0 = jv[r] * rs[r];
+          for (int j = 0; j < dim; ++j) {
+            const float jaj = ja[r + j], jvj = jv[r + j], Dj = rD[r + j];
+            e.q0 += 0.5f * Dj * jaj * jaj;
+            e.q1 += Dj * jvj * jaj;
+            e.q2 += 0.5f * Dj * jvj * jvj;
+            if (j > 0) {
+              const float uj = jaj * rs[r + j], vj = jvj * rs[r + j];
+              e.uu += uj * uj;
+              e.uv += uj * vj;
+              e.vv += vj * vj;
+            }
+          }
+          ell_ray_reference(e);
+          t = ell_eval(e, a);
+        } else {
+          t = eval_row(ja[r], jv[r], rD[r], rfl[r], kr, a);
+        }
         s.c += t.c;
         s.g += t.g;
         s.h += t.h;
@@ -380,9 +485,12 @@ DEV void solve_big_body(const MjhModel& m, const MjhData& d, float* smem, const 
     d.efc_Ma[vo + i] = Ma[i];
   }
   for (int r = lig; r < nefc; r += G) {
+    const int kr = kind[r] & 7;
+    if (kr == 4) ell_contact(r, true);
+    if (kr >= 4) continue;
     float f;
     int st;
-    row_force(kind[r], ja[r], rD[r], has_fl, rfl + r, f, st);
+    row_force(kr, ja[r], rD[r], has_fl, rfl + r, f, st);
     d.efc_force[eo + r] = f;
     d.efc_state[eo + r] = st;
   }

@@ -131,8 +131,8 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
     raise NotImplementedError(f"Unknown solver {int(opt.solver)}.")
   if int(opt.cone) not in (types.ConeType.PYRAMIDAL, types.ConeType.ELLIPTIC):
     raise NotImplementedError(f"Unknown cone {int(opt.cone)}.")
-  if int(opt.cone) == types.ConeType.ELLIPTIC and (mjm.nv > 64 or int(opt.solver) == types.SolverType.PGS):
-    raise NotImplementedError("Elliptic friction cones need the CG or Newton solver and at most 64 dofs.")
+  if int(opt.cone) == types.ConeType.ELLIPTIC and int(opt.solver) == types.SolverType.PGS:
+    raise NotImplementedError("PGS with elliptic friction cones is not implemented (CG and Newton solve elliptic cones at any model size).")
   if mjm.nv > 64 and int(opt.solver) == types.SolverType.PGS:
     raise NotImplementedError("PGS supports at most 64 dofs (CG and Newton have a generic path for larger models).")
   if mjm.nu and (np.asarray(mjm.actuator_trntype) != types.TrnType.JOINT).any():
@@ -311,8 +311,7 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
     m.act_dof_max = 0
   m.tree_nvmax = int(tree_dofnum.max()) if len(roots) else 0
   # nv > 64: worlds whose rows each touch one kinematic tree are solved per (world, tree) by the register-resident kernels
-  m.tree_solve = int(nv > 64 and m.ntree > 1 and m.tree_nvmax <= 64 and int(opt.solver) != types.SolverType.PGS
-                     and int(opt.cone) == types.ConeType.PYRAMIDAL)
+  m.tree_solve = int(nv > 64 and m.ntree > 1 and m.tree_nvmax <= 64 and int(opt.solver) != types.SolverType.PGS)
   # size classes of the island kernels: islands of <= 32 dofs run with 32 lanes and ceil(dofs / 4) quarter-rows -- the widest one is a
   # single tree unless two trees together fit --, islands of 33..64 dofs with 64 lanes
   small = sorted(int(n) for n in tree_dofnum if n <= 32)
@@ -567,7 +566,11 @@ def _data_shapes(m, nworld, nconmax, njmax, naconmax):
   return sh, njmax_pad, nv_pad
 
 
-def _alloc_data(m: types.Model, nworld, nconmax, njmax, naconmax, mjd=None):
+def _alloc_data(m: types.Model, nworld, nconmax, njmax, naconmax, mjd=None, nvmax=None):
+  if nvmax is None:
+    nvmax = m.nv
+  if nvmax < 0 or nvmax > m.nv:  # reference io.py:1731
+    raise ValueError(f"nvmax ({nvmax}) must be in [0, nv ({m.nv})]")
   if nconmax is None:
     nconmax = _default_nconmax(None, mjd)  # at least what the host data already holds (reference io.py:1284-1311)
   if njmax is None:
@@ -594,6 +597,7 @@ def _alloc_data(m: types.Model, nworld, nconmax, njmax, naconmax, mjd=None):
   d.nworld, d.nconmax, d.naconmax, d.njmax, d.njmax_pad, d.nv_pad = nworld, nconmax, naconmax, njmax, njmax_pad, nv_pad
   d.ws_order.assign(np.arange(nworld, dtype=np.int32))
   d.sleep_pass = 0
+  d.nvmax = int(nvmax)
   d.nsleepworld = shapes["ws_sleep_J"][0]
   _reset_sleep(m, d, None)
   if m.neq:
@@ -658,7 +662,7 @@ def make_data(mjm, nworld: int = 1, nconmax: Optional[int] = None, nccdmax: Opti
               naccdmax: Optional[int] = None, nvmax: Optional[int] = None) -> types.Data:
   """Creates a data object on device (reference io.py:1680); state = qpos0."""
   m = mjm if isinstance(mjm, types.Model) else _model_of(mjm)
-  d = _alloc_data(m, nworld, nconmax, njmax, naconmax)
+  d = _alloc_data(m, nworld, nconmax, njmax, naconmax, nvmax=nvmax)
   d.qpos.assign(np.tile(m.qpos0.numpy()[0], (nworld, 1)))
   return d
 
@@ -668,7 +672,7 @@ def put_data(mjm, mjd, nworld: int = 1, nconmax: Optional[int] = None, nccdmax: 
              naccdmax: Optional[int] = None, nvmax: Optional[int] = None) -> types.Data:
   """Moves data from host to a device (reference io.py:1890): the single host state is tiled nworld times."""
   m = mjm if isinstance(mjm, types.Model) else _model_of(mjm)
-  d = _alloc_data(m, nworld, nconmax, njmax, naconmax, mjd)
+  d = _alloc_data(m, nworld, nconmax, njmax, naconmax, mjd, nvmax=nvmax)
   if m.neq and getattr(mjd, "eq_active", None) is not None:
     d.eq_active.assign(np.tile(np.asarray(mjd.eq_active, dtype=np.int32).reshape(1, -1), (nworld, 1)))
   for name in ("qpos", "qvel", "act", "ctrl", "qacc_warmstart", "qfrc_applied", "xfrc_applied", "mocap_pos", "mocap_quat"):
@@ -685,6 +689,21 @@ def put_data(mjm, mjd, nworld: int = 1, nconmax: Optional[int] = None, nccdmax: 
     d.tree_awake.assign(np.tile((asleep < 0).astype(np.int32), (nworld, 1)))
     if getattr(mjd, "body_awake", None) is not None:
       d.body_awake.assign(np.tile(np.asarray(mjd.body_awake, dtype=np.int32).reshape(1, -1), (nworld, 1)))
+    elif d.body_awake.size and (asleep >= 0).any():
+      # (a host MjData without body_awake, e.g. mjcf.MjData with `tree_asleep[:] = arange(ntree)`: derive the tables the first wake /
+      # update_sleep stage would produce, sleep.py:171-215 -- the reference's host object carries MuJoCo's own)
+      treeid, mocap = m.body_treeid.numpy(), m.body_mocapid.numpy()
+      ba = np.where(treeid >= 0, np.where(asleep[0][np.maximum(treeid, 0)] < 0, int(types.SleepState.AWAKE), int(types.SleepState.ASLEEP)),
+                    np.where(mocap >= 0, int(types.SleepState.AWAKE), int(types.SleepState.STATIC))).astype(np.int32)
+      d.body_awake.assign(np.tile(ba, (nworld, 1)))
+      bind = np.concatenate([np.flatnonzero(ba != int(types.SleepState.ASLEEP)), np.zeros(int((ba == int(types.SleepState.ASLEEP)).sum()), dtype=np.int64)]).astype(np.int32)
+      d.body_awake_ind.assign(np.tile(bind, (nworld, 1)))
+      d.nbody_awake.fill_(int((ba != int(types.SleepState.ASLEEP)).sum()))
+      dof_awake = asleep[0][m.dof_treeid.numpy()] < 0
+      dind = np.concatenate([np.flatnonzero(dof_awake), np.zeros(int((~dof_awake).sum()), dtype=np.int64)]).astype(np.int32)
+      d.dof_awake_ind.assign(np.tile(dind, (nworld, 1)))
+      d.nv_awake.fill_(int(dof_awake.sum()))
+      d.ntree_awake.fill_(int((asleep < 0).sum()))
   return d
 
 

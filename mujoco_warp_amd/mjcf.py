@@ -130,6 +130,9 @@ class MjData:
     self.nf = 0
     self.nl = 0
     self.solver_niter = np.zeros(1, dtype=np.int32)
+    # sleep state (MjData.tree_asleep): < 0 awake (a countdown towards sleep), >= 0 asleep = next tree of the sleep cycle; the
+    # reference's `--init_asleep` sets tree_asleep[:] = arange(ntree) before put_data (cli.py:167-168): every tree asleep on its own
+    self.tree_asleep = np.full(int(getattr(m, "ntree", 0)), -(1 + 10), dtype=np.int32)
 
 
 def mj_resetDataKeyframe(m, d, key):

@@ -46,6 +46,9 @@ def main(argv=None):
   ap.add_argument("--nstep", type=int, default=None, help="default 1000, or the length of the --replay sequence")
   ap.add_argument("--nconmax", type=int, default=None)
   ap.add_argument("--njmax", type=int, default=None)
+  ap.add_argument("--nvmax", type=int, default=None, help="capacity for awake dofs per world (reference cli.py:45)")
+  ap.add_argument("--nccdmax", type=int, default=None, help="accepted for run.py compatibility (the CCD workspace is sized from nconmax here)")
+  ap.add_argument("--init_asleep", type=_bool, default=False, help="initialize all trees as asleep before simulation (requires sleep enabled; reference cli.py:48)")
   ap.add_argument("--keyframe", type=int, default=0)
   ap.add_argument("--replay", default=None, help="NPZ file with a `ctrl` [nstep, nu] sequence used as the centre of the control noise "
                   "(reference cli.py:53, 153-161); nstep defaults to its length; an initial qpos/qvel in the file is applied")
@@ -99,7 +102,11 @@ def main(argv=None):
     args.nstep = len(ctrls) if args.nstep is None else min(args.nstep, len(ctrls))
   if args.nstep is None:
     args.nstep = 1000
-  d = mjw.put_data(mjm, mjd, nworld=args.nworld, nconmax=args.nconmax, njmax=args.njmax)
+  if args.init_asleep:  # reference cli.py:167-168
+    if not (int(mjm.opt.enableflags) & int(mjw.EnableBit.SLEEP)):
+      raise ValueError("--init_asleep requires sleep to be enabled (-o opt.enableflags=SLEEP)")
+    mjd.tree_asleep[:] = np.arange(mjm.ntree, dtype=np.int32)
+  d = mjw.put_data(mjm, mjd, nworld=args.nworld, nconmax=args.nconmax, njmax=args.njmax, nvmax=args.nvmax)
   center = mjw.DeviceArray.from_numpy(np.asarray(mjd.ctrl, dtype=np.float32)) if mjm.nu else None
   centers = [mjw.DeviceArray.from_numpy(c) for c in ctrls[: args.nstep]] if ctrls is not None else None
 

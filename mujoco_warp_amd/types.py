@@ -627,6 +627,7 @@ class Data(_Dirty):
   ws_sleep_warm: DeviceArray = _arr(('nsleepworld', 'nv'), "float32")
   ws_sleep_flag: DeviceArray = _arr(('nworld',), "int32")
   sleep_pass: int = 0
+  nvmax: int = 0  # capacity for awake dofs per world (reference types.py Data.nvmax): exceeding it raises OverflowType.NVMAX
   nsleepworld: int = 0
   eq_active: DeviceArray = _arr(('nworld', 'neq'), "int32")
   ws_rk: DeviceArray = _arr(('nworld', 'nq+3*nv+2*na'), "float32")
