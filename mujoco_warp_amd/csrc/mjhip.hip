@@ -244,16 +244,15 @@ static thread_local bool g_fuse_euler = false;
 static thread_local bool g_riders_on_side = false;
 static int solve_supported(const MjhModel* m, const MjhData* d) {
   if (m->cone != CONE_PYRAMIDAL && m->cone != CONE_ELLIPTIC) return fail(MJH_E_UNSUPPORTED, "unknown cone type");
-  if (m->cone == CONE_ELLIPTIC && m->solver == SOL_PGS) return fail(MJH_E_UNSUPPORTED, "PGS with elliptic cones is not implemented");
-  if (m->nv > 64 && m->solver == SOL_PGS) return fail(MJH_E_UNSUPPORTED, "PGS supports at most 64 dofs");
   if (m->solver != SOL_NEWTON && m->solver != SOL_CG && m->solver != SOL_PGS) return fail(MJH_E_UNSUPPORTED, "unknown solver");
-  if (m->nv <= 64 && d->njmax > 192 && m->solver == SOL_PGS)
-    return fail(MJH_E_UNSUPPORTED, "njmax > 192 with PGS is not supported (the generic solver that takes the worlds with more than 192 rows is CG / Newton)");
+  if (m->nv <= 64 && d->njmax > 192 && m->solver == SOL_PGS && m->cone != CONE_ELLIPTIC)
+    return fail(MJH_E_UNSUPPORTED, "njmax > 192 with the register / LDS resident PGS kernels is not supported (nv <= 64, pyramidal)");
   return MJH_OK;
 }
 static int launch_solve_any(const MjhModel* m, const MjhData* d, bool with_factor, hipStream_t s) {
   if (int rc = solve_supported(m, d)) return rc;
   if (m->nv > 64) {  // no riders: they go with the integrator launch
+    if (m->solver == SOL_PGS) return launch_pgs(m, d, s);  // (the generic PGS kernel: csrc/pgs_big.hpp)
     if (m->tree_solve) {
       // constraint islands (trees joined by coupling rows): worlds whose islands all have at most 64 dofs are solved per island by the
       // register-resident kernels, the others by the generic solver below

@@ -1,0 +1,440 @@
+// pgs_big.hpp -- generic projected Gauss-Seidel: any number of dofs, pyramidal AND elliptic friction cones (round 3).
+//
+// The register / LDS resident PGS kernels (pgs.hpp) end at 64 dofs and know pyramidal rows only.  BASELINE configs[4] (aloha_clutter) asks
+// for PGS on a 136-dof model with elliptic cones, which the reference cannot run at all (it has no PGS: types.py:502).  This kernel is the
+// correctness path for those cases: one wavefront per world, the running acceleration and the row vectors in LDS, J and B = J M^-1 in
+// HBM / L2 (Data.ws_pgsB), M^-1 through the sparse L'DL factor (block diagonal over kinematic trees, no fill-in).
+//
+// Algorithm: MuJoCo C's dual PGS (engine_solver.c mj_solPGS) as restated in float64 by oracle/mjref.c:solve_pgs, which this kernel is
+// tested against.  Scalar rows: projected coordinate step (pgs.hpp).  Elliptic contact = block of `dim` rows updated together:
+//   * at the apex (no normal force): exact minimisation along the steepest feasible ray of the cone, v = (1, -mu_j^2 res_j / |mu o res_f|);
+//   * otherwise: exact minimisation along the current force direction (ray update: scales normal and friction together), then
+//   * the friction forces at fixed normal force: QCQP  min 0.5 v'A_ff v + v'b_c  s.t.  sum_j (v_j / mu_j)^2 <= f_n^2  (Newton on the
+//     multiplier, dense Cholesky of at most 5 x 5 in registers);
+//   * a block step that would increase the dual cost (round-off) is rejected, as for scalar rows.
+// The fixed point of these steps is the solution of the dual problem, which the oracle tests show equal to the Newton / CG solution of the
+// primal elliptic problem (tests/test_pgs.py: qacc to 2e-6 for condim 3 / 4 / 6, impratio 1 and 10).
+#pragma once
+#include "solver.hpp"
+
+struct PgsBigLayout {
+  int q, qs, tmp, force, aref, R, Ad, mu, info, blk, xs, M, L, dinv, total;
+};
+__host__ __device__ inline PgsBigLayout pgs_big_layout(int nv, int nC, int njmax, bool ell) {
+  PgsBigLayout p;
+  int o = 0;
+  p.q = o; o += nv;
+  p.qs = o; o += nv;
+  p.tmp = o; o += nv;
+  p.force = o; o += njmax;
+  p.aref = o; o += njmax;
+  p.R = o; o += njmax;
+  p.Ad = o; o += njmax;
+  p.mu = o; o += ell ? njmax : 0;      // friction coefficient of a friction row of an elliptic contact
+  p.info = o; o += njmax;               // row kind: 0 equality, 1 friction loss, 2 limit / contact, 8 + dim: first row of an elliptic contact, 7: its other rows
+  p.blk = o; o += ell ? 6 * njmax : 0;  // row r of an elliptic contact starting at r0: (A + R)[r][r0 .. r0 + 5]
+  p.xs = o; o += 64 * nv;               // 64 right-hand sides of the batched sparse solves (lane = row), [dof][lane]
+  p.M = o; o += nC;
+  p.L = o; o += nC;
+  p.dinv = o; o += nv;
+  p.total = ((o + 3) / 4) * 4;
+  return p;
+}
+
+// x = argmin 0.5 x'A x + x'b  s.t.  sum (x_i / mu_i)^2 <= r^2, n <= 5 (unused dimensions: A = identity, b = 0, mu = 1); oracle/mjref.c qcqp
+DEV void qcqp5(int n, const float (&A)[5][5], const float (&b)[5], const float (&mu)[5], float r, float (&x)[5]) {
+  float As[5][5], bs[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    bs[i] = i < n ? b[i] * mu[i] : 0.0f;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) As[i][j] = (i < n && j < n) ? A[i][j] * mu[i] * mu[j] : (i == j ? 1.0f : 0.0f);
+  }
+  float la = 0.0f, y[5] = {0, 0, 0, 0, 0};
+  bool active = false;
+  for (int it = 0; it < 20; ++it) {
+    float L[5][5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {  // Cholesky of As + la I (lower)
+      float s = As[j][j] + la;
+#pragma unroll
+      for (int k = 0; k < 5; ++k)
+        if (k < j) s -= L[j][k] * L[j][k];
+      const float l = sqrtf(fmaxf(s, MJ_MINVAL));
+      L[j][j] = l;
+#pragma unroll
+      for (int i = 0; i < 5; ++i)
+        if (i > j) {
+          float t = As[i][j];
+#pragma unroll
+          for (int k = 0; k < 5; ++k)
+            if (k < j) t -= L[i][k] * L[j][k];
+          L[i][j] = t / l;
+        }
+    }
+    auto solve = [&](const float (&rhs)[5], float (&out)[5]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        float t = rhs[i];
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+          if (k < i) t -= L[i][k] * out[k];
+        out[i] = t / L[i][i];
+      }
+#pragma unroll
+      for (int i = 4; i >= 0; --i) {
+        float t = out[i];
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+          if (k > i) t -= L[k][i] * out[k];
+        out[i] = t / L[i][i];
+      }
+    };
+    float nb[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) nb[i] = -bs[i];
+    solve(nb, y);
+    float val = -r * r;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) val += y[i] * y[i];
+    if (val < 1e-7f * r * r + 1e-20f) break;  // inside (or on) the ball, to float32 resolution
+    active = true;
+    float t[5];
+    solve(y, t);
+    float deriv = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) deriv -= 2.0f * y[i] * t[i];
+    const float delta = -val / deriv;
+    if (!(delta > 1e-7f * (la + 1e-20f))) break;
+    la += delta;
+  }
+  float s = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) s += y[i] * y[i];
+  const float sc = (active && s > r * r && s > 0.0f) ? r / sqrtf(s) : 1.0f;  // round-off: land on the boundary
+#pragma unroll
+  for (int i = 0; i < 5; ++i) x[i] = i < n ? y[i] * mu[i] * sc : 0.0f;
+}
+
+template <int G>
+DEV void pgs_big_body(const MjhModel& m, const MjhData& d, float* smem, int w) {
+  static_assert(G == 64, "one world per wavefront");
+  const int nv = m.nv, nC = m.nC, njmax = d.njmax, nvp = d.nv_pad;
+  const bool ell = m.cone == CONE_ELLIPTIC && d.nmaxpyramid > 1;
+  const PgsBigLayout lay = pgs_big_layout(nv, nC, njmax, ell);
+  int* shi = reinterpret_cast<int*>(smem);
+  const MStruct ms = load_mstruct<G>(m, shi, G);
+  const int lig = threadIdx.x & (G - 1);
+  float* S = smem + mstruct_ints(nv, nC);
+  float *q = S + lay.q, *qs = S + lay.qs, *tmp = S + lay.tmp, *force = S + lay.force, *aref = S + lay.aref, *Rr = S + lay.R, *Ad = S + lay.Ad,
+        *rmu = S + lay.mu, *blk = S + lay.blk, *xs = S + lay.xs, *Ml = S + lay.M, *Ll = S + lay.L, *dinv = S + lay.dinv;
+  int* info = reinterpret_cast<int*>(S + lay.info);
+  const int nefc = min(d.nefc[w], njmax), ne = d.ne[w], nf = d.nf[w], nl = d.nl[w];
+  const size_t vo = (size_t)w * nv, eo = (size_t)w * njmax;
+  const float* Jg = d.efc_J + (size_t)w * d.njmax_pad * nvp;
+  float* Bg = d.ws_pgsB + (size_t)w * d.njmax_pad * nvp;
+
+  // ---- M, sparse factor, qacc_smooth ------------------------------------------------------------------------------------------
+  gcopy<G>(Ml, d.M + (size_t)w * nC, nC, lig);
+  gcopy<G>(Ll, d.M + (size_t)w * nC, nC, lig);
+  gcopy<G>(qs, d.qfrc_smooth + vo, nv, lig);
+  gsync();
+  factor_ld<G>(ms, Ll, dinv, nv, lig);
+  solve_ld<G>(m, ms, Ll, dinv, qs, nv, lig);
+  gsync();
+  for (int i = lig; i < nv; i += G) d.qacc_smooth[vo + i] = qs[i];
+  if (nefc == 0) {
+    for (int i = lig; i < nv; i += G) {
+      d.qacc[vo + i] = qs[i];
+      d.qfrc_constraint[vo + i] = 0.0f;
+      d.efc_Ma[vo + i] = d.qfrc_smooth[vo + i];
+    }
+    if (lig == 0) d.solver_niter[w] = 0;
+    return;
+  }
+  // ---- B = J M^-1, 64 rows per batch: lane = row, its vector in LDS as xs[dof * 64 + lane] (sequential sparse L'DL solve per lane) ----
+  for (int r0 = 0; r0 < nefc; r0 += G) {
+    const int r = r0 + lig;
+    const bool has = r < nefc;
+    for (int c = 0; c < nv; ++c) xs[c * G + lig] = has ? Jg[(size_t)r * nvp + c] : 0.0f;
+    for (int k = nv - 1; k >= 0; --k) {  // x <- L^-T x
+      const int start = ms.rowadr[k], n = ms.rownnz[k];
+      const float xk = xs[k * G + lig];
+      for (int a = 0; a < n - 1; ++a) xs[ms.colind[start + a] * G + lig] -= Ll[start + a] * xk;
+    }
+    for (int k = 0; k < nv; ++k) xs[k * G + lig] *= dinv[k];
+    for (int k = 0; k < nv; ++k) {  // x <- L^-1 x (ancestors have smaller indices)
+      const int start = ms.rowadr[k], n = ms.rownnz[k];
+      float s = xs[k * G + lig];
+      for (int a = 0; a < n - 1; ++a) s -= Ll[start + a] * xs[ms.colind[start + a] * G + lig];
+      xs[k * G + lig] = s;
+    }
+    if (has) {
+      float sAR = 0.0f;
+      for (int c = 0; c < nv; ++c) {
+        const float bv = xs[c * G + lig];
+        Bg[(size_t)r * nvp + c] = bv;
+        sAR += Jg[(size_t)r * nvp + c] * bv;
+      }
+      for (int c = nv; c < nvp; ++c) Bg[(size_t)r * nvp + c] = 0.0f;
+      const float D = d.efc_D[eo + r];
+      aref[r] = d.efc_aref[eo + r];
+      Rr[r] = 1.0f / D;
+      Ad[r] = sAR + 1.0f / D;
+      info[r] = r >= ne + nf ? 2 : (r >= ne ? 1 : 0);
+      if (ell) rmu[r] = 1.0f;
+    }
+  }
+  __threadfence_block();
+  gsync();
+  // ---- elliptic contacts: row kinds, friction coefficients, the dim x dim blocks of A + R -----------------------------------------
+  if (ell) {
+    for (int r = ne + nf + nl + lig; r < nefc; r += G) {
+      const int cid = d.ws_efc_con[eo + r], c = cid >> 4, dimid = cid & 15;
+      const float* cr = d.ws_contact + ((size_t)w * d.concap + c) * CON_STRIDE;
+      const int* cri = reinterpret_cast<const int*>(cr);
+      if (cri[24] > 1) {
+        const int r0 = r - dimid, dim = min(cri[29], nefc - r0);
+        info[r] = dimid == 0 ? 8 + dim : 7;
+        rmu[r] = dimid == 0 ? 1.0f : cr[dimid <= 2 ? 14 : (dimid == 3 ? 15 : 16)];
+        for (int bq = 0; bq < 6; ++bq) {
+          float s = 0.0f;
+          if (bq < dim) {
+            for (int cc = 0; cc < nv; ++cc) s += Jg[(size_t)r * nvp + cc] * Bg[(size_t)(r0 + bq) * nvp + cc];
+            if (bq == dimid) s += Rr[r];
+          }
+          blk[6 * r + bq] = s;
+        }
+      }
+    }
+    gsync();
+  }
+  // ---- warm start: primal forces at qacc_warmstart, kept if their dual cost is negative (engine_forward.c warmstart) ----------------
+  const bool warm = !(m.disableflags & DSBL_WARMSTART);
+  for (int i = lig; i < nv; i += G) tmp[i] = d.qacc_warmstart[vo + i];
+  gsync();
+  float cpart = 0.0f;
+  for (int r = lig; r < nefc; r += G) {
+    float jw = 0.0f, jb = 0.0f;
+    for (int c = 0; c < nv; ++c) {
+      const float j = Jg[(size_t)r * nvp + c];
+      jw += j * tmp[c];
+      jb += j * qs[c];
+    }
+    xs[r] = jw - aref[r];  // Jaref at the warm-start point (xs is free now: reused as a row vector)
+    xs[njmax + r] = jb - aref[r];  // b_r
+  }
+  gsync();
+  for (int r = lig; r < nefc; r += G) {
+    float f = 0.0f;
+    if (warm) {
+      const int k = info[r];
+      if (k <= 2) {
+        int st;
+        row_force(k, xs[r], 1.0f / Rr[r], nf > 0, d.efc_frictionloss + eo + r, f, st);
+      } else {  // a row of an elliptic contact: the primal zones (solver.py:455-472), decided from the contact's rows together
+        int r0 = r;
+        while (info[r0] == 7) --r0;
+        const int dim = info[r0] - 8;
+        const float mu = d.ws_contact[((size_t)w * d.concap + (d.ws_efc_con[eo + r0] >> 4)) * CON_STRIDE + 14] * bf(m.opt_impratio_invsqrt, m.opt_impratio_invsqrt_nb, w, 1)[0];
+        float tt = 0.0f;
+        for (int j = 1; j < dim; ++j) tt += (xs[r0 + j] * rmu[r0 + j]) * (xs[r0 + j] * rmu[r0 + j]);
+        const float N = xs[r0] * mu, T = tt <= 0.0f ? 0.0f : sqrtf(tt);
+        const int zone = ell_zone(mu, N, T);
+        if (zone == ST_QUADRATIC) f = -xs[r] / Rr[r];
+        else if (zone == ST_CONE) {
+          const float fnm = -safe_div(1.0f / Rr[r0], mu * mu * (1.0f + mu * mu)) * (N - mu * T) * mu;
+          f = r == r0 ? fnm : -safe_div(fnm, T) * (xs[r] * rmu[r] * rmu[r]);
+        }
+      }
+    }
+    force[r] = f;
+    cpart += f * (xs[njmax + r] + 0.5f * Rr[r] * f);
+  }
+  gsync();
+  float ypart = 0.0f;
+  for (int c = lig; c < nv; c += G) {  // q - qacc_smooth = B' f; the A part of the cost is 0.5 (J' f) . (B' f)
+    float z = 0.0f, y = 0.0f;
+    if (warm)
+      for (int r = 0; r < nefc; ++r) {
+        const float f = force[r];
+        z += f * Bg[(size_t)r * nvp + c];
+        y += f * Jg[(size_t)r * nvp + c];
+      }
+    tmp[c] = z;
+    ypart += 0.5f * y * z;
+  }
+  const float cost = gsumg<G>(cpart + ypart);
+  const bool keep = warm && !(cost > 0.0f);
+  gsync();
+  for (int c = lig; c < nv; c += G) q[c] = qs[c] + (keep ? tmp[c] : 0.0f);
+  if (!keep)
+    for (int r = lig; r < nefc; r += G) force[r] = 0.0f;
+  gsync();
+
+  // ---- sweeps ---------------------------------------------------------------------------------------------------------------------
+  const float tolerance = bf(m.opt_tolerance, m.opt_tolerance_nb, w, 1)[0];
+  const float rscale = 1.0f / (bf(m.stat_meaninertia, m.stat_meaninertia_nb, w, 1)[0] * (float)max(nv, 1));
+  const int maxiter = m.iterations;
+  int niter = 0;
+  // J_r . q over the lanes' dofs (partial; reduce with gsumg / gsumg_n)
+  auto jq_part = [&](int r) __attribute__((always_inline)) {
+    float s = 0.0f;
+    for (int c = lig; c < nv; c += G) s += Jg[(size_t)r * nvp + c] * q[c];
+    return s;
+  };
+  while (niter < maxiter) {
+    float improvement = 0.0f;
+    for (int i = 0; i < nefc; ++i) {
+      const int k = info[i];
+      if (k <= 2) {
+        const float fold = force[i];
+        const float res = gsumg<G>(jq_part(i)) - aref[i] + Rr[i] * fold;
+        float fn = fold - res / Ad[i];
+        if (k == 2) fn = fmaxf(fn, 0.0f);
+        else if (k == 1) {
+          const float fl = d.efc_frictionloss[eo + i];
+          fn = fminf(fmaxf(fn, -fl), fl);
+        }
+        float delta = fn - fold;
+        float change = delta * (0.5f * delta * Ad[i] + res);
+        if (change > 1e-10f) {
+          delta = 0.0f;
+          change = 0.0f;
+        }
+        improvement -= change;
+        if (delta != 0.0f)
+          for (int c = lig; c < nv; c += G) q[c] += delta * Bg[(size_t)i * nvp + c];
+        if (lig == 0) force[i] = fold + delta;
+        gsync();
+        continue;
+      }
+      // ---- elliptic contact block (all lanes compute the small dense problem redundantly) ----------------------------------------
+      const int dim = k - 8;
+      float res[6], fold[6], A[6][6], mu[5], fnew[6];
+      {
+        float part[6];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) part[a] = a < dim ? jq_part(i + a) : 0.0f;
+        gsumg_n<G, 6>(part);
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+          fold[a] = a < dim ? force[i + a] : 0.0f;
+          res[a] = a < dim ? part[a] - aref[i + a] + Rr[i + a] * fold[a] : 0.0f;
+#pragma unroll
+          for (int bq = 0; bq < 6; ++bq) A[a][bq] = (a < dim && bq < dim) ? blk[6 * (i + a) + bq] : (a == bq ? 1.0f : 0.0f);
+          if (a > 0) mu[a - 1] = a < dim ? rmu[i + a] : 1.0f;
+        }
+      }
+      float fn;
+      if (fold[0] < MJ_MINVAL) {  // apex: steepest feasible ray of the cone
+        float sres = 0.0f, v[6], vAv = 0.0f;
+#pragma unroll
+        for (int a = 1; a < 6; ++a) sres += a < dim ? mu[a - 1] * mu[a - 1] * res[a] * res[a] : 0.0f;
+        sres = sqrtf(sres);
+        v[0] = 1.0f;
+#pragma unroll
+        for (int a = 1; a < 6; ++a) v[a] = (a < dim && sres > MJ_MINVAL) ? -mu[a - 1] * mu[a - 1] * res[a] / sres : 0.0f;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+          for (int bq = 0; bq < 6; ++bq) vAv += (a < dim && bq < dim) ? v[a] * A[a][bq] * v[bq] : 0.0f;
+        const float slope = res[0] - sres, t = (slope < 0.0f && vAv >= MJ_MINVAL) ? -slope / vAv : 0.0f;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) fnew[a] = a < dim ? t * v[a] : 0.0f;
+        fn = fnew[0];
+      } else {  // ray update
+        float vAv = 0.0f, vr = 0.0f;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+          float Av = 0.0f;
+#pragma unroll
+          for (int bq = 0; bq < 6; ++bq) Av += (a < dim && bq < dim) ? A[a][bq] * fold[bq] : 0.0f;
+          vAv += fold[a] * Av;
+          vr += fold[a] * res[a];
+        }
+        const float x = fmaxf(vAv >= MJ_MINVAL ? -vr / vAv : 0.0f, -1.0f);
+#pragma unroll
+        for (int a = 0; a < 6; ++a) fnew[a] = fold[a] + x * fold[a];
+        fn = fnew[0];
+      }
+      if (fn < MJ_MINVAL) {
+#pragma unroll
+        for (int a = 1; a < 6; ++a) fnew[a] = 0.0f;
+      } else {  // friction at fixed normal force
+        float Ac[5][5], bc[5], vv[5];
+#pragma unroll
+        for (int a = 1; a < 6; ++a) {
+          float bb = res[a] + A[a][0] * (fn - fold[0]);
+#pragma unroll
+          for (int c2 = 1; c2 < 6; ++c2) {
+            Ac[a - 1][c2 - 1] = A[a][c2];
+            bb -= (a < dim && c2 < dim) ? A[a][c2] * fold[c2] : 0.0f;
+          }
+          bc[a - 1] = a < dim ? bb : 0.0f;
+        }
+        qcqp5(dim - 1, Ac, bc, mu, fn, vv);
+#pragma unroll
+        for (int a = 1; a < 6; ++a) fnew[a] = a < dim ? vv[a - 1] : 0.0f;
+      }
+      float change = 0.0f, dl[6];
+#pragma unroll
+      for (int a = 0; a < 6; ++a) dl[a] = a < dim ? fnew[a] - fold[a] : 0.0f;
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
+        float s2 = 0.0f;
+#pragma unroll
+        for (int bq = 0; bq < 6; ++bq) s2 += (a < dim && bq < dim) ? A[a][bq] * dl[bq] : 0.0f;
+        change += dl[a] * (0.5f * s2 + res[a]);
+      }
+      const bool bad = change > 1e-10f;
+      if (!bad) {
+        improvement -= change;
+        for (int c = lig; c < nv; c += G) {
+          float s = 0.0f;
+          for (int a = 0; a < dim; ++a) s += dl[a] * Bg[(size_t)(i + a) * nvp + c];
+          q[c] += s;
+        }
+        if (lig < dim) force[i + lig] = fnew[0] * (lig == 0) + fnew[1] * (lig == 1) + fnew[2] * (lig == 2) + fnew[3] * (lig == 3) + fnew[4] * (lig == 4) + fnew[5] * (lig == 5);
+      }
+      gsync();
+      i += dim - 1;
+    }
+    ++niter;
+    if (improvement * rscale < tolerance) break;
+  }
+
+  // ---- finish: qfrc_constraint = J' f, qacc = qacc_smooth + B' f, dual states ---------------------------------------------------------
+  for (int c = lig; c < nv; c += G) {
+    float qc = 0.0f, dq = 0.0f;
+    for (int r = 0; r < nefc; ++r) {
+      const float f = force[r];
+      qc += f * Jg[(size_t)r * nvp + c];
+      dq += f * Bg[(size_t)r * nvp + c];
+    }
+    d.qacc[vo + c] = qs[c] + dq;
+    d.qfrc_constraint[vo + c] = qc;
+    d.efc_Ma[vo + c] = d.qfrc_smooth[vo + c] + qc;
+  }
+  for (int r = lig; r < nefc; r += G) {
+    const float f = force[r];
+    const int k = info[r];
+    int state;
+    if (k == 0) state = ST_QUADRATIC;
+    else if (k == 1) {
+      const float fl = d.efc_frictionloss[eo + r];
+      state = f <= -fl ? ST_LINEARPOS : (f >= fl ? ST_LINEARNEG : ST_QUADRATIC);
+    } else if (k == 2) state = f <= 0.0f ? ST_SATISFIED : ST_QUADRATIC;
+    else {  // elliptic contact: no normal force -> satisfied; friction on the cone's surface -> cone; strictly inside -> quadratic
+      int r0 = r;
+      while (info[r0] == 7) --r0;
+      const int dim = info[r0] - 8;
+      float tt = 0.0f;
+      for (int a = 1; a < dim; ++a) tt += (force[r0 + a] / rmu[r0 + a]) * (force[r0 + a] / rmu[r0 + a]);
+      state = force[r0] <= 0.0f ? ST_SATISFIED : (tt >= force[r0] * force[r0] * (1.0f - 1e-5f) ? ST_CONE : ST_QUADRATIC);
+    }
+    d.efc_force[eo + r] = f;
+    d.efc_state[eo + r] = state;
+  }
+  if (lig == 0) d.solver_niter[w] = niter;
+}

@@ -2,6 +2,7 @@
 #include "host.hpp"
 
 #include "pgs.hpp"
+#include "pgs_big.hpp"
 
 // PGS (pgs.hpp): one launch, no riders (publish + factor ride with the integrator launch, as for Newton)
 // REG: the register-resident sweep for njmax <= 64 (see pgs.hpp)
@@ -29,7 +30,22 @@ static int launch_pgs_t(const MjhModel* m, const MjhData* d, hipStream_t s) {
   if (d->njmax <= 64 && !no_reg) return launch_pgs_r<NV4, 64, true>(m, d, s);  // one world per wavefront
   return launch_pgs_r<NV4, SG, false>(m, d, s);
 }
+// generic PGS (pgs_big.hpp): more than 64 dofs, or elliptic friction cones -- one world per wavefront
+__global__ void __launch_bounds__(64) k_solve_pgs_big(MjhModel m, MjhData d) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  if ((int)blockIdx.x < d.nworld) pgs_big_body<64>(m, d, smem, (int)blockIdx.x);
+}
+static int launch_pgs_big(const MjhModel* m, const MjhData* d, hipStream_t s) {
+  if (!d->ws_pgsB) return fail(MJH_E_ARG, "Data.ws_pgsB missing (allocate Data with make_data / put_data for this model)");
+  const PgsBigLayout lay = pgs_big_layout(m->nv, m->nC, d->njmax, m->cone == CONE_ELLIPTIC && d->nmaxpyramid > 1);
+  const size_t lds = sizeof(int) * mstruct_ints(m->nv, m->nC) + sizeof(float) * lay.total;
+  if (lds > (size_t)kLdsPerCU) return fail(MJH_E_UNSUPPORTED, "k_solve_pgs_big: nv / njmax do not fit in LDS");
+  HIPCHK(set_lds(k_solve_pgs_big, lds));
+  hipLaunchKernelGGL(k_solve_pgs_big, dim3(d->nworld), dim3(64), lds, s, *m, *d);
+  return MJH_OK;
+}
 int launch_pgs(const MjhModel* m, const MjhData* d, hipStream_t s) {
+  if (m->nv > 64 || (m->cone == CONE_ELLIPTIC && d->nmaxpyramid > 1)) return launch_pgs_big(m, d, s);
   const int nv4 = (m->nv + 3) / 4;
   if (m->nv <= 32) {
     switch (nv4) {

@@ -131,10 +131,6 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
     raise NotImplementedError(f"Unknown solver {int(opt.solver)}.")
   if int(opt.cone) not in (types.ConeType.PYRAMIDAL, types.ConeType.ELLIPTIC):
     raise NotImplementedError(f"Unknown cone {int(opt.cone)}.")
-  if int(opt.cone) == types.ConeType.ELLIPTIC and int(opt.solver) == types.SolverType.PGS:
-    raise NotImplementedError("PGS with elliptic friction cones is not implemented (CG and Newton solve elliptic cones at any model size).")
-  if mjm.nv > 64 and int(opt.solver) == types.SolverType.PGS:
-    raise NotImplementedError("PGS supports at most 64 dofs (CG and Newton have a generic path for larger models).")
   if mjm.nu and (np.asarray(mjm.actuator_trntype) != types.TrnType.JOINT).any():
     raise NotImplementedError("Only joint transmissions are supported.")
   if mjm.nu:
@@ -559,11 +555,16 @@ def _data_shapes(m, nworld, nconmax, njmax, naconmax):
     ws_isl_dofadr=(W, (m.ntree + 1) if m.tree_solve else 0), ws_isl_dofmap=(W, nv if m.tree_solve else 0), ws_isl_dofinv=(W, nv if m.tree_solve else 0), ws_nisland=(W,), ws_isl_flags=(W,), ws_isl_list=(3, W if m.tree_solve else 0), ws_isl_count=(4,),
     ws_separable=(W,), ws_order=(W,), ws_ccd=(W if m._convex_pairs else 0, _ccd_words(max(int(m.opt.ccd_iterations), int(m.epa_iterations)), m.nhfield), 32),
     tree_asleep=(W, m.ntree), tree_awake=(W, m.ntree), body_awake=(W, nb), body_awake_ind=(W, nb), dof_awake_ind=(W, nv), ntree_awake=(W,), nbody_awake=(W,),
-    nv_awake=(W,), tree_island=(W, m.ntree), nisland=(W,), ws_sleep_J=(W if m.sleep_enabled else 0, njmax_pad, nv_pad), ws_sleep_warm=(W if m.sleep_enabled else 0, nv),
+    nv_awake=(W,), tree_island=(W, m.ntree), nisland=(W,), ws_pgsB=(W if _needs_pgs_big(m) else 0, njmax_pad, nv_pad), ws_sleep_J=(W if m.sleep_enabled else 0, njmax_pad, nv_pad), ws_sleep_warm=(W if m.sleep_enabled else 0, nv),
     ws_sleep_flag=(W,),
     sensordata=(W, m.nsensordata), energy=(W, 2), subtree_linvel=(W, nb, 3), subtree_angmom=(W, nb, 3), cfrc_ext=(W, nb, 6), eq_active=(W, m.neq), ws_rk=(W, nq + 3 * nv + 2 * na), ws_contact=(W, contact_cap(nconmax), 32),
   )
   return sh, njmax_pad, nv_pad
+
+
+def _needs_pgs_big(m: types.Model) -> bool:
+  """PGS with more than 64 dofs or elliptic cones runs the generic kernel (csrc/pgs_big.hpp), which keeps J M^-1 in Data.ws_pgsB."""
+  return int(m.opt.solver) == int(types.SolverType.PGS) and (m.nv > 64 or int(m.opt.cone) == int(types.ConeType.ELLIPTIC))
 
 
 def _alloc_data(m: types.Model, nworld, nconmax, njmax, naconmax, mjd=None, nvmax=None):
@@ -599,6 +600,7 @@ def _alloc_data(m: types.Model, nworld, nconmax, njmax, naconmax, mjd=None, nvma
   d.sleep_pass = 0
   d.nvmax = int(nvmax)
   d.nsleepworld = shapes["ws_sleep_J"][0]
+  d.npgsworld = shapes["ws_pgsB"][0]
   _reset_sleep(m, d, None)
   if m.neq:
     d.eq_active.assign(np.tile(m.eq_active0, (nworld, 1)))

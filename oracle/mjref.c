@@ -2405,6 +2405,43 @@ static double linesearch(const RefModel* m, RefData* d, Ctx* c, double search_do
  *   finish     : qfrc_constraint = J' f,  qacc = qacc_smooth + M^-1 qfrc_constraint, states from the forces
  * Parity unpinned (like the rest of this oracle); tests/test_oracle.py additionally checks that the PGS fixed point agrees
  * with the Newton solution of the primal problem, which pins the restatement against an independent algorithm. */
+/* min 0.5 v'A v + v'b  s.t.  sum_j (v_j / mu_j)^2 <= r^2   (n <= 5; MuJoCo's mju_QCQP family, used by mj_solPGS for the friction part of an
+ * elliptic contact): in the scaled variable y = v / mu the constraint is a ball; the unconstrained minimiser if it is inside, otherwise
+ * Newton on the multiplier lambda of |y(lambda)|^2 = r^2, y(lambda) = -(As + lambda I)^-1 bs.  Returns 1 when the constraint is active. */
+static int qcqp(int n, const double* A, const double* b, const double* mu, double r, double* v) {
+  double As[25], bs[5], L[25], y[5], t[5];
+  for (int i = 0; i < n; i++) {
+    bs[i] = b[i] * mu[i];
+    for (int j = 0; j < n; j++) As[i * n + j] = A[i * n + j] * mu[i] * mu[j];
+  }
+  double la = 0.0;
+  int active = 0;
+  for (int it = 0; it < 20; it++) {
+    memcpy(L, As, sizeof(double) * n * n);
+    for (int i = 0; i < n; i++) L[i * n + i] += la;
+    chol_factor(L, n);
+    for (int i = 0; i < n; i++) t[i] = -bs[i];
+    chol_solve(L, n, y, t);
+    double val = -r * r;
+    for (int i = 0; i < n; i++) val += y[i] * y[i];
+    if (val < 1e-10) break; /* inside (or on) the ball */
+    active = 1;
+    chol_solve(L, n, t, y); /* (As + la I)^-1 y */
+    double deriv = 0.0;
+    for (int i = 0; i < n; i++) deriv -= 2.0 * y[i] * t[i];
+    double delta = -val / deriv;
+    if (delta < 1e-10) break;
+    la += delta;
+  }
+  for (int i = 0; i < n; i++) v[i] = y[i] * mu[i];
+  if (active) { /* round-off: land exactly on the boundary */
+    double s = 0.0;
+    for (int i = 0; i < n; i++) s += y[i] * y[i];
+    if (s > r * r && s > 0.0) for (int i = 0; i < n; i++) v[i] *= r / sqrt(s);
+  }
+  return active;
+}
+
 static void solve_pgs(const RefModel* m, RefData* d, int nefc) {
   int nv = m->nv, ne = d->ne, nf = d->nf;
   double* buf = (double*)calloc((size_t)nefc * nv + (size_t)nefc * nefc + 3 * (size_t)nefc + 2 * (size_t)nv, sizeof(double));
@@ -2444,6 +2481,77 @@ static void solve_pgs(const RefModel* m, RefData* d, int nefc) {
   for (int iter = 0; iter < m->iterations; iter++) {
     double improvement = 0;
     for (int i = 0; i < nefc; i++) {
+      if (i >= ne + nf && d->efc_type[i] == CT_CONTACT_ELLIPTIC) {
+        /* elliptic contact: its dim rows are updated together (MuJoCo mj_solPGS): a projected step on the normal force with the friction
+         * forces held, then the friction forces as the QCQP  min 0.5 v'A_ff v + v'b_c  inside the cone section  sum (v_j / mu_j)^2 <= f_n^2 */
+        int con = d->efc_id[i], dim = d->con_dim[con];
+        if (i + dim > nefc) dim = nefc - i;
+        const double* fri = d->con_friction + 5 * con;
+        double res[6], oldf[6] = {0, 0, 0, 0, 0, 0}, Ac[25], bc[5], v[5], mu[5];
+        for (int a = 0; a < dim; a++) {
+          res[a] = b[i + a];
+          for (int k = 0; k < nefc; k++) res[a] += AR[(size_t)(i + a) * nefc + k] * f[k];
+          oldf[a] = f[i + a];
+        }
+        double fn;
+        if (oldf[0] < MINVAL) {
+          /* at the apex: leave it along the steepest feasible direction of the cone -- v = (1, -mu_j^2 res_j / s), s = |mu o res_f| (the
+           * boundary ray whose friction opposes the friction residual; the normal alone when there is none) -- if the cost decreases there:
+           * slope res_0 - s < 0; exact minimisation along v */
+          double sres = 0.0, vdir[6], vAv = 0.0;
+          for (int a = 1; a < dim; a++) sres += fri[a - 1] * fri[a - 1] * res[a] * res[a];
+          sres = sqrt(sres);
+          vdir[0] = 1.0;
+          for (int a = 1; a < dim; a++) vdir[a] = sres > MINVAL ? -fri[a - 1] * fri[a - 1] * res[a] / sres : 0.0;
+          for (int a = 0; a < dim; a++)
+            for (int c2 = 0; c2 < dim; c2++) vAv += vdir[a] * AR[(size_t)(i + a) * nefc + i + c2] * vdir[c2];
+          double slope = res[0] - sres, t = (slope < 0.0 && vAv >= MINVAL) ? -slope / vAv : 0.0;
+          for (int a = 0; a < dim; a++) f[i + a] = t * vdir[a];
+          fn = f[i];
+        } else { /* ray update: exact minimisation along the current force direction (scales normal and friction together) */
+          double vAv = 0.0, vr = 0.0, Av[6];
+          for (int a = 0; a < dim; a++) {
+            Av[a] = 0.0;
+            for (int c2 = 0; c2 < dim; c2++) Av[a] += AR[(size_t)(i + a) * nefc + i + c2] * oldf[c2];
+            vAv += oldf[a] * Av[a];
+            vr += oldf[a] * res[a];
+          }
+          double x = vAv >= MINVAL ? -vr / vAv : 0.0;
+          if (x < -1.0) x = -1.0; /* (the normal force stays non-negative) */
+          for (int a = 0; a < dim; a++) f[i + a] = oldf[a] + x * oldf[a];
+          fn = f[i];
+        }
+        double cur[6]; /* the force reached so far: the friction step below starts from it */
+        for (int a = 0; a < dim; a++) cur[a] = f[i + a];
+        if (fn < MINVAL) {
+          for (int a = 1; a < dim; a++) f[i + a] = 0.0;
+        } else {
+          for (int a = 1; a < dim; a++) { /* gradient wrt the friction forces = A_ff v + bc, with the normal force fixed at fn */
+            mu[a - 1] = fri[a - 1];
+            bc[a - 1] = res[a] + AR[(size_t)(i + a) * nefc + i] * (fn - oldf[0]);
+            for (int c2 = 1; c2 < dim; c2++) {
+              Ac[(a - 1) * (dim - 1) + (c2 - 1)] = AR[(size_t)(i + a) * nefc + i + c2];
+              bc[a - 1] -= AR[(size_t)(i + a) * nefc + i + c2] * oldf[c2];
+            }
+            (void)cur;
+          }
+          qcqp(dim - 1, Ac, bc, mu, fn, v);
+          for (int a = 1; a < dim; a++) f[i + a] = v[a - 1];
+        }
+        double change = 0.0;
+        for (int a = 0; a < dim; a++) {
+          double da = f[i + a] - oldf[a], s2 = 0.0;
+          for (int c2 = 0; c2 < dim; c2++) s2 += AR[(size_t)(i + a) * nefc + i + c2] * (f[i + c2] - oldf[c2]);
+          change += da * (0.5 * s2 + res[a]);
+        }
+        if (change > 1e-10) {
+          for (int a = 0; a < dim; a++) f[i + a] = oldf[a];
+          change = 0.0;
+        }
+        improvement -= change;
+        i += dim - 1;
+        continue;
+      }
       double res = b[i], Aii = AR[(size_t)i * nefc + i], old = f[i];
       for (int k = 0; k < nefc; k++) res += AR[(size_t)i * nefc + k] * f[k];
       double fn = old - res / Aii;
@@ -2466,6 +2574,13 @@ static void solve_pgs(const RefModel* m, RefData* d, int nefc) {
     else if (r < ne + nf) {
       double fl = d->efc_frictionloss[r];
       d->efc_state[r] = f[r] <= -fl ? ST_LINEARPOS : (f[r] >= fl ? ST_LINEARNEG : ST_QUADRATIC);
+    } else if (d->efc_type[r] == CT_CONTACT_ELLIPTIC) {
+      /* per contact: no normal force -> satisfied; friction on the cone's surface -> cone; strictly inside -> quadratic */
+      int con = d->efc_id[r], r0 = d->con_efc_address[10 * con], dim = d->con_dim[con];
+      const double* fri = d->con_friction + 5 * con;
+      double tt = 0.0;
+      for (int a = 1; a < dim && r0 + a < nefc; a++) tt += (f[r0 + a] / fri[a - 1]) * (f[r0 + a] / fri[a - 1]);
+      d->efc_state[r] = f[r0] <= 0.0 ? ST_SATISFIED : (tt >= f[r0] * f[r0] * (1.0 - 1e-9) ? ST_CONE : ST_QUADRATIC);
     } else d->efc_state[r] = f[r] <= 0.0 ? ST_SATISFIED : ST_QUADRATIC;
   }
   for (int i = 0; i < nv; i++) {  /* dualFinish */

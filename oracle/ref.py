@@ -213,8 +213,6 @@ class RefSim:
       ccd_tolerance=float(getattr(opt, 'ccd_tolerance', 1e-6)), timestep=float(opt.timestep),
       tolerance=float(opt.tolerance if tolerance is None else tolerance), ls_tolerance=float(opt.ls_tolerance),
       impratio=float(opt.impratio), meaninertia=float(mjm.stat.meaninertia))
-    if scalars["cone"] != 0 and scalars["solver"] == 0:
-      raise NotImplementedError("oracle: PGS with elliptic cones")
     special = {"gravity": np.asarray(opt.gravity, dtype=np.float64), "magnetic": np.asarray(getattr(opt, "magnetic", [0.0, -0.5, 0.0]), dtype=np.float64), "pair_geom": pairs, "nxn_pairid": pairid,
                "xpair_dim": getattr(mjm, "pair_dim", np.zeros(0)), "xpair_friction": getattr(mjm, "pair_friction", np.zeros(0)),
                "xpair_solref": getattr(mjm, "pair_solref", np.zeros(0)), "xpair_solreffriction": getattr(mjm, "pair_solreffriction", np.zeros(0)),

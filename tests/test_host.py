@@ -82,10 +82,9 @@ def test_unsupported_features_raise():
   with pytest.raises(NotImplementedError):
     mjw.mjcf.from_xml_string('<mujoco><worldbody><body><joint/><geom size=".1"/></body></worldbody>'
                              '<tendon><fixed><joint joint="x" coef="1"/></fixed></tendon></mujoco>')
-  # elliptic cones: CG / Newton only (the oracle's PGS restates MuJoCo C's pyramidal / frictionless projection)
+  # (round 3: PGS with elliptic cones and with more than 64 dofs is accepted: the generic kernel csrc/pgs_big.hpp, tests/test_pgs.py)
   m = mjw.mjcf.from_xml_string('<mujoco><option cone="elliptic" solver="PGS"/><worldbody><body><joint/><geom size=".1"/></body></worldbody></mujoco>')
-  with pytest.raises(NotImplementedError):
-    mjw.put_model(m)
+  assert mjw.put_model(m).opt.solver == int(mjw.SolverType.PGS)
   # structural elements the subset compiler does not expand are never skipped silently (they would change the model)
   for body in ('<composite type="grid"/>', '<body><joint/><geom size=".1"/><flexcomp name="f"/></body>'):
     with pytest.raises(NotImplementedError):
@@ -360,7 +359,7 @@ def test_declared_schema_matches_arrays(xml):
   assert dataclasses.is_dataclass(mjw.Model) and dataclasses.is_dataclass(mjw.Data)
   env = {k: getattr(m, k) for k in ("nq", "nv", "nu", "na", "nbody", "njnt", "ngeom", "nsite", "nkey", "nmocap", "neq", "nC", "npair",
                                     "nexplicit", "nbodylevel", "ndoflevel", "nmaxpyramid", "ntree", "nmesh", "nmeshvert", "nmeshpoly", "nmeshpolyvert", "nmeshpolymap", "nmeshgraph", "nhfield", "nhfielddata", "nsensor", "nsensordata", "nmat")}
-  env.update(nworld=d.nworld, njmax=d.njmax, njmax_pad=d.njmax_pad, nv_pad=d.nv_pad, naconmax=d.naconmax, concap=d.concap, nccdworld=d.nccdworld, nccdword=d.nccdword, ntreeadr=(m.ntree + 1) if m.tree_solve else 0, ntreerow=d.njmax if m.tree_solve else 0, ntreedof=m.nv if m.tree_solve else 0, ntreeworld=d.nworld if m.tree_solve else 0, nsleepworld=d.nsleepworld)
+  env.update(nworld=d.nworld, njmax=d.njmax, njmax_pad=d.njmax_pad, nv_pad=d.nv_pad, naconmax=d.naconmax, concap=d.concap, nccdworld=d.nccdworld, nccdword=d.nccdword, ntreeadr=(m.ntree + 1) if m.tree_solve else 0, ntreerow=d.njmax if m.tree_solve else 0, ntreedof=m.nv if m.tree_solve else 0, ntreeworld=d.nworld if m.tree_solve else 0, nsleepworld=d.nsleepworld, npgsworld=d.npgsworld)
   for obj in (m.opt, m.stat, m, d.contact, d.efc, d):
     _schema_check(obj, env, d.nworld)
 

@@ -290,3 +290,105 @@ def test_pgs_large_batch_properties():
   assert np.isfinite(q).all() and (q[:, 2] > 0.2).all()
   assert (d.overflow.numpy() & 0x1FF == 0).all()
   assert d.solver_niter.numpy().max() <= mjm.opt.iterations
+
+
+# ------------------------------------------------------------------------------------- elliptic cones, more than 64 dofs (round 3)
+@pytest.mark.parametrize("condim", [3, 4, 6])
+@pytest.mark.parametrize("impratio", [1.0, 10.0])
+def test_oracle_pgs_elliptic_fixed_point_is_the_newton_solution(condim, impratio):
+  """PGS on elliptic cones (per contact: apex ray / ray update / friction QCQP at fixed normal force, oracle/mjref.c:solve_pgs) solves the
+  dual problem; converged, it must reproduce the Newton solution of the primal elliptic problem -- an independent algorithm with
+  different zones, costs and cone parametrisation (solver.py:272-517).  Measured: qacc to 2e-6, forces to 5e-6."""
+  from tests.test_elliptic import _model
+
+  mjm = _model(condim)
+  mjm.opt.impratio = impratio
+  n = ref.RefSim(mjm, nconmax=32, njmax=128, solver=NEWTON, tolerance=1e-12, iterations=200, ls_iterations=100)
+  p = ref.RefSim(mjm, nconmax=32, njmax=128, solver=PGS, tolerance=1e-14, iterations=20000)
+  n.reset(key=0)
+  p.reset(key=0)
+  cone_rows = 0
+  for step in range(40):
+    for f in ("qpos", "qvel", "qacc_warmstart"):
+      getattr(p, f)[:] = getattr(n, f)
+    n.forward()
+    p.forward()
+    k = n.nefc
+    assert k == p.nefc and k > 0
+    assert relerr(p.qacc, n.qacc) <= 2e-5
+    assert relerr(p.efc_force[:k], n.efc_force[:k]) <= 5e-5
+    # every contact force inside its friction cone
+    for c in range(p.ncon):
+      r0, dim = p.con_efc_address[c][0], p.con_dim[c]
+      if r0 >= 0 and dim > 1:
+        tt = np.sqrt(np.sum((p.efc_force[r0 + 1 : r0 + dim] / p.con_friction[c][: dim - 1]) ** 2))
+        assert p.efc_force[r0] >= 0 and tt <= p.efc_force[r0] * (1 + 1e-9) + 1e-12
+    cone_rows += int((p.efc_state[:k] == 4).sum())
+    n.step()
+  assert cone_rows > 0  # sliding contacts on the cone's surface were part of the comparison
+
+
+def _check_pgs_cost(s, d, w, rel):
+  """The engine's forces under the oracle's float64 dual problem: inside every cone and no worse a minimiser than the oracle's own
+  after the same number of sweeps (PGS iterates are compared through the objective when it has not converged)."""
+  k = s.nefc
+  M, J = s.dense_M(), s.efc_J[:k]
+  A = J @ np.linalg.solve(M, J.T) + np.diag(1.0 / s.efc_D[:k])
+  b = J @ s.qacc_smooth - s.efc_aref[:k]
+  cost = lambda f: 0.5 * f @ A @ f + f @ b
+  fg, fo = d.efc.force.numpy()[w, :k].astype(np.float64), s.efc_force[:k]
+  assert cost(fg) <= cost(fo) + rel * abs(cost(fo)), (cost(fg), cost(fo))
+  for c in range(s.ncon):
+    r0, dim = s.con_efc_address[c][0], s.con_dim[c]
+    if r0 >= 0 and dim > 1 and s.efc_type[r0] == 7:
+      tt = np.sqrt(np.sum((fg[r0 + 1 : r0 + dim] / s.con_friction[c][: dim - 1]) ** 2))
+      assert fg[r0] >= 0 and tt <= fg[r0] * (1 + 1e-4) + 1e-6, (c, fg[r0], tt)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("condim", [3, 4, 6])
+def test_gpu_pgs_elliptic_matches_oracle(condim):
+  """The generic PGS kernel (csrc/pgs_big.hpp) on the elliptic scenes of tests/test_elliptic.py: converged solution vs the oracle's."""
+  from tests.test_elliptic import _model
+
+  mjm = _model(condim)
+  s, m, d = _pair(mjm, 3, 32, 128, 0, iterations=3000, tolerance=1e-9)
+  assert d.ws_pgsB.size > 0
+  worst = 0.0
+  for step in range(30):
+    _sync(s, d)
+    s.forward()
+    mjw.forward(m, d)
+    k = s.nefc
+    assert int(d.nefc.numpy()[-1]) == k
+    worst = max(worst, relerr(d.qacc.numpy()[-1], s.qacc))
+    assert relerr(d.efc.force.numpy()[-1, :k], s.efc_force[:k]) <= 2e-2
+    _check_pgs_cost(s, d, -1, 1e-4)
+    s.step()
+  print(f"pgs elliptic condim {condim}: qacc {worst:.3g}")
+  assert worst <= 5e-3, worst
+
+
+@pytest.mark.gpu
+def test_gpu_pgs_clutter_nv136():
+  """BASELINE configs[4] names PGS: the generic kernel on the 136-dof elliptic clutter model (sleeping off: it needs Newton, as in the
+  reference), per re-synchronised step against the oracle's PGS at the same sweep cap, compared through the dual objective."""
+  mjm = mjw.mjcf.load_xml(os.path.join(conftest.ROOT, "tests", "models", "clutter_synth.xml"))
+  mjm.opt.enableflags = 0
+  s, m, d = _pair(mjm, 2, 256, 384, 0, iterations=60)
+  worst_q = worst_v = 0.0
+  same = 0
+  for i in range(120):
+    _sync(s, d)
+    mjw.step(m, d)
+    s.step()
+    if int(d.nefc.numpy()[1]) != s.nefc:
+      continue
+    same += 1
+    if i % 10 == 0 and s.nefc:
+      _check_pgs_cost(s, d, 1, 2e-3)
+    worst_q = max(worst_q, relerr(d.qpos.numpy()[1], s.qpos))
+    worst_v = max(worst_v, relerr(d.qvel.numpy()[1], s.qvel))
+  print(f"pgs clutter: {same}/120 steps, qpos {worst_q:.3g} qvel {worst_v:.3g}")
+  assert same >= 100 and worst_q <= 1e-4 and worst_v <= 5e-2, (same, worst_q, worst_v)
+  assert np.isfinite(d.qpos.numpy()).all() and (d.qpos.numpy()[0] == d.qpos.numpy()[1]).all()

@@ -9,8 +9,11 @@ import mujoco_warp_amd as mjw
 nworld = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 nstep = int(sys.argv[2]) if len(sys.argv) > 2 else 500
 mjm = mjw.mjcf.load_xml(os.path.join(ROOT, "tests", "models", "clutter_synth.xml"))
-m = mjw.put_model(mjm)
-for init_asleep in (False, True):
+for init_asleep, solver in ((False, "newton"), (True, "newton"), (False, "pgs")):
+  mjm = mjw.mjcf.load_xml(os.path.join(ROOT, "tests", "models", "clutter_synth.xml"))
+  if solver == "pgs":  # BASELINE configs[4] names PGS: the generic kernel; sleeping needs Newton (as in the reference), so it is off here
+    mjw.override_model(mjm, ["opt.solver=pgs", "opt.enableflags=0"])
+  m = mjw.put_model(mjm)
   mjd = mjw.MjData(mjm)
   mjw.mj_resetDataKeyframe(mjm, mjd, 0)
   if init_asleep:
@@ -29,7 +32,7 @@ for init_asleep in (False, True):
     if i % 100 == 99:
       stats.append((i + 1, float(d.nefc.numpy().mean()), float(d.ws_ncon.numpy().mean()), float(d.ntree_awake.numpy().mean()), float(d.solver_niter.numpy().mean())))
   ovf = int(np.bitwise_or.reduce(d.overflow.numpy()))
-  print(f"clutter_synth nv {mjm.nv} nworld {nworld} init_asleep {int(init_asleep)}: {nworld * nstep / total:,.0f} env-steps/s ({total / nstep * 1e3:.3f} ms/step, per-step sync, noise untimed), "
+  print(f"clutter_synth nv {mjm.nv} nworld {nworld} solver {solver} init_asleep {int(init_asleep)}: {nworld * nstep / total:,.0f} env-steps/s ({total / nstep * 1e3:.3f} ms/step, per-step sync, noise untimed), "
         f"finite {bool(np.isfinite(d.qpos.numpy()).all())}, overflow bits {ovf:#x} (NVMAX {bool(ovf & 128)})")
   for st in stats:
     print("   step %4d: nefc %.1f ncon %.1f trees awake %.1f niter %.2f" % st)

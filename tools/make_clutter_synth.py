@@ -133,9 +133,10 @@ def main():
   </keyframe>
 </mujoco>
 """
-  out = os.path.join(ROOT, "tests", "models", "clutter_synth.xml")
-  open(out, "w").write(xml)
-  print("wrote", out)
+  for out in (os.path.join(ROOT, "tests", "models", "clutter_synth.xml"), os.path.join(ROOT, "benchmarks", "clutter_synth", "scene_clutter_synth.xml")):
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    open(out, "w").write(xml)
+    print("wrote", out)
 
 
 if __name__ == "__main__":
