@@ -5,11 +5,18 @@
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library;
  * the product path (mujoco_warp_amd) never does.
  *
- * PARITY UNPINNED: the arithmetic of record is MuJoCo C (mujoco 3.11.1.dev954833728, uv.lock:1053),
- * which is absent from /root/reference and from this environment, and the reference holds no golden
- * vectors for FK/CRBA/RNE/collision/solver/step.  This restatement follows the
- * reference's own kernels line by line (citations at each function) and is pinned only by
- * self-consistency checks in tests/ (energy, M symmetry/PD, M*(M^-1 y)=y, KKT residuals).
+ * PIN STATUS (round 3).  The arithmetic of record is MuJoCo C (mujoco 3.11.1.dev954833728, uv.lock:1053), absent from /root/reference
+ * and from this environment.  What pins this restatement instead:
+ *   - EXTERNALLY: the states MuJoCo C itself went through, recorded in the reference's benchmark input
+ *     benchmarks/unitree_g1/shuffle_dance.npz (qpos [251, 36], qvel [251, 35] at 50 Hz next to the controls): from every recorded frame,
+ *     four oracle steps land on the next recorded frame to the recording's float32 storage precision (qpos median 1.7e-7, qvel median
+ *     1.0e-5 over all 250 intervals; a free run tracks the recording for 100 frames).  That pins, for the G1 chain, MJCF compilation ->
+ *     FK -> CRBA -> RNE -> position actuators -> collision -> constraint rows -> Newton -> implicitfast (tests/test_reference_trajectory.py);
+ *   - every number the reference's own tests hold for this path (math vectors, key-0 contact / row counts, broadphase counts, the
+ *     GJK / EPA / multi-contact values of collision_gjk_test.py: tests/test_reference_vectors.py, test_convex.py, test_reference_gjk_gpu.py);
+ *   - MuJoCo-independent identities for the rest (energy, M (M^-1 y) = y, KKT residuals, Newton = CG = PGS fixed points, cone membership).
+ * UNPINNED still: CG and PGS as algorithms (only their fixed points are pinned, through Newton), elliptic cones, sleeping policy
+ * stand-ins, meshes / height fields beyond the reference-held numbers, sensors, rays.
  *
  * The struct layouts below are parsed by oracle/ref.py (one declaration per line, no macros).
  */

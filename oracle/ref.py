@@ -1,7 +1,7 @@
 """ctypes front-end of the float64 CPU oracle (oracle/mjref.c).  TEST INFRASTRUCTURE ONLY.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the
-product package `mujoco_warp_amd` never does.  PARITY UNPINNED: see oracle/mjref.h.
+product package `mujoco_warp_amd` never does.  Pin status (externally pinned for the G1 chain since round 3): see oracle/mjref.h.
 """
 
 import ctypes

@@ -34,8 +34,12 @@ for t in s.get("kernel_trace", []):
   if t["kernel"] in out["kernels"]:
     out["kernels"][t["kernel"]]["mean_us"] = t["mean_us"]
     k = out["kernels"][t["kernel"]]
-    if k.get("mfma_busy_cycles") and k.get("busy_cycles_sum"):
-      # MFMA pipe utilisation: busy cycles of the MFMA unit / busy cycles of the shader engines' SQs over the kernel (both summed over instances)
-      k["mfma_busy_frac_of_sq_busy"] = k["mfma_busy_cycles"] / k["busy_cycles_sum"]
+    if k.get("mfma_busy_cycles"):
+      # MFMA pipe utilisation: SQ_VALU_MFMA_BUSY_CYCLES (summed over the 1,024 SIMDs) / (kernel duration x 2.4 GHz x 1,024 SIMDs); and the
+      # arithmetic rate from the instruction count (v_mfma_f32_32x32x1_2b_f32: 2 blocks x 32 x 32 x 1 MACs = 4,096 flop per instruction)
+      k["mfma_util"] = k["mfma_busy_cycles"] / (t["mean_us"] * 2400.0 * 1024.0)
+      if k.get("mfma_insts"):
+        k["mfma_tflops"] = k["mfma_insts"] * 4096.0 / (t["mean_us"] * 1e-6) / 1e12
+        k["mfma_peak_note"] = "dense f32 MFMA peak of MI355X = 157 TFLOP/s (MI355X_MICROARCH.md); the H build is one phase of this kernel (16 % of it)"
 json.dump(out, open(dst, "w"), indent=1)
 print(json.dumps(out)[:600])
