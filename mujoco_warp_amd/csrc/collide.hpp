@@ -1041,15 +1041,16 @@ DEV PairParams contact_params(const MjhModel& m, int w, int g1, int g2, int pid 
 // Contact record (CON_REC words; CON_STRIDE in the per-world hand-off buffer d.ws_contact, so that a record is one
 // aligned 128-byte line):
 //   0 dist | 1-3 pos | 4-12 frame | 13 includemargin | 14-16 friction (slide, spin, roll) | 17-18 solref |
-//   19-23 solimp | 24 condim | 25-26 geoms | 27 collider contact id | 28 first efc row or -1 | 29 number of rows
+//   19-23 solimp | 24 condim | 25-26 geoms | 27 collider contact id | (explicit pair id + 1) << 8 | 28 first efc row or -1 | 29 number of rows |
+//   30-31 friction of tangent 2 / roll 2 (explicit <contact><pair> entries may be anisotropic; geom pairs repeat words 14 / 16)
 // (28-29 are filled by k_make_constraint).  k_collision hands the contacts of a world to k_make_constraint through
 // d.ws_contact[w]; the public, compact contact_* arrays are produced from the same records by publish_body
 // (appended to the integrator launch or run as k_publish_contacts).  The reference reserves public slots with one global atomic per
 // contact (collision_core.py write_contact); on MI355X one same-address device atomic per WORLD already cost 25-50 us
 // per launch (they resolve at the memory side, ~6 ns each, and every later load of the wave waits behind them).
 #define CON_WINDOW 16
-#define CON_REC 30
-#define CON_LDS 31  /* odd LDS stride: lane-per-contact reads are bank-conflict free */
+#define CON_REC 32
+#define CON_LDS 33  /* odd LDS stride: lane-per-contact reads are bank-conflict free */
 // per-world LDS: geom poses (12 words per geom) | candidate pair list | first contact slot << 8 | contact mask per
 // candidate | staging window of CON_WINDOW records
 // SAP broadphase (sap != 0) adds: projection bounds (2 words per geom, padded to a power of two for the bitonic sort) | sorted
@@ -1447,7 +1448,9 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
                        ri[24] = pp.condim;
                        ri[25] = g1;
                        ri[26] = g2;
-                       ri[27] = cid;
+                       ri[27] = cid | ((pid + 1) << 8);
+                       r[30] = pp.friction[1];
+                       r[31] = pp.friction[4];
                      }
                      ++slot;
                    };
@@ -1514,7 +1517,7 @@ __global__ void __launch_bounds__(256) k_collision(MjhModel m, MjhData d) {
 // 8192 worlds), so that no scan kernel has to run before it; the workgroup of the last world also writes the totals.
 // `sh` needs 64 ints of LDS.
 template <int G>
-DEV void publish_body(const MjhData& d, int self_prefix, int* sh, const Blk& b) {
+DEV void publish_body(const MjhData& d, int self_prefix, int* sh, const Blk& b, const float* pair_solreffriction = nullptr) {
   if ((int)threadIdx.x >= b.nthreads) return;
   const int lig = threadIdx.x & (G - 1), gib = threadIdx.x / G;
   const int w = b.w0 + gib;
@@ -1584,12 +1587,15 @@ DEV void publish_body(const MjhData& d, int self_prefix, int* sh, const Blk& b) 
     d.contact_dist[o] = r[0];
     d.contact_includemargin[o] = r[13];
     *reinterpret_cast<float2*>(d.contact_solref + 2 * o) = float2{r[17], r[18]};
-    *reinterpret_cast<float2*>(d.contact_solreffriction + 2 * o) = float2{0.0f, 0.0f};
+    {  // only explicit <contact><pair> entries carry a solreffriction (collision_core.py contact_params)
+      const int pid = (ri[27] >> 8) - 1;
+      *reinterpret_cast<float2*>(d.contact_solreffriction + 2 * o) = (pid >= 0 && pair_solreffriction) ? float2{pair_solreffriction[2 * pid], pair_solreffriction[2 * pid + 1]} : float2{0.0f, 0.0f};
+    }
     d.contact_dim[o] = ri[24];
     *reinterpret_cast<int2*>(d.contact_geom + 2 * o) = int2{ri[25], ri[26]};
     d.contact_worldid[o] = w;
     d.contact_type[o] = CONTACT_TYPE_CONSTRAINT;
-    d.contact_geomcollisionid[o] = ri[27];
+    d.contact_geomcollisionid[o] = ri[27] & 255;
     const int rbase = ri[28], ndim = ri[29];
     for (int k = 0; k < ndim; ++k)
       if (rbase >= 0 && rbase + k < njmax) d.efc_id[(size_t)w * njmax + rbase + k] = adr + c;
@@ -1598,7 +1604,7 @@ DEV void publish_body(const MjhData& d, int self_prefix, int* sh, const Blk& b) 
   for (int idx = lig; idx < 9 * n; idx += G) d.contact_frame[9 * o0 + idx] = rec[(idx / 9) * CON_STRIDE + 4 + idx % 9];
   for (int idx = lig; idx < 5 * n; idx += G) {
     const int q = idx % 5;
-    d.contact_friction[5 * o0 + idx] = rec[(idx / 5) * CON_STRIDE + 14 + (q < 2 ? 0 : q - 1 - (q == 4 ? 1 : 0))];
+    d.contact_friction[5 * o0 + idx] = rec[(idx / 5) * CON_STRIDE + CON_FRICTION_WORD(q)];
     d.contact_solimp[5 * o0 + idx] = rec[(idx / 5) * CON_STRIDE + 19 + q];
   }
   for (int idx = lig; idx < npyr * n; idx += G) {
@@ -1609,7 +1615,7 @@ DEV void publish_body(const MjhData& d, int self_prefix, int* sh, const Blk& b) 
 }
 
 template <int G>
-__global__ void __launch_bounds__(256) k_publish_contacts(MjhData d, int self_prefix) {
+__global__ void __launch_bounds__(256) k_publish_contacts(MjhData d, int self_prefix, const float* pair_solreffriction) {
   __shared__ int sh[64];
-  publish_body<G>(d, self_prefix, sh, blk_of_launch<G>());
+  publish_body<G>(d, self_prefix, sh, blk_of_launch<G>(), pair_solreffriction);
 }

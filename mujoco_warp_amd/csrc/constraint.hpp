@@ -336,7 +336,7 @@ DEV void make_constraint_body(const MjhModel& m, const MjhData& d, float* smem, 
       const int condim = cri[24];
       // pyramid rows 2(q-1), 2(q-1)+1 = normal component +- mu_q * component q (q = 1..condim-1): tangent 1, tangent 2,
       // spin, roll 1, roll 2.  All indexing below is static (fully unrolled), so nothing lives in scratch or movrel.
-      const float mu[6] = {0.0f, cr[14], cr[14], cr[15], cr[16], cr[16]};
+      const float mu[6] = {0.0f, cr[14], cr[30], cr[15], cr[16], cr[31]};
       for (int i0 = 0; i0 < nvp; i0 += G) {
         const int i = i0 + lig;
         V3 jp = V3{0, 0, 0}, jr = V3{0, 0, 0};
@@ -399,10 +399,10 @@ DEV void make_constraint_body(const MjhModel& m, const MjhData& d, float* smem, 
       const bool elliptic = m.cone == CONE_ELLIPTIC && condim > 1;
       if (elliptic) {
         // friction rows of an elliptic contact (constraint.py:4277-4294): regularisation scaled by 1 / impratio and by
-        // (mu_1 / mu_dim)^2, no position term in aref (solreffriction is rejected by put_model: the rows use solref)
+        // (mu_1 / mu_dim)^2, no position term in aref
         if (dimid > 0) invweight *= impr2 * impr2;
         if (dimid > 1) {
-          const float frii = cr[dimid == 2 ? 14 : (dimid == 3 ? 15 : 16)];
+          const float frii = cr[CON_FRICTION_WORD(dimid - 1)];
           invweight *= cr[14] * cr[14] / (frii * frii);
         }
       } else if (condim > 1) {
@@ -421,7 +421,13 @@ DEV void make_constraint_body(const MjhModel& m, const MjhData& d, float* smem, 
         }
       }
       const float vel = v0 + v1;
-      EfcRowOut eo_ = efc_row(dsbl, timestep, elliptic && dimid > 0 ? 0.0f : pos, pos, invweight, cr + 17, cr + 19, includemargin, vel);
+      // friction rows of an elliptic contact take the pair's solreffriction when it is set (constraint.py:4277-4283; explicit pairs only)
+      const float* ref = cr + 17;
+      if (elliptic && dimid > 0 && m.nexplicit) {
+        const int pid = (cri[27] >> 8) - 1;
+        if (pid >= 0 && (m.pair_solreffriction[2 * pid] != 0.0f || m.pair_solreffriction[2 * pid + 1] != 0.0f)) ref = m.pair_solreffriction + 2 * pid;
+      }
+      EfcRowOut eo_ = efc_row(dsbl, timestep, elliptic && dimid > 0 ? 0.0f : pos, pos, invweight, ref, cr + 19, includemargin, vel);
       d.efc_D[eo + r] = eo_.D;
       d.efc_aref[eo + r] = eo_.aref;
       d.efc_pos[eo + r] = eo_.pos;

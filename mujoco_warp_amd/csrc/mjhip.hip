@@ -99,8 +99,8 @@ static int launch_collision(const MjhModel* m, const MjhData* d, hipStream_t s) 
   return MJH_OK;
 }
 // compact public contact arrays, contact.efc_address and efc.id of contact rows from the per-world records
-static int launch_publish(const MjhData* d, hipStream_t s) {
-  hipLaunchKernelGGL(k_publish_contacts<G>, dim3((d->nworld + 7) / 8), dim3(256), 0, s, *d, 1);
+static int launch_publish(const MjhModel* m, const MjhData* d, hipStream_t s) {
+  hipLaunchKernelGGL(k_publish_contacts<G>, dim3((d->nworld + 7) / 8), dim3(256), 0, s, *d, 1, m->nexplicit ? m->pair_solreffriction : nullptr);
   return MJH_OK;
 }
 static int launch_constraint(const MjhModel* m, const MjhData* d, hipStream_t s) {
@@ -181,7 +181,7 @@ __global__ void __launch_bounds__(256) k_integrate_plus(MjhModel m, MjhData d, i
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int wpb = blockDim.x / G, bi = blockIdx.x;
   if (bi < nint) integrate_body<G>(m, d, mode, smem, Blk{bi * wpb, wpb, (int)blockDim.x});
-  else if (bi < nint + npub) publish_body<G>(d, 1, reinterpret_cast<int*>(smem), Blk{(bi - nint) * wpb, wpb, (int)blockDim.x});
+  else if (bi < nint + npub) publish_body<G>(d, 1, reinterpret_cast<int*>(smem), Blk{(bi - nint) * wpb, wpb, (int)blockDim.x}, m.nexplicit ? m.pair_solreffriction : nullptr);
   else factor_smooth_body<G>(m, d, 1, smem, Blk{(bi - nint - npub) * wpb, wpb, (int)blockDim.x});  // Newton only, see k_solve_plus
 }
 // k_fwd_pos + one workgroup that sorts the worlds by the PREVIOUS step's solver_niter (the solver schedule of this step)
@@ -459,7 +459,7 @@ static int run_sleep_step(const MjhModel* m, const MjhData* d, bool step, hipStr
   if (step) { Scope sc(K_INTEGRATE); TRY(launch_integrate(m, d, mode, s)); }
   {
     Scope sc(K_OTHER);
-    TRY(launch_publish(d, s));
+    TRY(launch_publish(m, d, s));
     TRY(launch_factor_smooth(m, d, 1, s));
   }
   if (step) {
@@ -477,10 +477,10 @@ static int run_stage(const MjhModel* m, const MjhData* d, int stage, hipStream_t
     case MJH_STAGE_FACTOR_M: { Scope sc(K_POS); return launch_pos(m, d, POS_FACTOR, POS_FACTOR, s); }
     case MJH_STAGE_COLLISION:
       { Scope sc(K_COLLISION); TRY(launch_collision(m, d, s)); }
-      { Scope sc(K_OTHER); return launch_publish(d, s); }
+      { Scope sc(K_OTHER); return launch_publish(m, d, s); }
     case MJH_STAGE_MAKE_CONSTRAINT:
       { Scope sc(K_CONSTRAINT); TRY(launch_constraint(m, d, s)); }
-      { Scope sc(K_OTHER); return launch_publish(d, s); }
+      { Scope sc(K_OTHER); return launch_publish(m, d, s); }
     case MJH_STAGE_TRANSMISSION: return MJH_OK;  // joint transmissions: length/moment are produced by fwd_actuation
     case MJH_STAGE_COM_VEL: { Scope sc(K_VEL); return launch_vel(m, d, VEL_COMVEL, VEL_COMVEL, s); }
     case MJH_STAGE_PASSIVE: { Scope sc(K_VEL); return launch_vel(m, d, VEL_PASSIVE, VEL_PASSIVE, s); }
@@ -497,7 +497,7 @@ static int run_stage(const MjhModel* m, const MjhData* d, int stage, hipStream_t
       { Scope sc(K_POS); TRY(launch_pos(m, d, POS_KINEMATICS, POS_FACTOR, s)); }
       { Scope sc(K_COLLISION); TRY(launch_collision(m, d, s)); }
       { Scope sc(K_CONSTRAINT); TRY(launch_constraint(m, d, s)); }
-      { Scope sc(K_OTHER); TRY(launch_publish(d, s)); }
+      { Scope sc(K_OTHER); TRY(launch_publish(m, d, s)); }
       return MJH_OK;
     case MJH_STAGE_RNE_POSTCONSTRAINT: {
       if (!d->cfrc_ext) return fail(MJH_E_ARG, "Data.cfrc_ext missing");
@@ -566,7 +566,7 @@ static int run_stage(const MjhModel* m, const MjhData* d, int stage, hipStream_t
         { Scope sc(K_OTHER); TRY(launch_sensor(m, d, 1, s)); }
         if (stage == MJH_STAGE_STEP) { Scope sc(K_INTEGRATE); TRY(launch_integrate(m, d, mode, s)); }
         Scope sc(K_OTHER);
-        TRY(launch_publish(d, s));
+        TRY(launch_publish(m, d, s));
         TRY(launch_factor_smooth(m, d, m->solver == SOL_NEWTON ? 1 : 0, s));  // CG and PGS write qacc_smooth themselves
         return MJH_OK;
       }
@@ -581,7 +581,7 @@ static int run_stage(const MjhModel* m, const MjhData* d, int stage, hipStream_t
       if (side) {
         HIPCHK(hipEventRecord(side->fork, s));
         HIPCHK(hipStreamWaitEvent(side->stream, side->fork, 0));
-        TRY(launch_publish(d, side->stream));
+        TRY(launch_publish(m, d, side->stream));
         TRY(launch_factor_smooth(m, d, 1, side->stream));
         HIPCHK(hipEventRecord(side->join, side->stream));
       }

@@ -18,7 +18,7 @@
 #include "solver.hpp"
 
 struct PgsBigLayout {
-  int q, qs, tmp, force, aref, R, Ad, mu, info, blk, xs, M, L, dinv, total;
+  int q, qs, tmp, force, aref, R, Ad, mu, info, tmask, blk, xs, M, L, dinv, total;
 };
 __host__ __device__ inline PgsBigLayout pgs_big_layout(int nv, int nC, int njmax, bool ell) {
   PgsBigLayout p;
@@ -31,9 +31,10 @@ __host__ __device__ inline PgsBigLayout pgs_big_layout(int nv, int nC, int njmax
   p.R = o; o += njmax;
   p.Ad = o; o += njmax;
   p.mu = o; o += ell ? njmax : 0;      // friction coefficient of a friction row of an elliptic contact
+  p.tmask = o; o += 2 * njmax;          // kinematic trees a row touches (bit t of a 64-bit mask; trees >= 64 set every bit: full range)
   p.info = o; o += njmax;               // row kind: 0 equality, 1 friction loss, 2 limit / contact, 8 + dim: first row of an elliptic contact, 7: its other rows
   p.blk = o; o += ell ? 6 * njmax : 0;  // row r of an elliptic contact starting at r0: (A + R)[r][r0 .. r0 + 5]
-  p.xs = o; o += 64 * nv;               // 64 right-hand sides of the batched sparse solves (lane = row), [dof][lane]
+  p.xs = o; o += (65 * nv > 2 * njmax ? 65 * nv : 2 * njmax);  // 64 right-hand sides of the batched sparse solves, [dof][65]; later two row vectors
   p.M = o; o += nC;
   p.L = o; o += nC;
   p.dinv = o; o += nv;
@@ -41,79 +42,91 @@ __host__ __device__ inline PgsBigLayout pgs_big_layout(int nv, int nC, int njmax
   return p;
 }
 
-// x = argmin 0.5 x'A x + x'b  s.t.  sum (x_i / mu_i)^2 <= r^2, n <= 5 (unused dimensions: A = identity, b = 0, mu = 1); oracle/mjref.c qcqp
-DEV void qcqp5(int n, const float (&A)[5][5], const float (&b)[5], const float (&mu)[5], float r, float (&x)[5]) {
-  float As[5][5], bs[5];
+// x = argmin 0.5 x'A x + x'b  s.t.  sum (x_i / mu_i)^2 <= r^2 in N = 2, 3 or 5 dimensions (condim 3 / 4 / 6); oracle/mjref.c qcqp.
+// A, b, mu are read from the leading N x N / N entries of 5-wide arrays.  Specialised on N: a contact of condim 3 costs a 2 x 2
+// factorisation per Newton step on the multiplier, not a padded 5 x 5 one (the padded version was 90 % of a sweep's time).
+template <int N>
+DEV void qcqpN(const float (&A)[5][5], const float (&b)[5], const float (&mu)[5], float r, float (&x)[5]) {
+  float As[N][N], bs[N];
 #pragma unroll
-  for (int i = 0; i < 5; ++i) {
-    bs[i] = i < n ? b[i] * mu[i] : 0.0f;
+  for (int i = 0; i < N; ++i) {
+    bs[i] = b[i] * mu[i];
 #pragma unroll
-    for (int j = 0; j < 5; ++j) As[i][j] = (i < n && j < n) ? A[i][j] * mu[i] * mu[j] : (i == j ? 1.0f : 0.0f);
+    for (int j = 0; j < N; ++j) As[i][j] = A[i][j] * mu[i] * mu[j];
   }
-  float la = 0.0f, y[5] = {0, 0, 0, 0, 0};
+  float la = 0.0f, y[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) y[i] = 0.0f;
   bool active = false;
   for (int it = 0; it < 20; ++it) {
-    float L[5][5];
+    float L[N][N];
 #pragma unroll
-    for (int j = 0; j < 5; ++j) {  // Cholesky of As + la I (lower)
+    for (int j = 0; j < N; ++j) {  // Cholesky of As + la I (lower)
       float s = As[j][j] + la;
 #pragma unroll
-      for (int k = 0; k < 5; ++k)
+      for (int k = 0; k < N; ++k)
         if (k < j) s -= L[j][k] * L[j][k];
       const float l = sqrtf(fmaxf(s, MJ_MINVAL));
       L[j][j] = l;
 #pragma unroll
-      for (int i = 0; i < 5; ++i)
+      for (int i = 0; i < N; ++i)
         if (i > j) {
           float t = As[i][j];
 #pragma unroll
-          for (int k = 0; k < 5; ++k)
+          for (int k = 0; k < N; ++k)
             if (k < j) t -= L[i][k] * L[j][k];
           L[i][j] = t / l;
         }
     }
-    auto solve = [&](const float (&rhs)[5], float (&out)[5]) __attribute__((always_inline)) {
+    auto solve = [&](const float (&rhs)[N], float (&out)[N]) __attribute__((always_inline)) {
 #pragma unroll
-      for (int i = 0; i < 5; ++i) {
+      for (int i = 0; i < N; ++i) {
         float t = rhs[i];
 #pragma unroll
-        for (int k = 0; k < 5; ++k)
+        for (int k = 0; k < N; ++k)
           if (k < i) t -= L[i][k] * out[k];
         out[i] = t / L[i][i];
       }
 #pragma unroll
-      for (int i = 4; i >= 0; --i) {
+      for (int i = N - 1; i >= 0; --i) {
         float t = out[i];
 #pragma unroll
-        for (int k = 0; k < 5; ++k)
+        for (int k = 0; k < N; ++k)
           if (k > i) t -= L[k][i] * out[k];
         out[i] = t / L[i][i];
       }
     };
-    float nb[5];
+    float nb[N];
 #pragma unroll
-    for (int i = 0; i < 5; ++i) nb[i] = -bs[i];
+    for (int i = 0; i < N; ++i) nb[i] = -bs[i];
     solve(nb, y);
     float val = -r * r;
 #pragma unroll
-    for (int i = 0; i < 5; ++i) val += y[i] * y[i];
+    for (int i = 0; i < N; ++i) val += y[i] * y[i];
     if (val < 1e-7f * r * r + 1e-20f) break;  // inside (or on) the ball, to float32 resolution
     active = true;
-    float t[5];
+    float t[N];
     solve(y, t);
     float deriv = 0.0f;
 #pragma unroll
-    for (int i = 0; i < 5; ++i) deriv -= 2.0f * y[i] * t[i];
+    for (int i = 0; i < N; ++i) deriv -= 2.0f * y[i] * t[i];
     const float delta = -val / deriv;
     if (!(delta > 1e-7f * (la + 1e-20f))) break;
     la += delta;
   }
   float s = 0.0f;
 #pragma unroll
-  for (int i = 0; i < 5; ++i) s += y[i] * y[i];
+  for (int i = 0; i < N; ++i) s += y[i] * y[i];
   const float sc = (active && s > r * r && s > 0.0f) ? r / sqrtf(s) : 1.0f;  // round-off: land on the boundary
 #pragma unroll
-  for (int i = 0; i < 5; ++i) x[i] = i < n ? y[i] * mu[i] * sc : 0.0f;
+  for (int i = 0; i < 5; ++i) x[i] = 0.0f;
+#pragma unroll
+  for (int i = 0; i < N; ++i) x[i] = y[i] * mu[i] * sc;
+}
+DEV void qcqp5(int n, const float (&A)[5][5], const float (&b)[5], const float (&mu)[5], float r, float (&x)[5]) {
+  if (n == 2) qcqpN<2>(A, b, mu, r, x);
+  else if (n == 3) qcqpN<3>(A, b, mu, r, x);
+  else qcqpN<5>(A, b, mu, r, x);
 }
 
 template <int G>
@@ -129,6 +142,9 @@ DEV void pgs_big_body(const MjhModel& m, const MjhData& d, float* smem, int w) {
   float *q = S + lay.q, *qs = S + lay.qs, *tmp = S + lay.tmp, *force = S + lay.force, *aref = S + lay.aref, *Rr = S + lay.R, *Ad = S + lay.Ad,
         *rmu = S + lay.mu, *blk = S + lay.blk, *xs = S + lay.xs, *Ml = S + lay.M, *Ll = S + lay.L, *dinv = S + lay.dinv;
   int* info = reinterpret_cast<int*>(S + lay.info);
+  unsigned* tmask = reinterpret_cast<unsigned*>(S + lay.tmask);
+  const int ntree = m.ntree;
+  const bool sparse_rows = ntree > 1 && ntree <= 64;  // rows touch one or two trees: the sweep visits those dof ranges only
   const int nefc = min(d.nefc[w], njmax), ne = d.ne[w], nf = d.nf[w], nl = d.nl[w];
   const size_t vo = (size_t)w * nv, eo = (size_t)w * njmax;
   const float* Jg = d.efc_J + (size_t)w * d.njmax_pad * nvp;
@@ -152,59 +168,101 @@ DEV void pgs_big_body(const MjhModel& m, const MjhData& d, float* smem, int w) {
     if (lig == 0) d.solver_niter[w] = 0;
     return;
   }
-  // ---- B = J M^-1, 64 rows per batch: lane = row, its vector in LDS as xs[dof * 64 + lane] (sequential sparse L'DL solve per lane) ----
+  // ---- B = J M^-1, 64 rows per batch.  Global traffic is always lane = dof (consecutive addresses of one row); the sparse L'DL solve
+  // runs lane = row on the LDS copy xs[dof * XS + row], XS = 65 (odd: both access directions are bank-conflict free).  (The first
+  // version read and wrote J / B with lane = row: 64 cache lines per load instruction, 1e9 L2 transactions per step -- 100 ms.)
+  constexpr int XS = G + 1;
   for (int r0 = 0; r0 < nefc; r0 += G) {
+    const int nb = min(G, nefc - r0);
+    for (int rr = 0; rr < G; ++rr)
+      for (int c = lig; c < nv; c += G) xs[c * XS + rr] = rr < nb ? Jg[(size_t)(r0 + rr) * nvp + c] : 0.0f;
+    gsync();
     const int r = r0 + lig;
     const bool has = r < nefc;
-    for (int c = 0; c < nv; ++c) xs[c * G + lig] = has ? Jg[(size_t)r * nvp + c] : 0.0f;
+    if (has) {  // trees this row touches (from the J copy, before the solve overwrites it)
+      unsigned m0 = 0u, m1 = 0u;
+      if (sparse_rows) {
+        for (int t = 0; t < ntree; ++t) {
+          const int a0 = m.tree_dofadr[t], n0 = m.tree_dofnum[t];
+          bool any = false;
+          for (int c = a0; c < a0 + n0; ++c) any = any || xs[c * XS + lig] != 0.0f;
+          if (any) {
+            if (t < 32) m0 |= 1u << t;
+            else m1 |= 1u << (t - 32);
+          }
+        }
+      }
+      tmask[2 * r] = m0;
+      tmask[2 * r + 1] = m1;
+    }
     for (int k = nv - 1; k >= 0; --k) {  // x <- L^-T x
       const int start = ms.rowadr[k], n = ms.rownnz[k];
-      const float xk = xs[k * G + lig];
-      for (int a = 0; a < n - 1; ++a) xs[ms.colind[start + a] * G + lig] -= Ll[start + a] * xk;
+      const float xk = xs[k * XS + lig];
+      for (int a = 0; a < n - 1; ++a) xs[ms.colind[start + a] * XS + lig] -= Ll[start + a] * xk;
     }
-    for (int k = 0; k < nv; ++k) xs[k * G + lig] *= dinv[k];
+    for (int k = 0; k < nv; ++k) xs[k * XS + lig] *= dinv[k];
     for (int k = 0; k < nv; ++k) {  // x <- L^-1 x (ancestors have smaller indices)
       const int start = ms.rowadr[k], n = ms.rownnz[k];
-      float s = xs[k * G + lig];
-      for (int a = 0; a < n - 1; ++a) s -= Ll[start + a] * xs[ms.colind[start + a] * G + lig];
-      xs[k * G + lig] = s;
+      float s = xs[k * XS + lig];
+      for (int a = 0; a < n - 1; ++a) s -= Ll[start + a] * xs[ms.colind[start + a] * XS + lig];
+      xs[k * XS + lig] = s;
     }
-    if (has) {
-      float sAR = 0.0f;
-      for (int c = 0; c < nv; ++c) {
-        const float bv = xs[c * G + lig];
-        Bg[(size_t)r * nvp + c] = bv;
-        sAR += Jg[(size_t)r * nvp + c] * bv;
+    gsync();
+    for (int rr = 0; rr < nb; ++rr) {  // store the B rows (lane = dof) and (A + R)_rr = J_r . B_r + R_r
+      float part = 0.0f;
+      for (int c = lig; c < nvp; c += G) {
+        const float bv = c < nv ? xs[c * XS + rr] : 0.0f;
+        Bg[(size_t)(r0 + rr) * nvp + c] = bv;
+        part += c < nv ? Jg[(size_t)(r0 + rr) * nvp + c] * bv : 0.0f;
       }
-      for (int c = nv; c < nvp; ++c) Bg[(size_t)r * nvp + c] = 0.0f;
-      const float D = d.efc_D[eo + r];
-      aref[r] = d.efc_aref[eo + r];
-      Rr[r] = 1.0f / D;
-      Ad[r] = sAR + 1.0f / D;
-      info[r] = r >= ne + nf ? 2 : (r >= ne ? 1 : 0);
-      if (ell) rmu[r] = 1.0f;
+      const float sAR = gsumg<G>(part);
+      if (lig == 0) {
+        const int rw = r0 + rr;
+        const float D = d.efc_D[eo + rw];
+        aref[rw] = d.efc_aref[eo + rw];
+        Rr[rw] = 1.0f / D;
+        Ad[rw] = sAR + 1.0f / D;
+        info[rw] = rw >= ne + nf ? 2 : (rw >= ne ? 1 : 0);
+        if (ell) rmu[rw] = 1.0f;
+      }
     }
+    gsync();
   }
   __threadfence_block();
   gsync();
+  // dot of two rows of J / B over the dofs of the trees row r touches (lane = dof: partial sums, to be reduced over the wavefront)
+  auto row_dots6 = [&](int r, int r0b, int dim, float (&part)[6]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int bq = 0; bq < 6; ++bq) part[bq] = 0.0f;
+    unsigned long long mk = sparse_rows ? ((unsigned long long)tmask[2 * r] | ((unsigned long long)tmask[2 * r + 1] << 32)) : 1ull;
+    while (mk) {
+      const int t = __builtin_ctzll(mk);
+      mk &= mk - 1;
+      const int a0 = sparse_rows ? m.tree_dofadr[t] : 0, n0 = sparse_rows ? m.tree_dofnum[t] : nv;
+      for (int c = a0 + lig; c < a0 + n0; c += G) {
+        const float j = Jg[(size_t)r * nvp + c];
+#pragma unroll
+        for (int bq = 0; bq < 6; ++bq)
+          if (bq < dim) part[bq] += j * Bg[(size_t)(r0b + bq) * nvp + c];
+      }
+    }
+  };
   // ---- elliptic contacts: row kinds, friction coefficients, the dim x dim blocks of A + R -----------------------------------------
   if (ell) {
-    for (int r = ne + nf + nl + lig; r < nefc; r += G) {
+    for (int r = ne + nf + nl; r < nefc; ++r) {  // (rows in turn, lanes over the row's dofs: coalesced)
       const int cid = d.ws_efc_con[eo + r], c = cid >> 4, dimid = cid & 15;
       const float* cr = d.ws_contact + ((size_t)w * d.concap + c) * CON_STRIDE;
       const int* cri = reinterpret_cast<const int*>(cr);
       if (cri[24] > 1) {
         const int r0 = r - dimid, dim = min(cri[29], nefc - r0);
-        info[r] = dimid == 0 ? 8 + dim : 7;
-        rmu[r] = dimid == 0 ? 1.0f : cr[dimid <= 2 ? 14 : (dimid == 3 ? 15 : 16)];
-        for (int bq = 0; bq < 6; ++bq) {
-          float s = 0.0f;
-          if (bq < dim) {
-            for (int cc = 0; cc < nv; ++cc) s += Jg[(size_t)r * nvp + cc] * Bg[(size_t)(r0 + bq) * nvp + cc];
-            if (bq == dimid) s += Rr[r];
-          }
-          blk[6 * r + bq] = s;
+        float part[6];
+        row_dots6(r, r0, dim, part);
+        gsumg_n<G, 6>(part);
+        if (lig == 0) {
+          info[r] = dimid == 0 ? 8 + dim : 7;
+          rmu[r] = dimid == 0 ? 1.0f : cr[CON_FRICTION_WORD(dimid - 1)];
         }
+        if (lig < 6) blk[6 * r + lig] = (lig < dim ? (lig == 0 ? part[0] : lig == 1 ? part[1] : lig == 2 ? part[2] : lig == 3 ? part[3] : lig == 4 ? part[4] : part[5]) : 0.0f) + (lig == dimid ? Rr[r] : 0.0f);
       }
     }
     gsync();
@@ -214,15 +272,25 @@ DEV void pgs_big_body(const MjhModel& m, const MjhData& d, float* smem, int w) {
   for (int i = lig; i < nv; i += G) tmp[i] = d.qacc_warmstart[vo + i];
   gsync();
   float cpart = 0.0f;
-  for (int r = lig; r < nefc; r += G) {
+  for (int r = 0; r < nefc; ++r) {  // Jaref at the warm-start point and b_r, rows in turn (lane = dof of the row's trees)
     float jw = 0.0f, jb = 0.0f;
-    for (int c = 0; c < nv; ++c) {
-      const float j = Jg[(size_t)r * nvp + c];
-      jw += j * tmp[c];
-      jb += j * qs[c];
+    unsigned long long mk = sparse_rows ? ((unsigned long long)tmask[2 * r] | ((unsigned long long)tmask[2 * r + 1] << 32)) : 1ull;
+    while (mk) {
+      const int t = __builtin_ctzll(mk);
+      mk &= mk - 1;
+      const int a0 = sparse_rows ? m.tree_dofadr[t] : 0, n0 = sparse_rows ? m.tree_dofnum[t] : nv;
+      for (int c = a0 + lig; c < a0 + n0; c += G) {
+        const float j = Jg[(size_t)r * nvp + c];
+        jw += j * tmp[c];
+        jb += j * qs[c];
+      }
     }
-    xs[r] = jw - aref[r];  // Jaref at the warm-start point (xs is free now: reused as a row vector)
-    xs[njmax + r] = jb - aref[r];  // b_r
+    float two[2] = {jw, jb};
+    gsumg_n<G, 2>(two);
+    if (lig == 0) {
+      xs[r] = two[0] - aref[r];          // (xs is free now: reused as two row vectors)
+      xs[njmax + r] = two[1] - aref[r];  // b_r
+    }
   }
   gsync();
   for (int r = lig; r < nefc; r += G) {
@@ -278,10 +346,34 @@ DEV void pgs_big_body(const MjhModel& m, const MjhData& d, float* smem, int w) {
   const int maxiter = m.iterations;
   int niter = 0;
   // J_r . q over the lanes' dofs (partial; reduce with gsumg / gsumg_n)
+  // (M^-1 is block diagonal over kinematic trees: row r of J and of B are zero outside the trees the row touches)
   auto jq_part = [&](int r) __attribute__((always_inline)) {
     float s = 0.0f;
-    for (int c = lig; c < nv; c += G) s += Jg[(size_t)r * nvp + c] * q[c];
+    if (sparse_rows) {
+      unsigned long long mk = (unsigned long long)tmask[2 * r] | ((unsigned long long)tmask[2 * r + 1] << 32);
+      while (mk) {
+        const int t = __builtin_ctzll(mk);
+        mk &= mk - 1;
+        const int a0 = m.tree_dofadr[t], n0 = m.tree_dofnum[t];
+        for (int c = a0 + lig; c < a0 + n0; c += G) s += Jg[(size_t)r * nvp + c] * q[c];
+      }
+    } else {
+      for (int c = lig; c < nv; c += G) s += Jg[(size_t)r * nvp + c] * q[c];
+    }
     return s;
+  };
+  auto q_add = [&](int r, float delta) __attribute__((always_inline)) {
+    if (sparse_rows) {
+      unsigned long long mk = (unsigned long long)tmask[2 * r] | ((unsigned long long)tmask[2 * r + 1] << 32);
+      while (mk) {
+        const int t = __builtin_ctzll(mk);
+        mk &= mk - 1;
+        const int a0 = m.tree_dofadr[t], n0 = m.tree_dofnum[t];
+        for (int c = a0 + lig; c < a0 + n0; c += G) q[c] += delta * Bg[(size_t)r * nvp + c];
+      }
+    } else {
+      for (int c = lig; c < nv; c += G) q[c] += delta * Bg[(size_t)r * nvp + c];
+    }
   };
   while (niter < maxiter) {
     float improvement = 0.0f;
@@ -303,8 +395,7 @@ DEV void pgs_big_body(const MjhModel& m, const MjhData& d, float* smem, int w) {
           change = 0.0f;
         }
         improvement -= change;
-        if (delta != 0.0f)
-          for (int c = lig; c < nv; c += G) q[c] += delta * Bg[(size_t)i * nvp + c];
+        if (delta != 0.0f) q_add(i, delta);
         if (lig == 0) force[i] = fold + delta;
         gsync();
         continue;
@@ -390,11 +481,8 @@ DEV void pgs_big_body(const MjhModel& m, const MjhData& d, float* smem, int w) {
       const bool bad = change > 1e-10f;
       if (!bad) {
         improvement -= change;
-        for (int c = lig; c < nv; c += G) {
-          float s = 0.0f;
-          for (int a = 0; a < dim; ++a) s += dl[a] * Bg[(size_t)(i + a) * nvp + c];
-          q[c] += s;
-        }
+        for (int a = 0; a < dim; ++a)
+          if (dl[a] != 0.0f) q_add(i + a, dl[a]);  // (the rows of a contact touch the same trees: disjoint lanes per dof, no race)
         if (lig < dim) force[i + lig] = fnew[0] * (lig == 0) + fnew[1] * (lig == 1) + fnew[2] * (lig == 2) + fnew[3] * (lig == 3) + fnew[4] * (lig == 4) + fnew[5] * (lig == 5);
       }
       gsync();

@@ -20,7 +20,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((!NEWT
   else if (!NEWTON) {
     const int wf = blockDim.x / 32, bi = (int)blockIdx.x - nsolve;
     if (bi < nfac) factor_smooth_body<32>(m, d, 0, smem, Blk{bi * wf, wf, (int)blockDim.x});
-    else publish_body<32>(d, 1, reinterpret_cast<int*>(smem), Blk{(bi - nfac) * wf, wf, (int)blockDim.x});
+    else publish_body<32>(d, 1, reinterpret_cast<int*>(smem), Blk{(bi - nfac) * wf, wf, (int)blockDim.x}, m.nexplicit ? m.pair_solreffriction : nullptr);
   }
 }
 // SG = lanes per world: 32 (two worlds per wavefront) for nv <= 32, 64 for 32 < nv <= 64.  with_factor appends the

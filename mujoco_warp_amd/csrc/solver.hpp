@@ -821,7 +821,7 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
           const float mu = cr[14] * impr2;
           rkind[k] = dimid == 0 ? 4 : 5;
           rmu[k] = mu;
-          rs[k] = dimid == 0 ? mu : cr[dimid <= 2 ? 14 : (dimid == 3 ? 15 : 16)];
+          rs[k] = dimid == 0 ? mu : cr[CON_FRICTION_WORD(dimid - 1)];
           rdm[k] = safe_div(d.efc_D[eo + R(r0)], mu * mu * (1.0f + mu * mu));
           rcon[k] = r0 | (dim << 8);
         }

@@ -129,7 +129,7 @@ DEV void solve_big_body(const MjhModel& m, const MjhData& d, float* smem, const 
           const float mu = cr[14] * bf(m.opt_impratio_invsqrt, m.opt_impratio_invsqrt_nb, w, 1)[0];
           kind[r] = dimid == 0 ? 4 : 5;
           rmu[r] = mu;
-          rs[r] = dimid == 0 ? mu : cr[dimid <= 2 ? 14 : (dimid == 3 ? 15 : 16)];
+          rs[r] = dimid == 0 ? mu : cr[CON_FRICTION_WORD(dimid - 1)];
           rdm[r] = safe_div(d.efc_D[eo + r0], mu * mu * (1.0f + mu * mu));
           rcon[r] = r0 | (dim << 16);
         }

@@ -192,7 +192,7 @@ __global__ void __launch_bounds__(64) k_rne_postconstraint(MjhModel m, MjhData d
           const int a = adr0 + 2 * i;
           const float d1 = a < d.njmax ? efc_force[a] : 0.0f, d2 = a + 1 < d.njmax ? efc_force[a + 1] : 0.0f;
           f[0] += d1 + d2;
-          f[i + 1] = (d1 - d2) * rec[i < 2 ? 14 : (i == 2 ? 15 : 16)];
+          f[i + 1] = (d1 - d2) * rec[CON_FRICTION_WORD(i)];
         }
     } else {
       for (int i = 0; i < condim; ++i)

@@ -193,11 +193,6 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
   nexplicit = int(getattr(mjm, "npair", 0))
   if nexplicit:
     condims |= set(int(c) for c in np.asarray(mjm.pair_dim))
-    fr = np.asarray(mjm.pair_friction, dtype=np.float64).reshape(-1, 5)
-    if (fr[:, 0] != fr[:, 1]).any() or (fr[:, 3] != fr[:, 4]).any():
-      raise NotImplementedError("explicit contact pairs with anisotropic friction (tangent1 != tangent2 or roll1 != roll2)")
-    if np.asarray(mjm.pair_solreffriction).any():
-      raise NotImplementedError("explicit contact pairs with solreffriction (only elliptic friction rows would use it)")
   if not condims <= {1, 3, 4, 6}:
     raise NotImplementedError(f"unsupported condim values {condims}")
 

@@ -409,6 +409,53 @@ def test_explicit_contact_pairs():
     assert relerr(d.qvel.numpy()[0], s.qvel) <= 2e-3
 
 
+ANISO_PAIR_XML = """
+<mujoco>
+  <option timestep="0.003" cone="{cone}" impratio="{impratio}"/>
+  <worldbody>
+    <geom name="floor" type="plane" size="0 0 .05"/>
+    <body name="sled" pos="0 0 .0495"><freejoint/><geom name="sled" type="box" size=".15 .1 .05"/></body>
+    <body name="puck" pos=".6 0 .029"><freejoint/><geom name="puck" type="cylinder" size=".08 .03"/></body>
+    <body name="ball" pos="-.6 0 .079"><freejoint/><geom name="ball" type="sphere" size=".08"/></body>
+  </worldbody>
+  <contact>
+    <pair geom1="floor" geom2="sled" condim="3" friction="0.9 0.2 0.01 0.001 0.001" solreffriction="0.05 1.2"/>
+    <pair geom1="floor" geom2="puck" condim="4" friction="0.3 0.8 0.03 0.001 0.001"/>
+    <pair geom1="floor" geom2="ball" condim="6" friction="0.6 0.6 0.02 0.004 0.0008" solreffriction="0.03 1"/>
+  </contact>
+  <keyframe><key qvel="1.2 0.9 0 0 0 0.4   0.5 -0.7 0 0 0 3   0.8 0.6 0 3 -2 1"/></keyframe>
+</mujoco>
+"""
+
+
+@pytest.mark.parametrize("cone,impratio", [("pyramidal", 1), ("elliptic", 1), ("elliptic", 5)])
+def test_anisotropic_pair_friction_and_solreffriction(cone, impratio):
+  """Explicit pairs with tangent 1 != tangent 2 and roll 1 != roll 2 friction, and `solreffriction` on the friction rows of elliptic
+  contacts (constraint.py:4277-4294; round 3 -- put_model used to reject both): rows, published contact parameters and 40 steps
+  against the oracle.  A sled with mu (0.9, 0.2) sliding diagonally turns towards its low-friction axis."""
+  mjm = mjw.mjcf.from_xml_string(ANISO_PAIR_XML.format(cone=cone, impratio=impratio))
+  s, m, d = _pair(mjm, nworld=2, nconmax=16, njmax=64, warm_steps=0, noise=False)
+  mjw.forward(m, d)
+  s.forward()
+  assert s.ncon >= 6
+  _check_contacts_and_rows(s, d, mjm, dist_atol=5e-7)
+  _check_solution(s, d)
+  adr, n = int(d.ws_conadr.numpy()[1]), s.ncon
+  np.testing.assert_allclose(d.contact.friction.numpy()[adr : adr + n], s.con_friction[:n], atol=1e-7)
+  np.testing.assert_allclose(d.contact.solreffriction.numpy()[adr : adr + n], s.con_solreffriction[:n], atol=1e-7)
+  assert {tuple(np.round(f, 4)) for f in s.con_friction[:n]} >= {(0.9, 0.2, 0.01, 0.001, 0.001), (0.3, 0.8, 0.03, 0.001, 0.001)}
+  for _ in range(40):
+    _sync(s, d)
+    mjw.step(m, d)
+    s.step()
+    assert relerr(d.qpos.numpy()[0], s.qpos) <= 1e-5
+    assert relerr(d.qvel.numpy()[0], s.qvel) <= 3e-3
+  v = s.qvel[:2]
+  # the plane's contact frame has tangent 1 = y, tangent 2 = -x (math.make_frame of the normal z): y (mu 0.9) is braked harder than x (mu 0.2),
+  # the sliding direction turns from 0.75 = 0.9 / 1.2 towards the x axis (measured 0.21 pyramidal, 0.19 elliptic)
+  assert abs(v[1]) / max(abs(v[0]), 1e-9) < 0.4
+
+
 def test_sphere_cylinder_rim_regime():
   """10 steps in, the small sphere still rolls over the cylinder's rim (the 40-step state above only has cap and side)."""
   mjm = mjw.mjcf.from_xml_string(conftest.SPHERE_CYLINDER_XML)
