@@ -280,6 +280,7 @@ typedef struct MjhData {
   int* ntree_awake; int* nbody_awake; int* nv_awake; /* [nworld] */
   int* tree_island;    /* [nworld, ntree] constraint island of each tree (numbered by smallest tree), -1: no constraint row (island.py:206) */
   int* nisland;        /* [nworld] */
+  float* ws_iacc;      /* [nworld, nv] qacc' of the fully implicit integrator (csrc/implicit.hpp), consumed by the integrator launch; empty unless opt.integrator == IMPLICIT */
   float* ws_pgsB;      /* [nworld, njmax_pad, nv_pad] rows of J M^-1 for the generic PGS kernel (csrc/pgs_big.hpp); empty unless the model is solved by it
                           (solver PGS with more than 64 dofs or elliptic cones) */
   float* ws_sleep_J;   /* [nworld, njmax_pad, nv_pad] efc.J with the columns of sleeping dofs zeroed: what the solver reads (see csrc/sleep.hpp) */
@@ -354,7 +355,7 @@ int mjh_timed_steps(const MjhModel* m, const MjhData* d, int nstep, int step0, f
 int mjh_release_thread_resources(void);
 
 const char* mjh_last_error(void);
-#define MJH_ABI_VERSION 33
+#define MJH_ABI_VERSION 34
 int mjh_abi_version(void); /* returns MJH_ABI_VERSION of the library that was loaded */
 
 #ifdef __cplusplus

@@ -22,7 +22,7 @@ __host__ __device__ inline IntLayout int_layout(int nv, int nC) {
   return p;
 }
 
-// mode: 0 = Euler (forward.py:387), 1 = implicitfast (forward.py:578)
+// mode: 0 = Euler (forward.py:387), 1 = implicitfast (forward.py:578), 2 = fully implicit (the solve is csrc/implicit.hpp; here: _advance)
 template <int G>
 DEV void integrate_body(const MjhModel& m, const MjhData& d, int mode, float* smem, const Blk& b) {
   if ((int)threadIdx.x >= b.nthreads) return;
@@ -41,10 +41,11 @@ DEV void integrate_body(const MjhModel& m, const MjhData& d, int mode, float* sm
   const float* damp = bf(m.dof_damping, m.dof_damping_nb, w, nv);
   PhaseClock pc(6, lig);
 
-  // does the velocity update need an implicit solve?
+  // does the velocity update need an implicit solve?  (mode 2: the fully implicit integrator solved its system in k_implicit_solve)
   bool implicit = false;
   if (mode == 1) implicit = true;
-  else if (!(dsbl & (DSBL_EULERDAMP | DSBL_DAMPER))) {
+  else if (mode == 2) implicit = false;
+  else if (mode == 0 && !(dsbl & (DSBL_EULERDAMP | DSBL_DAMPER))) {
     float mx = 0.0f;
     for (int i = lig; i < nv; i += G) mx = fmaxf(mx, fabsf(damp[i]));
     implicit = gmax<G>(mx) > 0.0f;
@@ -105,7 +106,7 @@ DEV void integrate_body(const MjhModel& m, const MjhData& d, int mode, float* sm
     solve_ld<G>(m, ms, L, dinv, x, nv, lig);
     pc.mark(3);
   } else {
-    gcopy<G>(x, d.qacc + vo, nv, lig);
+    gcopy<G>(x, (mode == 2 ? d.ws_iacc : d.qacc) + vo, nv, lig);
     gsync();
   }
 

@@ -12,6 +12,7 @@
 #include "constraint.hpp"
 #include "dev_common.hpp"
 #include "integrate.hpp"
+#include "implicit.hpp"
 #include "sensor.hpp"
 #include "sleep.hpp"
 #include "smooth.hpp"
@@ -22,6 +23,12 @@ int mjh_fail(int code, const char* fmt, const char* a) {
   snprintf(g_err, sizeof(g_err), fmt, a);
   return code;
 }
+
+#define TRY(x)               \
+  do {                       \
+    int rc_ = (x);           \
+    if (rc_ != MJH_OK) return rc_; \
+  } while (0)
 
 // pick threads per block in {256,128,64} maximising resident worlds per CU for the given LDS needs
 int pick_block(size_t shared_bytes, size_t per_world_bytes, int G, size_t* lds_out, bool prefer_small_arg) {
@@ -132,7 +139,19 @@ static int launch_sensor(const MjhModel* m, const MjhData* d, int stage, hipStre
   return MJH_OK;
 }
 static int launch_solve(const MjhModel* m, const MjhData* d, hipStream_t s);  // = the solver workgroups of k_solve_plus
+// the linear system of the fully implicit integrator (csrc/implicit.hpp): Data.ws_iacc = (M - h dF/dv)^-1 M qacc
+static int launch_implicit(const MjhModel* m, const MjhData* d, hipStream_t s) {
+  const ImpLayout lay = imp_layout(m->nv, m->nbody, 32);
+  int wpb = 2;
+  if (sizeof(float) * lay.total * 2 > (size_t)kLdsPerCU) wpb = 1;
+  const size_t lds = sizeof(float) * lay.total * wpb;
+  if (lds > (size_t)kLdsPerCU) return fail(MJH_E_UNSUPPORTED, "k_implicit_solve: nv / nbody do not fit in LDS");
+  HIPCHK(set_lds(k_implicit_solve<32>, lds));
+  hipLaunchKernelGGL(k_implicit_solve<32>, dim3((d->nworld + wpb - 1) / wpb), dim3(32 * wpb), lds, s, *m, *d);
+  return MJH_OK;
+}
 static int launch_integrate(const MjhModel* m, const MjhData* d, int mode, hipStream_t s) {
+  if (mode == 2) TRY(launch_implicit(m, d, s));
   const IntLayout lay = int_layout(m->nv, m->nC);
   size_t lds;
   const int threads = pick_block(sizeof(int) * mstruct_ints(m->nv, m->nC), sizeof(float) * lay.total, G, &lds);
@@ -307,6 +326,7 @@ static int launch_integrate_plus(const MjhModel* m, const MjhData* d, int mode, 
   // Newton: publication and factor workgroups ride here; CG: they already rode with the solver launch
   const int nint = integrate ? nb : 0, npub = with_factor ? nb : 0, nfac = with_factor ? nb : 0;
   if (nint + npub + nfac == 0) return MJH_OK;
+  if (integrate && mode == 2) TRY(launch_implicit(m, d, s));
   debug_occupancy("k_integrate_plus", k_integrate_plus<G>, nint + npub + nfac, 256, lds);
   hipLaunchKernelGGL(k_integrate_plus<G>, dim3(nint + npub + nfac), dim3(256), lds, s, *m, *d, mode, nint, npub);
   return MJH_OK;
@@ -335,18 +355,14 @@ static int launch_pos_plus(const MjhModel* m, const MjhData* d, int first, int l
   return MJH_OK;
 }
 
-#define TRY(x)               \
-  do {                       \
-    int rc_ = (x);           \
-    if (rc_ != MJH_OK) return rc_; \
-  } while (0)
 
 static int check(const MjhModel* m, const MjhData* d) {
   if (!m || !d) return fail(MJH_E_ARG, "null model/data");
   if (d->nworld <= 0) return fail(MJH_E_ARG, "nworld must be positive");
   if (d->concap <= 0 || !d->ws_contact) return fail(MJH_E_ARG, "Data.ws_contact / concap missing (allocate Data with make_data/put_data)");
-  if (m->integrator != INT_EULER && m->integrator != INT_IMPLICITFAST && m->integrator != INT_RK4)
-    return fail(MJH_E_UNSUPPORTED, "integrator must be Euler, RK4 or implicitfast");
+  if (m->integrator != INT_EULER && m->integrator != INT_IMPLICITFAST && m->integrator != INT_RK4 && m->integrator != INT_IMPLICIT)
+    return fail(MJH_E_UNSUPPORTED, "integrator must be Euler, RK4, implicit or implicitfast");
+  if (m->integrator == INT_IMPLICIT && (m->nv > 64 || !d->ws_iacc)) return fail(MJH_E_UNSUPPORTED, "fully implicit integrator: at most 64 dofs, Data allocated for this model");
   if (m->integrator == INT_RK4 && !d->ws_rk) return fail(MJH_E_ARG, "Data.ws_rk missing (allocate Data with make_data/put_data)");
   return MJH_OK;
 }
@@ -426,7 +442,7 @@ static int run_sleep_step(const MjhModel* m, const MjhData* d, bool step, hipStr
   if (m->solver != SOL_NEWTON) return fail(MJH_E_UNSUPPORTED, "sleeping requires the Newton solver (reference io.py:359)");
   if (step && m->integrator == INT_RK4) return fail(MJH_E_UNSUPPORTED, "sleeping with the RK4 integrator");
   const dim3 gw((d->nworld + 63) / 64), bw(64);
-  const int mode = m->integrator == INT_IMPLICITFAST ? 1 : 0;
+  const int mode = m->integrator == INT_IMPLICITFAST ? 1 : (m->integrator == INT_IMPLICIT ? 2 : 0);
   { Scope sc(K_OTHER); hipLaunchKernelGGL(k_sleep, gw, bw, 0, s, *m, *d, (int)SLP_WAKE); }
   { Scope sc(K_POS); TRY(launch_pos(m, d, POS_KINEMATICS, POS_CRB, s)); }
   { Scope sc(K_COLLISION); TRY(launch_collision(m, d, s)); }
@@ -492,7 +508,7 @@ static int run_stage(const MjhModel* m, const MjhData* d, int stage, hipStream_t
       { Scope sc(K_OTHER); return launch_factor_smooth(m, d, 1, s); }
     case MJH_STAGE_SOLVE: { Scope sc(K_SOLVE); return launch_solve(m, d, s); }
     case MJH_STAGE_EULER: { Scope sc(K_INTEGRATE); return launch_integrate(m, d, 0, s); }
-    case MJH_STAGE_IMPLICIT: { Scope sc(K_INTEGRATE); return launch_integrate(m, d, 1, s); }
+    case MJH_STAGE_IMPLICIT: { Scope sc(K_INTEGRATE); return launch_integrate(m, d, m->integrator == INT_IMPLICIT ? 2 : 1, s); }
     case MJH_STAGE_FWD_POSITION:
       { Scope sc(K_POS); TRY(launch_pos(m, d, POS_KINEMATICS, POS_FACTOR, s)); }
       { Scope sc(K_COLLISION); TRY(launch_collision(m, d, s)); }
@@ -552,7 +568,7 @@ static int run_stage(const MjhModel* m, const MjhData* d, int stage, hipStream_t
         TRY(run_stage(m, d, MJH_STAGE_FORWARD, s));
         return run_stage(m, d, MJH_STAGE_RUNGEKUTTA4, s);
       }
-      const int mode = m->integrator == INT_IMPLICITFAST ? 1 : 0;
+      const int mode = m->integrator == INT_IMPLICITFAST ? 1 : (m->integrator == INT_IMPLICIT ? 2 : 0);
       static const bool plain = getenv("MJH_PLAIN") != nullptr;  // developer knob: one plain kernel per stage, serial
       if ((g_instr && g_instr->on && g_instr->plain) || plain) {
         // profiling pass: one plain kernel per stage, so that the event pairs time one kernel at a time

@@ -124,8 +124,10 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
   for name in ("ntendon", "nflex", "nplugin"):
     if int(getattr(mjm, name, 0)) > 0:
       raise NotImplementedError(f"{name} > 0 is outside the hot-path scope of this engine")
-  if int(opt.integrator) not in (types.IntegratorType.EULER, types.IntegratorType.RK4, types.IntegratorType.IMPLICITFAST):
-    raise NotImplementedError(f"Integrator {int(opt.integrator)} is unsupported (Euler, RK4 and implicitfast only).")
+  if int(opt.integrator) not in (types.IntegratorType.EULER, types.IntegratorType.RK4, types.IntegratorType.IMPLICITFAST, types.IntegratorType.IMPLICIT):
+    raise NotImplementedError(f"Integrator {int(opt.integrator)} is unsupported.")
+  if int(opt.integrator) == types.IntegratorType.IMPLICIT and mjm.nv > 64:
+    raise NotImplementedError("The fully implicit integrator is implemented for models of at most 64 dofs (csrc/implicit.hpp); use implicitfast.")
   # (the reference rejects PGS, io.py solver check / types.py:502; this engine implements MuJoCo C's dual PGS, csrc/pgs.hpp)
   if int(opt.solver) not in (types.SolverType.PGS, types.SolverType.CG, types.SolverType.NEWTON):
     raise NotImplementedError(f"Unknown solver {int(opt.solver)}.")
@@ -550,7 +552,7 @@ def _data_shapes(m, nworld, nconmax, njmax, naconmax):
     ws_isl_dofadr=(W, (m.ntree + 1) if m.tree_solve else 0), ws_isl_dofmap=(W, nv if m.tree_solve else 0), ws_isl_dofinv=(W, nv if m.tree_solve else 0), ws_nisland=(W,), ws_isl_flags=(W,), ws_isl_list=(3, W if m.tree_solve else 0), ws_isl_count=(4,),
     ws_separable=(W,), ws_order=(W,), ws_ccd=(W if m._convex_pairs else 0, _ccd_words(max(int(m.opt.ccd_iterations), int(m.epa_iterations)), m.nhfield), 32),
     tree_asleep=(W, m.ntree), tree_awake=(W, m.ntree), body_awake=(W, nb), body_awake_ind=(W, nb), dof_awake_ind=(W, nv), ntree_awake=(W,), nbody_awake=(W,),
-    nv_awake=(W,), tree_island=(W, m.ntree), nisland=(W,), ws_pgsB=(W if _needs_pgs_big(m) else 0, njmax_pad, nv_pad), ws_sleep_J=(W if m.sleep_enabled else 0, njmax_pad, nv_pad), ws_sleep_warm=(W if m.sleep_enabled else 0, nv),
+    nv_awake=(W,), tree_island=(W, m.ntree), nisland=(W,), ws_iacc=(W if int(m.opt.integrator) == int(types.IntegratorType.IMPLICIT) else 0, nv), ws_pgsB=(W if _needs_pgs_big(m) else 0, njmax_pad, nv_pad), ws_sleep_J=(W if m.sleep_enabled else 0, njmax_pad, nv_pad), ws_sleep_warm=(W if m.sleep_enabled else 0, nv),
     ws_sleep_flag=(W,),
     sensordata=(W, m.nsensordata), energy=(W, 2), subtree_linvel=(W, nb, 3), subtree_angmom=(W, nb, 3), cfrc_ext=(W, nb, 6), eq_active=(W, m.neq), ws_rk=(W, nq + 3 * nv + 2 * na), ws_contact=(W, contact_cap(nconmax), 32),
   )
@@ -596,6 +598,7 @@ def _alloc_data(m: types.Model, nworld, nconmax, njmax, naconmax, mjd=None, nvma
   d.nvmax = int(nvmax)
   d.nsleepworld = shapes["ws_sleep_J"][0]
   d.npgsworld = shapes["ws_pgsB"][0]
+  d.nimpworld = shapes["ws_iacc"][0]
   _reset_sleep(m, d, None)
   if m.neq:
     d.eq_active.assign(np.tile(m.eq_active0, (nworld, 1)))

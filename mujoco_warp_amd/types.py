@@ -623,11 +623,13 @@ class Data(_Dirty):
   nv_awake: DeviceArray = _arr(('nworld',), "int32")
   tree_island: DeviceArray = _arr(('nworld', 'ntree'), "int32")
   nisland: DeviceArray = _arr(('nworld',), "int32")
+  ws_iacc: DeviceArray = _arr(('nimpworld', 'nv'), "float32")
   ws_pgsB: DeviceArray = _arr(('npgsworld', 'njmax_pad', 'nv_pad'), "float32")
   ws_sleep_J: DeviceArray = _arr(('nsleepworld', 'njmax_pad', 'nv_pad'), "float32")
   ws_sleep_warm: DeviceArray = _arr(('nsleepworld', 'nv'), "float32")
   ws_sleep_flag: DeviceArray = _arr(('nworld',), "int32")
   sleep_pass: int = 0
+  nimpworld: int = 0  # leading size of ws_iacc (nworld for the fully implicit integrator, else 0)
   npgsworld: int = 0  # leading size of ws_pgsB (nworld for models solved by the generic PGS kernel, else 0)
   nvmax: int = 0  # capacity for awake dofs per world (reference types.py Data.nvmax): exceeding it raises OverflowType.NVMAX
   nsleepworld: int = 0

@@ -3562,6 +3562,118 @@ void ref_implicitfast(const RefModel* m, RefData* d) {
   free(Mh);
 }
 
+/* d(qfrc_bias)/d(qvel), dense [nv x nv] (out[i * nv + k]): derivative.py:321-586 deriv_rne_vel (MuJoCo C mjd_rne_vel), column by column.
+ * For dof k: Dcvel[b] = cdof[k] on every body at or below dof k's body (added where com_vel adds it); Dcdof_dot[j] = Dcvel_before(j) x cdof[j]
+ * with com_vel's group rule (the three rotational dofs of a ball / free joint see the velocity before any of them; a free joint's first
+ * three dofs have cdof_dot = 0); Dcacc accumulates root -> leaf, Dcfrc_body = I Dcacc + Dcvel x* (I cvel) + cvel x* (I Dcvel), summed leaf ->
+ * root over subtrees, projected on cdof[i]. */
+void ref_deriv_rne_vel(const RefModel* m, const RefData* d, double* out) {
+  int nv = m->nv, nb = m->nbody;
+  double* buf = (double*)calloc((size_t)18 * nb, sizeof(double));
+  double *Dcvel = buf, *Dcacc = Dcvel + 6 * nb, *Dcfrc = Dcacc + 6 * nb;
+  for (int k = 0; k < nv; k++) {
+    memset(buf, 0, sizeof(double) * 18 * nb);
+    for (int b = 1; b < nb; b++) {
+      double cv[6], ca[6];
+      memcpy(cv, Dcvel + 6 * m->body_parentid[b], sizeof(cv));
+      memcpy(ca, Dcacc + 6 * m->body_parentid[b], sizeof(ca));
+      int dof = m->body_dofadr[b];
+      for (int j = m->body_jntadr[b]; j < m->body_jntadr[b] + m->body_jntnum[b]; j++) {
+        int t = m->jnt_type[j];
+        int ngrp = t == JNT_FREE ? 6 : (t == JNT_BALL ? 3 : 1);
+        /* (free joint: dofs 0..2 first -- their cdof_dot is zero --, then 3..5 as a group; ball: one group of three) */
+        int first = 0;
+        if (t == JNT_FREE) {
+          for (int q = 0; q < 3; q++) {
+            if (dof + q == k) { for (int c = 0; c < 6; c++) cv[c] += d->cdof[6 * k + c]; }
+            /* cdof_dot of these dofs is identically zero: nothing enters cacc */
+          }
+          first = 3;
+        }
+        double dd[6];
+        for (int q = first; q < ngrp; q++) { /* Dcdof_dot of the group from the velocity derivative BEFORE the group */
+          motion_cross(dd, cv, d->cdof + 6 * (dof + q));
+          for (int c = 0; c < 6; c++) ca[c] += dd[c] * d->qvel[dof + q];
+          if (dof + q == k)
+            for (int c = 0; c < 6; c++) ca[c] += d->cdof_dot[6 * k + c];
+        }
+        for (int q = first; q < ngrp; q++)
+          if (dof + q == k)
+            for (int c = 0; c < 6; c++) cv[c] += d->cdof[6 * k + c];
+        dof += ngrp;
+      }
+      memcpy(Dcvel + 6 * b, cv, sizeof(cv));
+      memcpy(Dcacc + 6 * b, ca, sizeof(ca));
+      double t1[6], icv[6], idcv[6], x1[6], x2[6];
+      inert_vec(t1, d->cinert + 10 * b, ca);
+      inert_vec(icv, d->cinert + 10 * b, d->cvel + 6 * b);
+      inert_vec(idcv, d->cinert + 10 * b, cv);
+      motion_cross_force(x1, cv, icv);
+      motion_cross_force(x2, d->cvel + 6 * b, idcv);
+      for (int c = 0; c < 6; c++) Dcfrc[6 * b + c] = t1[c] + x1[c] + x2[c];
+    }
+    for (int b = nb - 1; b > 0; b--)
+      for (int c = 0; c < 6; c++) Dcfrc[6 * m->body_parentid[b] + c] += Dcfrc[6 * b + c];
+    for (int i = 0; i < nv; i++) {
+      double s2 = 0.0;
+      for (int c = 0; c < 6; c++) s2 += d->cdof[6 * i + c] * Dcfrc[6 * m->dof_bodyid[i] + c];
+      out[(size_t)i * nv + k] = s2;
+    }
+  }
+  free(buf);
+}
+
+/* fully implicit in velocity (forward.py:578-600; MuJoCo C mj_implicit): (M - h dF/dv) qacc' = M qacc with F = qfrc_smooth =
+ * passive - bias + actuation, i.e. the matrix of implicitfast PLUS h d(qfrc_bias)/dv (non-symmetric): dense LU without pivoting
+ * (the reference factors the same matrix in its sparse "D structure", smooth.py:3481; the matrix is M plus an O(h) perturbation). */
+void ref_implicit(const RefModel* m, RefData* d) {
+  int nv = m->nv;
+  double* A = (double*)calloc((size_t)2 * nv * nv + 2 * nv, sizeof(double));
+  double *Dr = A + (size_t)nv * nv, *qacc = Dr + (size_t)nv * nv, *rhs = qacc + nv;
+  for (int i = 0; i < nv; i++)
+    for (int a = 0; a < m->M_rownnz[i]; a++) {
+      int j = m->M_colind[m->M_rowadr[i] + a];
+      A[(size_t)i * nv + j] = A[(size_t)j * nv + i] = d->M[m->M_rowadr[i] + a];
+    }
+  if (!(m->disableflags & DSBL_DAMPER))
+    for (int i = 0; i < nv; i++) A[(size_t)i * nv + i] += m->timestep * m->dof_damping[i];
+  if (!(m->disableflags & DSBL_ACTUATION))
+    for (int i = 0; i < m->nu; i++) {
+      double bias_vel = (m->actuator_biastype[i] == 1) ? m->actuator_biasprm[10 * i + 2] : 0.0;
+      double gain_vel = (m->actuator_gaintype[i] == 1) ? m->actuator_gainprm[10 * i + 2] : 0.0;
+      double ctrl = d->ctrl[i];
+      if (m->actuator_dyntype[i] != 0) ctrl = d->act[m->actuator_actadr[i]];
+      double dv = bias_vel + gain_vel * ctrl;
+      if (dv == 0.0) continue;
+      if (m->actuator_forcelimited[i]) {
+        double f = d->actuator_force[i];
+        if (f <= m->actuator_forcerange[2 * i] || f >= m->actuator_forcerange[2 * i + 1]) continue;
+      }
+      int dof = m->jnt_dofadr[m->actuator_trnid[2 * i]];
+      double g = m->actuator_gear[6 * i];
+      A[(size_t)dof * nv + dof] -= m->timestep * g * g * dv;
+    }
+  ref_deriv_rne_vel(m, d, Dr);
+  for (size_t e = 0; e < (size_t)nv * nv; e++) A[e] += m->timestep * Dr[e];
+  memcpy(rhs, d->Ma, sizeof(double) * nv);
+  for (int k = 0; k < nv; k++) { /* LU in place, no pivoting; forward substitution fused */
+    double piv = A[(size_t)k * nv + k];
+    for (int i = k + 1; i < nv; i++) {
+      double f = A[(size_t)i * nv + k] / piv;
+      if (f == 0.0) continue;
+      for (int j = k + 1; j < nv; j++) A[(size_t)i * nv + j] -= f * A[(size_t)k * nv + j];
+      rhs[i] -= f * rhs[k];
+    }
+  }
+  for (int i = nv - 1; i >= 0; i--) {
+    double s2 = rhs[i];
+    for (int j = i + 1; j < nv; j++) s2 -= A[(size_t)i * nv + j] * qacc[j];
+    qacc[i] = s2 / A[(size_t)i * nv + i];
+  }
+  advance(m, d, qacc);
+  free(A);
+}
+
 /* state update from t0 with explicit rates and step dt: act (_next_activation forward.py:134 with `scale`), qvel
  * (_next_velocity 117), qpos (_next_position 53 integrates `vel_pos`) */
 static void rk_set_state(const RefModel* m, RefData* d, const double* qpos0, const double* qvel0, const double* act0,
@@ -3620,6 +3732,7 @@ void ref_rungekutta4(const RefModel* m, RefData* d) {
 void ref_step(const RefModel* m, RefData* d) { /* forward.py:1368-1380 */
   ref_forward(m, d);
   if (m->integrator == INT_IMPLICITFAST) ref_implicitfast(m, d);
+  else if (m->integrator == INT_IMPLICIT) ref_implicit(m, d);
   else if (m->integrator == INT_RK4) ref_rungekutta4(m, d);
   else ref_euler(m, d);
   if (sleep_enabled(m)) { /* forward.py:345-349 (end of _advance) */

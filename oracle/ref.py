@@ -61,13 +61,15 @@ def lib():
     mp, dp = ctypes.POINTER(CRefModel), ctypes.POINTER(CRefData)
     for fn in ("kinematics", "com_pos", "crb", "factor_m", "collision", "make_constraint", "transmission", "com_vel",
                "passive", "rne", "fwd_position", "fwd_velocity", "fwd_actuation", "fwd_acceleration", "solve",
-               "forward", "euler", "implicitfast", "step"):
+               "forward", "euler", "implicitfast", "implicit", "step"):
       f = getattr(_lib, "ref_" + fn)
       f.argtypes = [mp, dp]
       f.restype = None
     dptr = ctypes.POINTER(ctypes.c_double)
     _lib.ref_solve_m.argtypes = [mp, dp, dptr, dptr]
     _lib.ref_mul_m.argtypes = [mp, dp, dptr, dptr]
+    _lib.ref_deriv_rne_vel.argtypes = [mp, dp, dptr]
+    _lib.ref_deriv_rne_vel.restype = None
     _lib.ref_ctrl_noise.argtypes = [mp, dp, dptr, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double]
     _lib.ref_halton.argtypes = [ctypes.c_int, ctypes.c_int]
     _lib.ref_halton.restype = ctypes.c_double

@@ -104,8 +104,7 @@ def test_unsupported_features_raise():
   with pytest.raises(NotImplementedError):
     mjw.put_model(m)
   m = mjw.mjcf.from_xml_string('<mujoco><option integrator="implicit"/><worldbody><body><joint/><geom size=".1"/></body></worldbody></mujoco>')
-  with pytest.raises(NotImplementedError):
-    mjw.put_model(m)
+  assert int(mjw.put_model(m).opt.integrator) == int(mjw.IntegratorType.IMPLICIT)  # (round 3: built for nv <= 64, tests/test_implicit.py)
 
 
 # ---------------------------------------------------------------------------------- C ABI
@@ -359,7 +358,7 @@ def test_declared_schema_matches_arrays(xml):
   assert dataclasses.is_dataclass(mjw.Model) and dataclasses.is_dataclass(mjw.Data)
   env = {k: getattr(m, k) for k in ("nq", "nv", "nu", "na", "nbody", "njnt", "ngeom", "nsite", "nkey", "nmocap", "neq", "nC", "npair",
                                     "nexplicit", "nbodylevel", "ndoflevel", "nmaxpyramid", "ntree", "nmesh", "nmeshvert", "nmeshpoly", "nmeshpolyvert", "nmeshpolymap", "nmeshgraph", "nhfield", "nhfielddata", "nsensor", "nsensordata", "nmat")}
-  env.update(nworld=d.nworld, njmax=d.njmax, njmax_pad=d.njmax_pad, nv_pad=d.nv_pad, naconmax=d.naconmax, concap=d.concap, nccdworld=d.nccdworld, nccdword=d.nccdword, ntreeadr=(m.ntree + 1) if m.tree_solve else 0, ntreerow=d.njmax if m.tree_solve else 0, ntreedof=m.nv if m.tree_solve else 0, ntreeworld=d.nworld if m.tree_solve else 0, nsleepworld=d.nsleepworld, npgsworld=d.npgsworld)
+  env.update(nworld=d.nworld, njmax=d.njmax, njmax_pad=d.njmax_pad, nv_pad=d.nv_pad, naconmax=d.naconmax, concap=d.concap, nccdworld=d.nccdworld, nccdword=d.nccdword, ntreeadr=(m.ntree + 1) if m.tree_solve else 0, ntreerow=d.njmax if m.tree_solve else 0, ntreedof=m.nv if m.tree_solve else 0, ntreeworld=d.nworld if m.tree_solve else 0, nsleepworld=d.nsleepworld, npgsworld=d.npgsworld, nimpworld=d.nimpworld)
   for obj in (m.opt, m.stat, m, d.contact, d.efc, d):
     _schema_check(obj, env, d.nworld)
 
