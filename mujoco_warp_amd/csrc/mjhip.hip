@@ -296,9 +296,12 @@ static int launch_solve_any(const MjhModel* m, const MjhData* d, bool with_facto
   // solver, which keeps J in HBM and is generic in njmax
   const int top = d->njmax > 192 ? 192 : all;
   if (m->nv <= 32) {
+    // CG, pyramidal: the worlds of at most 64 rows go to the one-world-per-wavefront kernel (solver_cgw.hpp)
+    static const int wide_min_nv = getenv("MJH_CGW_MIN_NV") ? atoi(getenv("MJH_CGW_MIN_NV")) : 13;
+    const bool wide = !newton && !ell && m->nv >= wide_min_nv;
     // rows per lane (32 lanes per world): 2 covers 64 rows (humanoid, panda), 6 covers 192
-    if (d->njmax <= 64) return s32(m, d, 2, with_factor, fe, s, -1, all);
-    if (int rc = s32(m, d, 2, false, fe, s, -1, 64)) return rc;
+    if (d->njmax <= 64) return wide ? launch_solve_cgw(m, d, with_factor, fe, s, -1, all) : s32(m, d, 2, with_factor, fe, s, -1, all);
+    if (int rc = wide ? launch_solve_cgw(m, d, false, fe, s, -1, 64) : s32(m, d, 2, false, fe, s, -1, 64)) return rc;
     if (int rc = s32(m, d, 6, with_factor, fe, s, 64, top)) return rc;
     return d->njmax > 192 ? launch_solve_big(m, d, s, 192) : MJH_OK;
   }
