@@ -296,9 +296,14 @@ static int launch_solve_any(const MjhModel* m, const MjhData* d, bool with_facto
   // solver, which keeps J in HBM and is generic in njmax
   const int top = d->njmax > 192 ? 192 : all;
   if (m->nv <= 32) {
-    // CG, pyramidal: the worlds of at most 64 rows go to the one-world-per-wavefront kernel (solver_cgw.hpp)
+    // CG, pyramidal, SMALL batches: one world per wavefront (solver_cgw.hpp).  A solve is a dependent chain of ~17 k instructions per
+    // wavefront of which the line search's per-wavefront bookkeeping is the bulk, so pairing two worlds in a wavefront (solve_body)
+    // halves the instruction count per world and wins whenever the SIMDs are issue bound (measured, humanoid: 8192 worlds 194 us
+    // one-per-wavefront vs 193 paired, 141 M vs 81 M VALU instructions); with at most ~3 wavefronts per SIMD the chain's latency
+    // decides instead and the shorter chain of the unpaired kernel wins (1024 worlds: 88 vs 112 us, 2048: 103 vs 120, 3072: 122 vs 124)
     static const int wide_min_nv = getenv("MJH_CGW_MIN_NV") ? atoi(getenv("MJH_CGW_MIN_NV")) : 13;
-    const bool wide = !newton && !ell && m->nv >= wide_min_nv;
+    static const int wide_max_nworld = getenv("MJH_CGW_MAX_NWORLD") ? atoi(getenv("MJH_CGW_MAX_NWORLD")) : 3072;
+    const bool wide = !newton && !ell && m->nv >= wide_min_nv && d->nworld <= wide_max_nworld;
     // rows per lane (32 lanes per world): 2 covers 64 rows (humanoid, panda), 6 covers 192
     if (d->njmax <= 64) return wide ? launch_solve_cgw(m, d, with_factor, fe, s, -1, all) : s32(m, d, 2, with_factor, fe, s, -1, all);
     if (int rc = wide ? launch_solve_cgw(m, d, false, fe, s, -1, 64) : s32(m, d, 2, false, fe, s, -1, 64)) return rc;

@@ -98,6 +98,29 @@ def _check_solution(s, d, w=-1, tol=SOLVE):
   assert int(d.overflow.numpy()[ww]) == 0
 
 
+def test_cg_small_and_large_batch_kernels_both_match_oracle():
+  """CG has two kernels (mjhip.hip launch_solve_any): one world per wavefront for batches of at most 3072 worlds (csrc/solver_cgw.hpp),
+  two worlds per wavefront above (csrc/solver.hpp).  The same state through both: each within the oracle tolerance, and the same answer."""
+  mjm = mjw.mjcf.load_xml(conftest.HUMANOID_XML)
+  s, m, d = _pair(mjm, nworld=4, nconmax=24, njmax=64, solver=int(mjw.SolverType.CG))
+  big = mjw.put_data(mjm, mjw.MjData(mjm), nworld=3200, nconmax=24, njmax=64)
+  _sync(s, big)
+  s.forward()
+  out = []
+  for dd in (d, big):
+    mjw.forward(m, dd)
+    _check_solution(s, dd)
+    q = dd.qacc.numpy()
+    assert (q == q[0]).all()
+    assert abs(int(dd.solver_niter.numpy()[0]) - s.solver_niter) <= 2
+    out.append(q[0].copy())
+  assert relerr(out[0], out[1]) <= 2e-4  # (different summation orders: agreement at the solver tolerance)
+  for _ in range(5):  # and through the fused step (Euler in the solver's epilogue)
+    mjw.step(m, d)
+    mjw.step(m, big)
+  assert relerr(d.qpos.numpy()[0], big.qpos.numpy()[0]) <= 1e-5 and relerr(d.qvel.numpy()[0], big.qvel.numpy()[0]) <= 1e-3
+
+
 @pytest.mark.parametrize("solver", [mjw.SolverType.NEWTON, mjw.SolverType.CG])
 def test_humanoid_forward_matches_oracle(solver):
   mjm = mjw.mjcf.load_xml(conftest.HUMANOID_XML)

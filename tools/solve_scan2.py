@@ -7,8 +7,8 @@ import numpy as np
 import mujoco_warp_amd as mjw
 solver = sys.argv[1] if len(sys.argv) > 1 else "cg"
 PLAIN = os.environ.get("PLAIN", "1") == "1"
-caps = (100, 32, 16, 8, 4, 2, 1, 0)
-for nworld in (1024, 8192):
+caps = tuple(int(x) for x in os.environ.get('CAPS', '100,32,16,8,4,2,1,0').split(','))
+for nworld in tuple(int(x) for x in os.environ.get('NWORLDS', '1024,8192').split(',')):
   mjm = mjw.mjcf.load_xml(os.path.join(ROOT, "benchmarks", "humanoid", "humanoid.xml"))
   mjw.override_model(mjm, [f"opt.solver={solver}"])
   m0 = mjw.put_model(mjm)
