@@ -62,7 +62,7 @@ constexpr int G = 32;
 static int launch_pos(const MjhModel* m, const MjhData* d, int first, int last, hipStream_t s) {
   const PosLayout lay = pos_layout(m->nq, m->nv, m->nbody, m->njnt, m->nC, last >= POS_FACTOR);
   size_t lds;
-  const int threads = pick_block(sizeof(int) * pos_shared_words(m->nv, m->nC, m->nbody, m->njnt, m->nbodylevel), sizeof(float) * lay.total, G, &lds);
+  const int threads = pick_block(sizeof(int) * pos_shared_words(m->nv, m->nC, m->nbody, m->njnt, m->nbodylevel, m->ngeom, m->nsite), sizeof(float) * lay.total, G, &lds);
   if (!threads) return fail(MJH_E_UNSUPPORTED, "k_fwd_pos: model does not fit in LDS");
   HIPCHK(set_lds(k_fwd_pos<G>, lds));
   const int wpb = threads / G;
@@ -348,7 +348,7 @@ static int launch_pos_plus(const MjhModel* m, const MjhData* d, int first, int l
   g_noise.n = 0;
   const PosLayout lay = pos_layout(m->nq, m->nv, m->nbody, m->njnt, m->nC, last >= POS_FACTOR);
   size_t lds;
-  const int threads = pick_block(sizeof(int) * pos_shared_words(m->nv, m->nC, m->nbody, m->njnt, m->nbodylevel), sizeof(float) * lay.total, G, &lds);
+  const int threads = pick_block(sizeof(int) * pos_shared_words(m->nv, m->nC, m->nbody, m->njnt, m->nbodylevel, m->ngeom, m->nsite), sizeof(float) * lay.total, G, &lds);
   if (!threads) return fail(MJH_E_UNSUPPORTED, "k_fwd_pos: model does not fit in LDS");
   *sched_done = threads >= 128;
   if (!*sched_done) {

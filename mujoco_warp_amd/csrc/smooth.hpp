@@ -22,7 +22,7 @@ struct MStruct {
 };
 
 template <int G>
-DEV MStruct load_mstruct(const MjhModel& m, int* sh, int nthreads) {
+DEV MStruct load_mstruct(const MjhModel& m, int* sh, int nthreads, bool sync = true) {
   // cooperative (whole block) copy of M_rowadr | M_rownnz | M_colind into LDS; ends with __syncthreads
   int nv = m.nv, nC = m.nC;
   for (int i = threadIdx.x; i < nv; i += nthreads) {
@@ -33,7 +33,7 @@ DEV MStruct load_mstruct(const MjhModel& m, int* sh, int nthreads) {
   int* lv = sh + 2 * nv + nC;
   for (int i = threadIdx.x; i < nv; i += nthreads) lv[i] = m.dof_tree[i];
   for (int i = threadIdx.x; i <= m.ndoflevel; i += nthreads) lv[nv + i] = m.dof_leveladr[i];
-  __syncthreads();
+  if (sync) __syncthreads();
   return MStruct{sh, sh + nv, sh + 2 * nv, lv, lv + nv};
 }
 // M_rowadr | M_rownnz | M_colind | dof_tree | dof_leveladr (ndoflevel <= nv)
@@ -52,7 +52,7 @@ DEV bool fk_table_ok(const MjhModel& m) {
   return m.body_pos_nb <= 1 && m.body_quat_nb <= 1 && m.jnt_pos_nb <= 1 && m.jnt_axis_nb <= 1 && m.qpos0_nb <= 1;
 }
 // cooperative (whole workgroup) fill; ends with __syncthreads
-DEV void load_fk_table(const MjhModel& m, float* T, int nthreads) {
+DEV void load_fk_table(const MjhModel& m, float* T, int nthreads, bool sync = true) {
   const int nbody = m.nbody, njnt = m.njnt;
   int* Ti = reinterpret_cast<int*>(T);
   for (int b = threadIdx.x; b < nbody; b += nthreads) {
@@ -79,7 +79,78 @@ DEV void load_fk_table(const MjhModel& m, float* T, int nthreads) {
   int* L = reinterpret_cast<int*>(J + FKJ * njnt);
   for (int i = threadIdx.x; i < nbody; i += nthreads) L[i] = m.body_tree[i];
   for (int i = threadIdx.x; i <= m.nbodylevel; i += nthreads) L[nbody + i] = m.body_leveladr[i];
-  __syncthreads();
+  if (sync) __syncthreads();
+}
+
+// Block-shared model table of the stages AFTER the kinematics (round 3): every model constant com_pos, crb and the geom / site poses
+// look up, staged with the kinematics table and the M-structure in ONE batch of loads at the start of the kernel.  Before, each stage
+// began with its own round trip to L2 (body_ipos, geom_bodyid -> ..., body_subtreenum -> body_mass[c] in a serial loop of up to nbody
+// loads, the dof_parentid chain of the mass-matrix rows ...): about twenty dependent trips of 500+ cycles in a kernel whose arithmetic
+// is 2,100 instructions per wavefront -- k_fwd_pos took 30 us for 1,024 worlds (one wavefront per SIMD) and 40 us for 8,192.
+// Structure of arrays, float / int words; valid when none of the staged fields is batched per world.
+struct PosTab {
+  const float *mass, *submass, *inertia, *ipos, *iquat, *armature, *gpos, *gquat, *spos, *squat;
+  const int *subnum, *rootid, *jbody, *jdof, *jtype, *dbody, *dparent, *gbody, *sbody;
+};
+__host__ __device__ inline int pos_tab_words(int nbody, int njnt, int nv, int ngeom, int nsite) {
+  return ((14 * nbody + 3 * njnt + 3 * nv + 8 * ngeom + 8 * nsite + 3) / 4) * 4;
+}
+DEV bool pos_tab_ok(const MjhModel& m) {
+  return fk_table_ok(m) && m.body_mass_nb <= 1 && m.body_subtreemass_nb <= 1 && m.body_inertia_nb <= 1 && m.body_ipos_nb <= 1 && m.body_iquat_nb <= 1 &&
+         m.dof_armature_nb <= 1 && m.geom_pos_nb <= 1 && m.geom_quat_nb <= 1 && m.site_pos_nb <= 1 && m.site_quat_nb <= 1;
+}
+// cooperative (whole workgroup) fill, no barrier: thread t stages body t, joint t, dof t, geom t, site t -- all loads independent
+DEV PosTab load_pos_tab(const MjhModel& m, float* T, int nthreads) {
+  const int nbody = m.nbody, njnt = m.njnt, nv = m.nv, ngeom = m.ngeom, nsite = m.nsite;
+  float* mass = T;
+  float* submass = mass + nbody;
+  float* inertia = submass + nbody;
+  float* ipos = inertia + 3 * nbody;
+  float* iquat = ipos + 3 * nbody;
+  int* subnum = reinterpret_cast<int*>(iquat + 4 * nbody);
+  int* rootid = subnum + nbody;
+  int* jbody = rootid + nbody;
+  int* jdof = jbody + njnt;
+  int* jtype = jdof + njnt;
+  float* armature = reinterpret_cast<float*>(jtype + njnt);
+  int* dbody = reinterpret_cast<int*>(armature + nv);
+  int* dparent = dbody + nv;
+  int* gbody = dparent + nv;
+  float* gpos = reinterpret_cast<float*>(gbody + ngeom);
+  float* gquat = gpos + 3 * ngeom;
+  int* sbody = reinterpret_cast<int*>(gquat + 4 * ngeom);
+  float* spos = reinterpret_cast<float*>(sbody + nsite);
+  float* squat = spos + 3 * nsite;
+  for (int b = threadIdx.x; b < nbody; b += nthreads) {
+    mass[b] = m.body_mass[b];
+    submass[b] = m.body_subtreemass[b];
+    subnum[b] = m.body_subtreenum[b];
+    rootid[b] = m.body_rootid[b];
+    for (int k = 0; k < 3; ++k) inertia[3 * b + k] = m.body_inertia[3 * b + k];
+    for (int k = 0; k < 3; ++k) ipos[3 * b + k] = m.body_ipos[3 * b + k];
+    for (int k = 0; k < 4; ++k) iquat[4 * b + k] = m.body_iquat[4 * b + k];
+  }
+  for (int j = threadIdx.x; j < njnt; j += nthreads) {
+    jbody[j] = m.jnt_bodyid[j];
+    jdof[j] = m.jnt_dofadr[j];
+    jtype[j] = m.jnt_type[j];
+  }
+  for (int i = threadIdx.x; i < nv; i += nthreads) {
+    armature[i] = m.dof_armature[i];
+    dbody[i] = m.dof_bodyid[i];
+    dparent[i] = m.dof_parentid[i];
+  }
+  for (int g = threadIdx.x; g < ngeom; g += nthreads) {
+    gbody[g] = m.geom_bodyid[g];
+    for (int k = 0; k < 3; ++k) gpos[3 * g + k] = m.geom_pos[3 * g + k];
+    for (int k = 0; k < 4; ++k) gquat[4 * g + k] = m.geom_quat[4 * g + k];
+  }
+  for (int g = threadIdx.x; g < nsite; g += nthreads) {
+    sbody[g] = m.site_bodyid[g];
+    for (int k = 0; k < 3; ++k) spos[3 * g + k] = m.site_pos[3 * g + k];
+    for (int k = 0; k < 4; ++k) squat[4 * g + k] = m.site_quat[4 * g + k];
+  }
+  return PosTab{mass, submass, inertia, ipos, iquat, armature, gpos, gquat, spos, squat, subnum, rootid, jbody, jdof, jtype, dbody, dparent, gbody, sbody};
 }
 
 // sparse L'DL factorisation in LDS (reference smooth.py:1183-1232 _qLD_acc/_qLDiag_div == MuJoCo mj_factorI).
@@ -159,17 +230,24 @@ __host__ __device__ inline PosLayout pos_layout(int nq, int nv, int nbody, int n
   PosLayout p;
   int o = 0;
   p.qpos = o; o += nq;
+  // xpos | xquat | xanchor | xaxis are dead (written back, last read by cdof) when crb starts: crb lives on top of them when it fits
+  const int pose0 = o;
   p.xpos = o; o += 3 * nbody;
   p.xquat = o; o += 4 * nbody;
+  p.xanchor = o; o += 3 * njnt;
+  p.xaxis = o; o += 3 * njnt;
+  const int pose_words = o - pose0;
   p.xmat = o; o += 9 * nbody;
   p.xipos = o; o += 3 * nbody;
   p.ximat = o; o += 9 * nbody;
-  p.xanchor = o; o += 3 * njnt;
-  p.xaxis = o; o += 3 * njnt;
   p.scom = o; o += 3 * nbody;
   p.cinert = o; o += 10 * nbody;
   p.cdof = o; o += 6 * nv;
-  p.crb = o; o += 10 * nbody;
+  if (10 * nbody <= pose_words) {
+    p.crb = pose0;
+  } else {
+    p.crb = o; o += 10 * nbody;
+  }
   if (nC <= 21 * nbody) {
     p.M = p.xmat;  // xmat, xipos, ximat are adjacent (21 nbody words) and no longer read once com_pos is done
   } else {
@@ -181,31 +259,40 @@ __host__ __device__ inline PosLayout pos_layout(int nq, int nv, int nbody, int n
   return p;
 }
 
-// block-shared words in front of the per-world slices: the larger of the M-structure and the kinematics table
-__host__ __device__ inline int pos_shared_words(int nv, int nC, int nbody, int njnt, int nlevel) {
-  const int a = mstruct_ints(nv, nC), b = fk_table_words(nbody, njnt, nlevel);
-  return a > b ? a : b;
+// block-shared words in front of the per-world slices: kinematics table | M-structure | table of the later stages
+__host__ __device__ inline int pos_shared_words(int nv, int nC, int nbody, int njnt, int nlevel, int ngeom, int nsite) {
+  return fk_table_words(nbody, njnt, nlevel) + mstruct_ints(nv, nC) + pos_tab_words(nbody, njnt, nv, ngeom, nsite);
 }
 
 enum { POS_KINEMATICS = 0, POS_COM = 1, POS_CRB = 2, POS_FACTOR = 3 };
 
-template <int G>
-DEV void fwd_pos_body(const MjhModel& m, const MjhData& d, int first, int last, float* smem, const Blk& b) {
+// TAB: the model tables of every stage are staged in LDS (pos_tab_ok); otherwise the stages read the (per-world batched) model arrays
+template <int G, bool TAB>
+DEV void fwd_pos_impl(const MjhModel& m, const MjhData& d, int first, int last, float* smem, const Blk& b) {
   if ((int)threadIdx.x >= b.nthreads) return;
   const int nq = m.nq, nv = m.nv, nbody = m.nbody, njnt = m.njnt, nC = m.nC;
   const PosLayout lay = pos_layout(nq, nv, nbody, njnt, nC, last >= POS_FACTOR);
-  int* shi = reinterpret_cast<int*>(smem);
-  const int shared_words = pos_shared_words(nv, nC, nbody, njnt, m.nbodylevel);
-  const bool fk_fast = first <= POS_KINEMATICS && fk_table_ok(m);
-  // the block-shared region holds the kinematics table first and the M-structure afterwards (both: one fill + barrier)
-  if (fk_fast) load_fk_table(m, smem, b.nthreads);
-  MStruct ms = MStruct{nullptr, nullptr, nullptr, nullptr, nullptr};
-  if (!fk_fast) ms = load_mstruct<G>(m, shi, b.nthreads);
+  const int fkw = fk_table_words(nbody, njnt, m.nbodylevel), msw = mstruct_ints(nv, nC);
+  const int shared_words = pos_shared_words(nv, nC, nbody, njnt, m.nbodylevel, m.ngeom, m.nsite);
+  const bool fk_fast = TAB && first <= POS_KINEMATICS;
   const int lig = threadIdx.x & (G - 1), gib = threadIdx.x / G;
   const int w = b.w0 + gib;
   const bool valid = w < d.nworld;  // (no early return: the workgroup meets again at the barriers below)
-  PhaseClock pc(1, lig);
   float* S = smem + shared_words + (size_t)gib * lay.total;
+  // the block-shared region: kinematics table | M-structure | table of the later stages, filled by ONE batch of loads together with
+  // the world's qpos row, one barrier
+  MStruct ms = MStruct{nullptr, nullptr, nullptr, nullptr, nullptr};
+  PosTab pt = PosTab{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  if (TAB) {
+    if (fk_fast) load_fk_table(m, smem, b.nthreads, false);
+    ms = load_mstruct<G>(m, reinterpret_cast<int*>(smem + fkw), b.nthreads, false);
+    pt = load_pos_tab(m, smem + fkw + msw, b.nthreads);
+    if (fk_fast && valid) gcopy<G>(S + lay.qpos, d.qpos + (size_t)w * nq, nq, lig);
+    __syncthreads();
+  } else {
+    ms = load_mstruct<G>(m, reinterpret_cast<int*>(smem + fkw), b.nthreads);
+  }
+  PhaseClock pc(1, lig);
   float *qpos = S + lay.qpos, *xpos = S + lay.xpos, *xquat = S + lay.xquat, *xmat = S + lay.xmat, *xipos = S + lay.xipos,
         *ximat = S + lay.ximat, *xanchor = S + lay.xanchor, *xaxis = S + lay.xaxis, *scom = S + lay.scom,
         *cinert = S + lay.cinert, *cdof = S + lay.cdof, *crb = S + lay.crb, *M = S + lay.M, *L = S + lay.L,
@@ -213,8 +300,6 @@ DEV void fwd_pos_body(const MjhModel& m, const MjhData& d, int first, int last, 
 
   // ---- kinematics (smooth.py:46-226) ---------------------------------------------------------------
   if (first <= POS_KINEMATICS && valid && fk_fast) {
-    gcopy<G>(qpos, d.qpos + (size_t)w * nq, nq, lig);
-    gsync();
     const float* TB = smem;
     const float* TJ = smem + FKB * nbody;
     const int* TL = reinterpret_cast<const int*>(TJ + FKJ * njnt);
@@ -361,15 +446,30 @@ DEV void fwd_pos_body(const MjhModel& m, const MjhData& d, int first, int last, 
       gsync();
     }
   }
-  if (fk_fast) {  // every wavefront is done with the kinematics table: the M-structure takes its place
-    __syncthreads();
-    ms = load_mstruct<G>(m, shi, b.nthreads);
-  }
+  if (fk_fast) __syncthreads();  // (the level loop wrote poses into the slices of other wavefronts' worlds)
   if (!valid) return;
   pc.mark(5);
+  // model constants: from the LDS table (TAB) or from the model arrays (batched fields)
+  const float* body_ipos = TAB ? pt.ipos : bf(m.body_ipos, m.body_ipos_nb, w, 3 * nbody);
+  const float* body_iquat = TAB ? pt.iquat : bf(m.body_iquat, m.body_iquat_nb, w, 4 * nbody);
+  const float* geom_pos = TAB ? pt.gpos : bf(m.geom_pos, m.geom_pos_nb, w, 3 * m.ngeom);
+  const float* geom_quat = TAB ? pt.gquat : bf(m.geom_quat, m.geom_quat_nb, w, 4 * m.ngeom);
+  const float* site_pos = TAB ? pt.spos : bf(m.site_pos, m.site_pos_nb, w, 3 * m.nsite);
+  const float* site_quat = TAB ? pt.squat : bf(m.site_quat, m.site_quat_nb, w, 4 * m.nsite);
+  const float* body_mass = TAB ? pt.mass : bf(m.body_mass, m.body_mass_nb, w, nbody);
+  const float* body_subtreemass = TAB ? pt.submass : bf(m.body_subtreemass, m.body_subtreemass_nb, w, nbody);
+  const float* body_inertia = TAB ? pt.inertia : bf(m.body_inertia, m.body_inertia_nb, w, 3 * nbody);
+  const float* armature = TAB ? pt.armature : bf(m.dof_armature, m.dof_armature_nb, w, nv);
+  const int* geom_bodyid = TAB ? pt.gbody : m.geom_bodyid;
+  const int* site_bodyid = TAB ? pt.sbody : m.site_bodyid;
+  const int* body_subtreenum = TAB ? pt.subnum : m.body_subtreenum;
+  const int* body_rootid = TAB ? pt.rootid : m.body_rootid;
+  const int* jnt_bodyid = TAB ? pt.jbody : m.jnt_bodyid;
+  const int* jnt_dofadr = TAB ? pt.jdof : m.jnt_dofadr;
+  const int* jnt_type = TAB ? pt.jtype : m.jnt_type;
+  const int* dof_bodyid = TAB ? pt.dbody : m.dof_bodyid;
+  const int* dof_parentid = TAB ? pt.dparent : m.dof_parentid;
   if (first <= POS_KINEMATICS) {
-    const float* body_ipos = bf(m.body_ipos, m.body_ipos_nb, w, 3 * nbody);
-    const float* body_iquat = bf(m.body_iquat, m.body_iquat_nb, w, 4 * nbody);
     for (int b = lig; b < nbody; b += G) {
       Q4 q = ld4(xquat + 4 * b);
       quat_to_mat(q, xmat + 9 * b);
@@ -378,10 +478,8 @@ DEV void fwd_pos_body(const MjhModel& m, const MjhData& d, int first, int last, 
     }
     pc.mark(6);
     {  // geoms and sites go straight to HBM (consumed by the collision kernel)
-      const float* geom_pos = bf(m.geom_pos, m.geom_pos_nb, w, 3 * m.ngeom);
-      const float* geom_quat = bf(m.geom_quat, m.geom_quat_nb, w, 4 * m.ngeom);
       for (int g = lig; g < m.ngeom; g += G) {
-        const int b = m.geom_bodyid[g];
+        const int b = geom_bodyid[g];
         Q4 q = ld4(xquat + 4 * b);
         float mat[9];
         st3(d.geom_xpos + ((size_t)w * m.ngeom + g) * 3, ld3(xpos + 3 * b) + rot_vec_quat(ld3(geom_pos + 3 * g), q));
@@ -389,10 +487,8 @@ DEV void fwd_pos_body(const MjhModel& m, const MjhData& d, int first, int last, 
         float* out = d.geom_xmat + ((size_t)w * m.ngeom + g) * 9;
         for (int k = 0; k < 9; ++k) out[k] = mat[k];
       }
-      const float* site_pos = bf(m.site_pos, m.site_pos_nb, w, 3 * m.nsite);
-      const float* site_quat = bf(m.site_quat, m.site_quat_nb, w, 4 * m.nsite);
       for (int s = lig; s < m.nsite; s += G) {
-        const int b = m.site_bodyid[s];
+        const int b = site_bodyid[s];
         Q4 q = ld4(xquat + 4 * b);
         float mat[9];
         st3(d.site_xpos + ((size_t)w * m.nsite + s) * 3, ld3(xpos + 3 * b) + rot_vec_quat(ld3(site_pos + 3 * s), q));
@@ -424,12 +520,9 @@ DEV void fwd_pos_body(const MjhModel& m, const MjhData& d, int first, int last, 
       gcopy<G>(xaxis, d.xaxis + (size_t)w * 3 * njnt, 3 * njnt, lig);
       gsync();
     }
-    const float* body_mass = bf(m.body_mass, m.body_mass_nb, w, nbody);
-    const float* body_subtreemass = bf(m.body_subtreemass, m.body_subtreemass_nb, w, nbody);
-    const float* body_inertia = bf(m.body_inertia, m.body_inertia_nb, w, 3 * nbody);
     for (int b = lig; b < nbody; b += G) {  // subtree = contiguous id range (depth-first numbering)
       V3 s = V3{0, 0, 0};
-      const int end = b + m.body_subtreenum[b];
+      const int end = b + body_subtreenum[b];
       for (int c = b; c < end; ++c) s = s + ld3(xipos + 3 * c) * body_mass[c];
       const float mass = body_subtreemass[b];
       if (mass != 0.0f) s = s * (1.0f / mass);
@@ -440,7 +533,7 @@ DEV void fwd_pos_body(const MjhModel& m, const MjhData& d, int first, int last, 
       const float* mat = ximat + 9 * b;
       V3 in = ld3(body_inertia + 3 * b);
       const float mass = body_mass[b];
-      V3 dif = ld3(xipos + 3 * b) - ld3(scom + 3 * m.body_rootid[b]);
+      V3 dif = ld3(xipos + 3 * b) - ld3(scom + 3 * body_rootid[b]);
       float t00 = mat[0] * in.x * mat[0] + mat[1] * in.y * mat[1] + mat[2] * in.z * mat[2];
       float t11 = mat[3] * in.x * mat[3] + mat[4] * in.y * mat[4] + mat[5] * in.z * mat[5];
       float t22 = mat[6] * in.x * mat[6] + mat[7] * in.y * mat[7] + mat[8] * in.z * mat[8];
@@ -460,10 +553,10 @@ DEV void fwd_pos_body(const MjhModel& m, const MjhData& d, int first, int last, 
       r[9] = mass;
     }
     for (int j = lig; j < njnt; j += G) {  // _cdof smooth.py:779
-      const int b = m.jnt_bodyid[j], t = m.jnt_type[j];
-      int dof = m.jnt_dofadr[j];
+      const int b = jnt_bodyid[j], t = jnt_type[j];
+      int dof = jnt_dofadr[j];
       const float* xm = xmat + 9 * b;
-      V3 off = ld3(scom + 3 * m.body_rootid[b]) - ld3(xanchor + 3 * j);
+      V3 off = ld3(scom + 3 * body_rootid[b]) - ld3(xanchor + 3 * j);
       if (t == JNT_FREE || t == JNT_BALL) {
         if (t == JNT_FREE) {
           for (int k = 0; k < 3; ++k) {
@@ -508,19 +601,18 @@ DEV void fwd_pos_body(const MjhModel& m, const MjhData& d, int first, int last, 
       float acc[10];
       for (int k = 0; k < 10; ++k) acc[k] = cinert[10 * b + k];
       if (b > 0) {
-        const int end = b + m.body_subtreenum[b];
+        const int end = b + body_subtreenum[b];
         for (int c = b + 1; c < end; ++c)
           for (int k = 0; k < 10; ++k) acc[k] += cinert[10 * c + k];
       }
       for (int k = 0; k < 10; ++k) crb[10 * b + k] = acc[k];
     }
     gsync();
-    const float* armature = bf(m.dof_armature, m.dof_armature_nb, w, nv);
     for (int i = lig; i < nv; i += G) {  // _M smooth.py:1048
       int adr = ms.rowadr[i] + ms.rownnz[i] - 1;
       float buf[6], ci[6];
       for (int k = 0; k < 6; ++k) ci[k] = cdof[6 * i + k];
-      inert_vec(crb + 10 * m.dof_bodyid[i], ci, buf);
+      inert_vec(crb + 10 * dof_bodyid[i], ci, buf);
       int j = i;
       float arm = armature[i];
       while (j >= 0) {
@@ -529,7 +621,7 @@ DEV void fwd_pos_body(const MjhModel& m, const MjhData& d, int first, int last, 
         M[adr] = s + arm;
         arm = 0.0f;
         --adr;
-        j = m.dof_parentid[j];
+        j = dof_parentid[j];
       }
     }
     gsync();
@@ -547,6 +639,11 @@ DEV void fwd_pos_body(const MjhModel& m, const MjhData& d, int first, int last, 
   gcopy<G>(d.qLD + (size_t)w * nC, L, nC, lig);
   gcopy<G>(d.qLDiagInv + (size_t)w * nv, dinv, nv, lig);
   pc.mark(3);
+}
+template <int G>
+DEV void fwd_pos_body(const MjhModel& m, const MjhData& d, int first, int last, float* smem, const Blk& b) {
+  if (pos_tab_ok(m)) fwd_pos_impl<G, true>(m, d, first, last, smem, b);
+  else fwd_pos_impl<G, false>(m, d, first, last, smem, b);
 }
 
 // ---------------------------------------------------------------------------------------------------

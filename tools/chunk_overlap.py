@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT)
 import numpy as np, torch
 import mujoco_warp_amd as mjw
 solver = sys.argv[1] if len(sys.argv) > 1 else "cg"
-NW, K = 8192, 200
+NW, K = 8192, int(os.environ.get('K', '200'))
 mjm = mjw.mjcf.load_xml(os.path.join(ROOT, "benchmarks", "humanoid", "humanoid.xml"))
 mjw.override_model(mjm, [f"opt.solver={solver}"])
 m = mjw.put_model(mjm)
@@ -29,7 +29,7 @@ def run(nchunk, sync_every, prio):
           mjw.step(m, ds[c])
       if sync_every:
         torch.cuda.synchronize()
-  loop(0, 200, False)
+  loop(0, int(os.environ.get('WARM', '200')), False)
   torch.cuda.synchronize()
   t0 = time.perf_counter()
   loop(200, 200 + K, True)
@@ -38,7 +38,7 @@ def run(nchunk, sync_every, prio):
   nit = np.mean([d.solver_niter.numpy().mean() for d in ds])
   print(f"chunks {nchunk} sync_per_step {int(sync_every)} prio {int(prio)}: {NW * K / dt / 1e6:6.2f} M env-steps/s  {dt / K * 1e3:.4f} ms/step niter {nit:.2f}", flush=True)
 
-for nchunk in (1, 2, 4, 8):
-  for sync_every in (False, True):
+for nchunk in tuple(int(x) for x in os.environ.get('CHUNKS', '1,2,4,8').split(',')):
+  for sync_every in ((False,) if os.environ.get('NOSYNC') else (False, True)):
     for prio in ((False, True) if nchunk > 1 else (False,)):
       run(nchunk, sync_every, prio)
