@@ -149,6 +149,103 @@ DEV float chol_solve_rows(const float (&h)[NVR], const float (&lt)[NVR], float r
   return x;
 }
 
+// ---- the same solve by a BLOCKED right-looking Cholesky (round 2 for the MFMA Newton kernel, round 3 generic in the group size):
+// factorisation, forward and backward substitution in one routine, nothing but the H row (NVR registers) held across it.
+//   h: row i of the SPD matrix on entry (the FULL row: the trailing block is kept symmetric), destroyed.  Lanes >= nv hold identity
+//   rows.  LDS, private to the lane group: panel (4 G floats), vec (G), save (12 NV4).
+// Per 4-column block: every lane parks its four raw panel entries and its running right-hand side in LDS (one round trip), refactors
+// the 4 x 4 diagonal block redundantly in registers (no cross-lane traffic), takes its own entries of L and applies the Schur update
+// from the RAW panel (h[k] -= (x Ld^-1) . p_k = L_i . L_k); the forward substitution rides along.  The backward substitution needs
+// columns of L, which live across lanes: per block four DPP reductions of h[c] * x, then the 4 x 4 back substitution in registers
+// from the block factors saved in LDS.  NVR / 4 LDS round trips per factorisation where chol_factor_rows needs NVR, and NVR^2 / 8
+// float4 panel reads where it needs NVR^2 / 2 scalar ones (the G1's 64-lane Newton kernel spent 65 % of its time there).
+DEV float rsqrt_nr(float pv) {  // v_rsq_f32 + one Newton step (~0.5 ulp), as chol_factor_rows
+  float inv = __builtin_amdgcn_rsqf(pv);
+  return inv * (1.5f - 0.5f * pv * inv * inv);
+}
+template <int NV4, int G>
+DEV float chol_factor_solve_g(float (&h)[4 * NV4], float g, float* panel, float* vec, float* save, int lig) {
+  constexpr int NVR = 4 * NV4;
+  float gacc = g, y = 0.0f;
+#pragma unroll
+  for (int jb = 0; jb < NV4; ++jb) {
+    const int j0 = 4 * jb;
+    gsync();  // the previous block's panel reads are issued before this write (one wavefront: LDS ops complete in order)
+    // unconditional (lanes >= NVR park junk in their own slot): a branch here splits the block, the compiler then sinks the
+    // previous block's Schur FMAs past it while their panel loads must stay before this write
+    *reinterpret_cast<float4*>(panel + 4 * lig) = make_float4(h[j0], h[j0 + 1], h[j0 + 2], h[j0 + 3]);
+    vec[lig] = gacc;
+    gsync();
+    const float4 d0 = *reinterpret_cast<const float4*>(panel + 4 * j0);
+    const float4 d1 = *reinterpret_cast<const float4*>(panel + 4 * (j0 + 1));
+    const float4 d2 = *reinterpret_cast<const float4*>(panel + 4 * (j0 + 2));
+    const float4 d3 = *reinterpret_cast<const float4*>(panel + 4 * (j0 + 3));
+    const float4 g4 = *reinterpret_cast<const float4*>(vec + j0);
+    const float r0 = rsqrt_nr(fmaxf(d0.x, MJ_MINVAL));
+    const float l10 = d1.x * r0, l20 = d2.x * r0, l30 = d3.x * r0;
+    const float r1 = rsqrt_nr(fmaxf(d1.y - l10 * l10, MJ_MINVAL));
+    const float l21 = (d2.y - l20 * l10) * r1, l31 = (d3.y - l30 * l10) * r1;
+    const float r2 = rsqrt_nr(fmaxf(d2.z - l20 * l20 - l21 * l21, MJ_MINVAL));
+    const float l32 = (d3.z - l30 * l20 - l31 * l21) * r2;
+    const float r3 = rsqrt_nr(fmaxf(d3.w - l30 * l30 - l31 * l31 - l32 * l32, MJ_MINVAL));
+    *reinterpret_cast<float4*>(save + 12 * jb) = make_float4(l10, l20, l30, r0);
+    *reinterpret_cast<float4*>(save + 12 * jb + 4) = make_float4(l21, l31, l32, r1);
+    *reinterpret_cast<float2*>(save + 12 * jb + 8) = make_float2(r2, r3);
+    const float x0 = h[j0] * r0;
+    const float x1 = (h[j0 + 1] - x0 * l10) * r1;
+    const float x2 = (h[j0 + 2] - x0 * l20 - x1 * l21) * r2;
+    const float x3 = (h[j0 + 3] - x0 * l30 - x1 * l31 - x2 * l32) * r3;
+    h[j0] = x0;
+    h[j0 + 1] = x1;
+    h[j0 + 2] = x2;
+    h[j0 + 3] = x3;
+    const float y0 = g4.x * r0;
+    const float y1 = (g4.y - l10 * y0) * r1;
+    const float y2 = (g4.z - l20 * y0 - l21 * y1) * r2;
+    const float y3 = (g4.w - l30 * y0 - l31 * y1 - l32 * y2) * r3;
+    y = lig == j0 ? y0 : y;  // (four selects: a nested conditional becomes branches)
+    y = lig == j0 + 1 ? y1 : y;
+    y = lig == j0 + 2 ? y2 : y;
+    y = lig == j0 + 3 ? y3 : y;
+    gacc -= x0 * y0 + x1 * y1 + x2 * y2 + x3 * y3;
+    if (jb + 1 < NV4) {
+      const float u3 = x3 * r3;
+      const float u2 = (x2 - l32 * u3) * r2;
+      const float u1 = (x1 - l21 * u2 - l31 * u3) * r1;
+      const float u0 = (x0 - l10 * u1 - l20 * u2 - l30 * u3) * r0;
+#pragma unroll
+      for (int k = j0 + 4; k < NVR; ++k) {
+        const float4 pk = *reinterpret_cast<const float4*>(panel + 4 * k);
+        h[k] = fmaf(-u3, pk.w, fmaf(-u2, pk.z, fmaf(-u1, pk.y, fmaf(-u0, pk.x, h[k]))));
+      }
+      __builtin_amdgcn_sched_barrier(0);  // finish the update here: deferring it keeps the panel rows in registers
+    }
+  }
+  gsync();
+  vec[lig] = y;
+  gsync();
+  float x = 0.0f;  // lanes >= NVR never receive a value: their (junk but finite) h entries are multiplied by zero
+#pragma unroll
+  for (int jb = NV4 - 1; jb >= 0; --jb) {
+    const int j0 = 4 * jb;
+    float t4[4] = {h[j0] * x, h[j0 + 1] * x, h[j0 + 2] * x, h[j0 + 3] * x};
+    gsumg_n<G, 4>(t4);
+    const float4 y4 = *reinterpret_cast<const float4*>(vec + j0);
+    const float4 sa = *reinterpret_cast<const float4*>(save + 12 * jb);      // l10 l20 l30 r0
+    const float4 sb = *reinterpret_cast<const float4*>(save + 12 * jb + 4);  // l21 l31 l32 r1
+    const float2 sc = *reinterpret_cast<const float2*>(save + 12 * jb + 8);  // r2 r3
+    const float x3 = (y4.w - t4[3]) * sc.y;
+    const float x2 = ((y4.z - t4[2]) - sb.z * x3) * sc.x;
+    const float x1 = ((y4.y - t4[1]) - sb.x * x2 - sb.y * x3) * sb.w;
+    const float x0 = ((y4.x - t4[0]) - sa.x * x1 - sa.y * x2 - sa.z * x3) * sa.w;
+    x = lig == j0 ? x0 : x;
+    x = lig == j0 + 1 ? x1 : x;
+    x = lig == j0 + 2 ? x2 : x;
+    x = lig == j0 + 3 ? x3 : x;
+  }
+  return x;
+}
+
 struct SolveLayout {
   int J, force, da, bsearch, bgrad, col, ex, cone, fl, total;
 };
@@ -165,8 +262,8 @@ __host__ __device__ inline SolveLayout solve_layout(int njmax) {
   p.da = o; o += NEWTON ? G * NR : 0;           // D * [state == QUADRATIC] (Newton: J^T D J)
   p.bsearch = o; o += G;                        // broadcast copies of the two nv-vectors other lanes read
   p.bgrad = o; o += G;
-  // Newton: Cholesky pivot column + 8-row transpose tile; CG: the double-buffered Gauss-Jordan pivot row only
-  p.col = o; o += NEWTON ? (8 * JS > 2 * G ? 8 * JS : 2 * G) : 2 * (NVR > G ? NVR : G);
+  // Newton: the blocked Cholesky's panel, right-hand side and block factors; CG: the double-buffered Gauss-Jordan pivot row only
+  p.col = o; o += NEWTON ? 5 * G + 12 * NV4 : 2 * (NVR > G ? NVR : G);  // (Newton: panel 4 G | vec G | save 12 NV4)
   // elliptic cones: per-row exchange lines (scaled Jaref / jv, the three quadratic-cost terms, the row's friction scale) through
   // which the rows of one contact see each other; Newton adds the cone Hessian block rows (6 words) + first row / size
   p.ex = o; o += ELL ? 6 * G * NR : 0;
@@ -718,7 +815,7 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
   // ---- qacc_smooth = M^-1 qfrc_smooth from the register-resident factor (the L'DL factor qLD is produced beside
   // the solver by k_factor_smooth).  CG: rows of M^-1, computed once per solve and reused as the preconditioner; it
   // also writes the public qacc_smooth.  Newton: only a cold start / an unconstrained world needs it (Cholesky of M).
-  float h[NVR], lt[NVR];  // Newton: H row / L row and L column; CG: h = row of M^-1
+  float h[NVR];  // Newton: H row, destroyed by the factorisation (rebuilt every iteration); CG: h = row of M^-1
   float qs = 0.0f;
   if (!NEWTON) {
     // (the J region is free until the rows are loaded below: it lends the 2 x 4 x NVR-word tile buffer)
@@ -740,9 +837,7 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
   } else if (nefc == 0 || !warm) {
 #pragma unroll
     for (int c = 0; c < NVR; ++c) h[c] = mrow[c];
-    float rdiag0;
-    chol_factor_rows<NVR, JS, G>(h, lt, rdiag0, col, lig);
-    qs = chol_solve_rows<NVR, G>(h, lt, rdiag0, fs);
+    qs = chol_factor_solve_g<NV4, G>(h, fs, col, col + 4 * G, col + 5 * G, lig);
     if (!active) qs = 0.0f;
   }
   float q = 0.0f;
@@ -979,9 +1074,7 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
           h[4 * c4 + 3] += jd0 * a4.w + jd1 * b4.w;
         }
       }
-      float rdiag;
-      chol_factor_rows<NVR, JS, G>(h, lt, rdiag, col, lig);
-      Mg = chol_solve_rows<NVR, G>(h, lt, rdiag, g);
+      Mg = chol_factor_solve_g<NV4, G>(h, g, col, col + 4 * G, col + 5 * G, lig);
       if (!active) Mg = 0.0f;
       srch = -Mg;
       search_dot = gsumg<G>(Mg * Mg);

@@ -58,11 +58,6 @@ __host__ __device__ inline int newton_min_pool(int njmax) {
   return (2 * 4 * NV4 > one ? 2 * 4 * NV4 : one);
 }
 
-DEV float rsqrt_nr(float pv) {  // v_rsq_f32 + one Newton step (~0.5 ulp), as chol_factor_rows
-  float inv = __builtin_amdgcn_rsqf(pv);
-  return inv * (1.5f - 0.5f * pv * inv * inv);
-}
-
 // x = H^-1 g by a blocked right-looking Cholesky with lane i owning row i (NVR <= 32) -- factorisation, forward and backward
 // substitution in one routine, nothing but the H row (NVR registers) held across it.
 //   h: row i of the SPD matrix on entry (the FULL row: the trailing block is kept symmetric), destroyed.  Lanes >= nv hold
