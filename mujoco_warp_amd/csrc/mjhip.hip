@@ -258,7 +258,7 @@ static int launch_mid(const MjhModel* m, const MjhData* d, bool sched, hipStream
   return MJH_OK;
 }
 // set by the fused STEP path when the solver launch also integrates (see euler_fusable)
-static thread_local bool g_fuse_euler = false;
+static thread_local int g_fuse_euler = 0;  // 1: explicit Euler, 2: implicitfast in the solver's epilogue
 // set by the fused path when the Newton riders run on the side stream (see side_stream)
 static thread_local bool g_riders_on_side = false;
 static int solve_supported(const MjhModel* m, const MjhData* d) {
@@ -284,7 +284,7 @@ static int launch_solve_any(const MjhModel* m, const MjhData* d, bool with_facto
   }
   if (m->solver == SOL_PGS) return launch_pgs(m, d, s);
   const bool newton = m->solver == SOL_NEWTON;
-  const int fe = g_fuse_euler ? 1 : 0;
+  const int fe = g_fuse_euler;
   const int all = 0x7fffffff;
   // the k_solve_plus instantiations live in their own translation units (host.hpp): pick by lanes per world and solver
   const bool ell = m->cone == CONE_ELLIPTIC && d->nmaxpyramid > 1;  // (condim 1 everywhere: the cone type is moot)
@@ -303,7 +303,7 @@ static int launch_solve_any(const MjhModel* m, const MjhData* d, bool with_facto
     // decides instead and the shorter chain of the unpaired kernel wins (1024 worlds: 88 vs 112 us, 2048: 103 vs 120, 3072: 122 vs 124)
     static const int wide_min_nv = getenv("MJH_CGW_MIN_NV") ? atoi(getenv("MJH_CGW_MIN_NV")) : 13;
     static const int wide_max_nworld = getenv("MJH_CGW_MAX_NWORLD") ? atoi(getenv("MJH_CGW_MAX_NWORLD")) : 3072;
-    const bool wide = !newton && !ell && m->nv >= wide_min_nv && d->nworld <= wide_max_nworld;
+    const bool wide = !newton && !ell && m->nv >= wide_min_nv && d->nworld <= wide_max_nworld && fe != 2;  // (its half rows of M do not serve the fused implicitfast update)
     // rows per lane (32 lanes per world): 2 covers 64 rows (humanoid, panda), 6 covers 192
     if (d->njmax <= 64) return wide ? launch_solve_cgw(m, d, with_factor, fe, s, -1, all) : s32(m, d, 2, with_factor, fe, s, -1, all);
     if (int rc = wide ? launch_solve_cgw(m, d, false, fe, s, -1, 64) : s32(m, d, 2, false, fe, s, -1, 64)) return rc;
@@ -595,14 +595,16 @@ static int run_stage(const MjhModel* m, const MjhData* d, int stage, hipStream_t
         return MJH_OK;
       }
       // fused step: four launches on the caller's stream (see "composite launches" above)
+      // (nv <= 32 only: beside the 64-lane solver of larger models the riders cost more than they save, G1 -3 %)
+      static const int side_nv = getenv("MJH_SIDE_NV") ? atoi(getenv("MJH_SIDE_NV")) : 32;  // developer knob
+      Side* side = (m->solver == SOL_NEWTON && m->nv <= side_nv && !(g_instr && g_instr->on)) ? side_stream() : nullptr;
       bool sched_done = false;
       { Scope sc(K_POS); TRY(launch_pos_plus(m, d, POS_KINEMATICS, POS_CRB, &sched_done, s)); }
       { Scope sc(K_MID); TRY(launch_mid(m, d, !sched_done, s)); }
       { Scope sc(K_OTHER); TRY(launch_sensor(m, d, 0, s)); }  // (no launch without sensors; before the solver, whose epilogue may integrate the state)
-      // (nv <= 32 only: beside the 64-lane solver of larger models the riders cost more than they save, G1 -3 %)
-      static const int side_nv = getenv("MJH_SIDE_NV") ? atoi(getenv("MJH_SIDE_NV")) : 32;  // developer knob
-      Side* side = (m->solver == SOL_NEWTON && m->nv <= side_nv && !(g_instr && g_instr->on)) ? side_stream() : nullptr;
       if (side) {
+        // (tried in round 3: forking the factor after k_fwd_pos, beside k_mid, with qacc_smooth as a separate solve after k_mid -- humanoid
+        // Newton + 1.5 %, Panda - 5 %: the extra launch and the slower k_mid cost more than the shorter join wait saves)
         HIPCHK(hipEventRecord(side->fork, s));
         HIPCHK(hipStreamWaitEvent(side->stream, side->fork, 0));
         TRY(launch_publish(m, d, side->stream));
@@ -612,14 +614,18 @@ static int run_stage(const MjhModel* m, const MjhData* d, int stage, hipStream_t
       // explicit Euler without activations: the velocity/position update is a few loads and stores per dof, done by the
       // solver's own epilogue (saves a launch); every other case keeps the integrator workgroups
       // (Newton: only when its riders run on the side stream -- otherwise the integrator launch exists anyway, for them)
-      const bool fuse_euler = stage == MJH_STAGE_STEP && m->integrator == INT_EULER && m->na == 0 && (m->solver == SOL_CG || side != nullptr) && m->nv <= 64 &&
-                              m->nsensor_acc == 0 &&  // (acceleration-stage sensors read qvel / qacc between the solver and the integrator)
-                              d->njmax <= 192 &&  // (beyond: some worlds go to the generic solver, which does not integrate)
-                              (m->disableflags & (DSBL_EULERDAMP | DSBL_DAMPER)) != 0;
+      const bool fusable = stage == MJH_STAGE_STEP && m->na == 0 && (m->solver == SOL_CG || side != nullptr) && m->nv <= 64 &&
+                           m->nsensor_acc == 0 &&  // (acceleration-stage sensors read qvel / qacc between the solver and the integrator)
+                           d->njmax <= 192;        // (beyond: some worlds go to the generic solver, which does not integrate)
+      // implicitfast without activations (round 3): the dense system (M + h D - h dA/dv) x = M qacc is solved from the M row the solver holds
+      static const bool no_fuse_impfast = getenv("MJH_NO_FUSE_IMPLICITFAST") != nullptr;  // developer knob (A/B)
+      const int fuse_euler = !fusable ? 0
+                             : (m->integrator == INT_EULER && (m->disableflags & (DSBL_EULERDAMP | DSBL_DAMPER)) != 0) ? 1
+                             : (m->integrator == INT_IMPLICITFAST && !no_fuse_impfast) ? 2 : 0;
       g_fuse_euler = fuse_euler;
       int rc;
       { Scope sc(K_SOLVE); rc = launch_solve_plus(m, d, s); }
-      g_fuse_euler = false;
+      g_fuse_euler = 0;
       TRY(rc);
       { Scope sc(K_OTHER); TRY(launch_sensor(m, d, 1, s)); }
       g_riders_on_side = side != nullptr;

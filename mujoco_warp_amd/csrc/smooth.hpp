@@ -219,6 +219,50 @@ DEV void mul_m_ld(const MStruct& ms, const float* M, const float* vec, float* re
   }
 }
 
+// -h d(qfrc_actuator)/d(qvel), the diagonal of implicitfast's system matrix beside the damping (derivative.py:1117 deriv_smooth_vel,
+// joint transmissions: gear^2 (bias_vel + gain_vel ctrl)), accumulated into `diag` -- an LDS line of >= nv floats, zeroed by the caller
+// and fenced (gsync) before and after.  One lane per ACTUATOR (the dof-major double loop costs nv x nu dependent table loads: measured
+// 40 % of the integrator kernel on the G1); contributions meet with LDS atomic adds, which is order-independent -- hence
+// deterministic -- as long as no dof has more than two actuators (float addition commutes); models beyond that keep the dof-major loop.
+template <int G>
+DEV void actuator_vel_diag(const MjhModel& m, const MjhData& d, int w, int lig, float h, float* diag) {
+  const int nu = m.nu, nv = m.nv;
+  const float* gear = bf(m.actuator_gear, m.actuator_gear_nb, w, 6 * nu);
+  auto act_dv = [&](int u, float& val) __attribute__((always_inline)) {
+    const float bias_vel = m.actuator_biastype[u] == 1 ? bf(m.actuator_biasprm, m.actuator_biasprm_nb, w, 10 * nu)[10 * u + 2] : 0.0f;
+    const float gain_vel = m.actuator_gaintype[u] == 1 ? bf(m.actuator_gainprm, m.actuator_gainprm_nb, w, 10 * nu)[10 * u + 2] : 0.0f;
+    // the RAW control, not the clamped one, multiplies the velocity gain (derivative.py:159-161, mjd_actuator_vel)
+    float ctrl = d.ctrl[(size_t)w * nu + u];
+    if (m.actuator_dyntype[u] != 0) ctrl = d.act[(size_t)w * m.na + m.actuator_actadr[u]];
+    const float dv = bias_vel + gain_vel * ctrl;
+    if (dv == 0.0f) return false;
+    if (m.actuator_forcelimited[u]) {
+      const float* fr = bf(m.actuator_forcerange, m.actuator_forcerange_nb, w, 2 * nu) + 2 * u;
+      const float f = d.actuator_force[(size_t)w * nu + u];
+      if (f <= fr[0] || f >= fr[1]) return false;
+    }
+    val = gear[6 * u] * gear[6 * u] * dv;
+    return true;
+  };
+  if (m.act_dof_max <= 2) {
+    for (int u = lig; u < nu; u += G) {
+      float val;
+      if (!act_dv(u, val)) continue;
+      atomicAdd(&diag[m.jnt_dofadr[m.actuator_trnid[2 * u]]], -h * val);
+    }
+  } else {
+    for (int i = lig; i < nv; i += G) {
+      float acc = 0.0f;
+      for (int u = 0; u < nu; ++u) {
+        float val;
+        if (m.jnt_dofadr[m.actuator_trnid[2 * u]] != i || !act_dv(u, val)) continue;
+        acc += val;
+      }
+      diag[i] -= h * acc;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------
 struct PosLayout {
   int qpos, xpos, xquat, xmat, xipos, ximat, xanchor, xaxis, scom, cinert, cdof, crb, M, L, dinv, total;

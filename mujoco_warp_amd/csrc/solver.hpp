@@ -246,6 +246,31 @@ DEV float chol_factor_solve_g(float (&h)[4 * NV4], float g, float* panel, float*
   return x;
 }
 
+// implicitfast fused into the solver's epilogue (round 3; forward.py:578-612, derivative.py:1117): x = (M + h D - h dA/dv)^-1 (M qacc) from
+// the register-resident row of M, for models without activations.  The integrator launch did this with the sparse L'DL factor of the
+// modified M -- a serial chain over the dofs -- and was 23 % of the Panda's step; here it is one blocked Cholesky of the dense row the
+// solver already holds.  `scratch`: 6 G + 12 NV4 floats of group-private LDS that nothing else uses any more.
+template <int NV4, int G>
+DEV float impfast_acc(const MjhModel& m, const MjhData& d, int w, int lig, bool active, const float (&mrow)[4 * NV4], float Ma, float* scratch) {
+  constexpr int NVR = 4 * NV4;
+  float *diag = scratch, *panel = scratch + G, *vec = panel + 4 * G, *save = vec + G;
+  const float h = bf(m.opt_timestep, m.opt_timestep_nb, w, 1)[0];
+  diag[lig] = 0.0f;
+  gsync();
+  if (!(m.disableflags & DSBL_ACTUATION)) actuator_vel_diag<G>(m, d, w, lig, h, diag);
+  gsync();
+  float dg = 0.0f;
+  if (active) {
+    dg = diag[lig];
+    if (!(m.disableflags & DSBL_DAMPER)) dg += h * bf(m.dof_damping, m.dof_damping_nb, w, m.nv)[lig];
+  }
+  float hh[NVR];
+#pragma unroll
+  for (int c = 0; c < NVR; ++c) hh[c] = mrow[c] + (c == lig ? dg : 0.0f);
+  const float x = chol_factor_solve_g<NV4, G>(hh, active ? Ma : 0.0f, panel, vec, save, lig);
+  return active ? x : 0.0f;
+}
+
 struct SolveLayout {
   int J, force, da, bsearch, bgrad, col, ex, cone, fl, total;
 };
@@ -257,7 +282,10 @@ __host__ __device__ inline SolveLayout solve_layout(int njmax) {
   const int njp = min(((njmax + 15) / 16) * 16, G * NR);
   SolveLayout p;
   int o = 0;
-  p.J = o; o += (njp > NVR ? njp : NVR) * JS;  // also stages the dense NVR x NVR copy of M
+  {  // also stages the dense NVR x NVR copy of M, and lends 6 G + 12 NV4 words to the fused implicitfast update
+    const int jw = (njp > NVR ? njp : NVR) * JS;
+    p.J = o; o += jw > 6 * G + 12 * NV4 ? jw : 6 * G + 12 * NV4;
+  }
   p.force = o; o += G * NR;                     // efc_force of the current iterate (for J^T f)
   p.da = o; o += NEWTON ? G * NR : 0;           // D * [state == QUADRATIC] (Newton: J^T D J)
   p.bsearch = o; o += G;                        // broadcast copies of the two nv-vectors other lanes read
@@ -290,8 +318,10 @@ DEV void row_force(int kind, float ja, float D, bool has_fl, const float* floss,
 // Explicit Euler step fused into the solver's epilogue (forward.py:387-417 without the implicit-damping branch, _advance
 // 276-349 for models without activations): lane i holds qacc[i]; `vbuf` is a group-private LDS line of >= nv floats.
 // Saves the integrator launch (~11 us per step) when the host knows the velocity update is explicit.
+// qacc_i: the acceleration the velocity update uses (the solver's qacc for Euler, the implicitfast solution otherwise); warm_i: the
+// solver's qacc, which becomes the next step's warm start either way.
 template <int G>
-DEV void euler_advance(const MjhModel& m, const MjhData& d, int w, int lig, bool active, float qacc_i, float* vbuf) {
+DEV void euler_advance(const MjhModel& m, const MjhData& d, int w, int lig, bool active, float qacc_i, float* vbuf, float warm_i) {
   const int nv = m.nv;
   const float h = bf(m.opt_timestep, m.opt_timestep_nb, w, 1)[0];
   const size_t vo = (size_t)w * nv;
@@ -299,7 +329,7 @@ DEV void euler_advance(const MjhModel& m, const MjhData& d, int w, int lig, bool
     const float v = d.qvel[vo + lig] + qacc_i * h;
     vbuf[lig] = v;
     d.qvel[vo + lig] = v;
-    d.qacc_warmstart[vo + lig] = qacc_i;
+    d.qacc_warmstart[vo + lig] = warm_i;
   }
   gsync();
   float* qpos = d.qpos + (size_t)w * m.nq;
@@ -854,7 +884,14 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
       d.efc_Ma[vo + lig] = Ma;
     }
     if (lig == 0 && !TREE) d.solver_niter[w] = 0;  // (TREE: k_tree_rows zeroed it; trees report with atomicMax)
-    if (fuse_euler && !TREE) euler_advance<G>(m, d, w, lig, active, q, bsearch);
+    if (fuse_euler && !TREE) {
+      float qi = q;
+      if (fuse_euler == 2) {
+        gsync();
+        qi = impfast_acc<NV4, G>(m, d, w, lig, active, mrow, Ma, Jl);
+      }
+      euler_advance<G>(m, d, w, lig, active, qi, bsearch, q);
+    }
     return;
   }
 
@@ -1318,7 +1355,9 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
   }
   if (fuse_euler && !TREE) {
     gsync();
-    euler_advance<G>(m, d, w, lig, active, q, bsearch);
+    float qi = q;
+    if (fuse_euler == 2) qi = impfast_acc<NV4, G>(m, d, w, lig, active, mrow, Ma, Jl);
+    euler_advance<G>(m, d, w, lig, active, qi, bsearch, q);
   }
   pc.mark(9);
 }

@@ -258,7 +258,7 @@ DEV void solve_cgw_body(const MjhModel& m, const MjhData& d, float* smem, const 
       d.efc_Ma[vo + ld] = Ma;
     }
     if (lig == 0) d.solver_niter[w] = 0;
-    if (fuse_euler) euler_advance<G>(m, d, w, lig, active && hf == 0, q, vbuf);
+    if (fuse_euler) euler_advance<G>(m, d, w, lig, active && hf == 0, q, vbuf, q);
     return;
   }
 
@@ -391,6 +391,6 @@ DEV void solve_cgw_body(const MjhModel& m, const MjhData& d, float* smem, const 
     d.solver_niter[w] = niter;
     if (ovf) atomicOr(d.overflow + w, ovf);
   }
-  if (fuse_euler) euler_advance<G>(m, d, w, lig, active && hf == 0, q, vbuf);
+  if (fuse_euler) euler_advance<G>(m, d, w, lig, active && hf == 0, q, vbuf, q);
   pc.mark(9);
 }

@@ -476,9 +476,12 @@ DEV void newton_pair(const MjhModel& m, const MjhData& d, float* S, const Newton
     d.solver_niter[w] = niter;
     if (ovf) atomicOr(d.overflow + w, ovf);
   }
-  if (fuse_euler && live) {
+  if (fuse_euler) {  // (wave-uniform: the blocked Cholesky of the implicitfast update runs in both halves, a parked world on identity rows)
     gsync();
-    euler_advance<G>(m, d, w, lig, active, q, bvec);
+    float qi = q;
+    // scratch: eforce | eda | bvec | panel are contiguous (288 floats >= 6 G + 12 NV4) and dead by now
+    if (fuse_euler == 2) qi = impfast_acc<NV4, G>(m, d, live ? w : 0, lig, active, mrow, Ma, eforce);
+    if (live) euler_advance<G>(m, d, w, lig, active, qi, bvec, q);
   }
   gsync();
   pc.mark(9);

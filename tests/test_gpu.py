@@ -98,6 +98,37 @@ def _check_solution(s, d, w=-1, tol=SOLVE):
   assert int(d.overflow.numpy()[ww]) == 0
 
 
+@pytest.mark.parametrize("model,solver", [("panda", mjw.SolverType.NEWTON), ("panda", mjw.SolverType.CG), ("g1", mjw.SolverType.CG)])
+def test_fused_implicitfast_equals_the_staged_integrator(model, solver):
+  """`step` solves implicitfast's dense system (M + h D - h dA/dv) x = M qacc in the solver's epilogue from the register-resident row of M
+  (csrc/solver.hpp impfast_acc) when the model has no activations; the stage API (`forward` then `implicit`) goes through the integrator
+  kernel's sparse L'DL factor.  Same update, two factorisations."""
+  mjm = mjw.mjcf.load_xml(conftest.PANDA_XML if model == "panda" else conftest.G1_XML)
+  mjm.opt.solver = int(solver)
+  assert int(mjm.opt.integrator) == int(mjw.IntegratorType.IMPLICITFAST) and mjm.na == 0
+  m = mjw.put_model(mjm)
+  nconmax, njmax = (8, 32) if model == "panda" else (48, 192)
+  d1 = mjw.make_data(mjm, nworld=5, nconmax=nconmax, njmax=njmax)
+  d2 = mjw.make_data(mjm, nworld=5, nconmax=nconmax, njmax=njmax)
+  if mjm.nkey:
+    for d in (d1, d2):
+      mjw.reset_data_keyframe(m, d, 0)
+  rng = np.random.default_rng(5)
+  for i in range(25):
+    ctrl = d1.ctrl.numpy() + rng.normal(scale=0.05, size=d1.ctrl.shape).astype(np.float32)
+    for name in ("qpos", "qvel", "qacc_warmstart", "time"):
+      getattr(d2, name).assign(getattr(d1, name).numpy())
+    d1.ctrl.assign(ctrl)
+    d2.ctrl.assign(ctrl)
+    mjw.step(m, d1)
+    mjw.forward(m, d2)
+    mjw.implicit(m, d2)
+    np.testing.assert_allclose(d1.qacc.numpy(), d2.qacc.numpy(), rtol=0, atol=1e-5 * max(1.0, np.abs(d2.qacc.numpy()).max()))
+    assert relerr(d1.qvel.numpy(), d2.qvel.numpy()) <= 2e-6, i
+    assert relerr(d1.qpos.numpy(), d2.qpos.numpy()) <= 1e-6, i
+    assert (d1.qacc_warmstart.numpy() == d1.qacc.numpy()).all()
+
+
 def test_cg_small_and_large_batch_kernels_both_match_oracle():
   """CG has two kernels (mjhip.hip launch_solve_any): one world per wavefront for batches of at most 3072 worlds (csrc/solver_cgw.hpp),
   two worlds per wavefront above (csrc/solver.hpp).  The same state through both: each within the oracle tolerance, and the same answer."""
