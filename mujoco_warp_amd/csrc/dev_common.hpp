@@ -90,7 +90,7 @@ DEV unsigned long long gballot(bool p) {
   if (G == 64) return b;
   const int wl = threadIdx.x & 63;
   const int base = wl & ~(G - 1);
-  return (b >> base) & ((1ull << G) - 1ull);
+  return (b >> base) & ((1ull << (G & 63)) - 1ull);  // (G == 64 returned above)
 }
 // ordered compaction helper: rank of this lane among set lanes of its group, and group total
 template <int G>

@@ -57,9 +57,19 @@ int pick_block(size_t shared_bytes, size_t per_world_bytes, int G, size_t* lds_o
   return best;
 }
 
-constexpr int G = 32;
+// Lanes per world of every kernel but the solvers (which choose their own): 32 -- two worlds per wavefront -- for models of at most 32 dofs
+// and bodies, 64 beyond (round 3): these kernels are chains of dependent steps whose loops stride over dofs / bodies / geoms by the
+// group size, so a model that needs two trips with 32 lanes needs one with 64 (three humanoids, nv 81: k_mid 690 -> 518 us, step + 22 %).
+static inline bool lanes64(const MjhModel* m) {
+  static const int force = getenv("MJH_LANES") ? atoi(getenv("MJH_LANES")) : 0;  // developer knob: 32 / 64
+  if (force) return force == 64;
+  // (models with GJK / EPA pairs stay at 32: Data.ws_ccd holds one polytope workspace per lane of a 32-lane group)
+  return (m->nv > 32 || m->nbody > 32) && !m->heavy_colliders;
+}
+// (k_fwd_pos: its loops run over bodies -- the G1, 35 dofs on 30 bodies, is 4 us slower with 64 lanes; three humanoids, 52 bodies, 25 us faster)
 
-static int launch_pos(const MjhModel* m, const MjhData* d, int first, int last, hipStream_t s) {
+template <int G>
+static int launch_pos_g(const MjhModel* m, const MjhData* d, int first, int last, hipStream_t s) {
   const PosLayout lay = pos_layout(m->nq, m->nv, m->nbody, m->njnt, m->nC, last >= POS_FACTOR);
   size_t lds;
   const int threads = pick_block(sizeof(int) * pos_shared_words(m->nv, m->nC, m->nbody, m->njnt, m->nbodylevel, m->ngeom, m->nsite), sizeof(float) * lay.total, G, &lds);
@@ -69,7 +79,9 @@ static int launch_pos(const MjhModel* m, const MjhData* d, int first, int last, 
   hipLaunchKernelGGL(k_fwd_pos<G>, dim3((d->nworld + wpb - 1) / wpb), dim3(threads), lds, s, *m, *d, first, last);
   return MJH_OK;
 }
-static int launch_vel(const MjhModel* m, const MjhData* d, int first, int last, hipStream_t s) {
+static int launch_pos(const MjhModel* m, const MjhData* d, int first, int last, hipStream_t s) { return lanes64(m) && m->nbody > 32 ? launch_pos_g<64>(m, d, first, last, s) : launch_pos_g<32>(m, d, first, last, s); }
+template <int G>
+static int launch_vel_g(const MjhModel* m, const MjhData* d, int first, int last, hipStream_t s) {
   const VelLayout lay = vel_layout(m->nq, m->nv, m->nbody, m->nC, m->nu);
   size_t lds;
   const int threads = pick_block(sizeof(int) * mstruct_ints(m->nv, m->nC), sizeof(float) * lay.total, G, &lds);
@@ -79,8 +91,10 @@ static int launch_vel(const MjhModel* m, const MjhData* d, int first, int last, 
   hipLaunchKernelGGL(k_fwd_vel<G>, dim3((d->nworld + wpb - 1) / wpb), dim3(threads), lds, s, *m, *d, first, last);
   return MJH_OK;
 }
+static int launch_vel(const MjhModel* m, const MjhData* d, int first, int last, hipStream_t s) { return lanes64(m) ? launch_vel_g<64>(m, d, first, last, s) : launch_vel_g<32>(m, d, first, last, s); }
 // public L'DL factor (qLD, qLDiagInv) and, on request, qacc_smooth: outputs nobody inside the step waits for
-static int launch_factor_smooth(const MjhModel* m, const MjhData* d, int write_qacc, hipStream_t s) {
+template <int G>
+static int launch_factor_smooth_g(const MjhModel* m, const MjhData* d, int write_qacc, hipStream_t s) {
   const FacLayout lay = fac_layout(m->nv, m->nC);
   size_t lds;
   const int threads = pick_block(sizeof(int) * mstruct_ints(m->nv, m->nC), sizeof(float) * lay.total, G, &lds);
@@ -90,7 +104,9 @@ static int launch_factor_smooth(const MjhModel* m, const MjhData* d, int write_q
   hipLaunchKernelGGL(k_factor_smooth<G>, dim3((d->nworld + wpb - 1) / wpb), dim3(threads), lds, s, *m, *d, write_qacc);
   return MJH_OK;
 }
-static int launch_collision(const MjhModel* m, const MjhData* d, hipStream_t s) {
+static int launch_factor_smooth(const MjhModel* m, const MjhData* d, int write_qacc, hipStream_t s) { return launch_factor_smooth_g<32>(m, d, write_qacc, s); }  // (chains over the sparse factor: more lanes per world only halve the worlds per wavefront)
+template <int G>
+static int launch_collision_g(const MjhModel* m, const MjhData* d, hipStream_t s) {
   size_t lds;
   const int threads = pick_block(0, sizeof(float) * collide_lds_words(m->ngeom, m->npair, d->concap, m->heavy_colliders ? m->broadphase : 0), G, &lds);
   if (!threads) return fail(MJH_E_UNSUPPORTED, "k_collision: pair list does not fit in LDS");
@@ -105,12 +121,16 @@ static int launch_collision(const MjhModel* m, const MjhData* d, hipStream_t s) 
   hipLaunchKernelGGL((k_collision<G, false>), dim3((d->nworld + wpb - 1) / wpb), dim3(threads), lds, s, *m, *d);
   return MJH_OK;
 }
+static int launch_collision(const MjhModel* m, const MjhData* d, hipStream_t s) { return lanes64(m) ? launch_collision_g<64>(m, d, s) : launch_collision_g<32>(m, d, s); }
 // compact public contact arrays, contact.efc_address and efc.id of contact rows from the per-world records
-static int launch_publish(const MjhModel* m, const MjhData* d, hipStream_t s) {
-  hipLaunchKernelGGL(k_publish_contacts<G>, dim3((d->nworld + 7) / 8), dim3(256), 0, s, *d, 1, m->nexplicit ? m->pair_solreffriction : nullptr);
+template <int G>
+static int launch_publish_g(const MjhModel* m, const MjhData* d, hipStream_t s) {
+  hipLaunchKernelGGL(k_publish_contacts<G>, dim3((d->nworld + 256 / G - 1) / (256 / G)), dim3(256), 0, s, *d, 1, m->nexplicit ? m->pair_solreffriction : nullptr);
   return MJH_OK;
 }
-static int launch_constraint(const MjhModel* m, const MjhData* d, hipStream_t s) {
+static int launch_publish(const MjhModel* m, const MjhData* d, hipStream_t s) { return launch_publish_g<32>(m, d, s); }  // (chains over the sparse factor: more lanes per world only halve the worlds per wavefront)
+template <int G>
+static int launch_constraint_g(const MjhModel* m, const MjhData* d, hipStream_t s) {
   const ConLayout lay = con_layout(m->nv, d->njmax, d->concap, m->nbody, m->ngeom);
   size_t lds;
   const int threads = pick_block(0, sizeof(float) * lay.total, G, &lds);
@@ -120,6 +140,7 @@ static int launch_constraint(const MjhModel* m, const MjhData* d, hipStream_t s)
   hipLaunchKernelGGL(k_make_constraint<G>, dim3((d->nworld + wpb - 1) / wpb), dim3(threads), lds, s, *m, *d);
   return MJH_OK;
 }
+static int launch_constraint(const MjhModel* m, const MjhData* d, hipStream_t s) { return lanes64(m) ? launch_constraint_g<64>(m, d, s) : launch_constraint_g<32>(m, d, s); }
 static int launch_sensor(const MjhModel* m, const MjhData* d, int stage, hipStream_t s) {  // stage 1: acceleration-stage sensors (after the solver)
   if (stage == 0 && ((m->enableflags & ENBL_ENERGY) || m->nsensor_energy > 0)) {  // Data.energy rides with the position / velocity stage sensors (forward.py:1326-1338)
     if (!d->energy) return fail(MJH_E_ARG, "Data.energy missing (allocate Data with make_data/put_data)");
@@ -150,7 +171,8 @@ static int launch_implicit(const MjhModel* m, const MjhData* d, hipStream_t s) {
   hipLaunchKernelGGL(k_implicit_solve<32>, dim3((d->nworld + wpb - 1) / wpb), dim3(32 * wpb), lds, s, *m, *d);
   return MJH_OK;
 }
-static int launch_integrate(const MjhModel* m, const MjhData* d, int mode, hipStream_t s) {
+template <int G>
+static int launch_integrate_g(const MjhModel* m, const MjhData* d, int mode, hipStream_t s) {
   if (mode == 2) TRY(launch_implicit(m, d, s));
   const IntLayout lay = int_layout(m->nv, m->nC);
   size_t lds;
@@ -161,6 +183,7 @@ static int launch_integrate(const MjhModel* m, const MjhData* d, int mode, hipSt
   hipLaunchKernelGGL(k_integrate<G>, dim3((d->nworld + wpb - 1) / wpb), dim3(threads), lds, s, *m, *d, mode);
   return MJH_OK;
 }
+static int launch_integrate(const MjhModel* m, const MjhData* d, int mode, hipStream_t s) { return launch_integrate_g<32>(m, d, mode, s); }  // (chains over the sparse factor: more lanes per world only halve the worlds per wavefront)
 
 // ---- composite launches of the fused step --------------------------------------------------------------------
 // Cross-stream fork/join costs 5-15 us per hop on the critical path (event record -> barrier packet -> dispatch),
@@ -222,18 +245,19 @@ __global__ void __launch_bounds__(256) k_fwd_pos_plus(MjhModel m, MjhData d, int
   }
 }
 
-static int launch_mid(const MjhModel* m, const MjhData* d, bool sched, hipStream_t s) {
+template <int G>
+static int launch_mid_g(const MjhModel* m, const MjhData* d, bool sched, hipStream_t s) {
   const ConLayout cl = con_layout(m->nv, d->njmax, d->concap, m->nbody, m->ngeom);
   const int stride_cc = std::max(cl.total, collide_lds_words(m->ngeom, m->npair, d->concap, m->heavy_colliders ? m->broadphase : 0) | 1);
   const VelLayout vl = vel_layout(m->nq, m->nv, m->nbody, m->nC, m->nu);
   const size_t ms_bytes = sizeof(int) * mstruct_ints(m->nv, m->nC);
   // 8 collision+constraint worlds per workgroup; as many fwd_vel worlds as fit in the same LDS footprint
-  int nw_cc = 8;
+  int nw_cc = 256 / G;
   while (nw_cc > 1 && sizeof(float) * stride_cc * nw_cc > (size_t)kLdsPerCU / 2) nw_cc >>= 1;
   size_t lds = sizeof(float) * stride_cc * nw_cc;
   int nw_v = (int)((lds > ms_bytes ? lds - ms_bytes : 0) / (sizeof(float) * vl.total));
   if (nw_v < 1) nw_v = 1;
-  if (nw_v > 8) nw_v = 8;
+  if (nw_v > 256 / G) nw_v = 256 / G;
   // an odd world count leaves half a wavefront slot empty: round up when the same number of workgroups still fits a CU
   if ((nw_v & 1) && nw_v < 8) {
     const size_t up = ms_bytes + sizeof(float) * vl.total * (nw_v + 1);
@@ -257,6 +281,7 @@ static int launch_mid(const MjhModel* m, const MjhData* d, bool sched, hipStream
   else hipLaunchKernelGGL((k_mid<G, false>), grid, block, lds, s, *m, *d, ncc, nvb, nw_cc, nw_v, stride_cc, sched ? 1 : 0);
   return MJH_OK;
 }
+static int launch_mid(const MjhModel* m, const MjhData* d, bool sched, hipStream_t s) { return lanes64(m) ? launch_mid_g<64>(m, d, sched, s) : launch_mid_g<32>(m, d, sched, s); }
 // set by the fused STEP path when the solver launch also integrates (see euler_fusable)
 static thread_local int g_fuse_euler = 0;  // 1: explicit Euler, 2: implicitfast in the solver's epilogue
 // set by the fused path when the Newton riders run on the side stream (see side_stream)
@@ -322,15 +347,16 @@ static int launch_solve_any(const MjhModel* m, const MjhData* d, bool with_facto
 static int launch_solve(const MjhModel* m, const MjhData* d, hipStream_t s) { return launch_solve_any(m, d, false, s); }
 static int launch_solve_plus(const MjhModel* m, const MjhData* d, hipStream_t s) { return launch_solve_any(m, d, true, s); }
 // integrator (optional) + publication of the contact arrays + solver schedule
-static int launch_integrate_plus(const MjhModel* m, const MjhData* d, int mode, bool integrate, hipStream_t s) {
+template <int G>
+static int launch_integrate_plus_g(const MjhModel* m, const MjhData* d, int mode, bool integrate, hipStream_t s) {
   const IntLayout lay = int_layout(m->nv, m->nC);
   const FacLayout fl = fac_layout(m->nv, m->nC);
   const size_t ms_bytes = sizeof(int) * mstruct_ints(m->nv, m->nC);
   const bool with_factor = (m->solver != SOL_CG || m->nv > 64) && !g_riders_on_side;
-  size_t lds = std::max(ms_bytes + sizeof(float) * std::max(lay.total, fl.total) * 8, (size_t)2048);
+  size_t lds = std::max(ms_bytes + sizeof(float) * std::max(lay.total, fl.total) * (256 / G), (size_t)2048);
   if (lds > (size_t)kLdsPerCU) return fail(MJH_E_UNSUPPORTED, "k_integrate: does not fit in LDS");
   HIPCHK(set_lds(k_integrate_plus<G>, lds));
-  const int nb = (d->nworld + 7) / 8;
+  const int nb = (d->nworld + 256 / G - 1) / (256 / G);
   // Newton: publication and factor workgroups ride here; CG: they already rode with the solver launch
   const int nint = integrate ? nb : 0, npub = with_factor ? nb : 0, nfac = with_factor ? nb : 0;
   if (nint + npub + nfac == 0) return MJH_OK;
@@ -339,11 +365,13 @@ static int launch_integrate_plus(const MjhModel* m, const MjhData* d, int mode, 
   hipLaunchKernelGGL(k_integrate_plus<G>, dim3(nint + npub + nfac), dim3(256), lds, s, *m, *d, mode, nint, npub);
   return MJH_OK;
 }
+static int launch_integrate_plus(const MjhModel* m, const MjhData* d, int mode, bool integrate, hipStream_t s) { return launch_integrate_plus_g<32>(m, d, mode, integrate, s); }  // (chains over the sparse factor: more lanes per world only halve the worlds per wavefront)
 // *sched_done: whether the launch carried the schedule workgroup (it needs >= 128 threads to be quick; otherwise it
 // rides with k_mid, whose workgroups always have 256)
 // control noise queued by mjh_timed_steps for the next fused step: it rides with that step's first launch
 static thread_local NoiseArgs g_noise = {0, 0, 0.0f, 0.0f, nullptr};
-static int launch_pos_plus(const MjhModel* m, const MjhData* d, int first, int last, bool* sched_done, hipStream_t s) {
+template <int G>
+static int launch_pos_plus_g(const MjhModel* m, const MjhData* d, int first, int last, bool* sched_done, hipStream_t s) {
   const NoiseArgs noise = g_noise;
   g_noise.n = 0;
   const PosLayout lay = pos_layout(m->nq, m->nv, m->nbody, m->njnt, m->nC, last >= POS_FACTOR);
@@ -362,6 +390,7 @@ static int launch_pos_plus(const MjhModel* m, const MjhData* d, int first, int l
   hipLaunchKernelGGL(k_fwd_pos_plus<G>, dim3(npos + 1 + nnoise), dim3(threads), lds, s, *m, *d, first, last, npos, noise);
   return MJH_OK;
 }
+static int launch_pos_plus(const MjhModel* m, const MjhData* d, int first, int last, bool* sched_done, hipStream_t s) { return lanes64(m) && m->nbody > 32 ? launch_pos_plus_g<64>(m, d, first, last, sched_done, s) : launch_pos_plus_g<32>(m, d, first, last, sched_done, s); }
 
 
 static int check(const MjhModel* m, const MjhData* d) {
@@ -565,7 +594,7 @@ static int run_stage(const MjhModel* m, const MjhData* d, int stage, hipStream_t
       for (int k = 0; k < 4; ++k) {
         if (k) TRY(run_stage(m, d, MJH_STAGE_FORWARD, s));
         Scope sc(K_INTEGRATE);
-        hipLaunchKernelGGL(k_rk4<G>, dim3((d->nworld + 7) / 8), dim3(8 * G), sizeof(float) * 8 * (m->nv + 1), s, *m, *d, k, A[k], B[k]);
+        hipLaunchKernelGGL(k_rk4<32>, dim3((d->nworld + 7) / 8), dim3(8 * 32), sizeof(float) * 8 * (m->nv + 1), s, *m, *d, k, A[k], B[k]);
       }
       return MJH_OK;
     }
@@ -640,6 +669,20 @@ static int run_stage(const MjhModel* m, const MjhData* d, int stage, hipStream_t
   }
 }
 
+template <int G>
+static int launch_solve_m_g(const MjhModel* m, const MjhData* d, float* x, const float* y, int mul, hipStream_t s) {
+  const IntLayout lay = int_layout(m->nv, m->nC);
+  size_t lds;
+  const int threads = pick_block(sizeof(int) * mstruct_ints(m->nv, m->nC), sizeof(float) * lay.total, G, &lds);
+  if (!threads) return fail(MJH_E_UNSUPPORTED, "k_solve_m: does not fit in LDS");
+  HIPCHK(set_lds(k_solve_m<G>, lds));
+  const int wpb = threads / G;
+  hipLaunchKernelGGL(k_solve_m<G>, dim3((d->nworld + wpb - 1) / wpb), dim3(threads), lds, s, *m, *d, x, y, mul);
+  HIPCHK(hipGetLastError());
+  return MJH_OK;
+}
+static int launch_solve_m(const MjhModel* m, const MjhData* d, float* x, const float* y, int mul, hipStream_t s) { return launch_solve_m_g<32>(m, d, x, y, mul, s); }  // (chains over the sparse factor: more lanes per world only halve the worlds per wavefront)
+
 // the C ABI is the only exported surface (the library is built with -fvisibility=hidden)
 #pragma GCC visibility push(default)
 extern "C" {
@@ -656,17 +699,6 @@ int mjh_stage(const MjhModel* m, const MjhData* d, int stage, void* stream) {
 int mjh_step(const MjhModel* m, const MjhData* d, void* stream) { return mjh_stage(m, d, MJH_STAGE_STEP, stream); }
 int mjh_forward(const MjhModel* m, const MjhData* d, void* stream) { return mjh_stage(m, d, MJH_STAGE_FORWARD, stream); }
 
-static int launch_solve_m(const MjhModel* m, const MjhData* d, float* x, const float* y, int mul, hipStream_t s) {
-  const IntLayout lay = int_layout(m->nv, m->nC);
-  size_t lds;
-  const int threads = pick_block(sizeof(int) * mstruct_ints(m->nv, m->nC), sizeof(float) * lay.total, G, &lds);
-  if (!threads) return fail(MJH_E_UNSUPPORTED, "k_solve_m: does not fit in LDS");
-  HIPCHK(set_lds(k_solve_m<G>, lds));
-  const int wpb = threads / G;
-  hipLaunchKernelGGL(k_solve_m<G>, dim3((d->nworld + wpb - 1) / wpb), dim3(threads), lds, s, *m, *d, x, y, mul);
-  HIPCHK(hipGetLastError());
-  return MJH_OK;
-}
 int mjh_solve_m(const MjhModel* m, const MjhData* d, float* x, const float* y, void* stream) {
   TRY(check(m, d));
   return launch_solve_m(m, d, x, y, 0, (hipStream_t)stream);
