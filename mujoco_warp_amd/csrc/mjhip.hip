@@ -293,6 +293,33 @@ static int solve_supported(const MjhModel* m, const MjhData* d) {
     return fail(MJH_E_UNSUPPORTED, "njmax > 192 with the register / LDS resident PGS kernels is not supported (nv <= 64, pyramidal)");
   return MJH_OK;
 }
+// Two auxiliary streams per host thread and device for the solver variants of the per-island dispatch (nv > 64): the rare island classes and
+// the generic solver touch islands / worlds the common-class launch skips, so they run beside it instead of after it.  Released by
+// mjh_release_thread_resources().
+struct Aux {
+  hipStream_t stream[2];
+  hipEvent_t fork, join[2];
+};
+static thread_local Aux* g_aux_per_dev[16] = {nullptr};
+static thread_local bool g_serial_solver = false;  // set while per-kernel instrumentation is on (one stream, one event pair per launch)
+static Aux* aux_streams() {
+  static const bool disabled = getenv("MJH_NO_AUX") != nullptr;  // developer knob
+  if (disabled || g_serial_solver) return nullptr;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  if (!g_aux_per_dev[dev]) {
+    Aux* a = new Aux();
+    bool ok = hipEventCreateWithFlags(&a->fork, hipEventDisableTiming) == hipSuccess;
+    for (int k = 0; k < 2 && ok; ++k)
+      ok = hipStreamCreateWithFlags(&a->stream[k], hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&a->join[k], hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+      delete a;  // (a partially created set leaks a handle or two: only on an already failing device)
+      return nullptr;
+    }
+    g_aux_per_dev[dev] = a;
+  }
+  return g_aux_per_dev[dev];
+}
 static int launch_solve_any(const MjhModel* m, const MjhData* d, bool with_factor, hipStream_t s) {
   if (int rc = solve_supported(m, d)) return rc;
   if (m->nv > 64) {  // no riders: they go with the integrator launch
@@ -303,7 +330,22 @@ static int launch_solve_any(const MjhModel* m, const MjhData* d, bool with_facto
       hipLaunchKernelGGL(k_isl_clear, dim3(1), dim3(64), 0, s, *d);
       hipLaunchKernelGGL(k_tree_rows, dim3(d->nworld), dim3(64), sizeof(int) * (size_t)(2 * std::max(d->njmax, 1) + 2 * m->ntree), s, *m, *d);
       const bool ell_t = m->cone == CONE_ELLIPTIC && d->nmaxpyramid > 1;
-      if (int rc = (m->solver == SOL_NEWTON ? (ell_t ? launch_solve_tree_newton_ell : launch_solve_tree_newton) : (ell_t ? launch_solve_tree_cg_ell : launch_solve_tree_cg))(m, d, s)) return rc;
+      Aux* aux = aux_streams();
+      hipStream_t s1 = aux ? aux->stream[0] : s, s2 = aux ? aux->stream[1] : s;
+      if (aux) {
+        HIPCHK(hipEventRecord(aux->fork, s));
+        HIPCHK(hipStreamWaitEvent(s1, aux->fork, 0));
+        HIPCHK(hipStreamWaitEvent(s2, aux->fork, 0));
+      }
+      int rc = (m->solver == SOL_NEWTON ? (ell_t ? launch_solve_tree_newton_ell : launch_solve_tree_newton) : (ell_t ? launch_solve_tree_cg_ell : launch_solve_tree_cg))(m, d, s, s1);
+      if (!rc) rc = launch_solve_big(m, d, s2);
+      if (aux) {  // (every fork rejoins the caller's stream, also on the error path: the streams may be under capture)
+        for (int k = 0; k < 2; ++k) {
+          HIPCHK(hipEventRecord(aux->join[k], aux->stream[k]));
+          HIPCHK(hipStreamWaitEvent(s, aux->join[k], 0));
+        }
+      }
+      return rc;
     }
     return launch_solve_big(m, d, s);
   }
@@ -772,6 +814,19 @@ int mjh_release_thread_resources(void) {
   // the calling thread's side streams and events (one set per device it stepped a Newton model on)
   int rc = MJH_OK;
   for (int dev = 0; dev < 16; ++dev) {
+    Aux* a = g_aux_per_dev[dev];
+    if (a) {
+      g_aux_per_dev[dev] = nullptr;
+      for (int k = 0; k < 2; ++k) {
+        if (hipStreamSynchronize(a->stream[k]) != hipSuccess) rc = MJH_E_LAUNCH;
+        if (hipEventDestroy(a->join[k]) != hipSuccess) rc = MJH_E_LAUNCH;
+        if (hipStreamDestroy(a->stream[k]) != hipSuccess) rc = MJH_E_LAUNCH;
+      }
+      if (hipEventDestroy(a->fork) != hipSuccess) rc = MJH_E_LAUNCH;
+      delete a;
+    }
+  }
+  for (int dev = 0; dev < 16; ++dev) {
     Side* sd = g_side_per_dev[dev];
     if (!sd) continue;
     g_side_per_dev[dev] = nullptr;
@@ -820,6 +875,7 @@ int mjh_timed_steps(const MjhModel* m, const MjhData* d, int nstep, int step0, f
   instr.on = per_kernel_ms != nullptr;
   instr.plain = plain_kernels != 0;
   g_instr = &instr;
+  g_serial_solver = instr.on;
   hipEvent_t t0, t1;
   HIPCHK(hipEventCreate(&t0));
   HIPCHK(hipEventCreate(&t1));
@@ -840,6 +896,7 @@ int mjh_timed_steps(const MjhModel* m, const MjhData* d, int nstep, int step0, f
   if (e == hipSuccess) e = hipEventSynchronize(t1);
   if (e == hipSuccess) e = instr.err;
   g_instr = nullptr;
+  g_serial_solver = false;
   float ms = 0.0f;
   hipEventElapsedTime(&ms, t0, t1);
   if (ms_out) *ms_out = ms;
