@@ -141,6 +141,14 @@ static int launch_constraint_g(const MjhModel* m, const MjhData* d, hipStream_t 
   return MJH_OK;
 }
 static int launch_constraint(const MjhModel* m, const MjhData* d, hipStream_t s) { return lanes64(m) ? launch_constraint_g<64>(m, d, s) : launch_constraint_g<32>(m, d, s); }
+static int launch_subtree_vel(const MjhModel* m, const MjhData* d, hipStream_t s) {
+  const int wpb = subtree_vel_wpb(m->nbody);
+  if (!wpb) return fail(MJH_E_UNSUPPORTED, "k_subtree_vel: nbody does not fit in LDS");
+  const size_t lds = sizeof(float) * 9 * m->nbody * wpb;
+  HIPCHK(set_lds(k_subtree_vel<32>, lds));
+  hipLaunchKernelGGL(k_subtree_vel<32>, dim3((d->nworld + wpb - 1) / wpb), dim3(32 * wpb), lds, s, *m, *d);
+  return MJH_OK;
+}
 static int launch_sensor(const MjhModel* m, const MjhData* d, int stage, hipStream_t s) {  // stage 1: acceleration-stage sensors (after the solver)
   if (stage == 0 && ((m->enableflags & ENBL_ENERGY) || m->nsensor_energy > 0)) {  // Data.energy rides with the position / velocity stage sensors (forward.py:1326-1338)
     if (!d->energy) return fail(MJH_E_ARG, "Data.energy missing (allocate Data with make_data/put_data)");
@@ -153,7 +161,7 @@ static int launch_sensor(const MjhModel* m, const MjhData* d, int stage, hipStre
   }
   if (stage == 0 && m->nsensor_subtree > 0) {
     if (!d->subtree_linvel || !d->subtree_angmom) return fail(MJH_E_ARG, "Data.subtree_linvel / subtree_angmom missing");
-    hipLaunchKernelGGL(k_subtree_vel, dim3((d->nworld + 63) / 64), dim3(64), 0, s, *m, *d);
+    TRY(launch_subtree_vel(m, d, s));
   }
   if (!d->sensordata) return fail(MJH_E_ARG, "Data.sensordata missing (allocate Data with make_data/put_data)");
   hipLaunchKernelGGL(k_sensor, dim3((d->nworld * m->nsensor + 255) / 256), dim3(256), 0, s, *m, *d, stage);
@@ -603,7 +611,7 @@ static int run_stage(const MjhModel* m, const MjhData* d, int stage, hipStream_t
     case MJH_STAGE_SUBTREE_VEL: {
       if (!d->subtree_linvel || !d->subtree_angmom) return fail(MJH_E_ARG, "Data.subtree_linvel / subtree_angmom missing");
       Scope sc(K_OTHER);
-      hipLaunchKernelGGL(k_subtree_vel, dim3((d->nworld + 63) / 64), dim3(64), 0, s, *m, *d);
+      TRY(launch_subtree_vel(m, d, s));
       return MJH_OK;
     }
     case MJH_STAGE_ENERGY: {
@@ -678,8 +686,15 @@ static int run_stage(const MjhModel* m, const MjhData* d, int stage, hipStream_t
         // Newton + 1.5 %, Panda - 5 %: the extra launch and the slower k_mid cost more than the shorter join wait saves)
         HIPCHK(hipEventRecord(side->fork, s));
         HIPCHK(hipStreamWaitEvent(side->stream, side->fork, 0));
-        TRY(launch_publish(m, d, side->stream));
-        TRY(launch_factor_smooth(m, d, 1, side->stream));
+        // both riders as roles of ONE launch (k_integrate_plus without integrator workgroups): their two chains overlap and one launch gap
+        // goes (round 3, same-box A/B in two interleaved pairs: humanoid Newton 0.2842 -> 0.2829 / 0.2835 -> 0.2822 ms, Panda 142.9 -> 142.0 us)
+        static const bool side_two = getenv("MJH_SIDE_TWO") != nullptr;  // developer knob (A/B): the two plain kernels of round 2
+        if (!side_two) {
+          TRY(launch_integrate_plus(m, d, mode, false, side->stream));
+        } else {
+          TRY(launch_publish(m, d, side->stream));
+          TRY(launch_factor_smooth(m, d, 1, side->stream));
+        }
         HIPCHK(hipEventRecord(side->join, side->stream));
       }
       // explicit Euler without activations: the velocity/position update is a few loads and stores per dof, done by the

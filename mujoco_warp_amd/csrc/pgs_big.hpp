@@ -17,8 +17,12 @@
 #pragma once
 #include "solver.hpp"
 
+#define PGSB_MAXWAVES 8
+// ctl words: 0 state (1: nothing to solve) | 1 compact | 2 packed elements | 8.. list bounds [PGSB_MAXWAVES + 1] | 24.. improvement partials
+// [2][PGSB_MAXWAVES] | 48.. tree labels [64] | 112.. tree group / row counts [64]
+#define PGSB_CTL 176
 struct PgsBigLayout {
-  int q, qs, tmp, force, aref, R, Ad, mu, info, tmask, blk, xs, M, L, dinv, total;
+  int q, qs, tmp, force, aref, R, Ad, mu, info, tmask, blk, coff, rlist, ctl, xs, M, L, dinv, total;
 };
 __host__ __device__ inline PgsBigLayout pgs_big_layout(int nv, int nC, int njmax, bool ell) {
   PgsBigLayout p;
@@ -34,6 +38,9 @@ __host__ __device__ inline PgsBigLayout pgs_big_layout(int nv, int nC, int njmax
   p.tmask = o; o += 2 * njmax;          // kinematic trees a row touches (bit t of a 64-bit mask; trees >= 64 set every bit: full range)
   p.info = o; o += njmax;               // row kind: 0 equality, 1 friction loss, 2 limit / contact, 8 + dim: first row of an elliptic contact, 7: its other rows
   p.blk = o; o += ell ? 6 * njmax : 0;  // row r of an elliptic contact starting at r0: (A + R)[r][r0 .. r0 + 5]
+  p.coff = o; o += njmax + 1;           // compact rows (see "compact rows" below): first element of row r in the packed arrays
+  p.rlist = o; o += njmax;              // the sweep's visits (first rows of blocks) grouped by wavefront (see "islands")
+  p.ctl = o; o += PGSB_CTL;             // hand-over from the set-up wavefront to the sweep: flags, island labels, list bounds, improvement sums
   p.xs = o; o += (65 * nv > 2 * njmax ? 65 * nv : 2 * njmax);  // 64 right-hand sides of the batched sparse solves, [dof][65]; later two row vectors
   p.M = o; o += nC;
   p.L = o; o += nC;
@@ -131,17 +138,28 @@ DEV void qcqp5(int n, const float (&A)[5][5], const float (&b)[5], const float (
 
 template <int G>
 DEV void pgs_big_body(const MjhModel& m, const MjhData& d, float* smem, int w) {
-  static_assert(G == 64, "one world per wavefront");
+  static_assert(G == 64, "wavefront-wide row updates");
   const int nv = m.nv, nC = m.nC, njmax = d.njmax, nvp = d.nv_pad;
   const bool ell = m.cone == CONE_ELLIPTIC && d.nmaxpyramid > 1;
   const PgsBigLayout lay = pgs_big_layout(nv, nC, njmax, ell);
   int* shi = reinterpret_cast<int*>(smem);
-  const MStruct ms = load_mstruct<G>(m, shi, G);
+  const MStruct ms = load_mstruct<G>(m, shi, blockDim.x);  // (whole workgroup; ends with a barrier)
   const int lig = threadIdx.x & (G - 1);
+  // One world per workgroup of up to PGSB_MAXWAVES wavefronts (round 3).  Wavefront 0 sets the problem up; the sweeps then run on all
+  // wavefronts: rows of different constraint islands do not interact (A is block diagonal over islands), so Gauss-Seidel over the rows of
+  // one island group is independent of the other groups -- each wavefront sweeps the rows of its own group of islands in row order, which
+  // leaves every island's iterates exactly those of the sequential sweep.  The convergence test stays the model-wide one (improvement summed
+  // over the groups after every sweep).
+  const int wv = threadIdx.x >> 6, nwv = min((int)(blockDim.x >> 6), PGSB_MAXWAVES);
   float* S = smem + mstruct_ints(nv, nC);
   float *q = S + lay.q, *qs = S + lay.qs, *tmp = S + lay.tmp, *force = S + lay.force, *aref = S + lay.aref, *Rr = S + lay.R, *Ad = S + lay.Ad,
         *rmu = S + lay.mu, *blk = S + lay.blk, *xs = S + lay.xs, *Ml = S + lay.M, *Ll = S + lay.L, *dinv = S + lay.dinv;
   int* info = reinterpret_cast<int*>(S + lay.info);
+  int* coff = reinterpret_cast<int*>(S + lay.coff);
+  int* rlist = reinterpret_cast<int*>(S + lay.rlist);
+  int* ctl = reinterpret_cast<int*>(S + lay.ctl);
+  int* ladr = ctl + 8;
+  float* imp = S + lay.ctl + 24;
   unsigned* tmask = reinterpret_cast<unsigned*>(S + lay.tmask);
   const int ntree = m.ntree;
   const bool sparse_rows = ntree > 1 && ntree <= 64;  // rows touch one or two trees: the sweep visits those dof ranges only
@@ -150,6 +168,8 @@ DEV void pgs_big_body(const MjhModel& m, const MjhData& d, float* smem, int w) {
   const float* Jg = d.efc_J + (size_t)w * d.njmax_pad * nvp;
   float* Bg = d.ws_pgsB + (size_t)w * d.njmax_pad * nvp;
 
+  if (wv == 0) [&]() __attribute__((always_inline)) {  // ---- set-up (wavefront 0; `return` leaves the set-up only) --------------------------
+  if (lig == 0) ctl[0] = 1;
   // ---- M, sparse factor, qacc_smooth ------------------------------------------------------------------------------------------
   gcopy<G>(Ml, d.M + (size_t)w * nC, nC, lig);
   gcopy<G>(Ll, d.M + (size_t)w * nC, nC, lig);
@@ -340,6 +360,182 @@ DEV void pgs_big_body(const MjhModel& m, const MjhData& d, float* smem, int w) {
     for (int r = lig; r < nefc; r += G) force[r] = 0.0f;
   gsync();
 
+  // ---- compact rows (round 3) ---------------------------------------------------------------------------------------------------------
+  // A sweep visits the rows one after the other and every visit used to start with a round trip to L2 for the row of J and end with one
+  // for the row of B -- 2 x nefc x sweeps dependent global loads per solve (clutter_synth: 50 k).  A row is non-zero on the dofs of the one or
+  // two kinematic trees it touches only, so the non-zero parts of J and B (and their column indices) of all rows are packed once into the LDS
+  // region the B build used for its right-hand sides: element l of row r sits at coff[r] + l and belongs to lane l.  The sweep then runs on
+  // LDS alone.  Falls back to the global rows when a row touches more than 64 dofs or the packed rows do not fit.
+  bool compact = sparse_rows;
+  int tot_c = 0;
+  if (compact) {
+    const int xs_words = (65 * nv > 2 * njmax ? 65 * nv : 2 * njmax);
+    if (ell) {  // the rows of an elliptic contact are updated together: give them one column set (the union of their trees)
+      for (int r0 = 0; r0 < nefc; r0 += G) {
+        const int r = r0 + lig;
+        unsigned m0 = 0u, m1 = 0u;
+        int dim = 0;
+        if (r < nefc && info[r] >= 8) {
+          dim = info[r] - 8;
+          for (int a = 0; a < dim; ++a) {
+            m0 |= tmask[2 * (r + a)];
+            m1 |= tmask[2 * (r + a) + 1];
+          }
+        }
+        gsync();
+        for (int a = 0; a < dim; ++a) {
+          tmask[2 * (r + a)] = m0;
+          tmask[2 * (r + a) + 1] = m1;
+        }
+        gsync();
+      }
+    }
+    int tot = 0, widest = 0;
+    for (int r0 = 0; r0 < nefc; r0 += G) {  // lane = row: its element count, then an exclusive scan over the batch
+      const int r = r0 + lig;
+      int n = 0;
+      if (r < nefc) {
+        unsigned long long mk = (unsigned long long)tmask[2 * r] | ((unsigned long long)tmask[2 * r + 1] << 32);
+        while (mk) {
+          n += m.tree_dofnum[__builtin_ctzll(mk)];
+          mk &= mk - 1;
+        }
+      }
+      int inc = n;
+#pragma unroll
+      for (int off = 1; off < G; off <<= 1) {
+        const int t = __shfl_up(inc, off, G);
+        if (lig >= off) inc += t;
+      }
+      if (r < nefc) coff[r] = tot + inc - n;
+      tot += __shfl(inc, G - 1, G);
+      widest = max(widest, n);
+    }
+    widest = max(widest, __shfl_xor(widest, 32, G));
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) widest = max(widest, __shfl_xor(widest, off, G));
+    if (lig == 0) coff[nefc] = tot;
+    compact = widest <= G && 3 * tot <= xs_words;
+    tot_c = tot;
+    gsync();
+    if (compact) {
+      float *Jc = xs, *Bc = xs + tot;
+      int* colc = reinterpret_cast<int*>(xs + 2 * tot);
+#pragma unroll 4
+      for (int r = 0; r < nefc; ++r) {
+        const int o = coff[r], n = coff[r + 1] - o;
+        unsigned long long mk = (unsigned long long)tmask[2 * r] | ((unsigned long long)tmask[2 * r + 1] << 32);
+        int base = 0, col = -1;
+        while (mk) {
+          const int t = __builtin_ctzll(mk);
+          mk &= mk - 1;
+          const int a0 = m.tree_dofadr[t], n0 = m.tree_dofnum[t];
+          if (lig >= base && lig < base + n0) col = a0 + lig - base;
+          base += n0;
+        }
+        if (lig < n) {
+          Jc[o + lig] = Jg[(size_t)r * nvp + col];
+          Bc[o + lig] = Bg[(size_t)r * nvp + col];
+          colc[o + lig] = col;
+        }
+      }
+      gsync();
+    }
+  }
+
+  // ---- islands: the sweep's visits (scalar rows, first rows of elliptic contacts) grouped by wavefront ------------------------------------
+  // Trees joined by a row belong to one island (min-label propagation over the rows' tree masks, as k_tree_rows does for CG / Newton); islands
+  // go to the wavefront with the fewest rows so far; every wavefront gets the visits of its islands in row order.  Without tree masks (one
+  // tree, or more than 64) and without packed rows everything stays on wavefront 0.
+  int* lab = ctl + 48;
+  int* grp = ctl + 112;
+  const bool split = compact && nwv > 1;
+  if (split) {
+    if (lig < ntree) lab[lig] = lig;
+    gsync();
+    for (int pass = 0; pass < ntree; ++pass) {
+      bool changed = false;
+      for (int r = lig; r < nefc; r += G) {
+        unsigned long long mk = (unsigned long long)tmask[2 * r] | ((unsigned long long)tmask[2 * r + 1] << 32);
+        if (mk & (mk - 1)) {  // two trees or more
+          int lo = ntree;
+          for (unsigned long long t = mk; t; t &= t - 1) lo = min(lo, lab[__builtin_ctzll(t)]);
+          for (unsigned long long t = mk; t; t &= t - 1) {
+            const int u = __builtin_ctzll(t);
+            if (lab[u] > lo) {
+              atomicMin(&lab[u], lo);
+              changed = true;
+            }
+          }
+        }
+      }
+      gsync();
+      if (lig < ntree) lab[lig] = lab[lab[lig]];
+      gsync();
+      if (!__any(changed)) break;
+    }
+    if (lig < ntree) grp[lig] = 0;
+    gsync();
+    for (int r = lig; r < nefc; r += G) {  // rows per island (at its root tree)
+      const unsigned long long mk = (unsigned long long)tmask[2 * r] | ((unsigned long long)tmask[2 * r + 1] << 32);
+      if (mk) atomicAdd(&grp[lab[__builtin_ctzll(mk)]], 1);
+    }
+    gsync();
+    if (lig == 0) {  // islands in tree order, each to the least loaded wavefront (a handful of islands: serial)
+      int load[PGSB_MAXWAVES];
+#pragma unroll
+      for (int k = 0; k < PGSB_MAXWAVES; ++k) load[k] = 0;
+      for (int t = 0; t < ntree; ++t) {
+        if (lab[t] != t) continue;
+        int best = 0;
+#pragma unroll
+        for (int k = 1; k < PGSB_MAXWAVES; ++k)
+          if (k < nwv && load[k] < load[best]) best = k;
+#pragma unroll
+        for (int k = 0; k < PGSB_MAXWAVES; ++k)
+          if (k == best) load[k] += grp[t];
+        grp[t] = -1 - best;  // (negative: a group, no longer a count)
+      }
+    }
+    gsync();
+    if (lig < ntree) lab[lig] = -1 - grp[lab[lig]];  // tree -> wavefront (every root's entry is final: read before any lane overwrites... see below)
+    gsync();
+  }
+  {
+    // (roots keep their own label, so lab[root] = group of root is what every tree of the island reads: the line above reads grp, not lab)
+    int adr = 0;
+    for (int k = 0; k < nwv; ++k) {
+      if (lig == 0) ladr[k] = adr;
+      for (int r0 = 0; r0 < nefc; r0 += G) {
+        const int r = r0 + lig;
+        bool mine = r < nefc && info[r] != 7;
+        if (mine) {
+          int g = 0;
+          if (split) {
+            const unsigned long long mk = (unsigned long long)tmask[2 * r] | ((unsigned long long)tmask[2 * r + 1] << 32);
+            g = mk ? lab[__builtin_ctzll(mk)] : 0;
+          }
+          mine = g == k;
+        }
+        const unsigned long long bits = __ballot(mine);
+        if (mine) rlist[adr + __popcll(bits & ((1ull << lig) - 1ull))] = r;
+        adr += __popcll(bits);
+      }
+    }
+    if (lig == 0) {
+      ladr[nwv] = adr;
+      ctl[1] = compact ? 1 : 0;
+      ctl[2] = tot_c;
+      ctl[0] = 0;
+    }
+  }
+  }();  // ---- end of the set-up ----------------------------------------------------------------------------------------------------------
+  __syncthreads();
+  if (ctl[0]) return;  // no active row: wavefront 0 wrote the unconstrained solution
+  const bool compact = ctl[1] != 0;
+  float *Jc = xs, *Bc = xs + ctl[2];
+  int* colc = reinterpret_cast<int*>(xs + 2 * ctl[2]);
+
   // ---- sweeps ---------------------------------------------------------------------------------------------------------------------
   const float tolerance = bf(m.opt_tolerance, m.opt_tolerance_nb, w, 1)[0];
   const float rscale = 1.0f / (bf(m.stat_meaninertia, m.stat_meaninertia_nb, w, 1)[0] * (float)max(nv, 1));
@@ -349,7 +545,10 @@ DEV void pgs_big_body(const MjhModel& m, const MjhData& d, float* smem, int w) {
   // (M^-1 is block diagonal over kinematic trees: row r of J and of B are zero outside the trees the row touches)
   auto jq_part = [&](int r) __attribute__((always_inline)) {
     float s = 0.0f;
-    if (sparse_rows) {
+    if (compact) {
+      const int o = coff[r];
+      if (lig < coff[r + 1] - o) s = Jc[o + lig] * q[colc[o + lig]];
+    } else if (sparse_rows) {
       unsigned long long mk = (unsigned long long)tmask[2 * r] | ((unsigned long long)tmask[2 * r + 1] << 32);
       while (mk) {
         const int t = __builtin_ctzll(mk);
@@ -363,7 +562,10 @@ DEV void pgs_big_body(const MjhModel& m, const MjhData& d, float* smem, int w) {
     return s;
   };
   auto q_add = [&](int r, float delta) __attribute__((always_inline)) {
-    if (sparse_rows) {
+    if (compact) {
+      const int o = coff[r];
+      if (lig < coff[r + 1] - o) q[colc[o + lig]] += delta * Bc[o + lig];
+    } else if (sparse_rows) {
       unsigned long long mk = (unsigned long long)tmask[2 * r] | ((unsigned long long)tmask[2 * r + 1] << 32);
       while (mk) {
         const int t = __builtin_ctzll(mk);
@@ -375,9 +577,11 @@ DEV void pgs_big_body(const MjhModel& m, const MjhData& d, float* smem, int w) {
       for (int c = lig; c < nv; c += G) q[c] += delta * Bg[(size_t)r * nvp + c];
     }
   };
+  const int v0 = ladr[wv], v1 = ladr[wv + 1];
   while (niter < maxiter) {
     float improvement = 0.0f;
-    for (int i = 0; i < nefc; ++i) {
+    for (int vi = v0; vi < v1; ++vi) {
+      const int i = rlist[vi];
       const int k = info[i];
       if (k <= 2) {
         const float fold = force[i];
@@ -481,16 +685,32 @@ DEV void pgs_big_body(const MjhModel& m, const MjhData& d, float* smem, int w) {
       const bool bad = change > 1e-10f;
       if (!bad) {
         improvement -= change;
+        if (compact) {  // (the rows of a contact touch the same trees: same columns, one read-modify-write of q per lane)
+          const int o = coff[i], n = coff[i + 1] - o;
+          if (lig < n) {
+            float dq = 0.0f;
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+              if (a < dim) dq += dl[a] * Bc[o + a * n + lig];
+            q[colc[o + lig]] += dq;
+          }
+        } else
         for (int a = 0; a < dim; ++a)
           if (dl[a] != 0.0f) q_add(i + a, dl[a]);  // (the rows of a contact touch the same trees: disjoint lanes per dof, no race)
         if (lig < dim) force[i + lig] = fnew[0] * (lig == 0) + fnew[1] * (lig == 1) + fnew[2] * (lig == 2) + fnew[3] * (lig == 3) + fnew[4] * (lig == 4) + fnew[5] * (lig == 5);
       }
       gsync();
-      i += dim - 1;
     }
+    // model-wide convergence test: the groups' improvements through LDS (double-buffered by sweep parity: one barrier per sweep)
+    if (lig == 0) imp[(niter & 1) * PGSB_MAXWAVES + wv] = improvement;
+    __syncthreads();
+    float total = 0.0f;
+    for (int k = 0; k < nwv; ++k) total += imp[(niter & 1) * PGSB_MAXWAVES + k];
     ++niter;
-    if (improvement * rscale < tolerance) break;
+    if (total * rscale < tolerance) break;
   }
+  __syncthreads();
+  if (wv != 0) return;
 
   // ---- finish: qfrc_constraint = J' f, qacc = qacc_smooth + B' f, dual states ---------------------------------------------------------
   for (int c = lig; c < nv; c += G) {

@@ -30,10 +30,11 @@ static int launch_pgs_t(const MjhModel* m, const MjhData* d, hipStream_t s) {
   if (d->njmax <= 64 && !no_reg) return launch_pgs_r<NV4, 64, true>(m, d, s);  // one world per wavefront
   return launch_pgs_r<NV4, SG, false>(m, d, s);
 }
-// generic PGS (pgs_big.hpp): more than 64 dofs, or elliptic friction cones -- one world per wavefront
-__global__ void __launch_bounds__(64) k_solve_pgs_big(MjhModel m, MjhData d) {
+// generic PGS (pgs_big.hpp): more than 64 dofs, or elliptic friction cones -- one world per workgroup of up to 8 wavefronts (the sweep runs
+// over the world's constraint islands in parallel; 128 VGPRs so that two workgroups share a CU)
+__global__ void __launch_bounds__(64 * PGSB_MAXWAVES) __attribute__((amdgpu_waves_per_eu(4, 8))) k_solve_pgs_big(MjhModel m, MjhData d) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  if ((int)blockIdx.x < d.nworld) pgs_big_body<64>(m, d, smem, (int)blockIdx.x);
+  pgs_big_body<64>(m, d, smem, (int)blockIdx.x);  // (grid = nworld; block-wide barriers inside: no early exit here)
 }
 static int launch_pgs_big(const MjhModel* m, const MjhData* d, hipStream_t s) {
   if (!d->ws_pgsB) return fail(MJH_E_ARG, "Data.ws_pgsB missing (allocate Data with make_data / put_data for this model)");
@@ -41,7 +42,10 @@ static int launch_pgs_big(const MjhModel* m, const MjhData* d, hipStream_t s) {
   const size_t lds = sizeof(int) * mstruct_ints(m->nv, m->nC) + sizeof(float) * lay.total;
   if (lds > (size_t)kLdsPerCU) return fail(MJH_E_UNSUPPORTED, "k_solve_pgs_big: nv / njmax do not fit in LDS");
   HIPCHK(set_lds(k_solve_pgs_big, lds));
-  hipLaunchKernelGGL(k_solve_pgs_big, dim3(d->nworld), dim3(64), lds, s, *m, *d);
+  // wavefronts per world: islands only exist between kinematic trees (a single tree is one island: one wavefront)
+  static const int waves_knob = getenv("MJH_PGSB_WAVES") ? atoi(getenv("MJH_PGSB_WAVES")) : PGSB_MAXWAVES;  // developer knob
+  const int waves = (m->ntree > 1 && m->ntree <= 64) ? std::max(1, std::min(std::min(waves_knob, PGSB_MAXWAVES), m->ntree)) : 1;
+  hipLaunchKernelGGL(k_solve_pgs_big, dim3(d->nworld), dim3(64 * waves), lds, s, *m, *d);
   return MJH_OK;
 }
 int launch_pgs(const MjhModel* m, const MjhData* d, hipStream_t s) {

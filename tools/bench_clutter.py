@@ -1,6 +1,6 @@
 """BASELINE configs[4]-class line: tests/models/clutter_synth.xml at nworld = 2048, nconmax = 256, njmax = 384 (the aloha_clutter registry
 sizes, benchmarks/aloha/__init__.py:46-61), Newton + elliptic + sleeping, with and without init_asleep, control noise on.
-python tools/bench_clutter.py [nworld] [nstep]"""
+python tools/bench_clutter.py [nworld] [nstep] [newton|pgs] [iterations]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -8,9 +8,15 @@ import numpy as np, torch
 import mujoco_warp_amd as mjw
 nworld = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 nstep = int(sys.argv[2]) if len(sys.argv) > 2 else 500
+only = sys.argv[3] if len(sys.argv) > 3 else None          # "newton" / "pgs": run that solver's configurations only
+iterations = int(sys.argv[4]) if len(sys.argv) > 4 else 0  # override opt.iterations (PGS: sweep cap; 1 = set-up cost of the solve)
 mjm = mjw.mjcf.load_xml(os.path.join(ROOT, "tests", "models", "clutter_synth.xml"))
 for init_asleep, solver in ((False, "newton"), (True, "newton"), (False, "pgs")):
+  if only and solver != only:
+    continue
   mjm = mjw.mjcf.load_xml(os.path.join(ROOT, "tests", "models", "clutter_synth.xml"))
+  if iterations:
+    mjw.override_model(mjm, [f"opt.iterations={iterations}"])
   if solver == "pgs":  # BASELINE configs[4] names PGS: the generic kernel; sleeping needs Newton (as in the reference), so it is off here
     mjw.override_model(mjm, ["opt.solver=pgs", "opt.enableflags=0"])
   m = mjw.put_model(mjm)
