@@ -81,8 +81,29 @@ def needs_build():
   return any(os.path.getmtime(s) > t for s in SOURCES + [HEADER])
 
 
+def _unit_key(unit):
+  """Hash of everything a translation unit is compiled from: its source, the headers it includes (transitively, quoted includes) and
+  the flags.  Keys the object cache below, so that touching one header recompiles only the units that see it."""
+  import hashlib
+
+  seen, todo = {}, [os.path.join(_PKG, "csrc", unit)]
+  while todo:
+    f = os.path.normpath(todo.pop())
+    if f in seen or not os.path.exists(f):
+      continue
+    seen[f] = open(f, "rb").read()
+    for inc in re.findall(rb'^\s*#\s*include\s+"([^"]+)"', seen[f], flags=re.M):
+      todo.append(os.path.join(os.path.dirname(f), inc.decode()))
+  h = hashlib.sha256(" ".join(HIPCC_FLAGS).encode())
+  for f in sorted(seen):
+    h.update(f.encode())
+    h.update(seen[f])
+  return h.hexdigest()[:20]
+
+
 def build(force=False, verbose=False):
-  """Compile libmjhip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+  """Compile libmjhip.so for gfx950 in-tree (hipcc cross-compiles without a GPU).  Objects are cached under build/objcache by the hash
+  of their inputs (MJH_NO_OBJCACHE=1 recompiles everything)."""
   if not force and not needs_build():
     return LIB_PATH
   # one builder at a time (N ranks of a multi-GPU launch may all find the library missing); write-then-rename so that a
@@ -96,18 +117,33 @@ def build(force=False, verbose=False):
     tmp = LIB_PATH + f".tmp{os.getpid()}"
     objdir = os.path.join(_ROOT, "build", f"obj{os.getpid()}")
     os.makedirs(objdir, exist_ok=True)
-    procs = []
-    for u in UNITS:
-      cmd = ["hipcc", *HIPCC_FLAGS, "-c", "-o", os.path.join(objdir, u + ".o"), os.path.join(_PKG, "csrc", u)]
-      if verbose:
-        print(" ".join(cmd))
-      procs.append((cmd, subprocess.Popen(cmd)))
     import shutil
 
+    cache = os.path.join(_ROOT, "build", "objcache")
+    use_cache = not os.environ.get("MJH_NO_OBJCACHE")
+    os.makedirs(cache, exist_ok=True)
+    procs = []
+    for u in UNITS:
+      obj = os.path.join(objdir, u + ".o")
+      cached = os.path.join(cache, f"{u}.{_unit_key(u)}.o")
+      if use_cache and os.path.exists(cached):
+        shutil.copyfile(cached, obj)
+        if verbose:
+          print(f"(cached) {u}")
+        continue
+      cmd = ["hipcc", *HIPCC_FLAGS, "-c", "-o", obj, os.path.join(_PKG, "csrc", u)]
+      if verbose:
+        print(" ".join(cmd))
+      procs.append((cmd, subprocess.Popen(cmd), obj, cached))
     failed = None
-    for cmd, pr in procs:
-      if pr.wait() != 0 and failed is None:
-        failed = (pr.returncode, cmd)
+    for cmd, pr, obj, cached in procs:
+      if pr.wait() != 0:
+        failed = failed or (pr.returncode, cmd)
+      elif use_cache:
+        for old in os.listdir(cache):  # one cached object per unit
+          if old.startswith(os.path.basename(obj)[:-2] + "."):
+            os.remove(os.path.join(cache, old))
+        shutil.copyfile(obj, cached)
     if failed:
       shutil.rmtree(objdir, ignore_errors=True)  # (objects of a failed build are of no use and pile up otherwise)
       raise subprocess.CalledProcessError(*failed)

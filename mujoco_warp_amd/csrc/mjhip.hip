@@ -522,18 +522,25 @@ static Side* side_stream() {
   }
   return per_dev[dev];
 }
+// one wavefront per world (csrc/sleep.hpp k_sleep)
+static int launch_sleep(const MjhModel* m, const MjhData* d, int phase, hipStream_t s) {
+  const size_t lds = sizeof(int) * sleep_lds(m->ntree, m->nbody, m->nv, d->njmax, d->concap).total;
+  if (lds > (size_t)kLdsPerCU) return fail(MJH_E_UNSUPPORTED, "k_sleep: the world's sleep tables do not fit in LDS");
+  HIPCHK(set_lds(k_sleep, lds));
+  hipLaunchKernelGGL(k_sleep, dim3(d->nworld), dim3(64), lds, s, *m, *d, phase);
+  return MJH_OK;
+}
 // forward / step of a model with sleeping enabled (forward.py:345-349, 652-675, 1290-1324, 1341-1347): the staged launch sequence
 // with the sleep bookkeeping between the stages (csrc/sleep.hpp)
 static int run_sleep_step(const MjhModel* m, const MjhData* d, bool step, hipStream_t s) {
   if (!d->tree_asleep || !d->ws_sleep_J) return fail(MJH_E_ARG, "Data sleep tables missing (allocate Data with make_data/put_data)");
   if (m->solver != SOL_NEWTON) return fail(MJH_E_UNSUPPORTED, "sleeping requires the Newton solver (reference io.py:359)");
   if (step && m->integrator == INT_RK4) return fail(MJH_E_UNSUPPORTED, "sleeping with the RK4 integrator");
-  const dim3 gw((d->nworld + 63) / 64), bw(64);
   const int mode = m->integrator == INT_IMPLICITFAST ? 1 : (m->integrator == INT_IMPLICIT ? 2 : 0);
-  { Scope sc(K_OTHER); hipLaunchKernelGGL(k_sleep, gw, bw, 0, s, *m, *d, (int)SLP_WAKE); }
+  { Scope sc(K_OTHER); TRY(launch_sleep(m, d, (int)SLP_WAKE, s)); }
   { Scope sc(K_POS); TRY(launch_pos(m, d, POS_KINEMATICS, POS_CRB, s)); }
   { Scope sc(K_COLLISION); TRY(launch_collision(m, d, s)); }
-  { Scope sc(K_OTHER); hipLaunchKernelGGL(k_sleep, gw, bw, 0, s, *m, *d, (int)SLP_WAKE_COLLISION); }
+  { Scope sc(K_OTHER); TRY(launch_sleep(m, d, (int)SLP_WAKE_COLLISION, s)); }
   {
     // pass 2: waking only ever lets more pairs through the sleep filter, so the pairs of pass 1 plus "the pairs pass 1 skipped that
     // involve a newly awakened body" are the pairs that pass the filter now: the woken worlds recompute their list
@@ -543,7 +550,7 @@ static int run_sleep_step(const MjhModel* m, const MjhData* d, bool step, hipStr
     TRY(launch_collision(m, &d2, s));
   }
   { Scope sc(K_CONSTRAINT); TRY(launch_constraint(m, d, s)); }
-  { Scope sc(K_OTHER); hipLaunchKernelGGL(k_sleep, gw, bw, 0, s, *m, *d, (int)SLP_POST_CONSTRAINT); }
+  { Scope sc(K_OTHER); TRY(launch_sleep(m, d, (int)SLP_POST_CONSTRAINT, s)); }
   { Scope sc(K_VEL); TRY(launch_vel(m, d, VEL_COMVEL, VEL_ACCEL, s)); }
   { Scope sc(K_OTHER); TRY(launch_sensor(m, d, 0, s)); }
   {
@@ -566,7 +573,7 @@ static int run_sleep_step(const MjhModel* m, const MjhData* d, bool step, hipStr
     TRY(launch_factor_smooth(m, d, 1, s));
   }
   if (step) {
-    { Scope sc(K_OTHER); hipLaunchKernelGGL(k_sleep, gw, bw, 0, s, *m, *d, (int)SLP_SLEEP); }
+    { Scope sc(K_OTHER); TRY(launch_sleep(m, d, (int)SLP_SLEEP, s)); }
     { Scope sc(K_VEL); TRY(launch_vel(m, d, VEL_COMVEL, VEL_RNE, s)); }
   }
   return MJH_OK;
@@ -633,7 +640,7 @@ static int run_stage(const MjhModel* m, const MjhData* d, int stage, hipStream_t
       const int phase = stage == MJH_STAGE_UPDATE_SLEEP ? SLP_UPDATE : stage == MJH_STAGE_WAKE ? SLP_WAKE : stage == MJH_STAGE_WAKE_COLLISION ? SLP_WAKE_COLLISION
                         : stage == MJH_STAGE_WAKE_EQUALITY ? SLP_WAKE_EQUALITY : stage == MJH_STAGE_ISLAND ? SLP_ISLAND : SLP_SLEEP;
       Scope sc(K_OTHER);
-      hipLaunchKernelGGL(k_sleep, dim3((d->nworld + 63) / 64), dim3(64), 0, s, *m, *d, phase);
+      TRY(launch_sleep(m, d, phase, s));
       return MJH_OK;
     }
     case MJH_STAGE_RUNGEKUTTA4: {

@@ -15,12 +15,42 @@
 // The fixed point of these steps is the solution of the dual problem, which the oracle tests show equal to the Newton / CG solution of the
 // primal elliptic problem (tests/test_pgs.py: qacc to 2e-6 for condim 3 / 4 / 6, impratio 1 and 10).
 #pragma once
+#include <type_traits>
+
 #include "solver.hpp"
 
 #define PGSB_MAXWAVES 8
-// ctl words: 0 state (1: nothing to solve) | 1 compact | 2 packed elements | 8.. list bounds [PGSB_MAXWAVES + 1] | 24.. improvement partials
-// [2][PGSB_MAXWAVES] | 48.. tree labels [64] | 112.. tree group / row counts [64]
-#define PGSB_CTL 176
+#define PGSB_MAXTRACKS (4 * PGSB_MAXWAVES)
+// ctl words: 0 state (1: nothing to solve) | 1 compact | 2 packed elements | 3 quarter tracks | 8.. list bounds [PGSB_MAXTRACKS + 1] |
+// 48.. improvement partials [2][PGSB_MAXWAVES] | 64.. tree labels [64] | 128.. tree group / row counts [64]
+#define PGSB_CTL 192
+// sums over a track of TW lanes (64: the wavefront; 16: one DPP row), result in every lane of the track
+template <int TW>
+DEV float tsum(float v) {
+  if (TW == 64) return gsumg<64>(v);
+  v = dpp_add_f<0x111, 0xf, 0xf>(v);  // row_shr:1 .. 8: lane 15 of the row holds the row sum
+  v = dpp_add_f<0x112, 0xf, 0xf>(v);
+  v = dpp_add_f<0x114, 0xf, 0xf>(v);
+  v = dpp_add_f<0x118, 0xf, 0xf>(v);
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + 15, 0xf, 0xf, true));  // row_newbcast:15
+}
+template <int TW, int N>
+DEV void tsum_n(float (&v)[N]) {
+  if (TW == 64) {
+    gsumg_n<64, N>(v);
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = dpp_add_f<0x111, 0xf, 0xf>(v[i]);
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = dpp_add_f<0x112, 0xf, 0xf>(v[i]);
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = dpp_add_f<0x114, 0xf, 0xf>(v[i]);
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = dpp_add_f<0x118, 0xf, 0xf>(v[i]);
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[i]), 0x150 + 15, 0xf, 0xf, true));
+}
 struct PgsBigLayout {
   int q, qs, tmp, force, aref, R, Ad, mu, info, tmask, blk, coff, rlist, ctl, xs, M, L, dinv, total;
 };
@@ -159,7 +189,7 @@ DEV void pgs_big_body(const MjhModel& m, const MjhData& d, float* smem, int w) {
   int* rlist = reinterpret_cast<int*>(S + lay.rlist);
   int* ctl = reinterpret_cast<int*>(S + lay.ctl);
   int* ladr = ctl + 8;
-  float* imp = S + lay.ctl + 24;
+  float* imp = S + lay.ctl + 48;
   unsigned* tmask = reinterpret_cast<unsigned*>(S + lay.tmask);
   const int ntree = m.ntree;
   const bool sparse_rows = ntree > 1 && ntree <= 64;  // rows touch one or two trees: the sweep visits those dof ranges only
@@ -367,7 +397,7 @@ DEV void pgs_big_body(const MjhModel& m, const MjhData& d, float* smem, int w) {
   // region the B build used for its right-hand sides: element l of row r sits at coff[r] + l and belongs to lane l.  The sweep then runs on
   // LDS alone.  Falls back to the global rows when a row touches more than 64 dofs or the packed rows do not fit.
   bool compact = sparse_rows;
-  int tot_c = 0;
+  int tot_c = 0, widest_c = 0;
   if (compact) {
     const int xs_words = (65 * nv > 2 * njmax ? 65 * nv : 2 * njmax);
     if (ell) {  // the rows of an elliptic contact are updated together: give them one column set (the union of their trees)
@@ -417,6 +447,7 @@ DEV void pgs_big_body(const MjhModel& m, const MjhData& d, float* smem, int w) {
     if (lig == 0) coff[nefc] = tot;
     compact = widest <= G && 3 * tot <= xs_words;
     tot_c = tot;
+    widest_c = widest;
     gsync();
     if (compact) {
       float *Jc = xs, *Bc = xs + tot;
@@ -447,9 +478,14 @@ DEV void pgs_big_body(const MjhModel& m, const MjhData& d, float* smem, int w) {
   // Trees joined by a row belong to one island (min-label propagation over the rows' tree masks, as k_tree_rows does for CG / Newton); islands
   // go to the wavefront with the fewest rows so far; every wavefront gets the visits of its islands in row order.  Without tree masks (one
   // tree, or more than 64) and without packed rows everything stays on wavefront 0.
-  int* lab = ctl + 48;
-  int* grp = ctl + 112;
+  int* lab = ctl + 64;
+  int* grp = ctl + 128;
   const bool split = compact && nwv > 1;
+  // tracks: a wavefront sweeps one island at a time with all 64 lanes, or -- when no row has more than 16 non-zeros -- four islands at a
+  // time, one per 16-lane DPP row (a row of J / B occupies one lane per non-zero; the small dense block problem is solved redundantly by
+  // the lanes of the track)
+  const bool quarter = split && widest_c <= 16;
+  const int ntrk = split ? nwv * (quarter ? 4 : 1) : 1;
   if (split) {
     if (lig < ntree) lab[lig] = lig;
     gsync();
@@ -481,30 +517,26 @@ DEV void pgs_big_body(const MjhModel& m, const MjhData& d, float* smem, int w) {
       if (mk) atomicAdd(&grp[lab[__builtin_ctzll(mk)]], 1);
     }
     gsync();
-    if (lig == 0) {  // islands in tree order, each to the least loaded wavefront (a handful of islands: serial)
-      int load[PGSB_MAXWAVES];
+    // islands in tree order, each to the least loaded track: lane k keeps the load of track k
+    int myload = 0;
+    for (int t = 0; t < ntree; ++t) {
+      if (lab[t] != t) continue;  // (wave-uniform: LDS value)
+      int mn = lig < ntrk ? myload : 0x7fffffff;
+      const int cand = mn;
 #pragma unroll
-      for (int k = 0; k < PGSB_MAXWAVES; ++k) load[k] = 0;
-      for (int t = 0; t < ntree; ++t) {
-        if (lab[t] != t) continue;
-        int best = 0;
-#pragma unroll
-        for (int k = 1; k < PGSB_MAXWAVES; ++k)
-          if (k < nwv && load[k] < load[best]) best = k;
-#pragma unroll
-        for (int k = 0; k < PGSB_MAXWAVES; ++k)
-          if (k == best) load[k] += grp[t];
-        grp[t] = -1 - best;  // (negative: a group, no longer a count)
-      }
+      for (int off = 32; off >= 1; off >>= 1) mn = min(mn, __shfl_xor(mn, off, G));
+      const int best = __builtin_ctzll(__ballot(cand == mn));
+      if (lig == best) myload += grp[t];
+      gsync();
+      if (lig == 0) grp[t] = -1 - best;  // (negative: a track, no longer a count)
+      gsync();
     }
-    gsync();
-    if (lig < ntree) lab[lig] = -1 - grp[lab[lig]];  // tree -> wavefront (every root's entry is final: read before any lane overwrites... see below)
+    if (lig < ntree) lab[lig] = -1 - grp[lab[lig]];  // tree -> track of its island (each lane rewrites its own entry only; roots' grp is final)
     gsync();
   }
   {
-    // (roots keep their own label, so lab[root] = group of root is what every tree of the island reads: the line above reads grp, not lab)
     int adr = 0;
-    for (int k = 0; k < nwv; ++k) {
+    for (int k = 0; k < ntrk; ++k) {
       if (lig == 0) ladr[k] = adr;
       for (int r0 = 0; r0 < nefc; r0 += G) {
         const int r = r0 + lig;
@@ -523,9 +555,10 @@ DEV void pgs_big_body(const MjhModel& m, const MjhData& d, float* smem, int w) {
       }
     }
     if (lig == 0) {
-      ladr[nwv] = adr;
+      for (int k = ntrk; k <= PGSB_MAXTRACKS; ++k) ladr[k] = adr;
       ctl[1] = compact ? 1 : 0;
       ctl[2] = tot_c;
+      ctl[3] = quarter ? 1 : 0;
       ctl[0] = 0;
     }
   }
@@ -543,11 +576,12 @@ DEV void pgs_big_body(const MjhModel& m, const MjhData& d, float* smem, int w) {
   int niter = 0;
   // J_r . q over the lanes' dofs (partial; reduce with gsumg / gsumg_n)
   // (M^-1 is block diagonal over kinematic trees: row r of J and of B are zero outside the trees the row touches)
+  int l = lig;  // lane within the track (set by run_sweeps)
   auto jq_part = [&](int r) __attribute__((always_inline)) {
     float s = 0.0f;
     if (compact) {
       const int o = coff[r];
-      if (lig < coff[r + 1] - o) s = Jc[o + lig] * q[colc[o + lig]];
+      if (l < coff[r + 1] - o) s = Jc[o + l] * q[colc[o + l]];
     } else if (sparse_rows) {
       unsigned long long mk = (unsigned long long)tmask[2 * r] | ((unsigned long long)tmask[2 * r + 1] << 32);
       while (mk) {
@@ -564,7 +598,7 @@ DEV void pgs_big_body(const MjhModel& m, const MjhData& d, float* smem, int w) {
   auto q_add = [&](int r, float delta) __attribute__((always_inline)) {
     if (compact) {
       const int o = coff[r];
-      if (lig < coff[r + 1] - o) q[colc[o + lig]] += delta * Bc[o + lig];
+      if (l < coff[r + 1] - o) q[colc[o + l]] += delta * Bc[o + l];
     } else if (sparse_rows) {
       unsigned long long mk = (unsigned long long)tmask[2 * r] | ((unsigned long long)tmask[2 * r + 1] << 32);
       while (mk) {
@@ -577,15 +611,25 @@ DEV void pgs_big_body(const MjhModel& m, const MjhData& d, float* smem, int w) {
       for (int c = lig; c < nv; c += G) q[c] += delta * Bg[(size_t)r * nvp + c];
     }
   };
-  const int v0 = ladr[wv], v1 = ladr[wv + 1];
+  auto run_sweeps = [&](auto TWc) __attribute__((always_inline)) {
+  constexpr int TW = decltype(TWc)::value, NTW = 64 / TW;
+  l = lig % TW;
+  const int trk = wv * NTW + lig / TW;
+  const int v0 = ladr[trk], nvis = ladr[trk + 1] - v0;
+  int nmax = nvis;  // the tracks of a wavefront visit in lockstep
+  if (NTW > 1) {
+    nmax = max(nmax, __shfl_xor(nmax, 16, 64));
+    nmax = max(nmax, __shfl_xor(nmax, 32, 64));
+  }
   while (niter < maxiter) {
     float improvement = 0.0f;
-    for (int vi = v0; vi < v1; ++vi) {
-      const int i = rlist[vi];
-      const int k = info[i];
-      if (k <= 2) {
+    for (int st = 0; st < nmax; ++st) {
+      const bool on = st < nvis;
+      const int i = on ? rlist[v0 + st] : 0;
+      const int k = on ? info[i] : -1;
+      if (k >= 0 && k <= 2) {
         const float fold = force[i];
-        const float res = gsumg<G>(jq_part(i)) - aref[i] + Rr[i] * fold;
+        const float res = tsum<TW>(jq_part(i)) - aref[i] + Rr[i] * fold;
         float fn = fold - res / Ad[i];
         if (k == 2) fn = fmaxf(fn, 0.0f);
         else if (k == 1) {
@@ -600,18 +644,16 @@ DEV void pgs_big_body(const MjhModel& m, const MjhData& d, float* smem, int w) {
         }
         improvement -= change;
         if (delta != 0.0f) q_add(i, delta);
-        if (lig == 0) force[i] = fold + delta;
-        gsync();
-        continue;
-      }
-      // ---- elliptic contact block (all lanes compute the small dense problem redundantly) ----------------------------------------
+        if (l == 0) force[i] = fold + delta;
+      } else if (k >= 8) {
+      // ---- elliptic contact block (all lanes of the track compute the small dense problem redundantly) ----------------------------
       const int dim = k - 8;
       float res[6], fold[6], A[6][6], mu[5], fnew[6];
       {
         float part[6];
 #pragma unroll
         for (int a = 0; a < 6; ++a) part[a] = a < dim ? jq_part(i + a) : 0.0f;
-        gsumg_n<G, 6>(part);
+        tsum_n<TW, 6>(part);
 #pragma unroll
         for (int a = 0; a < 6; ++a) {
           fold[a] = a < dim ? force[i + a] : 0.0f;
@@ -687,21 +729,26 @@ DEV void pgs_big_body(const MjhModel& m, const MjhData& d, float* smem, int w) {
         improvement -= change;
         if (compact) {  // (the rows of a contact touch the same trees: same columns, one read-modify-write of q per lane)
           const int o = coff[i], n = coff[i + 1] - o;
-          if (lig < n) {
+          if (l < n) {
             float dq = 0.0f;
 #pragma unroll
             for (int a = 0; a < 6; ++a)
-              if (a < dim) dq += dl[a] * Bc[o + a * n + lig];
-            q[colc[o + lig]] += dq;
+              if (a < dim) dq += dl[a] * Bc[o + a * n + l];
+            q[colc[o + l]] += dq;
           }
         } else
         for (int a = 0; a < dim; ++a)
           if (dl[a] != 0.0f) q_add(i + a, dl[a]);  // (the rows of a contact touch the same trees: disjoint lanes per dof, no race)
-        if (lig < dim) force[i + lig] = fnew[0] * (lig == 0) + fnew[1] * (lig == 1) + fnew[2] * (lig == 2) + fnew[3] * (lig == 3) + fnew[4] * (lig == 4) + fnew[5] * (lig == 5);
+        if (l < dim) force[i + l] = fnew[0] * (l == 0) + fnew[1] * (l == 1) + fnew[2] * (l == 2) + fnew[3] * (l == 3) + fnew[4] * (l == 4) + fnew[5] * (l == 5);
+      }
       }
       gsync();
     }
     // model-wide convergence test: the groups' improvements through LDS (double-buffered by sweep parity: one barrier per sweep)
+    if (NTW > 1) {
+      improvement += __shfl_xor(improvement, 16, 64);
+      improvement += __shfl_xor(improvement, 32, 64);
+    }
     if (lig == 0) imp[(niter & 1) * PGSB_MAXWAVES + wv] = improvement;
     __syncthreads();
     float total = 0.0f;
@@ -709,6 +756,9 @@ DEV void pgs_big_body(const MjhModel& m, const MjhData& d, float* smem, int w) {
     ++niter;
     if (total * rscale < tolerance) break;
   }
+  };
+  if (ctl[3]) run_sweeps(std::integral_constant<int, 16>{});
+  else run_sweeps(std::integral_constant<int, 64>{});
   __syncthreads();
   if (wv != 0) return;
 
