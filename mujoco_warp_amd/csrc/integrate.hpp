@@ -67,7 +67,7 @@ DEV void integrate_body(const MjhModel& m, const MjhData& d, int mode, float* sm
     }
     gsync();
     pc.mark(1);
-    factor_ld<G>(ms, L, dinv, nv, lig);
+    factor_ld<G>(ms, L, dinv, nv, lig, &m);
     pc.mark(2);
     solve_ld<G>(m, ms, L, dinv, x, nv, lig);
     pc.mark(3);

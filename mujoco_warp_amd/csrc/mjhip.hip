@@ -66,6 +66,16 @@ static inline bool lanes64(const MjhModel* m) {
   // (models with GJK / EPA pairs stay at 32: Data.ws_ccd holds one polytope workspace per lane of a 32-lane group)
   return (m->nv > 32 || m->nbody > 32) && !m->heavy_colliders;
 }
+// 16 lanes per world -- four worlds per wavefront -- in k_mid for small models (at most 16 dofs and bodies, light colliders; round 3): half the
+// wavefronts for the same worlds and still one trip per loop.  Same-box A/B: Panda 8192 worlds k_mid 62.0 -> 49.5 us, step 180 -> 164.6 us
+// (- 8.7 %).  Not for larger models (humanoid, 27 dofs on 17 bodies, forced with MJH_LANES16_ANY: k_mid 84 -> 101 us -- every loop needs two
+// trips) and not for k_fwd_pos (Panda 48.0 vs 49.1 us: its chain is the tree depth whatever the lane count; MJH_LANES16_POS turns it on).
+static inline bool lanes16(const MjhModel* m) {
+  static const int force = getenv("MJH_LANES") ? atoi(getenv("MJH_LANES")) : 0;  // developer knob: 16 / 32 / 64
+  static const bool any = getenv("MJH_LANES16_ANY") != nullptr;
+  if (force && force != 16) return false;
+  return ((m->nv <= 16 && m->nbody <= 16) || (force == 16 && any)) && !m->heavy_colliders;
+}
 // (k_fwd_pos: its loops run over bodies -- the G1, 35 dofs on 30 bodies, is 4 us slower with 64 lanes; three humanoids, 52 bodies, 25 us faster)
 
 template <int G>
@@ -267,7 +277,7 @@ static int launch_mid_g(const MjhModel* m, const MjhData* d, bool sched, hipStre
   if (nw_v < 1) nw_v = 1;
   if (nw_v > 256 / G) nw_v = 256 / G;
   // an odd world count leaves half a wavefront slot empty: round up when the same number of workgroups still fits a CU
-  if ((nw_v & 1) && nw_v < 8) {
+  if ((nw_v & 1) && nw_v < 256 / G) {
     const size_t up = ms_bytes + sizeof(float) * vl.total * (nw_v + 1);
     if ((size_t)kLdsPerCU / std::max(up, lds) == (size_t)kLdsPerCU / lds) ++nw_v;
     else --nw_v;
@@ -279,6 +289,12 @@ static int launch_mid_g(const MjhModel* m, const MjhData* d, bool sched, hipStre
   }
   lds = std::max(lds, ms_bytes + sizeof(float) * vl.total * nw_v);
   if (lds > (size_t)kLdsPerCU) return fail(MJH_E_UNSUPPORTED, "k_mid: model does not fit in LDS");
+  if constexpr (G == 16) {  // (light colliders only: lanes16)
+    HIPCHK(set_lds((k_mid<G, false>), lds));
+    const int ncc16 = (d->nworld + nw_cc - 1) / nw_cc, nvb16 = (d->nworld + nw_v - 1) / nw_v;
+    hipLaunchKernelGGL((k_mid<G, false>), dim3(ncc16 + nvb16 + (sched ? 1 : 0)), dim3(G * std::max(nw_cc, nw_v)), lds, s, *m, *d, ncc16, nvb16, nw_cc, nw_v, stride_cc, sched ? 1 : 0);
+    return MJH_OK;
+  } else {
   if (m->heavy_colliders) HIPCHK(set_lds((k_mid<G, true>), lds));
   else HIPCHK(set_lds((k_mid<G, false>), lds));
   const int ncc = (d->nworld + nw_cc - 1) / nw_cc, nvb = (d->nworld + nw_v - 1) / nw_v;
@@ -288,8 +304,9 @@ static int launch_mid_g(const MjhModel* m, const MjhData* d, bool sched, hipStre
   if (m->heavy_colliders) hipLaunchKernelGGL((k_mid<G, true>), grid, block, lds, s, *m, *d, ncc, nvb, nw_cc, nw_v, stride_cc, sched ? 1 : 0);
   else hipLaunchKernelGGL((k_mid<G, false>), grid, block, lds, s, *m, *d, ncc, nvb, nw_cc, nw_v, stride_cc, sched ? 1 : 0);
   return MJH_OK;
+  }
 }
-static int launch_mid(const MjhModel* m, const MjhData* d, bool sched, hipStream_t s) { return lanes64(m) ? launch_mid_g<64>(m, d, sched, s) : launch_mid_g<32>(m, d, sched, s); }
+static int launch_mid(const MjhModel* m, const MjhData* d, bool sched, hipStream_t s) { return lanes16(m) ? launch_mid_g<16>(m, d, sched, s) : lanes64(m) ? launch_mid_g<64>(m, d, sched, s) : launch_mid_g<32>(m, d, sched, s); }
 // set by the fused STEP path when the solver launch also integrates (see euler_fusable)
 static thread_local int g_fuse_euler = 0;  // 1: explicit Euler, 2: implicitfast in the solver's epilogue
 // set by the fused path when the Newton riders run on the side stream (see side_stream)
@@ -440,7 +457,7 @@ static int launch_pos_plus_g(const MjhModel* m, const MjhData* d, int first, int
   hipLaunchKernelGGL(k_fwd_pos_plus<G>, dim3(npos + 1 + nnoise), dim3(threads), lds, s, *m, *d, first, last, npos, noise);
   return MJH_OK;
 }
-static int launch_pos_plus(const MjhModel* m, const MjhData* d, int first, int last, bool* sched_done, hipStream_t s) { return lanes64(m) && m->nbody > 32 ? launch_pos_plus_g<64>(m, d, first, last, sched_done, s) : launch_pos_plus_g<32>(m, d, first, last, sched_done, s); }
+static int launch_pos_plus(const MjhModel* m, const MjhData* d, int first, int last, bool* sched_done, hipStream_t s) { static const bool pos16 = getenv("MJH_LANES16_POS") != nullptr; return lanes16(m) && pos16 ? launch_pos_plus_g<16>(m, d, first, last, sched_done, s) : lanes64(m) && m->nbody > 32 ? launch_pos_plus_g<64>(m, d, first, last, sched_done, s) : launch_pos_plus_g<32>(m, d, first, last, sched_done, s); }
 
 
 static int check(const MjhModel* m, const MjhData* d) {

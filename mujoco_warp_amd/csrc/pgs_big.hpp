@@ -205,7 +205,7 @@ DEV void pgs_big_body(const MjhModel& m, const MjhData& d, float* smem, int w) {
   gcopy<G>(Ll, d.M + (size_t)w * nC, nC, lig);
   gcopy<G>(qs, d.qfrc_smooth + vo, nv, lig);
   gsync();
-  factor_ld<G>(ms, Ll, dinv, nv, lig);
+  factor_ld<G>(ms, Ll, dinv, nv, lig, &m);
   solve_ld<G>(m, ms, Ll, dinv, qs, nv, lig);
   gsync();
   for (int i = lig; i < nv; i += G) d.qacc_smooth[vo + i] = qs[i];

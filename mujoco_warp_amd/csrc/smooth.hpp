@@ -158,8 +158,45 @@ DEV PosTab load_pos_tab(const MjhModel& m, float* T, int nthreads) {
 // ancestor rows are spread over the lanes (one ancestor row per lane, no write conflicts).
 // (Tried in round 2: one lane per (ancestor, column) pair, and a level-wise gather for the transposed solve -- the per-row chain of
 // dependent LDS round trips is what costs, ~1,800 cycles per row on the G1 either way; the gather was twice as slow.)
+// Several kinematic trees (round 3): M is block diagonal over them, so the s-th row from the end of EVERY tree is eliminated in the same
+// step -- the chain is tree_nvmax steps long instead of nv (three humanoids: 27 instead of 81; clutter_synth: 8 instead of 136).  Inside a
+// tree the order is the sequential one and no entry is shared between trees: bit-identical factors.
+// It pays when the trees are shallow: a step of the sequential version costs one row (its ancestors spread over the lanes), a step of the
+// tree-parallel one ceil(ntree (tree_nvmax - 1) / G) rows -- three humanoids (3 trees of 27 dofs, rows of up to 26 ancestors on 32 lanes): 81
+// steps against 27 x 3, no gain (measured: integrator launch 148 -> 174 us); clutter_synth (22 trees of at most 8 dofs): 136 against 8 x 5.
 template <int G>
-DEV void factor_ld(const MStruct& ms, float* L, float* dinv, int nv, int lig) {
+DEV bool ld_by_tree(const MjhModel& m) {
+  if (m.ntree <= 1) return false;
+  const int manc = max(m.tree_nvmax - 1, 1);
+  return m.nv >= 2 * m.tree_nvmax * ((m.ntree * manc + G - 1) / G);
+}
+template <int G>
+DEV void factor_ld(const MStruct& ms, float* L, float* dinv, int nv, int lig, const MjhModel* mt = nullptr) {
+  if (mt && ld_by_tree<G>(*mt)) {
+    const int nt = mt->ntree, maxd = mt->tree_nvmax, manc = max(maxd - 1, 1), nitem = nt * manc;
+    for (int s = 0; s < maxd; ++s) {
+      for (int item = lig; item < nitem; item += G) {  // item = (tree, ancestor slot of its current row)
+        const int t = item / manc, a = item - t * manc, nd = mt->tree_dofnum[t];
+        if (s >= nd) continue;
+        const int k = mt->tree_dofadr[t] + nd - 1 - s, start = ms.rowadr[k], n = ms.rownnz[k];
+        if (a >= n - 1) continue;
+        const float tt = L[start + a] / L[start + n - 1];
+        const int ai = ms.rowadr[ms.colind[start + a]];
+        for (int j = 0; j <= a; ++j) L[ai + j] -= L[start + j] * tt;
+      }
+      gsync();
+      for (int item = lig; item < nitem; item += G) {
+        const int t = item / manc, a = item - t * manc, nd = mt->tree_dofnum[t];
+        if (s >= nd) continue;
+        const int k = mt->tree_dofadr[t] + nd - 1 - s, start = ms.rowadr[k], n = ms.rownnz[k];
+        const float dk = L[start + n - 1];
+        if (a == 0) dinv[k] = 1.0f / dk;
+        if (a < n - 1) L[start + a] = L[start + a] / dk;
+      }
+    }
+    gsync();
+    return;
+  }
   for (int k = nv - 1; k >= 0; --k) {
     const int start = ms.rowadr[k], n = ms.rownnz[k], diag = start + n - 1;
     const float dk = L[diag];
@@ -178,6 +215,18 @@ DEV void factor_ld(const MStruct& ms, float* L, float* dinv, int nv, int lig) {
 // x <- (L' D L)^-1 x in LDS (reference solve_LD smooth.py:3187 == MuJoCo mj_solveLD)
 template <int G>
 DEV void solve_ld(const MjhModel& m, const MStruct& ms, const float* L, const float* dinv, float* x, int nv, int lig) {
+  if (ld_by_tree<G>(m)) {  // x <- L^-T x, one row of every kinematic tree per step (see factor_ld)
+    const int nt = m.ntree, maxd = m.tree_nvmax, manc = max(maxd - 1, 1), nitem = nt * manc;
+    for (int s = 0; s < maxd; ++s) {
+      for (int item = lig; item < nitem; item += G) {
+        const int t = item / manc, a = item - t * manc, nd = m.tree_dofnum[t];
+        if (s >= nd) continue;
+        const int k = m.tree_dofadr[t] + nd - 1 - s, start = ms.rowadr[k], n = ms.rownnz[k];
+        if (a < n - 1) x[ms.colind[start + a]] -= L[start + a] * x[k];
+      }
+      gsync();
+    }
+  } else
   for (int k = nv - 1; k >= 0; --k) {  // x <- L^-T x
     const int start = ms.rowadr[k], n = ms.rownnz[k];
     const float xk = x[k];
@@ -679,7 +728,7 @@ DEV void fwd_pos_impl(const MjhModel& m, const MjhData& d, int first, int last, 
   if (first == POS_FACTOR) gcopy<G>(L, d.M + (size_t)w * nC, nC, lig);
   else gcopy<G>(L, M, nC, lig);
   gsync();
-  factor_ld<G>(ms, L, dinv, nv, lig);
+  factor_ld<G>(ms, L, dinv, nv, lig, &m);
   gcopy<G>(d.qLD + (size_t)w * nC, L, nC, lig);
   gcopy<G>(d.qLDiagInv + (size_t)w * nv, dinv, nv, lig);
   pc.mark(3);
@@ -1044,7 +1093,7 @@ DEV void factor_smooth_body(const MjhModel& m, const MjhData& d, int write_qacc,
   gcopy<G>(L, d.M + (size_t)w * nC, nC, lig);
   if (write_qacc) gcopy<G>(x, d.qfrc_smooth + (size_t)w * nv, nv, lig);
   gsync();
-  factor_ld<G>(ms, L, dinv, nv, lig);
+  factor_ld<G>(ms, L, dinv, nv, lig, &m);
   if (write_qacc) solve_ld<G>(m, ms, L, dinv, x, nv, lig);
   gcopy<G>(d.qLD + (size_t)w * nC, L, nC, lig);
   gcopy<G>(d.qLDiagInv + (size_t)w * nv, dinv, nv, lig);

@@ -79,7 +79,7 @@ DEV void solve_big_body(const MjhModel& m, const MjhData& d, float* smem, const 
   gcopy<G>(fs, d.qfrc_smooth + vo, nv, lig);
   gcopy<G>(x, d.qfrc_smooth + vo, nv, lig);
   gsync();
-  factor_ld<G>(ms, Ll, dinv, nv, lig);
+  factor_ld<G>(ms, Ll, dinv, nv, lig, &m);
   solve_ld<G>(m, ms, Ll, dinv, x, nv, lig);
   gsync();
   for (int i = lig; i < nv; i += G) {
