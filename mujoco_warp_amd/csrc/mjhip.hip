@@ -528,8 +528,13 @@ static Side* side_stream() {
   if (!per_dev[dev]) {
     Side* sd = new Side();
     int least = 0, greatest = 0;
-    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
-    if (hipStreamCreateWithPriority(&sd->stream, hipStreamNonBlocking, least) != hipSuccess ||
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = greatest = 0;
+    // developer knob (A/B): "high" / "normal"; default: the lowest priority.  Measured (round 3, two interleaved triples on one box): no
+    // difference (0.2810 / 0.2803 / 0.2805 ms per Newton step) -- queue priority does not arbitrate CU slots.  The riders still end ~20 us
+    // after the solver (rocprofv3 timeline, profiles/round3_newton_summary.json): their workgroups only get slots as the solver's retire
+    const char* pe = getenv("MJH_SIDE_PRIO");
+    const int prio = pe && pe[0] == 'h' ? greatest : (pe && pe[0] == 'n' ? 0 : least);
+    if (hipStreamCreateWithPriority(&sd->stream, hipStreamNonBlocking, prio) != hipSuccess ||
         hipEventCreateWithFlags(&sd->fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&sd->join, hipEventDisableTiming) != hipSuccess) {
       delete sd;
