@@ -345,8 +345,22 @@ static Aux* aux_streams() {
   }
   return g_aux_per_dev[dev];
 }
+// The Newton riders as trailing workgroups of the MFMA solver launch (solver_newton.hpp) instead of a side-stream launch, for SMALL models
+// (round 3).  Where the solve is short the side stream's fork / join hops and the riders' late start set the step: Panda (nv 9, njmax 5: solver
+// 22 us) 135.0 -> 117.2 us per step (60.7 -> 69.9 M env-steps/s, two interleaved pairs on one box).  Where the solve is long the riders'
+// workgroups in its tail cost more than the join they save: humanoid (nv 27) 0.2824 / 0.2844 -> 0.2894 / 0.2897 ms, so the side stream stays
+// above 16 dofs.  Applies exactly when launch_solve_32_newton picks the MFMA kernel.  MJH_NEWTON_RIDERS=0 / 1 forces it off / on (developer knob).
+static thread_local bool g_newton_inline = false;
+static bool newton_inline_ok(const MjhModel* m, const MjhData* d) {
+  static const int force = getenv("MJH_NEWTON_RIDERS") ? atoi(getenv("MJH_NEWTON_RIDERS")) : -1;
+  static const bool old_path = getenv("MJH_OLD_NEWTON") != nullptr;
+  const bool ell = m->cone == CONE_ELLIPTIC && d->nmaxpyramid > 1;
+  const bool want = force >= 0 ? force != 0 : m->nv <= 16;
+  return want && !old_path && m->solver == SOL_NEWTON && !ell && m->nv <= 32 && d->njmax <= 64 && (double)d->nworld * std::max(m->nv, d->njmax) * 4.0 < 4.0e9;
+}
 static int launch_solve_any(const MjhModel* m, const MjhData* d, bool with_factor, hipStream_t s) {
   if (int rc = solve_supported(m, d)) return rc;
+  if (m->solver == SOL_NEWTON) with_factor = with_factor && g_newton_inline;
   if (m->nv > 64) {  // no riders: they go with the integrator launch
     if (m->solver == SOL_PGS) return launch_pgs(m, d, s);  // (the generic PGS kernel: csrc/pgs_big.hpp)
     if (m->tree_solve) {
@@ -705,7 +719,8 @@ static int run_stage(const MjhModel* m, const MjhData* d, int stage, hipStream_t
       // fused step: four launches on the caller's stream (see "composite launches" above)
       // (nv <= 32 only: beside the 64-lane solver of larger models the riders cost more than they save, G1 -3 %)
       static const int side_nv = getenv("MJH_SIDE_NV") ? atoi(getenv("MJH_SIDE_NV")) : 32;  // developer knob
-      Side* side = (m->solver == SOL_NEWTON && m->nv <= side_nv && !(g_instr && g_instr->on)) ? side_stream() : nullptr;
+      const bool inl = stage == MJH_STAGE_STEP && newton_inline_ok(m, d) && !(g_instr && g_instr->on);
+      Side* side = (m->solver == SOL_NEWTON && m->nv <= side_nv && !(g_instr && g_instr->on) && !inl) ? side_stream() : nullptr;
       bool sched_done = false;
       { Scope sc(K_POS); TRY(launch_pos_plus(m, d, POS_KINEMATICS, POS_CRB, &sched_done, s)); }
       { Scope sc(K_MID); TRY(launch_mid(m, d, !sched_done, s)); }
@@ -729,7 +744,7 @@ static int run_stage(const MjhModel* m, const MjhData* d, int stage, hipStream_t
       // explicit Euler without activations: the velocity/position update is a few loads and stores per dof, done by the
       // solver's own epilogue (saves a launch); every other case keeps the integrator workgroups
       // (Newton: only when its riders run on the side stream -- otherwise the integrator launch exists anyway, for them)
-      const bool fusable = stage == MJH_STAGE_STEP && m->na == 0 && (m->solver == SOL_CG || side != nullptr) && m->nv <= 64 &&
+      const bool fusable = stage == MJH_STAGE_STEP && m->na == 0 && (m->solver == SOL_CG || side != nullptr || inl) && m->nv <= 64 &&
                            m->nsensor_acc == 0 &&  // (acceleration-stage sensors read qvel / qacc between the solver and the integrator)
                            d->njmax <= 192;        // (beyond: some worlds go to the generic solver, which does not integrate)
       // implicitfast without activations (round 3): the dense system (M + h D - h dA/dv) x = M qacc is solved from the M row the solver holds
@@ -738,12 +753,14 @@ static int run_stage(const MjhModel* m, const MjhData* d, int stage, hipStream_t
                              : (m->integrator == INT_EULER && (m->disableflags & (DSBL_EULERDAMP | DSBL_DAMPER)) != 0) ? 1
                              : (m->integrator == INT_IMPLICITFAST && !no_fuse_impfast) ? 2 : 0;
       g_fuse_euler = fuse_euler;
+      g_newton_inline = inl;
       int rc;
       { Scope sc(K_SOLVE); rc = launch_solve_plus(m, d, s); }
       g_fuse_euler = 0;
+      g_newton_inline = false;
       TRY(rc);
       { Scope sc(K_OTHER); TRY(launch_sensor(m, d, 1, s)); }
-      g_riders_on_side = side != nullptr;
+      g_riders_on_side = side != nullptr || inl;  // (either way the integrator launch carries no riders)
       { Scope sc(K_INTEGRATE); rc = launch_integrate_plus(m, d, mode, stage == MJH_STAGE_STEP && !fuse_euler, s); }
       g_riders_on_side = false;
       TRY(rc);

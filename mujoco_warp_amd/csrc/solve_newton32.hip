@@ -6,7 +6,7 @@
 #include "solver_newton.hpp"
 
 template <int NV4, int WV>
-static int launch_newton_t(const MjhModel* m, const MjhData* d, int fuse_euler, hipStream_t s) {
+static int launch_newton_t(const MjhModel* m, const MjhData* d, int fuse_euler, bool riders, hipStream_t s) {
   constexpr int NVR = 4 * NV4;
   constexpr int JS = (NV4 & 1) ? NVR : NVR + 4;
   // pool rows: what 4 WV wavefronts per CU leave for J after the per-world scratch, at most 2 x njmax
@@ -18,9 +18,13 @@ static int launch_newton_t(const MjhModel* m, const MjhData* d, int fuse_euler, 
   pool = std::max(pool, newton_min_pool<NV4>(d->njmax));
   if (const char* e = getenv("MJH_NEWTON_POOL")) pool = std::max(atoi(e), newton_min_pool<NV4>(d->njmax));  // developer knob
   const NewtonLayout lay = newton_layout<NV4>(pool);
-  const size_t lds = sizeof(float) * lay.total;
+  size_t lds = sizeof(float) * lay.total;
+  const int nsolve = (d->nworld + 1) / 2, nrider = riders ? nsolve : 0;
+  if (riders) lds = std::max(lds, sizeof(int) * mstruct_ints(m->nv, m->nC) + sizeof(float) * fac_layout(m->nv, m->nC).total * 2);
   if (lds > (size_t)kLdsPerCU) return fail(MJH_E_UNSUPPORTED, "k_solve_newton: does not fit in LDS");
-  const dim3 grid((d->nworld + 1) / 2), block(64);
+  static const int rider_pct = getenv("MJH_RIDER_AT") ? atoi(getenv("MJH_RIDER_AT")) : 100;  // see solve_tu.hpp
+  const int rider_at = std::min(nsolve, (int)((long long)nsolve * std::max(rider_pct, 0) / 100));
+  const dim3 grid(nsolve + 2 * nrider), block(64);
   if (getenv("MJH_DEBUG_OCC")) {  // developer knob: resident workgroups per CU the runtime computes for this launch
     int nb = -1;
     if (pool >= 2 * cap) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_solve_newton<NV4, WV, true>, 64, lds);
@@ -29,32 +33,32 @@ static int launch_newton_t(const MjhModel* m, const MjhData* d, int fuse_euler, 
   }
   if (pool >= 2 * cap) {  // every pair fits: the single-turn instantiation
     HIPCHK(set_lds((k_solve_newton<NV4, WV, true>), lds));
-    hipLaunchKernelGGL((k_solve_newton<NV4, WV, true>), grid, block, lds, s, *m, *d, pool, fuse_euler);
+    hipLaunchKernelGGL((k_solve_newton<NV4, WV, true>), grid, block, lds, s, *m, *d, pool, fuse_euler, nrider, rider_at);
   } else {
     HIPCHK(set_lds((k_solve_newton<NV4, WV, false>), lds));
-    hipLaunchKernelGGL((k_solve_newton<NV4, WV, false>), grid, block, lds, s, *m, *d, pool, fuse_euler);
+    hipLaunchKernelGGL((k_solve_newton<NV4, WV, false>), grid, block, lds, s, *m, *d, pool, fuse_euler, nrider, rider_at);
   }
   return MJH_OK;
 }
 template <int WV>
-static int launch_newton_w(const MjhModel* m, const MjhData* d, int fuse_euler, hipStream_t s) {
+static int launch_newton_w(const MjhModel* m, const MjhData* d, int fuse_euler, bool riders, hipStream_t s) {
   switch ((m->nv + 3) / 4) {
     case 0:
-    case 1: return launch_newton_t<1, WV>(m, d, fuse_euler, s);
-    case 2: return launch_newton_t<2, WV>(m, d, fuse_euler, s);
-    case 3: return launch_newton_t<3, WV>(m, d, fuse_euler, s);
-    case 4: return launch_newton_t<4, WV>(m, d, fuse_euler, s);
-    case 5: return launch_newton_t<5, WV>(m, d, fuse_euler, s);
-    case 6: return launch_newton_t<6, WV>(m, d, fuse_euler, s);
-    case 7: return launch_newton_t<7, WV>(m, d, fuse_euler, s);
-    default: return launch_newton_t<8, WV>(m, d, fuse_euler, s);
+    case 1: return launch_newton_t<1, WV>(m, d, fuse_euler, riders, s);
+    case 2: return launch_newton_t<2, WV>(m, d, fuse_euler, riders, s);
+    case 3: return launch_newton_t<3, WV>(m, d, fuse_euler, riders, s);
+    case 4: return launch_newton_t<4, WV>(m, d, fuse_euler, riders, s);
+    case 5: return launch_newton_t<5, WV>(m, d, fuse_euler, riders, s);
+    case 6: return launch_newton_t<6, WV>(m, d, fuse_euler, riders, s);
+    case 7: return launch_newton_t<7, WV>(m, d, fuse_euler, riders, s);
+    default: return launch_newton_t<8, WV>(m, d, fuse_euler, riders, s);
   }
 }
 
-static int launch_newton(const MjhModel* m, const MjhData* d, int fuse_euler, hipStream_t s) {
+static int launch_newton(const MjhModel* m, const MjhData* d, int fuse_euler, bool riders, hipStream_t s) {
   // two wavefronts per SIMD is the measured optimum: at three (168 VGPRs) the register allocator still spills in the Cholesky
   static const int waves = getenv("MJH_NEWTON_WAVES") ? atoi(getenv("MJH_NEWTON_WAVES")) : 2;  // developer knob
-  return waves == 2 ? launch_newton_w<2>(m, d, fuse_euler, s) : launch_newton_w<3>(m, d, fuse_euler, s);
+  return waves == 2 ? launch_newton_w<2>(m, d, fuse_euler, riders, s) : launch_newton_w<3>(m, d, fuse_euler, riders, s);
 }
 
 int launch_solve_32_newton(const MjhModel* m, const MjhData* d, int nr, bool with_factor, int fuse_euler, hipStream_t s, int lo, int hi) {
@@ -62,7 +66,7 @@ int launch_solve_32_newton(const MjhModel* m, const MjhData* d, int nr, bool wit
   switch (nr) {
     case 2:
       // (32-bit byte offsets inside the kernel: nworld * max(nv, njmax) * 4 must fit)
-      if (!old_path && lo < 0 && hi >= 64 && d->njmax <= 64 && (double)d->nworld * std::max(m->nv, d->njmax) * 4.0 < 4.0e9) return launch_newton(m, d, fuse_euler, s);
+      if (!old_path && lo < 0 && hi >= 64 && d->njmax <= 64 && (double)d->nworld * std::max(m->nv, d->njmax) * 4.0 < 4.0e9) return launch_newton(m, d, fuse_euler, with_factor, s);
       return launch_solve_32<2, true>(m, d, with_factor, fuse_euler, s, lo, hi);
     case 6: return launch_solve_32<6, true>(m, d, with_factor, fuse_euler, s, lo, hi);
     default: return fail(MJH_E_ARG, "k_solve: unsupported rows per lane");

@@ -11,14 +11,18 @@
 #endif
 
 template <int NV4, int NR, bool NEWTON, int SG, bool ELL = false>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((!NEWTON && !ELL && SG == 32 && NR == 2) ? 3 : ((NEWTON && SG == 64 && MJH_N64_WAVES > 1) ? MJH_N64_WAVES : 1), 8))) k_solve_plus(MjhModel m, MjhData d, int nsolve, int nfac, int nefc_lo, int nefc_hi, int fuse_euler) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((!NEWTON && !ELL && SG == 32 && NR == 2) ? 3 : ((NEWTON && SG == 64 && MJH_N64_WAVES > 1) ? MJH_N64_WAVES : 1), 8))) k_solve_plus(MjhModel m, MjhData d, int nsolve, int nfac, int nefc_lo, int nefc_hi, int fuse_euler, int rider_at) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int wpb = blockDim.x / SG;
-  if ((int)blockIdx.x < nsolve) solve_body<NV4, NR, NEWTON, SG, ELL>(m, d, smem, Blk{(int)blockIdx.x * wpb, wpb, (int)blockDim.x}, nefc_lo, nefc_hi, fuse_euler);
+  // workgroups are dispatched in index order: [0, rider_at) solver (longest expected solves first), then the 2 nfac rider workgroups, then the
+  // remaining (short) solves
+  const int bx = (int)blockIdx.x, nrider = NEWTON ? 0 : 2 * nfac;
+  const int sb = bx < rider_at ? bx : bx - nrider;  // solver workgroup index when this is one
+  if (bx < rider_at || bx >= rider_at + nrider) solve_body<NV4, NR, NEWTON, SG, ELL>(m, d, smem, Blk{sb * wpb, wpb, (int)blockDim.x}, nefc_lo, nefc_hi, fuse_euler);
   // CG only: the Newton kernel holds 256 VGPRs (one wave per SIMD), which would throttle the riders too (measured
   // +120 us); for Newton they ride along with the integrator launch instead
   else if (!NEWTON) {
-    const int wf = blockDim.x / 32, bi = (int)blockIdx.x - nsolve;
+    const int wf = blockDim.x / 32, bi = bx - rider_at;
     if (bi < nfac) factor_smooth_body<32>(m, d, 0, smem, Blk{bi * wf, wf, (int)blockDim.x});
     else publish_body<32>(d, 1, reinterpret_cast<int*>(smem), Blk{(bi - nfac) * wf, wf, (int)blockDim.x}, m.nexplicit ? m.pair_solreffriction : nullptr);
   }
@@ -44,7 +48,12 @@ static int launch_solve_t(const MjhModel* m, const MjhData* d, bool with_factor,
   const int nsolve = (d->nworld + wpb - 1) / wpb, nfac = with_factor ? (d->nworld + wf - 1) / wf : 0;
   // riders (fused step, CG): factor workgroups, then as many contact-publication workgroups
   debug_occupancy(NEWTON ? "k_solve_plus<newton>" : "k_solve_plus<cg>", k_solve_plus<NV4, NR, NEWTON, SG, ELL>, nsolve + 2 * nfac, threads, lds);
-  hipLaunchKernelGGL((k_solve_plus<NV4, NR, NEWTON, SG, ELL>), dim3(nsolve + 2 * nfac), dim3(threads), lds, s, *m, *d, nsolve, nfac, nefc_lo, nefc_hi, fuse_euler);
+  // where the riders sit in the dispatch order, in per cent of the solver workgroups (developer knob; 100 = after all of them, the round-1 layout).
+  // Measured (round 3, humanoid CG, two interleaved rounds on one box): 100 -> 215.9 / 215.3 us per launch, 75 -> 280.4 / 280.7, 55 -> 268.6 / 267.6,
+  // 35 -> 279.1 / 279.0: riders dispatched among the solver workgroups cost four times what they cost in the launch's tail
+  static const int rider_pct = getenv("MJH_RIDER_AT") ? atoi(getenv("MJH_RIDER_AT")) : 100;
+  const int rider_at = std::min(nsolve, (int)((long long)nsolve * std::max(rider_pct, 0) / 100));
+  hipLaunchKernelGGL((k_solve_plus<NV4, NR, NEWTON, SG, ELL>), dim3(nsolve + 2 * nfac), dim3(threads), lds, s, *m, *d, nsolve, nfac, nefc_lo, nefc_hi, fuse_euler, rider_at);
   return MJH_OK;
 }
 template <int NR, bool NEWTON, bool ELL = false>

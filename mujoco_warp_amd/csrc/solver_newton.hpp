@@ -490,9 +490,9 @@ DEV void newton_pair(const MjhModel& m, const MjhData& d, float* S, const Newton
 // One wavefront = two schedule slots.  FULLPOOL: the pool holds 2 x min(njmax, 64) rows, every pair fits (no second turn).
 // Otherwise the pair shares the pool when its rows fit and is solved in two turns when they do not.
 template <int NV4, bool FULLPOOL>
-DEV void newton_body(const MjhModel& m, const MjhData& d, float* smem, int pool_rows, int fuse_euler) {
+DEV void newton_body(const MjhModel& m, const MjhData& d, float* smem, int pool_rows, int fuse_euler, int block) {
   const NewtonLayout lay = newton_layout<NV4>(pool_rows);
-  const int wave = (int)blockIdx.x * ((int)blockDim.x >> 6) + ((int)threadIdx.x >> 6);
+  const int wave = block * ((int)blockDim.x >> 6) + ((int)threadIdx.x >> 6);
   const int lane = threadIdx.x & 63, hf = lane >> 5;
   if (2 * wave >= d.nworld) return;  // whole wavefront beyond the world list
   float* S = smem + (size_t)((int)threadIdx.x >> 6) * lay.total;
@@ -520,7 +520,16 @@ DEV void newton_body(const MjhModel& m, const MjhData& d, float* smem, int pool_
 
 // WV = wavefronts per SIMD the register allocation is held to (3: 168 VGPRs, 2: 256)
 template <int NV4, int WV, bool FULLPOOL>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WV, 8))) k_solve_newton(MjhModel m, MjhData d, int pool_rows, int fuse_euler) {
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WV, 8))) k_solve_newton(MjhModel m, MjhData d, int pool_rows, int fuse_euler, int nrider, int rider_at) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  newton_body<NV4, FULLPOOL>(m, d, smem, pool_rows, fuse_euler);
+  // riders (round 3; small models, see mjhip.hip newton_inline_ok): 2 nrider one-wavefront workgroups -- the L'DL factor + qacc_smooth, then the contact
+  // publication, two worlds each -- inserted at workgroup rider_at of the dispatch order instead of running on a side stream
+  const int bx = (int)blockIdx.x;
+  if (bx >= rider_at && bx < rider_at + 2 * nrider) {
+    const int bi = bx - rider_at;
+    if (bi < nrider) factor_smooth_body<32>(m, d, 1, smem, Blk{bi * 2, 2, 64});
+    else publish_body<32>(d, 1, reinterpret_cast<int*>(smem), Blk{(bi - nrider) * 2, 2, 64}, m.nexplicit ? m.pair_solreffriction : nullptr);
+    return;
+  }
+  newton_body<NV4, FULLPOOL>(m, d, smem, pool_rows, fuse_euler, bx < rider_at ? bx : bx - 2 * nrider);
 }
