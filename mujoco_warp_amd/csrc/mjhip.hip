@@ -151,6 +151,14 @@ static int launch_constraint_g(const MjhModel* m, const MjhData* d, hipStream_t 
   return MJH_OK;
 }
 static int launch_constraint(const MjhModel* m, const MjhData* d, hipStream_t s) { return lanes64(m) ? launch_constraint_g<64>(m, d, s) : launch_constraint_g<32>(m, d, s); }
+static int launch_rne_postconstraint(const MjhModel* m, const MjhData* d, hipStream_t s) {
+  const int wpb = lds_wpb32((size_t)18 * m->nbody);
+  if (!wpb) return fail(MJH_E_UNSUPPORTED, "k_rne_postconstraint: nbody does not fit in LDS");
+  const size_t lds = sizeof(float) * 18 * m->nbody * wpb;
+  HIPCHK(set_lds(k_rne_postconstraint<32>, lds));
+  hipLaunchKernelGGL(k_rne_postconstraint<32>, dim3((d->nworld + wpb - 1) / wpb), dim3(32 * wpb), lds, s, *m, *d);
+  return MJH_OK;
+}
 static int launch_subtree_vel(const MjhModel* m, const MjhData* d, hipStream_t s) {
   const int wpb = subtree_vel_wpb(m->nbody);
   if (!wpb) return fail(MJH_E_UNSUPPORTED, "k_subtree_vel: nbody does not fit in LDS");
@@ -162,12 +170,12 @@ static int launch_subtree_vel(const MjhModel* m, const MjhData* d, hipStream_t s
 static int launch_sensor(const MjhModel* m, const MjhData* d, int stage, hipStream_t s) {  // stage 1: acceleration-stage sensors (after the solver)
   if (stage == 0 && ((m->enableflags & ENBL_ENERGY) || m->nsensor_energy > 0)) {  // Data.energy rides with the position / velocity stage sensors (forward.py:1326-1338)
     if (!d->energy) return fail(MJH_E_ARG, "Data.energy missing (allocate Data with make_data/put_data)");
-    hipLaunchKernelGGL(k_energy, dim3((d->nworld + 63) / 64), dim3(64), 0, s, *m, *d);
+    hipLaunchKernelGGL(k_energy<32>, dim3((d->nworld + 7) / 8), dim3(256), 0, s, *m, *d);
   }
   if (m->nsensor == 0 || (m->disableflags & DSBL_SENSOR) || (stage == 1 && m->nsensor_acc == 0)) return MJH_OK;
   if (stage == 1 && m->nsensor_frc > 0) {
     if (!d->cfrc_ext) return fail(MJH_E_ARG, "Data.cfrc_ext missing");
-    hipLaunchKernelGGL(k_rne_postconstraint, dim3((d->nworld + 63) / 64), dim3(64), 0, s, *m, *d);
+    TRY(launch_rne_postconstraint(m, d, s));
   }
   if (stage == 0 && m->nsensor_subtree > 0) {
     if (!d->subtree_linvel || !d->subtree_angmom) return fail(MJH_E_ARG, "Data.subtree_linvel / subtree_angmom missing");
@@ -648,7 +656,7 @@ static int run_stage(const MjhModel* m, const MjhData* d, int stage, hipStream_t
     case MJH_STAGE_RNE_POSTCONSTRAINT: {
       if (!d->cfrc_ext) return fail(MJH_E_ARG, "Data.cfrc_ext missing");
       Scope sc(K_OTHER);
-      hipLaunchKernelGGL(k_rne_postconstraint, dim3((d->nworld + 63) / 64), dim3(64), 0, s, *m, *d);
+      TRY(launch_rne_postconstraint(m, d, s));
       return MJH_OK;
     }
     case MJH_STAGE_SUBTREE_VEL: {
@@ -660,7 +668,7 @@ static int run_stage(const MjhModel* m, const MjhData* d, int stage, hipStream_t
     case MJH_STAGE_ENERGY: {
       if (!d->energy) return fail(MJH_E_ARG, "Data.energy missing (allocate Data with make_data/put_data)");
       Scope sc(K_OTHER);
-      hipLaunchKernelGGL(k_energy, dim3((d->nworld + 63) / 64), dim3(64), 0, s, *m, *d);
+      hipLaunchKernelGGL(k_energy<32>, dim3((d->nworld + 7) / 8), dim3(256), 0, s, *m, *d);
       return MJH_OK;
     }
     case MJH_STAGE_SENSOR: { Scope sc(K_OTHER); TRY(launch_sensor(m, d, 0, s)); return launch_sensor(m, d, 1, s); }

@@ -72,20 +72,23 @@ __global__ void __launch_bounds__(256) k_jac(MjhModel m, MjhData d, float* jacp,
 
 // sensor.energy_pos / energy_vel (sensor.py:2773-3018; EnableBit.ENERGY): Data.energy = (potential, kinetic).  Potential = -sum m g . xipos
 // + joint springs 0.5 k r^2 (r = displacement from qpos_spring; quaternion joints: the rotation vector); kinetic = 0.5 qvel . M qvel from
-// the sparse M (row i = the dof's ancestor chain, diagonal last).  One thread per world: a few hundred FLOPs.
-__global__ void __launch_bounds__(64) k_energy(MjhModel m, MjhData d) {
-  const int w = blockIdx.x * 64 + threadIdx.x;
+// the sparse M (row i = the dof's ancestor chain, diagonal last).  One 32-lane group per world: bodies / joints / dofs over the lanes, one
+// cross-lane sum per term (round 3; was one thread per world).
+template <int G>
+__global__ void __launch_bounds__(256) k_energy(MjhModel m, MjhData d) {
+  const int lig = threadIdx.x & (G - 1);
+  const int w = blockIdx.x * (blockDim.x / G) + threadIdx.x / G;
   if (w >= d.nworld) return;
   const V3 g = ld3(bf(m.opt_gravity, m.opt_gravity_nb, w, 3));
   const float* mass = bf(m.body_mass, m.body_mass_nb, w, m.nbody);
   float pot = 0.0f;
   if (!(m.disableflags & DSBL_GRAVITY))
-    for (int b = 1; b < m.nbody; ++b) pot -= mass[b] * dot(g, ld3(d.xipos + ((size_t)w * m.nbody + b) * 3));
+    for (int b = 1 + lig; b < m.nbody; b += G) pot -= mass[b] * dot(g, ld3(d.xipos + ((size_t)w * m.nbody + b) * 3));
   if (!(m.disableflags & DSBL_SPRING)) {
     const float* stiff = bf(m.jnt_stiffness, m.jnt_stiffness_nb, w, m.njnt);
     const float* qs = bf(m.qpos_spring, m.qpos_spring_nb, w, m.nq);
     const float* qpos = d.qpos + (size_t)w * m.nq;
-    for (int j = 0; j < m.njnt; ++j) {
+    for (int j = lig; j < m.njnt; j += G) {
       const float kk = stiff[j];
       if (kk == 0.0f) continue;
       const int qa = m.jnt_qposadr[j], t = m.jnt_type[j];
@@ -105,14 +108,18 @@ __global__ void __launch_bounds__(64) k_energy(MjhModel m, MjhData d) {
   const float* M = d.M + (size_t)w * m.nC;
   const float* v = d.qvel + (size_t)w * m.nv;
   float kin = 0.0f;
-  for (int i = 0; i < m.nv; ++i) {
+  for (int i = lig; i < m.nv; i += G) {
     const int adr = m.M_rowadr[i], nnz = m.M_rownnz[i];
     float acc = 0.5f * M[adr + nnz - 1] * v[i];  // diagonal is the last entry of the row
     for (int q = 0; q < nnz - 1; ++q) acc += M[adr + q] * v[m.M_colind[adr + q]];
     kin += v[i] * acc;
   }
-  d.energy[2 * w] = pot;
-  d.energy[2 * w + 1] = kin;
+  pot = gsum<G>(pot);
+  kin = gsum<G>(kin);
+  if (lig == 0) {
+    d.energy[2 * w] = pot;
+    d.energy[2 * w + 1] = kin;
+  }
 }
 
 // smooth.subtree_vel (smooth.py:3502-3662): linear velocity of every subtree's centre of mass and angular momentum of every subtree about
@@ -187,73 +194,80 @@ static inline int subtree_vel_wpb(int nbody) {
 
 // smooth.rne_postconstraint (smooth.py:1519-1826): cacc, cfrc_ext, cfrc_int with the constraint forces in.  cfrc_ext = applied Cartesian
 // forces + contact forces moved to the tree's centre of mass (spatial vectors: torque first); cacc from qacc down the tree; cfrc_int =
-// I cacc + v x* (I v) - cfrc_ext, summed towards the root.  One thread per world (equality rows: joint equalities exert no cfrc_ext).
-__global__ void __launch_bounds__(64) k_rne_postconstraint(MjhModel m, MjhData d) {
-  const int w = blockIdx.x * 64 + threadIdx.x, nb = m.nbody;
+// I cacc + v x* (I v) - cfrc_ext, summed towards the root (equality rows: joint equalities exert no cfrc_ext).
+// One 32-lane group per world, one lane per body (round 3; was one thread per world): every lane scans the world's contacts in order and keeps
+// those of its body (deterministic sums); cacc of a body = the world's -g + the per-body terms of its ancestor chain; cfrc_int = the sum of the
+// bodies' own terms over the depth-first id range of the subtree.  LDS: 18 nbody floats per world.
+template <int G>
+__global__ void __launch_bounds__(256) k_rne_postconstraint(MjhModel m, MjhData d) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lig = threadIdx.x & (G - 1), gib = threadIdx.x / G, nb = m.nbody;
+  const int w = blockIdx.x * (blockDim.x / G) + gib;
   if (w >= d.nworld) return;
-  float* cext = d.cfrc_ext + (size_t)w * nb * 6;
-  float* cint = d.cfrc_int + (size_t)w * nb * 6;
-  float* cacc = d.cacc + (size_t)w * nb * 6;
+  float* cext = smem + (size_t)gib * 18 * nb;  // cfrc_ext per body
+  float* loc = cext + 6 * nb;                 // per-body acceleration term, then cacc
+  float* own = loc + 6 * nb;                  // the body's own I cacc + v x* (I v) - cfrc_ext
   const float* scom = d.subtree_com + (size_t)w * nb * 3;
-  auto add_force = [&](int b, V3 force, V3 torque, V3 offset, float sgn) {  // support.transform_force: (torque - offset x force, force)
-    const V3 t = torque - cross(offset, force);
-    float* c = cext + 6 * b;
-    c[0] += sgn * t.x; c[1] += sgn * t.y; c[2] += sgn * t.z;
-    c[3] += sgn * force.x; c[4] += sgn * force.y; c[5] += sgn * force.z;
-  };
-  for (int b = 0; b < nb; ++b) {
-    for (int k = 0; k < 6; ++k) cext[6 * b + k] = 0.0f;
-    if (b == 0) continue;
-    const float* xf = d.xfrc_applied + ((size_t)w * nb + b) * 6;
-    add_force(b, ld3(xf), ld3(xf + 3), ld3(scom + 3 * m.body_rootid[b]) - ld3(d.xipos + ((size_t)w * nb + b) * 3), 1.0f);
-  }
-  // contacts: from the world's records (collide.hpp; the public contact arrays are published off the critical path and may not be
-  // there yet when the acceleration-stage sensors run); same decoding as k_contact_force
   const int ncon = min(d.ws_ncon[w], d.concap);
   const float* efc_force = d.efc_force + (size_t)w * d.njmax;
-  for (int c = 0; c < ncon; ++c) {
-    const float* rec = d.ws_contact + ((size_t)w * d.concap + c) * CON_STRIDE;
-    const int* reci = reinterpret_cast<const int*>(rec);
-    const int b1 = m.geom_bodyid[reci[25]], b2 = m.geom_bodyid[reci[26]], adr0 = reci[28], condim = reci[24];
-    if ((b1 == 0 && b2 == 0) || adr0 < 0) continue;
-    float f[6] = {0, 0, 0, 0, 0, 0};
-    if (m.cone == CONE_PYRAMIDAL) {
-      if (condim == 1) f[0] = adr0 < d.njmax ? efc_force[adr0] : 0.0f;
-      else
-        for (int i = 0; i < condim - 1; ++i) {
-          const int a = adr0 + 2 * i;
-          const float d1 = a < d.njmax ? efc_force[a] : 0.0f, d2 = a + 1 < d.njmax ? efc_force[a + 1] : 0.0f;
-          f[0] += d1 + d2;
-          f[i + 1] = (d1 - d2) * rec[CON_FRICTION_WORD(i)];
-        }
-    } else {
-      for (int i = 0; i < condim; ++i)
-        if (adr0 + i < d.njmax) f[i] = efc_force[adr0 + i];
-    }
-    const float* R = rec + 4;  // contact frame rows: normal, tangent 1, tangent 2
-    const V3 force = V3{f[0] * R[0] + f[1] * R[3] + f[2] * R[6], f[0] * R[1] + f[1] * R[4] + f[2] * R[7], f[0] * R[2] + f[1] * R[5] + f[2] * R[8]};
-    const V3 torque = V3{f[3] * R[0] + f[4] * R[3] + f[5] * R[6], f[3] * R[1] + f[4] * R[4] + f[5] * R[7], f[3] * R[2] + f[4] * R[5] + f[5] * R[8]};
-    const V3 pos = ld3(rec + 1);
-    if (b1) add_force(b1, force, torque, ld3(scom + 3 * m.body_rootid[b1]) - pos, -1.0f);
-    if (b2) add_force(b2, force, torque, ld3(scom + 3 * m.body_rootid[b2]) - pos, 1.0f);
-  }
-  const V3 g = ld3(bf(m.opt_gravity, m.opt_gravity_nb, w, 3));
   const float* qvel = d.qvel + (size_t)w * m.nv;
   const float* qacc = d.qacc + (size_t)w * m.nv;
-  for (int b = 0; b < nb; ++b) {
-    float a[6] = {0, 0, 0, 0, 0, 0};
-    if (b == 0) {
-      if (!(m.disableflags & DSBL_GRAVITY)) { a[3] = -g.x; a[4] = -g.y; a[5] = -g.z; }
-    } else {
-      for (int k = 0; k < 6; ++k) a[k] = cacc[6 * m.body_parentid[b] + k];
-      for (int j = 0; j < m.body_dofnum[b]; ++j) {
-        const int dof = m.body_dofadr[b] + j;
-        const float* cd = d.cdof + ((size_t)w * m.nv + dof) * 6;
-        const float* cdd = d.cdof_dot + ((size_t)w * m.nv + dof) * 6;
-        for (int k = 0; k < 6; ++k) a[k] += cdd[k] * qvel[dof] + cd[k] * qacc[dof];
+  for (int b = lig; b < nb; b += G) {
+    float c[6] = {0, 0, 0, 0, 0, 0};
+    auto add_force = [&](V3 force, V3 torque, V3 offset, float sgn) {  // support.transform_force: (torque - offset x force, force)
+      const V3 t = torque - cross(offset, force);
+      c[0] += sgn * t.x; c[1] += sgn * t.y; c[2] += sgn * t.z;
+      c[3] += sgn * force.x; c[4] += sgn * force.y; c[5] += sgn * force.z;
+    };
+    if (b > 0) {
+      const float* xf = d.xfrc_applied + ((size_t)w * nb + b) * 6;
+      add_force(ld3(xf), ld3(xf + 3), ld3(scom + 3 * m.body_rootid[b]) - ld3(d.xipos + ((size_t)w * nb + b) * 3), 1.0f);
+      // contacts: from the world's records (collide.hpp; the public contact arrays are published off the critical path and may not be
+      // there yet when the acceleration-stage sensors run); same decoding as k_contact_force
+      for (int cc = 0; cc < ncon; ++cc) {
+        const float* rec = d.ws_contact + ((size_t)w * d.concap + cc) * CON_STRIDE;
+        const int* reci = reinterpret_cast<const int*>(rec);
+        const int b1 = m.geom_bodyid[reci[25]], b2 = m.geom_bodyid[reci[26]], adr0 = reci[28], condim = reci[24];
+        if ((b1 != b && b2 != b) || adr0 < 0) continue;
+        float f[6] = {0, 0, 0, 0, 0, 0};
+        if (m.cone == CONE_PYRAMIDAL) {
+          if (condim == 1) f[0] = adr0 < d.njmax ? efc_force[adr0] : 0.0f;
+          else
+            for (int i = 0; i < condim - 1; ++i) {
+              const int a = adr0 + 2 * i;
+              const float d1 = a < d.njmax ? efc_force[a] : 0.0f, d2 = a + 1 < d.njmax ? efc_force[a + 1] : 0.0f;
+              f[0] += d1 + d2;
+              f[i + 1] = (d1 - d2) * rec[CON_FRICTION_WORD(i)];
+            }
+        } else {
+          for (int i = 0; i < condim; ++i)
+            if (adr0 + i < d.njmax) f[i] = efc_force[adr0 + i];
+        }
+        const float* R = rec + 4;  // contact frame rows: normal, tangent 1, tangent 2
+        const V3 force = V3{f[0] * R[0] + f[1] * R[3] + f[2] * R[6], f[0] * R[1] + f[1] * R[4] + f[2] * R[7], f[0] * R[2] + f[1] * R[5] + f[2] * R[8]};
+        const V3 torque = V3{f[3] * R[0] + f[4] * R[3] + f[5] * R[6], f[3] * R[1] + f[4] * R[4] + f[5] * R[7], f[3] * R[2] + f[4] * R[5] + f[5] * R[8]};
+        const V3 off = ld3(scom + 3 * m.body_rootid[b]) - ld3(rec + 1);
+        if (b1 == b) add_force(force, torque, off, -1.0f);
+        if (b2 == b) add_force(force, torque, off, 1.0f);
       }
     }
-    for (int k = 0; k < 6; ++k) cacc[6 * b + k] = a[k];
+    for (int k = 0; k < 6; ++k) cext[6 * b + k] = c[k];
+    float a[6] = {0, 0, 0, 0, 0, 0};  // this body's own term of cacc
+    for (int j = 0; b > 0 && j < m.body_dofnum[b]; ++j) {
+      const int dof = m.body_dofadr[b] + j;
+      const float* cd = d.cdof + ((size_t)w * m.nv + dof) * 6;
+      const float* cdd = d.cdof_dot + ((size_t)w * m.nv + dof) * 6;
+      for (int k = 0; k < 6; ++k) a[k] += cdd[k] * qvel[dof] + cd[k] * qacc[dof];
+    }
+    for (int k = 0; k < 6; ++k) loc[6 * b + k] = a[k];
+  }
+  gsync();
+  const V3 g = ld3(bf(m.opt_gravity, m.opt_gravity_nb, w, 3));
+  const bool grav = !(m.disableflags & DSBL_GRAVITY);
+  for (int b = lig; b < nb; b += G) {
+    float a[6] = {0, 0, 0, grav ? -g.x : 0.0f, grav ? -g.y : 0.0f, grav ? -g.z : 0.0f};
+    for (int p = b; p > 0; p = m.body_parentid[p])
+      for (int k = 0; k < 6; ++k) a[k] += loc[6 * p + k];
     float f1[6] = {0, 0, 0, 0, 0, 0}, iv[6], f2[6] = {0, 0, 0, 0, 0, 0};
     if (b > 0) {
       const float* ci = d.cinert + ((size_t)w * nb + b) * 10;
@@ -262,8 +276,24 @@ __global__ void __launch_bounds__(64) k_rne_postconstraint(MjhModel m, MjhData d
       inert_vec(ci, cv, iv);
       motion_cross_force(cv, iv, f2);
     }
-    for (int k = 0; k < 6; ++k) cint[6 * b + k] = b ? f1[k] + f2[k] - cext[6 * b + k] : 0.0f;
+    for (int k = 0; k < 6; ++k) {
+      own[6 * b + k] = b ? f1[k] + f2[k] - cext[6 * b + k] : 0.0f;
+      d.cacc[((size_t)w * nb + b) * 6 + k] = a[k];
+      d.cfrc_ext[((size_t)w * nb + b) * 6 + k] = cext[6 * b + k];
+    }
   }
-  for (int b = nb - 1; b > 0; --b)
-    for (int k = 0; k < 6; ++k) cint[6 * m.body_parentid[b] + k] += cint[6 * b + k];
+  gsync();
+  for (int b = lig; b < nb; b += G) {
+    float s[6] = {0, 0, 0, 0, 0, 0};
+    const int e = b + m.body_subtreenum[b];
+    for (int c = b; c < e; ++c)
+      for (int k = 0; k < 6; ++k) s[k] += own[6 * c + k];
+    for (int k = 0; k < 6; ++k) d.cfrc_int[((size_t)w * nb + b) * 6 + k] = s[k];
+  }
+}
+// worlds per 256-thread workgroup of a 32-lane-per-world kernel with `words` floats of LDS per world (0: does not fit in 64 KB)
+static inline int lds_wpb32(size_t words) {
+  int wpb = 8;
+  while (wpb > 0 && (size_t)wpb * words * sizeof(float) > 65536) wpb >>= 1;
+  return wpb;
 }
