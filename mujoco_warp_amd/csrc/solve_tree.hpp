@@ -49,18 +49,19 @@ static int launch_tree_t(const MjhModel* m, const MjhData* d, hipStream_t s, int
   hipLaunchKernelGGL((k_solve_tree<NV4, NR, NEWTON, SG, LOOPED, ELL>), dim3(grid), dim3(threads), lds, s, *m, *d, lo, hi, nv_lo, nv_hi, need);
   return MJH_OK;
 }
+// (nv_lo, nv_hi]: dofs of the islands this launch solves; nv4 >= ceil(nv_hi / 4)
 template <int NR, bool NEWTON, bool LOOPED, bool ELL = false>
-static int launch_tree_32(const MjhModel* m, const MjhData* d, int nv4, hipStream_t s, int lo, int hi, int need) {
+static int launch_tree_32(const MjhModel* m, const MjhData* d, int nv4, hipStream_t s, int lo, int hi, int need, int nv_lo = 0, int nv_hi = 32) {
   switch (nv4) {
     case 0:
-    case 1: return launch_tree_t<1, NR, NEWTON, 32, LOOPED, ELL>(m, d, s, lo, hi, 0, 32, need);
-    case 2: return launch_tree_t<2, NR, NEWTON, 32, LOOPED, ELL>(m, d, s, lo, hi, 0, 32, need);
-    case 3: return launch_tree_t<3, NR, NEWTON, 32, LOOPED, ELL>(m, d, s, lo, hi, 0, 32, need);
-    case 4: return launch_tree_t<4, NR, NEWTON, 32, LOOPED, ELL>(m, d, s, lo, hi, 0, 32, need);
-    case 5: return launch_tree_t<5, NR, NEWTON, 32, LOOPED, ELL>(m, d, s, lo, hi, 0, 32, need);
-    case 6: return launch_tree_t<6, NR, NEWTON, 32, LOOPED, ELL>(m, d, s, lo, hi, 0, 32, need);
-    case 7: return launch_tree_t<7, NR, NEWTON, 32, LOOPED, ELL>(m, d, s, lo, hi, 0, 32, need);
-    default: return launch_tree_t<8, NR, NEWTON, 32, LOOPED, ELL>(m, d, s, lo, hi, 0, 32, need);
+    case 1: return launch_tree_t<1, NR, NEWTON, 32, LOOPED, ELL>(m, d, s, lo, hi, nv_lo, nv_hi, need);
+    case 2: return launch_tree_t<2, NR, NEWTON, 32, LOOPED, ELL>(m, d, s, lo, hi, nv_lo, nv_hi, need);
+    case 3: return launch_tree_t<3, NR, NEWTON, 32, LOOPED, ELL>(m, d, s, lo, hi, nv_lo, nv_hi, need);
+    case 4: return launch_tree_t<4, NR, NEWTON, 32, LOOPED, ELL>(m, d, s, lo, hi, nv_lo, nv_hi, need);
+    case 5: return launch_tree_t<5, NR, NEWTON, 32, LOOPED, ELL>(m, d, s, lo, hi, nv_lo, nv_hi, need);
+    case 6: return launch_tree_t<6, NR, NEWTON, 32, LOOPED, ELL>(m, d, s, lo, hi, nv_lo, nv_hi, need);
+    case 7: return launch_tree_t<7, NR, NEWTON, 32, LOOPED, ELL>(m, d, s, lo, hi, nv_lo, nv_hi, need);
+    default: return launch_tree_t<8, NR, NEWTON, 32, LOOPED, ELL>(m, d, s, lo, hi, nv_lo, nv_hi, need);
   }
 }
 // the two-size row dispatch of the whole-world solver (mjhip.hip launch_solve_any), per island.  `s`: the launch of the common class (islands
@@ -70,7 +71,20 @@ template <bool NEWTON, bool ELL = false>
 static int launch_tree_all(const MjhModel* m, const MjhData* d, hipStream_t s, hipStream_t sr) {
   const int all = 0x7fffffff;
   // islands of at most 32 dofs: 2 rows per lane cover 64 rows (the common case: one block per two island slots), 6 cover 192
-  if (int rc = launch_tree_32<2, NEWTON, false, ELL>(m, d, m->isl_nv4, s, -1, 64, 0)) return rc;
+  // Size classes (round 3): the kernel is specialised on ceil(dofs / 4) of the WIDEST island the model can form, so a free body (6 dofs)
+  // was solved with 32-wide rows of M / H and an 8-block Cholesky when the model also holds wide islands (clutter_synth: isl_nv4 = 8).
+  // Models with small trees (the trees but the largest average at most 8 dofs) solve the islands of at most 8 / 16 dofs with the
+  // instantiations of that size; the classes touch disjoint islands, so the wider ones go to the stream of the rare classes.
+  static const bool no_classes = getenv("MJH_NO_ISLAND_CLASSES") != nullptr;  // developer knob (A/B)
+  const int top4 = m->isl_nv4;
+  const bool small = !no_classes && m->ntree > 1 && top4 > 2 && (m->nv - m->tree_nvmax) <= 8 * (m->ntree - 1);
+  if (small) {
+    if (int rc = launch_tree_32<2, NEWTON, false, ELL>(m, d, 2, s, -1, 64, 0, 0, 8)) return rc;
+    if (top4 > 4) {
+      if (int rc = launch_tree_32<2, NEWTON, false, ELL>(m, d, 4, sr, -1, 64, 0, 8, 16)) return rc;
+      if (int rc = launch_tree_32<2, NEWTON, false, ELL>(m, d, top4, sr, -1, 64, 0, 16, 32)) return rc;
+    } else if (int rc = launch_tree_32<2, NEWTON, false, ELL>(m, d, top4, sr, -1, 64, 0, 8, 32)) return rc;
+  } else if (int rc = launch_tree_32<2, NEWTON, false, ELL>(m, d, top4, s, -1, 64, 0)) return rc;
   if (d->njmax > 64)
     if (int rc = launch_tree_32<6, NEWTON, true, ELL>(m, d, m->isl_nv4, sr, 64, all, ISL_MANYROWS)) return rc;
   // islands of 33..64 dofs (several trees joined, or a wide tree): one island per wavefront, padded to 64 columns
