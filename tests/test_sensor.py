@@ -10,6 +10,8 @@ compose, cutoffs clamp.  The GPU path is compared with the oracle on a scene car
 import numpy as np
 import pytest
 
+import conftest
+
 import mujoco_warp_amd as mjw
 from mujoco_warp_amd import _npmath as nm
 from oracle import ref
@@ -283,3 +285,46 @@ def test_gpu_force_torque_vs_oracle():
     s._call("rne_postconstraint")
     for f in ("cacc", "cfrc_int", "cfrc_ext"):
       assert np.abs(getattr(d, f).numpy()[w] - getattr(s, f)).max() < 1e-2, f
+
+
+@pytest.mark.gpu
+def test_gpu_subtree_vel_rne_postconstraint_energy_beyond_32_bodies():
+  """The lane-group kernels of the sensor path (csrc/support.hpp: k_subtree_vel, k_rne_postconstraint, k_energy: one lane per body, subtree
+  quantities as range sums over depth-first body ids) on a model with more bodies than lanes -- three humanoids, 49 bodies, several trees,
+  contacts with the floor -- against the oracle's level-by-level recursions."""
+  mjm = mjw.mjcf.from_xml_string(conftest.multi_humanoid_xml(3))
+  assert mjm.nbody > 32
+  mjm.opt.enableflags |= int(mjw.EnableBit.ENERGY)
+  m = mjw.put_model(mjm)
+  d = mjw.make_data(mjm, nworld=3, nconmax=48, njmax=192)
+  rng = np.random.default_rng(3)
+  d.qvel.assign(rng.normal(scale=0.5, size=d.qvel.shape).astype(np.float32))
+  for _ in range(60):  # let the humanoids drop onto the floor: contact forces enter cfrc_ext
+    mjw.step(m, d)
+  mjw.forward(m, d)
+  mjw.subtree_vel(m, d)
+  mjw.rne_postconstraint(m, d)
+  mjw.energy_pos(m, d)
+  mjw.energy_vel(m, d)
+  assert int(d.ws_ncon.numpy().min()) > 0
+  for w in range(3):
+    s = ref.RefSim(mjm, nconmax=48, njmax=192)
+    s.qpos[:], s.qvel[:], s.qacc_warmstart[:] = d.qpos.numpy()[w], d.qvel.numpy()[w], d.qacc_warmstart.numpy()[w]
+    s.forward()
+    s._call("subtree_vel")
+    s._call("rne_postconstraint")
+    for f, tol in (("subtree_linvel", 2e-5), ("subtree_angmom", 2e-4), ("cacc", 5e-3), ("cfrc_ext", 5e-3), ("cfrc_int", 5e-3)):
+      a, b = getattr(d, f).numpy()[w], np.asarray(getattr(s, f))
+      assert np.abs(a - b).max() <= tol * max(1.0, np.abs(b).max()), (f, w, np.abs(a - b).max(), np.abs(b).max())
+    # Data.energy = (potential, kinetic): kinetic against 0.5 v' M v from the oracle's mass matrix, potential against -sum m g . xipos + springs
+    e = d.energy.numpy()[w]
+    v = np.asarray(s.qvel, dtype=np.float64)
+    kin = 0.5 * v @ np.asarray(s.mul_m(v))
+    assert abs(e[1] - kin) <= 1e-4 * max(1.0, abs(kin)), (e, kin)
+    pot = -float(np.sum(np.asarray(mjm.body_mass)[:, None] * np.asarray(s.xipos) * np.asarray(mjm.opt.gravity)[None, :]))
+    stiff = np.asarray(mjm.jnt_stiffness)
+    for j in np.nonzero(stiff)[0]:
+      assert int(mjm.jnt_type[j]) in (2, 3)  # slide / hinge springs only in this model
+      qa = int(mjm.jnt_qposadr[j])
+      pot += 0.5 * stiff[j] * (s.qpos[qa] - mjm.qpos_spring[qa]) ** 2
+    assert abs(e[0] - pot) <= 1e-4 * max(1.0, abs(pot)), (e, pot)
