@@ -25,6 +25,9 @@ SOURCES = [os.path.join(_PKG, "csrc", f) for f in UNITS + HEADERS]
 # scalar forms (tools/ubench.hip: v_pk_fma_f32 4.3 cycles vs v_fma_f32 2.06) and need register pairs plus v_mov shuffles: the Newton
 # kernel drops from 239 to 153 VGPRs and loses a third of its moves without it
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-fno-slp-vectorize", "-Wno-unused-value", "-Wno-pass-failed"]
+# (hardware division / sqrt in EVERY unit was measured in round 3: humanoid CG 0.3417 -> 0.3369 ms, Newton 0.2821 -> 0.2799 ms (+ 1.4 % / + 0.8 %, two
+# interleaved pairs), and one solver parity test moved past its bound (anisotropic elliptic friction, 1.06e-3 against 1e-3): not worth it.  Only
+# the PGS unit takes the flag, below.)
 
 # per-unit extra flags.  pgs_tu.hip: the Gauss-Seidel sweeps are one dependent chain per island in which every row visit divides and the
 # elliptic blocks' QCQP takes square roots; correctly rounded float32 division / sqrt are ~10-instruction sequences on gfx950, the hardware
