@@ -39,6 +39,7 @@ _NNAN = ["-fno-honor-nans", "-fno-signed-zeros"]  # no NaN / signed-zero bookkee
 UNIT_FLAGS = {"pgs_tu.hip": _FAST_DIV, "solve_cg32.hip": _FAST_DIV + _NNAN, "solve_cgw.hip": _FAST_DIV + _NNAN, "solve_cg64.hip": _FAST_DIV + _NNAN}
 # (machine-scheduler strategies for the CG unit, -mllvm -amdgpu-sched-strategy=...: max-ilp 207 -> 223 us per launch, max-memory-clause 208 -> 214:
 # the default stays)
+# (-fno-honor-infinities on top: 208.2 vs 207.5 us, noise)
 for _u in UNITS:  # every other solver unit: value-preserving for finite data, so the parity figures cannot move
   if _u.startswith("solve_") and _u not in UNIT_FLAGS:
     UNIT_FLAGS[_u] = _NNAN
