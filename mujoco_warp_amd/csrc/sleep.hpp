@@ -86,27 +86,7 @@ DEV void sleep_wake_tree(int* asleep, int nt, int treeid, int wakeval) {
     if (current == treeid) break;
   }
 }
-// sleep.py:273
-DEV bool tree_can_sleep(const MjhModel& m, const MjhData& d, int w, int t, float tol) {
-  if (m.tree_sleep_policy[t] == SLEEP_POLICY_AUTO_NEVER) return false;
-  const float* xfrc = d.xfrc_applied + (size_t)w * 6 * m.nbody;
-  for (int b = 0; b < m.nbody; ++b)
-    if (m.body_treeid[b] == t)
-      for (int i = 0; i < 6; ++i)
-        if (xfrc[6 * b + i] != 0.0f) return false;
-  const int adr = m.tree_dofadr[t], num = m.tree_dofnum[t];
-  const float* qfrc = d.qfrc_applied + (size_t)w * m.nv;
-  const float* qvel = d.qvel + (size_t)w * m.nv;
-  for (int k = 0; k < num; ++k)
-    if (qfrc[adr + k] != 0.0f) return false;
-  for (int k = 0; k < num; ++k) {
-    const float v = qvel[adr + k];
-    if (tol > 0.0f) {
-      if (fabsf(m.dof_length[adr + k] * v) >= tol) return false;
-    } else if (v != 0.0f) return false;
-  }
-  return true;
-}
+// (sleep.py:273 tree_can_sleep: policy check in sleep_phase, the force / velocity scans by all lanes in k_sleep)
 DEV int sleep_find(const int* parent, int x) {
   while (parent[x] != x) x = parent[x];
   return x;
@@ -167,14 +147,16 @@ DEV void sleep_island(const MjhModel& m, const MjhData& d, int w, const int* cg)
 }
 
 // the serial part of one phase on a world-local view of Data (see k_sleep)
-DEV void sleep_phase(const MjhModel& m, const MjhData& d, int w, int phase, const int* cg) {
+// busy[t] != 0: tree t fails the force / velocity part of tree_can_sleep (computed by all lanes in k_sleep for the phase's tolerance)
+DEV void sleep_phase(const MjhModel& m, const MjhData& d, int w, int phase, const int* cg, const int* busy) {
+  auto can_sleep = [&](int t) { return m.tree_sleep_policy[t] != SLEEP_POLICY_AUTO_NEVER && !busy[t]; };
   const int nt = m.ntree;
   int* asleep = d.tree_asleep + (size_t)w * nt;
   const int* tawake = d.tree_awake + (size_t)w * nt;
   if (phase == SLP_WAKE) {  // sleep.py:325, 721: user changes (velocity, applied forces, a stale awake table) wake a sleeping tree
     for (int t = 0; t < nt; ++t) {
       if (asleep[t] < 0) continue;
-      if (tawake[t] == 1 || !tree_can_sleep(m, d, w, t, 0.0f)) sleep_wake_tree(asleep, nt, t, SLEEP_AWAKE_VAL);
+      if (tawake[t] == 1 || !can_sleep(t)) sleep_wake_tree(asleep, nt, t, SLEEP_AWAKE_VAL);
     }
   } else if (phase == SLP_WAKE_COLLISION) {  // sleep.py:367, 744: a contact between an awake and a sleeping tree wakes the latter
     bool woke = false;
@@ -216,7 +198,7 @@ DEV void sleep_phase(const MjhModel& m, const MjhData& d, int w, int phase, cons
     for (int t = 0; t < nt; ++t) {  // 1. awake trees count towards sleep while they could sleep
       const int val = asleep[t];
       if (val >= 0) continue;
-      if (tree_can_sleep(m, d, w, t, m.opt_sleep_tolerance)) {
+      if (can_sleep(t)) {
         if (val < -1) asleep[t] = val + 1;
       } else {
         asleep[t] = SLEEP_AWAKE_VAL;
@@ -248,7 +230,7 @@ DEV void sleep_phase(const MjhModel& m, const MjhData& d, int w, int phase, cons
 
 // LDS of one world in k_sleep (ints): the sleep tables, the float vectors the walk reads, row types / ids, (tree 1, tree 2, first row) per contact
 struct SleepLds {
-  int asleep, tawake, bawake, bind, dind, isl, qvel, qacc, qfrc, xfrc, etype, eid, cg, total;
+  int asleep, tawake, bawake, bind, dind, isl, busy, qvel, qacc, qfrc, xfrc, etype, eid, cg, total;
 };
 __host__ __device__ inline SleepLds sleep_lds(int nt, int nb, int nv, int njmax, int concap) {
   SleepLds p;
@@ -256,6 +238,7 @@ __host__ __device__ inline SleepLds sleep_lds(int nt, int nb, int nv, int njmax,
   p.asleep = o; o += nt;
   p.tawake = o; o += nt;
   p.isl = o; o += nt;
+  p.busy = o; o += nt;
   p.bawake = o; o += nb;
   p.bind = o; o += nb;
   p.dind = o; o += nv;
@@ -276,7 +259,7 @@ __global__ void __launch_bounds__(64) k_sleep(MjhModel m, MjhData d, int phase) 
   const int nt = m.ntree, nb = m.nbody, nv = m.nv, njmax = d.njmax;
   const SleepLds L = sleep_lds(nt, nb, nv, njmax, d.concap);
   int *asleep = sl + L.asleep, *tawake = sl + L.tawake, *isl = sl + L.isl, *bawake = sl + L.bawake, *bind = sl + L.bind, *dind = sl + L.dind,
-      *etype = sl + L.etype, *eid = sl + L.eid, *cg = sl + L.cg;
+      *etype = sl + L.etype, *eid = sl + L.eid, *cg = sl + L.cg, *busy = sl + L.busy;
   float *qvel = reinterpret_cast<float*>(sl + L.qvel), *qacc = reinterpret_cast<float*>(sl + L.qacc), *qfrc = reinterpret_cast<float*>(sl + L.qfrc),
         *xfrc = reinterpret_cast<float*>(sl + L.xfrc);
   const int nefc = min(d.nefc[w], njmax), ncon = min(d.ws_ncon[w], d.concap);
@@ -309,6 +292,25 @@ __global__ void __launch_bounds__(64) k_sleep(MjhModel m, MjhData d, int phase) 
       cg[3 * c + 2] = rec[28];
     }
   gsync();
+  // ---- sleep.py:273 tree_can_sleep, the part that scans bodies and dofs: applied forces and velocities per tree, all lanes (the serial walk
+  // looked at every body for every tree: ntree x nbody loads, 100 us for 22 trees x 45 bodies) ----
+  if (vel) {
+    for (int t = lane; t < nt; t += 64) busy[t] = 0;
+    gsync();
+    const float tol = phase == SLP_WAKE ? 0.0f : m.opt_sleep_tolerance;
+    for (int b = lane; b < nb; b += 64) {
+      const int t = m.body_treeid[b];
+      bool f = false;
+      for (int i = 0; i < 6; ++i) f = f || xfrc[6 * b + i] != 0.0f;
+      if (t >= 0 && f) busy[t] = 1;  // (every writer stores the same value)
+    }
+    for (int i = lane; i < nv; i += 64) {
+      const float v = qvel[i];
+      const bool f = qfrc[i] != 0.0f || (tol > 0.0f ? fabsf(m.dof_length[i] * v) >= tol : v != 0.0f);
+      if (f) busy[m.dof_treeid[i]] = 1;
+    }
+    gsync();
+  }
   // ---- the serial walk on the world-local view (every per-world array it touches rebased to this world: used with w = 0) ----
   if (lane == 0) {
     MjhData v = d;
@@ -316,7 +318,7 @@ __global__ void __launch_bounds__(64) k_sleep(MjhModel m, MjhData d, int phase) 
     v.qvel = qvel; v.qacc = qacc; v.qfrc_applied = qfrc; v.xfrc_applied = xfrc; v.efc_type = etype; v.efc_id = eid;
     v.nefc = d.nefc + w; v.ws_ncon = d.ws_ncon + w; v.nisland = d.nisland + w; v.ws_sleep_flag = d.ws_sleep_flag + w;
     v.eq_active = d.eq_active + (size_t)w * m.neq;
-    sleep_phase(m, v, 0, phase, cg);
+    sleep_phase(m, v, 0, phase, cg, busy);
   }
   gsync();
   // ---- sleep.py:171-215 update_sleep (flg_staticawake = 0) by all lanes: ordered compaction with ballot ranks ----
