@@ -1,6 +1,7 @@
 """CPU tests of the host side: MJCF compiler, the C-ABI library (symbols only, no GPU compute), IO boundary."""
 
 import ctypes
+import os
 import re
 
 import numpy as np
@@ -419,3 +420,35 @@ def test_put_model_accepts_a_duck_typed_mjmodel(xml):
   d = mjw.make_data(strict, nworld=2)
   assert d.qpos.shape == (2, mjm.nq)
   assert len(log) > 100  # the whole model was read through the strict view
+
+
+def test_builder_object_cache_keys_follow_sources_and_flags(tmp_path, monkeypatch):
+  """The builder caches one object per translation unit under the hash of everything the unit is compiled from (its source, the quoted
+  headers it includes transitively, the flags): touching a header must change the key of exactly the units that include it."""
+  from mujoco_warp_amd import _abi
+
+  keys = {u: _abi._unit_key(u) for u in _abi.UNITS}
+  assert len(set(keys.values())) == len(keys)  # distinct units, distinct keys
+  assert keys == {u: _abi._unit_key(u) for u in _abi.UNITS}  # deterministic
+  # every unit listed exists, every header it reaches is in the declared source list (needs_build looks at that list)
+  import re
+
+  csrc = os.path.join(os.path.dirname(_abi.__file__), "csrc")
+  declared = set(_abi.UNITS + _abi.HEADERS)
+  for u in _abi.UNITS:
+    seen, todo = set(), [u]
+    while todo:
+      f = todo.pop()
+      if f in seen:
+        continue
+      seen.add(f)
+      for inc in re.findall(r'^\s*#\s*include\s+"([^"]+)"', open(os.path.join(csrc, f)).read(), flags=re.M):
+        if not inc.startswith(".."):
+          todo.append(inc)
+    assert seen <= declared, (u, seen - declared)
+  # flags are part of the key
+  monkeypatch.setitem(_abi.UNIT_FLAGS, "mjhip.hip", ["-DSOMETHING"])
+  assert _abi._unit_key("mjhip.hip") != keys["mjhip.hip"]
+  assert _abi._unit_key("pgs_tu.hip") == keys["pgs_tu.hip"]
+  # the per-unit flags only name real units
+  assert set(_abi.UNIT_FLAGS) <= set(_abi.UNITS)
