@@ -280,122 +280,26 @@ DEV void pgs_big_body(const MjhModel& m, const MjhData& d, float* smem, int w) {
   }
   __threadfence_block();
   gsync();
-  // dot of two rows of J / B over the dofs of the trees row r touches (lane = dof: partial sums, to be reduced over the wavefront)
-  auto row_dots6 = [&](int r, int r0b, int dim, float (&part)[6]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int bq = 0; bq < 6; ++bq) part[bq] = 0.0f;
-    unsigned long long mk = sparse_rows ? ((unsigned long long)tmask[2 * r] | ((unsigned long long)tmask[2 * r + 1] << 32)) : 1ull;
-    while (mk) {
-      const int t = __builtin_ctzll(mk);
-      mk &= mk - 1;
-      const int a0 = sparse_rows ? m.tree_dofadr[t] : 0, n0 = sparse_rows ? m.tree_dofnum[t] : nv;
-      for (int c = a0 + lig; c < a0 + n0; c += G) {
-        const float j = Jg[(size_t)r * nvp + c];
-#pragma unroll
-        for (int bq = 0; bq < 6; ++bq)
-          if (bq < dim) part[bq] += j * Bg[(size_t)(r0b + bq) * nvp + c];
-      }
-    }
-  };
-  // ---- elliptic contacts: row kinds, friction coefficients, the dim x dim blocks of A + R -----------------------------------------
+  // ---- elliptic contacts: row kinds and friction coefficients (lane = row) ------------------------------------------------------------
   if (ell) {
-    for (int r = ne + nf + nl; r < nefc; ++r) {  // (rows in turn, lanes over the row's dofs: coalesced)
+    for (int r = ne + nf + nl + lig; r < nefc; r += G) {
       const int cid = d.ws_efc_con[eo + r], c = cid >> 4, dimid = cid & 15;
       const float* cr = d.ws_contact + ((size_t)w * d.concap + c) * CON_STRIDE;
       const int* cri = reinterpret_cast<const int*>(cr);
       if (cri[24] > 1) {
         const int r0 = r - dimid, dim = min(cri[29], nefc - r0);
-        float part[6];
-        row_dots6(r, r0, dim, part);
-        gsumg_n<G, 6>(part);
-        if (lig == 0) {
-          info[r] = dimid == 0 ? 8 + dim : 7;
-          rmu[r] = dimid == 0 ? 1.0f : cr[CON_FRICTION_WORD(dimid - 1)];
-        }
-        if (lig < 6) blk[6 * r + lig] = (lig < dim ? (lig == 0 ? part[0] : lig == 1 ? part[1] : lig == 2 ? part[2] : lig == 3 ? part[3] : lig == 4 ? part[4] : part[5]) : 0.0f) + (lig == dimid ? Rr[r] : 0.0f);
+        info[r] = dimid == 0 ? 8 + dim : 7;
+        rmu[r] = dimid == 0 ? 1.0f : cr[CON_FRICTION_WORD(dimid - 1)];
       }
     }
     gsync();
   }
-  // ---- warm start: primal forces at qacc_warmstart, kept if their dual cost is negative (engine_forward.c warmstart) ----------------
-  const bool warm = !(m.disableflags & DSBL_WARMSTART);
-  for (int i = lig; i < nv; i += G) tmp[i] = d.qacc_warmstart[vo + i];
-  gsync();
-  float cpart = 0.0f;
-  for (int r = 0; r < nefc; ++r) {  // Jaref at the warm-start point and b_r, rows in turn (lane = dof of the row's trees)
-    float jw = 0.0f, jb = 0.0f;
-    unsigned long long mk = sparse_rows ? ((unsigned long long)tmask[2 * r] | ((unsigned long long)tmask[2 * r + 1] << 32)) : 1ull;
-    while (mk) {
-      const int t = __builtin_ctzll(mk);
-      mk &= mk - 1;
-      const int a0 = sparse_rows ? m.tree_dofadr[t] : 0, n0 = sparse_rows ? m.tree_dofnum[t] : nv;
-      for (int c = a0 + lig; c < a0 + n0; c += G) {
-        const float j = Jg[(size_t)r * nvp + c];
-        jw += j * tmp[c];
-        jb += j * qs[c];
-      }
-    }
-    float two[2] = {jw, jb};
-    gsumg_n<G, 2>(two);
-    if (lig == 0) {
-      xs[r] = two[0] - aref[r];          // (xs is free now: reused as two row vectors)
-      xs[njmax + r] = two[1] - aref[r];  // b_r
-    }
-  }
-  gsync();
-  for (int r = lig; r < nefc; r += G) {
-    float f = 0.0f;
-    if (warm) {
-      const int k = info[r];
-      if (k <= 2) {
-        int st;
-        row_force(k, xs[r], 1.0f / Rr[r], nf > 0, d.efc_frictionloss + eo + r, f, st);
-      } else {  // a row of an elliptic contact: the primal zones (solver.py:455-472), decided from the contact's rows together
-        int r0 = r;
-        while (info[r0] == 7) --r0;
-        const int dim = info[r0] - 8;
-        const float mu = d.ws_contact[((size_t)w * d.concap + (d.ws_efc_con[eo + r0] >> 4)) * CON_STRIDE + 14] * bf(m.opt_impratio_invsqrt, m.opt_impratio_invsqrt_nb, w, 1)[0];
-        float tt = 0.0f;
-        for (int j = 1; j < dim; ++j) tt += (xs[r0 + j] * rmu[r0 + j]) * (xs[r0 + j] * rmu[r0 + j]);
-        const float N = xs[r0] * mu, T = tt <= 0.0f ? 0.0f : sqrtf(tt);
-        const int zone = ell_zone(mu, N, T);
-        if (zone == ST_QUADRATIC) f = -xs[r] / Rr[r];
-        else if (zone == ST_CONE) {
-          const float fnm = -safe_div(1.0f / Rr[r0], mu * mu * (1.0f + mu * mu)) * (N - mu * T) * mu;
-          f = r == r0 ? fnm : -safe_div(fnm, T) * (xs[r] * rmu[r] * rmu[r]);
-        }
-      }
-    }
-    force[r] = f;
-    cpart += f * (xs[njmax + r] + 0.5f * Rr[r] * f);
-  }
-  gsync();
-  float ypart = 0.0f;
-  for (int c = lig; c < nv; c += G) {  // q - qacc_smooth = B' f; the A part of the cost is 0.5 (J' f) . (B' f)
-    float z = 0.0f, y = 0.0f;
-    if (warm)
-      for (int r = 0; r < nefc; ++r) {
-        const float f = force[r];
-        z += f * Bg[(size_t)r * nvp + c];
-        y += f * Jg[(size_t)r * nvp + c];
-      }
-    tmp[c] = z;
-    ypart += 0.5f * y * z;
-  }
-  const float cost = gsumg<G>(cpart + ypart);
-  const bool keep = warm && !(cost > 0.0f);
-  gsync();
-  for (int c = lig; c < nv; c += G) q[c] = qs[c] + (keep ? tmp[c] : 0.0f);
-  if (!keep)
-    for (int r = lig; r < nefc; r += G) force[r] = 0.0f;
-  gsync();
-
   // ---- compact rows (round 3) ---------------------------------------------------------------------------------------------------------
   // A sweep visits the rows one after the other and every visit used to start with a round trip to L2 for the row of J and end with one
   // for the row of B -- 2 x nefc x sweeps dependent global loads per solve (clutter_synth: 50 k).  A row is non-zero on the dofs of the one or
   // two kinematic trees it touches only, so the non-zero parts of J and B (and their column indices) of all rows are packed once into the LDS
-  // region the B build used for its right-hand sides: element l of row r sits at coff[r] + l and belongs to lane l.  The sweep then runs on
-  // LDS alone.  Falls back to the global rows when a row touches more than 64 dofs or the packed rows do not fit.
+  // region the B build used for its right-hand sides: element l of row r sits at coff[r] + l and belongs to lane l.  The block matrices, the warm
+  // start, the sweeps and the final products then run on LDS alone.  Falls back to the global rows when a row touches more than 64 dofs or the packed rows do not fit.
   bool compact = sparse_rows;
   int tot_c = 0, widest_c = 0;
   if (compact) {
@@ -445,13 +349,13 @@ DEV void pgs_big_body(const MjhModel& m, const MjhData& d, float* smem, int w) {
 #pragma unroll
     for (int off = 16; off >= 1; off >>= 1) widest = max(widest, __shfl_xor(widest, off, G));
     if (lig == 0) coff[nefc] = tot;
-    compact = widest <= G && 3 * tot <= xs_words;
+    compact = widest <= G && 3 * tot <= xs_words - 2 * njmax;  // (the first 2 njmax words stay the warm start's row vectors)
     tot_c = tot;
     widest_c = widest;
     gsync();
     if (compact) {
-      float *Jc = xs, *Bc = xs + tot;
-      int* colc = reinterpret_cast<int*>(xs + 2 * tot);
+      float *Jc = xs + 2 * njmax, *Bc = Jc + tot;
+      int* colc = reinterpret_cast<int*>(Bc + tot);
 #pragma unroll 4
       for (int r = 0; r < nefc; ++r) {
         const int o = coff[r], n = coff[r + 1] - o;
@@ -473,6 +377,146 @@ DEV void pgs_big_body(const MjhModel& m, const MjhData& d, float* smem, int w) {
       gsync();
     }
   }
+
+  const float *Jcs = xs + 2 * njmax, *Bcs = Jcs + tot_c;  // the packed rows, for the rest of the set-up
+  const int* colcs = reinterpret_cast<const int*>(Bcs + tot_c);
+  // dot of two rows of J / B over the dofs of the trees row r touches (lane = dof: partial sums, to be reduced over the wavefront)
+  auto row_dots6 = [&](int r, int r0b, int dim, float (&part)[6]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int bq = 0; bq < 6; ++bq) part[bq] = 0.0f;
+    unsigned long long mk = sparse_rows ? ((unsigned long long)tmask[2 * r] | ((unsigned long long)tmask[2 * r + 1] << 32)) : 1ull;
+    while (mk) {
+      const int t = __builtin_ctzll(mk);
+      mk &= mk - 1;
+      const int a0 = sparse_rows ? m.tree_dofadr[t] : 0, n0 = sparse_rows ? m.tree_dofnum[t] : nv;
+      for (int c = a0 + lig; c < a0 + n0; c += G) {
+        const float j = Jg[(size_t)r * nvp + c];
+#pragma unroll
+        for (int bq = 0; bq < 6; ++bq)
+          if (bq < dim) part[bq] += j * Bg[(size_t)(r0b + bq) * nvp + c];
+      }
+    }
+  };
+  // ---- elliptic contacts: row kinds, friction coefficients, the dim x dim blocks of A + R -----------------------------------------
+  if (ell) {
+    for (int r = ne + nf + nl; r < nefc; ++r) {  // (rows in turn, lanes over the row's non-zeros)
+      if (info[r] >= 7) {
+        int r0 = r;
+        while (info[r0] == 7) --r0;
+        const int dimid = r - r0, dim = info[r0] - 8;
+        float part[6];
+        if (compact) {  // (the rows of a contact share one column set: element l of every row is the same dof)
+          const int o = coff[r], n = coff[r + 1] - o;
+          const float j = lig < n ? Jcs[o + lig] : 0.0f;
+#pragma unroll
+          for (int bq = 0; bq < 6; ++bq) part[bq] = (bq < dim && lig < n) ? j * Bcs[coff[r0 + bq] + lig] : 0.0f;
+        } else {
+          row_dots6(r, r0, dim, part);
+        }
+        gsumg_n<G, 6>(part);
+        if (lig < 6) blk[6 * r + lig] = (lig < dim ? (lig == 0 ? part[0] : lig == 1 ? part[1] : lig == 2 ? part[2] : lig == 3 ? part[3] : lig == 4 ? part[4] : part[5]) : 0.0f) + (lig == dimid ? Rr[r] : 0.0f);
+      }
+    }
+    gsync();
+  }
+  // ---- warm start: primal forces at qacc_warmstart, kept if their dual cost is negative (engine_forward.c warmstart) ----------------
+  const bool warm = !(m.disableflags & DSBL_WARMSTART);
+  for (int i = lig; i < nv; i += G) tmp[i] = d.qacc_warmstart[vo + i];
+  gsync();
+  float cpart = 0.0f;
+  for (int r = 0; r < nefc; ++r) {  // Jaref at the warm-start point and b_r, rows in turn (lane = dof of the row's trees)
+    float jw = 0.0f, jb = 0.0f;
+    unsigned long long mk = sparse_rows ? ((unsigned long long)tmask[2 * r] | ((unsigned long long)tmask[2 * r + 1] << 32)) : 1ull;
+    if (compact) {
+      const int o = coff[r];
+      if (lig < coff[r + 1] - o) {
+        const float j = Jcs[o + lig];
+        const int c = colcs[o + lig];
+        jw = j * tmp[c];
+        jb = j * qs[c];
+      }
+      mk = 0ull;
+    }
+    while (mk) {
+      const int t = __builtin_ctzll(mk);
+      mk &= mk - 1;
+      const int a0 = sparse_rows ? m.tree_dofadr[t] : 0, n0 = sparse_rows ? m.tree_dofnum[t] : nv;
+      for (int c = a0 + lig; c < a0 + n0; c += G) {
+        const float j = Jg[(size_t)r * nvp + c];
+        jw += j * tmp[c];
+        jb += j * qs[c];
+      }
+    }
+    float two[2] = {jw, jb};
+    gsumg_n<G, 2>(two);
+    if (lig == 0) {
+      xs[r] = two[0] - aref[r];          // (xs is free now: reused as two row vectors)
+      xs[njmax + r] = two[1] - aref[r];  // b_r
+    }
+  }
+  gsync();
+  for (int r = lig; r < nefc; r += G) {
+    float f = 0.0f;
+    if (warm) {
+      const int k = info[r];
+      if (k <= 2) {
+        int st;
+        row_force(k, xs[r], 1.0f / Rr[r], nf > 0, d.efc_frictionloss + eo + r, f, st);
+      } else {  // a row of an elliptic contact: the primal zones (solver.py:455-472), decided from the contact's rows together
+        int r0 = r;
+        while (info[r0] == 7) --r0;
+        const int dim = info[r0] - 8;
+        const float mu = d.ws_contact[((size_t)w * d.concap + (d.ws_efc_con[eo + r0] >> 4)) * CON_STRIDE + 14] * bf(m.opt_impratio_invsqrt, m.opt_impratio_invsqrt_nb, w, 1)[0];
+        float tt = 0.0f;
+        for (int j = 1; j < dim; ++j) tt += (xs[r0 + j] * rmu[r0 + j]) * (xs[r0 + j] * rmu[r0 + j]);
+        const float N = xs[r0] * mu, T = tt <= 0.0f ? 0.0f : sqrtf(tt);
+        const int zone = ell_zone(mu, N, T);
+        if (zone == ST_QUADRATIC) f = -xs[r] / Rr[r];
+        else if (zone == ST_CONE) {
+          const float fnm = -safe_div(1.0f / Rr[r0], mu * mu * (1.0f + mu * mu)) * (N - mu * T) * mu;
+          f = r == r0 ? fnm : -safe_div(fnm, T) * (xs[r] * rmu[r] * rmu[r]);
+        }
+      }
+    }
+    force[r] = f;
+    cpart += f * (xs[njmax + r] + 0.5f * Rr[r] * f);
+  }
+  gsync();
+  float ypart = 0.0f;
+  if (compact) {  // rows in turn, every lane adds its element into z = B' f (tmp) and y = J' f (q: free until the line after the cost)
+    for (int c = lig; c < nv; c += G) tmp[c] = q[c] = 0.0f;
+    gsync();
+    if (warm)
+      for (int r = 0; r < nefc; ++r) {
+        const int o = coff[r];
+        const float f = force[r];
+        if (lig < coff[r + 1] - o && f != 0.0f) {
+          const int c = colcs[o + lig];
+          tmp[c] += f * Bcs[o + lig];
+          q[c] += f * Jcs[o + lig];
+        }
+        gsync();  // (the next row may reach the same dofs from other lanes)
+      }
+    for (int c = lig; c < nv; c += G) ypart += 0.5f * q[c] * tmp[c];
+  } else
+  for (int c = lig; c < nv; c += G) {  // q - qacc_smooth = B' f; the A part of the cost is 0.5 (J' f) . (B' f)
+    float z = 0.0f, y = 0.0f;
+    if (warm)
+      for (int r = 0; r < nefc; ++r) {
+        const float f = force[r];
+        z += f * Bg[(size_t)r * nvp + c];
+        y += f * Jg[(size_t)r * nvp + c];
+      }
+    tmp[c] = z;
+    ypart += 0.5f * y * z;
+  }
+  const float cost = gsumg<G>(cpart + ypart);
+  const bool keep = warm && !(cost > 0.0f);
+  gsync();
+  for (int c = lig; c < nv; c += G) q[c] = qs[c] + (keep ? tmp[c] : 0.0f);
+  if (!keep)
+    for (int r = lig; r < nefc; r += G) force[r] = 0.0f;
+  gsync();
 
   // ---- islands: the sweep's visits (scalar rows, first rows of elliptic contacts) grouped by wavefront ------------------------------------
   // Trees joined by a row belong to one island (min-label propagation over the rows' tree masks, as k_tree_rows does for CG / Newton); islands
@@ -566,8 +610,8 @@ DEV void pgs_big_body(const MjhModel& m, const MjhData& d, float* smem, int w) {
   __syncthreads();
   if (ctl[0]) return;  // no active row: wavefront 0 wrote the unconstrained solution
   const bool compact = ctl[1] != 0;
-  float *Jc = xs, *Bc = xs + ctl[2];
-  int* colc = reinterpret_cast<int*>(xs + 2 * ctl[2]);
+  float *Jc = xs + 2 * njmax, *Bc = Jc + ctl[2];
+  int* colc = reinterpret_cast<int*>(Bc + ctl[2]);
 
   // ---- sweeps ---------------------------------------------------------------------------------------------------------------------
   const float tolerance = bf(m.opt_tolerance, m.opt_tolerance_nb, w, 1)[0];
@@ -763,6 +807,25 @@ DEV void pgs_big_body(const MjhModel& m, const MjhData& d, float* smem, int w) {
   if (wv != 0) return;
 
   // ---- finish: qfrc_constraint = J' f, qacc = qacc_smooth + B' f, dual states ---------------------------------------------------------
+  if (compact) {  // J' f and B' f from the packed rows (rows in turn; tmp and q are free now)
+    for (int c = lig; c < nv; c += G) tmp[c] = q[c] = 0.0f;
+    gsync();
+    for (int r = 0; r < nefc; ++r) {
+      const int o = coff[r];
+      const float f = force[r];
+      if (lig < coff[r + 1] - o && f != 0.0f) {
+        const int c = colc[o + lig];
+        tmp[c] += f * Bc[o + lig];
+        q[c] += f * Jc[o + lig];
+      }
+      gsync();
+    }
+    for (int c = lig; c < nv; c += G) {
+      d.qacc[vo + c] = qs[c] + tmp[c];
+      d.qfrc_constraint[vo + c] = q[c];
+      d.efc_Ma[vo + c] = d.qfrc_smooth[vo + c] + q[c];
+    }
+  } else
   for (int c = lig; c < nv; c += G) {
     float qc = 0.0f, dq = 0.0f;
     for (int r = 0; r < nefc; ++r) {
