@@ -36,7 +36,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibil
 _FAST_DIV = ["-fno-hip-fp32-correctly-rounded-divide-sqrt"]
 _NNAN = ["-fno-honor-nans", "-fno-signed-zeros"]  # no NaN / signed-zero bookkeeping around min / max / select chains (the solvers produce neither)
 # (_NNAN on mjhip.hip -- kinematics, collision, constraint assembly -- was measured too: no gain, k_mid 84.4 vs 84.0 us)
-UNIT_FLAGS = {"pgs_tu.hip": _FAST_DIV, "solve_cg32.hip": _FAST_DIV + _NNAN, "solve_cgw.hip": _FAST_DIV + _NNAN, "solve_cg64.hip": _FAST_DIV + _NNAN}
+UNIT_FLAGS = {"pgs_tu.hip": _FAST_DIV + _NNAN, "solve_cg32.hip": _FAST_DIV + _NNAN, "solve_cgw.hip": _FAST_DIV + _NNAN, "solve_cg64.hip": _FAST_DIV + _NNAN}
 # (machine-scheduler strategies for the CG unit, -mllvm -amdgpu-sched-strategy=...: max-ilp 207 -> 223 us per launch, max-memory-clause 208 -> 214:
 # the default stays)
 # (-fno-honor-infinities on top: 208.2 vs 207.5 us, noise)
