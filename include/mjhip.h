@@ -118,6 +118,9 @@ typedef struct MjhModel {
   const float* jnt_stiffness; int jnt_stiffness_nb;
   const float* jnt_range; int jnt_range_nb;
   const float* jnt_margin; int jnt_margin_nb;
+  const int* jnt_actfrclimited; /* [njnt] clamp the summed actuator force on the joint's dof (forward.py:1121-1150)                */
+  const float* jnt_actfrcrange; int jnt_actfrcrange_nb; /* [*, njnt, 2]                                                        */
+  const int* jnt_actgravcomp;   /* [njnt] gravity compensation is applied through the actuators (passive.py:652, forward.py:1141)  */
   /* dofs */
   const int* dof_bodyid; const int* dof_jntid; const int* dof_parentid;
   const int* dof_grpadr;        /* first dof of the ball/free rotational triple containing the dof, else the dof itself */
@@ -172,6 +175,7 @@ typedef struct MjhModel {
   /* mesh polygon tables for the multi-contact recovery on mesh faces (types.py:1710-1733; csrc/convex.hpp ccd_multicontact_mesh) */
   int nmeshpoly;                /* polygons of all meshes; 0: no tables (mesh pairs then keep EPA's single contact)           */
   int npolygonmax;              /* the clip buffers hold 2 * npolygonmax points (collision_convex.py:1226-1234)               */
+  int nmeshdegmax;              /* polygons around one mesh vertex, at most (collision_convex.py:1233); 0: no multi-contact recovery on mesh faces */
   const int* mesh_polyadr;      /* [nmesh] first polygon                                                                     */
   const float* mesh_polynormal; /* [nmeshpoly, 3] outward normals, mesh frame                                                */
   const int* mesh_polyvertadr; const int* mesh_polyvertnum; /* [nmeshpoly] into mesh_polyvert                                */
@@ -355,7 +359,7 @@ int mjh_timed_steps(const MjhModel* m, const MjhData* d, int nstep, int step0, f
 int mjh_release_thread_resources(void);
 
 const char* mjh_last_error(void);
-#define MJH_ABI_VERSION 34
+#define MJH_ABI_VERSION 35
 int mjh_abi_version(void); /* returns MJH_ABI_VERSION of the library that was loaded */
 
 #ifdef __cplusplus

@@ -517,7 +517,8 @@ DEV void collide_convex(float tolerance, int iterations, int epa_iterations, int
   if (face >= 0 && anymesh && (!mm || (mm->disableflags & DSBL_MULTICCD) || mm->nmeshpoly == 0)) face = -1;
   if (face >= 0) {  // zero margin: up to four contacts from the EPA face, same distance and frame (collision_convex.py:888-960)
     V3 m1[4], m2[4];
-    n = anymesh ? ccd_multicontact_mesh(*mm, pt, face, w1, w2, a, b, m1, m2) : ccd_multicontact_box(pt, face, w1, w2, a, b, m1, m2);
+    n = anymesh ? ccd_multicontact_mesh(*mm, pt, face, w1, w2, a, b, m1, m2, scratch + (size_t)ccd_words(max(mm->ccd_iterations, mm->epa_iterations), mm->nhfield) * CCD_LANES)
+                : ccd_multicontact_box(pt, face, w1, w2, a, b, m1, m2);
     if (n == 0) return;
     const Frame f = make_frame3(dist <= margin ? m1[0] - m2[0] : m2[0] - m1[0]);
     for (int i = 0; i < n; ++i) emit(i, dist, 0.5f * (m1[i] + m2[i]), f.a, f.b, f.c);
@@ -1303,7 +1304,7 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
     return adr >= 0 ? m.mesh_graph + adr : nullptr;
   };
   // EPA polytope of this lane (convex.hpp): word k of lane l at k * 32 + l inside the world's slice of d.ws_ccd
-  float* ccd_scratch = (HEAVY && d.ws_ccd) ? d.ws_ccd + (size_t)w * ccd_words(max(m.ccd_iterations, m.epa_iterations), m.nhfield) * CCD_LANES + (lig & (CCD_LANES - 1)) : nullptr;
+  float* ccd_scratch = (HEAVY && d.ws_ccd) ? d.ws_ccd + (size_t)w * (ccd_words(max(m.ccd_iterations, m.epa_iterations), m.nhfield) + (m.nmeshdegmax > 0 ? ccd_mc_words(m.npolygonmax, m.nmeshdegmax) : 0)) * CCD_LANES + (lig & (CCD_LANES - 1)) : nullptr;
   const int hf0 = ccd_words(max(m.ccd_iterations, m.epa_iterations), 0);  // first word of the lane's height-field result table
   const float ccd_tol = HEAVY ? bf(m.opt_ccd_tolerance, m.opt_ccd_tolerance_nb, w, 1)[0] : 0.0f;
   const int ccd_it = min(m.ccd_iterations, CCD_MAX_ITER), epa_it = min(m.epa_iterations, CCD_MAX_ITER);

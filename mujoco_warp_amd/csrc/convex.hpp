@@ -41,6 +41,7 @@ __host__ __device__ inline int ccd_poly_words(int iterations) {
 __host__ __device__ inline int ccd_words(int iterations, int hfield = 0) {
   return ccd_poly_words(iterations) + CCD_CACHE_SLOTS * CCD_CACHE_WORDS + (hfield ? CCD_HF_WORDS : 0);
 }
+// (models with multi-contact recovery on mesh faces append ccd_mc_words(npolygonmax, nmeshdegmax) words per lane: further below)
 
 struct CcdGeom {
   int type;
@@ -858,26 +859,27 @@ DEV int mc_box_face(const CcdGeom& g, int idx, V3 (&face)[4]) {
   return 4;
 }
 DEV float mc_area4(V3 a, V3 b, V3 c, V3 d) { return 0.5f * length(cross(a - d, d - b) + cross(b - c, c - a)); }
-DEV void mc_polygon_quad(const V3* poly, int n, int (&res)[4]) {
+template <class Get>
+DEV void mc_polygon_quad_g(Get&& P, int n, int (&res)[4]) {
   int b = 1, c = 2, d = 3;
   res[0] = 0; res[1] = b; res[2] = c; res[3] = d;
-  float m = mc_area4(poly[0], poly[b], poly[c], poly[d]);
+  float m = mc_area4(P(0), P(b), P(c), P(d));
   for (int a = 0; a < n; ++a) {
     for (;;) {
-      float mn = mc_area4(poly[a], poly[b], poly[c], poly[(d + 1) % n]);
+      float mn = mc_area4(P(a), P(b), P(c), P((d + 1) % n));
       if (mn <= m) break;
       m = mn;
       d = (d + 1) % n;
       res[0] = a; res[1] = b; res[2] = c; res[3] = d;
       for (;;) {
-        mn = mc_area4(poly[a], poly[b], poly[(c + 1) % n], poly[d]);
+        mn = mc_area4(P(a), P(b), P((c + 1) % n), P(d));
         if (mn <= m) break;
         m = mn;
         c = (c + 1) % n;
         res[0] = a; res[1] = b; res[2] = c; res[3] = d;
       }
       for (;;) {
-        mn = mc_area4(poly[a], poly[(b + 1) % n], poly[c], poly[d]);
+        mn = mc_area4(P(a), P((b + 1) % n), P(c), P(d));
         if (mn <= m) break;
         m = mn;
         b = (b + 1) % n;
@@ -892,6 +894,9 @@ DEV void mc_polygon_quad(const V3* poly, int n, int (&res)[4]) {
       }
     }
   }
+}
+DEV void mc_polygon_quad(const V3* poly, int n, int (&res)[4]) {
+  mc_polygon_quad_g([&](int i) { return poly[i]; }, n, res);
 }
 // clip polygon face2 against the side planes of face1 (normal n): w2 = clipped points, w1 = w2 - dir; returns the number of contacts
 DEV int mc_polygon_clip(const V3 (&face1)[4], int nface1, const V3 (&face2)[4], int nface2, V3 n, V3 dir, V3 (&w1)[4], V3 (&w2)[4]) {
@@ -1042,10 +1047,35 @@ DEV int ccd_multicontact_box(const Poly& pt, int epa_face, V3 x1, V3 x2, const C
 
 // ---- multi-contact recovery with mesh faces (collision_gjk.py:1556-1700, 1891-1913, 2076-2300) ------------------------------------------
 // Pairs box-mesh / mesh-mesh, unless DisableBit.MULTICCD.  Same flow as ccd_multicontact_box with the mesh polygon tables of the Model
-// (types.py:1707-1733) in place of the box's closed forms.  Features hold up to MC_GN normals / polygon vertices (put_model checks the
-// meshes against it); the arrays are indexed dynamically, so this lives in scratch memory: a separate non-inlined function keeps it out of
-// the register budget of the narrowphase that calls it (it runs for the few pairs whose EPA face is a face-face / edge-face contact).
-#define MC_GN 8
+// (types.py:1707-1733) in place of the box's closed forms.  Like the reference (collision_convex.py:1346-1366) the feature buffers are
+// sized from the MODEL -- npolygonmax vertices per polygon, nmeshdegmax polygons around a vertex (aloha_pot: 76 / 43) -- and live in
+// the lane's slice of Data.ws_ccd behind the EPA polytope (word k of lane l at k * CCD_LANES + l, like the polytope itself); a separate
+// non-inlined function keeps it out of the register budget of the narrowphase that calls it (it runs for the few pairs whose EPA face
+// is a face-face / edge-face contact).
+__host__ __device__ inline int ccd_mc_p(int npolygonmax) { return npolygonmax > 4 ? npolygonmax : 4; }
+__host__ __device__ inline int ccd_mc_d(int nmeshdegmax) { return nmeshdegmax > 3 ? nmeshdegmax : 3; }
+__host__ __device__ inline int ccd_mc_words(int npolygonmax, int nmeshdegmax) {  // idx1 idx2 | n1 n2 endv | face1 face2 pn | pd | bufa bufb
+  return 11 * ccd_mc_d(nmeshdegmax) + 22 * ccd_mc_p(npolygonmax);
+}
+struct WsI {  // int array in the lane's interleaved workspace
+  int* p;
+  DEV int get(int i) const { return p[(size_t)i * CCD_LANES]; }
+  DEV void set(int i, int v) const { p[(size_t)i * CCD_LANES] = v; }
+};
+struct WsF {
+  float* p;
+  DEV float get(int i) const { return p[(size_t)i * CCD_LANES]; }
+  DEV void set(int i, float v) const { p[(size_t)i * CCD_LANES] = v; }
+};
+struct WsV {  // V3 array
+  float* p;
+  DEV V3 get(int i) const { return V3{p[(size_t)(3 * i) * CCD_LANES], p[(size_t)(3 * i + 1) * CCD_LANES], p[(size_t)(3 * i + 2) * CCD_LANES]}; }
+  DEV void set(int i, V3 v) const {
+    p[(size_t)(3 * i) * CCD_LANES] = v.x;
+    p[(size_t)(3 * i + 1) * CCD_LANES] = v.y;
+    p[(size_t)(3 * i + 2) * CCD_LANES] = v.z;
+  }
+};
 DEV int mc_intersect(const int* a1, int n1, const int* a2, int n2, int (&res)[2]) {
   int count = 0;
   for (int i = 0; i < n1; ++i)
@@ -1065,7 +1095,7 @@ DEV MeshTab mesh_tab(const MjhModel& m, const CcdGeom& g) {
   const int pa = m.mesh_polyadr[g.meshid], va = m.mesh_vertadr[g.meshid];
   return MeshTab{g.vert, m.mesh_polynormal + 3 * pa, m.mesh_polyvertadr + pa, m.mesh_polyvertnum + pa, m.mesh_polyvert, m.mesh_polymapadr + va, m.mesh_polymapnum + va, m.mesh_polymap};
 }
-DEV int mc_mesh_normals(int dim, const int (&fi)[3], const MeshTab& t, const float* rot, V3* nout, int* iout) {
+DEV int mc_mesh_normals(int dim, const int (&fi)[3], const MeshTab& t, const float* rot, int cap, const WsV& nout, const WsI& iout) {
   const int* m1 = t.polymap + t.polymapadr[fi[0]];
   const int n1 = t.polymapnum[fi[0]];
   if (dim == 3) {
@@ -1074,97 +1104,98 @@ DEV int mc_mesh_normals(int dim, const int (&fi)[3], const MeshTab& t, const flo
     if (n == 0) return 0;
     n = mc_intersect(edgeset, n, t.polymap + t.polymapadr[fi[2]], t.polymapnum[fi[2]], faceset);
     if (n == 0) return 0;
-    nout[0] = mat_mul(rot, ld3(t.polynormal + 3 * faceset[0]));
-    iout[0] = faceset[0];
+    nout.set(0, mat_mul(rot, ld3(t.polynormal + 3 * faceset[0])));
+    iout.set(0, faceset[0]);
     return 1;
   }
   if (dim == 2) {
     int edgeset[2];
     const int n = mc_intersect(m1, n1, t.polymap + t.polymapadr[fi[1]], t.polymapnum[fi[1]], edgeset);
     for (int i = 0; i < n; ++i) {
-      nout[i] = mat_mul(rot, ld3(t.polynormal + 3 * edgeset[i]));
-      iout[i] = edgeset[i];
+      nout.set(i, mat_mul(rot, ld3(t.polynormal + 3 * edgeset[i])));
+      iout.set(i, edgeset[i]);
     }
     return n;
   }
   if (dim == 1) {
-    const int n = min(n1, MC_GN);
+    const int n = min(n1, cap);
     for (int i = 0; i < n; ++i) {
-      nout[i] = mat_mul(rot, ld3(t.polynormal + 3 * m1[i]));
-      iout[i] = m1[i];
+      nout.set(i, mat_mul(rot, ld3(t.polynormal + 3 * m1[i])));
+      iout.set(i, m1[i]);
     }
     return n;
   }
   return 0;
 }
-DEV int mc_mesh_edge_normals(int dim, const MeshTab& t, const CcdGeom& g, V3 v1, V3 v2, int v1i, V3* nout, V3* endv) {
+DEV int mc_mesh_edge_normals(int dim, const MeshTab& t, const CcdGeom& g, V3 v1, V3 v2, int v1i, int cap, const WsV& nout, const WsV& endv) {
   if (dim == 2) {
-    endv[0] = v2;
-    nout[0] = normalize(v2 - v1);
+    endv.set(0, v2);
+    nout.set(0, normalize(v2 - v1));
     return 1;
   }
   if (dim == 1) {
     const int* pm = t.polymap + t.polymapadr[v1i];
-    const int n = min(t.polymapnum[v1i], MC_GN);
+    const int n = min(t.polymapnum[v1i], cap);
     for (int i = 0; i < n; ++i) {
       const int adr = t.polyvertadr[pm[i]], nv = t.polyvertnum[pm[i]];
       for (int j = 0; j < nv; ++j)
         if (t.polyvert[adr + j] == v1i) {
           const int k = j == 0 ? nv - 1 : j - 1;
-          endv[i] = mat_mul(g.rot, ld3(t.vert + 3 * t.polyvert[adr + k])) + g.pos;
-          nout[i] = normalize(endv[i] - v1);
+          const V3 e = mat_mul(g.rot, ld3(t.vert + 3 * t.polyvert[adr + k])) + g.pos;
+          endv.set(i, e);
+          nout.set(i, normalize(e - v1));
         }
     }
     return n;
   }
   return 0;
 }
-DEV int mc_mesh_face(const MeshTab& t, const CcdGeom& g, int idx, V3* face) {
-  const int adr = t.polyvertadr[idx], nv = min(t.polyvertnum[idx], MC_GN);
+DEV int mc_mesh_face(const MeshTab& t, const CcdGeom& g, int idx, int cap, const WsV& face) {
+  const int adr = t.polyvertadr[idx], nv = min(t.polyvertnum[idx], cap);
   int j = 0;
-  for (int i = nv - 1; i >= 0; --i) face[j++] = mat_mul(g.rot, ld3(t.vert + 3 * t.polyvert[adr + i])) + g.pos;
+  for (int i = nv - 1; i >= 0; --i) face.set(j++, mat_mul(g.rot, ld3(t.vert + 3 * t.polyvert[adr + i])) + g.pos);
   return nv;
 }
-// mc_polygon_clip for polygons of up to MC_GN vertices; cap = 2 * npolygonmax slots (collision_convex.py:1226-1234)
-DEV int mc_polygon_clip_n(const V3* face1, int nface1, const V3* face2, int nface2, V3 n, V3 dir, int cap, V3 (&w1)[4], V3 (&w2)[4]) {
+// mc_polygon_clip on workspace polygons; cap = 2 * npolygonmax slots per clip buffer (collision_convex.py:1346-1348)
+DEV int mc_polygon_clip_ws(const WsV& face1, int nface1, const WsV& face2, int nface2, V3 n, V3 dir, int cap, const WsV& pn, const WsF& pd, WsV poly, WsV clip,
+                           V3 (&w1)[4], V3 (&w2)[4]) {
   if (nface1 < 3) return 0;
-  V3 pn[MC_GN], bufa[2 * MC_GN], bufb[2 * MC_GN];
-  float pd[MC_GN];
-  V3* poly = bufa;
-  V3* clip = bufb;
-  cap = min(cap, 2 * MC_GN);
   for (int i = 0; i < nface1; ++i) {
-    const V3 a = face1[i], b = face1[(i + 1) % nface1];
-    pn[i] = cross(b - a, (a + n) - a);
-    pd[i] = dot(pn[i], a);
+    const V3 a = face1.get(i), b = face1.get((i + 1) % nface1);
+    const V3 pni = cross(b - a, (a + n) - a);
+    pn.set(i, pni);
+    pd.set(i, dot(pni, a));
   }
   int np = nface2, nc = 0;
-  for (int i = 0; i < nface2; ++i) poly[i] = face2[i];
+  for (int i = 0; i < nface2; ++i) poly.set(i, face2.get(i));
   for (int e = 0; e < nface1; ++e) {
+    const V3 fe = face1.get(e), pne = pn.get(e);
+    const float pde = pd.get(e);
+    V3 P = np > 0 ? poly.get(0) : V3{0, 0, 0};
     for (int i = 0; i < np; ++i) {
-      const V3 P = poly[i], Q = poly[(i + 1) % np];
-      const bool in1 = dot(P - face1[e], pn[e]) > -1e-10f, in2 = dot(Q - face1[e], pn[e]) > -1e-10f;
-      if (!in1 && !in2) continue;
+      const V3 Q = poly.get((i + 1) % np);
+      const bool in1 = dot(P - fe, pne) > -1e-10f, in2 = dot(Q - fe, pne) > -1e-10f;
       if (in1 && in2) {
-        if (nc < cap) clip[nc] = Q;
+        if (nc < cap) clip.set(nc, Q);
         ++nc;
-        continue;
+      } else if (in1 || in2) {
+        const V3 pq = Q - P;
+        const float dt = dot(pne, pq);
+        float t = fabsf(dt) < 1e-10f ? CCD_FLOAT_MAX : (pde - dot(pne, P)) / dt;
+        if (t > -CCD_INTERSECT_TOL && t < 1.0f + CCD_INTERSECT_TOL) {
+          t = clampf(t, 0.0f, 1.0f);
+          if (nc < cap) clip.set(nc, P + t * pq);
+          ++nc;
+        }
+        if (in2) {
+          if (nc < cap) clip.set(nc, Q);
+          ++nc;
+        }
       }
-      const V3 pq = Q - P;
-      const float dt = dot(pn[e], pq);
-      float t = fabsf(dt) < 1e-10f ? CCD_FLOAT_MAX : (pd[e] - dot(pn[e], P)) / dt;
-      if (t > -CCD_INTERSECT_TOL && t < 1.0f + CCD_INTERSECT_TOL) {
-        t = clampf(t, 0.0f, 1.0f);
-        if (nc < cap) clip[nc] = P + t * pq;
-        ++nc;
-      }
-      if (in2) {
-        if (nc < cap) clip[nc] = Q;
-        ++nc;
-      }
+      P = Q;
     }
     if (nc > cap) nc = cap;
-    V3* tmp = poly;
+    const WsV tmp = poly;
     poly = clip;
     clip = tmp;
     np = nc;
@@ -1174,9 +1205,10 @@ DEV int mc_polygon_clip_n(const V3* face1, int nface1, const V3* face2, int nfac
   if (nface2 == 2 && np > 2) {
     int b1 = 0, b2 = 1;
     float maxd = 0.0f;
-    for (int i = 0; i < np; ++i)
+    for (int i = 0; i < np; ++i) {
+      const V3 pi = poly.get(i);
       for (int j = i + 1; j < np; ++j) {
-        const V3 df = poly[j] - poly[i];
+        const V3 df = poly.get(j) - pi;
         const float d2 = dot(df, df);
         if (d2 > maxd) {
           maxd = d2;
@@ -1184,124 +1216,145 @@ DEV int mc_polygon_clip_n(const V3* face1, int nface1, const V3* face2, int nfac
           b2 = j;
         }
       }
-    w2[0] = poly[b1];
+    }
+    w2[0] = poly.get(b1);
     w1[0] = w2[0] - dir;
-    w2[1] = poly[b2];
+    w2[1] = poly.get(b2);
     w1[1] = w2[1] - dir;
     return 2;
   }
   if (np > 4) {
     int q[4];
-    mc_polygon_quad(poly, np, q);
+    mc_polygon_quad_g([&](int i) { return poly.get(i); }, np, q);
     for (int i = 0; i < 4; ++i) {
-      w2[i] = poly[q[i]];
+      w2[i] = poly.get(q[i]);
       w1[i] = w2[i] - dir;
     }
     return 4;
   }
   for (int i = 0; i < np; ++i) {
-    w2[i] = poly[i];
+    w2[i] = poly.get(i);
     w1[i] = w2[i] - dir;
   }
   return np;
 }
+// ws = the lane's multi-contact words (behind the polytope, the contact cache and the height-field table of Data.ws_ccd)
 __device__ __noinline__ int ccd_multicontact_mesh(const MjhModel& m, const Poly& pt, int epa_face, V3 x1, V3 x2, const CcdGeom& g1, const CcdGeom& g2,
-                                                  V3 (&w1)[4], V3 (&w2)[4]) {
+                                                  V3 (&w1)[4], V3 (&w2)[4], float* ws) {
   w1[0] = x1;
   w2[0] = x2;
   const unsigned fc = (unsigned)pt.face(epa_face);
   const int face[3] = {(int)(fc & 0x3FF), (int)((fc >> 10) & 0x3FF), (int)((fc >> 20) & 0x3FF)};
   const bool mesh1 = g1.type == G_MESH, mesh2 = g2.type == G_MESH;
   const MeshTab t1 = mesh1 ? mesh_tab(m, g1) : MeshTab{}, t2 = mesh2 ? mesh_tab(m, g2) : MeshTab{};
-  int fi1[3], fi2[3], idx1[MC_GN], idx2[MC_GN];
-  V3 fv1[3], fv2[3], n1[MC_GN], n2[MC_GN], endv[MC_GN];
+  const int D = ccd_mc_d(m.nmeshdegmax), P = ccd_mc_p(m.npolygonmax);
+  auto at = [&](int word) { return ws + (size_t)word * CCD_LANES; };
+  const WsI idx1{reinterpret_cast<int*>(at(0))}, idx2{reinterpret_cast<int*>(at(D))};
+  const WsV n1{at(2 * D)}, n2{at(5 * D)}, endv{at(8 * D)};
+  const int f0 = 11 * D;
+  const WsV face1{at(f0)}, face2{at(f0 + 3 * P)}, pn{at(f0 + 6 * P)};
+  const WsF pd{at(f0 + 9 * P)};
+  const WsV bufa{at(f0 + 10 * P)}, bufb{at(f0 + 16 * P)};
+  int fi1[3], fi2[3];
+  V3 fv1[3], fv2[3];
   const int nf1 = mc_feature_dim(pt, face, 0, fi1, fv1), nf2 = mc_feature_dim(pt, face, 1, fi2, fv2);
   const V3 dir = x2 - x1;
-  auto box_normals = [&](int dim, const int (&fi)[3], const float* rot, V3 d, V3* nout, int* iout) {
+  auto box_normals = [&](int dim, const int (&fi)[3], const float* rot, V3 d, const WsV& nout, const WsI& iout) {
     V3 nb[3];
     int ib[3] = {0, 0, 0};
     const int n = mc_box_normals(dim, fi, rot, d, nb, ib);
     for (int k = 0; k < n; ++k) {
-      nout[k] = nb[k];
-      iout[k] = ib[k];
+      nout.set(k, nb[k]);
+      iout.set(k, ib[k]);
     }
     return n;
   };
-  auto box_edge_normals = [&](int dim, const CcdGeom& g, V3 v1, V3 v2, int v1i, V3* nout, V3* ev) {
+  auto box_edge_normals = [&](int dim, const CcdGeom& g, V3 v1, V3 v2, int v1i, const WsV& nout, const WsV& ev) {
     V3 nb[3], eb[3];
     const int n = mc_box_edge_normals(dim, g, v1, v2, v1i, nb, eb);
     for (int k = 0; k < n; ++k) {
-      nout[k] = nb[k];
-      ev[k] = eb[k];
+      nout.set(k, nb[k]);
+      ev.set(k, eb[k]);
     }
     return n;
   };
-  auto box_face = [&](const CcdGeom& g, int idx, V3* f) {
+  auto box_face = [&](const CcdGeom& g, int idx, const WsV& f) {
     V3 fb[4];
     const int n = mc_box_face(g, idx, fb);
-    for (int k = 0; k < n; ++k) f[k] = fb[k];
+    for (int k = 0; k < n; ++k) f.set(k, fb[k]);
     return n;
   };
-  int nn1 = mesh1 ? mc_mesh_normals(nf1, fi1, t1, g1.rot, n1, idx1) : box_normals(nf1, fi1, g1.rot, -dir, n1, idx1);
-  int nn2 = mesh2 ? mc_mesh_normals(nf2, fi2, t2, g2.rot, n2, idx2) : box_normals(nf2, fi2, g2.rot, dir, n2, idx2);
+  int nn1 = mesh1 ? mc_mesh_normals(nf1, fi1, t1, g1.rot, D, n1, idx1) : box_normals(nf1, fi1, g1.rot, -dir, n1, idx1);
+  int nn2 = mesh2 ? mc_mesh_normals(nf2, fi2, t2, g2.rot, D, n2, idx2) : box_normals(nf2, fi2, g2.rot, dir, n2, idx2);
   bool edge1 = false, edge2 = false, found = false;
   int ri = 0, rj = 0;
-  for (int i = 0; i < nn1 && !found; ++i)
+  for (int i = 0; i < nn1 && !found; ++i) {
+    const V3 a = n1.get(i);
     for (int j = 0; j < nn2 && !found; ++j)
-      if (dot(n1[i], n2[j]) < -CCD_FACE_TOL) {
+      if (dot(a, n2.get(j)) < -CCD_FACE_TOL) {
         ri = i;
         rj = j;
         found = true;
       }
+  }
   if (!found) {
     if (nf1 < 3 && nf1 <= nf2) {
-      nn1 = mesh1 ? mc_mesh_edge_normals(nf1, t1, g1, fv1[0], fv1[1], fi1[0], n1, endv) : box_edge_normals(nf1, g1, fv1[0], fv1[1], fi1[0], n1, endv);
-      for (int i = 0; i < nn2 && !found; ++i)
+      nn1 = mesh1 ? mc_mesh_edge_normals(nf1, t1, g1, fv1[0], fv1[1], fi1[0], D, n1, endv) : box_edge_normals(nf1, g1, fv1[0], fv1[1], fi1[0], n1, endv);
+      for (int i = 0; i < nn2 && !found; ++i) {
+        const V3 b = n2.get(i);
         for (int j = 0; j < nn1 && !found; ++j)
-          if (fabsf(dot(n1[j], n2[i])) < CCD_EDGE_TOL) {
+          if (fabsf(dot(n1.get(j), b)) < CCD_EDGE_TOL) {
             ri = j;
             rj = i;
             found = true;
           }
+      }
       if (!found) return 1;
       edge1 = true;
     } else if (nf2 < 3) {
-      nn2 = mesh2 ? mc_mesh_edge_normals(nf2, t2, g2, fv2[0], fv2[1], fi2[0], n2, endv) : box_edge_normals(nf2, g2, fv2[0], fv2[1], fi2[0], n2, endv);
-      for (int i = 0; i < nn1 && !found; ++i)
+      nn2 = mesh2 ? mc_mesh_edge_normals(nf2, t2, g2, fv2[0], fv2[1], fi2[0], D, n2, endv) : box_edge_normals(nf2, g2, fv2[0], fv2[1], fi2[0], n2, endv);
+      for (int i = 0; i < nn1 && !found; ++i) {
+        const V3 a = n1.get(i);
         for (int j = 0; j < nn2 && !found; ++j)
-          if (fabsf(dot(n2[j], n1[i])) < CCD_EDGE_TOL) {
+          if (fabsf(dot(n2.get(j), a)) < CCD_EDGE_TOL) {
             ri = j;
             rj = i;
             found = true;
           }
+      }
       if (!found) return 1;
       edge2 = true;
     } else {
       return 1;
     }
   }
-  V3 face1[MC_GN], face2[MC_GN];
   int nface1, nface2;
   if (edge1) {
-    face1[0] = pt.vert(2 * face[0]);
-    face1[1] = endv[ri];
+    face1.set(0, pt.vert(2 * face[0]));
+    face1.set(1, endv.get(ri));
     nface1 = 2;
   } else {
-    const int ind = edge2 ? idx1[rj] : idx1[ri];
-    nface1 = mesh1 ? mc_mesh_face(t1, g1, ind, face1) : box_face(g1, ind, face1);
+    const int ind = edge2 ? idx1.get(rj) : idx1.get(ri);
+    nface1 = mesh1 ? mc_mesh_face(t1, g1, ind, P, face1) : box_face(g1, ind, face1);
   }
   if (edge2) {
-    face2[0] = pt.vert(2 * face[0] + 1);
-    face2[1] = endv[ri];
+    face2.set(0, pt.vert(2 * face[0] + 1));
+    face2.set(1, endv.get(ri));
     nface2 = 2;
   } else {
-    nface2 = mesh2 ? mc_mesh_face(t2, g2, idx2[rj], face2) : box_face(g2, idx2[rj], face2);
+    nface2 = mesh2 ? mc_mesh_face(t2, g2, idx2.get(rj), P, face2) : box_face(g2, idx2.get(rj), face2);
   }
   const float dn = length(dir);
-  const int cap = 2 * m.npolygonmax;
-  if (edge1) return mc_polygon_clip_n(face2, nface2, face1, nface1, n2[rj], (-dn) * n2[rj], cap, w2, w1);
-  if (edge2) return mc_polygon_clip_n(face1, nface1, face2, nface2, n1[rj], (-dn) * n1[rj], cap, w1, w2);
-  return mc_polygon_clip_n(face1, nface1, face2, nface2, n1[ri], dn * n2[rj], cap, w1, w2);
+  const int cap = 2 * P;
+  if (edge1) {
+    const V3 nn = n2.get(rj);
+    return mc_polygon_clip_ws(face2, nface2, face1, nface1, nn, (-dn) * nn, cap, pn, pd, bufa, bufb, w2, w1);
+  }
+  if (edge2) {
+    const V3 nn = n1.get(rj);
+    return mc_polygon_clip_ws(face1, nface1, face2, nface2, nn, (-dn) * nn, cap, pn, pd, bufa, bufb, w1, w2);
+  }
+  return mc_polygon_clip_ws(face1, nface1, face2, nface2, n1.get(ri), dn * n2.get(rj), cap, pn, pd, bufa, bufb, w1, w2);
 }
 
 DEV bool is_convex_pair(int t1, int t2) {

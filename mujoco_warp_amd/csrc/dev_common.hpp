@@ -149,13 +149,13 @@ DEV Q4 axis_angle_to_quat(V3 axis, float angle) {  // math.py:54
   sincosf(angle * 0.5f, &s, &c);  // precise version: FK accuracy matters
   return Q4{c, axis.x * s, axis.y * s, axis.z * s};
 }
-DEV Q4 quat_normalize(Q4 q) {
+DEV Q4 quat_normalize(Q4 q) {  // MuJoCo C mju_normalize4: a (near-)zero quaternion is the identity (keyframes of aloha_pot store 0 0 0 0)
   float n = sqrtf(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
-  if (n > 0.0f) {
+  if (n >= MJ_MINVAL) {
     float inv = 1.0f / n;
     return Q4{q.w * inv, q.x * inv, q.y * inv, q.z * inv};
   }
-  return q;
+  return Q4{1.0f, 0.0f, 0.0f, 0.0f};
 }
 DEV void quat_to_mat(Q4 q, float* m) {  // math.py:61
   float q00 = q.w * q.w, q01 = q.w * q.x, q02 = q.w * q.y, q03 = q.w * q.z;

@@ -893,7 +893,8 @@ DEV void fwd_vel_body(const MjhModel& m, const MjhData& d, int first, int last, 
       }
     }
     gsync();
-    for (int i = lig; i < nv; i += G) fpassive[i] = fspring[i] + fdamper[i] + fgrav[i];
+    // (passive.py:631-668: gravity compensation is passive unless the joint routes it through its actuators)
+    for (int i = lig; i < nv; i += G) fpassive[i] = fspring[i] + fdamper[i] + (m.jnt_actgravcomp[m.dof_jntid[i]] ? 0.0f : fgrav[i]);
     gsync();
     gcopy<G>(d.qfrc_spring + (size_t)w * nv, fspring, nv, lig);
     gcopy<G>(d.qfrc_damper + (size_t)w * nv, fdamper, nv, lig);
@@ -1017,6 +1018,17 @@ DEV void fwd_vel_body(const MjhModel& m, const MjhData& d, int first, int last, 
             if (m.jnt_dofadr[m.actuator_trnid[2 * u]] == i) s += gear[6 * u] * uforce[u];
           factuator[i] = s;
         }
+      }
+    }
+    gsync();
+    {  // forward.py:1121-1150 _qfrc_actuator_gravcomp_limits: actuator-level gravity compensation, then the joint's actuatorfrcrange
+      const float* afr = bf(m.jnt_actfrcrange, m.jnt_actfrcrange_nb, w, 2 * njnt);
+      for (int i = lig; i < nv; i += G) {
+        const int j = m.dof_jntid[i];
+        float q = factuator[i];
+        if (m.jnt_actgravcomp[j] && !(dsbl & DSBL_GRAVITY)) q += (first <= VEL_PASSIVE) ? fgrav[i] : d.qfrc_gravcomp[(size_t)w * nv + i];
+        if (m.jnt_actfrclimited[j]) q = clampf(q, afr[2 * j], afr[2 * j + 1]);
+        factuator[i] = q;
       }
     }
     gsync();

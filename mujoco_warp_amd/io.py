@@ -152,10 +152,6 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
       raise NotImplementedError("actuator actearly is not implemented.")
     if (np.asarray(getattr(mjm, "actuator_actnum", [0])) > 1).any():
       raise NotImplementedError("actuators with more than one activation variable are not implemented.")
-  for name, what in (("jnt_actfrclimited", "joint actuatorfrcrange (clamp of the summed actuator force, forward.py _qfrc_actuator)"),
-                     ("jnt_actgravcomp", "actuatorgravcomp (gravity compensation routed through the actuators)")):
-    if np.asarray(getattr(mjm, name, [0])).any():
-      raise NotImplementedError(f"{what} is not implemented.")
   for name in ("jnt_stiffnesspoly", "dof_dampingpoly"):
     if np.asarray(getattr(mjm, name, [0.0])).any():
       raise NotImplementedError(f"{name} (polynomial stiffness / damping) is not implemented.")
@@ -185,12 +181,6 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
         mid = int(np.asarray(getattr(mjm, "geom_dataid", np.full(len(gt), -1)))[g])
         if mid < 0 or not hasattr(mjm, "mesh_vert"):
           raise NotImplementedError("colliding mesh geom without mesh vertices (Model.mesh_vert / geom_dataid)")
-      if t in ((6, 7), (7, 7)) and not (int(opt.disableflags) & int(types.DisableBit.MULTICCD)):
-        # multi-contact recovery on mesh faces (collision_gjk.py:2076): features of up to 8 normals / polygon vertices (csrc/convex.hpp MC_GN)
-        pv, pm = np.asarray(getattr(mjm, "mesh_polyvertnum", np.zeros(0))), np.asarray(getattr(mjm, "mesh_polymapnum", np.zeros(0)))
-        if len(pv) and (int(pv.max()) > 8 or int(pm.max()) > 8):
-          raise NotImplementedError("multi-contact recovery on meshes with polygons of more than 8 vertices or vertices shared by more than 8 polygons "
-                                    "is not implemented: set <flag multiccd=\"disable\"/> (one contact per pair, as the reference then computes)")
   condims = set(int(c) for c in np.unique(np.asarray(mjm.geom_condim)[np.unique(pairs)])) if len(pairs) else set()
   nexplicit = int(getattr(mjm, "npair", 0))
   if nexplicit:
@@ -256,6 +246,10 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
   # the reference's default adds the OBB filter (io.py:405); contacts do not depend on the filter set (every filter is
   # conservative), only Data.ncollision does, and plane + sphere keeps the light collision kernel
   o.broadphase_filter = types.BroadphaseFilter.PLANE | types.BroadphaseFilter.SPHERE
+  if m._heavy_pairs:
+    # models that run the heavy collision instantiation anyway get the reference's full default (io.py:405): on the ALOHA scene the
+    # sphere test alone lets 760 of 9,154 pairs through to GJK (long extrusions, a table-sized box), the box filters 15
+    o.broadphase_filter |= types.BroadphaseFilter.AABB | types.BroadphaseFilter.OBB
   o.graph_conditional = False
   o.run_collision_detection = True
   o.warn_overflow = False
@@ -349,6 +343,8 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
     body_lastdof=lastdof, body_mocapid=_arr(getattr(mjm, "body_mocapid", np.full(nbody, -1)), i32), body_subtreenum=subtreenum, body_tree=order, body_leveladr=leveladr, body_dofmask=dofmask,
     jnt_type=jnt_type, jnt_qposadr=_arr(mjm.jnt_qposadr, i32), jnt_dofadr=jnt_dofadr, jnt_bodyid=_arr(mjm.jnt_bodyid, i32),
     jnt_limited=_arr(mjm.jnt_limited, i32),
+    jnt_actfrclimited=_arr(getattr(mjm, "jnt_actfrclimited", np.zeros(njnt)), i32), jnt_actgravcomp=_arr(getattr(mjm, "jnt_actgravcomp", np.zeros(njnt)), i32),
+    jnt_actfrcrange=_arr(getattr(mjm, "jnt_actfrcrange", np.zeros((njnt, 2))), f32).reshape(1, njnt, 2),
     dof_bodyid=_arr(mjm.dof_bodyid, i32), dof_jntid=dof_jnt, dof_parentid=dof_parent, dof_grpadr=grpadr, dof_tree=dorder,
     dof_leveladr=dleveladr, tree_dofadr=tree_dofadr, tree_dofnum=tree_dofnum, dof_treeid=dof_treeid, body_treeid=body_treeid,
     M_rownnz=_arr(mjm.M_rownnz, i32), M_rowadr=_arr(mjm.M_rowadr, i32), M_colind=_arr(mjm.M_colind, i32), M_dense=_m_dense(mjm, nv),
@@ -405,6 +401,8 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
   m.npolygonmax = 4 if nboxbox > 0 else 0
   if not (int(opt.disableflags) & int(types.DisableBit.MULTICCD)) and nboxmesh + nmeshmesh > 0:
     m.npolygonmax = max(int(host["mesh_polyvertnum"].max()) if m.nmeshpoly else 0, 4 if nboxmesh else m.npolygonmax)
+    # polygons around one vertex (collision_convex.py:1233 nmeshdegmax): sizes the normal / index buffers of the multi-contact recovery
+    m.nmeshdegmax = max(int(host["mesh_polymapnum"].max()) if len(host["mesh_polymapnum"]) else 0, 3)
   m.nmesh = int(host["mesh_vertadr"].shape[0])
   m.nmat = int(host["mat_rgba"].shape[0])
   m.sleep_enabled = int(bool(int(opt.enableflags) & int(types.EnableBit.SLEEP)) and not (int(opt.disableflags) & int(types.DisableBit.ISLAND)))
@@ -419,7 +417,7 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
   host["eq_data"] = _arr(getattr(mjm, "eq_data", np.zeros((0, 11))), f32).reshape(1, neq, 11)
   m.eq_active0 = _arr(getattr(mjm, "eq_active0", np.zeros(0)), i32)
   vec = {"geom_aabb": 6, "body_pos": 3, "body_quat": 4, "body_ipos": 3, "body_iquat": 4, "body_inertia": 3, "body_invweight0": 2,
-         "jnt_solref": 2, "jnt_solimp": 5, "jnt_pos": 3, "jnt_axis": 3, "jnt_range": 2, "dof_solref": 2, "dof_solimp": 5,
+         "jnt_solref": 2, "jnt_solimp": 5, "jnt_pos": 3, "jnt_axis": 3, "jnt_range": 2, "jnt_actfrcrange": 2, "dof_solref": 2, "dof_solimp": 5,
          "geom_solref": 2, "geom_solimp": 5, "geom_size": 3, "geom_pos": 3, "geom_quat": 4, "geom_friction": 3,
          "site_pos": 3, "site_quat": 4, "actuator_dynprm": 10, "actuator_gainprm": 10, "actuator_biasprm": 10,
          "actuator_ctrlrange": 2, "actuator_forcerange": 2, "actuator_actrange": 2, "actuator_gear": 6}
@@ -514,11 +512,15 @@ def c_model(m: types.Model):
   return c
 
 
-def _ccd_words(iterations: int, hfield: int = 0) -> int:
-  """Workspace words of one lane's EPA polytope (csrc/convex.hpp ccd_words)."""
+def _ccd_words(iterations: int, hfield: int = 0, npolygonmax: int = 0, nmeshdegmax: int = 0) -> int:
+  """Workspace words of one lane's EPA polytope (csrc/convex.hpp ccd_words) and, for models with multi-contact recovery on mesh faces
+  (nmeshdegmax > 0), its feature / clip buffers (ccd_mc_words: sized from the model like the reference's, collision_convex.py:1346-1366)."""
   it = min(int(iterations), 64)
   # polytope + contact cache (CCD_CACHE_SLOTS x CCD_CACHE_WORDS) + the height-field result table (CCD_HF_WORDS)
-  return 8 * (5 + it) + 5 * (6 + 5 * it) + 24 + 4 * 24 + (7 * 50 + 1 if hfield else 0)
+  words = 8 * (5 + it) + 5 * (6 + 5 * it) + 24 + 4 * 24 + (7 * 50 + 1 if hfield else 0)
+  if nmeshdegmax > 0:
+    words += 11 * max(int(nmeshdegmax), 3) + 22 * max(int(npolygonmax), 4)
+  return words
 
 
 def contact_cap(nconmax: int) -> int:
@@ -550,7 +552,7 @@ def _data_shapes(m, nworld, nconmax, njmax, naconmax):
     efc_margin=(W, njmax), efc_D=(W, njmax), efc_vel=(W, njmax), efc_aref=(W, njmax), efc_frictionloss=(W, njmax),
     efc_force=(W, njmax), ws_ncon=(W,), ws_conadr=(W,), ws_ncollision=(W,), ws_efc_con=(W, njmax), ws_tree_rowadr=(W, (m.ntree + 1) if m.tree_solve else 0), ws_tree_rowmap=(W, njmax if m.tree_solve else 0),
     ws_isl_dofadr=(W, (m.ntree + 1) if m.tree_solve else 0), ws_isl_dofmap=(W, nv if m.tree_solve else 0), ws_isl_dofinv=(W, nv if m.tree_solve else 0), ws_nisland=(W,), ws_isl_flags=(W,), ws_isl_list=(3, W if m.tree_solve else 0), ws_isl_count=(4,),
-    ws_separable=(W,), ws_order=(W,), ws_ccd=(W if m._convex_pairs else 0, _ccd_words(max(int(m.opt.ccd_iterations), int(m.epa_iterations)), m.nhfield), 32),
+    ws_separable=(W,), ws_order=(W,), ws_ccd=(W if m._convex_pairs else 0, _ccd_words(max(int(m.opt.ccd_iterations), int(m.epa_iterations)), m.nhfield, m.npolygonmax, m.nmeshdegmax), 32),
     tree_asleep=(W, m.ntree), tree_awake=(W, m.ntree), body_awake=(W, nb), body_awake_ind=(W, nb), dof_awake_ind=(W, nv), ntree_awake=(W,), nbody_awake=(W,),
     nv_awake=(W,), tree_island=(W, m.ntree), nisland=(W,), ws_iacc=(W if int(m.opt.integrator) == int(types.IntegratorType.IMPLICIT) else 0, nv), ws_pgsB=(W if _needs_pgs_big(m) else 0, njmax_pad, nv_pad), ws_sleep_J=(W if m.sleep_enabled else 0, njmax_pad, nv_pad), ws_sleep_warm=(W if m.sleep_enabled else 0, nv),
     ws_sleep_flag=(W,),

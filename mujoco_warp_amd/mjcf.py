@@ -621,14 +621,19 @@ def read_hfield_file(path):
   return nrow, ncol, np.frombuffer(raw, dtype="<f4", count=nrow * ncol, offset=8).astype(np.float64).reshape(nrow, ncol)
 
 
-def _compile_mesh(verts, maxhullvert=-1):
+def _compile_mesh(verts, maxhullvert=-1, faces=None, inertia="legacy"):
   """Convex collision asset from inline vertices (MJCF <mesh vertex="...">), following what MuJoCo's compiler does with a mesh:
   convex hull, volume / centre of mass / inertia of the hull (uniform density), vertices re-expressed in the frame centred at the
   centre of mass and aligned with the principal axes (the geom frame is composed with that offset).  UNPINNED like the rest of this
   loader (MuJoCo's compiler is not in the reference tree); the axis order / signs of the principal frame are this module's own
   (descending moments, right handed): the physics does not depend on them.  The hull's vertex adjacency is stored as a hill-climbing
   graph in MuJoCo's layout (meshes of 10 or more vertices are then searched by hill climbing, smaller ones exhaustively:
-  collision_gjk.py:156)."""
+  collision_gjk.py:156).
+
+  Mass properties (<mesh inertia=...>): "convex" -- and meshes without faces -- take them from the hull; "exact" from the signed
+  tetrahedra of the file's own triangles, "legacy" (MuJoCo's default) from the same tetrahedra with absolute volumes about the
+  area-weighted centroid of the faces (over-counts where a non-convex surface folds back).  A mesh whose faces enclose its hull's
+  volume IS convex: it keeps the hull path, so files and inline vertices of the same convex shape compile to identical models."""
   from scipy.spatial import ConvexHull
 
   verts = np.asarray(verts, dtype=np.float64).reshape(-1, 3)
@@ -643,17 +648,37 @@ def _compile_mesh(verts, maxhullvert=-1):
   hull_in = ConvexHull(verts) if maxhullvert >= 4 else hull
   centre = verts[hull_in.vertices].mean(axis=0)
   canon = np.array([[2, 1, 1], [1, 2, 1], [1, 1, 2]]) / 120.0  # integral of x x^T over the unit tetrahedron
-  for tri, eq in zip(hull_in.simplices, hull_in.equations):
-    a, b, c = verts[tri] - centre
-    if np.dot(np.cross(b - a, c - a), eq[:3]) < 0:
-      b, c = c, b
-    A = np.stack([a, b, c], axis=1)
-    det = np.linalg.det(A)  # 6 x signed volume of the tetrahedron (centre, a, b, c)
-    vol += det / 6.0
-    com += det / 24.0 * (a + b + c)
-    second += det * (A @ canon @ A.T)
+  # signed tetrahedra (centre, a, b, c) of all hull triangles at once, triangles oriented outwards
+  T = verts[hull_in.simplices] - centre  # [nf, 3 (vertex), 3 (xyz)]
+  flip = np.einsum("fk,fk->f", np.cross(T[:, 1] - T[:, 0], T[:, 2] - T[:, 0]), hull_in.equations[:, :3]) < 0
+  T[flip] = T[flip][:, [0, 2, 1]]
+  A = np.transpose(T, (0, 2, 1))  # columns a, b, c
+  det = np.linalg.det(A)  # 6 x signed volume
+  vol = float(det.sum() / 6.0)
+  com = (det[:, None] / 24.0 * T.sum(axis=1)).sum(axis=0)
+  second = np.einsum("f,fij,jk,flk->il", det, A, canon, A)
   com /= vol
   second -= vol * np.outer(com, com)  # second moment about the centre of mass
+  if inertia not in ("convex", "exact", "legacy"):
+    raise NotImplementedError(f"<mesh inertia={inertia!r}> (convex, exact and legacy are implemented)")
+  if faces is not None and len(faces) and inertia != "convex":
+    tri = verts[np.asarray(faces).reshape(-1, 3)]
+    areas = 0.5 * np.linalg.norm(np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]), axis=1)
+    ref = (areas[:, None] * tri.mean(axis=1)).sum(axis=0) / max(areas.sum(), MJ_MINVAL)
+    Tf = tri - ref
+    Af = np.transpose(Tf, (0, 2, 1))
+    detf = np.linalg.det(Af)
+    if inertia == "legacy":  # absolute pyramid volumes: orientation-independent, over-counts folds
+      Af = np.where((detf < 0)[:, None, None], Af[:, :, [0, 2, 1]], Af)
+      Tf = np.transpose(Af, (0, 2, 1))
+      detf = np.abs(detf)
+    volf = float(detf.sum() / 6.0)
+    if volf <= 0:
+      raise ValueError("mesh faces enclose no volume (inconsistent orientation?): use <mesh inertia=\"convex\"/> or \"legacy\"")
+    if abs(volf - vol) > 1e-6 * vol:  # a genuinely non-convex surface (float32 STL vertices leave 1e-8 between a convex file and its hull): mass properties from the faces, hull only for collision
+      comf = (detf[:, None] / 24.0 * Tf.sum(axis=1)).sum(axis=0) / volf
+      secondf = np.einsum("f,fij,jk,flk->il", detf, Af, canon, Af) - volf * np.outer(comf, comf)
+      vol, com, second = volf, comf + (ref - centre), secondf
   inertia = np.trace(second) * np.eye(3) - second
   w, v = np.linalg.eigh(inertia)
   order = np.argsort(-w)
@@ -663,14 +688,18 @@ def _compile_mesh(verts, maxhullvert=-1):
   vlocal = (verts - centre - com) @ v
   lo, hi = vlocal.min(axis=0), vlocal.max(axis=0)
   # polygon tables for multi-contact recovery (Model.mesh_poly*, types.py:1707-1733): coplanar hull triangles merged into convex
-  # polygons, vertices counter-clockwise seen from outside; per vertex the polygons it belongs to
+  # polygons, vertices counter-clockwise seen from outside; per vertex the polygons it belongs to.  A triangle joins the first group
+  # whose plane (that of the group's first triangle) it shares, else it opens a new group
+  eqs = hull.equations
+  gn, gd = np.zeros((len(eqs), 3)), np.zeros(len(eqs))
   groups = []
-  for tri, eq in zip(hull.simplices, hull.equations):
-    for gr in groups:
-      if np.dot(gr["n"], eq[:3]) > 1.0 - 1e-9 and abs(gr["d"] - eq[3]) < 1e-9 * max(1.0, abs(eq[3])):
-        gr["verts"].update(int(i) for i in tri)
-        break
+  for tri, eq in zip(hull.simplices, eqs):
+    ng = len(groups)
+    hit = np.flatnonzero((gn[:ng] @ eq[:3] > 1.0 - 1e-9) & (np.abs(gd[:ng] - eq[3]) < 1e-9 * max(1.0, abs(eq[3]))))
+    if len(hit):
+      groups[int(hit[0])]["verts"].update(int(i) for i in tri)
     else:
+      gn[ng], gd[ng] = eq[:3], eq[3]
       groups.append(dict(n=eq[:3].copy(), d=float(eq[3]), verts=set(int(i) for i in tri)))
   polys, normals = [], []
   for gr in groups:
@@ -683,7 +712,10 @@ def _compile_mesh(verts, maxhullvert=-1):
     ang = np.arctan2((pts - c) @ e2, (pts - c) @ e1)
     polys.append([ids[i] for i in np.argsort(ang)])
     normals.append(gr["n"] @ v)  # in the mesh frame
-  polymap = [[p for p, poly in enumerate(polys) if i in poly] for i in range(len(verts))]
+  polymap = [[] for _ in range(len(verts))]
+  for p, poly in enumerate(polys):
+    for i in poly:
+      polymap[i].append(p)
   # hill-climbing graph in MuJoCo's mesh_graph layout (numvert, numface, vert_edgeadr[numvert], vert_globalid[numvert],
   # edge_localid[numvert + 3 numface] = neighbours of each hull vertex as local ids, -1 terminated, face_globalid[3 numface]); consumed by
   # reference collision_gjk.py:170-196 and collision_primitive.py:131-243 for meshes of 10 or more vertices
@@ -777,6 +809,42 @@ def _compile(root, base_dir):
   world.inertial, world.joints, world.geoms, world.gravcomp, world.mocap = None, [], [], 0.0, False
   bodies.append(world)
 
+  def attach_mesh(g):
+    """Compiles the geom's mesh asset (once per asset) and moves the geom frame onto the mesh's inertial frame (MuJoCo's convention).
+    Called for colliding mesh geoms, and for non-colliding ones whose body takes its mass from its geoms."""
+    pos, quat = g["pos"], g["quat"]
+    asset = mesh_assets.get(g["mesh"])
+    if asset is None:
+      raise ValueError(f"geom refers to unknown mesh {g['mesh']!r}")
+    if g["mesh"] not in mesh_compiled:
+      faces = None
+      if "vertex" in asset:
+        v = np.array(_floats(asset["vertex"])).reshape(-1, 3)
+        if "face" in asset:
+          faces = np.array(_floats(asset["face"]), dtype=np.int64).reshape(-1, 3)
+      elif "file" in asset:  # STL / OBJ, relative to <compiler meshdir> (or assetdir), itself relative to the model file
+        for k in ("refpos", "refquat"):
+          if k in asset:
+            raise NotImplementedError(f"<mesh {k}=...>")
+        mdir = compiler["meshdir"] if compiler["meshdir"] is not None else (compiler["assetdir"] or "")
+        path = asset["file"] if os.path.isabs(asset["file"]) else os.path.join(base_dir or "", mdir, asset["file"])
+        if not os.path.exists(path):
+          raise FileNotFoundError(f"mesh {g['mesh']!r}: file {path!r} not found (colliding mesh geoms need their asset; non-colliding ones do not)")
+        v, faces = read_mesh_file(path)
+      else:
+        raise ValueError(f"mesh {g['mesh']!r} has neither vertex data nor a file")
+      sc = _vec(asset, "scale", [1, 1, 1])
+      v = v * sc
+      if faces is not None and np.prod(sc) < 0:  # a mirroring scale flips the triangles' orientation
+        faces = np.asarray(faces)[:, [0, 2, 1]]
+      mesh_compiled[g["mesh"]] = _compile_mesh(v, int(asset.get("maxhullvert", -1)), faces=faces, inertia=asset.get("inertia", "legacy"))
+    md = mesh_compiled[g["mesh"]]
+    g["meshdata"] = md
+    g["pos"] = pos + nm.rot_vec_quat(md["pos"], quat)  # the geom frame is the mesh's inertial frame (MuJoCo's convention)
+    g["quat"] = nm.quat_mul(quat, md["quat"])
+    g["size"] = md["aabb"][3:].copy()
+
+
   def parse_geom(elem, childclass, bodyid):
     base, explicit = _resolve("geom", elem, table, childclass)
     a = dict(base)
@@ -836,30 +904,7 @@ def _compile(root, base_dir):
       g["size"] = np.array([hs[0], hs[1], 0.25 * hs[2] + 0.5 * hs[3]])  # (unpinned: only rbound / aabb below enter the engine)
     g["meshdata"] = None
     if g["type"] == GEOM_MESH and (g["contype"] or g["conaffinity"]):
-      asset = mesh_assets.get(g["mesh"])
-      if asset is None:
-        raise ValueError(f"geom refers to unknown mesh {g['mesh']!r}")
-      if g["mesh"] not in mesh_compiled:
-        if "vertex" in asset:
-          v = np.array(_floats(asset["vertex"])).reshape(-1, 3)
-        elif "file" in asset:  # STL / OBJ, relative to <compiler meshdir> (or assetdir), itself relative to the model file
-          for k in ("refpos", "refquat"):
-            if k in asset:
-              raise NotImplementedError(f"<mesh {k}=...>")
-          mdir = compiler["meshdir"] if compiler["meshdir"] is not None else (compiler["assetdir"] or "")
-          path = asset["file"] if os.path.isabs(asset["file"]) else os.path.join(base_dir or "", mdir, asset["file"])
-          if not os.path.exists(path):
-            raise FileNotFoundError(f"mesh {g['mesh']!r}: file {path!r} not found (colliding mesh geoms need their asset; non-colliding ones do not)")
-          v, _ = read_mesh_file(path)
-        else:
-          raise ValueError(f"mesh {g['mesh']!r} has neither vertex data nor a file")
-        v = v * _vec(asset, "scale", [1, 1, 1])
-        mesh_compiled[g["mesh"]] = _compile_mesh(v, int(asset.get("maxhullvert", -1)))
-      md = mesh_compiled[g["mesh"]]
-      g["meshdata"] = md
-      g["pos"] = pos + nm.rot_vec_quat(md["pos"], quat)  # the geom frame is the mesh's inertial frame (MuJoCo's convention)
-      g["quat"] = nm.quat_mul(quat, md["quat"])
-      g["size"] = md["aabb"][3:].copy()
+      attach_mesh(g)
     return g
 
   def parse_joint(elem, childclass, bodyid, free=False):
@@ -1139,8 +1184,8 @@ def _compile(root, base_dir):
       if e.size != nrow * ncol:
         raise ValueError(f"hfield {name}: elevation has {e.size} values, expected {nrow * ncol}")
       e = e.reshape(nrow, ncol)[::-1]  # (MJCF lists the rows from the far edge (+y) first; MuJoCo stores row 0 at -y)
-    else:  # PNG or MuJoCo's binary height-field format, relative to <compiler assetdir> (or meshdir)
-      adir = compiler["assetdir"] if compiler["assetdir"] is not None else (compiler["meshdir"] or "")
+    else:  # PNG or MuJoCo's binary height-field format: like meshes, relative to <compiler meshdir>, which overrides assetdir
+      adir = compiler["meshdir"] if compiler["meshdir"] is not None else (compiler["assetdir"] or "")
       path = ha["file"] if os.path.isabs(ha["file"]) else os.path.join(base_dir or "", adir, ha["file"])
       if not os.path.exists(path):
         raise FileNotFoundError(f"hfield {name!r}: file {path!r} not found")
@@ -1230,6 +1275,8 @@ def _compile(root, base_dir):
     tot, com = 0.0, np.zeros(3)
     parts = []
     for g in b.geoms:
+      if g["type"] == GEOM_MESH and g["meshdata"] is None and ((g["mass"] or 0.0) > 0 or (g["mass"] is None and g["density"] > 0)):
+        attach_mesh(g)  # a non-colliding mesh geom that carries mass: its asset is needed after all (raises when the file is absent)
       vol, unit = _geom_volume_inertia(g["type"], g["size"])
       if g["meshdata"] is not None:
         vol, unit = g["meshdata"]["vol"], g["meshdata"]["unit"]
@@ -1443,6 +1490,17 @@ def _compile(root, base_dir):
         if len(v) != arr.shape[1]:
           raise ValueError(f"keyframe {name} size {len(v)} != {arr.shape[1]}")
         arr[i] = v
+  # MuJoCo's zero-quaternion rule (mju_normalize4: a quaternion of norm < mjMINVAL becomes the identity): test_data/aloha_pot stores
+  # the pot's free joint as 0 0 0 0 in two keys.  Non-zero quaternions stay as written (every consumer normalises them).
+  for i in range(m.nkey):
+    for j in range(m.njnt):
+      if m.jnt_type[j] in (0, 1):
+        a = int(m.jnt_qposadr[j]) + (3 if m.jnt_type[j] == 0 else 0)
+        if np.linalg.norm(m.key_qpos[i, a:a + 4]) < MJ_MINVAL:
+          m.key_qpos[i, a:a + 4] = [1.0, 0.0, 0.0, 0.0]
+    for j in range(m.nmocap):
+      if np.linalg.norm(m.key_mquat[i, 4 * j:4 * j + 4]) < MJ_MINVAL:
+        m.key_mquat[i, 4 * j:4 * j + 4] = [1.0, 0.0, 0.0, 0.0]
 
   # sizes not on the hot path
   m.ntendon = m.nflex = m.nplugin = 0

@@ -352,6 +352,9 @@ class Model(_Dirty):
   jnt_stiffness: DeviceArray = _arr(('*', 'njnt'), "float32")
   jnt_range: DeviceArray = _arr(('*', 'njnt', 2), "float32")
   jnt_margin: DeviceArray = _arr(('*', 'njnt'), "float32")
+  jnt_actfrclimited: DeviceArray = _arr(('njnt',), "int32")
+  jnt_actfrcrange: DeviceArray = _arr(('*', 'njnt', 2), "float32")
+  jnt_actgravcomp: DeviceArray = _arr(('njnt',), "int32")
   dof_bodyid: DeviceArray = _arr(('nv',), "int32")
   dof_jntid: DeviceArray = _arr(('nv',), "int32")
   dof_parentid: DeviceArray = _arr(('nv',), "int32")
@@ -447,6 +450,7 @@ class Model(_Dirty):
   nmeshpolyvert: int = 0
   nmeshpolymap: int = 0
   npolygonmax: int = 0
+  nmeshdegmax: int = 0
   nsensordata: int = 0
   nsensor_acc: int = 0
   nsensor_subtree: int = 0

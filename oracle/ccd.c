@@ -42,7 +42,7 @@ typedef struct CcdGeom {
   const int* polymapnum;
   const int* polymap;       /* global array of mesh-local polygon ids */
 } CcdGeom;
-#define MC_MAXN 32 /* normals / polygon vertices the restatement holds per feature (the reference sizes its buffers from the model) */
+#define MC_MAXN 128 /* normals / polygon vertices the restatement holds per feature (the reference sizes its buffers from the model: ref.py refuses models beyond this) */
 
 typedef struct GjkOut {
   int separated, dim;

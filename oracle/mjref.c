@@ -1,16 +1,25 @@
-/* oracle/mjref.c -- TEST INFRASTRUCTURE ONLY (see mjref.h header: "PARITY UNPINNED").
+/* oracle/mjref.c -- TEST INFRASTRUCTURE ONLY (pin status: mjref.h header -- externally pinned for the G1 chain since round 3, the
+ * ALOHA lift behaviour the reference holds in unroll_test.py:40-58 since round 4; CG / PGS as algorithms, elliptic cones and sleep
+ * policy stand-ins remain pinned through identities only).
  *
  * float64 single-world restatement of the reference's mj_step hot path.  Every function cites the
  * reference kernel(s) it follows (paths relative to /root/reference/mujoco_warp/_src/).
  * Deterministic ordering replaces the reference's atomic allocation: contacts are emitted in
  * geom-pair order, constraint rows in MuJoCo order (friction dofs, joint limits, contacts).
  */
-#include "mjref.h"
-
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+
+/* float32 build of the SAME restatement (make libmjref32.so: -DREF_REAL_FLOAT): every `double` below -- storage and arithmetic -- becomes
+   `float`; libm calls compute in double and round once, i.e. at least as accurately as their float versions.  It measures where the
+   float32 floor of the reference's algorithm sits (tools/parity_report.py); the float64 build stays the oracle. */
+#ifdef REF_REAL_FLOAT
+#define double float
+#endif
+
+#include "mjref.h"
 
 #define MINVAL 1e-15
 #define MAXVAL 1e10
@@ -76,9 +85,11 @@ static void axis_angle_to_quat(double* q, const double* axis, double angle) { /*
   double s = sin(angle * 0.5), c = cos(angle * 0.5);
   q[0] = c; q[1] = axis[0] * s; q[2] = axis[1] * s; q[3] = axis[2] * s;
 }
-static void quat_normalize(double* q) {
+static void quat_normalize(double* q) { /* MuJoCo C mju_normalize4: a (near-)zero quaternion becomes the identity -- the rule the
+  arithmetic of record applies to qpos in mj_kinematics and to keyframes at compile time (test_data/aloha_pot stores 0 0 0 0) */
   double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-  if (n > 0) { q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n; }
+  if (n < MINVAL) { q[0] = 1.0; q[1] = q[2] = q[3] = 0.0; }
+  else { q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n; }
 }
 static void quat_to_mat(double* m, const double* q) { /* math.py:61 */
   double q00 = q[0] * q[0], q01 = q[0] * q[1], q02 = q[0] * q[2], q03 = q[0] * q[3];
@@ -445,7 +456,10 @@ void ref_passive(const RefModel* m, RefData* d) {
       }
     }
   }
-  for (int i = 0; i < nv; i++) d->qfrc_passive[i] = d->qfrc_spring[i] + d->qfrc_damper[i] + d->qfrc_gravcomp[i];
+  for (int i = 0; i < nv; i++) { /* passive.py:631-668: gravcomp is passive unless the joint routes it through its actuators */
+    d->qfrc_passive[i] = d->qfrc_spring[i] + d->qfrc_damper[i];
+    if (!(m->disableflags & DSBL_GRAVITY) && !m->jnt_actgravcomp[m->dof_jntid[i]]) d->qfrc_passive[i] += d->qfrc_gravcomp[i];
+  }
 }
 
 /* ---------------------------------------------------------------- smooth.py:1353-1515 */
@@ -524,6 +538,11 @@ void ref_fwd_actuation(const RefModel* m, RefData* d) {
     d->actuator_force[i] = force;
     int dof = m->jnt_dofadr[m->actuator_trnid[2 * i]];
     d->qfrc_actuator[dof] += m->actuator_gear[6 * i] * force;
+  }
+  for (int i = 0; i < nv; i++) { /* forward.py:1121-1150 _qfrc_actuator_gravcomp_limits */
+    int j = m->dof_jntid[i];
+    if (!(m->disableflags & DSBL_GRAVITY) && m->jnt_actgravcomp[j]) d->qfrc_actuator[i] += d->qfrc_gravcomp[i];
+    if (m->jnt_actfrclimited[j]) d->qfrc_actuator[i] = clampd(d->qfrc_actuator[i], m->jnt_actfrcrange[2 * j], m->jnt_actfrcrange[2 * j + 1]);
   }
 }
 

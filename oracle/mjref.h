@@ -95,6 +95,9 @@ typedef struct RefModel {
   double* jnt_stiffness;
   double* jnt_range;
   double* jnt_margin;
+  int* jnt_actfrclimited;   /* types.py:1075: clamp of the summed actuator force on the joint (forward.py:1145-1147) */
+  double* jnt_actfrcrange;  /* [njnt, 2] */
+  int* jnt_actgravcomp;     /* gravity compensation routed through the actuators (passive.py:652, forward.py:1141) */
   int* dof_bodyid;
   int* dof_jntid;
   int* dof_parentid;

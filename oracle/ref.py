@@ -13,12 +13,14 @@ import numpy as np
 
 _DIR = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_DIR, "libmjref.so")
+_LIB32_PATH = os.path.join(_DIR, "libmjref32.so")  # the same restatement in float32: the float32 FLOOR of the algorithm, not an oracle
 
 
 def build(force=False):
   src = [os.path.join(_DIR, f) for f in ("mjref.c", "mjref.h", "ccd.c")]
-  if force or not os.path.exists(_LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in src):
-    subprocess.check_call(["make", "-C", _DIR, "-B", "libmjref.so"], stdout=subprocess.DEVNULL)
+  for path in (_LIB_PATH, _LIB32_PATH):
+    if force or not os.path.exists(path) or any(os.path.getmtime(s) > os.path.getmtime(path) for s in src):
+      subprocess.check_call(["make", "-C", _DIR, "-B", os.path.basename(path)], stdout=subprocess.DEVNULL)
   return _LIB_PATH
 
 
@@ -38,52 +40,70 @@ _MODEL_FIELDS = _parse_struct(_HEADER, "RefModel")
 _DATA_FIELDS = _parse_struct(_HEADER, "RefData")
 
 
-def _ctype(kind, ptr):
-  base = ctypes.c_int if kind == "int" else ctypes.c_double
-  return ctypes.POINTER(base) if ptr else base
+class _Real:
+  """One precision of the library: ctypes mirror of the structs (every `double` of the header is `float` in the float32 build),
+  numpy dtype, loaded library."""
+
+  def __init__(self, f32):
+    self.f32 = bool(f32)
+    self.c_real = ctypes.c_float if f32 else ctypes.c_double
+    self.np_real = np.float32 if f32 else np.float64
+    c_real = self.c_real
+
+    def ctype(kind, ptr):
+      base = ctypes.c_int if kind == "int" else c_real
+      return ctypes.POINTER(base) if ptr else base
+
+    self.ctype = ctype
+    self.CRefModel = type("CRefModel", (ctypes.Structure,), {"_fields_": [(n, ctype(k, p)) for n, k, p in _MODEL_FIELDS]})
+    self.CRefData = type("CRefData", (ctypes.Structure,), {"_fields_": [(n, ctype(k, p)) for n, k, p in _DATA_FIELDS]})
+    self._lib = None
+
+  def ptr(self, a):
+    return a.ctypes.data_as(ctypes.POINTER(self.c_real))
+
+  def arr(self, x):
+    return np.ascontiguousarray(x, dtype=self.np_real)
+
+  def lib(self):
+    if self._lib is None:
+      build()
+      L = ctypes.CDLL(_LIB32_PATH if self.f32 else _LIB_PATH)
+      mp, dp = ctypes.POINTER(self.CRefModel), ctypes.POINTER(self.CRefData)
+      for fn in ("kinematics", "com_pos", "crb", "factor_m", "collision", "make_constraint", "transmission", "com_vel",
+                 "passive", "rne", "fwd_position", "fwd_velocity", "fwd_actuation", "fwd_acceleration", "solve",
+                 "forward", "euler", "implicitfast", "implicit", "step"):
+        f = getattr(L, "ref_" + fn)
+        f.argtypes = [mp, dp]
+        f.restype = None
+      R = self.c_real
+      dptr = ctypes.POINTER(R)
+      L.ref_solve_m.argtypes = [mp, dp, dptr, dptr]
+      L.ref_mul_m.argtypes = [mp, dp, dptr, dptr]
+      L.ref_deriv_rne_vel.argtypes = [mp, dp, dptr]
+      L.ref_deriv_rne_vel.restype = None
+      L.ref_ctrl_noise.argtypes = [mp, dp, dptr, ctypes.c_int, ctypes.c_int, R, R]
+      L.ref_halton.argtypes = [ctypes.c_int, ctypes.c_int]
+      L.ref_halton.restype = R
+      L.ref_rollout.argtypes = [mp, dp, ctypes.c_int, ctypes.c_int, R, R, dptr, dptr]
+      L.ref_rollout.restype = ctypes.c_int
+      L.ref_closest_segment_to_segment_points.argtypes = [dptr] * 6
+      L.ref_closest_segment_to_segment_points.restype = None
+      for fn in (L.ref_upper_tri_index, L.ref_upper_trid_index):
+        fn.argtypes = [ctypes.c_int] * 3
+        fn.restype = ctypes.c_int
+      L.ref_ccd.argtypes = [ctypes.c_int, dptr, dptr, dptr, ctypes.c_int, dptr, dptr, dptr, R, R, R, ctypes.c_int, ctypes.c_int, dptr, dptr]
+      L.ref_ccd.restype = ctypes.c_int
+      self._lib = L
+    return self._lib
 
 
-class CRefModel(ctypes.Structure):
-  _fields_ = [(n, _ctype(k, p)) for n, k, p in _MODEL_FIELDS]
-
-
-class CRefData(ctypes.Structure):
-  _fields_ = [(n, _ctype(k, p)) for n, k, p in _DATA_FIELDS]
-
-
-_lib = None
+_F64, _F32 = _Real(False), _Real(True)
+CRefModel, CRefData = _F64.CRefModel, _F64.CRefData
 
 
 def lib():
-  global _lib
-  if _lib is None:
-    _lib = ctypes.CDLL(build())
-    mp, dp = ctypes.POINTER(CRefModel), ctypes.POINTER(CRefData)
-    for fn in ("kinematics", "com_pos", "crb", "factor_m", "collision", "make_constraint", "transmission", "com_vel",
-               "passive", "rne", "fwd_position", "fwd_velocity", "fwd_actuation", "fwd_acceleration", "solve",
-               "forward", "euler", "implicitfast", "implicit", "step"):
-      f = getattr(_lib, "ref_" + fn)
-      f.argtypes = [mp, dp]
-      f.restype = None
-    dptr = ctypes.POINTER(ctypes.c_double)
-    _lib.ref_solve_m.argtypes = [mp, dp, dptr, dptr]
-    _lib.ref_mul_m.argtypes = [mp, dp, dptr, dptr]
-    _lib.ref_deriv_rne_vel.argtypes = [mp, dp, dptr]
-    _lib.ref_deriv_rne_vel.restype = None
-    _lib.ref_ctrl_noise.argtypes = [mp, dp, dptr, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double]
-    _lib.ref_halton.argtypes = [ctypes.c_int, ctypes.c_int]
-    _lib.ref_halton.restype = ctypes.c_double
-    _lib.ref_rollout.argtypes = [mp, dp, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_double, dptr, dptr]
-    _lib.ref_rollout.restype = ctypes.c_int
-    _lib.ref_closest_segment_to_segment_points.argtypes = [dptr] * 6
-    _lib.ref_closest_segment_to_segment_points.restype = None
-    for fn in (_lib.ref_upper_tri_index, _lib.ref_upper_trid_index):
-      fn.argtypes = [ctypes.c_int] * 3
-      fn.restype = ctypes.c_int
-    _lib.ref_ccd.argtypes = [ctypes.c_int, dptr, dptr, dptr, ctypes.c_int, dptr, dptr, dptr, ctypes.c_double, ctypes.c_double, ctypes.c_double,
-                             ctypes.c_int, ctypes.c_int, dptr, dptr]
-    _lib.ref_ccd.restype = ctypes.c_int
-  return _lib
+  return _F64.lib()
 
 
 def ccd(type1, pos1, mat1, size1, type2, pos2, mat2, size2, margin=0.0, tolerance=1e-6, cutoff=1e30, iterations=35, multiccd=False, vert1=None, vert2=None):
@@ -182,9 +202,13 @@ class RefSim:
   """One float64 world: model struct + data arrays (numpy-owned) for the C oracle."""
 
   def __init__(self, mjm, nconmax=64, njmax=256, tolerance=None, solver=None, iterations=None, ls_iterations=None,
-               integrator=None, broadphase=0, broadphase_filter=3):
+               integrator=None, broadphase=0, broadphase_filter=3, real="f64"):
+    """real="f32" runs the float32 build of the same restatement (libmjref32.so): not an oracle but the float32 FLOOR of the
+    reference's algorithm on a CPU -- what an error against the float64 oracle is worth (tools/parity_report.py)."""
     self.mjm = mjm
     self._keep = []
+    R = self.R = {"f64": _F64, "f32": _F32}[real]
+    CRefModel, CRefData, _ctype = R.CRefModel, R.CRefData, R.ctype
     cm = CRefModel()
     opt = mjm.opt
     sizes = dict(nq=mjm.nq, nv=mjm.nv, nu=mjm.nu, na=mjm.na, nbody=mjm.nbody, njnt=mjm.njnt, ngeom=mjm.ngeom,
@@ -215,7 +239,7 @@ class RefSim:
       ccd_tolerance=float(getattr(opt, 'ccd_tolerance', 1e-6)), timestep=float(opt.timestep),
       tolerance=float(opt.tolerance if tolerance is None else tolerance), ls_tolerance=float(opt.ls_tolerance),
       impratio=float(opt.impratio), meaninertia=float(mjm.stat.meaninertia))
-    special = {"gravity": np.asarray(opt.gravity, dtype=np.float64), "magnetic": np.asarray(getattr(opt, "magnetic", [0.0, -0.5, 0.0]), dtype=np.float64), "pair_geom": pairs, "nxn_pairid": pairid,
+    special = {"gravity": np.asarray(opt.gravity, dtype=self.R.np_real), "magnetic": np.asarray(getattr(opt, "magnetic", [0.0, -0.5, 0.0]), dtype=self.R.np_real), "pair_geom": pairs, "nxn_pairid": pairid,
                "xpair_dim": getattr(mjm, "pair_dim", np.zeros(0)), "xpair_friction": getattr(mjm, "pair_friction", np.zeros(0)),
                "xpair_solref": getattr(mjm, "pair_solref", np.zeros(0)), "xpair_solreffriction": getattr(mjm, "pair_solreffriction", np.zeros(0)),
                "xpair_solimp": getattr(mjm, "pair_solimp", np.zeros(0)), "xpair_margin": getattr(mjm, "pair_margin", np.zeros(0)),
@@ -238,7 +262,7 @@ class RefSim:
         setattr(cm, name, sizes[name] if name in sizes else scalars[name])
         continue
       src = special[name] if name in special else getattr(mjm, name)
-      arr = np.ascontiguousarray(np.asarray(src), dtype=np.int32 if kind == "int" else np.float64)
+      arr = np.ascontiguousarray(np.asarray(src), dtype=np.int32 if kind == "int" else R.np_real)
       if arr.size == 0:
         arr = np.zeros(1, dtype=arr.dtype)
       self._keep.append(arr)
@@ -255,12 +279,12 @@ class RefSim:
         shape = (sizes[spec],)
       else:
         shape = tuple(sizes[s] if isinstance(s, str) else s for s in spec)
-      a = np.zeros(max(int(np.prod(shape)), 1), dtype=np.int32 if kind == "int" else np.float64)
+      a = np.zeros(max(int(np.prod(shape)), 1), dtype=np.int32 if kind == "int" else R.np_real)
       self.arr[name] = a
       setattr(cd, name, a.ctypes.data_as(_ctype(kind, True)))
       setattr(self, "_shape_" + name, shape)
     self.cd = cd
-    self.lib = lib()
+    self.lib = R.lib()
     self.reset()
 
   def reset(self, key=None):
@@ -306,28 +330,28 @@ class RefSim:
     self._call(name)
 
   def solve_m(self, y):
-    y = np.ascontiguousarray(y, dtype=np.float64)
+    y = np.ascontiguousarray(y, dtype=self.R.np_real)
     x = np.zeros_like(y)
-    dp = ctypes.POINTER(ctypes.c_double)
+    dp = ctypes.POINTER(self.R.c_real)
     self.lib.ref_solve_m(ctypes.byref(self.cm), ctypes.byref(self.cd), x.ctypes.data_as(dp), y.ctypes.data_as(dp))
     return x
 
   def mul_m(self, v):
-    v = np.ascontiguousarray(v, dtype=np.float64)
+    v = np.ascontiguousarray(v, dtype=self.R.np_real)
     r = np.zeros_like(v)
-    dp = ctypes.POINTER(ctypes.c_double)
+    dp = ctypes.POINTER(self.R.c_real)
     self.lib.ref_mul_m(ctypes.byref(self.cm), ctypes.byref(self.cd), r.ctypes.data_as(dp), v.ctypes.data_as(dp))
     return r
 
   def ctrl_noise(self, step, worldid, noise_std=0.01, noise_rate=0.1, center=None):
-    dp = ctypes.POINTER(ctypes.c_double)
-    c = np.zeros(max(self.mjm.nu, 1)) if center is None else np.ascontiguousarray(center, dtype=np.float64)
+    dp = ctypes.POINTER(self.R.c_real)
+    c = np.zeros(max(self.mjm.nu, 1), dtype=self.R.np_real) if center is None else np.ascontiguousarray(center, dtype=self.R.np_real)
     self.lib.ref_ctrl_noise(ctypes.byref(self.cm), ctypes.byref(self.cd), c.ctypes.data_as(dp), step, worldid, noise_std, noise_rate)
 
   def rollout(self, nstep, worldid=0, noise_std=0.01, noise_rate=0.1, record=True):
-    dp = ctypes.POINTER(ctypes.c_double)
-    qp = np.zeros((nstep, self.mjm.nq)) if record else None
-    qv = np.zeros((nstep, self.mjm.nv)) if record else None
+    dp = ctypes.POINTER(self.R.c_real)
+    qp = np.zeros((nstep, self.mjm.nq), dtype=self.R.np_real) if record else None
+    qv = np.zeros((nstep, self.mjm.nv), dtype=self.R.np_real) if record else None
     ok = self.lib.ref_rollout(ctypes.byref(self.cm), ctypes.byref(self.cd), nstep, worldid, noise_std, noise_rate,
                               qp.ctypes.data_as(dp) if record else None, qv.ctypes.data_as(dp) if record else None)
     return ok, qp, qv
@@ -336,25 +360,25 @@ class RefSim:
     """GJK / EPA / multi-contact on two geoms of the model at given poses (default: their current geom_xpos / geom_xmat); like the
     reference's test harness collision_gjk_test.py:_geom_dist.  Returns (dist, ncon, witness pairs [ncon, 2, 3])."""
     def arr(x, dflt):
-      return np.ascontiguousarray(np.asarray(dflt if x is None else x, dtype=np.float64).reshape(-1))
+      return np.ascontiguousarray(np.asarray(dflt if x is None else x, dtype=self.R.np_real).reshape(-1))
     p1, m1 = arr(pos1, self.geom_xpos[g1]), arr(mat1, self.geom_xmat[g1])
     p2, m2 = arr(pos2, self.geom_xpos[g2]), arr(mat2, self.geom_xmat[g2])
-    out, wit = np.zeros(9), np.zeros(48)
-    dp = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    out, wit = np.zeros(9, dtype=self.R.np_real), np.zeros(48, dtype=self.R.np_real)
+    dp = lambda a: a.ctypes.data_as(ctypes.POINTER(self.R.c_real))
     fn = self.lib.ref_ccd_geoms
     fn.restype = ctypes.c_int
-    n = fn(ctypes.byref(self.cm), int(g1), int(g2), dp(p1), dp(m1), dp(p2), dp(m2), ctypes.c_double(margin), ctypes.c_double(tolerance),
-           ctypes.c_double(cutoff), int(iterations), int(bool(multiccd)), dp(out), dp(wit))
+    n = fn(ctypes.byref(self.cm), int(g1), int(g2), dp(p1), dp(m1), dp(p2), dp(m2), self.R.c_real(margin), self.R.c_real(tolerance),
+           self.R.c_real(cutoff), int(iterations), int(bool(multiccd)), dp(out), dp(wit))
     return float(out[0]), n, wit.reshape(8, 2, 3)[: max(n, 0)].copy()
 
   def ray(self, pnt, vec, geomgroup=None, flg_static=True, bodyexclude=-1):
     """Nearest intersection of one ray with the model's primitive geoms at their current poses (ray.py:907 _ray): (dist, geomid, normal)."""
-    dp = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
-    p, v = np.ascontiguousarray(pnt, dtype=np.float64), np.ascontiguousarray(vec, dtype=np.float64)
-    gg = None if geomgroup is None else np.ascontiguousarray(geomgroup, dtype=np.float64)
-    gid, nrm = ctypes.c_int(-1), np.zeros(3)
+    dp = lambda a: a.ctypes.data_as(ctypes.POINTER(self.R.c_real))
+    p, v = np.ascontiguousarray(pnt, dtype=self.R.np_real), np.ascontiguousarray(vec, dtype=self.R.np_real)
+    gg = None if geomgroup is None else np.ascontiguousarray(geomgroup, dtype=self.R.np_real)
+    gid, nrm = ctypes.c_int(-1), np.zeros(3, dtype=self.R.np_real)
     fn = self.lib.ref_ray
-    fn.restype = ctypes.c_double
+    fn.restype = self.R.c_real
     dist = fn(ctypes.byref(self.cm), ctypes.byref(self.cd), dp(p), dp(v), None if gg is None else dp(gg), int(bool(flg_static)), int(bodyexclude), ctypes.byref(gid), dp(nrm))
     return float(dist), int(gid.value), nrm
 

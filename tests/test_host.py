@@ -101,9 +101,9 @@ def test_unsupported_features_raise():
   m = mjw.mjcf.from_xml_string('<mujoco><option><flag override="enable"/></option><worldbody><body><joint/><geom size=".1"/></body></worldbody></mujoco>')
   with pytest.raises(NotImplementedError):
     mjw.put_model(m)
+  # (joint actuatorfrcrange / actuatorgravcomp are implemented since round 4: tests/test_aloha_pot.py)
   m = mjw.mjcf.from_xml_string('<mujoco><worldbody><body><joint actuatorfrcrange="-1 1"/><geom size=".1"/></body></worldbody></mujoco>')
-  with pytest.raises(NotImplementedError):
-    mjw.put_model(m)
+  assert int(mjw.put_model(m).jnt_actfrclimited.numpy()[0]) == 1
   m = mjw.mjcf.from_xml_string('<mujoco><option integrator="implicit"/><worldbody><body><joint/><geom size=".1"/></body></worldbody></mujoco>')
   assert int(mjw.put_model(m).opt.integrator) == int(mjw.IntegratorType.IMPLICIT)  # (round 3: built for nv <= 64, tests/test_implicit.py)
 
