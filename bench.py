@@ -7,11 +7,15 @@ N > 1 without a torch.distributed environment: bench.py re-executes itself throu
 launched by torchrun it reads RANK / LOCAL_RANK / WORLD_SIZE.  Every rank checks that the group really has N ranks and
 that each rank owns a distinct device.
 
-A "step" is one pass of the mj_step hot path (control-noise kernel + step) over a batch of synthetic worlds that start
-from keyframe 0 and are decorrelated by the harness' Halton/OU control noise (reference cli.py:103-145, 240-297).  State
-is resident in HBM before the timed region starts; the timed region is bracketed by barrier + torch.cuda.synchronize()
-on both sides; `value` = all worlds of all ranks x K / MAX elapsed over ranks.  Worlds shard with no data-path
-collective; the only collective is the metrics all-reduce after the timed region.
+A "step" is one pass of the mj_step hot path over a batch of synthetic worlds that start from keyframe 0 and are decorrelated by
+the harness' Halton/OU control noise (reference cli.py:103-145, 240-297).  State is resident in HBM before the timed region
+starts.  TIMER PLACEMENT = THE REFERENCE'S (cli.py:289-292, testspeed.py:362): per step the control-noise kernel runs
+and is synchronised UNTIMED, then `step` + device synchronise is timed; `value` = all worlds of all ranks x K / MAX over ranks of the
+summed step times.  The window of exactly K steps (after W untimed warm-up steps) is bracketed by barrier + synchronize on both
+sides and measured THREE times from the same state: `value` is the median window, `windows` lists all three (box-to-box noise on
+this fleet is 20-40 %, run-to-run noise ~1 %: `box` carries a fingerprint -- the state-independent k_fwd_pos launch time and
+rocm-smi clocks / power when readable).  `back_to_back` = the same K steps enqueued without per-step syncs, noise inside.
+Worlds shard with no data-path collective; the only collective is the metrics all-reduce after the timed region.
   --scaling weak   (default) every GPU steps its own 8192 worlds  -> "scaling": "weak"
   --scaling strong 8192 worlds in total, shard_worlds(8192, rank, N) per GPU
 With N > 1 the line also carries the other mode as `other_scaling`.
@@ -19,10 +23,14 @@ With N > 1 the line also carries the other mode as `other_scaling`.
 Extra objects on the JSON line:
   roofline     -- dominant kernel (the solver launch): SURVEY 8(d) algorithmic HBM bytes per launch / mean launch time from
                   HIP events recorded on the launch stream (instrumented replay of the same K steps); `traffic` is null
-                  unless --pmc-profile names a rocprofv3 PMC summary of THIS solver's kernel
+                  unless --pmc-profile names a rocprofv3 PMC summary of THIS solver's kernel; `issue` = what actually bounds the three
+                  launches, from the same PMC summary: VALU issue fraction (SQ_INSTS_VALU x 2 cycles / SIMD busy cycles), LDS pipe
+                  busy fraction, resident waves per SIMD, wait fraction, HBM fraction of each kernel
   steady_1000  -- the reference's own measurement (testspeed.py:362, cli.py:289-292): 1000 steps from key 0, device sync per
                   step, control noise outside the timed region -- the state the published metric averages over, whatever
                   --steps / --warmup the caller passed
+  configs      -- the other BASELINE configs on this GPU, reference placement: unitree_g1_flat, franka_emika_panda, aloha_pot (the
+                  reference's in-tree ALOHA model, its registry sizes) and the configs[4]-class clutter_synth (Newton + sleep, PGS)
   cpu_baseline -- the float64 oracle ("port": restatement, NOT MuJoCo C) on the host cores, bounded sample
 """
 
@@ -134,29 +142,64 @@ def check_group(gpus):
   return rank, local_rank, world_size
 
 
+STATE_FIELDS = ("qpos", "qvel", "ctrl", "qacc_warmstart", "time", "solver_niter")
+NWINDOW = 3
+
+
+def reference_window(mjw, m, d, steps, step0):
+  """K steps with the reference's timer placement (cli.py:289-292): noise kernel + sync untimed, step + sync timed.  Returns seconds."""
+  import torch
+
+  total = 0.0
+  for i in range(steps):
+    mjw.ctrl_noise(m, d, step0 + i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    mjw.step(m, d)
+    torch.cuda.synchronize()
+    total += time.perf_counter() - t0
+  return total
+
+
 def measure(mjw, shard, m, mjm, nworld, world_offset, steps, warmup):
-  """W untimed warm-up steps, then exactly K timed steps (barrier + synchronize on both sides).  Returns the Data (for the
-  replays), a snapshot of the state at the start of the timed window and the per-rank measurement."""
+  """W untimed warm-up steps, then exactly K timed steps (barrier + synchronize on both sides), NWINDOW times from the same state.
+  Returns the Data (for the replays), a snapshot of the state at the start of the timed window and the per-rank measurement."""
   import torch
 
   d = mjw.make_data(mjm, nworld=nworld, nconmax=24, njmax=64)
   d.world_offset = world_offset  # global world ids: trajectories independent of the number of GPUs
   mjw.reset_data_keyframe(m, d, 0)
+  mjw.step(m, d)  # function attributes / first touch outside the timed region (the reference captures its graph before timing)
+  mjw.reset_data_keyframe(m, d, 0)
   if warmup:
     mjw.timed_steps(m, d, warmup, step0=0)
-  snapshot = {k: getattr(d, k).numpy().copy() for k in ("qpos", "qvel", "ctrl", "qacc_warmstart", "time")}
+  torch.cuda.synchronize()
+  snapshot = {k: getattr(d, k).numpy().copy() for k in STATE_FIELDS}
+  windows = []
+  for rep in range(NWINDOW):
+    for k, v in snapshot.items():
+      getattr(d, k).assign(v)
+    shard.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    windows.append(reference_window(mjw, m, d, steps, warmup))
+    torch.cuda.synchronize()
+    shard.barrier()
+    wall = time.perf_counter() - t0
+  qpos = d.qpos.numpy()
+  nefc, niter = np.minimum(d.nefc.numpy(), d.njmax), d.solver_niter.numpy()
+  nan_worlds, ovf_worlds = float(np.isnan(qpos).any(axis=1).sum()), float((d.overflow.numpy() != 0).sum())
+  # the same K steps enqueued back to back (no per-step sync, noise kernel inside): the engine's throughput when nothing waits for it
+  for k, v in snapshot.items():
+    getattr(d, k).assign(v)
   shard.barrier()
   torch.cuda.synchronize()
   t0 = time.perf_counter()
   ev_ms, _ = mjw.timed_steps(m, d, steps, step0=warmup)
   torch.cuda.synchronize()
   shard.barrier()
-  elapsed = time.perf_counter() - t0
-  qpos = d.qpos.numpy()
-  res = {
-    "elapsed": elapsed, "ev_ms": ev_ms, "nan_worlds": float(np.isnan(qpos).any(axis=1).sum()),
-    "ovf_worlds": float((d.overflow.numpy() != 0).sum()), "nefc": np.minimum(d.nefc.numpy(), d.njmax), "niter": d.solver_niter.numpy(),
-  }
+  b2b = time.perf_counter() - t0
+  res = {"windows": windows, "wall_last_window": wall, "b2b": b2b, "ev_ms": ev_ms, "nan_worlds": nan_worlds, "ovf_worlds": ovf_worlds, "nefc": nefc, "niter": niter}
   return d, snapshot, res
 
 
@@ -189,49 +232,81 @@ def steady_1000(mjw, m, mjm, nworld, world_offset, nstep=1000):
 
 
 def other_configs(mjw, nstep=200):
-  """BASELINE.json configs[2] and [3] on this GPU, off the timed headline: the model as authored (Newton, implicitfast), the
-  reference's measurement loop (per-step device sync, noise / replayed control untimed) over `nstep` steps after an untimed lead-in."""
+  """The other BASELINE.json configs on this GPU, off the timed headline: each model as authored (solver, integrator, cone, iteration caps),
+  the reference's measurement loop (per-step device sync, noise / replayed control untimed) over `nstep` steps after an untimed lead-in.
+    unitree_g1_flat, franka_emika_panda  -- configs[2] / [3]
+    aloha_pot                           -- the reference's in-tree ALOHA model (mujoco_warp/test_data/aloha_pot, all 134 assets) at the sizes of
+                                           its benchmark registry (benchmarks/aloha/__init__.py:15-25), replaying lift_pot.npz
+    clutter_synth, clutter_synth_pgs    -- configs[4] class (aloha_clutter's 216 meshes are not in the reference tree): nv 136, elliptic, impratio 10,
+                                           2048 worlds; Newton + sleeping + init_asleep as the reference's registry runs it, and the PGS solver configs[4] names"""
   import torch
 
+  B = os.path.join(ROOT, "benchmarks")
+  entries = (
+    dict(name="unitree_g1_flat", xml=os.path.join(B, "unitree_g1", "scene_flat.xml"), nworld=4096, nconmax=48, njmax=192, replay=os.path.join(B, "unitree_g1", "shuffle_dance.npz")),
+    dict(name="franka_emika_panda", xml=os.path.join(B, "franka_emika_panda", "scene.xml"), nworld=8192, nconmax=1, njmax=5),
+    dict(name="aloha_pot", xml=os.path.join(B, "aloha_pot", "scene.xml"), nworld=8192, nconmax=24, njmax=128, replay=os.path.join(B, "aloha_pot", "lift_pot.npz")),
+    dict(name="clutter_synth", xml=os.path.join(B, "clutter_synth", "scene_clutter_synth.xml"), nworld=2048, nconmax=256, njmax=384, nvmax=56,
+         override=["opt.enableflags=SLEEP"], init_asleep=True, hold_key_ctrl=True),
+    dict(name="clutter_synth_pgs", xml=os.path.join(B, "clutter_synth", "scene_clutter_synth.xml"), nworld=2048, nconmax=256, njmax=384,
+         override=["opt.solver=pgs", "opt.enableflags=0"], nstep=100, lead=50, hold_key_ctrl=True),
+  )
   out = {}
-  for name, rel, nworld, nconmax, njmax, replay in (
-      ("unitree_g1_flat", ("unitree_g1", "scene_flat.xml"), 4096, 48, 192, "shuffle_dance.npz"),
-      ("franka_emika_panda", ("franka_emika_panda", "scene.xml"), 8192, 1, 5, None)):
-    mjm = mjw.mjcf.load_xml(os.path.join(ROOT, "benchmarks", *rel))
-    m = mjw.put_model(mjm)
-    d = mjw.make_data(mjm, nworld=nworld, nconmax=nconmax, njmax=njmax)
-    if mjm.nkey:
-      mjw.reset_data_keyframe(m, d, 0)
-    center = None
-    if replay:  # the recorded controls are the noise centre (reference cli.py:119-145 with --replay)
-      ctrl = mjw.load_trajectory(os.path.join(ROOT, "benchmarks", rel[0], replay), mjm, mjw.MjData(mjm))
-      center = [mjw.DeviceArray.from_numpy(np.asarray(c, dtype=np.float32)) for c in ctrl[: 100 + nstep]]  # [nu]: the noise centre of every world
-      z = np.load(os.path.join(ROOT, "benchmarks", rel[0], replay))
-      if "qpos" in z.files and z["qpos"].shape[1] == mjm.nq:  # start where the recording starts: the controls were made for that state
-        d.qpos.assign(np.tile(z["qpos"][0].astype(np.float32), (nworld, 1)))
-        d.qvel.assign(np.tile(z["qvel"][0].astype(np.float32), (nworld, 1)))
-    total = nefc = niter = 0.0
-    for i in range(100 + nstep):
-      mjw.ctrl_noise(m, d, i, center=center[i] if center else None)
-      torch.cuda.synchronize()
-      t0 = time.perf_counter()
-      mjw.step(m, d)
-      torch.cuda.synchronize()
-      if i >= 100:
-        total += time.perf_counter() - t0
-        if i % 50 == 49:
-          nefc += float(np.minimum(d.nefc.numpy(), d.njmax).mean())
-          niter += float(d.solver_niter.numpy().mean())
-    ok = bool(np.isfinite(d.qpos.numpy()).all())
-    ms_b2b, _ = mjw.timed_steps(m, d, nstep, step0=100 + nstep)
-    out[name] = {"workload": f"{rel[1]}, nworld={nworld}, nconmax={nconmax}, njmax={njmax}, solver / integrator / iteration caps as authored"
-                             + (f", initial state and control centre from {replay} + noise" if replay else ", control noise"),
-                 "value": nworld * nstep / total, "unit": "env-steps/s", "nstep": nstep, "ms_per_step": 1e3 * total / nstep,
-                 "back_to_back_value": nworld * nstep / (ms_b2b * 1e-3), "nefc_mean": nefc / (nstep // 50), "solver_niter_mean": niter / (nstep // 50),
-                 "finite": ok, "overflow_bits": int(np.bitwise_or.reduce(d.overflow.numpy())),
-                 "timing": "reference placement (per-step sync, control untimed); back_to_back_value = the same steps enqueued without syncs"}
-    del d
+  for e in entries:
+    try:
+      out[e["name"]] = _config_run(mjw, torch, e, e.get("nstep", nstep), e.get("lead", 100))
+    except Exception as ex:  # a side config must not take the headline line down with it
+      out[e["name"]] = {"error": f"{type(ex).__name__}: {ex}"}
   return out
+
+
+def _config_run(mjw, torch, e, nstep, lead):
+  mjm = mjw.mjcf.load_xml(e["xml"])
+  if e.get("override"):
+    mjw.override_model(mjm, e["override"])
+  m = mjw.put_model(mjm)
+  mjd = mjw.MjData(mjm)
+  if mjm.nkey:
+    mjw.mj_resetDataKeyframe(mjm, mjd, 0)
+  center = None
+  if e.get("replay"):  # the recorded controls are the noise centre (reference cli.py:119-145 with --replay); the recording's start state is applied
+    ctrl = mjw.load_trajectory(e["replay"], mjm, mjd)
+    center = [mjw.DeviceArray.from_numpy(np.asarray(c, dtype=np.float32)) for c in ctrl[: lead + nstep]]
+  if e.get("init_asleep"):  # reference cli.py:167-168
+    mjd.tree_asleep[:] = np.arange(mjm.ntree, dtype=np.int32)
+  d = mjw.put_data(mjm, mjd, nworld=e["nworld"], nconmax=e["nconmax"], njmax=e["njmax"], nvmax=e.get("nvmax"))
+  hold = mjw.DeviceArray.from_numpy(np.asarray(mjd.ctrl, dtype=np.float32)) if (mjm.nu and center is None and e.get("hold_key_ctrl")) else None  # noise around the keyframe's controls
+  total = nefc = niter = ncon = 0.0
+  nstat = 0
+  for i in range(lead + nstep):
+    mjw.ctrl_noise(m, d, i, center=center[min(i, len(center) - 1)] if center else hold)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    mjw.step(m, d)
+    torch.cuda.synchronize()
+    if i >= lead:
+      total += time.perf_counter() - t0
+      if i % 50 == 49:
+        nefc += float(np.minimum(d.nefc.numpy(), d.njmax).mean())
+        niter += float(d.solver_niter.numpy().mean())
+        ncon += float(d.ws_ncon.numpy().mean())
+        nstat += 1
+  ok = bool(np.isfinite(d.qpos.numpy()).all())
+  ovf = int(np.bitwise_or.reduce(d.overflow.numpy()))
+  res = {"workload": f"{os.path.basename(e['xml'])}, nworld={e['nworld']}, nconmax={e['nconmax']}, njmax={e['njmax']}"
+                     + (f", nvmax={e['nvmax']}" if e.get("nvmax") else "") + (f", {' '.join(e['override'])}" if e.get("override") else "")
+                     + (", init_asleep" if e.get("init_asleep") else "") + ", solver / integrator / cone / iteration caps as authored"
+                     + (f", initial state and control centre from {os.path.basename(e['replay'])} + noise" if e.get("replay") else ", control noise"),
+         "nv": int(mjm.nv), "ngeom": int(mjm.ngeom), "solver": ["PGS", "CG", "NEWTON"][int(mjm.opt.solver)], "cone": ["pyramidal", "elliptic"][int(mjm.opt.cone)],
+         "value": e["nworld"] * nstep / total, "unit": "env-steps/s", "nstep": nstep, "ms_per_step": 1e3 * total / nstep,
+         "ncon_mean": ncon / max(nstat, 1), "nefc_mean": nefc / max(nstat, 1), "solver_niter_mean": niter / max(nstat, 1),
+         "finite": ok, "overflow_bits": ovf, "iteration_cap_worlds": int(((d.overflow.numpy() >> 9) & 1).sum()),
+         "timing": "reference placement (per-step sync, control untimed)"}
+  if int(mjm.opt.solver) != 0 and not (int(mjm.opt.enableflags) & int(mjw.EnableBit.SLEEP)):  # (timed_steps runs the fused, non-sleeping launch sequence)
+    ms_b2b, _ = mjw.timed_steps(m, d, nstep, step0=lead + nstep)
+    res["back_to_back_value"] = e["nworld"] * nstep / (ms_b2b * 1e-3)
+  del d
+  return res
 
 
 def main():
@@ -247,7 +322,7 @@ def main():
   ap.add_argument("--no-steady", action="store_true", help="skip the 1000-step reference-placement figure")
   ap.add_argument("--pmc-profile", default="auto", help="rocprofv3 PMC summary (tools/make_pmc_summary.py) of this solver's kernel; "
                   "auto = the committed profiles/round3_pmc_<solver>.json (labelled as such in traffic_source), none = null")
-  ap.add_argument("--no-configs", action="store_true", help="skip the BASELINE configs[2] / [3] figures (G1 4096 worlds, Panda 8192 worlds)")
+  ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configs (G1 4096 worlds, Panda 8192, aloha_pot 8192, clutter_synth 2048 Newton + PGS)")
   args = ap.parse_args()
   if args.gpus < 1:
     raise SystemExit("--gpus must be >= 1")
@@ -281,8 +356,12 @@ def main():
   def run(mode):
     off, cnt = shard_of(mode)
     d, snap, r = measure(mjw, shard, m, mjm, cnt, off, args.steps, args.warmup)
-    t_max, env_steps, nan_tot, ovf_tot = shard.reduce_metrics(r["elapsed"], float(cnt * args.steps), r["nan_worlds"], r["ovf_worlds"])
-    return d, snap, r, cnt, t_max, env_steps, nan_tot, ovf_tot
+    # every window: MAX over ranks of the summed step times; counters summed over ranks
+    red = [shard.reduce_metrics(w, float(cnt * args.steps), r["nan_worlds"], r["ovf_worlds"]) for w in r["windows"]]
+    r["windows_max"] = [x[0] for x in red]
+    r["b2b_max"] = shard.reduce_metrics(r["b2b"], 0.0, 0.0, 0.0)[0]
+    t_med = float(np.median(r["windows_max"]))
+    return d, snap, r, cnt, t_med, red[0][1], red[0][2], red[0][3]
 
   d, snapshot, r, nworld, t_max, env_steps, nan_tot, ovf_tot = run(args.scaling)
   nefc, niter = r["nefc"], r["niter"]
@@ -298,9 +377,12 @@ def main():
       "config": {"workload": f"humanoid.xml, nworld={args.nworld} {'per GPU' if args.scaling == 'weak' else 'in total'}, {args.solver.upper()} solver, Euler, pyramidal, "
                              "nconmax=24, njmax=64, key 0 + Halton/OU control noise (std 0.01, rate 0.1)",
                  "nworld_per_gpu": nworld, "nworld_total": total_worlds, "parallelism": f"worlds sharded over {world_size} GPU(s), no data-path collective"},
-      "timing": "K steps enqueued back to back on one stream (no per-step sync), control noise inside the timed region; the "
-                "reference's placement (per-step sync, noise untimed) is reported as steady_1000",
-      "event_ms_per_step_rank0": r["ev_ms"] / args.steps,
+      "timing": "the reference's placement (cli.py:289-292): per step the control-noise kernel + sync untimed, then step + device sync timed; "
+                f"value = median of {NWINDOW} windows of exactly K steps from the same state (max over ranks per window); back_to_back = the same steps without per-step syncs",
+      "windows": [{"value": env_steps / t, "ms_per_step": 1e3 * t / args.steps} for t in r["windows_max"]],
+      "window_spread": (max(r["windows_max"]) - min(r["windows_max"])) / t_max,
+      "back_to_back": {"value": env_steps / r["b2b_max"], "ms_per_step": 1e3 * r["b2b_max"] / args.steps, "event_ms_per_step_rank0": r["ev_ms"] / args.steps,
+                       "timing": "K steps enqueued on one stream, no per-step sync, control noise inside the timed region"},
       "converged_worlds": int(total_worlds - nan_tot), "overflow_worlds": int(ovf_tot),
       "nefc_mean": float(nefc.mean()), "nefc_p95": float(np.percentile(nefc, 95)),
       "solver_niter_mean": float(niter.mean()), "solver_niter_p95": float(np.percentile(niter, 95)),
@@ -327,13 +409,16 @@ def main():
                        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                        "traffic": traffic, "traffic_source": traffic_src, "bytes_per_launch": 4 * words_solve * nworld,
                        "us_per_launch": fused_us["solve"],
-                       "note": "the solver is VALU-issue / latency bound, not an HBM stream (profiles/): the HBM fraction is reported because the contract asks for it"}
+                       "note": "not an HBM stream: the kernel is a latency chain at ~2.5 waves per SIMD -- see `issue` (VALU issue ~1/3, LDS pipe ~1/3, HBM 3-5 %); "
+                               "the HBM fraction is reported because the contract asks for it"}
     t_pass = (fused_us["fwd_pos"] + fused_us["solve"]) * 1e-6
     pass_bytes = 4 * (words_crb + words_solve) * nworld
     out["pass_crba_solver"] = {"bytes": pass_bytes, "us": t_pass * 1e6, "achieved_GBs": pass_bytes / t_pass / 1e9,
                                "frac_of_8TBs": pass_bytes / t_pass / 1e9 / HBM_PEAK_GBS,
                                "note": "time = k_fwd_pos_plus (FK+CoM+CRBA fused) + the solver launch; bytes = SURVEY 8(d)"}
     out["fused_launch_us"] = fused_us
+    out["roofline"]["issue"] = _issue_from_profile(args.pmc_profile, args.solver)
+    out["box"] = box_fingerprint(fused_us.get("fwd_pos"))
     # per-stage trace: one plain kernel per stage (the reference's event-tracer granularity)
     for k, v in snapshot.items():
       getattr(d, k).assign(v)
@@ -368,15 +453,60 @@ def main():
     dist.destroy_process_group()
 
 
+def _committed_profile(solver):
+  for r in ("round4", "round3"):
+    p = os.path.join(ROOT, "profiles", f"{r}_pmc_{solver}.json")
+    if os.path.exists(p):
+      return p
+  return None
+
+
+def _issue_from_profile(path, solver):
+  """What bounds the three launches of the step, from the rocprofv3 PMC summary of the same workload and solver (tools/make_pmc_summary.py):
+  per kernel the VALU issue fraction (a wave64 VALU instruction occupies a SIMD-32 for 2 cycles: SQ_INSTS_VALU x 2 / (1,024 SIMDs x
+  busy cycles)), the LDS pipe's busy fraction, the resident waves per SIMD, the share of wave-cycles spent waiting and the HBM fraction."""
+  if path == "auto":
+    path = _committed_profile(solver)
+  if not path or path == "none" or not os.path.exists(path):
+    return None
+  try:
+    j = json.load(open(path))
+    if j.get("solver") != solver:
+      return None
+    out = {"source": os.path.relpath(path, ROOT) + " (PMC passes of the same workload and solver, not this process)", "window": j.get("window")}
+    for k, v in j.get("kernels", {}).items():
+      if v.get("valu_issue_frac") is None:
+        continue
+      if k in ("k_fwd_pos", "k_mid") or k == j.get("k_solve_kernel"):
+        out[k] = {q: v.get(q) for q in ("mean_us", "valu_issue_frac", "lds_busy_frac", "waves_per_simd", "wait_frac", "hbm_frac", "hbm_bytes_per_launch")}
+    return out
+  except Exception as e:
+    return {"error": f"{path}: {e}"}
+
+
+def box_fingerprint(fwd_pos_us):
+  """Box-to-box variance on this fleet is 20-40 %: the state-independent k_fwd_pos launch time identifies a slow box,
+  rocm-smi adds clocks and power where it can be read."""
+  out = {"k_fwd_pos_us": fwd_pos_us, "note": "k_fwd_pos does the same work every step (FK + CRBA of 8192 humanoids): 47-50 us on a fast box, 55+ on a slow one"}
+  try:
+    o = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--json"], capture_output=True, text=True, timeout=20).stdout
+    card = next(iter(json.loads(o).values()))
+    for key, val in card.items():
+      kl = key.lower()
+      if "sclk" in kl or "mclk" in kl or "power" in kl:
+        out[key] = val
+  except Exception as e:
+    out["rocm_smi"] = f"unavailable ({type(e).__name__})"
+  return out
+
+
 def _traffic_from_profile(path, solver):
   """HBM bytes per solver launch from a rocprofv3 PMC summary of the SAME solver's kernel (FETCH_SIZE x2 on gfx950 + WRITE_SIZE,
   separate passes: MI355X_MICROARCH.md).  Without such a profile the field is null: a number from another run is not a measurement."""
   committed = False
   if path == "auto":
-    path = os.path.join(ROOT, "profiles", f"round3_pmc_{solver}.json")
+    path = _committed_profile(solver)
     committed = True
-    if not os.path.exists(path):
-      path = None
   if not path or path == "none":
     return None, "not collected in this run (rocprofv3 --pmc needs its own passes; see profiles/)"
   try:

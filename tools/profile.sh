@@ -1,12 +1,13 @@
 #!/bin/bash
 # GPU box: rocprofv3 kernel trace + PMC passes of the headline bench; summaries land in gpurun_out/prof_<tag>/.
-# usage: tools/profile.sh <tag> [bench args...]
+# usage: [PROFILE_LAST=N] tools/profile.sh <tag> [bench args...]     (PROFILE_LAST: summarise only the last N dispatches of each kernel,
+#        e.g. 200 = the three timed windows + the back-to-back replay of `--steps 50`, without the warm-up that led to the window)
 set -u
 TAG=${1:-r1}; shift || true
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python $PWD/bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-roofline --no-steady --no-configs $*"
+BENCH="python $PWD/bench.py --steps 50 --no-cpu-baseline --no-roofline --no-steady --no-configs $*"  # (default --warmup 20; pass --warmup 300 for the steady window)
 cd /tmp
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $BENCH > $OUT/trace.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS -d $OUT/pmc_sq -o pmc -- $BENCH > $OUT/pmc_sq.log 2>&1

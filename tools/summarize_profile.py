@@ -43,14 +43,19 @@ def _short(n):
   return n[:60]
 
 
+LAST = int(os.environ.get("PROFILE_LAST", "0"))  # > 0: only the last N dispatches of every kernel (the timed windows, not the warm-up)
+
+
 def kernel_trace(dbpath):
   db = sqlite3.connect(dbpath)
   cur = db.cursor()
   t = _tables(cur)
   names = {r[0]: r[1] for r in cur.execute(f"select id, kernel_name from '{t['rocpd_info_kernel_symbol']}'")}
   agg = defaultdict(list)
-  for kid, s, e in cur.execute(f"select kernel_id, start, end from '{t['rocpd_kernel_dispatch']}'"):
+  for kid, s, e in cur.execute(f"select kernel_id, start, end from '{t['rocpd_kernel_dispatch']}' order by start"):
     agg[_short(names.get(kid, str(kid)))].append(e - s)
+  if LAST > 0:
+    agg = {k: v[-LAST:] for k, v in agg.items()}
   total = sum(sum(v) for v in agg.values())
   out = []
   for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
@@ -80,7 +85,13 @@ def pmc(dbpath):
   t = _tables(cur)
   names = {r[0]: r[1] for r in cur.execute(f"select id, kernel_name from '{t['rocpd_info_kernel_symbol']}'")}
   pmcn = {r[0]: r[1] for r in cur.execute(f"select id, name from '{t['rocpd_info_pmc']}'")}
-  ev2k = {r[0]: _short(names.get(r[1], str(r[1]))) for r in cur.execute(f"select event_id, kernel_id from '{t['rocpd_kernel_dispatch']}'")}
+  ev2k, order = {}, defaultdict(list)
+  for ev, kid in cur.execute(f"select event_id, kernel_id from '{t['rocpd_kernel_dispatch']}' order by start"):
+    ev2k[ev] = _short(names.get(kid, str(kid)))
+    order[ev2k[ev]].append(ev)
+  if LAST > 0:
+    keep = set(ev for evs in order.values() for ev in evs[-LAST:])
+    ev2k = {ev: k for ev, k in ev2k.items() if ev in keep}
   per = defaultdict(lambda: defaultdict(float))
   ndisp = defaultdict(set)
   for ev, pid, val in cur.execute(f"select event_id, pmc_id, value from '{t['rocpd_pmc_event']}'"):
