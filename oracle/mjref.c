@@ -65,7 +65,10 @@ static double v3normalize(double* a) { /* wp.normalize: zero stays zero */
   return n;
 }
 static double safe_div(double x, double y) { return x / (y != 0.0 ? y : MINVAL); }
-static double clampd(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
+static double clampd(double x, double lo, double hi) { /* wp.clamp = min(max(lo, x), hi): with lo > hi the result is hi -- _efc_row clamps the impedance to [dmin, dmax] of a solimp whose dmin exceeds dmax (aloha fingers: solimp 2 1 0.01 mixed with a default geom) */
+  double y = x > lo ? x : lo;
+  return y < hi ? y : hi;
+}
 
 static void mul_quat(double* r, const double* u, const double* v) { /* math.py:24 */
   double w = u[0] * v[0] - u[1] * v[1] - u[2] * v[2] - u[3] * v[3];
