@@ -226,7 +226,7 @@ typedef struct MjhModel {
 typedef struct MjhData {
   int nworld; int nconmax; int naconmax; int njmax; int njmax_pad; int nv_pad; int nmaxpyramid; int world_offset;
   int concap;          /* per-world contact capacity of ws_contact: clamp(2 nconmax, 16, 256)          */
-  int reserved0;
+  int nccdhand;        /* EPA entries the convex narrowphase can hand from k_ccd_gjk to k_ccd_epa per step (csrc/collide.hpp ccd_handcap) */
   /* state (types.py:2240-2262) */
   float* time; float* qpos; float* qvel; float* act; float* ctrl; float* qacc_warmstart;
   float* qfrc_applied; float* xfrc_applied;
@@ -259,8 +259,9 @@ typedef struct MjhData {
   int* ws_ncon;        /* [nworld]   contacts found per world                         */
   int* ws_conadr;      /* [nworld]   exclusive scan of ws_ncon = first public slot (k_contact_scan) */
   int* ws_ncollision;  /* [nworld]   broadphase candidates per world                  */
-  float* ws_ccd;       /* [nworld, ccd_words(ccd_iterations), 32] EPA polytopes of the convex narrowphase, one per lane of a world, interleaved by
-                          lane (csrc/convex.hpp); empty unless the model has convex (GJK) pairs */
+  float* ws_ccd;       /* workspace of the convex narrowphase (layout: csrc/convex.hpp ccd_layout -- per world the height-field prisms' polytopes, the
+                          per-candidate result cache and the candidate list; then the flat GJK list, the EPA hand-over records and the multi-contact
+                          buffers); empty unless the model has convex (GJK) pairs */
   /* constraint islands at tree granularity (MjhModel.tree_solve, csrc/constraint.hpp k_tree_rows); island k of a world: */
   int* ws_tree_rowadr; /* [nworld, ntree + 1] its rows are ws_tree_rowmap[rowadr[k] .. rowadr[k + 1])                       */
   int* ws_tree_rowmap; /* [nworld, njmax] constraint rows grouped by island                                                */
@@ -359,7 +360,7 @@ int mjh_timed_steps(const MjhModel* m, const MjhData* d, int nstep, int step0, f
 int mjh_release_thread_resources(void);
 
 const char* mjh_last_error(void);
-#define MJH_ABI_VERSION 35
+#define MJH_ABI_VERSION 36
 int mjh_abi_version(void); /* returns MJH_ABI_VERSION of the library that was loaded */
 
 #ifdef __cplusplus

@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_PKG, "libmjhip.so")
 UNITS = ["mjhip.hip", "solve_cg32.hip", "solve_cgw.hip", "solve_newton32.hip", "solve_cg64.hip", "solve_newton64.hip", "solve_ell_cg32.hip", "solve_ell_newton32.hip",
          "solve_ell_cg64.hip", "solve_ell_newton64.hip", "solve_tree_cg.hip", "solve_tree_newton.hip", "solve_tree_ell_cg.hip", "solve_tree_ell_newton.hip", "pgs_tu.hip", "solve_big.hip"]
 HEADERS = ["host.hpp", "solve_tu.hpp", "solve_tree.hpp", "dev_common.hpp", "smooth.hpp", "collide.hpp", "constraint.hpp", "solver.hpp", "solver_cgw.hpp", "solver_newton.hpp", "solver_big.hpp", "pgs.hpp",
-           "integrate.hpp", "implicit.hpp", "pgs_big.hpp", "sleep.hpp", "convex.hpp", "sensor.hpp", "support.hpp", "ray.hpp"]
+           "integrate.hpp", "implicit.hpp", "pgs_big.hpp", "sleep.hpp", "convex.hpp", "sensor.hpp", "support.hpp", "ray.hpp", "contact_rec.hpp"]
 SOURCES = [os.path.join(_PKG, "csrc", f) for f in UNITS + HEADERS]
 # -fno-slp-vectorize: the SLP vectoriser packs scalar float ops into v_pk_* pairs, which on gfx950 issue at HALF the rate of the
 # scalar forms (tools/ubench.hip: v_pk_fma_f32 4.3 cycles vs v_fma_f32 2.06) and need register pairs plus v_mov shuffles: the Newton

@@ -13,6 +13,7 @@
 #pragma once
 #include "dev_common.hpp"
 #include "convex.hpp"
+#include "contact_rec.hpp"
 
 // A collider reports each candidate contact through `emit(index, dist, pos, frame_row0, frame_row1, frame_row2)`.
 // The kernel runs every collider twice with different emitters (count, then write): nothing is buffered per
@@ -528,6 +529,88 @@ DEV void collide_convex(float tolerance, int iterations, int epa_iterations, int
   emit(0, dist, 0.5f * (w1 + w2), f.a, f.b, f.c);
 }
 
+// ---- the convex pair in two launches (round 4; convex.hpp header) -----------------------------------------------------------------------
+// GJK by ONE lane.  Returns 0: no contact, 1: one contact, emitted (no penetration deeper than the tolerance: EPA not needed), 2: EPA
+// needed -- `res` holds the simplex, idx1 / idx2 the mesh vertex caches the support function left
+template <class Emit>
+DEV int convex_gjk_lane(float tolerance, int iterations, int t1, int t2, V3 p1, const float* R1, V3 s1, V3 p2, const float* R2, V3 s2, float margin, float gap, Emit&& emit,
+                        const float* vert1, int nvert1, const float* vert2, int nvert2, const MjhModel& mm, int mesh1, int mesh2, GjkOut& res, int& idx1, int& idx2) {
+  auto graph_of = [&](int meshid) -> const int* { return (meshid >= 0 && mm.mesh_graphadr[meshid] >= 0) ? mm.mesh_graph + mm.mesh_graphadr[meshid] : nullptr; };
+  CcdGeom a = CcdGeom{t1, p1, R1, s1, margin, vert1, nvert1, -1, mesh1, graph_of(mesh1), -1, nullptr}, b = CcdGeom{t2, p2, R2, s2, margin, vert2, nvert2, -1, mesh2, graph_of(mesh2), -1, nullptr};
+  float dist;
+  V3 w1, w2;
+  const int r = ccd_gjk_phase(tolerance, gap, iterations, a, b, dist, w1, w2, res);
+  idx1 = a.index;
+  idx2 = b.index;
+  if (r == 2) return 2;
+  if (dist >= gap) return 0;
+  dist += margin;
+  const Frame f = make_frame3(dist <= margin ? w1 - w2 : w2 - w1);
+  emit(0, dist, 0.5f * (w1 + w2), f.a, f.b, f.c);
+  return 1;
+}
+// EPA + multi-contact recovery by the CG lanes of a group TOGETHER (identical arguments in every lane): from the simplex in `res`;
+// `poly` = the group's LDS polytope (stride 1), `mcws` = the group's multi-contact words (stride 1)
+template <int CG, class Emit>
+DEV void convex_epa_group(float tolerance, int epa_iterations, int t1, int t2, V3 p1, const float* R1, V3 s1, V3 p2, const float* R2, V3 s2, float margin, float gap, float* poly,
+                          int& overflow, Emit&& emit, const float* vert1, int nvert1, const float* vert2, int nvert2, const MjhModel& mm, int mesh1, int mesh2, GjkOut& res,
+                          int idx1, int idx2, int lig, float* mcws) {
+  auto graph_of = [&](int meshid) -> const int* { return (meshid >= 0 && mm.mesh_graphadr[meshid] >= 0) ? mm.mesh_graph + mm.mesh_graphadr[meshid] : nullptr; };
+  const CcdGeom a = CcdGeom{t1, p1, R1, s1, margin, vert1, nvert1, idx1, mesh1, graph_of(mesh1), idx1, nullptr}, b = CcdGeom{t2, p2, R2, s2, margin, vert2, nvert2, idx2, mesh2, graph_of(mesh2), idx2, nullptr};
+  float dist = res.dist;
+  V3 w1 = res.x1, w2 = res.x2;
+  int face;
+  Poly pt;
+  int n = ccd_epa_phase<CG>(tolerance, epa_iterations, a, b, res, poly, dist, w1, w2, overflow, face, pt, lig, 1);
+  if (n == 0 || dist >= gap) return;
+  dist += margin;
+  const bool anymesh = t1 == G_MESH || t2 == G_MESH;
+  if (face >= 0 && anymesh && ((mm.disableflags & DSBL_MULTICCD) || mm.nmeshpoly == 0)) face = -1;
+  if (face >= 0) {  // zero margin: up to four contacts from the EPA face, same distance and frame (collision_convex.py:888-960)
+    V3 m1[4], m2[4];
+    n = anymesh ? ccd_multicontact_mesh(mm, pt, face, w1, w2, a, b, m1, m2, mcws, 1) : ccd_multicontact_box(pt, face, w1, w2, a, b, m1, m2);
+    if (n == 0) return;
+    const Frame f = make_frame3(dist <= margin ? m1[0] - m2[0] : m2[0] - m1[0]);
+    for (int i = 0; i < n; ++i) emit(i, dist, 0.5f * (m1[i] + m2[i]), f.a, f.b, f.c);
+    return;
+  }
+  const Frame f = make_frame3(dist <= margin ? w1 - w2 : w2 - w1);
+  emit(0, dist, 0.5f * (w1 + w2), f.a, f.b, f.c);
+}
+// candidate capacity per world: every filtered pair for ordinary models; capped for big scenes (thousands of pairs of which few
+// survive the broadphase), where running out sets OverflowType.BROADPHASE like the reference's full pair queue
+__host__ __device__ inline int collide_ccap(int npair, int concap) {
+  const int cap = 8 * concap > 512 ? 8 * concap : 512;
+  return ((npair < cap ? npair : cap) + 3) / 4 * 4;
+}
+// EPA entries a Data can hold (Data.nccdhand): 32 per world on average, and never fewer than 4,096 (or every candidate of every world)
+// for small batches; beyond it OverflowType.CCD and the pair is dropped
+__host__ __device__ inline int ccd_handcap(int nworld, int ccap) {
+  const long long all = (long long)nworld * ccap, avg = (long long)nworld * (ccap < 32 ? ccap : 32), lo = all < 4096 ? all : 4096;
+  return (int)(avg > lo ? avg : lo);
+}
+DEV CcdLayout ccd_layout_of(const MjhModel& m, const MjhData& d) {
+  return ccd_layout(d.nworld, max(m.ccd_iterations, m.epa_iterations), m.nhfield, m.npolygonmax, m.nmeshdegmax, collide_ccap(m.npair, d.concap), d.nccdhand);
+}
+DEV bool is_ccd_pair(const MjhModel& m, int t1, int t2) {  // the pairs served by k_ccd_gjk / k_ccd_epa (height fields stay in the contact kernel)
+  return t1 != G_HFIELD && (is_convex_pair(t1, t2) || (!(m.disableflags & DSBL_NATIVECCD) && t1 == G_BOX && t2 == G_BOX));
+}
+// the cache entry of a convex candidate: count | distance | frame | up to four positions
+DEV void ccd_cache_store(float* cache, int& nem, int k, float dist, V3 pos, V3 fa, V3 fb, V3 fc, bool store) {
+  if (k < 4) {
+    if (store) {
+      if (k == 0) {
+        cache[1] = dist;
+        st3(cache + 2, fa);
+        st3(cache + 5, fb);
+        st3(cache + 8, fc);
+      }
+      st3(cache + 11 + 3 * k, pos);
+    }
+    nem = k + 1;
+  }
+}
+
 // plane - convex mesh (collision_primitive.py:52-274 plane_convex, the exhaustive branch: meshes without a hill-climbing graph or with
 // fewer than 10 vertices): the deepest vertex a, then among the vertices within 1 mm of it the one furthest from a, the one furthest
 // from the line a-b and the one furthest from the other two edges; vertices that were picked once become contacts (at most 4)
@@ -1039,19 +1122,7 @@ DEV PairParams contact_params(const MjhModel& m, int w, int g1, int g2, int pid 
   return p;
 }
 
-// Contact record (CON_REC words; CON_STRIDE in the per-world hand-off buffer d.ws_contact, so that a record is one
-// aligned 128-byte line):
-//   0 dist | 1-3 pos | 4-12 frame | 13 includemargin | 14-16 friction (slide, spin, roll) | 17-18 solref |
-//   19-23 solimp | 24 condim | 25-26 geoms | 27 collider contact id | (explicit pair id + 1) << 8 | 28 first efc row or -1 | 29 number of rows |
-//   30-31 friction of tangent 2 / roll 2 (explicit <contact><pair> entries may be anisotropic; geom pairs repeat words 14 / 16)
-// (28-29 are filled by k_make_constraint).  k_collision hands the contacts of a world to k_make_constraint through
-// d.ws_contact[w]; the public, compact contact_* arrays are produced from the same records by publish_body
-// (appended to the integrator launch or run as k_publish_contacts).  The reference reserves public slots with one global atomic per
-// contact (collision_core.py write_contact); on MI355X one same-address device atomic per WORLD already cost 25-50 us
-// per launch (they resolve at the memory side, ~6 ns each, and every later load of the wave waits behind them).
-#define CON_WINDOW 16
-#define CON_REC 32
-#define CON_LDS 33  /* odd LDS stride: lane-per-contact reads are bank-conflict free */
+// (contact record layout and publish_body: contact_rec.hpp)
 // per-world LDS: geom poses (12 words per geom) | candidate pair list | first contact slot << 8 | contact mask per
 // candidate | staging window of CON_WINDOW records
 // SAP broadphase (sap != 0) adds: projection bounds (2 words per geom, padded to a power of two for the bitonic sort) | sorted
@@ -1060,12 +1131,6 @@ __host__ __device__ inline int sap_pow2(int n) {
   int p = 1;
   while (p < n) p <<= 1;
   return p;
-}
-// candidate capacity per world: every filtered pair for ordinary models; capped for big scenes (thousands of pairs of which few
-// survive the broadphase), where running out sets OverflowType.BROADPHASE like the reference's full pair queue
-__host__ __device__ inline int collide_ccap(int npair, int concap) {
-  const int cap = 8 * concap > 512 ? 8 * concap : 512;
-  return ((npair < cap ? npair : cap) + 3) / 4 * 4;
 }
 __host__ __device__ inline int collide_lds_words(int ngeom, int npair, int concap, int sap = 0) {
   const int base = 12 * ngeom + 2 * collide_ccap(npair, concap) + CON_WINDOW * CON_LDS;
@@ -1122,7 +1187,10 @@ DEV bool obb_filter(const float* a1, const float* a2, float margin, V3 x1, V3 x2
 // HEAVY: the instantiation that also carries the large colliders (capsule-box, box-box) and the explicit <contact><pair>
 // parameter tables; models without them run the light one, whose register footprint (and with it the occupancy of k_mid: 125
 // VGPRs, exactly four waves per SIMD) is unchanged.  (Measured: the pair-id lookups alone cost the light k_mid 20 us.)
-template <int G, bool HEAVY = false>
+// MODE 0: the contact kernel (broadphase + both narrowphase passes; for models with GJK pairs -- Data.ws_ccd -- the candidate list and the
+// convex results come from the three launches in front of it).  MODE 1: k_ccd_broad -- the broadphase alone; the candidate list goes to
+// the world's slice of Data.ws_ccd, the convex candidates to the flat list of k_ccd_gjk.
+template <int G, bool HEAVY = false, int MODE = 0>
 DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const Blk& b, int stride_words = 0) {
   const int lig = threadIdx.x & (G - 1), gib = threadIdx.x / G;
   const int w = b.w0 + gib;
@@ -1138,13 +1206,21 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
   int* cslot = cand + ccap;
   float* rec = reinterpret_cast<float*>(cslot + ccap);
 
+  const bool pre = HEAVY && d.ws_ccd != nullptr;  // models with GJK pairs: k_ccd_broad / k_ccd_gjk / k_ccd_epa ran (or: this IS k_ccd_broad)
   if (m.disableflags & (DSBL_CONSTRAINT | DSBL_CONTACT)) {
-    if (lig == 0) {
+    if (lig == 0 && MODE == 0) {
       d.ws_ncon[w] = 0;
       d.ws_ncollision[w] = 0;
     }
     return;
   }
+  CcdLayout CL;
+  float* ccd_world = nullptr;
+  if (HEAVY && pre) {
+    CL = ccd_layout_of(m, d);
+    ccd_world = d.ws_ccd + (size_t)w * CL.world_stride;
+  }
+  int* gcand = ccd_world ? reinterpret_cast<int*>(ccd_world + CL.cand) : nullptr;  // ccap candidates | ncand, nbroad, nconvex
   PhaseClock pc(2, lig);
   gcopy<G>(gxpos, d.geom_xpos + (size_t)w * 3 * ng, 3 * ng, lig);
   gcopy<G>(gxmat, d.geom_xmat + (size_t)w * 9 * ng, 9 * ng, lig);
@@ -1162,6 +1238,13 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
   const int filt = HEAVY ? m.broadphase_filter : 3;
   const float* gaabb = HEAVY ? bf(m.geom_aabb, m.geom_aabb_nb, w, 6 * ng) : nullptr;
   unsigned* sapmark = nullptr;
+  int ncand = 0, nbroad = 0;
+  if (HEAVY && MODE == 0 && pre) {  // k_ccd_broad's list (the convex results are keyed by the rank in exactly this list)
+    nbroad = gcand[ccap + 1];
+    ncand = gcand[ccap];
+    for (int i = lig; i < ncand; i += G) cand[i] = gcand[i];
+    gsync();
+  } else {
   if (HEAVY && m.broadphase != 0) {
     // sweep and prune: project the bounding spheres on a fixed direction, sort by the lower bound (bitonic, in LDS), sweep
     const int np2 = sap_pow2(ng);
@@ -1230,7 +1313,6 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
     }
     gsync();
   }
-  int ncand = 0;
   for (int base = 0; base < npair; base += G) {
     const int p = base + lig;
     bool pass = false;
@@ -1273,10 +1355,60 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
     if (pass && ncand + rank < ccap) cand[ncand + rank] = p;
     ncand += tot;
   }
-  const int nbroad = ncand;  // candidates found (Data.ncollision); the capacity bounds what the narrowphase sees
+  nbroad = ncand;  // candidates found (Data.ncollision); the capacity bounds what the narrowphase sees
   if (ncand > ccap) ncand = ccap;
   gsync();
+  }
   pc.mark(1);
+  if constexpr (MODE == 1) {
+    // ---- k_ccd_broad: publish the candidate list; the convex candidates join the flat list of k_ccd_gjk (slot = rank among the
+    // world's convex candidates; ONE reservation per world)
+    int* cnt = reinterpret_cast<int*>(d.ws_ccd + CL.cnt);
+    int* list = reinterpret_cast<int*>(d.ws_ccd + CL.list);
+    int ncvx = 0;
+    for (int base = 0; base < ncand; base += G) {
+      const int ci = base + lig;
+      bool cvx = false;
+      int p = 0;
+      if (ci < ncand) {
+        p = cand[ci];
+        gcand[ci] = p;
+        const int t1 = m.geom_type[m.nxn_geom_pair[2 * p]], t2 = m.geom_type[m.nxn_geom_pair[2 * p + 1]];
+        cvx = is_ccd_pair(m, min(t1, t2), max(t1, t2));
+      }
+      int tot;
+      const int rank = grank<G>(cvx, lig, tot);
+      if (cvx) cslot[ci] = ncvx + rank;
+      ncvx += tot;
+    }
+    gsync();
+    int base0 = 0;
+    if (lig == 0) {
+      gcand[ccap] = ncand;
+      gcand[ccap + 1] = nbroad;
+      gcand[ccap + 2] = ncvx;
+      base0 = ncvx ? atomicAdd(cnt, ncvx) : 0;
+    }
+    base0 = __shfl(base0, 0, G);
+    if (base0 + ncvx > CL.listcap) {  // the flat list is full: these candidates are dropped (their cache entries say "no contact")
+      if (lig == 0) atomicOr(d.overflow + w, OVF_CCD);
+    }
+    for (int ci = lig; ci < ncand; ci += G) {
+      const int p = cand[ci];
+      const int t1 = m.geom_type[m.nxn_geom_pair[2 * p]], t2 = m.geom_type[m.nxn_geom_pair[2 * p + 1]];
+      if (!is_ccd_pair(m, min(t1, t2), max(t1, t2))) continue;
+      const int slot = cslot[ci];
+      reinterpret_cast<int*>(ccd_world + CL.cache + (size_t)slot * CCD_CACHE_WORDS)[0] = 0;
+      if (base0 + slot < CL.listcap) {
+        int* e = list + 4 * (size_t)(base0 + slot);
+        e[0] = w;
+        e[1] = p;
+        e[2] = slot;
+        e[3] = 0;
+      }
+    }
+    return;
+  }
 
   // ---- narrowphase, pass 1: contacts per candidate and their exclusive prefix (contacts stay in pair order) ----
   auto load_pair = [&](int p, int& g1, int& g2, int& t1, int& t2) {
@@ -1304,7 +1436,8 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
     return adr >= 0 ? m.mesh_graph + adr : nullptr;
   };
   // EPA polytope of this lane (convex.hpp): word k of lane l at k * 32 + l inside the world's slice of d.ws_ccd
-  float* ccd_scratch = (HEAVY && d.ws_ccd) ? d.ws_ccd + (size_t)w * (ccd_words(max(m.ccd_iterations, m.epa_iterations), m.nhfield) + (m.nmeshdegmax > 0 ? ccd_mc_words(m.npolygonmax, m.nmeshdegmax) : 0)) * CCD_LANES + (lig & (CCD_LANES - 1)) : nullptr;
+  float* ccd_scratch = (HEAVY && ccd_world && m.nhfield > 0) ? ccd_world + CL.hf + (lig & (CCD_LANES - 1)) : nullptr;  // height-field prisms only
+  const float* ccd_cache = ccd_world ? ccd_world + CL.cache : nullptr;  // results of k_ccd_gjk / k_ccd_epa, one entry per convex candidate
   const int hf0 = ccd_words(max(m.ccd_iterations, m.epa_iterations), 0);  // first word of the lane's height-field result table
   const float ccd_tol = HEAVY ? bf(m.opt_ccd_tolerance, m.opt_ccd_tolerance_nb, w, 1)[0] : 0.0f;
   const int ccd_it = min(m.ccd_iterations, CCD_MAX_ITER), epa_it = min(m.epa_iterations, CCD_MAX_ITER);
@@ -1337,11 +1470,14 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
     }
   };
   int ncon = 0;
+  int ncvx = 0;  // convex candidates seen so far: the slot of the next one's cached result
   for (int base = 0; base < ncand; base += G) {
     const int ci = base + lig;
     // which of the collider's (at most 8) contacts pass the margin test: pass 2 replays this mask instead of
     // re-testing, so the two passes agree even if the compiler contracts the distance arithmetic differently
     unsigned mask = 0u;
+    bool cvx = false;
+    float cvx_lim = 0.0f;
     if (HEAVY && m.nhfield > 0 && ccd_scratch) hf_coop(ci < ncand && hf_pair(cand[ci]), ci < ncand ? cand[ci] : 0, ci);
     if (ci < ncand) {
       int g1, g2, t1, t2;
@@ -1350,6 +1486,7 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
       const float margin = pid >= 0 ? m.pair_margin[pid] : gmargin[g1] + gmargin[g2];
       const float gap = pid >= 0 ? m.pair_gap[pid] : ggap[g1] + ggap[g2];
       const float lim = margin + gap;
+      cvx_lim = lim;
       auto count = [&](int k, float dist, V3, V3, V3, V3) { mask |= dist < lim ? (1u << (k & 7)) : 0u; };
       const float *mv1, *mv2;
       int mn1, mn2;
@@ -1357,30 +1494,22 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
       mesh_of(g2, t2, mv2, mn2);
       if (HEAVY && t1 == G_HFIELD) {  // (the group filled this lane's table just above; pass 2 reads it again)
         if (t2 >= G_SPHERE && ccd_scratch) hfield_select(ccd_scratch + (size_t)hf0 * CCD_LANES, count);
-      } else if (HEAVY && (is_convex_pair(t1, t2) || (box_ccd && t1 == G_BOX && t2 == G_BOX))) {
-        const int cslot_c = base / G;  // this lane's k-th candidate
-        float* cache = (ccd_scratch && cslot_c < CCD_CACHE_SLOTS) ? ccd_scratch + (size_t)(ccd_cache0 + cslot_c * CCD_CACHE_WORDS) * CCD_LANES : nullptr;
-        int nem = 0;
-        collide_convex(ccd_tol, ccd_it, epa_it, t1, t2, ld3(gxpos + 3 * g1), gxmat + 9 * g1, ld3(gsize + 3 * g1), ld3(gxpos + 3 * g2), gxmat + 9 * g2, ld3(gsize + 3 * g2),
-                       margin, gap, ccd_scratch, ccd_overflow, [&](int k, float dist, V3 pos, V3 fa, V3 fb, V3 fc) {
-                         count(k, dist, pos, fa, fb, fc);
-                         if (cache && k < 4) {
-                           if (k == 0) {
-                             cache[1 * CCD_LANES] = dist;
-                             const float fr[9] = {fa.x, fa.y, fa.z, fb.x, fb.y, fb.z, fc.x, fc.y, fc.z};
-                             for (int q = 0; q < 9; ++q) cache[(2 + q) * CCD_LANES] = fr[q];
-                           }
-                           cache[(11 + 3 * k) * CCD_LANES] = pos.x;
-                           cache[(12 + 3 * k) * CCD_LANES] = pos.y;
-                           cache[(13 + 3 * k) * CCD_LANES] = pos.z;
-                           nem = k + 1;
-                         }
-                       }, mv1, mn1, mv2, mn2, &m, t1 == G_MESH ? m.geom_dataid[g1] : -1, t2 == G_MESH ? m.geom_dataid[g2] : -1);
-        if (cache) reinterpret_cast<int*>(cache)[0] = nem;
+      } else if (HEAVY && is_ccd_pair(m, t1, t2)) {
+        cvx = true;  // (its result was computed by k_ccd_gjk / k_ccd_epa: read below, once the lane knows its slot)
       }
       else
         collide_pair<HEAVY>(t1, t2, ld3(gxpos + 3 * g1), gxmat + 9 * g1, ld3(gsize + 3 * g1), ld3(gxpos + 3 * g2), gxmat + 9 * g2,
                             ld3(gsize + 3 * g2), margin, count, mv2, mn2, graph_of_geom(g2, t2));
+    }
+    if constexpr (HEAVY) if (ccd_cache) {
+      int tot;
+      const int slot = ncvx + grank<G>(cvx, lig, tot);
+      ncvx += tot;
+      if (cvx) {
+        const float* cache = ccd_cache + (size_t)slot * CCD_CACHE_WORDS;
+        const int nem = reinterpret_cast<const int*>(cache)[0];
+        mask = (nem > 0 && cache[1] < cvx_lim) ? (1u << nem) - 1u : 0u;  // (the contacts of a pair share one distance)
+      }
     }
     const int nk = __popc(mask);
     int incl = nk;
@@ -1408,8 +1537,22 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
     }
     gsync();
     pc.mark(3);
+    int ncvx2 = 0;
     for (int base = 0; base < ncand; base += G) {
       const int ci = base + lig;
+      int myslot = -1;  // convex candidates: the slot of the cached result
+      if constexpr (HEAVY) if (ccd_cache) {
+        bool cvx = false;
+        if (ci < ncand) {
+          int g1, g2, t1, t2;
+          load_pair(cand[ci], g1, g2, t1, t2);
+          cvx = is_ccd_pair(m, t1, t2);
+        }
+        int tot;
+        const int rank = grank<G>(cvx, lig, tot);
+        if (cvx) myslot = ncvx2 + rank;
+        ncvx2 += tot;
+      }
       if (HEAVY && m.nhfield > 0 && ccd_scratch) {  // height-field candidates with contacts in this window: the group refills their tables
         bool want = false;
         if (ci < ncand && hf_pair(cand[ci])) {
@@ -1457,24 +1600,11 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
                    };
       if (HEAVY && t1 == G_HFIELD) {
         if (t2 >= G_SPHERE && ccd_scratch) hfield_select(ccd_scratch + (size_t)hf0 * CCD_LANES, write);
-      } else if (HEAVY && (is_convex_pair(t1, t2) || (box_ccd && t1 == G_BOX && t2 == G_BOX))) {
-        const int cslot_c = base / G;
-        if (ccd_scratch && cslot_c < CCD_CACHE_SLOTS) {  // replay the contacts pass 1 found
-          const float* cache = ccd_scratch + (size_t)(ccd_cache0 + cslot_c * CCD_CACHE_WORDS) * CCD_LANES;
+      } else if (HEAVY && is_ccd_pair(m, t1, t2)) {
+        if (myslot >= 0 && ccd_cache) {  // replay the contacts k_ccd_gjk / k_ccd_epa found
+          const float* cache = ccd_cache + (size_t)myslot * CCD_CACHE_WORDS;
           const int nem = reinterpret_cast<const int*>(cache)[0];
-          const float dist = cache[1 * CCD_LANES];
-          float fr[9];
-          for (int q = 0; q < 9; ++q) fr[q] = cache[(2 + q) * CCD_LANES];
-          for (int k = 0; k < nem; ++k)
-            write(k, dist, V3{cache[(11 + 3 * k) * CCD_LANES], cache[(12 + 3 * k) * CCD_LANES], cache[(13 + 3 * k) * CCD_LANES]}, V3{fr[0], fr[1], fr[2]},
-                  V3{fr[3], fr[4], fr[5]}, V3{fr[6], fr[7], fr[8]});
-        } else {
-          const float *mv1, *mv2;
-          int mn1, mn2;
-          mesh_of(g1, t1, mv1, mn1);
-          mesh_of(g2, t2, mv2, mn2);
-          collide_convex(ccd_tol, ccd_it, epa_it, t1, t2, ld3(gxpos + 3 * g1), gxmat + 9 * g1, ld3(gsize + 3 * g1), ld3(gxpos + 3 * g2), gxmat + 9 * g2,
-                         ld3(gsize + 3 * g2), margin, pp.gap, ccd_scratch, ccd_overflow, write, mv1, mn1, mv2, mn2, &m, t1 == G_MESH ? m.geom_dataid[g1] : -1, t2 == G_MESH ? m.geom_dataid[g2] : -1);
+          for (int k = 0; k < nem; ++k) write(k, cache[1], ld3(cache + 11 + 3 * k), ld3(cache + 2), ld3(cache + 5), ld3(cache + 8));
         }
       }
       else {
@@ -1504,115 +1634,153 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
   if (HEAVY && ccd_overflow) atomicOr(d.overflow + w, ccd_overflow);
 }
 
+// ---- the three launches of the convex narrowphase (convex.hpp header) -------------------------------------------------------------------
+__global__ void k_ccd_reset(int* cnt) {
+  if (threadIdx.x < 8) cnt[threadIdx.x] = 0;
+}
+template <int G>
+__global__ void __launch_bounds__(256) k_ccd_broad(MjhModel m, MjhData d) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  collision_body<G, true, 1>(m, d, smem, blk_of_launch<G>());
+}
+// one LANE per entry of the flat convex list: GJK; the result to the candidate's cache entry, penetrating pairs to the EPA list
+__global__ void __launch_bounds__(256) k_ccd_gjk(MjhModel m, MjhData d) {
+  const CcdLayout CL = ccd_layout_of(m, d);
+  int* cnt = reinterpret_cast<int*>(d.ws_ccd + CL.cnt);
+  const int nlist = min(cnt[0], CL.listcap);
+  // (the launch is sized for the device, not for the list's capacity: whole wavefronts walk the list with the grid's stride)
+  for (int t0 = blockIdx.x * blockDim.x; t0 < nlist; t0 += gridDim.x * blockDim.x) {
+  const int t = t0 + threadIdx.x;
+  int st = 0, w = 0, p = 0, slot = 0, idx1 = -1, idx2 = -1;
+  GjkOut res;
+  if (t < nlist) {
+    const int* e = reinterpret_cast<const int*>(d.ws_ccd + CL.list) + 4 * (size_t)t;
+    w = e[0];
+    p = e[1];
+    slot = e[2];
+    int g1 = m.nxn_geom_pair[2 * p], g2 = m.nxn_geom_pair[2 * p + 1];
+    int t1 = m.geom_type[g1], t2 = m.geom_type[g2];
+    if (t1 > t2) {
+      int x = g1; g1 = g2; g2 = x;
+      x = t1; t1 = t2; t2 = x;
+    }
+    const int ng = m.ngeom;
+    const int pid = m.nexplicit ? m.nxn_pairid[p] : -1;
+    const float* gmargin = bf(m.geom_margin, m.geom_margin_nb, w, ng);
+    const float* ggap = bf(m.geom_gap, m.geom_gap_nb, w, ng);
+    const float* gsize = bf(m.geom_size, m.geom_size_nb, w, 3 * ng);
+    const float margin = pid >= 0 ? m.pair_margin[pid] : gmargin[g1] + gmargin[g2];
+    const float gap = pid >= 0 ? m.pair_gap[pid] : ggap[g1] + ggap[g2];
+    const float* gxpos = d.geom_xpos + (size_t)w * 3 * ng;
+    const float* gxmat = d.geom_xmat + (size_t)w * 9 * ng;
+    const float *mv1 = nullptr, *mv2 = nullptr;
+    int mn1 = 0, mn2 = 0, me1 = -1, me2 = -1;
+    if (t1 == G_MESH) { me1 = m.geom_dataid[g1]; mv1 = m.mesh_vert + 3 * m.mesh_vertadr[me1]; mn1 = m.mesh_vertnum[me1]; }
+    if (t2 == G_MESH) { me2 = m.geom_dataid[g2]; mv2 = m.mesh_vert + 3 * m.mesh_vertadr[me2]; mn2 = m.mesh_vertnum[me2]; }
+    float* cache = d.ws_ccd + (size_t)w * CL.world_stride + CL.cache + (size_t)slot * CCD_CACHE_WORDS;
+    int nem = 0;
+    const float ccd_tol = bf(m.opt_ccd_tolerance, m.opt_ccd_tolerance_nb, w, 1)[0];
+    st = convex_gjk_lane(ccd_tol, min(m.ccd_iterations, CCD_MAX_ITER), t1, t2, ld3(gxpos + 3 * g1), gxmat + 9 * g1, ld3(gsize + 3 * g1), ld3(gxpos + 3 * g2), gxmat + 9 * g2,
+                         ld3(gsize + 3 * g2), margin, gap, [&](int k, float dist, V3 pos, V3 fa, V3 fb, V3 fc) { ccd_cache_store(cache, nem, k, dist, pos, fa, fb, fc, true); },
+                         mv1, mn1, mv2, mn2, m, me1, me2, res, idx1, idx2);
+    reinterpret_cast<int*>(cache)[0] = nem;
+  }
+  // penetrating pairs: one reservation per wavefront in the EPA list, then every such lane writes its hand-over record
+  const unsigned long long em = __ballot(st == 2);
+  if (em) {
+    const int lane = threadIdx.x & 63;
+    int base0 = 0;
+    if (lane == __ffsll((long long)em) - 1) base0 = atomicAdd(cnt + 1, __popcll(em));
+    base0 = __shfl(base0, __ffsll((long long)em) - 1, 64);
+    if (st == 2) {
+      const int h = base0 + __popcll(em & ((1ull << lane) - 1ull));
+      if (h < CL.handcap) {
+        float* hand = d.ws_ccd + CL.hand + (size_t)h * CCD_HAND_WORDS;
+        int* hi = reinterpret_cast<int*>(hand);
+        hi[0] = w; hi[1] = p; hi[2] = slot; hi[3] = idx1; hi[4] = idx2; hi[5] = res.dim; hi[6] = res.separated ? 1 : 0;
+        hand[7] = res.dist;
+        st3(hand + 8, res.x1);
+        st3(hand + 11, res.x2);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          st3(hand + 14 + 9 * i, res.s[i]);
+          st3(hand + 17 + 9 * i, res.s1[i]);
+          st3(hand + 20 + 9 * i, res.s2[i]);
+          hi[50 + i] = res.i1[i];
+          hi[54 + i] = res.i2[i];
+        }
+      } else {
+        atomicOr(d.overflow + w, OVF_CCD);  // more penetrating pairs than Data.nccdhand: dropped
+      }
+    }
+  }
+  }
+}
+// one lane GROUP per entry of the EPA list: polytope in the group's LDS, then the multi-contact recovery; lane 0 stores the result
+template <int G>
+__global__ void __launch_bounds__(256) k_ccd_epa(MjhModel m, MjhData d) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const CcdLayout CL = ccd_layout_of(m, d);
+  const int npend = min(reinterpret_cast<const int*>(d.ws_ccd + CL.cnt)[1], CL.handcap);
+  const int lig = threadIdx.x & (G - 1), gib = threadIdx.x / G;
+  const int it = max(m.ccd_iterations, m.epa_iterations);
+  float* poly = smem + (size_t)gib * ccd_coop_words(it);
+  for (int h = blockIdx.x * (blockDim.x / G) + gib; h < npend; h += gridDim.x * (blockDim.x / G)) {
+  const float* hand = d.ws_ccd + CL.hand + (size_t)h * CCD_HAND_WORDS;
+  const int* hi = reinterpret_cast<const int*>(hand);
+  const int w = hi[0], p = hi[1], slot = hi[2], idx1 = hi[3], idx2 = hi[4];
+  GjkOut res;
+  res.dim = hi[5];
+  res.separated = hi[6] != 0;
+  res.dist = hand[7];
+  res.x1 = ld3(hand + 8);
+  res.x2 = ld3(hand + 11);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    res.s[i] = ld3(hand + 14 + 9 * i);
+    res.s1[i] = ld3(hand + 17 + 9 * i);
+    res.s2[i] = ld3(hand + 20 + 9 * i);
+    res.i1[i] = hi[50 + i];
+    res.i2[i] = hi[54 + i];
+  }
+  int g1 = m.nxn_geom_pair[2 * p], g2 = m.nxn_geom_pair[2 * p + 1];
+  int t1 = m.geom_type[g1], t2 = m.geom_type[g2];
+  if (t1 > t2) {
+    int x = g1; g1 = g2; g2 = x;
+    x = t1; t1 = t2; t2 = x;
+  }
+  const int ng = m.ngeom;
+  const int pid = m.nexplicit ? m.nxn_pairid[p] : -1;
+  const float* gmargin = bf(m.geom_margin, m.geom_margin_nb, w, ng);
+  const float* ggap = bf(m.geom_gap, m.geom_gap_nb, w, ng);
+  const float* gsize = bf(m.geom_size, m.geom_size_nb, w, 3 * ng);
+  const float margin = pid >= 0 ? m.pair_margin[pid] : gmargin[g1] + gmargin[g2];
+  const float gap = pid >= 0 ? m.pair_gap[pid] : ggap[g1] + ggap[g2];
+  const float* gxpos = d.geom_xpos + (size_t)w * 3 * ng;
+  const float* gxmat = d.geom_xmat + (size_t)w * 9 * ng;
+  const float *mv1 = nullptr, *mv2 = nullptr;
+  int mn1 = 0, mn2 = 0, me1 = -1, me2 = -1;
+  if (t1 == G_MESH) { me1 = m.geom_dataid[g1]; mv1 = m.mesh_vert + 3 * m.mesh_vertadr[me1]; mn1 = m.mesh_vertnum[me1]; }
+  if (t2 == G_MESH) { me2 = m.geom_dataid[g2]; mv2 = m.mesh_vert + 3 * m.mesh_vertadr[me2]; mn2 = m.mesh_vertnum[me2]; }
+  float* cache = d.ws_ccd + (size_t)w * CL.world_stride + CL.cache + (size_t)slot * CCD_CACHE_WORDS;
+  float* mcws = d.ws_ccd + CL.mc + (size_t)h * CL.mcw;
+  int nem = 0, overflow = 0;
+  const float ccd_tol = bf(m.opt_ccd_tolerance, m.opt_ccd_tolerance_nb, w, 1)[0];
+  convex_epa_group<G>(ccd_tol, min(m.epa_iterations, CCD_MAX_ITER), t1, t2, ld3(gxpos + 3 * g1), gxmat + 9 * g1, ld3(gsize + 3 * g1), ld3(gxpos + 3 * g2), gxmat + 9 * g2, ld3(gsize + 3 * g2),
+                      margin, gap, poly, overflow, [&](int k, float dist, V3 pos, V3 fa, V3 fb, V3 fc) { ccd_cache_store(cache, nem, k, dist, pos, fa, fb, fc, lig == 0); },
+                      mv1, mn1, mv2, mn2, m, me1, me2, res, idx1, idx2, lig, mcws);
+  if (lig == 0) {
+    reinterpret_cast<int*>(cache)[0] = nem;
+    if (overflow) atomicOr(d.overflow + w, overflow);
+  }
+  gsync();
+  }
+}
+
 template <int G, bool HEAVY>
 __global__ void __launch_bounds__(256) k_collision(MjhModel m, MjhData d) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   collision_body<G, HEAVY>(m, d, smem, blk_of_launch<G>());
-}
-
-// ---- publication of the compact public contact arrays (off the critical path) ---------------------------------
-// publish_body: one group per world copies its records to the public SoA arrays (consecutive addresses per array),
-// fills contact.efc_address and the contact rows of efc.id.  Worlds are published in world order, so the public
-// arrays are deterministic (the reference's order depends on atomic arrival).
-// self_prefix: the workgroup first sums ws_ncon over all earlier worlds itself (the counts are L2-resident: 32 KB at
-// 8192 worlds), so that no scan kernel has to run before it; the workgroup of the last world also writes the totals.
-// `sh` needs 64 ints of LDS.
-template <int G>
-DEV void publish_body(const MjhData& d, int self_prefix, int* sh, const Blk& b, const float* pair_solreffriction = nullptr) {
-  if ((int)threadIdx.x >= b.nthreads) return;
-  const int lig = threadIdx.x & (G - 1), gib = threadIdx.x / G;
-  const int w = b.w0 + gib;
-  int adr_self = 0;
-  if (self_prefix) {
-    const int t = threadIdx.x, nwave = (b.nthreads + 63) / 64;
-    const bool last = b.w0 + b.nw >= d.nworld;
-    int s = 0, s2 = 0;
-    {  // 16-byte loads, all in flight before the first add (a dependent scalar loop costs ~0.5 us per trip)
-      const int4* p4 = reinterpret_cast<const int4*>(d.ws_ncon);
-      const int n4 = b.w0 >> 2;
-#pragma unroll 8
-      for (int i = t; i < n4; i += b.nthreads) {
-        const int4 v = p4[i];
-        s += v.x + v.y + v.z + v.w;
-      }
-      for (int i = (n4 << 2) + t; i < b.w0; i += b.nthreads) s += d.ws_ncon[i];
-    }
-    if (last) {
-      const int4* p4 = reinterpret_cast<const int4*>(d.ws_ncollision);
-      const int n4 = d.nworld >> 2;
-#pragma unroll 8
-      for (int i = t; i < n4; i += b.nthreads) {
-        const int4 v = p4[i];
-        s2 += v.x + v.y + v.z + v.w;
-      }
-      for (int i = (n4 << 2) + t; i < d.nworld; i += b.nthreads) s2 += d.ws_ncollision[i];
-    }
-    for (int off = 32; off > 0; off >>= 1) {
-      s += __shfl_xor(s, off, 64);
-      s2 += __shfl_xor(s2, off, 64);
-    }
-    if ((t & 63) == 0) {
-      sh[t >> 6] = s;
-      sh[16 + (t >> 6)] = s2;
-    }
-    __syncthreads();
-    int base = 0, tot2 = 0;
-    for (int k = 0; k < nwave; ++k) {
-      base += sh[k];
-      tot2 += sh[16 + k];
-    }
-    if (w < d.nworld) {
-      // exclusive prefix inside the workgroup: worlds of a workgroup are consecutive
-      int adr = base;
-      for (int i = b.w0; i < w; ++i) adr += d.ws_ncon[i];
-      adr_self = adr;
-      if (lig == 0) d.ws_conadr[w] = adr;
-      if (last && w == d.nworld - 1 && lig == 0) {
-        d.nacon[0] = adr + d.ws_ncon[w];
-        d.ncollision[0] = tot2;
-      }
-    }
-  }
-  if (w >= d.nworld) return;
-  const int ncon = d.ws_ncon[w], adr = self_prefix ? adr_self : d.ws_conadr[w], njmax = d.njmax, npyr = d.nmaxpyramid;
-  int n = ncon;
-  if (adr + n > d.naconmax) n = max(0, d.naconmax - adr);
-  if (n < ncon && lig == 0) atomicOr(d.overflow + w, OVF_NARROWPHASE);
-  const float* rec = d.ws_contact + (size_t)w * d.concap * CON_STRIDE;
-  const int* reci = reinterpret_cast<const int*>(rec);
-  const size_t o0 = (size_t)adr;
-  for (int c = lig; c < n; c += G) {  // one contact per lane: the scalar-per-contact arrays
-    const float* r = rec + c * CON_STRIDE;
-    const int* ri = reci + c * CON_STRIDE;
-    const size_t o = o0 + c;
-    d.contact_dist[o] = r[0];
-    d.contact_includemargin[o] = r[13];
-    *reinterpret_cast<float2*>(d.contact_solref + 2 * o) = float2{r[17], r[18]};
-    {  // only explicit <contact><pair> entries carry a solreffriction (collision_core.py contact_params)
-      const int pid = (ri[27] >> 8) - 1;
-      *reinterpret_cast<float2*>(d.contact_solreffriction + 2 * o) = (pid >= 0 && pair_solreffriction) ? float2{pair_solreffriction[2 * pid], pair_solreffriction[2 * pid + 1]} : float2{0.0f, 0.0f};
-    }
-    d.contact_dim[o] = ri[24];
-    *reinterpret_cast<int2*>(d.contact_geom + 2 * o) = int2{ri[25], ri[26]};
-    d.contact_worldid[o] = w;
-    d.contact_type[o] = CONTACT_TYPE_CONSTRAINT;
-    d.contact_geomcollisionid[o] = ri[27] & 255;
-    const int rbase = ri[28], ndim = ri[29];
-    for (int k = 0; k < ndim; ++k)
-      if (rbase >= 0 && rbase + k < njmax) d.efc_id[(size_t)w * njmax + rbase + k] = adr + c;
-  }
-  for (int idx = lig; idx < 3 * n; idx += G) d.contact_pos[3 * o0 + idx] = rec[(idx / 3) * CON_STRIDE + 1 + idx % 3];
-  for (int idx = lig; idx < 9 * n; idx += G) d.contact_frame[9 * o0 + idx] = rec[(idx / 9) * CON_STRIDE + 4 + idx % 9];
-  for (int idx = lig; idx < 5 * n; idx += G) {
-    const int q = idx % 5;
-    d.contact_friction[5 * o0 + idx] = rec[(idx / 5) * CON_STRIDE + CON_FRICTION_WORD(q)];
-    d.contact_solimp[5 * o0 + idx] = rec[(idx / 5) * CON_STRIDE + 19 + q];
-  }
-  for (int idx = lig; idx < npyr * n; idx += G) {
-    const int c = idx / npyr, k = idx % npyr;
-    const int rbase = reci[c * CON_STRIDE + 28], ndim = reci[c * CON_STRIDE + 29];
-    d.contact_efc_address[npyr * o0 + idx] = (rbase >= 0 && k < ndim && rbase + k < njmax) ? rbase + k : -1;
-  }
 }
 
 template <int G>

@@ -41,6 +41,58 @@ __host__ __device__ inline int ccd_poly_words(int iterations) {
 __host__ __device__ inline int ccd_words(int iterations, int hfield = 0) {
   return ccd_poly_words(iterations) + CCD_CACHE_SLOTS * CCD_CACHE_WORDS + (hfield ? CCD_HF_WORDS : 0);
 }
+// Round 4: the convex narrowphase as THREE LAUNCHES in front of the contact kernel (models with GJK pairs; csrc/collide.hpp).
+//   k_ccd_broad   one lane group per world: the broadphase (unchanged code), candidate list to the world's slice of Data.ws_ccd; the
+//                 convex candidates of all worlds go to ONE flat list (one reservation per world)
+//   k_ccd_gjk     one LANE per list entry, nothing but registers: GJK.  Its cost is the chain of dependent table loads of the support
+//                 function (hill climbing on a mesh graph: edge list -> vertex id -> vertex), which only concurrency hides -- as one
+//                 role of the heavy contact kernel (509 VGPRs, one wavefront per SIMD) every round trip stalled the SIMD.  Results
+//                 (separated / one shallow contact) go to the candidate's cache entry; penetrating pairs append their simplex to the
+//                 EPA list (one reservation per wavefront)
+//   k_ccd_epa     one lane GROUP per EPA entry: the polytope in ONE copy in the group's LDS (a lane used to walk its slice of global
+//                 memory at one round trip per face: 2 scans x 181 faces x 35 iterations), the nearest-face and visible-face scans and
+//                 the attachment of the horizon's faces spread over the lanes, the mesh support function spreading the neighbours of a
+//                 hill-climbing step over the lanes, the rest redundantly in every lane (uniform control flow, broadcast loads); then
+//                 the multi-contact recovery.  Arg-max / arg-min ties go to the smallest index like the serial loops: results are
+//                 identical to the one-lane code (the 17 reference-held GJK poses stay digit for digit).
+// The contact kernel (k_mid / k_collision) then only replays the cached results (count | distance | frame | up to four positions) in
+// its two passes.  (A first cut that ran whole pairs cooperatively inside the contact kernel, one after the other, was 30 % SLOWER on the
+// ALOHA scene: it serialised the GJK chains that the lanes had at least run side by side.)
+//
+// Layout of Data.ws_ccd (floats; csrc/collide.hpp and io.py size it with ccd_layout):
+//   per world  [hf]     per-lane polytope + result table of the height-field prisms, interleaved by lane (models with height fields)
+//              [cache]  ccap x CCD_CACHE_WORDS: one entry per convex candidate, slot = its rank among the world's convex candidates
+//              [cand]   ccap + 4 ints: the world's candidate pairs in canonical order | ncand, nbroad, nconvex
+//   tail       [cnt]    8 ints: list entries, EPA entries (zeroed by a memset node in front of k_ccd_broad)
+//              [list]   listcap x 4 ints: world, pair, slot, -
+//              [hand]   handcap x CCD_HAND_WORDS: list entry | vertex caches | the GJK simplex, for the EPA launch
+//              [mc]     handcap x ccd_mc_words: multi-contact buffers of the EPA groups (stride 1)
+#define CCD_HAND_WORDS 64
+struct CcdLayout {
+  size_t world_stride;  // floats per world
+  size_t hf, cache, cand;  // offsets inside a world's slice
+  size_t tail, cnt, list, hand, mc, total;  // offsets from the start of ws_ccd
+  int ccap, listcap, handcap, mcw;
+};
+__host__ __device__ inline CcdLayout ccd_layout(int nworld, int iterations, int nhfield, int npolygonmax, int nmeshdegmax, int ccap, int handcap) {
+  CcdLayout L;
+  L.ccap = ccap;
+  L.hf = 0;
+  L.cache = nhfield ? (size_t)(ccd_poly_words(iterations) + CCD_CACHE_SLOTS * CCD_CACHE_WORDS + CCD_HF_WORDS) * CCD_LANES : 0;
+  L.cand = L.cache + (size_t)ccap * CCD_CACHE_WORDS;
+  L.world_stride = ((L.cand + ccap + 4 + 3) / 4) * 4;
+  L.tail = L.world_stride * (size_t)nworld;
+  L.cnt = L.tail;
+  L.listcap = nworld * ccap;  // (every candidate of every world may be convex)
+  L.list = L.cnt + 8;
+  L.handcap = handcap;
+  L.hand = L.list + (size_t)L.listcap * 4;
+  L.mcw = nmeshdegmax > 0 ? 11 * (nmeshdegmax > 3 ? nmeshdegmax : 3) + 22 * (npolygonmax > 4 ? npolygonmax : 4) : 0;
+  L.mc = L.hand + (size_t)handcap * CCD_HAND_WORDS;
+  L.total = L.mc + (size_t)handcap * L.mcw;
+  return L;
+}
+__host__ __device__ inline int ccd_coop_words(int iterations) { return ((ccd_poly_words(iterations) + 3) / 4) * 4; }
 // (models with multi-contact recovery on mesh faces append ccd_mc_words(npolygonmax, nmeshdegmax) words per lane: further below)
 
 struct CcdGeom {
@@ -142,6 +194,78 @@ DEV V3 ccd_support(const CcdGeom& g, V3 dir, int& vid) {
   V3 out = mat_mul(g.rot, r) + g.pos;
   if (g.margin > 0.0f) out = out + dir * (0.5f * g.margin);
   return out;
+}
+
+// group-wide arg-max helpers (every lane receives the result)
+template <int G>
+DEV float gminf(float v) {
+#pragma unroll
+  for (int off = G / 2; off >= 1; off >>= 1) v = fminf(v, __shfl_xor(v, off, G));
+  return v;
+}
+template <int G>
+DEV int gmini(int v) {
+#pragma unroll
+  for (int off = G / 2; off >= 1; off >>= 1) v = min(v, __shfl_xor(v, off, G));
+  return v;
+}
+// ccd_support by the G lanes of a group together (all lanes pass the same arguments and receive the same result).  Meshes: the
+// neighbours of a hill-climbing step / the vertices of an exhaustive search are spread over the lanes; the serial loops take the FIRST
+// index that attains the maximum (strict >), the cached vertex winning ties, and so does this.  Other shapes: closed forms, redundantly.
+template <int G>
+DEV V3 ccd_support_c(const CcdGeom& g, V3 dir, int& vid, int lig) {
+  if (g.type != G_MESH) return ccd_support(g, dir, vid);
+  const V3 l = matT_mul(g.rot, dir);
+  if (!g.graph || g.nvert < 10) {
+    float best = -CCD_FLOAT_MAX;
+    int bi = 0x7fffffff;
+    for (int i = lig; i < g.nvert; i += G) {
+      const float dd = dot(ld3(g.vert + 3 * i), l);
+      if (dd > best) {
+        best = dd;
+        bi = i;
+      }
+    }
+    const float top = gmax<G>(best);
+    vid = gmini<G>(best == top ? bi : 0x7fffffff);
+    if (g.index > -1 && dot(ld3(g.vert + 3 * g.index), l) >= top) vid = g.index;
+    const_cast<CcdGeom&>(g).cache = vid;
+  } else {
+    const int numvert = g.graph[0], nedge = numvert + 3 * g.graph[1];
+    const int *edgeadr = g.graph + 2, *globalid = g.graph + 2 + numvert, *edge = g.graph + 2 + 2 * numvert;
+    int prev = -1, imax = g.index > -1 ? g.index : 0;
+    float best = dot(l, ld3(g.vert + 3 * globalid[imax]));
+    while (imax != prev) {
+      prev = imax;
+      const int e0 = edgeadr[imax], deg = (imax + 1 < numvert ? edgeadr[imax + 1] : nedge) - e0 - 1;  // (each list ends with -1)
+      for (int j0 = 0; j0 < deg; j0 += G) {
+        const int j = j0 + lig;
+        int nb = 0;
+        float dd = -CCD_FLOAT_MAX;
+        if (j < deg) {
+          nb = edge[e0 + j];
+          dd = dot(l, ld3(g.vert + 3 * globalid[nb]));
+        }
+        const float top = gmax<G>(dd);
+        if (top > best) {  // the first neighbour that attains the chunk's maximum (the serial scan keeps the first of equals)
+          const unsigned long long hit = gballot<G>(j < deg && dd == top);
+          best = top;
+          imax = __shfl(nb, __ffsll((long long)hit) - 1, G);
+        }
+      }
+    }
+    const_cast<CcdGeom&>(g).cache = imax;
+    vid = globalid[imax];
+  }
+  V3 out = mat_mul(g.rot, ld3(g.vert + 3 * vid)) + g.pos;
+  if (g.margin > 0.0f) out = out + dir * (0.5f * g.margin);
+  return out;
+}
+// CG = 0: the one-lane code; CG = lanes of the cooperating group
+template <int CG>
+DEV V3 ccd_sup(const CcdGeom& g, V3 dir, int& vid, int lig) {
+  if constexpr (CG > 0) return ccd_support_c<CG>(g, dir, vid, lig);
+  else return ccd_support(g, dir, vid);
 }
 
 DEV float ccd_det3(V3 a, V3 b, V3 c) { return dot(a, cross(b, c)); }
@@ -277,8 +401,9 @@ DEV V3 ccd_combine(int n, const float (&lam)[4], const V3 (&m)[4]) {
   return o;
 }
 
+template <int CG = 0>
 DEV void ccd_gjk(float tolerance, int iterations, const CcdGeom& g1, const CcdGeom& g2, V3 x1_0, V3 x2_0, float cutoff, bool is_discrete,
-                 GjkOut& res) {
+                 GjkOut& res, int lig = 0) {
   int n = 0;
   float lam[4] = {1.0f, 0.0f, 0.0f, 0.0f};
   const float epsilon = is_discrete ? 0.0f : 0.5f * tolerance * tolerance, min_norm = is_discrete ? CCD_MINVAL : tolerance;
@@ -312,7 +437,7 @@ DEV void ccd_gjk(float tolerance, int iterations, const CcdGeom& g1, const CcdGe
       }
     }
     int v1, v2;
-    const V3 p1 = ccd_support(g1, -dneg, v1), p2 = ccd_support(g2, dneg, v2);
+    const V3 p1 = ccd_sup<CG>(g1, -dneg, v1, lig), p2 = ccd_sup<CG>(g2, dneg, v2, lig);
     const_cast<CcdGeom&>(g1).index = g1.cache;  // collision_gjk.py:675-680 (only meshes read it)
     const_cast<CcdGeom&>(g2).index = g2.cache;
     const V3 sn = p1 - p2;
@@ -370,7 +495,7 @@ DEV void ccd_gjk(float tolerance, int iterations, const CcdGeom& g1, const CcdGe
   if (xnorm > 0.0f) {
     const V3 dir = xk * (1.0f / xnorm);
     int v;
-    const V3 p1 = ccd_support(g1, -dir, v), p2 = ccd_support(g2, dir, v);
+    const V3 p1 = ccd_sup<CG>(g1, -dir, v, lig), p2 = ccd_sup<CG>(g2, dir, v, lig);
     res.separated = dot(xk, p1 - p2) > 0.0f;
   }
   res.dist = (n == 4 && !res.separated) ? 0.0f : xnorm;
@@ -390,11 +515,12 @@ DEV void ccd_gjk(float tolerance, int iterations, const CcdGeom& g1, const CcdGe
 // ---- EPA polytope in the lane-interleaved workspace ------------------------------------------------------------------------------
 struct Poly {
   float* base;  // word 0 of this lane
+  int stride;   // words between consecutive entries: CCD_LANES in the lane-interleaved global workspace, 1 in the cooperative LDS copy
   int vcap, fcap, o_vidx, o_face, o_fpr, o_fn2, o_hor;
   int status, nvert, nface, nhorizon;
   V3 center;
-  DEV float& F(int k) const { return base[(size_t)k * CCD_LANES]; }
-  DEV int& I(int k) const { return reinterpret_cast<int*>(base)[(size_t)k * CCD_LANES]; }
+  DEV float& F(int k) const { return base[(size_t)k * stride]; }
+  DEV int& I(int k) const { return reinterpret_cast<int*>(base)[(size_t)k * stride]; }
   DEV V3 vert(int i) const { return V3{F(3 * i), F(3 * i + 1), F(3 * i + 2)}; }  // vertex pair v: 2v on geom 1, 2v + 1 on geom 2
   DEV void set_vert(int i, V3 p) const { F(3 * i) = p.x; F(3 * i + 1) = p.y; F(3 * i + 2) = p.z; }
   DEV V3 diff(int v) const { return vert(2 * v) - vert(2 * v + 1); }
@@ -404,8 +530,9 @@ struct Poly {
   DEV float& fn2(int f) const { return F(o_fn2 + f); }
   DEV int& hor(int i) const { return I(o_hor + i); }
 };
-DEV void poly_init(Poly& pt, float* base, int iterations) {
+DEV void poly_init(Poly& pt, float* base, int iterations, int stride = CCD_LANES) {
   pt.base = base;
+  pt.stride = stride;
   pt.vcap = 5 + iterations;
   pt.fcap = 6 + CCD_EPAFACES * iterations;
   pt.o_vidx = 6 * pt.vcap;
@@ -416,8 +543,12 @@ DEV void poly_init(Poly& pt, float* base, int iterations) {
   pt.status = pt.nvert = pt.nface = pt.nhorizon = 0;
   pt.center = V3{0.0f, 0.0f, 0.0f};
 }
+DEV float poly_attach_face_at(Poly& pt, int idx, int v1, int v2, int v3_);
 DEV float poly_attach_face(Poly& pt, int idx, int v1, int v2, int v3_) {
   if (pt.nface == pt.fcap) return 0.0f;
+  return poly_attach_face_at(pt, idx, v1, v2, v3_);
+}
+DEV float poly_attach_face_at(Poly& pt, int idx, int v1, int v2, int v3_) {  // (no capacity check: the caller owns slot idx)
   const V3 p1 = pt.diff(v1), p2 = pt.diff(v2), p3 = pt.diff(v3_);
   V3 r;
   if (ccd_origin_on_plane(p3, p2, p1, r)) return 0.0f;
@@ -430,10 +561,11 @@ DEV float poly_attach_face(Poly& pt, int idx, int v1, int v2, int v3_) {
   pt.fn2(idx) = n2;
   return n2;
 }
-DEV void poly_support(Poly& pt, int idx, const CcdGeom& g1, const CcdGeom& g2, V3 dir) {
+template <int CG = 0>
+DEV void poly_support(Poly& pt, int idx, const CcdGeom& g1, const CcdGeom& g2, V3 dir, int lig = 0) {
   int v1, v2;
-  pt.set_vert(2 * idx, ccd_support(g1, dir, v1));
-  pt.set_vert(2 * idx + 1, ccd_support(g2, -dir, v2));
+  pt.set_vert(2 * idx, ccd_sup<CG>(g1, dir, v1, lig));
+  pt.set_vert(2 * idx + 1, ccd_sup<CG>(g2, -dir, v2, lig));
   pt.vidx(2 * idx) = v1;
   pt.vidx(2 * idx + 1) = v2;
 }
@@ -485,7 +617,8 @@ DEV int ccd_ray_triangle(V3 v1, V3 v2, V3 v3_, V3 v4, V3 v5) {
 }
 
 // seed polytopes from GJK's 1-, 2-, 3-simplex; status 0: ready, -1: continue from the 2-simplex written into res, > 0: no depth
-DEV void poly_seed2(Poly& pt, GjkOut& res, const CcdGeom& g1, const CcdGeom& g2) {
+template <int CG = 0>
+DEV void poly_seed2(Poly& pt, GjkOut& res, const CcdGeom& g1, const CcdGeom& g2, int lig = 0) {
   const V3 df = res.s[1] - res.s[0];
   pt.center = 0.5f * (res.s[0] + res.s[1]);
   int index = 0;
@@ -501,9 +634,9 @@ DEV void poly_seed2(Poly& pt, GjkOut& res, const CcdGeom& g1, const CcdGeom& g2)
   const V3 d2 = mat_mul(R, d1), d3 = mat_mul(R, d2);
   poly_put(pt, 0, res, 0);
   poly_put(pt, 1, res, 1);
-  poly_support(pt, 2, g1, g2, d1 * (1.0f / length(d1)));
-  poly_support(pt, 3, g1, g2, d2 * (1.0f / length(d2)));
-  poly_support(pt, 4, g1, g2, d3 * (1.0f / length(d3)));
+  poly_support<CG>(pt, 2, g1, g2, d1 * (1.0f / length(d1)), lig);
+  poly_support<CG>(pt, 3, g1, g2, d2 * (1.0f / length(d2)), lig);
+  poly_support<CG>(pt, 4, g1, g2, d3 * (1.0f / length(d3)), lig);
   const int Fc[6][3] = {{0, 2, 3}, {0, 4, 2}, {0, 3, 4}, {1, 3, 2}, {1, 2, 4}, {1, 4, 3}};
   for (int f = 0; f < 6; ++f)
     if (poly_attach_face(pt, f, Fc[f][0], Fc[f][1], Fc[f][2]) < CCD_MIN_DIST2) {
@@ -519,7 +652,8 @@ DEV void poly_seed2(Poly& pt, GjkOut& res, const CcdGeom& g1, const CcdGeom& g2)
   pt.nface = 6;
   pt.status = 0;
 }
-DEV void poly_seed3(Poly& pt, const GjkOut& res, const CcdGeom& g1, const CcdGeom& g2) {
+template <int CG = 0>
+DEV void poly_seed3(Poly& pt, const GjkOut& res, const CcdGeom& g1, const CcdGeom& g2, int lig = 0) {
   pt.center = (res.s[0] + res.s[1] + res.s[2]) * (1.0f / 3.0f);
   V3 n = cross(res.s[1] - res.s[0], res.s[2] - res.s[0]);
   const float norm = length(n);
@@ -528,8 +662,8 @@ DEV void poly_seed3(Poly& pt, const GjkOut& res, const CcdGeom& g1, const CcdGeo
   poly_put(pt, 0, res, 0);
   poly_put(pt, 1, res, 1);
   poly_put(pt, 2, res, 2);
-  poly_support(pt, 3, g1, g2, -n);
-  poly_support(pt, 4, g1, g2, n);
+  poly_support<CG>(pt, 3, g1, g2, -n, lig);
+  poly_support<CG>(pt, 4, g1, g2, n, lig);
   const V3 v4 = pt.diff(3), v5 = pt.diff(4);
   if (ccd_tri_point_intersect(res.s[0], res.s[1], res.s[2], v4)) { pt.status = 3; return; }
   if (ccd_tri_point_intersect(res.s[0], res.s[1], res.s[2], v5)) { pt.status = 4; return; }
@@ -595,8 +729,10 @@ DEV void poly_delete_face(Poly& pt, int f) {
   pt.nhorizon = poly_add_edge(pt, (fc >> 20) & 0x3FF, fc & 0x3FF);
 }
 // returns the closest face (-1: no contact); dist <= 0 and the witness points of the penetration
+template <int CG = 0>
 DEV int ccd_epa(float tolerance, int iterations, Poly& pt, const CcdGeom& g1, const CcdGeom& g2, bool is_discrete, int& overflow, float& dist,
-                V3& x1, V3& x2) {
+                V3& x1, V3& x2, int lig = 0) {
+  static_assert(CG == 0 || CG >= CCD_MAX_HORIZON, "the horizon's faces are attached by one lane each");
   float upper = CCD_FLOAT_MAX, upper2 = CCD_FLOAT_MAX;
   const float epsilon = is_discrete ? CCD_MIN_EPATOL : tolerance;
   int idx = -1, nvalid = pt.nface;
@@ -604,12 +740,27 @@ DEV int ccd_epa(float tolerance, int iterations, Poly& pt, const CcdGeom& g1, co
     const int pidx = idx;
     idx = -1;
     float lower2 = CCD_FLOAT_MAX;
+    if constexpr (CG > 0) {  // nearest live face: lane-strided scan, then the smallest index among the lanes that hold the minimum
+      int bi = 0x7fffffff;
+      for (int i = lig; i < pt.nface; i += CG) {
+        const float n2 = pt.fn2(i);
+        if (!((unsigned)pt.face(i) & (CCD_FACE_DELETED | CCD_FACE_INVALID)) && n2 < lower2) {
+          bi = i;
+          lower2 = n2;
+        }
+      }
+      const float low = gminf<CG>(lower2);
+      const int first = gmini<CG>(lower2 == low ? bi : 0x7fffffff);
+      lower2 = low;
+      idx = first == 0x7fffffff ? -1 : first;
+    } else {
     for (int i = 0; i < pt.nface; ++i) {
       const float n2 = pt.fn2(i);
       if (!((unsigned)pt.face(i) & (CCD_FACE_DELETED | CCD_FACE_INVALID)) && n2 < lower2) {
         idx = i;
         lower2 = n2;
       }
+    }
     }
     if (lower2 > upper2 || idx < 0) {
       idx = pidx;
@@ -619,7 +770,7 @@ DEV int ccd_epa(float tolerance, int iterations, Poly& pt, const CcdGeom& g1, co
     const float lower = sqrtf(lower2);
     const int wi = pt.nvert;
     const V3 fpr = pt.fpr(idx);
-    poly_support(pt, wi, g1, g2, fpr * (1.0f / lower));
+    poly_support<CG>(pt, wi, g1, g2, fpr * (1.0f / lower), lig);
     const_cast<CcdGeom&>(g1).index = g1.cache;  // collision_gjk.py:1370-1373
     const_cast<CcdGeom&>(g2).index = g2.cache;
     const V3 w = pt.diff(wi);
@@ -643,6 +794,45 @@ DEV int ccd_epa(float tolerance, int iterations, Poly& pt, const CcdGeom& g1, co
       idx = -1;
       break;
     }
+    if constexpr (CG > 0) {
+      // faces visible from the new vertex: the test is spread over the lanes, the deletions (horizon edges toggle in a 24-entry list)
+      // follow in ascending face order like the serial scan
+      gsync();
+      for (int i0 = 0; i0 < pt.nface && idx != -1; i0 += CG) {
+        const int i = i0 + lig;
+        bool vis = false;
+        if (i < pt.nface && !((unsigned)pt.face(i) & CCD_FACE_DELETED)) vis = dot(pt.fpr(i), w) - pt.fn2(i) > 1e-10f;
+        unsigned long long vm = gballot<CG>(vis);
+        while (vm) {
+          const int f = i0 + __ffsll((long long)vm) - 1;
+          vm &= vm - 1;
+          if (!((unsigned)pt.face(f) & CCD_FACE_INVALID)) nvalid--;
+          poly_delete_face(pt, f);
+          if (pt.nhorizon == -1) {
+            overflow |= OVF_EPA_HORIZON;
+            idx = -1;
+            break;
+          }
+        }
+      }
+      // one lane per horizon edge attaches its face (slot nface + lane); the serial loop stops at the first degenerate face
+      const int nh = pt.nhorizon;
+      gsync();
+      float d2 = 1.0f;
+      const bool has = lig < nh;
+      if (has) {
+        const int e = pt.hor(lig);
+        d2 = pt.nface + lig < pt.fcap ? poly_attach_face_at(pt, pt.nface + lig, wi, e & 0x3FF, (e >> 10) & 0x3FF) : 0.0f;
+      }
+      const unsigned long long zm = gballot<CG>(has && d2 == 0.0f);
+      const int nadd = nh <= 0 ? 0 : (zm ? __ffsll((long long)zm) - 1 : nh);
+      const bool live = has && lig < nadd, ok = live && d2 >= lower2 && d2 <= upper2;
+      if (live && !ok) pt.face(pt.nface + lig) = (int)((unsigned)pt.face(pt.nface + lig) | CCD_FACE_INVALID);
+      nvalid += __popcll(gballot<CG>(ok));
+      pt.nface += nadd;
+      if (zm) idx = -1;
+      gsync();
+    } else {
     for (int i = 0; i < pt.nface; ++i) {
       const unsigned fc = (unsigned)pt.face(i);
       if (fc & CCD_FACE_DELETED) continue;
@@ -667,6 +857,7 @@ DEV int ccd_epa(float tolerance, int iterations, Poly& pt, const CcdGeom& g1, co
       if (d2 >= lower2 && d2 <= upper2) nvalid++;
       else pt.face(pt.nface - 1) = (int)((unsigned)pt.face(pt.nface - 1) | CCD_FACE_INVALID);
     }
+    }
     if (nvalid == 0 || idx == -1) break;
     pt.nhorizon = 0;
   }
@@ -685,13 +876,18 @@ DEV int ccd_epa(float tolerance, int iterations, Poly& pt, const CcdGeom& g1, co
 
 // gjk_phase + epa_phase: number of contacts (0 / 1), distance between the margin-inflated shapes and the witness points
 // face_out: the closest EPA face when the pair qualifies for multi-contact recovery (two boxes, zero margin), else -1
-DEV int ccd_run(float tolerance, float cutoff, int gjk_iterations, int epa_iterations, CcdGeom g1, CcdGeom g2, float* scratch, float& dist_out,
-                V3& x1, V3& x2, int& overflow, int& face_out, Poly& pt) {
+// collision_gjk.py:109 _discrete_geoms
+DEV bool ccd_is_discrete(const CcdGeom& g1, const CcdGeom& g2) {
+  return (g1.type == G_BOX || g1.type == G_MESH || g1.type == G_HFIELD) && (g2.type == G_BOX || g2.type == G_MESH || g2.type == G_HFIELD) && g1.margin == 0.0f && g2.margin == 0.0f;
+}
+// gjk_phase (collision_gjk.py:2350-2418).  Returns 1: done -- dist_out / x1 / x2 are the result (CCD_FLOAT_MAX: separated) --, 2: the
+// pair penetrates and EPA must run from the simplex in `res`; g1 / g2 leave with their margins and sizes restored and the mesh vertex
+// caches (`index`) of the last support calls: the state epa_phase continues from.
+template <int CG = 0>
+DEV int ccd_gjk_phase(float tolerance, float cutoff, int gjk_iterations, CcdGeom& g1, CcdGeom& g2, float& dist_out, V3& x1, V3& x2, GjkOut& res, int lig = 0) {
   const CcdGeom o1 = g1, o2 = g2;
-  face_out = -1;
   float full1 = 0.0f, full2 = 0.0f, size1 = 0.0f, size2 = 0.0f;
-  const bool is_discrete = (g1.type == G_BOX || g1.type == G_MESH || g1.type == G_HFIELD) && (g2.type == G_BOX || g2.type == G_MESH || g2.type == G_HFIELD) && g1.margin == 0.0f && g2.margin == 0.0f;  // collision_gjk.py:109
-  GjkOut res;
+  const bool is_discrete = ccd_is_discrete(g1, g2);
   if (g1.type == G_SPHERE || g1.type == G_CAPSULE) {
     size1 = g1.size.x;
     full1 = size1 + 0.5f * g1.margin;
@@ -706,7 +902,7 @@ DEV int ccd_run(float tolerance, float cutoff, int gjk_iterations, int epa_itera
   }
   if (size1 + size2 > 0.0f) {
     cutoff += full1 + full2;
-    ccd_gjk(tolerance, gjk_iterations, g1, g2, g1.pos, g2.pos, cutoff, is_discrete, res);
+    ccd_gjk<CG>(tolerance, gjk_iterations, g1, g2, g1.pos, g2.pos, cutoff, is_discrete, res, lig);
     if (res.dist > tolerance) {
       dist_out = res.dist;
       x1 = res.x1;
@@ -724,21 +920,31 @@ DEV int ccd_run(float tolerance, float cutoff, int gjk_iterations, int epa_itera
     g2.size = o2.size;
     cutoff -= full1 + full2;
   }
-  ccd_gjk(tolerance, gjk_iterations, g1, g2, g1.pos, g2.pos, cutoff, is_discrete, res);
+  ccd_gjk<CG>(tolerance, gjk_iterations, g1, g2, g1.pos, g2.pos, cutoff, is_discrete, res, lig);
   dist_out = res.dist;
   x1 = res.x1;
   x2 = res.x2;
   if (res.dist > tolerance || res.dim < 2 || res.separated) return 1;
-  poly_init(pt, scratch, epa_iterations);
-  if (res.dim == 2) poly_seed2(pt, res, g1, g2);
+  return 2;
+}
+// epa_phase (collision_gjk.py:2421-2526) from the state ccd_gjk_phase left (g1, g2, res; dist_out / x1 / x2 hold GJK's result and are
+// returned unchanged when the polytope cannot be seeded).  Returns the number of contacts (0 / 1); face_out: the closest EPA face when
+// the pair qualifies for multi-contact recovery, else -1.  CG > 0: by the CG lanes of a group together (polytope stride 1 in LDS).
+template <int CG = 0>
+DEV int ccd_epa_phase(float tolerance, int epa_iterations, const CcdGeom& g1, const CcdGeom& g2, GjkOut& res, float* scratch, float& dist_out, V3& x1, V3& x2,
+                      int& overflow, int& face_out, Poly& pt, int lig = 0, int pstride = CCD_LANES) {
+  face_out = -1;
+  const bool is_discrete = ccd_is_discrete(g1, g2);
+  poly_init(pt, scratch, epa_iterations, pstride);
+  if (res.dim == 2) poly_seed2<CG>(pt, res, g1, g2, lig);
   else if (res.dim == 4) poly_seed4(pt, res);
   if (res.dim == 3) {
     pt.status = 0;
-    poly_seed3(pt, res, g1, g2);
+    poly_seed3<CG>(pt, res, g1, g2, lig);
   }
   if (pt.status) return 1;
   float dist;
-  const int idx = ccd_epa(tolerance, epa_iterations, pt, g1, g2, is_discrete, overflow, dist, x1, x2);
+  const int idx = ccd_epa<CG>(tolerance, epa_iterations, pt, g1, g2, is_discrete, overflow, dist, x1, x2, lig);
   if (idx == -1) {
     dist_out = CCD_FLOAT_MAX;
     return 0;
@@ -746,6 +952,14 @@ DEV int ccd_run(float tolerance, float cutoff, int gjk_iterations, int epa_itera
   dist_out = dist;
   if (g1.margin == 0.0f && g2.margin == 0.0f && (g1.type == G_BOX || g1.type == G_MESH) && (g2.type == G_BOX || g2.type == G_MESH)) face_out = idx;  // collision_gjk.py:2517-2523
   return 1;
+}
+// gjk_phase + epa_phase by one lane (the height-field prisms; every pair before round 4)
+DEV int ccd_run(float tolerance, float cutoff, int gjk_iterations, int epa_iterations, CcdGeom g1, CcdGeom g2, float* scratch, float& dist_out,
+                V3& x1, V3& x2, int& overflow, int& face_out, Poly& pt) {
+  face_out = -1;
+  GjkOut res;
+  if (ccd_gjk_phase(tolerance, cutoff, gjk_iterations, g1, g2, dist_out, x1, x2, res) == 1) return 1;
+  return ccd_epa_phase(tolerance, epa_iterations, g1, g2, res, scratch, dist_out, x1, x2, overflow, face_out, pt);
 }
 
 // ---- multi-contact recovery for box pairs (collision_gjk.py:2076-2300, box branches) -------------------------------------------------
@@ -1057,23 +1271,26 @@ __host__ __device__ inline int ccd_mc_d(int nmeshdegmax) { return nmeshdegmax > 
 __host__ __device__ inline int ccd_mc_words(int npolygonmax, int nmeshdegmax) {  // idx1 idx2 | n1 n2 endv | face1 face2 pn | pd | bufa bufb
   return 11 * ccd_mc_d(nmeshdegmax) + 22 * ccd_mc_p(npolygonmax);
 }
-struct WsI {  // int array in the lane's interleaved workspace
+struct WsI {  // int array in the multi-contact workspace: entry i at p[i * st] (st = CCD_LANES in a lane-interleaved slice, 1 for an EPA group)
   int* p;
-  DEV int get(int i) const { return p[(size_t)i * CCD_LANES]; }
-  DEV void set(int i, int v) const { p[(size_t)i * CCD_LANES] = v; }
+  int st;
+  DEV int get(int i) const { return p[(size_t)i * st]; }
+  DEV void set(int i, int v) const { p[(size_t)i * st] = v; }
 };
 struct WsF {
   float* p;
-  DEV float get(int i) const { return p[(size_t)i * CCD_LANES]; }
-  DEV void set(int i, float v) const { p[(size_t)i * CCD_LANES] = v; }
+  int st;
+  DEV float get(int i) const { return p[(size_t)i * st]; }
+  DEV void set(int i, float v) const { p[(size_t)i * st] = v; }
 };
 struct WsV {  // V3 array
   float* p;
-  DEV V3 get(int i) const { return V3{p[(size_t)(3 * i) * CCD_LANES], p[(size_t)(3 * i + 1) * CCD_LANES], p[(size_t)(3 * i + 2) * CCD_LANES]}; }
+  int st;
+  DEV V3 get(int i) const { return V3{p[(size_t)(3 * i) * st], p[(size_t)(3 * i + 1) * st], p[(size_t)(3 * i + 2) * st]}; }
   DEV void set(int i, V3 v) const {
-    p[(size_t)(3 * i) * CCD_LANES] = v.x;
-    p[(size_t)(3 * i + 1) * CCD_LANES] = v.y;
-    p[(size_t)(3 * i + 2) * CCD_LANES] = v.z;
+    p[(size_t)(3 * i) * st] = v.x;
+    p[(size_t)(3 * i + 1) * st] = v.y;
+    p[(size_t)(3 * i + 2) * st] = v.z;
   }
 };
 DEV int mc_intersect(const int* a1, int n1, const int* a2, int n2, int (&res)[2]) {
@@ -1240,7 +1457,7 @@ DEV int mc_polygon_clip_ws(const WsV& face1, int nface1, const WsV& face2, int n
 }
 // ws = the lane's multi-contact words (behind the polytope, the contact cache and the height-field table of Data.ws_ccd)
 __device__ __noinline__ int ccd_multicontact_mesh(const MjhModel& m, const Poly& pt, int epa_face, V3 x1, V3 x2, const CcdGeom& g1, const CcdGeom& g2,
-                                                  V3 (&w1)[4], V3 (&w2)[4], float* ws) {
+                                                  V3 (&w1)[4], V3 (&w2)[4], float* ws, int wst = CCD_LANES) {
   w1[0] = x1;
   w2[0] = x2;
   const unsigned fc = (unsigned)pt.face(epa_face);
@@ -1248,13 +1465,13 @@ __device__ __noinline__ int ccd_multicontact_mesh(const MjhModel& m, const Poly&
   const bool mesh1 = g1.type == G_MESH, mesh2 = g2.type == G_MESH;
   const MeshTab t1 = mesh1 ? mesh_tab(m, g1) : MeshTab{}, t2 = mesh2 ? mesh_tab(m, g2) : MeshTab{};
   const int D = ccd_mc_d(m.nmeshdegmax), P = ccd_mc_p(m.npolygonmax);
-  auto at = [&](int word) { return ws + (size_t)word * CCD_LANES; };
-  const WsI idx1{reinterpret_cast<int*>(at(0))}, idx2{reinterpret_cast<int*>(at(D))};
-  const WsV n1{at(2 * D)}, n2{at(5 * D)}, endv{at(8 * D)};
+  auto at = [&](int word) { return ws + (size_t)word * wst; };
+  const WsI idx1{reinterpret_cast<int*>(at(0)), wst}, idx2{reinterpret_cast<int*>(at(D)), wst};
+  const WsV n1{at(2 * D), wst}, n2{at(5 * D), wst}, endv{at(8 * D), wst};
   const int f0 = 11 * D;
-  const WsV face1{at(f0)}, face2{at(f0 + 3 * P)}, pn{at(f0 + 6 * P)};
-  const WsF pd{at(f0 + 9 * P)};
-  const WsV bufa{at(f0 + 10 * P)}, bufb{at(f0 + 16 * P)};
+  const WsV face1{at(f0), wst}, face2{at(f0 + 3 * P), wst}, pn{at(f0 + 6 * P), wst};
+  const WsF pd{at(f0 + 9 * P), wst};
+  const WsV bufa{at(f0 + 10 * P), wst}, bufb{at(f0 + 16 * P), wst};
   int fi1[3], fi2[3];
   V3 fv1[3], fv2[3];
   const int nf1 = mc_feature_dim(pt, face, 0, fi1, fv1), nf2 = mc_feature_dim(pt, face, 1, fi2, fv2);

@@ -38,7 +38,7 @@ enum { ISL_LIST_MANYROWS = 0, ISL_LIST_WIDE = 1, ISL_LIST_GENERIC = 2 };  // Dat
 // word of a contact record holding friction coefficient j of the reference's Contact.friction[5] (tangent 1, tangent 2, spin, roll 1, roll 2)
 #define CON_FRICTION_WORD(j) ((j) == 0 ? 14 : (j) == 1 ? 30 : (j) == 2 ? 15 : (j) == 3 ? 16 : 31)
 enum { INT_EULER = 0, INT_RK4 = 1, INT_IMPLICIT = 2, INT_IMPLICITFAST = 3 };
-enum { OVF_NEFC = 1 << 0, OVF_NJMAX_NNZ = 1 << 1, OVF_BROADPHASE = 1 << 2, OVF_NARROWPHASE = 1 << 3, OVF_HFIELD = 1 << 5, OVF_NVMAX = 1 << 7, OVF_EPA_HORIZON = 1 << 8, OVF_ITERATIONS = 1 << 9, OVF_LS_ITERATIONS = 1 << 10 };
+enum { OVF_NEFC = 1 << 0, OVF_NJMAX_NNZ = 1 << 1, OVF_BROADPHASE = 1 << 2, OVF_NARROWPHASE = 1 << 3, OVF_CCD = 1 << 4, OVF_HFIELD = 1 << 5, OVF_NVMAX = 1 << 7, OVF_EPA_HORIZON = 1 << 8, OVF_ITERATIONS = 1 << 9, OVF_LS_ITERATIONS = 1 << 10 };
 enum { CONTACT_TYPE_CONSTRAINT = 1 };
 
 #define DEV __device__ __forceinline__

@@ -115,8 +115,32 @@ static int launch_factor_smooth_g(const MjhModel* m, const MjhData* d, int write
   return MJH_OK;
 }
 static int launch_factor_smooth(const MjhModel* m, const MjhData* d, int write_qacc, hipStream_t s) { return launch_factor_smooth_g<32>(m, d, write_qacc, s); }  // (chains over the sparse factor: more lanes per world only halve the worlds per wavefront)
+// the three launches of the convex narrowphase in front of a contact kernel (models with GJK pairs; csrc/convex.hpp header)
+template <int G>
+static int launch_ccd_pre(const MjhModel* m, const MjhData* d, hipStream_t s) {
+  const int it = std::max(m->ccd_iterations, m->epa_iterations);
+  const CcdLayout CL = ccd_layout(d->nworld, it, m->nhfield, m->npolygonmax, m->nmeshdegmax, collide_ccap(m->npair, d->concap), d->nccdhand);
+  hipLaunchKernelGGL(k_ccd_reset, dim3(1), dim3(64), 0, s, reinterpret_cast<int*>(d->ws_ccd + CL.cnt));  // list / EPA entry counters (a kernel, not a memset node: replayed inside hipGraphs)
+  size_t lds;
+  const int threads = pick_block(0, sizeof(float) * collide_lds_words(m->ngeom, m->npair, d->concap, m->broadphase), G, &lds);
+  if (!threads) return fail(MJH_E_UNSUPPORTED, "k_ccd_broad: pair list does not fit in LDS");
+  HIPCHK(set_lds((k_ccd_broad<G>), lds));
+  const int wpb = threads / G;
+  hipLaunchKernelGGL((k_ccd_broad<G>), dim3((d->nworld + wpb - 1) / wpb), dim3(threads), lds, s, *m, *d);
+  // (grids sized for the device -- 256 CUs x 8 workgroups --, not for the lists' capacities: the kernels walk their lists with the grid's stride)
+  hipLaunchKernelGGL(k_ccd_gjk, dim3(std::min((CL.listcap + 255) / 256, 2048)), dim3(256), 0, s, *m, *d);
+  const int gpb = 256 / G;
+  const size_t lds_epa = sizeof(float) * (size_t)ccd_coop_words(it) * gpb;
+  HIPCHK(set_lds((k_ccd_epa<G>), lds_epa));
+  hipLaunchKernelGGL((k_ccd_epa<G>), dim3(std::min((CL.handcap + gpb - 1) / gpb, 2048)), dim3(256), lds_epa, s, *m, *d);
+  return MJH_OK;
+}
 template <int G>
 static int launch_collision_g(const MjhModel* m, const MjhData* d, hipStream_t s) {
+  if (m->heavy_colliders && d->ws_ccd) {
+    const int rc = launch_ccd_pre<G>(m, d, s);
+    if (rc != MJH_OK) return rc;
+  }
   size_t lds;
   const int threads = pick_block(0, sizeof(float) * collide_lds_words(m->ngeom, m->npair, d->concap, m->heavy_colliders ? m->broadphase : 0), G, &lds);
   if (!threads) return fail(MJH_E_UNSUPPORTED, "k_collision: pair list does not fit in LDS");
@@ -273,6 +297,12 @@ __global__ void __launch_bounds__(256) k_fwd_pos_plus(MjhModel m, MjhData d, int
 
 template <int G>
 static int launch_mid_g(const MjhModel* m, const MjhData* d, bool sched, hipStream_t s) {
+  if constexpr (G != 16) {
+    if (m->heavy_colliders && d->ws_ccd) {
+      const int rc = launch_ccd_pre<G>(m, d, s);
+      if (rc != MJH_OK) return rc;
+    }
+  }
   const ConLayout cl = con_layout(m->nv, d->njmax, d->concap, m->nbody, m->ngeom);
   const int stride_cc = std::max(cl.total, collide_lds_words(m->ngeom, m->npair, d->concap, m->heavy_colliders ? m->broadphase : 0) | 1);
   const VelLayout vl = vel_layout(m->nq, m->nv, m->nbody, m->nC, m->nu);

@@ -2,7 +2,7 @@
 // libmjhip.so, see host.hpp)
 #include "host.hpp"
 
-#include "collide.hpp"
+#include "contact_rec.hpp"
 #include "smooth.hpp"
 #include "solver_cgw.hpp"
 

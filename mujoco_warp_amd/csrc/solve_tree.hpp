@@ -2,7 +2,7 @@
 #pragma once
 #include "host.hpp"
 
-#include "collide.hpp"
+#include "contact_rec.hpp"
 #include "smooth.hpp"
 #include "solver.hpp"
 

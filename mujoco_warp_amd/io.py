@@ -512,15 +512,32 @@ def c_model(m: types.Model):
   return c
 
 
-def _ccd_words(iterations: int, hfield: int = 0, npolygonmax: int = 0, nmeshdegmax: int = 0) -> int:
-  """Workspace words of one lane's EPA polytope (csrc/convex.hpp ccd_words) and, for models with multi-contact recovery on mesh faces
-  (nmeshdegmax > 0), its feature / clip buffers (ccd_mc_words: sized from the model like the reference's, collision_convex.py:1346-1366)."""
+def _collide_ccap(npair: int, concap: int) -> int:
+  """csrc/collide.hpp collide_ccap: candidate capacity of one world's narrowphase."""
+  cap = max(8 * concap, 512)
+  return (min(npair, cap) + 3) // 4 * 4
+
+
+def _ccd_handcap(nworld: int, ccap: int) -> int:
+  """csrc/collide.hpp ccd_handcap: EPA entries k_ccd_gjk can hand to k_ccd_epa per step (32 per world on average, at least 4096 or all)."""
+  return max(nworld * min(ccap, 32), min(nworld * ccap, 4096))
+
+
+def _ccd_words(nworld: int, iterations: int, hfield: int, npolygonmax: int, nmeshdegmax: int, ccap: int) -> int:
+  """Per-lane words of Data.ws_ccd [nworld, words, 32] such that it holds csrc/convex.hpp ccd_layout(...).total floats: per world the
+  height-field prisms' polytopes, the per-candidate result cache and the candidate list; then the flat GJK list, the EPA hand-over
+  records (CCD_HAND_WORDS = 64 each) and the multi-contact buffers of the EPA groups (sized from the model like the reference's,
+  collision_convex.py:1346-1366)."""
   it = min(int(iterations), 64)
-  # polytope + contact cache (CCD_CACHE_SLOTS x CCD_CACHE_WORDS) + the height-field result table (CCD_HF_WORDS)
-  words = 8 * (5 + it) + 5 * (6 + 5 * it) + 24 + 4 * 24 + (7 * 50 + 1 if hfield else 0)
-  if nmeshdegmax > 0:
-    words += 11 * max(int(nmeshdegmax), 3) + 22 * max(int(npolygonmax), 4)
-  return words
+  poly = 8 * (5 + it) + 5 * (6 + 5 * it) + 24
+  cache0 = (poly + 4 * 24 + 7 * 50 + 1) * 32 if hfield else 0
+  cand = cache0 + ccap * 24
+  world_stride = (cand + ccap + 4 + 3) // 4 * 4
+  handcap = _ccd_handcap(nworld, ccap)
+  listcap = nworld * ccap
+  mcw = 11 * max(int(nmeshdegmax), 3) + 22 * max(int(npolygonmax), 4) if nmeshdegmax > 0 else 0
+  total = world_stride * nworld + 8 + 4 * listcap + handcap * 64 + handcap * mcw
+  return (total + 32 * nworld - 1) // (32 * nworld)
 
 
 def contact_cap(nconmax: int) -> int:
@@ -552,7 +569,7 @@ def _data_shapes(m, nworld, nconmax, njmax, naconmax):
     efc_margin=(W, njmax), efc_D=(W, njmax), efc_vel=(W, njmax), efc_aref=(W, njmax), efc_frictionloss=(W, njmax),
     efc_force=(W, njmax), ws_ncon=(W,), ws_conadr=(W,), ws_ncollision=(W,), ws_efc_con=(W, njmax), ws_tree_rowadr=(W, (m.ntree + 1) if m.tree_solve else 0), ws_tree_rowmap=(W, njmax if m.tree_solve else 0),
     ws_isl_dofadr=(W, (m.ntree + 1) if m.tree_solve else 0), ws_isl_dofmap=(W, nv if m.tree_solve else 0), ws_isl_dofinv=(W, nv if m.tree_solve else 0), ws_nisland=(W,), ws_isl_flags=(W,), ws_isl_list=(3, W if m.tree_solve else 0), ws_isl_count=(4,),
-    ws_separable=(W,), ws_order=(W,), ws_ccd=(W if m._convex_pairs else 0, _ccd_words(max(int(m.opt.ccd_iterations), int(m.epa_iterations)), m.nhfield, m.npolygonmax, m.nmeshdegmax), 32),
+    ws_separable=(W,), ws_order=(W,), ws_ccd=(W if m._convex_pairs else 0, _ccd_words(W, max(int(m.opt.ccd_iterations), int(m.epa_iterations)), m.nhfield, m.npolygonmax, m.nmeshdegmax, _collide_ccap(int(m.npair), contact_cap(nconmax))), 32),
     tree_asleep=(W, m.ntree), tree_awake=(W, m.ntree), body_awake=(W, nb), body_awake_ind=(W, nb), dof_awake_ind=(W, nv), ntree_awake=(W,), nbody_awake=(W,),
     nv_awake=(W,), tree_island=(W, m.ntree), nisland=(W,), ws_iacc=(W if int(m.opt.integrator) == int(types.IntegratorType.IMPLICIT) else 0, nv), ws_pgsB=(W if _needs_pgs_big(m) else 0, njmax_pad, nv_pad), ws_sleep_J=(W if m.sleep_enabled else 0, njmax_pad, nv_pad), ws_sleep_warm=(W if m.sleep_enabled else 0, nv),
     ws_sleep_flag=(W,),
@@ -609,7 +626,7 @@ def _alloc_data(m: types.Model, nworld, nconmax, njmax, naconmax, mjd=None, nvma
   d.nccdworld, d.nccdword = shapes["ws_ccd"][0], shapes["ws_ccd"][1]
   d.world_offset = 0
   d.concap = contact_cap(nconmax)
-  d.reserved0 = 0
+  d.nccdhand = _ccd_handcap(nworld, _collide_ccap(int(m.npair), d.concap)) if shapes["ws_ccd"][0] else 0
   d.njmax_nnz = njmax * m.nv
   d._c = None
   d._dirty = True

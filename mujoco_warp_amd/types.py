@@ -648,9 +648,9 @@ class Data(_Dirty):
   nv_pad: int = 0
   nmaxpyramid: int = 0
   nccdworld: int = 0  # worlds with an EPA workspace: nworld if the model has convex (GJK) pairs, else 0
-  nccdword: int = 0  # workspace words per lane of a world (csrc/convex.hpp ccd_words)
+  nccdword: int = 0  # workspace words per lane of a world such that the array holds csrc/convex.hpp ccd_layout(...).total floats
   world_offset: int = 0
   concap: int = 0
-  reserved0: int = 0
+  nccdhand: int = 0  # EPA entries the convex narrowphase can hand over per step (csrc/collide.hpp ccd_handcap)
   njmax_nnz: int = 0
 
