@@ -99,6 +99,19 @@ def needs_build():
   return any(os.path.getmtime(s) > t for s in SOURCES + [HEADER])
 
 
+_TOOLCHAIN = None
+
+
+def _toolchain_id():
+  global _TOOLCHAIN
+  if _TOOLCHAIN is None:
+    try:
+      _TOOLCHAIN = subprocess.run(["hipcc", "--version"], capture_output=True, text=True, timeout=60).stdout.strip()
+    except Exception:
+      _TOOLCHAIN = "unknown"
+  return _TOOLCHAIN
+
+
 def _unit_key(unit):
   """Hash of everything a translation unit is compiled from: its source, the headers it includes (transitively, quoted includes) and
   the flags.  Keys the object cache below, so that touching one header recompiles only the units that see it."""
@@ -113,6 +126,7 @@ def _unit_key(unit):
     for inc in re.findall(rb'^\s*#\s*include\s+"([^"]+)"', seen[f], flags=re.M):
       todo.append(os.path.join(os.path.dirname(f), inc.decode()))
   h = hashlib.sha256(" ".join(HIPCC_FLAGS + UNIT_FLAGS.get(unit, [])).encode())
+  h.update(_toolchain_id().encode())  # (a ROCm upgrade must not link objects of the old compiler)
   for f in sorted(seen):
     h.update(f.encode())
     h.update(seen[f])
@@ -161,7 +175,8 @@ def build(force=False, verbose=False):
         for old in os.listdir(cache):  # one cached object per unit
           if old.startswith(os.path.basename(obj)[:-2] + "."):
             os.remove(os.path.join(cache, old))
-        shutil.copyfile(obj, cached)
+        shutil.copyfile(obj, cached + ".tmp")  # (atomic: an interrupted build must not leave a truncated object under a valid key)
+        os.replace(cached + ".tmp", cached)
     if failed:
       shutil.rmtree(objdir, ignore_errors=True)  # (objects of a failed build are of no use and pile up otherwise)
       raise subprocess.CalledProcessError(*failed)

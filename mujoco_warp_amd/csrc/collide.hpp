@@ -1132,6 +1132,11 @@ __host__ __device__ inline int sap_pow2(int n) {
   while (p < n) p <<= 1;
   return p;
 }
+// k_ccd_broad's slice: position | radius per geom (4 words), candidate list, slots, queue (+ the SAP arrays)
+__host__ __device__ inline int broad_lds_words(int ngeom, int npair, int concap, int sap = 0) {
+  const int base = 4 * ngeom + 2 * collide_ccap(npair, concap) + CON_WINDOW * CON_LDS;
+  return ((base + (sap ? 3 * sap_pow2(ngeom) + ((npair + 31) / 32 + 3) / 4 * 4 : 0)) + 3) / 4 * 4;
+}
 __host__ __device__ inline int collide_lds_words(int ngeom, int npair, int concap, int sap = 0) {
   const int base = 12 * ngeom + 2 * collide_ccap(npair, concap) + CON_WINDOW * CON_LDS;
   return base + (sap ? 3 * sap_pow2(ngeom) + ((npair + 31) / 32 + 3) / 4 * 4 : 0);
@@ -1194,14 +1199,40 @@ template <int G, bool HEAVY = false, int MODE = 0>
 DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const Blk& b, int stride_words = 0) {
   const int lig = threadIdx.x & (G - 1), gib = threadIdx.x / G;
   const int w = b.w0 + gib;
+  // k_ccd_broad: the per-geom model tables the pair loop reads (bounding radius, margin, gap, local box) staged ONCE per workgroup in LDS
+  // behind the worlds' slices (unless a field is batched per world): the loop's only global loads are then the coalesced pair ids -- with
+  // the tables in L2 every trip was two dependent round trips at one wavefront per SIMD (ALOHA scene, 9,154 pairs: 785 us per launch)
+  const float* tbl = nullptr;
+  bool zero_mg = false;
+  if constexpr (MODE == 1) {
+    if (m.geom_rbound_nb <= 1 && m.geom_margin_nb <= 1 && m.geom_gap_nb <= 1 && m.geom_aabb_nb <= 1) {
+      float* t = smem + (size_t)(blockDim.x / G) * broad_lds_words(m.ngeom, m.npair, d.concap, m.broadphase);
+      const int n = m.ngeom;
+      for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        t[i] = m.geom_rbound[i];
+        t[n + i] = m.geom_margin[i];
+        t[2 * n + i] = m.geom_gap[i];
+      }
+      for (int i = threadIdx.x; i < 6 * n; i += blockDim.x) t[3 * n + i] = m.geom_aabb[i];
+      tbl = t;
+      bool nz = false;
+      for (int i = threadIdx.x; i < n; i += blockDim.x) nz |= m.geom_margin[i] != 0.0f || m.geom_gap[i] != 0.0f;
+      zero_mg = !__syncthreads_or(nz);  // (also the barrier behind the staging) no margins, no gaps: the pair loop skips four table reads per pair
+    }
+  }
   if ((int)threadIdx.x >= b.nthreads || w >= d.nworld) return;
   // sleeping, second collision pass (forward.py:652-666): only worlds where a contact of pass 1 woke a tree can gain pairs
   if (HEAVY && d.sleep_pass == 2 && !d.ws_sleep_flag[w]) return;
   const int npair = m.npair, ng = m.ngeom, ncap = d.concap;
-  float* S = smem + (size_t)gib * (stride_words ? stride_words : collide_lds_words(ng, npair, ncap, HEAVY ? m.broadphase : 0));
-  float* gxpos = S;
-  float* gxmat = S + 3 * ng;
-  int* cand = reinterpret_cast<int*>(S + 12 * ng);
+  // k_ccd_broad keeps only what its pair loop reads in LDS -- position | bounding radius of every geom as ONE 16-byte read, the candidate
+  // list, the queue -- and reads the rotation matrices of the few pairs that reach the plane test / the box filters from global memory:
+  // 9.5 instead of 19 KB per world on the ALOHA scene (12 instead of 8 worlds per CU)
+  const int slice_words = MODE == 1 ? broad_lds_words(ng, npair, ncap, m.broadphase) : collide_lds_words(ng, npair, ncap, HEAVY ? m.broadphase : 0);
+  float* S = smem + (size_t)gib * (stride_words ? stride_words : slice_words);
+  float* gx4 = S;  // (MODE 1 only)
+  const float* gxpos = MODE == 1 ? d.geom_xpos + (size_t)w * 3 * m.ngeom : S;
+  const float* gxmat = MODE == 1 ? d.geom_xmat + (size_t)w * 9 * m.ngeom : S + 3 * ng;
+  int* cand = reinterpret_cast<int*>(S + (MODE == 1 ? 4 * ng : 12 * ng));
   const int ccap = collide_ccap(npair, ncap);
   int* cslot = cand + ccap;
   float* rec = reinterpret_cast<float*>(cslot + ccap);
@@ -1222,13 +1253,24 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
   }
   int* gcand = ccd_world ? reinterpret_cast<int*>(ccd_world + CL.cand) : nullptr;  // ccap candidates | ncand, nbroad, nconvex
   PhaseClock pc(2, lig);
-  gcopy<G>(gxpos, d.geom_xpos + (size_t)w * 3 * ng, 3 * ng, lig);
-  gcopy<G>(gxmat, d.geom_xmat + (size_t)w * 9 * ng, 9 * ng, lig);
-  const float* rbound = bf(m.geom_rbound, m.geom_rbound_nb, w, ng);
-  const float* gmargin = bf(m.geom_margin, m.geom_margin_nb, w, ng);
-  const float* ggap = bf(m.geom_gap, m.geom_gap_nb, w, ng);
+  if constexpr (MODE != 1) {
+    gcopy<G>(S, d.geom_xpos + (size_t)w * 3 * ng, 3 * ng, lig);
+    gcopy<G>(S + 3 * ng, d.geom_xmat + (size_t)w * 9 * ng, 9 * ng, lig);
+  }
+  const float* rbound = tbl ? tbl : bf(m.geom_rbound, m.geom_rbound_nb, w, ng);
+  const float* gmargin = tbl ? tbl + ng : bf(m.geom_margin, m.geom_margin_nb, w, ng);
+  const float* ggap = tbl ? tbl + 2 * ng : bf(m.geom_gap, m.geom_gap_nb, w, ng);
   const float* gsize = bf(m.geom_size, m.geom_size_nb, w, 3 * ng);
   gsync();
+  if constexpr (MODE == 1) {
+    for (int g = lig; g < ng; g += G) {
+      gx4[4 * g] = gxpos[3 * g];
+      gx4[4 * g + 1] = gxpos[3 * g + 1];
+      gx4[4 * g + 2] = gxpos[3 * g + 2];
+      gx4[4 * g + 3] = rbound[g];
+    }
+    gsync();
+  }
   pc.mark(0);
 
   // ---- broadphase (collision_driver.py:278-334 filters, 567-682 SAP, 684-770 NXN), ordered compaction --------------------
@@ -1236,7 +1278,7 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
   // broadphase.  Plane / bounding-sphere filters live in both instantiations; AABB / OBB filters and the sweep-and-prune
   // candidate generator only in the HEAVY one (the light k_mid sits exactly at its 4-waves-per-SIMD register budget).
   const int filt = HEAVY ? m.broadphase_filter : 3;
-  const float* gaabb = HEAVY ? bf(m.geom_aabb, m.geom_aabb_nb, w, 6 * ng) : nullptr;
+  const float* gaabb = HEAVY ? (tbl ? tbl + 3 * ng : bf(m.geom_aabb, m.geom_aabb_nb, w, 6 * ng)) : nullptr;
   unsigned* sapmark = nullptr;
   int ncand = 0, nbroad = 0;
   if (HEAVY && MODE == 0 && pre) {  // k_ccd_broad's list (the convex results are keyed by the rank in exactly this list)
@@ -1313,16 +1355,94 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
     }
     gsync();
   }
-  for (int base = 0; base < npair; base += G) {
-    const int p = base + lig;
-    bool pass = false;
+  // Pair loop in two stages (round 4).  Stage A: the cheap tests (plane distance / bounding spheres, the SAP mark, the sleep filter) on
+  // every filtered pair, PU per lane and trip.  Stage B (heavy instantiation): the box filters on the SURVIVORS only, which queue up in
+  // LDS in pair order and are served a full lane group at a time -- on the ALOHA scene 760 of 9,154 pairs survive stage A, scattered over
+  // nearly every trip: with the box filters inside the trip (~300 instructions) every trip paid them for one or two live lanes.
+  constexpr int PU = MODE == 1 ? 8 : (HEAVY ? 4 : 1);
+  constexpr int QCAP = HEAVY ? CON_WINDOW * CON_LDS : 0;  // the staging window's LDS is free until the narrowphase's second pass
+  static_assert(!HEAVY || QCAP >= (PU + 1) * 32, "queue: a trip's survivors behind a partial group");
+  int* queue = reinterpret_cast<int*>(rec);
+  int nq = 0;
+  const bool box_filters = HEAVY && (filt & 12) != 0;
+  auto stage_b = [&](bool all) __attribute__((always_inline)) {  // entries: pair | 1 << 30 if the pair skips the box filters (plane pairs)
+    while (nq >= G || (all && nq > 0)) {
+      const int n = nq < G ? nq : G;
+      bool pass = false;
+      int p = 0;
+      if (lig < n) {
+        const int e = queue[lig];
+        p = e & 0x3fffffff;
+        pass = true;
+        if (!(e >> 30)) {
+          const int g1 = m.nxn_geom_pair[2 * p], g2 = m.nxn_geom_pair[2 * p + 1];
+          const int pid = m.nexplicit ? m.nxn_pairid[p] : -1;
+          const float mg = pid >= 0 ? m.pair_margin[pid] + m.pair_gap[pid] : gmargin[g1] + ggap[g1] + gmargin[g2] + ggap[g2];
+          const V3 x1 = ld3(gxpos + 3 * g1), x2 = ld3(gxpos + 3 * g2);
+          if (filt & 4) pass = aabb_filter(gaabb + 6 * g1, gaabb + 6 * g2, mg, x1, x2, gxmat + 9 * g1, gxmat + 9 * g2);
+          if (pass && (filt & 8)) pass = obb_filter(gaabb + 6 * g1, gaabb + 6 * g2, mg, x1, x2, gxmat + 9 * g1, gxmat + 9 * g2);
+        }
+      }
+      int tot;
+      const int rank = grank<G>(pass, lig, tot);
+      if (pass && ncand + rank < ccap) cand[ncand + rank] = p;
+      ncand += tot;
+      // the rest of the queue moves to the front (fewer than PU * G + G entries)
+      gsync();
+      int moved[PU + 1];
+#pragma unroll
+      for (int k = 0; k <= PU; ++k) moved[k] = (n + k * G + lig < nq) ? queue[n + k * G + lig] : 0;
+      gsync();
+#pragma unroll
+      for (int k = 0; k <= PU; ++k)
+        if (n + k * G + lig < nq) queue[k * G + lig] = moved[k];
+      nq -= n;
+      gsync();
+    }
+  };
+#ifdef MJH_DBG_BROAD_SKIP  // (profiling variant, tools/build_variant_fast.py: the launch without its pair loop)
+  if (MODE == 1) nq = 0; else
+#endif
+  // (the pair ids of the NEXT trip are loaded before this trip's tests: at one wavefront per SIMD the table's L2 round trip -- 73 KB read by
+  // every world -- was the chain: 72 trips x ~2.5 us)
+  const int2* pairs2 = reinterpret_cast<const int2*>(m.nxn_geom_pair);
+  int2 cur[PU];
+#pragma unroll
+  for (int u = 0; u < PU; ++u) cur[u] = (u * G + lig < npair) ? pairs2[u * G + lig] : make_int2(0, 0);
+  for (int base = 0; base < npair; base += PU * G) {
+    bool passu[PU];
+    bool plainu[PU];
+    int2 nxt[PU];
+#pragma unroll
+    for (int u = 0; u < PU; ++u) {
+      const int pn = base + PU * G + u * G + lig;
+      nxt[u] = pn < npair ? pairs2[pn] : make_int2(0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < PU; ++u) {
+    const int p = base + u * G + lig;
+    bool pass = false, plain = false;
     if (p < npair && (!sapmark || ((sapmark[p >> 5] >> (p & 31)) & 1u))) {
-      const int g1 = m.nxn_geom_pair[2 * p], g2 = m.nxn_geom_pair[2 * p + 1];
-      const float rb1 = rbound[g1], rb2 = rbound[g2];
+      const int2 gg = cur[u];
+      const int g1 = gg.x, g2 = gg.y;
+      float rb1, rb2;
+      V3 x1, x2;
+      if constexpr (MODE == 1) {
+        const float4 a = *reinterpret_cast<const float4*>(gx4 + 4 * g1), c = *reinterpret_cast<const float4*>(gx4 + 4 * g2);
+        x1 = V3{a.x, a.y, a.z};
+        x2 = V3{c.x, c.y, c.z};
+        rb1 = a.w;
+        rb2 = c.w;
+      } else {
+        rb1 = rbound[g1];
+        rb2 = rbound[g2];
+        x1 = ld3(gxpos + 3 * g1);
+        x2 = ld3(gxpos + 3 * g2);
+      }
       const int pid = (HEAVY && m.nexplicit) ? m.nxn_pairid[p] : -1;
-      const float mg = pid >= 0 ? m.pair_margin[pid] + m.pair_gap[pid] : gmargin[g1] + ggap[g1] + gmargin[g2] + ggap[g2];
-      V3 x1 = ld3(gxpos + 3 * g1), x2 = ld3(gxpos + 3 * g2);
+      const float mg = pid >= 0 ? m.pair_margin[pid] + m.pair_gap[pid] : (zero_mg ? 0.0f : gmargin[g1] + ggap[g1] + gmargin[g2] + ggap[g2]);
       if (rb1 == 0.0f || rb2 == 0.0f) {
+        plain = true;
         if (!(filt & 1)) {
           pass = true;
         } else if (rb1 == 0.0f) {
@@ -1339,10 +1459,6 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
           V3 dif = x2 - x1;
           pass = dot(dif, dif) <= bound * bound;
         }
-        if (HEAVY) {
-          if (pass && (filt & 4)) pass = aabb_filter(gaabb + 6 * g1, gaabb + 6 * g2, mg, x1, x2, gxmat + 9 * g1, gxmat + 9 * g2);
-          if (pass && (filt & 8)) pass = obb_filter(gaabb + 6 * g1, gaabb + 6 * g2, mg, x1, x2, gxmat + 9 * g1, gxmat + 9 * g2);
-        }
       }
       if (HEAVY && m.sleep_enabled && pass) {  // collision_driver.py:494-503: no pair of two sleeping bodies, or of a sleeping and a static one
         const int* bawake = d.body_awake + (size_t)w * m.nbody;
@@ -1350,11 +1466,29 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
         if ((s1 == 0 && s2 == 0) || (s1 == 0 && s2 == -1) || (s2 == 0 && s1 == -1)) pass = false;
       }
     }
-    int tot;
-    const int rank = grank<G>(pass, lig, tot);
-    if (pass && ncand + rank < ccap) cand[ncand + rank] = p;
-    ncand += tot;
+    passu[u] = pass;
+    plainu[u] = plain;
+    }
+#pragma unroll
+    for (int u = 0; u < PU; ++u) {
+      int tot;
+      const int rank = grank<G>(passu[u], lig, tot);
+      if (!box_filters) {  // no stage B: the survivors are the candidates
+        if (passu[u] && ncand + rank < ccap) cand[ncand + rank] = base + u * G + lig;
+        ncand += tot;
+      } else {
+        if (passu[u]) queue[nq + rank] = (base + u * G + lig) | (plainu[u] ? (1 << 30) : 0);
+        nq += tot;
+      }
+    }
+    if (box_filters) {
+      gsync();
+      stage_b(false);
+    }
+#pragma unroll
+    for (int u = 0; u < PU; ++u) cur[u] = nxt[u];
   }
+  if (box_filters) stage_b(true);
   nbroad = ncand;  // candidates found (Data.ncollision); the capacity bounds what the narrowphase sees
   if (ncand > ccap) ncand = ccap;
   gsync();

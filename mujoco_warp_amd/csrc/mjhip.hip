@@ -122,7 +122,7 @@ static int launch_ccd_pre(const MjhModel* m, const MjhData* d, hipStream_t s) {
   const CcdLayout CL = ccd_layout(d->nworld, it, m->nhfield, m->npolygonmax, m->nmeshdegmax, collide_ccap(m->npair, d->concap), d->nccdhand);
   hipLaunchKernelGGL(k_ccd_reset, dim3(1), dim3(64), 0, s, reinterpret_cast<int*>(d->ws_ccd + CL.cnt));  // list / EPA entry counters (a kernel, not a memset node: replayed inside hipGraphs)
   size_t lds;
-  const int threads = pick_block(0, sizeof(float) * collide_lds_words(m->ngeom, m->npair, d->concap, m->broadphase), G, &lds);
+  const int threads = pick_block(sizeof(float) * 9 * m->ngeom, sizeof(float) * broad_lds_words(m->ngeom, m->npair, d->concap, m->broadphase), G, &lds);  // (+ the staged model tables)
   if (!threads) return fail(MJH_E_UNSUPPORTED, "k_ccd_broad: pair list does not fit in LDS");
   HIPCHK(set_lds((k_ccd_broad<G>), lds));
   const int wpb = threads / G;
