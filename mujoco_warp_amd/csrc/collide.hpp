@@ -1195,8 +1195,11 @@ DEV bool obb_filter(const float* a1, const float* a2, float margin, V3 x1, V3 x2
 // MODE 0: the contact kernel (broadphase + both narrowphase passes; for models with GJK pairs -- Data.ws_ccd -- the candidate list and the
 // convex results come from the three launches in front of it).  MODE 1: k_ccd_broad -- the broadphase alone; the candidate list goes to
 // the world's slice of Data.ws_ccd, the convex candidates to the flat list of k_ccd_gjk.
-template <int G, bool HEAVY = false, int MODE = 0>
+// HFT = false: the heavy instantiation without the height-field colliders (per-lane GJK / EPA on prisms: the largest register consumer left in
+// the contact kernel) for models without height fields
+template <int G, bool HEAVY = false, int MODE = 0, bool HFT = true>
 DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const Blk& b, int stride_words = 0) {
+  constexpr bool HFC = HEAVY && HFT && MODE == 0;
   const int lig = threadIdx.x & (G - 1), gib = threadIdx.x / G;
   const int w = b.w0 + gib;
   // k_ccd_broad: the per-geom model tables the pair loop reads (bounding radius, margin, gap, local box) staged ONCE per workgroup in LDS
@@ -1570,7 +1573,7 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
     return adr >= 0 ? m.mesh_graph + adr : nullptr;
   };
   // EPA polytope of this lane (convex.hpp): word k of lane l at k * 32 + l inside the world's slice of d.ws_ccd
-  float* ccd_scratch = (HEAVY && ccd_world && m.nhfield > 0) ? ccd_world + CL.hf + (lig & (CCD_LANES - 1)) : nullptr;  // height-field prisms only
+  float* ccd_scratch = (HFC && ccd_world && m.nhfield > 0) ? ccd_world + CL.hf + (lig & (CCD_LANES - 1)) : nullptr;  // height-field prisms only
   const float* ccd_cache = ccd_world ? ccd_world + CL.cache : nullptr;  // results of k_ccd_gjk / k_ccd_epa, one entry per convex candidate
   const int hf0 = ccd_words(max(m.ccd_iterations, m.epa_iterations), 0);  // first word of the lane's height-field result table
   const float ccd_tol = HEAVY ? bf(m.opt_ccd_tolerance, m.opt_ccd_tolerance_nb, w, 1)[0] : 0.0f;
@@ -1598,8 +1601,10 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
       int mn2;
       mesh_of(g2, t2, mv2, mn2);
       float* table = ccd_scratch - (lig & (CCD_LANES - 1)) + (owner & (CCD_LANES - 1)) + (size_t)hf0 * CCD_LANES;
-      hfield_fill<G>(m, ccd_tol, ccd_it, epa_it, g1, t2, ld3(gxpos + 3 * g1), gxmat + 9 * g1, ld3(gxpos + 3 * g2), gxmat + 9 * g2, ld3(gsize + 3 * g2), rbound[g2],
-                     gmargin[g1] + gmargin[g2], margin, ccd_scratch, table, ccd_overflow, lig, lig == owner, mv2, mn2, t2 == G_MESH ? m.geom_dataid[g2] : -1);
+      if constexpr (HFC) {
+        hfield_fill<G>(m, ccd_tol, ccd_it, epa_it, g1, t2, ld3(gxpos + 3 * g1), gxmat + 9 * g1, ld3(gxpos + 3 * g2), gxmat + 9 * g2, ld3(gsize + 3 * g2), rbound[g2],
+                       gmargin[g1] + gmargin[g2], margin, ccd_scratch, table, ccd_overflow, lig, lig == owner, mv2, mn2, t2 == G_MESH ? m.geom_dataid[g2] : -1);
+      }
       if (lig == owner) hf_have = myci;
     }
   };
@@ -1612,7 +1617,7 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
     unsigned mask = 0u;
     bool cvx = false;
     float cvx_lim = 0.0f;
-    if (HEAVY && m.nhfield > 0 && ccd_scratch) hf_coop(ci < ncand && hf_pair(cand[ci]), ci < ncand ? cand[ci] : 0, ci);
+    if (HFC && m.nhfield > 0 && ccd_scratch) hf_coop(ci < ncand && hf_pair(cand[ci]), ci < ncand ? cand[ci] : 0, ci);
     if (ci < ncand) {
       int g1, g2, t1, t2;
       load_pair(cand[ci], g1, g2, t1, t2);
@@ -1627,7 +1632,7 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
       mesh_of(g1, t1, mv1, mn1);
       mesh_of(g2, t2, mv2, mn2);
       if (HEAVY && t1 == G_HFIELD) {  // (the group filled this lane's table just above; pass 2 reads it again)
-        if (t2 >= G_SPHERE && ccd_scratch) hfield_select(ccd_scratch + (size_t)hf0 * CCD_LANES, count);
+        if constexpr (HFC) if (t2 >= G_SPHERE && ccd_scratch) hfield_select(ccd_scratch + (size_t)hf0 * CCD_LANES, count);
       } else if (HEAVY && is_ccd_pair(m, t1, t2)) {
         cvx = true;  // (its result was computed by k_ccd_gjk / k_ccd_epa: read below, once the lane knows its slot)
       }
@@ -1687,7 +1692,7 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
         if (cvx) myslot = ncvx2 + rank;
         ncvx2 += tot;
       }
-      if (HEAVY && m.nhfield > 0 && ccd_scratch) {  // height-field candidates with contacts in this window: the group refills their tables
+      if (HFC && m.nhfield > 0 && ccd_scratch) {  // height-field candidates with contacts in this window: the group refills their tables
         bool want = false;
         if (ci < ncand && hf_pair(cand[ci])) {
           const unsigned mk = (unsigned)cslot[ci] & 0xffu;
@@ -1733,7 +1738,7 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
                      ++slot;
                    };
       if (HEAVY && t1 == G_HFIELD) {
-        if (t2 >= G_SPHERE && ccd_scratch) hfield_select(ccd_scratch + (size_t)hf0 * CCD_LANES, write);
+        if constexpr (HFC) if (t2 >= G_SPHERE && ccd_scratch) hfield_select(ccd_scratch + (size_t)hf0 * CCD_LANES, write);
       } else if (HEAVY && is_ccd_pair(m, t1, t2)) {
         if (myslot >= 0 && ccd_cache) {  // replay the contacts k_ccd_gjk / k_ccd_epa found
           const float* cache = ccd_cache + (size_t)myslot * CCD_CACHE_WORDS;
@@ -1911,10 +1916,10 @@ __global__ void __launch_bounds__(256) k_ccd_epa(MjhModel m, MjhData d) {
   }
 }
 
-template <int G, bool HEAVY>
+template <int G, bool HEAVY, bool HFT = true>
 __global__ void __launch_bounds__(256) k_collision(MjhModel m, MjhData d) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  collision_body<G, HEAVY>(m, d, smem, blk_of_launch<G>());
+  collision_body<G, HEAVY, 0, HFT>(m, d, smem, blk_of_launch<G>());
 }
 
 template <int G>

@@ -145,9 +145,14 @@ static int launch_collision_g(const MjhModel* m, const MjhData* d, hipStream_t s
   const int threads = pick_block(0, sizeof(float) * collide_lds_words(m->ngeom, m->npair, d->concap, m->heavy_colliders ? m->broadphase : 0), G, &lds);
   if (!threads) return fail(MJH_E_UNSUPPORTED, "k_collision: pair list does not fit in LDS");
   if (m->heavy_colliders) {
-    HIPCHK(set_lds((k_collision<G, true>), lds));
     const int wpb_h = threads / G;
-    hipLaunchKernelGGL((k_collision<G, true>), dim3((d->nworld + wpb_h - 1) / wpb_h), dim3(threads), lds, s, *m, *d);
+    if (m->nhfield > 0) {
+      HIPCHK(set_lds((k_collision<G, true, true>), lds));
+      hipLaunchKernelGGL((k_collision<G, true, true>), dim3((d->nworld + wpb_h - 1) / wpb_h), dim3(threads), lds, s, *m, *d);
+    } else {  // (without the height-field colliders: the registers of their per-lane GJK / EPA)
+      HIPCHK(set_lds((k_collision<G, true, false>), lds));
+      hipLaunchKernelGGL((k_collision<G, true, false>), dim3((d->nworld + wpb_h - 1) / wpb_h), dim3(threads), lds, s, *m, *d);
+    }
     return MJH_OK;
   }
   HIPCHK(set_lds((k_collision<G, false>), lds));
@@ -245,7 +250,7 @@ static int launch_integrate(const MjhModel* m, const MjhData* d, int mode, hipSt
 //                     they fill the CUs that the solver's stragglers leave idle
 //   k_fwd_pos_plus  : k_fwd_pos + one workgroup computing the solver schedule from the previous step's solver_niter
 //   k_integrate_plus: integrator workgroups, then publish_contacts workgroups
-template <int G, bool HEAVY>
+template <int G, bool HEAVY, bool HFT = true>
 __global__ void __launch_bounds__(256) k_mid(MjhModel m, MjhData d, int ncc, int nvb, int nw_cc, int nw_v, int stride_cc, int sched) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   (void)nvb;
@@ -260,7 +265,7 @@ __global__ void __launch_bounds__(256) k_mid(MjhModel m, MjhData d, int ncc, int
   const bool is_cc = bi < ncc;
   if (is_cc) {
     const Blk b{cc_before * nw_cc, nw_cc, nw_cc * G};
-    collision_body<G, HEAVY>(m, d, smem, b, stride_cc);
+    collision_body<G, HEAVY, 0, HFT>(m, d, smem, b, stride_cc);
     __threadfence_block();  // the world's contact records (global) are read back by the same lanes
     make_constraint_body<G>(m, d, smem, b, stride_cc);
   } else {
@@ -333,13 +338,16 @@ static int launch_mid_g(const MjhModel* m, const MjhData* d, bool sched, hipStre
     hipLaunchKernelGGL((k_mid<G, false>), dim3(ncc16 + nvb16 + (sched ? 1 : 0)), dim3(G * std::max(nw_cc, nw_v)), lds, s, *m, *d, ncc16, nvb16, nw_cc, nw_v, stride_cc, sched ? 1 : 0);
     return MJH_OK;
   } else {
-  if (m->heavy_colliders) HIPCHK(set_lds((k_mid<G, true>), lds));
+  const bool hf = m->nhfield > 0;  // (heavy colliders without height fields: the instantiation without their per-lane GJK / EPA)
+  if (m->heavy_colliders && hf) HIPCHK(set_lds((k_mid<G, true, true>), lds));
+  else if (m->heavy_colliders) HIPCHK(set_lds((k_mid<G, true, false>), lds));
   else HIPCHK(set_lds((k_mid<G, false>), lds));
   const int ncc = (d->nworld + nw_cc - 1) / nw_cc, nvb = (d->nworld + nw_v - 1) / nw_v;
   const dim3 grid(ncc + nvb + (sched ? 1 : 0)), block(G * std::max(nw_cc, nw_v));
   if (m->heavy_colliders) debug_occupancy("k_mid<heavy>", k_mid<G, true>, (int)grid.x, (int)block.x, lds);
   else debug_occupancy("k_mid", k_mid<G, false>, (int)grid.x, (int)block.x, lds);
-  if (m->heavy_colliders) hipLaunchKernelGGL((k_mid<G, true>), grid, block, lds, s, *m, *d, ncc, nvb, nw_cc, nw_v, stride_cc, sched ? 1 : 0);
+  if (m->heavy_colliders && hf) hipLaunchKernelGGL((k_mid<G, true, true>), grid, block, lds, s, *m, *d, ncc, nvb, nw_cc, nw_v, stride_cc, sched ? 1 : 0);
+  else if (m->heavy_colliders) hipLaunchKernelGGL((k_mid<G, true, false>), grid, block, lds, s, *m, *d, ncc, nvb, nw_cc, nw_v, stride_cc, sched ? 1 : 0);
   else hipLaunchKernelGGL((k_mid<G, false>), grid, block, lds, s, *m, *d, ncc, nvb, nw_cc, nw_v, stride_cc, sched ? 1 : 0);
   return MJH_OK;
   }
