@@ -302,7 +302,7 @@ def _config_run(mjw, torch, e, nstep, lead):
          "ncon_mean": ncon / max(nstat, 1), "nefc_mean": nefc / max(nstat, 1), "solver_niter_mean": niter / max(nstat, 1),
          "finite": ok, "overflow_bits": ovf, "iteration_cap_worlds": int(((d.overflow.numpy() >> 9) & 1).sum()),
          "timing": "reference placement (per-step sync, control untimed)"}
-  if int(mjm.opt.solver) != 0 and not (int(mjm.opt.enableflags) & int(mjw.EnableBit.SLEEP)):  # (timed_steps runs the fused, non-sleeping launch sequence)
+  if int(mjm.opt.solver) != 0 and not (int(mjm.opt.enableflags) & int(mjw.EnableBit.SLEEP)) and not e.get("replay") and not e.get("hold_key_ctrl"):  # (timed_steps: fused launch sequence, noise around the ctrl-range midpoint -- the same workload only without a replayed / held control centre)
     ms_b2b, _ = mjw.timed_steps(m, d, nstep, step0=lead + nstep)
     res["back_to_back_value"] = e["nworld"] * nstep / (ms_b2b * 1e-3)
   del d

@@ -130,6 +130,9 @@ typedef struct MjhModel {
   const int* tree_sleep_policy; /* [ntree] SleepPolicy (types.py:296): 1 AUTO_NEVER, 2 AUTO_ALLOWED */
   const float* dof_length;      /* [nv] velocity weights of the sleep test (types.py:1098) */
   int act_dof_max;              /* largest number of actuators acting on one dof (implicit integrators: see csrc/integrate.hpp) */
+  int act_velfeedback;          /* 1: some actuator feeds velocity back with a positive sign (affine gain on velocity, or bias velocity coefficient > 0):
+                                   M + h D - h dA/dv may then be indefinite, and implicitfast keeps the integrator launch's L'DL solve instead of the
+                                   solver epilogue's Cholesky (csrc/solver.hpp impfast_acc) */
   int ntree;                    /* trees with at least one dof */
   int tree_nvmax;               /* dofs of the largest tree */
   int isl_nv4;                  /* ceil(dofs / 4) of the widest island of at most 32 dofs the model can form (kernel size class) */
@@ -360,7 +363,7 @@ int mjh_timed_steps(const MjhModel* m, const MjhData* d, int nstep, int step0, f
 int mjh_release_thread_resources(void);
 
 const char* mjh_last_error(void);
-#define MJH_ABI_VERSION 36
+#define MJH_ABI_VERSION 37
 int mjh_abi_version(void); /* returns MJH_ABI_VERSION of the library that was loaded */
 
 #ifdef __cplusplus

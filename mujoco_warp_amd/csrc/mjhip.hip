@@ -797,7 +797,7 @@ static int run_stage(const MjhModel* m, const MjhData* d, int stage, hipStream_t
       static const bool no_fuse_impfast = getenv("MJH_NO_FUSE_IMPLICITFAST") != nullptr;  // developer knob (A/B)
       const int fuse_euler = !fusable ? 0
                              : (m->integrator == INT_EULER && (m->disableflags & (DSBL_EULERDAMP | DSBL_DAMPER)) != 0) ? 1
-                             : (m->integrator == INT_IMPLICITFAST && !no_fuse_impfast) ? 2 : 0;
+                             : (m->integrator == INT_IMPLICITFAST && !no_fuse_impfast && !m->act_velfeedback) ? 2 : 0;  // (positive velocity feedback: the matrix may be indefinite -- the integrator launch's L'DL handles that, the epilogue's Cholesky does not)
       g_fuse_euler = fuse_euler;
       g_newton_inline = inl;
       int rc;

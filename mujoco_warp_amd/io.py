@@ -294,8 +294,14 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
   if mjm.nu:
     adof = np.asarray(mjm.jnt_dofadr)[np.asarray(mjm.actuator_trnid).reshape(-1, 2)[:, 0]]
     m.act_dof_max = int(np.bincount(adof, minlength=max(nv, 1)).max())
+    # d(force)/d(velocity) of an actuator = gainprm[2] * ctrl (affine gain) + biasprm[2] (affine bias): non-positive for every ctrl only
+    # without a gain term and with biasprm[2] <= 0 (a position servo's -kv); otherwise the implicitfast matrix can lose definiteness
+    gp, bp = np.asarray(mjm.actuator_gainprm, dtype=np.float64).reshape(nu, -1), np.asarray(mjm.actuator_biasprm, dtype=np.float64).reshape(nu, -1)
+    gt_, bt_ = np.asarray(mjm.actuator_gaintype).reshape(-1), np.asarray(mjm.actuator_biastype).reshape(-1)
+    m.act_velfeedback = int(bool(((gt_ == 1) & (gp[:, 2] != 0.0)).any() or ((bt_ == 1) & (bp[:, 2] > 0.0)).any()))
   else:
     m.act_dof_max = 0
+    m.act_velfeedback = 0
   m.tree_nvmax = int(tree_dofnum.max()) if len(roots) else 0
   # nv > 64: worlds whose rows each touch one kinematic tree are solved per (world, tree) by the register-resident kernels
   m.tree_solve = int(nv > 64 and m.ntree > 1 and m.tree_nvmax <= 64 and int(opt.solver) != types.SolverType.PGS)
@@ -711,7 +717,7 @@ def put_data(mjm, mjd, nworld: int = 1, nconmax: Optional[int] = None, nccdmax: 
     elif d.body_awake.size and (asleep >= 0).any():
       # (a host MjData without body_awake, e.g. mjcf.MjData with `tree_asleep[:] = arange(ntree)`: derive the tables the first wake /
       # update_sleep stage would produce, sleep.py:171-215 -- the reference's host object carries MuJoCo's own)
-      treeid, mocap = m.body_treeid.numpy(), m.body_mocapid.numpy()
+      treeid, mocap = m.body_treeid.numpy(), m.body_mocapid.numpy()[m.body_rootid.numpy()]  # (a body welded under a mocap body is posed by it: the root's mocap id, as csrc/sleep.hpp)
       ba = np.where(treeid >= 0, np.where(asleep[0][np.maximum(treeid, 0)] < 0, int(types.SleepState.AWAKE), int(types.SleepState.ASLEEP)),
                     np.where(mocap >= 0, int(types.SleepState.AWAKE), int(types.SleepState.STATIC))).astype(np.int32)
       d.body_awake.assign(np.tile(ba, (nworld, 1)))
@@ -873,7 +879,7 @@ def _reset_sleep(m, d, mask):
   """Every tree fully awake (reference io.py:2637-2670 reset_sleep; make_data io.py:1869-1871)."""
   nt, nb, nv = m.ntree, m.nbody, m.nv
   treeid = m.body_treeid.numpy()
-  mocap = m.body_mocapid.numpy()
+  mocap = m.body_mocapid.numpy()[m.body_rootid.numpy()]  # (the root's mocap id, as csrc/sleep.hpp: bodies welded under a mocap body move with it)
   body_awake = np.where(treeid >= 0, int(types.SleepState.AWAKE), np.where(mocap >= 0, int(types.SleepState.AWAKE), int(types.SleepState.STATIC))).astype(np.int32)
   vals = dict(tree_asleep=np.full((d.nworld, nt), -(1 + types.MJ_MINAWAKE), np.int32), tree_awake=np.ones((d.nworld, nt), np.int32),
               body_awake=np.tile(body_awake, (d.nworld, 1)), body_awake_ind=np.tile(np.arange(nb, dtype=np.int32), (d.nworld, 1)),

@@ -452,3 +452,15 @@ def test_builder_object_cache_keys_follow_sources_and_flags(tmp_path, monkeypatc
   assert _abi._unit_key("pgs_tu.hip") == keys["pgs_tu.hip"]
   # the per-unit flags only name real units
   assert set(_abi.UNIT_FLAGS) <= set(_abi.UNITS)
+
+
+def test_positive_velocity_feedback_keeps_implicitfast_out_of_the_solver_epilogue():
+  """M + h D - h dA/dv stays positive definite only while no actuator feeds velocity back with a positive sign; the fused epilogue factors
+  it by Cholesky, so models that can break that (affine gain on velocity, bias velocity coefficient > 0) carry Model.act_velfeedback and
+  keep the integrator launch's L'DL solve."""
+  base = '<mujoco><option integrator="implicitfast"/><worldbody><body><joint name="j"/><geom size=".1"/></body></worldbody><actuator>{}</actuator></mujoco>'
+  assert mjw.put_model(mjw.mjcf.from_xml_string(base.format('<position joint="j" kp="10" kv="1"/>'))).act_velfeedback == 0   # bias velocity term -kv
+  assert mjw.put_model(mjw.mjcf.from_xml_string(base.format('<motor joint="j"/>'))).act_velfeedback == 0
+  assert mjw.put_model(mjw.mjcf.from_xml_string(base.format('<general joint="j" biastype="affine" biasprm="0 0 0.5"/>'))).act_velfeedback == 1
+  assert mjw.put_model(mjw.mjcf.from_xml_string(base.format('<general joint="j" gaintype="affine" gainprm="1 0 -0.2"/>'))).act_velfeedback == 1
+  assert mjw.put_model(mjw.mjcf.load_xml(conftest.PANDA_XML)).act_velfeedback == 0  # (the Panda keeps the fused update)

@@ -3,6 +3,7 @@ height-field terrain, sleeping pile, sensor scene.  python tools/bench_scenes.py
 import os, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import mujoco_warp_amd as mjw
 from tests import test_hfield, test_mesh, test_sensor, test_sleep
