@@ -29,8 +29,8 @@ for k, c in s.get("pmc_per_dispatch", {}).items():
     k = out["kernels"][k]
     # What bounds the kernel (round 4).  SQ_BUSY_CYCLES is summed over the 32 shader engines: busy / 32 = the kernel's duration in shader
     # cycles.  A wave64 VALU instruction occupies its SIMD-32 for 2 cycles (MI355X_MICROARCH.md "Wave scheduling", profiles/round2_ubench.txt:
-    # v_fma_f32 2.06), 1,024 SIMDs; the LDS pipe is one per CU (256); SQ_WAVE_CYCLES counts 4 cycles per resident wave per quad-cycle
-    # tick on this part, so waves per SIMD = WAVE_CYCLES / (1,024 x duration) after the same normalisation used for WAIT_ANY / WAVE_CYCLES.
+    # v_fma_f32 2.06), 1,024 SIMDs; the LDS pipe is one per CU (256); SQ_WAVE_CYCLES / SQ_WAIT_ANY are in quad-cycles, so waves per SIMD =
+    # 4 x WAVE_CYCLES / (1,024 x duration) and the wait share is the plain ratio WAIT_ANY / WAVE_CYCLES.
     dur = (k["busy_cycles_sum"] or 0.0) / 32.0
     if dur > 0:
       if k["valu_insts_per_launch"] is not None:
@@ -38,7 +38,7 @@ for k, c in s.get("pmc_per_dispatch", {}).items():
       if k["lds_idx_active"] is not None:
         k["lds_busy_frac"] = k["lds_idx_active"] / (256.0 * dur)
       if k["wave_cycles"]:
-        k["waves_per_simd"] = k["wave_cycles"] / (1024.0 * dur)
+        k["waves_per_simd"] = 4.0 * k["wave_cycles"] / (1024.0 * dur)  # (SQ_WAVE_CYCLES and SQ_WAIT_ANY tick once per 4 cycles; SQ_BUSY_CYCLES counts cycles: it reproduces the launch durations)
         if k["wait_any"] is not None:
           k["wait_frac"] = k["wait_any"] / k["wave_cycles"]
       k["duration_cycles"] = dur
