@@ -418,7 +418,7 @@ def main():
                                "note": "time = k_fwd_pos_plus (FK+CoM+CRBA fused) + the solver launch; bytes = SURVEY 8(d)"}
     out["fused_launch_us"] = fused_us
     out["roofline"]["issue"] = _issue_from_profile(args.pmc_profile, args.solver)
-    out["box"] = box_fingerprint(fused_us.get("fwd_pos"))
+    out["box"] = box_fingerprint(fused_us.get("fwd_pos"), fused_us.get("mid"))
     # per-stage trace: one plain kernel per stage (the reference's event-tracer granularity)
     for k, v in snapshot.items():
       getattr(d, k).assign(v)
@@ -484,10 +484,15 @@ def _issue_from_profile(path, solver):
     return {"error": f"{path}: {e}"}
 
 
-def box_fingerprint(fwd_pos_us):
-  """Box-to-box variance on this fleet is 20-40 %: the state-independent k_fwd_pos launch time identifies a slow box,
-  rocm-smi adds clocks and power where it can be read."""
-  out = {"k_fwd_pos_us": fwd_pos_us, "note": "k_fwd_pos does the same work every step (FK + CRBA of 8192 humanoids): 47-50 us on a fast box, 55+ on a slow one"}
+def box_fingerprint(fwd_pos_us, mid_us=None):
+  """Box-to-box variance on this fleet is 20-40 % and does NOT follow the shader clock: round 4 measured the same build at
+  27.6 M (sclk 2150 MHz, 354 W; k_mid 69 us, solver 172 us) and at 19.5 M (sclk 2395 MHz, 465 W; k_mid 124 us, solver 236 us) env-steps/s with
+  k_fwd_pos at 52 / 54 us on both.  The memory-heavy k_mid launch is the discriminating fingerprint (69-85 us on a fast box, whatever the
+  contact state); rocm-smi adds clocks and power where it can be read."""
+  out = {"k_fwd_pos_us": fwd_pos_us, "k_mid_us": mid_us,
+         "slow_box": bool(mid_us is not None and mid_us > 95.0),
+         "note": "k_mid (collision + constraint assembly + velocity stage of 8192 humanoids, 150 MB of traffic) takes 69-85 us on a fast box and 105-125 us on a slow one; "
+                 "k_fwd_pos (52-54 us) does not tell them apart; slow_box = k_mid above 95 us"}
   try:
     o = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--json"], capture_output=True, text=True, timeout=20).stdout
     card = next(iter(json.loads(o).values()))

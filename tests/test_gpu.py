@@ -221,19 +221,23 @@ def test_per_step_parity_resynced(solver):
     s.step()
     worst_q = max(worst_q, relerr(d.qpos.numpy()[1], s.qpos))
     worst_v = max(worst_v, relerr(d.qvel.numpy()[1], s.qvel))
-  assert worst_q <= 1e-5, worst_q
-  assert worst_v <= 1e-3, worst_v
+  # measured (profiles/round4_parity_report.txt): Newton 2.1e-7 / 4.9e-5, CG 7.9e-7 / 2.0e-4; the float32 twin 1.8e-7 / 4.2e-5 and
+  # 8.3e-7 / 1.9e-4 -- bounds at about 2x the floor
+  tol_q, tol_v = (5e-7, 1e-4) if solver == mjw.SolverType.NEWTON else (2e-6, 4e-4)
+  assert worst_q <= tol_q, worst_q
+  assert worst_v <= tol_v, worst_v
   assert (d.overflow.numpy() == 0).all()
 
 
-# measured worst cases over these runs (tools/parity_report.py, profiles/round2_parity_report.txt): the bounds below are 2-4x them.
+# measured worst cases over these runs (tools/parity_report.py, profiles/round4_parity_report.txt, where the float32 twin of the oracle
+# shows the same figures: they are the float32 floor of the reference's algorithm): the bounds below are about 2x them.
 # qpos floor 1e-2 (rad / m), qvel floor 1e-1 (rad/s / m/s).  CG at the float32 tolerance (1e-6) stops on a different iterate than
 # the float64 oracle at the same tolerance, which is what its looser bounds measure; Newton lands inside the same basin.
 _ELEM_CASES = [
   ("humanoid", conftest.HUMANOID_XML, mjw.SolverType.NEWTON, 24, 64, 150, 8e-5, 2e-3),
-  ("humanoid", conftest.HUMANOID_XML, mjw.SolverType.CG, 24, 64, 150, 5e-4, 1e-2),
-  ("g1", conftest.G1_XML, mjw.SolverType.NEWTON, 48, 192, 60, 1e-5, 6e-4),
-  ("panda", conftest.PANDA_XML, mjw.SolverType.NEWTON, 8, 16, 60, 1e-6, 1e-5),
+  ("humanoid", conftest.HUMANOID_XML, mjw.SolverType.CG, 24, 64, 150, 2.5e-4, 6e-3),
+  ("g1", conftest.G1_XML, mjw.SolverType.NEWTON, 48, 192, 60, 1e-5, 4e-4),
+  ("panda", conftest.PANDA_XML, mjw.SolverType.NEWTON, 8, 16, 60, 4e-7, 5e-6),
   ("panda", conftest.PANDA_XML, mjw.SolverType.NEWTON, 1, 5, 60, 1e-6, 1e-5),  # BASELINE configs[3]: nconmax 1, njmax 5
 ]
 
@@ -778,20 +782,36 @@ def test_g1_cg_at_the_models_own_iteration_cap():
   mjm = mjw.mjcf.load_xml(conftest.G1_XML)
   assert mjm.opt.iterations == 10
   s, m, d = _pair(mjm, nworld=2, nconmax=48, njmax=192, solver=int(mjw.SolverType.CG), warm_steps=0)
+  # the float32 twin (the oracle's own sources compiled in float32) takes the same 10 iterations from the same state: its distance to
+  # the float64 iterate is what float32 alone does to an unconverged CG, and the engine has to stay within it
+  s32 = ref.RefSim(mjm, nconmax=48, njmax=192, tolerance=max(mjm.opt.tolerance, 1e-6), real="f32")
+  s32.reset(key=0 if mjm.nkey else None)
   worse = 0
+  e_gpu, e_twin = [], []
   for i in range(40):
     s.ctrl_noise(i, 0)
     _sync(s, d)
+    for f in ("qpos", "qvel", "act", "ctrl", "qacc_warmstart"):
+      if getattr(s, f).size:
+        getattr(s32, f)[:] = getattr(s, f)
     mjw.forward(m, d)
     s.forward()
+    s32.forward()
     if s.nefc == 0 or int(d.nefc.numpy()[1]) != s.nefc:
       s.step()
       continue
     c_gpu, c_ref, c_warm = _primal_cost(s, d.qacc.numpy()[1].astype(np.float64)), _primal_cost(s, s.qacc), _primal_cost(s, s.qacc_warmstart)
     assert c_gpu <= c_ref + 0.025 * abs(c_ref) + 1e-6, (i, c_gpu, c_ref)
     worse += c_gpu > c_warm
+    e_gpu.append(relerr(d.qacc.numpy()[1], s.qacc))
+    if s32.nefc == s.nefc:
+      e_twin.append(relerr(s32.qacc, s.qacc))
     s.step()
   assert worse == 0
+  # measured (profiles/round4_parity_report.txt, 60 steps): engine worst 0.40, twin worst 0.79
+  assert len(e_twin) >= 20
+  assert max(e_gpu) <= 1.5 * max(e_twin), (max(e_gpu), max(e_twin))
+  assert np.median(e_gpu) <= 2.0 * np.median(e_twin) + 1e-4, (np.median(e_gpu), np.median(e_twin))
 
 
 MANY_ROWS_XML = """
