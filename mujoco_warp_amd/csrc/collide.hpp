@@ -530,16 +530,17 @@ DEV void collide_convex(float tolerance, int iterations, int epa_iterations, int
 }
 
 // ---- the convex pair in two launches (round 4; convex.hpp header) -----------------------------------------------------------------------
-// GJK by ONE lane.  Returns 0: no contact, 1: one contact, emitted (no penetration deeper than the tolerance: EPA not needed), 2: EPA
+// GJK by ONE lane (CG = 0) or by the CG lanes of a group together (identical arguments in every lane; the mesh support function spreads the
+// neighbours of a hill-climbing step over the lanes).  Returns 0: no contact, 1: one contact, emitted (no penetration deeper than the tolerance: EPA not needed), 2: EPA
 // needed -- `res` holds the simplex, idx1 / idx2 the mesh vertex caches the support function left
-template <class Emit>
+template <int CG = 0, class Emit>
 DEV int convex_gjk_lane(float tolerance, int iterations, int t1, int t2, V3 p1, const float* R1, V3 s1, V3 p2, const float* R2, V3 s2, float margin, float gap, Emit&& emit,
-                        const float* vert1, int nvert1, const float* vert2, int nvert2, const MjhModel& mm, int mesh1, int mesh2, GjkOut& res, int& idx1, int& idx2) {
+                        const float* vert1, int nvert1, const float* vert2, int nvert2, const MjhModel& mm, int mesh1, int mesh2, GjkOut& res, int& idx1, int& idx2, int lig = 0) {
   auto graph_of = [&](int meshid) -> const int* { return (meshid >= 0 && mm.mesh_graphadr[meshid] >= 0) ? mm.mesh_graph + mm.mesh_graphadr[meshid] : nullptr; };
   CcdGeom a = CcdGeom{t1, p1, R1, s1, margin, vert1, nvert1, -1, mesh1, graph_of(mesh1), -1, nullptr}, b = CcdGeom{t2, p2, R2, s2, margin, vert2, nvert2, -1, mesh2, graph_of(mesh2), -1, nullptr};
   float dist;
   V3 w1, w2;
-  const int r = ccd_gjk_phase(tolerance, gap, iterations, a, b, dist, w1, w2, res);
+  const int r = ccd_gjk_phase<CG>(tolerance, gap, iterations, a, b, dist, w1, w2, res, lig);
   idx1 = a.index;
   idx2 = b.index;
   if (r == 2) return 2;
@@ -561,14 +562,23 @@ DEV void convex_epa_group(float tolerance, int epa_iterations, int t1, int t2, V
   V3 w1 = res.x1, w2 = res.x2;
   int face;
   Poly pt;
+#ifdef MJH_DBG_EPA_SKIP  // (profiling variants, tools/build_variant_fast.py: the launch without EPA / without the multi-contact recovery)
+  return;
+#endif
+  DBG_TICK_START();
   int n = ccd_epa_phase<CG>(tolerance, epa_iterations, a, b, res, poly, dist, w1, w2, overflow, face, pt, lig, 1);
+  DBG_TICK(2);  // EPA proper
   if (n == 0 || dist >= gap) return;
   dist += margin;
   const bool anymesh = t1 == G_MESH || t2 == G_MESH;
   if (face >= 0 && anymesh && ((mm.disableflags & DSBL_MULTICCD) || mm.nmeshpoly == 0)) face = -1;
+#ifdef MJH_DBG_EPA_NOMC
+  face = -1;
+#endif
   if (face >= 0) {  // zero margin: up to four contacts from the EPA face, same distance and frame (collision_convex.py:888-960)
     V3 m1[4], m2[4];
-    n = anymesh ? ccd_multicontact_mesh(mm, pt, face, w1, w2, a, b, m1, m2, mcws, 1) : ccd_multicontact_box(pt, face, w1, w2, a, b, m1, m2);
+    n = anymesh ? ccd_multicontact_mesh_inl(mm, pt, face, w1, w2, a, b, m1, m2, mcws, 1, poly, ccd_coop_poly_words(max(mm.ccd_iterations, mm.epa_iterations), mm.npolygonmax, mm.nmeshdegmax))
+                : ccd_multicontact_box(pt, face, w1, w2, a, b, m1, m2);
     if (n == 0) return;
     const Frame f = make_frame3(dist <= margin ? m1[0] - m2[0] : m2[0] - m1[0]);
     for (int i = 0; i < n; ++i) emit(i, dist, 0.5f * (m1[i] + m2[i]), f.a, f.b, f.c);
@@ -590,7 +600,7 @@ __host__ __device__ inline int ccd_handcap(int nworld, int ccap) {
   return (int)(avg > lo ? avg : lo);
 }
 DEV CcdLayout ccd_layout_of(const MjhModel& m, const MjhData& d) {
-  return ccd_layout(d.nworld, max(m.ccd_iterations, m.epa_iterations), m.nhfield, m.npolygonmax, m.nmeshdegmax, collide_ccap(m.npair, d.concap), d.nccdhand);
+  return ccd_layout(d.nworld, max(m.ccd_iterations, m.epa_iterations), m.nhfield, m.npolygonmax, m.nmeshdegmax, collide_ccap(m.npair, d.concap), d.nccdhand, m.npair);
 }
 DEV bool is_ccd_pair(const MjhModel& m, int t1, int t2) {  // the pairs served by k_ccd_gjk / k_ccd_epa (height fields stay in the contact kernel)
   return t1 != G_HFIELD && (is_convex_pair(t1, t2) || (!(m.disableflags & DSBL_NATIVECCD) && t1 == G_BOX && t2 == G_BOX));
@@ -1134,8 +1144,9 @@ __host__ __device__ inline int sap_pow2(int n) {
 }
 // k_ccd_broad's slice: position | radius per geom (4 words), candidate list, slots, queue (+ the SAP arrays)
 __host__ __device__ inline int broad_lds_words(int ngeom, int npair, int concap, int sap = 0) {
+  if (!sap) return 2 * collide_ccap(npair, concap);  // NXN: the filters ran in k_broad_mask -- candidate list and slots only
   const int base = 4 * ngeom + 2 * collide_ccap(npair, concap) + CON_WINDOW * CON_LDS;
-  return ((base + (sap ? 3 * sap_pow2(ngeom) + ((npair + 31) / 32 + 3) / 4 * 4 : 0)) + 3) / 4 * 4;
+  return ((base + 3 * sap_pow2(ngeom) + ((npair + 31) / 32 + 3) / 4 * 4) + 3) / 4 * 4;
 }
 __host__ __device__ inline int collide_lds_words(int ngeom, int npair, int concap, int sap = 0) {
   const int base = 12 * ngeom + 2 * collide_ccap(npair, concap) + CON_WINDOW * CON_LDS;
@@ -1208,7 +1219,7 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
   const float* tbl = nullptr;
   bool zero_mg = false;
   if constexpr (MODE == 1) {
-    if (m.geom_rbound_nb <= 1 && m.geom_margin_nb <= 1 && m.geom_gap_nb <= 1 && m.geom_aabb_nb <= 1) {
+    if (m.broadphase != 0 && m.geom_rbound_nb <= 1 && m.geom_margin_nb <= 1 && m.geom_gap_nb <= 1 && m.geom_aabb_nb <= 1) {  // (NXN: the filters ran in k_broad_mask)
       float* t = smem + (size_t)(blockDim.x / G) * broad_lds_words(m.ngeom, m.npair, d.concap, m.broadphase);
       const int n = m.ngeom;
       for (int i = threadIdx.x; i < n; i += blockDim.x) {
@@ -1235,7 +1246,7 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
   float* gx4 = S;  // (MODE 1 only)
   const float* gxpos = MODE == 1 ? d.geom_xpos + (size_t)w * 3 * m.ngeom : S;
   const float* gxmat = MODE == 1 ? d.geom_xmat + (size_t)w * 9 * m.ngeom : S + 3 * ng;
-  int* cand = reinterpret_cast<int*>(S + (MODE == 1 ? 4 * ng : 12 * ng));
+  int* cand = reinterpret_cast<int*>(S + (MODE == 1 ? (m.broadphase != 0 ? 4 * ng : 0) : 12 * ng));
   const int ccap = collide_ccap(npair, ncap);
   int* cslot = cand + ccap;
   float* rec = reinterpret_cast<float*>(cslot + ccap);
@@ -1265,7 +1276,7 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
   const float* ggap = tbl ? tbl + 2 * ng : bf(m.geom_gap, m.geom_gap_nb, w, ng);
   const float* gsize = bf(m.geom_size, m.geom_size_nb, w, 3 * ng);
   gsync();
-  if constexpr (MODE == 1) {
+  if (MODE == 1 && m.broadphase != 0) {  // (the NXN tests ran in k_broad_mask)
     for (int g = lig; g < ng; g += G) {
       gx4[4 * g] = gxpos[3 * g];
       gx4[4 * g + 1] = gxpos[3 * g + 1];
@@ -1369,12 +1380,13 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
   int nq = 0;
   const bool box_filters = HEAVY && (filt & 12) != 0;
   auto stage_b = [&](bool all) __attribute__((always_inline)) {  // entries: pair | 1 << 30 if the pair skips the box filters (plane pairs)
+    int qh = 0;  // the queue is consumed from its head; what stays behind (fewer than G entries) moves to the front at the end
     while (nq >= G || (all && nq > 0)) {
       const int n = nq < G ? nq : G;
       bool pass = false;
       int p = 0;
       if (lig < n) {
-        const int e = queue[lig];
+        const int e = queue[qh + lig];
         p = e & 0x3fffffff;
         pass = true;
         if (!(e >> 30)) {
@@ -1390,29 +1402,55 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
       const int rank = grank<G>(pass, lig, tot);
       if (pass && ncand + rank < ccap) cand[ncand + rank] = p;
       ncand += tot;
-      // the rest of the queue moves to the front (fewer than PU * G + G entries)
-      gsync();
-      int moved[PU + 1];
-#pragma unroll
-      for (int k = 0; k <= PU; ++k) moved[k] = (n + k * G + lig < nq) ? queue[n + k * G + lig] : 0;
-      gsync();
-#pragma unroll
-      for (int k = 0; k <= PU; ++k)
-        if (n + k * G + lig < nq) queue[k * G + lig] = moved[k];
+      qh += n;
       nq -= n;
-      gsync();
     }
+    if (qh > 0 && nq > 0) {
+      gsync();
+      const int v = lig < nq ? queue[qh + lig] : 0;
+      gsync();
+      if (lig < nq) queue[lig] = v;
+    }
+    gsync();
   };
 #ifdef MJH_DBG_BROAD_SKIP  // (profiling variant, tools/build_variant_fast.py: the launch without its pair loop)
   if (MODE == 1) nq = 0; else
 #endif
   // (the pair ids of the NEXT trip are loaded before this trip's tests: at one wavefront per SIMD the table's L2 round trip -- 73 KB read by
   // every world -- was the chain: 72 trips x ~2.5 us)
+  bool from_mask = false;
+  if constexpr (MODE == 1) {
+    // NXN broadphase: the filters ran in k_broad_mask; expand its mask in pair order -- each lane the set bits of one word per trip
+    if (m.broadphase == 0) {
+      from_mask = true;
+      const unsigned* mk = reinterpret_cast<const unsigned*>(ccd_world + CL.bmask);
+      for (int base = 0; base < CL.nbw; base += G) {
+        const int wi = base + lig;
+        unsigned bits = wi < CL.nbw ? mk[wi] : 0u;
+        const int cnt = __popc(bits);
+        int off = cnt;  // inclusive prefix over the lanes of the group
+#pragma unroll
+        for (int sft = 1; sft < G; sft <<= 1) {
+          const int o = __shfl_up(off, sft, G);
+          if (lig >= sft) off += o;
+        }
+        const int tot = __shfl(off, G - 1, G);
+        int o = ncand + off - cnt;
+        while (bits) {
+          const int bit = __ffs(bits) - 1;
+          bits &= bits - 1;
+          if (o < ccap) cand[o] = 32 * wi + bit;
+          ++o;
+        }
+        ncand += tot;
+      }
+    }
+  }
   const int2* pairs2 = reinterpret_cast<const int2*>(m.nxn_geom_pair);
   int2 cur[PU];
 #pragma unroll
   for (int u = 0; u < PU; ++u) cur[u] = (u * G + lig < npair) ? pairs2[u * G + lig] : make_int2(0, 0);
-  for (int base = 0; base < npair; base += PU * G) {
+  for (int base = 0; base < (from_mask ? 0 : npair); base += PU * G) {
     bool passu[PU];
     bool plainu[PU];
     int2 nxt[PU];
@@ -1491,7 +1529,7 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
 #pragma unroll
     for (int u = 0; u < PU; ++u) cur[u] = nxt[u];
   }
-  if (box_filters) stage_b(true);
+  if (box_filters && !from_mask) stage_b(true);
   nbroad = ncand;  // candidates found (Data.ncollision); the capacity bounds what the narrowphase sees
   if (ncand > ccap) ncand = ccap;
   gsync();
@@ -1774,6 +1812,156 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
 }
 
 // ---- the three launches of the convex narrowphase (convex.hpp header) -------------------------------------------------------------------
+// ---- k_broad_mask: the broadphase FILTERS of one world per workgroup, results as a bit mask over the pair list (round 4) -------------------
+// k_ccd_broad used to run the filters inside its per-world lane group: 32 lanes walking the world's whole pair list (ALOHA scene: 9,154
+// pairs, 36 trips of 256) with the candidate list and a queue in LDS -- at most 1.5 wavefronts per SIMD, 480 of the launch's 505 us.  The
+// tests of different pairs do not depend on each other and their results are ordered by the pair index alone, so they leave that kernel:
+//   * a workgroup (four wavefronts) takes one world; it stages, per geom, position | bounding radius, margin, gap and -- with the AABB filter
+//     on -- the world-aligned box (centre +- extent, the pair-independent half of _aabb_filter) in LDS, plus rotation and local box for the OBB filter: 34 words per geom;
+//   * a wavefront tests 64 consecutive pairs at a time: plane / bounding sphere, sleep state, then the box overlap as six compares;
+//   * the OBB filter (separating axes, ~250 instructions) runs on the survivors only, queued per wavefront and served 64 at a time;
+//   * the ballots of the tests are the world's mask (CcdLayout::bmask, bit p % 32 of word p / 32), which k_ccd_broad expands in pair order:
+//     the candidate list is the serial loop's.
+// Filters: collision_driver.py:124-275 (_aabb_filter, _obb_filter), 278-334 (_plane_filter, _sphere_filter), 494-503 (sleep).
+__host__ __device__ inline int bmask_lds_words(int ngeom, int npair) { return 34 * ngeom + 2 * ((npair + 63) / 64) + 4 * 256 + 8; }
+__global__ void __launch_bounds__(256) k_broad_mask(MjhModel m, MjhData d) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  if (m.disableflags & (DSBL_CONSTRAINT | DSBL_CONTACT)) return;
+  const int ng = m.ngeom, npair = m.npair, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int ngran = (npair + 63) / 64;
+  const CcdLayout CL = ccd_layout_of(m, d);
+  const int filt = m.broadphase_filter;
+  const bool use_aabb = (filt & 4) != 0, use_obb = (filt & 8) != 0;
+  float* gx4 = smem;                 // x y z rbound
+  float* hl = gx4 + 4 * ng;          // hi.x hi.y hi.z lo.x | lo.y lo.z - -   (world-aligned box of the geom's local box)
+  float* rl = hl + 8 * ng;           // rotation matrix (9 words of 12) and local box (6 words of 8): what the OBB filter reads
+  float* ab = rl + 12 * ng;
+  float* gm = ab + 8 * ng;           // margin
+  float* gp = gm + ng;               // gap
+  unsigned* fm = reinterpret_cast<unsigned*>(gp + ng);  // the world's mask
+  int2* queue = reinterpret_cast<int2*>(fm + ((2 * ngran + 1) & ~1)) + wv * 128;  // this wavefront's OBB queue: (pair, g1 | g2 << 16)
+  const int2* pairs2 = reinterpret_cast<const int2*>(m.nxn_geom_pair);
+  for (int w = blockIdx.x; w < d.nworld; w += gridDim.x) {
+    if (d.sleep_pass == 2 && !d.ws_sleep_flag[w]) continue;  // (uniform over the workgroup; k_ccd_broad skips these worlds too)
+    const float* gxpos = d.geom_xpos + (size_t)w * 3 * ng;
+    const float* gxmat = d.geom_xmat + (size_t)w * 9 * ng;
+    const float* gaabb = bf(m.geom_aabb, m.geom_aabb_nb, w, 6 * ng);
+    __syncthreads();  // the previous world's readers are done
+    bool nz = false;  // any margin or gap in this world's tables
+    {
+      const float* rb = bf(m.geom_rbound, m.geom_rbound_nb, w, ng);
+      const float* mg = bf(m.geom_margin, m.geom_margin_nb, w, ng);
+      const float* ga = bf(m.geom_gap, m.geom_gap_nb, w, ng);
+      for (int g = tid; g < ng; g += 256) {
+        const V3 x = ld3(gxpos + 3 * g);
+        *reinterpret_cast<float4*>(gx4 + 4 * g) = make_float4(x.x, x.y, x.z, rb[g]);
+        gm[g] = mg[g];
+        gp[g] = ga[g];
+        nz |= mg[g] != 0.0f || ga[g] != 0.0f;
+        if (use_aabb || use_obb) {
+          const float* R = gxmat + 9 * g;
+          const float* a = gaabb + 6 * g;
+          if (use_obb) {
+            *reinterpret_cast<float4*>(rl + 12 * g) = make_float4(R[0], R[1], R[2], R[3]);
+            *reinterpret_cast<float4*>(rl + 12 * g + 4) = make_float4(R[4], R[5], R[6], R[7]);
+            rl[12 * g + 8] = R[8];
+            *reinterpret_cast<float4*>(ab + 8 * g) = make_float4(a[0], a[1], a[2], a[3]);
+            *reinterpret_cast<float2*>(ab + 8 * g + 4) = make_float2(a[4], a[5]);
+          }
+          // as aabb_filter: centre R a + x, extent along world axis k = sum of the absolute terms
+          const V3 c = mat_mul(R, ld3(a)) + x;
+          const float sx = a[3], sy = a[4], sz = a[5];
+          const float ex = fabsf(R[0] * sx) + fabsf(R[1] * sy) + fabsf(R[2] * sz);
+          const float ey = fabsf(R[3] * sx) + fabsf(R[4] * sy) + fabsf(R[5] * sz);
+          const float ez = fabsf(R[6] * sx) + fabsf(R[7] * sy) + fabsf(R[8] * sz);
+          *reinterpret_cast<float4*>(hl + 8 * g) = make_float4(c.x + ex, c.y + ey, c.z + ez, c.x + -ex);
+          *reinterpret_cast<float2*>(hl + 8 * g + 4) = make_float2(c.y + -ey, c.z + -ez);
+        }
+      }
+    }
+    const bool zero_mg = !__syncthreads_or(nz);  // (also the barrier behind the staging) no margins, no gaps: four table reads per pair less
+    const int* bawake = m.sleep_enabled ? d.body_awake + (size_t)w * m.nbody : nullptr;
+    int nq = 0;
+    auto obb_round = [&](int n) __attribute__((always_inline)) {  // the first n queue entries (n <= 64)
+      if (lane < n) {
+        const int2 e = queue[lane];
+        const int p = e.x, g1 = e.y & 0xffff, g2 = (e.y >> 16) & 0xffff;
+        const int pid = m.nexplicit ? m.nxn_pairid[p] : -1;
+        const float mgn = pid >= 0 ? m.pair_margin[pid] + m.pair_gap[pid] : (zero_mg ? 0.0f : gm[g1] + gp[g1] + gm[g2] + gp[g2]);
+        const float4 a = *reinterpret_cast<const float4*>(gx4 + 4 * g1), b = *reinterpret_cast<const float4*>(gx4 + 4 * g2);
+        if (obb_filter(ab + 8 * g1, ab + 8 * g2, mgn, V3{a.x, a.y, a.z}, V3{b.x, b.y, b.z}, rl + 12 * g1, rl + 12 * g2))
+          atomicOr(fm + (p >> 5), 1u << (p & 31));
+      }
+    };
+    int2 nxt = (64 * wv + lane < npair) ? pairs2[64 * wv + lane] : make_int2(0, 0);
+    for (int gi = wv; gi < ngran; gi += 4) {
+      const int p = 64 * gi + lane;
+      const int2 cur = nxt;
+      nxt = (p + 256 < npair) ? pairs2[p + 256] : make_int2(0, 0);
+      bool pass = false, plain = false;
+      const int g1 = cur.x, g2 = cur.y;
+      if (p < npair) {
+        const float4 a = *reinterpret_cast<const float4*>(gx4 + 4 * g1), b = *reinterpret_cast<const float4*>(gx4 + 4 * g2);
+        const V3 x1 = V3{a.x, a.y, a.z}, x2 = V3{b.x, b.y, b.z};
+        const float rb1 = a.w, rb2 = b.w;
+        const int pid = m.nexplicit ? m.nxn_pairid[p] : -1;
+        const float mgn = pid >= 0 ? m.pair_margin[pid] + m.pair_gap[pid] : (zero_mg ? 0.0f : gm[g1] + gp[g1] + gm[g2] + gp[g2]);
+        if (rb1 == 0.0f || rb2 == 0.0f) {
+          plain = true;
+          if (!(filt & 1)) {
+            pass = true;
+          } else if (rb1 == 0.0f) {
+            const float* R = gxmat + 9 * g1;
+            pass = dot(x2 - x1, V3{R[2], R[5], R[8]}) <= rb2 + mgn;
+          } else {
+            const float* R = gxmat + 9 * g2;
+            pass = dot(x1 - x2, V3{R[2], R[5], R[8]}) <= rb1 + mgn;
+          }
+        } else {
+          pass = true;
+          if (filt & 2) {
+            const float bound = rb1 + rb2 + mgn;
+            const V3 dif = x2 - x1;
+            pass = dot(dif, dif) <= bound * bound;
+          }
+        }
+        if (bawake && pass) {  // collision_driver.py:494-503: no pair of two sleeping bodies, or of a sleeping and a static one
+          const int s1 = bawake[m.geom_bodyid[g1]], s2 = bawake[m.geom_bodyid[g2]];
+          if ((s1 == 0 && s2 == 0) || (s1 == 0 && s2 == -1) || (s2 == 0 && s1 == -1)) pass = false;
+        }
+        if (use_aabb && pass && !plain) {
+          const float4 h1 = *reinterpret_cast<const float4*>(hl + 8 * g1), h2 = *reinterpret_cast<const float4*>(hl + 8 * g2);
+          const float2 l1 = *reinterpret_cast<const float2*>(hl + 8 * g1 + 4), l2 = *reinterpret_cast<const float2*>(hl + 8 * g2 + 4);
+          if (h1.x + mgn < h2.w || h2.x + mgn < h1.w || h1.y + mgn < l2.x || h2.y + mgn < l1.x || h1.z + mgn < l2.y || h2.z + mgn < l1.y) pass = false;
+        }
+      }
+      const bool need = use_obb && pass && !plain;  // still to pass the OBB filter
+      const unsigned long long bn = __ballot(need), bp = __ballot(pass) & ~bn;
+      if (lane == 0) {
+        fm[2 * gi] = (unsigned)bp;
+        fm[2 * gi + 1] = (unsigned)(bp >> 32);
+      }
+      if (use_obb) {
+        if (need) queue[nq + __popcll(bn & ((1ull << lane) - 1ull))] = make_int2(p, g1 | (g2 << 16));
+        nq += __popcll(bn);
+        gsync();
+        if (nq >= 64) {
+          obb_round(64);
+          gsync();
+          const int2 v = (64 + lane < nq) ? queue[64 + lane] : make_int2(0, 0);
+          gsync();
+          if (64 + lane < nq) queue[lane] = v;
+          nq -= 64;
+          gsync();
+        }
+      }
+    }
+    if (use_obb && nq > 0) obb_round(nq);
+    __syncthreads();
+    unsigned* mk = reinterpret_cast<unsigned*>(d.ws_ccd + (size_t)w * CL.world_stride + CL.bmask);
+    for (int i = tid; i < 2 * ngran; i += 256) mk[i] = fm[i];
+  }
+}
 __global__ void k_ccd_reset(int* cnt) {
   if (threadIdx.x < 8) cnt[threadIdx.x] = 0;
 }
@@ -1782,14 +1970,30 @@ __global__ void __launch_bounds__(256) k_ccd_broad(MjhModel m, MjhData d) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   collision_body<G, true, 1>(m, d, smem, blk_of_launch<G>());
 }
-// one LANE per entry of the flat convex list: GJK; the result to the candidate's cache entry, penetrating pairs to the EPA list
-__global__ void __launch_bounds__(256) k_ccd_gjk(MjhModel m, MjhData d) {
+// GJK for every entry of the flat convex list; the result to the candidate's cache entry, penetrating pairs to the EPA list.
+// CGJ = 1: one LANE per entry.  CGJ = 8 / 16 / 32: a group of CGJ lanes per entry -- chosen by the launch when the list is too short to fill the
+// device with one lane per entry: on the ALOHA scene a world has 3-14 convex candidates (65 k lanes = ONE wavefront per SIMD) and a pair
+// evaluates 80-360 hill-climbing neighbours (the pot's vertices have up to 43) one after the other, three dependent loads each: 400 us of
+// latency on an idle device.  The group spreads a step's neighbours over its lanes (ccd_support_c: the serial scan's result, ties included).
+// The list's length is only known on the device: the launch enqueues the instantiations back to back and each returns at once unless the
+// length lies in its range [lo, hi).
+template <int CGJ>
+__global__ void __launch_bounds__(256) k_ccd_gjk(MjhModel m, MjhData d, int lo, int hi) {
   const CcdLayout CL = ccd_layout_of(m, d);
   int* cnt = reinterpret_cast<int*>(d.ws_ccd + CL.cnt);
+#ifdef MJH_DBG_GJK_STATS
+  g_dbg_cnt = cnt;
+#endif
+#ifdef MJH_DBG_GJK_CLOCK
+  g_dbg_gclk = cnt;
+  unsigned long long kt0_ = __builtin_amdgcn_s_memtime();
+#endif
   const int nlist = min(cnt[0], CL.listcap);
+  if (nlist < lo || nlist >= hi) return;
   // (the launch is sized for the device, not for the list's capacity: whole wavefronts walk the list with the grid's stride)
-  for (int t0 = blockIdx.x * blockDim.x; t0 < nlist; t0 += gridDim.x * blockDim.x) {
-  const int t = t0 + threadIdx.x;
+  const int lig = threadIdx.x & (CGJ - 1);
+  for (int t0 = blockIdx.x * (blockDim.x / CGJ); t0 < nlist; t0 += gridDim.x * (blockDim.x / CGJ)) {
+  const int t = t0 + (int)threadIdx.x / CGJ;
   int st = 0, w = 0, p = 0, slot = 0, idx1 = -1, idx2 = -1;
   GjkOut res;
   if (t < nlist) {
@@ -1819,10 +2023,25 @@ __global__ void __launch_bounds__(256) k_ccd_gjk(MjhModel m, MjhData d) {
     float* cache = d.ws_ccd + (size_t)w * CL.world_stride + CL.cache + (size_t)slot * CCD_CACHE_WORDS;
     int nem = 0;
     const float ccd_tol = bf(m.opt_ccd_tolerance, m.opt_ccd_tolerance_nb, w, 1)[0];
-    st = convex_gjk_lane(ccd_tol, min(m.ccd_iterations, CCD_MAX_ITER), t1, t2, ld3(gxpos + 3 * g1), gxmat + 9 * g1, ld3(gsize + 3 * g1), ld3(gxpos + 3 * g2), gxmat + 9 * g2,
-                         ld3(gsize + 3 * g2), margin, gap, [&](int k, float dist, V3 pos, V3 fa, V3 fb, V3 fc) { ccd_cache_store(cache, nem, k, dist, pos, fa, fb, fc, true); },
-                         mv1, mn1, mv2, mn2, m, me1, me2, res, idx1, idx2);
-    reinterpret_cast<int*>(cache)[0] = nem;
+#ifdef MJH_DBG_GJK_CLOCK
+    if (lig == 0) atomicAdd(cnt + 5, (int)((__builtin_amdgcn_s_memtime() - kt0_) >> 10));  // pair set-up
+    kt0_ = __builtin_amdgcn_s_memtime();
+#endif
+#ifdef MJH_DBG_GJK_ITER  // (profiling variants: 0 = the launch without GJK, n = at most n iterations)
+    const int gjk_cap = MJH_DBG_GJK_ITER;
+    if (gjk_cap > 0)
+#else
+    const int gjk_cap = CCD_MAX_ITER;
+#endif
+    st = convex_gjk_lane<(CGJ > 1 ? CGJ : 0)>(ccd_tol, min(m.ccd_iterations, gjk_cap), t1, t2, ld3(gxpos + 3 * g1), gxmat + 9 * g1, ld3(gsize + 3 * g1), ld3(gxpos + 3 * g2), gxmat + 9 * g2,
+                         ld3(gsize + 3 * g2), margin, gap, [&](int k, float dist, V3 pos, V3 fa, V3 fb, V3 fc) { ccd_cache_store(cache, nem, k, dist, pos, fa, fb, fc, lig == 0); },
+                         mv1, mn1, mv2, mn2, m, me1, me2, res, idx1, idx2, lig);
+    if (lig == 0) reinterpret_cast<int*>(cache)[0] = nem;
+#ifdef MJH_DBG_GJK_CLOCK
+    if (lig == 0) atomicAdd(cnt + 6, (int)((__builtin_amdgcn_s_memtime() - kt0_) >> 10));  // the whole GJK phase
+    kt0_ = __builtin_amdgcn_s_memtime();
+#endif
+    if (lig != 0) st = 0;  // (the group's first lane hands the pair over)
   }
   // penetrating pairs: one reservation per wavefront in the EPA list, then every such lane writes its hand-over record
   const unsigned long long em = __ballot(st == 2);
@@ -1861,9 +2080,12 @@ __global__ void __launch_bounds__(256) k_ccd_epa(MjhModel m, MjhData d) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const CcdLayout CL = ccd_layout_of(m, d);
   const int npend = min(reinterpret_cast<const int*>(d.ws_ccd + CL.cnt)[1], CL.handcap);
+#ifdef MJH_DBG_EPA_CLOCK
+  g_dbg_clk = reinterpret_cast<int*>(d.ws_ccd + CL.cnt);
+#endif
   const int lig = threadIdx.x & (G - 1), gib = threadIdx.x / G;
   const int it = max(m.ccd_iterations, m.epa_iterations);
-  float* poly = smem + (size_t)gib * ccd_coop_words(it);
+  float* poly = smem + (size_t)gib * ccd_coop_words(it, m.npolygonmax, m.nmeshdegmax);
   for (int h = blockIdx.x * (blockDim.x / G) + gib; h < npend; h += gridDim.x * (blockDim.x / G)) {
   const float* hand = d.ws_ccd + CL.hand + (size_t)h * CCD_HAND_WORDS;
   const int* hi = reinterpret_cast<const int*>(hand);

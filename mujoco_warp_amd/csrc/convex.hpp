@@ -70,17 +70,21 @@ __host__ __device__ inline int ccd_words(int iterations, int hfield = 0) {
 #define CCD_HAND_WORDS 64
 struct CcdLayout {
   size_t world_stride;  // floats per world
-  size_t hf, cache, cand;  // offsets inside a world's slice
+  size_t hf, cache, cand, bmask;  // offsets inside a world's slice
   size_t tail, cnt, list, hand, mc, total;  // offsets from the start of ws_ccd
-  int ccap, listcap, handcap, mcw;
+  int ccap, listcap, handcap, mcw, nbw;
 };
-__host__ __device__ inline CcdLayout ccd_layout(int nworld, int iterations, int nhfield, int npolygonmax, int nmeshdegmax, int ccap, int handcap) {
+__host__ __device__ inline CcdLayout ccd_layout(int nworld, int iterations, int nhfield, int npolygonmax, int nmeshdegmax, int ccap, int handcap, int npair) {
   CcdLayout L;
   L.ccap = ccap;
   L.hf = 0;
   L.cache = nhfield ? (size_t)(ccd_poly_words(iterations) + CCD_CACHE_SLOTS * CCD_CACHE_WORDS + CCD_HF_WORDS) * CCD_LANES : 0;
   L.cand = L.cache + (size_t)ccap * CCD_CACHE_WORDS;
-  L.world_stride = ((L.cand + ccap + 4 + 3) / 4) * 4;
+  // k_broad_mask's bit mask over the filtered pair list (bit p % 32 of word p / 32): the pairs that passed the broadphase filters; 64-pair
+  // granules, one per wavefront trip of that launch
+  L.nbw = 2 * ((npair + 63) / 64);
+  L.bmask = ((L.cand + ccap + 4 + 3) / 4) * 4;
+  L.world_stride = ((L.bmask + (size_t)L.nbw + 3) / 4) * 4;
   L.tail = L.world_stride * (size_t)nworld;
   L.cnt = L.tail;
   L.listcap = nworld * ccap;  // (every candidate of every world may be convex)
@@ -92,9 +96,53 @@ __host__ __device__ inline CcdLayout ccd_layout(int nworld, int iterations, int 
   L.total = L.mc + (size_t)handcap * L.mcw;
   return L;
 }
-__host__ __device__ inline int ccd_coop_words(int iterations) { return ((ccd_poly_words(iterations) + 3) / 4) * 4; }
+// LDS words of an EPA group: the polytope; for models with multi-contact recovery on mesh faces (nmeshdegmax > 0) also the polygon buffers of
+// that recovery -- the clipping planes and the two clip buffers (16 P words, P = npolygonmax) OVER the polytope, which is dead by the time
+// they are written, and the two faces (6 P words) behind them
+__host__ __device__ inline int ccd_coop_poly_words(int iterations, int npolygonmax, int nmeshdegmax) {
+  const int pw = ccd_poly_words(iterations), P = npolygonmax > 4 ? npolygonmax : 4;
+  return nmeshdegmax > 0 && 16 * P > pw ? 16 * P : pw;
+}
+__host__ __device__ inline int ccd_coop_words(int iterations, int npolygonmax, int nmeshdegmax) {
+  const int P = npolygonmax > 4 ? npolygonmax : 4;
+  return ((ccd_coop_poly_words(iterations, npolygonmax, nmeshdegmax) + (nmeshdegmax > 0 ? 6 * P : 0) + 3) / 4) * 4;
+}
 // (models with multi-contact recovery on mesh faces append ccd_mc_words(npolygonmax, nmeshdegmax) words per lane: further below)
 
+#ifdef MJH_DBG_GJK_STATS  // (profiling variant: GJK iterations / hill-climbing steps / neighbour evaluations summed into the list counters 2..6)
+__device__ int* g_dbg_cnt;
+#define DBG_COUNT(k, n) atomicAdd(g_dbg_cnt + (k), (n))
+#define DBG_MAX(k, n) atomicMax(g_dbg_cnt + (k), (n))
+#else
+#define DBG_COUNT(k, n)
+#define DBG_MAX(k, n)
+#endif
+#ifdef MJH_DBG_GJK_CLOCK  // (profiling variant: shader-clock ticks of k_ccd_gjk's phases, lane 0 of every group, summed into the counters 2..7 in units of 1024 ticks)
+__device__ int* g_dbg_gclk;
+#define GJK_TICK(k)                                                                 \
+  do {                                                                              \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();                   \
+    if (lig == 0) atomicAdd(g_dbg_gclk + (k), (int)((now_ - gjk_t0_) >> 10));        \
+    gjk_t0_ = __builtin_amdgcn_s_memtime();                                         \
+  } while (0)
+#define GJK_TICK_START() unsigned long long gjk_t0_ = __builtin_amdgcn_s_memtime()
+#else
+#define GJK_TICK(k)
+#define GJK_TICK_START()
+#endif
+#ifdef MJH_DBG_EPA_CLOCK  // (profiling variant: shader-clock ticks of the EPA kernel's phases, lane 0 of every group, summed into the counters 2..7 in units of 16 ticks)
+__device__ int* g_dbg_clk;
+#define DBG_TICK(k)                                                                      \
+  do {                                                                                   \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();                        \
+    if ((threadIdx.x & 31) == 0) atomicAdd(g_dbg_clk + (k), (int)((now_ - dbg_t0_) >> 4)); \
+    dbg_t0_ = __builtin_amdgcn_s_memtime();                                              \
+  } while (0)
+#define DBG_TICK_START() unsigned long long dbg_t0_ = __builtin_amdgcn_s_memtime()
+#else
+#define DBG_TICK(k)
+#define DBG_TICK_START()
+#endif
 struct CcdGeom {
   int type;
   V3 pos;
@@ -171,7 +219,9 @@ DEV V3 ccd_support(const CcdGeom& g, V3 dir, int& vid) {
     float best = dot(l, ld3(g.vert + 3 * globalid[imax]));
     while (imax != prev) {
       prev = imax;
+      DBG_COUNT(4, 1);
       for (int i = edgeadr[imax]; edge[i] >= 0; ++i) {
+        DBG_COUNT(5, 1);
         const float dd = dot(l, ld3(g.vert + 3 * globalid[edge[i]]));
         if (dd > best) {
           best = dd;
@@ -405,6 +455,7 @@ template <int CG = 0>
 DEV void ccd_gjk(float tolerance, int iterations, const CcdGeom& g1, const CcdGeom& g2, V3 x1_0, V3 x2_0, float cutoff, bool is_discrete,
                  GjkOut& res, int lig = 0) {
   int n = 0;
+  GJK_TICK_START();
   float lam[4] = {1.0f, 0.0f, 0.0f, 0.0f};
   const float epsilon = is_discrete ? 0.0f : 0.5f * tolerance * tolerance, min_norm = is_discrete ? CCD_MINVAL : tolerance;
   V3 xk = x1_0 - x2_0;
@@ -420,6 +471,8 @@ DEV void ccd_gjk(float tolerance, int iterations, const CcdGeom& g1, const CcdGe
   res.x1 = res.x2 = V3{0.0f, 0.0f, 0.0f};
   for (int it = 0; it < iterations; ++it) {
     if (xnorm < min_norm || fabsf(xnorm_prev - xnorm) < CCD_MINVAL) break;
+    DBG_COUNT(2, 1);
+    DBG_MAX(3, it + 1);
     V3 dneg = xk * (1.0f / xnorm);
     if (is_discrete && xnorm < 1e-4f) {
       if (n == 2) {
@@ -437,7 +490,9 @@ DEV void ccd_gjk(float tolerance, int iterations, const CcdGeom& g1, const CcdGe
       }
     }
     int v1, v2;
+    GJK_TICK(3);  // simplex arithmetic
     const V3 p1 = ccd_sup<CG>(g1, -dneg, v1, lig), p2 = ccd_sup<CG>(g2, dneg, v2, lig);
+    GJK_TICK(2);  // supports
     const_cast<CcdGeom&>(g1).index = g1.cache;  // collision_gjk.py:675-680 (only meshes read it)
     const_cast<CcdGeom&>(g2).index = g2.cache;
     const V3 sn = p1 - p2;
@@ -489,6 +544,7 @@ DEV void ccd_gjk(float tolerance, int iterations, const CcdGeom& g1, const CcdGe
     xnorm = sqrtf(dot(xk, xk));
     if (n == 4) break;
   }
+  GJK_TICK(3);
   res.separated = false;
   res.x1 = n == 0 ? x1_0 : ccd_combine(n, lam, res.s1);
   res.x2 = n == 0 ? x2_0 : ccd_combine(n, lam, res.s2);
@@ -498,6 +554,7 @@ DEV void ccd_gjk(float tolerance, int iterations, const CcdGeom& g1, const CcdGe
     const V3 p1 = ccd_sup<CG>(g1, -dir, v, lig), p2 = ccd_sup<CG>(g2, dir, v, lig);
     res.separated = dot(xk, p1 - p2) > 0.0f;
   }
+  GJK_TICK(4);  // closing support pair
   res.dist = (n == 4 && !res.separated) ? 0.0f : xnorm;
   res.dim = n;
   // The separation test above fires once the lower bound x_k . s reaches cutoff |x_k|; at convergence that bound is |x_k|^2, so a pair
@@ -1192,6 +1249,7 @@ DEV int mc_polygon_clip(const V3 (&face1)[4], int nface1, const V3 (&face2)[4], 
   return np;
 }
 DEV int ccd_multicontact_box(const Poly& pt, int epa_face, V3 x1, V3 x2, const CcdGeom& g1, const CcdGeom& g2, V3 (&w1)[4], V3 (&w2)[4]) {
+  DBG_TICK_START();
   w1[0] = x1;
   w2[0] = x2;
   const unsigned fc = (unsigned)pt.face(epa_face);
@@ -1377,6 +1435,9 @@ DEV int mc_mesh_face(const MeshTab& t, const CcdGeom& g, int idx, int cap, const
 DEV int mc_polygon_clip_ws(const WsV& face1, int nface1, const WsV& face2, int nface2, V3 n, V3 dir, int cap, const WsV& pn, const WsF& pd, WsV poly, WsV clip,
                            V3 (&w1)[4], V3 (&w2)[4]) {
   if (nface1 < 3) return 0;
+#ifdef MJH_DBG_EPA_CLOCK
+  unsigned long long dbg_c0_ = __builtin_amdgcn_s_memtime();
+#endif
   for (int i = 0; i < nface1; ++i) {
     const V3 a = face1.get(i), b = face1.get((i + 1) % nface1);
     const V3 pni = cross(b - a, (a + n) - a);
@@ -1418,6 +1479,10 @@ DEV int mc_polygon_clip_ws(const WsV& face1, int nface1, const WsV& face2, int n
     np = nc;
     nc = 0;
   }
+#ifdef MJH_DBG_EPA_CLOCK
+  if ((threadIdx.x & 31) == 0) atomicAdd(g_dbg_clk + 5, (int)((__builtin_amdgcn_s_memtime() - dbg_c0_) >> 4));  // planes + clip loop
+  dbg_c0_ = __builtin_amdgcn_s_memtime();
+#endif
   if (np < 1) return 0;
   if (nface2 == 2 && np > 2) {
     int b1 = 0, b2 = 1;
@@ -1447,6 +1512,10 @@ DEV int mc_polygon_clip_ws(const WsV& face1, int nface1, const WsV& face2, int n
       w2[i] = poly.get(q[i]);
       w1[i] = w2[i] - dir;
     }
+#ifdef MJH_DBG_EPA_CLOCK
+    if ((threadIdx.x & 31) == 0) atomicAdd(g_dbg_clk + 6, (int)((__builtin_amdgcn_s_memtime() - dbg_c0_) >> 4));  // pruning to four points
+    if ((threadIdx.x & 31) == 0) atomicAdd(g_dbg_clk + 7, np);
+#endif
     return 4;
   }
   for (int i = 0; i < np; ++i) {
@@ -1456,8 +1525,12 @@ DEV int mc_polygon_clip_ws(const WsV& face1, int nface1, const WsV& face2, int n
   return np;
 }
 // ws = the lane's multi-contact words (behind the polytope, the contact cache and the height-field table of Data.ws_ccd)
-__device__ __noinline__ int ccd_multicontact_mesh(const MjhModel& m, const Poly& pt, int epa_face, V3 x1, V3 x2, const CcdGeom& g1, const CcdGeom& g2,
-                                                  V3 (&w1)[4], V3 (&w2)[4], float* ws, int wst = CCD_LANES) {
+// (two entry points: inlined into k_ccd_epa -- behind a call every field of `m`, `pt`, `g1`, `g2` is a flat load from the caller's stack: the
+// out-of-line copy ran at ~18 cycles per instruction, 70 % of that launch -- and out of line for the one-lane callers of the contact kernel,
+// whose register budget it would otherwise raise)
+DEV int ccd_multicontact_mesh_inl(const MjhModel& m, const Poly& pt, int epa_face, V3 x1, V3 x2, const CcdGeom& g1, const CcdGeom& g2,
+                                  V3 (&w1)[4], V3 (&w2)[4], float* ws, int wst = CCD_LANES, float* lds = nullptr, int lds_face = 0) {
+  DBG_TICK_START();
   w1[0] = x1;
   w2[0] = x2;
   const unsigned fc = (unsigned)pt.face(epa_face);
@@ -1469,9 +1542,12 @@ __device__ __noinline__ int ccd_multicontact_mesh(const MjhModel& m, const Poly&
   const WsI idx1{reinterpret_cast<int*>(at(0)), wst}, idx2{reinterpret_cast<int*>(at(D)), wst};
   const WsV n1{at(2 * D), wst}, n2{at(5 * D), wst}, endv{at(8 * D), wst};
   const int f0 = 11 * D;
-  const WsV face1{at(f0), wst}, face2{at(f0 + 3 * P), wst}, pn{at(f0 + 6 * P), wst};
-  const WsF pd{at(f0 + 9 * P), wst};
-  const WsV bufa{at(f0 + 10 * P), wst}, bufb{at(f0 + 16 * P), wst};
+  // an EPA group (lds != nullptr): the polygon buffers in the group's LDS (ccd_coop_words) -- the clip loop and the pruning of the clipped
+  // polygon are serial chains of reads and writes of these buffers (ALOHA pot on the table: a 76-gon), in global memory 70 % of k_ccd_epa
+  const WsV face1 = lds ? WsV{lds + lds_face, 1} : WsV{at(f0), wst}, face2 = lds ? WsV{lds + lds_face + 3 * P, 1} : WsV{at(f0 + 3 * P), wst};
+  const WsV pn = lds ? WsV{lds, 1} : WsV{at(f0 + 6 * P), wst};
+  const WsF pd = lds ? WsF{lds + 3 * P, 1} : WsF{at(f0 + 9 * P), wst};
+  const WsV bufa = lds ? WsV{lds + 4 * P, 1} : WsV{at(f0 + 10 * P), wst}, bufb = lds ? WsV{lds + 10 * P, 1} : WsV{at(f0 + 16 * P), wst};
   int fi1[3], fi2[3];
   V3 fv1[3], fv2[3];
   const int nf1 = mc_feature_dim(pt, face, 0, fi1, fv1), nf2 = mc_feature_dim(pt, face, 1, fi2, fv2);
@@ -1503,6 +1579,7 @@ __device__ __noinline__ int ccd_multicontact_mesh(const MjhModel& m, const Poly&
   };
   int nn1 = mesh1 ? mc_mesh_normals(nf1, fi1, t1, g1.rot, D, n1, idx1) : box_normals(nf1, fi1, g1.rot, -dir, n1, idx1);
   int nn2 = mesh2 ? mc_mesh_normals(nf2, fi2, t2, g2.rot, D, n2, idx2) : box_normals(nf2, fi2, g2.rot, dir, n2, idx2);
+  DBG_TICK(3);  // normals
   bool edge1 = false, edge2 = false, found = false;
   int ri = 0, rj = 0;
   for (int i = 0; i < nn1 && !found; ++i) {
@@ -1561,6 +1638,7 @@ __device__ __noinline__ int ccd_multicontact_mesh(const MjhModel& m, const Poly&
   } else {
     nface2 = mesh2 ? mc_mesh_face(t2, g2, idx2.get(rj), P, face2) : box_face(g2, idx2.get(rj), face2);
   }
+  DBG_TICK(4);  // match + faces
   const float dn = length(dir);
   const int cap = 2 * P;
   if (edge1) {
@@ -1572,6 +1650,11 @@ __device__ __noinline__ int ccd_multicontact_mesh(const MjhModel& m, const Poly&
     return mc_polygon_clip_ws(face1, nface1, face2, nface2, nn, (-dn) * nn, cap, pn, pd, bufa, bufb, w1, w2);
   }
   return mc_polygon_clip_ws(face1, nface1, face2, nface2, n1.get(ri), dn * n2.get(rj), cap, pn, pd, bufa, bufb, w1, w2);
+}
+
+__device__ __noinline__ int ccd_multicontact_mesh(const MjhModel& m, const Poly& pt, int epa_face, V3 x1, V3 x2, const CcdGeom& g1, const CcdGeom& g2,
+                                                  V3 (&w1)[4], V3 (&w2)[4], float* ws, int wst = CCD_LANES) {
+  return ccd_multicontact_mesh_inl(m, pt, epa_face, x1, x2, g1, g2, w1, w2, ws, wst);
 }
 
 DEV bool is_convex_pair(int t1, int t2) {

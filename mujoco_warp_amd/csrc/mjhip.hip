@@ -119,18 +119,33 @@ static int launch_factor_smooth(const MjhModel* m, const MjhData* d, int write_q
 template <int G>
 static int launch_ccd_pre(const MjhModel* m, const MjhData* d, hipStream_t s) {
   const int it = std::max(m->ccd_iterations, m->epa_iterations);
-  const CcdLayout CL = ccd_layout(d->nworld, it, m->nhfield, m->npolygonmax, m->nmeshdegmax, collide_ccap(m->npair, d->concap), d->nccdhand);
+  const CcdLayout CL = ccd_layout(d->nworld, it, m->nhfield, m->npolygonmax, m->nmeshdegmax, collide_ccap(m->npair, d->concap), d->nccdhand, m->npair);
   hipLaunchKernelGGL(k_ccd_reset, dim3(1), dim3(64), 0, s, reinterpret_cast<int*>(d->ws_ccd + CL.cnt));  // list / EPA entry counters (a kernel, not a memset node: replayed inside hipGraphs)
+  if (m->broadphase == 0 && m->npair > 0) {  // NXN: the broadphase filters of every world as their own launch (a workgroup per world), results as bit masks
+    const size_t lds_mask = sizeof(float) * (size_t)bmask_lds_words(m->ngeom, m->npair);
+    if (lds_mask > 160 * 1024 || m->ngeom > 65535) return fail(MJH_E_UNSUPPORTED, "k_broad_mask: the geom tables do not fit in LDS");
+    HIPCHK(set_lds(k_broad_mask, lds_mask));
+    hipLaunchKernelGGL(k_broad_mask, dim3((unsigned)std::min(d->nworld, 8192)), dim3(256), lds_mask, s, *m, *d);
+  }
   size_t lds;
-  const int threads = pick_block(sizeof(float) * 9 * m->ngeom, sizeof(float) * broad_lds_words(m->ngeom, m->npair, d->concap, m->broadphase), G, &lds);  // (+ the staged model tables)
+  const int threads = pick_block(m->broadphase ? sizeof(float) * 9 * m->ngeom : 0, sizeof(float) * broad_lds_words(m->ngeom, m->npair, d->concap, m->broadphase), G, &lds);  // (+ the staged model tables)
   if (!threads) return fail(MJH_E_UNSUPPORTED, "k_ccd_broad: pair list does not fit in LDS");
   HIPCHK(set_lds((k_ccd_broad<G>), lds));
   const int wpb = threads / G;
   hipLaunchKernelGGL((k_ccd_broad<G>), dim3((d->nworld + wpb - 1) / wpb), dim3(threads), lds, s, *m, *d);
   // (grids sized for the device -- 256 CUs x 8 workgroups --, not for the lists' capacities: the kernels walk their lists with the grid's stride)
-  hipLaunchKernelGGL(k_ccd_gjk, dim3(std::min((CL.listcap + 255) / 256, 2048)), dim3(256), 0, s, *m, *d);
+  {
+    // lanes per pair by the length of the list (read on the device): one lane per pair needs >= 2 wavefronts per SIMD to hide its chains of
+    // dependent table loads; shorter lists give a pair 8 or 32 lanes (MJH_GJK_LANES: developer knob, forces one instantiation)
+    static const int force = getenv("MJH_GJK_LANES") ? atoi(getenv("MJH_GJK_LANES")) : 0;
+    const int all = 0x7fffffff, t8 = force ? (force == 32 ? all : 0) : 16384, t1 = force ? (force == 1 ? 0 : all) : 131072;
+    const int grid1 = std::min((CL.listcap + 255) / 256, 2048);
+    hipLaunchKernelGGL(k_ccd_gjk<32>, dim3(std::min((CL.listcap + 7) / 8, 4096)), dim3(256), 0, s, *m, *d, 0, t8);
+    hipLaunchKernelGGL(k_ccd_gjk<8>, dim3(std::min((CL.listcap + 31) / 32, 4096)), dim3(256), 0, s, *m, *d, t8, t1);
+    hipLaunchKernelGGL(k_ccd_gjk<1>, dim3(grid1), dim3(256), 0, s, *m, *d, t1, all);
+  }
   const int gpb = 256 / G;
-  const size_t lds_epa = sizeof(float) * (size_t)ccd_coop_words(it) * gpb;
+  const size_t lds_epa = sizeof(float) * (size_t)ccd_coop_words(it, m->npolygonmax, m->nmeshdegmax) * gpb;
   HIPCHK(set_lds((k_ccd_epa<G>), lds_epa));
   hipLaunchKernelGGL((k_ccd_epa<G>), dim3(std::min((CL.handcap + gpb - 1) / gpb, 2048)), dim3(256), lds_epa, s, *m, *d);
   return MJH_OK;

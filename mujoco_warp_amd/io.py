@@ -529,7 +529,7 @@ def _ccd_handcap(nworld: int, ccap: int) -> int:
   return max(nworld * min(ccap, 32), min(nworld * ccap, 4096))
 
 
-def _ccd_words(nworld: int, iterations: int, hfield: int, npolygonmax: int, nmeshdegmax: int, ccap: int) -> int:
+def _ccd_words(nworld: int, iterations: int, hfield: int, npolygonmax: int, nmeshdegmax: int, ccap: int, npair: int) -> int:
   """Per-lane words of Data.ws_ccd [nworld, words, 32] such that it holds csrc/convex.hpp ccd_layout(...).total floats: per world the
   height-field prisms' polytopes, the per-candidate result cache and the candidate list; then the flat GJK list, the EPA hand-over
   records (CCD_HAND_WORDS = 64 each) and the multi-contact buffers of the EPA groups (sized from the model like the reference's,
@@ -538,7 +538,8 @@ def _ccd_words(nworld: int, iterations: int, hfield: int, npolygonmax: int, nmes
   poly = 8 * (5 + it) + 5 * (6 + 5 * it) + 24
   cache0 = (poly + 4 * 24 + 7 * 50 + 1) * 32 if hfield else 0
   cand = cache0 + ccap * 24
-  world_stride = (cand + ccap + 4 + 3) // 4 * 4
+  bmask = (cand + ccap + 4 + 3) // 4 * 4  # k_broad_mask's bit mask over the pair list (64-pair granules)
+  world_stride = (bmask + 2 * ((npair + 63) // 64) + 3) // 4 * 4
   handcap = _ccd_handcap(nworld, ccap)
   listcap = nworld * ccap
   mcw = 11 * max(int(nmeshdegmax), 3) + 22 * max(int(npolygonmax), 4) if nmeshdegmax > 0 else 0
@@ -575,7 +576,7 @@ def _data_shapes(m, nworld, nconmax, njmax, naconmax):
     efc_margin=(W, njmax), efc_D=(W, njmax), efc_vel=(W, njmax), efc_aref=(W, njmax), efc_frictionloss=(W, njmax),
     efc_force=(W, njmax), ws_ncon=(W,), ws_conadr=(W,), ws_ncollision=(W,), ws_efc_con=(W, njmax), ws_tree_rowadr=(W, (m.ntree + 1) if m.tree_solve else 0), ws_tree_rowmap=(W, njmax if m.tree_solve else 0),
     ws_isl_dofadr=(W, (m.ntree + 1) if m.tree_solve else 0), ws_isl_dofmap=(W, nv if m.tree_solve else 0), ws_isl_dofinv=(W, nv if m.tree_solve else 0), ws_nisland=(W,), ws_isl_flags=(W,), ws_isl_list=(3, W if m.tree_solve else 0), ws_isl_count=(4,),
-    ws_separable=(W,), ws_order=(W,), ws_ccd=(W if m._convex_pairs else 0, _ccd_words(W, max(int(m.opt.ccd_iterations), int(m.epa_iterations)), m.nhfield, m.npolygonmax, m.nmeshdegmax, _collide_ccap(int(m.npair), contact_cap(nconmax))), 32),
+    ws_separable=(W,), ws_order=(W,), ws_ccd=(W if m._convex_pairs else 0, _ccd_words(W, max(int(m.opt.ccd_iterations), int(m.epa_iterations)), m.nhfield, m.npolygonmax, m.nmeshdegmax, _collide_ccap(int(m.npair), contact_cap(nconmax)), int(m.npair)), 32),
     tree_asleep=(W, m.ntree), tree_awake=(W, m.ntree), body_awake=(W, nb), body_awake_ind=(W, nb), dof_awake_ind=(W, nv), ntree_awake=(W,), nbody_awake=(W,),
     nv_awake=(W,), tree_island=(W, m.ntree), nisland=(W,), ws_iacc=(W if int(m.opt.integrator) == int(types.IntegratorType.IMPLICIT) else 0, nv), ws_pgsB=(W if _needs_pgs_big(m) else 0, njmax_pad, nv_pad), ws_sleep_J=(W if m.sleep_enabled else 0, njmax_pad, nv_pad), ws_sleep_warm=(W if m.sleep_enabled else 0, nv),
     ws_sleep_flag=(W,),
