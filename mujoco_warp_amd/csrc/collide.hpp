@@ -1205,7 +1205,7 @@ DEV bool obb_filter(const float* a1, const float* a2, float margin, V3 x1, V3 x2
 // VGPRs, exactly four waves per SIMD) is unchanged.  (Measured: the pair-id lookups alone cost the light k_mid 20 us.)
 // MODE 0: the contact kernel (broadphase + both narrowphase passes; for models with GJK pairs -- Data.ws_ccd -- the candidate list and the
 // convex results come from the three launches in front of it).  MODE 1: k_ccd_broad -- the broadphase alone; the candidate list goes to
-// the world's slice of Data.ws_ccd, the convex candidates to the flat list of k_ccd_gjk.
+// the world's slice of Data.ws_ccd (k_ccd_gjk finds the convex candidates by their rank in it).
 // HFT = false: the heavy instantiation without the height-field colliders (per-lane GJK / EPA on prisms: the largest register consumer left in
 // the contact kernel) for models without height fields
 template <int G, bool HEAVY = false, int MODE = 0, bool HFT = true>
@@ -1536,10 +1536,9 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
   }
   pc.mark(1);
   if constexpr (MODE == 1) {
-    // ---- k_ccd_broad: publish the candidate list; the convex candidates join the flat list of k_ccd_gjk (slot = rank among the
-    // world's convex candidates; ONE reservation per world)
+    // ---- k_ccd_broad: publish the candidate list; a convex candidate's slot = its rank among the world's convex candidates (its cache
+    // entry starts as "no contact" and carries the pair id for k_ccd_gjk, which walks (slot, world))
     int* cnt = reinterpret_cast<int*>(d.ws_ccd + CL.cnt);
-    int* list = reinterpret_cast<int*>(d.ws_ccd + CL.list);
     int ncvx = 0;
     for (int base = 0; base < ncand; base += G) {
       const int ci = base + lig;
@@ -1553,34 +1552,20 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
       }
       int tot;
       const int rank = grank<G>(cvx, lig, tot);
-      if (cvx) cslot[ci] = ncvx + rank;
+      if (cvx) {
+        int* ce = reinterpret_cast<int*>(ccd_world + CL.cache + (size_t)(ncvx + rank) * CCD_CACHE_WORDS);
+        ce[0] = 0;
+        ce[CCD_CACHE_WORDS - 1] = p;  // (the entry's spare word)
+      }
       ncvx += tot;
     }
-    gsync();
-    int base0 = 0;
     if (lig == 0) {
       gcand[ccap] = ncand;
       gcand[ccap + 1] = nbroad;
       gcand[ccap + 2] = ncvx;
-      base0 = ncvx ? atomicAdd(cnt, ncvx) : 0;
-    }
-    base0 = __shfl(base0, 0, G);
-    if (base0 + ncvx > CL.listcap) {  // the flat list is full: these candidates are dropped (their cache entries say "no contact")
-      if (lig == 0) atomicOr(d.overflow + w, OVF_CCD);
-    }
-    for (int ci = lig; ci < ncand; ci += G) {
-      const int p = cand[ci];
-      const int t1 = m.geom_type[m.nxn_geom_pair[2 * p]], t2 = m.geom_type[m.nxn_geom_pair[2 * p + 1]];
-      if (!is_ccd_pair(m, min(t1, t2), max(t1, t2))) continue;
-      const int slot = cslot[ci];
-      reinterpret_cast<int*>(ccd_world + CL.cache + (size_t)slot * CCD_CACHE_WORDS)[0] = 0;
-      if (base0 + slot < CL.listcap) {
-        int* e = list + 4 * (size_t)(base0 + slot);
-        e[0] = w;
-        e[1] = p;
-        e[2] = slot;
-        e[3] = 0;
-      }
+      // the longest convex list of any world (one atomic per world on one address costs ~50 us at 8192 worlds: only the worlds that raise
+      // the maximum issue it -- a stale read only means an atomic that changes nothing)
+      if (ncvx > __atomic_load_n(cnt, __ATOMIC_RELAXED)) atomicMax(cnt, ncvx);
     }
     return;
   }
@@ -1970,13 +1955,13 @@ __global__ void __launch_bounds__(256) k_ccd_broad(MjhModel m, MjhData d) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   collision_body<G, true, 1>(m, d, smem, blk_of_launch<G>());
 }
-// GJK for every entry of the flat convex list; the result to the candidate's cache entry, penetrating pairs to the EPA list.
+// GJK for every convex candidate of every world; the result to the candidate's cache entry, penetrating pairs to the EPA list.
 // CGJ = 1: one LANE per entry.  CGJ = 8 / 16 / 32: a group of CGJ lanes per entry -- chosen by the launch when the list is too short to fill the
 // device with one lane per entry: on the ALOHA scene a world has 3-14 convex candidates (65 k lanes = ONE wavefront per SIMD) and a pair
 // evaluates 80-360 hill-climbing neighbours (the pot's vertices have up to 43) one after the other, three dependent loads each: 400 us of
 // latency on an idle device.  The group spreads a step's neighbours over its lanes (ccd_support_c: the serial scan's result, ties included).
-// The list's length is only known on the device: the launch enqueues the instantiations back to back and each returns at once unless the
-// length lies in its range [lo, hi).
+// The number of work items is only known on the device: the launch enqueues the instantiations back to back and each returns at once
+// unless the number lies in its range [lo, hi).
 template <int CGJ>
 __global__ void __launch_bounds__(256) k_ccd_gjk(MjhModel m, MjhData d, int lo, int hi) {
   const CcdLayout CL = ccd_layout_of(m, d);
@@ -1988,19 +1973,27 @@ __global__ void __launch_bounds__(256) k_ccd_gjk(MjhModel m, MjhData d, int lo, 
   g_dbg_gclk = cnt;
   unsigned long long kt0_ = __builtin_amdgcn_s_memtime();
 #endif
-  const int nlist = min(cnt[0], CL.listcap);
-  if (nlist < lo || nlist >= hi) return;
+  const int nrank = min(cnt[0], CL.ccap), ntask = nrank * d.nworld;  // (slot, world) work items, empty ones included
+  if (ntask < lo || ntask >= hi) return;
   // (the launch is sized for the device, not for the list's capacity: whole wavefronts walk the list with the grid's stride)
   const int lig = threadIdx.x & (CGJ - 1);
-  for (int t0 = blockIdx.x * (blockDim.x / CGJ); t0 < nlist; t0 += gridDim.x * (blockDim.x / CGJ)) {
+  // Work item t = (rank r among a world's convex candidates, world w), worlds fastest: the lanes of a wavefront hold the SAME rank of
+  // consecutive worlds -- in a batch of similar worlds the same geom pair, hence one path through the support functions and the simplex
+  // code and the same mesh tables, where the flat list's order (a world's candidates side by side) made every wavefront run the union
+  // of eight different pairs' paths.  (The number of work items picks the instantiation.)
+  for (int t0 = blockIdx.x * (blockDim.x / CGJ); t0 < ntask; t0 += gridDim.x * (blockDim.x / CGJ)) {
   const int t = t0 + (int)threadIdx.x / CGJ;
   int st = 0, w = 0, p = 0, slot = 0, idx1 = -1, idx2 = -1;
   GjkOut res;
-  if (t < nlist) {
-    const int* e = reinterpret_cast<const int*>(d.ws_ccd + CL.list) + 4 * (size_t)t;
-    w = e[0];
-    p = e[1];
-    slot = e[2];
+  bool have = false;
+  if (t < ntask) {
+    slot = t / d.nworld;
+    w = t - slot * d.nworld;
+    const float* cw = d.ws_ccd + (size_t)w * CL.world_stride;
+    have = slot < reinterpret_cast<const int*>(cw + CL.cand)[CL.ccap + 2];
+    if (have) p = reinterpret_cast<const int*>(cw + CL.cache + (size_t)slot * CCD_CACHE_WORDS)[CCD_CACHE_WORDS - 1];
+  }
+  if (have) {
     int g1 = m.nxn_geom_pair[2 * p], g2 = m.nxn_geom_pair[2 * p + 1];
     int t1 = m.geom_type[g1], t2 = m.geom_type[g2];
     if (t1 > t2) {

@@ -41,14 +41,18 @@ __host__ __device__ inline int ccd_poly_words(int iterations) {
 __host__ __device__ inline int ccd_words(int iterations, int hfield = 0) {
   return ccd_poly_words(iterations) + CCD_CACHE_SLOTS * CCD_CACHE_WORDS + (hfield ? CCD_HF_WORDS : 0);
 }
-// Round 4: the convex narrowphase as THREE LAUNCHES in front of the contact kernel (models with GJK pairs; csrc/collide.hpp).
-//   k_ccd_broad   one lane group per world: the broadphase (unchanged code), candidate list to the world's slice of Data.ws_ccd; the
-//                 convex candidates of all worlds go to ONE flat list (one reservation per world)
-//   k_ccd_gjk     one LANE per list entry, nothing but registers: GJK.  Its cost is the chain of dependent table loads of the support
-//                 function (hill climbing on a mesh graph: edge list -> vertex id -> vertex), which only concurrency hides -- as one
-//                 role of the heavy contact kernel (509 VGPRs, one wavefront per SIMD) every round trip stalled the SIMD.  Results
-//                 (separated / one shallow contact) go to the candidate's cache entry; penetrating pairs append their simplex to the
-//                 EPA list (one reservation per wavefront)
+// Round 4: the convex narrowphase as its own LAUNCHES in front of the contact kernel (models with GJK pairs; csrc/collide.hpp).
+//   k_broad_mask  a workgroup per world: the broadphase filters of the whole pair list, results as a bit mask (NXN broadphase)
+//   k_ccd_broad   one lane group per world: the mask expanded in pair order (or the sweep-and-prune broadphase), candidate list to the
+//                 world's slice of Data.ws_ccd; a convex candidate's cache slot = its rank among the world's convex candidates
+//   k_ccd_gjk     GJK with nothing but registers, work items ordered (slot, world): a wavefront holds the same slot of consecutive
+//                 worlds -- in a batch of similar worlds one geom pair, one path through the code, the same mesh tables.  One lane per
+//                 item, or 8 / 32 lanes (the mesh support function spreads a hill-climbing step's neighbours over them) when there are
+//                 too few items to fill the device.  Its cost is the chain of dependent table loads of the support function (hill
+//                 climbing on a mesh graph: edge list -> vertex id -> vertex), which only concurrency hides -- as one role of the
+//                 heavy contact kernel (509 VGPRs, one wavefront per SIMD) every round trip stalled the SIMD.  Results (separated /
+//                 one shallow contact) go to the candidate's cache entry; penetrating pairs append their simplex to the EPA list
+//                 (one reservation per wavefront)
 //   k_ccd_epa     one lane GROUP per EPA entry: the polytope in ONE copy in the group's LDS (a lane used to walk its slice of global
 //                 memory at one round trip per face: 2 scans x 181 faces x 35 iterations), the nearest-face and visible-face scans and
 //                 the attachment of the horizon's faces spread over the lanes, the mesh support function spreading the neighbours of a
@@ -63,16 +67,15 @@ __host__ __device__ inline int ccd_words(int iterations, int hfield = 0) {
 //   per world  [hf]     per-lane polytope + result table of the height-field prisms, interleaved by lane (models with height fields)
 //              [cache]  ccap x CCD_CACHE_WORDS: one entry per convex candidate, slot = its rank among the world's convex candidates
 //              [cand]   ccap + 4 ints: the world's candidate pairs in canonical order | ncand, nbroad, nconvex
-//   tail       [cnt]    8 ints: list entries, EPA entries (zeroed by a memset node in front of k_ccd_broad)
-//              [list]   listcap x 4 ints: world, pair, slot, -
+//   tail       [cnt]    8 ints: longest convex candidate list of a world, EPA entries (zeroed by k_ccd_reset in front of k_ccd_broad)
 //              [hand]   handcap x CCD_HAND_WORDS: list entry | vertex caches | the GJK simplex, for the EPA launch
 //              [mc]     handcap x ccd_mc_words: multi-contact buffers of the EPA groups (stride 1)
 #define CCD_HAND_WORDS 64
 struct CcdLayout {
   size_t world_stride;  // floats per world
   size_t hf, cache, cand, bmask;  // offsets inside a world's slice
-  size_t tail, cnt, list, hand, mc, total;  // offsets from the start of ws_ccd
-  int ccap, listcap, handcap, mcw, nbw;
+  size_t tail, cnt, hand, mc, total;  // offsets from the start of ws_ccd
+  int ccap, handcap, mcw, nbw;
 };
 __host__ __device__ inline CcdLayout ccd_layout(int nworld, int iterations, int nhfield, int npolygonmax, int nmeshdegmax, int ccap, int handcap, int npair) {
   CcdLayout L;
@@ -87,10 +90,8 @@ __host__ __device__ inline CcdLayout ccd_layout(int nworld, int iterations, int 
   L.world_stride = ((L.bmask + (size_t)L.nbw + 3) / 4) * 4;
   L.tail = L.world_stride * (size_t)nworld;
   L.cnt = L.tail;
-  L.listcap = nworld * ccap;  // (every candidate of every world may be convex)
-  L.list = L.cnt + 8;
   L.handcap = handcap;
-  L.hand = L.list + (size_t)L.listcap * 4;
+  L.hand = L.cnt + 8;
   L.mcw = nmeshdegmax > 0 ? 11 * (nmeshdegmax > 3 ? nmeshdegmax : 3) + 22 * (npolygonmax > 4 ? npolygonmax : 4) : 0;
   L.mc = L.hand + (size_t)handcap * CCD_HAND_WORDS;
   L.total = L.mc + (size_t)handcap * L.mcw;

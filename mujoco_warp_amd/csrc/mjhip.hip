@@ -139,9 +139,10 @@ static int launch_ccd_pre(const MjhModel* m, const MjhData* d, hipStream_t s) {
     // dependent table loads; shorter lists give a pair 8 or 32 lanes (MJH_GJK_LANES: developer knob, forces one instantiation)
     static const int force = getenv("MJH_GJK_LANES") ? atoi(getenv("MJH_GJK_LANES")) : 0;
     const int all = 0x7fffffff, t8 = force ? (force == 32 ? all : 0) : 16384, t1 = force ? (force == 1 ? 0 : all) : 131072;
-    const int grid1 = std::min((CL.listcap + 255) / 256, 2048);
-    hipLaunchKernelGGL(k_ccd_gjk<32>, dim3(std::min((CL.listcap + 7) / 8, 4096)), dim3(256), 0, s, *m, *d, 0, t8);
-    hipLaunchKernelGGL(k_ccd_gjk<8>, dim3(std::min((CL.listcap + 31) / 32, 4096)), dim3(256), 0, s, *m, *d, t8, t1);
+    const long long cap = (long long)d->nworld * CL.ccap;  // work items at most
+    const int grid1 = (int)std::min<long long>((cap + 255) / 256, 2048);
+    hipLaunchKernelGGL(k_ccd_gjk<32>, dim3((unsigned)std::min<long long>((cap + 7) / 8, 4096)), dim3(256), 0, s, *m, *d, 0, t8);
+    hipLaunchKernelGGL(k_ccd_gjk<8>, dim3((unsigned)std::min<long long>((cap + 31) / 32, 4096)), dim3(256), 0, s, *m, *d, t8, t1);
     hipLaunchKernelGGL(k_ccd_gjk<1>, dim3(grid1), dim3(256), 0, s, *m, *d, t1, all);
   }
   const int gpb = 256 / G;

@@ -531,7 +531,7 @@ def _ccd_handcap(nworld: int, ccap: int) -> int:
 
 def _ccd_words(nworld: int, iterations: int, hfield: int, npolygonmax: int, nmeshdegmax: int, ccap: int, npair: int) -> int:
   """Per-lane words of Data.ws_ccd [nworld, words, 32] such that it holds csrc/convex.hpp ccd_layout(...).total floats: per world the
-  height-field prisms' polytopes, the per-candidate result cache and the candidate list; then the flat GJK list, the EPA hand-over
+  height-field prisms' polytopes, the per-candidate result cache and the candidate list; then the EPA hand-over
   records (CCD_HAND_WORDS = 64 each) and the multi-contact buffers of the EPA groups (sized from the model like the reference's,
   collision_convex.py:1346-1366)."""
   it = min(int(iterations), 64)
@@ -541,9 +541,8 @@ def _ccd_words(nworld: int, iterations: int, hfield: int, npolygonmax: int, nmes
   bmask = (cand + ccap + 4 + 3) // 4 * 4  # k_broad_mask's bit mask over the pair list (64-pair granules)
   world_stride = (bmask + 2 * ((npair + 63) // 64) + 3) // 4 * 4
   handcap = _ccd_handcap(nworld, ccap)
-  listcap = nworld * ccap
   mcw = 11 * max(int(nmeshdegmax), 3) + 22 * max(int(npolygonmax), 4) if nmeshdegmax > 0 else 0
-  total = world_stride * nworld + 8 + 4 * listcap + handcap * 64 + handcap * mcw
+  total = world_stride * nworld + 8 + handcap * 64 + handcap * mcw
   return (total + 32 * nworld - 1) // (32 * nworld)
 
 

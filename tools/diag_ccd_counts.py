@@ -30,7 +30,7 @@ for i in range(nstep):
     ws = d.ws_ccd.numpy().reshape(-1)
     cnt = ws[stride * nworld: stride * nworld + 8].view(np.int32)
     tail = ws[: stride * nworld].reshape(nworld, stride)[:, cand + ccap: cand + ccap + 3].view(np.int32)
-    print(f"step {i:4d}: convex list {cnt[0] / nworld:7.1f} / world, EPA entries {cnt[1] / nworld:6.1f} / world; candidates {tail[:, 0].mean():6.1f} (before cap {tail[:, 1].mean():6.1f}), convex {tail[:, 2].mean():6.1f}; ncon {d.ws_ncon.numpy().mean():.1f} nefc {d.nefc.numpy().mean():.1f}"
+    print(f"step {i:4d}: longest convex list {cnt[0]:3d}, EPA entries {cnt[1] / nworld:6.1f} / world; candidates {tail[:, 0].mean():6.1f} (before cap {tail[:, 1].mean():6.1f}), convex {tail[:, 2].mean():6.1f}; ncon {d.ws_ncon.numpy().mean():.1f} nefc {d.nefc.numpy().mean():.1f}"
           + (f" | EPA clock per entry (ticks): epa {16 * cnt[2] / max(cnt[1], 1):.0f}, mc normals {16 * cnt[3] / max(cnt[1], 1):.0f}, mc match+faces {16 * cnt[4] / max(cnt[1], 1):.0f}, clip {16 * cnt[5] / max(cnt[1], 1):.0f}, prune {16 * cnt[6] / max(cnt[1], 1):.0f}, clipped polygon {cnt[7] / max(cnt[1], 1):.1f} verts" if os.environ.get("MJH_LIB", "").endswith("epaclock.so") else "")
           + (f" | GJK clock per pair (ticks): set-up {1024 * cnt[5] / max(cnt[0], 1):.0f}, whole phase {1024 * cnt[6] / max(cnt[0], 1):.0f} of which supports {1024 * cnt[2] / max(cnt[0], 1):.0f}, simplex {1024 * cnt[3] / max(cnt[0], 1):.0f}, closing supports {1024 * cnt[4] / max(cnt[0], 1):.0f}" if os.environ.get("MJH_LIB", "").endswith("gjkclock.so") else "")
           + (f" | GJK iterations {cnt[2] / max(cnt[0], 1):.1f} / pair (max {cnt[3]}), hill-climb steps {cnt[4] / max(cnt[0], 1):.1f} / pair, neighbours {cnt[5] / max(cnt[0], 1):.1f} / pair" if cnt[2] and not os.environ.get("MJH_LIB", "").endswith("clock.so") else ""))
