@@ -16,7 +16,7 @@ HEADER = os.path.join(_ROOT, "include", "mjhip.h")
 LIB_PATH = os.path.join(_PKG, "libmjhip.so")
 # translation units of the library (compiled in parallel; the solver kernels are ~70 template instantiations) and the
 # headers they include
-UNITS = ["mjhip.hip", "solve_cg32.hip", "solve_cgw.hip", "solve_newton32.hip", "solve_cg64.hip", "solve_newton64.hip", "solve_ell_cg32.hip", "solve_ell_newton32.hip",
+UNITS = ["mjhip.hip", "solve_cg32.hip", "solve_ell_newton32_r1.hip", "solve_cgw.hip", "solve_newton32.hip", "solve_cg64.hip", "solve_newton64.hip", "solve_ell_cg32.hip", "solve_ell_newton32.hip",
          "solve_ell_cg64.hip", "solve_ell_newton64.hip", "solve_tree_cg.hip", "solve_tree_newton.hip", "solve_tree_ell_cg.hip", "solve_tree_ell_newton.hip", "pgs_tu.hip", "solve_big.hip"]
 HEADERS = ["host.hpp", "solve_tu.hpp", "solve_tree.hpp", "dev_common.hpp", "smooth.hpp", "collide.hpp", "constraint.hpp", "solver.hpp", "solver_cgw.hpp", "solver_newton.hpp", "solver_big.hpp", "pgs.hpp",
            "integrate.hpp", "implicit.hpp", "pgs_big.hpp", "sleep.hpp", "convex.hpp", "sensor.hpp", "support.hpp", "ray.hpp", "contact_rec.hpp"]

@@ -60,6 +60,8 @@ static void debug_occupancy(const char* name, K kernel, int grid, int threads, s
 // solver launches, one translation unit each (nr = rows per lane: 2 / 6 with 32 lanes per world, 1 / 2 / 3 with 64;
 // (lo, hi] = row-count range of the worlds this launch solves; fuse_euler: explicit Euler step in the solver epilogue)
 int launch_solve_32_cg(const MjhModel* m, const MjhData* d, int nr, bool with_factor, int fuse_euler, hipStream_t s, int lo, int hi);
+// one row per lane (worlds of at most 32 rows): solve_ell_newton32_r1.hip
+int launch_solve_32_newton_ell_r1(const MjhModel* m, const MjhData* d, bool with_factor, int fuse_euler, hipStream_t s, int lo, int hi);
 // CG with one world per wavefront (solver_cgw.hpp): nv <= 32, worlds of at most 64 rows, pyramidal cones
 int launch_solve_cgw(const MjhModel* m, const MjhData* d, bool with_factor, int fuse_euler, hipStream_t s, int lo, int hi);
 int launch_solve_32_newton(const MjhModel* m, const MjhData* d, int nr, bool with_factor, int fuse_euler, hipStream_t s, int lo, int hi);

@@ -287,50 +287,64 @@ __global__ void __launch_bounds__(256) k_solve_m(MjhModel m, MjhData d, float* x
 // Iteration counts are strongly correlated from step to step, so (i) the longest solves start first (LPT: no
 // long straggler wave at the tail of k_solve) and (ii) the two worlds sharing a wavefront need a similar number
 // of iterations (a wave runs for max(niter) of its two worlds).  Single workgroup; deterministic (stable sort).
-// `sh` needs 256 ints of LDS; any workgroup size that is a multiple of 64.  Global loads are batched eight deep ahead
+// `sh` needs 512 ints of LDS; any workgroup size that is a multiple of 64.  Global loads are batched eight deep ahead
 // of the LDS atomics (a load -> atomic -> store chain per world costs a full memory latency per iteration: 50-70 us
 // for 8192 worlds on one small workgroup), the 128-bin prefix is one wavefront scan.
 DEV void schedule_body(const MjhData& d, int* sh, int nthreads) {
+  // key: worlds that had more than 32 constraint rows first, then the others (the solver's one-row-per-lane instantiation takes the worlds
+  // of at most 32 rows in a launch of its own: with the two classes apart both launches run dense workgroups); inside a class by iteration
+  // count, longest first.  256 bins: `sh` needs 512 ints.
   int* hist = sh;
-  int* base = sh + 128;
+  int* base = sh + 256;
   const int t = threadIdx.x, n = d.nworld;
-  for (int i = t; i < 128; i += nthreads) hist[i] = 0;
+  auto bin = [](int niter, int nefc) { return (nefc > 32 ? 0 : 128) + 127 - min(max(niter, 0), 127); };
+  for (int i = t; i < 256; i += nthreads) hist[i] = 0;
   __syncthreads();
   for (int w0 = t; w0 < n; w0 += 8 * nthreads) {
-    int v[8];
+    int v[8], e[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = w0 + k * nthreads < n ? d.solver_niter[w0 + k * nthreads] : -1;
+    for (int k = 0; k < 8; ++k) {
+      v[k] = w0 + k * nthreads < n ? d.solver_niter[w0 + k * nthreads] : -1;
+      e[k] = w0 + k * nthreads < n ? d.nefc[w0 + k * nthreads] : 0;
+    }
 #pragma unroll
     for (int k = 0; k < 8; ++k)
-      if (w0 + k * nthreads < n) atomicAdd(&hist[127 - min(max(v[k], 0), 127)], 1);
+      if (w0 + k * nthreads < n) atomicAdd(&hist[bin(v[k], e[k])], 1);
   }
   __syncthreads();
-  if (t < 64) {  // exclusive prefix over the 128 bins: two bins per lane of the first wavefront
-    const int a = hist[2 * t], b = hist[2 * t + 1];
-    int incl = a + b;
+  if (t < 64) {  // exclusive prefix over the 256 bins: four bins per lane of the first wavefront
+    const int a0 = hist[4 * t], a1 = hist[4 * t + 1], a2 = hist[4 * t + 2], a3 = hist[4 * t + 3];
+    const int tot = a0 + a1 + a2 + a3;
+    int incl = tot;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
       const int u = __shfl_up(incl, off, 64);
       if (t >= off) incl += u;
     }
-    base[2 * t] = incl - a - b;
-    base[2 * t + 1] = incl - b;
+    const int ex = incl - tot;
+    base[4 * t] = ex;
+    base[4 * t + 1] = ex + a0;
+    base[4 * t + 2] = ex + a0 + a1;
+    base[4 * t + 3] = ex + a0 + a1 + a2;
   }
   __syncthreads();
   // scatter; the order inside a bucket is arbitrary (it only decides which wavefront hosts a world, never a result)
   for (int w0 = t; w0 < n; w0 += 8 * nthreads) {
-    int v[8], pos[8];
+    int v[8], e[8], pos[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = w0 + k * nthreads < n ? d.solver_niter[w0 + k * nthreads] : -1;
+    for (int k = 0; k < 8; ++k) {
+      v[k] = w0 + k * nthreads < n ? d.solver_niter[w0 + k * nthreads] : -1;
+      e[k] = w0 + k * nthreads < n ? d.nefc[w0 + k * nthreads] : 0;
+    }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) pos[k] = w0 + k * nthreads < n ? atomicAdd(&base[127 - min(max(v[k], 0), 127)], 1) : 0;
+    for (int k = 0; k < 8; ++k) pos[k] = w0 + k * nthreads < n ? atomicAdd(&base[bin(v[k], e[k])], 1) : 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k)
       if (w0 + k * nthreads < n) d.ws_order[pos[k]] = w0 + k * nthreads;
   }
 }
 __global__ void __launch_bounds__(1024) k_schedule_worlds(MjhData d) {
-  __shared__ int sh[256];
+  __shared__ int sh[512];
   schedule_body(d, sh, blockDim.x);
 }
 

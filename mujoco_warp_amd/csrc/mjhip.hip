@@ -472,11 +472,28 @@ static int launch_solve_any(const MjhModel* m, const MjhData* d, bool with_facto
     static const int wide_min_nv = getenv("MJH_CGW_MIN_NV") ? atoi(getenv("MJH_CGW_MIN_NV")) : 13;
     static const int wide_max_nworld = getenv("MJH_CGW_MAX_NWORLD") ? atoi(getenv("MJH_CGW_MAX_NWORLD")) : 3072;
     const bool wide = !newton && !ell && m->nv >= wide_min_nv && d->nworld <= wide_max_nworld && fe != 2;  // (its half rows of M do not serve the fused implicitfast update)
-    // rows per lane (32 lanes per world): 2 covers 64 rows (humanoid, panda), 6 covers 192
-    if (d->njmax <= 64) return wide ? launch_solve_cgw(m, d, with_factor, fe, s, -1, all) : s32(m, d, 2, with_factor, fe, s, -1, all);
-    if (int rc = wide ? launch_solve_cgw(m, d, false, fe, s, -1, 64) : s32(m, d, 2, false, fe, s, -1, 64)) return rc;
-    if (int rc = s32(m, d, 6, with_factor, fe, s, 64, top)) return rc;
-    return d->njmax > 192 ? launch_solve_big(m, d, s, 192) : MJH_OK;
+    // rows per lane (32 lanes per world): 1 covers 32 rows, 2 covers 64 rows (humanoid, panda), 6 covers 192.  Newton with elliptic cones has
+    // a one-row instantiation for the worlds of at most 32 rows (the ALOHA scene: nefc 24 on average, 27 at the 95th percentile): 155 instead
+    // of 191 VGPRs and 6.7 instead of 12.2 KB of LDS per world -- 2.9 instead of 1.6 wavefronts per SIMD -- and half the row work per lane:
+    // 333 -> 254 us per step there (MJH_SOLVE_R1=0: developer knob, off).  The launches follow one another on the caller's stream: a batch
+    // with worlds in both classes pays the latency of one more solve (on a side stream beside the 64-row launch the ALOHA scene LOST 17 %:
+    // 4.95 vs 5.97 M env-steps/s, the fork / join hops inside the step's graph).  (The same for CG with pyramidal cones was built and
+    // measured on the humanoid -- bit-identical results, but no gain: behind one another 0.471 vs 0.369 ms per step at nefc 46 where a
+    // quarter of the worlds are in the small class; side by side 0.370 vs 0.372 ms there and 0.349 vs 0.329 ms at nefc 32.  Not kept.)
+    static const bool r1_on = !getenv("MJH_SOLVE_R1") || atoi(getenv("MJH_SOLVE_R1")) != 0;
+    const bool r1 = r1_on && newton && ell && d->njmax > 32;
+    int lo2 = -1;
+    if (r1) {
+      if (int rc = launch_solve_32_newton_ell_r1(m, d, false, fe, s, -1, 32)) return rc;
+      lo2 = 32;
+    }
+    auto rest = [&]() -> int {
+      if (d->njmax <= 64) return wide ? launch_solve_cgw(m, d, with_factor, fe, s, -1, all) : s32(m, d, 2, with_factor, fe, s, lo2, all);
+      if (int rc = wide ? launch_solve_cgw(m, d, false, fe, s, -1, 64) : s32(m, d, 2, false, fe, s, lo2, 64)) return rc;
+      if (int rc = s32(m, d, 6, with_factor, fe, s, 64, top)) return rc;
+      return d->njmax > 192 ? launch_solve_big(m, d, s, 192) : MJH_OK;
+    };
+    return rest();
   }
   // 64 lanes per world: 1 / 2 / 3 rows per lane cover 64 / 128 / 192 rows.  The second launch of a pair runs after the
   // first on the same stream, so the split point is chosen to leave it (almost) empty: its real worlds would otherwise
@@ -526,7 +543,7 @@ static int launch_pos_plus_g(const MjhModel* m, const MjhData* d, int first, int
     if (noise.n) hipLaunchKernelGGL(k_ctrl_noise, dim3((noise.n + 255) / 256), dim3(256), 0, s, *m, *d, noise.center, noise.step, noise.noise_std, noise.noise_rate);
     return launch_pos(m, d, first, last, s);
   }
-  lds = std::max(lds, (size_t)1024);
+  lds = std::max(lds, (size_t)2048);  // (the schedule workgroup: 512 ints)
   HIPCHK(set_lds(k_fwd_pos_plus<G>, lds));
   const int wpb = threads / G, npos = (d->nworld + wpb - 1) / wpb, nnoise = (noise.n + threads - 1) / threads;
   debug_occupancy("k_fwd_pos_plus", k_fwd_pos_plus<G>, npos + 1 + nnoise, threads, lds);
