@@ -1962,8 +1962,11 @@ __global__ void __launch_bounds__(256) k_ccd_broad(MjhModel m, MjhData d) {
 // latency on an idle device.  The group spreads a step's neighbours over its lanes (ccd_support_c: the serial scan's result, ties included).
 // The number of work items is only known on the device: the launch enqueues the instantiations back to back and each returns at once
 // unless the number lies in its range [lo, hi).
+#ifndef MJH_GJK_WAVES  // wavefronts per SIMD the register allocation of k_ccd_gjk aims at (developer knob)
+#define MJH_GJK_WAVES 2
+#endif
 template <int CGJ>
-__global__ void __launch_bounds__(256) k_ccd_gjk(MjhModel m, MjhData d, int lo, int hi) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MJH_GJK_WAVES, 8))) k_ccd_gjk(MjhModel m, MjhData d, int lo, int hi) {
   const CcdLayout CL = ccd_layout_of(m, d);
   int* cnt = reinterpret_cast<int*>(d.ws_ccd + CL.cnt);
 #ifdef MJH_DBG_GJK_STATS
