@@ -220,6 +220,7 @@ def lib():
   L.mjh_efc_j_sparse.argtypes = [mp, dp, ctypes.c_int, vp, vp, vp, vp, vp]
   L.mjh_ctrl_noise.argtypes = [mp, dp, vp, ctypes.c_int, ctypes.c_float, ctypes.c_float, vp]
   L.mjh_graph_create.argtypes = [mp, dp, vp, ctypes.POINTER(vp)]
+  L.mjh_ws_ccd_floats.argtypes = [ctypes.c_int] * 7 + [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]
   L.mjh_graph_launch.argtypes = [vp, vp]
   L.mjh_graph_destroy.argtypes = [vp]
   L.mjh_timed_steps.argtypes = [mp, dp, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, vp,

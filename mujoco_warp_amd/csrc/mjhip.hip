@@ -870,6 +870,13 @@ static int launch_solve_m(const MjhModel* m, const MjhData* d, float* x, const f
 extern "C" {
 
 int mjh_abi_version(void) { return MJH_ABI_VERSION; }
+int mjh_ws_ccd_floats(int nworld, int iterations, int nhfield, int npolygonmax, int nmeshdegmax, int npair, int concap, double* floats_out, int* nccdhand_out) {
+  if (!floats_out || nworld < 0 || npair < 0 || concap < 0) return fail(MJH_E_ARG, "mjh_ws_ccd_floats: bad argument");
+  const int ccap = collide_ccap(npair, concap), hand = ccd_handcap(nworld, ccap);
+  *floats_out = (double)ccd_layout(nworld, iterations, nhfield, npolygonmax, nmeshdegmax, ccap, hand, npair).total;
+  if (nccdhand_out) *nccdhand_out = hand;
+  return MJH_OK;
+}
 const char* mjh_last_error(void) { return g_err; }
 
 int mjh_stage(const MjhModel* m, const MjhData* d, int stage, void* stream) {

@@ -119,6 +119,22 @@ def test_library_exports_every_declared_symbol():
   assert L.mjh_abi_version() == _abi.DEFINES["MJH_ABI_VERSION"] >= 12
 
 
+def test_ws_ccd_size_mirror_matches_the_library():
+  """io._ccd_words (what put_data allocates for Data.ws_ccd) against the library's own ccd_layout, through mjh_ws_ccd_floats: a binding
+  that allocates Data itself calls the latter; the Python mirror must never be smaller."""
+  from mujoco_warp_amd import io as mio
+  L = _abi.lib()
+  for nworld, it, hf, P, D, npair, nconmax in ((1, 35, 0, 0, 0, 3, 8), (64, 35, 1, 4, 3, 190, 24), (8192, 35, 0, 76, 43, 9154, 24), (2048, 50, 0, 12, 7, 780, 256),
+                                                (3, 64, 1, 8, 8, 1, 1), (512, 16, 0, 0, 0, 100000, 64)):
+    concap = mio.contact_cap(nconmax)
+    ccap = mio._collide_ccap(npair, concap)
+    out, hand = ctypes.c_double(), ctypes.c_int()
+    assert L.mjh_ws_ccd_floats(nworld, it, hf, P, D, npair, concap, ctypes.byref(out), ctypes.byref(hand)) == 0
+    assert hand.value == mio._ccd_handcap(nworld, ccap)
+    words = mio._ccd_words(nworld, it, hf, P, D, ccap, npair)
+    assert words * 32 * nworld >= out.value > (words - 1) * 32 * nworld, (nworld, it, hf, P, D, npair, words, out.value)
+
+
 def test_struct_layout_matches_header():
   assert ctypes.sizeof(_abi.CModel) % 8 == 0 and ctypes.sizeof(_abi.CData) % 8 == 0
   names = [n for n, _, _ in _abi.MODEL_FIELDS]
