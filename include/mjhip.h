@@ -363,7 +363,7 @@ int mjh_timed_steps(const MjhModel* m, const MjhData* d, int nstep, int step0, f
 int mjh_release_thread_resources(void);
 
 const char* mjh_last_error(void);
-#define MJH_ABI_VERSION 39
+#define MJH_ABI_VERSION 40
 /* floats of Data.ws_ccd for a model with GJK pairs (csrc/convex.hpp ccd_layout: per world the candidate list, the per-candidate result cache and the
    broadphase mask; then the EPA hand-over records and the multi-contact buffers) -- what a binding that allocates Data itself must provide;
    iterations = max(ccd_iterations, epa_iterations), concap = Data.concap.  Also returns Data.nccdhand through *nccdhand_out (may be NULL).  Host only. */

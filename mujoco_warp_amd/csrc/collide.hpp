@@ -1418,39 +1418,11 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
 #endif
   // (the pair ids of the NEXT trip are loaded before this trip's tests: at one wavefront per SIMD the table's L2 round trip -- 73 KB read by
   // every world -- was the chain: 72 trips x ~2.5 us)
-  bool from_mask = false;
-  if constexpr (MODE == 1) {
-    // NXN broadphase: the filters ran in k_broad_mask; expand its mask in pair order -- each lane the set bits of one word per trip
-    if (m.broadphase == 0) {
-      from_mask = true;
-      const unsigned* mk = reinterpret_cast<const unsigned*>(ccd_world + CL.bmask);
-      for (int base = 0; base < CL.nbw; base += G) {
-        const int wi = base + lig;
-        unsigned bits = wi < CL.nbw ? mk[wi] : 0u;
-        const int cnt = __popc(bits);
-        int off = cnt;  // inclusive prefix over the lanes of the group
-#pragma unroll
-        for (int sft = 1; sft < G; sft <<= 1) {
-          const int o = __shfl_up(off, sft, G);
-          if (lig >= sft) off += o;
-        }
-        const int tot = __shfl(off, G - 1, G);
-        int o = ncand + off - cnt;
-        while (bits) {
-          const int bit = __ffs(bits) - 1;
-          bits &= bits - 1;
-          if (o < ccap) cand[o] = 32 * wi + bit;
-          ++o;
-        }
-        ncand += tot;
-      }
-    }
-  }
   const int2* pairs2 = reinterpret_cast<const int2*>(m.nxn_geom_pair);
   int2 cur[PU];
 #pragma unroll
   for (int u = 0; u < PU; ++u) cur[u] = (u * G + lig < npair) ? pairs2[u * G + lig] : make_int2(0, 0);
-  for (int base = 0; base < (from_mask ? 0 : npair); base += PU * G) {
+  for (int base = 0; base < npair; base += PU * G) {
     bool passu[PU];
     bool plainu[PU];
     int2 nxt[PU];
@@ -1529,7 +1501,7 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
 #pragma unroll
     for (int u = 0; u < PU; ++u) cur[u] = nxt[u];
   }
-  if (box_filters && !from_mask) stage_b(true);
+  if (box_filters) stage_b(true);
   nbroad = ncand;  // candidates found (Data.ncollision); the capacity bounds what the narrowphase sees
   if (ncand > ccap) ncand = ccap;
   gsync();
@@ -1805,8 +1777,8 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
 //     on -- the world-aligned box (centre +- extent, the pair-independent half of _aabb_filter) in LDS, plus rotation and local box for the OBB filter: 34 words per geom;
 //   * a wavefront tests 64 consecutive pairs at a time: plane / bounding sphere, sleep state, then the box overlap as six compares;
 //   * the OBB filter (separating axes, ~250 instructions) runs on the survivors only, queued per wavefront and served 64 at a time;
-//   * the ballots of the tests are the world's mask (CcdLayout::bmask, bit p % 32 of word p / 32), which k_ccd_broad expands in pair order:
-//     the candidate list is the serial loop's.
+//   * the ballots of the tests are the world's mask over the pair list (in LDS), which the first wavefront expands in pair order at the end:
+//     the candidate list is the serial loop's, and the launch publishes it like k_ccd_broad does for the sweep-and-prune broadphase.
 // Filters: collision_driver.py:124-275 (_aabb_filter, _obb_filter), 278-334 (_plane_filter, _sphere_filter), 494-503 (sleep).
 __host__ __device__ inline int bmask_lds_words(int ngeom, int npair) { return 34 * ngeom + 2 * ((npair + 63) / 64) + 4 * 256 + 8; }
 __global__ void __launch_bounds__(256) k_broad_mask(MjhModel m, MjhData d) {
@@ -1943,12 +1915,88 @@ __global__ void __launch_bounds__(256) k_broad_mask(MjhModel m, MjhData d) {
     }
     if (use_obb && nq > 0) obb_round(nq);
     __syncthreads();
-    unsigned* mk = reinterpret_cast<unsigned*>(d.ws_ccd + (size_t)w * CL.world_stride + CL.bmask);
-    for (int i = tid; i < 2 * ngran; i += 256) mk[i] = fm[i];
+    // the first wavefront expands the mask in pair order and publishes the world's candidate list (what k_ccd_broad does for the sweep-and-
+    // prune broadphase): candidates, counts, and per convex candidate a cache entry "no contact" that carries the pair id
+    if (wv == 0) {
+      float* ccd_world = d.ws_ccd + (size_t)w * CL.world_stride;
+      int* gcand = reinterpret_cast<int*>(ccd_world + CL.cand);
+      int* cnt = reinterpret_cast<int*>(d.ws_ccd + CL.cnt);
+      const unsigned* cmask = reinterpret_cast<const unsigned*>(d.ws_ccd + CL.cmask);
+      const int ccap = CL.ccap;
+      int ncand = 0, ncvx = 0;
+      for (int base = 0; base < 2 * ngran; base += 64) {
+        const int wi = base + lane;
+        const unsigned bits = wi < 2 * ngran ? fm[wi] : 0u;
+        // convex pairs among them (k_ccd_reset's mask: the slot of a convex candidate = its rank is a prefix sum as well)
+        const unsigned cbits = wi < 2 * ngran ? bits & cmask[wi] : 0u;
+        const int c1 = __popc(bits), c2 = __popc(cbits);
+        int o1 = c1, o2 = c2;  // inclusive prefixes over the wavefront
+#pragma unroll
+        for (int sft = 1; sft < 64; sft <<= 1) {
+          const int u1 = __shfl_up(o1, sft, 64), u2 = __shfl_up(o2, sft, 64);
+          if (lane >= sft) {
+            o1 += u1;
+            o2 += u2;
+          }
+        }
+        const int t1 = __shfl(o1, 63, 64), t2 = __shfl(o2, 63, 64);
+        int a = ncand + o1 - c1, c = ncvx + o2 - c2;
+        for (unsigned b = bits; b; b &= b - 1) {
+          const int bit = __ffs(b) - 1, p = 32 * wi + bit;
+          if (a < ccap) {
+            gcand[a] = p;
+            if ((cbits >> bit) & 1u) {
+              int* ce = reinterpret_cast<int*>(ccd_world + CL.cache + (size_t)c * CCD_CACHE_WORDS);
+              ce[0] = 0;
+              ce[CCD_CACHE_WORDS - 1] = p;
+            }
+          }
+          if ((cbits >> bit) & 1u) ++c;
+          ++a;
+        }
+        // (candidates beyond the capacity are dropped, convex ones among them: count only the kept convex candidates)
+        const int kept_before = min(ncand, ccap), kept_after = min(ncand + t1, ccap);
+        if (kept_after - kept_before < t1) {  // the capacity ends inside this trip: recount the convex candidates that were kept
+          int kc = 0;
+          int a2 = ncand + o1 - c1;
+          for (unsigned b = bits; b; b &= b - 1) {
+            if (a2 < ccap && ((cbits >> (__ffs(b) - 1)) & 1u)) ++kc;
+            ++a2;
+          }
+#pragma unroll
+          for (int off = 32; off >= 1; off >>= 1) kc += __shfl_xor(kc, off, 64);
+          ncvx += kc;
+        } else {
+          ncvx += t2;
+        }
+        ncand += t1;
+      }
+      if (lane == 0) {
+        gcand[ccap] = min(ncand, ccap);
+        gcand[ccap + 1] = ncand;
+        gcand[ccap + 2] = ncvx;
+        if (ncvx > __atomic_load_n(cnt, __ATOMIC_RELAXED)) atomicMax(cnt, ncvx);  // (see k_ccd_broad)
+      }
+    }
   }
 }
-__global__ void k_ccd_reset(int* cnt) {
-  if (threadIdx.x < 8) cnt[threadIdx.x] = 0;
+// counters to zero; and which pairs of the filtered list are convex pairs (a wavefront per 64 pairs; the pair types are the model's, box-box
+// depends on DisableBit.NATIVECCD of the step) -- k_broad_mask ranks a world's convex candidates with it
+__global__ void __launch_bounds__(64) k_ccd_reset(MjhModel m, MjhData d) {
+  const CcdLayout CL = ccd_layout_of(m, d);
+  if (blockIdx.x == 0 && threadIdx.x < 8) reinterpret_cast<int*>(d.ws_ccd + CL.cnt)[threadIdx.x] = 0;
+  const int p = 64 * (int)blockIdx.x + (int)threadIdx.x;
+  bool cvx = false;
+  if (p < m.npair) {
+    const int t1 = m.geom_type[m.nxn_geom_pair[2 * p]], t2 = m.geom_type[m.nxn_geom_pair[2 * p + 1]];
+    cvx = is_ccd_pair(m, min(t1, t2), max(t1, t2));
+  }
+  const unsigned long long b = __ballot(cvx);
+  if (threadIdx.x == 0 && 2 * (int)blockIdx.x + 1 < CL.nbw) {
+    unsigned* cm = reinterpret_cast<unsigned*>(d.ws_ccd + CL.cmask);
+    cm[2 * blockIdx.x] = (unsigned)b;
+    cm[2 * blockIdx.x + 1] = (unsigned)(b >> 32);
+  }
 }
 template <int G>
 __global__ void __launch_bounds__(256) k_ccd_broad(MjhModel m, MjhData d) {

@@ -68,13 +68,14 @@ __host__ __device__ inline int ccd_words(int iterations, int hfield = 0) {
 //              [cache]  ccap x CCD_CACHE_WORDS: one entry per convex candidate, slot = its rank among the world's convex candidates
 //              [cand]   ccap + 4 ints: the world's candidate pairs in canonical order | ncand, nbroad, nconvex
 //   tail       [cnt]    8 ints: longest convex candidate list of a world, EPA entries (zeroed by k_ccd_reset in front of k_ccd_broad)
+//              [cmask]  2 ceil(npair / 64) words: which pairs of the list are convex pairs (k_ccd_reset)
 //              [hand]   handcap x CCD_HAND_WORDS: list entry | vertex caches | the GJK simplex, for the EPA launch
 //              [mc]     handcap x ccd_mc_words: multi-contact buffers of the EPA groups (stride 1)
 #define CCD_HAND_WORDS 64
 struct CcdLayout {
   size_t world_stride;  // floats per world
   size_t hf, cache, cand, bmask;  // offsets inside a world's slice
-  size_t tail, cnt, hand, mc, total;  // offsets from the start of ws_ccd
+  size_t tail, cnt, cmask, hand, mc, total;  // offsets from the start of ws_ccd
   int ccap, handcap, mcw, nbw;
 };
 __host__ __device__ inline CcdLayout ccd_layout(int nworld, int iterations, int nhfield, int npolygonmax, int nmeshdegmax, int ccap, int handcap, int npair) {
@@ -91,7 +92,8 @@ __host__ __device__ inline CcdLayout ccd_layout(int nworld, int iterations, int 
   L.tail = L.world_stride * (size_t)nworld;
   L.cnt = L.tail;
   L.handcap = handcap;
-  L.hand = L.cnt + 8;
+  L.cmask = L.cnt + 8;  // bit mask over the pair list: the pairs the convex launches serve (k_ccd_reset writes it: the pair types with the step's flags)
+  L.hand = ((L.cmask + (size_t)L.nbw + 3) / 4) * 4;
   L.mcw = nmeshdegmax > 0 ? 11 * (nmeshdegmax > 3 ? nmeshdegmax : 3) + 22 * (npolygonmax > 4 ? npolygonmax : 4) : 0;
   L.mc = L.hand + (size_t)handcap * CCD_HAND_WORDS;
   L.total = L.mc + (size_t)handcap * L.mcw;

@@ -120,19 +120,21 @@ template <int G>
 static int launch_ccd_pre(const MjhModel* m, const MjhData* d, hipStream_t s) {
   const int it = std::max(m->ccd_iterations, m->epa_iterations);
   const CcdLayout CL = ccd_layout(d->nworld, it, m->nhfield, m->npolygonmax, m->nmeshdegmax, collide_ccap(m->npair, d->concap), d->nccdhand, m->npair);
-  hipLaunchKernelGGL(k_ccd_reset, dim3(1), dim3(64), 0, s, reinterpret_cast<int*>(d->ws_ccd + CL.cnt));  // list / EPA entry counters (a kernel, not a memset node: replayed inside hipGraphs)
+  hipLaunchKernelGGL(k_ccd_reset, dim3(std::max((m->npair + 63) / 64, 1)), dim3(64), 0, s, *m, *d);  // counters, convex-pair mask (a kernel, not a memset node: replayed inside hipGraphs)
   if (m->broadphase == 0 && m->npair > 0) {  // NXN: the broadphase filters of every world as their own launch (a workgroup per world), results as bit masks
     const size_t lds_mask = sizeof(float) * (size_t)bmask_lds_words(m->ngeom, m->npair);
     if (lds_mask > 160 * 1024 || m->ngeom > 65535) return fail(MJH_E_UNSUPPORTED, "k_broad_mask: the geom tables do not fit in LDS");
     HIPCHK(set_lds(k_broad_mask, lds_mask));
     hipLaunchKernelGGL(k_broad_mask, dim3((unsigned)std::min(d->nworld, 8192)), dim3(256), lds_mask, s, *m, *d);
   }
-  size_t lds;
-  const int threads = pick_block(m->broadphase ? sizeof(float) * 9 * m->ngeom : 0, sizeof(float) * broad_lds_words(m->ngeom, m->npair, d->concap, m->broadphase), G, &lds);  // (+ the staged model tables)
-  if (!threads) return fail(MJH_E_UNSUPPORTED, "k_ccd_broad: pair list does not fit in LDS");
-  HIPCHK(set_lds((k_ccd_broad<G>), lds));
-  const int wpb = threads / G;
-  hipLaunchKernelGGL((k_ccd_broad<G>), dim3((d->nworld + wpb - 1) / wpb), dim3(threads), lds, s, *m, *d);
+  if (m->broadphase != 0 || m->npair == 0) {  // sweep-and-prune: the broadphase of a world by its lane group (k_broad_mask publishes the NXN list itself)
+    size_t lds;
+    const int threads = pick_block(sizeof(float) * 9 * m->ngeom, sizeof(float) * broad_lds_words(m->ngeom, m->npair, d->concap, m->broadphase), G, &lds);  // (+ the staged model tables)
+    if (!threads) return fail(MJH_E_UNSUPPORTED, "k_ccd_broad: pair list does not fit in LDS");
+    HIPCHK(set_lds((k_ccd_broad<G>), lds));
+    const int wpb = threads / G;
+    hipLaunchKernelGGL((k_ccd_broad<G>), dim3((d->nworld + wpb - 1) / wpb), dim3(threads), lds, s, *m, *d);
+  }
   // (grids sized for the device -- 256 CUs x 8 workgroups --, not for the lists' capacities: the kernels walk their lists with the grid's stride)
   {
     // lanes per pair by the length of the list (read on the device): one lane per pair needs >= 2 wavefronts per SIMD to hide its chains of

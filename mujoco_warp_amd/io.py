@@ -542,7 +542,8 @@ def _ccd_words(nworld: int, iterations: int, hfield: int, npolygonmax: int, nmes
   world_stride = (bmask + 2 * ((npair + 63) // 64) + 3) // 4 * 4
   handcap = _ccd_handcap(nworld, ccap)
   mcw = 11 * max(int(nmeshdegmax), 3) + 22 * max(int(npolygonmax), 4) if nmeshdegmax > 0 else 0
-  total = world_stride * nworld + 8 + handcap * 64 + handcap * mcw
+  hand = (world_stride * nworld + 8 + 2 * ((npair + 63) // 64) + 3) // 4 * 4  # (behind the counters and the convex-pair mask)
+  total = hand + handcap * 64 + handcap * mcw
   return (total + 32 * nworld - 1) // (32 * nworld)
 
 
