@@ -577,7 +577,7 @@ DEV void convex_epa_group(float tolerance, int epa_iterations, int t1, int t2, V
 #endif
   if (face >= 0) {  // zero margin: up to four contacts from the EPA face, same distance and frame (collision_convex.py:888-960)
     V3 m1[4], m2[4];
-    n = anymesh ? ccd_multicontact_mesh_inl(mm, pt, face, w1, w2, a, b, m1, m2, mcws, 1, poly, ccd_coop_poly_words(max(mm.ccd_iterations, mm.epa_iterations), mm.npolygonmax, mm.nmeshdegmax))
+    n = anymesh ? ccd_multicontact_mesh_inl(mm, pt, face, w1, w2, a, b, m1, m2, mcws, 1, poly, ccd_coop_face_offset(max(mm.ccd_iterations, mm.epa_iterations), mm.npolygonmax))
                 : ccd_multicontact_box(pt, face, w1, w2, a, b, m1, m2);
     if (n == 0) return;
     const Frame f = make_frame3(dist <= margin ? m1[0] - m2[0] : m2[0] - m1[0]);
@@ -2119,8 +2119,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MJH_GJ
   }
 }
 // one lane GROUP per entry of the EPA list: polytope in the group's LDS, then the multi-contact recovery; lane 0 stores the result
+#ifndef MJH_EPA_WAVES  // wavefronts per SIMD the register allocation of k_ccd_epa aims at (developer knob)
+#define MJH_EPA_WAVES 3
+#endif
 template <int G>
-__global__ void __launch_bounds__(256) k_ccd_epa(MjhModel m, MjhData d) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MJH_EPA_WAVES, 8))) k_ccd_epa(MjhModel m, MjhData d) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const CcdLayout CL = ccd_layout_of(m, d);
   const int npend = min(reinterpret_cast<const int*>(d.ws_ccd + CL.cnt)[1], CL.handcap);

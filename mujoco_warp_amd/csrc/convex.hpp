@@ -100,15 +100,18 @@ __host__ __device__ inline CcdLayout ccd_layout(int nworld, int iterations, int 
   return L;
 }
 // LDS words of an EPA group: the polytope; for models with multi-contact recovery on mesh faces (nmeshdegmax > 0) also the polygon buffers of
-// that recovery -- the clipping planes and the two clip buffers (16 P words, P = npolygonmax) OVER the polytope, which is dead by the time
-// they are written, and the two faces (6 P words) behind them
-__host__ __device__ inline int ccd_coop_poly_words(int iterations, int npolygonmax, int nmeshdegmax) {
-  const int pw = ccd_poly_words(iterations), P = npolygonmax > 4 ? npolygonmax : 4;
-  return nmeshdegmax > 0 && 16 * P > pw ? 16 * P : pw;
+// that recovery (P = npolygonmax): the two clip buffers (12 P words) from word 0 -- over the polytope, which is dead by the time they are
+// written -- and the two faces (6 P words) behind them, but not before the polytope's face records end (vertices, vertex ids and face
+// records are still read while the faces are gathered; the face normals / distances behind them are not)
+__host__ __device__ inline int ccd_coop_face_offset(int iterations, int npolygonmax) {
+  const int it = iterations < CCD_MAX_ITER ? iterations : CCD_MAX_ITER, P = npolygonmax > 4 ? npolygonmax : 4;
+  const int live = 8 * (5 + it) + (6 + CCD_EPAFACES * it);  // vertices (6 words) + vertex ids (2) per vertex, one word per face
+  return 12 * P > live ? 12 * P : live;
 }
 __host__ __device__ inline int ccd_coop_words(int iterations, int npolygonmax, int nmeshdegmax) {
-  const int P = npolygonmax > 4 ? npolygonmax : 4;
-  return ((ccd_coop_poly_words(iterations, npolygonmax, nmeshdegmax) + (nmeshdegmax > 0 ? 6 * P : 0) + 3) / 4) * 4;
+  const int pw = ccd_poly_words(iterations), P = npolygonmax > 4 ? npolygonmax : 4;
+  const int mc = nmeshdegmax > 0 ? ccd_coop_face_offset(iterations, npolygonmax) + 6 * P : 0;
+  return (((mc > pw ? mc : pw) + 3) / 4) * 4;
 }
 // (models with multi-contact recovery on mesh faces append ccd_mc_words(npolygonmax, nmeshdegmax) words per lane: further below)
 
@@ -1435,23 +1438,20 @@ DEV int mc_mesh_face(const MeshTab& t, const CcdGeom& g, int idx, int cap, const
   return nv;
 }
 // mc_polygon_clip on workspace polygons; cap = 2 * npolygonmax slots per clip buffer (collision_convex.py:1346-1348)
-DEV int mc_polygon_clip_ws(const WsV& face1, int nface1, const WsV& face2, int nface2, V3 n, V3 dir, int cap, const WsV& pn, const WsF& pd, WsV poly, WsV clip,
+DEV int mc_polygon_clip_ws(const WsV& face1, int nface1, const WsV& face2, int nface2, V3 n, V3 dir, int cap, WsV poly, WsV clip,
                            V3 (&w1)[4], V3 (&w2)[4]) {
   if (nface1 < 3) return 0;
 #ifdef MJH_DBG_EPA_CLOCK
   unsigned long long dbg_c0_ = __builtin_amdgcn_s_memtime();
 #endif
-  for (int i = 0; i < nface1; ++i) {
-    const V3 a = face1.get(i), b = face1.get((i + 1) % nface1);
-    const V3 pni = cross(b - a, (a + n) - a);
-    pn.set(i, pni);
-    pd.set(i, dot(pni, a));
-  }
+  // (the side plane of edge e -- normal cross(b - a, (a + n) - a), offset normal . a -- is computed where it is used instead of into a table
+  // first: the same arithmetic, 4 P words of workspace less)
   int np = nface2, nc = 0;
   for (int i = 0; i < nface2; ++i) poly.set(i, face2.get(i));
   for (int e = 0; e < nface1; ++e) {
-    const V3 fe = face1.get(e), pne = pn.get(e);
-    const float pde = pd.get(e);
+    const V3 fe = face1.get(e), fnx = face1.get((e + 1) % nface1);
+    const V3 pne = cross(fnx - fe, (fe + n) - fe);
+    const float pde = dot(pne, fe);
     V3 P = np > 0 ? poly.get(0) : V3{0, 0, 0};
     for (int i = 0; i < np; ++i) {
       const V3 Q = poly.get((i + 1) % np);
@@ -1548,9 +1548,7 @@ DEV int ccd_multicontact_mesh_inl(const MjhModel& m, const Poly& pt, int epa_fac
   // an EPA group (lds != nullptr): the polygon buffers in the group's LDS (ccd_coop_words) -- the clip loop and the pruning of the clipped
   // polygon are serial chains of reads and writes of these buffers (ALOHA pot on the table: a 76-gon), in global memory 70 % of k_ccd_epa
   const WsV face1 = lds ? WsV{lds + lds_face, 1} : WsV{at(f0), wst}, face2 = lds ? WsV{lds + lds_face + 3 * P, 1} : WsV{at(f0 + 3 * P), wst};
-  const WsV pn = lds ? WsV{lds, 1} : WsV{at(f0 + 6 * P), wst};
-  const WsF pd = lds ? WsF{lds + 3 * P, 1} : WsF{at(f0 + 9 * P), wst};
-  const WsV bufa = lds ? WsV{lds + 4 * P, 1} : WsV{at(f0 + 10 * P), wst}, bufb = lds ? WsV{lds + 10 * P, 1} : WsV{at(f0 + 16 * P), wst};
+  const WsV bufa = lds ? WsV{lds, 1} : WsV{at(f0 + 10 * P), wst}, bufb = lds ? WsV{lds + 6 * P, 1} : WsV{at(f0 + 16 * P), wst};
   int fi1[3], fi2[3];
   V3 fv1[3], fv2[3];
   const int nf1 = mc_feature_dim(pt, face, 0, fi1, fv1), nf2 = mc_feature_dim(pt, face, 1, fi2, fv2);
@@ -1646,13 +1644,13 @@ DEV int ccd_multicontact_mesh_inl(const MjhModel& m, const Poly& pt, int epa_fac
   const int cap = 2 * P;
   if (edge1) {
     const V3 nn = n2.get(rj);
-    return mc_polygon_clip_ws(face2, nface2, face1, nface1, nn, (-dn) * nn, cap, pn, pd, bufa, bufb, w2, w1);
+    return mc_polygon_clip_ws(face2, nface2, face1, nface1, nn, (-dn) * nn, cap, bufa, bufb, w2, w1);
   }
   if (edge2) {
     const V3 nn = n1.get(rj);
-    return mc_polygon_clip_ws(face1, nface1, face2, nface2, nn, (-dn) * nn, cap, pn, pd, bufa, bufb, w1, w2);
+    return mc_polygon_clip_ws(face1, nface1, face2, nface2, nn, (-dn) * nn, cap, bufa, bufb, w1, w2);
   }
-  return mc_polygon_clip_ws(face1, nface1, face2, nface2, n1.get(ri), dn * n2.get(rj), cap, pn, pd, bufa, bufb, w1, w2);
+  return mc_polygon_clip_ws(face1, nface1, face2, nface2, n1.get(ri), dn * n2.get(rj), cap, bufa, bufb, w1, w2);
 }
 
 __device__ __noinline__ int ccd_multicontact_mesh(const MjhModel& m, const Poly& pt, int epa_face, V3 x1, V3 x2, const CcdGeom& g1, const CcdGeom& g2,
