@@ -290,14 +290,14 @@ __global__ void __launch_bounds__(256) k_solve_m(MjhModel m, MjhData d, float* x
 // `sh` needs 512 ints of LDS; any workgroup size that is a multiple of 64.  Global loads are batched eight deep ahead
 // of the LDS atomics (a load -> atomic -> store chain per world costs a full memory latency per iteration: 50-70 us
 // for 8192 worlds on one small workgroup), the 128-bin prefix is one wavefront scan.
-DEV void schedule_body(const MjhData& d, int* sh, int nthreads) {
+DEV void schedule_body(const MjhData& d, int* sh, int nthreads, int cls = 32) {  // cls: the row count that separates the two classes
   // key: worlds that had more than 32 constraint rows first, then the others (the solver's one-row-per-lane instantiation takes the worlds
   // of at most 32 rows in a launch of its own: with the two classes apart both launches run dense workgroups); inside a class by iteration
   // count, longest first.  256 bins: `sh` needs 512 ints.
   int* hist = sh;
   int* base = sh + 256;
   const int t = threadIdx.x, n = d.nworld;
-  auto bin = [](int niter, int nefc) { return (nefc > 32 ? 0 : 128) + 127 - min(max(niter, 0), 127); };
+  auto bin = [cls](int niter, int nefc) { return (nefc > cls ? 0 : 128) + 127 - min(max(niter, 0), 127); };
   for (int i = t; i < 256; i += nthreads) hist[i] = 0;
   __syncthreads();
   for (int w0 = t; w0 < n; w0 += 8 * nthreads) {
@@ -343,9 +343,9 @@ DEV void schedule_body(const MjhData& d, int* sh, int nthreads) {
       if (w0 + k * nthreads < n) d.ws_order[pos[k]] = w0 + k * nthreads;
   }
 }
-__global__ void __launch_bounds__(1024) k_schedule_worlds(MjhData d) {
+__global__ void __launch_bounds__(1024) k_schedule_worlds(MjhData d, int cls) {
   __shared__ int sh[512];
-  schedule_body(d, sh, blockDim.x);
+  schedule_body(d, sh, blockDim.x, cls);
 }
 
 template <int G>

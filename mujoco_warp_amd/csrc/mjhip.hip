@@ -275,7 +275,7 @@ __global__ void __launch_bounds__(256) k_mid(MjhModel m, MjhData d, int ncc, int
   // sched: workgroup 0 sorts the solver schedule here instead of in the k_fwd_pos launch (models whose fwd_pos
   // workgroups are too small to do it quickly)
   if (sched && blockIdx.x == 0) {
-    schedule_body(d, reinterpret_cast<int*>(smem), blockDim.x);
+    schedule_body(d, reinterpret_cast<int*>(smem), blockDim.x, m.nv > 32 ? 64 : 32);
     return;
   }
   const int bi = (int)blockIdx.x - sched;
@@ -306,7 +306,7 @@ __global__ void __launch_bounds__(256) k_fwd_pos_plus(MjhModel m, MjhData d, int
   // the schedule workgroup goes FIRST: workgroups are dispatched in index order, so as the last one it would start
   // when the launch is nearly over and add its whole duration (~8 us) to it
   if (blockIdx.x == 0) {
-    schedule_body(d, reinterpret_cast<int*>(smem), blockDim.x);
+    schedule_body(d, reinterpret_cast<int*>(smem), blockDim.x, m.nv > 32 ? 64 : 32);
   } else if ((int)blockIdx.x <= npos) {
     const int wpb = blockDim.x / G;
     fwd_pos_body<G>(m, d, first, last, smem, Blk{((int)blockIdx.x - 1) * wpb, wpb, (int)blockDim.x});
@@ -501,8 +501,17 @@ static int launch_solve_any(const MjhModel* m, const MjhData* d, bool with_facto
   // first on the same stream, so the split point is chosen to leave it (almost) empty: its real worlds would otherwise
   // be a serial tail on an idle GPU (G1: 6 % of the worlds exceed 64 rows, practically none exceed 128)
   if (d->njmax <= 64) return s64(m, d, 1, with_factor, fe, s, -1, all);
-  if (d->njmax <= 128) return s64(m, d, 2, with_factor, fe, s, -1, all);
-  if (int rc = s64(m, d, 2, with_factor, fe, s, -1, 128)) return rc;
+  // (developer knob MJH_SOLVE64_R1=1: the worlds of at most 64 rows by the one-row instantiation -- half the J tile -- in a launch of their own.
+  // Measured on the G1 replay, 4096 worlds, nefc 68 on average: bit-identical states, 7.84 vs 9.14 M env-steps/s -- a second launch with real
+  // worlds costs the latency of one more solve.  Off.)
+  static const bool r1_64 = getenv("MJH_SOLVE64_R1") && atoi(getenv("MJH_SOLVE64_R1")) != 0;
+  int lo64 = -1;
+  if (r1_64) {
+    if (int rc = s64(m, d, 1, false, fe, s, -1, 64)) return rc;
+    lo64 = 64;
+  }
+  if (d->njmax <= 128) return s64(m, d, 2, with_factor, fe, s, lo64, all);
+  if (int rc = s64(m, d, 2, with_factor, fe, s, lo64, 128)) return rc;
   if (int rc = s64(m, d, 3, false, fe, s, 128, top)) return rc;
   return d->njmax > 192 ? launch_solve_big(m, d, s, 192) : MJH_OK;
 }
@@ -783,7 +792,7 @@ static int run_stage(const MjhModel* m, const MjhData* d, int stage, hipStream_t
       static const bool plain = getenv("MJH_PLAIN") != nullptr;  // developer knob: one plain kernel per stage, serial
       if ((g_instr && g_instr->on && g_instr->plain) || plain) {
         // profiling pass: one plain kernel per stage, so that the event pairs time one kernel at a time
-        { Scope sc(K_OTHER); hipLaunchKernelGGL(k_schedule_worlds, dim3(1), dim3(1024), 0, s, *d); }
+        { Scope sc(K_OTHER); hipLaunchKernelGGL(k_schedule_worlds, dim3(1), dim3(1024), 0, s, *d, m->nv > 32 ? 64 : 32); }
         { Scope sc(K_POS); TRY(launch_pos(m, d, POS_KINEMATICS, POS_CRB, s)); }
         { Scope sc(K_COLLISION); TRY(launch_collision(m, d, s)); }
         { Scope sc(K_CONSTRAINT); TRY(launch_constraint(m, d, s)); }

@@ -1,11 +1,7 @@
 #!/bin/bash
 mkdir -p gpurun_out
-for n in aloha_pot clutter_synth; do python tools/diag_state_hash.py $n 256 120 2>&1 | tail -n 1; done
-for v in "" epaw2 "" epaw2; do
-  lib=""; [ -n "$v" ] && lib=mujoco_warp_amd/libmjhip_$v.so
-  [ -n "$lib" ] && export MJH_LIB=$PWD/$lib || unset MJH_LIB
-  python benchmarks/run.py -f "aloha_pot|clutter_synth$" 2>&1 | grep steps_per_second | sed "s|^|lib=$v |"
+for r in 0 1 0 1; do
+  MJH_SOLVE64_R1=$r python benchmarks/run.py -f "unitree_g1_flat" 2>&1 | grep -E "steps_per_second" | sed "s|^|R1_64=$r |"
 done
-unset MJH_LIB
-timeout 300 bash tools/trace_lib.sh "" aloha_pot 600 2>&1 | grep -E "epa|gjk"
-timeout 900 python -m pytest tests -m gpu -q -x 2>&1 | tail -n 3
+MJH_SOLVE64_R1=1 python tools/diag_state_hash.py unitree_g1_flat 256 120 2>&1 | tail -n 1
+python tools/diag_state_hash.py unitree_g1_flat 256 120 2>&1 | tail -n 1
