@@ -306,6 +306,64 @@ def test_gpu_convex_scene_steps_match_oracle(solver):
   assert (d.overflow.numpy() == 0).all()
 
 
+# ---- broadphase of models with GJK pairs: k_broad_mask (NXN: a workgroup per world, bit mask over the pair list) against the sweep-and-prune
+# launch (k_ccd_broad) and against the oracle, for every filter combination, with margins, gaps and an explicit <contact><pair> ----
+CROWD_XML = CONVEX_SCENE_XML.replace("<worldbody>", """<default><geom margin="0.02" gap="0.005"/></default>
+  <contact><pair geom1="table" geom2="dome" margin="0.3" gap="0.1" condim="3"/></contact>
+  <worldbody>""").replace('name="table"', 'name="table" margin="0.05"').replace('name="dome"', 'name="dome" gap="0.02"')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bfilter", [1, 2, 3, 5, 7, 10, 11, 15])
+def test_gpu_broad_mask_equals_sap_and_oracle(bfilter):
+  import mujoco_warp_amd as mjw
+
+  mjm = mjw.mjcf.from_xml_string(CROWD_XML)
+  rng = np.random.default_rng(5)
+  nworld = 24
+  q0 = np.asarray(mjw.MjData(mjm).qpos, dtype=np.float64)
+  qs = np.tile(q0, (nworld, 1))
+  for w in range(1, nworld):  # world 0: the authored poses; the others: the free bodies thrown together over the table
+    for b in range(mjm.nq // 7):
+      qs[w, 7 * b: 7 * b + 3] = [rng.uniform(-0.5, 0.5), rng.uniform(-0.3, 0.3), rng.uniform(0.12, 0.35)]
+      quat = rng.normal(size=4)
+      qs[w, 7 * b + 3: 7 * b + 7] = quat / np.linalg.norm(quat)
+  found = {}
+  for bp in (mjw.BroadphaseType.NXN, mjw.BroadphaseType.SAP_TILE):
+    m = mjw.put_model(mjm)
+    m.opt.broadphase = int(bp)
+    m.opt.broadphase_filter = int(bfilter)
+    d = mjw.put_data(mjm, mjw.MjData(mjm), nworld=nworld, nconmax=48, njmax=192)
+    d.qpos.assign(qs.astype(np.float32))
+    mjw.kinematics(m, d)
+    mjw.collision(m, d)
+    assert (d.overflow.numpy() == 0).all()
+    ncon, adr, geom = d.ws_ncon.numpy(), d.ws_conadr.numpy(), d.contact.geom.numpy()
+    found[int(bp)] = (d.ws_ncollision.numpy().copy(), [tuple(map(tuple, geom[int(adr[w]): int(adr[w]) + int(ncon[w])])) for w in range(nworld)],
+                      d.contact.dist.numpy()[: int(ncon.sum())].copy())
+  a, b = found[int(mjw.BroadphaseType.NXN)], found[int(mjw.BroadphaseType.SAP_TILE)]
+  # (the sweep prunes by its own projection test whatever the filters: its candidate COUNT is its own -- checked against the oracle's sweep
+  # below --, the contacts are the same)
+  assert (b[0] <= a[0]).all(), (a[0], b[0])
+  assert a[1] == b[1]
+  assert np.array_equal(a[2], b[2])
+  ncoll = 0
+  for w in range(0, nworld, 3):
+    s = ref.RefSim(mjm, nconmax=48, njmax=192, broadphase=0, broadphase_filter=int(bfilter))
+    s.qpos[:] = qs[w]
+    s.stage("kinematics")
+    s.stage("collision")
+    assert int(a[0][w]) == s.ncollision, (w, int(a[0][w]), s.ncollision)
+    assert [tuple(g) for g in a[1][w]] == [tuple(int(x) for x in g) for g in s.con_geom[: s.ncon]], w
+    ncoll += s.ncollision
+    s2 = ref.RefSim(mjm, nconmax=48, njmax=192, broadphase=1, broadphase_filter=int(bfilter))
+    s2.qpos[:] = qs[w]
+    s2.stage("kinematics")
+    s2.stage("collision")
+    assert int(b[0][w]) == s2.ncollision, (w, int(b[0][w]), s2.ncollision)
+  assert ncoll >= 16
+
+
 # ---- box-box through CCD + multi-contact (the reference's default; the primitive mjc_BoxBox collider needs DisableBit.NATIVECCD) ----
 BOX_CCD_XML = """
 <mujoco>
