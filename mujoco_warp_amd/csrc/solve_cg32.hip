@@ -8,3 +8,16 @@ int launch_solve_32_cg(const MjhModel* m, const MjhData* d, int nr, bool with_fa
     default: return fail(MJH_E_ARG, "k_solve: unsupported rows per lane");
   }
 }
+
+#ifdef MJH_PHASE_CLOCK
+// profiling variant (tools/build_variant_fast.py clk32 solve_cg32.hip -DMJH_PHASE_CLOCK; tools/phase_clock.py --lib ...): this unit's copy of
+// the per-phase tick sums of solve_body
+extern "C" __attribute__((visibility("default"))) int mjh_debug_phase_ticks(unsigned long long* out, int reset) {
+  if (out) HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_ticks), sizeof(unsigned long long) * 64 * 8 * 16));
+  if (reset) {
+    static unsigned long long zeros[64 * 8 * 16] = {0};
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_phase_ticks), zeros, sizeof(zeros)));
+  }
+  return MJH_OK;
+}
+#endif

@@ -39,13 +39,17 @@ def main():
   ap.add_argument("--xml", default=os.path.join(ROOT, "benchmarks", "humanoid", "humanoid.xml"))
   ap.add_argument("--nconmax", type=int, default=24)
   ap.add_argument("--njmax", type=int, default=64)
+  ap.add_argument("--lib", default=None, help="an instrumented library built elsewhere (one unit with -DMJH_PHASE_CLOCK, tools/build_variant_fast.py) instead of the unity build")
   ap.add_argument("--iterations", type=int, default=-1, help="cap opt.iterations for the measured steps (state from the uncapped warm-up)")
   args = ap.parse_args()
-  if args.build_only or not os.path.exists(LIB):
-    build()
-    if args.build_only:
-      return
-  os.environ["MJH_LIB"] = LIB
+  if args.lib:
+    os.environ["MJH_LIB"] = os.path.abspath(args.lib)
+  else:
+    if args.build_only or not os.path.exists(LIB):
+      build()
+      if args.build_only:
+        return
+    os.environ["MJH_LIB"] = LIB
   import mujoco_warp_amd as mjw
   from mujoco_warp_amd import _abi
 
