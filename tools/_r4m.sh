@@ -1,8 +1,11 @@
 #!/bin/bash
 mkdir -p gpurun_out
-(echo "# python tools/phase_clock.py --solver cg --lib mujoco_warp_amd/libmjhip_clk32.so   (solve_cg32.hip compiled with -DMJH_PHASE_CLOCK; humanoid, 8192 worlds,"
- echo "# 50 steps after 100; shader-clock ticks of lane 0 of every world between the marks of solve_body, summed and divided by worlds x steps)"
- timeout 300 python tools/phase_clock.py --solver cg --lib mujoco_warp_amd/libmjhip_clk32.so 2>&1 | grep -v amdgpu | grep -A18 -E "^cg:|^solve:") > gpurun_out/round4_phase_cg.txt
-(echo "# python tools/phase_clock.py --solver newton --lib mujoco_warp_amd/libmjhip_clkn32.so   (solve_newton32.hip with -DMJH_PHASE_CLOCK)"
- timeout 300 python tools/phase_clock.py --solver newton --lib mujoco_warp_amd/libmjhip_clkn32.so 2>&1 | grep -v amdgpu | grep -A18 -E "^newton:|^solve:") > gpurun_out/round4_phase_newton.txt
-cat gpurun_out/round4_phase_cg.txt gpurun_out/round4_phase_newton.txt
+timeout 300 python tools/phase_clock.py --solver newton --lib mujoco_warp_amd/libmjhip_clkn64.so --xml benchmarks/unitree_g1/scene_flat.xml --nworld 4096 --nconmax 48 --njmax 192 2>&1 | grep -v amdgpu | grep -A18 -E "^newton:|^solve:" | grep -v ": 0 ticks" | grep -v "    0    0.0%" | tail -n 16
+for r in 1 2; do
+for lib in "" mujoco_warp_amd/libmjhip_prev.so; do
+  [ -n "$lib" ] && export MJH_LIB=$PWD/$lib || unset MJH_LIB
+  python benchmarks/run.py -f "unitree_g1_flat|three_humanoids|clutter_synth$" 2>&1 | grep steps_per_second | sed "s|^|lib=$lib |"
+done
+done
+unset MJH_LIB
+timeout 900 python -m pytest tests -m gpu -q -x 2>&1 | tail -n 3

@@ -3,8 +3,9 @@
 Builds libmjhip_clk.so with -DMJH_PHASE_CLOCK (lane 0 of every world adds shader-clock ticks between phase marks to a
 device table), runs N humanoid steps and prints each phase's share of its kernel and the absolute ticks per world-step.
 Run on the GPU box:  python tools/phase_clock.py [--solver cg|newton] [--build-only]
-(Last verified with ABI v16; the instrumented unity build of ABI v29 faults at launch -- not investigated: the figures quoted in
-DESIGN.md come from the v16 run.)
+Round 4: `--lib` takes a library in which ONE solver unit was compiled with -DMJH_PHASE_CLOCK (tools/build_variant_fast.py <tag> solve_cg32.hip
+-DMJH_PHASE_CLOCK; the units solve_cg32 / solve_newton32 / solve_newton64 carry the reader): profiles/round4_phase_*.txt.  (The unity build below
+was last verified with ABI v16 and does not include the units added since.)
 """
 import argparse, ctypes, os, subprocess, sys
 import numpy as np
