@@ -1148,7 +1148,11 @@ __host__ __device__ inline int broad_lds_words(int ngeom, int npair, int concap,
   const int base = 4 * ngeom + 2 * collide_ccap(npair, concap) + CON_WINDOW * CON_LDS;
   return ((base + 3 * sap_pow2(ngeom) + ((npair + 31) / 32 + 3) / 4 * 4) + 3) / 4 * 4;
 }
-__host__ __device__ inline int collide_lds_words(int ngeom, int npair, int concap, int sap = 0) {
+// pre: the candidate list and the convex results come from the launches in front of the kernel (models with GJK pairs) -- no broadphase here,
+// and the poses of the few candidates' geoms are read from global memory instead of staging all of them (ALOHA scene: 204 geoms = 9.8 of 16 KB
+// per world for some 14 candidates)
+__host__ __device__ inline int collide_lds_words(int ngeom, int npair, int concap, int sap = 0, bool pre = false) {
+  if (pre) return 2 * collide_ccap(npair, concap) + CON_WINDOW * CON_LDS;
   const int base = 12 * ngeom + 2 * collide_ccap(npair, concap) + CON_WINDOW * CON_LDS;
   return base + (sap ? 3 * sap_pow2(ngeom) + ((npair + 31) / 32 + 3) / 4 * 4 : 0);
 }
@@ -1241,17 +1245,18 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
   // k_ccd_broad keeps only what its pair loop reads in LDS -- position | bounding radius of every geom as ONE 16-byte read, the candidate
   // list, the queue -- and reads the rotation matrices of the few pairs that reach the plane test / the box filters from global memory:
   // 9.5 instead of 19 KB per world on the ALOHA scene (12 instead of 8 worlds per CU)
-  const int slice_words = MODE == 1 ? broad_lds_words(ng, npair, ncap, m.broadphase) : collide_lds_words(ng, npair, ncap, HEAVY ? m.broadphase : 0);
+  const bool pre = HEAVY && d.ws_ccd != nullptr;  // models with GJK pairs: k_ccd_broad / k_ccd_gjk / k_ccd_epa ran (or: this IS k_ccd_broad)
+  const bool geoms_global = MODE == 1 || pre;     // geom poses from global memory (MODE 0 without the launches in front: staged in LDS)
+  const int slice_words = MODE == 1 ? broad_lds_words(ng, npair, ncap, m.broadphase) : collide_lds_words(ng, npair, ncap, HEAVY ? m.broadphase : 0, pre);
   float* S = smem + (size_t)gib * (stride_words ? stride_words : slice_words);
   float* gx4 = S;  // (MODE 1 only)
-  const float* gxpos = MODE == 1 ? d.geom_xpos + (size_t)w * 3 * m.ngeom : S;
-  const float* gxmat = MODE == 1 ? d.geom_xmat + (size_t)w * 9 * m.ngeom : S + 3 * ng;
-  int* cand = reinterpret_cast<int*>(S + (MODE == 1 ? (m.broadphase != 0 ? 4 * ng : 0) : 12 * ng));
+  const float* gxpos = geoms_global ? d.geom_xpos + (size_t)w * 3 * m.ngeom : S;
+  const float* gxmat = geoms_global ? d.geom_xmat + (size_t)w * 9 * m.ngeom : S + 3 * ng;
+  int* cand = reinterpret_cast<int*>(S + (MODE == 1 ? (m.broadphase != 0 ? 4 * ng : 0) : (pre ? 0 : 12 * ng)));
   const int ccap = collide_ccap(npair, ncap);
   int* cslot = cand + ccap;
   float* rec = reinterpret_cast<float*>(cslot + ccap);
 
-  const bool pre = HEAVY && d.ws_ccd != nullptr;  // models with GJK pairs: k_ccd_broad / k_ccd_gjk / k_ccd_epa ran (or: this IS k_ccd_broad)
   if (m.disableflags & (DSBL_CONSTRAINT | DSBL_CONTACT)) {
     if (lig == 0 && MODE == 0) {
       d.ws_ncon[w] = 0;
@@ -1267,7 +1272,7 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
   }
   int* gcand = ccd_world ? reinterpret_cast<int*>(ccd_world + CL.cand) : nullptr;  // ccap candidates | ncand, nbroad, nconvex
   PhaseClock pc(2, lig);
-  if constexpr (MODE != 1) {
+  if (!geoms_global) {
     gcopy<G>(S, d.geom_xpos + (size_t)w * 3 * ng, 3 * ng, lig);
     gcopy<G>(S + 3 * ng, d.geom_xmat + (size_t)w * 9 * ng, 9 * ng, lig);
   }

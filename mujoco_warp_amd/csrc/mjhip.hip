@@ -160,7 +160,7 @@ static int launch_collision_g(const MjhModel* m, const MjhData* d, hipStream_t s
     if (rc != MJH_OK) return rc;
   }
   size_t lds;
-  const int threads = pick_block(0, sizeof(float) * collide_lds_words(m->ngeom, m->npair, d->concap, m->heavy_colliders ? m->broadphase : 0), G, &lds);
+  const int threads = pick_block(0, sizeof(float) * collide_lds_words(m->ngeom, m->npair, d->concap, m->heavy_colliders ? m->broadphase : 0, m->heavy_colliders && d->ws_ccd != nullptr), G, &lds);
   if (!threads) return fail(MJH_E_UNSUPPORTED, "k_collision: pair list does not fit in LDS");
   if (m->heavy_colliders) {
     const int wpb_h = threads / G;
@@ -327,7 +327,7 @@ static int launch_mid_g(const MjhModel* m, const MjhData* d, bool sched, hipStre
     }
   }
   const ConLayout cl = con_layout(m->nv, d->njmax, d->concap, m->nbody, m->ngeom);
-  const int stride_cc = std::max(cl.total, collide_lds_words(m->ngeom, m->npair, d->concap, m->heavy_colliders ? m->broadphase : 0) | 1);
+  const int stride_cc = std::max(cl.total, collide_lds_words(m->ngeom, m->npair, d->concap, m->heavy_colliders ? m->broadphase : 0, m->heavy_colliders && d->ws_ccd != nullptr) | 1);
   const VelLayout vl = vel_layout(m->nq, m->nv, m->nbody, m->nC, m->nu);
   const size_t ms_bytes = sizeof(int) * mstruct_ints(m->nv, m->nC);
   // 8 collision+constraint worlds per workgroup; as many fwd_vel worlds as fit in the same LDS footprint
