@@ -133,6 +133,8 @@ typedef struct MjhModel {
   int act_velfeedback;          /* 1: some actuator feeds velocity back with a positive sign (affine gain on velocity, or bias velocity coefficient > 0):
                                    M + h D - h dA/dv may then be indefinite, and implicitfast keeps the integrator launch's L'DL solve instead of the
                                    solver epilogue's Cholesky (csrc/solver.hpp impfast_acc) */
+  int cg_basis;                 /* 1: every contact the model can make has condim 3 (pyramidal: four rows spanned by three basis rows J_n, mu J_t1, mu J_t2):
+                                   CG at nv <= 32, njmax <= 64 runs the pooled contact-basis kernel (csrc/solver_cgp.hpp) */
   int ntree;                    /* trees with at least one dof */
   int tree_nvmax;               /* dofs of the largest tree */
   int isl_nv4;                  /* ceil(dofs / 4) of the widest island of at most 32 dofs the model can form (kernel size class) */
@@ -363,12 +365,15 @@ int mjh_timed_steps(const MjhModel* m, const MjhData* d, int nstep, int step0, f
 int mjh_release_thread_resources(void);
 
 const char* mjh_last_error(void);
-#define MJH_ABI_VERSION 40
+#define MJH_ABI_VERSION 41
 /* floats of Data.ws_ccd for a model with GJK pairs (csrc/convex.hpp ccd_layout: per world the candidate list, the per-candidate result cache and the
    broadphase mask; then the EPA hand-over records and the multi-contact buffers) -- what a binding that allocates Data itself must provide;
    iterations = max(ccd_iterations, epa_iterations), concap = Data.concap.  Also returns Data.nccdhand through *nccdhand_out (may be NULL).  Host only. */
 int mjh_ws_ccd_floats(int nworld, int iterations, int nhfield, int npolygonmax, int nmeshdegmax, int npair, int concap, double* floats_out, int* nccdhand_out);
 int mjh_abi_version(void); /* returns MJH_ABI_VERSION of the library that was loaded */
+/* hash of the sources and compiler flags the library was built from (csrc/build_id.hip); the Python loader compares it with the hash of the
+   sources on disk and rebuilds -- or refuses to load -- a library that does not match */
+const char* mjh_build_id(void);
 
 #ifdef __cplusplus
 }

@@ -16,9 +16,9 @@ HEADER = os.path.join(_ROOT, "include", "mjhip.h")
 LIB_PATH = os.path.join(_PKG, "libmjhip.so")
 # translation units of the library (compiled in parallel; the solver kernels are ~70 template instantiations) and the
 # headers they include
-UNITS = ["mjhip.hip", "solve_cg32.hip", "solve_ell_newton32_r1.hip", "solve_cgw.hip", "solve_newton32.hip", "solve_cg64.hip", "solve_newton64.hip", "solve_ell_cg32.hip", "solve_ell_newton32.hip",
-         "solve_ell_cg64.hip", "solve_ell_newton64.hip", "solve_tree_cg.hip", "solve_tree_newton.hip", "solve_tree_ell_cg.hip", "solve_tree_ell_newton.hip", "pgs_tu.hip", "solve_big.hip"]
-HEADERS = ["host.hpp", "solve_tu.hpp", "solve_tree.hpp", "dev_common.hpp", "smooth.hpp", "collide.hpp", "constraint.hpp", "solver.hpp", "solver_cgw.hpp", "solver_newton.hpp", "solver_big.hpp", "pgs.hpp",
+UNITS = ["mjhip.hip", "solve_cgp.hip", "solve_cg32.hip", "solve_ell_newton32_r1.hip", "solve_cgw.hip", "solve_newton32.hip", "solve_cg64.hip", "solve_newton64.hip", "solve_ell_cg32.hip", "solve_ell_newton32.hip",
+         "solve_ell_cg64.hip", "solve_ell_newton64.hip", "solve_tree_cg.hip", "solve_tree_newton.hip", "solve_tree_ell_cg.hip", "solve_tree_ell_newton.hip", "pgs_tu.hip", "solve_big.hip", "build_id.hip"]
+HEADERS = ["host.hpp", "solve_tu.hpp", "solve_tree.hpp", "dev_common.hpp", "smooth.hpp", "collide.hpp", "constraint.hpp", "solver.hpp", "solver_cgp.hpp", "solver_cgw.hpp", "solver_newton.hpp", "solver_big.hpp", "pgs.hpp",
            "integrate.hpp", "implicit.hpp", "pgs_big.hpp", "sleep.hpp", "convex.hpp", "sensor.hpp", "support.hpp", "ray.hpp", "contact_rec.hpp"]
 SOURCES = [os.path.join(_PKG, "csrc", f) for f in UNITS + HEADERS]
 # -fno-slp-vectorize: the SLP vectoriser packs scalar float ops into v_pk_* pairs, which on gfx950 issue at HALF the rate of the
@@ -36,7 +36,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibil
 _FAST_DIV = ["-fno-hip-fp32-correctly-rounded-divide-sqrt"]
 _NNAN = ["-fno-honor-nans", "-fno-signed-zeros"]  # no NaN / signed-zero bookkeeping around min / max / select chains (the solvers produce neither)
 # (_NNAN on mjhip.hip -- kinematics, collision, constraint assembly -- was measured too: no gain, k_mid 84.4 vs 84.0 us)
-UNIT_FLAGS = {"pgs_tu.hip": _FAST_DIV + _NNAN, "solve_cg32.hip": _FAST_DIV + _NNAN, "solve_cgw.hip": _FAST_DIV + _NNAN, "solve_cg64.hip": _FAST_DIV + _NNAN}
+UNIT_FLAGS = {"pgs_tu.hip": _FAST_DIV + _NNAN, "solve_cg32.hip": _FAST_DIV + _NNAN, "solve_cgp.hip": _FAST_DIV + _NNAN, "solve_cgw.hip": _FAST_DIV + _NNAN, "solve_cg64.hip": _FAST_DIV + _NNAN}
 # (machine-scheduler strategies for the CG unit, -mllvm -amdgpu-sched-strategy=...: max-ilp 207 -> 223 us per launch, max-memory-clause 208 -> 214:
 # the default stays)
 # (-fno-honor-infinities on top: 208.2 vs 207.5 us, noise)
@@ -92,11 +92,33 @@ class CData(ctypes.Structure):
   _fields_ = _mk(DATA_FIELDS)
 
 
+def source_build_id():
+  """Hash of everything libmjhip.so is built from: every file under csrc/, the header and the compiler flags.  Baked into the library by
+  build() (csrc/build_id.hip, mjh_build_id) and compared before every load: no mtime logic, so a pushed tree with fresh timestamps loads the
+  library it was built with and a tree whose sources changed never runs old kernels."""
+  import hashlib
+
+  h = hashlib.sha256(repr((HIPCC_FLAGS, sorted(UNIT_FLAGS.items()), UNITS)).encode())
+  d = os.path.join(_PKG, "csrc")
+  for f in sorted(os.listdir(d)) + [HEADER]:
+    path = f if os.path.isabs(f) else os.path.join(d, f)
+    if os.path.isfile(path) and path.endswith((".hip", ".hpp", ".h")):
+      h.update(os.path.basename(path).encode())
+      h.update(open(path, "rb").read())
+  return h.hexdigest()[:24]
+
+
+def library_build_id(path=None):
+  """The id baked into a built library (read from the file: the marker string of csrc/build_id.hip), None if the file is missing or carries none."""
+  path = path or LIB_PATH
+  if not os.path.exists(path):
+    return None
+  mm = re.search(rb"MJH_BUILD_ID=([0-9a-f]{24})", open(path, "rb").read())
+  return mm.group(1).decode() if mm else None
+
+
 def needs_build():
-  if not os.path.exists(LIB_PATH):
-    return True
-  t = os.path.getmtime(LIB_PATH)
-  return any(os.path.getmtime(s) > t for s in SOURCES + [HEADER])
+  return library_build_id() != source_build_id()
 
 
 _TOOLCHAIN = None
@@ -125,7 +147,7 @@ def _unit_key(unit):
     seen[f] = open(f, "rb").read()
     for inc in re.findall(rb'^\s*#\s*include\s+"([^"]+)"', seen[f], flags=re.M):
       todo.append(os.path.join(os.path.dirname(f), inc.decode()))
-  h = hashlib.sha256(" ".join(HIPCC_FLAGS + UNIT_FLAGS.get(unit, [])).encode())
+  h = hashlib.sha256(" ".join(HIPCC_FLAGS + UNIT_FLAGS.get(unit, []) + ([source_build_id()] if unit == "build_id.hip" else [])).encode())
   h.update(_toolchain_id().encode())  # (a ROCm upgrade must not link objects of the old compiler)
   for f in sorted(seen):
     h.update(f.encode())
@@ -163,7 +185,7 @@ def build(force=False, verbose=False):
         if verbose:
           print(f"(cached) {u}")
         continue
-      cmd = ["hipcc", *HIPCC_FLAGS, *UNIT_FLAGS.get(u, []), "-c", "-o", obj, os.path.join(_PKG, "csrc", u)]
+      cmd = ["hipcc", *HIPCC_FLAGS, *UNIT_FLAGS.get(u, []), *([f'-DMJH_BUILD_ID="{source_build_id()}"'] if u == "build_id.hip" else []), "-c", "-o", obj, os.path.join(_PKG, "csrc", u)]
       if verbose:
         print(" ".join(cmd))
       procs.append((cmd, subprocess.Popen(cmd), obj, cached))
@@ -199,12 +221,15 @@ def lib():
   global _lib
   if _lib is not None:
     return _lib
-  if needs_build():
+  # MJH_LIB (developer knob, tools/ab.sh): a variant build of the same ABI -- loaded as it is.  Otherwise the library must have been built from
+  # the sources on disk: a mismatch is rebuilt when a compiler is there and is an error when not (never a silent run of old kernels).
+  if not os.environ.get("MJH_LIB") and needs_build():
     try:
       build()
     except (OSError, subprocess.CalledProcessError) as e:
-      if not os.path.exists(LIB_PATH):
-        raise RuntimeError(f"libmjhip.so is missing and could not be built: {e}") from e
+      raise RuntimeError(f"libmjhip.so does not match the sources (library {library_build_id()}, sources {source_build_id()}) and could not be rebuilt: {e}") from e
+    if needs_build():
+      raise RuntimeError(f"libmjhip.so still does not match the sources after a rebuild (library {library_build_id()}, sources {source_build_id()})")
   # MJH_LIB: developer knob to A/B two builds of the same ABI in one GPU session (tools/ab.sh)
   L = ctypes.CDLL(os.environ.get("MJH_LIB", LIB_PATH))
   mp, dp, vp = ctypes.POINTER(CModel), ctypes.POINTER(CData), ctypes.c_void_p
@@ -226,8 +251,9 @@ def lib():
   L.mjh_timed_steps.argtypes = [mp, dp, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, vp,
                                 ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), ctypes.c_int]
   L.mjh_last_error.restype = ctypes.c_char_p
+  L.mjh_build_id.restype = ctypes.c_char_p
   for f in FUNCTIONS:
-    if f != "mjh_last_error":
+    if f not in ("mjh_last_error", "mjh_build_id"):
       getattr(L, f).restype = ctypes.c_int
   import atexit
 

@@ -228,6 +228,7 @@ struct NoiseArgs {  // one application of the benchmark's control noise (cli.py:
   int n, step;
   float noise_std, noise_rate;
   const float* center;
+  int sched;  // k_fwd_pos_plus only: its first workgroup sorts the solver schedule (0: the k_mid launch carries that workgroup)
 };
 DEV void ctrl_noise_elem(const MjhModel& m, const MjhData& d, const float* center, int step, float noise_std, float noise_rate, int idx) {
   const int nu = m.nu;
@@ -290,14 +291,16 @@ __global__ void __launch_bounds__(256) k_solve_m(MjhModel m, MjhData d, float* x
 // `sh` needs 512 ints of LDS; any workgroup size that is a multiple of 64.  Global loads are batched eight deep ahead
 // of the LDS atomics (a load -> atomic -> store chain per world costs a full memory latency per iteration: 50-70 us
 // for 8192 worlds on one small workgroup), the 128-bin prefix is one wavefront scan.
-DEV void schedule_body(const MjhData& d, int* sh, int nthreads, int cls = 32) {  // cls: the row count that separates the two classes
-  // key: worlds that had more than 32 constraint rows first, then the others (the solver's one-row-per-lane instantiation takes the worlds
+// cls: the row count that separates the two classes, 0: no classes (sched_cls below)
+DEV void schedule_body(const MjhData& d, int* sh, int nthreads, int cls = 0) {
+  // key: worlds that had more than `cls` constraint rows first, then the others (the solver's one-row-per-lane instantiation takes the worlds
   // of at most 32 rows in a launch of its own: with the two classes apart both launches run dense workgroups); inside a class by iteration
-  // count, longest first.  256 bins: `sh` needs 512 ints.
+  // count, longest first.  256 bins: `sh` needs 512 ints.  Without classes (cls = 0: every solver but Newton with elliptic cones) the row
+  // counts are not even loaded: this single workgroup rides in the k_fwd_pos launch and was its tail (round 5: fused launch 59 -> 50 us).
   int* hist = sh;
   int* base = sh + 256;
   const int t = threadIdx.x, n = d.nworld;
-  auto bin = [cls](int niter, int nefc) { return (nefc > cls ? 0 : 128) + 127 - min(max(niter, 0), 127); };
+  auto bin = [cls](int niter, int nefc) { return (cls == 0 || nefc > cls ? 0 : 128) + 127 - min(max(niter, 0), 127); };
   for (int i = t; i < 256; i += nthreads) hist[i] = 0;
   __syncthreads();
   for (int w0 = t; w0 < n; w0 += 8 * nthreads) {
@@ -305,7 +308,7 @@ DEV void schedule_body(const MjhData& d, int* sh, int nthreads, int cls = 32) { 
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       v[k] = w0 + k * nthreads < n ? d.solver_niter[w0 + k * nthreads] : -1;
-      e[k] = w0 + k * nthreads < n ? d.nefc[w0 + k * nthreads] : 0;
+      e[k] = cls && w0 + k * nthreads < n ? d.nefc[w0 + k * nthreads] : 0;
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k)
@@ -334,7 +337,7 @@ DEV void schedule_body(const MjhData& d, int* sh, int nthreads, int cls = 32) { 
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       v[k] = w0 + k * nthreads < n ? d.solver_niter[w0 + k * nthreads] : -1;
-      e[k] = w0 + k * nthreads < n ? d.nefc[w0 + k * nthreads] : 0;
+      e[k] = cls && w0 + k * nthreads < n ? d.nefc[w0 + k * nthreads] : 0;
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) pos[k] = w0 + k * nthreads < n ? atomicAdd(&base[bin(v[k], e[k])], 1) : 0;
@@ -343,6 +346,9 @@ DEV void schedule_body(const MjhData& d, int* sh, int nthreads, int cls = 32) { 
       if (w0 + k * nthreads < n) d.ws_order[pos[k]] = w0 + k * nthreads;
   }
 }
+// the row-count classes only matter where the solver launches a one-row-per-lane instantiation for the worlds of at most 32 rows
+// (mjhip.hip launch_solve_any: Newton with elliptic cones at nv <= 32 and njmax > 32)
+DEV int sched_cls(const MjhModel& m, const MjhData& d) { return (m.solver == SOL_NEWTON && m.cone == CONE_ELLIPTIC && m.nv <= 32 && d.njmax > 32) ? 32 : 0; }
 __global__ void __launch_bounds__(1024) k_schedule_worlds(MjhData d, int cls) {
   __shared__ int sh[512];
   schedule_body(d, sh, blockDim.x, cls);

@@ -275,7 +275,7 @@ __global__ void __launch_bounds__(256) k_mid(MjhModel m, MjhData d, int ncc, int
   // sched: workgroup 0 sorts the solver schedule here instead of in the k_fwd_pos launch (models whose fwd_pos
   // workgroups are too small to do it quickly)
   if (sched && blockIdx.x == 0) {
-    schedule_body(d, reinterpret_cast<int*>(smem), blockDim.x, m.nv > 32 ? 64 : 32);
+    schedule_body(d, reinterpret_cast<int*>(smem), blockDim.x, sched_cls(m, d));
     return;
   }
   const int bi = (int)blockIdx.x - sched;
@@ -306,7 +306,7 @@ __global__ void __launch_bounds__(256) k_fwd_pos_plus(MjhModel m, MjhData d, int
   // the schedule workgroup goes FIRST: workgroups are dispatched in index order, so as the last one it would start
   // when the launch is nearly over and add its whole duration (~8 us) to it
   if (blockIdx.x == 0) {
-    schedule_body(d, reinterpret_cast<int*>(smem), blockDim.x, m.nv > 32 ? 64 : 32);
+    if (noise.sched) schedule_body(d, reinterpret_cast<int*>(smem), blockDim.x, sched_cls(m, d));
   } else if ((int)blockIdx.x <= npos) {
     const int wpb = blockDim.x / G;
     fwd_pos_body<G>(m, d, first, last, smem, Blk{((int)blockIdx.x - 1) * wpb, wpb, (int)blockDim.x});
@@ -489,7 +489,20 @@ static int launch_solve_any(const MjhModel* m, const MjhData* d, bool with_facto
       if (int rc = launch_solve_32_newton_ell_r1(m, d, false, fe, s, -1, 32)) return rc;
       lo2 = 32;
     }
-    auto rest = [&]() -> int {
+    // CG, pyramidal, every contact condim 3, njmax <= 64 (the headline class): contact-basis rows in one row pool per workgroup, three
+    // wavefronts per SIMD (solver_cgp.hpp); the worlds it flags (friction-loss rows, a contact cut by njmax, a pool overflow) are solved by
+    // k_solve<cg> in the launch behind it, which is empty in the common case.  MJH_CG_KERNEL (developer knob, read at every call so that one
+    // process can compare the kernels): "cgp" / "pair" / "cgw" force one of the three CG kernels where it applies.
+    const char* force = getenv("MJH_CG_KERNEL");
+    const bool cgp_can = !newton && !ell && m->cg_basis && d->njmax <= 64 && m->nv >= 1;
+    const bool wide_f = force && !strcmp(force, "cgw") ? (!newton && !ell && fe != 2) : (force && (!strcmp(force, "cgp") || !strcmp(force, "pair")) ? false : wide);
+    const bool cgp = cgp_can && !wide_f && !(force && !strcmp(force, "pair")) && !(force && !strcmp(force, "cgw"));
+    if (cgp) {
+      if (int rc = launch_solve_cgp(m, d, with_factor, fe, s)) return rc;
+      static const bool no_fallback = getenv("MJH_CGP_NO_FALLBACK") != nullptr;  // developer knob (timing only: flagged worlds stay unsolved)
+      return no_fallback ? MJH_OK : launch_solve_32_cg(m, d, 2, false, fe, s, -2, all);
+    }
+    auto rest = [&, wide = wide_f]() -> int {
       if (d->njmax <= 64) return wide ? launch_solve_cgw(m, d, with_factor, fe, s, -1, all) : s32(m, d, 2, with_factor, fe, s, lo2, all);
       if (int rc = wide ? launch_solve_cgw(m, d, false, fe, s, -1, 64) : s32(m, d, 2, false, fe, s, lo2, 64)) return rc;
       if (int rc = s32(m, d, 6, with_factor, fe, s, 64, top)) return rc;
@@ -540,21 +553,24 @@ static int launch_integrate_plus(const MjhModel* m, const MjhData* d, int mode, 
 // *sched_done: whether the launch carried the schedule workgroup (it needs >= 128 threads to be quick; otherwise it
 // rides with k_mid, whose workgroups always have 256)
 // control noise queued by mjh_timed_steps for the next fused step: it rides with that step's first launch
-static thread_local NoiseArgs g_noise = {0, 0, 0.0f, 0.0f, nullptr};
+static thread_local NoiseArgs g_noise = {0, 0, 0.0f, 0.0f, nullptr, 0};
 template <int G>
 static int launch_pos_plus_g(const MjhModel* m, const MjhData* d, int first, int last, bool* sched_done, hipStream_t s) {
-  const NoiseArgs noise = g_noise;
+  NoiseArgs noise = g_noise;
   g_noise.n = 0;
   const PosLayout lay = pos_layout(m->nq, m->nv, m->nbody, m->njnt, m->nC, last >= POS_FACTOR);
   size_t lds;
   const int threads = pick_block(sizeof(int) * pos_shared_words(m->nv, m->nC, m->nbody, m->njnt, m->nbodylevel, m->ngeom, m->nsite), sizeof(float) * lay.total, G, &lds);
   if (!threads) return fail(MJH_E_UNSUPPORTED, "k_fwd_pos: model does not fit in LDS");
-  *sched_done = threads >= 128;
-  if (!*sched_done) {
+  // developer knob MJH_SCHED_IN_MID: the schedule workgroup rides in the (longer) k_mid launch instead
+  static const bool sched_mid = getenv("MJH_SCHED_IN_MID") != nullptr;
+  *sched_done = threads >= 128 && !sched_mid;
+  if (threads < 128) {
     if (noise.n) hipLaunchKernelGGL(k_ctrl_noise, dim3((noise.n + 255) / 256), dim3(256), 0, s, *m, *d, noise.center, noise.step, noise.noise_std, noise.noise_rate);
     return launch_pos(m, d, first, last, s);
   }
   lds = std::max(lds, (size_t)2048);  // (the schedule workgroup: 512 ints)
+  noise.sched = *sched_done ? 1 : 0;
   HIPCHK(set_lds(k_fwd_pos_plus<G>, lds));
   const int wpb = threads / G, npos = (d->nworld + wpb - 1) / wpb, nnoise = (noise.n + threads - 1) / threads;
   debug_occupancy("k_fwd_pos_plus", k_fwd_pos_plus<G>, npos + 1 + nnoise, threads, lds);
@@ -792,7 +808,7 @@ static int run_stage(const MjhModel* m, const MjhData* d, int stage, hipStream_t
       static const bool plain = getenv("MJH_PLAIN") != nullptr;  // developer knob: one plain kernel per stage, serial
       if ((g_instr && g_instr->on && g_instr->plain) || plain) {
         // profiling pass: one plain kernel per stage, so that the event pairs time one kernel at a time
-        { Scope sc(K_OTHER); hipLaunchKernelGGL(k_schedule_worlds, dim3(1), dim3(1024), 0, s, *d, m->nv > 32 ? 64 : 32); }
+        { Scope sc(K_OTHER); hipLaunchKernelGGL(k_schedule_worlds, dim3(1), dim3(1024), 0, s, *d, (m->solver == SOL_NEWTON && m->cone == CONE_ELLIPTIC && m->nv <= 32 && d->njmax > 32) ? 32 : 0); }
         { Scope sc(K_POS); TRY(launch_pos(m, d, POS_KINEMATICS, POS_CRB, s)); }
         { Scope sc(K_COLLISION); TRY(launch_collision(m, d, s)); }
         { Scope sc(K_CONSTRAINT); TRY(launch_constraint(m, d, s)); }
@@ -1045,7 +1061,7 @@ int mjh_timed_steps(const MjhModel* m, const MjhData* d, int nstep, int step0, f
     static const bool plain_env = getenv("MJH_PLAIN") != nullptr || getenv("MJH_NO_NOISE_FUSION") != nullptr;
     if (noise_std >= 0.0f && m->nu > 0) {
       if (instr.on || plain_env) rc = mjh_ctrl_noise(m, d, nullptr, step0 + i, noise_std, noise_rate, stream);
-      else g_noise = NoiseArgs{d->nworld * m->nu, step0 + i, noise_std, noise_rate, nullptr};
+      else g_noise = NoiseArgs{d->nworld * m->nu, step0 + i, noise_std, noise_rate, nullptr, 0};
     }
     if (rc == MJH_OK) rc = run_stage(m, d, MJH_STAGE_STEP, s);
     g_noise.n = 0;

@@ -736,6 +736,8 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
   const int w = TREE ? slot / m.ntree : d.ws_order[slot];
   const int tree = TREE ? slot - w * m.ntree : 0;  // island index
   if (TREE && (!d.ws_separable[w] || tree >= d.ws_nisland[w])) return;  // (an island of more than 64 dofs: the generic solver)
+  // nefc_lo == -2: the fallback launch behind the pooled CG kernel (solver_cgp.hpp) -- only the worlds it flagged solver_niter = -1
+  if (!TREE && nefc_lo == -2 && d.solver_niter[w] != -1) return;
   const int* dadr = TREE ? d.ws_isl_dofadr + (size_t)w * (m.ntree + 1) + tree : nullptr;
   const int nv = TREE ? dadr[1] - dadr[0] : nv_all;
   if (TREE && (nv <= nv_lo || nv > nv_hi)) return;

@@ -1,0 +1,359 @@
+// solver_cgp.hpp -- CG for the headline class (nv <= 32, njmax <= 64, pyramidal cones, every contact condim 3): all worlds of the batch
+// RESIDENT AT ONCE, four wavefronts per SIMD (round 5).
+//
+// Reference: the same functions as solver.hpp (solver.py:3283-3450 CG, 835-1347 line search, 1698-1822 constraint update, 1912-1947
+// qfrc_constraint); the pyramid rows of a contact are constraint.py:3751-3879 (_efc_contact_jac_dense): J_n + mu J_t1, J_n - mu J_t1,
+// J_n + mu J_t2, J_n - mu J_t2.
+//
+// Why a third CG mapping.  k_solve<cg> (solver.hpp) holds `64 x JS` words of J per world whatever its row count: 7.9 KB, ten two-world
+// wavefronts per CU = 2.5 per SIMD (2.08 measured), so the 4,096 wavefronts of 8,192 worlds run in two rounds, each a latency chain
+// at 29 % VALU issue (profiles/round4_pmc_cg_steady.json).  8,192 worlds are exactly FOUR two-world wavefronts per SIMD: if a
+// wavefront costs <= 10 KB of LDS and <= 128 VGPRs the whole batch is resident from the first cycle, there is no second round and
+// every SIMD always has four chains to interleave.  What buys the space:
+//   * contact-basis rows: the four pyramid rows of a condim-3 contact span N = J_n, T1 = mu J_t1, T2 = mu J_t2.  LDS holds the three
+//     basis rows (recovered from efc.J as (r0 + r1) / 2, (r0 - r1) / 2, (r2 - r3) / 2), J x of the four rows is formed inside the
+//     contact's lane quad as d_N +- d_T1, d_N +- d_T2 (three quad_perm DPP reads), and J^T f = N^T (f0 + f1 + f2 + f3) + T1^T (f0 - f1)
+//     + T2^T (f2 - f3) runs over three rows instead of four: - 25 % LDS words and - 25 % of the J^T f reads and FMAs;
+//   * one row POOL per workgroup: a world takes the rows it needs (3 per contact + 1 per limit / equality row, rounded to 4), the
+//     workgroup's worlds share `pool_rows`; the humanoid's steady state needs 35-38 per world, the pool gives 44 on average.  A world
+//     that does not fit (or has friction-loss rows / a truncated contact) is flagged solver_niter = -1 and solved by the fallback
+//     launch that follows on the same stream (k_solve<cg> restricted to flagged worlds: empty in the common case);
+//   * no vector ever goes through LDS: an nv-vector lives one element per lane, v_permlane16_swap + DPP row_newbcast feed the
+//     matrix-vector FMAs (solver_cgw.hpp's scheme in a 32-lane group), so LDS holds nothing but the pool;
+//   * J is dead when the solve ends: the fused integrator's scratch lines alias the world's pool rows.
+// Rows in the lanes: slot s = lane + 32 k (k = 0, 1).  Contacts first -- contact c owns the quad of slots 4c .. 4c + 3 (efc rows
+// np + 4c ..), then the np = ne + nf + nl plain rows (slot 4 nq + p = efc row p).  Basis row of slot (c, q < 3): 3c + q; of plain row
+// p: 3 nq + p.
+#pragma once
+#include "solver.hpp"
+#include "solver_cgw.hpp"
+
+// words of LDS in front of the pool: the workgroup's row requests (one int per world, at most 32 worlds)
+#define CGP_HEAD 64
+template <int NV4>
+__host__ __device__ inline int cgp_pool_rows(size_t lds_bytes) {
+  constexpr int NVR = 4 * NV4, JS = (NV4 & 1) ? NVR : NVR + 4;
+  const int words = (int)(lds_bytes / sizeof(float)) - CGP_HEAD;
+  return words <= 0 ? 0 : ((words / (JS + 1)) & ~3);
+}
+// rows every solved world allocates at least: the Gauss-Jordan tile of the prologue (2 x 4 x NVR words), the fused integrator's lines
+template <int NV4>
+__host__ __device__ inline int cgp_min_rows(int fuse_euler) {
+  constexpr int NVR = 4 * NV4, JS = (NV4 & 1) ? NVR : NVR + 4;
+  const int words = fuse_euler == 2 ? (6 * 32 + 12 * NV4 + 4 + 32) : (8 * NVR > 32 ? 8 * NVR : 32);
+  return (((words + JS - 1) / JS) + 3) & ~3;
+}
+
+template <int CTRL>
+DEV float qperm(float v) {  // quad_perm DPP read (CTRL = a | b << 2 | c << 4 | d << 6)
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+
+template <int NV4>
+DEV void solve_cgp_body(const MjhModel& m, const MjhData& d, float* smem, int slot0, int nwb, int pool_rows, int fuse_euler) {
+  constexpr int G = 32, NR = 2, NVR = 4 * NV4, JS = (NV4 & 1) ? NVR : NVR + 4;
+  constexpr int NA = NVR < 16 ? NVR : 16, NBX = NVR - NA;  // columns served by the a / b half of a broadcast pair
+  const int nv = m.nv, nC = m.nC, njmax = d.njmax, nvp = d.nv_pad;
+  const int lig = threadIdx.x & (G - 1), gib = threadIdx.x / G;
+  const int slot = slot0 + gib;
+  const bool valid = gib < nwb && slot < d.nworld;
+  int* cnt = reinterpret_cast<int*>(smem);
+  float* pool = smem + CGP_HEAD;
+  float* fbpool = pool + (size_t)pool_rows * JS;
+
+  // ---- row request of this world, then the workgroup's (sequential, identical in every lane) allocation ---------------------------
+  const int w = valid ? d.ws_order[slot] : 0;  // longest expected solve first (k_schedule_worlds)
+  int nefc = 0, ne = 0, nf = 0, np = 0, nq = 0, need = 0;
+  bool defer = false;
+  if (valid) {
+    nefc = min(d.nefc[w], njmax);
+    ne = d.ne[w];
+    nf = d.nf[w];
+    np = min(ne + nf + d.nl[w], nefc);
+    nq = (nefc - np) >> 2;
+    defer = nf > 0 || ((nefc - np) & 3) != 0 || nefc > 64;  // friction loss (three-zone rows), a contact cut by njmax: the fallback launch
+    const int nb = np + 3 * nq;
+    need = max((nb + 3) & ~3, cgp_min_rows<NV4>(fuse_euler));
+  }
+  if (lig == 0 && gib < 32) cnt[gib] = (valid && !defer) ? need : 0;
+  __syncthreads();
+  int base = 0;
+  {
+    int acc = 0;
+    for (int j = 0; j < nwb; ++j) {
+      const int c = cnt[j];
+      const bool fits = acc + c <= pool_rows;
+      if (j == gib) {
+        base = acc;
+        if (!fits) defer = true;
+      }
+      acc += fits ? c : 0;
+    }
+  }
+  if (!valid) return;
+  if (defer) {
+    if (lig == 0) d.solver_niter[w] = -1;  // (the fallback launch solves the worlds flagged -1 and writes their iteration count)
+    return;
+  }
+  float* Jl = pool + (size_t)base * JS;
+  float* fb = fbpool + base;
+  const int nb = np + 3 * nq, nb4 = (nb + 3) & ~3;
+  const size_t vo = (size_t)w * nv, eo = (size_t)w * njmax;
+  const bool active = lig < nv;
+  const int ligr = lig < NVR ? lig : NVR - 1;
+
+  PhaseClock pc(5, lig);
+  // ---- M row of this lane into registers through the model-wide dense address table (solver.hpp) ------------------------------------
+  float mrow[NVR];
+  {
+    const float* Mg = d.M + (size_t)w * nC;
+    const int nv4r = (nv + 3) >> 2;
+    const int4* tab = reinterpret_cast<const int4*>(m.M_dense) + (size_t)(active ? lig : 0) * nv4r;
+    int idx[NVR];
+#pragma unroll
+    for (int c4 = 0; c4 < NV4; ++c4) {
+      const int4 t4 = c4 < nv4r ? tab[c4] : make_int4(-1, -1, -1, -1);
+      idx[4 * c4] = t4.x; idx[4 * c4 + 1] = t4.y; idx[4 * c4 + 2] = t4.z; idx[4 * c4 + 3] = t4.w;
+    }
+#pragma unroll
+    for (int c = 0; c < NVR; ++c) {
+      const float v = Mg[idx[c] < 0 ? 0 : idx[c]];
+      mrow[c] = active ? (idx[c] < 0 ? 0.0f : v) : (c == lig ? 1.0f : 0.0f);
+    }
+  }
+  pc.mark(0);
+  const bool warm = !(m.disableflags & DSBL_WARMSTART);
+  const float fs = active ? d.qfrc_smooth[vo + lig] : 0.0f;
+  // lane i: sum_c A[i][c] x[c]; x arrives as a broadcast pair (a: x[l % 16], b: x[16 + l % 16]) and every x[c] an FMA needs is the DPP
+  // operand row_newbcast:c of one of the two -- no LDS.  (Every lane of the group must execute this: a DPP read from a lane that sits
+  // out a branch is zero.)
+  auto mul_row = [&](const float (&row)[NVR], const BV& x) __attribute__((always_inline)) {
+    float s[2] = {0.0f, 0.0f};
+    fma_rbc<0>(s, row, x.a, std::make_integer_sequence<int, NA>{});
+    if (NBX > 0) fma_rbc<NA>(s, row, x.b, std::make_integer_sequence<int, NBX>{});
+    return active ? s[0] + s[1] : 0.0f;
+  };
+  // ---- M^-1 (the CG preconditioner; the world's pool rows lend the tile buffer) and qacc_smooth with one step of refinement ----------
+  float h[NVR];
+  invert_rows_b4<NVR, G>(mrow, h, Jl, lig);
+  float qs = mul_row(h, bcast_prep(fs));
+  {
+    const float res = fs - mul_row(mrow, bcast_prep(qs));
+    qs += mul_row(h, bcast_prep(active ? res : 0.0f));
+  }
+  if (active) d.qacc_smooth[vo + lig] = qs;
+  float q = active ? (nefc > 0 && warm ? d.qacc_warmstart[vo + lig] : qs) : 0.0f;
+  pc.mark(1);
+  float Ma;
+  {
+    const BV qb = bcast_prep(q);
+    Ma = mul_row(mrow, qb);
+  }
+  if (nefc == 0) {  // unconstrained: qacc = qacc_smooth (solver.py:3684-3686)
+    if (active) {
+      d.qacc[vo + lig] = q;
+      d.qfrc_constraint[vo + lig] = 0.0f;
+      d.efc_Ma[vo + lig] = Ma;
+    }
+    if (lig == 0) d.solver_niter[w] = 0;
+    if (fuse_euler) {
+      float qi = q;
+      gsync();
+      if (fuse_euler == 2) qi = impfast_acc<NV4, G>(m, d, w, lig, active, mrow, Ma, Jl);
+      euler_advance<G>(m, d, w, lig, active, qi, Jl + (fuse_euler == 2 ? 6 * G + 12 * NV4 + 4 : 0), q);
+    }
+    return;
+  }
+
+  // ---- basis rows into the pool: contact c -> N, T1, T2 from its four pyramid rows; plain rows as they are ---------------------------
+  gsync();  // (the tile reads of the inversion are done)
+  {
+    const float* Jg = d.efc_J + (size_t)w * d.njmax_pad * nvp;
+    constexpr int J4 = JS / 4;
+    const int nvp4 = nvp >> 2;  // (nv_pad is a multiple of 4: rows of efc.J are 16-byte aligned)
+    for (int it = lig; it < nq * J4; it += G) {
+      const int c = it / J4, c4 = it - c * J4;
+      float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = r0, r2 = r0, r3 = r0;
+      if (c4 < nvp4) {
+        const float4* src = reinterpret_cast<const float4*>(Jg + (size_t)(np + 4 * c) * nvp) + c4;
+        r0 = src[0]; r1 = src[nvp4]; r2 = src[2 * nvp4]; r3 = src[3 * nvp4];
+      }
+      float4* dst = reinterpret_cast<float4*>(Jl + (size_t)(3 * c) * JS) + c4;
+      dst[0] = make_float4(0.5f * (r0.x + r1.x), 0.5f * (r0.y + r1.y), 0.5f * (r0.z + r1.z), 0.5f * (r0.w + r1.w));
+      dst[J4] = make_float4(0.5f * (r0.x - r1.x), 0.5f * (r0.y - r1.y), 0.5f * (r0.z - r1.z), 0.5f * (r0.w - r1.w));
+      dst[2 * J4] = make_float4(0.5f * (r2.x - r3.x), 0.5f * (r2.y - r3.y), 0.5f * (r2.z - r3.z), 0.5f * (r2.w - r3.w));
+    }
+    for (int it = lig; it < (nb4 - 3 * nq) * J4; it += G) {  // plain rows, then zero rows up to the multiple of 4
+      const int p = it / J4, c4 = it - p * J4;
+      float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if (p < np && c4 < nvp4) v = (reinterpret_cast<const float4*>(Jg + (size_t)p * nvp))[c4];
+      (reinterpret_cast<float4*>(Jl + (size_t)(3 * nq + p) * JS))[c4] = v;
+    }
+    for (int r = nb + lig; r < nb4; r += G) fb[r] = 0.0f;  // (the rows past nb carry zero force for good)
+  }
+  // ---- this lane's rows: D, kind, where their basis row and basis force live ---------------------------------------------------------
+  float rD[NR], rja[NR], rjv[NR];
+  int rkind[NR];         // 0 equality, 2 limit / contact, 3 padding (no friction-loss rows here)
+  int jro[NR];           // word offset in the world's pool of the basis row this lane reads in the row dots
+  int fbo[NR];           // basis row that takes this lane's basis force (-1: none)
+  bool isq[NR];
+  const int qd = lig & 3;
+#pragma unroll
+  for (int k = 0; k < NR; ++k) {
+    const int s = lig + G * k;
+    const bool has = s < nefc;
+    isq[k] = s < 4 * nq;
+    const int er = isq[k] ? np + s : s - 4 * nq;  // efc row of this slot
+    const int br = isq[k] ? 3 * (s >> 2) + (qd < 3 ? qd : 2) : (has ? s - nq : 0);
+    jro[k] = br * JS;
+    fbo[k] = !has ? -1 : (isq[k] ? (qd < 3 ? 3 * (s >> 2) + qd : -1) : s - nq);
+    rD[k] = has ? d.efc_D[eo + er] : 0.0f;
+    rkind[k] = !has ? 3 : (isq[k] ? 2 : (er < ne ? 0 : 2));
+    rjv[k] = 0.0f;
+    rja[k] = has ? d.efc_aref[eo + er] : 0.0f;  // (aref for now: Jaref = J q - aref below)
+  }
+  gsync();
+  // J[row of slot k, :] . x for both slots: the basis-row dot, then -- inside a contact's quad -- d_N +- d_T1 / d_N +- d_T2
+  auto j_dots = [&](const BV& x, float (&out)[NR]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      float jr[NVR];
+#pragma unroll
+      for (int c4 = 0; c4 < NV4; ++c4) {
+        const float4 j4 = *reinterpret_cast<const float4*>(Jl + jro[k] + 4 * c4);
+        jr[4 * c4] = j4.x; jr[4 * c4 + 1] = j4.y; jr[4 * c4 + 2] = j4.z; jr[4 * c4 + 3] = j4.w;
+      }
+      float s[2] = {0.0f, 0.0f};
+      fma_rbc<0>(s, jr, x.a, std::make_integer_sequence<int, NA>{});
+      if (NBX > 0) fma_rbc<NA>(s, jr, x.b, std::make_integer_sequence<int, NBX>{});
+      const float dt = s[0] + s[1];
+      const float dn = qperm<0x00>(dt), d1 = qperm<0x55>(dt), d2 = qperm<0xAA>(dt);
+      const float tq = qd < 2 ? d1 : d2;
+      out[k] = rkind[k] == 3 ? 0.0f : (isq[k] ? ((qd & 1) ? dn - tq : dn + tq) : dt);
+    }
+  };
+  {
+    float jq[NR];
+    j_dots(bcast_prep(q), jq);
+#pragma unroll
+    for (int k = 0; k < NR; ++k) rja[k] = rkind[k] != 3 ? jq[k] - rja[k] : 0.0f;
+  }
+  pc.mark(2);
+  const float tolerance = bf(m.opt_tolerance, m.opt_tolerance_nb, w, 1)[0];
+  const float ls_tolerance = bf(m.opt_ls_tolerance, m.opt_ls_tolerance_nb, w, 1)[0];
+  const float meaninertia = bf(m.stat_meaninertia, m.stat_meaninertia_nb, w, 1)[0];
+  const float scale = meaninertia * (float)nv;
+  const float rscale = 1.0f / scale;
+
+  float grad_dot = 0.0f, search_dot = 0.0f;
+  float g = 0.0f, Mg = 0.0f, pg = 0.0f, pMg = 0.0f, srch = 0.0f, qc = 0.0f;
+  float cg5[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+  int niter = 0;
+  const int maxiter = m.iterations, ls_iterations = m.ls_iterations;
+  int ovf = 0;
+  float improvement = 0.0f;
+  for (;;) {
+    // ---- force of this lane's rows (solver.py:1698-1822), folded to basis forces inside the contact quads -------------------------
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      const bool quad = rkind[k] == 0 || (rkind[k] == 2 && rja[k] < 0.0f);
+      const float f = quad ? -rD[k] * rja[k] : 0.0f;
+      const float a = qperm<0xB1>(f);              // the pair partner: f1 f0 f3 f2
+      const float sm = f + a, df = f - a;          // f0 + f1 | f2 + f3 ;  f0 - f1, f1 - f0, f2 - f3, f3 - f2
+      const float tot = sm + qperm<0x4E>(sm);      // f0 + f1 + f2 + f3
+      const float bq = qd == 0 ? tot : (qd == 1 ? -df : df);
+      if (fbo[k] >= 0) fb[fbo[k]] = isq[k] ? bq : f;
+    }
+    gsync();
+    // ---- qfrc_constraint = J^T force (solver.py:1912-1947) over the basis rows: lane = dof, four rows per step -----------------------
+    {
+      float s0 = 0.0f, s1 = 0.0f;
+      const float* Jc = Jl + ligr;
+#pragma unroll 2
+      for (int r = 0; r < nb4; r += 4) {
+        const float4 f4 = *reinterpret_cast<const float4*>(fb + r);
+        s0 += Jc[r * JS] * f4.x + Jc[(r + 2) * JS] * f4.z;
+        s1 += Jc[(r + 1) * JS] * f4.y + Jc[(r + 3) * JS] * f4.w;
+      }
+      qc = active ? s0 + s1 : 0.0f;
+    }
+    gsync();  // (the next iteration's force writes follow these reads)
+    // ---- gradient, preconditioned gradient, Polak-Ribiere direction (solver.py:3061-3220, 3283-3450) ----------------------------------
+    g = active ? (Ma - fs - qc) : 0.0f;
+    pc.mark(3);
+    Mg = mul_row(h, bcast_prep(g));
+    cg5[0] = g * g; cg5[1] = g * (Mg - pMg); cg5[2] = pg * pMg; cg5[3] = Mg * Mg; cg5[4] = Mg * srch;
+    gsumg_n<G, 5>(cg5);
+    grad_dot = cg5[0];
+    pc.mark(4);
+    if (niter == 0) {
+      srch = -Mg;
+      search_dot = cg5[3];
+      pg = g;
+      pMg = Mg;
+    } else {
+      const float imp = improvement * rscale, gradient = sqrtf(grad_dot) * rscale;
+      const float beta = fmaxf(0.0f, cg5[1] * __builtin_amdgcn_rcpf(fmaxf(MJ_MINVAL, cg5[2])));
+      const bool done = (imp < tolerance) || (gradient < tolerance);
+      if (done) break;
+      srch = -Mg + beta * srch;
+      search_dot = fmaxf(cg5[3] + beta * (beta * search_dot - 2.0f * cg5[4]), 0.0f);
+      pg = g;
+      pMg = Mg;
+      if (niter >= maxiter) {
+        ovf |= OVF_ITERATIONS;
+        break;
+      }
+    }
+    if (maxiter == 0) break;
+    // ---- mv = M search, jv = J search -----------------------------------------------------------------------------------------------
+    float mvi;
+    {
+      const BV sb = bcast_prep(srch);
+      mvi = mul_row(mrow, sb);
+      j_dots(sb, rjv);
+    }
+    pc.mark(5);
+    // ---- line search (solver.py:835-1347); rows and all sums stay in registers -----------------------------------------------------
+    const float g1 = srch * (Ma - fs);
+    const float gtol = fmaxf(tolerance * ls_tolerance * sqrtf(search_dot) * scale, 1e-6f);
+    float alpha = 0.0f;
+    improvement = 0.0f;
+    bool ls_converged = false;
+    line_search_rows<NR, G, false>(rja, rjv, rD, rkind, nullptr, g1, 0.5f * srch * mvi, fabsf(g1), gtol, ls_iterations, alpha, improvement, ls_converged);
+    if (!ls_converged) ovf |= OVF_LS_ITERATIONS;
+    pc.mark(6);
+    q += alpha * srch;
+    Ma += alpha * mvi;
+#pragma unroll
+    for (int k = 0; k < NR; ++k) rja[k] += alpha * rjv[k];
+    ++niter;
+    pc.mark(7);
+  }
+  pc.mark(8);
+  // ---- outputs -----------------------------------------------------------------------------------------------------------------------
+  if (active) {
+    d.qacc[vo + lig] = q;
+    d.qfrc_constraint[vo + lig] = qc;
+    d.efc_Ma[vo + lig] = Ma;
+  }
+#pragma unroll
+  for (int k = 0; k < NR; ++k)
+    if (rkind[k] != 3) {  // force / state at the final iterate: the expression of the last constraint update
+      const int s = lig + G * k, er = isq[k] ? np + s : s - 4 * nq;
+      const bool quad = rkind[k] == 0 || rja[k] < 0.0f;
+      d.efc_force[eo + er] = quad ? -rD[k] * rja[k] : 0.0f;
+      d.efc_state[eo + er] = quad ? ST_QUADRATIC : ST_SATISFIED;
+    }
+  if (lig == 0) {
+    d.solver_niter[w] = niter;
+    if (ovf) atomicOr(d.overflow + w, ovf);
+  }
+  if (fuse_euler) {
+    gsync();  // (J is dead: the integrator's lines alias the world's pool rows)
+    float qi = q;
+    if (fuse_euler == 2) qi = impfast_acc<NV4, G>(m, d, w, lig, active, mrow, Ma, Jl);
+    euler_advance<G>(m, d, w, lig, active, qi, Jl + (fuse_euler == 2 ? 6 * G + 12 * NV4 + 4 : 0), q);
+  }
+  pc.mark(9);
+}

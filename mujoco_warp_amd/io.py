@@ -463,6 +463,7 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
   m.nbodylevel, m.ndoflevel = nlevel, ndlevel
   m.nmaxcondim = int(max(condims)) if condims else 1
   m.nmaxpyramid = max(1, 2 * (m.nmaxcondim - 1))
+  m.cg_basis = int(condims == {3})
   m.key_qpos = _arr(getattr(mjm, "key_qpos", np.zeros((0, m.nq))), f32)
   m.key_qvel = _arr(getattr(mjm, "key_qvel", np.zeros((0, nv))), f32)
   m.key_ctrl = _arr(getattr(mjm, "key_ctrl", np.zeros((0, nu))), f32)

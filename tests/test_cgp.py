@@ -1,0 +1,157 @@
+"""GPU parity tests of the pooled contact-basis CG kernel (csrc/solver_cgp.hpp), forced at small batch sizes through the developer knob
+MJH_CG_KERNEL (read by the library at every solver launch): against the float64 oracle, against the two-worlds-per-wavefront kernel it
+replaces (csrc/solver.hpp), and through its fallback launch (worlds it flags solver_niter = -1)."""
+
+import os
+
+import numpy as np
+import pytest
+
+import conftest
+import mujoco_warp_amd as mjw
+from conftest import relerr
+from oracle import ref
+from test_gpu import _check_solution, _pair, _sync
+
+pytestmark = pytest.mark.gpu
+
+
+class _knob:
+  def __init__(self, **kv):
+    self.kv = kv
+
+  def __enter__(self):
+    self.old = {k: os.environ.get(k) for k in self.kv}
+    for k, v in self.kv.items():
+      if v is None:
+        os.environ.pop(k, None)
+      else:
+        os.environ[k] = str(v)
+
+  def __exit__(self, *a):
+    for k, v in self.old.items():
+      if v is None:
+        os.environ.pop(k, None)
+      else:
+        os.environ[k] = v
+
+
+def _cg_humanoid(nworld, warm_steps=15, **kw):
+  mjm = mjw.mjcf.load_xml(conftest.HUMANOID_XML)
+  s, m, d = _pair(mjm, nworld=nworld, nconmax=24, njmax=64, solver=int(mjw.SolverType.CG), warm_steps=warm_steps, **kw)
+  assert m.cg_basis == 1
+  return mjm, s, m, d
+
+
+@pytest.mark.parametrize("nworld,threads", [(3, 192), (16, 512), (37, 384), (70, 768)])
+def test_cgp_forward_matches_oracle_and_the_paired_kernel(nworld, threads):
+  """The same state through the pooled kernel (whole and partial workgroups, every workgroup size) and through k_solve<cg>: both
+  inside the oracle tolerance, the same iteration count, and the same answer to the solver tolerance."""
+  mjm, s, m, d = _cg_humanoid(nworld)
+  s.forward()
+  out = {}
+  for kernel in ("cgp", "pair"):
+    with _knob(MJH_CG_KERNEL=kernel, MJH_CGP_THREADS=threads):
+      d.qacc.fill_(float("inf"))
+      d.solver_niter.fill_(-7)
+      mjw.forward(m, d)
+    _check_solution(s, d)
+    q = d.qacc.numpy()
+    assert (q == q[0]).all()  # the same inputs in every world: bitwise the same outputs
+    assert (d.solver_niter.numpy() == d.solver_niter.numpy()[0]).all()
+    assert abs(int(d.solver_niter.numpy()[0]) - s.solver_niter) <= 2
+    out[kernel] = (q[0].copy(), d.efc.force.numpy()[0].copy(), d.efc.state.numpy()[0].copy(), int(d.solver_niter.numpy()[0]))
+  assert relerr(out["cgp"][0], out["pair"][0]) <= 2e-4
+  assert relerr(out["cgp"][1][: s.nefc], out["pair"][1][: s.nefc]) <= 2e-3
+  assert (out["cgp"][2][: s.nefc] == out["pair"][2][: s.nefc]).mean() >= 0.95
+  assert abs(out["cgp"][3] - out["pair"][3]) <= 2
+
+
+def test_cgp_per_step_parity_resynced():
+  """North-star parity through the pooled kernel and its fused Euler epilogue: one step from the oracle's state, 150 steps along its
+  trajectory (key 0: free fall, first contacts, the squat) -- the bounds of test_gpu.test_per_step_parity_resynced[CG]."""
+  mjm, s, m, d = _cg_humanoid(2, warm_steps=0)
+  worst_q = worst_v = 0.0
+  with _knob(MJH_CG_KERNEL="cgp"):
+    for i in range(150):
+      s.ctrl_noise(i, 0)
+      _sync(s, d)
+      mjw.step(m, d)
+      s.step()
+      worst_q = max(worst_q, relerr(d.qpos.numpy()[1], s.qpos))
+      worst_v = max(worst_v, relerr(d.qvel.numpy()[1], s.qvel))
+  assert worst_q <= 2e-6, worst_q
+  assert worst_v <= 4e-4, worst_v
+  assert (d.overflow.numpy() == 0).all()
+
+
+def test_cgp_worlds_in_different_states_against_the_paired_kernel():
+  """64 worlds driven apart by control noise (different contact sets and row counts in one workgroup's pool): every step both kernels
+  start from the same states and must agree world by world."""
+  mjm = mjw.mjcf.load_xml(conftest.HUMANOID_XML)
+  mjm.opt.solver = int(mjw.SolverType.CG)
+  m = mjw.put_model(mjm)
+  da = mjw.make_data(mjm, nworld=64, nconmax=24, njmax=64)
+  db = mjw.make_data(mjm, nworld=64, nconmax=24, njmax=64)
+  mjw.reset_data_keyframe(m, da, 0)
+  seen = set()
+  for i in range(400):
+    mjw.ctrl_noise(m, da, i, 0.3, 0.1)
+    if i % 20 == 0:
+      for name in ("qpos", "qvel", "ctrl", "qacc_warmstart", "time"):
+        getattr(db, name).assign(getattr(da, name).numpy())
+      with _knob(MJH_CG_KERNEL="pair"):
+        mjw.forward(m, db)
+      with _knob(MJH_CG_KERNEL="cgp", MJH_CGP_THREADS=256):
+        mjw.forward(m, da)
+      nefc = da.nefc.numpy()
+      seen |= set(int(x) for x in nefc)
+      assert (nefc == db.nefc.numpy()).all()
+      qa, qb = da.qacc.numpy(), db.qacc.numpy()
+      for w in range(64):
+        assert relerr(qa[w], qb[w]) <= 2e-3, (i, w, int(nefc[w]))  # (both stop at the solver tolerance, possibly an iteration apart)
+      dn = np.abs(da.solver_niter.numpy() - db.solver_niter.numpy())
+      assert dn.max() <= 6 and dn.mean() <= 1.0, (i, dn.max(), dn.mean())
+      assert (da.overflow.numpy() == 0).all()
+    with _knob(MJH_CG_KERNEL="cgp", MJH_CGP_THREADS=256):
+      mjw.step(m, da)
+  assert len(seen) >= 4, seen  # (the batch really held worlds with different row counts)
+  assert np.isfinite(da.qpos.numpy()).all()
+
+
+def test_cgp_pool_overflow_goes_to_the_fallback_launch():
+  """A pool too small for its workgroup's worlds (developer knob MJH_CGP_LDS): the worlds that do not fit are flagged solver_niter = -1
+  by the pooled kernel and solved by k_solve<cg> in the launch behind it -- every world ends inside the oracle tolerance."""
+  mjm, s, m, d = _cg_humanoid(24)
+  s.forward()
+  nb = (s.nefc - s.ne - s.nf - s.nl) // 4 * 3 + s.ne + s.nf + s.nl
+  lds = 4 * (64 + 29 * (2 * ((nb + 3) // 4 * 4) + 4))  # room for two worlds of this state (and not three) per workgroup
+  with _knob(MJH_CG_KERNEL="cgp", MJH_CGP_THREADS=256, MJH_CGP_LDS=lds):
+    mjw.forward(m, d)
+  niter = d.solver_niter.numpy()
+  assert (niter >= 0).all()
+  for w in range(d.nworld):
+    _check_solution(s, d, w=w)
+  q = d.qacc.numpy()
+  assert len({q[w].tobytes() for w in range(d.nworld)}) == 2  # two kernels took part
+  with _knob(MJH_CG_KERNEL="cgp", MJH_CGP_THREADS=256, MJH_CGP_LDS=lds):
+    for _ in range(5):  # and through the fused step: both kernels integrate their worlds
+      mjw.step(m, d)
+  qp = d.qpos.numpy()
+  assert relerr(qp, np.tile(qp[0], (d.nworld, 1))) <= 1e-5
+  assert (d.time.numpy() == d.time.numpy()[0]).all()
+
+
+def test_cgp_friction_loss_rows_are_left_to_the_fallback():
+  """Friction-loss rows (three-zone cost) are outside the pooled kernel: such worlds take the fallback launch and match the oracle."""
+  xml = open(conftest.HUMANOID_XML).read().replace('<joint name="abdomen_z"', '<joint frictionloss="0.4" name="abdomen_z"')
+  assert "frictionloss" in xml
+  mjm = mjw.mjcf.from_xml_string(xml)
+  s, m, d = _pair(mjm, nworld=5, nconmax=24, njmax=64, solver=int(mjw.SolverType.CG))
+  assert m.cg_basis == 1
+  s.forward()
+  assert s.nf == 1
+  with _knob(MJH_CG_KERNEL="cgp"):
+    mjw.forward(m, d)
+  assert (d.solver_niter.numpy() >= 0).all()
+  _check_solution(s, d)

@@ -480,3 +480,32 @@ def test_positive_velocity_feedback_keeps_implicitfast_out_of_the_solver_epilogu
   assert mjw.put_model(mjw.mjcf.from_xml_string(base.format('<general joint="j" biastype="affine" biasprm="0 0 0.5"/>'))).act_velfeedback == 1
   assert mjw.put_model(mjw.mjcf.from_xml_string(base.format('<general joint="j" gaintype="affine" gainprm="1 0 -0.2"/>'))).act_velfeedback == 1
   assert mjw.put_model(mjw.mjcf.load_xml(conftest.PANDA_XML)).act_velfeedback == 0  # (the Panda keeps the fused update)
+
+
+def test_library_carries_the_id_of_the_sources_it_was_built_from():
+  """csrc/build_id.hip bakes the hash of csrc/*, the header and the compiler flags into the library; the loader compares it with the sources
+  on disk (no mtime logic: a pushed tree with fresh timestamps must load, a tree whose sources changed must not run old kernels)."""
+  from mujoco_warp_amd import _abi
+
+  L = _abi.lib()
+  assert L.mjh_build_id().decode() == _abi.source_build_id() == _abi.library_build_id()
+  assert not _abi.needs_build()
+  os.utime(os.path.join(os.path.dirname(_abi.__file__), "csrc", "solver.hpp"))  # a fresh timestamp alone changes nothing
+  assert not _abi.needs_build()
+
+
+def test_stale_library_is_never_loaded_silently(monkeypatch):
+  """Sources that no longer match the library and no way to rebuild: lib() raises instead of falling through to the old file."""
+  import subprocess
+
+  from mujoco_warp_amd import _abi
+
+  def no_compiler(*a, **k):
+    raise subprocess.CalledProcessError(127, ["hipcc"])
+
+  monkeypatch.setattr(_abi, "_lib", None)
+  monkeypatch.setattr(_abi, "source_build_id", lambda: "0" * 24)
+  monkeypatch.setattr(_abi, "build", no_compiler)
+  monkeypatch.delenv("MJH_LIB", raising=False)
+  with pytest.raises(RuntimeError, match="does not match the sources"):
+    _abi.lib()
