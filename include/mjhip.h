@@ -133,8 +133,8 @@ typedef struct MjhModel {
   int act_velfeedback;          /* 1: some actuator feeds velocity back with a positive sign (affine gain on velocity, or bias velocity coefficient > 0):
                                    M + h D - h dA/dv may then be indefinite, and implicitfast keeps the integrator launch's L'DL solve instead of the
                                    solver epilogue's Cholesky (csrc/solver.hpp impfast_acc) */
-  int cg_basis;                 /* 1: every contact the model can make has condim 3 (pyramidal: four rows spanned by three basis rows J_n, mu J_t1, mu J_t2):
-                                   CG at nv <= 32, njmax <= 64 runs the pooled contact-basis kernel (csrc/solver_cgp.hpp) */
+  int cg_basis;                 /* 1: every contact the model can make has condim 1 or 3 (pyramidal condim 3: four rows spanned by the three basis rows
+                                   J_n, mu J_t1, mu J_t2): CG at nv <= 32, njmax <= 64 runs the pooled contact-basis kernel (csrc/solver_cgp.hpp) */
   int ntree;                    /* trees with at least one dof */
   int tree_nvmax;               /* dofs of the largest tree */
   int isl_nv4;                  /* ceil(dofs / 4) of the widest island of at most 32 dofs the model can form (kernel size class) */

@@ -31,7 +31,7 @@ static int launch_cgp_t(const MjhModel* m, const MjhData* d, bool with_factor, i
   size_t lds = (size_t)kLdsPerCU / (256 * CGP_WAVES / threads);
   if (const char* e = getenv("MJH_CGP_LDS")) lds = (size_t)atoi(e);  // developer knob: bytes of the header + pool of a workgroup
   const int wpb = threads / 32;
-  const int pool_rows = cgp_pool_rows<NV4>(lds);
+  const int pool_rows = cgp_pool_rows<NV4>(lds, wpb);
   if (pool_rows < cgp_min_rows<NV4>(fuse_euler)) return fail(MJH_E_UNSUPPORTED, "k_solve_cgp: pool too small");
   const FacLayout fl = fac_layout(m->nv, m->nC);
   if (with_factor) lds = std::max(lds, sizeof(int) * mstruct_ints(m->nv, m->nC) + sizeof(float) * fl.total * wpb);  // the riders' tables

@@ -1,5 +1,5 @@
-// solver_cgp.hpp -- CG for the headline class (nv <= 32, njmax <= 64, pyramidal cones, every contact condim 3): all worlds of the batch
-// RESIDENT AT ONCE, four wavefronts per SIMD (round 5).
+// solver_cgp.hpp -- CG for the headline class (nv <= 32, njmax <= 64, pyramidal cones, contacts of condim 1 or 3): contact-basis rows in one
+// row pool per workgroup, no vector through LDS (round 5).
 //
 // Reference: the same functions as solver.hpp (solver.py:3283-3450 CG, 835-1347 line search, 1698-1822 constraint update, 1912-1947
 // qfrc_constraint); the pyramid rows of a contact are constraint.py:3751-3879 (_efc_contact_jac_dense): J_n + mu J_t1, J_n - mu J_t1,
@@ -21,19 +21,20 @@
 //   * no vector ever goes through LDS: an nv-vector lives one element per lane, v_permlane16_swap + DPP row_newbcast feed the
 //     matrix-vector FMAs (solver_cgw.hpp's scheme in a 32-lane group), so LDS holds nothing but the pool;
 //   * J is dead when the solve ends: the fused integrator's scratch lines alias the world's pool rows.
-// Rows in the lanes: slot s = lane + 32 k (k = 0, 1).  Contacts first -- contact c owns the quad of slots 4c .. 4c + 3 (efc rows
-// np + 4c ..), then the np = ne + nf + nl plain rows (slot 4 nq + p = efc row p).  Basis row of slot (c, q < 3): 3c + q; of plain row
-// p: 3 nq + p.
+// Rows in the lanes: slot s = lane + 32 k (k = 0, 1).  The rows of condim-3 contacts first -- the q-th such contact owns the quad of slots
+// 4q .. 4q + 3 --, then every other row (equality, limit, frictionless contact) in efc order: a stable partition of the efc rows by
+// "pyramid row or not", computed per world from efc.type with two ballots; slotR[s] = efc row of slot s.  Basis row of slot (q, e < 3):
+// 3q + e; of the p-th other row: 3 nq + p.
 #pragma once
 #include "solver.hpp"
 #include "solver_cgw.hpp"
 
-// words of LDS in front of the pool: the workgroup's row requests (one int per world, at most 32 worlds)
+// words of LDS in front of the pool: the workgroup's row requests (one int per world, at most 32 worlds), then 64 ints per world: slotR
 #define CGP_HEAD 64
 template <int NV4>
-__host__ __device__ inline int cgp_pool_rows(size_t lds_bytes) {
+__host__ __device__ inline int cgp_pool_rows(size_t lds_bytes, int wpb) {
   constexpr int NVR = 4 * NV4, JS = (NV4 & 1) ? NVR : NVR + 4;
-  const int words = (int)(lds_bytes / sizeof(float)) - CGP_HEAD;
+  const int words = (int)(lds_bytes / sizeof(float)) - CGP_HEAD - 64 * wpb;
   return words <= 0 ? 0 : ((words / (JS + 1)) & ~3);
 }
 // rows every solved world allocates at least: the Gauss-Jordan tile of the prologue (2 x 4 x NVR words), the fused integrator's lines
@@ -58,7 +59,8 @@ DEV void solve_cgp_body(const MjhModel& m, const MjhData& d, float* smem, int sl
   const int slot = slot0 + gib;
   const bool valid = gib < nwb && slot < d.nworld;
   int* cnt = reinterpret_cast<int*>(smem);
-  float* pool = smem + CGP_HEAD;
+  int* slotR = reinterpret_cast<int*>(smem) + CGP_HEAD + 64 * gib;  // efc row of every slot of this world
+  float* pool = smem + CGP_HEAD + 64 * (blockDim.x / G);
   float* fbpool = pool + (size_t)pool_rows * JS;
 
   // ---- row request of this world, then the workgroup's (sequential, identical in every lane) allocation ---------------------------
@@ -69,9 +71,27 @@ DEV void solve_cgp_body(const MjhModel& m, const MjhData& d, float* smem, int sl
     nefc = min(d.nefc[w], njmax);
     ne = d.ne[w];
     nf = d.nf[w];
-    np = min(ne + nf + d.nl[w], nefc);
-    nq = (nefc - np) >> 2;
-    defer = nf > 0 || ((nefc - np) & 3) != 0 || nefc > 64;  // friction loss (three-zone rows), a contact cut by njmax: the fallback launch
+    const int npf = min(ne + nf + d.nl[w], nefc);  // rows in front of the contact rows
+    // stable partition of the efc rows: pyramid rows (efc.type, four per condim-3 contact) to the front, the others behind them in order
+    const size_t eo_ = (size_t)w * njmax;
+    bool is6[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int r = lig + G * k;
+      is6[k] = r >= npf && r < nefc && d.efc_type[eo_ + r] == CT_CONTACT_PYRAMIDAL;
+    }
+    const unsigned m0 = (unsigned)gballot<G>(is6[0]), m1 = (unsigned)gballot<G>(is6[1]);
+    const int n60 = __popc(m0), n6 = n60 + __popc(m1);
+    const unsigned below = (1u << lig) - 1u;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int r = lig + G * k;
+      const int c6 = k == 0 ? __popc(m0 & below) : n60 + __popc(m1 & below);
+      if (r < nefc && r < 64) slotR[is6[k] ? c6 : n6 + r - c6] = r;
+    }
+    nq = n6 >> 2;
+    np = nefc - n6;
+    defer = nf > 0 || (n6 & 3) != 0 || nefc > 64;  // friction loss (three-zone rows), a contact cut by njmax: the fallback launch
     const int nb = np + 3 * nq;
     need = max((nb + 3) & ~3, cgp_min_rows<NV4>(fuse_euler));
   }
@@ -175,7 +195,7 @@ DEV void solve_cgp_body(const MjhModel& m, const MjhData& d, float* smem, int sl
       const int c = it / J4, c4 = it - c * J4;
       float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = r0, r2 = r0, r3 = r0;
       if (c4 < nvp4) {
-        const float4* src = reinterpret_cast<const float4*>(Jg + (size_t)(np + 4 * c) * nvp) + c4;
+        const float4* src = reinterpret_cast<const float4*>(Jg + (size_t)slotR[4 * c] * nvp) + c4;  // (a contact's four rows are consecutive)
         r0 = src[0]; r1 = src[nvp4]; r2 = src[2 * nvp4]; r3 = src[3 * nvp4];
       }
       float4* dst = reinterpret_cast<float4*>(Jl + (size_t)(3 * c) * JS) + c4;
@@ -183,10 +203,10 @@ DEV void solve_cgp_body(const MjhModel& m, const MjhData& d, float* smem, int sl
       dst[J4] = make_float4(0.5f * (r0.x - r1.x), 0.5f * (r0.y - r1.y), 0.5f * (r0.z - r1.z), 0.5f * (r0.w - r1.w));
       dst[2 * J4] = make_float4(0.5f * (r2.x - r3.x), 0.5f * (r2.y - r3.y), 0.5f * (r2.z - r3.z), 0.5f * (r2.w - r3.w));
     }
-    for (int it = lig; it < (nb4 - 3 * nq) * J4; it += G) {  // plain rows, then zero rows up to the multiple of 4
+    for (int it = lig; it < (nb4 - 3 * nq) * J4; it += G) {  // the other rows, then zero rows up to the multiple of 4
       const int p = it / J4, c4 = it - p * J4;
       float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-      if (p < np && c4 < nvp4) v = (reinterpret_cast<const float4*>(Jg + (size_t)p * nvp))[c4];
+      if (p < np && c4 < nvp4) v = (reinterpret_cast<const float4*>(Jg + (size_t)slotR[4 * nq + p] * nvp))[c4];
       (reinterpret_cast<float4*>(Jl + (size_t)(3 * nq + p) * JS))[c4] = v;
     }
     for (int r = nb + lig; r < nb4; r += G) fb[r] = 0.0f;  // (the rows past nb carry zero force for good)
@@ -197,13 +217,15 @@ DEV void solve_cgp_body(const MjhModel& m, const MjhData& d, float* smem, int sl
   int jro[NR];           // word offset in the world's pool of the basis row this lane reads in the row dots
   int fbo[NR];           // basis row that takes this lane's basis force (-1: none)
   bool isq[NR];
+  int rer[NR];           // efc row of the slot
   const int qd = lig & 3;
 #pragma unroll
   for (int k = 0; k < NR; ++k) {
     const int s = lig + G * k;
     const bool has = s < nefc;
     isq[k] = s < 4 * nq;
-    const int er = isq[k] ? np + s : s - 4 * nq;  // efc row of this slot
+    const int er = has ? slotR[s] : 0;  // efc row of this slot
+    rer[k] = er;
     const int br = isq[k] ? 3 * (s >> 2) + (qd < 3 ? qd : 2) : (has ? s - nq : 0);
     jro[k] = br * JS;
     fbo[k] = !has ? -1 : (isq[k] ? (qd < 3 ? 3 * (s >> 2) + qd : -1) : s - nq);
@@ -340,10 +362,9 @@ DEV void solve_cgp_body(const MjhModel& m, const MjhData& d, float* smem, int sl
 #pragma unroll
   for (int k = 0; k < NR; ++k)
     if (rkind[k] != 3) {  // force / state at the final iterate: the expression of the last constraint update
-      const int s = lig + G * k, er = isq[k] ? np + s : s - 4 * nq;
       const bool quad = rkind[k] == 0 || rja[k] < 0.0f;
-      d.efc_force[eo + er] = quad ? -rD[k] * rja[k] : 0.0f;
-      d.efc_state[eo + er] = quad ? ST_QUADRATIC : ST_SATISFIED;
+      d.efc_force[eo + rer[k]] = quad ? -rD[k] * rja[k] : 0.0f;
+      d.efc_state[eo + rer[k]] = quad ? ST_QUADRATIC : ST_SATISFIED;
     }
   if (lig == 0) {
     d.solver_niter[w] = niter;

@@ -463,7 +463,13 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
   m.nbodylevel, m.ndoflevel = nlevel, ndlevel
   m.nmaxcondim = int(max(condims)) if condims else 1
   m.nmaxpyramid = max(1, 2 * (m.nmaxcondim - 1))
-  m.cg_basis = int(condims == {3})
+  # condim of every contact the model can make (collision_core.py contact_params: the geom of higher priority decides, the larger condim
+  # at equal priority; explicit pairs carry their own): only 1 and 3 -> CG may run the contact-basis kernel (csrc/solver_cgp.hpp)
+  gc_, gp_ = np.asarray(mjm.geom_condim).astype(int), np.asarray(mjm.geom_priority).astype(int)
+  pair_condims = set(int(gc_[a] if gp_[a] > gp_[b] else gc_[b] if gp_[b] > gp_[a] else max(gc_[a], gc_[b])) for a, b in pairs)
+  if nexplicit:
+    pair_condims |= set(int(c) for c in np.asarray(mjm.pair_dim))
+  m.cg_basis = int(pair_condims <= {1, 3})
   m.key_qpos = _arr(getattr(mjm, "key_qpos", np.zeros((0, m.nq))), f32)
   m.key_qvel = _arr(getattr(mjm, "key_qvel", np.zeros((0, nv))), f32)
   m.key_ctrl = _arr(getattr(mjm, "key_ctrl", np.zeros((0, nu))), f32)

@@ -438,7 +438,7 @@ class Model(_Dirty):
   nmaxcondim: int = 0
   epa_iterations: int = 0  # EPA iteration cap of the convex narrowphase (reference collision_convex.py:1223)
   act_dof_max: int = 0  # largest number of actuators acting on one dof
-  cg_basis: int = 0  # 1: every contact has condim 3 -- CG at nv <= 32, njmax <= 64 runs the pooled contact-basis kernel (csrc/solver_cgp.hpp)
+  cg_basis: int = 0  # 1: every contact has condim 1 or 3 -- CG at nv <= 32, njmax <= 64 runs the pooled contact-basis kernel (csrc/solver_cgp.hpp)
   act_velfeedback: int = 0  # 1: positive velocity feedback through an actuator is possible (implicitfast is then not fused into the solver)
   sleep_enabled: int = 0  # EnableBit.SLEEP set and DisableBit.ISLAND clear (reference forward.py:345)
   opt_sleep_tolerance: float = 0.0  # Option.sleep_tolerance (one value per model)

@@ -124,8 +124,9 @@ def test_cgp_pool_overflow_goes_to_the_fallback_launch():
   by the pooled kernel and solved by k_solve<cg> in the launch behind it -- every world ends inside the oracle tolerance."""
   mjm, s, m, d = _cg_humanoid(24)
   s.forward()
-  nb = (s.nefc - s.ne - s.nf - s.nl) // 4 * 3 + s.ne + s.nf + s.nl
-  lds = 4 * (64 + 29 * (2 * ((nb + 3) // 4 * 4) + 4))  # room for two worlds of this state (and not three) per workgroup
+  n6 = int((s.efc_type[: s.nefc] == 6).sum())
+  nb = n6 // 4 * 3 + s.nefc - n6
+  lds = 4 * (64 + 64 * 8 + 29 * (2 * ((nb + 3) // 4 * 4) + 4))  # room for two worlds of this state (and not three) per workgroup of 8
   with _knob(MJH_CG_KERNEL="cgp", MJH_CGP_THREADS=256, MJH_CGP_LDS=lds):
     mjw.forward(m, d)
   niter = d.solver_niter.numpy()

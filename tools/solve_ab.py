@@ -15,7 +15,9 @@ sys.path.insert(0, ROOT)
 import torch
 
 import mujoco_warp_amd as mjw
-from mujoco_warp_amd import forward as fw
+import importlib
+
+fw = importlib.import_module("mujoco_warp_amd.forward")
 
 p = argparse.ArgumentParser()
 p.add_argument("variants", nargs="*", default=[""])
