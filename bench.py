@@ -226,9 +226,14 @@ def steady_1000(mjw, m, mjm, nworld, world_offset, nstep=1000):
       nefc_sum += float(np.minimum(d.nefc.numpy(), d.njmax).mean())
       niter_sum += float(d.solver_niter.numpy().mean())
   ok = int(nworld - np.isnan(d.qpos.numpy()).any(axis=1).sum())
-  return {"value": nworld * nstep / total, "unit": "env-steps/s", "nstep": nstep, "ms_per_step": 1e3 * total / nstep,
-          "nefc_mean": nefc_sum / (nstep // 100), "solver_niter_mean": niter_sum / (nstep // 100), "converged_worlds": ok,
-          "timing": "reference placement: per-step device sync, control noise outside the timed region (cli.py:289-292), eager launches"}
+  out = {"value": nworld * nstep / total, "unit": "env-steps/s", "nstep": nstep, "ms_per_step": 1e3 * total / nstep,
+         "nefc_mean": nefc_sum / (nstep // 100), "solver_niter_mean": niter_sum / (nstep // 100), "converged_worlds": ok,
+         "timing": "reference placement: per-step device sync, control noise outside the timed region (cli.py:289-292), eager launches"}
+  # the fused step's launches at THIS state (HIP event pairs on the launch stream, 50 more steps): the steady-state roofline's clock
+  _, pk = mjw.timed_steps(m, d, 50, step0=nstep, per_kernel=True)
+  out["fused_launch_us"] = {n: 1e3 * t / 50 for n, t in zip(mjw.KERNEL_NAMES, pk) if t > 0}
+  out["nefc_mean_at_end"] = float(np.minimum(d.nefc.numpy(), d.njmax).mean())
+  return out
 
 
 def other_configs(mjw, nstep=200):
@@ -245,9 +250,14 @@ def other_configs(mjw, nstep=200):
   entries = (
     dict(name="unitree_g1_flat", xml=os.path.join(B, "unitree_g1", "scene_flat.xml"), nworld=4096, nconmax=48, njmax=192, replay=os.path.join(B, "unitree_g1", "shuffle_dance.npz")),
     dict(name="franka_emika_panda", xml=os.path.join(B, "franka_emika_panda", "scene.xml"), nworld=8192, nconmax=1, njmax=5),
+    dict(name="franka_emika_panda_shard", xml=os.path.join(B, "franka_emika_panda", "scene.xml"), nworld=1024, nconmax=1, njmax=5,
+         note="configs[3] per GPU: 8192 worlds over 8 GPUs = 1024 each -- a quarter of the device's wavefront slots, the step is launch latency"),
     dict(name="aloha_pot", xml=os.path.join(B, "aloha_pot", "scene.xml"), nworld=8192, nconmax=24, njmax=128, replay=os.path.join(B, "aloha_pot", "lift_pot.npz")),
     dict(name="clutter_synth", xml=os.path.join(B, "clutter_synth", "scene_clutter_synth.xml"), nworld=2048, nconmax=256, njmax=384, nvmax=56,
          override=["opt.enableflags=SLEEP"], init_asleep=True, hold_key_ctrl=True),
+    dict(name="clutter_synth_shard", xml=os.path.join(B, "clutter_synth", "scene_clutter_synth.xml"), nworld=256, nconmax=256, njmax=384, nvmax=56,
+         override=["opt.enableflags=SLEEP"], init_asleep=True, hold_key_ctrl=True, nstep=100, lead=50,
+         note="configs[4] per GPU: 2048 worlds over 8 GPUs = 256 each"),
     dict(name="clutter_synth_pgs", xml=os.path.join(B, "clutter_synth", "scene_clutter_synth.xml"), nworld=2048, nconmax=256, njmax=384,
          override=["opt.solver=pgs", "opt.enableflags=0"], nstep=100, lead=50, hold_key_ctrl=True),
   )
@@ -302,6 +312,9 @@ def _config_run(mjw, torch, e, nstep, lead):
          "ncon_mean": ncon / max(nstat, 1), "nefc_mean": nefc / max(nstat, 1), "solver_niter_mean": niter / max(nstat, 1),
          "finite": ok, "overflow_bits": ovf, "iteration_cap_worlds": int(((d.overflow.numpy() >> 9) & 1).sum()),
          "timing": "reference placement (per-step sync, control untimed)"}
+  if e.get("note"):
+    res["note"] = e["note"]
+    res["x8"] = {"value": 8 * res["value"], "note": "8 shards of this size, one per GPU, no data-path collective: the single-GPU figure x 8 (a projection, not a measured 8-GPU run)"}
   if int(mjm.opt.solver) != 0 and not (int(mjm.opt.enableflags) & int(mjw.EnableBit.SLEEP)) and not e.get("replay") and not e.get("hold_key_ctrl"):  # (timed_steps: fused launch sequence, noise around the ctrl-range midpoint -- the same workload only without a replayed / held control centre)
     ms_b2b, _ = mjw.timed_steps(m, d, nstep, step0=lead + nstep)
     res["back_to_back_value"] = e["nworld"] * nstep / (ms_b2b * 1e-3)
@@ -403,13 +416,13 @@ def main():
     words_crb = 1501                                                # CRBA(+factor) pass: cinert, cdof in; crb, M, qLD, qLDiagInv out
     t_dom = fused_us["solve"] * 1e-6
     achieved = 4 * words_solve * nworld / t_dom / 1e9
-    traffic, traffic_src = _traffic_from_profile(args.pmc_profile, args.solver)
-    out["roofline"] = {"kernel": {"pgs": "k_solve_pgs", "cg": "k_solve_plus<CG> (solver + L'DL-factor / publication riders)",
+    traffic, traffic_src = _traffic_from_profile(args.pmc_profile, args.solver, _window_of(args.warmup))
+    out["roofline"] = {"kernel": {"pgs": "k_solve_pgs", "cg": "k_solve_cgp_plus (pooled contact-basis CG + L'DL-factor / publication riders)",
                                   "newton": "k_solve_plus<NEWTON>"}[args.solver], "bound": "hbm",
                        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                        "traffic": traffic, "traffic_source": traffic_src, "bytes_per_launch": 4 * words_solve * nworld,
                        "us_per_launch": fused_us["solve"],
-                       "note": "not an HBM stream: the kernel is a latency chain at ~2.5 waves per SIMD -- see `issue` (VALU issue ~1/3, LDS pipe ~1/3, HBM 3-5 %); "
+                       "note": "not an HBM stream: the kernel is a latency chain at ~3 waves per SIMD -- see `issue` (VALU issue ~0.4, HBM 3-5 %); "
                                "the HBM fraction is reported because the contract asks for it"}
     t_pass = (fused_us["fwd_pos"] + fused_us["solve"]) * 1e-6
     pass_bytes = 4 * (words_crb + words_solve) * nworld
@@ -417,7 +430,8 @@ def main():
                                "frac_of_8TBs": pass_bytes / t_pass / 1e9 / HBM_PEAK_GBS,
                                "note": "time = k_fwd_pos_plus (FK+CoM+CRBA fused) + the solver launch; bytes = SURVEY 8(d)"}
     out["fused_launch_us"] = fused_us
-    out["roofline"]["issue"] = _issue_from_profile(args.pmc_profile, args.solver)
+    out["roofline"]["issue"] = _issue_from_profile(args.pmc_profile, args.solver, _window_of(args.warmup))
+    out["roofline"]["window"] = f"steps {args.warmup}..{args.warmup + args.steps} of the rollout from key 0 ({_window_of(args.warmup)}); the steady state is `roofline_steady`"
     out["box"] = box_fingerprint(fused_us.get("fwd_pos"), fused_us.get("mid"))
     # per-stage trace: one plain kernel per stage (the reference's event-tracer granularity)
     for k, v in snapshot.items():
@@ -439,6 +453,17 @@ def main():
   if rank == 0 and not args.no_steady:
     off, cnt = shard_of(args.scaling)
     out["steady_1000"] = steady_1000(mjw, m, mjm, cnt, off)
+    if not args.no_roofline and "solve" in out["steady_1000"].get("fused_launch_us", {}):
+      # the same roofline at the state the published metric averages over: the launch clock and nefc of the END of the 1000-step rollout, the
+      # counter traffic of the committed steady-window PMC summary
+      st = out["steady_1000"]
+      words = (1135 if args.solver == "cg" else 406) + 33 * st["nefc_mean_at_end"]
+      us = st["fused_launch_us"]["solve"]
+      ach = 4 * words * cnt / (us * 1e-6) / 1e9
+      tr, tr_src = _traffic_from_profile(args.pmc_profile, args.solver, "steady")
+      out["roofline_steady"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": tr, "traffic_source": tr_src,
+                                "bytes_per_launch": 4 * words * cnt, "us_per_launch": us, "nefc_mean": st["nefc_mean_at_end"],
+                                "window": "steps 1000..1050 of the rollout from key 0 (steady)", "issue": _issue_from_profile(args.pmc_profile, args.solver, "steady")}
   shard.barrier()
 
   if rank == 0 and world_size == 1 and not args.no_configs:
@@ -453,20 +478,27 @@ def main():
     dist.destroy_process_group()
 
 
-def _committed_profile(solver):
-  for r in ("round4", "round3"):
-    p = os.path.join(ROOT, "profiles", f"{r}_pmc_{solver}.json")
-    if os.path.exists(p):
-      return p
+def _committed_profile(solver, window="steady"):
+  """The committed rocprofv3 PMC summary of this solver's workload whose WINDOW of the rollout matches the timed one: "early" = the
+  driver's --warmup 5 window (free fall and first contacts, nefc ~12), "steady" = steps 300+ (the humanoid on the floor, nefc ~45)."""
+  for r in ("round5", "round4"):
+    for name in (f"{r}_pmc_{solver}_{window}.json", f"{r}_pmc_{solver}.json"):
+      p = os.path.join(ROOT, "profiles", name)
+      if os.path.exists(p):
+        return p
   return None
 
 
-def _issue_from_profile(path, solver):
+def _window_of(warmup):
+  return "early" if warmup < 100 else "steady"
+
+
+def _issue_from_profile(path, solver, window="steady"):
   """What bounds the three launches of the step, from the rocprofv3 PMC summary of the same workload and solver (tools/make_pmc_summary.py):
   per kernel the VALU issue fraction (a wave64 VALU instruction occupies a SIMD-32 for 2 cycles: SQ_INSTS_VALU x 2 / (1,024 SIMDs x
   busy cycles)), the LDS pipe's busy fraction, the resident waves per SIMD, the share of wave-cycles spent waiting and the HBM fraction."""
   if path == "auto":
-    path = _committed_profile(solver)
+    path = _committed_profile(solver, window)
   if not path or path == "none" or not os.path.exists(path):
     return None
   try:
@@ -505,12 +537,12 @@ def box_fingerprint(fwd_pos_us, mid_us=None):
   return out
 
 
-def _traffic_from_profile(path, solver):
+def _traffic_from_profile(path, solver, window="steady"):
   """HBM bytes per solver launch from a rocprofv3 PMC summary of the SAME solver's kernel (FETCH_SIZE x2 on gfx950 + WRITE_SIZE,
   separate passes: MI355X_MICROARCH.md).  Without such a profile the field is null: a number from another run is not a measurement."""
   committed = False
   if path == "auto":
-    path = _committed_profile(solver)
+    path = _committed_profile(solver, window)
     committed = True
   if not path or path == "none":
     return None, "not collected in this run (rocprofv3 --pmc needs its own passes; see profiles/)"

@@ -571,7 +571,8 @@ DEV void convex_epa_group(float tolerance, int epa_iterations, int t1, int t2, V
   if (n == 0 || dist >= gap) return;
   dist += margin;
   const bool anymesh = t1 == G_MESH || t2 == G_MESH;
-  if (face >= 0 && anymesh && ((mm.disableflags & DSBL_MULTICCD) || mm.nmeshpoly == 0)) face = -1;
+  // (nmeshdegmax == 0: the model was put with MULTICCD disabled -- no multi-contact scratch was sized, whatever the flag says now)
+  if (face >= 0 && anymesh && ((mm.disableflags & DSBL_MULTICCD) || mm.nmeshpoly == 0 || mm.nmeshdegmax == 0)) face = -1;
 #ifdef MJH_DBG_EPA_NOMC
   face = -1;
 #endif
@@ -1378,9 +1379,9 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
   // every filtered pair, PU per lane and trip.  Stage B (heavy instantiation): the box filters on the SURVIVORS only, which queue up in
   // LDS in pair order and are served a full lane group at a time -- on the ALOHA scene 760 of 9,154 pairs survive stage A, scattered over
   // nearly every trip: with the box filters inside the trip (~300 instructions) every trip paid them for one or two live lanes.
-  constexpr int PU = MODE == 1 ? 8 : (HEAVY ? 4 : 1);
+  constexpr int PU = MODE == 1 ? (G > 32 ? 4 : 8) : (HEAVY ? 4 : 1);  // (64-lane groups: fewer pairs per lane and trip, the queue below is sized for G (PU + 1) entries)
   constexpr int QCAP = HEAVY ? CON_WINDOW * CON_LDS : 0;  // the staging window's LDS is free until the narrowphase's second pass
-  static_assert(!HEAVY || QCAP >= (PU + 1) * 32, "queue: a trip's survivors behind a partial group");
+  static_assert(!HEAVY || QCAP >= (PU + 1) * G, "queue: a trip's survivors behind a partial group");
   int* queue = reinterpret_cast<int*>(rec);
   int nq = 0;
   const bool box_filters = HEAVY && (filt & 12) != 0;

@@ -296,23 +296,42 @@ DEV void schedule_body(const MjhData& d, int* sh, int nthreads, int cls = 0) {
   // key: worlds that had more than `cls` constraint rows first, then the others (the solver's one-row-per-lane instantiation takes the worlds
   // of at most 32 rows in a launch of its own: with the two classes apart both launches run dense workgroups); inside a class by iteration
   // count, longest first.  256 bins: `sh` needs 512 ints.  Without classes (cls = 0: every solver but Newton with elliptic cones) the row
-  // counts are not even loaded: this single workgroup rides in the k_fwd_pos launch and was its tail (round 5: fused launch 59 -> 50 us).
+  // counts are not even loaded.
+  // This single workgroup rides in the k_fwd_pos launch and was its tail (fused launch 59 us against 41 us for the plain kernel, round 4):
+  // round 5 keeps a thread's keys in registers -- ONE batch of up to 32 loads per thread, all in flight together, serves both the histogram
+  // and the scatter (it was two passes of 8-deep batches: eight dependent memory round trips for 8192 worlds on 256 threads).
   int* hist = sh;
   int* base = sh + 256;
   const int t = threadIdx.x, n = d.nworld;
   auto bin = [cls](int niter, int nefc) { return (cls == 0 || nefc > cls ? 0 : 128) + 127 - min(max(niter, 0), 127); };
   for (int i = t; i < 256; i += nthreads) hist[i] = 0;
   __syncthreads();
-  for (int w0 = t; w0 < n; w0 += 8 * nthreads) {
-    int v[8], e[8];
+  constexpr int KD = 32;
+  const bool one_batch = n <= KD * nthreads;
+  int key[KD];
+  if (one_batch) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      v[k] = w0 + k * nthreads < n ? d.solver_niter[w0 + k * nthreads] : -1;
-      e[k] = cls && w0 + k * nthreads < n ? d.nefc[w0 + k * nthreads] : 0;
+    for (int k = 0; k < KD; ++k) {
+      const int w = t + k * nthreads;
+      const int v = w < n ? d.solver_niter[w] : -1;
+      const int e = cls && w < n ? d.nefc[w] : 0;
+      key[k] = w < n ? bin(v, e) : -1;
     }
 #pragma unroll
-    for (int k = 0; k < 8; ++k)
-      if (w0 + k * nthreads < n) atomicAdd(&hist[bin(v[k], e[k])], 1);
+    for (int k = 0; k < KD; ++k)
+      if (key[k] >= 0) atomicAdd(&hist[key[k]], 1);
+  } else {
+    for (int w0 = t; w0 < n; w0 += 8 * nthreads) {
+      int v[8], e[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        v[k] = w0 + k * nthreads < n ? d.solver_niter[w0 + k * nthreads] : -1;
+        e[k] = cls && w0 + k * nthreads < n ? d.nefc[w0 + k * nthreads] : 0;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (w0 + k * nthreads < n) atomicAdd(&hist[bin(v[k], e[k])], 1);
+    }
   }
   __syncthreads();
   if (t < 64) {  // exclusive prefix over the 256 bins: four bins per lane of the first wavefront
@@ -332,6 +351,12 @@ DEV void schedule_body(const MjhData& d, int* sh, int nthreads, int cls = 0) {
   }
   __syncthreads();
   // scatter; the order inside a bucket is arbitrary (it only decides which wavefront hosts a world, never a result)
+  if (one_batch) {
+#pragma unroll
+    for (int k = 0; k < KD; ++k)
+      if (key[k] >= 0) d.ws_order[atomicAdd(&base[key[k]], 1)] = t + k * nthreads;
+    return;
+  }
   for (int w0 = t; w0 < n; w0 += 8 * nthreads) {
     int v[8], e[8], pos[8];
 #pragma unroll

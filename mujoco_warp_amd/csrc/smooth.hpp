@@ -1021,7 +1021,8 @@ DEV void fwd_vel_body(const MjhModel& m, const MjhData& d, int first, int last, 
       }
     }
     gsync();
-    {  // forward.py:1121-1150 _qfrc_actuator_gravcomp_limits: actuator-level gravity compensation, then the joint's actuatorfrcrange
+    if (nu > 0 && !(dsbl & DSBL_ACTUATION)) {  // forward.py:1121-1150 _qfrc_actuator_gravcomp_limits: actuator-level gravity compensation, then the
+      // joint's actuatorfrcrange -- not without actuators / with actuation disabled: the reference returns with qfrc_actuator = 0 (forward.py:1155-1159)
       const float* afr = bf(m.jnt_actfrcrange, m.jnt_actfrcrange_nb, w, 2 * njnt);
       for (int i = lig; i < nv; i += G) {
         const int j = m.dof_jntid[i];

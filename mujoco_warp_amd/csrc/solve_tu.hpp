@@ -18,6 +18,21 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((!NEWT
   // remaining (short) solves
   const int bx = (int)blockIdx.x, nrider = NEWTON ? 0 : 2 * nfac;
   const int sb = bx < rider_at ? bx : bx - nrider;  // solver workgroup index when this is one
+  if (nefc_lo == -2) {
+    // The fallback launch behind the pooled CG kernel (solver_cgp.hpp): every lane group scans 32 worlds' flags with one load and solves the
+    // worlds flagged solver_niter = -1 one after the other -- in the common case none, and the launch is 128 workgroups that load and leave.
+    const int lig = threadIdx.x & (SG - 1), gid = bx * wpb + (int)threadIdx.x / SG;
+    for (int c0 = gid * SG; c0 < d.nworld; c0 += (int)gridDim.x * wpb * SG) {
+      unsigned long long todo = gballot<SG>(c0 + lig < d.nworld && d.solver_niter[c0 + lig] == -1);
+      while (todo) {
+        const int bq = __ffsll((long long)todo) - 1;
+        todo &= todo - 1ull;
+        solve_body<NV4, NR, NEWTON, SG, ELL>(m, d, smem, Blk{0, wpb, (int)blockDim.x}, -1, nefc_hi, fuse_euler, 0, 0x7fffffff, c0 + bq);
+        gsync();
+      }
+    }
+    return;
+  }
   if (bx < rider_at || bx >= rider_at + nrider) solve_body<NV4, NR, NEWTON, SG, ELL>(m, d, smem, Blk{sb * wpb, wpb, (int)blockDim.x}, nefc_lo, nefc_hi, fuse_euler);
   // CG only: the Newton kernel holds 256 VGPRs (one wave per SIMD), which would throttle the riders too (measured
   // +120 us); for Newton they ride along with the integrator launch instead
@@ -45,7 +60,9 @@ static int launch_solve_t(const MjhModel* m, const MjhData* d, bool with_factor,
   with_factor = with_factor && !NEWTON;
   if (with_factor) lds = std::max(lds, ms_bytes + sizeof(float) * fl.total * wf);
   HIPCHK(set_lds((k_solve_plus<NV4, NR, NEWTON, SG, ELL>), lds));
-  const int nsolve = (d->nworld + wpb - 1) / wpb, nfac = with_factor ? (d->nworld + wf - 1) / wf : 0;
+  int nsolve = (d->nworld + wpb - 1) / wpb;
+  const int nfac = with_factor ? (d->nworld + wf - 1) / wf : 0;
+  if (nefc_lo == -2) nsolve = std::max(1, (d->nworld + wpb * SG - 1) / (wpb * SG));  // (fallback launch: one lane group per 32 (64) worlds)
   // riders (fused step, CG): factor workgroups, then as many contact-publication workgroups
   debug_occupancy(NEWTON ? "k_solve_plus<newton>" : "k_solve_plus<cg>", k_solve_plus<NV4, NR, NEWTON, SG, ELL>, nsolve + 2 * nfac, threads, lds);
   // where the riders sit in the dispatch order, in per cent of the solver workgroups (developer knob; 100 = after all of them, the round-1 layout).

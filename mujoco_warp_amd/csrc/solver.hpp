@@ -77,6 +77,34 @@ DEV void gsumg_n(float (&v)[N]) {
     for (int i = 0; i < N; ++i) v[i] = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v[i]), 0x3E0));
   }
 }
+// The same sums without the LDS crossbar (round 5, 32-lane groups): after the four row_shr steps lane 15 of each 16-lane row holds its row's
+// sum; v_permlane16_swap hands both rows' registers to both rows and two row_newbcast:15 reads add the two row sums -- the same bits in
+// every lane.  Seven VALU instructions per value instead of five + one ds_swizzle: a reduction is no LDS round trip any more (the CG
+// iteration had 4-5 of them on its dependent chain, and they were 23 of its 59 DS instructions).
+template <int N>
+DEV void gsum32_valu_n(float (&v)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = dpp_add_f<0x111, 0xf, 0xf>(v[i]);  // row_shr:1
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = dpp_add_f<0x112, 0xf, 0xf>(v[i]);  // row_shr:2
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = dpp_add_f<0x114, 0xf, 0xf>(v[i]);  // row_shr:4
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = dpp_add_f<0x118, 0xf, 0xf>(v[i]);  // row_shr:8
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[i]), __float_as_uint(v[i]), false, false);
+    const float lo = __int_as_float(__builtin_amdgcn_update_dpp(0, (int)sw[0], 0x15F, 0xf, 0xf, true));  // row_newbcast:15 of the even row's copy
+    const float hi = __int_as_float(__builtin_amdgcn_update_dpp(0, (int)sw[1], 0x15F, 0xf, 0xf, true));  // ... of the odd row's copy
+    v[i] = lo + hi;
+  }
+}
+// RED selects the broadcast of a group sum: 0 = gsumg_n (ds_swizzle), 1 = gsum32_valu_n (G = 32 only)
+template <int G, int N, int RED>
+DEV void gsum_sel(float (&v)[N]) {
+  if (RED == 1 && G == 32) gsum32_valu_n<N>(v);
+  else gsumg_n<G, N>(v);
+}
 // (A butterfly all-reduce -- quad_perm, row_half_mirror, row_mirror, v_permlane16_swap or ds_swizzle -- is two VALU ops
 // shorter and passes in isolation, but inside k_solve it broke parity with both cross-row variants; not pursued.)
 // division for step-size candidates and ratios that only steer the search (v_rcp_f32, 1 ulp; an IEEE divide is ~10 ops)
@@ -394,7 +422,7 @@ DEV bool in_bracket(P3 x, P3 y) { return (x.g < y.g && y.g < 0.0f) || (x.g > y.g
 #endif
 // ---- the line search (solver.py:835-1347) over rows held in registers; every sum of an evaluation round is reduced together
 // HAS_FL: friction-loss rows present (three-zone cost, rare): a compile-time switch, the common instantiation is branch-free
-template <int NR, int G, bool HAS_FL>
+template <int NR, int G, bool HAS_FL, int RED = 0>
 DEV void line_search_rows(const float (&rja)[NR], const float (&rjv)[NR], const float (&rD)[NR], const int (&rkind)[NR],
                           const float* floss_lane, float gauss1_lane, float gauss2_lane, float gauss1_abs_lane, float gtol_in, int ls_iterations,
                           float& alpha_out, float& improvement_out, bool& converged_out, int* iters_out = nullptr) {
@@ -442,12 +470,12 @@ DEV void line_search_rows(const float (&rja)[NR], const float (&rjv)[NR], const 
 #pragma unroll
   for (int k = 0; k < NR; ++k) eabs += fabsf(egrad0[k]);
   float r2[6] = {e.g, e.h, eabs, gauss1_lane, gauss2_lane, gauss1_abs_lane};
-  gsumg_n<G, 6>(r2);
+  gsum_sel<G, 6, RED>(r2);
   const float gauss1 = r2[3], gauss2 = r2[4];
   const float gtol = fmaxf(gtol_in, (MJH_LS_NOISE_ULPS * 5.96e-8f) * (r2[5] + r2[2]));
 #else
   float r2[4] = {e.g, e.h, gauss1_lane, gauss2_lane};
-  gsumg_n<G, 4>(r2);
+  gsum_sel<G, 4, RED>(r2);
   const float gauss1 = r2[2], gauss2 = r2[3];
   const float gtol = gtol_in;
 #endif
@@ -459,7 +487,7 @@ DEV void line_search_rows(const float (&rja)[NR], const float (&rjv)[NR], const 
   const float lo_alpha_in = -fast_div(p0.g, p0.h);
   const P3 el = eval(lo_alpha_in);
   float r3[3] = {el.c, el.g, el.h};
-  gsumg_n<G, 3>(r3);
+  gsum_sel<G, 3, RED>(r3);
   const P3 lo_in = finish(r3[0], r3[1], r3[2], lo_alpha_in);
   float alpha = 0.0f, improvement = 0.0f;
   bool ls_converged = fabsf(lo_in.g) < gtol && lo_in.c < 0.0f;
@@ -476,7 +504,7 @@ DEV void line_search_rows(const float (&rja)[NR], const float (&rjv)[NR], const 
       const float a_mid = 0.5f * (lo_alpha + hi_alpha);
       const P3 e1 = eval(a_lo), e2 = eval(a_hi), e3 = eval(a_mid);
       float r9[9] = {e1.c, e1.g, e1.h, e2.c, e2.g, e2.h, e3.c, e3.g, e3.h};
-      gsumg_n<G, 9>(r9);
+      gsum_sel<G, 9, RED>(r9);
       const P3 lo_next = finish(r9[0], r9[1], r9[2], a_lo), hi_next = finish(r9[3], r9[4], r9[5], a_hi), mid = finish(r9[6], r9[7], r9[8], a_mid);
       // Bracket update (solver.py:1222-1290).  The reference takes a candidate when its derivative lies strictly between the
       // bracket end's derivative and zero, for three candidates in turn -- each test on the end the previous one may have
@@ -722,7 +750,7 @@ DEV void invert_rows_b4(const float (&mrow)[NVR], float (&s)[NVR], float* buf, i
 // same kernel.  An instantiation serves the islands whose dof count lies in (nv_lo, nv_hi] (32 lanes: <= 32 dofs, 64 lanes: 33..64).
 template <int NV4, int NR, bool NEWTON, int G, bool ELL = false, bool TREE = false>
 DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk& b, int nefc_lo = -1, int nefc_hi = 0x7fffffff,
-                    int fuse_euler = 0, int nv_lo = 0, int nv_hi = 0x7fffffff) {
+                    int fuse_euler = 0, int nv_lo = 0, int nv_hi = 0x7fffffff, int w_direct = -1) {
   if ((int)threadIdx.x >= b.nthreads) return;
   constexpr int NVR = 4 * NV4;
   constexpr int JS = (NV4 & 1) ? NVR : NVR + 4;
@@ -731,13 +759,12 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
   const int lig = threadIdx.x & (G - 1), gib = threadIdx.x / G;
   const int slot = b.w0 + gib;
   if (TREE && gib >= b.nw) return;  // (a looped launch hands a block fewer islands than it has lane groups)
-  if (slot >= (TREE ? d.nworld * m.ntree : d.nworld)) return;
-  // worlds are scheduled longest-expected-solve first and paired with a similar neighbour (k_schedule_worlds)
-  const int w = TREE ? slot / m.ntree : d.ws_order[slot];
+  if (w_direct < 0 && slot >= (TREE ? d.nworld * m.ntree : d.nworld)) return;
+  // worlds are scheduled longest-expected-solve first and paired with a similar neighbour (k_schedule_worlds); w_direct: the caller names
+  // the world (the fallback launch behind the pooled CG kernel, solve_tu.hpp)
+  const int w = TREE ? slot / m.ntree : (w_direct >= 0 ? w_direct : d.ws_order[slot]);
   const int tree = TREE ? slot - w * m.ntree : 0;  // island index
   if (TREE && (!d.ws_separable[w] || tree >= d.ws_nisland[w])) return;  // (an island of more than 64 dofs: the generic solver)
-  // nefc_lo == -2: the fallback launch behind the pooled CG kernel (solver_cgp.hpp) -- only the worlds it flagged solver_niter = -1
-  if (!TREE && nefc_lo == -2 && d.solver_niter[w] != -1) return;
   const int* dadr = TREE ? d.ws_isl_dofadr + (size_t)w * (m.ntree + 1) + tree : nullptr;
   const int nv = TREE ? dadr[1] - dadr[0] : nv_all;
   if (TREE && (nv <= nv_lo || nv > nv_hi)) return;

@@ -1,25 +1,28 @@
 // solver_cgp.hpp -- CG for the headline class (nv <= 32, njmax <= 64, pyramidal cones, contacts of condim 1 or 3): contact-basis rows in one
-// row pool per workgroup, no vector through LDS (round 5).
+// row pool per workgroup, no vector through LDS, every LDS phase of an iteration one round trip (round 5).
 //
 // Reference: the same functions as solver.hpp (solver.py:3283-3450 CG, 835-1347 line search, 1698-1822 constraint update, 1912-1947
 // qfrc_constraint); the pyramid rows of a contact are constraint.py:3751-3879 (_efc_contact_jac_dense): J_n + mu J_t1, J_n - mu J_t1,
 // J_n + mu J_t2, J_n - mu J_t2.
 //
 // Why a third CG mapping.  k_solve<cg> (solver.hpp) holds `64 x JS` words of J per world whatever its row count: 7.9 KB, ten two-world
-// wavefronts per CU = 2.5 per SIMD (2.08 measured), so the 4,096 wavefronts of 8,192 worlds run in two rounds, each a latency chain
-// at 29 % VALU issue (profiles/round4_pmc_cg_steady.json).  8,192 worlds are exactly FOUR two-world wavefronts per SIMD: if a
-// wavefront costs <= 10 KB of LDS and <= 128 VGPRs the whole batch is resident from the first cycle, there is no second round and
-// every SIMD always has four chains to interleave.  What buys the space:
+// wavefronts per CU = 2.5 per SIMD (2.08 measured), and every wavefront is one latency chain at 29 % VALU issue
+// (profiles/round4_pmc_cg_steady.json): per iteration eleven dependent LDS round trips (J^T f in 16-row chunks, two vector broadcasts
+// through LDS lines, the line search's cross-lane sums).  Here:
 //   * contact-basis rows: the four pyramid rows of a condim-3 contact span N = J_n, T1 = mu J_t1, T2 = mu J_t2.  LDS holds the three
 //     basis rows (recovered from efc.J as (r0 + r1) / 2, (r0 - r1) / 2, (r2 - r3) / 2), J x of the four rows is formed inside the
 //     contact's lane quad as d_N +- d_T1, d_N +- d_T2 (three quad_perm DPP reads), and J^T f = N^T (f0 + f1 + f2 + f3) + T1^T (f0 - f1)
 //     + T2^T (f2 - f3) runs over three rows instead of four: - 25 % LDS words and - 25 % of the J^T f reads and FMAs;
-//   * one row POOL per workgroup: a world takes the rows it needs (3 per contact + 1 per limit / equality row, rounded to 4), the
-//     workgroup's worlds share `pool_rows`; the humanoid's steady state needs 35-38 per world, the pool gives 44 on average.  A world
-//     that does not fit (or has friction-loss rows / a truncated contact) is flagged solver_niter = -1 and solved by the fallback
-//     launch that follows on the same stream (k_solve<cg> restricted to flagged worlds: empty in the common case);
+//   * one row POOL per workgroup: a world takes the rows it needs (3 per condim-3 contact + 1 per other row, rounded to 4) instead of 64;
+//     three wavefronts per SIMD (the register budget: 168) leave 58 rows per world on average where the humanoid's steady state needs
+//     36-40.  A world that does not fit (or has friction-loss rows / a contact cut by njmax) is flagged solver_niter = -1 and solved by
+//     the fallback launch that follows on the same stream (k_solve<cg> restricted to flagged worlds: empty in the common case);
 //   * no vector ever goes through LDS: an nv-vector lives one element per lane, v_permlane16_swap + DPP row_newbcast feed the
-//     matrix-vector FMAs (solver_cgw.hpp's scheme in a 32-lane group), so LDS holds nothing but the pool;
+//     matrix-vector FMAs (solver_cgw.hpp's scheme in a 32-lane group) -- as v_fmac_f32_dpp, written in inline assembly: the compiler only
+//     folds a DPP move into VOP2 opcodes and selects the three-operand v_fma_f32 here (238 v_mov_b32_dpp + v_fma pairs measured);
+//   * J^T f in ONE round trip: lane (cq, rg) = (lane / 4, lane % 4) reads the columns 4 cq .. 4 cq + 3 of the rows rg, rg + 4, ... as
+//     16-byte words (a 36-row world: 9 reads per lane where the row loop needed 36 + 9), the basis forces arrive transposed the same
+//     way (fbT[rg][i]), two quad_perm adds fold the four row classes and lane l -- dof l -- finds its column in its own quad;
 //   * J is dead when the solve ends: the fused integrator's scratch lines alias the world's pool rows.
 // Rows in the lanes: slot s = lane + 32 k (k = 0, 1).  The rows of condim-3 contacts first -- the q-th such contact owns the quad of slots
 // 4q .. 4q + 3 --, then every other row (equality, limit, frictionless contact) in efc order: a stable partition of the efc rows by
@@ -29,13 +32,15 @@
 #include "solver.hpp"
 #include "solver_cgw.hpp"
 
-// words of LDS in front of the pool: the workgroup's row requests (one int per world, at most 32 worlds), then 64 ints per world: slotR
-#define CGP_HEAD 64
+// LDS of a workgroup: [CGP_HEAD ints: the worlds' row requests] [per world: slotR 64 ints | fbT 64 floats + 8 (the word lanes without a
+// basis force write to)] [pool: pool_rows x JS]
+#define CGP_HEAD 32
+#define CGP_WORLD 136
 template <int NV4>
 __host__ __device__ inline int cgp_pool_rows(size_t lds_bytes, int wpb) {
   constexpr int NVR = 4 * NV4, JS = (NV4 & 1) ? NVR : NVR + 4;
-  const int words = (int)(lds_bytes / sizeof(float)) - CGP_HEAD - 64 * wpb;
-  return words <= 0 ? 0 : ((words / (JS + 1)) & ~3);
+  const int words = (int)(lds_bytes / sizeof(float)) - CGP_HEAD - CGP_WORLD * wpb;
+  return words <= 0 ? 0 : ((words / JS) & ~3);
 }
 // rows every solved world allocates at least: the Gauss-Jordan tile of the prologue (2 x 4 x NVR words), the fused integrator's lines
 template <int NV4>
@@ -46,39 +51,87 @@ __host__ __device__ inline int cgp_min_rows(int fuse_euler) {
 }
 
 template <int CTRL>
-DEV float qperm(float v) {  // quad_perm DPP read (CTRL = a | b << 2 | c << 4 | d << 6)
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+DEV float qperm(float v) {  // quad_perm DPP read (CTRL = a | b << 2 | c << 4 | d << 6); every lane has a source: no old value to set up
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+// acc += a * (lane C of the reader's 16-lane row of xs): one VALU instruction
+template <int C>
+DEV void fmac_rbc(float& acc, float a, float xs) {
+  asm volatile("v_fmac_f32_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(xs), "v"(a), "n"(C));
+}
+// The hazard recogniser does not see into inline assembly: a DPP read needs two wait states after the VALU write of its source and five
+// after a VALU write of EXEC.  Tying the broadcast pair to the s_nop orders its producers in front of it and every fmac_rbc behind it.
+DEV void dpp_fence(BV& x) { asm volatile("s_nop 4" : "+v"(x.a), "+v"(x.b)); }
+template <int OFF, int N, int... C>
+DEV void fmac_seq(float (&s)[2], const float (&row)[N], float xs, std::integer_sequence<int, C...>) {
+  (fmac_rbc<C>(s[C & 1], row[OFF + C], xs), ...);
+}
+// two rows against the same vector, interleaved: four independent accumulator chains
+template <int N, int... C>
+DEV void fmac_seq2(float (&s)[4], const float (&r0)[N], const float (&r1)[N], float xs, std::integer_sequence<int, C...>) {
+  ((fmac_rbc<C>(s[C & 1], r0[C], xs), fmac_rbc<C>(s[2 + (C & 1)], r1[C], xs)), ...);
 }
 
 template <int NV4>
 DEV void solve_cgp_body(const MjhModel& m, const MjhData& d, float* smem, int slot0, int nwb, int pool_rows, int fuse_euler) {
-  constexpr int G = 32, NR = 2, NVR = 4 * NV4, JS = (NV4 & 1) ? NVR : NVR + 4;
+  constexpr int G = 32, NR = 2, NVR = 4 * NV4, JS = (NV4 & 1) ? NVR : NVR + 4, J4 = JS / 4;
   constexpr int NA = NVR < 16 ? NVR : 16, NBX = NVR - NA;  // columns served by the a / b half of a broadcast pair
   const int nv = m.nv, nC = m.nC, njmax = d.njmax, nvp = d.nv_pad;
   const int lig = threadIdx.x & (G - 1), gib = threadIdx.x / G;
   const int slot = slot0 + gib;
   const bool valid = gib < nwb && slot < d.nworld;
   int* cnt = reinterpret_cast<int*>(smem);
-  int* slotR = reinterpret_cast<int*>(smem) + CGP_HEAD + 64 * gib;  // efc row of every slot of this world
-  float* pool = smem + CGP_HEAD + 64 * (blockDim.x / G);
-  float* fbpool = pool + (size_t)pool_rows * JS;
+  int* slotR = reinterpret_cast<int*>(smem) + CGP_HEAD + CGP_WORLD * gib;  // efc row of every slot of this world
+  float* fbT = smem + CGP_HEAD + CGP_WORLD * gib + 64;                      // basis forces, transposed: fbT[(b & 3) * 16 + (b >> 2)]
+  float* pool = smem + CGP_HEAD + CGP_WORLD * (blockDim.x / G);
+  const bool active = lig < nv;
 
-  // ---- row request of this world, then the workgroup's (sequential, identical in every lane) allocation ---------------------------
+  // ---- every global load of the prologue that only needs the world index, issued together: the row counts and types, the dense address
+  // table of M (model-wide) and this lane's row of M through it, the dof scalars -------------------------------------------------------
   const int w = valid ? d.ws_order[slot] : 0;  // longest expected solve first (k_schedule_worlds)
-  int nefc = 0, ne = 0, nf = 0, np = 0, nq = 0, need = 0;
-  bool defer = false;
+  const size_t vo = (size_t)w * nv, eo = (size_t)w * njmax;
+  int idx[NVR];
+  {
+    const int nv4r = (nv + 3) >> 2;
+    const int4* tab = reinterpret_cast<const int4*>(m.M_dense) + (size_t)(active ? lig : 0) * nv4r;
+#pragma unroll
+    for (int c4 = 0; c4 < NV4; ++c4) {
+      const int4 t4 = c4 < nv4r ? tab[c4] : make_int4(-1, -1, -1, -1);
+      idx[4 * c4] = t4.x; idx[4 * c4 + 1] = t4.y; idx[4 * c4 + 2] = t4.z; idx[4 * c4 + 3] = t4.w;
+    }
+  }
+  int nefc = 0, ne = 0, nf = 0, npf = 0;
+  int ty[2] = {0, 0};
   if (valid) {
     nefc = min(d.nefc[w], njmax);
     ne = d.ne[w];
     nf = d.nf[w];
-    const int npf = min(ne + nf + d.nl[w], nefc);  // rows in front of the contact rows
-    // stable partition of the efc rows: pyramid rows (efc.type, four per condim-3 contact) to the front, the others behind them in order
-    const size_t eo_ = (size_t)w * njmax;
+    npf = ne + nf + d.nl[w];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) ty[k] = lig + G * k < njmax ? d.efc_type[eo + lig + G * k] : 0;
+  }
+  float mrow[NVR];
+  {
+    const float* Mg = d.M + (size_t)w * nC;
+#pragma unroll
+    for (int c = 0; c < NVR; ++c) {
+      const float v = Mg[idx[c] < 0 ? 0 : idx[c]];
+      mrow[c] = active ? (idx[c] < 0 ? 0.0f : v) : (c == lig ? 1.0f : 0.0f);
+    }
+  }
+  const float fs = active ? d.qfrc_smooth[vo + lig] : 0.0f;
+  const float qwarm = active ? d.qacc_warmstart[vo + lig] : 0.0f;
+
+  // ---- stable partition of the efc rows: pyramid rows (four per condim-3 contact) to the front, the others behind them in order --------
+  int np = 0, nq = 0, need = 0;
+  bool defer = false;
+  if (valid) {
+    npf = min(npf, nefc);
     bool is6[2];
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const int r = lig + G * k;
-      is6[k] = r >= npf && r < nefc && d.efc_type[eo_ + r] == CT_CONTACT_PYRAMIDAL;
+      is6[k] = r >= npf && r < nefc && ty[k] == CT_CONTACT_PYRAMIDAL;
     }
     const unsigned m0 = (unsigned)gballot<G>(is6[0]), m1 = (unsigned)gballot<G>(is6[1]);
     const int n60 = __popc(m0), n6 = n60 + __popc(m1);
@@ -88,14 +141,15 @@ DEV void solve_cgp_body(const MjhModel& m, const MjhData& d, float* smem, int sl
       const int r = lig + G * k;
       const int c6 = k == 0 ? __popc(m0 & below) : n60 + __popc(m1 & below);
       if (r < nefc && r < 64) slotR[is6[k] ? c6 : n6 + r - c6] = r;
+      fbT[r] = 0.0f;  // (basis rows past nb carry zero force for good)
     }
     nq = n6 >> 2;
     np = nefc - n6;
     defer = nf > 0 || (n6 & 3) != 0 || nefc > 64;  // friction loss (three-zone rows), a contact cut by njmax: the fallback launch
-    const int nb = np + 3 * nq;
-    need = max((nb + 3) & ~3, cgp_min_rows<NV4>(fuse_euler));
+    need = max((np + 3 * nq + 3) & ~3, cgp_min_rows<NV4>(fuse_euler));
   }
-  if (lig == 0 && gib < 32) cnt[gib] = (valid && !defer) ? need : 0;
+  // ---- the workgroup's (sequential, identical in every lane) pool allocation ---------------------------------------------------------
+  if (lig == 0 && gib < CGP_HEAD) cnt[gib] = (valid && !defer) ? need : 0;
   __syncthreads();
   int base = 0;
   {
@@ -116,41 +170,19 @@ DEV void solve_cgp_body(const MjhModel& m, const MjhData& d, float* smem, int sl
     return;
   }
   float* Jl = pool + (size_t)base * JS;
-  float* fb = fbpool + base;
   const int nb = np + 3 * nq, nb4 = (nb + 3) & ~3;
-  const size_t vo = (size_t)w * nv, eo = (size_t)w * njmax;
-  const bool active = lig < nv;
-  const int ligr = lig < NVR ? lig : NVR - 1;
 
   PhaseClock pc(5, lig);
-  // ---- M row of this lane into registers through the model-wide dense address table (solver.hpp) ------------------------------------
-  float mrow[NVR];
-  {
-    const float* Mg = d.M + (size_t)w * nC;
-    const int nv4r = (nv + 3) >> 2;
-    const int4* tab = reinterpret_cast<const int4*>(m.M_dense) + (size_t)(active ? lig : 0) * nv4r;
-    int idx[NVR];
-#pragma unroll
-    for (int c4 = 0; c4 < NV4; ++c4) {
-      const int4 t4 = c4 < nv4r ? tab[c4] : make_int4(-1, -1, -1, -1);
-      idx[4 * c4] = t4.x; idx[4 * c4 + 1] = t4.y; idx[4 * c4 + 2] = t4.z; idx[4 * c4 + 3] = t4.w;
-    }
-#pragma unroll
-    for (int c = 0; c < NVR; ++c) {
-      const float v = Mg[idx[c] < 0 ? 0 : idx[c]];
-      mrow[c] = active ? (idx[c] < 0 ? 0.0f : v) : (c == lig ? 1.0f : 0.0f);
-    }
-  }
   pc.mark(0);
   const bool warm = !(m.disableflags & DSBL_WARMSTART);
-  const float fs = active ? d.qfrc_smooth[vo + lig] : 0.0f;
   // lane i: sum_c A[i][c] x[c]; x arrives as a broadcast pair (a: x[l % 16], b: x[16 + l % 16]) and every x[c] an FMA needs is the DPP
   // operand row_newbcast:c of one of the two -- no LDS.  (Every lane of the group must execute this: a DPP read from a lane that sits
   // out a branch is zero.)
-  auto mul_row = [&](const float (&row)[NVR], const BV& x) __attribute__((always_inline)) {
+  auto mul_row = [&](const float (&row)[NVR], BV x) __attribute__((always_inline)) {
     float s[2] = {0.0f, 0.0f};
-    fma_rbc<0>(s, row, x.a, std::make_integer_sequence<int, NA>{});
-    if (NBX > 0) fma_rbc<NA>(s, row, x.b, std::make_integer_sequence<int, NBX>{});
+    dpp_fence(x);
+    fmac_seq<0>(s, row, x.a, std::make_integer_sequence<int, NA>{});
+    if (NBX > 0) fmac_seq<NA>(s, row, x.b, std::make_integer_sequence<int, NBX>{});
     return active ? s[0] + s[1] : 0.0f;
   };
   // ---- M^-1 (the CG preconditioner; the world's pool rows lend the tile buffer) and qacc_smooth with one step of refinement ----------
@@ -162,13 +194,9 @@ DEV void solve_cgp_body(const MjhModel& m, const MjhData& d, float* smem, int sl
     qs += mul_row(h, bcast_prep(active ? res : 0.0f));
   }
   if (active) d.qacc_smooth[vo + lig] = qs;
-  float q = active ? (nefc > 0 && warm ? d.qacc_warmstart[vo + lig] : qs) : 0.0f;
+  float q = active ? (nefc > 0 && warm ? qwarm : qs) : 0.0f;
   pc.mark(1);
-  float Ma;
-  {
-    const BV qb = bcast_prep(q);
-    Ma = mul_row(mrow, qb);
-  }
+  float Ma = mul_row(mrow, bcast_prep(q));
   if (nefc == 0) {  // unconstrained: qacc = qacc_smooth (solver.py:3684-3686)
     if (active) {
       d.qacc[vo + lig] = q;
@@ -185,11 +213,34 @@ DEV void solve_cgp_body(const MjhModel& m, const MjhData& d, float* smem, int sl
     return;
   }
 
-  // ---- basis rows into the pool: contact c -> N, T1, T2 from its four pyramid rows; plain rows as they are ---------------------------
+  // ---- this lane's rows: efc row, D, aref (loads first), kind, where their basis row and basis force live ----------------------------
+  float rD[NR], rja[NR], rjv[NR];
+  int rkind[NR];  // 0 equality, 2 limit / contact, 3 padding (no friction-loss rows here)
+  int jro[NR];    // word offset in the world's pool of the basis row this lane reads in the row dots
+  int fbo[NR];    // word of fbT that takes this lane's basis force (64: none -- the spare word)
+  bool isq[NR];
+  int rer[NR];    // efc row of the slot
+  const int qd = lig & 3;
+#pragma unroll
+  for (int k = 0; k < NR; ++k) {
+    const int s = lig + G * k;
+    const bool has = s < nefc;
+    isq[k] = s < 4 * nq;
+    const int er = has ? slotR[s] : 0;
+    rer[k] = er;
+    const int br = isq[k] ? 3 * (s >> 2) + (qd < 3 ? qd : 2) : (has ? s - nq : 0);
+    const int bf_ = isq[k] ? (qd < 3 ? 3 * (s >> 2) + qd : -1) : s - nq;  // basis row that takes this slot's force
+    jro[k] = br * JS;
+    fbo[k] = (!has || bf_ < 0) ? 64 : (bf_ & 3) * 16 + (bf_ >> 2);
+    rD[k] = has ? d.efc_D[eo + er] : 0.0f;
+    rkind[k] = !has ? 3 : (isq[k] ? 2 : (er < ne ? 0 : 2));
+    rjv[k] = 0.0f;
+    rja[k] = has ? d.efc_aref[eo + er] : 0.0f;  // (aref for now: Jaref = J q - aref below)
+  }
+  // ---- basis rows into the pool: contact c -> N, T1, T2 from its four pyramid rows; the other rows as they are -------------------------
   gsync();  // (the tile reads of the inversion are done)
   {
     const float* Jg = d.efc_J + (size_t)w * d.njmax_pad * nvp;
-    constexpr int J4 = JS / 4;
     const int nvp4 = nvp >> 2;  // (nv_pad is a multiple of 4: rows of efc.J are 16-byte aligned)
     for (int it = lig; it < nq * J4; it += G) {
       const int c = it / J4, c4 = it - c * J4;
@@ -209,46 +260,37 @@ DEV void solve_cgp_body(const MjhModel& m, const MjhData& d, float* smem, int sl
       if (p < np && c4 < nvp4) v = (reinterpret_cast<const float4*>(Jg + (size_t)slotR[4 * nq + p] * nvp))[c4];
       (reinterpret_cast<float4*>(Jl + (size_t)(3 * nq + p) * JS))[c4] = v;
     }
-    for (int r = nb + lig; r < nb4; r += G) fb[r] = 0.0f;  // (the rows past nb carry zero force for good)
-  }
-  // ---- this lane's rows: D, kind, where their basis row and basis force live ---------------------------------------------------------
-  float rD[NR], rja[NR], rjv[NR];
-  int rkind[NR];         // 0 equality, 2 limit / contact, 3 padding (no friction-loss rows here)
-  int jro[NR];           // word offset in the world's pool of the basis row this lane reads in the row dots
-  int fbo[NR];           // basis row that takes this lane's basis force (-1: none)
-  bool isq[NR];
-  int rer[NR];           // efc row of the slot
-  const int qd = lig & 3;
-#pragma unroll
-  for (int k = 0; k < NR; ++k) {
-    const int s = lig + G * k;
-    const bool has = s < nefc;
-    isq[k] = s < 4 * nq;
-    const int er = has ? slotR[s] : 0;  // efc row of this slot
-    rer[k] = er;
-    const int br = isq[k] ? 3 * (s >> 2) + (qd < 3 ? qd : 2) : (has ? s - nq : 0);
-    jro[k] = br * JS;
-    fbo[k] = !has ? -1 : (isq[k] ? (qd < 3 ? 3 * (s >> 2) + qd : -1) : s - nq);
-    rD[k] = has ? d.efc_D[eo + er] : 0.0f;
-    rkind[k] = !has ? 3 : (isq[k] ? 2 : (er < ne ? 0 : 2));
-    rjv[k] = 0.0f;
-    rja[k] = has ? d.efc_aref[eo + er] : 0.0f;  // (aref for now: Jaref = J q - aref below)
   }
   gsync();
-  // J[row of slot k, :] . x for both slots: the basis-row dot, then -- inside a contact's quad -- d_N +- d_T1 / d_N +- d_T2
-  auto j_dots = [&](const BV& x, float (&out)[NR]) __attribute__((always_inline)) {
+  // J[row of slot k, :] . x for both slots: the two basis-row dots interleaved (four accumulator chains), then -- inside a contact's quad --
+  // d_N +- d_T1 / d_N +- d_T2
+  auto j_dots = [&](BV x, float (&out)[NR]) __attribute__((always_inline)) {
+    float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    dpp_fence(x);
+    {
+      float r0[NA], r1[NA];
+#pragma unroll
+      for (int c4 = 0; c4 < NA / 4; ++c4) {
+        const float4 a4 = *reinterpret_cast<const float4*>(Jl + jro[0] + 4 * c4), b4 = *reinterpret_cast<const float4*>(Jl + jro[1] + 4 * c4);
+        r0[4 * c4] = a4.x; r0[4 * c4 + 1] = a4.y; r0[4 * c4 + 2] = a4.z; r0[4 * c4 + 3] = a4.w;
+        r1[4 * c4] = b4.x; r1[4 * c4 + 1] = b4.y; r1[4 * c4 + 2] = b4.z; r1[4 * c4 + 3] = b4.w;
+      }
+      fmac_seq2(s, r0, r1, x.a, std::make_integer_sequence<int, NA>{});
+    }
+    if (NBX > 0) {
+      constexpr int NB_ = NBX > 0 ? NBX : 4;
+      float r0[NB_], r1[NB_];
+#pragma unroll
+      for (int c4 = 0; c4 < NBX / 4; ++c4) {
+        const float4 a4 = *reinterpret_cast<const float4*>(Jl + jro[0] + NA + 4 * c4), b4 = *reinterpret_cast<const float4*>(Jl + jro[1] + NA + 4 * c4);
+        r0[4 * c4] = a4.x; r0[4 * c4 + 1] = a4.y; r0[4 * c4 + 2] = a4.z; r0[4 * c4 + 3] = a4.w;
+        r1[4 * c4] = b4.x; r1[4 * c4 + 1] = b4.y; r1[4 * c4 + 2] = b4.z; r1[4 * c4 + 3] = b4.w;
+      }
+      fmac_seq2(s, r0, r1, x.b, std::make_integer_sequence<int, NBX>{});
+    }
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
-      float jr[NVR];
-#pragma unroll
-      for (int c4 = 0; c4 < NV4; ++c4) {
-        const float4 j4 = *reinterpret_cast<const float4*>(Jl + jro[k] + 4 * c4);
-        jr[4 * c4] = j4.x; jr[4 * c4 + 1] = j4.y; jr[4 * c4 + 2] = j4.z; jr[4 * c4 + 3] = j4.w;
-      }
-      float s[2] = {0.0f, 0.0f};
-      fma_rbc<0>(s, jr, x.a, std::make_integer_sequence<int, NA>{});
-      if (NBX > 0) fma_rbc<NA>(s, jr, x.b, std::make_integer_sequence<int, NBX>{});
-      const float dt = s[0] + s[1];
+      const float dt = s[2 * k] + s[2 * k + 1];
       const float dn = qperm<0x00>(dt), d1 = qperm<0x55>(dt), d2 = qperm<0xAA>(dt);
       const float tq = qd < 2 ? d1 : d2;
       out[k] = rkind[k] == 3 ? 0.0f : (isq[k] ? ((qd & 1) ? dn - tq : dn + tq) : dt);
@@ -266,6 +308,10 @@ DEV void solve_cgp_body(const MjhModel& m, const MjhData& d, float* smem, int sl
   const float meaninertia = bf(m.stat_meaninertia, m.stat_meaninertia_nb, w, 1)[0];
   const float scale = meaninertia * (float)nv;
   const float rscale = 1.0f / scale;
+  // J^T f: lane (cq, rg) reads the columns 4 cq .. 4 cq + 3 of the rows rg + 4 i; rows of a 16-row batch past nb4 are redirected to the
+  // world's last (initialised) rows -- their forces are zero
+  const int cq = min(lig >> 2, J4 - 1), rg = lig & 3;
+  const float* Jq = Jl + 4 * cq;
 
   float grad_dot = 0.0f, search_dot = 0.0f;
   float g = 0.0f, Mg = 0.0f, pg = 0.0f, pMg = 0.0f, srch = 0.0f, qc = 0.0f;
@@ -280,24 +326,37 @@ DEV void solve_cgp_body(const MjhModel& m, const MjhData& d, float* smem, int sl
     for (int k = 0; k < NR; ++k) {
       const bool quad = rkind[k] == 0 || (rkind[k] == 2 && rja[k] < 0.0f);
       const float f = quad ? -rD[k] * rja[k] : 0.0f;
-      const float a = qperm<0xB1>(f);              // the pair partner: f1 f0 f3 f2
-      const float sm = f + a, df = f - a;          // f0 + f1 | f2 + f3 ;  f0 - f1, f1 - f0, f2 - f3, f3 - f2
-      const float tot = sm + qperm<0x4E>(sm);      // f0 + f1 + f2 + f3
+      const float a = qperm<0xB1>(f);          // the pair partner: f1 f0 f3 f2
+      const float sm = f + a, df = f - a;      // f0 + f1 | f2 + f3 ;  f0 - f1, f1 - f0, f2 - f3, f3 - f2
+      const float tot = sm + qperm<0x4E>(sm);  // f0 + f1 + f2 + f3
       const float bq = qd == 0 ? tot : (qd == 1 ? -df : df);
-      if (fbo[k] >= 0) fb[fbo[k]] = isq[k] ? bq : f;
+      fbT[fbo[k]] = isq[k] ? bq : f;
     }
     gsync();
-    // ---- qfrc_constraint = J^T force (solver.py:1912-1947) over the basis rows: lane = dof, four rows per step -----------------------
+    // ---- qfrc_constraint = J^T force (solver.py:1912-1947) over the basis rows, one LDS round trip ------------------------------------
     {
-      float s0 = 0.0f, s1 = 0.0f;
-      const float* Jc = Jl + ligr;
-#pragma unroll 2
-      for (int r = 0; r < nb4; r += 4) {
-        const float4 f4 = *reinterpret_cast<const float4*>(fb + r);
-        s0 += Jc[r * JS] * f4.x + Jc[(r + 2) * JS] * f4.z;
-        s1 += Jc[(r + 1) * JS] * f4.y + Jc[(r + 3) * JS] * f4.w;
+      float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+      auto batch = [&](int kb) __attribute__((always_inline)) {
+        const float4 f4 = *reinterpret_cast<const float4*>(fbT + rg * 16 + 4 * kb);
+        const float ff[4] = {f4.x, f4.y, f4.z, f4.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int r = min(16 * kb + 4 * j, nb4 - 4) + rg;
+          const float4 j4 = *reinterpret_cast<const float4*>(Jq + r * JS);
+          a0 += j4.x * ff[j]; a1 += j4.y * ff[j]; a2 += j4.z * ff[j]; a3 += j4.w * ff[j];
+        }
+      };
+      batch(0);  // (two branches instead of one per batch: every divergent `if` is half a dozen scalar instructions on the chain)
+      if (nb4 > 16) {
+        batch(1);
+        batch(2);
       }
-      qc = active ? s0 + s1 : 0.0f;
+      if (nb4 > 48) batch(3);
+      // the four row classes of a column quad are one lane quad: two butterfly adds, then lane l (dof l) takes column l % 4
+      a0 += qperm<0xB1>(a0); a1 += qperm<0xB1>(a1); a2 += qperm<0xB1>(a2); a3 += qperm<0xB1>(a3);
+      a0 += qperm<0x4E>(a0); a1 += qperm<0x4E>(a1); a2 += qperm<0x4E>(a2); a3 += qperm<0x4E>(a3);
+      const float mine = qd == 0 ? a0 : (qd == 1 ? a1 : (qd == 2 ? a2 : a3));
+      qc = active ? mine : 0.0f;
     }
     gsync();  // (the next iteration's force writes follow these reads)
     // ---- gradient, preconditioned gradient, Polak-Ribiere direction (solver.py:3061-3220, 3283-3450) ----------------------------------
@@ -305,7 +364,7 @@ DEV void solve_cgp_body(const MjhModel& m, const MjhData& d, float* smem, int sl
     pc.mark(3);
     Mg = mul_row(h, bcast_prep(g));
     cg5[0] = g * g; cg5[1] = g * (Mg - pMg); cg5[2] = pg * pMg; cg5[3] = Mg * Mg; cg5[4] = Mg * srch;
-    gsumg_n<G, 5>(cg5);
+    gsum32_valu_n<5>(cg5);
     grad_dot = cg5[0];
     pc.mark(4);
     if (niter == 0) {
@@ -342,7 +401,7 @@ DEV void solve_cgp_body(const MjhModel& m, const MjhData& d, float* smem, int sl
     float alpha = 0.0f;
     improvement = 0.0f;
     bool ls_converged = false;
-    line_search_rows<NR, G, false>(rja, rjv, rD, rkind, nullptr, g1, 0.5f * srch * mvi, fabsf(g1), gtol, ls_iterations, alpha, improvement, ls_converged);
+    line_search_rows<NR, G, false, 1>(rja, rjv, rD, rkind, nullptr, g1, 0.5f * srch * mvi, fabsf(g1), gtol, ls_iterations, alpha, improvement, ls_converged);
     if (!ls_converged) ovf |= OVF_LS_ITERATIONS;
     pc.mark(6);
     q += alpha * srch;

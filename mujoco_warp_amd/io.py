@@ -470,6 +470,7 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
   if nexplicit:
     pair_condims |= set(int(c) for c in np.asarray(mjm.pair_dim))
   m.cg_basis = int(pair_condims <= {1, 3})
+  m._ccd_flags_at_put = int(opt.disableflags)
   m.key_qpos = _arr(getattr(mjm, "key_qpos", np.zeros((0, m.nq))), f32)
   m.key_qvel = _arr(getattr(mjm, "key_qvel", np.zeros((0, nv))), f32)
   m.key_ctrl = _arr(getattr(mjm, "key_ctrl", np.zeros((0, nu))), f32)
@@ -508,6 +509,13 @@ def c_model(m: types.Model):
     elif name.endswith("_nb"):
       continue
     elif name in ("integrator", "cone", "solver", "iterations", "ls_iterations", "disableflags", "enableflags", "broadphase", "broadphase_filter", "ccd_iterations"):
+      if name == "disableflags":
+        # the convex narrowphase's buffers (Model.nmeshdegmax / npolygonmax, Data.ws_ccd) were sized from these two bits at put_model /
+        # make_data; the reference re-derives them at every call (collision_convex.py:1226, 1346-1366), this engine cannot: a change needs a new
+        # put_model (kernels that branch on the live flags would run past buffers sized for the old ones)
+        ccd_bits = int(types.DisableBit.NATIVECCD) | int(types.DisableBit.MULTICCD)
+        if (int(m.opt.disableflags) ^ int(m._ccd_flags_at_put)) & ccd_bits:
+          raise ValueError("opt.disableflags: NATIVECCD / MULTICCD changed after put_model -- the convex narrowphase's buffers were sized from them; call put_model again")
       setattr(c, name, int(getattr(m.opt, name)))
     elif name == "opt_sleep_tolerance":
       setattr(c, name, float(m.opt_sleep_tolerance))

@@ -512,7 +512,7 @@ void ref_transmission(const RefModel* m, RefData* d) {
 void ref_fwd_actuation(const RefModel* m, RefData* d) {
   int nv = m->nv;
   for (int i = 0; i < nv; i++) d->qfrc_actuator[i] = 0.0;
-  if (m->disableflags & DSBL_ACTUATION) {
+  if (m->nu == 0 || (m->disableflags & DSBL_ACTUATION)) { /* forward.py:1155-1159: no actuators or actuation disabled -- qfrc_actuator stays zero, joint-level actuator gravity compensation included */
     for (int i = 0; i < m->nu; i++) d->actuator_force[i] = 0.0;
     return;
   }

@@ -5,7 +5,7 @@
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library;
  * the product path (mujoco_warp_amd) never does.
  *
- * PIN STATUS (round 4).  The arithmetic of record is MuJoCo C (mujoco 3.11.1.dev954833728, uv.lock:1053), absent from /root/reference
+ * PIN STATUS (round 4, unchanged in round 5).  The arithmetic of record is MuJoCo C (mujoco 3.11.1.dev954833728, uv.lock:1053), absent from /root/reference
  * and from this environment.  What pins this restatement instead:
  *   - EXTERNALLY: the states MuJoCo C itself went through, recorded in the reference's benchmark input
  *     benchmarks/unitree_g1/shuffle_dance.npz (qpos [251, 36], qvel [251, 35] at 50 Hz next to the controls): from every recorded frame,
@@ -13,8 +13,8 @@
  *     1.0e-5 over all 250 intervals; a free run tracks the recording for 100 frames).  That pins, for the G1 chain, MJCF compilation ->
  *     FK -> CRBA -> RNE -> position actuators -> collision -> constraint rows -> Newton -> implicitfast (tests/test_reference_trajectory.py);
  *   - EXTERNALLY, second anchor (round 4): the reference's own golden for the aloha task (unroll_test.py:40-58: replay lift_pot.npz on
- *     test_data/aloha_pot/scene.xml, the pot ends above z = 0.1 and the lid stays 0.06 above it).  Both cones reproduce it in float64
- *     (pot z 0.108, lid 0.168: tests/test_aloha_pot.py) -- mesh compilation (134 files), joint-level actuator force range + gravity
+ *     test_data/aloha_pot/scene.xml, the pot body ends above z = 0.069 and the lid body above z = 0.16).  Both cones reproduce it in
+ *     float64 (pot z 0.108, lid 0.168: tests/test_aloha_pot.py) -- mesh compilation (134 files), joint-level actuator force range + gravity
  *     compensation routing, the zero-quaternion rule, GJK / EPA / mesh multicontact on real assets, elliptic and pyramidal rows;
  *   - every number the reference's own tests hold for this path (math vectors, key-0 contact / row counts, broadphase counts, the
  *     GJK / EPA / multi-contact values of collision_gjk_test.py: tests/test_reference_vectors.py, test_convex.py, test_reference_gjk_gpu.py);

@@ -30,6 +30,10 @@ def _short(n):
     return "k_solve_big"
   if "k_solve_newton" in n:
     return "k_solve_newton"
+  if "k_solve_cgp" in n:
+    return "k_solve_cgp"
+  if "k_solve_cgw" in n:
+    return "k_solve_cgw"
   if "k_rk4" in n:
     return "k_rk4"
   if "k_mid" in n:
