@@ -75,6 +75,35 @@ __host__ __device__ inline ConLayout con_layout(int nv, int njmax, int ncap, int
   return p;
 }
 
+// sums of N values over the G lanes of a group, the result in every lane (VALU only: DPP row shifts, then the row sums are combined)
+template <int G, int N>
+DEV void csum_n(float (&v)[N]) {
+  static_assert(G == 16 || G == 32 || G == 64, "lane groups of 16, 32 or 64");
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = dpp_add_f<0x111, 0xf, 0xf>(v[i]);  // row_shr:1
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = dpp_add_f<0x112, 0xf, 0xf>(v[i]);  // row_shr:2
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = dpp_add_f<0x114, 0xf, 0xf>(v[i]);  // row_shr:4
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = dpp_add_f<0x118, 0xf, 0xf>(v[i]);  // row_shr:8: lane 15 of every 16-lane row holds the row's sum
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    if (G == 16) {
+      v[i] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[i]), 0x15F, 0xf, 0xf, true));  // row_newbcast:15
+    } else if (G == 32) {
+      const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[i]), __float_as_uint(v[i]), false, false);
+      const float lo = __int_as_float(__builtin_amdgcn_update_dpp(0, (int)sw[0], 0x15F, 0xf, 0xf, true));
+      const float hi = __int_as_float(__builtin_amdgcn_update_dpp(0, (int)sw[1], 0x15F, 0xf, 0xf, true));
+      v[i] = lo + hi;
+    } else {
+      float x = dpp_add_f<0x142, 0xa, 0xf>(v[i]);  // row_bcast:15 into rows 1 and 3
+      x = dpp_add_f<0x143, 0xc, 0xf>(x);           // row_bcast:31 into rows 2 and 3: lane 63 holds the wavefront's sum
+      v[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+    }
+  }
+}
+
 template <int G>
 DEV void make_constraint_body(const MjhModel& m, const MjhData& d, float* smem, const Blk& b, int stride_words = 0) {
   const int lig = threadIdx.x & (G - 1), gib = threadIdx.x / G;
@@ -310,51 +339,79 @@ DEV void make_constraint_body(const MjhModel& m, const MjhData& d, float* smem, 
   }
   gsync();
   pc.mark(3);
+  // Contacts, a window of CON_WINDOW records at a time (round 5; the round-4 loop walked the active contacts one after the other through
+  // five dependent LDS hops each -- list -> record -> geom body -> root body -> subtree com -- and a later pass re-read the finished J rows
+  // from global memory for J qvel: 2.8 k cycles per contact, 36 % + 29 % of this kernel):
+  //   1. the window's raw records are staged with consecutive addresses (one memory round trip);
+  //   2. PREPASS, one lane per active contact: everything the Jacobian needs that is the same for all dofs -- the offsets of the contact
+  //      point from the two root bodies' subtree centres, the dof masks of the two bodies, the frame, the friction coefficients, first
+  //      row / row count -- is written back as a compact record in ACTIVE order (slot a - a0): the dof loop below reads it with six
+  //      16-byte broadcast loads whose addresses depend on nothing but the loop counter;
+  //   3. dof loop, lane = dof: the six Jacobian components, the rows (coalesced 128-byte stores), and the components' products with qvel,
+  //      group-reduced to the basis velocities v_n, v_t1 .. of the contact (kept in the compact record): J qvel of every row is a
+  //      combination of them, nothing is read back;
+  //   4. the window's rows, lane = row: D, aref, pos, margin, vel, type, id.
   const int nw = (nv + 31) / 32;
+  const float impr2 = bf(m.opt_impratio_invsqrt, m.opt_impratio_invsqrt_nb, w, 1)[0];
+  const float* biw = bf(m.body_invweight0, m.body_invweight0_nb, w, 2 * nbody);
   int a = 0;
   for (int wbase = 0; wbase < ncon && a < nactive; wbase += CON_WINDOW) {
     const int wend = min(wbase + CON_WINDOW, ncon);
     if (clist[3 * a] >= wend) continue;  // no active contact in this window
-    // stage the window's records with consecutive addresses: one memory round trip for up to 16 contacts
     for (int idx = lig; idx < (wend - wbase) * CON_STRIDE; idx += G) cwin[idx] = crec[(size_t)wbase * CON_STRIDE + idx];
     gsync();
-    for (; a < nactive; ++a) {
+    // the active contacts of this window: a0 .. a1 - 1 (at most CON_WINDOW <= G of them)
+    const int a0 = a;
+    int a1;
+    bool cut;  // the row budget ended inside this window: the rest of the contacts get no rows
+    {
+      const int la = a0 + lig;
+      const bool inwin = lig < CON_WINDOW && la < nactive && clist[3 * la] < wend;
+      const unsigned long long bw = gballot<G>(inwin), bo = gballot<G>(inwin && clist[3 * la + 1] < njmax);
+      const int nin = __popcll(bw), nok = __popcll(bo);  // (contacts are in order and their first rows increase: both sets are prefixes)
+      a1 = a0 + nok;
+      cut = nok < nin;
+    }
+    if (a1 == a0) {
+      if (cut) a = nactive;
+      gsync();
+      continue;
+    }
+    // dof loop
+    for (a = a0; a < a1; ++a) {
       const int c = clist[3 * a], rbase = clist[3 * a + 1], ndim = clist[3 * a + 2];
-      if (c >= wend) break;
-      if (rbase >= njmax) {
-        a = nactive;
-        break;
-      }
-      const float* cr = cwin + (c - wbase) * CON_STRIDE;
+      float* cr = cwin + (c - wbase) * CON_STRIDE;
       const int* cri = reinterpret_cast<const int*>(cr);
-      const int g1 = cri[25], g2 = cri[26];
-      const int b1 = gbody[g1], b2 = gbody[g2];
+      const int b1 = gbody[cri[25]], b2 = gbody[cri[26]];
       const V3 cpos = ld3(cr + 1);
       const V3 off1 = cpos - ld3(scom + 3 * broot[b1]);
       const V3 off2 = cpos - ld3(scom + 3 * broot[b2]);
       const V3 f0 = ld3(cr + 4), f1 = ld3(cr + 7), f2 = ld3(cr + 10);
       const int condim = cri[24];
-      // pyramid rows 2(q-1), 2(q-1)+1 = normal component +- mu_q * component q (q = 1..condim-1): tangent 1, tangent 2,
-      // spin, roll 1, roll 2.  All indexing below is static (fully unrolled), so nothing lives in scratch or movrel.
       const float mu[6] = {0.0f, cr[14], cr[30], cr[15], cr[16], cr[31]};
+      float vs[3] = {0.0f, 0.0f, 0.0f}, vr[3] = {0.0f, 0.0f, 0.0f};  // this lane's share of the basis velocities (vr: spin / roll, condim > 3 only)
       for (int i0 = 0; i0 < nvp; i0 += G) {
         const int i = i0 + lig;
         V3 jp = V3{0, 0, 0}, jr = V3{0, 0, 0};
+        float qv = 0.0f;
         if (i < nv) {
-          const bool a1 = bmask[b1 * nw + (i >> 5)] & (1u << (i & 31));
-          const bool a2 = bmask[b2 * nw + (i >> 5)] & (1u << (i & 31));
+          const bool a1_ = bmask[b1 * nw + (i >> 5)] & (1u << (i & 31));
+          const bool a2_ = bmask[b2 * nw + (i >> 5)] & (1u << (i & 31));
           const V3 ang = ld3(cdof + 6 * i), lin = ld3(cdof + 6 * i + 3);
-          if (a2) {
+          qv = qvel[i];
+          if (a2_) {
             jp = jp + lin + cross(ang, off2);
             jr = jr + ang;
           }
-          if (a1) {
+          if (a1_) {
             jp = jp - (lin + cross(ang, off1));
             jr = jr - ang;
           }
         }
+        const float comp[6] = {dot(f0, jp), dot(f1, jp), dot(f2, jp), dot(f0, jr), dot(f1, jr), dot(f2, jr)};
+        vs[0] += comp[0] * qv; vs[1] += comp[1] * qv; vs[2] += comp[2] * qv;
+        if (condim > 3) { vr[0] += comp[3] * qv; vr[1] += comp[4] * qv; vr[2] += comp[5] * qv; }
         if (i < nvp) {
-          const float comp[6] = {dot(f0, jp), dot(f1, jp), dot(f2, jp), dot(f0, jr), dot(f1, jr), dot(f2, jr)};
           if (condim == 1) {
             if (rbase < njmax) J[(size_t)rbase * nvp + i] = comp[0];
           } else if (m.cone == CONE_ELLIPTIC) {  // rows = normal, tangent 1, tangent 2, spin, roll 1, roll 2 (constraint.py:3836-3847)
@@ -362,6 +419,7 @@ DEV void make_constraint_body(const MjhModel& m, const MjhData& d, float* smem, 
             for (int q = 0; q < 6; ++q)
               if (q < ndim && rbase + q < njmax) J[(size_t)(rbase + q) * nvp + i] = comp[q];
           } else {
+            // pyramid rows 2(q-1), 2(q-1)+1 = normal component +- mu_q * component q (q = 1..condim-1): tangent 1, tangent 2, spin, roll 1, roll 2
 #pragma unroll
             for (int q = 1; q < 6; ++q) {
               if (q < condim && 2 * (q - 1) + 1 < ndim) {
@@ -373,72 +431,73 @@ DEV void make_constraint_body(const MjhModel& m, const MjhData& d, float* smem, 
           }
         }
       }
+      // basis velocities of this contact: sums over the dofs (every lane of the group takes part; lanes past nv hold zeros)
+      csum_n<G, 3>(vs);
+      if (lig < 3) cr[17 + lig] = lig == 0 ? vs[0] : (lig == 1 ? vs[1] : vs[2]);  // (the record's solref / solimp words: the rows below read those from global memory)
+      if (condim > 3) {
+        csum_n<G, 3>(vr);
+        if (lig < 3) cr[20 + lig] = lig == 0 ? vr[0] : (lig == 1 ? vr[1] : vr[2]);
+      }
     }
     gsync();
-  }
-  // the rows' velocities J qvel are taken row-per-lane from the finished J below (one dot product per row instead of up to
-  // six cross-lane reductions per contact inside the serial contact loop); the rows were written by other lanes of this
-  // wavefront: make them visible first
-  __threadfence_block();
-  gsync();
-  pc.mark(4);
-  // per-row contact parameters (lane per row)
-  {
-    const int nrow = min(nefc, njmax);
-    const float impr2 = bf(m.opt_impratio_invsqrt, m.opt_impratio_invsqrt_nb, w, 1)[0];
-    const float* biw = bf(m.body_invweight0, m.body_invweight0_nb, w, 2 * nbody);
-    for (int r = nrow_noncontact + lig; r < nrow; r += G) {
-      const int c = row2con[r] >> 4, dimid = row2con[r] & 15;
-      const float* cr = crec + c * CON_STRIDE;
-      const int* cri = creci + c * CON_STRIDE;
-      const float includemargin = cr[13];
-      const float pos = cr[0] - includemargin;
-      const int condim = cri[24];
-      const int b1 = gbody[cri[25]], b2 = gbody[cri[26]];
-      float invweight = biw[2 * b1] + biw[2 * b2];
-      const bool elliptic = m.cone == CONE_ELLIPTIC && condim > 1;
-      if (elliptic) {
-        // friction rows of an elliptic contact (constraint.py:4277-4294): regularisation scaled by 1 / impratio and by
-        // (mu_1 / mu_dim)^2, no position term in aref
-        if (dimid > 0) invweight *= impr2 * impr2;
-        if (dimid > 1) {
-          const float frii = cr[CON_FRICTION_WORD(dimid - 1)];
-          invweight *= cr[14] * cr[14] / (frii * frii);
+    pc.mark(4);
+    // the window's rows (lane per row)
+    {
+      const int r_lo = clist[3 * a0 + 1], r_hi = min(clist[3 * (a1 - 1) + 1] + clist[3 * (a1 - 1) + 2], njmax);
+      for (int r = r_lo + lig; r < r_hi; r += G) {
+        const int c = row2con[r] >> 4, dimid = row2con[r] & 15;
+        const float* cr = crec + c * CON_STRIDE;
+        const int* cri = creci + c * CON_STRIDE;
+        const float* pr = cwin + (c - wbase) * CON_STRIDE;
+        const float includemargin = cr[13];
+        const float pos = cr[0] - includemargin;
+        const int condim = cri[24];
+        const int b1 = gbody[cri[25]], b2 = gbody[cri[26]];
+        float invweight = biw[2 * b1] + biw[2 * b2];
+        const bool elliptic = m.cone == CONE_ELLIPTIC && condim > 1;
+        float vel;
+        if (elliptic) {
+          // friction rows of an elliptic contact (constraint.py:4277-4294): regularisation scaled by 1 / impratio and by
+          // (mu_1 / mu_dim)^2, no position term in aref
+          if (dimid > 0) invweight *= impr2 * impr2;
+          if (dimid > 1) {
+            const float frii = cr[CON_FRICTION_WORD(dimid - 1)];
+            invweight *= cr[14] * cr[14] / (frii * frii);
+          }
+          vel = pr[17 + dimid];
+        } else if (condim > 1) {
+          const float fri0 = cr[14];
+          invweight = invweight + fri0 * fri0 * invweight;
+          invweight = invweight * 2.0f * fri0 * fri0 * impr2 * impr2;
+          const int q = 1 + (dimid >> 1);  // the friction component of this pyramid row
+          const float muq = cr[CON_FRICTION_WORD(q - 1)], vt = pr[17 + q];
+          vel = (dimid & 1) ? pr[17] - muq * vt : pr[17] + muq * vt;
+        } else {
+          vel = pr[17];
         }
-      } else if (condim > 1) {
-        const float fri0 = cr[14];
-        invweight = invweight + fri0 * fri0 * invweight;
-        invweight = invweight * 2.0f * fri0 * fri0 * impr2 * impr2;
-      }
-      float v0 = 0.0f, v1 = 0.0f;
-      {
-        const float4* Jr = reinterpret_cast<const float4*>(J + (size_t)r * nvp);  // nvp % 4 == 0, rows are 16-byte aligned
-        for (int c4 = 0; c4 < nvp / 4; ++c4) {
-          const float4 j4 = Jr[c4];
-          const int c = 4 * c4;  // (padding columns of J are zero; qvel has nv entries)
-          v0 += j4.x * qvel[c] + (c + 2 < nv ? j4.z * qvel[c + 2] : 0.0f);
-          v1 += (c + 1 < nv ? j4.y * qvel[c + 1] : 0.0f) + (c + 3 < nv ? j4.w * qvel[c + 3] : 0.0f);
+        // friction rows of an elliptic contact take the pair's solreffriction when it is set (constraint.py:4277-4283; explicit pairs only)
+        const float* ref = cr + 17;
+        if (elliptic && dimid > 0 && m.nexplicit) {
+          const int pid = (cri[27] >> 8) - 1;
+          if (pid >= 0 && (m.pair_solreffriction[2 * pid] != 0.0f || m.pair_solreffriction[2 * pid + 1] != 0.0f)) ref = m.pair_solreffriction + 2 * pid;
         }
+        EfcRowOut eo_ = efc_row(dsbl, timestep, elliptic && dimid > 0 ? 0.0f : pos, pos, invweight, ref, cr + 19, includemargin, vel);
+        d.efc_D[eo + r] = eo_.D;
+        d.efc_aref[eo + r] = eo_.aref;
+        d.efc_pos[eo + r] = eo_.pos;
+        d.efc_margin[eo + r] = includemargin;
+        d.efc_vel[eo + r] = vel;
+        d.efc_frictionloss[eo + r] = 0.0f;
+        d.efc_type[eo + r] = condim == 1 ? CT_CONTACT_FRICTIONLESS : (elliptic ? CT_CONTACT_ELLIPTIC : CT_CONTACT_PYRAMIDAL);
+        d.efc_id[eo + r] = c;  // world-local; k_publish_contacts rewrites it with the public contact id
+        if (m.cone == CONE_ELLIPTIC || m.tree_solve) d.ws_efc_con[eo + r] = row2con[r];  // the solver groups the rows of a contact / of a tree
       }
-      const float vel = v0 + v1;
-      // friction rows of an elliptic contact take the pair's solreffriction when it is set (constraint.py:4277-4283; explicit pairs only)
-      const float* ref = cr + 17;
-      if (elliptic && dimid > 0 && m.nexplicit) {
-        const int pid = (cri[27] >> 8) - 1;
-        if (pid >= 0 && (m.pair_solreffriction[2 * pid] != 0.0f || m.pair_solreffriction[2 * pid + 1] != 0.0f)) ref = m.pair_solreffriction + 2 * pid;
-      }
-      EfcRowOut eo_ = efc_row(dsbl, timestep, elliptic && dimid > 0 ? 0.0f : pos, pos, invweight, ref, cr + 19, includemargin, vel);
-      d.efc_D[eo + r] = eo_.D;
-      d.efc_aref[eo + r] = eo_.aref;
-      d.efc_pos[eo + r] = eo_.pos;
-      d.efc_margin[eo + r] = includemargin;
-      d.efc_vel[eo + r] = vel;
-      d.efc_frictionloss[eo + r] = 0.0f;
-      d.efc_type[eo + r] = condim == 1 ? CT_CONTACT_FRICTIONLESS : (elliptic ? CT_CONTACT_ELLIPTIC : CT_CONTACT_PYRAMIDAL);
-      d.efc_id[eo + r] = c;  // world-local; k_publish_contacts rewrites it with the public contact id
-      if (m.cone == CONE_ELLIPTIC || m.tree_solve) d.ws_efc_con[eo + r] = row2con[r];  // the solver groups the rows of a contact / of a tree
     }
+    gsync();  // (the next window overwrites the compact records)
+    a = a1;
+    if (cut) a = nactive;
   }
+  pc.mark(5);
   if (lig == 0) {
     d.ne[w] = ne;
     d.nf[w] = nf;

@@ -307,15 +307,32 @@ DEV void schedule_body(const MjhData& d, int* sh, int nthreads, int cls = 0) {
   for (int i = t; i < 256; i += nthreads) hist[i] = 0;
   __syncthreads();
   constexpr int KD = 32;
-  const bool one_batch = n <= KD * nthreads;
+  const bool one_batch = n <= KD * nthreads && (n & 3) == 0;
   int key[KD];
   if (one_batch) {
+    // Eight 16-byte loads per thread (thread t: worlds 4 (t + k nthreads) .. + 3), from clamped addresses and tied together below: a load
+    // behind a per-key condition is a branch, and the compiler then waited for every load before it issued the next (32 dependent round
+    // trips: the 13 us this workgroup took, measured as its launch's tail).
+    int4 v4[KD / 4], e4[KD / 4];
 #pragma unroll
-    for (int k = 0; k < KD; ++k) {
-      const int w = t + k * nthreads;
-      const int v = w < n ? d.solver_niter[w] : -1;
-      const int e = cls && w < n ? d.nefc[w] : 0;
-      key[k] = w < n ? bin(v, e) : -1;
+    for (int k = 0; k < KD / 4; ++k) v4[k] = reinterpret_cast<const int4*>(d.solver_niter)[min(t + k * nthreads, n / 4 - 1)];
+    if (cls) {
+#pragma unroll
+      for (int k = 0; k < KD / 4; ++k) e4[k] = reinterpret_cast<const int4*>(d.nefc)[min(t + k * nthreads, n / 4 - 1)];
+    } else {
+#pragma unroll
+      for (int k = 0; k < KD / 4; ++k) e4[k] = make_int4(0, 0, 0, 0);
+    }
+    // (all in flight before the first use)
+    asm volatile("" ::"v"(v4[0].x), "v"(v4[0].y), "v"(v4[0].z), "v"(v4[0].w), "v"(v4[1].x), "v"(v4[1].y), "v"(v4[1].z), "v"(v4[1].w), "v"(v4[2].x), "v"(v4[2].y),
+                 "v"(v4[2].z), "v"(v4[2].w), "v"(v4[3].x), "v"(v4[3].y), "v"(v4[3].z), "v"(v4[3].w), "v"(v4[4].x), "v"(v4[5].x), "v"(v4[6].x), "v"(v4[7].x));
+#pragma unroll
+    for (int k = 0; k < KD / 4; ++k) {
+      const bool ok = t + k * nthreads < n / 4;
+      key[4 * k] = ok ? bin(v4[k].x, e4[k].x) : -1;
+      key[4 * k + 1] = ok ? bin(v4[k].y, e4[k].y) : -1;
+      key[4 * k + 2] = ok ? bin(v4[k].z, e4[k].z) : -1;
+      key[4 * k + 3] = ok ? bin(v4[k].w, e4[k].w) : -1;
     }
 #pragma unroll
     for (int k = 0; k < KD; ++k)
@@ -354,7 +371,7 @@ DEV void schedule_body(const MjhData& d, int* sh, int nthreads, int cls = 0) {
   if (one_batch) {
 #pragma unroll
     for (int k = 0; k < KD; ++k)
-      if (key[k] >= 0) d.ws_order[atomicAdd(&base[key[k]], 1)] = t + k * nthreads;
+      if (key[k] >= 0) d.ws_order[atomicAdd(&base[key[k]], 1)] = 4 * (t + (k >> 2) * nthreads) + (k & 3);
     return;
   }
   for (int w0 = t; w0 < n; w0 += 8 * nthreads) {

@@ -269,16 +269,19 @@ static int launch_integrate(const MjhModel* m, const MjhData* d, int mode, hipSt
 //   k_fwd_pos_plus  : k_fwd_pos + one workgroup computing the solver schedule from the previous step's solver_niter
 //   k_integrate_plus: integrator workgroups, then publish_contacts workgroups
 template <int G, bool HEAVY, bool HFT = true>
-__global__ void __launch_bounds__(256) k_mid(MjhModel m, MjhData d, int ncc, int nvb, int nw_cc, int nw_v, int stride_cc, int sched) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((!HEAVY && G >= 32) ? 4 : 1, 8))) k_mid(MjhModel m, MjhData d, int ncc, int nvb, int nw_cc, int nw_v, int stride_cc, int sched) {  // (the light instantiation: four wavefronts per SIMD = 128 registers, its occupancy since round 3)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   (void)nvb;
   // sched: workgroup 0 sorts the solver schedule here instead of in the k_fwd_pos launch (models whose fwd_pos
   // workgroups are too small to do it quickly)
-  if (sched && blockIdx.x == 0) {
+  // (LAST in the dispatch order, round 5: every launch of the step fills the device's workgroup slots exactly -- LDS-bound, four per CU --, so
+  // one more workgroup in front pushes a real one into a second round: + 7 us here, + 8 us in k_fwd_pos_plus, measured.  Behind the
+  // velocity-stage workgroups it takes the first slot one of them frees and ends inside the spread of their finish times.)
+  if (sched && blockIdx.x == gridDim.x - 1) {
     schedule_body(d, reinterpret_cast<int*>(smem), blockDim.x, sched_cls(m, d));
     return;
   }
-  const int bi = (int)blockIdx.x - sched;
+  const int bi = (int)blockIdx.x;
   const int cc_before = bi < ncc ? (int)bi : ncc;               // longest jobs first: all CC workgroups, then fwd_vel
   const bool is_cc = bi < ncc;
   if (is_cc) {
@@ -562,7 +565,10 @@ static int launch_pos_plus_g(const MjhModel* m, const MjhData* d, int first, int
   size_t lds;
   const int threads = pick_block(sizeof(int) * pos_shared_words(m->nv, m->nC, m->nbody, m->njnt, m->nbodylevel, m->ngeom, m->nsite), sizeof(float) * lay.total, G, &lds);
   if (!threads) return fail(MJH_E_UNSUPPORTED, "k_fwd_pos: model does not fit in LDS");
-  // developer knob MJH_SCHED_IN_MID: the schedule workgroup rides in the (longer) k_mid launch instead
+  // The schedule workgroup is this launch's first workgroup.  Round 5: its sort was a chain of 32 dependent memory round trips (13 us: the tail of
+  // whichever launch carried it -- fused k_fwd_pos 48 us against 39 us without it); with its loads in one batch (integrate.hpp schedule_body) it
+  // costs this launch 2 us.  Same box, steady state / first steps, ms per step: here 0.2914 / 0.2698, as k_mid's last workgroup 0.2902 / 0.2745
+  // (MJH_SCHED_IN_MID=1, developer knob).
   static const bool sched_mid = getenv("MJH_SCHED_IN_MID") != nullptr;
   *sched_done = threads >= 128 && !sched_mid;
   if (threads < 128) {
