@@ -93,6 +93,76 @@ DEV void fmac_seq2(float (&s)[4], const float (&r0)[N], const float (&r1)[N], fl
   if constexpr (NT >= 16) { fmac4_rbc<12>(s[0], s[1], r0[12], r0[13], r0[14], r0[15], xs); fmac4_rbc<12>(s[2], s[3], r1[12], r1[13], r1[14], r1[15], xs); }
 }
 
+// invert_rows_b4 (solver.hpp) with the 4 x 4 pivot block inverted through its L D L^T factors: the block is symmetric positive definite (a
+// Schur complement of M), and every lane inverts it redundantly -- the unrolled Gauss-Jordan of solver.hpp is 150 of the 280 VALU instructions
+// of a block step, this is 70.  P^-1 = L^-T D^-1 L^-1 from the lower triangle of P.
+template <int NVR, int G>
+DEV void invert_rows_b4s(const float (&mrow)[NVR], float (&s)[NVR], float* buf, int lig) {
+#pragma unroll
+  for (int c = 0; c < NVR; ++c) s[c] = mrow[c];
+#pragma unroll
+  for (int kb = 0; kb < NVR / 4; ++kb) {
+    constexpr int T = 4 * NVR;
+    const int k = 4 * kb;
+    float* pb = buf + (kb & 1) * T;
+    const int q = lig - k;  // 0..3 for the lanes of the pivot block
+    if (q >= 0 && q < 4) {
+#pragma unroll
+      for (int c4 = 0; c4 < NVR / 4; ++c4) *reinterpret_cast<float4*>(pb + q * NVR + 4 * c4) = make_float4(s[4 * c4], s[4 * c4 + 1], s[4 * c4 + 2], s[4 * c4 + 3]);
+    }
+    gsync();
+    const float4 P0 = *reinterpret_cast<const float4*>(pb + k), P1 = *reinterpret_cast<const float4*>(pb + NVR + k),
+                 P2 = *reinterpret_cast<const float4*>(pb + 2 * NVR + k), P3 = *reinterpret_cast<const float4*>(pb + 3 * NVR + k);
+    // L D L^T of the lower triangle
+    const float i0 = 1.0f / P0.x;
+    const float l10 = P1.x * i0, l20 = P2.x * i0, l30 = P3.x * i0;
+    const float i1 = 1.0f / (P1.y - l10 * P1.x);
+    const float t21 = P2.y - l20 * P1.x, t31 = P3.y - l30 * P1.x;
+    const float l21 = t21 * i1, l31 = t31 * i1;
+    const float i2 = 1.0f / (P2.z - l20 * P2.x - l21 * t21);
+    const float t32 = P3.z - l30 * P2.x - l31 * t21;
+    const float l32 = t32 * i2;
+    const float i3 = 1.0f / (P3.w - l30 * P3.x - l31 * t31 - l32 * t32);
+    // N = L^-1 (unit lower triangular)
+    const float n10 = -l10, n21 = -l21, n32 = -l32;
+    const float n20 = -l20 - l21 * n10, n31 = -l31 - l32 * n21;
+    const float n30 = -l30 - l31 * n10 - l32 * n20;
+    // P^-1 = N^T D^-1 N (symmetric)
+    const float e30 = i3 * n30, e31 = i3 * n31, e32 = i3 * n32, e20 = i2 * n20, e21 = i2 * n21, e10 = i1 * n10;
+    float Pi[4][4];
+    Pi[3][3] = i3;
+    Pi[2][3] = Pi[3][2] = e32;
+    Pi[1][3] = Pi[3][1] = e31;
+    Pi[0][3] = Pi[3][0] = e30;
+    Pi[2][2] = i2 + n32 * e32;
+    Pi[1][2] = Pi[2][1] = e21 + n31 * e32;
+    Pi[0][2] = Pi[2][0] = e20 + n30 * e32;
+    Pi[1][1] = i1 + n21 * e21 + n31 * e31;
+    Pi[0][1] = Pi[1][0] = e10 + n20 * e21 + n30 * e31;
+    Pi[0][0] = i0 + n10 * e10 + n20 * e20 + n30 * e30;
+    const bool inb = q >= 0 && q < 4;
+    float F[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const float out = s[k] * Pi[0][p] + s[k + 1] * Pi[1][p] + s[k + 2] * Pi[2][p] + s[k + 3] * Pi[3][p];
+      const float own = (q == p ? 1.0f : 0.0f) - (q == 0 ? Pi[0][p] : (q == 1 ? Pi[1][p] : (q == 2 ? Pi[2][p] : Pi[3][p])));
+      F[p] = inb ? own : out;
+    }
+#pragma unroll
+    for (int c4 = 0; c4 < NVR / 4; ++c4) {
+      if (c4 == kb) continue;
+      const float4 r0 = *reinterpret_cast<const float4*>(pb + 4 * c4), r1 = *reinterpret_cast<const float4*>(pb + NVR + 4 * c4),
+                   r2 = *reinterpret_cast<const float4*>(pb + 2 * NVR + 4 * c4), r3 = *reinterpret_cast<const float4*>(pb + 3 * NVR + 4 * c4);
+      s[4 * c4] -= F[0] * r0.x + F[1] * r1.x + F[2] * r2.x + F[3] * r3.x;
+      s[4 * c4 + 1] -= F[0] * r0.y + F[1] * r1.y + F[2] * r2.y + F[3] * r3.y;
+      s[4 * c4 + 2] -= F[0] * r0.z + F[1] * r1.z + F[2] * r2.z + F[3] * r3.z;
+      s[4 * c4 + 3] -= F[0] * r0.w + F[1] * r1.w + F[2] * r2.w + F[3] * r3.w;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s[k + e] = (q == e ? 1.0f : 0.0f) - F[e];
+  }
+}
+
 template <int NV4>
 DEV void solve_cgp_body(const MjhModel& m, const MjhData& d, float* smem, int slot0, int nwb, int pool_rows, int fuse_euler) {
   constexpr int G = 32, NR = 2, NVR = 4 * NV4, JS = (NV4 & 1) ? NVR : NVR + 4, J4 = JS / 4;
@@ -208,7 +278,7 @@ DEV void solve_cgp_body(const MjhModel& m, const MjhData& d, float* smem, int sl
   };
   // ---- M^-1 (the CG preconditioner; the world's pool rows lend the tile buffer) and qacc_smooth with one step of refinement ----------
   float h[NVR];
-  invert_rows_b4<NVR, G>(mrow, h, Jl, lig);
+  invert_rows_b4s<NVR, G>(mrow, h, Jl, lig);
   float qs = mul_row(h, bcast_prep(fs));
   {
     const float res = fs - mul_row(mrow, bcast_prep(qs));

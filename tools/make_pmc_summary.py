@@ -18,7 +18,7 @@ WIDE_SHARE = {"k_fwd_pos": 0.0, "k_mid": 0.0, "k_integrate": 0.0, "k_fwd_vel": 0
 for k, c in s.get("pmc_per_dispatch", {}).items():
   if "fetch_bytes_raw" in c:
     raw = c["fetch_bytes_raw"]
-    share = WIDE_SHARE.get(k, 0.75 if k.startswith("k_solve") else None)  # solver: J is ~3/4 of what it reads
+    share = WIDE_SHARE.get(k, 0.75 if k.startswith("k_solve") else None)  # (k_solve_cgp too: J rows by float4)  # solver: J is ~3/4 of what it reads
     est = raw * (1.0 + share) if share is not None else None
     out["kernels"][k] = {"fetch_bytes_raw": raw, "fetch_bytes_x2": 2 * raw, "fetch_bytes_calibrated": est, "wide_load_share_assumed": share,
                          "write_bytes_per_launch": c.get("write_bytes"),
@@ -42,7 +42,7 @@ for k, c in s.get("pmc_per_dispatch", {}).items():
         if k["wait_any"] is not None:
           k["wait_frac"] = k["wait_any"] / k["wave_cycles"]
       k["duration_cycles"] = dur
-dom = [k for k in out["kernels"] if k.startswith("k_solve<") or k == "k_solve_newton"]
+dom = [k for k in out["kernels"] if k.startswith("k_solve<") or k in ("k_solve_newton", "k_solve_cgp", "k_solve_cgw")]
 dom.sort(key=lambda k: -(out["kernels"][k].get("busy_cycles_sum") or 0.0))
 if dom:
   out["k_solve_hbm_bytes_per_launch"] = out["kernels"][dom[0]]["hbm_bytes_per_launch"]
