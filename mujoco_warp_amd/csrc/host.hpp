@@ -65,7 +65,8 @@ int launch_solve_32_newton_ell_r1(const MjhModel* m, const MjhData* d, bool with
 // CG with one world per wavefront (solver_cgw.hpp): nv <= 32, worlds of at most 64 rows, pyramidal cones
 int launch_solve_cgw(const MjhModel* m, const MjhData* d, bool with_factor, int fuse_euler, hipStream_t s, int lo, int hi);
 // CG with contact-basis rows in one row pool per workgroup (solver_cgp.hpp): nv <= 32, njmax <= 64, MjhModel.cg_basis; worlds it cannot take
-// are flagged solver_niter = -1 for the fallback launch (launch_solve_32_cg with lo = -2)
+// are flagged solver_niter = -1 for the fallback launch (launch_solve_32_cg_deferred, solve_cg32.hip)
+int launch_solve_32_cg_deferred(const MjhModel* m, const MjhData* d, int fuse_euler, hipStream_t s);
 int launch_solve_cgp(const MjhModel* m, const MjhData* d, bool with_factor, int fuse_euler, hipStream_t s);
 int launch_solve_32_newton(const MjhModel* m, const MjhData* d, int nr, bool with_factor, int fuse_euler, hipStream_t s, int lo, int hi);
 int launch_solve_64_cg(const MjhModel* m, const MjhData* d, int nr, bool with_factor, int fuse_euler, hipStream_t s, int lo, int hi);

@@ -388,9 +388,15 @@ DEV void schedule_body(const MjhData& d, int* sh, int nthreads, int cls = 0) {
       if (w0 + k * nthreads < n) d.ws_order[pos[k]] = w0 + k * nthreads;
   }
 }
-// the row-count classes only matter where the solver launches a one-row-per-lane instantiation for the worlds of at most 32 rows
-// (mjhip.hip launch_solve_any: Newton with elliptic cones at nv <= 32 and njmax > 32)
-DEV int sched_cls(const MjhModel& m, const MjhData& d) { return (m.solver == SOL_NEWTON && m.cone == CONE_ELLIPTIC && m.nv <= 32 && d.njmax > 32) ? 32 : 0; }
+// The row-count classes matter (i) where the solver launches a one-row-per-lane instantiation for the worlds of at most 32 rows (mjhip.hip
+// launch_solve_any: Newton with elliptic cones at nv <= 32 and njmax > 32) and (ii) for the 64-lane kernels of models with more than 32 dofs,
+// one world per wavefront: there a solve's length follows the row count (the Hessian build) more than the iteration count, and "worlds of more
+// than 64 rows first" is the longest-first order (G1, 4096 worlds: 8.2 M env-steps/s with the classes, 6.9 M without -- measured in round 5
+// when the classes were dropped for every model).
+DEV int sched_cls(const MjhModel& m, const MjhData& d) {
+  if (m.nv > 32) return 64;
+  return (m.solver == SOL_NEWTON && m.cone == CONE_ELLIPTIC && d.njmax > 32) ? 32 : 0;
+}
 __global__ void __launch_bounds__(1024) k_schedule_worlds(MjhData d, int cls) {
   __shared__ int sh[512];
   schedule_body(d, sh, blockDim.x, cls);

@@ -503,7 +503,7 @@ static int launch_solve_any(const MjhModel* m, const MjhData* d, bool with_facto
     if (cgp) {
       if (int rc = launch_solve_cgp(m, d, with_factor, fe, s)) return rc;
       static const bool no_fallback = getenv("MJH_CGP_NO_FALLBACK") != nullptr;  // developer knob (timing only: flagged worlds stay unsolved)
-      return no_fallback ? MJH_OK : launch_solve_32_cg(m, d, 2, false, fe, s, -2, all);
+      return no_fallback ? MJH_OK : launch_solve_32_cg_deferred(m, d, fe, s);
     }
     auto rest = [&, wide = wide_f]() -> int {
       if (d->njmax <= 64) return wide ? launch_solve_cgw(m, d, with_factor, fe, s, -1, all) : s32(m, d, 2, with_factor, fe, s, lo2, all);
@@ -814,7 +814,7 @@ static int run_stage(const MjhModel* m, const MjhData* d, int stage, hipStream_t
       static const bool plain = getenv("MJH_PLAIN") != nullptr;  // developer knob: one plain kernel per stage, serial
       if ((g_instr && g_instr->on && g_instr->plain) || plain) {
         // profiling pass: one plain kernel per stage, so that the event pairs time one kernel at a time
-        { Scope sc(K_OTHER); hipLaunchKernelGGL(k_schedule_worlds, dim3(1), dim3(1024), 0, s, *d, (m->solver == SOL_NEWTON && m->cone == CONE_ELLIPTIC && m->nv <= 32 && d->njmax > 32) ? 32 : 0); }
+        { Scope sc(K_OTHER); hipLaunchKernelGGL(k_schedule_worlds, dim3(1), dim3(1024), 0, s, *d, m->nv > 32 ? 64 : ((m->solver == SOL_NEWTON && m->cone == CONE_ELLIPTIC && d->njmax > 32) ? 32 : 0)); /* = sched_cls, integrate.hpp */ }
         { Scope sc(K_POS); TRY(launch_pos(m, d, POS_KINEMATICS, POS_CRB, s)); }
         { Scope sc(K_COLLISION); TRY(launch_collision(m, d, s)); }
         { Scope sc(K_CONSTRAINT); TRY(launch_constraint(m, d, s)); }

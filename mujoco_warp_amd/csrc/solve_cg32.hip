@@ -9,6 +9,21 @@ int launch_solve_32_cg(const MjhModel* m, const MjhData* d, int nr, bool with_fa
   }
 }
 
+// the worlds the pooled CG kernel flagged (solver_cgp.hpp): k_solve<cg>'s body, two rows per lane
+int launch_solve_32_cg_deferred(const MjhModel* m, const MjhData* d, int fuse_euler, hipStream_t s) {
+  switch ((m->nv + 3) / 4) {
+    case 0:
+    case 1: return launch_solve_deferred_t<1, 2, false, 32>(m, d, fuse_euler, s);
+    case 2: return launch_solve_deferred_t<2, 2, false, 32>(m, d, fuse_euler, s);
+    case 3: return launch_solve_deferred_t<3, 2, false, 32>(m, d, fuse_euler, s);
+    case 4: return launch_solve_deferred_t<4, 2, false, 32>(m, d, fuse_euler, s);
+    case 5: return launch_solve_deferred_t<5, 2, false, 32>(m, d, fuse_euler, s);
+    case 6: return launch_solve_deferred_t<6, 2, false, 32>(m, d, fuse_euler, s);
+    case 7: return launch_solve_deferred_t<7, 2, false, 32>(m, d, fuse_euler, s);
+    default: return launch_solve_deferred_t<8, 2, false, 32>(m, d, fuse_euler, s);
+  }
+}
+
 #ifdef MJH_PHASE_CLOCK
 // profiling variant (tools/build_variant_fast.py clk32 solve_cg32.hip -DMJH_PHASE_CLOCK; tools/phase_clock.py --lib ...): this unit's copy of
 // the per-phase tick sums of solve_body

@@ -18,21 +18,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((!NEWT
   // remaining (short) solves
   const int bx = (int)blockIdx.x, nrider = NEWTON ? 0 : 2 * nfac;
   const int sb = bx < rider_at ? bx : bx - nrider;  // solver workgroup index when this is one
-  if (nefc_lo == -2) {
-    // The fallback launch behind the pooled CG kernel (solver_cgp.hpp): every lane group scans 32 worlds' flags with one load and solves the
-    // worlds flagged solver_niter = -1 one after the other -- in the common case none, and the launch is 128 workgroups that load and leave.
-    const int lig = threadIdx.x & (SG - 1), gid = bx * wpb + (int)threadIdx.x / SG;
-    for (int c0 = gid * SG; c0 < d.nworld; c0 += (int)gridDim.x * wpb * SG) {
-      unsigned long long todo = gballot<SG>(c0 + lig < d.nworld && d.solver_niter[c0 + lig] == -1);
-      while (todo) {
-        const int bq = __ffsll((long long)todo) - 1;
-        todo &= todo - 1ull;
-        solve_body<NV4, NR, NEWTON, SG, ELL>(m, d, smem, Blk{0, wpb, (int)blockDim.x}, -1, nefc_hi, fuse_euler, 0, 0x7fffffff, c0 + bq);
-        gsync();
-      }
-    }
-    return;
-  }
   if (bx < rider_at || bx >= rider_at + nrider) solve_body<NV4, NR, NEWTON, SG, ELL>(m, d, smem, Blk{sb * wpb, wpb, (int)blockDim.x}, nefc_lo, nefc_hi, fuse_euler);
   // CG only: the Newton kernel holds 256 VGPRs (one wave per SIMD), which would throttle the riders too (measured
   // +120 us); for Newton they ride along with the integrator launch instead
@@ -60,9 +45,7 @@ static int launch_solve_t(const MjhModel* m, const MjhData* d, bool with_factor,
   with_factor = with_factor && !NEWTON;
   if (with_factor) lds = std::max(lds, ms_bytes + sizeof(float) * fl.total * wf);
   HIPCHK(set_lds((k_solve_plus<NV4, NR, NEWTON, SG, ELL>), lds));
-  int nsolve = (d->nworld + wpb - 1) / wpb;
-  const int nfac = with_factor ? (d->nworld + wf - 1) / wf : 0;
-  if (nefc_lo == -2) nsolve = std::max(1, (d->nworld + wpb * SG - 1) / (wpb * SG));  // (fallback launch: one lane group per 32 (64) worlds)
+  const int nsolve = (d->nworld + wpb - 1) / wpb, nfac = with_factor ? (d->nworld + wf - 1) / wf : 0;
   // riders (fused step, CG): factor workgroups, then as many contact-publication workgroups
   debug_occupancy(NEWTON ? "k_solve_plus<newton>" : "k_solve_plus<cg>", k_solve_plus<NV4, NR, NEWTON, SG, ELL>, nsolve + 2 * nfac, threads, lds);
   // where the riders sit in the dispatch order, in per cent of the solver workgroups (developer knob; 100 = after all of them, the round-1 layout).
@@ -71,6 +54,36 @@ static int launch_solve_t(const MjhModel* m, const MjhData* d, bool with_factor,
   static const int rider_pct = getenv("MJH_RIDER_AT") ? atoi(getenv("MJH_RIDER_AT")) : 100;
   const int rider_at = std::min(nsolve, (int)((long long)nsolve * std::max(rider_pct, 0) / 100));
   hipLaunchKernelGGL((k_solve_plus<NV4, NR, NEWTON, SG, ELL>), dim3(nsolve + 2 * nfac), dim3(threads), lds, s, *m, *d, nsolve, nfac, nefc_lo, nefc_hi, fuse_euler, rider_at);
+  return MJH_OK;
+}
+// The fallback launch behind the pooled CG kernel (solver_cgp.hpp): every lane group scans SG worlds' flags with one load and solves the worlds
+// flagged solver_niter = -1 one after the other -- in the common case none, and the launch is a few workgroups that load and leave.  A kernel of
+// its own (instantiated in solve_cg32.hip only): as a mode of k_solve_plus the second inlined copy of solve_body cost EVERY instantiation registers
+// (the 64-lane Newton kernel went from 207 to 280 and from two wavefronts per SIMD to one: G1 8.2 -> 6.9 M env-steps/s, measured in round 5).
+template <int NV4, int NR, bool NEWTON, int SG, bool ELL = false>
+__global__ void __launch_bounds__(256) k_solve_deferred(MjhModel m, MjhData d, int fuse_euler) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int wpb = blockDim.x / SG;
+  const int lig = threadIdx.x & (SG - 1), gid = (int)blockIdx.x * wpb + (int)threadIdx.x / SG;
+  for (int c0 = gid * SG; c0 < d.nworld; c0 += (int)gridDim.x * wpb * SG) {
+    unsigned long long todo = gballot<SG>(c0 + lig < d.nworld && d.solver_niter[c0 + lig] == -1);
+    while (todo) {
+      const int bq = __ffsll((long long)todo) - 1;
+      todo &= todo - 1ull;
+      solve_body<NV4, NR, NEWTON, SG, ELL>(m, d, smem, Blk{0, wpb, (int)blockDim.x}, -1, 0x7fffffff, fuse_euler, 0, 0x7fffffff, c0 + bq);
+      gsync();
+    }
+  }
+}
+template <int NV4, int NR, bool NEWTON, int SG, bool ELL = false>
+static int launch_solve_deferred_t(const MjhModel* m, const MjhData* d, int fuse_euler, hipStream_t s) {
+  const SolveLayout lay = solve_layout<NV4, NR, SG, NEWTON, ELL>(d->njmax);
+  size_t lds;
+  const int threads = pick_block(0, sizeof(float) * lay.total, SG, &lds, true);
+  if (!threads) return fail(MJH_E_UNSUPPORTED, "k_solve_deferred: njmax x nv does not fit in LDS");
+  HIPCHK(set_lds((k_solve_deferred<NV4, NR, NEWTON, SG, ELL>), lds));
+  const int wpb = threads / SG;
+  hipLaunchKernelGGL((k_solve_deferred<NV4, NR, NEWTON, SG, ELL>), dim3(std::max(1, (d->nworld + wpb * SG - 1) / (wpb * SG))), dim3(threads), lds, s, *m, *d, fuse_euler);
   return MJH_OK;
 }
 template <int NR, bool NEWTON, bool ELL = false>
