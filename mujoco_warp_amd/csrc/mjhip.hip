@@ -8,6 +8,16 @@
 // Nothing here allocates or synchronises (hipGraph-capturable); workspace lives in MjhData.
 #include "host.hpp"
 
+#include "contact_rec.hpp"
+// developer knobs of the k_mid occupancy experiment (round 5, LAB_NOTES.md R5): contacts per staging window, wavefronts per SIMD of the light k_mid
+#ifdef MJH_CON_WINDOW
+#undef CON_WINDOW
+#define CON_WINDOW MJH_CON_WINDOW
+#endif
+#ifndef MJH_MID_WAVES
+#define MJH_MID_WAVES 4
+#endif
+
 #include "collide.hpp"
 #include "constraint.hpp"
 #include "dev_common.hpp"
@@ -269,7 +279,7 @@ static int launch_integrate(const MjhModel* m, const MjhData* d, int mode, hipSt
 //   k_fwd_pos_plus  : k_fwd_pos + one workgroup computing the solver schedule from the previous step's solver_niter
 //   k_integrate_plus: integrator workgroups, then publish_contacts workgroups
 template <int G, bool HEAVY, bool HFT = true>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((!HEAVY && G >= 32) ? 4 : 1, 8))) k_mid(MjhModel m, MjhData d, int ncc, int nvb, int nw_cc, int nw_v, int stride_cc, int sched) {  // (the light instantiation: four wavefronts per SIMD = 128 registers, its occupancy since round 3)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((!HEAVY && G >= 32) ? MJH_MID_WAVES : 1, 8))) k_mid(MjhModel m, MjhData d, int ncc, int nvb, int nw_cc, int nw_v, int stride_cc, int sched) {  // (the light instantiation: four wavefronts per SIMD = 128 registers, its occupancy since round 3)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   (void)nvb;
   // sched: workgroup 0 sorts the solver schedule here instead of in the k_fwd_pos launch (models whose fwd_pos

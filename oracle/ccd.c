@@ -639,6 +639,12 @@ static int ccd_epa(double tolerance, int iterations, Polytope* pt, const CcdGeom
   return idx;
 }
 
+/* Branch trace of ccd_run (round 5: which gate of gjk_phase, collision_gjk.py:2376-2414, a pair leaves through; read by tools / tests through
+ * ref_ccd_trace in mjref.c): 1 shrunk cores separated (inflate, 2396-2400) | 2 GJK distance above the tolerance (2412) | 3 simplex of fewer than
+ * two points (2412) | 4 GJK's own `separated` flag (2412) | 5 polytope seed degenerate: GJK's answer stands | 6 EPA failed | 7 EPA depth. */
+static int g_ccd_branch, g_ccd_gjk_dim, g_ccd_gjk_sep;
+static double g_ccd_gjk_dist;
+
 static int ccd_discrete(int t1, int t2) { return (t1 == G_BOX || t1 == G_MESH || t1 == G_HFIELD) && (t2 == G_BOX || t2 == G_MESH || t2 == G_HFIELD); } /* 109 */
 
 /* ccd = gjk_phase + epa_phase (collision_gjk.py:2350-2575).  Returns the number of contacts (0 / 1); *face_out = closest EPA
@@ -657,6 +663,7 @@ static int ccd_run(double tolerance, double cutoff, int gjk_iterations, int epa_
     cutoff += full1 + full2;
     ccd_gjk(tolerance, gjk_iterations, &g1, &g2, g1.pos, g2.pos, cutoff, is_discrete, &res);
     if (res.dist > tolerance) {
+      g_ccd_branch = 1; g_ccd_gjk_dist = res.dist; g_ccd_gjk_dim = res.dim; g_ccd_gjk_sep = res.separated;
       *dist_out = res.dist;
       v3cpy(x1, res.x1);
       v3cpy(x2, res.x2);
@@ -678,6 +685,8 @@ static int ccd_run(double tolerance, double cutoff, int gjk_iterations, int epa_
   *dist_out = res.dist;
   v3cpy(x1, res.x1);
   v3cpy(x2, res.x2);
+  g_ccd_gjk_dist = res.dist; g_ccd_gjk_dim = res.dim; g_ccd_gjk_sep = res.separated;
+  g_ccd_branch = res.dist > tolerance ? 2 : (res.dim < 2 ? 3 : (res.separated ? 4 : 7));
   if (res.dist > tolerance || res.dim < 2 || res.separated) return 1;
   /* ---- EPA ---- */
   if (epa_iterations > CCD_MAX_ITER) epa_iterations = CCD_MAX_ITER;
@@ -690,10 +699,10 @@ static int ccd_run(double tolerance, double cutoff, int gjk_iterations, int epa_
     pt->status = 0;
     pt_seed3(pt, &res, &g1, &g2);
   }
-  if (pt->status) return 1; /* origin on the boundary: GJK's answer stands */
+  if (pt->status) { g_ccd_branch = 5; return 1; } /* origin on the boundary: GJK's answer stands */
   double dist;
   int idx = ccd_epa(tolerance, epa_iterations, pt, &g1, &g2, is_discrete, overflow, &dist, x1, x2);
-  if (idx == -1) { *dist_out = CCD_FLOAT_MAX; return 0; }
+  if (idx == -1) { g_ccd_branch = 6; *dist_out = CCD_FLOAT_MAX; return 0; }
   *dist_out = dist;
   if (g1.margin == 0.0 && g2.margin == 0.0 && (g1.type == G_BOX || g1.type == G_MESH) && (g2.type == G_BOX || g2.type == G_MESH)) *face_out = idx; /* 2517-2523 */
   return 1;

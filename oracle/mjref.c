@@ -1085,6 +1085,24 @@ static int box_box(const double* p1, const double* R1, const double* s1, const d
 
 #include "ccd.c"
 
+/* ---- branch trace of the convex narrowphase (test infrastructure: which gate of gjk_phase every convex pair of a collision pass left through) ---- */
+#define CCD_TRACE_CAP 4096
+typedef struct CcdTrace { int g1, g2, branch, dim, sep, n; double gjk_dist, dist; } CcdTrace;
+static CcdTrace g_trace[CCD_TRACE_CAP];
+static int g_trace_on = 0, g_trace_n = 0;
+void ref_ccd_trace_start(void) { g_trace_on = 1; g_trace_n = 0; }
+/* ints: [n, 6] = g1 g2 branch dim separated contacts; reals: [n, 2] = GJK distance, final distance; returns the number of records */
+int ref_ccd_trace_get(int* ints, double* reals, int cap) {
+  int n = g_trace_n < cap ? g_trace_n : cap;
+  for (int i = 0; i < n; i++) {
+    ints[6 * i] = g_trace[i].g1; ints[6 * i + 1] = g_trace[i].g2; ints[6 * i + 2] = g_trace[i].branch;
+    ints[6 * i + 3] = g_trace[i].dim; ints[6 * i + 4] = g_trace[i].sep; ints[6 * i + 5] = g_trace[i].n;
+    reals[2 * i] = g_trace[i].gjk_dist; reals[2 * i + 1] = g_trace[i].dist;
+  }
+  g_trace_on = 0;
+  return n;
+}
+
 /* contact of a convex pair through GJK / EPA (collision_convex.py:747-977 eval_ccd_write_contact): both geoms carry the pair's
  * margin (support points are inflated by half of it), the GJK cutoff is the gap, and the distance is reported un-inflated */
 static void mesh_of(const RefModel* m, int g, const double** vert, int* nvert) {
@@ -1143,6 +1161,11 @@ static int ccd_contact(const RefModel* m, int g1, int g2, int t1, const double* 
   double dist, w1[4][3], w2[4][3], nrm[3];
   int face;
   int n = ccd_run(m->ccd_tolerance, gap, m->ccd_iterations, m->epa_iterations, a, b, &dist, w1[0], w2[0], overflow, &face, &pt);
+  if (g_trace_on && g_trace_n < CCD_TRACE_CAP) { /* (test infrastructure: tools/ccd_branch_report.py) */
+    CcdTrace* t = &g_trace[g_trace_n++];
+    t->g1 = g1; t->g2 = g2; t->branch = g_ccd_branch; t->dim = g_ccd_gjk_dim; t->sep = g_ccd_gjk_sep; t->n = n;
+    t->gjk_dist = g_ccd_gjk_dist; t->dist = dist;
+  }
   if (n == 0 || dist >= gap) return 0;
   dist += margin;
   if (face >= 0 && multiccd_pair(m, &a, &b)) { /* zero margin: recover up to four contacts from the EPA face (collision_convex.py:875-917) */

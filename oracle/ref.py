@@ -329,6 +329,20 @@ class RefSim:
   def stage(self, name):
     self._call(name)
 
+  def ccd_trace_start(self):
+    """Arm the branch trace of the convex narrowphase (oracle/ccd.c): the next collision pass records, per convex pair, the gate of
+    gjk_phase (collision_gjk.py:2376-2414) it left through."""
+    self.lib.ref_ccd_trace_start()
+
+  def ccd_trace(self, cap=4096):
+    """[(g1, g2, branch, simplex dim, separated flag, contacts, GJK distance, final distance)] of the traced pass; branch: 1 shrunk cores
+    separated | 2 GJK distance > tolerance | 3 simplex < 2 points | 4 GJK `separated` | 5 degenerate polytope seed | 6 EPA failed | 7 EPA depth."""
+    ints = np.zeros((cap, 6), dtype=np.int32)
+    reals = np.zeros((cap, 2), dtype=self.R.np_real)
+    self.lib.ref_ccd_trace_get.restype = ctypes.c_int
+    n = self.lib.ref_ccd_trace_get(ints.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), reals.ctypes.data_as(ctypes.POINTER(self.R.c_real)), cap)
+    return [tuple(int(x) for x in ints[i]) + (float(reals[i, 0]), float(reals[i, 1])) for i in range(n)]
+
   def solve_m(self, y):
     y = np.ascontiguousarray(y, dtype=self.R.np_real)
     x = np.zeros_like(y)

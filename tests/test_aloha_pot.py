@@ -364,6 +364,47 @@ def test_float32_restatement_loses_the_resting_contact(aloha, cone):
   assert (0.3 < frac < 0.6) if cone == mjw.ConeType.PYRAMIDAL else (0.01 < frac < 0.12), frac
 
 
+def test_float32_loss_is_the_gjk_distance_gate_of_the_reference(aloha):
+  """WHICH gate of the reference's gjk_phase drops the resting contact in float32 (round-4 verdict, item 7), traced with the branch trace of
+  oracle/ccd.c on the steps 150-400 of the pyramidal lift (the pot resting on the table): in float64 GJK encloses the origin (4-point simplex,
+  distance 0) and EPA recovers the 1.4e-5 m depth; in float32 GJK stops on a 3-point simplex at +1e-7 .. +2e-6 m and the pair leaves through
+  `result.dist > tolerance` (collision_gjk.py:2412, ccd tolerance 1e-6) -- or, below the tolerance, through the degenerate polytope seed
+  (GJK's positive distance stands).  The reference's own gates, not a reading of this restatement: tools/ccd_branch_report.py prints the
+  full table (profiles/round5_ccd_branch_report.txt: 413 + 5 of 419 lost steps)."""
+  mjm = _with_cone(aloha, mjw.ConeType.PYRAMIDAL)
+  keys = find_keys(mjm, "lift_pot")
+  s = ref.RefSim(mjm, nconmax=64, njmax=256, broadphase_filter=15)
+  t = ref.RefSim(mjm, nconmax=64, njmax=256, broadphase_filter=15, real="f32")
+  s.reset(key=keys[0])
+  t.reset(key=keys[0])
+  gates, lost = {}, 0
+  for i, ctrl in enumerate(make_trajectory(mjm, keys)):
+    if i >= 400:
+      break
+    s.ctrl[:] = ctrl
+    if i >= 150:
+      for name in ("qpos", "qvel", "qacc_warmstart", "ctrl"):
+        getattr(t, name)[:] = getattr(s, name)
+      for sim in (s, t):
+        sim.stage("kinematics")
+        sim.stage("com_pos")
+        sim.ccd_trace_start()
+        sim.stage("collision")
+      tr64 = {(r[0], r[1]): r for r in s.ccd_trace()}
+      tr32 = {(r[0], r[1]): r for r in t.ccd_trace()}
+      if t.ncon < s.ncon:
+        lost += 1
+        for pair, r64 in tr64.items():
+          r32 = tr32.get(pair)
+          if r32 is not None and r64[7] < 0.0 and not r32[7] < 0.0:
+            assert r64[2] == 7 and r64[3] == 4 and r64[6] == 0.0  # float64: origin enclosed, EPA depth
+            assert 0.0 < r32[6] < 1e-4  # float32: a small POSITIVE GJK distance
+            gates[r32[2]] = gates.get(r32[2], 0) + 1
+    s.step()
+  assert lost > 50, lost
+  assert set(gates) <= {2, 5} and gates.get(2, 0) >= 0.9 * sum(gates.values()), gates
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("cone", [mjw.ConeType.PYRAMIDAL, mjw.ConeType.ELLIPTIC])
 def test_gpu_per_step_parity_along_the_lift(aloha, cone):

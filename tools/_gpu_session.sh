@@ -1,7 +1,7 @@
 #!/bin/bash
-# scratch GPU session (overwritten per use): $1 = tag
 cd ${GRAFT_REPO_ROOT:-.}
 O=gpurun_out/$1; mkdir -p $O
-timeout 600 python tools/config_ab.py unitree_g1_flat 2>&1 | grep -v amdgpu.ids | tee $O/g1.log
-timeout 600 python tools/solve_ab.py --at 5,300 --json $O/ab_main.json "MJH_CG_KERNEL=pair" "" > $O/ab_main.log 2>&1; grep "^at" $O/ab_main.log
-timeout 3000 python -m pytest tests/ -q -m gpu -x > $O/tests_all.log 2>&1; tail -3 $O/tests_all.log
+for L in "" mid5 mid4w8 ""; do
+  if [ -n "$L" ]; then export MJH_LIB=$PWD/mujoco_warp_amd/libmjhip_$L.so; else unset MJH_LIB; fi
+  echo "== lib $L"; MJH_DEBUG_OCC=1 timeout 600 python tools/solve_ab.py --at 5,300 "" 2>&1 | grep "^at\|k_mid " | sort | uniq | head -4
+done
