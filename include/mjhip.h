@@ -202,6 +202,14 @@ typedef struct MjhModel {
   const int* nxn_pairid;        /* [npair] explicit pair index or -1 (io.py:575-590)             */
   const int* nxn_pairindex;     /* [ngeom (ngeom - 1) / 2] index into nxn_geom_pair of the unordered geom pair (math.upper_tri_index
                                    order) or -1 when the pair is filtered out: the SAP sweep's lookup (collision_driver.py:485) */
+  /* k_broad_mask's group pre-test (host: io.py cull_tables): the pair list regrouped by pairs of geom groups (the colliding geoms among
+     the consecutive geoms of one moving body; every static geom its own group); a group's sphere is centred on its centre geom */
+  const int* cull_geom;         /* [ncullgeom, 2] geom + (group << 16), the group's centre geom: the colliding geoms, group by group   */
+  const int* cull_group;        /* [ncullgroup, 2] centre geom, number of colliding geoms (description; not read by the kernels)       */
+  const int* cull_pair;         /* [ncullpair, 4] group, group (-1: explicit pairs, always tested), centre geom 1 + (centre geom 2 << 16),
+                                   first entry of cull_list + (count << 24), count <= 16                                              */
+  const int* cull_list;         /* [npair, 2] index into nxn_geom_pair, g1 + (g2 << 16)                                               */
+  int ncullgeom; int ncullgroup; int ncullpair;
   /* explicit contact pairs (types.py Model.pair_*): parameters that replace the geom mixing */
   const int* pair_dim; const float* pair_friction; const float* pair_solref; const float* pair_solreffriction;
   const float* pair_solimp; const float* pair_margin; const float* pair_gap;
@@ -365,7 +373,7 @@ int mjh_timed_steps(const MjhModel* m, const MjhData* d, int nstep, int step0, f
 int mjh_release_thread_resources(void);
 
 const char* mjh_last_error(void);
-#define MJH_ABI_VERSION 41
+#define MJH_ABI_VERSION 42
 /* floats of Data.ws_ccd for a model with GJK pairs (csrc/convex.hpp ccd_layout: per world the candidate list, the per-candidate result cache and the
    broadphase mask; then the EPA hand-over records and the multi-contact buffers) -- what a binding that allocates Data itself must provide;
    iterations = max(ccd_iterations, epa_iterations), concap = Data.concap.  Also returns Data.nccdhand through *nccdhand_out (may be NULL).  Host only. */

@@ -1786,7 +1786,38 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
 //   * the ballots of the tests are the world's mask over the pair list (in LDS), which the first wavefront expands in pair order at the end:
 //     the candidate list is the serial loop's, and the launch publishes it like k_ccd_broad does for the sweep-and-prune broadphase.
 // Filters: collision_driver.py:124-275 (_aabb_filter, _obb_filter), 278-334 (_plane_filter, _sphere_filter), 494-503 (sleep).
-__host__ __device__ inline int bmask_lds_words(int ngeom, int npair) { return 34 * ngeom + 2 * ((npair + 63) / 64) + 4 * 256 + 8; }
+// Round 5, the group pre-test: the ALOHA scene's world tested 9,154 bounding-sphere pairs to keep ~30 (201 us per step at 8192 worlds, LDS reads of
+// two geoms per pair).  The host regroups the pair list by pairs of geom GROUPS (io.py cull_tables: the consecutive geoms of one moving body;
+// a static geom is its own group); a world builds one bounding sphere per group from the staged geom spheres (+ margins and gaps), tests
+// the group pairs, and runs the pair filters only on the pairs of the surviving group pairs -- flattened over the workgroup's lanes by a
+// prefix sum of their counts.  A pair whose spheres overlap lies in two groups whose spheres overlap (triangle inequality; the group
+// radius carries a 1e-4 relative slack for the float32 sums), so the mask is the one every pair's test would give.  Groups holding a plane
+// (rbound 0: the plane filter decides) are open, as is every group when the sphere filter is off; explicit pairs are always tested.
+struct BmaskLayout {  // word offsets of a workgroup's LDS (the box tables only with their filters on)
+  int gx4, hl, rl, ab, gm, gp, fm, queue, gc4, surv, pre, cnt, cgl, total;
+};
+__host__ __device__ inline BmaskLayout bmask_layout(int ngeom, int npair, int filt, int ncullgeom, int ngroup, int ncullpair) {
+  BmaskLayout L;
+  int o = 0;
+  L.gx4 = o; o += 4 * ngeom;                            // x y z rbound
+  L.hl = o; o += (filt & 4) ? 8 * ngeom : 0;            // hi.x hi.y hi.z lo.x | lo.y lo.z - -   (world-aligned box of the geom's local box)
+  L.rl = o; o += (filt & 8) ? 15 * ngeom : 0;           // rotation matrix (9 words) | local box (6 words): what the OBB filter reads
+  L.ab = L.rl + 9;
+  o = (o + 3) & ~3;
+  L.gm = o; o += ngeom;                                 // margin
+  L.gp = o; o += ngeom;                                 // gap
+  L.fm = o; o += (2 * ((npair + 63) / 64) + 1) & ~1;    // the world's mask over the pair list
+  o = (o + 1) & ~1;
+  L.queue = o; o += 4 * 256;                            // a wavefront's OBB queue: 128 x (pair, g1 | g2 << 16)
+  o = (o + 3) & ~3;
+  L.gc4 = o; o += ngroup;                               // group radii (float bits: atomicMax target; +inf: open)
+  L.surv = o; o += ncullpair;                           // surviving rows of cull_pair: first entry of cull_list | count << 24
+  L.pre = o; o += 16;                                   // per-wavefront totals of the expansion's prefix sums
+  L.cnt = o; o += 2;                                    // survivors
+  L.cgl = o;
+  L.total = o + 4;
+  return L;
+}
 __global__ void __launch_bounds__(256) k_broad_mask(MjhModel m, MjhData d) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if (m.disableflags & (DSBL_CONSTRAINT | DSBL_CONTACT)) return;
@@ -1795,15 +1826,25 @@ __global__ void __launch_bounds__(256) k_broad_mask(MjhModel m, MjhData d) {
   const CcdLayout CL = ccd_layout_of(m, d);
   const int filt = m.broadphase_filter;
   const bool use_aabb = (filt & 4) != 0, use_obb = (filt & 8) != 0;
-  float* gx4 = smem;                 // x y z rbound
-  float* hl = gx4 + 4 * ng;          // hi.x hi.y hi.z lo.x | lo.y lo.z - -   (world-aligned box of the geom's local box)
-  float* rl = hl + 8 * ng;           // rotation matrix (9 words of 12) and local box (6 words of 8): what the OBB filter reads
-  float* ab = rl + 12 * ng;
-  float* gm = ab + 8 * ng;           // margin
-  float* gp = gm + ng;               // gap
-  unsigned* fm = reinterpret_cast<unsigned*>(gp + ng);  // the world's mask
-  int2* queue = reinterpret_cast<int2*>(fm + ((2 * ngran + 1) & ~1)) + wv * 128;  // this wavefront's OBB queue: (pair, g1 | g2 << 16)
-  const int2* pairs2 = reinterpret_cast<const int2*>(m.nxn_geom_pair);
+  const int ngrp = m.ncullgroup, ncp = m.ncullpair;
+  const BmaskLayout L = bmask_layout(ng, npair, filt, m.ncullgeom, ngrp, ncp);
+  float* gx4 = smem + L.gx4;
+  float* hl = smem + L.hl;
+  float* rl = smem + L.rl;
+  float* ab = smem + L.ab;
+  float* gm = smem + L.gm;
+  float* gp = smem + L.gp;
+  unsigned* fm = reinterpret_cast<unsigned*>(smem + L.fm);
+  int2* queue = reinterpret_cast<int2*>(smem + L.queue) + wv * 128;  // this wavefront's OBB queue
+  int* gw = reinterpret_cast<int*>(smem + L.gc4);
+  int* surv = reinterpret_cast<int*>(smem + L.surv);
+  int* wtot = reinterpret_cast<int*>(smem + L.pre);
+  int* nsurv_p = reinterpret_cast<int*>(smem + L.cnt);
+  const int2* cgeom = reinterpret_cast<const int2*>(m.cull_geom);
+  const int4* cpair = reinterpret_cast<const int4*>(m.cull_pair);
+  const int2* clist = reinterpret_cast<const int2*>(m.cull_list);
+  const unsigned* cmask = reinterpret_cast<const unsigned*>(d.ws_ccd + CL.cmask);
+  const int inf_bits = 0x7f800000;
   for (int w = blockIdx.x; w < d.nworld; w += gridDim.x) {
     if (d.sleep_pass == 2 && !d.ws_sleep_flag[w]) continue;  // (uniform over the workgroup; k_ccd_broad skips these worlds too)
     const float* gxpos = d.geom_xpos + (size_t)w * 3 * ng;
@@ -1825,25 +1866,66 @@ __global__ void __launch_bounds__(256) k_broad_mask(MjhModel m, MjhData d) {
           const float* R = gxmat + 9 * g;
           const float* a = gaabb + 6 * g;
           if (use_obb) {
-            *reinterpret_cast<float4*>(rl + 12 * g) = make_float4(R[0], R[1], R[2], R[3]);
-            *reinterpret_cast<float4*>(rl + 12 * g + 4) = make_float4(R[4], R[5], R[6], R[7]);
-            rl[12 * g + 8] = R[8];
-            *reinterpret_cast<float4*>(ab + 8 * g) = make_float4(a[0], a[1], a[2], a[3]);
-            *reinterpret_cast<float2*>(ab + 8 * g + 4) = make_float2(a[4], a[5]);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) rl[15 * g + k] = R[k];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) ab[15 * g + k] = a[k];
           }
-          // as aabb_filter: centre R a + x, extent along world axis k = sum of the absolute terms
-          const V3 c = mat_mul(R, ld3(a)) + x;
-          const float sx = a[3], sy = a[4], sz = a[5];
-          const float ex = fabsf(R[0] * sx) + fabsf(R[1] * sy) + fabsf(R[2] * sz);
-          const float ey = fabsf(R[3] * sx) + fabsf(R[4] * sy) + fabsf(R[5] * sz);
-          const float ez = fabsf(R[6] * sx) + fabsf(R[7] * sy) + fabsf(R[8] * sz);
-          *reinterpret_cast<float4*>(hl + 8 * g) = make_float4(c.x + ex, c.y + ey, c.z + ez, c.x + -ex);
-          *reinterpret_cast<float2*>(hl + 8 * g + 4) = make_float2(c.y + -ey, c.z + -ez);
+          if (use_aabb) {  // as aabb_filter: centre R a + x, extent along world axis k = sum of the absolute terms
+            const V3 c = mat_mul(R, ld3(a)) + x;
+            const float sx = a[3], sy = a[4], sz = a[5];
+            const float ex = fabsf(R[0] * sx) + fabsf(R[1] * sy) + fabsf(R[2] * sz);
+            const float ey = fabsf(R[3] * sx) + fabsf(R[4] * sy) + fabsf(R[5] * sz);
+            const float ez = fabsf(R[6] * sx) + fabsf(R[7] * sy) + fabsf(R[8] * sz);
+            *reinterpret_cast<float4*>(hl + 8 * g) = make_float4(c.x + ex, c.y + ey, c.z + ez, c.x + -ex);
+            *reinterpret_cast<float2*>(hl + 8 * g + 4) = make_float2(c.y + -ey, c.z + -ez);
+          }
         }
       }
+      for (int i = tid; i < 2 * ngran; i += 256) fm[i] = 0u;
+      for (int i = tid; i < ngrp; i += 256) gw[i] = (filt & 2) ? 0 : inf_bits;  // (sphere filter off: every group open)
+      if (tid < 2) nsurv_p[tid] = 0;
     }
     const bool zero_mg = !__syncthreads_or(nz);  // (also the barrier behind the staging) no margins, no gaps: four table reads per pair less
     const int* bawake = m.sleep_enabled ? d.body_awake + (size_t)w * m.nbody : nullptr;
+    // the groups' bounding spheres: centred on the group's centre geom (the host's choice), radius to the farthest of its colliding geoms --
+    // a lane per geom, the maximum through an LDS atomic on the float's bits (radii are >= 0)
+    for (int j = tid; j < m.ncullgeom; j += 256) {
+      const int2 e = cgeom[j];
+      const int k = e.x & 0xffff, g = (e.x >> 16) & 0xffff;
+      const float4 a = *reinterpret_cast<const float4*>(gx4 + 4 * k), c = *reinterpret_cast<const float4*>(gx4 + 4 * e.y);
+      const V3 dc = V3{a.x - c.x, a.y - c.y, a.z - c.z};
+      const float R = (sqrtf(dot(dc, dc)) + a.w + (zero_mg ? 0.0f : gm[k] + gp[k])) * 1.0001f + 1e-6f;
+      atomicMax(gw + g, a.w == 0.0f ? inf_bits : __float_as_int(fmaxf(R, 0.0f)));
+    }
+    __syncthreads();
+    // the rows of cull_pair whose group spheres overlap (or are open), in any order: the mask orders the result
+    for (int base = 0; base < ncp; base += 1024) {  // (four trips' table loads in flight together)
+      int4 e4[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = base + 256 * j + tid;
+        e4[j] = k < ncp ? cpair[k] : make_int4(-2, 0, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int4 e = e4[j];
+        bool keep = e.x != -2;
+        if (e.x >= 0) {
+          const float4 a = *reinterpret_cast<const float4*>(gx4 + 4 * (e.z & 0xffff)), b = *reinterpret_cast<const float4*>(gx4 + 4 * ((e.z >> 16) & 0xffff));
+          const float bound = __int_as_float(gw[e.x]) + __int_as_float(gw[e.y]);
+          const V3 dif = V3{b.x - a.x, b.y - a.y, b.z - a.z};
+          keep = !(dot(dif, dif) > bound * bound);
+        }
+        const unsigned long long bb = __ballot(keep);
+        int at = 0;
+        if (lane == 0 && bb) at = atomicAdd(nsurv_p, __popcll(bb));
+        at = __shfl(at, 0, 64);
+        if (keep) surv[at + __popcll(bb & ((1ull << lane) - 1ull))] = e.w;
+      }
+    }
+    __syncthreads();
+    const int nsurv = nsurv_p[0];
     int nq = 0;
     auto obb_round = [&](int n) __attribute__((always_inline)) {  // the first n queue entries (n <= 64)
       if (lane < n) {
@@ -1852,18 +1934,27 @@ __global__ void __launch_bounds__(256) k_broad_mask(MjhModel m, MjhData d) {
         const int pid = m.nexplicit ? m.nxn_pairid[p] : -1;
         const float mgn = pid >= 0 ? m.pair_margin[pid] + m.pair_gap[pid] : (zero_mg ? 0.0f : gm[g1] + gp[g1] + gm[g2] + gp[g2]);
         const float4 a = *reinterpret_cast<const float4*>(gx4 + 4 * g1), b = *reinterpret_cast<const float4*>(gx4 + 4 * g2);
-        if (obb_filter(ab + 8 * g1, ab + 8 * g2, mgn, V3{a.x, a.y, a.z}, V3{b.x, b.y, b.z}, rl + 12 * g1, rl + 12 * g2))
+        if (obb_filter(ab + 15 * g1, ab + 15 * g2, mgn, V3{a.x, a.y, a.z}, V3{b.x, b.y, b.z}, rl + 15 * g1, rl + 15 * g2))
           atomicOr(fm + (p >> 5), 1u << (p & 31));
       }
     };
-    int2 nxt = (64 * wv + lane < npair) ? pairs2[64 * wv + lane] : make_int2(0, 0);
-    for (int gi = wv; gi < ngran; gi += 4) {
-      const int p = 64 * gi + lane;
-      const int2 cur = nxt;
-      nxt = (p + 256 < npair) ? pairs2[p + 256] : make_int2(0, 0);
+    // the pairs of the surviving rows (at most 16 entries each): a 16-lane quarter wavefront takes four rows per trip, their entries loaded
+    // together; the loops are uniform over the workgroup
+    const int sg = tid >> 4, sl = tid & 15;
+    for (int s0 = 0; s0 < nsurv; s0 += 64) {
+      int2 c4[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int idx = s0 + 16 * j + sg;
+        const int sv = idx < nsurv ? surv[idx] : 0;
+        c4[j] = sl < ((sv >> 24) & 0xff) ? clist[(sv & 0xffffff) + sl] : make_int2(-1, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+      const int2 cur = c4[j];
       bool pass = false, plain = false;
-      const int g1 = cur.x, g2 = cur.y;
-      if (p < npair) {
+      const int p = cur.x, g1 = cur.y & 0xffff, g2 = (cur.y >> 16) & 0xffff;
+      if (p >= 0) {
         const float4 a = *reinterpret_cast<const float4*>(gx4 + 4 * g1), b = *reinterpret_cast<const float4*>(gx4 + 4 * g2);
         const V3 x1 = V3{a.x, a.y, a.z}, x2 = V3{b.x, b.y, b.z};
         const float rb1 = a.w, rb2 = b.w;
@@ -1899,12 +1990,9 @@ __global__ void __launch_bounds__(256) k_broad_mask(MjhModel m, MjhData d) {
         }
       }
       const bool need = use_obb && pass && !plain;  // still to pass the OBB filter
-      const unsigned long long bn = __ballot(need), bp = __ballot(pass) & ~bn;
-      if (lane == 0) {
-        fm[2 * gi] = (unsigned)bp;
-        fm[2 * gi + 1] = (unsigned)(bp >> 32);
-      }
+      if (pass && !need) atomicOr(fm + (p >> 5), 1u << (p & 31));
       if (use_obb) {
+        const unsigned long long bn = __ballot(need);
         if (need) queue[nq + __popcll(bn & ((1ull << lane) - 1ull))] = make_int2(p, g1 | (g2 << 16));
         nq += __popcll(bn);
         gsync();
@@ -1918,22 +2006,23 @@ __global__ void __launch_bounds__(256) k_broad_mask(MjhModel m, MjhData d) {
           gsync();
         }
       }
+      }
     }
     if (use_obb && nq > 0) obb_round(nq);
     __syncthreads();
-    // the first wavefront expands the mask in pair order and publishes the world's candidate list (what k_ccd_broad does for the sweep-and-
-    // prune broadphase): candidates, counts, and per convex candidate a cache entry "no contact" that carries the pair id
-    if (wv == 0) {
+    // the mask expanded in pair order = the world's candidate list (what k_ccd_broad publishes for the sweep-and-prune broadphase):
+    // candidates, counts, and per convex candidate a cache entry "no contact" that carries the pair id.  A lane per mask word; a candidate's
+    // position and a convex candidate's slot are prefix sums over the workgroup (wavefront scans + the wavefronts' totals through LDS)
+    {
       float* ccd_world = d.ws_ccd + (size_t)w * CL.world_stride;
       int* gcand = reinterpret_cast<int*>(ccd_world + CL.cand);
       int* cnt = reinterpret_cast<int*>(d.ws_ccd + CL.cnt);
-      const unsigned* cmask = reinterpret_cast<const unsigned*>(d.ws_ccd + CL.cmask);
       const int ccap = CL.ccap;
-      int ncand = 0, ncvx = 0;
-      for (int base = 0; base < 2 * ngran; base += 64) {
-        const int wi = base + lane;
+      int ncand = 0, ncvx = 0;  // (uniform over the workgroup)
+      for (int base = 0; base < 2 * ngran; base += 256) {
+        const int wi = base + tid;
         const unsigned bits = wi < 2 * ngran ? fm[wi] : 0u;
-        // convex pairs among them (k_ccd_reset's mask: the slot of a convex candidate = its rank is a prefix sum as well)
+        // convex pairs among them (k_ccd_reset's mask)
         const unsigned cbits = wi < 2 * ngran ? bits & cmask[wi] : 0u;
         const int c1 = __popc(bits), c2 = __popc(cbits);
         int o1 = c1, o2 = c2;  // inclusive prefixes over the wavefront
@@ -1945,39 +2034,45 @@ __global__ void __launch_bounds__(256) k_broad_mask(MjhModel m, MjhData d) {
             o2 += u2;
           }
         }
-        const int t1 = __shfl(o1, 63, 64), t2 = __shfl(o2, 63, 64);
-        int a = ncand + o1 - c1, c = ncvx + o2 - c2;
+        if (lane == 63) {
+          wtot[2 * wv] = o1;
+          wtot[2 * wv + 1] = o2;
+        }
+        __syncthreads();
+        int a = ncand + o1 - c1, c = ncvx + o2 - c2, t1 = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (k < wv) {
+            a += wtot[2 * k];
+            c += wtot[2 * k + 1];
+          }
+          t1 += wtot[2 * k];
+        }
+        int kc = 0;  // convex candidates of this lane inside the capacity
         for (unsigned b = bits; b; b &= b - 1) {
           const int bit = __ffs(b) - 1, p = 32 * wi + bit;
+          const bool cv = (cbits >> bit) & 1u;
           if (a < ccap) {
             gcand[a] = p;
-            if ((cbits >> bit) & 1u) {
+            if (cv) {
               int* ce = reinterpret_cast<int*>(ccd_world + CL.cache + (size_t)c * CCD_CACHE_WORDS);
               ce[0] = 0;
               ce[CCD_CACHE_WORDS - 1] = p;
+              ++kc;
             }
           }
-          if ((cbits >> bit) & 1u) ++c;
+          if (cv) ++c;
           ++a;
         }
-        // (candidates beyond the capacity are dropped, convex ones among them: count only the kept convex candidates)
-        const int kept_before = min(ncand, ccap), kept_after = min(ncand + t1, ccap);
-        if (kept_after - kept_before < t1) {  // the capacity ends inside this trip: recount the convex candidates that were kept
-          int kc = 0;
-          int a2 = ncand + o1 - c1;
-          for (unsigned b = bits; b; b &= b - 1) {
-            if (a2 < ccap && ((cbits >> (__ffs(b) - 1)) & 1u)) ++kc;
-            ++a2;
-          }
+        // (candidates beyond the capacity are dropped, convex ones among them: only the kept convex candidates count)
 #pragma unroll
-          for (int off = 32; off >= 1; off >>= 1) kc += __shfl_xor(kc, off, 64);
-          ncvx += kc;
-        } else {
-          ncvx += t2;
-        }
+        for (int off = 32; off >= 1; off >>= 1) kc += __shfl_xor(kc, off, 64);
+        if (lane == 0) wtot[8 + wv] = kc;
+        __syncthreads();
+        ncvx += wtot[8] + wtot[9] + wtot[10] + wtot[11];
         ncand += t1;
       }
-      if (lane == 0) {
+      if (tid == 0) {
         gcand[ccap] = min(ncand, ccap);
         gcand[ccap + 1] = ncand;
         gcand[ccap + 2] = ncvx;

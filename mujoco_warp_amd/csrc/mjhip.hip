@@ -132,7 +132,7 @@ static int launch_ccd_pre(const MjhModel* m, const MjhData* d, hipStream_t s) {
   const CcdLayout CL = ccd_layout(d->nworld, it, m->nhfield, m->npolygonmax, m->nmeshdegmax, collide_ccap(m->npair, d->concap), d->nccdhand, m->npair);
   hipLaunchKernelGGL(k_ccd_reset, dim3(std::max((m->npair + 63) / 64, 1)), dim3(64), 0, s, *m, *d);  // counters, convex-pair mask (a kernel, not a memset node: replayed inside hipGraphs)
   if (m->broadphase == 0 && m->npair > 0) {  // NXN: the broadphase filters of every world as their own launch (a workgroup per world), results as bit masks
-    const size_t lds_mask = sizeof(float) * (size_t)bmask_lds_words(m->ngeom, m->npair);
+    const size_t lds_mask = sizeof(float) * (size_t)bmask_layout(m->ngeom, m->npair, m->broadphase_filter, m->ncullgeom, m->ncullgroup, m->ncullpair).total;
     if (lds_mask > 160 * 1024 || m->ngeom > 65535) return fail(MJH_E_UNSUPPORTED, "k_broad_mask: the geom tables do not fit in LDS");
     HIPCHK(set_lds(k_broad_mask, lds_mask));
     hipLaunchKernelGGL(k_broad_mask, dim3((unsigned)std::min(d->nworld, 8192)), dim3(256), lds_mask, s, *m, *d);

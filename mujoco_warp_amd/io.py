@@ -110,6 +110,63 @@ def _arr(x, dtype):
   return np.ascontiguousarray(np.asarray(x), dtype=dtype)
 
 
+def cull_tables(geom_bodyid, pairs, pairid, geom_pos=None, geom_rbound=None):
+  """Tables of k_broad_mask's group pre-test (csrc/collide.hpp): the pair list regrouped by PAIRS OF GEOM GROUPS, so that a world tests one
+  bounding sphere per group pair before the bounding spheres of its geom pairs (the reference tests every geom pair, collision_driver.py:
+  278-334; the pre-test only skips pairs whose sphere test must fail, the mask it produces is the same).
+
+  A group is a maximal run of consecutive geoms of one moving body; every geom of the world body (static scenery spreads over the whole
+  scene) is a group of its own; a group's sphere encloses its COLLIDING geoms only (the geoms of some non-explicit pair -- visual geoms have
+  no bounding radius) and is centred on one of them, the CENTRE GEOM (the one that gives the smallest sphere in the body frame; any choice
+  is valid, the kernel measures the radius in every world).  Returns
+    cull_geom  [ncullgeom, 2]  geom + (group << 16) | the group's centre geom -- the colliding geoms, group by group
+    cull_group [ncullgroup, 2] centre geom | number of colliding geoms (host-side description, not read by the kernel)
+    cull_pair  [ncullpair, 4]  group | group | centre geom 1 + (centre geom 2 << 16) | first entry of cull_list + (count << 24), count <= 16
+                               (longer group pairs are split into several rows); group -1: explicit pairs, whose margins are their own,
+                               always tested
+    cull_list  [npair, 2]      pair index | g1 + (g2 << 16)."""
+  geom_bodyid = np.asarray(geom_bodyid).astype(np.int64)
+  ng = len(geom_bodyid)
+  i32 = np.int32
+  if ng == 0 or len(pairs) == 0 or ng > 65535 or len(pairs) >= (1 << 24):
+    return np.zeros((0, 2), i32), np.zeros((0, 2), i32), np.zeros((0, 4), i32), np.zeros((0, 2), i32)
+  pairid = np.asarray(pairid)
+  new = np.ones(ng, dtype=bool)
+  new[1:] = (geom_bodyid[1:] != geom_bodyid[:-1]) | (geom_bodyid[1:] == 0)
+  run = np.cumsum(new) - 1  # run of every geom
+  used = np.zeros(ng, dtype=bool)
+  used[pairs[pairid < 0].ravel()] = True
+  geoms = np.flatnonzero(used)
+  runs, first, count = np.unique(run[geoms], return_index=True, return_counts=True)  # (geoms ascending: a run's geoms are consecutive entries)
+  gid = np.full(run.max() + 1, -1, dtype=np.int64)
+  gid[runs] = np.arange(len(runs))
+  centre = np.zeros(len(runs), dtype=np.int64)
+  for k, (a, n) in enumerate(zip(first, count)):
+    gs = geoms[a: a + n]
+    centre[k] = gs[0]
+    if n > 1 and geom_pos is not None and geom_rbound is not None:
+      x, rb = np.asarray(geom_pos, dtype=np.float64).reshape(-1, 3)[gs], np.asarray(geom_rbound, dtype=np.float64).reshape(-1)[gs]
+      radius = (np.linalg.norm(x[:, None, :] - x[None, :, :], axis=2) + rb[None, :]).max(axis=1)
+      centre[k] = gs[int(np.argmin(radius))]
+  cgeom = np.stack([geoms + (gid[run[geoms]] << 16), centre[gid[run[geoms]]]], axis=1)
+  g1, g2 = pairs[:, 0].astype(np.int64), pairs[:, 1].astype(np.int64)
+  key = gid[run[g1]] * (len(runs) + 1) + gid[run[g2]]
+  key[pairid >= 0] = -1
+  order = np.argsort(key, kind="stable")
+  ks = key[order]
+  start = np.flatnonzero(np.append(True, ks[1:] != ks[:-1]))
+  cnt = np.diff(np.append(start, len(ks)))
+  # (at most 16 entries per row: a quarter wavefront serves a surviving row, long group pairs are split)
+  nchunk = (cnt + 15) // 16
+  rows = np.repeat(np.arange(len(cnt)), nchunk)
+  within = np.arange(len(rows)) - np.repeat(np.cumsum(nchunk) - nchunk, nchunk)
+  ka, start, cnt = ks[start][rows], start[rows] + 16 * within, np.minimum(16, cnt[rows] - 16 * within)
+  ga, gb = np.where(ka < 0, -1, ka // (len(runs) + 1)), np.where(ka < 0, -1, ka % (len(runs) + 1))
+  cp = np.stack([ga, gb, np.where(ka < 0, 0, centre[ga] + (centre[gb] << 16)), start + (cnt << 24)], axis=1)
+  cl = np.stack([order, g1[order] + (g2[order] << 16)], axis=1)
+  return cgeom.astype(i32), np.stack([centre, count], axis=1).astype(i32), cp.astype(i32), cl.astype(i32)
+
+
 def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
   """Creates a model on device (reference io.py:259).
 
@@ -167,6 +224,7 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
   if (int(opt.enableflags) & int(types.EnableBit.SLEEP)) and int(opt.integrator) == int(types.IntegratorType.RK4):
     raise NotImplementedError("sleeping with the RK4 integrator is not implemented.")
   pairs, pairid = geom_pairs_with_ids(mjm)
+  cull = cull_tables(mjm.geom_bodyid, pairs, pairid, mjm.geom_pos, mjm.geom_rbound)
   gt = np.asarray(mjm.geom_type)
   for a, b in pairs:
     t = (int(min(gt[a], gt[b])), int(max(gt[a], gt[b])))
@@ -373,6 +431,7 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
     mesh_polyvertadr=_arr(getattr(mjm, "mesh_polyvertadr", np.zeros(0)), i32), mesh_polyvertnum=_arr(getattr(mjm, "mesh_polyvertnum", np.zeros(0)), i32),
     mesh_polyvert=_arr(getattr(mjm, "mesh_polyvert", np.zeros(0)), i32), mesh_polymapadr=_arr(getattr(mjm, "mesh_polymapadr", np.zeros(0)), i32),
     mesh_polymapnum=_arr(getattr(mjm, "mesh_polymapnum", np.zeros(0)), i32), mesh_polymap=_arr(getattr(mjm, "mesh_polymap", np.zeros(0)), i32), nxn_geom_pair=pairs, nxn_pairid=pairid, nxn_pairindex=_pair_index(ngeom, pairs),
+    cull_geom=cull[0], cull_group=cull[1], cull_pair=cull[2], cull_list=cull[3],
     pair_dim=_arr(getattr(mjm, "pair_dim", np.zeros(0)), i32), pair_friction=_arr(getattr(mjm, "pair_friction", np.zeros((0, 5))), f32).reshape(-1, 5),
     pair_solref=_arr(getattr(mjm, "pair_solref", np.zeros((0, 2))), f32).reshape(-1, 2),
     pair_solreffriction=_arr(getattr(mjm, "pair_solreffriction", np.zeros((0, 2))), f32).reshape(-1, 2),
@@ -458,6 +517,7 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
       setattr(m, name, da)
   m.opt, m.stat = o, s
   m.npair = int(len(pairs))
+  m.ncullgeom, m.ncullgroup, m.ncullpair = int(len(cull[0])), int(len(cull[1])), int(len(cull[2]))
   m.nexplicit = nexplicit
   m.nxn_geom_pair_filtered = m.nxn_geom_pair
   m.nbodylevel, m.ndoflevel = nlevel, ndlevel

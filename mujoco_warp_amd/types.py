@@ -398,6 +398,10 @@ class Model(_Dirty):
   nxn_geom_pair: DeviceArray = _arr(('npair', 2), "int32")
   nxn_pairid: DeviceArray = _arr(('npair',), "int32")
   nxn_pairindex: DeviceArray = _arr(('ngeom*(ngeom-1)//2',), "int32")
+  cull_geom: DeviceArray = _arr(('ncullgeom', 2), "int32")  # k_broad_mask's group pre-test (io.cull_tables)
+  cull_group: DeviceArray = _arr(('ncullgroup', 2), "int32")
+  cull_pair: DeviceArray = _arr(('ncullpair', 4), "int32")
+  cull_list: DeviceArray = _arr(('npair', 2), "int32")
   pair_dim: DeviceArray = _arr(('nexplicit',), "int32")
   pair_friction: DeviceArray = _arr(('nexplicit', 5), "float32")
   pair_solref: DeviceArray = _arr(('nexplicit', 2), "float32")
@@ -432,6 +436,9 @@ class Model(_Dirty):
   stat: "Statistic" = None
   npair: int = 0
   nexplicit: int = 0
+  ncullgeom: int = 0
+  ncullgroup: int = 0
+  ncullpair: int = 0
   nxn_geom_pair_filtered: DeviceArray = _arr(('npair', 2), "int32")
   nbodylevel: int = 0
   ndoflevel: int = 0

@@ -364,6 +364,75 @@ def test_gpu_broad_mask_equals_sap_and_oracle(bfilter):
   assert ncoll >= 16
 
 
+def _cluster_xml(nbody=7, seed=3):
+  """Free bodies of three or four geoms each (sphere, capsule, box, ellipsoid at offsets of the body's size) over a table on legs: the geom
+  groups of k_broad_mask's pre-test hold several geoms, the static scenery is a group per geom."""
+  r = np.random.default_rng(seed)
+  lines = ['<mujoco><option timestep="0.003"/><default><geom margin="0.01" gap="0.002"/></default>',
+           '<contact><pair geom1="top" geom2="g0_0" margin="0.2" gap="0.05" condim="3"/></contact><worldbody>',
+           '<geom name="floor" type="plane" size="0 0 .05"/><geom name="top" type="box" size=".6 .5 .02" pos="0 0 .3"/>']
+  for k, (x, y) in enumerate(((.55, .45), (-.55, .45), (.55, -.45), (-.55, -.45))):
+    lines.append(f'<geom name="leg{k}" type="cylinder" size=".03 .14" pos="{x} {y} .14"/>')
+  for b in range(nbody):
+    lines.append(f'<body name="b{b}" pos="{r.uniform(-.5, .5):.3f} {r.uniform(-.4, .4):.3f} {r.uniform(.4, .6):.3f}"><freejoint/>')
+    for g in range(3 + b % 2):
+      t = ("sphere", "capsule", "box", "ellipsoid")[(b + g) % 4]
+      size = {"sphere": ".03", "capsule": ".02 .04", "box": ".03 .02 .025", "ellipsoid": ".035 .02 .025"}[t]
+      lines.append(f'<geom name="g{b}_{g}" type="{t}" size="{size}" pos="{r.uniform(-.08, .08):.3f} {r.uniform(-.08, .08):.3f} {r.uniform(-.08, .08):.3f}"'
+                   + (' margin="0.03"' if g == 1 else "") + "/>")
+    lines.append("</body>")
+  lines.append("</worldbody></mujoco>")
+  return "\n".join(lines)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bfilter", [1, 2, 3, 7, 15])
+def test_gpu_broad_mask_group_pretest_keeps_every_candidate(bfilter):
+  """k_broad_mask tests one bounding sphere per pair of geom groups before the geom pairs (round 5): with several geoms per body, geom
+  margins, an explicit pair of its own margin, a plane and static scenery the candidate count and the contact list of every world are the
+  oracle's NXN broadphase's (which tests every pair, collision_driver.py:278-334) and the sweep-and-prune launch's."""
+  import mujoco_warp_amd as mjw
+
+  mjm = mjw.mjcf.from_xml_string(_cluster_xml())
+  m = mjw.put_model(mjm)
+  assert m.ncullgroup == 6 + 7 and 0 < m.ncullpair < m.npair  # floor, top, four legs: a group each; a group per body
+  assert int((m.cull_pair.numpy()[:, 3] >> 24).sum()) == m.npair and int((m.cull_pair.numpy()[:, 0] < 0).sum()) == 1 and int((m.cull_pair.numpy()[:, 3] >> 24).max()) <= 16
+  rng = np.random.default_rng(11)
+  nworld = 40
+  q0 = np.asarray(mjw.MjData(mjm).qpos, dtype=np.float64)
+  qs = np.tile(q0, (nworld, 1))
+  for w in range(1, nworld):  # the bodies thrown together over (and under) the table, closer with the world index
+    spread = 0.6 * (1.0 - w / nworld) + 0.08
+    for b in range(mjm.nq // 7):
+      qs[w, 7 * b: 7 * b + 3] = [rng.uniform(-spread, spread), rng.uniform(-spread, spread), rng.uniform(0.05, 0.5)]
+      quat = rng.normal(size=4)
+      qs[w, 7 * b + 3: 7 * b + 7] = quat / np.linalg.norm(quat)
+  found = {}
+  for bp in (mjw.BroadphaseType.NXN, mjw.BroadphaseType.SAP_TILE):
+    m = mjw.put_model(mjm)
+    m.opt.broadphase = int(bp)
+    m.opt.broadphase_filter = int(bfilter)
+    d = mjw.put_data(mjm, mjw.MjData(mjm), nworld=nworld, nconmax=96, njmax=384)
+    d.qpos.assign(qs.astype(np.float32))
+    mjw.kinematics(m, d)
+    mjw.collision(m, d)
+    assert (d.overflow.numpy() == 0).all()
+    ncon, adr, geom = d.ws_ncon.numpy(), d.ws_conadr.numpy(), d.contact.geom.numpy()
+    found[int(bp)] = (d.ws_ncollision.numpy().copy(), [tuple(map(tuple, geom[int(adr[w]): int(adr[w]) + int(ncon[w])])) for w in range(nworld)])
+  a, b = found[int(mjw.BroadphaseType.NXN)], found[int(mjw.BroadphaseType.SAP_TILE)]
+  assert a[1] == b[1]
+  ncoll = 0
+  for w in range(0, nworld, 4):
+    s = ref.RefSim(mjm, nconmax=96, njmax=384, broadphase=0, broadphase_filter=int(bfilter))
+    s.qpos[:] = qs[w]
+    s.stage("kinematics")
+    s.stage("collision")
+    assert int(a[0][w]) == s.ncollision, (w, int(a[0][w]), s.ncollision)
+    assert [tuple(g) for g in a[1][w]] == [tuple(int(x) for x in g) for g in s.con_geom[: s.ncon]], w
+    ncoll += s.ncollision
+  assert ncoll >= 40
+
+
 # ---- box-box through CCD + multi-contact (the reference's default; the primitive mjc_BoxBox collider needs DisableBit.NATIVECCD) ----
 BOX_CCD_XML = """
 <mujoco>

@@ -198,3 +198,12 @@ def test_random_model_meshes(seed):
   """The same random trees with boxes / ellipsoids / cylinders replaced by random convex polytopes (inline mesh assets), every geom
   colliding with every other: mesh support in GJK / EPA, plane-mesh, and (even seeds) multi-contact recovery on mesh faces."""
   _run_seed(seed, mjw.SolverType.NEWTON if seed % 2 else mjw.SolverType.CG, convex_pairs=True, meshes=True)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MJH_FUZZ_CGP_SEEDS", "24"))))
+def test_random_model_pooled_cg(seed, monkeypatch):
+  """CG through the pooled contact-basis kernel (csrc/solver_cgp.hpp; forced at this batch size by the developer knob MJH_CG_KERNEL, which
+  the library reads at every launch) on the same random trees: every nv / 4 instantiation, equality-free trees with limit rows and mixed
+  condim-1 / condim-3 contacts, the fused Euler and implicitfast epilogues, and -- the seeds with friction loss -- its fallback launch."""
+  monkeypatch.setenv("MJH_CG_KERNEL", "cgp")
+  _run_seed(seed, mjw.SolverType.CG, njmax_dev=64)

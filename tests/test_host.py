@@ -373,7 +373,7 @@ def test_declared_schema_matches_arrays(xml):
   m = mjw.put_model(mjm)
   d = mjw.make_data(mjm, nworld=3, nconmax=7, njmax=21)
   assert dataclasses.is_dataclass(mjw.Model) and dataclasses.is_dataclass(mjw.Data)
-  env = {k: getattr(m, k) for k in ("nq", "nv", "nu", "na", "nbody", "njnt", "ngeom", "nsite", "nkey", "nmocap", "neq", "nC", "npair",
+  env = {k: getattr(m, k) for k in ("nq", "nv", "nu", "na", "nbody", "njnt", "ngeom", "nsite", "nkey", "nmocap", "neq", "nC", "npair", "ncullgeom", "ncullgroup", "ncullpair",
                                     "nexplicit", "nbodylevel", "ndoflevel", "nmaxpyramid", "ntree", "nmesh", "nmeshvert", "nmeshpoly", "nmeshpolyvert", "nmeshpolymap", "nmeshgraph", "nhfield", "nhfielddata", "nsensor", "nsensordata", "nmat")}
   env.update(nworld=d.nworld, njmax=d.njmax, njmax_pad=d.njmax_pad, nv_pad=d.nv_pad, naconmax=d.naconmax, concap=d.concap, nccdworld=d.nccdworld, nccdword=d.nccdword, ntreeadr=(m.ntree + 1) if m.tree_solve else 0, ntreerow=d.njmax if m.tree_solve else 0, ntreedof=m.nv if m.tree_solve else 0, ntreeworld=d.nworld if m.tree_solve else 0, nsleepworld=d.nsleepworld, npgsworld=d.npgsworld, nimpworld=d.nimpworld)
   for obj in (m.opt, m.stat, m, d.contact, d.efc, d):
@@ -509,3 +509,35 @@ def test_stale_library_is_never_loaded_silently(monkeypatch):
   monkeypatch.delenv("MJH_LIB", raising=False)
   with pytest.raises(RuntimeError, match="does not match the sources"):
     _abi.lib()
+
+
+@pytest.mark.parametrize("scene", ["humanoid", "aloha_pot"])
+def test_cull_tables_regroup_the_pair_list(scene):
+  """io.cull_tables (k_broad_mask's group pre-test): every pair of the filtered list exactly once; the entries of a group pair lie in its
+  two groups; a group holds the colliding geoms of a run of one moving body's geoms, every static geom is a group of its own."""
+  xml = conftest.HUMANOID_XML if scene == "humanoid" else os.path.join(conftest.ROOT, "benchmarks", "aloha_pot", "scene.xml")
+  mjm = mjw.mjcf.load_xml(xml)
+  pairs, pairid = io.geom_pairs_with_ids(mjm)
+  cgeom, group, cpair, clist = io.cull_tables(mjm.geom_bodyid, pairs, pairid, mjm.geom_pos, mjm.geom_rbound)
+  geoms, ggroup = cgeom[:, 0] & 0xffff, cgeom[:, 0] >> 16
+  assert sorted(clist[:, 0].tolist()) == list(range(len(pairs)))
+  assert (clist[:, 1] == pairs[clist[:, 0], 0] + (pairs[clist[:, 0], 1] << 16)).all()
+  assert group[:, 1].sum() == len(geoms) and (np.diff(geoms) > 0).all() and (np.diff(ggroup) >= 0).all()
+  assert set(geoms.tolist()) == set(pairs[pairid < 0].ravel().tolist())
+  body = np.asarray(mjm.geom_bodyid)
+  gid = np.full(mjm.ngeom, -1)
+  for k, (centre, n) in enumerate(group):
+    gs = geoms[ggroup == k]
+    gid[gs] = k
+    assert len(gs) == n and centre in gs and (cgeom[ggroup == k, 1] == centre).all()
+    assert (body[gs] == body[gs[0]]).all() and (n == 1 or body[gs[0]] != 0)
+  start, count = cpair[:, 3] & 0xffffff, cpair[:, 3] >> 24
+  assert count.sum() == len(pairs) and count.max() <= 16 and (start == np.concatenate([[0], np.cumsum(count)[:-1]])).all()
+  for (g1, g2, cc, _), st, n in zip(cpair, start, count):
+    p = clist[st: st + n, 0]
+    if g1 < 0:
+      assert (pairid[p] >= 0).all()
+    else:
+      assert (gid[pairs[p, 0]] == g1).all() and (gid[pairs[p, 1]] == g2).all() and (pairid[p] < 0).all()
+      assert cc == group[g1, 0] + (group[g2, 0] << 16)
+  assert len(cpair) < len(pairs) or len(pairs) <= 1
