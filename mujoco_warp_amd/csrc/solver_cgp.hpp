@@ -29,6 +29,7 @@
 // "pyramid row or not", computed per world from efc.type with two ballots; slotR[s] = efc row of slot s.  Basis row of slot (q, e < 3):
 // 3q + e; of the p-th other row: 3 nq + p.
 #pragma once
+#include <type_traits>
 #include "solver.hpp"
 #include "solver_cgw.hpp"
 
@@ -356,15 +357,20 @@ DEV void solve_cgp_body(const MjhModel& m, const MjhData& d, float* smem, int sl
   // J[row of slot k, :] . x for both slots: the two basis-row dots interleaved (four accumulator chains), then -- inside a contact's quad --
   // d_N +- d_T1 / d_N +- d_T2
   // `mv` (optional): M x rides between the J loads and their use -- its 28 FMAs cover the LDS latency of the first batch
-  auto j_dots = [&](BV x, float (&out)[NR], float* mv) __attribute__((always_inline)) {
+  // NX = 1: a wavefront whose worlds have at most G rows -- every lane's second slot is empty -- reads and multiplies one row per lane
+  auto j_dots = [&](auto nxt, BV x, float (&out)[NR], float* mv) __attribute__((always_inline)) {
+    constexpr int NX = decltype(nxt)::value;
     float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     float r0[NA], r1[NA];
     auto load_a = [&]() __attribute__((always_inline)) {
 #pragma unroll
       for (int c4 = 0; c4 < NA / 4; ++c4) {
-        const float4 a4 = *reinterpret_cast<const float4*>(Jl + jro[0] + 4 * c4), b4 = *reinterpret_cast<const float4*>(Jl + jro[1] + 4 * c4);
+        const float4 a4 = *reinterpret_cast<const float4*>(Jl + jro[0] + 4 * c4);
         r0[4 * c4] = a4.x; r0[4 * c4 + 1] = a4.y; r0[4 * c4 + 2] = a4.z; r0[4 * c4 + 3] = a4.w;
-        r1[4 * c4] = b4.x; r1[4 * c4 + 1] = b4.y; r1[4 * c4 + 2] = b4.z; r1[4 * c4 + 3] = b4.w;
+        if constexpr (NX > 1) {
+          const float4 b4 = *reinterpret_cast<const float4*>(Jl + jro[1] + 4 * c4);
+          r1[4 * c4] = b4.x; r1[4 * c4 + 1] = b4.y; r1[4 * c4 + 2] = b4.z; r1[4 * c4 + 3] = b4.w;
+        }
       }
     };
     if constexpr (NV4 <= 7) load_a();  // (32 more live registers across the M product: the 32-column instantiation has none to spare)
@@ -381,15 +387,30 @@ DEV void solve_cgp_body(const MjhModel& m, const MjhData& d, float* smem, int sl
     if constexpr (NBX > 0) {
 #pragma unroll
       for (int c4 = 0; c4 < NBX / 4; ++c4) {
-        const float4 a4 = *reinterpret_cast<const float4*>(Jl + jro[0] + NA + 4 * c4), b4 = *reinterpret_cast<const float4*>(Jl + jro[1] + NA + 4 * c4);
+        const float4 a4 = *reinterpret_cast<const float4*>(Jl + jro[0] + NA + 4 * c4);
         q0[4 * c4] = a4.x; q0[4 * c4 + 1] = a4.y; q0[4 * c4 + 2] = a4.z; q0[4 * c4 + 3] = a4.w;
-        q1[4 * c4] = b4.x; q1[4 * c4 + 1] = b4.y; q1[4 * c4 + 2] = b4.z; q1[4 * c4 + 3] = b4.w;
+        if constexpr (NX > 1) {
+          const float4 b4 = *reinterpret_cast<const float4*>(Jl + jro[1] + NA + 4 * c4);
+          q1[4 * c4] = b4.x; q1[4 * c4 + 1] = b4.y; q1[4 * c4 + 2] = b4.z; q1[4 * c4 + 3] = b4.w;
+        }
       }
     }
-    fmac_seq2<NA, NA>(s, r0, r1, x.a);
-    if constexpr (NBX > 0) fmac_seq2<NB_, NBX>(s, q0, q1, x.b);
+    if constexpr (NX > 1) {
+      fmac_seq2<NA, NA>(s, r0, r1, x.a);
+      if constexpr (NBX > 0) fmac_seq2<NB_, NBX>(s, q0, q1, x.b);
+    } else {
+      float s2[2] = {0.0f, 0.0f};
+      fmac_seq<0, NA, NA>(s2, r0, x.a);
+      if constexpr (NBX > 0) fmac_seq<0, NB_, NBX>(s2, q0, x.b);
+      s[0] = s2[0];
+      s[1] = s2[1];
+    }
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
+      if (k >= NX) {
+        out[k] = 0.0f;
+        continue;
+      }
       const float dt = s[2 * k] + s[2 * k + 1];
       const float dn = qperm<0x00>(dt), d1 = qperm<0x55>(dt), d2 = qperm<0xAA>(dt);
       const float tq = qd < 2 ? d1 : d2;
@@ -399,7 +420,7 @@ DEV void solve_cgp_body(const MjhModel& m, const MjhData& d, float* smem, int sl
   };
   {
     float jq[NR];
-    j_dots(bcast_prep(q), jq, nullptr);
+    j_dots(std::integral_constant<int, NR>{}, bcast_prep(q), jq, nullptr);
 #pragma unroll
     for (int k = 0; k < NR; ++k) rja[k] = rkind[k] != 3 ? jq[k] - rja[k] : 0.0f;
   }
@@ -422,10 +443,13 @@ DEV void solve_cgp_body(const MjhModel& m, const MjhData& d, float* smem, int sl
   const int maxiter = m.iterations, ls_iterations = m.ls_iterations;
   int ovf = 0;
   float improvement = 0.0f;
+  const bool short16 = __ballot(nb16 > 16) == 0ull;
+  auto iterate = [&](auto nxt) __attribute__((always_inline)) {
+  constexpr int NX = decltype(nxt)::value;
   for (;;) {
     // ---- force of this lane's rows (solver.py:1698-1822), folded to basis forces inside the contact quads -------------------------
 #pragma unroll
-    for (int k = 0; k < NR; ++k) {
+    for (int k = 0; k < NX; ++k) {
       const bool quad = (rkind[k] == 0) | ((rkind[k] == 2) & (rja[k] < 0.0f));  // (bitwise: no short-circuit branches on the chain)
       const float f = quad ? -rD[k] * rja[k] : 0.0f;
       const float a = qperm<0xB1>(f);          // the pair partner: f1 f0 f3 f2
@@ -450,7 +474,7 @@ DEV void solve_cgp_body(const MjhModel& m, const MjhData& d, float* smem, int sl
       // two round trips at most: batches 0 + 1 always (batch 1 of a world of at most 16 rows re-reads batch 0 against zero forces), batches
       // 2 + 3 behind one branch
       batch(0, Jq);
-      batch(1, Jq1);
+      if (!(NX == 1 && short16)) batch(1, Jq1);  // (uniform over the wavefront: both worlds within 16 basis rows)
       if (nb16 > 32) {
         batch(2, Jq2);
         batch(3, Jq3);
@@ -492,7 +516,7 @@ DEV void solve_cgp_body(const MjhModel& m, const MjhData& d, float* smem, int sl
     if (maxiter == 0) break;
     // ---- mv = M search, jv = J search -----------------------------------------------------------------------------------------------
     float mvi;
-    j_dots(bcast_prep(srch), rjv, &mvi);
+    j_dots(nxt, bcast_prep(srch), rjv, &mvi);
     pc.mark(5);
     // ---- line search (solver.py:835-1347); rows and all sums stay in registers -----------------------------------------------------
     const float g1 = srch * (Ma - fs);
@@ -500,16 +524,26 @@ DEV void solve_cgp_body(const MjhModel& m, const MjhData& d, float* smem, int sl
     float alpha = 0.0f;
     improvement = 0.0f;
     bool ls_converged = false;
-    line_search_rows<NR, G, false, 1>(rja, rjv, rD, rkind, nullptr, g1, 0.5f * srch * mvi, fabsf(g1), gtol, ls_iterations, alpha, improvement, ls_converged);
+    if constexpr (NX == NR) {
+      line_search_rows<NR, G, false, 1>(rja, rjv, rD, rkind, nullptr, g1, 0.5f * srch * mvi, fabsf(g1), gtol, ls_iterations, alpha, improvement, ls_converged);
+    } else {
+      const float ja1[1] = {rja[0]}, jv1[1] = {rjv[0]}, D1[1] = {rD[0]};
+      const int kind1[1] = {rkind[0]};
+      line_search_rows<1, G, false, 1>(ja1, jv1, D1, kind1, nullptr, g1, 0.5f * srch * mvi, fabsf(g1), gtol, ls_iterations, alpha, improvement, ls_converged);
+    }
     if (!ls_converged) ovf |= OVF_LS_ITERATIONS;
     pc.mark(6);
     q += alpha * srch;
     Ma += alpha * mvi;
 #pragma unroll
-    for (int k = 0; k < NR; ++k) rja[k] += alpha * rjv[k];
+    for (int k = 0; k < NX; ++k) rja[k] += alpha * rjv[k];
     ++niter;
     pc.mark(7);
   }
+  };
+  // (uniform over the wavefront: both its worlds within G rows -- the driver's window of the headline rollout, free fall and first contacts)
+  if (__ballot(nefc > G) == 0ull) iterate(std::integral_constant<int, 1>{});
+  else iterate(std::integral_constant<int, NR>{});
   pc.mark(8);
   // ---- outputs -----------------------------------------------------------------------------------------------------------------------
   if (active) {
