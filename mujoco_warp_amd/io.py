@@ -604,7 +604,7 @@ def _ccd_handcap(nworld: int, ccap: int) -> int:
   return max(nworld * min(ccap, 32), min(nworld * ccap, 4096))
 
 
-def _ccd_words(nworld: int, iterations: int, hfield: int, npolygonmax: int, nmeshdegmax: int, ccap: int, npair: int) -> int:
+def _ccd_words(nworld: int, iterations: int, hfield: int, npolygonmax: int, nmeshdegmax: int, ccap: int, npair: int, handcap: Optional[int] = None) -> int:
   """Per-lane words of Data.ws_ccd [nworld, words, 32] such that it holds csrc/convex.hpp ccd_layout(...).total floats: per world the
   height-field prisms' polytopes, the per-candidate result cache and the candidate list; then the EPA hand-over
   records (CCD_HAND_WORDS = 64 each) and the multi-contact buffers of the EPA groups (sized from the model like the reference's,
@@ -615,7 +615,7 @@ def _ccd_words(nworld: int, iterations: int, hfield: int, npolygonmax: int, nmes
   cand = cache0 + ccap * 24
   bmask = (cand + ccap + 4 + 3) // 4 * 4  # k_broad_mask's bit mask over the pair list (64-pair granules)
   world_stride = (bmask + 2 * ((npair + 63) // 64) + 3) // 4 * 4
-  handcap = _ccd_handcap(nworld, ccap)
+  handcap = _ccd_handcap(nworld, ccap) if handcap is None else int(handcap)
   mcw = 11 * max(int(nmeshdegmax), 3) + 22 * max(int(npolygonmax), 4) if nmeshdegmax > 0 else 0
   hand = (world_stride * nworld + 8 + 2 * ((npair + 63) // 64) + 3) // 4 * 4  # (behind the counters and the convex-pair mask)
   total = hand + handcap * 64 + handcap * mcw
@@ -627,7 +627,7 @@ def contact_cap(nconmax: int) -> int:
   return int(min(max(2 * nconmax, 16), 256))
 
 
-def _data_shapes(m, nworld, nconmax, njmax, naconmax):
+def _data_shapes(m, nworld, nconmax, njmax, naconmax, handcap=None):
   njmax_pad, nv_pad = _get_padded_sizes(m.nv, njmax)
   nb, nv, nq, nu, na, ng, nj, ns, nC = m.nbody, m.nv, m.nq, m.nu, m.na, m.ngeom, m.njnt, m.nsite, m.nC
   W = nworld
@@ -651,7 +651,7 @@ def _data_shapes(m, nworld, nconmax, njmax, naconmax):
     efc_margin=(W, njmax), efc_D=(W, njmax), efc_vel=(W, njmax), efc_aref=(W, njmax), efc_frictionloss=(W, njmax),
     efc_force=(W, njmax), ws_ncon=(W,), ws_conadr=(W,), ws_ncollision=(W,), ws_efc_con=(W, njmax), ws_tree_rowadr=(W, (m.ntree + 1) if m.tree_solve else 0), ws_tree_rowmap=(W, njmax if m.tree_solve else 0),
     ws_isl_dofadr=(W, (m.ntree + 1) if m.tree_solve else 0), ws_isl_dofmap=(W, nv if m.tree_solve else 0), ws_isl_dofinv=(W, nv if m.tree_solve else 0), ws_nisland=(W,), ws_isl_flags=(W,), ws_isl_list=(3, W if m.tree_solve else 0), ws_isl_count=(4,),
-    ws_separable=(W,), ws_order=(W,), ws_ccd=(W if m._convex_pairs else 0, _ccd_words(W, max(int(m.opt.ccd_iterations), int(m.epa_iterations)), m.nhfield, m.npolygonmax, m.nmeshdegmax, _collide_ccap(int(m.npair), contact_cap(nconmax)), int(m.npair)), 32),
+    ws_separable=(W,), ws_order=(W,), ws_ccd=(W if m._convex_pairs else 0, _ccd_words(W, max(int(m.opt.ccd_iterations), int(m.epa_iterations)), m.nhfield, m.npolygonmax, m.nmeshdegmax, _collide_ccap(int(m.npair), contact_cap(nconmax)), int(m.npair), handcap), 32),
     tree_asleep=(W, m.ntree), tree_awake=(W, m.ntree), body_awake=(W, nb), body_awake_ind=(W, nb), dof_awake_ind=(W, nv), ntree_awake=(W,), nbody_awake=(W,),
     nv_awake=(W,), tree_island=(W, m.ntree), nisland=(W,), ws_iacc=(W if int(m.opt.integrator) == int(types.IntegratorType.IMPLICIT) else 0, nv), ws_pgsB=(W if _needs_pgs_big(m) else 0, njmax_pad, nv_pad), ws_sleep_J=(W if m.sleep_enabled else 0, njmax_pad, nv_pad), ws_sleep_warm=(W if m.sleep_enabled else 0, nv),
     ws_sleep_flag=(W,),
@@ -665,7 +665,7 @@ def _needs_pgs_big(m: types.Model) -> bool:
   return int(m.opt.solver) == int(types.SolverType.PGS) and (m.nv > 64 or int(m.opt.cone) == int(types.ConeType.ELLIPTIC))
 
 
-def _alloc_data(m: types.Model, nworld, nconmax, njmax, naconmax, mjd=None, nvmax=None):
+def _alloc_data(m: types.Model, nworld, nconmax, njmax, naconmax, mjd=None, nvmax=None, nccdmax=None, naccdmax=None):
   if nvmax is None:
     nvmax = m.nv
   if nvmax < 0 or nvmax > m.nv:  # reference io.py:1731
@@ -684,7 +684,20 @@ def _alloc_data(m: types.Model, nworld, nconmax, njmax, naconmax, mjd=None, nvma
     naconmax = nworld * nconmax
   if naconmax < 0:
     raise ValueError("naconmax must be >= 0")
-  shapes, njmax_pad, nv_pad = _data_shapes(m, nworld, nconmax, njmax, naconmax)
+  # nccdmax / naccdmax (reference io.py:1741-1753: CCD contacts per world / in total): the number of penetrating convex pairs k_ccd_gjk can
+  # hand to k_ccd_epa per step (Data.nccdhand).  Pairs beyond it are dropped and flagged in Data.overflow (OVF_CCD = 16); WHICH pairs depends
+  # on the order the wavefronts reserve their entries, so size it for the scene.  Default: 32 per world on average (csrc/collide.hpp ccd_handcap).
+  if nccdmax is not None:
+    if nccdmax < 0:
+      raise ValueError("nccdmax must be >= 0")
+    if nccdmax > nconmax:
+      raise ValueError(f"nccdmax ({nccdmax}) must be <= nconmax ({nconmax})")
+  if naccdmax is not None and naccdmax < 0:
+    raise ValueError("naccdmax must be >= 0")
+  handcap = None
+  if m._convex_pairs and (naccdmax is not None or nccdmax is not None):
+    handcap = max(int(naccdmax) if naccdmax is not None else int(nccdmax) * nworld, 1)
+  shapes, njmax_pad, nv_pad = _data_shapes(m, nworld, nconmax, njmax, naconmax, handcap)
   d = types.Data()
   d.contact = types.Contact()
   d.efc = types.Constraint()
@@ -708,7 +721,7 @@ def _alloc_data(m: types.Model, nworld, nconmax, njmax, naconmax, mjd=None, nvma
   d.nccdworld, d.nccdword = shapes["ws_ccd"][0], shapes["ws_ccd"][1]
   d.world_offset = 0
   d.concap = contact_cap(nconmax)
-  d.nccdhand = _ccd_handcap(nworld, _collide_ccap(int(m.npair), d.concap)) if shapes["ws_ccd"][0] else 0
+  d.nccdhand = (handcap if handcap is not None else _ccd_handcap(nworld, _collide_ccap(int(m.npair), d.concap))) if shapes["ws_ccd"][0] else 0
   d.njmax_nnz = njmax * m.nv
   d._c = None
   d._dirty = True
@@ -763,7 +776,7 @@ def make_data(mjm, nworld: int = 1, nconmax: Optional[int] = None, nccdmax: Opti
               naccdmax: Optional[int] = None, nvmax: Optional[int] = None) -> types.Data:
   """Creates a data object on device (reference io.py:1680); state = qpos0."""
   m = mjm if isinstance(mjm, types.Model) else _model_of(mjm)
-  d = _alloc_data(m, nworld, nconmax, njmax, naconmax, nvmax=nvmax)
+  d = _alloc_data(m, nworld, nconmax, njmax, naconmax, nvmax=nvmax, nccdmax=nccdmax, naccdmax=naccdmax)
   d.qpos.assign(np.tile(m.qpos0.numpy()[0], (nworld, 1)))
   return d
 
@@ -773,7 +786,7 @@ def put_data(mjm, mjd, nworld: int = 1, nconmax: Optional[int] = None, nccdmax: 
              naccdmax: Optional[int] = None, nvmax: Optional[int] = None) -> types.Data:
   """Moves data from host to a device (reference io.py:1890): the single host state is tiled nworld times."""
   m = mjm if isinstance(mjm, types.Model) else _model_of(mjm)
-  d = _alloc_data(m, nworld, nconmax, njmax, naconmax, mjd, nvmax=nvmax)
+  d = _alloc_data(m, nworld, nconmax, njmax, naconmax, mjd, nvmax=nvmax, nccdmax=nccdmax, naccdmax=naccdmax)
   if m.neq and getattr(mjd, "eq_active", None) is not None:
     d.eq_active.assign(np.tile(np.asarray(mjd.eq_active, dtype=np.int32).reshape(1, -1), (nworld, 1)))
   for name in ("qpos", "qvel", "act", "ctrl", "qacc_warmstart", "qfrc_applied", "xfrc_applied", "mocap_pos", "mocap_quat"):

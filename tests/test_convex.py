@@ -364,6 +364,47 @@ def test_gpu_broad_mask_equals_sap_and_oracle(bfilter):
   assert ncoll >= 16
 
 
+@pytest.mark.gpu
+def test_gpu_nccdmax_sizes_the_epa_hand_over_list():
+  """make_data(nccdmax=...) / (naccdmax=...) size Data.nccdhand and ws_ccd (reference io.py:1741-1753: CCD contacts per world / in total;
+  nccdmax <= nconmax); without them the engine's default stands; models without GJK pairs allocate nothing."""
+  import mujoco_warp_amd as mjw
+  from mujoco_warp_amd import io as mio
+
+  mjm = mjw.mjcf.from_xml_string(CONVEX_SCENE_XML)
+  d0 = mjw.make_data(mjm, nworld=16, nconmax=32, njmax=128)
+  assert d0.nccdhand == mio._ccd_handcap(16, mio._collide_ccap(int(mjw.put_model(mjm).npair), d0.concap))
+  d1 = mjw.make_data(mjm, nworld=16, nconmax=32, njmax=128, nccdmax=2)
+  assert d1.nccdhand == 32 and d1.nccdword < d0.nccdword
+  d2 = mjw.make_data(mjm, nworld=16, nconmax=32, njmax=128, naccdmax=7)
+  assert d2.nccdhand == 7
+  with pytest.raises(ValueError):
+    mjw.make_data(mjm, nworld=2, nconmax=8, njmax=64, nccdmax=9)
+  with pytest.raises(ValueError):
+    mjw.make_data(mjm, nworld=2, nconmax=8, njmax=64, nccdmax=-1)
+
+
+@pytest.mark.gpu
+def test_gpu_small_nccdmax_drops_pairs_and_says_so():
+  """An EPA hand-over list smaller than the scene's penetrating convex pairs: the surplus pairs are dropped and every world that lost one
+  carries OverflowType.CCD; with room for all of them the contacts are those of the default allocation."""
+  import mujoco_warp_amd as mjw
+
+  mjm = mjw.mjcf.from_xml_string(CONVEX_SCENE_XML)
+  m = mjw.put_model(mjm)
+  out = {}
+  for tag, kw in (("default", {}), ("roomy", dict(nccdmax=16)), ("tight", dict(naccdmax=3))):
+    d = mjw.put_data(mjm, mjw.MjData(mjm), nworld=4, nconmax=32, njmax=128, **kw)
+    for _ in range(40):
+      mjw.step(m, d)
+    out[tag] = (d.ws_ncon.numpy().copy(), d.overflow.numpy().copy(), d.qpos.numpy().copy())
+  assert (out["default"][1] == 0).all() and (out["roomy"][1] == 0).all()
+  assert np.array_equal(out["default"][0], out["roomy"][0]) and np.array_equal(out["default"][2], out["roomy"][2])
+  assert (out["tight"][1] & int(mjw.OverflowType.CCD)).any()
+  assert out["tight"][0].sum() < out["default"][0].sum() or (out["tight"][2] != out["default"][2]).any()
+  assert np.isfinite(out["tight"][2]).all()
+
+
 def _cluster_xml(nbody=7, seed=3):
   """Free bodies of three or four geoms each (sphere, capsule, box, ellipsoid at offsets of the body's size) over a table on legs: the geom
   groups of k_broad_mask's pre-test hold several geoms, the static scenery is a group per geom."""

@@ -41,6 +41,7 @@ def main():
   ap.add_argument("--nconmax", type=int, default=24)
   ap.add_argument("--njmax", type=int, default=64)
   ap.add_argument("--lib", default=None, help="an instrumented library built elsewhere (one unit with -DMJH_PHASE_CLOCK, tools/build_variant_fast.py) instead of the unity build")
+  ap.add_argument("--warm", type=int, default=100, help="rollout steps before the measured window")
   ap.add_argument("--iterations", type=int, default=-1, help="cap opt.iterations for the measured steps (state from the uncapped warm-up)")
   args = ap.parse_args()
   if args.lib:
@@ -60,7 +61,7 @@ def main():
   mjd = mjw.MjData(mjm)
   mjw.mj_resetDataKeyframe(mjm, mjd, 0)
   d = mjw.put_data(mjm, mjd, nworld=args.nworld, nconmax=args.nconmax, njmax=args.njmax)
-  mjw.timed_steps(m, d, 100, step0=0)  # warm-up into the steady contact regime
+  mjw.timed_steps(m, d, args.warm, step0=0)  # warm-up (default: into the steady contact regime)
   L = _abi.lib()
   L.mjh_debug_phase_ticks.argtypes = [ctypes.c_void_p, ctypes.c_int]
   if args.iterations >= 0:
@@ -69,7 +70,7 @@ def main():
     m = mjw.put_model(mjm)
     args.steps = 1
   L.mjh_debug_phase_ticks(None, 1)
-  ms, _ = mjw.timed_steps(m, d, args.steps, step0=100)
+  ms, _ = mjw.timed_steps(m, d, args.steps, step0=args.warm)
   buf = np.zeros((64, 8, 16), dtype=np.uint64)
   L.mjh_debug_phase_ticks(buf.ctypes.data, 0)
   print(f"{args.solver}: {ms / args.steps * 1e3:.1f} us/step (instrumented build)")
