@@ -497,38 +497,8 @@ DEV int box_box(V3 P1, const float* R1, V3 S1, V3 P2, const float* R2, V3 S2, fl
   return n;
 }
 
-// runs the collider for geoms (g1,g2) with type1 <= type2
-// convex pair through GJK / EPA (collision_convex.py:747-977): both geoms carry the pair's margin (support points are inflated by
+// convex pairs go through GJK / EPA (collision_convex.py:747-977): both geoms carry the pair's margin (support points are inflated by
 // half of it), the GJK cutoff is the gap, the reported distance is un-inflated, the contact sits midway between the witness points
-template <class Emit>
-DEV void collide_convex(float tolerance, int iterations, int epa_iterations, int t1, int t2, V3 p1, const float* R1, V3 s1, V3 p2, const float* R2, V3 s2, float margin,
-                        float gap, float* scratch, int& overflow, Emit&& emit, const float* vert1 = nullptr, int nvert1 = 0, const float* vert2 = nullptr, int nvert2 = 0,
-                        const MjhModel* mm = nullptr, int mesh1 = -1, int mesh2 = -1) {
-  auto graph_of = [&](int meshid) -> const int* { return (mm && meshid >= 0 && mm->mesh_graphadr[meshid] >= 0) ? mm->mesh_graph + mm->mesh_graphadr[meshid] : nullptr; };
-  const CcdGeom a = CcdGeom{t1, p1, R1, s1, margin, vert1, nvert1, -1, mesh1, graph_of(mesh1), -1, nullptr}, b = CcdGeom{t2, p2, R2, s2, margin, vert2, nvert2, -1, mesh2, graph_of(mesh2), -1, nullptr};
-  float dist;
-  V3 w1, w2;
-  int face;
-  Poly pt;
-  int n = ccd_run(tolerance, gap, iterations, epa_iterations, a, b, scratch, dist, w1, w2, overflow, face, pt);
-  if (n == 0 || dist >= gap) return;
-  dist += margin;
-  // multi-contact recovery (collision_convex.py:875-889): box-box always; box-mesh / mesh-mesh unless DisableBit.MULTICCD (meshes need their polygon tables)
-  const bool anymesh = t1 == G_MESH || t2 == G_MESH;
-  if (face >= 0 && anymesh && (!mm || (mm->disableflags & DSBL_MULTICCD) || mm->nmeshpoly == 0)) face = -1;
-  if (face >= 0) {  // zero margin: up to four contacts from the EPA face, same distance and frame (collision_convex.py:888-960)
-    V3 m1[4], m2[4];
-    n = anymesh ? ccd_multicontact_mesh(*mm, pt, face, w1, w2, a, b, m1, m2, scratch + (size_t)ccd_words(max(mm->ccd_iterations, mm->epa_iterations), mm->nhfield) * CCD_LANES)
-                : ccd_multicontact_box(pt, face, w1, w2, a, b, m1, m2);
-    if (n == 0) return;
-    const Frame f = make_frame3(dist <= margin ? m1[0] - m2[0] : m2[0] - m1[0]);
-    for (int i = 0; i < n; ++i) emit(i, dist, 0.5f * (m1[i] + m2[i]), f.a, f.b, f.c);
-    return;
-  }
-  const Frame f = make_frame3(dist <= margin ? w1 - w2 : w2 - w1);
-  emit(0, dist, 0.5f * (w1 + w2), f.a, f.b, f.c);
-}
-
 // ---- the convex pair in two launches (round 4; convex.hpp header) -----------------------------------------------------------------------
 // GJK by ONE lane (CG = 0) or by the CG lanes of a group together (identical arguments in every lane; the mesh support function spreads the
 // neighbours of a hill-climbing step over the lanes).  Returns 0: no contact, 1: one contact, emitted (no penetration deeper than the tolerance: EPA not needed), 2: EPA
@@ -2272,7 +2242,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MJH_EP
   if (t1 == G_MESH) { me1 = m.geom_dataid[g1]; mv1 = m.mesh_vert + 3 * m.mesh_vertadr[me1]; mn1 = m.mesh_vertnum[me1]; }
   if (t2 == G_MESH) { me2 = m.geom_dataid[g2]; mv2 = m.mesh_vert + 3 * m.mesh_vertadr[me2]; mn2 = m.mesh_vertnum[me2]; }
   float* cache = d.ws_ccd + (size_t)w * CL.world_stride + CL.cache + (size_t)slot * CCD_CACHE_WORDS;
-  float* mcws = d.ws_ccd + CL.mc + (size_t)h * CL.mcw;
+  float* mcws = d.ws_ccd + CL.mc + (size_t)(blockIdx.x * (blockDim.x / G) + gib) * CL.mcw;  // (this group's scratch, reused entry after entry)
   int nem = 0, overflow = 0;
   const float ccd_tol = bf(m.opt_ccd_tolerance, m.opt_ccd_tolerance_nb, w, 1)[0];
   convex_epa_group<G>(ccd_tol, min(m.epa_iterations, CCD_MAX_ITER), t1, t2, ld3(gxpos + 3 * g1), gxmat + 9 * g1, ld3(gsize + 3 * g1), ld3(gxpos + 3 * g2), gxmat + 9 * g2, ld3(gsize + 3 * g2),

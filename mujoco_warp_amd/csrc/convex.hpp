@@ -78,6 +78,8 @@ struct CcdLayout {
   size_t tail, cnt, cmask, hand, mc, total;  // offsets from the start of ws_ccd
   int ccap, handcap, mcw, nbw;
 };
+// lane groups of one k_ccd_epa launch at most (its grid: min(entries / groups per workgroup, 2048) workgroups of at most 8 groups)
+__host__ __device__ inline int ccd_epa_groups(int handcap) { return handcap + 7 < 16384 ? handcap + 7 : 16384; }
 __host__ __device__ inline CcdLayout ccd_layout(int nworld, int iterations, int nhfield, int npolygonmax, int nmeshdegmax, int ccap, int handcap, int npair) {
   CcdLayout L;
   L.ccap = ccap;
@@ -94,9 +96,12 @@ __host__ __device__ inline CcdLayout ccd_layout(int nworld, int iterations, int 
   L.handcap = handcap;
   L.cmask = L.cnt + 8;  // bit mask over the pair list: the pairs the convex launches serve (k_ccd_reset writes it: the pair types with the step's flags)
   L.hand = ((L.cmask + (size_t)L.nbw + 3) / 4) * 4;
-  L.mcw = nmeshdegmax > 0 ? 11 * (nmeshdegmax > 3 ? nmeshdegmax : 3) + 22 * (npolygonmax > 4 ? npolygonmax : 4) : 0;
+  // multi-contact scratch of k_ccd_epa: the vertex-normal lists of the two features (11 D words) per RESIDENT lane group -- a group works its
+  // entries off one after the other -- not per entry (round 4 sized it per entry and with 22 P polygon words that live in LDS: 2.25 of the
+  // ALOHA scene's 2.75 GB)
+  L.mcw = nmeshdegmax > 0 ? 11 * (nmeshdegmax > 3 ? nmeshdegmax : 3) : 0;
   L.mc = L.hand + (size_t)handcap * CCD_HAND_WORDS;
-  L.total = L.mc + (size_t)handcap * L.mcw;
+  L.total = L.mc + (size_t)ccd_epa_groups(handcap) * L.mcw;
   return L;
 }
 // LDS words of an EPA group: the polytope; for models with multi-contact recovery on mesh faces (nmeshdegmax > 0) also the polygon buffers of
@@ -1651,11 +1656,6 @@ DEV int ccd_multicontact_mesh_inl(const MjhModel& m, const Poly& pt, int epa_fac
     return mc_polygon_clip_ws(face1, nface1, face2, nface2, nn, (-dn) * nn, cap, bufa, bufb, w1, w2);
   }
   return mc_polygon_clip_ws(face1, nface1, face2, nface2, n1.get(ri), dn * n2.get(rj), cap, bufa, bufb, w1, w2);
-}
-
-__device__ __noinline__ int ccd_multicontact_mesh(const MjhModel& m, const Poly& pt, int epa_face, V3 x1, V3 x2, const CcdGeom& g1, const CcdGeom& g2,
-                                                  V3 (&w1)[4], V3 (&w2)[4], float* ws, int wst = CCD_LANES) {
-  return ccd_multicontact_mesh_inl(m, pt, epa_face, x1, x2, g1, g2, w1, w2, ws, wst);
 }
 
 DEV bool is_convex_pair(int t1, int t2) {
