@@ -548,7 +548,7 @@ DEV void convex_epa_group(float tolerance, int epa_iterations, int t1, int t2, V
 #endif
   if (face >= 0) {  // zero margin: up to four contacts from the EPA face, same distance and frame (collision_convex.py:888-960)
     V3 m1[4], m2[4];
-    n = anymesh ? ccd_multicontact_mesh_inl(mm, pt, face, w1, w2, a, b, m1, m2, mcws, 1, poly, ccd_coop_face_offset(max(mm.ccd_iterations, mm.epa_iterations), mm.npolygonmax))
+    n = anymesh ? ccd_multicontact_mesh_inl(mm, pt, face, w1, w2, a, b, m1, m2, mcws, 1, poly, ccd_coop_face_offset(max(mm.ccd_iterations, mm.epa_iterations), mm.npolygonmax, mm.nmeshdegmax), ccd_coop_scratch_offset(max(mm.ccd_iterations, mm.epa_iterations)), lig, CG)
                 : ccd_multicontact_box(pt, face, w1, w2, a, b, m1, m2);
     if (n == 0) return;
     const Frame f = make_frame3(dist <= margin ? m1[0] - m2[0] : m2[0] - m1[0]);
@@ -2242,7 +2242,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MJH_EP
   if (t1 == G_MESH) { me1 = m.geom_dataid[g1]; mv1 = m.mesh_vert + 3 * m.mesh_vertadr[me1]; mn1 = m.mesh_vertnum[me1]; }
   if (t2 == G_MESH) { me2 = m.geom_dataid[g2]; mv2 = m.mesh_vert + 3 * m.mesh_vertadr[me2]; mn2 = m.mesh_vertnum[me2]; }
   float* cache = d.ws_ccd + (size_t)w * CL.world_stride + CL.cache + (size_t)slot * CCD_CACHE_WORDS;
-  float* mcws = d.ws_ccd + CL.mc + (size_t)(blockIdx.x * (blockDim.x / G) + gib) * CL.mcw;  // (this group's scratch, reused entry after entry)
+  float* mcws = nullptr;  // (the multi-contact recovery's lists live in the group's LDS)
   int nem = 0, overflow = 0;
   const float ccd_tol = bf(m.opt_ccd_tolerance, m.opt_ccd_tolerance_nb, w, 1)[0];
   convex_epa_group<G>(ccd_tol, min(m.epa_iterations, CCD_MAX_ITER), t1, t2, ld3(gxpos + 3 * g1), gxmat + 9 * g1, ld3(gsize + 3 * g1), ld3(gxpos + 3 * g2), gxmat + 9 * g2, ld3(gsize + 3 * g2),

@@ -78,8 +78,6 @@ struct CcdLayout {
   size_t tail, cnt, cmask, hand, mc, total;  // offsets from the start of ws_ccd
   int ccap, handcap, mcw, nbw;
 };
-// lane groups of one k_ccd_epa launch at most (its grid: min(entries / groups per workgroup, 2048) workgroups of at most 8 groups)
-__host__ __device__ inline int ccd_epa_groups(int handcap) { return handcap + 7 < 16384 ? handcap + 7 : 16384; }
 __host__ __device__ inline CcdLayout ccd_layout(int nworld, int iterations, int nhfield, int npolygonmax, int nmeshdegmax, int ccap, int handcap, int npair) {
   CcdLayout L;
   L.ccap = ccap;
@@ -96,26 +94,33 @@ __host__ __device__ inline CcdLayout ccd_layout(int nworld, int iterations, int 
   L.handcap = handcap;
   L.cmask = L.cnt + 8;  // bit mask over the pair list: the pairs the convex launches serve (k_ccd_reset writes it: the pair types with the step's flags)
   L.hand = ((L.cmask + (size_t)L.nbw + 3) / 4) * 4;
-  // multi-contact scratch of k_ccd_epa: the vertex-normal lists of the two features (11 D words) per RESIDENT lane group -- a group works its
-  // entries off one after the other -- not per entry (round 4 sized it per entry and with 22 P polygon words that live in LDS: 2.25 of the
-  // ALOHA scene's 2.75 GB)
-  L.mcw = nmeshdegmax > 0 ? 11 * (nmeshdegmax > 3 ? nmeshdegmax : 3) : 0;
+  // (the multi-contact recovery of k_ccd_epa works in the lane group's LDS: round 4 kept 11 D + 22 P words of global scratch per entry --
+  // 2.25 of the ALOHA scene's 2.75 GB)
+  L.mcw = 0;
   L.mc = L.hand + (size_t)handcap * CCD_HAND_WORDS;
-  L.total = L.mc + (size_t)ccd_epa_groups(handcap) * L.mcw;
+  L.total = L.mc;
   return L;
 }
 // LDS words of an EPA group: the polytope; for models with multi-contact recovery on mesh faces (nmeshdegmax > 0) also the polygon buffers of
 // that recovery (P = npolygonmax): the two clip buffers (12 P words) from word 0 -- over the polytope, which is dead by the time they are
 // written -- and the two faces (6 P words) behind them, but not before the polytope's face records end (vertices, vertex ids and face
 // records are still read while the faces are gathered; the face normals / distances behind them are not)
-__host__ __device__ inline int ccd_coop_face_offset(int iterations, int npolygonmax) {
-  const int it = iterations < CCD_MAX_ITER ? iterations : CCD_MAX_ITER, P = npolygonmax > 4 ? npolygonmax : 4;
-  const int live = 8 * (5 + it) + (6 + CCD_EPAFACES * it);  // vertices (6 words) + vertex ids (2) per vertex, one word per face
-  return 12 * P > live ? 12 * P : live;
+// the multi-contact recovery's feature lists (vertex-normal indices and normals of the two features, edge end points: 11 D words, D =
+// nmeshdegmax) sit right behind the polytope's live records (round 5; global memory before: the serial loops over them -- up to 43 x 43
+// normal pairs on the ALOHA pot -- were three quarters of k_ccd_epa); the faces start behind them; the clip buffers, written when the lists
+// are dead, cover them.
+__host__ __device__ inline int ccd_coop_scratch_offset(int iterations) {
+  const int it = iterations < CCD_MAX_ITER ? iterations : CCD_MAX_ITER;
+  return (8 * (5 + it) + (6 + CCD_EPAFACES * it) + 3) & ~3;  // vertices (6 words) + vertex ids (2) per vertex, one word per face
+}
+__host__ __device__ inline int ccd_coop_face_offset(int iterations, int npolygonmax, int nmeshdegmax) {
+  const int P = npolygonmax > 4 ? npolygonmax : 4, D = nmeshdegmax > 3 ? nmeshdegmax : 3;
+  const int lists_end = ccd_coop_scratch_offset(iterations) + 11 * D;
+  return 12 * P > lists_end ? 12 * P : lists_end;
 }
 __host__ __device__ inline int ccd_coop_words(int iterations, int npolygonmax, int nmeshdegmax) {
   const int pw = ccd_poly_words(iterations), P = npolygonmax > 4 ? npolygonmax : 4;
-  const int mc = nmeshdegmax > 0 ? ccd_coop_face_offset(iterations, npolygonmax) + 6 * P : 0;
+  const int mc = nmeshdegmax > 0 ? ccd_coop_face_offset(iterations, npolygonmax, nmeshdegmax) + 6 * P : 0;
   return (((mc > pw ? mc : pw) + 3) / 4) * 4;
 }
 // (models with multi-contact recovery on mesh faces append ccd_mc_words(npolygonmax, nmeshdegmax) words per lane: further below)
@@ -1381,7 +1386,9 @@ DEV MeshTab mesh_tab(const MjhModel& m, const CcdGeom& g) {
   const int pa = m.mesh_polyadr[g.meshid], va = m.mesh_vertadr[g.meshid];
   return MeshTab{g.vert, m.mesh_polynormal + 3 * pa, m.mesh_polyvertadr + pa, m.mesh_polyvertnum + pa, m.mesh_polyvert, m.mesh_polymapadr + va, m.mesh_polymapnum + va, m.mesh_polymap};
 }
-DEV int mc_mesh_normals(int dim, const int (&fi)[3], const MeshTab& t, const float* rot, int cap, const WsV& nout, const WsI& iout) {
+// (lig, cg: lane of a cooperating group and its width -- the lists of a high-degree vertex, one dependent pair of table loads per entry, are
+// gathered one entry per lane; 0, 1: serial.  The caller fences before it reads.)
+DEV int mc_mesh_normals(int dim, const int (&fi)[3], const MeshTab& t, const float* rot, int cap, const WsV& nout, const WsI& iout, int lig = 0, int cg = 1) {
   const int* m1 = t.polymap + t.polymapadr[fi[0]];
   const int n1 = t.polymapnum[fi[0]];
   if (dim == 3) {
@@ -1405,15 +1412,16 @@ DEV int mc_mesh_normals(int dim, const int (&fi)[3], const MeshTab& t, const flo
   }
   if (dim == 1) {
     const int n = min(n1, cap);
-    for (int i = 0; i < n; ++i) {
-      nout.set(i, mat_mul(rot, ld3(t.polynormal + 3 * m1[i])));
-      iout.set(i, m1[i]);
+    for (int i = lig; i < n; i += cg) {
+      const int pi = m1[i];
+      nout.set(i, mat_mul(rot, ld3(t.polynormal + 3 * pi)));
+      iout.set(i, pi);
     }
     return n;
   }
   return 0;
 }
-DEV int mc_mesh_edge_normals(int dim, const MeshTab& t, const CcdGeom& g, V3 v1, V3 v2, int v1i, int cap, const WsV& nout, const WsV& endv) {
+DEV int mc_mesh_edge_normals(int dim, const MeshTab& t, const CcdGeom& g, V3 v1, V3 v2, int v1i, int cap, const WsV& nout, const WsV& endv, int lig = 0, int cg = 1) {
   if (dim == 2) {
     endv.set(0, v2);
     nout.set(0, normalize(v2 - v1));
@@ -1422,7 +1430,7 @@ DEV int mc_mesh_edge_normals(int dim, const MeshTab& t, const CcdGeom& g, V3 v1,
   if (dim == 1) {
     const int* pm = t.polymap + t.polymapadr[v1i];
     const int n = min(t.polymapnum[v1i], cap);
-    for (int i = 0; i < n; ++i) {
+    for (int i = lig; i < n; i += cg) {
       const int adr = t.polyvertadr[pm[i]], nv = t.polyvertnum[pm[i]];
       for (int j = 0; j < nv; ++j)
         if (t.polyvert[adr + j] == v1i) {
@@ -1436,10 +1444,9 @@ DEV int mc_mesh_edge_normals(int dim, const MeshTab& t, const CcdGeom& g, V3 v1,
   }
   return 0;
 }
-DEV int mc_mesh_face(const MeshTab& t, const CcdGeom& g, int idx, int cap, const WsV& face) {
+DEV int mc_mesh_face(const MeshTab& t, const CcdGeom& g, int idx, int cap, const WsV& face, int lig = 0, int cg = 1) {
   const int adr = t.polyvertadr[idx], nv = min(t.polyvertnum[idx], cap);
-  int j = 0;
-  for (int i = nv - 1; i >= 0; --i) face.set(j++, mat_mul(g.rot, ld3(t.vert + 3 * t.polyvert[adr + i])) + g.pos);
+  for (int j = lig; j < nv; j += cg) face.set(j, mat_mul(g.rot, ld3(t.vert + 3 * t.polyvert[adr + nv - 1 - j])) + g.pos);  // (reversed order)
   return nv;
 }
 // mc_polygon_clip on workspace polygons; cap = 2 * npolygonmax slots per clip buffer (collision_convex.py:1346-1348)
@@ -1537,7 +1544,11 @@ DEV int mc_polygon_clip_ws(const WsV& face1, int nface1, const WsV& face2, int n
 // out-of-line copy ran at ~18 cycles per instruction, 70 % of that launch -- and out of line for the one-lane callers of the contact kernel,
 // whose register budget it would otherwise raise)
 DEV int ccd_multicontact_mesh_inl(const MjhModel& m, const Poly& pt, int epa_face, V3 x1, V3 x2, const CcdGeom& g1, const CcdGeom& g2,
-                                  V3 (&w1)[4], V3 (&w2)[4], float* ws, int wst = CCD_LANES, float* lds = nullptr, int lds_face = 0) {
+                                  V3 (&w1)[4], V3 (&w2)[4], float* ws, int wst = CCD_LANES, float* lds = nullptr, int lds_face = 0, int lds_lists = -1, int lig = 0, int cg = 1) {
+  if (lds && lds_lists >= 0) {  // the feature lists in the group's LDS (ccd_coop_scratch_offset)
+    ws = lds + lds_lists;
+    wst = 1;
+  }
   DBG_TICK_START();
   w1[0] = x1;
   w2[0] = x2;
@@ -1583,8 +1594,9 @@ DEV int ccd_multicontact_mesh_inl(const MjhModel& m, const Poly& pt, int epa_fac
     for (int k = 0; k < n; ++k) f.set(k, fb[k]);
     return n;
   };
-  int nn1 = mesh1 ? mc_mesh_normals(nf1, fi1, t1, g1.rot, D, n1, idx1) : box_normals(nf1, fi1, g1.rot, -dir, n1, idx1);
-  int nn2 = mesh2 ? mc_mesh_normals(nf2, fi2, t2, g2.rot, D, n2, idx2) : box_normals(nf2, fi2, g2.rot, dir, n2, idx2);
+  int nn1 = mesh1 ? mc_mesh_normals(nf1, fi1, t1, g1.rot, D, n1, idx1, lig, cg) : box_normals(nf1, fi1, g1.rot, -dir, n1, idx1);
+  int nn2 = mesh2 ? mc_mesh_normals(nf2, fi2, t2, g2.rot, D, n2, idx2, lig, cg) : box_normals(nf2, fi2, g2.rot, dir, n2, idx2);
+  gsync();  // (the lists were gathered a lane per entry)
   DBG_TICK(3);  // normals
   bool edge1 = false, edge2 = false, found = false;
   int ri = 0, rj = 0;
@@ -1599,7 +1611,8 @@ DEV int ccd_multicontact_mesh_inl(const MjhModel& m, const Poly& pt, int epa_fac
   }
   if (!found) {
     if (nf1 < 3 && nf1 <= nf2) {
-      nn1 = mesh1 ? mc_mesh_edge_normals(nf1, t1, g1, fv1[0], fv1[1], fi1[0], D, n1, endv) : box_edge_normals(nf1, g1, fv1[0], fv1[1], fi1[0], n1, endv);
+      nn1 = mesh1 ? mc_mesh_edge_normals(nf1, t1, g1, fv1[0], fv1[1], fi1[0], D, n1, endv, lig, cg) : box_edge_normals(nf1, g1, fv1[0], fv1[1], fi1[0], n1, endv);
+      gsync();
       for (int i = 0; i < nn2 && !found; ++i) {
         const V3 b = n2.get(i);
         for (int j = 0; j < nn1 && !found; ++j)
@@ -1612,7 +1625,8 @@ DEV int ccd_multicontact_mesh_inl(const MjhModel& m, const Poly& pt, int epa_fac
       if (!found) return 1;
       edge1 = true;
     } else if (nf2 < 3) {
-      nn2 = mesh2 ? mc_mesh_edge_normals(nf2, t2, g2, fv2[0], fv2[1], fi2[0], D, n2, endv) : box_edge_normals(nf2, g2, fv2[0], fv2[1], fi2[0], n2, endv);
+      nn2 = mesh2 ? mc_mesh_edge_normals(nf2, t2, g2, fv2[0], fv2[1], fi2[0], D, n2, endv, lig, cg) : box_edge_normals(nf2, g2, fv2[0], fv2[1], fi2[0], n2, endv);
+      gsync();
       for (int i = 0; i < nn1 && !found; ++i) {
         const V3 a = n1.get(i);
         for (int j = 0; j < nn2 && !found; ++j)
@@ -1629,21 +1643,23 @@ DEV int ccd_multicontact_mesh_inl(const MjhModel& m, const Poly& pt, int epa_fac
     }
   }
   int nface1, nface2;
+  const V3 end_ri = (edge1 || edge2) ? endv.get(ri) : V3{0.0f, 0.0f, 0.0f};  // (read before a face is written: in LDS the first face covers the end of this list)
   if (edge1) {
     face1.set(0, pt.vert(2 * face[0]));
-    face1.set(1, endv.get(ri));
+    face1.set(1, end_ri);
     nface1 = 2;
   } else {
     const int ind = edge2 ? idx1.get(rj) : idx1.get(ri);
-    nface1 = mesh1 ? mc_mesh_face(t1, g1, ind, P, face1) : box_face(g1, ind, face1);
+    nface1 = mesh1 ? mc_mesh_face(t1, g1, ind, P, face1, lig, cg) : box_face(g1, ind, face1);
   }
   if (edge2) {
     face2.set(0, pt.vert(2 * face[0] + 1));
-    face2.set(1, endv.get(ri));
+    face2.set(1, end_ri);
     nface2 = 2;
   } else {
-    nface2 = mesh2 ? mc_mesh_face(t2, g2, idx2.get(rj), P, face2) : box_face(g2, idx2.get(rj), face2);
+    nface2 = mesh2 ? mc_mesh_face(t2, g2, idx2.get(rj), P, face2, lig, cg) : box_face(g2, idx2.get(rj), face2);
   }
+  gsync();  // (the faces were gathered a lane per vertex)
   DBG_TICK(4);  // match + faces
   const float dn = length(dir);
   const int cap = 2 * P;

@@ -157,10 +157,14 @@ static int launch_ccd_pre(const MjhModel* m, const MjhData* d, hipStream_t s) {
     hipLaunchKernelGGL(k_ccd_gjk<8>, dim3((unsigned)std::min<long long>((cap + 31) / 32, 4096)), dim3(256), 0, s, *m, *d, t8, t1);
     hipLaunchKernelGGL(k_ccd_gjk<1>, dim3(grid1), dim3(256), 0, s, *m, *d, t1, all);
   }
-  const int gpb = 256 / G;
-  const size_t lds_epa = sizeof(float) * (size_t)ccd_coop_words(it, m->npolygonmax, m->nmeshdegmax) * gpb;
+  // lane groups per workgroup: a group's LDS (polytope + the multi-contact polygon buffers: 11.7 KB on the ALOHA scene) decides how many are
+  // resident on a CU -- eight groups in one 256-thread workgroup leave room for ONE workgroup there; smaller workgroups pack the LDS
+  static const int epa_threads = getenv("MJH_EPA_THREADS") ? atoi(getenv("MJH_EPA_THREADS")) : 256;  // developer knob
+  const size_t group_bytes = sizeof(float) * (size_t)ccd_coop_words(it, m->npolygonmax, m->nmeshdegmax);
+  const int gpb = std::max(epa_threads / G, 1);
+  const size_t lds_epa = group_bytes * gpb;
   HIPCHK(set_lds((k_ccd_epa<G>), lds_epa));
-  hipLaunchKernelGGL((k_ccd_epa<G>), dim3(std::min((CL.handcap + gpb - 1) / gpb, 2048)), dim3(256), lds_epa, s, *m, *d);
+  hipLaunchKernelGGL((k_ccd_epa<G>), dim3(std::min((CL.handcap + gpb - 1) / gpb, 16384 / 8)), dim3(G * gpb), lds_epa, s, *m, *d);
   return MJH_OK;
 }
 template <int G>

@@ -616,7 +616,7 @@ def _ccd_words(nworld: int, iterations: int, hfield: int, npolygonmax: int, nmes
   bmask = (cand + ccap + 4 + 3) // 4 * 4  # k_broad_mask's bit mask over the pair list (64-pair granules)
   world_stride = (bmask + 2 * ((npair + 63) // 64) + 3) // 4 * 4
   handcap = _ccd_handcap(nworld, ccap) if handcap is None else int(handcap)
-  mcw = 11 * max(int(nmeshdegmax), 3) if nmeshdegmax > 0 else 0  # (per resident EPA lane group, csrc/convex.hpp ccd_epa_groups)
+  mcw = 0  # (the multi-contact recovery works in LDS)
   hand = (world_stride * nworld + 8 + 2 * ((npair + 63) // 64) + 3) // 4 * 4  # (behind the counters and the convex-pair mask)
   total = hand + handcap * 64 + min(handcap + 7, 16384) * mcw
   return (total + 32 * nworld - 1) // (32 * nworld)
