@@ -2191,7 +2191,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MJH_GJ
 }
 // one lane GROUP per entry of the EPA list: polytope in the group's LDS, then the multi-contact recovery; lane 0 stores the result
 #ifndef MJH_EPA_WAVES  // wavefronts per SIMD the register allocation of k_ccd_epa aims at (developer knob)
-#define MJH_EPA_WAVES 3
+// (round 5: 2 -- 237 VGPRs, no spills -- instead of 3 -- 168 VGPRs, 60 spilled: with the multi-contact recovery inlined the spills sit in its
+// serial loops; ALOHA scene, 8192 worlds, same box: 941 -> 911 us per step)
+#define MJH_EPA_WAVES 2
 #endif
 template <int G>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MJH_EPA_WAVES, 8))) k_ccd_epa(MjhModel m, MjhData d) {

@@ -1377,6 +1377,30 @@ DEV int mc_intersect(const int* a1, int n1, const int* a2, int n2, int (&res)[2]
       }
   return count;
 }
+// the same by the cg lanes of a group together (identical arguments in every lane): a lane per (i, j) pair, matches taken in the serial
+// loop's order -- the lists are table reads of two dependent loads per element, n1 x n2 of them one after the other for the serial loop
+template <class A1, class A2>
+DEV int mc_intersect_g(A1&& a1, int n1, A2&& a2, int n2, int (&res)[2], int lig, int cg) {
+  int count = 0;
+  const int total = n1 * n2, g0 = (int)(threadIdx.x & 63) - lig;  // first lane of the group in its wavefront
+  const unsigned long long gmask = cg >= 64 ? ~0ull : ((1ull << cg) - 1ull);
+  for (int base = 0; base < total && count < 2; base += cg) {
+    const int k = base + lig;
+    int val = 0;
+    bool hit = false;
+    if (k < total) {
+      const int i = k / n2;
+      val = a1(i);
+      hit = val == a2(k - i * n2);
+    }
+    unsigned long long b = (__ballot(hit) >> g0) & gmask;
+    while (b && count < 2) {
+      res[count++] = __shfl(val, g0 + __ffsll((long long)b) - 1, 64);
+      b &= b - 1ull;
+    }
+  }
+  return count;
+}
 struct MeshTab {  // the polygon tables of one mesh, offset to it
   const float* vert;
   const float* polynormal;
@@ -1392,18 +1416,25 @@ DEV int mc_mesh_normals(int dim, const int (&fi)[3], const MeshTab& t, const flo
   const int* m1 = t.polymap + t.polymapadr[fi[0]];
   const int n1 = t.polymapnum[fi[0]];
   if (dim == 3) {
-    int edgeset[2], faceset[2];
-    int n = mc_intersect(m1, n1, t.polymap + t.polymapadr[fi[1]], t.polymapnum[fi[1]], edgeset);
+    int edgeset[2] = {0, 0}, faceset[2] = {0, 0};
+    const int *m2 = t.polymap + t.polymapadr[fi[1]], *m3 = t.polymap + t.polymapadr[fi[2]];
+    const int n2 = t.polymapnum[fi[1]], n3 = t.polymapnum[fi[2]];
+    int n;
+    if (cg > 1) n = mc_intersect_g([&](int i) { return m1[i]; }, n1, [&](int j) { return m2[j]; }, n2, edgeset, lig, cg);
+    else n = mc_intersect(m1, n1, m2, n2, edgeset);
     if (n == 0) return 0;
-    n = mc_intersect(edgeset, n, t.polymap + t.polymapadr[fi[2]], t.polymapnum[fi[2]], faceset);
+    if (cg > 1) n = mc_intersect_g([&](int i) { return i == 0 ? edgeset[0] : edgeset[1]; }, n, [&](int j) { return m3[j]; }, n3, faceset, lig, cg);
+    else n = mc_intersect(edgeset, n, m3, n3, faceset);
     if (n == 0) return 0;
     nout.set(0, mat_mul(rot, ld3(t.polynormal + 3 * faceset[0])));
     iout.set(0, faceset[0]);
     return 1;
   }
   if (dim == 2) {
-    int edgeset[2];
-    const int n = mc_intersect(m1, n1, t.polymap + t.polymapadr[fi[1]], t.polymapnum[fi[1]], edgeset);
+    int edgeset[2] = {0, 0};
+    const int* m2 = t.polymap + t.polymapadr[fi[1]];
+    const int n2 = t.polymapnum[fi[1]];
+    const int n = cg > 1 ? mc_intersect_g([&](int i) { return m1[i]; }, n1, [&](int j) { return m2[j]; }, n2, edgeset, lig, cg) : mc_intersect(m1, n1, m2, n2, edgeset);
     for (int i = 0; i < n; ++i) {
       nout.set(i, mat_mul(rot, ld3(t.polynormal + 3 * edgeset[i])));
       iout.set(i, edgeset[i]);

@@ -150,7 +150,8 @@ static int launch_ccd_pre(const MjhModel* m, const MjhData* d, hipStream_t s) {
     // lanes per pair by the length of the list (read on the device): one lane per pair needs >= 2 wavefronts per SIMD to hide its chains of
     // dependent table loads; shorter lists give a pair 8 or 32 lanes (MJH_GJK_LANES: developer knob, forces one instantiation)
     static const int force = getenv("MJH_GJK_LANES") ? atoi(getenv("MJH_GJK_LANES")) : 0;
-    const int all = 0x7fffffff, t8 = force ? (force == 32 ? all : 0) : 16384, t1 = force ? (force == 1 ? 0 : all) : 131072;
+    static const int t8_env = getenv("MJH_GJK_T8") ? atoi(getenv("MJH_GJK_T8")) : 16384, t1_env = getenv("MJH_GJK_T1") ? atoi(getenv("MJH_GJK_T1")) : 131072;  // developer knobs
+    const int all = 0x7fffffff, t8 = force ? (force == 32 ? all : 0) : t8_env, t1 = force ? (force == 1 ? 0 : all) : std::max(t1_env, t8_env);
     const long long cap = (long long)d->nworld * CL.ccap;  // work items at most
     const int grid1 = (int)std::min<long long>((cap + 255) / 256, 2048);
     hipLaunchKernelGGL(k_ccd_gjk<32>, dim3((unsigned)std::min<long long>((cap + 7) / 8, 4096)), dim3(256), 0, s, *m, *d, 0, t8);
