@@ -474,6 +474,58 @@ def test_gpu_broad_mask_group_pretest_keeps_every_candidate(bfilter):
   assert ncoll >= 40
 
 
+@pytest.mark.gpu
+def test_gpu_broad_mask_group_pretest_with_per_world_bounding_radii():
+  """Domain randomisation: Model.geom_rbound and geom_margin batched per world (reference types.py:822-833).  The group spheres of
+  k_broad_mask's pre-test are measured in every world from that world's radii and margins: the candidate count of every world equals a
+  brute-force count of the plane / sphere tests over the whole pair list (collision_driver.py:278-334) with that world's values."""
+  import mujoco_warp_amd as mjw
+
+  nworld = 48
+  mjm = mjw.mjcf.from_xml_string(_cluster_xml(nbody=8, seed=5))
+  m = mjw.put_model(mjm, batch_sizes={"geom_rbound": nworld, "geom_margin": nworld})
+  rng = np.random.default_rng(21)
+  rb0, mg0 = m.geom_rbound.numpy()[0].copy(), m.geom_margin.numpy()[0].copy()
+  rb = rb0[None, :] * rng.uniform(0.6, 2.5, (nworld, len(rb0)))  # (planes keep radius 0)
+  mg = mg0[None, :] * rng.uniform(0.0, 3.0, (nworld, len(mg0)))
+  m.geom_rbound.assign(rb.astype(np.float32))
+  m.geom_margin.assign(mg.astype(np.float32))
+  m.opt.broadphase = int(mjw.BroadphaseType.NXN)
+  m.opt.broadphase_filter = 3  # plane + sphere
+  d = mjw.put_data(mjm, mjw.MjData(mjm), nworld=nworld, nconmax=128, njmax=512)
+  q0 = np.asarray(mjw.MjData(mjm).qpos, dtype=np.float64)
+  qs = np.tile(q0, (nworld, 1))
+  for w in range(nworld):
+    spread = 0.55 * (1.0 - w / nworld) + 0.1
+    for b in range(mjm.nq // 7):
+      qs[w, 7 * b: 7 * b + 3] = [rng.uniform(-spread, spread), rng.uniform(-spread, spread), rng.uniform(0.05, 0.5)]
+      quat = rng.normal(size=4)
+      qs[w, 7 * b + 3: 7 * b + 7] = quat / np.linalg.norm(quat)
+  d.qpos.assign(qs.astype(np.float32))
+  mjw.kinematics(m, d)
+  mjw.collision(m, d)
+  got = d.ws_ncollision.numpy()
+  x, R = d.geom_xpos.numpy().astype(np.float64), d.geom_xmat.numpy().astype(np.float64).reshape(nworld, -1, 3, 3)
+  rbf, mgf, gap = m.geom_rbound.numpy().astype(np.float64), m.geom_margin.numpy().astype(np.float64), m.geom_gap.numpy().astype(np.float64)[0]
+  pairs, pid = m.nxn_geom_pair.numpy(), m.nxn_pairid.numpy()
+  pm, pg = m.pair_margin.numpy().astype(np.float64), m.pair_gap.numpy().astype(np.float64)
+  want = np.zeros(nworld, dtype=np.int64)
+  edge = 0
+  for w in range(nworld):
+    for (g1, g2), e in zip(pairs, pid):
+      mgn = pm[e] + pg[e] if e >= 0 else mgf[w, g1] + gap[g1] + mgf[w, g2] + gap[g2]
+      r1, r2 = rbf[w, g1], rbf[w, g2]
+      if r1 == 0.0 or r2 == 0.0:
+        pl, ot = (g1, g2) if r1 == 0.0 else (g2, g1)
+        val, bound = float(np.dot(x[w, ot] - x[w, pl], R[w, pl][:, 2])), rbf[w, ot] + mgn
+      else:
+        val, bound = float(np.linalg.norm(x[w, g2] - x[w, g1])), r1 + r2 + mgn
+      want[w] += val <= bound
+      edge += abs(val - bound) < 1e-5 * max(bound, 1.0)  # (decided inside float32 resolution: either answer is right)
+  assert np.abs(got - want).sum() <= edge, (got, want, edge)
+  assert want.sum() > 10 * nworld and len(set(want.tolist())) > 5
+
+
 # ---- box-box through CCD + multi-contact (the reference's default; the primitive mjc_BoxBox collider needs DisableBit.NATIVECCD) ----
 BOX_CCD_XML = """
 <mujoco>
