@@ -4,6 +4,10 @@ MJH_FUZZ_COLLIDER_SEEDS / MJH_FUZZ_CONVEX_SEEDS for more.  Last full sweep (fina
 through CCD + multi-contact -- 313 pass, 3 skip on the mass-matrix condition and 4 (46, 242, 275, 315) exceed the per-step bounds by EPA
 facet noise or a face-alignment decision at its 1.6 mrad threshold: qpos 3e-5 .. 2.3e-3; + 16 random-convex-mesh seeds, MJH_FUZZ_MESH_SEEDS: 200 run, 182 pass, 18 skip on the row budget): random kinematic trees with mixed joint / geom / actuator types against the float64 oracle.
 
+Round-5 sweep (final build; MJH_FUZZ_SEEDS=200, PGS 12, COLLIDER / CONVEX / MESH 160 each, MJH_FUZZ_CGP_SEEDS=300 through the pooled CG kernel): 967 pass, 22 skip,
+3 exceed a bound -- convex 46 (above), collider 86 (CG: qpos 3.1e-5) and pooled 91 (CG: qpos 3.0e-5); the last two are float32 CG stopping iterations before the
+float64 oracle (5 vs 8, 14 vs 16): the round-4 CG kernel exceeds the same bounds on the same seeds (qacc 3e-2 on 91 against 1e-5 for the pooled kernel), Newton passes both.
+
 The fixed models (humanoid, G1, Panda, pendula, free bodies, pile) pin specific code paths; these seeds sweep the
 combinations: free / ball / hinge / slide joints at random depths, limits, damping, springs, armature, friction loss,
 sphere / capsule / box / ellipsoid / cylinder geoms resting on or falling to a plane, sphere-sphere / sphere-capsule /
