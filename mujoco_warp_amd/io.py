@@ -162,7 +162,8 @@ def cull_tables(geom_bodyid, pairs, pairid, geom_pos=None, geom_rbound=None):
   within = np.arange(len(rows)) - np.repeat(np.cumsum(nchunk) - nchunk, nchunk)
   ka, start, cnt = ks[start][rows], start[rows] + 16 * within, np.minimum(16, cnt[rows] - 16 * within)
   ga, gb = np.where(ka < 0, -1, ka // (len(runs) + 1)), np.where(ka < 0, -1, ka % (len(runs) + 1))
-  cp = np.stack([ga, gb, np.where(ka < 0, 0, centre[ga] + (centre[gb] << 16)), start + (cnt << 24)], axis=1)
+  cen = np.append(centre, 0)  # (rows of explicit pairs, group -1, have no centre geoms: the padding entry)
+  cp = np.stack([ga, gb, np.where(ka < 0, 0, cen[ga] + (cen[gb] << 16)), start + (cnt << 24)], axis=1)
   cl = np.stack([order, g1[order] + (g2[order] << 16)], axis=1)
   return cgeom.astype(i32), np.stack([centre, count], axis=1).astype(i32), cp.astype(i32), cl.astype(i32)
 

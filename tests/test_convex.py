@@ -475,6 +475,37 @@ def test_gpu_broad_mask_group_pretest_keeps_every_candidate(bfilter):
 
 
 @pytest.mark.gpu
+def test_gpu_broad_mask_with_explicit_pairs_only():
+  """A model whose only pairs are explicit <contact><pair>s (every geom has contype = conaffinity = 0), one of them a GJK pair: the pre-test's
+  tables hold no groups, every row is 'always tested' -- contacts as the oracle's."""
+  import mujoco_warp_amd as mjw
+  from tests.conftest import relerr
+
+  xml = """<mujoco><option timestep="0.003"/><default><geom contype="0" conaffinity="0"/></default>
+  <worldbody><geom name="floor" type="plane" size="0 0 .05"/>
+    <body name="a" pos="0 0 .06"><freejoint/><geom name="ea" type="ellipsoid" size=".08 .05 .05"/></body>
+    <body name="b" pos=".05 .01 .15"><freejoint/><geom name="eb" type="ellipsoid" size=".06 .05 .04"/></body>
+  </worldbody>
+  <contact><pair geom1="floor" geom2="ea"/><pair geom1="ea" geom2="eb" margin="0.01"/></contact></mujoco>"""
+  mjm = mjw.mjcf.from_xml_string(xml)
+  m = mjw.put_model(mjm)
+  assert m.npair == 2 and m.ncullgeom == 0 and m.ncullgroup == 0 and (m.cull_pair.numpy()[:, 0] == -1).all()
+  s = ref.RefSim(mjm, nconmax=16, njmax=64)
+  s.reset()
+  d = mjw.put_data(mjm, mjw.MjData(mjm), nworld=3, nconmax=16, njmax=64)
+  seen = 0
+  for i in range(60):
+    for name in ("qpos", "qvel", "qacc_warmstart"):
+      getattr(d, name).assign(np.tile(getattr(s, name).astype(np.float32), (3, 1)))
+    mjw.step(m, d)
+    s.step()
+    assert int(d.ws_ncon.numpy()[2]) == s.ncon, i
+    seen += s.ncon
+    assert relerr(d.qpos.numpy()[2], s.qpos) <= 2e-5
+  assert seen >= 60 and (d.overflow.numpy() == 0).all()
+
+
+@pytest.mark.gpu
 def test_gpu_broad_mask_group_pretest_with_per_world_bounding_radii():
   """Domain randomisation: Model.geom_rbound and geom_margin batched per world (reference types.py:822-833).  The group spheres of
   k_broad_mask's pre-test are measured in every world from that world's radii and margins: the candidate count of every world equals a

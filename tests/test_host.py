@@ -541,3 +541,24 @@ def test_cull_tables_regroup_the_pair_list(scene):
       assert (gid[pairs[p, 0]] == g1).all() and (gid[pairs[p, 1]] == g2).all() and (pairid[p] < 0).all()
       assert cc == group[g1, 0] + (group[g2, 0] << 16)
   assert len(cpair) < len(pairs) or len(pairs) <= 1
+
+
+def test_cull_tables_edge_cases():
+  """io.cull_tables: no pairs / too many geoms -> empty tables (the kernel then tests nothing because there is nothing to test); explicit
+  pairs only -> rows of group -1 and no group spheres; a long group pair is split into rows of at most 16 pairs that still cover it once."""
+  e = io.cull_tables(np.array([0, 1, 1]), np.zeros((0, 2), np.int32), np.zeros(0, np.int32))
+  assert [len(a) for a in e] == [0, 0, 0, 0]
+  pairs = np.array([[0, 1], [0, 2], [1, 2]], np.int32)
+  cgeom, group, cpair, clist = io.cull_tables(np.array([0, 1, 2]), pairs, np.array([0, 1, 2], np.int32))
+  assert len(cgeom) == 0 and len(group) == 0 and (cpair[:, 0] == -1).all() and (cpair[:, 3] >> 24).sum() == 3 and sorted(clist[:, 0].tolist()) == [0, 1, 2]
+  # two bodies of 7 geoms each: 49 pairs between them = rows of 16, 16, 16, 1
+  body = np.array([1] * 7 + [2] * 7)
+  pairs = np.array([(a, b) for a in range(7) for b in range(7, 14)], np.int32)
+  pos = np.random.default_rng(0).normal(size=(14, 3))
+  cgeom, group, cpair, clist = io.cull_tables(body, pairs, np.full(len(pairs), -1, np.int32), pos, np.full(14, 0.1))
+  assert len(group) == 2 and group[:, 1].tolist() == [7, 7] and (cpair[:, 3] >> 24).tolist() == [16, 16, 16, 1]
+  assert (cpair[:, 0] == 0).all() and (cpair[:, 1] == 1).all() and sorted(clist[:, 0].tolist()) == list(range(49))
+  # the centre geom: the one with the smallest enclosing radius over its group
+  x = pos[:7]
+  want = int(np.argmin((np.linalg.norm(x[:, None] - x[None], axis=2) + 0.1).max(axis=1)))
+  assert group[0, 0] == want and (cgeom[:7, 1] == want).all()
