@@ -134,6 +134,7 @@ static int launch_ccd_pre(const MjhModel* m, const MjhData* d, hipStream_t s) {
   if (m->broadphase == 0 && m->npair > 0) {  // NXN: the broadphase filters of every world as their own launch (a workgroup per world), results as bit masks
     const size_t lds_mask = sizeof(float) * (size_t)bmask_layout(m->ngeom, m->npair, m->broadphase_filter, m->ncullgeom, m->ncullgroup, m->ncullpair).total;
     if (lds_mask > 160 * 1024 || m->ngeom > 65535) return fail(MJH_E_UNSUPPORTED, "k_broad_mask: the geom tables do not fit in LDS");
+    if (m->ncullpair <= 0 || !m->cull_pair || !m->cull_list) return fail(MJH_E_ARG, "k_broad_mask: Model.cull_pair / cull_list missing (io.py cull_tables; a binding must build them, INTEGRATION.md ABI v42)");
     HIPCHK(set_lds(k_broad_mask, lds_mask));
     hipLaunchKernelGGL(k_broad_mask, dim3((unsigned)std::min(d->nworld, 8192)), dim3(256), lds_mask, s, *m, *d);
   }
