@@ -1763,6 +1763,9 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
 // prefix sum of their counts.  A pair whose spheres overlap lies in two groups whose spheres overlap (triangle inequality; the group
 // radius carries a 1e-4 relative slack for the float32 sums), so the mask is the one every pair's test would give.  Groups holding a plane
 // (rbound 0: the plane filter decides) are open, as is every group when the sphere filter is off; explicit pairs are always tested.
+// rows of cull_pair a workgroup takes at a time (the survivors' list in LDS is this long at most: a scene of hundreds of one-geom bodies has
+// as many rows as pairs)
+#define BMASK_ROWCHUNK 4096
 struct BmaskLayout {  // word offsets of a workgroup's LDS (the box tables only with their filters on)
   int gx4, hl, rl, ab, gm, gp, fm, queue, gc4, surv, pre, cnt, cgl, total;
 };
@@ -1781,7 +1784,7 @@ __host__ __device__ inline BmaskLayout bmask_layout(int ngeom, int npair, int fi
   L.queue = o; o += 4 * 256;                            // a wavefront's OBB queue: 128 x (pair, g1 | g2 << 16)
   o = (o + 3) & ~3;
   L.gc4 = o; o += ngroup;                               // group radii (float bits: atomicMax target; +inf: open)
-  L.surv = o; o += ncullpair;                           // surviving rows of cull_pair: first entry of cull_list | count << 24
+  L.surv = o; o += ncullpair < BMASK_ROWCHUNK ? ncullpair : BMASK_ROWCHUNK;  // surviving rows of cull_pair (of one chunk of rows): first entry of cull_list | count << 24
   L.pre = o; o += 16;                                   // per-wavefront totals of the expansion's prefix sums
   L.cnt = o; o += 2;                                    // survivors
   L.cgl = o;
@@ -1869,13 +1872,32 @@ __global__ void __launch_bounds__(256) k_broad_mask(MjhModel m, MjhData d) {
       atomicMax(gw + g, a.w == 0.0f ? inf_bits : __float_as_int(fmaxf(R, 0.0f)));
     }
     __syncthreads();
+    int nq = 0;
+    auto obb_round = [&](int n) __attribute__((always_inline)) {  // the first n queue entries (n <= 64)
+      if (lane < n) {
+        const int2 e = queue[lane];
+        const int p = e.x, g1 = e.y & 0xffff, g2 = (e.y >> 16) & 0xffff;
+        const int pid = m.nexplicit ? m.nxn_pairid[p] : -1;
+        const float mgn = pid >= 0 ? m.pair_margin[pid] + m.pair_gap[pid] : (zero_mg ? 0.0f : gm[g1] + gp[g1] + gm[g2] + gp[g2]);
+        const float4 a = *reinterpret_cast<const float4*>(gx4 + 4 * g1), b = *reinterpret_cast<const float4*>(gx4 + 4 * g2);
+        if (obb_filter(ab + 15 * g1, ab + 15 * g2, mgn, V3{a.x, a.y, a.z}, V3{b.x, b.y, b.z}, rl + 15 * g1, rl + 15 * g2))
+          atomicOr(fm + (p >> 5), 1u << (p & 31));
+      }
+    };
     // the rows of cull_pair whose group spheres overlap (or are open), in any order: the mask orders the result
-    for (int base = 0; base < ncp; base += 1024) {  // (four trips' table loads in flight together)
+    for (int r0 = 0; r0 < ncp; r0 += BMASK_ROWCHUNK) {  // (one pass for up to BMASK_ROWCHUNK rows)
+    const int r1 = min(ncp, r0 + BMASK_ROWCHUNK);
+    if (r0 > 0) {  // the previous chunk's list was read to its end
+      __syncthreads();
+      if (tid == 0) nsurv_p[0] = 0;
+      __syncthreads();
+    }
+    for (int base = r0; base < r1; base += 1024) {  // (four trips' table loads in flight together)
       int4 e4[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int k = base + 256 * j + tid;
-        e4[j] = k < ncp ? cpair[k] : make_int4(-2, 0, 0, 0);
+        e4[j] = k < r1 ? cpair[k] : make_int4(-2, 0, 0, 0);
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -1896,18 +1918,6 @@ __global__ void __launch_bounds__(256) k_broad_mask(MjhModel m, MjhData d) {
     }
     __syncthreads();
     const int nsurv = nsurv_p[0];
-    int nq = 0;
-    auto obb_round = [&](int n) __attribute__((always_inline)) {  // the first n queue entries (n <= 64)
-      if (lane < n) {
-        const int2 e = queue[lane];
-        const int p = e.x, g1 = e.y & 0xffff, g2 = (e.y >> 16) & 0xffff;
-        const int pid = m.nexplicit ? m.nxn_pairid[p] : -1;
-        const float mgn = pid >= 0 ? m.pair_margin[pid] + m.pair_gap[pid] : (zero_mg ? 0.0f : gm[g1] + gp[g1] + gm[g2] + gp[g2]);
-        const float4 a = *reinterpret_cast<const float4*>(gx4 + 4 * g1), b = *reinterpret_cast<const float4*>(gx4 + 4 * g2);
-        if (obb_filter(ab + 15 * g1, ab + 15 * g2, mgn, V3{a.x, a.y, a.z}, V3{b.x, b.y, b.z}, rl + 15 * g1, rl + 15 * g2))
-          atomicOr(fm + (p >> 5), 1u << (p & 31));
-      }
-    };
     // the pairs of the surviving rows (at most 16 entries each): a 16-lane quarter wavefront takes four rows per trip, their entries loaded
     // together; the loops are uniform over the workgroup
     const int sg = tid >> 4, sl = tid & 15;
@@ -1977,6 +1987,7 @@ __global__ void __launch_bounds__(256) k_broad_mask(MjhModel m, MjhData d) {
         }
       }
       }
+    }
     }
     if (use_obb && nq > 0) obb_round(nq);
     __syncthreads();

@@ -475,6 +475,60 @@ def test_gpu_broad_mask_group_pretest_keeps_every_candidate(bfilter):
 
 
 @pytest.mark.gpu
+def test_gpu_broad_mask_many_small_bodies():
+  """120 free bodies of two geoms each (spheres, capsules, ellipsoids: GJK pairs among them) = 28,800 pairs in 7,260 rows of the pre-test's
+  table: the rows go through the workgroup in chunks of BMASK_ROWCHUNK (the survivors' list in LDS stays bounded) and the mask is expanded
+  in more than two trips -- candidate counts and contact lists as the oracle's NXN broadphase."""
+  import mujoco_warp_amd as mjw
+
+  r = np.random.default_rng(7)
+  lines = ['<mujoco><option timestep="0.003"/><worldbody><geom name="floor" type="plane" size="0 0 .05"/>']
+  n = 120
+  for b in range(n):
+    lines.append(f'<body pos="{r.uniform(-.6, .6):.3f} {r.uniform(-.6, .6):.3f} {r.uniform(.02, .5):.3f}"><freejoint/>')
+    for g in range(2):
+      t = ("sphere", "capsule", "ellipsoid")[(b + g) % 3]
+      size = {"sphere": ".03", "capsule": ".02 .03", "ellipsoid": ".035 .02 .025"}[t]
+      lines.append(f'<geom type="{t}" size="{size}" pos="{.04 * g} 0 0"/>')
+    lines.append("</body>")
+  lines.append("</worldbody></mujoco>")
+  mjm = mjw.mjcf.from_xml_string("\n".join(lines))
+  m = mjw.put_model(mjm)
+  assert m.npair == 2 * n * (2 * n - 1) // 2 - n + 2 * n and m.ncullpair > 4096 and (m.npair + 63) // 64 * 2 > 512
+  nworld = 3
+  q0 = np.asarray(mjw.MjData(mjm).qpos, dtype=np.float64)
+  qs = np.tile(q0, (nworld, 1))
+  for w in range(1, nworld):
+    qs[w, 0::7] *= 0.7 ** w  # (pulled together: more candidates)
+    qs[w, 1::7] *= 0.7 ** w
+  found = {}
+  for bp in (mjw.BroadphaseType.NXN, mjw.BroadphaseType.SAP_TILE):
+    mm = mjw.put_model(mjm)
+    mm.opt.broadphase = int(bp)
+    d = mjw.put_data(mjm, mjw.MjData(mjm), nworld=nworld, nconmax=256, njmax=64)
+    d.qpos.assign(qs.astype(np.float32))
+    mjw.kinematics(mm, d)
+    mjw.collision(mm, d)
+    assert (d.overflow.numpy() == 0).all()
+    ncon, adr, geom = d.ws_ncon.numpy(), d.ws_conadr.numpy(), d.contact.geom.numpy()
+    found[int(bp)] = (d.ws_ncollision.numpy().copy(), [[tuple(int(x) for x in g) for g in geom[int(adr[w]): int(adr[w]) + int(ncon[w])]] for w in range(nworld)])
+  nxn, sap = found[int(mjw.BroadphaseType.NXN)], found[int(mjw.BroadphaseType.SAP_TILE)]
+  assert nxn[1] == sap[1]  # the same contacts, in the same order, through either broadphase (the narrowphase is shared)
+  total = 0
+  for w in range(nworld):
+    s = ref.RefSim(mjm, nconmax=256, njmax=64, broadphase=0, broadphase_filter=int(m.opt.broadphase_filter))
+    s.qpos[:] = qs[w]
+    s.stage("kinematics")
+    s.stage("collision")
+    assert int(nxn[0][w]) == s.ncollision, (w, int(nxn[0][w]), s.ncollision)
+    # (random placements interpenetrate deeply: which of a body's two geoms EPA reports in float32 / float64 may differ -- the pair sets agree closely)
+    a_, b_ = set(nxn[1][w]), set(tuple(int(x) for x in g) for g in s.con_geom[: s.ncon])
+    assert len(a_ & b_) >= 0.9 * max(len(a_), len(b_)), (w, len(a_), len(b_), len(a_ & b_))
+    total += s.ncollision
+  assert total > 300
+
+
+@pytest.mark.gpu
 def test_gpu_broad_mask_with_explicit_pairs_only():
   """A model whose only pairs are explicit <contact><pair>s (every geom has contype = conaffinity = 0), one of them a GJK pair: the pre-test's
   tables hold no groups, every row is 'always tested' -- contacts as the oracle's."""
