@@ -163,7 +163,9 @@ static int launch_ccd_pre(const MjhModel* m, const MjhData* d, hipStream_t s) {
   // resident on a CU -- eight groups in one 256-thread workgroup leave room for ONE workgroup there; smaller workgroups pack the LDS
   static const int epa_threads = getenv("MJH_EPA_THREADS") ? atoi(getenv("MJH_EPA_THREADS")) : 256;  // developer knob
   const size_t group_bytes = sizeof(float) * (size_t)ccd_coop_words(it, m->npolygonmax, m->nmeshdegmax);
-  const int gpb = std::max(epa_threads / G, 1);
+  int gpb = std::max(epa_threads / G, 1);
+  while (gpb > 1 && group_bytes * gpb > (size_t)kLdsPerCU) gpb >>= 1;  // (a mesh vertex of very high degree: long feature lists per group)
+  if (group_bytes > (size_t)kLdsPerCU) return fail(MJH_E_UNSUPPORTED, "k_ccd_epa: a lane group's polytope and multi-contact lists do not fit in LDS (mesh vertex degree / polygon size too large)");
   const size_t lds_epa = group_bytes * gpb;
   HIPCHK(set_lds((k_ccd_epa<G>), lds_epa));
   hipLaunchKernelGGL((k_ccd_epa<G>), dim3(std::min((CL.handcap + gpb - 1) / gpb, 16384 / 8)), dim3(G * gpb), lds_epa, s, *m, *d);

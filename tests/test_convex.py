@@ -475,6 +475,41 @@ def test_gpu_broad_mask_group_pretest_keeps_every_candidate(bfilter):
 
 
 @pytest.mark.gpu
+def test_gpu_epa_groups_shrink_for_a_high_degree_vertex():
+  """A cone of 300 sides: its apex has 300 adjacent polygons and its base is a 300-gon, so one EPA lane group's LDS (polytope, feature
+  lists of 11 x 300 words, polygon buffers of 18 x 300) is 22 KB -- eight groups do not fit in a CU's LDS and the launch takes fewer groups
+  per workgroup.  Base down and apex down on a box: contacts as the oracle's."""
+  import mujoco_warp_amd as mjw
+
+  n = 300
+  ang = 2 * np.pi * np.arange(n) / n
+  pts = np.concatenate([[[0.0, 0.0, 0.12]], np.stack([0.08 * np.cos(ang), 0.08 * np.sin(ang), np.zeros(n)], axis=1)])
+  verts = " ".join(f"{x:.6f}" for x in pts.reshape(-1))
+  xml = f"""<mujoco><option timestep="0.002"/><asset><mesh name="cone" vertex="{verts}"/></asset>
+  <worldbody><geom name="table" type="box" size=".5 .5 .05" pos="0 0 .05"/>
+    <body name="down" pos="-.2 0 .0995"><freejoint/><geom type="mesh" mesh="cone"/></body>
+    <body name="up" pos=".2 0 .2195" euler="180 0 0"><freejoint/><geom type="mesh" mesh="cone"/></body>
+  </worldbody></mujoco>"""
+  mjm = mjw.mjcf.from_xml_string(xml)
+  m = mjw.put_model(mjm)
+  assert m.nmeshdegmax >= 300 and m.npolygonmax >= 300
+  s = ref.RefSim(mjm, nconmax=16, njmax=64)
+  s.reset()
+  s.stage("kinematics")
+  s.stage("collision")
+  d = mjw.put_data(mjm, mjw.MjData(mjm), nworld=5, nconmax=16, njmax=64)
+  mjw.kinematics(m, d)
+  mjw.collision(m, d)
+  assert (d.overflow.numpy() == 0).all()
+  ncon = d.ws_ncon.numpy()
+  assert (ncon == s.ncon).all() and s.ncon >= 5, (ncon, s.ncon)  # four points under the base, one at the apex
+  adr = int(d.ws_conadr.numpy()[3])
+  dist, pos = d.contact.dist.numpy()[adr: adr + s.ncon], d.contact.pos.numpy()[adr: adr + s.ncon]
+  assert np.abs(dist - np.asarray(s.con_dist[: s.ncon])).max() <= 1e-5
+  assert np.abs(np.sort(pos[:, 2]) - np.sort(np.asarray(s.con_pos[: s.ncon])[:, 2])).max() <= 1e-4
+
+
+@pytest.mark.gpu
 def test_gpu_broad_mask_many_small_bodies():
   """120 free bodies of two geoms each (spheres, capsules, ellipsoids: GJK pairs among them) = 28,800 pairs in 7,260 rows of the pre-test's
   table: the rows go through the workgroup in chunks of BMASK_ROWCHUNK (the survivors' list in LDS stays bounded) and the mask is expanded
