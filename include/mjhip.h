@@ -273,8 +273,8 @@ typedef struct MjhData {
   int* ws_conadr;      /* [nworld]   exclusive scan of ws_ncon = first public slot (k_contact_scan) */
   int* ws_ncollision;  /* [nworld]   broadphase candidates per world                  */
   float* ws_ccd;       /* workspace of the convex narrowphase (layout: csrc/convex.hpp ccd_layout -- per world the height-field prisms' polytopes, the
-                          per-candidate result cache and the candidate list; then the flat GJK list, the EPA hand-over records and the multi-contact
-                          buffers); empty unless the model has convex (GJK) pairs */
+                          per-candidate result cache, the candidate list and the broadphase mask; then the counters, the convex-pair mask and
+                          nccdhand EPA hand-over records of 64 floats); empty unless the model has convex (GJK) pairs */
   /* constraint islands at tree granularity (MjhModel.tree_solve, csrc/constraint.hpp k_tree_rows); island k of a world: */
   int* ws_tree_rowadr; /* [nworld, ntree + 1] its rows are ws_tree_rowmap[rowadr[k] .. rowadr[k + 1])                       */
   int* ws_tree_rowmap; /* [nworld, njmax] constraint rows grouped by island                                                */
@@ -375,8 +375,10 @@ int mjh_release_thread_resources(void);
 const char* mjh_last_error(void);
 #define MJH_ABI_VERSION 42
 /* floats of Data.ws_ccd for a model with GJK pairs (csrc/convex.hpp ccd_layout: per world the candidate list, the per-candidate result cache and the
-   broadphase mask; then the EPA hand-over records and the multi-contact buffers) -- what a binding that allocates Data itself must provide;
-   iterations = max(ccd_iterations, epa_iterations), concap = Data.concap.  Also returns Data.nccdhand through *nccdhand_out (may be NULL).  Host only. */
+   broadphase mask; then the counters, the convex-pair mask and the EPA hand-over records) -- what a binding that allocates Data itself must
+   provide; iterations = max(ccd_iterations, epa_iterations), concap = Data.concap.  Also returns the default Data.nccdhand through *nccdhand_out
+   (may be NULL); a binding that sets its own nccdhand (the reference's nccdmax x nworld / naccdmax) adds 64 floats per entry beyond it.
+   npolygonmax / nmeshdegmax no longer enter (the multi-contact recovery works in LDS since round 5).  Host only. */
 int mjh_ws_ccd_floats(int nworld, int iterations, int nhfield, int npolygonmax, int nmeshdegmax, int npair, int concap, double* floats_out, int* nccdhand_out);
 int mjh_abi_version(void); /* returns MJH_ABI_VERSION of the library that was loaded */
 /* hash of the sources and compiler flags the library was built from (csrc/build_id.hip); the Python loader compares it with the hash of the
