@@ -185,3 +185,41 @@ def test_solver_schedule_is_a_permutation_sorted_by_the_previous_iteration_count
   keys = np.minimum(prev[order], 127)
   assert (np.diff(keys) <= 0).all()
   assert len(set(prev.tolist())) > 3  # (the worlds really differed)
+
+
+def _snake_xml(nlink):
+  """A free-floating snake of `nlink` hinge links lying on the floor (nv = 6 + nlink): every third link's sphere (condim 3) touches the plane,
+  so that the rows stay inside njmax = 64."""
+  lines = ['<mujoco><option timestep="0.003" solver="CG"/><default><geom condim="3" friction="0.9 0.02 0.001"/><joint armature="0.01" damping="0.05"/></default>',
+           '<worldbody><geom name="floor" type="plane" size="0 0 .05"/><body name="l0" pos="0 0 .05"><freejoint/><geom type="sphere" size=".05"/>']
+  for k in range(nlink):
+    ax = "0 1 0" if k % 2 else "0 0 1"
+    touch = "" if (k + 1) % 3 == 0 else ' contype="0" conaffinity="0"'
+    lines.append(f'<body name="l{k + 1}" pos=".11 0 0"><joint type="hinge" axis="{ax}" range="-40 40" limited="true"/><geom type="sphere" size=".05"{touch}/>')
+  lines.append("</body>" * (nlink + 1) + "</worldbody></mujoco>")
+  return "\n".join(lines)
+
+
+@pytest.mark.parametrize("nlink", [14, 18, 22, 26])
+def test_cgp_other_widths(nlink):
+  """The instantiations of the pooled kernel the humanoid does not use: nv = 20, 24, 28, 32 (NV4 = 5 .. 8; the last two at the register
+  budget) -- a snake settling on the floor, per-step parity with the oracle through the pooled kernel and its fused Euler epilogue."""
+  mjm = mjw.mjcf.from_xml_string(_snake_xml(nlink))
+  assert mjm.nv == 6 + nlink
+  s, m, d = _pair(mjm, nworld=2, nconmax=32, njmax=64, solver=int(mjw.SolverType.CG), warm_steps=0)
+  assert m.cg_basis == 1
+  worst_q = worst_v = 0.0
+  rows = set()
+  mixed = lambda a, b: float(np.abs(np.asarray(a, dtype=np.float64) - b).max() / max(1.0, np.abs(b).max()))  # (the snake comes to rest: velocities of 1e-4)
+  with _knob(MJH_CG_KERNEL="cgp"):
+    for i in range(120):
+      _sync(s, d)
+      mjw.step(m, d)
+      s.step()
+      rows.add(int(s.nefc))
+      worst_q = max(worst_q, mixed(d.qpos.numpy()[1], s.qpos))
+      worst_v = max(worst_v, mixed(d.qvel.numpy()[1], s.qvel))
+  assert 0 < max(rows) <= 64, rows
+  assert worst_q <= 5e-6, worst_q
+  assert worst_v <= 1e-3, worst_v
+  assert ((d.overflow.numpy() & ~(512 | 1024)) == 0).all()
