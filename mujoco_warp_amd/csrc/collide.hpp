@@ -1745,24 +1745,28 @@ DEV void collision_body(const MjhModel& m, const MjhData& d, float* smem, const 
 }
 
 // ---- the three launches of the convex narrowphase (convex.hpp header) -------------------------------------------------------------------
-// ---- k_broad_mask: the broadphase FILTERS of one world per workgroup, results as a bit mask over the pair list (round 4) -------------------
+// ---- k_broad_mask: the broadphase FILTERS of one world per workgroup, results as a bit mask over the pair list (rounds 4 and 5) ---------
 // k_ccd_broad used to run the filters inside its per-world lane group: 32 lanes walking the world's whole pair list (ALOHA scene: 9,154
-// pairs, 36 trips of 256) with the candidate list and a queue in LDS -- at most 1.5 wavefronts per SIMD, 480 of the launch's 505 us.  The
-// tests of different pairs do not depend on each other and their results are ordered by the pair index alone, so they leave that kernel:
-//   * a workgroup (four wavefronts) takes one world; it stages, per geom, position | bounding radius, margin, gap and -- with the AABB filter
-//     on -- the world-aligned box (centre +- extent, the pair-independent half of _aabb_filter) in LDS, plus rotation and local box for the OBB filter: 34 words per geom;
-//   * a wavefront tests 64 consecutive pairs at a time: plane / bounding sphere, sleep state, then the box overlap as six compares;
-//   * the OBB filter (separating axes, ~250 instructions) runs on the survivors only, queued per wavefront and served 64 at a time;
-//   * the ballots of the tests are the world's mask over the pair list (in LDS), which the first wavefront expands in pair order at the end:
-//     the candidate list is the serial loop's, and the launch publishes it like k_ccd_broad does for the sweep-and-prune broadphase.
+// pairs) with the candidate list and a queue in LDS -- at most 1.5 wavefronts per SIMD, 480 of the launch's 505 us.  The tests of different
+// pairs do not depend on each other and their results are ordered by the pair index alone, so they left that kernel (round 4: every pair
+// tested, 64 per wavefront trip: 201 us).  Round 5 tests GROUPS of geoms first:
+//   * the host regroups the pair list by pairs of geom groups (io.py cull_tables: the colliding geoms among the consecutive geoms of one
+//     moving body; a static geom is its own group) into ROWS of at most 16 pairs;
+//   * a workgroup (four wavefronts) takes one world; it stages, per geom, position | bounding radius, margin, gap, with the AABB filter on the
+//     world-aligned box (centre +- extent, the pair-independent half of _aabb_filter), with the OBB filter on rotation and local box;
+//   * a lane per colliding geom measures its group's bounding sphere around the group's centre geom (LDS atomicMax on the radius bits; the
+//     radius carries a 1e-4 relative slack for the float32 sums; a group holding a plane -- rbound 0: the plane filter decides -- is open, as
+//     is every group when the sphere filter is off; rows of explicit pairs are always tested);
+//   * a lane per row tests the two group spheres; surviving rows are compacted (BMASK_ROWCHUNK rows at a time);
+//   * a quarter wavefront per surviving row, four rows in flight, runs the pair filters: plane / bounding sphere, sleep state, the box
+//     overlap as six compares; passing pairs set their bit of the world's mask (LDS atomicOr); the OBB filter (separating axes, ~250
+//     instructions) runs on the pairs that got that far, queued per wavefront and served 64 at a time;
+//   * the mask is expanded in pair order by the whole workgroup (prefix sums over its four wavefronts): the candidate list is the serial
+//     loop's, and the launch publishes it like k_ccd_broad does for the sweep-and-prune broadphase.
+// A pair whose spheres overlap lies in two groups whose spheres overlap (triangle inequality), so the mask is the one every pair's test gives.
+// ALOHA scene: 201 -> 160 us (staging 30, group spheres 4, rows 18, pair filters 76 -- two thirds of it the OBB arithmetic on the ~900 pairs
+// that pass the sphere test --, expansion 30).
 // Filters: collision_driver.py:124-275 (_aabb_filter, _obb_filter), 278-334 (_plane_filter, _sphere_filter), 494-503 (sleep).
-// Round 5, the group pre-test: the ALOHA scene's world tested 9,154 bounding-sphere pairs to keep ~30 (201 us per step at 8192 worlds, LDS reads of
-// two geoms per pair).  The host regroups the pair list by pairs of geom GROUPS (io.py cull_tables: the consecutive geoms of one moving body;
-// a static geom is its own group); a world builds one bounding sphere per group from the staged geom spheres (+ margins and gaps), tests
-// the group pairs, and runs the pair filters only on the pairs of the surviving group pairs -- flattened over the workgroup's lanes by a
-// prefix sum of their counts.  A pair whose spheres overlap lies in two groups whose spheres overlap (triangle inequality; the group
-// radius carries a 1e-4 relative slack for the float32 sums), so the mask is the one every pair's test would give.  Groups holding a plane
-// (rbound 0: the plane filter decides) are open, as is every group when the sphere filter is off; explicit pairs are always tested.
 // rows of cull_pair a workgroup takes at a time (the survivors' list in LDS is this long at most: a scene of hundreds of one-geom bodies has
 // as many rows as pairs)
 #define BMASK_ROWCHUNK 4096

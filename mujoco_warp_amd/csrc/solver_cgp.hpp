@@ -24,6 +24,9 @@
 //     16-byte words (a 36-row world: 9 reads per lane where the row loop needed 36 + 9), the basis forces arrive transposed the same
 //     way (fbT[rg][i]), two quad_perm adds fold the four row classes and lane l -- dof l -- finds its column in its own quad;
 //   * J is dead when the solve ends: the fused integrator's scratch lines alias the world's pool rows.
+//   * a wavefront whose two worlds have at most 32 rows (the driver's window of the headline rollout: free fall, first contacts) runs an
+//     instantiation of the iteration loop with ONE row per lane -- row dots, forces and line search over one slot, J^T f without the second
+//     16-row batch when both worlds are within 16 basis rows --, picked by a ballot in front of the loop.
 // Rows in the lanes: slot s = lane + 32 k (k = 0, 1).  The rows of condim-3 contacts first -- the q-th such contact owns the quad of slots
 // 4q .. 4q + 3 --, then every other row (equality, limit, frictionless contact) in efc order: a stable partition of the efc rows by
 // "pyramid row or not", computed per world from efc.type with two ballots; slotR[s] = efc row of slot s.  Basis row of slot (q, e < 3):
