@@ -84,7 +84,14 @@ def usable_cores():
 
 
 def cpu_baseline(xml, solver, budget_s=8.0, nstep=500):
-  """Oracle ("port") on the host: single-thread rate, then one independent rollout stream per usable core."""
+  """Oracle ("port") on the host: single-thread rate, then one independent rollout stream per usable core.  Compiled for this host
+  (`-O3 -march=native`) before the workers fork; the flags are part of `sample`."""
+  from oracle import ref
+
+  try:
+    flags = ref.use_native_build()
+  except Exception as e:  # (no compiler on the box: the -O2 build that travelled with the repo)
+    flags = f"prebuilt oracle/libmjref.so (-O2; native build failed: {type(e).__name__})"
   one = _cpu_worker((xml, 0, 3.0, nstep, solver))
   cores = usable_cores()
   t0 = time.perf_counter()
@@ -96,7 +103,7 @@ def cpu_baseline(xml, solver, budget_s=8.0, nstep=500):
     "value": total / max(r[1] for r in res), "unit": "env-steps/s", "cores": cores, "kind": "port",
     "single_thread": one[0] / one[1],
     "sample": f"{cores} processes x ~{budget_s:.0f}s of {nstep}-step humanoid.xml rollouts (key 0 + control noise), float64 oracle "
-              f"(restatement of the reference algorithm, NOT MuJoCo C: not installable here or on the GPU box); single-thread figure from a 3 s run; wall {wall:.1f}s",
+              f"(restatement of the reference algorithm, NOT MuJoCo C: not installable here or on the GPU box), built on this host with `{flags}`; single-thread figure from a 3 s run; wall {wall:.1f}s",
   }
 
 
@@ -249,6 +256,9 @@ def other_configs(mjw, nstep=200):
   B = os.path.join(ROOT, "benchmarks")
   entries = (
     dict(name="unitree_g1_flat", xml=os.path.join(B, "unitree_g1", "scene_flat.xml"), nworld=4096, nconmax=48, njmax=192, replay=os.path.join(B, "unitree_g1", "shuffle_dance.npz")),
+    dict(name="humanoid_shard", xml=os.path.join(B, "humanoid", "humanoid.xml"), nworld=1024, nconmax=24, njmax=64, override=["opt.solver=cg"], lead=300, launch_us=True,
+         note="the headline under STRONG scaling: 8192 worlds over 8 GPUs = 1024 each (`solver_kernel` names the CG mapping the dispatch picks at this size); "
+              "8 x this figure is the single-GPU lower bound of an 8-GPU strong-scaling run"),
     dict(name="franka_emika_panda", xml=os.path.join(B, "franka_emika_panda", "scene.xml"), nworld=8192, nconmax=1, njmax=5),
     dict(name="franka_emika_panda_shard", xml=os.path.join(B, "franka_emika_panda", "scene.xml"), nworld=1024, nconmax=1, njmax=5,
          note="configs[3] per GPU: 8192 worlds over 8 GPUs = 1024 each -- a quarter of the device's wavefront slots, the step is launch latency"),
@@ -307,7 +317,7 @@ def _config_run(mjw, torch, e, nstep, lead):
                      + (f", nvmax={e['nvmax']}" if e.get("nvmax") else "") + (f", {' '.join(e['override'])}" if e.get("override") else "")
                      + (", init_asleep" if e.get("init_asleep") else "") + ", solver / integrator / cone / iteration caps as authored"
                      + (f", initial state and control centre from {os.path.basename(e['replay'])} + noise" if e.get("replay") else ", control noise"),
-         "nv": int(mjm.nv), "ngeom": int(mjm.ngeom), "solver": ["PGS", "CG", "NEWTON"][int(mjm.opt.solver)], "cone": ["pyramidal", "elliptic"][int(mjm.opt.cone)],
+         "nv": int(mjm.nv), "ngeom": int(mjm.ngeom), "solver": ["PGS", "CG", "NEWTON"][int(mjm.opt.solver)], "solver_kernel": mjw.solver_kernel(m, d), "cone": ["pyramidal", "elliptic"][int(mjm.opt.cone)],
          "value": e["nworld"] * nstep / total, "unit": "env-steps/s", "nstep": nstep, "ms_per_step": 1e3 * total / nstep,
          "ncon_mean": ncon / max(nstat, 1), "nefc_mean": nefc / max(nstat, 1), "solver_niter_mean": niter / max(nstat, 1),
          "finite": ok, "overflow_bits": ovf, "iteration_cap_worlds": int(((d.overflow.numpy() >> 9) & 1).sum()),
@@ -318,6 +328,9 @@ def _config_run(mjw, torch, e, nstep, lead):
   if int(mjm.opt.solver) != 0 and not (int(mjm.opt.enableflags) & int(mjw.EnableBit.SLEEP)) and not e.get("replay") and not e.get("hold_key_ctrl"):  # (timed_steps: fused launch sequence, noise around the ctrl-range midpoint -- the same workload only without a replayed / held control centre)
     ms_b2b, _ = mjw.timed_steps(m, d, nstep, step0=lead + nstep)
     res["back_to_back_value"] = e["nworld"] * nstep / (ms_b2b * 1e-3)
+    if e.get("launch_us"):
+      _, pk = mjw.timed_steps(m, d, 50, step0=lead + 2 * nstep, per_kernel=True)
+      res["fused_launch_us"] = {n: 1e3 * t / 50 for n, t in zip(mjw.KERNEL_NAMES, pk) if t > 0}
   del d
   return res
 
@@ -334,7 +347,7 @@ def main():
   ap.add_argument("--no-roofline", action="store_true")
   ap.add_argument("--no-steady", action="store_true", help="skip the 1000-step reference-placement figure")
   ap.add_argument("--pmc-profile", default="auto", help="rocprofv3 PMC summary (tools/make_pmc_summary.py) of this solver's kernel; "
-                  "auto = the committed profiles/round3_pmc_<solver>.json (labelled as such in traffic_source), none = null")
+                  "auto = the newest committed profiles/round<N>_pmc_<solver>_<early|steady>.json whose window matches --warmup (labelled as such in traffic_source), none = null")
   ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configs (G1 4096 worlds, Panda 8192, aloha_pot 8192, clutter_synth 2048 Newton + PGS)")
   args = ap.parse_args()
   if args.gpus < 1:
@@ -418,7 +431,7 @@ def main():
     achieved = 4 * words_solve * nworld / t_dom / 1e9
     traffic, traffic_src = _traffic_from_profile(args.pmc_profile, args.solver, _window_of(args.warmup))
     out["roofline"] = {"kernel": {"pgs": "k_solve_pgs", "cg": "k_solve_cgp_plus (pooled contact-basis CG + L'DL-factor / publication riders)",
-                                  "newton": "k_solve_plus<NEWTON>"}[args.solver], "bound": "hbm",
+                                  "newton": "k_solve_plus<NEWTON>"}[args.solver], "solver_kernel": mjw.solver_kernel(m, d), "bound": "hbm",
                        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                        "traffic": traffic, "traffic_source": traffic_src, "bytes_per_launch": 4 * words_solve * nworld,
                        "us_per_launch": fused_us["solve"],
@@ -481,7 +494,7 @@ def main():
 def _committed_profile(solver, window="steady"):
   """The committed rocprofv3 PMC summary of this solver's workload whose WINDOW of the rollout matches the timed one: "early" = the
   driver's --warmup 5 window (free fall and first contacts, nefc ~12), "steady" = steps 300+ (the humanoid on the floor, nefc ~45)."""
-  for r in ("round5", "round4"):
+  for r in ("round6", "round5", "round4"):
     for name in (f"{r}_pmc_{solver}_{window}.json", f"{r}_pmc_{solver}.json"):
       p = os.path.join(ROOT, "profiles", name)
       if os.path.exists(p):

@@ -21,18 +21,37 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 
 
-def discover():
+def discover(registry=HERE):
   out = []
-  for entry in sorted(os.listdir(HERE)):
-    init = os.path.join(HERE, entry, "__init__.py")
+  for entry in sorted(os.listdir(registry)):
+    init = os.path.join(registry, entry, "__init__.py")
     if not os.path.isfile(init):
       continue
     spec = importlib.util.spec_from_file_location(f"_bench_{entry}", init)
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     for b in getattr(mod, "BENCHMARKS", []):
-      out.append((os.path.join(HERE, entry), dict(b)))
+      out.append((os.path.join(registry, entry), dict(b)))
   return out
+
+
+def command(folder, b, nstep=None):
+  """The testspeed command of one registry entry -- the reference's rule (benchmarks/run.py:128-149): fixed flags, `replay` resolved against
+  the benchmark's folder, EVERY other field forwarded as --field=value (a list: once per item), so that an entry written for the reference runs
+  unchanged.  Fields of the reference's registry that configure things outside the hot path (`assets`: git checkouts; `note`) are not flags."""
+  cmd = [sys.executable, "-m", "mujoco_warp_amd.testspeed", os.path.join(folder, b["mjcf"]), "--clear_warp_cache=false", "--format=short",
+         "--event_trace=true", "--memory=true", "--measure_solver=true", "--measure_alloc=true"]
+  for field, value in b.items():
+    if field == "replay":
+      cmd.append("--replay=" + os.path.join(folder, value))
+    elif field == "nstep" and nstep is not None:
+      continue
+    elif field not in ("name", "assets", "mjcf", "_dir", "note"):
+      for item in (value if isinstance(value, (list, tuple)) else [value]):
+        cmd.append(f"--{field}={item}")
+  if nstep is not None:
+    cmd.append(f"--nstep={nstep}")
+  return cmd
 
 
 def main():
@@ -40,30 +59,16 @@ def main():
   ap.add_argument("-f", "--filter", default=".*", help="regex on benchmark names")
   ap.add_argument("--nstep", type=int, default=None)
   ap.add_argument("--list", action="store_true")
+  ap.add_argument("--registry", default=HERE, help="directory of benchmark folders (default: this one); a copy of the reference's benchmarks/ works as it is")
   args = ap.parse_args()
   rc = 0
-  for folder, b in discover():
+  for folder, b in discover(args.registry):
     if not re.search(args.filter, b["name"]):
       continue
     if args.list:
       print(b["name"], b)
       continue
-    cmd = [sys.executable, "-m", "mujoco_warp_amd.testspeed", os.path.join(folder, b["mjcf"]), f"--nworld={b['nworld']}",
-           f"--nconmax={b['nconmax']}", f"--njmax={b['njmax']}", "--format=short", "--event_trace=true", "--measure_alloc=true",
-           "--measure_solver=true"]
-    nstep = args.nstep if args.nstep is not None else b.get("nstep")
-    if nstep is not None:
-      cmd.append(f"--nstep={nstep}")
-    for key in ("nvmax", "nccdmax"):
-      if b.get(key) is not None:
-        cmd.append(f"--{key}={b[key]}")
-    if b.get("init_asleep"):
-      cmd.append("--init_asleep=true")
-    if b.get("replay"):
-      cmd.append("--replay=" + os.path.join(folder, b["replay"]))
-    for o in b.get("override", []):
-      cmd += ["-o", o]
-    p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True)
+    p = subprocess.run(command(folder, b, args.nstep), cwd=ROOT, capture_output=True, text=True)
     if p.returncode != 0:
       print(f"{b['name']}.error {p.stderr.strip().splitlines()[-1] if p.stderr.strip() else 'failed'}")
       rc = 1

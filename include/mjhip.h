@@ -373,7 +373,17 @@ int mjh_timed_steps(const MjhModel* m, const MjhData* d, int nstep, int step0, f
 int mjh_release_thread_resources(void);
 
 const char* mjh_last_error(void);
-#define MJH_ABI_VERSION 42
+/* Developer knobs -- the ONE test hook.  The library snapshots the MJH_* environment variables once, when it is loaded, and never calls getenv on a
+ * launch path; this call sets (value != NULL) or clears (NULL) an entry of that snapshot afterwards, e.g. mjh_dev_knob("MJH_CG_KERNEL", "pair") to run
+ * the two-worlds-per-wavefront CG kernel where the dispatch would pick the pooled one.  Knobs select between kernels / launch shapes that all pass the
+ * parity suite; none skips work.  Knobs cached at first use (most of them: see csrc) keep their first value.  Not to be called while another
+ * thread is inside a mjh_* call.  Host only. */
+int mjh_dev_knob(const char* name, const char* value);
+/* Name of the solver mapping the dispatch picks for (m, d) in a fused step -- "cgp" (pooled contact-basis CG, csrc/solver_cgp.hpp), "cgw" (one world per
+ * wavefront), "pair" (k_solve<cg>), "newton_mfma", "newton32", "cg64", "newton64", "*_ell", "tree+big", "big", "pgs", "pgs_big", "unsupported" -- so that a
+ * test or a bench line can say which kernel it measured without a knob.  Static string; host only; launches nothing. */
+const char* mjh_solver_kernel(const MjhModel* m, const MjhData* d);
+#define MJH_ABI_VERSION 43
 /* floats of Data.ws_ccd for a model with GJK pairs (csrc/convex.hpp ccd_layout: per world the candidate list, the per-candidate result cache and the
    broadphase mask; then the counters, the convex-pair mask and the EPA hand-over records) -- what a binding that allocates Data itself must
    provide; iterations = max(ccd_iterations, epa_iterations), concap = Data.concap.  Also returns the default Data.nccdhand through *nccdhand_out

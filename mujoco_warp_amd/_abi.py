@@ -252,8 +252,11 @@ def lib():
                                 ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), ctypes.c_int]
   L.mjh_last_error.restype = ctypes.c_char_p
   L.mjh_build_id.restype = ctypes.c_char_p
+  L.mjh_dev_knob.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
+  L.mjh_solver_kernel.argtypes = [mp, dp]
+  L.mjh_solver_kernel.restype = ctypes.c_char_p
   for f in FUNCTIONS:
-    if f not in ("mjh_last_error", "mjh_build_id"):
+    if f not in ("mjh_last_error", "mjh_build_id", "mjh_solver_kernel"):
       getattr(L, f).restype = ctypes.c_int
   import atexit
 
@@ -264,6 +267,28 @@ def lib():
 
 class EngineError(RuntimeError):
   pass
+
+
+def set_knob(name, value):
+  """The library's one test hook (mjh_dev_knob, include/mjhip.h): set (str / int) or clear (None) a developer knob of the loaded library.  The
+  library never reads the environment after it was loaded, so os.environ has no effect on a running process."""
+  check(lib().mjh_dev_knob(name.encode(), None if value is None else str(value).encode()))
+
+
+class dev_knobs:
+  """with dev_knobs(MJH_CG_KERNEL="pair"): ...  -- knobs set for the block (tests, A/B tools), cleared afterwards."""
+
+  def __init__(self, **kv):
+    self.kv = kv
+
+  def __enter__(self):
+    for k, v in self.kv.items():
+      set_knob(k, v)
+    return self
+
+  def __exit__(self, *a):
+    for k in self.kv:
+      set_knob(k, None)
 
 
 def check(rc):

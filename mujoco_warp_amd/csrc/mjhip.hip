@@ -34,6 +34,40 @@ int mjh_fail(int code, const char* fmt, const char* a) {
   return code;
 }
 
+// ---- developer knobs: a table filled ONCE from the environment when the library is loaded; mjh_dev_knob overrides entries (host.hpp) ----
+#include <atomic>
+#include <map>
+#include <string>
+extern char** environ;
+namespace {
+struct KnobTable {
+  std::mutex mu;
+  std::map<std::string, std::string> kv;  // (node-based: a value's storage does not move when other keys are added)
+  std::atomic<int> n{0};
+  KnobTable() {
+    for (char** e = environ; e && *e; ++e) {
+      if (strncmp(*e, "MJH_", 4) != 0) continue;
+      const char* eq = strchr(*e, '=');
+      if (eq) kv[std::string(*e, eq - *e)] = std::string(eq + 1);
+    }
+    n.store((int)kv.size());
+  }
+};
+KnobTable& knobs() {
+  static KnobTable t;  // (constructed at first use or by the initialiser below, whichever comes first: before any launch)
+  return t;
+}
+struct KnobInit {
+  KnobInit() { knobs(); }
+} g_knob_init;  // library load
+}  // namespace
+const char* mjh_knob(const char* name) {
+  KnobTable& t = knobs();
+  if (t.n.load(std::memory_order_acquire) == 0) return nullptr;  // the product path: no knob set, no lock, no lookup
+  std::lock_guard<std::mutex> lock(t.mu);
+  auto it = t.kv.find(name);
+  return it == t.kv.end() ? nullptr : it->second.c_str();
+}
 #define TRY(x)               \
   do {                       \
     int rc_ = (x);           \
@@ -42,7 +76,7 @@ int mjh_fail(int code, const char* fmt, const char* a) {
 
 // pick threads per block in {256,128,64} maximising resident worlds per CU for the given LDS needs
 int pick_block(size_t shared_bytes, size_t per_world_bytes, int G, size_t* lds_out, bool prefer_small_arg) {
-  static const int small_env = getenv("MJH_SMALL_BLOCKS") ? atoi(getenv("MJH_SMALL_BLOCKS")) : -1;  // developer knob
+  static const int small_env = mjh_knob("MJH_SMALL_BLOCKS") ? atoi(mjh_knob("MJH_SMALL_BLOCKS")) : -1;  // developer knob
   const bool prefer_small = small_env >= 0 ? (small_env != 0) : prefer_small_arg;
   int best = 0, best_worlds = -1;
   // ties go to the first candidate: large blocks amortise the block-shared tables, small blocks retire as soon as
@@ -71,7 +105,7 @@ int pick_block(size_t shared_bytes, size_t per_world_bytes, int G, size_t* lds_o
 // and bodies, 64 beyond (round 3): these kernels are chains of dependent steps whose loops stride over dofs / bodies / geoms by the
 // group size, so a model that needs two trips with 32 lanes needs one with 64 (three humanoids, nv 81: k_mid 690 -> 518 us, step + 22 %).
 static inline bool lanes64(const MjhModel* m) {
-  static const int force = getenv("MJH_LANES") ? atoi(getenv("MJH_LANES")) : 0;  // developer knob: 32 / 64
+  static const int force = mjh_knob("MJH_LANES") ? atoi(mjh_knob("MJH_LANES")) : 0;  // developer knob: 32 / 64
   if (force) return force == 64;
   // (models with GJK / EPA pairs stay at 32: Data.ws_ccd holds one polytope workspace per lane of a 32-lane group)
   return (m->nv > 32 || m->nbody > 32) && !m->heavy_colliders;
@@ -81,8 +115,8 @@ static inline bool lanes64(const MjhModel* m) {
 // (- 8.7 %).  Not for larger models (humanoid, 27 dofs on 17 bodies, forced with MJH_LANES16_ANY: k_mid 84 -> 101 us -- every loop needs two
 // trips) and not for k_fwd_pos (Panda 48.0 vs 49.1 us: its chain is the tree depth whatever the lane count; MJH_LANES16_POS turns it on).
 static inline bool lanes16(const MjhModel* m) {
-  static const int force = getenv("MJH_LANES") ? atoi(getenv("MJH_LANES")) : 0;  // developer knob: 16 / 32 / 64
-  static const bool any = getenv("MJH_LANES16_ANY") != nullptr;
+  static const int force = mjh_knob("MJH_LANES") ? atoi(mjh_knob("MJH_LANES")) : 0;  // developer knob: 16 / 32 / 64
+  static const bool any = mjh_knob("MJH_LANES16_ANY") != nullptr;
   if (force && force != 16) return false;
   return ((m->nv <= 16 && m->nbody <= 16) || (force == 16 && any)) && !m->heavy_colliders;
 }
@@ -150,8 +184,8 @@ static int launch_ccd_pre(const MjhModel* m, const MjhData* d, hipStream_t s) {
   {
     // lanes per pair by the length of the list (read on the device): one lane per pair needs >= 2 wavefronts per SIMD to hide its chains of
     // dependent table loads; shorter lists give a pair 8 or 32 lanes (MJH_GJK_LANES: developer knob, forces one instantiation)
-    static const int force = getenv("MJH_GJK_LANES") ? atoi(getenv("MJH_GJK_LANES")) : 0;
-    static const int t8_env = getenv("MJH_GJK_T8") ? atoi(getenv("MJH_GJK_T8")) : 16384, t1_env = getenv("MJH_GJK_T1") ? atoi(getenv("MJH_GJK_T1")) : 131072;  // developer knobs
+    static const int force = mjh_knob("MJH_GJK_LANES") ? atoi(mjh_knob("MJH_GJK_LANES")) : 0;
+    static const int t8_env = mjh_knob("MJH_GJK_T8") ? atoi(mjh_knob("MJH_GJK_T8")) : 16384, t1_env = mjh_knob("MJH_GJK_T1") ? atoi(mjh_knob("MJH_GJK_T1")) : 131072;  // developer knobs
     const int all = 0x7fffffff, t8 = force ? (force == 32 ? all : 0) : t8_env, t1 = force ? (force == 1 ? 0 : all) : std::max(t1_env, t8_env);
     const long long cap = (long long)d->nworld * CL.ccap;  // work items at most
     const int grid1 = (int)std::min<long long>((cap + 255) / 256, 2048);
@@ -161,7 +195,7 @@ static int launch_ccd_pre(const MjhModel* m, const MjhData* d, hipStream_t s) {
   }
   // lane groups per workgroup: a group's LDS (polytope + the multi-contact polygon buffers: 11.7 KB on the ALOHA scene) decides how many are
   // resident on a CU -- eight groups in one 256-thread workgroup leave room for ONE workgroup there; smaller workgroups pack the LDS
-  static const int epa_threads = getenv("MJH_EPA_THREADS") ? atoi(getenv("MJH_EPA_THREADS")) : 256;  // developer knob
+  static const int epa_threads = mjh_knob("MJH_EPA_THREADS") ? atoi(mjh_knob("MJH_EPA_THREADS")) : 256;  // developer knob
   const size_t group_bytes = sizeof(float) * (size_t)ccd_coop_words(it, m->npolygonmax, m->nmeshdegmax);
   int gpb = std::max(epa_threads / G, 1);
   while (gpb > 1 && group_bytes * gpb > (size_t)kLdsPerCU) gpb >>= 1;  // (a mesh vertex of very high degree: long feature lists per group)
@@ -365,7 +399,7 @@ static int launch_mid_g(const MjhModel* m, const MjhData* d, bool sched, hipStre
     else --nw_v;
   }
   if (nw_v < 1) nw_v = 1;
-  if (const char* e = getenv("MJH_MID_W")) {  // tuning knob (developer only): worlds per workgroup of both roles
+  if (const char* e = mjh_knob("MJH_MID_W")) {  // tuning knob (developer only): worlds per workgroup of both roles
     nw_cc = nw_v = atoi(e);
     lds = sizeof(float) * stride_cc * nw_cc;
   }
@@ -413,7 +447,7 @@ struct Aux {
 static thread_local Aux* g_aux_per_dev[16] = {nullptr};
 static thread_local bool g_serial_solver = false;  // set while per-kernel instrumentation is on (one stream, one event pair per launch)
 static Aux* aux_streams() {
-  static const bool disabled = getenv("MJH_NO_AUX") != nullptr;  // developer knob
+  static const bool disabled = mjh_knob("MJH_NO_AUX") != nullptr;  // developer knob
   if (disabled || g_serial_solver) return nullptr;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
@@ -437,11 +471,35 @@ static Aux* aux_streams() {
 // above 16 dofs.  Applies exactly when launch_solve_32_newton picks the MFMA kernel.  MJH_NEWTON_RIDERS=0 / 1 forces it off / on (developer knob).
 static thread_local bool g_newton_inline = false;
 static bool newton_inline_ok(const MjhModel* m, const MjhData* d) {
-  static const int force = getenv("MJH_NEWTON_RIDERS") ? atoi(getenv("MJH_NEWTON_RIDERS")) : -1;
-  static const bool old_path = getenv("MJH_OLD_NEWTON") != nullptr;
+  static const int force = mjh_knob("MJH_NEWTON_RIDERS") ? atoi(mjh_knob("MJH_NEWTON_RIDERS")) : -1;
+  static const bool old_path = mjh_knob("MJH_OLD_NEWTON") != nullptr;
   const bool ell = m->cone == CONE_ELLIPTIC && d->nmaxpyramid > 1;
   const bool want = force >= 0 ? force != 0 : m->nv <= 16;
   return want && !old_path && m->solver == SOL_NEWTON && !ell && m->nv <= 32 && d->njmax <= 64 && (double)d->nworld * std::max(m->nv, d->njmax) * 4.0 < 4.0e9;
+}
+// Which CG kernel serves the class nv <= 32, pyramidal cones (the ONE place that decides; mjh_solver_kernel reports it).
+//   CG32_CGW  one world per wavefront (solver_cgw.hpp): SMALL batches.  A solve is a dependent chain of ~17 k instructions per wavefront of which
+//             the line search's per-wavefront bookkeeping is the bulk, so pairing two worlds in a wavefront halves the instruction count per world
+//             and wins whenever the SIMDs are issue bound (measured, humanoid: 8192 worlds 194 us one-per-wavefront vs 193 paired, 141 M vs 81 M
+//             VALU instructions); with at most ~3 wavefronts per SIMD the chain's latency decides instead and the shorter chain of the unpaired
+//             kernel wins (1024 worlds: 88 vs 112 us, 2048: 103 vs 120, 3072: 122 vs 124)
+//   CG32_CGP  the pooled contact-basis kernel (solver_cgp.hpp): larger batches of models whose contacts are condim 1 / 3 and that have no
+//             friction-loss rows (MjhModel.cg_basis), njmax <= 64
+//   CG32_PAIR k_solve<cg> (solver.hpp): everything else
+// MJH_CG_KERNEL = cgp / pair / cgw (developer knob; tests set it through mjh_dev_knob) forces one of the three where it applies.
+enum { CG32_PAIR = 0, CG32_CGW = 1, CG32_CGP = 2 };
+static int cg32_choice(const MjhModel* m, const MjhData* d, int fe) {
+  const bool newton = m->solver == SOL_NEWTON, ell = m->cone == CONE_ELLIPTIC && d->nmaxpyramid > 1;
+  if (newton || ell || m->solver == SOL_PGS || m->nv > 32) return CG32_PAIR;
+  static const int wide_min_nv = mjh_knob("MJH_CGW_MIN_NV") ? atoi(mjh_knob("MJH_CGW_MIN_NV")) : 13;
+  static const int wide_max_nworld = mjh_knob("MJH_CGW_MAX_NWORLD") ? atoi(mjh_knob("MJH_CGW_MAX_NWORLD")) : 3072;
+  const bool wide = m->nv >= wide_min_nv && d->nworld <= wide_max_nworld && fe != 2;  // (its half rows of M do not serve the fused implicitfast update)
+  const bool cgp_can = m->cg_basis && d->njmax <= 64 && m->nv >= 1;
+  const char* force = mjh_knob("MJH_CG_KERNEL");
+  if (force && !strcmp(force, "cgw")) return fe != 2 ? CG32_CGW : CG32_PAIR;
+  if (force && !strcmp(force, "pair")) return CG32_PAIR;
+  if (force && !strcmp(force, "cgp")) return cgp_can ? CG32_CGP : CG32_PAIR;
+  return wide ? CG32_CGW : (cgp_can ? CG32_CGP : CG32_PAIR);
 }
 static int launch_solve_any(const MjhModel* m, const MjhData* d, bool with_factor, hipStream_t s) {
   if (int rc = solve_supported(m, d)) return rc;
@@ -487,14 +545,8 @@ static int launch_solve_any(const MjhModel* m, const MjhData* d, bool with_facto
   // solver, which keeps J in HBM and is generic in njmax
   const int top = d->njmax > 192 ? 192 : all;
   if (m->nv <= 32) {
-    // CG, pyramidal, SMALL batches: one world per wavefront (solver_cgw.hpp).  A solve is a dependent chain of ~17 k instructions per
-    // wavefront of which the line search's per-wavefront bookkeeping is the bulk, so pairing two worlds in a wavefront (solve_body)
-    // halves the instruction count per world and wins whenever the SIMDs are issue bound (measured, humanoid: 8192 worlds 194 us
-    // one-per-wavefront vs 193 paired, 141 M vs 81 M VALU instructions); with at most ~3 wavefronts per SIMD the chain's latency
-    // decides instead and the shorter chain of the unpaired kernel wins (1024 worlds: 88 vs 112 us, 2048: 103 vs 120, 3072: 122 vs 124)
-    static const int wide_min_nv = getenv("MJH_CGW_MIN_NV") ? atoi(getenv("MJH_CGW_MIN_NV")) : 13;
-    static const int wide_max_nworld = getenv("MJH_CGW_MAX_NWORLD") ? atoi(getenv("MJH_CGW_MAX_NWORLD")) : 3072;
-    const bool wide = !newton && !ell && m->nv >= wide_min_nv && d->nworld <= wide_max_nworld && fe != 2;  // (its half rows of M do not serve the fused implicitfast update)
+    const int cgk = cg32_choice(m, d, fe);  // (above)
+    const bool wide_f = cgk == CG32_CGW, cgp = cgk == CG32_CGP;
     // rows per lane (32 lanes per world): 1 covers 32 rows, 2 covers 64 rows (humanoid, panda), 6 covers 192.  Newton with elliptic cones has
     // a one-row instantiation for the worlds of at most 32 rows (the ALOHA scene: nefc 24 on average, 27 at the 95th percentile): 155 instead
     // of 191 VGPRs and 6.7 instead of 12.2 KB of LDS per world -- 2.9 instead of 1.6 wavefronts per SIMD -- and half the row work per lane:
@@ -503,25 +555,19 @@ static int launch_solve_any(const MjhModel* m, const MjhData* d, bool with_facto
     // 4.95 vs 5.97 M env-steps/s, the fork / join hops inside the step's graph).  (The same for CG with pyramidal cones was built and
     // measured on the humanoid -- bit-identical results, but no gain: behind one another 0.471 vs 0.369 ms per step at nefc 46 where a
     // quarter of the worlds are in the small class; side by side 0.370 vs 0.372 ms there and 0.349 vs 0.329 ms at nefc 32.  Not kept.)
-    static const bool r1_on = !getenv("MJH_SOLVE_R1") || atoi(getenv("MJH_SOLVE_R1")) != 0;
+    static const bool r1_on = !mjh_knob("MJH_SOLVE_R1") || atoi(mjh_knob("MJH_SOLVE_R1")) != 0;
     const bool r1 = r1_on && newton && ell && d->njmax > 32;
     int lo2 = -1;
     if (r1) {
       if (int rc = launch_solve_32_newton_ell_r1(m, d, false, fe, s, -1, 32)) return rc;
       lo2 = 32;
     }
-    // CG, pyramidal, every contact condim 3, njmax <= 64 (the headline class): contact-basis rows in one row pool per workgroup, three
-    // wavefronts per SIMD (solver_cgp.hpp); the worlds it flags (friction-loss rows, a contact cut by njmax, a pool overflow) are solved by
-    // k_solve<cg> in the launch behind it, which is empty in the common case.  MJH_CG_KERNEL (developer knob, read at every call so that one
-    // process can compare the kernels): "cgp" / "pair" / "cgw" force one of the three CG kernels where it applies.
-    const char* force = getenv("MJH_CG_KERNEL");
-    const bool cgp_can = !newton && !ell && m->cg_basis && d->njmax <= 64 && m->nv >= 1;
-    const bool wide_f = force && !strcmp(force, "cgw") ? (!newton && !ell && fe != 2) : (force && (!strcmp(force, "cgp") || !strcmp(force, "pair")) ? false : wide);
-    const bool cgp = cgp_can && !wide_f && !(force && !strcmp(force, "pair")) && !(force && !strcmp(force, "cgw"));
+    // CG, pyramidal, contacts of condim 1 / 3, njmax <= 64 (the headline class): contact-basis rows in one row pool per workgroup, three
+    // wavefronts per SIMD (solver_cgp.hpp); the worlds it flags (a contact cut by njmax, a pool overflow) are solved by k_solve<cg> in the
+    // launch behind it, which is empty in the common case.
     if (cgp) {
       if (int rc = launch_solve_cgp(m, d, with_factor, fe, s)) return rc;
-      static const bool no_fallback = getenv("MJH_CGP_NO_FALLBACK") != nullptr;  // developer knob (timing only: flagged worlds stay unsolved)
-      return no_fallback ? MJH_OK : launch_solve_32_cg_deferred(m, d, fe, s);
+      return launch_solve_32_cg_deferred(m, d, fe, s);
     }
     auto rest = [&, wide = wide_f]() -> int {
       if (d->njmax <= 64) return wide ? launch_solve_cgw(m, d, with_factor, fe, s, -1, all) : s32(m, d, 2, with_factor, fe, s, lo2, all);
@@ -538,7 +584,7 @@ static int launch_solve_any(const MjhModel* m, const MjhData* d, bool with_facto
   // (developer knob MJH_SOLVE64_R1=1: the worlds of at most 64 rows by the one-row instantiation -- half the J tile -- in a launch of their own.
   // Measured on the G1 replay, 4096 worlds, nefc 68 on average: bit-identical states, 7.84 vs 9.14 M env-steps/s -- a second launch with real
   // worlds costs the latency of one more solve.  Off.)
-  static const bool r1_64 = getenv("MJH_SOLVE64_R1") && atoi(getenv("MJH_SOLVE64_R1")) != 0;
+  static const bool r1_64 = mjh_knob("MJH_SOLVE64_R1") && atoi(mjh_knob("MJH_SOLVE64_R1")) != 0;
   int lo64 = -1;
   if (r1_64) {
     if (int rc = s64(m, d, 1, false, fe, s, -1, 64)) return rc;
@@ -551,6 +597,22 @@ static int launch_solve_any(const MjhModel* m, const MjhData* d, bool with_facto
 }
 static int launch_solve(const MjhModel* m, const MjhData* d, hipStream_t s) { return launch_solve_any(m, d, false, s); }
 static int launch_solve_plus(const MjhModel* m, const MjhData* d, hipStream_t s) { return launch_solve_any(m, d, true, s); }
+// name of the solver mapping launch_solve_any picks for (m, d) in a fused step -- the decision functions above, nothing launched
+static const char* solver_kernel_name(const MjhModel* m, const MjhData* d) {
+  if (solve_supported(m, d)) return "unsupported";
+  if (m->solver == SOL_PGS) return m->nv > 64 || (m->cone == CONE_ELLIPTIC && d->nmaxpyramid > 1) ? "pgs_big" : "pgs";
+  if (m->nv > 64) return m->tree_solve ? "tree+big" : "big";
+  const bool newton = m->solver == SOL_NEWTON, ell = m->cone == CONE_ELLIPTIC && d->nmaxpyramid > 1;
+  if (m->nv > 32) return newton ? (ell ? "newton64_ell" : "newton64") : (ell ? "cg64_ell" : "cg64");
+  if (newton) return ell ? "newton32_ell" : (d->njmax <= 64 ? "newton_mfma" : "newton32");
+  if (ell) return "cg32_ell";
+  const int fe = (m->integrator == INT_EULER || m->integrator == INT_IMPLICITFAST) ? 1 : 0;  // (only fe == 2 changes the choice, and only for cgw)
+  switch (cg32_choice(m, d, fe)) {
+    case CG32_CGW: return "cgw";
+    case CG32_CGP: return "cgp";
+    default: return "pair";
+  }
+}
 // integrator (optional) + publication of the contact arrays + solver schedule
 template <int G>
 static int launch_integrate_plus_g(const MjhModel* m, const MjhData* d, int mode, bool integrate, hipStream_t s) {
@@ -587,7 +649,7 @@ static int launch_pos_plus_g(const MjhModel* m, const MjhData* d, int first, int
   // whichever launch carried it -- fused k_fwd_pos 48 us against 39 us without it); with its loads in one batch (integrate.hpp schedule_body) it
   // costs this launch 2 us.  Same box, steady state / first steps, ms per step: here 0.2914 / 0.2698, as k_mid's last workgroup 0.2902 / 0.2745
   // (MJH_SCHED_IN_MID=1, developer knob).
-  static const bool sched_mid = getenv("MJH_SCHED_IN_MID") != nullptr;
+  static const bool sched_mid = mjh_knob("MJH_SCHED_IN_MID") != nullptr;
   *sched_done = threads >= 128 && !sched_mid;
   if (threads < 128) {
     if (noise.n) hipLaunchKernelGGL(k_ctrl_noise, dim3((noise.n + 255) / 256), dim3(256), 0, s, *m, *d, noise.center, noise.step, noise.noise_std, noise.noise_rate);
@@ -601,7 +663,7 @@ static int launch_pos_plus_g(const MjhModel* m, const MjhData* d, int first, int
   hipLaunchKernelGGL(k_fwd_pos_plus<G>, dim3(npos + 1 + nnoise), dim3(threads), lds, s, *m, *d, first, last, npos, noise);
   return MJH_OK;
 }
-static int launch_pos_plus(const MjhModel* m, const MjhData* d, int first, int last, bool* sched_done, hipStream_t s) { static const bool pos16 = getenv("MJH_LANES16_POS") != nullptr; return lanes16(m) && pos16 ? launch_pos_plus_g<16>(m, d, first, last, sched_done, s) : lanes64(m) && m->nbody > 32 ? launch_pos_plus_g<64>(m, d, first, last, sched_done, s) : launch_pos_plus_g<32>(m, d, first, last, sched_done, s); }
+static int launch_pos_plus(const MjhModel* m, const MjhData* d, int first, int last, bool* sched_done, hipStream_t s) { static const bool pos16 = mjh_knob("MJH_LANES16_POS") != nullptr; return lanes16(m) && pos16 ? launch_pos_plus_g<16>(m, d, first, last, sched_done, s) : lanes64(m) && m->nbody > 32 ? launch_pos_plus_g<64>(m, d, first, last, sched_done, s) : launch_pos_plus_g<32>(m, d, first, last, sched_done, s); }
 
 
 static int check(const MjhModel* m, const MjhData* d) {
@@ -665,7 +727,7 @@ struct Side {
 static thread_local Side* g_side_per_dev[16] = {nullptr};
 static Side* side_stream() {
   Side** per_dev = g_side_per_dev;
-  static const bool disabled = getenv("MJH_NO_SIDE") != nullptr;  // developer knob
+  static const bool disabled = mjh_knob("MJH_NO_SIDE") != nullptr;  // developer knob
   if (disabled) return nullptr;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
@@ -676,7 +738,7 @@ static Side* side_stream() {
     // developer knob (A/B): "high" / "normal"; default: the lowest priority.  Measured (round 3, two interleaved triples on one box): no
     // difference (0.2810 / 0.2803 / 0.2805 ms per Newton step) -- queue priority does not arbitrate CU slots.  The riders still end ~20 us
     // after the solver (rocprofv3 timeline, profiles/round3_newton_summary.json): their workgroups only get slots as the solver's retire
-    const char* pe = getenv("MJH_SIDE_PRIO");
+    const char* pe = mjh_knob("MJH_SIDE_PRIO");
     const int prio = pe && pe[0] == 'h' ? greatest : (pe && pe[0] == 'n' ? 0 : least);
     if (hipStreamCreateWithPriority(&sd->stream, hipStreamNonBlocking, prio) != hipSuccess ||
         hipEventCreateWithFlags(&sd->fork, hipEventDisableTiming) != hipSuccess ||
@@ -829,7 +891,7 @@ static int run_stage(const MjhModel* m, const MjhData* d, int stage, hipStream_t
         return run_stage(m, d, MJH_STAGE_RUNGEKUTTA4, s);
       }
       const int mode = m->integrator == INT_IMPLICITFAST ? 1 : (m->integrator == INT_IMPLICIT ? 2 : 0);
-      static const bool plain = getenv("MJH_PLAIN") != nullptr;  // developer knob: one plain kernel per stage, serial
+      static const bool plain = mjh_knob("MJH_PLAIN") != nullptr;  // developer knob: one plain kernel per stage, serial
       if ((g_instr && g_instr->on && g_instr->plain) || plain) {
         // profiling pass: one plain kernel per stage, so that the event pairs time one kernel at a time
         { Scope sc(K_OTHER); hipLaunchKernelGGL(k_schedule_worlds, dim3(1), dim3(1024), 0, s, *d, m->nv > 32 ? 64 : ((m->solver == SOL_NEWTON && m->cone == CONE_ELLIPTIC && d->njmax > 32) ? 32 : 0)); /* = sched_cls, integrate.hpp */ }
@@ -848,7 +910,7 @@ static int run_stage(const MjhModel* m, const MjhData* d, int stage, hipStream_t
       }
       // fused step: four launches on the caller's stream (see "composite launches" above)
       // (nv <= 32 only: beside the 64-lane solver of larger models the riders cost more than they save, G1 -3 %)
-      static const int side_nv = getenv("MJH_SIDE_NV") ? atoi(getenv("MJH_SIDE_NV")) : 32;  // developer knob
+      static const int side_nv = mjh_knob("MJH_SIDE_NV") ? atoi(mjh_knob("MJH_SIDE_NV")) : 32;  // developer knob
       const bool inl = stage == MJH_STAGE_STEP && newton_inline_ok(m, d) && !(g_instr && g_instr->on);
       Side* side = (m->solver == SOL_NEWTON && m->nv <= side_nv && !(g_instr && g_instr->on) && !inl) ? side_stream() : nullptr;
       bool sched_done = false;
@@ -862,7 +924,7 @@ static int run_stage(const MjhModel* m, const MjhData* d, int stage, hipStream_t
         HIPCHK(hipStreamWaitEvent(side->stream, side->fork, 0));
         // both riders as roles of ONE launch (k_integrate_plus without integrator workgroups): their two chains overlap and one launch gap
         // goes (round 3, same-box A/B in two interleaved pairs: humanoid Newton 0.2842 -> 0.2829 / 0.2835 -> 0.2822 ms, Panda 142.9 -> 142.0 us)
-        static const bool side_two = getenv("MJH_SIDE_TWO") != nullptr;  // developer knob (A/B): the two plain kernels of round 2
+        static const bool side_two = mjh_knob("MJH_SIDE_TWO") != nullptr;  // developer knob (A/B): the two plain kernels of round 2
         if (!side_two) {
           TRY(launch_integrate_plus(m, d, mode, false, side->stream));
         } else {
@@ -878,7 +940,7 @@ static int run_stage(const MjhModel* m, const MjhData* d, int stage, hipStream_t
                            m->nsensor_acc == 0 &&  // (acceleration-stage sensors read qvel / qacc between the solver and the integrator)
                            d->njmax <= 192;        // (beyond: some worlds go to the generic solver, which does not integrate)
       // implicitfast without activations (round 3): the dense system (M + h D - h dA/dv) x = M qacc is solved from the M row the solver holds
-      static const bool no_fuse_impfast = getenv("MJH_NO_FUSE_IMPLICITFAST") != nullptr;  // developer knob (A/B)
+      static const bool no_fuse_impfast = mjh_knob("MJH_NO_FUSE_IMPLICITFAST") != nullptr;  // developer knob (A/B)
       const int fuse_euler = !fusable ? 0
                              : (m->integrator == INT_EULER && (m->disableflags & (DSBL_EULERDAMP | DSBL_DAMPER)) != 0) ? 1
                              : (m->integrator == INT_IMPLICITFAST && !no_fuse_impfast && !m->act_velfeedback) ? 2 : 0;  // (positive velocity feedback: the matrix may be indefinite -- the integrator launch's L'DL handles that, the epilogue's Cholesky does not)
@@ -929,6 +991,16 @@ int mjh_ws_ccd_floats(int nworld, int iterations, int nhfield, int npolygonmax, 
   return MJH_OK;
 }
 const char* mjh_last_error(void) { return g_err; }
+int mjh_dev_knob(const char* name, const char* value) {
+  if (!name || strncmp(name, "MJH_", 4) != 0) return fail(MJH_E_ARG, "mjh_dev_knob: knob names start with MJH_");
+  KnobTable& t = knobs();
+  std::lock_guard<std::mutex> lock(t.mu);
+  if (value) t.kv[name] = value;
+  else t.kv.erase(name);
+  t.n.store((int)t.kv.size(), std::memory_order_release);
+  return MJH_OK;
+}
+const char* mjh_solver_kernel(const MjhModel* m, const MjhData* d) { return (m && d) ? solver_kernel_name(m, d) : "unsupported"; }
 
 int mjh_stage(const MjhModel* m, const MjhData* d, int stage, void* stream) {
   TRY(check(m, d));
@@ -1082,7 +1154,7 @@ int mjh_timed_steps(const MjhModel* m, const MjhData* d, int nstep, int step0, f
   for (int i = 0; i < nstep && rc == MJH_OK; ++i) {
     // the noise of step i rides with that step's first launch (the fused path); the per-kernel profiling passes and the plain
     // path keep it as its own kernel
-    static const bool plain_env = getenv("MJH_PLAIN") != nullptr || getenv("MJH_NO_NOISE_FUSION") != nullptr;
+    static const bool plain_env = mjh_knob("MJH_PLAIN") != nullptr || mjh_knob("MJH_NO_NOISE_FUSION") != nullptr;
     if (noise_std >= 0.0f && m->nu > 0) {
       if (instr.on || plain_env) rc = mjh_ctrl_noise(m, d, nullptr, step0 + i, noise_std, noise_rate, stream);
       else g_noise = NoiseArgs{d->nworld * m->nu, step0 + i, noise_std, noise_rate, nullptr, 0};

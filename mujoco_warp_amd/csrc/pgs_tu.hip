@@ -20,13 +20,13 @@ static int launch_pgs_r(const MjhModel* m, const MjhData* d, hipStream_t s) {
   if (!threads) return fail(MJH_E_UNSUPPORTED, "k_solve_pgs: njmax x nv does not fit in LDS");
   HIPCHK(set_lds((k_solve_pgs<NV4, SG, REG>), lds));
   const int wpb = threads / SG;
-  static const int refresh = getenv("MJH_PGS_REFRESH") ? atoi(getenv("MJH_PGS_REFRESH")) : 8;  // developer knob (REG sweep): residual rebuild period
+  static const int refresh = mjh_knob("MJH_PGS_REFRESH") ? atoi(mjh_knob("MJH_PGS_REFRESH")) : 8;  // developer knob (REG sweep): residual rebuild period
   hipLaunchKernelGGL((k_solve_pgs<NV4, SG, REG>), dim3((d->nworld + wpb - 1) / wpb), dim3(threads), lds, s, *m, *d, refresh);
   return MJH_OK;
 }
 template <int NV4, int SG>
 static int launch_pgs_t(const MjhModel* m, const MjhData* d, hipStream_t s) {
-  static const bool no_reg = getenv("MJH_PGS_NOREG") != nullptr;  // developer knob: force the general (LDS) sweep
+  static const bool no_reg = mjh_knob("MJH_PGS_NOREG") != nullptr;  // developer knob: force the general (LDS) sweep
   if (d->njmax <= 64 && !no_reg) return launch_pgs_r<NV4, 64, true>(m, d, s);  // one world per wavefront
   return launch_pgs_r<NV4, SG, false>(m, d, s);
 }
@@ -43,7 +43,7 @@ static int launch_pgs_big(const MjhModel* m, const MjhData* d, hipStream_t s) {
   if (lds > (size_t)kLdsPerCU) return fail(MJH_E_UNSUPPORTED, "k_solve_pgs_big: nv / njmax do not fit in LDS");
   HIPCHK(set_lds(k_solve_pgs_big, lds));
   // wavefronts per world: islands only exist between kinematic trees (a single tree is one island: one wavefront)
-  static const int waves_knob = getenv("MJH_PGSB_WAVES") ? atoi(getenv("MJH_PGSB_WAVES")) : PGSB_MAXWAVES;  // developer knob
+  static const int waves_knob = mjh_knob("MJH_PGSB_WAVES") ? atoi(mjh_knob("MJH_PGSB_WAVES")) : PGSB_MAXWAVES;  // developer knob
   const int waves = (m->ntree > 1 && m->ntree <= 64) ? std::max(1, std::min(std::min(waves_knob, PGSB_MAXWAVES), m->ntree)) : 1;
   hipLaunchKernelGGL(k_solve_pgs_big, dim3(d->nworld), dim3(64 * waves), lds, s, *m, *d);
   return MJH_OK;

@@ -29,9 +29,9 @@ static int launch_cgp_t(const MjhModel* m, const MjhData* d, bool with_factor, i
   // measured at 8192 humanoids, steady state / first steps: 64 threads 168.3 / 172.9 us, 128: 166.9 / 168.9, 192: 170.2 / 173.3; 384 and
   // 768 (an earlier build): 255 and 202 against 182 for 64
   int threads = 128;
-  if (const char* e = getenv("MJH_CGP_THREADS")) threads = std::min(CGP_MAXT, std::max(64, (atoi(e) / 64) * 64));
+  if (const char* e = mjh_knob("MJH_CGP_THREADS")) threads = std::min(CGP_MAXT, std::max(64, (atoi(e) / 64) * 64));
   size_t lds = ((size_t)kLdsPerCU / (256 * CGP_WAVES / threads)) & ~(size_t)1023;  // (whole KB: the allocation granularity must not cost a workgroup)
-  if (const char* e = getenv("MJH_CGP_LDS")) lds = (size_t)atoi(e);  // developer knob: bytes of the header + pool of a workgroup
+  if (const char* e = mjh_knob("MJH_CGP_LDS")) lds = (size_t)atoi(e);  // developer knob: bytes of the header + pool of a workgroup
   const int wpb = threads / 32;
   const int pool_rows = cgp_pool_rows<NV4>(lds, wpb);
   if (pool_rows < cgp_min_rows<NV4>(fuse_euler)) return fail(MJH_E_UNSUPPORTED, "k_solve_cgp: pool too small");

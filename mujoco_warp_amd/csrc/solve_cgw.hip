@@ -29,7 +29,7 @@ static int launch_cgw_t(const MjhModel* m, const MjhData* d, bool with_factor, i
   size_t lds;
   int threads = pick_block(0, sizeof(float) * lay.total, 64, &lds, true);
   if (!threads) return fail(MJH_E_UNSUPPORTED, "k_solve_cgw: njmax x nv does not fit in LDS");
-  if (const char* e = getenv("MJH_SOLVE_THREADS")) {  // tuning knob (developer only)
+  if (const char* e = mjh_knob("MJH_SOLVE_THREADS")) {  // tuning knob (developer only)
     threads = std::max(atoi(e), 64);
     lds = sizeof(float) * lay.total * (threads / 64);
   }

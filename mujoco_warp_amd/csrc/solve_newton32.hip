@@ -16,16 +16,16 @@ static int launch_newton_t(const MjhModel* m, const MjhData* d, int fuse_euler, 
   const int cap = d->njmax < 64 ? d->njmax : 64;
   pool = std::min(pool, 2 * cap);
   pool = std::max(pool, newton_min_pool<NV4>(d->njmax));
-  if (const char* e = getenv("MJH_NEWTON_POOL")) pool = std::max(atoi(e), newton_min_pool<NV4>(d->njmax));  // developer knob
+  if (const char* e = mjh_knob("MJH_NEWTON_POOL")) pool = std::max(atoi(e), newton_min_pool<NV4>(d->njmax));  // developer knob
   const NewtonLayout lay = newton_layout<NV4>(pool);
   size_t lds = sizeof(float) * lay.total;
   const int nsolve = (d->nworld + 1) / 2, nrider = riders ? nsolve : 0;
   if (riders) lds = std::max(lds, sizeof(int) * mstruct_ints(m->nv, m->nC) + sizeof(float) * fac_layout(m->nv, m->nC).total * 2);
   if (lds > (size_t)kLdsPerCU) return fail(MJH_E_UNSUPPORTED, "k_solve_newton: does not fit in LDS");
-  static const int rider_pct = getenv("MJH_RIDER_AT") ? atoi(getenv("MJH_RIDER_AT")) : 100;  // see solve_tu.hpp
+  static const int rider_pct = mjh_knob("MJH_RIDER_AT") ? atoi(mjh_knob("MJH_RIDER_AT")) : 100;  // see solve_tu.hpp
   const int rider_at = std::min(nsolve, (int)((long long)nsolve * std::max(rider_pct, 0) / 100));
   const dim3 grid(nsolve + 2 * nrider), block(64);
-  if (getenv("MJH_DEBUG_OCC")) {  // developer knob: resident workgroups per CU the runtime computes for this launch
+  if (mjh_knob("MJH_DEBUG_OCC")) {  // developer knob: resident workgroups per CU the runtime computes for this launch
     int nb = -1;
     if (pool >= 2 * cap) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_solve_newton<NV4, WV, true>, 64, lds);
     else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_solve_newton<NV4, WV, false>, 64, lds);
@@ -57,12 +57,12 @@ static int launch_newton_w(const MjhModel* m, const MjhData* d, int fuse_euler, 
 
 static int launch_newton(const MjhModel* m, const MjhData* d, int fuse_euler, bool riders, hipStream_t s) {
   // two wavefronts per SIMD is the measured optimum: at three (168 VGPRs) the register allocator still spills in the Cholesky
-  static const int waves = getenv("MJH_NEWTON_WAVES") ? atoi(getenv("MJH_NEWTON_WAVES")) : 2;  // developer knob
+  static const int waves = mjh_knob("MJH_NEWTON_WAVES") ? atoi(mjh_knob("MJH_NEWTON_WAVES")) : 2;  // developer knob
   return waves == 2 ? launch_newton_w<2>(m, d, fuse_euler, riders, s) : launch_newton_w<3>(m, d, fuse_euler, riders, s);
 }
 
 int launch_solve_32_newton(const MjhModel* m, const MjhData* d, int nr, bool with_factor, int fuse_euler, hipStream_t s, int lo, int hi) {
-  static const bool old_path = getenv("MJH_OLD_NEWTON") != nullptr;  // developer knob: A/B against the VALU solver
+  static const bool old_path = mjh_knob("MJH_OLD_NEWTON") != nullptr;  // developer knob: A/B against the VALU solver
   switch (nr) {
     case 2:
       // (32-bit byte offsets inside the kernel: nworld * max(nv, njmax) * 4 must fit)

@@ -75,7 +75,7 @@ static int launch_tree_all(const MjhModel* m, const MjhData* d, hipStream_t s, h
   // was solved with 32-wide rows of M / H and an 8-block Cholesky when the model also holds wide islands (clutter_synth: isl_nv4 = 8).
   // Models with small trees (the trees but the largest average at most 8 dofs) solve the islands of at most 8 / 16 dofs with the
   // instantiations of that size; the classes touch disjoint islands, so the wider ones go to the stream of the rare classes.
-  static const bool no_classes = getenv("MJH_NO_ISLAND_CLASSES") != nullptr;  // developer knob (A/B)
+  static const bool no_classes = mjh_knob("MJH_NO_ISLAND_CLASSES") != nullptr;  // developer knob (A/B)
   const int top4 = m->isl_nv4;
   const bool small = !no_classes && m->ntree > 1 && top4 > 2 && (m->nv - m->tree_nvmax) <= 8 * (m->ntree - 1);
   if (small) {

@@ -37,7 +37,7 @@ static int launch_solve_t(const MjhModel* m, const MjhData* d, bool with_factor,
   size_t lds;
   int threads = pick_block(0, sizeof(float) * lay.total, SG, &lds, true);
   if (!threads) return fail(MJH_E_UNSUPPORTED, "k_solve: njmax x nv does not fit in LDS");
-  if (const char* e = getenv("MJH_SOLVE_THREADS")) {  // tuning knob (developer only)
+  if (const char* e = mjh_knob("MJH_SOLVE_THREADS")) {  // tuning knob (developer only)
     threads = std::max(atoi(e), SG);
     lds = sizeof(float) * lay.total * (threads / SG);
   }
@@ -51,7 +51,7 @@ static int launch_solve_t(const MjhModel* m, const MjhData* d, bool with_factor,
   // where the riders sit in the dispatch order, in per cent of the solver workgroups (developer knob; 100 = after all of them, the round-1 layout).
   // Measured (round 3, humanoid CG, two interleaved rounds on one box): 100 -> 215.9 / 215.3 us per launch, 75 -> 280.4 / 280.7, 55 -> 268.6 / 267.6,
   // 35 -> 279.1 / 279.0: riders dispatched among the solver workgroups cost four times what they cost in the launch's tail
-  static const int rider_pct = getenv("MJH_RIDER_AT") ? atoi(getenv("MJH_RIDER_AT")) : 100;
+  static const int rider_pct = mjh_knob("MJH_RIDER_AT") ? atoi(mjh_knob("MJH_RIDER_AT")) : 100;
   const int rider_at = std::min(nsolve, (int)((long long)nsolve * std::max(rider_pct, 0) / 100));
   hipLaunchKernelGGL((k_solve_plus<NV4, NR, NEWTON, SG, ELL>), dim3(nsolve + 2 * nfac), dim3(threads), lds, s, *m, *d, nsolve, nfac, nefc_lo, nefc_hi, fuse_euler, rider_at);
   return MJH_OK;

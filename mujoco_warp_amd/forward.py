@@ -320,6 +320,12 @@ class StepGraph:
       pass
 
 
+def solver_kernel(m, d) -> str:
+  """Name of the solver mapping the library's dispatch picks for (m, d) in a fused step (mjh_solver_kernel): "cgp", "cgw", "pair",
+  "newton_mfma", ... -- what a test or a bench line measured, without a developer knob."""
+  return _abi.lib().mjh_solver_kernel(ctypes.byref(io.c_model(m)), ctypes.byref(io.c_data(d))).decode()
+
+
 def timed_steps(m, d, nstep: int, step0: int = 0, noise_std: float = 0.01, noise_rate: float = 0.1, per_kernel: bool = False,
                 plain_kernels: bool = False):
   """Run nstep x (ctrl_noise + step) bracketed by HIP events on the launch stream.

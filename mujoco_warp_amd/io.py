@@ -530,7 +530,11 @@ def put_model(mjm, batch_sizes: Optional[dict] = None) -> types.Model:
   pair_condims = set(int(gc_[a] if gp_[a] > gp_[b] else gc_[b] if gp_[b] > gp_[a] else max(gc_[a], gc_[b])) for a, b in pairs)
   if nexplicit:
     pair_condims |= set(int(c) for c in np.asarray(mjm.pair_dim))
-  m.cg_basis = int(pair_condims <= {1, 3})
+  # ... and no friction-loss rows (their three-zone cost is outside that kernel: it would hand EVERY world to its fallback launch, which
+  # solves flagged worlds one after the other -- ADVICE round 5); the kernel still defers a world that shows up with nf > 0 (a model whose
+  # frictionloss was edited after put_model), so this flag is about speed, not correctness
+  has_floss = bool(np.any(np.asarray(getattr(mjm, "dof_frictionloss", 0.0)) > 0)) or bool(np.any(np.asarray(getattr(mjm, "tendon_frictionloss", 0.0)) > 0))
+  m.cg_basis = int(pair_condims <= {1, 3} and not has_floss)
   m._ccd_flags_at_put = int(opt.disableflags)
   m.key_qpos = _arr(getattr(mjm, "key_qpos", np.zeros((0, m.nq))), f32)
   m.key_qvel = _arr(getattr(mjm, "key_qvel", np.zeros((0, nv))), f32)
@@ -586,6 +590,11 @@ def c_model(m: types.Model):
         raise ValueError(f"unknown broadphase filter bits {bf_:#x}")
       if int(m.opt.broadphase) not in (0, 1, 2):
         raise ValueError(f"unknown broadphase {int(m.opt.broadphase)}")
+      if int(m.opt.broadphase) == 0 and m._convex_pairs and int(m.npair) > 0 and int(m.ncullpair) == 0:
+        # (io.cull_tables declines models beyond its 16-bit geom / 24-bit pair packing -- put_model picks SAP for those; NXN
+        # forced on one would fail every step with MJH_E_ARG in launch_ccd_pre: say so here)
+        raise NotImplementedError(f"opt.broadphase = NXN with convex pairs needs the pair-group tables, which hold at most 65535 geoms and 2^24 pairs "
+                                  f"(this model: {int(m.ngeom)} geoms, {int(m.npair)} pairs): use SAP")
       setattr(c, name, int(bool(m._heavy_pairs or bf_ != 3 or int(m.opt.broadphase) != 0 or m.sleep_enabled)))  # (sleep filter: heavy instantiation only)  # (the light instantiation hard-wires plane + sphere)
     else:
       setattr(c, name, int(getattr(m, name)))

@@ -9,7 +9,10 @@ Mirrors /root/reference/mujoco_warp/testspeed.py (flags 51-61, metrics 359-378) 
 Timer placement is the reference's: per step, the control-noise kernel runs and is synchronised OUTSIDE the timed
 region; the timed region is one hipGraph launch of `step` + device synchronise (cli.py:289-292).  Output keys of
 --format=short|json are the reference's (jit_duration, run_time, steps_per_second, converged_worlds, *_memory,
-ncon_mean/p95, nefc_mean/p95, solver_niter_mean/p95) plus the flattened per-stage trace in ns per world-step.
+ncon_mean/p95, nefc_mean/p95, solver_niter_mean/p95) plus the flattened event trace in ns per world-step under the reference's
+@event_scope names (step, step.forward, step.forward.fwd_position, step.forward.fwd_position.fwd_kinematics.kinematics, ...).
+
+Installed as the console script `mjwarp-testspeed` (pyproject.toml; reference pyproject.toml:72-73).
 """
 
 import argparse
@@ -36,6 +39,54 @@ def _memory(obj, prefix=""):
     elif hasattr(v, "__dict__") and not isinstance(v, (int, float, str)) and type(v).__module__.endswith("types"):
       out.update(_memory(v, prefix + k + "."))
   return out
+
+
+def _event_trace(mjw, mjm, m, d, args, centers, center, nstep=20):
+  """The reference's EventTracer output (`step`, `step.forward`, `step.forward.fwd_position`, ... : the @event_scope nesting of
+  forward.py:388-1380 / smooth.py / collision_driver.py:885 / constraint.py:4898 / solver.py:3671), ns per world-step: `nstep` extra steps run
+  stage by stage -- ONE plain kernel per reference stage function, bracketed by HIP events on the launch stream -- so every key maps 1:1 to the
+  reference function of that name.  (The timed rollout above runs the fused step; a fused launch has no per-stage time.)  Models with sleeping
+  enabled run extra sleep stages between these (forward.py:652-678): their trace keeps the fused launches' granularity."""
+  import torch
+
+  sleep = bool(int(mjm.opt.enableflags) & int(mjw.EnableBit.SLEEP)) and not bool(int(mjm.opt.disableflags) & int(mjw.DisableBit.ISLAND))
+  if sleep:
+    ms, pk = mjw.timed_steps(m, d, nstep, step0=args.nstep, noise_std=args.noise_std, noise_rate=args.noise_rate, per_kernel=True, plain_kernels=True)
+    ns = {k: 1e6 * v / nstep / args.nworld for k, v in zip(mjw.KERNEL_NAMES, pk)}
+    fwd_position = ns["fwd_pos"] + ns["collision"] + ns["make_constraint"]
+    forward = fwd_position + ns["fwd_vel"] + ns["solve"]
+    return {"step": forward + ns["integrate"], "step.forward": forward, "step.forward.fwd_position": fwd_position,
+            "step.forward.fwd_position.collision": ns["collision"], "step.forward.fwd_position.make_constraint": ns["make_constraint"],
+            "step.forward.fwd_velocity": ns["fwd_vel"], "step.forward.solve": ns["solve"], "step.euler": ns["integrate"]}
+  integ = {int(mjw.IntegratorType.EULER): ("euler", mjw.euler), int(mjw.IntegratorType.RK4): ("rungekutta4", mjw.rungekutta4),
+           int(mjw.IntegratorType.IMPLICIT): ("implicit", mjw.implicit), int(mjw.IntegratorType.IMPLICITFAST): ("implicit", mjw.implicit)}[int(mjm.opt.integrator)]
+  # (reference order: forward.py:1342-1366 with fwd_position(factorize=False) 636-678 and fwd_acceleration(factorize=True) 1291)
+  stages = [("step.forward.fwd_position.fwd_kinematics.kinematics", mjw.kinematics), ("step.forward.fwd_position.fwd_kinematics.com_pos", mjw.com_pos),
+            ("step.forward.fwd_position.crb", mjw.crb), ("step.forward.fwd_position.collision", mjw.collision),
+            ("step.forward.fwd_position.make_constraint", mjw.make_constraint), ("step.forward.fwd_position.transmission", mjw.transmission),
+            ("step.forward.fwd_velocity.com_vel", mjw.com_vel), ("step.forward.fwd_velocity.passive", mjw.passive), ("step.forward.fwd_velocity.rne", mjw.rne),
+            ("step.forward.fwd_actuation", mjw.fwd_actuation), ("step.forward.fwd_acceleration.factor_m", mjw.factor_m),
+            ("step.forward.fwd_acceleration", mjw.fwd_acceleration), ("step.forward.solve", mjw.solve), ("step." + integ[0], integ[1])]
+  if mjm.nsensor:
+    stages.insert(6, ("step.forward.sensor_pos", mjw.sensor_pos))
+    stages.insert(-1, ("step.forward.sensor_acc", mjw.sensor_acc))
+  ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in stages] for _ in range(nstep)]
+  for i in range(nstep):
+    if mjm.nu:
+      mjw.ctrl_noise(m, d, args.nstep + i, args.noise_std, args.noise_rate, centers[-1] if centers is not None else center)
+    for (name, fn), (e0, e1) in zip(stages, ev[i]):
+      e0.record()
+      fn(m, d)
+      e1.record()
+  torch.cuda.synchronize()
+  leaf = {name: sum(e0.elapsed_time(e1) for e0, e1 in (ev[i][k] for i in range(nstep))) * 1e6 / nstep / args.nworld for k, (name, _) in enumerate(stages)}
+  trace = {}
+  for name, v in leaf.items():  # a scope's time = its own launch (if it has one) + its children's
+    parts = name.split(".")
+    for j in range(1, len(parts) + 1):
+      key = ".".join(parts[:j])
+      trace[key] = trace.get(key, 0.0) + v
+  return trace
 
 
 def main(argv=None):
@@ -149,18 +200,7 @@ def main(argv=None):
 
   trace = {}
   if args.event_trace and args.function == "step":
-    # per-kernel HIP-event timing of a few extra steps (the reference's EventTracer keys, ns per world-step)
-    ms, pk = mjw.timed_steps(m, d, 20, step0=args.nstep, noise_std=args.noise_std, noise_rate=args.noise_rate, per_kernel=True,
-                             plain_kernels=True)
-    ns = {k: 1e6 * v / 20 / args.nworld for k, v in zip(mjw.KERNEL_NAMES, pk)}
-    fwd_position = ns["fwd_pos"] + ns["collision"] + ns["make_constraint"]
-    forward = fwd_position + ns["fwd_vel"] + ns["solve"]
-    trace = {
-      "step": forward + ns["integrate"], "step.forward": forward, "step.forward.fwd_position": fwd_position,
-      "step.forward.fwd_position.kinematics_com_pos_crb": ns["fwd_pos"], "step.forward.fwd_position.collision": ns["collision"],
-      "step.forward.fwd_position.make_constraint": ns["make_constraint"],
-      "step.forward.fwd_velocity_actuation_acceleration": ns["fwd_vel"], "step.forward.solve": ns["solve"], "step.euler": ns["integrate"],
-    }
+    trace = _event_trace(mjw, mjm, m, d, args, centers, center)
 
   nconverged = int(np.sum(~np.any(np.isnan(d.qpos.numpy()), axis=1)))
   steps = args.nworld * args.nstep

@@ -24,6 +24,26 @@ def build(force=False):
   return _LIB_PATH
 
 
+_NATIVE_FLAGS = ["-O3", "-march=native", "-fPIC", "-std=gnu99", "-Wno-unused-function", "-fno-fast-math"]
+
+
+def use_native_build():
+  """bench.py's cpu_baseline leg only (the stand-in for MuJoCo C is compiled `-O3 -march=native`): compile the float64 restatement
+  for THIS host's cores into oracle/_native/ and make it the library the next RefSim loads.  Not the oracle of the parity tests (those keep
+  the -O2 -ffp-contract=off build: bit-reproducible across hosts).  Returns the flags used, for the bench line."""
+  global _LIB_PATH
+  out = os.path.join(_DIR, "_native", "libmjref_native.so")
+  os.makedirs(os.path.dirname(out), exist_ok=True)
+  src = os.path.join(_DIR, "mjref.c")
+  if not os.path.exists(out) or os.path.getmtime(src) > os.path.getmtime(out):
+    tmp = out + f".tmp{os.getpid()}"
+    subprocess.check_call(["gcc", *_NATIVE_FLAGS, "-shared", "-o", tmp, src, "-lm"], cwd=_DIR)
+    os.replace(tmp, out)
+  if _F64._lib is None:
+    _LIB_PATH = out
+  return "gcc " + " ".join(_NATIVE_FLAGS)
+
+
 def _parse_struct(header, name):
   body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), header, re.S).group(1)
   fields = []

@@ -1,8 +1,7 @@
 """GPU parity tests of the pooled contact-basis CG kernel (csrc/solver_cgp.hpp), forced at small batch sizes through the developer knob
-MJH_CG_KERNEL (read by the library at every solver launch): against the float64 oracle, against the two-worlds-per-wavefront kernel it
+MJH_CG_KERNEL (set through the library's test hook mjh_dev_knob; tests/test_headline_batch.py runs the same kernel through the product
+dispatch at 8192 worlds): against the float64 oracle, against the two-worlds-per-wavefront kernel it
 replaces (csrc/solver.hpp), and through its fallback launch (worlds it flags solver_niter = -1)."""
-
-import os
 
 import numpy as np
 import pytest
@@ -16,24 +15,7 @@ from test_gpu import _check_solution, _pair, _sync
 pytestmark = pytest.mark.gpu
 
 
-class _knob:
-  def __init__(self, **kv):
-    self.kv = kv
-
-  def __enter__(self):
-    self.old = {k: os.environ.get(k) for k in self.kv}
-    for k, v in self.kv.items():
-      if v is None:
-        os.environ.pop(k, None)
-      else:
-        os.environ[k] = str(v)
-
-  def __exit__(self, *a):
-    for k, v in self.old.items():
-      if v is None:
-        os.environ.pop(k, None)
-      else:
-        os.environ[k] = v
+from mujoco_warp_amd._abi import dev_knobs as _knob  # (the library's one test hook, mjh_dev_knob: it never reads the environment after load)
 
 
 def _cg_humanoid(nworld, warm_steps=15, **kw):
@@ -157,10 +139,16 @@ def test_cgp_friction_loss_rows_are_left_to_the_fallback():
   assert "frictionloss" in xml
   mjm = mjw.mjcf.from_xml_string(xml)
   s, m, d = _pair(mjm, nworld=5, nconmax=24, njmax=64, solver=int(mjw.SolverType.CG))
-  assert m.cg_basis == 1
+  # a model WITH friction loss is not dispatched to the pooled kernel at all (every world would take the fallback launch: ADVICE round 5) ...
+  assert m.cg_basis == 0
+  assert mjw.solver_kernel(m, mjw.make_data(mjm, nworld=8192, nconmax=24, njmax=64)) == "pair"
   s.forward()
   assert s.nf == 1
+  # ... and the kernel's own guard (a world that shows up with nf > 0, e.g. frictionloss edited after put_model) still hands it over
+  m.cg_basis = 1
+  m._dirty = True
   with _knob(MJH_CG_KERNEL="cgp"):
+    assert mjw.solver_kernel(m, d) == "cgp"
     mjw.forward(m, d)
   assert (d.solver_niter.numpy() >= 0).all()
   _check_solution(s, d)

@@ -205,9 +205,11 @@ def test_random_model_meshes(seed):
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("MJH_FUZZ_CGP_SEEDS", "24"))))
-def test_random_model_pooled_cg(seed, monkeypatch):
-  """CG through the pooled contact-basis kernel (csrc/solver_cgp.hpp; forced at this batch size by the developer knob MJH_CG_KERNEL, which
-  the library reads at every launch) on the same random trees: every nv / 4 instantiation, equality-free trees with limit rows and mixed
+def test_random_model_pooled_cg(seed):
+  """CG through the pooled contact-basis kernel (csrc/solver_cgp.hpp; forced at this batch size by the developer knob MJH_CG_KERNEL, set through
+  the library's test hook mjh_dev_knob) on the same random trees: every nv / 4 instantiation, equality-free trees with limit rows and mixed
   condim-1 / condim-3 contacts, the fused Euler and implicitfast epilogues, and -- the seeds with friction loss -- its fallback launch."""
-  monkeypatch.setenv("MJH_CG_KERNEL", "cgp")
-  _run_seed(seed, mjw.SolverType.CG, njmax_dev=64)
+  from mujoco_warp_amd._abi import dev_knobs
+
+  with dev_knobs(MJH_CG_KERNEL="cgp"):
+    _run_seed(seed, mjw.SolverType.CG, njmax_dev=64)

@@ -1,5 +1,5 @@
-"""A/B of solver-kernel variants inside ONE process on the headline workload (humanoid, 8192 worlds, CG): the knobs the library reads at
-every launch (MJH_CG_KERNEL, MJH_CGP_THREADS, MJH_CGP_LDS) are switched between timed windows, so that every variant sees the same box, the
+"""A/B of solver-kernel variants inside ONE process on the headline workload (humanoid, 8192 worlds, CG): the knobs the library looks up at
+every launch (MJH_CG_KERNEL, MJH_CGP_THREADS, MJH_CGP_LDS; set through mjh_dev_knob) are switched between timed windows, so that every variant sees the same box, the
 same clocks and (nearly) the same states.
 
 usage: python tools/solve_ab.py [--nworld 8192] [--at 5,300] [--steps 20] [--reps 3] "VAR=x VAR2=y" "..." ...
@@ -37,21 +37,21 @@ mjw.reset_data_keyframe(m, d, 0)
 STATE = ("qpos", "qvel", "ctrl", "qacc_warmstart", "time", "solver_niter")
 
 
-def setenv(spec):
-  changed = {}
+from mujoco_warp_amd import _abi
+
+
+def setenv(spec):  # (through the library's test hook mjh_dev_knob: it does not read the environment after load)
+  changed = []
   for kv in spec.split():
     k, v = kv.split("=", 1)
-    changed[k] = os.environ.get(k)
-    os.environ[k] = v
+    _abi.set_knob(k, v)
+    changed.append(k)
   return changed
 
 
 def restore(changed):
-  for k, v in changed.items():
-    if v is None:
-      os.environ.pop(k, None)
-    else:
-      os.environ[k] = v
+  for k in changed:
+    _abi.set_knob(k, None)
 
 
 out = {}
@@ -75,8 +75,9 @@ for at in [int(x) for x in a.at.split(",")]:
       restore(ch)
       torch.cuda.synchronize()
       if rep:
-        res[v].append((ms / a.steps, [x / a.steps * 1e3 for x in pk], float(d.solver_niter.numpy().mean()), float(d.nefc.numpy().mean()),
-                       int((d.solver_niter.numpy() < 0).sum()), bool(np.isfinite(d.qpos.numpy()).all())))
+        ni = d.solver_niter.numpy()
+        res[v].append((ms / a.steps, [x / a.steps * 1e3 for x in pk], float(ni.mean()), float(d.nefc.numpy().mean()),
+                       int((ni < 0).sum()), bool(np.isfinite(d.qpos.numpy()).all()), int(ni.max()), float(np.percentile(ni, 99)), int(d.nefc.numpy().max())))
   for k, t in keep.items():
     getattr(d, k).t.copy_(t)
   for v in a.variants:
@@ -85,7 +86,7 @@ for at in [int(x) for x in a.at.split(",")]:
     pkm = np.median(np.array([x[1] for x in r]), axis=0)
     names = fw.KERNEL_NAMES
     row = {"ms_per_step": round(msm, 4), "env_steps_per_s_M": round(a.nworld / msm / 1e3, 2), "niter": round(r[-1][2], 2), "nefc": round(r[-1][3], 1),
-           "unsolved": r[-1][4], "finite": r[-1][5], **{names[i]: round(float(pkm[i]), 1) for i in range(len(names)) if pkm[i] > 0}}
+           "unsolved": r[-1][4], "finite": r[-1][5], "niter_max": r[-1][6], "niter_p99": r[-1][7], "nefc_max": r[-1][8], **{names[i]: round(float(pkm[i]), 1) for i in range(len(names)) if pkm[i] > 0}}
     out.setdefault(str(at), {})[v or "default"] = row
     print(f"at {at:4d} [{v or 'default':40s}]", json.dumps(row), flush=True)
 if a.json:
