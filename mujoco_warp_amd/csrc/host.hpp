@@ -82,10 +82,11 @@ int launch_solve_32_newton_ell(const MjhModel* m, const MjhData* d, int nr, bool
 int launch_solve_64_cg_ell(const MjhModel* m, const MjhData* d, int nr, bool with_factor, int fuse_euler, hipStream_t s, int lo, int hi);
 int launch_solve_64_newton_ell(const MjhModel* m, const MjhData* d, int nr, bool with_factor, int fuse_euler, hipStream_t s, int lo, int hi);
 // per-(world, island) solves for nv > 64 (solve_tree_*.hip)
-int launch_solve_tree_cg(const MjhModel* m, const MjhData* d, hipStream_t s, hipStream_t sr);
-int launch_solve_tree_newton(const MjhModel* m, const MjhData* d, hipStream_t s, hipStream_t sr);
-int launch_solve_tree_cg_ell(const MjhModel* m, const MjhData* d, hipStream_t s, hipStream_t sr);      // (elliptic cones: solve_tree_ell_*.hip)
-int launch_solve_tree_newton_ell(const MjhModel* m, const MjhData* d, hipStream_t s, hipStream_t sr);
+// (s: the common island class; sr, sr2, sr3: the rare classes -- 8..16 dofs, 16..32 dofs, many rows / 33..64 dofs -- which touch disjoint islands)
+int launch_solve_tree_cg(const MjhModel* m, const MjhData* d, hipStream_t s, hipStream_t sr, hipStream_t sr2, hipStream_t sr3);
+int launch_solve_tree_newton(const MjhModel* m, const MjhData* d, hipStream_t s, hipStream_t sr, hipStream_t sr2, hipStream_t sr3);
+int launch_solve_tree_cg_ell(const MjhModel* m, const MjhData* d, hipStream_t s, hipStream_t sr, hipStream_t sr2, hipStream_t sr3);      // (elliptic cones: solve_tree_ell_*.hip)
+int launch_solve_tree_newton_ell(const MjhModel* m, const MjhData* d, hipStream_t s, hipStream_t sr, hipStream_t sr2, hipStream_t sr3);
 int launch_pgs(const MjhModel* m, const MjhData* d, hipStream_t s);
 // generic LDS solver (solver_big.hpp): nv > 64, and the worlds of a small model with more than nefc_lo = 192 rows
 int launch_solve_big(const MjhModel* m, const MjhData* d, hipStream_t s, int nefc_lo = -1);

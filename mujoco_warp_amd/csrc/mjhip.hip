@@ -437,12 +437,13 @@ static int solve_supported(const MjhModel* m, const MjhData* d) {
     return fail(MJH_E_UNSUPPORTED, "njmax > 192 with the register / LDS resident PGS kernels is not supported (nv <= 64, pyramidal)");
   return MJH_OK;
 }
-// Two auxiliary streams per host thread and device for the solver variants of the per-island dispatch (nv > 64): the rare island classes and
-// the generic solver touch islands / worlds the common-class launch skips, so they run beside it instead of after it.  Released by
-// mjh_release_thread_resources().
+// Auxiliary streams per host thread and device for the solver variants of the per-island dispatch (nv > 64): the rare island classes (one
+// stream each: round 6) and the generic solver touch islands / worlds the common-class launch skips, so they run beside it instead of
+// after it.  Released by mjh_release_thread_resources().
+#define MJH_NAUX 4
 struct Aux {
-  hipStream_t stream[2];
-  hipEvent_t fork, join[2];
+  hipStream_t stream[MJH_NAUX];
+  hipEvent_t fork, join[MJH_NAUX];
 };
 static thread_local Aux* g_aux_per_dev[16] = {nullptr};
 static thread_local bool g_serial_solver = false;  // set while per-kernel instrumentation is on (one stream, one event pair per launch)
@@ -454,7 +455,7 @@ static Aux* aux_streams() {
   if (!g_aux_per_dev[dev]) {
     Aux* a = new Aux();
     bool ok = hipEventCreateWithFlags(&a->fork, hipEventDisableTiming) == hipSuccess;
-    for (int k = 0; k < 2 && ok; ++k)
+    for (int k = 0; k < MJH_NAUX && ok; ++k)
       ok = hipStreamCreateWithFlags(&a->stream[k], hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&a->join[k], hipEventDisableTiming) == hipSuccess;
     if (!ok) {
       delete a;  // (a partially created set leaks a handle or two: only on an already failing device)
@@ -501,6 +502,9 @@ static int cg32_choice(const MjhModel* m, const MjhData* d, int fe) {
   if (force && !strcmp(force, "cgp")) return cgp_can ? CG32_CGP : CG32_PAIR;
   return wide ? CG32_CGW : (cgp_can ? CG32_CGP : CG32_PAIR);
 }
+#ifndef MJH_SOLVE64_SPLIT_DEFAULT
+#define MJH_SOLVE64_SPLIT_DEFAULT 0
+#endif
 static int launch_solve_any(const MjhModel* m, const MjhData* d, bool with_factor, hipStream_t s) {
   if (int rc = solve_supported(m, d)) return rc;
   if (m->solver == SOL_NEWTON) with_factor = with_factor && g_newton_inline;
@@ -513,16 +517,15 @@ static int launch_solve_any(const MjhModel* m, const MjhData* d, bool with_facto
       hipLaunchKernelGGL(k_tree_rows, dim3(d->nworld), dim3(64), sizeof(int) * (size_t)(2 * std::max(d->njmax, 1) + 2 * m->ntree), s, *m, *d);
       const bool ell_t = m->cone == CONE_ELLIPTIC && d->nmaxpyramid > 1;
       Aux* aux = aux_streams();
-      hipStream_t s1 = aux ? aux->stream[0] : s, s2 = aux ? aux->stream[1] : s;
+      hipStream_t s1 = aux ? aux->stream[0] : s, s2 = aux ? aux->stream[1] : s, s3 = aux ? aux->stream[2] : s, s4 = aux ? aux->stream[3] : s;
       if (aux) {
         HIPCHK(hipEventRecord(aux->fork, s));
-        HIPCHK(hipStreamWaitEvent(s1, aux->fork, 0));
-        HIPCHK(hipStreamWaitEvent(s2, aux->fork, 0));
+        for (int k = 0; k < MJH_NAUX; ++k) HIPCHK(hipStreamWaitEvent(aux->stream[k], aux->fork, 0));
       }
-      int rc = (m->solver == SOL_NEWTON ? (ell_t ? launch_solve_tree_newton_ell : launch_solve_tree_newton) : (ell_t ? launch_solve_tree_cg_ell : launch_solve_tree_cg))(m, d, s, s1);
+      int rc = (m->solver == SOL_NEWTON ? (ell_t ? launch_solve_tree_newton_ell : launch_solve_tree_newton) : (ell_t ? launch_solve_tree_cg_ell : launch_solve_tree_cg))(m, d, s, s1, s3, s4);
       if (!rc) rc = launch_solve_big(m, d, s2);
       if (aux) {  // (every fork rejoins the caller's stream, also on the error path: the streams may be under capture)
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < MJH_NAUX; ++k) {
           HIPCHK(hipEventRecord(aux->join[k], aux->stream[k]));
           HIPCHK(hipStreamWaitEvent(s, aux->join[k], 0));
         }
@@ -589,6 +592,27 @@ static int launch_solve_any(const MjhModel* m, const MjhData* d, bool with_facto
   if (r1_64) {
     if (int rc = s64(m, d, 1, false, fe, s, -1, 64)) return rc;
     lo64 = 64;
+  }
+  // Round 6: the same split with the two launches BESIDE one another (an auxiliary stream, fork / join through events).  The kernel is bound by
+  // LDS per world (one-row instantiation 12.6 KB, two-row 23.7 KB: 8 against 6 worlds per CU on the G1), so the few-row worlds at their own
+  // size shorten the batch by a partial round -- as long as they do not wait for the many-row launch.  MJH_SOLVE64_SPLIT=0 / 1 (developer knob).
+  static const int split_knob = mjh_knob("MJH_SOLVE64_SPLIT") ? atoi(mjh_knob("MJH_SOLVE64_SPLIT")) : MJH_SOLVE64_SPLIT_DEFAULT;
+  Aux* aux64 = (split_knob && !r1_64) ? aux_streams() : nullptr;
+  if (aux64) {
+    HIPCHK(hipEventRecord(aux64->fork, s));
+    HIPCHK(hipStreamWaitEvent(aux64->stream[0], aux64->fork, 0));
+    int rc = s64(m, d, 1, false, fe, aux64->stream[0], -1, 64);
+    if (!rc) {
+      if (d->njmax <= 128) rc = s64(m, d, 2, with_factor, fe, s, 64, all);
+      else {
+        rc = s64(m, d, 2, with_factor, fe, s, 64, 128);
+        if (!rc) rc = s64(m, d, 3, false, fe, s, 128, top);
+        if (!rc && d->njmax > 192) rc = launch_solve_big(m, d, s, 192);
+      }
+    }
+    HIPCHK(hipEventRecord(aux64->join[0], aux64->stream[0]));  // (every fork rejoins the caller's stream, also on the error path)
+    HIPCHK(hipStreamWaitEvent(s, aux64->join[0], 0));
+    return rc;
   }
   if (d->njmax <= 128) return s64(m, d, 2, with_factor, fe, s, lo64, all);
   if (int rc = s64(m, d, 2, with_factor, fe, s, lo64, 128)) return rc;
@@ -796,6 +820,8 @@ static int run_sleep_step(const MjhModel* m, const MjhData* d, bool step, hipStr
   { Scope sc(K_OTHER); TRY(launch_sensor(m, d, 1, s)); }
   if (step) { Scope sc(K_INTEGRATE); TRY(launch_integrate(m, d, mode, s)); }
   {
+    // (round 6: these two public-output launches beside the solver on the side stream LOSE here -- clutter_synth 1.53 -> 1.36 M env-steps/s, two
+    // interleaved pairs: their workgroups take LDS slots from the island solves, which are the step's critical path)
     Scope sc(K_OTHER);
     TRY(launch_publish(m, d, s));
     TRY(launch_factor_smooth(m, d, 1, s));
@@ -1087,7 +1113,7 @@ int mjh_release_thread_resources(void) {
     Aux* a = g_aux_per_dev[dev];
     if (a) {
       g_aux_per_dev[dev] = nullptr;
-      for (int k = 0; k < 2; ++k) {
+      for (int k = 0; k < MJH_NAUX; ++k) {
         if (hipStreamSynchronize(a->stream[k]) != hipSuccess) rc = MJH_E_LAUNCH;
         if (hipEventDestroy(a->join[k]) != hipSuccess) rc = MJH_E_LAUNCH;
         if (hipStreamDestroy(a->stream[k]) != hipSuccess) rc = MJH_E_LAUNCH;

@@ -65,10 +65,12 @@ static int launch_tree_32(const MjhModel* m, const MjhData* d, int nv4, hipStrea
   }
 }
 // the two-size row dispatch of the whole-world solver (mjhip.hip launch_solve_any), per island.  `s`: the launch of the common class (islands
-// of at most 32 dofs and 64 rows); `sr`: the launches of the rare classes, which touch disjoint islands and may run beside it (round 3: on
-// one stream the five launches of a three-humanoid step -- each mostly tail -- took 920 us in sequence)
+// of at most 32 dofs and 64 rows); `sr`, `sr2`, `sr3`: the launches of the rare classes, which touch disjoint islands and run beside it (round 3:
+// on one stream the five launches of a three-humanoid step -- each mostly tail -- took 920 us in sequence; round 6: every class a stream of
+// its own -- on clutter_synth the 8..16-dof, 16..32-dof and many-row launches followed one another on ONE side stream, 324 + 134 + 134 us of
+// latency chains that touch disjoint islands)
 template <bool NEWTON, bool ELL = false>
-static int launch_tree_all(const MjhModel* m, const MjhData* d, hipStream_t s, hipStream_t sr) {
+static int launch_tree_all(const MjhModel* m, const MjhData* d, hipStream_t s, hipStream_t sr, hipStream_t sr2, hipStream_t sr3) {
   const int all = 0x7fffffff;
   // islands of at most 32 dofs: 2 rows per lane cover 64 rows (the common case: one block per two island slots), 6 cover 192
   // Size classes (round 3): the kernel is specialised on ceil(dofs / 4) of the WIDEST island the model can form, so a free body (6 dofs)
@@ -82,14 +84,14 @@ static int launch_tree_all(const MjhModel* m, const MjhData* d, hipStream_t s, h
     if (int rc = launch_tree_32<2, NEWTON, false, ELL>(m, d, 2, s, -1, 64, 0, 0, 8)) return rc;
     if (top4 > 4) {
       if (int rc = launch_tree_32<2, NEWTON, false, ELL>(m, d, 4, sr, -1, 64, 0, 8, 16)) return rc;
-      if (int rc = launch_tree_32<2, NEWTON, false, ELL>(m, d, top4, sr, -1, 64, 0, 16, 32)) return rc;
+      if (int rc = launch_tree_32<2, NEWTON, false, ELL>(m, d, top4, sr2, -1, 64, 0, 16, 32)) return rc;
     } else if (int rc = launch_tree_32<2, NEWTON, false, ELL>(m, d, top4, sr, -1, 64, 0, 8, 32)) return rc;
   } else if (int rc = launch_tree_32<2, NEWTON, false, ELL>(m, d, top4, s, -1, 64, 0)) return rc;
   if (d->njmax > 64)
-    if (int rc = launch_tree_32<6, NEWTON, true, ELL>(m, d, m->isl_nv4, sr, 64, all, ISL_MANYROWS)) return rc;
+    if (int rc = launch_tree_32<6, NEWTON, true, ELL>(m, d, m->isl_nv4, sr3, 64, all, ISL_MANYROWS)) return rc;
   // islands of 33..64 dofs (several trees joined, or a wide tree): one island per wavefront, padded to 64 columns
-  if (d->njmax <= 64) return launch_tree_t<16, 1, NEWTON, 64, true, ELL>(m, d, sr, -1, all, 32, 64, ISL_WIDE);
-  if (int rc = launch_tree_t<16, 2, NEWTON, 64, true, ELL>(m, d, sr, -1, 128, 32, 64, ISL_WIDE)) return rc;
-  if (d->njmax > 128) return launch_tree_t<16, 3, NEWTON, 64, true, ELL>(m, d, sr, 128, all, 32, 64, ISL_WIDE);
+  if (d->njmax <= 64) return launch_tree_t<16, 1, NEWTON, 64, true, ELL>(m, d, sr3, -1, all, 32, 64, ISL_WIDE);
+  if (int rc = launch_tree_t<16, 2, NEWTON, 64, true, ELL>(m, d, sr3, -1, 128, 32, 64, ISL_WIDE)) return rc;
+  if (d->njmax > 128) return launch_tree_t<16, 3, NEWTON, 64, true, ELL>(m, d, sr3, 128, all, 32, 64, ISL_WIDE);
   return MJH_OK;
 }

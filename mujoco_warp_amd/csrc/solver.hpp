@@ -191,12 +191,37 @@ DEV float rsqrt_nr(float pv) {  // v_rsq_f32 + one Newton step (~0.5 ulp), as ch
   float inv = __builtin_amdgcn_rsqf(pv);
   return inv * (1.5f - 0.5f * pv * inv * inv);
 }
-template <int NV4, int G>
+// FACTOR = false (round 6, the Newton solver's factor reuse: solver.py:2670-2733 _update_gradient_cholesky_blocked_skip_unchanged): `h` already
+// holds the rows of L and `save` the block factors of an earlier call -- only the two substitutions run (NV4 LDS round trips for the
+// right-hand side, no panel, no Schur update).
+template <int NV4, int G, bool FACTOR = true>
 DEV float chol_factor_solve_g(float (&h)[4 * NV4], float g, float* panel, float* vec, float* save, int lig) {
   constexpr int NVR = 4 * NV4;
   float gacc = g, y = 0.0f;
+  if constexpr (!FACTOR) {
 #pragma unroll
-  for (int jb = 0; jb < NV4; ++jb) {
+    for (int jb = 0; jb < NV4; ++jb) {
+      const int j0 = 4 * jb;
+      gsync();
+      vec[lig] = gacc;
+      gsync();
+      const float4 g4 = *reinterpret_cast<const float4*>(vec + j0);
+      const float4 sa = *reinterpret_cast<const float4*>(save + 12 * jb);      // l10 l20 l30 r0
+      const float4 sb = *reinterpret_cast<const float4*>(save + 12 * jb + 4);  // l21 l31 l32 r1
+      const float2 sc = *reinterpret_cast<const float2*>(save + 12 * jb + 8);  // r2 r3
+      const float y0 = g4.x * sa.w;
+      const float y1 = (g4.y - sa.x * y0) * sb.w;
+      const float y2 = (g4.z - sa.y * y0 - sb.x * y1) * sc.x;
+      const float y3 = (g4.w - sa.z * y0 - sb.y * y1 - sb.z * y2) * sc.y;
+      y = lig == j0 ? y0 : y;
+      y = lig == j0 + 1 ? y1 : y;
+      y = lig == j0 + 2 ? y2 : y;
+      y = lig == j0 + 3 ? y3 : y;
+      gacc -= h[j0] * y0 + h[j0 + 1] * y1 + h[j0 + 2] * y2 + h[j0 + 3] * y3;
+    }
+  }
+#pragma unroll
+  for (int jb = 0; jb < (FACTOR ? NV4 : 0); ++jb) {
     const int j0 = 4 * jb;
     gsync();  // the previous block's panel reads are issued before this write (one wavefront: LDS ops complete in order)
     // unconditional (lanes >= NVR park junk in their own slot): a branch here splits the block, the compiler then sinks the
@@ -875,6 +900,15 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
   // the solver by k_factor_smooth).  CG: rows of M^-1, computed once per solve and reused as the preconditioner; it
   // also writes the public qacc_smooth.  Newton: only a cold start / an unconstrained world needs it (Cholesky of M).
   float h[NVR];  // Newton: H row, destroyed by the factorisation (rebuilt every iteration); CG: h = row of M^-1
+  // Incremental Hessian + factor reuse (round 6; solver.py:3222-3280 _update_gradient_incremental, 2670-2733 skip_unchanged; pyramidal /
+  // frictionless only, as the reference: _use_incremental 3509-3511).  One world per wavefront, widths whose registers hold a second copy of
+  // the row: `hs` keeps H of the last build; an iteration adds (D_new - D_old) J_r^T J_r for the rows whose QUADRATIC state flipped --
+  // typically a handful of the G1's ~70 rows -- and re-factorises; when no row flipped it keeps the factor and only substitutes.
+  constexpr bool INC = NEWTON && !ELL && !TREE && G == 64 && NV4 <= 10;
+  float hs[INC ? NVR : 1];
+  float pda[NR];  // D [state == QUADRATIC] of this lane's rows at the last build
+#pragma unroll
+  for (int k = 0; k < NR; ++k) pda[k] = 0.0f;
   float qs = 0.0f;
   if (!NEWTON) {
     // (the J region is free until the rows are loaded below: it lends the 2 x 4 x NVR-word tile buffer)
@@ -1073,6 +1107,9 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
       for (int k = 0; k < NR; ++k) exu[lig + G * k] = rja[k] * rs[k];
       gsync();
     }
+    bool chg[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) chg[k] = false;
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
       const float ja = rja[k], D = rD[k];
@@ -1083,7 +1120,15 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
       bool cone = false;
       if (ELL && rkind[k] >= 4) ell_row_force(k, force, state, cone);
       eforce[lig + G * k] = force;
-      if (NEWTON) eda[lig + G * k] = state == ST_QUADRATIC ? D : 0.0f;
+      if (NEWTON) {
+        const float da = state == ST_QUADRATIC ? D : 0.0f;
+        // (INC, after the first build: the line carries the CHANGE of D [quadratic] since the last build)
+        eda[lig + G * k] = (INC && niter > 0) ? da - pda[k] : da;
+        if (INC) {
+          if (niter > 0 && da != pda[k]) chg[k] = true;
+          pda[k] = da;
+        }
+      }
       if (ELL && NEWTON) einfo[lig + G * k] = cone ? rcon[k] : -1;
     }
     gsync();
@@ -1115,32 +1160,74 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
     if (NEWTON && done_early) break;
     if (NEWTON) {
       // H row = M row + sum_r (D_r [state_r == QUADRATIC]) J[r][i] J[r][:]   (JTDAJ, solver.py:2365-2440)
+      bool refactor = true;
+      bool full = true;
+      if constexpr (INC) {
+        if (niter > 0) {
+          // rows whose quadratic state flipped since the last build (one world per wavefront: the masks are wavefront-uniform)
+          full = false;
+          refactor = false;
 #pragma unroll
-      for (int c = 0; c < NVR; ++c) h[c] = mrow[c];
-      for (int r = 0; r < nefc4; r += 2) {  // two rows per LDS round trip (padding rows have J = 0, D = 0)
-        float jd0 = Jl[r * JS + ligr] * eda[r], jd1 = Jl[(r + 1) * JS + ligr] * eda[r + 1];
-        if (ELL) {  // rows of a contact in the cone zone: (C J_c)[a][lane's dof] replaces D J[r][lane's dof]
-          const int i0 = einfo[r], i1 = r + 1 < nefc ? einfo[r + 1] : -1;
-          if (i0 >= 0) {
-            jd0 = 0.0f;
-            for (int bq = 0; bq < (i0 >> 8); ++bq) jd0 += econe[6 * r + bq] * Jl[((i0 & 255) + bq) * JS + ligr];
-          }
-          if (i1 >= 0) {
-            jd1 = 0.0f;
-            for (int bq = 0; bq < (i1 >> 8); ++bq) jd1 += econe[6 * (r + 1) + bq] * Jl[((i1 & 255) + bq) * JS + ligr];
-          }
-        }
+          for (int k = 0; k < NR; ++k) {
+            unsigned long long mk = __ballot(chg[k]);
+            refactor |= mk != 0ull;
+            while (mk) {
+              const int r = __builtin_ctzll(mk) + G * k;
+              mk &= mk - 1ull;
+              const float jd = Jl[r * JS + ligr] * eda[r];
 #pragma unroll
-        for (int c4 = 0; c4 < NV4; ++c4) {
-          const float4 a4 = *reinterpret_cast<const float4*>(Jl + r * JS + 4 * c4);
-          const float4 b4 = *reinterpret_cast<const float4*>(Jl + (r + 1) * JS + 4 * c4);
-          h[4 * c4] += jd0 * a4.x + jd1 * b4.x;
-          h[4 * c4 + 1] += jd0 * a4.y + jd1 * b4.y;
-          h[4 * c4 + 2] += jd0 * a4.z + jd1 * b4.z;
-          h[4 * c4 + 3] += jd0 * a4.w + jd1 * b4.w;
+              for (int c4 = 0; c4 < NV4; ++c4) {
+                const float4 a4 = *reinterpret_cast<const float4*>(Jl + r * JS + 4 * c4);
+                hs[4 * c4] += jd * a4.x;
+                hs[4 * c4 + 1] += jd * a4.y;
+                hs[4 * c4 + 2] += jd * a4.z;
+                hs[4 * c4 + 3] += jd * a4.w;
+              }
+            }
+          }
+          if (refactor) {
+#pragma unroll
+            for (int c = 0; c < NVR; ++c) h[c] = hs[c];
+          }
         }
       }
-      Mg = chol_factor_solve_g<NV4, G>(h, g, col, col + 4 * G, col + 5 * G, lig);
+      if (full) {
+#pragma unroll
+        for (int c = 0; c < NVR; ++c) h[c] = mrow[c];
+        for (int r = 0; r < nefc4; r += 2) {  // two rows per LDS round trip (padding rows have J = 0, D = 0)
+          float jd0 = Jl[r * JS + ligr] * eda[r], jd1 = Jl[(r + 1) * JS + ligr] * eda[r + 1];
+          if (ELL) {  // rows of a contact in the cone zone: (C J_c)[a][lane's dof] replaces D J[r][lane's dof]
+            const int i0 = einfo[r], i1 = r + 1 < nefc ? einfo[r + 1] : -1;
+            if (i0 >= 0) {
+              jd0 = 0.0f;
+              for (int bq = 0; bq < (i0 >> 8); ++bq) jd0 += econe[6 * r + bq] * Jl[((i0 & 255) + bq) * JS + ligr];
+            }
+            if (i1 >= 0) {
+              jd1 = 0.0f;
+              for (int bq = 0; bq < (i1 >> 8); ++bq) jd1 += econe[6 * (r + 1) + bq] * Jl[((i1 & 255) + bq) * JS + ligr];
+            }
+          }
+#pragma unroll
+          for (int c4 = 0; c4 < NV4; ++c4) {
+            const float4 a4 = *reinterpret_cast<const float4*>(Jl + r * JS + 4 * c4);
+            const float4 b4 = *reinterpret_cast<const float4*>(Jl + (r + 1) * JS + 4 * c4);
+            h[4 * c4] += jd0 * a4.x + jd1 * b4.x;
+            h[4 * c4 + 1] += jd0 * a4.y + jd1 * b4.y;
+            h[4 * c4 + 2] += jd0 * a4.z + jd1 * b4.z;
+            h[4 * c4 + 3] += jd0 * a4.w + jd1 * b4.w;
+          }
+        }
+        if constexpr (INC) {
+#pragma unroll
+          for (int c = 0; c < NVR; ++c) hs[c] = h[c];
+        }
+      }
+      if constexpr (INC) {
+        Mg = refactor ? chol_factor_solve_g<NV4, G>(h, g, col, col + 4 * G, col + 5 * G, lig)
+                      : chol_factor_solve_g<NV4, G, false>(h, g, col, col + 4 * G, col + 5 * G, lig);
+      } else {
+        Mg = chol_factor_solve_g<NV4, G>(h, g, col, col + 4 * G, col + 5 * G, lig);
+      }
       if (!active) Mg = 0.0f;
       srch = -Mg;
       search_dot = gsumg<G>(Mg * Mg);

@@ -464,7 +464,9 @@ def test_gpu_per_step_parity_along_the_lift(aloha, cone):
         f"qvel median {np.median(ev):.2e} p99 {np.percentile(ev, 99):.2e} max {np.max(ev):.2e}; dist median {np.median(dist_err):.2e} max {np.max(dist_err):.2e}")
   # Whether the resting contact is seen -- and whether a finger contact recovers 2 or 4 points (a 1.6 mrad face-alignment threshold) -- is
   # rounding noise in float32 (test above): 44 % of the pyramidal steps lose the table contact on the CPU twin, the GPU loses a similar share,
-  # and two float32 evaluation orders (fused multiply-adds or not) flip independently.  Measured over several runs: decisions equal to the
+  # and two float32 evaluation orders (fused multiply-adds or not) flip independently.  (Not run to run: the engine is bitwise
+  # reproducible on this replay -- test_gpu_convex_pipeline_is_bitwise_reproducible below; the spread is between BUILDS, whose compilers
+  # contract different multiply-adds.)  Measured over several builds: decisions equal to the
   # twin's in 709-914 of 1001 steps (pyramidal) / 907-944 (elliptic), equal to the float64 oracle's in 549-593 / 904-918, equal to one of
   # the two in 865 / 939.  Values are compared on the steps where the engine and the oracle agree; the behavioural golden is the test below.
   worst = max(onesided) if onesided else (0.0,)
