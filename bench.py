@@ -243,7 +243,7 @@ def steady_1000(mjw, m, mjm, nworld, world_offset, nstep=1000):
   return out
 
 
-def other_configs(mjw, nstep=200):
+def other_configs(mjw, nstep=200, only=None):
   """The other BASELINE.json configs on this GPU, off the timed headline: each model as authored (solver, integrator, cone, iteration caps),
   the reference's measurement loop (per-step device sync, noise / replayed control untimed) over `nstep` steps after an untimed lead-in.
     unitree_g1_flat, franka_emika_panda  -- configs[2] / [3]
@@ -273,6 +273,8 @@ def other_configs(mjw, nstep=200):
   )
   out = {}
   for e in entries:
+    if only and not any(e["name"] == o for o in only):
+      continue
     try:
       out[e["name"]] = _config_run(mjw, torch, e, e.get("nstep", nstep), e.get("lead", 100))
     except Exception as ex:  # a side config must not take the headline line down with it
@@ -298,11 +300,18 @@ def _config_run(mjw, torch, e, nstep, lead):
   hold = mjw.DeviceArray.from_numpy(np.asarray(mjd.ctrl, dtype=np.float32)) if (mjm.nu and center is None and e.get("hold_key_ctrl")) else None  # noise around the keyframe's controls
   total = nefc = niter = ncon = 0.0
   nstat = 0
+  # Steps of MANY launches (sleeping: ~20 plain kernels; more than 64 dofs: per-island solver launches on forked streams) are replayed from a
+  # hipGraph of `step`, the reference's own mechanism (cli.py:262-290: capture once, launch + sync per step); the few-launch steps are launched
+  # eagerly like the headline (a graph replay is ~6 us slower there: LAB_NOTES R5.6).  Round 6, clutter_synth: eager 1.28 M, graph 1.53 M.
+  graph = mjw.StepGraph(m, d) if (m.sleep_enabled or mjm.nv > 64) else None
   for i in range(lead + nstep):
     mjw.ctrl_noise(m, d, i, center=center[min(i, len(center) - 1)] if center else hold)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    mjw.step(m, d)
+    if graph is not None:
+      graph.launch()
+    else:
+      mjw.step(m, d)
     torch.cuda.synchronize()
     if i >= lead:
       total += time.perf_counter() - t0
@@ -321,7 +330,7 @@ def _config_run(mjw, torch, e, nstep, lead):
          "value": e["nworld"] * nstep / total, "unit": "env-steps/s", "nstep": nstep, "ms_per_step": 1e3 * total / nstep,
          "ncon_mean": ncon / max(nstat, 1), "nefc_mean": nefc / max(nstat, 1), "solver_niter_mean": niter / max(nstat, 1),
          "finite": ok, "overflow_bits": ovf, "iteration_cap_worlds": int(((d.overflow.numpy() >> 9) & 1).sum()),
-         "timing": "reference placement (per-step sync, control untimed)"}
+         "timing": "reference placement (per-step sync, control untimed)" + (", hipGraph replay of step as the reference (cli.py:262-290)" if graph is not None else ", eager launches")}
   if e.get("note"):
     res["note"] = e["note"]
     res["x8"] = {"value": 8 * res["value"], "note": "8 shards of this size, one per GPU, no data-path collective: the single-GPU figure x 8 (a projection, not a measured 8-GPU run)"}
@@ -348,6 +357,7 @@ def main():
   ap.add_argument("--no-steady", action="store_true", help="skip the 1000-step reference-placement figure")
   ap.add_argument("--pmc-profile", default="auto", help="rocprofv3 PMC summary (tools/make_pmc_summary.py) of this solver's kernel; "
                   "auto = the newest committed profiles/round<N>_pmc_<solver>_<early|steady>.json whose window matches --warmup (labelled as such in traffic_source), none = null")
+  ap.add_argument("--configs-only", default="", help="comma-separated names: run only these entries of `configs` (developer: A/B of one config)")
   ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configs (G1 4096 worlds, Panda 8192, aloha_pot 8192, clutter_synth 2048 Newton + PGS)")
   args = ap.parse_args()
   if args.gpus < 1:
@@ -480,7 +490,7 @@ def main():
   shard.barrier()
 
   if rank == 0 and world_size == 1 and not args.no_configs:
-    out["configs"] = other_configs(mjw)
+    out["configs"] = other_configs(mjw, only=[x for x in args.configs_only.split(",") if x] or None)
   if rank == 0 and cpu is not None:
     out["cpu_baseline"] = cpu
   if rank == 0:

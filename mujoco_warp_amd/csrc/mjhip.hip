@@ -441,6 +441,7 @@ static int solve_supported(const MjhModel* m, const MjhData* d) {
 // stream each: round 6) and the generic solver touch islands / worlds the common-class launch skips, so they run beside it instead of
 // after it.  Released by mjh_release_thread_resources().
 #define MJH_NAUX 4
+#define MJH_NAUX_EAGER 4  // (see launch_solve_any: eager launches pay for the forks while few islands are awake, and win afterwards)
 struct Aux {
   hipStream_t stream[MJH_NAUX];
   hipEvent_t fork, join[MJH_NAUX];
@@ -517,15 +518,26 @@ static int launch_solve_any(const MjhModel* m, const MjhData* d, bool with_facto
       hipLaunchKernelGGL(k_tree_rows, dim3(d->nworld), dim3(64), sizeof(int) * (size_t)(2 * std::max(d->njmax, 1) + 2 * m->ntree), s, *m, *d);
       const bool ell_t = m->cone == CONE_ELLIPTIC && d->nmaxpyramid > 1;
       Aux* aux = aux_streams();
-      hipStream_t s1 = aux ? aux->stream[0] : s, s2 = aux ? aux->stream[1] : s, s3 = aux ? aux->stream[2] : s, s4 = aux ? aux->stream[3] : s;
+      // One stream per rare island class (round 6).  clutter_synth, 2048 worlds, steps 100-300 (tools/clutter_ab.py, bit-identical states, two
+      // interleaved rounds): hipGraph replay -- the reference's own way to run a step, cli.py:262-290 -- none 1.27, one shared side stream 1.29,
+      // one each 1.43 M env-steps/s; eager launches 1.28 / 1.28 / 1.40.  (Eager, steps 0-100 -- five trees awake, every class launch nearly
+      // empty -- the forks are host API calls on the critical path: 1.74 / 1.48 / 1.51; the graph replay does not pay them: 1.75 / 1.73 / 1.78.)
+      int naux = 0;
+      if (aux) {
+        hipStreamCaptureStatus cst = hipStreamCaptureStatusNone;
+        naux = (hipStreamIsCapturing(s, &cst) == hipSuccess && cst == hipStreamCaptureStatusActive) ? MJH_NAUX : MJH_NAUX_EAGER;
+        static const int cap = mjh_knob("MJH_NAUX") ? atoi(mjh_knob("MJH_NAUX")) : -1;  // developer knob (A/B): 2 = one side stream for the rare classes, 4 = one each
+        if (cap >= 2 && cap <= MJH_NAUX) naux = cap;
+      }
+      hipStream_t s1 = aux ? aux->stream[0] : s, s2 = aux ? aux->stream[1] : s, s3 = naux > 2 ? aux->stream[2] : s1, s4 = naux > 3 ? aux->stream[3] : s1;
       if (aux) {
         HIPCHK(hipEventRecord(aux->fork, s));
-        for (int k = 0; k < MJH_NAUX; ++k) HIPCHK(hipStreamWaitEvent(aux->stream[k], aux->fork, 0));
+        for (int k = 0; k < naux; ++k) HIPCHK(hipStreamWaitEvent(aux->stream[k], aux->fork, 0));
       }
       int rc = (m->solver == SOL_NEWTON ? (ell_t ? launch_solve_tree_newton_ell : launch_solve_tree_newton) : (ell_t ? launch_solve_tree_cg_ell : launch_solve_tree_cg))(m, d, s, s1, s3, s4);
       if (!rc) rc = launch_solve_big(m, d, s2);
       if (aux) {  // (every fork rejoins the caller's stream, also on the error path: the streams may be under capture)
-        for (int k = 0; k < MJH_NAUX; ++k) {
+        for (int k = 0; k < naux; ++k) {
           HIPCHK(hipEventRecord(aux->join[k], aux->stream[k]));
           HIPCHK(hipStreamWaitEvent(s, aux->join[k], 0));
         }
@@ -747,6 +759,7 @@ enum { K_NOISE = 0, K_POS = 1, K_COLLISION = 2, K_CONSTRAINT = 3, K_VEL = 4, K_S
 struct Side {
   hipStream_t stream;
   hipEvent_t fork, join;
+  bool owns_stream;
 };
 static thread_local Side* g_side_per_dev[16] = {nullptr};
 static Side* side_stream() {
@@ -764,7 +777,15 @@ static Side* side_stream() {
     // after the solver (rocprofv3 timeline, profiles/round3_newton_summary.json): their workgroups only get slots as the solver's retire
     const char* pe = mjh_knob("MJH_SIDE_PRIO");
     const int prio = pe && pe[0] == 'h' ? greatest : (pe && pe[0] == 'n' ? 0 : least);
-    if (hipStreamCreateWithPriority(&sd->stream, hipStreamNonBlocking, prio) != hipSuccess ||
+    // Round 6: the side stream IS the first auxiliary stream of the per-island solver (aux_streams; the two are never used by the same step).
+    // A stream of its own cost every later model of the process its solver concurrency: once it existed -- any Newton model of at most 32
+    // dofs stepped earlier -- the four class launches of clutter_synth ran 25 % slower (1.43 -> 1.07 M env-steps/s, tools/interference_probe.py:
+    // the runtime multiplexes user streams onto a few hardware queues, and streams that share one run in order).  MJH_SIDE_PRIO (a priority of
+    // its own) therefore implies a stream of its own.
+    Aux* shared = pe ? nullptr : aux_streams();
+    sd->owns_stream = shared == nullptr;
+    if (shared) sd->stream = shared->stream[0];
+    if ((sd->owns_stream && hipStreamCreateWithPriority(&sd->stream, hipStreamNonBlocking, prio) != hipSuccess) ||
         hipEventCreateWithFlags(&sd->fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&sd->join, hipEventDisableTiming) != hipSuccess) {
       delete sd;
@@ -1107,8 +1128,19 @@ int mjh_ctrl_noise(const MjhModel* m, const MjhData* d, const float* ctrl_center
 }
 
 int mjh_release_thread_resources(void) {
-  // the calling thread's side streams and events (one set per device it stepped a Newton model on)
+  // the calling thread's side streams and events (one set per device it stepped a Newton model on); the Newton side stream first: it may be
+  // an alias of the first auxiliary stream
   int rc = MJH_OK;
+  for (int dev = 0; dev < 16; ++dev) {
+    Side* sd = g_side_per_dev[dev];
+    if (!sd) continue;
+    g_side_per_dev[dev] = nullptr;
+    if (hipStreamSynchronize(sd->stream) != hipSuccess) rc = MJH_E_LAUNCH;
+    if (hipEventDestroy(sd->fork) != hipSuccess) rc = MJH_E_LAUNCH;
+    if (hipEventDestroy(sd->join) != hipSuccess) rc = MJH_E_LAUNCH;
+    if (sd->owns_stream && hipStreamDestroy(sd->stream) != hipSuccess) rc = MJH_E_LAUNCH;
+    delete sd;
+  }
   for (int dev = 0; dev < 16; ++dev) {
     Aux* a = g_aux_per_dev[dev];
     if (a) {
@@ -1121,16 +1153,6 @@ int mjh_release_thread_resources(void) {
       if (hipEventDestroy(a->fork) != hipSuccess) rc = MJH_E_LAUNCH;
       delete a;
     }
-  }
-  for (int dev = 0; dev < 16; ++dev) {
-    Side* sd = g_side_per_dev[dev];
-    if (!sd) continue;
-    g_side_per_dev[dev] = nullptr;
-    if (hipStreamSynchronize(sd->stream) != hipSuccess) rc = MJH_E_LAUNCH;
-    if (hipEventDestroy(sd->fork) != hipSuccess) rc = MJH_E_LAUNCH;
-    if (hipEventDestroy(sd->join) != hipSuccess) rc = MJH_E_LAUNCH;
-    if (hipStreamDestroy(sd->stream) != hipSuccess) rc = MJH_E_LAUNCH;
-    delete sd;
   }
   return rc == MJH_OK ? MJH_OK : fail(rc, "mjh_release_thread_resources: %s", "a HIP call failed");
 }

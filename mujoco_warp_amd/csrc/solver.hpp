@@ -904,7 +904,10 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
   // frictionless only, as the reference: _use_incremental 3509-3511).  One world per wavefront, widths whose registers hold a second copy of
   // the row: `hs` keeps H of the last build; an iteration adds (D_new - D_old) J_r^T J_r for the rows whose QUADRATIC state flipped --
   // typically a handful of the G1's ~70 rows -- and re-factorises; when no row flipped it keeps the factor and only substitutes.
-  constexpr bool INC = NEWTON && !ELL && !TREE && G == 64 && NV4 <= 10;
+  // 32 lanes per world / island (two per wavefront; the per-island kernels of models beyond 64 dofs: three_humanoids): the same, the flipped
+  // rows of the two halves walked in lockstep, each half deciding for itself whether it re-factorises -- no world's arithmetic depends on
+  // its wavefront partner.
+  constexpr bool INC = NEWTON && !ELL && ((G == 64 && !TREE && NV4 <= 10) || (G == 32 && NV4 <= 8 && NR <= 2));
   float hs[INC ? NVR : 1];
   float pda[NR];  // D [state == QUADRATIC] of this lane's rows at the last build
 #pragma unroll
@@ -1169,12 +1172,13 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
           refactor = false;
 #pragma unroll
           for (int k = 0; k < NR; ++k) {
-            unsigned long long mk = __ballot(chg[k]);
+            unsigned long long mk = gballot<G>(chg[k]);  // this lane group's flipped rows (G = 64: the wavefront's)
             refactor |= mk != 0ull;
-            while (mk) {
-              const int r = __builtin_ctzll(mk) + G * k;
-              mk &= mk - 1ull;
-              const float jd = Jl[r * JS + ligr] * eda[r];
+            while (__ballot(mk != 0ull)) {
+              const bool on = mk != 0ull;
+              const int r = on ? __builtin_ctzll(mk) + G * k : 0;
+              mk &= mk - 1ull;  // (0 stays 0)
+              const float jd = on ? Jl[r * JS + ligr] * eda[r] : 0.0f;
 #pragma unroll
               for (int c4 = 0; c4 < NV4; ++c4) {
                 const float4 a4 = *reinterpret_cast<const float4*>(Jl + r * JS + 4 * c4);
@@ -1223,8 +1227,9 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
         }
       }
       if constexpr (INC) {
-        Mg = refactor ? chol_factor_solve_g<NV4, G>(h, g, col, col + 4 * G, col + 5 * G, lig)
-                      : chol_factor_solve_g<NV4, G, false>(h, g, col, col + 4 * G, col + 5 * G, lig);
+        // (G = 32: `refactor` is uniform over a lane group, not over the wavefront -- halves that disagree run both paths one after the other)
+        if (refactor) Mg = chol_factor_solve_g<NV4, G>(h, g, col, col + 4 * G, col + 5 * G, lig);
+        else Mg = chol_factor_solve_g<NV4, G, false>(h, g, col, col + 4 * G, col + 5 * G, lig);
       } else {
         Mg = chol_factor_solve_g<NV4, G>(h, g, col, col + 4 * G, col + 5 * G, lig);
       }
