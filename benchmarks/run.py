@@ -35,12 +35,12 @@ def discover(registry=HERE):
   return out
 
 
-def command(folder, b, nstep=None):
+def command(folder, b, nstep=None, event_trace=True):
   """The testspeed command of one registry entry -- the reference's rule (benchmarks/run.py:128-149): fixed flags, `replay` resolved against
   the benchmark's folder, EVERY other field forwarded as --field=value (a list: once per item), so that an entry written for the reference runs
   unchanged.  Fields of the reference's registry that configure things outside the hot path (`assets`: git checkouts; `note`) are not flags."""
   cmd = [sys.executable, "-m", "mujoco_warp_amd.testspeed", os.path.join(folder, b["mjcf"]), "--clear_warp_cache=false", "--format=short",
-         "--event_trace=true", "--memory=true", "--measure_solver=true", "--measure_alloc=true"]
+         f"--event_trace={'true' if event_trace else 'false'}", "--memory=true", "--measure_solver=true", "--measure_alloc=true"]
   for field, value in b.items():
     if field == "replay":
       cmd.append("--replay=" + os.path.join(folder, value))
@@ -59,6 +59,7 @@ def main():
   ap.add_argument("-f", "--filter", default=".*", help="regex on benchmark names")
   ap.add_argument("--nstep", type=int, default=None)
   ap.add_argument("--list", action="store_true")
+  ap.add_argument("--no-trace", action="store_true", help="skip the per-stage event trace after the rollout (profiling runs: the rollout's launches only)")
   ap.add_argument("--registry", default=HERE, help="directory of benchmark folders (default: this one); a copy of the reference's benchmarks/ works as it is")
   args = ap.parse_args()
   rc = 0
@@ -68,7 +69,7 @@ def main():
     if args.list:
       print(b["name"], b)
       continue
-    p = subprocess.run(command(folder, b, args.nstep), cwd=ROOT, capture_output=True, text=True)
+    p = subprocess.run(command(folder, b, args.nstep, not args.no_trace), cwd=ROOT, capture_output=True, text=True)
     if p.returncode != 0:
       print(f"{b['name']}.error {p.stderr.strip().splitlines()[-1] if p.stderr.strip() else 'failed'}")
       rc = 1

@@ -342,15 +342,14 @@ DEV void make_constraint_body(const MjhModel& m, const MjhData& d, float* smem, 
   // Contacts, a window of CON_WINDOW records at a time (round 5; the round-4 loop walked the active contacts one after the other through
   // five dependent LDS hops each -- list -> record -> geom body -> root body -> subtree com -- and a later pass re-read the finished J rows
   // from global memory for J qvel: 2.8 k cycles per contact, 36 % + 29 % of this kernel):
-  //   1. the window's raw records are staged with consecutive addresses (one memory round trip);
-  //   2. PREPASS, one lane per active contact: everything the Jacobian needs that is the same for all dofs -- the offsets of the contact
-  //      point from the two root bodies' subtree centres, the dof masks of the two bodies, the frame, the friction coefficients, first
-  //      row / row count -- is written back as a compact record in ACTIVE order (slot a - a0): the dof loop below reads it with six
-  //      16-byte broadcast loads whose addresses depend on nothing but the loop counter;
-  //   3. dof loop, lane = dof: the six Jacobian components, the rows (coalesced 128-byte stores), and the components' products with qvel,
-  //      group-reduced to the basis velocities v_n, v_t1 .. of the contact (kept in the compact record): J qvel of every row is a
-  //      combination of them, nothing is read back;
-  //   4. the window's rows, lane = row: D, aref, pos, margin, vel, type, id.
+  //   1. the window's raw records are staged in LDS with consecutive addresses (`cwin`: one memory round trip);
+  //   2. dof loop over the window's active contacts, lane = dof: the record is read from `cwin` (broadcast reads), the six Jacobian components
+  //      give the rows (coalesced 128-byte stores) and, multiplied with qvel and group-reduced, the contact's basis velocities v_n, v_t1, v_t2
+  //      (and the three spin / roll ones for condim > 3), which OVERWRITE words 17 .. 22 of the staged record -- its solref / solimp words:
+  //      from here on those are only valid in the global record `crec`;
+  //   3. the window's rows, lane = row: D, aref, pos, margin, type, id -- and vel as a combination of the contact's basis velocities
+  //      (nothing of J is read back); solref / solimp come from `crec`.
+  // (An earlier design note here described a pre-pass that rewrote compact records in active order; it was never what the code does.)
   const int nw = (nv + 31) / 32;
   const float impr2 = bf(m.opt_impratio_invsqrt, m.opt_impratio_invsqrt_nb, w, 1)[0];
   const float* biw = bf(m.body_invweight0, m.body_invweight0_nb, w, 2 * nbody);

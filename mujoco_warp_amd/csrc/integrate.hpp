@@ -310,7 +310,8 @@ DEV void schedule_body(const MjhData& d, int* sh, int nthreads, int cls = 0) {
   const bool one_batch = n <= KD * nthreads && (n & 3) == 0;
   int key[KD];
   if (one_batch) {
-    // Eight 16-byte loads per thread (thread t: worlds 4 (t + k nthreads) .. + 3), from clamped addresses and tied together below: a load
+    // KD / 4 = eight 16-byte loads per thread and array (solver_niter; with row classes also nefc: sixteen in all) -- thread t: worlds
+    // 4 (t + k nthreads) .. + 3 --, from clamped addresses and tied together below: a load
     // behind a per-key condition is a branch, and the compiler then waited for every load before it issued the next (32 dependent round
     // trips: the 13 us this workgroup took, measured as its launch's tail).
     int4 v4[KD / 4], e4[KD / 4];

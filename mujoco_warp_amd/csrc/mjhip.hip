@@ -627,8 +627,13 @@ static int launch_solve_any(const MjhModel* m, const MjhData* d, bool with_facto
     return rc;
   }
   if (d->njmax <= 128) return s64(m, d, 2, with_factor, fe, s, lo64, all);
-  if (int rc = s64(m, d, 2, with_factor, fe, s, lo64, 128)) return rc;
-  if (int rc = s64(m, d, 3, false, fe, s, 128, top)) return rc;
+  // Round 6: a launch's J tile is sized for the rows it can meet (solve_layout(min(njmax, hi))).  Lowering the two-row launch's bound to 112 rows
+  // fits one more G1 world per CU (19.3 instead of 21.7 KB: 8 instead of 7) -- measured, two interleaved rounds, bit-identical states: 9.54 M
+  // env-steps/s at 128, 9.47 at 112, 9.44 at 96: the launch is not bound by whole LDS rounds.  The bound stays 128; MJH_SOLVE64_HI2 (developer knob).
+  static const int hi2_knob = mjh_knob("MJH_SOLVE64_HI2") ? atoi(mjh_knob("MJH_SOLVE64_HI2")) : 0;
+  const int hi2 = (hi2_knob >= 80 && hi2_knob <= 128) ? (hi2_knob & ~15) : 128;
+  if (int rc = s64(m, d, 2, with_factor, fe, s, lo64, hi2)) return rc;
+  if (int rc = s64(m, d, 3, false, fe, s, hi2, top)) return rc;
   return d->njmax > 192 ? launch_solve_big(m, d, s, 192) : MJH_OK;
 }
 static int launch_solve(const MjhModel* m, const MjhData* d, hipStream_t s) { return launch_solve_any(m, d, false, s); }

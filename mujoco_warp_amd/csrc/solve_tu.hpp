@@ -31,7 +31,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((!NEWT
 // L'DL-factor workgroups (fused step, CG); without it the launch is the plain `solve` stage.
 template <int NV4, int NR, bool NEWTON, int SG, bool ELL = false>
 static int launch_solve_t(const MjhModel* m, const MjhData* d, bool with_factor, int fuse_euler, hipStream_t s, int nefc_lo, int nefc_hi) {
-  const SolveLayout lay = solve_layout<NV4, NR, SG, NEWTON, ELL>(d->njmax);
+  const SolveLayout lay = solve_layout<NV4, NR, SG, NEWTON, ELL>(std::min(d->njmax, nefc_hi));  // (as solve_body: rows this launch can meet)
   const FacLayout fl = fac_layout(m->nv, m->nC);
   const size_t ms_bytes = sizeof(int) * mstruct_ints(m->nv, m->nC);  // riders only: the solver keeps no shared tables
   size_t lds;

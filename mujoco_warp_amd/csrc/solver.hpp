@@ -780,7 +780,8 @@ DEV void solve_body(const MjhModel& m, const MjhData& d, float* smem, const Blk&
   constexpr int NVR = 4 * NV4;
   constexpr int JS = (NV4 & 1) ? NVR : NVR + 4;
   const int nv_all = m.nv, nC = m.nC, njmax = d.njmax, nvp = d.nv_pad;
-  const SolveLayout lay = solve_layout<NV4, NR, G, NEWTON, ELL, TREE>(njmax);
+  // (the J tile is sized for the rows THIS launch can meet: a row-class launch that stops at nefc_hi < njmax holds fewer rows -- more worlds per CU)
+  const SolveLayout lay = solve_layout<NV4, NR, G, NEWTON, ELL, TREE>(TREE ? njmax : min(njmax, nefc_hi));
   const int lig = threadIdx.x & (G - 1), gib = threadIdx.x / G;
   const int slot = b.w0 + gib;
   if (TREE && gib >= b.nw) return;  // (a looped launch hands a block fewer islands than it has lane groups)

@@ -130,11 +130,13 @@ def test_fused_implicitfast_equals_the_staged_integrator(model, solver):
 
 
 def test_cg_small_and_large_batch_kernels_both_match_oracle():
-  """CG has two kernels (mjhip.hip launch_solve_any): one world per wavefront for batches of at most 3072 worlds (csrc/solver_cgw.hpp),
-  two worlds per wavefront above (csrc/solver.hpp).  The same state through both: each within the oracle tolerance, and the same answer."""
+  """CG on this model has two product kernels (mjhip.hip cg32_choice): one world per wavefront for batches of at most 3072 worlds
+  (csrc/solver_cgw.hpp), the pooled contact-basis kernel above (csrc/solver_cgp.hpp; `mjw.solver_kernel` names them).  The same state
+  through both: each within the oracle tolerance, and the same answer.  (Diverged worlds at 8192: tests/test_headline_batch.py.)"""
   mjm = mjw.mjcf.load_xml(conftest.HUMANOID_XML)
   s, m, d = _pair(mjm, nworld=4, nconmax=24, njmax=64, solver=int(mjw.SolverType.CG))
   big = mjw.put_data(mjm, mjw.MjData(mjm), nworld=3200, nconmax=24, njmax=64)
+  assert mjw.solver_kernel(m, d) == "cgw" and mjw.solver_kernel(m, big) == "cgp"
   _sync(s, big)
   s.forward()
   out = []

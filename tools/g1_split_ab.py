@@ -31,9 +31,12 @@ for i in range(400):
 print(json.dumps({"M_env_steps_per_s": round(cfg["nworld"] * 300 / tot / 1e6, 3), "us_per_step": round(tot / 300 * 1e6, 1), "niter": float(d.solver_niter.numpy().mean()), "nefc": float(d.nefc.numpy().mean()),
                   "finite": bool(np.isfinite(d.qpos.numpy()).all()), "qpos_sum": float(np.abs(d.qpos.numpy()).sum())}))
 '''
+variants = [v for v in (sys.argv[1:] or ["MJH_SOLVE64_SPLIT=0", "MJH_SOLVE64_SPLIT=1"])]
 for rep in range(2):
-  for name in ("g1", "three"):
-    for split in ("0", "1"):
-      env = dict(os.environ, MJH_SOLVE64_SPLIT=split)
+  for name in ("g1",):
+    for v in variants:
+      env = dict(os.environ)
+      k, val = v.split("=")
+      env[k] = val
       p = subprocess.run([sys.executable, "-c", code, ROOT, name], env=env, capture_output=True, text=True, timeout=600)
-      print(name, "split", split, p.stdout.strip().splitlines()[-1] if p.stdout.strip() else p.stderr[-300:], flush=True)
+      print(name, v, p.stdout.strip().splitlines()[-1] if p.stdout.strip() else p.stderr[-300:], flush=True)
