@@ -2128,6 +2128,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MJH_GJ
     w = t - slot * d.nworld;
     const float* cw = d.ws_ccd + (size_t)w * CL.world_stride;
     have = slot < reinterpret_cast<const int*>(cw + CL.cand)[CL.ccap + 2];
+    // sleeping, second collision pass (forward.py:652-666): a world where no contact of pass 1 woke a tree keeps its candidate list, its result
+    // cache and its contacts from pass 1 (k_broad_mask and k_collision skip it too) -- without this gate pass 2 re-ran GJK and EPA for every
+    // world: 230 us of the 1,430 us clutter_synth step (round 6, dispatch timeline)
+    if (have && d.sleep_pass == 2 && !d.ws_sleep_flag[w]) have = false;
     if (have) p = reinterpret_cast<const int*>(cw + CL.cache + (size_t)slot * CCD_CACHE_WORDS)[CCD_CACHE_WORDS - 1];
   }
   if (have) {
