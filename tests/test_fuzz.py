@@ -7,6 +7,8 @@ facet noise or a face-alignment decision at its 1.6 mrad threshold: qpos 3e-5 ..
 Round-5 sweep (final build; MJH_FUZZ_SEEDS=200, PGS 12, COLLIDER / CONVEX / MESH 160 each, MJH_FUZZ_CGP_SEEDS=300 through the pooled CG kernel): 967 pass, 22 skip,
 3 exceed a bound -- convex 46 (above), collider 86 (CG: qpos 3.1e-5) and pooled 91 (CG: qpos 3.0e-5); the last two are float32 CG stopping iterations before the
 float64 oracle (5 vs 8, 14 vs 16): the round-4 CG kernel exceeds the same bounds on the same seeds (qacc 3e-2 on 91 against 1e-5 for the pooled kernel), Newton passes both.
+Round-6 sweep (final build: incremental Hessian in the Newton kernels of solver.hpp, knob table, class streams; same seed counts): the same 967 / 22 / 3, the three
+exceeding seeds with the same figures to every printed digit (profiles/round6_fuzz_wide.log).
 
 The fixed models (humanoid, G1, Panda, pendula, free bodies, pile) pin specific code paths; these seeds sweep the
 combinations: free / ball / hinge / slide joints at random depths, limits, damping, springs, armature, friction loss,
