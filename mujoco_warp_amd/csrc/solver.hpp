@@ -79,7 +79,7 @@ DEV void gsumg_n(float (&v)[N]) {
 }
 // The same sums without the LDS crossbar (round 5, 32-lane groups): after the four row_shr steps lane 15 of each 16-lane row holds its row's
 // sum; v_permlane16_swap hands both rows' registers to both rows and two row_newbcast:15 reads add the two row sums -- the same bits in
-// every lane.  Seven VALU instructions per value instead of five + one ds_swizzle: a reduction is no LDS round trip any more (the CG
+// every lane.  Six (round 5: seven) VALU instructions per value instead of five + one ds_swizzle: a reduction is no LDS round trip any more (the CG
 // iteration had 4-5 of them on its dependent chain, and they were 23 of its 59 DS instructions).
 template <int N>
 DEV void gsum32_valu_n(float (&v)[N]) {
@@ -91,13 +91,15 @@ DEV void gsum32_valu_n(float (&v)[N]) {
   for (int i = 0; i < N; ++i) v[i] = dpp_add_f<0x114, 0xf, 0xf>(v[i]);  // row_shr:4
 #pragma unroll
   for (int i = 0; i < N; ++i) v[i] = dpp_add_f<0x118, 0xf, 0xf>(v[i]);  // row_shr:8
+  // (round 6: add the two rows' copies first, broadcast once -- lane 15 then holds even-row sum + odd-row sum, the same two operands in the
+  // same order as the two broadcasts + add this replaces: bit-identical, one VALU instruction per value fewer)
 #pragma unroll
   for (int i = 0; i < N; ++i) {
     const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[i]), __float_as_uint(v[i]), false, false);
-    const float lo = __int_as_float(__builtin_amdgcn_update_dpp(0, (int)sw[0], 0x15F, 0xf, 0xf, true));  // row_newbcast:15 of the even row's copy
-    const float hi = __int_as_float(__builtin_amdgcn_update_dpp(0, (int)sw[1], 0x15F, 0xf, 0xf, true));  // ... of the odd row's copy
-    v[i] = lo + hi;
+    v[i] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);  // every lane: even row's copy + odd row's copy of its lane position
   }
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[i]), 0x15F, 0xf, 0xf, true));  // row_newbcast:15
 }
 // RED selects the broadcast of a group sum: 0 = gsumg_n (ds_swizzle), 1 = gsum32_valu_n (G = 32 only)
 template <int G, int N, int RED>

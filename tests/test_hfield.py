@@ -124,19 +124,25 @@ def test_gpu_hfield_vs_oracle():
   assert m.nhfield == 1 and m.heavy_colliders == 1
   d = mjw.make_data(mjm, nworld=2, nconmax=64, njmax=256)
   sims = [ref.RefSim(mjm, nconmax=64, njmax=256) for _ in range(2)]
+  # the float32 build of the oracle, stepped from the same states: how often float32 ALONE picks another contact set than float64 on this
+  # terrain -- the yardstick for the engine's flicker count below (round 6)
+  twins = [ref.RefSim(mjm, nconmax=64, njmax=256, real="f32") for _ in range(2)]
   q = d.qpos.numpy()
   q[1, 0::7] += 0.021
   d.qpos.assign(q)
   seen = set()
-  flicker = total = 0
+  flicker = total = twin_flicker = 0
   for step in range(250):
     for w, s in enumerate(sims):
-      s.qpos[:] = d.qpos.numpy()[w]
-      s.qvel[:] = d.qvel.numpy()[w]
-      s.qacc_warmstart[:] = d.qacc_warmstart.numpy()[w]
+      for sim in (s, twins[w]):
+        sim.qpos[:] = d.qpos.numpy()[w]
+        sim.qvel[:] = d.qvel.numpy()[w]
+        sim.qacc_warmstart[:] = d.qacc_warmstart.numpy()[w]
     mjw.step(m, d)
     for w, s in enumerate(sims):
       s.step()
+      twins[w].step()
+      twin_flicker += int(twins[w].ncon != s.ncon or relerr(twins[w].qpos, s.qpos) >= 3e-4)
       total += 1
       err = relerr(d.qpos.numpy()[w], s.qpos)
       # The selection of the (up to four) contacts of a pair is ill-conditioned by construction: which of two neighbouring prisms with the
@@ -148,7 +154,10 @@ def test_gpu_hfield_vs_oracle():
         assert err < 5e-3, (step, w)
         continue
       seen |= {int(s.con_geom[c][1]) for c in range(s.ncon)}
+  print(f"hfield: engine picks another contact set than the float64 oracle on {flicker} of {total} world-steps, the float32 oracle on {twin_flicker}")
   assert flicker <= 0.3 * total, (flicker, total)
+  # not an engine property: the float32 build of the reference's own algorithm flips about as often (measured: see the print)
+  assert flicker <= 2 * twin_flicker + 0.05 * total, (flicker, twin_flicker, total)
   assert seen == {1, 2, 3, 4, 5, 6}
   assert (d.overflow.numpy() == 0).all()
 
