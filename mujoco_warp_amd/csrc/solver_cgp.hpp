@@ -20,9 +20,10 @@
 //   * no vector ever goes through LDS: an nv-vector lives one element per lane, v_permlane16_swap + DPP row_newbcast feed the
 //     matrix-vector FMAs (solver_cgw.hpp's scheme in a 32-lane group) -- as v_fmac_f32_dpp, written in inline assembly: the compiler only
 //     folds a DPP move into VOP2 opcodes and selects the three-operand v_fma_f32 here (238 v_mov_b32_dpp + v_fma pairs measured);
-//   * J^T f in ONE round trip: lane (cq, rg) = (lane / 4, lane % 4) reads the columns 4 cq .. 4 cq + 3 of the rows rg, rg + 4, ... as
-//     16-byte words (a 36-row world: 9 reads per lane where the row loop needed 36 + 9), the basis forces arrive transposed the same
-//     way (fbT[rg][i]), two quad_perm adds fold the four row classes and lane l -- dof l -- finds its column in its own quad;
+//   * J^T f in ONE round trip: lane (cq, rg) = (lane / 4, lane % 4) reads the columns 4 cq .. 4 cq + 3 of the rows 4 rg .. 4 rg + 3 of every
+//     16-row batch as 16-byte words (a 36-row world: 12 reads per lane where the row loop needed 36 + 9; round 6: rows 4 apart across the
+//     quad's lanes, conflict-free), the lane's four basis forces as one more, two quad_perm adds fold the four row classes and lane l --
+//     dof l -- finds its column in its own quad;
 //   * J is dead when the solve ends: the fused integrator's scratch lines alias the world's pool rows.
 //   * a wavefront whose two worlds have at most 32 rows (the driver's window of the headline rollout: free fall, first contacts) runs an
 //     instantiation of the iteration loop with ONE row per lane -- row dots, forces and line search over one slot, J^T f without the second
@@ -177,7 +178,7 @@ DEV void solve_cgp_body(const MjhModel& m, const MjhData& d, float* smem, int sl
   const bool valid = gib < nwb && slot < d.nworld;
   int* cnt = reinterpret_cast<int*>(smem);
   int* slotR = reinterpret_cast<int*>(smem) + CGP_HEAD + CGP_WORLD * gib;  // efc row of every slot of this world
-  float* fbT = smem + CGP_HEAD + CGP_WORLD * gib + 64;                      // basis forces, transposed: fbT[(b & 3) * 16 + (b >> 2)]
+  float* fbT = smem + CGP_HEAD + CGP_WORLD * gib + 64;                      // basis forces fbT[b] (+ the spare word 64)
   float* pool = smem + CGP_HEAD + CGP_WORLD * (blockDim.x / G);
   const bool active = lig < nv;
 
@@ -326,7 +327,7 @@ DEV void solve_cgp_body(const MjhModel& m, const MjhData& d, float* smem, int sl
     const int br = isq[k] ? 3 * (s >> 2) + (qd < 3 ? qd : 2) : (has ? s - nq : 0);
     const int bf_ = isq[k] ? (qd < 3 ? 3 * (s >> 2) + qd : -1) : s - nq;  // basis row that takes this slot's force
     jro[k] = br * JS;
-    fbo[k] = (!has || bf_ < 0) ? 64 : (bf_ & 3) * 16 + (bf_ >> 2);
+    fbo[k] = (!has || bf_ < 0) ? 64 : bf_;
     rD[k] = has ? d.efc_D[eo + er] : 0.0f;
     rkind[k] = !has ? 3 : (isq[k] ? 2 : (er < ne ? 0 : 2));
     rjv[k] = 0.0f;
@@ -434,8 +435,14 @@ DEV void solve_cgp_body(const MjhModel& m, const MjhData& d, float* smem, int sl
   const float scale = meaninertia * (float)nv;
   const float rscale = 1.0f / scale;
   // J^T f: lane (cq, rg) reads the columns 4 cq .. 4 cq + 3 of the rows rg + 4 i: one base address, every row an immediate offset
-  const int cq = min(lig >> 2, J4 - 1), rg = lig & 3;
-  const float* Jq = Jl + 4 * cq + rg * JS;
+  // Round 6: lane (cq, rg) takes the rows 4 rg .. 4 rg + 3 of a 16-row batch (it took rg, rg + 4, rg + 8, rg + 12).  The four lanes of a column
+  // quad then read rows 4 apart at the same time: with rows of JS = 12 / 20 / 28 / 36 words their bank offsets are 0 / 16 / 32 / 48 (mod 64),
+  // and the 16 float4 of a ds_read_b128 lane group tile the 64 banks exactly -- the reads are conflict-free, where rows 1 apart collided pairwise
+  // (twice the LDS cycles: SQ_LDS_BANK_CONFLICT 7.0 M cycles per launch in round 5, 23 % of the LDS pipe).  Lanes past the last column quad
+  // (their sums are dropped) read the quad four below their own instead of the last one, which would break the tiling.
+  const int qd4 = lig >> 2;
+  const int cq = qd4 < J4 ? qd4 : (qd4 - 4 >= 0 && qd4 - 4 < J4 ? qd4 - 4 : J4 - 1), rg = lig & 3;
+  const float* Jq = Jl + 4 * cq + 4 * rg * JS;
   // (a batch past the world's rows is redirected to its last one: finite numbers against zero forces instead of another world's LDS)
   const float *Jq1 = Jq + min(16, nb16 - 16) * JS, *Jq2 = Jq + min(32, nb16 - 16) * JS, *Jq3 = Jq + min(48, nb16 - 16) * JS;
 
@@ -466,9 +473,9 @@ DEV void solve_cgp_body(const MjhModel& m, const MjhData& d, float* smem, int sl
     {
       float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
       auto batch = [&](int kb, const float* Jb) __attribute__((always_inline)) {
-        const float4 f4 = *reinterpret_cast<const float4*>(fbT + rg * 16 + 4 * kb);
-        const float4 j0 = *reinterpret_cast<const float4*>(Jb), j1 = *reinterpret_cast<const float4*>(Jb + 4 * JS),
-                     j2 = *reinterpret_cast<const float4*>(Jb + 8 * JS), j3 = *reinterpret_cast<const float4*>(Jb + 12 * JS);
+        const float4 f4 = *reinterpret_cast<const float4*>(fbT + 16 * kb + 4 * rg);  // the basis forces of the lane's four rows
+        const float4 j0 = *reinterpret_cast<const float4*>(Jb), j1 = *reinterpret_cast<const float4*>(Jb + JS),
+                     j2 = *reinterpret_cast<const float4*>(Jb + 2 * JS), j3 = *reinterpret_cast<const float4*>(Jb + 3 * JS);
         a0 += j0.x * f4.x; a1 += j0.y * f4.x; a2 += j0.z * f4.x; a3 += j0.w * f4.x;
         a0 += j1.x * f4.y; a1 += j1.y * f4.y; a2 += j1.z * f4.y; a3 += j1.w * f4.y;
         a0 += j2.x * f4.z; a1 += j2.y * f4.z; a2 += j2.z * f4.z; a3 += j2.w * f4.z;
