@@ -39,6 +39,9 @@
 
 // LDS of a workgroup: [CGP_HEAD ints: the worlds' row requests] [per world: slotR 64 ints | fbT 64 floats + 8 (the word lanes without a
 // basis force write to)] [pool: pool_rows x JS]
+#ifndef MJH_CGP_HOIST
+#define MJH_CGP_HOIST 1  // 1: the J words of batch 0 in front of the force hand-over (round 6: - 0.5 .. 1.4 % on the launch, bit-identical); 2: batch 1 as well
+#endif
 #define CGP_HEAD 32
 #define CGP_WORLD 136
 template <int NV4>
@@ -457,6 +460,19 @@ DEV void solve_cgp_body(const MjhModel& m, const MjhData& d, float* smem, int sl
   auto iterate = [&](auto nxt) __attribute__((always_inline)) {
   constexpr int NX = decltype(nxt)::value;
   for (;;) {
+#if MJH_CGP_HOIST
+    // the J words of batch 0 are loop invariant: issued in front of the force update and its LDS hand-over instead of behind the fence, their
+    // latency rides under both (steps 300-320: solver launch 158.3 -> 156.1 us, three interleaved rounds; steps 5-25 unchanged)
+    const float4 hj0 = *reinterpret_cast<const float4*>(Jq), hj1 = *reinterpret_cast<const float4*>(Jq + JS),
+                 hj2 = *reinterpret_cast<const float4*>(Jq + 2 * JS), hj3 = *reinterpret_cast<const float4*>(Jq + 3 * JS);
+#endif
+#if MJH_CGP_HOIST > 1
+    float4 gj0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), gj1 = gj0, gj2 = gj0, gj3 = gj0;
+    if (!(NX == 1 && short16)) {
+      gj0 = *reinterpret_cast<const float4*>(Jq1); gj1 = *reinterpret_cast<const float4*>(Jq1 + JS);
+      gj2 = *reinterpret_cast<const float4*>(Jq1 + 2 * JS); gj3 = *reinterpret_cast<const float4*>(Jq1 + 3 * JS);
+    }
+#endif
     // ---- force of this lane's rows (solver.py:1698-1822), folded to basis forces inside the contact quads -------------------------
 #pragma unroll
     for (int k = 0; k < NX; ++k) {
@@ -483,8 +499,28 @@ DEV void solve_cgp_body(const MjhModel& m, const MjhData& d, float* smem, int sl
       };
       // two round trips at most: batches 0 + 1 always (batch 1 of a world of at most 16 rows re-reads batch 0 against zero forces), batches
       // 2 + 3 behind one branch
+#if MJH_CGP_HOIST
+      {
+        const float4 f4 = *reinterpret_cast<const float4*>(fbT + 4 * rg);
+        a0 += hj0.x * f4.x; a1 += hj0.y * f4.x; a2 += hj0.z * f4.x; a3 += hj0.w * f4.x;
+        a0 += hj1.x * f4.y; a1 += hj1.y * f4.y; a2 += hj1.z * f4.y; a3 += hj1.w * f4.y;
+        a0 += hj2.x * f4.z; a1 += hj2.y * f4.z; a2 += hj2.z * f4.z; a3 += hj2.w * f4.z;
+        a0 += hj3.x * f4.w; a1 += hj3.y * f4.w; a2 += hj3.z * f4.w; a3 += hj3.w * f4.w;
+      }
+#else
       batch(0, Jq);
-      if (!(NX == 1 && short16)) batch(1, Jq1);  // (uniform over the wavefront: both worlds within 16 basis rows)
+#endif
+#if MJH_CGP_HOIST > 1
+      if (!(NX == 1 && short16)) {
+        const float4 f4 = *reinterpret_cast<const float4*>(fbT + 16 + 4 * rg);
+        a0 += gj0.x * f4.x; a1 += gj0.y * f4.x; a2 += gj0.z * f4.x; a3 += gj0.w * f4.x;
+        a0 += gj1.x * f4.y; a1 += gj1.y * f4.y; a2 += gj1.z * f4.y; a3 += gj1.w * f4.y;
+        a0 += gj2.x * f4.z; a1 += gj2.y * f4.z; a2 += gj2.z * f4.z; a3 += gj2.w * f4.z;
+        a0 += gj3.x * f4.w; a1 += gj3.y * f4.w; a2 += gj3.z * f4.w; a3 += gj3.w * f4.w;
+      }
+#else
+      if (!(NX == 1 && short16)) batch(1, Jq1);
+#endif  // (uniform over the wavefront: both worlds within 16 basis rows)
       if (nb16 > 32) {
         batch(2, Jq2);
         batch(3, Jq3);
