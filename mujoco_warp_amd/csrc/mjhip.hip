@@ -529,15 +529,26 @@ static int launch_solve_any(const MjhModel* m, const MjhData* d, bool with_facto
         static const int cap = mjh_knob("MJH_NAUX") ? atoi(mjh_knob("MJH_NAUX")) : -1;  // developer knob (A/B): 2 = one side stream for the rare classes, 4 = one each
         if (cap >= 2 && cap <= MJH_NAUX) naux = cap;
       }
-      hipStream_t s1 = aux ? aux->stream[0] : s, s2 = aux ? aux->stream[1] : s, s3 = naux > 2 ? aux->stream[2] : s1, s4 = naux > 3 ? aux->stream[3] : s1;
+      // stream 0: islands of 8..16 dofs; 1: the generic solver (worlds with an island beyond 64 dofs); 2: 16..32 dofs; 3: many rows / 33..64 dofs.
+      // MJH_BIG_SHARES=1 (developer knob, A/B): the generic solver behind the 16..32-dof class on stream 2 -- four branches instead of five (the
+      // runtime has four hardware queues by default: R6.7).  Measured, two interleaved rounds: clutter_synth 1.55 / 1.54, three_humanoids
+      // 5.18 / 5.17 M env-steps/s -- nothing; off.
+      static const bool big_shares = mjh_knob("MJH_BIG_SHARES") && atoi(mjh_knob("MJH_BIG_SHARES")) != 0;
+      const bool share = big_shares && naux > 2;
+      bool used[MJH_NAUX] = {false, false, false, false};
+      for (int k = 0; k < naux; ++k) used[k] = !(share && k == 1);
+      hipStream_t s1 = aux ? aux->stream[0] : s, s3 = naux > 2 ? aux->stream[2] : s1, s4 = naux > 3 ? aux->stream[3] : s1;
+      hipStream_t s2 = !aux ? s : (share ? s3 : aux->stream[1]);
       if (aux) {
         HIPCHK(hipEventRecord(aux->fork, s));
-        for (int k = 0; k < naux; ++k) HIPCHK(hipStreamWaitEvent(aux->stream[k], aux->fork, 0));
+        for (int k = 0; k < naux; ++k)
+          if (used[k]) HIPCHK(hipStreamWaitEvent(aux->stream[k], aux->fork, 0));
       }
       int rc = (m->solver == SOL_NEWTON ? (ell_t ? launch_solve_tree_newton_ell : launch_solve_tree_newton) : (ell_t ? launch_solve_tree_cg_ell : launch_solve_tree_cg))(m, d, s, s1, s3, s4);
       if (!rc) rc = launch_solve_big(m, d, s2);
       if (aux) {  // (every fork rejoins the caller's stream, also on the error path: the streams may be under capture)
         for (int k = 0; k < naux; ++k) {
+          if (!used[k]) continue;
           HIPCHK(hipEventRecord(aux->join[k], aux->stream[k]));
           HIPCHK(hipStreamWaitEvent(s, aux->join[k], 0));
         }
